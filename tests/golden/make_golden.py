@@ -1,0 +1,350 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE ITSELF (build container only).
+
+Usage (from the repo root, in the container that has /root/reference):
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference (ZackHodari/morgana, pure Python) is imported from /root/reference with empty in-memory stand-ins for
+its un-vendored third-party imports (tts_data_tools, tensorboardX, bandmat) - SURVEY.md Appendix A.  Nothing of the
+reference's source is written anywhere: the .npz files hold only inputs and the outputs the reference computed.
+Model weights come from this repo's deterministic numpy generator (morgana_amd.synthetic) loaded into reference-shaped
+torch modules, so fixtures stay small (curves, norms, sampled elements) and reproducible on the GPU box.
+
+Fixtures:
+  g1_upsample_index.npz   dur cases -> int64 frame->phone map with -1 pads (bit exact)
+  g2_upsample_values.npz  gathered values + autograd backward (segment sum)
+  g3_sequence_mask.npz    masks for uint8 / float32 / int64
+  g4_masked_mse.npz       loss + grad for D in {1, 80, 187}, with / without seq_len
+  g5_normalisers.npz      mvn / minmax normalise + denormalise incl. std 0 and max == min
+  g6_f0_model.npz         README F0Model at C1: 20-step Adam loss curve, step-1 grad norms + samples, final checksums
+  g7_gru.npz              RecurrentCuDNNWrapper(GRU): outputs, final hidden, grads; small RNN_SPSS-layout model curve
+  g9_ema_lr.npz           EMA update, Noam / CyclicNoam sequences, metrics.Mean
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.dont_write_bytecode = True
+
+
+def import_reference():
+    names = ['tts_data_tools', 'tts_data_tools.file_io', 'tts_data_tools.utils', 'tts_data_tools.data_sources',
+             'tensorboardX', 'bandmat', 'bandmat.linalg']
+    for name in names:
+        sys.modules[name] = types.ModuleType(name)
+    tdt = sys.modules['tts_data_tools']
+    tdt.file_io = sys.modules['tts_data_tools.file_io']
+    tdt.utils = sys.modules['tts_data_tools.utils']
+    tdt.data_sources = sys.modules['tts_data_tools.data_sources']
+    tdt.utils.get_file_ids = lambda *a, **k: []
+    tdt.file_io.load_json = lambda path: {}
+    tdt.file_io.save_json = lambda obj, path: None
+    sys.modules['tensorboardX'].SummaryWriter = type('SummaryWriter', (), {'__init__': lambda self, *a, **k: None})
+    sys.modules['bandmat'].linalg = sys.modules['bandmat.linalg']
+    sys.path.insert(0, '/root/reference')
+    import morgana  # noqa: F401
+    from morgana import utils, losses, data, base_models, lr_schedules, metrics
+    return utils, losses, data, base_models, lr_schedules, metrics
+
+
+def main():
+    import torch
+    import torch.nn as nn
+    from morgana_amd import synthetic
+
+    utils, losses, data, base_models, lr_schedules, metrics = import_reference()
+    torch.manual_seed(synthetic.REFERENCE_SEED)
+    torch.set_num_threads(4)
+    rng = np.random.RandomState(20261003)
+
+    # ---------------------------------------------------------------- G1: index map
+    g1 = {}
+    cases = {
+        'zeros_inside': np.array([[2, 0, 3, 1], [0, 0, 4, 0], [1, 1, 1, 1]], dtype=np.int64),
+        'trailing_pads': np.array([[5, 2, 0, 0, 0], [1, 1, 1, 1, 1], [7, 0, 0, 0, 0]], dtype=np.int64),
+        'single_phone': np.array([[6]], dtype=np.int64),
+        'ragged_totals': rng.randint(0, 9, size=(7, 11)).astype(np.int64),
+        'tmax_boundary': np.array([[3, 3, 3], [9, 0, 0], [0, 0, 9], [4, 4, 0]], dtype=np.int64),
+        'all_zero_item': np.array([[0, 0, 0], [2, 1, 3]], dtype=np.int64),
+        'long': rng.randint(1, 40, size=(5, 64)).astype(np.int64),
+    }
+
+    def ref_index(dur):
+        # The reference builds the map internally; recover it by upsampling a (B, P, 1) tensor holding the phone index
+        # (+1 so that the zero pad row decodes to -1).
+        b, p = dur.shape
+        src = torch.arange(1, p + 1, dtype=torch.float64)[None, :, None].repeat(b, 1, 1)
+        up = utils.upsample_to_repetitions(src, torch.from_numpy(dur)[:, :, None])
+        return (up[:, :, 0].numpy().astype(np.int64) - 1)
+
+    for name, dur in cases.items():
+        g1[name + '__dur'] = dur
+        g1[name + '__idx'] = ref_index(dur)
+    np.savez_compressed(os.path.join(HERE, 'g1_upsample_index.npz'), **g1)
+
+    # ---------------------------------------------------------------- G2: values + backward
+    g2 = {}
+    x = torch.from_numpy(rng.standard_normal((3, 5, 4)).astype(np.float32)).requires_grad_(True)
+    dur = torch.tensor([[2, 0, 3, 1, 1], [1, 1, 1, 1, 1], [0, 4, 0, 0, 2]], dtype=torch.int64)
+    up = utils.upsample_to_repetitions(x, dur[:, :, None])
+    gout = torch.from_numpy(rng.standard_normal(tuple(up.shape)).astype(np.float32))
+    up.backward(gout)
+    g2.update(x=x.detach().numpy(), dur=dur.numpy(), out=up.detach().numpy(), grad_out=gout.numpy(),
+              grad_x=x.grad.numpy())
+    up2 = utils.upsample_to_repetitions(x.detach(), dur)          # 2-D durations are accepted (utils.py:202)
+    g2['out_2d_dur'] = up2.numpy()
+    np.savez_compressed(os.path.join(HERE, 'g2_upsample_values.npz'), **g2)
+
+    # ---------------------------------------------------------------- G3: sequence_mask
+    g3 = {}
+    seq_len = torch.tensor([6, 4, 1, 7, 0], dtype=torch.int64)
+    g3['seq_len'] = seq_len.numpy()
+    g3['mask_default'] = utils.sequence_mask(seq_len).numpy()
+    g3['mask_float32_len9'] = utils.sequence_mask(seq_len, max_len=9, dtype=torch.float32).numpy()
+    g3['mask_long_len3'] = utils.sequence_mask(seq_len, max_len=3, dtype=torch.long).numpy()
+    np.savez_compressed(os.path.join(HERE, 'g3_sequence_mask.npz'), **g3)
+
+    # ---------------------------------------------------------------- G4: masked MSE
+    g4 = {}
+    for dim in (1, 80, 187):
+        b, t = 5, 23
+        p = torch.from_numpy(rng.standard_normal((b, t, dim)).astype(np.float32)).requires_grad_(True)
+        y = torch.from_numpy(rng.standard_normal((b, t, dim)).astype(np.float32))
+        sl = torch.tensor([23, 1, 17, 9, 20], dtype=torch.int64)
+        loss = losses.mse(p, y, sl)
+        loss.backward()
+        g4['d%d__pred' % dim] = p.detach().numpy()
+        g4['d%d__target' % dim] = y.numpy()
+        g4['d%d__seq_len' % dim] = sl.numpy()
+        g4['d%d__loss' % dim] = loss.detach().numpy()
+        g4['d%d__grad' % dim] = p.grad.numpy().copy()
+        p.grad = None
+        loss = losses.mse(p, y)
+        loss.backward()
+        g4['d%d__loss_nolen' % dim] = loss.detach().numpy()
+        g4['d%d__grad_nolen' % dim] = p.grad.numpy().copy()
+    p = torch.zeros(2, 3, 1)
+    g4['zero_len_loss'] = losses.mse(p, p + 1, torch.tensor([0, 2])).numpy()       # NaN (0/0), no guard
+    np.savez_compressed(os.path.join(HERE, 'g4_masked_mse.npz'), **g4)
+
+    # ---------------------------------------------------------------- G5: normalisers
+    g5 = {}
+    dim = 7
+    feat = rng.standard_normal((3, 6, dim)).astype(np.float32) * 3 + 1
+    mean = rng.standard_normal(dim).astype(np.float32)
+    std = np.abs(rng.standard_normal(dim)).astype(np.float32)
+    std[2] = 0.0
+    mmin = rng.standard_normal(dim).astype(np.float32)
+    mmax = mmin + np.abs(rng.standard_normal(dim)).astype(np.float32)
+    mmax[4] = mmin[4]
+    g5.update(feat=feat, mean=mean, std=std, mmin=mmin, mmax=mmax)
+    for kind, arr in (('np', lambda a: a.copy()), ('torch', lambda a: torch.from_numpy(a.copy()))):
+        conv = (lambda r: r) if kind == 'np' else (lambda r: r.numpy())
+        with np.errstate(all='ignore'):
+            g5['mvn_norm_' + kind] = conv(data.normalise_mvn(arr(feat), arr(mean), arr(std)))
+            g5['mvn_denorm_' + kind] = conv(data.denormalise_mvn(arr(feat), arr(mean), arr(std)))
+            g5['minmax_norm_' + kind] = conv(data.normalise_minmax(arr(feat), arr(mmin), arr(mmax)))
+            g5['minmax_denorm_' + kind] = conv(data.denormalise_minmax(arr(feat), arr(mmin), arr(mmax)))
+    np.savez_compressed(os.path.join(HERE, 'g5_normalisers.npz'), **g5)
+
+    # ---------------------------------------------------------------- G6: README F0Model at C1
+    class F0Model(base_models.BaseSPSS):
+        def __init__(self, dims):
+            super(F0Model, self).__init__()
+            mods = []
+            for i in range(len(dims) - 1):
+                mods.append(nn.Linear(dims[i], dims[i + 1]))
+                if i < len(dims) - 2:
+                    mods.append(nn.Sigmoid())
+            self.layers = utils.SequentialWithRecurrent(*mods)
+
+        def predict(self, features):
+            x = utils.upsample_to_repetitions(features['normalised_lab'], features['dur'])
+            pred, _ = self.layers(x, seq_len=features['n_frames'])          # returns (out, hiddens): utils.py:418
+            return {'pred_norm_lf0': pred}
+
+        def loss(self, features, output_features):
+            return losses.mse(output_features['pred_norm_lf0'], features['normalised_lf0'], features['n_frames'])
+
+    def to_torch(features):
+        return {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in features.items()}
+
+    def load(model, state):
+        own = model.state_dict()
+        for k, v in state.items():
+            own[k].copy_(torch.from_numpy(v))
+
+    g6 = {}
+    dims = (600, 512, 128, 32, 1)
+    model = F0Model(dims)
+    load(model, synthetic.f0_model_state())
+    batches = [to_torch(synthetic.make_batch(8, 200, frames_per_phone=12.5, seed=synthetic.REFERENCE_SEED + 100 * i))
+               for i in range(4)]
+    optimizer = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=0.0)
+    curve = []
+    sample_idx = {}
+    for step in range(20):
+        optimizer.zero_grad()
+        loss, out = model(batches[step % 4])
+        loss.backward()
+        if step == 0:
+            g6['step1_pred_sample'] = out['pred_norm_lf0'].detach().numpy()[:, ::25, 0]
+            for name, prm in model.named_parameters():
+                g = prm.grad.detach().numpy().ravel()
+                idx = rng.choice(g.size, size=min(64, g.size), replace=False)
+                sample_idx[name] = idx
+                g6['step1_gradnorm__' + name] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+                g6['step1_gradidx__' + name] = idx.astype(np.int64)
+                g6['step1_gradval__' + name] = g[idx]
+        optimizer.step()
+        curve.append(loss.item())
+    g6['loss_curve'] = np.array(curve, dtype=np.float64)
+    for name, prm in model.named_parameters():
+        v = prm.detach().numpy().astype(np.float64)
+        g6['final_sum__' + name] = v.sum()
+        g6['final_abs_sum__' + name] = np.abs(v).sum()
+    # Ragged batch with weight decay, 5 steps (n_frames differ -> padding rows and per-utterance normalisation matter).
+    model = F0Model(dims)
+    load(model, synthetic.f0_model_state())
+    ragged = to_torch(synthetic.make_batch(6, (40, 120), seed=77))
+    optimizer = torch.optim.Adam(model.parameters(), lr=0.005, weight_decay=1e-3)
+    curve = []
+    for step in range(5):
+        optimizer.zero_grad()
+        loss, out = model(ragged)
+        loss.backward()
+        optimizer.step()
+        curve.append(loss.item())
+    g6['ragged_loss_curve'] = np.array(curve, dtype=np.float64)
+    g6['ragged_last_pred_sample'] = out['pred_norm_lf0'].detach().numpy()[:, ::7, 0]
+    np.savez_compressed(os.path.join(HERE, 'g6_f0_model.npz'), **g6)
+
+    # ---------------------------------------------------------------- G7: GRU wrapper
+    g7 = {}
+    for tag, (bsz, t_in, i_dim, hid, lens) in {
+            'h8': (4, 9, 3, 8, [6, 4, 1, 7]),
+            'h32': (5, 12, 16, 32, [12, 3, 12, 7, 1])}.items():
+        gru = nn.GRU(i_dim, hid, batch_first=True)
+        st = synthetic.init_gru(np.random.RandomState(5 + hid), i_dim, hid)
+        with torch.no_grad():
+            gru.weight_ih_l0.copy_(torch.from_numpy(st[0]))
+            gru.weight_hh_l0.copy_(torch.from_numpy(st[1]))
+            gru.bias_ih_l0.copy_(torch.from_numpy(st[2]))
+            gru.bias_hh_l0.copy_(torch.from_numpy(st[3]))
+        wrapper = utils.RecurrentCuDNNWrapper(gru)
+        xin = torch.from_numpy(rng.standard_normal((bsz, t_in, i_dim)).astype(np.float32)).requires_grad_(True)
+        sl = torch.tensor(lens, dtype=torch.int64)
+        out, hn = wrapper(xin, None, sl)
+        gout = torch.from_numpy(rng.standard_normal(tuple(out.shape)).astype(np.float32))
+        ghn = torch.from_numpy(rng.standard_normal(tuple(hn.shape)).astype(np.float32))
+        (out * gout).sum().backward(retain_graph=True)
+        g7[tag + '__x'] = xin.detach().numpy()
+        g7[tag + '__seq_len'] = sl.numpy()
+        g7[tag + '__out'] = out.detach().numpy()
+        g7[tag + '__hn'] = hn.detach().numpy()
+        g7[tag + '__grad_out'] = gout.numpy()
+        g7[tag + '__grad_x'] = xin.grad.numpy().copy()
+        for pname in ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0'):
+            g7[tag + '__grad_' + pname] = getattr(gru, pname).grad.numpy().copy()
+            getattr(gru, pname).grad = None
+        xin.grad = None
+        # with an initial hidden state and a gradient on the final hidden
+        h0 = torch.from_numpy(rng.standard_normal((1, bsz, hid)).astype(np.float32)).requires_grad_(True)
+        out, hn = wrapper(xin, h0, sl)
+        ((out * gout).sum() + (hn * ghn).sum()).backward()
+        g7[tag + '__h0'] = h0.detach().numpy()
+        g7[tag + '__grad_hn'] = ghn.numpy()
+        g7[tag + '__out_h0'] = out.detach().numpy()
+        g7[tag + '__hn_h0'] = hn.detach().numpy()
+        g7[tag + '__grad_x_h0'] = xin.grad.numpy().copy()
+        g7[tag + '__grad_h0'] = h0.grad.numpy().copy()
+        g7[tag + '__grad_weight_hh_l0_h0'] = gru.weight_hh_l0.grad.numpy().copy()
+
+    class RNNModel(base_models.BaseSPSS):
+        def __init__(self, lab_dim, hidden, post, out_dim):
+            super(RNNModel, self).__init__()
+            self.layers = utils.SequentialWithRecurrent(
+                nn.Linear(lab_dim, hidden), nn.Sigmoid(),
+                utils.RecurrentCuDNNWrapper(nn.GRU(hidden, hidden, batch_first=True)),
+                nn.Linear(hidden, post), nn.Sigmoid(), nn.Linear(post, out_dim))
+
+        def predict(self, features):
+            x = utils.upsample_to_repetitions(features['normalised_lab'], features['dur'])
+            pred, hiddens = self.layers(x, seq_len=features['n_frames'])
+            return {'pred': pred}
+
+        def loss(self, features, output_features):
+            return losses.mse(output_features['pred'], features['normalised_mcep'], features['n_frames'])
+
+    lab_dim, hidden, post, out_dim = 40, 32, 24, 5
+    model = RNNModel(lab_dim, hidden, post, out_dim)
+    state = synthetic.rnn_spss_state(seed=31, lab_dim=lab_dim, hidden=hidden, post=post, out_dim=out_dim)
+    load(model, state)
+    feats = to_torch(synthetic.make_batch(6, (20, 60), lab_dim=lab_dim, out_dim=out_dim, target_name='mcep',
+                                          frames_per_phone=6.0, seed=99))
+    optimizer = torch.optim.Adam(model.parameters(), lr=0.01)
+    curve = []
+    for step in range(8):
+        optimizer.zero_grad()
+        loss, out = model(feats)
+        loss.backward()
+        if step == 0:
+            g7['rnn__step1_pred'] = out['pred'].detach().numpy()
+            for name, prm in model.named_parameters():
+                g7['rnn__step1_grad__' + name] = prm.grad.detach().numpy().copy()
+        optimizer.step()
+        curve.append(loss.item())
+    g7['rnn__loss_curve'] = np.array(curve, dtype=np.float64)
+    g7['rnn__dims'] = np.array([lab_dim, hidden, post, out_dim], dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, 'g7_gru.npz'), **g7)
+
+    # ---------------------------------------------------------------- G9: EMA, LR schedules, metrics.Mean
+    g9 = {}
+    lin_a, lin_b = nn.Linear(4, 3), nn.Linear(4, 3)
+    g9['ema_shadow0'] = np.concatenate([p.detach().numpy().ravel() for p in lin_a.parameters()])
+    ema = utils.ExponentialMovingAverage(lin_a, 0.9)
+    steps = []
+    for step in range(3):
+        with torch.no_grad():
+            for p in lin_b.parameters():
+                p.add_(0.1 * (step + 1))
+        steps.append(np.concatenate([p.detach().numpy().ravel() for p in lin_b.parameters()]))
+        ema.update_params(lin_b)
+    g9['ema_params_seq'] = np.stack(steps)
+    g9['ema_shadow_final'] = np.concatenate([p.detach().numpy().ravel() for p in lin_a.parameters()])
+    g9['ema_decay'] = np.float64(0.9)
+
+    def lr_sequence(cls, n, **kwargs):
+        opt = torch.optim.SGD([nn.Parameter(torch.zeros(1))], lr=1.0)
+        sched = cls(opt, **kwargs)
+        seq = []
+        for _ in range(n):
+            seq.append(opt.param_groups[0]['lr'])
+            opt.step()
+            sched.step()
+        return np.array(seq, dtype=np.float64)
+
+    g9['noam_w4'] = lr_sequence(lr_schedules.NoamLR, 12, warmup_steps=4)
+    g9['cyclic_noam_w4_c9'] = lr_sequence(lr_schedules.CyclicNoamLR, 24, warmup_steps=4, cycle_steps=9)
+    g9['cyclic_noam_w4_trig'] = lr_sequence(lr_schedules.CyclicNoamLR, 30, warmup_steps=4, cycle_trigger=0.5)
+    g9['constant'] = lr_sequence(lr_schedules.DummyLR, 5)
+    mean = metrics.Mean()
+    vals = rng.standard_normal(6).astype(np.float32)
+    for v in vals:
+        mean.accumulate(torch.tensor(v))
+    g9['mean_inputs'] = vals
+    g9['mean_result'] = np.float64(float(mean.result()))
+    np.savez_compressed(os.path.join(HERE, 'g9_ema_lr.npz'), **g9)
+
+    for name in sorted(os.listdir(HERE)):
+        if name.endswith('.npz'):
+            print('%-28s %8d bytes' % (name, os.path.getsize(os.path.join(HERE, name))))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,230 @@
+"""Pins the oracle (oracle/ref_cpu.py, oracle/ref_torch.py, oracle/oracle_c.c) against the golden vectors that
+tests/golden/make_golden.py produced by running the reference itself.  CPU only."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from morgana_amd import synthetic
+from oracle import ref_cpu, ref_torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RTOL = 1e-4   # north star: 1e-4 relative fp32
+
+
+def _c_oracle():
+    path = os.path.join(REPO, 'oracle', 'liboracle_c.so')
+    if not os.path.exists(path):
+        subprocess.check_call(['make', '-C', os.path.join(REPO, 'oracle')])
+    lib = ctypes.CDLL(path)
+    lib.oracle_upsample_index.restype = ctypes.c_int64
+    lib.oracle_masked_mse.restype = ctypes.c_float
+    return lib
+
+
+def test_g1_index_map_bit_exact(golden):
+    g = golden('g1_upsample_index.npz')
+    lib = _c_oracle()
+    names = sorted(k[:-5] for k in g if k.endswith('__dur'))
+    assert len(names) >= 7
+    for name in names:
+        dur, want = g[name + '__dur'], g[name + '__idx']
+        idx, lens = ref_cpu.upsample_index(dur)
+        assert idx.dtype == np.int64 and np.array_equal(idx, want), name
+        assert np.array_equal(lens, dur.sum(axis=1))
+        # (B, P, 1) durations give the same map (utils.py:202)
+        assert np.array_equal(ref_cpu.upsample_index(dur[:, :, None])[0], want)
+        # C leg
+        b, p = dur.shape
+        dur_c = np.ascontiguousarray(dur)
+        tmax = lib.oracle_upsample_index(dur_c.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(b), ctypes.c_int64(p),
+                                         ctypes.c_int64(0), None, None)
+        assert tmax == want.shape[1]
+        out = np.empty((b, tmax), dtype=np.int64)
+        nfr = np.empty((b,), dtype=np.int64)
+        lib.oracle_upsample_index(dur_c.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(b), ctypes.c_int64(p),
+                                  ctypes.c_int64(tmax), out.ctypes.data_as(ctypes.c_void_p),
+                                  nfr.ctypes.data_as(ctypes.c_void_p))
+        assert np.array_equal(out, want), name
+        assert np.array_equal(nfr, lens)
+
+
+def test_g1_float_durations_raise():
+    with pytest.raises(TypeError):
+        ref_cpu.upsample_index(np.ones((2, 3), dtype=np.float32))
+
+
+def test_g2_upsample_values_and_backward(golden):
+    g = golden('g2_upsample_values.npz')
+    out = ref_cpu.upsample_to_repetitions(g['x'], g['dur'][:, :, None])
+    assert np.array_equal(out, g['out'])
+    assert np.array_equal(ref_cpu.upsample_to_repetitions(g['x'], g['dur']), g['out_2d_dur'])
+    gx = ref_cpu.upsample_backward(g['grad_out'], g['dur'], g['x'].shape[1])
+    np.testing.assert_allclose(gx, g['grad_x'], rtol=1e-6, atol=1e-6)
+    # torch leg
+    out_t = ref_torch.upsample_to_repetitions(torch.from_numpy(g['x']), torch.from_numpy(g['dur'])[:, :, None])
+    assert np.array_equal(out_t.numpy(), g['out'])
+
+
+def test_g3_sequence_mask(golden):
+    g = golden('g3_sequence_mask.npz')
+    sl = g['seq_len']
+    m = ref_cpu.sequence_mask(sl)
+    assert m.dtype == np.uint8 and np.array_equal(m, g['mask_default'])
+    assert np.array_equal(ref_cpu.sequence_mask(sl, 9, np.float32), g['mask_float32_len9'])
+    assert np.array_equal(ref_cpu.sequence_mask(sl, 3, np.int64), g['mask_long_len3'])
+    assert np.array_equal(ref_torch.sequence_mask(torch.from_numpy(sl)).numpy(), g['mask_default'])
+
+
+@pytest.mark.parametrize('dim', [1, 80, 187])
+def test_g4_masked_mse(golden, dim):
+    g = golden('g4_masked_mse.npz')
+    p, y, sl = g['d%d__pred' % dim], g['d%d__target' % dim], g['d%d__seq_len' % dim]
+    np.testing.assert_allclose(ref_cpu.mse(p, y, sl), g['d%d__loss' % dim], rtol=1e-5)
+    np.testing.assert_allclose(ref_cpu.mse_grad(p, y, sl), g['d%d__grad' % dim], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(ref_cpu.mse(p, y), g['d%d__loss_nolen' % dim], rtol=1e-5)
+    np.testing.assert_allclose(ref_cpu.mse_grad(p, y), g['d%d__grad_nolen' % dim], rtol=1e-5, atol=1e-9)
+    lib = _c_oracle()
+    grad = np.empty_like(p)
+    b, t, d = p.shape
+    loss = lib.oracle_masked_mse(p.ctypes.data_as(ctypes.c_void_p), y.ctypes.data_as(ctypes.c_void_p),
+                                 sl.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(b), ctypes.c_int64(t),
+                                 ctypes.c_int64(d), grad.ctypes.data_as(ctypes.c_void_p))
+    np.testing.assert_allclose(loss, g['d%d__loss' % dim], rtol=1e-5)
+    np.testing.assert_allclose(grad, g['d%d__grad' % dim], rtol=1e-5, atol=1e-9)
+
+
+def test_g4_zero_length_is_nan(golden):
+    g = golden('g4_masked_mse.npz')
+    assert np.isnan(g['zero_len_loss'])
+    p = np.zeros((2, 3, 1), dtype=np.float32)
+    assert np.isnan(ref_cpu.mse(p, p + 1, np.array([0, 2])))
+
+
+def test_g5_normalisers(golden):
+    g = golden('g5_normalisers.npz')
+    f = g['feat']
+    with np.errstate(all='ignore'):
+        for kind in ('np', 'torch'):
+            np.testing.assert_allclose(ref_cpu.normalise_mvn(f, g['mean'], g['std']), g['mvn_norm_' + kind], rtol=1e-6)
+            np.testing.assert_allclose(ref_cpu.denormalise_mvn(f, g['mean'], g['std']), g['mvn_denorm_' + kind],
+                                       rtol=1e-6)
+            np.testing.assert_allclose(ref_cpu.normalise_minmax(f, g['mmin'], g['mmax']), g['minmax_norm_' + kind],
+                                       rtol=1e-6)
+            np.testing.assert_allclose(ref_cpu.denormalise_minmax(f, g['mmin'], g['mmax']),
+                                       g['minmax_denorm_' + kind], rtol=1e-6)
+    # std == 0 column divides by the 1e-8 epsilon; max == min column uses scale 1
+    assert np.all(np.abs(g['mvn_norm_np'][..., 2]) > 1e5)
+    np.testing.assert_allclose(g['minmax_norm_np'][..., 4], f[..., 4] - g['mmin'][4], rtol=1e-6)
+
+
+def _c1_batches():
+    return [synthetic.make_batch(8, 200, seed=synthetic.REFERENCE_SEED + 100 * i) for i in range(4)]
+
+
+def test_g6_f0_model_numpy_oracle(golden):
+    g = golden('g6_f0_model.npz')
+    state = synthetic.f0_model_state()
+    batches = _c1_batches()
+    loss, pred, grads = ref_cpu.f0_forward_backward(state, batches[0])
+    np.testing.assert_allclose(loss, g['loss_curve'][0], rtol=RTOL)
+    np.testing.assert_allclose(pred[:, ::25, 0], g['step1_pred_sample'], rtol=RTOL, atol=1e-6)
+    for key in grads:
+        flat = grads[key].ravel()
+        np.testing.assert_allclose(np.sqrt((flat.astype(np.float64) ** 2).sum()), g['step1_gradnorm__' + key],
+                                   rtol=RTOL)
+        want = g['step1_gradval__' + key]
+        np.testing.assert_allclose(flat[g['step1_gradidx__' + key]], want, rtol=1e-3,
+                                   atol=1e-4 * np.abs(want).max())
+    curve = ref_cpu.f0_train(state, batches, 20, lr=0.01)
+    np.testing.assert_allclose(curve, g['loss_curve'], rtol=RTOL)
+    for key in state:
+        np.testing.assert_allclose(state[key].astype(np.float64).sum(), g['final_sum__' + key], rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(np.abs(state[key].astype(np.float64)).sum(), g['final_abs_sum__' + key], rtol=1e-3)
+
+
+def test_g6_f0_model_torch_oracle(golden):
+    g = golden('g6_f0_model.npz')
+    torch.set_num_threads(4)
+    model = ref_torch.load_state(ref_torch.F0Model(), synthetic.f0_model_state())
+    batches = [ref_torch.to_torch(b) for b in _c1_batches()]
+    curve = ref_torch.train_steps(model, batches, 20, lr=0.01)
+    np.testing.assert_allclose(curve, g['loss_curve'], rtol=1e-5)
+    model = ref_torch.load_state(ref_torch.F0Model(), synthetic.f0_model_state())
+    ragged = ref_torch.to_torch(synthetic.make_batch(6, (40, 120), seed=77))
+    curve = ref_torch.train_steps(model, [ragged], 5, lr=0.005, weight_decay=1e-3)
+    np.testing.assert_allclose(curve, g['ragged_loss_curve'], rtol=1e-5)
+
+
+def test_g6_ragged_weight_decay_numpy_oracle(golden):
+    g = golden('g6_f0_model.npz')
+    state = synthetic.f0_model_state()
+    ragged = synthetic.make_batch(6, (40, 120), seed=77)
+    curve = ref_cpu.f0_train(state, [ragged], 5, lr=0.005, weight_decay=1e-3)
+    np.testing.assert_allclose(curve, g['ragged_loss_curve'], rtol=RTOL)
+    _, pred, _ = ref_cpu.f0_forward_backward(state, ragged)   # after 5 updates == prediction of step 6; only shape
+    assert pred[:, ::7, 0].shape == g['ragged_last_pred_sample'].shape
+
+
+@pytest.mark.parametrize('tag', ['h8', 'h32'])
+def test_g7_gru_wrapper(golden, tag):
+    g = golden('g7_gru.npz')
+    hid = int(tag[1:])
+    i_dim = g[tag + '__x'].shape[2]
+    w_ih, w_hh, b_ih, b_hh = synthetic.init_gru(np.random.RandomState(5 + hid), i_dim, hid)
+    x, sl = g[tag + '__x'], g[tag + '__seq_len']
+    out, hn, cache = ref_cpu.gru_forward(x, sl, w_ih, w_hh, b_ih, b_hh)
+    assert out.shape == g[tag + '__out'].shape            # time cropped to max(seq_len)
+    np.testing.assert_allclose(out, g[tag + '__out'], rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(hn, g[tag + '__hn'], rtol=RTOL, atol=1e-6)
+    for b, n in enumerate(sl):
+        assert np.all(out[b, n:] == 0)
+    gr = ref_cpu.gru_backward(g[tag + '__grad_out'], None, x, sl, w_ih, w_hh, cache)
+    np.testing.assert_allclose(gr['x'], g[tag + '__grad_x'], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(gr['w_ih'], g[tag + '__grad_weight_ih_l0'], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(gr['w_hh'], g[tag + '__grad_weight_hh_l0'], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(gr['b_ih'], g[tag + '__grad_bias_ih_l0'], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(gr['b_hh'], g[tag + '__grad_bias_hh_l0'], rtol=1e-3, atol=1e-5)
+    # initial hidden + gradient on the final hidden
+    out, hn, cache = ref_cpu.gru_forward(x, sl, w_ih, w_hh, b_ih, b_hh, h0=g[tag + '__h0'])
+    np.testing.assert_allclose(out, g[tag + '__out_h0'], rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(hn, g[tag + '__hn_h0'], rtol=RTOL, atol=1e-6)
+    gr = ref_cpu.gru_backward(g[tag + '__grad_out'], g[tag + '__grad_hn'], x, sl, w_ih, w_hh, cache)
+    np.testing.assert_allclose(gr['x'], g[tag + '__grad_x_h0'], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(gr['h0'], g[tag + '__grad_h0'], rtol=1e-3, atol=1e-5)
+
+
+def test_g7_rnn_model(golden):
+    g = golden('g7_gru.npz')
+    lab_dim, hidden, post, out_dim = [int(v) for v in g['rnn__dims']]
+    state = synthetic.rnn_spss_state(seed=31, lab_dim=lab_dim, hidden=hidden, post=post, out_dim=out_dim)
+    feats = synthetic.make_batch(6, (20, 60), lab_dim=lab_dim, out_dim=out_dim, target_name='mcep',
+                                 frames_per_phone=6.0, seed=99)
+    loss, pred, grads = ref_cpu.rnn_forward_backward(state, feats)
+    np.testing.assert_allclose(loss, g['rnn__loss_curve'][0], rtol=RTOL)
+    np.testing.assert_allclose(pred, g['rnn__step1_pred'], rtol=1e-3, atol=1e-5)
+    for key in ref_cpu.RNN_KEYS:
+        want = g['rnn__step1_grad__' + key]
+        np.testing.assert_allclose(grads[key], want, rtol=1e-3, atol=1e-4 * np.abs(want).max())
+    # torch leg: 8-step curve
+    model = ref_torch.load_state(ref_torch.RNNModel(lab_dim, hidden, post, out_dim), state)
+    curve = ref_torch.train_steps(model, [ref_torch.to_torch(feats)], 8, lr=0.01)
+    np.testing.assert_allclose(curve, g['rnn__loss_curve'], rtol=1e-5)
+
+
+def test_g9_ema_lr_mean(golden):
+    g = golden('g9_ema_lr.npz')
+    shadow = g['ema_shadow0'].copy()
+    for params in g['ema_params_seq']:
+        ref_cpu.ema_update(shadow, params, float(g['ema_decay']))
+    np.testing.assert_allclose(shadow, g['ema_shadow_final'], rtol=1e-6)
+    np.testing.assert_allclose([ref_cpu.noam_scale(s, 4) for s in range(12)], g['noam_w4'], rtol=1e-12)
+    np.testing.assert_allclose([ref_cpu.cyclic_noam_scale(s, 4, cycle_steps=9) for s in range(24)],
+                               g['cyclic_noam_w4_c9'], rtol=1e-12)
+    np.testing.assert_allclose([ref_cpu.cyclic_noam_scale(s, 4, cycle_trigger=0.5) for s in range(30)],
+                               g['cyclic_noam_w4_trig'], rtol=1e-12)
+    assert np.all(g['constant'] == 1.0)
+    np.testing.assert_allclose(ref_cpu.metric_mean(g['mean_inputs']), g['mean_result'], rtol=1e-5)
