@@ -1,0 +1,230 @@
+#!/usr/bin/env python
+"""bench.py - acoustic frames/sec of one training step (zero_grad + forward + backward + [all-reduce] + Adam) of the
+README F0Model 600->512->128->32->1 on synthetic 256 x 1000-frame utterance batches per GPU (BASELINE config C2; C3 at N>1).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  Inputs are resident in HBM before the timed region.  `roofline` is measured live with
+HIP events on the kernel's own stream for the dominant kernel; `cpu_baseline` times the oracle's torch-CPU restatement
+of the reference step on a bounded sample on the host cores (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from morgana_amd import data, distributed, models, ops, optim, synthetic  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0
+# Algorithmic FLOPs per frame of the F0Model step: fwd 753,728 + wgrad 753,728 + dgrad(L2-4) 139,328
+F0_FLOPS_PER_FRAME = 1646784.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--config', default='c2', choices=['c2', 'c4'])
+    ap.add_argument('--batch', type=int, default=None, help='utterances per GPU (default 256 for c2, 64 for c4)')
+    ap.add_argument('--frames', type=int, default=1000)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    return ap.parse_args()
+
+
+def time_kernel(fn, iters=10, warm=2):
+    """Average duration (ms) of `fn` (which launches on torch's current stream) measured with HIP events on it."""
+    for _ in range(warm):
+        fn()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(iters):
+        fn()
+    end.record()
+    end.synchronize()
+    return start.elapsed_time(end) / iters
+
+
+def roofline_f0(features, model, precision):
+    """Time the GEMM kernels of the step in isolation and report the dominant one against the MFMA roof."""
+    lab = features['normalised_lab']
+    b, p, k = lab.shape
+    t = features['normalised_lf0'].shape[1]
+    m = b * t
+    dur2d = features['dur'].reshape(b, -1).contiguous()
+    _, rows = ops.upsample_index(dur2d, t)
+    rows = rows.view(-1)
+    lins = [mod for mod in model.layers if isinstance(mod, torch.nn.Linear)]
+    w1, b1, w2 = lins[0].weight.detach(), lins[0].bias.detach(), lins[1].weight.detach()
+    n1, n2 = w1.shape[0], w2.shape[0]
+    kernels = []
+    if precision == 'bf16':
+        tab = ops.cast_pad_bf16(lab.view(b * p, k))
+        w1b = ops.cast_pad_bf16(w1)
+        h1 = ops.linear_fwd_bf16(tab, rows, m, k, w1b, b1, n1, ops.ACT_SIGMOID)
+        dz1 = torch.randn(m, n1, device=lab.device).to(torch.bfloat16)
+        dz2 = torch.randn(m, ops.pad8(n2), device=lab.device).to(torch.bfloat16)
+        w2t = ops.cast_transpose_bf16(w2)
+        kernels.append(('linear_fwd_bf16 L1 (gather-fused 600->512 + bias + sigmoid)', 2.0 * m * k * n1,
+                        lambda: ops.linear_fwd_bf16(tab, rows, m, k, w1b, b1, n1, ops.ACT_SIGMOID)))
+        kernels.append(('linear_wgrad_bf16 L1 (gather-fused dW1 = dZ1^T X)', 2.0 * m * k * n1,
+                        lambda: ops.linear_wgrad_bf16(dz1, tab, rows, m, n1, k)))
+        kernels.append(('linear_dgrad_bf16 L2 (dZ1 = dZ2 W2 * H1(1-H1))', 2.0 * m * n1 * n2,
+                        lambda: ops.linear_dgrad_bf16(dz2, m, n2, w2t, n1, h1)))
+        peak = MFMA_BF16_PEAK_TFLOPS
+    else:
+        tab = lab.view(b * p, k)
+        h1 = ops.linear_fwd_f32(tab, rows, m, w1, b1, ops.ACT_SIGMOID)
+        dz1 = torch.randn(m, n1, device=lab.device)
+        dz2 = torch.randn(m, n2, device=lab.device)
+        kernels.append(('linear_fwd_f32 L1 (gather-fused 600->512 + bias + sigmoid)', 2.0 * m * k * n1,
+                        lambda: ops.linear_fwd_f32(tab, rows, m, w1, b1, ops.ACT_SIGMOID)))
+        kernels.append(('linear_wgrad_f32 L1 (gather-fused dW1 = dZ1^T X)', 2.0 * m * k * n1,
+                        lambda: ops.linear_wgrad_f32(dz1, tab, rows, n1, k)))
+        kernels.append(('linear_dgrad_f32 L2 (dZ1 = dZ2 W2 * H1(1-H1))', 2.0 * m * n1 * n2,
+                        lambda: ops.linear_dgrad_f32(dz2, w2, h1)))
+        peak = MFMA_F32_PEAK_TFLOPS
+    measured = []
+    for name, flops, fn in kernels:
+        ms = time_kernel(fn)
+        measured.append({'kernel': name, 'ms': round(ms, 4), 'tflops': round(flops / (ms * 1e-3) / 1e12, 2)})
+    dom = max(measured, key=lambda r: r['ms'])
+    return {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': dom['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
+            'frac': round(dom['tflops'] / peak, 4), 'traffic': None, 'ms_per_launch': dom['ms'], 'kernels': measured}
+
+
+def cpu_baseline_f0(frames):
+    """Oracle torch-CPU restatement of the reference step on a bounded sample (64 utterances of the C2 batch)."""
+    from oracle import ref_torch
+    n_threads = os.cpu_count() or 1
+    try:
+        n_threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    torch.set_num_threads(n_threads)
+    sample_b = 64
+    feats = ref_torch.to_torch(synthetic.make_batch(sample_b, frames))
+    model = ref_torch.load_state(ref_torch.F0Model(), synthetic.f0_model_state())
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+
+    def step():
+        opt.zero_grad()
+        loss, _ = model(feats)
+        loss.backward()
+        opt.step()
+
+    for _ in range(2):
+        step()
+    n_timed, t0 = 0, time.perf_counter()
+    while n_timed < 8 and (time.perf_counter() - t0) < 25.0:
+        step()
+        n_timed += 1
+    dt = (time.perf_counter() - t0) / n_timed
+    return {'value': round(sample_b * frames / dt, 1), 'unit': 'frames/s', 'cores': n_threads, 'kind': 'port',
+            'sample': '%d timed steps (2 warm-up) of %d x %d-frame utterances (1/4 of the C2 batch), torch-CPU fp32 '
+                      'restatement of the reference step (oracle/ref_torch.py)' % (n_timed, sample_b, frames)}
+
+
+def main():
+    args = parse_args()
+    rank, local_rank, world = distributed.init()
+    if world != args.gpus and world > 1:
+        raise SystemExit('--gpus %d does not match WORLD_SIZE %d' % (args.gpus, world))
+    n_gpus = max(world, 1)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    torch.manual_seed(synthetic.REFERENCE_SEED)
+    if args.config == 'c2':
+        per_gpu = args.batch or 256
+        feats_np = synthetic.make_batch(per_gpu, args.frames, rank=rank)
+        model = models.F0Model(precision=args.precision).to(dev)
+        state = synthetic.f0_model_state()
+        name, target = 'F0Model 600-512-128-32-1 (README.rst:65-73)', 'normalised_lf0'
+    else:
+        per_gpu = args.batch or 64
+        feats_np = synthetic.make_batch(per_gpu, args.frames, out_dim=80, target_name='mcep', rank=rank)
+        model = models.RNNSPSS(precision=args.precision).to(dev)
+        state = synthetic.rnn_spss_state()
+        name, target = 'RNN_SPSS Linear-512/GRU-512/Linear-256/80 (models/RNN_SPSS.py:32-42 layout)', 'normalised_mcep'
+    own = model.state_dict()
+    for key, value in state.items():
+        own[key].copy_(torch.from_numpy(value))
+    features = data.to_device(feats_np, dev)
+    frames_per_step = int(feats_np['n_frames'].sum())
+    optimizer = optim.Adam(model.parameters(), lr=0.01)
+
+    def step():
+        optimizer.zero_grad()
+        loss, _ = model(features)
+        loss.backward()
+        optimizer.step()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    final_loss = float(distributed.mean_scalar(loss.detach()).item())
+
+    result = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n_gpus * frames_per_step * args.steps / elapsed
+        result = {
+            'metric': 'acoustic frames/sec (fwd+bwd+step), F0Model 600->1, batch 256x1000' if args.config == 'c2'
+            else 'acoustic frames/sec (fwd+bwd+step), RNN_SPSS GRU-512 600->80, batch 64x1000',
+            'value': round(value, 1), 'unit': 'frames/s', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.precision, 'data': 'synthetic',
+            'config': {'workload': '%s, %d utterances x %d frames per GPU, P=%d phones, synthetic lab/dur/%s, '
+                                   'Adam lr 0.01, fp32 master weights' % (name, per_gpu, args.frames,
+                                                                          feats_np['dur'].shape[1], target),
+                       'global_batch': per_gpu * n_gpus, 'frames_per_utterance': args.frames,
+                       'parallelism': 'dp%d' % n_gpus},
+            'final_loss': round(final_loss, 6),
+        }
+        if args.config == 'c2':
+            step_tflops = F0_FLOPS_PER_FRAME * frames_per_step / (ms_per_step * 1e-3) / 1e12
+            peak = MFMA_BF16_PEAK_TFLOPS if args.precision == 'bf16' else MFMA_F32_PEAK_TFLOPS
+            result['step_algorithmic_tflops'] = round(step_tflops, 2)
+            result['step_frac_of_mfma_peak'] = round(step_tflops / peak, 4)
+    if rank == 0 and args.config == 'c2' and not args.no_roofline:
+        result['roofline'] = roofline_f0(features, model, args.precision)
+    if rank == 0 and n_gpus == 1 and args.config == 'c2' and not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline_f0(args.frames)
+    distributed.barrier()
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,173 @@
+/*
+ * morgana_hip.h - C ABI of libmorgana_hip.so: the MI355X (gfx950) kernels behind morgana's acoustic-model
+ * training hot path (ExperimentBuilder.train_epoch -> BaseSPSS.forward -> backward -> Adam).
+ *
+ * The reference (ZackHodari/morgana) is pure Python and has no FFI; every entry point below replaces the
+ * PyTorch-eager op sequence of the cited reference lines.  The reference-side binding a maintainer would add is
+ * the ctypes stub shown in INTEGRATION.md (morgana_amd/_lib.py is that stub, used by this repo's own host layer).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / C++ types.  All pointers are DEVICE pointers unless a
+ *     parameter is documented as host.  `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - Every function is asynchronous on `stream`, never allocates or frees memory and never synchronises the
+ *     device: the caller owns outputs and workspaces (sizes from the *_workspace_bytes helpers).
+ *   - Return value: 0 on success, negative MG_E* on error; mg_last_error() gives a thread-local message.
+ *   - Row-major everywhere.  "bf16" buffers hold raw 16-bit bfloat16 values (uint16_t).
+ *   - Gather convention ("rows"): an int32 array, one entry per output row, holding the source-table row or -1
+ *     for the all-zero pad row (reference: the zero `padder` frame appended at utils.py:206-207).
+ */
+#ifndef MORGANA_HIP_H
+#define MORGANA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MG_OK 0
+#define MG_EINVAL (-1)   /* bad argument (shape, alignment, null pointer) */
+#define MG_ELAUNCH (-2)  /* HIP reported a launch error */
+#define MG_EWORKSPACE (-3) /* workspace too small */
+
+#define MG_ACT_NONE 0
+#define MG_ACT_SIGMOID 1
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Library
+ * ---------------------------------------------------------------------------------------------------------------- */
+const char* mg_last_error(void);
+int mg_version(void);           /* ABI version, bumped on incompatible change */
+const char* mg_build_arch(void); /* "gfx950" */
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * K1  upsample_to_repetitions            reference: morgana/utils.py:175-228
+ * ---------------------------------------------------------------------------------------------------------------- */
+/* n_frames[b] = sum_p dur[b,p]; *tmax = max_b n_frames[b]  (utils.py:198-199).  dur int64 [B,P]. */
+int mg_upsample_lengths(const int64_t* dur, int B, int P, int64_t* n_frames, int64_t* tmax, void* stream);
+
+/* Frame->phone map (utils.py:214-220, the per-utterance np.repeat loop).  Any of the outputs may be NULL.
+ *   idx64 [B,t_cap]  phone index or -1   (the reference's `repeated_idxs`, bit exact)
+ *   rows32[B,t_cap]  b*P + phone or -1   (flat source row, the gather convention of this library)
+ * Frames t >= n_frames[b] get -1.  Requires t_cap >= 0 and P <= 16384.  If t_cap < n_frames[b] the row is cropped. */
+int mg_upsample_index(const int64_t* dur, int B, int P, int t_cap, int64_t* idx64, int32_t* rows32, void* stream);
+
+/* out[m,:] = rows[m] < 0 ? 0 : src[rows[m],:]   (utils.py:226).  src [R,F] f32, out [M,F] f32. */
+int mg_gather_rows_f32(const float* src, const int32_t* rows, float* out, int64_t M, int F, void* stream);
+/* Same gather, output converted to bf16 with leading dimension ldo >= F; columns F..ldo-1 are zero filled. */
+int mg_gather_rows_bf16(const float* src, const int32_t* rows, uint16_t* out, int64_t M, int F, int ldo, void* stream);
+
+/* Adjoint of the gather (autograd of utils.py:226): grad_src[b,p,:] = sum of grad_out[b,t,:] over the frames of
+ * phone p (frames of a phone are contiguous).  grad_out [B,T,F], dur int64 [B,P], grad_src [B,P,F]. Deterministic. */
+int mg_upsample_backward_f32(const float* grad_out, const int64_t* dur, float* grad_src, int B, int P, int T, int F,
+                             void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * sequence_mask                           reference: morgana/utils.py:115-144
+ * ---------------------------------------------------------------------------------------------------------------- */
+/* mask[b,t] = t < seq_len[b].  elem_size selects the output type: 1 = uint8, 4 = float32, 8 = int64. */
+int mg_sequence_mask(const int64_t* seq_len, int B, int max_len, void* mask, int elem_size, int as_float,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * K4  seq_len-masked MSE, forward + backward   reference: morgana/losses.py:29-51
+ * ---------------------------------------------------------------------------------------------------------------- */
+/* loss = mean_{b,d}( sum_t m[b,t] (p-y)^2 / n_b ), n_b = min(seq_len[b], T) (T when seq_len == NULL);
+ * grad = 2 (p-y) m / (n_b B D) * grad_scale, written for every element (zeros on padding).  n_b == 0 gives NaN,
+ * as the reference does.  pred/target [B,T,D] f32; loss: one float; grad may be NULL.
+ * workspace: mg_masked_mse_workspace_bytes(B,T,D) bytes.  Deterministic two-stage reduction (no atomics). */
+size_t mg_masked_mse_workspace_bytes(int B, int T, int D);
+int mg_masked_mse_f32(const float* pred, const float* target, const int64_t* seq_len, int B, int T, int D,
+                      float grad_scale, float* loss, float* grad, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * K5  mvn / minmax normalisers            reference: morgana/data.py:533-538, 579-590
+ * ---------------------------------------------------------------------------------------------------------------- */
+#define MG_NORM_MVN 0         /* (x - mean) / (std_dev + 1e-8)       p0 = mean, p1 = std_dev */
+#define MG_DENORM_MVN 1       /* x * std_dev + mean                                             */
+#define MG_NORM_MINMAX 2      /* (x - mmin) / scale,  scale = mmax - mmin, |scale| <= 1e-8 -> 1  p0 = mmin, p1 = mmax */
+#define MG_DENORM_MINMAX 3    /* x * scale + mmin                                               */
+/* x, out: n_rows x D f32 (any leading batch dims flattened); p0, p1: D f32.  In place (out == x) is allowed. */
+int mg_normalise_f32(const float* x, float* out, const float* p0, const float* p1, int64_t n_rows, int D, int kind,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * K2  Linear (+Sigmoid) stack             reference: nn.Linear / nn.Sigmoid in README.rst:65-73 run by
+ *                                         SequentialWithRecurrent.forward, morgana/utils.py:401-418
+ * f32 = exact fp32 (v_mfma_f32_32x32x2_f32), the 1e-4 parity mode.
+ * bf16 = bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16), the throughput mode.
+ * ---------------------------------------------------------------------------------------------------------------- */
+/* Y[m,:] = act( A[row(m),:] W^T + bias ).  A [*,K] (lda), rows NULL = identity else gather; W [N,K]; Y [M,N] (ldy). */
+int mg_linear_fwd_f32(const float* A, int lda, const int32_t* rows, int64_t M, int K, const float* W,
+                      const float* bias, int N, float* Y, int ldy, int act, void* stream);
+/* dX = (dY W) [* H (1-H)].  dY [M,N]; W [N,K]; H NULL or [M,K] = the sigmoid OUTPUT feeding this layer; dX [M,K]. */
+int mg_linear_dgrad_f32(const float* dY, int64_t M, int N, const float* W, int K, const float* H, float* dX,
+                        void* stream);
+/* dW[n,k] (+)= sum_m dY[m,n] A[row(m),k];  db[n] (+)= sum_m dY[m,n].  accumulate != 0 adds into dW/db.
+ * workspace: mg_linear_wgrad_workspace_bytes(M,N,K).  Deterministic (split-M slabs + ordered reduce). */
+size_t mg_linear_wgrad_workspace_bytes(int64_t M, int N, int K);
+int mg_linear_wgrad_f32(const float* dY, const float* A, int lda, const int32_t* rows, int64_t M, int N, int K,
+                        float* dW, float* db, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* bf16 variants: A, W, H, Y are bf16; K and N of the bf16 buffers are padded: lda/ldw/ldy multiples of 8 elements,
+ * padding columns must be zero (mg_cast_pad_bf16 / mg_gather_rows_bf16 produce such buffers).  bias, dW, db f32. */
+/* Y is bf16 [M,ldy] (y_f32 == 0) or f32 [M,ldy] (y_f32 != 0); ldy a multiple of 8; columns N..ldy-1 are written as 0. */
+int mg_linear_fwd_bf16(const uint16_t* A, int lda, const int32_t* rows, int64_t M, int K, const uint16_t* W, int ldw,
+                       const float* bias, int N, void* Y, int ldy, int y_f32, int act, void* stream);
+/* WT = W^T as bf16 [K,N] (ldwt). */
+int mg_linear_dgrad_bf16(const uint16_t* dY, int lddy, int64_t M, int N, const uint16_t* WT, int ldwt, int K,
+                         const uint16_t* H, int ldh, void* dX, int lddx, int dx_f32, void* stream);
+int mg_linear_wgrad_bf16(const uint16_t* dY, int lddy, const uint16_t* A, int lda, const int32_t* rows, int64_t M,
+                         int N, int K, float* dW, float* db, int accumulate, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+/* dst[r, 0:cols] = bf16(src[r, 0:cols]), dst[r, cols:ldd] = 0.  src f32 [rows, cols] (lds). */
+int mg_cast_pad_bf16(const float* src, int lds, uint16_t* dst, int ldd, int64_t rows, int cols, void* stream);
+/* dst[c, 0:rows] = bf16(src[r, c]) transposed, dst [cols, ldd], zero padded. */
+int mg_cast_transpose_bf16(const float* src, int lds, uint16_t* dst, int ldd, int rows, int cols, void* stream);
+/* dst f32 [rows, cols] = src bf16 [rows, cols] (lds). */
+int mg_cast_bf16_f32(const uint16_t* src, int lds, float* dst, int ldd, int64_t rows, int cols, void* stream);
+/* elementwise sigmoid forward / backward for a stand-alone nn.Sigmoid. */
+int mg_sigmoid_f32(const float* x, float* y, int64_t n, void* stream);
+int mg_sigmoid_grad_f32(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * K3  GRU through RecurrentCuDNNWrapper   reference: morgana/utils.py:345-393 + torch.nn.GRU (gates r, z, n)
+ * The sort / pack / unpack of the reference only restricts item b to its first seq_len[b] steps; here that is a
+ * per-item length mask, outputs beyond the length are exactly 0 and h_n is the state at the last valid step.
+ * ---------------------------------------------------------------------------------------------------------------- */
+/* Forward recurrence, one launch per step.
+ *   xproj  [B,T,3H] = x W_ih^T + b_ih (computed with mg_linear_fwd_*); w_hh [3H,H]; b_hh [3H]; seq_len NULL or int64 [B]
+ *   hstate [B,T+1,H]: slot 0 must hold h0 (or zeros) on entry; slot t+1 receives the state after step t (frozen once
+ *                     t >= seq_len[b]), so h_n = hstate[:, T, :] and h_{t-1} = hstate[:, t, :] for the backward
+ *   out    [B,T,H]   = h_t on valid steps, exactly 0 on padded steps (pad_packed_sequence, utils.py:383)
+ *   saved  [B,T,4H]  = (r, z, n, W_hn h + b_hn) for the backward */
+int mg_gru_fwd_f32(const float* xproj, const float* w_hh, const float* b_hh, const int64_t* seq_len, int B, int T, int H,
+                   float* hstate, float* out, float* saved, void* stream);
+/* BPTT, one launch per step.  grad_out [B,T,H]; grad_hn NULL or [B,H] (gradient of h_n).
+ * Produces dxproj [B,T,3H] (= dL/d xproj: feed to wgrad / dgrad of W_ih), dhproj [B,T,3H] (= dL/d(h W_hh^T + b_hh):
+ * dW_hh = dhproj^T h_prev with h_prev rows = hstate[:, t, :], db_hh = column sums) and dh0 [B,H].
+ * workspace: mg_gru_bwd_workspace_bytes(B,H). */
+size_t mg_gru_bwd_workspace_bytes(int B, int H);
+int mg_gru_bwd_f32(const float* grad_out, const float* grad_hn, const float* hstate, const float* saved, const float* w_hh,
+                   const int64_t* seq_len, int B, int T, int H, float* dxproj, float* dhproj, float* dh0, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Optimiser / EMA                         reference: torch.optim.Adam at experiment_builder.py:516, :468-474;
+ *                                         ExponentialMovingAverage.update_params, morgana/utils.py:443-456
+ * ---------------------------------------------------------------------------------------------------------------- */
+/* One Adam step over a flat fp32 parameter buffer (torch defaults: L2 weight decay added to the gradient).
+ * grad is read as grad * grad_scale (1/world_size after a sum all-reduce).  step is 1-based. */
+int mg_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+                     void* stream);
+/* shadow -= (1 - decay) * (shadow - param). */
+int mg_ema_update_f32(float* shadow, const float* param, int64_t n, float decay, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MORGANA_HIP_H */

@@ -1,0 +1,92 @@
+"""ctypes binding of ``libmorgana_hip.so`` (C ABI declared in ``include/morgana_hip.h``).
+
+This is the stub a maintainer of the reference would add: the reference has no FFI of its own, its
+hot path is PyTorch eager.  There is NO fallback: if the shared library is missing or a call fails, an exception is
+raised.  Nothing here imports the oracle.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmorgana_hip.so')
+
+c_void_p, c_int, c_int64, c_float, c_size_t, c_char_p = (
+    ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t, ctypes.c_char_p)
+
+# name -> (restype, argtypes); must list every symbol of include/morgana_hip.h (checked by tests/test_abi.py).
+SIGNATURES = {
+    'mg_last_error': (c_char_p, []),
+    'mg_version': (c_int, []),
+    'mg_build_arch': (c_char_p, []),
+    'mg_upsample_lengths': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'mg_upsample_index': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'mg_gather_rows_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    'mg_gather_rows_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    'mg_upsample_backward_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'mg_sequence_mask': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    'mg_masked_mse_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'mg_masked_mse_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
+                                  c_void_p, c_size_t, c_void_p]),
+    'mg_normalise_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    'mg_linear_fwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                                  c_int, c_int, c_void_p]),
+    'mg_linear_dgrad_f32': (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'mg_linear_wgrad_workspace_bytes': (c_size_t, [c_int64, c_int, c_int]),
+    'mg_linear_wgrad_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
+                                    c_int, c_void_p, c_size_t, c_void_p]),
+    'mg_linear_fwd_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_int,
+                                   c_void_p, c_int, c_int, c_int, c_void_p]),
+    'mg_linear_dgrad_bf16': (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                                     c_void_p, c_int, c_int, c_void_p]),
+    'mg_linear_wgrad_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p,
+                                     c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'mg_cast_pad_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    'mg_cast_transpose_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'mg_cast_bf16_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    'mg_sigmoid_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    'mg_sigmoid_grad_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    'mg_gru_fwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                               c_void_p, c_void_p]),
+    'mg_gru_bwd_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'mg_gru_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'mg_adam_step_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
+                                 c_float, c_int64, c_float, c_void_p]),
+    'mg_ema_update_f32': (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
+}
+
+_lib = None
+
+
+class MorganaHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the HIP library once and attach the signatures.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MorganaHipError(
+            'libmorgana_hip.so is missing (%s): build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            'or `make -C morgana_amd/csrc`.  There is no CPU fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().mg_last_error().decode('utf-8', 'replace')
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = last_error()
+        if rc == -1:
+            raise ValueError('%s: %s' % (what, msg))
+        raise MorganaHipError('%s failed (code %d): %s' % (what, rc, msg))

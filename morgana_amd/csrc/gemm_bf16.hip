@@ -1,0 +1,473 @@
+// K2 (bf16 throughput mode) - Linear forward / dgrad / wgrad on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).
+//
+// Reference: the nn.Linear + nn.Sigmoid stack of README.rst:65-73 run by SequentialWithRecurrent.forward
+// (morgana/utils.py:401-418) and its autograd backward; the reference runs them as fp32 ATen addmm/sigmoid kernels.
+//
+// Operand maps of v_mfma_f32_32x32x16_bf16 (lane l, r = l&31, h = l>>5): A[row r][k = 8h+j], B[k = 8h+j][col r],
+// j = 0..7 (one 16-byte fragment); C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+//
+//   gemm_nt  C = A' B^T   both operands contraction-contiguous ([m][k], [n][k]): fragments are ds_read_b128 from
+//            64-byte LDS rows whose 16-byte chunks are XOR-swizzled by (row>>2)&3 (conflict free for the 4x16 lane
+//            groups of ds_read_b128).  Used for forward (B = W) and dgrad (A = dY, B = W^T).
+//   gemm_tn  C = A^T B    both operands contraction-strided ([m][n], [m][k]): tiles are straight row copies and the
+//            fragments come from ds_read_b64_tr_b16 (hardware transpose read); rows padded to 320 bytes so the 4 rows
+//            a half wave touches land on disjoint banks.  Used for wgrad, split over M into fp32 slabs that are
+//            summed in a fixed order (deterministic; no float atomics).
+// The layer-1 gather (upsample_to_repetitions) is fused into the A-tile loaders through the `rows` array.
+// Epilogues stage the fp32 accumulators through LDS so that every global store is a 16-byte lane (8 bf16).
+#include "common.h"
+
+typedef __bf16 bfv8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bfv4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define EPI_BIAS 0
+#define EPI_BIAS_SIGMOID 1
+#define EPI_SIGMOID_GRAD 2
+
+#define NT_BK 32  // contraction depth per LDS tile (2 MFMA k-steps)
+
+__device__ __forceinline__ u32x4 ldg16(const uint16_t* p) { return *reinterpret_cast<const u32x4*>(p); }
+
+// C[M,N] (bf16, ldc) = epi( A'[M,Kc] * B[N,Kc]^T ).  lda/ldb multiples of 8, padding columns zero.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
+                                                           int64_t M, const uint16_t* __restrict__ Bm, int ldb, int N,
+                                                           const float* __restrict__ bias, const uint16_t* __restrict__ H, int ldh,
+                                                           void* __restrict__ Cv, int ldc, int tiles_n, int c_f32) {
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int IT_A = (BM * 4 + 255) / 256;
+    constexpr int IT_B = (BN * 4 + 255) / 256;
+    constexpr int STG_LD = WN + 4;                       // fp32 staging row pitch (floats)
+    constexpr int TILE_BYTES = (BM + BN) * 64;
+    constexpr int STG_BYTES = 4 * WM * STG_LD * 4;
+    constexpr int LDS_BYTES = TILE_BYTES > STG_BYTES ? TILE_BYTES : STG_BYTES;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + BM * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+    const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * BM;
+    const int n0 = (blockIdx.x % tiles_n) * BN;
+    const int kc = lda < ldb ? lda : ldb;                // columns beyond are zero in the shorter operand
+    const int n_kt = (kc + NT_BK - 1) / NT_BK;
+
+    const uint16_t* a_ptr[IT_A];
+#pragma unroll
+    for (int i = 0; i < IT_A; ++i) {
+        const int f = tid + 256 * i;
+        const int64_t m = m0 + (f >> 2);
+        a_ptr[i] = nullptr;
+        if (f < BM * 4 && m < M) {
+            if (rows) {
+                const int r = rows[m];
+                if (r >= 0) a_ptr[i] = A + (size_t)r * lda;
+            } else {
+                a_ptr[i] = A + (size_t)m * lda;
+            }
+        }
+    }
+    const uint16_t* b_ptr[IT_B];
+#pragma unroll
+    for (int i = 0; i < IT_B; ++i) {
+        const int f = tid + 256 * i;
+        const int n = n0 + (f >> 2);
+        b_ptr[i] = (f < BN * 4 && n < N) ? Bm + (size_t)n * ldb : nullptr;
+    }
+
+    u32x4 ra[IT_A], rb[IT_B];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < IT_A; ++i) {
+            const int k = k0 + ((tid + 256 * i) & 3) * 8;
+            ra[i] = (a_ptr[i] && k < lda) ? ldg16(a_ptr[i] + k) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < IT_B; ++i) {
+            const int k = k0 + ((tid + 256 * i) & 3) * 8;
+            rb[i] = (b_ptr[i] && k < ldb) ? ldg16(b_ptr[i] + k) : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < IT_A; ++i) {
+            const int f = tid + 256 * i;
+            if (f < BM * 4) {
+                const int row = f >> 2, c = f & 3;
+                *reinterpret_cast<u32x4*>(As + row * 64 + ((c ^ ((row >> 2) & 3)) << 4)) = ra[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < IT_B; ++i) {
+            const int f = tid + 256 * i;
+            if (f < BN * 4) {
+                const int row = f >> 2, c = f & 3;
+                *reinterpret_cast<u32x4*>(Bs + row * 64 + ((c ^ ((row >> 2) & 3)) << 4)) = rb[i];
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int lr = lane & 31, lh = lane >> 5;
+    load_tiles(0);
+    store_tiles();
+    __syncthreads();
+    for (int kt = 0; kt < n_kt; ++kt) {
+        if (kt + 1 < n_kt) load_tiles((kt + 1) * NT_BK);
+#pragma unroll
+        for (int ks = 0; ks < NT_BK / 16; ++ks) {
+            const int c = ks * 2 + lh;
+            bfv8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm0 + i * 32 + lr;
+                a[i] = *reinterpret_cast<const bfv8*>(As + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn0 + j * 32 + lr;
+                b[j] = *reinterpret_cast<const bfv8*>(Bs + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (kt + 1 < n_kt) {
+            store_tiles();
+            __syncthreads();
+        }
+    }
+
+    // Epilogue: stage this wave's WM x WN fp32 tile in LDS, then 8 columns (16 bytes of bf16) per lane.
+    float* stg = reinterpret_cast<float*>(smem) + wave * WM * STG_LD;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stg[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * STG_LD + j * 32 + lr] = acc[i][j][r];
+    __syncthreads();
+    constexpr int CPR = WN / 8;          // 16-byte chunks per row
+    constexpr int RPI = 64 / CPR;        // rows per wave instruction
+#pragma unroll
+    for (int it = 0; it < WM / RPI; ++it) {
+        const int rl = it * RPI + lane / CPR;
+        const int cl = (lane % CPR) * 8;
+        const int64_t row = m0 + wm0 + rl;
+        const int col = n0 + wn0 + cl;
+        if (row >= M || col >= ldc) continue;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(&stg[rl * STG_LD + cl]);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(&stg[rl * STG_LD + cl + 4]);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        bfv8 hv;
+        if (EPI == EPI_SIGMOID_GRAD) hv = *reinterpret_cast<const bfv8*>(H + (size_t)row * ldh + col);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = v[e];
+            if (col + e >= N) x = 0.f;
+            else if (EPI == EPI_BIAS) x += bias ? bias[col + e] : 0.f;
+            else if (EPI == EPI_BIAS_SIGMOID) x = mg_sigmoid(x + (bias ? bias[col + e] : 0.f));
+            else {
+                const float h = (float)hv[e];
+                x = x * h * (1.f - h);
+            }
+            v[e] = x;
+        }
+        if (c_f32) {
+            float* crow = reinterpret_cast<float*>(Cv) + (size_t)row * ldc + col;
+            *reinterpret_cast<f32x4*>(crow) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(crow + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+            bfv8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+            *reinterpret_cast<bfv8*>(reinterpret_cast<uint16_t*>(Cv) + (size_t)row * ldc + col) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// wgrad: slab[s][n][k] = sum_{m in split s} dY[m][n] * A'[m][k];  bslab[s][n] = sum_m dY[m][n]
+// ---------------------------------------------------------------------------------------------------------------------
+#define TN_BM 32  // contraction rows per LDS tile (2 MFMA k-steps)
+
+__device__ __forceinline__ bfv8 tr_frag(const unsigned char* tile, int pitch, int col0, int lane, int ks) {
+    // 32x32x16 operand whose contraction index is the LDS row: lane group g = lane>>4 covers operand rows/cols
+    // 16*(g&1) .. +15 and contraction rows 8*(g>>1) .. +7 of k-step ks; lane 4q+p of the group supplies the address
+    // of row q, columns 4p..4p+3 of its 4x16 block (ds_read_b64_tr_b16), two blocks give the 8 contraction values.
+    const int i = lane & 15, g = lane >> 4;
+    const int q = i >> 2, p = i & 3;
+    const int mrow = ks * 16 + 8 * (g >> 1) + q;
+    const unsigned char* addr = tile + mrow * pitch + (col0 + 16 * (g & 1) + 4 * p) * 2;
+    const bfv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(addr));
+    const bfv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(addr + 4 * pitch));
+    bfv8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+template <int BNT, int BKT, int WAVES_N, int WAVES_K>
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const uint16_t* __restrict__ dY, int lddy, const uint16_t* __restrict__ A, int lda,
+                                                         const int32_t* __restrict__ rows, int64_t M, int N, int K, int64_t m_chunk,
+                                                         float* __restrict__ slab, float* __restrict__ bslab, int tiles_k) {
+    constexpr int WN = BNT / WAVES_N, WK = BKT / WAVES_K;
+    constexpr int TN = WN / 32, TK = WK / 32;
+    constexpr int PY = BNT * 2 + ((BNT * 2) % 256 == 0 ? 64 : 0);   // LDS row pitch in bytes
+    constexpr int PX = BKT * 2 + ((BKT * 2) % 256 == 0 ? 64 : 0);
+    constexpr int CY = BNT / 8, CX = BKT / 8;                      // 16-byte chunks per row
+    constexpr int IT_Y = (TN_BM * CY + 255) / 256;
+    constexpr int IT_X = (TN_BM * CX + 255) / 256;
+    static_assert(WAVES_N * WAVES_K == 4, "4 waves per workgroup");
+
+    __shared__ __attribute__((aligned(16))) unsigned char Ys[TN_BM * PY];
+    __shared__ __attribute__((aligned(16))) unsigned char Xs[TN_BM * PX];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn0 = (wave / WAVES_K) * WN, wk0 = (wave % WAVES_K) * WK;
+    const int n0 = (blockIdx.x / tiles_k) * BNT;
+    const int k0 = (blockIdx.x % tiles_k) * BKT;
+    const int s = blockIdx.y;
+    const int64_t m_lo = (int64_t)s * m_chunk;
+    const int64_t m_hi = min(M, m_lo + m_chunk);
+    const bool do_bias = (blockIdx.x % tiles_k) == 0 && bslab != nullptr;
+
+    u32x4 ry[IT_Y], rx[IT_X];
+    auto load_tiles = [&](int64_t mb) {
+#pragma unroll
+        for (int i = 0; i < IT_Y; ++i) {
+            const int f = tid + 256 * i;
+            ry[i] = u32x4{0u, 0u, 0u, 0u};
+            if (f < TN_BM * CY) {
+                const int64_t m = mb + f / CY;
+                const int c = n0 + (f % CY) * 8;
+                if (m < m_hi && c < lddy) ry[i] = ldg16(dY + (size_t)m * lddy + c);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < IT_X; ++i) {
+            const int f = tid + 256 * i;
+            rx[i] = u32x4{0u, 0u, 0u, 0u};
+            if (f < TN_BM * CX) {
+                const int64_t m = mb + f / CX;
+                const int c = k0 + (f % CX) * 8;
+                if (m < m_hi && c < lda) {
+                    int64_t src = m;
+                    if (rows) src = rows[m];
+                    if (src >= 0) rx[i] = ldg16(A + (size_t)src * lda + c);
+                }
+            }
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < IT_Y; ++i) {
+            const int f = tid + 256 * i;
+            if (f < TN_BM * CY) *reinterpret_cast<u32x4*>(Ys + (f / CY) * PY + (f % CY) * 16) = ry[i];
+        }
+#pragma unroll
+        for (int i = 0; i < IT_X; ++i) {
+            const int f = tid + 256 * i;
+            if (f < TN_BM * CX) *reinterpret_cast<u32x4*>(Xs + (f / CX) * PX + (f % CX) * 16) = rx[i];
+        }
+    };
+
+    f32x16 acc[TN][TK];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bsum = 0.f;
+
+    if (m_lo < m_hi) {
+        load_tiles(m_lo);
+        store_tiles();
+        __syncthreads();
+        for (int64_t mb = m_lo; mb < m_hi; mb += TN_BM) {
+            const bool more = mb + TN_BM < m_hi;
+            if (more) load_tiles(mb + TN_BM);
+#pragma unroll
+            for (int ks = 0; ks < TN_BM / 16; ++ks) {
+                bfv8 a[TN], b[TK];
+#pragma unroll
+                for (int i = 0; i < TN; ++i) a[i] = tr_frag(Ys, PY, wn0 + i * 32, lane, ks);
+#pragma unroll
+                for (int j = 0; j < TK; ++j) b[j] = tr_frag(Xs, PX, wk0 + j * 32, lane, ks);
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            if (do_bias && tid < BNT) {
+#pragma unroll
+                for (int r = 0; r < TN_BM; ++r) bsum += mg_bf2f(*reinterpret_cast<const uint16_t*>(Ys + r * PY + tid * 2));
+            }
+            __syncthreads();
+            if (more) {
+                store_tiles();
+                __syncthreads();
+            }
+        }
+    }
+
+    const int lr = lane & 31, lh = lane >> 5;
+    float* out = slab + (size_t)s * N * K;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+#pragma unroll
+        for (int j = 0; j < TK; ++j) {
+            const int col = k0 + wk0 + j * 32 + lr;
+            if (col >= K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n0 + wn0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < N) out[(size_t)row * K + col] = acc[i][j][r];
+            }
+        }
+    }
+    if (do_bias && tid < BNT && n0 + tid < N) bslab[(size_t)s * N + n0 + tid] = bsum;
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_bf16path_kernel(const float* __restrict__ slab, int64_t n, int S, float* __restrict__ dst, int accumulate) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float v = accumulate ? dst[i] : 0.f;
+        for (int s = 0; s < S; ++s) v += slab[(size_t)s * n + i];
+        dst[i] = v;
+    }
+}
+
+struct WgradPlanB {
+    int tiles_n, tiles_k, S;
+    int64_t m_chunk;
+    bool narrow;
+};
+
+// Must match wgrad_plan() in gemm_f32.hip (shared workspace-size helper mg_linear_wgrad_workspace_bytes).
+static WgradPlanB wgrad_plan_b(int64_t M, int N, int K) {
+    WgradPlanB p;
+    p.narrow = N <= 32;
+    const int bnt = p.narrow ? 32 : 128;
+    p.tiles_n = (int)mg_ceil_div(N, bnt);
+    p.tiles_k = (int)mg_ceil_div(K, 128);
+    const int64_t tiles = (int64_t)p.tiles_n * p.tiles_k;
+    int64_t S = mg_ceil_div(1024, tiles);
+    const int64_t max_s = mg_ceil_div(M, 512);
+    if (S > max_s) S = max_s;
+    if (S < 1) S = 1;
+    if (S > 65535) S = 65535;
+    p.m_chunk = mg_align_up((size_t)mg_ceil_div(M, S), 32);
+    p.S = (int)mg_ceil_div(M, p.m_chunk);
+    if (p.S < 1) p.S = 1;
+    return p;
+}
+
+static bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
+
+extern "C" {
+
+int mg_linear_fwd_bf16(const uint16_t* A, int lda, const int32_t* rows, int64_t M, int K, const uint16_t* W, int ldw,
+                       const float* bias, int N, void* Y, int ldy, int y_f32, int act, void* stream) {
+    MG_CHECK_ARG(A && W && Y && M >= 0 && K > 0 && N > 0, "mg_linear_fwd_bf16: bad arguments (M=%lld K=%d N=%d)", (long long)M, K, N);
+    MG_CHECK_ARG(lda >= K && ldw >= K && ldy >= N && lda % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0,
+                 "mg_linear_fwd_bf16: lda=%d ldw=%d ldy=%d must be multiples of 8 and cover K=%d / N=%d", lda, ldw, ldy, K, N);
+    MG_CHECK_ARG(al16(A) && al16(W) && al16(Y), "mg_linear_fwd_bf16: buffers must be 16-byte aligned");
+    MG_CHECK_ARG(act == MG_ACT_NONE || act == MG_ACT_SIGMOID, "mg_linear_fwd_bf16: unknown activation %d", act);
+    if (M == 0) return MG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (N <= 32) {
+        const int tn = (int)mg_ceil_div(ldy, 32);
+        const int64_t blocks = mg_ceil_div(M, 128) * tn;
+        MG_CHECK_ARG(blocks < 2147483647LL, "mg_linear_fwd_bf16: grid too large");
+        if (act == MG_ACT_SIGMOID)
+            hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 32, 4, 1, EPI_BIAS_SIGMOID>), dim3((unsigned)blocks), dim3(256), 0, st, A, lda, rows, M, W, ldw, N, bias, nullptr, 0, Y, ldy, tn, y_f32);
+        else
+            hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 32, 4, 1, EPI_BIAS>), dim3((unsigned)blocks), dim3(256), 0, st, A, lda, rows, M, W, ldw, N, bias, nullptr, 0, Y, ldy, tn, y_f32);
+    } else {
+        const int tn = (int)mg_ceil_div(ldy, 128);
+        const int64_t blocks = mg_ceil_div(M, 128) * tn;
+        MG_CHECK_ARG(blocks < 2147483647LL, "mg_linear_fwd_bf16: grid too large");
+        if (act == MG_ACT_SIGMOID)
+            hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128, 2, 2, EPI_BIAS_SIGMOID>), dim3((unsigned)blocks), dim3(256), 0, st, A, lda, rows, M, W, ldw, N, bias, nullptr, 0, Y, ldy, tn, y_f32);
+        else
+            hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128, 2, 2, EPI_BIAS>), dim3((unsigned)blocks), dim3(256), 0, st, A, lda, rows, M, W, ldw, N, bias, nullptr, 0, Y, ldy, tn, y_f32);
+    }
+    MG_CHECK_LAUNCH("mg_linear_fwd_bf16");
+    return MG_OK;
+}
+
+int mg_linear_dgrad_bf16(const uint16_t* dY, int lddy, int64_t M, int N, const uint16_t* WT, int ldwt, int K,
+                         const uint16_t* H, int ldh, void* dX, int lddx, int dx_f32, void* stream) {
+    MG_CHECK_ARG(dY && WT && dX && M >= 0 && N > 0 && K > 0, "mg_linear_dgrad_bf16: bad arguments (M=%lld N=%d K=%d)", (long long)M, N, K);
+    MG_CHECK_ARG(lddy >= N && ldwt >= N && lddx >= K && lddy % 8 == 0 && ldwt % 8 == 0 && lddx % 8 == 0 && (!H || (ldh >= K && ldh % 8 == 0)),
+                 "mg_linear_dgrad_bf16: leading dimensions must be multiples of 8 and cover N=%d / K=%d (lddy=%d ldwt=%d lddx=%d ldh=%d)", N, K, lddy, ldwt, lddx, ldh);
+    MG_CHECK_ARG(al16(dY) && al16(WT) && al16(dX) && (!H || al16(H)), "mg_linear_dgrad_bf16: buffers must be 16-byte aligned");
+    if (M == 0) return MG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    // C[M,K] = dY[M,N] * WT[K,N]^T : the NT kernel with contraction N, output width K.
+    if (K <= 32) {
+        const int tn = (int)mg_ceil_div(lddx, 32);
+        const int64_t blocks = mg_ceil_div(M, 128) * tn;
+        if (H)
+            hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 32, 4, 1, EPI_SIGMOID_GRAD>), dim3((unsigned)blocks), dim3(256), 0, st, dY, lddy, nullptr, M, WT, ldwt, K, nullptr, H, ldh, dX, lddx, tn, dx_f32);
+        else
+            hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 32, 4, 1, EPI_BIAS>), dim3((unsigned)blocks), dim3(256), 0, st, dY, lddy, nullptr, M, WT, ldwt, K, nullptr, nullptr, 0, dX, lddx, tn, dx_f32);
+    } else {
+        const int tn = (int)mg_ceil_div(lddx, 128);
+        const int64_t blocks = mg_ceil_div(M, 128) * tn;
+        MG_CHECK_ARG(blocks < 2147483647LL, "mg_linear_dgrad_bf16: grid too large");
+        if (H)
+            hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128, 2, 2, EPI_SIGMOID_GRAD>), dim3((unsigned)blocks), dim3(256), 0, st, dY, lddy, nullptr, M, WT, ldwt, K, nullptr, H, ldh, dX, lddx, tn, dx_f32);
+        else
+            hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128, 2, 2, EPI_BIAS>), dim3((unsigned)blocks), dim3(256), 0, st, dY, lddy, nullptr, M, WT, ldwt, K, nullptr, nullptr, 0, dX, lddx, tn, dx_f32);
+    }
+    MG_CHECK_LAUNCH("mg_linear_dgrad_bf16");
+    return MG_OK;
+}
+
+int mg_linear_wgrad_bf16(const uint16_t* dY, int lddy, const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N,
+                         int K, float* dW, float* db, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    MG_CHECK_ARG(dY && A && dW && M > 0 && N > 0 && K > 0, "mg_linear_wgrad_bf16: bad arguments (M=%lld N=%d K=%d)", (long long)M, N, K);
+    MG_CHECK_ARG(lddy >= N && lda >= K && lddy % 8 == 0 && lda % 8 == 0, "mg_linear_wgrad_bf16: lddy=%d lda=%d must be multiples of 8 covering N=%d / K=%d", lddy, lda, N, K);
+    MG_CHECK_ARG(al16(dY) && al16(A), "mg_linear_wgrad_bf16: buffers must be 16-byte aligned");
+    if (!workspace || workspace_bytes < mg_linear_wgrad_workspace_bytes(M, N, K)) {
+        mg_set_error("mg_linear_wgrad_bf16: workspace of %zu bytes needed, got %zu", mg_linear_wgrad_workspace_bytes(M, N, K), workspace_bytes);
+        return MG_EWORKSPACE;
+    }
+    const WgradPlanB p = wgrad_plan_b(M, N, K);
+    float* slab = (float*)workspace;
+    float* bslab = slab + (size_t)p.S * N * K;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)(p.tiles_n * p.tiles_k), (unsigned)p.S);
+    if (p.narrow)
+        hipLaunchKernelGGL((wgrad_bf16_kernel<32, 128, 1, 4>), grid, dim3(256), 0, st, dY, lddy, A, lda, rows, M, N, K, p.m_chunk, slab, db ? bslab : nullptr, p.tiles_k);
+    else
+        hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, dY, lddy, A, lda, rows, M, N, K, p.m_chunk, slab, db ? bslab : nullptr, p.tiles_k);
+    MG_CHECK_LAUNCH("mg_linear_wgrad_bf16/partial");
+    const int64_t nk = (int64_t)N * K;
+    int64_t blocks = mg_ceil_div(nk, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(slab_reduce_bf16path_kernel, dim3((unsigned)blocks), dim3(256), 0, st, slab, nk, p.S, dW, accumulate);
+    MG_CHECK_LAUNCH("mg_linear_wgrad_bf16/reduce");
+    if (db) {
+        hipLaunchKernelGGL(slab_reduce_bf16path_kernel, dim3((unsigned)mg_ceil_div(N, 256)), dim3(256), 0, st, bslab, (int64_t)N, p.S, db, accumulate);
+        MG_CHECK_LAUNCH("mg_linear_wgrad_bf16/reduce_bias");
+    }
+    return MG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,210 @@
+// K3 - GRU recurrence behind RecurrentCuDNNWrapper (reference: morgana/utils.py:345-393 around torch.nn.GRU,
+// used at models/f0_test_model.py:32-39; gate order r, z, n).
+//
+// Split of the work (all matmul-shaped work on MFMA):
+//   * input projection  xproj = x W_ih^T + b_ih   one big GEMM over all B*T frames (mg_linear_fwd_*), done by the caller
+//   * recurrence        T dependent steps of [B,H] x [H,3H]: one launch per step (this file).  Each workgroup owns a
+//                       16 (batch) x 16 (hidden unit) tile, its 4 waves split the contraction, fragments are loaded
+//                       straight from L2 as 16-byte lanes (h_{t-1} and W_hh are L2 resident: 128 KB + 3 MB at H=512),
+//                       v_mfma_f32_16x16x4_f32 accumulates the three gate pre-activations, a 12 KB LDS exchange sums
+//                       the 4 partials and the cell non-linearity is applied in the same kernel.
+//   * BPTT              one launch per step: dstate_t = carry + dhproj_{t+1} W_hh (MFMA), then the gate derivatives
+//   * dW_ih, dW_hh, dx  big GEMMs over all frames after the loop (mg_linear_wgrad_* / mg_linear_dgrad_*), caller side
+//
+// The reference sorts by length and packs; packing only restricts item b to its first seq_len[b] steps, so here a
+// per-item length mask freezes the state (h_n = state at the last valid step) and zeroes the padded outputs.
+//
+// 16x16x4 fragment trick: lane l = 16*q + i holds, for a 16-deep contraction block, the 4 consecutive values
+// k = 4q .. 4q+3 of row i (one 16-byte load); MFMA number e consumes element e, i.e. k = 4q + e.  A and B use the
+// same (q, e) <-> k map, so the block's 16 products are each taken exactly once.
+#include "common.h"
+
+#define GT 16  // tile edge (batch x hidden units)
+
+__device__ __forceinline__ f32x4 ld4_guard(const float* p, int valid, bool vec) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (valid >= 4 && vec) {
+        v = *reinterpret_cast<const f32x4*>(p);
+    } else {
+        if (valid > 0) v.x = p[0];
+        if (valid > 1) v.y = p[1];
+        if (valid > 2) v.z = p[2];
+        if (valid > 3) v.w = p[3];
+    }
+    return v;
+}
+
+// One forward step t.  hstate [B, T+1, H]: slot t holds h_{t-1} (slot 0 = h0), slot t+1 receives h_t.
+__global__ __launch_bounds__(256) void gru_fwd_step_kernel(const float* __restrict__ xproj, const float* __restrict__ w_hh,
+                                                           const float* __restrict__ b_hh, const int64_t* __restrict__ seq_len,
+                                                           int B, int T, int H, int t, float* __restrict__ hstate,
+                                                           float* __restrict__ out, float* __restrict__ saved, int vec) {
+    __shared__ float red[4][3][GT * GT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    const int j0 = blockIdx.x * GT, b0 = blockIdx.y * GT;
+    const int brow = b0 + li;   // A-operand row (batch item) of this lane
+    const int jrow = j0 + li;   // B-operand column (hidden unit) of this lane
+    const float* hp = hstate + ((size_t)(brow < B ? brow : 0) * (T + 1) + t) * H;
+    const float* wr = w_hh + (size_t)(jrow < H ? jrow : 0) * H;
+    const float* wz = wr + (size_t)H * H;
+    const float* wn = wz + (size_t)H * H;
+
+    f32x4 acc_r = {0.f, 0.f, 0.f, 0.f}, acc_z = acc_r, acc_n = acc_r;
+    for (int k0 = wave * 16; k0 < H; k0 += 64) {
+        const int k = k0 + 4 * q;
+        const int valid = H - k;
+        f32x4 a = (brow < B) ? ld4_guard(hp + k, valid, vec) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 br = {0.f, 0.f, 0.f, 0.f}, bz = br, bn = br;
+        if (jrow < H) {
+            br = ld4_guard(wr + k, valid, vec);
+            bz = ld4_guard(wz + k, valid, vec);
+            bn = ld4_guard(wn + k, valid, vec);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], br[e], acc_r, 0, 0, 0);
+            acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bz[e], acc_z, 0, 0, 0);
+            acc_n = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bn[e], acc_n, 0, 0, 0);
+        }
+    }
+    // C/D layout 16x16: col = lane&15 (hidden unit), row = 4*(lane>>4) + reg (batch item).
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int e = (4 * q + r) * GT + li;
+        red[wave][0][e] = acc_r[r];
+        red[wave][1][e] = acc_z[r];
+        red[wave][2][e] = acc_n[r];
+    }
+    __syncthreads();
+    const int bl = tid >> 4, jl = tid & 15;
+    const int b = b0 + bl, j = j0 + jl;
+    if (b < B && j < H) {
+        const int e = bl * GT + jl;
+        const float hr = ((red[0][0][e] + red[1][0][e]) + (red[2][0][e] + red[3][0][e])) + b_hh[j];
+        const float hz = ((red[0][1][e] + red[1][1][e]) + (red[2][1][e] + red[3][1][e])) + b_hh[H + j];
+        const float hn = ((red[0][2][e] + red[1][2][e]) + (red[2][2][e] + red[3][2][e])) + b_hh[2 * H + j];
+        const size_t row = (size_t)b * T + t;
+        const float* xp = xproj + row * 3 * H;
+        const float r = mg_sigmoid(xp[j] + hr);
+        const float z = mg_sigmoid(xp[H + j] + hz);
+        const float n = tanhf(xp[2 * H + j] + r * hn);
+        const float hprev = hstate[((size_t)b * (T + 1) + t) * H + j];
+        const float hnew = (1.f - z) * n + z * hprev;
+        const bool active = seq_len ? ((int64_t)t < seq_len[b]) : true;
+        hstate[((size_t)b * (T + 1) + t + 1) * H + j] = active ? hnew : hprev;
+        out[row * H + j] = active ? hnew : 0.f;
+        float* sv = saved + row * 4 * H;
+        sv[j] = r;
+        sv[H + j] = z;
+        sv[2 * H + j] = n;
+        sv[3 * H + j] = hn;
+    }
+}
+
+// One backward step.  t in [0, T): dstate_t = carry + dhproj[:, t+1, :] W_hh (skipped at t == T-1), then gate
+// derivatives of step t; carry <- dh_t * z_t (or dstate_t for finished items).  t == -1: only the matmul, result
+// (the gradient of h0) goes to dh0.
+__global__ __launch_bounds__(256) void gru_bwd_step_kernel(const float* __restrict__ grad_out, const float* __restrict__ hstate,
+                                                           const float* __restrict__ saved, const float* __restrict__ w_hh,
+                                                           const int64_t* __restrict__ seq_len, int B, int T, int H, int t,
+                                                           float* __restrict__ dxproj, float* __restrict__ dhproj,
+                                                           float* __restrict__ carry, float* __restrict__ dh0, int vec) {
+    __shared__ float red[4][GT * GT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    const int j0 = blockIdx.x * GT, b0 = blockIdx.y * GT;
+    const int G = 3 * H;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (t + 1 < T) {
+        const int brow = b0 + li;
+        const int jcol = j0 + li;
+        const float* dp = dhproj + ((size_t)(brow < B ? brow : 0) * T + (t + 1)) * G;
+        for (int g0 = wave * 16; g0 < G; g0 += 64) {
+            const int g = g0 + 4 * q;
+            f32x4 a = (brow < B) ? ld4_guard(dp + g, G - g, vec) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float bv = 0.f;
+                if (jcol < H && g + e < G) bv = w_hh[(size_t)(g + e) * H + jcol];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bv, acc, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][(4 * q + r) * GT + li] = acc[r];
+    __syncthreads();
+    const int bl = tid >> 4, jl = tid & 15;
+    const int b = b0 + bl, j = j0 + jl;
+    if (b < B && j < H) {
+        const int e = bl * GT + jl;
+        const float dstate = carry[(size_t)b * H + j] + ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e]));
+        if (t < 0) {
+            dh0[(size_t)b * H + j] = dstate;
+            return;
+        }
+        const size_t row = (size_t)b * T + t;
+        const bool active = seq_len ? ((int64_t)t < seq_len[b]) : true;
+        float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, c = dstate;
+        if (active) {
+            const float* sv = saved + row * 4 * H;
+            const float r = sv[j], z = sv[H + j], n = sv[2 * H + j], hn = sv[3 * H + j];
+            const float hprev = hstate[((size_t)b * (T + 1) + t) * H + j];
+            const float dh = dstate + grad_out[row * H + j];
+            dn = dh * (1.f - z) * (1.f - n * n);
+            dz = dh * (hprev - n) * z * (1.f - z);
+            dr = dn * hn * r * (1.f - r);
+            dnr = dn * r;
+            c = dh * z;
+        }
+        float* dx = dxproj + row * G;
+        float* dhp = dhproj + row * G;
+        dx[j] = dr;  dx[H + j] = dz;  dx[2 * H + j] = dn;
+        dhp[j] = dr; dhp[H + j] = dz; dhp[2 * H + j] = dnr;
+        carry[(size_t)b * H + j] = c;
+    }
+}
+
+__global__ __launch_bounds__(256) void gru_init_carry_kernel(const float* __restrict__ grad_hn, float* __restrict__ carry, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) carry[i] = grad_hn ? grad_hn[i] : 0.f;
+}
+
+extern "C" {
+
+int mg_gru_fwd_f32(const float* xproj, const float* w_hh, const float* b_hh, const int64_t* seq_len, int B, int T, int H,
+                   float* hstate, float* out, float* saved, void* stream) {
+    MG_CHECK_ARG(xproj && w_hh && b_hh && hstate && out && saved && B > 0 && T > 0 && H > 0, "mg_gru_fwd_f32: bad arguments (B=%d T=%d H=%d)", B, T, H);
+    const int vec = (H % 4 == 0) && (((uintptr_t)hstate | (uintptr_t)w_hh) % 16 == 0);
+    dim3 grid((unsigned)mg_ceil_div(H, GT), (unsigned)mg_ceil_div(B, GT));
+    for (int t = 0; t < T; ++t) {
+        hipLaunchKernelGGL(gru_fwd_step_kernel, grid, dim3(256), 0, (hipStream_t)stream, xproj, w_hh, b_hh, seq_len, B, T, H, t, hstate, out, saved, vec);
+    }
+    MG_CHECK_LAUNCH("mg_gru_fwd_f32");
+    return MG_OK;
+}
+
+size_t mg_gru_bwd_workspace_bytes(int B, int H) { return mg_align_up((size_t)B * H * sizeof(float), 256); }
+
+int mg_gru_bwd_f32(const float* grad_out, const float* grad_hn, const float* hstate, const float* saved, const float* w_hh,
+                   const int64_t* seq_len, int B, int T, int H, float* dxproj, float* dhproj, float* dh0, void* workspace,
+                   size_t workspace_bytes, void* stream) {
+    MG_CHECK_ARG(grad_out && hstate && saved && w_hh && dxproj && dhproj && dh0 && B > 0 && T > 0 && H > 0,
+                 "mg_gru_bwd_f32: bad arguments (B=%d T=%d H=%d)", B, T, H);
+    if (!workspace || workspace_bytes < mg_gru_bwd_workspace_bytes(B, H)) {
+        mg_set_error("mg_gru_bwd_f32: workspace of %zu bytes needed, got %zu", mg_gru_bwd_workspace_bytes(B, H), workspace_bytes);
+        return MG_EWORKSPACE;
+    }
+    float* carry = (float*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    const int vec = ((3 * H) % 4 == 0) && (((uintptr_t)dhproj) % 16 == 0);
+    int64_t n = (int64_t)B * H;
+    hipLaunchKernelGGL(gru_init_carry_kernel, dim3((unsigned)mg_ceil_div(n, 256)), dim3(256), 0, st, grad_hn, carry, n);
+    dim3 grid((unsigned)mg_ceil_div(H, GT), (unsigned)mg_ceil_div(B, GT));
+    for (int t = T - 1; t >= -1; --t) {
+        hipLaunchKernelGGL(gru_bwd_step_kernel, grid, dim3(256), 0, st, grad_out, hstate, saved, w_hh, seq_len, B, T, H, t, dxproj, dhproj, carry, dh0, vec);
+    }
+    MG_CHECK_LAUNCH("mg_gru_bwd_f32");
+    return MG_OK;
+}
+
+}  // extern "C"

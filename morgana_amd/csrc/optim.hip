@@ -1,0 +1,157 @@
+// Optimiser-side elementwise kernels: fused flat Adam (torch.optim.Adam at experiment_builder.py:516 / :474),
+// EMA (morgana/utils.py:443-456), fp32<->bf16 casts for the bf16 GEMM operands, stand-alone sigmoid.
+// All HBM-bound; one pass over flat buffers (the reference's foreach Adam is ~10 passes over 8 tensors).
+#include "common.h"
+
+#include <math.h>
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, float beta1,
+                                                   float beta2, float eps, float weight_decay, float step_size,
+                                                   float bc2_sqrt, float grad_scale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float p = param[i];
+        float g = grad[i] * grad_scale;
+        if (weight_decay != 0.f) g = g + weight_decay * p;       // L2 penalty added to the gradient
+        float mi = m[i];
+        mi = mi + (g - mi) * (1.f - beta1);                      // exp_avg.lerp_(grad, 1 - beta1)
+        float vi = v[i] * beta2 + (1.f - beta2) * g * g;         // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p = p - step_size * (mi / denom);                        // param.addcdiv_(exp_avg, denom, value=-step_size)
+        param[i] = p;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ shadow, const float* __restrict__ param, int64_t n, float one_minus_decay) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float s = shadow[i];
+        shadow[i] = s - one_minus_decay * (s - param[i]);
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_pad_bf16_kernel(const float* __restrict__ src, int lds, uint16_t* __restrict__ dst,
+                                                            int ldd, int64_t rows, int cols) {
+    const int64_t n = rows * ldd;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / ldd;
+        const int c = (int)(i - r * ldd);
+        dst[i] = c < cols ? mg_f2bf(src[r * lds + c]) : (uint16_t)0;
+    }
+}
+
+// dst[c, r] = src[r, c]; 32x32 LDS tile transpose.
+__global__ __launch_bounds__(256) void cast_transpose_bf16_kernel(const float* __restrict__ src, int lds, uint16_t* __restrict__ dst,
+                                                                  int ldd, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < rows && c < cols) ? src[(size_t)r * lds + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;   // output row c, output column r
+        if (c < cols && r < ldd) dst[(size_t)c * ldd + r] = r < rows ? mg_f2bf(tile[tx][j]) : (uint16_t)0;
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const uint16_t* __restrict__ src, int lds, float* __restrict__ dst,
+                                                            int ldd, int64_t rows, int cols) {
+    const int64_t n = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        dst[r * ldd + c] = mg_bf2f(src[r * lds + c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void sigmoid_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = mg_sigmoid(x[i]);
+}
+
+__global__ __launch_bounds__(256) void sigmoid_grad_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                           float* __restrict__ dx, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float s = y[i];
+        dx[i] = dy[i] * s * (1.f - s);
+    }
+}
+
+static int flat_grid(int64_t n) {
+    int64_t blocks = mg_ceil_div(n, 256 * 4);
+    if (blocks > 4096) blocks = 4096;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+extern "C" {
+
+int mg_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream) {
+    MG_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n >= 0 && step >= 1, "mg_adam_step_f32: bad arguments (n=%lld step=%lld)",
+                 (long long)n, (long long)step);
+    if (n == 0) return MG_OK;
+    // Host-side scalars in double, as torch computes them in Python floats.
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    hipLaunchKernelGGL(adam_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
+                       beta1, beta2, eps, weight_decay, step_size, bc2_sqrt, grad_scale);
+    MG_CHECK_LAUNCH("mg_adam_step_f32");
+    return MG_OK;
+}
+
+int mg_ema_update_f32(float* shadow, const float* param, int64_t n, float decay, void* stream) {
+    MG_CHECK_ARG(shadow && param && n >= 0, "mg_ema_update_f32: bad arguments");
+    if (n == 0) return MG_OK;
+    hipLaunchKernelGGL(ema_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, shadow, param, n, 1.0f - decay);
+    MG_CHECK_LAUNCH("mg_ema_update_f32");
+    return MG_OK;
+}
+
+int mg_cast_pad_bf16(const float* src, int lds, uint16_t* dst, int ldd, int64_t rows, int cols, void* stream) {
+    MG_CHECK_ARG(src && dst && rows >= 0 && cols > 0 && lds >= cols && ldd >= cols, "mg_cast_pad_bf16: bad arguments (rows=%lld cols=%d lds=%d ldd=%d)",
+                 (long long)rows, cols, lds, ldd);
+    if (rows == 0) return MG_OK;
+    hipLaunchKernelGGL(cast_pad_bf16_kernel, dim3(flat_grid(rows * ldd)), dim3(256), 0, (hipStream_t)stream, src, lds, dst, ldd, rows, cols);
+    MG_CHECK_LAUNCH("mg_cast_pad_bf16");
+    return MG_OK;
+}
+
+int mg_cast_transpose_bf16(const float* src, int lds, uint16_t* dst, int ldd, int rows, int cols, void* stream) {
+    MG_CHECK_ARG(src && dst && rows > 0 && cols > 0 && lds >= cols && ldd >= rows, "mg_cast_transpose_bf16: bad arguments (rows=%d cols=%d lds=%d ldd=%d)",
+                 rows, cols, lds, ldd);
+    dim3 grid((unsigned)mg_ceil_div(cols, 32), (unsigned)mg_ceil_div(ldd, 32));
+    hipLaunchKernelGGL(cast_transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, lds, dst, ldd, rows, cols);
+    MG_CHECK_LAUNCH("mg_cast_transpose_bf16");
+    return MG_OK;
+}
+
+int mg_cast_bf16_f32(const uint16_t* src, int lds, float* dst, int ldd, int64_t rows, int cols, void* stream) {
+    MG_CHECK_ARG(src && dst && rows >= 0 && cols > 0 && lds >= cols && ldd >= cols, "mg_cast_bf16_f32: bad arguments");
+    if (rows == 0) return MG_OK;
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(flat_grid(rows * cols)), dim3(256), 0, (hipStream_t)stream, src, lds, dst, ldd, rows, cols);
+    MG_CHECK_LAUNCH("mg_cast_bf16_f32");
+    return MG_OK;
+}
+
+int mg_sigmoid_f32(const float* x, float* y, int64_t n, void* stream) {
+    MG_CHECK_ARG(x && y && n >= 0, "mg_sigmoid_f32: bad arguments");
+    if (n == 0) return MG_OK;
+    hipLaunchKernelGGL(sigmoid_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    MG_CHECK_LAUNCH("mg_sigmoid_f32");
+    return MG_OK;
+}
+
+int mg_sigmoid_grad_f32(const float* dy, const float* y, float* dx, int64_t n, void* stream) {
+    MG_CHECK_ARG(dy && y && dx && n >= 0, "mg_sigmoid_grad_f32: bad arguments");
+    if (n == 0) return MG_OK;
+    hipLaunchKernelGGL(sigmoid_grad_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n);
+    MG_CHECK_LAUNCH("mg_sigmoid_grad_f32");
+    return MG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,240 @@
+// K1 - upsample_to_repetitions as a segmented repeat (reference: morgana/utils.py:175-228).
+//
+// The reference builds the frame->phone map on the host (two D2H syncs, a Python loop of np.repeat over the batch,
+// one H2D) and then runs an advanced-index gather.  Here the map is built on the device: one workgroup per
+// utterance scans the durations in LDS and every frame binary-searches its phone (coalesced int stores); the gather
+// moves whole rows with 16-byte lanes.  Both are HBM-bound: algorithmic bytes = B*P*F*4 read (L2/MALL resident,
+// each phone row is re-read dur times) + B*T*F*s written.
+#include "common.h"
+
+#define MG_MAX_PHONES 12288
+
+// Inclusive scan of dur[b, 0:P] into cum[0:P] (LDS, int32).  256 threads; scratch holds 256 ints.
+__device__ __forceinline__ void block_scan_durations(const int64_t* __restrict__ dur_row, int P, int* cum, int* scratch) {
+    const int tid = threadIdx.x;
+    const int per = (P + 255) / 256;
+    const int lo = tid * per;
+    const int hi = min(lo + per, P);
+    int local = 0;
+    for (int p = lo; p < hi; ++p) {
+        long long d = dur_row[p];
+        local += d > 0 ? (int)d : 0;
+    }
+    scratch[tid] = local;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over the 256 partials.
+    for (int off = 1; off < 256; off <<= 1) {
+        int v = tid >= off ? scratch[tid - off] : 0;
+        __syncthreads();
+        scratch[tid] += v;
+        __syncthreads();
+    }
+    int run = tid > 0 ? scratch[tid - 1] : 0;
+    for (int p = lo; p < hi; ++p) {
+        long long d = dur_row[p];
+        run += d > 0 ? (int)d : 0;
+        cum[p] = run;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void upsample_lengths_kernel(const int64_t* __restrict__ dur, int P,
+                                                               int64_t* __restrict__ n_frames,
+                                                               unsigned long long* __restrict__ tmax) {
+    __shared__ long long red[4];
+    const int b = blockIdx.x;
+    long long s = 0;
+    for (int p = threadIdx.x; p < P; p += 256) s += dur[(size_t)b * P + p];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long total = red[0] + red[1] + red[2] + red[3];
+        if (n_frames) n_frames[b] = total;
+        if (tmax && total > 0) atomicMax(tmax, (unsigned long long)total);
+    }
+}
+
+__global__ __launch_bounds__(256) void upsample_index_kernel(const int64_t* __restrict__ dur, int P, int t_cap,
+                                                             int64_t* __restrict__ idx64, int32_t* __restrict__ rows32) {
+    extern __shared__ __attribute__((aligned(16))) int smem_i[];
+    int* scratch = smem_i;
+    int* cum = smem_i + 256;
+    const int b = blockIdx.x;
+    block_scan_durations(dur + (size_t)b * P, P, cum, scratch);
+    const int total = P > 0 ? cum[P - 1] : 0;
+    for (int t = threadIdx.x; t < t_cap; t += 256) {
+        int phone = -1;
+        if (t < total) {
+            // first p with cum[p] > t  (phones of duration 0 are skipped, as np.repeat does)
+            int lo = 0, hi = P - 1;
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if (cum[mid] > t) hi = mid; else lo = mid + 1;
+            }
+            phone = lo;
+        }
+        const size_t o = (size_t)b * t_cap + t;
+        if (idx64) idx64[o] = phone;
+        if (rows32) rows32[o] = phone < 0 ? -1 : b * P + phone;
+    }
+}
+
+// One wave per output row, 16 bytes per lane.
+template <bool VEC4>
+__global__ __launch_bounds__(256) void gather_rows_f32_kernel(const float* __restrict__ src, const int32_t* __restrict__ rows,
+                                                              float* __restrict__ out, int64_t M, int F) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t m = wave; m < M; m += n_waves) {
+        const int r = rows ? rows[m] : (int)m;
+        if (VEC4) {
+            const int f4 = F >> 2;
+            const f32x4* s = reinterpret_cast<const f32x4*>(src + (size_t)(r < 0 ? 0 : r) * F);
+            f32x4* o = reinterpret_cast<f32x4*>(out + (size_t)m * F);
+            for (int c = lane; c < f4; c += 64) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (r >= 0) v = s[c];
+                o[c] = v;
+            }
+        } else {
+            const float* s = src + (size_t)(r < 0 ? 0 : r) * F;
+            float* o = out + (size_t)m * F;
+            for (int c = lane; c < F; c += 64) o[c] = r >= 0 ? s[c] : 0.f;
+        }
+    }
+}
+
+// bf16 output, 8 elements (16 bytes) per lane, zero fill up to ldo.
+__global__ __launch_bounds__(256) void gather_rows_bf16_kernel(const float* __restrict__ src, const int32_t* __restrict__ rows,
+                                                               uint16_t* __restrict__ out, int64_t M, int F, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    const int chunks = ldo >> 3;
+    const bool vec = (F & 3) == 0;
+    for (int64_t m = wave; m < M; m += n_waves) {
+        const int r = rows ? rows[m] : (int)m;
+        const float* s = src + (size_t)(r < 0 ? 0 : r) * F;
+        uint16_t* o = out + (size_t)m * ldo;
+        for (int c = lane; c < chunks; c += 64) {
+            const int k = c << 3;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            if (r >= 0) {
+                if (vec && k + 8 <= F) {
+                    f32x4 a = *reinterpret_cast<const f32x4*>(s + k);
+                    f32x4 c4 = *reinterpret_cast<const f32x4*>(s + k + 4);
+                    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+                    v[4] = c4.x; v[5] = c4.y; v[6] = c4.z; v[7] = c4.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (k + j < F) v[j] = s[k + j];
+                }
+            }
+            bf16x8 p;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p[j] = (short)mg_f2bf(v[j]);
+            *reinterpret_cast<bf16x8*>(o + k) = p;
+        }
+    }
+}
+
+// grad_src[b,p,:] = sum_{t in phone p} grad_out[b,t,:].  grid (B, phone_chunks); one wave per phone.
+__global__ __launch_bounds__(256) void upsample_backward_kernel(const float* __restrict__ grad_out, const int64_t* __restrict__ dur,
+                                                                float* __restrict__ grad_src, int P, int T, int F) {
+    extern __shared__ __attribute__((aligned(16))) int smem_i[];
+    int* scratch = smem_i;
+    int* cum = smem_i + 256;
+    const int b = blockIdx.x;
+    block_scan_durations(dur + (size_t)b * P, P, cum, scratch);
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int n_waves = gridDim.y * 4;
+    for (int p = wave; p < P; p += n_waves) {
+        const int start = min(p > 0 ? cum[p - 1] : 0, T);
+        const int end = min(cum[p], T);
+        const float* g = grad_out + (size_t)b * T * F;
+        float* o = grad_src + ((size_t)b * P + p) * F;
+        for (int c = lane; c < F; c += 64) {
+            float acc = 0.f;
+            for (int t = start; t < end; ++t) acc += g[(size_t)t * F + c];
+            o[c] = acc;
+        }
+    }
+}
+
+extern "C" {
+
+int mg_upsample_lengths(const int64_t* dur, int B, int P, int64_t* n_frames, int64_t* tmax, void* stream) {
+    MG_CHECK_ARG(dur && B > 0 && P > 0, "mg_upsample_lengths: need dur, B > 0, P > 0 (B=%d P=%d)", B, P);
+    hipStream_t st = (hipStream_t)stream;
+    if (tmax) {
+        if (hipMemsetAsync(tmax, 0, sizeof(int64_t), st) != hipSuccess) {
+            mg_set_error("mg_upsample_lengths: memset failed");
+            return MG_ELAUNCH;
+        }
+    }
+    hipLaunchKernelGGL(upsample_lengths_kernel, dim3(B), dim3(256), 0, st, dur, P, n_frames, (unsigned long long*)tmax);
+    MG_CHECK_LAUNCH("mg_upsample_lengths");
+    return MG_OK;
+}
+
+int mg_upsample_index(const int64_t* dur, int B, int P, int t_cap, int64_t* idx64, int32_t* rows32, void* stream) {
+    MG_CHECK_ARG(dur && B > 0 && P > 0 && t_cap >= 0, "mg_upsample_index: bad shape B=%d P=%d t_cap=%d", B, P, t_cap);
+    MG_CHECK_ARG(P <= MG_MAX_PHONES, "mg_upsample_index: P=%d exceeds %d phones per utterance", P, MG_MAX_PHONES);
+    MG_CHECK_ARG((int64_t)B * P < 2147483647LL, "mg_upsample_index: B*P overflows int32 row ids");
+    if (t_cap == 0) return MG_OK;
+    const size_t lds = (size_t)(256 + P) * sizeof(int);
+    hipLaunchKernelGGL(upsample_index_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, dur, P, t_cap, idx64, rows32);
+    MG_CHECK_LAUNCH("mg_upsample_index");
+    return MG_OK;
+}
+
+static int gather_grid(int64_t M) {
+    int64_t blocks = mg_ceil_div(M, 4);
+    if (blocks > 8192) blocks = 8192;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+int mg_gather_rows_f32(const float* src, const int32_t* rows, float* out, int64_t M, int F, void* stream) {
+    MG_CHECK_ARG(src && out && M >= 0 && F > 0, "mg_gather_rows_f32: bad arguments (M=%lld F=%d)", (long long)M, F);
+    if (M == 0) return MG_OK;
+    const bool vec = (F % 4 == 0) && (((uintptr_t)src | (uintptr_t)out) % 16 == 0);
+    if (vec)
+        hipLaunchKernelGGL(gather_rows_f32_kernel<true>, dim3(gather_grid(M)), dim3(256), 0, (hipStream_t)stream, src, rows, out, M, F);
+    else
+        hipLaunchKernelGGL(gather_rows_f32_kernel<false>, dim3(gather_grid(M)), dim3(256), 0, (hipStream_t)stream, src, rows, out, M, F);
+    MG_CHECK_LAUNCH("mg_gather_rows_f32");
+    return MG_OK;
+}
+
+int mg_gather_rows_bf16(const float* src, const int32_t* rows, uint16_t* out, int64_t M, int F, int ldo, void* stream) {
+    MG_CHECK_ARG(src && out && M >= 0 && F > 0, "mg_gather_rows_bf16: bad arguments (M=%lld F=%d)", (long long)M, F);
+    MG_CHECK_ARG(ldo >= F && ldo % 8 == 0, "mg_gather_rows_bf16: ldo=%d must be >= F=%d and a multiple of 8", ldo, F);
+    MG_CHECK_ARG(((uintptr_t)out % 16 == 0) && ((uintptr_t)src % 16 == 0), "mg_gather_rows_bf16: buffers must be 16-byte aligned");
+    if (M == 0) return MG_OK;
+    hipLaunchKernelGGL(gather_rows_bf16_kernel, dim3(gather_grid(M)), dim3(256), 0, (hipStream_t)stream, src, rows, out, M, F, ldo);
+    MG_CHECK_LAUNCH("mg_gather_rows_bf16");
+    return MG_OK;
+}
+
+int mg_upsample_backward_f32(const float* grad_out, const int64_t* dur, float* grad_src, int B, int P, int T, int F,
+                             void* stream) {
+    MG_CHECK_ARG(grad_out && dur && grad_src && B > 0 && P > 0 && T >= 0 && F > 0,
+                 "mg_upsample_backward_f32: bad arguments (B=%d P=%d T=%d F=%d)", B, P, T, F);
+    MG_CHECK_ARG(P <= MG_MAX_PHONES, "mg_upsample_backward_f32: P=%d exceeds %d", P, MG_MAX_PHONES);
+    int chunks = (int)mg_ceil_div(P, 8);
+    if (chunks > 16) chunks = 16;
+    if (chunks < 1) chunks = 1;
+    const size_t lds = (size_t)(256 + P) * sizeof(int);
+    hipLaunchKernelGGL(upsample_backward_kernel, dim3(B, chunks), dim3(256), lds, (hipStream_t)stream, grad_out, dur, grad_src, P, T, F);
+    MG_CHECK_LAUNCH("mg_upsample_backward_f32");
+    return MG_OK;
+}
+
+}  // extern "C"

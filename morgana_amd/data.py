@@ -1,0 +1,191 @@
+"""Mirror of the normaliser part of ``morgana.data`` (the arithmetic is on the hot path; file/JSON plumbing is not).
+
+Reference: morgana/data.py - ``normalise_mvn`` / ``denormalise_mvn`` :533-538, ``normalise_minmax`` /
+``denormalise_minmax`` :579-590, ``_FeatureNormaliser`` :252-386, ``MeanVarianceNormaliser`` :541-564,
+``MinMaxNormaliser`` :593-616.
+
+As in the reference, every function works on NumPy arrays (loader side, host arithmetic: data.py:119-127) and on
+torch tensors (model side, README.rst:87); device tensors go through the fused HIP elementwise kernel.
+"""
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+def _is_np(x):
+    return isinstance(x, np.ndarray)
+
+
+class _NormFn(torch.autograd.Function):
+    """out = kernel(x; p0, p1).  d out / d x is the per-column scale (1/(std+eps), std, 1/scale or scale)."""
+
+    @staticmethod
+    def forward(ctx, x, p0, p1, kind):
+        ctx.kind = kind
+        ctx.save_for_backward(p0, p1)
+        return ops.normalise(x, p0, p1, kind)
+
+    @staticmethod
+    def backward(ctx, grad):
+        p0, p1 = ctx.saved_tensors
+        kind = ctx.kind
+        if kind == ops.NORM_MVN:
+            scale = 1.0 / (p1 + 1e-8)
+        elif kind == ops.DENORM_MVN:
+            scale = p1
+        else:
+            scale = p1 - p0
+            scale = torch.where(scale.abs() <= 1e-8, torch.ones_like(scale), scale)
+            if kind == ops.NORM_MINMAX:
+                scale = 1.0 / scale
+        return grad * scale, None, None, None
+
+
+def _device_norm(feature, p0, p1, kind):
+    if not feature.is_cuda:
+        raise RuntimeError('morgana_amd normalisers take NumPy arrays (host, loader side) or device tensors; '
+                           'got a CPU torch tensor (there is no CPU fallback for the device path)')
+    p0 = p0.to(device=feature.device, dtype=torch.float32).reshape(-1)
+    p1 = p1.to(device=feature.device, dtype=torch.float32).reshape(-1)
+    return _NormFn.apply(feature, p0, p1, kind)
+
+
+def normalise_mvn(feature, mean, std_dev):
+    if _is_np(feature):
+        return (feature - mean[..., None, :]) / (std_dev[..., None, :] + 1e-8)      # data.py:533-534
+    return _device_norm(feature, mean, std_dev, ops.NORM_MVN)
+
+
+def denormalise_mvn(feature, mean, std_dev):
+    if _is_np(feature):
+        return (feature * std_dev[..., None, :]) + mean[..., None, :]              # data.py:537-538
+    return _device_norm(feature, mean, std_dev, ops.DENORM_MVN)
+
+
+def normalise_minmax(feature, mmin, mmax):
+    if _is_np(feature):
+        scale = mmax - mmin
+        scale[abs(scale) <= 1e-8] = 1.                                             # data.py:580-581
+        return (feature - mmin[..., None, :]) / scale[..., None, :]
+    return _device_norm(feature, mmin, mmax, ops.NORM_MINMAX)
+
+
+def denormalise_minmax(feature, mmin, mmax):
+    if _is_np(feature):
+        scale = mmax - mmin
+        scale[abs(scale) <= 1e-8] = 1.
+        return (feature * scale[..., None, :]) + mmin[..., None, :]
+    return _device_norm(feature, mmin, mmax, ops.DENORM_MINMAX)
+
+
+class _FeatureNormaliser(object):
+    """Abstract feature normaliser exposing ``normalise`` / ``denormalise`` (data.py:252-386)."""
+
+    def __init__(self, name, use_deltas=False, file_pattern='{name}.json'):
+        self.name = name
+        self.use_deltas = use_deltas
+        self.file_pattern = file_pattern
+        self.params = None
+        self.params_torch = None
+        if self.use_deltas:
+            self.delta_params = None
+            self.delta_params_torch = None
+
+    def _normalise(self, feature, **params):
+        raise NotImplementedError("Underlying calculation of normalisation should be implemented in a subclass.")
+
+    def _denormalise(self, feature, **params):
+        raise NotImplementedError("Underlying calculation of denormalisation should be implemented in a subclass.")
+
+    def normalise(self, feature, deltas=False):
+        params = self.fetch_params(type(feature), deltas=deltas)
+        return self._normalise(feature, **params)
+
+    def denormalise(self, feature, deltas=False):
+        params = self.fetch_params(type(feature), deltas=deltas)
+        return self._denormalise(feature, **params)
+
+    def fetch_params(self, data_type=np.ndarray, deltas=False):
+        if deltas:
+            return self.delta_params_torch if data_type == torch.Tensor else self.delta_params
+        return self.params_torch if data_type == torch.Tensor else self.params
+
+    @staticmethod
+    def _from_json(file_path):
+        with open(file_path, 'r') as f:
+            feat_params = json.load(f)
+        return {name: np.array(param, dtype=np.float32) for name, param in feat_params.items()}
+
+    @staticmethod
+    def _to_torch(params, device='cpu'):
+        return {name: torch.tensor(param).to(device) for name, param in params.items()}
+
+    def set_params(self, params, delta_params=None, device='cpu'):
+        """Install parameters directly (synthetic runs have no JSON files)."""
+        self.params = {k: np.asarray(v, dtype=np.float32) for k, v in params.items()}
+        self.params_torch = self._to_torch(self.params, device=device)
+        if self.use_deltas and delta_params is not None:
+            self.delta_params = {k: np.asarray(v, dtype=np.float32) for k, v in delta_params.items()}
+            self.delta_params_torch = self._to_torch(self.delta_params, device=device)
+        return self
+
+    def load_params(self, data_dir, data_root='.', device='cpu'):
+        params_file = os.path.join(data_root, data_dir, self.file_pattern.format(name=self.name))
+        self.params = self._from_json(params_file)
+        self.params_torch = self._to_torch(self.params, device=device)
+        if self.use_deltas:
+            delta_file = os.path.join(data_root, data_dir, self.file_pattern.format(name=self.name + '_deltas'))
+            self.delta_params = self._from_json(delta_file)
+            self.delta_params_torch = self._to_torch(self.delta_params, device=device)
+
+
+class MeanVarianceNormaliser(_FeatureNormaliser):
+    """Zero mean / unit variance; parameters ``mean`` / ``std_dev`` from ``{name}_mvn.json`` (data.py:541-564)."""
+
+    def __init__(self, name, use_deltas=False):
+        super(MeanVarianceNormaliser, self).__init__(name, use_deltas, '{name}_mvn.json')
+
+    def _normalise(self, feature, **params):
+        return normalise_mvn(feature, params['mean'], params['std_dev'])
+
+    def _denormalise(self, feature, **params):
+        return denormalise_mvn(feature, params['mean'], params['std_dev'])
+
+
+class MinMaxNormaliser(_FeatureNormaliser):
+    """Range [0, 1]; parameters ``mmin`` / ``mmax`` from ``{name}_minmax.json`` (data.py:593-616)."""
+
+    def __init__(self, name, use_deltas=False):
+        super(MinMaxNormaliser, self).__init__(name, use_deltas, '{name}_minmax.json')
+
+    def _normalise(self, feature, **params):
+        return normalise_minmax(feature, params['mmin'], params['mmax'])
+
+    def _denormalise(self, feature, **params):
+        return denormalise_minmax(feature, params['mmin'], params['mmax'])
+
+
+class Normalisers(dict):
+    """Dictionary of normalisers that loads every member's parameters (data.py:225-247)."""
+
+    def __init__(self, normaliser_sources, normalisation_dir, data_root='.', device='cpu'):
+        super(Normalisers, self).__init__()
+        self.normalisation_dir = os.path.join(data_root, normalisation_dir)
+        self.device = device
+        for name, source in normaliser_sources.items():
+            self[name] = source
+            self[name].load_params(self.normalisation_dir, device=self.device)
+
+
+def to_device(features, device):
+    """``ToDeviceWrapper.to_device`` over a feature dict (data.py:648-663); numpy arrays are uploaded too."""
+    out = {}
+    for key, value in features.items():
+        if isinstance(value, np.ndarray):
+            value = torch.from_numpy(value)
+        out[key] = value.to(device) if isinstance(value, torch.Tensor) else value
+    return out

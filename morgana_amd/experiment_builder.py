@@ -1,0 +1,112 @@
+"""The training loop of ``morgana.experiment_builder.ExperimentBuilder`` restated around the HIP hot path.
+
+Reference: ``train_epoch`` experiment_builder.py:431-505 (loop body :464-494), ``run_train`` :507-560, model / EMA
+construction :267-281, :386-396.  Only what the hot path needs is mirrored (batch loop, Adam, LR schedules, EMA,
+loss bookkeeping, checkpoints); CLI, logging, plotting and the file data loaders are out of scope.
+
+Differences that matter on a 0.3-1 ms step: the batch loss stays on the device (the reference calls ``.item()`` and
+formats the loss every batch: >= 3 host syncs per step, experiment_builder.py:480-490) and is read once per epoch;
+``zero_grad`` / all-reduce / Adam work on flat buffers (morgana_amd.optim.Adam).
+"""
+import copy
+import json
+import os
+
+import torch
+
+from . import lr_schedules
+from . import utils
+from .optim import Adam
+
+
+class ExperimentBuilder(object):
+    def __init__(self, model_class, model_kwargs=None, learning_rate=0.01, weight_decay=0., lr_schedule_name='constant',
+                 lr_schedule_kwargs=None, ema_decay=0., device='cuda:0', start_epoch=1, end_epoch=50,
+                 experiment_dir=None, model_checkpoint_interval=1, checkpoint_path=None, **unused):
+        self.model_class = model_class
+        self.model_kwargs = model_kwargs or {}
+        self.learning_rate = learning_rate
+        self.weight_decay = weight_decay
+        self.lr_schedule_name = lr_schedule_name
+        self.lr_schedule_kwargs = lr_schedule_kwargs or {}
+        self.ema_decay = ema_decay
+        self.device = device
+        self.start_epoch = start_epoch
+        self.end_epoch = end_epoch
+        self.epoch = start_epoch
+        self.experiment_dir = experiment_dir
+        self.model_checkpoint_interval = model_checkpoint_interval
+        self.analysis_kwargs = {}
+        self._lr_schedule = lr_schedules.init_lr_schedule(lr_schedule_name, **self.lr_schedule_kwargs)
+
+        self.model = self.build_model(model_class, self.model_kwargs, checkpoint_path)      # :267, :386-396
+        if self.ema_decay:                                                                  # :276-281
+            self.ema_model = copy.deepcopy(self.model)
+            self.ema = utils.ExponentialMovingAverage(self.ema_model, self.ema_decay)
+
+    def build_model(self, model_class, model_kwargs, checkpoint_path=None):
+        model = model_class(**model_kwargs)
+        model = model.to(self.device)
+        if checkpoint_path:
+            model.load_parameters(checkpoint_path, device=self.device)
+        return model
+
+    def make_optimizer(self, **kwargs):
+        return Adam(self.model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay, **kwargs)  # :516
+
+    def train_epoch(self, data_loader, optimizer, lr_schedule=None, gen_output=False, out_dir=None):
+        """One pass over ``data_loader`` (an iterable of feature dicts already on the device); returns the mean loss."""
+        self.model.mode = 'train'
+        self.model.metrics.reset_state('train')
+        if out_dir:
+            os.makedirs(out_dir, exist_ok=True)
+
+        loss = None
+        n_batches = len(data_loader)
+        i = -1
+        for i, features in enumerate(data_loader):
+            self.model.step = (self.epoch - 1) * n_batches + i + 1
+
+            optimizer.zero_grad()                                                # :468
+            batch_loss, output_features = self.model(features)                   # :471
+            batch_loss.backward()                                                # :473
+            optimizer.step()                                                     # :474
+
+            if lr_schedule is not None and self.lr_schedule_name in lr_schedules.BATCH_LR_SCHEDULES:
+                lr_schedule.step()                                               # :477-478
+
+            batch_loss = batch_loss.detach()
+            loss = batch_loss if loss is None else loss + batch_loss             # :480, kept on the device
+
+            if self.ema_decay:
+                self.ema.update_params(self.model)                               # :483-484
+
+            self.model.metrics.accumulate(self.model.mode, loss=batch_loss)      # :487
+
+            if gen_output:
+                self.model.analysis_for_train_batch(features, output_features, out_dir=out_dir,
+                                                    **self.analysis_kwargs)
+        if gen_output:
+            self.model.analysis_for_train_epoch(out_dir=out_dir, **self.analysis_kwargs)
+        if out_dir:
+            with open(os.path.join(out_dir, 'metrics.json'), 'w') as f:          # :499-501
+                json.dump(self.model.metrics.results_as_json_dict('train'), f)
+        self.model.mode = ''
+        return float(loss.item()) / (i + 1)                                      # :505 (one sync per epoch)
+
+    def run_train(self, train_loader):
+        """Epoch loop of experiment_builder.py:507-560 (training part)."""
+        optimizer = self.make_optimizer()
+        lr_schedule = self._lr_schedule(optimizer)
+        history = []
+        for self.epoch in range(self.start_epoch, self.end_epoch + 1):
+            out_dir = os.path.join(self.experiment_dir, 'train', 'epoch_{}'.format(self.epoch)) \
+                if self.experiment_dir else None
+            history.append(self.train_epoch(train_loader, optimizer, lr_schedule, out_dir=out_dir))
+            if self.experiment_dir and self.epoch % self.model_checkpoint_interval == 0:
+                self.model.save_parameters(self.experiment_dir, self.epoch)      # :532-542
+                if self.ema_decay:
+                    self.ema_model.save_parameters(self.experiment_dir, '{}_ema'.format(self.epoch))
+            if self.lr_schedule_name in lr_schedules.EPOCH_LR_SCHEDULES:
+                lr_schedule.step()                                               # :559-560
+        return history

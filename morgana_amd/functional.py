@@ -1,0 +1,214 @@
+"""torch.autograd glue over the HIP kernels: every forward and backward below is a call into libmorgana_hip.so.
+
+Three nodes cover the hot path of the reference's train step (experiment_builder.py:468-474):
+  UpsampleFn      utils.upsample_to_repetitions (utils.py:175-228) and its adjoint (per-phone segment sum)
+  LinearStackFn   a run of nn.Linear(+nn.Sigmoid) modules (README.rst:65-73), optionally fed by the fused gather
+  GRUFn           RecurrentCuDNNWrapper(nn.GRU) with seq_len (utils.py:345-393)
+  MaskedMSEFn     losses.mse (losses.py:29-51): loss and d loss / d prediction come out of one kernel pass
+
+Precision: 'fp32' = exact-fp32 MFMA (parity mode, 1e-4 vs the reference), 'bf16' = bf16 operands / fp32 accumulate
+(throughput mode; master weights, biases, loss and optimiser state stay fp32).
+"""
+import torch
+
+from . import ops
+
+_PRECISION = 'fp32'
+
+
+def set_precision(precision):
+    """Global default for modules that do not pin their own precision: 'fp32' or 'bf16'."""
+    global _PRECISION
+    if precision not in ('fp32', 'bf16'):
+        raise ValueError("precision must be 'fp32' or 'bf16', got %r" % (precision,))
+    _PRECISION = precision
+
+
+def get_precision():
+    return _PRECISION
+
+
+class UpsampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sequence_feature, dur2d, t_cap):
+        x = ops._require(sequence_feature, torch.float32, 'sequence_feature')
+        b, p, f = x.shape
+        _, rows = ops.upsample_index(dur2d, t_cap)
+        out = ops.gather_rows(x.view(b * p, f), rows.view(-1)).view(b, t_cap, f)
+        ctx.save_for_backward(dur2d)
+        ctx.n_phones = p
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (dur2d,) = ctx.saved_tensors
+        return ops.upsample_backward(grad_out.contiguous(), dur2d, ctx.n_phones), None, None
+
+
+class LinearStackFn(torch.autograd.Function):
+    """y = L_n(...sigma(L_1(x))...) over rows of a 2-D input (or of a gathered table).
+
+    forward(ctx, spec, x2d, rows, *params); spec = (acts, precision); params = w0, b0, w1, b1, ... (bias may be None).
+    With ``rows`` the input row m is ``x2d[rows[m]]`` (zero row for -1): the frame-rate tensor is never materialised.
+    """
+
+    @staticmethod
+    def forward(ctx, spec, x2d, rows, *params):
+        acts, precision = spec
+        n_layers = len(acts)
+        weights = [params[2 * i] for i in range(n_layers)]
+        biases = [params[2 * i + 1] for i in range(n_layers)]
+        x2d = ops._require(x2d, torch.float32, 'input')
+        m = rows.numel() if rows is not None else x2d.shape[0]
+        ctx.spec, ctx.m = spec, m
+        ctx.has_bias = [b is not None for b in biases]
+        ctx.dims = [(w.shape[0], w.shape[1]) for w in weights]
+        if x2d.shape[1] != weights[0].shape[1]:
+            raise ValueError('Linear expects %d input features, got %d' % (weights[0].shape[1], x2d.shape[1]))
+        hidden = []
+        if precision == 'fp32':
+            a, r = x2d, rows
+            for i in range(n_layers):
+                w = ops._require(weights[i], torch.float32, 'weight')
+                a = ops.linear_fwd_f32(a, r, m, w, biases[i], acts[i])
+                r = None
+                hidden.append(a)
+            out = a
+            ctx.save_for_backward(x2d, rows, *weights, *hidden)
+        else:
+            a = ops.cast_pad_bf16(x2d)
+            a0, r = a, rows
+            for i in range(n_layers):
+                n, k = weights[i].shape
+                w_bf = ops.cast_pad_bf16(ops._require(weights[i], torch.float32, 'weight'))
+                last = i == n_layers - 1
+                a = ops.linear_fwd_bf16(a, r, m, k, w_bf, biases[i], n, acts[i], out_f32=last)
+                r = None
+                hidden.append(a)
+            n_last = weights[-1].shape[0]
+            out = hidden[-1]
+            if out.shape[1] != n_last:
+                out = out[:, :n_last].contiguous()
+                # keep the padded fp32 activation only if a trailing sigmoid needs it in backward
+            ctx.save_for_backward(a0, rows, *weights, *hidden[:-1], out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        acts, precision = ctx.spec
+        n_layers = len(acts)
+        saved = ctx.saved_tensors
+        x_in, rows = saved[0], saved[1]
+        weights = saved[2:2 + n_layers]
+        hidden = saved[2 + n_layers:]
+        m = ctx.m
+        grads = [None] * (2 * n_layers)
+        need_x = ctx.needs_input_grad[1]
+        g = grad_out.contiguous()
+        if acts[-1] == ops.ACT_SIGMOID:
+            g = ops.sigmoid_grad(g, hidden[-1])
+        grad_x = None
+        if precision == 'fp32':
+            for i in range(n_layers - 1, -1, -1):
+                n, k = ctx.dims[i]
+                a_in, r = (x_in, rows) if i == 0 else (hidden[i - 1], None)
+                dw, db = ops.linear_wgrad_f32(g, a_in, r, n, k, want_bias=ctx.has_bias[i])
+                grads[2 * i], grads[2 * i + 1] = dw, db
+                if i > 0:
+                    h = hidden[i - 1] if acts[i - 1] == ops.ACT_SIGMOID else None
+                    g = ops.linear_dgrad_f32(g, weights[i], h)
+                elif need_x:
+                    grad_x = ops.linear_dgrad_f32(g, weights[0], None)
+        else:
+            g = ops.cast_pad_bf16(g)
+            for i in range(n_layers - 1, -1, -1):
+                n, k = ctx.dims[i]
+                a_in, r = (x_in, rows) if i == 0 else (hidden[i - 1], None)
+                dw, db = ops.linear_wgrad_bf16(g, a_in, r, m, n, k, want_bias=ctx.has_bias[i])
+                grads[2 * i], grads[2 * i + 1] = dw, db
+                if i > 0:
+                    wt = ops.cast_transpose_bf16(weights[i])
+                    h = hidden[i - 1] if acts[i - 1] == ops.ACT_SIGMOID else None
+                    g = ops.linear_dgrad_bf16(g, m, n, wt, k, h)
+                elif need_x:
+                    wt = ops.cast_transpose_bf16(weights[0])
+                    grad_x = ops.linear_dgrad_bf16(g, m, n, wt, k, None, out_f32=True)
+                    if grad_x.shape[1] != k:
+                        grad_x = grad_x[:, :k].contiguous()
+        if need_x and rows is not None:
+            raise RuntimeError('LinearStackFn: gradient w.r.t. a gathered input is not available on the fused path; '
+                               'materialise the upsample first (upsample_to_repetitions(..., fused=False))')
+        return (None, grad_x, None) + tuple(grads)
+
+
+class GRUFn(torch.autograd.Function):
+    """One GRU layer (batch_first) restricted to seq_len[b] steps per item; returns (outputs, h_n)."""
+
+    @staticmethod
+    def forward(ctx, precision, x, h0, seq_len, w_ih, w_hh, b_ih, b_hh):
+        x = ops._require(x, torch.float32, 'inputs')
+        b, t, i_dim = x.shape
+        hid = w_hh.shape[1]
+        x2 = x.view(b * t, i_dim)
+        if precision == 'fp32':
+            xproj = ops.linear_fwd_f32(x2, None, b * t, w_ih, b_ih, ops.ACT_NONE)
+            x_saved = x2
+        else:
+            x_saved = ops.cast_pad_bf16(x2)
+            xproj = ops.linear_fwd_bf16(x_saved, None, b * t, i_dim, ops.cast_pad_bf16(w_ih), b_ih, 3 * hid,
+                                        ops.ACT_NONE, out_f32=True)
+            if xproj.shape[1] != 3 * hid:
+                xproj = xproj[:, :3 * hid].contiguous()
+        out, hstate, saved = ops.gru_fwd(xproj.view(b, t, 3 * hid), w_hh.contiguous(), b_hh.contiguous(), seq_len, h0,
+                                         b, t, hid)
+        ctx.precision = precision
+        ctx.shape = (b, t, i_dim, hid)
+        ctx.has_h0 = h0 is not None
+        ctx.save_for_backward(x_saved, seq_len, w_ih, w_hh, hstate, saved)
+        return out, hstate[:, t].unsqueeze(0).contiguous()
+
+    @staticmethod
+    def backward(ctx, grad_out, grad_hn):
+        x_saved, seq_len, w_ih, w_hh, hstate, saved = ctx.saved_tensors
+        b, t, i_dim, hid = ctx.shape
+        g_out = grad_out.contiguous() if grad_out is not None else torch.zeros((b, t, hid), dtype=torch.float32,
+                                                                                device=hstate.device)
+        g_hn = grad_hn.reshape(b, hid).contiguous() if grad_hn is not None else None
+        dxproj, dhproj, dh0 = ops.gru_bwd(g_out, g_hn, hstate, saved, w_hh, seq_len, b, t, hid)
+        m = b * t
+        dxp2, dhp2 = dxproj.view(m, 3 * hid), dhproj.view(m, 3 * hid)
+        # h_{t-1} rows of hstate (B, T+1, H): row b*(T+1) + t
+        prev_rows = (torch.arange(b, device=hstate.device, dtype=torch.int32)[:, None] * (t + 1) +
+                     torch.arange(t, device=hstate.device, dtype=torch.int32)[None, :]).reshape(-1).contiguous()
+        hs2 = hstate.view(b * (t + 1), hid)
+        need_x = ctx.needs_input_grad[1]
+        dx = None
+        if ctx.precision == 'fp32':
+            dw_ih, db_ih = ops.linear_wgrad_f32(dxp2, x_saved, None, 3 * hid, i_dim)
+            dw_hh, db_hh = ops.linear_wgrad_f32(dhp2, hs2, prev_rows, 3 * hid, hid)
+            if need_x:
+                dx = ops.linear_dgrad_f32(dxp2, w_ih, None).view(b, t, i_dim)
+        else:
+            dxp_bf, dhp_bf = ops.cast_pad_bf16(dxp2), ops.cast_pad_bf16(dhp2)
+            dw_ih, db_ih = ops.linear_wgrad_bf16(dxp_bf, x_saved, None, m, 3 * hid, i_dim)
+            dw_hh, db_hh = ops.linear_wgrad_bf16(dhp_bf, ops.cast_pad_bf16(hs2), prev_rows, m, 3 * hid, hid)
+            if need_x:
+                dx = ops.linear_dgrad_bf16(dxp_bf, m, 3 * hid, ops.cast_transpose_bf16(w_ih), i_dim, None,
+                                           out_f32=True)
+                if dx.shape[1] != i_dim:
+                    dx = dx[:, :i_dim].contiguous()
+                dx = dx.view(b, t, i_dim)
+        return (None, dx, dh0.view(1, b, hid) if ctx.has_h0 else None, None, dw_ih, dw_hh, db_ih, db_hh)
+
+
+class MaskedMSEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, predictions, targets, seq_len):
+        loss, grad = ops.masked_mse(predictions, targets, seq_len, want_grad=ctx.needs_input_grad[0])
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        (grad,) = ctx.saved_tensors
+        return grad * grad_loss, None, None

@@ -1,0 +1,302 @@
+"""Tensor-level wrappers over the C ABI: validate, allocate outputs (torch is the allocator), launch on torch's current
+HIP stream.  No arithmetic happens here and nothing falls back to torch ops: a missing library or a CPU tensor raises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_SIGMOID = 0, 1
+NORM_MVN, DENORM_MVN, NORM_MINMAX, DENORM_MINMAX = 0, 1, 2, 3
+
+_workspaces = {}
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require(t, dtype, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError('%s must be a torch.Tensor, got %s' % (name, type(t)))
+    if not t.is_cuda:
+        raise _lib.MorganaHipError('%s is on %s: the morgana_amd ops run only on an MI355X device (no CPU fallback)'
+                                   % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError('%s must be %s, got %s' % (name, dtype, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def workspace(nbytes, device):
+    """One grow-only scratch buffer per device; all kernels of a step run on one stream, so it is shared."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def pad8(n):
+    return (n + 7) // 8 * 8
+
+
+# ----------------------------------------------------------------------------------------------------------------- K1
+def upsample_lengths(dur):
+    """dur int64 (B, P) -> (n_frames int64 (B,), tmax int64 0-d), both on device (no sync)."""
+    lib = _lib.load()
+    dur = _require(dur, torch.int64, 'dur')
+    b, p = dur.shape
+    n_frames = torch.empty((b,), dtype=torch.int64, device=dur.device)
+    tmax = torch.empty((), dtype=torch.int64, device=dur.device)
+    _lib.check(lib.mg_upsample_lengths(_p(dur), b, p, _p(n_frames), _p(tmax), _stream()), 'mg_upsample_lengths')
+    return n_frames, tmax
+
+
+def upsample_index(dur, t_cap, want_idx64=False, want_rows=True):
+    lib = _lib.load()
+    dur = _require(dur, torch.int64, 'dur')
+    b, p = dur.shape
+    idx64 = torch.empty((b, t_cap), dtype=torch.int64, device=dur.device) if want_idx64 else None
+    rows = torch.empty((b, t_cap), dtype=torch.int32, device=dur.device) if want_rows else None
+    _lib.check(lib.mg_upsample_index(_p(dur), b, p, int(t_cap), _p(idx64), _p(rows), _stream()), 'mg_upsample_index')
+    return idx64, rows
+
+
+def gather_rows(src2d, rows, out_bf16=False):
+    lib = _lib.load()
+    src2d = _require(src2d, torch.float32, 'src')
+    rows = _require(rows, torch.int32, 'rows')
+    m, f = rows.numel(), src2d.shape[1]
+    if out_bf16:
+        ldo = pad8(f)
+        out = torch.empty((m, ldo), dtype=torch.bfloat16, device=src2d.device)
+        _lib.check(lib.mg_gather_rows_bf16(_p(src2d), _p(rows), _p(out), m, f, ldo, _stream()), 'mg_gather_rows_bf16')
+    else:
+        out = torch.empty((m, f), dtype=torch.float32, device=src2d.device)
+        _lib.check(lib.mg_gather_rows_f32(_p(src2d), _p(rows), _p(out), m, f, _stream()), 'mg_gather_rows_f32')
+    return out
+
+
+def upsample_backward(grad_out, dur, n_phones):
+    lib = _lib.load()
+    grad_out = _require(grad_out, torch.float32, 'grad_out')
+    dur = _require(dur, torch.int64, 'dur')
+    b, t, f = grad_out.shape
+    grad_src = torch.empty((b, n_phones, f), dtype=torch.float32, device=grad_out.device)
+    _lib.check(lib.mg_upsample_backward_f32(_p(grad_out), _p(dur), _p(grad_src), b, n_phones, t, f, _stream()),
+               'mg_upsample_backward_f32')
+    return grad_src
+
+
+# --------------------------------------------------------------------------------------------------- mask / K4 / K5
+_MASK_TYPES = {torch.uint8: (1, 0), torch.bool: (1, 0), torch.int8: (1, 0), torch.float32: (4, 1), torch.int32: (4, 0),
+               torch.int64: (8, 0), torch.float64: (8, 1)}
+
+
+def sequence_mask(seq_len, max_len, dtype):
+    lib = _lib.load()
+    seq_len = _require(seq_len, torch.int64, 'seq_len')
+    if dtype not in _MASK_TYPES:
+        raise TypeError('sequence_mask: unsupported mask dtype %s' % dtype)
+    elem, as_float = _MASK_TYPES[dtype]
+    b = seq_len.shape[0]
+    mask = torch.empty((b, max_len, 1), dtype=dtype, device=seq_len.device)
+    _lib.check(lib.mg_sequence_mask(_p(seq_len), b, int(max_len), _p(mask), elem, as_float, _stream()),
+               'mg_sequence_mask')
+    return mask
+
+
+def masked_mse(pred, target, seq_len, want_grad, grad_scale=1.0):
+    """Returns (loss 0-d f32 tensor, grad or None)."""
+    lib = _lib.load()
+    pred = _require(pred, torch.float32, 'predictions')
+    target = _require(target, torch.float32, 'targets')
+    if pred.shape != target.shape or pred.dim() != 3:
+        raise ValueError('mse: predictions %s and targets %s must both be (B, T, D)' % (tuple(pred.shape),
+                                                                                     tuple(target.shape)))
+    if seq_len is not None:
+        seq_len = _require(seq_len, torch.int64, 'seq_len')
+    b, t, d = pred.shape
+    loss = torch.empty((), dtype=torch.float32, device=pred.device)
+    grad = torch.empty_like(pred) if want_grad else None
+    nbytes = lib.mg_masked_mse_workspace_bytes(b, t, d)
+    ws = workspace(nbytes, pred.device)
+    _lib.check(lib.mg_masked_mse_f32(_p(pred), _p(target), _p(seq_len), b, t, d, float(grad_scale), _p(loss), _p(grad),
+                                     _p(ws), ws.numel(), _stream()), 'mg_masked_mse_f32')
+    return loss, grad
+
+
+def normalise(x, p0, p1, kind):
+    lib = _lib.load()
+    x = _require(x, torch.float32, 'feature')
+    p0 = _require(p0, torch.float32, 'param0')
+    p1 = _require(p1, torch.float32, 'param1')
+    d = x.shape[-1]
+    if p0.numel() != d or p1.numel() != d:
+        raise ValueError('normaliser parameters have %d / %d entries, feature dim is %d' % (p0.numel(), p1.numel(), d))
+    out = torch.empty_like(x)
+    _lib.check(lib.mg_normalise_f32(_p(x), _p(out), _p(p0), _p(p1), x.numel() // d, d, kind, _stream()),
+               'mg_normalise_f32')
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------- K2
+def linear_fwd_f32(a, rows, m, weight, bias, act):
+    """a: (R, K) f32 table/input; rows: int32 (m,) or None.  Returns (m, N) f32."""
+    lib = _lib.load()
+    n, k = weight.shape
+    y = torch.empty((m, n), dtype=torch.float32, device=weight.device)
+    _lib.check(lib.mg_linear_fwd_f32(_p(a), a.shape[1], _p(rows), m, k, _p(weight), _p(bias), n, _p(y), n, act,
+                                     _stream()), 'mg_linear_fwd_f32')
+    return y
+
+
+def linear_dgrad_f32(dy, weight, h):
+    lib = _lib.load()
+    n, k = weight.shape
+    m = dy.shape[0]
+    dx = torch.empty((m, k), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.mg_linear_dgrad_f32(_p(dy), m, n, _p(weight), k, _p(h), _p(dx), _stream()), 'mg_linear_dgrad_f32')
+    return dx
+
+
+def linear_wgrad_f32(dy, a, rows, n, k, want_bias=True):
+    lib = _lib.load()
+    m = dy.shape[0]
+    dw = torch.empty((n, k), dtype=torch.float32, device=dy.device)
+    db = torch.empty((n,), dtype=torch.float32, device=dy.device) if want_bias else None
+    nbytes = lib.mg_linear_wgrad_workspace_bytes(m, n, k)
+    ws = workspace(nbytes, dy.device)
+    _lib.check(lib.mg_linear_wgrad_f32(_p(dy), _p(a), a.shape[1], _p(rows), m, n, k, _p(dw), _p(db), 0, _p(ws),
+                                       ws.numel(), _stream()), 'mg_linear_wgrad_f32')
+    return dw, db
+
+
+def cast_pad_bf16(x2d, ld=None):
+    lib = _lib.load()
+    rows, cols = x2d.shape
+    ld = pad8(cols) if ld is None else ld
+    out = torch.empty((rows, ld), dtype=torch.bfloat16, device=x2d.device)
+    _lib.check(lib.mg_cast_pad_bf16(_p(x2d), x2d.shape[1], _p(out), ld, rows, cols, _stream()), 'mg_cast_pad_bf16')
+    return out
+
+
+def cast_transpose_bf16(x2d):
+    """(rows, cols) f32 -> (cols, pad8(rows)) bf16."""
+    lib = _lib.load()
+    rows, cols = x2d.shape
+    ld = pad8(rows)
+    out = torch.empty((cols, ld), dtype=torch.bfloat16, device=x2d.device)
+    _lib.check(lib.mg_cast_transpose_bf16(_p(x2d), cols, _p(out), ld, rows, cols, _stream()), 'mg_cast_transpose_bf16')
+    return out
+
+
+def cast_bf16_f32(x_bf16, cols):
+    lib = _lib.load()
+    rows, ld = x_bf16.shape
+    out = torch.empty((rows, cols), dtype=torch.float32, device=x_bf16.device)
+    _lib.check(lib.mg_cast_bf16_f32(_p(x_bf16), ld, _p(out), cols, rows, cols, _stream()), 'mg_cast_bf16_f32')
+    return out
+
+
+def linear_fwd_bf16(a, rows, m, k, w_bf16, bias, n, act, out_f32=False):
+    """a: (R, lda) bf16; w_bf16: (n, ldw) bf16.  Returns (m, pad8(n)) bf16 (or f32), padding columns zero."""
+    lib = _lib.load()
+    ldy = pad8(n)
+    y = torch.empty((m, ldy), dtype=torch.float32 if out_f32 else torch.bfloat16, device=a.device)
+    _lib.check(lib.mg_linear_fwd_bf16(_p(a), a.shape[1], _p(rows), m, k, _p(w_bf16), w_bf16.shape[1], _p(bias), n,
+                                      _p(y), ldy, 1 if out_f32 else 0, act, _stream()), 'mg_linear_fwd_bf16')
+    return y
+
+
+def linear_dgrad_bf16(dy, m, n, wt_bf16, k, h, out_f32=False):
+    """dy (m, lddy) bf16; wt_bf16 = W^T (k, pad8(n)) bf16; h None or (m, ldh) bf16.  Returns (m, pad8(k)) bf16/f32."""
+    lib = _lib.load()
+    lddx = pad8(k)
+    dx = torch.empty((m, lddx), dtype=torch.float32 if out_f32 else torch.bfloat16, device=dy.device)
+    _lib.check(lib.mg_linear_dgrad_bf16(_p(dy), dy.shape[1], m, n, _p(wt_bf16), wt_bf16.shape[1], k, _p(h),
+                                        h.shape[1] if h is not None else 0, _p(dx), lddx, 1 if out_f32 else 0,
+                                        _stream()), 'mg_linear_dgrad_bf16')
+    return dx
+
+
+def linear_wgrad_bf16(dy, a, rows, m, n, k, want_bias=True):
+    lib = _lib.load()
+    dw = torch.empty((n, k), dtype=torch.float32, device=dy.device)
+    db = torch.empty((n,), dtype=torch.float32, device=dy.device) if want_bias else None
+    nbytes = lib.mg_linear_wgrad_workspace_bytes(m, n, k)
+    ws = workspace(nbytes, dy.device)
+    _lib.check(lib.mg_linear_wgrad_bf16(_p(dy), dy.shape[1], _p(a), a.shape[1], _p(rows), m, n, k, _p(dw), _p(db), 0,
+                                        _p(ws), ws.numel(), _stream()), 'mg_linear_wgrad_bf16')
+    return dw, db
+
+
+def sigmoid(x):
+    lib = _lib.load()
+    x = _require(x, torch.float32, 'input')
+    y = torch.empty_like(x)
+    _lib.check(lib.mg_sigmoid_f32(_p(x), _p(y), x.numel(), _stream()), 'mg_sigmoid_f32')
+    return y
+
+
+def sigmoid_grad(dy, y):
+    lib = _lib.load()
+    dy = _require(dy, torch.float32, 'grad')
+    dx = torch.empty_like(y)
+    _lib.check(lib.mg_sigmoid_grad_f32(_p(dy), _p(y), _p(dx), y.numel(), _stream()), 'mg_sigmoid_grad_f32')
+    return dx
+
+
+# ----------------------------------------------------------------------------------------------------------------- K3
+def gru_fwd(xproj, w_hh, b_hh, seq_len, h0, b, t, h):
+    """xproj (b, t, 3h) f32.  Returns (out (b,t,h), hstate (b,t+1,h), saved (b,t,4h))."""
+    lib = _lib.load()
+    dev = xproj.device
+    hstate = torch.empty((b, t + 1, h), dtype=torch.float32, device=dev)
+    if h0 is None:
+        hstate[:, 0].zero_()
+    else:
+        hstate[:, 0].copy_(h0.reshape(b, h))
+    out = torch.empty((b, t, h), dtype=torch.float32, device=dev)
+    saved = torch.empty((b, t, 4 * h), dtype=torch.float32, device=dev)
+    _lib.check(lib.mg_gru_fwd_f32(_p(xproj), _p(w_hh), _p(b_hh), _p(seq_len), b, t, h, _p(hstate), _p(out), _p(saved),
+                                  _stream()), 'mg_gru_fwd_f32')
+    return out, hstate, saved
+
+
+def gru_bwd(grad_out, grad_hn, hstate, saved, w_hh, seq_len, b, t, h):
+    lib = _lib.load()
+    dev = grad_out.device
+    dxproj = torch.empty((b, t, 3 * h), dtype=torch.float32, device=dev)
+    dhproj = torch.empty((b, t, 3 * h), dtype=torch.float32, device=dev)
+    dh0 = torch.empty((b, h), dtype=torch.float32, device=dev)
+    nbytes = lib.mg_gru_bwd_workspace_bytes(b, h)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)   # own buffer: lives across the wgrad calls that follow
+    _lib.check(lib.mg_gru_bwd_f32(_p(grad_out), _p(grad_hn), _p(hstate), _p(saved), _p(w_hh), _p(seq_len), b, t, h,
+                                  _p(dxproj), _p(dhproj), _p(dh0), _p(ws), ws.numel(), _stream()), 'mg_gru_bwd_f32')
+    return dxproj, dhproj, dh0
+
+
+# ------------------------------------------------------------------------------------------------------- optimiser
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, betas, eps, weight_decay, step, grad_scale=1.0):
+    lib = _lib.load()
+    for name, t in (('param', param), ('grad', grad), ('exp_avg', exp_avg), ('exp_avg_sq', exp_avg_sq)):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError('adam_step: %s must be a contiguous float32 device tensor' % name)
+    _lib.check(lib.mg_adam_step_f32(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), float(lr),
+                                    float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step),
+                                    float(grad_scale), _stream()), 'mg_adam_step_f32')
+
+
+def ema_update(shadow, param, decay):
+    lib = _lib.load()
+    if not (shadow.is_cuda and shadow.is_contiguous() and param.is_contiguous()):
+        raise ValueError('ema_update: tensors must be contiguous device tensors')
+    _lib.check(lib.mg_ema_update_f32(_p(shadow), _p(param), shadow.numel(), float(decay), _stream()),
+               'mg_ema_update_f32')

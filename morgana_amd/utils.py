@@ -1,0 +1,257 @@
+"""Host-side mirror of ``morgana.utils`` for the training hot path: same names, arguments and error behaviour, with the
+per-frame compute done by the HIP kernels of libmorgana_hip.so (no torch-op or CPU fallback for the in-scope ops).
+
+Reference: morgana/utils.py - ``sequence_mask`` :115-144, ``upsample_to_repetitions`` :175-228,
+``RecurrentCuDNNWrapper`` :333-393, ``SequentialWithRecurrent`` :396-418, ``ExponentialMovingAverage`` :421-456.
+"""
+import torch
+import torch.nn as nn
+
+from . import functional as F_hip
+from . import ops
+
+_LEGACY_TYPES = {
+    'ByteTensor': torch.uint8, 'CharTensor': torch.int8, 'FloatTensor': torch.float32, 'DoubleTensor': torch.float64,
+    'IntTensor': torch.int32, 'LongTensor': torch.int64, 'BoolTensor': torch.bool,
+}
+
+
+def _as_dtype(dtype):
+    """Accept torch dtypes and the legacy tensor types the reference passes to ``Tensor.type`` (torch.ByteTensor)."""
+    if isinstance(dtype, torch.dtype):
+        return dtype
+    name = getattr(dtype, '__name__', str(dtype)).split('.')[-1]
+    if name in _LEGACY_TYPES:
+        return _LEGACY_TYPES[name]
+    raise TypeError('unsupported mask type %r' % (dtype,))
+
+
+def infer_device(tensor):
+    """morgana/utils.py:147-156."""
+    if tensor.is_cuda:
+        return torch.device('cuda:{}'.format(tensor.get_device()))
+    return torch.device('cpu')
+
+
+def sequence_mask(seq_len, max_len=None, dtype=torch.ByteTensor, device=None):
+    """(batch_size,) lengths -> (batch_size, max_len, 1) mask.  morgana/utils.py:115-144."""
+    if max_len is None:
+        max_len = torch.max(seq_len).item()
+    seq_len = seq_len if seq_len.dtype == torch.int64 else seq_len.long()
+    return ops.sequence_mask(seq_len, int(max_len), _as_dtype(dtype))
+
+
+class UpsampledSequence(object):
+    """Lazy result of ``upsample_to_repetitions(..., fused=True)``: the phone-rate source plus the frame->row map.
+
+    ``SequentialWithRecurrent`` feeds it to the first Linear through the gather-fused GEMM loader, so the
+    (B, Tmax, feat) tensor never exists in HBM.  ``materialise()`` gives the ordinary dense tensor.
+    """
+
+    def __init__(self, sequence_feature, dur2d, rows):
+        self.source = sequence_feature
+        self.dur = dur2d
+        self.rows = rows                       # int32 (B, Tmax): b*P + phone, or -1
+        self.shape = (sequence_feature.shape[0], rows.shape[1], sequence_feature.shape[2])
+
+    def materialise(self):
+        return F_hip.UpsampleFn.apply(self.source, self.dur, self.rows.shape[1])
+
+
+def upsample_to_repetitions(sequence_feature, repeats, max_len=None, fused=False):
+    """Copies sequence items according to a number of repetitions, as ``np.repeat`` does.  morgana/utils.py:175-228.
+
+    sequence_feature (B, P, F) float32; repeats (B, P, 1) or (B, P) integer -> (B, max_b sum_p repeats, F).
+    ``max_len`` (optional, not in the reference) supplies Tmax when the caller knows it (the padded target length),
+    which removes the one device->host sync that sizing the output otherwise needs; the reference has three.
+    """
+    if repeats.is_floating_point() or repeats.dtype == torch.bool:
+        raise TypeError('upsample_to_repetitions: repeats must be an integer tensor, got %s' % repeats.dtype)
+    batch_size = sequence_feature.shape[0]
+    dur2d = repeats.reshape((batch_size, -1))
+    dur2d = dur2d if dur2d.dtype == torch.int64 else dur2d.long()
+    dur2d = dur2d.contiguous()
+    if dur2d.shape[1] != sequence_feature.shape[1]:
+        raise ValueError('repeats has %d items per sequence, sequence_feature has %d'
+                         % (dur2d.shape[1], sequence_feature.shape[1]))
+    if max_len is None:
+        _, tmax = ops.upsample_lengths(dur2d)
+        max_len = int(tmax.item())
+    if fused and not sequence_feature.requires_grad:
+        _, rows = ops.upsample_index(dur2d, int(max_len))
+        return UpsampledSequence(sequence_feature, dur2d, rows)
+    return F_hip.UpsampleFn.apply(sequence_feature, dur2d, int(max_len))
+
+
+class RecurrentCuDNNWrapper(nn.Module):
+    """Wraps a torch recurrent layer with the sort / pack / unpack semantics of morgana/utils.py:333-393.
+
+    ``nn.GRU`` (single layer, unidirectional, batch_first - the shape used by models/f0_test_model.py:32-39) runs on
+    the HIP recurrence; its parameters stay the wrapped layer's own (``layer.weight_ih_l0`` ...), so state_dict keys
+    match the reference.  Other layers (LSTM, multi-layer, bidirectional) are outside this round's scope and run
+    through torch's packed-sequence path on the device.
+    """
+
+    def __init__(self, layer, precision=None):
+        super(RecurrentCuDNNWrapper, self).__init__()
+        self.layer = layer
+        self.precision = precision
+
+    def _hip_gru(self):
+        layer = self.layer
+        return (isinstance(layer, nn.GRU) and layer.num_layers == 1 and not layer.bidirectional and layer.batch_first
+                and layer.bias and getattr(layer, 'proj_size', 0) == 0)
+
+    def _run_gru(self, inputs, hidden, seq_len):
+        layer = self.layer
+        precision = self.precision or F_hip.get_precision()
+        return F_hip.GRUFn.apply(precision, inputs, hidden, seq_len, layer.weight_ih_l0, layer.weight_hh_l0,
+                                 layer.bias_ih_l0, layer.bias_hh_l0)
+
+    def forward(self, inputs, hidden=None, seq_len=None):
+        if seq_len is None:
+            if isinstance(inputs, nn.utils.rnn.PackedSequence):
+                return self.layer(inputs, hx=hidden)
+            elif inputs.ndim == 2:
+                seq_dim = 1 if self.layer.batch_first else 0
+                inputs = inputs.unsqueeze(seq_dim)
+                if self._hip_gru():
+                    outputs, hidden = self._run_gru(inputs.contiguous(), hidden, None)
+                else:
+                    outputs, hidden = self.layer(inputs, hx=hidden)
+                return outputs.squeeze(seq_dim), hidden
+            else:
+                raise ValueError('If no seq_len is provided to RecurrentCuDNNWrapper the data must be already packed'
+                                 f'or must be for one time slice only. For non-packed input got shape, {inputs.shape}')
+
+        if self._hip_gru():
+            seq_len = seq_len if seq_len.dtype == torch.int64 else seq_len.long()
+            t_out = int(torch.max(seq_len).item())          # pad_packed_sequence crops to the longest item
+            if t_out != inputs.shape[1]:
+                inputs = inputs[:, :t_out]
+            return self._run_gru(inputs.contiguous(), hidden, seq_len.contiguous())
+
+        # Out-of-scope layer types: the reference's own torch path (utils.py:366-391).
+        sorted_idxs = torch.argsort(seq_len, descending=True)
+        packed = nn.utils.rnn.pack_padded_sequence(inputs[sorted_idxs, ...], seq_len[sorted_idxs].cpu(),
+                                                   batch_first=True)
+        if hidden is not None:
+            if self.layer.mode == 'LSTM':
+                hidden = (hidden[0][:, sorted_idxs, :], hidden[1][:, sorted_idxs, :])
+            else:
+                hidden = hidden[:, sorted_idxs, :]
+        packed_outputs, hidden = self.layer(packed, hx=hidden)
+        sorted_outputs, _ = nn.utils.rnn.pad_packed_sequence(packed_outputs, batch_first=True)
+        unsort = torch.argsort(sorted_idxs)
+        outputs = sorted_outputs[unsort, ...]
+        if self.layer.mode == 'LSTM':
+            hidden = (hidden[0][:, unsort, :], hidden[1][:, unsort, :])
+        else:
+            hidden = hidden[:, unsort, :]
+        return outputs, hidden
+
+
+class SequentialWithRecurrent(nn.Sequential):
+    """``nn.Sequential`` taking ``hiddens`` / ``seq_len`` for recurrent members; returns ``(output, hiddens)``.
+
+    Reference: morgana/utils.py:396-418.  Runs of ``nn.Linear`` (+ ``nn.Sigmoid``) are executed as one fused HIP node
+    (MFMA GEMM with bias+sigmoid epilogue forward; wgrad and sigmoid-grad-fused dgrad backward).  The modules stay
+    ordinary ``nn.Linear`` objects, so ``state_dict`` keys (``layers.0.weight`` ...) match the reference's checkpoints.
+    """
+
+    def __init__(self, *args, precision=None):
+        super(SequentialWithRecurrent, self).__init__(*args)
+        self.precision = precision
+
+    def _linear_run(self, modules, start):
+        """Collect [Linear, Sigmoid?]+ starting at ``start``; returns (end, [(linear, act), ...])."""
+        run, i = [], start
+        while i < len(modules) and type(modules[i]) is nn.Linear:
+            act = ops.ACT_NONE
+            nxt = i + 1
+            if nxt < len(modules) and type(modules[nxt]) is nn.Sigmoid:
+                act, nxt = ops.ACT_SIGMOID, nxt + 1
+            run.append((modules[i], act))
+            i = nxt
+        return i, run
+
+    def forward(self, input, hiddens=None, seq_len=None):
+        modules = list(self._modules.values())
+        if hiddens is None:
+            hiddens = [None] * len(modules)
+        precision = self.precision or F_hip.get_precision()
+
+        i = 0
+        while i < len(modules):
+            module = modules[i]
+            if type(module) is nn.Linear:
+                end, run = self._linear_run(modules, i)
+                if isinstance(input, UpsampledSequence):
+                    lead, x2d, rows = input.shape[:2], input.source.reshape(-1, input.source.shape[-1]), \
+                        input.rows.reshape(-1)
+                else:
+                    lead, x2d, rows = input.shape[:-1], input.reshape(-1, input.shape[-1]), None
+                params = []
+                for lin, _ in run:
+                    params += [lin.weight, lin.bias]
+                spec = (tuple(act for _, act in run), precision)
+                out = F_hip.LinearStackFn.apply(spec, x2d, rows, *params)
+                input = out.view(*lead, out.shape[-1])
+                i = end
+                continue
+
+            if isinstance(input, UpsampledSequence):
+                input = input.materialise()
+
+            if isinstance(module, RecurrentCuDNNWrapper):
+                input, hiddens[i] = module(input, hiddens[i], seq_len)
+            elif isinstance(module, nn.RNNBase):
+                input, hiddens[i] = module(input, hiddens[i])
+            elif type(module) is nn.Sigmoid:
+                shape = input.shape
+                input = _SigmoidFn.apply(input.reshape(-1)).view(shape)
+            else:
+                input = module(input)
+            i += 1
+
+        if isinstance(input, UpsampledSequence):
+            input = input.materialise()
+        return input, hiddens
+
+
+class _SigmoidFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = ops.sigmoid(x)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad):
+        (y,) = ctx.saved_tensors
+        return ops.sigmoid_grad(grad.contiguous(), y)
+
+
+class ExponentialMovingAverage(object):
+    """EMA helper applying updates to a separate EMA model: ``shadow = decay*shadow + (1-decay)*x``.
+
+    Reference: morgana/utils.py:421-456.  ``shadow[name]`` aliases the EMA model's ``param.data`` as in the reference.
+    """
+
+    def __init__(self, model, decay):
+        self.model = model
+        self.decay = decay
+        self.shadow = {}
+        for name, param in self.model.named_parameters():
+            if param.requires_grad:
+                self.shadow[name] = param.data
+
+    def _update_param(self, name, x):
+        assert name in self.shadow
+        ops.ema_update(self.shadow[name], x.contiguous(), self.decay)
+
+    def update_params(self, other_model):
+        assert other_model is not self.model
+        for name, param in other_model.named_parameters():
+            if name in self.shadow:
+                self._update_param(name, param.data)

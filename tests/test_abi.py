@@ -1,0 +1,74 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads and exports exactly what include/morgana_hip.h
+declares, the ctypes signature table covers it, and the product path refuses to run without a device / library."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import morgana_amd
+from morgana_amd import _lib, ops
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, 'include', 'morgana_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(mg_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), 'libmorgana_hip.so does not export %s' % name
+    assert sorted(_lib.SIGNATURES) == declared
+
+
+def test_library_identity_calls():
+    lib = _lib.load()
+    assert lib.mg_version() == 1
+    assert lib.mg_build_arch() == b'gfx950'
+    assert lib.mg_masked_mse_workspace_bytes(4, 100, 3) >= 4 * 4
+    assert lib.mg_linear_wgrad_workspace_bytes(256000, 512, 600) >= 512 * 600 * 4
+    assert lib.mg_gru_bwd_workspace_bytes(64, 512) >= 64 * 512 * 4
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    lib = _lib.load()
+    rc = lib.mg_upsample_index(None, 0, 0, 0, None, None, None)
+    assert rc == -1 and 'mg_upsample_index' in _lib.last_error()
+    with pytest.raises(ValueError):
+        _lib.check(rc, 'mg_upsample_index')
+
+
+def test_no_cpu_fallback():
+    from morgana_amd import utils, losses
+    x = torch.zeros(2, 3, 4)
+    dur = torch.ones(2, 3, 1, dtype=torch.int64)
+    with pytest.raises(_lib.MorganaHipError):
+        utils.upsample_to_repetitions(x, dur, max_len=3)
+    with pytest.raises(_lib.MorganaHipError):
+        losses.mse(torch.zeros(2, 3, 1), torch.zeros(2, 3, 1), torch.tensor([3, 2]))
+    with pytest.raises(TypeError):
+        utils.upsample_to_repetitions(x, torch.ones(2, 3, 1))          # float durations, as the reference
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(REPO, 'morgana_amd')
+    for root, _, files in os.walk(pkg):
+        for name in files:
+            if name.endswith('.py'):
+                text = open(os.path.join(root, name)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', text, flags=re.M), name
+
+
+def test_state_dict_keys_match_reference_layout():
+    from morgana_amd import models
+    assert sorted(models.F0Model().state_dict()) == sorted(
+        ['layers.%d.%s' % (i, k) for i in (0, 2, 4, 6) for k in ('weight', 'bias')])
+    keys = sorted(models.RNNSPSS().state_dict())
+    assert 'layers.2.layer.weight_ih_l0' in keys and 'layers.5.bias' in keys

@@ -1,0 +1,449 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): every check goes through the C ABI of libmorgana_hip.so and is
+compared with the oracle (oracle/ref_cpu.py) and/or the golden vectors generated from the reference.
+
+Tolerances: integer index work is bit exact; fp32 mode is held to the north star's 1e-4 relative; bf16 throughput mode
+is held to 2e-2 relative (bf16 has an 8-bit mantissa: 4e-3 per rounding), stated per test.
+"""
+import numpy as np
+import pytest
+import torch
+
+from morgana_amd import data, losses, models, ops, optim, synthetic, utils
+from morgana_amd import functional as F_hip
+from oracle import ref_cpu
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4           # fp32 parity bar (north star)
+RTOL_BF16 = 2e-2      # bf16 throughput mode
+
+DEV = 'cuda:0'
+
+
+def dev(x, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+def rel_err(got, want):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    return np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
+
+
+# ------------------------------------------------------------------------------------------------------------ K1
+def test_upsample_index_golden_bit_exact(golden):
+    g = golden('g1_upsample_index.npz')
+    for name in sorted(k[:-5] for k in g if k.endswith('__dur')):
+        dur, want = g[name + '__dur'], g[name + '__idx']
+        d = dev(dur)
+        n_frames, tmax = ops.upsample_lengths(d)
+        assert int(tmax.item()) == want.shape[1]
+        assert np.array_equal(n_frames.cpu().numpy(), dur.sum(axis=1))
+        idx64, rows = ops.upsample_index(d, want.shape[1], want_idx64=True)
+        assert idx64.dtype == torch.int64 and np.array_equal(idx64.cpu().numpy(), want), name
+        p = dur.shape[1]
+        want_rows = np.where(want < 0, -1, want + np.arange(dur.shape[0])[:, None] * p)
+        assert np.array_equal(rows.cpu().numpy(), want_rows)
+
+
+@pytest.mark.parametrize('shape', [(256, 80, 1000), (64, 160, 2000), (3, 1, 5), (17, 300, 4097)])
+def test_upsample_index_full_size_vs_oracle(shape):
+    b, p, t = shape
+    rng = np.random.RandomState(b + p)
+    dur = np.zeros((b, p), dtype=np.int64)
+    for i in range(b):
+        n_ph = rng.randint(1, p + 1)
+        total = rng.randint(n_ph, t + 1)
+        dur[i, :n_ph] = synthetic._durations(rng, total, n_ph)
+    if b > 2:
+        dur[1] = 0                                     # an utterance with no frames at all
+    want, lens = ref_cpu.upsample_index(dur)
+    idx64, _ = ops.upsample_index(dev(dur), want.shape[1] + 3, want_idx64=True)     # t_cap beyond Tmax: -1 fill
+    got = idx64.cpu().numpy()
+    assert np.array_equal(got[:, :want.shape[1]], want)
+    assert np.all(got[:, want.shape[1]:] == -1)
+
+
+def test_upsample_values_and_backward(golden):
+    g = golden('g2_upsample_values.npz')
+    x = dev(g['x']).requires_grad_(True)
+    out = utils.upsample_to_repetitions(x, dev(g['dur'])[:, :, None])
+    assert np.array_equal(out.detach().cpu().numpy(), g['out'])           # a pure copy: bit exact
+    out.backward(dev(g['grad_out']))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g['grad_x'], rtol=1e-6, atol=1e-6)
+    out2 = utils.upsample_to_repetitions(x.detach(), dev(g['dur']))       # 2-D durations
+    assert np.array_equal(out2.cpu().numpy(), g['out_2d_dur'])
+    with pytest.raises(TypeError):
+        utils.upsample_to_repetitions(x.detach(), dev(g['dur']).float())
+
+
+def test_upsample_full_size_copy_and_segment_sum():
+    feats = synthetic.make_batch(32, (300, 2000), lab_dim=600, seed=5)
+    lab, dur = feats['normalised_lab'], feats['dur']
+    want = ref_cpu.upsample_to_repetitions(lab, dur)
+    x = dev(lab).requires_grad_(True)
+    out = utils.upsample_to_repetitions(x, dev(dur))
+    assert out.shape == want.shape
+    assert np.array_equal(out.detach().cpu().numpy(), want)
+    # adjoint property: <U x, g> == <x, U^T g>
+    g = torch.randn_like(out)
+    out.backward(g)
+    lhs = (out.detach().double() * g.double()).sum().item()
+    rhs = (x.detach().double() * x.grad.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-6 * abs(lhs)
+    # bf16 gather with zero padded leading dimension
+    _, rows = ops.upsample_index(dev(dur[:, :, 0]), want.shape[1])
+    bf = ops.gather_rows(dev(lab).view(-1, 600), rows.view(-1), out_bf16=True)
+    assert bf.shape[1] == 600
+    np.testing.assert_allclose(bf.float().cpu().numpy().reshape(want.shape), want, rtol=8e-3, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------- mask / K4 / K5
+def test_sequence_mask(golden):
+    g = golden('g3_sequence_mask.npz')
+    sl = dev(g['seq_len'])
+    m = utils.sequence_mask(sl)
+    assert m.dtype == torch.uint8 and np.array_equal(m.cpu().numpy(), g['mask_default'])
+    m = utils.sequence_mask(sl, max_len=9, dtype=torch.float32)
+    assert np.array_equal(m.cpu().numpy(), g['mask_float32_len9'])
+    m = utils.sequence_mask(sl, max_len=3, dtype=torch.long)
+    assert m.dtype == torch.int64 and np.array_equal(m.cpu().numpy(), g['mask_long_len3'])
+    m = utils.sequence_mask(sl, dtype=torch.ByteTensor)                    # the reference's legacy type object
+    assert np.array_equal(m.cpu().numpy(), g['mask_default'])
+
+
+@pytest.mark.parametrize('dim', [1, 80, 187])
+def test_masked_mse_golden(golden, dim):
+    g = golden('g4_masked_mse.npz')
+    p = dev(g['d%d__pred' % dim]).requires_grad_(True)
+    y = dev(g['d%d__target' % dim])
+    sl = dev(g['d%d__seq_len' % dim])
+    loss = losses.mse(p, y, sl)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g['d%d__loss' % dim], rtol=1e-5)
+    np.testing.assert_allclose(p.grad.cpu().numpy(), g['d%d__grad' % dim], rtol=1e-5, atol=1e-9)
+    p.grad = None
+    loss = losses.mse(p, y)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g['d%d__loss_nolen' % dim], rtol=1e-5)
+    np.testing.assert_allclose(p.grad.cpu().numpy(), g['d%d__grad_nolen' % dim], rtol=1e-5, atol=1e-9)
+
+
+def test_masked_mse_zero_length_is_nan_and_full_size():
+    p = torch.zeros(2, 3, 1, device=DEV)
+    assert torch.isnan(losses.mse(p, p + 1, torch.tensor([0, 2], device=DEV)))
+    rng = np.random.RandomState(3)
+    for (b, t, d) in [(256, 1000, 1), (64, 1000, 80), (64, 1999, 187)]:
+        pred = rng.standard_normal((b, t, d)).astype(np.float32)
+        tgt = rng.standard_normal((b, t, d)).astype(np.float32)
+        sl = rng.randint(1, t + 1, size=b).astype(np.int64)
+        sl[0] = t
+        pt = dev(pred).requires_grad_(True)
+        loss = losses.mse(pt, dev(tgt), dev(sl))
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), ref_cpu.mse(pred, tgt, sl), rtol=1e-5)
+        np.testing.assert_allclose(pt.grad.cpu().numpy(), ref_cpu.mse_grad(pred, tgt, sl), rtol=1e-5, atol=1e-12)
+        # deterministic: two runs give identical bits
+        loss2 = losses.mse(pt.detach(), dev(tgt), dev(sl))
+        assert loss2.item() == loss.item()
+
+
+def test_normalisers(golden):
+    g = golden('g5_normalisers.npz')
+    f = dev(g['feat'])
+    mvn = data.MeanVarianceNormaliser('lf0').set_params({'mean': g['mean'], 'std_dev': g['std']}, device=DEV)
+    mm = data.MinMaxNormaliser('lab').set_params({'mmin': g['mmin'], 'mmax': g['mmax']}, device=DEV)
+    np.testing.assert_allclose(mvn.normalise(f).cpu().numpy(), g['mvn_norm_torch'], rtol=1e-6)
+    np.testing.assert_allclose(mvn.denormalise(f).cpu().numpy(), g['mvn_denorm_torch'], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(mm.normalise(f).cpu().numpy(), g['minmax_norm_torch'], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(mm.denormalise(f).cpu().numpy(), g['minmax_denorm_torch'], rtol=1e-6, atol=1e-7)
+    # NumPy inputs take the host path (loader side), as in the reference
+    with np.errstate(all='ignore'):
+        np.testing.assert_allclose(mvn.normalise(g['feat']), g['mvn_norm_np'], rtol=1e-6)
+        np.testing.assert_allclose(mm.normalise(g['feat']), g['minmax_norm_np'], rtol=1e-6)
+    # round trip on a full-size lab tensor (size independent property)
+    x = torch.rand(256, 80, 600, device=DEV)
+    mmin = torch.rand(600) - 0.5
+    mmax = mmin + torch.rand(600) + 0.1
+    mm2 = data.MinMaxNormaliser('lab').set_params({'mmin': mmin.numpy(), 'mmax': mmax.numpy()}, device=DEV)
+    back = mm2.denormalise(mm2.normalise(x))
+    assert (back - x).abs().max().item() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------------------ K2
+LINEAR_SHAPES = [(1000, 600, 512), (777, 609, 256), (300, 512, 128), (513, 128, 32), (1600, 32, 1), (130, 64, 3),
+                 (64, 40, 96)]
+
+
+@pytest.mark.parametrize('shape', LINEAR_SHAPES)
+@pytest.mark.parametrize('gather', [False, True])
+def test_linear_kernels_fp32(shape, gather):
+    m, k, n = shape
+    rng = np.random.RandomState(m + k + n)
+    w = rng.uniform(-0.1, 0.1, (n, k)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, (n,)).astype(np.float32)
+    if gather:
+        table = rng.uniform(0, 1, (max(m // 7, 2), k)).astype(np.float32)
+        rows = rng.randint(-1, table.shape[0], size=m).astype(np.int32)
+        a = np.where(rows[:, None] < 0, 0, table[np.maximum(rows, 0)]).astype(np.float32)
+        a_dev, rows_dev = dev(table), dev(rows)
+    else:
+        a = rng.uniform(0, 1, (m, k)).astype(np.float32)
+        a_dev, rows_dev = dev(a), None
+    for act in (ops.ACT_NONE, ops.ACT_SIGMOID):
+        y = ops.linear_fwd_f32(a_dev, rows_dev, m, dev(w), dev(b), act).cpu().numpy()
+        want = a.astype(np.float64) @ w.T.astype(np.float64) + b
+        if act:
+            want = 1 / (1 + np.exp(-want))
+        assert rel_err(y, want) < 1e-5, (shape, act)
+    dy = rng.standard_normal((m, n)).astype(np.float32)
+    dw, db = ops.linear_wgrad_f32(dev(dy), a_dev, rows_dev, n, k)
+    assert rel_err(dw.cpu().numpy(), dy.T.astype(np.float64) @ a.astype(np.float64)) < 1e-5
+    assert rel_err(db.cpu().numpy(), dy.astype(np.float64).sum(axis=0)) < 1e-5
+    h = rng.uniform(0.05, 0.95, (m, k)).astype(np.float32)
+    dx = ops.linear_dgrad_f32(dev(dy), dev(w), None).cpu().numpy()
+    assert rel_err(dx, dy.astype(np.float64) @ w.astype(np.float64)) < 1e-5
+    dxh = ops.linear_dgrad_f32(dev(dy), dev(w), dev(h)).cpu().numpy()
+    assert rel_err(dxh, (dy.astype(np.float64) @ w.astype(np.float64)) * h * (1 - h)) < 1e-5
+
+
+def _bf16_round(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(torch.bfloat16).float().numpy()
+
+
+@pytest.mark.parametrize('shape', LINEAR_SHAPES)
+@pytest.mark.parametrize('gather', [False, True])
+def test_linear_kernels_bf16(shape, gather):
+    """bf16 operands are exact inputs here (pre-rounded), so only accumulation order and the output rounding differ:
+    outputs are compared at 1e-2 (bf16 output rounding 4e-3), fp32 weight gradients at 1e-4."""
+    m, k, n = shape
+    rng = np.random.RandomState(m + k + n + 1)
+    w = _bf16_round(rng.uniform(-0.1, 0.1, (n, k)).astype(np.float32))
+    b = rng.uniform(-0.1, 0.1, (n,)).astype(np.float32)
+    if gather:
+        table = _bf16_round(rng.uniform(0, 1, (max(m // 7, 2), k)).astype(np.float32))
+        rows = rng.randint(-1, table.shape[0], size=m).astype(np.int32)
+        a = np.where(rows[:, None] < 0, 0, table[np.maximum(rows, 0)]).astype(np.float32)
+        a_dev, rows_dev = ops.cast_pad_bf16(dev(table)), dev(rows)
+    else:
+        a = _bf16_round(rng.uniform(0, 1, (m, k)).astype(np.float32))
+        a_dev, rows_dev = ops.cast_pad_bf16(dev(a)), None
+    w_bf = ops.cast_pad_bf16(dev(w))
+    assert a_dev.shape[1] % 8 == 0 and torch.all(a_dev[:, k:] == 0)
+    for act in (ops.ACT_NONE, ops.ACT_SIGMOID):
+        want = a.astype(np.float64) @ w.T.astype(np.float64) + b
+        if act:
+            want = 1 / (1 + np.exp(-want))
+        y = ops.linear_fwd_bf16(a_dev, rows_dev, m, k, w_bf, dev(b), n, act)
+        assert y.dtype == torch.bfloat16 and y.shape == (m, ops.pad8(n))
+        assert torch.all(y[:, n:] == 0)
+        assert rel_err(y[:, :n].float().cpu().numpy(), want) < 1e-2, (shape, act)
+        y32 = ops.linear_fwd_bf16(a_dev, rows_dev, m, k, w_bf, dev(b), n, act, out_f32=True)
+        assert y32.dtype == torch.float32 and rel_err(y32[:, :n].cpu().numpy(), want) < 1e-4, (shape, act)
+    dy = _bf16_round(rng.standard_normal((m, n)).astype(np.float32))
+    dy_bf = ops.cast_pad_bf16(dev(dy))
+    dw, db = ops.linear_wgrad_bf16(dy_bf, a_dev, rows_dev, m, n, k)
+    assert rel_err(dw.cpu().numpy(), dy.T.astype(np.float64) @ a.astype(np.float64)) < 1e-4
+    assert rel_err(db.cpu().numpy(), dy.astype(np.float64).sum(axis=0)) < 1e-4
+    wt = ops.cast_transpose_bf16(dev(w))
+    assert wt.shape == (k, ops.pad8(n))
+    np.testing.assert_array_equal(wt[:, :n].float().cpu().numpy(), w.T)
+    dx = ops.linear_dgrad_bf16(dy_bf, m, n, wt, k, None, out_f32=True)
+    assert rel_err(dx[:, :k].cpu().numpy(), dy.astype(np.float64) @ w.astype(np.float64)) < 1e-4
+    h = _bf16_round(rng.uniform(0.05, 0.95, (m, k)).astype(np.float32))
+    dxh = ops.linear_dgrad_bf16(dy_bf, m, n, wt, k, ops.cast_pad_bf16(dev(h)))
+    assert torch.all(dxh[:, k:] == 0)
+    assert rel_err(dxh[:, :k].float().cpu().numpy(), (dy.astype(np.float64) @ w.astype(np.float64)) * h * (1 - h)) < 1e-2
+
+
+# ---------------------------------------------------------------------------------------------- whole models
+def _load_state(model, state):
+    own = model.state_dict()
+    for key, value in state.items():
+        own[key].copy_(torch.from_numpy(value))
+    return model
+
+
+def _c1_batches():
+    return [data.to_device(synthetic.make_batch(8, 200, seed=synthetic.REFERENCE_SEED + 100 * i), DEV)
+            for i in range(4)]
+
+
+def _train(model, batches, n_steps, lr, weight_decay=0.0):
+    opt = optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay)
+    curve = []
+    for step in range(n_steps):
+        opt.zero_grad()
+        loss, _ = model(batches[step % len(batches)])
+        loss.backward()
+        opt.step()
+        curve.append(loss.item())
+    return curve
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_f0_model_fp32_golden_curve_and_grads(golden, fused):
+    g = golden('g6_f0_model.npz')
+    model = _load_state(models.F0Model(precision='fp32', fused_upsample=fused).to(DEV), synthetic.f0_model_state())
+    batches = _c1_batches()
+    loss, out = model(batches[0])
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g['loss_curve'][0], rtol=RTOL)
+    np.testing.assert_allclose(out['pred_norm_lf0'].detach().cpu().numpy()[:, ::25, 0], g['step1_pred_sample'],
+                               rtol=RTOL, atol=1e-6)
+    for name, prm in model.named_parameters():
+        flat = prm.grad.cpu().numpy().ravel()
+        np.testing.assert_allclose(np.sqrt((flat.astype(np.float64) ** 2).sum()), g['step1_gradnorm__' + name],
+                                   rtol=RTOL)
+        want = g['step1_gradval__' + name]
+        np.testing.assert_allclose(flat[g['step1_gradidx__' + name]], want, rtol=1e-3,
+                                   atol=1e-4 * np.abs(want).max())
+    model.zero_grad()
+    curve = _train(model, batches, 20, lr=0.01)
+    np.testing.assert_allclose(curve, g['loss_curve'], rtol=RTOL)            # 20-step Adam loss curve, 1e-4
+    for name, prm in model.named_parameters():
+        v = prm.detach().cpu().numpy().astype(np.float64)
+        np.testing.assert_allclose(v.sum(), g['final_sum__' + name], rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(np.abs(v).sum(), g['final_abs_sum__' + name], rtol=1e-3)
+
+
+def test_f0_model_fp32_ragged_weight_decay(golden):
+    g = golden('g6_f0_model.npz')
+    model = _load_state(models.F0Model(precision='fp32').to(DEV), synthetic.f0_model_state())
+    ragged = data.to_device(synthetic.make_batch(6, (40, 120), seed=77), DEV)
+    curve = _train(model, [ragged], 5, lr=0.005, weight_decay=1e-3)
+    np.testing.assert_allclose(curve, g['ragged_loss_curve'], rtol=RTOL)
+
+
+def test_f0_model_bf16_tracks_golden_curve(golden):
+    g = golden('g6_f0_model.npz')
+    model = _load_state(models.F0Model(precision='bf16').to(DEV), synthetic.f0_model_state())
+    curve = _train(model, _c1_batches(), 20, lr=0.01)
+    np.testing.assert_allclose(curve, g['loss_curve'], rtol=RTOL_BF16)
+
+
+@pytest.mark.parametrize('precision,tol', [('fp32', RTOL), ('bf16', RTOL_BF16)])
+def test_f0_model_full_size_vs_oracle(precision, tol):
+    """BASELINE config C2 (256 x 1000 frames) forward + backward against the numpy oracle."""
+    feats = synthetic.make_batch(256, 1000)
+    state = synthetic.f0_model_state()
+    want_loss, want_pred, want_grads = ref_cpu.f0_forward_backward(state, feats)
+    model = _load_state(models.F0Model(precision=precision).to(DEV), state)
+    loss, out = model(data.to_device(feats, DEV))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), want_loss, rtol=tol)
+    pred = out['pred_norm_lf0'].detach().cpu().numpy()
+    assert pred.shape == want_pred.shape
+    assert rel_err(pred, want_pred) < (1e-4 if precision == 'fp32' else 3e-2)
+    for name, prm in model.named_parameters():
+        assert rel_err(prm.grad.cpu().numpy(), want_grads[name]) < (1e-3 if precision == 'fp32' else 5e-2), name
+
+
+@pytest.mark.parametrize('tag', ['h8', 'h32'])
+def test_gru_wrapper_golden(golden, tag):
+    g = golden('g7_gru.npz')
+    hid = int(tag[1:])
+    x_np, sl_np = g[tag + '__x'], g[tag + '__seq_len']
+    i_dim = x_np.shape[2]
+    gru = torch.nn.GRU(i_dim, hid, batch_first=True).to(DEV)
+    st = synthetic.init_gru(np.random.RandomState(5 + hid), i_dim, hid)
+    with torch.no_grad():
+        for prm, val in zip((gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0), st):
+            prm.copy_(dev(val))
+    wrapper = utils.RecurrentCuDNNWrapper(gru, precision='fp32')
+    x = dev(x_np).requires_grad_(True)
+    sl = dev(sl_np)
+    out, hn = wrapper(x, None, sl)
+    assert tuple(out.shape) == g[tag + '__out'].shape and tuple(hn.shape) == g[tag + '__hn'].shape
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g[tag + '__out'], rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(hn.detach().cpu().numpy(), g[tag + '__hn'], rtol=RTOL, atol=1e-6)
+    for b, n in enumerate(sl_np):
+        assert torch.all(out[b, n:] == 0)                                 # padded steps exactly zero
+    (out * dev(g[tag + '__grad_out'])).sum().backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g[tag + '__grad_x'], rtol=1e-3, atol=1e-5)
+    for pname in ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0'):
+        np.testing.assert_allclose(getattr(gru, pname).grad.cpu().numpy(), g[tag + '__grad_' + pname], rtol=1e-3,
+                                   atol=1e-5)
+        getattr(gru, pname).grad = None
+    x.grad = None
+    h0 = dev(g[tag + '__h0']).requires_grad_(True)
+    out, hn = wrapper(x, h0, sl)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g[tag + '__out_h0'], rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(hn.detach().cpu().numpy(), g[tag + '__hn_h0'], rtol=RTOL, atol=1e-6)
+    ((out * dev(g[tag + '__grad_out'])).sum() + (hn * dev(g[tag + '__grad_hn'])).sum()).backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g[tag + '__grad_x_h0'], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(h0.grad.cpu().numpy(), g[tag + '__grad_h0'], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(gru.weight_hh_l0.grad.cpu().numpy(), g[tag + '__grad_weight_hh_l0_h0'], rtol=1e-3,
+                               atol=1e-5)
+
+
+def test_gru_wrapper_errors_and_single_step():
+    gru = torch.nn.GRU(4, 8, batch_first=True).to(DEV)
+    wrapper = utils.RecurrentCuDNNWrapper(gru, precision='fp32')
+    with pytest.raises(ValueError):
+        wrapper(torch.zeros(2, 3, 4, device=DEV))                         # 3-D input without seq_len (utils.py:361-363)
+    x = torch.randn(5, 4, device=DEV)
+    out, hn = wrapper(x)                                                  # one time slice (utils.py:351-358)
+    ref_out, ref_hn = gru(x.unsqueeze(1))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref_out.squeeze(1).detach().cpu().numpy(), rtol=1e-4,
+                               atol=1e-6)
+
+
+def test_rnn_model_golden(golden):
+    g = golden('g7_gru.npz')
+    lab_dim, hidden, post, out_dim = [int(v) for v in g['rnn__dims']]
+    state = synthetic.rnn_spss_state(seed=31, lab_dim=lab_dim, hidden=hidden, post=post, out_dim=out_dim)
+    feats = data.to_device(synthetic.make_batch(6, (20, 60), lab_dim=lab_dim, out_dim=out_dim, target_name='mcep',
+                                                frames_per_phone=6.0, seed=99), DEV)
+    model = _load_state(models.RNNSPSS(lab_dim, hidden, post, out_dim, precision='fp32').to(DEV), state)
+    loss, out = model(feats)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g['rnn__loss_curve'][0], rtol=RTOL)
+    np.testing.assert_allclose(out['pred_norm_mcep'].detach().cpu().numpy(), g['rnn__step1_pred'], rtol=1e-3, atol=1e-5)
+    for name, prm in model.named_parameters():
+        want = g['rnn__step1_grad__' + name]
+        np.testing.assert_allclose(prm.grad.cpu().numpy(), want, rtol=1e-3, atol=1e-4 * np.abs(want).max())
+    model.zero_grad()
+    curve = _train(model, [feats], 8, lr=0.01)
+    np.testing.assert_allclose(curve, g['rnn__loss_curve'], rtol=RTOL)
+    # bf16 GEMMs around the fp32 recurrence track the same curve
+    model = _load_state(models.RNNSPSS(lab_dim, hidden, post, out_dim, precision='bf16').to(DEV), state)
+    curve = _train(model, [feats], 8, lr=0.01)
+    np.testing.assert_allclose(curve, g['rnn__loss_curve'], rtol=RTOL_BF16)
+
+
+def test_rnn_model_c4_shape_vs_oracle():
+    """GRU-512 model at a reduced batch of BASELINE config C4 (8 x 120 frames, ragged) against the numpy oracle."""
+    feats = synthetic.make_batch(8, (60, 120), out_dim=80, target_name='mcep', seed=11)
+    state = synthetic.rnn_spss_state()
+    want_loss, want_pred, want_grads = ref_cpu.rnn_forward_backward(state, feats)
+    model = _load_state(models.RNNSPSS(precision='fp32').to(DEV), state)
+    loss, out = model(data.to_device(feats, DEV))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), want_loss, rtol=RTOL)
+    assert rel_err(out['pred_norm_mcep'].detach().cpu().numpy(), want_pred) < 1e-4
+    for name, prm in model.named_parameters():
+        assert rel_err(prm.grad.cpu().numpy(), want_grads[name]) < 1e-3, name
+
+
+# ------------------------------------------------------------------------------------------- optimiser / EMA
+def test_adam_and_ema_vs_oracle(golden):
+    rng = np.random.RandomState(0)
+    p0 = rng.standard_normal(10007).astype(np.float32)
+    for wd in (0.0, 1e-2):
+        p_ref = p0.copy()
+        ref = ref_cpu.Adam([p_ref], lr=0.01, weight_decay=wd)
+        prm = torch.nn.Parameter(dev(p0.copy()))
+        opt = optim.Adam([prm], lr=0.01, weight_decay=wd)
+        for step in range(5):
+            gnp = rng.standard_normal(10007).astype(np.float32) * (10.0 ** rng.randint(-6, 2))
+            ref.step([gnp])
+            opt.zero_grad()
+            prm.grad.copy_(dev(gnp))
+            opt.step()
+        np.testing.assert_allclose(prm.detach().cpu().numpy(), p_ref, rtol=1e-5, atol=1e-7)
+    g = golden('g9_ema_lr.npz')
+    shadow = dev(g['ema_shadow0'].copy())
+    for params in g['ema_params_seq']:
+        ops.ema_update(shadow, dev(params), float(g['ema_decay']))
+    np.testing.assert_allclose(shadow.cpu().numpy(), g['ema_shadow_final'], rtol=1e-6)
