@@ -1,0 +1,79 @@
+"""world_size-2 gloo tests on CPU of the data-parallel path: contiguous utterance shards + ONE flat all-reduce per step
+must reproduce the single-process run on the global batch."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from morgana_amd import distributed, optim, synthetic
+from oracle import ref_torch
+
+import helpers
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _single_process(n_steps, ragged):
+    torch.set_num_threads(1)
+    model = helpers.init_small(helpers.CpuF0Model(dims=(24, 16, 8, 1)), seed=1)
+    frames = (30, 90) if ragged else 50
+    batch = ref_torch.to_torch(synthetic.make_batch(8, frames, lab_dim=24, frames_per_phone=5.0, seed=17))
+    opt = optim.Adam(model.parameters(), lr=0.01, weight_decay=1e-3, kernel=helpers.cpu_adam_kernel)
+    losses = []
+    for _ in range(n_steps):
+        opt.zero_grad()
+        loss, _ = model(batch)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    return opt.flat_buffers()['param'].numpy().copy(), losses
+
+
+@pytest.mark.parametrize('world', [2, 4])
+@pytest.mark.parametrize('mode', ['fixed', 'ragged'])
+def test_data_parallel_equals_global_batch(tmp_path, world, mode):
+    out = str(tmp_path / 'dp.npz')
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), OMP_NUM_THREADS='1')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, 'tests', '_dist_worker.py'), out, '4', mode],
+                                      env=env, cwd=REPO))
+    for p in procs:
+        assert p.wait(timeout=240) == 0
+    got = np.load(out)
+    want_flat, want_losses = _single_process(4, mode == 'ragged')
+    for replica in got['replicas']:                         # replicas stay bit-identical to each other
+        assert np.array_equal(replica, got['replicas'][0])
+    np.testing.assert_allclose(got['flat'], want_flat, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(got['losses'], want_losses, rtol=1e-5)
+
+
+def test_shard_slices_and_cropping():
+    batch = synthetic.make_batch(8, (30, 90), lab_dim=6, seed=2)
+    seen = []
+    for rank in range(4):
+        shard = synthetic.shard_batch(batch, rank, 4)
+        sl = distributed.shard_slice(8, rank, 4)
+        assert np.array_equal(shard['n_frames'], batch['n_frames'][sl])
+        t = int(shard['n_frames'].max())
+        assert shard['normalised_lf0'].shape[1] == t
+        assert np.array_equal(shard['normalised_lf0'], batch['normalised_lf0'][sl, :t])
+        assert np.array_equal(shard['dur'].sum(axis=(1, 2)), shard['n_frames'])
+        seen += shard['name']
+    assert seen == batch['name']
+    with pytest.raises(ValueError):
+        distributed.shard_slice(10, 0, 4)
