@@ -107,14 +107,34 @@ def roofline_f0(features, model, precision):
             'frac': round(dom['tflops'] / peak, 4), 'traffic': None, 'ms_per_launch': dom['ms'], 'kernels': measured}
 
 
+def host_cores():
+    """CPU threads this process may really use: affinity, capped by the cgroup CPU quota (the GPU box gives a 1-GPU job
+    a share of the host, not all of its cores) and by 32 (the 64 x 1000-frame sample does not scale further)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            text = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if text[0] != 'max':
+                    n = min(n, max(1, int(int(text[0]) / int(text[1]))))
+            else:
+                quota = int(text[0])
+                period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, 32))
+
+
 def cpu_baseline_f0(frames):
     """Oracle torch-CPU restatement of the reference step on a bounded sample (64 utterances of the C2 batch)."""
     from oracle import ref_torch
-    n_threads = os.cpu_count() or 1
-    try:
-        n_threads = len(os.sched_getaffinity(0))
-    except AttributeError:
-        pass
+    n_threads = host_cores()
     torch.set_num_threads(n_threads)
     sample_b = 64
     feats = ref_torch.to_torch(synthetic.make_batch(sample_b, frames))
