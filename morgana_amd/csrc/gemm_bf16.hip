@@ -344,10 +344,26 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const uint16_t* __restr
 }
 
 __global__ __launch_bounds__(256) void slab_reduce_bf16path_kernel(const float* __restrict__ slab, int64_t n, int S, float* __restrict__ dst, int accumulate) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        float v = accumulate ? dst[i] : 0.f;
-        for (int s = 0; s < S; ++s) v += slab[(size_t)s * n + i];
-        dst[i] = v;
+    // 16 consecutive elements x 16 slab partitions per workgroup: partition p sums slabs p, p+16, ... in ascending
+    // order, the 16 partials are then added in ascending p (fixed order -> bitwise reproducible).
+    __shared__ float part[16][17];
+    const int e = threadIdx.x & 15, p = threadIdx.x >> 4;
+    for (int64_t base = (int64_t)blockIdx.x * 16; base < n; base += (int64_t)gridDim.x * 16) {
+        const int64_t i = base + e;
+        float v = 0.f;
+        if (i < n) {
+#pragma unroll 4
+            for (int s = p; s < S; s += 16) v += slab[(size_t)s * n + i];
+        }
+        part[p][e] = v;
+        __syncthreads();
+        if (p == 0 && i < n) {
+            float t = accumulate ? dst[i] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += part[q][e];
+            dst[i] = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -378,6 +394,13 @@ static WgradPlanB wgrad_plan_b(int64_t M, int N, int K) {
 
 static bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 
+// large-tile kernels (gemm_bf16_big.hip)
+int mg_try_nt_big(const uint16_t* A, int lda, const int32_t* rows, int64_t M, int K, const uint16_t* Bm, int ldb, int N,
+                  const float* bias, const uint16_t* H, int ldh, void* C, int ldc, int c_f32, int epi, hipStream_t st);
+int mg_wgrad_big_plan(int64_t M, int N, int K, int lda, int lddy, int* S_out, int* m_chunk_out);
+int mg_launch_wgrad_big(const uint16_t* dY, int lddy, const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K,
+                        int S, int m_chunk, float* slab, float* bslab, hipStream_t st);
+
 extern "C" {
 
 int mg_linear_fwd_bf16(const uint16_t* A, int lda, const int32_t* rows, int64_t M, int K, const uint16_t* W, int ldw,
@@ -389,6 +412,11 @@ int mg_linear_fwd_bf16(const uint16_t* A, int lda, const int32_t* rows, int64_t 
     MG_CHECK_ARG(act == MG_ACT_NONE || act == MG_ACT_SIGMOID, "mg_linear_fwd_bf16: unknown activation %d", act);
     if (M == 0) return MG_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (ldy == N && mg_try_nt_big(A, lda, rows, M, K, W, ldw, N, bias, nullptr, 0, Y, ldy, y_f32,
+                                  act == MG_ACT_SIGMOID ? EPI_BIAS_SIGMOID : EPI_BIAS, st) > 0) {
+        MG_CHECK_LAUNCH("mg_linear_fwd_bf16/big");
+        return MG_OK;
+    }
     if (N <= 32) {
         const int tn = (int)mg_ceil_div(ldy, 32);
         const int64_t blocks = mg_ceil_div(M, 128) * tn;
@@ -419,6 +447,11 @@ int mg_linear_dgrad_bf16(const uint16_t* dY, int lddy, int64_t M, int N, const u
     if (M == 0) return MG_OK;
     hipStream_t st = (hipStream_t)stream;
     // C[M,K] = dY[M,N] * WT[K,N]^T : the NT kernel with contraction N, output width K.
+    if (lddx == K && mg_try_nt_big(dY, lddy, nullptr, M, N, WT, ldwt, K, nullptr, H, ldh, dX, lddx, dx_f32,
+                                   H ? EPI_SIGMOID_GRAD : EPI_BIAS, st) > 0) {
+        MG_CHECK_LAUNCH("mg_linear_dgrad_bf16/big");
+        return MG_OK;
+    }
     if (K <= 32) {
         const int tn = (int)mg_ceil_div(lddx, 32);
         const int64_t blocks = mg_ceil_div(M, 128) * tn;
@@ -448,23 +481,28 @@ int mg_linear_wgrad_bf16(const uint16_t* dY, int lddy, const uint16_t* A, int ld
         mg_set_error("mg_linear_wgrad_bf16: workspace of %zu bytes needed, got %zu", mg_linear_wgrad_workspace_bytes(M, N, K), workspace_bytes);
         return MG_EWORKSPACE;
     }
-    const WgradPlanB p = wgrad_plan_b(M, N, K);
+    WgradPlanB p = wgrad_plan_b(M, N, K);
     float* slab = (float*)workspace;
-    float* bslab = slab + (size_t)p.S * N * K;
     hipStream_t st = (hipStream_t)stream;
+    int big_s = 0, big_chunk = 0;
+    const bool big = mg_wgrad_big_plan(M, N, K, lda, lddy, &big_s, &big_chunk) > 0;
+    if (big) p.S = big_s;
+    float* bslab = slab + (size_t)p.S * N * K;
     dim3 grid((unsigned)(p.tiles_n * p.tiles_k), (unsigned)p.S);
-    if (p.narrow)
+    if (big)
+        mg_launch_wgrad_big(dY, lddy, A, lda, rows, M, N, K, big_s, big_chunk, slab, db ? bslab : nullptr, st);
+    else if (p.narrow)
         hipLaunchKernelGGL((wgrad_bf16_kernel<32, 128, 1, 4>), grid, dim3(256), 0, st, dY, lddy, A, lda, rows, M, N, K, p.m_chunk, slab, db ? bslab : nullptr, p.tiles_k);
     else
         hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, dY, lddy, A, lda, rows, M, N, K, p.m_chunk, slab, db ? bslab : nullptr, p.tiles_k);
     MG_CHECK_LAUNCH("mg_linear_wgrad_bf16/partial");
     const int64_t nk = (int64_t)N * K;
-    int64_t blocks = mg_ceil_div(nk, 256);
-    if (blocks > 2048) blocks = 2048;
+    int64_t blocks = mg_ceil_div(nk, 16);
+    if (blocks > 32768) blocks = 32768;
     hipLaunchKernelGGL(slab_reduce_bf16path_kernel, dim3((unsigned)blocks), dim3(256), 0, st, slab, nk, p.S, dW, accumulate);
     MG_CHECK_LAUNCH("mg_linear_wgrad_bf16/reduce");
     if (db) {
-        hipLaunchKernelGGL(slab_reduce_bf16path_kernel, dim3((unsigned)mg_ceil_div(N, 256)), dim3(256), 0, st, bslab, (int64_t)N, p.S, db, accumulate);
+        hipLaunchKernelGGL(slab_reduce_bf16path_kernel, dim3((unsigned)mg_ceil_div(N, 16)), dim3(256), 0, st, bslab, (int64_t)N, p.S, db, accumulate);
         MG_CHECK_LAUNCH("mg_linear_wgrad_bf16/reduce_bias");
     }
     return MG_OK;

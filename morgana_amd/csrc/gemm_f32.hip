@@ -322,10 +322,26 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const float* __restrict_
 
 // dst[i] = (accumulate ? dst[i] : 0) + sum_s slab[s][i], s ascending (deterministic).
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int64_t n, int S, float* __restrict__ dst, int accumulate) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        float v = accumulate ? dst[i] : 0.f;
-        for (int s = 0; s < S; ++s) v += slab[(size_t)s * n + i];
-        dst[i] = v;
+    // 16 consecutive elements x 16 slab partitions per workgroup: partition p sums slabs p, p+16, ... in ascending
+    // order, the 16 partials are then added in ascending p (fixed order -> bitwise reproducible).
+    __shared__ float part[16][17];
+    const int e = threadIdx.x & 15, p = threadIdx.x >> 4;
+    for (int64_t base = (int64_t)blockIdx.x * 16; base < n; base += (int64_t)gridDim.x * 16) {
+        const int64_t i = base + e;
+        float v = 0.f;
+        if (i < n) {
+#pragma unroll 4
+            for (int s = p; s < S; s += 16) v += slab[(size_t)s * n + i];
+        }
+        part[p][e] = v;
+        __syncthreads();
+        if (p == 0 && i < n) {
+            float t = accumulate ? dst[i] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += part[q][e];
+            dst[i] = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -417,7 +433,18 @@ int mg_linear_dgrad_f32(const float* dY, int64_t M, int N, const float* W, int K
 size_t mg_linear_wgrad_workspace_bytes(int64_t M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 256;
     const WgradPlan p = wgrad_plan(M, N, K);
-    return mg_align_up((size_t)p.S * ((size_t)N * K + (size_t)N) * sizeof(float), 256);
+    int64_t S = p.S;
+    if (N % 128 == 0) {   // the wide bf16 kernel (gemm_bf16_big.hip) may split further: size for the larger plan
+        int64_t sb = mg_ceil_div(256, N / 128);
+        int64_t chunk = mg_align_up((size_t)mg_ceil_div(M, sb), 32);
+        while (chunk > 8192) {
+            sb *= 2;
+            chunk = mg_align_up((size_t)mg_ceil_div(M, sb), 32);
+        }
+        sb = mg_ceil_div(M, chunk);
+        if (sb > S) S = sb;
+    }
+    return mg_align_up((size_t)S * ((size_t)N * K + (size_t)N) * sizeof(float), 256);
 }
 
 int mg_linear_wgrad_f32(const float* dY, const float* A, int lda, const int32_t* rows, int64_t M, int N, int K, float* dW,
@@ -441,12 +468,12 @@ int mg_linear_wgrad_f32(const float* dY, const float* A, int lda, const int32_t*
         hipLaunchKernelGGL((wgrad_f32_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, dY, N, A, lda, rows, M, N, K, p.m_chunk, slab, db ? bslab : nullptr, p.tiles_k, vec_y, vec_a);
     MG_CHECK_LAUNCH("mg_linear_wgrad_f32/partial");
     const int64_t nk = (int64_t)N * K;
-    int64_t blocks = mg_ceil_div(nk, 256);
-    if (blocks > 2048) blocks = 2048;
+    int64_t blocks = mg_ceil_div(nk, 16);
+    if (blocks > 32768) blocks = 32768;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, slab, nk, p.S, dW, accumulate);
     MG_CHECK_LAUNCH("mg_linear_wgrad_f32/reduce");
     if (db) {
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)mg_ceil_div(N, 256)), dim3(256), 0, st, bslab, (int64_t)N, p.S, db, accumulate);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)mg_ceil_div(N, 16)), dim3(256), 0, st, bslab, (int64_t)N, p.S, db, accumulate);
         MG_CHECK_LAUNCH("mg_linear_wgrad_f32/reduce_bias");
     }
     return MG_OK;

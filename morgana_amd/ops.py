@@ -42,8 +42,13 @@ def workspace(nbytes, device):
     return buf
 
 
-def pad8(n):
-    return (n + 7) // 8 * 8
+def pad_ld(n):
+    """Leading dimension of a bf16 buffer with n columns: a multiple of 64 (the large-tile kernels' K step) once the
+    row is at least 64 wide, a multiple of 8 (one 16-byte chunk) below that.  Padding columns hold zeros."""
+    return (n + 63) // 64 * 64 if n >= 64 else (n + 7) // 8 * 8
+
+
+pad8 = pad_ld
 
 
 # ----------------------------------------------------------------------------------------------------------------- K1

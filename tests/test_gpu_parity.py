@@ -94,8 +94,8 @@ def test_upsample_full_size_copy_and_segment_sum():
     # bf16 gather with zero padded leading dimension
     _, rows = ops.upsample_index(dev(dur[:, :, 0]), want.shape[1])
     bf = ops.gather_rows(dev(lab).view(-1, 600), rows.view(-1), out_bf16=True)
-    assert bf.shape[1] == 600
-    np.testing.assert_allclose(bf.float().cpu().numpy().reshape(want.shape), want, rtol=8e-3, atol=1e-6)
+    assert bf.shape[1] == ops.pad_ld(600) and torch.all(bf[:, 600:] == 0)
+    np.testing.assert_allclose(bf[:, :600].float().cpu().numpy().reshape(want.shape), want, rtol=8e-3, atol=1e-6)
 
 
 # ------------------------------------------------------------------------------------------- mask / K4 / K5
@@ -172,7 +172,10 @@ def test_normalisers(golden):
 
 # ------------------------------------------------------------------------------------------------------------ K2
 LINEAR_SHAPES = [(1000, 600, 512), (777, 609, 256), (300, 512, 128), (513, 128, 32), (1600, 32, 1), (130, 64, 3),
-                 (64, 40, 96)]
+                 (64, 40, 96),
+                 # shapes that take the large-tile LDS-DMA kernels (M >= 2048 / 4096, N % 128 == 0), with ragged M tails
+                 (4999, 600, 512), (4500, 512, 128), (4100, 128, 512), (6001, 200, 256), (5003, 600, 384),
+                 (8200, 512, 1536)]
 
 
 @pytest.mark.parametrize('shape', LINEAR_SHAPES)
@@ -235,7 +238,7 @@ def test_linear_kernels_bf16(shape, gather):
         if act:
             want = 1 / (1 + np.exp(-want))
         y = ops.linear_fwd_bf16(a_dev, rows_dev, m, k, w_bf, dev(b), n, act)
-        assert y.dtype == torch.bfloat16 and y.shape == (m, ops.pad8(n))
+        assert y.dtype == torch.bfloat16 and y.shape == (m, ops.pad_ld(n))
         assert torch.all(y[:, n:] == 0)
         assert rel_err(y[:, :n].float().cpu().numpy(), want) < 1e-2, (shape, act)
         y32 = ops.linear_fwd_bf16(a_dev, rows_dev, m, k, w_bf, dev(b), n, act, out_f32=True)
@@ -246,7 +249,7 @@ def test_linear_kernels_bf16(shape, gather):
     assert rel_err(dw.cpu().numpy(), dy.T.astype(np.float64) @ a.astype(np.float64)) < 1e-4
     assert rel_err(db.cpu().numpy(), dy.astype(np.float64).sum(axis=0)) < 1e-4
     wt = ops.cast_transpose_bf16(dev(w))
-    assert wt.shape == (k, ops.pad8(n))
+    assert wt.shape == (k, ops.pad_ld(n))
     np.testing.assert_array_equal(wt[:, :n].float().cpu().numpy(), w.T)
     dx = ops.linear_dgrad_bf16(dy_bf, m, n, wt, k, None, out_f32=True)
     assert rel_err(dx[:, :k].cpu().numpy(), dy.astype(np.float64) @ w.astype(np.float64)) < 1e-4
