@@ -26,9 +26,19 @@ typedef __bf16 bfv4 __attribute__((ext_vector_type(4)));
 #define MG_ZERO_ELEMS 16384
 __device__ uint16_t g_zero_row[MG_ZERO_ELEMS];   // zero-initialised: source of pad rows / out-of-range rows
 
+// LDS-DMA of 64 x 16 bytes: lane l's 16 bytes land at LDS byte (lds_wave_base + 16 l).  Issued from inline asm on
+// purpose: hipcc then keeps no record of a pending LDS write, so it neither drains vmcnt in front of the fragment reads
+// (it does for ds_read_b64_tr_b16 behind the builtin form: one s_waitcnt vmcnt(0) per step, measured) nor in front of
+// __syncthreads; completion is tracked by the counted waits of WAIT_VM_BARRIER below.  M0 is saved and restored inside
+// the statement (cdna_hip_programming.md section 5.7).
 __device__ __forceinline__ void glds16(const uint16_t* src, unsigned char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+    const unsigned lds_off = (unsigned)(unsigned long long)((__attribute__((address_space(3))) unsigned char*)lds_wave_base);
+    const unsigned lds_uni = __builtin_amdgcn_readfirstlane(lds_off);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_uni)
+                 : "memory");
 }
 
 __device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
@@ -37,47 +47,57 @@ __device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + 
 #define WAIT_LGKM_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // ---------------------------------------------------------------------------------------------------------------------
-// gemm_nt_big: BM = 256, BN in {256, 128}, BK = 64.  LDS rows are 128 bytes (8 chunks of 16 B); chunk c of tile row r is
-// stored at chunk position c ^ ((r >> 1) & 7): conflict free for the 4 x 16 lane groups of ds_read_b128.
-// Requires lda, ldb multiples of 64 with zero padding, N a multiple of BN... (checked by the launcher).
+// gemm_nt_big: BM = 256, BN in {256, 128}, BK = 32, FOUR LDS stages (three tiles of LDS-DMA in flight, one barrier per
+// stage).  LDS rows are 64 bytes (4 chunks of 16 B); chunk c of tile row r is stored at chunk position c ^ ((r>>2)&3):
+// conflict free for the 4 x 16 lane groups of ds_read_b128.
+// The MFMA is issued with the operands swapped (weights as A, frames as B), so the accumulator tile is C^T: the lane
+// holds one output ROW (frame) and its registers hold 4-column groups of it.  The epilogue therefore runs entirely in
+// registers (bias / sigmoid / sigmoid-grad per register, bf16 pack, v_permlane32_swap to widen to 16-byte stores): no
+// LDS staging and no per-element index arithmetic (the first version spent ~45 % of its cycles there, profiles/r1).
+// Requires lda, ldb multiples of 64 (zero padded), N % BN == 0, ldc == N, (SIGMOID_GRAD) ldh >= N.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int BN, int EPI>
+#define NT_STAGES 4
+
+template <int BN, int EPI, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
                                                           int64_t M, int K, const uint16_t* __restrict__ Bm, int ldb, int N,
                                                           const float* __restrict__ bias, const uint16_t* __restrict__ H, int ldh,
-                                                          void* __restrict__ Cv, int ldc, int tiles_n, int c_f32) {
+                                                          void* __restrict__ Cv, int ldc, int tiles_m, int tiles_n, int c_f32) {
     constexpr int BM = 256;
     constexpr int WAVES_N = BN / 64;              // 4 or 2
     constexpr int WAVES_M = 8 / WAVES_N;          // 2 or 4
     constexpr int WM = BM / WAVES_M;              // 128 or 64
     constexpr int TM = WM / 32, TN = 2;
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
     constexpr int STAGE = A_BYTES + B_BYTES;
-    constexpr int GA = BM / 64;                   // 1 KB row groups (8 rows) per wave for A: 4
-    constexpr int GB = BN / 64;                   // for B: 4 or 2
-    constexpr int NL = GA + GB;                   // LDS-DMA instructions per wave per K tile
-    constexpr int STG_LD = 68;                    // fp32 staging pitch (floats): 32 rows x 64 cols per wave and pass
-    constexpr int STG_BYTES = 8 * 32 * STG_LD * 4;
-    constexpr int LDS_BYTES = 2 * STAGE > STG_BYTES ? 2 * STAGE : STG_BYTES;
+    constexpr int GA = BM / 16 / 8;               // 1 KB pieces (16 rows) per wave for A: 2
+    constexpr int GB = BN / 16 / 8;               // for B: 2 or 1
+    constexpr int NL = GA + GB;                   // LDS-DMA instructions per wave per stage: 4 or 3
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NT_STAGES * STAGE];
+
+    // XCD-aware tile order: blocks b and b + 8 share an XCD (its L2); give them the N tiles of ONE M tile so the A rows
+    // and the H tile are fetched into that L2 once.
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int tile_n = jj % tiles_n;
+    const int tile_m = (jj / tiles_n) * 8 + xcd;
+    if (tile_m >= tiles_m) return;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * 64;
-    const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * BM;
-    const int n0 = (blockIdx.x % tiles_n) * BN;
-    const int kc = lda < ldb ? lda : ldb;
-    const int n_kt = kc / 64;
+    const int64_t m0 = (int64_t)tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int n_kt = (K + 31) / 32;               // stages that hold real columns (lda, ldb >= 64 * ceil(K / 64))
 
-    // Per-lane DMA sources.  Group g covers tile rows 8g..8g+7; lane l writes LDS row 8g + (l>>3), chunk position l&7,
-    // and therefore fetches source chunk (l&7) ^ ((row>>1)&7) of that row.
+    // Per-lane DMA sources.  Piece g covers tile rows 16g..16g+15; lane l writes row 16g + (l>>2), chunk position l&3,
+    // and therefore fetches source chunk (l&3) ^ ((row>>2)&3) of that row.
     const uint16_t* asrc[GA];
     const uint16_t* bsrc[GB];
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
-        const int row = (wave * GA + i) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const int row = (wave * GA + i) * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
         const int64_t m = m0 + row;
         const uint16_t* p = g_zero_row;
         if (m < M) {
@@ -92,20 +112,22 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __rest
     }
 #pragma unroll
     for (int i = 0; i < GB; ++i) {
-        const int row = (wave * GB + i) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const int row = (wave * GB + i) * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
         const int n = n0 + row;
         bsrc[i] = (n < N ? Bm + (size_t)n * ldb : g_zero_row) + c * 8;
     }
 
     auto issue = [&](int kt) {
-        unsigned char* st = smem + (kt & 1) * STAGE;
+        unsigned char* st = smem + (kt & (NT_STAGES - 1)) * STAGE;
+        if (ABL == 1 && kt > 0) return;            // ablation: no DMA after the first tile (timing only, wrong results)
 #pragma unroll
-        for (int i = 0; i < GA; ++i) glds16(asrc[i] + kt * 64, st + (wave * GA + i) * 1024);
+        for (int i = 0; i < GA; ++i) glds16(asrc[i] + kt * 32, st + (wave * GA + i) * 1024);
 #pragma unroll
-        for (int i = 0; i < GB; ++i) glds16(bsrc[i] + kt * 64, st + A_BYTES + (wave * GB + i) * 1024);
+        for (int i = 0; i < GB; ++i) glds16(bsrc[i] + kt * 32, st + A_BYTES + (wave * GB + i) * 1024);
     };
 
+    // acc[i][j] holds C^T of the (i, j) 32 x 32 sub-tile: lane&31 = frame row, registers = output columns.
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -115,99 +137,178 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __rest
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int lr = lane & 31, lh = lane >> 5;
-    const int ks_last = ((K - (n_kt - 1) * 64) + 15) / 16;       // k-steps of the last tile that hold real columns
+    // fragment byte offsets inside a stage for k-step 0; k-step 1 is the same offset XOR 32
+    int aoff[TM], boff[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = wm0 + i * 32 + lr;
+        aoff[i] = row * 64 + ((lh ^ ((row >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wn0 + j * 32 + lr;
+        boff[j] = A_BYTES + row * 64 + ((lh ^ ((row >> 2) & 3)) << 4);
+    }
 
     issue(0);
+    if (n_kt > 1) issue(1);
+    if (n_kt > 2) issue(2);
     for (int kt = 0; kt < n_kt; ++kt) {
-        if (kt + 1 < n_kt) {
-            issue(kt + 1);
-            if (NL == 8) WAIT_VM_BARRIER(8); else WAIT_VM_BARRIER(6);
+        if (kt + 2 < n_kt) {
+            if (NL == 4) WAIT_VM_BARRIER(8); else WAIT_VM_BARRIER(6);
+        } else if (kt + 1 < n_kt) {
+            if (NL == 4) WAIT_VM_BARRIER(4); else WAIT_VM_BARRIER(3);
         } else {
             WAIT_VM_BARRIER(0);
         }
-        const unsigned char* As = smem + (kt & 1) * STAGE;
-        const unsigned char* Bs = As + A_BYTES;
-        const int n_ks = (kt + 1 < n_kt) ? 4 : (ks_last < 4 ? ks_last : 4);
-        for (int ks = 0; ks < n_ks; ++ks) {
-            const int c = ks * 2 + lh;
+        if (kt + 3 < n_kt) issue(kt + 3);        // refills the stage every wave finished reading before this barrier
+        const unsigned char* st = smem + (kt & (NT_STAGES - 1)) * STAGE;
+        if (ABL == 2) continue;                    // ablation: DMA only
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
             bfv8 a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = wm0 + i * 32 + lr;
-                a[i] = *reinterpret_cast<const bfv8*>(As + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-            }
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bfv8*>(st + (aoff[i] ^ (ks << 5)));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = wn0 + j * 32 + lr;
-                b[j] = *reinterpret_cast<const bfv8*>(Bs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-            }
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bfv8*>(st + (boff[j] ^ (ks << 5)));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    if (EPI == EPI_SIGMOID_GRAD) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                }
         }
-        WAIT_LGKM_BARRIER();     // every wave has its fragments in registers: the stage may be refilled
     }
 
-    // Epilogue: per pass one 32 x 64 fp32 sub-tile of this wave goes through a private LDS slab so that the global
-    // stores are whole 16-byte (bf16) or 32-byte (fp32) row pieces, 8 lanes per 128-byte row.
-    float* stg = reinterpret_cast<float*>(smem) + wave * 32 * STG_LD;
+    if (EPI == EPI_SIGMOID_GRAD) {
+        // Memory-bound variant (dX = (dY W) * H (1 - H), K small): plain C layout, fp32 sub-tiles staged through LDS so that
+        // H is read and dX written as whole 16-byte row pieces (8 lanes per 128-byte row segment).
+        constexpr int STG_LD = 68;
+        WAIT_LGKM_BARRIER();                                   // all waves are done with the tile stages
+        float* stg = reinterpret_cast<float*>(smem) + wave * 32 * STG_LD;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * STG_LD + j * 32 + lr] = acc[i][j][r];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int rl = it * 8 + (lane >> 3);
+                const int cl = (lane & 7) * 8;
+                const int64_t row = m0 + wm0 + i * 32 + rl;
+                const int col = n0 + wn0 + cl;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(&stg[rl * STG_LD + cl]);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(&stg[rl * STG_LD + cl + 4]);
+                if (row >= M) continue;
+                const bfv8 hv = *reinterpret_cast<const bfv8*>(H + (size_t)row * ldh + col);
+                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float h = (float)hv[e];
+                    v[e] = v[e] * h * (1.f - h);
+                }
+                if (c_f32) {
+                    float* crow = reinterpret_cast<float*>(Cv) + (size_t)row * ldc + col;
+                    *reinterpret_cast<f32x4*>(crow) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(crow + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                } else {
+                    bfv8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+                    *reinterpret_cast<bfv8*>(reinterpret_cast<uint16_t*>(Cv) + (size_t)row * ldc + col) = o;
+                }
+            }
+        }
+        return;
+    }
+
+    // Epilogue in registers.  Sub-tile (i, j): this lane's frame row m = m0 + wm0 + 32 i + (lane & 31); register 4g + e
+    // is column n0 + wn0 + 32 j + 8 g + 4 (lane >> 5) + e.
+    float bv[TN][16];
+    if (EPI != EPI_SIGMOID_GRAD) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * STG_LD + j * 32 + lr] = acc[i][j][r];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int rl = it * 8 + (lane >> 3);
-            const int cl = (lane & 7) * 8;
-            const int64_t row = m0 + wm0 + i * 32 + rl;
-            const int col = n0 + wn0 + cl;
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(&stg[rl * STG_LD + cl]);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(&stg[rl * STG_LD + cl + 4]);
-            if (row >= M || col >= ldc) continue;
-            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            bfv8 hv;
-            if (EPI == EPI_SIGMOID_GRAD) hv = *reinterpret_cast<const bfv8*>(H + (size_t)row * ldh + col);
+                for (int e = 0; e < 4; ++e) bv[j][4 * g + e] = bias ? bias[n0 + wn0 + j * 32 + 8 * g + 4 * lh + e] : 0.f;
+    }
+    const float kNegLog2e = -1.4426950408889634f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float x = v[e];
-                if (col + e >= N) x = 0.f;
-                else if (EPI == EPI_BIAS) x += bias ? bias[col + e] : 0.f;
-                else if (EPI == EPI_BIAS_SIGMOID) x = fast_sigmoid(x + (bias ? bias[col + e] : 0.f));
-                else {
-                    const float h = (float)hv[e];
-                    x = x * h * (1.f - h);
+    for (int i = 0; i < TM; ++i) {
+        const int64_t m = m0 + wm0 + i * 32 + lr;
+        const bool live = m < M;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cbase = n0 + wn0 + j * 32 + 4 * lh;          // column of register group 0
+            float v[16];
+            if (EPI == EPI_SIGMOID_GRAD) {
+                bfv4 hv[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    hv[g] = live ? *reinterpret_cast<const bfv4*>(H + (size_t)m * ldh + cbase + 8 * g) : bfv4{0, 0, 0, 0};
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float h = (float)hv[g][e];
+                        v[4 * g + e] = acc[i][j][4 * g + e] * h * (1.f - h);
+                    }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float x = acc[i][j][r] + bv[j][r];
+                    if (EPI == EPI_BIAS_SIGMOID) x = __frcp_rn(1.f + exp2f(x * kNegLog2e));
+                    v[r] = x;
                 }
-                v[e] = x;
             }
             if (c_f32) {
-                float* crow = reinterpret_cast<float*>(Cv) + (size_t)row * ldc + col;
-                *reinterpret_cast<f32x4*>(crow) = f32x4{v[0], v[1], v[2], v[3]};
-                *reinterpret_cast<f32x4*>(crow + 4) = f32x4{v[4], v[5], v[6], v[7]};
-            } else {
-                bfv8 o;
+                if (live) {
+                    float* crow = reinterpret_cast<float*>(Cv) + (size_t)m * ldc + cbase;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
-                *reinterpret_cast<bfv8*>(reinterpret_cast<uint16_t*>(Cv) + (size_t)row * ldc + col) = o;
+                    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(crow + 8 * g) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+                }
+            } else {
+                // pack 4 columns -> 2 dwords per group; pair groups (g, g+1) through v_permlane32_swap so that lanes
+                // 0-31 own columns 8g..8g+7 and lanes 32-63 own 8g+8..8g+15 of their row: one 16-byte store each.
+                unsigned int pk[4][2];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    typedef __bf16 bfv2 __attribute__((ext_vector_type(2)));
+                    const bfv2 lo = bfv2{(__bf16)v[4 * g], (__bf16)v[4 * g + 1]};
+                    const bfv2 hi = bfv2{(__bf16)v[4 * g + 2], (__bf16)v[4 * g + 3]};
+                    pk[g][0] = __builtin_bit_cast(unsigned int, lo);
+                    pk[g][1] = __builtin_bit_cast(unsigned int, hi);
+                }
+                uint16_t* crow = reinterpret_cast<uint16_t*>(Cv) + (size_t)m * ldc + (n0 + wn0 + j * 32);
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+                    if (live) {
+                        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+                        *reinterpret_cast<u32x4_t*>(crow + 8 * g + 8 * lh) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
+                    }
+                }
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// wgrad_big: output tile 128 (n) x BKT (k), BKT = 64 * TKW (TKW = 10 -> 640, 8 -> 512); contraction over m in steps of 32.
+// wgrad_big: output tile 128 (n) x BKT (k), BKT = 64 * TKW (TKW = 10 -> 640, 8 -> 512); contraction over m in steps of 32,
+// THREE LDS stages (two steps of LDS-DMA in flight, one barrier per step).
 // LDS tiles are straight row copies ([m][n], [m][k]); fragments come from ds_read_b64_tr_b16.  16-byte chunk c of
 // tile row r sits at chunk position c ^ ((r & 3) << 2), i.e. the 64-byte blocks of a row are XORed with r & 3, so the 4
 // rows x 64 bytes a half wave touches in one transposed read fall on all 64 banks.
 // Row indices of the workgroup's whole m range are parked in LDS first, so the loop issues no VGPR-destination loads.
 // ---------------------------------------------------------------------------------------------------------------------
-#define WG_ROWS_MAX 8192
+#define WG_ROWS_MAX 4096
+#define WG_STAGES 3
 
-template <int TKW>
+template <int TKW, int ABL = 0>
 __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restrict__ dY, int lddy, const uint16_t* __restrict__ A, int lda,
                                                         const int32_t* __restrict__ rows, int64_t M, int N, int K, int m_chunk,
                                                         float* __restrict__ slab, float* __restrict__ bslab) {
@@ -218,10 +319,10 @@ __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restri
     constexpr int STAGE = Y_BYTES + X_BYTES;
     constexpr int NX = X_BYTES / 1024 / 8;        // X LDS-DMA instructions per wave per step: 5 or 4
     constexpr int NLW = 1 + NX;                   // + one for dY
-    constexpr int LDS_BYTES = 2 * STAGE + WG_ROWS_MAX * 4;
+    constexpr int LDS_BYTES = WG_STAGES * STAGE + WG_ROWS_MAX * 4;
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
-    int* row_lds = reinterpret_cast<int*>(smem + 2 * STAGE);
+    int* row_lds = reinterpret_cast<int*>(smem + WG_STAGES * STAGE);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -255,16 +356,19 @@ __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restri
     }
 
     auto issue = [&](int step) {                 // rows [32 step, 32 step + 32) of this workgroup's range
-        unsigned char* st = smem + (step & 1) * STAGE;
+        unsigned char* st = smem + (step % WG_STAGES) * STAGE;
+        if (ABL == 1 && step > 0) return;
         {
             const int ml = step * 32 + y_row;
             const uint16_t* p = (ml < n_rows) ? dY + (size_t)(m_lo + ml) * lddy + n0 + y_c * 8 : g_zero_row;
             glds16(p, st + wave * 1024);
         }
+        int rr[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) rr[i] = row_lds[step * 32 + x_row[i]];     // all index reads first: one lgkmcnt wait
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const int r = row_lds[step * 32 + x_row[i]];
-            const uint16_t* p = (r >= 0) ? A + (size_t)r * lda + x_off[i] : g_zero_row;
+            const uint16_t* p = (rr[i] >= 0) ? A + (size_t)rr[i] * lda + x_off[i] : g_zero_row;
             glds16(p, st + Y_BYTES + (wave * NX + i) * 1024);
         }
     };
@@ -276,6 +380,21 @@ __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restri
         for (int j = 0; j < TKT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // Bias gradient db[n] = sum_m dY[m][n] rides on the matrix pipe: dY^T times a block of ones.  With K <= BKT - 32 the
+    // last 32-column tile of the k-wave 3 is pure padding, so its B fragment is replaced by ones (no extra MFMA, no
+    // extra registers); otherwise k-wave 0 carries two extra accumulators (TKW == 8 has the registers for it).
+    constexpr bool kExtraBias = (TKW == 8);
+    const bool free_tile = !kExtraBias && K <= BKT - 32;
+    const bool bias_free = bslab != nullptr && free_tile && (wave & 3) == 3;
+    const bool bias_extra = bslab != nullptr && kExtraBias && (wave & 3) == 0;
+    const bool bias_valu = bslab != nullptr && !kExtraBias && !free_tile;
+    f32x16 accb[kExtraBias ? 2 : 1];
+#pragma unroll
+    for (int i = 0; i < (kExtraBias ? 2 : 1); ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+    const __bf16 one_bf = (__bf16)1.0f;
+    const bfv8 ones = bfv8{one_bf, one_bf, one_bf, one_bf, one_bf, one_bf, one_bf, one_bf};
     float bsum = 0.f;
 
     const int n_steps = (n_rows + 31) / 32;
@@ -284,51 +403,65 @@ __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restri
     const int q = li >> 2, p4 = li & 3;
     const int cgrp = 16 * (g & 1) + 4 * p4;       // column offset inside a 32-wide operand tile
     const int rbase = 8 * (g >> 1) + q;           // contraction row inside a 16-deep k-step
+    // byte offsets of this lane's transposed reads for k-step 0 (k-step 1 = + 16 rows); row & 3 == q for both
+    const int sw = q << 2;
+    int yoff[2], xoff[TKT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int col = wn0 + i * 32 + cgrp;
+        yoff[i] = rbase * PY + ((((col >> 3) ^ sw) << 4) | ((col & 7) << 1));
+    }
+#pragma unroll
+    for (int j = 0; j < TKT; ++j) {
+        const int col = wk0 + j * 32 + cgrp;
+        xoff[j] = Y_BYTES + rbase * PX + ((((col >> 3) ^ sw) << 4) | ((col & 7) << 1));
+    }
 
     if (n_steps > 0) issue(0);
+    if (n_steps > 1) issue(1);
     for (int step = 0; step < n_steps; ++step) {
         if (step + 1 < n_steps) {
-            issue(step + 1);
             if (NLW == 6) WAIT_VM_BARRIER(6); else WAIT_VM_BARRIER(5);
         } else {
             WAIT_VM_BARRIER(0);
         }
-        const unsigned char* Ys = smem + (step & 1) * STAGE;
-        const unsigned char* Xs = Ys + Y_BYTES;
+        if (step + 2 < n_steps) issue(step + 2);  // refills the stage every wave finished reading before this barrier
+        const unsigned char* st = smem + (step % WG_STAGES) * STAGE;
+        if (ABL == 2) continue;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int mrow = ks * 16 + rbase;
-            const int sw = (mrow & 3) << 2;
             bfv8 a[2], b[TKT];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int col = wn0 + i * 32 + cgrp;
-                const unsigned char* ad = Ys + mrow * PY + ((((col >> 3) ^ sw) << 4) | ((col & 7) << 1));
+                const unsigned char* ad = st + yoff[i] + ks * 16 * PY;
                 const bfv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(ad));
                 const bfv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(ad + 4 * PY));
                 a[i] = bfv8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
 #pragma unroll
             for (int j = 0; j < TKT; ++j) {
-                const int col = wk0 + j * 32 + cgrp;
-                const unsigned char* ad = Xs + mrow * PX + ((((col >> 3) ^ sw) << 4) | ((col & 7) << 1));
+                const unsigned char* ad = st + xoff[j] + ks * 16 * PX;
                 const bfv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(ad));
                 const bfv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(ad + 4 * PX));
                 b[j] = bfv8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
+            if (bias_free) b[TKT - 1] = ones;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < TKT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            if (kExtraBias && bias_extra) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], ones, accb[i], 0, 0, 0);
+            }
         }
-        if (bslab != nullptr && tid < BNT) {
+        if (bias_valu && tid < BNT) {
 #pragma unroll 8
             for (int r = 0; r < 32; ++r) {
                 const int cpos = (tid >> 3) ^ ((r & 3) << 2);
-                bsum += mg_bf2f(*reinterpret_cast<const uint16_t*>(Ys + r * PY + (cpos << 4) + ((tid & 7) << 1)));
+                bsum += mg_bf2f(*reinterpret_cast<const uint16_t*>(st + r * PY + (cpos << 4) + ((tid & 7) << 1)));
             }
         }
-        WAIT_LGKM_BARRIER();
     }
 
     const int lr = lane & 31, lh = lane >> 5;
@@ -346,13 +479,27 @@ __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restri
             }
         }
     }
-    if (bslab != nullptr && tid < BNT && n0 + tid < N) bslab[(size_t)s * N + n0 + tid] = bsum;
+    if (bias_valu && tid < BNT && n0 + tid < N) bslab[(size_t)s * N + n0 + tid] = bsum;
+    if ((bias_free || bias_extra) && lr == 0) {            // every column of the ones-product holds the same sums
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n0 + wn0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float v = bias_free ? acc[i][TKT - 1][r] : accb[kExtraBias ? i : 0][r];
+                if (row < N) bslab[(size_t)s * N + row] = v;
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Launch helpers used by the entry points in gemm_bf16.hip.  Each returns 1 if it launched, 0 if the shape does not
 // qualify (the caller then uses the generic 128 x 128 kernels), negative on error.
 // ---------------------------------------------------------------------------------------------------------------------
+static int g_ablation = 0;   // debug / profiling only: 1 = no DMA after the first tile, 2 = DMA only (results invalid)
+extern "C" void mg_debug_set_ablation(int v) { g_ablation = v; }
+
 static bool big16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 
 int mg_try_nt_big(const uint16_t* A, int lda, const int32_t* rows, int64_t M, int K, const uint16_t* Bm, int ldb, int N,
@@ -360,14 +507,20 @@ int mg_try_nt_big(const uint16_t* A, int lda, const int32_t* rows, int64_t M, in
     if (M < 2048 || lda % 64 != 0 || ldb % 64 != 0 || lda > MG_ZERO_ELEMS - 64 || ldb > MG_ZERO_ELEMS - 64) return 0;
     if (N % 128 != 0 || ldc < N || ldc % 8 != 0 || !big16(A) || !big16(Bm) || !big16(C)) return 0;
     if (epi == EPI_SIGMOID_GRAD && (!H || ldh % 8 != 0 || ldh < N)) return 0;
+    if (ldc != N || lda < (K + 63) / 64 * 64 || ldb < (K + 63) / 64 * 64) return 0;
     const bool wide = (N % 256 == 0);
     const int bn = wide ? 256 : 128;
     const int tiles_n = N / bn;
-    const int64_t blocks = mg_ceil_div(M, 256) * tiles_n;
-    if (blocks >= 2147483647LL) return 0;
+    const int64_t tiles_m = mg_ceil_div(M, 256);
+    const int64_t blocks = mg_ceil_div(tiles_m, 8) * 8 * tiles_n;
+    if (blocks >= 2147483647LL || tiles_m >= 2147483647LL) return 0;
     dim3 grid((unsigned)blocks), block(512);
-#define LAUNCH_NT(BN_, EPI_) hipLaunchKernelGGL((gemm_nt_big_kernel<BN_, EPI_>), grid, block, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, H, ldh, C, ldc, tiles_n, c_f32)
-    if (wide) {
+#define LAUNCH_NT(BN_, EPI_) hipLaunchKernelGGL((gemm_nt_big_kernel<BN_, EPI_>), grid, block, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, H, ldh, C, ldc, (int)tiles_m, tiles_n, c_f32)
+    if (wide && epi == EPI_BIAS_SIGMOID && g_ablation == 1) {
+        hipLaunchKernelGGL((gemm_nt_big_kernel<256, EPI_BIAS_SIGMOID, 1>), grid, block, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, H, ldh, C, ldc, (int)tiles_m, tiles_n, c_f32);
+    } else if (wide && epi == EPI_BIAS_SIGMOID && g_ablation == 2) {
+        hipLaunchKernelGGL((gemm_nt_big_kernel<256, EPI_BIAS_SIGMOID, 2>), grid, block, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, H, ldh, C, ldc, (int)tiles_m, tiles_n, c_f32);
+    } else if (wide) {
         if (epi == EPI_BIAS) LAUNCH_NT(256, EPI_BIAS);
         else if (epi == EPI_BIAS_SIGMOID) LAUNCH_NT(256, EPI_BIAS_SIGMOID);
         else LAUNCH_NT(256, EPI_SIGMOID_GRAD);
@@ -387,7 +540,7 @@ int mg_wgrad_big_plan(int64_t M, int N, int K, int lda, int lddy, int* S_out, in
     const int tiles_n = N / 128;
     int64_t S = mg_ceil_div(256, tiles_n);
     int64_t m_chunk = mg_align_up((size_t)mg_ceil_div(M, S), 32);
-    while (m_chunk > WG_ROWS_MAX) {
+    while (m_chunk > WG_ROWS_MAX) {  // row indices of a workgroup's range live in LDS
         S *= 2;
         m_chunk = mg_align_up((size_t)mg_ceil_div(M, S), 32);
     }
@@ -401,7 +554,11 @@ int mg_wgrad_big_plan(int64_t M, int N, int K, int lda, int lddy, int* S_out, in
 int mg_launch_wgrad_big(const uint16_t* dY, int lddy, const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K,
                         int S, int m_chunk, float* slab, float* bslab, hipStream_t st) {
     dim3 grid((unsigned)(N / 128), (unsigned)S), block(512);
-    if (lda == 640)
+    if (lda == 640 && g_ablation == 1)
+        hipLaunchKernelGGL((wgrad_big_kernel<10, 1>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab);
+    else if (lda == 640 && g_ablation == 2)
+        hipLaunchKernelGGL((wgrad_big_kernel<10, 2>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab);
+    else if (lda == 640)
         hipLaunchKernelGGL((wgrad_big_kernel<10>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab);
     else
         hipLaunchKernelGGL((wgrad_big_kernel<8>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab);

@@ -437,7 +437,7 @@ size_t mg_linear_wgrad_workspace_bytes(int64_t M, int N, int K) {
     if (N % 128 == 0) {   // the wide bf16 kernel (gemm_bf16_big.hip) may split further: size for the larger plan
         int64_t sb = mg_ceil_div(256, N / 128);
         int64_t chunk = mg_align_up((size_t)mg_ceil_div(M, sb), 32);
-        while (chunk > 8192) {
+        while (chunk > 4096) {
             sb *= 2;
             chunk = mg_align_up((size_t)mg_ceil_div(M, sb), 32);
         }

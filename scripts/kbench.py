@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the individual GEMM kernels at the C2 shapes (HIP-event timing on the launch stream).
+Usage: python scripts/kbench.py [iters] [which,comma,separated]   (which: fwd1,fwd2,dgrad2,wgrad1,wgrad2)"""
+import os
+import sys
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from morgana_amd import ops, synthetic, data  # noqa: E402
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    which = sys.argv[2].split(',') if len(sys.argv) > 2 else ['fwd1', 'fwd2', 'dgrad2', 'wgrad1', 'wgrad2']
+    dev = 'cuda:0'
+    feats = data.to_device(synthetic.make_batch(256, 1000), dev)
+    lab = feats['normalised_lab']
+    b, p, k = lab.shape
+    t = 1000
+    m = b * t
+    _, rows = ops.upsample_index(feats['dur'].reshape(b, -1).contiguous(), t)
+    rows = rows.view(-1)
+    st = synthetic.f0_model_state()
+    w1 = torch.from_numpy(st['layers.0.weight']).to(dev)
+    b1 = torch.from_numpy(st['layers.0.bias']).to(dev)
+    w2 = torch.from_numpy(st['layers.2.weight']).to(dev)
+    b2 = torch.from_numpy(st['layers.2.bias']).to(dev)
+    tab = ops.cast_pad_bf16(lab.view(b * p, k))
+    w1b, w2b = ops.cast_pad_bf16(w1), ops.cast_pad_bf16(w2)
+    w2t = ops.cast_transpose_bf16(w2)
+    h1 = ops.linear_fwd_bf16(tab, rows, m, k, w1b, b1, 512, ops.ACT_SIGMOID)
+    dz1 = (torch.randn(m, 512, device=dev) * 0.01).to(torch.bfloat16)
+    dz2 = (torch.randn(m, 128, device=dev) * 0.01).to(torch.bfloat16)
+    cases = {
+        'fwd1': (2.0 * m * 600 * 512, lambda: ops.linear_fwd_bf16(tab, rows, m, k, w1b, b1, 512, ops.ACT_SIGMOID)),
+        'fwd2': (2.0 * m * 512 * 128, lambda: ops.linear_fwd_bf16(h1, None, m, 512, w2b, b2, 128, ops.ACT_SIGMOID)),
+        'dgrad2': (2.0 * m * 512 * 128, lambda: ops.linear_dgrad_bf16(dz2, m, 128, w2t, 512, h1)),
+        'wgrad1': (2.0 * m * 600 * 512, lambda: ops.linear_wgrad_bf16(dz1, tab, rows, m, 512, 600)),
+        'wgrad2': (2.0 * m * 512 * 128, lambda: ops.linear_wgrad_bf16(dz2, h1, None, m, 128, 512)),
+    }
+    import ctypes
+    from morgana_amd import _lib
+    lib = _lib.load()
+    abl = int(os.environ.get('MG_ABLATION', '0'))
+    lib.mg_debug_set_ablation(ctypes.c_int(abl))
+    print('ablation', abl)
+    for name in which:
+        flops, fn = cases[name]
+        for _ in range(2):
+            fn()
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        for _ in range(iters):
+            fn()
+        end.record()
+        end.synchronize()
+        ms = start.elapsed_time(end) / iters
+        print('%-8s %8.1f us  %8.1f TFLOP/s' % (name, ms * 1e3, flops / ms / 1e9))
+
+
+if __name__ == '__main__':
+    main()
