@@ -441,7 +441,7 @@ size_t mg_linear_wgrad_workspace_bytes(int64_t M, int N, int K) {
             sb *= 2;
             chunk = mg_align_up((size_t)mg_ceil_div(M, sb), 32);
         }
-        sb = mg_ceil_div(M, chunk);
+        sb = mg_align_up((size_t)mg_ceil_div(M, chunk), 8);
         if (sb > S) S = sb;
     }
     return mg_align_up((size_t)S * ((size_t)N * K + (size_t)N) * sizeof(float), 256);

@@ -45,7 +45,9 @@ def main():
     lib = _lib.load()
     abl = int(os.environ.get('MG_ABLATION', '0'))
     lib.mg_debug_set_ablation(ctypes.c_int(abl))
-    print('ablation', abl)
+    var = int(os.environ.get('MG_VARIANT', '0'))
+    lib.mg_debug_set_variant(ctypes.c_int(var))
+    print('ablation', abl, 'variant', var)
     for name in which:
         flops, fn = cases[name]
         for _ in range(2):
