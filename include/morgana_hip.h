@@ -127,11 +127,36 @@ int mg_linear_wgrad_bf16(const uint16_t* dY, int lddy, const uint16_t* A, int ld
 int mg_cast_pad_bf16(const float* src, int lds, uint16_t* dst, int ldd, int64_t rows, int cols, void* stream);
 /* dst[c, 0:rows] = bf16(src[r, c]) transposed, dst [cols, ldd], zero padded. */
 int mg_cast_transpose_bf16(const float* src, int lds, uint16_t* dst, int ldd, int rows, int cols, void* stream);
+/* Batched weight refresh (one launch for a whole layer stack): for each descriptor, dst = bf16(src) [rows, ldd] and / or
+ * dst_t = bf16(src^T) [cols, ldt], zero padded; either output may be NULL.  `descs` is a HOST array, count <= MG_CAST_MAX. */
+#define MG_CAST_MAX 16
+typedef struct {
+    const float* src; /* device, fp32 [rows, cols], contiguous */
+    int rows, cols;
+    uint16_t* dst;    /* device bf16 [rows, ldd] or NULL */
+    int ldd;
+    uint16_t* dst_t;  /* device bf16 [cols, ldt] or NULL */
+    int ldt;
+} mg_cast_desc;
+int mg_cast_params_bf16(const mg_cast_desc* descs, int count, void* stream);
 /* dst f32 [rows, cols] = src bf16 [rows, cols] (lds). */
 int mg_cast_bf16_f32(const uint16_t* src, int lds, float* dst, int ldd, int64_t rows, int cols, void* stream);
 /* elementwise sigmoid forward / backward for a stand-alone nn.Sigmoid. */
 int mg_sigmoid_f32(const float* x, float* y, int64_t n, void* stream);
 int mg_sigmoid_grad_f32(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+
+/* Fused tail of a Linear/Sigmoid stack ending in ... -> 128 -> 32 -> 1 under the masked MSE (the README F0Model's layers 3-4,
+ * README.rst:65-73, with morgana/losses.py:29-51), bf16 mode: forward of both layers, the loss, and the whole backward
+ * through both, in one pass over H2.
+ *   H2 bf16 [B*T, ldh] (the 128 sigmoid outputs of the previous layer); W3 f32 [32,128], b3 [32], W4 f32 [1,32], b4 [1];
+ *   target f32 [B*T] (D = 1); seq_len int64 [B] or NULL; grad_scale multiplies dL/dpred.
+ * Outputs: pred f32 [B*T]; loss f32 [1]; dZ2 bf16 [B*T, ldh] = dL/d(pre-activation of the 128-wide layer);
+ *   grads f32 [32*128 + 32 + 32 + 1] = dW3 | db3 | dW4 | db4 (accumulate != 0 adds into it).
+ * workspace: mg_f0_tail_workspace_bytes(B*T).  Deterministic. */
+size_t mg_f0_tail_workspace_bytes(int64_t M);
+int mg_f0_tail_bf16(const uint16_t* H2, int ldh, int K3, const float* W3, const float* b3, const float* W4, const float* b4,
+                    const float* target, const int64_t* seq_len, int B, int T, float grad_scale, float* pred, float* loss,
+                    uint16_t* dZ2, float* grads, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * K3  GRU through RecurrentCuDNNWrapper   reference: morgana/utils.py:345-393 + torch.nn.GRU (gates r, z, n)

@@ -42,9 +42,14 @@ SIGNATURES = {
                                      c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'mg_cast_pad_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
     'mg_cast_transpose_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'mg_cast_params_bf16': (c_int, [c_void_p, c_int, c_void_p]),
     'mg_cast_bf16_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
     'mg_sigmoid_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     'mg_sigmoid_grad_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    'mg_f0_tail_workspace_bytes': (c_size_t, [c_int64]),
+    'mg_f0_tail_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
+                                c_void_p]),
     'mg_gru_fwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p]),
     'mg_gru_bwd_workspace_bytes': (c_size_t, [c_int, c_int]),
@@ -55,6 +60,15 @@ SIGNATURES = {
     'mg_ema_update_f32': (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
 }
 
+
+
+class CastDesc(ctypes.Structure):
+    """mg_cast_desc of include/morgana_hip.h."""
+    _fields_ = [('src', c_void_p), ('rows', c_int), ('cols', c_int), ('dst', c_void_p), ('ldd', c_int),
+                ('dst_t', c_void_p), ('ldt', c_int)]
+
+
+CAST_MAX = 16
 _lib = None
 
 

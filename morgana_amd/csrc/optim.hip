@@ -80,6 +80,42 @@ __global__ __launch_bounds__(256) void sigmoid_grad_kernel(const float* __restri
     }
 }
 
+// All weight matrices of a layer stack in ONE launch: descriptor d gives an fp32 [rows, cols] matrix and asks for its
+// bf16 copy [rows, ldd] (zero padded) and / or its bf16 transpose [cols, ldt] (zero padded).  blockIdx.y = descriptor.
+struct CastBatch {
+    int count;
+    mg_cast_desc d[MG_CAST_MAX];
+};
+
+__global__ __launch_bounds__(256) void cast_params_kernel(CastBatch batch) {
+    __shared__ float tile[32][33];
+    const mg_cast_desc d = batch.d[blockIdx.y];
+    if (d.dst) {
+        const int64_t n = (int64_t)d.rows * d.ldd;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+            const int r = (int)(i / d.ldd), c = (int)(i - (int64_t)r * d.ldd);
+            d.dst[i] = c < d.cols ? mg_f2bf(d.src[(size_t)r * d.cols + c]) : (uint16_t)0;
+        }
+    }
+    if (d.dst_t) {
+        const int tiles_c = (d.cols + 31) / 32, tiles_r = (d.ldt + 31) / 32;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        for (int t = blockIdx.x; t < tiles_c * tiles_r; t += gridDim.x) {
+            const int c0 = (t % tiles_c) * 32, r0 = (t / tiles_c) * 32;
+            __syncthreads();
+            for (int j = ty; j < 32; j += 8) {
+                const int r = r0 + j, c = c0 + tx;
+                tile[j][tx] = (r < d.rows && c < d.cols) ? d.src[(size_t)r * d.cols + c] : 0.f;
+            }
+            __syncthreads();
+            for (int j = ty; j < 32; j += 8) {
+                const int c = c0 + j, r = r0 + tx;
+                if (c < d.cols && r < d.ldt) d.dst_t[(size_t)c * d.ldt + r] = r < d.rows ? mg_f2bf(tile[tx][j]) : (uint16_t)0;
+            }
+        }
+    }
+}
+
 static int flat_grid(int64_t n) {
     int64_t blocks = mg_ceil_div(n, 256 * 4);
     if (blocks > 4096) blocks = 4096;
@@ -127,6 +163,22 @@ int mg_cast_transpose_bf16(const float* src, int lds, uint16_t* dst, int ldd, in
     dim3 grid((unsigned)mg_ceil_div(cols, 32), (unsigned)mg_ceil_div(ldd, 32));
     hipLaunchKernelGGL(cast_transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, lds, dst, ldd, rows, cols);
     MG_CHECK_LAUNCH("mg_cast_transpose_bf16");
+    return MG_OK;
+}
+
+int mg_cast_params_bf16(const mg_cast_desc* descs, int count, void* stream) {
+    MG_CHECK_ARG(descs && count > 0 && count <= MG_CAST_MAX, "mg_cast_params_bf16: count %d not in 1..%d", count, MG_CAST_MAX);
+    CastBatch batch;
+    batch.count = count;
+    for (int i = 0; i < count; ++i) {
+        const mg_cast_desc& d = descs[i];
+        MG_CHECK_ARG(d.src && d.rows > 0 && d.cols > 0 && (d.dst || d.dst_t), "mg_cast_params_bf16: bad descriptor %d", i);
+        MG_CHECK_ARG(!d.dst || d.ldd >= d.cols, "mg_cast_params_bf16: descriptor %d: ldd %d < cols %d", i, d.ldd, d.cols);
+        MG_CHECK_ARG(!d.dst_t || d.ldt >= d.rows, "mg_cast_params_bf16: descriptor %d: ldt %d < rows %d", i, d.ldt, d.rows);
+        batch.d[i] = d;
+    }
+    hipLaunchKernelGGL(cast_params_kernel, dim3(64, count), dim3(256), 0, (hipStream_t)stream, batch);
+    MG_CHECK_LAUNCH("mg_cast_params_bf16");
     return MG_OK;
 }
 

@@ -141,6 +141,108 @@ class LinearStackFn(torch.autograd.Function):
         return (None, grad_x, None) + tuple(grads)
 
 
+def _deliver_param_grads(params, flat, offsets, grad_loss=None):
+    """Hand the parameter gradients held in one contiguous buffer `flat` (parameter order) to autograd.
+
+    Fast path: the parameters belong to morgana_amd.optim.Adam (flag `_mg_direct_grad`) and their .grad tensors are
+    consecutive views of ITS flat gradient buffer in the same order - then one fused add (times grad_loss) into that
+    buffer replaces one autograd accumulation kernel per parameter, and None is returned for every parameter.
+    Otherwise ordinary per-parameter gradient tensors are returned.
+    """
+    live = [p for p in params if p is not None]
+    direct = all(getattr(p, '_mg_direct_grad', False) and p.grad is not None and p.grad.is_contiguous() for p in live)
+    if direct:
+        base = live[0].grad.data_ptr()
+        for p, off in zip(live, offsets):
+            if p.grad.data_ptr() != base + 4 * off or p.grad.dtype != torch.float32:
+                direct = False
+                break
+    if direct:
+        seg = live[0].grad.reshape(-1).as_strided((flat.numel(),), (1,))
+        if grad_loss is None:
+            seg.add_(flat)
+        else:
+            seg.addcmul_(flat, grad_loss)
+        return [None] * len(params)
+    out, j = [], 0
+    for p in params:
+        if p is None:
+            out.append(None)
+            continue
+        g = flat[offsets[j]:offsets[j] + p.numel()].view(p.shape)
+        out.append(g if grad_loss is None else g * grad_loss)
+        j += 1
+    return out
+
+
+class LinearStackMSEFn(torch.autograd.Function):
+    """bf16 Linear/Sigmoid stack ending in ... -> 128 -> 32 -> 1 TOGETHER with the masked MSE (losses.py:29-51).
+
+    forward(ctx, acts, x2d, rows, target (B,T,1), seq_len, *params) -> (loss, pred (B,T,1)).
+    Layers up to the 128-wide one run as in LinearStackFn; the last two layers, the loss and their whole backward are ONE
+    kernel (mg_f0_tail_bf16) that leaves dL/d(pre-activation of the 128-wide layer) for the remaining backward.
+    `pred` is returned for reporting only (non-differentiable): the loss is the one consumer of the prediction.
+    """
+
+    @staticmethod
+    def forward(ctx, acts, x2d, rows, target, seq_len, *params):
+        n_layers = len(acts)
+        weights = [params[2 * i] for i in range(n_layers)]
+        biases = [params[2 * i + 1] for i in range(n_layers)]
+        x2d = ops._require(x2d, torch.float32, 'input')
+        target = ops._require(target, torch.float32, 'targets')
+        b, t = target.shape[0], target.shape[1]
+        m = b * t
+        if (rows.numel() if rows is not None else x2d.shape[0]) != m:
+            raise ValueError('prediction rows (%d) and target rows (%d) differ' % (
+                rows.numel() if rows is not None else x2d.shape[0], m))
+        lead = n_layers - 2
+        w_bf, w_t = ops.cast_params_bf16(weights[:lead], want_t=tuple(range(1, lead)))
+        a = ops.cast_pad_bf16(x2d)
+        a0, r = a, rows
+        hidden = []
+        for i in range(lead):
+            n, k = weights[i].shape
+            a = ops.linear_fwd_bf16(a, r, m, k, w_bf[i], biases[i], n, acts[i])
+            r = None
+            hidden.append(a)
+        sizes = [p.numel() for p in params]
+        offsets = [0]
+        for sz in sizes[:-1]:
+            offsets.append(offsets[-1] + sz)
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=x2d.device)
+        tail_off = offsets[2 * lead]
+        pred, loss, dz2 = ops.f0_tail(hidden[-1], weights[lead], biases[lead], weights[lead + 1], biases[lead + 1],
+                                      target.reshape(-1), seq_len, b, t, flat[tail_off:])
+        ctx.acts, ctx.m, ctx.lead = acts, m, lead
+        ctx.dims = [(w.shape[0], w.shape[1]) for w in weights]
+        ctx.offsets = offsets
+        ctx.params = list(params)
+        ctx.save_for_backward(a0, rows, dz2, flat, *hidden[:-1], *[wt for wt in w_t if wt is not None])
+        pred = pred.view(b, t, 1)
+        ctx.mark_non_differentiable(pred)
+        return loss, pred
+
+    @staticmethod
+    def backward(ctx, grad_loss, grad_pred):
+        saved = ctx.saved_tensors
+        a0, rows, g, flat = saved[0], saved[1], saved[2], saved[3]
+        lead, m = ctx.lead, ctx.m
+        hidden = list(saved[4:4 + lead - 1])                  # outputs of layers 0 .. lead-2
+        w_t = [None] + list(saved[4 + lead - 1:])             # transposed bf16 weights of layers 1 .. lead-1
+        for i in range(lead - 1, -1, -1):
+            n, k = ctx.dims[i]
+            a_in, r = (a0, rows) if i == 0 else (hidden[i - 1], None)
+            ow = flat[ctx.offsets[2 * i]:ctx.offsets[2 * i] + n * k].view(n, k)
+            ob = flat[ctx.offsets[2 * i + 1]:ctx.offsets[2 * i + 1] + n]
+            ops.linear_wgrad_bf16(g, a_in, r, m, n, k, out_w=ow, out_b=ob)
+            if i > 0:
+                h = hidden[i - 1] if ctx.acts[i - 1] == ops.ACT_SIGMOID else None
+                g = ops.linear_dgrad_bf16(g, m, n, w_t[i], k, h)
+        grads = _deliver_param_grads(ctx.params, flat, ctx.offsets, grad_loss)
+        return (None, None, None, None, None) + tuple(grads)
+
+
 class GRUFn(torch.autograd.Function):
     """One GRU layer (batch_first) restricted to seq_len[b] steps per item; returns (outputs, h_n)."""
 

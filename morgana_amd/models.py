@@ -15,8 +15,9 @@ from .base_models import BaseSPSS
 
 class F0Model(BaseSPSS):
     def __init__(self, input_dim=600, hidden_dims=(512, 128, 32), output_dim=1, target_name='lf0', precision=None,
-                 fused_upsample=True):
+                 fused_upsample=True, fused_loss=True):
         super(F0Model, self).__init__()
+        self.fused_loss = fused_loss
         dims = (input_dim,) + tuple(hidden_dims) + (output_dim,)
         mods = []
         for i in range(len(dims) - 1):
@@ -47,6 +48,20 @@ class F0Model(BaseSPSS):
     def loss(self, features, output_features):
         return losses.mse(output_features['pred_norm_' + self.target_name],
                           features['normalised_' + self.target_name], features['n_frames'])
+
+    def forward(self, features):
+        """``predict`` + ``loss`` (base_models.py:279-285) with the stack's tail and the loss fused when a target is at hand
+        (``SequentialWithRecurrent.forward_mse``); identical outputs otherwise."""
+        target = features.get('normalised_' + self.target_name)
+        if target is None or not self.fused_loss:
+            return super(F0Model, self).forward(features)
+        x = utils.upsample_to_repetitions(features['normalised_lab'], features['dur'], max_len=target.shape[1],
+                                          fused=self.fused_upsample)
+        loss, pred_norm = self.layers.forward_mse(x, target, seq_len=features['n_frames'])
+        outputs = {'pred_norm_' + self.target_name: pred_norm}
+        if self.target_name in self.normalisers:
+            outputs['pred_' + self.target_name] = self.normalisers[self.target_name].denormalise(pred_norm.detach())
+        return loss, outputs
 
 
 class RNNSPSS(BaseSPSS):

@@ -231,15 +231,56 @@ def linear_dgrad_bf16(dy, m, n, wt_bf16, k, h, out_f32=False):
     return dx
 
 
-def linear_wgrad_bf16(dy, a, rows, m, n, k, want_bias=True):
+def linear_wgrad_bf16(dy, a, rows, m, n, k, want_bias=True, out_w=None, out_b=None):
+    """out_w / out_b: optional preallocated fp32 destinations (e.g. slices of one gradient buffer)."""
     lib = _lib.load()
-    dw = torch.empty((n, k), dtype=torch.float32, device=dy.device)
-    db = torch.empty((n,), dtype=torch.float32, device=dy.device) if want_bias else None
+    dw = out_w if out_w is not None else torch.empty((n, k), dtype=torch.float32, device=dy.device)
+    db = None
+    if want_bias:
+        db = out_b if out_b is not None else torch.empty((n,), dtype=torch.float32, device=dy.device)
     nbytes = lib.mg_linear_wgrad_workspace_bytes(m, n, k)
     ws = workspace(nbytes, dy.device)
     _lib.check(lib.mg_linear_wgrad_bf16(_p(dy), dy.shape[1], _p(a), a.shape[1], _p(rows), m, n, k, _p(dw), _p(db), 0,
                                         _p(ws), ws.numel(), _stream()), 'mg_linear_wgrad_bf16')
     return dw, db
+
+
+def cast_params_bf16(weights, want_plain=True, want_t=()):
+    """One launch: bf16 copies [N, pad_ld(K)] of every fp32 weight and, for the indices in `want_t`, the transposed
+    copies [K, pad_ld(N)].  Returns (plain list, transposed list with None where not requested)."""
+    lib = _lib.load()
+    if len(weights) > _lib.CAST_MAX:
+        raise ValueError('cast_params_bf16: at most %d matrices per call' % _lib.CAST_MAX)
+    descs = (_lib.CastDesc * len(weights))()
+    plain, trans = [], []
+    for i, w in enumerate(weights):
+        w = _require(w, torch.float32, 'weight')
+        n, k = w.shape
+        wb = torch.empty((n, pad_ld(k)), dtype=torch.bfloat16, device=w.device) if want_plain else None
+        wt = torch.empty((k, pad_ld(n)), dtype=torch.bfloat16, device=w.device) if i in want_t else None
+        descs[i].src, descs[i].rows, descs[i].cols = w.data_ptr(), n, k
+        descs[i].dst, descs[i].ldd = (wb.data_ptr() if wb is not None else None), (wb.shape[1] if wb is not None else 0)
+        descs[i].dst_t, descs[i].ldt = (wt.data_ptr() if wt is not None else None), (wt.shape[1] if wt is not None else 0)
+        plain.append(wb)
+        trans.append(wt)
+    _lib.check(lib.mg_cast_params_bf16(ctypes.cast(descs, ctypes.c_void_p), len(weights), _stream()),
+               'mg_cast_params_bf16')
+    return plain, trans
+
+
+def f0_tail(h2, w3, b3, w4, b4, target, seq_len, b, t, grads_out, grad_scale=1.0):
+    """Fused layers 3-4 + masked MSE, forward and backward (mg_f0_tail_bf16).  Returns (pred (b*t,), loss 0-d, dz2)."""
+    lib = _lib.load()
+    m = b * t
+    pred = torch.empty((m,), dtype=torch.float32, device=h2.device)
+    loss = torch.empty((), dtype=torch.float32, device=h2.device)
+    dz2 = torch.empty_like(h2)
+    nbytes = lib.mg_f0_tail_workspace_bytes(m)
+    ws = workspace(nbytes, h2.device)
+    _lib.check(lib.mg_f0_tail_bf16(_p(h2), h2.shape[1], w3.shape[1], _p(w3), _p(b3), _p(w4), _p(b4), _p(target),
+                                   _p(seq_len), b, t, float(grad_scale), _p(pred), _p(loss), _p(dz2), _p(grads_out), 0,
+                                   _p(ws), ws.numel(), _stream()), 'mg_f0_tail_bf16')
+    return pred, loss, dz2
 
 
 def sigmoid(x):

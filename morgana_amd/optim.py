@@ -42,6 +42,7 @@ class Adam(torch.optim.Optimizer):
                 flat_p[off:off + n].copy_(p.data.reshape(-1))
                 p.data = flat_p[off:off + n].view_as(p)
                 p.grad = flat_g[off:off + n].view_as(p)
+                p._mg_direct_grad = True          # functional._deliver_param_grads may add into flat_g directly
                 off += n
             self._flat.append({'param': flat_p, 'grad': flat_g, 'exp_avg': torch.zeros_like(flat_p),
                                'exp_avg_sq': torch.zeros_like(flat_p), 'step': 0, 'params': plist})

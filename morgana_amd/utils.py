@@ -175,6 +175,45 @@ class SequentialWithRecurrent(nn.Sequential):
             i = nxt
         return i, run
 
+    def _fused_mse_spec(self, targets, precision):
+        """acts of the stack if it is [Linear, Sigmoid]* ... Linear(*,128), Sigmoid, Linear(128,32), Sigmoid, Linear(32,1) in
+        bf16 mode with a 1-dimensional target (the README F0Model shape) - the case mg_f0_tail_bf16 fuses; else None."""
+        modules = list(self._modules.values())
+        end, run = self._linear_run(modules, 0)
+        if end != len(modules) or len(run) < 3 or precision != 'bf16' or targets.shape[-1] != 1:
+            return None
+        dims = [lin.weight.shape for lin, _ in run]
+        acts = tuple(act for _, act in run)
+        ok = (tuple(dims[-1]) == (1, 32) and tuple(dims[-2]) == (32, 128) and acts[-1] == ops.ACT_NONE and
+              all(a == ops.ACT_SIGMOID for a in acts[:-1]) and all(lin.bias is not None for lin, _ in run) and
+              all(d[0] % 128 == 0 for d in dims[:-2]))
+        return (run, acts) if ok else None
+
+    def forward_mse(self, input, targets, seq_len=None):
+        """``loss, prediction`` of ``losses.mse(self(input)[0], targets, seq_len)``.
+
+        Same numbers as calling the container and then ``losses.mse`` (reference: README.rst:84-97), but when the stack has
+        the README F0Model's tail (... -> 128 -> 32 -> 1, bf16 mode) its last two layers, the loss and their backward run
+        as one kernel.  Any other stack takes the ordinary path.  ``prediction`` is detached on the fused path.
+        """
+        from . import losses
+        precision = self.precision or F_hip.get_precision()
+        fused = self._fused_mse_spec(targets, precision)
+        if fused is None:
+            out, _ = self.forward(input, seq_len=seq_len)
+            return losses.mse(out, targets, seq_len), out
+        run, acts = fused
+        if isinstance(input, UpsampledSequence):
+            x2d, rows = input.source.reshape(-1, input.source.shape[-1]), input.rows.reshape(-1)
+        else:
+            x2d, rows = input.reshape(-1, input.shape[-1]), None
+        if seq_len is not None and seq_len.dtype != torch.int64:
+            seq_len = seq_len.long()
+        params = []
+        for lin, _ in run:
+            params += [lin.weight, lin.bias]
+        return F_hip.LinearStackMSEFn.apply(acts, x2d, rows, targets, seq_len, *params)
+
     def forward(self, input, hiddens=None, seq_len=None):
         modules = list(self._modules.values())
         if hiddens is None:

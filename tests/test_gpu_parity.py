@@ -259,6 +259,59 @@ def test_linear_kernels_bf16(shape, gather):
     assert rel_err(dxh[:, :k].float().cpu().numpy(), (dy.astype(np.float64) @ w.astype(np.float64)) * h * (1 - h)) < 1e-2
 
 
+def test_cast_params_batched():
+    rng = np.random.RandomState(4)
+    ws = [rng.standard_normal(sh).astype(np.float32) for sh in [(512, 600), (128, 512), (32, 128), (1, 32)]]
+    plain, trans = ops.cast_params_bf16([dev(w) for w in ws], want_t=(1, 2))
+    for w, wb in zip(ws, plain):
+        assert wb.shape == (w.shape[0], ops.pad_ld(w.shape[1]))
+        np.testing.assert_array_equal(wb[:, :w.shape[1]].float().cpu().numpy(), _bf16_round(w))
+        assert torch.all(wb[:, w.shape[1]:] == 0)
+    assert trans[0] is None and trans[3] is None
+    for i in (1, 2):
+        assert trans[i].shape == (ws[i].shape[1], ops.pad_ld(ws[i].shape[0]))
+        np.testing.assert_array_equal(trans[i][:, :ws[i].shape[0]].float().cpu().numpy(), _bf16_round(ws[i]).T)
+
+
+@pytest.mark.parametrize('bt', [(7, 45), (64, 1000), (3, 32)])
+def test_fused_tail_kernel_vs_numpy(bt):
+    """mg_f0_tail_bf16 (layers 3-4 + masked MSE, forward and backward) against a float64 restatement fed the same
+    bf16-rounded H2 / W3.  Outputs are fp32 except dZ2 (bf16)."""
+    b, t = bt
+    m = b * t
+    rng = np.random.RandomState(b * t)
+    h2 = _bf16_round(rng.uniform(0.05, 0.95, (m, 128)).astype(np.float32))
+    w3 = rng.uniform(-0.2, 0.2, (32, 128)).astype(np.float32)
+    b3 = rng.uniform(-0.1, 0.1, 32).astype(np.float32)
+    w4 = rng.uniform(-0.3, 0.3, (1, 32)).astype(np.float32)
+    b4 = rng.uniform(-0.1, 0.1, 1).astype(np.float32)
+    tgt = rng.standard_normal(m).astype(np.float32)
+    sl = rng.randint(1, t + 1, size=b).astype(np.int64)
+    sl[0] = t
+    grads = torch.empty(32 * 128 + 32 + 32 + 1, device=DEV)
+    pred, loss, dz2 = ops.f0_tail(ops.cast_pad_bf16(dev(h2)), dev(w3), dev(b3), dev(w4), dev(b4), dev(tgt), dev(sl), b, t,
+                                  grads)
+    w3r = _bf16_round(w3).astype(np.float64)
+    z3 = h2.astype(np.float64) @ w3r.T + b3
+    h3 = 1 / (1 + np.exp(-z3))
+    p = h3 @ w4[0].astype(np.float64) + b4[0]
+    mask = (np.arange(t)[None, :] < sl[:, None]).reshape(-1).astype(np.float64)
+    nb = np.repeat(sl, t).astype(np.float64)
+    e = p - tgt
+    want_loss = (mask * e * e / nb).sum() / b
+    dpred = 2 * e * mask / (nb * b)
+    dz3 = dpred[:, None] * w4[0][None, :] * h3 * (1 - h3)
+    want_dz2 = (dz3 @ w3r) * h2 * (1 - h2)
+    np.testing.assert_allclose(pred.cpu().numpy(), p, rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(loss.item(), want_loss, rtol=2e-3)
+    assert rel_err(dz2[:, :128].float().cpu().numpy(), want_dz2) < 2e-2
+    g = grads.cpu().numpy().astype(np.float64)
+    assert rel_err(g[:4096].reshape(32, 128), dz3.T @ h2) < 1e-2
+    assert rel_err(g[4096:4128], dz3.sum(axis=0)) < 1e-2
+    assert rel_err(g[4128:4160], dpred @ h3) < 1e-2
+    assert abs(g[4160] - dpred.sum()) < 1e-2 * np.abs(dpred).sum()
+
+
 # ---------------------------------------------------------------------------------------------- whole models
 def _load_state(model, state):
     own = model.state_dict()
@@ -318,11 +371,28 @@ def test_f0_model_fp32_ragged_weight_decay(golden):
     np.testing.assert_allclose(curve, g['ragged_loss_curve'], rtol=RTOL)
 
 
-def test_f0_model_bf16_tracks_golden_curve(golden):
+@pytest.mark.parametrize('fused_loss', [True, False])
+def test_f0_model_bf16_tracks_golden_curve(golden, fused_loss):
     g = golden('g6_f0_model.npz')
-    model = _load_state(models.F0Model(precision='bf16').to(DEV), synthetic.f0_model_state())
+    model = _load_state(models.F0Model(precision='bf16', fused_loss=fused_loss).to(DEV), synthetic.f0_model_state())
     curve = _train(model, _c1_batches(), 20, lr=0.01)
     np.testing.assert_allclose(curve, g['loss_curve'], rtol=RTOL_BF16)
+
+
+def test_f0_model_bf16_fused_and_unfused_agree_on_ragged_batch():
+    feats = data.to_device(synthetic.make_batch(12, (300, 700), seed=21), DEV)
+    out = {}
+    for fused in (True, False):
+        model = _load_state(models.F0Model(precision='bf16', fused_loss=fused).to(DEV), synthetic.f0_model_state())
+        opt = optim.Adam(model.parameters(), lr=0.01)
+        opt.zero_grad()
+        loss, o = model(feats)
+        loss.backward()
+        out[fused] = (loss.item(), o['pred_norm_lf0'].detach().cpu().numpy(),
+                      opt.flat_buffers()['grad'].cpu().numpy().copy())
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=2e-3)
+    assert np.abs(out[True][1] - out[False][1]).max() < 5e-3
+    assert rel_err(out[True][2], out[False][2]) < 3e-2
 
 
 @pytest.mark.parametrize('precision,tol', [('fp32', RTOL), ('bf16', RTOL_BF16)])
