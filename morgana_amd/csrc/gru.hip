@@ -51,22 +51,32 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(const float* __restri
     const float* wn = wz + (size_t)H * H;
 
     f32x4 acc_r = {0.f, 0.f, 0.f, 0.f}, acc_z = acc_r, acc_n = acc_r;
-    for (int k0 = wave * 16; k0 < H; k0 += 64) {
+    // Software pipeline over the 16-deep contraction blocks this wave owns (wave, wave + 4, ...): the loads of block i + 1
+    // are in flight while block i feeds the matrix pipe (h and W_hh come from L2; a dependent load is ~1 us otherwise).
+    auto load_blk = [&](int k0, f32x4& a, f32x4& br, f32x4& bz, f32x4& bn) {
         const int k = k0 + 4 * q;
         const int valid = H - k;
-        f32x4 a = (brow < B) ? ld4_guard(hp + k, valid, vec) : f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 br = {0.f, 0.f, 0.f, 0.f}, bz = br, bn = br;
+        a = (brow < B) ? ld4_guard(hp + k, valid, vec) : f32x4{0.f, 0.f, 0.f, 0.f};
+        br = bz = bn = f32x4{0.f, 0.f, 0.f, 0.f};
         if (jrow < H) {
             br = ld4_guard(wr + k, valid, vec);
             bz = ld4_guard(wz + k, valid, vec);
             bn = ld4_guard(wn + k, valid, vec);
         }
+    };
+    f32x4 a0, r0, z0, n0, a1, r1, z1, n1;
+    int k0 = wave * 16;
+    if (k0 < H) load_blk(k0, a0, r0, z0, n0);
+    for (; k0 < H; k0 += 64) {
+        const bool more = k0 + 64 < H;
+        if (more) load_blk(k0 + 64, a1, r1, z1, n1);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], br[e], acc_r, 0, 0, 0);
-            acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bz[e], acc_z, 0, 0, 0);
-            acc_n = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bn[e], acc_n, 0, 0, 0);
+            acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], r0[e], acc_r, 0, 0, 0);
+            acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], z0[e], acc_z, 0, 0, 0);
+            acc_n = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], n0[e], acc_n, 0, 0, 0);
         }
+        if (more) { a0 = a1; r0 = r1; z0 = z1; n0 = n1; }
     }
     // C/D layout 16x16: col = lane&15 (hidden unit), row = 4*(lane>>4) + reg (batch item).
 #pragma unroll
@@ -120,14 +130,25 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(const float* __restri
         const int brow = b0 + li;
         const int jcol = j0 + li;
         const float* dp = dhproj + ((size_t)(brow < B ? brow : 0) * T + (t + 1)) * G;
-        for (int g0 = wave * 16; g0 < G; g0 += 64) {
+        auto load_blk = [&](int g0, f32x4& a, float (&bv)[4]) {
             const int g = g0 + 4 * q;
-            f32x4 a = (brow < B) ? ld4_guard(dp + g, G - g, vec) : f32x4{0.f, 0.f, 0.f, 0.f};
+            a = (brow < B) ? ld4_guard(dp + g, G - g, vec) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float bv = 0.f;
-                if (jcol < H && g + e < G) bv = w_hh[(size_t)(g + e) * H + jcol];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bv, acc, 0, 0, 0);
+            for (int e = 0; e < 4; ++e) bv[e] = (jcol < H && g + e < G) ? w_hh[(size_t)(g + e) * H + jcol] : 0.f;
+        };
+        f32x4 a0, a1;
+        float b0v[4], b1v[4];
+        int g0 = wave * 16;
+        if (g0 < G) load_blk(g0, a0, b0v);
+        for (; g0 < G; g0 += 64) {
+            const bool more = g0 + 64 < G;
+            if (more) load_blk(g0 + 64, a1, b1v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b0v[e], acc, 0, 0, 0);
+            if (more) {
+                a0 = a1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b0v[e] = b1v[e];
             }
         }
     }

@@ -221,6 +221,7 @@ class LinearStackMSEFn(torch.autograd.Function):
         ctx.save_for_backward(a0, rows, dz2, flat, *hidden[:-1], *[wt for wt in w_t if wt is not None])
         pred = pred.view(b, t, 1)
         ctx.mark_non_differentiable(pred)
+        ctx.set_materialize_grads(False)
         return loss, pred
 
     @staticmethod
