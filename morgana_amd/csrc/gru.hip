@@ -35,6 +35,9 @@ __device__ __forceinline__ f32x4 ld4_guard(const float* p, int valid, bool vec) 
 }
 
 // One forward step t.  hstate [B, T+1, H]: slot t holds h_{t-1} (slot 0 = h0), slot t+1 receives h_t.
+// NB > 0: the wave owns exactly NB contraction blocks (H == 64 NB): all of their fragments are requested up front
+// (4 NB 16-byte loads per lane in flight), so the L2 round trip is paid once per step instead of once per block.
+template <int NB>
 __global__ __launch_bounds__(256) void gru_fwd_step_kernel(const float* __restrict__ xproj, const float* __restrict__ w_hh,
                                                            const float* __restrict__ b_hh, const int64_t* __restrict__ seq_len,
                                                            int B, int T, int H, int t, float* __restrict__ hstate,
@@ -64,19 +67,46 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(const float* __restri
             bn = ld4_guard(wn + k, valid, vec);
         }
     };
-    f32x4 a0, r0, z0, n0, a1, r1, z1, n1;
-    int k0 = wave * 16;
-    if (k0 < H) load_blk(k0, a0, r0, z0, n0);
-    for (; k0 < H; k0 += 64) {
-        const bool more = k0 + 64 < H;
-        if (more) load_blk(k0 + 64, a1, r1, z1, n1);
+    // Operands of the cell update (this thread's batch item / hidden unit), requested before the contraction so that
+    // their HBM latency (xproj is streamed, never cached) hides under it.
+    const int bl = tid >> 4, jl = tid & 15;
+    const int b = b0 + bl, j = j0 + jl;
+    const bool mine = b < B && j < H;
+    const size_t row = (size_t)(mine ? b : 0) * T + t;
+    const float* xp = xproj + row * 3 * H;
+    const int jj = mine ? j : 0;
+    const float xr = xp[jj], xz = xp[H + jj], xn = xp[2 * H + jj];
+    const float hprev = hstate[((size_t)(mine ? b : 0) * (T + 1) + t) * H + jj];
+    const float bhr = b_hh[jj], bhz = b_hh[H + jj], bhn = b_hh[2 * H + jj];
+    const bool active = seq_len ? ((int64_t)t < seq_len[mine ? b : 0]) : true;
+
+    if (NB > 0) {
+        f32x4 fa[NB > 0 ? NB : 1], fr[NB > 0 ? NB : 1], fz[NB > 0 ? NB : 1], fn[NB > 0 ? NB : 1];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], r0[e], acc_r, 0, 0, 0);
-            acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], z0[e], acc_z, 0, 0, 0);
-            acc_n = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], n0[e], acc_n, 0, 0, 0);
+        for (int i = 0; i < NB; ++i) load_blk(wave * 16 + 64 * i, fa[i], fr[i], fz[i], fn[i]);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fr[i][e], acc_r, 0, 0, 0);
+                acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fz[i][e], acc_z, 0, 0, 0);
+                acc_n = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fn[i][e], acc_n, 0, 0, 0);
+            }
+    } else {
+        f32x4 a0, r0, z0, n0, a1, r1, z1, n1;
+        int k0 = wave * 16;
+        if (k0 < H) load_blk(k0, a0, r0, z0, n0);
+        for (; k0 < H; k0 += 64) {
+            const bool more = k0 + 64 < H;
+            if (more) load_blk(k0 + 64, a1, r1, z1, n1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], r0[e], acc_r, 0, 0, 0);
+                acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], z0[e], acc_z, 0, 0, 0);
+                acc_n = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], n0[e], acc_n, 0, 0, 0);
+            }
+            if (more) { a0 = a1; r0 = r1; z0 = z1; n0 = n1; }
         }
-        if (more) { a0 = a1; r0 = r1; z0 = z1; n0 = n1; }
     }
     // C/D layout 16x16: col = lane&15 (hidden unit), row = 4*(lane>>4) + reg (batch item).
 #pragma unroll
@@ -87,21 +117,15 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(const float* __restri
         red[wave][2][e] = acc_n[r];
     }
     __syncthreads();
-    const int bl = tid >> 4, jl = tid & 15;
-    const int b = b0 + bl, j = j0 + jl;
-    if (b < B && j < H) {
+    if (mine) {
         const int e = bl * GT + jl;
-        const float hr = ((red[0][0][e] + red[1][0][e]) + (red[2][0][e] + red[3][0][e])) + b_hh[j];
-        const float hz = ((red[0][1][e] + red[1][1][e]) + (red[2][1][e] + red[3][1][e])) + b_hh[H + j];
-        const float hn = ((red[0][2][e] + red[1][2][e]) + (red[2][2][e] + red[3][2][e])) + b_hh[2 * H + j];
-        const size_t row = (size_t)b * T + t;
-        const float* xp = xproj + row * 3 * H;
-        const float r = mg_sigmoid(xp[j] + hr);
-        const float z = mg_sigmoid(xp[H + j] + hz);
-        const float n = tanhf(xp[2 * H + j] + r * hn);
-        const float hprev = hstate[((size_t)b * (T + 1) + t) * H + j];
+        const float hr = ((red[0][0][e] + red[1][0][e]) + (red[2][0][e] + red[3][0][e])) + bhr;
+        const float hz = ((red[0][1][e] + red[1][1][e]) + (red[2][1][e] + red[3][1][e])) + bhz;
+        const float hn = ((red[0][2][e] + red[1][2][e]) + (red[2][2][e] + red[3][2][e])) + bhn;
+        const float r = mg_sigmoid(xr + hr);
+        const float z = mg_sigmoid(xz + hz);
+        const float n = tanhf(xn + r * hn);
         const float hnew = (1.f - z) * n + z * hprev;
-        const bool active = seq_len ? ((int64_t)t < seq_len[b]) : true;
         hstate[((size_t)b * (T + 1) + t + 1) * H + j] = active ? hnew : hprev;
         out[row * H + j] = active ? hnew : 0.f;
         float* sv = saved + row * 4 * H;
@@ -115,6 +139,7 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(const float* __restri
 // One backward step.  t in [0, T): dstate_t = carry + dhproj[:, t+1, :] W_hh (skipped at t == T-1), then gate
 // derivatives of step t; carry <- dh_t * z_t (or dstate_t for finished items).  t == -1: only the matmul, result
 // (the gradient of h0) goes to dh0.
+template <int NB>
 __global__ __launch_bounds__(256) void gru_bwd_step_kernel(const float* __restrict__ grad_out, const float* __restrict__ hstate,
                                                            const float* __restrict__ saved, const float* __restrict__ w_hh,
                                                            const int64_t* __restrict__ seq_len, int B, int T, int H, int t,
@@ -126,6 +151,17 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(const float* __restri
     const int j0 = blockIdx.x * GT, b0 = blockIdx.y * GT;
     const int G = 3 * H;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // cell-update operands of this thread, requested early (see the forward kernel)
+    const int bl = tid >> 4, jl = tid & 15;
+    const int b = b0 + bl, j = j0 + jl;
+    const bool mine = b < B && j < H && t >= 0;
+    const size_t row = (size_t)(mine ? b : 0) * T + (t >= 0 ? t : 0);
+    const int jj = mine ? j : 0;
+    const float* sv = saved + row * 4 * H;
+    const float s_r = sv[jj], s_z = sv[H + jj], s_n = sv[2 * H + jj], s_hn = sv[3 * H + jj];
+    const float hprev = hstate[((size_t)(mine ? b : 0) * (T + 1) + (t >= 0 ? t : 0)) * H + jj];
+    const float gout = grad_out[row * H + jj];
+    const float cin = carry[(size_t)((b < B) ? b : 0) * H + ((j < H) ? j : 0)];
     if (t + 1 < T) {
         const int brow = b0 + li;
         const int jcol = j0 + li;
@@ -136,42 +172,48 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(const float* __restri
 #pragma unroll
             for (int e = 0; e < 4; ++e) bv[e] = (jcol < H && g + e < G) ? w_hh[(size_t)(g + e) * H + jcol] : 0.f;
         };
-        f32x4 a0, a1;
-        float b0v[4], b1v[4];
-        int g0 = wave * 16;
-        if (g0 < G) load_blk(g0, a0, b0v);
-        for (; g0 < G; g0 += 64) {
-            const bool more = g0 + 64 < G;
-            if (more) load_blk(g0 + 64, a1, b1v);
+        if (NB > 0) {
+            f32x4 fa[NB > 0 ? NB : 1];
+            float fb[NB > 0 ? NB : 1][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b0v[e], acc, 0, 0, 0);
-            if (more) {
-                a0 = a1;
+            for (int i = 0; i < NB; ++i) load_blk(wave * 16 + 64 * i, fa[i], fb[i]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) b0v[e] = b1v[e];
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[i][e], acc, 0, 0, 0);
+        } else {
+            f32x4 a0, a1;
+            float b0v[4], b1v[4];
+            int g0 = wave * 16;
+            if (g0 < G) load_blk(g0, a0, b0v);
+            for (; g0 < G; g0 += 64) {
+                const bool more = g0 + 64 < G;
+                if (more) load_blk(g0 + 64, a1, b1v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b0v[e], acc, 0, 0, 0);
+                if (more) {
+                    a0 = a1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b0v[e] = b1v[e];
+                }
             }
         }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][(4 * q + r) * GT + li] = acc[r];
     __syncthreads();
-    const int bl = tid >> 4, jl = tid & 15;
-    const int b = b0 + bl, j = j0 + jl;
     if (b < B && j < H) {
         const int e = bl * GT + jl;
-        const float dstate = carry[(size_t)b * H + j] + ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e]));
+        const float dstate = cin + ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e]));
         if (t < 0) {
             dh0[(size_t)b * H + j] = dstate;
             return;
         }
-        const size_t row = (size_t)b * T + t;
         const bool active = seq_len ? ((int64_t)t < seq_len[b]) : true;
         float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, c = dstate;
         if (active) {
-            const float* sv = saved + row * 4 * H;
-            const float r = sv[j], z = sv[H + j], n = sv[2 * H + j], hn = sv[3 * H + j];
-            const float hprev = hstate[((size_t)b * (T + 1) + t) * H + j];
-            const float dh = dstate + grad_out[row * H + j];
+            const float r = s_r, z = s_z, n = s_n, hn = s_hn;
+            const float dh = dstate + gout;
             dn = dh * (1.f - z) * (1.f - n * n);
             dz = dh * (hprev - n) * z * (1.f - z);
             dr = dn * hn * r * (1.f - r);
@@ -198,7 +240,10 @@ int mg_gru_fwd_f32(const float* xproj, const float* w_hh, const float* b_hh, con
     const int vec = (H % 4 == 0) && (((uintptr_t)hstate | (uintptr_t)w_hh) % 16 == 0);
     dim3 grid((unsigned)mg_ceil_div(H, GT), (unsigned)mg_ceil_div(B, GT));
     for (int t = 0; t < T; ++t) {
-        hipLaunchKernelGGL(gru_fwd_step_kernel, grid, dim3(256), 0, (hipStream_t)stream, xproj, w_hh, b_hh, seq_len, B, T, H, t, hstate, out, saved, vec);
+        if (H == 512 && vec)
+            hipLaunchKernelGGL(gru_fwd_step_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, xproj, w_hh, b_hh, seq_len, B, T, H, t, hstate, out, saved, vec);
+        else
+            hipLaunchKernelGGL(gru_fwd_step_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, xproj, w_hh, b_hh, seq_len, B, T, H, t, hstate, out, saved, vec);
     }
     MG_CHECK_LAUNCH("mg_gru_fwd_f32");
     return MG_OK;
@@ -222,7 +267,10 @@ int mg_gru_bwd_f32(const float* grad_out, const float* grad_hn, const float* hst
     hipLaunchKernelGGL(gru_init_carry_kernel, dim3((unsigned)mg_ceil_div(n, 256)), dim3(256), 0, st, grad_hn, carry, n);
     dim3 grid((unsigned)mg_ceil_div(H, GT), (unsigned)mg_ceil_div(B, GT));
     for (int t = T - 1; t >= -1; --t) {
-        hipLaunchKernelGGL(gru_bwd_step_kernel, grid, dim3(256), 0, st, grad_out, hstate, saved, w_hh, seq_len, B, T, H, t, dxproj, dhproj, carry, dh0, vec);
+        if (H == 512 && vec)
+            hipLaunchKernelGGL(gru_bwd_step_kernel<24>, grid, dim3(256), 0, st, grad_out, hstate, saved, w_hh, seq_len, B, T, H, t, dxproj, dhproj, carry, dh0, vec);
+        else
+            hipLaunchKernelGGL(gru_bwd_step_kernel<0>, grid, dim3(256), 0, st, grad_out, hstate, saved, w_hh, seq_len, B, T, H, t, dxproj, dhproj, carry, dh0, vec);
     }
     MG_CHECK_LAUNCH("mg_gru_bwd_f32");
     return MG_OK;
