@@ -189,3 +189,46 @@ def to_device(features, device):
             value = torch.from_numpy(value)
         out[key] = value.to(device) if isinstance(value, torch.Tensor) else value
     return out
+
+
+_TO_TORCH_DTYPE = {np.dtype('float16'): torch.float16, np.dtype('float32'): torch.float32,
+                   np.dtype('float64'): torch.float64, np.dtype('int8'): torch.int8, np.dtype('int16'): torch.int16,
+                   np.dtype('int32'): torch.int32, np.dtype('int64'): torch.int64, np.dtype('bool'): torch.bool,
+                   int: torch.int64, float: torch.float32, bool: torch.bool}
+
+
+def collate_fn(batch):
+    """List of per-utterance feature dicts -> batched dict (reference: ``FilesDataset.collate_fn``, data.py:159-224).
+
+    Sequence features (ndarray, ndim > 1) are zero padded to ``(B, max_len, feat_dim)``; 1-d arrays and python scalars
+    become ``(B, ...)`` tensors (ints -> int64); anything else (names) stays a list.
+    """
+    batch_size = len(batch)
+    out = {}
+    for key in batch[0].keys():
+        items = [item[key] for item in batch]
+        first = items[0]
+        if isinstance(first, np.ndarray) and first.ndim > 1:
+            max_len = max(len(x) for x in items)
+            dtype = _TO_TORCH_DTYPE[first.dtype]
+            batched = torch.zeros((batch_size, max_len, first.shape[-1]), dtype=dtype)
+            for i, x in enumerate(items):
+                batched[i, :x.shape[0], ...] = torch.tensor(x, dtype=dtype)
+            out[key] = batched
+        elif isinstance(first, np.ndarray) and first.dtype in _TO_TORCH_DTYPE:
+            out[key] = torch.tensor(np.stack(items), dtype=_TO_TORCH_DTYPE[first.dtype])
+        elif not isinstance(first, np.ndarray) and type(first) in _TO_TORCH_DTYPE:
+            out[key] = torch.tensor(items, dtype=_TO_TORCH_DTYPE[type(first)])
+        else:
+            out[key] = items
+    return out
+
+
+def load_utterance(features, normalisers):
+    """One utterance as ``FilesDataset.__getitem__`` yields it (data.py:106-154): every feature that has a normaliser also
+    gets its ``normalised_`` twin, computed on the host in NumPy and cast to float32 (data.py:119-127)."""
+    out = dict(features)
+    for name, normaliser in normalisers.items():
+        if name in features:
+            out['normalised_' + name] = normaliser.normalise(features[name]).astype(np.float32)
+    return out
