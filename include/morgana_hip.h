@@ -123,6 +123,16 @@ int mg_linear_wgrad_bf16(const uint16_t* dY, int lddy, const uint16_t* A, int ld
                          int N, int K, float* dW, float* db, int accumulate, void* workspace, size_t workspace_bytes,
                          void* stream);
 
+/* Fused backward of Linear(K -> N) + Sigmoid feeding Linear(N -> N2): dW, db of the FIRST layer straight from dZ2, the
+ * pre-activation gradient of the second one, without materialising dZ1 = (dZ2 W2) * H1 (1 - H1):
+ *   dZ2 bf16 [M, lddz] (N2 = 128 columns); W2T = W2^T bf16 [N, ldwt]; H1 bf16 [M, ldh] (sigmoid outputs, N % 128 == 0);
+ *   A bf16 [*, lda = 640] with `rows` (the layer-1 input, gathered), 512 < K <= 608.
+ * dW f32 [N, K], db f32 [N] (accumulate != 0 adds).  workspace: mg_linear_bwd_fused_workspace_bytes(M, N, K). */
+size_t mg_linear_bwd_fused_workspace_bytes(int64_t M, int N, int K);
+int mg_linear_bwd_fused_bf16(const uint16_t* dZ2, int lddz, int N2, const uint16_t* W2T, int ldwt, const uint16_t* H1, int ldh,
+                             const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K, float* dW, float* db,
+                             int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
 /* dst[r, 0:cols] = bf16(src[r, 0:cols]), dst[r, cols:ldd] = 0.  src f32 [rows, cols] (lds). */
 int mg_cast_pad_bf16(const float* src, int lds, uint16_t* dst, int ldd, int64_t rows, int cols, void* stream);
 /* dst[c, 0:rows] = bf16(src[r, c]) transposed, dst [cols, ldd], zero padded. */

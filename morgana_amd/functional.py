@@ -237,6 +237,13 @@ class LinearStackMSEFn(torch.autograd.Function):
             ow = flat[ctx.offsets[2 * i]:ctx.offsets[2 * i] + n * k].view(n, k)
             ob = flat[ctx.offsets[2 * i + 1]:ctx.offsets[2 * i + 1] + n]
             ops.linear_wgrad_bf16(g, a_in, r, m, n, k, out_w=ow, out_b=ob)
+            if i == 1 and ctx.acts[0] == ops.ACT_SIGMOID and ops.can_fuse_bwd(m, n, k, ctx.dims[0][1], a0.shape[1]):
+                # layer 0's dW, db straight from this layer's dZ: dZ_0 = (dZ_1 W_1) * H_0 (1 - H_0) stays on chip
+                n0_, k0_ = ctx.dims[0]
+                ops.linear_bwd_fused_bf16(g, w_t[1], hidden[0], a0, rows, m, n0_, k0_,
+                                          out_w=flat[ctx.offsets[0]:ctx.offsets[0] + n0_ * k0_].view(n0_, k0_),
+                                          out_b=flat[ctx.offsets[1]:ctx.offsets[1] + n0_])
+                break
             if i > 0:
                 h = hidden[i - 1] if ctx.acts[i - 1] == ops.ACT_SIGMOID else None
                 g = ops.linear_dgrad_bf16(g, m, n, w_t[i], k, h)

@@ -245,6 +245,24 @@ def linear_wgrad_bf16(dy, a, rows, m, n, k, want_bias=True, out_w=None, out_b=No
     return dw, db
 
 
+def can_fuse_bwd(m, n2, n_hidden, k0, lda0):
+    """Shapes mg_linear_bwd_fused_bf16 handles (the README F0Model's first two layers at training batch sizes)."""
+    return n2 == 128 and n_hidden % 128 == 0 and 512 < k0 <= 608 and lda0 == 640 and m >= 4096
+
+
+def linear_bwd_fused_bf16(dz2, wt2, h1, a, rows, m, n_hidden, k0, out_w=None, out_b=None):
+    """dW, db of Linear(k0 -> n_hidden)+Sigmoid from dz2 = dL/d(pre-activation of the following Linear(n_hidden -> 128))."""
+    lib = _lib.load()
+    dw = out_w if out_w is not None else torch.empty((n_hidden, k0), dtype=torch.float32, device=dz2.device)
+    db = out_b if out_b is not None else torch.empty((n_hidden,), dtype=torch.float32, device=dz2.device)
+    nbytes = lib.mg_linear_bwd_fused_workspace_bytes(m, n_hidden, k0)
+    ws = workspace(nbytes, dz2.device)
+    _lib.check(lib.mg_linear_bwd_fused_bf16(_p(dz2), dz2.shape[1], 128, _p(wt2), wt2.shape[1], _p(h1), h1.shape[1], _p(a),
+                                            a.shape[1], _p(rows), m, n_hidden, k0, _p(dw), _p(db), 0, _p(ws), ws.numel(),
+                                            _stream()), 'mg_linear_bwd_fused_bf16')
+    return dw, db
+
+
 def cast_params_bf16(weights, want_plain=True, want_t=()):
     """One launch: bf16 copies [N, pad_ld(K)] of every fp32 weight and, for the indices in `want_t`, the transposed
     copies [K, pad_ld(N)].  Returns (plain list, transposed list with None where not requested)."""

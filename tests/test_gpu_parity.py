@@ -312,6 +312,27 @@ def test_fused_tail_kernel_vs_numpy(bt):
     assert abs(g[4160] - dpred.sum()) < 1e-2 * np.abs(dpred).sum()
 
 
+@pytest.mark.parametrize('m,n_hidden', [(4999, 512), (9000, 256)])
+def test_fused_backward_kernel_vs_numpy(m, n_hidden):
+    """mg_linear_bwd_fused_bf16: dW1, db1 from dZ2 without materialising dZ1 = (dZ2 W2) * H1 (1 - H1)."""
+    k0 = 600
+    rng = np.random.RandomState(m)
+    table = _bf16_round(rng.uniform(0, 1, (m // 9, k0)).astype(np.float32))
+    rows = rng.randint(-1, table.shape[0], size=m).astype(np.int32)
+    x = np.where(rows[:, None] < 0, 0, table[np.maximum(rows, 0)]).astype(np.float64)
+    w2 = _bf16_round(rng.uniform(-0.1, 0.1, (128, n_hidden)).astype(np.float32))
+    h1 = _bf16_round(rng.uniform(0.05, 0.95, (m, n_hidden)).astype(np.float32))
+    dz2 = _bf16_round((rng.standard_normal((m, 128)) * 0.01).astype(np.float32))
+    dz1 = (dz2.astype(np.float64) @ w2.astype(np.float64)) * h1 * (1 - h1)
+    dz1_bf = _bf16_round(dz1.astype(np.float32)).astype(np.float64)          # the kernel rounds dZ1 to bf16 in LDS
+    want_w, want_b = dz1_bf.T @ x, dz1_bf.sum(axis=0)
+    wt2 = ops.cast_transpose_bf16(dev(w2))
+    dw, db = ops.linear_bwd_fused_bf16(ops.cast_pad_bf16(dev(dz2)), wt2, ops.cast_pad_bf16(dev(h1)),
+                                       ops.cast_pad_bf16(dev(table)), dev(rows), m, n_hidden, k0)
+    assert rel_err(dw.cpu().numpy(), want_w) < 5e-3
+    assert rel_err(db.cpu().numpy(), want_b) < 5e-3
+
+
 # ---------------------------------------------------------------------------------------------- whole models
 def _load_state(model, state):
     own = model.state_dict()
