@@ -60,7 +60,8 @@ def time_kernel(fn, iters=10, warm=2):
 
 
 def roofline_f0(features, model, precision):
-    """Time the GEMM kernels of the step in isolation and report the dominant one against the MFMA roof."""
+    """Time the GEMM kernels of the step in isolation (HIP events on the launch stream) and report the dominant one
+    against the MFMA roof.  FLOPs are the algorithmic 2*M*K*N of the products the launch replaces."""
     lab = features['normalised_lab']
     b, p, k = lab.shape
     t = features['normalised_lf0'].shape[1]
@@ -69,42 +70,55 @@ def roofline_f0(features, model, precision):
     _, rows = ops.upsample_index(dur2d, t)
     rows = rows.view(-1)
     lins = [mod for mod in model.layers if isinstance(mod, torch.nn.Linear)]
-    w1, b1, w2 = lins[0].weight.detach(), lins[0].bias.detach(), lins[1].weight.detach()
+    w1, b1, w2, b2 = lins[0].weight.detach(), lins[0].bias.detach(), lins[1].weight.detach(), lins[1].bias.detach()
     n1, n2 = w1.shape[0], w2.shape[0]
     kernels = []
     if precision == 'bf16':
         tab = ops.cast_pad_bf16(lab.view(b * p, k))
-        w1b = ops.cast_pad_bf16(w1)
+        (w1b, w2b), (_, w2t) = ops.cast_params_bf16([w1, w2], want_t=(1,))
         h1 = ops.linear_fwd_bf16(tab, rows, m, k, w1b, b1, n1, ops.ACT_SIGMOID)
-        dz1 = torch.randn(m, n1, device=lab.device).to(torch.bfloat16)
-        dz2 = torch.randn(m, ops.pad8(n2), device=lab.device).to(torch.bfloat16)
-        w2t = ops.cast_transpose_bf16(w2)
-        kernels.append(('linear_fwd_bf16 L1 (gather-fused 600->512 + bias + sigmoid)', 2.0 * m * k * n1,
-                        lambda: ops.linear_fwd_bf16(tab, rows, m, k, w1b, b1, n1, ops.ACT_SIGMOID)))
-        kernels.append(('linear_wgrad_bf16 L1 (gather-fused dW1 = dZ1^T X)', 2.0 * m * k * n1,
-                        lambda: ops.linear_wgrad_bf16(dz1, tab, rows, m, n1, k)))
-        kernels.append(('linear_dgrad_bf16 L2 (dZ1 = dZ2 W2 * H1(1-H1))', 2.0 * m * n1 * n2,
-                        lambda: ops.linear_dgrad_bf16(dz2, m, n2, w2t, n1, h1)))
+        dz2 = (torch.randn(m, ops.pad_ld(n2), device=lab.device) * 0.01).to(torch.bfloat16)
+        kernels.append(('gemm_nt_big_kernel<256>: layer-1 forward (gather-fused 600->512 + bias + sigmoid)',
+                        2.0 * m * k * n1, lambda: ops.linear_fwd_bf16(tab, rows, m, k, w1b, b1, n1, ops.ACT_SIGMOID)))
+        kernels.append(('gemm_nt_big_kernel<128>: layer-2 forward (512->128 + bias + sigmoid)', 2.0 * m * n1 * n2,
+                        lambda: ops.linear_fwd_bf16(h1, None, m, n1, w2b, b2, n2, ops.ACT_SIGMOID)))
+        if ops.can_fuse_bwd(m, n2, n1, k, tab.shape[1]):
+            kernels.append(('wgrad_fused_kernel: layer-2 dgrad + sigmoid-grad + layer-1 wgrad (gather-fused), dZ1 on chip',
+                            2.0 * m * n1 * n2 + 2.0 * m * k * n1,
+                            lambda: ops.linear_bwd_fused_bf16(dz2, w2t, h1, tab, rows, m, n1, k)))
+        else:
+            dz1 = (torch.randn(m, n1, device=lab.device) * 0.01).to(torch.bfloat16)
+            kernels.append(('wgrad_big_kernel<10>: layer-1 wgrad (gather-fused)', 2.0 * m * k * n1,
+                            lambda: ops.linear_wgrad_bf16(dz1, tab, rows, m, n1, k)))
+        kernels.append(('wgrad_big_kernel<8>: layer-2 wgrad (dZ2^T H1)', 2.0 * m * n1 * n2,
+                        lambda: ops.linear_wgrad_bf16(dz2, h1, None, m, n2, n1)))
         peak = MFMA_BF16_PEAK_TFLOPS
     else:
         tab = lab.view(b * p, k)
         h1 = ops.linear_fwd_f32(tab, rows, m, w1, b1, ops.ACT_SIGMOID)
         dz1 = torch.randn(m, n1, device=lab.device)
         dz2 = torch.randn(m, n2, device=lab.device)
-        kernels.append(('linear_fwd_f32 L1 (gather-fused 600->512 + bias + sigmoid)', 2.0 * m * k * n1,
+        kernels.append(('gemm_f32_kernel: layer-1 forward (gather-fused 600->512 + bias + sigmoid)', 2.0 * m * k * n1,
                         lambda: ops.linear_fwd_f32(tab, rows, m, w1, b1, ops.ACT_SIGMOID)))
-        kernels.append(('linear_wgrad_f32 L1 (gather-fused dW1 = dZ1^T X)', 2.0 * m * k * n1,
+        kernels.append(('wgrad_f32_kernel: layer-1 wgrad (gather-fused)', 2.0 * m * k * n1,
                         lambda: ops.linear_wgrad_f32(dz1, tab, rows, n1, k)))
-        kernels.append(('linear_dgrad_f32 L2 (dZ1 = dZ2 W2 * H1(1-H1))', 2.0 * m * n1 * n2,
+        kernels.append(('gemm_f32_kernel: layer-2 dgrad (dZ2 W2 * H1(1-H1))', 2.0 * m * n1 * n2,
                         lambda: ops.linear_dgrad_f32(dz2, w2, h1)))
         peak = MFMA_F32_PEAK_TFLOPS
     measured = []
     for name, flops, fn in kernels:
         ms = time_kernel(fn)
-        measured.append({'kernel': name, 'ms': round(ms, 4), 'tflops': round(flops / (ms * 1e-3) / 1e12, 2)})
+        measured.append({'kernel': name, 'ms': round(ms, 4), 'gflop': round(flops / 1e9, 1),
+                         'tflops': round(flops / (ms * 1e-3) / 1e12, 2)})
     dom = max(measured, key=lambda r: r['ms'])
+    traffic = None
+    try:   # HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
+        table = json.load(open(os.path.join(REPO, 'profiles', 'r1_hbm_traffic.json')))
+        traffic = table.get(dom['kernel'].split(':')[0])
+    except (OSError, ValueError):
+        pass
     return {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': dom['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
-            'frac': round(dom['tflops'] / peak, 4), 'traffic': None, 'ms_per_launch': dom['ms'], 'kernels': measured}
+            'frac': round(dom['tflops'] / peak, 4), 'traffic': traffic, 'ms_per_launch': dom['ms'], 'kernels': measured}
 
 
 def host_cores():
@@ -165,8 +179,10 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit('--gpus %d does not match WORLD_SIZE %d' % (args.gpus, world))
     n_gpus = max(world, 1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % max(n_dev, 1)          # several ranks may share one GPU in the gloo rehearsal on a 1-GPU box
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
 
     torch.manual_seed(synthetic.REFERENCE_SEED)
     if args.config == 'c2':
