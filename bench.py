@@ -38,7 +38,8 @@ def parse_args():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
-    ap.add_argument('--config', default='c2', choices=['c2', 'c4'])
+    ap.add_argument('--config', default='c2', choices=['c2', 'c4', 'c5'],
+                    help='c2: F0Model 256x1000 (headline); c4: GRU-512 600->80, 64x1000; c5: GRU-512 600->187, 64 ragged 300-2000')
     ap.add_argument('--batch', type=int, default=None, help='utterances per GPU (default 256 for c2, 64 for c4)')
     ap.add_argument('--frames', type=int, default=1000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -191,12 +192,18 @@ def main():
         model = models.F0Model(precision=args.precision).to(dev)
         state = synthetic.f0_model_state()
         name, target = 'F0Model 600-512-128-32-1 (README.rst:65-73)', 'normalised_lf0'
-    else:
+    elif args.config == 'c4':
         per_gpu = args.batch or 64
         feats_np = synthetic.make_batch(per_gpu, args.frames, out_dim=80, target_name='mcep', rank=rank)
         model = models.RNNSPSS(precision=args.precision).to(dev)
         state = synthetic.rnn_spss_state()
         name, target = 'RNN_SPSS Linear-512/GRU-512/Linear-256/80 (models/RNN_SPSS.py:32-42 layout)', 'normalised_mcep'
+    else:
+        per_gpu = args.batch or 64
+        feats_np = synthetic.make_batch(per_gpu, (300, 2000), out_dim=187, target_name='mcep', rank=rank)
+        model = models.RNNSPSS(output_dim=187, precision=args.precision).to(dev)
+        state = synthetic.rnn_spss_state(out_dim=187)
+        name, target = 'RNN_SPSS Linear-512/GRU-512/Linear-256/187 WORLD params, ragged 300-2000 frames', 'normalised_mcep'
     own = model.state_dict()
     for key, value in state.items():
         own[key].copy_(torch.from_numpy(value))
@@ -234,8 +241,9 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = n_gpus * frames_per_step * args.steps / elapsed
         result = {
-            'metric': 'acoustic frames/sec (fwd+bwd+step), F0Model 600->1, batch 256x1000' if args.config == 'c2'
-            else 'acoustic frames/sec (fwd+bwd+step), RNN_SPSS GRU-512 600->80, batch 64x1000',
+            'metric': {'c2': 'acoustic frames/sec (fwd+bwd+step), F0Model 600->1, batch 256x1000',
+                       'c4': 'acoustic frames/sec (fwd+bwd+step), RNN_SPSS GRU-512 600->80, batch 64x1000',
+                       'c5': 'acoustic frames/sec (fwd+bwd+step), RNN_SPSS GRU-512 600->187, batch 64 x 300-2000 frames'}[args.config],
             'value': round(value, 1), 'unit': 'frames/s', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.precision, 'data': 'synthetic',

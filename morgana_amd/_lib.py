@@ -93,8 +93,6 @@ def load():
         fn = getattr(lib, name)
         fn.restype = restype
         fn.argtypes = argtypes
-    if os.environ.get('MG_VARIANT'):          # kernel-geometry tuning knob (debug only; see gemm_bf16_big.hip)
-        lib.mg_debug_set_variant(ctypes.c_int(int(os.environ['MG_VARIANT'])))
     _lib = lib
     return lib
 

@@ -15,6 +15,7 @@
 // X is double buffered (LDS-DMA two steps ahead of use), the small dZ2 / H1 tiles are refilled while P2 runs.
 // Deterministic: split-M slabs + ordered reduce (shared with the unfused wgrad).
 #include "common.h"
+#include "slab_reduce.h"
 
 typedef __bf16 bfv8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bfv4 __attribute__((ext_vector_type(4)));
@@ -23,17 +24,6 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 #define FZ_ELEMS 16384
 __device__ uint16_t g_fused_zero_row[FZ_ELEMS];
-
-// Non-temporal form for operands that are streamed once (dZ2, H1): keeps them from evicting the re-used X rows from L2.
-__device__ __forceinline__ void fglds16_nt(const uint16_t* src, unsigned char* lds_wave_base) {
-    const unsigned lds_off = (unsigned)(unsigned long long)((__attribute__((address_space(3))) unsigned char*)lds_wave_base);
-    const unsigned lds_uni = __builtin_amdgcn_readfirstlane(lds_off);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(src), "s"(lds_uni)
-                 : "memory");
-}
 
 __device__ __forceinline__ void fglds16(const uint16_t* src, unsigned char* lds_wave_base) {
     const unsigned lds_off = (unsigned)(unsigned long long)((__attribute__((address_space(3))) unsigned char*)lds_wave_base);
@@ -57,7 +47,6 @@ __device__ __forceinline__ void fglds16(const uint16_t* src, unsigned char* lds_
 #define F_ROWS (F_YS + 8192)
 #define F_LDS (F_ROWS + F_ROWS_MAX * 4)
 
-template <int XCD_MAP, int NT_STREAM>
 __global__ __launch_bounds__(512) void wgrad_fused_kernel(const uint16_t* __restrict__ dZ2, int lddz, const uint16_t* __restrict__ W2T,
                                                           int ldwt, const uint16_t* __restrict__ H1, int ldh,
                                                           const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
@@ -74,15 +63,8 @@ __global__ __launch_bounds__(512) void wgrad_fused_kernel(const uint16_t* __rest
     const int wn0 = (wave >> 2) * 64;
     const int wk0 = (wave & 3) * (TKT * 32);
     const int tiles_n = N / F_BNT;
-    int n0, s;
-    if (XCD_MAP) {     // blocks b, b + 8, ... share an XCD: give them the n tiles of one split (X rows shared through its L2)
-        const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
-        n0 = (jj % tiles_n) * F_BNT;
-        s = (jj / tiles_n) * 8 + xcd;
-    } else {
-        n0 = (blockIdx.x % tiles_n) * F_BNT;
-        s = blockIdx.x / tiles_n;
-    }
+    const int n0 = (blockIdx.x % tiles_n) * F_BNT;      // n tile fastest (XCD-grouped order and non-temporal streaming of
+    const int s = blockIdx.x / tiles_n;                 // dZ2 / H1 were measured: both within noise, 351-364 us)
     const int64_t m_lo = (int64_t)s * m_chunk;
     const int64_t m_hi = min(M, m_lo + (int64_t)m_chunk);
     const int n_rows = m_hi > m_lo ? (int)(m_hi - m_lo) : 0;
@@ -131,13 +113,8 @@ __global__ __launch_bounds__(512) void wgrad_fused_kernel(const uint16_t* __rest
     const int h1_col = n0 + 8 * (lane & 15);
     auto issue_small = [&](int step) {
         const int mz = step * 32 + dz_row, mh = step * 32 + h1_row;
-        if (NT_STREAM) {
-            fglds16_nt(mz < n_rows ? dZ2 + (size_t)(m_lo + mz) * lddz + dz_col : g_fused_zero_row, smem + F_DZ + wave * 1024);
-            fglds16_nt(mh < n_rows ? H1 + (size_t)(m_lo + mh) * ldh + h1_col : g_fused_zero_row, smem + F_H1 + wave * 1024);
-        } else {
-            fglds16(mz < n_rows ? dZ2 + (size_t)(m_lo + mz) * lddz + dz_col : g_fused_zero_row, smem + F_DZ + wave * 1024);
-            fglds16(mh < n_rows ? H1 + (size_t)(m_lo + mh) * ldh + h1_col : g_fused_zero_row, smem + F_H1 + wave * 1024);
-        }
+        fglds16(mz < n_rows ? dZ2 + (size_t)(m_lo + mz) * lddz + dz_col : g_fused_zero_row, smem + F_DZ + wave * 1024);
+        fglds16(mh < n_rows ? H1 + (size_t)(m_lo + mh) * ldh + h1_col : g_fused_zero_row, smem + F_H1 + wave * 1024);
     };
 
     f32x16 acc[2][TKT];
@@ -267,30 +244,6 @@ __global__ __launch_bounds__(512) void wgrad_fused_kernel(const uint16_t* __rest
     }
 }
 
-__global__ __launch_bounds__(256) void fused_slab_reduce_kernel(const float* __restrict__ slab, int64_t n, int S, float* __restrict__ dst, int accumulate) {
-    __shared__ float part[16][17];
-    const int e = threadIdx.x & 15, p = threadIdx.x >> 4;
-    for (int64_t base = (int64_t)blockIdx.x * 16; base < n; base += (int64_t)gridDim.x * 16) {
-        const int64_t i = base + e;
-        float v = 0.f;
-        if (i < n) {
-#pragma unroll 4
-            for (int s = p; s < S; s += 16) v += slab[(size_t)s * n + i];
-        }
-        part[p][e] = v;
-        __syncthreads();
-        if (p == 0 && i < n) {
-            float t = accumulate ? dst[i] : 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) t += part[q][e];
-            dst[i] = t;
-        }
-        __syncthreads();
-    }
-}
-
-static int g_fused_variant = 0;   // tuning knob: bit 0 = XCD-aware block order, bit 1 = non-temporal streaming operands
-extern "C" void mg_debug_set_fused_variant(int v) { g_fused_variant = v; }
 
 static void fused_plan(int64_t M, int N, int* S, int* m_chunk) {
     const int tiles_n = N / F_BNT;
@@ -300,7 +253,7 @@ static void fused_plan(int64_t M, int N, int* S, int* m_chunk) {
         s *= 2;
         chunk = mg_align_up((size_t)mg_ceil_div(M, s), 32);
     }
-    *S = (int)mg_align_up((size_t)mg_ceil_div(M, chunk), 8);     // multiple of 8 (XCD-aware order); empty splits write zeros
+    *S = (int)mg_ceil_div(M, chunk);
     *m_chunk = (int)chunk;
 }
 
@@ -331,21 +284,12 @@ int mg_linear_bwd_fused_bf16(const uint16_t* dZ2, int lddz, int N2, const uint16
     float* slab = (float*)workspace;
     float* bslab = slab + (size_t)S * N * K;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)((N / F_BNT) * S)), block(512);
-#define LAUNCH_FUSED(X_, NT_) hipLaunchKernelGGL((wgrad_fused_kernel<X_, NT_>), grid, block, 0, st, dZ2, lddz, W2T, ldwt, H1, ldh, A, lda, rows, M, N, K, chunk, slab, bslab)
-    switch (g_fused_variant) {
-        case 1: LAUNCH_FUSED(1, 0); break;
-        case 2: LAUNCH_FUSED(0, 1); break;
-        case 3: LAUNCH_FUSED(1, 1); break;
-        default: LAUNCH_FUSED(0, 0); break;
-    }
-#undef LAUNCH_FUSED
+    hipLaunchKernelGGL(wgrad_fused_kernel, dim3((unsigned)((N / F_BNT) * S)), dim3(512), 0, st, dZ2, lddz, W2T, ldwt, H1, ldh, A, lda, rows, M,
+                       N, K, chunk, slab, bslab);
     MG_CHECK_LAUNCH("mg_linear_bwd_fused_bf16/main");
     const int64_t nk = (int64_t)N * K;
-    int64_t blocks = mg_ceil_div(nk, 16);
-    if (blocks > 32768) blocks = 32768;
-    hipLaunchKernelGGL(fused_slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, slab, nk, S, dW, accumulate);
-    hipLaunchKernelGGL(fused_slab_reduce_kernel, dim3((unsigned)mg_ceil_div(N, 16)), dim3(256), 0, st, bslab, (int64_t)N, S, db, accumulate);
+    mg_launch_slab_reduce(slab, nk, nk, S, dW, accumulate, st);
+    mg_launch_slab_reduce(bslab, N, N, S, db, accumulate, st);
     MG_CHECK_LAUNCH("mg_linear_bwd_fused_bf16/reduce");
     return MG_OK;
 }

@@ -16,6 +16,7 @@
 // The layer-1 gather (upsample_to_repetitions) is fused into the A-tile loaders through the `rows` array.
 // Epilogues stage the fp32 accumulators through LDS so that every global store is a 16-byte lane (8 bf16).
 #include "common.h"
+#include "slab_reduce.h"
 
 typedef __bf16 bfv8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bfv4 __attribute__((ext_vector_type(4)));
@@ -343,29 +344,6 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const uint16_t* __restr
     if (do_bias && tid < BNT && n0 + tid < N) bslab[(size_t)s * N + n0 + tid] = bsum;
 }
 
-__global__ __launch_bounds__(256) void slab_reduce_bf16path_kernel(const float* __restrict__ slab, int64_t n, int S, float* __restrict__ dst, int accumulate) {
-    // 16 consecutive elements x 16 slab partitions per workgroup: partition p sums slabs p, p+16, ... in ascending
-    // order, the 16 partials are then added in ascending p (fixed order -> bitwise reproducible).
-    __shared__ float part[16][17];
-    const int e = threadIdx.x & 15, p = threadIdx.x >> 4;
-    for (int64_t base = (int64_t)blockIdx.x * 16; base < n; base += (int64_t)gridDim.x * 16) {
-        const int64_t i = base + e;
-        float v = 0.f;
-        if (i < n) {
-#pragma unroll 4
-            for (int s = p; s < S; s += 16) v += slab[(size_t)s * n + i];
-        }
-        part[p][e] = v;
-        __syncthreads();
-        if (p == 0 && i < n) {
-            float t = accumulate ? dst[i] : 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) t += part[q][e];
-            dst[i] = t;
-        }
-        __syncthreads();
-    }
-}
 
 struct WgradPlanB {
     int tiles_n, tiles_k, S;
@@ -497,12 +475,10 @@ int mg_linear_wgrad_bf16(const uint16_t* dY, int lddy, const uint16_t* A, int ld
         hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, dY, lddy, A, lda, rows, M, N, K, p.m_chunk, slab, db ? bslab : nullptr, p.tiles_k);
     MG_CHECK_LAUNCH("mg_linear_wgrad_bf16/partial");
     const int64_t nk = (int64_t)N * K;
-    int64_t blocks = mg_ceil_div(nk, 16);
-    if (blocks > 32768) blocks = 32768;
-    hipLaunchKernelGGL(slab_reduce_bf16path_kernel, dim3((unsigned)blocks), dim3(256), 0, st, slab, nk, p.S, dW, accumulate);
+    mg_launch_slab_reduce(slab, nk, nk, p.S, dW, accumulate, st);
     MG_CHECK_LAUNCH("mg_linear_wgrad_bf16/reduce");
     if (db) {
-        hipLaunchKernelGGL(slab_reduce_bf16path_kernel, dim3((unsigned)mg_ceil_div(N, 16)), dim3(256), 0, st, bslab, (int64_t)N, p.S, db, accumulate);
+        mg_launch_slab_reduce(bslab, N, N, p.S, db, accumulate, st);
         MG_CHECK_LAUNCH("mg_linear_wgrad_bf16/reduce_bias");
     }
     return MG_OK;

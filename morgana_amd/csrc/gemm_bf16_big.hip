@@ -1,19 +1,20 @@
 // K2 (bf16 throughput mode), large-tile kernels for the shapes that dominate the step:
-//   gemm_nt_big   C[M,N] = epi(A'[M,K] B[N,K]^T)    256 x {256,128} tiles, BK = 64      (forward, dgrad)
-//   wgrad_big     dW[N,K] = dY[M,N]^T A'[M,K]        128 x {640,512} tiles over split M    (weight gradients)
+//   gemm_nt_big   C[M,N] = epi(A'[M,K] B[N,K]^T)    256 x {256,128} tiles, BK = 32, 4 LDS stages   (forward, dgrad)
+//   wgrad_big     dW[N,K] = dY[M,N]^T A'[M,K]        128 x {640,512} tiles over split M, 3 stages   (weight gradients)
 // Reference: the nn.Linear + nn.Sigmoid stack of README.rst:65-73 (morgana/utils.py:401-418) and its backward.
 //
-// Why these shapes (measured on MI355X with the 128 x 128 kernels of gemm_bf16.hip, profiles/r1_*):
-//   * a 128 x 128 x 32 tile moves 16 KB through L2->LDS per 1 MFLOP; at the ~30 B/clk a CU sustains from L2 that caps
-//     the MFMA pipe below 50 %.  256 x 256 x 64 moves 64 KB per 8.4 MFLOP (2x the FLOP per byte).
+// Why these shapes (measured on MI355X with the 128 x 128 kernels of gemm_bf16.hip, profiles/):
+//   * a 128 x 128 x 32 tile moves 16 KB through L2->LDS per 1 MFLOP, a 256 x 256 tile half of that per FLOP;
 //   * the 128 x 128 wgrad re-read dZ1 (262 MB) once per 128-wide K tile: FETCH_SIZE 0.71 GB (x2 on gfx950) per launch.
 //     A 128 x 640 tile covers all of K, so dY is read exactly once; X (the gathered phone rows) comes from L2/MALL.
 // Mechanics (cdna_hip_programming.md section 5): tiles are filled by global_load_lds_dwordx4 (LDS-DMA: no VGPR staging,
-// no ds_write), two LDS stages, the next tile's DMA stays in flight across a raw s_barrier behind a COUNTED
-// s_waitcnt vmcnt(N); the LDS image is lane-linear, so the bank swizzle is applied to the per-lane SOURCE address and
-// again on the fragment reads (the same involution on both sides).  The per-lane source address is also what fuses
-// the upsample gather: a lane simply points at its phone row (or at a zero row for the -1 pad index).
+// no ds_write), several LDS stages, the next stages' DMA stays in flight across a raw s_barrier behind a COUNTED
+// s_waitcnt vmcnt(N) (one barrier per stage); the LDS image is lane-linear, so the bank swizzle is applied to the per-lane
+// SOURCE address and again on the fragment reads (the same involution on both sides).  The per-lane source address is
+// also what fuses the upsample gather: a lane simply points at its phone row (or at a zero row for the -1 pad index).
 // 512 threads = 8 waves, one workgroup per CU (2 waves per SIMD).
+// Tried and dropped (all within +-8 % on the layer-1 forward shape): 128 x 256 tiles x 2 workgroups per CU,
+// 128 x 128 x 3 per CU, 3 instead of 4 stages, two 64-deep stages, XCD-grouped wgrad block order, non-temporal streams.
 #include "common.h"
 
 typedef __bf16 bfv8 __attribute__((ext_vector_type(8)));
@@ -58,7 +59,7 @@ __device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + 
 // ---------------------------------------------------------------------------------------------------------------------
 #define NT_STAGES 4
 
-template <int BN, int EPI, int ABL = 0>
+template <int BN, int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
                                                           int64_t M, int K, const uint16_t* __restrict__ Bm, int ldb, int N,
                                                           const float* __restrict__ bias, const uint16_t* __restrict__ H, int ldh,
@@ -120,7 +121,6 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __rest
 
     auto issue = [&](int kt) {
         unsigned char* st = smem + (kt & (NT_STAGES - 1)) * STAGE;
-        if ((ABL == 1 || ABL == 3 || ABL == 4) && kt > 0) return;   // ablation: no DMA after the first tile (timing only)
 #pragma unroll
         for (int i = 0; i < GA; ++i) glds16(asrc[i] + kt * 32, st + (wave * GA + i) * 1024);
 #pragma unroll
@@ -163,8 +163,6 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __rest
         }
         if (kt + 3 < n_kt) issue(kt + 3);        // refills the stage every wave finished reading before this barrier
         const unsigned char* st = smem + (kt & (NT_STAGES - 1)) * STAGE;
-        if (ABL == 2 || ABL == 3) continue;        // ablation: DMA only / neither
-        if (ABL == 4) st = smem;                   // ablation: fragments always from stage 0 (loop-invariant reads)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bfv8 a[TM], b[TN];
@@ -299,227 +297,6 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// gemm_nt_cfg: the same pipeline with every geometry knob a template parameter, so that SEVERAL independent workgroups
-// fit one CU (e.g. 128 x 256 tiles, 256 threads, 3 stages = 72 KB LDS -> two workgroups per CU): while one workgroup
-// sits in its prologue (row-index loads, first DMA), epilogue (sigmoid, stores) or at a barrier, the other one owns
-// the matrix pipe.  With one 512-thread workgroup per CU those phases are dead time (ablation in profiles/r1: 233 us
-// without any DMA versus 63 us of pure MFMA time on the layer-1 forward shape).
-// ---------------------------------------------------------------------------------------------------------------------
-template <int N>
-__device__ __forceinline__ void wait_vm_barrier() { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory"); }
-
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI, int WGS_PER_CU>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WGS_PER_CU * WAVES_M * WAVES_N / 4)
-void gemm_nt_cfg_kernel(const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows, int64_t M, int K,
-                        const uint16_t* __restrict__ Bm, int ldb, int N, const float* __restrict__ bias,
-                        const uint16_t* __restrict__ H, int ldh, void* __restrict__ Cv, int ldc, int tiles_m, int tiles_n,
-                        int c_f32) {
-    constexpr int NW = WAVES_M * WAVES_N;
-    constexpr int NT = 64 * NW;
-    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
-    constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
-    constexpr int STAGE = A_BYTES + B_BYTES;
-    constexpr int GA = BM / 16 / NW, GB = BN / 16 / NW;
-    constexpr int NL = GA + GB;
-    constexpr int STG_LD = 68;
-    constexpr int STG_BYTES = (EPI == EPI_SIGMOID_GRAD) ? NW * 32 * STG_LD * 4 : 0;
-    constexpr int LDS_BYTES = STAGES * STAGE > STG_BYTES ? STAGES * STAGE : STG_BYTES;
-    static_assert(GA >= 1 && GB >= 1 && TM >= 1 && TN >= 1, "tile too small for the wave grid");
-    static_assert(STAGES == 3 || STAGES == 4, "3 or 4 stages");
-
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
-
-    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
-    const int tile_n = jj % tiles_n;
-    const int tile_m = (jj / tiles_n) * 8 + xcd;
-    if (tile_m >= tiles_m) return;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
-    const int64_t m0 = (int64_t)tile_m * BM;
-    const int n0 = tile_n * BN;
-    const int n_kt = (K + 31) / 32;
-
-    const uint16_t* asrc[GA];
-    const uint16_t* bsrc[GB];
-#pragma unroll
-    for (int i = 0; i < GA; ++i) {
-        const int row = (wave * GA + i) * 16 + (lane >> 2);
-        const int c = (lane & 3) ^ ((row >> 2) & 3);
-        const int64_t m = m0 + row;
-        const uint16_t* p = g_zero_row;
-        if (m < M) {
-            if (rows) {
-                const int r = rows[m];
-                if (r >= 0) p = A + (size_t)r * lda;
-            } else {
-                p = A + (size_t)m * lda;
-            }
-        }
-        asrc[i] = p + c * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < GB; ++i) {
-        const int row = (wave * GB + i) * 16 + (lane >> 2);
-        const int c = (lane & 3) ^ ((row >> 2) & 3);
-        const int n = n0 + row;
-        bsrc[i] = (n < N ? Bm + (size_t)n * ldb : g_zero_row) + c * 8;
-    }
-    auto issue = [&](int kt) {
-        unsigned char* st = smem + (kt % STAGES) * STAGE;
-#pragma unroll
-        for (int i = 0; i < GA; ++i) glds16(asrc[i] + kt * 32, st + (wave * GA + i) * 1024);
-#pragma unroll
-        for (int i = 0; i < GB; ++i) glds16(bsrc[i] + kt * 32, st + A_BYTES + (wave * GB + i) * 1024);
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int lr = lane & 31, lh = lane >> 5;
-    int aoff[TM], boff[TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = wm0 + i * 32 + lr;
-        aoff[i] = row * 64 + ((lh ^ ((row >> 2) & 3)) << 4);
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int row = wn0 + j * 32 + lr;
-        boff[j] = A_BYTES + row * 64 + ((lh ^ ((row >> 2) & 3)) << 4);
-    }
-
-    issue(0);
-    if (n_kt > 1) issue(1);
-    if (STAGES == 4 && n_kt > 2) issue(2);
-    for (int kt = 0; kt < n_kt; ++kt) {
-        const int ahead = n_kt - 1 - kt;                 // tiles issued after tile kt that may stay in flight
-        if (STAGES == 4) {
-            if (ahead >= 2) wait_vm_barrier<2 * NL>(); else if (ahead == 1) wait_vm_barrier<NL>(); else wait_vm_barrier<0>();
-        } else {
-            if (ahead >= 1) wait_vm_barrier<NL>(); else wait_vm_barrier<0>();
-        }
-        if (kt + STAGES - 1 < n_kt) issue(kt + STAGES - 1);
-        const unsigned char* st = smem + (kt % STAGES) * STAGE;
-        bfv8 a[2][TM], b[2][TN];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[ks][i] = *reinterpret_cast<const bfv8*>(st + (aoff[i] ^ (ks << 5)));
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[ks][j] = *reinterpret_cast<const bfv8*>(st + (boff[j] ^ (ks << 5)));
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (EPI == EPI_SIGMOID_GRAD) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ks][j], a[ks][i], acc[i][j], 0, 0, 0);
-                }
-    }
-
-    if (EPI == EPI_SIGMOID_GRAD) {
-        WAIT_LGKM_BARRIER();
-        float* stg = reinterpret_cast<float*>(smem) + wave * 32 * STG_LD;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int jp = 0; jp < TN; jp += 2) {             // 64 columns per pass
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * STG_LD + j * 32 + lr] = acc[i][jp + j][r];
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int rl = it * 8 + (lane >> 3);
-                    const int cl = (lane & 7) * 8;
-                    const int64_t row = m0 + wm0 + i * 32 + rl;
-                    const int col = n0 + wn0 + jp * 32 + cl;
-                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(&stg[rl * STG_LD + cl]);
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(&stg[rl * STG_LD + cl + 4]);
-                    if (row >= M) continue;
-                    const bfv8 hv = *reinterpret_cast<const bfv8*>(H + (size_t)row * ldh + col);
-                    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float h = (float)hv[e];
-                        v[e] = v[e] * h * (1.f - h);
-                    }
-                    if (c_f32) {
-                        float* crow = reinterpret_cast<float*>(Cv) + (size_t)row * ldc + col;
-                        *reinterpret_cast<f32x4*>(crow) = f32x4{v[0], v[1], v[2], v[3]};
-                        *reinterpret_cast<f32x4*>(crow + 4) = f32x4{v[4], v[5], v[6], v[7]};
-                    } else {
-                        bfv8 o;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
-                        *reinterpret_cast<bfv8*>(reinterpret_cast<uint16_t*>(Cv) + (size_t)row * ldc + col) = o;
-                    }
-                }
-            }
-        }
-        return;
-    }
-
-    const float kNegLog2e = -1.4426950408889634f;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        float bv[16];
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bv[4 * g + e] = bias ? bias[n0 + wn0 + j * 32 + 8 * g + 4 * lh + e] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int64_t m = m0 + wm0 + i * 32 + lr;
-            const bool live = m < M;
-            const int cbase = n0 + wn0 + j * 32 + 4 * lh;
-            float v[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float x = acc[i][j][r] + bv[r];
-                if (EPI == EPI_BIAS_SIGMOID) x = __frcp_rn(1.f + exp2f(x * kNegLog2e));
-                v[r] = x;
-            }
-            if (c_f32) {
-                if (live) {
-                    float* crow = reinterpret_cast<float*>(Cv) + (size_t)m * ldc + cbase;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(crow + 8 * g) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
-                }
-            } else {
-                unsigned int pk[4][2];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    typedef __bf16 bfv2 __attribute__((ext_vector_type(2)));
-                    pk[g][0] = __builtin_bit_cast(unsigned int, bfv2{(__bf16)v[4 * g], (__bf16)v[4 * g + 1]});
-                    pk[g][1] = __builtin_bit_cast(unsigned int, bfv2{(__bf16)v[4 * g + 2], (__bf16)v[4 * g + 3]});
-                }
-                uint16_t* crow = reinterpret_cast<uint16_t*>(Cv) + (size_t)m * ldc + (n0 + wn0 + j * 32);
-#pragma unroll
-                for (int g = 0; g < 4; g += 2) {
-                    const auto r0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
-                    const auto r1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
-                    if (live) {
-                        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-                        *reinterpret_cast<u32x4_t*>(crow + 8 * g + 8 * lh) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
-                    }
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // wgrad_big: output tile 128 (n) x BKT (k), BKT = 64 * TKW (TKW = 10 -> 640, 8 -> 512); contraction over m in steps of 32,
 // THREE LDS stages (two steps of LDS-DMA in flight, one barrier per step).
 // LDS tiles are straight row copies ([m][n], [m][k]); fragments come from ds_read_b64_tr_b16.  16-byte chunk c of
@@ -530,7 +307,7 @@ void gemm_nt_cfg_kernel(const uint16_t* __restrict__ A, int lda, const int32_t* 
 #define WG_ROWS_MAX 4096
 #define WG_STAGES 3
 
-template <int TKW, int ABL = 0>
+template <int TKW>
 __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restrict__ dY, int lddy, const uint16_t* __restrict__ A, int lda,
                                                         const int32_t* __restrict__ rows, int64_t M, int N, int K, int m_chunk,
                                                         float* __restrict__ slab, float* __restrict__ bslab) {
@@ -582,7 +359,6 @@ __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restri
 
     auto issue = [&](int step) {                 // rows [32 step, 32 step + 32) of this workgroup's range
         unsigned char* st = smem + (step % WG_STAGES) * STAGE;
-        if (ABL == 1 && step > 0) return;
         {
             const int ml = step * 32 + y_row;
             const uint16_t* p = (ml < n_rows) ? dY + (size_t)(m_lo + ml) * lddy + n0 + y_c * 8 : g_zero_row;
@@ -652,7 +428,6 @@ __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restri
         }
         if (step + 2 < n_steps) issue(step + 2);  // refills the stage every wave finished reading before this barrier
         const unsigned char* st = smem + (step % WG_STAGES) * STAGE;
-        if (ABL == 2) continue;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bfv8 a[2], b[TKT];
@@ -722,11 +497,6 @@ __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restri
 // Launch helpers used by the entry points in gemm_bf16.hip.  Each returns 1 if it launched, 0 if the shape does not
 // qualify (the caller then uses the generic 128 x 128 kernels), negative on error.
 // ---------------------------------------------------------------------------------------------------------------------
-static int g_variant = 0;    // debug / tuning: selects the NT tile geometry (0 = default)
-extern "C" void mg_debug_set_variant(int v) { g_variant = v; }
-static int g_ablation = 0;   // debug / profiling only: 1 = no DMA after the first tile, 2 = DMA only (results invalid)
-extern "C" void mg_debug_set_ablation(int v) { g_ablation = v; }
-
 static bool big16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 
 int mg_try_nt_big(const uint16_t* A, int lda, const int32_t* rows, int64_t M, int K, const uint16_t* Bm, int ldb, int N,
@@ -743,34 +513,7 @@ int mg_try_nt_big(const uint16_t* A, int lda, const int32_t* rows, int64_t M, in
     if (blocks >= 2147483647LL || tiles_m >= 2147483647LL) return 0;
     dim3 grid((unsigned)blocks), block(512);
 #define LAUNCH_NT(BN_, EPI_) hipLaunchKernelGGL((gemm_nt_big_kernel<BN_, EPI_>), grid, block, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, H, ldh, C, ldc, (int)tiles_m, tiles_n, c_f32)
-#define LAUNCH_CFG(BM_, BN_, WM_, WN_, ST_, EPI_, WG_)                                                                          \
-    do {                                                                                                                   \
-        const int tn_ = N / BN_;                                                                                           \
-        const int64_t tm_ = mg_ceil_div(M, BM_);                                                                           \
-        const int64_t nb_ = mg_ceil_div(tm_, 8) * 8 * tn_;                                                                 \
-        hipLaunchKernelGGL((gemm_nt_cfg_kernel<BM_, BN_, WM_, WN_, ST_, EPI_, WG_>), dim3((unsigned)nb_), dim3(64 * WM_ * WN_), 0, st, \
-                           A, lda, rows, M, K, Bm, ldb, N, bias, H, ldh, C, ldc, (int)tm_, tn_, c_f32);                     \
-    } while (0)
-#define LAUNCH_CFG_EPI(BM_, BN_, WM_, WN_, ST_, WG_)                                     \
-    do {                                                                                 \
-        if (epi == EPI_BIAS) LAUNCH_CFG(BM_, BN_, WM_, WN_, ST_, EPI_BIAS, WG_);          \
-        else if (epi == EPI_BIAS_SIGMOID) LAUNCH_CFG(BM_, BN_, WM_, WN_, ST_, EPI_BIAS_SIGMOID, WG_); \
-        else LAUNCH_CFG(BM_, BN_, WM_, WN_, ST_, EPI_SIGMOID_GRAD, WG_);                  \
-    } while (0)
-    if (g_variant == 1 && wide) { LAUNCH_CFG_EPI(128, 256, 2, 2, 3, 2); return 1; }      // 2 WGs/CU, 72 KB each
-    if (g_variant == 2) { LAUNCH_CFG_EPI(128, 128, 2, 2, 3, 3); return 1; }              // 3 WGs/CU, 48 KB each
-    if (g_variant == 3 && wide) { LAUNCH_CFG_EPI(256, 256, 2, 4, 4, 1); return 1; }      // same geometry as the default
-    if (g_variant == 4) { LAUNCH_CFG_EPI(128, 128, 2, 2, 4, 2); return 1; }              // 2 WGs/CU, 64 KB each, 4 stages
-    if (g_variant == 5 && wide) { LAUNCH_CFG_EPI(256, 256, 2, 4, 3, 1); return 1; }      // 3 stages, 96 KB
-    if (wide && epi == EPI_BIAS_SIGMOID && g_ablation == 1) {
-        hipLaunchKernelGGL((gemm_nt_big_kernel<256, EPI_BIAS_SIGMOID, 1>), grid, block, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, H, ldh, C, ldc, (int)tiles_m, tiles_n, c_f32);
-    } else if (wide && epi == EPI_BIAS_SIGMOID && g_ablation == 2) {
-        hipLaunchKernelGGL((gemm_nt_big_kernel<256, EPI_BIAS_SIGMOID, 2>), grid, block, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, H, ldh, C, ldc, (int)tiles_m, tiles_n, c_f32);
-    } else if (wide && epi == EPI_BIAS_SIGMOID && g_ablation == 3) {
-        hipLaunchKernelGGL((gemm_nt_big_kernel<256, EPI_BIAS_SIGMOID, 3>), grid, block, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, H, ldh, C, ldc, (int)tiles_m, tiles_n, c_f32);
-    } else if (wide && epi == EPI_BIAS_SIGMOID && g_ablation == 4) {
-        hipLaunchKernelGGL((gemm_nt_big_kernel<256, EPI_BIAS_SIGMOID, 4>), grid, block, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, H, ldh, C, ldc, (int)tiles_m, tiles_n, c_f32);
-    } else if (wide) {
+    if (wide) {
         if (epi == EPI_BIAS) LAUNCH_NT(256, EPI_BIAS);
         else if (epi == EPI_BIAS_SIGMOID) LAUNCH_NT(256, EPI_BIAS_SIGMOID);
         else LAUNCH_NT(256, EPI_SIGMOID_GRAD);
@@ -804,11 +547,7 @@ int mg_wgrad_big_plan(int64_t M, int N, int K, int lda, int lddy, int* S_out, in
 int mg_launch_wgrad_big(const uint16_t* dY, int lddy, const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K,
                         int S, int m_chunk, float* slab, float* bslab, hipStream_t st) {
     dim3 grid((unsigned)((N / 128) * S)), block(512);
-    if (lda == 640 && g_ablation == 1)
-        hipLaunchKernelGGL((wgrad_big_kernel<10, 1>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab);
-    else if (lda == 640 && g_ablation == 2)
-        hipLaunchKernelGGL((wgrad_big_kernel<10, 2>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab);
-    else if (lda == 640)
+    if (lda == 640)
         hipLaunchKernelGGL((wgrad_big_kernel<10>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab);
     else
         hipLaunchKernelGGL((wgrad_big_kernel<8>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab);

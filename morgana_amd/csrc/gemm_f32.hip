@@ -15,6 +15,7 @@
 // The layer-1 gather (upsample_to_repetitions) is fused into the A-tile loader: the (B*T, 600) frame-rate input
 // never exists in HBM.
 #include "common.h"
+#include "slab_reduce.h"
 
 #define GK 16  // contraction depth of one LDS tile
 
@@ -320,30 +321,6 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const float* __restrict_
     if (do_bias && tid < BNT && n0 + tid < N) bslab[(size_t)s * N + n0 + tid] = bsum;
 }
 
-// dst[i] = (accumulate ? dst[i] : 0) + sum_s slab[s][i], s ascending (deterministic).
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int64_t n, int S, float* __restrict__ dst, int accumulate) {
-    // 16 consecutive elements x 16 slab partitions per workgroup: partition p sums slabs p, p+16, ... in ascending
-    // order, the 16 partials are then added in ascending p (fixed order -> bitwise reproducible).
-    __shared__ float part[16][17];
-    const int e = threadIdx.x & 15, p = threadIdx.x >> 4;
-    for (int64_t base = (int64_t)blockIdx.x * 16; base < n; base += (int64_t)gridDim.x * 16) {
-        const int64_t i = base + e;
-        float v = 0.f;
-        if (i < n) {
-#pragma unroll 4
-            for (int s = p; s < S; s += 16) v += slab[(size_t)s * n + i];
-        }
-        part[p][e] = v;
-        __syncthreads();
-        if (p == 0 && i < n) {
-            float t = accumulate ? dst[i] : 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) t += part[q][e];
-            dst[i] = t;
-        }
-        __syncthreads();
-    }
-}
 
 static bool aligned16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 
@@ -468,12 +445,10 @@ int mg_linear_wgrad_f32(const float* dY, const float* A, int lda, const int32_t*
         hipLaunchKernelGGL((wgrad_f32_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, dY, N, A, lda, rows, M, N, K, p.m_chunk, slab, db ? bslab : nullptr, p.tiles_k, vec_y, vec_a);
     MG_CHECK_LAUNCH("mg_linear_wgrad_f32/partial");
     const int64_t nk = (int64_t)N * K;
-    int64_t blocks = mg_ceil_div(nk, 16);
-    if (blocks > 32768) blocks = 32768;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, slab, nk, p.S, dW, accumulate);
+    mg_launch_slab_reduce(slab, nk, nk, p.S, dW, accumulate, st);
     MG_CHECK_LAUNCH("mg_linear_wgrad_f32/reduce");
     if (db) {
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)mg_ceil_div(N, 16)), dim3(256), 0, st, bslab, (int64_t)N, p.S, db, accumulate);
+        mg_launch_slab_reduce(bslab, N, N, p.S, db, accumulate, st);
         MG_CHECK_LAUNCH("mg_linear_wgrad_f32/reduce_bias");
     }
     return MG_OK;

@@ -15,6 +15,7 @@
 // Partial sums are reduced lane -> wave -> workgroup in a fixed order and finished by an ordered slab reduce
 // (deterministic, no atomics).
 #include "common.h"
+#include "slab_reduce.h"
 
 typedef __bf16 bfv8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bfv4 __attribute__((ext_vector_type(4)));
@@ -262,28 +263,6 @@ __global__ __launch_bounds__(256, 2) void f0_tail_kernel(const uint16_t* __restr
     for (int e = tid; e < TAIL_SLAB; e += 256) out[e] = red[e];
 }
 
-// dst[i] (+)= sum_s slab[s][i] in ascending s (16-way partitioned, fixed order), i < n.
-__global__ __launch_bounds__(256) void tail_reduce_kernel(const float* __restrict__ slab, int n, int stride, int S,
-                                                          float* __restrict__ dst, int accumulate) {
-    __shared__ float part[16][17];
-    const int e = threadIdx.x & 15, p = threadIdx.x >> 4;
-    for (int base = blockIdx.x * 16; base < n; base += gridDim.x * 16) {
-        const int i = base + e;
-        float v = 0.f;
-        if (i < n)
-            for (int s = p; s < S; s += 16) v += slab[(size_t)s * stride + i];
-        part[p][e] = v;
-        __syncthreads();
-        if (p == 0 && i < n) {
-            float t = accumulate ? dst[i] : 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) t += part[q][e];
-            dst[i] = t;
-        }
-        __syncthreads();
-    }
-}
-
 static int tail_blocks(int64_t M) {
     int64_t tiles = mg_ceil_div(M, 32);
     int64_t blocks = mg_ceil_div(tiles, 4);
@@ -315,8 +294,8 @@ int mg_f0_tail_bf16(const uint16_t* H2, int ldh, int K3, const float* W3, const 
     MG_CHECK_LAUNCH("mg_f0_tail_bf16/main");
     // grads = [dW3 (32*128) | db3 (32) | dW4 (32) | db4 (1)]; the loss is the last slab entry
     const int n_grads = TAIL_SLAB - 1;
-    hipLaunchKernelGGL(tail_reduce_kernel, dim3((n_grads + 15) / 16), dim3(256), 0, st, slab, n_grads, TAIL_SLAB, blocks, grads, accumulate);
-    hipLaunchKernelGGL(tail_reduce_kernel, dim3(1), dim3(256), 0, st, slab + (TAIL_SLAB - 1), 1, TAIL_SLAB, blocks, loss, 0);
+    mg_launch_slab_reduce(slab, n_grads, TAIL_SLAB, blocks, grads, accumulate, st);
+    mg_launch_slab_reduce(slab + (TAIL_SLAB - 1), 1, TAIL_SLAB, blocks, loss, 0, st);
     MG_CHECK_LAUNCH("mg_f0_tail_bf16/reduce");
     return MG_OK;
 }

@@ -41,16 +41,6 @@ def main():
         'wgrad2': (2.0 * m * 512 * 128, lambda: ops.linear_wgrad_bf16(dz2, h1, None, m, 128, 512)),
         'fused': (2.0 * m * 600 * 512 + 2.0 * m * 512 * 128, lambda: ops.linear_bwd_fused_bf16(dz2, w2t, h1, tab, rows, m, 512, 600)),
     }
-    import ctypes
-    from morgana_amd import _lib
-    lib = _lib.load()
-    abl = int(os.environ.get('MG_ABLATION', '0'))
-    lib.mg_debug_set_ablation(ctypes.c_int(abl))
-    var = int(os.environ.get('MG_VARIANT', '0'))
-    lib.mg_debug_set_variant(ctypes.c_int(var))
-    fvar = int(os.environ.get('MG_FUSED_VARIANT', '0'))
-    lib.mg_debug_set_fused_variant(ctypes.c_int(fvar))
-    print('ablation', abl, 'variant', var, 'fused_variant', fvar)
     for name in which:
         flops, fn = cases[name]
         for _ in range(2):
