@@ -161,7 +161,8 @@ int mg_sigmoid_grad_f32(const float* dy, const float* y, float* dx, int64_t n, v
  *   H2 bf16 [B*T, ldh] (the 128 sigmoid outputs of the previous layer); W3 f32 [32,128], b3 [32], W4 f32 [1,32], b4 [1];
  *   target f32 [B*T] (D = 1); seq_len int64 [B] or NULL; grad_scale multiplies dL/dpred.
  * Outputs: pred f32 [B*T]; loss f32 [1]; dZ2 bf16 [B*T, ldh] = dL/d(pre-activation of the 128-wide layer);
- *   grads f32 [32*128 + 32 + 32 + 1] = dW3 | db3 | dW4 | db4 (accumulate != 0 adds into it).
+ *   grads f32 [32*128 + 32 + 32 + 1] = dW3 | db3 | dW4 | db4 (accumulate != 0 adds into it).  If `loss` points at the
+ *   float right behind `grads` (and accumulate == 0) both are finished by a single reduce launch.
  * workspace: mg_f0_tail_workspace_bytes(B*T).  Deterministic. */
 size_t mg_f0_tail_workspace_bytes(int64_t M);
 int mg_f0_tail_bf16(const uint16_t* H2, int ldh, int K3, const float* W3, const float* b3, const float* W4, const float* b4,

@@ -294,8 +294,12 @@ int mg_f0_tail_bf16(const uint16_t* H2, int ldh, int K3, const float* W3, const 
     MG_CHECK_LAUNCH("mg_f0_tail_bf16/main");
     // grads = [dW3 (32*128) | db3 (32) | dW4 (32) | db4 (1)]; the loss is the last slab entry
     const int n_grads = TAIL_SLAB - 1;
-    mg_launch_slab_reduce(slab, n_grads, TAIL_SLAB, blocks, grads, accumulate, st);
-    mg_launch_slab_reduce(slab + (TAIL_SLAB - 1), 1, TAIL_SLAB, blocks, loss, 0, st);
+    if (loss == grads + n_grads && !accumulate) {
+        mg_launch_slab_reduce(slab, TAIL_SLAB, TAIL_SLAB, blocks, grads, 0, st);      // loss stored right behind the gradients
+    } else {
+        mg_launch_slab_reduce(slab, n_grads, TAIL_SLAB, blocks, grads, accumulate, st);
+        mg_launch_slab_reduce(slab + (TAIL_SLAB - 1), 1, TAIL_SLAB, blocks, loss, 0, st);
+    }
     MG_CHECK_LAUNCH("mg_f0_tail_bf16/reduce");
     return MG_OK;
 }

@@ -210,7 +210,7 @@ class LinearStackMSEFn(torch.autograd.Function):
         offsets = [0]
         for sz in sizes[:-1]:
             offsets.append(offsets[-1] + sz)
-        flat = torch.empty(sum(sizes), dtype=torch.float32, device=x2d.device)
+        flat = torch.empty(sum(sizes) + 1, dtype=torch.float32, device=x2d.device)    # + 1: the loss (see ops.f0_tail)
         tail_off = offsets[2 * lead]
         pred, loss, dz2 = ops.f0_tail(hidden[-1], weights[lead], biases[lead], weights[lead + 1], biases[lead + 1],
                                       target.reshape(-1), seq_len, b, t, flat[tail_off:])
@@ -247,7 +247,7 @@ class LinearStackMSEFn(torch.autograd.Function):
             if i > 0:
                 h = hidden[i - 1] if ctx.acts[i - 1] == ops.ACT_SIGMOID else None
                 g = ops.linear_dgrad_bf16(g, m, n, w_t[i], k, h)
-        grads = _deliver_param_grads(ctx.params, flat, ctx.offsets, grad_loss)
+        grads = _deliver_param_grads(ctx.params, flat[:flat.numel() - 1], ctx.offsets, grad_loss)
         return (None, None, None, None, None) + tuple(grads)
 
 

@@ -291,7 +291,9 @@ def f0_tail(h2, w3, b3, w4, b4, target, seq_len, b, t, grads_out, grad_scale=1.0
     lib = _lib.load()
     m = b * t
     pred = torch.empty((m,), dtype=torch.float32, device=h2.device)
-    loss = torch.empty((), dtype=torch.float32, device=h2.device)
+    n_grads = 32 * 128 + 32 + 32 + 1
+    # a gradient buffer with one spare float behind the tail's gradients receives the loss from the same reduce launch
+    loss = grads_out[n_grads] if grads_out.numel() > n_grads else torch.empty((), dtype=torch.float32, device=h2.device)
     dz2 = torch.empty_like(h2)
     nbytes = lib.mg_f0_tail_workspace_bytes(m)
     ws = workspace(nbytes, h2.device)
