@@ -191,6 +191,19 @@ int mg_gru_bwd_f32(const float* grad_out, const float* grad_hn, const float* hst
                    const int64_t* seq_len, int B, int T, int H, float* dxproj, float* dhproj, float* dh0, void* workspace,
                    size_t workspace_bytes, void* stream);
 
+/* LSTM through RecurrentCuDNNWrapper   reference: morgana/utils.py:345-393 + torch.nn.LSTM (gates i, f, g, o), the cell of
+ * the reference's shipped acoustic model (models/RNN_SPSS.py:36-37).  Same conventions as the GRU entry points:
+ *   xproj [B,T,4H] = x W_ih^T + b_ih; w_hh [4H,H]; b_hh [4H]; hstate / cstate [B,T+1,H] with slot 0 = (h0, c0) on entry;
+ *   out [B,T,H] zero on padded steps; saved [B,T,4H] = activated gates (i, f, g, o).
+ * Backward: dgates [B,T,4H] = dL/d(gate pre-activations) (feeds dW_ih, dW_hh, both biases and dx); dh0, dc0 [B,H];
+ *   grad_hn / grad_cn NULL or [B,H]; workspace mg_lstm_bwd_workspace_bytes(B,H). */
+int mg_lstm_fwd_f32(const float* xproj, const float* w_hh, const float* b_hh, const int64_t* seq_len, int B, int T, int H,
+                    float* hstate, float* cstate, float* out, float* saved, void* stream);
+size_t mg_lstm_bwd_workspace_bytes(int B, int H);
+int mg_lstm_bwd_f32(const float* grad_out, const float* grad_hn, const float* grad_cn, const float* cstate, const float* saved,
+                    const float* w_hh, const int64_t* seq_len, int B, int T, int H, float* dgates, float* dh0, float* dc0,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Optimiser / EMA                         reference: torch.optim.Adam at experiment_builder.py:516, :468-474;
  *                                         ExponentialMovingAverage.update_params, morgana/utils.py:443-456

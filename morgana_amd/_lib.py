@@ -58,6 +58,11 @@ SIGNATURES = {
     'mg_gru_bwd_workspace_bytes': (c_size_t, [c_int, c_int]),
     'mg_gru_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'mg_lstm_fwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p]),
+    'mg_lstm_bwd_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'mg_lstm_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'mg_adam_step_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                  c_float, c_int64, c_float, c_void_p]),
     'mg_ema_update_f32': (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),

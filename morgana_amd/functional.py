@@ -311,6 +311,66 @@ class GRUFn(torch.autograd.Function):
         return (None, dx, dh0.view(1, b, hid) if ctx.has_h0 else None, None, dw_ih, dw_hh, db_ih, db_hh)
 
 
+class LSTMFn(torch.autograd.Function):
+    """One LSTM layer (batch_first) restricted to seq_len[b] steps per item; returns (outputs, h_n, c_n)."""
+
+    @staticmethod
+    def forward(ctx, precision, x, h0, c0, seq_len, w_ih, w_hh, b_ih, b_hh):
+        x = ops._require(x, torch.float32, 'inputs')
+        b, t, i_dim = x.shape
+        hid = w_hh.shape[1]
+        x2 = x.view(b * t, i_dim)
+        if precision == 'fp32':
+            xproj = ops.linear_fwd_f32(x2, None, b * t, w_ih, b_ih, ops.ACT_NONE)
+            x_saved = x2
+        else:
+            x_saved = ops.cast_pad_bf16(x2)
+            xproj = ops.linear_fwd_bf16(x_saved, None, b * t, i_dim, ops.cast_pad_bf16(w_ih), b_ih, 4 * hid,
+                                        ops.ACT_NONE, out_f32=True)
+            if xproj.shape[1] != 4 * hid:
+                xproj = xproj[:, :4 * hid].contiguous()
+        out, hstate, cstate, saved = ops.lstm_fwd(xproj.view(b, t, 4 * hid), w_hh.contiguous(), b_hh.contiguous(), seq_len,
+                                                  h0, c0, b, t, hid)
+        ctx.precision = precision
+        ctx.shape = (b, t, i_dim, hid)
+        ctx.has_h0, ctx.has_c0 = h0 is not None, c0 is not None
+        ctx.save_for_backward(x_saved, seq_len, w_ih, w_hh, hstate, cstate, saved)
+        return out, hstate[:, t].unsqueeze(0).contiguous(), cstate[:, t].unsqueeze(0).contiguous()
+
+    @staticmethod
+    def backward(ctx, grad_out, grad_hn, grad_cn):
+        x_saved, seq_len, w_ih, w_hh, hstate, cstate, saved = ctx.saved_tensors
+        b, t, i_dim, hid = ctx.shape
+        dev = hstate.device
+        g_out = grad_out.contiguous() if grad_out is not None else torch.zeros((b, t, hid), dtype=torch.float32, device=dev)
+        g_hn = grad_hn.reshape(b, hid).contiguous() if grad_hn is not None else None
+        g_cn = grad_cn.reshape(b, hid).contiguous() if grad_cn is not None else None
+        dgates, dh0, dc0 = ops.lstm_bwd(g_out, g_hn, g_cn, cstate, saved, w_hh, seq_len, b, t, hid)
+        m = b * t
+        dg2 = dgates.view(m, 4 * hid)
+        prev_rows = (torch.arange(b, device=dev, dtype=torch.int32)[:, None] * (t + 1) +
+                     torch.arange(t, device=dev, dtype=torch.int32)[None, :]).reshape(-1).contiguous()
+        hs2 = hstate.view(b * (t + 1), hid)
+        need_x = ctx.needs_input_grad[1]
+        dx = None
+        if ctx.precision == 'fp32':
+            dw_ih, db = ops.linear_wgrad_f32(dg2, x_saved, None, 4 * hid, i_dim)
+            dw_hh, _ = ops.linear_wgrad_f32(dg2, hs2, prev_rows, 4 * hid, hid, want_bias=False)
+            if need_x:
+                dx = ops.linear_dgrad_f32(dg2, w_ih, None).view(b, t, i_dim)
+        else:
+            dg_bf = ops.cast_pad_bf16(dg2)
+            dw_ih, db = ops.linear_wgrad_bf16(dg_bf, x_saved, None, m, 4 * hid, i_dim)
+            dw_hh, _ = ops.linear_wgrad_bf16(dg_bf, ops.cast_pad_bf16(hs2), prev_rows, m, 4 * hid, hid, want_bias=False)
+            if need_x:
+                dx = ops.linear_dgrad_bf16(dg_bf, m, 4 * hid, ops.cast_transpose_bf16(w_ih), i_dim, None, out_f32=True)
+                if dx.shape[1] != i_dim:
+                    dx = dx[:, :i_dim].contiguous()
+                dx = dx.view(b, t, i_dim)
+        return (None, dx, dh0.view(1, b, hid) if ctx.has_h0 else None, dc0.view(1, b, hid) if ctx.has_c0 else None, None,
+                dw_ih, dw_hh, db, db.clone())
+
+
 class MaskedMSEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, predictions, targets, seq_len):

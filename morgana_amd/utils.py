@@ -86,10 +86,10 @@ def upsample_to_repetitions(sequence_feature, repeats, max_len=None, fused=False
 class RecurrentCuDNNWrapper(nn.Module):
     """Wraps a torch recurrent layer with the sort / pack / unpack semantics of morgana/utils.py:333-393.
 
-    ``nn.GRU`` (single layer, unidirectional, batch_first - the shape used by models/f0_test_model.py:32-39) runs on
-    the HIP recurrence; its parameters stay the wrapped layer's own (``layer.weight_ih_l0`` ...), so state_dict keys
-    match the reference.  Other layers (LSTM, multi-layer, bidirectional) are outside this round's scope and run
-    through torch's packed-sequence path on the device.
+    ``nn.GRU`` (single layer, unidirectional, batch_first - the shape used by models/f0_test_model.py:32-39) and
+    ``nn.LSTM`` (any number of layers, unidirectional, batch_first - models/RNN_SPSS.py:36-37) run on the HIP recurrences;
+    the parameters stay the wrapped layer's own (``layer.weight_ih_l0`` ...), so state_dict keys match the reference.
+    Other layer types (bidirectional, projections, multi-layer GRU) run through torch's packed-sequence path on the device.
     """
 
     def __init__(self, layer, precision=None):
@@ -101,6 +101,28 @@ class RecurrentCuDNNWrapper(nn.Module):
         layer = self.layer
         return (isinstance(layer, nn.GRU) and layer.num_layers == 1 and not layer.bidirectional and layer.batch_first
                 and layer.bias and getattr(layer, 'proj_size', 0) == 0)
+
+    def _hip_lstm(self):
+        layer = self.layer
+        return (isinstance(layer, nn.LSTM) and not layer.bidirectional and layer.batch_first and layer.bias and
+                getattr(layer, 'proj_size', 0) == 0 and (layer.dropout == 0 or not layer.training))
+
+    def _run_lstm(self, inputs, hidden, seq_len):
+        """nn.LSTM with num_layers >= 1 as a chain of single-layer HIP recurrences; hidden = (h0, c0), each
+        (num_layers, B, H), returned in the same layout (utils.py:374-375, 388-389)."""
+        layer = self.layer
+        precision = self.precision or F_hip.get_precision()
+        h0s, c0s = (None, None) if hidden is None else hidden
+        out, hns, cns = inputs, [], []
+        for k in range(layer.num_layers):
+            h0 = h0s[k:k + 1] if h0s is not None else None
+            c0 = c0s[k:k + 1] if c0s is not None else None
+            out, hn, cn = F_hip.LSTMFn.apply(precision, out.contiguous(), h0, c0, seq_len,
+                                             getattr(layer, 'weight_ih_l%d' % k), getattr(layer, 'weight_hh_l%d' % k),
+                                             getattr(layer, 'bias_ih_l%d' % k), getattr(layer, 'bias_hh_l%d' % k))
+            hns.append(hn)
+            cns.append(cn)
+        return out, (torch.cat(hns, dim=0), torch.cat(cns, dim=0))
 
     def _run_gru(self, inputs, hidden, seq_len):
         layer = self.layer
@@ -117,6 +139,8 @@ class RecurrentCuDNNWrapper(nn.Module):
                 inputs = inputs.unsqueeze(seq_dim)
                 if self._hip_gru():
                     outputs, hidden = self._run_gru(inputs.contiguous(), hidden, None)
+                elif self._hip_lstm():
+                    outputs, hidden = self._run_lstm(inputs.contiguous(), hidden, None)
                 else:
                     outputs, hidden = self.layer(inputs, hx=hidden)
                 return outputs.squeeze(seq_dim), hidden
@@ -124,12 +148,13 @@ class RecurrentCuDNNWrapper(nn.Module):
                 raise ValueError('If no seq_len is provided to RecurrentCuDNNWrapper the data must be already packed'
                                  f'or must be for one time slice only. For non-packed input got shape, {inputs.shape}')
 
-        if self._hip_gru():
+        if self._hip_gru() or self._hip_lstm():
             seq_len = seq_len if seq_len.dtype == torch.int64 else seq_len.long()
             t_out = int(torch.max(seq_len).item())          # pad_packed_sequence crops to the longest item
             if t_out != inputs.shape[1]:
                 inputs = inputs[:, :t_out]
-            return self._run_gru(inputs.contiguous(), hidden, seq_len.contiguous())
+            run = self._run_gru if self._hip_gru() else self._run_lstm
+            return run(inputs.contiguous(), hidden, seq_len.contiguous())
 
         # Out-of-scope layer types: the reference's own torch path (utils.py:366-391).
         sorted_idxs = torch.argsort(seq_len, descending=True)

@@ -475,3 +475,49 @@ def g8_plumbing():
 
 if __name__ == '__main__' and (len(sys.argv) == 1 or sys.argv[1] == 'g8'):
     g8_plumbing()
+
+
+def g10_lstm():
+    """G10: RecurrentCuDNNWrapper(nn.LSTM) of the reference: 1 and 2 layers, ragged seq_len, with and without (h0, c0)."""
+    import torch
+    import torch.nn as nn
+    from morgana_amd import synthetic
+    utils, losses, data, base_models, lr_schedules, metrics = import_reference()
+    rng = np.random.RandomState(1010)
+    g = {}
+    for tag, (layers, bsz, t_in, i_dim, hid, lens) in {'l1': (1, 4, 9, 5, 8, [6, 9, 1, 4]), 'l2': (2, 5, 11, 12, 16, [11, 3, 7, 11, 2])}.items():
+        lstm = nn.LSTM(i_dim, hid, num_layers=layers, batch_first=True)
+        prm_rng = np.random.RandomState(77 + hid)
+        with torch.no_grad():
+            for name, prm in lstm.named_parameters():
+                prm.copy_(torch.from_numpy(prm_rng.uniform(-0.4, 0.4, size=tuple(prm.shape)).astype(np.float32)))
+                g['%s__param__%s' % (tag, name)] = prm.detach().numpy().copy()
+        wrapper = utils.RecurrentCuDNNWrapper(lstm)
+        x = torch.from_numpy(rng.standard_normal((bsz, t_in, i_dim)).astype(np.float32)).requires_grad_(True)
+        sl = torch.tensor(lens, dtype=torch.int64)
+        out, (hn, cn) = wrapper(x, None, sl)
+        gout = torch.from_numpy(rng.standard_normal(tuple(out.shape)).astype(np.float32))
+        (out * gout).sum().backward()
+        g[tag + '__x'], g[tag + '__seq_len'] = x.detach().numpy(), sl.numpy()
+        g[tag + '__out'], g[tag + '__hn'], g[tag + '__cn'] = out.detach().numpy(), hn.detach().numpy(), cn.detach().numpy()
+        g[tag + '__grad_out'], g[tag + '__grad_x'] = gout.numpy(), x.grad.numpy().copy()
+        for name, prm in lstm.named_parameters():
+            g['%s__grad__%s' % (tag, name)] = prm.grad.numpy().copy()
+            prm.grad = None
+        x.grad = None
+        h0 = torch.from_numpy(rng.standard_normal((layers, bsz, hid)).astype(np.float32)).requires_grad_(True)
+        c0 = torch.from_numpy(rng.standard_normal((layers, bsz, hid)).astype(np.float32)).requires_grad_(True)
+        ghn = torch.from_numpy(rng.standard_normal((layers, bsz, hid)).astype(np.float32))
+        gcn = torch.from_numpy(rng.standard_normal((layers, bsz, hid)).astype(np.float32))
+        out, (hn, cn) = wrapper(x, (h0, c0), sl)
+        ((out * gout).sum() + (hn * ghn).sum() + (cn * gcn).sum()).backward()
+        g[tag + '__h0'], g[tag + '__c0'], g[tag + '__grad_hn'], g[tag + '__grad_cn'] = h0.detach().numpy(), c0.detach().numpy(), ghn.numpy(), gcn.numpy()
+        g[tag + '__out_s'], g[tag + '__hn_s'], g[tag + '__cn_s'] = out.detach().numpy(), hn.detach().numpy(), cn.detach().numpy()
+        g[tag + '__grad_x_s'], g[tag + '__grad_h0'], g[tag + '__grad_c0'] = x.grad.numpy().copy(), h0.grad.numpy().copy(), c0.grad.numpy().copy()
+        g[tag + '__grad_whh0_s'] = lstm.weight_hh_l0.grad.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, 'g10_lstm.npz'), **g)
+    print('g10_lstm.npz', os.path.getsize(os.path.join(HERE, 'g10_lstm.npz')), 'bytes')
+
+
+if __name__ == '__main__' and (len(sys.argv) == 1 or sys.argv[1] == 'g10'):
+    g10_lstm()

@@ -488,6 +488,70 @@ def test_gru_wrapper_errors_and_single_step():
                                atol=1e-6)
 
 
+@pytest.mark.parametrize('tag,layers', [('l1', 1), ('l2', 2)])
+def test_lstm_wrapper_golden(golden, tag, layers):
+    """RecurrentCuDNNWrapper(nn.LSTM), 1 and 2 layers, against the reference's outputs, states and gradients (G10)."""
+    g = golden('g10_lstm.npz')
+    x_np, sl_np = g[tag + '__x'], g[tag + '__seq_len']
+    i_dim, hid = x_np.shape[2], g[tag + '__hn'].shape[2]
+    lstm = torch.nn.LSTM(i_dim, hid, num_layers=layers, batch_first=True).to(DEV)
+    with torch.no_grad():
+        for name, prm in lstm.named_parameters():
+            prm.copy_(dev(g['%s__param__%s' % (tag, name)]))
+    wrapper = utils.RecurrentCuDNNWrapper(lstm, precision='fp32')
+    x = dev(x_np).requires_grad_(True)
+    sl = dev(sl_np)
+    out, (hn, cn) = wrapper(x, None, sl)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g[tag + '__out'], rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(hn.detach().cpu().numpy(), g[tag + '__hn'], rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(cn.detach().cpu().numpy(), g[tag + '__cn'], rtol=RTOL, atol=1e-6)
+    for b, n in enumerate(sl_np):
+        assert torch.all(out[b, n:] == 0)
+    (out * dev(g[tag + '__grad_out'])).sum().backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g[tag + '__grad_x'], rtol=1e-3, atol=1e-5)
+    for name, prm in lstm.named_parameters():
+        np.testing.assert_allclose(prm.grad.cpu().numpy(), g['%s__grad__%s' % (tag, name)], rtol=1e-3, atol=1e-5)
+        prm.grad = None
+    x.grad = None
+    h0, c0 = dev(g[tag + '__h0']).requires_grad_(True), dev(g[tag + '__c0']).requires_grad_(True)
+    out, (hn, cn) = wrapper(x, (h0, c0), sl)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g[tag + '__out_s'], rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(hn.detach().cpu().numpy(), g[tag + '__hn_s'], rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(cn.detach().cpu().numpy(), g[tag + '__cn_s'], rtol=RTOL, atol=1e-6)
+    ((out * dev(g[tag + '__grad_out'])).sum() + (hn * dev(g[tag + '__grad_hn'])).sum() +
+     (cn * dev(g[tag + '__grad_cn'])).sum()).backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g[tag + '__grad_x_s'], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(h0.grad.cpu().numpy(), g[tag + '__grad_h0'], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(c0.grad.cpu().numpy(), g[tag + '__grad_c0'], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(lstm.weight_hh_l0.grad.cpu().numpy(), g[tag + '__grad_whh0_s'], rtol=1e-3, atol=1e-5)
+
+
+def test_lstm_512_two_layers_vs_oracle():
+    """The reference's shipped cell size (LSTM-512, models/RNN_SPSS.py:36-37) on the H = 512 fast path, bf16 GEMMs around."""
+    rng = np.random.RandomState(12)
+    b, t, hid = 6, 40, 512
+    lstm = torch.nn.LSTM(hid, hid, num_layers=2, batch_first=True).to(DEV)
+    params = []
+    with torch.no_grad():
+        for k in range(2):
+            layer = []
+            for name in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh'):
+                prm = getattr(lstm, '%s_l%d' % (name, k))
+                val = rng.uniform(-0.05, 0.05, size=tuple(prm.shape)).astype(np.float32)
+                prm.copy_(dev(val))
+                layer.append(val)
+            params.append(layer)
+    x_np = rng.standard_normal((b, t, hid)).astype(np.float32)
+    sl_np = np.array([40, 13, 27, 40, 1, 33], dtype=np.int64)
+    want = x_np
+    for k in range(2):
+        want, hn, cn, _ = ref_cpu.lstm_forward(want, sl_np, *params[k])
+    for precision, tol in (('fp32', 1e-4), ('bf16', 2e-2)):
+        out, (h, c) = utils.RecurrentCuDNNWrapper(lstm, precision=precision)(dev(x_np), None, dev(sl_np))
+        assert rel_err(out.detach().cpu().numpy(), want) < tol, precision
+        assert rel_err(h[1].detach().cpu().numpy(), hn[0]) < tol
+
+
 def test_rnn_model_golden(golden):
     g = golden('g7_gru.npz')
     lab_dim, hidden, post, out_dim = [int(v) for v in g['rnn__dims']]

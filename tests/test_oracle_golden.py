@@ -228,3 +228,43 @@ def test_g9_ema_lr_mean(golden):
                                g['cyclic_noam_w4_trig'], rtol=1e-12)
     assert np.all(g['constant'] == 1.0)
     np.testing.assert_allclose(ref_cpu.metric_mean(g['mean_inputs']), g['mean_result'], rtol=1e-5)
+
+
+def _lstm_layers(g, tag, layers):
+    return [[g['%s__param__%s_l%d' % (tag, name, k)] for name in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+            for k in range(layers)]
+
+
+@pytest.mark.parametrize('tag,layers', [('l1', 1), ('l2', 2)])
+def test_g10_lstm_wrapper(golden, tag, layers):
+    """Oracle LSTM (forward + BPTT, chained for multi-layer) against the reference's RecurrentCuDNNWrapper(nn.LSTM)."""
+    g = golden('g10_lstm.npz')
+    params = _lstm_layers(g, tag, layers)
+    x, sl = g[tag + '__x'], g[tag + '__seq_len']
+    h0, c0 = g[tag + '__h0'], g[tag + '__c0']
+    inp, caches, inputs, hns, cns = x, [], [], [], []
+    for k in range(layers):
+        inputs.append(inp)
+        inp, hn, cn, cache = ref_cpu.lstm_forward(inp, sl, *params[k], h0=h0[k], c0=c0[k])
+        caches.append(cache)
+        hns.append(hn)
+        cns.append(cn)
+    np.testing.assert_allclose(inp, g[tag + '__out_s'], rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(np.concatenate(hns), g[tag + '__hn_s'], rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(np.concatenate(cns), g[tag + '__cn_s'], rtol=RTOL, atol=1e-6)
+    grad = g[tag + '__grad_out']
+    for k in range(layers - 1, -1, -1):
+        gr = ref_cpu.lstm_backward(grad, g[tag + '__grad_hn'][k], g[tag + '__grad_cn'][k], inputs[k], params[k][0],
+                                   params[k][1], caches[k])
+        np.testing.assert_allclose(gr['h0'][0], g[tag + '__grad_h0'][k], rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(gr['c0'][0], g[tag + '__grad_c0'][k], rtol=1e-3, atol=1e-5)
+        if k == 0:
+            np.testing.assert_allclose(gr['w_hh'], g[tag + '__grad_whh0_s'], rtol=1e-3, atol=1e-5)
+        grad = gr['x']
+    np.testing.assert_allclose(grad, g[tag + '__grad_x_s'], rtol=1e-3, atol=1e-5)
+    # without initial state: outputs only
+    inp = x
+    for k in range(layers):
+        inp, hn, cn, _ = ref_cpu.lstm_forward(inp, sl, *params[k])
+    assert inp.shape == g[tag + '__out'].shape
+    np.testing.assert_allclose(inp, g[tag + '__out'], rtol=RTOL, atol=1e-6)
