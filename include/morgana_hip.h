@@ -58,6 +58,15 @@ int mg_gather_rows_f32(const float* src, const int32_t* rows, float* out, int64_
 /* Same gather, output converted to bf16 with leading dimension ldo >= F; columns F..ldo-1 are zero filled. */
 int mg_gather_rows_bf16(const float* src, const int32_t* rows, uint16_t* out, int64_t M, int F, int ldo, void* stream);
 
+/* Gather fused with the frame-level concat the shipped models do right after it (models/RNN_SPSS.py:76-81,
+ * models/f0_test_model.py:78-79: upsample_to_repetitions, then torch.cat with `normalised_counters`):
+ *   out[m, 0:F] = src[rows[m], :] (0 where rows[m] < 0), out[m, F:F+C] = extra[m, 0:C], out[m, F+C:ldo] = 0.
+ * extra [M,C] f32.  The bf16 form needs ldo % 8 == 0 and produces the padded layer-1 operand directly. */
+int mg_gather_concat_f32(const float* src, const int32_t* rows, const float* extra, float* out, int64_t M, int F, int C,
+                         int ldo, void* stream);
+int mg_gather_concat_bf16(const float* src, const int32_t* rows, const float* extra, uint16_t* out, int64_t M, int F, int C,
+                          int ldo, void* stream);
+
 /* Adjoint of the gather (autograd of utils.py:226): grad_src[b,p,:] = sum of grad_out[b,t,:] over the frames of
  * phone p (frames of a phone are contiguous).  grad_out [B,T,F], dur int64 [B,P], grad_src [B,P,F]. Deterministic. */
 int mg_upsample_backward_f32(const float* grad_out, const int64_t* dur, float* grad_src, int B, int P, int T, int F,
@@ -81,6 +90,34 @@ size_t mg_masked_mse_workspace_bytes(int B, int T, int D);
 int mg_masked_mse_f32(const float* pred, const float* target, const int64_t* seq_len, int B, int T, int D,
                       float grad_scale, float* loss, float* grad, void* workspace, size_t workspace_bytes,
                       void* stream);
+
+/* Same contract with binary cross entropy as the per-element loss (reference: losses.bce, morgana/losses.py:54-56, used for
+ * the voicing stream at models/RNN_SPSS.py:137): -(y log p + (1-y) log(1-p)), logs clamped at -100 as torch does. */
+int mg_masked_bce_f32(const float* pred, const float* target, const int64_t* seq_len, int B, int T, int D,
+                      float grad_scale, float* loss, float* grad, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
+/* Multi-stream loss (reference: LSTMAcousticModel.loss, models/RNN_SPSS.py:120-139, with the torch.sigmoid of :93):
+ * pred [B,T,D] f32 holds the streams side by side (torch.split at :87-88); stream k covers columns col0..col0+width-1
+ * and is scored against its own target [B,T,width] (row stride ldt) with losses.mse (MG_LOSS_MSE) or with
+ * losses.bce(sigmoid(pred)) (MG_LOSS_SIGMOID_BCE).  loss = mean over streams of the per-stream sequence loss
+ * (the `loss / 4.` of :139).  grad [B,T,D] (may be NULL) = grad_scale * d loss / d pred, zero in columns no stream
+ * covers; prob [B,T,width] (may be NULL) receives sigmoid(pred) of the one BCE stream (`pred_vuv`, :93).
+ * `streams` is a HOST array, n_streams <= MG_STREAMS_MAX. */
+#define MG_STREAMS_MAX 8
+#define MG_LOSS_MSE 0
+#define MG_LOSS_SIGMOID_BCE 1
+typedef struct {
+    const float* target;
+    int ldt;
+    int col0;
+    int width;
+    int kind;
+} mg_stream_desc;
+size_t mg_stream_loss_workspace_bytes(int B, int T, int D);
+int mg_stream_loss_f32(const float* pred, const mg_stream_desc* streams, int n_streams, const int64_t* seq_len, int B, int T,
+                       int D, float grad_scale, float* loss, float* grad, float* prob, void* workspace,
+                       size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * K5  mvn / minmax normalisers            reference: morgana/data.py:533-538, 579-590

@@ -22,11 +22,18 @@ SIGNATURES = {
     'mg_upsample_index': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'mg_gather_rows_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     'mg_gather_rows_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    'mg_gather_concat_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    'mg_gather_concat_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     'mg_upsample_backward_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'mg_sequence_mask': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     'mg_masked_mse_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'mg_masked_mse_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
                                   c_void_p, c_size_t, c_void_p]),
+    'mg_masked_bce_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
+                                  c_void_p, c_size_t, c_void_p]),
+    'mg_stream_loss_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'mg_stream_loss_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_size_t, c_void_p]),
     'mg_normalise_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     'mg_linear_fwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                   c_int, c_int, c_void_p]),
@@ -76,7 +83,14 @@ class CastDesc(ctypes.Structure):
                 ('dst_t', c_void_p), ('ldt', c_int)]
 
 
+class StreamDesc(ctypes.Structure):
+    """mg_stream_desc of include/morgana_hip.h."""
+    _fields_ = [('target', c_void_p), ('ldt', c_int), ('col0', c_int), ('width', c_int), ('kind', c_int)]
+
+
 CAST_MAX = 16
+STREAMS_MAX = 8
+LOSS_MSE, LOSS_SIGMOID_BCE = 0, 1
 _lib = None
 
 

@@ -27,7 +27,22 @@ __global__ __launch_bounds__(256) void sequence_mask_kernel(const int64_t* __res
 }
 
 // Stage 1: grid (chunks, B).  partial[b*chunks + chunk] = sum over the chunk of m*(p-y)^2; grad written if non-null.
-template <bool VEC4>
+// KIND 0: squared error (losses.py:49-51).  KIND 1: binary cross entropy with torch's log clamp at -100 (losses.py:54-56).
+template <int KIND>
+__device__ __forceinline__ void seq_loss_elem(float p, float y, float& l, float& g) {
+    if (KIND == 0) {
+        const float d = p - y;
+        l = d * d;
+        g = 2.f * d;
+    } else {
+        const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(logf(1.f - p), -100.f);
+        l = -(y * lp + (1.f - y) * lq);
+        // torch's binary_cross_entropy backward: (p - y) / max(p (1 - p), 1e-12), not the derivative of the clamped logs
+        g = (p - y) / fmaxf((1.f - p) * p, 1e-12f);
+    }
+}
+
+template <bool VEC4, int KIND>
 __global__ __launch_bounds__(256) void masked_mse_stage1(const float* __restrict__ pred, const float* __restrict__ target,
                                                          const int64_t* __restrict__ seq_len, int T, int D, float grad_scale,
                                                          int B, float* __restrict__ grad, float* __restrict__ partial) {
@@ -39,8 +54,8 @@ __global__ __launch_bounds__(256) void masked_mse_stage1(const float* __restrict
     if (n_b > T) n_b = T;
     if (n_b < 0) n_b = 0;
     const int64_t valid_elems = n_b * D;
-    // 2 * grad_scale / (n_b * B * D); n_b == 0 gives inf so that 0 * inf = NaN on every element of that utterance.
-    const float coef = (2.0f * grad_scale) / ((float)n_b * (float)((int64_t)B * D));
+    // grad_scale / (n_b * B * D); n_b == 0 gives inf so that 0 * inf = NaN on every element of that utterance.
+    const float coef = grad_scale / ((float)n_b * (float)((int64_t)B * D));
     const size_t base = (size_t)b * row_elems;
     const int64_t lo = (int64_t)chunk * MSE_CHUNK;
     const int64_t hi = min(lo + (int64_t)MSE_CHUNK, row_elems);
@@ -52,19 +67,21 @@ __global__ __launch_bounds__(256) void masked_mse_stage1(const float* __restrict
             f32x4 g;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float d = p[j] - y[j];
+                float l, dl;
+                seq_loss_elem<KIND>(p[j], y[j], l, dl);
                 const float m = (e + j) < valid_elems ? 1.f : 0.f;
-                acc += d * d * m;
-                g[j] = (d * m) * coef;
+                acc += l * m;
+                g[j] = (dl * m) * coef;
             }
             if (grad) *reinterpret_cast<f32x4*>(grad + base + e) = g;
         }
     } else {
         for (int64_t e = lo + threadIdx.x; e < hi; e += 256) {
-            const float d = pred[base + e] - target[base + e];
+            float l, dl;
+            seq_loss_elem<KIND>(pred[base + e], target[base + e], l, dl);
             const float m = e < valid_elems ? 1.f : 0.f;
-            acc += d * d * m;
-            if (grad) grad[base + e] = (d * m) * coef;
+            acc += l * m;
+            if (grad) grad[base + e] = (dl * m) * coef;
         }
     }
     acc = mg_wave_sum(acc);
@@ -75,7 +92,7 @@ __global__ __launch_bounds__(256) void masked_mse_stage1(const float* __restrict
 
 // Stage 2: one workgroup.  loss = (1/(B*D)) * sum_b ( sum_chunks partial[b,:] / n_b ), fixed summation order.
 __global__ __launch_bounds__(256) void masked_mse_stage2(const float* __restrict__ partial, const int64_t* __restrict__ seq_len,
-                                                         int B, int T, int D, int chunks, float* __restrict__ loss) {
+                                                         int B, int T, float final_div, int chunks, float* __restrict__ loss) {
     __shared__ float red[256];
     float acc = 0.f;
     for (int b = threadIdx.x; b < B; b += 256) {
@@ -92,7 +109,7 @@ __global__ __launch_bounds__(256) void masked_mse_stage2(const float* __restrict
         if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0) loss[0] = red[0] / (float)((int64_t)B * D);
+    if (threadIdx.x == 0) loss[0] = red[0] / final_div;
 }
 
 __global__ __launch_bounds__(256) void normalise_kernel(const float* __restrict__ x, float* __restrict__ out,
@@ -122,6 +139,108 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float* __restrict_
     }
 }
 
+
+// Multi-stream loss of the LSTM acoustic model (reference: models/RNN_SPSS.py:120-139): the prediction's columns are
+// split into streams (lf0 deltas, vuv, mcep deltas, bap deltas), each stream has its own target tensor and is scored
+// with losses.mse or - after torch.sigmoid - losses.bce; the stream losses are averaged.  One pass over pred.
+struct stream_args {
+    mg_stream_desc s[MG_STREAMS_MAX];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void stream_loss_stage1(const float* __restrict__ pred, stream_args sa,
+                                                          const int64_t* __restrict__ seq_len, int T, int D, float grad_scale,
+                                                          int B, float* __restrict__ grad, float* __restrict__ prob,
+                                                          float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char col_stream[];  // D entries: stream of a column or 0xff
+    __shared__ float red[4];
+    __shared__ float col_w[MG_STREAMS_MAX];
+    for (int c = threadIdx.x; c < D; c += 256) {
+        unsigned char which = 0xff;
+        for (int k = 0; k < sa.n; ++k)
+            if (c >= sa.s[k].col0 && c < sa.s[k].col0 + sa.s[k].width) which = (unsigned char)k;
+        col_stream[c] = which;
+    }
+    // weight of one element of stream k in the total: 1 / (B * width_k * n_streams)   (mean over (b,d), mean over streams)
+    if (threadIdx.x < MG_STREAMS_MAX)
+        col_w[threadIdx.x] = threadIdx.x < sa.n ? 1.f / ((float)B * (float)sa.s[threadIdx.x].width * (float)sa.n) : 0.f;
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int64_t row_elems = (int64_t)T * D;
+    int64_t n_b = seq_len ? seq_len[b] : (int64_t)T;
+    if (n_b > T) n_b = T;
+    if (n_b < 0) n_b = 0;
+    const float inv_nb = grad_scale / (float)n_b;   // inf for an empty utterance: 0 * inf = NaN, as the reference's 0 / 0
+    const size_t base = (size_t)b * row_elems;
+    const int64_t lo = (int64_t)blockIdx.x * MSE_CHUNK;
+    const int64_t hi = min(lo + (int64_t)MSE_CHUNK, row_elems);
+    int t = (int)((lo + threadIdx.x) / D);
+    int c = (int)((lo + threadIdx.x) - (int64_t)t * D);
+    const int dt = 256 / D, dc = 256 % D;
+    float acc = 0.f;
+    for (int64_t e = lo + threadIdx.x; e < hi; e += 256) {
+        const int k = col_stream[c];
+        float g = 0.f;
+        if (k != 0xff) {
+            const mg_stream_desc& sd = sa.s[k];
+            const size_t ti = ((size_t)b * T + t) * sd.ldt + (c - sd.col0);
+            const float y = sd.target[ti];
+            const float x = pred[base + e];
+            float l, dl;
+            if (sd.kind == MG_LOSS_MSE) {
+                seq_loss_elem<0>(x, y, l, dl);
+            } else {
+                const float p = 1.f / (1.f + expf(-x));        // torch.sigmoid, models/RNN_SPSS.py:93
+                seq_loss_elem<1>(p, y, l, dl);
+                dl *= (1.f - p) * p;                           // sigmoid backward
+                if (prob) prob[((size_t)b * T + t) * sd.width + (c - sd.col0)] = p;
+            }
+            const float m = t < n_b ? 1.f : 0.f;
+            acc += l * m * col_w[k];
+            g = (dl * m) * (inv_nb * col_w[k]);
+        }
+        if (grad) grad[base + e] = g;
+        t += dt;
+        c += dc;
+        if (c >= D) { c -= D; ++t; }
+    }
+    acc = mg_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+static size_t masked_ws_bytes(int B, int T, int D) {
+    const int64_t chunks = mg_ceil_div((int64_t)T * D, MSE_CHUNK);
+    return mg_align_up((size_t)B * (size_t)(chunks < 1 ? 1 : chunks) * sizeof(float), 256);
+}
+
+static int masked_loss(int kind, const float* pred, const float* target, const int64_t* seq_len, int B, int T, int D,
+                       float grad_scale, float* loss, float* grad, void* workspace, size_t workspace_bytes, void* stream) {
+    MG_CHECK_ARG(pred && target && loss && B > 0 && T > 0 && D > 0, "mg_masked_mse_f32: bad arguments (B=%d T=%d D=%d)", B, T, D);
+    MG_CHECK_ARG(B <= 65535, "mg_masked_mse_f32: B=%d exceeds 65535", B);
+    if (!workspace || workspace_bytes < masked_ws_bytes(B, T, D)) {
+        mg_set_error("mg_masked_mse_f32: workspace of %zu bytes needed, got %zu", masked_ws_bytes(B, T, D), workspace_bytes);
+        return MG_EWORKSPACE;
+    }
+    const int chunks = (int)mg_ceil_div((int64_t)T * D, MSE_CHUNK);
+    const bool vec = (((int64_t)T * D) % 4 == 0) &&
+                     ((((uintptr_t)pred | (uintptr_t)target | (uintptr_t)(grad ? grad : pred)) % 16) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+#define LAUNCH_S1(V_, K_) hipLaunchKernelGGL((masked_mse_stage1<V_, K_>), dim3(chunks, B), dim3(256), 0, st, pred, target, seq_len, T, D, grad_scale, B, grad, partial)
+    if (kind == 0) {
+        if (vec) LAUNCH_S1(true, 0); else LAUNCH_S1(false, 0);
+    } else {
+        if (vec) LAUNCH_S1(true, 1); else LAUNCH_S1(false, 1);
+    }
+#undef LAUNCH_S1
+    MG_CHECK_LAUNCH("mg_masked_mse_f32/stage1");
+    hipLaunchKernelGGL(masked_mse_stage2, dim3(1), dim3(256), 0, st, partial, seq_len, B, T, (float)((int64_t)B * D), chunks, loss);
+    MG_CHECK_LAUNCH("mg_masked_mse_f32/stage2");
+    return MG_OK;
+}
+
 extern "C" {
 
 int mg_sequence_mask(const int64_t* seq_len, int B, int max_len, void* mask, int elem_size, int as_float, void* stream) {
@@ -135,31 +254,53 @@ int mg_sequence_mask(const int64_t* seq_len, int B, int max_len, void* mask, int
     return MG_OK;
 }
 
-size_t mg_masked_mse_workspace_bytes(int B, int T, int D) {
-    const int64_t chunks = mg_ceil_div((int64_t)T * D, MSE_CHUNK);
-    return mg_align_up((size_t)B * (size_t)(chunks < 1 ? 1 : chunks) * sizeof(float), 256);
-}
+size_t mg_masked_mse_workspace_bytes(int B, int T, int D) { return masked_ws_bytes(B, T, D); }
 
 int mg_masked_mse_f32(const float* pred, const float* target, const int64_t* seq_len, int B, int T, int D,
                       float grad_scale, float* loss, float* grad, void* workspace, size_t workspace_bytes, void* stream) {
-    MG_CHECK_ARG(pred && target && loss && B > 0 && T > 0 && D > 0, "mg_masked_mse_f32: bad arguments (B=%d T=%d D=%d)", B, T, D);
-    MG_CHECK_ARG(B <= 65535, "mg_masked_mse_f32: B=%d exceeds 65535", B);
-    if (!workspace || workspace_bytes < mg_masked_mse_workspace_bytes(B, T, D)) {
-        mg_set_error("mg_masked_mse_f32: workspace of %zu bytes needed, got %zu", mg_masked_mse_workspace_bytes(B, T, D), workspace_bytes);
+    return masked_loss(0, pred, target, seq_len, B, T, D, grad_scale, loss, grad, workspace, workspace_bytes, stream);
+}
+
+int mg_masked_bce_f32(const float* pred, const float* target, const int64_t* seq_len, int B, int T, int D,
+                      float grad_scale, float* loss, float* grad, void* workspace, size_t workspace_bytes, void* stream) {
+    return masked_loss(1, pred, target, seq_len, B, T, D, grad_scale, loss, grad, workspace, workspace_bytes, stream);
+}
+
+size_t mg_stream_loss_workspace_bytes(int B, int T, int D) { return masked_ws_bytes(B, T, D); }
+
+int mg_stream_loss_f32(const float* pred, const mg_stream_desc* streams, int n_streams, const int64_t* seq_len, int B, int T, int D,
+                       float grad_scale, float* loss, float* grad, float* prob, void* workspace, size_t workspace_bytes,
+                       void* stream) {
+    MG_CHECK_ARG(pred && streams && loss && B > 0 && T > 0 && D > 0, "mg_stream_loss_f32: bad arguments (B=%d T=%d D=%d)", B, T, D);
+    MG_CHECK_ARG(n_streams >= 1 && n_streams <= MG_STREAMS_MAX, "mg_stream_loss_f32: n_streams=%d not in 1..%d", n_streams, MG_STREAMS_MAX);
+    MG_CHECK_ARG(B <= 65535 && D <= 16384, "mg_stream_loss_f32: B=%d or D=%d too large", B, D);
+    stream_args sa;
+    sa.n = n_streams;
+    int n_bce = 0;
+    for (int k = 0; k < n_streams; ++k) {
+        const mg_stream_desc& d = streams[k];
+        MG_CHECK_ARG(d.target && d.width > 0 && d.col0 >= 0 && d.col0 + d.width <= D && d.ldt >= d.width,
+                     "mg_stream_loss_f32: stream %d (col0=%d width=%d ldt=%d) does not fit D=%d", k, d.col0, d.width, d.ldt, D);
+        MG_CHECK_ARG(d.kind == MG_LOSS_MSE || d.kind == MG_LOSS_SIGMOID_BCE, "mg_stream_loss_f32: stream %d has unknown kind %d", k, d.kind);
+        for (int j = 0; j < k; ++j)
+            MG_CHECK_ARG(d.col0 >= streams[j].col0 + streams[j].width || streams[j].col0 >= d.col0 + d.width,
+                         "mg_stream_loss_f32: streams %d and %d overlap", j, k);
+        n_bce += d.kind == MG_LOSS_SIGMOID_BCE;
+        sa.s[k] = d;
+    }
+    MG_CHECK_ARG(!prob || n_bce == 1, "mg_stream_loss_f32: prob output needs exactly one sigmoid-BCE stream, got %d", n_bce);
+    if (!workspace || workspace_bytes < masked_ws_bytes(B, T, D)) {
+        mg_set_error("mg_stream_loss_f32: workspace of %zu bytes needed, got %zu", masked_ws_bytes(B, T, D), workspace_bytes);
         return MG_EWORKSPACE;
     }
     const int chunks = (int)mg_ceil_div((int64_t)T * D, MSE_CHUNK);
-    const bool vec = (((int64_t)T * D) % 4 == 0) &&
-                     ((((uintptr_t)pred | (uintptr_t)target | (uintptr_t)(grad ? grad : pred)) % 16) == 0);
     hipStream_t st = (hipStream_t)stream;
     float* partial = (float*)workspace;
-    if (vec)
-        hipLaunchKernelGGL(masked_mse_stage1<true>, dim3(chunks, B), dim3(256), 0, st, pred, target, seq_len, T, D, grad_scale, B, grad, partial);
-    else
-        hipLaunchKernelGGL(masked_mse_stage1<false>, dim3(chunks, B), dim3(256), 0, st, pred, target, seq_len, T, D, grad_scale, B, grad, partial);
-    MG_CHECK_LAUNCH("mg_masked_mse_f32/stage1");
-    hipLaunchKernelGGL(masked_mse_stage2, dim3(1), dim3(256), 0, st, partial, seq_len, B, T, D, chunks, loss);
-    MG_CHECK_LAUNCH("mg_masked_mse_f32/stage2");
+    hipLaunchKernelGGL(stream_loss_stage1, dim3(chunks, B), dim3(256), (size_t)mg_align_up((size_t)D, 16), st, pred, sa, seq_len, T, D,
+                       grad_scale, B, grad, prob, partial);
+    MG_CHECK_LAUNCH("mg_stream_loss_f32/stage1");
+    hipLaunchKernelGGL(masked_mse_stage2, dim3(1), dim3(256), 0, st, partial, seq_len, B, T, 1.f, chunks, loss);
+    MG_CHECK_LAUNCH("mg_stream_loss_f32/stage2");
     return MG_OK;
 }
 

@@ -144,6 +144,52 @@ __global__ __launch_bounds__(256) void gather_rows_bf16_kernel(const float* __re
     }
 }
 
+
+// Gather + concat: out[m, 0:F] = src[rows[m], :] (0 for rows[m] < 0), out[m, F:F+C] = extra[m, 0:C], out[m, F+C:ldo] = 0.
+// The layer-1 input of the shipped models: upsampled labels next to the frame-level counters
+// (models/RNN_SPSS.py:76-81, models/f0_test_model.py:78-79: upsample_to_repetitions + torch.cat).  One wave per row;
+// OUT_BF16 writes 8 converted elements (16 bytes) per lane, the f32 form writes one float per lane and step.
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void gather_concat_kernel(const float* __restrict__ src, const int32_t* __restrict__ rows,
+                                                            const float* __restrict__ extra, void* __restrict__ out_, int64_t M,
+                                                            int F, int C, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    const bool vec = (F & 3) == 0;
+    for (int64_t m = wave; m < M; m += n_waves) {
+        const int r = rows ? rows[m] : (int)m;
+        const float* s = src + (size_t)(r < 0 ? 0 : r) * F;
+        const float* x = extra + (size_t)m * C;
+        if (OUT_BF16) {
+            uint16_t* o = (uint16_t*)out_ + (size_t)m * ldo;
+            for (int c = lane; c < (ldo >> 3); c += 64) {
+                const int k = c << 3;
+                float v[8];
+                if (r >= 0 && vec && k + 8 <= F) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(s + k);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(s + k + 4);
+                    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+                    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int e = k + j;
+                        v[j] = e < F ? (r >= 0 ? s[e] : 0.f) : (e < F + C ? x[e - F] : 0.f);
+                    }
+                }
+                bf16x8 p;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) p[j] = (short)mg_f2bf(v[j]);
+                *reinterpret_cast<bf16x8*>(o + k) = p;
+            }
+        } else {
+            float* o = (float*)out_ + (size_t)m * ldo;
+            for (int e = lane; e < ldo; e += 64) o[e] = e < F ? (r >= 0 ? s[e] : 0.f) : (e < F + C ? x[e - F] : 0.f);
+        }
+    }
+}
+
 // grad_src[b,p,:] = sum_{t in phone p} grad_out[b,t,:].  grid (B, phone_chunks); one wave per phone.
 __global__ __launch_bounds__(256) void upsample_backward_kernel(const float* __restrict__ grad_out, const int64_t* __restrict__ dur,
                                                                 float* __restrict__ grad_src, int P, int T, int F) {
@@ -220,6 +266,27 @@ int mg_gather_rows_bf16(const float* src, const int32_t* rows, uint16_t* out, in
     if (M == 0) return MG_OK;
     hipLaunchKernelGGL(gather_rows_bf16_kernel, dim3(gather_grid(M)), dim3(256), 0, (hipStream_t)stream, src, rows, out, M, F, ldo);
     MG_CHECK_LAUNCH("mg_gather_rows_bf16");
+    return MG_OK;
+}
+
+int mg_gather_concat_f32(const float* src, const int32_t* rows, const float* extra, float* out, int64_t M, int F, int C,
+                         int ldo, void* stream) {
+    MG_CHECK_ARG(src && extra && out && M >= 0 && F > 0 && C > 0, "mg_gather_concat_f32: bad arguments (M=%lld F=%d C=%d)", (long long)M, F, C);
+    MG_CHECK_ARG(ldo >= F + C, "mg_gather_concat_f32: ldo=%d must be >= F+C=%d", ldo, F + C);
+    if (M == 0) return MG_OK;
+    hipLaunchKernelGGL(gather_concat_kernel<false>, dim3(gather_grid(M)), dim3(256), 0, (hipStream_t)stream, src, rows, extra, (void*)out, M, F, C, ldo);
+    MG_CHECK_LAUNCH("mg_gather_concat_f32");
+    return MG_OK;
+}
+
+int mg_gather_concat_bf16(const float* src, const int32_t* rows, const float* extra, uint16_t* out, int64_t M, int F, int C,
+                          int ldo, void* stream) {
+    MG_CHECK_ARG(src && extra && out && M >= 0 && F > 0 && C > 0, "mg_gather_concat_bf16: bad arguments (M=%lld F=%d C=%d)", (long long)M, F, C);
+    MG_CHECK_ARG(ldo >= F + C && ldo % 8 == 0, "mg_gather_concat_bf16: ldo=%d must be >= F+C=%d and a multiple of 8", ldo, F + C);
+    MG_CHECK_ARG(((uintptr_t)out % 16 == 0) && ((uintptr_t)src % 16 == 0), "mg_gather_concat_bf16: buffers must be 16-byte aligned");
+    if (M == 0) return MG_OK;
+    hipLaunchKernelGGL(gather_concat_kernel<true>, dim3(gather_grid(M)), dim3(256), 0, (hipStream_t)stream, src, rows, extra, (void*)out, M, F, C, ldo);
+    MG_CHECK_LAUNCH("mg_gather_concat_bf16");
     return MG_OK;
 }
 

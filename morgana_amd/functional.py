@@ -58,13 +58,16 @@ class LinearStackFn(torch.autograd.Function):
         n_layers = len(acts)
         weights = [params[2 * i] for i in range(n_layers)]
         biases = [params[2 * i + 1] for i in range(n_layers)]
-        x2d = ops._require(x2d, torch.float32, 'input')
+        # a bf16 input is an already padded layer-1 operand (ops.gather_concat); anything else must be fp32
+        pre_cast = precision == 'bf16' and x2d.dtype == torch.bfloat16
+        x2d = ops._require(x2d, torch.bfloat16 if pre_cast else torch.float32, 'input')
         m = rows.numel() if rows is not None else x2d.shape[0]
         ctx.spec, ctx.m = spec, m
         ctx.has_bias = [b is not None for b in biases]
         ctx.dims = [(w.shape[0], w.shape[1]) for w in weights]
-        if x2d.shape[1] != weights[0].shape[1]:
-            raise ValueError('Linear expects %d input features, got %d' % (weights[0].shape[1], x2d.shape[1]))
+        k_in = weights[0].shape[1]
+        if x2d.shape[1] != (ops.pad_ld(k_in) if pre_cast else k_in):
+            raise ValueError('Linear expects %d input features, got %d' % (k_in, x2d.shape[1]))
         hidden = []
         if precision == 'fp32':
             a, r = x2d, rows
@@ -76,7 +79,7 @@ class LinearStackFn(torch.autograd.Function):
             out = a
             ctx.save_for_backward(x2d, rows, *weights, *hidden)
         else:
-            a = ops.cast_pad_bf16(x2d)
+            a = x2d if pre_cast else ops.cast_pad_bf16(x2d)
             a0, r = a, rows
             for i in range(n_layers):
                 n, k = weights[i].shape
@@ -373,12 +376,32 @@ class LSTMFn(torch.autograd.Function):
 
 class MaskedMSEFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, predictions, targets, seq_len):
-        loss, grad = ops.masked_mse(predictions, targets, seq_len, want_grad=ctx.needs_input_grad[0])
+    def forward(ctx, predictions, targets, seq_len, kind='mse'):
+        loss, grad = ops.masked_mse(predictions, targets, seq_len, want_grad=ctx.needs_input_grad[0], kind=kind)
         ctx.save_for_backward(grad)
         return loss
 
     @staticmethod
     def backward(ctx, grad_loss):
         (grad,) = ctx.saved_tensors
-        return grad * grad_loss, None, None
+        return grad * grad_loss, None, None, None
+
+
+class StreamLossFn(torch.autograd.Function):
+    """Multi-stream loss of models/RNN_SPSS.py:120-139 in one pass: returns (loss, sigmoid of the BCE stream or None)."""
+
+    @staticmethod
+    def forward(ctx, predictions, seq_len, kinds, want_prob, *targets):
+        loss, grad, prob = ops.stream_loss(predictions, targets, kinds, seq_len, want_grad=ctx.needs_input_grad[0],
+                                           want_prob=want_prob)
+        ctx.save_for_backward(grad)
+        ctx.n_targets = len(targets)
+        ctx.set_materialize_grads(False)
+        if prob is not None:
+            ctx.mark_non_differentiable(prob)
+        return loss, prob
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_prob):
+        (grad,) = ctx.saved_tensors
+        return (grad * grad_loss, None, None, None) + (None,) * ctx.n_targets

@@ -3,8 +3,11 @@
 * ``F0Model``  - README stack Linear/Sigmoid 600-512-128-32-1 (README.rst:53-97; configs C1-C3).
 * ``RNNSPSS``  - Linear-512 / sigmoid / GRU-512 / Linear-256 / sigmoid / Linear-out, the layer layout of
                  models/RNN_SPSS.py:32-42 with the GRU cell of models/f0_test_model.py:32-39 (configs C4-C5).
-``SequentialWithRecurrent`` returns ``(output, hiddens)`` (utils.py:418), so both unpack it.
+* ``LSTMAcousticModel`` - the reference's shipped acoustic model, models/RNN_SPSS.py:20-139: 609-dim input (labels +
+                 counters), Linear-512 / sigmoid / 8 x LSTM-512 / Linear-256 / sigmoid / Linear-199, four output streams.
+``SequentialWithRecurrent`` returns ``(output, hiddens)`` (utils.py:418), so all of them unpack it.
 """
+import torch
 import torch.nn as nn
 
 from . import data
@@ -99,3 +102,87 @@ class RNNSPSS(BaseSPSS):
     def loss(self, features, output_features):
         return losses.mse(output_features['pred_norm_' + self.target_name],
                           features['normalised_' + self.target_name], features['n_frames'])
+
+
+class LSTMAcousticModel(BaseSPSS):
+    """models/RNN_SPSS.py:20-139 against this package: same constructor arguments, layer container (so the reference's
+    state_dict keys ``layers.0.weight`` ... ``layers.{3+k}.layer.weight_ih_l0`` ... load unchanged), ``predict`` outputs and
+    ``loss``.  MLPG (``_prepare_output``, :108-118) is generation-time CPU post-processing on detached outputs and is not part
+    of this package; ``predict`` returns the normalised delta streams and the voicing probability."""
+
+    STREAMS = ('lf0', 'vuv', 'mcep', 'bap')
+
+    def __init__(self, input_dim=600 + 9, output_dims=None, dropout_prob=0., num_layers=8, hidden_dim=512, post_dim=256,
+                 precision=None, fused_upsample=True, fused_loss=True):
+        if output_dims is None:
+            output_dims = {'lf0': 1 * 3, 'vuv': 1, 'mcep': 60 * 3, 'bap': 5 * 3}
+        super(LSTMAcousticModel, self).__init__()
+        self.input_dim = input_dim
+        self.output_dims = output_dims
+        self.dropout_prob = dropout_prob
+        self.num_layers = num_layers
+        self.fused_upsample = fused_upsample
+        self.fused_loss = fused_loss
+        self.layers = utils.SequentialWithRecurrent(
+            nn.Linear(self.input_dim, hidden_dim),
+            nn.Sigmoid(),
+            nn.Dropout(p=self.dropout_prob),
+            *[utils.RecurrentCuDNNWrapper(nn.LSTM(hidden_dim, hidden_dim, dropout=self.dropout_prob, batch_first=True),
+                                          precision=precision)
+              for _ in range(self.num_layers)],
+            nn.Linear(hidden_dim, post_dim),
+            nn.Sigmoid(),
+            nn.Dropout(p=self.dropout_prob),
+            nn.Linear(post_dim, sum(self.output_dims.values())),
+            precision=precision)
+
+    def normaliser_sources(self):
+        return {
+            'dur': data.MeanVarianceNormaliser('dur'),
+            'lab': data.MinMaxNormaliser('lab'),
+            'counters': data.MinMaxNormaliser('counters'),
+            'lf0': data.MeanVarianceNormaliser('lf0', use_deltas=True),
+            'mcep': data.MeanVarianceNormaliser('mcep', use_deltas=True),
+            'bap': data.MeanVarianceNormaliser('bap', use_deltas=True),
+        }
+
+    def _run_layers(self, features):
+        norm_counters = features['normalised_counters']
+        norm_lab_at_frame_rate = utils.upsample_to_repetitions(features['normalised_lab'], features['dur'],
+                                                               max_len=norm_counters.shape[1], fused=self.fused_upsample)
+        model_inputs = utils.concat_frame_features(norm_lab_at_frame_rate, norm_counters)
+        pred_norm_deltas, _ = self.layers(model_inputs, seq_len=features['n_frames'])
+        return pred_norm_deltas
+
+    def _split(self, pred_norm_deltas, pred_vuv=None):
+        output_dims = [self.output_dims[n] for n in self.STREAMS]
+        lf0, vuv, mcep, bap = torch.split(pred_norm_deltas, output_dims, dim=-1)
+        return {
+            'normalised_lf0_deltas': lf0,
+            'normalised_mcep_deltas': mcep,
+            'normalised_bap_deltas': bap,
+            'vuv': torch.sigmoid(vuv) if pred_vuv is None else pred_vuv,
+        }
+
+    def predict(self, features):
+        return self._split(self._run_layers(features))
+
+    def loss(self, features, output_features):
+        n_frames = features['n_frames']
+        loss = 0.
+        loss += losses.mse(output_features['normalised_lf0_deltas'], features['normalised_lf0_deltas'], n_frames)
+        loss += losses.mse(output_features['normalised_mcep_deltas'], features['normalised_mcep_deltas'], n_frames)
+        loss += losses.mse(output_features['normalised_bap_deltas'], features['normalised_bap_deltas'], n_frames)
+        loss += losses.bce(output_features['vuv'].type(torch.float), features['vuv'].type(torch.float), n_frames)
+        return loss / 4.
+
+    def forward(self, features):
+        """``predict`` + ``loss`` (base_models.py:279-285); with ``fused_loss`` the split, the sigmoid and the four masked
+        losses run as one pass over the prediction (``losses.multi_stream``), same numbers."""
+        if not self.fused_loss:
+            return super(LSTMAcousticModel, self).forward(features)
+        pred_norm_deltas = self._run_layers(features)
+        targets = [features['vuv'] if n == 'vuv' else features['normalised_%s_deltas' % n] for n in self.STREAMS]
+        kinds = ['sigmoid_bce' if n == 'vuv' else 'mse' for n in self.STREAMS]
+        loss, pred_vuv = losses.multi_stream(pred_norm_deltas, targets, kinds, features['n_frames'], want_prob=True)
+        return loss, self._split(pred_norm_deltas.detach(), pred_vuv)

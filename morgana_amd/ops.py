@@ -88,6 +88,27 @@ def gather_rows(src2d, rows, out_bf16=False):
     return out
 
 
+def gather_concat(src2d, rows, extra2d, out_bf16=False):
+    """[src2d[rows] | extra2d] per frame (mg_gather_concat_*): f32 (M, F+C), or bf16 (M, pad_ld(F+C)) zero padded."""
+    lib = _lib.load()
+    src2d = _require(src2d, torch.float32, 'src')
+    extra2d = _require(extra2d, torch.float32, 'extra')
+    rows = _require(rows, torch.int32, 'rows')
+    m, f, c = rows.numel(), src2d.shape[1], extra2d.shape[1]
+    if extra2d.shape[0] != m:
+        raise ValueError('gather_concat: %d frame rows but %d rows of frame-level features' % (m, extra2d.shape[0]))
+    if out_bf16:
+        ldo = pad_ld(f + c)
+        out = torch.empty((m, ldo), dtype=torch.bfloat16, device=src2d.device)
+        _lib.check(lib.mg_gather_concat_bf16(_p(src2d), _p(rows), _p(extra2d), _p(out), m, f, c, ldo, _stream()),
+                   'mg_gather_concat_bf16')
+    else:
+        out = torch.empty((m, f + c), dtype=torch.float32, device=src2d.device)
+        _lib.check(lib.mg_gather_concat_f32(_p(src2d), _p(rows), _p(extra2d), _p(out), m, f, c, f + c, _stream()),
+                   'mg_gather_concat_f32')
+    return out
+
+
 def upsample_backward(grad_out, dur, n_phones):
     lib = _lib.load()
     grad_out = _require(grad_out, torch.float32, 'grad_out')
@@ -117,8 +138,8 @@ def sequence_mask(seq_len, max_len, dtype):
     return mask
 
 
-def masked_mse(pred, target, seq_len, want_grad, grad_scale=1.0):
-    """Returns (loss 0-d f32 tensor, grad or None)."""
+def masked_mse(pred, target, seq_len, want_grad, grad_scale=1.0, kind='mse'):
+    """Returns (loss 0-d f32 tensor, grad or None).  kind: 'mse' or 'bce'."""
     lib = _lib.load()
     pred = _require(pred, torch.float32, 'predictions')
     target = _require(target, torch.float32, 'targets')
@@ -132,9 +153,44 @@ def masked_mse(pred, target, seq_len, want_grad, grad_scale=1.0):
     grad = torch.empty_like(pred) if want_grad else None
     nbytes = lib.mg_masked_mse_workspace_bytes(b, t, d)
     ws = workspace(nbytes, pred.device)
-    _lib.check(lib.mg_masked_mse_f32(_p(pred), _p(target), _p(seq_len), b, t, d, float(grad_scale), _p(loss), _p(grad),
-                                     _p(ws), ws.numel(), _stream()), 'mg_masked_mse_f32')
+    fn = lib.mg_masked_mse_f32 if kind == 'mse' else lib.mg_masked_bce_f32
+    _lib.check(fn(_p(pred), _p(target), _p(seq_len), b, t, d, float(grad_scale), _p(loss), _p(grad), _p(ws), ws.numel(),
+                  _stream()), 'mg_masked_%s_f32' % kind)
     return loss, grad
+
+
+def stream_loss(pred, targets, kinds, seq_len, want_grad, want_prob=False, grad_scale=1.0):
+    """Multi-stream loss (mg_stream_loss_f32): pred (B, T, sum of widths), targets[k] (B, T, width_k) scored side by side
+    in column order, kinds[k] in {'mse', 'sigmoid_bce'}.  Returns (loss 0-d, grad or None, prob or None)."""
+    lib = _lib.load()
+    pred = _require(pred, torch.float32, 'predictions')
+    if pred.dim() != 3 or len(targets) != len(kinds) or not 1 <= len(targets) <= _lib.STREAMS_MAX:
+        raise ValueError('stream_loss: predictions must be (B, T, D) with 1..%d streams' % _lib.STREAMS_MAX)
+    b, t, d = pred.shape
+    if sum(int(y.shape[-1]) for y in targets) != d:
+        raise ValueError('stream_loss: stream widths %s do not add up to D=%d' % ([int(y.shape[-1]) for y in targets], d))
+    if seq_len is not None:
+        seq_len = _require(seq_len, torch.int64, 'seq_len')
+    descs = (_lib.StreamDesc * len(targets))()
+    keep, col0, prob = [], 0, None
+    for k, (y, kind) in enumerate(zip(targets, kinds)):
+        y = _require(y, torch.float32, 'targets[%d]' % k)
+        if y.dim() != 3 or y.shape[0] != b or y.shape[1] != t:
+            raise ValueError('stream_loss: targets[%d] %s does not match predictions (%d, %d, *)' % (k, tuple(y.shape), b, t))
+        keep.append(y)
+        w = int(y.shape[2])
+        descs[k].target, descs[k].ldt, descs[k].col0, descs[k].width = y.data_ptr(), w, col0, w
+        descs[k].kind = {'mse': _lib.LOSS_MSE, 'sigmoid_bce': _lib.LOSS_SIGMOID_BCE}[kind]
+        if kind == 'sigmoid_bce' and want_prob:
+            prob = torch.empty((b, t, w), dtype=torch.float32, device=pred.device)
+        col0 += w
+    loss = torch.empty((), dtype=torch.float32, device=pred.device)
+    grad = torch.empty_like(pred) if want_grad else None
+    ws = workspace(lib.mg_stream_loss_workspace_bytes(b, t, d), pred.device)
+    _lib.check(lib.mg_stream_loss_f32(_p(pred), ctypes.cast(descs, ctypes.c_void_p), len(targets), _p(seq_len), b, t, d,
+                                      float(grad_scale), _p(loss), _p(grad), _p(prob), _p(ws), ws.numel(), _stream()),
+               'mg_stream_loss_f32')
+    return loss, grad, prob
 
 
 def normalise(x, p0, p1, kind):

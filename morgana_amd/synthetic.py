@@ -125,3 +125,53 @@ def rnn_spss_state(seed=REFERENCE_SEED, lab_dim=600, hidden=512, post=256, out_d
     state['layers.3.weight'], state['layers.3.bias'] = init_linear(rng, hidden, post)
     state['layers.5.weight'], state['layers.5.bias'] = init_linear(rng, post, out_dim)
     return state
+
+
+ACOUSTIC_STREAMS = (('lf0', 3, 'mse'), ('vuv', 1, 'sigmoid_bce'), ('mcep', 180, 'mse'), ('bap', 15, 'mse'))
+
+
+def init_lstm(rng, in_dim, hidden):
+    """U(-1/sqrt(H), 1/sqrt(H)) LSTM parameters in torch's layout: gates stacked (i, f, g, o) along dim 0."""
+    bound = 1.0 / np.sqrt(hidden)
+    w_ih = rng.uniform(-bound, bound, size=(4 * hidden, in_dim)).astype(np.float32)
+    w_hh = rng.uniform(-bound, bound, size=(4 * hidden, hidden)).astype(np.float32)
+    b_ih = rng.uniform(-bound, bound, size=(4 * hidden,)).astype(np.float32)
+    b_hh = rng.uniform(-bound, bound, size=(4 * hidden,)).astype(np.float32)
+    return w_ih, w_hh, b_ih, b_hh
+
+
+def lstm_acoustic_state(seed=REFERENCE_SEED, input_dim=609, hidden=512, post=256, output_dim=199, num_layers=8):
+    """state_dict (numpy) of the reference's LSTMAcousticModel (models/RNN_SPSS.py:32-42): Linear, Sigmoid, Dropout,
+    ``num_layers`` single-layer LSTM wrappers, Linear, Sigmoid, Dropout, Linear - keys are the reference's."""
+    rng = np.random.RandomState(seed % (2 ** 32))
+    state = {}
+    state['layers.0.weight'], state['layers.0.bias'] = init_linear(rng, input_dim, hidden)
+    for k in range(num_layers):
+        w_ih, w_hh, b_ih, b_hh = init_lstm(rng, hidden, hidden)
+        prefix = 'layers.%d.layer.' % (3 + k)
+        state[prefix + 'weight_ih_l0'], state[prefix + 'weight_hh_l0'] = w_ih, w_hh
+        state[prefix + 'bias_ih_l0'], state[prefix + 'bias_hh_l0'] = b_ih, b_hh
+    state['layers.%d.weight' % (3 + num_layers)], state['layers.%d.bias' % (3 + num_layers)] = init_linear(rng, hidden, post)
+    state['layers.%d.weight' % (6 + num_layers)], state['layers.%d.bias' % (6 + num_layers)] = init_linear(rng, post, output_dim)
+    return state
+
+
+def make_acoustic_batch(batch_size, n_frames, lab_dim=600, counters_dim=9, streams=ACOUSTIC_STREAMS, frames_per_phone=12.5,
+                        seed=REFERENCE_SEED, rank=0):
+    """Feature dict for the LSTM acoustic model (models/RNN_SPSS.py:60-71, 73-82): ``make_batch``'s lab / dur / n_frames plus
+    frame-level ``normalised_counters`` ~ U[0,1) and one target per stream - ``normalised_<name>_deltas`` ~ N(0,1) for the
+    regression streams, ``vuv`` in {0, 1}; pads beyond each utterance's length are zero."""
+    feats = make_batch(batch_size, n_frames, lab_dim=lab_dim, out_dim=1, target_name='unused', frames_per_phone=frames_per_phone,
+                       seed=seed, rank=rank)
+    del feats['normalised_unused']
+    rng = np.random.RandomState((seed + rank + 7919) % (2 ** 32))
+    lens = feats['n_frames']
+    max_t = int(lens.max())
+    mask = (np.arange(max_t)[None, :] < lens[:, None])[..., None]
+    feats['normalised_counters'] = (rng.random_sample((batch_size, max_t, counters_dim)) * mask).astype(np.float32)
+    for name, width, kind in streams:
+        if kind == 'mse':
+            feats['normalised_%s_deltas' % name] = (rng.standard_normal((batch_size, max_t, width)) * mask).astype(np.float32)
+        else:
+            feats[name] = ((rng.random_sample((batch_size, max_t, width)) > 0.4) * mask).astype(np.float32)
+    return feats

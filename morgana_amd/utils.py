@@ -58,6 +58,37 @@ class UpsampledSequence(object):
         return F_hip.UpsampleFn.apply(self.source, self.dur, self.rows.shape[1])
 
 
+class UpsampledConcat(object):
+    """Lazy ``torch.cat((upsample_to_repetitions(sequence_feature, repeats), frame_feature), dim=-1)`` - the model input of
+    models/RNN_SPSS.py:76-81 and models/f0_test_model.py:78-79.  ``SequentialWithRecurrent`` turns it into the first Linear's
+    operand with one gather+concat pass (bf16 and padded in bf16 mode); ``materialise()`` gives the dense fp32 tensor."""
+
+    def __init__(self, upsampled, frame_feature):
+        if frame_feature.shape[:2] != tuple(upsampled.shape[:2]):
+            raise RuntimeError('Sizes of tensors must match except in dimension 2. Expected %s but got %s'
+                               % (tuple(upsampled.shape[:2]), tuple(frame_feature.shape[:2])))
+        self.upsampled = upsampled
+        self.frame_feature = frame_feature
+        self.shape = tuple(upsampled.shape[:2]) + (upsampled.shape[2] + frame_feature.shape[2],)
+
+    def operand(self, out_bf16):
+        up = self.upsampled
+        return ops.gather_concat(up.source.reshape(-1, up.source.shape[-1]), up.rows.reshape(-1),
+                                 self.frame_feature.reshape(-1, self.frame_feature.shape[-1]), out_bf16=out_bf16)
+
+    def materialise(self):
+        return self.operand(False).view(self.shape)
+
+
+def concat_frame_features(upsampled, frame_feature):
+    """``torch.cat((upsampled, frame_feature), dim=-1)`` that keeps a fused upsample lazy (see ``UpsampledConcat``)."""
+    if isinstance(upsampled, UpsampledSequence) and not frame_feature.requires_grad:
+        return UpsampledConcat(upsampled, frame_feature)
+    if isinstance(upsampled, UpsampledSequence):
+        upsampled = upsampled.materialise()
+    return torch.cat((upsampled, frame_feature), dim=-1)
+
+
 def upsample_to_repetitions(sequence_feature, repeats, max_len=None, fused=False):
     """Copies sequence items according to a number of repetitions, as ``np.repeat`` does.  morgana/utils.py:175-228.
 
@@ -189,13 +220,20 @@ class SequentialWithRecurrent(nn.Sequential):
         self.precision = precision
 
     def _linear_run(self, modules, start):
-        """Collect [Linear, Sigmoid?]+ starting at ``start``; returns (end, [(linear, act), ...])."""
+        """Collect [Linear, Sigmoid?, identity Dropout?]+ starting at ``start``; returns (end, [(linear, act), ...]).
+        ``nn.Dropout`` with p == 0 or in eval mode (the reference's models pass dropout_prob=0., models/RNN_SPSS.py:21) is the
+        identity and does not break a run; an active dropout does."""
+        def identity_dropout(mod):
+            return type(mod) is nn.Dropout and (mod.p == 0 or not mod.training)
+
         run, i = [], start
         while i < len(modules) and type(modules[i]) is nn.Linear:
             act = ops.ACT_NONE
             nxt = i + 1
             if nxt < len(modules) and type(modules[nxt]) is nn.Sigmoid:
                 act, nxt = ops.ACT_SIGMOID, nxt + 1
+            while nxt < len(modules) and identity_dropout(modules[nxt]):
+                nxt += 1
             run.append((modules[i], act))
             i = nxt
         return i, run
@@ -253,6 +291,8 @@ class SequentialWithRecurrent(nn.Sequential):
                 if isinstance(input, UpsampledSequence):
                     lead, x2d, rows = input.shape[:2], input.source.reshape(-1, input.source.shape[-1]), \
                         input.rows.reshape(-1)
+                elif isinstance(input, UpsampledConcat):
+                    lead, x2d, rows = input.shape[:2], input.operand(precision == 'bf16'), None
                 else:
                     lead, x2d, rows = input.shape[:-1], input.reshape(-1, input.shape[-1]), None
                 params = []
@@ -264,7 +304,7 @@ class SequentialWithRecurrent(nn.Sequential):
                 i = end
                 continue
 
-            if isinstance(input, UpsampledSequence):
+            if isinstance(input, (UpsampledSequence, UpsampledConcat)):
                 input = input.materialise()
 
             if isinstance(module, RecurrentCuDNNWrapper):
@@ -278,7 +318,7 @@ class SequentialWithRecurrent(nn.Sequential):
                 input = module(input)
             i += 1
 
-        if isinstance(input, UpsampledSequence):
+        if isinstance(input, (UpsampledSequence, UpsampledConcat)):
             input = input.materialise()
         return input, hiddens
 

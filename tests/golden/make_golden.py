@@ -521,3 +521,132 @@ def g10_lstm():
 
 if __name__ == '__main__' and (len(sys.argv) == 1 or sys.argv[1] == 'g10'):
     g10_lstm()
+
+
+def g11_bce():
+    """G11: losses.bce of the reference (the voicing stream, models/RNN_SPSS.py:137): loss + grad, with / without seq_len,
+    including saturated probabilities 0 and 1 where torch clamps the logs at -100."""
+    import torch
+    utils, losses, data, base_models, lr_schedules, metrics = import_reference()
+    rng = np.random.RandomState(1111)
+    g = {}
+    for dim in (1, 3):
+        b, t = 5, 23
+        pn = (1.0 / (1.0 + np.exp(-3 * rng.standard_normal((b, t, dim))))).astype(np.float32)
+        pn[0, 0, 0], pn[1, 0, 0], pn[2, 3, 0], pn[3, 2, 0] = 0.0, 1.0, 1.0, 0.0      # saturated: both right and wrong
+        y = torch.from_numpy((rng.rand(b, t, dim) > 0.5).astype(np.float32))
+        y[0, 0, 0], y[1, 0, 0], y[2, 3, 0], y[3, 2, 0] = 0.0, 1.0, 0.0, 1.0
+        p = torch.from_numpy(pn).requires_grad_(True)
+        sl = torch.tensor([23, 1, 17, 9, 20], dtype=torch.int64)
+        loss = losses.bce(p, y, sl)
+        loss.backward()
+        g['d%d__pred' % dim] = pn
+        g['d%d__target' % dim] = y.numpy()
+        g['d%d__seq_len' % dim] = sl.numpy()
+        g['d%d__loss' % dim] = loss.detach().numpy()
+        g['d%d__grad' % dim] = p.grad.numpy().copy()
+        p.grad = None
+        loss = losses.bce(p, y)
+        loss.backward()
+        g['d%d__loss_nolen' % dim] = loss.detach().numpy()
+        g['d%d__grad_nolen' % dim] = p.grad.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, 'g11_bce.npz'), **g)
+    print('g11_bce.npz', os.path.getsize(os.path.join(HERE, 'g11_bce.npz')), 'bytes')
+
+
+if __name__ == '__main__' and (len(sys.argv) == 1 or sys.argv[1] == 'g11'):
+    g11_bce()
+
+
+def g12_lstm_acoustic():
+    """G12: the reference's LSTM acoustic model (models/RNN_SPSS.py:20-139) at toy size, assembled from the reference's own
+    building blocks (the module itself needs pyworld / tts_data_tools.wav_gen / bandmat to import): layer container and
+    predict/loss written out as in that file, MLPG left out (detached post-processing).  Holds the multi-stream loss alone
+    (loss + gradient on random predictions) and 6 Adam steps of the whole model."""
+    import torch
+    import torch.nn as nn
+    from morgana_amd import synthetic
+    utils, losses, data, base_models, lr_schedules, metrics = import_reference()
+    g = {}
+    streams = (('lf0', 3, 'mse'), ('vuv', 1, 'sigmoid_bce'), ('mcep', 6, 'mse'), ('bap', 3, 'mse'))
+    widths = [w for _, w, _ in streams]
+    lab_dim, counters_dim, hidden, post, num_layers = 20, 4, 16, 12, 3
+
+    def loss_fn(features, outputs):                                             # models/RNN_SPSS.py:120-139
+        n_frames = features['n_frames']
+        loss = 0.
+        loss += losses.mse(outputs['normalised_lf0_deltas'], features['normalised_lf0_deltas'], n_frames)
+        loss += losses.mse(outputs['normalised_mcep_deltas'], features['normalised_mcep_deltas'], n_frames)
+        loss += losses.mse(outputs['normalised_bap_deltas'], features['normalised_bap_deltas'], n_frames)
+        loss += losses.bce(outputs['vuv'].type(torch.float), features['vuv'].type(torch.float), n_frames)
+        return loss / 4.
+
+    def split(pred):                                                            # models/RNN_SPSS.py:86-93
+        lf0, vuv, mcep, bap = torch.split(pred, widths, dim=-1)
+        return {'normalised_lf0_deltas': lf0, 'normalised_mcep_deltas': mcep, 'normalised_bap_deltas': bap,
+                'vuv': torch.sigmoid(vuv)}
+
+    feats_np = synthetic.make_acoustic_batch(5, (10, 30), lab_dim=lab_dim, counters_dim=counters_dim, streams=streams,
+                                             frames_per_phone=5.0, seed=1212)
+    feats = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in feats_np.items()}
+
+    # the loss alone, on random predictions (large logits included so that the sigmoid saturates)
+    rng = np.random.RandomState(12)
+    max_t = int(feats_np['n_frames'].max())
+    pred_np = (rng.standard_normal((5, max_t, sum(widths))) * 2).astype(np.float32)
+    pred_np[0, 0, 3], pred_np[1, 1, 3], pred_np[2, 2, 3] = 40.0, -40.0, 110.0
+    pred = torch.from_numpy(pred_np).requires_grad_(True)
+    loss = loss_fn(feats, split(pred))
+    loss.backward()
+    g['loss__pred'] = pred_np
+    g['loss__value'] = loss.detach().numpy()
+    g['loss__grad'] = pred.grad.numpy().copy()
+    g['loss__vuv'] = torch.sigmoid(pred.detach()[..., 3:4]).numpy()
+
+    class Model(base_models.BaseSPSS):
+        def __init__(self):
+            super(Model, self).__init__()
+            self.layers = utils.SequentialWithRecurrent(                        # models/RNN_SPSS.py:32-42
+                nn.Linear(lab_dim + counters_dim, hidden), nn.Sigmoid(), nn.Dropout(p=0.),
+                *[utils.RecurrentCuDNNWrapper(nn.LSTM(hidden, hidden, dropout=0., batch_first=True))
+                  for _ in range(num_layers)],
+                nn.Linear(hidden, post), nn.Sigmoid(), nn.Dropout(p=0.),
+                nn.Linear(post, sum(widths)))
+
+        def predict(self, features):                                            # models/RNN_SPSS.py:73-85
+            at_frame_rate = utils.upsample_to_repetitions(features['normalised_lab'], features['dur'])
+            model_inputs = torch.cat((at_frame_rate, features['normalised_counters']), dim=-1)
+            pred, _ = self.layers(model_inputs, seq_len=features['n_frames'])
+            return split(pred)
+
+        def loss(self, features, output_features):
+            return loss_fn(features, output_features)
+
+    model = Model()
+    state = synthetic.lstm_acoustic_state(seed=1213, input_dim=lab_dim + counters_dim, hidden=hidden, post=post,
+                                          output_dim=sum(widths), num_layers=num_layers)
+    own = model.state_dict()
+    assert sorted(own.keys()) == sorted(state.keys()), (sorted(own.keys()), sorted(state.keys()))
+    for k, v in state.items():
+        own[k].copy_(torch.from_numpy(v))
+    optimizer = torch.optim.Adam(model.parameters(), lr=0.01)
+    curve = []
+    for step in range(6):
+        optimizer.zero_grad()
+        loss, out = model(feats)
+        loss.backward()
+        if step == 0:
+            for name in ('normalised_lf0_deltas', 'normalised_mcep_deltas', 'normalised_bap_deltas', 'vuv'):
+                g['model__step1_' + name] = out[name].detach().numpy()
+            for name, prm in model.named_parameters():
+                g['model__step1_grad__' + name] = prm.grad.detach().numpy().copy()
+        optimizer.step()
+        curve.append(loss.item())
+    g['model__loss_curve'] = np.array(curve, dtype=np.float64)
+    g['model__dims'] = np.array([lab_dim, counters_dim, hidden, post, num_layers] + widths, dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, 'g12_lstm_acoustic.npz'), **g)
+    print('g12_lstm_acoustic.npz', os.path.getsize(os.path.join(HERE, 'g12_lstm_acoustic.npz')), 'bytes; curve', curve)
+
+
+if __name__ == '__main__' and (len(sys.argv) == 1 or sys.argv[1] == 'g12'):
+    g12_lstm_acoustic()

@@ -129,6 +129,24 @@ def test_masked_mse_golden(golden, dim):
     np.testing.assert_allclose(p.grad.cpu().numpy(), g['d%d__grad_nolen' % dim], rtol=1e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize('dim', [1, 3])
+def test_masked_bce_golden(golden, dim):
+    """losses.bce (voicing stream): saturated probabilities included; tolerance 1e-5 relative fp32."""
+    g = golden('g11_bce.npz')
+    p = dev(g['d%d__pred' % dim]).requires_grad_(True)
+    y = dev(g['d%d__target' % dim])
+    sl = dev(g['d%d__seq_len' % dim])
+    loss = losses.bce(p, y, sl)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g['d%d__loss' % dim], rtol=1e-5)
+    np.testing.assert_allclose(p.grad.cpu().numpy(), g['d%d__grad' % dim], rtol=1e-5, atol=1e-9)
+    p.grad = None
+    loss = losses.bce(p, y)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g['d%d__loss_nolen' % dim], rtol=1e-5)
+    np.testing.assert_allclose(p.grad.cpu().numpy(), g['d%d__grad_nolen' % dim], rtol=1e-5, atol=1e-9)
+
+
 def test_masked_mse_zero_length_is_nan_and_full_size():
     p = torch.zeros(2, 3, 1, device=DEV)
     assert torch.isnan(losses.mse(p, p + 1, torch.tensor([0, 2], device=DEV)))
@@ -585,6 +603,112 @@ def test_rnn_model_c4_shape_vs_oracle():
     loss.backward()
     np.testing.assert_allclose(loss.item(), want_loss, rtol=RTOL)
     assert rel_err(out['pred_norm_mcep'].detach().cpu().numpy(), want_pred) < 1e-4
+    for name, prm in model.named_parameters():
+        assert rel_err(prm.grad.cpu().numpy(), want_grads[name]) < 1e-3, name
+
+
+# ------------------------------------------------------------------------ LSTM acoustic model (models/RNN_SPSS.py)
+G12_STREAMS = (('lf0', 3, 'mse'), ('vuv', 1, 'sigmoid_bce'), ('mcep', 6, 'mse'), ('bap', 3, 'mse'))
+
+
+def _stream_targets(feats, streams):
+    return [feats[name] if kind != 'mse' else feats['normalised_%s_deltas' % name] for name, _, kind in streams]
+
+
+def test_multi_stream_loss_golden(golden):
+    """3 x mse + bce(sigmoid) over 4 (models/RNN_SPSS.py:120-139) in one kernel, against the reference's four losses."""
+    g = golden('g12_lstm_acoustic.npz')
+    feats = data.to_device(synthetic.make_acoustic_batch(5, (10, 30), lab_dim=20, counters_dim=4, streams=G12_STREAMS,
+                                                         frames_per_phone=5.0, seed=1212), DEV)
+    pred = dev(g['loss__pred']).requires_grad_(True)
+    loss, prob = losses.multi_stream(pred, _stream_targets(feats, G12_STREAMS), [k for _, _, k in G12_STREAMS],
+                                     feats['n_frames'], want_prob=True)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g['loss__value'], rtol=1e-5)
+    np.testing.assert_allclose(pred.grad.cpu().numpy(), g['loss__grad'], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(prob.cpu().numpy(), g['loss__vuv'], rtol=1e-5, atol=1e-30)
+
+
+def test_multi_stream_loss_full_width_vs_oracle():
+    """The shipped model's 199 columns (3 + 1 + 180 + 15), ragged lengths, one empty utterance -> NaN as in the reference."""
+    feats = synthetic.make_acoustic_batch(6, (100, 333), seed=5)
+    rng = np.random.RandomState(6)
+    pred = (rng.standard_normal((6, int(feats['n_frames'].max()), 199)) * 1.5).astype(np.float32)
+    kinds = [k for _, _, k in synthetic.ACOUSTIC_STREAMS]
+    want_loss, want_grad = ref_cpu.multi_stream_loss(pred, _stream_targets(feats, synthetic.ACOUSTIC_STREAMS), kinds,
+                                                     feats['n_frames'])
+    d = data.to_device(feats, DEV)
+    p = dev(pred).requires_grad_(True)
+    loss, _ = losses.multi_stream(p, _stream_targets(d, synthetic.ACOUSTIC_STREAMS), kinds, d['n_frames'])
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), want_loss, rtol=1e-5)
+    assert rel_err(p.grad.cpu().numpy(), want_grad) < 1e-5
+    seq = d['n_frames'].clone()
+    seq[2] = 0
+    loss, _ = losses.multi_stream(p, _stream_targets(d, synthetic.ACOUSTIC_STREAMS), kinds, seq)
+    assert torch.isnan(loss)
+
+
+@pytest.mark.parametrize('f,c', [(600, 9), (20, 4), (7, 1)])
+def test_gather_concat_vs_numpy(f, c):
+    """upsample_to_repetitions + torch.cat with frame-level counters (models/RNN_SPSS.py:76-81) as one pass: exact copies."""
+    rng = np.random.RandomState(f)
+    src = rng.standard_normal((50, f)).astype(np.float32)
+    rows = rng.randint(-1, 50, size=777).astype(np.int32)
+    extra = rng.standard_normal((777, c)).astype(np.float32)
+    want = np.concatenate((np.where(rows[:, None] < 0, 0, src[np.maximum(rows, 0)]), extra), axis=1)
+    got = ops.gather_concat(dev(src), dev(rows), dev(extra))
+    assert np.array_equal(got.cpu().numpy(), want)
+    got = ops.gather_concat(dev(src), dev(rows), dev(extra), out_bf16=True)
+    assert got.shape == (777, ops.pad_ld(f + c)) and got.dtype == torch.bfloat16
+    assert np.array_equal(got[:, :f + c].float().cpu().numpy(), torch.from_numpy(want).bfloat16().float().numpy())
+    assert float(got[:, f + c:].float().abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_lstm_acoustic_model_golden(golden, fused):
+    """Linear / 3 x LSTM wrapper / Linear / Linear with counters concat and the 4-stream loss: loss, outputs, every gradient
+    and 6 Adam steps against the reference (fp32 mode, north-star tolerance); bf16 GEMMs track the curve."""
+    g = golden('g12_lstm_acoustic.npz')
+    lab_dim, counters_dim, hidden, post, num_layers = [int(v) for v in g['model__dims'][:5]]
+    dims = {'lf0': 3, 'vuv': 1, 'mcep': 6, 'bap': 3}
+    state = synthetic.lstm_acoustic_state(seed=1213, input_dim=lab_dim + counters_dim, hidden=hidden, post=post,
+                                          output_dim=13, num_layers=num_layers)
+    feats = data.to_device(synthetic.make_acoustic_batch(5, (10, 30), lab_dim=lab_dim, counters_dim=counters_dim,
+                                                         streams=G12_STREAMS, frames_per_phone=5.0, seed=1212), DEV)
+
+    def build(precision):
+        model = models.LSTMAcousticModel(lab_dim + counters_dim, dims, num_layers=num_layers, hidden_dim=hidden, post_dim=post,
+                                         precision=precision, fused_upsample=fused, fused_loss=fused)
+        return _load_state(model.to(DEV), state)
+
+    model = build('fp32')
+    loss, out = model(feats)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g['model__loss_curve'][0], rtol=RTOL)
+    for name in ('normalised_lf0_deltas', 'normalised_mcep_deltas', 'normalised_bap_deltas', 'vuv'):
+        np.testing.assert_allclose(out[name].detach().cpu().numpy(), g['model__step1_' + name], rtol=1e-3, atol=1e-5)
+    for name, prm in model.named_parameters():
+        want = g['model__step1_grad__' + name]
+        np.testing.assert_allclose(prm.grad.cpu().numpy(), want, rtol=1e-3, atol=1e-4 * np.abs(want).max(), err_msg=name)
+    model.zero_grad()
+    curve = _train(model, [feats], 6, lr=0.01)
+    np.testing.assert_allclose(curve, g['model__loss_curve'], rtol=RTOL)
+    curve = _train(build('bf16'), [feats], 6, lr=0.01)
+    np.testing.assert_allclose(curve, g['model__loss_curve'], rtol=RTOL_BF16)
+
+
+def test_lstm_acoustic_model_shipped_shape_vs_oracle():
+    """The shipped layout (609 -> 512 -> LSTM-512 x 2 -> 256 -> 199; 2 of the 8 recurrent layers to keep the CPU oracle in
+    seconds) on a ragged batch against the numpy oracle."""
+    feats = synthetic.make_acoustic_batch(4, (40, 90), seed=21)
+    state = synthetic.lstm_acoustic_state(num_layers=2)
+    want_loss, want_pred, want_grads = ref_cpu.lstm_acoustic_forward_backward(state, feats, synthetic.ACOUSTIC_STREAMS, 2)
+    model = _load_state(models.LSTMAcousticModel(num_layers=2, precision='fp32').to(DEV), state)
+    loss, out = model(data.to_device(feats, DEV))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), want_loss, rtol=RTOL)
+    assert rel_err(out['normalised_mcep_deltas'].cpu().numpy(), want_pred[..., 4:184]) < 1e-4
     for name, prm in model.named_parameters():
         assert rel_err(prm.grad.cpu().numpy(), want_grads[name]) < 1e-3, name
 

@@ -97,6 +97,16 @@ def test_g4_masked_mse(golden, dim):
     np.testing.assert_allclose(grad, g['d%d__grad' % dim], rtol=1e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize('dim', [1, 3])
+def test_g11_bce(golden, dim):
+    g = golden('g11_bce.npz')
+    p, y, sl = g['d%d__pred' % dim], g['d%d__target' % dim], g['d%d__seq_len' % dim]
+    np.testing.assert_allclose(ref_cpu.bce(p, y, sl), g['d%d__loss' % dim], rtol=1e-5)
+    np.testing.assert_allclose(ref_cpu.bce_grad(p, y, sl), g['d%d__grad' % dim], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(ref_cpu.bce(p, y), g['d%d__loss_nolen' % dim], rtol=1e-5)
+    np.testing.assert_allclose(ref_cpu.bce_grad(p, y), g['d%d__grad_nolen' % dim], rtol=1e-5, atol=1e-9)
+
+
 def test_g4_zero_length_is_nan(golden):
     g = golden('g4_masked_mse.npz')
     assert np.isnan(g['zero_len_loss'])
@@ -268,3 +278,39 @@ def test_g10_lstm_wrapper(golden, tag, layers):
         inp, hn, cn, _ = ref_cpu.lstm_forward(inp, sl, *params[k])
     assert inp.shape == g[tag + '__out'].shape
     np.testing.assert_allclose(inp, g[tag + '__out'], rtol=RTOL, atol=1e-6)
+
+
+G12_STREAMS = (('lf0', 3, 'mse'), ('vuv', 1, 'sigmoid_bce'), ('mcep', 6, 'mse'), ('bap', 3, 'mse'))
+
+
+def _g12_features():
+    return synthetic.make_acoustic_batch(5, (10, 30), lab_dim=20, counters_dim=4, streams=G12_STREAMS, frames_per_phone=5.0,
+                                         seed=1212)
+
+
+def test_g12_multi_stream_loss(golden):
+    """models/RNN_SPSS.py:120-139 (3 x mse + bce(sigmoid) over 4) on random predictions with saturated logits."""
+    g = golden('g12_lstm_acoustic.npz')
+    feats = _g12_features()
+    targets = [feats['vuv'] if kind != 'mse' else feats['normalised_%s_deltas' % name] for name, _, kind in G12_STREAMS]
+    loss, grad = ref_cpu.multi_stream_loss(g['loss__pred'], targets, [k for _, _, k in G12_STREAMS], feats['n_frames'])
+    np.testing.assert_allclose(loss, g['loss__value'], rtol=1e-5)
+    np.testing.assert_allclose(grad, g['loss__grad'], rtol=1e-4, atol=1e-8)
+
+
+def test_g12_lstm_acoustic_model(golden):
+    g = golden('g12_lstm_acoustic.npz')
+    lab_dim, counters_dim, hidden, post, num_layers = [int(v) for v in g['model__dims'][:5]]
+    feats = _g12_features()
+    state = synthetic.lstm_acoustic_state(seed=1213, input_dim=lab_dim + counters_dim, hidden=hidden, post=post,
+                                          output_dim=13, num_layers=num_layers)
+    loss, pred, grads = ref_cpu.lstm_acoustic_forward_backward(state, feats, G12_STREAMS, num_layers)
+    np.testing.assert_allclose(loss, g['model__loss_curve'][0], rtol=1e-5)
+    np.testing.assert_allclose(pred[..., 0:3], g['model__step1_normalised_lf0_deltas'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(ref_cpu.sigmoid(pred[..., 3:4]), g['model__step1_vuv'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(pred[..., 4:10], g['model__step1_normalised_mcep_deltas'], rtol=1e-4, atol=1e-6)
+    for key in ref_cpu.lstm_acoustic_keys(num_layers):
+        ref = g['model__step1_grad__' + key]
+        np.testing.assert_allclose(grads[key], ref, rtol=1e-3, atol=1e-4 * np.abs(ref).max(), err_msg=key)
+    curve = ref_cpu.lstm_acoustic_train(state, feats, G12_STREAMS, num_layers, 6, lr=0.01)
+    np.testing.assert_allclose(curve, g['model__loss_curve'], rtol=1e-4)
