@@ -38,6 +38,11 @@ extern "C" {
  * Library
  * ---------------------------------------------------------------------------------------------------------------- */
 const char* mg_last_error(void);
+/* Kernel scheduling knobs for experiments (A/B runs inside one process); every value computes the same results.
+ * key MG_TUNE_STAGGER: 0 = default schedule of the large bf16 GEMM kernels, other values select measured alternatives. */
+#define MG_TUNING_KEYS 8
+#define MG_TUNE_STAGGER 0
+int mg_set_tuning(int key, int value);
 int mg_version(void);           /* ABI version, bumped on incompatible change */
 const char* mg_build_arch(void); /* "gfx950" */
 

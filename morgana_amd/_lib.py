@@ -16,6 +16,7 @@ c_void_p, c_int, c_int64, c_float, c_size_t, c_char_p = (
 # name -> (restype, argtypes); must list every symbol of include/morgana_hip.h (checked by tests/test_abi.py).
 SIGNATURES = {
     'mg_last_error': (c_char_p, []),
+    'mg_set_tuning': (c_int, [c_int, c_int]),
     'mg_version': (c_int, []),
     'mg_build_arch': (c_char_p, []),
     'mg_upsample_lengths': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -103,11 +104,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get('MORGANA_HIP_LIB', LIB_PATH)      # the diagnostic build (make diag) for scripts/stamps.py
+    if not os.path.exists(path):
         raise MorganaHipError(
             'libmorgana_hip.so is missing (%s): build it with `python -c "import __graft_entry__ as g; g.build()"` '
-            'or `make -C morgana_amd/csrc`.  There is no CPU fallback.' % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+            'or `make -C morgana_amd/csrc`.  There is no CPU fallback.' % path)
+    lib = ctypes.CDLL(path)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = restype

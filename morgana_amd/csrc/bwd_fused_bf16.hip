@@ -22,6 +22,7 @@ typedef __bf16 bfv4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bfv2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
+MG_STAMP_DECL(g_stamps_fz);
 #define FZ_ELEMS 16384
 __device__ uint16_t g_fused_zero_row[FZ_ELEMS];
 
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(512) void wgrad_fused_kernel(const uint16_t* __rest
                                                           int ldwt, const uint16_t* __restrict__ H1, int ldh,
                                                           const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
                                                           int64_t M, int N, int K, int m_chunk, float* __restrict__ slab,
-                                                          float* __restrict__ bslab) {
+                                                          float* __restrict__ bslab, int variant) {
     constexpr int TKT = 5;
     constexpr int PY = 256, PX = F_BKT * 2;
     constexpr int NX = 5;
@@ -60,6 +61,12 @@ __global__ __launch_bounds__(512) void wgrad_fused_kernel(const uint16_t* __rest
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef MG_STAMPS
+    unsigned long long ts0, ts1 = 0, ts2, ts3, tr0, tr1, ta, tb, sum_wait_a = 0, sum_issue_x = 0, sum_p1 = 0, sum_wait_b = 0,
+                       sum_issue_s = 0, sum_p2 = 0;
+    MG_STAMP(ts0);
+    MG_STAMP_REAL(tr0);
+#endif
     const int wn0 = (wave >> 2) * 64;
     const int wk0 = (wave & 3) * (TKT * 32);
     const int tiles_n = N / F_BNT;
@@ -159,9 +166,17 @@ __global__ __launch_bounds__(512) void wgrad_fused_kernel(const uint16_t* __rest
         issue_small(0);
     }
     for (int step = 0; step < n_steps; ++step) {
+        MG_STAMP(ta);
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");          // A: X(step), dZ2/H1(step), W2T landed
+        MG_STAMP(tb);
+        MG_STAMP_ADD(sum_wait_a, tb, ta);
+#ifdef MG_STAMPS
+        if (step == 0) ts1 = tb;
+#endif
         if (step + 1 < n_steps) issue_x(step + 1);
-        if (wave < 4) {
+        MG_STAMP(ta);
+        MG_STAMP_ADD(sum_issue_x, ta, tb);
+        if (wave < 4 && variant != 2) {
             // ---- P1: dZ1s^T tile = W2T_s . dZ2^T, 8 k-steps over the N2 = 128 outputs of layer 2 -------------------------
             f32x16 d;
 #pragma unroll
@@ -189,8 +204,14 @@ __global__ __launch_bounds__(512) void wgrad_fused_kernel(const uint16_t* __rest
                 *reinterpret_cast<u32x2*>(smem + F_YS + mi * 256 + ((c ^ ((mi & 3) << 2)) << 4) + 8 * lh) = pk;
             }
         }
+        MG_STAMP(tb);
+        MG_STAMP_ADD(sum_p1, tb, ta);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");         // B: the dZ1 tile is complete
+        MG_STAMP(ta);
+        MG_STAMP_ADD(sum_wait_b, ta, tb);
         if (step + 1 < n_steps) issue_small(step + 1);                           // dZ2 / H1 tiles are free again
+        MG_STAMP(tb);
+        MG_STAMP_ADD(sum_issue_s, tb, ta);
         // ---- P2: dW1s += dZ1s^T . X ------------------------------------------------------------------------------------
         const unsigned char* xs = smem + F_X + (step & 1) * 40960;
 #pragma unroll
@@ -211,13 +232,19 @@ __global__ __launch_bounds__(512) void wgrad_fused_kernel(const uint16_t* __rest
                 b[j] = bfv8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
             if (bias_free) b[TKT - 1] = ones;
+            if (variant == 3) continue;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < TKT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        MG_STAMP(ta);
+        MG_STAMP_ADD(sum_p2, ta, tb);
     }
 
+#ifdef MG_STAMPS
+    MG_STAMP(ts2);
+#endif
     const int lr = lane & 31;
     float* out = slab + (size_t)s * N * K;
 #pragma unroll
@@ -242,6 +269,24 @@ __global__ __launch_bounds__(512) void wgrad_fused_kernel(const uint16_t* __rest
                 if (row < N) bslab[(size_t)s * N + row] = acc[i][TKT - 1][r];
             }
     }
+#ifdef MG_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MG_STAMP(ts3);
+    MG_STAMP_REAL(tr1);
+    const int sb = blockIdx.x;
+    MG_STAMP_STORE(g_stamps_fz, sb, wave, lane, 0, ts0);
+    MG_STAMP_STORE(g_stamps_fz, sb, wave, lane, 1, ts1);
+    MG_STAMP_STORE(g_stamps_fz, sb, wave, lane, 2, ts2);
+    MG_STAMP_STORE(g_stamps_fz, sb, wave, lane, 3, ts3);
+    MG_STAMP_STORE(g_stamps_fz, sb, wave, lane, 4, tr0);
+    MG_STAMP_STORE(g_stamps_fz, sb, wave, lane, 5, tr1);
+    MG_STAMP_STORE(g_stamps_fz, sb, wave, lane, 6, sum_wait_a);
+    MG_STAMP_STORE(g_stamps_fz, sb, wave, lane, 7, sum_issue_x);
+    MG_STAMP_STORE(g_stamps_fz, sb, wave, lane, 8, sum_p1);
+    MG_STAMP_STORE(g_stamps_fz, sb, wave, lane, 9, sum_wait_b);
+    MG_STAMP_STORE(g_stamps_fz, sb, wave, lane, 10, sum_issue_s);
+    MG_STAMP_STORE(g_stamps_fz, sb, wave, lane, 11, sum_p2);
+#endif
 }
 
 
@@ -285,7 +330,7 @@ int mg_linear_bwd_fused_bf16(const uint16_t* dZ2, int lddz, int N2, const uint16
     float* bslab = slab + (size_t)S * N * K;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(wgrad_fused_kernel, dim3((unsigned)((N / F_BNT) * S)), dim3(512), 0, st, dZ2, lddz, W2T, ldwt, H1, ldh, A, lda, rows, M,
-                       N, K, chunk, slab, bslab);
+                       N, K, chunk, slab, bslab, g_mg_tuning[MG_TUNE_STAGGER]);
     MG_CHECK_LAUNCH("mg_linear_bwd_fused_bf16/main");
     const int64_t nk = (int64_t)N * K;
     mg_launch_slab_reduce(slab, nk, nk, S, dW, accumulate, st);
@@ -295,3 +340,9 @@ int mg_linear_bwd_fused_bf16(const uint16_t* dZ2, int lddz, int N2, const uint16
 }
 
 }  // extern "C"
+
+#ifdef MG_STAMPS
+extern "C" int mg_diag_read_stamps_fz(void* dst, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps_fz), bytes < sizeof(g_stamps_fz) ? bytes : sizeof(g_stamps_fz), 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -30,6 +30,8 @@ void mg_set_error(const char* fmt, ...);
     } while (0)
 
 static inline int64_t mg_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+extern int g_mg_tuning[];
+
 static inline size_t mg_align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
 #ifdef __HIPCC__
@@ -46,10 +48,52 @@ __device__ __forceinline__ uint16_t mg_f2bf(float x) {
 __device__ __forceinline__ float mg_bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
 __device__ __forceinline__ float mg_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// bf16-mode sigmoid: one v_exp_f32 and one v_rcp_f32 (1 ulp each, far below the bf16 rounding of the result).  1/(1+e) through
+// `/` or __frcp_rn is the IEEE division sequence (div_scale, rcp, 6 fma, div_fmas, div_fixup) and exp2f adds denormal
+// handling: ~20 VALU instructions per value, which made the layer-1 forward epilogue a third of its kernel.
+__device__ __forceinline__ float mg_sigmoid_fast(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
 
 __device__ __forceinline__ float mg_wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+#endif
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// In-kernel stamps (cdna_hip_programming.md section 7).  Compiled only into the DIAGNOSTIC library
+// (make diag -> ../libmorgana_hip_diag.so, -DMG_STAMPS); the product library contains none of this.
+// Each stamping kernel owns a file-local buffer: [block][wave 0 or 4][MG_STAMP_SLOTS] shader-clock values.
+// ---------------------------------------------------------------------------------------------------------------------
+#define MG_STAMP_SLOTS 16
+#define MG_STAMP_BLOCKS 4096
+#ifdef MG_STAMPS
+#define MG_STAMP_DECL(name) __device__ unsigned long long name[MG_STAMP_BLOCKS * 2 * MG_STAMP_SLOTS]
+#define MG_STAMP(var)                                                                         \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");           \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+    } while (0)
+#define MG_STAMP_REAL(var)                                                                    \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");       \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+    } while (0)
+#define MG_STAMP_ADD(sum, t1, t0) ((sum) += (t1) - (t0))
+#define MG_STAMP_STORE(buf, block, wave, lane, slot, value)                                   \
+    do {                                                                                      \
+        if ((block) < MG_STAMP_BLOCKS && ((wave) & 3) == 0 && (lane) == 0)                    \
+            buf[((size_t)(block) * 2 + ((wave) >> 2)) * MG_STAMP_SLOTS + (slot)] = (value);   \
+    } while (0)
+#else
+#define MG_STAMP_DECL(name)
+#define MG_STAMP(var) do { } while (0)
+#define MG_STAMP_REAL(var) do { } while (0)
+#define MG_STAMP_ADD(sum, t1, t0) do { } while (0)
+#define MG_STAMP_STORE(buf, block, wave, lane, slot, value) do { } while (0)
 #endif

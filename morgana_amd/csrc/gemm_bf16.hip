@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const uint16_t* __res
             float x = v[e];
             if (col + e >= N) x = 0.f;
             else if (EPI == EPI_BIAS) x += bias ? bias[col + e] : 0.f;
-            else if (EPI == EPI_BIAS_SIGMOID) x = mg_sigmoid(x + (bias ? bias[col + e] : 0.f));
+            else if (EPI == EPI_BIAS_SIGMOID) x = mg_sigmoid_fast(x + (bias ? bias[col + e] : 0.f));
             else {
                 const float h = (float)hv[e];
                 x = x * h * (1.f - h);

@@ -42,7 +42,6 @@ __device__ __forceinline__ void glds16(const uint16_t* src, unsigned char* lds_w
                  : "memory");
 }
 
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
 
 #define WAIT_VM_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_barrier" ::: "memory")
 #define WAIT_LGKM_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -58,12 +57,14 @@ __device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + 
 // Requires lda, ldb multiples of 64 (zero padded), N % BN == 0, ldc == N, (SIGMOID_GRAD) ldh >= N.
 // ---------------------------------------------------------------------------------------------------------------------
 #define NT_STAGES 4
+MG_STAMP_DECL(g_stamps_nt);
 
 template <int BN, int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
                                                           int64_t M, int K, const uint16_t* __restrict__ Bm, int ldb, int N,
                                                           const float* __restrict__ bias, const uint16_t* __restrict__ H, int ldh,
-                                                          void* __restrict__ Cv, int ldc, int tiles_m, int tiles_n, int c_f32) {
+                                                          void* __restrict__ Cv, int ldc, int tiles_m, int tiles_n, int c_f32,
+                                                          int variant) {
     constexpr int BM = 256;
     constexpr int WAVES_N = BN / 64;              // 4 or 2
     constexpr int WAVES_M = 8 / WAVES_N;          // 2 or 4
@@ -86,6 +87,11 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __rest
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef MG_STAMPS
+    unsigned long long ts0, ts1 = 0, ts2, ts3, tr0, tr1, ta, tb, sum_wait = 0, sum_issue = 0;
+    MG_STAMP(ts0);
+    MG_STAMP_REAL(tr0);
+#endif
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * 64;
     const int64_t m0 = (int64_t)tile_m * BM;
     const int n0 = tile_n * BN;
@@ -150,10 +156,19 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __rest
         boff[j] = A_BYTES + row * 64 + ((lh ^ ((row >> 2) & 3)) << 4);
     }
 
+    const bool late = variant == 1 && wave >= 4;
+    // Phase stagger (variant >= 2): the first round of workgroups (one per CU) starts spread over about one tile time, so
+    // that the CUs' store bursts (128 KB per tile) and prologue fetches stop coinciding; later workgroups inherit the phase
+    // of the CU they land on.
+    if (variant >= 2 && blockIdx.x < 256) {
+        const int units = (blockIdx.x * 5) & 15;
+        for (int i = 0; i < units * (variant - 1); ++i) __builtin_amdgcn_s_sleep(32);
+    }
     issue(0);
     if (n_kt > 1) issue(1);
     if (n_kt > 2) issue(2);
     for (int kt = 0; kt < n_kt; ++kt) {
+        MG_STAMP(ta);
         if (kt + 2 < n_kt) {
             if (NL == 4) WAIT_VM_BARRIER(8); else WAIT_VM_BARRIER(6);
         } else if (kt + 1 < n_kt) {
@@ -161,7 +176,17 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __rest
         } else {
             WAIT_VM_BARRIER(0);
         }
-        if (kt + 3 < n_kt) issue(kt + 3);        // refills the stage every wave finished reading before this barrier
+        MG_STAMP(tb);
+        MG_STAMP_ADD(sum_wait, tb, ta);
+#ifdef MG_STAMPS
+        if (kt == 0) ts1 = tb;
+#endif
+        // The stage refilled here is the one every wave finished reading before this barrier.  Waves w and w + 4 share a
+        // SIMD: the lower half issues its LDS-DMA before its MFMAs, the upper half after them, so that one wave's DMA issue
+        // (60-185 cycles per piece) runs under the other's matrix work instead of both stalling together.
+        if (!late && kt + 3 < n_kt) issue(kt + 3);
+        MG_STAMP(ta);
+        MG_STAMP_ADD(sum_issue, ta, tb);
         const unsigned char* st = smem + (kt & (NT_STAGES - 1)) * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -178,8 +203,16 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __rest
                     else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
                 }
         }
+        if (late && kt + 3 < n_kt) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue(kt + 3);
+        }
     }
 
+#ifdef MG_STAMPS
+    MG_STAMP(ts2);
+    // the diagnostic build ends with the epilogue's stores drained, so that its stamp covers them
+#endif
     if (EPI == EPI_SIGMOID_GRAD) {
         // Memory-bound variant (dX = (dY W) * H (1 - H), K small): plain C layout, fp32 sub-tiles staged through LDS so that
         // H is read and dX written as whole 16-byte row pieces (8 lanes per 128-byte row segment).
@@ -223,8 +256,8 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __rest
         return;
     }
 
-    // Epilogue in registers.  Sub-tile (i, j): this lane's frame row m = m0 + wm0 + 32 i + (lane & 31); register 4g + e
-    // is column n0 + wn0 + 32 j + 8 g + 4 (lane >> 5) + e.
+    // Accumulator layout of sub-tile (i, j): this lane's frame row m = m0 + wm0 + 32 i + (lane & 31); register 4g + e is
+    // column n0 + wn0 + 32 j + 8 g + 4 (lane >> 5) + e.
     float bv[TN][16];
     if (EPI != EPI_SIGMOID_GRAD) {
 #pragma unroll
@@ -234,66 +267,79 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __rest
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bv[j][4 * g + e] = bias ? bias[n0 + wn0 + j * 32 + 8 * g + 4 * lh + e] : 0.f;
     }
-    const float kNegLog2e = -1.4426950408889634f;
+    if (!c_f32) {
+        // bf16 output: rows leave through a wave-private LDS patch so that a store instruction writes whole 128-byte row
+        // segments (8 lanes x 16 B).  Stored straight from the accumulator layout (lane = row) every lane of a store hits a
+        // different row: 16-byte transactions, measured 16-25k cycles per 256 x 256 tile against ~33k for its whole main loop.
+        constexpr int SP = 144;                                // patch row pitch: 64 columns x 2 B + 16 B of bank spread
+        WAIT_LGKM_BARRIER();                                   // every wave is done with the tile stages
+        unsigned char* patch = smem + wave * (32 * SP);
+        const int prow = lane >> 3, pchunk = lane & 7;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = acc[i][j][4 * g + e] + bv[j][4 * g + e];
+                        if (EPI == EPI_BIAS_SIGMOID) x = mg_sigmoid_fast(x);
+                        v[e] = x;
+                    }
+                    typedef __bf16 bfv2 __attribute__((ext_vector_type(2)));
+                    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+                    const u32x2_t pk = u32x2_t{__builtin_bit_cast(unsigned int, bfv2{(__bf16)v[0], (__bf16)v[1]}),
+                                               __builtin_bit_cast(unsigned int, bfv2{(__bf16)v[2], (__bf16)v[3]})};
+                    *reinterpret_cast<u32x2_t*>(patch + lr * SP + (j * 32 + 8 * g + 4 * lh) * 2) = pk;
+                }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+                const int rl = it * 8 + prow;
+                const u32x4_t o = *reinterpret_cast<const u32x4_t*>(patch + rl * SP + pchunk * 16);
+                const int64_t m = m0 + wm0 + i * 32 + rl;
+                if (m < M) *reinterpret_cast<u32x4_t*>(reinterpret_cast<uint16_t*>(Cv) + (size_t)m * ldc + n0 + wn0 + pchunk * 8) = o;
+            }
+        }
+    } else
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int64_t m = m0 + wm0 + i * 32 + lr;
         const bool live = m < M;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int cbase = n0 + wn0 + j * 32 + 4 * lh;          // column of register group 0
-            float v[16];
-            if (EPI == EPI_SIGMOID_GRAD) {
-                bfv4 hv[4];
+            // fp32 output (a wide last layer): straight from the registers, 16 bytes per lane and 4-column group
+            if (!live) continue;
+            float* crow = reinterpret_cast<float*>(Cv) + (size_t)m * ldc + n0 + wn0 + j * 32 + 4 * lh;
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    hv[g] = live ? *reinterpret_cast<const bfv4*>(H + (size_t)m * ldh + cbase + 8 * g) : bfv4{0, 0, 0, 0};
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float h = (float)hv[g][e];
-                        v[4 * g + e] = acc[i][j][4 * g + e] * h * (1.f - h);
-                    }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float x = acc[i][j][r] + bv[j][r];
-                    if (EPI == EPI_BIAS_SIGMOID) x = __frcp_rn(1.f + exp2f(x * kNegLog2e));
-                    v[r] = x;
+                for (int e = 0; e < 4; ++e) {
+                    float x = acc[i][j][4 * g + e] + bv[j][4 * g + e];
+                    if (EPI == EPI_BIAS_SIGMOID) x = mg_sigmoid_fast(x);
+                    v[e] = x;
                 }
-            }
-            if (c_f32) {
-                if (live) {
-                    float* crow = reinterpret_cast<float*>(Cv) + (size_t)m * ldc + cbase;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(crow + 8 * g) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
-                }
-            } else {
-                // pack 4 columns -> 2 dwords per group; pair groups (g, g+1) through v_permlane32_swap so that lanes
-                // 0-31 own columns 8g..8g+7 and lanes 32-63 own 8g+8..8g+15 of their row: one 16-byte store each.
-                unsigned int pk[4][2];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    typedef __bf16 bfv2 __attribute__((ext_vector_type(2)));
-                    const bfv2 lo = bfv2{(__bf16)v[4 * g], (__bf16)v[4 * g + 1]};
-                    const bfv2 hi = bfv2{(__bf16)v[4 * g + 2], (__bf16)v[4 * g + 3]};
-                    pk[g][0] = __builtin_bit_cast(unsigned int, lo);
-                    pk[g][1] = __builtin_bit_cast(unsigned int, hi);
-                }
-                uint16_t* crow = reinterpret_cast<uint16_t*>(Cv) + (size_t)m * ldc + (n0 + wn0 + j * 32);
-#pragma unroll
-                for (int g = 0; g < 4; g += 2) {
-                    const auto r0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
-                    const auto r1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
-                    if (live) {
-                        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-                        *reinterpret_cast<u32x4_t*>(crow + 8 * g + 8 * lh) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
-                    }
-                }
+                *reinterpret_cast<f32x4*>(crow + 8 * g) = f32x4{v[0], v[1], v[2], v[3]};
             }
         }
     }
+#ifdef MG_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MG_STAMP(ts3);
+    MG_STAMP_REAL(tr1);
+    const int sb = blockIdx.x;
+    MG_STAMP_STORE(g_stamps_nt, sb, wave, lane, 0, ts0);
+    MG_STAMP_STORE(g_stamps_nt, sb, wave, lane, 1, ts1);
+    MG_STAMP_STORE(g_stamps_nt, sb, wave, lane, 2, ts2);
+    MG_STAMP_STORE(g_stamps_nt, sb, wave, lane, 3, ts3);
+    MG_STAMP_STORE(g_stamps_nt, sb, wave, lane, 4, tr0);
+    MG_STAMP_STORE(g_stamps_nt, sb, wave, lane, 5, tr1);
+    MG_STAMP_STORE(g_stamps_nt, sb, wave, lane, 6, sum_wait);
+    MG_STAMP_STORE(g_stamps_nt, sb, wave, lane, 7, sum_issue);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -306,6 +352,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __rest
 // ---------------------------------------------------------------------------------------------------------------------
 #define WG_ROWS_MAX 4096
 #define WG_STAGES 3
+MG_STAMP_DECL(g_stamps_wg);
 
 template <int TKW>
 __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restrict__ dY, int lddy, const uint16_t* __restrict__ A, int lda,
@@ -325,6 +372,11 @@ __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restri
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef MG_STAMPS
+    unsigned long long ts0, ts1 = 0, ts2, ts3, tr0, tr1, ta, tb, sum_wait = 0, sum_issue = 0;
+    MG_STAMP(ts0);
+    MG_STAMP_REAL(tr0);
+#endif
     const int wn0 = (wave >> 2) * 64;             // 2 waves along n
     const int wk0 = (wave & 3) * (TKT * 32);      // 4 waves along k
     // Block order: n tile fastest, then split (measured: grouping the n tiles of a split on one XCD so that they share the
@@ -421,12 +473,20 @@ __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restri
     if (n_steps > 0) issue(0);
     if (n_steps > 1) issue(1);
     for (int step = 0; step < n_steps; ++step) {
+        MG_STAMP(ta);
         if (step + 1 < n_steps) {
             if (NLW == 6) WAIT_VM_BARRIER(6); else WAIT_VM_BARRIER(5);
         } else {
             WAIT_VM_BARRIER(0);
         }
+        MG_STAMP(tb);
+        MG_STAMP_ADD(sum_wait, tb, ta);
+#ifdef MG_STAMPS
+        if (step == 0) ts1 = tb;
+#endif
         if (step + 2 < n_steps) issue(step + 2);  // refills the stage every wave finished reading before this barrier
+        MG_STAMP(ta);
+        MG_STAMP_ADD(sum_issue, ta, tb);
         const unsigned char* st = smem + (step % WG_STAGES) * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -464,6 +524,9 @@ __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restri
         }
     }
 
+#ifdef MG_STAMPS
+    MG_STAMP(ts2);
+#endif
     const int lr = lane & 31, lh = lane >> 5;
     float* out = slab + (size_t)s * N * K;
 #pragma unroll
@@ -491,6 +554,20 @@ __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restri
             }
         }
     }
+#ifdef MG_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MG_STAMP(ts3);
+    MG_STAMP_REAL(tr1);
+    const int sb = blockIdx.x;
+    MG_STAMP_STORE(g_stamps_wg, sb, wave, lane, 0, ts0);
+    MG_STAMP_STORE(g_stamps_wg, sb, wave, lane, 1, ts1);
+    MG_STAMP_STORE(g_stamps_wg, sb, wave, lane, 2, ts2);
+    MG_STAMP_STORE(g_stamps_wg, sb, wave, lane, 3, ts3);
+    MG_STAMP_STORE(g_stamps_wg, sb, wave, lane, 4, tr0);
+    MG_STAMP_STORE(g_stamps_wg, sb, wave, lane, 5, tr1);
+    MG_STAMP_STORE(g_stamps_wg, sb, wave, lane, 6, sum_wait);
+    MG_STAMP_STORE(g_stamps_wg, sb, wave, lane, 7, sum_issue);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -512,7 +589,7 @@ int mg_try_nt_big(const uint16_t* A, int lda, const int32_t* rows, int64_t M, in
     const int64_t blocks = mg_ceil_div(tiles_m, 8) * 8 * tiles_n;
     if (blocks >= 2147483647LL || tiles_m >= 2147483647LL) return 0;
     dim3 grid((unsigned)blocks), block(512);
-#define LAUNCH_NT(BN_, EPI_) hipLaunchKernelGGL((gemm_nt_big_kernel<BN_, EPI_>), grid, block, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, H, ldh, C, ldc, (int)tiles_m, tiles_n, c_f32)
+#define LAUNCH_NT(BN_, EPI_) hipLaunchKernelGGL((gemm_nt_big_kernel<BN_, EPI_>), grid, block, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, H, ldh, C, ldc, (int)tiles_m, tiles_n, c_f32, g_mg_tuning[MG_TUNE_STAGGER])
     if (wide) {
         if (epi == EPI_BIAS) LAUNCH_NT(256, EPI_BIAS);
         else if (epi == EPI_BIAS_SIGMOID) LAUNCH_NT(256, EPI_BIAS_SIGMOID);
@@ -553,3 +630,12 @@ int mg_launch_wgrad_big(const uint16_t* dY, int lddy, const uint16_t* A, int lda
         hipLaunchKernelGGL((wgrad_big_kernel<8>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab);
     return 1;
 }
+
+#ifdef MG_STAMPS
+extern "C" int mg_diag_read_stamps_wg(void* dst, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps_wg), bytes < sizeof(g_stamps_wg) ? bytes : sizeof(g_stamps_wg), 0, hipMemcpyDeviceToHost);
+}
+extern "C" int mg_diag_read_stamps_nt(void* dst, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps_nt), bytes < sizeof(g_stamps_nt) ? bytes : sizeof(g_stamps_nt), 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -12,7 +12,15 @@ void mg_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+int g_mg_tuning[MG_TUNING_KEYS] = {0};
+
 extern "C" {
+
+int mg_set_tuning(int key, int value) {
+    MG_CHECK_ARG(key >= 0 && key < MG_TUNING_KEYS, "mg_set_tuning: key %d not in 0..%d", key, MG_TUNING_KEYS - 1);
+    g_mg_tuning[key] = value;
+    return MG_OK;
+}
 
 const char* mg_last_error(void) { return g_error; }
 

@@ -95,7 +95,6 @@ __global__ __launch_bounds__(256, 2) void f0_tail_kernel(const uint16_t* __restr
     float db4p = 0.f, lossp = 0.f;
 
     const int64_t n_tiles = (M + 31) / 32;
-    const float kNegLog2e = -1.4426950408889634f;
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
         const int64_t m = tile * 32 + mi;
         const bool live = m < M;
@@ -125,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void f0_tail_kernel(const uint16_t* __restr
         float ph = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            h3[r] = __frcp_rn(1.f + exp2f((z[r] + b3v[r]) * kNegLog2e));
+            h3[r] = mg_sigmoid_fast(z[r] + b3v[r]);
             ph += h3[r] * w4v[r];
         }
         const float p = ph + __shfl_xor(ph, 32, 64) + b4v;

@@ -41,18 +41,32 @@ def main():
         'wgrad2': (2.0 * m * 512 * 128, lambda: ops.linear_wgrad_bf16(dz2, h1, None, m, 128, 512)),
         'fused': (2.0 * m * 600 * 512 + 2.0 * m * 512 * 128, lambda: ops.linear_bwd_fused_bf16(dz2, w2t, h1, tab, rows, m, 512, 600)),
     }
+    from morgana_amd import _lib
+    lib = _lib.load()
+    variants = [int(v) for v in os.environ.get('MG_VARIANTS', '0').split(',')]
+    rounds = int(os.environ.get('MG_ROUNDS', '3'))
     for name in which:
         flops, fn = cases[name]
         for _ in range(2):
             fn()
-        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        start.record()
-        for _ in range(iters):
-            fn()
-        end.record()
-        end.synchronize()
-        ms = start.elapsed_time(end) / iters
-        print('%-8s %8.1f us  %8.1f TFLOP/s' % (name, ms * 1e3, flops / ms / 1e9))
+        # interleaved rounds in one process: variants x rounds, median and min per variant
+        times = {v: [] for v in variants}
+        for _ in range(rounds):
+            for v in variants:
+                lib.mg_set_tuning(0, v)
+                fn()
+                start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                start.record()
+                for _ in range(iters):
+                    fn()
+                end.record()
+                end.synchronize()
+                times[v].append(start.elapsed_time(end) / iters)
+        lib.mg_set_tuning(0, 0)
+        for v in variants:
+            ts = sorted(times[v])
+            med = ts[len(ts) // 2]
+            print('%-8s variant %d  median %8.1f us (min %8.1f)  %8.1f TFLOP/s' % (name, v, med * 1e3, ts[0] * 1e3, flops / med / 1e9))
 
 
 if __name__ == '__main__':
