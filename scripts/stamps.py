@@ -77,10 +77,9 @@ def main():
     for _ in range(3):
         ops.linear_bwd_fused_bf16(dz2, w2t, h1, tab, rows, m, 512, 600)
     torch.cuda.synchronize()
-    s = read(lib, 'mg_diag_read_stamps_fz', 256)
-    report('wgrad_fused (dgrad2 + wgrad1)', s,
-           [('  loop: barrier A (vmcnt 0)', s[..., 6]), ('  loop: X DMA issue', s[..., 7]), ('  loop: P1 (waves 0-3)', s[..., 8]),
-            ('  loop: barrier B', s[..., 9]), ('  loop: dZ2/H1 DMA issue', s[..., 10]), ('  loop: P2', s[..., 11])])
+    s = read(lib, 'mg_diag_read_stamps_fp', 256)
+    report('wgrad_fused_pipe (dgrad2 + wgrad1, gathered input)', s,
+           [('  loop: barrier', s[..., 6]), ('  loop: DMA issue + look-ahead reads', s[..., 7]), ('  loop: P1 and P2', s[..., 8])])
 
 
 if __name__ == '__main__':
