@@ -41,6 +41,33 @@ __global__ __launch_bounds__(256) void cast_pad_bf16_kernel(const float* __restr
     }
 }
 
+// Eight columns per thread: two 16-byte loads, one 16-byte store (needs lds % 4 == 0, ldd % 8 == 0, 16-byte aligned buffers).
+// The element-wise form above spends a 64-bit division per element and moves 2 bytes per lane: 2.9 TB/s on the 49 MB label
+// table of config C2 against ~2x that here.
+__global__ __launch_bounds__(256) void cast_pad_bf16_x8_kernel(const float* __restrict__ src, int lds, uint16_t* __restrict__ dst,
+                                                               int ldd, int64_t rows, int cols) {
+    const int chunks = ldd >> 3;
+    const int64_t n = rows * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / chunks;
+        const int c0 = (int)(i - r * chunks) << 3;
+        float v[8];
+        const float* sp = src + r * lds + c0;
+        if (c0 + 8 <= cols) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+            v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (c0 + j < cols) ? sp[j] : 0.f;
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (short)mg_f2bf(v[j]);
+        *reinterpret_cast<bf16x8*>(dst + r * ldd + c0) = o;
+    }
+}
+
 // dst[c, r] = src[r, c]; 32x32 LDS tile transpose.
 __global__ __launch_bounds__(256) void cast_transpose_bf16_kernel(const float* __restrict__ src, int lds, uint16_t* __restrict__ dst,
                                                                   int ldd, int rows, int cols) {
@@ -152,7 +179,10 @@ int mg_cast_pad_bf16(const float* src, int lds, uint16_t* dst, int ldd, int64_t 
     MG_CHECK_ARG(src && dst && rows >= 0 && cols > 0 && lds >= cols && ldd >= cols, "mg_cast_pad_bf16: bad arguments (rows=%lld cols=%d lds=%d ldd=%d)",
                  (long long)rows, cols, lds, ldd);
     if (rows == 0) return MG_OK;
-    hipLaunchKernelGGL(cast_pad_bf16_kernel, dim3(flat_grid(rows * ldd)), dim3(256), 0, (hipStream_t)stream, src, lds, dst, ldd, rows, cols);
+    if (lds % 4 == 0 && ldd % 8 == 0 && (((uintptr_t)src | (uintptr_t)dst) % 16) == 0)
+        hipLaunchKernelGGL(cast_pad_bf16_x8_kernel, dim3(flat_grid(rows * (ldd / 8))), dim3(256), 0, (hipStream_t)stream, src, lds, dst, ldd, rows, cols);
+    else
+        hipLaunchKernelGGL(cast_pad_bf16_kernel, dim3(flat_grid(rows * ldd)), dim3(256), 0, (hipStream_t)stream, src, lds, dst, ldd, rows, cols);
     MG_CHECK_LAUNCH("mg_cast_pad_bf16");
     return MG_OK;
 }
