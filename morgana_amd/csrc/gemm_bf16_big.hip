@@ -56,15 +56,13 @@ __device__ __forceinline__ void glds16(const uint16_t* src, unsigned char* lds_w
 // LDS staging and no per-element index arithmetic (the first version spent ~45 % of its cycles there, profiles/r1).
 // Requires lda, ldb multiples of 64 (zero padded), N % BN == 0, ldc == N, (SIGMOID_GRAD) ldh >= N.
 // ---------------------------------------------------------------------------------------------------------------------
-#define NT_STAGES 4
 MG_STAMP_DECL(g_stamps_nt);
 
 template <int BN, int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
                                                           int64_t M, int K, const uint16_t* __restrict__ Bm, int ldb, int N,
                                                           const float* __restrict__ bias, const uint16_t* __restrict__ H, int ldh,
-                                                          void* __restrict__ Cv, int ldc, int tiles_m, int tiles_n, int c_f32,
-                                                          int variant) {
+                                                          void* __restrict__ Cv, int ldc, int tiles_m, int tiles_n, int c_f32) {
     constexpr int BM = 256;
     constexpr int WAVES_N = BN / 64;              // 4 or 2
     constexpr int WAVES_M = 8 / WAVES_N;          // 2 or 4
@@ -75,8 +73,11 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __rest
     constexpr int GA = BM / 16 / 8;               // 1 KB pieces (16 rows) per wave for A: 2
     constexpr int GB = BN / 16 / 8;               // for B: 2 or 1
     constexpr int NL = GA + GB;                   // LDS-DMA instructions per wave per stage: 4 or 3
+    // Stages: 4 x 32 KB for the square tile; 6 x 24 KB for the 128-wide one, whose shapes (K >> N: layer-2 forward) stream A
+    // from HBM - five tiles in flight per CU cover the HBM latency at ~6 TB/s, three do not (87 -> see DESIGN.md).
+    constexpr int NS = (BN == 256) ? 4 : 6;
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NT_STAGES * STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
 
     // XCD-aware tile order: blocks b and b + 8 share an XCD (its L2); give them the N tiles of ONE M tile so the A rows
     // and the H tile are fetched into that L2 once.
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __rest
     }
 
     auto issue = [&](int kt) {
-        unsigned char* st = smem + (kt & (NT_STAGES - 1)) * STAGE;
+        unsigned char* st = smem + (kt % NS) * STAGE;
 #pragma unroll
         for (int i = 0; i < GA; ++i) glds16(asrc[i] + kt * 32, st + (wave * GA + i) * 1024);
 #pragma unroll
@@ -156,38 +157,34 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __rest
         boff[j] = A_BYTES + row * 64 + ((lh ^ ((row >> 2) & 3)) << 4);
     }
 
-    const bool late = variant == 1 && wave >= 4;
-    // Phase stagger (variant >= 2): the first round of workgroups (one per CU) starts spread over about one tile time, so
-    // that the CUs' store bursts (128 KB per tile) and prologue fetches stop coinciding; later workgroups inherit the phase
-    // of the CU they land on.
-    if (variant >= 2 && blockIdx.x < 256) {
-        const int units = (blockIdx.x * 5) & 15;
-        for (int i = 0; i < units * (variant - 1); ++i) __builtin_amdgcn_s_sleep(32);
-    }
-    issue(0);
-    if (n_kt > 1) issue(1);
-    if (n_kt > 2) issue(2);
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < n_kt) issue(p);
     for (int kt = 0; kt < n_kt; ++kt) {
         MG_STAMP(ta);
-        if (kt + 2 < n_kt) {
-            if (NL == 4) WAIT_VM_BARRIER(8); else WAIT_VM_BARRIER(6);
-        } else if (kt + 1 < n_kt) {
-            if (NL == 4) WAIT_VM_BARRIER(4); else WAIT_VM_BARRIER(3);
-        } else {
-            WAIT_VM_BARRIER(0);
+        // tiles issued so far: min(n_kt, kt + NS - 1); tile kt must have landed: min(n_kt - 1 - kt, NS - 2) tiles may stay
+        // in flight, NL LDS-DMA instructions each (vmcnt takes an immediate, hence the ladder)
+        {
+            const int fly = min(n_kt - 1 - kt, NS - 2);
+            if (NL == 4) {
+                if (fly >= 2) WAIT_VM_BARRIER(8); else if (fly == 1) WAIT_VM_BARRIER(4); else WAIT_VM_BARRIER(0);
+            } else if (NS == 4) {
+                if (fly >= 2) WAIT_VM_BARRIER(6); else if (fly == 1) WAIT_VM_BARRIER(3); else WAIT_VM_BARRIER(0);
+            } else {
+                if (fly >= 4) WAIT_VM_BARRIER(12); else if (fly == 3) WAIT_VM_BARRIER(9); else if (fly == 2) WAIT_VM_BARRIER(6);
+                else if (fly == 1) WAIT_VM_BARRIER(3); else WAIT_VM_BARRIER(0);
+            }
         }
         MG_STAMP(tb);
         MG_STAMP_ADD(sum_wait, tb, ta);
 #ifdef MG_STAMPS
         if (kt == 0) ts1 = tb;
 #endif
-        // The stage refilled here is the one every wave finished reading before this barrier.  Waves w and w + 4 share a
-        // SIMD: the lower half issues its LDS-DMA before its MFMAs, the upper half after them, so that one wave's DMA issue
-        // (60-185 cycles per piece) runs under the other's matrix work instead of both stalling together.
-        if (!late && kt + 3 < n_kt) issue(kt + 3);
+        // the stage refilled here is the one every wave finished reading before this barrier
+        if (kt + NS - 1 < n_kt) issue(kt + NS - 1);
         MG_STAMP(ta);
         MG_STAMP_ADD(sum_issue, ta, tb);
-        const unsigned char* st = smem + (kt & (NT_STAGES - 1)) * STAGE;
+        const unsigned char* st = smem + (kt % NS) * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bfv8 a[TM], b[TN];
@@ -202,10 +199,6 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __rest
                     if (EPI == EPI_SIGMOID_GRAD) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
                     else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
                 }
-        }
-        if (late && kt + 3 < n_kt) {
-            __builtin_amdgcn_sched_barrier(0);
-            issue(kt + 3);
         }
     }
 
@@ -339,6 +332,277 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __rest
     MG_STAMP_STORE(g_stamps_nt, sb, wave, lane, 5, tr1);
     MG_STAMP_STORE(g_stamps_nt, sb, wave, lane, 6, sum_wait);
     MG_STAMP_STORE(g_stamps_nt, sb, wave, lane, 7, sum_issue);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// gemm_nt_persist: the same tile program as gemm_nt_big for the bias / bias + sigmoid epilogues with bf16 output, as ONE
+// resident workgroup per CU that walks its tiles while the LDS-DMA stream runs on across tile boundaries.
+// Why (in-kernel stamps of the per-tile kernel): every tile began with an empty ring - "entry -> first stage
+// landed" was 11 % of the layer-1 forward and 22 % of the layer-2 forward, every CU bursting 96-120 KB at HBM at once -
+// and ended with its stores draining while nothing was in flight.  Here the first NS - 1 stages of the next tile are
+// issued during the last k-steps of the current one, so the matrix pipe restarts right behind the epilogue, whose stores
+// drain under the next tile's loop.
+// vmcnt is one in-order counter for LDS-DMA and stores: behind a tile boundary the waits let the epilogue's NST stores ride
+// along (allowance = in-flight stages * NL + NST for the first NS - 1 k-steps of a tile, see the ladder below).
+// The row indices of all of the workgroup's tiles are parked in LDS up front (<= 8 tiles), so the loop issues no
+// VGPR-destination load.  The epilogue's row patch is the stage consumed last (BN = 256: exactly 32 KB) or a region of its
+// own (BN = 128).
+// ---------------------------------------------------------------------------------------------------------------------
+#define NTP_MAX_TILES 8
+__device__ uint16_t g_ntp_sink[64 * 8];            // where the stores of rows past M go: every wave issues exactly NST stores
+MG_STAMP_DECL(g_stamps_ntp);
+
+#define NTP_WAIT_CASE(N) case N: WAIT_VM_BARRIER(N); break;
+
+template <int BN, int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
+                                                              int64_t M, int K, const uint16_t* __restrict__ Bm, int ldb, int N,
+                                                              const float* __restrict__ bias, uint16_t* __restrict__ C, int ldc,
+                                                              int tiles_m, int tiles_n) {
+    constexpr int BM = 256;
+    constexpr int WAVES_N = BN / 64;              // 4 or 2
+    constexpr int WAVES_M = 8 / WAVES_N;          // 2 or 4
+    constexpr int WM = BM / WAVES_M;              // 128 or 64
+    constexpr int TM = WM / 32, TN = 2;
+    constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
+    constexpr int STAGE = A_BYTES + B_BYTES;      // 32 KB or 24 KB
+    constexpr int GA = BM / 16 / 8;               // 1 KB pieces (16 rows) per wave for A: 2
+    constexpr int GB = BN / 16 / 8;               // for B: 2 or 1
+    constexpr int NL = GA + GB;                   // LDS-DMA instructions per wave per stage: 4 or 3
+    constexpr int NS = (BN == 256) ? 4 : 5;
+    constexpr int NST = TM * 4;                   // epilogue stores per wave per tile: 16 or 8
+    constexpr int ROWTAB = NS * STAGE;            // int32[NTP_MAX_TILES][256]
+    constexpr int PATCH = ROWTAB + NTP_MAX_TILES * BM * 4;
+    constexpr int SP = 128;                       // patch row: 64 columns x 2 B, 16-byte chunk c of row r at c ^ (r & 7)
+    constexpr int LDS_BYTES = PATCH + (BN == 256 ? 0 : 8 * 32 * SP);
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    int* rowtab = reinterpret_cast<int*>(smem + ROWTAB);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef MG_STAMPS
+    unsigned long long ts0, ts1 = 0, ts2, ts3, tr0, tr1, ta, tb, sum_wait = 0, sum_epi = 0;
+    MG_STAMP(ts0);
+    MG_STAMP_REAL(tr0);
+#endif
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * 64;
+    const int n_kt = (K + 31) / 32;
+
+    // Virtual block v = blockIdx.x + i gridDim.x (gridDim.x a multiple of 8) keeps the XCD-aware order of gemm_nt_big: the N
+    // tiles of one M tile go to blocks 8 apart, which share an XCD and its L2.
+    auto tile_of = [&](int i, int& tile_m, int& tile_n) {
+        const int v = blockIdx.x + i * gridDim.x;
+        const int xcd = v & 7, jj = v >> 3;
+        tile_n = jj % tiles_n;
+        tile_m = (jj / tiles_n) * 8 + xcd;
+    };
+    int n_my = 0;                                 // the launcher makes (gridDim.x / 8) a multiple of tiles_n: one N tile per workgroup
+    for (int i = 0; i < NTP_MAX_TILES; ++i) {
+        int tm, tn;
+        tile_of(i, tm, tn);
+        if (tm < tiles_m) n_my = i + 1;
+    }
+    // park the source rows of every tile of this workgroup (-1: zero row)
+    for (int e = tid; e < n_my * BM; e += 512) {
+        int tm, tn;
+        tile_of(e / BM, tm, tn);
+        const int64_t m = (int64_t)tm * BM + (e % BM);
+        int r = -1;
+        if (m < M) r = rows ? rows[m] : (int)m;
+        rowtab[e] = r;
+    }
+    __syncthreads();
+    if (n_my == 0) return;
+
+    // issue cursor: tile i_t, k-tile i_k, ring slot i_s, per-lane sources of that tile
+    const uint16_t* asrc[GA];
+    const uint16_t* bsrc[GB];
+    auto set_sources = [&](int i) {
+        int tm, tn;
+        tile_of(i, tm, tn);
+#pragma unroll
+        for (int g = 0; g < GA; ++g) {
+            const int row = (wave * GA + g) * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            const int r = rowtab[i * BM + row];
+            asrc[g] = (r >= 0 ? A + (size_t)r * lda : g_zero_row) + c * 8;
+        }
+#pragma unroll
+        for (int g = 0; g < GB; ++g) {
+            const int row = (wave * GB + g) * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            const int n = tn * BN + row;
+            bsrc[g] = (n < N ? Bm + (size_t)n * ldb : g_zero_row) + c * 8;
+        }
+    };
+    int i_t = 0, i_k = 0, i_s = 0;
+    set_sources(0);
+    auto issue_next = [&]() {                     // next stage of the stream, if any is left
+        if (i_t >= n_my) return;
+        unsigned char* st = smem + i_s * STAGE;
+#pragma unroll
+        for (int g = 0; g < GA; ++g) glds16(asrc[g] + i_k * 32, st + (wave * GA + g) * 1024);
+#pragma unroll
+        for (int g = 0; g < GB; ++g) glds16(bsrc[g] + i_k * 32, st + A_BYTES + (wave * GB + g) * 1024);
+        i_s = (i_s + 1 == NS) ? 0 : i_s + 1;
+        if (++i_k == n_kt) {
+            i_k = 0;
+            if (++i_t < n_my) set_sources(i_t);
+        }
+    };
+
+    const int lr = lane & 31, lh = lane >> 5;
+    int aoff[TM], boff[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = wm0 + i * 32 + lr;
+        aoff[i] = row * 64 + ((lh ^ ((row >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wn0 + j * 32 + lr;
+        boff[j] = A_BYTES + row * 64 + ((lh ^ ((row >> 2) & 3)) << 4);
+    }
+
+    // Bias in accumulator order (register 4 q + e <-> column 32 j + 8 q + 4 lh + e).  Loaded before the loop and re-defined
+    // behind an explicit wait: a VGPR-destination load inside the tile loop makes hipcc drain vmcnt - the whole prefetched ring
+    // and the stores - in front of its first use.
+    float bv[TN][16];
+    auto load_bias = [&](int n0) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[j][4 * q + e] = bias ? bias[n0 + wn0 + j * 32 + 8 * q + 4 * lh + e] : 0.f;
+    };
+    {
+        int tm, tn;
+        tile_of(0, tm, tn);
+        load_bias(tn * BN);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bv[j][r]));
+    }
+
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p) issue_next();
+
+    const int g_total = n_my * n_kt;
+    int g = 0, c_s = 0;                           // global stage counter, its ring slot
+    for (int ti = 0; ti < n_my; ++ti) {
+        int tile_m, tile_n;
+        tile_of(ti, tile_m, tile_n);
+        const int64_t m0 = (int64_t)tile_m * BM;
+        const int n0 = tile_n * BN;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        for (int kt = 0; kt < n_kt; ++kt, ++g) {
+            MG_STAMP(ta);
+            // stages issued so far: min(g_total, g + NS - 1); stage g must have landed; younger than it are
+            // min(g_total - 1 - g, NS - 2) stages and, for the first NS - 1 k-steps behind a tile boundary, the NST stores
+            {
+                const int allow = min(g_total - 1 - g, NS - 2) * NL + ((ti > 0 && kt < NS - 1) ? NST : 0);
+                switch (allow) {
+                    NTP_WAIT_CASE(0) NTP_WAIT_CASE(3) NTP_WAIT_CASE(4) NTP_WAIT_CASE(6) NTP_WAIT_CASE(8) NTP_WAIT_CASE(9)
+                    NTP_WAIT_CASE(11) NTP_WAIT_CASE(12) NTP_WAIT_CASE(14) NTP_WAIT_CASE(16) NTP_WAIT_CASE(17) NTP_WAIT_CASE(20)
+                    NTP_WAIT_CASE(24)
+                    default: WAIT_VM_BARRIER(0); break;
+                }
+            }
+            MG_STAMP(tb);
+            MG_STAMP_ADD(sum_wait, tb, ta);
+#ifdef MG_STAMPS
+            if (g == 0) ts1 = tb;
+#endif
+            issue_next();                         // refills the slot every wave finished with before this barrier
+            const unsigned char* st = smem + c_s * STAGE;
+            // All fragment reads of the stage first, then the MFMAs (pinned with sched_group_barrier): left alone hipcc reads
+            // two to four fragments at a time with an lgkmcnt(0) in front of every MFMA group - six exposed LDS round trips per
+            // stage with both waves of a SIMD waiting in step.
+            bfv8 a[2][TM], b[2][TN];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[ks][i] = *reinterpret_cast<const bfv8*>(st + (aoff[i] ^ (ks << 5)));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[ks][j] = *reinterpret_cast<const bfv8*>(st + (boff[j] ^ (ks << 5)));
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ks][j], a[ks][i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);
+            if (kt + 1 < n_kt) c_s = (c_s + 1 == NS) ? 0 : c_s + 1;
+        }
+
+        // ---- epilogue: bias (+ sigmoid), bf16, whole 128-byte row segments through the LDS patch ---------------------------
+        MG_STAMP(ta);
+        WAIT_LGKM_BARRIER();                      // every wave is done with the last stage
+        unsigned char* patch = (BN == 256 ? smem + c_s * STAGE : smem + PATCH) + wave * (32 * SP);
+        c_s = (c_s + 1 == NS) ? 0 : c_s + 1;
+        const int prow = lane >> 3, pchunk = lane & 7;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = acc[i][j][4 * q + e] + bv[j][4 * q + e];
+                        if (EPI == EPI_BIAS_SIGMOID) x = mg_sigmoid_fast(x);
+                        v[e] = x;
+                    }
+                    typedef __bf16 bfv2 __attribute__((ext_vector_type(2)));
+                    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+                    const u32x2_t pk = u32x2_t{__builtin_bit_cast(unsigned int, bfv2{(__bf16)v[0], (__bf16)v[1]}),
+                                               __builtin_bit_cast(unsigned int, bfv2{(__bf16)v[2], (__bf16)v[3]})};
+                    const int chunk = 4 * j + q;                              // columns 32 j + 8 q .. + 7 of the 64-wide strip
+                    *reinterpret_cast<u32x2_t*>(patch + lr * SP + ((chunk ^ (lr & 7)) << 4) + 8 * lh) = pk;
+                }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+                const int rl = it * 8 + prow;
+                const u32x4_t o = *reinterpret_cast<const u32x4_t*>(patch + rl * SP + ((pchunk ^ (rl & 7)) << 4));
+                const int64_t m = m0 + wm0 + i * 32 + rl;
+                uint16_t* dst = (m < M) ? C + (size_t)m * ldc + n0 + wn0 + pchunk * 8 : g_ntp_sink + lane * 8;
+                *reinterpret_cast<u32x4_t*>(dst) = o;     // unconditional: the counted vmcnt waits rely on NST stores per wave
+            }
+        }
+        MG_STAMP(tb);
+        MG_STAMP_ADD(sum_epi, tb, ta);
+    }
+#ifdef MG_STAMPS
+    MG_STAMP(ts2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MG_STAMP(ts3);
+    MG_STAMP_REAL(tr1);
+    const int sb = blockIdx.x;
+    MG_STAMP_STORE(g_stamps_ntp, sb, wave, lane, 0, ts0);
+    MG_STAMP_STORE(g_stamps_ntp, sb, wave, lane, 1, ts1);
+    MG_STAMP_STORE(g_stamps_ntp, sb, wave, lane, 2, ts2);
+    MG_STAMP_STORE(g_stamps_ntp, sb, wave, lane, 3, ts3);
+    MG_STAMP_STORE(g_stamps_ntp, sb, wave, lane, 4, tr0);
+    MG_STAMP_STORE(g_stamps_ntp, sb, wave, lane, 5, tr1);
+    MG_STAMP_STORE(g_stamps_ntp, sb, wave, lane, 6, sum_wait);
+    MG_STAMP_STORE(g_stamps_ntp, sb, wave, lane, 7, sum_epi);
 #endif
 }
 
@@ -588,8 +852,25 @@ int mg_try_nt_big(const uint16_t* A, int lda, const int32_t* rows, int64_t M, in
     const int64_t tiles_m = mg_ceil_div(M, 256);
     const int64_t blocks = mg_ceil_div(tiles_m, 8) * 8 * tiles_n;
     if (blocks >= 2147483647LL || tiles_m >= 2147483647LL) return 0;
+    // Persistent form: bias / bias + sigmoid with bf16 output, at least one ring of k-tiles per tile, a stores-per-row pattern
+    // that needs every store of a row in range (M is arbitrary: rows past the end are skipped per lane).
+    const int n_kt = (K + 31) / 32;
+    if (!c_f32 && epi != EPI_SIGMOID_GRAD && n_kt >= 5 && M < 2147483647LL && 32 % tiles_n == 0 && g_mg_tuning[MG_TUNE_STAGGER] != 6) {
+        int64_t g = 256;                                             // one resident workgroup per CU
+        while (mg_ceil_div(blocks, g) > NTP_MAX_TILES) g += 256;    // more tiles than a workgroup parks rows for: more groups
+        if (g > blocks) g = mg_ceil_div(blocks, 8 * tiles_n) * 8 * tiles_n;
+        dim3 pgrid((unsigned)g), pblock(512);
+#define LAUNCH_NTP(BN_, EPI_) hipLaunchKernelGGL((gemm_nt_persist_kernel<BN_, EPI_>), pgrid, pblock, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, (uint16_t*)C, ldc, (int)tiles_m, tiles_n)
+        if (wide) {
+            if (epi == EPI_BIAS) LAUNCH_NTP(256, EPI_BIAS); else LAUNCH_NTP(256, EPI_BIAS_SIGMOID);
+        } else {
+            if (epi == EPI_BIAS) LAUNCH_NTP(128, EPI_BIAS); else LAUNCH_NTP(128, EPI_BIAS_SIGMOID);
+        }
+#undef LAUNCH_NTP
+        return 1;
+    }
     dim3 grid((unsigned)blocks), block(512);
-#define LAUNCH_NT(BN_, EPI_) hipLaunchKernelGGL((gemm_nt_big_kernel<BN_, EPI_>), grid, block, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, H, ldh, C, ldc, (int)tiles_m, tiles_n, c_f32, g_mg_tuning[MG_TUNE_STAGGER])
+#define LAUNCH_NT(BN_, EPI_) hipLaunchKernelGGL((gemm_nt_big_kernel<BN_, EPI_>), grid, block, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, H, ldh, C, ldc, (int)tiles_m, tiles_n, c_f32)
     if (wide) {
         if (epi == EPI_BIAS) LAUNCH_NT(256, EPI_BIAS);
         else if (epi == EPI_BIAS_SIGMOID) LAUNCH_NT(256, EPI_BIAS_SIGMOID);
@@ -632,6 +913,9 @@ int mg_launch_wgrad_big(const uint16_t* dY, int lddy, const uint16_t* A, int lda
 }
 
 #ifdef MG_STAMPS
+extern "C" int mg_diag_read_stamps_ntp(void* dst, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps_ntp), bytes < sizeof(g_stamps_ntp) ? bytes : sizeof(g_stamps_ntp), 0, hipMemcpyDeviceToHost);
+}
 extern "C" int mg_diag_read_stamps_wg(void* dst, size_t bytes) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps_wg), bytes < sizeof(g_stamps_wg) ? bytes : sizeof(g_stamps_wg), 0, hipMemcpyDeviceToHost);
 }

@@ -65,9 +65,17 @@ def main():
     for _ in range(3):
         h1 = ops.linear_fwd_bf16(tab, rows, m, k, w1b, b1, 512, ops.ACT_SIGMOID)
     torch.cuda.synchronize()
-    s = read(lib, 'mg_diag_read_stamps_nt', 2000)
-    report('gemm_nt_big<256, sigmoid> (layer-1 forward)', s,
-           [('  loop: vmcnt wait + barrier', s[..., 6]), ('  loop: LDS-DMA issue', s[..., 7])])
+    s = read(lib, 'mg_diag_read_stamps_ntp', 256)
+    report('gemm_nt_persist<256, sigmoid> (layer-1 forward; "main loop" spans all tiles of the workgroup)', s,
+           [('  vmcnt wait + barrier', s[..., 6]), ('  epilogues', s[..., 7])])
+    w2b = ops.cast_pad_bf16(w2)
+    b2 = torch.from_numpy(st['layers.2.bias']).to(dev)
+    for _ in range(3):
+        ops.linear_fwd_bf16(h1, None, m, 512, w2b, b2, 128, ops.ACT_SIGMOID)
+    torch.cuda.synchronize()
+    s = read(lib, 'mg_diag_read_stamps_ntp', 256)
+    report('gemm_nt_persist<128, sigmoid> (layer-2 forward)', s,
+           [('  vmcnt wait + barrier', s[..., 6]), ('  epilogues', s[..., 7])])
     for _ in range(3):
         ops.linear_wgrad_bf16(dz1, tab, rows, m, 512, 600)
     torch.cuda.synchronize()
