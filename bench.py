@@ -23,7 +23,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-from morgana_amd import data, distributed, models, ops, optim, synthetic  # noqa: E402
+from morgana_amd import _lib, data, distributed, models, ops, optim, synthetic  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3
@@ -80,12 +80,12 @@ def roofline_f0(features, model, precision):
         (w1b, w2b), (_, w2t) = ops.cast_params_bf16([w1, w2], want_t=(1,))
         h1 = ops.linear_fwd_bf16(tab, rows, m, k, w1b, b1, n1, ops.ACT_SIGMOID)
         dz2 = (torch.randn(m, ops.pad_ld(n2), device=lab.device) * 0.01).to(torch.bfloat16)
-        kernels.append(('gemm_nt_big_kernel<256>: layer-1 forward (gather-fused 600->512 + bias + sigmoid)',
+        kernels.append(('gemm_nt_persist_kernel<256>: layer-1 forward (gather-fused 600->512 + bias + sigmoid)',
                         2.0 * m * k * n1, lambda: ops.linear_fwd_bf16(tab, rows, m, k, w1b, b1, n1, ops.ACT_SIGMOID)))
-        kernels.append(('gemm_nt_big_kernel<128>: layer-2 forward (512->128 + bias + sigmoid)', 2.0 * m * n1 * n2,
+        kernels.append(('gemm_nt_persist_kernel<128>: layer-2 forward (512->128 + bias + sigmoid)', 2.0 * m * n1 * n2,
                         lambda: ops.linear_fwd_bf16(h1, None, m, n1, w2b, b2, n2, ops.ACT_SIGMOID)))
         if ops.can_fuse_bwd(m, n2, n1, k, tab.shape[1]):
-            kernels.append(('wgrad_fused_kernel: layer-2 dgrad + sigmoid-grad + layer-1 wgrad (gather-fused), dZ1 on chip',
+            kernels.append(('wgrad_fused_pipe_kernel: layer-2 dgrad + sigmoid-grad + layer-1 wgrad (gather-fused), dZ1 on chip',
                             2.0 * m * n1 * n2 + 2.0 * m * k * n1,
                             lambda: ops.linear_bwd_fused_bf16(dz2, w2t, h1, tab, rows, m, n1, k)))
         else:
@@ -108,10 +108,13 @@ def roofline_f0(features, model, precision):
                         lambda: ops.linear_dgrad_f32(dz2, w2, h1)))
         peak = MFMA_F32_PEAK_TFLOPS
     measured = []
+    lib = _lib.load()
+    lib.mg_set_tuning(1, 1)          # MG_TUNE_SKIP_REDUCE: time the GEMM kernel alone, without its slab-reduce launches
     for name, flops, fn in kernels:
         ms = time_kernel(fn)
         measured.append({'kernel': name, 'ms': round(ms, 4), 'gflop': round(flops / 1e9, 1),
                          'tflops': round(flops / (ms * 1e-3) / 1e12, 2)})
+    lib.mg_set_tuning(1, 0)
     dom = max(measured, key=lambda r: r['ms'])
     traffic = None
     try:   # HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)

@@ -39,9 +39,12 @@ extern "C" {
  * ---------------------------------------------------------------------------------------------------------------- */
 const char* mg_last_error(void);
 /* Kernel scheduling knobs for experiments (A/B runs inside one process); every value computes the same results.
- * key MG_TUNE_STAGGER: 0 = default schedule of the large bf16 GEMM kernels, other values select measured alternatives. */
+ * key MG_TUNE_STAGGER: 0 = default schedule of the large bf16 GEMM kernels, other values select measured alternatives
+ * (6: per-tile instead of persistent NT kernel, 7: single-buffered instead of pipelined fused backward). */
 #define MG_TUNING_KEYS 8
 #define MG_TUNE_STAGGER 0
+#define MG_TUNE_SKIP_REDUCE 1   /* != 0: weight-gradient entry points launch their GEMM kernel only, not the slab reduce that
+                                 * finishes dW / db (results are then NOT valid) - lets bench.py time the kernel alone */
 int mg_set_tuning(int key, int value);
 int mg_version(void);           /* ABI version, bumped on incompatible change */
 const char* mg_build_arch(void); /* "gfx950" */

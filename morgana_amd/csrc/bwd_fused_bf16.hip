@@ -409,8 +409,8 @@ MG_STAMP_DECL(g_stamps_fp);
 __global__ __launch_bounds__(512) void wgrad_fused_pipe_kernel(const uint16_t* __restrict__ dZ2, int lddz, const uint16_t* __restrict__ W2T,
                                                                int ldwt, const uint16_t* __restrict__ H1, int ldh,
                                                                const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
-                                                               int64_t M, int N, int K, int m_chunk, float* __restrict__ slab,
-                                                               float* __restrict__ bslab) {
+                                                               int64_t M, int N, int K, int m_chunk, int n_splits,
+                                                               float* __restrict__ slab, float* __restrict__ bslab) {
     constexpr int TKT = 5;
     constexpr int PY = 256, PX = F_BKT * 2;
     constexpr int NX = 5;
@@ -428,8 +428,13 @@ __global__ __launch_bounds__(512) void wgrad_fused_pipe_kernel(const uint16_t* _
     const int wn0 = (wave >> 2) * 64;
     const int wk0 = (wave & 3) * (TKT * 32);
     const int tiles_n = N / F_BNT;
-    const int n0 = (blockIdx.x % tiles_n) * F_BNT;
-    const int s = blockIdx.x / tiles_n;
+    // Blocks b, b + 8, b + 16, ... share an XCD and its L2: the tiles_n workgroups of one frame range go there, so the range's
+    // dZ2 tiles leave HBM once instead of once per n tile (FETCH_SIZE x 2 of the n-tile-fastest order: 619 MB per launch
+    // against 327 MB of dZ2 + H1).
+    const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3;
+    const int n0 = (jq % tiles_n) * F_BNT;
+    const int s = (jq / tiles_n) * 8 + xcd;
+    if (s >= n_splits) return;
     const int64_t m_lo = (int64_t)s * m_chunk;
     const int64_t m_hi = min(M, m_lo + (int64_t)m_chunk);
     const int n_rows = m_hi > m_lo ? (int)(m_hi - m_lo) : 0;
@@ -823,8 +828,8 @@ int mg_linear_bwd_fused_bf16(const uint16_t* dZ2, int lddz, int N2, const uint16
     float* bslab = slab + (size_t)S * N * K;
     hipStream_t st = (hipStream_t)stream;
     if (rows && g_mg_tuning[MG_TUNE_STAGGER] != 7)
-        hipLaunchKernelGGL(wgrad_fused_pipe_kernel, dim3((unsigned)((N / F_BNT) * S)), dim3(512), 0, st, dZ2, lddz, W2T, ldwt, H1, ldh, A, lda,
-                           rows, M, N, K, chunk, slab, bslab);
+        hipLaunchKernelGGL(wgrad_fused_pipe_kernel, dim3((unsigned)((N / F_BNT) * mg_align_up((size_t)S, 8))), dim3(512), 0, st, dZ2, lddz, W2T,
+                           ldwt, H1, ldh, A, lda, rows, M, N, K, chunk, S, slab, bslab);
     else
         hipLaunchKernelGGL(wgrad_fused_kernel, dim3((unsigned)((N / F_BNT) * S)), dim3(512), 0, st, dZ2, lddz, W2T, ldwt, H1, ldh, A, lda, rows, M,
                            N, K, chunk, slab, bslab);
