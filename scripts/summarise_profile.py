@@ -25,12 +25,16 @@ def short(name):
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else 'r1'
     out = os.path.join(REPO, 'profiles')
-    stats = glob.glob(os.path.join(REPO, 'gpurun_out', 'prof_%s_stats' % tag, '*', '*kernel_stats.csv'))
+    def newest(pattern):                          # gpurun merges every call's files into gpurun_out/: take the latest run
+        found = sorted(glob.glob(pattern), key=os.path.getmtime)
+        return found[-1:] if found else []
+
+    stats = newest(os.path.join(REPO, 'gpurun_out', 'prof_%s_stats' % tag, '*', '*kernel_stats.csv'))
     if stats:
         shutil.copy(stats[0], os.path.join(out, '%s_bench_c2_bf16_kernel_stats.csv' % tag))
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     for counter, sub in (('FETCH_SIZE', 'fetch'), ('WRITE_SIZE', 'write')):
-        for path in glob.glob(os.path.join(REPO, 'gpurun_out', 'prof_%s_%s' % (tag, sub), '*', '*counter_collection.csv')):
+        for path in newest(os.path.join(REPO, 'gpurun_out', 'prof_%s_%s' % (tag, sub), '*', '*counter_collection.csv')):
             for row in csv.DictReader(open(path)):
                 if row['Counter_Name'] == counter:
                     per[short(row['Kernel_Name'])][counter].append(float(row['Counter_Value']))
