@@ -331,14 +331,25 @@ def test_fused_tail_kernel_vs_numpy(bt):
     assert abs(g[4160] - dpred.sum()) < 1e-2 * np.abs(dpred).sum()
 
 
+@pytest.mark.parametrize('rows_kind', ['random', 'runs', 'identity'])
 @pytest.mark.parametrize('m,n_hidden', [(4999, 512), (9000, 256)])
-def test_fused_backward_kernel_vs_numpy(m, n_hidden):
-    """mg_linear_bwd_fused_bf16: dW1, db1 from dZ2 without materialising dZ1 = (dZ2 W2) * H1 (1 - H1)."""
+def test_fused_backward_kernel_vs_numpy(m, n_hidden, rows_kind):
+    """mg_linear_bwd_fused_bf16: dW1, db1 from dZ2 without materialising dZ1 = (dZ2 W2) * H1 (1 - H1).
+    rows: 'random' = every frame its own source row incl. -1 pads (the run-staged ring cannot prefetch: its slow path),
+    'runs' = phone-like runs of equal rows (the case it is built for), 'identity' = no gather (the single-buffered kernel)."""
     k0 = 600
     rng = np.random.RandomState(m)
-    table = _bf16_round(rng.uniform(0, 1, (m // 9, k0)).astype(np.float32))
-    rows = rng.randint(-1, table.shape[0], size=m).astype(np.int32)
-    x = np.where(rows[:, None] < 0, 0, table[np.maximum(rows, 0)]).astype(np.float64)
+    if rows_kind == 'identity':
+        table = _bf16_round(rng.uniform(0, 1, (m, k0)).astype(np.float32))
+        rows, x = None, table.astype(np.float64)
+    else:
+        table = _bf16_round(rng.uniform(0, 1, (m // 9, k0)).astype(np.float32))
+        if rows_kind == 'random':
+            rows = rng.randint(-1, table.shape[0], size=m).astype(np.int32)
+        else:
+            lens = rng.randint(1, 40, size=m)
+            rows = np.repeat(rng.randint(-1, table.shape[0], size=m), lens)[:m].astype(np.int32)
+        x = np.where(rows[:, None] < 0, 0, table[np.maximum(rows, 0)]).astype(np.float64)
     w2 = _bf16_round(rng.uniform(-0.1, 0.1, (128, n_hidden)).astype(np.float32))
     h1 = _bf16_round(rng.uniform(0.05, 0.95, (m, n_hidden)).astype(np.float32))
     dz2 = _bf16_round((rng.standard_normal((m, 128)) * 0.01).astype(np.float32))
@@ -347,7 +358,7 @@ def test_fused_backward_kernel_vs_numpy(m, n_hidden):
     want_w, want_b = dz1_bf.T @ x, dz1_bf.sum(axis=0)
     wt2 = ops.cast_transpose_bf16(dev(w2))
     dw, db = ops.linear_bwd_fused_bf16(ops.cast_pad_bf16(dev(dz2)), wt2, ops.cast_pad_bf16(dev(h1)),
-                                       ops.cast_pad_bf16(dev(table)), dev(rows), m, n_hidden, k0)
+                                       ops.cast_pad_bf16(dev(table)), dev(rows) if rows is not None else None, m, n_hidden, k0)
     assert rel_err(dw.cpu().numpy(), want_w) < 5e-3
     assert rel_err(db.cpu().numpy(), want_b) < 5e-3
 
