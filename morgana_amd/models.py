@@ -3,6 +3,8 @@
 * ``F0Model``  - README stack Linear/Sigmoid 600-512-128-32-1 (README.rst:53-97; configs C1-C3).
 * ``RNNSPSS``  - Linear-512 / sigmoid / GRU-512 / Linear-256 / sigmoid / Linear-out, the layer layout of
                  models/RNN_SPSS.py:32-42 with the GRU cell of models/f0_test_model.py:32-39 (configs C4-C5).
+* ``GRUF0Model`` - the reference's shipped F0 model, models/f0_test_model.py:21-107: 609-dim input, Linear-256 / sigmoid /
+                 GRU-64 x 3 / Linear-64 / sigmoid / Linear-3 (lf0 + deltas).
 * ``LSTMAcousticModel`` - the reference's shipped acoustic model, models/RNN_SPSS.py:20-139: 609-dim input (labels +
                  counters), Linear-512 / sigmoid / 8 x LSTM-512 / Linear-256 / sigmoid / Linear-199, four output streams.
 ``SequentialWithRecurrent`` returns ``(output, hiddens)`` (utils.py:418), so all of them unpack it.
@@ -186,3 +188,49 @@ class LSTMAcousticModel(BaseSPSS):
         kinds = ['sigmoid_bce' if n == 'vuv' else 'mse' for n in self.STREAMS]
         loss, pred_vuv = losses.multi_stream(pred_norm_deltas, targets, kinds, features['n_frames'], want_prob=True)
         return loss, self._split(pred_norm_deltas.detach(), pred_vuv)
+
+
+class GRUF0Model(BaseSPSS):
+    """models/f0_test_model.py:21-107 against this package: same constructor arguments, the same layer container (state_dict
+    keys ``layers.0.weight``, ``layers.3.layer.weight_ih_l0`` ... load unchanged), ``predict`` / ``loss``.  MLPG (:86-89) is
+    detached CPU post-processing for the LF0 metric and is not part of this package."""
+
+    def __init__(self, dropout_prob=0., input_dim=600 + 9, output_dim=1 * 3, precision=None, fused_upsample=True):
+        super(GRUF0Model, self).__init__()
+        self.input_dim = input_dim
+        self.output_dim = output_dim
+        self.fused_upsample = fused_upsample
+        self.layers = utils.SequentialWithRecurrent(
+            nn.Linear(self.input_dim, 256),
+            nn.Sigmoid(),
+            nn.Dropout(p=dropout_prob),
+            utils.RecurrentCuDNNWrapper(nn.GRU(256, 64, batch_first=True), precision=precision),
+            nn.Dropout(p=dropout_prob),
+            utils.RecurrentCuDNNWrapper(nn.GRU(64, 64, batch_first=True), precision=precision),
+            nn.Dropout(p=dropout_prob),
+            utils.RecurrentCuDNNWrapper(nn.GRU(64, 64, batch_first=True), precision=precision),
+            nn.Dropout(p=dropout_prob),
+            nn.Linear(64, 64),
+            nn.Sigmoid(),
+            nn.Dropout(p=dropout_prob),
+            nn.Linear(64, self.output_dim),
+            precision=precision)
+
+    def normaliser_sources(self):
+        return {
+            'dur': data.MeanVarianceNormaliser('dur'),
+            'lab': data.MinMaxNormaliser('lab'),
+            'counters': data.MinMaxNormaliser('counters'),
+            'lf0': data.MeanVarianceNormaliser('lf0', use_deltas=True),
+        }
+
+    def predict(self, features):
+        norm_counters = features['normalised_counters']
+        norm_lab_at_frame_rate = utils.upsample_to_repetitions(features['normalised_lab'], features['dur'],
+                                                               max_len=norm_counters.shape[1], fused=self.fused_upsample)
+        model_inputs = utils.concat_frame_features(norm_lab_at_frame_rate, norm_counters)
+        pred_norm_lf0_deltas, _ = self.layers(model_inputs, seq_len=features['n_frames'])
+        return {'normalised_lf0_deltas': pred_norm_lf0_deltas}
+
+    def loss(self, features, output_features):
+        return losses.mse(output_features['normalised_lf0_deltas'], features['normalised_lf0_deltas'], features['n_frames'])

@@ -175,3 +175,20 @@ def make_acoustic_batch(batch_size, n_frames, lab_dim=600, counters_dim=9, strea
         else:
             feats[name] = ((rng.random_sample((batch_size, max_t, width)) > 0.4) * mask).astype(np.float32)
     return feats
+
+
+def gru_f0_state(seed=REFERENCE_SEED, input_dim=609, d1=256, hidden=64, post=64, output_dim=3):
+    """state_dict (numpy) of the shipped F0 model (models/f0_test_model.py:28-45): Linear(input, d1), Sigmoid, Dropout,
+    GRU(d1, hidden), Dropout, GRU(hidden, hidden), Dropout, GRU(hidden, hidden), Dropout, Linear(hidden, post), Sigmoid,
+    Dropout, Linear(post, output) - keys are the reference's (the wrappers sit at layers.3, .5, .7)."""
+    rng = np.random.RandomState(seed % (2 ** 32))
+    state = {}
+    state['layers.0.weight'], state['layers.0.bias'] = init_linear(rng, input_dim, d1)
+    for idx, in_dim in ((3, d1), (5, hidden), (7, hidden)):
+        w_ih, w_hh, b_ih, b_hh = init_gru(rng, in_dim, hidden)
+        prefix = 'layers.%d.layer.' % idx
+        state[prefix + 'weight_ih_l0'], state[prefix + 'weight_hh_l0'] = w_ih, w_hh
+        state[prefix + 'bias_ih_l0'], state[prefix + 'bias_hh_l0'] = b_ih, b_hh
+    state['layers.9.weight'], state['layers.9.bias'] = init_linear(rng, hidden, post)
+    state['layers.12.weight'], state['layers.12.bias'] = init_linear(rng, post, output_dim)
+    return state

@@ -650,3 +650,65 @@ def g12_lstm_acoustic():
 
 if __name__ == '__main__' and (len(sys.argv) == 1 or sys.argv[1] == 'g12'):
     g12_lstm_acoustic()
+
+
+def g13_gru_f0():
+    """G13: the shipped F0 model (models/f0_test_model.py:21-107) at toy size from the reference's own building blocks:
+    609-style input (upsampled labels + frame-level counters), Linear / sigmoid / dropout(0) / three single-layer GRU wrappers /
+    Linear / sigmoid / Linear -> lf0 deltas, losses.mse; MLPG (detached post-processing) left out.  6 Adam steps."""
+    import torch
+    import torch.nn as nn
+    from morgana_amd import synthetic
+    utils, losses, data, base_models, lr_schedules, metrics = import_reference()
+    lab_dim, counters_dim, d1, hid, post, out_dim = 20, 4, 24, 16, 16, 3
+
+    class Model(base_models.BaseSPSS):
+        def __init__(self):
+            super(Model, self).__init__()
+            self.layers = utils.SequentialWithRecurrent(                        # models/f0_test_model.py:28-45
+                nn.Linear(lab_dim + counters_dim, d1), nn.Sigmoid(), nn.Dropout(p=0.),
+                utils.RecurrentCuDNNWrapper(nn.GRU(d1, hid, batch_first=True)), nn.Dropout(p=0.),
+                utils.RecurrentCuDNNWrapper(nn.GRU(hid, hid, batch_first=True)), nn.Dropout(p=0.),
+                utils.RecurrentCuDNNWrapper(nn.GRU(hid, hid, batch_first=True)), nn.Dropout(p=0.),
+                nn.Linear(hid, post), nn.Sigmoid(), nn.Dropout(p=0.),
+                nn.Linear(post, out_dim))
+
+        def predict(self, features):                                            # models/f0_test_model.py:76-84
+            at_frame_rate = utils.upsample_to_repetitions(features['normalised_lab'], features['dur'])
+            model_inputs = torch.cat((at_frame_rate, features['normalised_counters']), dim=-1)
+            pred, _ = self.layers(model_inputs, seq_len=features['n_frames'])
+            return {'normalised_lf0_deltas': pred}
+
+        def loss(self, features, output_features):                              # models/f0_test_model.py:99-102
+            return losses.mse(output_features['normalised_lf0_deltas'], features['normalised_lf0_deltas'], features['n_frames'])
+
+    streams = (('lf0', out_dim, 'mse'),)
+    feats_np = synthetic.make_acoustic_batch(5, (10, 30), lab_dim=lab_dim, counters_dim=counters_dim, streams=streams,
+                                             frames_per_phone=5.0, seed=1313)
+    feats = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in feats_np.items()}
+    model = Model()
+    state = synthetic.gru_f0_state(seed=1314, input_dim=lab_dim + counters_dim, d1=d1, hidden=hid, post=post, output_dim=out_dim)
+    own = model.state_dict()
+    assert sorted(own.keys()) == sorted(state.keys()), (sorted(own.keys()), sorted(state.keys()))
+    for k, v in state.items():
+        own[k].copy_(torch.from_numpy(v))
+    optimizer = torch.optim.Adam(model.parameters(), lr=0.01)
+    g, curve = {}, []
+    for step in range(6):
+        optimizer.zero_grad()
+        loss, out = model(feats)
+        loss.backward()
+        if step == 0:
+            g['step1_pred'] = out['normalised_lf0_deltas'].detach().numpy()
+            for name, prm in model.named_parameters():
+                g['step1_grad__' + name] = prm.grad.detach().numpy().copy()
+        optimizer.step()
+        curve.append(loss.item())
+    g['loss_curve'] = np.array(curve, dtype=np.float64)
+    g['dims'] = np.array([lab_dim, counters_dim, d1, hid, post, out_dim], dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, 'g13_gru_f0.npz'), **g)
+    print('g13_gru_f0.npz', os.path.getsize(os.path.join(HERE, 'g13_gru_f0.npz')), 'bytes; curve', curve)
+
+
+if __name__ == '__main__' and (len(sys.argv) == 1 or sys.argv[1] == 'g13'):
+    g13_gru_f0()

@@ -725,6 +725,56 @@ def test_lstm_acoustic_model_shipped_shape_vs_oracle():
         assert rel_err(prm.grad.cpu().numpy(), want_grads[name]) < 1e-3, name
 
 
+class _ToyGRUF0(models.GRUF0Model):
+    """GRUF0Model with the layer widths of golden G13 (the class fixes 256 / 64 / 64 as the reference file does)."""
+
+    def __init__(self, input_dim, d1, hid, post, out_dim, precision, fused):
+        models.BaseSPSS.__init__(self)
+        nn = torch.nn
+        self.fused_upsample = fused
+        self.layers = utils.SequentialWithRecurrent(
+            nn.Linear(input_dim, d1), nn.Sigmoid(), nn.Dropout(p=0.),
+            utils.RecurrentCuDNNWrapper(nn.GRU(d1, hid, batch_first=True), precision=precision), nn.Dropout(p=0.),
+            utils.RecurrentCuDNNWrapper(nn.GRU(hid, hid, batch_first=True), precision=precision), nn.Dropout(p=0.),
+            utils.RecurrentCuDNNWrapper(nn.GRU(hid, hid, batch_first=True), precision=precision), nn.Dropout(p=0.),
+            nn.Linear(hid, post), nn.Sigmoid(), nn.Dropout(p=0.), nn.Linear(post, out_dim), precision=precision)
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_gru_f0_model_golden(golden, fused):
+    """The shipped F0 model (models/f0_test_model.py): counters concat, three GRU wrappers; loss, prediction, every gradient
+    and 6 Adam steps against the reference (fp32 mode)."""
+    g = golden('g13_gru_f0.npz')
+    lab_dim, counters_dim, d1, hid, post, out_dim = [int(v) for v in g['dims']]
+    feats = data.to_device(synthetic.make_acoustic_batch(5, (10, 30), lab_dim=lab_dim, counters_dim=counters_dim,
+                                                         streams=(('lf0', out_dim, 'mse'),), frames_per_phone=5.0, seed=1313), DEV)
+    state = synthetic.gru_f0_state(seed=1314, input_dim=lab_dim + counters_dim, d1=d1, hidden=hid, post=post, output_dim=out_dim)
+    model = _load_state(_ToyGRUF0(lab_dim + counters_dim, d1, hid, post, out_dim, 'fp32', fused).to(DEV), state)
+    loss, out = model(feats)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g['loss_curve'][0], rtol=RTOL)
+    np.testing.assert_allclose(out['normalised_lf0_deltas'].detach().cpu().numpy(), g['step1_pred'], rtol=1e-3, atol=1e-5)
+    for name, prm in model.named_parameters():
+        want = g['step1_grad__' + name]
+        np.testing.assert_allclose(prm.grad.cpu().numpy(), want, rtol=1e-3, atol=1e-4 * np.abs(want).max(), err_msg=name)
+    model.zero_grad()
+    np.testing.assert_allclose(_train(model, [feats], 6, lr=0.01), g['loss_curve'], rtol=RTOL)
+
+
+def test_gru_f0_model_shipped_shape_vs_oracle():
+    """The shipped widths (609 -> 256 -> GRU-64 x 3 -> 64 -> 3) on a ragged batch against the numpy oracle."""
+    feats = synthetic.make_acoustic_batch(4, (40, 90), streams=(('lf0', 3, 'mse'),), seed=23)
+    state = synthetic.gru_f0_state()
+    want_loss, want_pred, want_grads = ref_cpu.gru_f0_forward_backward(state, feats)
+    model = _load_state(models.GRUF0Model(precision='fp32').to(DEV), state)
+    loss, out = model(data.to_device(feats, DEV))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), want_loss, rtol=RTOL)
+    assert rel_err(out['normalised_lf0_deltas'].detach().cpu().numpy(), want_pred) < 1e-4
+    for name, prm in model.named_parameters():
+        assert rel_err(prm.grad.cpu().numpy(), want_grads[name]) < 1e-3, name
+
+
 # ------------------------------------------------------------------------------------------- optimiser / EMA
 def test_adam_and_ema_vs_oracle(golden):
     rng = np.random.RandomState(0)

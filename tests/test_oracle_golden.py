@@ -314,3 +314,19 @@ def test_g12_lstm_acoustic_model(golden):
         np.testing.assert_allclose(grads[key], ref, rtol=1e-3, atol=1e-4 * np.abs(ref).max(), err_msg=key)
     curve = ref_cpu.lstm_acoustic_train(state, feats, G12_STREAMS, num_layers, 6, lr=0.01)
     np.testing.assert_allclose(curve, g['model__loss_curve'], rtol=1e-4)
+
+
+def test_g13_gru_f0_model(golden):
+    """The shipped F0 model layout (models/f0_test_model.py:28-45: three GRU wrappers, counters concat) at toy size."""
+    g = golden('g13_gru_f0.npz')
+    lab_dim, counters_dim, d1, hid, post, out_dim = [int(v) for v in g['dims']]
+    feats = synthetic.make_acoustic_batch(5, (10, 30), lab_dim=lab_dim, counters_dim=counters_dim,
+                                          streams=(('lf0', out_dim, 'mse'),), frames_per_phone=5.0, seed=1313)
+    state = synthetic.gru_f0_state(seed=1314, input_dim=lab_dim + counters_dim, d1=d1, hidden=hid, post=post, output_dim=out_dim)
+    loss, pred, grads = ref_cpu.gru_f0_forward_backward(state, feats)
+    np.testing.assert_allclose(loss, g['loss_curve'][0], rtol=1e-5)
+    np.testing.assert_allclose(pred, g['step1_pred'], rtol=1e-4, atol=1e-6)
+    for key in ref_cpu.GRU_F0_KEYS:
+        ref = g['step1_grad__' + key]
+        np.testing.assert_allclose(grads[key], ref, rtol=1e-3, atol=1e-4 * np.abs(ref).max(), err_msg=key)
+    np.testing.assert_allclose(ref_cpu.gru_f0_train(state, feats, 6, lr=0.01), g['loss_curve'], rtol=1e-4)
