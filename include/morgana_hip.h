@@ -66,6 +66,16 @@ int mg_gather_rows_f32(const float* src, const int32_t* rows, float* out, int64_
 /* Same gather, output converted to bf16 with leading dimension ldo >= F; columns F..ldo-1 are zero filled. */
 int mg_gather_rows_bf16(const float* src, const int32_t* rows, uint16_t* out, int64_t M, int F, int ldo, void* stream);
 
+/* Segment index maps (reference: split_to_segments / get_segment_ends, morgana/utils.py:231-330; the same scan-and-index
+ * pattern as mg_upsample_index).  seg_lens int64 [B,S]; T = length of the sequence feature; L = longest segment.
+ *   split [B,S,L] : flat source row b*T + start_s + j of position j of segment s, -1 where j >= len_s (the zero padder)
+ *   ends  [B,S]   : flat source row b*T + cumsum_s - 1 of the last frame of segment s, -1 for empty segments
+ * Either output may be NULL.  Feed them to mg_gather_rows_f32; rows that would fall beyond T come out as -1.
+ * mg_scatter_rows_f32 is the adjoint of such a gather (distinct targets): dst[rows[m],:] = src[m,:] for rows[m] >= 0;
+ * dst must be zero-filled by the caller. */
+int mg_segment_index(const int64_t* seg_lens, int B, int S, int T, int L, int32_t* split, int32_t* ends, void* stream);
+int mg_scatter_rows_f32(const float* src, const int32_t* rows, float* dst, int64_t M, int F, void* stream);
+
 /* Gather fused with the frame-level concat the shipped models do right after it (models/RNN_SPSS.py:76-81,
  * models/f0_test_model.py:78-79: upsample_to_repetitions, then torch.cat with `normalised_counters`):
  *   out[m, 0:F] = src[rows[m], :] (0 where rows[m] < 0), out[m, F:F+C] = extra[m, 0:C], out[m, F+C:ldo] = 0.

@@ -81,6 +81,50 @@ __global__ __launch_bounds__(256) void upsample_index_kernel(const int64_t* __re
     }
 }
 
+
+// Segment index maps (reference: split_to_segments / get_segment_ends, morgana/utils.py:231-330).  One workgroup per
+// sequence; seg_lens [S] is scanned in LDS exactly as the durations of K1 are.
+//   split[b, s, j] = b * T + start_s + j  for j < len_s (and start_s + j < T), else -1     (the reference's segment_idxs)
+//   ends[b, s]     = b * T + cumsum_s - 1 for len_s > 0 (and cumsum_s <= T), else -1      (cumsum * mask - 1, :325-328)
+__global__ __launch_bounds__(256) void segment_index_kernel(const int64_t* __restrict__ seg_lens, int S, int T, int L,
+                                                            int32_t* __restrict__ split, int32_t* __restrict__ ends) {
+    extern __shared__ __attribute__((aligned(16))) int smem_i[];
+    int* scratch = smem_i;
+    int* cum = smem_i + 256;
+    const int b = blockIdx.x;
+    block_scan_durations(seg_lens + (size_t)b * S, S, cum, scratch);
+    if (ends) {
+        for (int s = threadIdx.x; s < S; s += 256) {
+            const int len = cum[s] - (s ? cum[s - 1] : 0);
+            ends[(size_t)b * S + s] = (len > 0 && cum[s] <= T) ? b * T + cum[s] - 1 : -1;
+        }
+    }
+    if (split) {
+        const int64_t n = (int64_t)S * L;
+        for (int64_t e = threadIdx.x; e < n; e += 256) {
+            const int s = (int)(e / L), j = (int)(e - (int64_t)s * L);
+            const int start = s ? cum[s - 1] : 0;
+            const int len = cum[s] - start;
+            split[(size_t)b * n + e] = (j < len && start + j < T) ? b * T + start + j : -1;
+        }
+    }
+}
+
+// dst[rows[m], :] = src[m, :] for rows[m] >= 0 (the targets are distinct: the adjoint of a gather whose rows are unique).
+__global__ __launch_bounds__(256) void scatter_rows_f32_kernel(const float* __restrict__ src, const int32_t* __restrict__ rows,
+                                                               float* __restrict__ dst, int64_t M, int F) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t m = wave; m < M; m += n_waves) {
+        const int r = rows[m];
+        if (r < 0) continue;
+        const float* s = src + (size_t)m * F;
+        float* o = dst + (size_t)r * F;
+        for (int c = lane; c < F; c += 64) o[c] = s[c];
+    }
+}
+
 // One wave per output row, 16 bytes per lane.
 template <bool VEC4>
 __global__ __launch_bounds__(256) void gather_rows_f32_kernel(const float* __restrict__ src, const int32_t* __restrict__ rows,
@@ -245,6 +289,25 @@ static int gather_grid(int64_t M) {
     int64_t blocks = mg_ceil_div(M, 4);
     if (blocks > 8192) blocks = 8192;
     return (int)(blocks < 1 ? 1 : blocks);
+}
+
+int mg_segment_index(const int64_t* seg_lens, int B, int S, int T, int L, int32_t* split, int32_t* ends, void* stream) {
+    MG_CHECK_ARG(seg_lens && B > 0 && S > 0 && T >= 0 && L >= 0, "mg_segment_index: bad arguments (B=%d S=%d T=%d L=%d)", B, S, T, L);
+    MG_CHECK_ARG(S <= MG_MAX_PHONES, "mg_segment_index: S=%d exceeds %d segments per sequence", S, MG_MAX_PHONES);
+    MG_CHECK_ARG((int64_t)B * T < 2147483647LL, "mg_segment_index: B*T overflows int32 row ids");
+    if (!split && !ends) return MG_OK;
+    const size_t lds = (size_t)(256 + S) * sizeof(int);
+    hipLaunchKernelGGL(segment_index_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, seg_lens, S, T, L, L > 0 ? split : nullptr, ends);
+    MG_CHECK_LAUNCH("mg_segment_index");
+    return MG_OK;
+}
+
+int mg_scatter_rows_f32(const float* src, const int32_t* rows, float* dst, int64_t M, int F, void* stream) {
+    MG_CHECK_ARG(src && rows && dst && M >= 0 && F > 0, "mg_scatter_rows_f32: bad arguments (M=%lld F=%d)", (long long)M, F);
+    if (M == 0) return MG_OK;
+    hipLaunchKernelGGL(scatter_rows_f32_kernel, dim3(gather_grid(M)), dim3(256), 0, (hipStream_t)stream, src, rows, dst, M, F);
+    MG_CHECK_LAUNCH("mg_scatter_rows_f32");
+    return MG_OK;
 }
 
 int mg_gather_rows_f32(const float* src, const int32_t* rows, float* out, int64_t M, int F, void* stream) {

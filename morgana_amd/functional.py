@@ -405,3 +405,19 @@ class StreamLossFn(torch.autograd.Function):
     def backward(ctx, grad_loss, _grad_prob):
         (grad,) = ctx.saved_tensors
         return (grad * grad_loss, None, None, None) + (None,) * ctx.n_targets
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """out[m] = x2d[rows[m]] (zero for -1) with distinct non-negative rows: backward is a scatter."""
+
+    @staticmethod
+    def forward(ctx, x2d, rows):
+        x2d = ops._require(x2d, torch.float32, 'sequence_feature')
+        ctx.save_for_backward(rows)
+        ctx.n_src = x2d.shape[0]
+        return ops.gather_rows(x2d, rows)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (rows,) = ctx.saved_tensors
+        return ops.scatter_rows(grad_out.contiguous(), rows, ctx.n_src), None

@@ -88,6 +88,29 @@ def gather_rows(src2d, rows, out_bf16=False):
     return out
 
 
+def segment_index(seg_lens2d, t, max_len=None, want_split=True, want_ends=True):
+    """Flat row maps of split_to_segments / get_segment_ends (mg_segment_index): (split int32 (B,S,L) or None, ends (B,S))."""
+    lib = _lib.load()
+    seg_lens2d = _require(seg_lens2d, torch.int64, 'segment_lens')
+    b, s = seg_lens2d.shape
+    length = int(max_len) if want_split else 0
+    split = torch.empty((b, s, length), dtype=torch.int32, device=seg_lens2d.device) if want_split else None
+    ends = torch.empty((b, s), dtype=torch.int32, device=seg_lens2d.device) if want_ends else None
+    _lib.check(lib.mg_segment_index(_p(seg_lens2d), b, s, int(t), length, _p(split), _p(ends), _stream()), 'mg_segment_index')
+    return split, ends
+
+
+def scatter_rows(src2d, rows, n_dst_rows):
+    """Adjoint of gather_rows for distinct targets: zeros (n_dst_rows, F) with dst[rows[m]] = src2d[m]."""
+    lib = _lib.load()
+    src2d = _require(src2d, torch.float32, 'src')
+    rows = _require(rows, torch.int32, 'rows')
+    dst = torch.zeros((n_dst_rows, src2d.shape[1]), dtype=torch.float32, device=src2d.device)
+    _lib.check(lib.mg_scatter_rows_f32(_p(src2d), _p(rows), _p(dst), rows.numel(), src2d.shape[1], _stream()),
+               'mg_scatter_rows_f32')
+    return dst
+
+
 def gather_concat(src2d, rows, extra2d, out_bf16=False):
     """[src2d[rows] | extra2d] per frame (mg_gather_concat_*): f32 (M, F+C), or bf16 (M, pad_ld(F+C)) zero padded."""
     lib = _lib.load()

@@ -2,7 +2,7 @@
 per-frame compute done by the HIP kernels of libmorgana_hip.so (no torch-op or CPU fallback for the in-scope ops).
 
 Reference: morgana/utils.py - ``sequence_mask`` :115-144, ``upsample_to_repetitions`` :175-228,
-``RecurrentCuDNNWrapper`` :333-393, ``SequentialWithRecurrent`` :396-418, ``ExponentialMovingAverage`` :421-456.
+``split_to_segments`` :231-285, ``get_segment_ends`` :288-330, ``RecurrentCuDNNWrapper`` :333-393, ``SequentialWithRecurrent`` :396-418, ``ExponentialMovingAverage`` :421-456.
 """
 import torch
 import torch.nn as nn
@@ -112,6 +112,37 @@ def upsample_to_repetitions(sequence_feature, repeats, max_len=None, fused=False
         _, rows = ops.upsample_index(dur2d, int(max_len))
         return UpsampledSequence(sequence_feature, dur2d, rows)
     return F_hip.UpsampleFn.apply(sequence_feature, dur2d, int(max_len))
+
+
+def _segment_lens_2d(sequence_feature, segment_lens):
+    if segment_lens.is_floating_point() or segment_lens.dtype == torch.bool:
+        raise TypeError('segment_lens must be an integer tensor, got %s' % segment_lens.dtype)
+    lens2d = segment_lens.reshape((sequence_feature.shape[0], -1))
+    return (lens2d if lens2d.dtype == torch.int64 else lens2d.long()).contiguous()
+
+
+def split_to_segments(sequence_feature, segment_lens):
+    """Splits a sequence into zero-padded segments.  morgana/utils.py:231-285.
+
+    sequence_feature (B, T, F) float32; segment_lens (B, S, 1) or (B, S) integer -> (B, S, max segment length, F).
+    The reference builds the index array in a host loop over batch items and segments; here one kernel scans the lengths and
+    writes the flat row map, a second gathers.  ``segment_lens.max().item()`` is the one sync the output shape needs (the
+    reference has it too, :250)."""
+    lens2d = _segment_lens_2d(sequence_feature, segment_lens)
+    b, t, f = sequence_feature.shape
+    max_segment_len = int(lens2d.max().item())
+    split, _ = ops.segment_index(lens2d, t, max_len=max_segment_len, want_ends=False)
+    out = F_hip.GatherRowsFn.apply(sequence_feature.reshape(b * t, f), split.reshape(-1))
+    return out.view(b, lens2d.shape[1], max_segment_len, f)
+
+
+def get_segment_ends(sequence_feature, segment_lens):
+    """Feature at the last position of each segment, zeros for empty segments.  morgana/utils.py:288-330."""
+    lens2d = _segment_lens_2d(sequence_feature, segment_lens)
+    b, t, f = sequence_feature.shape
+    _, ends = ops.segment_index(lens2d, t, want_split=False)
+    out = F_hip.GatherRowsFn.apply(sequence_feature.reshape(b * t, f), ends.reshape(-1))
+    return out.view(b, lens2d.shape[1], f)
 
 
 class RecurrentCuDNNWrapper(nn.Module):

@@ -712,3 +712,38 @@ def g13_gru_f0():
 
 if __name__ == '__main__' and (len(sys.argv) == 1 or sys.argv[1] == 'g13'):
     g13_gru_f0()
+
+
+def g14_segments():
+    """G14: utils.split_to_segments / utils.get_segment_ends of the reference (utils.py:231-330): values and the gradient
+    w.r.t. the sequence feature, with zero-length and trailing-pad segments."""
+    import torch
+    utils, losses, data, base_models, lr_schedules, metrics = import_reference()
+    rng = np.random.RandomState(1414)
+    g = {}
+    for tag, (b, t, f, lens) in {
+            'small': (3, 10, 4, [[3, 0, 4, 2], [10, 0, 0, 0], [1, 1, 1, 5]]),
+            'wide': (4, 37, 9, [[5, 9, 7, 1, 3, 0, 0], [12, 12, 13, 0, 0, 0, 0], [1, 1, 1, 1, 1, 1, 1], [0, 20, 0, 17, 0, 0, 0]])}.items():
+        x = torch.from_numpy(rng.standard_normal((b, t, f)).astype(np.float32)).requires_grad_(True)
+        sl = torch.tensor(lens, dtype=torch.int64).unsqueeze(-1)
+        seg = utils.split_to_segments(x, sl)
+        gs = torch.from_numpy(rng.standard_normal(tuple(seg.shape)).astype(np.float32))
+        (seg * gs).sum().backward()
+        g[tag + '__x'] = x.detach().numpy()
+        g[tag + '__lens'] = sl.numpy()
+        g[tag + '__split'] = seg.detach().numpy()
+        g[tag + '__split_grad_out'] = gs.numpy()
+        g[tag + '__split_grad_x'] = x.grad.numpy().copy()
+        x.grad = None
+        ends = utils.get_segment_ends(x, sl)
+        ge = torch.from_numpy(rng.standard_normal(tuple(ends.shape)).astype(np.float32))
+        (ends * ge).sum().backward()
+        g[tag + '__ends'] = ends.detach().numpy()
+        g[tag + '__ends_grad_out'] = ge.numpy()
+        g[tag + '__ends_grad_x'] = x.grad.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, 'g14_segments.npz'), **g)
+    print('g14_segments.npz', os.path.getsize(os.path.join(HERE, 'g14_segments.npz')), 'bytes')
+
+
+if __name__ == '__main__' and (len(sys.argv) == 1 or sys.argv[1] == 'g14'):
+    g14_segments()

@@ -99,6 +99,38 @@ def test_upsample_full_size_copy_and_segment_sum():
     np.testing.assert_allclose(bf[:, :600].float().cpu().numpy().reshape(want.shape), want, rtol=8e-3, atol=1e-6)
 
 
+@pytest.mark.parametrize('tag', ['small', 'wide'])
+def test_segment_ops_golden(golden, tag):
+    """split_to_segments / get_segment_ends (utils.py:231-330): values bit exact (pure copies), gradients bit exact."""
+    g = golden('g14_segments.npz')
+    x = dev(g[tag + '__x']).requires_grad_(True)
+    lens = dev(g[tag + '__lens'])
+    seg = utils.split_to_segments(x, lens)
+    assert np.array_equal(seg.detach().cpu().numpy(), g[tag + '__split'])
+    (seg * dev(g[tag + '__split_grad_out'])).sum().backward()
+    assert np.array_equal(x.grad.cpu().numpy(), g[tag + '__split_grad_x'])
+    x.grad = None
+    ends = utils.get_segment_ends(x, lens)
+    assert np.array_equal(ends.detach().cpu().numpy(), g[tag + '__ends'])
+    (ends * dev(g[tag + '__ends_grad_out'])).sum().backward()
+    assert np.array_equal(x.grad.cpu().numpy(), g[tag + '__ends_grad_x'])
+
+
+def test_segment_ops_full_size_vs_oracle():
+    """Phone segments of a C5-like ragged batch: frames -> (phones, frames per phone) and back (adjoint of the split)."""
+    feats = synthetic.make_batch(16, (300, 2000), lab_dim=8, out_dim=80, target_name='mcep', seed=9)
+    x, dur = feats['normalised_mcep'], feats['dur']
+    want = ref_cpu.split_to_segments(x, dur)
+    xt = dev(x).requires_grad_(True)
+    seg = utils.split_to_segments(xt, dev(dur))
+    assert np.array_equal(seg.detach().cpu().numpy(), want)
+    assert np.array_equal(utils.get_segment_ends(xt, dev(dur)).detach().cpu().numpy(), ref_cpu.get_segment_ends(x, dur))
+    seg.backward(seg.detach())                              # scatter of the split itself gives the valid frames back
+    n = feats['n_frames']
+    mask = (np.arange(x.shape[1])[None, :] < n[:, None])[..., None]
+    assert np.array_equal(xt.grad.cpu().numpy(), x * mask)
+
+
 # ------------------------------------------------------------------------------------------- mask / K4 / K5
 def test_sequence_mask(golden):
     g = golden('g3_sequence_mask.npz')

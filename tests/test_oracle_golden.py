@@ -330,3 +330,12 @@ def test_g13_gru_f0_model(golden):
         ref = g['step1_grad__' + key]
         np.testing.assert_allclose(grads[key], ref, rtol=1e-3, atol=1e-4 * np.abs(ref).max(), err_msg=key)
     np.testing.assert_allclose(ref_cpu.gru_f0_train(state, feats, 6, lr=0.01), g['loss_curve'], rtol=1e-4)
+
+
+@pytest.mark.parametrize('tag', ['small', 'wide'])
+def test_g14_segment_ops(golden, tag):
+    """split_to_segments / get_segment_ends (utils.py:231-330), incl. zero-length segments."""
+    g = golden('g14_segments.npz')
+    x, lens = g[tag + '__x'], g[tag + '__lens']
+    assert np.array_equal(ref_cpu.split_to_segments(x, lens), g[tag + '__split'])
+    assert np.array_equal(ref_cpu.get_segment_ends(x, lens), g[tag + '__ends'])
