@@ -145,6 +145,12 @@ int mg_stream_loss_f32(const float* pred, const mg_stream_desc* streams, int n_s
 #define MG_NORM_MINMAX 2      /* (x - mmin) / scale,  scale = mmax - mmin, |scale| <= 1e-8 -> 1  p0 = mmin, p1 = mmax */
 #define MG_DENORM_MINMAX 3    /* x * scale + mmin                                               */
 /* x, out: n_rows x D f32 (any leading batch dims flattened); p0, p1: D f32.  In place (out == x) is allowed. */
+/* Device-side collate of one sequence feature (reference: normalise on load, data.py:119-127; zero-padding collate_fn,
+ * data.py:159-224; ToDeviceWrapper, :648-663).  packed f32 [sum_b len_b, D]: the batch's utterances back to back;
+ * offsets int64 [B+1]: their first rows (offsets[B] = total).  raw_out / norm_out [B,T,D] (either may be NULL): the feature
+ * zero padded to T frames and its normalised twin (kind MG_NORM_MVN or MG_NORM_MINMAX), zero in the pad frames. */
+int mg_pad_normalise_f32(const float* packed, const int64_t* offsets, int B, int T, int D, const float* p0, const float* p1,
+                         int kind, float* raw_out, float* norm_out, void* stream);
 int mg_normalise_f32(const float* x, float* out, const float* p0, const float* p1, int64_t n_rows, int D, int kind,
                      void* stream);
 

@@ -37,6 +37,8 @@ SIGNATURES = {
     'mg_stream_loss_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'mg_stream_loss_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_size_t, c_void_p]),
+    'mg_pad_normalise_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                     c_void_p]),
     'mg_normalise_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     'mg_linear_fwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                   c_int, c_int, c_void_p]),

@@ -210,6 +210,42 @@ __global__ __launch_bounds__(256) void stream_loss_stage1(const float* __restric
     if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+
+// Device-side collate (reference: FilesDataset.__getitem__ normalising on the host, data.py:119-127, then collate_fn's zero
+// padding, :159-224, then ToDeviceWrapper, :648-663): the utterances of a batch arrive packed back to back ([sum of
+// lengths, D], one H2D copy) with their start offsets; one pass writes the zero-padded raw feature and / or its normalised
+// twin.  Pad frames are zero in both (the reference pads the already normalised feature with zeros).  grid (chunks, B).
+__global__ __launch_bounds__(256) void pad_normalise_kernel(const float* __restrict__ packed, const int64_t* __restrict__ offsets,
+                                                            int T, int D, const float* __restrict__ p0, const float* __restrict__ p1,
+                                                            int kind, float* __restrict__ raw_out, float* __restrict__ norm_out) {
+    const int b = blockIdx.y;
+    const int64_t lo = offsets[b];
+    int64_t len = offsets[b + 1] - lo;
+    if (len > T) len = T;
+    const int64_t row_elems = (int64_t)T * D, valid = len * D;
+    const float* src = packed + lo * D;
+    const size_t base = (size_t)b * row_elems;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < row_elems; e += (int64_t)gridDim.x * 256) {
+        float v = 0.f, r = 0.f;
+        if (e < valid) {
+            v = src[e];
+            if (norm_out) {
+                const int d = (int)(e % D);
+                const float a = p0[d], c = p1[d];
+                if (kind == MG_NORM_MVN) {
+                    r = (v - a) / (c + 1e-8f);
+                } else {
+                    float scale = c - a;
+                    if (fabsf(scale) <= 1e-8f) scale = 1.f;
+                    r = (v - a) / scale;
+                }
+            }
+        }
+        if (raw_out) raw_out[base + e] = v;
+        if (norm_out) norm_out[base + e] = r;
+    }
+}
+
 static size_t masked_ws_bytes(int B, int T, int D) {
     const int64_t chunks = mg_ceil_div((int64_t)T * D, MSE_CHUNK);
     return mg_align_up((size_t)B * (size_t)(chunks < 1 ? 1 : chunks) * sizeof(float), 256);
@@ -301,6 +337,22 @@ int mg_stream_loss_f32(const float* pred, const mg_stream_desc* streams, int n_s
     MG_CHECK_LAUNCH("mg_stream_loss_f32/stage1");
     hipLaunchKernelGGL(masked_mse_stage2, dim3(1), dim3(256), 0, st, partial, seq_len, B, T, 1.f, chunks, loss);
     MG_CHECK_LAUNCH("mg_stream_loss_f32/stage2");
+    return MG_OK;
+}
+
+int mg_pad_normalise_f32(const float* packed, const int64_t* offsets, int B, int T, int D, const float* p0, const float* p1,
+                         int kind, float* raw_out, float* norm_out, void* stream) {
+    MG_CHECK_ARG(packed && offsets && B > 0 && T >= 0 && D > 0, "mg_pad_normalise_f32: bad arguments (B=%d T=%d D=%d)", B, T, D);
+    MG_CHECK_ARG(raw_out || norm_out, "mg_pad_normalise_f32: no output requested");
+    MG_CHECK_ARG(!norm_out || (p0 && p1 && (kind == MG_NORM_MVN || kind == MG_NORM_MINMAX)),
+                 "mg_pad_normalise_f32: a normalised output needs parameters and kind MG_NORM_MVN or MG_NORM_MINMAX (kind=%d)", kind);
+    MG_CHECK_ARG(B <= 65535, "mg_pad_normalise_f32: B=%d exceeds 65535", B);
+    if (T == 0) return MG_OK;
+    int64_t chunks = mg_ceil_div((int64_t)T * D, 256 * 8);
+    if (chunks > 1024) chunks = 1024;
+    hipLaunchKernelGGL(pad_normalise_kernel, dim3((unsigned)chunks, B), dim3(256), 0, (hipStream_t)stream, packed, offsets, T, D, p0, p1, kind,
+                       raw_out, norm_out);
+    MG_CHECK_LAUNCH("mg_pad_normalise_f32");
     return MG_OK;
 }
 

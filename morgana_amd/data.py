@@ -232,3 +232,50 @@ def load_utterance(features, normalisers):
         if name in features:
             out['normalised_' + name] = normaliser.normalise(features[name]).astype(np.float32)
     return out
+
+
+def collate_to_device(batch, normalisers, device):
+    """``load_utterance`` + ``collate_fn`` + ``to_device`` for a list of RAW per-utterance feature dicts, with the float
+    sequence features normalised and zero padded on the device (reference: data.py:119-127, 159-224, 648-663).
+
+    Every float32 sequence feature travels as ONE packed host buffer (utterances back to back, pinned when possible) and one
+    kernel pass (mg_pad_normalise_f32) writes the padded raw feature and - where ``normalisers`` has its name - the
+    ``normalised_`` twin; the host never touches per-frame data beyond the concatenation.  Other features (integer
+    durations, scalars, names) take the ordinary collate path.  Same values as the reference's host pipeline to fp32
+    rounding of the normaliser arithmetic (the host version divides in float32 NumPy as well)."""
+    device = torch.device(device)
+    out, rest = {}, []
+    for key in batch[0].keys():
+        first = batch[0][key]
+        if not (isinstance(first, np.ndarray) and first.ndim == 2 and first.dtype == np.float32):
+            rest.append(key)
+            continue
+        items = [item[key] for item in batch]
+        lens = np.array([x.shape[0] for x in items], dtype=np.int64)
+        offsets = torch.from_numpy(np.concatenate(([0], np.cumsum(lens))).astype(np.int64))
+        packed = torch.from_numpy(np.ascontiguousarray(np.concatenate(items, axis=0)))
+        if device.type == 'cuda':
+            packed, offsets = packed.pin_memory(), offsets.pin_memory()
+        packed, offsets = packed.to(device, non_blocking=True), offsets.to(device, non_blocking=True)
+        kind = p0 = p1 = None
+        normaliser = normalisers.get(key) if normalisers is not None else None
+        if isinstance(normaliser, MeanVarianceNormaliser):
+            prm = normaliser.fetch_params(torch.Tensor)
+            kind, p0, p1 = ops.NORM_MVN, prm['mean'].to(device), prm['std_dev'].to(device)
+        elif isinstance(normaliser, MinMaxNormaliser):
+            prm = normaliser.fetch_params(torch.Tensor)
+            kind, p0, p1 = ops.NORM_MINMAX, prm['mmin'].to(device), prm['mmax'].to(device)
+        raw, norm = ops.pad_normalise(packed, offsets, int(lens.max()), p0, p1, kind)
+        out[key] = raw
+        if norm is not None:
+            out['normalised_' + key] = norm
+    if rest:
+        plain = collate_fn([{key: item[key] for key in rest} for item in batch])
+        for key, value in plain.items():
+            out[key] = value.to(device) if isinstance(value, torch.Tensor) else value
+        for key in rest:                                  # integer sequence features with a normaliser (dur) stay on the host path
+            normaliser = normalisers.get(key) if normalisers is not None else None
+            if normaliser is not None and isinstance(batch[0][key], np.ndarray):
+                twin = collate_fn([{key: normaliser.normalise(item[key]).astype(np.float32)} for item in batch])[key]
+                out['normalised_' + key] = twin.to(device)
+    return out

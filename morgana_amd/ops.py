@@ -216,6 +216,25 @@ def stream_loss(pred, targets, kinds, seq_len, want_grad, want_prob=False, grad_
     return loss, grad, prob
 
 
+def pad_normalise(packed, offsets, t, p0=None, p1=None, kind=None, want_raw=True):
+    """Packed utterances (sum len, D) + offsets (B+1) -> (raw (B,t,D) or None, normalised (B,t,D) or None)."""
+    lib = _lib.load()
+    packed = _require(packed, torch.float32, 'packed feature')
+    offsets = _require(offsets, torch.int64, 'offsets')
+    b, d = offsets.numel() - 1, packed.shape[1]
+    raw = torch.empty((b, t, d), dtype=torch.float32, device=packed.device) if want_raw else None
+    norm = None
+    if kind is not None:
+        p0 = _require(p0, torch.float32, 'param0')
+        p1 = _require(p1, torch.float32, 'param1')
+        if p0.numel() != d or p1.numel() != d:
+            raise ValueError('normaliser parameters have %d / %d entries, feature dim is %d' % (p0.numel(), p1.numel(), d))
+        norm = torch.empty((b, t, d), dtype=torch.float32, device=packed.device)
+    _lib.check(lib.mg_pad_normalise_f32(_p(packed), _p(offsets), b, int(t), d, _p(p0), _p(p1), -1 if kind is None else kind,
+                                        _p(raw), _p(norm), _stream()), 'mg_pad_normalise_f32')
+    return raw, norm
+
+
 def normalise(x, p0, p1, kind):
     lib = _lib.load()
     x = _require(x, torch.float32, 'feature')

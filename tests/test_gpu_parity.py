@@ -131,6 +131,36 @@ def test_segment_ops_full_size_vs_oracle():
     assert np.array_equal(xt.grad.cpu().numpy(), x * mask)
 
 
+def test_collate_to_device_matches_host_pipeline():
+    """normalise-on-load + zero-padding collate + upload (data.py:119-127, 159-224, 648-663) against the device-side collate."""
+    rng = np.random.RandomState(44)
+    norms = {'lab': data.MinMaxNormaliser('lab').set_params({'mmin': rng.rand(20).astype(np.float32),
+                                                             'mmax': (1.5 + rng.rand(20)).astype(np.float32)}, device=DEV),
+             'lf0': data.MeanVarianceNormaliser('lf0').set_params({'mean': rng.randn(3).astype(np.float32),
+                                                                   'std_dev': (0.5 + rng.rand(3)).astype(np.float32)}, device=DEV),
+             'dur': data.MeanVarianceNormaliser('dur').set_params({'mean': np.array([7.0], np.float32),
+                                                                   'std_dev': np.array([3.0], np.float32)}, device=DEV)}
+    batch = []
+    for i, (n_ph, n_fr) in enumerate([(5, 40), (9, 77), (1, 3), (7, 64)]):
+        batch.append({'name': 'utt%d' % i, 'n_frames': n_fr, 'n_phones': n_ph,
+                      'dur': rng.randint(1, 12, size=(n_ph, 1)).astype(np.int64),
+                      'lab': (rng.rand(n_ph, 20) * 2).astype(np.float32),
+                      'lf0': rng.randn(n_fr, 3).astype(np.float32),
+                      'vuv': (rng.rand(n_fr, 1) > 0.5)})
+    want = data.to_device(data.collate_fn([data.load_utterance(item, norms) for item in batch]), DEV)
+    got = data.collate_to_device(batch, norms, DEV)
+    assert sorted(got.keys()) == sorted(want.keys())
+    for key, value in want.items():
+        if isinstance(value, torch.Tensor):
+            assert got[key].shape == value.shape and got[key].dtype == value.dtype, key
+            if value.is_floating_point():
+                np.testing.assert_allclose(got[key].cpu().numpy(), value.cpu().numpy(), rtol=1e-6, atol=1e-7, err_msg=key)
+            else:
+                assert torch.equal(got[key], value), key
+        else:
+            assert got[key] == value, key
+
+
 # ------------------------------------------------------------------------------------------- mask / K4 / K5
 def test_sequence_mask(golden):
     g = golden('g3_sequence_mask.npz')
