@@ -65,7 +65,7 @@ __global__ __launch_bounds__(512) void wgrad_fused_kernel(const uint16_t* __rest
                                                           int ldwt, const uint16_t* __restrict__ H1, int ldh,
                                                           const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
                                                           int64_t M, int N, int K, int m_chunk, float* __restrict__ slab,
-                                                          float* __restrict__ bslab) {
+                                                          float* __restrict__ bslab, int64_t sstride) {
     constexpr int TKT = 5;
     constexpr int PY = 256, PX = F_BKT * 2;
     constexpr int NX = 5;
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(512) void wgrad_fused_kernel(const uint16_t* __rest
     MG_STAMP(ts2);
 #endif
     const int lr = lane & 31, lh = lane >> 5;
-    float* out = slab + (size_t)s * N * K;
+    float* out = slab + (size_t)s * sstride;        // split s: [N*K weights | N bias sums], sstride floats apart
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(512) void wgrad_fused_kernel(const uint16_t* __rest
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = n0 + wn0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < N) bslab[(size_t)s * N + row] = acc[i][TKT - 1][r];
+                if (row < N) bslab[(size_t)s * sstride + row] = acc[i][TKT - 1][r];
             }
     }
 #ifdef MG_STAMPS
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(512) void wgrad_fused_pipe_kernel(const uint16_t* _
                                                                int ldwt, const uint16_t* __restrict__ H1, int ldh,
                                                                const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
                                                                int64_t M, int N, int K, int m_chunk, int n_splits,
-                                                               float* __restrict__ slab, float* __restrict__ bslab) {
+                                                               float* __restrict__ slab, float* __restrict__ bslab, int64_t sstride) {
     constexpr int TKT = 5;
     constexpr int PY = 256, PX = F_BKT * 2;
     constexpr int NX = 5;
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(512) void wgrad_fused_pipe_kernel(const uint16_t* _
     MG_STAMP(ts2);
 #endif
     const int lr = lane & 31, lh = lane >> 5;
-    float* out = slab + (size_t)s * N * K;
+    float* out = slab + (size_t)s * sstride;        // split s: [N*K weights | N bias sums], sstride floats apart
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(512) void wgrad_fused_pipe_kernel(const uint16_t* _
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = n0 + wn0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < N) bslab[(size_t)s * N + row] = acc[i][TKT - 1][r];
+                if (row < N) bslab[(size_t)s * sstride + row] = acc[i][TKT - 1][r];
             }
     }
 #ifdef MG_STAMPS
@@ -824,19 +824,25 @@ int mg_linear_bwd_fused_bf16(const uint16_t* dZ2, int lddz, int N2, const uint16
     }
     int S, chunk;
     fused_plan(M, N, &S, &chunk);
+    // split s of the workspace: [N*K weight partials | N bias partials]; when db sits right behind dW (one flat gradient
+    // buffer) a single reduce launch finishes both
+    const int64_t nk = (int64_t)N * K, sstride = nk + N;
     float* slab = (float*)workspace;
-    float* bslab = slab + (size_t)S * N * K;
+    float* bslab = slab + nk;
     hipStream_t st = (hipStream_t)stream;
     if (rows && g_mg_tuning[MG_TUNE_STAGGER] != 7)
         hipLaunchKernelGGL(wgrad_fused_pipe_kernel, dim3((unsigned)((N / F_BNT) * mg_align_up((size_t)S, 8))), dim3(512), 0, st, dZ2, lddz, W2T,
-                           ldwt, H1, ldh, A, lda, rows, M, N, K, chunk, S, slab, bslab);
+                           ldwt, H1, ldh, A, lda, rows, M, N, K, chunk, S, slab, bslab, sstride);
     else
         hipLaunchKernelGGL(wgrad_fused_kernel, dim3((unsigned)((N / F_BNT) * S)), dim3(512), 0, st, dZ2, lddz, W2T, ldwt, H1, ldh, A, lda, rows, M,
-                           N, K, chunk, slab, bslab);
+                           N, K, chunk, slab, bslab, sstride);
     MG_CHECK_LAUNCH("mg_linear_bwd_fused_bf16/main");
-    const int64_t nk = (int64_t)N * K;
-    mg_launch_slab_reduce(slab, nk, nk, S, dW, accumulate, st);
-    mg_launch_slab_reduce(bslab, N, N, S, db, accumulate, st);
+    if (db == dW + nk) {
+        mg_launch_slab_reduce(slab, sstride, sstride, S, dW, accumulate, st);
+    } else {
+        mg_launch_slab_reduce(slab, nk, sstride, S, dW, accumulate, st);
+        mg_launch_slab_reduce(bslab, N, sstride, S, db, accumulate, st);
+    }
     MG_CHECK_LAUNCH("mg_linear_bwd_fused_bf16/reduce");
     return MG_OK;
 }

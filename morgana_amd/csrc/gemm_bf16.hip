@@ -377,7 +377,7 @@ int mg_try_nt_big(const uint16_t* A, int lda, const int32_t* rows, int64_t M, in
                   const float* bias, const uint16_t* H, int ldh, void* C, int ldc, int c_f32, int epi, hipStream_t st);
 int mg_wgrad_big_plan(int64_t M, int N, int K, int lda, int lddy, int* S_out, int* m_chunk_out);
 int mg_launch_wgrad_big(const uint16_t* dY, int lddy, const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K,
-                        int S, int m_chunk, float* slab, float* bslab, hipStream_t st);
+                        int S, int m_chunk, float* slab, float* bslab, int64_t sstride, hipStream_t st);
 
 extern "C" {
 
@@ -465,16 +465,30 @@ int mg_linear_wgrad_bf16(const uint16_t* dY, int lddy, const uint16_t* A, int ld
     int big_s = 0, big_chunk = 0;
     const bool big = mg_wgrad_big_plan(M, N, K, lda, lddy, &big_s, &big_chunk) > 0;
     if (big) p.S = big_s;
+    const int64_t nk = (int64_t)N * K;
+    if (big) {
+        // wide tiles: split s of the workspace = [N*K weight partials | N bias partials]; with db right behind dW (one flat
+        // gradient buffer) a single reduce launch finishes both
+        const int64_t sstride = nk + N;
+        float* bslab = slab + nk;
+        mg_launch_wgrad_big(dY, lddy, A, lda, rows, M, N, K, big_s, big_chunk, slab, db ? bslab : nullptr, sstride, st);
+        MG_CHECK_LAUNCH("mg_linear_wgrad_bf16/partial");
+        if (db && db == dW + nk) {
+            mg_launch_slab_reduce(slab, sstride, sstride, p.S, dW, accumulate, st);
+        } else {
+            mg_launch_slab_reduce(slab, nk, sstride, p.S, dW, accumulate, st);
+            if (db) mg_launch_slab_reduce(bslab, N, sstride, p.S, db, accumulate, st);
+        }
+        MG_CHECK_LAUNCH("mg_linear_wgrad_bf16/reduce");
+        return MG_OK;
+    }
     float* bslab = slab + (size_t)p.S * N * K;
     dim3 grid((unsigned)(p.tiles_n * p.tiles_k), (unsigned)p.S);
-    if (big)
-        mg_launch_wgrad_big(dY, lddy, A, lda, rows, M, N, K, big_s, big_chunk, slab, db ? bslab : nullptr, st);
-    else if (p.narrow)
+    if (p.narrow)
         hipLaunchKernelGGL((wgrad_bf16_kernel<32, 128, 1, 4>), grid, dim3(256), 0, st, dY, lddy, A, lda, rows, M, N, K, p.m_chunk, slab, db ? bslab : nullptr, p.tiles_k);
     else
         hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, dY, lddy, A, lda, rows, M, N, K, p.m_chunk, slab, db ? bslab : nullptr, p.tiles_k);
     MG_CHECK_LAUNCH("mg_linear_wgrad_bf16/partial");
-    const int64_t nk = (int64_t)N * K;
     mg_launch_slab_reduce(slab, nk, nk, p.S, dW, accumulate, st);
     MG_CHECK_LAUNCH("mg_linear_wgrad_bf16/reduce");
     if (db) {

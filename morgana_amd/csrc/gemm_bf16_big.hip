@@ -621,7 +621,7 @@ MG_STAMP_DECL(g_stamps_wg);
 template <int TKW>
 __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restrict__ dY, int lddy, const uint16_t* __restrict__ A, int lda,
                                                         const int32_t* __restrict__ rows, int64_t M, int N, int K, int m_chunk,
-                                                        float* __restrict__ slab, float* __restrict__ bslab) {
+                                                        float* __restrict__ slab, float* __restrict__ bslab, int64_t sstride) {
     constexpr int BNT = 128, BKT = 64 * TKW;
     constexpr int TKT = BKT / 4 / 32;             // 32-column MFMA tiles per wave along k (4 waves along k): 5 or 4
     constexpr int PY = BNT * 2, PX = BKT * 2;     // LDS row pitches in bytes: 256, 1280 / 1024
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restri
     MG_STAMP(ts2);
 #endif
     const int lr = lane & 31, lh = lane >> 5;
-    float* out = slab + (size_t)s * N * K;
+    float* out = slab + (size_t)s * sstride;        // split s: [N*K weights | bias sums behind them when bslab = slab + N*K]
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restri
             }
         }
     }
-    if (bias_valu && tid < BNT && n0 + tid < N) bslab[(size_t)s * N + n0 + tid] = bsum;
+    if (bias_valu && tid < BNT && n0 + tid < N) bslab[(size_t)s * sstride + n0 + tid] = bsum;
     if ((bias_free || bias_extra) && lr == 0) {            // every column of the ones-product holds the same sums
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -814,7 +814,7 @@ __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restri
             for (int r = 0; r < 16; ++r) {
                 const int row = n0 + wn0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const float v = bias_free ? acc[i][TKT - 1][r] : accb[kExtraBias ? i : 0][r];
-                if (row < N) bslab[(size_t)s * N + row] = v;
+                if (row < N) bslab[(size_t)s * sstride + row] = v;
             }
         }
     }
@@ -903,12 +903,12 @@ int mg_wgrad_big_plan(int64_t M, int N, int K, int lda, int lddy, int* S_out, in
 }
 
 int mg_launch_wgrad_big(const uint16_t* dY, int lddy, const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K,
-                        int S, int m_chunk, float* slab, float* bslab, hipStream_t st) {
+                        int S, int m_chunk, float* slab, float* bslab, int64_t sstride, hipStream_t st) {
     dim3 grid((unsigned)((N / 128) * S)), block(512);
     if (lda == 640)
-        hipLaunchKernelGGL((wgrad_big_kernel<10>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab);
+        hipLaunchKernelGGL((wgrad_big_kernel<10>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride);
     else
-        hipLaunchKernelGGL((wgrad_big_kernel<8>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab);
+        hipLaunchKernelGGL((wgrad_big_kernel<8>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride);
     return 1;
 }
 
