@@ -24,6 +24,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 from morgana_amd import _lib, data, distributed, models, ops, optim, synthetic  # noqa: E402
+from morgana_amd import functional as F_hip  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3
@@ -224,7 +225,7 @@ def main():
     def step():
         optimizer.zero_grad()
         loss, _ = model(features)
-        loss.backward()
+        F_hip.backward(loss)             # what ExperimentBuilder.train_epoch calls: loss.backward() with a cached unit gradient
         optimizer.step()
         return loss
 

@@ -14,6 +14,7 @@ import os
 
 import torch
 
+from . import functional as F_hip
 from . import lr_schedules
 from . import utils
 from .optim import Adam
@@ -69,7 +70,7 @@ class ExperimentBuilder(object):
 
             optimizer.zero_grad()                                                # :468
             batch_loss, output_features = self.model(features)                   # :471
-            batch_loss.backward()                                                # :473
+            F_hip.backward(batch_loss)                                           # :473 (loss.backward(), cached unit gradient)
             optimizer.step()                                                     # :474
 
             if lr_schedule is not None and self.lr_schedule_name in lr_schedules.BATCH_LR_SCHEDULES:
