@@ -265,6 +265,44 @@ int mg_lstm_bwd_f32(const float* grad_out, const float* grad_hn, const float* gr
                     const float* w_hh, const int64_t* seq_len, int B, int T, int H, float* dgates, float* dh0, float* dc0,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* A stack of LSTM layers run skewed in time (reference: the 8 x RecurrentCuDNNWrapper(nn.LSTM) of models/RNN_SPSS.py:36-37,
+ * or one multi-layer nn.LSTM): layer l runs `lag` steps behind layer l-1 and ONE launch per step serves every layer, so the
+ * stack costs T + (L-1) lag dependent launches instead of L T.  The caller interleaves, every `lag` steps, the GEMMs that turn
+ * the outputs a layer has just finished into the next chunk of its upper neighbour's input projections (forward) or the
+ * gate gradients of a layer into the next chunk of its lower neighbour's output gradients (backward).
+ *   forward  step s: layer l processes time t = s - l*lag (0 <= t < T), reading xproj rows of times x_t0 .. x_t0+x_T-1
+ *   backward step u: layer l processes time t = T_pad-1 - (u - (L-1-l)*lag), T_pad = ceil(T/lag)*lag; t = -1 finishes
+ *                    dh0 / dc0; grad_out (NULL = zero) holds times g_t0 .. g_t0+g_T-1; carry_h / carry_c [B,H] must hold
+ *                    grad_hn / grad_cn (or zeros) before the first step.
+ * Buffers per layer as in mg_lstm_fwd_f32 / mg_lstm_bwd_f32.  `layers` is a HOST array, n_layers <= MG_LSTM_MAX_LAYERS. */
+#define MG_LSTM_MAX_LAYERS 8
+typedef struct {
+    const float* xproj;
+    int x_T, x_t0;
+    const float* w_hh;
+    const float* b_hh;
+    float* hstate;
+    float* cstate;
+    float* out;
+    float* saved;
+} mg_lstm_fwd_layer;
+typedef struct {
+    const float* grad_out;
+    int g_T, g_t0;
+    const float* cstate;
+    const float* saved;
+    const float* w_hh;
+    float* dgates;
+    float* carry_h;
+    float* carry_c;
+    float* dh0;
+    float* dc0;
+} mg_lstm_bwd_layer;
+int mg_lstm_stack_fwd_f32(const mg_lstm_fwd_layer* layers, int n_layers, const int64_t* seq_len, int B, int T, int H, int lag,
+                          int s_begin, int s_end, void* stream);
+int mg_lstm_stack_bwd_f32(const mg_lstm_bwd_layer* layers, int n_layers, const int64_t* seq_len, int B, int T, int H, int lag,
+                          int u_begin, int u_end, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Optimiser / EMA                         reference: torch.optim.Adam at experiment_builder.py:516, :468-474;
  *                                         ExponentialMovingAverage.update_params, morgana/utils.py:443-456

@@ -75,6 +75,8 @@ SIGNATURES = {
     'mg_lstm_bwd_workspace_bytes': (c_size_t, [c_int, c_int]),
     'mg_lstm_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'mg_lstm_stack_fwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'mg_lstm_stack_bwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'mg_adam_step_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                  c_float, c_int64, c_float, c_void_p]),
     'mg_ema_update_f32': (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
@@ -93,6 +95,20 @@ class StreamDesc(ctypes.Structure):
     _fields_ = [('target', c_void_p), ('ldt', c_int), ('col0', c_int), ('width', c_int), ('kind', c_int)]
 
 
+class LstmFwdLayer(ctypes.Structure):
+    """mg_lstm_fwd_layer of include/morgana_hip.h."""
+    _fields_ = [('xproj', c_void_p), ('x_T', c_int), ('x_t0', c_int), ('w_hh', c_void_p), ('b_hh', c_void_p),
+                ('hstate', c_void_p), ('cstate', c_void_p), ('out', c_void_p), ('saved', c_void_p)]
+
+
+class LstmBwdLayer(ctypes.Structure):
+    """mg_lstm_bwd_layer of include/morgana_hip.h."""
+    _fields_ = [('grad_out', c_void_p), ('g_T', c_int), ('g_t0', c_int), ('cstate', c_void_p), ('saved', c_void_p),
+                ('w_hh', c_void_p), ('dgates', c_void_p), ('carry_h', c_void_p), ('carry_c', c_void_p), ('dh0', c_void_p),
+                ('dc0', c_void_p)]
+
+
+LSTM_MAX_LAYERS = 8
 CAST_MAX = 16
 STREAMS_MAX = 8
 LOSS_MSE, LOSS_SIGMOID_BCE = 0, 1
@@ -118,6 +134,9 @@ def load():
         fn = getattr(lib, name)
         fn.restype = restype
         fn.argtypes = argtypes
+    for item in filter(None, os.environ.get('MG_TUNE', '').split(',')):      # experiments: MG_TUNE=key:value[,key:value]
+        key, value = item.split(':')
+        lib.mg_set_tuning(int(key), int(value))
     _lib = lib
     return lib
 

@@ -387,6 +387,182 @@ class LSTMFn(torch.autograd.Function):
                 dw_ih, dw_hh, db, db.clone())
 
 
+LSTM_STACK_LAG = 32       # steps a layer of a skewed stack runs behind the one below (and frames per projection chunk)
+
+
+class LSTMStackFn(torch.autograd.Function):
+    """L stacked single-layer LSTMs (the 8 x RecurrentCuDNNWrapper(nn.LSTM) of models/RNN_SPSS.py:36-37, or one multi-layer
+    nn.LSTM) run skewed in time: layer l works ``lag`` steps behind layer l - 1 and one launch per step serves every layer
+    (mg_lstm_stack_fwd_f32 / _bwd_f32), T + (L - 1) lag dependent launches instead of L T.  Every ``lag`` steps the chunk of
+    outputs a layer has just finished goes through its upper neighbour's input projection (forward), the chunk of gate
+    gradients through its own W_ih towards the layer below (backward).  Same arithmetic as L chained ``LSTMFn`` calls.
+
+    forward(ctx, precision, lag, x (B,T,I), seq_len, h0s, c0s ((L,B,H) or None), *params) with params = w_ih, w_hh, b_ih, b_hh per
+    layer; returns (outputs of the top layer (B,T,H), h_n (L,B,H), c_n (L,B,H))."""
+
+    @staticmethod
+    def _chunk_rows(b, t, lag, device):
+        rows = []
+        for c0 in range(0, t, lag):
+            tt = torch.arange(c0, min(t, c0 + lag), device=device, dtype=torch.int32)
+            rows.append((torch.arange(b, device=device, dtype=torch.int32)[:, None] * t + tt[None, :]).reshape(-1).contiguous())
+        return rows
+
+    @staticmethod
+    def forward(ctx, precision, lag, x, seq_len, h0s, c0s, *params):
+        from . import _lib
+        n_layers = len(params) // 4
+        w_ih = [params[4 * l] for l in range(n_layers)]
+        w_hh = [params[4 * l + 1].contiguous() for l in range(n_layers)]
+        b_ih = [params[4 * l + 2] for l in range(n_layers)]
+        b_hh = [params[4 * l + 3].contiguous() for l in range(n_layers)]
+        x = ops._require(x, torch.float32, 'inputs')
+        b, t, i_dim = x.shape
+        hid = w_hh[0].shape[1]
+        dev = x.device
+        x2 = x.view(b * t, i_dim)
+        if precision == 'fp32':
+            x_saved = x2
+            xproj0 = ops.linear_fwd_f32(x2, None, b * t, w_ih[0], b_ih[0], ops.ACT_NONE)
+            w_bf = None
+        else:
+            x_saved = ops.cast_pad_bf16(x2)
+            w_bf = [ops.cast_pad_bf16(w) for w in w_ih]
+            xproj0 = ops.linear_fwd_bf16(x_saved, None, b * t, i_dim, w_bf[0], b_ih[0], 4 * hid, ops.ACT_NONE, out_f32=True)
+            if xproj0.shape[1] != 4 * hid:
+                xproj0 = xproj0[:, :4 * hid].contiguous()
+        hstate = [torch.empty((b, t + 1, hid), dtype=torch.float32, device=dev) for _ in range(n_layers)]
+        cstate = [torch.empty((b, t + 1, hid), dtype=torch.float32, device=dev) for _ in range(n_layers)]
+        for l in range(n_layers):
+            for state, init in ((hstate[l], h0s), (cstate[l], c0s)):
+                if init is None:
+                    state[:, 0].zero_()
+                else:
+                    state[:, 0].copy_(init[l].reshape(b, hid))
+        out = [torch.empty((b, t, hid), dtype=torch.float32, device=dev) for _ in range(n_layers)]
+        saved = [torch.empty((b, t, 4 * hid), dtype=torch.float32, device=dev) for _ in range(n_layers)]
+        rows = LSTMStackFn._chunk_rows(b, t, lag, dev)
+        n_chunks = len(rows)
+        descs = (_lib.LstmFwdLayer * n_layers)()
+        for l in range(n_layers):
+            d = descs[l]
+            d.w_hh, d.b_hh = w_hh[l].data_ptr(), b_hh[l].data_ptr()
+            d.hstate, d.cstate, d.out, d.saved = hstate[l].data_ptr(), cstate[l].data_ptr(), out[l].data_ptr(), saved[l].data_ptr()
+        descs[0].xproj, descs[0].x_T, descs[0].x_t0 = xproj0.data_ptr(), t, 0
+        chunk = [None] * n_layers                   # keeps the current projection chunk of each upper layer alive
+        def project(l, c):
+            m = rows[c].numel()
+            below = out[l - 1].view(b * t, hid)
+            if precision == 'fp32':
+                return ops.linear_fwd_f32(below, rows[c], m, w_ih[l], b_ih[l], ops.ACT_NONE)
+            a_bf = ops.gather_rows(below, rows[c], out_bf16=True)
+            xp = ops.linear_fwd_bf16(a_bf, None, m, hid, w_bf[l], b_ih[l], 4 * hid, ops.ACT_NONE, out_f32=True)
+            return xp if xp.shape[1] == 4 * hid else xp[:, :4 * hid].contiguous()
+
+        for s0 in range(0, t + (n_layers - 1) * lag, lag):
+            todo = [(l, s0 // lag - l) for l in range(1, n_layers) if 0 <= s0 // lag - l < n_chunks]
+            for l, c in todo:
+                xp = project(l, c)
+                chunk[l] = xp
+                descs[l].xproj, descs[l].x_T, descs[l].x_t0 = xp.data_ptr(), rows[c].numel() // b, c * lag
+            for l in range(1, n_layers):
+                if chunk[l] is None:
+                    descs[l].xproj, descs[l].x_T, descs[l].x_t0 = xproj0.data_ptr(), 1, -1      # not reached yet: never read
+            ops.lstm_stack_fwd(descs, n_layers, seq_len, b, t, hid, lag, s0, s0 + lag)
+        ctx.precision, ctx.lag = precision, lag
+        ctx.shape = (b, t, i_dim, hid, n_layers)
+        ctx.has_h0, ctx.has_c0 = h0s is not None, c0s is not None
+        ctx.save_for_backward(x_saved, seq_len, *w_ih, *w_hh, *hstate, *cstate, *saved, *out[:-1])
+        hn = torch.stack([hstate[l][:, t] for l in range(n_layers)], dim=0)
+        cn = torch.stack([cstate[l][:, t] for l in range(n_layers)], dim=0)
+        return out[-1], hn, cn
+
+    @staticmethod
+    def backward(ctx, grad_out, grad_hn, grad_cn):
+        from . import _lib
+        b, t, i_dim, hid, n_layers = ctx.shape
+        precision, lag = ctx.precision, ctx.lag
+        sv = ctx.saved_tensors
+        x_saved, seq_len = sv[0], sv[1]
+        pos = 2
+        w_ih = sv[pos:pos + n_layers]; pos += n_layers
+        w_hh = sv[pos:pos + n_layers]; pos += n_layers
+        hstate = sv[pos:pos + n_layers]; pos += n_layers
+        cstate = sv[pos:pos + n_layers]; pos += n_layers
+        saved = sv[pos:pos + n_layers]; pos += n_layers
+        outs = sv[pos:pos + n_layers - 1]
+        dev = hstate[0].device
+        g_top = grad_out.contiguous() if grad_out is not None else None
+        dgates = [torch.empty((b, t, 4 * hid), dtype=torch.float32, device=dev) for _ in range(n_layers)]
+        carry_h = [(grad_hn[l].reshape(b, hid).clone() if grad_hn is not None else torch.zeros((b, hid), dtype=torch.float32, device=dev))
+                   for l in range(n_layers)]
+        carry_c = [(grad_cn[l].reshape(b, hid).clone() if grad_cn is not None else torch.zeros((b, hid), dtype=torch.float32, device=dev))
+                   for l in range(n_layers)]
+        dh0 = torch.empty((n_layers, b, hid), dtype=torch.float32, device=dev)
+        dc0 = torch.empty((n_layers, b, hid), dtype=torch.float32, device=dev)
+        rows = LSTMStackFn._chunk_rows(b, t, lag, dev)
+        n_chunks = len(rows)
+        w_t_bf = [ops.cast_transpose_bf16(w) for w in w_ih] if precision == 'bf16' else None
+        descs = (_lib.LstmBwdLayer * n_layers)()
+        for l in range(n_layers):
+            d = descs[l]
+            d.cstate, d.saved, d.w_hh, d.dgates = cstate[l].data_ptr(), saved[l].data_ptr(), w_hh[l].data_ptr(), dgates[l].data_ptr()
+            d.carry_h, d.carry_c = carry_h[l].data_ptr(), carry_c[l].data_ptr()
+            d.dh0, d.dc0 = dh0[l].data_ptr(), dc0[l].data_ptr()
+            d.grad_out, d.g_T, d.g_t0 = None, 1, 0
+        top = descs[n_layers - 1]
+        top.grad_out, top.g_T, top.g_t0 = (g_top.data_ptr() if g_top is not None else None), t, 0
+        chunk = [None] * n_layers
+        t_pad = n_chunks * lag
+        u_end = t_pad + (n_layers - 1) * lag + 1
+        def back_project(l, c):
+            m = rows[c].numel()
+            above = dgates[l + 1].view(b * t, 4 * hid)
+            if precision == 'fp32':
+                return ops.linear_dgrad_f32(ops.gather_rows(above, rows[c]), w_ih[l + 1], None)
+            dx = ops.linear_dgrad_bf16(ops.gather_rows(above, rows[c], out_bf16=True), m, 4 * hid, w_t_bf[l + 1], hid, None, out_f32=True)
+            return dx if dx.shape[1] == hid else dx[:, :hid].contiguous()
+
+        for u0 in range(0, u_end, lag):
+            todo = [(l, n_chunks - 1 - (u0 // lag - (n_layers - 1 - l))) for l in range(n_layers - 2, -1, -1)]
+            todo = [(l, c) for l, c in todo if 0 <= c < n_chunks]
+            for l, c in todo:
+                dx = back_project(l, c)
+                chunk[l] = dx
+                descs[l].grad_out, descs[l].g_T, descs[l].g_t0 = dx.data_ptr(), rows[c].numel() // b, c * lag
+            ops.lstm_stack_bwd(descs, n_layers, seq_len, b, t, hid, lag, u0, min(u0 + lag, u_end))
+        # weight gradients and the gradient w.r.t. the stack's input: big GEMMs over all frames, as for a single layer
+        m = b * t
+        prev_rows = (torch.arange(b, device=dev, dtype=torch.int32)[:, None] * (t + 1) +
+                     torch.arange(t, device=dev, dtype=torch.int32)[None, :]).reshape(-1).contiguous()
+        grads = []
+        for l in range(n_layers):
+            dg2 = dgates[l].view(m, 4 * hid)
+            hs2 = hstate[l].view(b * (t + 1), hid)
+            in_dim = i_dim if l == 0 else hid
+            if precision == 'fp32':
+                x_in = x_saved if l == 0 else outs[l - 1].view(m, hid)
+                dw_ih, db = ops.linear_wgrad_f32(dg2, x_in, None, 4 * hid, in_dim)
+                dw_hh, _ = ops.linear_wgrad_f32(dg2, hs2, prev_rows, 4 * hid, hid, want_bias=False)
+            else:
+                dg_bf = ops.cast_pad_bf16(dg2)
+                x_in = x_saved if l == 0 else ops.cast_pad_bf16(outs[l - 1].view(m, hid))
+                dw_ih, db = ops.linear_wgrad_bf16(dg_bf, x_in, None, m, 4 * hid, in_dim)
+                dw_hh, _ = ops.linear_wgrad_bf16(dg_bf, ops.cast_pad_bf16(hs2), prev_rows, m, 4 * hid, hid, want_bias=False)
+            grads += [dw_ih, dw_hh, db, db.clone()]
+        dx = None
+        if ctx.needs_input_grad[2]:
+            dg2 = dgates[0].view(m, 4 * hid)
+            if precision == 'fp32':
+                dx = ops.linear_dgrad_f32(dg2, w_ih[0], None).view(b, t, i_dim)
+            else:
+                dx = ops.linear_dgrad_bf16(ops.cast_pad_bf16(dg2), m, 4 * hid, w_t_bf[0], i_dim, None, out_f32=True)
+                if dx.shape[1] != i_dim:
+                    dx = dx[:, :i_dim].contiguous()
+                dx = dx.view(b, t, i_dim)
+        return (None, None, dx, None, dh0 if ctx.has_h0 else None, dc0 if ctx.has_c0 else None) + tuple(grads)
+
+
 class MaskedMSEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, predictions, targets, seq_len, kind='mse'):

@@ -478,6 +478,18 @@ def lstm_bwd(grad_out, grad_hn, grad_cn, cstate, saved, w_hh, seq_len, b, t, h):
     return dgates, dh0, dc0
 
 
+def lstm_stack_fwd(descs, n_layers, seq_len, b, t, h, lag, s_begin, s_end):
+    lib = _lib.load()
+    _lib.check(lib.mg_lstm_stack_fwd_f32(ctypes.cast(descs, ctypes.c_void_p), n_layers, _p(seq_len), b, t, h, lag, s_begin, s_end,
+                                         _stream()), 'mg_lstm_stack_fwd_f32')
+
+
+def lstm_stack_bwd(descs, n_layers, seq_len, b, t, h, lag, u_begin, u_end):
+    lib = _lib.load()
+    _lib.check(lib.mg_lstm_stack_bwd_f32(ctypes.cast(descs, ctypes.c_void_p), n_layers, _p(seq_len), b, t, h, lag, u_begin, u_end,
+                                         _stream()), 'mg_lstm_stack_bwd_f32')
+
+
 # ------------------------------------------------------------------------------------------------------- optimiser
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, betas, eps, weight_decay, step, grad_scale=1.0):
     lib = _lib.load()

@@ -169,22 +169,26 @@ class RecurrentCuDNNWrapper(nn.Module):
         return (isinstance(layer, nn.LSTM) and not layer.bidirectional and layer.batch_first and layer.bias and
                 getattr(layer, 'proj_size', 0) == 0 and (layer.dropout == 0 or not layer.training))
 
+    def _lstm_params(self):
+        layer = self.layer
+        params = []
+        for k in range(layer.num_layers):
+            params += [getattr(layer, 'weight_ih_l%d' % k), getattr(layer, 'weight_hh_l%d' % k),
+                       getattr(layer, 'bias_ih_l%d' % k), getattr(layer, 'bias_hh_l%d' % k)]
+        return params
+
     def _run_lstm(self, inputs, hidden, seq_len):
-        """nn.LSTM with num_layers >= 1 as a chain of single-layer HIP recurrences; hidden = (h0, c0), each
-        (num_layers, B, H), returned in the same layout (utils.py:374-375, 388-389)."""
+        """nn.LSTM with num_layers >= 1; hidden = (h0, c0), each (num_layers, B, H), returned in the same layout
+        (utils.py:374-375, 388-389).  Several layers run as one time-skewed stack (functional.LSTMStackFn)."""
         layer = self.layer
         precision = self.precision or F_hip.get_precision()
         h0s, c0s = (None, None) if hidden is None else hidden
-        out, hns, cns = inputs, [], []
-        for k in range(layer.num_layers):
-            h0 = h0s[k:k + 1] if h0s is not None else None
-            c0 = c0s[k:k + 1] if c0s is not None else None
-            out, hn, cn = F_hip.LSTMFn.apply(precision, out.contiguous(), h0, c0, seq_len,
-                                             getattr(layer, 'weight_ih_l%d' % k), getattr(layer, 'weight_hh_l%d' % k),
-                                             getattr(layer, 'bias_ih_l%d' % k), getattr(layer, 'bias_hh_l%d' % k))
-            hns.append(hn)
-            cns.append(cn)
-        return out, (torch.cat(hns, dim=0), torch.cat(cns, dim=0))
+        if layer.num_layers == 1:
+            out, hn, cn = F_hip.LSTMFn.apply(precision, inputs.contiguous(), h0s, c0s, seq_len, *self._lstm_params())
+            return out, (hn, cn)
+        out, hn, cn = F_hip.LSTMStackFn.apply(precision, F_hip.LSTM_STACK_LAG, inputs.contiguous(), seq_len, h0s, c0s,
+                                              *self._lstm_params())
+        return out, (hn, cn)
 
     def _run_gru(self, inputs, hidden, seq_len):
         layer = self.layer
@@ -269,6 +273,30 @@ class SequentialWithRecurrent(nn.Sequential):
             i = nxt
         return i, run
 
+    @staticmethod
+    def _lstm_run(modules, start, hiddens, seq_len):
+        """Indices of consecutive RecurrentCuDNNWrapper(single-layer nn.LSTM) modules from ``start`` (identity Dropouts between
+        them skipped) that can run as one skewed stack: same hidden size, no initial hidden states, seq_len given, at most
+        functional's layer limit.  Returns (index behind the run, [module indices])."""
+        run, i, last_hidden = [], start, None
+        while i < len(modules) and seq_len is not None and len(run) < 8:
+            mod = modules[i]
+            if type(mod) is nn.Dropout and (mod.p == 0 or not mod.training) and run:
+                i += 1
+                continue
+            ok = (isinstance(mod, RecurrentCuDNNWrapper) and mod._hip_lstm() and mod.layer.num_layers == 1 and hiddens[i] is None and
+                  (last_hidden is None or mod.layer.input_size == last_hidden))
+            if not ok:
+                break
+            run.append(i)
+            last_hidden = mod.layer.hidden_size
+            if run and mod.layer.hidden_size != modules[run[0]].layer.hidden_size:
+                run.pop()
+                break
+            i += 1
+        end = (run[-1] + 1) if run else start
+        return end, run
+
     def _fused_mse_spec(self, targets, precision):
         """acts of the stack if it is [Linear, Sigmoid]* ... Linear(*,128), Sigmoid, Linear(128,32), Sigmoid, Linear(32,1) in
         bf16 mode with a 1-dimensional target (the README F0Model shape) - the case mg_f0_tail_bf16 fuses; else None."""
@@ -337,6 +365,20 @@ class SequentialWithRecurrent(nn.Sequential):
 
             if isinstance(input, (UpsampledSequence, UpsampledConcat)):
                 input = input.materialise()
+
+            if isinstance(module, RecurrentCuDNNWrapper):
+                end, run = self._lstm_run(modules, i, hiddens, seq_len)
+                if len(run) > 1:
+                    # consecutive single-layer LSTM wrappers (models/RNN_SPSS.py:36-37): one time-skewed stack
+                    params = []
+                    for k in run:
+                        params += modules[k]._lstm_params()
+                    input, hn, cn = F_hip.LSTMStackFn.apply(precision, F_hip.LSTM_STACK_LAG, input.contiguous(), seq_len, None,
+                                                            None, *params)
+                    for pos, k in enumerate(run):
+                        hiddens[k] = (hn[pos:pos + 1], cn[pos:pos + 1])
+                    i = end
+                    continue
 
             if isinstance(module, RecurrentCuDNNWrapper):
                 input, hiddens[i] = module(input, hiddens[i], seq_len)

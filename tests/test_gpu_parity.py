@@ -681,6 +681,44 @@ def test_rnn_model_c4_shape_vs_oracle():
         assert rel_err(prm.grad.cpu().numpy(), want_grads[name]) < 1e-3, name
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_lstm_stack_skewed_equals_chained_layers(precision):
+    """functional.LSTMStackFn (layers skewed in time, one launch per step for all of them, projections chunk by chunk) against
+    the same layers run one after the other (LSTMFn): T well beyond the lag, ragged lengths, a length-0 tail chunk, gradients
+    on the outputs and on the final states.  fp32 mode: the same products, summed in a different order by the stack's wide
+    step kernels (whole contraction per wave instead of a 4-way split) - equal to 1e-5."""
+    torch.manual_seed(5)
+    b, t, i_dim, hid, n_layers = 5, 100, 24, 16, 3
+    x = torch.randn(b, t, i_dim, device=DEV, requires_grad=True)
+    seq_len = torch.tensor([100, 37, 64, 1, 99], device=DEV)
+    params = []
+    for l in range(n_layers):
+        params += [torch.randn(4 * hid, i_dim if l == 0 else hid, device=DEV) * 0.3, torch.randn(4 * hid, hid, device=DEV) * 0.3,
+                   torch.randn(4 * hid, device=DEV) * 0.1, torch.randn(4 * hid, device=DEV) * 0.1]
+    params = [p.requires_grad_(True) for p in params]
+    g_out = torch.randn(b, t, hid, device=DEV)
+    g_hn, g_cn = torch.randn(n_layers, b, hid, device=DEV), torch.randn(n_layers, b, hid, device=DEV)
+
+    def run(stacked):
+        for p in [x] + params:
+            p.grad = None
+        if stacked:
+            out, hn, cn = F_hip.LSTMStackFn.apply(precision, 32, x, seq_len, None, None, *params)
+        else:
+            out, hns, cns = x, [], []
+            for l in range(n_layers):
+                out, h, c = F_hip.LSTMFn.apply(precision, out.contiguous(), None, None, seq_len, *params[4 * l:4 * l + 4])
+                hns.append(h)
+                cns.append(c)
+            hn, cn = torch.cat(hns, 0), torch.cat(cns, 0)
+        ((out * g_out).sum() + (hn * g_hn).sum() + (cn * g_cn).sum()).backward()
+        return [out.detach(), hn.detach(), cn.detach(), x.grad.clone()] + [p.grad.clone() for p in params]
+
+    want, got = run(False), run(True)
+    for w, g in zip(want, got):
+        assert rel_err(g.cpu().numpy(), w.cpu().numpy()) < (1e-5 if precision == 'fp32' else RTOL_BF16)
+
+
 # ------------------------------------------------------------------------ LSTM acoustic model (models/RNN_SPSS.py)
 G12_STREAMS = (('lf0', 3, 'mse'), ('vuv', 1, 'sigmoid_bce'), ('mcep', 6, 'mse'), ('bap', 3, 'mse'))
 
