@@ -852,8 +852,6 @@ int mg_try_nt_big(const uint16_t* A, int lda, const int32_t* rows, int64_t M, in
     const int64_t tiles_m = mg_ceil_div(M, 256);
     const int64_t blocks = mg_ceil_div(tiles_m, 8) * 8 * tiles_n;
     if (blocks >= 2147483647LL || tiles_m >= 2147483647LL) return 0;
-    if (blocks < 128) return 0;      // fewer 256-row tiles than half the CUs (e.g. the 2048-frame chunks of a skewed LSTM stack): the
-                                     // 128 x 128 kernel spreads the same product over 4x the workgroups
     // Persistent form: bias / bias + sigmoid with bf16 output, at least one ring of k-tiles per tile, a stores-per-row pattern
     // that needs every store of a row in range (M is arbitrary: rows past the end are skipped per lane).
     const int n_kt = (K + 31) / 32;
