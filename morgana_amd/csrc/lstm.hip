@@ -344,8 +344,10 @@ int mg_lstm_bwd_f32(const float* grad_out, const float* grad_hn, const float* gr
 // With all layers in one launch a step takes 25 us forward / 34 us backward for 8 x LSTM-512 at batch 64 (one layer alone: 10 /
 // 11 us): 128 MB of W_hh and h fragments cross L2 -> L1 per step, i.e. the launch is bound by ~5 TB/s of L2 delivery.  A form
 // with a whole contraction per wave (64 batch x 16 hidden per workgroup, cell update on the accumulators, no LDS) was tried
-// and is SLOWER (32 us): its four waves each pull their own copy of the 128 KB W_hh slice through a 32 KB L1.  The next step
-// is that form with the W_hh slice staged once per workgroup through LDS (65 MB per step).
+// and is SLOWER (32 us): its four waves each pull their own copy of the 128 KB W_hh slice through a 32 KB L1; with the slice
+// staged once per workgroup through LDS (64- or 128-column chunks, double buffered) it takes the same 25 us as the tiles - also
+// with a single layer active, i.e. the time is one workgroup's dependent chain: 512 exact-fp32 MFMAs per wave (8 us), the
+// chunk fetches and the cell update's scattered operand loads behind them.
 // Every `lag` steps the caller computes the next chunk of input projections of the upper layers (a GEMM over the lag
 // outputs the layer below has just finished) - forward - and of output gradients of the lower layers - backward.
 // Step s of the forward pass: layer l is at time t = s - l lag.  Step u of the backward pass: layer l is at time
