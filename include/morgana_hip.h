@@ -252,6 +252,16 @@ int mg_gru_bwd_f32(const float* grad_out, const float* grad_hn, const float* hst
                    const int64_t* seq_len, int B, int T, int H, float* dxproj, float* dhproj, float* dh0, void* workspace,
                    size_t workspace_bytes, void* stream);
 
+/* The same recurrence with bf16 matmul operands (throughput mode; cell arithmetic, states, gate values and all outputs stay
+ * f32): w_hh_bf = bf16(W_hh) [3H, ldw]; hstate_bf [B,T+1,H] is a bf16 shadow of hstate that the caller initialises at slot 0 and
+ * the kernel extends; backward takes w_hh_t_bf = bf16(W_hh^T) [H, ldt >= 3H] and fills dhproj_bf [B,T,3H], the shadow of dhproj.
+ * Needs H % 128 == 0 (H <= 1024). */
+int mg_gru_fwd_bf16(const float* xproj, const uint16_t* w_hh_bf, int ldw, const float* b_hh, const int64_t* seq_len, int B, int T,
+                    int H, float* hstate, uint16_t* hstate_bf, float* out, float* saved, void* stream);
+int mg_gru_bwd_bf16(const float* grad_out, const float* grad_hn, const float* hstate, const float* saved,
+                    const uint16_t* w_hh_t_bf, int ldt, const int64_t* seq_len, int B, int T, int H, float* dxproj, float* dhproj,
+                    uint16_t* dhproj_bf, float* dh0, void* workspace, size_t workspace_bytes, void* stream);
+
 /* LSTM through RecurrentCuDNNWrapper   reference: morgana/utils.py:345-393 + torch.nn.LSTM (gates i, f, g, o), the cell of
  * the reference's shipped acoustic model (models/RNN_SPSS.py:36-37).  Same conventions as the GRU entry points:
  *   xproj [B,T,4H] = x W_ih^T + b_ih; w_hh [4H,H]; b_hh [4H]; hstate / cstate [B,T+1,H] with slot 0 = (h0, c0) on entry;

@@ -228,6 +228,168 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(const float* __restri
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16-operand recurrence (throughput mode).  Same tiles, same 4-way K split, same cell arithmetic in fp32; only the two
+// matmul operands are bf16: a bf16 shadow of the state (written by each step next to the fp32 one) against a bf16 copy of
+// W_hh, on v_mfma_f32_16x16x32_bf16 (lane l holds row l & 15, k = 8 (l >> 4) .. + 7: one 16-byte load per fragment).
+// Per step a workgroup pulls half the bytes of the fp32 form through L2 and spends 12 instead of 96 MFMAs per wave.
+// Needs H % 128 == 0 (each wave owns H / 4 contraction columns in 32-deep steps).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __bf16 gbf8 __attribute__((ext_vector_type(8)));
+#define GB_MAXSTEPS 8                              // H / 128 MFMA k-steps per wave: H <= 1024
+
+__global__ __launch_bounds__(256) void gru_fwd_step_bf16_kernel(const float* __restrict__ xproj, const uint16_t* __restrict__ w_bf, int ldw,
+                                                                const float* __restrict__ b_hh, const int64_t* __restrict__ seq_len,
+                                                                int B, int T, int H, int t, float* __restrict__ hstate,
+                                                                uint16_t* __restrict__ hstate_bf, float* __restrict__ out,
+                                                                float* __restrict__ saved) {
+    __shared__ float red[4][3][GT * GT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    const int j0 = blockIdx.x * GT, b0 = blockIdx.y * GT;
+    const int brow = b0 + li, jrow = j0 + li;
+    const uint16_t* hp = hstate_bf + ((size_t)(brow < B ? brow : 0) * (T + 1) + t) * H;
+    const uint16_t* wr = w_bf + (size_t)(jrow < H ? jrow : 0) * ldw;
+    const uint16_t* wz = wr + (size_t)H * ldw;
+    const uint16_t* wn = wz + (size_t)H * ldw;
+    const int n_steps = H / 128;
+    const int kbase = wave * (H / 4) + 8 * q;
+
+    const int bl = tid >> 4, jl = tid & 15;
+    const int b = b0 + bl, j = j0 + jl;
+    const bool mine = b < B && j < H;
+    const size_t row = (size_t)(mine ? b : 0) * T + t;
+    const float* xp = xproj + row * 3 * H;
+    const int jj = mine ? j : 0;
+    const float xr = xp[jj], xz = xp[H + jj], xn = xp[2 * H + jj];
+    const float hprev = hstate[((size_t)(mine ? b : 0) * (T + 1) + t) * H + jj];
+    const float bhr = b_hh[jj], bhz = b_hh[H + jj], bhn = b_hh[2 * H + jj];
+    const bool active = seq_len ? ((int64_t)t < seq_len[mine ? b : 0]) : true;
+
+    gbf8 fa[GB_MAXSTEPS], fr[GB_MAXSTEPS], fz[GB_MAXSTEPS], fn[GB_MAXSTEPS];
+#pragma unroll
+    for (int i = 0; i < GB_MAXSTEPS; ++i)
+        if (i < n_steps) {
+            const int k = kbase + 32 * i;
+            fa[i] = *reinterpret_cast<const gbf8*>(hp + k);
+            fr[i] = *reinterpret_cast<const gbf8*>(wr + k);
+            fz[i] = *reinterpret_cast<const gbf8*>(wz + k);
+            fn[i] = *reinterpret_cast<const gbf8*>(wn + k);
+        }
+    f32x4 acc_r = {0.f, 0.f, 0.f, 0.f}, acc_z = acc_r, acc_n = acc_r;
+#pragma unroll
+    for (int i = 0; i < GB_MAXSTEPS; ++i)
+        if (i < n_steps) {
+            acc_r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fr[i], acc_r, 0, 0, 0);
+            acc_z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fz[i], acc_z, 0, 0, 0);
+            acc_n = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fn[i], acc_n, 0, 0, 0);
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int e = (4 * q + r) * GT + li;
+        red[wave][0][e] = acc_r[r];
+        red[wave][1][e] = acc_z[r];
+        red[wave][2][e] = acc_n[r];
+    }
+    __syncthreads();
+    if (mine) {
+        const int e = bl * GT + jl;
+        const float hr = ((red[0][0][e] + red[1][0][e]) + (red[2][0][e] + red[3][0][e])) + bhr;
+        const float hz = ((red[0][1][e] + red[1][1][e]) + (red[2][1][e] + red[3][1][e])) + bhz;
+        const float hn = ((red[0][2][e] + red[1][2][e]) + (red[2][2][e] + red[3][2][e])) + bhn;
+        const float r = mg_sigmoid(xr + hr);
+        const float z = mg_sigmoid(xz + hz);
+        const float n = tanhf(xn + r * hn);
+        const float hnew = (1.f - z) * n + z * hprev;
+        const float hnext = active ? hnew : hprev;
+        const size_t nxt = ((size_t)b * (T + 1) + t + 1) * H + j;
+        hstate[nxt] = hnext;
+        hstate_bf[nxt] = mg_f2bf(hnext);
+        out[row * H + j] = active ? hnew : 0.f;
+        float* sv = saved + row * 4 * H;
+        sv[j] = r;
+        sv[H + j] = z;
+        sv[2 * H + j] = n;
+        sv[3 * H + j] = hn;
+    }
+}
+
+// Backward step with bf16 matmul operands: dhproj_bf [B, T, 3H] is the bf16 shadow of dhproj (written here), wt_bf [H, ldt] =
+// W_hh^T, so both fragments are 16-byte row loads; the contraction runs over the 3H gate rows (each wave 3H / 4 of them).
+// Needs (3 H) % 128 == 0.
+#define GBB_MAXSTEPS 24                            // 3 H / 128: H <= 1024
+
+__global__ __launch_bounds__(256) void gru_bwd_step_bf16_kernel(const float* __restrict__ grad_out, const float* __restrict__ hstate,
+                                                                const float* __restrict__ saved, const uint16_t* __restrict__ wt_bf, int ldt,
+                                                                const int64_t* __restrict__ seq_len, int B, int T, int H, int t,
+                                                                float* __restrict__ dxproj, float* __restrict__ dhproj,
+                                                                uint16_t* __restrict__ dhproj_bf, float* __restrict__ carry,
+                                                                float* __restrict__ dh0) {
+    __shared__ float red[4][GT * GT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    const int j0 = blockIdx.x * GT, b0 = blockIdx.y * GT;
+    const int G = 3 * H;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int bl = tid >> 4, jl = tid & 15;
+    const int b = b0 + bl, j = j0 + jl;
+    const bool mine = b < B && j < H && t >= 0;
+    const size_t row = (size_t)(mine ? b : 0) * T + (t >= 0 ? t : 0);
+    const int jj = mine ? j : 0;
+    const float* sv = saved + row * 4 * H;
+    const float s_r = sv[jj], s_z = sv[H + jj], s_n = sv[2 * H + jj], s_hn = sv[3 * H + jj];
+    const float hprev = hstate[((size_t)(mine ? b : 0) * (T + 1) + (t >= 0 ? t : 0)) * H + jj];
+    const float gout = grad_out[row * H + jj];
+    const float cin = carry[(size_t)((b < B) ? b : 0) * H + ((j < H) ? j : 0)];
+    if (t + 1 < T) {
+        const int brow = b0 + li, jcol = j0 + li;
+        const uint16_t* dp = dhproj_bf + ((size_t)(brow < B ? brow : 0) * T + (t + 1)) * G;
+        const uint16_t* wp = wt_bf + (size_t)(jcol < H ? jcol : 0) * ldt;
+        const int n_steps = G / 128;
+        const int gbase = wave * (G / 4) + 8 * q;
+        gbf8 fa[GBB_MAXSTEPS], fb[GBB_MAXSTEPS];
+#pragma unroll
+        for (int i = 0; i < GBB_MAXSTEPS; ++i)
+            if (i < n_steps) {
+                fa[i] = *reinterpret_cast<const gbf8*>(dp + gbase + 32 * i);
+                fb[i] = *reinterpret_cast<const gbf8*>(wp + gbase + 32 * i);
+            }
+#pragma unroll
+        for (int i = 0; i < GBB_MAXSTEPS; ++i)
+            if (i < n_steps) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[i], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][(4 * q + r) * GT + li] = acc[r];
+    __syncthreads();
+    if (b < B && j < H) {
+        const int e = bl * GT + jl;
+        const float dstate = cin + ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e]));
+        if (t < 0) {
+            dh0[(size_t)b * H + j] = dstate;
+            return;
+        }
+        const bool active = seq_len ? ((int64_t)t < seq_len[b]) : true;
+        float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, c = dstate;
+        if (active) {
+            const float r = s_r, z = s_z, n = s_n, hn = s_hn;
+            const float dh = dstate + gout;
+            dn = dh * (1.f - z) * (1.f - n * n);
+            dz = dh * (hprev - n) * z * (1.f - z);
+            dr = dn * hn * r * (1.f - r);
+            dnr = dn * r;
+            c = dh * z;
+        }
+        float* dx = dxproj + row * G;
+        float* dhp = dhproj + row * G;
+        uint16_t* dhb = dhproj_bf + row * G;
+        dx[j] = dr;  dx[H + j] = dz;  dx[2 * H + j] = dn;
+        dhp[j] = dr; dhp[H + j] = dz; dhp[2 * H + j] = dnr;
+        dhb[j] = mg_f2bf(dr); dhb[H + j] = mg_f2bf(dz); dhb[2 * H + j] = mg_f2bf(dnr);
+        carry[(size_t)b * H + j] = c;
+    }
+}
+
 __global__ __launch_bounds__(256) void gru_init_carry_kernel(const float* __restrict__ grad_hn, float* __restrict__ carry, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) carry[i] = grad_hn ? grad_hn[i] : 0.f;
 }
@@ -273,6 +435,45 @@ int mg_gru_bwd_f32(const float* grad_out, const float* grad_hn, const float* hst
             hipLaunchKernelGGL(gru_bwd_step_kernel<0>, grid, dim3(256), 0, st, grad_out, hstate, saved, w_hh, seq_len, B, T, H, t, dxproj, dhproj, carry, dh0, vec);
     }
     MG_CHECK_LAUNCH("mg_gru_bwd_f32");
+    return MG_OK;
+}
+
+int mg_gru_fwd_bf16(const float* xproj, const uint16_t* w_hh_bf, int ldw, const float* b_hh, const int64_t* seq_len, int B, int T, int H,
+                    float* hstate, uint16_t* hstate_bf, float* out, float* saved, void* stream) {
+    MG_CHECK_ARG(xproj && w_hh_bf && b_hh && hstate && hstate_bf && out && saved && B > 0 && T > 0 && H > 0,
+                 "mg_gru_fwd_bf16: bad arguments (B=%d T=%d H=%d)", B, T, H);
+    MG_CHECK_ARG(H % 128 == 0 && H / 128 <= GB_MAXSTEPS && ldw >= H && ldw % 8 == 0, "mg_gru_fwd_bf16: needs H %% 128 == 0, H <= %d (H=%d ldw=%d)",
+                 128 * GB_MAXSTEPS, H, ldw);
+    MG_CHECK_ARG((((uintptr_t)w_hh_bf | (uintptr_t)hstate_bf) % 16) == 0, "mg_gru_fwd_bf16: bf16 buffers must be 16-byte aligned");
+    dim3 grid((unsigned)mg_ceil_div(H, GT), (unsigned)mg_ceil_div(B, GT));
+    for (int t = 0; t < T; ++t)
+        hipLaunchKernelGGL(gru_fwd_step_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, xproj, w_hh_bf, ldw, b_hh, seq_len, B, T, H, t,
+                           hstate, hstate_bf, out, saved);
+    MG_CHECK_LAUNCH("mg_gru_fwd_bf16");
+    return MG_OK;
+}
+
+int mg_gru_bwd_bf16(const float* grad_out, const float* grad_hn, const float* hstate, const float* saved, const uint16_t* w_hh_t_bf,
+                    int ldt, const int64_t* seq_len, int B, int T, int H, float* dxproj, float* dhproj, uint16_t* dhproj_bf, float* dh0,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+    MG_CHECK_ARG(grad_out && hstate && saved && w_hh_t_bf && dxproj && dhproj && dhproj_bf && dh0 && B > 0 && T > 0 && H > 0,
+                 "mg_gru_bwd_bf16: bad arguments (B=%d T=%d H=%d)", B, T, H);
+    MG_CHECK_ARG((3 * H) % 128 == 0 && 3 * H / 128 <= GBB_MAXSTEPS && ldt >= 3 * H && ldt % 8 == 0,
+                 "mg_gru_bwd_bf16: needs 3 H %% 128 == 0, H <= %d (H=%d ldt=%d)", 128 * GBB_MAXSTEPS / 3, H, ldt);
+    MG_CHECK_ARG((((uintptr_t)w_hh_t_bf | (uintptr_t)dhproj_bf) % 16) == 0, "mg_gru_bwd_bf16: bf16 buffers must be 16-byte aligned");
+    if (!workspace || workspace_bytes < mg_gru_bwd_workspace_bytes(B, H)) {
+        mg_set_error("mg_gru_bwd_bf16: workspace of %zu bytes needed, got %zu", mg_gru_bwd_workspace_bytes(B, H), workspace_bytes);
+        return MG_EWORKSPACE;
+    }
+    float* carry = (float*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    int64_t n = (int64_t)B * H;
+    hipLaunchKernelGGL(gru_init_carry_kernel, dim3((unsigned)mg_ceil_div(n, 256)), dim3(256), 0, st, grad_hn, carry, n);
+    dim3 grid((unsigned)mg_ceil_div(H, GT), (unsigned)mg_ceil_div(B, GT));
+    for (int t = T - 1; t >= -1; --t)
+        hipLaunchKernelGGL(gru_bwd_step_bf16_kernel, grid, dim3(256), 0, st, grad_out, hstate, saved, w_hh_t_bf, ldt, seq_len, B, T, H, t, dxproj,
+                           dhproj, dhproj_bf, carry, dh0);
+    MG_CHECK_LAUNCH("mg_gru_bwd_bf16");
     return MG_OK;
 }
 

@@ -9,6 +9,8 @@ Three nodes cover the hot path of the reference's train step (experiment_builder
 Precision: 'fp32' = exact-fp32 MFMA (parity mode, 1e-4 vs the reference), 'bf16' = bf16 operands / fp32 accumulate
 (throughput mode; master weights, biases, loss and optimiser state stay fp32).
 """
+import os
+
 import torch
 
 from . import ops
@@ -267,6 +269,16 @@ class LinearStackMSEFn(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(grads)
 
 
+# In bf16 precision the GRU recurrence runs its two per-step matmuls on bf16 operands (fp32 accumulate, fp32 cell arithmetic and
+# states) when the hidden size allows it; set_recurrence_bf16(False) keeps the exact-fp32 MFMA recurrence under bf16 layers.
+RECURRENCE_BF16 = os.environ.get('MORGANA_RECURRENCE', 'bf16') != 'fp32'
+
+
+def set_recurrence_bf16(enabled):
+    global RECURRENCE_BF16
+    RECURRENCE_BF16 = bool(enabled)
+
+
 class GRUFn(torch.autograd.Function):
     """One GRU layer (batch_first) restricted to seq_len[b] steps per item; returns (outputs, h_n)."""
 
@@ -285,22 +297,32 @@ class GRUFn(torch.autograd.Function):
                                         ops.ACT_NONE, out_f32=True)
             if xproj.shape[1] != 3 * hid:
                 xproj = xproj[:, :3 * hid].contiguous()
-        out, hstate, saved = ops.gru_fwd(xproj.view(b, t, 3 * hid), w_hh.contiguous(), b_hh.contiguous(), seq_len, h0,
-                                         b, t, hid)
+        ctx.bf16_recurrence = precision == 'bf16' and RECURRENCE_BF16 and ops.gru_bf16_ok(hid)
+        hstate_bf = None
+        if ctx.bf16_recurrence:
+            out, hstate, saved, hstate_bf = ops.gru_fwd_bf16(xproj.view(b, t, 3 * hid), w_hh.contiguous(), b_hh.contiguous(),
+                                                             seq_len, h0, b, t, hid)
+        else:
+            out, hstate, saved = ops.gru_fwd(xproj.view(b, t, 3 * hid), w_hh.contiguous(), b_hh.contiguous(), seq_len, h0,
+                                             b, t, hid)
         ctx.precision = precision
         ctx.shape = (b, t, i_dim, hid)
         ctx.has_h0 = h0 is not None
-        ctx.save_for_backward(x_saved, seq_len, w_ih, w_hh, hstate, saved)
+        ctx.save_for_backward(x_saved, seq_len, w_ih, w_hh, hstate, saved, hstate_bf)
         return out, hstate[:, t].unsqueeze(0).contiguous()
 
     @staticmethod
     def backward(ctx, grad_out, grad_hn):
-        x_saved, seq_len, w_ih, w_hh, hstate, saved = ctx.saved_tensors
+        x_saved, seq_len, w_ih, w_hh, hstate, saved, hstate_bf = ctx.saved_tensors
         b, t, i_dim, hid = ctx.shape
         g_out = grad_out.contiguous() if grad_out is not None else torch.zeros((b, t, hid), dtype=torch.float32,
                                                                                 device=hstate.device)
         g_hn = grad_hn.reshape(b, hid).contiguous() if grad_hn is not None else None
-        dxproj, dhproj, dh0 = ops.gru_bwd(g_out, g_hn, hstate, saved, w_hh, seq_len, b, t, hid)
+        dhproj_bf = None
+        if ctx.bf16_recurrence:
+            dxproj, dhproj, dh0, dhproj_bf = ops.gru_bwd_bf16(g_out, g_hn, hstate, saved, w_hh, seq_len, b, t, hid)
+        else:
+            dxproj, dhproj, dh0 = ops.gru_bwd(g_out, g_hn, hstate, saved, w_hh, seq_len, b, t, hid)
         m = b * t
         dxp2, dhp2 = dxproj.view(m, 3 * hid), dhproj.view(m, 3 * hid)
         # h_{t-1} rows of hstate (B, T+1, H): row b*(T+1) + t
@@ -315,9 +337,12 @@ class GRUFn(torch.autograd.Function):
             if need_x:
                 dx = ops.linear_dgrad_f32(dxp2, w_ih, None).view(b, t, i_dim)
         else:
-            dxp_bf, dhp_bf = ops.cast_pad_bf16(dxp2), ops.cast_pad_bf16(dhp2)
+            dxp_bf = ops.cast_pad_bf16(dxp2)
+            # the bf16 recurrence already wrote the bf16 shadows of dhproj and of the states
+            dhp_bf = dhproj_bf.view(m, 3 * hid) if dhproj_bf is not None else ops.cast_pad_bf16(dhp2)
+            hs_bf = hstate_bf.view(b * (t + 1), hid) if hstate_bf is not None else ops.cast_pad_bf16(hs2)
             dw_ih, db_ih = ops.linear_wgrad_bf16(dxp_bf, x_saved, None, m, 3 * hid, i_dim)
-            dw_hh, db_hh = ops.linear_wgrad_bf16(dhp_bf, ops.cast_pad_bf16(hs2), prev_rows, m, 3 * hid, hid)
+            dw_hh, db_hh = ops.linear_wgrad_bf16(dhp_bf, hs_bf, prev_rows, m, 3 * hid, hid)
             if need_x:
                 dx = ops.linear_dgrad_bf16(dxp_bf, m, 3 * hid, ops.cast_transpose_bf16(w_ih), i_dim, None,
                                            out_f32=True)

@@ -447,6 +447,48 @@ def gru_bwd(grad_out, grad_hn, hstate, saved, w_hh, seq_len, b, t, h):
     return dxproj, dhproj, dh0
 
 
+def gru_bf16_ok(h):
+    """The bf16-operand recurrence needs H % 128 == 0 and H <= 1024 (include/morgana_hip.h: mg_gru_fwd_bf16)."""
+    return h % 128 == 0 and h <= 1024
+
+
+def gru_fwd_bf16(xproj, w_hh, b_hh, seq_len, h0, b, t, h):
+    """gru_fwd with bf16 matmul operands.  Returns (out, hstate, saved, hstate_bf (b,t+1,h) bf16)."""
+    lib = _lib.load()
+    dev = xproj.device
+    hstate = torch.empty((b, t + 1, h), dtype=torch.float32, device=dev)
+    hstate_bf = torch.empty((b, t + 1, h), dtype=torch.bfloat16, device=dev)
+    if h0 is None:
+        hstate[:, 0].zero_()
+        hstate_bf[:, 0].zero_()
+    else:
+        hstate[:, 0].copy_(h0.reshape(b, h))
+        hstate_bf[:, 0].copy_(h0.reshape(b, h))
+    w_bf = cast_pad_bf16(w_hh)
+    out = torch.empty((b, t, h), dtype=torch.float32, device=dev)
+    saved = torch.empty((b, t, 4 * h), dtype=torch.float32, device=dev)
+    _lib.check(lib.mg_gru_fwd_bf16(_p(xproj), _p(w_bf), w_bf.shape[1], _p(b_hh), _p(seq_len), b, t, h, _p(hstate), _p(hstate_bf),
+                                   _p(out), _p(saved), _stream()), 'mg_gru_fwd_bf16')
+    return out, hstate, saved, hstate_bf
+
+
+def gru_bwd_bf16(grad_out, grad_hn, hstate, saved, w_hh, seq_len, b, t, h):
+    """gru_bwd with bf16 matmul operands.  Returns (dxproj, dhproj, dh0, dhproj_bf (b,t,3h) bf16)."""
+    lib = _lib.load()
+    dev = grad_out.device
+    dxproj = torch.empty((b, t, 3 * h), dtype=torch.float32, device=dev)
+    dhproj = torch.empty((b, t, 3 * h), dtype=torch.float32, device=dev)
+    dhproj_bf = torch.empty((b, t, 3 * h), dtype=torch.bfloat16, device=dev)
+    dh0 = torch.empty((b, h), dtype=torch.float32, device=dev)
+    wt_bf = cast_transpose_bf16(w_hh)                              # (h, 3h)
+    nbytes = lib.mg_gru_bwd_workspace_bytes(b, h)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _lib.check(lib.mg_gru_bwd_bf16(_p(grad_out), _p(grad_hn), _p(hstate), _p(saved), _p(wt_bf), wt_bf.shape[1], _p(seq_len), b, t, h,
+                                   _p(dxproj), _p(dhproj), _p(dhproj_bf), _p(dh0), _p(ws), ws.numel(), _stream()),
+               'mg_gru_bwd_bf16')
+    return dxproj, dhproj, dh0, dhproj_bf
+
+
 def lstm_fwd(xproj, w_hh, b_hh, seq_len, h0, c0, b, t, h):
     """xproj (b, t, 4h) f32.  Returns (out (b,t,h), hstate (b,t+1,h), cstate (b,t+1,h), saved (b,t,4h))."""
     lib = _lib.load()

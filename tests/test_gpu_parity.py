@@ -681,6 +681,71 @@ def test_rnn_model_c4_shape_vs_oracle():
         assert rel_err(prm.grad.cpu().numpy(), want_grads[name]) < 1e-3, name
 
 
+@pytest.mark.parametrize('b,t,hid', [(5, 37, 128), (16, 50, 512), (33, 12, 256)])
+def test_gru_bf16_recurrence_vs_fp32(b, t, hid):
+    """mg_gru_fwd_bf16 / mg_gru_bwd_bf16 (bf16 matmul operands, fp32 cell) against the exact-fp32 recurrence on the same
+    inputs: ragged lengths incl. a full and a 1-step item, partial batch tiles, an initial state, gradients on outputs and
+    h_n.  Tolerance 1e-2 relative (bf16 operand rounding, 2^-9 per product, fp32 accumulation); the bf16 shadows must be
+    exactly the rounded fp32 buffers."""
+    rng = np.random.RandomState(hid + b)
+    xproj = dev(rng.standard_normal((b, t, 3 * hid)).astype(np.float32))
+    w_hh = dev((rng.uniform(-1, 1, (3 * hid, hid)) / np.sqrt(hid)).astype(np.float32))
+    b_hh = dev(rng.uniform(-0.1, 0.1, 3 * hid).astype(np.float32))
+    h0 = dev(rng.standard_normal((b, hid)).astype(np.float32) * 0.5)
+    sl_np = rng.randint(1, t + 1, size=b).astype(np.int64)
+    sl_np[0], sl_np[-1] = t, 1
+    sl = dev(sl_np)
+    assert ops.gru_bf16_ok(hid)
+    out32, hs32, sv32 = ops.gru_fwd(xproj, w_hh, b_hh, sl, h0, b, t, hid)
+    out16, hs16, sv16, hs_bf = ops.gru_fwd_bf16(xproj, w_hh, b_hh, sl, h0, b, t, hid)
+    assert rel_err(out16.cpu().numpy(), out32.cpu().numpy()) < 1e-2
+    assert rel_err(hs16.cpu().numpy(), hs32.cpu().numpy()) < 1e-2
+    assert rel_err(sv16.cpu().numpy(), sv32.cpu().numpy()) < 1e-2
+    assert torch.equal(hs_bf, hs16.to(torch.bfloat16))
+    for i, n in enumerate(sl_np):
+        assert torch.all(out16[i, n:] == 0)
+        assert torch.equal(hs16[i, n:], hs16[i, n:n + 1].expand(t + 1 - n, hid))
+    g_out = dev(rng.standard_normal((b, t, hid)).astype(np.float32))
+    g_hn = dev(rng.standard_normal((b, hid)).astype(np.float32))
+    # same saved tensors for both, so that only the backward recurrence differs
+    dx32, dh32, d032 = ops.gru_bwd(g_out, g_hn, hs32, sv32, w_hh, sl, b, t, hid)
+    dx16, dh16, d016, dh_bf = ops.gru_bwd_bf16(g_out, g_hn, hs32, sv32, w_hh, sl, b, t, hid)
+    assert rel_err(dx16.cpu().numpy(), dx32.cpu().numpy()) < 1e-2
+    assert rel_err(dh16.cpu().numpy(), dh32.cpu().numpy()) < 1e-2
+    assert rel_err(d016.cpu().numpy(), d032.cpu().numpy()) < 1e-2
+    assert torch.equal(dh_bf, dh16.to(torch.bfloat16))
+    # deterministic
+    again = ops.gru_bwd_bf16(g_out, g_hn, hs32, sv32, w_hh, sl, b, t, hid)
+    assert torch.equal(again[0], dx16) and torch.equal(again[2], d016)
+
+
+def test_gru_bf16_recurrence_rejects_bad_sizes():
+    x = torch.zeros(2, 3, 3 * 96, device=DEV)
+    assert not ops.gru_bf16_ok(96)
+    with pytest.raises(ValueError, match='H % 128'):
+        ops.gru_fwd_bf16(x, torch.zeros(3 * 96, 96, device=DEV), torch.zeros(3 * 96, device=DEV), None, None, 2, 3, 96)
+
+
+@pytest.mark.parametrize('recurrence_bf16', [True, False])
+def test_rnn_model_c4_shape_bf16_vs_oracle(recurrence_bf16):
+    """GRU-512 model (BASELINE C4 widths) in bf16 precision, with the bf16-operand and with the exact-fp32 recurrence, against
+    the fp32 numpy oracle at the bf16 tolerance: loss and predictions 2e-2, every gradient 5e-2 (relative L2)."""
+    feats = synthetic.make_batch(8, (60, 120), out_dim=80, target_name='mcep', seed=11)
+    state = synthetic.rnn_spss_state()
+    want_loss, want_pred, want_grads = ref_cpu.rnn_forward_backward(state, feats)
+    F_hip.set_recurrence_bf16(recurrence_bf16)
+    try:
+        model = _load_state(models.RNNSPSS(precision='bf16').to(DEV), state)
+        loss, out = model(data.to_device(feats, DEV))
+        loss.backward()
+    finally:
+        F_hip.set_recurrence_bf16(True)
+    np.testing.assert_allclose(loss.item(), want_loss, rtol=RTOL_BF16)
+    assert rel_err(out['pred_norm_mcep'].detach().cpu().numpy(), want_pred) < 2e-2
+    for name, prm in model.named_parameters():
+        assert rel_err(prm.grad.cpu().numpy(), want_grads[name]) < 5e-2, name
+
+
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
 def test_lstm_stack_skewed_equals_chained_layers(precision):
     """functional.LSTMStackFn (layers skewed in time, one launch per step for all of them, projections chunk by chunk) against
