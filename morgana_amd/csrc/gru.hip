@@ -18,6 +18,7 @@
 // k = 4q .. 4q+3 of row i (one 16-byte load); MFMA number e consumes element e, i.e. k = 4q + e.  A and B use the
 // same (q, e) <-> k map, so the block's 16 products are each taken exactly once.
 #include "common.h"
+#include "gru_cell.h"
 
 #define GT 16  // tile edge (batch x hidden units)
 
@@ -295,13 +296,11 @@ __global__ __launch_bounds__(256) void gru_fwd_step_bf16_kernel(const float* __r
     __syncthreads();
     if (mine) {
         const int e = bl * GT + jl;
-        const float hr = ((red[0][0][e] + red[1][0][e]) + (red[2][0][e] + red[3][0][e])) + bhr;
-        const float hz = ((red[0][1][e] + red[1][1][e]) + (red[2][1][e] + red[3][1][e])) + bhz;
-        const float hn = ((red[0][2][e] + red[1][2][e]) + (red[2][2][e] + red[3][2][e])) + bhn;
-        const float r = mg_sigmoid(xr + hr);
-        const float z = mg_sigmoid(xz + hz);
-        const float n = tanhf(xn + r * hn);
-        const float hnew = (1.f - z) * n + z * hprev;
+        const float hr = mg_gru_sum4(red[0][0][e], red[1][0][e], red[2][0][e], red[3][0][e], bhr);
+        const float hz = mg_gru_sum4(red[0][1][e], red[1][1][e], red[2][1][e], red[3][1][e], bhz);
+        const float hn = mg_gru_sum4(red[0][2][e], red[1][2][e], red[2][2][e], red[3][2][e], bhn);
+        const mg_gru_cell_out c = mg_gru_cell(xr, xz, xn, hr, hz, hn, hprev);
+        const float r = c.r, z = c.z, n = c.n, hnew = c.hnew;
         const float hnext = active ? hnew : hprev;
         const size_t nxt = ((size_t)b * (T + 1) + t + 1) * H + j;
         hstate[nxt] = hnext;

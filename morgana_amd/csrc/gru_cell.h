@@ -1,0 +1,27 @@
+// The GRU cell arithmetic shared by the launch-per-step and the persistent bf16-operand kernels (gru.hip, gru_persist.hip), with
+// floating-point contraction pinned off so that both evaluate bit-identical expressions whatever code surrounds the call:
+// the persistent kernel's hand-off protocol is tested by exact equality against the per-step kernels.
+// Gate order and formulas: torch.nn.GRU as used by the reference (morgana/utils.py:345-393).
+#pragma once
+
+#include "common.h"
+
+struct mg_gru_cell_out {
+    float r, z, n, hnew;
+};
+
+__device__ __forceinline__ mg_gru_cell_out mg_gru_cell(float xr, float xz, float xn, float hr, float hz, float hn, float hprev) {
+#pragma clang fp contract(off)
+    mg_gru_cell_out o;
+    o.r = mg_sigmoid(xr + hr);
+    o.z = mg_sigmoid(xz + hz);
+    o.n = tanhf(xn + o.r * hn);
+    o.hnew = (1.f - o.z) * o.n + o.z * hprev;
+    return o;
+}
+
+// sum of the 4 waves' partial pre-activations plus the bias, in a fixed order
+__device__ __forceinline__ float mg_gru_sum4(float a, float b, float c, float d, float bias) {
+#pragma clang fp contract(off)
+    return ((a + b) + (c + d)) + bias;
+}

@@ -1,0 +1,285 @@
+// K3p - the GRU recurrence as ONE launch (throughput mode, bf16 matmul operands): W_hh stays in registers for all T steps and
+// the workgroups hand the new state to each other through memory instead of ending the kernel after every step.
+// Reference semantics: morgana/utils.py:345-393 (RecurrentCuDNNWrapper around torch.nn.GRU), same arithmetic as
+// gru_fwd_step_bf16_kernel / gru_bwd_step_bf16_kernel (gru.hip), which stay as the path for shapes this file does not cover.
+//
+// Decomposition.  Batch items never interact inside the recurrence, so the batch is cut into 8 independent GROUPS of
+// R = ceil(B / 8) items; a group is served by H / 16 workgroups (SLOTS), slot s owning hidden units [16 s, 16 s + 16) of all
+// three gates: 48 rows of W_hh (bf16, 48 KB at H = 512) = 48 VGPRs per lane, loaded once.  Group = blockIdx % 8, so that the
+// workgroups of a group usually share an XCD (blocks are dealt round-robin); that is a speed affinity only - the protocol below is
+// placement independent.  Per step a workgroup reads the group's whole state h_{t-1} (R x H bf16), runs 3 H / 128 MFMAs per wave,
+// sums its 4 waves' partials through LDS, applies the cell and publishes its 16 columns of h_t.
+//
+// Hand-off (cdna_hip_programming.md §6 Guideline 16, form R1 with sc1 loads in place of the acquire): every byte of the bf16
+// state that another workgroup reads in this launch is written by a 16-byte sc1 (write-through) store of wave 0, drained with
+// s_waitcnt vmcnt(0), then ONE lane stores the slot's flag (epoch = t + 1, sc1).  The consumer's wave 0 polls the group's flags
+// (one 4-byte sc1 load per lane, one lane per slot), joins a workgroup barrier, and every load of the state is a
+// buffer_load_dwordx4 sc1 to registers.  Flags are zeroed by a memset node ahead of every launch; every spin is bounded and a
+// time-out sets the status word (mg_gru_persist_status) and makes the workgroup return.
+// fp32 copies of the state, the outputs and the saved gate values are plain stores (nobody reads them before the kernel ends;
+// a thread carries its own h_{t-1} element in a register).
+//
+// Steps at or beyond the longest sequence of a group need no matmul and no hand-off: the state is frozen and the outputs are
+// zero, so the group finishes them without synchronising (ragged batches: BASELINE config C5).
+#include "common.h"
+#include "gru_cell.h"
+
+#define GT 16
+#define GP_GROUPS 8
+#define GP_SLOTS 32                          // flag words per group (H <= 512)
+#define GP_KSTEPS 4                          // H / 128 MFMA k-steps per wave, H <= 512
+#define GP_SPIN_LIMIT (1u << 20)
+#define GP_SYNC_WORDS (GP_GROUPS * GP_SLOTS + 4)   // flags + {status, 3 pad}: 1040 bytes, a multiple of 16
+
+typedef __bf16 gbf8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+__device__ __forceinline__ gbf8 as_bf8(u32x4 v) {
+    union { u32x4 u; gbf8 b; } c;
+    c.u = v;
+    return c.b;
+}
+
+// wave 0: wait until every slot's flag of the group has reached `epoch`.  Returns false after GP_SPIN_LIMIT polls.
+__device__ __forceinline__ bool gp_wait_flags(gu32* flags, int n_slots, unsigned epoch, int lane) {
+    for (unsigned spins = 0;; ++spins) {
+        const unsigned f = lane < n_slots ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+        if (__all(f >= epoch)) return true;
+        if (spins > GP_SPIN_LIMIT) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+template <int MT, int KS>
+__global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __restrict__ xproj, const uint16_t* __restrict__ w_bf, int ldw,
+                                                              const float* __restrict__ b_hh, const int64_t* __restrict__ seq_len,
+                                                              int B, int T, int H, int R, float* __restrict__ hstate,
+                                                              uint16_t* hstate_bf, float* __restrict__ out,
+                                                              float* __restrict__ saved, unsigned* sync) {
+    __shared__ float red[4][3][MT][GT * GT];
+    __shared__ __attribute__((aligned(16))) uint16_t hb[MT][GT][GT];
+    __shared__ int s_abort;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    const int group = blockIdx.x % GP_GROUPS, slot = blockIdx.x / GP_GROUPS;
+    const int n_slots = H / GT;
+    const int row0 = group * R;
+    const int nrows = min(R, B - row0);
+    if (slot >= n_slots || nrows <= 0) return;
+    const int j0 = slot * GT;
+    gu32* flags = (gu32*)sync + group * GP_SLOTS;
+    gu32* status = (gu32*)sync + GP_GROUPS * GP_SLOTS;
+    if (tid == 0) s_abort = 0;
+
+    // longest sequence of the group
+    int gmax = 0;
+    for (int r = 0; r < nrows; ++r) {
+        const int64_t n = seq_len ? seq_len[row0 + r] : (int64_t)T;
+        gmax = max(gmax, (int)(n < T ? n : T));
+    }
+
+    // W_hh fragments of this slot, for the whole launch
+    const int kbase = wave * (H / 4) + 8 * q;
+    gbf8 fr[KS], fz[KS], fn[KS];
+    {
+        const uint16_t* wr = w_bf + (size_t)(j0 + li) * ldw;
+        const uint16_t* wz = wr + (size_t)H * ldw;
+        const uint16_t* wn = wz + (size_t)H * ldw;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            fr[i] = *reinterpret_cast<const gbf8*>(wr + kbase + 32 * i);
+            fz[i] = *reinterpret_cast<const gbf8*>(wz + kbase + 32 * i);
+            fn[i] = *reinterpret_cast<const gbf8*>(wn + kbase + 32 * i);
+        }
+    }
+    const auto rs_h = __builtin_amdgcn_make_buffer_rsrc((void*)hstate_bf, 0, (int)((size_t)B * (T + 1) * H * 2), 0x00020000);
+
+    // cell role: thread (bl, jl) owns element (row0 + 16 m + bl, j0 + jl) in every step
+    const int bl = tid >> 4, jl = tid & 15;
+    const int j = j0 + jl;
+    const float bhr = b_hh[j], bhz = b_hh[H + j], bhn = b_hh[2 * H + j];
+    float hprev[MT];
+    int len[MT];
+    bool mine[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        mine[m] = 16 * m + bl < nrows;
+        const int b = row0 + (mine[m] ? 16 * m + bl : 0);
+        hprev[m] = hstate[((size_t)b * (T + 1)) * H + j];
+        len[m] = seq_len ? (int)min((int64_t)T, seq_len[b]) : T;
+    }
+    __syncthreads();
+
+    for (int t = 0; t < gmax; ++t) {
+        // this step's input projections: independent of the hand-off, requested ahead of the poll
+        float xr[MT], xz[MT], xn[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int b = row0 + (mine[m] ? 16 * m + bl : 0);
+            const float* xp = xproj + ((size_t)b * T + t) * 3 * H;
+            xr[m] = xp[j];
+            xz[m] = xp[H + j];
+            xn[m] = xp[2 * H + j];
+        }
+        if (t > 0) {
+            if (wave == 0 && !gp_wait_flags(flags, n_slots, (unsigned)t, lane)) s_abort = 1;
+            __syncthreads();
+            if (s_abort) {
+                if (tid == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        }
+        // h_{t-1} of the group: bf16, sc1 loads only
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const bool valid = 16 * m + li < nrows;
+            const unsigned off = (unsigned)((((size_t)(row0 + (valid ? 16 * m + li : 0)) * (T + 1) + t) * H + kbase) * 2);
+            u32x4 raw[KS];
+#pragma unroll
+            for (int i = 0; i < KS; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_h, off + 64 * i, 0, 16);
+            __builtin_amdgcn_sched_barrier(0);          // all KS loads in flight before the first MFMA waits (one round trip)
+            f32x4 acc_r = {0.f, 0.f, 0.f, 0.f}, acc_z = acc_r, acc_n = acc_r;
+#pragma unroll
+            for (int i = 0; i < KS; ++i) {
+                const gbf8 a = as_bf8(raw[i]);
+                acc_r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, fr[i], acc_r, 0, 0, 0);
+                acc_z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, fz[i], acc_z, 0, 0, 0);
+                acc_n = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, fn[i], acc_n, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = (4 * q + r) * GT + li;
+                red[wave][0][m][e] = acc_r[r];
+                red[wave][1][m][e] = acc_z[r];
+                red[wave][2][m][e] = acc_n[r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int e = bl * GT + jl;
+            const float hr = mg_gru_sum4(red[0][0][m][e], red[1][0][m][e], red[2][0][m][e], red[3][0][m][e], bhr);
+            const float hz = mg_gru_sum4(red[0][1][m][e], red[1][1][m][e], red[2][1][m][e], red[3][1][m][e], bhz);
+            const float hn = mg_gru_sum4(red[0][2][m][e], red[1][2][m][e], red[2][2][m][e], red[3][2][m][e], bhn);
+            const mg_gru_cell_out c = mg_gru_cell(xr[m], xz[m], xn[m], hr, hz, hn, hprev[m]);
+            const float r = c.r, z = c.z, n = c.n, hnew = c.hnew;
+            const bool active = t < len[m];
+            const float hnext = active ? hnew : hprev[m];
+            hprev[m] = hnext;
+            hb[m][bl][jl] = mg_f2bf(hnext);
+            if (mine[m]) {
+                const int b = row0 + 16 * m + bl;
+                const size_t row = (size_t)b * T + t;
+                hstate[((size_t)b * (T + 1) + t + 1) * H + j] = hnext;
+                out[row * H + j] = active ? hnew : 0.f;
+                float* sv = saved + row * 4 * H;
+                sv[j] = r;
+                sv[H + j] = z;
+                sv[2 * H + j] = n;
+                sv[3 * H + j] = hn;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // publish the slot's 16 columns of h_t: 32 bytes per item = two 16-byte sc1 stores
+            auto rs_w = rs_h;
+            if (lane < 2 * 16 * MT) {
+                const int rrow = lane >> 1, half = lane & 1;
+                if (rrow < nrows) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(&hb[rrow >> 4][rrow & 15][8 * half]);
+                    const unsigned off = (unsigned)((((size_t)(row0 + rrow) * (T + 1) + t + 1) * H + j0 + 8 * half) * 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rs_w, off, 0, 16);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(flags + slot, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // beyond the group's longest sequence: state frozen, outputs zero - no matmul, no hand-off
+    for (int t = gmax; t < T; ++t) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            if (mine[m]) {
+                const int b = row0 + 16 * m + bl;
+                const size_t row = (size_t)b * T + t;
+                const size_t nxt = ((size_t)b * (T + 1) + t + 1) * H + j;
+                hstate[nxt] = hprev[m];
+                hstate_bf[nxt] = mg_f2bf(hprev[m]);
+                out[row * H + j] = 0.f;
+                float* sv = saved + row * 4 * H;
+                sv[j] = 0.f;
+                sv[H + j] = 0.f;
+                sv[2 * H + j] = 0.f;
+                sv[3 * H + j] = 0.f;
+            }
+    }
+}
+
+extern "C" {
+
+size_t mg_gru_persist_workspace_bytes(void) { return (size_t)GP_SYNC_WORDS * sizeof(unsigned); }
+
+int mg_gru_persist_supported(int B, int T, int H) {
+    if (B <= 0 || T <= 0 || H <= 0) return 0;
+    if (H % 128 != 0 || H > 128 * GP_KSTEPS) return 0;
+    if (mg_ceil_div(B, GP_GROUPS) > 32) return 0;
+    if ((size_t)B * (T + 1) * (size_t)H * 3 * 2 >= ((size_t)1 << 31)) return 0;     // 32-bit buffer offsets (backward: 3 H wide)
+    return 1;
+}
+
+int mg_gru_persist_status(const void* workspace, void* stream) {
+    unsigned st = 0;
+    if (hipMemcpyAsync(&st, (const unsigned*)workspace + GP_GROUPS * GP_SLOTS, sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream) !=
+            hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+        mg_set_error("mg_gru_persist_status: could not read the status word");
+        return MG_ELAUNCH;
+    }
+    if (st != 0) {
+        mg_set_error("persistent GRU kernel timed out waiting for another workgroup (status %u): results are invalid", st);
+        return MG_ELAUNCH;
+    }
+    return MG_OK;
+}
+
+int mg_gru_fwd_persist_bf16(const float* xproj, const uint16_t* w_hh_bf, int ldw, const float* b_hh, const int64_t* seq_len, int B, int T,
+                            int H, float* hstate, uint16_t* hstate_bf, float* out, float* saved, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+    MG_CHECK_ARG(xproj && w_hh_bf && b_hh && hstate && hstate_bf && out && saved && B > 0 && T > 0 && H > 0,
+                 "mg_gru_fwd_persist_bf16: bad arguments (B=%d T=%d H=%d)", B, T, H);
+    MG_CHECK_ARG(mg_gru_persist_supported(B, T, H) && ldw >= H && ldw % 8 == 0,
+                 "mg_gru_fwd_persist_bf16: unsupported shape (B=%d T=%d H=%d ldw=%d): needs H %% 128 == 0, H <= 512, B <= 256", B, T, H, ldw);
+    MG_CHECK_ARG((((uintptr_t)w_hh_bf | (uintptr_t)hstate_bf | (uintptr_t)workspace) % 16) == 0,
+                 "mg_gru_fwd_persist_bf16: bf16 buffers and workspace must be 16-byte aligned");
+    if (!workspace || workspace_bytes < mg_gru_persist_workspace_bytes()) {
+        mg_set_error("mg_gru_fwd_persist_bf16: workspace of %zu bytes needed, got %zu", mg_gru_persist_workspace_bytes(), workspace_bytes);
+        return MG_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(workspace, 0, mg_gru_persist_workspace_bytes(), st) != hipSuccess) {
+        mg_set_error("mg_gru_fwd_persist_bf16: memset failed");
+        return MG_ELAUNCH;
+    }
+    const int R = (int)mg_ceil_div(B, GP_GROUPS);
+    const unsigned grid = (unsigned)(GP_GROUPS * (H / GT));
+#define GP_FWD(MT, KS)                                                                                                                  \
+    hipLaunchKernelGGL((gru_fwd_persist_kernel<MT, KS>), dim3(grid), dim3(256), 0, st, xproj, w_hh_bf, ldw, b_hh, seq_len, B, T, H, R, hstate, \
+                       hstate_bf, out, saved, (unsigned*)workspace)
+#define GP_FWD_KS(MT)            \
+    switch (H / 128) {           \
+        case 1: GP_FWD(MT, 1); break; \
+        case 2: GP_FWD(MT, 2); break; \
+        case 3: GP_FWD(MT, 3); break; \
+        default: GP_FWD(MT, 4); break; \
+    }
+    if (R <= 16) {
+        GP_FWD_KS(1)
+    } else {
+        GP_FWD_KS(2)
+    }
+    MG_CHECK_LAUNCH("mg_gru_fwd_persist_bf16");
+    return MG_OK;
+}
+
+}  // extern "C"

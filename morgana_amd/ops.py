@@ -3,6 +3,8 @@ HIP stream.  No arithmetic happens here and nothing falls back to torch ops: a m
 """
 import ctypes
 
+import os
+
 import torch
 
 from . import _lib
@@ -452,9 +454,39 @@ def gru_bf16_ok(h):
     return h % 128 == 0 and h <= 1024
 
 
-def gru_fwd_bf16(xproj, w_hh, b_hh, seq_len, h0, b, t, h):
-    """gru_fwd with bf16 matmul operands.  Returns (out, hstate, saved, hstate_bf (b,t+1,h) bf16)."""
+_PERSIST_WORKSPACES = []          # sync blocks of persistent launches whose status word has not been read yet
+PERSISTENT_RECURRENCE = os.environ.get('MORGANA_PERSISTENT', '1') != '0'
+
+
+def gru_persist_ok(b, t, h):
+    return PERSISTENT_RECURRENCE and bool(_lib.load().mg_gru_persist_supported(b, t, h))
+
+
+def _persist_workspace(dev):
+    nbytes = _lib.load().mg_gru_persist_workspace_bytes()
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _PERSIST_WORKSPACES.append(ws)
+    if len(_PERSIST_WORKSPACES) > 64:
+        check_persistent_status()
+    return ws
+
+
+def check_persistent_status():
+    """Synchronise and raise if a persistent recurrent kernel gave up waiting for a peer workgroup (its results are invalid).
+    Called by the training loop once per step (ExperimentBuilder), by bench.py and by the tests."""
     lib = _lib.load()
+    pending = list(_PERSIST_WORKSPACES)
+    del _PERSIST_WORKSPACES[:]
+    for ws in pending:
+        _lib.check(lib.mg_gru_persist_status(_p(ws), _stream()), 'mg_gru_persist_status')
+
+
+def gru_fwd_bf16(xproj, w_hh, b_hh, seq_len, h0, b, t, h, persistent=None):
+    """gru_fwd with bf16 matmul operands.  Returns (out, hstate, saved, hstate_bf (b,t+1,h) bf16).
+    persistent: one launch for all steps (None = whenever the shape is covered)."""
+    lib = _lib.load()
+    if persistent is None:
+        persistent = gru_persist_ok(b, t, h)
     dev = xproj.device
     hstate = torch.empty((b, t + 1, h), dtype=torch.float32, device=dev)
     hstate_bf = torch.empty((b, t + 1, h), dtype=torch.bfloat16, device=dev)
@@ -467,8 +499,14 @@ def gru_fwd_bf16(xproj, w_hh, b_hh, seq_len, h0, b, t, h):
     w_bf = cast_pad_bf16(w_hh)
     out = torch.empty((b, t, h), dtype=torch.float32, device=dev)
     saved = torch.empty((b, t, 4 * h), dtype=torch.float32, device=dev)
-    _lib.check(lib.mg_gru_fwd_bf16(_p(xproj), _p(w_bf), w_bf.shape[1], _p(b_hh), _p(seq_len), b, t, h, _p(hstate), _p(hstate_bf),
-                                   _p(out), _p(saved), _stream()), 'mg_gru_fwd_bf16')
+    if persistent:
+        ws = _persist_workspace(dev)
+        _lib.check(lib.mg_gru_fwd_persist_bf16(_p(xproj), _p(w_bf), w_bf.shape[1], _p(b_hh), _p(seq_len), b, t, h, _p(hstate),
+                                               _p(hstate_bf), _p(out), _p(saved), _p(ws), ws.numel(), _stream()),
+                   'mg_gru_fwd_persist_bf16')
+    else:
+        _lib.check(lib.mg_gru_fwd_bf16(_p(xproj), _p(w_bf), w_bf.shape[1], _p(b_hh), _p(seq_len), b, t, h, _p(hstate), _p(hstate_bf),
+                                       _p(out), _p(saved), _stream()), 'mg_gru_fwd_bf16')
     return out, hstate, saved, hstate_bf
 
 

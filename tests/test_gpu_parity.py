@@ -719,6 +719,35 @@ def test_gru_bf16_recurrence_vs_fp32(b, t, hid):
     assert torch.equal(again[0], dx16) and torch.equal(again[2], d016)
 
 
+@pytest.mark.parametrize('b,t,hid', [(64, 60, 512), (5, 37, 128), (33, 20, 256), (200, 9, 128), (130, 25, 384)])
+def test_gru_persistent_equals_stepwise(b, t, hid):
+    """The one-launch recurrence (gru_persist.hip: W_hh in registers, state handed between workgroups with write-through
+    stores and flags) against the launch-per-step kernels on the same inputs: same operands, same summation order and the
+    same cell code (csrc/gru_cell.h, contraction pinned), so the results must be EQUAL; steps beyond a group's longest sequence
+    write zero gate values.
+    Repeated to catch a stale hand-off (every element of every step depends on all hand-offs before it)."""
+    rng = np.random.RandomState(hid + b)
+    xproj = dev(rng.standard_normal((b, t, 3 * hid)).astype(np.float32))
+    w_hh = dev((rng.uniform(-1, 1, (3 * hid, hid)) / np.sqrt(hid)).astype(np.float32))
+    b_hh = dev(rng.uniform(-0.1, 0.1, 3 * hid).astype(np.float32))
+    h0 = dev(rng.standard_normal((b, hid)).astype(np.float32) * 0.5)
+    sl_np = rng.randint(1, t + 1, size=b).astype(np.int64)
+    sl_np[0] = t
+    sl_np[-1] = 1
+    assert ops.gru_persist_ok(b, t, hid)
+    for sl in (dev(sl_np), None):
+        want = ops.gru_fwd_bf16(xproj, w_hh, b_hh, sl, h0, b, t, hid, persistent=False)
+        for rep in range(3):
+            got = ops.gru_fwd_bf16(xproj, w_hh, b_hh, sl, h0, b, t, hid, persistent=True)
+            ops.check_persistent_status()
+            for name, g, w in zip(('out', 'hstate', 'saved', 'hstate_bf'), got, want):
+                g, w = g.float().cpu().numpy(), w.float().cpu().numpy()
+                if name == 'saved' and sl is not None:
+                    live = (np.arange(t)[None, :] < sl_np[:, None])[:, :, None]
+                    g, w = g * live, w * live
+                np.testing.assert_array_equal(g, w, err_msg='%s rep %d' % (name, rep))
+
+
 def test_gru_bf16_recurrence_rejects_bad_sizes():
     x = torch.zeros(2, 3, 3 * 96, device=DEV)
     assert not ops.gru_bf16_ok(96)
