@@ -245,6 +245,7 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    ops.check_persistent_status()        # raises if a persistent recurrent kernel timed out (results would be invalid)
     final_loss = float(distributed.mean_scalar(loss.detach()).item())
 
     result = None

@@ -267,14 +267,20 @@ int mg_gru_bwd_bf16(const float* grad_out, const float* grad_hn, const float* hs
  * Same arguments and results as mg_gru_fwd_bf16 / mg_gru_bwd_bf16 plus a workspace of mg_gru_persist_workspace_bytes() holding the
  * flags and a status word.  mg_gru_persist_supported(B, T, H) != 0 says the shape is covered (H % 128 == 0, H <= 512,
  * B <= 256, buffers < 2 GiB); other shapes return MG_EINVAL - use the per-step entry points.  All workgroups of the launch
- * must be resident together (at most 256 of 256 threads): the calling stream must own the device.  Every wait in the kernel is
- * bounded; mg_gru_persist_status(workspace, stream) synchronises the stream and returns MG_ELAUNCH if a wait timed out. */
+ * must be resident together (at most 256 of 256 threads): the calling stream must own the device.  The workspace (16-byte
+ * aligned, zeroed ONCE by the caller after allocating it) may be reused by later launches on the same stream: each launch resets
+ * the flags itself, the status word behind them is sticky.  Every wait in the kernel is bounded;
+ * mg_gru_persist_status(workspace, stream) synchronises the stream, returns MG_ELAUNCH if any launch since the last call timed
+ * out (its results are invalid) and clears the word. */
 size_t mg_gru_persist_workspace_bytes(void);
 int mg_gru_persist_supported(int B, int T, int H);
-int mg_gru_persist_status(const void* workspace, void* stream);
+int mg_gru_persist_status(void* workspace, void* stream);
 int mg_gru_fwd_persist_bf16(const float* xproj, const uint16_t* w_hh_bf, int ldw, const float* b_hh, const int64_t* seq_len, int B,
                             int T, int H, float* hstate, uint16_t* hstate_bf, float* out, float* saved, void* workspace,
                             size_t workspace_bytes, void* stream);
+int mg_gru_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const float* hstate, const float* saved,
+                            const uint16_t* w_hh_t_bf, int ldt, const int64_t* seq_len, int B, int T, int H, float* dxproj,
+                            float* dhproj, uint16_t* dhproj_bf, float* dh0, void* workspace, size_t workspace_bytes, void* stream);
 
 /* LSTM through RecurrentCuDNNWrapper   reference: morgana/utils.py:345-393 + torch.nn.LSTM (gates i, f, g, o), the cell of
  * the reference's shipped acoustic model (models/RNN_SPSS.py:36-37).  Same conventions as the GRU entry points:

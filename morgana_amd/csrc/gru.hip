@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void gru_bwd_step_bf16_kernel(const float* __r
     __syncthreads();
     if (b < B && j < H) {
         const int e = bl * GT + jl;
-        const float dstate = cin + ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e]));
+        const float dstate = mg_gru_dstate(cin, red[0][e], red[1][e], red[2][e], red[3][e]);
         if (t < 0) {
             dh0[(size_t)b * H + j] = dstate;
             return;
@@ -371,13 +371,8 @@ __global__ __launch_bounds__(256) void gru_bwd_step_bf16_kernel(const float* __r
         const bool active = seq_len ? ((int64_t)t < seq_len[b]) : true;
         float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, c = dstate;
         if (active) {
-            const float r = s_r, z = s_z, n = s_n, hn = s_hn;
-            const float dh = dstate + gout;
-            dn = dh * (1.f - z) * (1.f - n * n);
-            dz = dh * (hprev - n) * z * (1.f - z);
-            dr = dn * hn * r * (1.f - r);
-            dnr = dn * r;
-            c = dh * z;
+            const mg_gru_cell_grad g = mg_gru_cell_bwd(dstate, gout, s_r, s_z, s_n, s_hn, hprev);
+            dr = g.dr; dz = g.dz; dn = g.dn; dnr = g.dnr; c = g.carry;
         }
         float* dx = dxproj + row * G;
         float* dhp = dhproj + row * G;

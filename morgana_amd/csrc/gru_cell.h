@@ -25,3 +25,26 @@ __device__ __forceinline__ float mg_gru_sum4(float a, float b, float c, float d,
 #pragma clang fp contract(off)
     return ((a + b) + (c + d)) + bias;
 }
+
+struct mg_gru_cell_grad {
+    float dr, dz, dn, dnr, carry;
+};
+
+// dstate = carry-in + the 4 waves' partial sums of dhproj_{t+1} W_hh, in a fixed order
+__device__ __forceinline__ float mg_gru_dstate(float carry_in, float a, float b, float c, float d) {
+#pragma clang fp contract(off)
+    return carry_in + ((a + b) + (c + d));
+}
+
+// gradient of one active GRU step: dstate = d loss / d h_t from the later steps, gout = d loss / d output_t
+__device__ __forceinline__ mg_gru_cell_grad mg_gru_cell_bwd(float dstate, float gout, float r, float z, float n, float hn, float hprev) {
+#pragma clang fp contract(off)
+    mg_gru_cell_grad g;
+    const float dh = dstate + gout;
+    g.dn = dh * (1.f - z) * (1.f - n * n);
+    g.dz = dh * (hprev - n) * z * (1.f - z);
+    g.dr = g.dn * hn * r * (1.f - r);
+    g.dnr = g.dn * r;
+    g.carry = dh * z;
+    return g;
+}

@@ -15,7 +15,7 @@
 // s_waitcnt vmcnt(0), then ONE lane stores the slot's flag (epoch = t + 1, sc1).  The consumer's wave 0 polls the group's flags
 // (one 4-byte sc1 load per lane, one lane per slot), joins a workgroup barrier, and every load of the state is a
 // buffer_load_dwordx4 sc1 to registers.  Flags are zeroed by a memset node ahead of every launch; every spin is bounded and a
-// time-out sets the status word (mg_gru_persist_status) and makes the workgroup return.
+// time-out sets the sticky status word behind the flags (mg_gru_persist_status) and makes the workgroup return.
 // fp32 copies of the state, the outputs and the saved gate values are plain stores (nobody reads them before the kernel ends;
 // a thread carries its own h_{t-1} element in a register).
 //
@@ -216,6 +216,160 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
     }
 }
 
+// Backward recurrence in one launch.  Slot s of a group owns d h[:, 16 s .. 16 s + 16): per step t (T-1 down to 0, then the
+// t = -1 pass that yields dh0) it needs dhproj_{t+1} of the whole group (R x 3H bf16: the hand-off, rows written by all
+// slots in the step before), contracts it with its 16 rows of W_hh^T (16 x 3H bf16 = 48 VGPRs per lane at H = 512, resident),
+// applies the gate derivatives and publishes its 3 x 16 columns of dhproj_t.  The carry (d loss / d h_{t-1} through the z
+// path) stays in a register of the thread that owns the element.  Epoch of row t = gmax - t (gmax = the group's longest
+// sequence): rows at or beyond gmax are all-zero, written without synchronising before the dependent steps start.
+template <int MT, int KS>
+__global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __restrict__ grad_out, const float* __restrict__ grad_hn,
+                                                              const float* __restrict__ hstate, const float* __restrict__ saved,
+                                                              const uint16_t* __restrict__ wt_bf, int ldt,
+                                                              const int64_t* __restrict__ seq_len, int B, int T, int H, int R,
+                                                              float* __restrict__ dxproj, float* __restrict__ dhproj,
+                                                              uint16_t* dhproj_bf, float* __restrict__ dh0, unsigned* sync) {
+    __shared__ float red[4][MT][GT * GT];
+    __shared__ __attribute__((aligned(16))) uint16_t pub[MT][GT][3][GT];
+    __shared__ int s_abort;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    const int group = blockIdx.x % GP_GROUPS, slot = blockIdx.x / GP_GROUPS;
+    const int n_slots = H / GT;
+    const int row0 = group * R;
+    const int nrows = min(R, B - row0);
+    if (slot >= n_slots || nrows <= 0) return;
+    const int j0 = slot * GT;
+    const int G = 3 * H;
+    gu32* flags = (gu32*)sync + group * GP_SLOTS;
+    gu32* status = (gu32*)sync + GP_GROUPS * GP_SLOTS;
+    if (tid == 0) s_abort = 0;
+
+    int gmax = 0;
+    for (int r = 0; r < nrows; ++r) {
+        const int64_t n = seq_len ? seq_len[row0 + r] : (int64_t)T;
+        gmax = max(gmax, (int)(n < T ? n : T));
+    }
+
+    // W_hh^T fragments: lane (li, q) holds row j0 + li, gate rows gbase + 32 i .. + 7
+    const int gbase = wave * (G / 4) + 8 * q;
+    gbf8 fb[KS];
+    {
+        const uint16_t* wp = wt_bf + (size_t)(j0 + li) * ldt + gbase;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) fb[i] = *reinterpret_cast<const gbf8*>(wp + 32 * i);
+    }
+    const auto rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)dhproj_bf, 0, (int)((size_t)B * T * G * 2), 0x00020000);
+
+    const int bl = tid >> 4, jl = tid & 15;
+    const int j = j0 + jl;
+    float carry[MT];
+    int len[MT];
+    bool mine[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        mine[m] = 16 * m + bl < nrows;
+        const int b = row0 + (mine[m] ? 16 * m + bl : 0);
+        carry[m] = grad_hn ? grad_hn[(size_t)b * H + j] : 0.f;
+        len[m] = seq_len ? (int)min((int64_t)T, seq_len[b]) : T;
+    }
+    // rows beyond the group's longest sequence: zero gradients, carry untouched, nothing to wait for
+    for (int t = T - 1; t >= gmax; --t) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            if (mine[m]) {
+                const size_t row = (size_t)(row0 + 16 * m + bl) * T + t;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    dxproj[row * G + g * H + j] = 0.f;
+                    dhproj[row * G + g * H + j] = 0.f;
+                    dhproj_bf[row * G + g * H + j] = 0;
+                }
+            }
+    }
+    __syncthreads();
+
+    for (int t = gmax - 1; t >= -1; --t) {
+        const int tt = t >= 0 ? t : 0;
+        // operands of the cell that do not depend on the hand-off
+        float s_r[MT], s_z[MT], s_n[MT], s_hn[MT], hprev[MT], gout[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int b = row0 + (mine[m] ? 16 * m + bl : 0);
+            const size_t row = (size_t)b * T + tt;
+            const float* sv = saved + row * 4 * H;
+            s_r[m] = sv[j];
+            s_z[m] = sv[H + j];
+            s_n[m] = sv[2 * H + j];
+            s_hn[m] = sv[3 * H + j];
+            hprev[m] = hstate[((size_t)b * (T + 1) + tt) * H + j];
+            gout[m] = grad_out[row * H + j];
+        }
+        const bool need_mm = t + 1 < gmax;               // row t + 1 holds gradients of a live step
+        if (need_mm) {
+            if (wave == 0 && !gp_wait_flags(flags, n_slots, (unsigned)(gmax - t - 1), lane)) s_abort = 1;
+            __syncthreads();
+            if (s_abort) {
+                if (tid == 0) __hip_atomic_store(status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const bool valid = 16 * m + li < nrows;
+                const unsigned off = (unsigned)((((size_t)(row0 + (valid ? 16 * m + li : 0)) * T + t + 1) * G + gbase) * 2);
+                u32x4 raw[KS];
+#pragma unroll
+                for (int i = 0; i < KS; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_d, off + 64 * i, 0, 16);
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < KS; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(raw[i]), fb[i], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave][m][(4 * q + r) * GT + li] = acc[r];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int e = bl * GT + jl;
+            const float dstate = need_mm ? mg_gru_dstate(carry[m], red[0][m][e], red[1][m][e], red[2][m][e], red[3][m][e]) : carry[m];
+            if (t < 0) {
+                if (mine[m]) dh0[(size_t)(row0 + 16 * m + bl) * H + j] = dstate;
+                continue;
+            }
+            float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, c = dstate;
+            if (t < len[m]) {
+                const mg_gru_cell_grad g = mg_gru_cell_bwd(dstate, gout[m], s_r[m], s_z[m], s_n[m], s_hn[m], hprev[m]);
+                dr = g.dr; dz = g.dz; dn = g.dn; dnr = g.dnr; c = g.carry;
+            }
+            carry[m] = c;
+            pub[m][bl][0][jl] = mg_f2bf(dr);
+            pub[m][bl][1][jl] = mg_f2bf(dz);
+            pub[m][bl][2][jl] = mg_f2bf(dnr);
+            if (mine[m]) {
+                const size_t row = (size_t)(row0 + 16 * m + bl) * T + t;
+                float* dx = dxproj + row * G;
+                float* dhp = dhproj + row * G;
+                dx[j] = dr;  dx[H + j] = dz;  dx[2 * H + j] = dn;
+                dhp[j] = dr; dhp[H + j] = dz; dhp[2 * H + j] = dnr;
+            }
+        }
+        if (t < 0) break;
+        __syncthreads();
+        if (wave == 0) {
+            // publish dhproj_t[:, gate, 16 s .. 16 s + 16) for the 3 gates: 6 pieces of 16 bytes per item
+            for (int p = lane; p < 6 * nrows; p += 64) {
+                const int rrow = p / 6, piece = p - 6 * rrow, gate = piece >> 1, half = piece & 1;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(&pub[rrow >> 4][rrow & 15][gate][8 * half]);
+                const unsigned off = (unsigned)((((size_t)(row0 + rrow) * T + t) * G + gate * H + j0 + 8 * half) * 2);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_d, off, 0, 16);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(flags + slot, (unsigned)(gmax - t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 extern "C" {
 
 size_t mg_gru_persist_workspace_bytes(void) { return (size_t)GP_SYNC_WORDS * sizeof(unsigned); }
@@ -228,7 +382,7 @@ int mg_gru_persist_supported(int B, int T, int H) {
     return 1;
 }
 
-int mg_gru_persist_status(const void* workspace, void* stream) {
+int mg_gru_persist_status(void* workspace, void* stream) {
     unsigned st = 0;
     if (hipMemcpyAsync(&st, (const unsigned*)workspace + GP_GROUPS * GP_SLOTS, sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream) !=
             hipSuccess ||
@@ -237,6 +391,7 @@ int mg_gru_persist_status(const void* workspace, void* stream) {
         return MG_ELAUNCH;
     }
     if (st != 0) {
+        hipMemsetAsync((unsigned*)workspace + GP_GROUPS * GP_SLOTS, 0, 16, (hipStream_t)stream);     // sticky until reported
         mg_set_error("persistent GRU kernel timed out waiting for another workgroup (status %u): results are invalid", st);
         return MG_ELAUNCH;
     }
@@ -257,7 +412,7 @@ int mg_gru_fwd_persist_bf16(const float* xproj, const uint16_t* w_hh_bf, int ldw
         return MG_EWORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(workspace, 0, mg_gru_persist_workspace_bytes(), st) != hipSuccess) {
+    if (hipMemsetAsync(workspace, 0, (size_t)GP_GROUPS * GP_SLOTS * sizeof(unsigned), st) != hipSuccess) {
         mg_set_error("mg_gru_fwd_persist_bf16: memset failed");
         return MG_ELAUNCH;
     }
@@ -279,6 +434,45 @@ int mg_gru_fwd_persist_bf16(const float* xproj, const uint16_t* w_hh_bf, int ldw
         GP_FWD_KS(2)
     }
     MG_CHECK_LAUNCH("mg_gru_fwd_persist_bf16");
+    return MG_OK;
+}
+
+int mg_gru_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const float* hstate, const float* saved, const uint16_t* w_hh_t_bf,
+                            int ldt, const int64_t* seq_len, int B, int T, int H, float* dxproj, float* dhproj, uint16_t* dhproj_bf,
+                            float* dh0, void* workspace, size_t workspace_bytes, void* stream) {
+    MG_CHECK_ARG(grad_out && hstate && saved && w_hh_t_bf && dxproj && dhproj && dhproj_bf && dh0 && B > 0 && T > 0 && H > 0,
+                 "mg_gru_bwd_persist_bf16: bad arguments (B=%d T=%d H=%d)", B, T, H);
+    MG_CHECK_ARG(mg_gru_persist_supported(B, T, H) && ldt >= 3 * H && ldt % 8 == 0,
+                 "mg_gru_bwd_persist_bf16: unsupported shape (B=%d T=%d H=%d ldt=%d): needs H %% 128 == 0, H <= 512, B <= 256", B, T, H, ldt);
+    MG_CHECK_ARG((((uintptr_t)w_hh_t_bf | (uintptr_t)dhproj_bf | (uintptr_t)workspace) % 16) == 0,
+                 "mg_gru_bwd_persist_bf16: bf16 buffers and workspace must be 16-byte aligned");
+    if (!workspace || workspace_bytes < mg_gru_persist_workspace_bytes()) {
+        mg_set_error("mg_gru_bwd_persist_bf16: workspace of %zu bytes needed, got %zu", mg_gru_persist_workspace_bytes(), workspace_bytes);
+        return MG_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(workspace, 0, (size_t)GP_GROUPS * GP_SLOTS * sizeof(unsigned), st) != hipSuccess) {
+        mg_set_error("mg_gru_bwd_persist_bf16: memset failed");
+        return MG_ELAUNCH;
+    }
+    const int R = (int)mg_ceil_div(B, GP_GROUPS);
+    const unsigned grid = (unsigned)(GP_GROUPS * (H / GT));
+#define GP_BWD(MT, KS)                                                                                                                      \
+    hipLaunchKernelGGL((gru_bwd_persist_kernel<MT, KS>), dim3(grid), dim3(256), 0, st, grad_out, grad_hn, hstate, saved, w_hh_t_bf, ldt, seq_len, \
+                       B, T, H, R, dxproj, dhproj, dhproj_bf, dh0, (unsigned*)workspace)
+#define GP_BWD_KS(MT)                  \
+    switch (H / 128) {                 \
+        case 1: GP_BWD(MT, 3); break;  \
+        case 2: GP_BWD(MT, 6); break;  \
+        case 3: GP_BWD(MT, 9); break;  \
+        default: GP_BWD(MT, 12); break; \
+    }
+    if (R <= 16) {
+        GP_BWD_KS(1)
+    } else {
+        GP_BWD_KS(2)
+    }
+    MG_CHECK_LAUNCH("mg_gru_bwd_persist_bf16");
     return MG_OK;
 }
 

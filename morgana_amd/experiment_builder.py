@@ -16,6 +16,7 @@ import torch
 
 from . import functional as F_hip
 from . import lr_schedules
+from . import ops
 from . import utils
 from .optim import Adam
 
@@ -93,6 +94,7 @@ class ExperimentBuilder(object):
             with open(os.path.join(out_dir, 'metrics.json'), 'w') as f:          # :499-501
                 json.dump(self.model.metrics.results_as_json_dict('train'), f)
         self.model.mode = ''
+        ops.check_persistent_status()                                            # persistent recurrent kernels: any time-out?
         return float(loss.item()) / (i + 1)                                      # :505 (one sync per epoch)
 
     def run_train(self, train_loader):

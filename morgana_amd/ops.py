@@ -454,7 +454,7 @@ def gru_bf16_ok(h):
     return h % 128 == 0 and h <= 1024
 
 
-_PERSIST_WORKSPACES = []          # sync blocks of persistent launches whose status word has not been read yet
+_PERSIST_WORKSPACES = {}          # (device, stream) -> sync block shared by the persistent launches of that stream
 PERSISTENT_RECURRENCE = os.environ.get('MORGANA_PERSISTENT', '1') != '0'
 
 
@@ -463,22 +463,20 @@ def gru_persist_ok(b, t, h):
 
 
 def _persist_workspace(dev):
-    nbytes = _lib.load().mg_gru_persist_workspace_bytes()
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    _PERSIST_WORKSPACES.append(ws)
-    if len(_PERSIST_WORKSPACES) > 64:
-        check_persistent_status()
+    key = (dev, torch.cuda.current_stream().cuda_stream)
+    ws = _PERSIST_WORKSPACES.get(key)
+    if ws is None:
+        ws = torch.zeros(_lib.load().mg_gru_persist_workspace_bytes(), dtype=torch.uint8, device=dev)
+        _PERSIST_WORKSPACES[key] = ws
     return ws
 
 
 def check_persistent_status():
-    """Synchronise and raise if a persistent recurrent kernel gave up waiting for a peer workgroup (its results are invalid).
-    Called by the training loop once per step (ExperimentBuilder), by bench.py and by the tests."""
+    """Synchronise and raise if a persistent recurrent kernel launched since the last call gave up waiting for a peer workgroup
+    (its results are invalid).  Called once per epoch by ExperimentBuilder, by bench.py, smoke() and the GPU tests."""
     lib = _lib.load()
-    pending = list(_PERSIST_WORKSPACES)
-    del _PERSIST_WORKSPACES[:]
-    for ws in pending:
-        _lib.check(lib.mg_gru_persist_status(_p(ws), _stream()), 'mg_gru_persist_status')
+    for (dev, stream), ws in list(_PERSIST_WORKSPACES.items()):
+        _lib.check(lib.mg_gru_persist_status(_p(ws), ctypes.c_void_p(stream)), 'mg_gru_persist_status')
 
 
 def gru_fwd_bf16(xproj, w_hh, b_hh, seq_len, h0, b, t, h, persistent=None):
@@ -510,15 +508,23 @@ def gru_fwd_bf16(xproj, w_hh, b_hh, seq_len, h0, b, t, h, persistent=None):
     return out, hstate, saved, hstate_bf
 
 
-def gru_bwd_bf16(grad_out, grad_hn, hstate, saved, w_hh, seq_len, b, t, h):
+def gru_bwd_bf16(grad_out, grad_hn, hstate, saved, w_hh, seq_len, b, t, h, persistent=None):
     """gru_bwd with bf16 matmul operands.  Returns (dxproj, dhproj, dh0, dhproj_bf (b,t,3h) bf16)."""
     lib = _lib.load()
+    if persistent is None:
+        persistent = gru_persist_ok(b, t, h)
     dev = grad_out.device
     dxproj = torch.empty((b, t, 3 * h), dtype=torch.float32, device=dev)
     dhproj = torch.empty((b, t, 3 * h), dtype=torch.float32, device=dev)
     dhproj_bf = torch.empty((b, t, 3 * h), dtype=torch.bfloat16, device=dev)
     dh0 = torch.empty((b, h), dtype=torch.float32, device=dev)
     wt_bf = cast_transpose_bf16(w_hh)                              # (h, 3h)
+    if persistent:
+        ws = _persist_workspace(dev)
+        _lib.check(lib.mg_gru_bwd_persist_bf16(_p(grad_out), _p(grad_hn), _p(hstate), _p(saved), _p(wt_bf), wt_bf.shape[1], _p(seq_len),
+                                               b, t, h, _p(dxproj), _p(dhproj), _p(dhproj_bf), _p(dh0), _p(ws), ws.numel(), _stream()),
+                   'mg_gru_bwd_persist_bf16')
+        return dxproj, dhproj, dh0, dhproj_bf
     nbytes = lib.mg_gru_bwd_workspace_bytes(b, h)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     _lib.check(lib.mg_gru_bwd_bf16(_p(grad_out), _p(grad_hn), _p(hstate), _p(saved), _p(wt_bf), wt_bf.shape[1], _p(seq_len), b, t, h,

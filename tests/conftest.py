@@ -22,3 +22,12 @@ def load_golden(name):
 @pytest.fixture(scope='session')
 def golden():
     return load_golden
+
+
+@pytest.fixture(autouse=True)
+def _persistent_kernels_completed(request):
+    """After every GPU test: fail it if a persistent recurrent kernel gave up waiting for a peer workgroup."""
+    yield
+    if request.node.get_closest_marker('gpu') is not None:
+        from morgana_amd import ops
+        ops.check_persistent_status()

@@ -697,7 +697,7 @@ def test_gru_bf16_recurrence_vs_fp32(b, t, hid):
     sl = dev(sl_np)
     assert ops.gru_bf16_ok(hid)
     out32, hs32, sv32 = ops.gru_fwd(xproj, w_hh, b_hh, sl, h0, b, t, hid)
-    out16, hs16, sv16, hs_bf = ops.gru_fwd_bf16(xproj, w_hh, b_hh, sl, h0, b, t, hid)
+    out16, hs16, sv16, hs_bf = ops.gru_fwd_bf16(xproj, w_hh, b_hh, sl, h0, b, t, hid, persistent=False)
     assert rel_err(out16.cpu().numpy(), out32.cpu().numpy()) < 1e-2
     assert rel_err(hs16.cpu().numpy(), hs32.cpu().numpy()) < 1e-2
     assert rel_err(sv16.cpu().numpy(), sv32.cpu().numpy()) < 1e-2
@@ -709,13 +709,13 @@ def test_gru_bf16_recurrence_vs_fp32(b, t, hid):
     g_hn = dev(rng.standard_normal((b, hid)).astype(np.float32))
     # same saved tensors for both, so that only the backward recurrence differs
     dx32, dh32, d032 = ops.gru_bwd(g_out, g_hn, hs32, sv32, w_hh, sl, b, t, hid)
-    dx16, dh16, d016, dh_bf = ops.gru_bwd_bf16(g_out, g_hn, hs32, sv32, w_hh, sl, b, t, hid)
+    dx16, dh16, d016, dh_bf = ops.gru_bwd_bf16(g_out, g_hn, hs32, sv32, w_hh, sl, b, t, hid, persistent=False)
     assert rel_err(dx16.cpu().numpy(), dx32.cpu().numpy()) < 1e-2
     assert rel_err(dh16.cpu().numpy(), dh32.cpu().numpy()) < 1e-2
     assert rel_err(d016.cpu().numpy(), d032.cpu().numpy()) < 1e-2
     assert torch.equal(dh_bf, dh16.to(torch.bfloat16))
     # deterministic
-    again = ops.gru_bwd_bf16(g_out, g_hn, hs32, sv32, w_hh, sl, b, t, hid)
+    again = ops.gru_bwd_bf16(g_out, g_hn, hs32, sv32, w_hh, sl, b, t, hid, persistent=False)
     assert torch.equal(again[0], dx16) and torch.equal(again[2], d016)
 
 
@@ -746,6 +746,16 @@ def test_gru_persistent_equals_stepwise(b, t, hid):
                     live = (np.arange(t)[None, :] < sl_np[:, None])[:, :, None]
                     g, w = g * live, w * live
                 np.testing.assert_array_equal(g, w, err_msg='%s rep %d' % (name, rep))
+        g_out = dev(rng.standard_normal((b, t, hid)).astype(np.float32))
+        g_hn = dev(rng.standard_normal((b, hid)).astype(np.float32))
+        out, hstate, saved, _ = want
+        for grad_hn in (g_hn, None):
+            want_b = ops.gru_bwd_bf16(g_out, grad_hn, hstate, saved, w_hh, sl, b, t, hid, persistent=False)
+            for rep in range(3):
+                got_b = ops.gru_bwd_bf16(g_out, grad_hn, hstate, saved, w_hh, sl, b, t, hid, persistent=True)
+                ops.check_persistent_status()
+                for name, g, w in zip(('dxproj', 'dhproj', 'dh0', 'dhproj_bf'), got_b, want_b):
+                    np.testing.assert_array_equal(g.float().cpu().numpy(), w.float().cpu().numpy(), err_msg='%s rep %d' % (name, rep))
 
 
 def test_gru_bf16_recurrence_rejects_bad_sizes():
