@@ -43,6 +43,8 @@ const char* mg_last_error(void);
  * (6: per-tile instead of persistent NT kernel, 7: single-buffered instead of pipelined fused backward). */
 #define MG_TUNING_KEYS 8
 #define MG_TUNE_STAGGER 0
+#define MG_TUNE_GRU_HANDOFF 2   /* persistent GRU kernels: 0 = groups found on one XCD hand the state over through that XCD's L2,
+                                 * 1 = always write-through (sc1) stores, the placement-independent form */
 #define MG_TUNE_SKIP_REDUCE 1   /* != 0: weight-gradient entry points launch their GEMM kernel only, not the slab reduce that
                                  * finishes dW / db (results are then NOT valid) - lets bench.py time the kernel alone */
 int mg_set_tuning(int key, int value);

@@ -29,7 +29,8 @@
 #define GP_SLOTS 32                          // flag words per group (H <= 512)
 #define GP_KSTEPS 4                          // H / 128 MFMA k-steps per wave, H <= 512
 #define GP_SPIN_LIMIT (1u << 20)
-#define GP_SYNC_WORDS (GP_GROUPS * GP_SLOTS + 4)   // flags + {status, 3 pad}: 1040 bytes, a multiple of 16
+#define GP_FLAG_WORDS (2 * GP_GROUPS * GP_SLOTS)   // per launch (zeroed by a memset node): step flags [8][32], XCC ids [8][32]
+#define GP_SYNC_WORDS (GP_FLAG_WORDS + 4)          // + {sticky status, 3 pad}: 2064 bytes, a multiple of 16
 
 typedef __bf16 gbf8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -39,6 +40,15 @@ __device__ __forceinline__ gbf8 as_bf8(u32x4 v) {
     union { u32x4 u; gbf8 b; } c;
     c.u = v;
     return c.b;
+}
+
+// the slot's flag: written through (sc1) in general; within one XCD a store that stays in the shared L2 (workgroup scope = no
+// sc1 bit; the pollers' sc1 loads are L2-served)
+__device__ __forceinline__ void gp_store_flag(gu32* flag, unsigned epoch, int one_xcd) {
+    if (one_xcd)
+        __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else
+        __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // wave 0: wait until every slot's flag of the group has reached `epoch`.  Returns false after GP_SPIN_LIMIT polls.
@@ -51,15 +61,43 @@ __device__ __forceinline__ bool gp_wait_flags(gu32* flags, int n_slots, unsigned
     }
 }
 
+MG_STAMP_DECL(g_stamps_gp);
+
+// Where the group runs.  Every workgroup publishes the id of the XCD it is on (s_getreg HW_REG_XCC_ID) and reads the ids of the
+// group's other slots - once per launch, with the placement-independent sc1 protocol.  If they are all equal, the whole group
+// shares one L2: the hand-off stores may then stay plain (the line stays in that L2, where the readers' sc1 loads - which only
+// bypass their own CU's L1 - find it) instead of being written through to memory and fetched back over the fabric.  The
+// block -> XCD map itself is never assumed: a group spread over several XCDs keeps the write-through form.
+// Returns 1 = one XCD, 0 = several, -1 = timed out.
+__device__ __forceinline__ int gp_group_on_one_xcd(gu32* xcc_tab, int slot, int n_slots, int tid, int* s_word) {
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(id));
+    if (tid == 0) __hip_atomic_store(xcc_tab + slot, id + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 64) {
+        int result = -1;
+        for (unsigned spins = 0; spins <= GP_SPIN_LIMIT; ++spins) {
+            const unsigned v = tid < n_slots ? __hip_atomic_load(xcc_tab + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : id + 1u;
+            if (__all(v != 0u)) {
+                result = __all(v == id + 1u) ? 1 : 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (tid == 0) *s_word = result;
+    }
+    __syncthreads();
+    return *s_word;
+}
+
 template <int MT, int KS>
 __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __restrict__ xproj, const uint16_t* __restrict__ w_bf, int ldw,
                                                               const float* __restrict__ b_hh, const int64_t* __restrict__ seq_len,
                                                               int B, int T, int H, int R, float* __restrict__ hstate,
                                                               uint16_t* hstate_bf, float* __restrict__ out,
-                                                              float* __restrict__ saved, unsigned* sync) {
+                                                              float* __restrict__ saved, unsigned* sync, int force_sc1) {
     __shared__ float red[4][3][MT][GT * GT];
     __shared__ __attribute__((aligned(16))) uint16_t hb[MT][GT][GT];
-    __shared__ int s_abort;
+    __shared__ int s_abort, s_xcd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
     const int group = blockIdx.x % GP_GROUPS, slot = blockIdx.x / GP_GROUPS;
@@ -69,8 +107,13 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
     if (slot >= n_slots || nrows <= 0) return;
     const int j0 = slot * GT;
     gu32* flags = (gu32*)sync + group * GP_SLOTS;
-    gu32* status = (gu32*)sync + GP_GROUPS * GP_SLOTS;
+    gu32* status = (gu32*)sync + GP_FLAG_WORDS;
     if (tid == 0) s_abort = 0;
+    const int one_xcd = force_sc1 ? 0 : gp_group_on_one_xcd((gu32*)sync + GP_GROUPS * GP_SLOTS + group * GP_SLOTS, slot, n_slots, tid, &s_xcd);
+    if (one_xcd < 0) {
+        if (tid == 0) __hip_atomic_store(status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
 
     // longest sequence of the group
     int gmax = 0;
@@ -111,7 +154,13 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
     }
     __syncthreads();
 
+#ifdef MG_STAMPS
+    unsigned long long ta = 0, tb = 0, ts0 = 0, ts1 = 0, tr0 = 0, tr1 = 0, sum_poll = 0, sum_load = 0, sum_mm = 0, sum_cell = 0, sum_pub = 0;
+    MG_STAMP(ts0);
+    MG_STAMP_REAL(tr0);
+#endif
     for (int t = 0; t < gmax; ++t) {
+        MG_STAMP(ta);
         // this step's input projections: independent of the hand-off, requested ahead of the poll
         float xr[MT], xz[MT], xn[MT];
 #pragma unroll
@@ -130,6 +179,8 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
                 return;
             }
         }
+        MG_STAMP(tb);
+        MG_STAMP_ADD(sum_poll, tb, ta);
         // h_{t-1} of the group: bf16, sc1 loads only
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -139,6 +190,11 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
 #pragma unroll
             for (int i = 0; i < KS; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_h, off + 64 * i, 0, 16);
             __builtin_amdgcn_sched_barrier(0);          // all KS loads in flight before the first MFMA waits (one round trip)
+#ifdef MG_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            MG_STAMP(ta);
+            MG_STAMP_ADD(sum_load, ta, tb);
+#endif
             f32x4 acc_r = {0.f, 0.f, 0.f, 0.f}, acc_z = acc_r, acc_n = acc_r;
 #pragma unroll
             for (int i = 0; i < KS; ++i) {
@@ -156,6 +212,8 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
             }
         }
         __syncthreads();
+        MG_STAMP(tb);
+        MG_STAMP_ADD(sum_mm, tb, ta);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int e = bl * GT + jl;
@@ -181,6 +239,8 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
             }
         }
         __syncthreads();
+        MG_STAMP(ta);
+        MG_STAMP_ADD(sum_cell, ta, tb);
         if (wave == 0) {
             // publish the slot's 16 columns of h_t: 32 bytes per item = two 16-byte sc1 stores
             auto rs_w = rs_h;
@@ -189,13 +249,32 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
                 if (rrow < nrows) {
                     const u32x4 v = *reinterpret_cast<const u32x4*>(&hb[rrow >> 4][rrow & 15][8 * half]);
                     const unsigned off = (unsigned)((((size_t)(row0 + rrow) * (T + 1) + t + 1) * H + j0 + 8 * half) * 2);
-                    __builtin_amdgcn_raw_buffer_store_b128(v, rs_w, off, 0, 16);
+                    if (one_xcd)
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_w, off, 0, 0);      // stays in the group's L2
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_w, off, 0, 16);     // sc1: written through
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(flags + slot, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) gp_store_flag(flags + slot, (unsigned)(t + 1), one_xcd);
         }
+        MG_STAMP(tb);
+        MG_STAMP_ADD(sum_pub, tb, ta);
     }
+#ifdef MG_STAMPS
+    MG_STAMP(ts1);
+    MG_STAMP_REAL(tr1);
+    MG_STAMP_STORE(g_stamps_gp, blockIdx.x, wave, lane, 0, ts0);
+    MG_STAMP_STORE(g_stamps_gp, blockIdx.x, wave, lane, 1, ts1);
+    MG_STAMP_STORE(g_stamps_gp, blockIdx.x, wave, lane, 2, tr0);
+    MG_STAMP_STORE(g_stamps_gp, blockIdx.x, wave, lane, 3, tr1);
+    MG_STAMP_STORE(g_stamps_gp, blockIdx.x, wave, lane, 4, sum_poll);
+    MG_STAMP_STORE(g_stamps_gp, blockIdx.x, wave, lane, 5, sum_load);
+    MG_STAMP_STORE(g_stamps_gp, blockIdx.x, wave, lane, 6, sum_mm);
+    MG_STAMP_STORE(g_stamps_gp, blockIdx.x, wave, lane, 7, sum_cell);
+    MG_STAMP_STORE(g_stamps_gp, blockIdx.x, wave, lane, 8, sum_pub);
+    MG_STAMP_STORE(g_stamps_gp, blockIdx.x, wave, lane, 9, (unsigned long long)gmax);
+#endif
     // beyond the group's longest sequence: state frozen, outputs zero - no matmul, no hand-off
     for (int t = gmax; t < T; ++t) {
 #pragma unroll
@@ -228,10 +307,10 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
                                                               const uint16_t* __restrict__ wt_bf, int ldt,
                                                               const int64_t* __restrict__ seq_len, int B, int T, int H, int R,
                                                               float* __restrict__ dxproj, float* __restrict__ dhproj,
-                                                              uint16_t* dhproj_bf, float* __restrict__ dh0, unsigned* sync) {
+                                                              uint16_t* dhproj_bf, float* __restrict__ dh0, unsigned* sync, int force_sc1) {
     __shared__ float red[4][MT][GT * GT];
     __shared__ __attribute__((aligned(16))) uint16_t pub[MT][GT][3][GT];
-    __shared__ int s_abort;
+    __shared__ int s_abort, s_xcd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
     const int group = blockIdx.x % GP_GROUPS, slot = blockIdx.x / GP_GROUPS;
@@ -242,8 +321,13 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
     const int j0 = slot * GT;
     const int G = 3 * H;
     gu32* flags = (gu32*)sync + group * GP_SLOTS;
-    gu32* status = (gu32*)sync + GP_GROUPS * GP_SLOTS;
+    gu32* status = (gu32*)sync + GP_FLAG_WORDS;
     if (tid == 0) s_abort = 0;
+    const int one_xcd = force_sc1 ? 0 : gp_group_on_one_xcd((gu32*)sync + GP_GROUPS * GP_SLOTS + group * GP_SLOTS, slot, n_slots, tid, &s_xcd);
+    if (one_xcd < 0) {
+        if (tid == 0) __hip_atomic_store(status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
 
     int gmax = 0;
     for (int r = 0; r < nrows; ++r) {
@@ -362,16 +446,20 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
                 const int rrow = p / 6, piece = p - 6 * rrow, gate = piece >> 1, half = piece & 1;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(&pub[rrow >> 4][rrow & 15][gate][8 * half]);
                 const unsigned off = (unsigned)((((size_t)(row0 + rrow) * T + t) * G + gate * H + j0 + 8 * half) * 2);
-                __builtin_amdgcn_raw_buffer_store_b128(v, rs_d, off, 0, 16);
+                if (one_xcd)
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rs_d, off, 0, 0);
+                else
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rs_d, off, 0, 16);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(flags + slot, (unsigned)(gmax - t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) gp_store_flag(flags + slot, (unsigned)(gmax - t), one_xcd);
         }
     }
 }
 
 extern "C" {
 
+// workspace: [step flags 8 x 32 words | XCC ids 8 x 32 words | status word + 3 pad]
 size_t mg_gru_persist_workspace_bytes(void) { return (size_t)GP_SYNC_WORDS * sizeof(unsigned); }
 
 int mg_gru_persist_supported(int B, int T, int H) {
@@ -384,14 +472,14 @@ int mg_gru_persist_supported(int B, int T, int H) {
 
 int mg_gru_persist_status(void* workspace, void* stream) {
     unsigned st = 0;
-    if (hipMemcpyAsync(&st, (const unsigned*)workspace + GP_GROUPS * GP_SLOTS, sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream) !=
+    if (hipMemcpyAsync(&st, (const unsigned*)workspace + GP_FLAG_WORDS, sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream) !=
             hipSuccess ||
         hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
         mg_set_error("mg_gru_persist_status: could not read the status word");
         return MG_ELAUNCH;
     }
     if (st != 0) {
-        hipMemsetAsync((unsigned*)workspace + GP_GROUPS * GP_SLOTS, 0, 16, (hipStream_t)stream);     // sticky until reported
+        hipMemsetAsync((unsigned*)workspace + GP_FLAG_WORDS, 0, 16, (hipStream_t)stream);     // sticky until reported
         mg_set_error("persistent GRU kernel timed out waiting for another workgroup (status %u): results are invalid", st);
         return MG_ELAUNCH;
     }
@@ -412,7 +500,7 @@ int mg_gru_fwd_persist_bf16(const float* xproj, const uint16_t* w_hh_bf, int ldw
         return MG_EWORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(workspace, 0, (size_t)GP_GROUPS * GP_SLOTS * sizeof(unsigned), st) != hipSuccess) {
+    if (hipMemsetAsync(workspace, 0, (size_t)GP_FLAG_WORDS * sizeof(unsigned), st) != hipSuccess) {
         mg_set_error("mg_gru_fwd_persist_bf16: memset failed");
         return MG_ELAUNCH;
     }
@@ -420,7 +508,7 @@ int mg_gru_fwd_persist_bf16(const float* xproj, const uint16_t* w_hh_bf, int ldw
     const unsigned grid = (unsigned)(GP_GROUPS * (H / GT));
 #define GP_FWD(MT, KS)                                                                                                                  \
     hipLaunchKernelGGL((gru_fwd_persist_kernel<MT, KS>), dim3(grid), dim3(256), 0, st, xproj, w_hh_bf, ldw, b_hh, seq_len, B, T, H, R, hstate, \
-                       hstate_bf, out, saved, (unsigned*)workspace)
+                       hstate_bf, out, saved, (unsigned*)workspace, g_mg_tuning[MG_TUNE_GRU_HANDOFF] == 1)
 #define GP_FWD_KS(MT)            \
     switch (H / 128) {           \
         case 1: GP_FWD(MT, 1); break; \
@@ -451,7 +539,7 @@ int mg_gru_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const f
         return MG_EWORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(workspace, 0, (size_t)GP_GROUPS * GP_SLOTS * sizeof(unsigned), st) != hipSuccess) {
+    if (hipMemsetAsync(workspace, 0, (size_t)GP_FLAG_WORDS * sizeof(unsigned), st) != hipSuccess) {
         mg_set_error("mg_gru_bwd_persist_bf16: memset failed");
         return MG_ELAUNCH;
     }
@@ -459,7 +547,7 @@ int mg_gru_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const f
     const unsigned grid = (unsigned)(GP_GROUPS * (H / GT));
 #define GP_BWD(MT, KS)                                                                                                                      \
     hipLaunchKernelGGL((gru_bwd_persist_kernel<MT, KS>), dim3(grid), dim3(256), 0, st, grad_out, grad_hn, hstate, saved, w_hh_t_bf, ldt, seq_len, \
-                       B, T, H, R, dxproj, dhproj, dhproj_bf, dh0, (unsigned*)workspace)
+                       B, T, H, R, dxproj, dhproj, dhproj_bf, dh0, (unsigned*)workspace, g_mg_tuning[MG_TUNE_GRU_HANDOFF] == 1)
 #define GP_BWD_KS(MT)                  \
     switch (H / 128) {                 \
         case 1: GP_BWD(MT, 3); break;  \
@@ -477,3 +565,9 @@ int mg_gru_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const f
 }
 
 }  // extern "C"
+
+#ifdef MG_STAMPS
+extern "C" int mg_diag_read_stamps_gp(void* dst, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps_gp), bytes < sizeof(g_stamps_gp) ? bytes : sizeof(g_stamps_gp), 0, hipMemcpyDeviceToHost);
+}
+#endif

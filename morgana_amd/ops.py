@@ -462,11 +462,14 @@ def gru_persist_ok(b, t, h):
     return PERSISTENT_RECURRENCE and bool(_lib.load().mg_gru_persist_supported(b, t, h))
 
 
-def _persist_workspace(dev):
+def _persist_workspace(dev, b, h):
     key = (dev, torch.cuda.current_stream().cuda_stream)
+    need = _lib.load().mg_gru_persist_workspace_bytes()
     ws = _PERSIST_WORKSPACES.get(key)
-    if ws is None:
-        ws = torch.zeros(_lib.load().mg_gru_persist_workspace_bytes(), dtype=torch.uint8, device=dev)
+    if ws is None or ws.numel() < need:
+        if ws is not None:
+            check_persistent_status()                 # read the old block's status word before dropping it
+        ws = torch.zeros(need, dtype=torch.uint8, device=dev)
         _PERSIST_WORKSPACES[key] = ws
     return ws
 
@@ -498,7 +501,7 @@ def gru_fwd_bf16(xproj, w_hh, b_hh, seq_len, h0, b, t, h, persistent=None):
     out = torch.empty((b, t, h), dtype=torch.float32, device=dev)
     saved = torch.empty((b, t, 4 * h), dtype=torch.float32, device=dev)
     if persistent:
-        ws = _persist_workspace(dev)
+        ws = _persist_workspace(dev, b, h)
         _lib.check(lib.mg_gru_fwd_persist_bf16(_p(xproj), _p(w_bf), w_bf.shape[1], _p(b_hh), _p(seq_len), b, t, h, _p(hstate),
                                                _p(hstate_bf), _p(out), _p(saved), _p(ws), ws.numel(), _stream()),
                    'mg_gru_fwd_persist_bf16')
@@ -520,7 +523,7 @@ def gru_bwd_bf16(grad_out, grad_hn, hstate, saved, w_hh, seq_len, b, t, h, persi
     dh0 = torch.empty((b, h), dtype=torch.float32, device=dev)
     wt_bf = cast_transpose_bf16(w_hh)                              # (h, 3h)
     if persistent:
-        ws = _persist_workspace(dev)
+        ws = _persist_workspace(dev, b, h)
         _lib.check(lib.mg_gru_bwd_persist_bf16(_p(grad_out), _p(grad_hn), _p(hstate), _p(saved), _p(wt_bf), wt_bf.shape[1], _p(seq_len),
                                                b, t, h, _p(dxproj), _p(dhproj), _p(dhproj_bf), _p(dh0), _p(ws), ws.numel(), _stream()),
                    'mg_gru_bwd_persist_bf16')

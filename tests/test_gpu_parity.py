@@ -719,8 +719,17 @@ def test_gru_bf16_recurrence_vs_fp32(b, t, hid):
     assert torch.equal(again[0], dx16) and torch.equal(again[2], d016)
 
 
+@pytest.fixture
+def gru_handoff(request):
+    from morgana_amd import _lib
+    _lib.load().mg_set_tuning(2, request.param)       # MG_TUNE_GRU_HANDOFF: 0 = through the XCD's L2 where verified, 1 = always sc1
+    yield request.param
+    _lib.load().mg_set_tuning(2, 0)
+
+
+@pytest.mark.parametrize('gru_handoff', [0, 1], indirect=True)
 @pytest.mark.parametrize('b,t,hid', [(64, 60, 512), (5, 37, 128), (33, 20, 256), (200, 9, 128), (130, 25, 384)])
-def test_gru_persistent_equals_stepwise(b, t, hid):
+def test_gru_persistent_equals_stepwise(b, t, hid, gru_handoff):
     """The one-launch recurrence (gru_persist.hip: W_hh in registers, state handed between workgroups with write-through
     stores and flags) against the launch-per-step kernels on the same inputs: same operands, same summation order and the
     same cell code (csrc/gru_cell.h, contraction pinned), so the results must be EQUAL; steps beyond a group's longest sequence
