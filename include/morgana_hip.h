@@ -266,15 +266,15 @@ int mg_gru_bwd_bf16(const float* grad_out, const float* grad_hn, const float* hs
 
 /* The bf16-operand recurrence as ONE launch per direction (persistent kernel: W_hh in registers for all T steps, the state
  * handed between workgroups through write-through stores and per-slot flags; the batch is cut into 8 independent groups).
- * Same arguments and results as mg_gru_fwd_bf16 / mg_gru_bwd_bf16 plus a workspace of mg_gru_persist_workspace_bytes() holding the
- * flags and a status word.  mg_gru_persist_supported(B, T, H) != 0 says the shape is covered (H % 128 == 0, H <= 512,
+ * Same arguments and results as mg_gru_fwd_bf16 / mg_gru_bwd_bf16 plus a workspace of mg_gru_persist_workspace_bytes(B, H) holding the
+ * hand-off ring, the flags and a status word.  mg_gru_persist_supported(B, T, H) != 0 says the shape is covered (H % 128 == 0, H <= 512,
  * B <= 256, buffers < 2 GiB); other shapes return MG_EINVAL - use the per-step entry points.  All workgroups of the launch
  * must be resident together (at most 256 of 256 threads): the calling stream must own the device.  The workspace (16-byte
  * aligned, zeroed ONCE by the caller after allocating it) may be reused by later launches on the same stream: each launch resets
  * the flags itself, the status word behind them is sticky.  Every wait in the kernel is bounded;
  * mg_gru_persist_status(workspace, stream) synchronises the stream, returns MG_ELAUNCH if any launch since the last call timed
  * out (its results are invalid) and clears the word. */
-size_t mg_gru_persist_workspace_bytes(void);
+size_t mg_gru_persist_workspace_bytes(int B, int H);
 int mg_gru_persist_supported(int B, int T, int H);
 int mg_gru_persist_status(void* workspace, void* stream);
 int mg_gru_fwd_persist_bf16(const float* xproj, const uint16_t* w_hh_bf, int ldw, const float* b_hh, const int64_t* seq_len, int B,

@@ -71,7 +71,7 @@ SIGNATURES = {
                                 c_void_p, c_void_p]),
     'mg_gru_bwd_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    'mg_gru_persist_workspace_bytes': (c_size_t, []),
+    'mg_gru_persist_workspace_bytes': (c_size_t, [c_int, c_int]),
     'mg_gru_persist_supported': (c_int, [c_int, c_int, c_int]),
     'mg_gru_persist_status': (c_int, [c_void_p, c_void_p]),
     'mg_gru_fwd_persist_bf16': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,

@@ -1,7 +1,9 @@
 // The GRU cell arithmetic shared by the launch-per-step and the persistent bf16-operand kernels (gru.hip, gru_persist.hip), with
 // floating-point contraction pinned off so that both evaluate bit-identical expressions whatever code surrounds the call:
 // the persistent kernel's hand-off protocol is tested by exact equality against the per-step kernels.
-// Gate order and formulas: torch.nn.GRU as used by the reference (morgana/utils.py:345-393).
+// Gate order and formulas: torch.nn.GRU as used by the reference (morgana/utils.py:345-393).  Throughput (bf16) mode only: the
+// sigmoid / tanh are the v_exp_f32 + v_rcp_f32 forms (about 2e-7 absolute error, far below the bf16 operand rounding of this
+// mode); the fp32 parity kernels in gru.hip keep expf / tanhf.
 #pragma once
 
 #include "common.h"
@@ -13,9 +15,9 @@ struct mg_gru_cell_out {
 __device__ __forceinline__ mg_gru_cell_out mg_gru_cell(float xr, float xz, float xn, float hr, float hz, float hn, float hprev) {
 #pragma clang fp contract(off)
     mg_gru_cell_out o;
-    o.r = mg_sigmoid(xr + hr);
-    o.z = mg_sigmoid(xz + hz);
-    o.n = tanhf(xn + o.r * hn);
+    o.r = mg_sigmoid_fast(xr + hr);
+    o.z = mg_sigmoid_fast(xz + hz);
+    o.n = 2.f * mg_sigmoid_fast(2.f * (xn + o.r * hn)) - 1.f;      // tanh; saturates cleanly (exp2 -> inf -> rcp -> 0)
     o.hnew = (1.f - o.z) * o.n + o.z * hprev;
     return o;
 }

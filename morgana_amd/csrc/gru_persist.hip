@@ -93,8 +93,8 @@ template <int MT, int KS>
 __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __restrict__ xproj, const uint16_t* __restrict__ w_bf, int ldw,
                                                               const float* __restrict__ b_hh, const int64_t* __restrict__ seq_len,
                                                               int B, int T, int H, int R, float* __restrict__ hstate,
-                                                              uint16_t* hstate_bf, float* __restrict__ out,
-                                                              float* __restrict__ saved, unsigned* sync, int force_sc1) {
+                                                              uint16_t* __restrict__ hstate_bf, float* __restrict__ out,
+                                                              float* __restrict__ saved, unsigned* sync, uint16_t* ring, int force_sc1) {
     __shared__ float red[4][3][MT][GT * GT];
     __shared__ __attribute__((aligned(16))) uint16_t hb[MT][GT][GT];
     __shared__ int s_abort, s_xcd;
@@ -136,23 +136,63 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
             fn[i] = *reinterpret_cast<const gbf8*>(wn + kbase + 32 * i);
         }
     }
-    const auto rs_h = __builtin_amdgcn_make_buffer_rsrc((void*)hstate_bf, 0, (int)((size_t)B * (T + 1) * H * 2), 0x00020000);
+    // Hand-off ring: [2 (epoch parity)][8 groups][H / 16 slots][R items][16 units] bf16.  A slot's tile is contiguous (R x 32 bytes:
+    // whole 128-byte lines written by one store instruction), and the two parities are reused all launch long, so the lines stay
+    // resident in L2 - a state written to fresh addresses every step (the [B, T+1, H] shadow) costs an L2 line allocation per
+    // step and was read back 2.6x slower (1290 vs 490 cycles for the 4 loads of a lane).
+    const unsigned par_bytes = (unsigned)(GP_GROUPS * n_slots * R * 32);
+    const auto rs_ring = __builtin_amdgcn_make_buffer_rsrc((void*)ring, 0, (int)(2 * par_bytes), 0x00020000);
+    // reader: lane (li, q) of wave w, k-step i wants units kbase + 32 i .. + 7 = slot kbase / 16 + 2 i, half q & 1, of item li
+    const unsigned rd_base = (unsigned)(((group * n_slots + (kbase >> 4)) * R) * 32 + 16 * (q & 1));
+    const unsigned rd_kstep = (unsigned)(2 * R * 32);
+    const unsigned wr_base = (unsigned)(((group * n_slots + slot) * R) * 32);
 
     // cell role: thread (bl, jl) owns element (row0 + 16 m + bl, j0 + jl) in every step
     const int bl = tid >> 4, jl = tid & 15;
     const int j = j0 + jl;
     const float bhr = b_hh[j], bhz = b_hh[H + j], bhn = b_hh[2 * H + j];
-    float hprev[MT];
+    float hprev[MT], xr[MT], xz[MT], xn[MT];
     int len[MT];
     bool mine[MT];
+    const float* xp[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         mine[m] = 16 * m + bl < nrows;
         const int b = row0 + (mine[m] ? 16 * m + bl : 0);
         hprev[m] = hstate[((size_t)b * (T + 1)) * H + j];
         len[m] = seq_len ? (int)min((int64_t)T, seq_len[b]) : T;
+        hb[m][bl][jl] = mg_f2bf(hprev[m]);
+        xp[m] = xproj + (size_t)b * T * 3 * H + j;
+        xr[m] = xp[m][0];                        // input projections of step 0; step t + 1's are requested during step t
+        xz[m] = xp[m][H];
+        xn[m] = xp[m][2 * H];
     }
     __syncthreads();
+
+    // wave 0 publishes the tile in hb as epoch e (state h_e) into ring parity e & 1, then raises the slot's flag to e + 1;
+    // wave 1 writes the same tile to the bf16 shadow of the state (read by the weight-gradient GEMM after the launch)
+    auto publish = [&](int e) {
+        if (wave <= 1 && lane < 2 * 16 * MT) {
+            const int rrow = lane >> 1, half = lane & 1;
+            if (rrow < nrows) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(&hb[rrow >> 4][rrow & 15][8 * half]);
+                if (wave == 0) {
+                    const unsigned off = (e & 1) * par_bytes + wr_base + (unsigned)(rrow * 32 + half * 16);
+                    if (one_xcd)
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 0);      // stays in the group's L2
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 16);     // sc1: written through
+                } else if (e > 0) {
+                    *reinterpret_cast<u32x4*>(hstate_bf + ((size_t)(row0 + rrow) * (T + 1) + e) * H + j0 + 8 * half) = v;
+                }
+            }
+        }
+        if (wave == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) gp_store_flag(flags + slot, (unsigned)(e + 1), one_xcd);
+        }
+    };
+    publish(0);
 
 #ifdef MG_STAMPS
     unsigned long long ta = 0, tb = 0, ts0 = 0, ts1 = 0, tr0 = 0, tr1 = 0, sum_poll = 0, sum_load = 0, sum_mm = 0, sum_cell = 0, sum_pub = 0;
@@ -161,44 +201,45 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
 #endif
     for (int t = 0; t < gmax; ++t) {
         MG_STAMP(ta);
-        // this step's input projections: independent of the hand-off, requested ahead of the poll
-        float xr[MT], xz[MT], xn[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int b = row0 + (mine[m] ? 16 * m + bl : 0);
-            const float* xp = xproj + ((size_t)b * T + t) * 3 * H;
-            xr[m] = xp[j];
-            xz[m] = xp[H + j];
-            xn[m] = xp[2 * H + j];
-        }
-        if (t > 0) {
-            if (wave == 0 && !gp_wait_flags(flags, n_slots, (unsigned)t, lane)) s_abort = 1;
-            __syncthreads();
-            if (s_abort) {
-                if (tid == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return;
-            }
+        if (wave == 0 && !gp_wait_flags(flags, n_slots, (unsigned)(t + 1), lane)) s_abort = 1;
+        __syncthreads();
+        if (s_abort) {
+            if (tid == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
         }
         MG_STAMP(tb);
         MG_STAMP_ADD(sum_poll, tb, ta);
-        // h_{t-1} of the group: bf16, sc1 loads only
+        // h_t of the group: bf16, sc1 loads only; then the next step's input projections (first touch: HBM latency, hidden behind
+        // this step - vector memory returns in order, so they must not be queued AHEAD of the state loads or the flag poll)
+        u32x4 raw[MT][KS];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const bool valid = 16 * m + li < nrows;
-            const unsigned off = (unsigned)((((size_t)(row0 + (valid ? 16 * m + li : 0)) * (T + 1) + t) * H + kbase) * 2);
-            u32x4 raw[KS];
+            const unsigned off = (t & 1) * par_bytes + rd_base + (unsigned)((valid ? 16 * m + li : 0) * 32);
 #pragma unroll
-            for (int i = 0; i < KS; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_h, off + 64 * i, 0, 16);
-            __builtin_amdgcn_sched_barrier(0);          // all KS loads in flight before the first MFMA waits (one round trip)
+            for (int i = 0; i < KS; ++i) raw[m][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ring, off + i * rd_kstep, 0, 16);
+        }
+        float xr1[MT], xz1[MT], xn1[MT];
+        const int t1 = t + 1 < T ? t + 1 : t;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float* x1 = xp[m] + (size_t)t1 * 3 * H;
+            xr1[m] = x1[0];
+            xz1[m] = x1[H];
+            xn1[m] = x1[2 * H];
+        }
+        __builtin_amdgcn_sched_barrier(0);          // every load in flight before the first MFMA waits (one round trip)
 #ifdef MG_STAMPS
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            MG_STAMP(ta);
-            MG_STAMP_ADD(sum_load, ta, tb);
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        MG_STAMP(ta);
+        MG_STAMP_ADD(sum_load, ta, tb);
 #endif
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
             f32x4 acc_r = {0.f, 0.f, 0.f, 0.f}, acc_z = acc_r, acc_n = acc_r;
 #pragma unroll
             for (int i = 0; i < KS; ++i) {
-                const gbf8 a = as_bf8(raw[i]);
+                const gbf8 a = as_bf8(raw[m][i]);
                 acc_r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, fr[i], acc_r, 0, 0, 0);
                 acc_z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, fz[i], acc_z, 0, 0, 0);
                 acc_n = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, fn[i], acc_n, 0, 0, 0);
@@ -214,6 +255,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
         __syncthreads();
         MG_STAMP(tb);
         MG_STAMP_ADD(sum_mm, tb, ta);
+        float g_r[MT], g_z[MT], g_n[MT], g_hn[MT], g_new[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int e = bl * GT + jl;
@@ -221,45 +263,34 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
             const float hz = mg_gru_sum4(red[0][1][m][e], red[1][1][m][e], red[2][1][m][e], red[3][1][m][e], bhz);
             const float hn = mg_gru_sum4(red[0][2][m][e], red[1][2][m][e], red[2][2][m][e], red[3][2][m][e], bhn);
             const mg_gru_cell_out c = mg_gru_cell(xr[m], xz[m], xn[m], hr, hz, hn, hprev[m]);
-            const float r = c.r, z = c.z, n = c.n, hnew = c.hnew;
-            const bool active = t < len[m];
-            const float hnext = active ? hnew : hprev[m];
-            hprev[m] = hnext;
-            hb[m][bl][jl] = mg_f2bf(hnext);
-            if (mine[m]) {
-                const int b = row0 + 16 * m + bl;
-                const size_t row = (size_t)b * T + t;
-                hstate[((size_t)b * (T + 1) + t + 1) * H + j] = hnext;
-                out[row * H + j] = active ? hnew : 0.f;
-                float* sv = saved + row * 4 * H;
-                sv[j] = r;
-                sv[H + j] = z;
-                sv[2 * H + j] = n;
-                sv[3 * H + j] = hn;
-            }
+            g_r[m] = c.r; g_z[m] = c.z; g_n[m] = c.n; g_hn[m] = hn; g_new[m] = c.hnew;
+            hprev[m] = t < len[m] ? c.hnew : hprev[m];
+            hb[m][bl][jl] = mg_f2bf(hprev[m]);
         }
         __syncthreads();
         MG_STAMP(ta);
         MG_STAMP_ADD(sum_cell, ta, tb);
-        if (wave == 0) {
-            // publish the slot's 16 columns of h_t: 32 bytes per item = two 16-byte sc1 stores
-            auto rs_w = rs_h;
-            if (lane < 2 * 16 * MT) {
-                const int rrow = lane >> 1, half = lane & 1;
-                if (rrow < nrows) {
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(&hb[rrow >> 4][rrow & 15][8 * half]);
-                    const unsigned off = (unsigned)((((size_t)(row0 + rrow) * (T + 1) + t + 1) * H + j0 + 8 * half) * 2);
-                    if (one_xcd)
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_w, off, 0, 0);      // stays in the group's L2
-                    else
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_w, off, 0, 16);     // sc1: written through
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) gp_store_flag(flags + slot, (unsigned)(t + 1), one_xcd);
-        }
+        publish(t + 1);                             // first: the other workgroups wait for exactly this
         MG_STAMP(tb);
         MG_STAMP_ADD(sum_pub, tb, ta);
+        // fp32 results of the step (nobody reads them before the kernel ends)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (mine[m]) {
+                const int b = row0 + 16 * m + bl;
+                const size_t row = (size_t)b * T + t;
+                hstate[((size_t)b * (T + 1) + t + 1) * H + j] = hprev[m];
+                out[row * H + j] = t < len[m] ? g_new[m] : 0.f;
+                float* sv = saved + row * 4 * H;
+                sv[j] = g_r[m];
+                sv[H + j] = g_z[m];
+                sv[2 * H + j] = g_n[m];
+                sv[3 * H + j] = g_hn[m];
+            }
+            xr[m] = xr1[m];
+            xz[m] = xz1[m];
+            xn[m] = xn1[m];
+        }
     }
 #ifdef MG_STAMPS
     MG_STAMP(ts1);
@@ -296,18 +327,20 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
 }
 
 // Backward recurrence in one launch.  Slot s of a group owns d h[:, 16 s .. 16 s + 16): per step t (T-1 down to 0, then the
-// t = -1 pass that yields dh0) it needs dhproj_{t+1} of the whole group (R x 3H bf16: the hand-off, rows written by all
-// slots in the step before), contracts it with its 16 rows of W_hh^T (16 x 3H bf16 = 48 VGPRs per lane at H = 512, resident),
-// applies the gate derivatives and publishes its 3 x 16 columns of dhproj_t.  The carry (d loss / d h_{t-1} through the z
-// path) stays in a register of the thread that owns the element.  Epoch of row t = gmax - t (gmax = the group's longest
-// sequence): rows at or beyond gmax are all-zero, written without synchronising before the dependent steps start.
+// t = -1 pass that yields dh0) it needs dhproj_{t+1} of the whole group (R x 3H bf16: the hand-off, written by all slots in
+// the step before), contracts it with its 16 rows of W_hh^T (16 x 3H bf16 = 48 VGPRs per lane at H = 512, resident), applies
+// the gate derivatives and publishes its 3 x 16 columns of dhproj_t.  The carry (d loss / d h_{t-1} through the z path) stays
+// in a register of the thread that owns the element.  Flag of a slot = gmax - t once row t is published (gmax = the group's
+// longest sequence): rows at or beyond gmax are all-zero, written without synchronising before the dependent steps start.
+// Ring: [2 (t parity)][8 groups][H / 16 slots][R items][3 gates][16 units] bf16, a slot's tile contiguous (R x 96 bytes).
 template <int MT, int KS>
 __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __restrict__ grad_out, const float* __restrict__ grad_hn,
                                                               const float* __restrict__ hstate, const float* __restrict__ saved,
                                                               const uint16_t* __restrict__ wt_bf, int ldt,
                                                               const int64_t* __restrict__ seq_len, int B, int T, int H, int R,
                                                               float* __restrict__ dxproj, float* __restrict__ dhproj,
-                                                              uint16_t* dhproj_bf, float* __restrict__ dh0, unsigned* sync, int force_sc1) {
+                                                              uint16_t* __restrict__ dhproj_bf, float* __restrict__ dh0, unsigned* sync,
+                                                              uint16_t* ring, int force_sc1) {
     __shared__ float red[4][MT][GT * GT];
     __shared__ __attribute__((aligned(16))) uint16_t pub[MT][GT][3][GT];
     __shared__ int s_abort, s_xcd;
@@ -338,24 +371,35 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
     // W_hh^T fragments: lane (li, q) holds row j0 + li, gate rows gbase + 32 i .. + 7
     const int gbase = wave * (G / 4) + 8 * q;
     gbf8 fb[KS];
+    unsigned rd_off[KS];                               // ring offset of k-step i (item 0, parity 0)
     {
         const uint16_t* wp = wt_bf + (size_t)(j0 + li) * ldt + gbase;
 #pragma unroll
-        for (int i = 0; i < KS; ++i) fb[i] = *reinterpret_cast<const gbf8*>(wp + 32 * i);
+        for (int i = 0; i < KS; ++i) {
+            fb[i] = *reinterpret_cast<const gbf8*>(wp + 32 * i);
+            const int g = gbase + 32 * i, gate = g / H, col = g - gate * H;
+            rd_off[i] = (unsigned)((((group * n_slots + (col >> 4)) * R) * 3 + gate) * 32 + 16 * (q & 1));
+        }
     }
-    const auto rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)dhproj_bf, 0, (int)((size_t)B * T * G * 2), 0x00020000);
+    const unsigned par_bytes = (unsigned)(GP_GROUPS * n_slots * R * 96);
+    const auto rs_ring = __builtin_amdgcn_make_buffer_rsrc((void*)ring, 0, (int)(2 * par_bytes), 0x00020000);
+    const unsigned wr_base = (unsigned)(((group * n_slots + slot) * R) * 96);
 
     const int bl = tid >> 4, jl = tid & 15;
     const int j = j0 + jl;
     float carry[MT];
     int len[MT];
     bool mine[MT];
+    const float *p_sv[MT], *p_h[MT], *p_g[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         mine[m] = 16 * m + bl < nrows;
         const int b = row0 + (mine[m] ? 16 * m + bl : 0);
         carry[m] = grad_hn ? grad_hn[(size_t)b * H + j] : 0.f;
         len[m] = seq_len ? (int)min((int64_t)T, seq_len[b]) : T;
+        p_sv[m] = saved + (size_t)b * T * 4 * H + j;
+        p_h[m] = hstate + (size_t)b * (T + 1) * H + j;
+        p_g[m] = grad_out + (size_t)b * T * H + j;
     }
     // rows beyond the group's longest sequence: zero gradients, carry untouched, nothing to wait for
     for (int t = T - 1; t >= gmax; --t) {
@@ -371,25 +415,26 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
                 }
             }
     }
+    // cell operands of step gmax - 1; step t - 1's are requested during step t
+    float s_r[MT], s_z[MT], s_n[MT], s_hn[MT], hprev[MT], gout[MT];
+    {
+        const int t0 = gmax > 0 ? gmax - 1 : 0;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float* sv = p_sv[m] + (size_t)t0 * 4 * H;
+            s_r[m] = sv[0];
+            s_z[m] = sv[H];
+            s_n[m] = sv[2 * H];
+            s_hn[m] = sv[3 * H];
+            hprev[m] = p_h[m][(size_t)t0 * H];
+            gout[m] = p_g[m][(size_t)t0 * H];
+        }
+    }
     __syncthreads();
 
     for (int t = gmax - 1; t >= -1; --t) {
-        const int tt = t >= 0 ? t : 0;
-        // operands of the cell that do not depend on the hand-off
-        float s_r[MT], s_z[MT], s_n[MT], s_hn[MT], hprev[MT], gout[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int b = row0 + (mine[m] ? 16 * m + bl : 0);
-            const size_t row = (size_t)b * T + tt;
-            const float* sv = saved + row * 4 * H;
-            s_r[m] = sv[j];
-            s_z[m] = sv[H + j];
-            s_n[m] = sv[2 * H + j];
-            s_hn[m] = sv[3 * H + j];
-            hprev[m] = hstate[((size_t)b * (T + 1) + tt) * H + j];
-            gout[m] = grad_out[row * H + j];
-        }
         const bool need_mm = t + 1 < gmax;               // row t + 1 holds gradients of a live step
+        u32x4 raw[MT][KS];
         if (need_mm) {
             if (wave == 0 && !gp_wait_flags(flags, n_slots, (unsigned)(gmax - t - 1), lane)) s_abort = 1;
             __syncthreads();
@@ -400,67 +445,106 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const bool valid = 16 * m + li < nrows;
-                const unsigned off = (unsigned)((((size_t)(row0 + (valid ? 16 * m + li : 0)) * T + t + 1) * G + gbase) * 2);
-                u32x4 raw[KS];
+                const unsigned off = ((t + 1) & 1) * par_bytes + (unsigned)((valid ? 16 * m + li : 0) * 96);
 #pragma unroll
-                for (int i = 0; i < KS; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_d, off + 64 * i, 0, 16);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < KS; ++i) raw[m][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ring, off + rd_off[i], 0, 16);
+            }
+        }
+        // the next step's cell operands (first touch: HBM latency), queued BEHIND the hand-off loads
+        float s_r1[MT], s_z1[MT], s_n1[MT], s_hn1[MT], hprev1[MT], gout1[MT];
+        {
+            const int t1 = t > 0 ? t - 1 : 0;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const float* sv = p_sv[m] + (size_t)t1 * 4 * H;
+                s_r1[m] = sv[0];
+                s_z1[m] = sv[H];
+                s_n1[m] = sv[2 * H];
+                s_hn1[m] = sv[3 * H];
+                hprev1[m] = p_h[m][(size_t)t1 * H];
+                gout1[m] = p_g[m][(size_t)t1 * H];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (need_mm) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < KS; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(raw[i]), fb[i], acc, 0, 0, 0);
+                for (int i = 0; i < KS; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(raw[m][i]), fb[i], acc, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) red[wave][m][(4 * q + r) * GT + li] = acc[r];
             }
             __syncthreads();
         }
+        float o_dr[MT], o_dz[MT], o_dn[MT], o_dnr[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int e = bl * GT + jl;
             const float dstate = need_mm ? mg_gru_dstate(carry[m], red[0][m][e], red[1][m][e], red[2][m][e], red[3][m][e]) : carry[m];
-            if (t < 0) {
-                if (mine[m]) dh0[(size_t)(row0 + 16 * m + bl) * H + j] = dstate;
-                continue;
-            }
             float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, c = dstate;
-            if (t < len[m]) {
+            if (t >= 0 && t < len[m]) {
                 const mg_gru_cell_grad g = mg_gru_cell_bwd(dstate, gout[m], s_r[m], s_z[m], s_n[m], s_hn[m], hprev[m]);
                 dr = g.dr; dz = g.dz; dn = g.dn; dnr = g.dnr; c = g.carry;
             }
             carry[m] = c;
+            o_dr[m] = dr; o_dz[m] = dz; o_dn[m] = dn; o_dnr[m] = dnr;
             pub[m][bl][0][jl] = mg_f2bf(dr);
             pub[m][bl][1][jl] = mg_f2bf(dz);
             pub[m][bl][2][jl] = mg_f2bf(dnr);
+        }
+        if (t < 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                if (mine[m]) dh0[(size_t)(row0 + 16 * m + bl) * H + j] = carry[m];
+            break;
+        }
+        __syncthreads();
+        if (wave <= 1) {
+            // dhproj_t[:, gate, 16 s .. 16 s + 16) for the 3 gates: 6 pieces of 16 bytes per item, contiguous in the ring;
+            // wave 0 publishes, wave 1 writes the bf16 shadow for the weight-gradient GEMM
+            for (int p = lane; p < 6 * nrows; p += 64) {
+                const u32x4 v = reinterpret_cast<const u32x4*>(&pub[0][0][0][0])[p];
+                if (wave == 0) {
+                    const unsigned off = (t & 1) * par_bytes + wr_base + (unsigned)(p * 16);
+                    if (one_xcd)
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 0);
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 16);
+                } else {
+                    const int rrow = p / 6, piece = p - 6 * rrow;
+                    *reinterpret_cast<u32x4*>(dhproj_bf + ((size_t)(row0 + rrow) * T + t) * G + (piece >> 1) * H + j0 + 8 * (piece & 1)) = v;
+                }
+            }
+            if (wave == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) gp_store_flag(flags + slot, (unsigned)(gmax - t), one_xcd);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
             if (mine[m]) {
                 const size_t row = (size_t)(row0 + 16 * m + bl) * T + t;
                 float* dx = dxproj + row * G;
                 float* dhp = dhproj + row * G;
-                dx[j] = dr;  dx[H + j] = dz;  dx[2 * H + j] = dn;
-                dhp[j] = dr; dhp[H + j] = dz; dhp[2 * H + j] = dnr;
+                dx[j] = o_dr[m];  dx[H + j] = o_dz[m];  dx[2 * H + j] = o_dn[m];
+                dhp[j] = o_dr[m]; dhp[H + j] = o_dz[m]; dhp[2 * H + j] = o_dnr[m];
             }
-        }
-        if (t < 0) break;
-        __syncthreads();
-        if (wave == 0) {
-            // publish dhproj_t[:, gate, 16 s .. 16 s + 16) for the 3 gates: 6 pieces of 16 bytes per item
-            for (int p = lane; p < 6 * nrows; p += 64) {
-                const int rrow = p / 6, piece = p - 6 * rrow, gate = piece >> 1, half = piece & 1;
-                const u32x4 v = *reinterpret_cast<const u32x4*>(&pub[rrow >> 4][rrow & 15][gate][8 * half]);
-                const unsigned off = (unsigned)((((size_t)(row0 + rrow) * T + t) * G + gate * H + j0 + 8 * half) * 2);
-                if (one_xcd)
-                    __builtin_amdgcn_raw_buffer_store_b128(v, rs_d, off, 0, 0);
-                else
-                    __builtin_amdgcn_raw_buffer_store_b128(v, rs_d, off, 0, 16);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) gp_store_flag(flags + slot, (unsigned)(gmax - t), one_xcd);
+            s_r[m] = s_r1[m]; s_z[m] = s_z1[m]; s_n[m] = s_n1[m]; s_hn[m] = s_hn1[m];
+            hprev[m] = hprev1[m]; gout[m] = gout1[m];
         }
     }
 }
 
 extern "C" {
 
-// workspace: [step flags 8 x 32 words | XCC ids 8 x 32 words | status word + 3 pad]
-size_t mg_gru_persist_workspace_bytes(void) { return (size_t)GP_SYNC_WORDS * sizeof(unsigned); }
+// workspace: [step flags 8 x 32 words | XCC ids 8 x 32 words | status word + 3 pad] [hand-off ring: 2 parities x 8 groups x
+// R items x 3H units bf16 (backward; forward uses a third of it)]
+#define GP_RING_OFFSET ((size_t)GP_SYNC_WORDS * sizeof(unsigned))
+size_t mg_gru_persist_workspace_bytes(int B, int H) {
+    if (B <= 0 || H <= 0) return GP_RING_OFFSET;
+    return GP_RING_OFFSET + (size_t)2 * GP_GROUPS * mg_ceil_div(B, GP_GROUPS) * 3 * H * 2;
+}
 
 int mg_gru_persist_supported(int B, int T, int H) {
     if (B <= 0 || T <= 0 || H <= 0) return 0;
@@ -495,8 +579,8 @@ int mg_gru_fwd_persist_bf16(const float* xproj, const uint16_t* w_hh_bf, int ldw
                  "mg_gru_fwd_persist_bf16: unsupported shape (B=%d T=%d H=%d ldw=%d): needs H %% 128 == 0, H <= 512, B <= 256", B, T, H, ldw);
     MG_CHECK_ARG((((uintptr_t)w_hh_bf | (uintptr_t)hstate_bf | (uintptr_t)workspace) % 16) == 0,
                  "mg_gru_fwd_persist_bf16: bf16 buffers and workspace must be 16-byte aligned");
-    if (!workspace || workspace_bytes < mg_gru_persist_workspace_bytes()) {
-        mg_set_error("mg_gru_fwd_persist_bf16: workspace of %zu bytes needed, got %zu", mg_gru_persist_workspace_bytes(), workspace_bytes);
+    if (!workspace || workspace_bytes < mg_gru_persist_workspace_bytes(B, H)) {
+        mg_set_error("mg_gru_fwd_persist_bf16: workspace of %zu bytes needed, got %zu", mg_gru_persist_workspace_bytes(B, H), workspace_bytes);
         return MG_EWORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -508,7 +592,7 @@ int mg_gru_fwd_persist_bf16(const float* xproj, const uint16_t* w_hh_bf, int ldw
     const unsigned grid = (unsigned)(GP_GROUPS * (H / GT));
 #define GP_FWD(MT, KS)                                                                                                                  \
     hipLaunchKernelGGL((gru_fwd_persist_kernel<MT, KS>), dim3(grid), dim3(256), 0, st, xproj, w_hh_bf, ldw, b_hh, seq_len, B, T, H, R, hstate, \
-                       hstate_bf, out, saved, (unsigned*)workspace, g_mg_tuning[MG_TUNE_GRU_HANDOFF] == 1)
+                       hstate_bf, out, saved, (unsigned*)workspace, (uint16_t*)((char*)workspace + GP_RING_OFFSET), g_mg_tuning[MG_TUNE_GRU_HANDOFF] == 1)
 #define GP_FWD_KS(MT)            \
     switch (H / 128) {           \
         case 1: GP_FWD(MT, 1); break; \
@@ -534,8 +618,8 @@ int mg_gru_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const f
                  "mg_gru_bwd_persist_bf16: unsupported shape (B=%d T=%d H=%d ldt=%d): needs H %% 128 == 0, H <= 512, B <= 256", B, T, H, ldt);
     MG_CHECK_ARG((((uintptr_t)w_hh_t_bf | (uintptr_t)dhproj_bf | (uintptr_t)workspace) % 16) == 0,
                  "mg_gru_bwd_persist_bf16: bf16 buffers and workspace must be 16-byte aligned");
-    if (!workspace || workspace_bytes < mg_gru_persist_workspace_bytes()) {
-        mg_set_error("mg_gru_bwd_persist_bf16: workspace of %zu bytes needed, got %zu", mg_gru_persist_workspace_bytes(), workspace_bytes);
+    if (!workspace || workspace_bytes < mg_gru_persist_workspace_bytes(B, H)) {
+        mg_set_error("mg_gru_bwd_persist_bf16: workspace of %zu bytes needed, got %zu", mg_gru_persist_workspace_bytes(B, H), workspace_bytes);
         return MG_EWORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -547,7 +631,8 @@ int mg_gru_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const f
     const unsigned grid = (unsigned)(GP_GROUPS * (H / GT));
 #define GP_BWD(MT, KS)                                                                                                                      \
     hipLaunchKernelGGL((gru_bwd_persist_kernel<MT, KS>), dim3(grid), dim3(256), 0, st, grad_out, grad_hn, hstate, saved, w_hh_t_bf, ldt, seq_len, \
-                       B, T, H, R, dxproj, dhproj, dhproj_bf, dh0, (unsigned*)workspace, g_mg_tuning[MG_TUNE_GRU_HANDOFF] == 1)
+                       B, T, H, R, dxproj, dhproj, dhproj_bf, dh0, (unsigned*)workspace, (uint16_t*)((char*)workspace + GP_RING_OFFSET),           \
+                       g_mg_tuning[MG_TUNE_GRU_HANDOFF] == 1)
 #define GP_BWD_KS(MT)                  \
     switch (H / 128) {                 \
         case 1: GP_BWD(MT, 3); break;  \

@@ -464,7 +464,7 @@ def gru_persist_ok(b, t, h):
 
 def _persist_workspace(dev, b, h):
     key = (dev, torch.cuda.current_stream().cuda_stream)
-    need = _lib.load().mg_gru_persist_workspace_bytes()
+    need = _lib.load().mg_gru_persist_workspace_bytes(b, h)
     ws = _PERSIST_WORKSPACES.get(key)
     if ws is None or ws.numel() < need:
         if ws is not None:
