@@ -354,9 +354,13 @@ __global__ __launch_bounds__(256) void gru_bwd_step_bf16_kernel(const float* __r
                 fa[i] = *reinterpret_cast<const gbf8*>(dp + gbase + 32 * i);
                 fb[i] = *reinterpret_cast<const gbf8*>(wp + gbase + 32 * i);
             }
+        // three independent accumulation chains (k-steps i = c mod 3): a dependent v_mfma_f32_16x16x32_bf16 chain of 3 H / 128
+        // links would cost its full latency per link; same order in gru_persist.hip
+        f32x4 acc3[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int i = 0; i < GBB_MAXSTEPS; ++i)
-            if (i < n_steps) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[i], acc, 0, 0, 0);
+            if (i < n_steps) acc3[i % 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[i], acc3[i % 3], 0, 0, 0);
+        acc = (acc3[0] + acc3[1]) + acc3[2];
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][(4 * q + r) * GT + li] = acc[r];

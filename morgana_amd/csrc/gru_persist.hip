@@ -62,6 +62,7 @@ __device__ __forceinline__ bool gp_wait_flags(gu32* flags, int n_slots, unsigned
 }
 
 MG_STAMP_DECL(g_stamps_gp);
+MG_STAMP_DECL(g_stamps_gpb);
 
 // Where the group runs.  Every workgroup publishes the id of the XCD it is on (s_getreg HW_REG_XCC_ID) and reads the ids of the
 // group's other slots - once per launch, with the placement-independent sc1 protocol.  If they are all equal, the whole group
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
                                                               uint16_t* __restrict__ dhproj_bf, float* __restrict__ dh0, unsigned* sync,
                                                               uint16_t* ring, int force_sc1) {
     __shared__ float red[4][MT][GT * GT];
-    __shared__ __attribute__((aligned(16))) uint16_t pub[MT][GT][3][GT];
+    __shared__ __attribute__((aligned(16))) uint16_t pub[3][MT * GT][GT];
     __shared__ int s_abort, s_xcd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
         for (int i = 0; i < KS; ++i) {
             fb[i] = *reinterpret_cast<const gbf8*>(wp + 32 * i);
             const int g = gbase + 32 * i, gate = g / H, col = g - gate * H;
-            rd_off[i] = (unsigned)((((group * n_slots + (col >> 4)) * R) * 3 + gate) * 32 + 16 * (q & 1));
+            rd_off[i] = (unsigned)((((group * n_slots + (col >> 4)) * 3 + gate) * R) * 32 + 16 * (q & 1));
         }
     }
     const unsigned par_bytes = (unsigned)(GP_GROUPS * n_slots * R * 96);
@@ -415,6 +416,18 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
                 }
             }
     }
+    // the slot's tile as 16-byte pieces: piece p = (gate, item, half) in ring order; lane handles pieces lane + 64 k
+    constexpr int PIECES = (6 * GT * MT + 63) / 64;
+    bool pc_ok[PIECES];
+    int pc_lds[PIECES];
+    size_t pc_shadow[PIECES];
+#pragma unroll
+    for (int k = 0; k < PIECES; ++k) {
+        const int pc = lane + 64 * k, gate = pc / (2 * R), rem = pc - gate * 2 * R, rrow = rem >> 1, half = rem & 1;
+        pc_ok[k] = gate < 3 && rrow < nrows;
+        pc_lds[k] = (gate * MT * GT + rrow) * GT + 8 * half;
+        pc_shadow[k] = (size_t)(row0 + rrow) * T * G + gate * H + j0 + 8 * half;
+    }
     // cell operands of step gmax - 1; step t - 1's are requested during step t
     float s_r[MT], s_z[MT], s_n[MT], s_hn[MT], hprev[MT], gout[MT];
     {
@@ -432,9 +445,15 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
     }
     __syncthreads();
 
+#ifdef MG_STAMPS
+    unsigned long long ta = 0, tb = 0, ts0 = 0, ts1 = 0, tr0 = 0, tr1 = 0, sum_poll = 0, sum_load = 0, sum_mm = 0, sum_cell = 0, sum_pub = 0;
+    MG_STAMP(ts0);
+    MG_STAMP_REAL(tr0);
+#endif
     for (int t = gmax - 1; t >= -1; --t) {
         const bool need_mm = t + 1 < gmax;               // row t + 1 holds gradients of a live step
         u32x4 raw[MT][KS];
+        MG_STAMP(ta);
         if (need_mm) {
             if (wave == 0 && !gp_wait_flags(flags, n_slots, (unsigned)(gmax - t - 1), lane)) s_abort = 1;
             __syncthreads();
@@ -442,14 +461,19 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
                 if (tid == 0) __hip_atomic_store(status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return;
             }
+            MG_STAMP(tb);
+            MG_STAMP_ADD(sum_poll, tb, ta);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const bool valid = 16 * m + li < nrows;
-                const unsigned off = ((t + 1) & 1) * par_bytes + (unsigned)((valid ? 16 * m + li : 0) * 96);
+                const unsigned off = ((t + 1) & 1) * par_bytes + (unsigned)((valid ? 16 * m + li : 0) * 32);
 #pragma unroll
                 for (int i = 0; i < KS; ++i) raw[m][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ring, off + rd_off[i], 0, 16);
             }
         }
+#ifdef MG_STAMPS
+        if (!need_mm) tb = ta;
+#endif
         // the next step's cell operands (first touch: HBM latency), queued BEHIND the hand-off loads
         float s_r1[MT], s_z1[MT], s_n1[MT], s_hn1[MT], hprev1[MT], gout1[MT];
         {
@@ -466,17 +490,26 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+#ifdef MG_STAMPS
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        MG_STAMP(ta);
+        MG_STAMP_ADD(sum_load, ta, tb);
+#endif
         if (need_mm) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                f32x4 acc3[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // KS is a multiple of 3
 #pragma unroll
-                for (int i = 0; i < KS; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(raw[m][i]), fb[i], acc, 0, 0, 0);
+                for (int i = 0; i < KS; ++i)
+                    acc3[i % 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(raw[m][i]), fb[i], acc3[i % 3], 0, 0, 0);
+                const f32x4 acc = (acc3[0] + acc3[1]) + acc3[2];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) red[wave][m][(4 * q + r) * GT + li] = acc[r];
             }
             __syncthreads();
         }
+        MG_STAMP(tb);
+        MG_STAMP_ADD(sum_mm, tb, ta);
         float o_dr[MT], o_dz[MT], o_dn[MT], o_dnr[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -489,9 +522,9 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
             }
             carry[m] = c;
             o_dr[m] = dr; o_dz[m] = dz; o_dn[m] = dn; o_dnr[m] = dnr;
-            pub[m][bl][0][jl] = mg_f2bf(dr);
-            pub[m][bl][1][jl] = mg_f2bf(dz);
-            pub[m][bl][2][jl] = mg_f2bf(dnr);
+            pub[0][16 * m + bl][jl] = mg_f2bf(dr);
+            pub[1][16 * m + bl][jl] = mg_f2bf(dz);
+            pub[2][16 * m + bl][jl] = mg_f2bf(dnr);
         }
         if (t < 0) {
 #pragma unroll
@@ -500,20 +533,24 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
             break;
         }
         __syncthreads();
+        MG_STAMP(ta);
+        MG_STAMP_ADD(sum_cell, ta, tb);
         if (wave <= 1) {
-            // dhproj_t[:, gate, 16 s .. 16 s + 16) for the 3 gates: 6 pieces of 16 bytes per item, contiguous in the ring;
+            // dhproj_t[:, gate, 16 s .. 16 s + 16): per gate R items x 32 bytes, the slot's 3 R x 32 bytes contiguous in the ring;
             // wave 0 publishes, wave 1 writes the bf16 shadow for the weight-gradient GEMM
-            for (int p = lane; p < 6 * nrows; p += 64) {
-                const u32x4 v = reinterpret_cast<const u32x4*>(&pub[0][0][0][0])[p];
-                if (wave == 0) {
-                    const unsigned off = (t & 1) * par_bytes + wr_base + (unsigned)(p * 16);
-                    if (one_xcd)
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 0);
-                    else
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 16);
-                } else {
-                    const int rrow = p / 6, piece = p - 6 * rrow;
-                    *reinterpret_cast<u32x4*>(dhproj_bf + ((size_t)(row0 + rrow) * T + t) * G + (piece >> 1) * H + j0 + 8 * (piece & 1)) = v;
+#pragma unroll
+            for (int k = 0; k < PIECES; ++k) {
+                if (pc_ok[k]) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(&pub[0][0][0] + pc_lds[k]);
+                    if (wave == 0) {
+                        const unsigned off = (t & 1) * par_bytes + wr_base + (unsigned)((lane + 64 * k) * 16);
+                        if (one_xcd)
+                            __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 0);
+                        else
+                            __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 16);
+                    } else {
+                        *reinterpret_cast<u32x4*>(dhproj_bf + pc_shadow[k] + (size_t)t * G) = v;
+                    }
                 }
             }
             if (wave == 0) {
@@ -521,6 +558,8 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
                 if (lane == 0) gp_store_flag(flags + slot, (unsigned)(gmax - t), one_xcd);
             }
         }
+        MG_STAMP(tb);
+        MG_STAMP_ADD(sum_pub, tb, ta);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             if (mine[m]) {
@@ -534,6 +573,20 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
             hprev[m] = hprev1[m]; gout[m] = gout1[m];
         }
     }
+#ifdef MG_STAMPS
+    MG_STAMP(ts1);
+    MG_STAMP_REAL(tr1);
+    MG_STAMP_STORE(g_stamps_gpb, blockIdx.x, wave, lane, 0, ts0);
+    MG_STAMP_STORE(g_stamps_gpb, blockIdx.x, wave, lane, 1, ts1);
+    MG_STAMP_STORE(g_stamps_gpb, blockIdx.x, wave, lane, 2, tr0);
+    MG_STAMP_STORE(g_stamps_gpb, blockIdx.x, wave, lane, 3, tr1);
+    MG_STAMP_STORE(g_stamps_gpb, blockIdx.x, wave, lane, 4, sum_poll);
+    MG_STAMP_STORE(g_stamps_gpb, blockIdx.x, wave, lane, 5, sum_load);
+    MG_STAMP_STORE(g_stamps_gpb, blockIdx.x, wave, lane, 6, sum_mm);
+    MG_STAMP_STORE(g_stamps_gpb, blockIdx.x, wave, lane, 7, sum_cell);
+    MG_STAMP_STORE(g_stamps_gpb, blockIdx.x, wave, lane, 8, sum_pub);
+    MG_STAMP_STORE(g_stamps_gpb, blockIdx.x, wave, lane, 9, (unsigned long long)gmax);
+#endif
 }
 
 extern "C" {
@@ -563,7 +616,7 @@ int mg_gru_persist_status(void* workspace, void* stream) {
         return MG_ELAUNCH;
     }
     if (st != 0) {
-        hipMemsetAsync((unsigned*)workspace + GP_FLAG_WORDS, 0, 16, (hipStream_t)stream);     // sticky until reported
+        (void)hipMemsetAsync((unsigned*)workspace + GP_FLAG_WORDS, 0, 16, (hipStream_t)stream);     // sticky until reported
         mg_set_error("persistent GRU kernel timed out waiting for another workgroup (status %u): results are invalid", st);
         return MG_ELAUNCH;
     }
@@ -652,6 +705,9 @@ int mg_gru_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const f
 }  // extern "C"
 
 #ifdef MG_STAMPS
+extern "C" int mg_diag_read_stamps_gpb(void* dst, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps_gpb), bytes < sizeof(g_stamps_gpb) ? bytes : sizeof(g_stamps_gpb), 0, hipMemcpyDeviceToHost);
+}
 extern "C" int mg_diag_read_stamps_gp(void* dst, size_t bytes) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps_gp), bytes < sizeof(g_stamps_gp) ? bytes : sizeof(g_stamps_gp), 0, hipMemcpyDeviceToHost);
 }
