@@ -61,6 +61,11 @@ __device__ __forceinline__ bool gp_wait_flags(gu32* flags, int n_slots, unsigned
     }
 }
 
+// Workgroup barrier for LDS hand-overs inside the step loops: waits for this wave's LDS operations only.  __syncthreads() also
+// drains the wave's global stores (its release fence = s_waitcnt vmcnt(0)): the waves that write a step's fp32 results would
+// then reach the next barrier a store round trip late, every step.
+__device__ __forceinline__ void gp_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 MG_STAMP_DECL(g_stamps_gp);
 MG_STAMP_DECL(g_stamps_gpb);
 
@@ -98,6 +103,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
                                                               float* __restrict__ saved, unsigned* sync, uint16_t* ring, int force_sc1) {
     __shared__ float red[4][3][MT][GT * GT];
     __shared__ __attribute__((aligned(16))) uint16_t hb[MT][GT][GT];
+    __shared__ float res[MT][6][GT * GT];          // a step's fp32 results on their way to waves 2 and 3, which store them
     __shared__ int s_abort, s_xcd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
     for (int t = 0; t < gmax; ++t) {
         MG_STAMP(ta);
         if (wave == 0 && !gp_wait_flags(flags, n_slots, (unsigned)(t + 1), lane)) s_abort = 1;
-        __syncthreads();
+        gp_lds_barrier();
         if (s_abort) {
             if (tid == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
@@ -253,10 +259,9 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
                 red[wave][2][m][e] = acc_n[r];
             }
         }
-        __syncthreads();
+        gp_lds_barrier();
         MG_STAMP(tb);
         MG_STAMP_ADD(sum_mm, tb, ta);
-        float g_r[MT], g_z[MT], g_n[MT], g_hn[MT], g_new[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int e = bl * GT + jl;
@@ -264,30 +269,45 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
             const float hz = mg_gru_sum4(red[0][1][m][e], red[1][1][m][e], red[2][1][m][e], red[3][1][m][e], bhz);
             const float hn = mg_gru_sum4(red[0][2][m][e], red[1][2][m][e], red[2][2][m][e], red[3][2][m][e], bhn);
             const mg_gru_cell_out c = mg_gru_cell(xr[m], xz[m], xn[m], hr, hz, hn, hprev[m]);
-            g_r[m] = c.r; g_z[m] = c.z; g_n[m] = c.n; g_hn[m] = hn; g_new[m] = c.hnew;
             hprev[m] = t < len[m] ? c.hnew : hprev[m];
             hb[m][bl][jl] = mg_f2bf(hprev[m]);
+            res[m][0][e] = hprev[m];
+            res[m][1][e] = t < len[m] ? c.hnew : 0.f;
+            res[m][2][e] = c.r;
+            res[m][3][e] = c.z;
+            res[m][4][e] = c.n;
+            res[m][5][e] = hn;
         }
-        __syncthreads();
+        gp_lds_barrier();
         MG_STAMP(ta);
         MG_STAMP_ADD(sum_cell, ta, tb);
         publish(t + 1);                             // first: the other workgroups wait for exactly this
         MG_STAMP(tb);
         MG_STAMP_ADD(sum_pub, tb, ta);
-        // fp32 results of the step (nobody reads them before the kernel ends)
+        // fp32 results of the step (nobody reads them before the kernel ends): written by waves 2 and 3 only.  The acknowledgement
+        // of a store to a fresh line takes about as long as a whole step; in wave 0's in-order memory queue it would sit in front of
+        // the flag poll and the publish drain, and waves 2 and 3 only wait at the next barrier anyway.
+        if (wave >= 2) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int e = (tid - 128) + 128 * half, rb = e >> 4, cj = j0 + (e & 15);
+                    if (16 * m + rb < nrows) {
+                        const int b = row0 + 16 * m + rb;
+                        const size_t row = (size_t)b * T + t;
+                        hstate[((size_t)b * (T + 1) + t + 1) * H + cj] = res[m][0][e];
+                        out[row * H + cj] = res[m][1][e];
+                        float* sv = saved + row * 4 * H + cj;
+                        sv[0] = res[m][2][e];
+                        sv[H] = res[m][3][e];
+                        sv[2 * H] = res[m][4][e];
+                        sv[3 * H] = res[m][5][e];
+                    }
+                }
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            if (mine[m]) {
-                const int b = row0 + 16 * m + bl;
-                const size_t row = (size_t)b * T + t;
-                hstate[((size_t)b * (T + 1) + t + 1) * H + j] = hprev[m];
-                out[row * H + j] = t < len[m] ? g_new[m] : 0.f;
-                float* sv = saved + row * 4 * H;
-                sv[j] = g_r[m];
-                sv[H + j] = g_z[m];
-                sv[2 * H + j] = g_n[m];
-                sv[3 * H + j] = g_hn[m];
-            }
             xr[m] = xr1[m];
             xz[m] = xz1[m];
             xn[m] = xn1[m];
@@ -344,6 +364,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
                                                               uint16_t* ring, int force_sc1) {
     __shared__ float red[4][MT][GT * GT];
     __shared__ __attribute__((aligned(16))) uint16_t pub[3][MT * GT][GT];
+    __shared__ float res[MT][4][GT * GT];          // dr, dz, dn, dn r of the step for waves 2 and 3, which store them
     __shared__ int s_abort, s_xcd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
@@ -456,7 +477,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
         MG_STAMP(ta);
         if (need_mm) {
             if (wave == 0 && !gp_wait_flags(flags, n_slots, (unsigned)(gmax - t - 1), lane)) s_abort = 1;
-            __syncthreads();
+            gp_lds_barrier();
             if (s_abort) {
                 if (tid == 0) __hip_atomic_store(status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return;
@@ -506,11 +527,10 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
 #pragma unroll
                 for (int r = 0; r < 4; ++r) red[wave][m][(4 * q + r) * GT + li] = acc[r];
             }
-            __syncthreads();
+            gp_lds_barrier();
         }
         MG_STAMP(tb);
         MG_STAMP_ADD(sum_mm, tb, ta);
-        float o_dr[MT], o_dz[MT], o_dn[MT], o_dnr[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int e = bl * GT + jl;
@@ -521,7 +541,10 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
                 dr = g.dr; dz = g.dz; dn = g.dn; dnr = g.dnr; c = g.carry;
             }
             carry[m] = c;
-            o_dr[m] = dr; o_dz[m] = dz; o_dn[m] = dn; o_dnr[m] = dnr;
+            res[m][0][e] = dr;
+            res[m][1][e] = dz;
+            res[m][2][e] = dn;
+            res[m][3][e] = dnr;
             pub[0][16 * m + bl][jl] = mg_f2bf(dr);
             pub[1][16 * m + bl][jl] = mg_f2bf(dz);
             pub[2][16 * m + bl][jl] = mg_f2bf(dnr);
@@ -532,7 +555,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
                 if (mine[m]) dh0[(size_t)(row0 + 16 * m + bl) * H + j] = carry[m];
             break;
         }
-        __syncthreads();
+        gp_lds_barrier();
         MG_STAMP(ta);
         MG_STAMP_ADD(sum_cell, ta, tb);
         if (wave <= 1) {
@@ -560,15 +583,24 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
         }
         MG_STAMP(tb);
         MG_STAMP_ADD(sum_pub, tb, ta);
+        if (wave >= 2) {                                // fp32 results: waves 2 and 3 only (see the forward kernel)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int e = (tid - 128) + 128 * half, rb = e >> 4, cj = j0 + (e & 15);
+                    if (16 * m + rb < nrows) {
+                        const size_t row = (size_t)(row0 + 16 * m + rb) * T + t;
+                        float* dx = dxproj + row * G + cj;
+                        float* dhp = dhproj + row * G + cj;
+                        const float dr = res[m][0][e], dz = res[m][1][e];
+                        dx[0] = dr;  dx[H] = dz;  dx[2 * H] = res[m][2][e];
+                        dhp[0] = dr; dhp[H] = dz; dhp[2 * H] = res[m][3][e];
+                    }
+                }
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            if (mine[m]) {
-                const size_t row = (size_t)(row0 + 16 * m + bl) * T + t;
-                float* dx = dxproj + row * G;
-                float* dhp = dhproj + row * G;
-                dx[j] = o_dr[m];  dx[H + j] = o_dz[m];  dx[2 * H + j] = o_dn[m];
-                dhp[j] = o_dr[m]; dhp[H + j] = o_dz[m]; dhp[2 * H + j] = o_dnr[m];
-            }
             s_r[m] = s_r1[m]; s_z[m] = s_z1[m]; s_n[m] = s_n1[m]; s_hn[m] = s_hn1[m];
             hprev[m] = hprev1[m]; gout[m] = gout1[m];
         }
