@@ -127,6 +127,47 @@ def roofline_f0(features, model, precision):
             'frac': round(dom['tflops'] / peak, 4), 'traffic': traffic, 'ms_per_launch': dom['ms'], 'kernels': measured}
 
 
+def roofline_gru(features, model, precision, target):
+    """Time the two recurrence launches of the GRU layer in isolation.  T dependent steps of a [B,H] x [H,3H] product: the
+    roof that the arithmetic sees is MFMA, but the launch is bound by the per-step hand-off latency between workgroups
+    (DESIGN.md section 5); the fraction of the MFMA roof is reported as it is."""
+    b, t = features[target].shape[:2]
+    gru = [mod for mod in model.modules() if isinstance(mod, torch.nn.GRU)][0]
+    hid = gru.hidden_size
+    dev = features[target].device
+    seq_len = features['n_frames'].to(dev).view(-1)
+    steps = int(seq_len.max().item())
+    w_hh, b_hh = gru.weight_hh_l0.detach(), gru.bias_hh_l0.detach()
+    xproj = torch.randn(b, t, 3 * hid, device=dev)
+    g_out = torch.randn(b, t, hid, device=dev) * 0.01
+    flops = 2.0 * float(seq_len.sum().item()) * 3 * hid * hid
+    if precision == 'bf16' and ops.gru_bf16_ok(hid):
+        tag = 'persist' if ops.gru_persist_ok(b, t, hid) else 'step_bf16'
+        out, hstate, saved, _ = ops.gru_fwd_bf16(xproj, w_hh, b_hh, seq_len, None, b, t, hid)
+        runs = [('gru_fwd_%s_kernel: GRU forward recurrence, %d dependent steps' % (tag, steps),
+                 lambda: ops.gru_fwd_bf16(xproj, w_hh, b_hh, seq_len, None, b, t, hid)),
+                ('gru_bwd_%s_kernel: GRU backward recurrence, %d dependent steps' % (tag, steps),
+                 lambda: ops.gru_bwd_bf16(g_out, None, hstate, saved, w_hh, seq_len, b, t, hid))]
+        peak = MFMA_BF16_PEAK_TFLOPS
+    else:
+        out, hstate, saved = ops.gru_fwd(xproj, w_hh, b_hh, seq_len, None, b, t, hid)
+        runs = [('gru_fwd_step_kernel x %d launches' % steps, lambda: ops.gru_fwd(xproj, w_hh, b_hh, seq_len, None, b, t, hid)),
+                ('gru_bwd_step_kernel x %d launches' % steps,
+                 lambda: ops.gru_bwd(g_out, None, hstate, saved, w_hh, seq_len, b, t, hid))]
+        peak = MFMA_F32_PEAK_TFLOPS
+    measured = []
+    for name, fn in runs:
+        ms = time_kernel(fn, iters=5, warm=2)
+        measured.append({'kernel': name, 'ms': round(ms, 4), 'gflop': round(flops / 1e9, 1),
+                         'tflops': round(flops / (ms * 1e-3) / 1e12, 2), 'us_per_step': round(ms * 1e3 / steps, 3)})
+    ops.check_persistent_status()
+    dom = max(measured, key=lambda r: r['ms'])
+    return {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': dom['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
+            'frac': round(dom['tflops'] / peak, 4), 'traffic': None, 'ms_per_launch': dom['ms'],
+            'note': 'latency-bound chain: %.2f us per dependent step (hand-off between workgroups), not an MFMA-rate limit'
+                    % dom['us_per_step'], 'kernels': measured}
+
+
 def host_cores():
     """CPU threads this process may really use: affinity, capped by the cgroup CPU quota (the GPU box gives a 1-GPU job
     a share of the host, not all of its cores) and by 32 (the 64 x 1000-frame sample does not scale further)."""
@@ -274,6 +315,8 @@ def main():
             result['step_frac_of_mfma_peak'] = round(step_tflops / peak, 4)
     if rank == 0 and args.config == 'c2' and not args.no_roofline:
         result['roofline'] = roofline_f0(features, model, args.precision)
+    if rank == 0 and args.config in ('c4', 'c5') and not args.no_roofline:
+        result['roofline'] = roofline_gru(features, model, args.precision, target)
     if rank == 0 and n_gpus == 1 and args.config == 'c2' and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline_f0(args.frames)
     distributed.barrier()
