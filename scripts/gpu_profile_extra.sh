@@ -13,5 +13,7 @@ done
 cd "$ROOT"
 timeout -k 10 300 python scripts/stamps.py > gpurun_out/stamps_r1.txt 2>&1
 echo "[stamps] exit $?"
+timeout -k 10 300 python scripts/stamps_gru.py > gpurun_out/stamps_gru_r1.txt 2>&1
+echo "[stamps gru] exit $?"
 tail -1 gpurun_out/prof_r1_c4.log | cut -c1-250
 tail -1 gpurun_out/prof_r1_lstm.log | cut -c1-250

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Per-phase cycle shares of the persistent GRU forward kernel (flags hand-off), from the DIAGNOSTIC library's in-kernel stamps.
-Usage: MORGANA_HIP_LIB=morgana_amd/libmorgana_hip_diag.so MG_TUNE=2:1 python scripts/stamps_gru.py"""
+"""Per-phase cycle shares of the persistent GRU forward kernel (both directions), from the DIAGNOSTIC library's in-kernel stamps.
+Usage: MORGANA_HIP_LIB=morgana_amd/libmorgana_hip_diag.so python scripts/stamps_gru.py   (MG_TUNE=2:1: the write-through hand-off)"""
 import ctypes
 import os
 import sys
@@ -11,7 +11,7 @@ import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 os.environ.setdefault('MORGANA_HIP_LIB', os.path.join(REPO, 'morgana_amd', 'libmorgana_hip_diag.so'))
-os.environ.setdefault('MG_TUNE', '2:1')
+os.environ.setdefault('MG_TUNE', '2:0')
 from morgana_amd import _lib, ops  # noqa: E402
 
 SLOTS, BLOCKS = 16, 4096
