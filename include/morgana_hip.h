@@ -284,6 +284,20 @@ int mg_gru_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const f
                             const uint16_t* w_hh_t_bf, int ldt, const int64_t* seq_len, int B, int T, int H, float* dxproj,
                             float* dhproj, uint16_t* dhproj_bf, float* dh0, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The LSTM recurrence (gates i, f, g, o) in the same persistent form: bf16 matmul operands, fp32 cell, one launch per
+ * direction.  w_hh_bf = bf16(W_hh) [4H, ldw]; hstate_bf [B,T+1,H] = bf16 shadow of hstate (slot 0 set by the caller, the rest
+ * written here); backward takes w_hh_t_bf = bf16(W_hh^T) [H, ldt >= 4H] and fills dgates [B,T,4H] and its bf16 shadow dgates_bf.
+ * Other arguments as mg_lstm_fwd_f32 / mg_lstm_bwd_f32.  Workspace, status word and residency requirement: as for the GRU entry
+ * points (mg_gru_persist_workspace_bytes(B, H) covers both; mg_gru_persist_status reads the shared status word). */
+int mg_lstm_persist_supported(int B, int T, int H);
+int mg_lstm_fwd_persist_bf16(const float* xproj, const uint16_t* w_hh_bf, int ldw, const float* b_hh, const int64_t* seq_len, int B,
+                             int T, int H, float* hstate, float* cstate, uint16_t* hstate_bf, float* out, float* saved,
+                             void* workspace, size_t workspace_bytes, void* stream);
+int mg_lstm_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const float* grad_cn, const float* cstate,
+                             const float* saved, const uint16_t* w_hh_t_bf, int ldt, const int64_t* seq_len, int B, int T, int H,
+                             float* dgates, uint16_t* dgates_bf, float* dh0, float* dc0, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
 /* LSTM through RecurrentCuDNNWrapper   reference: morgana/utils.py:345-393 + torch.nn.LSTM (gates i, f, g, o), the cell of
  * the reference's shipped acoustic model (models/RNN_SPSS.py:36-37).  Same conventions as the GRU entry points:
  *   xproj [B,T,4H] = x W_ih^T + b_ih; w_hh [4H,H]; b_hh [4H]; hstate / cstate [B,T+1,H] with slot 0 = (h0, c0) on entry;

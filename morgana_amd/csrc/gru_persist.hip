@@ -24,76 +24,10 @@
 #include "common.h"
 #include "gru_cell.h"
 
-#define GT 16
-#define GP_GROUPS 8
-#define GP_SLOTS 32                          // flag words per group (H <= 512)
-#define GP_KSTEPS 4                          // H / 128 MFMA k-steps per wave, H <= 512
-#define GP_SPIN_LIMIT (1u << 20)
-#define GP_FLAG_WORDS (2 * GP_GROUPS * GP_SLOTS)   // per launch (zeroed by a memset node): step flags [8][32], XCC ids [8][32]
-#define GP_SYNC_WORDS (GP_FLAG_WORDS + 4)          // + {sticky status, 3 pad}: 2064 bytes, a multiple of 16
-
-typedef __bf16 gbf8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(1))) unsigned gu32;
-
-__device__ __forceinline__ gbf8 as_bf8(u32x4 v) {
-    union { u32x4 u; gbf8 b; } c;
-    c.u = v;
-    return c.b;
-}
-
-// the slot's flag: written through (sc1) in general; within one XCD a store that stays in the shared L2 (workgroup scope = no
-// sc1 bit; the pollers' sc1 loads are L2-served)
-__device__ __forceinline__ void gp_store_flag(gu32* flag, unsigned epoch, int one_xcd) {
-    if (one_xcd)
-        __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else
-        __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// wave 0: wait until every slot's flag of the group has reached `epoch`.  Returns false after GP_SPIN_LIMIT polls.
-__device__ __forceinline__ bool gp_wait_flags(gu32* flags, int n_slots, unsigned epoch, int lane) {
-    for (unsigned spins = 0;; ++spins) {
-        const unsigned f = lane < n_slots ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
-        if (__all(f >= epoch)) return true;
-        if (spins > GP_SPIN_LIMIT) return false;
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
-
-// Workgroup barrier for LDS hand-overs inside the step loops: waits for this wave's LDS operations only.  __syncthreads() also
-// drains the wave's global stores (its release fence = s_waitcnt vmcnt(0)): the waves that write a step's fp32 results would
-// then reach the next barrier a store round trip late, every step.
-__device__ __forceinline__ void gp_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#include "persist_common.h"
 
 MG_STAMP_DECL(g_stamps_gp);
 MG_STAMP_DECL(g_stamps_gpb);
-
-// Where the group runs.  Every workgroup publishes the id of the XCD it is on (s_getreg HW_REG_XCC_ID) and reads the ids of the
-// group's other slots - once per launch, with the placement-independent sc1 protocol.  If they are all equal, the whole group
-// shares one L2: the hand-off stores may then stay plain (the line stays in that L2, where the readers' sc1 loads - which only
-// bypass their own CU's L1 - find it) instead of being written through to memory and fetched back over the fabric.  The
-// block -> XCD map itself is never assumed: a group spread over several XCDs keeps the write-through form.
-// Returns 1 = one XCD, 0 = several, -1 = timed out.
-__device__ __forceinline__ int gp_group_on_one_xcd(gu32* xcc_tab, int slot, int n_slots, int tid, int* s_word) {
-    unsigned id;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(id));
-    if (tid == 0) __hip_atomic_store(xcc_tab + slot, id + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid < 64) {
-        int result = -1;
-        for (unsigned spins = 0; spins <= GP_SPIN_LIMIT; ++spins) {
-            const unsigned v = tid < n_slots ? __hip_atomic_load(xcc_tab + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : id + 1u;
-            if (__all(v != 0u)) {
-                result = __all(v == id + 1u) ? 1 : 0;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        if (tid == 0) *s_word = result;
-    }
-    __syncthreads();
-    return *s_word;
-}
 
 template <int MT, int KS>
 __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __restrict__ xproj, const uint16_t* __restrict__ w_bf, int ldw,
@@ -625,10 +559,9 @@ extern "C" {
 
 // workspace: [step flags 8 x 32 words | XCC ids 8 x 32 words | status word + 3 pad] [hand-off ring: 2 parities x 8 groups x
 // R items x 3H units bf16 (backward; forward uses a third of it)]
-#define GP_RING_OFFSET ((size_t)GP_SYNC_WORDS * sizeof(unsigned))
 size_t mg_gru_persist_workspace_bytes(int B, int H) {
     if (B <= 0 || H <= 0) return GP_RING_OFFSET;
-    return GP_RING_OFFSET + (size_t)2 * GP_GROUPS * mg_ceil_div(B, GP_GROUPS) * 3 * H * 2;
+    return GP_RING_OFFSET + (size_t)2 * GP_GROUPS * mg_ceil_div(B, GP_GROUPS) * 4 * H * 2;      // 4 H: also serves lstm_persist.hip
 }
 
 int mg_gru_persist_supported(int B, int T, int H) {

@@ -1,0 +1,548 @@
+// K4p - the LSTM recurrence as ONE launch per direction (throughput mode, bf16 matmul operands), the scheme of gru_persist.hip
+// applied to torch.nn.LSTM behind RecurrentCuDNNWrapper (reference: morgana/utils.py:345-393, models/RNN_SPSS.py:36-37; gate
+// order i, f, g, o).  The batch is cut into 8 independent groups of R = ceil(B / 8) items; a group is served by H / 16
+// workgroups, each owning 16 hidden units of all four gates with its 64 rows of W_hh (bf16: 64 VGPRs per lane at H = 512)
+// resident for all T steps; h_t and c_t of an element stay in registers of the thread that owns it.  Hand-off of the bf16
+// state between the workgroups of a group, the same-XCD / write-through forms, the L2-resident ring, the raw LDS barriers and
+// the rule that nothing slow may be queued in front of wave 0's poll, loads and drain: see gru_persist.hip.
+// Arithmetic: bf16 operands for the two per-step products, fp32 accumulation, fp32 cell with the v_exp_f32 / v_rcp_f32
+// sigmoid and tanh; states, gate values and all outputs fp32.  The fp32 parity mode stays on lstm.hip's per-step kernels.
+#include "persist_common.h"
+
+__device__ __forceinline__ float lp_tanh_fast(float x) { return 2.f * mg_sigmoid_fast(2.f * x) - 1.f; }
+
+template <int MT, int KS>
+__global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(const float* __restrict__ xproj, const uint16_t* __restrict__ w_bf, int ldw,
+                                                               const float* __restrict__ b_hh, const int64_t* __restrict__ seq_len,
+                                                               int B, int T, int H, int R, float* __restrict__ hstate,
+                                                               float* __restrict__ cstate, uint16_t* __restrict__ hstate_bf,
+                                                               float* __restrict__ out, float* __restrict__ saved, unsigned* sync,
+                                                               uint16_t* ring, int force_sc1) {
+    __shared__ float red[4][4][MT][GT * GT];
+    __shared__ __attribute__((aligned(16))) uint16_t hb[MT][GT][GT];
+    __shared__ float res[MT][7][GT * GT];          // h, c, out, i, f, g, o of the step for waves 2 and 3, which store them
+    __shared__ int s_abort, s_xcd;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    const int group = blockIdx.x % GP_GROUPS, slot = blockIdx.x / GP_GROUPS;
+    const int n_slots = H / GT;
+    const int row0 = group * R;
+    const int nrows = min(R, B - row0);
+    if (slot >= n_slots || nrows <= 0) return;
+    const int j0 = slot * GT;
+    gu32* flags = (gu32*)sync + group * GP_SLOTS;
+    gu32* status = (gu32*)sync + GP_FLAG_WORDS;
+    if (tid == 0) s_abort = 0;
+    const int one_xcd = force_sc1 ? 0 : gp_group_on_one_xcd((gu32*)sync + GP_GROUPS * GP_SLOTS + group * GP_SLOTS, slot, n_slots, tid, &s_xcd);
+    if (one_xcd < 0) {
+        if (tid == 0) __hip_atomic_store(status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    int gmax = 0;
+    for (int r = 0; r < nrows; ++r) {
+        const int64_t n = seq_len ? seq_len[row0 + r] : (int64_t)T;
+        gmax = max(gmax, (int)(n < T ? n : T));
+    }
+    // W_hh fragments of this slot (4 gates x 16 units), for the whole launch
+    const int kbase = wave * (H / 4) + 8 * q;
+    gbf8 fw[4][KS];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint16_t* wp = w_bf + ((size_t)g * H + j0 + li) * ldw + kbase;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) fw[g][i] = *reinterpret_cast<const gbf8*>(wp + 32 * i);
+    }
+    // ring of h tiles: [2 (epoch parity)][8 groups][H / 16 slots][R items][16 units] bf16 (as in gru_persist.hip)
+    const unsigned par_bytes = (unsigned)(GP_GROUPS * n_slots * R * 32);
+    const auto rs_ring = __builtin_amdgcn_make_buffer_rsrc((void*)ring, 0, (int)(2 * par_bytes), 0x00020000);
+    const unsigned rd_base = (unsigned)(((group * n_slots + (kbase >> 4)) * R) * 32 + 16 * (q & 1));
+    const unsigned rd_kstep = (unsigned)(2 * R * 32);
+    const unsigned wr_base = (unsigned)(((group * n_slots + slot) * R) * 32);
+
+    const int bl = tid >> 4, jl = tid & 15;
+    const int j = j0 + jl;
+    float bh[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bh[g] = b_hh[g * H + j];
+    float hprev[MT], cprev[MT], xg[MT][4];
+    int len[MT];
+    bool mine[MT];
+    const float* xp[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        mine[m] = 16 * m + bl < nrows;
+        const int b = row0 + (mine[m] ? 16 * m + bl : 0);
+        hprev[m] = hstate[((size_t)b * (T + 1)) * H + j];
+        cprev[m] = cstate[((size_t)b * (T + 1)) * H + j];
+        len[m] = seq_len ? (int)min((int64_t)T, seq_len[b]) : T;
+        hb[m][bl][jl] = mg_f2bf(hprev[m]);
+        xp[m] = xproj + (size_t)b * T * 4 * H + j;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xg[m][g] = xp[m][g * H];          // step 0; step t + 1's are requested during step t
+    }
+    __syncthreads();
+
+    // wave 0 publishes the tile in hb as epoch e (state h_e), then raises the slot's flag to e + 1; wave 1 writes the bf16 shadow
+    auto publish = [&](int e) {
+        if (wave <= 1 && lane < 2 * 16 * MT) {
+            const int rrow = lane >> 1, half = lane & 1;
+            if (rrow < nrows) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(&hb[rrow >> 4][rrow & 15][8 * half]);
+                if (wave == 0) {
+                    const unsigned off = (e & 1) * par_bytes + wr_base + (unsigned)(rrow * 32 + half * 16);
+                    if (one_xcd)
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 0);
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 16);
+                } else if (e > 0) {
+                    *reinterpret_cast<u32x4*>(hstate_bf + ((size_t)(row0 + rrow) * (T + 1) + e) * H + j0 + 8 * half) = v;
+                }
+            }
+        }
+        if (wave == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) gp_store_flag(flags + slot, (unsigned)(e + 1), one_xcd);
+        }
+    };
+    publish(0);
+
+    for (int t = 0; t < gmax; ++t) {
+        if (wave == 0 && !gp_wait_flags(flags, n_slots, (unsigned)(t + 1), lane)) s_abort = 1;
+        gp_lds_barrier();
+        if (s_abort) {
+            if (tid == 0) __hip_atomic_store(status, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        u32x4 raw[MT][KS];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const bool valid = 16 * m + li < nrows;
+            const unsigned off = (t & 1) * par_bytes + rd_base + (unsigned)((valid ? 16 * m + li : 0) * 32);
+#pragma unroll
+            for (int i = 0; i < KS; ++i) raw[m][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ring, off + i * rd_kstep, 0, 16);
+        }
+        float xg1[MT][4];
+        const int t1 = t + 1 < T ? t + 1 : t;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xg1[m][g] = xp[m][(size_t)t1 * 4 * H + g * H];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < KS; ++i) {
+                const gbf8 a = as_bf8(raw[m][i]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, fw[g][i], acc[g], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = (4 * q + r) * GT + li;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) red[wave][g][m][e] = acc[g][r];
+            }
+        }
+        gp_lds_barrier();
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int e = bl * GT + jl;
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                pre[g] = xg[m][g] + (((red[0][g][m][e] + red[1][g][m][e]) + (red[2][g][m][e] + red[3][g][m][e])) + bh[g]);
+            const float ig = mg_sigmoid_fast(pre[0]), fg = mg_sigmoid_fast(pre[1]), gg = lp_tanh_fast(pre[2]), og = mg_sigmoid_fast(pre[3]);
+            const float cnew = fg * cprev[m] + ig * gg;
+            const float hnew = og * lp_tanh_fast(cnew);
+            const bool active = t < len[m];
+            hprev[m] = active ? hnew : hprev[m];
+            cprev[m] = active ? cnew : cprev[m];
+            hb[m][bl][jl] = mg_f2bf(hprev[m]);
+            res[m][0][e] = hprev[m];
+            res[m][1][e] = cprev[m];
+            res[m][2][e] = active ? hnew : 0.f;
+            res[m][3][e] = ig;
+            res[m][4][e] = fg;
+            res[m][5][e] = gg;
+            res[m][6][e] = og;
+        }
+        gp_lds_barrier();
+        publish(t + 1);
+        if (wave >= 2) {                                // fp32 results: waves 2 and 3 only (their stores are off wave 0's queue)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int e = (tid - 128) + 128 * half, rb = e >> 4, cj = j0 + (e & 15);
+                    if (16 * m + rb < nrows) {
+                        const int b = row0 + 16 * m + rb;
+                        const size_t row = (size_t)b * T + t;
+                        const size_t nxt = ((size_t)b * (T + 1) + t + 1) * H + cj;
+                        hstate[nxt] = res[m][0][e];
+                        cstate[nxt] = res[m][1][e];
+                        out[row * H + cj] = res[m][2][e];
+                        float* sv = saved + row * 4 * H + cj;
+                        sv[0] = res[m][3][e];
+                        sv[H] = res[m][4][e];
+                        sv[2 * H] = res[m][5][e];
+                        sv[3 * H] = res[m][6][e];
+                    }
+                }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xg[m][g] = xg1[m][g];
+    }
+    // beyond the group's longest sequence: states frozen, outputs zero - no matmul, no hand-off
+    for (int t = gmax; t < T; ++t) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            if (mine[m]) {
+                const int b = row0 + 16 * m + bl;
+                const size_t row = (size_t)b * T + t;
+                const size_t nxt = ((size_t)b * (T + 1) + t + 1) * H + j;
+                hstate[nxt] = hprev[m];
+                cstate[nxt] = cprev[m];
+                hstate_bf[nxt] = mg_f2bf(hprev[m]);
+                out[row * H + j] = 0.f;
+                float* sv = saved + row * 4 * H;
+                sv[j] = 0.f;
+                sv[H + j] = 0.f;
+                sv[2 * H + j] = 0.f;
+                sv[3 * H + j] = 0.f;
+            }
+    }
+}
+
+// Backward.  Slot s owns d h[:, 16 s .. + 16): per step t (T-1 .. 0, then t = -1 for dh0 / dc0) it needs dgates_{t+1} of the whole
+// group (R x 4H bf16, the hand-off), contracts it with its 16 rows of W_hh^T (16 x 4H bf16 = 64 VGPRs per lane at H = 512),
+// applies the cell derivatives and publishes its 4 x 16 columns of dgates_t.  carry_h (the part of d h_{t-1} that does not go
+// through the matmul: only where the item was frozen) and carry_c stay in registers.  Flag of a slot = gmax - t once row t is
+// published.  Ring: [2 (t parity)][8 groups][H / 16 slots][4 gates][R items][16 units] bf16.
+template <int MT, int KS>
+__global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(const float* __restrict__ grad_out, const float* __restrict__ grad_hn,
+                                                               const float* __restrict__ grad_cn, const float* __restrict__ cstate,
+                                                               const float* __restrict__ saved, const uint16_t* __restrict__ wt_bf, int ldt,
+                                                               const int64_t* __restrict__ seq_len, int B, int T, int H, int R,
+                                                               float* __restrict__ dgates, uint16_t* __restrict__ dgates_bf,
+                                                               float* __restrict__ dh0, float* __restrict__ dc0, unsigned* sync,
+                                                               uint16_t* ring, int force_sc1) {
+    __shared__ float red[4][MT][GT * GT];
+    __shared__ __attribute__((aligned(16))) uint16_t pub[4][MT * GT][GT];
+    __shared__ float res[MT][4][GT * GT];
+    __shared__ int s_abort, s_xcd;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    const int group = blockIdx.x % GP_GROUPS, slot = blockIdx.x / GP_GROUPS;
+    const int n_slots = H / GT;
+    const int row0 = group * R;
+    const int nrows = min(R, B - row0);
+    if (slot >= n_slots || nrows <= 0) return;
+    const int j0 = slot * GT;
+    const int G = 4 * H;
+    gu32* flags = (gu32*)sync + group * GP_SLOTS;
+    gu32* status = (gu32*)sync + GP_FLAG_WORDS;
+    if (tid == 0) s_abort = 0;
+    const int one_xcd = force_sc1 ? 0 : gp_group_on_one_xcd((gu32*)sync + GP_GROUPS * GP_SLOTS + group * GP_SLOTS, slot, n_slots, tid, &s_xcd);
+    if (one_xcd < 0) {
+        if (tid == 0) __hip_atomic_store(status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    int gmax = 0;
+    for (int r = 0; r < nrows; ++r) {
+        const int64_t n = seq_len ? seq_len[row0 + r] : (int64_t)T;
+        gmax = max(gmax, (int)(n < T ? n : T));
+    }
+    const int gbase = wave * (G / 4) + 8 * q;           // = wave * H + 8 q: wave w contracts over gate w
+    gbf8 fb[KS];
+    unsigned rd_off[KS];
+    {
+        const uint16_t* wp = wt_bf + (size_t)(j0 + li) * ldt + gbase;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            fb[i] = *reinterpret_cast<const gbf8*>(wp + 32 * i);
+            const int g = gbase + 32 * i, gate = g / H, col = g - gate * H;
+            rd_off[i] = (unsigned)((((group * n_slots + (col >> 4)) * 4 + gate) * R) * 32 + 16 * (q & 1));
+        }
+    }
+    const unsigned par_bytes = (unsigned)(GP_GROUPS * n_slots * R * 128);
+    const auto rs_ring = __builtin_amdgcn_make_buffer_rsrc((void*)ring, 0, (int)(2 * par_bytes), 0x00020000);
+    const unsigned wr_base = (unsigned)(((group * n_slots + slot) * R) * 128);
+
+    const int bl = tid >> 4, jl = tid & 15;
+    const int j = j0 + jl;
+    float carry_h[MT], carry_c[MT];
+    int len[MT];
+    bool mine[MT];
+    const float *p_sv[MT], *p_c[MT], *p_g[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        mine[m] = 16 * m + bl < nrows;
+        const int b = row0 + (mine[m] ? 16 * m + bl : 0);
+        carry_h[m] = grad_hn ? grad_hn[(size_t)b * H + j] : 0.f;
+        carry_c[m] = grad_cn ? grad_cn[(size_t)b * H + j] : 0.f;
+        len[m] = seq_len ? (int)min((int64_t)T, seq_len[b]) : T;
+        p_sv[m] = saved + (size_t)b * T * 4 * H + j;
+        p_c[m] = cstate + (size_t)b * (T + 1) * H + j;
+        p_g[m] = grad_out + (size_t)b * T * H + j;
+    }
+    for (int t = T - 1; t >= gmax; --t) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            if (mine[m]) {
+                const size_t row = (size_t)(row0 + 16 * m + bl) * T + t;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    dgates[row * G + g * H + j] = 0.f;
+                    dgates_bf[row * G + g * H + j] = 0;
+                }
+            }
+    }
+    constexpr int PIECES = (8 * GT * MT + 63) / 64;
+    bool pc_ok[PIECES];
+    int pc_lds[PIECES];
+    size_t pc_shadow[PIECES];
+#pragma unroll
+    for (int k = 0; k < PIECES; ++k) {
+        const int pc = lane + 64 * k, gate = pc / (2 * R), rem = pc - gate * 2 * R, rrow = rem >> 1, half = rem & 1;
+        pc_ok[k] = gate < 4 && rrow < nrows;
+        pc_lds[k] = (gate * MT * GT + rrow) * GT + 8 * half;
+        pc_shadow[k] = (size_t)(row0 + rrow) * T * G + gate * H + j0 + 8 * half;
+    }
+    // cell operands of step gmax - 1 (c_new of a step is c_prev of the step after it: carried over in a register)
+    float s_g4[MT][4], c_prev[MT], c_new[MT], gout[MT];
+    {
+        const int t0 = gmax > 0 ? gmax - 1 : 0;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) s_g4[m][g] = p_sv[m][(size_t)t0 * 4 * H + g * H];
+            c_prev[m] = p_c[m][(size_t)t0 * H];
+            c_new[m] = p_c[m][(size_t)(t0 + 1) * H];
+            gout[m] = p_g[m][(size_t)t0 * H];
+        }
+    }
+    __syncthreads();
+
+    for (int t = gmax - 1; t >= -1; --t) {
+        const bool need_mm = t + 1 < gmax;
+        u32x4 raw[MT][KS];
+        if (need_mm) {
+            if (wave == 0 && !gp_wait_flags(flags, n_slots, (unsigned)(gmax - t - 1), lane)) s_abort = 1;
+            gp_lds_barrier();
+            if (s_abort) {
+                if (tid == 0) __hip_atomic_store(status, 5u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const bool valid = 16 * m + li < nrows;
+                const unsigned off = ((t + 1) & 1) * par_bytes + (unsigned)((valid ? 16 * m + li : 0) * 32);
+#pragma unroll
+                for (int i = 0; i < KS; ++i) raw[m][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ring, off + rd_off[i], 0, 16);
+            }
+        }
+        float s_g41[MT][4], c_prev1[MT], gout1[MT];
+        {
+            const int t1 = t > 0 ? t - 1 : 0;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) s_g41[m][g] = p_sv[m][(size_t)t1 * 4 * H + g * H];
+                c_prev1[m] = p_c[m][(size_t)t1 * H];
+                gout1[m] = p_g[m][(size_t)t1 * H];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (need_mm) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                f32x4 acc4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int i = 0; i < KS; ++i)
+                    acc4[i % 4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(raw[m][i]), fb[i], acc4[i % 4], 0, 0, 0);
+                const f32x4 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave][m][(4 * q + r) * GT + li] = acc[r];
+            }
+            gp_lds_barrier();
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int e = bl * GT + jl;
+            const float dh_state = need_mm ? carry_h[m] + ((red[0][m][e] + red[1][m][e]) + (red[2][m][e] + red[3][m][e])) : carry_h[m];
+            float di = 0.f, df = 0.f, dg = 0.f, d_o = 0.f, ch = dh_state, cc = carry_c[m];
+            if (t >= 0 && t < len[m]) {
+                const float s_i = s_g4[m][0], s_f = s_g4[m][1], s_g = s_g4[m][2], s_o = s_g4[m][3];
+                const float dh = dh_state + gout[m];
+                const float tc = lp_tanh_fast(c_new[m]);
+                const float dc = carry_c[m] + dh * s_o * (1.f - tc * tc);
+                di = dc * s_g * s_i * (1.f - s_i);
+                df = dc * c_prev[m] * s_f * (1.f - s_f);
+                dg = dc * s_i * (1.f - s_g * s_g);
+                d_o = dh * tc * s_o * (1.f - s_o);
+                ch = 0.f;                 // all of dh_{t-1} comes through the matmul with the gates of this step
+                cc = dc * s_f;
+            }
+            carry_h[m] = ch;
+            carry_c[m] = cc;
+            res[m][0][e] = di;
+            res[m][1][e] = df;
+            res[m][2][e] = dg;
+            res[m][3][e] = d_o;
+            pub[0][16 * m + bl][jl] = mg_f2bf(di);
+            pub[1][16 * m + bl][jl] = mg_f2bf(df);
+            pub[2][16 * m + bl][jl] = mg_f2bf(dg);
+            pub[3][16 * m + bl][jl] = mg_f2bf(d_o);
+        }
+        if (t < 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                if (mine[m]) {
+                    dh0[(size_t)(row0 + 16 * m + bl) * H + j] = carry_h[m];
+                    dc0[(size_t)(row0 + 16 * m + bl) * H + j] = carry_c[m];
+                }
+            break;
+        }
+        gp_lds_barrier();
+        if (wave <= 1) {
+#pragma unroll
+            for (int k = 0; k < PIECES; ++k) {
+                if (pc_ok[k]) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(&pub[0][0][0] + pc_lds[k]);
+                    if (wave == 0) {
+                        const unsigned off = (t & 1) * par_bytes + wr_base + (unsigned)((lane + 64 * k) * 16);
+                        if (one_xcd)
+                            __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 0);
+                        else
+                            __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 16);
+                    } else {
+                        *reinterpret_cast<u32x4*>(dgates_bf + pc_shadow[k] + (size_t)t * G) = v;
+                    }
+                }
+            }
+            if (wave == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) gp_store_flag(flags + slot, (unsigned)(gmax - t), one_xcd);
+            }
+        }
+        if (wave >= 2) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int e = (tid - 128) + 128 * half, rb = e >> 4, cj = j0 + (e & 15);
+                    if (16 * m + rb < nrows) {
+                        float* dgp = dgates + ((size_t)(row0 + 16 * m + rb) * T + t) * G + cj;
+                        dgp[0] = res[m][0][e];
+                        dgp[H] = res[m][1][e];
+                        dgp[2 * H] = res[m][2][e];
+                        dgp[3 * H] = res[m][3][e];
+                    }
+                }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) s_g4[m][g] = s_g41[m][g];
+            c_new[m] = c_prev[m];
+            c_prev[m] = c_prev1[m];
+            gout[m] = gout1[m];
+        }
+    }
+}
+
+extern "C" {
+
+int mg_lstm_persist_supported(int B, int T, int H) {
+    if (B <= 0 || T <= 0 || H <= 0) return 0;
+    if (H % 128 != 0 || H > 128 * GP_KSTEPS) return 0;
+    if (mg_ceil_div(B, GP_GROUPS) > 32) return 0;
+    return 1;
+}
+
+int mg_lstm_fwd_persist_bf16(const float* xproj, const uint16_t* w_hh_bf, int ldw, const float* b_hh, const int64_t* seq_len, int B, int T,
+                             int H, float* hstate, float* cstate, uint16_t* hstate_bf, float* out, float* saved, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    MG_CHECK_ARG(xproj && w_hh_bf && b_hh && hstate && cstate && hstate_bf && out && saved && B > 0 && T > 0 && H > 0,
+                 "mg_lstm_fwd_persist_bf16: bad arguments (B=%d T=%d H=%d)", B, T, H);
+    MG_CHECK_ARG(mg_lstm_persist_supported(B, T, H) && ldw >= H && ldw % 8 == 0,
+                 "mg_lstm_fwd_persist_bf16: unsupported shape (B=%d T=%d H=%d ldw=%d): needs H %% 128 == 0, H <= 512, B <= 256", B, T, H, ldw);
+    MG_CHECK_ARG((((uintptr_t)w_hh_bf | (uintptr_t)hstate_bf | (uintptr_t)workspace) % 16) == 0,
+                 "mg_lstm_fwd_persist_bf16: bf16 buffers and workspace must be 16-byte aligned");
+    if (!workspace || workspace_bytes < mg_gru_persist_workspace_bytes(B, H)) {
+        mg_set_error("mg_lstm_fwd_persist_bf16: workspace of %zu bytes needed, got %zu", mg_gru_persist_workspace_bytes(B, H), workspace_bytes);
+        return MG_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(workspace, 0, (size_t)GP_FLAG_WORDS * sizeof(unsigned), st) != hipSuccess) {
+        mg_set_error("mg_lstm_fwd_persist_bf16: memset failed");
+        return MG_ELAUNCH;
+    }
+    const int R = (int)mg_ceil_div(B, GP_GROUPS);
+    const unsigned grid = (unsigned)(GP_GROUPS * (H / GT));
+#define LP_FWD(MT, KS)                                                                                                                          \
+    hipLaunchKernelGGL((lstm_fwd_persist_kernel<MT, KS>), dim3(grid), dim3(256), 0, st, xproj, w_hh_bf, ldw, b_hh, seq_len, B, T, H, R, hstate, \
+                       cstate, hstate_bf, out, saved, (unsigned*)workspace, (uint16_t*)((char*)workspace + GP_RING_OFFSET),                   \
+                       g_mg_tuning[MG_TUNE_GRU_HANDOFF] == 1)
+#define LP_FWD_KS(MT)                 \
+    switch (H / 128) {                \
+        case 1: LP_FWD(MT, 1); break; \
+        case 2: LP_FWD(MT, 2); break; \
+        case 3: LP_FWD(MT, 3); break; \
+        default: LP_FWD(MT, 4); break; \
+    }
+    if (R <= 16) {
+        LP_FWD_KS(1)
+    } else {
+        LP_FWD_KS(2)
+    }
+    MG_CHECK_LAUNCH("mg_lstm_fwd_persist_bf16");
+    return MG_OK;
+}
+
+int mg_lstm_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const float* grad_cn, const float* cstate, const float* saved,
+                             const uint16_t* w_hh_t_bf, int ldt, const int64_t* seq_len, int B, int T, int H, float* dgates,
+                             uint16_t* dgates_bf, float* dh0, float* dc0, void* workspace, size_t workspace_bytes, void* stream) {
+    MG_CHECK_ARG(grad_out && cstate && saved && w_hh_t_bf && dgates && dgates_bf && dh0 && dc0 && B > 0 && T > 0 && H > 0,
+                 "mg_lstm_bwd_persist_bf16: bad arguments (B=%d T=%d H=%d)", B, T, H);
+    MG_CHECK_ARG(mg_lstm_persist_supported(B, T, H) && ldt >= 4 * H && ldt % 8 == 0,
+                 "mg_lstm_bwd_persist_bf16: unsupported shape (B=%d T=%d H=%d ldt=%d): needs H %% 128 == 0, H <= 512, B <= 256", B, T, H, ldt);
+    MG_CHECK_ARG((((uintptr_t)w_hh_t_bf | (uintptr_t)dgates_bf | (uintptr_t)workspace) % 16) == 0,
+                 "mg_lstm_bwd_persist_bf16: bf16 buffers and workspace must be 16-byte aligned");
+    if (!workspace || workspace_bytes < mg_gru_persist_workspace_bytes(B, H)) {
+        mg_set_error("mg_lstm_bwd_persist_bf16: workspace of %zu bytes needed, got %zu", mg_gru_persist_workspace_bytes(B, H), workspace_bytes);
+        return MG_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(workspace, 0, (size_t)GP_FLAG_WORDS * sizeof(unsigned), st) != hipSuccess) {
+        mg_set_error("mg_lstm_bwd_persist_bf16: memset failed");
+        return MG_ELAUNCH;
+    }
+    const int R = (int)mg_ceil_div(B, GP_GROUPS);
+    const unsigned grid = (unsigned)(GP_GROUPS * (H / GT));
+#define LP_BWD(MT, KS)                                                                                                                        \
+    hipLaunchKernelGGL((lstm_bwd_persist_kernel<MT, KS>), dim3(grid), dim3(256), 0, st, grad_out, grad_hn, grad_cn, cstate, saved, w_hh_t_bf, ldt, \
+                       seq_len, B, T, H, R, dgates, dgates_bf, dh0, dc0, (unsigned*)workspace,                                              \
+                       (uint16_t*)((char*)workspace + GP_RING_OFFSET), g_mg_tuning[MG_TUNE_GRU_HANDOFF] == 1)
+#define LP_BWD_KS(MT)                   \
+    switch (H / 128) {                  \
+        case 1: LP_BWD(MT, 4); break;   \
+        case 2: LP_BWD(MT, 8); break;   \
+        case 3: LP_BWD(MT, 12); break;  \
+        default: LP_BWD(MT, 16); break; \
+    }
+    if (R <= 16) {
+        LP_BWD_KS(1)
+    } else {
+        LP_BWD_KS(2)
+    }
+    MG_CHECK_LAUNCH("mg_lstm_bwd_persist_bf16");
+    return MG_OK;
+}
+
+}  // extern "C"

@@ -352,6 +352,11 @@ class GRUFn(torch.autograd.Function):
         return (None, dx, dh0.view(1, b, hid) if ctx.has_h0 else None, None, dw_ih, dw_hh, db_ih, db_hh)
 
 
+def lstm_persistent(precision, b, t, hid):
+    """bf16 mode runs an LSTM layer as two persistent launches (csrc/lstm_persist.hip) when the shape is covered."""
+    return precision == 'bf16' and RECURRENCE_BF16 and ops.lstm_persist_ok(b, t, hid)
+
+
 class LSTMFn(torch.autograd.Function):
     """One LSTM layer (batch_first) restricted to seq_len[b] steps per item; returns (outputs, h_n, c_n)."""
 
@@ -370,23 +375,33 @@ class LSTMFn(torch.autograd.Function):
                                         ops.ACT_NONE, out_f32=True)
             if xproj.shape[1] != 4 * hid:
                 xproj = xproj[:, :4 * hid].contiguous()
-        out, hstate, cstate, saved = ops.lstm_fwd(xproj.view(b, t, 4 * hid), w_hh.contiguous(), b_hh.contiguous(), seq_len,
-                                                  h0, c0, b, t, hid)
+        ctx.persistent = lstm_persistent(precision, b, t, hid)
+        hstate_bf = None
+        if ctx.persistent:
+            out, hstate, cstate, saved, hstate_bf = ops.lstm_fwd_bf16(xproj.view(b, t, 4 * hid), w_hh.contiguous(), b_hh.contiguous(),
+                                                                      seq_len, h0, c0, b, t, hid)
+        else:
+            out, hstate, cstate, saved = ops.lstm_fwd(xproj.view(b, t, 4 * hid), w_hh.contiguous(), b_hh.contiguous(), seq_len,
+                                                      h0, c0, b, t, hid)
         ctx.precision = precision
         ctx.shape = (b, t, i_dim, hid)
         ctx.has_h0, ctx.has_c0 = h0 is not None, c0 is not None
-        ctx.save_for_backward(x_saved, seq_len, w_ih, w_hh, hstate, cstate, saved)
+        ctx.save_for_backward(x_saved, seq_len, w_ih, w_hh, hstate, cstate, saved, hstate_bf)
         return out, hstate[:, t].unsqueeze(0).contiguous(), cstate[:, t].unsqueeze(0).contiguous()
 
     @staticmethod
     def backward(ctx, grad_out, grad_hn, grad_cn):
-        x_saved, seq_len, w_ih, w_hh, hstate, cstate, saved = ctx.saved_tensors
+        x_saved, seq_len, w_ih, w_hh, hstate, cstate, saved, hstate_bf = ctx.saved_tensors
         b, t, i_dim, hid = ctx.shape
         dev = hstate.device
         g_out = grad_out.contiguous() if grad_out is not None else torch.zeros((b, t, hid), dtype=torch.float32, device=dev)
         g_hn = grad_hn.reshape(b, hid).contiguous() if grad_hn is not None else None
         g_cn = grad_cn.reshape(b, hid).contiguous() if grad_cn is not None else None
-        dgates, dh0, dc0 = ops.lstm_bwd(g_out, g_hn, g_cn, cstate, saved, w_hh, seq_len, b, t, hid)
+        dgates_bf = None
+        if ctx.persistent:
+            dgates, dh0, dc0, dgates_bf = ops.lstm_bwd_bf16(g_out, g_hn, g_cn, cstate, saved, w_hh, seq_len, b, t, hid)
+        else:
+            dgates, dh0, dc0 = ops.lstm_bwd(g_out, g_hn, g_cn, cstate, saved, w_hh, seq_len, b, t, hid)
         m = b * t
         dg2 = dgates.view(m, 4 * hid)
         prev_rows = (torch.arange(b, device=dev, dtype=torch.int32)[:, None] * (t + 1) +
@@ -400,9 +415,11 @@ class LSTMFn(torch.autograd.Function):
             if need_x:
                 dx = ops.linear_dgrad_f32(dg2, w_ih, None).view(b, t, i_dim)
         else:
-            dg_bf = ops.cast_pad_bf16(dg2)
+            # the persistent recurrence already wrote the bf16 shadows of the gate gradients and of the states
+            dg_bf = dgates_bf.view(m, 4 * hid) if dgates_bf is not None else ops.cast_pad_bf16(dg2)
+            hs_bf = hstate_bf.view(b * (t + 1), hid) if hstate_bf is not None else ops.cast_pad_bf16(hs2)
             dw_ih, db = ops.linear_wgrad_bf16(dg_bf, x_saved, None, m, 4 * hid, i_dim)
-            dw_hh, _ = ops.linear_wgrad_bf16(dg_bf, ops.cast_pad_bf16(hs2), prev_rows, m, 4 * hid, hid, want_bias=False)
+            dw_hh, _ = ops.linear_wgrad_bf16(dg_bf, hs_bf, prev_rows, m, 4 * hid, hid, want_bias=False)
             if need_x:
                 dx = ops.linear_dgrad_bf16(dg_bf, m, 4 * hid, ops.cast_transpose_bf16(w_ih), i_dim, None, out_f32=True)
                 if dx.shape[1] != i_dim:

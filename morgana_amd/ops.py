@@ -567,6 +567,49 @@ def lstm_bwd(grad_out, grad_hn, grad_cn, cstate, saved, w_hh, seq_len, b, t, h):
     return dgates, dh0, dc0
 
 
+def lstm_persist_ok(b, t, h):
+    """The one-launch bf16-operand LSTM recurrence covers this shape (include/morgana_hip.h: mg_lstm_fwd_persist_bf16)."""
+    return PERSISTENT_RECURRENCE and bool(_lib.load().mg_lstm_persist_supported(b, t, h))
+
+
+def lstm_fwd_bf16(xproj, w_hh, b_hh, seq_len, h0, c0, b, t, h):
+    """lstm_fwd with bf16 matmul operands, one persistent launch.  Returns (out, hstate, cstate, saved, hstate_bf)."""
+    lib = _lib.load()
+    dev = xproj.device
+    hstate = torch.empty((b, t + 1, h), dtype=torch.float32, device=dev)
+    cstate = torch.empty((b, t + 1, h), dtype=torch.float32, device=dev)
+    hstate_bf = torch.empty((b, t + 1, h), dtype=torch.bfloat16, device=dev)
+    for state, init in ((hstate, h0), (cstate, c0), (hstate_bf, h0)):
+        if init is None:
+            state[:, 0].zero_()
+        else:
+            state[:, 0].copy_(init.reshape(b, h))
+    w_bf = cast_pad_bf16(w_hh)
+    out = torch.empty((b, t, h), dtype=torch.float32, device=dev)
+    saved = torch.empty((b, t, 4 * h), dtype=torch.float32, device=dev)
+    ws = _persist_workspace(dev, b, h)
+    _lib.check(lib.mg_lstm_fwd_persist_bf16(_p(xproj), _p(w_bf), w_bf.shape[1], _p(b_hh), _p(seq_len), b, t, h, _p(hstate), _p(cstate),
+                                            _p(hstate_bf), _p(out), _p(saved), _p(ws), ws.numel(), _stream()),
+               'mg_lstm_fwd_persist_bf16')
+    return out, hstate, cstate, saved, hstate_bf
+
+
+def lstm_bwd_bf16(grad_out, grad_hn, grad_cn, cstate, saved, w_hh, seq_len, b, t, h):
+    """lstm_bwd with bf16 matmul operands, one persistent launch.  Returns (dgates, dh0, dc0, dgates_bf)."""
+    lib = _lib.load()
+    dev = grad_out.device
+    dgates = torch.empty((b, t, 4 * h), dtype=torch.float32, device=dev)
+    dgates_bf = torch.empty((b, t, 4 * h), dtype=torch.bfloat16, device=dev)
+    dh0 = torch.empty((b, h), dtype=torch.float32, device=dev)
+    dc0 = torch.empty((b, h), dtype=torch.float32, device=dev)
+    wt_bf = cast_transpose_bf16(w_hh)                              # (h, 4h)
+    ws = _persist_workspace(dev, b, h)
+    _lib.check(lib.mg_lstm_bwd_persist_bf16(_p(grad_out), _p(grad_hn), _p(grad_cn), _p(cstate), _p(saved), _p(wt_bf), wt_bf.shape[1],
+                                            _p(seq_len), b, t, h, _p(dgates), _p(dgates_bf), _p(dh0), _p(dc0), _p(ws), ws.numel(),
+                                            _stream()), 'mg_lstm_bwd_persist_bf16')
+    return dgates, dh0, dc0, dgates_bf
+
+
 def lstm_stack_fwd(descs, n_layers, seq_len, b, t, h, lag, s_begin, s_end):
     lib = _lib.load()
     _lib.check(lib.mg_lstm_stack_fwd_f32(ctypes.cast(descs, ctypes.c_void_p), n_layers, _p(seq_len), b, t, h, lag, s_begin, s_end,

@@ -186,6 +186,15 @@ class RecurrentCuDNNWrapper(nn.Module):
         if layer.num_layers == 1:
             out, hn, cn = F_hip.LSTMFn.apply(precision, inputs.contiguous(), h0s, c0s, seq_len, *self._lstm_params())
             return out, (hn, cn)
+        if F_hip.lstm_persistent(precision, inputs.shape[0], inputs.shape[1], layer.hidden_size):
+            # persistent recurrence: a layer is two launches, so the layers simply follow each other
+            params, out, hns, cns = self._lstm_params(), inputs.contiguous(), [], []
+            for k in range(layer.num_layers):
+                out, hn, cn = F_hip.LSTMFn.apply(precision, out, None if h0s is None else h0s[k:k + 1],
+                                                 None if c0s is None else c0s[k:k + 1], seq_len, *params[4 * k:4 * k + 4])
+                hns.append(hn)
+                cns.append(cn)
+            return out, (torch.cat(hns, 0), torch.cat(cns, 0))
         out, hn, cn = F_hip.LSTMStackFn.apply(precision, F_hip.LSTM_STACK_LAG, inputs.contiguous(), seq_len, h0s, c0s,
                                               *self._lstm_params())
         return out, (hn, cn)
@@ -368,8 +377,10 @@ class SequentialWithRecurrent(nn.Sequential):
 
             if isinstance(module, RecurrentCuDNNWrapper):
                 end, run = self._lstm_run(modules, i, hiddens, seq_len)
-                if len(run) > 1:
-                    # consecutive single-layer LSTM wrappers (models/RNN_SPSS.py:36-37): one time-skewed stack
+                hid = modules[run[0]].layer.hidden_size if run else 0
+                if len(run) > 1 and not F_hip.lstm_persistent(precision, input.shape[0], input.shape[1], hid):
+                    # consecutive single-layer LSTM wrappers (models/RNN_SPSS.py:36-37): one time-skewed stack (per-step
+                    # launches); with the persistent recurrence each wrapper is two launches and runs on its own below
                     params = []
                     for k in run:
                         params += modules[k]._lstm_params()

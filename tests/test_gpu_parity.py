@@ -767,6 +767,58 @@ def test_gru_persistent_equals_stepwise(b, t, hid, gru_handoff):
                     np.testing.assert_array_equal(g.float().cpu().numpy(), w.float().cpu().numpy(), err_msg='%s rep %d' % (name, rep))
 
 
+@pytest.mark.parametrize('b,t,hid', [(64, 40, 512), (5, 37, 128), (33, 20, 256), (200, 9, 128)])
+def test_lstm_persistent_vs_fp32_and_between_handoff_forms(b, t, hid):
+    """The one-launch LSTM recurrence (csrc/lstm_persist.hip, bf16 matmul operands) against the exact-fp32 per-step kernels on
+    the same inputs at 1e-2 relative (operand rounding 2^-9 per product, fp32 accumulation and cell), forward and backward,
+    ragged lengths, initial states and gradients on the final states.  The hand-off protocol itself: the same-XCD form and
+    the forced write-through form must give IDENTICAL bits, and so must repeated runs (a stale hand-off would not repeat)."""
+    from morgana_amd import _lib
+    rng = np.random.RandomState(hid + b)
+    xproj = dev(rng.standard_normal((b, t, 4 * hid)).astype(np.float32))
+    w_hh = dev((rng.uniform(-1, 1, (4 * hid, hid)) / np.sqrt(hid)).astype(np.float32))
+    b_hh = dev(rng.uniform(-0.1, 0.1, 4 * hid).astype(np.float32))
+    h0 = dev(rng.standard_normal((b, hid)).astype(np.float32) * 0.5)
+    c0 = dev(rng.standard_normal((b, hid)).astype(np.float32) * 0.5)
+    sl_np = rng.randint(1, t + 1, size=b).astype(np.int64)
+    sl_np[0], sl_np[-1] = t, 1
+    sl = dev(sl_np)
+    live = (np.arange(t)[None, :] < sl_np[:, None])[:, :, None]
+    assert ops.lstm_persist_ok(b, t, hid)
+    want = ops.lstm_fwd(xproj, w_hh, b_hh, sl, h0, c0, b, t, hid)
+    g_out = dev(rng.standard_normal((b, t, hid)).astype(np.float32))
+    g_hn = dev(rng.standard_normal((b, hid)).astype(np.float32))
+    g_cn = dev(rng.standard_normal((b, hid)).astype(np.float32))
+    want_b = ops.lstm_bwd(g_out, g_hn, g_cn, want[2], want[3], w_hh, sl, b, t, hid)
+    first = None
+    try:
+        for mode in (0, 1, 0):
+            _lib.load().mg_set_tuning(2, mode)
+            got = ops.lstm_fwd_bf16(xproj, w_hh, b_hh, sl, h0, c0, b, t, hid)
+            # backward on the fp32 run's saved tensors, so that only the backward recurrence differs
+            got_b = ops.lstm_bwd_bf16(g_out, g_hn, g_cn, want[2], want[3], w_hh, sl, b, t, hid)
+            ops.check_persistent_status()
+            arrays = [a.float().cpu().numpy() for a in got + got_b]
+            if first is None:
+                first = arrays
+                for name, g, w in zip(('out', 'hstate', 'cstate', 'saved'), arrays[:4], want):
+                    w = w.cpu().numpy()
+                    if name == 'saved':
+                        g, w = g * live, w * live
+                    assert rel_err(g, w) < 1e-2, name
+                assert np.array_equal(arrays[4], got[1].to(torch.bfloat16).float().cpu().numpy())       # bf16 shadow of hstate
+                for i, n in enumerate(sl_np):
+                    assert np.all(arrays[0][i, n:] == 0)
+                for name, g, w in zip(('dgates', 'dh0', 'dc0'), arrays[5:8], want_b):
+                    assert rel_err(g, w.cpu().numpy()) < 1e-2, name
+                assert np.array_equal(arrays[8], got_b[0].to(torch.bfloat16).float().cpu().numpy())     # bf16 shadow of dgates
+            else:
+                for k, (g, w) in enumerate(zip(arrays, first)):
+                    np.testing.assert_array_equal(g, w, err_msg='array %d, hand-off mode %d' % (k, mode))
+    finally:
+        _lib.load().mg_set_tuning(2, 0)
+
+
 def test_gru_bf16_recurrence_rejects_bad_sizes():
     x = torch.zeros(2, 3, 3 * 96, device=DEV)
     assert not ops.gru_bf16_ok(96)
