@@ -298,6 +298,32 @@ int mg_lstm_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const 
                              float* dgates, uint16_t* dgates_bf, float* dh0, float* dc0, void* workspace, size_t workspace_bytes,
                              void* stream);
 
+/* A whole stack of L LSTM layers (2 <= L <= MG_LSTM_MAX_LAYERS, the 8 x nn.LSTM(512, 512) of models/RNN_SPSS.py:36-37) forward
+ * in ONE launch: a wavefront over (layer, time) - T + L - 1 dependent steps instead of L T.  Layer 0 takes xproj = x W_ih^T +
+ * b_ih [B,T,4H] from memory; the layers above compute their input projection inside the step from the hand-off tiles of the
+ * layer below (w_ih_bf = bf16(W_ih) [4H, ldwi], input size == H).  Per layer the outputs of mg_lstm_fwd_persist_bf16.
+ * mg_lstm_pstack_supported(B, T, H, L): H % 128 == 0, H <= 512 and L G H / 16 <= 512 workgroups for a group count G in
+ * {8, 4, 2, 1} with ceil(B / G) <= 32 (L = 8, H = 512: B <= 64).  All workgroups must be resident together, two per CU.
+ * The workspace (mg_lstm_pstack_workspace_bytes, zeroed once by the caller) carries the sticky status word at the same offset
+ * as the other persistent entry points (mg_gru_persist_status). */
+typedef struct {
+    const float* xproj;           /* layer 0 only */
+    const uint16_t* w_ih_bf;      /* layers >= 1 */
+    const float* b_ih;            /* layers >= 1 */
+    const uint16_t* w_hh_bf;
+    const float* b_hh;
+    float* hstate;                /* [B,T+1,H], slot 0 = h0 set by the caller */
+    float* cstate;                /* [B,T+1,H], slot 0 = c0 set by the caller */
+    uint16_t* hstate_bf;          /* [B,T+1,H] bf16 shadow, slot 0 set by the caller */
+    float* out;                   /* [B,T,H] */
+    float* saved;                 /* [B,T,4H] gate values i, f, g, o */
+    int ldwi, ldwh;
+} mg_lstm_pstack_layer;
+int mg_lstm_pstack_supported(int B, int T, int H, int L);
+size_t mg_lstm_pstack_workspace_bytes(int B, int H, int L);
+int mg_lstm_pstack_fwd_bf16(const mg_lstm_pstack_layer* layers, int L, const int64_t* seq_len, int B, int T, int H, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 /* LSTM through RecurrentCuDNNWrapper   reference: morgana/utils.py:345-393 + torch.nn.LSTM (gates i, f, g, o), the cell of
  * the reference's shipped acoustic model (models/RNN_SPSS.py:36-37).  Same conventions as the GRU entry points:
  *   xproj [B,T,4H] = x W_ih^T + b_ih; w_hh [4H,H]; b_hh [4H]; hstate / cstate [B,T+1,H] with slot 0 = (h0, c0) on entry;

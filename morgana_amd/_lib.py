@@ -91,6 +91,9 @@ SIGNATURES = {
     'mg_lstm_bwd_workspace_bytes': (c_size_t, [c_int, c_int]),
     'mg_lstm_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'mg_lstm_pstack_supported': (c_int, [c_int, c_int, c_int, c_int]),
+    'mg_lstm_pstack_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'mg_lstm_pstack_fwd_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'mg_lstm_stack_fwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'mg_lstm_stack_bwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'mg_adam_step_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
@@ -115,6 +118,13 @@ class LstmFwdLayer(ctypes.Structure):
     """mg_lstm_fwd_layer of include/morgana_hip.h."""
     _fields_ = [('xproj', c_void_p), ('x_T', c_int), ('x_t0', c_int), ('w_hh', c_void_p), ('b_hh', c_void_p),
                 ('hstate', c_void_p), ('cstate', c_void_p), ('out', c_void_p), ('saved', c_void_p)]
+
+
+class LstmPStackLayer(ctypes.Structure):
+    """mg_lstm_pstack_layer of include/morgana_hip.h."""
+    _fields_ = [('xproj', c_void_p), ('w_ih_bf', c_void_p), ('b_ih', c_void_p), ('w_hh_bf', c_void_p), ('b_hh', c_void_p),
+                ('hstate', c_void_p), ('cstate', c_void_p), ('hstate_bf', c_void_p), ('out', c_void_p), ('saved', c_void_p),
+                ('ldwi', c_int), ('ldwh', c_int)]
 
 
 class LstmBwdLayer(ctypes.Structure):

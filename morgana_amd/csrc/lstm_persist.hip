@@ -456,6 +456,315 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(const float* __re
     }
 }
 
+// =====================================================================================================================
+// The whole LSTM STACK forward in one launch: a wavefront over (layer, time).  Layer l's step t needs its own h_{t-1} and the
+// layer below's h_t, so L stacked layers take T + L - 1 dependent steps instead of L T when every layer has its own
+// workgroups: workgroup = (layer, group, slot), G groups of R = ceil(B / G) items with L G H / 16 <= 512 workgroups (two per
+// CU, <= 256 VGPRs each).  Layers above the first compute their input projection inside the step (their W_ih slice is
+// resident next to the W_hh slice: 128 VGPRs per lane at H = 512) from tiles the layer below publishes.
+// A (layer, group) fills half an XCD (32 of its 64 workgroup slots), so neighbouring layers live on different XCDs: every
+// layer therefore publishes its tile twice -
+//   ring A  2 epochs, for its OWN next step: the single-layer protocol (plain stores + flag A when the group shares an XCD)
+//   ring X  4 epochs, for the layer ABOVE: always write-through (sc1) stores + sc1 flag X, written by wave 1, off wave 0's
+//           publish -> poll path; the extra fabric latency is hidden by the pipeline as long as the ring is deep enough
+// and three conditions gate step t of layer l (one poll: lanes 0-31 own A flags, 32-63 the lower layer's X flags, a second
+// load for the upper layer's X flags):
+//   own   A flags >= t + 1         h_t of this layer is published (epoch e = state h_e; flag = e + 1)
+//   lower X flags >= t + 2         h_{t+1} of the layer below (its output of step t) is published
+//   upper X flags >= t - 2         the layer above has finished its step t - 4: the epoch t - 3 that this step's ring-X
+//                                  publish (epoch t + 1, same slot) overwrites is no longer read
+// Layer 0 takes xproj = x W_ih^T + b_ih from memory (one GEMM before the launch), as the single-layer kernel does.
+// =====================================================================================================================
+struct LstmPStack {
+    mg_lstm_pstack_layer l[MG_LSTM_MAX_LAYERS];
+};
+
+// workspace of the stack kernel: [512 words unused | status word + 3 pad (same place as in the single-layer kernels)]
+// [flags A: up to 64 (layer, group) ids x 32 words] [flags X: 64 x 32] [XCC ids: 64 x 32] [rings A: L x 2 epochs] [rings X: L x 4]
+#define LPS_MAX_IDS 64                                       // L G <= 512 / (H / 16) and H >= 128
+#define LPS_XDEPTH 4
+#define LPS_FLAGA_WORD (GP_FLAG_WORDS + 4)
+#define LPS_FLAGX_WORD (LPS_FLAGA_WORD + LPS_MAX_IDS * GP_SLOTS)
+#define LPS_XCC_WORD (LPS_FLAGX_WORD + LPS_MAX_IDS * GP_SLOTS)
+#define LPS_RING_OFFSET ((size_t)(LPS_XCC_WORD + LPS_MAX_IDS * GP_SLOTS) * sizeof(unsigned))
+
+__device__ __forceinline__ bool lps_wait(gu32* own, unsigned need_own, gu32* lower, unsigned need_lower, gu32* upper, unsigned need_upper,
+                                         int n_slots, int lane) {
+    const int sl = lane & 31;
+    gu32* p = (lane < 32 || !lower) ? own : lower;
+    const unsigned need = (lane < 32 || !lower) ? need_own : need_lower;
+    for (unsigned spins = 0;; ++spins) {
+        const unsigned f = sl < n_slots ? __hip_atomic_load(p + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
+        const unsigned u = (upper && lane < n_slots) ? __hip_atomic_load(upper + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need_upper;
+        if (__all(f >= need && (int)u >= (int)need_upper)) return true;
+        if (spins > GP_SPIN_LIMIT) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+template <int MT, int KS>
+__global__ __launch_bounds__(256, 2) void lstm_stack_fwd_persist_kernel(LstmPStack a, const int64_t* __restrict__ seq_len, int B, int T, int H,
+                                                                        int L, int G, int R, unsigned* sync, uint16_t* rings, int force_sc1) {
+    __shared__ float red[4][4][MT][GT * GT];
+    __shared__ __attribute__((aligned(16))) uint16_t hb[MT][GT][GT];
+    __shared__ float res[MT][7][GT * GT];
+    __shared__ int s_abort, s_xcd;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    const int n_ids = L * G;
+    const int id = blockIdx.x % n_ids, slot = blockIdx.x / n_ids;
+    const int layer = id / G, group = id - layer * G;
+    const int n_slots = H / GT;
+    const int row0 = group * R;
+    const int nrows = min(R, B - row0);
+    if (slot >= n_slots || nrows <= 0) return;
+    const mg_lstm_pstack_layer& P = a.l[layer];
+    const int j0 = slot * GT;
+    gu32* flags_a = (gu32*)sync + LPS_FLAGA_WORD + id * GP_SLOTS;
+    gu32* flags_x = (gu32*)sync + LPS_FLAGX_WORD + id * GP_SLOTS;
+    gu32* flags_lo = layer > 0 ? flags_x - G * GP_SLOTS : (gu32*)nullptr;
+    gu32* flags_up = layer + 1 < L ? flags_x + G * GP_SLOTS : (gu32*)nullptr;
+    gu32* status = (gu32*)sync + GP_FLAG_WORDS;
+    if (tid == 0) s_abort = 0;
+    const int one_xcd = force_sc1 ? 0 : gp_group_on_one_xcd((gu32*)sync + LPS_XCC_WORD + id * GP_SLOTS, slot, n_slots, tid, &s_xcd);
+    if (one_xcd < 0) {
+        if (tid == 0) __hip_atomic_store(status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    int gmax = 0;
+    for (int r = 0; r < nrows; ++r) {
+        const int64_t n = seq_len ? seq_len[row0 + r] : (int64_t)T;
+        gmax = max(gmax, (int)(n < T ? n : T));
+    }
+    const int kbase = wave * (H / 4) + 8 * q;
+    // fwi: the W_ih slice of a layer above the first.  Layer 0 has no such slice and keeps its xproj values of this step and of
+    // the next one in the same registers (XG / XG1 below) - the kernel sits at the 256-VGPR limit of two workgroups per CU.
+    gbf8 fwh[4][KS];
+    u32x4 fwi[4][KS];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint16_t* wp = P.w_hh_bf + ((size_t)g * H + j0 + li) * P.ldwh + kbase;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            fwh[g][i] = *reinterpret_cast<const gbf8*>(wp + 32 * i);
+            fwi[g][i] = u32x4{0u, 0u, 0u, 0u};
+        }
+        if (layer > 0) {
+            const uint16_t* wi = P.w_ih_bf + ((size_t)g * H + j0 + li) * P.ldwi + kbase;
+#pragma unroll
+            for (int i = 0; i < KS; ++i) fwi[g][i] = *reinterpret_cast<const u32x4*>(wi + 32 * i);
+        }
+    }
+#define XG(m, g) fwi[(m) / KS][(m) % KS][g]                    /* layer 0: xproj of this step, item tile m, gate g */
+#define XG1(m, g) fwi[(MT + (m)) / KS][(MT + (m)) % KS][g]    /* layer 0: xproj of the next step */
+    // rings: A [layer][2 epochs][G groups][H / 16 slots][R items][16 units] bf16, then X [layer][4 epochs][...]
+    const unsigned par_bytes = (unsigned)(G * n_slots * R * 32);
+    const unsigned x_base = (unsigned)L * 2 * par_bytes;
+    const auto rs_ring = __builtin_amdgcn_make_buffer_rsrc((void*)rings, 0, (int)((2 + LPS_XDEPTH) * par_bytes * L), 0x00020000);
+    const unsigned ring_own = (unsigned)layer * 2 * par_bytes;
+    const unsigned ring_x = x_base + (unsigned)layer * LPS_XDEPTH * par_bytes;
+    const unsigned ring_lo = x_base + (unsigned)(layer > 0 ? layer - 1 : 0) * LPS_XDEPTH * par_bytes;
+    const unsigned rd_base = (unsigned)(((group * n_slots + (kbase >> 4)) * R) * 32 + 16 * (q & 1));
+    const unsigned rd_kstep = (unsigned)(2 * R * 32);
+    const unsigned wr_base = (unsigned)(((group * n_slots + slot) * R) * 32);
+
+    const int bl = tid >> 4, jl = tid & 15;
+    const int j = j0 + jl;
+    float bsum[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bsum[g] = P.b_hh[g * H + j] + (layer > 0 ? P.b_ih[g * H + j] : 0.f);
+    float hprev[MT], cprev[MT];
+    int len[MT];
+    bool mine[MT];
+    const float* xp[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        mine[m] = 16 * m + bl < nrows;
+        const int b = row0 + (mine[m] ? 16 * m + bl : 0);
+        hprev[m] = P.hstate[((size_t)b * (T + 1)) * H + j];
+        cprev[m] = P.cstate[((size_t)b * (T + 1)) * H + j];
+        len[m] = seq_len ? (int)min((int64_t)T, seq_len[b]) : T;
+        hb[m][bl][jl] = mg_f2bf(hprev[m]);
+        xp[m] = (layer == 0 ? P.xproj : P.b_hh) + (layer == 0 ? (size_t)b * T * 4 * H + j : 0);
+        if (layer == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) XG(m, g) = __float_as_uint(xp[m][g * H]);
+        }
+    }
+    __syncthreads();
+
+    // wave 0: ring A + flag A (this layer's own recurrence); wave 1: ring X + flag X (for the layer above and as this layer's
+    // progress report to the layer below) and the bf16 shadow of the state
+    auto publish = [&](int e) {
+        if (wave <= 1) {
+            if (lane < 2 * 16 * MT) {
+                const int rrow = lane >> 1, half = lane & 1;
+                if (rrow < nrows) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(&hb[rrow >> 4][rrow & 15][8 * half]);
+                    const unsigned tile = wr_base + (unsigned)(rrow * 32 + half * 16);
+                    if (wave == 0) {
+                        const unsigned off = ring_own + (e & 1) * par_bytes + tile;
+                        if (one_xcd)
+                            __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 0);
+                        else
+                            __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 16);
+                    } else {
+                        if (layer + 1 < L)
+                            __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, ring_x + (e & (LPS_XDEPTH - 1)) * par_bytes + tile, 0, 16);
+                        if (e > 0) *reinterpret_cast<u32x4*>(P.hstate_bf + ((size_t)(row0 + rrow) * (T + 1) + e) * H + j0 + 8 * half) = v;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                if (wave == 0)
+                    gp_store_flag(flags_a + slot, (unsigned)(e + 1), one_xcd);
+                else
+                    __hip_atomic_store(flags_x + slot, (unsigned)(e + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    publish(0);
+
+    for (int t = 0; t < gmax; ++t) {
+        if (wave == 0 && !lps_wait(flags_a, (unsigned)(t + 1), flags_lo, (unsigned)(t + 2), flags_up, (unsigned)(t - (LPS_XDEPTH - 2)), n_slots, lane))
+            s_abort = 1;
+        gp_lds_barrier();
+        if (s_abort) {
+            if (tid == 0) __hip_atomic_store(status, 6u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        // hand-off tiles: this layer's h_t (ring A) and the lower layer's h_{t+1} (its ring X).  The second M tile's loads are
+        // issued between the first tile's MFMAs, each into the register its k-step has just freed (two tiles in flight at once
+        // do not fit in 256 VGPRs next to the 128 of the two weight slices); their latency hides behind the first tile's MFMAs.
+        auto tile_off = [&](int m) {
+            const bool valid = 16 * m + li < nrows;
+            return rd_base + (unsigned)((valid ? 16 * m + li : 0) * 32);
+        };
+        const unsigned own0 = ring_own + (t & 1) * par_bytes, low0 = ring_lo + ((t + 1) & (LPS_XDEPTH - 1)) * par_bytes;
+        u32x4 raw[KS], rawx[KS];
+        {
+            const unsigned ro = tile_off(0);
+#pragma unroll
+            for (int i = 0; i < KS; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ring, own0 + ro + i * rd_kstep, 0, 16);
+            if (layer > 0) {
+#pragma unroll
+                for (int i = 0; i < KS; ++i) rawx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ring, low0 + ro + i * rd_kstep, 0, 16);
+            }
+        }
+        if (layer == 0) {
+            const int t1 = t + 1 < T ? t + 1 : t;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) XG1(m, g) = __float_as_uint(xp[m][(size_t)t1 * 4 * H + g * H]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const unsigned rn = m + 1 < MT ? tile_off(m + 1) : 0u;
+            f32x4 acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < KS; ++i) {
+                const gbf8 av = as_bf8(raw[i]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, fwh[g][i], acc[g], 0, 0, 0);
+                if (m + 1 < MT) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ring, own0 + rn + i * rd_kstep, 0, 16);
+            }
+            if (layer > 0) {
+#pragma unroll
+                for (int i = 0; i < KS; ++i) {
+                    const gbf8 av = as_bf8(rawx[i]);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, as_bf8(fwi[g][i]), acc[g], 0, 0, 0);
+                    if (m + 1 < MT) rawx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ring, low0 + rn + i * rd_kstep, 0, 16);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = (4 * q + r) * GT + li;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) red[wave][g][m][e] = acc[g][r];
+            }
+        }
+        gp_lds_barrier();
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int e = bl * GT + jl;
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                pre[g] = (layer == 0 ? __uint_as_float(XG(m, g)) : 0.f) +
+                         (((red[0][g][m][e] + red[1][g][m][e]) + (red[2][g][m][e] + red[3][g][m][e])) + bsum[g]);
+            const float ig = mg_sigmoid_fast(pre[0]), fg = mg_sigmoid_fast(pre[1]), gg = lp_tanh_fast(pre[2]), og = mg_sigmoid_fast(pre[3]);
+            const float cnew = fg * cprev[m] + ig * gg;
+            const float hnew = og * lp_tanh_fast(cnew);
+            const bool active = t < len[m];
+            hprev[m] = active ? hnew : hprev[m];
+            cprev[m] = active ? cnew : cprev[m];
+            hb[m][bl][jl] = mg_f2bf(hprev[m]);
+            res[m][0][e] = hprev[m];
+            res[m][1][e] = cprev[m];
+            res[m][2][e] = active ? hnew : 0.f;
+            res[m][3][e] = ig;
+            res[m][4][e] = fg;
+            res[m][5][e] = gg;
+            res[m][6][e] = og;
+        }
+        gp_lds_barrier();
+        publish(t + 1);
+        if (wave >= 2) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int e = (tid - 128) + 128 * half, rb = e >> 4, cj = j0 + (e & 15);
+                    if (16 * m + rb < nrows) {
+                        const int b = row0 + 16 * m + rb;
+                        const size_t row = (size_t)b * T + t;
+                        const size_t nxt = ((size_t)b * (T + 1) + t + 1) * H + cj;
+                        P.hstate[nxt] = res[m][0][e];
+                        P.cstate[nxt] = res[m][1][e];
+                        P.out[row * H + cj] = res[m][2][e];
+                        float* sv = P.saved + row * 4 * H + cj;
+                        sv[0] = res[m][3][e];
+                        sv[H] = res[m][4][e];
+                        sv[2 * H] = res[m][5][e];
+                        sv[3 * H] = res[m][6][e];
+                    }
+                }
+        }
+        if (layer == 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) XG(m, g) = XG1(m, g);
+        }
+    }
+#undef XG
+#undef XG1
+    for (int t = gmax; t < T; ++t) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            if (mine[m]) {
+                const int b = row0 + 16 * m + bl;
+                const size_t row = (size_t)b * T + t;
+                const size_t nxt = ((size_t)b * (T + 1) + t + 1) * H + j;
+                P.hstate[nxt] = hprev[m];
+                P.cstate[nxt] = cprev[m];
+                P.hstate_bf[nxt] = mg_f2bf(hprev[m]);
+                P.out[row * H + j] = 0.f;
+                float* sv = P.saved + row * 4 * H;
+                sv[j] = 0.f;
+                sv[H + j] = 0.f;
+                sv[2 * H + j] = 0.f;
+                sv[3 * H + j] = 0.f;
+            }
+    }
+}
+
 extern "C" {
 
 int mg_lstm_persist_supported(int B, int T, int H) {
@@ -542,6 +851,76 @@ int mg_lstm_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const 
         LP_BWD_KS(2)
     }
     MG_CHECK_LAUNCH("mg_lstm_bwd_persist_bf16");
+    return MG_OK;
+}
+
+static int lps_groups(int B, int H, int L) {
+    // the largest G in {8, 4, 2, 1} with L G H / 16 <= 512 workgroups (two per CU) and at most 32 items per group; 0 = none
+    for (int G = 8; G >= 1; G >>= 1) {
+        if ((long)L * G * (H / GT) > 512) continue;
+        if (mg_ceil_div(B, G) > 32) return 0;
+        return G;
+    }
+    return 0;
+}
+
+int mg_lstm_pstack_supported(int B, int T, int H, int L) {
+    if (B <= 0 || T <= 0 || H <= 0 || L < 2 || L > MG_LSTM_MAX_LAYERS) return 0;
+    if (H % 128 != 0 || H > 128 * GP_KSTEPS) return 0;
+    return lps_groups(B, H, L) > 0;
+}
+
+size_t mg_lstm_pstack_workspace_bytes(int B, int H, int L) {
+    const int G = lps_groups(B, H, L);
+    if (G <= 0) return 0;
+    return LPS_RING_OFFSET + (size_t)L * (2 + LPS_XDEPTH) * G * mg_ceil_div(B, G) * H * 2;
+}
+
+int mg_lstm_pstack_fwd_bf16(const mg_lstm_pstack_layer* layers, int L, const int64_t* seq_len, int B, int T, int H, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+    MG_CHECK_ARG(layers && mg_lstm_pstack_supported(B, T, H, L), "mg_lstm_pstack_fwd_bf16: unsupported shape (B=%d T=%d H=%d L=%d)", B, T, H, L);
+    LstmPStack a;
+    for (int l = 0; l < L; ++l) {
+        a.l[l] = layers[l];
+        const mg_lstm_pstack_layer& p = layers[l];
+        MG_CHECK_ARG(p.w_hh_bf && p.b_hh && p.hstate && p.cstate && p.hstate_bf && p.out && p.saved && p.ldwh >= H && p.ldwh % 8 == 0,
+                     "mg_lstm_pstack_fwd_bf16: layer %d: bad arguments", l);
+        MG_CHECK_ARG(l == 0 ? p.xproj != nullptr : (p.w_ih_bf && p.b_ih && p.ldwi >= H && p.ldwi % 8 == 0),
+                     "mg_lstm_pstack_fwd_bf16: layer %d: %s", l, l == 0 ? "xproj missing" : "w_ih_bf / b_ih missing");
+        MG_CHECK_ARG((((uintptr_t)p.w_hh_bf | (uintptr_t)p.w_ih_bf | (uintptr_t)p.hstate_bf) % 16) == 0,
+                     "mg_lstm_pstack_fwd_bf16: layer %d: bf16 buffers must be 16-byte aligned", l);
+    }
+    if (!workspace || workspace_bytes < mg_lstm_pstack_workspace_bytes(B, H, L) || ((uintptr_t)workspace % 16) != 0) {
+        mg_set_error("mg_lstm_pstack_fwd_bf16: 16-byte aligned workspace of %zu bytes needed, got %zu", mg_lstm_pstack_workspace_bytes(B, H, L),
+                     workspace_bytes);
+        return MG_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync((unsigned*)workspace + LPS_FLAGA_WORD, 0, (size_t)3 * LPS_MAX_IDS * GP_SLOTS * sizeof(unsigned), st) != hipSuccess) {
+        mg_set_error("mg_lstm_pstack_fwd_bf16: memset failed");
+        return MG_ELAUNCH;
+    }
+    const int G = lps_groups(B, H, L);
+    const int R = (int)mg_ceil_div(B, G);
+    const unsigned grid = (unsigned)(L * G * (H / GT));
+    uint16_t* rings = (uint16_t*)((char*)workspace + LPS_RING_OFFSET);
+    const int force = g_mg_tuning[MG_TUNE_GRU_HANDOFF] == 1;
+#define LPS_FWD(MT, KS)                                                                                                                  \
+    hipLaunchKernelGGL((lstm_stack_fwd_persist_kernel<MT, KS>), dim3(grid), dim3(256), 0, st, a, seq_len, B, T, H, L, G, R, (unsigned*)workspace, \
+                       rings, force)
+#define LPS_FWD_KS(MT)                 \
+    switch (H / 128) {                 \
+        case 1: LPS_FWD(MT, 1); break; \
+        case 2: LPS_FWD(MT, 2); break; \
+        case 3: LPS_FWD(MT, 3); break; \
+        default: LPS_FWD(MT, 4); break; \
+    }
+    if (R <= 16) {
+        LPS_FWD_KS(1)
+    } else {
+        LPS_FWD_KS(2)
+    }
+    MG_CHECK_LAUNCH("mg_lstm_pstack_fwd_bf16");
     return MG_OK;
 }
 

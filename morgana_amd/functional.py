@@ -429,6 +429,90 @@ class LSTMFn(torch.autograd.Function):
                 dw_ih, dw_hh, db, db.clone())
 
 
+class LSTMStackPersistFn(torch.autograd.Function):
+    """L stacked single-layer LSTMs (the 8 x RecurrentCuDNNWrapper(nn.LSTM(512, 512)) of models/RNN_SPSS.py:36-37, or one
+    multi-layer nn.LSTM) in bf16 mode: the forward of the whole stack is ONE persistent launch, a wavefront over (layer, time)
+    (csrc/lstm_persist.hip, mg_lstm_pstack_fwd_bf16); the backward runs the layers top-down, each as one persistent launch
+    (mg_lstm_bwd_persist_bf16) between the weight-gradient and input-gradient GEMMs.  Same results as L chained LSTMFn calls
+    up to the summation order of the fused input projection.
+
+    forward(ctx, x (B,T,I), seq_len, h0s, c0s ((L,B,H) or None), *params) with params = w_ih, w_hh, b_ih, b_hh per layer;
+    returns (outputs of the top layer (B,T,H), h_n (L,B,H), c_n (L,B,H))."""
+
+    @staticmethod
+    def forward(ctx, x, seq_len, h0s, c0s, *params):
+        n_layers = len(params) // 4
+        w_ih = [params[4 * l] for l in range(n_layers)]
+        w_hh = [params[4 * l + 1].contiguous() for l in range(n_layers)]
+        b_ih = [params[4 * l + 2].contiguous() for l in range(n_layers)]
+        b_hh = [params[4 * l + 3].contiguous() for l in range(n_layers)]
+        x = ops._require(x, torch.float32, 'inputs')
+        b, t, i_dim = x.shape
+        hid = w_hh[0].shape[1]
+        x_saved = ops.cast_pad_bf16(x.view(b * t, i_dim))
+        xproj0 = ops.linear_fwd_bf16(x_saved, None, b * t, i_dim, ops.cast_pad_bf16(w_ih[0]), b_ih[0], 4 * hid, ops.ACT_NONE,
+                                     out_f32=True)
+        if xproj0.shape[1] != 4 * hid:
+            xproj0 = xproj0[:, :4 * hid].contiguous()
+        out, hstate, cstate, saved, hstate_bf = ops.lstm_pstack_fwd(xproj0.view(b, t, 4 * hid), w_ih, w_hh, b_ih, b_hh, seq_len, h0s, c0s,
+                                                                    b, t, hid)
+        ctx.shape = (b, t, i_dim, hid, n_layers)
+        ctx.has_h0, ctx.has_c0 = h0s is not None, c0s is not None
+        ctx.save_for_backward(x_saved, seq_len, *w_ih, *w_hh, *cstate, *saved, *hstate_bf)
+        hn = torch.stack([hstate[l][:, t] for l in range(n_layers)], dim=0)
+        cn = torch.stack([cstate[l][:, t] for l in range(n_layers)], dim=0)
+        return out[-1], hn, cn
+
+    @staticmethod
+    def backward(ctx, grad_out, grad_hn, grad_cn):
+        b, t, i_dim, hid, n_layers = ctx.shape
+        sv = ctx.saved_tensors
+        x_saved, seq_len = sv[0], sv[1]
+        pos = 2
+        w_ih = sv[pos:pos + n_layers]; pos += n_layers
+        w_hh = sv[pos:pos + n_layers]; pos += n_layers
+        cstate = sv[pos:pos + n_layers]; pos += n_layers
+        saved = sv[pos:pos + n_layers]; pos += n_layers
+        hstate_bf = sv[pos:pos + n_layers]
+        dev = x_saved.device
+        m = b * t
+        batch = torch.arange(b, device=dev, dtype=torch.int32)[:, None] * (t + 1)
+        steps = torch.arange(t, device=dev, dtype=torch.int32)[None, :]
+        prev_rows = (batch + steps).reshape(-1).contiguous()              # h_{t-1} of hstate (B, T+1, H): row b (T+1) + t
+        next_rows = (batch + steps + 1).reshape(-1).contiguous()          # h_t: the input of the layer above at step t
+        g_out = grad_out.contiguous() if grad_out is not None else torch.zeros((b, t, hid), dtype=torch.float32, device=dev)
+        grads = [None] * (4 * n_layers)
+        dh0 = torch.empty((n_layers, b, hid), dtype=torch.float32, device=dev)
+        dc0 = torch.empty((n_layers, b, hid), dtype=torch.float32, device=dev)
+        dx = None
+        for l in range(n_layers - 1, -1, -1):
+            g_hn = grad_hn[l].reshape(b, hid).contiguous() if grad_hn is not None else None
+            g_cn = grad_cn[l].reshape(b, hid).contiguous() if grad_cn is not None else None
+            dgates, dh0_l, dc0_l, dg_bf = ops.lstm_bwd_bf16(g_out, g_hn, g_cn, cstate[l], saved[l], w_hh[l], seq_len, b, t, hid)
+            dh0[l], dc0[l] = dh0_l, dc0_l
+            dg_bf = dg_bf.view(m, 4 * hid)
+            if l == 0:
+                dw_ih, db = ops.linear_wgrad_bf16(dg_bf, x_saved, None, m, 4 * hid, i_dim)
+            else:
+                dw_ih, db = ops.linear_wgrad_bf16(dg_bf, hstate_bf[l - 1].view(b * (t + 1), hid), next_rows, m, 4 * hid, hid)
+            dw_hh, _ = ops.linear_wgrad_bf16(dg_bf, hstate_bf[l].view(b * (t + 1), hid), prev_rows, m, 4 * hid, hid, want_bias=False)
+            grads[4 * l:4 * l + 4] = [dw_ih, dw_hh, db, db.clone()]
+            if l > 0 or ctx.needs_input_grad[0]:
+                k_in = hid if l > 0 else i_dim
+                d_in = ops.linear_dgrad_bf16(dg_bf, m, 4 * hid, ops.cast_transpose_bf16(w_ih[l]), k_in, None, out_f32=True)
+                if d_in.shape[1] != k_in:
+                    d_in = d_in[:, :k_in].contiguous()
+                if l > 0:
+                    g_out = d_in.view(b, t, hid)
+                else:
+                    dx = d_in.view(b, t, i_dim)
+        return (dx, None, dh0 if ctx.has_h0 else None, dc0 if ctx.has_c0 else None, *grads)
+
+
+def lstm_stack_persistent(precision, b, t, hid, n_layers):
+    return precision == 'bf16' and RECURRENCE_BF16 and n_layers >= 2 and ops.lstm_pstack_ok(b, t, hid, n_layers)
+
+
 LSTM_STACK_LAG = 32       # steps a layer of a skewed stack runs behind the one below (and frames per projection chunk)
 
 

@@ -478,8 +478,8 @@ def check_persistent_status():
     """Synchronise and raise if a persistent recurrent kernel launched since the last call gave up waiting for a peer workgroup
     (its results are invalid).  Called once per epoch by ExperimentBuilder, by bench.py, smoke() and the GPU tests."""
     lib = _lib.load()
-    for (dev, stream), ws in list(_PERSIST_WORKSPACES.items()):
-        _lib.check(lib.mg_gru_persist_status(_p(ws), ctypes.c_void_p(stream)), 'mg_gru_persist_status')
+    for key, ws in list(_PERSIST_WORKSPACES.items()):
+        _lib.check(lib.mg_gru_persist_status(_p(ws), ctypes.c_void_p(key[1])), 'mg_gru_persist_status')
 
 
 def gru_fwd_bf16(xproj, w_hh, b_hh, seq_len, h0, b, t, h, persistent=None):
@@ -608,6 +608,55 @@ def lstm_bwd_bf16(grad_out, grad_hn, grad_cn, cstate, saved, w_hh, seq_len, b, t
                                             _p(seq_len), b, t, h, _p(dgates), _p(dgates_bf), _p(dh0), _p(dc0), _p(ws), ws.numel(),
                                             _stream()), 'mg_lstm_bwd_persist_bf16')
     return dgates, dh0, dc0, dgates_bf
+
+
+def lstm_pstack_ok(b, t, h, n_layers):
+    """The whole-stack forward wavefront (mg_lstm_pstack_fwd_bf16) covers this shape."""
+    return PERSISTENT_RECURRENCE and bool(_lib.load().mg_lstm_pstack_supported(b, t, h, n_layers))
+
+
+def lstm_pstack_fwd(xproj0, w_ih, w_hh, b_ih, b_hh, seq_len, h0s, c0s, b, t, h):
+    """L stacked LSTM layers forward in one persistent launch.  xproj0 (b,t,4h) f32 = layer 0's input projection incl. b_ih;
+    w_ih[l] (l >= 1), w_hh[l] f32 (cast to bf16 here).  Returns per-layer lists (out, hstate, cstate, saved, hstate_bf)."""
+    lib = _lib.load()
+    dev = xproj0.device
+    n_layers = len(w_hh)
+    out, hstate, cstate, saved, hstate_bf, keep = [], [], [], [], [], []
+    descs = (_lib.LstmPStackLayer * n_layers)()
+    for l in range(n_layers):
+        hs = torch.empty((b, t + 1, h), dtype=torch.float32, device=dev)
+        cs = torch.empty((b, t + 1, h), dtype=torch.float32, device=dev)
+        hb = torch.empty((b, t + 1, h), dtype=torch.bfloat16, device=dev)
+        for state, init in ((hs, h0s), (cs, c0s), (hb, h0s)):
+            if init is None:
+                state[:, 0].zero_()
+            else:
+                state[:, 0].copy_(init[l].reshape(b, h))
+        o = torch.empty((b, t, h), dtype=torch.float32, device=dev)
+        sv = torch.empty((b, t, 4 * h), dtype=torch.float32, device=dev)
+        whb = cast_pad_bf16(w_hh[l])
+        d = descs[l]
+        d.w_hh_bf, d.ldwh, d.b_hh = whb.data_ptr(), whb.shape[1], b_hh[l].data_ptr()
+        if l == 0:
+            d.xproj = xproj0.data_ptr()
+        else:
+            wib = cast_pad_bf16(w_ih[l])
+            d.w_ih_bf, d.ldwi, d.b_ih = wib.data_ptr(), wib.shape[1], b_ih[l].data_ptr()
+            keep.append(wib)
+        d.hstate, d.cstate, d.hstate_bf, d.out, d.saved = hs.data_ptr(), cs.data_ptr(), hb.data_ptr(), o.data_ptr(), sv.data_ptr()
+        keep.append(whb)
+        out.append(o); hstate.append(hs); cstate.append(cs); saved.append(sv); hstate_bf.append(hb)
+    key = (dev, torch.cuda.current_stream().cuda_stream, 'pstack')
+    need = lib.mg_lstm_pstack_workspace_bytes(b, h, n_layers)
+    ws = _PERSIST_WORKSPACES.get(key)
+    if ws is None or ws.numel() < need:
+        if ws is not None:
+            check_persistent_status()
+        ws = torch.zeros(need, dtype=torch.uint8, device=dev)
+        _PERSIST_WORKSPACES[key] = ws
+    _lib.check(lib.mg_lstm_pstack_fwd_bf16(ctypes.cast(descs, ctypes.c_void_p), n_layers, _p(seq_len), b, t, h, _p(ws), ws.numel(),
+                                           _stream()), 'mg_lstm_pstack_fwd_bf16')
+    return out, hstate, cstate, saved, hstate_bf
 
 
 def lstm_stack_fwd(descs, n_layers, seq_len, b, t, h, lag, s_begin, s_end):

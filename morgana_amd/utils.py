@@ -186,6 +186,9 @@ class RecurrentCuDNNWrapper(nn.Module):
         if layer.num_layers == 1:
             out, hn, cn = F_hip.LSTMFn.apply(precision, inputs.contiguous(), h0s, c0s, seq_len, *self._lstm_params())
             return out, (hn, cn)
+        if F_hip.lstm_stack_persistent(precision, inputs.shape[0], inputs.shape[1], layer.hidden_size, layer.num_layers):
+            out, hn, cn = F_hip.LSTMStackPersistFn.apply(inputs.contiguous(), seq_len, h0s, c0s, *self._lstm_params())
+            return out, (hn, cn)
         if F_hip.lstm_persistent(precision, inputs.shape[0], inputs.shape[1], layer.hidden_size):
             # persistent recurrence: a layer is two launches, so the layers simply follow each other
             params, out, hns, cns = self._lstm_params(), inputs.contiguous(), [], []
@@ -378,6 +381,17 @@ class SequentialWithRecurrent(nn.Sequential):
             if isinstance(module, RecurrentCuDNNWrapper):
                 end, run = self._lstm_run(modules, i, hiddens, seq_len)
                 hid = modules[run[0]].layer.hidden_size if run else 0
+                if len(run) > 1 and F_hip.lstm_stack_persistent(precision, input.shape[0], input.shape[1], hid, len(run)):
+                    # consecutive single-layer LSTM wrappers (models/RNN_SPSS.py:36-37): the whole stack's forward is one
+                    # persistent launch (a wavefront over layers and time)
+                    params = []
+                    for k in run:
+                        params += modules[k]._lstm_params()
+                    input, hn, cn = F_hip.LSTMStackPersistFn.apply(input.contiguous(), seq_len, None, None, *params)
+                    for pos, k in enumerate(run):
+                        hiddens[k] = (hn[pos:pos + 1], cn[pos:pos + 1])
+                    i = end
+                    continue
                 if len(run) > 1 and not F_hip.lstm_persistent(precision, input.shape[0], input.shape[1], hid):
                     # consecutive single-layer LSTM wrappers (models/RNN_SPSS.py:36-37): one time-skewed stack (per-step
                     # launches); with the persistent recurrence each wrapper is two launches and runs on its own below

@@ -819,6 +819,65 @@ def test_lstm_persistent_vs_fp32_and_between_handoff_forms(b, t, hid):
         _lib.load().mg_set_tuning(2, 0)
 
 
+@pytest.mark.parametrize('b,t,i_dim,hid,n_layers', [(64, 50, 512, 512, 8), (20, 30, 24, 128, 3), (40, 25, 256, 256, 4), (9, 33, 40, 128, 2)])
+def test_lstm_stack_wavefront_vs_chained_layers(b, t, i_dim, hid, n_layers):
+    """functional.LSTMStackPersistFn (all layers' forward in one persistent launch, a wavefront over layer and time with the
+    upper layers' input projection computed inside the step) against the same layers run one after the other: bf16 mode
+    both, so equal up to the summation order of the input projection (1e-2 relative on outputs, final states and every
+    gradient), and 2e-2 against the fp32 chain.  Ragged lengths with a full and a 1-step item; gradients on outputs and
+    final states.  The same-XCD and the write-through hand-off forms and repeated runs must give identical bits."""
+    from morgana_amd import _lib
+    torch.manual_seed(hid + n_layers)
+    x = torch.randn(b, t, i_dim, device=DEV, requires_grad=True)
+    sl_np = np.random.RandomState(b).randint(1, t + 1, size=b).astype(np.int64)
+    sl_np[0], sl_np[-1] = t, 1
+    seq_len = dev(sl_np)
+    params = []
+    for l in range(n_layers):
+        k = i_dim if l == 0 else hid
+        params += [torch.randn(4 * hid, k, device=DEV) / k ** 0.5, torch.randn(4 * hid, hid, device=DEV) / hid ** 0.5,
+                   torch.randn(4 * hid, device=DEV) * 0.1, torch.randn(4 * hid, device=DEV) * 0.1]
+    params = [p.requires_grad_(True) for p in params]
+    g_out = torch.randn(b, t, hid, device=DEV)
+    g_hn, g_cn = torch.randn(n_layers, b, hid, device=DEV), torch.randn(n_layers, b, hid, device=DEV)
+    assert F_hip.lstm_stack_persistent('bf16', b, t, hid, n_layers)
+
+    def run(kind):
+        for p in [x] + params:
+            p.grad = None
+        if kind == 'wavefront':
+            out, hn, cn = F_hip.LSTMStackPersistFn.apply(x, seq_len, None, None, *params)
+        else:
+            out, hns, cns = x, [], []
+            for l in range(n_layers):
+                out, h, c = F_hip.LSTMFn.apply(kind, out.contiguous(), None, None, seq_len, *params[4 * l:4 * l + 4])
+                hns.append(h)
+                cns.append(c)
+            hn, cn = torch.cat(hns, 0), torch.cat(cns, 0)
+        ((out * g_out).sum() + (hn * g_hn).sum() + (cn * g_cn).sum()).backward()
+        ops.check_persistent_status()
+        return [v.detach().cpu().numpy().copy() for v in (out, hn, cn, x.grad, *[p.grad for p in params])]
+
+    want_bf, want_32 = run('bf16'), run('fp32')
+    first = None
+    try:
+        for mode in (0, 1, 0):
+            _lib.load().mg_set_tuning(2, mode)
+            got = run('wavefront')
+            if first is None:
+                first = got
+                for k, (g, w, w32) in enumerate(zip(got, want_bf, want_32)):
+                    assert rel_err(g, w) < 1e-2, (k, 'vs bf16 chain')
+                    assert rel_err(g, w32) < 2e-2, (k, 'vs fp32 chain')
+                for i, n in enumerate(sl_np):
+                    assert np.all(got[0][i, n:] == 0)
+            else:
+                for k, (g, w) in enumerate(zip(got, first)):
+                    np.testing.assert_array_equal(g, w, err_msg='output %d, hand-off mode %d' % (k, mode))
+    finally:
+        _lib.load().mg_set_tuning(2, 0)
+
+
 def test_gru_bf16_recurrence_rejects_bad_sizes():
     x = torch.zeros(2, 3, 3 * 96, device=DEV)
     assert not ops.gru_bf16_ok(96)
