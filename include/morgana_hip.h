@@ -301,7 +301,8 @@ int mg_lstm_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const 
 /* A whole stack of L LSTM layers (2 <= L <= MG_LSTM_MAX_LAYERS, the 8 x nn.LSTM(512, 512) of models/RNN_SPSS.py:36-37) forward
  * in ONE launch: a wavefront over (layer, time) - T + L - 1 dependent steps instead of L T.  Layer 0 takes xproj = x W_ih^T +
  * b_ih [B,T,4H] from memory; the layers above compute their input projection inside the step from the hand-off tiles of the
- * layer below (w_ih_bf = bf16(W_ih) [4H, ldwi], input size == H).  Per layer the outputs of mg_lstm_fwd_persist_bf16.
+ * layer below (w_ih_bf = bf16(W_ih) [4H, ldwi], input size == H).  Per layer: cstate, saved and hstate_bf complete; of hstate
+ * only slot T (h_n); out only for the top layer (the other layers' out buffers are not written).
  * mg_lstm_pstack_supported(B, T, H, L): H % 128 == 0, H <= 512 and L G H / 16 <= 512 workgroups for a group count G in
  * {8, 4, 2, 1} with ceil(B / G) <= 32 (L = 8, H = 512: B <= 64).  All workgroups must be resident together, two per CU.
  * The workspace (mg_lstm_pstack_workspace_bytes, zeroed once by the caller) carries the sticky status word at the same offset
@@ -312,10 +313,10 @@ typedef struct {
     const float* b_ih;            /* layers >= 1 */
     const uint16_t* w_hh_bf;
     const float* b_hh;
-    float* hstate;                /* [B,T+1,H], slot 0 = h0 set by the caller */
+    float* hstate;                /* [B,T+1,H], slot 0 = h0 set by the caller; only slot T (h_n) is written */
     float* cstate;                /* [B,T+1,H], slot 0 = c0 set by the caller */
     uint16_t* hstate_bf;          /* [B,T+1,H] bf16 shadow, slot 0 set by the caller */
-    float* out;                   /* [B,T,H] */
+    float* out;                   /* [B,T,H]; written for the top layer only */
     float* saved;                 /* [B,T,4H] gate values i, f, g, o */
     int ldwi, ldwh;
 } mg_lstm_pstack_layer;

@@ -475,6 +475,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(const float* __re
 //                                  publish (epoch t + 1, same slot) overwrites is no longer read
 // Layer 0 takes xproj = x W_ih^T + b_ih from memory (one GEMM before the launch), as the single-layer kernel does.
 // =====================================================================================================================
+MG_STAMP_DECL(g_stamps_lps);
+
 struct LstmPStack {
     mg_lstm_pstack_layer l[MG_LSTM_MAX_LAYERS];
 };
@@ -488,15 +490,27 @@ struct LstmPStack {
 #define LPS_XCC_WORD (LPS_FLAGX_WORD + LPS_MAX_IDS * GP_SLOTS)
 #define LPS_RING_OFFSET ((size_t)(LPS_XCC_WORD + LPS_MAX_IDS * GP_SLOTS) * sizeof(unsigned))
 
-__device__ __forceinline__ bool lps_wait(gu32* own, unsigned need_own, gu32* lower, unsigned need_lower, gu32* upper, unsigned need_upper,
-                                         int n_slots, int lane) {
-    const int sl = lane & 31;
-    gu32* p = (lane < 32 || !lower) ? own : lower;
-    const unsigned need = (lane < 32 || !lower) ? need_own : need_lower;
-    for (unsigned spins = 0;; ++spins) {
-        const unsigned f = sl < n_slots ? __hip_atomic_load(p + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
-        const unsigned u = (upper && lane < n_slots) ? __hip_atomic_load(upper + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need_upper;
-        if (__all(f >= need && (int)u >= (int)need_upper)) return true;
+// wave 0: the three conditions of a step.  The neighbour layers' X flags are written through (sc1), so every poll of them is a
+// fabric round trip; they are normally far ahead, so each lane keeps the last value it saw (seen_lo / seen_up) and they are
+// polled again only when that no longer suffices.  Own A flags: the single-layer poll loop.
+__device__ __forceinline__ bool lps_wait(gu32* own, unsigned need_own, gu32* lower, int need_lower, unsigned& seen_lo, gu32* upper,
+                                         int need_upper, unsigned& seen_up, int n_slots, int lane) {
+    unsigned spins = 0;
+    if (lower) {
+        while (!__all(lane >= n_slots || (int)seen_lo >= need_lower)) {
+            if (lane < n_slots) seen_lo = __hip_atomic_load(lower + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (++spins > GP_SPIN_LIMIT) return false;
+        }
+    }
+    if (upper) {
+        while (!__all(lane >= n_slots || (int)seen_up >= need_upper)) {
+            if (lane < n_slots) seen_up = __hip_atomic_load(upper + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (++spins > GP_SPIN_LIMIT) return false;
+        }
+    }
+    for (;; ++spins) {
+        const unsigned f = lane < n_slots ? __hip_atomic_load(own + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need_own;
+        if (__all(f >= need_own)) return true;
         if (spins > GP_SPIN_LIMIT) return false;
         __builtin_amdgcn_s_sleep(1);
     }
@@ -507,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void lstm_stack_fwd_persist_kernel(LstmPSta
                                                                         int L, int G, int R, unsigned* sync, uint16_t* rings, int force_sc1) {
     __shared__ float red[4][4][MT][GT * GT];
     __shared__ __attribute__((aligned(16))) uint16_t hb[MT][GT][GT];
-    __shared__ float res[MT][7][GT * GT];
+    __shared__ __attribute__((aligned(16))) float res[MT][6][GT * GT];   // c, out, i, f, g, o of the step on their way to waves 2 and 3
     __shared__ int s_abort, s_xcd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
@@ -537,8 +551,8 @@ __global__ __launch_bounds__(256, 2) void lstm_stack_fwd_persist_kernel(LstmPSta
         gmax = max(gmax, (int)(n < T ? n : T));
     }
     const int kbase = wave * (H / 4) + 8 * q;
-    // fwi: the W_ih slice of a layer above the first.  Layer 0 has no such slice and keeps its xproj values of this step and of
-    // the next one in the same registers (XG / XG1 below) - the kernel sits at the 256-VGPR limit of two workgroups per CU.
+    // fwi: the W_ih slice of a layer above the first.  Layer 0 has no such slice and keeps its xproj values of the current
+    // step in the same registers (XG below) - the kernel sits at the 256-VGPR limit of two workgroups per CU.
     gbf8 fwh[4][KS];
     u32x4 fwi[4][KS];
 #pragma unroll
@@ -556,7 +570,6 @@ __global__ __launch_bounds__(256, 2) void lstm_stack_fwd_persist_kernel(LstmPSta
         }
     }
 #define XG(m, g) fwi[(m) / KS][(m) % KS][g]                    /* layer 0: xproj of this step, item tile m, gate g */
-#define XG1(m, g) fwi[(MT + (m)) / KS][(MT + (m)) % KS][g]    /* layer 0: xproj of the next step */
     // rings: A [layer][2 epochs][G groups][H / 16 slots][R items][16 units] bf16, then X [layer][4 epochs][...]
     const unsigned par_bytes = (unsigned)(G * n_slots * R * 32);
     const unsigned x_base = (unsigned)L * 2 * par_bytes;
@@ -615,25 +628,41 @@ __global__ __launch_bounds__(256, 2) void lstm_stack_fwd_persist_kernel(LstmPSta
                     }
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) {
-                if (wave == 0)
-                    gp_store_flag(flags_a + slot, (unsigned)(e + 1), one_xcd);
-                else
-                    __hip_atomic_store(flags_x + slot, (unsigned)(e + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (wave == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) gp_store_flag(flags_a + slot, (unsigned)(e + 1), one_xcd);
             }
         }
     };
+    // wave 1 raises flag X for an epoch only once its write-through stores are done; it does not wait for them at the publish
+    // (it would hold up the workgroup's next barrier by a fabric round trip) but in the next step, behind the MFMAs
+    auto raise_x = [&](int e) {
+        if (wave == 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(flags_x + slot, (unsigned)(e + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    unsigned seen_lo = 0, seen_up = 0;
     publish(0);
+    raise_x(0);
+#ifdef MG_STAMPS
+    unsigned long long ta = 0, tb = 0, ts0 = 0, ts1 = 0, tr0 = 0, tr1 = 0, sum_poll = 0, sum_load = 0, sum_mm = 0, sum_cell = 0, sum_pub = 0;
+    MG_STAMP(ts0);
+    MG_STAMP_REAL(tr0);
+#endif
 
     for (int t = 0; t < gmax; ++t) {
-        if (wave == 0 && !lps_wait(flags_a, (unsigned)(t + 1), flags_lo, (unsigned)(t + 2), flags_up, (unsigned)(t - (LPS_XDEPTH - 2)), n_slots, lane))
+        float xg1[MT][4];                            // layer 0: the next step's xproj values, in flight until the end of the step
+        MG_STAMP(ta);
+        if (wave == 0 && !lps_wait(flags_a, (unsigned)(t + 1), flags_lo, t + 2, seen_lo, flags_up, t - (LPS_XDEPTH - 2), seen_up, n_slots, lane))
             s_abort = 1;
         gp_lds_barrier();
         if (s_abort) {
             if (tid == 0) __hip_atomic_store(status, 6u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
+        MG_STAMP(tb);
+        MG_STAMP_ADD(sum_poll, tb, ta);
         // hand-off tiles: this layer's h_t (ring A) and the lower layer's h_{t+1} (its ring X).  The second M tile's loads are
         // issued between the first tile's MFMAs, each into the register its k-step has just freed (two tiles in flight at once
         // do not fit in 256 VGPRs next to the 128 of the two weight slices); their latency hides behind the first tile's MFMAs.
@@ -652,14 +681,12 @@ __global__ __launch_bounds__(256, 2) void lstm_stack_fwd_persist_kernel(LstmPSta
                 for (int i = 0; i < KS; ++i) rawx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ring, low0 + ro + i * rd_kstep, 0, 16);
             }
         }
-        if (layer == 0) {
-            const int t1 = t + 1 < T ? t + 1 : t;
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) XG1(m, g) = __float_as_uint(xp[m][(size_t)t1 * 4 * H + g * H]);
-        }
         __builtin_amdgcn_sched_barrier(0);
+#ifdef MG_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MG_STAMP(ta);
+        MG_STAMP_ADD(sum_load, ta, tb);
+#endif
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const unsigned rn = m + 1 < MT ? tile_off(m + 1) : 0u;
@@ -689,7 +716,19 @@ __global__ __launch_bounds__(256, 2) void lstm_stack_fwd_persist_kernel(LstmPSta
                 for (int g = 0; g < 4; ++g) red[wave][g][m][e] = acc[g][r];
             }
         }
+        if (t > 0) raise_x(t);                        // epoch t's write-through stores (issued a step ago) have long landed
+        if (layer == 0) {
+            // the next step's xproj values (first touch: HBM latency): requested only now, behind every hand-off load of this
+            // step - memory returns in order, and the second tile's loads must not wait for these
+            const int t1 = t + 1 < T ? t + 1 : t;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) xg1[m][g] = xp[m][(size_t)t1 * 4 * H + g * H];
+        }
         gp_lds_barrier();
+        MG_STAMP(tb);
+        MG_STAMP_ADD(sum_mm, tb, ta);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int e = bl * GT + jl;
@@ -705,46 +744,61 @@ __global__ __launch_bounds__(256, 2) void lstm_stack_fwd_persist_kernel(LstmPSta
             hprev[m] = active ? hnew : hprev[m];
             cprev[m] = active ? cnew : cprev[m];
             hb[m][bl][jl] = mg_f2bf(hprev[m]);
-            res[m][0][e] = hprev[m];
-            res[m][1][e] = cprev[m];
-            res[m][2][e] = active ? hnew : 0.f;
-            res[m][3][e] = ig;
-            res[m][4][e] = fg;
-            res[m][5][e] = gg;
-            res[m][6][e] = og;
+            res[m][0][e] = cprev[m];
+            res[m][1][e] = active ? hnew : 0.f;
+            res[m][2][e] = ig;
+            res[m][3][e] = fg;
+            res[m][4][e] = gg;
+            res[m][5][e] = og;
         }
         gp_lds_barrier();
+        MG_STAMP(ta);
+        MG_STAMP_ADD(sum_cell, ta, tb);
         publish(t + 1);
+        MG_STAMP(tb);
+        MG_STAMP_ADD(sum_pub, tb, ta);
         if (wave >= 2) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int e = (tid - 128) + 128 * half, rb = e >> 4, cj = j0 + (e & 15);
-                    if (16 * m + rb < nrows) {
-                        const int b = row0 + 16 * m + rb;
-                        const size_t row = (size_t)b * T + t;
-                        const size_t nxt = ((size_t)b * (T + 1) + t + 1) * H + cj;
-                        P.hstate[nxt] = res[m][0][e];
-                        P.cstate[nxt] = res[m][1][e];
-                        P.out[row * H + cj] = res[m][2][e];
-                        float* sv = P.saved + row * 4 * H + cj;
-                        sv[0] = res[m][3][e];
-                        sv[H] = res[m][4][e];
-                        sv[2 * H] = res[m][5][e];
-                        sv[3 * H] = res[m][6][e];
-                    }
+            // fp32 results needed after the launch: c_t and the gate values of every layer (BPTT), the outputs of the top layer
+            // only (the layers in between are read through the rings; their fp32 states are not kept - h_n is written at the end).
+            // 16-byte stores: job = (array, item tile), 64 lanes per job = 16 items x 4 column quads; wave 2 and wave 3 split the jobs.
+            const int n_arrays = layer + 1 == L ? 6 : 5;              // array 1 = out: top layer only
+            const int rb = lane >> 2, c4 = 4 * (lane & 3);
+            for (int job = wave - 2; job < n_arrays * MT; job += 2) {
+                const int m = job % MT, k0 = job / MT, k = (k0 >= 1 && n_arrays == 5) ? k0 + 1 : k0;
+                if (16 * m + rb < nrows) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(&res[m][k][rb * GT + c4]);
+                    const int b = row0 + 16 * m + rb;
+                    float* dst = k == 0   ? P.cstate + ((size_t)b * (T + 1) + t + 1) * H
+                                 : k == 1 ? P.out + ((size_t)b * T + t) * H
+                                          : P.saved + ((size_t)b * T + t) * 4 * H + (size_t)(k - 2) * H;
+                    *reinterpret_cast<f32x4*>(dst + j0 + c4) = v;
                 }
+            }
         }
         if (layer == 0) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) XG(m, g) = XG1(m, g);
+                for (int g = 0; g < 4; ++g) XG(m, g) = __float_as_uint(xg1[m][g]);
         }
     }
 #undef XG
-#undef XG1
+#ifdef MG_STAMPS
+    MG_STAMP(ts1);
+    MG_STAMP_REAL(tr1);
+    MG_STAMP_STORE(g_stamps_lps, blockIdx.x, wave, lane, 0, ts0);
+    MG_STAMP_STORE(g_stamps_lps, blockIdx.x, wave, lane, 1, ts1);
+    MG_STAMP_STORE(g_stamps_lps, blockIdx.x, wave, lane, 2, tr0);
+    MG_STAMP_STORE(g_stamps_lps, blockIdx.x, wave, lane, 3, tr1);
+    MG_STAMP_STORE(g_stamps_lps, blockIdx.x, wave, lane, 4, sum_poll);
+    MG_STAMP_STORE(g_stamps_lps, blockIdx.x, wave, lane, 5, sum_load);
+    MG_STAMP_STORE(g_stamps_lps, blockIdx.x, wave, lane, 6, sum_mm);
+    MG_STAMP_STORE(g_stamps_lps, blockIdx.x, wave, lane, 7, sum_cell);
+    MG_STAMP_STORE(g_stamps_lps, blockIdx.x, wave, lane, 8, sum_pub);
+    MG_STAMP_STORE(g_stamps_lps, blockIdx.x, wave, lane, 9, (unsigned long long)gmax);
+    MG_STAMP_STORE(g_stamps_lps, blockIdx.x, wave, lane, 10, (unsigned long long)(layer * 1000 + one_xcd));
+#endif
+    if (gmax > 0) raise_x(gmax);
     for (int t = gmax; t < T; ++t) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -752,10 +806,9 @@ __global__ __launch_bounds__(256, 2) void lstm_stack_fwd_persist_kernel(LstmPSta
                 const int b = row0 + 16 * m + bl;
                 const size_t row = (size_t)b * T + t;
                 const size_t nxt = ((size_t)b * (T + 1) + t + 1) * H + j;
-                P.hstate[nxt] = hprev[m];
                 P.cstate[nxt] = cprev[m];
                 P.hstate_bf[nxt] = mg_f2bf(hprev[m]);
-                P.out[row * H + j] = 0.f;
+                if (layer + 1 == L) P.out[row * H + j] = 0.f;
                 float* sv = P.saved + row * 4 * H;
                 sv[j] = 0.f;
                 sv[H + j] = 0.f;
@@ -763,6 +816,10 @@ __global__ __launch_bounds__(256, 2) void lstm_stack_fwd_persist_kernel(LstmPSta
                 sv[3 * H + j] = 0.f;
             }
     }
+    // h_n: the only fp32 state row kept (slot T of hstate)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+        if (mine[m]) P.hstate[((size_t)(row0 + 16 * m + bl) * (T + 1) + T) * H + j] = hprev[m];
 }
 
 extern "C" {
@@ -925,3 +982,9 @@ int mg_lstm_pstack_fwd_bf16(const mg_lstm_pstack_layer* layers, int L, const int
 }
 
 }  // extern "C"
+
+#ifdef MG_STAMPS
+extern "C" int mg_diag_read_stamps_lps(void* dst, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps_lps), bytes < sizeof(g_stamps_lps) ? bytes : sizeof(g_stamps_lps), 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -461,7 +461,7 @@ class LSTMStackPersistFn(torch.autograd.Function):
         ctx.save_for_backward(x_saved, seq_len, *w_ih, *w_hh, *cstate, *saved, *hstate_bf)
         hn = torch.stack([hstate[l][:, t] for l in range(n_layers)], dim=0)
         cn = torch.stack([cstate[l][:, t] for l in range(n_layers)], dim=0)
-        return out[-1], hn, cn
+        return out, hn, cn
 
     @staticmethod
     def backward(ctx, grad_out, grad_hn, grad_cn):

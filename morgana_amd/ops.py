@@ -617,11 +617,12 @@ def lstm_pstack_ok(b, t, h, n_layers):
 
 def lstm_pstack_fwd(xproj0, w_ih, w_hh, b_ih, b_hh, seq_len, h0s, c0s, b, t, h):
     """L stacked LSTM layers forward in one persistent launch.  xproj0 (b,t,4h) f32 = layer 0's input projection incl. b_ih;
-    w_ih[l] (l >= 1), w_hh[l] f32 (cast to bf16 here).  Returns per-layer lists (out, hstate, cstate, saved, hstate_bf)."""
+    w_ih[l] (l >= 1), w_hh[l] f32 (cast to bf16 here).  Returns (out of the top layer, per-layer lists hstate, cstate, saved,
+    hstate_bf); of hstate[l] only the rows 0 (h0) and T (h_n) are valid."""
     lib = _lib.load()
     dev = xproj0.device
     n_layers = len(w_hh)
-    out, hstate, cstate, saved, hstate_bf, keep = [], [], [], [], [], []
+    hstate, cstate, saved, hstate_bf, keep, o = [], [], [], [], [], None
     descs = (_lib.LstmPStackLayer * n_layers)()
     for l in range(n_layers):
         hs = torch.empty((b, t + 1, h), dtype=torch.float32, device=dev)
@@ -632,7 +633,8 @@ def lstm_pstack_fwd(xproj0, w_ih, w_hh, b_ih, b_hh, seq_len, h0s, c0s, b, t, h):
                 state[:, 0].zero_()
             else:
                 state[:, 0].copy_(init[l].reshape(b, h))
-        o = torch.empty((b, t, h), dtype=torch.float32, device=dev)
+        if l == n_layers - 1:
+            o = torch.empty((b, t, h), dtype=torch.float32, device=dev)
         sv = torch.empty((b, t, 4 * h), dtype=torch.float32, device=dev)
         whb = cast_pad_bf16(w_hh[l])
         d = descs[l]
@@ -643,9 +645,10 @@ def lstm_pstack_fwd(xproj0, w_ih, w_hh, b_ih, b_hh, seq_len, h0s, c0s, b, t, h):
             wib = cast_pad_bf16(w_ih[l])
             d.w_ih_bf, d.ldwi, d.b_ih = wib.data_ptr(), wib.shape[1], b_ih[l].data_ptr()
             keep.append(wib)
-        d.hstate, d.cstate, d.hstate_bf, d.out, d.saved = hs.data_ptr(), cs.data_ptr(), hb.data_ptr(), o.data_ptr(), sv.data_ptr()
+        d.hstate, d.cstate, d.hstate_bf, d.saved = hs.data_ptr(), cs.data_ptr(), hb.data_ptr(), sv.data_ptr()
+        d.out = o.data_ptr() if o is not None else sv.data_ptr()         # never written below the top layer
         keep.append(whb)
-        out.append(o); hstate.append(hs); cstate.append(cs); saved.append(sv); hstate_bf.append(hb)
+        hstate.append(hs); cstate.append(cs); saved.append(sv); hstate_bf.append(hb)
     key = (dev, torch.cuda.current_stream().cuda_stream, 'pstack')
     need = lib.mg_lstm_pstack_workspace_bytes(b, h, n_layers)
     ws = _PERSIST_WORKSPACES.get(key)
@@ -656,7 +659,7 @@ def lstm_pstack_fwd(xproj0, w_ih, w_hh, b_ih, b_hh, seq_len, h0s, c0s, b, t, h):
         _PERSIST_WORKSPACES[key] = ws
     _lib.check(lib.mg_lstm_pstack_fwd_bf16(ctypes.cast(descs, ctypes.c_void_p), n_layers, _p(seq_len), b, t, h, _p(ws), ws.numel(),
                                            _stream()), 'mg_lstm_pstack_fwd_bf16')
-    return out, hstate, cstate, saved, hstate_bf
+    return o, hstate, cstate, saved, hstate_bf
 
 
 def lstm_stack_fwd(descs, n_layers, seq_len, b, t, h, lag, s_begin, s_end):
