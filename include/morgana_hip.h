@@ -280,13 +280,17 @@ int mg_gru_persist_status(void* workspace, void* stream);
 int mg_gru_fwd_persist_bf16(const float* xproj, const uint16_t* w_hh_bf, int ldw, const float* b_hh, const int64_t* seq_len, int B,
                             int T, int H, float* hstate, uint16_t* hstate_bf, float* out, float* saved, void* workspace,
                             size_t workspace_bytes, void* stream);
+/* backward: dxproj_bf (optional) = bf16 shadow of dxproj [B,T,3H]; dxproj and dhproj (both or neither) may be NULL when the caller
+ * only needs the bf16 shadows (the weight- and input-gradient GEMMs of bf16 mode) - the fp32 arrays are then not written */
 int mg_gru_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const float* hstate, const float* saved,
                             const uint16_t* w_hh_t_bf, int ldt, const int64_t* seq_len, int B, int T, int H, float* dxproj,
-                            float* dhproj, uint16_t* dhproj_bf, float* dh0, void* workspace, size_t workspace_bytes, void* stream);
+                            float* dhproj, uint16_t* dhproj_bf, uint16_t* dxproj_bf, float* dh0, void* workspace,
+                            size_t workspace_bytes, void* stream);
 
 /* The LSTM recurrence (gates i, f, g, o) in the same persistent form: bf16 matmul operands, fp32 cell, one launch per
  * direction.  w_hh_bf = bf16(W_hh) [4H, ldw]; hstate_bf [B,T+1,H] = bf16 shadow of hstate (slot 0 set by the caller, the rest
- * written here); backward takes w_hh_t_bf = bf16(W_hh^T) [H, ldt >= 4H] and fills dgates [B,T,4H] and its bf16 shadow dgates_bf.
+ * written here); backward takes w_hh_t_bf = bf16(W_hh^T) [H, ldt >= 4H] and fills dgates [B,T,4H] (optional: NULL = not written)
+ * and its bf16 shadow dgates_bf.
  * Other arguments as mg_lstm_fwd_f32 / mg_lstm_bwd_f32.  Workspace, status word and residency requirement: as for the GRU entry
  * points (mg_gru_persist_workspace_bytes(B, H) covers both; mg_gru_persist_status reads the shared status word). */
 int mg_lstm_persist_supported(int B, int T, int H);

@@ -294,10 +294,10 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
                                                               const uint16_t* __restrict__ wt_bf, int ldt,
                                                               const int64_t* __restrict__ seq_len, int B, int T, int H, int R,
                                                               float* __restrict__ dxproj, float* __restrict__ dhproj,
-                                                              uint16_t* __restrict__ dhproj_bf, float* __restrict__ dh0, unsigned* sync,
+                                                              uint16_t* __restrict__ dhproj_bf, uint16_t* __restrict__ dxproj_bf, float* __restrict__ dh0, unsigned* sync,
                                                               uint16_t* ring, int force_sc1) {
     __shared__ float red[4][MT][GT * GT];
-    __shared__ __attribute__((aligned(16))) uint16_t pub[3][MT * GT][GT];
+    __shared__ __attribute__((aligned(16))) uint16_t pub[4][MT * GT][GT];      // dr, dz, dn r (the hand-off) and dn (dxproj shadow only)
     __shared__ float res[MT][4][GT * GT];          // dr, dz, dn, dn r of the step for waves 2 and 3, which store them
     __shared__ int s_abort, s_xcd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -365,21 +365,23 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
                 const size_t row = (size_t)(row0 + 16 * m + bl) * T + t;
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
-                    dxproj[row * G + g * H + j] = 0.f;
-                    dhproj[row * G + g * H + j] = 0.f;
+                    if (dxproj) dxproj[row * G + g * H + j] = 0.f;
+                    if (dhproj) dhproj[row * G + g * H + j] = 0.f;
                     dhproj_bf[row * G + g * H + j] = 0;
+                    if (dxproj_bf) dxproj_bf[row * G + g * H + j] = 0;
                 }
             }
     }
     // the slot's tile as 16-byte pieces: piece p = (gate, item, half) in ring order; lane handles pieces lane + 64 k
     constexpr int PIECES = (6 * GT * MT + 63) / 64;
-    bool pc_ok[PIECES];
+    bool pc_ok[PIECES], pc_gate2[PIECES];
     int pc_lds[PIECES];
     size_t pc_shadow[PIECES];
 #pragma unroll
     for (int k = 0; k < PIECES; ++k) {
         const int pc = lane + 64 * k, gate = pc / (2 * R), rem = pc - gate * 2 * R, rrow = rem >> 1, half = rem & 1;
         pc_ok[k] = gate < 3 && rrow < nrows;
+        pc_gate2[k] = gate == 2;
         pc_lds[k] = (gate * MT * GT + rrow) * GT + 8 * half;
         pc_shadow[k] = (size_t)(row0 + rrow) * T * G + gate * H + j0 + 8 * half;
     }
@@ -482,6 +484,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
             pub[0][16 * m + bl][jl] = mg_f2bf(dr);
             pub[1][16 * m + bl][jl] = mg_f2bf(dz);
             pub[2][16 * m + bl][jl] = mg_f2bf(dnr);
+            pub[3][16 * m + bl][jl] = mg_f2bf(dn);
         }
         if (t < 0) {
 #pragma unroll
@@ -507,6 +510,10 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
                             __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 16);
                     } else {
                         *reinterpret_cast<u32x4*>(dhproj_bf + pc_shadow[k] + (size_t)t * G) = v;
+                        if (dxproj_bf) {                 // (dr, dz, dn): the n plane differs from the hand-off's dn r
+                            const u32x4 vx = pc_gate2[k] ? *reinterpret_cast<const u32x4*>(&pub[0][0][0] + pc_lds[k] + MT * GT * GT) : v;
+                            *reinterpret_cast<u32x4*>(dxproj_bf + pc_shadow[k] + (size_t)t * G) = vx;
+                        }
                     }
                 }
             }
@@ -517,7 +524,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
         }
         MG_STAMP(tb);
         MG_STAMP_ADD(sum_pub, tb, ta);
-        if (wave >= 2) {                                // fp32 results: waves 2 and 3 only (see the forward kernel)
+        if (wave >= 2 && dxproj) {                      // fp32 results (optional): waves 2 and 3 only (see the forward kernel)
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -629,12 +636,13 @@ int mg_gru_fwd_persist_bf16(const float* xproj, const uint16_t* w_hh_bf, int ldw
 
 int mg_gru_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const float* hstate, const float* saved, const uint16_t* w_hh_t_bf,
                             int ldt, const int64_t* seq_len, int B, int T, int H, float* dxproj, float* dhproj, uint16_t* dhproj_bf,
-                            float* dh0, void* workspace, size_t workspace_bytes, void* stream) {
-    MG_CHECK_ARG(grad_out && hstate && saved && w_hh_t_bf && dxproj && dhproj && dhproj_bf && dh0 && B > 0 && T > 0 && H > 0,
+                            uint16_t* dxproj_bf, float* dh0, void* workspace, size_t workspace_bytes, void* stream) {
+    MG_CHECK_ARG(grad_out && hstate && saved && w_hh_t_bf && dhproj_bf && dh0 && B > 0 && T > 0 && H > 0 && (!dxproj == !dhproj) &&
+                     (dxproj || dxproj_bf),
                  "mg_gru_bwd_persist_bf16: bad arguments (B=%d T=%d H=%d)", B, T, H);
     MG_CHECK_ARG(mg_gru_persist_supported(B, T, H) && ldt >= 3 * H && ldt % 8 == 0,
                  "mg_gru_bwd_persist_bf16: unsupported shape (B=%d T=%d H=%d ldt=%d): needs H %% 128 == 0, H <= 512, B <= 256", B, T, H, ldt);
-    MG_CHECK_ARG((((uintptr_t)w_hh_t_bf | (uintptr_t)dhproj_bf | (uintptr_t)workspace) % 16) == 0,
+    MG_CHECK_ARG((((uintptr_t)w_hh_t_bf | (uintptr_t)dhproj_bf | (uintptr_t)dxproj_bf | (uintptr_t)workspace) % 16) == 0,
                  "mg_gru_bwd_persist_bf16: bf16 buffers and workspace must be 16-byte aligned");
     if (!workspace || workspace_bytes < mg_gru_persist_workspace_bytes(B, H)) {
         mg_set_error("mg_gru_bwd_persist_bf16: workspace of %zu bytes needed, got %zu", mg_gru_persist_workspace_bytes(B, H), workspace_bytes);
@@ -649,7 +657,7 @@ int mg_gru_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const f
     const unsigned grid = (unsigned)(GP_GROUPS * (H / GT));
 #define GP_BWD(MT, KS)                                                                                                                      \
     hipLaunchKernelGGL((gru_bwd_persist_kernel<MT, KS>), dim3(grid), dim3(256), 0, st, grad_out, grad_hn, hstate, saved, w_hh_t_bf, ldt, seq_len, \
-                       B, T, H, R, dxproj, dhproj, dhproj_bf, dh0, (unsigned*)workspace, (uint16_t*)((char*)workspace + GP_RING_OFFSET),           \
+                       B, T, H, R, dxproj, dhproj, dhproj_bf, dxproj_bf, dh0, (unsigned*)workspace, (uint16_t*)((char*)workspace + GP_RING_OFFSET),           \
                        g_mg_tuning[MG_TUNE_GRU_HANDOFF] == 1)
 #define GP_BWD_KS(MT)                  \
     switch (H / 128) {                 \

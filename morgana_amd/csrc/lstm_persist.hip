@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(const float* __re
                 const size_t row = (size_t)(row0 + 16 * m + bl) * T + t;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    dgates[row * G + g * H + j] = 0.f;
+                    if (dgates) dgates[row * G + g * H + j] = 0.f;
                     dgates_bf[row * G + g * H + j] = 0;
                 }
             }
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(const float* __re
                 if (lane == 0) gp_store_flag(flags + slot, (unsigned)(gmax - t), one_xcd);
             }
         }
-        if (wave >= 2) {
+        if (wave >= 2 && dgates) {                      // optional fp32 copy of the gate gradients
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -874,7 +874,7 @@ int mg_lstm_fwd_persist_bf16(const float* xproj, const uint16_t* w_hh_bf, int ld
 int mg_lstm_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const float* grad_cn, const float* cstate, const float* saved,
                              const uint16_t* w_hh_t_bf, int ldt, const int64_t* seq_len, int B, int T, int H, float* dgates,
                              uint16_t* dgates_bf, float* dh0, float* dc0, void* workspace, size_t workspace_bytes, void* stream) {
-    MG_CHECK_ARG(grad_out && cstate && saved && w_hh_t_bf && dgates && dgates_bf && dh0 && dc0 && B > 0 && T > 0 && H > 0,
+    MG_CHECK_ARG(grad_out && cstate && saved && w_hh_t_bf && dgates_bf && dh0 && dc0 && B > 0 && T > 0 && H > 0,
                  "mg_lstm_bwd_persist_bf16: bad arguments (B=%d T=%d H=%d)", B, T, H);
     MG_CHECK_ARG(mg_lstm_persist_supported(B, T, H) && ldt >= 4 * H && ldt % 8 == 0,
                  "mg_lstm_bwd_persist_bf16: unsupported shape (B=%d T=%d H=%d ldt=%d): needs H %% 128 == 0, H <= 512, B <= 256", B, T, H, ldt);

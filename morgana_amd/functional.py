@@ -269,6 +269,23 @@ class LinearStackMSEFn(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(grads)
 
 
+_STATE_ROWS = {}
+
+
+def state_rows(b, t, device, shift=0):
+    """int32 row indices b (T+1) + t + shift, t < T, into a (B, T+1, H) state array viewed as (B (T+1), H): shift 0 = h_{t-1}
+    (the recurrent operand of step t), shift 1 = h_t.  Cached per shape: five tiny launches per call otherwise."""
+    key = (b, t, str(device), shift)
+    rows = _STATE_ROWS.get(key)
+    if rows is None:
+        rows = (torch.arange(b, device=device, dtype=torch.int32)[:, None] * (t + 1) +
+                torch.arange(t, device=device, dtype=torch.int32)[None, :] + shift).reshape(-1).contiguous()
+        if len(_STATE_ROWS) > 64:
+            _STATE_ROWS.clear()
+        _STATE_ROWS[key] = rows
+    return rows
+
+
 # In bf16 precision the GRU recurrence runs its two per-step matmuls on bf16 operands (fp32 accumulate, fp32 cell arithmetic and
 # states) when the hidden size allows it; set_recurrence_bf16(False) keeps the exact-fp32 MFMA recurrence under bf16 layers.
 RECURRENCE_BF16 = os.environ.get('MORGANA_RECURRENCE', 'bf16') != 'fp32'
@@ -318,16 +335,19 @@ class GRUFn(torch.autograd.Function):
         g_out = grad_out.contiguous() if grad_out is not None else torch.zeros((b, t, hid), dtype=torch.float32,
                                                                                 device=hstate.device)
         g_hn = grad_hn.reshape(b, hid).contiguous() if grad_hn is not None else None
-        dhproj_bf = None
-        if ctx.bf16_recurrence:
+        dhproj_bf = dxproj_bf = dxp2 = dhp2 = None
+        m = b * t
+        if ctx.bf16_recurrence and ops.gru_persist_ok(b, t, hid):
+            # persistent recurrence: only the bf16 shadows of the gate gradients are written (the GEMMs below take bf16)
+            dxproj_bf, dhproj_bf, dh0 = ops.gru_bwd_bf16(g_out, g_hn, hstate, saved, w_hh, seq_len, b, t, hid, shadows_only=True)
+        elif ctx.bf16_recurrence:
             dxproj, dhproj, dh0, dhproj_bf = ops.gru_bwd_bf16(g_out, g_hn, hstate, saved, w_hh, seq_len, b, t, hid)
+            dxp2, dhp2 = dxproj.view(m, 3 * hid), dhproj.view(m, 3 * hid)
         else:
             dxproj, dhproj, dh0 = ops.gru_bwd(g_out, g_hn, hstate, saved, w_hh, seq_len, b, t, hid)
-        m = b * t
-        dxp2, dhp2 = dxproj.view(m, 3 * hid), dhproj.view(m, 3 * hid)
+            dxp2, dhp2 = dxproj.view(m, 3 * hid), dhproj.view(m, 3 * hid)
         # h_{t-1} rows of hstate (B, T+1, H): row b*(T+1) + t
-        prev_rows = (torch.arange(b, device=hstate.device, dtype=torch.int32)[:, None] * (t + 1) +
-                     torch.arange(t, device=hstate.device, dtype=torch.int32)[None, :]).reshape(-1).contiguous()
+        prev_rows = state_rows(b, t, hstate.device)
         hs2 = hstate.view(b * (t + 1), hid)
         need_x = ctx.needs_input_grad[1]
         dx = None
@@ -337,7 +357,7 @@ class GRUFn(torch.autograd.Function):
             if need_x:
                 dx = ops.linear_dgrad_f32(dxp2, w_ih, None).view(b, t, i_dim)
         else:
-            dxp_bf = ops.cast_pad_bf16(dxp2)
+            dxp_bf = dxproj_bf.view(m, 3 * hid) if dxproj_bf is not None else ops.cast_pad_bf16(dxp2)
             # the bf16 recurrence already wrote the bf16 shadows of dhproj and of the states
             dhp_bf = dhproj_bf.view(m, 3 * hid) if dhproj_bf is not None else ops.cast_pad_bf16(dhp2)
             hs_bf = hstate_bf.view(b * (t + 1), hid) if hstate_bf is not None else ops.cast_pad_bf16(hs2)
@@ -399,13 +419,12 @@ class LSTMFn(torch.autograd.Function):
         g_cn = grad_cn.reshape(b, hid).contiguous() if grad_cn is not None else None
         dgates_bf = None
         if ctx.persistent:
-            dgates, dh0, dc0, dgates_bf = ops.lstm_bwd_bf16(g_out, g_hn, g_cn, cstate, saved, w_hh, seq_len, b, t, hid)
+            dgates, dh0, dc0, dgates_bf = ops.lstm_bwd_bf16(g_out, g_hn, g_cn, cstate, saved, w_hh, seq_len, b, t, hid, want_f32=False)
         else:
             dgates, dh0, dc0 = ops.lstm_bwd(g_out, g_hn, g_cn, cstate, saved, w_hh, seq_len, b, t, hid)
         m = b * t
-        dg2 = dgates.view(m, 4 * hid)
-        prev_rows = (torch.arange(b, device=dev, dtype=torch.int32)[:, None] * (t + 1) +
-                     torch.arange(t, device=dev, dtype=torch.int32)[None, :]).reshape(-1).contiguous()
+        dg2 = dgates.view(m, 4 * hid) if dgates is not None else None
+        prev_rows = state_rows(b, t, dev)
         hs2 = hstate.view(b * (t + 1), hid)
         need_x = ctx.needs_input_grad[1]
         dx = None
@@ -476,10 +495,8 @@ class LSTMStackPersistFn(torch.autograd.Function):
         hstate_bf = sv[pos:pos + n_layers]
         dev = x_saved.device
         m = b * t
-        batch = torch.arange(b, device=dev, dtype=torch.int32)[:, None] * (t + 1)
-        steps = torch.arange(t, device=dev, dtype=torch.int32)[None, :]
-        prev_rows = (batch + steps).reshape(-1).contiguous()              # h_{t-1} of hstate (B, T+1, H): row b (T+1) + t
-        next_rows = (batch + steps + 1).reshape(-1).contiguous()          # h_t: the input of the layer above at step t
+        prev_rows = state_rows(b, t, dev)                                 # h_{t-1} of hstate (B, T+1, H): row b (T+1) + t
+        next_rows = state_rows(b, t, dev, shift=1)                        # h_t: the input of the layer above at step t
         g_out = grad_out.contiguous() if grad_out is not None else torch.zeros((b, t, hid), dtype=torch.float32, device=dev)
         grads = [None] * (4 * n_layers)
         dh0 = torch.empty((n_layers, b, hid), dtype=torch.float32, device=dev)
@@ -488,7 +505,7 @@ class LSTMStackPersistFn(torch.autograd.Function):
         for l in range(n_layers - 1, -1, -1):
             g_hn = grad_hn[l].reshape(b, hid).contiguous() if grad_hn is not None else None
             g_cn = grad_cn[l].reshape(b, hid).contiguous() if grad_cn is not None else None
-            dgates, dh0_l, dc0_l, dg_bf = ops.lstm_bwd_bf16(g_out, g_hn, g_cn, cstate[l], saved[l], w_hh[l], seq_len, b, t, hid)
+            _, dh0_l, dc0_l, dg_bf = ops.lstm_bwd_bf16(g_out, g_hn, g_cn, cstate[l], saved[l], w_hh[l], seq_len, b, t, hid, want_f32=False)
             dh0[l], dc0[l] = dh0_l, dc0_l
             dg_bf = dg_bf.view(m, 4 * hid)
             if l == 0:
@@ -659,8 +676,7 @@ class LSTMStackFn(torch.autograd.Function):
             ops.lstm_stack_bwd(descs, n_layers, seq_len, b, t, hid, lag, u0, min(u0 + lag, u_end))
         # weight gradients and the gradient w.r.t. the stack's input: big GEMMs over all frames, as for a single layer
         m = b * t
-        prev_rows = (torch.arange(b, device=dev, dtype=torch.int32)[:, None] * (t + 1) +
-                     torch.arange(t, device=dev, dtype=torch.int32)[None, :]).reshape(-1).contiguous()
+        prev_rows = state_rows(b, t, dev)
         grads = []
         for l in range(n_layers):
             dg2 = dgates[l].view(m, 4 * hid)

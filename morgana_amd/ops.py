@@ -511,12 +511,23 @@ def gru_fwd_bf16(xproj, w_hh, b_hh, seq_len, h0, b, t, h, persistent=None):
     return out, hstate, saved, hstate_bf
 
 
-def gru_bwd_bf16(grad_out, grad_hn, hstate, saved, w_hh, seq_len, b, t, h, persistent=None):
-    """gru_bwd with bf16 matmul operands.  Returns (dxproj, dhproj, dh0, dhproj_bf (b,t,3h) bf16)."""
+def gru_bwd_bf16(grad_out, grad_hn, hstate, saved, w_hh, seq_len, b, t, h, persistent=None, shadows_only=False):
+    """gru_bwd with bf16 matmul operands.  Returns (dxproj, dhproj, dh0, dhproj_bf (b,t,3h) bf16).
+    shadows_only (persistent kernel only): returns (dxproj_bf, dhproj_bf, dh0) and does not write the fp32 arrays."""
     lib = _lib.load()
     if persistent is None:
         persistent = gru_persist_ok(b, t, h)
     dev = grad_out.device
+    if shadows_only and persistent:
+        dxproj_bf = torch.empty((b, t, 3 * h), dtype=torch.bfloat16, device=dev)
+        dhproj_bf = torch.empty((b, t, 3 * h), dtype=torch.bfloat16, device=dev)
+        dh0 = torch.empty((b, h), dtype=torch.float32, device=dev)
+        wt_bf = cast_transpose_bf16(w_hh)
+        ws = _persist_workspace(dev, b, h)
+        _lib.check(lib.mg_gru_bwd_persist_bf16(_p(grad_out), _p(grad_hn), _p(hstate), _p(saved), _p(wt_bf), wt_bf.shape[1], _p(seq_len),
+                                               b, t, h, None, None, _p(dhproj_bf), _p(dxproj_bf), _p(dh0), _p(ws), ws.numel(),
+                                               _stream()), 'mg_gru_bwd_persist_bf16')
+        return dxproj_bf, dhproj_bf, dh0
     dxproj = torch.empty((b, t, 3 * h), dtype=torch.float32, device=dev)
     dhproj = torch.empty((b, t, 3 * h), dtype=torch.float32, device=dev)
     dhproj_bf = torch.empty((b, t, 3 * h), dtype=torch.bfloat16, device=dev)
@@ -525,8 +536,8 @@ def gru_bwd_bf16(grad_out, grad_hn, hstate, saved, w_hh, seq_len, b, t, h, persi
     if persistent:
         ws = _persist_workspace(dev, b, h)
         _lib.check(lib.mg_gru_bwd_persist_bf16(_p(grad_out), _p(grad_hn), _p(hstate), _p(saved), _p(wt_bf), wt_bf.shape[1], _p(seq_len),
-                                               b, t, h, _p(dxproj), _p(dhproj), _p(dhproj_bf), _p(dh0), _p(ws), ws.numel(), _stream()),
-                   'mg_gru_bwd_persist_bf16')
+                                               b, t, h, _p(dxproj), _p(dhproj), _p(dhproj_bf), None, _p(dh0), _p(ws), ws.numel(),
+                                               _stream()), 'mg_gru_bwd_persist_bf16')
         return dxproj, dhproj, dh0, dhproj_bf
     nbytes = lib.mg_gru_bwd_workspace_bytes(b, h)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -594,11 +605,12 @@ def lstm_fwd_bf16(xproj, w_hh, b_hh, seq_len, h0, c0, b, t, h):
     return out, hstate, cstate, saved, hstate_bf
 
 
-def lstm_bwd_bf16(grad_out, grad_hn, grad_cn, cstate, saved, w_hh, seq_len, b, t, h):
-    """lstm_bwd with bf16 matmul operands, one persistent launch.  Returns (dgates, dh0, dc0, dgates_bf)."""
+def lstm_bwd_bf16(grad_out, grad_hn, grad_cn, cstate, saved, w_hh, seq_len, b, t, h, want_f32=True):
+    """lstm_bwd with bf16 matmul operands, one persistent launch.  Returns (dgates, dh0, dc0, dgates_bf); want_f32=False: the
+    fp32 gate gradients are not written (dgates = None) - bf16 mode's GEMMs take the shadow."""
     lib = _lib.load()
     dev = grad_out.device
-    dgates = torch.empty((b, t, 4 * h), dtype=torch.float32, device=dev)
+    dgates = torch.empty((b, t, 4 * h), dtype=torch.float32, device=dev) if want_f32 else None
     dgates_bf = torch.empty((b, t, 4 * h), dtype=torch.bfloat16, device=dev)
     dh0 = torch.empty((b, h), dtype=torch.float32, device=dev)
     dc0 = torch.empty((b, h), dtype=torch.float32, device=dev)

@@ -765,6 +765,10 @@ def test_gru_persistent_equals_stepwise(b, t, hid, gru_handoff):
                 ops.check_persistent_status()
                 for name, g, w in zip(('dxproj', 'dhproj', 'dh0', 'dhproj_bf'), got_b, want_b):
                     np.testing.assert_array_equal(g.float().cpu().numpy(), w.float().cpu().numpy(), err_msg='%s rep %d' % (name, rep))
+            # the form GRUFn uses in bf16 mode: only the bf16 shadows are written
+            dx_bf, dh_bf, dh0 = ops.gru_bwd_bf16(g_out, grad_hn, hstate, saved, w_hh, sl, b, t, hid, persistent=True, shadows_only=True)
+            ops.check_persistent_status()
+            assert torch.equal(dx_bf, want_b[0].to(torch.bfloat16)) and torch.equal(dh_bf, want_b[3]) and torch.equal(dh0, want_b[2])
 
 
 @pytest.mark.parametrize('b,t,hid', [(64, 40, 512), (5, 37, 128), (33, 20, 256), (200, 9, 128)])
