@@ -168,6 +168,47 @@ def roofline_gru(features, model, precision, target):
                     % dom['us_per_step'], 'kernels': measured}
 
 
+def roofline_lstm(features, model, precision):
+    """Time the recurrence launches of the LSTM stack in isolation: the whole-stack forward wavefront (one launch) and one
+    layer's backward recurrence.  Same remark as roofline_gru: dependent chains, the MFMA fraction is reported as it is."""
+    wrappers = [mod for mod in model.modules() if isinstance(mod, torch.nn.LSTM)]
+    n_layers, hid = len(wrappers), wrappers[0].hidden_size
+    b = features['n_frames'].shape[0]
+    dev = features['n_frames'].device
+    seq_len = features['n_frames'].to(dev).view(-1)
+    t = int(seq_len.max().item())
+    w_ih = [m.weight_ih_l0.detach() for m in wrappers]
+    w_hh = [m.weight_hh_l0.detach() for m in wrappers]
+    b_ih = [m.bias_ih_l0.detach() for m in wrappers]
+    b_hh = [m.bias_hh_l0.detach() for m in wrappers]
+    xproj = torch.randn(b, t, 4 * hid, device=dev)
+    g_out = torch.randn(b, t, hid, device=dev) * 0.01
+    frames = float(seq_len.sum().item())
+    measured = []
+    if precision == 'bf16' and ops.lstm_pstack_ok(b, t, hid, n_layers):
+        out, hstate, cstate, saved, hstate_bf = ops.lstm_pstack_fwd(xproj, w_ih, w_hh, b_ih, b_hh, seq_len, None, None, b, t, hid)
+        flops_f = 2.0 * frames * 4 * hid * hid * (2 * n_layers - 1)       # W_hh of every layer + W_ih of the layers above the first
+        ms = time_kernel(lambda: ops.lstm_pstack_fwd(xproj, w_ih, w_hh, b_ih, b_hh, seq_len, None, None, b, t, hid), iters=3, warm=1)
+        measured.append({'kernel': 'lstm_stack_fwd_persist_kernel: %d layers, %d wavefront steps' % (n_layers, t + n_layers - 1),
+                         'ms': round(ms, 4), 'gflop': round(flops_f / 1e9, 1), 'tflops': round(flops_f / (ms * 1e-3) / 1e12, 2),
+                         'us_per_step': round(ms * 1e3 / (t + n_layers - 1), 3)})
+        flops_b = 2.0 * frames * 4 * hid * hid
+        ms = time_kernel(lambda: ops.lstm_bwd_bf16(g_out, None, None, cstate[0], saved[0], w_hh[0], seq_len, b, t, hid, want_f32=False),
+                         iters=3, warm=1)
+        measured.append({'kernel': 'lstm_bwd_persist_kernel: one layer, %d dependent steps (x %d layers per training step)' % (t, n_layers),
+                         'ms': round(ms, 4), 'gflop': round(flops_b / 1e9, 1), 'tflops': round(flops_b / (ms * 1e-3) / 1e12, 2),
+                         'us_per_step': round(ms * 1e3 / t, 3)})
+        ops.check_persistent_status()
+    if not measured:
+        return None
+    dom = max(measured, key=lambda r: r['ms'])
+    peak = MFMA_BF16_PEAK_TFLOPS
+    return {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': dom['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
+            'frac': round(dom['tflops'] / peak, 4), 'traffic': None, 'ms_per_launch': dom['ms'],
+            'note': 'latency / L2-traffic bound chain: %.2f us per dependent step, not an MFMA-rate limit' % dom['us_per_step'],
+            'kernels': measured}
+
+
 def host_cores():
     """CPU threads this process may really use: affinity, capped by the cgroup CPU quota (the GPU box gives a 1-GPU job
     a share of the host, not all of its cores) and by 32 (the 64 x 1000-frame sample does not scale further)."""
@@ -317,6 +358,10 @@ def main():
         result['roofline'] = roofline_f0(features, model, args.precision)
     if rank == 0 and args.config in ('c4', 'c5') and not args.no_roofline:
         result['roofline'] = roofline_gru(features, model, args.precision, target)
+    if rank == 0 and args.config == 'lstm' and not args.no_roofline:
+        roof = roofline_lstm(features, model, args.precision)
+        if roof is not None:
+            result['roofline'] = roof
     if rank == 0 and n_gpus == 1 and args.config == 'c2' and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline_f0(args.frames)
     distributed.barrier()
