@@ -139,6 +139,23 @@ int mg_stream_loss_f32(const float* pred, const mg_stream_desc* streams, int n_s
                        int D, float grad_scale, float* loss, float* grad, float* prob, void* workspace,
                        size_t workspace_bytes, void* stream);
 
+/* Streaming metrics (reference: morgana/metrics.py:359-695; accumulated inside the shipped model's loss() every step,
+ * models/RNN_SPSS.py:120-129): accum[0] += sum, accum[1] += count on the device - no host read-back (the reference calls .item()
+ * per accumulate).  kind: MG_METRIC_MEAN (target only), _SQDIFF (RMSE / MelCepDistortion), _ABSDIFF (MAE), _ROOT_SQ (Distortion:
+ * per-frame root of the summed squares), _SQDIFF_VOICED (F0Distortion), _SQDIFF_VOICED_EXP (LF0Distortion: on exp of both).
+ * target / pred [B,T,D] f32, columns [col0, col0 + width) take part; voiced [B,T] f32 0/1 (voiced kinds); seq_len may be NULL.
+ * The masked count is in frames, the unmasked one in elements, as in the reference (metrics.py:383-394). */
+#define MG_METRIC_MEAN 0
+#define MG_METRIC_SQDIFF 1
+#define MG_METRIC_ABSDIFF 2
+#define MG_METRIC_ROOT_SQ 3
+#define MG_METRIC_SQDIFF_VOICED 4
+#define MG_METRIC_SQDIFF_VOICED_EXP 5
+size_t mg_metric_workspace_bytes(void);
+int mg_metric_accumulate_f32(int kind, const float* target, const float* pred, const float* voiced, const int64_t* seq_len, int B,
+                             int T, int D, int col0, int width, double* accum, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * K5  mvn / minmax normalisers            reference: morgana/data.py:533-538, 579-590
  * ---------------------------------------------------------------------------------------------------------------- */

@@ -83,6 +83,9 @@ SIGNATURES = {
                                          c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'mg_lstm_bwd_persist_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                                          c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'mg_metric_workspace_bytes': (c_size_t, []),
+    'mg_metric_accumulate_f32': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                         c_void_p, c_size_t, c_void_p]),
     'mg_gru_bwd_workspace_bytes': (c_size_t, [c_int, c_int]),
     'mg_gru_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

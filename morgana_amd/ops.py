@@ -703,3 +703,26 @@ def ema_update(shadow, param, decay):
         raise ValueError('ema_update: tensors must be contiguous device tensors')
     _lib.check(lib.mg_ema_update_f32(_p(shadow), _p(param), shadow.numel(), float(decay), _stream()),
                'mg_ema_update_f32')
+
+
+# ----------------------------------------------------------------------------------------------------------- metrics
+METRIC_MEAN, METRIC_SQDIFF, METRIC_ABSDIFF, METRIC_ROOT_SQ, METRIC_SQDIFF_VOICED, METRIC_SQDIFF_VOICED_EXP = range(6)
+
+
+def metric_accumulate(kind, accum, target, pred=None, voiced=None, seq_len=None, col0=0, width=None):
+    """accum (2,) float64 on the device: accum += (sum, count) of one batch (csrc/metrics.hip).  target / pred (B, T, D) f32."""
+    lib = _lib.load()
+    target = _require(target, torch.float32, 'target')
+    if target.dim() != 3:
+        raise ValueError('metric inputs must have shape (batch, time, features), got %s' % (tuple(target.shape),))
+    b, t, d = target.shape
+    width = d - col0 if width is None else width
+    if pred is not None:
+        pred = _require(pred, torch.float32, 'pred')
+        if pred.shape != target.shape:
+            raise ValueError('target %s and prediction %s differ in shape' % (tuple(target.shape), tuple(pred.shape)))
+    if voiced is not None:
+        voiced = voiced.reshape(b, t).to(torch.float32).contiguous()
+    ws = torch.empty(lib.mg_metric_workspace_bytes(), dtype=torch.uint8, device=target.device)
+    _lib.check(lib.mg_metric_accumulate_f32(kind, _p(target), _p(pred), _p(voiced), _p(seq_len), b, t, d, col0, width, _p(accum), _p(ws),
+                                            ws.numel(), _stream()), 'mg_metric_accumulate_f32')

@@ -19,6 +19,8 @@ Fixtures:
   g6_f0_model.npz         README F0Model at C1: 20-step Adam loss curve, step-1 grad norms + samples, final checksums
   g7_gru.npz              RecurrentCuDNNWrapper(GRU): outputs, final hidden, grads; small RNN_SPSS-layout model curve
   g9_ema_lr.npz           EMA update, Noam / CyclicNoam sequences, metrics.Mean
+  g10 .. g14              LSTM wrapper, BCE, the shipped LSTM acoustic model and GRU F0 model, segment ops (see the functions)
+  g15_metrics.npz         streaming metrics (Mean / RMSE / MAE / Distortion / MelCepDistortion / F0 / LF0): sum, count, result
 """
 import os
 import sys
@@ -747,3 +749,59 @@ def g14_segments():
 
 if __name__ == '__main__' and (len(sys.argv) == 1 or sys.argv[1] == 'g14'):
     g14_segments()
+
+
+def g15_metrics():
+    """G15: the streaming metrics the shipped acoustic model registers (models/RNN_SPSS.py:44-48) plus their base classes,
+    morgana/metrics.py:359-695: two accumulate calls each (ragged seq_len, then none where the class allows it) -> sum, count
+    and result as the reference computes them."""
+    import torch
+    utils, losses, data, base_models, lr_schedules, metrics = import_reference()
+    rng = np.random.RandomState(1515)
+    g = {}
+    b, t = 5, 23
+    seq = np.array([23, 7, 15, 1, 20], dtype=np.int64)
+    g['seq_len'] = seq
+    sl = torch.from_numpy(seq)
+
+    def arr(d, scale=1.0, shift=0.0):
+        return (rng.standard_normal((b, t, d)) * scale + shift).astype(np.float32)
+
+    def run(name, metric, calls):
+        metric.reset_state()           # as Handler.reset_state does at the start of an epoch (RMSE.__init__ does not create the sums)
+        for args in calls:
+            metric.accumulate(*[torch.from_numpy(a) if isinstance(a, np.ndarray) else a for a in args])
+        g[name + '__sum'] = np.float64(float(metric.sum))
+        g[name + '__count'] = np.float64(float(metric.count))
+        g[name + '__result'] = np.float64(float(metric.result()))
+
+    for d in (1, 5):
+        x1, x2 = arr(d), arr(d)
+        g['mean_d%d__x1' % d], g['mean_d%d__x2' % d] = x1, x2
+        run('mean_d%d' % d, metrics.Mean(), [(x1, sl), (x2, None)])
+        t1, p1, t2, p2 = arr(d), arr(d), arr(d), arr(d)
+        for k, v in (('t1', t1), ('p1', p1), ('t2', t2), ('p2', p2)):
+            g['pair_d%d__%s' % (d, k)] = v
+        run('rmse_d%d' % d, metrics.RMSE(), [(t1, p1, sl), (t2, p2, None)])
+        run('mae_d%d' % d, metrics.MAE(), [(t1, p1, sl), (t2, p2, None)])
+        run('distortion_d%d' % d, metrics.Distortion(), [(t1, p1, sl), (t2, p2, None)])
+    # mel-cepstral distortion ignores c0 (60-dim static mcep of the shipped model)
+    t1, p1 = arr(60, 0.3), arr(60, 0.3)
+    g['mcd__t1'], g['mcd__p1'] = t1, p1
+    run('mcd', metrics.MelCepDistortion(), [(t1, p1, sl), (t1[:, ::-1].copy(), p1, None)])
+    # LF0 distortion in Hz on voiced frames only
+    lt, lp = arr(1, 0.2, 5.0), arr(1, 0.2, 5.0)
+    voiced = rng.rand(b, t, 1) > 0.4
+    g['lf0__t'], g['lf0__p'], g['lf0__voiced'] = lt, lp, voiced
+    run('lf0', metrics.LF0Distortion(), [(lt, lp, torch.from_numpy(voiced), sl), (lp, lt, torch.from_numpy(~voiced), None)])
+    run('f0', metrics.F0Distortion(), [(np.exp(lt), np.exp(lp), torch.from_numpy(voiced), sl)])
+    # V/UV accuracy as the model accumulates it: Mean of a float comparison
+    vuv_t, vuv_p = rng.rand(b, t, 1) > 0.5, rng.rand(b, t, 1) > 0.5
+    g['vuv__t'], g['vuv__p'] = vuv_t, vuv_p
+    run('vuv_acc', metrics.Mean(), [((vuv_t == vuv_p).astype(np.float32), sl)])
+    np.savez_compressed(os.path.join(HERE, 'g15_metrics.npz'), **g)
+    print('g15_metrics.npz', os.path.getsize(os.path.join(HERE, 'g15_metrics.npz')), 'bytes')
+
+
+if __name__ == '__main__' and (len(sys.argv) == 1 or sys.argv[1] == 'g15'):
+    g15_metrics()

@@ -1124,3 +1124,47 @@ def test_adam_and_ema_vs_oracle(golden):
     for params in g['ema_params_seq']:
         ops.ema_update(shadow, dev(params), float(g['ema_decay']))
     np.testing.assert_allclose(shadow.cpu().numpy(), g['ema_shadow_final'], rtol=1e-5, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------- streaming metrics
+@pytest.mark.parametrize('name,cls,kind', [('mean_d5', 'DeviceMean', 'mean'), ('rmse_d5', 'RMSE', 'sqdiff'), ('mae_d1', 'MAE', 'absdiff'),
+                                           ('distortion_d5', 'Distortion', 'root_sq'), ('mcd', 'MelCepDistortion', 'sqdiff'),
+                                           ('lf0', 'LF0Distortion', 'sqdiff_voiced_exp'), ('f0', 'F0Distortion', 'sqdiff_voiced'),
+                                           ('vuv_acc', 'DeviceMean', 'mean')])
+def test_streaming_metrics_golden(golden, name, cls, kind):
+    """morgana_amd.metrics device accumulators (csrc/metrics.hip) against the reference's sum / count / result for the same
+    accumulate calls (tests/golden/g15_metrics.npz): count exact, sum and result to 1e-5."""
+    from morgana_amd import metrics
+    from test_oracle_golden import metric_calls
+    g = golden('g15_metrics.npz')
+    metric = getattr(metrics, cls)()
+    for call in metric_calls(g, name):
+        args = [dev(np.ascontiguousarray(call['target']))]
+        if 'pred' in call:
+            args.append(dev(np.ascontiguousarray(call['pred'])))
+        if 'voiced' in call:
+            args.append(dev(call['voiced']))
+        metric.accumulate(*args, seq_len=dev(call['seq_len']) if 'seq_len' in call else None)
+    assert float(metric.count) == float(g[name + '__count'])
+    np.testing.assert_allclose(float(metric.sum), float(g[name + '__sum']), rtol=1e-5)
+    np.testing.assert_allclose(float(metric.result()), float(g[name + '__result']), rtol=1e-5)
+
+
+def test_streaming_metric_full_size_vs_oracle():
+    """MelCepDistortion and LF0Distortion at the shipped model's batch (64 x 1000 frames, 60 mel-cepstra) against the numpy oracle."""
+    from morgana_amd import metrics
+    rng = np.random.RandomState(77)
+    b, t = 64, 1000
+    seq = rng.randint(300, t + 1, size=b).astype(np.int64)
+    tm, pm = rng.standard_normal((b, t, 60)).astype(np.float32), rng.standard_normal((b, t, 60)).astype(np.float32)
+    mcd = metrics.MelCepDistortion()
+    mcd.accumulate(dev(tm), dev(pm), seq_len=dev(seq))
+    s, c = ref_cpu.metric_sums('sqdiff', tm, pm, seq_len=seq, col0=1)
+    np.testing.assert_allclose(float(mcd.result()), ref_cpu.metric_result('sqdiff', s, c), rtol=1e-5)
+    lt, lp = (rng.standard_normal((b, t, 1)) * 0.2 + 5).astype(np.float32), (rng.standard_normal((b, t, 1)) * 0.2 + 5).astype(np.float32)
+    voiced = rng.rand(b, t, 1) > 0.3
+    lf0 = metrics.LF0Distortion()
+    lf0.accumulate(dev(lt), dev(lp), dev(voiced), seq_len=dev(seq))
+    s, c = ref_cpu.metric_sums('sqdiff_voiced_exp', lt, lp, voiced=voiced, seq_len=seq)
+    assert float(lf0.count) == c
+    np.testing.assert_allclose(float(lf0.result()), ref_cpu.metric_result('sqdiff_voiced_exp', s, c), rtol=1e-5)

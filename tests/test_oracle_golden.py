@@ -339,3 +339,45 @@ def test_g14_segment_ops(golden, tag):
     x, lens = g[tag + '__x'], g[tag + '__lens']
     assert np.array_equal(ref_cpu.split_to_segments(x, lens), g[tag + '__split'])
     assert np.array_equal(ref_cpu.get_segment_ends(x, lens), g[tag + '__ends'])
+
+
+METRIC_CASES = [('mean_d1', 'mean', None), ('mean_d5', 'mean', None), ('rmse_d1', 'sqdiff', None), ('rmse_d5', 'sqdiff', None),
+                ('mae_d1', 'absdiff', None), ('mae_d5', 'absdiff', None), ('distortion_d1', 'root_sq', None),
+                ('distortion_d5', 'root_sq', None), ('mcd', 'sqdiff', None), ('lf0', 'sqdiff_voiced_exp', None),
+                ('f0', 'sqdiff_voiced', None), ('vuv_acc', 'mean', None)]
+
+
+def metric_calls(g, name):
+    """The accumulate calls tests/golden/make_golden.py:g15_metrics made for `name`: [(kind kwargs)]."""
+    sl = g['seq_len']
+    if name.startswith('mean_d'):
+        d = name[-1]
+        return [dict(target=g['mean_d%s__x1' % d], seq_len=sl), dict(target=g['mean_d%s__x2' % d])]
+    if name[:-3] in ('rmse', 'mae', 'distortion'):
+        d = name[-1]
+        return [dict(target=g['pair_d%s__t1' % d], pred=g['pair_d%s__p1' % d], seq_len=sl),
+                dict(target=g['pair_d%s__t2' % d], pred=g['pair_d%s__p2' % d])]
+    if name == 'mcd':
+        return [dict(target=g['mcd__t1'], pred=g['mcd__p1'], seq_len=sl, col0=1),
+                dict(target=g['mcd__t1'][:, ::-1].copy(), pred=g['mcd__p1'], col0=1)]
+    if name == 'lf0':
+        return [dict(target=g['lf0__t'], pred=g['lf0__p'], voiced=g['lf0__voiced'], seq_len=sl),
+                dict(target=g['lf0__p'], pred=g['lf0__t'], voiced=~g['lf0__voiced'])]
+    if name == 'f0':
+        return [dict(target=np.exp(g['lf0__t']), pred=np.exp(g['lf0__p']), voiced=g['lf0__voiced'], seq_len=sl)]
+    if name == 'vuv_acc':
+        return [dict(target=(g['vuv__t'] == g['vuv__p']).astype(np.float32), seq_len=sl)]
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize('name,kind,_', METRIC_CASES)
+def test_g15_streaming_metrics(golden, name, kind, _):
+    """oracle.ref_cpu.metric_sums / metric_result against the reference's streaming metrics (sum, count, result)."""
+    g = golden('g15_metrics.npz')
+    total = count = 0.0
+    for call in metric_calls(g, name):
+        s, c = ref_cpu.metric_sums(kind, **call)
+        total, count = total + s, count + c
+    np.testing.assert_allclose(count, float(g[name + '__count']), rtol=0, atol=0)
+    np.testing.assert_allclose(total, float(g[name + '__sum']), rtol=2e-5)
+    np.testing.assert_allclose(ref_cpu.metric_result(kind, total, count), float(g[name + '__result']), rtol=2e-5)
