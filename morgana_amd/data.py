@@ -279,3 +279,34 @@ def collate_to_device(batch, normalisers, device):
                 twin = collate_fn([{key: normaliser.normalise(item[key]).astype(np.float32)} for item in batch])[key]
                 out['normalised_' + key] = twin.to(device)
     return out
+
+
+class DeviceBatches(object):
+    """The DataLoader + ``ToDeviceWrapper`` of the reference (data.py:50-55, :648-663) for utterances that are already in host
+    memory: an iterable of feature dicts on ``device``, each batch padded and normalised there by ``collate_to_device``.
+
+    ``utterances`` is a sequence of RAW per-utterance feature dicts (what a ``_DataSource`` returns: float32 ``(len, D)``
+    arrays, integer ``dur``, python ints, the name); ``normalisers`` maps feature names to normalisers (``Normalisers`` or a
+    dict).  Batches are contiguous slices in the given order, or a fresh permutation per epoch from ``shuffle`` = a
+    ``numpy.random.RandomState`` (the reference shuffles with torch's global generator, data.py:50); the last, smaller batch
+    is kept, as ``DataLoader`` does by default.  ``ExperimentBuilder.train_epoch`` takes it like any other loader."""
+
+    def __init__(self, utterances, batch_size, normalisers, device, shuffle=None):
+        if batch_size <= 0:
+            raise ValueError('batch_size must be positive, got %r' % (batch_size,))
+        self.utterances = list(utterances)
+        self.batch_size = int(batch_size)
+        self.normalisers = normalisers
+        self.device = torch.device(device)
+        self.shuffle = shuffle
+
+    def __len__(self):
+        return (len(self.utterances) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        order = np.arange(len(self.utterances))
+        if self.shuffle is not None:
+            order = self.shuffle.permutation(len(self.utterances))
+        for start in range(0, len(order), self.batch_size):
+            batch = [self.utterances[i] for i in order[start:start + self.batch_size]]
+            yield collate_to_device(batch, self.normalisers, self.device)

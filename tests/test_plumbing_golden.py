@@ -140,3 +140,47 @@ def test_train_epoch_with_ema_and_noam_on_gpu():
         np.testing.assert_allclose(v.cpu().numpy(), ref.state_dict()[k].numpy(), rtol=1e-3, atol=1e-5)
     for k, v in eb.ema_model.state_dict().items():
         np.testing.assert_allclose(v.cpu().numpy(), shadow[k], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_train_epoch_from_device_batches_matches_host_collate():
+    """ExperimentBuilder.train_epoch fed by data.DeviceBatches (raw utterances -> pad + normalise on the device) against the
+    same epoch fed by the host pipeline (normalise-on-load, collate_fn, to_device: data.py:119-127, 159-224, 648-663): same
+    batches, so the same mean loss and the same parameters afterwards (fp32 mode, 1e-5)."""
+    rng = np.random.RandomState(5)
+    lab_dim = 24
+    norms = {'lab': data.MinMaxNormaliser('lab').set_params({'mmin': rng.rand(lab_dim).astype(np.float32) * 0.1,
+                                                             'mmax': (1.0 + rng.rand(lab_dim)).astype(np.float32)}, device='cuda:0'),
+             'lf0': data.MeanVarianceNormaliser('lf0').set_params({'mean': np.array([5.0], np.float32),
+                                                                   'std_dev': np.array([0.3], np.float32)}, device='cuda:0')}
+    utterances = []
+    for i in range(10):
+        n_ph = int(rng.randint(3, 9))
+        dur = rng.randint(1, 8, size=(n_ph, 1)).astype(np.int64)
+        n_fr = int(dur.sum())
+        utterances.append({'name': 'utt%02d' % i, 'n_frames': n_fr, 'n_phones': n_ph, 'dur': dur,
+                           'lab': rng.rand(n_ph, lab_dim).astype(np.float32),
+                           'lf0': (5.0 + 0.3 * rng.randn(n_fr, 1)).astype(np.float32)})
+    kwargs = {'input_dim': lab_dim, 'hidden_dims': (16, 8), 'output_dim': 1, 'precision': 'fp32'}
+    state = synthetic.f0_model_state(seed=9, dims=(lab_dim, 16, 8, 1))
+
+    def run(loader):
+        eb = experiment_builder.ExperimentBuilder(models.F0Model, model_kwargs=kwargs, learning_rate=0.02, device='cuda:0')
+        own = eb.model.state_dict()
+        for k, v in state.items():
+            own[k].copy_(torch.from_numpy(v))
+        mean_loss = eb.train_epoch(loader, eb.make_optimizer())
+        return mean_loss, {k: v.cpu().numpy().copy() for k, v in eb.model.state_dict().items()}
+
+    device_loader = data.DeviceBatches(utterances, 4, norms, 'cuda:0')
+    assert len(device_loader) == 3
+    host_loader = [data.to_device(data.collate_fn([data.load_utterance(u, norms) for u in utterances[i:i + 4]]), 'cuda:0')
+                   for i in range(0, 10, 4)]
+    got_loss, got = run(device_loader)
+    want_loss, want = run(host_loader)
+    assert got_loss == pytest.approx(want_loss, rel=1e-5)
+    for k in want:
+        np.testing.assert_allclose(got[k], want[k], rtol=1e-4, atol=1e-6, err_msg=k)
+    shuffled = data.DeviceBatches(utterances, 4, norms, 'cuda:0', shuffle=np.random.RandomState(0))
+    names = [n for batch in shuffled for n in batch['name']]
+    assert sorted(names) == sorted(u['name'] for u in utterances) and names != [u['name'] for u in utterances]
