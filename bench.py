@@ -39,7 +39,7 @@ def parse_args():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
-    ap.add_argument('--config', default='c2', choices=['c2', 'c4', 'c5', 'lstm'],
+    ap.add_argument('--config', default='c2', choices=['c2', 'c4', 'c5', 'lstm', 'f0gru'],
                     help='c2: F0Model 256x1000 (headline); c4: GRU-512 600->80, 64x1000; c5: GRU-512 600->187, 64 ragged 300-2000; '
                          'lstm: the shipped LSTMAcousticModel 609->512->8xLSTM-512->256->199, 64x1000')
     ap.add_argument('--batch', type=int, default=None, help='utterances per GPU (default 256 for c2, 64 for c4)')
@@ -285,6 +285,12 @@ def main():
         model = models.RNNSPSS(precision=args.precision).to(dev)
         state = synthetic.rnn_spss_state()
         name, target = 'RNN_SPSS Linear-512/GRU-512/Linear-256/80 (models/RNN_SPSS.py:32-42 layout)', 'normalised_mcep'
+    elif args.config == 'f0gru':
+        per_gpu = args.batch or 64
+        feats_np = synthetic.make_acoustic_batch(per_gpu, args.frames, streams=(('lf0', 3, 'mse'),), rank=rank)
+        model = models.GRUF0Model(precision=args.precision).to(dev)
+        state = synthetic.gru_f0_state()
+        name, target = 'shipped F0 model 609-256-3xGRU64-64-3 (models/f0_test_model.py:28-45)', 'lf0 deltas'
     elif args.config == 'lstm':
         per_gpu = args.batch or 64
         feats_np = synthetic.make_acoustic_batch(per_gpu, args.frames, rank=rank)
@@ -338,7 +344,8 @@ def main():
             'metric': {'c2': 'acoustic frames/sec (fwd+bwd+step), F0Model 600->1, batch 256x1000',
                        'c4': 'acoustic frames/sec (fwd+bwd+step), RNN_SPSS GRU-512 600->80, batch 64x1000',
                        'c5': 'acoustic frames/sec (fwd+bwd+step), RNN_SPSS GRU-512 600->187, batch 64 x 300-2000 frames',
-                       'lstm': 'acoustic frames/sec (fwd+bwd+step), LSTMAcousticModel 8xLSTM-512 609->199, batch 64x1000'}[args.config],
+                       'lstm': 'acoustic frames/sec (fwd+bwd+step), LSTMAcousticModel 8xLSTM-512 609->199, batch 64x1000',
+                       'f0gru': 'acoustic frames/sec (fwd+bwd+step), shipped GRU F0 model 3xGRU-64 609->3, batch 64x1000'}[args.config],
             'value': round(value, 1), 'unit': 'frames/s', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.precision, 'data': 'synthetic',

@@ -271,6 +271,17 @@ int mg_gru_bwd_f32(const float* grad_out, const float* grad_hn, const float* hst
                    const int64_t* seq_len, int B, int T, int H, float* dxproj, float* dhproj, float* dh0, void* workspace,
                    size_t workspace_bytes, void* stream);
 
+/* Small hidden sizes (H = 64 or 128, e.g. the GRU-64 layers of models/f0_test_model.py): the same recurrence, exact fp32, as ONE
+ * launch per direction in which a workgroup owns 256 / H items outright (W_hh in its registers, the state in its LDS, no
+ * hand-off between workgroups).  Same arguments and results as mg_gru_fwd_f32 / mg_gru_bwd_f32 (no workspace); sums over the
+ * contraction in a different order (equal to fp32 rounding).  mg_gru_fwd_f32 / mg_gru_bwd_f32 route here themselves when
+ * mg_gru_small_supported(H) != 0. */
+int mg_gru_small_supported(int H);
+int mg_gru_fwd_small_f32(const float* xproj, const float* w_hh, const float* b_hh, const int64_t* seq_len, int B, int T, int H,
+                         float* hstate, float* out, float* saved, void* stream);
+int mg_gru_bwd_small_f32(const float* grad_out, const float* grad_hn, const float* hstate, const float* saved, const float* w_hh,
+                         const int64_t* seq_len, int B, int T, int H, float* dxproj, float* dhproj, float* dh0, void* stream);
+
 /* The same recurrence with bf16 matmul operands (throughput mode; cell arithmetic, states, gate values and all outputs stay
  * f32): w_hh_bf = bf16(W_hh) [3H, ldw]; hstate_bf [B,T+1,H] is a bf16 shadow of hstate that the caller initialises at slot 0 and
  * the kernel extends; backward takes w_hh_t_bf = bf16(W_hh^T) [H, ldt >= 3H] and fills dhproj_bf [B,T,3H], the shadow of dhproj.

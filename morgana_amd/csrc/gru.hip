@@ -397,6 +397,8 @@ extern "C" {
 int mg_gru_fwd_f32(const float* xproj, const float* w_hh, const float* b_hh, const int64_t* seq_len, int B, int T, int H,
                    float* hstate, float* out, float* saved, void* stream) {
     MG_CHECK_ARG(xproj && w_hh && b_hh && hstate && out && saved && B > 0 && T > 0 && H > 0, "mg_gru_fwd_f32: bad arguments (B=%d T=%d H=%d)", B, T, H);
+    if (mg_gru_small_supported(H) && ((uintptr_t)w_hh % 16) == 0)         // one launch, workgroup-local recurrence (gru_small.hip)
+        return mg_gru_fwd_small_f32(xproj, w_hh, b_hh, seq_len, B, T, H, hstate, out, saved, stream);
     const int vec = (H % 4 == 0) && (((uintptr_t)hstate | (uintptr_t)w_hh) % 16 == 0);
     dim3 grid((unsigned)mg_ceil_div(H, GT), (unsigned)mg_ceil_div(B, GT));
     for (int t = 0; t < T; ++t) {
@@ -420,6 +422,7 @@ int mg_gru_bwd_f32(const float* grad_out, const float* grad_hn, const float* hst
         mg_set_error("mg_gru_bwd_f32: workspace of %zu bytes needed, got %zu", mg_gru_bwd_workspace_bytes(B, H), workspace_bytes);
         return MG_EWORKSPACE;
     }
+    if (mg_gru_small_supported(H)) return mg_gru_bwd_small_f32(grad_out, grad_hn, hstate, saved, w_hh, seq_len, B, T, H, dxproj, dhproj, dh0, stream);
     float* carry = (float*)workspace;
     hipStream_t st = (hipStream_t)stream;
     const int vec = ((3 * H) % 4 == 0) && (((uintptr_t)dhproj) % 16 == 0);

@@ -882,6 +882,39 @@ def test_lstm_stack_wavefront_vs_chained_layers(b, t, i_dim, hid, n_layers):
         _lib.load().mg_set_tuning(2, 0)
 
 
+@pytest.mark.parametrize('b,t,hid', [(5, 37, 64), (64, 50, 64), (1, 9, 128), (37, 21, 128)])
+def test_gru_small_hidden_single_workgroup_vs_step_kernels(b, t, hid):
+    """csrc/gru_small.hip (H = 64 / 128: a workgroup owns its items outright, W_hh in registers, state in LDS, one launch per
+    direction, exact fp32) against the launch-per-step fp32 kernels on the same inputs: same products, summed in one chain per
+    output instead of four partial chains - 1e-5 relative.  Ragged lengths, initial state, gradients on outputs and h_n."""
+    from morgana_amd import _lib
+    rng = np.random.RandomState(hid + b)
+    xproj = dev(rng.standard_normal((b, t, 3 * hid)).astype(np.float32))
+    w_hh = dev((rng.uniform(-1, 1, (3 * hid, hid)) / np.sqrt(hid)).astype(np.float32))
+    b_hh = dev(rng.uniform(-0.1, 0.1, 3 * hid).astype(np.float32))
+    h0 = dev(rng.standard_normal((b, hid)).astype(np.float32) * 0.5)
+    sl_np = rng.randint(1, t + 1, size=b).astype(np.int64)
+    sl_np[0] = t
+    g_out = dev(rng.standard_normal((b, t, hid)).astype(np.float32))
+    g_hn = dev(rng.standard_normal((b, hid)).astype(np.float32))
+    lib = _lib.load()
+    assert lib.mg_gru_small_supported(hid)
+    for sl in (dev(sl_np), None):
+        got = ops.gru_fwd(xproj, w_hh, b_hh, sl, h0, b, t, hid)
+        got_b = ops.gru_bwd(g_out, g_hn, got[1], got[2], w_hh, sl, b, t, hid)
+        lib.mg_set_tuning(3, 1)                       # the per-step kernels
+        try:
+            want = ops.gru_fwd(xproj, w_hh, b_hh, sl, h0, b, t, hid)
+            want_b = ops.gru_bwd(g_out, g_hn, got[1], got[2], w_hh, sl, b, t, hid)
+        finally:
+            lib.mg_set_tuning(3, 0)
+        for name, g, w in zip(('out', 'hstate', 'saved', 'dxproj', 'dhproj', 'dh0'), got + got_b, want + want_b):
+            assert rel_err(g.cpu().numpy(), w.cpu().numpy()) < 1e-5, name
+        if sl is not None:
+            for i, n in enumerate(sl_np):
+                assert torch.all(got[0][i, n:] == 0)
+
+
 def test_gru_bf16_recurrence_rejects_bad_sizes():
     x = torch.zeros(2, 3, 3 * 96, device=DEV)
     assert not ops.gru_bf16_ok(96)
