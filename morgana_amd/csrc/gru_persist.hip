@@ -576,7 +576,7 @@ int mg_gru_persist_supported(int B, int T, int H) {
     if (H % 128 != 0 || H > 128 * GP_KSTEPS) return 0;
     if (mg_ceil_div(B, GP_GROUPS) > 32) return 0;
     if ((size_t)B * (T + 1) * (size_t)H * 3 * 2 >= ((size_t)1 << 31)) return 0;     // 32-bit buffer offsets (backward: 3 H wide)
-    return 1;
+    return gp_device_holds((long)GP_GROUPS * (H / GT));
 }
 
 int mg_gru_persist_status(void* workspace, void* stream) {

@@ -828,7 +828,7 @@ int mg_lstm_persist_supported(int B, int T, int H) {
     if (B <= 0 || T <= 0 || H <= 0) return 0;
     if (H % 128 != 0 || H > 128 * GP_KSTEPS) return 0;
     if (mg_ceil_div(B, GP_GROUPS) > 32) return 0;
-    return 1;
+    return gp_device_holds((long)GP_GROUPS * (H / GT));
 }
 
 int mg_lstm_fwd_persist_bf16(const float* xproj, const uint16_t* w_hh_bf, int ldw, const float* b_hh, const int64_t* seq_len, int B, int T,
@@ -924,7 +924,8 @@ static int lps_groups(int B, int H, int L) {
 int mg_lstm_pstack_supported(int B, int T, int H, int L) {
     if (B <= 0 || T <= 0 || H <= 0 || L < 2 || L > MG_LSTM_MAX_LAYERS) return 0;
     if (H % 128 != 0 || H > 128 * GP_KSTEPS) return 0;
-    return lps_groups(B, H, L) > 0;
+    const int G = lps_groups(B, H, L);
+    return G > 0 && gp_device_holds((long)L * G * (H / GT));
 }
 
 size_t mg_lstm_pstack_workspace_bytes(int B, int H, int L) {

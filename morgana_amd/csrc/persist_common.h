@@ -8,7 +8,7 @@
 #define GP_GROUPS 8
 #define GP_SLOTS 32                          // flag words per group (H <= 512)
 #define GP_KSTEPS 4                          // H / 128 MFMA k-steps per wave, H <= 512
-#define GP_SPIN_LIMIT (1u << 20)
+#define GP_SPIN_LIMIT (1u << 22)              // polls before a wait gives up (a poll is 0.2-0.5 us: 1-2 s)
 #define GP_FLAG_WORDS (2 * GP_GROUPS * GP_SLOTS)   // per launch (zeroed by a memset node): step flags [8][32], XCC ids [8][32]
 #define GP_SYNC_WORDS (GP_FLAG_WORDS + 4)          // + {sticky status, 3 pad}: 2064 bytes, a multiple of 16
 
@@ -70,6 +70,19 @@ __device__ __forceinline__ int gp_group_on_one_xcd(gu32* xcc_tab, int slot, int 
     }
     __syncthreads();
     return *s_word;
+}
+
+// Residency: every workgroup of a persistent launch must be on the device at once.  The kernels need up to 256 VGPRs, i.e. as
+// few as two 256-thread workgroups per CU: a launch is offered only if the current device has room for `workgroups` at two
+// per CU (MI355X: 256 CUs; a partitioned or harvested device simply takes the per-step kernels instead of timing out).
+static inline int gp_device_holds(long workgroups) {
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        cus = n;
+    }
+    return cus > 0 && workgroups <= 2L * cus;
 }
 
 // workspace: [step flags 8 x 32 words | XCC ids 8 x 32 words | status word + 3 pad] [hand-off ring]
