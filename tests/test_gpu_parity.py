@@ -846,21 +846,29 @@ def test_lstm_stack_wavefront_vs_chained_layers(b, t, i_dim, hid, n_layers):
     g_hn, g_cn = torch.randn(n_layers, b, hid, device=DEV), torch.randn(n_layers, b, hid, device=DEV)
     assert F_hip.lstm_stack_persistent('bf16', b, t, hid, n_layers)
 
+    # initial states for every layer in the smaller cases (a multi-layer nn.LSTM called with `hidden`), none in the first
+    h0s = c0s = None
+    if b != 64:
+        h0s = (torch.randn(n_layers, b, hid, device=DEV) * 0.5).requires_grad_(True)
+        c0s = (torch.randn(n_layers, b, hid, device=DEV) * 0.5).requires_grad_(True)
+
     def run(kind):
-        for p in [x] + params:
+        for p in [x] + params + ([h0s, c0s] if h0s is not None else []):
             p.grad = None
         if kind == 'wavefront':
-            out, hn, cn = F_hip.LSTMStackPersistFn.apply(x, seq_len, None, None, *params)
+            out, hn, cn = F_hip.LSTMStackPersistFn.apply(x, seq_len, h0s, c0s, *params)
         else:
             out, hns, cns = x, [], []
             for l in range(n_layers):
-                out, h, c = F_hip.LSTMFn.apply(kind, out.contiguous(), None, None, seq_len, *params[4 * l:4 * l + 4])
+                out, h, c = F_hip.LSTMFn.apply(kind, out.contiguous(), None if h0s is None else h0s[l:l + 1],
+                                               None if c0s is None else c0s[l:l + 1], seq_len, *params[4 * l:4 * l + 4])
                 hns.append(h)
                 cns.append(c)
             hn, cn = torch.cat(hns, 0), torch.cat(cns, 0)
         ((out * g_out).sum() + (hn * g_hn).sum() + (cn * g_cn).sum()).backward()
         ops.check_persistent_status()
-        return [v.detach().cpu().numpy().copy() for v in (out, hn, cn, x.grad, *[p.grad for p in params])]
+        extra = [h0s.grad, c0s.grad] if h0s is not None else []
+        return [v.detach().cpu().numpy().copy() for v in (out, hn, cn, x.grad, *[p.grad for p in params], *extra)]
 
     want_bf, want_32 = run('bf16'), run('fp32')
     first = None
