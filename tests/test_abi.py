@@ -55,6 +55,24 @@ def test_no_cpu_fallback():
         losses.mse(torch.zeros(2, 3, 1), torch.zeros(2, 3, 1), torch.tensor([3, 2]))
     with pytest.raises(TypeError):
         utils.upsample_to_repetitions(x, torch.ones(2, 3, 1))          # float durations, as the reference
+    from morgana_amd import metrics
+    with pytest.raises(_lib.MorganaHipError):                          # streaming metrics: device accumulators only
+        metrics.RMSE().accumulate(torch.zeros(2, 3, 1), torch.zeros(2, 3, 1), torch.tensor([3, 2]))
+
+
+def test_device_batches_shapes_without_a_gpu():
+    """data.DeviceBatches: batch count, order and the kept last partial batch (the collate itself needs the device)."""
+    import numpy as np
+    from morgana_amd import data
+    utts = [{'name': 'u%d' % i} for i in range(10)]
+    loader = data.DeviceBatches(utts, 4, {}, 'cpu')
+    assert len(loader) == 3
+    names = [b['name'] for b in loader]                                # only non-numeric features: no kernel involved
+    assert names == [['u0', 'u1', 'u2', 'u3'], ['u4', 'u5', 'u6', 'u7'], ['u8', 'u9']]
+    shuffled = [n for b in data.DeviceBatches(utts, 4, {}, 'cpu', shuffle=np.random.RandomState(1)) for n in b['name']]
+    assert sorted(shuffled) == sorted(u['name'] for u in utts) and shuffled != [u['name'] for u in utts]
+    with pytest.raises(ValueError):
+        data.DeviceBatches(utts, 0, {}, 'cpu')
 
 
 def test_product_does_not_import_oracle():
