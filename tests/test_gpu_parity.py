@@ -771,7 +771,7 @@ def test_gru_persistent_equals_stepwise(b, t, hid, gru_handoff):
             assert torch.equal(dx_bf, want_b[0].to(torch.bfloat16)) and torch.equal(dh_bf, want_b[3]) and torch.equal(dh0, want_b[2])
 
 
-@pytest.mark.parametrize('b,t,hid', [(64, 40, 512), (5, 37, 128), (33, 20, 256), (200, 9, 128)])
+@pytest.mark.parametrize('b,t,hid', [(64, 40, 512), (5, 37, 128), (33, 20, 256), (200, 9, 128), (12, 15, 384), (3, 1, 128)])
 def test_lstm_persistent_vs_fp32_and_between_handoff_forms(b, t, hid):
     """The one-launch LSTM recurrence (csrc/lstm_persist.hip, bf16 matmul operands) against the exact-fp32 per-step kernels on
     the same inputs at 1e-2 relative (operand rounding 2^-9 per product, fp32 accumulation and cell), forward and backward,
@@ -886,6 +886,18 @@ def test_lstm_stack_wavefront_vs_chained_layers(b, t, i_dim, hid, n_layers):
             else:
                 for k, (g, w) in enumerate(zip(got, first)):
                     np.testing.assert_array_equal(g, w, err_msg='output %d, hand-off mode %d' % (k, mode))
+        if b == 64:
+            # the same under uneven load: a side stream keeps CUs and memory busy while the 512 workgroups of the wavefront start
+            side = torch.cuda.Stream()
+            junk = torch.randn(4096, 4096, device=DEV)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side):
+                for _ in range(8):
+                    junk @ junk
+            got = run('wavefront')
+            torch.cuda.synchronize()
+            for k, (g, w) in enumerate(zip(got, first)):
+                np.testing.assert_array_equal(g, w, err_msg='output %d under concurrent load' % k)
     finally:
         _lib.load().mg_set_tuning(2, 0)
 
@@ -921,6 +933,50 @@ def test_gru_small_hidden_single_workgroup_vs_step_kernels(b, t, hid):
         if sl is not None:
             for i, n in enumerate(sl_np):
                 assert torch.all(got[0][i, n:] == 0)
+
+
+def test_gru_persistent_under_concurrent_load_and_edge_shapes():
+    """Hand-off protocol of the persistent GRU kernels away from the quiet, lock-step case: (1) a side stream keeps the memory
+    system and the CUs busy with large copies and GEMMs while the recurrence runs (uneven load: workgroups start late, polls
+    and drains are delayed) - results must still EQUAL the per-step kernels; (2) T = 1, B = 1 and B = 256 (32 items per group,
+    two MFMA row tiles)."""
+    rng = np.random.RandomState(3)
+    side = torch.cuda.Stream()
+    junk_a = torch.randn(4096, 4096, device=DEV)
+    junk_b = torch.empty(64 * 1024 * 1024, device=DEV)
+
+    def case(b, t, hid, loaded):
+        xproj = dev(rng.standard_normal((b, t, 3 * hid)).astype(np.float32))
+        w_hh = dev((rng.uniform(-1, 1, (3 * hid, hid)) / np.sqrt(hid)).astype(np.float32))
+        b_hh = dev(rng.uniform(-0.1, 0.1, 3 * hid).astype(np.float32))
+        sl_np = rng.randint(1, t + 1, size=b).astype(np.int64)
+        sl_np[0] = t
+        sl = dev(sl_np)
+        g_out = dev(rng.standard_normal((b, t, hid)).astype(np.float32))
+        want = ops.gru_fwd_bf16(xproj, w_hh, b_hh, sl, None, b, t, hid, persistent=False)
+        want_b = ops.gru_bwd_bf16(g_out, None, want[1], want[2], w_hh, sl, b, t, hid, persistent=False)
+        torch.cuda.synchronize()
+        if loaded:
+            with torch.cuda.stream(side):
+                for _ in range(6):
+                    junk_b.copy_(junk_b.flip(0))
+                    junk_a @ junk_a
+        got = ops.gru_fwd_bf16(xproj, w_hh, b_hh, sl, None, b, t, hid, persistent=True)
+        got_b = ops.gru_bwd_bf16(g_out, None, want[1], want[2], w_hh, sl, b, t, hid, persistent=True)
+        torch.cuda.synchronize()
+        ops.check_persistent_status()
+        live = (np.arange(t)[None, :] < sl_np[:, None])[:, :, None]
+        for name, g, w in zip(('out', 'hstate', 'saved', 'hstate_bf', 'dxproj', 'dhproj', 'dh0', 'dhproj_bf'), got + got_b, want + want_b):
+            g, w = g.float().cpu().numpy(), w.float().cpu().numpy()
+            if name == 'saved':
+                g, w = g * live, w * live
+            np.testing.assert_array_equal(g, w, err_msg='%s (B=%d T=%d H=%d loaded=%s)' % (name, b, t, hid, loaded))
+
+    case(64, 200, 512, loaded=True)
+    case(64, 200, 512, loaded=True)
+    case(7, 1, 128, loaded=False)
+    case(1, 33, 256, loaded=False)
+    case(256, 6, 128, loaded=False)
 
 
 def test_gru_bf16_recurrence_rejects_bad_sizes():
