@@ -282,6 +282,17 @@ int mg_gru_fwd_small_f32(const float* xproj, const float* w_hh, const float* b_h
 int mg_gru_bwd_small_f32(const float* grad_out, const float* grad_hn, const float* hstate, const float* saved, const float* w_hh,
                          const int64_t* seq_len, int B, int T, int H, float* dxproj, float* dhproj, float* dh0, void* stream);
 
+/* fp32 parity mode as ONE launch per direction for 256 <= H <= 512, H % 64 == 0, B <= 128: the group / slot scheme of the bf16
+ * persistent kernels below with fp32 hand-off tiles and the exact-fp32 MFMA in the per-step kernels' block order, the same cell
+ * code - results bit-identical to mg_gru_fwd_f32 / mg_gru_bwd_f32 on the live steps (gate values of steps beyond an item
+ * group's longest sequence are written as zeros).  Workspace, status word and residency: as for mg_gru_fwd_persist_bf16. */
+int mg_gru_persist_f32_supported(int B, int T, int H);
+int mg_gru_fwd_persist_f32(const float* xproj, const float* w_hh, const float* b_hh, const int64_t* seq_len, int B, int T, int H,
+                           float* hstate, float* out, float* saved, void* workspace, size_t workspace_bytes, void* stream);
+int mg_gru_bwd_persist_f32(const float* grad_out, const float* grad_hn, const float* hstate, const float* saved, const float* w_hh,
+                           const int64_t* seq_len, int B, int T, int H, float* dxproj, float* dhproj, float* dh0, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 /* The same recurrence with bf16 matmul operands (throughput mode; cell arithmetic, states, gate values and all outputs stay
  * f32): w_hh_bf = bf16(W_hh) [3H, ldw]; hstate_bf [B,T+1,H] is a bf16 shadow of hstate that the caller initialises at slot 0 and
  * the kernel extends; backward takes w_hh_t_bf = bf16(W_hh^T) [H, ldt >= 3H] and fills dhproj_bf [B,T,3H], the shadow of dhproj.

@@ -90,6 +90,11 @@ SIGNATURES = {
     'mg_gru_fwd_small_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mg_gru_bwd_small_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),
+    'mg_gru_persist_f32_supported': (c_int, [c_int, c_int, c_int]),
+    'mg_gru_fwd_persist_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_size_t, c_void_p]),
+    'mg_gru_bwd_persist_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_size_t, c_void_p]),
     'mg_gru_bwd_workspace_bytes': (c_size_t, [c_int, c_int]),
     'mg_gru_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

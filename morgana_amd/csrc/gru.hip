@@ -120,13 +120,11 @@ __global__ __launch_bounds__(256) void gru_fwd_step_kernel(const float* __restri
     __syncthreads();
     if (mine) {
         const int e = bl * GT + jl;
-        const float hr = ((red[0][0][e] + red[1][0][e]) + (red[2][0][e] + red[3][0][e])) + bhr;
-        const float hz = ((red[0][1][e] + red[1][1][e]) + (red[2][1][e] + red[3][1][e])) + bhz;
-        const float hn = ((red[0][2][e] + red[1][2][e]) + (red[2][2][e] + red[3][2][e])) + bhn;
-        const float r = mg_sigmoid(xr + hr);
-        const float z = mg_sigmoid(xz + hz);
-        const float n = tanhf(xn + r * hn);
-        const float hnew = (1.f - z) * n + z * hprev;
+        const float hr = mg_gru_sum4(red[0][0][e], red[1][0][e], red[2][0][e], red[3][0][e], bhr);
+        const float hz = mg_gru_sum4(red[0][1][e], red[1][1][e], red[2][1][e], red[3][1][e], bhz);
+        const float hn = mg_gru_sum4(red[0][2][e], red[1][2][e], red[2][2][e], red[3][2][e], bhn);
+        const mg_gru_cell_out c = mg_gru_cell_exact(xr, xz, xn, hr, hz, hn, hprev);
+        const float r = c.r, z = c.z, n = c.n, hnew = c.hnew;
         hstate[((size_t)b * (T + 1) + t + 1) * H + j] = active ? hnew : hprev;
         out[row * H + j] = active ? hnew : 0.f;
         float* sv = saved + row * 4 * H;
@@ -205,7 +203,7 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(const float* __restri
     __syncthreads();
     if (b < B && j < H) {
         const int e = bl * GT + jl;
-        const float dstate = cin + ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e]));
+        const float dstate = mg_gru_dstate(cin, red[0][e], red[1][e], red[2][e], red[3][e]);
         if (t < 0) {
             dh0[(size_t)b * H + j] = dstate;
             return;
@@ -213,13 +211,8 @@ __global__ __launch_bounds__(256) void gru_bwd_step_kernel(const float* __restri
         const bool active = seq_len ? ((int64_t)t < seq_len[b]) : true;
         float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, c = dstate;
         if (active) {
-            const float r = s_r, z = s_z, n = s_n, hn = s_hn;
-            const float dh = dstate + gout;
-            dn = dh * (1.f - z) * (1.f - n * n);
-            dz = dh * (hprev - n) * z * (1.f - z);
-            dr = dn * hn * r * (1.f - r);
-            dnr = dn * r;
-            c = dh * z;
+            const mg_gru_cell_grad g = mg_gru_cell_bwd(dstate, gout, s_r, s_z, s_n, s_hn, hprev);
+            dr = g.dr; dz = g.dz; dn = g.dn; dnr = g.dnr; c = g.carry;
         }
         float* dx = dxproj + row * G;
         float* dhp = dhproj + row * G;

@@ -50,3 +50,15 @@ __device__ __forceinline__ mg_gru_cell_grad mg_gru_cell_bwd(float dstate, float 
     g.carry = dh * z;
     return g;
 }
+
+// The exact-fp32 cell of the parity-mode kernels (expf / tanhf), shared by the launch-per-step and the persistent fp32 kernels
+// with contraction pinned off for the same reason as above.
+__device__ __forceinline__ mg_gru_cell_out mg_gru_cell_exact(float xr, float xz, float xn, float hr, float hz, float hn, float hprev) {
+#pragma clang fp contract(off)
+    mg_gru_cell_out o;
+    o.r = mg_sigmoid(xr + hr);
+    o.z = mg_sigmoid(xz + hz);
+    o.n = tanhf(xn + o.r * hn);
+    o.hnew = (1.f - o.z) * o.n + o.z * hprev;
+    return o;
+}

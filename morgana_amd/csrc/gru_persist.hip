@@ -562,13 +562,349 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
 #endif
 }
 
+// =====================================================================================================================
+// fp32 parity mode, persistent: the same group / slot scheme with exact-fp32 operands - fp32 hand-off tiles (64 bytes per
+// item and slot), v_mfma_f32_16x16x4_f32 with the launch-per-step kernels' block order (wave w owns the 16-deep blocks
+// w, w + 4, ... of the contraction; products and sums in the same sequence) and the same cell code (gru_cell.h), so the results
+// are bit-identical to gru_fwd_step_kernel / gru_bwd_step_kernel - which is how the hand-off is tested.  One M tile: groups
+// of at most 16 items (B <= 128).  The exact-fp32 MFMA rate (96 MFMAs of 32 cycles per wave and step) bounds the step at
+// about 1.3 us, against 8.8 / 9.5 us for a launch per step.
+// =====================================================================================================================
+template <int KS>          // KS = H / 64 contraction blocks per wave
+__global__ __launch_bounds__(256) void gru_fwd_persist_f32_kernel(const float* __restrict__ xproj, const float* __restrict__ w_hh,
+                                                                  const float* __restrict__ b_hh, const int64_t* __restrict__ seq_len,
+                                                                  int B, int T, int H, int R, float* __restrict__ hstate,
+                                                                  float* __restrict__ out, float* __restrict__ saved, unsigned* sync,
+                                                                  float* ring, int force_sc1) {
+    __shared__ float red[4][3][GT * GT];
+    __shared__ __attribute__((aligned(16))) float hb[GT][GT];
+    __shared__ float res[5][GT * GT];              // out, r, z, n, hn of the step for waves 2 and 3 (h itself goes through hb)
+    __shared__ int s_abort, s_xcd;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    const int group = blockIdx.x % GP_GROUPS, slot = blockIdx.x / GP_GROUPS;
+    const int n_slots = H / GT;
+    const int row0 = group * R;
+    const int nrows = min(R, B - row0);
+    if (slot >= n_slots || nrows <= 0) return;
+    const int j0 = slot * GT;
+    gu32* flags = (gu32*)sync + group * GP_SLOTS;
+    gu32* status = (gu32*)sync + GP_FLAG_WORDS;
+    if (tid == 0) s_abort = 0;
+    const int one_xcd = force_sc1 ? 0 : gp_group_on_one_xcd((gu32*)sync + GP_GROUPS * GP_SLOTS + group * GP_SLOTS, slot, n_slots, tid, &s_xcd);
+    if (one_xcd < 0) {
+        if (tid == 0) __hip_atomic_store(status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    int gmax = 0;
+    for (int r = 0; r < nrows; ++r) {
+        const int64_t n = seq_len ? seq_len[row0 + r] : (int64_t)T;
+        gmax = max(gmax, (int)(n < T ? n : T));
+    }
+    // W_hh fragments: block i of this wave = columns 16 (wave + 4 i) + 4 q .. + 3 of rows j0 + li of the three gates
+    f32x4 fr[KS], fz[KS], fn[KS];
+    {
+        const float* wr = w_hh + (size_t)(j0 + li) * H + 4 * q;
+        const float* wz = wr + (size_t)H * H;
+        const float* wn = wz + (size_t)H * H;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            const int k0 = 16 * (wave + 4 * i);
+            fr[i] = *reinterpret_cast<const f32x4*>(wr + k0);
+            fz[i] = *reinterpret_cast<const f32x4*>(wz + k0);
+            fn[i] = *reinterpret_cast<const f32x4*>(wn + k0);
+        }
+    }
+    // ring: [2 (epoch parity)][8 groups][H / 16 slots][R items][16 units] f32: a contraction block IS a slot's tile
+    const unsigned par_bytes = (unsigned)(GP_GROUPS * n_slots * R * 64);
+    const auto rs_ring = __builtin_amdgcn_make_buffer_rsrc((void*)ring, 0, (int)(2 * par_bytes), 0x00020000);
+    const unsigned rd_base = (unsigned)(((group * n_slots + wave) * R) * 64 + 16 * q);
+    const unsigned rd_blk = (unsigned)(4 * R * 64);
+    const unsigned wr_base = (unsigned)(((group * n_slots + slot) * R) * 64);
+
+    const int bl = tid >> 4, jl = tid & 15;
+    const int j = j0 + jl;
+    const float bhr = b_hh[j], bhz = b_hh[H + j], bhn = b_hh[2 * H + j];
+    const bool mine = bl < nrows;
+    const int b = row0 + (mine ? bl : 0);
+    float hprev = hstate[((size_t)b * (T + 1)) * H + j];
+    const int len = seq_len ? (int)min((int64_t)T, seq_len[b]) : T;
+    hb[bl][jl] = hprev;
+    const float* xp = xproj + (size_t)b * T * 3 * H + j;
+    float xr = xp[0], xz = xp[H], xn = xp[2 * H];
+    __syncthreads();
+
+    auto publish = [&](int e) {
+        if (wave == 0) {
+            const int rrow = lane >> 2, piece = lane & 3;
+            if (rrow < nrows) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(&hb[rrow][4 * piece]);
+                const unsigned off = (e & 1) * par_bytes + wr_base + (unsigned)(rrow * 64 + piece * 16);
+                if (one_xcd)
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 0);
+                else
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 16);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) gp_store_flag(flags + slot, (unsigned)(e + 1), one_xcd);
+        }
+    };
+    publish(0);
+
+    for (int t = 0; t < gmax; ++t) {
+        if (wave == 0 && !gp_wait_flags(flags, n_slots, (unsigned)(t + 1), lane)) s_abort = 1;
+        gp_lds_barrier();
+        if (s_abort) {
+            if (tid == 0) __hip_atomic_store(status, 7u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        u32x4 raw[KS];
+        {
+            const unsigned off = (t & 1) * par_bytes + rd_base + (unsigned)((li < nrows ? li : 0) * 64);
+#pragma unroll
+            for (int i = 0; i < KS; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ring, off + i * rd_blk, 0, 16);
+        }
+        const int t1 = t + 1 < T ? t + 1 : t;
+        const float xr1 = xp[(size_t)t1 * 3 * H], xz1 = xp[(size_t)t1 * 3 * H + H], xn1 = xp[(size_t)t1 * 3 * H + 2 * H];
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc_r = {0.f, 0.f, 0.f, 0.f}, acc_z = acc_r, acc_n = acc_r;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            union { u32x4 u; f32x4 f; } a;
+            a.u = raw[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(a.f[e], fr[i][e], acc_r, 0, 0, 0);
+                acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(a.f[e], fz[i][e], acc_z, 0, 0, 0);
+                acc_n = __builtin_amdgcn_mfma_f32_16x16x4f32(a.f[e], fn[i][e], acc_n, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = (4 * q + r) * GT + li;
+            red[wave][0][e] = acc_r[r];
+            red[wave][1][e] = acc_z[r];
+            red[wave][2][e] = acc_n[r];
+        }
+        gp_lds_barrier();
+        {
+            const int e = bl * GT + jl;
+            const float hr = mg_gru_sum4(red[0][0][e], red[1][0][e], red[2][0][e], red[3][0][e], bhr);
+            const float hz = mg_gru_sum4(red[0][1][e], red[1][1][e], red[2][1][e], red[3][1][e], bhz);
+            const float hn = mg_gru_sum4(red[0][2][e], red[1][2][e], red[2][2][e], red[3][2][e], bhn);
+            const mg_gru_cell_out c = mg_gru_cell_exact(xr, xz, xn, hr, hz, hn, hprev);
+            const bool active = t < len;
+            hprev = active ? c.hnew : hprev;
+            hb[bl][jl] = hprev;
+            res[0][e] = active ? c.hnew : 0.f;
+            res[1][e] = c.r;
+            res[2][e] = c.z;
+            res[3][e] = c.n;
+            res[4][e] = hn;
+        }
+        gp_lds_barrier();
+        publish(t + 1);
+        if (wave >= 2) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int e = (tid - 128) + 128 * half, rb = e >> 4, cj = j0 + (e & 15);
+                if (rb < nrows) {
+                    const int bb = row0 + rb;
+                    const size_t row = (size_t)bb * T + t;
+                    hstate[((size_t)bb * (T + 1) + t + 1) * H + cj] = hb[rb][e & 15];
+                    out[row * H + cj] = res[0][e];
+                    float* sv = saved + row * 4 * H + cj;
+                    sv[0] = res[1][e];
+                    sv[H] = res[2][e];
+                    sv[2 * H] = res[3][e];
+                    sv[3 * H] = res[4][e];
+                }
+            }
+        }
+        xr = xr1;
+        xz = xz1;
+        xn = xn1;
+    }
+    // beyond the group's longest sequence: state frozen, outputs zero, gate values (never read by the backward there) zero
+    for (int t = gmax; t < T; ++t) {
+        if (mine) {
+            const size_t row = (size_t)b * T + t;
+            hstate[((size_t)b * (T + 1) + t + 1) * H + j] = hprev;
+            out[row * H + j] = 0.f;
+            float* sv = saved + row * 4 * H;
+            sv[j] = 0.f;
+            sv[H + j] = 0.f;
+            sv[2 * H + j] = 0.f;
+            sv[3 * H + j] = 0.f;
+        }
+    }
+}
+
+template <int KS>          // KS = 3 H / 64 contraction blocks per wave
+__global__ __launch_bounds__(256) void gru_bwd_persist_f32_kernel(const float* __restrict__ grad_out, const float* __restrict__ grad_hn,
+                                                                  const float* __restrict__ hstate, const float* __restrict__ saved,
+                                                                  const float* __restrict__ w_hh, const int64_t* __restrict__ seq_len,
+                                                                  int B, int T, int H, int R, float* __restrict__ dxproj,
+                                                                  float* __restrict__ dhproj, float* __restrict__ dh0, unsigned* sync,
+                                                                  float* ring, int force_sc1) {
+    __shared__ float red[4][GT * GT];
+    __shared__ __attribute__((aligned(16))) float pub[3][GT][GT];   // dr, dz, dn r tiles on their way to the ring
+    __shared__ float res[GT * GT];                                   // dn (dxproj's third gate) for waves 2 and 3
+    __shared__ int s_abort, s_xcd;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    const int group = blockIdx.x % GP_GROUPS, slot = blockIdx.x / GP_GROUPS;
+    const int n_slots = H / GT;
+    const int row0 = group * R;
+    const int nrows = min(R, B - row0);
+    if (slot >= n_slots || nrows <= 0) return;
+    const int j0 = slot * GT;
+    const int G = 3 * H;
+    gu32* flags = (gu32*)sync + group * GP_SLOTS;
+    gu32* status = (gu32*)sync + GP_FLAG_WORDS;
+    if (tid == 0) s_abort = 0;
+    const int one_xcd = force_sc1 ? 0 : gp_group_on_one_xcd((gu32*)sync + GP_GROUPS * GP_SLOTS + group * GP_SLOTS, slot, n_slots, tid, &s_xcd);
+    if (one_xcd < 0) {
+        if (tid == 0) __hip_atomic_store(status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    int gmax = 0;
+    for (int r = 0; r < nrows; ++r) {
+        const int64_t n = seq_len ? seq_len[row0 + r] : (int64_t)T;
+        gmax = max(gmax, (int)(n < T ? n : T));
+    }
+    // block i of this wave = gate rows 16 (wave + 4 i) + 4 q + e: W_hh[that row][j0 + li] as the B operand; its A tile sits in the
+    // ring at (slot = block % n_slots, gate = block / n_slots)
+    float fb[KS][4];
+    unsigned rd_off[KS];
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+        const int blk = wave + 4 * i, gate = blk / n_slots, sl = blk - gate * n_slots;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fb[i][e] = w_hh[(size_t)(16 * blk + 4 * q + e) * H + j0 + li];
+        rd_off[i] = (unsigned)((((group * n_slots + sl) * 3 + gate) * R) * 64 + 16 * q);
+    }
+    const unsigned par_bytes = (unsigned)(GP_GROUPS * n_slots * R * 192);
+    const auto rs_ring = __builtin_amdgcn_make_buffer_rsrc((void*)ring, 0, (int)(2 * par_bytes), 0x00020000);
+    const unsigned wr_base = (unsigned)(((group * n_slots + slot) * R) * 192);
+
+    const int bl = tid >> 4, jl = tid & 15;
+    const int j = j0 + jl;
+    const bool mine = bl < nrows;
+    const int b = row0 + (mine ? bl : 0);
+    const int len = seq_len ? (int)min((int64_t)T, seq_len[b]) : T;
+    float carry = (mine && grad_hn) ? grad_hn[(size_t)b * H + j] : 0.f;
+    const float* p_sv = saved + (size_t)b * T * 4 * H + j;
+    const float* p_h = hstate + (size_t)b * (T + 1) * H + j;
+    const float* p_g = grad_out + (size_t)b * T * H + j;
+    for (int t = T - 1; t >= gmax; --t) {
+        if (mine) {
+            const size_t row = (size_t)b * T + t;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                dxproj[row * G + g * H + j] = 0.f;
+                dhproj[row * G + g * H + j] = 0.f;
+            }
+        }
+    }
+    const int t0 = gmax > 0 ? gmax - 1 : 0;
+    float s_r = p_sv[(size_t)t0 * 4 * H], s_z = p_sv[(size_t)t0 * 4 * H + H], s_n = p_sv[(size_t)t0 * 4 * H + 2 * H],
+          s_hn = p_sv[(size_t)t0 * 4 * H + 3 * H], hprev = p_h[(size_t)t0 * H], gout = p_g[(size_t)t0 * H];
+    __syncthreads();
+
+    for (int t = gmax - 1; t >= -1; --t) {
+        const bool need_mm = t + 1 < gmax;
+        u32x4 raw[KS];
+        if (need_mm) {
+            if (wave == 0 && !gp_wait_flags(flags, n_slots, (unsigned)(gmax - t - 1), lane)) s_abort = 1;
+            gp_lds_barrier();
+            if (s_abort) {
+                if (tid == 0) __hip_atomic_store(status, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            const unsigned off = ((t + 1) & 1) * par_bytes + (unsigned)((li < nrows ? li : 0) * 64);
+#pragma unroll
+            for (int i = 0; i < KS; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ring, off + rd_off[i], 0, 16);
+        }
+        const int t1 = t > 0 ? t - 1 : 0;
+        const float s_r1 = p_sv[(size_t)t1 * 4 * H], s_z1 = p_sv[(size_t)t1 * 4 * H + H], s_n1 = p_sv[(size_t)t1 * 4 * H + 2 * H],
+                    s_hn1 = p_sv[(size_t)t1 * 4 * H + 3 * H], hprev1 = p_h[(size_t)t1 * H], gout1 = p_g[(size_t)t1 * H];
+        __builtin_amdgcn_sched_barrier(0);
+        if (need_mm) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < KS; ++i) {
+                union { u32x4 u; f32x4 f; } a;
+                a.u = raw[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.f[e], fb[i][e], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][(4 * q + r) * GT + li] = acc[r];
+            gp_lds_barrier();
+        }
+        {
+            const int e = bl * GT + jl;
+            // t + 1 == T: the per-step kernel adds a zero accumulator here; carry + 0 is carry (also for -0: results compare equal)
+            const float dstate = need_mm ? mg_gru_dstate(carry, red[0][e], red[1][e], red[2][e], red[3][e]) : carry;
+            float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, c = dstate;
+            if (t >= 0 && t < len) {
+                const mg_gru_cell_grad g = mg_gru_cell_bwd(dstate, gout, s_r, s_z, s_n, s_hn, hprev);
+                dr = g.dr; dz = g.dz; dn = g.dn; dnr = g.dnr; c = g.carry;
+            }
+            carry = c;
+            pub[0][bl][jl] = dr;
+            pub[1][bl][jl] = dz;
+            pub[2][bl][jl] = dnr;
+            res[e] = dn;
+        }
+        if (t < 0) {
+            if (mine) dh0[(size_t)b * H + j] = carry;
+            break;
+        }
+        gp_lds_barrier();
+        if (wave == 0) {
+            // the slot's tile: 3 gates x R items x 64 bytes, contiguous in the ring; piece p = (gate, item, quarter)
+            for (int pc = lane; pc < 12 * R; pc += 64) {
+                const int gate = pc / (4 * R), rem = pc - gate * 4 * R, rrow = rem >> 2, piece = rem & 3;
+                if (rrow < nrows) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(&pub[gate][rrow][4 * piece]);
+                    const unsigned off = (t & 1) * par_bytes + wr_base + (unsigned)(pc * 16);
+                    if (one_xcd)
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 0);
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 16);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) gp_store_flag(flags + slot, (unsigned)(gmax - t), one_xcd);
+        }
+        if (wave >= 2) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int e = (tid - 128) + 128 * half, rb = e >> 4, cc = e & 15;
+                if (rb < nrows) {
+                    const size_t row = (size_t)(row0 + rb) * T + t;
+                    float* dx = dxproj + row * G + j0 + cc;
+                    float* dhp = dhproj + row * G + j0 + cc;
+                    const float dr = pub[0][rb][cc], dz = pub[1][rb][cc];
+                    dx[0] = dr;  dx[H] = dz;  dx[2 * H] = res[e];
+                    dhp[0] = dr; dhp[H] = dz; dhp[2 * H] = pub[2][rb][cc];
+                }
+            }
+        }
+        s_r = s_r1; s_z = s_z1; s_n = s_n1; s_hn = s_hn1; hprev = hprev1; gout = gout1;
+    }
+}
+
 extern "C" {
 
 // workspace: [step flags 8 x 32 words | XCC ids 8 x 32 words | status word + 3 pad] [hand-off ring: 2 parities x 8 groups x
-// R items x 3H units bf16 (backward; forward uses a third of it)]
+// R items x 12 H bytes]. The widest user is the fp32 backward (3 H fp32 per item); the bf16 backward needs 3 H bf16, the bf16
+// LSTM kernels 4 H bf16, the forward kernels H units.
 size_t mg_gru_persist_workspace_bytes(int B, int H) {
     if (B <= 0 || H <= 0) return GP_RING_OFFSET;
-    return GP_RING_OFFSET + (size_t)2 * GP_GROUPS * mg_ceil_div(B, GP_GROUPS) * 4 * H * 2;      // 4 H: also serves lstm_persist.hip
+    return GP_RING_OFFSET + (size_t)2 * GP_GROUPS * mg_ceil_div(B, GP_GROUPS) * 12 * H;
 }
 
 int mg_gru_persist_supported(int B, int T, int H) {
@@ -672,6 +1008,74 @@ int mg_gru_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const f
         GP_BWD_KS(2)
     }
     MG_CHECK_LAUNCH("mg_gru_bwd_persist_bf16");
+    return MG_OK;
+}
+
+int mg_gru_persist_f32_supported(int B, int T, int H) {
+    if (B <= 0 || T <= 0 || H <= 0 || g_mg_tuning[3] == 1) return 0;
+    if (H % 64 != 0 || H > 512 || H < 256) return 0;                       // H = 64 / 128: gru_small.hip
+    if (mg_ceil_div(B, GP_GROUPS) > 16) return 0;                           // one 16-row MFMA tile per group
+    return gp_device_holds((long)GP_GROUPS * (H / GT));
+}
+
+int mg_gru_fwd_persist_f32(const float* xproj, const float* w_hh, const float* b_hh, const int64_t* seq_len, int B, int T, int H,
+                           float* hstate, float* out, float* saved, void* workspace, size_t workspace_bytes, void* stream) {
+    MG_CHECK_ARG(xproj && w_hh && b_hh && hstate && out && saved, "mg_gru_fwd_persist_f32: null argument");
+    MG_CHECK_ARG(mg_gru_persist_f32_supported(B, T, H), "mg_gru_fwd_persist_f32: unsupported shape (B=%d T=%d H=%d)", B, T, H);
+    MG_CHECK_ARG((((uintptr_t)w_hh | (uintptr_t)workspace) % 16) == 0, "mg_gru_fwd_persist_f32: w_hh and workspace must be 16-byte aligned");
+    if (!workspace || workspace_bytes < mg_gru_persist_workspace_bytes(B, H)) {
+        mg_set_error("mg_gru_fwd_persist_f32: workspace of %zu bytes needed, got %zu", mg_gru_persist_workspace_bytes(B, H), workspace_bytes);
+        return MG_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(workspace, 0, (size_t)GP_FLAG_WORDS * sizeof(unsigned), st) != hipSuccess) {
+        mg_set_error("mg_gru_fwd_persist_f32: memset failed");
+        return MG_ELAUNCH;
+    }
+    const int R = (int)mg_ceil_div(B, GP_GROUPS);
+    const unsigned grid = (unsigned)(GP_GROUPS * (H / GT));
+    float* ring = (float*)((char*)workspace + GP_RING_OFFSET);
+    const int force = g_mg_tuning[MG_TUNE_GRU_HANDOFF] == 1;
+#define GPF_FWD(KS) hipLaunchKernelGGL((gru_fwd_persist_f32_kernel<KS>), dim3(grid), dim3(256), 0, st, xproj, w_hh, b_hh, seq_len, B, T, H, R, hstate, out, saved, (unsigned*)workspace, ring, force)
+    switch (H / 64) {
+        case 4: GPF_FWD(4); break;
+        case 5: GPF_FWD(5); break;
+        case 6: GPF_FWD(6); break;
+        case 7: GPF_FWD(7); break;
+        default: GPF_FWD(8); break;
+    }
+    MG_CHECK_LAUNCH("mg_gru_fwd_persist_f32");
+    return MG_OK;
+}
+
+int mg_gru_bwd_persist_f32(const float* grad_out, const float* grad_hn, const float* hstate, const float* saved, const float* w_hh,
+                           const int64_t* seq_len, int B, int T, int H, float* dxproj, float* dhproj, float* dh0, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    MG_CHECK_ARG(grad_out && hstate && saved && w_hh && dxproj && dhproj && dh0, "mg_gru_bwd_persist_f32: null argument");
+    MG_CHECK_ARG(mg_gru_persist_f32_supported(B, T, H), "mg_gru_bwd_persist_f32: unsupported shape (B=%d T=%d H=%d)", B, T, H);
+    MG_CHECK_ARG(((uintptr_t)workspace % 16) == 0, "mg_gru_bwd_persist_f32: workspace must be 16-byte aligned");
+    if (!workspace || workspace_bytes < mg_gru_persist_workspace_bytes(B, H)) {
+        mg_set_error("mg_gru_bwd_persist_f32: workspace of %zu bytes needed, got %zu", mg_gru_persist_workspace_bytes(B, H), workspace_bytes);
+        return MG_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(workspace, 0, (size_t)GP_FLAG_WORDS * sizeof(unsigned), st) != hipSuccess) {
+        mg_set_error("mg_gru_bwd_persist_f32: memset failed");
+        return MG_ELAUNCH;
+    }
+    const int R = (int)mg_ceil_div(B, GP_GROUPS);
+    const unsigned grid = (unsigned)(GP_GROUPS * (H / GT));
+    float* ring = (float*)((char*)workspace + GP_RING_OFFSET);
+    const int force = g_mg_tuning[MG_TUNE_GRU_HANDOFF] == 1;
+#define GPF_BWD(KS) hipLaunchKernelGGL((gru_bwd_persist_f32_kernel<KS>), dim3(grid), dim3(256), 0, st, grad_out, grad_hn, hstate, saved, w_hh, seq_len, B, T, H, R, dxproj, dhproj, dh0, (unsigned*)workspace, ring, force)
+    switch (H / 64) {
+        case 4: GPF_BWD(12); break;
+        case 5: GPF_BWD(15); break;
+        case 6: GPF_BWD(18); break;
+        case 7: GPF_BWD(21); break;
+        default: GPF_BWD(24); break;
+    }
+    MG_CHECK_LAUNCH("mg_gru_bwd_persist_f32");
     return MG_OK;
 }
 

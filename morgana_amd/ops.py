@@ -420,10 +420,17 @@ def sigmoid_grad(dy, y):
 
 
 # ----------------------------------------------------------------------------------------------------------------- K3
-def gru_fwd(xproj, w_hh, b_hh, seq_len, h0, b, t, h):
-    """xproj (b, t, 3h) f32.  Returns (out (b,t,h), hstate (b,t+1,h), saved (b,t,4h))."""
+def gru_persist_f32_ok(b, t, h):
+    return PERSISTENT_RECURRENCE and bool(_lib.load().mg_gru_persist_f32_supported(b, t, h))
+
+
+def gru_fwd(xproj, w_hh, b_hh, seq_len, h0, b, t, h, persistent=None):
+    """xproj (b, t, 3h) f32.  Returns (out (b,t,h), hstate (b,t+1,h), saved (b,t,4h)).  persistent: the one-launch fp32 kernel
+    (None = whenever the shape is covered; bit-identical to the per-step kernels on the live steps)."""
     lib = _lib.load()
     dev = xproj.device
+    if persistent is None:
+        persistent = gru_persist_f32_ok(b, t, h)
     hstate = torch.empty((b, t + 1, h), dtype=torch.float32, device=dev)
     if h0 is None:
         hstate[:, 0].zero_()
@@ -431,17 +438,29 @@ def gru_fwd(xproj, w_hh, b_hh, seq_len, h0, b, t, h):
         hstate[:, 0].copy_(h0.reshape(b, h))
     out = torch.empty((b, t, h), dtype=torch.float32, device=dev)
     saved = torch.empty((b, t, 4 * h), dtype=torch.float32, device=dev)
+    if persistent:
+        ws = _persist_workspace(dev, b, h)
+        _lib.check(lib.mg_gru_fwd_persist_f32(_p(xproj), _p(w_hh), _p(b_hh), _p(seq_len), b, t, h, _p(hstate), _p(out), _p(saved),
+                                              _p(ws), ws.numel(), _stream()), 'mg_gru_fwd_persist_f32')
+        return out, hstate, saved
     _lib.check(lib.mg_gru_fwd_f32(_p(xproj), _p(w_hh), _p(b_hh), _p(seq_len), b, t, h, _p(hstate), _p(out), _p(saved),
                                   _stream()), 'mg_gru_fwd_f32')
     return out, hstate, saved
 
 
-def gru_bwd(grad_out, grad_hn, hstate, saved, w_hh, seq_len, b, t, h):
+def gru_bwd(grad_out, grad_hn, hstate, saved, w_hh, seq_len, b, t, h, persistent=None):
     lib = _lib.load()
     dev = grad_out.device
     dxproj = torch.empty((b, t, 3 * h), dtype=torch.float32, device=dev)
     dhproj = torch.empty((b, t, 3 * h), dtype=torch.float32, device=dev)
     dh0 = torch.empty((b, h), dtype=torch.float32, device=dev)
+    if persistent is None:
+        persistent = gru_persist_f32_ok(b, t, h)
+    if persistent:
+        ws = _persist_workspace(dev, b, h)
+        _lib.check(lib.mg_gru_bwd_persist_f32(_p(grad_out), _p(grad_hn), _p(hstate), _p(saved), _p(w_hh), _p(seq_len), b, t, h,
+                                              _p(dxproj), _p(dhproj), _p(dh0), _p(ws), ws.numel(), _stream()), 'mg_gru_bwd_persist_f32')
+        return dxproj, dhproj, dh0
     nbytes = lib.mg_gru_bwd_workspace_bytes(b, h)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)   # own buffer: lives across the wgrad calls that follow
     _lib.check(lib.mg_gru_bwd_f32(_p(grad_out), _p(grad_hn), _p(hstate), _p(saved), _p(w_hh), _p(seq_len), b, t, h,
