@@ -44,6 +44,8 @@ def parse_args():
                          'lstm: the shipped LSTMAcousticModel 609->512->8xLSTM-512->256->199, 64x1000')
     ap.add_argument('--batch', type=int, default=None, help='utterances per GPU (default 256 for c2, 64 for c4)')
     ap.add_argument('--frames', type=int, default=1000)
+    ap.add_argument('--no-generate', action='store_true',
+                    help='lstm / f0gru: leave out the MLPG + metrics part of the step (the reference runs it inside predict / loss)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     return ap.parse_args()
@@ -287,14 +289,14 @@ def main():
         name, target = 'RNN_SPSS Linear-512/GRU-512/Linear-256/80 (models/RNN_SPSS.py:32-42 layout)', 'normalised_mcep'
     elif args.config == 'f0gru':
         per_gpu = args.batch or 64
-        feats_np = synthetic.make_acoustic_batch(per_gpu, args.frames, streams=(('lf0', 3, 'mse'),), rank=rank)
-        model = models.GRUF0Model(precision=args.precision).to(dev)
+        feats_np = synthetic.make_acoustic_batch(per_gpu, args.frames, streams=(('lf0', 3, 'mse'),), rank=rank, with_raw=True)
+        model = models.GRUF0Model(precision=args.precision, generate=not args.no_generate).to(dev)
         state = synthetic.gru_f0_state()
         name, target = 'shipped F0 model 609-256-3xGRU64-64-3 (models/f0_test_model.py:28-45)', 'lf0 deltas'
     elif args.config == 'lstm':
         per_gpu = args.batch or 64
-        feats_np = synthetic.make_acoustic_batch(per_gpu, args.frames, rank=rank)
-        model = models.LSTMAcousticModel(precision=args.precision).to(dev)
+        feats_np = synthetic.make_acoustic_batch(per_gpu, args.frames, rank=rank, with_raw=True)
+        model = models.LSTMAcousticModel(precision=args.precision, generate=not args.no_generate).to(dev)
         state = synthetic.lstm_acoustic_state()
         name, target = 'LSTMAcousticModel 609-512-8xLSTM512-256-199 (models/RNN_SPSS.py:32-42)', 'lf0/vuv/mcep/bap streams'
     else:
@@ -306,6 +308,12 @@ def main():
     own = model.state_dict()
     for key, value in state.items():
         own[key].copy_(torch.from_numpy(value))
+    if args.config in ('lstm', 'f0gru'):
+        # delta-stream normaliser parameters as ExperimentBuilder would load them: the step then includes the shipped models'
+        # MLPG + streaming metrics (models/RNN_SPSS.py:84-129, models/f0_test_model.py:78-105), all on the device
+        synthetic.acoustic_normalisers(model, device=dev)
+        model.mode = 'train'
+        model.metrics.reset_state('train')
     features = data.to_device(feats_np, dev)
     frames_per_step = int(feats_np['n_frames'].sum())
     optimizer = optim.Adam(model.parameters(), lr=0.01)

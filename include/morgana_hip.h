@@ -157,6 +157,21 @@ int mg_metric_accumulate_f32(int kind, const float* target, const float* pred, c
                              void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * K8  maximum-likelihood parameter generation    reference: morgana/viz/synthesis.py:79-178 (MLPG), :8-36 (_build_win_mats),
+ *     :39-77 (_build_poe); called per training step from predict() - models/f0_test_model.py:86-89, models/RNN_SPSS.py:107-118
+ * ----------------------------------------------------------------------------------------------------------------
+ * means f32 [B,T,W*D] (stream column w*D + d = window w of dimension d), variances f32 [W*D] (var_per_frame = 0, the global
+ * variance both call sites pass) or [B,T,W*D] (var_per_frame = 1); seq_len int64 [B] or NULL; windows as parallel arrays:
+ * win_l / win_u [W] ints (left / right extent, l + u <= 4), win_coeff [W][5] doubles (first l + u + 1 used).  Each utterance is
+ * cut to its length and its first / last frame repeated `padding` times (:113-120, :156-157).  Per (b, d) the banded SPD system
+ * sum_w W_w^T diag(1/var_w) W_w x = sum_w W_w^T (mean_w/var_w) is solved in float64 (LDL^T on the band); out [B,T,D] (f32, or
+ * f64 if out_f64) holds the trajectory, zero past seq_len.  workspace: mg_mlpg_workspace_bytes(...) bytes. */
+size_t mg_mlpg_workspace_bytes(int B, int T, int D, int padding, int n_windows, const int* win_l, const int* win_u);
+int mg_mlpg_f32(const float* means, const float* variances, int var_per_frame, const int64_t* seq_len, int B, int T, int D,
+                int n_windows, const int* win_l, const int* win_u, const double* win_coeff, int padding, void* out, int out_f64,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * K5  mvn / minmax normalisers            reference: morgana/data.py:533-538, 579-590
  * ---------------------------------------------------------------------------------------------------------------- */
 #define MG_NORM_MVN 0         /* (x - mean) / (std_dev + 1e-8)       p0 = mean, p1 = std_dev */

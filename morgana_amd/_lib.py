@@ -86,6 +86,9 @@ SIGNATURES = {
     'mg_metric_workspace_bytes': (c_size_t, []),
     'mg_metric_accumulate_f32': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                          c_void_p, c_size_t, c_void_p]),
+    'mg_mlpg_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'mg_mlpg_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                            c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'mg_gru_small_supported': (c_int, [c_int]),
     'mg_gru_fwd_small_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mg_gru_bwd_small_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,

@@ -14,6 +14,9 @@ import torch
 
 
 class Mean(object):
+    """morgana/metrics.py:359-397.  Unmasked calls (the loss bookkeeping of the train loop) are a torch sum; with ``seq_len`` the
+    masked sum and the frame count come from the device kernel (csrc/metrics.hip) - no ``.item()`` as at metrics.py:394."""
+
     def __init__(self, hidden=False):
         self.hidden = hidden
         self.reset_state()
@@ -23,13 +26,24 @@ class Mean(object):
         self.count = 0.
 
     def accumulate(self, tensor, seq_len=None):
-        if seq_len is not None:
-            raise NotImplementedError('Mean.accumulate with seq_len is outside the hot path')
-        self.sum = self.sum + torch.sum(tensor.detach())
-        self.count += tensor.numel()
+        if seq_len is None:
+            self.sum = self.sum + torch.sum(tensor.detach())
+            self.count = self.count + tensor.numel()
+            return
+        from . import ops
+        accum = torch.zeros(2, dtype=torch.float64, device=tensor.device)
+        ops.metric_accumulate(ops.METRIC_MEAN, accum, tensor.detach().to(torch.float32), seq_len=seq_len)
+        self.sum = self.sum + accum[0]
+        self.count = self.count + accum[1]
 
     def result(self, *args):
         return self.sum / (self.count + 1e-8)
+
+    def result_as_json(self, *args):
+        return float(self.result(*args))
+
+    def __str__(self):
+        return '{:.3f}'.format(float(self.result()))
 
 
 class _DeviceMetric(object):
@@ -59,6 +73,12 @@ class _DeviceMetric(object):
 
     def result(self, *args):
         return self.sum / (self.count + 1e-8)
+
+    def result_as_json(self, *args):
+        return float(self.result(*args))
+
+    def __str__(self):
+        return '{:.3f}'.format(float(self.result()))
 
 
 class DeviceMean(_DeviceMetric):
@@ -121,28 +141,58 @@ class MelCepDistortion(RMSE):
 
 
 class Handler(object):
-    """Tracks metrics per mode ('train' / 'valid' / 'test'), morgana/metrics.py:52-186 (collection logic only)."""
+    """Container for running a set of metrics, morgana/metrics.py:50-186: named collections ('all', 'train', 'valid', 'test')
+    of name -> metric; the constructor's metrics go to 'all', 'train' and 'valid', ``add_metrics('all', ...)`` to every
+    collection, and a metric added to several collections is ONE object shared between them, as in the reference."""
 
     def __init__(self, **metrics):
-        self._factories = {name: type(metric) for name, metric in metrics.items()}
-        self.collections = {}
+        self.hidden = False
+        self.collections = {'all': metrics, 'train': {}, 'valid': {}, 'test': {}}
+        self.metrics = self.collections['all']
+        self.add_metrics(('train', 'valid'), **metrics)
 
-    def _collection(self, mode):
-        if mode not in self.collections:
-            self.collections[mode] = {name: cls() for name, cls in self._factories.items()}
-        return self.collections[mode]
+    def __getitem__(self, name):
+        if name in self.collections:
+            return self.collections[name]
+        raise ValueError("No collection found by the name {}".format(name))
 
-    def reset_state(self, mode):
-        for metric in self._collection(mode).values():
+    def add_metrics(self, collections=('all',), **kwargs):
+        if isinstance(collections, str) or not hasattr(collections, '__iter__'):
+            collections = [collections]
+        if 'all' in collections:
+            collections = list(self.collections.keys())
+        for collection_name in collections:
+            self.collections[collection_name].update(kwargs)
+        self.metrics.update(kwargs)
+
+    def add_collection(self, collection, from_collections=tuple()):
+        if isinstance(from_collections, str) or not hasattr(from_collections, '__iter__'):
+            from_collections = [from_collections]
+        self.collections[collection] = {}
+        for from_collection in from_collections:
+            self[collection].update(self[from_collection])
+
+    def reset_state(self, collection, *args):
+        for metric in self[collection].values():
             metric.reset_state()
 
-    def accumulate(self, mode, **kwargs):
-        for name, value in kwargs.items():
-            metric = self._collection(mode)[name]
-            if isinstance(value, (tuple, list)):
-                metric.accumulate(*value)
+    def accumulate(self, collection, **kwargs):
+        for metric_name, inputs in kwargs.items():
+            inputs = list(inputs) if isinstance(inputs, (tuple, list)) else [inputs]          # utils.listify
+            if isinstance(inputs[-1], dict):
+                inputs, kwinputs = inputs[:-1], inputs[-1]
             else:
-                metric.accumulate(value)
+                kwinputs = dict()
+            self[collection][metric_name].accumulate(*inputs, **kwinputs)
 
-    def results_as_json_dict(self, mode):
-        return {name: float(metric.result()) for name, metric in self._collection(mode).items()}
+    def result(self, collection='all', *args):
+        return {name: metric.result(*args) for name, metric in self[collection].items()}
+
+    def results_as_json_dict(self, collection='all', prefix=''):
+        return {prefix + name: metric.result_as_json() for name, metric in self[collection].items() if not metric.hidden}
+
+    def results_as_str_dict(self, collection='all', prefix=''):
+        return {prefix + name: str(metric) for name, metric in self[collection].items() if not metric.hidden}
+
+    def __str__(self):
+        return ' | '.join('{} = {}'.format(name, value) for name, value in self.results_as_str_dict('all').items())

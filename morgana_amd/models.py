@@ -14,8 +14,15 @@ import torch.nn as nn
 
 from . import data
 from . import losses
+from . import metrics
 from . import utils
+from . import viz
 from .base_models import BaseSPSS
+
+
+def _has_delta_params(normalisers, name):
+    norm = normalisers.get(name)
+    return norm is not None and getattr(norm, 'delta_params_torch', None) is not None
 
 
 class F0Model(BaseSPSS):
@@ -109,16 +116,19 @@ class RNNSPSS(BaseSPSS):
 class LSTMAcousticModel(BaseSPSS):
     """models/RNN_SPSS.py:20-139 against this package: same constructor arguments, layer container (so the reference's
     state_dict keys ``layers.0.weight`` ... ``layers.{3+k}.layer.weight_ih_l0`` ... load unchanged), ``predict`` outputs and
-    ``loss``.  MLPG (``_prepare_output``, :108-118) is generation-time CPU post-processing on detached outputs and is not part
-    of this package; ``predict`` returns the normalised delta streams and the voicing probability."""
+    ``loss``, and the metrics registered at :44-48 and accumulated in ``loss`` (:120-129).  ``_prepare_output`` (:107-118:
+    denormalise the delta streams, MLPG against the global delta variances, padding 100) runs on the device
+    (``viz.synthesis.MLPG``, csrc/mlpg.hip) instead of through numpy on the host; it and the metrics are active whenever the
+    normalisers carry delta parameters, i.e. under ``ExperimentBuilder`` as in the reference (``generate=False`` turns both off)."""
 
     STREAMS = ('lf0', 'vuv', 'mcep', 'bap')
 
     def __init__(self, input_dim=600 + 9, output_dims=None, dropout_prob=0., num_layers=8, hidden_dim=512, post_dim=256,
-                 precision=None, fused_upsample=True, fused_loss=True):
+                 precision=None, fused_upsample=True, fused_loss=True, generate=True):
         if output_dims is None:
             output_dims = {'lf0': 1 * 3, 'vuv': 1, 'mcep': 60 * 3, 'bap': 5 * 3}
         super(LSTMAcousticModel, self).__init__()
+        self.generate = generate
         self.input_dim = input_dim
         self.output_dims = output_dims
         self.dropout_prob = dropout_prob
@@ -137,6 +147,11 @@ class LSTMAcousticModel(BaseSPSS):
             nn.Dropout(p=self.dropout_prob),
             nn.Linear(post_dim, sum(self.output_dims.values())),
             precision=precision)
+        self.metrics.add_metrics('all',                                              # models/RNN_SPSS.py:44-48
+                                 LF0_RMSE_Hz=metrics.LF0Distortion(),
+                                 VUV_accuracy=metrics.Mean(),
+                                 MCEP_distortion=metrics.MelCepDistortion(),
+                                 BAP_distortion=metrics.Distortion())
 
     def normaliser_sources(self):
         return {
@@ -166,11 +181,39 @@ class LSTMAcousticModel(BaseSPSS):
             'vuv': torch.sigmoid(vuv) if pred_vuv is None else pred_vuv,
         }
 
+    def _generating(self):
+        return self.generate and all(_has_delta_params(self.normalisers, n) for n in ('lf0', 'mcep', 'bap'))
+
+    def _prepare_output(self, name, pred_norm_deltas, seq_len=None):
+        """models/RNN_SPSS.py:107-118, without leaving the device."""
+        pred_deltas = self.normalisers[name].denormalise(pred_norm_deltas.detach(), deltas=True)
+        return viz.synthesis.MLPG(means=pred_deltas, variances=self.normalisers[name].delta_params_torch['std_dev'] ** 2,
+                                  padding_size=100, seq_len=seq_len)
+
+    def _with_trajectories(self, outputs, n_frames):
+        if self._generating():
+            for name in ('lf0', 'mcep', 'bap'):                                      # :88-93
+                outputs[name] = self._prepare_output(name, outputs['normalised_%s_deltas' % name], n_frames)
+        return outputs
+
+    def _accumulate_metrics(self, features, output_features):
+        if not self._generating():
+            return
+        n_frames = features['n_frames']
+        vuv = output_features['vuv'] > 0.5                                           # :121-129
+        self.metrics.accumulate(
+            self.mode,
+            LF0_RMSE_Hz=(features['lf0'], output_features['lf0'], vuv, n_frames),
+            VUV_accuracy=((features['vuv'] == vuv).type(torch.float), n_frames),
+            MCEP_distortion=(features['mcep'], output_features['mcep'], n_frames),
+            BAP_distortion=(features['bap'], output_features['bap'], n_frames))
+
     def predict(self, features):
-        return self._split(self._run_layers(features))
+        return self._with_trajectories(self._split(self._run_layers(features)), features['n_frames'])
 
     def loss(self, features, output_features):
         n_frames = features['n_frames']
+        self._accumulate_metrics(features, output_features)
         loss = 0.
         loss += losses.mse(output_features['normalised_lf0_deltas'], features['normalised_lf0_deltas'], n_frames)
         loss += losses.mse(output_features['normalised_mcep_deltas'], features['normalised_mcep_deltas'], n_frames)
@@ -187,16 +230,20 @@ class LSTMAcousticModel(BaseSPSS):
         targets = [features['vuv'] if n == 'vuv' else features['normalised_%s_deltas' % n] for n in self.STREAMS]
         kinds = ['sigmoid_bce' if n == 'vuv' else 'mse' for n in self.STREAMS]
         loss, pred_vuv = losses.multi_stream(pred_norm_deltas, targets, kinds, features['n_frames'], want_prob=True)
-        return loss, self._split(pred_norm_deltas.detach(), pred_vuv)
+        outputs = self._with_trajectories(self._split(pred_norm_deltas.detach(), pred_vuv), features['n_frames'])
+        self._accumulate_metrics(features, outputs)
+        return loss, outputs
 
 
 class GRUF0Model(BaseSPSS):
     """models/f0_test_model.py:21-107 against this package: same constructor arguments, the same layer container (state_dict
-    keys ``layers.0.weight``, ``layers.3.layer.weight_ih_l0`` ... load unchanged), ``predict`` / ``loss``.  MLPG (:86-89) is
-    detached CPU post-processing for the LF0 metric and is not part of this package."""
+    keys ``layers.0.weight``, ``layers.3.layer.weight_ih_l0`` ... load unchanged), ``predict`` / ``loss`` and the LF0 metric
+    (:47-48, :101-103).  MLPG (:86-89) runs on the device (``viz.synthesis.MLPG``, csrc/mlpg.hip); it and the metric are active
+    whenever the 'lf0' normaliser carries delta parameters, i.e. under ``ExperimentBuilder`` (``generate=False`` turns both off)."""
 
-    def __init__(self, dropout_prob=0., input_dim=600 + 9, output_dim=1 * 3, precision=None, fused_upsample=True):
+    def __init__(self, dropout_prob=0., input_dim=600 + 9, output_dim=1 * 3, precision=None, fused_upsample=True, generate=True):
         super(GRUF0Model, self).__init__()
+        self.generate = generate
         self.input_dim = input_dim
         self.output_dim = output_dim
         self.fused_upsample = fused_upsample
@@ -215,6 +262,7 @@ class GRUF0Model(BaseSPSS):
             nn.Dropout(p=dropout_prob),
             nn.Linear(64, self.output_dim),
             precision=precision)
+        self.metrics.add_metrics('all', LF0_RMSE_Hz=metrics.LF0Distortion())         # models/f0_test_model.py:47-48
 
     def normaliser_sources(self):
         return {
@@ -229,8 +277,20 @@ class GRUF0Model(BaseSPSS):
         norm_lab_at_frame_rate = utils.upsample_to_repetitions(features['normalised_lab'], features['dur'],
                                                                max_len=norm_counters.shape[1], fused=self.fused_upsample)
         model_inputs = utils.concat_frame_features(norm_lab_at_frame_rate, norm_counters)
-        pred_norm_lf0_deltas, _ = self.layers(model_inputs, seq_len=features['n_frames'])
-        return {'normalised_lf0_deltas': pred_norm_lf0_deltas}
+        n_frames = features['n_frames']
+        pred_norm_lf0_deltas, _ = self.layers(model_inputs, seq_len=n_frames)
+        outputs = {'normalised_lf0_deltas': pred_norm_lf0_deltas}
+        if self.generate and _has_delta_params(self.normalisers, 'lf0'):
+            # MLPG to select the most probable trajectory given the delta and delta-delta features (:83-89)
+            pred_lf0_deltas = self.normalisers['lf0'].denormalise(pred_norm_lf0_deltas.detach(), deltas=True)
+            global_variance = self.normalisers['lf0'].delta_params_torch['std_dev'] ** 2
+            outputs['lf0'] = viz.synthesis.MLPG(pred_lf0_deltas, global_variance, padding_size=100, seq_len=n_frames)
+        return outputs
 
     def loss(self, features, output_features):
-        return losses.mse(output_features['normalised_lf0_deltas'], features['normalised_lf0_deltas'], features['n_frames'])
+        seq_len = features['n_frames']
+        loss = losses.mse(output_features['normalised_lf0_deltas'], features['normalised_lf0_deltas'], seq_len)
+        if 'lf0' in output_features:
+            self.metrics.accumulate(self.mode,                                       # :101-103
+                                    LF0_RMSE_Hz=(features['lf0'], output_features['lf0'], features['vuv'], seq_len))
+        return loss

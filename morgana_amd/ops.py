@@ -745,3 +745,49 @@ def metric_accumulate(kind, accum, target, pred=None, voiced=None, seq_len=None,
     ws = torch.empty(lib.mg_metric_workspace_bytes(), dtype=torch.uint8, device=target.device)
     _lib.check(lib.mg_metric_accumulate_f32(kind, _p(target), _p(pred), _p(voiced), _p(seq_len), b, t, d, col0, width, _p(accum), _p(ws),
                                             ws.numel(), _stream()), 'mg_metric_accumulate_f32')
+
+
+MLPG_MAX_WINDOWS, MLPG_MAX_COEFF = 4, 5
+
+
+def mlpg(means, variances, windows, padding_size=0, seq_len=None, out_dtype=torch.float32):
+    """Most probable trajectories of (B, T, W*D) f32 delta-stream means (csrc/mlpg.hip, morgana/viz/synthesis.py:79-178).
+    variances (W*D,) global or (B, T, W*D) per frame, f32; windows [(l, u, coeffs)]; returns (B, T, D), zero past seq_len."""
+    lib = _lib.load()
+    means = _require(means, torch.float32, 'means')
+    variances = _require(variances, torch.float32, 'variances')
+    if means.dim() != 3:
+        raise ValueError('means must have shape (batch, time, windows * features), got %s' % (tuple(means.shape),))
+    b, t, width = means.shape
+    n_win = len(windows)
+    if n_win == 0 or n_win > MLPG_MAX_WINDOWS or width % n_win != 0:
+        raise ValueError('%d windows for %d stream columns (1..%d windows, columns a multiple of it)' % (n_win, width, MLPG_MAX_WINDOWS))
+    d = width // n_win
+    if variances.dim() == 1 and variances.shape[0] == width:
+        per_frame = 0
+    elif variances.shape == means.shape:
+        per_frame = 1
+    else:
+        raise ValueError('variances %s fit neither (%d,) nor %s' % (tuple(variances.shape), width, tuple(means.shape)))
+    win_l = (ctypes.c_int * n_win)()
+    win_u = (ctypes.c_int * n_win)()
+    win_c = (ctypes.c_double * (n_win * MLPG_MAX_COEFF))()
+    for w, (l, u, coeff) in enumerate(windows):
+        l, u = int(l), int(u)
+        if l < 0 or u < 0 or len(coeff) != l + u + 1:                 # the asserts of synthesis.py:30-31
+            raise ValueError('window %d: %d coefficients for extents l=%d, u=%d' % (w, len(coeff), l, u))
+        if l + u + 1 > MLPG_MAX_COEFF:
+            raise ValueError('window %d is wider than %d coefficients' % (w, MLPG_MAX_COEFF))
+        win_l[w], win_u[w] = l, u
+        for k, c in enumerate(coeff):
+            win_c[w * MLPG_MAX_COEFF + k] = float(c)
+    if seq_len is not None:
+        seq_len = _require(seq_len, torch.int64, 'seq_len')
+    if out_dtype not in (torch.float32, torch.float64):
+        raise TypeError('out_dtype must be torch.float32 or torch.float64')
+    out = torch.empty((b, t, d), dtype=out_dtype, device=means.device)
+    nbytes = lib.mg_mlpg_workspace_bytes(b, t, d, int(padding_size), n_win, win_l, win_u)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=means.device)
+    _lib.check(lib.mg_mlpg_f32(_p(means), _p(variances), per_frame, _p(seq_len), b, t, d, n_win, win_l, win_u, win_c, int(padding_size),
+                               _p(out), int(out_dtype == torch.float64), _p(ws), ws.numel(), _stream()), 'mg_mlpg_f32')
+    return out

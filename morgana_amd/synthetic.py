@@ -157,7 +157,7 @@ def lstm_acoustic_state(seed=REFERENCE_SEED, input_dim=609, hidden=512, post=256
 
 
 def make_acoustic_batch(batch_size, n_frames, lab_dim=600, counters_dim=9, streams=ACOUSTIC_STREAMS, frames_per_phone=12.5,
-                        seed=REFERENCE_SEED, rank=0):
+                        seed=REFERENCE_SEED, rank=0, with_raw=False):
     """Feature dict for the LSTM acoustic model (models/RNN_SPSS.py:60-71, 73-82): ``make_batch``'s lab / dur / n_frames plus
     frame-level ``normalised_counters`` ~ U[0,1) and one target per stream - ``normalised_<name>_deltas`` ~ N(0,1) for the
     regression streams, ``vuv`` in {0, 1}; pads beyond each utterance's length are zero."""
@@ -174,7 +174,35 @@ def make_acoustic_batch(batch_size, n_frames, lab_dim=600, counters_dim=9, strea
             feats['normalised_%s_deltas' % name] = (rng.standard_normal((batch_size, max_t, width)) * mask).astype(np.float32)
         else:
             feats[name] = ((rng.random_sample((batch_size, max_t, width)) > 0.4) * mask).astype(np.float32)
+    if with_raw:
+        # the un-normalised static features the shipped models' metrics compare the MLPG trajectories with
+        # (models/RNN_SPSS.py:124-129, models/f0_test_model.py:101-103); drawn from their own stream so the rest is unchanged
+        raw = np.random.RandomState((seed + rank + 104729) % (2 ** 32))
+        for name, width, kind in streams:
+            if kind == 'mse':
+                offset = 5.0 if name == 'lf0' else 0.0
+                feats[name] = ((raw.standard_normal((batch_size, max_t, width // 3)) * 0.3 + offset) * mask).astype(np.float32)
+        if 'vuv' not in feats:
+            feats['vuv'] = ((raw.random_sample((batch_size, max_t, 1)) > 0.4) * mask).astype(np.float32)
     return feats
+
+
+def acoustic_normalisers(model, device='cpu', seed=REFERENCE_SEED):
+    """Install synthetic mean-variance parameters (static and delta) on the model's delta-stream normalisers, standing in for
+    the ``*_mvn.json`` / ``*_deltas_mvn.json`` files ``ExperimentBuilder`` loads (morgana/data.py:362-385): with them the shipped
+    models run their MLPG + metrics step as under the reference's builder."""
+    rng = np.random.RandomState((seed + 15485863) % (2 ** 32))
+    model.normalisers = model.normaliser_sources()
+    widths = getattr(model, 'output_dims', None) or {'lf0': model.output_dim}
+    for name, norm in model.normalisers.items():
+        if not getattr(norm, 'use_deltas', False):
+            continue
+        width = widths[name]
+        mean = rng.standard_normal(width).astype(np.float32) * 0.1
+        mean[:width // 3] += 5.0 if name == 'lf0' else 0.0
+        std = rng.uniform(0.2, 0.6, width).astype(np.float32)
+        norm.set_params({'mean': mean[:width // 3], 'std_dev': std[:width // 3]}, {'mean': mean, 'std_dev': std}, device=device)
+    return model.normalisers
 
 
 def gru_f0_state(seed=REFERENCE_SEED, input_dim=609, d1=256, hidden=64, post=64, output_dim=3):

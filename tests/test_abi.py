@@ -58,6 +58,32 @@ def test_no_cpu_fallback():
     from morgana_amd import metrics
     with pytest.raises(_lib.MorganaHipError):                          # streaming metrics: device accumulators only
         metrics.RMSE().accumulate(torch.zeros(2, 3, 1), torch.zeros(2, 3, 1), torch.tensor([3, 2]))
+    with pytest.raises(_lib.MorganaHipError):                          # masked Mean (the shipped model's V/UV accuracy) likewise
+        metrics.Mean().accumulate(torch.zeros(2, 3, 1), torch.tensor([3, 2]))
+    from morgana_amd.viz import synthesis
+    with pytest.raises(_lib.MorganaHipError):                          # MLPG: no host solver behind the reference's signature
+        synthesis.MLPG(torch.zeros(2, 5, 3), torch.ones(3), padding_size=2, seq_len=torch.tensor([5, 4]))
+
+
+def test_metrics_handler_collections():
+    """morgana/metrics.py:50-186: constructor metrics land in 'all', 'train' and 'valid'; add_metrics('all') reaches every
+    collection; one metric object is shared by the collections it was added to; kwargs dicts are passed through."""
+    from morgana_amd import metrics
+    handler = metrics.Handler(loss=metrics.Mean())
+    extra = metrics.Mean()
+    handler.add_metrics('all', extra=extra)
+    handler.add_metrics('test', only_test=metrics.Mean(hidden=True))
+    assert set(handler['train']) == {'loss', 'extra'} and set(handler['test']) == {'extra', 'only_test'}
+    assert handler['train']['extra'] is handler['valid']['extra'] is extra
+    handler.accumulate('train', loss=torch.tensor([1., 3.]), extra=(torch.tensor([2.]), {'seq_len': None}))
+    assert handler.results_as_json_dict('valid') == {'loss': pytest.approx(2.0), 'extra': pytest.approx(2.0)}
+    assert 'only_test' not in handler.results_as_json_dict('test')
+    handler.reset_state('train')
+    assert handler.results_as_json_dict('train', prefix='x_') == {'x_loss': 0.0, 'x_extra': 0.0}
+    with pytest.raises(ValueError, match='No collection'):
+        handler.accumulate('', loss=torch.tensor([1.]))
+    handler.add_collection('synth', from_collections='test')
+    assert set(handler['synth']) == {'extra', 'only_test'}
 
 
 def test_device_batches_shapes_without_a_gpu():

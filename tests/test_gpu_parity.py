@@ -1189,6 +1189,7 @@ class _ToyGRUF0(models.GRUF0Model):
         models.BaseSPSS.__init__(self)
         nn = torch.nn
         self.fused_upsample = fused
+        self.generate = False
         self.layers = utils.SequentialWithRecurrent(
             nn.Linear(input_dim, d1), nn.Sigmoid(), nn.Dropout(p=0.),
             utils.RecurrentCuDNNWrapper(nn.GRU(d1, hid, batch_first=True), precision=precision), nn.Dropout(p=0.),
@@ -1297,3 +1298,161 @@ def test_streaming_metric_full_size_vs_oracle():
     s, c = ref_cpu.metric_sums('sqdiff_voiced_exp', lt, lp, voiced=voiced, seq_len=seq)
     assert float(lf0.count) == c
     np.testing.assert_allclose(float(lf0.result()), ref_cpu.metric_result('sqdiff_voiced_exp', s, c), rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------------------ MLPG
+MLPG_WINDOWS_5PT = ((0, 0, (1.0,)), (2, 2, (-0.2, -0.1, 0.0, 0.1, 0.2)), (1, 1, (1.0, -2.0, 1.0)))
+
+
+@pytest.mark.parametrize('windows,pad,b,t,d', [(None, 0, 3, 26, 2), (None, 100, 5, 60, 3), (MLPG_WINDOWS_5PT, 4, 4, 33, 5),
+                                               (((0, 0, (1.0,)),), 3, 2, 10, 4)])
+def test_mlpg_vs_oracle(windows, pad, b, t, d):
+    """mg_mlpg_f32 (csrc/mlpg.hip: band rows in one pass, banded LDL^T per system in float64) against the float64 CPU restatement
+    of morgana/viz/synthesis.py:79-178: ragged lengths incl. a full and a 1-frame utterance, global and per-frame variances,
+    default / 5-point / static-only windows, with and without burn-in padding.  1e-6 relative on the float32 trajectories
+    (float32 rounding of the float64 solution; the summation order inside the band differs from bandmat's), 1e-11 on the
+    float64 output; frames past seq_len exactly zero."""
+    from morgana_amd import ops
+    from morgana_amd.viz import synthesis
+    n_win = 3 if windows is None else len(windows)
+    rng = np.random.RandomState(b * t + pad)
+    means = rng.standard_normal((b, t, n_win * d)).astype(np.float32)
+    seq = rng.randint(2, t + 1, size=b).astype(np.int64)
+    seq[0], seq[-1] = t, 1
+    win = synthesis.DEFAULT_WINDOWS if windows is None else windows
+    for variances in (rng.uniform(0.3, 2.0, n_win * d).astype(np.float32), rng.uniform(0.3, 2.0, means.shape).astype(np.float32)):
+        want = ref_cpu.mlpg(means, variances, windows=windows, padding_size=pad, seq_len=seq)
+        scale = np.abs(want).max()
+        got = ops.mlpg(dev(means), dev(variances), win, padding_size=pad, seq_len=dev(seq))
+        assert got.dtype == torch.float32 and tuple(got.shape) == (b, t, d)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=1e-6 * scale)
+        got64 = ops.mlpg(dev(means), dev(variances), win, padding_size=pad, seq_len=dev(seq), out_dtype=torch.float64)
+        np.testing.assert_allclose(got64.cpu().numpy(), want, rtol=0, atol=1e-11 * scale)
+        for i, n in enumerate(seq):
+            assert torch.all(got[i, n:] == 0)
+    # no seq_len: every utterance runs to T
+    want = ref_cpu.mlpg(means, variances, windows=windows, padding_size=pad)
+    np.testing.assert_allclose(ops.mlpg(dev(means), dev(variances), win, padding_size=pad).cpu().numpy(), want, rtol=0,
+                               atol=1e-6 * np.abs(want).max())
+
+
+def test_mlpg_reference_signature():
+    """morgana_amd.viz.synthesis.MLPG as the reference's call sites use it (models/f0_test_model.py:86-89: tensors, global variance,
+    padding 100, seq_len tensor -> float tensor on the device; a single numpy sequence -> float64 array without the batch axis)."""
+    from morgana_amd.viz import synthesis
+    rng = np.random.RandomState(3)
+    means = rng.standard_normal((6, 80, 3)).astype(np.float32)
+    var = (rng.uniform(0.2, 1.5, 3) ** 2).astype(np.float32)
+    seq = np.array([80, 41, 7, 80, 1, 63], np.int64)
+    want = ref_cpu.mlpg(means, var, padding_size=100, seq_len=seq)
+    got = synthesis.MLPG(dev(means), dev(var), padding_size=100, seq_len=dev(seq))
+    assert isinstance(got, torch.Tensor) and got.is_cuda and got.dtype == torch.float32
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=1e-6 * np.abs(want).max())
+    single = synthesis.MLPG(means[1, :41], var, padding_size=100)
+    assert isinstance(single, np.ndarray) and single.dtype == np.float64 and single.shape == (41, 1)
+    np.testing.assert_allclose(single, want[1, :41], rtol=0, atol=1e-11 * np.abs(want).max())
+    with pytest.raises(ValueError, match='coefficients'):
+        synthesis.MLPG(dev(means), dev(var), windows=[(1, 1, np.array([1.0]))] * 3)
+    with pytest.raises(ValueError, match='windows'):
+        synthesis.MLPG(dev(means[..., :2]), dev(var[:2]))
+
+
+def test_mlpg_full_size_properties():
+    """The LSTM acoustic model's streams at its batch (64 x 1000 frames, 60 mel-cepstra, padding 100; 3 840 systems of up to 1 200
+    unknowns): a sample of systems against the oracle, and over ALL of them the defining property - the residual of the normal
+    equations P x = b evaluated in float64 from the float64 trajectory - below 1e-9 of |b|."""
+    from morgana_amd import ops
+    from morgana_amd.viz import synthesis
+    rng = np.random.RandomState(9)
+    b, t, d = 64, 1000, 60
+    means = rng.standard_normal((b, t, 3 * d)).astype(np.float32)
+    var = rng.uniform(0.1, 2.0, 3 * d).astype(np.float32)
+    seq = rng.randint(300, t + 1, size=b).astype(np.int64)
+    seq[0] = t
+    got = ops.mlpg(dev(means), dev(var), synthesis.DEFAULT_WINDOWS, padding_size=0, seq_len=dev(seq), out_dtype=torch.float64).cpu().numpy()
+    padded = ops.mlpg(dev(means), dev(var), synthesis.DEFAULT_WINDOWS, padding_size=100, seq_len=dev(seq)).cpu().numpy()
+    for i in (0, 17, 63):
+        want = ref_cpu.mlpg(means[i:i + 1, :, [5, d + 5, 2 * d + 5]], var[[5, d + 5, 2 * d + 5]], padding_size=100, seq_len=seq[i:i + 1])
+        np.testing.assert_allclose(padded[i, :, 5], want[0, :, 0], rtol=0, atol=1e-6 * np.abs(want).max())
+    # residual of sum_w W_w^T diag(tau_w) (W_w x - mu_w) = 0 without padding, all systems at once
+    tau = (1.0 / var).astype(np.float64).reshape(3, d)
+    mu_tau = (means / var).astype(np.float64).reshape(b, t, 3, d)
+    worst = 0.0
+    for i in range(b):
+        n = int(seq[i])
+        x = got[i, :n]                                                     # (n, d)
+        xp = np.concatenate((np.zeros((1, d)), x, np.zeros((1, d))), 0)
+        delta = 0.5 * (xp[2:] - xp[:-2])
+        ddelta = xp[2:] - 2.0 * xp[1:-1] + xp[:-2]
+        res = [x * tau[0] - mu_tau[i, :n, 0], delta * tau[1] - mu_tau[i, :n, 1], ddelta * tau[2] - mu_tau[i, :n, 2]]
+        rp = [np.concatenate((np.zeros((1, d)), r, np.zeros((1, d))), 0) for r in res]
+        grad = res[0] + 0.5 * (rp[1][:-2] - rp[1][2:]) + (rp[2][:-2] - 2.0 * rp[2][1:-1] + rp[2][2:])
+        worst = max(worst, np.abs(grad).max() / np.abs(mu_tau[i, :n]).max())
+    assert worst < 1e-9, worst
+
+
+def _mvn_denorm(x, params):
+    return x * params['std_dev'] + params['mean']                        # morgana/data.py:536-538
+
+
+@pytest.mark.parametrize('fused_loss', [True, False])
+def test_lstm_acoustic_model_generation_and_metrics(fused_loss):
+    """The shipped acoustic model's full step as the reference runs it under its builder (models/RNN_SPSS.py:84-129): the delta
+    streams denormalised and turned into trajectories by MLPG (padding 100, global delta variances) and the four metrics
+    accumulated inside loss().  Trajectories against the CPU restatement applied to the model's own delta outputs (1e-5 of the
+    stream's scale: float32 denormalise + float32 trajectory), metrics against oracle.metric_sums on those trajectories (1e-4)."""
+    feats_np = synthetic.make_acoustic_batch(4, (40, 90), seed=31, with_raw=True)
+    model = _load_state(models.LSTMAcousticModel(num_layers=2, precision='fp32', fused_loss=fused_loss).to(DEV),
+                        synthetic.lstm_acoustic_state(num_layers=2))
+    synthetic.acoustic_normalisers(model, device=DEV)
+    model.mode = 'train'
+    model.metrics.reset_state('train')
+    feats = data.to_device(feats_np, DEV)
+    for _ in range(2):                                                   # two accumulate calls, as two steps of an epoch
+        loss, out = model(feats)
+    seq = feats_np['n_frames']
+    vuv = out['vuv'].detach().cpu().numpy() > 0.5
+    results = model.metrics.results_as_json_dict('train')
+    kinds = {'lf0': ('LF0_RMSE_Hz', 'sqdiff_voiced_exp'), 'mcep': ('MCEP_distortion', 'sqdiff'), 'bap': ('BAP_distortion', 'root_sq')}
+    for name, (metric_name, kind) in kinds.items():
+        norm = model.normalisers[name]
+        deltas = _mvn_denorm(out['normalised_%s_deltas' % name].detach().cpu().numpy(), norm.delta_params)
+        want = ref_cpu.mlpg(deltas, norm.delta_params['std_dev'] ** 2, padding_size=100, seq_len=seq)
+        got = out[name].cpu().numpy()
+        assert got.shape == feats_np[name].shape
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-5 * np.abs(want).max(), err_msg=name)
+        s, c = ref_cpu.metric_sums(kind, feats_np[name], got, voiced=vuv if name == 'lf0' else None, seq_len=seq,
+                                   col0=1 if name == 'mcep' else 0)
+        np.testing.assert_allclose(results[metric_name], ref_cpu.metric_result(kind, 2 * s, 2 * c), rtol=1e-4, err_msg=metric_name)
+    s, c = ref_cpu.metric_sums('mean', (feats_np['vuv'] == vuv).astype(np.float32), seq_len=seq)
+    np.testing.assert_allclose(results['VUV_accuracy'], ref_cpu.metric_result('mean', s, c), rtol=1e-6)
+    # generation off: the training outputs only, no metric touched
+    quiet = models.LSTMAcousticModel(num_layers=2, precision='fp32', generate=False).to(DEV)
+    synthetic.acoustic_normalisers(quiet, device=DEV)
+    assert 'lf0' not in quiet(feats)[1]
+
+
+def test_gru_f0_model_generation_and_metric():
+    """models/f0_test_model.py:78-105 as run under the builder: MLPG of the denormalised LF0 deltas and LF0_RMSE_Hz accumulated in
+    loss() against the feature's own voicing flags; a model without normaliser parameters (plain synthetic runs) skips both."""
+    feats_np = synthetic.make_acoustic_batch(6, (30, 120), streams=(('lf0', 3, 'mse'),), seed=37, with_raw=True)
+    model = _load_state(models.GRUF0Model(precision='fp32').to(DEV), synthetic.gru_f0_state())
+    feats = data.to_device(feats_np, DEV)
+    assert set(model(feats)[1]) == {'normalised_lf0_deltas'}
+    synthetic.acoustic_normalisers(model, device=DEV)
+    model.mode = 'train'
+    model.metrics.reset_state('train')
+    loss, out = model(feats)
+    loss.backward()
+    norm = model.normalisers['lf0']
+    deltas = _mvn_denorm(out['normalised_lf0_deltas'].detach().cpu().numpy(), norm.delta_params)
+    want = ref_cpu.mlpg(deltas, norm.delta_params['std_dev'] ** 2, padding_size=100, seq_len=feats_np['n_frames'])
+    np.testing.assert_allclose(out['lf0'].cpu().numpy(), want, rtol=0, atol=1e-5 * np.abs(want).max())
+    assert not out['lf0'].requires_grad
+    s, c = ref_cpu.metric_sums('sqdiff_voiced_exp', feats_np['lf0'], out['lf0'].cpu().numpy(), voiced=feats_np['vuv'] > 0.5,
+                               seq_len=feats_np['n_frames'])
+    np.testing.assert_allclose(model.metrics.results_as_json_dict('train')['LF0_RMSE_Hz'],
+                               ref_cpu.metric_result('sqdiff_voiced_exp', s, c), rtol=1e-4)
+    with pytest.raises(ValueError, match='No collection'):               # mode unset, as in the reference outside its builder
+        model.mode = ''
+        model(feats)

@@ -381,3 +381,58 @@ def test_g15_streaming_metrics(golden, name, kind, _):
     np.testing.assert_allclose(count, float(g[name + '__count']), rtol=0, atol=0)
     np.testing.assert_allclose(total, float(g[name + '__sum']), rtol=2e-5)
     np.testing.assert_allclose(ref_cpu.metric_result(kind, total, count), float(g[name + '__result']), rtol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------------------------ MLPG
+# The reference's MLPG needs `bandmat`, which this image lacks: no golden vector exists (oracle header: parity unpinned by
+# reference execution).  The restatement is pinned against the definition written out densely and against cases with known
+# answers.
+WINDOWS_5PT = ((0, 0, (1.0,)), (2, 2, (-0.2, -0.1, 0.0, 0.1, 0.2)), (1, 1, (1.0, -2.0, 1.0)))
+
+
+def mlpg_dense(mu, var, windows, pad):
+    """morgana/viz/synthesis.py:39-77, :156-171 for one feature dimension with explicit N x N window matrices."""
+    edge = lambda x: np.concatenate((np.repeat(x[[0]], pad, 0), x, np.repeat(x[[-1]], pad, 0)), 0)
+    mu, var = edge(np.asarray(mu, np.float64)), edge(np.asarray(var, np.float64))
+    n = mu.shape[0]
+    prec, b = np.zeros((n, n)), np.zeros(n)
+    for w, (l, u, c) in enumerate(windows):
+        win = np.zeros((n, n))
+        for s in range(n):
+            for k in range(-l, u + 1):
+                if 0 <= s + k < n:
+                    win[s, s + k] = c[l + k]
+        prec += win.T @ np.diag(1.0 / var[:, w]) @ win
+        b += win.T @ (mu[:, w] / var[:, w])
+    return np.linalg.solve(prec, b)[pad:n - pad]
+
+
+@pytest.mark.parametrize('windows,pad', [(ref_cpu.MLPG_DEFAULT_WINDOWS, 0), (ref_cpu.MLPG_DEFAULT_WINDOWS, 7), (WINDOWS_5PT, 4)])
+def test_mlpg_oracle_vs_dense_definition(windows, pad):
+    rng = np.random.RandomState(len(windows[1][2]) + pad)
+    b, t, d = 3, 26, 2
+    means = rng.standard_normal((b, t, 3 * d))
+    seq_len = [t, 11, 1]
+    for variances in (rng.uniform(0.3, 2.0, 3 * d), rng.uniform(0.3, 2.0, (b, t, 3 * d))):
+        got = ref_cpu.mlpg(means, variances, windows=windows, padding_size=pad, seq_len=seq_len)
+        assert got.shape == (b, t, d)
+        for i in range(b):
+            n = seq_len[i]
+            assert np.all(got[i, n:] == 0)
+            for k in range(d):
+                var = np.broadcast_to(variances[k::d], (n, 3)) if variances.ndim == 1 else variances[i, :n, k::d]
+                np.testing.assert_allclose(got[i, :n, k], mlpg_dense(means[i, :n, k::d], var, windows, pad), rtol=1e-10, atol=1e-12)
+
+
+def test_mlpg_oracle_known_answers():
+    rng = np.random.RandomState(5)
+    static = rng.standard_normal((1, 15, 1))
+    # a static window alone: the trajectory is the means
+    np.testing.assert_allclose(ref_cpu.mlpg(static, np.ones(1), windows=((0, 0, (1.0,)),)), static, rtol=1e-12)
+    # three zero-extent windows with gains a_w: per frame x = sum_w a_w mu_w / var_w / sum_w a_w^2 / var_w
+    means = rng.standard_normal((2, 15, 3))
+    var, gain = np.array([1.0, 0.5, 2.0]), np.array([1.0, -2.0, 0.5])
+    got = ref_cpu.mlpg(means, var, windows=tuple((0, 0, (a,)) for a in gain))
+    np.testing.assert_allclose(got[..., 0], (means * gain / var).sum(-1) / (gain ** 2 / var).sum(), rtol=1e-12)
+    # single sequence in, single sequence out
+    assert ref_cpu.mlpg(means[0], np.array([1.0, 0.5, 0.5])).shape == (15, 1)
