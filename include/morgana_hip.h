@@ -206,6 +206,24 @@ size_t mg_linear_wgrad_workspace_bytes(int64_t M, int N, int K);
 int mg_linear_wgrad_f32(const float* dY, const float* A, int lda, const int32_t* rows, int64_t M, int N, int K,
                         float* dW, float* db, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Phone-rate first layer (csrc/phone_rate.hip): Linear commutes with upsample_to_repetitions' row repetition (reference:
+ * morgana/utils.py:175-228 feeding README.rst:65-73 / morgana/utils.py:401-418), so the first layer's product runs once per
+ * phone and these three kernels move between phone rate and frame rate.
+ *  mg_segment_bounds  seg_start / seg_end int32 [R]: the run of frames f with rows[f] == r (0, 0 if none).  rows int32 [M] as
+ *                     mg_upsample_index writes them (b*P + phone, -1 = padding); the frames of a row must be consecutive.
+ *                     rows_mapped (optional, int32 [M]): rows with -1 replaced by pad_row (the table row of a zero input).
+ *  mg_expand_rows     H[f, :] = act(Z[rows[f], :] + bias) (Z row = 0 for rows[f] < 0); Z f32 [R, ldz]; H bf16 (h_bf16) or f32
+ *                     [M, ldh], columns N..ldh-1 zeroed; N, ldh multiples of 8.
+ *  mg_segment_sum     out[r, :] = sum of G[f, :] over the frames of row r (fp32 accumulation, frame order), r < R; rows
+ *                     R..R+extra-1 of out take the frames with rows[f] < 0 (those of the j-th of `extra` equal shares of the frame axis go to row R + j).  G, out bf16
+ *                     (g_bf16) or f32. */
+int mg_segment_bounds(const int32_t* rows, int64_t M, int R, int32_t* seg_start, int32_t* seg_end, int32_t* rows_mapped,
+                      int pad_row, void* stream);
+int mg_expand_rows(const float* Z, int ldz, const int32_t* rows, int64_t M, const float* bias, int N, int act, void* H, int ldh,
+                   int h_bf16, void* stream);
+int mg_segment_sum(const void* G, int ldg, int g_bf16, const int32_t* rows, int64_t M, const int32_t* seg_start,
+                   const int32_t* seg_end, int R, int extra, int N, void* out, int ldo, void* stream);
+
 /* bf16 variants: A, W, H, Y are bf16; K and N of the bf16 buffers are padded: lda/ldw/ldy multiples of 8 elements,
  * padding columns must be zero (mg_cast_pad_bf16 / mg_gather_rows_bf16 produce such buffers).  bias, dW, db f32. */
 /* Y is bf16 [M,ldy] (y_f32 == 0) or f32 [M,ldy] (y_f32 != 0); ldy a multiple of 8; columns N..ldy-1 are written as 0. */
@@ -214,6 +232,10 @@ int mg_linear_fwd_bf16(const uint16_t* A, int lda, const int32_t* rows, int64_t 
 /* WT = W^T as bf16 [K,N] (ldwt). */
 int mg_linear_dgrad_bf16(const uint16_t* dY, int lddy, int64_t M, int N, const uint16_t* WT, int ldwt, int K,
                          const uint16_t* H, int ldh, void* dX, int lddx, int dx_f32, void* stream);
+/* The same with H read from a table: frame m's sigmoid output is H[h_rows[m]] (phone-rate first layer; h_rows >= 0).  Needs the
+ * wide-tile shape (M >= 2048, K % 128 == 0, lddy and ldwt multiples of 64); MG_EINVAL otherwise. */
+int mg_linear_dgrad_gathered_bf16(const uint16_t* dY, int lddy, int64_t M, int N, const uint16_t* WT, int ldwt, int K,
+                                  const uint16_t* H, int ldh, const int32_t* h_rows, void* dX, int lddx, int dx_f32, void* stream);
 int mg_linear_wgrad_bf16(const uint16_t* dY, int lddy, const uint16_t* A, int lda, const int32_t* rows, int64_t M,
                          int N, int K, float* dW, float* db, int accumulate, void* workspace, size_t workspace_bytes,
                          void* stream);

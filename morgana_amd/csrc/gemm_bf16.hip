@@ -374,7 +374,8 @@ static bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 
 // large-tile kernels (gemm_bf16_big.hip)
 int mg_try_nt_big(const uint16_t* A, int lda, const int32_t* rows, int64_t M, int K, const uint16_t* Bm, int ldb, int N,
-                  const float* bias, const uint16_t* H, int ldh, void* C, int ldc, int c_f32, int epi, hipStream_t st);
+                  const float* bias, const uint16_t* H, int ldh, const int32_t* h_rows, void* C, int ldc, int c_f32, int epi,
+                  hipStream_t st);
 int mg_wgrad_big_plan(int64_t M, int N, int K, int lda, int lddy, int* S_out, int* m_chunk_out);
 int mg_launch_wgrad_big(const uint16_t* dY, int lddy, const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K,
                         int S, int m_chunk, float* slab, float* bslab, int64_t sstride, hipStream_t st);
@@ -390,7 +391,7 @@ int mg_linear_fwd_bf16(const uint16_t* A, int lda, const int32_t* rows, int64_t 
     MG_CHECK_ARG(act == MG_ACT_NONE || act == MG_ACT_SIGMOID, "mg_linear_fwd_bf16: unknown activation %d", act);
     if (M == 0) return MG_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (ldy == N && mg_try_nt_big(A, lda, rows, M, K, W, ldw, N, bias, nullptr, 0, Y, ldy, y_f32,
+    if (ldy == N && mg_try_nt_big(A, lda, rows, M, K, W, ldw, N, bias, nullptr, 0, nullptr, Y, ldy, y_f32,
                                   act == MG_ACT_SIGMOID ? EPI_BIAS_SIGMOID : EPI_BIAS, st) > 0) {
         MG_CHECK_LAUNCH("mg_linear_fwd_bf16/big");
         return MG_OK;
@@ -425,7 +426,7 @@ int mg_linear_dgrad_bf16(const uint16_t* dY, int lddy, int64_t M, int N, const u
     if (M == 0) return MG_OK;
     hipStream_t st = (hipStream_t)stream;
     // C[M,K] = dY[M,N] * WT[K,N]^T : the NT kernel with contraction N, output width K.
-    if (lddx == K && mg_try_nt_big(dY, lddy, nullptr, M, N, WT, ldwt, K, nullptr, H, ldh, dX, lddx, dx_f32,
+    if (lddx == K && mg_try_nt_big(dY, lddy, nullptr, M, N, WT, ldwt, K, nullptr, H, ldh, nullptr, dX, lddx, dx_f32,
                                    H ? EPI_SIGMOID_GRAD : EPI_BIAS, st) > 0) {
         MG_CHECK_LAUNCH("mg_linear_dgrad_bf16/big");
         return MG_OK;
@@ -447,6 +448,25 @@ int mg_linear_dgrad_bf16(const uint16_t* dY, int lddy, int64_t M, int N, const u
             hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128, 2, 2, EPI_BIAS>), dim3((unsigned)blocks), dim3(256), 0, st, dY, lddy, nullptr, M, WT, ldwt, K, nullptr, nullptr, 0, dX, lddx, tn, dx_f32);
     }
     MG_CHECK_LAUNCH("mg_linear_dgrad_bf16");
+    return MG_OK;
+}
+
+// dX = (dY W) * H[h_rows] (1 - H[h_rows]): mg_linear_dgrad_bf16 with the sigmoid outputs read from a TABLE (the phone-rate first
+// layer, csrc/phone_rate.hip: frame m's activation row is table row h_rows[m], >= 0).  Wide-tile kernel only.
+int mg_linear_dgrad_gathered_bf16(const uint16_t* dY, int lddy, int64_t M, int N, const uint16_t* WT, int ldwt, int K,
+                                  const uint16_t* H, int ldh, const int32_t* h_rows, void* dX, int lddx, int dx_f32, void* stream) {
+    MG_CHECK_ARG(dY && WT && dX && H && h_rows && M > 0 && N > 0 && K > 0, "mg_linear_dgrad_gathered_bf16: bad arguments (M=%lld N=%d K=%d)",
+                 (long long)M, N, K);
+    MG_CHECK_ARG(lddy >= N && ldwt >= N && lddx >= K && lddy % 8 == 0 && ldwt % 8 == 0 && lddx % 8 == 0 && ldh >= K && ldh % 8 == 0,
+                 "mg_linear_dgrad_gathered_bf16: leading dimensions must be multiples of 8 and cover N=%d / K=%d", N, K);
+    MG_CHECK_ARG(al16(dY) && al16(WT) && al16(dX) && al16(H), "mg_linear_dgrad_gathered_bf16: buffers must be 16-byte aligned");
+    if (!(lddx == K && mg_try_nt_big(dY, lddy, nullptr, M, N, WT, ldwt, K, nullptr, H, ldh, h_rows, dX, lddx, dx_f32, EPI_SIGMOID_GRAD,
+                                     (hipStream_t)stream) > 0)) {
+        mg_set_error("mg_linear_dgrad_gathered_bf16: shape outside the wide-tile kernel (M=%lld N=%d K=%d lddy=%d ldwt=%d)", (long long)M, N, K,
+                     lddy, ldwt);
+        return MG_EINVAL;
+    }
+    MG_CHECK_LAUNCH("mg_linear_dgrad_gathered_bf16");
     return MG_OK;
 }
 

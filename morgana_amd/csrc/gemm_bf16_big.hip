@@ -62,7 +62,8 @@ template <int BN, int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
                                                           int64_t M, int K, const uint16_t* __restrict__ Bm, int ldb, int N,
                                                           const float* __restrict__ bias, const uint16_t* __restrict__ H, int ldh,
-                                                          void* __restrict__ Cv, int ldc, int tiles_m, int tiles_n, int c_f32) {
+                                                          const int32_t* __restrict__ h_rows, void* __restrict__ Cv, int ldc, int tiles_m,
+                                                          int tiles_n, int c_f32) {
     constexpr int BM = 256;
     constexpr int WAVES_N = BN / 64;              // 4 or 2
     constexpr int WAVES_M = 8 / WAVES_N;          // 2 or 4
@@ -227,7 +228,9 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __rest
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(&stg[rl * STG_LD + cl]);
                 const f32x4 v1 = *reinterpret_cast<const f32x4*>(&stg[rl * STG_LD + cl + 4]);
                 if (row >= M) continue;
-                const bfv8 hv = *reinterpret_cast<const bfv8*>(H + (size_t)row * ldh + col);
+                // H row: the output row itself, or (phone-rate first layer) the table row its frame was gathered from
+                const int64_t hrow = h_rows ? (int64_t)h_rows[row] : row;
+                const bfv8 hv = *reinterpret_cast<const bfv8*>(H + (size_t)hrow * ldh + col);
                 float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -841,7 +844,8 @@ __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restri
 static bool big16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 
 int mg_try_nt_big(const uint16_t* A, int lda, const int32_t* rows, int64_t M, int K, const uint16_t* Bm, int ldb, int N,
-                  const float* bias, const uint16_t* H, int ldh, void* C, int ldc, int c_f32, int epi, hipStream_t st) {
+                  const float* bias, const uint16_t* H, int ldh, const int32_t* h_rows, void* C, int ldc, int c_f32, int epi,
+                  hipStream_t st) {
     if (M < 2048 || lda % 64 != 0 || ldb % 64 != 0 || lda > MG_ZERO_ELEMS - 64 || ldb > MG_ZERO_ELEMS - 64) return 0;
     if (N % 128 != 0 || ldc < N || ldc % 8 != 0 || !big16(A) || !big16(Bm) || !big16(C)) return 0;
     if (epi == EPI_SIGMOID_GRAD && (!H || ldh % 8 != 0 || ldh < N)) return 0;
@@ -870,7 +874,7 @@ int mg_try_nt_big(const uint16_t* A, int lda, const int32_t* rows, int64_t M, in
         return 1;
     }
     dim3 grid((unsigned)blocks), block(512);
-#define LAUNCH_NT(BN_, EPI_) hipLaunchKernelGGL((gemm_nt_big_kernel<BN_, EPI_>), grid, block, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, H, ldh, C, ldc, (int)tiles_m, tiles_n, c_f32)
+#define LAUNCH_NT(BN_, EPI_) hipLaunchKernelGGL((gemm_nt_big_kernel<BN_, EPI_>), grid, block, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, H, ldh, h_rows, C, ldc, (int)tiles_m, tiles_n, c_f32)
     if (wide) {
         if (epi == EPI_BIAS) LAUNCH_NT(256, EPI_BIAS);
         else if (epi == EPI_BIAS_SIGMOID) LAUNCH_NT(256, EPI_BIAS_SIGMOID);

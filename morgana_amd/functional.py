@@ -84,23 +84,37 @@ class LinearStackFn(torch.autograd.Function):
         if x2d.shape[1] != (ops.pad_ld(k_in) if pre_cast else k_in):
             raise ValueError('Linear expects %d input features, got %d' % (k_in, x2d.shape[1]))
         hidden = []
+        # phone-rate first layer (csrc/phone_rate.hip): the product once per table row, then a gather of the result
+        n_table = x2d.shape[0]
+        phone_rate = (rows is not None and not pre_cast and n_layers > 1
+                      and ops.phone_rate_ok(n_table, m, weights[0].shape[0], acts[0]))
+        ctx.phone_rate = phone_rate
+        seg = ops.segment_bounds(rows, n_table) if phone_rate else None
         if precision == 'fp32':
             a, r = x2d, rows
             for i in range(n_layers):
                 w = ops._require(weights[i], torch.float32, 'weight')
-                a = ops.linear_fwd_f32(a, r, m, w, biases[i], acts[i])
+                if i == 0 and phone_rate:
+                    z = ops.linear_fwd_f32(a, None, n_table, w, None, ops.ACT_NONE)
+                    a = ops.expand_rows(z, rows, biases[0], w.shape[0], acts[0], bf16=False)
+                else:
+                    a = ops.linear_fwd_f32(a, r, m, w, biases[i], acts[i])
                 r = None
                 hidden.append(a)
             out = a
             ctx.save_for_backward(x2d, rows, *weights, *hidden)
         else:
-            a = x2d if pre_cast else ops.cast_pad_bf16(x2d)
+            a = x2d if pre_cast else ops.cast_pad_bf16(x2d, extra_rows=ops.PHONE_RATE_EXTRA if phone_rate else 0)
             a0, r = a, rows
             for i in range(n_layers):
                 n, k = weights[i].shape
                 w_bf = ops.cast_pad_bf16(ops._require(weights[i], torch.float32, 'weight'))
                 last = i == n_layers - 1
-                a = ops.linear_fwd_bf16(a, r, m, k, w_bf, biases[i], n, acts[i], out_f32=last)
+                if i == 0 and phone_rate:
+                    z = ops.linear_fwd_bf16(a, None, n_table, k, w_bf, None, n, ops.ACT_NONE, out_f32=True)
+                    a = ops.expand_rows(z, rows, biases[0], n, acts[0], bf16=True)
+                else:
+                    a = ops.linear_fwd_bf16(a, r, m, k, w_bf, biases[i], n, acts[i], out_f32=last)
                 r = None
                 hidden.append(a)
             n_last = weights[-1].shape[0]
@@ -109,6 +123,7 @@ class LinearStackFn(torch.autograd.Function):
                 out = out[:, :n_last].contiguous()
                 # keep the padded fp32 activation only if a trailing sigmoid needs it in backward
             ctx.save_for_backward(a0, rows, *weights, *hidden[:-1], out)
+        ctx.seg = seg
         return out
 
     @staticmethod
@@ -130,7 +145,14 @@ class LinearStackFn(torch.autograd.Function):
             for i in range(n_layers - 1, -1, -1):
                 n, k = ctx.dims[i]
                 a_in, r = (x_in, rows) if i == 0 else (hidden[i - 1], None)
-                dw, db = ops.linear_wgrad_f32(g, a_in, r, n, k, want_bias=ctx.has_bias[i])
+                if i == 0 and ctx.phone_rate:
+                    n_table = x_in.shape[0]
+                    g_rows = ops.segment_sum(g, rows, ctx.seg, n_table, n)
+                    dw, db = ops.linear_wgrad_f32(g_rows[:n_table], x_in, None, n, k, want_bias=ctx.has_bias[i])
+                    if db is not None:
+                        db += g_rows[n_table:].sum(0)          # gradients of padding frames (their input row is zero)
+                else:
+                    dw, db = ops.linear_wgrad_f32(g, a_in, r, n, k, want_bias=ctx.has_bias[i])
                 grads[2 * i], grads[2 * i + 1] = dw, db
                 if i > 0:
                     h = hidden[i - 1] if acts[i - 1] == ops.ACT_SIGMOID else None
@@ -142,7 +164,12 @@ class LinearStackFn(torch.autograd.Function):
             for i in range(n_layers - 1, -1, -1):
                 n, k = ctx.dims[i]
                 a_in, r = (x_in, rows) if i == 0 else (hidden[i - 1], None)
-                dw, db = ops.linear_wgrad_bf16(g, a_in, r, m, n, k, want_bias=ctx.has_bias[i])
+                if i == 0 and ctx.phone_rate:
+                    n_table = x_in.shape[0] - ops.PHONE_RATE_EXTRA
+                    g_rows = ops.segment_sum(g, rows, ctx.seg, n_table, n)
+                    dw, db = ops.linear_wgrad_bf16(g_rows, x_in, None, g_rows.shape[0], n, k, want_bias=ctx.has_bias[i])
+                else:
+                    dw, db = ops.linear_wgrad_bf16(g, a_in, r, m, n, k, want_bias=ctx.has_bias[i])
                 grads[2 * i], grads[2 * i + 1] = dw, db
                 if i > 0:
                     wt = ops.cast_transpose_bf16(weights[i])
@@ -216,13 +243,25 @@ class LinearStackMSEFn(torch.autograd.Function):
                 rows.numel() if rows is not None else x2d.shape[0], m))
         lead = n_layers - 2
         w_bf, w_t = ops.cast_params_bf16(weights[:lead], want_t=tuple(range(1, lead)))
-        a = ops.cast_pad_bf16(x2d)
+        # phone-rate first layer, table form (csrc/phone_rate.hip): H1 = sigmoid(X W0^T + b0) is computed once per phone (the
+        # extra zero rows behind the table give sigmoid(b0), the activation of padding frames) and layer 2 gathers its rows
+        n_table = x2d.shape[0]
+        phone_rate = (rows is not None and lead == 2
+                      and ops.phone_rate_table_ok(n_table, m, weights[0].shape[0], weights[1].shape[0], acts[0]))
+        ctx.phone_rate = phone_rate
+        ctx.seg = None
+        if phone_rate:
+            ctx.seg, rows = ops.segment_bounds(rows, n_table, pad_row=n_table)
+        a = ops.cast_pad_bf16(x2d, extra_rows=ops.PHONE_RATE_EXTRA if phone_rate else 0)
         a0, r = a, rows
         hidden = []
         for i in range(lead):
             n, k = weights[i].shape
-            a = ops.linear_fwd_bf16(a, r, m, k, w_bf[i], biases[i], n, acts[i])
-            r = None
+            if i == 0 and phone_rate:
+                a = ops.linear_fwd_bf16(a, None, a.shape[0], k, w_bf[0], biases[0], n, acts[0])     # (R + extra, n0) table
+            else:
+                a = ops.linear_fwd_bf16(a, r, m, k, w_bf[i], biases[i], n, acts[i])
+                r = None
             hidden.append(a)
         sizes = [p.numel() for p in params]
         offsets = [0]
@@ -252,17 +291,27 @@ class LinearStackMSEFn(torch.autograd.Function):
         for i in range(lead - 1, -1, -1):
             n, k = ctx.dims[i]
             a_in, r = (a0, rows) if i == 0 else (hidden[i - 1], None)
+            if i == 1 and ctx.phone_rate:
+                r = rows                                      # hidden[0] is the per-phone table: gather its rows
             ow = flat[ctx.offsets[2 * i]:ctx.offsets[2 * i] + n * k].view(n, k)
             ob = flat[ctx.offsets[2 * i + 1]:ctx.offsets[2 * i + 1] + n]
+            if i == 0 and ctx.phone_rate:
+                # dW_0 = (per-phone sums of dZ_0)^T X_phone; the extra rows carry the padding frames into db_0
+                g_rows = ops.segment_sum(g, rows, ctx.seg, a0.shape[0] - ops.PHONE_RATE_EXTRA, n)
+                ops.linear_wgrad_bf16(g_rows, a0, None, g_rows.shape[0], n, k, out_w=ow, out_b=ob)
+                break
             ops.linear_wgrad_bf16(g, a_in, r, m, n, k, out_w=ow, out_b=ob)
-            if i == 1 and ctx.acts[0] == ops.ACT_SIGMOID and ops.can_fuse_bwd(m, n, k, ctx.dims[0][1], a0.shape[1]):
+            if (i == 1 and not ctx.phone_rate and ctx.acts[0] == ops.ACT_SIGMOID
+                    and ops.can_fuse_bwd(m, n, k, ctx.dims[0][1], a0.shape[1])):
                 # layer 0's dW, db straight from this layer's dZ: dZ_0 = (dZ_1 W_1) * H_0 (1 - H_0) stays on chip
                 n0_, k0_ = ctx.dims[0]
                 ops.linear_bwd_fused_bf16(g, w_t[1], hidden[0], a0, rows, m, n0_, k0_,
                                           out_w=flat[ctx.offsets[0]:ctx.offsets[0] + n0_ * k0_].view(n0_, k0_),
                                           out_b=flat[ctx.offsets[1]:ctx.offsets[1] + n0_])
                 break
-            if i > 0:
+            if i == 1 and ctx.phone_rate:
+                g = ops.linear_dgrad_gathered_bf16(g, m, n, w_t[1], k, hidden[0], rows)
+            elif i > 0:
                 h = hidden[i - 1] if ctx.acts[i - 1] == ops.ACT_SIGMOID else None
                 g = ops.linear_dgrad_bf16(g, m, n, w_t[i], k, h)
         grads = _deliver_param_grads(ctx.params, flat[:flat.numel() - 1], ctx.offsets, grad_loss)

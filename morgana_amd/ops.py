@@ -283,11 +283,14 @@ def linear_wgrad_f32(dy, a, rows, n, k, want_bias=True):
     return dw, db
 
 
-def cast_pad_bf16(x2d, ld=None):
+def cast_pad_bf16(x2d, ld=None, extra_rows=0):
+    """(rows, cols) f32 -> (rows + extra_rows, ld) bf16, padding columns and the extra rows zero."""
     lib = _lib.load()
     rows, cols = x2d.shape
     ld = pad8(cols) if ld is None else ld
-    out = torch.empty((rows, ld), dtype=torch.bfloat16, device=x2d.device)
+    out = torch.empty((rows + extra_rows, ld), dtype=torch.bfloat16, device=x2d.device)
+    if extra_rows:
+        out[rows:].zero_()
     _lib.check(lib.mg_cast_pad_bf16(_p(x2d), x2d.shape[1], _p(out), ld, rows, cols, _stream()), 'mg_cast_pad_bf16')
     return out
 
@@ -790,4 +793,64 @@ def mlpg(means, variances, windows, padding_size=0, seq_len=None, out_dtype=torc
     ws = torch.empty(nbytes, dtype=torch.uint8, device=means.device)
     _lib.check(lib.mg_mlpg_f32(_p(means), _p(variances), per_frame, _p(seq_len), b, t, d, n_win, win_l, win_u, win_c, int(padding_size),
                                _p(out), int(out_dtype == torch.float64), _p(ws), ws.numel(), _stream()), 'mg_mlpg_f32')
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- phone-rate first layer
+PHONE_RATE = os.environ.get('MORGANA_PHONE_RATE', '1') != '0'
+PHONE_RATE_EXTRA = 1024          # rows behind the table that collect the gradients of padding frames (for the bias gradient)
+
+
+def phone_rate_ok(n_table_rows, m, n, act):
+    """First layer on a gathered table: run the product once per table row when there are fewer table rows than frames."""
+    return PHONE_RATE and n % 8 == 0 and n_table_rows < m and act in (ACT_NONE, ACT_SIGMOID)
+
+
+def segment_bounds(rows, n_table_rows, pad_row=None):
+    """(2, R) int32 frame runs per table row; with ``pad_row`` also the map with -1 replaced by that row (returned second)."""
+    lib = _lib.load()
+    rows = _require(rows, torch.int32, 'rows')
+    seg = torch.empty((2, n_table_rows), dtype=torch.int32, device=rows.device)
+    mapped = torch.empty_like(rows) if pad_row is not None else None
+    _lib.check(lib.mg_segment_bounds(_p(rows), rows.numel(), n_table_rows, _p(seg[0]), _p(seg[1]), _p(mapped),
+                                     -1 if pad_row is None else int(pad_row), _stream()), 'mg_segment_bounds')
+    return seg if pad_row is None else (seg, mapped)
+
+
+def phone_rate_table_ok(n_table_rows, m, n0, n1, act):
+    """The table form of the phone-rate first layer (bf16 mode): sigmoid(X_phone W0^T + b0) is kept per phone and the second
+    layer's GEMMs gather its rows, so the frame-rate activation never exists.  Needs the wide-tile kernels' shapes."""
+    return (PHONE_RATE and act == ACT_SIGMOID and n_table_rows < m and m >= 4096 and n_table_rows >= 2048
+            and n0 % 128 == 0 and 384 < n0 <= 512 and pad8(n1) % 64 == 0)
+
+
+def linear_dgrad_gathered_bf16(dy, m, n, wt_bf16, k, h_table, h_rows):
+    """linear_dgrad_bf16 with the sigmoid outputs read from the per-phone table: dx[f] = (dy[f] W) h (1 - h), h = h_table[h_rows[f]]."""
+    lib = _lib.load()
+    dx = torch.empty((m, pad8(k)), dtype=torch.bfloat16, device=dy.device)
+    _lib.check(lib.mg_linear_dgrad_gathered_bf16(_p(dy), dy.shape[1], m, n, _p(wt_bf16), wt_bf16.shape[1], k, _p(h_table),
+                                                 h_table.shape[1], _p(h_rows), _p(dx), dx.shape[1], 0, _stream()),
+               'mg_linear_dgrad_gathered_bf16')
+    return dx
+
+
+def expand_rows(z, rows, bias, n, act, bf16):
+    """H[f] = act(z[rows[f]] + bias): (m, pad8(n)) bf16 or (m, n) f32 from the (R, ldz) f32 table (csrc/phone_rate.hip)."""
+    lib = _lib.load()
+    z = _require(z, torch.float32, 'table')
+    m = rows.numel()
+    ldh = pad8(n) if bf16 else n
+    h = torch.empty((m, ldh), dtype=torch.bfloat16 if bf16 else torch.float32, device=z.device)
+    _lib.check(lib.mg_expand_rows(_p(z), z.shape[1], _p(rows), m, _p(bias), n, act, _p(h), ldh, int(bf16), _stream()), 'mg_expand_rows')
+    return h
+
+
+def segment_sum(g, rows, seg, n_table_rows, n, extra=PHONE_RATE_EXTRA):
+    """(R + extra, ld) sums of the frame-rate rows of g per table row; the extra rows take the frames with row -1."""
+    lib = _lib.load()
+    bf16 = g.dtype == torch.bfloat16
+    g = _require(g, torch.bfloat16 if bf16 else torch.float32, 'gradient')
+    out = torch.empty((n_table_rows + extra, g.shape[1]), dtype=g.dtype, device=g.device)
+    _lib.check(lib.mg_segment_sum(_p(g), g.shape[1], int(bf16), _p(rows), rows.numel(), _p(seg[0]), _p(seg[1]), n_table_rows, extra, n,
+                                  _p(out), out.shape[1], _stream()), 'mg_segment_sum')
     return out

@@ -1456,3 +1456,83 @@ def test_gru_f0_model_generation_and_metric():
     with pytest.raises(ValueError, match='No collection'):               # mode unset, as in the reference outside its builder
         model.mode = ''
         model(feats)
+
+
+# ------------------------------------------------------------------------------------------ phone-rate first layer
+def _ragged_rows(rng, b, p, t):
+    """Frame -> table-row map as mg_upsample_index writes it: utterance i's phones repeated dur times, -1 past its end."""
+    rows = np.full((b, t), -1, np.int32)
+    for i in range(b):
+        dur = rng.randint(0, 5, size=p)
+        dur[rng.randint(p)] += 3
+        idx = np.repeat(np.arange(p), dur)[:t]
+        rows[i, :len(idx)] = i * p + idx
+    return rows
+
+
+@pytest.mark.parametrize('bf16', [True, False])
+def test_phone_rate_kernels_vs_numpy(bf16):
+    """mg_segment_bounds / mg_expand_rows / mg_segment_sum (csrc/phone_rate.hip) against numpy on a ragged map with empty phones
+    and padding frames: bounds exact; expand = act(table[row] + bias) to 1e-6 (fp32) / one bf16 rounding; segment sums of bf16 /
+    fp32 frame rows in fp32, padding frames collected in the extra rows (their total checked)."""
+    from morgana_amd import ops
+    rng = np.random.RandomState(41 + bf16)
+    b, p, t, n = 7, 9, 40, 72
+    rows = _ragged_rows(rng, b, p, t)
+    flat = rows.reshape(-1)
+    r_tab = b * p
+    seg = ops.segment_bounds(dev(flat), r_tab).cpu().numpy()
+    for r in range(r_tab):
+        where = np.nonzero(flat == r)[0]
+        want = (where[0], where[-1] + 1) if len(where) else (0, 0)
+        assert (seg[0, r], seg[1, r]) == want
+    table = rng.standard_normal((r_tab, n)).astype(np.float32)
+    bias = rng.standard_normal(n).astype(np.float32)
+    want = np.where(flat[:, None] >= 0, table[np.maximum(flat, 0)], 0.0) + bias
+    want_sig = 1.0 / (1.0 + np.exp(-want.astype(np.float64)))
+    for act, ref in ((ops.ACT_NONE, want), (ops.ACT_SIGMOID, want_sig)):
+        got = ops.expand_rows(dev(table), dev(flat), dev(bias), n, act, bf16=bf16)
+        got = got.float().cpu().numpy()[:, :n]
+        np.testing.assert_allclose(got, ref, rtol=2 ** -8 if bf16 else 1e-6, atol=1e-6)
+    grad = rng.standard_normal((b * t, n)).astype(np.float32)
+    g_dev = dev(grad).to(torch.bfloat16) if bf16 else dev(grad)
+    grad = g_dev.float().cpu().numpy()
+    extra = 5
+    sums = ops.segment_sum(g_dev, dev(flat), dev(seg), r_tab, n, extra=extra).float().cpu().numpy()
+    assert sums.shape == (r_tab + extra, n)
+    want_rows = np.stack([grad[flat == r].sum(0) for r in range(r_tab)])
+    np.testing.assert_allclose(sums[:r_tab], want_rows, rtol=2 ** -7 if bf16 else 1e-5, atol=1e-5)
+    np.testing.assert_allclose(sums[r_tab:].sum(0), grad[flat < 0].sum(0), rtol=0, atol=(0.15 if bf16 else 1e-4))
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp32'])
+def test_phone_rate_first_layer_equals_frame_rate(precision):
+    """The F0Model step with the first Linear run once per phone (gather(X) W^T = gather(X W^T)) against the same step with the
+    frame-rate gather-fused GEMMs: the prediction and the loss are EQUAL in bf16 mode (same fp32 dot product, bias add and sigmoid
+    per frame row) and within 1e-6 in fp32 mode; every gradient agrees to the mode's tolerance (the per-phone sums regroup the same
+    frame gradients; in bf16 mode the sums are rounded to bf16 once more before the weight-gradient GEMM)."""
+    from morgana_amd import ops
+    feats = data.to_device(synthetic.make_batch(24, (150, 400), seed=5), DEV)
+
+    def run(phone_rate):
+        old = ops.PHONE_RATE
+        ops.PHONE_RATE = phone_rate
+        try:
+            model = _load_state(models.F0Model(precision=precision).to(DEV), synthetic.f0_model_state())
+            loss, out = model(feats)
+            loss.backward()
+            return loss.item(), out['pred_norm_lf0'].detach().cpu().numpy(), {k: v.grad.cpu().numpy() for k, v in model.named_parameters()}
+        finally:
+            ops.PHONE_RATE = old
+
+    loss_p, pred_p, grads_p = run(True)
+    loss_f, pred_f, grads_f = run(False)
+    if precision == 'bf16':
+        assert loss_p == loss_f
+        np.testing.assert_array_equal(pred_p, pred_f)
+    else:
+        np.testing.assert_allclose(loss_p, loss_f, rtol=1e-6)
+        np.testing.assert_allclose(pred_p, pred_f, rtol=1e-4, atol=1e-6)
+    for name in grads_f:
+        tol = 2e-2 if precision == 'bf16' else 1e-4
+        assert rel_err(grads_p[name], grads_f[name]) < tol, name
