@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument('--frames', type=int, default=1000)
     ap.add_argument('--no-generate', action='store_true',
                     help='lstm / f0gru: leave out the MLPG + metrics part of the step (the reference runs it inside predict / loss)')
+    ap.add_argument('--no-graph', action='store_true',
+                    help='c2: launch every kernel of the step from Python instead of replaying the captured HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     return ap.parse_args()
@@ -325,6 +327,18 @@ def main():
         optimizer.step()
         return loss
 
+    # The F0Model step's kernels sum to ~0.3 ms, less than the Python / autograd / launch path around them: replay the step as a
+    # HIP graph (same kernels, same buffers; morgana_amd/graphs.py).  The longer recurrent steps gain nothing from it.
+    graph_note = None
+    if args.config == 'c2' and not args.no_graph:
+        try:
+            from morgana_amd import graphs
+            step = graphs.GraphedTrainStep(model, optimizer, features)
+            graph_note = 'hip graph replay (%s)' % ('forward+backward graph, eager all-reduce, update graph' if world > 1
+                                                    else 'one graph per step')
+        except Exception as exc:                      # capture refused: time the eager loop and say so
+            graph_note = 'eager launches (graph capture failed: %s)' % str(exc).splitlines()[0][:200]
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         loss = step()
     torch.cuda.synchronize()
@@ -364,6 +378,8 @@ def main():
                        'parallelism': 'dp%d' % n_gpus},
             'final_loss': round(final_loss, 6),
         }
+        if graph_note is not None:
+            result['config']['launch'] = graph_note
         if args.config == 'c2':
             step_tflops = F0_FLOPS_PER_FRAME * frames_per_step / (ms_per_step * 1e-3) / 1e12
             peak = MFMA_BF16_PEAK_TFLOPS if args.precision == 'bf16' else MFMA_F32_PEAK_TFLOPS

@@ -465,6 +465,12 @@ int mg_lstm_stack_bwd_f32(const mg_lstm_bwd_layer* layers, int n_layers, const i
 int mg_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                      float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
                      void* stream);
+/* The same step with its two step-dependent scalars read from DEVICE memory (scalars[0] = lr / (1 - beta1^step),
+ * scalars[1] = sqrt(1 - beta2^step); mg_adam_scalars forms them on the host exactly as mg_adam_step_f32 does): the launch can be
+ * captured in a hipGraph and replayed for every step with only those 8 bytes rewritten. */
+void mg_adam_scalars(float lr, float beta1, float beta2, int64_t step, float* out2);
+int mg_adam_step_dev_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1,
+                         float beta2, float eps, float weight_decay, const float* scalars, float grad_scale, void* stream);
 /* shadow -= (1 - decay) * (shadow - param). */
 int mg_ema_update_f32(float* shadow, const float* param, int64_t n, float decay, void* stream);
 

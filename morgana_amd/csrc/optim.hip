@@ -24,6 +24,28 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ param, co
     }
 }
 
+// The same update with (step_size, bc2_sqrt) read from device memory: a captured launch (hipGraph replay of the whole training step,
+// morgana_amd/graphs.py) must not bake the step-dependent scalars into its arguments.
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ param, const float* __restrict__ grad,
+                                                       float* __restrict__ m, float* __restrict__ v, int64_t n, float beta1,
+                                                       float beta2, float eps, float weight_decay,
+                                                       const float* __restrict__ scalars, float grad_scale) {
+    const float step_size = scalars[0], bc2_sqrt = scalars[1];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float p = param[i];
+        float g = grad[i] * grad_scale;
+        if (weight_decay != 0.f) g = g + weight_decay * p;
+        float mi = m[i];
+        mi = mi + (g - mi) * (1.f - beta1);
+        float vi = v[i] * beta2 + (1.f - beta2) * g * g;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p = p - step_size * (mi / denom);
+        param[i] = p;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ shadow, const float* __restrict__ param, int64_t n, float one_minus_decay) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float s = shadow[i];
@@ -164,6 +186,24 @@ int mg_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp
     hipLaunchKernelGGL(adam_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
                        beta1, beta2, eps, weight_decay, step_size, bc2_sqrt, grad_scale);
     MG_CHECK_LAUNCH("mg_adam_step_f32");
+    return MG_OK;
+}
+
+// (step_size, bc2_sqrt) of step `step` exactly as mg_adam_step_f32 forms them (host doubles), for mg_adam_step_dev_f32
+void mg_adam_scalars(float lr, float beta1, float beta2, int64_t step, float* out2) {
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    out2[0] = (float)((double)lr / bc1);
+    out2[1] = (float)sqrt(bc2);
+}
+
+int mg_adam_step_dev_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1, float beta2,
+                         float eps, float weight_decay, const float* scalars, float grad_scale, void* stream) {
+    MG_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && scalars && n >= 0, "mg_adam_step_dev_f32: bad arguments (n=%lld)", (long long)n);
+    if (n == 0) return MG_OK;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
+                       beta1, beta2, eps, weight_decay, scalars, grad_scale);
+    MG_CHECK_LAUNCH("mg_adam_step_dev_f32");
     return MG_OK;
 }
 

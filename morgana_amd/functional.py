@@ -288,30 +288,38 @@ class LinearStackMSEFn(torch.autograd.Function):
         lead, m = ctx.lead, ctx.m
         hidden = list(saved[4:4 + lead - 1])                  # outputs of layers 0 .. lead-2
         w_t = [None] + list(saved[4 + lead - 1:])             # transposed bf16 weights of layers 1 .. lead-1
+        def grad_slots(i):
+            n_, k_ = ctx.dims[i]
+            return (flat[ctx.offsets[2 * i]:ctx.offsets[2 * i] + n_ * k_].view(n_, k_),
+                    flat[ctx.offsets[2 * i + 1]:ctx.offsets[2 * i + 1] + n_])
+
+        if ctx.phone_rate:
+            # Layer 0's activation is constant over the frames of a phone, so below dZ_1 everything runs at phone rate:
+            #   S = per-phone sums of dZ_1 (csrc/phone_rate.hip; padding frames -> the extra rows, whose table rows are sigmoid(b_0))
+            #   dW_1 = S^T H_table,   dZ_0(phone) = (S W_1) * H_table (1 - H_table),   dW_0 = dZ_0(phone)^T X_phone
+            (n1, k1), (n0, k0) = ctx.dims[1], ctx.dims[0]
+            table = hidden[0]
+            sums = ops.segment_sum(g, rows, ctx.seg, table.shape[0] - ops.PHONE_RATE_EXTRA, n1)
+            ow, ob = grad_slots(1)
+            ops.linear_wgrad_bf16(sums, table, None, table.shape[0], n1, k1, out_w=ow, out_b=ob)
+            dz0 = ops.linear_dgrad_bf16(sums, table.shape[0], n1, w_t[1], k1, table)
+            ow, ob = grad_slots(0)
+            ops.linear_wgrad_bf16(dz0, a0, None, table.shape[0], n0, k0, out_w=ow, out_b=ob)
+            grads = _deliver_param_grads(ctx.params, flat[:flat.numel() - 1], ctx.offsets, grad_loss)
+            return (None, None, None, None, None) + tuple(grads)
         for i in range(lead - 1, -1, -1):
             n, k = ctx.dims[i]
             a_in, r = (a0, rows) if i == 0 else (hidden[i - 1], None)
-            if i == 1 and ctx.phone_rate:
-                r = rows                                      # hidden[0] is the per-phone table: gather its rows
-            ow = flat[ctx.offsets[2 * i]:ctx.offsets[2 * i] + n * k].view(n, k)
-            ob = flat[ctx.offsets[2 * i + 1]:ctx.offsets[2 * i + 1] + n]
-            if i == 0 and ctx.phone_rate:
-                # dW_0 = (per-phone sums of dZ_0)^T X_phone; the extra rows carry the padding frames into db_0
-                g_rows = ops.segment_sum(g, rows, ctx.seg, a0.shape[0] - ops.PHONE_RATE_EXTRA, n)
-                ops.linear_wgrad_bf16(g_rows, a0, None, g_rows.shape[0], n, k, out_w=ow, out_b=ob)
-                break
+            ow, ob = grad_slots(i)
             ops.linear_wgrad_bf16(g, a_in, r, m, n, k, out_w=ow, out_b=ob)
-            if (i == 1 and not ctx.phone_rate and ctx.acts[0] == ops.ACT_SIGMOID
-                    and ops.can_fuse_bwd(m, n, k, ctx.dims[0][1], a0.shape[1])):
+            if i == 1 and ctx.acts[0] == ops.ACT_SIGMOID and ops.can_fuse_bwd(m, n, k, ctx.dims[0][1], a0.shape[1]):
                 # layer 0's dW, db straight from this layer's dZ: dZ_0 = (dZ_1 W_1) * H_0 (1 - H_0) stays on chip
                 n0_, k0_ = ctx.dims[0]
                 ops.linear_bwd_fused_bf16(g, w_t[1], hidden[0], a0, rows, m, n0_, k0_,
                                           out_w=flat[ctx.offsets[0]:ctx.offsets[0] + n0_ * k0_].view(n0_, k0_),
                                           out_b=flat[ctx.offsets[1]:ctx.offsets[1] + n0_])
                 break
-            if i == 1 and ctx.phone_rate:
-                g = ops.linear_dgrad_gathered_bf16(g, m, n, w_t[1], k, hidden[0], rows)
-            elif i > 0:
+            if i > 0:
                 h = hidden[i - 1] if ctx.acts[i - 1] == ops.ACT_SIGMOID else None
                 g = ops.linear_dgrad_bf16(g, m, n, w_t[i], k, h)
         grads = _deliver_param_grads(ctx.params, flat[:flat.numel() - 1], ctx.offsets, grad_loss)

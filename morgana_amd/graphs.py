@@ -1,0 +1,71 @@
+"""HIP-graph replay of the training step.
+
+The reference's loop body (``experiment_builder.py:468-474``: ``zero_grad``, ``model(features)``, ``backward``, ``optimizer.step``)
+is ~35 kernel launches in this package; once the kernels of the README F0Model step sum to 0.3 ms the Python / autograd / launch
+path around them (0.5 ms per step) is what bounds the step.  ``GraphedTrainStep`` captures the step once into HIP graphs
+(``torch.cuda.CUDAGraph`` = hipGraph on ROCm) and replays it: the same kernels on the same buffers, one launch from the host.
+
+What makes the step capturable: every kernel of the path is launched on torch's current stream with no host synchronisation,
+scratch comes from torch's allocator (graph-private pool during capture), and the only step-dependent scalars - Adam's bias
+corrections - are read from device memory (``optim.Adam.advance`` / ``step_captured``, ``mg_adam_step_dev_f32``).  With more than
+one rank the gradient all-reduce stays OUTSIDE the graphs (forward + backward graph, eager RCCL all-reduce, update graph).
+
+The captured step works on fixed buffers: ``features`` must be the same device tensors for every replay (copy a new batch into
+them with ``load``; shapes must not change).  Metrics accumulated inside ``loss`` keep accumulating - their accumulators are device
+tensors.  The learning rate may change between replays (it enters through ``advance``).
+"""
+import torch
+
+from . import functional
+
+
+class GraphedTrainStep(object):
+    def __init__(self, model, optimizer, features, warmup=3):
+        self.model, self.optimizer, self.features = model, optimizer, features
+        self.loss = None
+        self.output = None
+        self._multi = optimizer._world() > 1
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                    # allocator and workspace warm-up, off the capture
+                self._eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._fwd_bwd = torch.cuda.CUDAGraph()
+        self.optimizer.prepare_capture()               # capture records the launches, it does not run them
+        with torch.cuda.graph(self._fwd_bwd):
+            self.optimizer.zero_grad()
+            self.loss, self.output = self.model(self.features)
+            functional.backward(self.loss)
+            if not self._multi:
+                self.optimizer.step_captured()
+        self._update = None
+        if self._multi:
+            self.optimizer.exchange_gradients()
+            self._update = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._update, pool=self._fwd_bwd.pool()):
+                self.optimizer.step_captured()
+        self.steps_done = warmup
+
+    def _eager_step(self):
+        self.optimizer.zero_grad()
+        loss, _ = self.model(self.features)
+        functional.backward(loss)
+        self.optimizer.step()
+
+    def load(self, features):
+        """Copy a new batch (same keys, shapes and dtypes) into the captured buffers."""
+        for key, value in features.items():
+            if isinstance(value, torch.Tensor):
+                self.features[key].copy_(value, non_blocking=True)
+
+    def __call__(self):
+        """One training step; returns the (device, 0-d) loss tensor of the captured step - valid until the next call."""
+        self.optimizer.advance()
+        self._fwd_bwd.replay()
+        if self._update is not None:
+            self.optimizer.exchange_gradients()
+            self._update.replay()
+        self.steps_done += 1
+        return self.loss

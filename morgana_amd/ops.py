@@ -719,6 +719,21 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, betas, eps, weight_decay, st
                                     float(grad_scale), _stream()), 'mg_adam_step_f32')
 
 
+def adam_scalars(lr, betas, step):
+    """(step_size, bc2_sqrt) of one Adam step as two float32, formed as mg_adam_step_f32 forms them."""
+    out = (ctypes.c_float * 2)()
+    _lib.load().mg_adam_scalars(float(lr), float(betas[0]), float(betas[1]), int(step), out)
+    return out[0], out[1]
+
+
+def adam_step_dev(param, grad, exp_avg, exp_avg_sq, betas, eps, weight_decay, scalars, grad_scale=1.0):
+    """adam_step with (step_size, bc2_sqrt) read from the 2-float device tensor ``scalars`` (capturable in a HIP graph)."""
+    lib = _lib.load()
+    _lib.check(lib.mg_adam_step_dev_f32(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), float(betas[0]),
+                                        float(betas[1]), float(eps), float(weight_decay), _p(scalars), float(grad_scale), _stream()),
+               'mg_adam_step_dev_f32')
+
+
 def ema_update(shadow, param, decay):
     lib = _lib.load()
     if not (shadow.is_cuda and shadow.is_contiguous() and param.is_contiguous()):

@@ -66,6 +66,47 @@ class Adam(torch.optim.Optimizer):
             return dist.get_world_size(self.process_group)
         return 1
 
+    # ---- HIP-graph support (morgana_amd/graphs.py): the captured update reads its step-dependent scalars from device memory
+    def _scalar_buffers(self, flat):
+        if 'scalars' not in flat:
+            flat['scalars'] = torch.zeros(2, dtype=torch.float32, device=flat['param'].device)
+            flat['scalars_host'] = torch.zeros(2, dtype=torch.float32).pin_memory()
+        return flat['scalars'], flat['scalars_host']
+
+    def exchange_gradients(self):
+        """The step's one gradient all-reduce (no-op on one rank); ``step`` calls it, a graphed step calls it between its graphs."""
+        if self._world() > 1:
+            for flat in self._flat:
+                if flat is not None:
+                    dist.all_reduce(flat['grad'], op=dist.ReduceOp.SUM, group=self.process_group)
+
+    def prepare_capture(self):
+        for flat in self._flat:
+            if flat is not None:
+                self._scalar_buffers(flat)
+
+    def advance(self):
+        """Count one step and stage its (step_size, bc2_sqrt) for the captured update: an 8-byte async copy per group, issued on
+        the current stream ahead of the graph replay that consumes it."""
+        for group, flat in zip(self.param_groups, self._flat):
+            if flat is None:
+                continue
+            flat['step'] += 1
+            dev, host = self._scalar_buffers(flat)
+            host[0], host[1] = ops.adam_scalars(group['lr'], group['betas'], flat['step'])
+            dev.copy_(host, non_blocking=True)
+
+    @torch.no_grad()
+    def step_captured(self):
+        """The parameter update alone, from device-resident scalars (call ``advance`` before each replay).  No all-reduce here."""
+        world = self._world()
+        for group, flat in zip(self.param_groups, self._flat):
+            if flat is None:
+                continue
+            dev, _ = self._scalar_buffers(flat)
+            ops.adam_step_dev(flat['param'], flat['grad'], flat['exp_avg'], flat['exp_avg_sq'], group['betas'], group['eps'],
+                              group['weight_decay'], dev, 1.0 / world)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None

@@ -1536,3 +1536,39 @@ def test_phone_rate_first_layer_equals_frame_rate(precision):
     for name in grads_f:
         tol = 2e-2 if precision == 'bf16' else 1e-4
         assert rel_err(grads_p[name], grads_f[name]) < tol, name
+
+
+def test_graphed_train_step_equals_eager_steps():
+    """graphs.GraphedTrainStep (zero_grad, forward, backward and the Adam update captured once as a HIP graph and replayed; Adam's
+    step-dependent scalars read from device memory) against the same number of eager steps: same kernels in the same order on the
+    same data, so parameters, both Adam moments and the loss must be EQUAL bit for bit - also across a learning-rate change."""
+    from morgana_amd import graphs, optim
+    feats = data.to_device(synthetic.make_batch(32, 200, seed=8), DEV)
+
+    def fresh():
+        model = _load_state(models.F0Model(precision='bf16').to(DEV), synthetic.f0_model_state())
+        return model, optim.Adam(model.parameters(), lr=0.01)
+
+    model_e, opt_e = fresh()
+    losses_e = []
+    for i in range(9):
+        if i == 7:
+            opt_e.param_groups[0]['lr'] = 0.003
+        opt_e.zero_grad()
+        loss, _ = model_e(feats)
+        loss.backward()
+        opt_e.step()
+        losses_e.append(loss.item())
+    model_g, opt_g = fresh()
+    step = graphs.GraphedTrainStep(model_g, opt_g, feats, warmup=3)          # 3 eager steps, then the capture (which runs nothing)
+    assert step.steps_done == 3
+    losses_g = []
+    for i in range(3, 9):
+        if i == 7:
+            opt_g.param_groups[0]['lr'] = 0.003
+        losses_g.append(step().item())
+    assert losses_g == losses_e[3:]
+    flat_e, flat_g = opt_e.flat_buffers(), opt_g.flat_buffers()
+    assert flat_e['step'] == flat_g['step'] == 9
+    for key in ('param', 'exp_avg', 'exp_avg_sq'):
+        assert torch.equal(flat_e[key], flat_g[key]), key
