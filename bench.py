@@ -80,7 +80,34 @@ def roofline_f0(features, model, precision):
     w1, b1, w2, b2 = lins[0].weight.detach(), lins[0].bias.detach(), lins[1].weight.detach(), lins[1].bias.detach()
     n1, n2 = w1.shape[0], w2.shape[0]
     kernels = []
-    if precision == 'bf16':
+    bound = {}
+    if precision == 'bf16' and ops.phone_rate_table_ok(b * p, m, n1, n2, ops.ACT_SIGMOID):
+        # the step as LinearStackMSEFn runs it (phone-rate first layer, table form): layer 1 once per phone, layer 2 gathering the
+        # per-phone activation table, everything below dZ2 at phone rate after one segment sum
+        extra = ops.PHONE_RATE_EXTRA
+        r_tab = b * p + extra
+        seg, rows_p = ops.segment_bounds(rows, b * p, pad_row=b * p)
+        tab = ops.cast_pad_bf16(lab.view(b * p, k), extra_rows=extra)
+        (w1b, w2b), (_, w2t) = ops.cast_params_bf16([w1, w2], want_t=(1,))
+        h_tab = ops.linear_fwd_bf16(tab, None, r_tab, k, w1b, b1, n1, ops.ACT_SIGMOID)
+        dz2 = (torch.randn(m, ops.pad_ld(n2), device=lab.device) * 0.01).to(torch.bfloat16)
+        sums = ops.segment_sum(dz2, rows_p, seg, b * p, n2)
+        dz1 = ops.linear_dgrad_bf16(sums, r_tab, n2, w2t, n1, h_tab)
+        kernels.append(('gemm_nt_persist_kernel<256>: layer-1 forward at phone rate (%d rows, 600->512 + bias + sigmoid)' % r_tab,
+                        2.0 * r_tab * k * n1, lambda: ops.linear_fwd_bf16(tab, None, r_tab, k, w1b, b1, n1, ops.ACT_SIGMOID)))
+        kernels.append(('gemm_nt_persist_kernel<128>: layer-2 forward, rows gathered from the per-phone table (512->128 + bias + sigmoid)',
+                        2.0 * m * n1 * n2, lambda: ops.linear_fwd_bf16(h_tab, rows_p, m, n1, w2b, b2, n2, ops.ACT_SIGMOID)))
+        kernels.append(('segment_sum_kernel: per-phone sums of dZ2 (reads M x 128 bf16 once)', 0.0,
+                        lambda: ops.segment_sum(dz2, rows_p, seg, b * p, n2)))
+        bound['segment_sum_kernel'] = ('hbm', (m + r_tab) * ops.pad_ld(n2) * 2.0)
+        kernels.append(('wgrad_big_kernel<8>: layer-2 wgrad at phone rate (sums^T table)', 2.0 * r_tab * n1 * n2,
+                        lambda: ops.linear_wgrad_bf16(sums, h_tab, None, r_tab, n2, n1)))
+        kernels.append(('gemm_nt_big_kernel<256>: layer-2 dgrad + sigmoid-grad at phone rate', 2.0 * r_tab * n1 * n2,
+                        lambda: ops.linear_dgrad_bf16(sums, r_tab, n2, w2t, n1, h_tab)))
+        kernels.append(('wgrad_big_kernel<10>: layer-1 wgrad at phone rate (dZ1^T lab)', 2.0 * r_tab * k * n1,
+                        lambda: ops.linear_wgrad_bf16(dz1, tab, None, r_tab, n1, k)))
+        peak = MFMA_BF16_PEAK_TFLOPS
+    elif precision == 'bf16':
         tab = ops.cast_pad_bf16(lab.view(b * p, k))
         (w1b, w2b), (_, w2t) = ops.cast_params_bf16([w1, w2], want_t=(1,))
         h1 = ops.linear_fwd_bf16(tab, rows, m, k, w1b, b1, n1, ops.ACT_SIGMOID)
@@ -121,12 +148,18 @@ def roofline_f0(features, model, precision):
                          'tflops': round(flops / (ms * 1e-3) / 1e12, 2)})
     lib.mg_set_tuning(1, 0)
     dom = max(measured, key=lambda r: r['ms'])
+    short = dom['kernel'].split(':')[0]
     traffic = None
     try:   # HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
         table = json.load(open(os.path.join(REPO, 'profiles', 'r1_hbm_traffic.json')))
-        traffic = table.get(dom['kernel'].split(':')[0])
+        traffic = table.get(short)
     except (OSError, ValueError):
         pass
+    if short in bound:               # a kernel that moves bytes, not FLOPs: price it against the HBM roof
+        kind, nbytes = bound[short]
+        gbs = nbytes / (dom['ms'] * 1e-3) / 1e9
+        return {'bound': kind, 'kernel': dom['kernel'], 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic, 'ms_per_launch': dom['ms'], 'kernels': measured}
     return {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': dom['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
             'frac': round(dom['tflops'] / peak, 4), 'traffic': traffic, 'ms_per_launch': dom['ms'], 'kernels': measured}
 
@@ -385,6 +418,18 @@ def main():
             peak = MFMA_BF16_PEAK_TFLOPS if args.precision == 'bf16' else MFMA_F32_PEAK_TFLOPS
             result['step_algorithmic_tflops'] = round(step_tflops, 2)
             result['step_frac_of_mfma_peak'] = round(step_tflops / peak, 4)
+            # step_algorithmic_* prices the REFERENCE's algorithm (every product at frame rate).  With the
+            # phone-rate first layer the kernels multiply less: layer 1 and everything below dZ2 run on B*P (+ pad) rows.
+            lab_shape = feats_np['normalised_lab'].shape
+            r_tab = lab_shape[0] * lab_shape[1] + ops.PHONE_RATE_EXTRA
+            if args.precision == 'bf16' and ops.phone_rate_table_ok(r_tab - ops.PHONE_RATE_EXTRA, frames_per_step, 512, 128,
+                                                                    ops.ACT_SIGMOID):
+                executed = (2 * 2.0 * r_tab * lab_shape[2] * 512 + 2 * 2.0 * r_tab * 512 * 128
+                            + 2.0 * frames_per_step * 512 * 128 + 3 * 2.0 * frames_per_step * (128 * 32 + 32))
+                result['step_executed_tflops'] = round(executed / (ms_per_step * 1e-3) / 1e12, 2)
+                result['flops_note'] = ('step_algorithmic_tflops counts the reference algorithm (all products at frame rate); the '
+                                        'phone-rate first layer executes %.1f GFLOP per step instead of %.1f'
+                                        % (executed / 1e9, F0_FLOPS_PER_FRAME * frames_per_step / 1e9))
     if rank == 0 and args.config == 'c2' and not args.no_roofline:
         result['roofline'] = roofline_f0(features, model, args.precision)
     if rank == 0 and args.config in ('c4', 'c5') and not args.no_roofline:

@@ -34,7 +34,9 @@ class GraphedTrainStep(object):
         torch.cuda.synchronize()
         self._fwd_bwd = torch.cuda.CUDAGraph()
         self.optimizer.prepare_capture()               # capture records the launches, it does not run them
-        with torch.cuda.graph(self._fwd_bwd):
+        # with a process group alive its watchdog thread polls events while we capture: judge only this thread's calls
+        mode = dict(capture_error_mode='thread_local') if self._multi else {}
+        with torch.cuda.graph(self._fwd_bwd, **mode):
             self.optimizer.zero_grad()
             self.loss, self.output = self.model(self.features)
             functional.backward(self.loss)
@@ -44,7 +46,7 @@ class GraphedTrainStep(object):
         if self._multi:
             self.optimizer.exchange_gradients()
             self._update = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._update, pool=self._fwd_bwd.pool()):
+            with torch.cuda.graph(self._update, pool=self._fwd_bwd.pool(), **mode):
                 self.optimizer.step_captured()
         self.steps_done = warmup
 
