@@ -208,19 +208,15 @@ int mg_linear_wgrad_f32(const float* dY, const float* A, int lda, const int32_t*
 
 /* Phone-rate first layer (csrc/phone_rate.hip): Linear commutes with upsample_to_repetitions' row repetition (reference:
  * morgana/utils.py:175-228 feeding README.rst:65-73 / morgana/utils.py:401-418), so the first layer's product runs once per
- * phone and these three kernels move between phone rate and frame rate.
+ * phone and these kernels move between phone rate and frame rate.
  *  mg_segment_bounds  seg_start / seg_end int32 [R]: the run of frames f with rows[f] == r (0, 0 if none).  rows int32 [M] as
  *                     mg_upsample_index writes them (b*P + phone, -1 = padding); the frames of a row must be consecutive.
  *                     rows_mapped (optional, int32 [M]): rows with -1 replaced by pad_row (the table row of a zero input).
- *  mg_expand_rows     H[f, :] = act(Z[rows[f], :] + bias) (Z row = 0 for rows[f] < 0); Z f32 [R, ldz]; H bf16 (h_bf16) or f32
- *                     [M, ldh], columns N..ldh-1 zeroed; N, ldh multiples of 8.
  *  mg_segment_sum     out[r, :] = sum of G[f, :] over the frames of row r (fp32 accumulation, frame order), r < R; rows
  *                     R..R+extra-1 of out take the frames with rows[f] < 0 (those of the j-th of `extra` equal shares of the frame axis go to row R + j).  G, out bf16
  *                     (g_bf16) or f32. */
 int mg_segment_bounds(const int32_t* rows, int64_t M, int R, int32_t* seg_start, int32_t* seg_end, int32_t* rows_mapped,
                       int pad_row, void* stream);
-int mg_expand_rows(const float* Z, int ldz, const int32_t* rows, int64_t M, const float* bias, int N, int act, void* H, int ldh,
-                   int h_bf16, void* stream);
 int mg_segment_sum(const void* G, int ldg, int g_bf16, const int32_t* rows, int64_t M, const int32_t* seg_start,
                    const int32_t* seg_end, int R, int extra, int N, void* out, int ldo, void* stream);
 

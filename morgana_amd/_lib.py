@@ -92,7 +92,6 @@ SIGNATURES = {
     'mg_segment_bounds': (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'mg_linear_dgrad_gathered_bf16': (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                               c_int, c_int, c_void_p]),
-    'mg_expand_rows': (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     'mg_segment_sum': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
                                c_void_p]),
     'mg_mlpg_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

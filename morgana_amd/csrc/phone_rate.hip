@@ -3,14 +3,15 @@
 // Linear(600, 512) + Sigmoid over all B*T frame rows (README.rst:65-73, morgana/utils.py:401-418).  A Linear commutes with
 // repeating rows:  gather(X) W^T = gather(X W^T).  So the 600-wide product is done ONCE PER PHONE (B*P rows, 12.5x fewer than
 // frames at the synthetic 12.5 frames per phone) and the frame-rate activation is a gather of that table:
-//     forward   Z = X_phone W^T (fp32, existing GEMM)            H[f] = act(Z[row(f)] + b)             (expand_rows_kernel)
-//     backward  dZ_phone[r] = sum over the frames f of phone r of dZ[f]   (segment_sum_kernel)         dW = dZ_phone^T X_phone
-// Per frame row the fp32 dot product, the bias add and the sigmoid are the same operations in the same order as in the
-// frame-rate GEMM epilogue, so H is unchanged; dW sums the same bf16 (fp32 in parity mode) frame gradients, grouped by phone.
-// Both kernels are HBM bound: expand writes M x N activations (reads of Z hit L2: a phone's row is used by consecutive
-// frames), segment_sum reads M x N gradients once.  Frames with row -1 (padding past an utterance's end, the reference's zero
-// row, utils.py:206-214) take Z = 0 in expand; in segment_sum their gradients go to `extra` rows behind the table's R rows
-// (the input rows there are zero, so dW ignores them and the bias gradient still sums every frame).
+//     forward   H_table = sigmoid(X_phone W^T + b) with the existing GEMM on B*P (+ padding) rows; the NEXT layer's GEMM gathers
+//               rows of the table through the row map (segment_bounds_kernel writes it with -1 -> the table's zero-input row)
+//     backward  S[r] = sum over the frames f of phone r of dZ_next[f]  (segment_sum_kernel); sigma'(H) is constant over a phone's
+//               frames, so dW_next = S^T H_table, dZ = (S W_next) * H_table (1 - H_table), dW = dZ^T X_phone all run on table rows
+// Per frame row the fp32 dot product, the bias add, the sigmoid and the bf16 rounding are the same operations in the same
+// order as in the frame-rate GEMM epilogue, so the activations are unchanged.  segment_sum is HBM bound (reads the M x N
+// gradient once).  Frames with row -1 (padding past an utterance's end, the reference's zero row, utils.py:206-214) use the
+// table rows behind the R phone rows (zero inputs: sigmoid(b)); their gradients are summed into those `extra` rows, so dW
+// ignores them (their input is zero) and the bias gradients still see every frame.
 #include "common.h"
 
 typedef uint32_t pr_u32x4 __attribute__((ext_vector_type(4)));
@@ -45,55 +46,6 @@ template <> struct PrStore<float> {
         *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
     }
 };
-
-// H[f, c] = act(Z[rows[f], c] + bias[c]).  A thread owns one 8-column chunk (its bias values stay in registers) and walks frame
-// rows with a grid stride, four rows per trip so that four Z-row loads are in flight; threadIdx.y picks the row inside a block.
-// N % 8 == 0; columns N..ldh-1 are zeroed.
-#define EXPAND_ROWS_PER_BLOCK 4
-#define EXPAND_UNROLL 4
-template <typename OutT, bool FAST>
-__global__ __launch_bounds__(256) void expand_rows_kernel(const float* __restrict__ Z, int ldz, const int32_t* __restrict__ rows,
-                                                          int64_t M, const float* __restrict__ bias, int N, int act,
-                                                          OutT* __restrict__ H, int ldh) {
-    const int c = (blockIdx.y * 64 + threadIdx.x) * 8;
-    if (c >= ldh) return;
-    const bool live = c < N;
-    float bv[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = (live && bias) ? bias[c + e] : 0.f;
-    const int64_t stride = (int64_t)gridDim.x * EXPAND_ROWS_PER_BLOCK;
-    for (int64_t f0 = (int64_t)blockIdx.x * EXPAND_ROWS_PER_BLOCK + threadIdx.y; f0 < M; f0 += stride * EXPAND_UNROLL) {
-        f32x4 lo[EXPAND_UNROLL], hi[EXPAND_UNROLL];
-#pragma unroll
-        for (int u = 0; u < EXPAND_UNROLL; ++u) {
-            const int64_t f = f0 + u * stride;
-            const int r = (live && f < M) ? rows[f] : -1;
-            if (r >= 0) {
-                lo[u] = *reinterpret_cast<const f32x4*>(Z + (size_t)r * ldz + c);
-                hi[u] = *reinterpret_cast<const f32x4*>(Z + (size_t)r * ldz + c + 4);
-            } else {
-                lo[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                hi[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < EXPAND_UNROLL; ++u) {
-            const int64_t f = f0 + u * stride;
-            if (f >= M) break;
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float x = 0.f;
-                if (live) {
-                    x = (e < 4 ? lo[u][e & 3] : hi[u][e & 3]) + bv[e];
-                    if (act == MG_ACT_SIGMOID) x = FAST ? mg_sigmoid_fast(x) : mg_sigmoid(x);
-                }
-                v[e] = x;
-            }
-            PrStore<OutT>::put(H + (size_t)f * ldh + c, v);
-        }
-    }
-}
 
 template <typename T> struct PrLoad;
 template <> struct PrLoad<uint16_t> {
@@ -178,26 +130,6 @@ int mg_segment_bounds(const int32_t* rows, int64_t M, int R, int32_t* seg_start,
     hipLaunchKernelGGL(segment_bounds_kernel, dim3((unsigned)mg_ceil_div(M, 256)), dim3(256), 0, st, rows, M, R, seg_start, seg_end,
                        rows_mapped, pad_row);
     MG_CHECK_LAUNCH("mg_segment_bounds");
-    return MG_OK;
-}
-
-int mg_expand_rows(const float* Z, int ldz, const int32_t* rows, int64_t M, const float* bias, int N, int act, void* H, int ldh,
-                   int h_bf16, void* stream) {
-    MG_CHECK_ARG(Z && rows && H && M > 0 && N > 0, "mg_expand_rows: bad arguments (M=%lld N=%d)", (long long)M, N);
-    MG_CHECK_ARG(N % 8 == 0 && ldz % 4 == 0 && ldz >= N && ldh % 8 == 0 && ldh >= N, "mg_expand_rows: N=%d ldz=%d ldh=%d (N, ldh multiples of 8)", N,
-                 ldz, ldh);
-    MG_CHECK_ARG(((uintptr_t)Z % 16) == 0 && ((uintptr_t)H % 16) == 0, "mg_expand_rows: buffers must be 16-byte aligned");
-    MG_CHECK_ARG(act == MG_ACT_NONE || act == MG_ACT_SIGMOID, "mg_expand_rows: unknown activation %d", act);
-    const unsigned col_blocks = (unsigned)mg_ceil_div(ldh / 8, 64);
-    int64_t row_blocks = mg_ceil_div(M, EXPAND_ROWS_PER_BLOCK * EXPAND_UNROLL);
-    if (row_blocks > 16384) row_blocks = 16384;
-    const dim3 grid((unsigned)row_blocks, col_blocks), block(64, EXPAND_ROWS_PER_BLOCK);
-    hipStream_t st = (hipStream_t)stream;
-    if (h_bf16)
-        hipLaunchKernelGGL((expand_rows_kernel<uint16_t, true>), grid, block, 0, st, Z, ldz, rows, M, bias, N, act, (uint16_t*)H, ldh);
-    else
-        hipLaunchKernelGGL((expand_rows_kernel<float, false>), grid, block, 0, st, Z, ldz, rows, M, bias, N, act, (float*)H, ldh);
-    MG_CHECK_LAUNCH("mg_expand_rows");
     return MG_OK;
 }
 

@@ -84,37 +84,23 @@ class LinearStackFn(torch.autograd.Function):
         if x2d.shape[1] != (ops.pad_ld(k_in) if pre_cast else k_in):
             raise ValueError('Linear expects %d input features, got %d' % (k_in, x2d.shape[1]))
         hidden = []
-        # phone-rate first layer (csrc/phone_rate.hip): the product once per table row, then a gather of the result
-        n_table = x2d.shape[0]
-        phone_rate = (rows is not None and not pre_cast and n_layers > 1
-                      and ops.phone_rate_ok(n_table, m, weights[0].shape[0], acts[0]))
-        ctx.phone_rate = phone_rate
-        seg = ops.segment_bounds(rows, n_table) if phone_rate else None
         if precision == 'fp32':
             a, r = x2d, rows
             for i in range(n_layers):
                 w = ops._require(weights[i], torch.float32, 'weight')
-                if i == 0 and phone_rate:
-                    z = ops.linear_fwd_f32(a, None, n_table, w, None, ops.ACT_NONE)
-                    a = ops.expand_rows(z, rows, biases[0], w.shape[0], acts[0], bf16=False)
-                else:
-                    a = ops.linear_fwd_f32(a, r, m, w, biases[i], acts[i])
+                a = ops.linear_fwd_f32(a, r, m, w, biases[i], acts[i])
                 r = None
                 hidden.append(a)
             out = a
             ctx.save_for_backward(x2d, rows, *weights, *hidden)
         else:
-            a = x2d if pre_cast else ops.cast_pad_bf16(x2d, extra_rows=ops.PHONE_RATE_EXTRA if phone_rate else 0)
+            a = x2d if pre_cast else ops.cast_pad_bf16(x2d)
             a0, r = a, rows
             for i in range(n_layers):
                 n, k = weights[i].shape
                 w_bf = ops.cast_pad_bf16(ops._require(weights[i], torch.float32, 'weight'))
                 last = i == n_layers - 1
-                if i == 0 and phone_rate:
-                    z = ops.linear_fwd_bf16(a, None, n_table, k, w_bf, None, n, ops.ACT_NONE, out_f32=True)
-                    a = ops.expand_rows(z, rows, biases[0], n, acts[0], bf16=True)
-                else:
-                    a = ops.linear_fwd_bf16(a, r, m, k, w_bf, biases[i], n, acts[i], out_f32=last)
+                a = ops.linear_fwd_bf16(a, r, m, k, w_bf, biases[i], n, acts[i], out_f32=last)
                 r = None
                 hidden.append(a)
             n_last = weights[-1].shape[0]
@@ -123,7 +109,6 @@ class LinearStackFn(torch.autograd.Function):
                 out = out[:, :n_last].contiguous()
                 # keep the padded fp32 activation only if a trailing sigmoid needs it in backward
             ctx.save_for_backward(a0, rows, *weights, *hidden[:-1], out)
-        ctx.seg = seg
         return out
 
     @staticmethod
@@ -145,14 +130,7 @@ class LinearStackFn(torch.autograd.Function):
             for i in range(n_layers - 1, -1, -1):
                 n, k = ctx.dims[i]
                 a_in, r = (x_in, rows) if i == 0 else (hidden[i - 1], None)
-                if i == 0 and ctx.phone_rate:
-                    n_table = x_in.shape[0]
-                    g_rows = ops.segment_sum(g, rows, ctx.seg, n_table, n)
-                    dw, db = ops.linear_wgrad_f32(g_rows[:n_table], x_in, None, n, k, want_bias=ctx.has_bias[i])
-                    if db is not None:
-                        db += g_rows[n_table:].sum(0)          # gradients of padding frames (their input row is zero)
-                else:
-                    dw, db = ops.linear_wgrad_f32(g, a_in, r, n, k, want_bias=ctx.has_bias[i])
+                dw, db = ops.linear_wgrad_f32(g, a_in, r, n, k, want_bias=ctx.has_bias[i])
                 grads[2 * i], grads[2 * i + 1] = dw, db
                 if i > 0:
                     h = hidden[i - 1] if acts[i - 1] == ops.ACT_SIGMOID else None
@@ -164,12 +142,7 @@ class LinearStackFn(torch.autograd.Function):
             for i in range(n_layers - 1, -1, -1):
                 n, k = ctx.dims[i]
                 a_in, r = (x_in, rows) if i == 0 else (hidden[i - 1], None)
-                if i == 0 and ctx.phone_rate:
-                    n_table = x_in.shape[0] - ops.PHONE_RATE_EXTRA
-                    g_rows = ops.segment_sum(g, rows, ctx.seg, n_table, n)
-                    dw, db = ops.linear_wgrad_bf16(g_rows, x_in, None, g_rows.shape[0], n, k, want_bias=ctx.has_bias[i])
-                else:
-                    dw, db = ops.linear_wgrad_bf16(g, a_in, r, m, n, k, want_bias=ctx.has_bias[i])
+                dw, db = ops.linear_wgrad_bf16(g, a_in, r, m, n, k, want_bias=ctx.has_bias[i])
                 grads[2 * i], grads[2 * i + 1] = dw, db
                 if i > 0:
                     wt = ops.cast_transpose_bf16(weights[i])

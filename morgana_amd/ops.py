@@ -812,13 +812,9 @@ def mlpg(means, variances, windows, padding_size=0, seq_len=None, out_dtype=torc
 
 
 # ---------------------------------------------------------------------------------------------- phone-rate first layer
+# MORGANA_PHONE_RATE=0: every product at frame rate (the reference's order of operations)
 PHONE_RATE = os.environ.get('MORGANA_PHONE_RATE', '1') != '0'
 PHONE_RATE_EXTRA = 1024          # rows behind the table that collect the gradients of padding frames (for the bias gradient)
-
-
-def phone_rate_ok(n_table_rows, m, n, act):
-    """First layer on a gathered table: run the product once per table row when there are fewer table rows than frames."""
-    return PHONE_RATE and n % 8 == 0 and n_table_rows < m and act in (ACT_NONE, ACT_SIGMOID)
 
 
 def segment_bounds(rows, n_table_rows, pad_row=None):
@@ -847,17 +843,6 @@ def linear_dgrad_gathered_bf16(dy, m, n, wt_bf16, k, h_table, h_rows):
                                                  h_table.shape[1], _p(h_rows), _p(dx), dx.shape[1], 0, _stream()),
                'mg_linear_dgrad_gathered_bf16')
     return dx
-
-
-def expand_rows(z, rows, bias, n, act, bf16):
-    """H[f] = act(z[rows[f]] + bias): (m, pad8(n)) bf16 or (m, n) f32 from the (R, ldz) f32 table (csrc/phone_rate.hip)."""
-    lib = _lib.load()
-    z = _require(z, torch.float32, 'table')
-    m = rows.numel()
-    ldh = pad8(n) if bf16 else n
-    h = torch.empty((m, ldh), dtype=torch.bfloat16 if bf16 else torch.float32, device=z.device)
-    _lib.check(lib.mg_expand_rows(_p(z), z.shape[1], _p(rows), m, _p(bias), n, act, _p(h), ldh, int(bf16), _stream()), 'mg_expand_rows')
-    return h
 
 
 def segment_sum(g, rows, seg, n_table_rows, n, extra=PHONE_RATE_EXTRA):

@@ -1472,28 +1472,23 @@ def _ragged_rows(rng, b, p, t):
 
 @pytest.mark.parametrize('bf16', [True, False])
 def test_phone_rate_kernels_vs_numpy(bf16):
-    """mg_segment_bounds / mg_expand_rows / mg_segment_sum (csrc/phone_rate.hip) against numpy on a ragged map with empty phones
-    and padding frames: bounds exact; expand = act(table[row] + bias) to 1e-6 (fp32) / one bf16 rounding; segment sums of bf16 /
-    fp32 frame rows in fp32, padding frames collected in the extra rows (their total checked)."""
+    """mg_segment_bounds / mg_segment_sum (csrc/phone_rate.hip) against numpy on a ragged map with empty phones and padding frames:
+    bounds and the mapped rows exact; segment sums of bf16 / fp32 frame rows in fp32, padding frames collected in the extra rows
+    (their total checked), also when the map already carries the pad row instead of -1."""
     from morgana_amd import ops
     rng = np.random.RandomState(41 + bf16)
     b, p, t, n = 7, 9, 40, 72
     rows = _ragged_rows(rng, b, p, t)
     flat = rows.reshape(-1)
     r_tab = b * p
+    seg_dev, mapped = ops.segment_bounds(dev(flat), r_tab, pad_row=r_tab)
+    np.testing.assert_array_equal(mapped.cpu().numpy(), np.where(flat < 0, r_tab, flat))
     seg = ops.segment_bounds(dev(flat), r_tab).cpu().numpy()
+    np.testing.assert_array_equal(seg, seg_dev.cpu().numpy())
     for r in range(r_tab):
         where = np.nonzero(flat == r)[0]
         want = (where[0], where[-1] + 1) if len(where) else (0, 0)
         assert (seg[0, r], seg[1, r]) == want
-    table = rng.standard_normal((r_tab, n)).astype(np.float32)
-    bias = rng.standard_normal(n).astype(np.float32)
-    want = np.where(flat[:, None] >= 0, table[np.maximum(flat, 0)], 0.0) + bias
-    want_sig = 1.0 / (1.0 + np.exp(-want.astype(np.float64)))
-    for act, ref in ((ops.ACT_NONE, want), (ops.ACT_SIGMOID, want_sig)):
-        got = ops.expand_rows(dev(table), dev(flat), dev(bias), n, act, bf16=bf16)
-        got = got.float().cpu().numpy()[:, :n]
-        np.testing.assert_allclose(got, ref, rtol=2 ** -8 if bf16 else 1e-6, atol=1e-6)
     grad = rng.standard_normal((b * t, n)).astype(np.float32)
     g_dev = dev(grad).to(torch.bfloat16) if bf16 else dev(grad)
     grad = g_dev.float().cpu().numpy()
@@ -1503,14 +1498,16 @@ def test_phone_rate_kernels_vs_numpy(bf16):
     want_rows = np.stack([grad[flat == r].sum(0) for r in range(r_tab)])
     np.testing.assert_allclose(sums[:r_tab], want_rows, rtol=2 ** -7 if bf16 else 1e-5, atol=1e-5)
     np.testing.assert_allclose(sums[r_tab:].sum(0), grad[flat < 0].sum(0), rtol=0, atol=(0.15 if bf16 else 1e-4))
+    again = ops.segment_sum(g_dev, mapped, dev(seg), r_tab, n, extra=extra)
+    assert torch.equal(again.float().cpu(), torch.from_numpy(sums))
 
 
-@pytest.mark.parametrize('precision', ['bf16', 'fp32'])
-def test_phone_rate_first_layer_equals_frame_rate(precision):
-    """The F0Model step with the first Linear run once per phone (gather(X) W^T = gather(X W^T)) against the same step with the
-    frame-rate gather-fused GEMMs: the prediction and the loss are EQUAL in bf16 mode (same fp32 dot product, bias add and sigmoid
-    per frame row) and within 1e-6 in fp32 mode; every gradient agrees to the mode's tolerance (the per-phone sums regroup the same
-    frame gradients; in bf16 mode the sums are rounded to bf16 once more before the weight-gradient GEMM)."""
+def test_phone_rate_first_layer_equals_frame_rate():
+    """The F0Model step (bf16 mode) on a ragged batch (padding frames present) with the first Linear run once per phone and
+    everything below dZ2 at phone rate against the same step with every product at frame rate (MORGANA_PHONE_RATE=0, the
+    reference's order of operations): prediction and loss are EQUAL - per frame row the same fp32 dot product, bias add, sigmoid and
+    bf16 rounding, then the same kernels; every gradient within 2e-2 relative L2 (the per-phone sums regroup the same bf16 frame
+    gradients and are rounded to bf16 once more before the weight-gradient GEMMs)."""
     from morgana_amd import ops
     feats = data.to_device(synthetic.make_batch(24, (150, 400), seed=5), DEV)
 
@@ -1518,7 +1515,7 @@ def test_phone_rate_first_layer_equals_frame_rate(precision):
         old = ops.PHONE_RATE
         ops.PHONE_RATE = phone_rate
         try:
-            model = _load_state(models.F0Model(precision=precision).to(DEV), synthetic.f0_model_state())
+            model = _load_state(models.F0Model(precision='bf16').to(DEV), synthetic.f0_model_state())
             loss, out = model(feats)
             loss.backward()
             return loss.item(), out['pred_norm_lf0'].detach().cpu().numpy(), {k: v.grad.cpu().numpy() for k, v in model.named_parameters()}
@@ -1527,15 +1524,10 @@ def test_phone_rate_first_layer_equals_frame_rate(precision):
 
     loss_p, pred_p, grads_p = run(True)
     loss_f, pred_f, grads_f = run(False)
-    if precision == 'bf16':
-        assert loss_p == loss_f
-        np.testing.assert_array_equal(pred_p, pred_f)
-    else:
-        np.testing.assert_allclose(loss_p, loss_f, rtol=1e-6)
-        np.testing.assert_allclose(pred_p, pred_f, rtol=1e-4, atol=1e-6)
+    assert loss_p == loss_f
+    np.testing.assert_array_equal(pred_p, pred_f)
     for name in grads_f:
-        tol = 2e-2 if precision == 'bf16' else 1e-4
-        assert rel_err(grads_p[name], grads_f[name]) < tol, name
+        assert rel_err(grads_p[name], grads_f[name]) < 2e-2, name
 
 
 def test_graphed_train_step_equals_eager_steps():
@@ -1572,3 +1564,20 @@ def test_graphed_train_step_equals_eager_steps():
     assert flat_e['step'] == flat_g['step'] == 9
     for key in ('param', 'exp_avg', 'exp_avg_sq'):
         assert torch.equal(flat_e[key], flat_g[key]), key
+
+
+def test_dgrad_with_table_gathered_sigmoid_outputs():
+    """mg_linear_dgrad_gathered_bf16 (sigmoid outputs read from the per-phone table through a row map) against mg_linear_dgrad_bf16
+    on the materialised frame-rate activation: same kernel, same arithmetic - EQUAL."""
+    from morgana_amd import ops
+    rng = np.random.RandomState(12)
+    m, n, k, r_tab = 4096, 128, 512, 300
+    dy = dev(rng.standard_normal((m, n)).astype(np.float32) * 0.1).to(torch.bfloat16)
+    wt = dev(rng.standard_normal((k, n)).astype(np.float32) * 0.05).to(torch.bfloat16)
+    table = torch.sigmoid(dev(rng.standard_normal((r_tab, k)).astype(np.float32))).to(torch.bfloat16)
+    rows = dev(np.sort(rng.randint(0, r_tab, size=m)).astype(np.int32))
+    want = ops.linear_dgrad_bf16(dy, m, n, wt, k, table[rows.long()].contiguous())
+    got = ops.linear_dgrad_gathered_bf16(dy, m, n, wt, k, table, rows)
+    assert torch.equal(got, want)
+    with pytest.raises(ValueError):
+        ops.linear_dgrad_gathered_bf16(dy[:100], 100, n, wt, k, table, rows[:100])         # below the wide-tile kernel's sizes
