@@ -215,6 +215,17 @@ int mg_linear_wgrad_f32(const float* dY, const float* A, int lda, const int32_t*
  *  mg_segment_sum     out[r, :] = sum of G[f, :] over the frames of row r (fp32 accumulation, frame order), r < R; rows
  *                     R..R+extra-1 of out take the frames with rows[f] < 0 (those of the j-th of `extra` equal shares of the frame axis go to row R + j).  G, out bf16
  *                     (g_bf16) or f32. */
+/*  mg_phone_target_stats  what the masked MSE (morgana/losses.py:29-51) needs per table row when every frame of a row shares one
+ *                     prediction: weight[r] = sum of the frame weights [t < n_b] / (n_b B) of the row's frames, ybar[r] = their weighted
+ *                     mean target, loss_const = sum_r sum_f w_f (y_f - ybar[r])^2.  Then
+ *                     loss = sum_r weight[r] (pred[r] - ybar[r])^2 + loss_const  exactly, with the same gradient (mg_f0_tail_rows_bf16).
+ *                     target f32 [B*T]; ybar, weight f32 [R + extra]; rows R.. take the padding frames. */
+/*  mg_expand_column_f32  out[f] = table[rows[f]] for a one-column f32 table (the per-phone prediction repeated to frames); rows >= 0. */
+int mg_expand_column_f32(const float* table, const int32_t* rows, int64_t M, float* out, void* stream);
+size_t mg_phone_target_stats_workspace_bytes(int R, int extra);
+int mg_phone_target_stats(const float* target, const int32_t* rows, int64_t M, const int32_t* seg_start, const int32_t* seg_end,
+                          const int64_t* seq_len, int B, int T, int R, int extra, float* ybar, float* weight, float* loss_const,
+                          void* workspace, size_t workspace_bytes, void* stream);
 int mg_segment_bounds(const int32_t* rows, int64_t M, int R, int32_t* seg_start, int32_t* seg_end, int32_t* rows_mapped,
                       int pad_row, void* stream);
 int mg_segment_sum(const void* G, int ldg, int g_bf16, const int32_t* rows, int64_t M, const int32_t* seg_start,
@@ -281,6 +292,11 @@ size_t mg_f0_tail_workspace_bytes(int64_t M);
 int mg_f0_tail_bf16(const uint16_t* H2, int ldh, int K3, const float* W3, const float* b3, const float* W4, const float* b4,
                     const float* target, const int64_t* seq_len, int B, int T, float grad_scale, float* pred, float* loss,
                     uint16_t* dZ2, float* grads, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* The tail on M rows that each stand for a group of frames sharing one input row (phone-rate step): loss = sum_m row_weight[m]
+ * (pred[m] - target[m])^2 and its whole backward; target / row_weight from mg_phone_target_stats. */
+int mg_f0_tail_rows_bf16(const uint16_t* H2, int ldh, int K3, const float* W3, const float* b3, const float* W4, const float* b4,
+                         const float* target, const float* row_weight, int64_t M, float grad_scale, float* pred, float* loss,
+                         uint16_t* dZ2, float* grads, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * K3  GRU through RecurrentCuDNNWrapper   reference: morgana/utils.py:345-393 + torch.nn.GRU (gates r, z, n)

@@ -89,6 +89,12 @@ SIGNATURES = {
     'mg_adam_scalars': (None, [c_float, c_float, c_float, c_int64, c_void_p]),
     'mg_adam_step_dev_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p,
                                      c_float, c_void_p]),
+    'mg_f0_tail_rows_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                     c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'mg_expand_column_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    'mg_phone_target_stats_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'mg_phone_target_stats': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'mg_segment_bounds': (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'mg_linear_dgrad_gathered_bf16': (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                               c_int, c_int, c_void_p]),

@@ -115,6 +115,122 @@ __global__ __launch_bounds__(64) void segment_sum_kernel(const T* __restrict__ G
     if (c < ldo) PrStore<T>::put(out + (size_t)r * ldo + c, acc);
 }
 
+// Per table row: the frames it stands for, as the masked MSE sees them (morgana/losses.py:29-51: frame weight w_f = [t < n_b] / (n_b B)).
+// weight[r] = sum_f w_f, ybar[r] = sum_f w_f y_f / weight[r]; then  sum_f w_f (p - y_f)^2 = weight[r] (p - ybar[r])^2 + c_r  for
+// any prediction p shared by the row's frames, c_r = sum_f w_f (y_f - ybar[r])^2 (two passes over the row's frames).  The c_r are
+// summed per block into `partial`.  Blocks [0, phone_blocks): 16 lanes per phone row (its ~12 consecutive frames).  Blocks behind
+// them: one WAVE per extra row, which takes the padding frames of its share of the frame axis, 64 frames per look.
+__device__ __forceinline__ float pr_frame_weight(int64_t f, const int64_t* __restrict__ seq_len, int B, int T) {
+    const int b = (int)(f / T);
+    const int t = (int)(f - (int64_t)b * T);
+    int64_t nb = seq_len ? seq_len[b] : (int64_t)T;
+    if (nb > T) nb = T;
+    if (nb < 0) nb = 0;
+    const float maskf = (int64_t)t < nb ? 1.f : 0.f;
+    return maskf * (1.f / ((float)nb * (float)B));          // n_b == 0 -> 0 * inf = NaN, as the reference
+}
+
+__global__ __launch_bounds__(256) void phone_target_stats_kernel(const float* __restrict__ target, const int32_t* __restrict__ rows,
+                                                                 int64_t M, const int32_t* __restrict__ seg_start,
+                                                                 const int32_t* __restrict__ seg_end,
+                                                                 const int64_t* __restrict__ seq_len, int B, int T, int R, int extra,
+                                                                 int phone_blocks, float* __restrict__ ybar,
+                                                                 float* __restrict__ weight, float* __restrict__ partial) {
+    __shared__ float red[256];
+    float c = 0.f;
+    if ((int)blockIdx.x < phone_blocks) {
+        // 16 lanes per phone row: its frames lie in one utterance, so the weight of a live frame is one value per row
+        const int r = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+        float w_sum = 0.f, wy = 0.f, inv = 0.f;
+        int lo = 0, hi = 0, t0 = 0, nb = 0;
+        if (r < R) {
+            lo = seg_start[r];
+            hi = seg_end[r];
+            const int b = lo / T;
+            t0 = lo - b * T;
+            int64_t n = seq_len ? seq_len[b] : (int64_t)T;
+            n = n > T ? T : (n < 0 ? 0 : n);
+            nb = (int)n;
+            inv = 1.f / ((float)nb * (float)B);                  // n_b == 0 -> inf; 0 * inf = NaN below, as the reference
+            for (int f = lo + sub; f < hi; f += 16) {
+                const float w = (t0 + (f - lo) < nb ? 1.f : 0.f) * inv;
+                w_sum += w;
+                wy += w * target[f];
+            }
+        }
+#pragma unroll
+        for (int d = 8; d > 0; d >>= 1) {
+            w_sum += __shfl_xor(w_sum, d, 64);
+            wy += __shfl_xor(wy, d, 64);
+        }
+        const float mean = w_sum > 0.f ? wy / w_sum : 0.f;
+        for (int f = lo + sub; f < hi; f += 16) {
+            const float d = target[f] - mean;
+            c += ((t0 + (f - lo) < nb ? 1.f : 0.f) * inv) * d * d;
+        }
+        if (r < R && sub == 0) {
+            ybar[r] = mean;
+            weight[r] = w_sum;
+        }
+    } else {
+        const int lane = threadIdx.x & 63;
+        const int j = ((int)blockIdx.x - phone_blocks) * 4 + (threadIdx.x >> 6);        // extra row of this wave
+        if (j < extra) {
+            const int64_t chunk = (M + extra - 1) / extra, lo = (int64_t)j * chunk, hi = lo + chunk < M ? lo + chunk : M;
+            float w_sum = 0.f, wy = 0.f;
+            for (int64_t f = lo + lane; f < hi; f += 64) {
+                const int rf = rows[f];
+                if (rf < 0 || rf >= R) {
+                    const float w = pr_frame_weight(f, seq_len, B, T);
+                    w_sum += w;
+                    wy += w * target[f];
+                }
+            }
+            w_sum = mg_wave_sum(w_sum);
+            wy = mg_wave_sum(wy);
+            const float mean = w_sum > 0.f ? wy / w_sum : 0.f;
+            for (int64_t f = lo + lane; f < hi; f += 64) {
+                const int rf = rows[f];
+                if (rf < 0 || rf >= R) {
+                    const float d = target[f] - mean;
+                    c += pr_frame_weight(f, seq_len, B, T) * d * d;
+                }
+            }
+            if (lane == 0) {
+                ybar[R + j] = mean;
+                weight[R + j] = w_sum;
+            }
+        }
+    }
+    red[threadIdx.x] = c;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// out[f] = table[rows[f]] for a one-column table (the repeated prediction); rows >= 0
+__global__ __launch_bounds__(256) void expand_column_kernel(const float* __restrict__ table, const int32_t* __restrict__ rows, int64_t M,
+                                                            float* __restrict__ out) {
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f < M) out[f] = table[rows[f]];
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+    __shared__ float red[256];
+    float v = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) v += partial[i];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
 extern "C" {
 
 int mg_segment_bounds(const int32_t* rows, int64_t M, int R, int32_t* seg_start, int32_t* seg_end, int32_t* rows_mapped, int pad_row,
@@ -149,6 +265,37 @@ int mg_segment_sum(const void* G, int ldg, int g_bf16, const int32_t* rows, int6
         hipLaunchKernelGGL((segment_sum_kernel<float>), grid, dim3(64), 0, st, (const float*)G, ldg, rows, M, seg_start, seg_end, R, extra, N,
                            (float*)out, ldo);
     MG_CHECK_LAUNCH("mg_segment_sum");
+    return MG_OK;
+}
+
+size_t mg_phone_target_stats_workspace_bytes(int R, int extra) {
+    return (size_t)(mg_ceil_div(R, 16) + mg_ceil_div(extra, 4)) * sizeof(float);
+}
+
+int mg_phone_target_stats(const float* target, const int32_t* rows, int64_t M, const int32_t* seg_start, const int32_t* seg_end,
+                          const int64_t* seq_len, int B, int T, int R, int extra, float* ybar, float* weight, float* loss_const,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    MG_CHECK_ARG(target && rows && seg_start && seg_end && ybar && weight && loss_const && B > 0 && T > 0 && R > 0 && extra >= 0 &&
+                     M == (int64_t)B * T,
+                 "mg_phone_target_stats: bad arguments (M=%lld B=%d T=%d R=%d extra=%d)", (long long)M, B, T, R, extra);
+    if (!workspace || workspace_bytes < mg_phone_target_stats_workspace_bytes(R, extra)) {
+        mg_set_error("mg_phone_target_stats: workspace of %zu bytes needed, got %zu", mg_phone_target_stats_workspace_bytes(R, extra),
+                     workspace_bytes);
+        return MG_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int phone_blocks = (int)mg_ceil_div(R, 16), blocks = phone_blocks + (int)mg_ceil_div(extra, 4);
+    hipLaunchKernelGGL(phone_target_stats_kernel, dim3(blocks), dim3(256), 0, st, target, rows, M, seg_start, seg_end, seq_len, B, T, R, extra,
+                       phone_blocks, ybar, weight, (float*)workspace);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, blocks, loss_const);
+    MG_CHECK_LAUNCH("mg_phone_target_stats");
+    return MG_OK;
+}
+
+int mg_expand_column_f32(const float* table, const int32_t* rows, int64_t M, float* out, void* stream) {
+    MG_CHECK_ARG(table && rows && out && M > 0, "mg_expand_column_f32: bad arguments (M=%lld)", (long long)M);
+    hipLaunchKernelGGL(expand_column_kernel, dim3((unsigned)mg_ceil_div(M, 256)), dim3(256), 0, (hipStream_t)stream, table, rows, M, out);
+    MG_CHECK_LAUNCH("mg_expand_column_f32");
     return MG_OK;
 }
 

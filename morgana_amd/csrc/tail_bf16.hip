@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void f0_tail_kernel(const uint16_t* __restr
                                                          const float* __restrict__ b4, const float* __restrict__ target,
                                                          const int64_t* __restrict__ seq_len, int64_t M, int B, int T,
                                                          float grad_scale, float* __restrict__ pred, uint16_t* __restrict__ dZ2,
-                                                         float* __restrict__ slab) {
+                                                         float* __restrict__ slab, const float* __restrict__ row_weight) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[TAIL_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mi = lane & 31, lh = lane >> 5;
@@ -131,7 +131,18 @@ __global__ __launch_bounds__(256, 2) void f0_tail_kernel(const uint16_t* __restr
 
         // (5) masked MSE of this frame
         float dpred = 0.f;
-        if (live) {
+        if (live && row_weight) {
+            // phone-rate rows (mg_f0_tail_rows_bf16): the row stands for the frames of one phone; w = sum of their loss weights,
+            // target = their weighted mean (mg_phone_target_stats), so w (p - target)^2 has the gradient of the frames' total
+            const float e = p - target[m];
+            const float w = row_weight[m];
+            dpred = (e * w) * (2.f * grad_scale);
+            if (lh == 0) {
+                pred[m] = p;
+                lossp += e * e * w;
+                db4p += dpred;
+            }
+        } else if (live) {
             const int b = (int)(m / T);
             const int t = (int)(m - (int64_t)b * T);
             int64_t nb = seq_len ? seq_len[b] : (int64_t)T;
@@ -273,24 +284,23 @@ extern "C" {
 
 size_t mg_f0_tail_workspace_bytes(int64_t M) { return mg_align_up((size_t)tail_blocks(M) * TAIL_SLAB * sizeof(float), 256); }
 
-int mg_f0_tail_bf16(const uint16_t* H2, int ldh, int K3, const float* W3, const float* b3, const float* W4, const float* b4,
-                    const float* target, const int64_t* seq_len, int B, int T, float grad_scale, float* pred, float* loss,
-                    uint16_t* dZ2, float* grads, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
-    MG_CHECK_ARG(H2 && W3 && b3 && W4 && b4 && target && pred && loss && dZ2 && grads && B > 0 && T > 0,
-                 "mg_f0_tail_bf16: bad arguments (B=%d T=%d)", B, T);
-    MG_CHECK_ARG(K3 == TAIL_K && ldh >= TAIL_K && ldh % 8 == 0, "mg_f0_tail_bf16: needs a 128-wide hidden layer (K3=%d ldh=%d)", K3, ldh);
-    MG_CHECK_ARG((((uintptr_t)H2 | (uintptr_t)dZ2) % 16) == 0, "mg_f0_tail_bf16: H2 / dZ2 must be 16-byte aligned");
-    const int64_t M = (int64_t)B * T;
+static int f0_tail_launch(const char* name, const uint16_t* H2, int ldh, int K3, const float* W3, const float* b3, const float* W4,
+                          const float* b4, const float* target, const int64_t* seq_len, const float* row_weight, int64_t M, int B, int T,
+                          float grad_scale, float* pred, float* loss, uint16_t* dZ2, float* grads, int accumulate, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+    MG_CHECK_ARG(H2 && W3 && b3 && W4 && b4 && target && pred && loss && dZ2 && grads && M > 0, "%s: bad arguments (M=%lld)", name, (long long)M);
+    MG_CHECK_ARG(K3 == TAIL_K && ldh >= TAIL_K && ldh % 8 == 0, "%s: needs a 128-wide hidden layer (K3=%d ldh=%d)", name, K3, ldh);
+    MG_CHECK_ARG((((uintptr_t)H2 | (uintptr_t)dZ2) % 16) == 0, "%s: H2 / dZ2 must be 16-byte aligned", name);
     if (!workspace || workspace_bytes < mg_f0_tail_workspace_bytes(M)) {
-        mg_set_error("mg_f0_tail_bf16: workspace of %zu bytes needed, got %zu", mg_f0_tail_workspace_bytes(M), workspace_bytes);
+        mg_set_error("%s: workspace of %zu bytes needed, got %zu", name, mg_f0_tail_workspace_bytes(M), workspace_bytes);
         return MG_EWORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
     const int blocks = tail_blocks(M);
     float* slab = (float*)workspace;
     hipLaunchKernelGGL(f0_tail_kernel, dim3(blocks), dim3(256), 0, st, H2, ldh, W3, b3, W4, b4, target, seq_len, M, B, T, grad_scale,
-                       pred, dZ2, slab);
-    MG_CHECK_LAUNCH("mg_f0_tail_bf16/main");
+                       pred, dZ2, slab, row_weight);
+    MG_CHECK_LAUNCH(name);
     // grads = [dW3 (32*128) | db3 (32) | dW4 (32) | db4 (1)]; the loss is the last slab entry
     const int n_grads = TAIL_SLAB - 1;
     if (loss == grads + n_grads && !accumulate) {
@@ -299,8 +309,26 @@ int mg_f0_tail_bf16(const uint16_t* H2, int ldh, int K3, const float* W3, const 
         mg_launch_slab_reduce(slab, n_grads, TAIL_SLAB, blocks, grads, accumulate, st);
         mg_launch_slab_reduce(slab + (TAIL_SLAB - 1), 1, TAIL_SLAB, blocks, loss, 0, st);
     }
-    MG_CHECK_LAUNCH("mg_f0_tail_bf16/reduce");
+    MG_CHECK_LAUNCH(name);
     return MG_OK;
+}
+
+int mg_f0_tail_bf16(const uint16_t* H2, int ldh, int K3, const float* W3, const float* b3, const float* W4, const float* b4,
+                    const float* target, const int64_t* seq_len, int B, int T, float grad_scale, float* pred, float* loss,
+                    uint16_t* dZ2, float* grads, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    MG_CHECK_ARG(B > 0 && T > 0, "mg_f0_tail_bf16: bad arguments (B=%d T=%d)", B, T);
+    return f0_tail_launch("mg_f0_tail_bf16", H2, ldh, K3, W3, b3, W4, b4, target, seq_len, nullptr, (int64_t)B * T, B, T, grad_scale, pred,
+                          loss, dZ2, grads, accumulate, workspace, workspace_bytes, stream);
+}
+
+// The same tail on M rows that each stand for a GROUP of frames with one shared input row (the phone-rate step, csrc/phone_rate.hip):
+// loss = sum_m row_weight[m] (pred[m] - target[m])^2 and its backward; target / row_weight f32 [M] from mg_phone_target_stats.
+int mg_f0_tail_rows_bf16(const uint16_t* H2, int ldh, int K3, const float* W3, const float* b3, const float* W4, const float* b4,
+                         const float* target, const float* row_weight, int64_t M, float grad_scale, float* pred, float* loss,
+                         uint16_t* dZ2, float* grads, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    MG_CHECK_ARG(row_weight, "mg_f0_tail_rows_bf16: row_weight is null");
+    return f0_tail_launch("mg_f0_tail_rows_bf16", H2, ldh, K3, W3, b3, W4, b4, target, nullptr, row_weight, M, 1, (int)(M < 2147483647LL ? M : 1),
+                          grad_scale, pred, loss, dZ2, grads, accumulate, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

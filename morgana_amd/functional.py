@@ -216,25 +216,51 @@ class LinearStackMSEFn(torch.autograd.Function):
                 rows.numel() if rows is not None else x2d.shape[0], m))
         lead = n_layers - 2
         w_bf, w_t = ops.cast_params_bf16(weights[:lead], want_t=tuple(range(1, lead)))
-        # phone-rate first layer, table form (csrc/phone_rate.hip): H1 = sigmoid(X W0^T + b0) is computed once per phone (the
-        # extra zero rows behind the table give sigmoid(b0), the activation of padding frames) and layer 2 gathers its rows
+        # Phone-rate step (csrc/phone_rate.hip).  The stack's input is upsample_to_repetitions(lab, dur): every phone row repeated.
+        # Linear and Sigmoid commute with repeating rows, and the README model has no frame-level input, so EVERY layer's output is
+        # constant over a phone's frames: the layers run once per phone row (plus extra zero rows = what padding frames gather),
+        # the prediction is repeated instead of the input, and the masked MSE over a phone's frames reduces exactly to
+        #     sum_f w_f (p - y_f)^2 = W (p - ybar)^2 + const        (W, ybar, const from the targets alone: mg_phone_target_stats)
+        # whose gradient the fused tail forms per phone row.
         n_table = x2d.shape[0]
         phone_rate = (rows is not None and lead == 2
                       and ops.phone_rate_table_ok(n_table, m, weights[0].shape[0], weights[1].shape[0], acts[0]))
         ctx.phone_rate = phone_rate
-        ctx.seg = None
         if phone_rate:
-            ctx.seg, rows = ops.segment_bounds(rows, n_table, pad_row=n_table)
-        a = ops.cast_pad_bf16(x2d, extra_rows=ops.PHONE_RATE_EXTRA if phone_rate else 0)
+            extra = ops.PHONE_RATE_EXTRA
+            seg, rows = ops.segment_bounds(rows, n_table, pad_row=n_table)
+            a0 = ops.cast_pad_bf16(x2d, extra_rows=extra)
+            n_rows = a0.shape[0]
+            hidden, a = [], a0
+            for i in range(lead):
+                n, k = weights[i].shape
+                a = ops.linear_fwd_bf16(a, None, n_rows, k, w_bf[i], biases[i], n, acts[i])
+                hidden.append(a)
+            sizes = [p.numel() for p in params]
+            offsets = [0]
+            for sz in sizes[:-1]:
+                offsets.append(offsets[-1] + sz)
+            flat = torch.empty(sum(sizes) + 1, dtype=torch.float32, device=x2d.device)
+            ybar, weight, const = ops.phone_target_stats(target.reshape(-1), rows, seg, seq_len, b, t, n_table, extra)
+            pred_rows, loss, dz2 = ops.f0_tail_rows(hidden[-1], weights[lead], biases[lead], weights[lead + 1], biases[lead + 1],
+                                                    ybar, weight, flat[offsets[2 * lead]:])
+            loss = loss + const
+            pred = ops.expand_column(pred_rows, rows).view(b, t, 1)
+            ctx.acts, ctx.m, ctx.lead = acts, m, lead
+            ctx.dims = [(w.shape[0], w.shape[1]) for w in weights]
+            ctx.offsets = offsets
+            ctx.params = list(params)
+            ctx.save_for_backward(a0, rows, dz2, flat, *hidden[:-1], *[wt for wt in w_t if wt is not None])
+            ctx.mark_non_differentiable(pred)
+            ctx.set_materialize_grads(False)
+            return loss, pred
+        a = ops.cast_pad_bf16(x2d)
         a0, r = a, rows
         hidden = []
         for i in range(lead):
             n, k = weights[i].shape
-            if i == 0 and phone_rate:
-                a = ops.linear_fwd_bf16(a, None, a.shape[0], k, w_bf[0], biases[0], n, acts[0])     # (R + extra, n0) table
-            else:
-                a = ops.linear_fwd_bf16(a, r, m, k, w_bf[i], biases[i], n, acts[i])
-                r = None
+            a = ops.linear_fwd_bf16(a, r, m, k, w_bf[i], biases[i], n, acts[i])
+            r = None
             hidden.append(a)
         sizes = [p.numel() for p in params]
         offsets = [0]
@@ -267,15 +293,13 @@ class LinearStackMSEFn(torch.autograd.Function):
                     flat[ctx.offsets[2 * i + 1]:ctx.offsets[2 * i + 1] + n_])
 
         if ctx.phone_rate:
-            # Layer 0's activation is constant over the frames of a phone, so below dZ_1 everything runs at phone rate:
-            #   S = per-phone sums of dZ_1 (csrc/phone_rate.hip; padding frames -> the extra rows, whose table rows are sigmoid(b_0))
-            #   dW_1 = S^T H_table,   dZ_0(phone) = (S W_1) * H_table (1 - H_table),   dW_0 = dZ_0(phone)^T X_phone
+            # g is dL/dZ_1 per TABLE row already (the tail ran on phone rows with the frames' summed loss weights), so the remaining
+            # backward is the ordinary chain on R + extra rows:  dW_1 = g^T H_table,  dZ_0 = (g W_1) * H (1 - H),  dW_0 = dZ_0^T X
             (n1, k1), (n0, k0) = ctx.dims[1], ctx.dims[0]
             table = hidden[0]
-            sums = ops.segment_sum(g, rows, ctx.seg, table.shape[0] - ops.PHONE_RATE_EXTRA, n1)
             ow, ob = grad_slots(1)
-            ops.linear_wgrad_bf16(sums, table, None, table.shape[0], n1, k1, out_w=ow, out_b=ob)
-            dz0 = ops.linear_dgrad_bf16(sums, table.shape[0], n1, w_t[1], k1, table)
+            ops.linear_wgrad_bf16(g, table, None, table.shape[0], n1, k1, out_w=ow, out_b=ob)
+            dz0 = ops.linear_dgrad_bf16(g, table.shape[0], n1, w_t[1], k1, table)
             ow, ob = grad_slots(0)
             ops.linear_wgrad_bf16(dz0, a0, None, table.shape[0], n0, k0, out_w=ow, out_b=ob)
             grads = _deliver_param_grads(ctx.params, flat[:flat.numel() - 1], ctx.offsets, grad_loss)

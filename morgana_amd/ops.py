@@ -406,6 +406,44 @@ def f0_tail(h2, w3, b3, w4, b4, target, seq_len, b, t, grads_out, grad_scale=1.0
     return pred, loss, dz2
 
 
+def f0_tail_rows(h2, w3, b3, w4, b4, target_rows, row_weight, grads_out, grad_scale=1.0):
+    """f0_tail on table rows that each stand for a group of frames (mg_f0_tail_rows_bf16): loss = sum_m w[m] (pred[m] - y[m])^2.
+    Returns (pred (rows,), loss 0-d, dz2 (rows, ld))."""
+    lib = _lib.load()
+    m = h2.shape[0]
+    pred = torch.empty((m,), dtype=torch.float32, device=h2.device)
+    n_grads = 32 * 128 + 32 + 32 + 1
+    loss = grads_out[n_grads] if grads_out.numel() > n_grads else torch.empty((), dtype=torch.float32, device=h2.device)
+    dz2 = torch.empty_like(h2)
+    ws = workspace(lib.mg_f0_tail_workspace_bytes(m), h2.device)
+    _lib.check(lib.mg_f0_tail_rows_bf16(_p(h2), h2.shape[1], w3.shape[1], _p(w3), _p(b3), _p(w4), _p(b4), _p(target_rows), _p(row_weight),
+                                        m, float(grad_scale), _p(pred), _p(loss), _p(dz2), _p(grads_out), 0, _p(ws), ws.numel(),
+                                        _stream()), 'mg_f0_tail_rows_bf16')
+    return pred, loss, dz2
+
+
+def phone_target_stats(target, rows, seg, seq_len, b, t, n_table_rows, extra):
+    """(ybar (R + extra,), weight (R + extra,), loss_const 0-d) of the masked MSE per table row (mg_phone_target_stats)."""
+    lib = _lib.load()
+    target = _require(target, torch.float32, 'targets')
+    stats = torch.empty((2, n_table_rows + extra), dtype=torch.float32, device=target.device)
+    const = torch.empty((), dtype=torch.float32, device=target.device)
+    ws = torch.empty(lib.mg_phone_target_stats_workspace_bytes(n_table_rows, extra), dtype=torch.uint8, device=target.device)
+    _lib.check(lib.mg_phone_target_stats(_p(target), _p(rows), rows.numel(), _p(seg[0]), _p(seg[1]), _p(seq_len), b, t, n_table_rows,
+                                         extra, _p(stats[0]), _p(stats[1]), _p(const), _p(ws), ws.numel(), _stream()),
+               'mg_phone_target_stats')
+    return stats[0], stats[1], const
+
+
+def expand_column(table, rows):
+    """out[f] = table[rows[f]] for a (rows,) f32 table and an int32 map without negative entries (mg_expand_column_f32)."""
+    lib = _lib.load()
+    table = _require(table, torch.float32, 'table')
+    out = torch.empty((rows.numel(),), dtype=torch.float32, device=table.device)
+    _lib.check(lib.mg_expand_column_f32(_p(table), _p(rows), rows.numel(), _p(out), _stream()), 'mg_expand_column_f32')
+    return out
+
+
 def sigmoid(x):
     lib = _lib.load()
     x = _require(x, torch.float32, 'input')

@@ -1503,11 +1503,12 @@ def test_phone_rate_kernels_vs_numpy(bf16):
 
 
 def test_phone_rate_first_layer_equals_frame_rate():
-    """The F0Model step (bf16 mode) on a ragged batch (padding frames present) with the first Linear run once per phone and
-    everything below dZ2 at phone rate against the same step with every product at frame rate (MORGANA_PHONE_RATE=0, the
-    reference's order of operations): prediction and loss are EQUAL - per frame row the same fp32 dot product, bias add, sigmoid and
-    bf16 rounding, then the same kernels; every gradient within 2e-2 relative L2 (the per-phone sums regroup the same bf16 frame
-    gradients and are rounded to bf16 once more before the weight-gradient GEMMs)."""
+    """The F0Model step (bf16 mode) on a ragged batch (padding frames present) run at phone rate - every layer once per phone row, the
+    prediction repeated instead of the input, the masked MSE of a phone's frames reduced to W (p - ybar)^2 + const - against the same
+    step with every product at frame rate (MORGANA_PHONE_RATE=0, the reference's order of operations): the prediction is EQUAL (per
+    row the same fp32 dot products, bias adds, sigmoids and bf16 roundings in the same kernels), the loss agrees to 1e-5 (the same
+    squared errors, grouped by phone) and every gradient within 2e-2 relative L2 (frame gradients are summed before instead of after
+    the bf16 roundings of the backward chain)."""
     from morgana_amd import ops
     feats = data.to_device(synthetic.make_batch(24, (150, 400), seed=5), DEV)
 
@@ -1524,7 +1525,7 @@ def test_phone_rate_first_layer_equals_frame_rate():
 
     loss_p, pred_p, grads_p = run(True)
     loss_f, pred_f, grads_f = run(False)
-    assert loss_p == loss_f
+    np.testing.assert_allclose(loss_p, loss_f, rtol=1e-5)
     np.testing.assert_array_equal(pred_p, pred_f)
     for name in grads_f:
         assert rel_err(grads_p[name], grads_f[name]) < 2e-2, name
