@@ -82,28 +82,29 @@ def roofline_f0(features, model, precision):
     kernels = []
     bound = {}
     if precision == 'bf16' and ops.phone_rate_table_ok(b * p, m, n1, n2, ops.ACT_SIGMOID):
-        # the step as LinearStackMSEFn runs it (phone-rate first layer, table form): layer 1 once per phone, layer 2 gathering the
-        # per-phone activation table, everything below dZ2 at phone rate after one segment sum
+        # the step as LinearStackMSEFn runs it (whole stack at phone rate): every layer on the B*P phone rows + the extra zero rows,
+        # the masked MSE reduced per phone, the backward chain on the same rows
         extra = ops.PHONE_RATE_EXTRA
         r_tab = b * p + extra
         seg, rows_p = ops.segment_bounds(rows, b * p, pad_row=b * p)
         tab = ops.cast_pad_bf16(lab.view(b * p, k), extra_rows=extra)
         (w1b, w2b), (_, w2t) = ops.cast_params_bf16([w1, w2], want_t=(1,))
         h_tab = ops.linear_fwd_bf16(tab, None, r_tab, k, w1b, b1, n1, ops.ACT_SIGMOID)
-        dz2 = (torch.randn(m, ops.pad_ld(n2), device=lab.device) * 0.01).to(torch.bfloat16)
-        sums = ops.segment_sum(dz2, rows_p, seg, b * p, n2)
-        dz1 = ops.linear_dgrad_bf16(sums, r_tab, n2, w2t, n1, h_tab)
+        dz2 = (torch.randn(r_tab, ops.pad_ld(n2), device=lab.device) * 0.01).to(torch.bfloat16)
+        dz1 = ops.linear_dgrad_bf16(dz2, r_tab, n2, w2t, n1, h_tab)
+        target = features['normalised_lf0'].reshape(-1)
+        seq_len = features['n_frames']
         kernels.append(('gemm_nt_persist_kernel<256>: layer-1 forward at phone rate (%d rows, 600->512 + bias + sigmoid)' % r_tab,
                         2.0 * r_tab * k * n1, lambda: ops.linear_fwd_bf16(tab, None, r_tab, k, w1b, b1, n1, ops.ACT_SIGMOID)))
-        kernels.append(('gemm_nt_persist_kernel<128>: layer-2 forward, rows gathered from the per-phone table (512->128 + bias + sigmoid)',
-                        2.0 * m * n1 * n2, lambda: ops.linear_fwd_bf16(h_tab, rows_p, m, n1, w2b, b2, n2, ops.ACT_SIGMOID)))
-        kernels.append(('segment_sum_kernel: per-phone sums of dZ2 (reads M x 128 bf16 once)', 0.0,
-                        lambda: ops.segment_sum(dz2, rows_p, seg, b * p, n2)))
-        bound['segment_sum_kernel'] = ('hbm', (m + r_tab) * ops.pad_ld(n2) * 2.0)
-        kernels.append(('wgrad_big_kernel<8>: layer-2 wgrad at phone rate (sums^T table)', 2.0 * r_tab * n1 * n2,
-                        lambda: ops.linear_wgrad_bf16(sums, h_tab, None, r_tab, n2, n1)))
+        kernels.append(('gemm_nt_persist_kernel<128>: layer-2 forward at phone rate (512->128 + bias + sigmoid)',
+                        2.0 * r_tab * n1 * n2, lambda: ops.linear_fwd_bf16(h_tab, None, r_tab, n1, w2b, b2, n2, ops.ACT_SIGMOID)))
+        kernels.append(('phone_target_stats_kernel: per-phone weight / mean target / constant of the masked MSE (reads the M targets)', 0.0,
+                        lambda: ops.phone_target_stats(target, rows_p, seg, seq_len, b, t, b * p, extra)))
+        bound['phone_target_stats_kernel'] = ('hbm', m * 4.0 * 2 + r_tab * 8.0)
+        kernels.append(('wgrad_big_kernel<8>: layer-2 wgrad at phone rate (dZ2^T table)', 2.0 * r_tab * n1 * n2,
+                        lambda: ops.linear_wgrad_bf16(dz2, h_tab, None, r_tab, n2, n1)))
         kernels.append(('gemm_nt_big_kernel<256>: layer-2 dgrad + sigmoid-grad at phone rate', 2.0 * r_tab * n1 * n2,
-                        lambda: ops.linear_dgrad_bf16(sums, r_tab, n2, w2t, n1, h_tab)))
+                        lambda: ops.linear_dgrad_bf16(dz2, r_tab, n2, w2t, n1, h_tab)))
         kernels.append(('wgrad_big_kernel<10>: layer-1 wgrad at phone rate (dZ1^T lab)', 2.0 * r_tab * k * n1,
                         lambda: ops.linear_wgrad_bf16(dz1, tab, None, r_tab, n1, k)))
         peak = MFMA_BF16_PEAK_TFLOPS
@@ -419,16 +420,16 @@ def main():
             result['step_algorithmic_tflops'] = round(step_tflops, 2)
             result['step_frac_of_mfma_peak'] = round(step_tflops / peak, 4)
             # step_algorithmic_* prices the REFERENCE's algorithm (every product at frame rate).  With the
-            # phone-rate first layer the kernels multiply less: layer 1 and everything below dZ2 run on B*P (+ pad) rows.
+            # phone-rate step the kernels multiply less: every layer runs on the B*P (+ pad) phone rows.
             lab_shape = feats_np['normalised_lab'].shape
             r_tab = lab_shape[0] * lab_shape[1] + ops.PHONE_RATE_EXTRA
             if args.precision == 'bf16' and ops.phone_rate_table_ok(r_tab - ops.PHONE_RATE_EXTRA, frames_per_step, 512, 128,
                                                                     ops.ACT_SIGMOID):
-                executed = (2 * 2.0 * r_tab * lab_shape[2] * 512 + 2 * 2.0 * r_tab * 512 * 128
-                            + 2.0 * frames_per_step * 512 * 128 + 3 * 2.0 * frames_per_step * (128 * 32 + 32))
+                fwd = lab_shape[2] * 512 + 512 * 128 + 128 * 32 + 32
+                executed = 2.0 * r_tab * (2 * fwd + (512 * 128 + 128 * 32 + 32))      # forward + wgrad of 4 layers, dgrad of layers 2-4
                 result['step_executed_tflops'] = round(executed / (ms_per_step * 1e-3) / 1e12, 2)
                 result['flops_note'] = ('step_algorithmic_tflops counts the reference algorithm (all products at frame rate); the '
-                                        'phone-rate first layer executes %.1f GFLOP per step instead of %.1f'
+                                        'phone-rate step executes %.1f GFLOP per step instead of %.1f'
                                         % (executed / 1e9, F0_FLOPS_PER_FRAME * frames_per_step / 1e9))
     if rank == 0 and args.config == 'c2' and not args.no_roofline:
         result['roofline'] = roofline_f0(features, model, args.precision)

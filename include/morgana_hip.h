@@ -223,6 +223,9 @@ int mg_linear_wgrad_f32(const float* dY, const float* A, int lda, const int32_t*
 /*  mg_expand_column_f32  out[f] = table[rows[f]] for a one-column f32 table (the per-phone prediction repeated to frames); rows >= 0. */
 int mg_expand_column_f32(const float* table, const int32_t* rows, int64_t M, float* out, void* stream);
 size_t mg_phone_target_stats_workspace_bytes(int R, int extra);
+/* loss_const may be NULL: then mg_phone_loss_const_add(workspace, R, extra, loss) adds the constant to a loss in place later on
+ * (the workspace must be left untouched in between). */
+int mg_phone_loss_const_add(const void* workspace, int R, int extra, float* loss, void* stream);
 int mg_phone_target_stats(const float* target, const int32_t* rows, int64_t M, const int32_t* seg_start, const int32_t* seg_end,
                           const int64_t* seq_len, int B, int T, int R, int extra, float* ybar, float* weight, float* loss_const,
                           void* workspace, size_t workspace_bytes, void* stream);

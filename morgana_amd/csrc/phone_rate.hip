@@ -218,7 +218,8 @@ __global__ __launch_bounds__(256) void expand_column_kernel(const float* __restr
     if (f < M) out[f] = table[rows[f]];
 }
 
-__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int n, float* __restrict__ out,
+                                                           int accumulate) {
     __shared__ float red[256];
     float v = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) v += partial[i];
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
         if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = red[0];
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + red[0] : red[0];
 }
 
 extern "C" {
@@ -238,8 +239,9 @@ int mg_segment_bounds(const int32_t* rows, int64_t M, int R, int32_t* seg_start,
     MG_CHECK_ARG(rows && seg_start && seg_end && M > 0 && R > 0 && M < 2147483647LL, "mg_segment_bounds: bad arguments (M=%lld R=%d)",
                  (long long)M, R);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(seg_start, 0, (size_t)R * sizeof(int32_t), st) != hipSuccess ||
-        hipMemsetAsync(seg_end, 0, (size_t)R * sizeof(int32_t), st) != hipSuccess) {
+    const bool joined = seg_end == seg_start + R;                   // one (2, R) buffer: one memset node
+    if (hipMemsetAsync(seg_start, 0, (size_t)R * sizeof(int32_t) * (joined ? 2 : 1), st) != hipSuccess ||
+        (!joined && hipMemsetAsync(seg_end, 0, (size_t)R * sizeof(int32_t), st) != hipSuccess)) {
         mg_set_error("mg_segment_bounds: memset failed");
         return MG_ELAUNCH;
     }
@@ -275,7 +277,7 @@ size_t mg_phone_target_stats_workspace_bytes(int R, int extra) {
 int mg_phone_target_stats(const float* target, const int32_t* rows, int64_t M, const int32_t* seg_start, const int32_t* seg_end,
                           const int64_t* seq_len, int B, int T, int R, int extra, float* ybar, float* weight, float* loss_const,
                           void* workspace, size_t workspace_bytes, void* stream) {
-    MG_CHECK_ARG(target && rows && seg_start && seg_end && ybar && weight && loss_const && B > 0 && T > 0 && R > 0 && extra >= 0 &&
+    MG_CHECK_ARG(target && rows && seg_start && seg_end && ybar && weight && B > 0 && T > 0 && R > 0 && extra >= 0 &&
                      M == (int64_t)B * T,
                  "mg_phone_target_stats: bad arguments (M=%lld B=%d T=%d R=%d extra=%d)", (long long)M, B, T, R, extra);
     if (!workspace || workspace_bytes < mg_phone_target_stats_workspace_bytes(R, extra)) {
@@ -287,8 +289,17 @@ int mg_phone_target_stats(const float* target, const int32_t* rows, int64_t M, c
     const int phone_blocks = (int)mg_ceil_div(R, 16), blocks = phone_blocks + (int)mg_ceil_div(extra, 4);
     hipLaunchKernelGGL(phone_target_stats_kernel, dim3(blocks), dim3(256), 0, st, target, rows, M, seg_start, seg_end, seq_len, B, T, R, extra,
                        phone_blocks, ybar, weight, (float*)workspace);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, blocks, loss_const);
+    if (loss_const) hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, blocks, loss_const, 0);
     MG_CHECK_LAUNCH("mg_phone_target_stats");
+    return MG_OK;
+}
+
+// loss += the constant term of mg_phone_target_stats (its per-block partial sums still in `workspace`), after the tail wrote loss
+int mg_phone_loss_const_add(const void* workspace, int R, int extra, float* loss, void* stream) {
+    MG_CHECK_ARG(workspace && loss && R > 0 && extra >= 0, "mg_phone_loss_const_add: bad arguments");
+    const int blocks = (int)(mg_ceil_div(R, 16) + mg_ceil_div(extra, 4));
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, blocks, loss, 1);
+    MG_CHECK_LAUNCH("mg_phone_loss_const_add");
     return MG_OK;
 }
 

@@ -423,16 +423,21 @@ def f0_tail_rows(h2, w3, b3, w4, b4, target_rows, row_weight, grads_out, grad_sc
 
 
 def phone_target_stats(target, rows, seg, seq_len, b, t, n_table_rows, extra):
-    """(ybar (R + extra,), weight (R + extra,), loss_const 0-d) of the masked MSE per table row (mg_phone_target_stats)."""
+    """(ybar (R + extra,), weight (R + extra,), partials) of the masked MSE per table row (mg_phone_target_stats); ``partials`` holds
+    the per-block sums of the loss's constant term for ``phone_loss_const_add``."""
     lib = _lib.load()
     target = _require(target, torch.float32, 'targets')
     stats = torch.empty((2, n_table_rows + extra), dtype=torch.float32, device=target.device)
-    const = torch.empty((), dtype=torch.float32, device=target.device)
     ws = torch.empty(lib.mg_phone_target_stats_workspace_bytes(n_table_rows, extra), dtype=torch.uint8, device=target.device)
     _lib.check(lib.mg_phone_target_stats(_p(target), _p(rows), rows.numel(), _p(seg[0]), _p(seg[1]), _p(seq_len), b, t, n_table_rows,
-                                         extra, _p(stats[0]), _p(stats[1]), _p(const), _p(ws), ws.numel(), _stream()),
+                                         extra, _p(stats[0]), _p(stats[1]), None, _p(ws), ws.numel(), _stream()),
                'mg_phone_target_stats')
-    return stats[0], stats[1], const
+    return stats[0], stats[1], ws
+
+
+def phone_loss_const_add(partials, n_table_rows, extra, loss):
+    """loss (0-d f32, in place) += the constant term left by phone_target_stats."""
+    _lib.check(_lib.load().mg_phone_loss_const_add(_p(partials), n_table_rows, extra, _p(loss), _stream()), 'mg_phone_loss_const_add')
 
 
 def expand_column(table, rows):
