@@ -484,6 +484,8 @@ int mg_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp
  * scalars[1] = sqrt(1 - beta2^step); mg_adam_scalars forms them on the host exactly as mg_adam_step_f32 does): the launch can be
  * captured in a hipGraph and replayed for every step with only those 8 bytes rewritten. */
 void mg_adam_scalars(float lr, float beta1, float beta2, int64_t step, float* out2);
+/* dst[0..1] = (a, b) in stream order, the values carried as kernel arguments (safe however far the host runs ahead). */
+int mg_store_pair_f32(float* dst, float a, float b, void* stream);
 int mg_adam_step_dev_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1,
                          float beta2, float eps, float weight_decay, const float* scalars, float grad_scale, void* stream);
 /* shadow -= (1 - decay) * (shadow - param). */

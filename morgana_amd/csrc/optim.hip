@@ -189,6 +189,20 @@ int mg_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp
     return MG_OK;
 }
 
+__global__ void store_pair_kernel(float* __restrict__ dst, float a, float b) {
+    dst[0] = a;
+    dst[1] = b;
+}
+
+// dst[0..1] = (a, b) in stream order.  The values travel as kernel arguments, so the host may run any number of steps ahead of the
+// device (an async copy from one reused pinned buffer would be read when the copy executes, not when it was issued).
+int mg_store_pair_f32(float* dst, float a, float b, void* stream) {
+    MG_CHECK_ARG(dst, "mg_store_pair_f32: null destination");
+    hipLaunchKernelGGL(store_pair_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dst, a, b);
+    MG_CHECK_LAUNCH("mg_store_pair_f32");
+    return MG_OK;
+}
+
 // (step_size, bc2_sqrt) of step `step` exactly as mg_adam_step_f32 forms them (host doubles), for mg_adam_step_dev_f32
 void mg_adam_scalars(float lr, float beta1, float beta2, int64_t step, float* out2) {
     const double bc1 = 1.0 - pow((double)beta1, (double)step);

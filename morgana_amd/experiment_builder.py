@@ -24,7 +24,7 @@ from .optim import Adam
 class ExperimentBuilder(object):
     def __init__(self, model_class, model_kwargs=None, learning_rate=0.01, weight_decay=0., lr_schedule_name='constant',
                  lr_schedule_kwargs=None, ema_decay=0., device='cuda:0', start_epoch=1, end_epoch=50,
-                 experiment_dir=None, model_checkpoint_interval=1, checkpoint_path=None, **unused):
+                 experiment_dir=None, model_checkpoint_interval=1, checkpoint_path=None, use_graphs=False, **unused):
         self.model_class = model_class
         self.model_kwargs = model_kwargs or {}
         self.learning_rate = learning_rate
@@ -39,6 +39,8 @@ class ExperimentBuilder(object):
         self.experiment_dir = experiment_dir
         self.model_checkpoint_interval = model_checkpoint_interval
         self.analysis_kwargs = {}
+        self.use_graphs = use_graphs          # replay repeated batch shapes as HIP graphs (morgana_amd/graphs.py); off = eager launches
+        self._graph_cache = None
         self._lr_schedule = lr_schedules.init_lr_schedule(lr_schedule_name, **self.lr_schedule_kwargs)
 
         self.model = self.build_model(model_class, self.model_kwargs, checkpoint_path)      # :267, :386-396
@@ -69,10 +71,17 @@ class ExperimentBuilder(object):
         for i, features in enumerate(data_loader):
             self.model.step = (self.epoch - 1) * n_batches + i + 1
 
-            optimizer.zero_grad()                                                # :468
-            batch_loss, output_features = self.model(features)                   # :471
-            F_hip.backward(batch_loss)                                           # :473 (loss.backward(), cached unit gradient)
-            optimizer.step()                                                     # :474
+            if self.use_graphs:
+                # the same four calls, captured once per batch shape and replayed (graphs.GraphedStepCache)
+                if self._graph_cache is None or self._graph_cache.optimizer is not optimizer:
+                    from . import graphs
+                    self._graph_cache = graphs.GraphedStepCache(self.model, optimizer)
+                batch_loss, output_features = self._graph_cache.step(features)
+            else:
+                optimizer.zero_grad()                                            # :468
+                batch_loss, output_features = self.model(features)               # :471
+                F_hip.backward(batch_loss)                                       # :473 (loss.backward(), cached unit gradient)
+                optimizer.step()                                                 # :474
 
             if lr_schedule is not None and self.lr_schedule_name in lr_schedules.BATCH_LR_SCHEDULES:
                 lr_schedule.step()                                               # :477-478

@@ -25,12 +25,13 @@ class GraphedTrainStep(object):
         self.loss = None
         self.output = None
         self._multi = optimizer._world() > 1
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):                    # allocator and workspace warm-up, off the capture
-                self._eager_step()
-        torch.cuda.current_stream().wait_stream(side)
+        if warmup:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):                # allocator and workspace warm-up, off the capture; these ARE training steps
+                    self._eager_step()
+            torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._fwd_bwd = torch.cuda.CUDAGraph()
         self.optimizer.prepare_capture()               # capture records the launches, it does not run them
@@ -71,3 +72,42 @@ class GraphedTrainStep(object):
             self._update.replay()
         self.steps_done += 1
         return self.loss
+
+
+class GraphedStepCache(object):
+    """Graph replay inside a training loop whose batches repeat a few shapes (``ExperimentBuilder(use_graphs=True)``).
+
+    A batch whose (name, shape, dtype) signature is new runs eagerly - an ordinary training step, which also warms up allocator and
+    workspaces for that shape; the second batch of a signature is captured into static copies of its tensors (capture runs
+    nothing) and replayed, and every later one is copied into those buffers and replayed.  No step is ever run twice or skipped, so
+    the loop trains exactly as the eager loop does (bit-identical, tests/test_gpu_parity.py)."""
+
+    def __init__(self, model, optimizer, max_graphs=8):
+        self.model, self.optimizer, self.max_graphs = model, optimizer, max_graphs
+        self._seen = set()
+        self._steps = {}
+
+    @staticmethod
+    def signature(features):
+        return tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in features.items() if isinstance(v, torch.Tensor)))
+
+    def step(self, features):
+        """zero_grad, forward, backward, optimizer step on ``features``; returns (loss, output_features)."""
+        key = self.signature(features)
+        graphed = self._steps.get(key)
+        if graphed is None and key in self._seen and len(self._steps) < self.max_graphs:
+            static = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in features.items()}
+            graphed = self._steps[key] = GraphedTrainStep(self.model, self.optimizer, static, warmup=0)
+        elif graphed is not None:
+            graphed.load(features)
+        if graphed is not None:
+            for k, v in features.items():              # non-tensor entries (utterance names) follow the batch
+                if not isinstance(v, torch.Tensor):
+                    graphed.features[k] = v
+            return graphed().clone(), graphed.output      # the loss buffer is rewritten by the next replay: hand out a copy
+        self._seen.add(key)
+        self.optimizer.zero_grad()
+        loss, output = self.model(features)
+        functional.backward(loss)
+        self.optimizer.step()
+        return loss, output

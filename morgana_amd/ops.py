@@ -769,6 +769,11 @@ def adam_scalars(lr, betas, step):
     return out[0], out[1]
 
 
+def store_pair(dst, a, b):
+    """dst[0:2] = (a, b) in stream order; the values are kernel arguments, not a host buffer read later."""
+    _lib.check(_lib.load().mg_store_pair_f32(_p(dst), float(a), float(b), _stream()), 'mg_store_pair_f32')
+
+
 def adam_step_dev(param, grad, exp_avg, exp_avg_sq, betas, eps, weight_decay, scalars, grad_scale=1.0):
     """adam_step with (step_size, bc2_sqrt) read from the 2-float device tensor ``scalars`` (capturable in a HIP graph)."""
     lib = _lib.load()

@@ -70,8 +70,7 @@ class Adam(torch.optim.Optimizer):
     def _scalar_buffers(self, flat):
         if 'scalars' not in flat:
             flat['scalars'] = torch.zeros(2, dtype=torch.float32, device=flat['param'].device)
-            flat['scalars_host'] = torch.zeros(2, dtype=torch.float32).pin_memory()
-        return flat['scalars'], flat['scalars_host']
+        return flat['scalars']
 
     def exchange_gradients(self):
         """The step's one gradient all-reduce (no-op on one rank); ``step`` calls it, a graphed step calls it between its graphs."""
@@ -86,15 +85,15 @@ class Adam(torch.optim.Optimizer):
                 self._scalar_buffers(flat)
 
     def advance(self):
-        """Count one step and stage its (step_size, bc2_sqrt) for the captured update: an 8-byte async copy per group, issued on
-        the current stream ahead of the graph replay that consumes it."""
+        """Count one step and stage its (step_size, bc2_sqrt) for the captured update: one 1-thread launch per group on the current
+        stream ahead of the graph replay that consumes it, the two values carried as kernel arguments (the host runs many replays
+        ahead of the device; a copy from a reused host buffer would be read too late)."""
         for group, flat in zip(self.param_groups, self._flat):
             if flat is None:
                 continue
             flat['step'] += 1
-            dev, host = self._scalar_buffers(flat)
-            host[0], host[1] = ops.adam_scalars(group['lr'], group['betas'], flat['step'])
-            dev.copy_(host, non_blocking=True)
+            step_size, bc2_sqrt = ops.adam_scalars(group['lr'], group['betas'], flat['step'])
+            ops.store_pair(self._scalar_buffers(flat), step_size, bc2_sqrt)
 
     @torch.no_grad()
     def step_captured(self):
@@ -103,7 +102,7 @@ class Adam(torch.optim.Optimizer):
         for group, flat in zip(self.param_groups, self._flat):
             if flat is None:
                 continue
-            dev, _ = self._scalar_buffers(flat)
+            dev = self._scalar_buffers(flat)
             ops.adam_step_dev(flat['param'], flat['grad'], flat['exp_avg'], flat['exp_avg_sq'], group['betas'], group['eps'],
                               group['weight_decay'], dev, 1.0 / world)
 

@@ -1530,6 +1530,28 @@ def test_phone_rate_first_layer_equals_frame_rate():
     for name in grads_f:
         assert rel_err(grads_p[name], grads_f[name]) < 2e-2, name
 
+    # no seq_len: every frame counts, padding frames included (their prediction is the stack's value on a zero row) - the extra
+    # table rows carry their loss terms and gradients
+    def run_unmasked(phone_rate):
+        old = ops.PHONE_RATE
+        ops.PHONE_RATE = phone_rate
+        try:
+            model = _load_state(models.F0Model(precision='bf16').to(DEV), synthetic.f0_model_state())
+            frames = utils.upsample_to_repetitions(feats['normalised_lab'], feats['dur'], max_len=feats['normalised_lf0'].shape[1],
+                                                   fused=True)
+            loss, pred = model.layers.forward_mse(frames, feats['normalised_lf0'], seq_len=None)
+            loss.backward()
+            return loss.item(), pred.detach().cpu().numpy(), {k: v.grad.cpu().numpy() for k, v in model.named_parameters()}
+        finally:
+            ops.PHONE_RATE = old
+
+    loss_p, pred_p, grads_p = run_unmasked(True)
+    loss_f, pred_f, grads_f = run_unmasked(False)
+    np.testing.assert_allclose(loss_p, loss_f, rtol=1e-5)
+    np.testing.assert_array_equal(pred_p, pred_f)
+    for name in grads_f:
+        assert rel_err(grads_p[name], grads_f[name]) < 2e-2, name
+
 
 def test_graphed_train_step_equals_eager_steps():
     """graphs.GraphedTrainStep (zero_grad, forward, backward and the Adam update captured once as a HIP graph and replayed; Adam's
@@ -1556,11 +1578,11 @@ def test_graphed_train_step_equals_eager_steps():
     step = graphs.GraphedTrainStep(model_g, opt_g, feats, warmup=3)          # 3 eager steps, then the capture (which runs nothing)
     assert step.steps_done == 3
     losses_g = []
-    for i in range(3, 9):
+    for i in range(3, 9):                        # no host synchronisation inside the loop: the host runs ahead of the replays
         if i == 7:
             opt_g.param_groups[0]['lr'] = 0.003
-        losses_g.append(step().item())
-    assert losses_g == losses_e[3:]
+        losses_g.append(step().clone())
+    assert [v.item() for v in losses_g] == losses_e[3:]
     flat_e, flat_g = opt_e.flat_buffers(), opt_g.flat_buffers()
     assert flat_e['step'] == flat_g['step'] == 9
     for key in ('param', 'exp_avg', 'exp_avg_sq'):
@@ -1582,3 +1604,27 @@ def test_dgrad_with_table_gathered_sigmoid_outputs():
     assert torch.equal(got, want)
     with pytest.raises(ValueError):
         ops.linear_dgrad_gathered_bf16(dy[:100], 100, n, wt, k, table, rows[:100])         # below the wide-tile kernel's sizes
+
+
+def test_experiment_builder_graph_replay_equals_eager_loop():
+    """ExperimentBuilder(use_graphs=True): batches of a repeated shape are replayed as HIP graphs (first occurrence eager, second
+    captured, later ones copied into the captured buffers), a batch of another shape in between runs eagerly - against the eager loop
+    on the same batches: epoch losses and final parameters EQUAL, with a per-batch Noam learning-rate schedule."""
+    from morgana_amd import experiment_builder
+    batches = [data.to_device(synthetic.make_batch(16, 120, seed=40 + i), DEV) for i in range(5)]
+    batches.insert(3, data.to_device(synthetic.make_batch(8, 90, seed=77), DEV))
+
+    def train(use_graphs):
+        torch.manual_seed(3)
+        builder = experiment_builder.ExperimentBuilder(models.F0Model, dict(precision='bf16'), learning_rate=0.01,
+                                                       lr_schedule_name='noam', lr_schedule_kwargs=dict(warmup_steps=4),
+                                                       device=DEV, end_epoch=2, use_graphs=use_graphs)
+        _load_state(builder.model, synthetic.f0_model_state())
+        history = builder.run_train(batches)
+        return history, {k: v.detach().clone() for k, v in builder.model.named_parameters()}
+
+    hist_e, params_e = train(False)
+    hist_g, params_g = train(True)
+    assert hist_g == hist_e
+    for name in params_e:
+        assert torch.equal(params_g[name], params_e[name]), name
