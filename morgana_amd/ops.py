@@ -13,6 +13,7 @@ ACT_NONE, ACT_SIGMOID = 0, 1
 NORM_MVN, DENORM_MVN, NORM_MINMAX, DENORM_MINMAX = 0, 1, 2, 3
 
 _workspaces = {}
+_retired = []
 
 
 def _p(t):
@@ -35,10 +36,13 @@ def _require(t, dtype, name):
 
 
 def workspace(nbytes, device):
-    """One grow-only scratch buffer per device; all kernels of a step run on one stream, so it is shared."""
+    """One grow-only scratch buffer per device; all kernels of a step run on one stream, so it is shared.  A buffer that is
+    outgrown is kept alive (``_retired``): a captured HIP graph (morgana_amd/graphs.py) may still launch kernels that point at it."""
     key = (device.index if device.index is not None else torch.cuda.current_device())
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _retired.append(buf)
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = buf
     return buf
