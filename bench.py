@@ -392,6 +392,32 @@ def main():
     ops.check_persistent_status()        # raises if a persistent recurrent kernel timed out (results would be invalid)
     final_loss = float(distributed.mean_scalar(loss.detach()).item())
 
+    # C2, one rank: the same model and batch with every product at frame rate (the reference's order of operations,
+    # MORGANA_PHONE_RATE=0), timed the same way right after - reported next to the headline value, never as it
+    frame_rate = None
+    if args.config == 'c2' and world == 1 and args.precision == 'bf16' and ops.PHONE_RATE and not args.no_graph:
+        try:
+            ops.PHONE_RATE = False
+            from morgana_amd import graphs
+            fr_model = models.F0Model(precision=args.precision).to(dev)
+            fr_model.load_state_dict(model.state_dict())
+            fr_step = graphs.GraphedTrainStep(fr_model, optim.Adam(fr_model.parameters(), lr=0.01), features)
+            for _ in range(args.warmup):
+                fr_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                fr_step()
+            torch.cuda.synchronize()
+            fr_ms = (time.perf_counter() - t1) / args.steps * 1e3
+            frame_rate = {'ms_per_step': round(fr_ms, 4), 'value': round(frames_per_step / (fr_ms * 1e-3), 1), 'unit': 'frames/s',
+                          'what': 'MORGANA_PHONE_RATE=0: every product on B*T frame rows (gather-fused layer-1 GEMM, fused dgrad+wgrad), '
+                                  'same graph replay'}
+        except Exception as exc:
+            frame_rate = {'error': str(exc).splitlines()[0][:200]}
+        finally:
+            ops.PHONE_RATE = True
+
     result = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -414,6 +440,8 @@ def main():
         }
         if graph_note is not None:
             result['config']['launch'] = graph_note
+        if frame_rate is not None:
+            result['frame_rate_order'] = frame_rate
         if args.config == 'c2':
             step_tflops = F0_FLOPS_PER_FRAME * frames_per_step / (ms_per_step * 1e-3) / 1e12
             peak = MFMA_BF16_PEAK_TFLOPS if args.precision == 'bf16' else MFMA_F32_PEAK_TFLOPS
