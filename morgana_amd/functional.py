@@ -69,14 +69,17 @@ class LinearStackFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, spec, x2d, rows, *params):
-        acts, precision = spec
+        acts, precision = spec[:2]
+        extra = spec[2] if len(spec) > 2 else 0       # zero rows appended behind x2d (phone-rate tables: what padding frames gather)
         n_layers = len(acts)
         weights = [params[2 * i] for i in range(n_layers)]
         biases = [params[2 * i + 1] for i in range(n_layers)]
         # a bf16 input is an already padded layer-1 operand (ops.gather_concat); anything else must be fp32
         pre_cast = precision == 'bf16' and x2d.dtype == torch.bfloat16
         x2d = ops._require(x2d, torch.bfloat16 if pre_cast else torch.float32, 'input')
-        m = rows.numel() if rows is not None else x2d.shape[0]
+        if extra and (pre_cast or rows is not None or ctx.needs_input_grad[1]):
+            raise ValueError('LinearStackFn: extra zero rows go with a plain fp32 input that needs no gradient')
+        m = rows.numel() if rows is not None else x2d.shape[0] + extra
         ctx.spec, ctx.m = spec, m
         ctx.has_bias = [b is not None for b in biases]
         ctx.dims = [(w.shape[0], w.shape[1]) for w in weights]
@@ -85,6 +88,8 @@ class LinearStackFn(torch.autograd.Function):
             raise ValueError('Linear expects %d input features, got %d' % (k_in, x2d.shape[1]))
         hidden = []
         if precision == 'fp32':
+            if extra:
+                x2d = torch.cat((x2d, x2d.new_zeros((extra, x2d.shape[1]))))
             a, r = x2d, rows
             for i in range(n_layers):
                 w = ops._require(weights[i], torch.float32, 'weight')
@@ -94,7 +99,7 @@ class LinearStackFn(torch.autograd.Function):
             out = a
             ctx.save_for_backward(x2d, rows, *weights, *hidden)
         else:
-            a = x2d if pre_cast else ops.cast_pad_bf16(x2d)
+            a = x2d if pre_cast else ops.cast_pad_bf16(x2d, extra_rows=extra)
             a0, r = a, rows
             for i in range(n_layers):
                 n, k = weights[i].shape
@@ -113,7 +118,7 @@ class LinearStackFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        acts, precision = ctx.spec
+        acts, precision = ctx.spec[:2]
         n_layers = len(acts)
         saved = ctx.saved_tensors
         x_in, rows = saved[0], saved[1]
@@ -351,23 +356,34 @@ def set_recurrence_bf16(enabled):
 
 
 class GRUFn(torch.autograd.Function):
-    """One GRU layer (batch_first) restricted to seq_len[b] steps per item; returns (outputs, h_n)."""
+    """One GRU layer (batch_first) restricted to seq_len[b] steps per item; returns (outputs, h_n).
+
+    With ``rows`` (int32 (B, T), every entry >= 0) and ``seg`` the input is a TABLE ``x`` (rows, I) whose row ``rows[b, t]`` is the
+    input of frame (b, t) - the phone-rate form (csrc/phone_rate.hip): the input projection runs once per table row and its rows
+    are repeated (``mg_gather_rows_f32``); backward sums the gate gradients per table row (``mg_segment_sum``) before the
+    weight-gradient and input-gradient GEMMs, which then run on table rows too."""
 
     @staticmethod
-    def forward(ctx, precision, x, h0, seq_len, w_ih, w_hh, b_ih, b_hh):
+    def forward(ctx, precision, x, h0, seq_len, w_ih, w_hh, b_ih, b_hh, rows=None, seg=None):
         x = ops._require(x, torch.float32, 'inputs')
-        b, t, i_dim = x.shape
         hid = w_hh.shape[1]
-        x2 = x.view(b * t, i_dim)
+        if rows is not None:
+            (b, t), i_dim = rows.shape, x.shape[1]
+            x2, m_in = x, x.shape[0]
+        else:
+            b, t, i_dim = x.shape
+            x2, m_in = x.view(b * t, i_dim), b * t
         if precision == 'fp32':
-            xproj = ops.linear_fwd_f32(x2, None, b * t, w_ih, b_ih, ops.ACT_NONE)
+            xproj = ops.linear_fwd_f32(x2, None, m_in, w_ih, b_ih, ops.ACT_NONE)
             x_saved = x2
         else:
             x_saved = ops.cast_pad_bf16(x2)
-            xproj = ops.linear_fwd_bf16(x_saved, None, b * t, i_dim, ops.cast_pad_bf16(w_ih), b_ih, 3 * hid,
+            xproj = ops.linear_fwd_bf16(x_saved, None, m_in, i_dim, ops.cast_pad_bf16(w_ih), b_ih, 3 * hid,
                                         ops.ACT_NONE, out_f32=True)
             if xproj.shape[1] != 3 * hid:
                 xproj = xproj[:, :3 * hid].contiguous()
+        if rows is not None:
+            xproj = ops.gather_rows(xproj, rows.reshape(-1))          # the repetition, applied to the projected rows
         ctx.bf16_recurrence = precision == 'bf16' and RECURRENCE_BF16 and ops.gru_bf16_ok(hid)
         hstate_bf = None
         if ctx.bf16_recurrence:
@@ -379,12 +395,12 @@ class GRUFn(torch.autograd.Function):
         ctx.precision = precision
         ctx.shape = (b, t, i_dim, hid)
         ctx.has_h0 = h0 is not None
-        ctx.save_for_backward(x_saved, seq_len, w_ih, w_hh, hstate, saved, hstate_bf)
+        ctx.save_for_backward(x_saved, seq_len, w_ih, w_hh, hstate, saved, hstate_bf, rows, seg)
         return out, hstate[:, t].unsqueeze(0).contiguous()
 
     @staticmethod
     def backward(ctx, grad_out, grad_hn):
-        x_saved, seq_len, w_ih, w_hh, hstate, saved, hstate_bf = ctx.saved_tensors
+        x_saved, seq_len, w_ih, w_hh, hstate, saved, hstate_bf, rows, seg = ctx.saved_tensors
         b, t, i_dim, hid = ctx.shape
         g_out = grad_out.contiguous() if grad_out is not None else torch.zeros((b, t, hid), dtype=torch.float32,
                                                                                 device=hstate.device)
@@ -405,25 +421,34 @@ class GRUFn(torch.autograd.Function):
         hs2 = hstate.view(b * (t + 1), hid)
         need_x = ctx.needs_input_grad[1]
         dx = None
+        m_in = m
+        if rows is not None:
+            m_in = x_saved.shape[0]                       # table rows: phone rows + the extra rows of the padding frames
+            n_phone = m_in - ops.PHONE_RATE_EXTRA
         if ctx.precision == 'fp32':
+            if rows is not None:
+                dxp2 = ops.segment_sum(dxp2.contiguous(), rows.reshape(-1), seg, n_phone, 3 * hid)
             dw_ih, db_ih = ops.linear_wgrad_f32(dxp2, x_saved, None, 3 * hid, i_dim)
             dw_hh, db_hh = ops.linear_wgrad_f32(dhp2, hs2, prev_rows, 3 * hid, hid)
             if need_x:
-                dx = ops.linear_dgrad_f32(dxp2, w_ih, None).view(b, t, i_dim)
+                dx = ops.linear_dgrad_f32(dxp2, w_ih, None)
+                dx = dx if rows is not None else dx.view(b, t, i_dim)
         else:
             dxp_bf = dxproj_bf.view(m, 3 * hid) if dxproj_bf is not None else ops.cast_pad_bf16(dxp2)
+            if rows is not None:
+                dxp_bf = ops.segment_sum(dxp_bf, rows.reshape(-1), seg, n_phone, 3 * hid)
             # the bf16 recurrence already wrote the bf16 shadows of dhproj and of the states
             dhp_bf = dhproj_bf.view(m, 3 * hid) if dhproj_bf is not None else ops.cast_pad_bf16(dhp2)
             hs_bf = hstate_bf.view(b * (t + 1), hid) if hstate_bf is not None else ops.cast_pad_bf16(hs2)
-            dw_ih, db_ih = ops.linear_wgrad_bf16(dxp_bf, x_saved, None, m, 3 * hid, i_dim)
+            dw_ih, db_ih = ops.linear_wgrad_bf16(dxp_bf, x_saved, None, m_in, 3 * hid, i_dim)
             dw_hh, db_hh = ops.linear_wgrad_bf16(dhp_bf, hs_bf, prev_rows, m, 3 * hid, hid)
             if need_x:
-                dx = ops.linear_dgrad_bf16(dxp_bf, m, 3 * hid, ops.cast_transpose_bf16(w_ih), i_dim, None,
+                dx = ops.linear_dgrad_bf16(dxp_bf, m_in, 3 * hid, ops.cast_transpose_bf16(w_ih), i_dim, None,
                                            out_f32=True)
                 if dx.shape[1] != i_dim:
                     dx = dx[:, :i_dim].contiguous()
-                dx = dx.view(b, t, i_dim)
-        return (None, dx, dh0.view(1, b, hid) if ctx.has_h0 else None, None, dw_ih, dw_hh, db_ih, db_hh)
+                dx = dx if rows is not None else dx.view(b, t, i_dim)
+        return (None, dx, dh0.view(1, b, hid) if ctx.has_h0 else None, None, dw_ih, dw_hh, db_ih, db_hh, None, None)
 
 
 def lstm_persistent(precision, b, t, hid):

@@ -887,6 +887,12 @@ def phone_rate_table_ok(n_table_rows, m, n0, n1, act):
             and n0 % 128 == 0 and 384 < n0 <= 512 and pad8(n1) % 64 == 0)
 
 
+def phone_rate_gru_ok(n_table_rows, m, width):
+    """Linear / Sigmoid layers between an upsample and a GRU wrapper on the phone rows (utils.PhoneTable): worth it when there are
+    several frames per phone; the table's width must suit mg_segment_sum (multiple of 8)."""
+    return PHONE_RATE and width % 8 == 0 and 2 * (n_table_rows + PHONE_RATE_EXTRA) <= m
+
+
 def linear_dgrad_gathered_bf16(dy, m, n, wt_bf16, k, h_table, h_rows):
     """linear_dgrad_bf16 with the sigmoid outputs read from the per-phone table: dx[f] = (dy[f] W) h (1 - h), h = h_table[h_rows[f]]."""
     lib = _lib.load()

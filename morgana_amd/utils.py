@@ -58,6 +58,26 @@ class UpsampledSequence(object):
         return F_hip.UpsampleFn.apply(self.source, self.dur, self.rows.shape[1])
 
 
+class PhoneTable(object):
+    """Lazy frame-rate tensor whose frames repeat the rows of a TABLE: ``table`` (B*P + extra rows, F) holds one row per phone
+    (the extra rows: what padding frames gather) and ``rows`` (B, T) int32 is the frame -> phone-row map of the upsample (-1 =
+    padding).  Produced by ``SequentialWithRecurrent`` when Linear / Sigmoid layers directly follow an ``UpsampledSequence`` and a
+    GRU wrapper comes next: those layers commute with repeating rows, so they run on the phone rows and the wrapper repeats the
+    rows of ITS input projection instead (``functional.GRUFn`` with ``rows``)."""
+
+    def __init__(self, table, rows, n_phone_rows):
+        self.table, self.rows, self.n_phone_rows = table, rows, n_phone_rows
+        self.shape = (rows.shape[0], rows.shape[1], table.shape[1])
+        self.ndim = 3
+
+    def crop(self, t_out):
+        return self if t_out == self.rows.shape[1] else PhoneTable(self.table, self.rows[:, :t_out].contiguous(), self.n_phone_rows)
+
+    def maps(self):
+        """(frame runs per phone row, map with -1 -> the first extra row) for the current (possibly cropped) frame axis."""
+        return ops.segment_bounds(self.rows.reshape(-1), self.n_phone_rows, pad_row=self.n_phone_rows)
+
+
 class UpsampledConcat(object):
     """Lazy ``torch.cat((upsample_to_repetitions(sequence_feature, repeats), frame_feature), dim=-1)`` - the model input of
     models/RNN_SPSS.py:76-81 and models/f0_test_model.py:78-79.  ``SequentialWithRecurrent`` turns it into the first Linear's
@@ -205,6 +225,10 @@ class RecurrentCuDNNWrapper(nn.Module):
     def _run_gru(self, inputs, hidden, seq_len):
         layer = self.layer
         precision = self.precision or F_hip.get_precision()
+        if isinstance(inputs, PhoneTable):
+            seg, rows = inputs.maps()
+            return F_hip.GRUFn.apply(precision, inputs.table, hidden, seq_len, layer.weight_ih_l0, layer.weight_hh_l0,
+                                     layer.bias_ih_l0, layer.bias_hh_l0, rows.view(inputs.rows.shape), seg)
         return F_hip.GRUFn.apply(precision, inputs, hidden, seq_len, layer.weight_ih_l0, layer.weight_hh_l0,
                                  layer.bias_ih_l0, layer.bias_hh_l0)
 
@@ -229,6 +253,8 @@ class RecurrentCuDNNWrapper(nn.Module):
         if self._hip_gru() or self._hip_lstm():
             seq_len = seq_len if seq_len.dtype == torch.int64 else seq_len.long()
             t_out = int(torch.max(seq_len).item())          # pad_packed_sequence crops to the longest item
+            if isinstance(inputs, PhoneTable):
+                return self._run_gru(inputs.crop(t_out), hidden, seq_len.contiguous())
             if t_out != inputs.shape[1]:
                 inputs = inputs[:, :t_out]
             run = self._run_gru if self._hip_gru() else self._run_lstm
@@ -359,6 +385,20 @@ class SequentialWithRecurrent(nn.Sequential):
             module = modules[i]
             if type(module) is nn.Linear:
                 end, run = self._linear_run(modules, i)
+                nxt = modules[end] if end < len(modules) else None
+                n_src = input.source.shape[0] * input.source.shape[1] if isinstance(input, UpsampledSequence) else 0
+                if (isinstance(input, UpsampledSequence) and isinstance(nxt, RecurrentCuDNNWrapper) and nxt._hip_gru()
+                        and seq_len is not None and ops.phone_rate_gru_ok(n_src, input.rows.numel(), run[-1][0].weight.shape[0])):
+                    # Linear / Sigmoid commute with the row repetition of the upsample: run them on the phone rows (+ zero rows for
+                    # the padding frames) and hand the GRU wrapper a table + row map; it repeats the rows of its own input projection
+                    params = []
+                    for lin, _ in run:
+                        params += [lin.weight, lin.bias]
+                    spec = (tuple(act for _, act in run), precision, ops.PHONE_RATE_EXTRA)
+                    table = F_hip.LinearStackFn.apply(spec, input.source.reshape(-1, input.source.shape[-1]), None, *params)
+                    input = PhoneTable(table, input.rows, n_src)
+                    i = end
+                    continue
                 if isinstance(input, UpsampledSequence):
                     lead, x2d, rows = input.shape[:2], input.source.reshape(-1, input.source.shape[-1]), \
                         input.rows.reshape(-1)

@@ -1628,3 +1628,34 @@ def test_experiment_builder_graph_replay_equals_eager_loop():
     assert hist_g == hist_e
     for name in params_e:
         assert torch.equal(params_g[name], params_e[name]), name
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp32'])
+def test_phone_rate_gru_input_equals_frame_rate(precision):
+    """RNN_SPSS layout (Linear-512 + Sigmoid on the upsampled labels, then GRU-512) with the Linear and the GRU's input projection run
+    once per phone row (utils.PhoneTable, GRUFn with a row map; ragged batch, padding frames present) against the same step with
+    every product at frame rate (MORGANA_PHONE_RATE=0): per row the same GEMM arithmetic, so loss and prediction are EQUAL; gradients
+    within 2e-2 (bf16: the gate gradients are summed per phone before the bf16 GEMMs) / 1e-4 (fp32) relative L2."""
+    from morgana_amd import ops
+    feats = data.to_device(synthetic.make_batch(32, (150, 260), out_dim=80, target_name='mcep', seed=9, frames_per_phone=5.0), DEV)
+
+    def run(phone_rate):
+        old = ops.PHONE_RATE
+        ops.PHONE_RATE = phone_rate
+        try:
+            model = _load_state(models.RNNSPSS(precision=precision).to(DEV), synthetic.rnn_spss_state())
+            loss, out = model(feats)
+            loss.backward()
+            ops.check_persistent_status()
+            return loss.item(), out['pred_norm_mcep'].detach().cpu().numpy(), {k: v.grad.cpu().numpy() for k, v in model.named_parameters()}
+        finally:
+            ops.PHONE_RATE = old
+
+    n_src = feats['normalised_lab'].shape[0] * feats['normalised_lab'].shape[1]
+    assert ops.phone_rate_gru_ok(n_src, feats['normalised_mcep'].shape[0] * feats['normalised_mcep'].shape[1], 512)
+    loss_p, pred_p, grads_p = run(True)
+    loss_f, pred_f, grads_f = run(False)
+    assert loss_p == loss_f
+    np.testing.assert_array_equal(pred_p, pred_f)
+    for name in grads_f:
+        assert rel_err(grads_p[name], grads_f[name]) < (2e-2 if precision == 'bf16' else 1e-4), name
