@@ -48,6 +48,8 @@ def parse_args():
                     help='lstm / f0gru: leave out the MLPG + metrics part of the step (the reference runs it inside predict / loss)')
     ap.add_argument('--no-graph', action='store_true',
                     help='c2: launch every kernel of the step from Python instead of replaying the captured HIP graph')
+    ap.add_argument('--no-compare', action='store_true',
+                    help='c2: skip the extra leg that times the frame-rate order of operations (frame_rate_order in the JSON line)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     return ap.parse_args()
@@ -395,7 +397,8 @@ def main():
     # C2, one rank: the same model and batch with every product at frame rate (the reference's order of operations,
     # MORGANA_PHONE_RATE=0), timed the same way right after - reported next to the headline value, never as it
     frame_rate = None
-    if args.config == 'c2' and world == 1 and args.precision == 'bf16' and ops.PHONE_RATE and not args.no_graph:
+    if (args.config == 'c2' and world == 1 and args.precision == 'bf16' and ops.PHONE_RATE and not args.no_graph
+            and not args.no_compare):
         try:
             ops.PHONE_RATE = False
             from morgana_amd import graphs

@@ -14,10 +14,10 @@ run() {
     if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "step timed out - stopping"; exit $rc; fi
     return 0
 }
-BENCH="python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline ${BENCH_ARGS}"
+BENCH="python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-compare ${BENCH_ARGS}"
 run 600 prof_${TAG}_stats.log rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof_${TAG}_stats" -- $BENCH
-run 600 prof_${TAG}_fetch.log rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$ROOT/gpurun_out/prof_${TAG}_fetch" -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline ${BENCH_ARGS}
-run 600 prof_${TAG}_write.log rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$ROOT/gpurun_out/prof_${TAG}_write" -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline ${BENCH_ARGS}
+run 600 prof_${TAG}_fetch.log rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$ROOT/gpurun_out/prof_${TAG}_fetch" -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-compare ${BENCH_ARGS}
+run 600 prof_${TAG}_write.log rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$ROOT/gpurun_out/prof_${TAG}_write" -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-compare ${BENCH_ARGS}
 cd "$ROOT"
 find gpurun_out/prof_${TAG}_stats gpurun_out/prof_${TAG}_fetch gpurun_out/prof_${TAG}_write -name "*.csv" | head -20
 du -sh gpurun_out
