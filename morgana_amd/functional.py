@@ -164,6 +164,29 @@ class LinearStackFn(torch.autograd.Function):
         return (None, grad_x, None) + tuple(grads)
 
 
+class RepeatTableRowsFn(torch.autograd.Function):
+    """``upsample_to_repetitions`` (morgana/utils.py:175-228) applied AFTER a row-wise stack instead of before it: out[f] =
+    table[rows[f]] for a table of phone rows + extra rows (rows: -1 already mapped to the first extra row).  Backward sums each
+    phone's frames (``mg_segment_sum``; padding frames into the extra rows), so the stack's whole backward runs on table rows."""
+
+    @staticmethod
+    def forward(ctx, table, rows, seg, n_phone_rows):
+        table = ops._require(table, torch.float32, 'table')
+        ctx.save_for_backward(rows, seg)
+        ctx.n_phone_rows, ctx.extra, ctx.width = n_phone_rows, table.shape[0] - n_phone_rows, table.shape[1]
+        return ops.gather_rows(table, rows)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        rows, seg = ctx.saved_tensors
+        g = grad_out.contiguous()
+        width = ctx.width
+        if width % 8 != 0:                       # mg_segment_sum works on 8-column chunks: pad narrow outputs (the 1-wide F0 stream)
+            g = torch.nn.functional.pad(g, (0, 8 - width % 8))
+        sums = ops.segment_sum(g, rows, seg, ctx.n_phone_rows, g.shape[1], extra=ctx.extra)
+        return (sums[:, :width].contiguous() if sums.shape[1] != width else sums), None, None, None
+
+
 def _deliver_param_grads(params, flat, offsets, grad_loss=None):
     """Hand the parameter gradients held in one contiguous buffer `flat` (parameter order) to autograd.
 

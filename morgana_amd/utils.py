@@ -399,6 +399,20 @@ class SequentialWithRecurrent(nn.Sequential):
                     input = PhoneTable(table, input.rows, n_src)
                     i = end
                     continue
+                if (isinstance(input, UpsampledSequence) and end == len(modules)
+                        and ops.phone_rate_gru_ok(n_src, input.rows.numel(), 8)):
+                    # the stack ends in this run and sees nothing but the repeated phone rows: every layer commutes with the
+                    # repetition, so the run works on the phone rows (+ zero rows for padding frames) and its OUTPUT is repeated
+                    params = []
+                    for lin, _ in run:
+                        params += [lin.weight, lin.bias]
+                    spec = (tuple(act for _, act in run), precision, ops.PHONE_RATE_EXTRA)
+                    table = F_hip.LinearStackFn.apply(spec, input.source.reshape(-1, input.source.shape[-1]), None, *params)
+                    seg, rows_mapped = ops.segment_bounds(input.rows.reshape(-1), n_src, pad_row=n_src)
+                    out = F_hip.RepeatTableRowsFn.apply(table, rows_mapped, seg, n_src)
+                    input = out.view(input.shape[0], input.shape[1], out.shape[-1])
+                    i = end
+                    continue
                 if isinstance(input, UpsampledSequence):
                     lead, x2d, rows = input.shape[:2], input.source.reshape(-1, input.source.shape[-1]), \
                         input.rows.reshape(-1)

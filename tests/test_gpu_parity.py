@@ -1659,3 +1659,30 @@ def test_phone_rate_gru_input_equals_frame_rate(precision):
     np.testing.assert_array_equal(pred_p, pred_f)
     for name in grads_f:
         assert rel_err(grads_p[name], grads_f[name]) < (2e-2 if precision == 'bf16' else 1e-4), name
+
+
+def test_phone_rate_fp32_stack_equals_frame_rate():
+    """fp32 parity mode of the F0Model (generic LinearStackFn, no fused tail): the stack ends in the linear run, so it runs on the
+    phone rows and its 1-wide output is repeated (RepeatTableRowsFn) - against MORGANA_PHONE_RATE=0 on a ragged batch: the same
+    kernels per row, so the prediction is EQUAL and the loss agrees to 1e-6; gradients to 1e-4 relative L2 (frame gradients summed
+    per phone before the GEMMs instead of inside them)."""
+    from morgana_amd import ops
+    feats = data.to_device(synthetic.make_batch(24, (150, 400), seed=6), DEV)
+
+    def run(phone_rate):
+        old = ops.PHONE_RATE
+        ops.PHONE_RATE = phone_rate
+        try:
+            model = _load_state(models.F0Model(precision='fp32').to(DEV), synthetic.f0_model_state())
+            loss, out = model(feats)
+            loss.backward()
+            return loss.item(), out['pred_norm_lf0'].detach().cpu().numpy(), {k: v.grad.cpu().numpy() for k, v in model.named_parameters()}
+        finally:
+            ops.PHONE_RATE = old
+
+    loss_p, pred_p, grads_p = run(True)
+    loss_f, pred_f, grads_f = run(False)
+    np.testing.assert_allclose(loss_p, loss_f, rtol=1e-6)
+    np.testing.assert_array_equal(pred_p, pred_f)
+    for name in grads_f:
+        assert rel_err(grads_p[name], grads_f[name]) < 1e-4, name
