@@ -62,6 +62,10 @@ int mg_upsample_lengths(const int64_t* dur, int B, int P, int64_t* n_frames, int
  *   rows32[B,t_cap]  b*P + phone or -1   (flat source row, the gather convention of this library)
  * Frames t >= n_frames[b] get -1.  Requires t_cap >= 0 and P <= 16384.  If t_cap < n_frames[b] the row is cropped. */
 int mg_upsample_index(const int64_t* dur, int B, int P, int t_cap, int64_t* idx64, int32_t* rows32, void* stream);
+/* The same launch also writing the phone-rate maps (csrc/phone_rate.hip): rows_mapped = rows32 with -1 replaced by pad_row, and
+ * seg_start / seg_end int32 [B*P] = the run of frame ids (b * t_cap + t) of every phone row, (0, 0) for a phone without frames. */
+int mg_upsample_index_maps(const int64_t* dur, int B, int P, int t_cap, int32_t* rows32, int32_t* rows_mapped, int pad_row,
+                           int32_t* seg_start, int32_t* seg_end, void* stream);
 
 /* out[m,:] = rows[m] < 0 ? 0 : src[rows[m],:]   (utils.py:226).  src [R,F] f32, out [M,F] f32. */
 int mg_gather_rows_f32(const float* src, const int32_t* rows, float* out, int64_t M, int F, void* stream);

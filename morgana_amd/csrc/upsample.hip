@@ -57,7 +57,9 @@ __global__ __launch_bounds__(256) void upsample_lengths_kernel(const int64_t* __
 }
 
 __global__ __launch_bounds__(256) void upsample_index_kernel(const int64_t* __restrict__ dur, int P, int t_cap,
-                                                             int64_t* __restrict__ idx64, int32_t* __restrict__ rows32) {
+                                                             int64_t* __restrict__ idx64, int32_t* __restrict__ rows32,
+                                                             int32_t* __restrict__ rows_mapped, int pad_row,
+                                                             int32_t* __restrict__ seg_start, int32_t* __restrict__ seg_end) {
     extern __shared__ __attribute__((aligned(16))) int smem_i[];
     int* scratch = smem_i;
     int* cum = smem_i + 256;
@@ -78,6 +80,15 @@ __global__ __launch_bounds__(256) void upsample_index_kernel(const int64_t* __re
         const size_t o = (size_t)b * t_cap + t;
         if (idx64) idx64[o] = phone;
         if (rows32) rows32[o] = phone < 0 ? -1 : b * P + phone;
+        if (rows_mapped) rows_mapped[o] = phone < 0 ? pad_row : b * P + phone;
+    }
+    if (seg_start) {
+        // the frame run of each phone row, as mg_segment_bounds finds it from the map: (0, 0) for a phone without frames
+        for (int p = threadIdx.x; p < P; p += 256) {
+            const int s = min(p ? cum[p - 1] : 0, t_cap), e = min(cum[p], t_cap);
+            seg_start[(size_t)b * P + p] = e > s ? b * t_cap + s : 0;
+            seg_end[(size_t)b * P + p] = e > s ? b * t_cap + e : 0;
+        }
     }
 }
 
@@ -280,8 +291,24 @@ int mg_upsample_index(const int64_t* dur, int B, int P, int t_cap, int64_t* idx6
     MG_CHECK_ARG((int64_t)B * P < 2147483647LL, "mg_upsample_index: B*P overflows int32 row ids");
     if (t_cap == 0) return MG_OK;
     const size_t lds = (size_t)(256 + P) * sizeof(int);
-    hipLaunchKernelGGL(upsample_index_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, dur, P, t_cap, idx64, rows32);
+    hipLaunchKernelGGL(upsample_index_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, dur, P, t_cap, idx64, rows32, nullptr, 0,
+                       nullptr, nullptr);
     MG_CHECK_LAUNCH("mg_upsample_index");
+    return MG_OK;
+}
+
+// mg_upsample_index + what the phone-rate step needs from mg_segment_bounds, in the same launch: rows_mapped (-1 -> pad_row) and the
+// frame run [seg_start, seg_end) of every phone row (frame ids b * t_cap + t).
+int mg_upsample_index_maps(const int64_t* dur, int B, int P, int t_cap, int32_t* rows32, int32_t* rows_mapped, int pad_row,
+                           int32_t* seg_start, int32_t* seg_end, void* stream) {
+    MG_CHECK_ARG(dur && rows32 && rows_mapped && seg_start && seg_end && B > 0 && P > 0 && t_cap > 0,
+                 "mg_upsample_index_maps: bad arguments (B=%d P=%d t_cap=%d)", B, P, t_cap);
+    MG_CHECK_ARG(P <= MG_MAX_PHONES, "mg_upsample_index_maps: P=%d exceeds %d phones per utterance", P, MG_MAX_PHONES);
+    MG_CHECK_ARG((int64_t)B * P < 2147483647LL && (int64_t)B * t_cap < 2147483647LL, "mg_upsample_index_maps: int32 ids overflow");
+    const size_t lds = (size_t)(256 + P) * sizeof(int);
+    hipLaunchKernelGGL(upsample_index_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, dur, P, t_cap, nullptr, rows32, rows_mapped,
+                       pad_row, seg_start, seg_end);
+    MG_CHECK_LAUNCH("mg_upsample_index_maps");
     return MG_OK;
 }
 

@@ -232,6 +232,9 @@ class LinearStackMSEFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, acts, x2d, rows, target, seq_len, *params):
+        maps = None
+        if len(acts) == 2 and not isinstance(acts[0], int):       # (acts, maps): phone-rate maps that came with the frame map
+            acts, maps = acts
         n_layers = len(acts)
         weights = [params[2 * i] for i in range(n_layers)]
         biases = [params[2 * i + 1] for i in range(n_layers)]
@@ -256,7 +259,7 @@ class LinearStackMSEFn(torch.autograd.Function):
         ctx.phone_rate = phone_rate
         if phone_rate:
             extra = ops.PHONE_RATE_EXTRA
-            seg, rows = ops.segment_bounds(rows, n_table, pad_row=n_table)
+            seg, rows = maps if maps is not None else ops.segment_bounds(rows, n_table, pad_row=n_table)
             a0 = ops.cast_pad_bf16(x2d, extra_rows=extra)
             n_rows = a0.shape[0]
             hidden, a = [], a0

@@ -79,6 +79,18 @@ def upsample_index(dur, t_cap, want_idx64=False, want_rows=True):
     return idx64, rows
 
 
+def upsample_index_maps(dur, t_cap):
+    """(rows (B, T) int32 with -1 padding, rows_mapped (-1 -> B*P), seg (2, B*P) frame runs) in one launch (mg_upsample_index_maps)."""
+    lib = _lib.load()
+    dur = _require(dur, torch.int64, 'dur')
+    b, p = dur.shape
+    rows = torch.empty((2, b, t_cap), dtype=torch.int32, device=dur.device)
+    seg = torch.empty((2, b * p), dtype=torch.int32, device=dur.device)
+    _lib.check(lib.mg_upsample_index_maps(_p(dur), b, p, int(t_cap), _p(rows[0]), _p(rows[1]), b * p, _p(seg[0]), _p(seg[1]),
+                                          _stream()), 'mg_upsample_index_maps')
+    return rows[0], rows[1], seg
+
+
 def gather_rows(src2d, rows, out_bf16=False):
     lib = _lib.load()
     src2d = _require(src2d, torch.float32, 'src')

@@ -48,11 +48,19 @@ class UpsampledSequence(object):
     (B, Tmax, feat) tensor never exists in HBM.  ``materialise()`` gives the ordinary dense tensor.
     """
 
-    def __init__(self, sequence_feature, dur2d, rows):
+    def __init__(self, sequence_feature, dur2d, rows, maps=None):
         self.source = sequence_feature
         self.dur = dur2d
         self.rows = rows                       # int32 (B, Tmax): b*P + phone, or -1
+        self.maps = maps                       # (seg (2, B*P) frame runs, rows with -1 -> B*P) from the same launch, or None
         self.shape = (sequence_feature.shape[0], rows.shape[1], sequence_feature.shape[2])
+
+    def phone_maps(self):
+        """(frame runs per phone row, row map with -1 -> the first row behind the B*P phone rows) for the phone-rate paths."""
+        if self.maps is None:
+            n_rows = self.source.shape[0] * self.source.shape[1]
+            self.maps = ops.segment_bounds(self.rows.reshape(-1), n_rows, pad_row=n_rows)
+        return self.maps
 
     def materialise(self):
         return F_hip.UpsampleFn.apply(self.source, self.dur, self.rows.shape[1])
@@ -65,8 +73,8 @@ class PhoneTable(object):
     GRU wrapper comes next: those layers commute with repeating rows, so they run on the phone rows and the wrapper repeats the
     rows of ITS input projection instead (``functional.GRUFn`` with ``rows``)."""
 
-    def __init__(self, table, rows, n_phone_rows):
-        self.table, self.rows, self.n_phone_rows = table, rows, n_phone_rows
+    def __init__(self, table, rows, n_phone_rows, maps=None):
+        self.table, self.rows, self.n_phone_rows, self._maps = table, rows, n_phone_rows, maps
         self.shape = (rows.shape[0], rows.shape[1], table.shape[1])
         self.ndim = 3
 
@@ -75,7 +83,9 @@ class PhoneTable(object):
 
     def maps(self):
         """(frame runs per phone row, map with -1 -> the first extra row) for the current (possibly cropped) frame axis."""
-        return ops.segment_bounds(self.rows.reshape(-1), self.n_phone_rows, pad_row=self.n_phone_rows)
+        if self._maps is None:
+            self._maps = ops.segment_bounds(self.rows.reshape(-1), self.n_phone_rows, pad_row=self.n_phone_rows)
+        return self._maps
 
 
 class UpsampledConcat(object):
@@ -129,6 +139,9 @@ def upsample_to_repetitions(sequence_feature, repeats, max_len=None, fused=False
         _, tmax = ops.upsample_lengths(dur2d)
         max_len = int(tmax.item())
     if fused and not sequence_feature.requires_grad:
+        if ops.PHONE_RATE and int(max_len) > 0:
+            rows, rows_mapped, seg = ops.upsample_index_maps(dur2d, int(max_len))
+            return UpsampledSequence(sequence_feature, dur2d, rows, maps=(seg, rows_mapped.reshape(-1)))
         _, rows = ops.upsample_index(dur2d, int(max_len))
         return UpsampledSequence(sequence_feature, dur2d, rows)
     return F_hip.UpsampleFn.apply(sequence_feature, dur2d, int(max_len))
@@ -363,8 +376,9 @@ class SequentialWithRecurrent(nn.Sequential):
             out, _ = self.forward(input, seq_len=seq_len)
             return losses.mse(out, targets, seq_len), out
         run, acts = fused
+        maps = None
         if isinstance(input, UpsampledSequence):
-            x2d, rows = input.source.reshape(-1, input.source.shape[-1]), input.rows.reshape(-1)
+            x2d, rows, maps = input.source.reshape(-1, input.source.shape[-1]), input.rows.reshape(-1), input.maps
         else:
             x2d, rows = input.reshape(-1, input.shape[-1]), None
         if seq_len is not None and seq_len.dtype != torch.int64:
@@ -372,7 +386,7 @@ class SequentialWithRecurrent(nn.Sequential):
         params = []
         for lin, _ in run:
             params += [lin.weight, lin.bias]
-        return F_hip.LinearStackMSEFn.apply(acts, x2d, rows, targets, seq_len, *params)
+        return F_hip.LinearStackMSEFn.apply((acts, maps), x2d, rows, targets, seq_len, *params)
 
     def forward(self, input, hiddens=None, seq_len=None):
         modules = list(self._modules.values())
@@ -396,7 +410,7 @@ class SequentialWithRecurrent(nn.Sequential):
                         params += [lin.weight, lin.bias]
                     spec = (tuple(act for _, act in run), precision, ops.PHONE_RATE_EXTRA)
                     table = F_hip.LinearStackFn.apply(spec, input.source.reshape(-1, input.source.shape[-1]), None, *params)
-                    input = PhoneTable(table, input.rows, n_src)
+                    input = PhoneTable(table, input.rows, n_src, maps=input.phone_maps())
                     i = end
                     continue
                 if (isinstance(input, UpsampledSequence) and end == len(modules)
@@ -408,7 +422,7 @@ class SequentialWithRecurrent(nn.Sequential):
                         params += [lin.weight, lin.bias]
                     spec = (tuple(act for _, act in run), precision, ops.PHONE_RATE_EXTRA)
                     table = F_hip.LinearStackFn.apply(spec, input.source.reshape(-1, input.source.shape[-1]), None, *params)
-                    seg, rows_mapped = ops.segment_bounds(input.rows.reshape(-1), n_src, pad_row=n_src)
+                    seg, rows_mapped = input.phone_maps()
                     out = F_hip.RepeatTableRowsFn.apply(table, rows_mapped, seg, n_src)
                     input = out.view(input.shape[0], input.shape[1], out.shape[-1])
                     i = end

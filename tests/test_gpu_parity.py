@@ -1686,3 +1686,18 @@ def test_phone_rate_fp32_stack_equals_frame_rate():
     np.testing.assert_array_equal(pred_p, pred_f)
     for name in grads_f:
         assert rel_err(grads_p[name], grads_f[name]) < 1e-4, name
+
+
+def test_upsample_index_maps_match_separate_launches():
+    """mg_upsample_index_maps (frame map, pad-mapped map and per-phone frame runs in one launch) against mg_upsample_index +
+    mg_segment_bounds: EQUAL, with zero durations, a capped frame axis (phones cut or dropped by t_cap) and padding frames."""
+    from morgana_amd import ops
+    rng = np.random.RandomState(17)
+    dur = rng.randint(0, 6, size=(9, 23)).astype(np.int64)
+    dur[3] = 0
+    dur[4, :5] = 40
+    for t_cap in (int(dur.sum(1).max()), 60):
+        _, rows = ops.upsample_index(dev(dur), t_cap)
+        seg, mapped = ops.segment_bounds(rows.reshape(-1), dur.size, pad_row=dur.size)
+        rows2, mapped2, seg2 = ops.upsample_index_maps(dev(dur), t_cap)
+        assert torch.equal(rows2, rows) and torch.equal(mapped2.reshape(-1), mapped) and torch.equal(seg2, seg)
