@@ -226,6 +226,9 @@ int mg_linear_wgrad_f32(const float* dY, const float* A, int lda, const int32_t*
  *                     target f32 [B*T]; ybar, weight f32 [R + extra]; rows R.. take the padding frames. */
 /*  mg_expand_column_f32  out[f] = table[rows[f]] for a one-column f32 table (the per-phone prediction repeated to frames); rows >= 0. */
 int mg_expand_column_f32(const float* table, const int32_t* rows, int64_t M, float* out, void* stream);
+/* ... and mg_phone_loss_const_add in the same launch (stats_workspace as left by mg_phone_target_stats). */
+int mg_expand_column_loss_f32(const float* table, const int32_t* rows, int64_t M, float* out, const void* stats_workspace, int R,
+                              int extra, float* loss, void* stream);
 size_t mg_phone_target_stats_workspace_bytes(int R, int extra);
 /* loss_const may be NULL: then mg_phone_loss_const_add(workspace, R, extra, loss) adds the constant to a loss in place later on
  * (the workspace must be left untouched in between). */

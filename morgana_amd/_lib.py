@@ -92,6 +92,7 @@ SIGNATURES = {
                                      c_float, c_void_p]),
     'mg_f0_tail_rows_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                      c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'mg_expand_column_loss_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'mg_expand_column_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     'mg_phone_loss_const_add': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'mg_phone_target_stats_workspace_bytes': (c_size_t, [c_int, c_int]),

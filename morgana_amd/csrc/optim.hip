@@ -261,7 +261,7 @@ int mg_cast_params_bf16(const mg_cast_desc* descs, int count, void* stream) {
         MG_CHECK_ARG(!d.dst_t || d.ldt >= d.rows, "mg_cast_params_bf16: descriptor %d: ldt %d < rows %d", i, d.ldt, d.rows);
         batch.d[i] = d;
     }
-    hipLaunchKernelGGL(cast_params_kernel, dim3(64, count), dim3(256), 0, (hipStream_t)stream, batch);
+    hipLaunchKernelGGL(cast_params_kernel, dim3(256, count), dim3(256), 0, (hipStream_t)stream, batch);
     MG_CHECK_LAUNCH("mg_cast_params_bf16");
     return MG_OK;
 }

@@ -211,11 +211,26 @@ __global__ __launch_bounds__(256) void phone_target_stats_kernel(const float* __
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
-// out[f] = table[rows[f]] for a one-column table (the repeated prediction); rows >= 0
+// out[f] = table[rows[f]] for a one-column table (the repeated prediction); rows >= 0.  With `partial` the LAST block also adds the
+// per-block partial sums of the loss's constant term to `loss` in place (a fixed-order sum by one block: deterministic) - the
+// kernel runs after the tail wrote the loss, and this saves a launch node of its own.
 __global__ __launch_bounds__(256) void expand_column_kernel(const float* __restrict__ table, const int32_t* __restrict__ rows, int64_t M,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, const float* __restrict__ partial, int n_partial,
+                                                            float* __restrict__ loss) {
+    __shared__ float red[256];
     const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (f < M) out[f] = table[rows[f]];
+    if (partial && blockIdx.x == gridDim.x - 1) {
+        float v = 0.f;
+        for (int i = threadIdx.x; i < n_partial; i += 256) v += partial[i];
+        red[threadIdx.x] = v;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) loss[0] += red[0];
+    }
 }
 
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int n, float* __restrict__ out,
@@ -305,8 +320,21 @@ int mg_phone_loss_const_add(const void* workspace, int R, int extra, float* loss
 
 int mg_expand_column_f32(const float* table, const int32_t* rows, int64_t M, float* out, void* stream) {
     MG_CHECK_ARG(table && rows && out && M > 0, "mg_expand_column_f32: bad arguments (M=%lld)", (long long)M);
-    hipLaunchKernelGGL(expand_column_kernel, dim3((unsigned)mg_ceil_div(M, 256)), dim3(256), 0, (hipStream_t)stream, table, rows, M, out);
+    hipLaunchKernelGGL(expand_column_kernel, dim3((unsigned)mg_ceil_div(M, 256)), dim3(256), 0, (hipStream_t)stream, table, rows, M, out,
+                       nullptr, 0, nullptr);
     MG_CHECK_LAUNCH("mg_expand_column_f32");
+    return MG_OK;
+}
+
+// mg_expand_column_f32 and mg_phone_loss_const_add in one launch (the phone-rate step's last two nodes of the forward)
+int mg_expand_column_loss_f32(const float* table, const int32_t* rows, int64_t M, float* out, const void* stats_workspace, int R,
+                              int extra, float* loss, void* stream) {
+    MG_CHECK_ARG(table && rows && out && stats_workspace && loss && M > 0 && R > 0 && extra >= 0,
+                 "mg_expand_column_loss_f32: bad arguments (M=%lld)", (long long)M);
+    const int n_partial = (int)(mg_ceil_div(R, 16) + mg_ceil_div(extra, 4));
+    hipLaunchKernelGGL(expand_column_kernel, dim3((unsigned)mg_ceil_div(M, 256)), dim3(256), 0, (hipStream_t)stream, table, rows, M, out,
+                       (const float*)stats_workspace, n_partial, loss);
+    MG_CHECK_LAUNCH("mg_expand_column_loss_f32");
     return MG_OK;
 }
 

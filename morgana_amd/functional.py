@@ -275,8 +275,7 @@ class LinearStackMSEFn(torch.autograd.Function):
             ybar, weight, partials = ops.phone_target_stats(target.reshape(-1), rows, seg, seq_len, b, t, n_table, extra)
             pred_rows, loss, dz2 = ops.f0_tail_rows(hidden[-1], weights[lead], biases[lead], weights[lead + 1], biases[lead + 1],
                                                     ybar, weight, flat[offsets[2 * lead]:])
-            ops.phone_loss_const_add(partials, n_table, extra, loss)
-            pred = ops.expand_column(pred_rows, rows).view(b, t, 1)
+            pred = ops.expand_column(pred_rows, rows, loss_const=(partials, n_table, extra, loss)).view(b, t, 1)
             ctx.acts, ctx.m, ctx.lead = acts, m, lead
             ctx.dims = [(w.shape[0], w.shape[1]) for w in weights]
             ctx.offsets = offsets

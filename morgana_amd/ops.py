@@ -456,12 +456,18 @@ def phone_loss_const_add(partials, n_table_rows, extra, loss):
     _lib.check(_lib.load().mg_phone_loss_const_add(_p(partials), n_table_rows, extra, _p(loss), _stream()), 'mg_phone_loss_const_add')
 
 
-def expand_column(table, rows):
-    """out[f] = table[rows[f]] for a (rows,) f32 table and an int32 map without negative entries (mg_expand_column_f32)."""
+def expand_column(table, rows, loss_const=None):
+    """out[f] = table[rows[f]] for a (rows,) f32 table and an int32 map without negative entries (mg_expand_column_f32).
+    ``loss_const`` = (partials, n_table_rows, extra, loss): the same launch adds phone_target_stats' constant to ``loss`` in place."""
     lib = _lib.load()
     table = _require(table, torch.float32, 'table')
     out = torch.empty((rows.numel(),), dtype=torch.float32, device=table.device)
-    _lib.check(lib.mg_expand_column_f32(_p(table), _p(rows), rows.numel(), _p(out), _stream()), 'mg_expand_column_f32')
+    if loss_const is None:
+        _lib.check(lib.mg_expand_column_f32(_p(table), _p(rows), rows.numel(), _p(out), _stream()), 'mg_expand_column_f32')
+    else:
+        partials, n_table_rows, extra, loss = loss_const
+        _lib.check(lib.mg_expand_column_loss_f32(_p(table), _p(rows), rows.numel(), _p(out), _p(partials), n_table_rows, extra,
+                                                 _p(loss), _stream()), 'mg_expand_column_loss_f32')
     return out
 
 

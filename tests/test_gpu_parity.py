@@ -1701,3 +1701,34 @@ def test_upsample_index_maps_match_separate_launches():
         seg, mapped = ops.segment_bounds(rows.reshape(-1), dur.size, pad_row=dur.size)
         rows2, mapped2, seg2 = ops.upsample_index_maps(dev(dur), t_cap)
         assert torch.equal(rows2, rows) and torch.equal(mapped2.reshape(-1), mapped) and torch.equal(seg2, seg)
+
+
+@pytest.mark.parametrize('masked', [True, False])
+def test_phone_target_stats_reduce_the_masked_mse_exactly(masked):
+    """mg_phone_target_stats / mg_phone_loss_const_add: for predictions that are constant over the frames of a table row the masked MSE
+    of morgana/losses.py:29-51 equals sum_r W_r (p_r - ybar_r)^2 + const.  Checked against the frame-by-frame numpy loss on a ragged
+    map with empty phones and padding frames, with seq_len (padding frames partly inside it) and without: weights exact to 1e-6,
+    the reassembled loss to 1e-5."""
+    from morgana_amd import ops
+    rng = np.random.RandomState(23 + masked)
+    b, p, t, extra = 6, 11, 48, 8
+    rows = _ragged_rows(rng, b, p, t)
+    flat = rows.reshape(-1)
+    r_tab = b * p
+    target = rng.standard_normal(b * t).astype(np.float32)
+    seq_np = rng.randint(10, t + 1, size=b).astype(np.int64) if masked else None
+    seg, mapped = ops.segment_bounds(dev(flat), r_tab, pad_row=r_tab)
+    ybar, weight, partials = ops.phone_target_stats(dev(target), mapped, seg, dev(seq_np) if masked else None, b, t, r_tab, extra)
+    loss = torch.zeros((), device=DEV)
+    ops.phone_loss_const_add(partials, r_tab, extra, loss)
+    # frame weights of the reference loss
+    nb = seq_np if masked else np.full(b, t)
+    w = ((np.arange(t)[None, :] < nb[:, None]) / (nb[:, None] * float(b))).reshape(-1)
+    chunk = -(-b * t // extra)
+    row_of = np.where(flat >= 0, flat, r_tab + np.arange(b * t) // chunk)          # padding frames: the extra row of their share
+    want_w = np.bincount(row_of, weights=w, minlength=r_tab + extra)
+    np.testing.assert_allclose(weight.cpu().numpy(), want_w, rtol=1e-5, atol=1e-9)
+    pred_rows = rng.standard_normal(r_tab + extra)
+    frame_loss = float((w * (pred_rows[row_of] - target) ** 2).sum())
+    got = float((weight.double().cpu().numpy() * (pred_rows - ybar.double().cpu().numpy()) ** 2).sum() + loss.item())
+    np.testing.assert_allclose(got, frame_loss, rtol=1e-5)
