@@ -45,7 +45,6 @@ class GraphedTrainStep(object):
                 self.optimizer.step_captured()
         self._update = None
         if self._multi:
-            self.optimizer.exchange_gradients()
             self._update = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._update, pool=self._fwd_bwd.pool(), **mode):
                 self.optimizer.step_captured()
