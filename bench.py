@@ -459,6 +459,7 @@ def main():
                 fwd = lab_shape[2] * 512 + 512 * 128 + 128 * 32 + 32
                 executed = 2.0 * r_tab * (2 * fwd + (512 * 128 + 128 * 32 + 32))      # forward + wgrad of 4 layers, dgrad of layers 2-4
                 result['step_executed_tflops'] = round(executed / (ms_per_step * 1e-3) / 1e12, 2)
+                result['step_executed_frac_of_mfma_peak'] = round(executed / (ms_per_step * 1e-3) / 1e12 / peak, 4)
                 result['flops_note'] = ('step_algorithmic_tflops counts the reference algorithm (all products at frame rate); the '
                                         'phone-rate step executes %.1f GFLOP per step instead of %.1f'
                                         % (executed / 1e9, F0_FLOPS_PER_FRAME * frames_per_step / 1e9))
