@@ -370,7 +370,7 @@ def main():
         try:
             from morgana_amd import graphs
             step = graphs.GraphedTrainStep(model, optimizer, features)
-            graph_note = 'hip graph replay (%s)' % ('forward+backward graph, eager all-reduce, update graph' if world > 1
+            graph_note = 'hip graph replay (%s)' % ('forward+backward graph, eager all-reduce, update kernel' if world > 1
                                                     else 'one graph per step')
         except Exception as exc:                      # capture refused: time the eager loop and say so
             graph_note = 'eager launches (graph capture failed: %s)' % str(exc).splitlines()[0][:200]

@@ -8,7 +8,8 @@ path around them (0.5 ms per step) is what bounds the step.  ``GraphedTrainStep`
 What makes the step capturable: every kernel of the path is launched on torch's current stream with no host synchronisation,
 scratch comes from torch's allocator (graph-private pool during capture), and the only step-dependent scalars - Adam's bias
 corrections - are read from device memory (``optim.Adam.advance`` / ``step_captured``, ``mg_adam_step_dev_f32``).  With more than
-one rank the gradient all-reduce stays OUTSIDE the graphs (forward + backward graph, eager RCCL all-reduce, update graph).
+one rank the gradient all-reduce stays OUTSIDE the graph (forward + backward graph, eager RCCL all-reduce, the one-kernel update
+launched directly).
 
 The captured step works on fixed buffers: ``features`` must be the same device tensors for every replay (copy a new batch into
 them with ``load``; shapes must not change).  Metrics accumulated inside ``loss`` keep accumulating - their accumulators are device
@@ -43,11 +44,6 @@ class GraphedTrainStep(object):
             functional.backward(self.loss)
             if not self._multi:
                 self.optimizer.step_captured()
-        self._update = None
-        if self._multi:
-            self._update = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._update, pool=self._fwd_bwd.pool(), **mode):
-                self.optimizer.step_captured()
         self.steps_done = warmup
 
     def _eager_step(self):
@@ -66,9 +62,9 @@ class GraphedTrainStep(object):
         """One training step; returns the (device, 0-d) loss tensor of the captured step - valid until the next call."""
         self.optimizer.advance()
         self._fwd_bwd.replay()
-        if self._update is not None:
-            self.optimizer.exchange_gradients()
-            self._update.replay()
+        if self._multi:
+            self.optimizer.exchange_gradients()        # the step's one RCCL all-reduce, outside the graph
+            self.optimizer.step_captured()             # one kernel: launched directly
         self.steps_done += 1
         return self.loss
 
