@@ -897,6 +897,7 @@ int mg_wgrad_big_plan(int64_t M, int N, int K, int lda, int lddy, int* S_out, in
     // phone-rate shapes (M ~ 2e4 rows): 48 splits x 4 n-tiles = 192 workgroups beat 64 x 4 (45.6 vs 49.7 us with the reduce at
     // M = 21 504, N = 512, K = 600: a third less partial-slab traffic); never more splits than the workspace was sized for
     if (M <= 32768 && tiles_n >= 4) S = 192 / tiles_n;
+    if (M <= 32768 && tiles_n == 1) S = 96;                  // N = 128 at the same M: 24.2 vs 27.7 us (224 splits write 59 MB of slabs)
     int64_t m_chunk = mg_align_up((size_t)mg_ceil_div(M, S), 32);
     while (m_chunk > WG_ROWS_MAX) {  // row indices of a workgroup's range live in LDS
         S *= 2;
