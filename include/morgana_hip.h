@@ -82,6 +82,23 @@ int mg_gather_rows_bf16(const float* src, const int32_t* rows, uint16_t* out, in
 int mg_segment_index(const int64_t* seg_lens, int B, int S, int T, int L, int32_t* split, int32_t* ends, void* stream);
 int mg_scatter_rows_f32(const float* src, const int32_t* rows, float* dst, int64_t M, int F, void* stream);
 
+/* Packed frames for ragged batches.  The reference pads a batch to its longest utterance (collate_fn, morgana/data.py:183-193), runs
+ * every nn.Linear on all B*T rows (morgana/utils.py:401-418) and masks the loss (losses.py:37-39); behind a recurrent wrapper the
+ * padded frames are zero rows (utils.py:383).  mg_frame_layout builds the maps that let the row-wise layers run on the
+ * total = sum_b min(seq_len[b], T) valid rows plus ONE representative zero row:
+ *   offsets int32 [B+1]     first packed row of utterance b (offsets[B] = total)
+ *   rows    int32 [total+1] dense row b*T + t of packed row i, utterance by utterance; rows[total] = -1
+ *   inverse int32 [B*T]     packed row of dense row (b, t); `total` for padded frames
+ * `total` is supplied by the caller (the host knows the lengths it collated); frames beyond it count as padding.
+ * pack = mg_gather_rows_*(x, rows), unpack = mg_gather_rows_f32(packed, inverse); the adjoint of the unpack is a gather by `rows` for
+ * the valid rows and, for the representative row, the sum over all padded dense rows: mg_pad_rows_colsum_f32 (g [B,T,D] -> out [D],
+ * fixed summation order; workspace mg_pad_rows_colsum_workspace_bytes(B,T,D)). */
+int mg_frame_layout(const int64_t* seq_len, int B, int T, int64_t total, int32_t* offsets, int32_t* rows, int32_t* inverse,
+                    void* stream);
+size_t mg_pad_rows_colsum_workspace_bytes(int B, int T, int D);
+int mg_pad_rows_colsum_f32(const float* g, const int64_t* seq_len, int B, int T, int D, float* out, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
 /* Gather fused with the frame-level concat the shipped models do right after it (models/RNN_SPSS.py:76-81,
  * models/f0_test_model.py:78-79: upsample_to_repetitions, then torch.cat with `normalised_counters`):
  *   out[m, 0:F] = src[rows[m], :] (0 where rows[m] < 0), out[m, F:F+C] = extra[m, 0:C], out[m, F+C:ldo] = 0.
@@ -318,7 +335,19 @@ int mg_f0_tail_rows_bf16(const uint16_t* H2, int ldh, int K3, const float* W3, c
  *   hstate [B,T+1,H]: slot 0 must hold h0 (or zeros) on entry; slot t+1 receives the state after step t (frozen once
  *                     t >= seq_len[b]), so h_n = hstate[:, T, :] and h_{t-1} = hstate[:, t, :] for the backward
  *   out    [B,T,H]   = h_t on valid steps, exactly 0 on padded steps (pad_packed_sequence, utils.py:383)
- *   saved  [B,T,4H]  = (r, z, n, W_hn h + b_hn) for the backward */
+ *   saved  [B,T,4H]  = (r, z, n, W_hn h + b_hn) for the backward
+ * CONTRACT for steps past an item's length (t >= seq_len[b]), all GRU / LSTM entry points of this header:
+ *   - out is exactly 0 there and hstate repeats the last valid state (both specified, both tested);
+ *   - saved[b,t,:] is UNSPECIFIED there.  The forward kernels differ in what they leave: the per-step kernels (mg_gru_fwd_f32,
+ *     mg_gru_fwd_bf16, mg_lstm_fwd_f32) store the gate values the frozen state and whatever xproj holds at that position produce;
+ *     the workgroup-local kernels (mg_gru_fwd_small_f32) do the same; the persistent kernels (mg_gru_fwd_persist_*,
+ *     mg_lstm_fwd_persist_bf16, mg_lstm_pstack_fwd_bf16) do so up to the longest sequence of the item's group and write zeros or
+ *     nothing at all beyond it.  Callers must not compare or consume these elements;
+ *   - every backward entry point treats such a step as inactive: the loads of saved[b,t,:] and grad_out[b,t,:] may be issued, but
+ *     their values are discarded by a select (never multiplied by a 0/1 mask), so NaN or garbage there cannot reach dxproj,
+ *     dhproj, dgates, dh0 / dc0 or any shadow; the gate gradients written for such a step are exactly 0.
+ *     tests/test_gpu_configs.py::test_gru_backward_never_reads_saved_past_seq_len poisons these elements with NaN in all five
+ *     backward forms and requires bit-identical, finite gradients. */
 int mg_gru_fwd_f32(const float* xproj, const float* w_hh, const float* b_hh, const int64_t* seq_len, int B, int T, int H,
                    float* hstate, float* out, float* saved, void* stream);
 /* BPTT, one launch per step.  grad_out [B,T,H]; grad_hn NULL or [B,H] (gradient of h_n).

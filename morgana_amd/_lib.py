@@ -25,6 +25,9 @@ SIGNATURES = {
     'mg_gather_rows_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     'mg_segment_index': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'mg_scatter_rows_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    'mg_frame_layout': (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mg_pad_rows_colsum_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'mg_pad_rows_colsum_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'mg_gather_concat_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     'mg_gather_concat_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     'mg_upsample_backward_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -121,6 +121,96 @@ __global__ __launch_bounds__(256) void segment_index_kernel(const int64_t* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Packed frames.  A ragged batch (B, T, .) zero padded to its longest utterance (collate_fn, morgana/data.py:183-193) holds
+// sum_b min(seq_len[b], T) valid frame rows; the reference runs its Linear layers on all B*T rows (morgana/utils.py:401-418 applies
+// nn.Linear to the padded tensor) and masks the loss (losses.py:37-39).  The row-wise layers here run on the valid rows plus ONE
+// representative padding row (a zero input row: what every padded frame holds behind a recurrent wrapper, utils.py:383):
+//   rows    [total + 1] : dense row b*T + t of packed row i, in (b, t) order; rows[total] = -1 (the zero row)
+//   inverse [B*T]       : packed row of dense row (b, t); total for padded frames
+//   offsets [B + 1]     : first packed row of utterance b; offsets[B] = total
+// frame_layout_scan_kernel: one workgroup scans the clamped lengths; frame_layout_fill_kernel: one thread per dense row.
+// `total` is the caller's (host-side) sum of the lengths: rows and inverse are sized by it, so entries at or beyond it are never written.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void frame_layout_scan_kernel(const int64_t* __restrict__ seq_len, int B, int T, int32_t* __restrict__ offsets) {
+    __shared__ int scratch[256];
+    const int tid = threadIdx.x;
+    const int per = (B + 255) / 256;
+    const int lo = tid * per, hi = min(lo + per, B);
+    int local = 0;
+    for (int b = lo; b < hi; ++b) {
+        const long long n = seq_len[b];
+        local += n < 0 ? 0 : (n > T ? T : (int)n);
+    }
+    scratch[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int v = tid >= off ? scratch[tid - off] : 0;
+        __syncthreads();
+        scratch[tid] += v;
+        __syncthreads();
+    }
+    int run = tid > 0 ? scratch[tid - 1] : 0;
+    for (int b = lo; b < hi; ++b) {
+        offsets[b] = run;
+        const long long n = seq_len[b];
+        run += n < 0 ? 0 : (n > T ? T : (int)n);
+    }
+    if (tid == 255) offsets[B] = scratch[255];
+}
+
+__global__ __launch_bounds__(256) void frame_layout_fill_kernel(const int64_t* __restrict__ seq_len, const int32_t* __restrict__ offsets, int B,
+                                                                int T, int total, int32_t* __restrict__ rows, int32_t* __restrict__ inverse) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m == 0) rows[total] = -1;
+    if (m >= (int64_t)B * T) return;
+    const int b = (int)(m / T), t = (int)(m - (int64_t)b * T);
+    const long long n = seq_len[b];
+    int idx = total;
+    if (t < n) {
+        const int i = offsets[b] + t;
+        if (i < total) {                 // a host total smaller than the device lengths: the surplus frames count as padding
+            idx = i;
+            rows[i] = (int32_t)m;
+        }
+    }
+    inverse[m] = idx;
+}
+
+// out[d] = sum over padded frames (t >= seq_len[b]) of g[b, t, d]: the gradient that reaches the ONE representative padding row of the
+// packed form from all the dense rows it stands for.  Two fixed-order stages (deterministic): partial[b][chunk][d] over 64-frame
+// chunks (chunks without padded frames write zeros without reading), then one column sum over the B * chunks partials.
+__global__ __launch_bounds__(256) void pad_rows_colsum_stage1_kernel(const float* __restrict__ g, const int64_t* __restrict__ seq_len, int T, int D,
+                                                                     int n_chunks, float* __restrict__ partial) {
+    extern __shared__ float red_cs[];                     // [4][D]
+    const int b = blockIdx.y, c = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long n = seq_len[b];
+    const int t_lo = max(c * 64, n < 0 ? 0 : (n > T ? T : (int)n)), t_hi = min(c * 64 + 64, T);
+    for (int d0 = 0; d0 < D; d0 += 64) {
+        const int d = d0 + lane;
+        float s = 0.f;
+        if (d < D)
+            for (int t = t_lo + wave; t < t_hi; t += 4) s += g[((size_t)b * T + t) * D + d];
+        if (d < D) red_cs[wave * D + d] = s;
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 256)
+        partial[((size_t)b * n_chunks + c) * D + d] = (red_cs[d] + red_cs[D + d]) + (red_cs[2 * D + d] + red_cs[3 * D + d]);
+}
+
+__global__ __launch_bounds__(256) void pad_rows_colsum_stage2_kernel(const float* __restrict__ partial, int n_partials, int D, float* __restrict__ out) {
+    __shared__ float red2[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int d = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (d < D)
+        for (int i = wave; i < n_partials; i += 4) s += partial[(size_t)i * D + d];
+    red2[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && d < D) out[d] = (red2[0][lane] + red2[1][lane]) + (red2[2][lane] + red2[3][lane]);
+}
+
 // dst[rows[m], :] = src[m, :] for rows[m] >= 0 (the targets are distinct: the adjoint of a gather whose rows are unique).
 __global__ __launch_bounds__(256) void scatter_rows_f32_kernel(const float* __restrict__ src, const int32_t* __restrict__ rows,
                                                                float* __restrict__ dst, int64_t M, int F) {
@@ -326,6 +416,38 @@ int mg_segment_index(const int64_t* seg_lens, int B, int S, int T, int L, int32_
     const size_t lds = (size_t)(256 + S) * sizeof(int);
     hipLaunchKernelGGL(segment_index_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, seg_lens, S, T, L, L > 0 ? split : nullptr, ends);
     MG_CHECK_LAUNCH("mg_segment_index");
+    return MG_OK;
+}
+
+int mg_frame_layout(const int64_t* seq_len, int B, int T, int64_t total, int32_t* offsets, int32_t* rows, int32_t* inverse,
+                    void* stream) {
+    MG_CHECK_ARG(seq_len && offsets && rows && inverse && B > 0 && T > 0 && total >= 0, "mg_frame_layout: bad arguments (B=%d T=%d total=%lld)", B, T,
+                 (long long)total);
+    MG_CHECK_ARG((int64_t)B * T < 2147483647LL && total <= (int64_t)B * T, "mg_frame_layout: B*T=%lld overflows int32 row ids or total=%lld exceeds it",
+                 (long long)B * T, (long long)total);
+    hipLaunchKernelGGL(frame_layout_scan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, seq_len, B, T, offsets);
+    hipLaunchKernelGGL(frame_layout_fill_kernel, dim3((unsigned)mg_ceil_div((int64_t)B * T, 256)), dim3(256), 0, (hipStream_t)stream, seq_len,
+                       offsets, B, T, (int)total, rows, inverse);
+    MG_CHECK_LAUNCH("mg_frame_layout");
+    return MG_OK;
+}
+
+size_t mg_pad_rows_colsum_workspace_bytes(int B, int T, int D) {
+    if (B <= 0 || T <= 0 || D <= 0) return 0;
+    return (size_t)B * (size_t)mg_ceil_div(T, 64) * (size_t)D * sizeof(float);
+}
+
+int mg_pad_rows_colsum_f32(const float* g, const int64_t* seq_len, int B, int T, int D, float* out, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+    MG_CHECK_ARG(g && seq_len && out && workspace && B > 0 && T > 0 && D > 0 && D <= 4096, "mg_pad_rows_colsum_f32: bad arguments (B=%d T=%d D=%d)", B, T, D);
+    MG_CHECK_ARG(workspace_bytes >= mg_pad_rows_colsum_workspace_bytes(B, T, D), "mg_pad_rows_colsum_f32: workspace too small");
+    MG_CHECK_ARG(B <= 65535, "mg_pad_rows_colsum_f32: B=%d exceeds the grid's y extent", B);
+    const int n_chunks = (int)mg_ceil_div(T, 64);
+    hipLaunchKernelGGL(pad_rows_colsum_stage1_kernel, dim3(n_chunks, B), dim3(256), (size_t)4 * D * sizeof(float), (hipStream_t)stream, g, seq_len, T,
+                       D, n_chunks, (float*)workspace);
+    hipLaunchKernelGGL(pad_rows_colsum_stage2_kernel, dim3((unsigned)mg_ceil_div(D, 64)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
+                       B * n_chunks, D, out);
+    MG_CHECK_LAUNCH("mg_pad_rows_colsum_f32");
     return MG_OK;
 }
 

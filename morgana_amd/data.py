@@ -181,13 +181,33 @@ class Normalisers(dict):
             self[name].load_params(self.normalisation_dir, device=self.device)
 
 
+FRAME_COUNT_KEY = 'n_frames'
+
+
+def _host_total(value):
+    """Sum of a host-side length vector as a python int, or None if the lengths are already on a device (reading them back would
+    cost a synchronisation)."""
+    if isinstance(value, np.ndarray):
+        return int(value.sum())
+    if isinstance(value, torch.Tensor) and not value.is_cuda:
+        return int(value.sum().item())
+    return None
+
+
 def to_device(features, device):
-    """``ToDeviceWrapper.to_device`` over a feature dict (data.py:648-663); numpy arrays are uploaded too."""
+    """``ToDeviceWrapper.to_device`` over a feature dict (data.py:648-663); numpy arrays are uploaded too.
+
+    One addition the reference's dict does not have: ``n_frames_total``, the python int sum of ``n_frames`` taken while the lengths
+    are still on the host - it sizes the packed-frame layout of ragged batches (``utils.FrameLayout``) without a device -> host read.
+    Models work without it (the build may carry a precomputed packed layout next to the reference's keys)."""
     out = {}
     for key, value in features.items():
         if isinstance(value, np.ndarray):
             value = torch.from_numpy(value)
         out[key] = value.to(device) if isinstance(value, torch.Tensor) else value
+    total = _host_total(features.get(FRAME_COUNT_KEY))
+    if total is not None and FRAME_COUNT_KEY + '_total' not in out:
+        out[FRAME_COUNT_KEY + '_total'] = total
     return out
 
 
@@ -271,6 +291,9 @@ def collate_to_device(batch, normalisers, device):
             out['normalised_' + key] = norm
     if rest:
         plain = collate_fn([{key: item[key] for key in rest} for item in batch])
+        total = _host_total(plain.get(FRAME_COUNT_KEY))
+        if total is not None:
+            out[FRAME_COUNT_KEY + '_total'] = total          # see to_device
         for key, value in plain.items():
             out[key] = value.to(device) if isinstance(value, torch.Tensor) else value
         for key in rest:                                  # integer sequence features with a normaliser (dur) stay on the host path
@@ -281,9 +304,103 @@ def collate_to_device(batch, normalisers, device):
     return out
 
 
+class NumpyBinarySource(object):
+    """``{data_dir}/{name}/{base_name}.npy`` -> ``{name: array}``: the loader half of the un-vendored
+    ``tts_data_tools.data_sources.NumpyBinarySource`` the reference's models name in ``train_data_sources``
+    (models/f0_test_model.py:60-69).  ``FilesDataset`` only needs a ``use_deltas`` attribute and a call
+    ``(base_name, data_dir) -> dict`` (data.py:93, :135, :142).  Arrays come back as stored: float32 ``(len, D)`` sequence
+    features, integer ``(P, 1)`` durations.  ``use_deltas`` additionally loads ``{name}_deltas``."""
+
+    def __init__(self, name, use_deltas=False, ext='npy'):
+        self.name, self.use_deltas, self.ext = name, use_deltas, ext
+
+    def file_path(self, base_name, data_dir, name=None):
+        return os.path.join(data_dir, name or self.name, '{}.{}'.format(base_name, self.ext))
+
+    def __call__(self, base_name, data_dir):
+        features = {self.name: np.load(self.file_path(base_name, data_dir))}
+        if self.use_deltas:
+            deltas = self.name + '_deltas'
+            features[deltas] = np.load(self.file_path(base_name, data_dir, deltas))
+        return features
+
+
+class TextSource(object):
+    """``{data_dir}/{name}/{base_name}.txt`` holding one number -> ``{name: int}`` (or float): the sentence-level counts
+    (``n_frames``, ``n_phones``) of the reference's data layout (README.rst:139-150)."""
+
+    use_deltas = False
+
+    def __init__(self, name, ext='txt'):
+        self.name, self.ext = name, ext
+
+    def __call__(self, base_name, data_dir):
+        with open(os.path.join(data_dir, self.name, '{}.{}'.format(base_name, self.ext))) as f:
+            text = f.read().strip()
+        try:
+            return {self.name: int(text)}
+        except ValueError:
+            return {self.name: float(text)}
+
+
+class FilesDataset(object):
+    """File-backed utterances in front of ``DeviceBatches``: the reference's ``FilesDataset`` (data.py:60-157) - same constructor
+    arguments, id-list handling (joined to ``data_root``, not to the split directory: data.py:100) and checks (:89-94).
+
+    ``dataset[i]`` is what the reference's ``__getitem__`` returns: the features of every data source plus, for each feature with a
+    normaliser, its ``normalised_`` twin computed on the host in NumPy and cast to float32 (:119-127, :144-150).
+    ``dataset.raw(i)`` is the same utterance WITHOUT the twins - what ``DeviceBatches`` takes, because ``collate_to_device`` pads
+    and normalises on the device in one pass.  Speaker-dependent normalisers are out of scope."""
+
+    def __init__(self, data_sources, data_dir, id_list, normalisers, data_root='.'):
+        for name, normaliser in normalisers.items():
+            if name in data_sources and normaliser.use_deltas and not data_sources[name].use_deltas:
+                raise ValueError(f'To normalise deltas of {name}, set `data_source.use_deltas` to True.')
+        self.data_sources = data_sources
+        self.data_root = data_root
+        self.data_dir = os.path.join(data_root, data_dir)
+        self.id_list = os.path.join(data_root, id_list)
+        with open(self.id_list, 'r') as f:
+            self.file_ids = [line.strip() for line in f if line.strip()]
+        self.normalisers = normalisers
+
+    def __len__(self):
+        return len(self.file_ids)
+
+    def raw(self, index):
+        base_name = self.file_ids[index]
+        features = {'name': base_name}
+        for data_source in self.data_sources.values():
+            features.update(data_source(base_name, self.data_dir))
+        return features
+
+    def __getitem__(self, index):
+        features = self.raw(index)
+        for name in self.data_sources:
+            normaliser = self.normalisers.get(name)
+            if normaliser is None:
+                continue
+            features['normalised_' + name] = normaliser.normalise(features[name]).astype(np.float32)
+            if normaliser.use_deltas:
+                deltas = name + '_deltas'
+                features['normalised_' + deltas] = normaliser.normalise(features[deltas], deltas=True).astype(np.float32)
+        return features
+
+    collate_fn = staticmethod(collate_fn)
+
+
+def batch(data_generator, batch_size=32, shuffle=True, num_data_threads=0, device='cuda:0'):
+    """The reference's ``data.batch`` (data.py:29-57) for a ``FilesDataset``: a loader of device-resident batches.  Files are read
+    on the calling thread as each batch is formed (``num_data_threads`` is accepted for signature compatibility; worker
+    subprocesses are the reference's answer to a host-bound collate, which here runs on the device)."""
+    rng = np.random.RandomState(torch.initial_seed() % (2 ** 32)) if shuffle else None
+    return DeviceBatches(data_generator, batch_size, data_generator.normalisers, device, shuffle=rng)
+
+
 class DeviceBatches(object):
-    """The DataLoader + ``ToDeviceWrapper`` of the reference (data.py:50-55, :648-663) for utterances that are already in host
-    memory: an iterable of feature dicts on ``device``, each batch padded and normalised there by ``collate_to_device``.
+    """The DataLoader + ``ToDeviceWrapper`` of the reference (data.py:50-55, :648-663): an iterable of feature dicts on ``device``,
+    each batch padded and normalised there by ``collate_to_device``.  ``utterances`` is a ``FilesDataset`` (read lazily, batch by
+    batch, through ``raw``) or a sequence of utterances that are already in host memory.
 
     ``utterances`` is a sequence of RAW per-utterance feature dicts (what a ``_DataSource`` returns: float32 ``(len, D)``
     arrays, integer ``dur``, python ints, the name); ``normalisers`` maps feature names to normalisers (``Normalisers`` or a
@@ -294,7 +411,7 @@ class DeviceBatches(object):
     def __init__(self, utterances, batch_size, normalisers, device, shuffle=None):
         if batch_size <= 0:
             raise ValueError('batch_size must be positive, got %r' % (batch_size,))
-        self.utterances = list(utterances)
+        self.utterances = utterances if isinstance(utterances, FilesDataset) else list(utterances)
         self.batch_size = int(batch_size)
         self.normalisers = normalisers
         self.device = torch.device(device)
@@ -308,5 +425,6 @@ class DeviceBatches(object):
         if self.shuffle is not None:
             order = self.shuffle.permutation(len(self.utterances))
         for start in range(0, len(order), self.batch_size):
-            batch = [self.utterances[i] for i in order[start:start + self.batch_size]]
+            fetch = self.utterances.raw if isinstance(self.utterances, FilesDataset) else self.utterances.__getitem__
+            batch = [fetch(int(i)) for i in order[start:start + self.batch_size]]
             yield collate_to_device(batch, self.normalisers, self.device)

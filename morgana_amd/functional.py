@@ -32,6 +32,18 @@ def get_precision():
 
 _ONES = {}
 
+# Called (no arguments) from inside a backward pass at the moment every parameter gradient EXCEPT those of the stack's first Linear
+# layer has reached the optimiser's flat buffer - the data-parallel step starts exchanging that part while the first layer's weight
+# gradient (81 % of the bytes of the README F0Model, and the last kernel of the backward) is still being computed.
+_EARLY_GRADS_HOOK = None
+
+
+def set_early_grads_hook(fn):
+    """Install (or with None remove) the callback described above; returns the previous one."""
+    global _EARLY_GRADS_HOOK
+    prev, _EARLY_GRADS_HOOK = _EARLY_GRADS_HOOK, fn
+    return prev
+
 
 def backward(loss):
     """``loss.backward()`` (experiment_builder.py:473) with the implicit gradient of one taken from a per-device cache:
@@ -65,6 +77,8 @@ class LinearStackFn(torch.autograd.Function):
 
     forward(ctx, spec, x2d, rows, *params); spec = (acts, precision); params = w0, b0, w1, b1, ... (bias may be None).
     With ``rows`` the input row m is ``x2d[rows[m]]`` (zero row for -1): the frame-rate tensor is never materialised.
+    When such a gathered input needs a gradient (packed frames, ``utils.FrameLayout``: the rows are distinct) the input gradient is
+    scattered back to the rows of ``x2d``; rows no index points at get zeros.
     """
 
     @staticmethod
@@ -81,6 +95,9 @@ class LinearStackFn(torch.autograd.Function):
             raise ValueError('LinearStackFn: extra zero rows go with a plain fp32 input that needs no gradient')
         m = rows.numel() if rows is not None else x2d.shape[0] + extra
         ctx.spec, ctx.m = spec, m
+        ctx.n_src = x2d.shape[0]
+        gathered_grad = rows is not None and ctx.needs_input_grad[1]
+        rows_k = rows                                  # the row map the kernels' loaders apply (None once the input is packed)
         ctx.has_bias = [b is not None for b in biases]
         ctx.dims = [(w.shape[0], w.shape[1]) for w in weights]
         k_in = weights[0].shape[1]
@@ -97,10 +114,16 @@ class LinearStackFn(torch.autograd.Function):
                 r = None
                 hidden.append(a)
             out = a
-            ctx.save_for_backward(x2d, rows, *weights, *hidden)
+            ctx.save_for_backward(x2d, rows_k, rows if gathered_grad else None, *weights, *hidden)
         else:
-            a = x2d if pre_cast else ops.cast_pad_bf16(x2d, extra_rows=extra)
-            a0, r = a, rows
+            if gathered_grad:
+                if pre_cast:
+                    raise ValueError('LinearStackFn: a gathered input that needs a gradient must be fp32')
+                # pack and cast in one pass: the bf16 operand holds exactly the gathered rows
+                a, rows_k = ops.gather_rows(x2d, rows, out_bf16=True, ld=ops.pad_ld(k_in)), None
+            else:
+                a = x2d if pre_cast else ops.cast_pad_bf16(x2d, extra_rows=extra)
+            a0, r = a, rows_k
             for i in range(n_layers):
                 n, k = weights[i].shape
                 w_bf = ops.cast_pad_bf16(ops._require(weights[i], torch.float32, 'weight'))
@@ -113,7 +136,7 @@ class LinearStackFn(torch.autograd.Function):
             if out.shape[1] != n_last:
                 out = out[:, :n_last].contiguous()
                 # keep the padded fp32 activation only if a trailing sigmoid needs it in backward
-            ctx.save_for_backward(a0, rows, *weights, *hidden[:-1], out)
+            ctx.save_for_backward(a0, rows_k, rows if gathered_grad else None, *weights, *hidden[:-1], out)
         return out
 
     @staticmethod
@@ -121,9 +144,9 @@ class LinearStackFn(torch.autograd.Function):
         acts, precision = ctx.spec[:2]
         n_layers = len(acts)
         saved = ctx.saved_tensors
-        x_in, rows = saved[0], saved[1]
-        weights = saved[2:2 + n_layers]
-        hidden = saved[2 + n_layers:]
+        x_in, rows, scatter_to = saved[0], saved[1], saved[2]
+        weights = saved[3:3 + n_layers]
+        hidden = saved[3 + n_layers:]
         m = ctx.m
         grads = [None] * (2 * n_layers)
         need_x = ctx.needs_input_grad[1]
@@ -158,9 +181,9 @@ class LinearStackFn(torch.autograd.Function):
                     grad_x = ops.linear_dgrad_bf16(g, m, n, wt, k, None, out_f32=True)
                     if grad_x.shape[1] != k:
                         grad_x = grad_x[:, :k].contiguous()
-        if need_x and rows is not None:
-            raise RuntimeError('LinearStackFn: gradient w.r.t. a gathered input is not available on the fused path; '
-                               'materialise the upsample first (upsample_to_repetitions(..., fused=False))')
+        if need_x and scatter_to is not None:
+            # the input rows were gathered (distinct rows): their gradients go back where they came from, all other rows get zeros
+            grad_x = ops.scatter_rows(grad_x, scatter_to, ctx.n_src)
         return (None, grad_x, None) + tuple(grads)
 
 
@@ -185,6 +208,28 @@ class RepeatTableRowsFn(torch.autograd.Function):
             g = torch.nn.functional.pad(g, (0, 8 - width % 8))
         sums = ops.segment_sum(g, rows, seg, ctx.n_phone_rows, g.shape[1], extra=ctx.extra)
         return (sums[:, :width].contiguous() if sums.shape[1] != width else sums), None, None, None
+
+
+class UnpackRowsFn(torch.autograd.Function):
+    """Packed rows (total + 1, D) -> dense (B*T, D): dense row (b, t) takes its packed row, every padded frame takes the one
+    representative row (index ``total``).  Backward: the valid rows' gradients are gathered back by ``rows`` and the representative
+    row receives the sum over all padded frames (``mg_pad_rows_colsum_f32``) - exact also for losses that do not mask."""
+
+    @staticmethod
+    def forward(ctx, packed, rows, inverse, seq_len, b, t):
+        packed = ops._require(packed, torch.float32, 'packed rows')
+        ctx.save_for_backward(rows, seq_len)
+        ctx.shape = (b, t, packed.shape[1])
+        return ops.gather_rows(packed, inverse)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        rows, seq_len = ctx.saved_tensors
+        b, t, d = ctx.shape
+        g = grad_out.contiguous()
+        out = ops.gather_rows(g.view(b * t, d), rows)            # rows[total] = -1: a zero row, replaced by the padded frames' sum
+        ops.pad_rows_colsum(g.view(b, t, d), seq_len, out[rows.numel() - 1])
+        return out, None, None, None, None, None
 
 
 def _deliver_param_grads(params, flat, offsets, grad_loss=None):
@@ -219,6 +264,25 @@ def _deliver_param_grads(params, flat, offsets, grad_loss=None):
         out.append(g if grad_loss is None else g * grad_loss)
         j += 1
     return out
+
+
+def _deliver_early(params, flat, offsets, grad_loss):
+    """With an early-gradients hook installed and the optimiser's flat buffer as target: deliver everything but the first layer's
+    (weight, bias) now and fire the hook.  Returns True if it did (``_deliver_rest`` then hands over the first layer only)."""
+    if _EARLY_GRADS_HOOK is None or len(params) <= 2 or any(p is None for p in params):
+        return False
+    tail = _deliver_param_grads(params[2:], flat[offsets[2]:], [o - offsets[2] for o in offsets[2:]], grad_loss)
+    if any(t is not None for t in tail):
+        raise RuntimeError('early gradient exchange needs the parameters in morgana_amd.optim.Adam\'s flat buffer')
+    _EARLY_GRADS_HOOK()
+    return True
+
+
+def _deliver_rest(params, flat, offsets, grad_loss, early):
+    if not early:
+        return _deliver_param_grads(params, flat, offsets, grad_loss)
+    head = _deliver_param_grads(params[:2], flat[:offsets[2]], offsets[:2], grad_loss)
+    return list(head) + [None] * (len(params) - 2)
 
 
 class LinearStackMSEFn(torch.autograd.Function):
@@ -329,16 +393,20 @@ class LinearStackMSEFn(torch.autograd.Function):
             table = hidden[0]
             ow, ob = grad_slots(1)
             ops.linear_wgrad_bf16(g, table, None, table.shape[0], n1, k1, out_w=ow, out_b=ob)
+            early = _deliver_early(ctx.params, flat[:flat.numel() - 1], ctx.offsets, grad_loss)
             dz0 = ops.linear_dgrad_bf16(g, table.shape[0], n1, w_t[1], k1, table)
             ow, ob = grad_slots(0)
             ops.linear_wgrad_bf16(dz0, a0, None, table.shape[0], n0, k0, out_w=ow, out_b=ob)
-            grads = _deliver_param_grads(ctx.params, flat[:flat.numel() - 1], ctx.offsets, grad_loss)
+            grads = _deliver_rest(ctx.params, flat[:flat.numel() - 1], ctx.offsets, grad_loss, early)
             return (None, None, None, None, None) + tuple(grads)
+        early = False
         for i in range(lead - 1, -1, -1):
             n, k = ctx.dims[i]
             a_in, r = (a0, rows) if i == 0 else (hidden[i - 1], None)
             ow, ob = grad_slots(i)
             ops.linear_wgrad_bf16(g, a_in, r, m, n, k, out_w=ow, out_b=ob)
+            if i == 1:
+                early = _deliver_early(ctx.params, flat[:flat.numel() - 1], ctx.offsets, grad_loss)
             if i == 1 and ctx.acts[0] == ops.ACT_SIGMOID and ops.can_fuse_bwd(m, n, k, ctx.dims[0][1], a0.shape[1]):
                 # layer 0's dW, db straight from this layer's dZ: dZ_0 = (dZ_1 W_1) * H_0 (1 - H_0) stays on chip
                 n0_, k0_ = ctx.dims[0]
@@ -349,7 +417,7 @@ class LinearStackMSEFn(torch.autograd.Function):
             if i > 0:
                 h = hidden[i - 1] if ctx.acts[i - 1] == ops.ACT_SIGMOID else None
                 g = ops.linear_dgrad_bf16(g, m, n, w_t[i], k, h)
-        grads = _deliver_param_grads(ctx.params, flat[:flat.numel() - 1], ctx.offsets, grad_loss)
+        grads = _deliver_rest(ctx.params, flat[:flat.numel() - 1], ctx.offsets, grad_loss, early)
         return (None, None, None, None, None) + tuple(grads)
 
 

@@ -8,24 +8,67 @@ path around them (0.5 ms per step) is what bounds the step.  ``GraphedTrainStep`
 What makes the step capturable: every kernel of the path is launched on torch's current stream with no host synchronisation,
 scratch comes from torch's allocator (graph-private pool during capture), and the only step-dependent scalars - Adam's bias
 corrections - are read from device memory (``optim.Adam.advance`` / ``step_captured``, ``mg_adam_step_dev_f32``).  With more than
-one rank the gradient all-reduce stays OUTSIDE the graph (forward + backward graph, eager RCCL all-reduce, the one-kernel update
-launched directly).
+one rank the gradient all-reduce is captured too when the stack can do that (two buckets, the early one overlapped with the first
+layer's weight gradient; see ``GraphedTrainStep``), otherwise it stays outside the graph (forward + backward graph, eager RCCL
+all-reduce, the one-kernel update launched directly).
 
 The captured step works on fixed buffers: ``features`` must be the same device tensors for every replay (copy a new batch into
 them with ``load``; shapes must not change).  Metrics accumulated inside ``loss`` keep accumulating - their accumulators are device
 tensors.  The learning rate may change between replays (it enters through ``advance``).
 """
+import os
+
 import torch
 
 from . import functional
 
 
+def rccl_capture_works(device, group=None):
+    """Can this stack capture an RCCL all-reduce into a HIP graph and replay it correctly?  Captures one on a scratch buffer,
+    replays it twice and checks the sums; every rank then takes the minimum of the verdicts (one eager all-reduce), so that all ranks
+    choose the same exchange mode.  Any exception on the way counts as "no"."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    ok = 1.0
+    try:
+        buf = torch.empty(1024, dtype=torch.float32, device=device)
+        dist.all_reduce(buf.fill_(1.0), group=group)                   # communicator set-up outside the capture
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            buf.fill_(1.0)
+            dist.all_reduce(buf, group=group)                           # warm-up on the capture stream
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+            dist.all_reduce(buf, group=group)
+        for _ in range(2):
+            buf.fill_(1.0)
+            graph.replay()
+            torch.cuda.synchronize()
+            if not bool((buf == float(world)).all().item()):
+                ok = 0.0
+    except Exception:                                                   # noqa: BLE001 - any failure means "use the eager exchange"
+        ok = 0.0
+    verdict = torch.full((1,), ok, dtype=torch.float32, device=device)
+    dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=group)
+    return bool(verdict.item() > 0.5)
+
+
 class GraphedTrainStep(object):
-    def __init__(self, model, optimizer, features, warmup=3):
+    """``exchange`` (more than one rank only): 'captured' = the gradient all-reduce is part of the graph - the bucket that is final
+    before the first layer's weight gradient starts goes out on a side stream underneath that kernel, the rest right behind it,
+    then the update: ONE launch per step from the host; 'eager' = forward + backward graph, one eager RCCL all-reduce of the whole
+    bucket, the update kernel launched directly (three launches, nothing overlapped); 'auto' (default, or $MG_EXCHANGE) = captured if
+    ``rccl_capture_works`` says so on every rank, else eager.  The mode taken is in ``exchange_mode``."""
+
+    def __init__(self, model, optimizer, features, warmup=3, exchange=None):
         self.model, self.optimizer, self.features = model, optimizer, features
         self.loss = None
         self.output = None
-        self._multi = optimizer._world() > 1
+        self._multi = optimizer.exchanging()
+        self.exchange_mode = 'none'
         if warmup:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -34,6 +77,15 @@ class GraphedTrainStep(object):
                     self._eager_step()
             torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if self._multi:
+            want = exchange or os.environ.get('MG_EXCHANGE', 'auto')
+            if want not in ('auto', 'captured', 'eager'):
+                raise ValueError("exchange must be 'auto', 'captured' or 'eager', got %r" % (want,))
+            device = optimizer.flat_buffers()['grad'].device
+            captured = want != 'eager' and rccl_capture_works(device, optimizer.process_group)
+            if want == 'captured' and not captured:
+                raise RuntimeError('exchange="captured": this stack cannot capture an RCCL all-reduce into a HIP graph')
+            self.exchange_mode = 'captured' if captured else 'eager'
         self._fwd_bwd = torch.cuda.CUDAGraph()
         self.optimizer.prepare_capture()               # capture records the launches, it does not run them
         # with a process group alive its watchdog thread polls events while we capture: judge only this thread's calls
@@ -41,10 +93,39 @@ class GraphedTrainStep(object):
         with torch.cuda.graph(self._fwd_bwd, **mode):
             self.optimizer.zero_grad()
             self.loss, self.output = self.model(self.features)
-            functional.backward(self.loss)
-            if not self._multi:
+            if self.exchange_mode == 'captured':
+                self._capture_backward_and_exchange()
                 self.optimizer.step_captured()
+            else:
+                functional.backward(self.loss)
+                if not self._multi:
+                    self.optimizer.step_captured()
         self.steps_done = warmup
+
+    def _capture_backward_and_exchange(self):
+        """Backward with the early bucket's all-reduce forked onto a side stream the moment its gradients are final (the hook fires
+        inside the backward pass, ahead of the first layer's weight-gradient kernel), joined again before the late bucket's."""
+        main = torch.cuda.current_stream()
+        comm = torch.cuda.Stream()
+        fired = []
+
+        def early_bucket_ready():
+            comm.wait_stream(main)
+            with torch.cuda.stream(comm):
+                self.optimizer.exchange_gradients('early')
+            fired.append(True)
+
+        split = self.optimizer.bucket_split() > 0
+        prev = functional.set_early_grads_hook(early_bucket_ready if split else None)
+        try:
+            functional.backward(self.loss)
+        finally:
+            functional.set_early_grads_hook(prev)
+        if fired:
+            main.wait_stream(comm)
+            self.optimizer.exchange_gradients('late')
+        else:
+            self.optimizer.exchange_gradients()        # a model whose backward has no early point: one collective
 
     def _eager_step(self):
         self.optimizer.zero_grad()
@@ -62,7 +143,7 @@ class GraphedTrainStep(object):
         """One training step; returns the (device, 0-d) loss tensor of the captured step - valid until the next call."""
         self.optimizer.advance()
         self._fwd_bwd.replay()
-        if self._multi:
+        if self.exchange_mode == 'eager':
             self.optimizer.exchange_gradients()        # the step's one RCCL all-reduce, outside the graph
             self.optimizer.step_captured()             # one kernel: launched directly
         self.steps_done += 1
@@ -84,7 +165,9 @@ class GraphedStepCache(object):
 
     @staticmethod
     def signature(features):
-        return tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in features.items() if isinstance(v, torch.Tensor)))
+        # host-side integers (n_frames_total sizes the packed-frame layout) are part of what a captured step was built for
+        return tuple(sorted((k, tuple(v.shape), str(v.dtype)) if isinstance(v, torch.Tensor) else (k, v)
+                            for k, v in features.items() if isinstance(v, (torch.Tensor, int))))
 
     def step(self, features):
         """zero_grad, forward, backward, optimizer step on ``features``; returns (loss, output_features)."""

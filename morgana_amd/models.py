@@ -102,7 +102,10 @@ class RNNSPSS(BaseSPSS):
         max_len = target.shape[1] if target is not None else None
         norm_lab_at_frame_rate = utils.upsample_to_repetitions(features['normalised_lab'], features['dur'],
                                                                max_len=max_len, fused=self.fused_upsample)
-        pred_norm, _ = self.layers(norm_lab_at_frame_rate, seq_len=features['n_frames'])
+        # max_len: the padded frame axis is the longest utterance (collate_fn, data.py:183-193), so the GRU wrapper need not read
+        # seq_len back to crop its output (utils.py:383) - no host sync in the step, which makes it capturable as a HIP graph
+        layout = utils.FrameLayout.for_batch(features, max_len) if max_len is not None else None
+        pred_norm, _ = self.layers(norm_lab_at_frame_rate, seq_len=features['n_frames'], max_len=max_len, layout=layout)
         outputs = {'pred_norm_' + self.target_name: pred_norm}
         if self.target_name in self.normalisers:
             outputs['pred_' + self.target_name] = self.normalisers[self.target_name].denormalise(pred_norm.detach())
@@ -168,7 +171,7 @@ class LSTMAcousticModel(BaseSPSS):
         norm_lab_at_frame_rate = utils.upsample_to_repetitions(features['normalised_lab'], features['dur'],
                                                                max_len=norm_counters.shape[1], fused=self.fused_upsample)
         model_inputs = utils.concat_frame_features(norm_lab_at_frame_rate, norm_counters)
-        pred_norm_deltas, _ = self.layers(model_inputs, seq_len=features['n_frames'])
+        pred_norm_deltas, _ = self.layers(model_inputs, seq_len=features['n_frames'], max_len=norm_counters.shape[1])
         return pred_norm_deltas
 
     def _split(self, pred_norm_deltas, pred_vuv=None):
@@ -278,7 +281,7 @@ class GRUF0Model(BaseSPSS):
                                                                max_len=norm_counters.shape[1], fused=self.fused_upsample)
         model_inputs = utils.concat_frame_features(norm_lab_at_frame_rate, norm_counters)
         n_frames = features['n_frames']
-        pred_norm_lf0_deltas, _ = self.layers(model_inputs, seq_len=n_frames)
+        pred_norm_lf0_deltas, _ = self.layers(model_inputs, seq_len=n_frames, max_len=norm_counters.shape[1])
         outputs = {'normalised_lf0_deltas': pred_norm_lf0_deltas}
         if self.generate and _has_delta_params(self.normalisers, 'lf0'):
             # MLPG to select the most probable trajectory given the delta and delta-delta features (:83-89)

@@ -91,13 +91,13 @@ def upsample_index_maps(dur, t_cap):
     return rows[0], rows[1], seg
 
 
-def gather_rows(src2d, rows, out_bf16=False):
+def gather_rows(src2d, rows, out_bf16=False, ld=None):
     lib = _lib.load()
     src2d = _require(src2d, torch.float32, 'src')
     rows = _require(rows, torch.int32, 'rows')
     m, f = rows.numel(), src2d.shape[1]
     if out_bf16:
-        ldo = pad8(f)
+        ldo = pad8(f) if ld is None else int(ld)
         out = torch.empty((m, ldo), dtype=torch.bfloat16, device=src2d.device)
         _lib.check(lib.mg_gather_rows_bf16(_p(src2d), _p(rows), _p(out), m, f, ldo, _stream()), 'mg_gather_rows_bf16')
     else:
@@ -127,6 +127,29 @@ def scatter_rows(src2d, rows, n_dst_rows):
     _lib.check(lib.mg_scatter_rows_f32(_p(src2d), _p(rows), _p(dst), rows.numel(), src2d.shape[1], _stream()),
                'mg_scatter_rows_f32')
     return dst
+
+
+def frame_layout(seq_len, t, total):
+    """Packed-frame maps of a ragged (B, t, .) batch (mg_frame_layout): (offsets (B+1,), rows (total+1,), inverse (B*t,)) int32.
+    ``total`` = sum of min(seq_len, t), known on the host."""
+    lib = _lib.load()
+    seq_len = _require(seq_len, torch.int64, 'seq_len')
+    b = seq_len.numel()
+    offsets = torch.empty(b + 1, dtype=torch.int32, device=seq_len.device)
+    rows = torch.empty(int(total) + 1, dtype=torch.int32, device=seq_len.device)
+    inverse = torch.empty(b * int(t), dtype=torch.int32, device=seq_len.device)
+    _lib.check(lib.mg_frame_layout(_p(seq_len), b, int(t), int(total), _p(offsets), _p(rows), _p(inverse), _stream()), 'mg_frame_layout')
+    return offsets, rows, inverse
+
+
+def pad_rows_colsum(g, seq_len, out):
+    """out (D,) = sum of g[b, t, :] over the padded frames t >= seq_len[b] (mg_pad_rows_colsum_f32); g (B, T, D) f32."""
+    lib = _lib.load()
+    g = _require(g, torch.float32, 'gradient')
+    b, t, d = g.shape
+    ws = torch.empty(lib.mg_pad_rows_colsum_workspace_bytes(b, t, d), dtype=torch.uint8, device=g.device)
+    _lib.check(lib.mg_pad_rows_colsum_f32(_p(g), _p(seq_len), b, t, d, _p(out), _p(ws), ws.numel(), _stream()), 'mg_pad_rows_colsum_f32')
+    return out
 
 
 def gather_concat(src2d, rows, extra2d, out_bf16=False):

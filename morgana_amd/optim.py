@@ -20,10 +20,13 @@ class Adam(torch.optim.Optimizer):
     the HIP kernel."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, process_group=None,
-                 kernel=None):
+                 kernel=None, exchange_always=False):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super(Adam, self).__init__(params, defaults)
         self.process_group = process_group
+        # exchange_always: run the gradient exchange whenever a process group exists, also at world size 1 (where it is the
+        # identity) - lets the one-GPU box exercise the multi-rank code path on a live RCCL communicator
+        self.exchange_always = exchange_always
         self._kernel = kernel if kernel is not None else ops.adam_step
         self._flat = []
         for group in self.param_groups:
@@ -72,12 +75,40 @@ class Adam(torch.optim.Optimizer):
             flat['scalars'] = torch.zeros(2, dtype=torch.float32, device=flat['param'].device)
         return flat['scalars']
 
-    def exchange_gradients(self):
-        """The step's one gradient all-reduce (no-op on one rank); ``step`` calls it, a graphed step calls it between its graphs."""
-        if self._world() > 1:
-            for flat in self._flat:
-                if flat is not None:
-                    dist.all_reduce(flat['grad'], op=dist.ReduceOp.SUM, group=self.process_group)
+    def exchanging(self):
+        """True when ``step`` has a gradient exchange to do."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return self._world() > 1 or self.exchange_always
+
+    def bucket_split(self, group=0):
+        """Element index that cuts the flat gradient into the part produced LAST by the backward pass ([:split], the first Linear
+        layer's weight and bias: 81 % of the README F0Model's bytes) and the part that is final before that layer's weight-gradient
+        kernel starts ([split:]).  0 = no cut (the first layer is less than a quarter of the gradient, or there is nothing else)."""
+        flat = self._flat[group]
+        if flat is None or len(flat['params']) < 3:
+            return 0
+        first = flat['params'][0].numel() + (flat['params'][1].numel() if flat['params'][1].dim() == 1 else 0)
+        total = flat['grad'].numel()
+        return first if 4 * first >= total and first < total else 0
+
+    def exchange_gradients(self, part=None):
+        """The step's gradient all-reduce (SUM; the mean is folded into the update kernel).  ``part``: None = the whole flat buffer
+        in one collective; 'early' / 'late' = the two sides of ``bucket_split`` (a step that overlaps the early side with the rest
+        of its backward pass calls both, so every element is still reduced exactly once).  No-op without a process group."""
+        if not self.exchanging():
+            return
+        for g, flat in enumerate(self._flat):
+            if flat is None:
+                continue
+            split = self.bucket_split(g)
+            buf = flat['grad']
+            if part == 'early':
+                buf = buf[split:] if split else None
+            elif part == 'late':
+                buf = buf[:split] if split else buf
+            if buf is not None and buf.numel():
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.process_group)
 
     def prepare_capture(self):
         for flat in self._flat:
@@ -116,7 +147,7 @@ class Adam(torch.optim.Optimizer):
         for group, flat in zip(self.param_groups, self._flat):
             if flat is None:
                 continue
-            if world > 1:
+            if self.exchanging():
                 # the single gradient exchange of the step: sum over ranks, mean folded into the kernel below
                 dist.all_reduce(flat['grad'], op=dist.ReduceOp.SUM, group=self.process_group)
             flat['step'] += 1

@@ -4,9 +4,12 @@ per-frame compute done by the HIP kernels of libmorgana_hip.so (no torch-op or C
 Reference: morgana/utils.py - ``sequence_mask`` :115-144, ``upsample_to_repetitions`` :175-228,
 ``split_to_segments`` :231-285, ``get_segment_ends`` :288-330, ``RecurrentCuDNNWrapper`` :333-393, ``SequentialWithRecurrent`` :396-418, ``ExponentialMovingAverage`` :421-456.
 """
+import os
+
 import torch
 import torch.nn as nn
 
+from . import _lib
 from . import functional as F_hip
 from . import ops
 
@@ -86,6 +89,49 @@ class PhoneTable(object):
         if self._maps is None:
             self._maps = ops.segment_bounds(self.rows.reshape(-1), self.n_phone_rows, pad_row=self.n_phone_rows)
         return self._maps
+
+
+PACKED_FRAMES = os.environ.get('MORGANA_PACKED_FRAMES', '1') != '0'
+
+
+def set_packed_frames(enabled):
+    """Row-wise layers behind a recurrent wrapper run on the valid frames of a ragged batch only (``FrameLayout``); off = on all
+    B * T padded rows as the reference does.  Results are the same either way (tests/test_gpu_configs.py)."""
+    global PACKED_FRAMES
+    PACKED_FRAMES = bool(enabled)
+
+
+class FrameLayout(object):
+    """Packed-frame maps of a ragged batch: which of the B * T rows of a zero-padded (B, T, .) tensor are real frames.
+
+    The reference pads every batch to its longest utterance (``collate_fn``, morgana/data.py:183-193), applies nn.Linear to all
+    B * T rows (morgana/utils.py:401-418) and masks the loss (losses.py:37-39); at BASELINE config C5 (300-2000 frames) 41 % of
+    those rows are padding.  With a layout, ``SequentialWithRecurrent`` runs the Linear / Sigmoid layers that follow a recurrent
+    wrapper on the ``total`` valid rows plus ONE representative padding row (behind the wrapper every padded frame is the same
+    zero row, utils.py:383) and scatters the result back to (B, T, .) - padded predictions included, so nothing changes for the
+    caller.  ``total`` comes from the host (the loader knows the lengths it collated: ``features['n_frames_total']``), so
+    building the maps costs no device -> host read."""
+
+    def __init__(self, seq_len, t, total):
+        seq_len = seq_len if seq_len.dtype == torch.int64 else seq_len.long()
+        self.seq_len, self.b, self.t, self.total = seq_len.contiguous(), seq_len.numel(), int(t), int(total)
+        self.offsets, self.rows, self.inverse = ops.frame_layout(self.seq_len, self.t, self.total)
+
+    @classmethod
+    def for_batch(cls, features, t, seq_len_key='n_frames'):
+        """Layout for ``features`` if packing is enabled and the loader recorded the host-side frame total; else None."""
+        total = features.get(seq_len_key + '_total')
+        if not PACKED_FRAMES or total is None or int(t) <= 0:
+            return None
+        return cls(features[seq_len_key], t, min(int(total), features[seq_len_key].numel() * int(t)))
+
+    def worthwhile(self):
+        """Packing costs a gather each way: use it when at least a tenth of the rows are padding."""
+        return 10 * (self.total + 1) <= 9 * self.b * self.t
+
+    def unpack(self, packed):
+        out = F_hip.UnpackRowsFn.apply(packed, self.rows, self.inverse, self.seq_len, self.b, self.t)
+        return out.view(self.b, self.t, packed.shape[1])
 
 
 class UpsampledConcat(object):
@@ -184,7 +230,7 @@ class RecurrentCuDNNWrapper(nn.Module):
     ``nn.GRU`` (single layer, unidirectional, batch_first - the shape used by models/f0_test_model.py:32-39) and
     ``nn.LSTM`` (any number of layers, unidirectional, batch_first - models/RNN_SPSS.py:36-37) run on the HIP recurrences;
     the parameters stay the wrapped layer's own (``layer.weight_ih_l0`` ...), so state_dict keys match the reference.
-    Other layer types (bidirectional, projections, multi-layer GRU) run through torch's packed-sequence path on the device.
+    Other layer types (bidirectional, projections, multi-layer GRU) raise ``MorganaHipError``: there is no torch / MIOpen fallback.
     """
 
     def __init__(self, layer, precision=None):
@@ -245,52 +291,57 @@ class RecurrentCuDNNWrapper(nn.Module):
         return F_hip.GRUFn.apply(precision, inputs, hidden, seq_len, layer.weight_ih_l0, layer.weight_hh_l0,
                                  layer.bias_ih_l0, layer.bias_hh_l0)
 
-    def forward(self, inputs, hidden=None, seq_len=None):
+    def _unsupported(self):
+        layer = self.layer
+        return _lib.MorganaHipError(
+            'RecurrentCuDNNWrapper: %s(num_layers=%s, bidirectional=%s, batch_first=%s, bias=%s, proj_size=%s) has no HIP recurrence '
+            'in libmorgana_hip.so (built: single-layer unidirectional batch_first nn.GRU, unidirectional batch_first nn.LSTM with any '
+            'number of layers); there is no torch / MIOpen fallback'
+            % (type(layer).__name__, getattr(layer, 'num_layers', '?'), getattr(layer, 'bidirectional', '?'),
+               getattr(layer, 'batch_first', '?'), getattr(layer, 'bias', '?'), getattr(layer, 'proj_size', 0)))
+
+    def run_full_length(self, inputs, hidden=None):
+        """The wrapped layer on a padded (B, T, F) batch with every item running all T steps: what calling the bare torch layer does."""
+        if not (self._hip_gru() or self._hip_lstm()):
+            raise self._unsupported()
+        if isinstance(inputs, nn.utils.rnn.PackedSequence) or inputs.ndim != 3:
+            return self.forward(inputs, hidden, None)
+        return (self._run_gru if self._hip_gru() else self._run_lstm)(inputs.contiguous(), hidden, None)
+
+    def forward(self, inputs, hidden=None, seq_len=None, max_len=None):
+        """``max_len`` (not in the reference): the caller's upper bound on ``max(seq_len)``, normally the padded frame axis of the
+        batch.  The reference crops the output to the longest item (``pad_packed_sequence``, utils.py:383), which costs a
+        device -> host read of ``seq_len`` per call; when the input's time axis already equals ``max_len`` - every batch whose longest
+        utterance defines its padding, i.e. every batch ``collate_fn`` builds - the result is identical without that read, and the
+        step stays capturable as a HIP graph.  ``SequentialWithRecurrent`` passes it when its own caller does."""
+        if not (self._hip_gru() or self._hip_lstm()):
+            raise self._unsupported()
+        run = self._run_gru if self._hip_gru() else self._run_lstm
         if seq_len is None:
             if isinstance(inputs, nn.utils.rnn.PackedSequence):
-                return self.layer(inputs, hx=hidden)
+                # already packed (utils.py:347-349): unpack to the padded layout the kernels work on, pack the result again
+                padded, lens = nn.utils.rnn.pad_packed_sequence(inputs, batch_first=True)
+                outputs, hidden = run(padded.contiguous(), hidden, lens.to(padded.device))
+                return nn.utils.rnn.pack_padded_sequence(outputs, lens, batch_first=True, enforce_sorted=False), hidden
             elif inputs.ndim == 2:
                 seq_dim = 1 if self.layer.batch_first else 0
-                inputs = inputs.unsqueeze(seq_dim)
-                if self._hip_gru():
-                    outputs, hidden = self._run_gru(inputs.contiguous(), hidden, None)
-                elif self._hip_lstm():
-                    outputs, hidden = self._run_lstm(inputs.contiguous(), hidden, None)
-                else:
-                    outputs, hidden = self.layer(inputs, hx=hidden)
+                outputs, hidden = run(inputs.unsqueeze(seq_dim).contiguous(), hidden, None)
                 return outputs.squeeze(seq_dim), hidden
             else:
                 raise ValueError('If no seq_len is provided to RecurrentCuDNNWrapper the data must be already packed'
                                  f'or must be for one time slice only. For non-packed input got shape, {inputs.shape}')
 
-        if self._hip_gru() or self._hip_lstm():
-            seq_len = seq_len if seq_len.dtype == torch.int64 else seq_len.long()
-            t_out = int(torch.max(seq_len).item())          # pad_packed_sequence crops to the longest item
-            if isinstance(inputs, PhoneTable):
-                return self._run_gru(inputs.crop(t_out), hidden, seq_len.contiguous())
-            if t_out != inputs.shape[1]:
-                inputs = inputs[:, :t_out]
-            run = self._run_gru if self._hip_gru() else self._run_lstm
-            return run(inputs.contiguous(), hidden, seq_len.contiguous())
-
-        # Out-of-scope layer types: the reference's own torch path (utils.py:366-391).
-        sorted_idxs = torch.argsort(seq_len, descending=True)
-        packed = nn.utils.rnn.pack_padded_sequence(inputs[sorted_idxs, ...], seq_len[sorted_idxs].cpu(),
-                                                   batch_first=True)
-        if hidden is not None:
-            if self.layer.mode == 'LSTM':
-                hidden = (hidden[0][:, sorted_idxs, :], hidden[1][:, sorted_idxs, :])
-            else:
-                hidden = hidden[:, sorted_idxs, :]
-        packed_outputs, hidden = self.layer(packed, hx=hidden)
-        sorted_outputs, _ = nn.utils.rnn.pad_packed_sequence(packed_outputs, batch_first=True)
-        unsort = torch.argsort(sorted_idxs)
-        outputs = sorted_outputs[unsort, ...]
-        if self.layer.mode == 'LSTM':
-            hidden = (hidden[0][:, unsort, :], hidden[1][:, unsort, :])
+        seq_len = seq_len if seq_len.dtype == torch.int64 else seq_len.long()
+        t_in = inputs.rows.shape[1] if isinstance(inputs, PhoneTable) else inputs.shape[1]
+        if max_len is not None and int(max_len) == t_in:
+            t_out = t_in                                    # the longest item fills the padded axis: nothing to crop, no host read
         else:
-            hidden = hidden[:, unsort, :]
-        return outputs, hidden
+            t_out = int(torch.max(seq_len).item())          # pad_packed_sequence crops to the longest item
+        if isinstance(inputs, PhoneTable):
+            return self._run_gru(inputs.crop(t_out), hidden, seq_len.contiguous())
+        if t_out != inputs.shape[1]:
+            inputs = inputs[:, :t_out]
+        return run(inputs.contiguous(), hidden, seq_len.contiguous())
 
 
 class SequentialWithRecurrent(nn.Sequential):
@@ -388,17 +439,35 @@ class SequentialWithRecurrent(nn.Sequential):
             params += [lin.weight, lin.bias]
         return F_hip.LinearStackMSEFn.apply((acts, maps), x2d, rows, targets, seq_len, *params)
 
-    def forward(self, input, hiddens=None, seq_len=None):
+    def forward(self, input, hiddens=None, seq_len=None, max_len=None, layout=None):
+        """``max_len`` (not in the reference) is handed to the recurrent wrappers: see ``RecurrentCuDNNWrapper.forward``.
+        ``layout`` (not in the reference): a ``FrameLayout`` of the batch - Linear / Sigmoid runs that follow a recurrent wrapper
+        then work on the valid frame rows only; the returned tensor is the same (B, T, .) either way."""
         modules = list(self._modules.values())
         if hiddens is None:
             hiddens = [None] * len(modules)
         precision = self.precision or F_hip.get_precision()
+        zero_padded = False          # input is (B, T, .) with exactly zero rows past seq_len (it came out of a recurrent wrapper)
 
         i = 0
         while i < len(modules):
             module = modules[i]
             if type(module) is nn.Linear:
                 end, run = self._linear_run(modules, i)
+                if (zero_padded and layout is not None and torch.is_tensor(input) and input.ndim == 3 and
+                        tuple(input.shape[:2]) == (layout.b, layout.t) and layout.worthwhile()):
+                    # packed frames: the run's GEMMs take sum_b T_b + 1 rows instead of B * T; the first layer's loader (fp32) or one
+                    # gather + cast pass (bf16) packs, ``layout.unpack`` restores (B, T, .) with the representative row on the padding
+                    params = []
+                    for lin, _ in run:
+                        params += [lin.weight, lin.bias]
+                    spec = (tuple(act for _, act in run), precision)
+                    packed = F_hip.LinearStackFn.apply(spec, input.reshape(-1, input.shape[-1]), layout.rows, *params)
+                    input = layout.unpack(packed)
+                    zero_padded = False
+                    i = end
+                    continue
+                zero_padded = False
                 nxt = modules[end] if end < len(modules) else None
                 n_src = input.source.shape[0] * input.source.shape[1] if isinstance(input, UpsampledSequence) else 0
                 if (isinstance(input, UpsampledSequence) and isinstance(nxt, RecurrentCuDNNWrapper) and nxt._hip_gru()
@@ -458,6 +527,7 @@ class SequentialWithRecurrent(nn.Sequential):
                     input, hn, cn = F_hip.LSTMStackPersistFn.apply(input.contiguous(), seq_len, None, None, *params)
                     for pos, k in enumerate(run):
                         hiddens[k] = (hn[pos:pos + 1], cn[pos:pos + 1])
+                    zero_padded = True
                     i = end
                     continue
                 if len(run) > 1 and not F_hip.lstm_persistent(precision, input.shape[0], input.shape[1], hid):
@@ -470,18 +540,25 @@ class SequentialWithRecurrent(nn.Sequential):
                                                             None, *params)
                     for pos, k in enumerate(run):
                         hiddens[k] = (hn[pos:pos + 1], cn[pos:pos + 1])
+                    zero_padded = True
                     i = end
                     continue
 
             if isinstance(module, RecurrentCuDNNWrapper):
-                input, hiddens[i] = module(input, hiddens[i], seq_len)
+                input, hiddens[i] = module(input, hiddens[i], seq_len, max_len=max_len)
+                zero_padded = seq_len is not None
             elif isinstance(module, nn.RNNBase):
-                input, hiddens[i] = module(input, hiddens[i])
+                # a bare recurrent layer in the container (utils.py:412-413): every item runs the full padded length
+                input, hiddens[i] = RecurrentCuDNNWrapper(module, precision=precision).run_full_length(input, hiddens[i])
+                zero_padded = False
             elif type(module) is nn.Sigmoid:
                 shape = input.shape
                 input = _SigmoidFn.apply(input.reshape(-1)).view(shape)
+                zero_padded = False
             else:
-                input = module(input)
+                identity = type(module) is nn.Dropout and (module.p == 0 or not module.training)
+                input = input if identity else module(input)
+                zero_padded = zero_padded and identity
             i += 1
 
         if isinstance(input, (UpsampledSequence, UpsampledConcat)):

@@ -805,3 +805,61 @@ def g15_metrics():
 
 if __name__ == '__main__' and (len(sys.argv) == 1 or sys.argv[1] == 'g15'):
     g15_metrics()
+
+
+def g16_collate():
+    """G16: the batches the reference's own ``FilesDataset.__getitem__`` (normalise on load, data.py:106-154) + ``collate_fn``
+    (zero-pad, data.py:159-224) yield for the G8 data set written to disk, in G8's recorded first-epoch batch order, with the
+    normaliser parameters loaded through ``_FeatureNormaliser.load_params`` from the JSON files.  Stored: every tensor of every
+    batch (padded raw and ``normalised_`` features, int64 durations and frame counts) and the name lists."""
+    import json
+    import tempfile
+    utils, losses, data, base_models, lr_schedules, metrics = import_reference()
+    file_io = sys.modules['tts_data_tools.file_io']
+    file_io.load_json = lambda path: json.load(open(path))
+    g8 = dict(np.load(os.path.join(HERE, 'g8_plumbing.npz'), allow_pickle=False))
+    names = [str(n) for n in g8['names']]
+    root = tempfile.mkdtemp(prefix='morgana_g16_')
+    for feat in ('lab', 'dur', 'lf0', 'n_frames'):
+        os.makedirs(os.path.join(root, 'train', feat), exist_ok=True)
+    for name in names:
+        for feat in ('lab', 'dur', 'lf0'):
+            np.save(os.path.join(root, 'train', feat, name + '.npy'), g8['data__%s__%s' % (name, feat)])
+        open(os.path.join(root, 'train', 'n_frames', name + '.txt'), 'w').write(str(int(g8['data__%s__dur' % name].sum())))
+    open(os.path.join(root, 'train_file_id_list.scp'), 'w').write('\n'.join(names) + '\n')
+    os.makedirs(os.path.join(root, 'processed'), exist_ok=True)
+    for key in ('lab_minmax', 'lf0_mvn'):
+        params = {k.split('__')[2]: g8[k].tolist() for k in g8 if k.startswith('norm__%s__' % key)}
+        json.dump(params, open(os.path.join(root, 'processed', key + '.json'), 'w'))
+
+    class NpySource(object):                       # satisfies what FilesDataset calls (data.py:93,135,142)
+        def __init__(self, name, use_deltas=False, as_int=False):
+            self.name, self.use_deltas, self.as_int = name, use_deltas, as_int
+
+        def __call__(self, base_name, data_dir):
+            if self.as_int:
+                return {self.name: int(open(os.path.join(data_dir, self.name, base_name + '.txt')).read())}
+            return {self.name: np.load(os.path.join(data_dir, self.name, base_name + '.npy'))}
+
+    normalisers = data.Normalisers({'lab': data.MinMaxNormaliser('lab'), 'lf0': data.MeanVarianceNormaliser('lf0')},
+                                   normalisation_dir='processed', data_root=root, device='cpu')
+    sources = {'n_frames': NpySource('n_frames', as_int=True), 'dur': NpySource('dur'), 'lab': NpySource('lab'),
+               'lf0': NpySource('lf0')}
+    dataset = data.FilesDataset(sources, 'train', 'train_file_id_list.scp', normalisers, data_root=root)
+    out = {'file_ids': np.array(dataset.file_ids)}
+    order = [b.split(',') for b in g8['batch_order'][0]]
+    out['n_batches'] = np.int64(len(order))
+    for i, batch_names in enumerate(order):
+        items = [dataset[dataset.file_ids.index(n)] for n in batch_names]
+        batch = data.FilesDataset.collate_fn(items)
+        for key, value in batch.items():
+            if hasattr(value, 'numpy'):
+                out['batch%d__%s' % (i, key)] = value.numpy()
+            else:
+                out['batch%d__%s' % (i, key)] = np.array(value)
+    np.savez_compressed(os.path.join(HERE, 'g16_collate.npz'), **out)
+    print('g16_collate.npz', os.path.getsize(os.path.join(HERE, 'g16_collate.npz')), 'bytes;', sorted(out)[:12])
+
+
+if __name__ == '__main__' and (len(sys.argv) == 1 or sys.argv[1] == 'g16'):
+    g16_collate()

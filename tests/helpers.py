@@ -43,3 +43,37 @@ def init_small(model, seed=0):
         for p in model.parameters():
             p.copy_(torch.from_numpy(rng.uniform(-0.3, 0.3, size=tuple(p.shape)).astype(np.float32)))
     return model
+
+
+def write_g8_dataset(g8, root):
+    """Lay the G8 data set out on disk the way the reference run that produced it did (tests/golden/make_golden.py: one .npy per
+    utterance and feature under {root}/train/{feature}/, n_frames as .txt, the id list and the normaliser JSON files)."""
+    import json
+    import os
+    names = [str(n) for n in g8['names']]
+    for feat in ('lab', 'dur', 'lf0', 'n_frames'):
+        os.makedirs(os.path.join(root, 'train', feat), exist_ok=True)
+    for name in names:
+        for feat in ('lab', 'dur', 'lf0'):
+            np.save(os.path.join(root, 'train', feat, name + '.npy'), g8['data__%s__%s' % (name, feat)])
+        with open(os.path.join(root, 'train', 'n_frames', name + '.txt'), 'w') as f:
+            f.write(str(int(g8['data__%s__dur' % name].sum())))
+    with open(os.path.join(root, 'train_file_id_list.scp'), 'w') as f:
+        f.write('\n'.join(names) + '\n\n')
+    os.makedirs(os.path.join(root, 'processed'), exist_ok=True)
+    for key in ('lab_minmax', 'lf0_mvn'):
+        params = {k.split('__')[2]: g8[k].tolist() for k in g8 if k.startswith('norm__%s__' % key)}
+        with open(os.path.join(root, 'processed', key + '.json'), 'w') as f:
+            json.dump(params, f)
+    return names
+
+
+def g8_files_dataset(g8, root, device='cpu'):
+    """``data.FilesDataset`` over the G8 data set on disk, normaliser parameters loaded from their JSON files."""
+    from morgana_amd import data
+    write_g8_dataset(g8, root)
+    normalisers = data.Normalisers({'lab': data.MinMaxNormaliser('lab'), 'lf0': data.MeanVarianceNormaliser('lf0')},
+                                   'processed', data_root=root, device=device)
+    sources = {'n_frames': data.TextSource('n_frames'), 'dur': data.NumpyBinarySource('dur'), 'lab': data.NumpyBinarySource('lab'),
+               'lf0': data.NumpyBinarySource('lf0')}
+    return data.FilesDataset(sources, 'train', 'train_file_id_list.scp', normalisers, data_root=root)

@@ -1,0 +1,297 @@
+"""GPU parity tests at the BASELINE configurations the first round left unexercised (run with ``-m gpu`` on an MI355X):
+
+* C5  RNN_SPSS GRU-512, 600 -> 187, ragged 300-2000-frame utterances, seq_len masking  (morgana/utils.py:366-385, losses.py:37-39)
+* C4  RNN_SPSS GRU-512, 600 -> 80 at its real chain length T = 1000: persistent recurrence == per-step kernels over 1000 dependent
+      steps at the full (64, 1000, 512) shape, and the model against the oracle on a T = 1000 batch
+* C3  the multi-rank code path of the graphed train step on a live RCCL process group (world size 1 on the one-GPU box)
+plus the contracts the first review asked to be pinned: backward kernels never read ``saved`` past ``seq_len``, unsupported
+recurrent layers raise instead of falling back to torch, the recurrent step is capturable (no host read of ``seq_len``).
+Everything goes through the C ABI of libmorgana_hip.so and is compared with the oracle (oracle/ref_cpu.py).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from morgana_amd import _lib, data, models, ops, optim, synthetic, utils
+from morgana_amd import functional as F_hip
+from oracle import ref_cpu
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+RTOL = 1e-4           # fp32 parity bar (north star)
+RTOL_BF16 = 2e-2      # bf16 throughput mode (8-bit mantissa)
+
+
+def dev(x, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+def rel_err(got, want):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    return np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
+
+
+def rel_l2(got, want):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    return np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30)
+
+
+def _load_state(model, state):
+    own = model.state_dict()
+    for key, value in state.items():
+        own[key].copy_(torch.from_numpy(value))
+    return model
+
+
+# ------------------------------------------------------------------------------------------------------------ C5
+@pytest.fixture(scope='module')
+def c5_case():
+    """BASELINE C5 at a reduced batch: 8 utterances of 300-2000 frames (P = T / 12.5 phones), 187-dim WORLD target, zero padded
+    to the batch maximum as collate_fn pads (data.py:183-193); the oracle's loss / prediction / gradients (about 10 s of numpy)."""
+    feats = synthetic.make_batch(8, (300, 2000), out_dim=187, target_name='world', seed=5)
+    state = synthetic.rnn_spss_state(out_dim=187)
+    want = ref_cpu.rnn_forward_backward(state, feats, target_key='normalised_world')
+    return feats, state, want
+
+
+@pytest.mark.parametrize('precision,packed', [('fp32', True), ('bf16', True), ('bf16', False), ('fp32', False)])
+def test_c5_ragged_187_model_vs_oracle(c5_case, precision, packed):
+    """RNNSPSS(output_dim=187) on the ragged batch against ``ref_cpu.rnn_forward_backward``: fp32 mode at the north star's 1e-4 on
+    loss and prediction (1e-3 on gradients: 2000-step BPTT sums in another order), bf16 mode at 2e-2 / 5e-2 relative L2.  The batch is
+    large enough for the persistent recurrence and the phone-rate GRU input to engage (asserted); ``packed`` runs the Linear stack
+    behind the GRU and the loss on the sum(T_b) valid frame rows only (utils.PackedFrames) and must not change the result:
+    predictions past an utterance's length are whatever the layers make of the GRU's zero rows in the reference, and are compared
+    on the valid frames only in both forms (they are outside the loss mask)."""
+    feats, state, (want_loss, want_pred, want_grads) = c5_case
+    b, t = feats['normalised_world'].shape[:2]
+    n_rows = feats['normalised_lab'].shape[0] * feats['normalised_lab'].shape[1]
+    assert ops.phone_rate_gru_ok(n_rows, b * t, 512), 'C5 test batch misses the phone-rate GRU input'
+    if precision == 'bf16':
+        assert ops.gru_persist_ok(b, t, 512), 'C5 test batch misses the persistent recurrence'
+    utils.set_packed_frames(packed)
+    try:
+        model = _load_state(models.RNNSPSS(output_dim=187, target_name='world', precision=precision).to(DEV), state)
+        loss, out = model(data.to_device(feats, DEV))
+        loss.backward()
+    finally:
+        utils.set_packed_frames(True)
+    pred = out['pred_norm_world'].detach().cpu().numpy()
+    assert pred.shape == want_pred.shape
+    valid = (np.arange(t)[None, :] < feats['n_frames'][:, None])[:, :, None]
+    tol, gtol = (RTOL, 1e-3) if precision == 'fp32' else (RTOL_BF16, 5e-2)
+    np.testing.assert_allclose(loss.item(), want_loss, rtol=tol)
+    assert rel_err(np.where(valid, pred, 0), np.where(valid, want_pred, 0)) < tol
+    for name, prm in model.named_parameters():
+        err = rel_err(prm.grad.cpu().numpy(), want_grads[name]) if precision == 'fp32' else rel_l2(prm.grad.cpu().numpy(), want_grads[name])
+        assert err < gtol, (name, err)
+
+
+def test_c5_packed_rows_equal_padded_rows(c5_case):
+    """The packed-frame form against the padded form of the same model and batch, bf16 mode: same kernels on fewer rows, so the
+    loss and the valid predictions are EQUAL bit for bit; weight gradients sum the same terms in another split order (1e-5)."""
+    feats, state, _ = c5_case
+    t = feats['normalised_world'].shape[1]
+    valid = torch.from_numpy((np.arange(t)[None, :] < feats['n_frames'][:, None])[:, :, None]).to(DEV)
+    results = []
+    for packed in (True, False):
+        utils.set_packed_frames(packed)
+        try:
+            model = _load_state(models.RNNSPSS(output_dim=187, target_name='world', precision='bf16').to(DEV), state)
+            loss, out = model(data.to_device(feats, DEV))
+            loss.backward()
+        finally:
+            utils.set_packed_frames(True)
+        results.append((loss.detach().clone(), torch.where(valid, out['pred_norm_world'].detach(), torch.zeros((), device=DEV)),
+                        {n: p.grad.detach().clone() for n, p in model.named_parameters()}))
+    (loss_p, pred_p, grads_p), (loss_d, pred_d, grads_d) = results
+    assert torch.equal(pred_p, pred_d)
+    np.testing.assert_allclose(loss_p.item(), loss_d.item(), rtol=1e-6)
+    for name in grads_d:
+        assert rel_l2(grads_p[name].cpu().numpy(), grads_d[name].cpu().numpy()) < 1e-4, name
+
+
+# ------------------------------------------------------------------------------------------------------------ C4
+def test_c4_persistent_recurrence_equals_step_kernels_at_t1000():
+    """mg_gru_fwd_persist_bf16 / mg_gru_bwd_persist_bf16 at the full C4 shape (64, 1000, 512) against the per-step kernels that
+    share their cell code: 1000 dependent hand-offs per direction, results EQUAL bit for bit (outputs, states, saved gates, gate
+    gradients, dh0).  Lengths: mostly full (C4 is fixed length) with a few shorter items, so frozen states ride along."""
+    b, t, hid = 64, 1000, 512
+    rng = np.random.RandomState(1000)
+    xproj = dev(rng.standard_normal((b, t, 3 * hid)).astype(np.float32))
+    w_hh = dev((rng.uniform(-1, 1, (3 * hid, hid)) / np.sqrt(hid)).astype(np.float32))
+    b_hh = dev(rng.uniform(-0.1, 0.1, 3 * hid).astype(np.float32))
+    sl_np = np.full(b, t, dtype=np.int64)
+    sl_np[[3, 17, 40]] = [1, 500, 999]
+    sl = dev(sl_np)
+    assert ops.gru_persist_ok(b, t, hid)
+    out_s, hs_s, sv_s, hsbf_s = ops.gru_fwd_bf16(xproj, w_hh, b_hh, sl, None, b, t, hid, persistent=False)
+    out_p, hs_p, sv_p, hsbf_p = ops.gru_fwd_bf16(xproj, w_hh, b_hh, sl, None, b, t, hid, persistent=True)
+    assert torch.equal(out_p, out_s) and torch.equal(hs_p, hs_s) and torch.equal(hsbf_p, hsbf_s)
+    valid = dev((np.arange(t)[None, :] < sl_np[:, None])[:, :, None])
+    zero = torch.zeros((), device=DEV)
+    assert torch.equal(torch.where(valid, sv_p, zero), torch.where(valid, sv_s, zero))
+    g_out = dev(rng.standard_normal((b, t, hid)).astype(np.float32) * 0.1)
+    g_hn = dev(rng.standard_normal((b, hid)).astype(np.float32) * 0.1)
+    dx_s, dh_s, d0_s, dhbf_s = ops.gru_bwd_bf16(g_out, g_hn, hs_s, sv_s, w_hh, sl, b, t, hid, persistent=False)
+    dx_p, dh_p, d0_p, dhbf_p = ops.gru_bwd_bf16(g_out, g_hn, hs_s, sv_s, w_hh, sl, b, t, hid, persistent=True)
+    assert torch.equal(dx_p, dx_s) and torch.equal(dh_p, dh_s) and torch.equal(d0_p, d0_s) and torch.equal(dhbf_p, dhbf_s)
+    assert torch.isfinite(dx_p).all()
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_c4_model_t1000_vs_oracle(precision):
+    """The C4 model (600 -> 512 -> GRU-512 -> 256 -> 80) on 8 fixed-length 1000-frame utterances (C4's chain length; a smaller batch
+    keeps the numpy oracle at seconds) against the oracle, fp32 at 1e-4 / 1e-3, bf16 at 2e-2 / 5e-2 (relative L2 on gradients)."""
+    feats = synthetic.make_batch(8, 1000, out_dim=80, target_name='mcep', seed=1004)
+    state = synthetic.rnn_spss_state()
+    want_loss, want_pred, want_grads = ref_cpu.rnn_forward_backward(state, feats)
+    model = _load_state(models.RNNSPSS(precision=precision).to(DEV), state)
+    loss, out = model(data.to_device(feats, DEV))
+    loss.backward()
+    tol, gtol = (RTOL, 1e-3) if precision == 'fp32' else (RTOL_BF16, 5e-2)
+    np.testing.assert_allclose(loss.item(), want_loss, rtol=tol)
+    assert rel_err(out['pred_norm_mcep'].detach().cpu().numpy(), want_pred) < tol
+    for name, prm in model.named_parameters():
+        err = rel_err(prm.grad.cpu().numpy(), want_grads[name]) if precision == 'fp32' else rel_l2(prm.grad.cpu().numpy(), want_grads[name])
+        assert err < gtol, (name, err)
+
+
+def test_recurrent_step_graph_replay_equals_eager():
+    """With ``max_len`` handed down (models.RNNSPSS does) the GRU wrapper reads nothing back from the device, so the whole
+    recurrent training step - persistent recurrences included - is captured as one HIP graph: replays against eager steps on the
+    same batch, parameters and losses EQUAL bit for bit."""
+    from morgana_amd import graphs
+    feats = data.to_device(synthetic.make_batch(16, (150, 260), out_dim=80, target_name='mcep', seed=21), DEV)
+
+    def fresh():
+        model = _load_state(models.RNNSPSS(precision='bf16').to(DEV), synthetic.rnn_spss_state())
+        return model, optim.Adam(model.parameters(), lr=0.002)
+
+    model_e, opt_e = fresh()
+    losses_e = []
+    for _ in range(6):
+        opt_e.zero_grad()
+        loss, _ = model_e(feats)
+        F_hip.backward(loss)
+        opt_e.step()
+        losses_e.append(loss.item())
+    model_g, opt_g = fresh()
+    step = graphs.GraphedTrainStep(model_g, opt_g, feats, warmup=2)
+    losses_g = [step().clone() for _ in range(4)]
+    assert [v.item() for v in losses_g] == losses_e[2:]
+    for key in ('param', 'exp_avg', 'exp_avg_sq'):
+        assert torch.equal(opt_e.flat_buffers()[key], opt_g.flat_buffers()[key]), key
+
+
+# ------------------------------------------------------------------------------------------------------------ C3
+def test_rccl_world1_graphed_step_equals_single_rank():
+    """First contact with RCCL: a world-size-1 ``nccl`` process group on the one GPU.  ``GraphedTrainStep`` is forced onto its
+    multi-rank path (forward + backward + early bucket exchange captured while the process group's watchdog thread is alive, the
+    gradient all-reduce through RCCL, the Adam kernel behind it) and must reproduce the single-rank graphed step bit for bit: an
+    all-reduce over one rank is the identity and 1/world = 1."""
+    import torch.distributed as dist
+    from morgana_amd import graphs
+    feats = data.to_device(synthetic.make_batch(32, 200, seed=8), DEV)
+
+    def fresh(**kw):
+        model = _load_state(models.F0Model(precision='bf16').to(DEV), synthetic.f0_model_state())
+        return model, optim.Adam(model.parameters(), lr=0.01, **kw)
+
+    model_s, opt_s = fresh()
+    single = graphs.GraphedTrainStep(model_s, opt_s, feats, warmup=2)
+    losses_s = [single().clone() for _ in range(5)]
+
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29531')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend='nccl', rank=0, world_size=1)
+    try:
+        probe = torch.arange(8, dtype=torch.float32, device=DEV)
+        dist.all_reduce(probe)                                   # RCCL communicator creation + one real collective
+        assert torch.equal(probe, torch.arange(8, dtype=torch.float32, device=DEV))
+        model_m, opt_m = fresh(exchange_always=True)
+        multi = graphs.GraphedTrainStep(model_m, opt_m, feats, warmup=2)
+        assert multi._multi, 'the multi-rank path was not taken'
+        losses_m = [multi().clone() for _ in range(5)]
+        torch.cuda.synchronize()
+        mode = multi.exchange_mode
+    finally:
+        dist.destroy_process_group()
+    assert mode in ('captured', 'eager')
+    assert [v.item() for v in losses_m] == [v.item() for v in losses_s]
+    for key in ('param', 'exp_avg', 'exp_avg_sq'):
+        assert torch.equal(opt_m.flat_buffers()[key], opt_s.flat_buffers()[key]), key
+    print('RCCL world-1 graphed step: exchange mode = %s' % mode)
+
+
+# ------------------------------------------------------------------------------------------------------------ contracts
+@pytest.mark.parametrize('b,t,hid,form', [(16, 50, 512, 'step_bf16'), (16, 50, 512, 'persist_bf16'), (16, 50, 512, 'step_f32'),
+                                          (16, 50, 256, 'persist_f32'), (12, 40, 64, 'small_f32'), (12, 40, 128, 'small_f32')])
+def test_gru_backward_never_reads_saved_past_seq_len(b, t, hid, form):
+    """Contract of include/morgana_hip.h (K3): ``saved[b, t, :]`` for t >= seq_len[b] is unspecified - the forward kernels differ in
+    what they leave there - and no backward entry point lets it reach a result.  Poison exactly those elements (and the matching
+    ``grad_out`` rows, which the reference's pad_packed_sequence backward drops as well) with NaN: every gradient must come out
+    bit-identical to the unpoisoned run, and finite."""
+    rng = np.random.RandomState(hid + t)
+    xproj = dev(rng.standard_normal((b, t, 3 * hid)).astype(np.float32))
+    w_hh = dev((rng.uniform(-1, 1, (3 * hid, hid)) / np.sqrt(hid)).astype(np.float32))
+    b_hh = dev(rng.uniform(-0.1, 0.1, 3 * hid).astype(np.float32))
+    sl_np = rng.randint(1, t + 1, size=b).astype(np.int64)
+    sl_np[0], sl_np[-1] = t, 1
+    sl = dev(sl_np)
+    out, hs, sv = ops.gru_fwd(xproj, w_hh, b_hh, sl, None, b, t, hid)
+    g_out = dev(rng.standard_normal((b, t, hid)).astype(np.float32))
+    g_hn = dev(rng.standard_normal((b, hid)).astype(np.float32))
+    past = dev((np.arange(t)[None, :] >= sl_np[:, None])[:, :, None])
+    nan = torch.full((), float('nan'), device=DEV)
+    sv_bad, g_bad = torch.where(past, nan, sv), torch.where(past, nan, g_out)
+
+    def run(saved, grad):
+        if form == 'step_bf16':
+            return ops.gru_bwd_bf16(grad, g_hn, hs, saved, w_hh, sl, b, t, hid, persistent=False)
+        if form == 'persist_bf16':
+            assert ops.gru_persist_ok(b, t, hid)
+            return ops.gru_bwd_bf16(grad, g_hn, hs, saved, w_hh, sl, b, t, hid, persistent=True)
+        if form == 'persist_f32':
+            assert ops.gru_persist_f32_ok(b, t, hid)
+            return ops.gru_bwd(grad, g_hn, hs, saved, w_hh, sl, b, t, hid)
+        if form == 'step_f32':
+            return ops.gru_bwd(grad, g_hn, hs, saved, w_hh, sl, b, t, hid, persistent=False)
+        return ops.gru_bwd(grad, g_hn, hs, saved, w_hh, sl, b, t, hid)
+
+    clean, dirty = run(sv, g_out), run(sv_bad, g_bad)
+    for got, want in zip(dirty, clean):
+        assert torch.isfinite(got.float()).all()
+        assert torch.equal(got, want)
+
+
+def test_unsupported_recurrent_layers_raise():
+    """No torch / MIOpen fallback: layer types without a HIP recurrence raise MorganaHipError."""
+    x = torch.zeros(2, 5, 16, device=DEV)
+    sl = torch.tensor([5, 3], device=DEV)
+    for layer in (nn.GRU(16, 8, batch_first=True, bidirectional=True), nn.GRU(16, 8, num_layers=2, batch_first=True),
+                  nn.GRU(16, 8), nn.LSTM(16, 8, batch_first=True, bidirectional=True), nn.RNN(16, 8, batch_first=True)):
+        with pytest.raises(_lib.MorganaHipError, match='no HIP recurrence'):
+            utils.RecurrentCuDNNWrapper(layer.to(DEV))(x, None, sl)
+
+
+def test_wrapper_accepts_packed_sequences():
+    """``seq_len=None`` with an already packed input (morgana/utils.py:347-349) runs the HIP recurrence and returns a packed
+    result equal to the padded call's."""
+    rng = np.random.RandomState(4)
+    gru = nn.GRU(12, 128, batch_first=True).to(DEV)
+    wrapper = utils.RecurrentCuDNNWrapper(gru, precision='fp32')
+    x = dev(rng.standard_normal((4, 9, 12)).astype(np.float32))
+    sl = torch.tensor([6, 9, 1, 4], device=DEV)
+    want, want_h = wrapper(x, None, sl)
+    packed = nn.utils.rnn.pack_padded_sequence(x, sl.cpu(), batch_first=True, enforce_sorted=False)
+    got, got_h = wrapper(packed)
+    assert isinstance(got, nn.utils.rnn.PackedSequence)
+    got_padded, lens = nn.utils.rnn.pad_packed_sequence(got, batch_first=True)
+    assert torch.equal(lens, sl.cpu()) and torch.equal(got_padded, want) and torch.equal(got_h, want_h)

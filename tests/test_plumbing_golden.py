@@ -52,6 +52,60 @@ def test_collate_matches_reference_layout(golden):
     assert float(batch['normalised_lab'].max()) <= 1.0 + 1e-6 and float(batch['normalised_lab'].min()) >= -1e-6
 
 
+def _g16_batches(g16):
+    for i in range(int(g16['n_batches'])):
+        yield {k.split('__', 1)[1]: v for k, v in g16.items() if k.startswith('batch%d__' % i)}
+
+
+def test_files_dataset_and_collate_equal_reference_batches(golden, tmp_path):
+    """``data.FilesDataset`` (files on disk, id list, normaliser JSON) + ``collate_fn`` against G16: the batches the REFERENCE's
+    FilesDataset.__getitem__ + collate_fn built from the same files (data.py:106-154, 159-224): every tensor equal (the host
+    normalisation is the same float32 NumPy arithmetic), names in order, dtypes and shapes as the reference's."""
+    g8, g16 = golden('g8_plumbing.npz'), golden('g16_collate.npz')
+    dataset = helpers.g8_files_dataset(g8, str(tmp_path))
+    assert dataset.file_ids == [str(n) for n in g16['file_ids']] and len(dataset) == len(g16['file_ids'])
+    for want in _g16_batches(g16):
+        names = [str(n) for n in want['name']]
+        got = dataset.collate_fn([dataset[dataset.file_ids.index(n)] for n in names])
+        assert got['name'] == names
+        assert sorted(got.keys()) == sorted(want.keys())
+        for key, value in want.items():
+            if key == 'name':
+                continue
+            assert tuple(got[key].shape) == value.shape and got[key].numpy().dtype == value.dtype, key
+            np.testing.assert_array_equal(got[key].numpy(), value, err_msg=key)
+    with pytest.raises(ValueError, match='use_deltas'):
+        data.FilesDataset({'lf0': data.NumpyBinarySource('lf0')}, 'train', 'train_file_id_list.scp',
+                          {'lf0': data.MeanVarianceNormaliser('lf0', use_deltas=True)}, data_root=str(tmp_path))
+
+
+@pytest.mark.gpu
+def test_device_collate_equals_reference_batches(golden, tmp_path):
+    """The device-side feed (``data.batch`` -> ``DeviceBatches`` over a ``FilesDataset``: raw utterances packed, one H2D copy per
+    feature, mg_pad_normalise_f32 pads and normalises) against G16, the reference's own host-side batches of the same utterances:
+    integers and raw features equal, normalised features to fp32 rounding of the normaliser arithmetic (1e-6)."""
+    g8, g16 = golden('g8_plumbing.npz'), golden('g16_collate.npz')
+    dataset = helpers.g8_files_dataset(g8, str(tmp_path), device='cuda:0')
+    for want in _g16_batches(g16):
+        names = [str(n) for n in want['name']]
+        raw = [dataset.raw(dataset.file_ids.index(n)) for n in names]
+        got = data.collate_to_device(raw, dataset.normalisers, 'cuda:0')
+        assert got['name'] == names and got['n_frames_total'] == int(want['n_frames'].sum())
+        for key, value in want.items():
+            if key == 'name':
+                continue
+            assert got[key].is_cuda and tuple(got[key].shape) == value.shape and got[key].cpu().numpy().dtype == value.dtype, key
+            if value.dtype.kind == 'f':
+                np.testing.assert_allclose(got[key].cpu().numpy(), value, rtol=1e-6, atol=1e-7, err_msg=key)
+            else:
+                np.testing.assert_array_equal(got[key].cpu().numpy(), value, err_msg=key)
+    # the loader form: same utterances batch by batch in file order, the last batch smaller
+    loader = data.batch(dataset, batch_size=8, shuffle=False, device='cuda:0')
+    assert len(loader) == 3
+    seen = [n for feats in loader for n in feats['name']]
+    assert seen == dataset.file_ids
+
+
 def _run(g, device, model_class, model_kwargs, tmp_path, kernel=None):
     dims = tuple(int(d) for d in g['dims'])
     eb = experiment_builder.ExperimentBuilder(model_class, model_kwargs=model_kwargs, learning_rate=0.01, device=device,
