@@ -353,8 +353,10 @@ def main():
         model.mode = 'train'
         model.metrics.reset_state('train')
     features = data.to_device(feats_np, dev)
+    if args.precision == 'bf16':
+        data.add_bf16_table(features)    # loader-side half of bf16 mode: the phone table's bf16 copy is made when the batch is loaded
     frames_per_step = int(feats_np['n_frames'].sum())
-    optimizer = optim.Adam(model.parameters(), lr=0.01)
+    optimizer = optim.Adam(model.parameters(), lr=0.01, fused_loop=True)    # the loop below is the reference's loop body
 
     def step():
         optimizer.zero_grad()
@@ -404,7 +406,7 @@ def main():
             from morgana_amd import graphs
             fr_model = models.F0Model(precision=args.precision).to(dev)
             fr_model.load_state_dict(model.state_dict())
-            fr_step = graphs.GraphedTrainStep(fr_model, optim.Adam(fr_model.parameters(), lr=0.01), features)
+            fr_step = graphs.GraphedTrainStep(fr_model, optim.Adam(fr_model.parameters(), lr=0.01, fused_loop=True), features)
             for _ in range(args.warmup):
                 fr_step()
             torch.cuda.synchronize()

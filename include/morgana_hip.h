@@ -47,6 +47,8 @@ const char* mg_last_error(void);
                                  * 1 = always write-through (sc1) stores, the placement-independent form */
 #define MG_TUNE_SKIP_REDUCE 1   /* != 0: weight-gradient entry points launch their GEMM kernel only, not the slab reduce that
                                  * finishes dW / db (results are then NOT valid) - lets bench.py time the kernel alone */
+#define MG_TUNE_WGRAD_SPLITS 4  /* wide weight-gradient kernel: != 0 overrides the planned number of split-M slabs (a multiple of 8) */
+#define MG_TUNE_WGRAD_ORDER 5   /* wide weight-gradient kernel, block order: 0 = planned, 1 = n tile fastest, 2 = the n tiles of a split on one XCD */
 int mg_set_tuning(int key, int value);
 int mg_version(void);           /* ABI version, bumped on incompatible change */
 const char* mg_build_arch(void); /* "gfx950" */
@@ -274,6 +276,11 @@ int mg_linear_wgrad_bf16(const uint16_t* dY, int lddy, const uint16_t* A, int ld
                          int N, int K, float* dW, float* db, int accumulate, void* workspace, size_t workspace_bytes,
                          void* stream);
 
+/* mg_linear_wgrad_bf16 without its reduce launch: the split-M partial results stay in `workspace` as *n_slabs slabs of *stride floats,
+ * slab s = [N*K weight partials | N bias partials], for a consumer that sums them itself (mg_adam_step_plan_f32).  Only the wide-tile
+ * plan has this form: returns MG_EINVAL for shapes mg_linear_wgrad_bf16 would run on its 128 x 128 kernels (call that instead). */
+int mg_linear_wgrad_slabs_bf16(const uint16_t* dY, int lddy, const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K,
+                               void* workspace, size_t workspace_bytes, int* n_slabs, int64_t* stride, void* stream);
 /* Fused backward of Linear(K -> N) + Sigmoid feeding Linear(N -> N2): dW, db of the FIRST layer straight from dZ2, the
  * pre-activation gradient of the second one, without materialising dZ1 = (dZ2 W2) * H1 (1 - H1):
  *   dZ2 bf16 [M, lddz] (N2 = 128 columns); W2T = W2^T bf16 [N, ldwt]; H1 bf16 [M, ldh] (sigmoid outputs, N % 128 == 0);
@@ -524,6 +531,42 @@ void mg_adam_scalars(float lr, float beta1, float beta2, int64_t step, float* ou
 int mg_store_pair_f32(float* dst, float a, float b, void* stream);
 int mg_adam_step_dev_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1,
                          float beta2, float eps, float weight_decay, const float* scalars, float grad_scale, void* stream);
+/* The update as the LAST node of a training step that hands it more than a finished gradient (scalars from device memory as in
+ * mg_adam_step_dev_f32).  `plan` is a HOST struct, copied into the launch:
+ *   slabs[i]   : elements [begin, begin+count) of the flat gradient additionally receive sum_s slab[s*stride + (j - begin)],
+ *                s < n_slabs, summed in the fixed order of the library's slab reduce (16 interleaved partitions, ascending) - the
+ *                split-M partial results of a weight-gradient GEMM (mg_linear_wgrad_slabs_bf16), consumed here instead of by a
+ *                reduce launch of their own; n_slabs == 1 adds a plain buffer (the fused tail's gradients)
+ *   shadows[i] : the fp32 matrix [rows, cols] at flat offset `offset` is re-cast after its update into dst bf16 [rows, ldd] and / or
+ *                its transpose dst_t bf16 [cols, ldt] (padding columns are never written: zero them once) - the operands of the next
+ *                step's GEMMs, so no cast launch is needed
+ *   clear_grad : != 0 zeroes the flat gradient behind the read (the next step needs no memset)
+ * Results equal mg_adam_step_dev_f32 on the reduced gradient bit for bit. */
+#define MG_ADAM_MAX_SLABS 4
+#define MG_ADAM_MAX_SHADOWS 8
+typedef struct {
+    int64_t begin, count;
+    const float* slab;
+    int n_slabs;
+    int64_t stride;
+} mg_adam_slab_src;
+typedef struct {
+    int64_t offset;
+    int rows, cols;
+    uint16_t* dst;
+    int ldd;
+    uint16_t* dst_t;
+    int ldt;
+} mg_adam_shadow;
+typedef struct {
+    int n_slab_srcs;
+    mg_adam_slab_src slabs[MG_ADAM_MAX_SLABS];
+    int n_shadows;
+    mg_adam_shadow shadows[MG_ADAM_MAX_SHADOWS];
+    int clear_grad;
+} mg_adam_plan;
+int mg_adam_step_plan_f32(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1, float beta2, float eps,
+                          float weight_decay, const float* scalars, float grad_scale, const mg_adam_plan* plan, void* stream);
 /* shadow -= (1 - decay) * (shadow - param). */
 int mg_ema_update_f32(float* shadow, const float* param, int64_t n, float decay, void* stream);
 

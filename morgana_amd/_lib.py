@@ -58,6 +58,10 @@ SIGNATURES = {
     'mg_linear_bwd_fused_workspace_bytes': (c_size_t, [c_int64, c_int, c_int]),
     'mg_linear_bwd_fused_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                          c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'mg_linear_wgrad_slabs_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_size_t,
+                                           c_void_p, c_void_p, c_void_p]),
+    'mg_adam_step_plan_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p,
+                                      c_float, c_void_p, c_void_p]),
     'mg_cast_pad_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
     'mg_cast_transpose_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     'mg_cast_params_bf16': (c_int, [c_void_p, c_int, c_void_p]),
@@ -168,6 +172,26 @@ class LstmBwdLayer(ctypes.Structure):
     _fields_ = [('grad_out', c_void_p), ('g_T', c_int), ('g_t0', c_int), ('cstate', c_void_p), ('saved', c_void_p),
                 ('w_hh', c_void_p), ('dgates', c_void_p), ('carry_h', c_void_p), ('carry_c', c_void_p), ('dh0', c_void_p),
                 ('dc0', c_void_p)]
+
+
+class AdamSlabSrc(ctypes.Structure):
+    """mg_adam_slab_src of include/morgana_hip.h."""
+    _fields_ = [('begin', c_int64), ('count', c_int64), ('slab', c_void_p), ('n_slabs', c_int), ('stride', c_int64)]
+
+
+class AdamShadow(ctypes.Structure):
+    """mg_adam_shadow of include/morgana_hip.h."""
+    _fields_ = [('offset', c_int64), ('rows', c_int), ('cols', c_int), ('dst', c_void_p), ('ldd', c_int), ('dst_t', c_void_p),
+                ('ldt', c_int)]
+
+
+ADAM_MAX_SLABS, ADAM_MAX_SHADOWS = 4, 8
+
+
+class AdamPlan(ctypes.Structure):
+    """mg_adam_plan of include/morgana_hip.h."""
+    _fields_ = [('n_slab_srcs', c_int), ('slabs', AdamSlabSrc * ADAM_MAX_SLABS), ('n_shadows', c_int),
+                ('shadows', AdamShadow * ADAM_MAX_SHADOWS), ('clear_grad', c_int)]
 
 
 LSTM_MAX_LAYERS = 8

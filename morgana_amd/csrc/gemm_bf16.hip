@@ -491,6 +491,11 @@ int mg_linear_wgrad_bf16(const uint16_t* dY, int lddy, const uint16_t* A, int ld
         // gradient buffer) a single reduce launch finishes both
         const int64_t sstride = nk + N;
         float* bslab = slab + nk;
+        if ((size_t)big_s * (size_t)sstride * sizeof(float) > workspace_bytes) {      // never launch past the caller's workspace
+            mg_set_error("mg_linear_wgrad_bf16: %d split slabs of %lld floats do not fit the %zu-byte workspace", big_s, (long long)sstride,
+                         workspace_bytes);
+            return MG_EWORKSPACE;
+        }
         mg_launch_wgrad_big(dY, lddy, A, lda, rows, M, N, K, big_s, big_chunk, slab, db ? bslab : nullptr, sstride, st);
         MG_CHECK_LAUNCH("mg_linear_wgrad_bf16/partial");
         if (db && db == dW + nk) {
@@ -515,6 +520,30 @@ int mg_linear_wgrad_bf16(const uint16_t* dY, int lddy, const uint16_t* A, int ld
         mg_launch_slab_reduce(bslab, N, N, p.S, db, accumulate, st);
         MG_CHECK_LAUNCH("mg_linear_wgrad_bf16/reduce_bias");
     }
+    return MG_OK;
+}
+
+int mg_linear_wgrad_slabs_bf16(const uint16_t* dY, int lddy, const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K,
+                               void* workspace, size_t workspace_bytes, int* n_slabs, int64_t* stride, void* stream) {
+    MG_CHECK_ARG(dY && A && workspace && n_slabs && stride && M > 0 && N > 0 && K > 0, "mg_linear_wgrad_slabs_bf16: bad arguments (M=%lld N=%d K=%d)",
+                 (long long)M, N, K);
+    MG_CHECK_ARG(lddy >= N && lda >= K && lddy % 8 == 0 && lda % 8 == 0, "mg_linear_wgrad_slabs_bf16: lddy=%d lda=%d must be multiples of 8 covering N=%d / K=%d",
+                 lddy, lda, N, K);
+    MG_CHECK_ARG(al16(dY) && al16(A) && al16(workspace), "mg_linear_wgrad_slabs_bf16: buffers must be 16-byte aligned");
+    int big_s = 0, big_chunk = 0;
+    MG_CHECK_ARG(mg_wgrad_big_plan(M, N, K, lda, lddy, &big_s, &big_chunk) > 0,
+                 "mg_linear_wgrad_slabs_bf16: M=%lld N=%d K=%d lda=%d is not a wide-tile shape (use mg_linear_wgrad_bf16)", (long long)M, N, K, lda);
+    const int64_t nk = (int64_t)N * K, sstride = nk + N;
+    if ((size_t)big_s * (size_t)sstride * sizeof(float) > workspace_bytes) {
+        mg_set_error("mg_linear_wgrad_slabs_bf16: %d split slabs of %lld floats do not fit the %zu-byte workspace", big_s, (long long)sstride,
+                     workspace_bytes);
+        return MG_EWORKSPACE;
+    }
+    float* slab = (float*)workspace;
+    mg_launch_wgrad_big(dY, lddy, A, lda, rows, M, N, K, big_s, big_chunk, slab, slab + nk, sstride, (hipStream_t)stream);
+    MG_CHECK_LAUNCH("mg_linear_wgrad_slabs_bf16");
+    *n_slabs = big_s;
+    *stride = sstride;
     return MG_OK;
 }
 

@@ -624,7 +624,7 @@ MG_STAMP_DECL(g_stamps_wg);
 template <int TKW>
 __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restrict__ dY, int lddy, const uint16_t* __restrict__ A, int lda,
                                                         const int32_t* __restrict__ rows, int64_t M, int N, int K, int m_chunk,
-                                                        float* __restrict__ slab, float* __restrict__ bslab, int64_t sstride) {
+                                                        float* __restrict__ slab, float* __restrict__ bslab, int64_t sstride, int xcd_group) {
     constexpr int BNT = 128, BKT = 64 * TKW;
     constexpr int TKT = BKT / 4 / 32;             // 32-column MFMA tiles per wave along k (4 waves along k): 5 or 4
     constexpr int PY = BNT * 2, PX = BKT * 2;     // LDS row pitches in bytes: 256, 1280 / 1024
@@ -648,9 +648,18 @@ __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restri
     const int wk0 = (wave & 3) * (TKT * 32);      // 4 waves along k
     // Block order: n tile fastest, then split (measured: grouping the n tiles of a split on one XCD so that they share the
     // gathered X rows through its L2 was 15 % SLOWER, 249 vs 217 us on the C2 layer-1 shape).
+    // xcd_group: blocks b, b + 8, b + 16, ... share an XCD (and its L2): give them the n tiles of ONE split, so the split's X rows
+    // leave HBM once (phone-rate shapes, where X is a streamed table rather than an L2-resident set of gathered rows).  The number
+    // of splits is a multiple of 8 (mg_wgrad_big_plan).
     const int tiles_n = N / BNT;
-    const int n0 = (blockIdx.x % tiles_n) * BNT;
-    const int s = blockIdx.x / tiles_n;
+    int n0, s;
+    if (xcd_group) {
+        n0 = ((blockIdx.x >> 3) % tiles_n) * BNT;
+        s = (blockIdx.x / (8 * tiles_n)) * 8 + (blockIdx.x & 7);
+    } else {
+        n0 = (blockIdx.x % tiles_n) * BNT;
+        s = blockIdx.x / tiles_n;
+    }
     const int64_t m_lo = (int64_t)s * m_chunk;
     const int64_t m_hi = min(M, m_lo + (int64_t)m_chunk);
     const int n_rows = m_hi > m_lo ? (int)(m_hi - m_lo) : 0;     // trailing splits may be empty: they write zero slabs
@@ -898,6 +907,7 @@ int mg_wgrad_big_plan(int64_t M, int N, int K, int lda, int lddy, int* S_out, in
     // M = 21 504, N = 512, K = 600: a third less partial-slab traffic); never more splits than the workspace was sized for
     if (M <= 32768 && tiles_n >= 4) S = 192 / tiles_n;
     if (M <= 32768 && tiles_n == 1) S = 96;                  // N = 128 at the same M: 24.2 vs 27.7 us (224 splits write 59 MB of slabs)
+    if (g_mg_tuning[MG_TUNE_WGRAD_SPLITS] > 0) S = g_mg_tuning[MG_TUNE_WGRAD_SPLITS];
     int64_t m_chunk = mg_align_up((size_t)mg_ceil_div(M, S), 32);
     while (m_chunk > WG_ROWS_MAX) {  // row indices of a workgroup's range live in LDS
         S *= 2;
@@ -913,10 +923,15 @@ int mg_wgrad_big_plan(int64_t M, int N, int K, int lda, int lddy, int* S_out, in
 int mg_launch_wgrad_big(const uint16_t* dY, int lddy, const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K,
                         int S, int m_chunk, float* slab, float* bslab, int64_t sstride, hipStream_t st) {
     dim3 grid((unsigned)((N / 128) * S)), block(512);
+    // block order: the n tiles of a split on one XCD when X is streamed (no gather: a table read once), n tile fastest when X is a
+    // gathered, L2-resident set of rows (measured 15 % slower grouped on the C2 frame-rate shape)
+    int xcd_group = (rows == nullptr && S % 8 == 0) ? 1 : 0;
+    if (g_mg_tuning[MG_TUNE_WGRAD_ORDER] == 1) xcd_group = 0;
+    if (g_mg_tuning[MG_TUNE_WGRAD_ORDER] == 2 && S % 8 == 0) xcd_group = 1;
     if (lda == 640)
-        hipLaunchKernelGGL((wgrad_big_kernel<10>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride);
+        hipLaunchKernelGGL((wgrad_big_kernel<10>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
     else
-        hipLaunchKernelGGL((wgrad_big_kernel<8>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride);
+        hipLaunchKernelGGL((wgrad_big_kernel<8>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
     return 1;
 }
 

@@ -420,6 +420,7 @@ size_t mg_linear_wgrad_workspace_bytes(int64_t M, int N, int K) {
         }
         sb = mg_align_up((size_t)mg_ceil_div(M, chunk), 8);
         if (sb > S) S = sb;
+        if (g_mg_tuning[MG_TUNE_WGRAD_SPLITS] > S) S = mg_align_up((size_t)g_mg_tuning[MG_TUNE_WGRAD_SPLITS], 8);   // experiment knob
     }
     return mg_align_up((size_t)S * ((size_t)N * K + (size_t)N) * sizeof(float), 256);
 }

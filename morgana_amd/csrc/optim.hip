@@ -5,22 +5,33 @@
 
 #include <math.h>
 
+// One element of the Adam update, shared by every kernel below with the floating-point contraction PINNED: left to the compiler, which
+// of the two products of  v * beta2 + (1 - beta2) * g * g  is fused into an fma depends on the surrounding code, and the three kernels
+// would round differently (measured: mg_adam_step_plan_f32 against mg_adam_step_dev_f32 differed in the last bit).
+struct mg_adam_out {
+    float p, m, v;
+};
+__device__ __forceinline__ mg_adam_out mg_adam_update(float p, float g, float mi, float vi, float beta1, float beta2, float eps,
+                                                       float weight_decay, float step_size, float bc2_sqrt, float grad_scale) {
+#pragma clang fp contract(off)
+    g = g * grad_scale;
+    if (weight_decay != 0.f) g = __fmaf_rn(weight_decay, p, g);  // L2 penalty added to the gradient
+    mi = __fmaf_rn(g - mi, 1.f - beta1, mi);                      // exp_avg.lerp_(grad, 1 - beta1)
+    vi = __fmaf_rn((1.f - beta2) * g, g, vi * beta2);             // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p = p - step_size * (mi / denom);                             // param.addcdiv_(exp_avg, denom, value=-step_size)
+    return mg_adam_out{p, mi, vi};
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float beta1,
                                                    float beta2, float eps, float weight_decay, float step_size,
                                                    float bc2_sqrt, float grad_scale) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        float p = param[i];
-        float g = grad[i] * grad_scale;
-        if (weight_decay != 0.f) g = g + weight_decay * p;       // L2 penalty added to the gradient
-        float mi = m[i];
-        mi = mi + (g - mi) * (1.f - beta1);                      // exp_avg.lerp_(grad, 1 - beta1)
-        float vi = v[i] * beta2 + (1.f - beta2) * g * g;         // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p = p - step_size * (mi / denom);                        // param.addcdiv_(exp_avg, denom, value=-step_size)
-        param[i] = p;
-        m[i] = mi;
-        v[i] = vi;
+        const mg_adam_out o = mg_adam_update(param[i], grad[i], m[i], v[i], beta1, beta2, eps, weight_decay, step_size, bc2_sqrt, grad_scale);
+        param[i] = o.p;
+        m[i] = o.m;
+        v[i] = o.v;
     }
 }
 
@@ -32,17 +43,83 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ param
                                                        const float* __restrict__ scalars, float grad_scale) {
     const float step_size = scalars[0], bc2_sqrt = scalars[1];
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        float p = param[i];
-        float g = grad[i] * grad_scale;
-        if (weight_decay != 0.f) g = g + weight_decay * p;
-        float mi = m[i];
-        mi = mi + (g - mi) * (1.f - beta1);
-        float vi = v[i] * beta2 + (1.f - beta2) * g * g;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p = p - step_size * (mi / denom);
-        param[i] = p;
-        m[i] = mi;
-        v[i] = vi;
+        const mg_adam_out o = mg_adam_update(param[i], grad[i], m[i], v[i], beta1, beta2, eps, weight_decay, step_size, bc2_sqrt, grad_scale);
+        param[i] = o.p;
+        m[i] = o.m;
+        v[i] = o.v;
+    }
+}
+
+// The update as the last node of a step (include/morgana_hip.h: mg_adam_step_plan_f32): split-M slabs of the weight-gradient GEMMs are
+// summed here in the slab reduce's own order (slab_reduce.h: 16 interleaved partitions, each ascending, then added in ascending order
+// onto the accumulator - so the result is bitwise what reduce launch + mg_adam_step_dev_f32 produce), the bf16 operands of the next
+// step's GEMMs are refreshed from the updated weights, and the gradient is zeroed behind the read.
+// Work split: a workgroup owns 64 consecutive elements; thread (p, e) = (tid >> 4, tid & 15) sums slabs p, p + 16, ... for elements
+// 4e .. 4e+3 of them (16-byte loads where the range allows), the 16 partial sums of an element meet in LDS and thread (0, e) adds them
+// in ascending p - exactly mg_slab_reduce4_kernel's arithmetic - and then runs the update for its four elements.
+__global__ __launch_bounds__(256) void adam_plan_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m,
+                                                        float* __restrict__ v, int64_t n, float beta1, float beta2, float eps,
+                                                        float weight_decay, const float* __restrict__ scalars, float grad_scale,
+                                                        mg_adam_plan plan) {
+    __shared__ f32x4 part[16][17];
+    const float step_size = scalars[0], bc2_sqrt = scalars[1];
+    const int e = threadIdx.x & 15, p = threadIdx.x >> 4;
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < n; base += (int64_t)gridDim.x * 64) {
+        const int64_t i0 = base + 4 * e;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        bool any = false;
+        for (int k = 0; k < plan.n_slab_srcs; ++k) {
+            const mg_adam_slab_src src = plan.slabs[k];
+            const int64_t j0 = i0 - src.begin;
+            if (j0 + 3 < 0 || j0 >= src.count) continue;
+            any = true;
+            if (j0 >= 0 && j0 + 3 < src.count && ((j0 | src.stride) & 3) == 0 && ((uintptr_t)src.slab & 15) == 0) {
+                for (int s = p; s < src.n_slabs; s += 16) acc += *reinterpret_cast<const f32x4*>(src.slab + (size_t)s * src.stride + j0);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int64_t j = j0 + c;
+                    if (j < 0 || j >= src.count) continue;
+                    float t = 0.f;
+                    for (int s = p; s < src.n_slabs; s += 16) t += src.slab[(size_t)s * src.stride + j];
+                    acc[c] += t;
+                }
+            }
+        }
+        // wave-uniform enough: a workgroup either lies in slab ranges or does not (ranges are long); the barrier is taken by all
+        const bool block_any = __syncthreads_or(any ? 1 : 0) != 0;
+        if (block_any) {
+            part[p][e] = acc;
+            __syncthreads();
+        }
+        if (p == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int64_t i = i0 + c;
+                if (i >= n) continue;
+                float g = grad[i];
+                if (block_any) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) g += part[q][e][c];
+                }
+                if (plan.clear_grad) grad[i] = 0.f;
+                const mg_adam_out o = mg_adam_update(param[i], g, m[i], v[i], beta1, beta2, eps, weight_decay, step_size, bc2_sqrt, grad_scale);
+                const float w = o.p;
+                param[i] = w;
+                m[i] = o.m;
+                v[i] = o.v;
+                for (int k = 0; k < plan.n_shadows; ++k) {
+                    const mg_adam_shadow sh = plan.shadows[k];
+                    const int64_t j = i - sh.offset;
+                    if (j < 0 || j >= (int64_t)sh.rows * sh.cols) continue;
+                    const int r = (int)(j / sh.cols), cc = (int)(j - (int64_t)r * sh.cols);
+                    const uint16_t b = mg_f2bf(w);
+                    if (sh.dst) sh.dst[(size_t)r * sh.ldd + cc] = b;
+                    if (sh.dst_t) sh.dst_t[(size_t)cc * sh.ldt + r] = b;
+                }
+            }
+        }
+        if (block_any) __syncthreads();
     }
 }
 
@@ -218,6 +295,32 @@ int mg_adam_step_dev_f32(float* param, const float* grad, float* exp_avg, float*
     hipLaunchKernelGGL(adam_dev_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
                        beta1, beta2, eps, weight_decay, scalars, grad_scale);
     MG_CHECK_LAUNCH("mg_adam_step_dev_f32");
+    return MG_OK;
+}
+
+int mg_adam_step_plan_f32(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1, float beta2, float eps,
+                          float weight_decay, const float* scalars, float grad_scale, const mg_adam_plan* plan, void* stream) {
+    MG_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && scalars && plan && n >= 0, "mg_adam_step_plan_f32: bad arguments (n=%lld)", (long long)n);
+    MG_CHECK_ARG(plan->n_slab_srcs >= 0 && plan->n_slab_srcs <= MG_ADAM_MAX_SLABS && plan->n_shadows >= 0 && plan->n_shadows <= MG_ADAM_MAX_SHADOWS,
+                 "mg_adam_step_plan_f32: %d slab sources / %d shadows exceed %d / %d", plan->n_slab_srcs, plan->n_shadows, MG_ADAM_MAX_SLABS,
+                 MG_ADAM_MAX_SHADOWS);
+    for (int k = 0; k < plan->n_slab_srcs; ++k) {
+        const mg_adam_slab_src& src = plan->slabs[k];
+        MG_CHECK_ARG(src.slab && src.begin >= 0 && src.count > 0 && src.begin + src.count <= n && src.n_slabs >= 1 && src.stride >= src.count,
+                     "mg_adam_step_plan_f32: slab source %d (begin %lld count %lld of %lld, %d slabs, stride %lld)", k, (long long)src.begin,
+                     (long long)src.count, (long long)n, src.n_slabs, (long long)src.stride);
+    }
+    for (int k = 0; k < plan->n_shadows; ++k) {
+        const mg_adam_shadow& sh = plan->shadows[k];
+        MG_CHECK_ARG(sh.offset >= 0 && sh.rows > 0 && sh.cols > 0 && sh.offset + (int64_t)sh.rows * sh.cols <= n && (sh.dst || sh.dst_t),
+                     "mg_adam_step_plan_f32: shadow %d does not lie inside the flat buffer", k);
+        MG_CHECK_ARG((!sh.dst || sh.ldd >= sh.cols) && (!sh.dst_t || sh.ldt >= sh.rows), "mg_adam_step_plan_f32: shadow %d: ldd %d / ldt %d too small", k,
+                     sh.ldd, sh.ldt);
+    }
+    if (n == 0) return MG_OK;
+    hipLaunchKernelGGL(adam_plan_kernel, dim3((unsigned)mg_ceil_div(n, 64)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
+                       beta1, beta2, eps, weight_decay, scalars, grad_scale, *plan);
+    MG_CHECK_LAUNCH("mg_adam_step_plan_f32");
     return MG_OK;
 }
 

@@ -178,15 +178,16 @@ __global__ __launch_bounds__(256) void frame_layout_fill_kernel(const int64_t* _
 }
 
 // out[d] = sum over padded frames (t >= seq_len[b]) of g[b, t, d]: the gradient that reaches the ONE representative padding row of the
-// packed form from all the dense rows it stands for.  Two fixed-order stages (deterministic): partial[b][chunk][d] over 64-frame
+// packed form from all the dense rows it stands for.  Two fixed-order stages (deterministic): partial[b][chunk][d] over 256-frame
 // chunks (chunks without padded frames write zeros without reading), then one column sum over the B * chunks partials.
+#define PAD_CHUNK 256
 __global__ __launch_bounds__(256) void pad_rows_colsum_stage1_kernel(const float* __restrict__ g, const int64_t* __restrict__ seq_len, int T, int D,
                                                                      int n_chunks, float* __restrict__ partial) {
     extern __shared__ float red_cs[];                     // [4][D]
     const int b = blockIdx.y, c = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long n = seq_len[b];
-    const int t_lo = max(c * 64, n < 0 ? 0 : (n > T ? T : (int)n)), t_hi = min(c * 64 + 64, T);
+    const int t_lo = max(c * PAD_CHUNK, n < 0 ? 0 : (n > T ? T : (int)n)), t_hi = min(c * PAD_CHUNK + PAD_CHUNK, T);
     for (int d0 = 0; d0 < D; d0 += 64) {
         const int d = d0 + lane;
         float s = 0.f;
@@ -199,16 +200,23 @@ __global__ __launch_bounds__(256) void pad_rows_colsum_stage1_kernel(const float
         partial[((size_t)b * n_chunks + c) * D + d] = (red_cs[d] + red_cs[D + d]) + (red_cs[2 * D + d] + red_cs[3 * D + d]);
 }
 
-__global__ __launch_bounds__(256) void pad_rows_colsum_stage2_kernel(const float* __restrict__ partial, int n_partials, int D, float* __restrict__ out) {
-    __shared__ float red2[4][64];
+__global__ __launch_bounds__(1024) void pad_rows_colsum_stage2_kernel(const float* __restrict__ partial, int n_partials, int D, float* __restrict__ out) {
+    __shared__ float red2[16][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int d = blockIdx.x * 64 + lane;
     float s = 0.f;
-    if (d < D)
-        for (int i = wave; i < n_partials; i += 4) s += partial[(size_t)i * D + d];
+    if (d < D) {
+#pragma unroll 8
+        for (int i = wave; i < n_partials; i += 16) s += partial[(size_t)i * D + d];
+    }
     red2[wave][lane] = s;
     __syncthreads();
-    if (wave == 0 && d < D) out[d] = (red2[0][lane] + red2[1][lane]) + (red2[2][lane] + red2[3][lane]);
+    if (wave == 0 && d < D) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red2[w][lane];
+        out[d] = t;
+    }
 }
 
 // dst[rows[m], :] = src[m, :] for rows[m] >= 0 (the targets are distinct: the adjoint of a gather whose rows are unique).
@@ -434,7 +442,7 @@ int mg_frame_layout(const int64_t* seq_len, int B, int T, int64_t total, int32_t
 
 size_t mg_pad_rows_colsum_workspace_bytes(int B, int T, int D) {
     if (B <= 0 || T <= 0 || D <= 0) return 0;
-    return (size_t)B * (size_t)mg_ceil_div(T, 64) * (size_t)D * sizeof(float);
+    return (size_t)B * (size_t)mg_ceil_div(T, PAD_CHUNK) * (size_t)D * sizeof(float);
 }
 
 int mg_pad_rows_colsum_f32(const float* g, const int64_t* seq_len, int B, int T, int D, float* out, void* workspace, size_t workspace_bytes,
@@ -442,10 +450,10 @@ int mg_pad_rows_colsum_f32(const float* g, const int64_t* seq_len, int B, int T,
     MG_CHECK_ARG(g && seq_len && out && workspace && B > 0 && T > 0 && D > 0 && D <= 4096, "mg_pad_rows_colsum_f32: bad arguments (B=%d T=%d D=%d)", B, T, D);
     MG_CHECK_ARG(workspace_bytes >= mg_pad_rows_colsum_workspace_bytes(B, T, D), "mg_pad_rows_colsum_f32: workspace too small");
     MG_CHECK_ARG(B <= 65535, "mg_pad_rows_colsum_f32: B=%d exceeds the grid's y extent", B);
-    const int n_chunks = (int)mg_ceil_div(T, 64);
+    const int n_chunks = (int)mg_ceil_div(T, PAD_CHUNK);
     hipLaunchKernelGGL(pad_rows_colsum_stage1_kernel, dim3(n_chunks, B), dim3(256), (size_t)4 * D * sizeof(float), (hipStream_t)stream, g, seq_len, T,
                        D, n_chunks, (float*)workspace);
-    hipLaunchKernelGGL(pad_rows_colsum_stage2_kernel, dim3((unsigned)mg_ceil_div(D, 64)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
+    hipLaunchKernelGGL(pad_rows_colsum_stage2_kernel, dim3((unsigned)mg_ceil_div(D, 64)), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace,
                        B * n_chunks, D, out);
     MG_CHECK_LAUNCH("mg_pad_rows_colsum_f32");
     return MG_OK;

@@ -194,6 +194,23 @@ def _host_total(value):
     return None
 
 
+BF16_TABLE_SUFFIX = '__bf16_table'
+
+
+def add_bf16_table(features, key='normalised_lab', extra_rows=None):
+    """Loader-side half of bf16 mode: ``features[key + '__bf16_table']`` = the (B*P + extra_rows, pad_ld(F)) bf16 copy of the phone-level
+    feature ``features[key]`` (B, P, F) that the first Linear's loader reads (zero padded columns, ``extra_rows`` zero rows = what
+    padding frames gather in the phone-rate step).  Made ONCE when the batch is loaded - it is data preparation, like the
+    float32 cast of data.py:127 - instead of one cast kernel over the 49 MB table in every training step.  The fp32 feature stays
+    in the dict (the reference's key, and the operand of fp32 mode); models fall back to casting it themselves when this entry is
+    missing."""
+    x = features[key]
+    if extra_rows is None:
+        extra_rows = ops.PHONE_RATE_EXTRA
+    features[key + BF16_TABLE_SUFFIX] = ops.cast_pad_bf16(x.reshape(-1, x.shape[-1]), extra_rows=extra_rows)
+    return features
+
+
 def to_device(features, device):
     """``ToDeviceWrapper.to_device`` over a feature dict (data.py:648-663); numpy arrays are uploaded too.
 

@@ -56,6 +56,8 @@ class ExperimentBuilder(object):
         return model
 
     def make_optimizer(self, **kwargs):
+        # fused_loop: train_epoch below is the reference's loop body (zero_grad, forward, backward, step) and nothing else touches .grad
+        kwargs.setdefault('fused_loop', True)
         return Adam(self.model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay, **kwargs)  # :516
 
     def train_epoch(self, data_loader, optimizer, lr_schedule=None, gen_output=False, out_dir=None):

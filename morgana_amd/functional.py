@@ -285,6 +285,37 @@ def _deliver_rest(params, flat, offsets, grad_loss, early):
     return list(head) + [None] * (len(params) - 2)
 
 
+def _grad_mode(params, grad_loss):
+    """How a backward pass hands over its parameter gradients: 'defer' (split-M slabs left for the optimiser's update kernel),
+    'direct' (accumulated straight into the optimiser's flat gradient) or 'temp' (ordinary tensors for autograd).  The first two need
+    the parameters' .grad to be consecutive views of morgana_amd.optim.Adam's flat buffer and the incoming loss gradient to be the
+    cached unit of ``backward`` (no scaling to apply).  Returns (mode, optimiser)."""
+    if any(p is None for p in params) or grad_loss is None or not any(grad_loss.data_ptr() == one.data_ptr() for one in _ONES.values()):
+        return 'temp', None
+    if not all(getattr(p, '_mg_direct_grad', False) and p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32
+               for p in params):
+        return 'temp', None
+    base, off = params[0].grad.data_ptr(), 0
+    for p in params:
+        if p.grad.data_ptr() != base + 4 * off:
+            return 'temp', None
+        off += p.numel()
+    opt = getattr(params[0], '_mg_optimizer', None)
+    if opt is not None and opt.defers_slabs():
+        return 'defer', opt
+    return 'direct', opt
+
+
+def _wgrad_into(mode, opt, w_param, b_param, g, a_in, rows, m, n, k):
+    """dW, db of one layer into the optimiser: deferred slabs where the shape has them, else reduced into .grad (accumulating)."""
+    if mode == 'defer' and ops.wgrad_slabs_ok(m, n, k, a_in.shape[1], g.shape[1]):
+        slab, n_slabs, stride = ops.linear_wgrad_slabs_bf16(g, a_in, rows, m, n, k, slab=getattr(w_param, '_mg_slab_buf', None))
+        w_param._mg_slab_buf = slab                      # one buffer per layer, reused every step (and by every graph replay)
+        opt.defer_slabs(w_param, n * k + n, slab, n_slabs, stride)
+    else:
+        ops.linear_wgrad_bf16(g, a_in, rows, m, n, k, out_w=w_param.grad, out_b=b_param.grad, accumulate=True)
+
+
 class LinearStackMSEFn(torch.autograd.Function):
     """bf16 Linear/Sigmoid stack ending in ... -> 128 -> 32 -> 1 TOGETHER with the masked MSE (losses.py:29-51).
 
@@ -296,9 +327,11 @@ class LinearStackMSEFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, acts, x2d, rows, target, seq_len, *params):
-        maps = None
-        if len(acts) == 2 and not isinstance(acts[0], int):       # (acts, maps): phone-rate maps that came with the frame map
-            acts, maps = acts
+        acts_in = acts
+        maps = table_bf16 = None
+        if len(acts) in (2, 3) and not isinstance(acts[0], int):  # (acts, maps[, table]): phone-rate maps that came with the frame map,
+            acts, maps = acts[0], acts[1]                         # and the loader's bf16 copy of the phone table (data.add_bf16_table)
+            table_bf16 = acts_in[2] if len(acts_in) == 3 else None
         n_layers = len(acts)
         weights = [params[2 * i] for i in range(n_layers)]
         biases = [params[2 * i + 1] for i in range(n_layers)]
@@ -310,7 +343,9 @@ class LinearStackMSEFn(torch.autograd.Function):
             raise ValueError('prediction rows (%d) and target rows (%d) differ' % (
                 rows.numel() if rows is not None else x2d.shape[0], m))
         lead = n_layers - 2
-        w_bf, w_t = ops.cast_params_bf16(weights[:lead], want_t=tuple(range(1, lead)))
+        # bf16 operands of the leading layers: copies that live on the parameters and are kept current by the optimiser's update
+        # kernel (ops.param_shadows) - a training step launches no weight cast
+        w_bf, w_t = ops.param_shadows(weights[:lead], want_t=tuple(range(1, lead)))
         # Phone-rate step (csrc/phone_rate.hip).  The stack's input is upsample_to_repetitions(lab, dur): every phone row repeated.
         # Linear and Sigmoid commute with repeating rows, and the README model has no frame-level input, so EVERY layer's output is
         # constant over a phone's frames: the layers run once per phone row (plus extra zero rows = what padding frames gather),
@@ -324,7 +359,10 @@ class LinearStackMSEFn(torch.autograd.Function):
         if phone_rate:
             extra = ops.PHONE_RATE_EXTRA
             seg, rows = maps if maps is not None else ops.segment_bounds(rows, n_table, pad_row=n_table)
-            a0 = ops.cast_pad_bf16(x2d, extra_rows=extra)
+            if table_bf16 is not None and tuple(table_bf16.shape) == (n_table + extra, ops.pad_ld(x2d.shape[1])):
+                a0 = table_bf16                                   # cast once when the batch was loaded, not once per step
+            else:
+                a0 = ops.cast_pad_bf16(x2d, extra_rows=extra)
             n_rows = a0.shape[0]
             hidden, a = [], a0
             for i in range(lead):
@@ -348,7 +386,10 @@ class LinearStackMSEFn(torch.autograd.Function):
             ctx.mark_non_differentiable(pred)
             ctx.set_materialize_grads(False)
             return loss, pred
-        a = ops.cast_pad_bf16(x2d)
+        if table_bf16 is not None and table_bf16.shape[0] >= x2d.shape[0] and table_bf16.shape[1] == ops.pad_ld(x2d.shape[1]):
+            a = table_bf16                                        # rows beyond the phone rows are never indexed by the gather
+        else:
+            a = ops.cast_pad_bf16(x2d)
         a0, r = a, rows
         hidden = []
         for i in range(lead):
@@ -385,6 +426,40 @@ class LinearStackMSEFn(torch.autograd.Function):
             n_, k_ = ctx.dims[i]
             return (flat[ctx.offsets[2 * i]:ctx.offsets[2 * i] + n_ * k_].view(n_, k_),
                     flat[ctx.offsets[2 * i + 1]:ctx.offsets[2 * i + 1] + n_])
+
+        mode, opt = _grad_mode(ctx.params, grad_loss)
+        if mode != 'temp':
+            # The gradients go where the optimiser reads them, without a temporary and an add in between: either straight into its flat
+            # buffer (the reduce launches accumulate there) or - one rank, fused loop - as split-M slabs the update kernel sums itself.
+            params = ctx.params
+            tail_off = ctx.offsets[2 * lead]
+            tail_count = flat.numel() - 1 - tail_off
+            m_rows = hidden[0].shape[0] if ctx.phone_rate else m
+            r0 = None if ctx.phone_rate else rows
+            top = lead - 1                                            # the 128-wide layer: its dZ came out of the fused tail
+            n, k = ctx.dims[top]
+            _wgrad_into(mode, opt, params[2 * top], params[2 * top + 1], g, hidden[top - 1] if top > 0 else a0, None if top > 0 else r0,
+                        m_rows, n, k)
+            if mode == 'defer':
+                opt.defer_slabs(params[2 * lead], tail_count, flat[tail_off:tail_off + tail_count], 1, tail_count)
+            else:
+                params[2 * lead].grad.reshape(-1).as_strided((tail_count,), (1,)).add_(flat[tail_off:tail_off + tail_count])
+            for i in range(top, 0, -1):
+                n, k = ctx.dims[i]
+                if i == 1 and _EARLY_GRADS_HOOK is not None:
+                    _EARLY_GRADS_HOOK()                               # everything but the first layer's gradient is final
+                if (not ctx.phone_rate and i == 1 and ctx.acts[0] == ops.ACT_SIGMOID and
+                        ops.can_fuse_bwd(m, n, k, ctx.dims[0][1], a0.shape[1])):
+                    n0_, k0_ = ctx.dims[0]
+                    ops.linear_bwd_fused_bf16(g, w_t[1], hidden[0], a0, rows, m, n0_, k0_, out_w=params[0].grad, out_b=params[1].grad,
+                                              accumulate=True)
+                    break
+                h = hidden[i - 1] if ctx.acts[i - 1] == ops.ACT_SIGMOID else None
+                g = ops.linear_dgrad_bf16(g, m_rows, n, w_t[i], k, h)
+                n_, k_ = ctx.dims[i - 1]
+                _wgrad_into(mode, opt, params[2 * (i - 1)], params[2 * (i - 1) + 1], g, hidden[i - 2] if i > 1 else a0,
+                            None if i > 1 else r0, m_rows, n_, k_)
+            return (None, None, None, None, None) + (None,) * len(params)
 
         if ctx.phone_rate:
             # g is dL/dZ_1 per TABLE row already (the tail ran on phone rows with the frames' summed loss weights), so the remaining

@@ -67,6 +67,9 @@ class GraphedTrainStep(object):
         self.model, self.optimizer, self.features = model, optimizer, features
         self.loss = None
         self.output = None
+        # this object runs exactly the reference's loop body, so the optimiser may treat it as one unit: the update kernel zeroes the
+        # gradient behind its read and (one rank) sums the weight-gradient slabs the backward pass leaves for it (optim.Adam.fused_loop)
+        optimizer.fused_loop = True
         self._multi = optimizer.exchanging()
         self.exchange_mode = 'none'
         if warmup:

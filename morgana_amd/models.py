@@ -68,7 +68,7 @@ class F0Model(BaseSPSS):
         if target is None or not self.fused_loss:
             return super(F0Model, self).forward(features)
         x = utils.upsample_to_repetitions(features['normalised_lab'], features['dur'], max_len=target.shape[1],
-                                          fused=self.fused_upsample)
+                                          fused=self.fused_upsample, table_bf16=features.get('normalised_lab' + data.BF16_TABLE_SUFFIX))
         loss, pred_norm = self.layers.forward_mse(x, target, seq_len=features['n_frames'])
         outputs = {'pred_norm_' + self.target_name: pred_norm}
         if self.target_name in self.normalisers:

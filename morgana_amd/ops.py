@@ -373,8 +373,8 @@ def linear_dgrad_bf16(dy, m, n, wt_bf16, k, h, out_f32=False):
     return dx
 
 
-def linear_wgrad_bf16(dy, a, rows, m, n, k, want_bias=True, out_w=None, out_b=None):
-    """out_w / out_b: optional preallocated fp32 destinations (e.g. slices of one gradient buffer)."""
+def linear_wgrad_bf16(dy, a, rows, m, n, k, want_bias=True, out_w=None, out_b=None, accumulate=False):
+    """out_w / out_b: optional preallocated fp32 destinations (e.g. slices of one gradient buffer); accumulate adds into them."""
     lib = _lib.load()
     dw = out_w if out_w is not None else torch.empty((n, k), dtype=torch.float32, device=dy.device)
     db = None
@@ -382,9 +382,31 @@ def linear_wgrad_bf16(dy, a, rows, m, n, k, want_bias=True, out_w=None, out_b=No
         db = out_b if out_b is not None else torch.empty((n,), dtype=torch.float32, device=dy.device)
     nbytes = lib.mg_linear_wgrad_workspace_bytes(m, n, k)
     ws = workspace(nbytes, dy.device)
-    _lib.check(lib.mg_linear_wgrad_bf16(_p(dy), dy.shape[1], _p(a), a.shape[1], _p(rows), m, n, k, _p(dw), _p(db), 0,
+    _lib.check(lib.mg_linear_wgrad_bf16(_p(dy), dy.shape[1], _p(a), a.shape[1], _p(rows), m, n, k, _p(dw), _p(db), int(bool(accumulate)),
                                         _p(ws), ws.numel(), _stream()), 'mg_linear_wgrad_bf16')
     return dw, db
+
+
+def wgrad_slabs_ok(m, n, k, lda, lddy):
+    """Shapes whose weight gradient runs on the wide-tile kernel and can leave its split-M slabs to the optimiser
+    (mg_linear_wgrad_slabs_bf16; the plan of csrc/gemm_bf16_big.hip)."""
+    # m <= 32768: the plan then cuts 48-96 slabs; at frame-rate row counts it cuts 256, which a reduce launch of its own sums faster
+    # than the update kernel's one thread per element (101 us measured for 256 slabs of the 128 x 512 gradient)
+    return (4096 <= m <= 32768 and n % 128 == 0 and lddy >= n and lddy % 8 == 0 and
+            ((lda == 640 and 512 < k <= 640) or (lda == 512 and 384 < k <= 512)))
+
+
+def linear_wgrad_slabs_bf16(dy, a, rows, m, n, k, slab=None):
+    """linear_wgrad_bf16 without the reduce: returns (slab buffer, n_slabs, stride); slab s holds [n*k weight partials | n bias
+    partials].  ``slab`` = a buffer to reuse (kept by the caller until the optimiser has consumed it)."""
+    lib = _lib.load()
+    nbytes = lib.mg_linear_wgrad_workspace_bytes(m, n, k)
+    if slab is None or slab.numel() < nbytes:
+        slab = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
+    n_slabs, stride = ctypes.c_int(0), ctypes.c_int64(0)
+    _lib.check(lib.mg_linear_wgrad_slabs_bf16(_p(dy), dy.shape[1], _p(a), a.shape[1], _p(rows), m, n, k, _p(slab), slab.numel(),
+                                              ctypes.byref(n_slabs), ctypes.byref(stride), _stream()), 'mg_linear_wgrad_slabs_bf16')
+    return slab, n_slabs.value, stride.value
 
 
 def can_fuse_bwd(m, n2, n_hidden, k0, lda0):
@@ -392,7 +414,7 @@ def can_fuse_bwd(m, n2, n_hidden, k0, lda0):
     return n2 == 128 and n_hidden % 128 == 0 and 512 < k0 <= 608 and lda0 == 640 and m >= 4096
 
 
-def linear_bwd_fused_bf16(dz2, wt2, h1, a, rows, m, n_hidden, k0, out_w=None, out_b=None):
+def linear_bwd_fused_bf16(dz2, wt2, h1, a, rows, m, n_hidden, k0, out_w=None, out_b=None, accumulate=False):
     """dW, db of Linear(k0 -> n_hidden)+Sigmoid from dz2 = dL/d(pre-activation of the following Linear(n_hidden -> 128))."""
     lib = _lib.load()
     dw = out_w if out_w is not None else torch.empty((n_hidden, k0), dtype=torch.float32, device=dz2.device)
@@ -400,7 +422,7 @@ def linear_bwd_fused_bf16(dz2, wt2, h1, a, rows, m, n_hidden, k0, out_w=None, ou
     nbytes = lib.mg_linear_bwd_fused_workspace_bytes(m, n_hidden, k0)
     ws = workspace(nbytes, dz2.device)
     _lib.check(lib.mg_linear_bwd_fused_bf16(_p(dz2), dz2.shape[1], 128, _p(wt2), wt2.shape[1], _p(h1), h1.shape[1], _p(a),
-                                            a.shape[1], _p(rows), m, n_hidden, k0, _p(dw), _p(db), 0, _p(ws), ws.numel(),
+                                            a.shape[1], _p(rows), m, n_hidden, k0, _p(dw), _p(db), int(bool(accumulate)), _p(ws), ws.numel(),
                                             _stream()), 'mg_linear_bwd_fused_bf16')
     return dw, db
 
@@ -426,6 +448,38 @@ def cast_params_bf16(weights, want_plain=True, want_t=()):
     _lib.check(lib.mg_cast_params_bf16(ctypes.cast(descs, ctypes.c_void_p), len(weights), _stream()),
                'mg_cast_params_bf16')
     return plain, trans
+
+
+def param_shadows(weights, want_t=()):
+    """bf16 operands of a run of fp32 weight matrices: ([N, pad_ld(K)] copies, transposes [K, pad_ld(N)] for the indices in
+    ``want_t``, None elsewhere).  The copies live ON the parameter (``w._mg_shadow``) and are kept current by
+    ``morgana_amd.optim.Adam``'s update kernel, which re-casts every weight it has just changed (mg_adam_step_plan_f32), so a training
+    step launches no cast at all; a weight changed by anything else (``load_state_dict``, another optimiser: its torch version
+    counter moves; or one of our updates that did not refresh it: ``_mg_updates`` moves) is simply cast again here."""
+    stale = []
+    for i, w in enumerate(weights):
+        sh = getattr(w, '_mg_shadow', None)
+        ok = (sh is not None and sh['version'] == (w._version, getattr(w, '_mg_updates', 0)) and sh['plain'].device == w.device
+              and (i not in want_t or sh['t'] is not None))
+        if not ok:
+            stale.append(i)
+    if stale:
+        descs = (_lib.CastDesc * len(stale))()
+        for j, i in enumerate(stale):
+            w = _require(weights[i], torch.float32, 'weight')
+            n, k = w.shape
+            old = getattr(w, '_mg_shadow', None)
+            plain = old['plain'] if old is not None and old['plain'].device == w.device else \
+                torch.zeros((n, pad_ld(k)), dtype=torch.bfloat16, device=w.device)
+            trans = old['t'] if old is not None and old['t'] is not None and old['t'].device == w.device else None
+            if trans is None and i in want_t:
+                trans = torch.zeros((k, pad_ld(n)), dtype=torch.bfloat16, device=w.device)
+            descs[j].src, descs[j].rows, descs[j].cols = w.data_ptr(), n, k
+            descs[j].dst, descs[j].ldd = plain.data_ptr(), plain.shape[1]
+            descs[j].dst_t, descs[j].ldt = (trans.data_ptr(), trans.shape[1]) if trans is not None else (None, 0)
+            w._mg_shadow = {'plain': plain, 't': trans, 'version': (w._version, getattr(w, '_mg_updates', 0))}
+        _lib.check(_lib.load().mg_cast_params_bf16(ctypes.cast(descs, ctypes.c_void_p), len(stale), _stream()), 'mg_cast_params_bf16')
+    return [w._mg_shadow['plain'] for w in weights], [w._mg_shadow['t'] if i in want_t else None for i, w in enumerate(weights)]
 
 
 def f0_tail(h2, w3, b3, w4, b4, target, seq_len, b, t, grads_out, grad_scale=1.0):
@@ -825,6 +879,30 @@ def adam_step_dev(param, grad, exp_avg, exp_avg_sq, betas, eps, weight_decay, sc
     _lib.check(lib.mg_adam_step_dev_f32(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), float(betas[0]),
                                         float(betas[1]), float(eps), float(weight_decay), _p(scalars), float(grad_scale), _stream()),
                'mg_adam_step_dev_f32')
+
+
+def adam_step_plan(param, grad, exp_avg, exp_avg_sq, betas, eps, weight_decay, scalars, grad_scale=1.0, slab_srcs=(), shadows=(),
+                   clear_grad=False):
+    """The update as the last node of a step (mg_adam_step_plan_f32): ``slab_srcs`` = [(begin, count, slab tensor, n_slabs, stride)]
+    are summed into the gradient on the fly (split-M partial results of the weight-gradient GEMMs, in the slab reduce's order),
+    ``shadows`` = [(offset, rows, cols, bf16 [rows, ldd] or None, bf16 transpose [cols, ldt] or None)] are refreshed from the
+    updated weights, ``clear_grad`` zeroes the flat gradient behind the read."""
+    lib = _lib.load()
+    if len(slab_srcs) > _lib.ADAM_MAX_SLABS or len(shadows) > _lib.ADAM_MAX_SHADOWS:
+        raise ValueError('adam_step_plan: at most %d slab sources and %d shadows' % (_lib.ADAM_MAX_SLABS, _lib.ADAM_MAX_SHADOWS))
+    plan = _lib.AdamPlan()
+    plan.n_slab_srcs, plan.n_shadows, plan.clear_grad = len(slab_srcs), len(shadows), int(bool(clear_grad))
+    for i, (begin, count, slab, n_slabs, stride) in enumerate(slab_srcs):
+        src = plan.slabs[i]
+        src.begin, src.count, src.slab, src.n_slabs, src.stride = int(begin), int(count), slab.data_ptr(), int(n_slabs), int(stride)
+    for i, (offset, rows, cols, dst, dst_t) in enumerate(shadows):
+        sh = plan.shadows[i]
+        sh.offset, sh.rows, sh.cols = int(offset), int(rows), int(cols)
+        sh.dst, sh.ldd = (dst.data_ptr(), dst.shape[1]) if dst is not None else (None, 0)
+        sh.dst_t, sh.ldt = (dst_t.data_ptr(), dst_t.shape[1]) if dst_t is not None else (None, 0)
+    _lib.check(lib.mg_adam_step_plan_f32(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), float(betas[0]),
+                                         float(betas[1]), float(eps), float(weight_decay), _p(scalars), float(grad_scale),
+                                         ctypes.byref(plan), _stream()), 'mg_adam_step_plan_f32')
 
 
 def ema_update(shadow, param, decay):

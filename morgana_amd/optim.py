@@ -4,10 +4,14 @@ Stands where the reference constructs ``torch.optim.Adam(model.parameters(), lr,
 (experiment_builder.py:516) and calls ``zero_grad`` / ``step`` (:468, :474).  Same update rule and defaults.
 
 MI355X design: parameters, gradients and both moments are views into four contiguous buffers, so
-  * ``zero_grad`` is one memset,
-  * the data-parallel exchange is ONE RCCL all-reduce of the whole gradient (1.5 MB for the F0Model) per step,
-    with the 1/world_size mean folded into the Adam kernel's gradient read,
-  * ``step`` is one elementwise kernel (mg_adam_step_f32) instead of ~10 foreach passes over 8 tensors.
+  * ``zero_grad`` is one memset - or nothing at all: with ``fused_loop`` the update kernel zeroes the gradient behind its read,
+  * the data-parallel exchange is ONE RCCL all-reduce of the whole gradient (1.5 MB for the F0Model) per step (or two buckets, the
+    early one overlapped with the backward pass: ``exchange_gradients``), with the 1/world_size mean folded into the update kernel's
+    gradient read,
+  * ``step`` is one elementwise kernel (mg_adam_step_plan_f32) instead of ~10 foreach passes over 8 tensors - and that kernel is
+    also the step's last consumer of everything the backward pass left for it: it sums the split-M slabs of the weight-gradient
+    GEMMs itself (no reduce launches, one rank only) and re-casts each weight it has changed into the bf16 operands the next
+    step's GEMMs read (no cast launches).
 """
 import torch
 import torch.distributed as dist
@@ -17,17 +21,25 @@ from . import ops
 
 class Adam(torch.optim.Optimizer):
     """``kernel`` is a test seam: the CPU-only unit tests inject the oracle's update there; on a device it is always
-    the HIP kernel."""
+    the HIP kernel.
+
+    ``fused_loop``: the caller runs the reference's loop body - ``zero_grad(); loss = model(...); loss.backward(); step()``
+    (experiment_builder.py:468-474) - and nothing reads ``.grad`` between ``backward`` and ``step``.  Then (a) ``step`` leaves the
+    gradient buffer zeroed and the following ``zero_grad`` is free, (b) on one rank the backward pass may leave split-M partial
+    results of its weight-gradient GEMMs for ``step`` to sum (``defer_slabs``) instead of reducing them into ``.grad`` itself.
+    ``ExperimentBuilder`` and ``graphs.GraphedTrainStep`` own exactly that loop and switch it on; off (the default) keeps torch's
+    semantics to the letter (``.grad`` complete after ``backward``, untouched by ``step``)."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, process_group=None,
-                 kernel=None, exchange_always=False):
+                 kernel=None, exchange_always=False, fused_loop=False):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super(Adam, self).__init__(params, defaults)
         self.process_group = process_group
         # exchange_always: run the gradient exchange whenever a process group exists, also at world size 1 (where it is the
         # identity) - lets the one-GPU box exercise the multi-rank code path on a live RCCL communicator
         self.exchange_always = exchange_always
-        self._kernel = kernel if kernel is not None else ops.adam_step
+        self.fused_loop = bool(fused_loop)
+        self._kernel = kernel
         self._flat = []
         for group in self.param_groups:
             plist = [p for p in group['params'] if p.requires_grad]
@@ -37,7 +49,7 @@ class Adam(torch.optim.Optimizer):
             device, total = plist[0].device, sum(p.numel() for p in plist)
             flat_p = torch.empty(total, dtype=torch.float32, device=device)
             flat_g = torch.zeros(total, dtype=torch.float32, device=device)
-            off = 0
+            off, offsets = 0, {}
             for p in plist:
                 if p.dtype != torch.float32 or p.device != device:
                     raise ValueError('Adam: all parameters of a group must be float32 on one device')
@@ -46,17 +58,27 @@ class Adam(torch.optim.Optimizer):
                 p.data = flat_p[off:off + n].view_as(p)
                 p.grad = flat_g[off:off + n].view_as(p)
                 p._mg_direct_grad = True          # functional._deliver_param_grads may add into flat_g directly
+                p._mg_optimizer = self            # functional asks it whether slabs may be deferred (weak: the param outlives nothing here)
+                offsets[id(p)] = off
                 off += n
             self._flat.append({'param': flat_p, 'grad': flat_g, 'exp_avg': torch.zeros_like(flat_p),
-                               'exp_avg_sq': torch.zeros_like(flat_p), 'step': 0, 'params': plist})
+                               'exp_avg_sq': torch.zeros_like(flat_p), 'step': 0, 'params': plist, 'offsets': offsets,
+                               'pending': [], 'clean': False})
 
     def flat_buffers(self, group=0):
         return self._flat[group]
 
+    def _on_device(self):
+        return self._kernel is None and any(f is not None and f['param'].is_cuda for f in self._flat)
+
     def zero_grad(self, set_to_none=False):
         for flat in self._flat:
             if flat is not None:
-                flat['grad'].zero_()
+                if flat['clean']:
+                    flat['clean'] = False         # the last step's kernel zeroed the buffer; trusted once (see class docstring)
+                else:
+                    flat['grad'].zero_()
+                flat['pending'] = []              # partial results nobody consumed belong to a gradient that is being dropped
                 off = 0
                 for p in flat['params']:          # re-attach views a caller may have dropped (set_to_none habits)
                     n = p.numel()
@@ -68,6 +90,30 @@ class Adam(torch.optim.Optimizer):
         if dist.is_available() and dist.is_initialized():
             return dist.get_world_size(self.process_group)
         return 1
+
+    # ---- what the backward pass may leave for the update kernel -------------------------------------------------------------
+    def defers_slabs(self):
+        """May a weight-gradient GEMM leave its split-M slabs unreduced for ``step``?  Only in the fused loop, on the device,
+        and when no exchange needs the finished gradient first."""
+        return self.fused_loop and self._on_device() and not self.exchanging()
+
+    def defer_slabs(self, first_param, count, slab, n_slabs, stride):
+        """Register partial results: elements [offset of ``first_param``, + count) of the flat gradient are ADDITIONALLY the sum of
+        ``n_slabs`` slabs of ``stride`` floats in ``slab`` (kept alive here until the step has consumed them)."""
+        for flat in self._flat:
+            if flat is not None and id(first_param) in flat['offsets']:
+                flat['pending'].append((flat['offsets'][id(first_param)], int(count), slab, int(n_slabs), int(stride)))
+                return
+        raise ValueError('defer_slabs: the parameter is not one of this optimiser\'s')
+
+    def _shadows(self, flat):
+        """(offset, rows, cols, plain, transposed) for every 2-D parameter that carries bf16 operand copies (ops.param_shadows)."""
+        out = []
+        for p in flat['params']:
+            sh = getattr(p, '_mg_shadow', None)
+            if sh is not None and p.dim() == 2 and sh['plain'].device == p.device:
+                out.append((flat['offsets'][id(p)], p.shape[0], p.shape[1], sh['plain'], sh['t'], p))
+        return out
 
     # ---- HIP-graph support (morgana_amd/graphs.py): the captured update reads its step-dependent scalars from device memory
     def _scalar_buffers(self, flat):
@@ -126,16 +172,27 @@ class Adam(torch.optim.Optimizer):
             step_size, bc2_sqrt = ops.adam_scalars(group['lr'], group['betas'], flat['step'])
             ops.store_pair(self._scalar_buffers(flat), step_size, bc2_sqrt)
 
+    def _launch(self, group, flat, world):
+        """The update kernel with everything this step left for it (see the module docstring)."""
+        shadows = self._shadows(flat)
+        pending, flat['pending'] = flat['pending'], []
+        ops.adam_step_plan(flat['param'], flat['grad'], flat['exp_avg'], flat['exp_avg_sq'], group['betas'], group['eps'],
+                           group['weight_decay'], self._scalar_buffers(flat), 1.0 / world, slab_srcs=pending,
+                           shadows=[sh[:5] for sh in shadows], clear_grad=self.fused_loop)
+        flat['clean'] = self.fused_loop
+        for p in flat['params']:
+            p._mg_updates = getattr(p, '_mg_updates', 0) + 1
+        for sh in shadows:                                   # refreshed by the kernel: current again
+            p = sh[5]
+            p._mg_shadow['version'] = (p._version, p._mg_updates)
+
     @torch.no_grad()
     def step_captured(self):
         """The parameter update alone, from device-resident scalars (call ``advance`` before each replay).  No all-reduce here."""
         world = self._world()
         for group, flat in zip(self.param_groups, self._flat):
-            if flat is None:
-                continue
-            dev = self._scalar_buffers(flat)
-            ops.adam_step_dev(flat['param'], flat['grad'], flat['exp_avg'], flat['exp_avg_sq'], group['betas'], group['eps'],
-                              group['weight_decay'], dev, 1.0 / world)
+            if flat is not None:
+                self._launch(group, flat, world)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -151,6 +208,12 @@ class Adam(torch.optim.Optimizer):
                 # the single gradient exchange of the step: sum over ranks, mean folded into the kernel below
                 dist.all_reduce(flat['grad'], op=dist.ReduceOp.SUM, group=self.process_group)
             flat['step'] += 1
-            self._kernel(flat['param'], flat['grad'], flat['exp_avg'], flat['exp_avg_sq'], group['lr'], group['betas'],
-                         group['eps'], group['weight_decay'], flat['step'], 1.0 / world)
+            if self._kernel is not None or not flat['param'].is_cuda:
+                kernel = self._kernel if self._kernel is not None else ops.adam_step
+                kernel(flat['param'], flat['grad'], flat['exp_avg'], flat['exp_avg_sq'], group['lr'], group['betas'],
+                       group['eps'], group['weight_decay'], flat['step'], 1.0 / world)
+                continue
+            step_size, bc2_sqrt = ops.adam_scalars(group['lr'], group['betas'], flat['step'])
+            ops.store_pair(self._scalar_buffers(flat), step_size, bc2_sqrt)
+            self._launch(group, flat, world)
         return loss

@@ -51,11 +51,12 @@ class UpsampledSequence(object):
     (B, Tmax, feat) tensor never exists in HBM.  ``materialise()`` gives the ordinary dense tensor.
     """
 
-    def __init__(self, sequence_feature, dur2d, rows, maps=None):
+    def __init__(self, sequence_feature, dur2d, rows, maps=None, table_bf16=None):
         self.source = sequence_feature
         self.dur = dur2d
         self.rows = rows                       # int32 (B, Tmax): b*P + phone, or -1
         self.maps = maps                       # (seg (2, B*P) frame runs, rows with -1 -> B*P) from the same launch, or None
+        self.table_bf16 = table_bf16           # the loader's bf16 copy of the source rows (data.add_bf16_table), or None
         self.shape = (sequence_feature.shape[0], rows.shape[1], sequence_feature.shape[2])
 
     def phone_maps(self):
@@ -165,7 +166,7 @@ def concat_frame_features(upsampled, frame_feature):
     return torch.cat((upsampled, frame_feature), dim=-1)
 
 
-def upsample_to_repetitions(sequence_feature, repeats, max_len=None, fused=False):
+def upsample_to_repetitions(sequence_feature, repeats, max_len=None, fused=False, table_bf16=None):
     """Copies sequence items according to a number of repetitions, as ``np.repeat`` does.  morgana/utils.py:175-228.
 
     sequence_feature (B, P, F) float32; repeats (B, P, 1) or (B, P) integer -> (B, max_b sum_p repeats, F).
@@ -187,9 +188,9 @@ def upsample_to_repetitions(sequence_feature, repeats, max_len=None, fused=False
     if fused and not sequence_feature.requires_grad:
         if ops.PHONE_RATE and int(max_len) > 0:
             rows, rows_mapped, seg = ops.upsample_index_maps(dur2d, int(max_len))
-            return UpsampledSequence(sequence_feature, dur2d, rows, maps=(seg, rows_mapped.reshape(-1)))
+            return UpsampledSequence(sequence_feature, dur2d, rows, maps=(seg, rows_mapped.reshape(-1)), table_bf16=table_bf16)
         _, rows = ops.upsample_index(dur2d, int(max_len))
-        return UpsampledSequence(sequence_feature, dur2d, rows)
+        return UpsampledSequence(sequence_feature, dur2d, rows, table_bf16=table_bf16)
     return F_hip.UpsampleFn.apply(sequence_feature, dur2d, int(max_len))
 
 
@@ -427,9 +428,10 @@ class SequentialWithRecurrent(nn.Sequential):
             out, _ = self.forward(input, seq_len=seq_len)
             return losses.mse(out, targets, seq_len), out
         run, acts = fused
-        maps = None
+        maps = table = None
         if isinstance(input, UpsampledSequence):
             x2d, rows, maps = input.source.reshape(-1, input.source.shape[-1]), input.rows.reshape(-1), input.maps
+            table = input.table_bf16
         else:
             x2d, rows = input.reshape(-1, input.shape[-1]), None
         if seq_len is not None and seq_len.dtype != torch.int64:
@@ -437,7 +439,7 @@ class SequentialWithRecurrent(nn.Sequential):
         params = []
         for lin, _ in run:
             params += [lin.weight, lin.bias]
-        return F_hip.LinearStackMSEFn.apply((acts, maps), x2d, rows, targets, seq_len, *params)
+        return F_hip.LinearStackMSEFn.apply((acts, maps, table), x2d, rows, targets, seq_len, *params)
 
     def forward(self, input, hiddens=None, seq_len=None, max_len=None, layout=None):
         """``max_len`` (not in the reference) is handed to the recurrent wrappers: see ``RecurrentCuDNNWrapper.forward``.

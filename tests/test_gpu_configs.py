@@ -295,3 +295,82 @@ def test_wrapper_accepts_packed_sequences():
     assert isinstance(got, nn.utils.rnn.PackedSequence)
     got_padded, lens = nn.utils.rnn.pad_packed_sequence(got, batch_first=True)
     assert torch.equal(lens, sl.cpu()) and torch.equal(got_padded, want) and torch.equal(got_h, want_h)
+
+
+# ------------------------------------------------------------------------------------------------------------ fused update
+@pytest.mark.parametrize('n_slabs,aligned', [(48, True), (96, True), (5, False), (1, False)])
+def test_adam_plan_kernel_equals_reduce_then_adam(n_slabs, aligned):
+    """mg_adam_step_plan_f32 (split-M slabs summed inside the update, bf16 operand copies refreshed, gradient zeroed behind the read)
+    against the separate launches it replaces - slab reduce (mg_linear_wgrad_bf16's) into the gradient, mg_adam_step_dev_f32, a cast:
+    parameters, both moments and the bf16 copies EQUAL bit for bit; the gradient buffer is zero afterwards.  Ranges that are not
+    16-byte aligned take the element-wise path."""
+    rng = np.random.RandomState(n_slabs)
+    rows, cols = 24, 40
+    n_mat = rows * cols
+    begin = 64 if aligned else 37
+    count = n_mat + rows if aligned else n_mat + rows - 3
+    n = begin + count + 29
+    stride = count + (0 if aligned else 1)
+    param = dev(rng.standard_normal(n).astype(np.float32))
+    grad = dev(rng.standard_normal(n).astype(np.float32) * 0.1)
+    m0 = dev(rng.standard_normal(n).astype(np.float32) * 0.01)
+    v0 = dev(np.abs(rng.standard_normal(n)).astype(np.float32) * 0.01)
+    slabs = dev(rng.standard_normal((n_slabs, stride)).astype(np.float32) * 0.05)
+    scalars = torch.tensor(ops.adam_scalars(0.01, (0.9, 0.999), 3), dtype=torch.float32, device=DEV)
+    # reference: the slab reduce's order (16 interleaved partitions, ascending, then ascending over partitions) on the host in fp32
+    want_grad = grad.clone()
+    acc = want_grad[begin:begin + count].clone()
+    parts = []
+    for p in range(min(16, n_slabs)):
+        t = torch.zeros(count, device=DEV)
+        for s in range(p, n_slabs, 16):
+            t = t + slabs[s, :count]
+        parts.append(t)
+    for t in parts:
+        acc = acc + t
+    want_grad[begin:begin + count] = acc
+    p_ref, m_ref, v_ref = param.clone(), m0.clone(), v0.clone()
+    ops.adam_step_dev(p_ref, want_grad, m_ref, v_ref, (0.9, 0.999), 1e-8, 0.01, scalars, 0.5)
+    plain = torch.zeros((rows, 64), dtype=torch.bfloat16, device=DEV)
+    trans = torch.zeros((cols, 64), dtype=torch.bfloat16, device=DEV)
+    p_got, g_got, m_got, v_got = param.clone(), grad.clone(), m0.clone(), v0.clone()
+    ops.adam_step_plan(p_got, g_got, m_got, v_got, (0.9, 0.999), 1e-8, 0.01, scalars, 0.5,
+                       slab_srcs=[(begin, count, slabs, n_slabs, stride)], shadows=[(begin, rows, cols, plain, trans)], clear_grad=True)
+    assert torch.equal(p_got, p_ref) and torch.equal(m_got, m_ref) and torch.equal(v_got, v_ref)
+    assert torch.count_nonzero(g_got) == 0
+    w = p_ref[begin:begin + n_mat].view(rows, cols)
+    assert torch.equal(plain[:, :cols], w.to(torch.bfloat16)) and torch.count_nonzero(plain[:, cols:]) == 0
+    assert torch.equal(trans[:, :rows], w.t().to(torch.bfloat16)) and torch.count_nonzero(trans[:, rows:]) == 0
+    with pytest.raises(ValueError):
+        ops.adam_step_plan(p_got, g_got, m_got, v_got, (0.9, 0.999), 1e-8, 0.0, scalars, 1.0, slab_srcs=[(n - 4, 16, slabs, 1, stride)])
+
+
+def test_fused_loop_step_equals_plain_loop():
+    """The reference's loop body with ``optim.Adam(fused_loop=True)`` (weight-gradient slabs left to the update kernel, bf16 weight copies
+    refreshed by it, zero_grad free, the loader's bf16 phone table) against the same loop with the default optimiser (every gradient
+    reduced into .grad by the backward pass, weights re-cast per step, memset per step, table cast per step): losses, parameters and
+    moments EQUAL bit for bit over several steps, at the phone-rate and at the frame-rate order of operations."""
+    for phone_rate in (True, False):
+        results = []
+        for fused in (False, True):
+            ops.PHONE_RATE = phone_rate
+            try:
+                feats = data.to_device(synthetic.make_batch(48, (200, 240), seed=4, frames_per_phone=5.0), DEV)
+                if fused:
+                    data.add_bf16_table(feats)
+                model = _load_state(models.F0Model(precision='bf16').to(DEV), synthetic.f0_model_state())
+                opt = optim.Adam(model.parameters(), lr=0.01, fused_loop=fused)
+                losses = []
+                for _ in range(5):
+                    opt.zero_grad()
+                    loss, _ = model(feats)
+                    F_hip.backward(loss)
+                    opt.step()
+                    losses.append(loss.item())
+            finally:
+                ops.PHONE_RATE = True
+            flat = opt.flat_buffers()
+            results.append((losses, flat['param'].clone(), flat['exp_avg'].clone(), flat['exp_avg_sq'].clone()))
+        (l0, p0, m0, v0), (l1, p1, m1, v1) = results
+        assert l0 == l1, phone_rate
+        assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1), phone_rate
