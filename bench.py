@@ -83,6 +83,7 @@ def roofline_f0(features, model, precision):
     n1, n2 = w1.shape[0], w2.shape[0]
     kernels = []
     bound = {}
+    algo_bytes = {}      # least bytes a launch of the kernel must move: operands once + result once (bf16 operands, fp32 gradients)
     if precision == 'bf16' and ops.phone_rate_table_ok(b * p, m, n1, n2, ops.ACT_SIGMOID):
         # the step as LinearStackMSEFn runs it (whole stack at phone rate): every layer on the B*P phone rows + the extra zero rows,
         # the masked MSE reduced per phone, the backward chain on the same rows
@@ -103,6 +104,12 @@ def roofline_f0(features, model, precision):
         kernels.append(('phone_target_stats_kernel: per-phone weight / mean target / constant of the masked MSE (reads the M targets)', 0.0,
                         lambda: ops.phone_target_stats(target, rows_p, seg, seq_len, b, t, b * p, extra)))
         bound['phone_target_stats_kernel'] = ('hbm', m * 4.0 * 2 + r_tab * 8.0)
+        ldk = tab.shape[1]
+        algo_bytes.update({'gemm_nt_persist_kernel<256>': 2.0 * (r_tab * ldk + n1 * ldk + r_tab * n1),
+                           'gemm_nt_persist_kernel<128>': 2.0 * (r_tab * n1 + n2 * n1 + r_tab * n2),
+                           'wgrad_big_kernel<8>': 2.0 * (r_tab * n2 + r_tab * n1) + 4.0 * n2 * n1,
+                           'gemm_nt_big_kernel<256>': 2.0 * (r_tab * n2 + n1 * n2 + 2 * r_tab * n1),
+                           'wgrad_big_kernel<10>': 2.0 * (r_tab * n1 + r_tab * ldk) + 4.0 * n1 * k})
         kernels.append(('wgrad_big_kernel<8>: layer-2 wgrad at phone rate (dZ2^T table)', 2.0 * r_tab * n1 * n2,
                         lambda: ops.linear_wgrad_bf16(dz2, h_tab, None, r_tab, n2, n1)))
         kernels.append(('gemm_nt_big_kernel<256>: layer-2 dgrad + sigmoid-grad at phone rate', 2.0 * r_tab * n1 * n2,
@@ -129,6 +136,12 @@ def roofline_f0(features, model, precision):
                             lambda: ops.linear_wgrad_bf16(dz1, tab, rows, m, n1, k)))
         kernels.append(('wgrad_big_kernel<8>: layer-2 wgrad (dZ2^T H1)', 2.0 * m * n1 * n2,
                         lambda: ops.linear_wgrad_bf16(dz2, h1, None, m, n2, n1)))
+        n_tab, ldk = tab.shape
+        algo_bytes.update({'gemm_nt_persist_kernel<256>': 2.0 * (n_tab * ldk + n1 * ldk + m * n1) + 4.0 * m,
+                           'gemm_nt_persist_kernel<128>': 2.0 * (m * n1 + n2 * n1 + m * n2),
+                           'wgrad_fused_pipe_kernel': 2.0 * (m * n2 + m * n1 + n_tab * ldk) + 4.0 * m + 4.0 * n1 * k,
+                           'wgrad_big_kernel<10>': 2.0 * (m * n1 + n_tab * ldk) + 4.0 * m + 4.0 * n1 * k,
+                           'wgrad_big_kernel<8>': 2.0 * (m * n2 + m * n1) + 4.0 * n2 * n1})
         peak = MFMA_BF16_PEAK_TFLOPS
     else:
         tab = lab.view(b * p, k)
@@ -152,19 +165,33 @@ def roofline_f0(features, model, precision):
     lib.mg_set_tuning(1, 0)
     dom = max(measured, key=lambda r: r['ms'])
     short = dom['kernel'].split(':')[0]
+    # HBM bytes per launch of the dominant kernel from the committed PMC passes of this round (scripts/gpu_profile.sh:
+    # 2 x FETCH_SIZE + WRITE_SIZE on gfx950, MI355X_MICROARCH.md), and the bytes the launch has to move at the very least
     traffic = None
-    try:   # HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
-        table = json.load(open(os.path.join(REPO, 'profiles', 'r1_hbm_traffic.json')))
-        traffic = table.get(short)
-    except (OSError, ValueError):
-        pass
-    if short in bound:               # a kernel that moves bytes, not FLOPs: price it against the HBM roof
-        kind, nbytes = bound[short]
+    for table_name in ('r2_hbm_traffic.json', 'r1_hbm_traffic.json'):
+        try:
+            table = json.load(open(os.path.join(REPO, 'profiles', table_name)))
+            if table.get(short) is not None:
+                traffic = table.get(short)
+                break
+        except (OSError, ValueError):
+            pass
+    algorithmic_bytes = algo_bytes.get(short)
+    out = {'kernel': dom['kernel'], 'ms_per_launch': dom['ms'], 'traffic': traffic, 'algorithmic_bytes': algorithmic_bytes}
+    # which roof bounds the launch is read off the counters: a kernel that moves more than 0.6 of the 8 TB/s spec is memory bound
+    # whatever its FLOPs are (the first round labelled such a kernel "mfma")
+    moved = traffic if traffic is not None else algorithmic_bytes
+    hbm_gbs = moved / (dom['ms'] * 1e-3) / 1e9 if moved else 0.0
+    if short in bound or hbm_gbs > 0.6 * HBM_PEAK_GBS:
+        nbytes = bound[short][1] if short in bound else algorithmic_bytes
         gbs = nbytes / (dom['ms'] * 1e-3) / 1e9
-        return {'bound': kind, 'kernel': dom['kernel'], 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic, 'ms_per_launch': dom['ms'], 'kernels': measured}
-    return {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': dom['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
-            'frac': round(dom['tflops'] / peak, 4), 'traffic': traffic, 'ms_per_launch': dom['ms'], 'kernels': measured}
+        out.update({'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
+                    'measured_traffic_gbs': round(hbm_gbs, 1), 'mfma_tflops': dom['tflops']})
+    else:
+        out.update({'bound': 'mfma', 'achieved': dom['tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(dom['tflops'] / peak, 4),
+                    'measured_traffic_gbs': round(hbm_gbs, 1)})
+    out['kernels'] = measured
+    return out
 
 
 def roofline_gru(features, model, precision, target):
@@ -273,13 +300,13 @@ def host_cores():
     return max(1, min(n, 32))
 
 
-def cpu_baseline_f0(frames):
-    """Oracle torch-CPU restatement of the reference step on a bounded sample (64 utterances of the C2 batch)."""
+def cpu_baseline_f0(per_gpu, frames):
+    """Oracle torch-CPU restatement of the reference step (oracle/ref_torch.py: the same torch ops in the reference's order, proven
+    equal to the imported reference by the golden vectors) on the FULL C2 batch, on the host cores of this box: all threads the
+    process may use, then one thread.  Bounded: the N-thread leg times 5 steps after 2 warm-ups (about 1 s
+    per step), the 1-thread leg as many steps as fit in 30 s after one warm-up (at least one)."""
     from oracle import ref_torch
-    n_threads = host_cores()
-    torch.set_num_threads(n_threads)
-    sample_b = 64
-    feats = ref_torch.to_torch(synthetic.make_batch(sample_b, frames))
+    feats = ref_torch.to_torch(synthetic.make_batch(per_gpu, frames))
     model = ref_torch.load_state(ref_torch.F0Model(), synthetic.f0_model_state())
     opt = torch.optim.Adam(model.parameters(), lr=0.01)
 
@@ -289,16 +316,99 @@ def cpu_baseline_f0(frames):
         loss.backward()
         opt.step()
 
-    for _ in range(2):
+    def timed(n_threads, warm, max_steps, budget_s):
+        torch.set_num_threads(n_threads)
+        for _ in range(warm):
+            step()
+        n_timed, t0 = 0, time.perf_counter()
+        while n_timed < max_steps and (n_timed == 0 or (time.perf_counter() - t0) < budget_s):
+            step()
+            n_timed += 1
+        return n_timed, (time.perf_counter() - t0) / n_timed
+
+    n_threads = host_cores()
+    n_multi, dt_multi = timed(n_threads, 2, 5, 40.0)
+    n_single, dt_single = timed(1, 1, 5, 30.0)
+    torch.set_num_threads(n_threads)
+    total = per_gpu * frames
+    return {'value': round(total / dt_multi, 1), 'unit': 'frames/s', 'cores': n_threads, 'kind': 'port',
+            'single_thread': {'value': round(total / dt_single, 1), 'unit': 'frames/s', 'cores': 1, 'steps': n_single,
+                              's_per_step': round(dt_single, 3)},
+            's_per_step': round(dt_multi, 3),
+            'sample': '%d timed steps (2 warm-up) on %d threads and %d timed step(s) (1 warm-up) on 1 thread of the full %d x %d-frame C2 '
+                      'batch, torch-CPU fp32 restatement of the reference step (oracle/ref_torch.py)'
+                      % (n_multi, n_threads, n_single, per_gpu, frames)}
+
+
+def loss_curve_deviation(dev):
+    """SURVEY.md section 8d "Reporting": maximum relative deviation of this build's loss curve from the REFERENCE's own curve (golden G6:
+    20 Adam steps of the README F0Model at config C1, produced by the imported reference, tests/golden/make_golden.py), in the
+    benchmarked bf16 mode and in fp32 parity mode.  The north star's 1e-4 is a claim about fp32 mode; bf16 is stated next to it."""
+    path = os.path.join(REPO, 'tests', 'golden', 'g6_f0_model.npz')
+    if not os.path.exists(path):
+        return None
+    g = dict(np.load(path, allow_pickle=False))
+    want = np.asarray(g['loss_curve'], dtype=np.float64)
+    # the batches G6 was generated on: four C1 batches (8 x 200 frames) cycled, lr 0.01 (tests/golden/make_golden.py, tests/test_gpu_parity.py)
+    batches = [data.to_device(synthetic.make_batch(8, 200, seed=synthetic.REFERENCE_SEED + 100 * i), dev) for i in range(4)]
+    out = {'reference': 'tests/golden/g6_f0_model.npz: 20 Adam steps (lr 0.01) of the README F0Model at config C1, computed by the imported '
+                        'reference on CPU in fp32', 'what': 'max over the 20 steps of |loss - reference loss| / reference loss'}
+    for precision in ('bf16', 'fp32'):
+        model = models.F0Model(precision=precision).to(dev)
+        own = model.state_dict()
+        for key, value in synthetic.f0_model_state().items():
+            own[key].copy_(torch.from_numpy(value))
+        opt = optim.Adam(model.parameters(), lr=0.01)
+        curve = []
+        for i in range(len(want)):
+            opt.zero_grad()
+            loss, _ = model(batches[i % len(batches)])
+            F_hip.backward(loss)
+            opt.step()
+            curve.append(loss.item())
+        out[precision] = float('%.3g' % float(np.max(np.abs(np.asarray(curve) - want) / np.abs(want))))
+    return out
+
+
+def timed_leg(step, steps, warmup):
+    for _ in range(warmup):
         step()
-    n_timed, t0 = 0, time.perf_counter()
-    while n_timed < 8 and (time.perf_counter() - t0) < 25.0:
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
         step()
-        n_timed += 1
-    dt = (time.perf_counter() - t0) / n_timed
-    return {'value': round(sample_b * frames / dt, 1), 'unit': 'frames/s', 'cores': n_threads, 'kind': 'port',
-            'sample': '%d timed steps (2 warm-up) of %d x %d-frame utterances (1/4 of the C2 batch), torch-CPU fp32 '
-                      'restatement of the reference step (oracle/ref_torch.py)' % (n_timed, sample_b, frames)}
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def c4_leg(dev, precision):
+    """BASELINE config C4 (RNN_SPSS GRU-512, 600 -> 80, 64 x 1000 frames) timed in the same run as the headline, so that the recurrent
+    model's number is a driver-timed one as well: a few eager steps (4 ms each; the recurrences are two persistent launches)."""
+    feats_np = synthetic.make_batch(64, 1000, out_dim=80, target_name='mcep')
+    model = models.RNNSPSS(precision=precision).to(dev)
+    own = model.state_dict()
+    for key, value in synthetic.rnn_spss_state().items():
+        own[key].copy_(torch.from_numpy(value))
+    feats = data.to_device(feats_np, dev)
+    opt = optim.Adam(model.parameters(), lr=0.01, fused_loop=True)
+
+    def step():
+        opt.zero_grad()
+        loss, _ = model(feats)
+        F_hip.backward(loss)
+        opt.step()
+
+    ms = timed_leg(step, 10, 3)
+    ops.check_persistent_status()
+    frames = int(feats_np['n_frames'].sum())
+    # fwd MACs per frame 307,200 + 786,432 + 786,432 + 131,072 + 20,480 (SURVEY.md section 8d); backward = wgrad of everything + dgrad of all
+    # but the first layer
+    macs = 307200 + 786432 + 786432 + 131072 + 20480
+    flops = 2.0 * frames * (3 * macs - 307200)
+    return {'workload': 'C4: RNN_SPSS Linear-512 / GRU-512 / Linear-256 / 80, 64 x 1000 frames, eager launches, %s' % precision,
+            'ms_per_step': round(ms, 4), 'value': round(frames / (ms * 1e-3), 1), 'unit': 'frames/s',
+            'tflops': round(flops / (ms * 1e-3) / 1e12, 2), 'frac_of_mfma_peak': round(flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            'note': 'T = 1000 dependent steps per direction bound the step (latency chain), not the MFMA rate'}
 
 
 def main():
@@ -415,15 +525,34 @@ def main():
                 fr_step()
             torch.cuda.synchronize()
             fr_ms = (time.perf_counter() - t1) / args.steps * 1e3
+            fr_tflops = F0_FLOPS_PER_FRAME * frames_per_step / (fr_ms * 1e-3) / 1e12
             frame_rate = {'ms_per_step': round(fr_ms, 4), 'value': round(frames_per_step / (fr_ms * 1e-3), 1), 'unit': 'frames/s',
-                          'what': 'MORGANA_PHONE_RATE=0: every product on B*T frame rows (gather-fused layer-1 GEMM, fused dgrad+wgrad), '
-                                  'same graph replay'}
+                          'tflops': round(fr_tflops, 1), 'frac_of_mfma_peak': round(fr_tflops / MFMA_BF16_PEAK_TFLOPS, 4),
+                          'what': 'MORGANA_PHONE_RATE=0: the reference\'s order of operations - every product on the B*T frame rows '
+                                  '(gather-fused layer-1 GEMM, fused dgrad+wgrad), same graph replay; tflops = the algorithmic '
+                                  '%.1f GFLOP per step (SURVEY.md section 8d) over this time: an ACHIEVED rate, the matrix cores '
+                                  'execute every one of those products' % (F0_FLOPS_PER_FRAME * frames_per_step / 1e9)}
         except Exception as exc:
             frame_rate = {'error': str(exc).splitlines()[0][:200]}
         finally:
             ops.PHONE_RATE = True
 
     result = None
+    form_note = ''
+    phone_rate_step = False
+    if args.config == 'c2':
+        lab_shape = feats_np['normalised_lab'].shape
+        phone_rate_step = (args.precision == 'bf16' and ops.phone_rate_table_ok(lab_shape[0] * lab_shape[1], frames_per_step, 512, 128,
+                                                                                ops.ACT_SIGMOID))
+        if phone_rate_step:
+            form_note = ('; STEP AT PHONE RATE: the model has no frame-level input, so Linear / Sigmoid commute with '
+                         'upsample_to_repetitions and every layer runs on the %d phone rows (+ %d zero rows) instead of the %d frame '
+                         'rows - %.1fx fewer products than the reference\'s order of operations, same outputs (frame_rate_order '
+                         'times that order); bf16 phone table prepared by the loader'
+                         % (lab_shape[0] * lab_shape[1], ops.PHONE_RATE_EXTRA, frames_per_step,
+                            frames_per_step / float(lab_shape[0] * lab_shape[1] + ops.PHONE_RATE_EXTRA)))
+        else:
+            form_note = '; every product at frame rate (the reference\'s order of operations)'
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n_gpus * frames_per_step * args.steps / elapsed
@@ -437,8 +566,8 @@ def main():
             'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.precision, 'data': 'synthetic',
             'config': {'workload': '%s, %d utterances x %d frames per GPU, P=%d phones, synthetic lab/dur/%s, '
-                                   'Adam lr 0.01, fp32 master weights' % (name, per_gpu, args.frames,
-                                                                          feats_np['dur'].shape[1], target),
+                                   'Adam lr 0.01, fp32 master weights%s' % (name, per_gpu, args.frames,
+                                                                            feats_np['dur'].shape[1], target, form_note),
                        'global_batch': per_gpu * n_gpus, 'frames_per_utterance': args.frames,
                        'parallelism': 'dp%d' % n_gpus},
             'final_loss': round(final_loss, 6),
@@ -448,23 +577,25 @@ def main():
         if frame_rate is not None:
             result['frame_rate_order'] = frame_rate
         if args.config == 'c2':
-            step_tflops = F0_FLOPS_PER_FRAME * frames_per_step / (ms_per_step * 1e-3) / 1e12
             peak = MFMA_BF16_PEAK_TFLOPS if args.precision == 'bf16' else MFMA_F32_PEAK_TFLOPS
-            result['step_algorithmic_tflops'] = round(step_tflops, 2)
-            result['step_frac_of_mfma_peak'] = round(step_tflops / peak, 4)
-            # step_algorithmic_* prices the REFERENCE's algorithm (every product at frame rate).  With the
-            # phone-rate step the kernels multiply less: every layer runs on the B*P (+ pad) phone rows.
-            lab_shape = feats_np['normalised_lab'].shape
-            r_tab = lab_shape[0] * lab_shape[1] + ops.PHONE_RATE_EXTRA
-            if args.precision == 'bf16' and ops.phone_rate_table_ok(r_tab - ops.PHONE_RATE_EXTRA, frames_per_step, 512, 128,
-                                                                    ops.ACT_SIGMOID):
+            algorithmic = F0_FLOPS_PER_FRAME * frames_per_step
+            if phone_rate_step:
+                r_tab = lab_shape[0] * lab_shape[1] + ops.PHONE_RATE_EXTRA
                 fwd = lab_shape[2] * 512 + 512 * 128 + 128 * 32 + 32
                 executed = 2.0 * r_tab * (2 * fwd + (512 * 128 + 128 * 32 + 32))      # forward + wgrad of 4 layers, dgrad of layers 2-4
-                result['step_executed_tflops'] = round(executed / (ms_per_step * 1e-3) / 1e12, 2)
-                result['step_executed_frac_of_mfma_peak'] = round(executed / (ms_per_step * 1e-3) / 1e12 / peak, 4)
-                result['flops_note'] = ('step_algorithmic_tflops counts the reference algorithm (all products at frame rate); the '
-                                        'phone-rate step executes %.1f GFLOP per step instead of %.1f'
-                                        % (executed / 1e9, F0_FLOPS_PER_FRAME * frames_per_step / 1e9))
+            else:
+                executed = algorithmic
+            ex_tflops = executed / (ms_per_step * 1e-3) / 1e12
+            result['step_executed'] = {'gflop_per_step': round(executed / 1e9, 1), 'tflops': round(ex_tflops, 2),
+                                       'frac_of_mfma_peak': round(ex_tflops / peak, 4),
+                                       'what': 'what the matrix cores multiply in one step of the headline form'}
+            if phone_rate_step:
+                # NOT a fraction of peak: the reference algorithm's FLOPs over a step that performs 12x fewer of them
+                result['reference_equivalent'] = {'gflop_per_step': round(algorithmic / 1e9, 1),
+                                                  'tflops_equivalent': round(algorithmic / (ms_per_step * 1e-3) / 1e12, 1),
+                                                  'what': 'FLOPs of the reference\'s order of operations (SURVEY.md section 8d) divided by the '
+                                                          'phone-rate step time: an equivalence figure, not an achieved rate and not a '
+                                                          'fraction of any roof - the achieved frame-rate figure is frame_rate_order'}
     if rank == 0 and args.config == 'c2' and not args.no_roofline:
         result['roofline'] = roofline_f0(features, model, args.precision)
     if rank == 0 and args.config in ('c4', 'c5') and not args.no_roofline:
@@ -473,8 +604,17 @@ def main():
         roof = roofline_lstm(features, model, args.precision)
         if roof is not None:
             result['roofline'] = roof
+    if rank == 0 and n_gpus == 1 and args.config == 'c2' and args.precision == 'bf16' and not args.no_compare:
+        try:
+            result['c4'] = c4_leg(dev, args.precision)
+        except Exception as exc:
+            result['c4'] = {'error': str(exc).splitlines()[0][:200]}
+        try:
+            result['loss_curve_deviation'] = loss_curve_deviation(dev)
+        except Exception as exc:
+            result['loss_curve_deviation'] = {'error': str(exc).splitlines()[0][:200]}
     if rank == 0 and n_gpus == 1 and args.config == 'c2' and not args.no_cpu_baseline:
-        result['cpu_baseline'] = cpu_baseline_f0(args.frames)
+        result['cpu_baseline'] = cpu_baseline_f0(per_gpu, args.frames)
     distributed.barrier()
     if rank == 0:
         print(json.dumps(result))

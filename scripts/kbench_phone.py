@@ -36,7 +36,7 @@ def main():
     b1 = torch.zeros(n1, device=dev)
     cases = [('wgrad1 (dZ1^T table, 512x600)', 2.0 * r_tab * k * n1, lambda: ops.linear_wgrad_bf16(dz1, tab, None, r_tab, n1, k)),
              ('wgrad2 (dZ2^T H1, 128x512)', 2.0 * r_tab * n1 * n2, lambda: ops.linear_wgrad_bf16(dz2, h1, None, r_tab, n2, n1))]
-    variants = [(0, 0), (0, 1), (0, 2), (24, 2), (32, 2), (40, 2), (48, 2), (64, 2), (32, 1), (64, 1), (96, 2), (128, 2)]
+    variants = [(0, 0)]
     rounds = 3
     for skip in (1, 0):
         lib.mg_set_tuning(1, skip)
@@ -56,6 +56,20 @@ def main():
     lib.mg_set_tuning(5, 0)
     l1 = lambda: ops.linear_fwd_bf16(tab, None, r_tab, k, w1b, b1, n1, ops.ACT_SIGMOID)
     print('fwd1 phone rate: %.1f us' % timed(l1, iters))
+    w2t = (torch.randn(n1, n2, device=dev) * 0.05).to(torch.bfloat16)
+    ident = torch.arange(r_tab, device=dev, dtype=torch.int32)
+    dg = lambda: ops.linear_dgrad_bf16(dz2, r_tab, n2, w2t, n1, h1)
+    wg = lambda: ops.linear_wgrad_bf16(dz1, tab, None, r_tab, n1, k)
+    fz = lambda: ops.linear_bwd_fused_bf16(dz2, w2t, h1, tab, ident, r_tab, n1, k)
+    fz0 = lambda: ops.linear_bwd_fused_bf16(dz2, w2t, h1, tab, None, r_tab, n1, k)
+    for name, fn in (('dgrad2', dg), ('wgrad1 + reduce', wg), ('fused bwd (identity rows, pipelined) + reduce', fz), ('fused bwd (no rows, single buffered) + reduce', fz0)):
+        ts = sorted(timed(fn, iters) for _ in range(3))
+        print('%-50s median %7.1f us' % (name, ts[1]))
+    lib.mg_set_tuning(1, 1)
+    for name, fn in (('wgrad1 alone', wg), ('fused bwd (identity rows) alone', fz), ('fused bwd (no rows) alone', fz0)):
+        ts = sorted(timed(fn, iters) for _ in range(3))
+        print('%-50s median %7.1f us' % (name, ts[1]))
+    lib.mg_set_tuning(1, 0)
 
 
 if __name__ == '__main__':

@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""In-kernel stamps (diagnostic library, `make -C morgana_amd/csrc diag`) of the phone-rate step's GEMM kernels: M = 21 504 table rows,
+one tile (or one split) per workgroup.  Usage: MORGANA_HIP_LIB=morgana_amd/libmorgana_hip_diag.so python scripts/stamps_phone.py"""
+import os
+import sys
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, 'scripts'))
+sys.path.insert(0, REPO)
+os.environ.setdefault('MORGANA_HIP_LIB', os.path.join(REPO, 'morgana_amd', 'libmorgana_hip_diag.so'))
+from stamps import read, report  # noqa: E402
+from morgana_amd import _lib, ops  # noqa: E402
+
+
+def main():
+    dev = 'cuda:0'
+    lib = _lib.load()
+    r_tab, k, n1, n2 = 21504, 600, 512, 128
+    tab = torch.rand(r_tab, 640, device=dev).to(torch.bfloat16)
+    tab[:, 600:] = 0
+    w1b = (torch.randn(n1, 640, device=dev) * 0.05).to(torch.bfloat16)
+    w2b = (torch.randn(n2, n1, device=dev) * 0.05).to(torch.bfloat16)
+    b1, b2 = torch.zeros(n1, device=dev), torch.zeros(n2, device=dev)
+    dz1 = (torch.randn(r_tab, n1, device=dev) * 0.01).to(torch.bfloat16)
+    dz2 = (torch.randn(r_tab, n2, device=dev) * 0.01).to(torch.bfloat16)
+    h1 = None
+    for _ in range(3):
+        h1 = ops.linear_fwd_bf16(tab, None, r_tab, k, w1b, b1, n1, ops.ACT_SIGMOID)
+    torch.cuda.synchronize()
+    s = read(lib, 'mg_diag_read_stamps_ntp', 168)
+    report('gemm_nt_persist<256> layer-1 forward at phone rate (168 workgroups, one 256 x 256 x 640 tile each)', s,
+           [('  vmcnt wait + barrier', s[..., 6]), ('  epilogues', s[..., 7])])
+    for _ in range(3):
+        ops.linear_fwd_bf16(h1, None, r_tab, n1, w2b, b2, n2, ops.ACT_SIGMOID)
+    torch.cuda.synchronize()
+    s = read(lib, 'mg_diag_read_stamps_ntp', 84)
+    report('gemm_nt_persist<128> layer-2 forward at phone rate (84 workgroups)', s,
+           [('  vmcnt wait + barrier', s[..., 6]), ('  epilogues', s[..., 7])])
+    for _ in range(3):
+        ops.linear_wgrad_bf16(dz1, tab, None, r_tab, n1, k)
+    torch.cuda.synchronize()
+    s = read(lib, 'mg_diag_read_stamps_wg', 192)
+    report('wgrad_big<10> layer-1 weight gradient at phone rate (48 splits x 4 n tiles, 14 steps each)', s,
+           [('  loop: vmcnt wait + barrier', s[..., 6]), ('  loop: LDS-DMA issue', s[..., 7])])
+    for _ in range(3):
+        ops.linear_wgrad_bf16(dz2, h1, None, r_tab, n2, n1)
+    torch.cuda.synchronize()
+    s = read(lib, 'mg_diag_read_stamps_wg', 96)
+    report('wgrad_big<8> layer-2 weight gradient at phone rate (96 splits, 7 steps each)', s,
+           [('  loop: vmcnt wait + barrier', s[..., 6]), ('  loop: LDS-DMA issue', s[..., 7])])
+
+
+if __name__ == '__main__':
+    main()
