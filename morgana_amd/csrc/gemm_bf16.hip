@@ -364,6 +364,7 @@ static WgradPlanB wgrad_plan_b(int64_t M, int N, int K) {
     if (S > max_s) S = max_s;
     if (S < 1) S = 1;
     if (S > 65535) S = 65535;
+    if (g_mg_tuning[MG_TUNE_WGRAD_ORDER] == 3 && g_mg_tuning[MG_TUNE_WGRAD_SPLITS] > 0) S = g_mg_tuning[MG_TUNE_WGRAD_SPLITS];   // experiment
     p.m_chunk = mg_align_up((size_t)mg_ceil_div(M, S), 32);
     p.S = (int)mg_ceil_div(M, p.m_chunk);
     if (p.S < 1) p.S = 1;
@@ -483,7 +484,7 @@ int mg_linear_wgrad_bf16(const uint16_t* dY, int lddy, const uint16_t* A, int ld
     float* slab = (float*)workspace;
     hipStream_t st = (hipStream_t)stream;
     int big_s = 0, big_chunk = 0;
-    const bool big = mg_wgrad_big_plan(M, N, K, lda, lddy, &big_s, &big_chunk) > 0;
+    const bool big = g_mg_tuning[MG_TUNE_WGRAD_ORDER] != 3 && mg_wgrad_big_plan(M, N, K, lda, lddy, &big_s, &big_chunk) > 0;
     if (big) p.S = big_s;
     const int64_t nk = (int64_t)N * K;
     if (big) {

@@ -17,6 +17,8 @@
 // 128 x 128 x 3 per CU, 3 instead of 4 stages, two 64-deep stages, XCD-grouped wgrad block order, non-temporal streams.
 #include "common.h"
 
+#include <type_traits>
+
 typedef __bf16 bfv8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bfv4 __attribute__((ext_vector_type(4)));
 
@@ -352,13 +354,25 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __rest
 // VGPR-destination load.  The epilogue's row patch is the stage consumed last (BN = 256: exactly 32 KB) or a region of its
 // own (BN = 128).
 // ---------------------------------------------------------------------------------------------------------------------
-#define NTP_MAX_TILES 8
+#define NTP_MAX_TILES(BN_) ((BN_) == 256 ? 8 : 7)  // tiles a workgroup parks row indices for (1 KB each); the 128-wide form is at the 160 KB LDS limit
 __device__ uint16_t g_ntp_sink[64 * 8];            // where the stores of rows past M go: every wave issues exactly NST stores
 MG_STAMP_DECL(g_stamps_ntp);
 
-#define NTP_WAIT_CASE(N) case N: WAIT_VM_BARRIER(N); break;
+#define WAIT_VM_LGKM_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define NTP_WAIT_CASE(N) case N: WAIT_VM_LGKM_BARRIER(N); break;
 
-template <int BN, int EPI>
+// BK: contraction depth of one LDS stage.  32 (64-byte LDS rows, 4 stages of 32 KB) for the square tile, whose operands sit in L2;
+// 64 (128-byte rows, 3 stages of 48 KB) for the 128-wide tile, whose A operand streams from HBM: a DMA instruction then fetches whole
+// 128-byte lines (8 rows x 128 B instead of 16 rows x 64 B) - with half lines the layer-2 forward read its 262 MB of H1 at 4.5 TB/s,
+// with whole lines (timing probe on this kernel) 20 % faster.  The square tile gains nothing from it (same probe: 180 -> 177 us).
+// STAG (cdna_hip_programming.md section 5, the 8-phase template's wave-group stagger): waves 4-7 run half a k-step behind waves 0-3.
+// A k-step is two intervals separated by barriers: the leading group reads its fragments from LDS (and issues its share of the
+// LDS-DMA) in the first and multiplies in the second; the lagging group multiplies the PREVIOUS step's fragments in the first and reads
+// in the second, so that on every SIMD one wave feeds the matrix pipe while the other one occupies LDS.  MEASURED SLOWER than both
+// groups in lockstep on this kernel (layer-1 forward 203 vs 180 us, stamps: an interval takes ~1 000 cycles, not the 512 of its 16
+// MFMAs - the reading group's 4 LDS-DMA pieces + 12 ds_read_b128 take that long to issue, MI355X_MICROARCH.md "LDS-DMA piece issue
+// cost"), so it is kept as an experiment only (MG_TUNE_STAGGER = 4).  The groups fall back into step at every tile end.
+template <int BN, int EPI, bool STAG, int BK>
 __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
                                                               int64_t M, int K, const uint16_t* __restrict__ Bm, int ldb, int N,
                                                               const float* __restrict__ bias, uint16_t* __restrict__ C, int ldc,
@@ -368,17 +382,25 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
     constexpr int WAVES_M = 8 / WAVES_N;          // 2 or 4
     constexpr int WM = BM / WAVES_M;              // 128 or 64
     constexpr int TM = WM / 32, TN = 2;
-    constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
-    constexpr int STAGE = A_BYTES + B_BYTES;      // 32 KB or 24 KB
-    constexpr int GA = BM / 16 / 8;               // 1 KB pieces (16 rows) per wave for A: 2
-    constexpr int GB = BN / 16 / 8;               // for B: 2 or 1
-    constexpr int NL = GA + GB;                   // LDS-DMA instructions per wave per stage: 4 or 3
-    constexpr int NS = (BN == 256) ? 4 : 5;
+    constexpr int ROWB = BK * 2;                  // bytes of a stage row: 64 or 128
+    constexpr int KS = BK / 16;                   // 16-deep MFMA steps per stage: 2 or 4
+    constexpr int LPR = ROWB / 16;                // lanes (16-byte chunks) per row: 4 or 8
+    constexpr int RPP = 64 / LPR;                 // rows per 1 KB DMA piece: 16 or 8
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+    constexpr int STAGE = A_BYTES + B_BYTES;      // 32 KB (BN 256, BK 32), 24 KB (BN 128, BK 32) or 48 KB (BN 128, BK 64)
+    constexpr int GA = BM / RPP / 8;              // 1 KB pieces per wave for A: 2 or 4
+    constexpr int GB = BN / RPP / 8;              // for B: 2, 1 or 2
+    constexpr int NL = GA + GB;                   // LDS-DMA instructions per wave per stage: 4, 3 or 6
+    constexpr int NS = (BK == 64) ? 3 : ((BN == 256) ? 4 : 5);
     constexpr int NST = TM * 4;                   // epilogue stores per wave per tile: 16 or 8
-    constexpr int ROWTAB = NS * STAGE;            // int32[NTP_MAX_TILES][256]
-    constexpr int PATCH = ROWTAB + NTP_MAX_TILES * BM * 4;
+    constexpr int ROWTAB = NS * STAGE;            // int32[MAXT][256]
+    constexpr int MAXT = NTP_MAX_TILES(BN);
+    constexpr int PATCH = ROWTAB + MAXT * BM * 4;
     constexpr int SP = 128;                       // patch row: 64 columns x 2 B, 16-byte chunk c of row r at c ^ (r & 7)
-    constexpr int LDS_BYTES = PATCH + (BN == 256 ? 0 : 8 * 32 * SP);
+    constexpr bool kPatchInRing = STAGE >= 8 * 32 * SP;     // the epilogue's row patch fits the ring slot consumed last
+    constexpr int BIAS_OFF = PATCH + (kPatchInRing ? 0 : 8 * 32 * SP);
+    constexpr int LDS_BYTES = BIAS_OFF + BN * 4;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     int* rowtab = reinterpret_cast<int*>(smem + ROWTAB);
@@ -391,7 +413,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
     MG_STAMP_REAL(tr0);
 #endif
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * 64;
-    const int n_kt = (K + 31) / 32;
+    const int n_kt = (K + BK - 1) / BK;           // stages that hold real columns (lda, ldb >= 64 * ceil(K / 64))
 
     // Virtual block v = blockIdx.x + i gridDim.x (gridDim.x a multiple of 8) keeps the XCD-aware order of gemm_nt_big: the N
     // tiles of one M tile go to blocks 8 apart, which share an XCD and its L2.
@@ -402,7 +424,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
         tile_m = (jj / tiles_n) * 8 + xcd;
     };
     int n_my = 0;                                 // the launcher makes (gridDim.x / 8) a multiple of tiles_n: one N tile per workgroup
-    for (int i = 0; i < NTP_MAX_TILES; ++i) {
+    for (int i = 0; i < MAXT; ++i) {
         int tm, tn;
         tile_of(i, tm, tn);
         if (tm < tiles_m) n_my = i + 1;
@@ -419,6 +441,9 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
     __syncthreads();
     if (n_my == 0) return;
 
+    // chunk swizzle of a stage row (the same involution on the DMA source and on the fragment reads): conflict free for the four 16-lane
+    // groups of ds_read_b128 - 64-byte rows: chunk ^ ((row >> 2) & 3); 128-byte rows: chunk ^ ((row >> 1) & 7)
+    auto swz = [](int row) { return BK == 32 ? ((row >> 2) & 3) : ((row >> 1) & 7); };
     // issue cursor: tile i_t, k-tile i_k, ring slot i_s, per-lane sources of that tile
     const uint16_t* asrc[GA];
     const uint16_t* bsrc[GB];
@@ -427,15 +452,15 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
         tile_of(i, tm, tn);
 #pragma unroll
         for (int g = 0; g < GA; ++g) {
-            const int row = (wave * GA + g) * 16 + (lane >> 2);
-            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            const int row = (wave * GA + g) * RPP + lane / LPR;
+            const int c = (lane % LPR) ^ swz(row);
             const int r = rowtab[i * BM + row];
             asrc[g] = (r >= 0 ? A + (size_t)r * lda : g_zero_row) + c * 8;
         }
 #pragma unroll
         for (int g = 0; g < GB; ++g) {
-            const int row = (wave * GB + g) * 16 + (lane >> 2);
-            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            const int row = (wave * GB + g) * RPP + lane / LPR;
+            const int c = (lane % LPR) ^ swz(row);
             const int n = tn * BN + row;
             bsrc[g] = (n < N ? Bm + (size_t)n * ldb : g_zero_row) + c * 8;
         }
@@ -446,9 +471,9 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
         if (i_t >= n_my) return;
         unsigned char* st = smem + i_s * STAGE;
 #pragma unroll
-        for (int g = 0; g < GA; ++g) glds16(asrc[g] + i_k * 32, st + (wave * GA + g) * 1024);
+        for (int g = 0; g < GA; ++g) glds16(asrc[g] + i_k * BK, st + (wave * GA + g) * 1024);
 #pragma unroll
-        for (int g = 0; g < GB; ++g) glds16(bsrc[g] + i_k * 32, st + A_BYTES + (wave * GB + g) * 1024);
+        for (int g = 0; g < GB; ++g) glds16(bsrc[g] + i_k * BK, st + A_BYTES + (wave * GB + g) * 1024);
         i_s = (i_s + 1 == NS) ? 0 : i_s + 1;
         if (++i_k == n_kt) {
             i_k = 0;
@@ -457,46 +482,70 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
     };
 
     const int lr = lane & 31, lh = lane >> 5;
-    int aoff[TM], boff[TN];
+    // byte offset of this lane's fragment of MFMA step ks inside a stage: row base + ((2 ks + lh) ^ swz(row)) * 16
+    int abase[TM], bbase[TN], asw[TM], bsw[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int row = wm0 + i * 32 + lr;
-        aoff[i] = row * 64 + ((lh ^ ((row >> 2) & 3)) << 4);
+        abase[i] = row * ROWB;
+        asw[i] = lh ^ swz(row);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int row = wn0 + j * 32 + lr;
-        boff[j] = A_BYTES + row * 64 + ((lh ^ ((row >> 2) & 3)) << 4);
+        bbase[j] = A_BYTES + row * ROWB;
+        bsw[j] = lh ^ swz(row);
     }
 
-    // Bias in accumulator order (register 4 q + e <-> column 32 j + 8 q + 4 lh + e).  Loaded before the loop and re-defined
-    // behind an explicit wait: a VGPR-destination load inside the tile loop makes hipcc drain vmcnt - the whole prefetched ring
-    // and the stores - in front of its first use.
-    float bv[TN][16];
-    auto load_bias = [&](int n0) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bv[j][4 * q + e] = bias ? bias[n0 + wn0 + j * 32 + 8 * q + 4 * lh + e] : 0.f;
-    };
+    // The workgroup's bias slice (one N tile per workgroup) is parked in LDS next to the row table and read back in accumulator order
+    // (register 4 q + e <-> column 32 j + 8 q + 4 lh + e) by each epilogue: held in 32 registers for the whole kernel, as it first was,
+    // it pushed the staggered loop (fragments live across the barrier) over the 256-VGPR limit.  A VGPR-destination global load inside
+    // the tile loop is not an option either: hipcc drains vmcnt - the whole prefetched ring and the stores - in front of its first use.
+    float* bias_lds = reinterpret_cast<float*>(smem + BIAS_OFF);
     {
         int tm, tn;
         tile_of(0, tm, tn);
-        load_bias(tn * BN);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bv[j][r]));
+        for (int c = tid; c < BN; c += 512) bias_lds[c] = (bias && tn * BN + c < N) ? bias[tn * BN + c] : 0.f;
+        __syncthreads();                          // plain barrier: no LDS-DMA is in flight yet
     }
 
 #pragma unroll
     for (int p = 0; p < NS - 1; ++p) issue_next();
 
+    // All fragment reads of a stage first, then its MFMAs (pinned with sched_group_barrier): left alone hipcc reads two to four
+    // fragments at a time with an lgkmcnt(0) in front of every MFMA group - six exposed LDS round trips per stage.
+    const bool lag = STAG && wave >= 4;           // wave-uniform
+    bfv8 fa[KS][TM], fb[KS][TN];
+    auto read_frags = [&](const unsigned char* st) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const bfv8*>(st + abase[i] + ((asw[i] ^ (2 * ks)) << 4));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[ks][j] = *reinterpret_cast<const bfv8*>(st + bbase[j] + ((bsw[j] ^ (2 * ks)) << 4));
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, KS * (TM + TN), 0);
+    };
+    auto mfma_all = [&](f32x16 (&acc)[TM][TN]) {
+        if (STAG) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, KS * TM * TN, 0);
+        if (STAG) __builtin_amdgcn_s_setprio(0);
+    };
+
     const int g_total = n_my * n_kt;
     int g = 0, c_s = 0;                           // global stage counter, its ring slot
+    // The tile loop exists twice, once per wave group (LAG = the group that runs half a k-step behind), selected once by a wave-uniform
+    // branch: with the group tested inside one loop body the register allocator has to reconcile the two schedules at every merge
+    // point and spills (425-569 VGPRs of scratch measured); as two independent loops each stays within 256.
+    auto run_tiles = [&](auto lag_c) {
+    constexpr bool LAG = decltype(lag_c)::value;
     for (int ti = 0; ti < n_my; ++ti) {
         int tile_m, tile_n;
         tile_of(ti, tile_m, tile_n);
@@ -513,52 +562,64 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
         for (int kt = 0; kt < n_kt; ++kt, ++g) {
             MG_STAMP(ta);
             // stages issued so far: min(g_total, g + NS - 1); stage g must have landed; younger than it are
-            // min(g_total - 1 - g, NS - 2) stages and, for the first NS - 1 k-steps behind a tile boundary, the NST stores
+            // min(g_total - 1 - g, NS - 2) stages and, for the first NS - 1 k-steps behind a tile boundary, the NST stores.
+            // The wait also retires this wave's LDS reads (lgkmcnt): the lagging group comes here straight from its fragment reads,
+            // and the slot they came from is refilled right behind this barrier.
             {
                 const int allow = min(g_total - 1 - g, NS - 2) * NL + ((ti > 0 && kt < NS - 1) ? NST : 0);
+                __builtin_amdgcn_sched_barrier(0);
                 switch (allow) {
                     NTP_WAIT_CASE(0) NTP_WAIT_CASE(3) NTP_WAIT_CASE(4) NTP_WAIT_CASE(6) NTP_WAIT_CASE(8) NTP_WAIT_CASE(9)
                     NTP_WAIT_CASE(11) NTP_WAIT_CASE(12) NTP_WAIT_CASE(14) NTP_WAIT_CASE(16) NTP_WAIT_CASE(17) NTP_WAIT_CASE(20)
                     NTP_WAIT_CASE(24)
-                    default: WAIT_VM_BARRIER(0); break;
+                    default: WAIT_VM_LGKM_BARRIER(0); break;
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             MG_STAMP(tb);
             MG_STAMP_ADD(sum_wait, tb, ta);
 #ifdef MG_STAMPS
             if (g == 0) ts1 = tb;
 #endif
-            issue_next();                         // refills the slot every wave finished with before this barrier
             const unsigned char* st = smem + c_s * STAGE;
-            // All fragment reads of the stage first, then the MFMAs (pinned with sched_group_barrier): left alone hipcc reads
-            // two to four fragments at a time with an lgkmcnt(0) in front of every MFMA group - six exposed LDS round trips per
-            // stage with both waves of a SIMD waiting in step.
-            bfv8 a[2][TM], b[2][TN];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[ks][i] = *reinterpret_cast<const bfv8*>(st + (aoff[i] ^ (ks << 5)));
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[ks][j] = *reinterpret_cast<const bfv8*>(st + (boff[j] ^ (ks << 5)));
+            if (!STAG) {
+                issue_next();                     // refills the slot every wave finished with before this barrier
+                read_frags(st);
+                mfma_all(acc);
+            } else {
+                if (!LAG) {
+                    issue_next();
+                    read_frags(st);
+                } else if (kt > 0) {
+                    mfma_all(acc);                // the previous step's fragments
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if (!LAG) {
+                    mfma_all(acc);
+                } else {
+                    issue_next();
+                    read_frags(st);
+                }
             }
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ks][j], a[ks][i], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);
             if (kt + 1 < n_kt) c_s = (c_s + 1 == NS) ? 0 : c_s + 1;
         }
 
         // ---- epilogue: bias (+ sigmoid), bf16, whole 128-byte row segments through the LDS patch ---------------------------
         MG_STAMP(ta);
-        WAIT_LGKM_BARRIER();                      // every wave is done with the last stage
-        unsigned char* patch = (BN == 256 ? smem + c_s * STAGE : smem + PATCH) + wave * (32 * SP);
+        __builtin_amdgcn_sched_barrier(0);
+        WAIT_LGKM_BARRIER();                      // every wave is done with the last stage (the lagging group has just read it)
+        __builtin_amdgcn_sched_barrier(0);
+        if (STAG && LAG) mfma_all(acc);           // its last multiply runs while the leading group starts the epilogue
+        unsigned char* patch = (kPatchInRing ? smem + c_s * STAGE : smem + PATCH) + wave * (32 * SP);
         c_s = (c_s + 1 == NS) ? 0 : c_s + 1;
         const int prow = lane >> 3, pchunk = lane & 7;
+        f32x4 bv[TN][4];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[j][q] = *reinterpret_cast<const f32x4*>(bias_lds + wn0 + j * 32 + 8 * q + 4 * lh);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -568,7 +629,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float x = acc[i][j][4 * q + e] + bv[j][4 * q + e];
+                        float x = acc[i][j][4 * q + e] + bv[j][q][e];
                         if (EPI == EPI_BIAS_SIGMOID) x = mg_sigmoid_fast(x);
                         v[e] = x;
                     }
@@ -592,6 +653,8 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
         MG_STAMP(tb);
         MG_STAMP_ADD(sum_epi, tb, ta);
     }
+    };
+    if (lag) run_tiles(std::true_type{}); else run_tiles(std::false_type{});
 #ifdef MG_STAMPS
     MG_STAMP(ts2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -870,14 +933,19 @@ int mg_try_nt_big(const uint16_t* A, int lda, const int32_t* rows, int64_t M, in
     const int n_kt = (K + 31) / 32;
     if (!c_f32 && epi != EPI_SIGMOID_GRAD && n_kt >= 5 && M < 2147483647LL && 32 % tiles_n == 0 && g_mg_tuning[MG_TUNE_STAGGER] != 6) {
         int64_t g = 256;                                             // one resident workgroup per CU
-        while (mg_ceil_div(blocks, g) > NTP_MAX_TILES) g += 256;    // more tiles than a workgroup parks rows for: more groups
+        while (mg_ceil_div(blocks, g) > NTP_MAX_TILES(bn)) g += 256;    // more tiles than a workgroup parks rows for: more groups
         if (g > blocks) g = mg_ceil_div(blocks, 8 * tiles_n) * 8 * tiles_n;
         dim3 pgrid((unsigned)g), pblock(512);
-#define LAUNCH_NTP(BN_, EPI_) hipLaunchKernelGGL((gemm_nt_persist_kernel<BN_, EPI_>), pgrid, pblock, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, (uint16_t*)C, ldc, (int)tiles_m, tiles_n)
+#define LAUNCH_NTP(BN_, EPI_, STAG_, BK_) hipLaunchKernelGGL((gemm_nt_persist_kernel<BN_, EPI_, STAG_, BK_>), pgrid, pblock, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, (uint16_t*)C, ldc, (int)tiles_m, tiles_n)
+        const bool stag = g_mg_tuning[MG_TUNE_STAGGER] == 4;     // experiment: the two wave groups half a k-step apart (measured slower)
+        const bool deep = g_mg_tuning[MG_TUNE_STAGGER] != 3;     // 128-wide tile: 64-deep stages (whole 128-byte lines per DMA row); 3 = 32-deep
         if (wide) {
-            if (epi == EPI_BIAS) LAUNCH_NTP(256, EPI_BIAS); else LAUNCH_NTP(256, EPI_BIAS_SIGMOID);
+            if (stag) { if (epi == EPI_BIAS) LAUNCH_NTP(256, EPI_BIAS, true, 32); else LAUNCH_NTP(256, EPI_BIAS_SIGMOID, true, 32); }
+            else { if (epi == EPI_BIAS) LAUNCH_NTP(256, EPI_BIAS, false, 32); else LAUNCH_NTP(256, EPI_BIAS_SIGMOID, false, 32); }
+        } else if (deep) {
+            if (epi == EPI_BIAS) LAUNCH_NTP(128, EPI_BIAS, false, 64); else LAUNCH_NTP(128, EPI_BIAS_SIGMOID, false, 64);
         } else {
-            if (epi == EPI_BIAS) LAUNCH_NTP(128, EPI_BIAS); else LAUNCH_NTP(128, EPI_BIAS_SIGMOID);
+            if (epi == EPI_BIAS) LAUNCH_NTP(128, EPI_BIAS, false, 32); else LAUNCH_NTP(128, EPI_BIAS_SIGMOID, false, 32);
         }
 #undef LAUNCH_NTP
         return 1;

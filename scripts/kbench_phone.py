@@ -36,7 +36,7 @@ def main():
     b1 = torch.zeros(n1, device=dev)
     cases = [('wgrad1 (dZ1^T table, 512x600)', 2.0 * r_tab * k * n1, lambda: ops.linear_wgrad_bf16(dz1, tab, None, r_tab, n1, k)),
              ('wgrad2 (dZ2^T H1, 128x512)', 2.0 * r_tab * n1 * n2, lambda: ops.linear_wgrad_bf16(dz2, h1, None, r_tab, n2, n1))]
-    variants = [(0, 0)]
+    variants = [(0, 0), (8, 3), (12, 3), (16, 3), (24, 3), (32, 3), (42, 3)]
     rounds = 3
     for skip in (1, 0):
         lib.mg_set_tuning(1, skip)
