@@ -108,11 +108,77 @@ class ExperimentBuilder(object):
         ops.check_persistent_status()                                            # persistent recurrent kernels: any time-out?
         return float(loss.item()) / (i + 1)                                      # :505 (one sync per epoch)
 
-    def run_train(self, train_loader):
-        """Epoch loop of experiment_builder.py:507-560 (training part)."""
+    def _eval_model(self, model):
+        """The model an evaluation pass runs: the one given, else the EMA twin when EMA is on, else the trained one (:629-632)."""
+        if model is not None:
+            return model
+        return self.ema_model if self.ema_decay else self.model
+
+    @torch.no_grad()
+    def valid_epoch(self, data_loader, model=None, gen_output=False, out_dir=None):
+        """One evaluation pass: ``model(features)`` without backward / step, the batch loss into ``metrics`` under 'valid', the
+        ``analysis_for_valid_*`` hooks when output is requested, ``metrics.json``; returns the mean loss (experiment_builder.py:562-620).
+        As in ``train_epoch`` the loss stays on the device and is read once per epoch (the reference reads it every batch, :596)."""
+        model = self._eval_model(model)
+        model.mode = 'valid'
+        model.metrics.reset_state('valid')
+        if out_dir:
+            os.makedirs(out_dir, exist_ok=True)
+        loss, n_batches, i = None, len(data_loader), -1
+        for i, features in enumerate(data_loader):
+            self.model.step = (self.epoch - 1) * n_batches + i + 1
+            batch_loss, output_features = model(features)
+            batch_loss = batch_loss.detach()
+            loss = batch_loss if loss is None else loss + batch_loss
+            model.metrics.accumulate(model.mode, loss=batch_loss)
+            if gen_output:
+                model.analysis_for_valid_batch(features, output_features, out_dir=out_dir, **self.analysis_kwargs)
+        if gen_output:
+            model.analysis_for_valid_epoch(out_dir=out_dir, **self.analysis_kwargs)
+        if out_dir:
+            with open(os.path.join(out_dir, 'metrics.json'), 'w') as f:
+                json.dump(model.metrics.results_as_json_dict('valid'), f)
+        model.mode = ''
+        ops.check_persistent_status()
+        return float(loss.item()) / (i + 1)
+
+    @torch.no_grad()
+    def test_epoch(self, data_loader, model=None, out_dir=None):
+        """Generation pass: ``model.predict(features)`` and the ``analysis_for_test_*`` hooks, no loss (experiment_builder.py:639-680)."""
+        model = self._eval_model(model)
+        if out_dir:
+            os.makedirs(out_dir, exist_ok=True)
+        model.mode = 'test'
+        model.metrics.reset_state('test')
+        n_batches = len(data_loader)
+        for i, features in enumerate(data_loader):
+            self.model.step = (self.epoch - 1) * n_batches + i + 1
+            output_features = model.predict(features)
+            model.analysis_for_test_batch(features, output_features, out_dir=out_dir, **self.analysis_kwargs)
+        model.analysis_for_test_epoch(out_dir=out_dir, **self.analysis_kwargs)
+        if out_dir:
+            with open(os.path.join(out_dir, 'metrics.json'), 'w') as f:
+                json.dump(model.metrics.results_as_json_dict('test'), f)
+        model.mode = ''
+        ops.check_persistent_status()
+
+    def run_valid(self, valid_loader, gen_output=False):
+        """experiment_builder.py:622-637."""
+        out_dir = os.path.join(self.experiment_dir, 'valid', 'epoch_{}'.format(self.epoch)) if self.experiment_dir else None
+        return self.valid_epoch(valid_loader, gen_output=gen_output, out_dir=out_dir)
+
+    def run_test(self, test_loader):
+        """experiment_builder.py:682-693."""
+        out_dir = os.path.join(self.experiment_dir, 'test', 'epoch_{}'.format(self.epoch)) if self.experiment_dir else None
+        self.test_epoch(test_loader, out_dir=out_dir)
+
+    def run_train(self, train_loader, valid_loader=None, test_loader=None):
+        """Epoch loop of experiment_builder.py:507-560: train, checkpoint, optional evaluation and generation passes, epoch-level
+        LR schedule ('plateau' steps on the validation loss, :549-551).  Returns the per-epoch training losses."""
         optimizer = self.make_optimizer()
         lr_schedule = self._lr_schedule(optimizer)
         history = []
+        self.valid_history = []
         for self.epoch in range(self.start_epoch, self.end_epoch + 1):
             out_dir = os.path.join(self.experiment_dir, 'train', 'epoch_{}'.format(self.epoch)) \
                 if self.experiment_dir else None
@@ -121,6 +187,13 @@ class ExperimentBuilder(object):
                 self.model.save_parameters(self.experiment_dir, self.epoch)      # :532-542
                 if self.ema_decay:
                     self.ema_model.save_parameters(self.experiment_dir, '{}_ema'.format(self.epoch))
+            if valid_loader is not None:
+                valid_loss = self.run_valid(valid_loader)                        # :545-551
+                self.valid_history.append(valid_loss)
+                if self.lr_schedule_name == 'plateau':
+                    lr_schedule.step(valid_loss)
+            if test_loader is not None:
+                self.run_test(test_loader)                                       # :554-556
             if self.lr_schedule_name in lr_schedules.EPOCH_LR_SCHEDULES:
                 lr_schedule.step()                                               # :559-560
         return history

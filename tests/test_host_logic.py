@@ -151,6 +151,32 @@ def test_train_epoch_semantics(tmp_path):
     assert opt.param_groups[0]['lr'] == pytest.approx(ref_opt.param_groups[0]['lr'])
 
 
+def test_valid_and_test_epochs(tmp_path):
+    """Evaluation passes of experiment_builder.py:562-680: no parameter moves, mean loss and metrics.json as the reference keeps them,
+    the EMA twin is the one evaluated when EMA is on, test_epoch calls predict and the analysis hooks only."""
+    batches = [ref_torch.to_torch(synthetic.make_batch(4, 40, lab_dim=24, frames_per_phone=5.0, seed=s)) for s in (4, 5)]
+    eb = experiment_builder.ExperimentBuilder(helpers.CpuF0Model, model_kwargs={'dims': (24, 16, 8, 1)}, device='cpu',
+                                              experiment_dir=str(tmp_path), end_epoch=1, ema_decay=0.9)
+    helpers.init_small(eb.model, seed=6)
+    helpers.init_small(eb.ema_model, seed=7)                       # a different twin: shows which model is evaluated
+    before = [p.detach().clone() for p in eb.model.parameters()]
+    want = []
+    with torch.no_grad():
+        for feats in batches:
+            want.append(eb.ema_model(feats)[0].item())
+    got = eb.run_valid(batches)
+    assert got == pytest.approx(np.mean(want), rel=1e-6)
+    saved = json.load(open(os.path.join(str(tmp_path), 'valid', 'epoch_1', 'metrics.json')))
+    assert saved['loss'] == pytest.approx(ref_cpu.metric_mean(want), rel=1e-5)
+    assert eb.ema_model.mode == '' and all(torch.equal(a, b) for a, b in zip(before, eb.model.parameters()))
+    assert eb.valid_epoch(batches, model=eb.model) != pytest.approx(got)          # an explicit model overrides the twin
+
+    seen = []
+    eb.ema_model.analysis_for_test_batch = lambda features, output_features, out_dir, **kw: seen.append(sorted(output_features))
+    eb.run_test(batches)
+    assert seen == [['pred_norm_lf0']] * 2 and os.path.exists(os.path.join(str(tmp_path), 'test', 'epoch_1', 'metrics.json'))
+
+
 def test_checkpoint_round_trip(tmp_path):
     model = helpers.init_small(helpers.CpuF0Model(dims=(24, 16, 8, 1)), seed=8)
     path = model.save_parameters(str(tmp_path), 3)
