@@ -421,6 +421,19 @@ int mg_gru_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const f
                             float* dhproj, uint16_t* dhproj_bf, uint16_t* dxproj_bf, float* dh0, void* workspace,
                             size_t workspace_bytes, void* stream);
 
+/* fp32 parity mode of the LSTM recurrence as ONE launch per direction for 256 <= H <= 512, H % 64 == 0, B <= 128 (csrc/lstm_persist_f32.hip):
+ * W_hh resident in registers, fp32 hand-off tiles, the exact-fp32 MFMA in the per-step kernels' block order and the same cell code -
+ * results bit-identical to mg_lstm_fwd_f32 / mg_lstm_bwd_f32 on the live steps (gate values of steps beyond an item group's longest
+ * sequence are written as zeros).  Arguments as mg_lstm_fwd_f32 / mg_lstm_bwd_f32 (grad_out may be NULL = zero); workspace
+ * (mg_gru_persist_workspace_bytes(B, H)), status word and residency requirement as for mg_gru_fwd_persist_bf16. */
+int mg_lstm_persist_f32_supported(int B, int T, int H);
+int mg_lstm_fwd_persist_f32(const float* xproj, const float* w_hh, const float* b_hh, const int64_t* seq_len, int B, int T, int H,
+                            float* hstate, float* cstate, float* out, float* saved, void* workspace, size_t workspace_bytes,
+                            void* stream);
+int mg_lstm_bwd_persist_f32(const float* grad_out, const float* grad_hn, const float* grad_cn, const float* cstate, const float* saved,
+                            const float* w_hh, const int64_t* seq_len, int B, int T, int H, float* dgates, float* dh0, float* dc0,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 /* The LSTM recurrence (gates i, f, g, o) in the same persistent form: bf16 matmul operands, fp32 cell, one launch per
  * direction.  w_hh_bf = bf16(W_hh) [4H, ldw]; hstate_bf [B,T+1,H] = bf16 shadow of hstate (slot 0 set by the caller, the rest
  * written here); backward takes w_hh_t_bf = bf16(W_hh^T) [H, ldt >= 4H] and fills dgates [B,T,4H] (optional: NULL = not written)

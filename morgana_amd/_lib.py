@@ -78,6 +78,11 @@ SIGNATURES = {
                                 c_void_p, c_void_p]),
     'mg_gru_bwd_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'mg_lstm_persist_f32_supported': (c_int, [c_int, c_int, c_int]),
+    'mg_lstm_fwd_persist_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_size_t, c_void_p]),
+    'mg_lstm_bwd_persist_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'mg_gru_persist_workspace_bytes': (c_size_t, [c_int, c_int]),
     'mg_gru_persist_supported': (c_int, [c_int, c_int, c_int]),
     'mg_gru_persist_status': (c_int, [c_void_p, c_void_p]),

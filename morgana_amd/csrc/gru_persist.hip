@@ -900,11 +900,11 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_f32_kernel(const float* _
 extern "C" {
 
 // workspace: [step flags 8 x 32 words | XCC ids 8 x 32 words | status word + 3 pad] [hand-off ring: 2 parities x 8 groups x
-// R items x 12 H bytes]. The widest user is the fp32 backward (3 H fp32 per item); the bf16 backward needs 3 H bf16, the bf16
-// LSTM kernels 4 H bf16, the forward kernels H units.
+// R items x 16 H bytes]. The widest user is the fp32 LSTM backward (4 H fp32 per item); the fp32 GRU backward needs 3 H fp32, the
+// bf16 backwards 3 H / 4 H bf16, the forward kernels H units.
 size_t mg_gru_persist_workspace_bytes(int B, int H) {
     if (B <= 0 || H <= 0) return GP_RING_OFFSET;
-    return GP_RING_OFFSET + (size_t)2 * GP_GROUPS * mg_ceil_div(B, GP_GROUPS) * 12 * H;
+    return GP_RING_OFFSET + (size_t)2 * GP_GROUPS * mg_ceil_div(B, GP_GROUPS) * 16 * H;
 }
 
 int mg_gru_persist_supported(int B, int T, int H) {

@@ -8,6 +8,7 @@
 // dW_ih, dW_hh, db and dx are big GEMMs over all frames after the loop (both biases see the same dgates).
 // Items past their length keep (h, c) frozen and emit zeros, as the packed sequence of the reference does.
 #include "common.h"
+#include "lstm_cell.h"
 
 #define LT 16
 
@@ -112,10 +113,9 @@ __device__ __forceinline__ void lstm_fwd_step_body(const float* __restrict__ xpr
         const int e = bl * LT + jl;
         float pre[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) pre[g] = xg[g] + (((red[0][g][e] + red[1][g][e]) + (red[2][g][e] + red[3][g][e])) + bh[g]);
-        const float ig = mg_sigmoid(pre[0]), fg = mg_sigmoid(pre[1]), gg = tanhf(pre[2]), og = mg_sigmoid(pre[3]);
-        const float cnew = fg * cprev + ig * gg;
-        const float hnew = og * tanhf(cnew);
+        for (int g = 0; g < 4; ++g) pre[g] = mg_lstm_pre(xg[g], red[0][g][e], red[1][g][e], red[2][g][e], red[3][g][e], bh[g]);
+        const mg_lstm_cell_out cell = mg_lstm_cell_exact(pre[0], pre[1], pre[2], pre[3], cprev);     // lstm_cell.h: contraction pinned
+        const float ig = cell.i, fg = cell.f, gg = cell.g, og = cell.o, cnew = cell.c, hnew = cell.h;
         const size_t nxt = ((size_t)b * (T + 1) + t + 1) * H + j;
         hstate[nxt] = active ? hnew : hprev;
         cstate[nxt] = active ? cnew : cprev;
@@ -229,7 +229,7 @@ __device__ __forceinline__ void lstm_bwd_step_body(const float* __restrict__ gra
     __syncthreads();
     if (!in_range) return;
     const int e = bl * LT + jl;
-    const float dh_state = ch_in + ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e]));
+    const float dh_state = mg_lstm_dstate(ch_in, red[0][e], red[1][e], red[2][e], red[3][e]);
     const float dc_state = cc_in;
     if (t < 0) {
         dh0[(size_t)b * H + j] = dh_state;
@@ -239,15 +239,13 @@ __device__ __forceinline__ void lstm_bwd_step_body(const float* __restrict__ gra
     const bool active = seq_len ? ((int64_t)t < seq_len[b]) : true;
     float di = 0.f, df = 0.f, dg = 0.f, d_o = 0.f, ch = dh_state, cc = dc_state;
     if (mine && active) {
-        const float dh = dh_state + gout;
-        const float tc = tanhf(c_new);
-        const float dc = dc_state + dh * s_o * (1.f - tc * tc);
-        di = dc * s_g * s_i * (1.f - s_i);
-        df = dc * c_prev * s_f * (1.f - s_f);
-        dg = dc * s_i * (1.f - s_g * s_g);
-        d_o = dh * tc * s_o * (1.f - s_o);
+        const mg_lstm_cell_grad cg = mg_lstm_cell_bwd(dh_state, dc_state, gout, s_i, s_f, s_g, s_o, c_prev, c_new);   // lstm_cell.h
+        di = cg.di;
+        df = cg.df;
+        dg = cg.dg;
+        d_o = cg.d_o;
         ch = 0.f;                 // all of dh_{t-1} comes through the matmul with the gates of this step
-        cc = dc * s_f;
+        cc = cg.cc;
     }
     float* dgp = dgates + row * G;
     dgp[j] = di;

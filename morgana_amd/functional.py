@@ -624,6 +624,13 @@ def lstm_persistent(precision, b, t, hid):
     return precision == 'bf16' and RECURRENCE_BF16 and ops.lstm_persist_ok(b, t, hid)
 
 
+def lstm_layerwise(precision, b, t, hid):
+    """A stack of LSTM layers runs layer by layer (two persistent launches each) rather than as the time-skewed stack of per-step
+    launches: bf16 mode with the persistent bf16-operand recurrence, or fp32 parity mode with the persistent fp32 one
+    (csrc/lstm_persist_f32.hip: bit-identical to the per-step kernels, without the launch per time step)."""
+    return lstm_persistent(precision, b, t, hid) or (precision == 'fp32' and ops.lstm_persist_f32_ok(b, t, hid))
+
+
 class LSTMFn(torch.autograd.Function):
     """One LSTM layer (batch_first) restricted to seq_len[b] steps per item; returns (outputs, h_n, c_n)."""
 

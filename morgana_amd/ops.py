@@ -711,10 +711,18 @@ def gru_bwd_bf16(grad_out, grad_hn, hstate, saved, w_hh, seq_len, b, t, h, persi
     return dxproj, dhproj, dh0, dhproj_bf
 
 
-def lstm_fwd(xproj, w_hh, b_hh, seq_len, h0, c0, b, t, h):
-    """xproj (b, t, 4h) f32.  Returns (out (b,t,h), hstate (b,t+1,h), cstate (b,t+1,h), saved (b,t,4h))."""
+def lstm_persist_f32_ok(b, t, h):
+    """The one-launch fp32 LSTM recurrence covers this shape (include/morgana_hip.h: mg_lstm_fwd_persist_f32)."""
+    return PERSISTENT_RECURRENCE and bool(_lib.load().mg_lstm_persist_f32_supported(b, t, h))
+
+
+def lstm_fwd(xproj, w_hh, b_hh, seq_len, h0, c0, b, t, h, persistent=None):
+    """xproj (b, t, 4h) f32.  Returns (out (b,t,h), hstate (b,t+1,h), cstate (b,t+1,h), saved (b,t,4h)).  persistent: the one-launch
+    fp32 kernel (None = whenever the shape is covered; bit-identical to the per-step kernels on the live steps)."""
     lib = _lib.load()
     dev = xproj.device
+    if persistent is None:
+        persistent = lstm_persist_f32_ok(b, t, h)
     hstate = torch.empty((b, t + 1, h), dtype=torch.float32, device=dev)
     cstate = torch.empty((b, t + 1, h), dtype=torch.float32, device=dev)
     for state, init in ((hstate, h0), (cstate, c0)):
@@ -724,17 +732,29 @@ def lstm_fwd(xproj, w_hh, b_hh, seq_len, h0, c0, b, t, h):
             state[:, 0].copy_(init.reshape(b, h))
     out = torch.empty((b, t, h), dtype=torch.float32, device=dev)
     saved = torch.empty((b, t, 4 * h), dtype=torch.float32, device=dev)
+    if persistent:
+        ws = _persist_workspace(dev, b, h)
+        _lib.check(lib.mg_lstm_fwd_persist_f32(_p(xproj), _p(w_hh), _p(b_hh), _p(seq_len), b, t, h, _p(hstate), _p(cstate), _p(out),
+                                               _p(saved), _p(ws), ws.numel(), _stream()), 'mg_lstm_fwd_persist_f32')
+        return out, hstate, cstate, saved
     _lib.check(lib.mg_lstm_fwd_f32(_p(xproj), _p(w_hh), _p(b_hh), _p(seq_len), b, t, h, _p(hstate), _p(cstate), _p(out),
                                    _p(saved), _stream()), 'mg_lstm_fwd_f32')
     return out, hstate, cstate, saved
 
 
-def lstm_bwd(grad_out, grad_hn, grad_cn, cstate, saved, w_hh, seq_len, b, t, h):
+def lstm_bwd(grad_out, grad_hn, grad_cn, cstate, saved, w_hh, seq_len, b, t, h, persistent=None):
     lib = _lib.load()
     dev = grad_out.device
     dgates = torch.empty((b, t, 4 * h), dtype=torch.float32, device=dev)
     dh0 = torch.empty((b, h), dtype=torch.float32, device=dev)
     dc0 = torch.empty((b, h), dtype=torch.float32, device=dev)
+    if persistent is None:
+        persistent = lstm_persist_f32_ok(b, t, h)
+    if persistent:
+        ws = _persist_workspace(dev, b, h)
+        _lib.check(lib.mg_lstm_bwd_persist_f32(_p(grad_out), _p(grad_hn), _p(grad_cn), _p(cstate), _p(saved), _p(w_hh), _p(seq_len), b, t, h,
+                                               _p(dgates), _p(dh0), _p(dc0), _p(ws), ws.numel(), _stream()), 'mg_lstm_bwd_persist_f32')
+        return dgates, dh0, dc0
     nbytes = lib.mg_lstm_bwd_workspace_bytes(b, h)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     _lib.check(lib.mg_lstm_bwd_f32(_p(grad_out), _p(grad_hn), _p(grad_cn), _p(cstate), _p(saved), _p(w_hh), _p(seq_len), b,

@@ -269,7 +269,7 @@ class RecurrentCuDNNWrapper(nn.Module):
         if F_hip.lstm_stack_persistent(precision, inputs.shape[0], inputs.shape[1], layer.hidden_size, layer.num_layers):
             out, hn, cn = F_hip.LSTMStackPersistFn.apply(inputs.contiguous(), seq_len, h0s, c0s, *self._lstm_params())
             return out, (hn, cn)
-        if F_hip.lstm_persistent(precision, inputs.shape[0], inputs.shape[1], layer.hidden_size):
+        if F_hip.lstm_layerwise(precision, inputs.shape[0], inputs.shape[1], layer.hidden_size):
             # persistent recurrence: a layer is two launches, so the layers simply follow each other
             params, out, hns, cns = self._lstm_params(), inputs.contiguous(), [], []
             for k in range(layer.num_layers):
@@ -532,7 +532,7 @@ class SequentialWithRecurrent(nn.Sequential):
                     zero_padded = True
                     i = end
                     continue
-                if len(run) > 1 and not F_hip.lstm_persistent(precision, input.shape[0], input.shape[1], hid):
+                if len(run) > 1 and not F_hip.lstm_layerwise(precision, input.shape[0], input.shape[1], hid):
                     # consecutive single-layer LSTM wrappers (models/RNN_SPSS.py:36-37): one time-skewed stack (per-step
                     # launches); with the persistent recurrence each wrapper is two launches and runs on its own below
                     params = []

@@ -374,3 +374,67 @@ def test_fused_loop_step_equals_plain_loop():
         (l0, p0, m0, v0), (l1, p1, m1, v1) = results
         assert l0 == l1, phone_rate
         assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1), phone_rate
+
+
+# ------------------------------------------------------------------------------------------------------------ fp32 persistent LSTM
+@pytest.mark.parametrize('b,t,hid', [(16, 50, 512), (33, 23, 256), (5, 70, 384), (128, 9, 320), (1, 1, 512)])
+@pytest.mark.parametrize('handoff', [0, 1])
+def test_lstm_persistent_fp32_equals_step_kernels(b, t, hid, handoff):
+    """mg_lstm_fwd_persist_f32 / mg_lstm_bwd_persist_f32 (one launch per direction, W_hh resident in registers, fp32 hand-off tiles
+    between workgroups) against the launch-per-step kernels mg_lstm_fwd_f32 / mg_lstm_bwd_f32, which share their block order and
+    cell code (csrc/lstm_cell.h): outputs, both states, gate gradients, dh0 / dc0 EQUAL bit for bit on ragged batches with an
+    initial state, gradients on outputs and on the final states, in the same-XCD and in the forced write-through hand-off form;
+    saved gates compared on the live steps (past an item's length they are unspecified by contract)."""
+    lib = _lib.load()
+    rng = np.random.RandomState(hid + b + t)
+    xproj = dev(rng.standard_normal((b, t, 4 * hid)).astype(np.float32))
+    w_hh = dev((rng.uniform(-1, 1, (4 * hid, hid)) / np.sqrt(hid)).astype(np.float32))
+    b_hh = dev(rng.uniform(-0.1, 0.1, 4 * hid).astype(np.float32))
+    h0 = dev(rng.standard_normal((b, hid)).astype(np.float32) * 0.5)
+    c0 = dev(rng.standard_normal((b, hid)).astype(np.float32) * 0.5)
+    sl_np = rng.randint(1, t + 1, size=b).astype(np.int64)
+    sl_np[0] = t
+    if b > 2:
+        sl_np[-1] = 1
+    sl = dev(sl_np)
+    assert ops.lstm_persist_f32_ok(b, t, hid)
+    lib.mg_set_tuning(2, handoff)
+    try:
+        out_s, hs_s, cs_s, sv_s = ops.lstm_fwd(xproj, w_hh, b_hh, sl, h0, c0, b, t, hid, persistent=False)
+        out_p, hs_p, cs_p, sv_p = ops.lstm_fwd(xproj, w_hh, b_hh, sl, h0, c0, b, t, hid, persistent=True)
+        assert torch.equal(out_p, out_s) and torch.equal(hs_p, hs_s) and torch.equal(cs_p, cs_s)
+        valid = dev((np.arange(t)[None, :] < sl_np[:, None])[:, :, None])
+        zero = torch.zeros((), device=DEV)
+        assert torch.equal(torch.where(valid, sv_p, zero), torch.where(valid, sv_s, zero))
+        g_out = dev(rng.standard_normal((b, t, hid)).astype(np.float32))
+        g_hn = dev(rng.standard_normal((b, hid)).astype(np.float32))
+        g_cn = dev(rng.standard_normal((b, hid)).astype(np.float32))
+        # the contract's other half: gate values and output gradients past an item's length never reach a result
+        nan = torch.full((), float('nan'), device=DEV)
+        sv_bad, g_bad = torch.where(valid, sv_s, nan), torch.where(valid, g_out, nan)
+        dg_s, dh_s, dc_s = ops.lstm_bwd(g_out, g_hn, g_cn, cs_s, sv_s, w_hh, sl, b, t, hid, persistent=False)
+        dg_p, dh_p, dc_p = ops.lstm_bwd(g_bad, g_hn, g_cn, cs_s, sv_bad, w_hh, sl, b, t, hid, persistent=True)
+        dg_q, dh_q, dc_q = ops.lstm_bwd(g_bad, g_hn, g_cn, cs_s, sv_bad, w_hh, sl, b, t, hid, persistent=False)
+    finally:
+        lib.mg_set_tuning(2, 0)
+    for got in ((dg_p, dh_p, dc_p), (dg_q, dh_q, dc_q)):
+        for g, w in zip(got, (dg_s, dh_s, dc_s)):
+            assert torch.isfinite(g).all() and torch.equal(g, w)
+
+
+def test_lstm_fp32_model_runs_on_persistent_recurrence_vs_oracle():
+    """Two stacked LSTM-512 wrappers in fp32 parity mode now run layer by layer on the persistent recurrence (functional.lstm_layerwise)
+    instead of the time-skewed stack of per-step launches: against the numpy oracle at the north star's 1e-4."""
+    rng = np.random.RandomState(3)
+    b, t, hid = 6, 40, 512
+    lstm = nn.LSTM(64, hid, num_layers=2, batch_first=True).to(DEV)
+    x_np = rng.standard_normal((b, t, 64)).astype(np.float32)
+    sl_np = np.array([40, 13, 27, 1, 40, 33], dtype=np.int64)
+    assert F_hip.lstm_layerwise('fp32', b, t, hid)
+    params = [[getattr(lstm, '%s_l%d' % (n, k)).detach().cpu().numpy() for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')] for k in range(2)]
+    want = x_np
+    for k in range(2):
+        want, hn, cn, _ = ref_cpu.lstm_forward(want, sl_np, *params[k])
+    out, (h, c) = utils.RecurrentCuDNNWrapper(lstm, precision='fp32')(dev(x_np), None, dev(sl_np))
+    assert rel_err(out.detach().cpu().numpy(), want) < RTOL
+    assert rel_err(h[1].detach().cpu().numpy(), hn[0]) < RTOL and rel_err(c[1].detach().cpu().numpy(), cn[0]) < RTOL
