@@ -372,11 +372,18 @@ MG_STAMP_DECL(g_stamps_ntp);
 // groups in lockstep on this kernel (layer-1 forward 203 vs 180 us, stamps: an interval takes ~1 000 cycles, not the 512 of its 16
 // MFMAs - the reading group's 4 LDS-DMA pieces + 12 ds_read_b128 take that long to issue, MI355X_MICROARCH.md "LDS-DMA piece issue
 // cost"), so it is kept as an experiment only (MG_TUNE_STAGGER = 4).  The groups fall back into step at every tile end.
-template <int BN, int EPI, bool STAG, int BK>
+// PIPE (square tile, 32-deep stages, both wave groups in lockstep): the k-step as a half-step software pipeline.  The fragments of a
+// stage are two sets (MFMA steps ks = 0 / 1, 6 reads and 8 MFMAs each); a set is read half a step before it is multiplied, and the
+// stage boundary (counted vmcnt + barrier, then the LDS-DMA of the stage NS ahead into the slot just vacated) sits BETWEEN the two
+// halves:   [8 MFMA (kt, 0)] [wait: stage kt+1 landed; barrier] [DMA stage kt+NS -> slot kt; read (kt+1, 0)] [8 MFMA (kt, 1)] [read (kt+1, 1)]
+// so that no MFMA ever waits for an LDS read issued in its own half and the DMA issue (60-185 cycles per piece) runs beside MFMAs.
+// The slot of a stage is refilled right behind the barrier that follows its last read, so the epilogue's row patch cannot live in the
+// ring: it is a region of its own with 64-byte rows (32 rows x 32 columns per wave and pass, 16 KB in all).
+template <int BN, int EPI, bool STAG, int BK, bool PIPE = false>
 __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
                                                               int64_t M, int K, const uint16_t* __restrict__ Bm, int ldb, int N,
                                                               const float* __restrict__ bias, uint16_t* __restrict__ C, int ldc,
-                                                              int tiles_m, int tiles_n) {
+                                                              int tiles_m, int tiles_n, int probe) {
     constexpr int BM = 256;
     constexpr int WAVES_N = BN / 64;              // 4 or 2
     constexpr int WAVES_M = 8 / WAVES_N;          // 2 or 4
@@ -397,8 +404,10 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
     constexpr int MAXT = NTP_MAX_TILES(BN);
     constexpr int PATCH = ROWTAB + MAXT * BM * 4;
     constexpr int SP = 128;                       // patch row: 64 columns x 2 B, 16-byte chunk c of row r at c ^ (r & 7)
-    constexpr bool kPatchInRing = STAGE >= 8 * 32 * SP;     // the epilogue's row patch fits the ring slot consumed last
-    constexpr int BIAS_OFF = PATCH + (kPatchInRing ? 0 : 8 * 32 * SP);
+    static_assert(!PIPE || (BN == 256 && BK == 32 && !STAG), "PIPE: square tile, 32-deep stages, lockstep");
+    constexpr bool kPatchInRing = !PIPE && STAGE >= 8 * 32 * SP;     // the epilogue's row patch fits the ring slot consumed last
+    constexpr int SPP = 64;                       // PIPE: patch row = 32 columns x 2 B, chunk c of row r at c ^ ((r >> 1) & 3)
+    constexpr int BIAS_OFF = PATCH + (kPatchInRing ? 0 : (PIPE ? 8 * 32 * SPP : 8 * 32 * SP));
     constexpr int LDS_BYTES = BIAS_OFF + BN * 4;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
@@ -470,10 +479,13 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
     auto issue_next = [&]() {                     // next stage of the stream, if any is left
         if (i_t >= n_my) return;
         unsigned char* st = smem + i_s * STAGE;
+        // probe bits (timing experiments, results garbage): 1 = no A pieces, 2 = no B pieces, 4 = no fragment reads, 8 = no MFMAs, 16 = no epilogue
 #pragma unroll
-        for (int g = 0; g < GA; ++g) glds16(asrc[g] + i_k * BK, st + (wave * GA + g) * 1024);
+        for (int g = 0; g < GA; ++g)
+            if (!(probe & 1)) glds16(asrc[g] + i_k * BK, st + (wave * GA + g) * 1024);
 #pragma unroll
-        for (int g = 0; g < GB; ++g) glds16(bsrc[g] + i_k * BK, st + A_BYTES + (wave * GB + g) * 1024);
+        for (int g = 0; g < GB; ++g)
+            if (!(probe & 2)) glds16(bsrc[g] + i_k * BK, st + A_BYTES + (wave * GB + g) * 1024);
         i_s = (i_s + 1 == NS) ? 0 : i_s + 1;
         if (++i_k == n_kt) {
             i_k = 0;
@@ -510,13 +522,14 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
     }
 
 #pragma unroll
-    for (int p = 0; p < NS - 1; ++p) issue_next();
+    for (int p = 0; p < (PIPE ? NS : NS - 1); ++p) issue_next();       // PIPE fills every slot: slot g % NS is refilled during step g
 
     // All fragment reads of a stage first, then its MFMAs (pinned with sched_group_barrier): left alone hipcc reads two to four
     // fragments at a time with an lgkmcnt(0) in front of every MFMA group - six exposed LDS round trips per stage.
     const bool lag = STAG && wave >= 4;           // wave-uniform
     bfv8 fa[KS][TM], fb[KS][TN];
     auto read_frags = [&](const unsigned char* st) {
+        if (probe & 4) return;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -527,6 +540,16 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
         __builtin_amdgcn_sched_group_barrier(0x100, KS * (TM + TN), 0);
     };
     auto mfma_all = [&](f32x16 (&acc)[TM][TN]) {
+        if (probe & 8) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[ks][i]));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb[ks][j]));
+            }
+            return;
+        }
         if (STAG) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
@@ -539,8 +562,31 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
         if (STAG) __builtin_amdgcn_s_setprio(0);
     };
 
+    auto read_half = [&](const unsigned char* st, int ks) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const bfv8*>(st + abase[i] + ((asw[i] ^ (2 * ks)) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[ks][j] = *reinterpret_cast<const bfv8*>(st + bbase[j] + ((bsw[j] ^ (2 * ks)) << 4));
+    };
+    auto mfma_half = [&](f32x16 (&acc)[TM][TN], int ks) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+    };
+
     const int g_total = n_my * n_kt;
     int g = 0, c_s = 0;                           // global stage counter, its ring slot
+    if (PIPE) {
+        // stage 0 landed (up to NS - 1 younger stages may stay in flight), then both fragment sets of it
+        switch (min(g_total - 1, NS - 1) * NL) {
+            NTP_WAIT_CASE(4) NTP_WAIT_CASE(8) NTP_WAIT_CASE(12)
+            default: WAIT_VM_LGKM_BARRIER(0); break;
+        }
+        read_half(smem, 0);
+        read_half(smem, 1);
+    }
     // The tile loop exists twice, once per wave group (LAG = the group that runs half a k-step behind), selected once by a wave-uniform
     // branch: with the group tested inside one loop body the register allocator has to reconcile the two schedules at every merge
     // point and spills (425-569 VGPRs of scratch measured); as two independent loops each stays within 256.
@@ -559,6 +605,34 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+        if (PIPE) {
+            for (int kt = 0; kt < n_kt; ++kt, ++g) {
+                const bool more = g + 1 < g_total;
+                mfma_half(acc, 0);
+                const unsigned char* st_next = smem + ((g + 1) % NS) * STAGE;
+                if (more) {
+                    // stage g + 1 must have landed; issued so far: stages up to g + NS - 1, so g + 2 and g + 3 may stay in flight, and
+                    // the previous tile's NST stores while they are younger than stage g + 1's DMA (first NS - 1 steps of a tile)
+                    const int allow = max(0, min(g_total - 2 - g, NS - 2)) * NL + ((ti > 0 && kt < NS - 1) ? NST : 0);
+                    MG_STAMP(ta);
+                    __builtin_amdgcn_sched_barrier(0);
+                    switch (allow) {
+                        NTP_WAIT_CASE(0) NTP_WAIT_CASE(4) NTP_WAIT_CASE(8) NTP_WAIT_CASE(16) NTP_WAIT_CASE(20) NTP_WAIT_CASE(24)
+                        default: WAIT_VM_LGKM_BARRIER(0); break;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    MG_STAMP(tb);
+                    MG_STAMP_ADD(sum_wait, tb, ta);
+#ifdef MG_STAMPS
+                    if (g == 0) ts1 = tb;
+#endif
+                    issue_next();                  // stage g + NS into the slot every wave has just finished reading
+                    read_half(st_next, 0);
+                }
+                mfma_half(acc, 1);
+                if (more) read_half(st_next, 1);
+            }
+        } else
         for (int kt = 0; kt < n_kt; ++kt, ++g) {
             MG_STAMP(ta);
             // stages issued so far: min(g_total, g + NS - 1); stage g must have landed; younger than it are
@@ -566,7 +640,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
             // The wait also retires this wave's LDS reads (lgkmcnt): the lagging group comes here straight from its fragment reads,
             // and the slot they came from is refilled right behind this barrier.
             {
-                const int allow = min(g_total - 1 - g, NS - 2) * NL + ((ti > 0 && kt < NS - 1) ? NST : 0);
+                const int allow = min(g_total - 1 - g, NS - 2) * (((probe & 3) == 3) ? 0 : ((probe & 3) ? NL / 2 : NL)) + ((ti > 0 && kt < NS - 1 && !(probe & 16)) ? NST : 0);
                 __builtin_amdgcn_sched_barrier(0);
                 switch (allow) {
                     NTP_WAIT_CASE(0) NTP_WAIT_CASE(3) NTP_WAIT_CASE(4) NTP_WAIT_CASE(6) NTP_WAIT_CASE(8) NTP_WAIT_CASE(9)
@@ -608,6 +682,56 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
 
         // ---- epilogue: bias (+ sigmoid), bf16, whole 128-byte row segments through the LDS patch ---------------------------
         MG_STAMP(ta);
+        if (probe & 16) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
+            WAIT_LGKM_BARRIER();
+            c_s = (c_s + 1 == NS) ? 0 : c_s + 1;
+            continue;
+        }
+        if (PIPE) {
+            // wave-private patch outside the ring: no barrier; 32 rows x 32 columns per pass, rows leave as 64-byte segments
+            unsigned char* patch = smem + PATCH + wave * (32 * SPP);
+            const int prow = lane >> 2, pchunk = lane & 3;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_lds + wn0 + j * 32 + 8 * q + 4 * lh);
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float x = acc[i][j][4 * q + e] + bq[e];
+                            if (EPI == EPI_BIAS_SIGMOID) x = mg_sigmoid_fast(x);
+                            v[e] = x;
+                        }
+                        typedef __bf16 bfv2 __attribute__((ext_vector_type(2)));
+                        typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+                        const u32x2_t pk = u32x2_t{__builtin_bit_cast(unsigned int, bfv2{(__bf16)v[0], (__bf16)v[1]}),
+                                                   __builtin_bit_cast(unsigned int, bfv2{(__bf16)v[2], (__bf16)v[3]})};
+                        *reinterpret_cast<u32x2_t*>(patch + lr * SPP + ((q ^ ((lr >> 1) & 3)) << 4) + 8 * lh) = pk;
+                    }
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+                        const int rl = it * 16 + prow;
+                        const u32x4_t o = *reinterpret_cast<const u32x4_t*>(patch + rl * SPP + ((pchunk ^ ((rl >> 1) & 3)) << 4));
+                        const int64_t m = m0 + wm0 + i * 32 + rl;
+                        uint16_t* dst = (m < M) ? C + (size_t)m * ldc + n0 + wn0 + j * 32 + pchunk * 8 : g_ntp_sink + lane * 8;
+                        *reinterpret_cast<u32x4_t*>(dst) = o;     // unconditional: the counted vmcnt waits rely on NST stores per wave
+                    }
+                }
+            }
+            MG_STAMP(tb);
+            MG_STAMP_ADD(sum_epi, tb, ta);
+            continue;
+        }
         __builtin_amdgcn_sched_barrier(0);
         WAIT_LGKM_BARRIER();                      // every wave is done with the last stage (the lagging group has just read it)
         __builtin_amdgcn_sched_barrier(0);
@@ -936,10 +1060,15 @@ int mg_try_nt_big(const uint16_t* A, int lda, const int32_t* rows, int64_t M, in
         while (mg_ceil_div(blocks, g) > NTP_MAX_TILES(bn)) g += 256;    // more tiles than a workgroup parks rows for: more groups
         if (g > blocks) g = mg_ceil_div(blocks, 8 * tiles_n) * 8 * tiles_n;
         dim3 pgrid((unsigned)g), pblock(512);
-#define LAUNCH_NTP(BN_, EPI_, STAG_, BK_) hipLaunchKernelGGL((gemm_nt_persist_kernel<BN_, EPI_, STAG_, BK_>), pgrid, pblock, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, (uint16_t*)C, ldc, (int)tiles_m, tiles_n)
+        const int probe = g_mg_tuning[MG_TUNE_STAGGER] >= 32 ? g_mg_tuning[MG_TUNE_STAGGER] - 32 : 0;      // timing probes: 32 + bit mask
+#define LAUNCH_NTP(BN_, EPI_, STAG_, BK_) hipLaunchKernelGGL((gemm_nt_persist_kernel<BN_, EPI_, STAG_, BK_>), pgrid, pblock, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, (uint16_t*)C, ldc, (int)tiles_m, tiles_n, probe)
         const bool stag = g_mg_tuning[MG_TUNE_STAGGER] == 4;     // experiment: the two wave groups half a k-step apart (measured slower)
         const bool deep = g_mg_tuning[MG_TUNE_STAGGER] != 3;     // 128-wide tile: 64-deep stages (whole 128-byte lines per DMA row); 3 = 32-deep
-        if (wide) {
+        const bool pipe = g_mg_tuning[MG_TUNE_STAGGER] == 2;     // experiment: half-step software pipeline of the square tile
+        if (wide && pipe) {
+            if (epi == EPI_BIAS) hipLaunchKernelGGL((gemm_nt_persist_kernel<256, EPI_BIAS, false, 32, true>), pgrid, pblock, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, (uint16_t*)C, ldc, (int)tiles_m, tiles_n, probe);
+            else hipLaunchKernelGGL((gemm_nt_persist_kernel<256, EPI_BIAS_SIGMOID, false, 32, true>), pgrid, pblock, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, (uint16_t*)C, ldc, (int)tiles_m, tiles_n, probe);
+        } else if (wide) {
             if (stag) { if (epi == EPI_BIAS) LAUNCH_NTP(256, EPI_BIAS, true, 32); else LAUNCH_NTP(256, EPI_BIAS_SIGMOID, true, 32); }
             else { if (epi == EPI_BIAS) LAUNCH_NTP(256, EPI_BIAS, false, 32); else LAUNCH_NTP(256, EPI_BIAS_SIGMOID, false, 32); }
         } else if (deep) {

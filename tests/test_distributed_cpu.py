@@ -77,3 +77,47 @@ def test_shard_slices_and_cropping():
     assert seen == batch['name']
     with pytest.raises(ValueError):
         distributed.shard_slice(10, 0, 4)
+
+
+def _bucket_worker(rank, world, port, out_dir):
+    """Two-bucket gradient exchange (optim.Adam.exchange_gradients('early' / 'late'), graphs.GraphedTrainStep's multi-rank path) against
+    the single whole-buffer all-reduce: every element reduced exactly once, bit-identical sums."""
+    import os
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from morgana_amd import optim
+    import helpers
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        results = {}
+        for mode in ('whole', 'buckets'):
+            model = helpers.init_small(helpers.CpuF0Model(dims=(24, 16, 8, 1)), seed=3)
+            opt = optim.Adam(model.parameters(), lr=0.01, kernel=helpers.cpu_adam_kernel)
+            rng = np.random.RandomState(100 + rank)
+            flat = opt.flat_buffers()
+            flat['grad'].copy_(torch.from_numpy(rng.standard_normal(flat['grad'].numel()).astype(np.float32)))
+            split = opt.bucket_split()
+            assert split == 24 * 16 + 16                      # the first Linear's weight + bias: produced last by the backward pass
+            if mode == 'whole':
+                opt.exchange_gradients()
+            else:
+                opt.exchange_gradients('early')
+                opt.exchange_gradients('late')
+            results[mode] = flat['grad'].clone()
+        assert torch.equal(results['whole'], results['buckets'])
+        np.save(os.path.join(out_dir, 'bucket_rank%d.npy' % rank), results['buckets'].numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_bucket_exchange_equals_single_all_reduce(tmp_path):
+    import numpy as np
+    import torch.multiprocessing as mp
+    port = 29641
+    mp.spawn(_bucket_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / 'bucket_rank0.npy'), np.load(tmp_path / 'bucket_rank1.npy')
+    assert np.array_equal(a, b)                           # replicas hold identical reduced gradients
+    want = np.random.RandomState(100).standard_normal(a.size).astype(np.float32) + np.random.RandomState(101).standard_normal(a.size).astype(np.float32)
+    np.testing.assert_array_equal(a, want)
