@@ -379,11 +379,19 @@ MG_STAMP_DECL(g_stamps_ntp);
 // so that no MFMA ever waits for an LDS read issued in its own half and the DMA issue (60-185 cycles per piece) runs beside MFMAs.
 // The slot of a stage is refilled right behind the barrier that follows its last read, so the epilogue's row patch cannot live in the
 // ring: it is a region of its own with 64-byte rows (32 rows x 32 columns per wave and pass, 16 KB in all).
-template <int BN, int EPI, bool STAG, int BK, bool PIPE = false>
+// MODE 2 = SPREAD (experiment): the stage order of the default, but the four LDS-DMA pieces of the stage NS - 1 ahead are issued one at
+// a time between the MFMAs, at MFMA slots 4 q + off with off different for the eight waves' SIMD partners (0..3): the address path
+// takes a 1 KB piece in at ~32 B/clk, and a wave stands at the issue while the queue is full - with all 32 pieces of a stage issued
+// at once that is up to 1 000 cycles per k-step in which no wave of the workgroup issues an MFMA.
+// MODE 5 = ROLE (timing probe, results garbage): can the MFMAs and the LDS-DMA of DIFFERENT waves overlap?  Waves 0-3 issue no DMA and
+// read no fragments but run every MFMA twice; waves 4-7 issue every piece twice, read their fragments and run no MFMA; every wait is
+// vmcnt(0).  Same DMA bytes and MFMA count per k-step as the real kernel.
+template <int BN, int EPI, bool STAG, int BK, int MODE = 0>
 __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
                                                               int64_t M, int K, const uint16_t* __restrict__ Bm, int ldb, int N,
                                                               const float* __restrict__ bias, uint16_t* __restrict__ C, int ldc,
                                                               int tiles_m, int tiles_n, int probe) {
+    constexpr bool PIPE = MODE == 1, ROLE = MODE == 5, SPREAD = MODE == 2;
     constexpr int BM = 256;
     constexpr int WAVES_N = BN / 64;              // 4 or 2
     constexpr int WAVES_M = 8 / WAVES_N;          // 2 or 4
@@ -476,22 +484,40 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
     };
     int i_t = 0, i_k = 0, i_s = 0;
     set_sources(0);
-    auto issue_next = [&]() {                     // next stage of the stream, if any is left
+    auto issue_next = [&](int reps = 1) {         // next stage of the stream, if any is left
         if (i_t >= n_my) return;
         unsigned char* st = smem + i_s * STAGE;
         // probe bits (timing experiments, results garbage): 1 = no A pieces, 2 = no B pieces, 4 = no fragment reads, 8 = no MFMAs, 16 = no epilogue
+        for (int rep = 0; rep < reps; ++rep) {
 #pragma unroll
         for (int g = 0; g < GA; ++g)
             if (!(probe & 1)) glds16(asrc[g] + i_k * BK, st + (wave * GA + g) * 1024);
 #pragma unroll
         for (int g = 0; g < GB; ++g)
             if (!(probe & 2)) glds16(bsrc[g] + i_k * BK, st + A_BYTES + (wave * GB + g) * 1024);
+        }
         i_s = (i_s + 1 == NS) ? 0 : i_s + 1;
         if (++i_k == n_kt) {
             i_k = 0;
             if (++i_t < n_my) set_sources(i_t);
         }
     };
+
+    auto issue_piece = [&](int q) {               // SPREAD: piece q of the next stage; advance_stage() after the last
+        if (i_t >= n_my) return;
+        unsigned char* st = smem + i_s * STAGE;
+        if (q < GA) glds16(asrc[q < GA ? q : 0] + i_k * BK, st + (wave * GA + q) * 1024);
+        else glds16(bsrc[q < GA ? 0 : q - GA] + i_k * BK, st + A_BYTES + (wave * GB + (q - GA)) * 1024);
+    };
+    auto advance_stage = [&]() {
+        if (i_t >= n_my) return;
+        i_s = (i_s + 1 == NS) ? 0 : i_s + 1;
+        if (++i_k == n_kt) {
+            i_k = 0;
+            if (++i_t < n_my) set_sources(i_t);
+        }
+    };
+    const int spread_off = (probe & 32) ? 0 : ((wave + (wave >> 2)) & 3);     // partners on a SIMD (w, w + 4) differ by one slot
 
     const int lr = lane & 31, lh = lane >> 5;
     // byte offset of this lane's fragment of MFMA step ks inside a stage: row base + ((2 ks + lh) ^ swz(row)) * 16
@@ -522,12 +548,21 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
     }
 
 #pragma unroll
-    for (int p = 0; p < (PIPE ? NS : NS - 1); ++p) issue_next();       // PIPE fills every slot: slot g % NS is refilled during step g
+    for (int p = 0; p < (PIPE ? NS : NS - 1); ++p) issue_next(ROLE ? (wave < 4 ? 0 : 2) : 1);       // PIPE fills every slot: slot g % NS is refilled during step g
 
     // All fragment reads of a stage first, then its MFMAs (pinned with sched_group_barrier): left alone hipcc reads two to four
     // fragments at a time with an lgkmcnt(0) in front of every MFMA group - six exposed LDS round trips per stage.
-    const bool lag = STAG && wave >= 4;           // wave-uniform
+    const bool lag = (STAG || ROLE) && wave >= 4; // wave-uniform
     bfv8 fa[KS][TM], fb[KS][TN];
+    if (ROLE) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[ks][i] = bfv8{};
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[ks][j] = bfv8{};
+        }
+    }
     auto read_frags = [&](const unsigned char* st) {
         if (probe & 4) return;
 #pragma unroll
@@ -640,8 +675,9 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
             // The wait also retires this wave's LDS reads (lgkmcnt): the lagging group comes here straight from its fragment reads,
             // and the slot they came from is refilled right behind this barrier.
             {
-                const int allow = min(g_total - 1 - g, NS - 2) * (((probe & 3) == 3) ? 0 : ((probe & 3) ? NL / 2 : NL)) + ((ti > 0 && kt < NS - 1 && !(probe & 16)) ? NST : 0);
+                const int allow = ROLE ? (LAG ? min(g_total - 1 - g, NS - 2) * 2 * NL : 0) : min(g_total - 1 - g, NS - 2) * (((probe & 3) == 3) ? 0 : ((probe & 3) ? NL / 2 : NL)) + ((ti > 0 && kt < NS - 1 && !(probe & 16)) ? NST : 0);
                 __builtin_amdgcn_sched_barrier(0);
+                if (!(probe & 64))                // probe bit 64: no wait, no barrier (only meaningful without DMA and reads)
                 switch (allow) {
                     NTP_WAIT_CASE(0) NTP_WAIT_CASE(3) NTP_WAIT_CASE(4) NTP_WAIT_CASE(6) NTP_WAIT_CASE(8) NTP_WAIT_CASE(9)
                     NTP_WAIT_CASE(11) NTP_WAIT_CASE(12) NTP_WAIT_CASE(14) NTP_WAIT_CASE(16) NTP_WAIT_CASE(17) NTP_WAIT_CASE(20)
@@ -656,7 +692,32 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
             if (g == 0) ts1 = tb;
 #endif
             const unsigned char* st = smem + c_s * STAGE;
-            if (!STAG) {
+            if (SPREAD) {
+                static_assert(!SPREAD || (NL == 4 && KS * TM * TN == 16), "SPREAD: 4 pieces over 16 MFMAs");
+                read_frags(st);
+#pragma unroll
+                for (int mi = 0; mi < 16; ++mi) {
+                    if (spread_off == (mi & 3)) issue_piece(mi >> 2);      // the slot every wave finished with before this barrier
+                    const int ks = mi / (TM * TN), i = (mi / TN) % TM, j = mi % TN;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+                }
+                advance_stage();
+            } else if (ROLE) {
+                if (LAG) {
+                    issue_next(2);
+                    read_frags(st);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[ks][i]));
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb[ks][j]));
+                    }
+                } else {
+                    mfma_all(acc);
+                    mfma_all(acc);
+                }
+            } else if (!STAG) {
                 issue_next();                     // refills the slot every wave finished with before this barrier
                 read_frags(st);
                 mfma_all(acc);
@@ -1060,14 +1121,20 @@ int mg_try_nt_big(const uint16_t* A, int lda, const int32_t* rows, int64_t M, in
         while (mg_ceil_div(blocks, g) > NTP_MAX_TILES(bn)) g += 256;    // more tiles than a workgroup parks rows for: more groups
         if (g > blocks) g = mg_ceil_div(blocks, 8 * tiles_n) * 8 * tiles_n;
         dim3 pgrid((unsigned)g), pblock(512);
-        const int probe = g_mg_tuning[MG_TUNE_STAGGER] >= 32 ? g_mg_tuning[MG_TUNE_STAGGER] - 32 : 0;      // timing probes: 32 + bit mask
+        const int probe = g_mg_tuning[MG_TUNE_STAGGER] >= 256 ? g_mg_tuning[MG_TUNE_STAGGER] - 256 : g_mg_tuning[MG_TUNE_STAGGER] >= 32 ? g_mg_tuning[MG_TUNE_STAGGER] - 32 : 0;      // timing probes: 32 + bit mask
 #define LAUNCH_NTP(BN_, EPI_, STAG_, BK_) hipLaunchKernelGGL((gemm_nt_persist_kernel<BN_, EPI_, STAG_, BK_>), pgrid, pblock, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, (uint16_t*)C, ldc, (int)tiles_m, tiles_n, probe)
         const bool stag = g_mg_tuning[MG_TUNE_STAGGER] == 4;     // experiment: the two wave groups half a k-step apart (measured slower)
         const bool deep = g_mg_tuning[MG_TUNE_STAGGER] != 3;     // 128-wide tile: 64-deep stages (whole 128-byte lines per DMA row); 3 = 32-deep
         const bool pipe = g_mg_tuning[MG_TUNE_STAGGER] == 2;     // experiment: half-step software pipeline of the square tile
-        if (wide && pipe) {
-            if (epi == EPI_BIAS) hipLaunchKernelGGL((gemm_nt_persist_kernel<256, EPI_BIAS, false, 32, true>), pgrid, pblock, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, (uint16_t*)C, ldc, (int)tiles_m, tiles_n, probe);
-            else hipLaunchKernelGGL((gemm_nt_persist_kernel<256, EPI_BIAS_SIGMOID, false, 32, true>), pgrid, pblock, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, (uint16_t*)C, ldc, (int)tiles_m, tiles_n, probe);
+        if (wide && (g_mg_tuning[MG_TUNE_STAGGER] == 5 || g_mg_tuning[MG_TUNE_STAGGER] == 11)) {     // SPREAD (11: every wave at the same slots)
+            const int pr = g_mg_tuning[MG_TUNE_STAGGER] == 11 ? 32 : 0;
+            if (epi == EPI_BIAS) hipLaunchKernelGGL((gemm_nt_persist_kernel<256, EPI_BIAS, false, 32, 2>), pgrid, pblock, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, (uint16_t*)C, ldc, (int)tiles_m, tiles_n, pr);
+            else hipLaunchKernelGGL((gemm_nt_persist_kernel<256, EPI_BIAS_SIGMOID, false, 32, 2>), pgrid, pblock, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, (uint16_t*)C, ldc, (int)tiles_m, tiles_n, pr);
+        } else if (wide && (g_mg_tuning[MG_TUNE_STAGGER] == 9 || g_mg_tuning[MG_TUNE_STAGGER] == 10 || g_mg_tuning[MG_TUNE_STAGGER] == 12 || g_mg_tuning[MG_TUNE_STAGGER] == 13)) {             // ROLE probe, without the epilogue (10: and without the MFMAs)
+            hipLaunchKernelGGL((gemm_nt_persist_kernel<256, EPI_BIAS_SIGMOID, false, 32, 5>), pgrid, pblock, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, (uint16_t*)C, ldc, (int)tiles_m, tiles_n, g_mg_tuning[MG_TUNE_STAGGER] == 9 ? 16 : g_mg_tuning[MG_TUNE_STAGGER] == 10 ? 24 : g_mg_tuning[MG_TUNE_STAGGER] == 12 ? 23 : 23 + 64);   // 12: MFMAs only (waves 0-3, 32 per k-step), 13: and no barrier
+        } else if (wide && pipe) {
+            if (epi == EPI_BIAS) hipLaunchKernelGGL((gemm_nt_persist_kernel<256, EPI_BIAS, false, 32, 1>), pgrid, pblock, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, (uint16_t*)C, ldc, (int)tiles_m, tiles_n, probe);
+            else hipLaunchKernelGGL((gemm_nt_persist_kernel<256, EPI_BIAS_SIGMOID, false, 32, 1>), pgrid, pblock, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, (uint16_t*)C, ldc, (int)tiles_m, tiles_n, probe);
         } else if (wide) {
             if (stag) { if (epi == EPI_BIAS) LAUNCH_NTP(256, EPI_BIAS, true, 32); else LAUNCH_NTP(256, EPI_BIAS_SIGMOID, true, 32); }
             else { if (epi == EPI_BIAS) LAUNCH_NTP(256, EPI_BIAS, false, 32); else LAUNCH_NTP(256, EPI_BIAS_SIGMOID, false, 32); }

@@ -17,12 +17,14 @@ def main():
     dev = 'cuda:0'
     torch.manual_seed(0)
     bad = 0
-    for m, r_tab, gather in ((256000, 20480, True), (21504, 21504, False), (4099, 700, True), (70000, 70000, False)):
-        k, n = 600, 512
-        tab = torch.rand(r_tab, 640, device=dev).to(torch.bfloat16)
-        tab[:, 600:] = 0
-        w = (torch.randn(n, 640, device=dev) * 0.05).to(torch.bfloat16)
-        w[:, 600:] = 0
+    for m, r_tab, gather, k, n in ((256000, 20480, True, 600, 512), (21504, 21504, False, 600, 512), (4099, 700, True, 600, 512),
+                                   (70000, 70000, False, 600, 512), (256000, 256000, False, 512, 128), (21504, 21504, False, 512, 128),
+                                   (5000, 5000, False, 512, 128)):
+        kp = (k + 63) // 64 * 64
+        tab = torch.rand(r_tab, kp, device=dev).to(torch.bfloat16)
+        tab[:, k:] = 0
+        w = (torch.randn(n, kp, device=dev) * 0.05).to(torch.bfloat16)
+        w[:, k:] = 0
         bias = torch.randn(n, device=dev) * 0.1
         rows = None
         if gather:
@@ -39,7 +41,7 @@ def main():
         for v, act, o in outs:
             same = torch.equal(o, ref[act])
             bad += not same
-            print('M=%6d gather=%d variant %d act %d: %s' % (m, gather, v, act, 'equal' if same else 'DIFFERENT (max %g)' % (o.float() - ref[act].float()).abs().max().item()))
+            print('M=%6d N=%d gather=%d variant %d act %d: %s' % (m, n, gather, v, act, 'equal' if same else 'DIFFERENT (max %g)' % (o.float() - ref[act].float()).abs().max().item()))
     sys.exit(1 if bad else 0)
 
 
