@@ -47,6 +47,7 @@ const char* mg_last_error(void);
                                  * 1 = always write-through (sc1) stores, the placement-independent form */
 #define MG_TUNE_SKIP_REDUCE 1   /* != 0: weight-gradient entry points launch their GEMM kernel only, not the slab reduce that
                                  * finishes dW / db (results are then NOT valid) - lets bench.py time the kernel alone */
+#define MG_TUNE_LSTM_BWD_STACK 3 /* mg_lstm_pstack_bwd_bf16: 0 = 32 hidden units per slot where they fit (one workgroup per CU), 1 = 16 (two per CU) */
 #define MG_TUNE_WGRAD_SPLITS 4  /* wide weight-gradient kernel: != 0 overrides the planned number of split-M slabs (a multiple of 8) */
 #define MG_TUNE_WGRAD_ORDER 5   /* wide weight-gradient kernel, block order: 0 = planned, 1 = n tile fastest, 2 = the n tiles of a split on one XCD */
 int mg_set_tuning(int key, int value);
@@ -474,6 +475,35 @@ typedef struct {
 int mg_lstm_pstack_supported(int B, int T, int H, int L);
 size_t mg_lstm_pstack_workspace_bytes(int B, int H, int L);
 int mg_lstm_pstack_fwd_bf16(const mg_lstm_pstack_layer* layers, int L, const int64_t* seq_len, int B, int T, int H, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
+/* The backward of the same stack in ONE launch (reference: autograd through the 8 chained nn.LSTM of models/RNN_SPSS.py:36-37): the
+ * forward's wavefront run down in time and down through the layers.  Layer l's step t takes the gate gradients of the layer above
+ * at step t through that layer's W_ih inside the step (d out^l_t = dgates^{l+1}_t W_ih^{l+1}) instead of a grad_out row from memory,
+ * so the L - 1 input-gradient GEMMs between per-layer launches go as well.  Per layer: dgates_bf [B,T,4H] (bf16 gate gradients
+ * i, f, g, o: the operand of the weight-gradient GEMMs and, for layer 0, of the input-gradient GEMM; exactly 0 on padded steps),
+ * optionally the fp32 copy dgates, dh0 / dc0 [B,H].  Same arithmetic as L chained mg_lstm_bwd_persist_bf16 calls with
+ * mg_linear_dgrad_bf16 between them, up to the summation order of the in-step product.
+ * mg_lstm_pstack_bwd_supported(B, T, H, L): H % 128 == 0, H <= 512, B T 4H < 2^31 and L G H / 32 <= 256 workgroups (one per CU, a
+ * slot of 32 hidden units) or L G H / 16 <= 512 (two per CU) for a group count G in {8, 4, 2, 1} with ceil(B / G) <= 32.
+ * Workspace: mg_lstm_pstack_bwd_workspace_bytes, zeroed once by the caller, status word as for the other persistent launches. */
+typedef struct {
+    const float* grad_out;          /* top layer only: [B,T,H] or NULL (zero); ignored below the top */
+    const float* grad_hn;           /* NULL or [B,H] */
+    const float* grad_cn;           /* NULL or [B,H] */
+    const float* cstate;            /* [B,T+1,H] of the forward */
+    const float* saved;             /* [B,T,4H] gate values of the forward */
+    const uint16_t* w_hh_t_bf;      /* bf16(W_hh^T) [H, ldt] */
+    const uint16_t* w_ih_up_t_bf;   /* layers below the top: bf16(W_ih^T) of the layer ABOVE, [H, ldt_up] */
+    float* dgates;                  /* NULL or [B,T,4H] */
+    uint16_t* dgates_bf;            /* [B,T,4H] */
+    float* dh0;                     /* [B,H] */
+    float* dc0;                     /* [B,H] */
+    int ldt, ldt_up;
+} mg_lstm_pstack_bwd_layer;
+int mg_lstm_pstack_bwd_supported(int B, int T, int H, int L);
+size_t mg_lstm_pstack_bwd_workspace_bytes(int B, int H, int L);
+int mg_lstm_pstack_bwd_bf16(const mg_lstm_pstack_bwd_layer* layers, int L, const int64_t* seq_len, int B, int T, int H, void* workspace,
                             size_t workspace_bytes, void* stream);
 
 /* LSTM through RecurrentCuDNNWrapper   reference: morgana/utils.py:345-393 + torch.nn.LSTM (gates i, f, g, o), the cell of

@@ -139,6 +139,9 @@ SIGNATURES = {
     'mg_lstm_pstack_supported': (c_int, [c_int, c_int, c_int, c_int]),
     'mg_lstm_pstack_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'mg_lstm_pstack_fwd_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'mg_lstm_pstack_bwd_supported': (c_int, [c_int, c_int, c_int, c_int]),
+    'mg_lstm_pstack_bwd_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'mg_lstm_pstack_bwd_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'mg_lstm_stack_fwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'mg_lstm_stack_bwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'mg_adam_step_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
@@ -170,6 +173,13 @@ class LstmPStackLayer(ctypes.Structure):
     _fields_ = [('xproj', c_void_p), ('w_ih_bf', c_void_p), ('b_ih', c_void_p), ('w_hh_bf', c_void_p), ('b_hh', c_void_p),
                 ('hstate', c_void_p), ('cstate', c_void_p), ('hstate_bf', c_void_p), ('out', c_void_p), ('saved', c_void_p),
                 ('ldwi', c_int), ('ldwh', c_int)]
+
+
+class LstmPStackBwdLayer(ctypes.Structure):
+    """mg_lstm_pstack_bwd_layer of include/morgana_hip.h."""
+    _fields_ = [('grad_out', c_void_p), ('grad_hn', c_void_p), ('grad_cn', c_void_p), ('cstate', c_void_p), ('saved', c_void_p),
+                ('w_hh_t_bf', c_void_p), ('w_ih_up_t_bf', c_void_p), ('dgates', c_void_p), ('dgates_bf', c_void_p),
+                ('dh0', c_void_p), ('dc0', c_void_p), ('ldt', c_int), ('ldt_up', c_int)]
 
 
 class LstmBwdLayer(ctypes.Structure):

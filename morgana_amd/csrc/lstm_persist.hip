@@ -822,6 +822,358 @@ __global__ __launch_bounds__(256, 2) void lstm_stack_fwd_persist_kernel(LstmPSta
         if (mine[m]) P.hstate[((size_t)(row0 + 16 * m + bl) * (T + 1) + T) * H + j] = hprev[m];
 }
 
+// =====================================================================================================================
+// The whole LSTM STACK backward in one launch: the forward's wavefront run down in time and down through the layers.  Layer l's
+// step t needs its own gate gradients of step t + 1 (through W_hh, as in lstm_bwd_persist_kernel) and, instead of a grad_out row
+// from memory, the gate gradients of the layer ABOVE at step t through that layer's W_ih: d out^l_t = dgates^{l+1}_t W_ih^{l+1}.
+// So L layers take T + L dependent steps instead of L (T + 1) + (L - 1) input-gradient GEMMs between the launches.
+// Workgroup = (layer, group, slot); a slot owns 16 UT hidden units (UT = 2: one 256-thread workgroup per CU with up to 512
+// VGPRs, its rows of W_hh^T and of the upper W_ih^T resident in 256 of them; UT = 1: two workgroups per CU as in the forward).
+// Per step a workgroup takes in two hand-off tiles of R x 4H bf16 (its own and the upper layer's gate gradients): 256 KB at
+// R = 32, H = 512 - four times the forward's - and that intake (66-73 GB/s per CU from L2), not the latency chain, sets the step
+// time; UT = 2 halves it per CU against UT = 1 (one workgroup per CU reads each tile once for 32 units).
+// Rings (bf16, [G][H / 16 unit tiles][4 gates][R items][16 units] per epoch):
+//   ring A  2 epochs (t parity), this layer's own next step; plain stores + flag A when the (layer, group) shares an XCD
+//   ring X  4 epochs (t mod 4), for the layer BELOW: always write-through (sc1), written by wave 1, flag X raised a step later
+// Conditions of step t (wave 0, one poll each; the neighbours' flags are cached per lane as in the forward):
+//   own   A flags >= gmax - t - 1      dgates_{t+1} of this layer is published (flag = steps published = gmax - t after step t)
+//   upper X flags >= gmax - t          the layer above has published its step t
+//   lower X flags >= gmax - t - 4      the layer below has finished step t + 4, whose ring-X epoch this step's publish overwrites
+// (the lowest layer stores no ring X and raises its X flags as a progress report only).
+// =====================================================================================================================
+// The cell derivatives of one ACTIVE step with contraction pinned off: the UT = 1 and UT = 2 instantiations must produce the same
+// bits (tests compare them), and left to itself hipcc fuses these products and sums differently from one instantiation to the next.
+struct lp_cell_grad {
+    float di, df, dg, d_o, cc;
+};
+__device__ __forceinline__ lp_cell_grad lp_cell_bwd_fast(float dh_state, float dc_state, float g_in, float s_i, float s_f, float s_g, float s_o,
+                                                         float c_prev, float c_new) {
+#pragma clang fp contract(off)
+    lp_cell_grad r;
+    const float dh = dh_state + g_in;
+    const float tc = 2.f * mg_sigmoid_fast(2.f * c_new) - 1.f;
+    const float dc = dc_state + dh * s_o * (1.f - tc * tc);
+    r.di = dc * s_g * s_i * (1.f - s_i);
+    r.df = dc * c_prev * s_f * (1.f - s_f);
+    r.dg = dc * s_i * (1.f - s_g * s_g);
+    r.d_o = dh * tc * s_o * (1.f - s_o);
+    r.cc = dc * s_f;
+    return r;
+}
+
+struct LstmPStackBwd {
+    mg_lstm_pstack_bwd_layer l[MG_LSTM_MAX_LAYERS];
+};
+
+template <int MT, int KS, int UT>
+__global__ __launch_bounds__(256, UT == 1 ? 2 : 1) void lstm_stack_bwd_persist_kernel(LstmPStackBwd a, const int64_t* __restrict__ seq_len, int B,
+                                                                                      int T, int H, int L, int G, int R, unsigned* sync,
+                                                                                      uint16_t* rings, int force_sc1) {
+    __shared__ float red[4][2][UT][MT][GT * GT];
+    __shared__ __attribute__((aligned(16))) uint16_t pub[UT][4][MT * GT][GT];
+    __shared__ __attribute__((aligned(16))) float res[UT][MT][4][GT * GT];
+    __shared__ int s_abort, s_xcd;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    const int n_ids = L * G;
+    const int id = blockIdx.x % n_ids, slot = blockIdx.x / n_ids;
+    const int layer = id / G, group = id - layer * G;
+    const int n16 = H / GT, n_slots = n16 / UT;
+    const int row0 = group * R;
+    const int nrows = min(R, B - row0);
+    if (slot >= n_slots || nrows <= 0) return;
+    const mg_lstm_pstack_bwd_layer& P = a.l[layer];
+    const bool top = layer + 1 == L;
+    const int j0 = slot * GT * UT;
+    const int G4 = 4 * H;
+    gu32* flags_a = (gu32*)sync + LPS_FLAGA_WORD + id * GP_SLOTS;
+    gu32* flags_x = (gu32*)sync + LPS_FLAGX_WORD + id * GP_SLOTS;
+    gu32* flags_up = !top ? flags_x + G * GP_SLOTS : (gu32*)nullptr;
+    gu32* flags_lo = layer > 0 ? flags_x - G * GP_SLOTS : (gu32*)nullptr;
+    gu32* status = (gu32*)sync + GP_FLAG_WORDS;
+    if (tid == 0) s_abort = 0;
+    const int one_xcd = force_sc1 ? 0 : gp_group_on_one_xcd((gu32*)sync + LPS_XCC_WORD + id * GP_SLOTS, slot, n_slots, tid, &s_xcd);
+    if (one_xcd < 0) {
+        if (tid == 0) __hip_atomic_store(status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    int gmax = 0;
+    for (int r = 0; r < nrows; ++r) {
+        const int64_t n = seq_len ? seq_len[row0 + r] : (int64_t)T;
+        gmax = max(gmax, (int)(n < T ? n : T));
+    }
+    // wave w contracts over gate w: columns [w H, (w + 1) H) of the gate-gradient rows, 32 per MFMA, lane (li, q) holds 8 of them
+    const int gbase = wave * H + 8 * q;
+    gbf8 fhh[UT][KS], fih[UT][KS];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+        const uint16_t* wp = P.w_hh_t_bf + (size_t)(j0 + GT * u + li) * P.ldt + gbase;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            fhh[u][i] = *reinterpret_cast<const gbf8*>(wp + 32 * i);
+            fih[u][i] = fhh[u][i];
+        }
+        if (!top) {
+            const uint16_t* wq = P.w_ih_up_t_bf + (size_t)(j0 + GT * u + li) * P.ldt_up + gbase;
+#pragma unroll
+            for (int i = 0; i < KS; ++i) fih[u][i] = *reinterpret_cast<const gbf8*>(wq + 32 * i);
+        }
+    }
+    const unsigned par_bytes = (unsigned)(G * n16 * R * 128);
+    const unsigned x_base = (unsigned)L * 2 * par_bytes;
+    const auto rs_ring = __builtin_amdgcn_make_buffer_rsrc((void*)rings, 0, (int)((2 + LPS_XDEPTH) * par_bytes * L), 0x00020000);
+    const unsigned ring_own = (unsigned)layer * 2 * par_bytes;
+    const unsigned ring_x = x_base + (unsigned)layer * LPS_XDEPTH * par_bytes;
+    const unsigned ring_up = x_base + (unsigned)(top ? layer : layer + 1) * LPS_XDEPTH * par_bytes;
+    const unsigned rd_base = (unsigned)((((group * n16 + (q >> 1)) * 4 + wave) * R) * 32 + 16 * (q & 1));
+    const unsigned rd_kstep = (unsigned)(2 * 4 * R * 32);
+    const unsigned wr_base = (unsigned)(((group * n16 + slot * UT) * R) * 128);
+
+    const int bl = tid >> 4, jl = tid & 15;
+    float carry_h[MT][UT], carry_c[MT][UT];
+    int len[MT];
+    bool mine[MT];
+    const float *p_sv[MT], *p_c[MT], *p_g[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        mine[m] = 16 * m + bl < nrows;
+        const int b = row0 + (mine[m] ? 16 * m + bl : 0);
+        len[m] = seq_len ? (int)min((int64_t)T, seq_len[b]) : T;
+        p_sv[m] = P.saved + (size_t)b * T * 4 * H + j0 + jl;
+        p_c[m] = P.cstate + (size_t)b * (T + 1) * H + j0 + jl;
+        p_g[m] = (top && P.grad_out) ? P.grad_out + (size_t)b * T * H + j0 + jl : (const float*)nullptr;
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            carry_h[m][u] = P.grad_hn ? P.grad_hn[(size_t)b * H + j0 + GT * u + jl] : 0.f;
+            carry_c[m][u] = P.grad_cn ? P.grad_cn[(size_t)b * H + j0 + GT * u + jl] : 0.f;
+        }
+    }
+    for (int t = T - 1; t >= gmax; --t) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            if (mine[m]) {
+                const size_t row = (size_t)(row0 + 16 * m + bl) * T + t;
+#pragma unroll
+                for (int u = 0; u < UT; ++u)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (P.dgates) P.dgates[row * G4 + g * H + j0 + GT * u + jl] = 0.f;
+                        P.dgates_bf[row * G4 + g * H + j0 + GT * u + jl] = 0;
+                    }
+            }
+    }
+    // cell operands of step gmax - 1 (c_new of a step is c_prev of the step after it: carried over in a register)
+    float s_g4[MT][UT][4], c_prev[MT][UT], c_new[MT][UT], gout[MT][UT];
+    {
+        const int t0 = gmax > 0 ? gmax - 1 : 0;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int u = 0; u < UT; ++u) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) s_g4[m][u][g] = p_sv[m][(size_t)t0 * 4 * H + g * H + GT * u];
+                c_prev[m][u] = p_c[m][(size_t)t0 * H + GT * u];
+                c_new[m][u] = p_c[m][(size_t)(t0 + 1) * H + GT * u];
+                gout[m][u] = p_g[m] ? p_g[m][(size_t)t0 * H + GT * u] : 0.f;
+            }
+    }
+    __syncthreads();
+
+    // 16-byte pieces of the slot's published tile ([u][gate][R][2 halves]): piece lane + 64 k of every step, decomposed once
+    constexpr int PIECES = 2 * UT * MT;
+    const int n_pieces = UT * 8 * R;
+    int pc_lds[PIECES];
+    unsigned pc_sh[PIECES];
+    unsigned pc_ok = 0;
+#pragma unroll
+    for (int k = 0; k < PIECES; ++k) {
+        const int pc = lane + 64 * k;
+        const int u = pc / (8 * R), rem = pc - u * 8 * R, gate = rem / (2 * R), rem2 = rem - gate * 2 * R, rrow = rem2 >> 1, half = rem2 & 1;
+        if (pc < n_pieces && rrow < nrows) pc_ok |= 1u << k;
+        pc_lds[k] = ((min(u, UT - 1) * 4 + gate) * MT * GT + rrow) * GT + 8 * half;
+        pc_sh[k] = (unsigned)(((size_t)(row0 + rrow) * T) * G4 + gate * H + j0 + GT * u + 8 * half);
+    }
+    auto raise_x = [&](int steps) {                   // wave 1: the write-through stores of the step before have landed by now
+        if (wave == 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(flags_x + slot, (unsigned)steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    unsigned seen_up = 0, seen_lo = 0;
+
+    for (int t = gmax - 1; t >= -1; --t) {
+        const bool need_mm = t + 1 < gmax;
+        const bool need_x = !top && t >= 0;
+        if (wave == 0 && !lps_wait(flags_a, need_mm ? (unsigned)(gmax - t - 1) : 0u, need_x ? flags_up : (gu32*)nullptr, gmax - t, seen_up,
+                                   (layer > 0 && t >= 0) ? flags_lo : (gu32*)nullptr, gmax - t - LPS_XDEPTH, seen_lo, n_slots, lane))
+            s_abort = 1;
+        gp_lds_barrier();
+        if (s_abort) {
+            if (tid == 0) __hip_atomic_store(status, 7u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        // jobs of the step: (item tile m, product p) with p = 0: own gate gradients of step t + 1 x W_hh^T, p = 1: the upper layer's
+        // of step t x its W_ih^T.  One job's 16-row tile is in flight in raw[]; the next job's loads go into each register as the
+        // MFMAs free it.
+        const unsigned own0 = ring_own + ((t + 1) & 1) * par_bytes, up0 = ring_up + (unsigned)(t & (LPS_XDEPTH - 1)) * par_bytes;
+        auto job_off = [&](int m, int p) {
+            const bool valid = 16 * m + li < nrows;
+            return (p == 0 ? own0 : up0) + rd_base + (unsigned)((valid ? 16 * m + li : 0) * 32);
+        };
+        u32x4 raw[KS];
+        if (need_mm || need_x) {
+            const unsigned o0 = job_off(0, need_mm ? 0 : 1);
+#pragma unroll
+            for (int i = 0; i < KS; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ring, o0 + i * rd_kstep, 0, 16);
+        }
+        // the next step's cell operands (first touch: HBM latency), requested behind the first hand-off tile
+        float s_g41[MT][UT][4], c_prev1[MT][UT], gout1[MT][UT];
+        {
+            const int t1 = t > 0 ? t - 1 : 0;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int u = 0; u < UT; ++u) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) s_g41[m][u][g] = p_sv[m][(size_t)t1 * 4 * H + g * H + GT * u];
+                    c_prev1[m][u] = p_c[m][(size_t)t1 * H + GT * u];
+                    gout1[m][u] = p_g[m] ? p_g[m][(size_t)t1 * H + GT * u] : 0.f;
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                if (p == 0 ? !need_mm : !need_x) continue;
+                // the job after this one
+                bool has_next;
+                unsigned nxt = 0;
+                if (p == 0 && need_x) {
+                    has_next = true;
+                    nxt = job_off(m, 1);
+                } else {
+                    has_next = m + 1 < MT;
+                    nxt = job_off(m + 1 < MT ? m + 1 : m, need_mm ? 0 : 1);
+                }
+                f32x4 acc[UT][2];
+#pragma unroll
+                for (int u = 0; u < UT; ++u) acc[u][0] = acc[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < KS; ++i) {
+                    const gbf8 av = as_bf8(raw[i]);
+#pragma unroll
+                    for (int u = 0; u < UT; ++u)
+                        acc[u][i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, p == 0 ? fhh[u][i] : fih[u][i], acc[u][i & 1], 0, 0, 0);
+                    if (has_next) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ring, nxt + i * rd_kstep, 0, 16);
+                }
+#pragma unroll
+                for (int u = 0; u < UT; ++u) {
+                    const f32x4 s = acc[u][0] + acc[u][1];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[wave][p][u][m][(4 * q + r) * GT + li] = s[r];
+                }
+            }
+        }
+        if (need_mm && layer > 0) raise_x(gmax - t - 1);          // step t + 1's ring-X stores were issued a step ago
+        gp_lds_barrier();
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int e = bl * GT + jl;
+#pragma unroll
+            for (int u = 0; u < UT; ++u) {
+                const float dh_state = need_mm ? carry_h[m][u] + ((red[0][0][u][m][e] + red[1][0][u][m][e]) + (red[2][0][u][m][e] + red[3][0][u][m][e]))
+                                               : carry_h[m][u];
+                const float g_in = need_x ? ((red[0][1][u][m][e] + red[1][1][u][m][e]) + (red[2][1][u][m][e] + red[3][1][u][m][e])) : gout[m][u];
+                float di = 0.f, df = 0.f, dg = 0.f, d_o = 0.f, ch = dh_state, cc = carry_c[m][u];
+                if (t >= 0 && t < len[m]) {
+                    const lp_cell_grad cg = lp_cell_bwd_fast(dh_state, carry_c[m][u], g_in, s_g4[m][u][0], s_g4[m][u][1], s_g4[m][u][2],
+                                                             s_g4[m][u][3], c_prev[m][u], c_new[m][u]);
+                    di = cg.di;
+                    df = cg.df;
+                    dg = cg.dg;
+                    d_o = cg.d_o;
+                    ch = 0.f;                 // all of dh_{t-1} comes through the matmul with the gates of this step
+                    cc = cg.cc;
+                }
+                carry_h[m][u] = ch;
+                carry_c[m][u] = cc;
+                if (P.dgates) {
+                    res[u][m][0][e] = di;
+                    res[u][m][1][e] = df;
+                    res[u][m][2][e] = dg;
+                    res[u][m][3][e] = d_o;
+                }
+                pub[u][0][16 * m + bl][jl] = mg_f2bf(di);
+                pub[u][1][16 * m + bl][jl] = mg_f2bf(df);
+                pub[u][2][16 * m + bl][jl] = mg_f2bf(dg);
+                pub[u][3][16 * m + bl][jl] = mg_f2bf(d_o);
+            }
+        }
+        if (t < 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                if (mine[m]) {
+#pragma unroll
+                    for (int u = 0; u < UT; ++u) {
+                        P.dh0[(size_t)(row0 + 16 * m + bl) * H + j0 + GT * u + jl] = carry_h[m][u];
+                        P.dc0[(size_t)(row0 + 16 * m + bl) * H + j0 + GT * u + jl] = carry_c[m][u];
+                    }
+                }
+            break;
+        }
+        gp_lds_barrier();
+        // wave 0: ring A + flag A; wave 1: ring X (layers above the lowest); wave 2: the bf16 shadow the weight-gradient GEMMs read;
+        // wave 3: the optional fp32 copy
+        if (wave <= 2) {
+#pragma unroll
+            for (int k = 0; k < PIECES; ++k) {
+                const int pc = lane + 64 * k;
+                if ((pc_ok >> k) & 1u) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(&pub[0][0][0][0] + pc_lds[k]);
+                    if (wave == 0) {
+                        const unsigned off = ring_own + (unsigned)(t & 1) * par_bytes + wr_base + (unsigned)pc * 16;
+                        if (one_xcd)
+                            __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 0);
+                        else
+                            __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 16);
+                    } else if (wave == 1) {
+                        if (layer > 0)
+                            __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, ring_x + (unsigned)(t & (LPS_XDEPTH - 1)) * par_bytes + wr_base + (unsigned)pc * 16, 0, 16);
+                    } else {
+                        *reinterpret_cast<u32x4*>(P.dgates_bf + (size_t)pc_sh[k] + (size_t)t * G4) = v;
+                    }
+                }
+            }
+            if (wave == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) gp_store_flag(flags_a + slot, (unsigned)(gmax - t), one_xcd);
+            }
+            if (wave == 1 && layer == 0 && lane == 0)         // progress report only
+                __hip_atomic_store(flags_x + slot, (unsigned)(gmax - t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (P.dgates) {
+            for (int job = lane; job < UT * MT * 4 * 64; job += 64) {       // 16-byte stores: (u, m, gate, 16 rows x 4 column quads)
+                const int e4 = job & 63, k = job >> 6, gate = k & 3, m = (k >> 2) % MT, u = k / (4 * MT);
+                const int rb = e4 >> 2, c4 = 4 * (e4 & 3);
+                if (16 * m + rb < nrows)
+                    *reinterpret_cast<f32x4*>(P.dgates + ((size_t)(row0 + 16 * m + rb) * T + t) * G4 + gate * H + j0 + GT * u + c4) =
+                        *reinterpret_cast<const f32x4*>(&res[u][m][gate][rb * GT + c4]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int u = 0; u < UT; ++u) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) s_g4[m][u][g] = s_g41[m][u][g];
+                c_new[m][u] = c_prev[m][u];
+                c_prev[m][u] = c_prev1[m][u];
+                gout[m][u] = gout1[m][u];
+            }
+    }
+    if (gmax > 0 && layer > 0) raise_x(gmax);          // the last step's ring-X stores (nobody below waits for more)
+}
+
 extern "C" {
 
 int mg_lstm_persist_supported(int B, int T, int H) {
@@ -979,6 +1331,93 @@ int mg_lstm_pstack_fwd_bf16(const mg_lstm_pstack_layer* layers, int L, const int
         LPS_FWD_KS(2)
     }
     MG_CHECK_LAUNCH("mg_lstm_pstack_fwd_bf16");
+    return MG_OK;
+}
+
+
+static int lpsb_plan(int B, int H, int L, int* G_out, int* UT_out) {
+    // units per slot: 32 (UT = 2, one workgroup per CU) unless MG_TUNE_LSTM_BWD_STACK = 1 asks for 16 (two per CU); the largest G in
+    // {8, 4, 2, 1} whose L G H / (16 UT) workgroups are all resident, with at most 32 items per group and L G <= 64 flag rows
+    for (int UT = g_mg_tuning[MG_TUNE_LSTM_BWD_STACK] == 1 ? 1 : 2; UT >= 1; --UT)
+        for (int G = 8; G >= 1; G >>= 1) {
+            const long wgs = (long)L * G * (H / (GT * UT));
+            if (wgs > (UT == 2 ? 256 : 512) || L * G > LPS_MAX_IDS || !gp_device_holds(UT == 2 ? 2 * wgs : wgs)) continue;
+            if (mg_ceil_div(B, G) > 32) break;
+            *G_out = G;
+            *UT_out = UT;
+            return 1;
+        }
+    return 0;
+}
+
+int mg_lstm_pstack_bwd_supported(int B, int T, int H, int L) {
+    if (B <= 0 || T <= 0 || H <= 0 || L < 2 || L > MG_LSTM_MAX_LAYERS) return 0;
+    if (H % 128 != 0 || H > 128 * GP_KSTEPS) return 0;
+    if ((long)B * T * 4 * H >= 2147483647L) return 0;
+    int G, UT;
+    return lpsb_plan(B, H, L, &G, &UT);
+}
+
+size_t mg_lstm_pstack_bwd_workspace_bytes(int B, int H, int L) {
+    int G, UT;
+    if (!lpsb_plan(B, H, L, &G, &UT)) return 0;
+    return LPS_RING_OFFSET + (size_t)L * (2 + LPS_XDEPTH) * G * mg_ceil_div(B, G) * H * 8;
+}
+
+int mg_lstm_pstack_bwd_bf16(const mg_lstm_pstack_bwd_layer* layers, int L, const int64_t* seq_len, int B, int T, int H, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+    MG_CHECK_ARG(layers && mg_lstm_pstack_bwd_supported(B, T, H, L), "mg_lstm_pstack_bwd_bf16: unsupported shape (B=%d T=%d H=%d L=%d)", B, T, H, L);
+    LstmPStackBwd a;
+    for (int l = 0; l < L; ++l) {
+        a.l[l] = layers[l];
+        const mg_lstm_pstack_bwd_layer& p = layers[l];
+        MG_CHECK_ARG(p.cstate && p.saved && p.w_hh_t_bf && p.dgates_bf && p.dh0 && p.dc0 && p.ldt >= 4 * H && p.ldt % 8 == 0,
+                     "mg_lstm_pstack_bwd_bf16: layer %d: bad arguments", l);
+        MG_CHECK_ARG(l + 1 == L || (p.w_ih_up_t_bf && p.ldt_up >= 4 * H && p.ldt_up % 8 == 0),
+                     "mg_lstm_pstack_bwd_bf16: layer %d: the transposed W_ih of the layer above is missing", l);
+        MG_CHECK_ARG((((uintptr_t)p.w_hh_t_bf | (uintptr_t)p.w_ih_up_t_bf | (uintptr_t)p.dgates_bf | (uintptr_t)p.dgates) % 16) == 0,
+                     "mg_lstm_pstack_bwd_bf16: layer %d: weight and gate-gradient buffers must be 16-byte aligned", l);
+    }
+    if (!workspace || workspace_bytes < mg_lstm_pstack_bwd_workspace_bytes(B, H, L) || ((uintptr_t)workspace % 16) != 0) {
+        mg_set_error("mg_lstm_pstack_bwd_bf16: 16-byte aligned workspace of %zu bytes needed, got %zu", mg_lstm_pstack_bwd_workspace_bytes(B, H, L),
+                     workspace_bytes);
+        return MG_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync((unsigned*)workspace + LPS_FLAGA_WORD, 0, (size_t)3 * LPS_MAX_IDS * GP_SLOTS * sizeof(unsigned), st) != hipSuccess) {
+        mg_set_error("mg_lstm_pstack_bwd_bf16: memset failed");
+        return MG_ELAUNCH;
+    }
+    int G = 0, UT = 0;
+    lpsb_plan(B, H, L, &G, &UT);
+    const int R = (int)mg_ceil_div(B, G);
+    const unsigned grid = (unsigned)(L * G * (H / (GT * UT)));
+    uint16_t* rings = (uint16_t*)((char*)workspace + LPS_RING_OFFSET);
+    const int force = g_mg_tuning[MG_TUNE_GRU_HANDOFF] == 1;
+#define LPS_BWD(MT, KS, UT_)                                                                                                               \
+    hipLaunchKernelGGL((lstm_stack_bwd_persist_kernel<MT, KS, UT_>), dim3(grid), dim3(256), 0, st, a, seq_len, B, T, H, L, G, R, (unsigned*)workspace, \
+                       rings, force)
+#define LPS_BWD_KS(MT, UT_)                    \
+    switch (H / 128) {                         \
+        case 1: LPS_BWD(MT, 4, UT_); break;    \
+        case 2: LPS_BWD(MT, 8, UT_); break;    \
+        case 3: LPS_BWD(MT, 12, UT_); break;   \
+        default: LPS_BWD(MT, 16, UT_); break;  \
+    }
+    if (UT == 2) {
+        if (R <= 16) {
+            LPS_BWD_KS(1, 2)
+        } else {
+            LPS_BWD_KS(2, 2)
+        }
+    } else {
+        if (R <= 16) {
+            LPS_BWD_KS(1, 1)
+        } else {
+            LPS_BWD_KS(2, 1)
+        }
+    }
+    MG_CHECK_LAUNCH("mg_lstm_pstack_bwd_bf16");
     return MG_OK;
 }
 

@@ -702,12 +702,18 @@ class LSTMFn(torch.autograd.Function):
                 dw_ih, dw_hh, db, db.clone())
 
 
+# False (MORGANA_LSTM_STACK_BACKWARD=0): the stack's backward runs layer by layer (one persistent launch + three GEMMs per layer)
+LSTM_STACK_BACKWARD = os.environ.get('MORGANA_LSTM_STACK_BACKWARD', '1') != '0'
+
+
 class LSTMStackPersistFn(torch.autograd.Function):
     """L stacked single-layer LSTMs (the 8 x RecurrentCuDNNWrapper(nn.LSTM(512, 512)) of models/RNN_SPSS.py:36-37, or one
     multi-layer nn.LSTM) in bf16 mode: the forward of the whole stack is ONE persistent launch, a wavefront over (layer, time)
-    (csrc/lstm_persist.hip, mg_lstm_pstack_fwd_bf16); the backward runs the layers top-down, each as one persistent launch
-    (mg_lstm_bwd_persist_bf16) between the weight-gradient and input-gradient GEMMs.  Same results as L chained LSTMFn calls
-    up to the summation order of the fused input projection.
+    (csrc/lstm_persist.hip, mg_lstm_pstack_fwd_bf16), and so is the backward (mg_lstm_pstack_bwd_bf16: the same wavefront run down in
+    time and through the layers, the gradient a layer hands to the one below computed inside the step), followed by the weight-gradient
+    GEMMs; where that launch does not cover the shape the layers run top-down, each as one persistent launch (mg_lstm_bwd_persist_bf16)
+    between its weight-gradient and input-gradient GEMMs.  Same results as L chained LSTMFn calls up to the summation order of the
+    in-step products.
 
     forward(ctx, x (B,T,I), seq_len, h0s, c0s ((L,B,H) or None), *params) with params = w_ih, w_hh, b_ih, b_hh per layer;
     returns (outputs of the top layer (B,T,H), h_n (L,B,H), c_n (L,B,H))."""
@@ -753,9 +759,28 @@ class LSTMStackPersistFn(torch.autograd.Function):
         next_rows = state_rows(b, t, dev, shift=1)                        # h_t: the input of the layer above at step t
         g_out = grad_out.contiguous() if grad_out is not None else torch.zeros((b, t, hid), dtype=torch.float32, device=dev)
         grads = [None] * (4 * n_layers)
+        dx = None
+        if LSTM_STACK_BACKWARD and ops.lstm_pstack_bwd_ok(b, t, hid, n_layers):
+            # one wavefront launch for every layer's recurrence and the input gradients between the layers, then the weight gradients
+            g_hn = [grad_hn[l] for l in range(n_layers)] if grad_hn is not None else None
+            g_cn = [grad_cn[l] for l in range(n_layers)] if grad_cn is not None else None
+            _, dg_bfs, dh0, dc0 = ops.lstm_pstack_bwd(g_out, g_hn, g_cn, cstate, saved, w_ih, w_hh, seq_len, b, t, hid)
+            for l in range(n_layers):
+                dg_bf = dg_bfs[l].view(m, 4 * hid)
+                if l == 0:
+                    dw_ih, db = ops.linear_wgrad_bf16(dg_bf, x_saved, None, m, 4 * hid, i_dim)
+                else:
+                    dw_ih, db = ops.linear_wgrad_bf16(dg_bf, hstate_bf[l - 1].view(b * (t + 1), hid), next_rows, m, 4 * hid, hid)
+                dw_hh, _ = ops.linear_wgrad_bf16(dg_bf, hstate_bf[l].view(b * (t + 1), hid), prev_rows, m, 4 * hid, hid, want_bias=False)
+                grads[4 * l:4 * l + 4] = [dw_ih, dw_hh, db, db.clone()]
+            if ctx.needs_input_grad[0]:
+                dx = ops.linear_dgrad_bf16(dg_bfs[0].view(m, 4 * hid), m, 4 * hid, ops.cast_transpose_bf16(w_ih[0]), i_dim, None, out_f32=True)
+                if dx.shape[1] != i_dim:
+                    dx = dx[:, :i_dim].contiguous()
+                dx = dx.view(b, t, i_dim)
+            return (dx, None, dh0 if ctx.has_h0 else None, dc0 if ctx.has_c0 else None, *grads)
         dh0 = torch.empty((n_layers, b, hid), dtype=torch.float32, device=dev)
         dc0 = torch.empty((n_layers, b, hid), dtype=torch.float32, device=dev)
-        dx = None
         for l in range(n_layers - 1, -1, -1):
             g_hn = grad_hn[l].reshape(b, hid).contiguous() if grad_hn is not None else None
             g_cn = grad_cn[l].reshape(b, hid).contiguous() if grad_cn is not None else None

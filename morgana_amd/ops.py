@@ -858,6 +858,58 @@ def lstm_pstack_fwd(xproj0, w_ih, w_hh, b_ih, b_hh, seq_len, h0s, c0s, b, t, h):
     return o, hstate, cstate, saved, hstate_bf
 
 
+def lstm_pstack_bwd_ok(b, t, h, n_layers):
+    """The whole-stack backward wavefront (mg_lstm_pstack_bwd_bf16) covers this shape."""
+    return PERSISTENT_RECURRENCE and bool(_lib.load().mg_lstm_pstack_bwd_supported(b, t, h, n_layers))
+
+
+def lstm_pstack_bwd(grad_out, grad_hn, grad_cn, cstate, saved, w_ih, w_hh, seq_len, b, t, h, want_f32=False):
+    """L stacked LSTM layers backward in one persistent launch.  grad_out (b,t,h) f32 = gradient of the TOP layer's outputs; grad_hn /
+    grad_cn None or per-layer lists of (b,h) tensors (None entries allowed); cstate[l], saved[l] from lstm_pstack_fwd; w_ih[l] (l >= 1)
+    and w_hh[l] f32.  Returns per-layer lists (dgates or None, dgates_bf) and dh0, dc0 as (L,b,h) tensors."""
+    lib = _lib.load()
+    dev = grad_out.device
+    n_layers = len(w_hh)
+    descs = (_lib.LstmPStackBwdLayer * n_layers)()
+    dgates, dgates_bf, keep = [], [], []
+    dh0 = torch.empty((n_layers, b, h), dtype=torch.float32, device=dev)
+    dc0 = torch.empty((n_layers, b, h), dtype=torch.float32, device=dev)
+    for l in range(n_layers):
+        d = descs[l]
+        wt = cast_transpose_bf16(w_hh[l])                                # (h, 4h)
+        keep.append(wt)
+        d.w_hh_t_bf, d.ldt = wt.data_ptr(), wt.shape[1]
+        if l + 1 < n_layers:
+            wu = cast_transpose_bf16(w_ih[l + 1])                        # (h, 4h): the layer above reads this layer's outputs
+            keep.append(wu)
+            d.w_ih_up_t_bf, d.ldt_up = wu.data_ptr(), wu.shape[1]
+        else:
+            d.grad_out = grad_out.data_ptr()
+        for name, src in (('grad_hn', grad_hn), ('grad_cn', grad_cn)):
+            if src is not None and src[l] is not None:
+                g = _require(src[l].reshape(b, h), torch.float32, name)
+                keep.append(g)
+                setattr(d, name, g.data_ptr())
+        dg = torch.empty((b, t, 4 * h), dtype=torch.float32, device=dev) if want_f32 else None
+        dgb = torch.empty((b, t, 4 * h), dtype=torch.bfloat16, device=dev)
+        d.cstate, d.saved = cstate[l].data_ptr(), saved[l].data_ptr()
+        d.dgates, d.dgates_bf = (dg.data_ptr() if dg is not None else None), dgb.data_ptr()
+        d.dh0, d.dc0 = dh0[l].data_ptr(), dc0[l].data_ptr()
+        dgates.append(dg)
+        dgates_bf.append(dgb)
+    key = (dev, torch.cuda.current_stream().cuda_stream, 'pstack_bwd')
+    need = lib.mg_lstm_pstack_bwd_workspace_bytes(b, h, n_layers)
+    ws = _PERSIST_WORKSPACES.get(key)
+    if ws is None or ws.numel() < need:
+        if ws is not None:
+            check_persistent_status()
+        ws = torch.zeros(need, dtype=torch.uint8, device=dev)
+        _PERSIST_WORKSPACES[key] = ws
+    _lib.check(lib.mg_lstm_pstack_bwd_bf16(ctypes.cast(descs, ctypes.c_void_p), n_layers, _p(seq_len), b, t, h, _p(ws), ws.numel(),
+                                           _stream()), 'mg_lstm_pstack_bwd_bf16')
+    return dgates, dgates_bf, dh0, dc0
+
+
 def lstm_stack_fwd(descs, n_layers, seq_len, b, t, h, lag, s_begin, s_end):
     lib = _lib.load()
     _lib.check(lib.mg_lstm_stack_fwd_f32(ctypes.cast(descs, ctypes.c_void_p), n_layers, _p(seq_len), b, t, h, lag, s_begin, s_end,

@@ -438,3 +438,112 @@ def test_lstm_fp32_model_runs_on_persistent_recurrence_vs_oracle():
     out, (h, c) = utils.RecurrentCuDNNWrapper(lstm, precision='fp32')(dev(x_np), None, dev(sl_np))
     assert rel_err(out.detach().cpu().numpy(), want) < RTOL
     assert rel_err(h[1].detach().cpu().numpy(), hn[0]) < RTOL and rel_err(c[1].detach().cpu().numpy(), cn[0]) < RTOL
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+# The LSTM stack's backward as one wavefront launch (csrc/lstm_persist.hip, mg_lstm_pstack_bwd_bf16)
+@pytest.mark.gpu
+@pytest.mark.parametrize('b,t,i_dim,hid,n_layers', [(64, 70, 512, 512, 8), (64, 40, 96, 512, 3), (20, 30, 24, 128, 3), (9, 33, 40, 128, 2),
+                                                    (40, 25, 64, 384, 4)])
+def test_lstm_stack_backward_wavefront_vs_layer_by_layer(b, t, i_dim, hid, n_layers):
+    """The same forward (one wavefront launch), then the backward twice: as ONE wavefront launch over (layer, time) with the gradient a
+    layer hands to the layer below computed inside the step, and layer by layer (one persistent launch + the input-gradient GEMM per
+    layer).  bf16 operands and fp32 accumulation in both; the in-step products are summed in a different order than the GEMM's, so the
+    gradients agree to 5e-3 relative (measured ~1e-3), not bit for bit.  Ragged lengths with a full and a 1-step item, gradients on
+    the outputs and on every layer's final states, initial states given.  Both slot widths (32 units: one workgroup per CU, 16: two)
+    and both hand-off forms must give identical bits, run after run."""
+    assert ops.lstm_pstack_bwd_ok(b, t, hid, n_layers)
+    torch.manual_seed(3 * hid + n_layers)
+    x = torch.randn(b, t, i_dim, device=DEV, requires_grad=True)
+    sl_np = np.random.RandomState(b + t).randint(1, t + 1, size=b).astype(np.int64)
+    sl_np[0], sl_np[-1] = t, 1
+    seq_len = dev(sl_np)
+    params = []
+    for l in range(n_layers):
+        k = i_dim if l == 0 else hid
+        params += [torch.randn(4 * hid, k, device=DEV) / k ** 0.5, torch.randn(4 * hid, hid, device=DEV) / hid ** 0.5,
+                   torch.randn(4 * hid, device=DEV) * 0.1, torch.randn(4 * hid, device=DEV) * 0.1]
+    params = [p.requires_grad_(True) for p in params]
+    h0s = (torch.randn(n_layers, b, hid, device=DEV) * 0.5).requires_grad_(True)
+    c0s = (torch.randn(n_layers, b, hid, device=DEV) * 0.5).requires_grad_(True)
+    g_out = torch.randn(b, t, hid, device=DEV)
+    g_hn, g_cn = torch.randn(n_layers, b, hid, device=DEV), torch.randn(n_layers, b, hid, device=DEV)
+    leaves = [x, h0s, c0s] + params
+
+    def run(stack_backward):
+        for p in leaves:
+            p.grad = None
+        F_hip.LSTM_STACK_BACKWARD = stack_backward
+        try:
+            out, hn, cn = F_hip.LSTMStackPersistFn.apply(x, seq_len, h0s, c0s, *params)
+            ((out * g_out).sum() + (hn * g_hn).sum() + (cn * g_cn).sum()).backward()
+        finally:
+            F_hip.LSTM_STACK_BACKWARD = True
+        ops.check_persistent_status()
+        return [p.grad.detach().cpu().numpy().copy() for p in leaves]
+
+    want = run(False)
+    lib = _lib.load()
+    first = None
+    try:
+        for width, handoff in ((0, 0), (1, 0), (0, 1), (0, 0)):
+            lib.mg_set_tuning(3, width)
+            lib.mg_set_tuning(2, handoff)
+            got = run(True)
+            if first is None:
+                first = got
+                for k, (g, w) in enumerate(zip(got, want)):
+                    assert np.all(np.isfinite(g)), k
+                    assert rel_err(g, w) < 5e-3, (k, rel_err(g, w))
+            else:
+                for k, (g, w) in enumerate(zip(got, first)):
+                    np.testing.assert_array_equal(g, w, err_msg='gradient %d, slot width %d, hand-off %d' % (k, width, handoff))
+    finally:
+        lib.mg_set_tuning(3, 0)
+        lib.mg_set_tuning(2, 0)
+
+
+@pytest.mark.gpu
+def test_lstm_stack_backward_gate_gradients_and_fp32_copy():
+    """ops.lstm_pstack_bwd itself: per layer the bf16 gate gradients against ops.lstm_bwd_bf16 fed with the gradient the layer above hands
+    down (its gate gradients through W_ih), the optional fp32 copy rounds to the bf16 shadow, padded steps are exactly zero, no
+    final-state gradients (NULL pointers), groups whose items are all shorter than T, and NaN in `saved` / `grad_out` past an item's
+    length reaching nothing."""
+    b, t, hid, n_layers = 24, 21, 256, 3
+    assert ops.lstm_pstack_bwd_ok(b, t, hid, n_layers)
+    torch.manual_seed(11)
+    sl_np = np.random.RandomState(5).randint(1, t - 2, size=b).astype(np.int64)
+    sl_np[3] = t
+    seq_len = dev(sl_np)
+    w_ih = [torch.randn(4 * hid, hid, device=DEV) / hid ** 0.5 for _ in range(n_layers)]
+    w_hh = [torch.randn(4 * hid, hid, device=DEV) / hid ** 0.5 for _ in range(n_layers)]
+    b_ih = [torch.randn(4 * hid, device=DEV) * 0.1 for _ in range(n_layers)]
+    b_hh = [torch.randn(4 * hid, device=DEV) * 0.1 for _ in range(n_layers)]
+    xproj0 = torch.randn(b, t, 4 * hid, device=DEV)
+    _, _, cstate, saved, _ = ops.lstm_pstack_fwd(xproj0, w_ih, w_hh, b_ih, b_hh, seq_len, None, None, b, t, hid)
+    g_out = torch.randn(b, t, hid, device=DEV)
+    dgates, dgates_bf, dh0, dc0 = ops.lstm_pstack_bwd(g_out, None, None, cstate, saved, w_ih, w_hh, seq_len, b, t, hid, want_f32=True)
+    ops.check_persistent_status()
+    m = b * t
+    g = g_out
+    for l in range(n_layers - 1, -1, -1):
+        _, dh0_l, dc0_l, want_bf = ops.lstm_bwd_bf16(g, None, None, cstate[l], saved[l], w_hh[l], seq_len, b, t, hid, want_f32=False)
+        got, want = dgates_bf[l].float().cpu().numpy(), want_bf.float().cpu().numpy()
+        assert rel_err(got, want) < 1e-2, (l, rel_err(got, want))
+        assert rel_err(dh0[l].cpu().numpy(), dh0_l.cpu().numpy()) < 1e-2 and rel_err(dc0[l].cpu().numpy(), dc0_l.cpu().numpy()) < 1e-2
+        np.testing.assert_array_equal(dgates[l].to(torch.bfloat16).float().cpu().numpy(), got)
+        for i, n in enumerate(sl_np):
+            assert np.all(got[i, n:] == 0)
+        if l > 0:
+            # what the layer hands down, from the WAVEFRONT's gate gradients (so that errors do not compound over the layers)
+            g = ops.linear_dgrad_bf16(dgates_bf[l].view(m, 4 * hid), m, 4 * hid, ops.cast_transpose_bf16(w_ih[l]), hid, None,
+                                      out_f32=True)[:, :hid].contiguous().view(b, t, hid)
+    # the contract of include/morgana_hip.h: saved[b, t, :] past an item's length is unspecified and must not reach any result
+    past = (torch.arange(t, device=DEV)[None, :] >= seq_len[:, None])[:, :, None]
+    nan = torch.full((), float('nan'), device=DEV)
+    bad = [torch.where(past, nan, s) for s in saved]
+    _, dgates_bf2, dh02, dc02 = ops.lstm_pstack_bwd(torch.where(past, nan, g_out), None, None, cstate, bad, w_ih, w_hh, seq_len, b, t, hid)
+    ops.check_persistent_status()
+    for l in range(n_layers):
+        assert torch.equal(dgates_bf2[l], dgates_bf[l]), l
+    assert torch.equal(dh02, dh0) and torch.equal(dc02, dc0)
