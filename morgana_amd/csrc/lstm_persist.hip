@@ -841,6 +841,50 @@ __global__ __launch_bounds__(256, 2) void lstm_stack_fwd_persist_kernel(LstmPSta
 //   lower X flags >= gmax - t - 4      the layer below has finished step t + 4, whose ring-X epoch this step's publish overwrites
 // (the lowest layer stores no ring X and raises its X flags as a progress report only).
 // =====================================================================================================================
+// VW-wide fp32 vectors of the backward stack kernel's cell phase (VW = 1, 2 or 4 consecutive hidden units): one load / store each
+template <int VW>
+struct lp_vec {
+    float v[VW] = {};
+};
+template <int VW>
+__device__ __forceinline__ lp_vec<VW> lp_ld(const float* p) {
+    lp_vec<VW> r;
+    if constexpr (VW == 4) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(p);
+        r.v[0] = x[0], r.v[1] = x[1], r.v[2] = x[2], r.v[3] = x[3];
+    } else if constexpr (VW == 2) {
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        const f32x2_t x = *reinterpret_cast<const f32x2_t*>(p);
+        r.v[0] = x[0], r.v[1] = x[1];
+    } else {
+        r.v[0] = *p;
+    }
+    return r;
+}
+template <int VW>
+__device__ __forceinline__ void lp_st(float* p, const lp_vec<VW>& a) {
+    if constexpr (VW == 4) {
+        *reinterpret_cast<f32x4*>(p) = f32x4{a.v[0], a.v[1], a.v[2], a.v[3]};
+    } else if constexpr (VW == 2) {
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<f32x2_t*>(p) = f32x2_t{a.v[0], a.v[1]};
+    } else {
+        *p = a.v[0];
+    }
+}
+template <int VW>
+__device__ __forceinline__ void lp_st_bf(uint16_t* p, const lp_vec<VW>& a) {
+    if constexpr (VW == 4) {
+        typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2_t*>(p) = u32x2_t{(unsigned)mg_f2bf(a.v[0]) | ((unsigned)mg_f2bf(a.v[1]) << 16),
+                                                 (unsigned)mg_f2bf(a.v[2]) | ((unsigned)mg_f2bf(a.v[3]) << 16)};
+    } else if constexpr (VW == 2) {
+        *reinterpret_cast<unsigned*>(p) = (unsigned)mg_f2bf(a.v[0]) | ((unsigned)mg_f2bf(a.v[1]) << 16);
+    } else {
+        *p = mg_f2bf(a.v[0]);
+    }
+}
+
 // The cell derivatives of one ACTIVE step with contraction pinned off: the UT = 1 and UT = 2 instantiations must produce the same
 // bits (tests compare them), and left to itself hipcc fuses these products and sums differently from one instantiation to the next.
 struct lp_cell_grad {
@@ -929,53 +973,41 @@ __global__ __launch_bounds__(256, UT == 1 ? 2 : 1) void lstm_stack_bwd_persist_k
     const unsigned rd_kstep = (unsigned)(2 * 4 * R * 32);
     const unsigned wr_base = (unsigned)(((group * n16 + slot * UT) * R) * 128);
 
-    const int bl = tid >> 4, jl = tid & 15;
-    float carry_h[MT][UT], carry_c[MT][UT];
-    int len[MT];
-    bool mine[MT];
-    const float *p_sv[MT], *p_c[MT], *p_g[MT];
+    // Cell phase: a thread owns VW = MT UT consecutive hidden units of ONE item row of ONE (item tile, unit tile) pair, so that every
+    // LDS and memory access of the phase is one VW-wide vector (VW = 4: b128 reads of the partial sums, 8-byte bf16 publishes).
+    constexpr int VW = MT * UT;                       // 1, 2 or 4
+    constexpr int CPR = GT / VW;                      // threads per row of a 16-unit tile
+    const int ctile = tid / (256 / VW), cwithin = tid - ctile * (256 / VW);
+    const int cm = ctile / UT, cu = ctile - cm * UT;  // item tile, unit tile
+    const int crow = cwithin / CPR, cc0 = (cwithin - crow * CPR) * VW;
+    const int ce = crow * GT + cc0;                   // element offset inside a 16 x 16 tile
+    const bool mine = 16 * cm + crow < nrows;
+    const int cb = row0 + (mine ? 16 * cm + crow : 0);
+    const int cj = j0 + GT * cu + cc0;                // first hidden unit of the thread
+    const int len = seq_len ? (int)min((int64_t)T, seq_len[cb]) : T;
+    const float* p_sv = P.saved + (size_t)cb * T * 4 * H + cj;
+    const float* p_c = P.cstate + (size_t)cb * (T + 1) * H + cj;
+    const float* p_g = (top && P.grad_out) ? P.grad_out + (size_t)cb * T * H + cj : (const float*)nullptr;
+    lp_vec<VW> carry_h = P.grad_hn ? lp_ld<VW>(P.grad_hn + (size_t)cb * H + cj) : lp_vec<VW>{};
+    lp_vec<VW> carry_c = P.grad_cn ? lp_ld<VW>(P.grad_cn + (size_t)cb * H + cj) : lp_vec<VW>{};
+    if (mine)
+        for (int t = T - 1; t >= gmax; --t) {
+            const size_t row = (size_t)cb * T + t;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        mine[m] = 16 * m + bl < nrows;
-        const int b = row0 + (mine[m] ? 16 * m + bl : 0);
-        len[m] = seq_len ? (int)min((int64_t)T, seq_len[b]) : T;
-        p_sv[m] = P.saved + (size_t)b * T * 4 * H + j0 + jl;
-        p_c[m] = P.cstate + (size_t)b * (T + 1) * H + j0 + jl;
-        p_g[m] = (top && P.grad_out) ? P.grad_out + (size_t)b * T * H + j0 + jl : (const float*)nullptr;
-#pragma unroll
-        for (int u = 0; u < UT; ++u) {
-            carry_h[m][u] = P.grad_hn ? P.grad_hn[(size_t)b * H + j0 + GT * u + jl] : 0.f;
-            carry_c[m][u] = P.grad_cn ? P.grad_cn[(size_t)b * H + j0 + GT * u + jl] : 0.f;
-        }
-    }
-    for (int t = T - 1; t >= gmax; --t) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-            if (mine[m]) {
-                const size_t row = (size_t)(row0 + 16 * m + bl) * T + t;
-#pragma unroll
-                for (int u = 0; u < UT; ++u)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        if (P.dgates) P.dgates[row * G4 + g * H + j0 + GT * u + jl] = 0.f;
-                        P.dgates_bf[row * G4 + g * H + j0 + GT * u + jl] = 0;
-                    }
+            for (int g = 0; g < 4; ++g) {
+                if (P.dgates) lp_st<VW>(P.dgates + row * G4 + g * H + cj, lp_vec<VW>{});
+                lp_st_bf<VW>(P.dgates_bf + row * G4 + g * H + cj, lp_vec<VW>{});
             }
-    }
-    // cell operands of step gmax - 1 (c_new of a step is c_prev of the step after it: carried over in a register)
-    float s_g4[MT][UT][4], c_prev[MT][UT], c_new[MT][UT], gout[MT][UT];
+        }
+    // cell operands of step gmax - 1 (c_new of a step is c_prev of the step after it: carried over in registers)
+    lp_vec<VW> s_g4[4], c_prev, c_new, gout;
     {
         const int t0 = gmax > 0 ? gmax - 1 : 0;
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int u = 0; u < UT; ++u) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) s_g4[m][u][g] = p_sv[m][(size_t)t0 * 4 * H + g * H + GT * u];
-                c_prev[m][u] = p_c[m][(size_t)t0 * H + GT * u];
-                c_new[m][u] = p_c[m][(size_t)(t0 + 1) * H + GT * u];
-                gout[m][u] = p_g[m] ? p_g[m][(size_t)t0 * H + GT * u] : 0.f;
-            }
+        for (int g = 0; g < 4; ++g) s_g4[g] = lp_ld<VW>(p_sv + (size_t)t0 * 4 * H + g * H);
+        c_prev = lp_ld<VW>(p_c + (size_t)t0 * H);
+        c_new = lp_ld<VW>(p_c + (size_t)(t0 + 1) * H);
+        gout = p_g ? lp_ld<VW>(p_g + (size_t)t0 * H) : lp_vec<VW>{};
     }
     __syncthreads();
 
@@ -1000,62 +1032,35 @@ __global__ __launch_bounds__(256, UT == 1 ? 2 : 1) void lstm_stack_bwd_persist_k
         }
     };
     unsigned seen_up = 0, seen_lo = 0;
+#ifdef MG_STAMPS
+    unsigned long long ta = 0, tb = 0, ts0 = 0, ts1 = 0, tr0 = 0, tr1 = 0, sum_poll = 0, sum_load = 0, sum_mm = 0, sum_cell = 0, sum_pub = 0;
+    MG_STAMP(ts0);
+    MG_STAMP_REAL(tr0);
+#endif
 
     for (int t = gmax - 1; t >= -1; --t) {
         const bool need_mm = t + 1 < gmax;
         const bool need_x = !top && t >= 0;
-        if (wave == 0 && !lps_wait(flags_a, need_mm ? (unsigned)(gmax - t - 1) : 0u, need_x ? flags_up : (gu32*)nullptr, gmax - t, seen_up,
-                                   (layer > 0 && t >= 0) ? flags_lo : (gu32*)nullptr, gmax - t - LPS_XDEPTH, seen_lo, n_slots, lane))
-            s_abort = 1;
-        gp_lds_barrier();
-        if (s_abort) {
-            if (tid == 0) __hip_atomic_store(status, 7u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-        // jobs of the step: (item tile m, product p) with p = 0: own gate gradients of step t + 1 x W_hh^T, p = 1: the upper layer's
-        // of step t x its W_ih^T.  One job's 16-row tile is in flight in raw[]; the next job's loads go into each register as the
+        // One product of the step over the MT item tiles: p = 0 this layer's gate gradients of step t + 1 x W_hh^T, p = 1 the upper
+        // layer's of step t x its W_ih^T.  One 16-row tile is in flight in raw[]; the next tile's loads go into each register as the
         // MFMAs free it.
         const unsigned own0 = ring_own + ((t + 1) & 1) * par_bytes, up0 = ring_up + (unsigned)(t & (LPS_XDEPTH - 1)) * par_bytes;
-        auto job_off = [&](int m, int p) {
-            const bool valid = 16 * m + li < nrows;
-            return (p == 0 ? own0 : up0) + rd_base + (unsigned)((valid ? 16 * m + li : 0) * 32);
-        };
-        u32x4 raw[KS];
-        if (need_mm || need_x) {
-            const unsigned o0 = job_off(0, need_mm ? 0 : 1);
+        auto run_jobs = [&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            auto job_off = [&](int m) {
+                const bool valid = 16 * m + li < nrows;
+                return (p == 0 ? own0 : up0) + rd_base + (unsigned)((valid ? 16 * m + li : 0) * 32);
+            };
+            u32x4 raw[KS];
+            {
+                const unsigned o0 = job_off(0);
 #pragma unroll
-            for (int i = 0; i < KS; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ring, o0 + i * rd_kstep, 0, 16);
-        }
-        // the next step's cell operands (first touch: HBM latency), requested behind the first hand-off tile
-        float s_g41[MT][UT][4], c_prev1[MT][UT], gout1[MT][UT];
-        {
-            const int t1 = t > 0 ? t - 1 : 0;
+                for (int i = 0; i < KS; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ring, o0 + i * rd_kstep, 0, 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int u = 0; u < UT; ++u) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) s_g41[m][u][g] = p_sv[m][(size_t)t1 * 4 * H + g * H + GT * u];
-                    c_prev1[m][u] = p_c[m][(size_t)t1 * H + GT * u];
-                    gout1[m][u] = p_g[m] ? p_g[m][(size_t)t1 * H + GT * u] : 0.f;
-                }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                if (p == 0 ? !need_mm : !need_x) continue;
-                // the job after this one
-                bool has_next;
-                unsigned nxt = 0;
-                if (p == 0 && need_x) {
-                    has_next = true;
-                    nxt = job_off(m, 1);
-                } else {
-                    has_next = m + 1 < MT;
-                    nxt = job_off(m + 1 < MT ? m + 1 : m, need_mm ? 0 : 1);
-                }
+            for (int m = 0; m < MT; ++m) {
+                const unsigned nxt = job_off(m + 1 < MT ? m + 1 : m);
                 f32x4 acc[UT][2];
 #pragma unroll
                 for (int u = 0; u < UT; ++u) acc[u][0] = acc[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1065,7 +1070,7 @@ __global__ __launch_bounds__(256, UT == 1 ? 2 : 1) void lstm_stack_bwd_persist_k
 #pragma unroll
                     for (int u = 0; u < UT; ++u)
                         acc[u][i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, p == 0 ? fhh[u][i] : fih[u][i], acc[u][i & 1], 0, 0, 0);
-                    if (has_next) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ring, nxt + i * rd_kstep, 0, 16);
+                    if (m + 1 < MT) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ring, nxt + i * rd_kstep, 0, 16);
                 }
 #pragma unroll
                 for (int u = 0; u < UT; ++u) {
@@ -1074,21 +1079,69 @@ __global__ __launch_bounds__(256, UT == 1 ? 2 : 1) void lstm_stack_bwd_persist_k
                     for (int r = 0; r < 4; ++r) red[wave][p][u][m][(4 * q + r) * GT + li] = s[r];
                 }
             }
+        };
+        // Phase A: the product with the upper layer's gate gradients.  It does not depend on this layer's own step t + 1 and the layer
+        // above is normally steps ahead: it runs while the other slots' publishes of step t + 1 are still on their way.
+        MG_STAMP(ta);
+        if (need_x) {
+            if (wave == 0 && !lps_wait(flags_a, 0u, flags_up, gmax - t, seen_up, (gu32*)nullptr, 0, seen_lo, n_slots, lane)) s_abort = 1;
+            gp_lds_barrier();
+            if (s_abort) {
+                if (tid == 0) __hip_atomic_store(status, 7u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            run_jobs(std::integral_constant<int, 1>{});
         }
+        MG_STAMP(tb);
+        MG_STAMP_ADD(sum_load, tb, ta);
+        // the next step's cell operands (first touch: HBM latency): requested behind phase A's loads, back before phase B waits on its own
+        lp_vec<VW> s_g41[4], c_prev1, gout1;
+        {
+            const int t1 = t > 0 ? t - 1 : 0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) s_g41[g] = lp_ld<VW>(p_sv + (size_t)t1 * 4 * H + g * H);
+            c_prev1 = lp_ld<VW>(p_c + (size_t)t1 * H);
+            gout1 = p_g ? lp_ld<VW>(p_g + (size_t)t1 * H) : lp_vec<VW>{};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // Phase B: this layer's own recurrence - the chain that sets the step time
+        MG_STAMP(ta);
+        if (wave == 0 && !lps_wait(flags_a, need_mm ? (unsigned)(gmax - t - 1) : 0u, (gu32*)nullptr, 0, seen_up,
+                                   (layer > 0 && t >= 0) ? flags_lo : (gu32*)nullptr, gmax - t - LPS_XDEPTH, seen_lo, n_slots, lane))
+            s_abort = 1;
+        gp_lds_barrier();
+        if (s_abort) {
+            if (tid == 0) __hip_atomic_store(status, 7u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        MG_STAMP(tb);
+        MG_STAMP_ADD(sum_poll, tb, ta);
+        MG_STAMP(ta);
+        if (need_mm) run_jobs(std::integral_constant<int, 0>{});
         if (need_mm && layer > 0) raise_x(gmax - t - 1);          // step t + 1's ring-X stores were issued a step ago
         gp_lds_barrier();
+        MG_STAMP(tb);
+        MG_STAMP_ADD(sum_mm, tb, ta);
+        {
+            lp_vec<VW> part[2][4];
+            if (need_mm) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int e = bl * GT + jl;
+                for (int w = 0; w < 4; ++w) part[0][w] = lp_ld<VW>(&red[w][0][cu][cm][ce]);
+            }
+            if (need_x) {
 #pragma unroll
-            for (int u = 0; u < UT; ++u) {
-                const float dh_state = need_mm ? carry_h[m][u] + ((red[0][0][u][m][e] + red[1][0][u][m][e]) + (red[2][0][u][m][e] + red[3][0][u][m][e]))
-                                               : carry_h[m][u];
-                const float g_in = need_x ? ((red[0][1][u][m][e] + red[1][1][u][m][e]) + (red[2][1][u][m][e] + red[3][1][u][m][e])) : gout[m][u];
-                float di = 0.f, df = 0.f, dg = 0.f, d_o = 0.f, ch = dh_state, cc = carry_c[m][u];
-                if (t >= 0 && t < len[m]) {
-                    const lp_cell_grad cg = lp_cell_bwd_fast(dh_state, carry_c[m][u], g_in, s_g4[m][u][0], s_g4[m][u][1], s_g4[m][u][2],
-                                                             s_g4[m][u][3], c_prev[m][u], c_new[m][u]);
+                for (int w = 0; w < 4; ++w) part[1][w] = lp_ld<VW>(&red[w][1][cu][cm][ce]);
+            }
+            lp_vec<VW> vdi, vdf, vdg, vdo;
+            const bool active = t >= 0 && t < len;
+#pragma unroll
+            for (int v = 0; v < VW; ++v) {
+                const float dh_state = need_mm ? carry_h.v[v] + ((part[0][0].v[v] + part[0][1].v[v]) + (part[0][2].v[v] + part[0][3].v[v])) : carry_h.v[v];
+                const float g_in = need_x ? ((part[1][0].v[v] + part[1][1].v[v]) + (part[1][2].v[v] + part[1][3].v[v])) : gout.v[v];
+                float di = 0.f, df = 0.f, dg = 0.f, d_o = 0.f, ch = dh_state, cc = carry_c.v[v];
+                if (active) {
+                    const lp_cell_grad cg = lp_cell_bwd_fast(dh_state, carry_c.v[v], g_in, s_g4[0].v[v], s_g4[1].v[v], s_g4[2].v[v], s_g4[3].v[v],
+                                                             c_prev.v[v], c_new.v[v]);
                     di = cg.di;
                     df = cg.df;
                     dg = cg.dg;
@@ -1096,33 +1149,34 @@ __global__ __launch_bounds__(256, UT == 1 ? 2 : 1) void lstm_stack_bwd_persist_k
                     ch = 0.f;                 // all of dh_{t-1} comes through the matmul with the gates of this step
                     cc = cg.cc;
                 }
-                carry_h[m][u] = ch;
-                carry_c[m][u] = cc;
-                if (P.dgates) {
-                    res[u][m][0][e] = di;
-                    res[u][m][1][e] = df;
-                    res[u][m][2][e] = dg;
-                    res[u][m][3][e] = d_o;
-                }
-                pub[u][0][16 * m + bl][jl] = mg_f2bf(di);
-                pub[u][1][16 * m + bl][jl] = mg_f2bf(df);
-                pub[u][2][16 * m + bl][jl] = mg_f2bf(dg);
-                pub[u][3][16 * m + bl][jl] = mg_f2bf(d_o);
+                carry_h.v[v] = ch;
+                carry_c.v[v] = cc;
+                vdi.v[v] = di;
+                vdf.v[v] = df;
+                vdg.v[v] = dg;
+                vdo.v[v] = d_o;
             }
+            if (P.dgates) {
+                lp_st<VW>(&res[cu][cm][0][ce], vdi);
+                lp_st<VW>(&res[cu][cm][1][ce], vdf);
+                lp_st<VW>(&res[cu][cm][2][ce], vdg);
+                lp_st<VW>(&res[cu][cm][3][ce], vdo);
+            }
+            lp_st_bf<VW>(&pub[cu][0][16 * cm + crow][cc0], vdi);
+            lp_st_bf<VW>(&pub[cu][1][16 * cm + crow][cc0], vdf);
+            lp_st_bf<VW>(&pub[cu][2][16 * cm + crow][cc0], vdg);
+            lp_st_bf<VW>(&pub[cu][3][16 * cm + crow][cc0], vdo);
         }
         if (t < 0) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-                if (mine[m]) {
-#pragma unroll
-                    for (int u = 0; u < UT; ++u) {
-                        P.dh0[(size_t)(row0 + 16 * m + bl) * H + j0 + GT * u + jl] = carry_h[m][u];
-                        P.dc0[(size_t)(row0 + 16 * m + bl) * H + j0 + GT * u + jl] = carry_c[m][u];
-                    }
-                }
+            if (mine) {
+                lp_st<VW>(P.dh0 + (size_t)cb * H + cj, carry_h);
+                lp_st<VW>(P.dc0 + (size_t)cb * H + cj, carry_c);
+            }
             break;
         }
         gp_lds_barrier();
+        MG_STAMP(ta);
+        MG_STAMP_ADD(sum_cell, ta, tb);
         // wave 0: ring A + flag A; wave 1: ring X (layers above the lowest); wave 2: the bf16 shadow the weight-gradient GEMMs read;
         // wave 3: the optional fp32 copy
         if (wave <= 2) {
@@ -1151,6 +1205,8 @@ __global__ __launch_bounds__(256, UT == 1 ? 2 : 1) void lstm_stack_bwd_persist_k
             }
             if (wave == 1 && layer == 0 && lane == 0)         // progress report only
                 __hip_atomic_store(flags_x + slot, (unsigned)(gmax - t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            MG_STAMP(tb);
+            MG_STAMP_ADD(sum_pub, tb, ta);
         } else if (P.dgates) {
             for (int job = lane; job < UT * MT * 4 * 64; job += 64) {       // 16-byte stores: (u, m, gate, 16 rows x 4 column quads)
                 const int e4 = job & 63, k = job >> 6, gate = k & 3, m = (k >> 2) % MT, u = k / (4 * MT);
@@ -1161,16 +1217,26 @@ __global__ __launch_bounds__(256, UT == 1 ? 2 : 1) void lstm_stack_bwd_persist_k
             }
         }
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int u = 0; u < UT; ++u) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) s_g4[m][u][g] = s_g41[m][u][g];
-                c_new[m][u] = c_prev[m][u];
-                c_prev[m][u] = c_prev1[m][u];
-                gout[m][u] = gout1[m][u];
-            }
+        for (int g = 0; g < 4; ++g) s_g4[g] = s_g41[g];
+        c_new = c_prev;
+        c_prev = c_prev1;
+        gout = gout1;
     }
+#ifdef MG_STAMPS
+    MG_STAMP(ts1);
+    MG_STAMP_REAL(tr1);
+    MG_STAMP_STORE(g_stamps_lps, blockIdx.x, wave, lane, 0, ts0);
+    MG_STAMP_STORE(g_stamps_lps, blockIdx.x, wave, lane, 1, ts1);
+    MG_STAMP_STORE(g_stamps_lps, blockIdx.x, wave, lane, 2, tr0);
+    MG_STAMP_STORE(g_stamps_lps, blockIdx.x, wave, lane, 3, tr1);
+    MG_STAMP_STORE(g_stamps_lps, blockIdx.x, wave, lane, 4, sum_poll);
+    MG_STAMP_STORE(g_stamps_lps, blockIdx.x, wave, lane, 5, sum_load);
+    MG_STAMP_STORE(g_stamps_lps, blockIdx.x, wave, lane, 6, sum_mm);
+    MG_STAMP_STORE(g_stamps_lps, blockIdx.x, wave, lane, 7, sum_cell);
+    MG_STAMP_STORE(g_stamps_lps, blockIdx.x, wave, lane, 8, sum_pub);
+    MG_STAMP_STORE(g_stamps_lps, blockIdx.x, wave, lane, 9, (unsigned long long)(gmax + 1));
+    MG_STAMP_STORE(g_stamps_lps, blockIdx.x, wave, lane, 10, (unsigned long long)(layer * 1000 + one_xcd));
+#endif
     if (gmax > 0 && layer > 0) raise_x(gmax);          // the last step's ring-X stores (nobody below waits for more)
 }
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Per-phase cycles per step of the LSTM stack forward wavefront kernel (diagnostic library, in-kernel stamps), by layer.
-Usage: MORGANA_HIP_LIB=morgana_amd/libmorgana_hip_diag.so python scripts/stamps_lstm_stack.py"""
+"""Per-phase cycles per step of the LSTM stack wavefront kernels (diagnostic library, in-kernel stamps), by layer: the forward, or with
+the argument `bwd` the backward (its `loads` = until the first hand-off tile has landed, `mfma+sum` = all four tile products).
+Usage: MORGANA_HIP_LIB=morgana_amd/libmorgana_hip_diag.so python scripts/stamps_lstm_stack.py [bwd]"""
 import ctypes
 import os
 import sys
@@ -19,14 +20,21 @@ SLOTS, BLOCKS = 16, 4096
 def main():
     dev = 'cuda:0'
     lib = _lib.load()
+    lib.mg_set_tuning(3, int(os.environ.get('MG_WIDTH', '0')))
     b, t, h, n_layers = 64, 1000, 512, 8
     g = torch.Generator(device=dev).manual_seed(0)
     xproj = torch.randn(b, t, 4 * h, device=dev, generator=g)
     w_ih = [torch.randn(4 * h, h, device=dev, generator=g) / h ** 0.5 for _ in range(n_layers)]
     w_hh = [torch.randn(4 * h, h, device=dev, generator=g) / h ** 0.5 for _ in range(n_layers)]
     bias = [torch.zeros(4 * h, device=dev) for _ in range(n_layers)]
+    n_wg = 512
     for _ in range(3):
-        ops.lstm_pstack_fwd(xproj, w_ih, w_hh, bias, bias, None, None, None, b, t, h)
+        _, _, cstate, saved, _ = ops.lstm_pstack_fwd(xproj, w_ih, w_hh, bias, bias, None, None, None, b, t, h)
+    if len(sys.argv) > 1 and sys.argv[1] == 'bwd':
+        g_out = torch.randn(b, t, h, device=dev, generator=g)
+        for _ in range(3):
+            ops.lstm_pstack_bwd(g_out, None, None, cstate, saved, w_ih, w_hh, None, b, t, h)
+        n_wg = 256 if os.environ.get('MG_WIDTH', '0') == '0' else 512
     torch.cuda.synchronize()
     ops.check_persistent_status()
     buf = np.zeros(BLOCKS * 2 * SLOTS, dtype=np.uint64)
@@ -34,7 +42,7 @@ def main():
     fn.restype = ctypes.c_int
     fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
     assert fn(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes) == 0
-    st = buf.reshape(BLOCKS, 2, SLOTS)[:512, 0].astype(np.int64)
+    st = buf.reshape(BLOCKS, 2, SLOTS)[:n_wg, 0].astype(np.int64)
     life = st[:, 1] - st[:, 0]
     real_ns = (st[:, 3] - st[:, 2]) * 10.0
     steps = st[:, 9]
