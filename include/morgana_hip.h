@@ -47,7 +47,7 @@ const char* mg_last_error(void);
                                  * 1 = always write-through (sc1) stores, the placement-independent form */
 #define MG_TUNE_SKIP_REDUCE 1   /* != 0: weight-gradient entry points launch their GEMM kernel only, not the slab reduce that
                                  * finishes dW / db (results are then NOT valid) - lets bench.py time the kernel alone */
-#define MG_TUNE_LSTM_BWD_STACK 3 /* mg_lstm_pstack_bwd_bf16: 0 = 32 hidden units per slot where they fit (one workgroup per CU), 1 = 16 (two per CU) */
+#define MG_TUNE_LSTM_BWD_STACK 6 /* mg_lstm_pstack_bwd_bf16: 0 = 32 hidden units per slot where they fit (one workgroup per CU), 1 = 16 (two per CU) */
 #define MG_TUNE_WGRAD_SPLITS 4  /* wide weight-gradient kernel: != 0 overrides the planned number of split-M slabs (a multiple of 8) */
 #define MG_TUNE_WGRAD_ORDER 5   /* wide weight-gradient kernel, block order: 0 = planned, 1 = n tile fastest, 2 = the n tiles of a split on one XCD */
 int mg_set_tuning(int key, int value);

@@ -42,7 +42,7 @@ def main():
 
     for name, fn, width in (('wavefront, 32 units per slot', wavefront, 0), ('wavefront, 16 units per slot', wavefront, 1),
                             ('layer by layer', layerwise, 0)):
-        lib.mg_set_tuning(3, width)
+        lib.mg_set_tuning(6, width)
         fn()
         torch.cuda.synchronize()
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -53,7 +53,7 @@ def main():
         end.synchronize()
         ops.check_persistent_status()
         print('%-32s %8.3f ms per backward' % (name, start.elapsed_time(end) / iters))
-    lib.mg_set_tuning(3, 0)
+    lib.mg_set_tuning(6, 0)
 
 
 if __name__ == '__main__':

@@ -20,7 +20,7 @@ SLOTS, BLOCKS = 16, 4096
 def main():
     dev = 'cuda:0'
     lib = _lib.load()
-    lib.mg_set_tuning(3, int(os.environ.get('MG_WIDTH', '0')))
+    lib.mg_set_tuning(6, int(os.environ.get('MG_WIDTH', '0')))
     b, t, h, n_layers = 64, 1000, 512, 8
     g = torch.Generator(device=dev).manual_seed(0)
     xproj = torch.randn(b, t, 4 * h, device=dev, generator=g)

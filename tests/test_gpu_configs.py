@@ -487,7 +487,7 @@ def test_lstm_stack_backward_wavefront_vs_layer_by_layer(b, t, i_dim, hid, n_lay
     first = None
     try:
         for width, handoff in ((0, 0), (1, 0), (0, 1), (0, 0)):
-            lib.mg_set_tuning(3, width)
+            lib.mg_set_tuning(6, width)
             lib.mg_set_tuning(2, handoff)
             got = run(True)
             if first is None:
@@ -499,7 +499,7 @@ def test_lstm_stack_backward_wavefront_vs_layer_by_layer(b, t, i_dim, hid, n_lay
                 for k, (g, w) in enumerate(zip(got, first)):
                     np.testing.assert_array_equal(g, w, err_msg='gradient %d, slot width %d, hand-off %d' % (k, width, handoff))
     finally:
-        lib.mg_set_tuning(3, 0)
+        lib.mg_set_tuning(6, 0)
         lib.mg_set_tuning(2, 0)
 
 
