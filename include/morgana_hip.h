@@ -506,6 +506,44 @@ size_t mg_lstm_pstack_bwd_workspace_bytes(int B, int H, int L);
 int mg_lstm_pstack_bwd_bf16(const mg_lstm_pstack_bwd_layer* layers, int L, const int64_t* seq_len, int B, int T, int H, void* workspace,
                             size_t workspace_bytes, void* stream);
 
+/* A STACK of small GRU layers (reference: the three RecurrentCuDNNWrapper(nn.GRU(., 64)) of the shipped F0 model,
+ * models/f0_test_model.py:31-37, one after the other through SequentialWithRecurrent, utils.py:396-418) as ONE launch per direction:
+ * the workgroup-local kernels above run as a wavefront over (layer, time), one workgroup per (layer, block of 4 items).  Layers above
+ * the first compute their input projection inside the step (w_ih [3H, H], b_ih: their input IS the lower layer's output, input size
+ * == H) and, backward, the gradient they hand to the layer below (dxproj_t W_ih), so the projection and input-gradient GEMMs between
+ * the layers go.  Exact fp32; per layer the same results as mg_gru_fwd_small_f32 / mg_gru_bwd_small_f32 fed with the neighbouring
+ * layer's rows, up to the summation order of those in-step products.
+ * Hand-off buffers: `out` of every layer below the top (forward) and `dxin` of every layer below the top (backward) are filled with a
+ * sentinel by the entry point and written exactly once per element by the producing layer; after the launch they hold ordinary
+ * values (`out`: the layer's outputs, zero on padded steps, as from mg_gru_fwd_f32).
+ * mg_gru_stack_small_supported: H == 64, 2 <= L <= MG_GRU_STACK_MAX_LAYERS, all L ceil(B / 4) workgroups resident.
+ * Workspace (mg_gru_stack_small_workspace_bytes, zeroed once by the caller): the sticky status word of mg_gru_persist_status. */
+#define MG_GRU_STACK_MAX_LAYERS 4
+typedef struct {
+    /* forward */
+    const float* xproj;     /* layer 0: [B,T,3H] = x W_ih^T + b_ih */
+    const float* w_ih;      /* layers >= 1: [3H,H] (both directions) */
+    const float* b_ih;      /* layers >= 1: [3H] */
+    const float* w_hh;      /* [3H,H] (both directions) */
+    const float* b_hh;      /* [3H] */
+    float* hstate;          /* [B,T+1,H], slot 0 = h0 on entry (read by the backward) */
+    float* out;             /* [B,T,H] */
+    float* saved;           /* [B,T,4H] (read by the backward) */
+    /* backward */
+    const float* grad_out;  /* top layer: [B,T,H] */
+    const float* grad_hn;   /* NULL or [B,H] */
+    float* dxin;            /* layers below the top: [B,T,H], the gradient of the layer's outputs as the layer above hands it down */
+    float* dxproj;          /* [B,T,3H] */
+    float* dhproj;          /* [B,T,3H] */
+    float* dh0;             /* [B,H] */
+} mg_gru_stack_layer;
+int mg_gru_stack_small_supported(int B, int T, int H, int L);
+size_t mg_gru_stack_small_workspace_bytes(void);
+int mg_gru_stack_fwd_small_f32(const mg_gru_stack_layer* layers, int L, const int64_t* seq_len, int B, int T, int H, void* workspace,
+                               size_t workspace_bytes, void* stream);
+int mg_gru_stack_bwd_small_f32(const mg_gru_stack_layer* layers, int L, const int64_t* seq_len, int B, int T, int H, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
 /* LSTM through RecurrentCuDNNWrapper   reference: morgana/utils.py:345-393 + torch.nn.LSTM (gates i, f, g, o), the cell of
  * the reference's shipped acoustic model (models/RNN_SPSS.py:36-37).  Same conventions as the GRU entry points:
  *   xproj [B,T,4H] = x W_ih^T + b_ih; w_hh [4H,H]; b_hh [4H]; hstate / cstate [B,T+1,H] with slot 0 = (h0, c0) on entry;

@@ -136,6 +136,10 @@ SIGNATURES = {
     'mg_lstm_bwd_workspace_bytes': (c_size_t, [c_int, c_int]),
     'mg_lstm_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'mg_gru_stack_small_supported': (c_int, [c_int, c_int, c_int, c_int]),
+    'mg_gru_stack_small_workspace_bytes': (c_size_t, []),
+    'mg_gru_stack_fwd_small_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'mg_gru_stack_bwd_small_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'mg_lstm_pstack_supported': (c_int, [c_int, c_int, c_int, c_int]),
     'mg_lstm_pstack_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'mg_lstm_pstack_fwd_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
@@ -173,6 +177,13 @@ class LstmPStackLayer(ctypes.Structure):
     _fields_ = [('xproj', c_void_p), ('w_ih_bf', c_void_p), ('b_ih', c_void_p), ('w_hh_bf', c_void_p), ('b_hh', c_void_p),
                 ('hstate', c_void_p), ('cstate', c_void_p), ('hstate_bf', c_void_p), ('out', c_void_p), ('saved', c_void_p),
                 ('ldwi', c_int), ('ldwh', c_int)]
+
+
+class GruStackLayer(ctypes.Structure):
+    """mg_gru_stack_layer of include/morgana_hip.h."""
+    _fields_ = [('xproj', c_void_p), ('w_ih', c_void_p), ('b_ih', c_void_p), ('w_hh', c_void_p), ('b_hh', c_void_p),
+                ('hstate', c_void_p), ('out', c_void_p), ('saved', c_void_p), ('grad_out', c_void_p), ('grad_hn', c_void_p),
+                ('dxin', c_void_p), ('dxproj', c_void_p), ('dhproj', c_void_p), ('dh0', c_void_p)]
 
 
 class LstmPStackBwdLayer(ctypes.Structure):

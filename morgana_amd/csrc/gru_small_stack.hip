@@ -1,0 +1,364 @@
+// K3w - a STACK of small GRU layers (H = 64: the three RecurrentCuDNNWrapper(nn.GRU(., 64)) of the shipped F0 model,
+// models/f0_test_model.py:31-37) as ONE launch per direction, exact fp32: the kernels of gru_small.hip run as a wavefront over
+// (layer, time).  A workgroup still owns R = 4 items outright - W_hh in registers, state in LDS, nothing to synchronise inside a
+// layer - and there is one such workgroup per (layer, item block): layer l works on step t while layer l - 1 is a few steps ahead,
+// so L layers take T + a few dependent steps instead of L T, and the input-projection GEMMs of the upper layers (forward) and the
+// input-gradient GEMMs between the layers (backward) go: a workgroup that owns its items outright holds every gate column of
+// them, so x_t W_ih^T (forward) and dxproj_t W_ih (backward) are local products with W_ih resident next to W_hh.
+// Hand-off between the layers of an item block: the value itself is the flag.  The buffer a layer hands down or up ([B, T, H]
+// fp32: `out` of a lower layer, `dxin` of an upper one) is filled with a sentinel (all bits set: a NaN no arithmetic produces)
+// by a memset ahead of the launch; the producer stores its H values of a step write-through (sc1), each consumer thread loads
+// ITS element (sc1) two steps before it needs it and re-loads while it still reads the sentinel.  No flag word, no fence, no
+// drain of the producer's stores; a dword store is atomic, and every (b, t) element is written exactly once (zeros on padded steps).
+// Every spin is bounded; a time-out sets the sticky status word (mg_gru_persist_status) and the workgroup stops polling.
+// Arithmetic of a layer: gru_small.hip's (expf / tanhf cell, fp32 products on v_mfma_f32_4x4x1); layer 0's input projection
+// comes from memory as there, the upper layers' from the in-kernel product (one chain per output, bias added behind).
+#include "common.h"
+
+#include "persist_common.h"
+
+#define GSS_SENTINEL 0xFFFFFFFFu
+
+struct GssLayers {
+    mg_gru_stack_layer l[MG_GRU_STACK_MAX_LAYERS];
+};
+
+__device__ __forceinline__ float gss_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void gss_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// the consumer's side of the hand-off: `v` was loaded a while ago; poll while it is still the sentinel
+__device__ __forceinline__ float gss_take(float v, const float* p, bool& dead, gu32* status, unsigned code) {
+    if (__float_as_uint(v) != GSS_SENTINEL || dead) return v;
+    for (unsigned spins = 0; spins < GP_SPIN_LIMIT; ++spins) {
+        v = gss_load(p);
+        if (__float_as_uint(v) != GSS_SENTINEL) return v;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    dead = true;
+    __hip_atomic_store(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return 0.f;
+}
+
+__global__ __launch_bounds__(256) void gru_stack_fwd_small64_kernel(GssLayers a, const int64_t* __restrict__ seq_len, int B, int T, int L,
+                                                                    int nblk, unsigned* sync) {
+    constexpr int H = 64, G = 192, R = 4, LDH = H + 4, LDG = G + 4;
+    __shared__ __attribute__((aligned(16))) float hs[R][LDH];       // h_{t-1}; rows of missing items stay zero
+    __shared__ __attribute__((aligned(16))) float xs[2][R][LDH];    // upper layers: the lower layer's output of step t (parity t & 1)
+    __shared__ __attribute__((aligned(16))) float gl[R][LDG];       // recurrent pre-activations of the three gates
+    __shared__ __attribute__((aligned(16))) float gx[R][LDG];       // upper layers: input pre-activations
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int layer = blockIdx.x / nblk, blk = blockIdx.x - layer * nblk;
+    const mg_gru_stack_layer& P = a.l[layer];
+    const bool upper = layer > 0, hands_up = layer + 1 < L;
+    gu32* status = (gu32*)sync + GP_FLAG_WORDS;
+    const int row0 = blk * R;
+    const int nrows = min(R, B - row0);
+    // wave g < 3 owns gate g: lane L holds row g H + L of W_hh (and of W_ih above the first layer) for the whole launch
+    f32x4 fw[H / 4], fwi[H / 4];
+    if (wave < 3) {
+        const float* wp = P.w_hh + (size_t)(wave * H + lane) * H;
+#pragma unroll
+        for (int k4 = 0; k4 < H / 4; ++k4) {
+            fw[k4] = *reinterpret_cast<const f32x4*>(wp + 4 * k4);
+            fwi[k4] = fw[k4];
+        }
+        if (upper) {
+            const float* wi = P.w_ih + (size_t)(wave * H + lane) * H;
+#pragma unroll
+            for (int k4 = 0; k4 < H / 4; ++k4) fwi[k4] = *reinterpret_cast<const f32x4*>(wi + 4 * k4);
+        }
+    }
+    for (int e = tid; e < R * LDH; e += 256) {
+        (&hs[0][0])[e] = 0.f;
+        (&xs[0][0][0])[e] = 0.f;
+        (&xs[1][0][0])[e] = 0.f;
+    }
+    __syncthreads();
+    const int er = tid >> 6, ej = tid & 63;                          // cell role: item er, unit ej
+    const bool mine = er < nrows;
+    const int b = row0 + (mine ? er : 0);
+    const int len = seq_len ? (int)min((int64_t)T, seq_len[b]) : T;
+    const float bhr = P.b_hh[ej], bhz = P.b_hh[H + ej], bhn = P.b_hh[2 * H + ej];
+    const float bir = upper ? P.b_ih[ej] : 0.f, biz = upper ? P.b_ih[H + ej] : 0.f, bin = upper ? P.b_ih[2 * H + ej] : 0.f;
+    float hprev = mine ? P.hstate[((size_t)b * (T + 1)) * H + ej] : 0.f;
+    if (mine) hs[er][ej] = hprev;
+    const float* xp = (upper ? P.b_hh : P.xproj + (size_t)b * T * G) + (upper ? 0 : ej);        // layer 0: projected input rows
+    const float* xin = upper ? a.l[layer - 1].out + (size_t)b * T * H + ej : P.b_hh;             // above: the lower layer's outputs
+    float xr = 0.f, xz = 0.f, xn = 0.f;
+    float xa = 0.f, xb = 0.f;                                         // above: x of steps t + 1 and t + 2, requested two steps ahead
+    bool dead = false;
+    if (!upper) {
+        xr = xp[0], xz = xp[H], xn = xp[2 * H];
+    } else if (mine) {
+        float x0 = gss_load(xin);
+        xa = T > 1 ? gss_load(xin + H) : 0.f;
+        xb = T > 2 ? gss_load(xin + 2 * H) : 0.f;
+        xs[0][er][ej] = gss_take(x0, xin, dead, status, 8u);
+    }
+    __syncthreads();
+
+    // one step; x_use holds x_{t+1} (consumed at the end of the step, then reloaded with x_{t+3})
+    auto step = [&](int t, float& x_use) {
+        const int t1 = t + 1 < T ? t + 1 : t;
+        float xr1 = 0.f, xz1 = 0.f, xn1 = 0.f;
+        if (!upper) xr1 = xp[(size_t)t1 * G], xz1 = xp[(size_t)t1 * G + H], xn1 = xp[(size_t)t1 * G + 2 * H];
+        if (wave < 3) {
+            f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int k4 = 0; k4 < H / 4; ++k4) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(&hs[lane & 3][4 * k4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], fw[k4][e], acc[e], 0, 0, 0);
+            }
+            const f32x4 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+            for (int i = 0; i < R; ++i) gl[i][wave * H + lane] = sum[i];
+            if (upper) {
+                f32x4 acx[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int k4 = 0; k4 < H / 4; ++k4) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(&xs[t & 1][lane & 3][4 * k4]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acx[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], fwi[k4][e], acx[e], 0, 0, 0);
+                }
+                const f32x4 sx = (acx[0] + acx[1]) + (acx[2] + acx[3]);
+#pragma unroll
+                for (int i = 0; i < R; ++i) gx[i][wave * H + lane] = sx[i];
+            }
+        }
+        gp_lds_barrier();
+        if (mine) {
+            if (upper) xr = gx[er][ej] + bir, xz = gx[er][H + ej] + biz, xn = gx[er][2 * H + ej] + bin;
+            const float hr = gl[er][ej] + bhr, hz = gl[er][H + ej] + bhz, hn = gl[er][2 * H + ej] + bhn;
+            const float r = mg_sigmoid(xr + hr);
+            const float z = mg_sigmoid(xz + hz);
+            const float n = tanhf(xn + r * hn);
+            const float hnew = (1.f - z) * n + z * hprev;
+            const bool active = t < len;
+            hprev = active ? hnew : hprev;
+            hs[er][ej] = hprev;
+            const size_t row = (size_t)b * T + t;
+            P.hstate[((size_t)b * (T + 1) + t + 1) * H + ej] = hprev;
+            if (hands_up)
+                gss_store(P.out + row * H + ej, active ? hnew : 0.f);
+            else
+                P.out[row * H + ej] = active ? hnew : 0.f;
+            float* sv = P.saved + row * 4 * H;
+            sv[ej] = r;
+            sv[H + ej] = z;
+            sv[2 * H + ej] = n;
+            sv[3 * H + ej] = hn;
+            if (upper && t + 1 < T) {
+                xs[(t + 1) & 1][er][ej] = gss_take(x_use, xin + (size_t)(t + 1) * H, dead, status, 8u);
+                if (t + 3 < T) x_use = gss_load(xin + (size_t)(t + 3) * H);
+            }
+        }
+        xr = xr1;
+        xz = xz1;
+        xn = xn1;
+        gp_lds_barrier();
+    };
+    int t = 0;
+    for (; t + 1 < T; t += 2) {
+        step(t, xa);
+        step(t + 1, xb);
+    }
+    if (t < T) step(t, xa);
+}
+
+// Backward.  dl = dhproj_{t+1} = (dr, dz, dn r) feeds dstate_t = carry + dl W_hh as in gru_bwd_small64_kernel; above the first layer
+// dlx = dxproj_{t+1} = (dr, dz, dn) also goes through the layer's own W_ih in the same phase: d x_{t+1} = dlx W_ih is what the layer
+// below adds to its state gradient in place of a grad_out row, and is handed down through `dxin` (sentinel protocol above).
+__global__ __launch_bounds__(256) void gru_stack_bwd_small64_kernel(GssLayers a, const int64_t* __restrict__ seq_len, int B, int T, int L,
+                                                                    int nblk, unsigned* sync) {
+    constexpr int H = 64, G = 192, R = 4, LDG = G + 4, KW = G / 4;  // KW = 48 gate rows per wave
+    __shared__ __attribute__((aligned(16))) float dl[R][LDG];
+    __shared__ __attribute__((aligned(16))) float dlx[R][LDG];
+    __shared__ float part[4][R][H];
+    __shared__ float partx[4][R][H];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int layer = blockIdx.x / nblk, blk = blockIdx.x - layer * nblk;
+    const mg_gru_stack_layer& P = a.l[layer];
+    const bool upper = layer > 0, top = layer + 1 == L;
+    gu32* status = (gu32*)sync + GP_FLAG_WORDS;
+    const int row0 = blk * R;
+    const int nrows = min(R, B - row0);
+    float fw[KW], fwi[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        fw[k] = P.w_hh[(size_t)(wave * KW + k) * H + lane];
+        fwi[k] = upper ? P.w_ih[(size_t)(wave * KW + k) * H + lane] : 0.f;
+    }
+    for (int e = tid; e < R * LDG; e += 256) {
+        (&dl[0][0])[e] = 0.f;
+        (&dlx[0][0])[e] = 0.f;
+    }
+    const int er = tid >> 6, ej = tid & 63;
+    const bool mine = er < nrows;
+    const int b = row0 + (mine ? er : 0);
+    const int len = seq_len ? (int)min((int64_t)T, seq_len[b]) : T;
+    float carry = (mine && P.grad_hn) ? P.grad_hn[(size_t)b * H + ej] : 0.f;
+    const float* p_sv = P.saved + (size_t)b * T * 4 * H + ej;
+    const float* p_h = P.hstate + (size_t)b * (T + 1) * H + ej;
+    const float* p_g = (top ? P.grad_out : P.dxin) + (size_t)b * T * H + ej;       // below the top: what the layer above hands down
+    float* p_dx = upper ? a.l[layer - 1].dxin + (size_t)b * T * H + ej : (float*)nullptr;
+    float s_r = p_sv[(size_t)(T - 1) * 4 * H], s_z = p_sv[(size_t)(T - 1) * 4 * H + H], s_n = p_sv[(size_t)(T - 1) * 4 * H + 2 * H],
+          s_hn = p_sv[(size_t)(T - 1) * 4 * H + 3 * H], hprev = p_h[(size_t)(T - 1) * H];
+    // gradient rows of steps T - 1 and T - 2, requested ahead (below the top: polled when taken)
+    float ga = 0.f, gb = 0.f;
+    bool dead = false;
+    if (mine) {
+        ga = top ? p_g[(size_t)(T - 1) * H] : gss_load(p_g + (size_t)(T - 1) * H);
+        if (T > 1) gb = top ? p_g[(size_t)(T - 2) * H] : gss_load(p_g + (size_t)(T - 2) * H);
+    }
+    __syncthreads();
+
+    // one step; g_use holds grad row t (taken in the cell phase, then reloaded with row t - 2)
+    auto step = [&](int t, float& g_use) {
+        const int t1 = t > 0 ? t - 1 : 0;
+        const float s_r1 = p_sv[(size_t)t1 * 4 * H], s_z1 = p_sv[(size_t)t1 * 4 * H + H], s_n1 = p_sv[(size_t)t1 * 4 * H + 2 * H],
+                    s_hn1 = p_sv[(size_t)t1 * 4 * H + 3 * H], hprev1 = p_h[(size_t)t1 * H];
+        if (t + 1 < T) {
+            f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int k4 = 0; k4 < KW / 4; ++k4) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(&dl[lane & 3][wave * KW + 4 * k4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], fw[4 * k4 + e], acc[e], 0, 0, 0);
+            }
+            const f32x4 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+            for (int i = 0; i < R; ++i) part[wave][i][lane] = sum[i];
+            if (upper) {
+                f32x4 acx[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int k4 = 0; k4 < KW / 4; ++k4) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(&dlx[lane & 3][wave * KW + 4 * k4]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acx[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], fwi[4 * k4 + e], acx[e], 0, 0, 0);
+                }
+                const f32x4 sx = (acx[0] + acx[1]) + (acx[2] + acx[3]);
+#pragma unroll
+                for (int i = 0; i < R; ++i) partx[wave][i][lane] = sx[i];
+            }
+        }
+        gp_lds_barrier();
+        if (mine) {
+            if (upper && t + 1 < T)           // d x_{t+1}: the row the layer below takes as its grad_out of step t + 1
+                gss_store(p_dx + (size_t)(t + 1) * H, (partx[0][er][ej] + partx[1][er][ej]) + (partx[2][er][ej] + partx[3][er][ej]));
+            const float dstate = carry + (t + 1 < T ? ((part[0][er][ej] + part[1][er][ej]) + (part[2][er][ej] + part[3][er][ej])) : 0.f);
+            if (t < 0) {
+                P.dh0[(size_t)b * H + ej] = dstate;
+            } else {
+                const float gout = top ? g_use : gss_take(g_use, p_g + (size_t)t * H, dead, status, 9u);
+                if (t >= 2) g_use = top ? p_g[(size_t)(t - 2) * H] : gss_load(p_g + (size_t)(t - 2) * H);
+                float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, c = dstate;
+                if (t < len) {
+                    const float dh = dstate + gout;
+                    dn = dh * (1.f - s_z) * (1.f - s_n * s_n);
+                    dz = dh * (hprev - s_n) * s_z * (1.f - s_z);
+                    dr = dn * s_hn * s_r * (1.f - s_r);
+                    dnr = dn * s_r;
+                    c = dh * s_z;
+                }
+                carry = c;
+                dl[er][ej] = dr;
+                dl[er][H + ej] = dz;
+                dl[er][2 * H + ej] = dnr;
+                if (upper) {
+                    dlx[er][ej] = dr;
+                    dlx[er][H + ej] = dz;
+                    dlx[er][2 * H + ej] = dn;
+                }
+                const size_t row = (size_t)b * T + t;
+                float* dx = P.dxproj + row * G;
+                float* dhp = P.dhproj + row * G;
+                dx[ej] = dr;  dx[H + ej] = dz;  dx[2 * H + ej] = dn;
+                dhp[ej] = dr; dhp[H + ej] = dz; dhp[2 * H + ej] = dnr;
+            }
+        }
+        s_r = s_r1; s_z = s_z1; s_n = s_n1; s_hn = s_hn1; hprev = hprev1;
+        gp_lds_barrier();
+    };
+    int t = T - 1;
+    for (; t >= 1; t -= 2) {
+        step(t, ga);
+        step(t - 1, gb);
+    }
+    // t is 0 (T odd: one real step left, then the state-gradient step) or -1 (T even)
+    if (t == 0) {
+        step(0, ga);
+        step(-1, gb);
+    } else {
+        step(-1, ga);
+    }
+}
+
+extern "C" {
+
+int mg_gru_stack_small_supported(int B, int T, int H, int L) {
+    if (B <= 0 || T <= 0 || H != 64 || L < 2 || L > MG_GRU_STACK_MAX_LAYERS || g_mg_tuning[3] == 1) return 0;
+    // every (layer, item block) workgroup must be resident at once: one per CU is plenty at these sizes
+    return gp_device_holds(2L * L * mg_ceil_div(B, 4));
+}
+
+size_t mg_gru_stack_small_workspace_bytes(void) { return (size_t)GP_SYNC_WORDS * sizeof(unsigned); }
+
+static int gss_check(const char* who, const mg_gru_stack_layer* layers, int L, int B, int T, int H, void* workspace, size_t workspace_bytes) {
+    MG_CHECK_ARG(layers && mg_gru_stack_small_supported(B, T, H, L), "%s: unsupported shape (B=%d T=%d H=%d L=%d): H = 64, 2..%d layers", who, B, T,
+                 H, L, MG_GRU_STACK_MAX_LAYERS);
+    if (!workspace || workspace_bytes < mg_gru_stack_small_workspace_bytes()) {
+        mg_set_error("%s: workspace of %zu bytes needed, got %zu", who, mg_gru_stack_small_workspace_bytes(), workspace_bytes);
+        return MG_EWORKSPACE;
+    }
+    return MG_OK;
+}
+
+int mg_gru_stack_fwd_small_f32(const mg_gru_stack_layer* layers, int L, const int64_t* seq_len, int B, int T, int H, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    const int rc = gss_check("mg_gru_stack_fwd_small_f32", layers, L, B, T, H, workspace, workspace_bytes);
+    if (rc != MG_OK) return rc;
+    GssLayers a;
+    hipStream_t st = (hipStream_t)stream;
+    for (int l = 0; l < L; ++l) {
+        a.l[l] = layers[l];
+        const mg_gru_stack_layer& p = layers[l];
+        MG_CHECK_ARG(p.w_hh && p.b_hh && p.hstate && p.out && p.saved && (l == 0 ? p.xproj != nullptr : (p.w_ih && p.b_ih)),
+                     "mg_gru_stack_fwd_small_f32: layer %d: bad arguments", l);
+        MG_CHECK_ARG((((uintptr_t)p.w_hh | (uintptr_t)p.w_ih) % 16) == 0, "mg_gru_stack_fwd_small_f32: layer %d: weights must be 16-byte aligned", l);
+        // the hand-off buffer of every layer but the top one starts as all-sentinel
+        if (l + 1 < L && hipMemsetAsync(p.out, 0xFF, (size_t)B * T * H * sizeof(float), st) != hipSuccess) {
+            mg_set_error("mg_gru_stack_fwd_small_f32: memset failed");
+            return MG_ELAUNCH;
+        }
+    }
+    const int nblk = (int)mg_ceil_div(B, 4);
+    hipLaunchKernelGGL(gru_stack_fwd_small64_kernel, dim3((unsigned)(L * nblk)), dim3(256), 0, st, a, seq_len, B, T, L, nblk, (unsigned*)workspace);
+    MG_CHECK_LAUNCH("mg_gru_stack_fwd_small_f32");
+    return MG_OK;
+}
+
+int mg_gru_stack_bwd_small_f32(const mg_gru_stack_layer* layers, int L, const int64_t* seq_len, int B, int T, int H, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    const int rc = gss_check("mg_gru_stack_bwd_small_f32", layers, L, B, T, H, workspace, workspace_bytes);
+    if (rc != MG_OK) return rc;
+    GssLayers a;
+    hipStream_t st = (hipStream_t)stream;
+    for (int l = 0; l < L; ++l) {
+        a.l[l] = layers[l];
+        const mg_gru_stack_layer& p = layers[l];
+        MG_CHECK_ARG(p.w_hh && p.hstate && p.saved && p.dxproj && p.dhproj && p.dh0 && (l == 0 || p.w_ih) &&
+                         (l + 1 == L ? p.grad_out != nullptr : p.dxin != nullptr),
+                     "mg_gru_stack_bwd_small_f32: layer %d: bad arguments", l);
+        if (l + 1 < L && hipMemsetAsync(p.dxin, 0xFF, (size_t)B * T * H * sizeof(float), st) != hipSuccess) {
+            mg_set_error("mg_gru_stack_bwd_small_f32: memset failed");
+            return MG_ELAUNCH;
+        }
+    }
+    const int nblk = (int)mg_ceil_div(B, 4);
+    hipLaunchKernelGGL(gru_stack_bwd_small64_kernel, dim3((unsigned)(L * nblk)), dim3(256), 0, st, a, seq_len, B, T, L, nblk, (unsigned*)workspace);
+    MG_CHECK_LAUNCH("mg_gru_stack_bwd_small_f32");
+    return MG_OK;
+}
+
+}  // extern "C"

@@ -624,6 +624,95 @@ def lstm_persistent(precision, b, t, hid):
     return precision == 'bf16' and RECURRENCE_BF16 and ops.lstm_persist_ok(b, t, hid)
 
 
+GRU_STACK_WAVEFRONT = os.environ.get('MORGANA_GRU_STACK_WAVEFRONT', '1') != '0'
+
+
+def gru_stack_small(b, t, hid, n_layers):
+    """Consecutive small GRU layers run as one wavefront launch per direction (csrc/gru_small_stack.hip)."""
+    return GRU_STACK_WAVEFRONT and n_layers >= 2 and ops.gru_stack_small_ok(b, t, hid, n_layers)
+
+
+class GRUStackSmallFn(torch.autograd.Function):
+    """L stacked single-layer GRUs with a small hidden size (the three RecurrentCuDNNWrapper(nn.GRU(., 64)) of models/f0_test_model.py:
+    31-37): forward and backward are ONE launch each, a wavefront over (layer, time) of the workgroup-local small-GRU kernels
+    (mg_gru_stack_fwd_small_f32 / _bwd_small_f32).  The upper layers' input projections and the gradients handed down between the
+    layers are products inside the step (exact fp32 in both precision modes); layer 0's input projection and every weight gradient
+    are GEMMs in the mode's precision, as in ``GRUFn``.
+
+    forward(ctx, precision, x (B,T,I), seq_len, h0s ((L,B,H) or None), *params) with params = w_ih, w_hh, b_ih, b_hh per layer;
+    returns (outputs of the top layer (B,T,H), h_n (L,B,H))."""
+
+    @staticmethod
+    def forward(ctx, precision, x, seq_len, h0s, *params):
+        n_layers = len(params) // 4
+        w_ih = [params[4 * l].contiguous() for l in range(n_layers)]
+        w_hh = [params[4 * l + 1].contiguous() for l in range(n_layers)]
+        b_ih = [params[4 * l + 2].contiguous() for l in range(n_layers)]
+        b_hh = [params[4 * l + 3].contiguous() for l in range(n_layers)]
+        x = ops._require(x, torch.float32, 'inputs')
+        b, t, i_dim = x.shape
+        hid = w_hh[0].shape[1]
+        x2 = x.view(b * t, i_dim)
+        if precision == 'fp32':
+            xproj0 = ops.linear_fwd_f32(x2, None, b * t, w_ih[0], b_ih[0], ops.ACT_NONE)
+            x_saved = x2
+        else:
+            x_saved = ops.cast_pad_bf16(x2)
+            xproj0 = ops.linear_fwd_bf16(x_saved, None, b * t, i_dim, ops.cast_pad_bf16(w_ih[0]), b_ih[0], 3 * hid, ops.ACT_NONE,
+                                         out_f32=True)
+            if xproj0.shape[1] != 3 * hid:
+                xproj0 = xproj0[:, :3 * hid].contiguous()
+        outs, hstates, saveds = ops.gru_stack_small_fwd(xproj0.view(b, t, 3 * hid), w_ih, w_hh, b_ih, b_hh, seq_len, h0s, b, t, hid)
+        ctx.precision = precision
+        ctx.shape = (b, t, i_dim, hid, n_layers)
+        ctx.has_h0 = h0s is not None
+        ctx.save_for_backward(x_saved, seq_len, *w_ih, *w_hh, *hstates, *saveds, *outs[:-1])
+        hn = torch.stack([hstates[l][:, t] for l in range(n_layers)], dim=0)
+        return outs[-1], hn
+
+    @staticmethod
+    def backward(ctx, grad_out, grad_hn):
+        b, t, i_dim, hid, n_layers = ctx.shape
+        sv = ctx.saved_tensors
+        x_saved, seq_len = sv[0], sv[1]
+        pos = 2
+        w_ih = sv[pos:pos + n_layers]; pos += n_layers
+        w_hh = sv[pos:pos + n_layers]; pos += n_layers
+        hstate = sv[pos:pos + n_layers]; pos += n_layers
+        saved = sv[pos:pos + n_layers]; pos += n_layers
+        lower_out = sv[pos:pos + n_layers - 1]
+        dev = x_saved.device
+        m = b * t
+        g_out = grad_out.contiguous() if grad_out is not None else torch.zeros((b, t, hid), dtype=torch.float32, device=dev)
+        g_hn = [grad_hn[l] for l in range(n_layers)] if grad_hn is not None else None
+        dxprojs, dhprojs, dh0 = ops.gru_stack_small_bwd(g_out, g_hn, hstate, saved, w_ih, w_hh, seq_len, b, t, hid)
+        prev_rows = state_rows(b, t, dev)
+        grads = [None] * (4 * n_layers)
+        dx = None
+        for l in range(n_layers):
+            dxp2, dhp2 = dxprojs[l].view(m, 3 * hid), dhprojs[l].view(m, 3 * hid)
+            hs2 = hstate[l].view(b * (t + 1), hid)
+            k_in = i_dim if l == 0 else hid
+            if ctx.precision == 'fp32':
+                x_in = x_saved if l == 0 else lower_out[l - 1].view(m, hid)
+                dw_ih, db_ih = ops.linear_wgrad_f32(dxp2, x_in, None, 3 * hid, k_in)
+                dw_hh, db_hh = ops.linear_wgrad_f32(dhp2, hs2, prev_rows, 3 * hid, hid)
+                if l == 0 and ctx.needs_input_grad[1]:
+                    dx = ops.linear_dgrad_f32(dxp2, w_ih[0], None).view(b, t, i_dim)
+            else:
+                dxp_bf, dhp_bf = ops.cast_pad_bf16(dxp2), ops.cast_pad_bf16(dhp2)
+                x_in = x_saved if l == 0 else ops.cast_pad_bf16(lower_out[l - 1].view(m, hid))
+                dw_ih, db_ih = ops.linear_wgrad_bf16(dxp_bf, x_in, None, m, 3 * hid, k_in)
+                dw_hh, db_hh = ops.linear_wgrad_bf16(dhp_bf, ops.cast_pad_bf16(hs2), prev_rows, m, 3 * hid, hid)
+                if l == 0 and ctx.needs_input_grad[1]:
+                    dx = ops.linear_dgrad_bf16(dxp_bf, m, 3 * hid, ops.cast_transpose_bf16(w_ih[0]), i_dim, None, out_f32=True)
+                    if dx.shape[1] != i_dim:
+                        dx = dx[:, :i_dim].contiguous()
+                    dx = dx.view(b, t, i_dim)
+            grads[4 * l:4 * l + 4] = [dw_ih, dw_hh, db_ih, db_hh]
+        return (None, dx, None, dh0 if ctx.has_h0 else None, *grads)
+
+
 def lstm_layerwise(precision, b, t, hid):
     """A stack of LSTM layers runs layer by layer (two persistent launches each) rather than as the time-skewed stack of per-step
     launches: bf16 mode with the persistent bf16-operand recurrence, or fp32 parity mode with the persistent fp32 one

@@ -858,6 +858,86 @@ def lstm_pstack_fwd(xproj0, w_ih, w_hh, b_ih, b_hh, seq_len, h0s, c0s, b, t, h):
     return o, hstate, cstate, saved, hstate_bf
 
 
+def gru_stack_small_ok(b, t, h, n_layers):
+    """The small-GRU stack wavefront (mg_gru_stack_fwd_small_f32 / _bwd_small_f32) covers this shape."""
+    return PERSISTENT_RECURRENCE and bool(_lib.load().mg_gru_stack_small_supported(b, t, h, n_layers))
+
+
+def _gru_stack_workspace(dev):
+    lib = _lib.load()
+    key = (dev, torch.cuda.current_stream().cuda_stream, 'gru_stack')
+    ws = _PERSIST_WORKSPACES.get(key)
+    if ws is None:
+        ws = torch.zeros(lib.mg_gru_stack_small_workspace_bytes(), dtype=torch.uint8, device=dev)
+        _PERSIST_WORKSPACES[key] = ws
+    return ws
+
+
+def gru_stack_small_fwd(xproj0, w_ih, w_hh, b_ih, b_hh, seq_len, h0s, b, t, h):
+    """L stacked small GRU layers forward in one launch.  xproj0 (b,t,3h) f32 = layer 0's input projection incl. b_ih; w_ih[l], b_ih[l]
+    for l >= 1 (input size == h); h0s None or (L,b,h).  Returns per-layer lists (out, hstate, saved)."""
+    lib = _lib.load()
+    dev = xproj0.device
+    n_layers = len(w_hh)
+    descs = (_lib.GruStackLayer * n_layers)()
+    outs, hstates, saveds = [], [], []
+    for l in range(n_layers):
+        hs = torch.empty((b, t + 1, h), dtype=torch.float32, device=dev)
+        if h0s is None:
+            hs[:, 0].zero_()
+        else:
+            hs[:, 0].copy_(h0s[l].reshape(b, h))
+        o = torch.empty((b, t, h), dtype=torch.float32, device=dev)
+        sv = torch.empty((b, t, 4 * h), dtype=torch.float32, device=dev)
+        d = descs[l]
+        d.w_hh, d.b_hh = w_hh[l].data_ptr(), b_hh[l].data_ptr()
+        if l == 0:
+            d.xproj = xproj0.data_ptr()
+        else:
+            d.w_ih, d.b_ih = w_ih[l].data_ptr(), b_ih[l].data_ptr()
+        d.hstate, d.out, d.saved = hs.data_ptr(), o.data_ptr(), sv.data_ptr()
+        outs.append(o); hstates.append(hs); saveds.append(sv)
+    ws = _gru_stack_workspace(dev)
+    _lib.check(lib.mg_gru_stack_fwd_small_f32(ctypes.cast(descs, ctypes.c_void_p), n_layers, _p(seq_len), b, t, h, _p(ws), ws.numel(),
+                                              _stream()), 'mg_gru_stack_fwd_small_f32')
+    return outs, hstates, saveds
+
+
+def gru_stack_small_bwd(grad_out, grad_hn, hstate, saved, w_ih, w_hh, seq_len, b, t, h):
+    """The backward of gru_stack_small_fwd in one launch.  grad_out (b,t,h) = gradient of the TOP layer's outputs; grad_hn None or a
+    per-layer list of (b,h) tensors / None.  Returns per-layer lists (dxproj, dhproj) and dh0 (L,b,h)."""
+    lib = _lib.load()
+    dev = grad_out.device
+    n_layers = len(w_hh)
+    descs = (_lib.GruStackLayer * n_layers)()
+    dxprojs, dhprojs, keep = [], [], []
+    dh0 = torch.empty((n_layers, b, h), dtype=torch.float32, device=dev)
+    for l in range(n_layers):
+        d = descs[l]
+        d.w_hh = w_hh[l].data_ptr()
+        if l > 0:
+            d.w_ih = w_ih[l].data_ptr()
+        d.hstate, d.saved = hstate[l].data_ptr(), saved[l].data_ptr()
+        if l + 1 == n_layers:
+            d.grad_out = grad_out.data_ptr()
+        else:
+            dxin = torch.empty((b, t, h), dtype=torch.float32, device=dev)
+            keep.append(dxin)
+            d.dxin = dxin.data_ptr()
+        if grad_hn is not None and grad_hn[l] is not None:
+            g = _require(grad_hn[l].reshape(b, h), torch.float32, 'grad_hn')
+            keep.append(g)
+            d.grad_hn = g.data_ptr()
+        dxp = torch.empty((b, t, 3 * h), dtype=torch.float32, device=dev)
+        dhp = torch.empty((b, t, 3 * h), dtype=torch.float32, device=dev)
+        d.dxproj, d.dhproj, d.dh0 = dxp.data_ptr(), dhp.data_ptr(), dh0[l].data_ptr()
+        dxprojs.append(dxp); dhprojs.append(dhp)
+    ws = _gru_stack_workspace(dev)
+    _lib.check(lib.mg_gru_stack_bwd_small_f32(ctypes.cast(descs, ctypes.c_void_p), n_layers, _p(seq_len), b, t, h, _p(ws), ws.numel(),
+                                              _stream()), 'mg_gru_stack_bwd_small_f32')
+    return dxprojs, dhprojs, dh0
+
+
 def lstm_pstack_bwd_ok(b, t, h, n_layers):
     """The whole-stack backward wavefront (mg_lstm_pstack_bwd_bf16) covers this shape."""
     return PERSISTENT_RECURRENCE and bool(_lib.load().mg_lstm_pstack_bwd_supported(b, t, h, n_layers))

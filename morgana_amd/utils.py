@@ -257,6 +257,10 @@ class RecurrentCuDNNWrapper(nn.Module):
                        getattr(layer, 'bias_ih_l%d' % k), getattr(layer, 'bias_hh_l%d' % k)]
         return params
 
+    def _gru_params(self):
+        layer = self.layer
+        return [layer.weight_ih_l0, layer.weight_hh_l0, layer.bias_ih_l0, layer.bias_hh_l0]
+
     def _run_lstm(self, inputs, hidden, seq_len):
         """nn.LSTM with num_layers >= 1; hidden = (h0, c0), each (num_layers, B, H), returned in the same layout
         (utils.py:374-375, 388-389).  Several layers run as one time-skewed stack (functional.LSTMStackFn)."""
@@ -400,6 +404,27 @@ class SequentialWithRecurrent(nn.Sequential):
         end = (run[-1] + 1) if run else start
         return end, run
 
+    @staticmethod
+    def _gru_run(modules, start, hiddens, seq_len):
+        """Indices of consecutive RecurrentCuDNNWrapper(single-layer nn.GRU) modules from ``start`` (identity Dropouts between them
+        skipped) with one small hidden size, no initial hidden states and seq_len given - the stack of models/f0_test_model.py:31-37,
+        which runs as one wavefront launch per direction.  Returns (index behind the run, [module indices])."""
+        run, i, last_hidden = [], start, None
+        while i < len(modules) and seq_len is not None and len(run) < 4:
+            mod = modules[i]
+            if type(mod) is nn.Dropout and (mod.p == 0 or not mod.training) and run:
+                i += 1
+                continue
+            ok = (isinstance(mod, RecurrentCuDNNWrapper) and mod._hip_gru() and mod.layer.num_layers == 1 and hiddens[i] is None and
+                  (last_hidden is None or (mod.layer.input_size == last_hidden and mod.layer.hidden_size == last_hidden)))
+            if not ok:
+                break
+            run.append(i)
+            last_hidden = mod.layer.hidden_size
+            i += 1
+        end = (run[-1] + 1) if run else start
+        return end, run
+
     def _fused_mse_spec(self, targets, precision):
         """acts of the stack if it is [Linear, Sigmoid]* ... Linear(*,128), Sigmoid, Linear(128,32), Sigmoid, Linear(32,1) in
         bf16 mode with a 1-dimensional target (the README F0Model shape) - the case mg_f0_tail_bf16 fuses; else None."""
@@ -516,6 +541,23 @@ class SequentialWithRecurrent(nn.Sequential):
 
             if isinstance(input, (UpsampledSequence, UpsampledConcat)):
                 input = input.materialise()
+
+            if isinstance(module, RecurrentCuDNNWrapper) and module._hip_gru() and torch.is_tensor(input) and input.ndim == 3:
+                end, run = self._gru_run(modules, i, hiddens, seq_len)
+                t_in = input.shape[1]
+                if (len(run) > 1 and max_len is not None and int(max_len) == t_in and
+                        F_hip.gru_stack_small(input.shape[0], t_in, modules[run[0]].layer.hidden_size, len(run))):
+                    # consecutive small GRU wrappers (models/f0_test_model.py:31-37): one wavefront launch per direction
+                    params = []
+                    for k in run:
+                        params += modules[k]._gru_params()
+                    sl = seq_len if seq_len.dtype == torch.int64 else seq_len.long()
+                    input, hn = F_hip.GRUStackSmallFn.apply(precision, input.contiguous(), sl.contiguous(), None, *params)
+                    for pos, k in enumerate(run):
+                        hiddens[k] = hn[pos:pos + 1]
+                    zero_padded = True
+                    i = end
+                    continue
 
             if isinstance(module, RecurrentCuDNNWrapper):
                 end, run = self._lstm_run(modules, i, hiddens, seq_len)

@@ -547,3 +547,83 @@ def test_lstm_stack_backward_gate_gradients_and_fp32_copy():
     for l in range(n_layers):
         assert torch.equal(dgates_bf2[l], dgates_bf[l]), l
     assert torch.equal(dh02, dh0) and torch.equal(dc02, dc0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+# The stack of small GRU layers as one wavefront launch per direction (csrc/gru_small_stack.hip)
+@pytest.mark.gpu
+@pytest.mark.parametrize('b,t,i_dim,n_layers,precision', [(64, 120, 256, 3, 'fp32'), (13, 57, 40, 2, 'fp32'), (5, 1, 24, 3, 'fp32'),
+                                                         (30, 64, 96, 4, 'fp32'), (64, 90, 256, 3, 'bf16')])
+def test_gru_small_stack_wavefront_vs_chained_layers(b, t, i_dim, n_layers, precision):
+    """functional.GRUStackSmallFn (the GRU-64 layers of models/f0_test_model.py:31-37 as ONE launch per direction: a wavefront over layer
+    and time, the upper layers' input projections and the gradients between the layers computed inside the step) against the same
+    layers chained through functional.GRUFn.  fp32 mode: exact fp32 on both sides, only the summation order of those in-step products
+    differs - 1e-4 relative on outputs, final states and every gradient (measured ~1e-6).  bf16 mode: the chain rounds the upper
+    layers' inputs and gate gradients to bf16 for its GEMMs, the wavefront keeps them in fp32 - 2e-2.  Ragged lengths with a full and
+    a 1-step item, gradients on outputs and final states; odd and even T, T = 1; run twice: identical bits."""
+    hid = 64
+    assert F_hip.gru_stack_small(b, t, hid, n_layers)
+    torch.manual_seed(7 * b + n_layers)
+    x = torch.randn(b, t, i_dim, device=DEV, requires_grad=True)
+    sl_np = np.random.RandomState(b + t).randint(1, t + 1, size=b).astype(np.int64)
+    sl_np[0], sl_np[-1] = t, 1
+    seq_len = dev(sl_np)
+    params = []
+    for l in range(n_layers):
+        k = i_dim if l == 0 else hid
+        params += [torch.randn(3 * hid, k, device=DEV) / k ** 0.5, torch.randn(3 * hid, hid, device=DEV) / hid ** 0.5,
+                   torch.randn(3 * hid, device=DEV) * 0.1, torch.randn(3 * hid, device=DEV) * 0.1]
+    params = [p.requires_grad_(True) for p in params]
+    g_out = torch.randn(b, t, hid, device=DEV)
+    g_hn = torch.randn(n_layers, b, hid, device=DEV)
+    leaves = [x] + params
+
+    def run(kind):
+        for p in leaves:
+            p.grad = None
+        if kind == 'wavefront':
+            out, hn = F_hip.GRUStackSmallFn.apply(precision, x, seq_len, None, *params)
+        else:
+            out, hns = x, []
+            for l in range(n_layers):
+                out, h = F_hip.GRUFn.apply(precision, out.contiguous(), None, seq_len, *params[4 * l:4 * l + 4])
+                hns.append(h)
+            hn = torch.cat(hns, 0)
+        ((out * g_out).sum() + (hn * g_hn).sum()).backward()
+        ops.check_persistent_status()
+        return [v.detach().cpu().numpy().copy() for v in (out, hn, *[p.grad for p in leaves])]
+
+    want = run('chain')
+    got = run('wavefront')
+    tol = 1e-4 if precision == 'fp32' else 2e-2
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert np.all(np.isfinite(g)), k
+        assert rel_err(g, w) < tol, (k, rel_err(g, w))
+    for i, n in enumerate(sl_np):
+        assert np.all(got[0][i, n:] == 0)
+    again = run('wavefront')
+    for k, (g, w) in enumerate(zip(again, got)):
+        np.testing.assert_array_equal(g, w, err_msg='output %d of the second run' % k)
+
+
+@pytest.mark.gpu
+def test_gru_f0_model_runs_on_the_stack_wavefront():
+    """models.GRUF0Model (the shipped F0 model) takes the wavefront for its three GRU-64 wrappers: loss and every parameter gradient
+    against the same model with the wavefront switched off (fp32 mode, 1e-4)."""
+    torch.manual_seed(0)
+    feats = data.to_device(synthetic.make_acoustic_batch(6, (60, 150), streams=(('lf0', 3, 'mse'),), seed=5), DEV)
+    grads = {}
+    try:
+        for flag in (False, True):
+            F_hip.GRU_STACK_WAVEFRONT = flag
+            torch.manual_seed(1)
+            model = models.GRUF0Model(precision='fp32', generate=False).to(DEV)
+            loss, _ = model(feats)
+            loss.backward()
+            ops.check_persistent_status()
+            grads[flag] = [float(loss.detach())] + [p.grad.detach().cpu().numpy().copy() for p in model.parameters()]
+    finally:
+        F_hip.GRU_STACK_WAVEFRONT = True
+    assert abs(grads[True][0] - grads[False][0]) < 1e-5 * max(1.0, abs(grads[False][0]))
+    for k, (g, w) in enumerate(zip(grads[True][1:], grads[False][1:])):
+        assert rel_err(g, w) < 1e-4, (k, rel_err(g, w))
