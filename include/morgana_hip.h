@@ -49,6 +49,7 @@ const char* mg_last_error(void);
                                  * finishes dW / db (results are then NOT valid) - lets bench.py time the kernel alone */
 #define MG_TUNE_LSTM_BWD_STACK 6 /* mg_lstm_pstack_bwd_bf16: 0 = 32 hidden units per slot where they fit (one workgroup per CU), 1 = 16 (two per CU) */
 #define MG_TUNE_WGRAD_SPLITS 4  /* wide weight-gradient kernel: != 0 overrides the planned number of split-M slabs (a multiple of 8) */
+#define MG_TUNE_PROBE 7         /* timing probes of mg_f0_l2tail_bf16 (results garbage): 1 = no H1 loads, 2 = no tail, 4 = no layer-2 MFMAs, 8 = no sigmoid of H2 */
 #define MG_TUNE_WGRAD_ORDER 5   /* wide weight-gradient kernel, block order: 0 = planned, 1 = n tile fastest, 2 = the n tiles of a split on one XCD */
 int mg_set_tuning(int key, int value);
 int mg_version(void);           /* ABI version, bumped on incompatible change */
@@ -332,6 +333,23 @@ int mg_f0_tail_bf16(const uint16_t* H2, int ldh, int K3, const float* W3, const 
 int mg_f0_tail_rows_bf16(const uint16_t* H2, int ldh, int K3, const float* W3, const float* b3, const float* W4, const float* b4,
                          const float* target, const float* row_weight, int64_t M, float grad_scale, float* pred, float* loss,
                          uint16_t* dZ2, float* grads, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The 512 -> 128 Linear + Sigmoid in front of that tail fused INTO it (README.rst:65-73 layers 2-4 + morgana/losses.py:29-51):
+ * one pass over H1, the 128-wide activation H2 never reaches memory (the backward of layer 2 needs dZ2 and H1 only).
+ *   H1 bf16 [B*T, ldh1] (the 512 sigmoid outputs of the first layer); W2 bf16 [128, ldw2] (the optimiser's bf16 copy of the
+ *   weight, mg_cast_params_bf16 / mg_adam_step_plan_f32), b2 f32 [128]; everything else as mg_f0_tail_bf16.
+ * Outputs as mg_f0_tail_bf16, with dZ2 bf16 [B*T, lddz].  Same arithmetic per frame as mg_linear_fwd_bf16 + mg_f0_tail_bf16
+ * up to the summation order inside the 512-deep dot products.  workspace: mg_f0_l2tail_workspace_bytes(B*T).  Deterministic. */
+size_t mg_f0_l2tail_workspace_bytes(int64_t M);
+int mg_f0_l2tail_bf16(const uint16_t* H1, int ldh1, int K2, const uint16_t* W2, int ldw2, int N2, const float* b2, const float* W3,
+                      const float* b3, const float* W4, const float* b4, const float* target, const int64_t* seq_len, int B, int T,
+                      float grad_scale, float* pred, float* loss, uint16_t* dZ2, int lddz, float* grads, int accumulate, void* workspace,
+                      size_t workspace_bytes, void* stream);
+/* ... on M rows that each stand for a group of frames (phone-rate step), as mg_f0_tail_rows_bf16. */
+int mg_f0_l2tail_rows_bf16(const uint16_t* H1, int ldh1, int K2, const uint16_t* W2, int ldw2, int N2, const float* b2, const float* W3,
+                           const float* b3, const float* W4, const float* b4, const float* target, const float* row_weight, int64_t M,
+                           float grad_scale, float* pred, float* loss, uint16_t* dZ2, int lddz, float* grads, int accumulate,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * K3  GRU through RecurrentCuDNNWrapper   reference: morgana/utils.py:345-393 + torch.nn.GRU (gates r, z, n)

@@ -1,0 +1,524 @@
+// Second hidden layer TOGETHER with the fused tail of the README F0Model (README.rst:65-73 layers 2-4 + morgana/losses.py:29-51),
+// bf16 throughput mode:
+//
+//     H2 = sigmoid(H1 W2^T + b2)    H3 = sigmoid(H2 W3^T + b3)    pred = H3 w4 + b4    L = masked MSE(pred, target, seq_len)
+//     dpred = dL/dpred   dZ3 = (dpred w4) * H3 (1 - H3)   dZ2 = (dZ3 W3) * H2 (1 - H2)
+//     dW3 = dZ3^T H2, db3, dW4 = dpred^T H3, db4
+//
+// in ONE pass over H1 (M x 512 bf16).  The unfused pair (gemm_nt_persist<128> then f0_tail_kernel, tail_bf16.hip) wrote H2
+// (65 MB at C2) and read it back: 68 + 43 us for 40 GFLOP, both kernels HBM / latency bound.  H2 is needed by nothing else - the
+// backward of layer 2 wants dZ2 and H1 only - so here it never leaves the registers:
+//   * one 256-thread workgroup per CU, ONE wave per SIMD with up to 512 registers; W2 (128 x 512 bf16 = 128 KB) is resident
+//     in LDS for the whole launch, 16-byte chunk c of row n at c ^ (n & 15) (conflict free for ds_read_b128's 16-lane groups);
+//   * a wave owns 32-frame tiles.  H2^T = W2 . H1^T with the WEIGHTS as the A operand (v_mfma_f32_32x32x16_bf16, 4 blocks of 32
+//     units x 32 k-steps): the lane then holds ONE frame, so its slice of H1 comes straight from global memory into the B
+//     operand registers - 32 x 16 bytes of the frame's own row, no LDS staging, no transposition - and the next tile's rows are
+//     requested while this tile multiplies (two half-tile register buffers of 64 VGPRs: 16-32 KB in flight per wave);
+//     the contraction order inside a k-step is permuted so that a lane reads 64 contiguous bytes per 128-byte line
+//     (lane half lh takes bytes [64 lh, 64 lh + 64) of each line; W2's fragment addresses follow the same permutation);
+//   * the accumulator layout of H2^T (lane = frame, registers = units) IS the B-operand layout of the next product up to a
+//     permutation of the contraction index, so Z3^T = W3 . H2^T takes the bf16-rounded H2 registers as they are (W3 fragments
+//     pre-permuted in LDS, cdna_hip_programming.md section 3), and H2 (1 - H2) is formed from the same registers;
+//   * everything after that is the tail kernel's chain (same arithmetic, same order; tail_bf16.hip): sigmoid, the 32-wide dot
+//     with w4, the masked MSE term, dZ3, dH2^T = W3^T . dZ3^T, dZ2 stored as 16-byte row pieces, dW3 += dZ3^T . H2 through
+//     ds_read_b64_tr_b16 (the H2 tile goes through a 2 KB per-wave LDS patch in four 32-unit slices).
+// Partial sums are reduced lane -> wave -> workgroup in a fixed order and finished by an ordered slab reduce (no atomics).
+#include "common.h"
+#include "slab_reduce.h"
+
+typedef __bf16 bfv8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bfv4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bfv2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define LT_K 512
+#define LT_N2 128
+#define LT_N3 32
+#define LT_SLAB (LT_N3 * LT_N2 + LT_N3 + LT_N3 + 2)      // dW3 | db3 | dW4 | db4 | loss   (the tail kernel's slab)
+
+// LDS map (bytes)
+#define LT_W2 0                                          // 128 rows x 1024 B, chunk c of row n at c ^ (n & 15)
+#define LT_ZF (LT_N2 * LT_K * 2)                         // A fragments of Z3^T = W3 . H2^T: [8 k-steps][64 lanes][16 B]
+#define LT_W3P (LT_ZF + 8 * 64 * 16)                     // A fragments of dH2^T = W3^T . dZ3^T: [4 kt][2 s][64 lanes][16 B]
+#define LT_B2 (LT_W3P + 8 * 64 * 16)                     // b2 f32[128]
+#define LT_WAVE0 (LT_B2 + LT_N2 * 4)                     // per wave: 2 KB patch (dZ3 tile, then the four H2 slices)
+#define LT_WAVE_BYTES 2048
+#define LT_LDS (LT_WAVE0 + 4 * LT_WAVE_BYTES)            // 156,160 B: one workgroup per CU
+
+__device__ unsigned int g_lt_sink[512];                   // where the stores of rows past M go (no branch around a store)
+
+// 16 x 16-bit transposed fragment of a [32 rows][64 B] patch: lane gets column 16 (g & 1) + (lane & 15)... as the 32x32x16 A / B
+// operand wants it (row = contraction index).  swz: 16-byte chunk c of row m stored at c ^ ((m >> 2) & 3).
+__device__ __forceinline__ bfv8 lt_tr_frag(const unsigned char* tile, int lane, int ks, bool swz) {
+    const int i = lane & 15, g = lane >> 4;
+    const int q = i >> 2, p = i & 3;
+    const int mrow = ks * 16 + 8 * (g >> 1) + q;
+    const int col = 16 * (g & 1) + 4 * p;
+    const int c = col >> 3, in = (col & 7) << 1;
+    const int c_lo = swz ? (c ^ ((mrow >> 2) & 3)) : c;
+    const int c_hi = swz ? (c ^ (((mrow + 4) >> 2) & 3)) : c;
+    const bfv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(tile + mrow * 64 + ((c_lo << 4) | in)));
+    const bfv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(tile + (mrow + 4) * 64 + ((c_hi << 4) | in)));
+    return bfv8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+// PROBE (timing experiments through MG_TUNE_PROBE, results garbage): 1 = no H1 loads inside the loop, 2 = no tail (steps 2-9),
+// 4 = no layer-2 MFMAs, 8 = no sigmoid on H2, 16 = no steps 8-9, 32 = no step 9.  The product kernel is PROBE = 0.
+template <int PROBE>
+__global__ __launch_bounds__(256, 1) void f0_l2tail_kernel(const uint16_t* __restrict__ H1, int ldh1, const uint16_t* __restrict__ W2,
+                                                           int ldw2, const float* __restrict__ b2, const float* __restrict__ W3,
+                                                           const float* __restrict__ b3, const float* __restrict__ W4,
+                                                           const float* __restrict__ b4, const float* __restrict__ target,
+                                                           const int64_t* __restrict__ seq_len, int64_t M, int B, int T,
+                                                           float grad_scale, float* __restrict__ pred, uint16_t* __restrict__ dZ2,
+                                                           int lddz, float* __restrict__ slab, const float* __restrict__ row_weight) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LT_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mi = lane & 31, lh = lane >> 5;
+
+    // ---- one-time: W2 (bf16 as it is), the two permuted W3 fragment tables, b2 ------------------------------------------
+    // Every load of a batch is in flight before the first LDS store (a copy loop of load -> store pairs cost ~15 us per launch: at
+    // the phone-rate row count the whole kernel is one tile per wave behind this prologue).
+    {
+        unsigned short* w3s = reinterpret_cast<unsigned short*>(smem + LT_WAVE0);       // W3 as bf16 [32][128], staged in the patches
+        float w3v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w3v[i] = W3[tid + 256 * i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            u32x4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = tid + 256 * (8 * q + i), n = e >> 6, c = e & 63;
+                v[i] = *reinterpret_cast<const u32x4*>(W2 + (size_t)n * ldw2 + c * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = tid + 256 * (8 * q + i), n = e >> 6, c = e & 63;
+                *reinterpret_cast<u32x4*>(smem + LT_W2 + n * (LT_K * 2) + ((c ^ (n & 15)) << 4)) = v[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w3s[tid + 256 * i] = mg_f2bf(w3v[i]);
+        if (tid < LT_N2) *reinterpret_cast<float*>(smem + LT_B2 + tid * 4) = b2[tid];
+        __syncthreads();
+        // fragment f = tid + 256 i: f < 512 -> Z3 fragments [st = 2 blk + s][lane]: element j = W3[lane & 31][unit of B slot j];
+        //                           f >= 512 -> dH2 fragments [kt][s][lane]: element j = W3[unit3 of slot j][32 kt + (lane & 31)]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + 256 * i, l = f & 63, r = l & 31, h = l >> 5, g = (f >> 6) & 7;
+            unsigned short el[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int u = 8 * (j >> 2) + 4 * h + (j & 3);                             // slot j of lane half h inside a 16-unit step
+                el[j] = (f < 512) ? w3s[r * LT_N2 + 16 * g + u] : w3s[(16 * (g & 1) + u) * LT_N2 + 32 * (g >> 1) + r];
+            }
+            *reinterpret_cast<u32x4*>(smem + LT_ZF + f * 16) = u32x4{el[0] | ((unsigned)el[1] << 16), el[2] | ((unsigned)el[3] << 16),
+                                                                   el[4] | ((unsigned)el[5] << 16), el[6] | ((unsigned)el[7] << 16)};
+        }
+        __syncthreads();                                   // the staged W3 is done with: its bytes become the waves' patches
+    }
+
+    unsigned char* patch = smem + LT_WAVE0 + wave * LT_WAVE_BYTES;
+
+    // register r of a C^T tile <-> unit offset 8 (r >> 2) + 4 lh + (r & 3)
+    float b3v[16], w4v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int n = 8 * (r >> 2) + 4 * lh + (r & 3);
+        b3v[r] = b3[n];
+        w4v[r] = W4[n];
+    }
+    const float b4v = b4[0];
+
+    f32x16 acc_w3[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_w3[kt][r] = 0.f;
+    float dw4p[16], db3p[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dw4p[r] = db3p[r] = 0.f;
+    float db4p = 0.f, lossp = 0.f;
+
+    // W2 fragment of MFMA step j = 4 a + c, unit block blk: row 32 blk + mi, 16-byte chunk 8 a + 4 lh + c (this lane's B slot of
+    // step j holds H1[frame][64 a + 32 lh + 8 c .. + 7]) at position chunk ^ (mi & 15):  bits 0-3 of the chunk are (8 (a & 1) + c)
+    // ^ (4 lh) ^ (mi & 15), bits 4-5 are a >> 1.
+    const int w2_lane = LT_W2 + mi * (LT_K * 2);
+    const int xl = (mi & 15) ^ (4 * lh);
+
+    const int64_t n_tiles = (M + 31) / 32;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    auto load_half = [&](u32x4 (&dst)[16], int64_t tile, int half) {
+        int64_t mm = tile * 32 + mi;
+        if (mm > M - 1) mm = M - 1;                         // rows past the end: any valid row (their results are discarded)
+        const uint16_t* hp = H1 + (size_t)mm * ldh1 + 256 * half + 32 * lh;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dst[4 * a + c] = *reinterpret_cast<const u32x4*>(hp + 64 * a + 8 * c);
+    };
+    auto load_half_p = [&](u32x4 (&dst)[16], int64_t tile, int half) {
+        if (!(PROBE & 1)) load_half(dst, tile, half);
+    };
+
+    // Per-frame scalars of the loss, fetched one tile ahead and IN FRONT of that tile's H1 rows: vector memory returns in issue
+    // order, so a target load issued inside the tail would wait for the whole prefetch of the next tile.
+    //   row_weight mode: s1 = weight;  seq_len mode: s1 = [t < n_b], s2 = (float) n_b
+    auto load_scalars = [&](int64_t tile_, float& tg, float& s1, float& s2) {
+        int64_t mm = tile_ * 32 + mi;
+        if (mm > M - 1) mm = M - 1;
+        tg = target[mm];
+        if (row_weight) {
+            s1 = row_weight[mm];
+            s2 = 0.f;
+        } else {
+            const unsigned mu = (unsigned)mm, b = mu / (unsigned)T, t = mu - b * (unsigned)T;     // M < 2^31 (checked by the launcher)
+            int64_t nb = seq_len ? seq_len[b] : (int64_t)T;
+            if (nb > T) nb = T;
+            if (nb < 0) nb = 0;
+            s1 = (int64_t)t < nb ? 1.f : 0.f;
+            s2 = (float)nb;
+        }
+    };
+
+    f32x16 acc[4];
+    auto bias_acc = [&]() {                                // register 4 q + e of block blk <-> unit 32 blk + 8 q + 4 lh + e
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(smem + LT_B2 + (32 * blk + 8 * q + 4 * lh) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[blk][4 * q + e] = bq[e];
+            }
+    };
+    bias_acc();
+    float* const pred_sink = reinterpret_cast<float*>(g_lt_sink) + lane;
+    uint16_t* const dz_sink = reinterpret_cast<uint16_t*>(g_lt_sink) + lane * 8;
+
+    // dZ2 / pred of a tile are stored at the top of the NEXT iteration, in front of that iteration's prefetch: issued in the tail
+    // they queue behind the 32 row loads of the next tile (vector memory issues in order) and the wave stands at the store until
+    // those have gone out - the tail then no longer overlaps the stream it was meant to hide.
+    u32x4 dzst[8];
+    uint16_t* dzp = dz_sink;
+    float* predp = pred_sink;
+    float pst = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dzst[i] = u32x4{0u, 0u, 0u, 0u};
+
+    u32x4 ha[16], hb[16];
+    float tg_n = 0.f, s1_n = 0.f, s2_n = 0.f;
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile < n_tiles) {
+        load_scalars(tile, tg_n, s1_n, s2_n);
+        load_half(ha, tile, 0);
+        load_half(hb, tile, 1);
+    }
+    for (; tile < n_tiles; tile += stride) {
+        const int64_t m = tile * 32 + mi;
+        const bool live = m < M;
+        const float tg = tg_n, s1 = s1_n, s2 = s2_n;
+        load_scalars(tile + stride, tg_n, s1_n, s2_n);
+        if (!(PROBE & 64)) {
+            *predp = pst;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4*>(dzp + 32 * (i >> 1) + 16 * (i & 1)) = dzst[i];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // (1) H2^T = W2 . H1^T + b2 (the accumulators start from the bias, loaded at the end of the previous tile)
+        // W2 fragments are read LT_AHEAD MFMA groups (4 MFMAs = one k-step over the four unit blocks) ahead of their use and the order
+        // is pinned: left alone hipcc puts every ds_read_b128 right in front of its MFMA with an lgkmcnt(0) between them - 128 exposed
+        // LDS round trips per tile on a wave that has no partner on its SIMD.
+        auto w2frag = [&](int j, int blk) -> bfv8 {
+            const int a = j >> 2, c = j & 3;
+            return *reinterpret_cast<const bfv8*>(smem + w2_lane + blk * 32 * (LT_K * 2) + (a >> 1) * 256 + ((xl ^ (8 * (a & 1) + c)) << 4));
+        };
+        constexpr int LT_AHEAD = 2;
+        bfv8 wf[LT_AHEAD + 1][4];
+#pragma unroll
+        for (int j = 0; j < LT_AHEAD; ++j) {
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) wf[j][blk] = w2frag(j, blk);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        }
+        const int64_t next = tile + stride;                  // past the last tile: rows clamp to M - 1, the values are never used
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            if (j + LT_AHEAD < 32) {
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk) wf[(j + LT_AHEAD) % (LT_AHEAD + 1)][blk] = w2frag(j + LT_AHEAD, blk);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            }
+            const u32x4 hv = j < 16 ? ha[j & 15] : hb[j & 15];
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) {
+                if (PROBE & 4) {
+                    asm volatile("" ::"v"(wf[j % (LT_AHEAD + 1)][blk]), "v"(hv));
+                    continue;
+                }
+                acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j % (LT_AHEAD + 1)][blk], __builtin_bit_cast(bfv8, hv), acc[blk], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            if (j == 15) {                                   // the registers just consumed take the next tile's first half
+                load_half_p(ha, next, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 16, 0);
+            }
+        }
+        load_half_p(hb, next, 1);
+        if (PROBE & 2) {
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[blk][r]));
+            continue;
+        }
+
+        // (2) sigmoid, bf16: hq[2 blk + s] = registers 8 s .. 8 s + 7 of block blk = B fragment of Z3's k-step 2 blk + s.
+        //     The W3 fragments of step 3 are requested first: their LDS latency passes under the sigmoids.
+        bfv8 zf[8];
+#pragma unroll
+        for (int st = 0; st < 8; ++st) zf[st] = *reinterpret_cast<const bfv8*>(smem + LT_ZF + (st * 64 + lane) * 16);
+        u32x4 hq[8];
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            unsigned int w[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (PROBE & 8) ? acc[blk][4 * q + e] : mg_sigmoid_fast(acc[blk][4 * q + e]);
+                w[2 * q] = __builtin_bit_cast(unsigned int, bfv2{(__bf16)v[0], (__bf16)v[1]});
+                w[2 * q + 1] = __builtin_bit_cast(unsigned int, bfv2{(__bf16)v[2], (__bf16)v[3]});
+            }
+            hq[2 * blk] = u32x4{w[0], w[1], w[2], w[3]};
+            hq[2 * blk + 1] = u32x4{w[4], w[5], w[6], w[7]};
+        }
+
+        // (3) Z3^T = W3 . H2^T; the W3^T fragments of step 8 are requested behind it
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 8; ++st) z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[st], __builtin_bit_cast(bfv8, hq[st]), z, 0, 0, 0);
+        bfv8 w3p[8];
+#pragma unroll
+        for (int st = 0; st < 8; ++st) w3p[st] = *reinterpret_cast<const bfv8*>(smem + LT_W3P + (st * 64 + lane) * 16);
+
+        // (4) sigmoid, prediction
+        float h3[16];
+        float ph = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            h3[r] = mg_sigmoid_fast(z[r] + b3v[r]);
+            ph += h3[r] * w4v[r];
+        }
+        // ph of the other lane half (the other 16 units of this frame): v_permlane32_swap instead of a trip through LDS
+        const auto phs = __builtin_amdgcn_permlane32_swap(__float_as_uint(ph), __float_as_uint(ph), false, false);
+        const float p = (__uint_as_float(phs[0]) + __uint_as_float(phs[1])) + b4v;
+
+        // (5) masked MSE of this frame: tail_bf16.hip (5) without branches.  row_weight mode: a = weight, c = 2 g, l = 1;
+        //     seq_len mode: a = [t < n_b], inv = 1 / (n_b B) (n_b == 0 -> inf: 0 * inf = NaN, as the reference), c = 2 g inv, l = inv;
+        //     dpred = (e a) c, loss term = (e e a) l: the same products in the same order as the branches of the tail kernel
+        const float inv = 1.f / (s2 * (float)B);
+        const float cw = row_weight ? 2.f * grad_scale : 2.f * grad_scale * inv;
+        const float lw = row_weight ? 1.f : inv;
+        const float e = p - tg;
+        const float dpred = live ? (e * s1) * cw : 0.f;
+        if (lh == 0) {
+            lossp += live ? (e * e * s1) * lw : 0.f;
+            db4p += dpred;
+        }
+        predp = (live && lh == 0) ? pred + m : pred_sink;
+        pst = p;
+
+        // (6) backward of layer 4 and of the layer-3 sigmoid
+        float dz3[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dz3[r] = dpred * w4v[r] * h3[r] * (1.f - h3[r]);
+            dw4p[r] += dpred * h3[r];
+            db3p[r] += dz3[r];
+        }
+        // (7) dZ3 as bf16: registers 8 s .. 8 s + 7 are the B fragment of k-step s; the row-major copy goes to the patch
+        u32x4 dzf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            unsigned int w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                w[q] = __builtin_bit_cast(unsigned int, bfv2{(__bf16)dz3[8 * s + 2 * q], (__bf16)dz3[8 * s + 2 * q + 1]});
+            dzf[s] = u32x4{w[0], w[1], w[2], w[3]};
+            *reinterpret_cast<u32x2*>(patch + mi * 64 + (16 * s + 4 * lh) * 2) = u32x2{w[0], w[1]};
+            *reinterpret_cast<u32x2*>(patch + mi * 64 + (16 * s + 8 + 4 * lh) * 2) = u32x2{w[2], w[3]};
+        }
+        bfv8 dzt[2];                                         // dZ3^T fragments of the dW3 product (contraction over frames)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) dzt[s] = lt_tr_frag(patch, lane, s, false);
+
+        // (8) per 32-unit block kt of layer 2: dH2^T = W3^T . dZ3^T, dZ2 = dH2 * H2 (1 - H2) written as 16-byte row pieces;
+        // (9) dW3[:, block kt] += dZ3^T . H2[:, block kt] with the H2 slice read back transposed from the patch (LDS operations of a
+        //     wave execute in order: the slice store cannot overtake the transposed reads of the previous occupant)
+        if (PROBE & 16) {
+            asm volatile("" ::"v"(dzt[0]), "v"(dzt[1]), "v"(dzf[0]), "v"(dzf[1]));
+            continue;
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f32x16 d;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3p[kt * 2 + s], __builtin_bit_cast(bfv8, dzf[s]), d, 0, 0, 0);
+            }
+            unsigned int pk[4][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                // H2 of units 32 kt + 8 g + 4 lh + e = registers 4 g + e of block kt = words 2 (g & 1), 2 (g & 1) + 1 of hq[2 kt + (g >> 1)]
+                const unsigned int w0 = hq[2 * kt + (g >> 1)][2 * (g & 1)], w1 = hq[2 * kt + (g >> 1)][2 * (g & 1) + 1];
+                const float h[4] = {__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xffff0000u), __uint_as_float(w1 << 16),
+                                    __uint_as_float(w1 & 0xffff0000u)};
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = d[4 * g + e] * h[e] * (1.f - h[e]);
+                pk[g][0] = __builtin_bit_cast(unsigned int, bfv2{(__bf16)v[0], (__bf16)v[1]});
+                pk[g][1] = __builtin_bit_cast(unsigned int, bfv2{(__bf16)v[2], (__bf16)v[3]});
+                if (!(PROBE & 32)) *reinterpret_cast<u32x2*>(patch + mi * 64 + ((g ^ ((mi >> 2) & 3)) << 4) + 8 * lh) = u32x2{w0, w1};
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                const auto r0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+                dzst[2 * kt + (g >> 1)] = u32x4{r0[0], r1[0], r0[1], r1[1]};          // row m, columns 32 kt + 8 g + 8 lh ..
+            }
+#pragma unroll
+            for (int s = 0; s < (PROBE & 32 ? 0 : 2); ++s) {
+                const bfv8 bq = lt_tr_frag(patch, lane, s, true);
+                acc_w3[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dzt[s], bq, acc_w3[kt], 0, 0, 0);
+            }
+        }
+        dzp = live ? dZ2 + (size_t)m * lddz + 8 * lh : dz_sink;
+        bias_acc();                                         // the next tile's accumulators (their registers were free until here)
+    }
+    *predp = pst;                                          // the last tile's results
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4*>(dzp + 32 * (i >> 1) + 16 * (i & 1)) = dzst[i];
+
+    // ---- reduction: lanes (frames) -> wave -> workgroup, fixed order (as tail_bf16.hip) -----------------------------------
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+            dw4p[r] += __shfl_xor(dw4p[r], off, 64);
+            db3p[r] += __shfl_xor(db3p[r], off, 64);
+        }
+    }
+    db4p = mg_wave_sum(db4p);
+    lossp = mg_wave_sum(lossp);
+
+    __syncthreads();                                   // every wave is done with W2: its region takes the four waves' sums
+    float* red = reinterpret_cast<float*>(smem + LT_W2);               // [4 waves][LT_SLAB]
+    float* mine = red + wave * LT_SLAB;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = (r & 3) + 8 * (r >> 2) + 4 * lh;             // plain C layout: row = hidden unit n
+            const int k = 32 * kt + mi;                                //                 col = input feature k
+            mine[n * LT_N2 + k] = acc_w3[kt][r];
+        }
+    if (mi == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = 8 * (r >> 2) + 4 * lh + (r & 3);
+            mine[LT_N3 * LT_N2 + n] = db3p[r];
+            mine[LT_N3 * LT_N2 + LT_N3 + n] = dw4p[r];
+        }
+    }
+    if (lane == 0) {
+        mine[LT_N3 * LT_N2 + 2 * LT_N3] = db4p;
+        mine[LT_N3 * LT_N2 + 2 * LT_N3 + 1] = lossp;
+    }
+    __syncthreads();
+    float* out = slab + (size_t)blockIdx.x * LT_SLAB;
+    for (int e = tid; e < LT_SLAB; e += 256) out[e] = ((red[e] + red[LT_SLAB + e]) + red[2 * LT_SLAB + e]) + red[3 * LT_SLAB + e];
+}
+
+static int l2tail_blocks(int64_t M) {
+    int64_t blocks = mg_ceil_div(mg_ceil_div(M, 32), 4);
+    if (blocks > 256) blocks = 256;                    // one resident workgroup per CU (156 KB of LDS each)
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+extern "C" {
+
+size_t mg_f0_l2tail_workspace_bytes(int64_t M) { return mg_align_up((size_t)l2tail_blocks(M) * LT_SLAB * sizeof(float), 256); }
+
+static int f0_l2tail_launch(const char* name, const uint16_t* H1, int ldh1, int K2, const uint16_t* W2, int ldw2, int N2, const float* b2,
+                            const float* W3, const float* b3, const float* W4, const float* b4, const float* target,
+                            const int64_t* seq_len, const float* row_weight, int64_t M, int B, int T, float grad_scale, float* pred,
+                            float* loss, uint16_t* dZ2, int lddz, float* grads, int accumulate, void* workspace, size_t workspace_bytes,
+                            void* stream) {
+    MG_CHECK_ARG(H1 && W2 && b2 && W3 && b3 && W4 && b4 && target && pred && loss && dZ2 && grads && M > 0 && M < 2147483647LL,
+                 "%s: bad arguments (M=%lld)", name, (long long)M);
+    MG_CHECK_ARG(K2 == LT_K && N2 == LT_N2 && ldh1 >= LT_K && ldh1 % 8 == 0 && ldw2 >= LT_K && ldw2 % 8 == 0 && lddz >= LT_N2 && lddz % 8 == 0,
+                 "%s: needs a 512 -> 128 layer (K2=%d N2=%d ldh1=%d ldw2=%d lddz=%d)", name, K2, N2, ldh1, ldw2, lddz);
+    MG_CHECK_ARG((((uintptr_t)H1 | (uintptr_t)W2 | (uintptr_t)dZ2) % 16) == 0, "%s: H1 / W2 / dZ2 must be 16-byte aligned", name);
+    if (!workspace || workspace_bytes < mg_f0_l2tail_workspace_bytes(M)) {
+        mg_set_error("%s: workspace of %zu bytes needed, got %zu", name, mg_f0_l2tail_workspace_bytes(M), workspace_bytes);
+        return MG_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = l2tail_blocks(M);
+    float* slab = (float*)workspace;
+#define LT_LAUNCH(P_) hipLaunchKernelGGL(f0_l2tail_kernel<P_>, dim3(blocks), dim3(256), 0, st, H1, ldh1, W2, ldw2, b2, W3, b3, W4, b4, target, seq_len, M, B, T, grad_scale, pred, dZ2, lddz, slab, row_weight)
+    switch (g_mg_tuning[MG_TUNE_PROBE]) {
+        case 1: LT_LAUNCH(1); break;
+        case 2: LT_LAUNCH(2); break;
+        case 3: LT_LAUNCH(3); break;
+        case 4: LT_LAUNCH(4); break;
+        case 6: LT_LAUNCH(6); break;
+        case 7: LT_LAUNCH(7); break;
+        case 8: LT_LAUNCH(8); break;
+        case 16: LT_LAUNCH(16); break;
+        case 32: LT_LAUNCH(32); break;
+        case 17: LT_LAUNCH(17); break;
+        default: LT_LAUNCH(0); break;
+    }
+#undef LT_LAUNCH
+    MG_CHECK_LAUNCH(name);
+    // grads = [dW3 (32*128) | db3 (32) | dW4 (32) | db4 (1)]; the loss is the last slab entry
+    const int n_grads = LT_SLAB - 1;
+    if (loss == grads + n_grads && !accumulate) {
+        mg_launch_slab_reduce(slab, LT_SLAB, LT_SLAB, blocks, grads, 0, st);          // loss stored right behind the gradients
+    } else {
+        mg_launch_slab_reduce(slab, n_grads, LT_SLAB, blocks, grads, accumulate, st);
+        mg_launch_slab_reduce(slab + (LT_SLAB - 1), 1, LT_SLAB, blocks, loss, 0, st);
+    }
+    MG_CHECK_LAUNCH(name);
+    return MG_OK;
+}
+
+int mg_f0_l2tail_bf16(const uint16_t* H1, int ldh1, int K2, const uint16_t* W2, int ldw2, int N2, const float* b2, const float* W3,
+                      const float* b3, const float* W4, const float* b4, const float* target, const int64_t* seq_len, int B, int T,
+                      float grad_scale, float* pred, float* loss, uint16_t* dZ2, int lddz, float* grads, int accumulate, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    MG_CHECK_ARG(B > 0 && T > 0, "mg_f0_l2tail_bf16: bad arguments (B=%d T=%d)", B, T);
+    return f0_l2tail_launch("mg_f0_l2tail_bf16", H1, ldh1, K2, W2, ldw2, N2, b2, W3, b3, W4, b4, target, seq_len, nullptr, (int64_t)B * T, B, T,
+                            grad_scale, pred, loss, dZ2, lddz, grads, accumulate, workspace, workspace_bytes, stream);
+}
+
+int mg_f0_l2tail_rows_bf16(const uint16_t* H1, int ldh1, int K2, const uint16_t* W2, int ldw2, int N2, const float* b2, const float* W3,
+                           const float* b3, const float* W4, const float* b4, const float* target, const float* row_weight, int64_t M,
+                           float grad_scale, float* pred, float* loss, uint16_t* dZ2, int lddz, float* grads, int accumulate,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    MG_CHECK_ARG(row_weight, "mg_f0_l2tail_rows_bf16: row_weight is null");
+    return f0_l2tail_launch("mg_f0_l2tail_rows_bf16", H1, ldh1, K2, W2, ldw2, N2, b2, W3, b3, W4, b4, target, nullptr, row_weight, M, 1,
+                            (int)(M < 2147483647LL ? M : 1), grad_scale, pred, loss, dZ2, lddz, grads, accumulate, workspace,
+                            workspace_bytes, stream);
+}
+
+}  // extern "C"

@@ -321,7 +321,8 @@ class LinearStackMSEFn(torch.autograd.Function):
 
     forward(ctx, acts, x2d, rows, target (B,T,1), seq_len, *params) -> (loss, pred (B,T,1)).
     Layers up to the 128-wide one run as in LinearStackFn; the last two layers, the loss and their whole backward are ONE
-    kernel (mg_f0_tail_bf16) that leaves dL/d(pre-activation of the 128-wide layer) for the remaining backward.
+    kernel (mg_f0_tail_bf16) that leaves dL/d(pre-activation of the 128-wide layer) for the remaining backward; when the 128-wide
+    layer is 512 -> 128 + sigmoid it runs inside that kernel too (mg_f0_l2tail_bf16) and its output is never written.
     `pred` is returned for reporting only (non-differentiable): the loss is the one consumer of the prediction.
     """
 
@@ -346,6 +347,9 @@ class LinearStackMSEFn(torch.autograd.Function):
         # bf16 operands of the leading layers: copies that live on the parameters and are kept current by the optimiser's update
         # kernel (ops.param_shadows) - a training step launches no weight cast
         w_bf, w_t = ops.param_shadows(weights[:lead], want_t=tuple(range(1, lead)))
+        # The 512 -> 128 sigmoid layer in front of the tail runs inside the tail kernel (csrc/l2tail_bf16.hip): its 128-wide output is
+        # needed by nothing but the tail, so it is never written (frame rate: 68 + 43 us and 130 MB of traffic -> one pass over H1)
+        l2tail = lead >= 2 and ops.l2tail_ok(weights[lead - 1], weights[lead], weights[lead + 1], acts[lead - 1])
         # Phone-rate step (csrc/phone_rate.hip).  The stack's input is upsample_to_repetitions(lab, dur): every phone row repeated.
         # Linear and Sigmoid commute with repeating rows, and the README model has no frame-level input, so EVERY layer's output is
         # constant over a phone's frames: the layers run once per phone row (plus extra zero rows = what padding frames gather),
@@ -365,7 +369,7 @@ class LinearStackMSEFn(torch.autograd.Function):
                 a0 = ops.cast_pad_bf16(x2d, extra_rows=extra)
             n_rows = a0.shape[0]
             hidden, a = [], a0
-            for i in range(lead):
+            for i in range(lead - (1 if l2tail else 0)):
                 n, k = weights[i].shape
                 a = ops.linear_fwd_bf16(a, None, n_rows, k, w_bf[i], biases[i], n, acts[i])
                 hidden.append(a)
@@ -375,14 +379,18 @@ class LinearStackMSEFn(torch.autograd.Function):
                 offsets.append(offsets[-1] + sz)
             flat = torch.empty(sum(sizes) + 1, dtype=torch.float32, device=x2d.device)
             ybar, weight, partials = ops.phone_target_stats(target.reshape(-1), rows, seg, seq_len, b, t, n_table, extra)
-            pred_rows, loss, dz2 = ops.f0_tail_rows(hidden[-1], weights[lead], biases[lead], weights[lead + 1], biases[lead + 1],
-                                                    ybar, weight, flat[offsets[2 * lead]:])
+            if l2tail:
+                pred_rows, loss, dz2 = ops.f0_l2tail_rows(hidden[-1], w_bf[lead - 1], biases[lead - 1], weights[lead], biases[lead],
+                                                          weights[lead + 1], biases[lead + 1], ybar, weight, flat[offsets[2 * lead]:])
+            else:
+                pred_rows, loss, dz2 = ops.f0_tail_rows(hidden[-1], weights[lead], biases[lead], weights[lead + 1], biases[lead + 1],
+                                                        ybar, weight, flat[offsets[2 * lead]:])
             pred = ops.expand_column(pred_rows, rows, loss_const=(partials, n_table, extra, loss)).view(b, t, 1)
             ctx.acts, ctx.m, ctx.lead = acts, m, lead
             ctx.dims = [(w.shape[0], w.shape[1]) for w in weights]
             ctx.offsets = offsets
             ctx.params = list(params)
-            ctx.save_for_backward(a0, rows, dz2, flat, *hidden[:-1], *[wt for wt in w_t if wt is not None])
+            ctx.save_for_backward(a0, rows, dz2, flat, *hidden[:lead - 1], *[wt for wt in w_t if wt is not None])
             ctx.mark_non_differentiable(pred)
             ctx.set_materialize_grads(False)
             return loss, pred
@@ -392,7 +400,7 @@ class LinearStackMSEFn(torch.autograd.Function):
             a = ops.cast_pad_bf16(x2d)
         a0, r = a, rows
         hidden = []
-        for i in range(lead):
+        for i in range(lead - (1 if l2tail else 0)):
             n, k = weights[i].shape
             a = ops.linear_fwd_bf16(a, r, m, k, w_bf[i], biases[i], n, acts[i])
             r = None
@@ -403,13 +411,17 @@ class LinearStackMSEFn(torch.autograd.Function):
             offsets.append(offsets[-1] + sz)
         flat = torch.empty(sum(sizes) + 1, dtype=torch.float32, device=x2d.device)    # + 1: the loss (see ops.f0_tail)
         tail_off = offsets[2 * lead]
-        pred, loss, dz2 = ops.f0_tail(hidden[-1], weights[lead], biases[lead], weights[lead + 1], biases[lead + 1],
-                                      target.reshape(-1), seq_len, b, t, flat[tail_off:])
+        if l2tail:
+            pred, loss, dz2 = ops.f0_l2tail(hidden[-1], w_bf[lead - 1], biases[lead - 1], weights[lead], biases[lead], weights[lead + 1],
+                                            biases[lead + 1], target.reshape(-1), seq_len, b, t, flat[tail_off:])
+        else:
+            pred, loss, dz2 = ops.f0_tail(hidden[-1], weights[lead], biases[lead], weights[lead + 1], biases[lead + 1],
+                                          target.reshape(-1), seq_len, b, t, flat[tail_off:])
         ctx.acts, ctx.m, ctx.lead = acts, m, lead
         ctx.dims = [(w.shape[0], w.shape[1]) for w in weights]
         ctx.offsets = offsets
         ctx.params = list(params)
-        ctx.save_for_backward(a0, rows, dz2, flat, *hidden[:-1], *[wt for wt in w_t if wt is not None])
+        ctx.save_for_backward(a0, rows, dz2, flat, *hidden[:lead - 1], *[wt for wt in w_t if wt is not None])
         pred = pred.view(b, t, 1)
         ctx.mark_non_differentiable(pred)
         ctx.set_materialize_grads(False)

@@ -515,6 +515,43 @@ def f0_tail_rows(h2, w3, b3, w4, b4, target_rows, row_weight, grads_out, grad_sc
     return pred, loss, dz2
 
 
+def l2tail_ok(w2, w3, w4, act2):
+    """The 512 -> 128 sigmoid layer and the 128 -> 32 -> 1 tail as ONE kernel (csrc/l2tail_bf16.hip): shapes it is built for."""
+    return (tuple(w2.shape) == (128, 512) and tuple(w3.shape) == (32, 128) and tuple(w4.shape) == (1, 32) and act2 == ACT_SIGMOID
+            and os.environ.get('MORGANA_L2TAIL', '1') != '0')
+
+
+def f0_l2tail(h1, w2_bf, b2, w3, b3, w4, b4, target, seq_len, b, t, grads_out, grad_scale=1.0):
+    """Layer 2 (512 -> 128, sigmoid) + layers 3-4 + masked MSE, forward and backward, in one pass over H1 (mg_f0_l2tail_bf16).
+    Returns (pred (b*t,), loss 0-d, dz2 (b*t, 128) bf16); the 128-wide activation is never written."""
+    lib = _lib.load()
+    m = b * t
+    pred = torch.empty((m,), dtype=torch.float32, device=h1.device)
+    n_grads = 32 * 128 + 32 + 32 + 1
+    loss = grads_out[n_grads] if grads_out.numel() > n_grads else torch.empty((), dtype=torch.float32, device=h1.device)
+    dz2 = torch.empty((m, 128), dtype=torch.bfloat16, device=h1.device)
+    ws = workspace(lib.mg_f0_l2tail_workspace_bytes(m), h1.device)
+    _lib.check(lib.mg_f0_l2tail_bf16(_p(h1), h1.shape[1], 512, _p(w2_bf), w2_bf.shape[1], 128, _p(b2), _p(w3), _p(b3), _p(w4), _p(b4),
+                                     _p(target), _p(seq_len), b, t, float(grad_scale), _p(pred), _p(loss), _p(dz2), 128,
+                                     _p(grads_out), 0, _p(ws), ws.numel(), _stream()), 'mg_f0_l2tail_bf16')
+    return pred, loss, dz2
+
+
+def f0_l2tail_rows(h1, w2_bf, b2, w3, b3, w4, b4, target_rows, row_weight, grads_out, grad_scale=1.0):
+    """f0_l2tail on table rows that each stand for a group of frames (mg_f0_l2tail_rows_bf16, the phone-rate step)."""
+    lib = _lib.load()
+    m = h1.shape[0]
+    pred = torch.empty((m,), dtype=torch.float32, device=h1.device)
+    n_grads = 32 * 128 + 32 + 32 + 1
+    loss = grads_out[n_grads] if grads_out.numel() > n_grads else torch.empty((), dtype=torch.float32, device=h1.device)
+    dz2 = torch.empty((m, 128), dtype=torch.bfloat16, device=h1.device)
+    ws = workspace(lib.mg_f0_l2tail_workspace_bytes(m), h1.device)
+    _lib.check(lib.mg_f0_l2tail_rows_bf16(_p(h1), h1.shape[1], 512, _p(w2_bf), w2_bf.shape[1], 128, _p(b2), _p(w3), _p(b3), _p(w4),
+                                          _p(b4), _p(target_rows), _p(row_weight), m, float(grad_scale), _p(pred), _p(loss), _p(dz2),
+                                          128, _p(grads_out), 0, _p(ws), ws.numel(), _stream()), 'mg_f0_l2tail_rows_bf16')
+    return pred, loss, dz2
+
+
 def phone_target_stats(target, rows, seg, seq_len, b, t, n_table_rows, extra):
     """(ybar (R + extra,), weight (R + extra,), partials) of the masked MSE per table row (mg_phone_target_stats); ``partials`` holds
     the per-block sums of the loss's constant term for ``phone_loss_const_add``."""

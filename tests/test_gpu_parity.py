@@ -393,6 +393,90 @@ def test_fused_tail_kernel_vs_numpy(bt):
     assert abs(g[4160] - dpred.sum()) < 1e-2 * np.abs(dpred).sum()
 
 
+@pytest.mark.parametrize('bt', [(7, 45), (64, 1000), (3, 32), (1, 1)])
+def test_l2tail_kernel_vs_numpy_and_unfused_pair(bt):
+    """mg_f0_l2tail_bf16 (the 512 -> 128 sigmoid layer inside the fused tail: README.rst:65-73 layers 2-4 + losses.py:29-51, forward
+    and backward in one pass over H1) against a float64 restatement fed the same bf16 operands and the kernel's own bf16 rounding of
+    H2, and against the unfused pair it replaces (mg_linear_fwd_bf16 + mg_f0_tail_bf16): those two differ only in the summation
+    order inside the 512-deep dot products."""
+    b, t = bt
+    m = b * t
+    rng = np.random.RandomState(b * t + 1)
+    h1 = _bf16_round(rng.uniform(0.05, 0.95, (m, 512)).astype(np.float32))
+    w2 = rng.uniform(-0.08, 0.08, (128, 512)).astype(np.float32)
+    b2 = rng.uniform(-0.1, 0.1, 128).astype(np.float32)
+    w3 = rng.uniform(-0.2, 0.2, (32, 128)).astype(np.float32)
+    b3 = rng.uniform(-0.1, 0.1, 32).astype(np.float32)
+    w4 = rng.uniform(-0.3, 0.3, (1, 32)).astype(np.float32)
+    b4 = rng.uniform(-0.1, 0.1, 1).astype(np.float32)
+    tgt = rng.standard_normal(m).astype(np.float32)
+    sl = rng.randint(1, t + 1, size=b).astype(np.int64)
+    sl[0] = t
+    h1_d = ops.cast_pad_bf16(dev(h1))
+    (w2_bf,), _ = ops.cast_params_bf16([dev(w2)])
+    grads = torch.full((32 * 128 + 32 + 32 + 1 + 1,), float('nan'), device=DEV)
+    pred, loss, dz2 = ops.f0_l2tail(h1_d, w2_bf, dev(b2), dev(w3), dev(b3), dev(w4), dev(b4), dev(tgt), dev(sl), b, t, grads)
+    assert loss.data_ptr() == grads[4161:].data_ptr()                 # the loss came out of the gradients' reduce launch
+
+    w2r, w3r = _bf16_round(w2).astype(np.float64), _bf16_round(w3).astype(np.float64)
+    h2 = _bf16_round((1 / (1 + np.exp(-(h1.astype(np.float64) @ w2r.T + b2)))).astype(np.float32)).astype(np.float64)
+    z3 = h2 @ w3r.T + b3
+    h3 = 1 / (1 + np.exp(-z3))
+    p = h3 @ w4[0].astype(np.float64) + b4[0]
+    mask = (np.arange(t)[None, :] < sl[:, None]).reshape(-1).astype(np.float64)
+    nb = np.repeat(sl, t).astype(np.float64)
+    e = p - tgt
+    want_loss = (mask * e * e / nb).sum() / b
+    dpred = 2 * e * mask / (nb * b)
+    dz3 = dpred[:, None] * w4[0][None, :] * h3 * (1 - h3)
+    want_dz2 = (dz3 @ w3r) * h2 * (1 - h2)
+    np.testing.assert_allclose(pred.cpu().numpy(), p, rtol=3e-3, atol=3e-3)
+    np.testing.assert_allclose(loss.item(), want_loss, rtol=3e-3)
+    assert rel_err(dz2.float().cpu().numpy(), want_dz2) < 2e-2
+    g = grads.cpu().numpy().astype(np.float64)
+    assert np.isfinite(g).all()
+    assert rel_err(g[:4096].reshape(32, 128), dz3.T @ h2) < 1e-2
+    assert rel_err(g[4096:4128], dz3.sum(axis=0)) < 1e-2
+    assert rel_err(g[4128:4160], dpred @ h3) < 1e-2
+    assert abs(g[4160] - dpred.sum()) < 1e-2 * np.abs(dpred).sum() + 1e-12
+
+    # the pair it replaces
+    h2_d = ops.linear_fwd_bf16(h1_d, None, m, 512, w2_bf, dev(b2), 128, ops.ACT_SIGMOID)
+    grads_u = torch.empty(32 * 128 + 32 + 32 + 1 + 1, device=DEV)
+    pred_u, loss_u, dz2_u = ops.f0_tail(h2_d, dev(w3), dev(b3), dev(w4), dev(b4), dev(tgt), dev(sl), b, t, grads_u)
+    np.testing.assert_allclose(pred.cpu().numpy(), pred_u.cpu().numpy(), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(loss.item(), loss_u.item(), rtol=1e-3)
+    assert rel_err(dz2.float().cpu().numpy(), dz2_u[:, :128].float().cpu().numpy()) < 1e-2
+    assert rel_err(grads[:4161].cpu().numpy(), grads_u[:4161].cpu().numpy()) < 1e-2
+    # run to run: bit identical
+    grads2 = torch.empty_like(grads)
+    pred2, loss2, dz2_2 = ops.f0_l2tail(h1_d, w2_bf, dev(b2), dev(w3), dev(b3), dev(w4), dev(b4), dev(tgt), dev(sl), b, t, grads2)
+    assert torch.equal(pred, pred2) and torch.equal(dz2, dz2_2) and torch.equal(grads, grads2)
+
+
+def test_l2tail_rows_kernel_vs_unfused_pair():
+    """mg_f0_l2tail_rows_bf16 (phone-rate form: rows that stand for groups of frames, weights and mean targets from
+    mg_phone_target_stats) against mg_linear_fwd_bf16 + mg_f0_tail_rows_bf16."""
+    m = 21504
+    rng = np.random.RandomState(11)
+    h1_d = ops.cast_pad_bf16(dev(rng.uniform(0.05, 0.95, (m, 512)).astype(np.float32)))
+    (w2_bf,), _ = ops.cast_params_bf16([dev(rng.uniform(-0.08, 0.08, (128, 512)).astype(np.float32))])
+    b2 = dev(rng.uniform(-0.1, 0.1, 128).astype(np.float32))
+    w3, b3 = dev(rng.uniform(-0.2, 0.2, (32, 128)).astype(np.float32)), dev(rng.uniform(-0.1, 0.1, 32).astype(np.float32))
+    w4, b4 = dev(rng.uniform(-0.3, 0.3, (1, 32)).astype(np.float32)), dev(rng.uniform(-0.1, 0.1, 1).astype(np.float32))
+    ybar = dev(rng.standard_normal(m).astype(np.float32))
+    weight = dev((rng.uniform(0, 1, m) * (rng.uniform(0, 1, m) > 0.1) / m).astype(np.float32))
+    grads = torch.empty(32 * 128 + 32 + 32 + 1 + 1, device=DEV)
+    pred, loss, dz2 = ops.f0_l2tail_rows(h1_d, w2_bf, b2, w3, b3, w4, b4, ybar, weight, grads)
+    h2_d = ops.linear_fwd_bf16(h1_d, None, m, 512, w2_bf, b2, 128, ops.ACT_SIGMOID)
+    grads_u = torch.empty_like(grads)
+    pred_u, loss_u, dz2_u = ops.f0_tail_rows(h2_d, w3, b3, w4, b4, ybar, weight, grads_u)
+    np.testing.assert_allclose(pred.cpu().numpy(), pred_u.cpu().numpy(), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(loss.item(), loss_u.item(), rtol=1e-3)
+    assert rel_err(dz2.float().cpu().numpy(), dz2_u[:, :128].float().cpu().numpy()) < 1e-2
+    assert rel_err(grads[:4161].cpu().numpy(), grads_u[:4161].cpu().numpy()) < 1e-2
+
+
 @pytest.mark.parametrize('rows_kind', ['random', 'runs', 'identity'])
 @pytest.mark.parametrize('m,n_hidden', [(4999, 512), (9000, 256)])
 def test_fused_backward_kernel_vs_numpy(m, n_hidden, rows_kind):
