@@ -292,6 +292,11 @@ size_t mg_linear_bwd_fused_workspace_bytes(int64_t M, int N, int K);
 int mg_linear_bwd_fused_bf16(const uint16_t* dZ2, int lddz, int N2, const uint16_t* W2T, int ldwt, const uint16_t* H1, int ldh,
                              const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K, float* dW, float* db,
                              int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* The same without its reduce launch: the split-M partial results stay in `workspace` as *n_slabs slabs of *stride floats, slab s =
+ * [N*K weight partials | N bias partials] (the layout of mg_linear_wgrad_slabs_bf16), for mg_adam_step_plan_f32 to sum. */
+int mg_linear_bwd_fused_slabs_bf16(const uint16_t* dZ2, int lddz, int N2, const uint16_t* W2T, int ldwt, const uint16_t* H1, int ldh,
+                                   const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K, void* workspace,
+                                   size_t workspace_bytes, int* n_slabs, int64_t* stride, void* stream);
 
 /* dst[r, 0:cols] = bf16(src[r, 0:cols]), dst[r, cols:ldd] = 0.  src f32 [rows, cols] (lds). */
 int mg_cast_pad_bf16(const float* src, int lds, uint16_t* dst, int ldd, int64_t rows, int cols, void* stream);

@@ -809,34 +809,51 @@ size_t mg_linear_bwd_fused_workspace_bytes(int64_t M, int N, int K) {
     return mg_align_up((size_t)S * ((size_t)N * K + N) * sizeof(float), 256);
 }
 
-int mg_linear_bwd_fused_bf16(const uint16_t* dZ2, int lddz, int N2, const uint16_t* W2T, int ldwt, const uint16_t* H1, int ldh,
-                             const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K, float* dW, float* db,
-                             int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
-    MG_CHECK_ARG(dZ2 && W2T && H1 && A && dW && db && M > 0, "mg_linear_bwd_fused_bf16: null argument or empty batch");
+static int fused_launch(const char* name, const uint16_t* dZ2, int lddz, int N2, const uint16_t* W2T, int ldwt, const uint16_t* H1, int ldh,
+                        const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K, void* workspace, size_t workspace_bytes,
+                        int* S_out, int64_t* sstride_out, hipStream_t st) {
+    MG_CHECK_ARG(dZ2 && W2T && H1 && A && M > 0, "%s: null argument or empty batch", name);
     MG_CHECK_ARG(N2 == F_N2 && lddz >= F_N2 && ldwt >= F_N2 && lddz % 8 == 0 && ldwt % 8 == 0,
-                 "mg_linear_bwd_fused_bf16: the second layer must have %d outputs (N2=%d lddz=%d ldwt=%d)", F_N2, N2, lddz, ldwt);
-    MG_CHECK_ARG(N % F_BNT == 0 && ldh >= N && ldh % 8 == 0, "mg_linear_bwd_fused_bf16: hidden width %d must be a multiple of %d (ldh=%d)", N, F_BNT, ldh);
-    MG_CHECK_ARG(lda == F_BKT && K > 512 && K <= F_BKT - 32, "mg_linear_bwd_fused_bf16: needs 512 < K <= 608 with lda = 640 (K=%d lda=%d)", K, lda);
-    MG_CHECK_ARG((((uintptr_t)dZ2 | (uintptr_t)W2T | (uintptr_t)H1 | (uintptr_t)A) % 16) == 0, "mg_linear_bwd_fused_bf16: buffers must be 16-byte aligned");
+                 "%s: the second layer must have %d outputs (N2=%d lddz=%d ldwt=%d)", name, F_N2, N2, lddz, ldwt);
+    MG_CHECK_ARG(N % F_BNT == 0 && ldh >= N && ldh % 8 == 0, "%s: hidden width %d must be a multiple of %d (ldh=%d)", name, N, F_BNT, ldh);
+    MG_CHECK_ARG(lda == F_BKT && K > 512 && K <= F_BKT - 32, "%s: needs 512 < K <= 608 with lda = 640 (K=%d lda=%d)", name, K, lda);
+    MG_CHECK_ARG((((uintptr_t)dZ2 | (uintptr_t)W2T | (uintptr_t)H1 | (uintptr_t)A) % 16) == 0, "%s: buffers must be 16-byte aligned", name);
     if (!workspace || workspace_bytes < mg_linear_bwd_fused_workspace_bytes(M, N, K)) {
-        mg_set_error("mg_linear_bwd_fused_bf16: workspace of %zu bytes needed, got %zu", mg_linear_bwd_fused_workspace_bytes(M, N, K), workspace_bytes);
+        mg_set_error("%s: workspace of %zu bytes needed, got %zu", name, mg_linear_bwd_fused_workspace_bytes(M, N, K), workspace_bytes);
         return MG_EWORKSPACE;
     }
     int S, chunk;
     fused_plan(M, N, &S, &chunk);
-    // split s of the workspace: [N*K weight partials | N bias partials]; when db sits right behind dW (one flat gradient
-    // buffer) a single reduce launch finishes both
+    // split s of the workspace: [N*K weight partials | N bias partials]
     const int64_t nk = (int64_t)N * K, sstride = nk + N;
     float* slab = (float*)workspace;
     float* bslab = slab + nk;
-    hipStream_t st = (hipStream_t)stream;
     if (rows && g_mg_tuning[MG_TUNE_STAGGER] != 7)
         hipLaunchKernelGGL(wgrad_fused_pipe_kernel, dim3((unsigned)((N / F_BNT) * mg_align_up((size_t)S, 8))), dim3(512), 0, st, dZ2, lddz, W2T,
                            ldwt, H1, ldh, A, lda, rows, M, N, K, chunk, S, slab, bslab, sstride);
     else
         hipLaunchKernelGGL(wgrad_fused_kernel, dim3((unsigned)((N / F_BNT) * S)), dim3(512), 0, st, dZ2, lddz, W2T, ldwt, H1, ldh, A, lda, rows, M,
                            N, K, chunk, slab, bslab, sstride);
-    MG_CHECK_LAUNCH("mg_linear_bwd_fused_bf16/main");
+    MG_CHECK_LAUNCH(name);
+    *S_out = S;
+    *sstride_out = sstride;
+    return MG_OK;
+}
+
+int mg_linear_bwd_fused_bf16(const uint16_t* dZ2, int lddz, int N2, const uint16_t* W2T, int ldwt, const uint16_t* H1, int ldh,
+                             const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K, float* dW, float* db,
+                             int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    MG_CHECK_ARG(dW && db, "mg_linear_bwd_fused_bf16: null gradient buffer");
+    hipStream_t st = (hipStream_t)stream;
+    int S = 0;
+    int64_t sstride = 0;
+    const int rc = fused_launch("mg_linear_bwd_fused_bf16", dZ2, lddz, N2, W2T, ldwt, H1, ldh, A, lda, rows, M, N, K, workspace, workspace_bytes,
+                                &S, &sstride, st);
+    if (rc != MG_OK) return rc;
+    // when db sits right behind dW (one flat gradient buffer) a single reduce launch finishes both
+    const int64_t nk = (int64_t)N * K;
+    float* slab = (float*)workspace;
+    float* bslab = slab + nk;
     if (db == dW + nk) {
         mg_launch_slab_reduce(slab, sstride, sstride, S, dW, accumulate, st);
     } else {
@@ -845,6 +862,14 @@ int mg_linear_bwd_fused_bf16(const uint16_t* dZ2, int lddz, int N2, const uint16
     }
     MG_CHECK_LAUNCH("mg_linear_bwd_fused_bf16/reduce");
     return MG_OK;
+}
+
+int mg_linear_bwd_fused_slabs_bf16(const uint16_t* dZ2, int lddz, int N2, const uint16_t* W2T, int ldwt, const uint16_t* H1, int ldh,
+                                   const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K, void* workspace,
+                                   size_t workspace_bytes, int* n_slabs, int64_t* stride, void* stream) {
+    MG_CHECK_ARG(n_slabs && stride, "mg_linear_bwd_fused_slabs_bf16: null output argument");
+    return fused_launch("mg_linear_bwd_fused_slabs_bf16", dZ2, lddz, N2, W2T, ldwt, H1, ldh, A, lda, rows, M, N, K, workspace, workspace_bytes,
+                        n_slabs, stride, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -463,8 +463,14 @@ class LinearStackMSEFn(torch.autograd.Function):
                 if (not ctx.phone_rate and i == 1 and ctx.acts[0] == ops.ACT_SIGMOID and
                         ops.can_fuse_bwd(m, n, k, ctx.dims[0][1], a0.shape[1])):
                     n0_, k0_ = ctx.dims[0]
-                    ops.linear_bwd_fused_bf16(g, w_t[1], hidden[0], a0, rows, m, n0_, k0_, out_w=params[0].grad, out_b=params[1].grad,
-                                              accumulate=True)
+                    if mode == 'defer':                               # its split-M slabs stay for the update kernel to sum
+                        slab, n_slabs, stride = ops.linear_bwd_fused_slabs_bf16(g, w_t[1], hidden[0], a0, rows, m, n0_, k0_,
+                                                                                slab=getattr(params[0], '_mg_fused_slab_buf', None))
+                        params[0]._mg_fused_slab_buf = slab
+                        opt.defer_slabs(params[0], n0_ * k0_ + n0_, slab, n_slabs, stride)
+                    else:
+                        ops.linear_bwd_fused_bf16(g, w_t[1], hidden[0], a0, rows, m, n0_, k0_, out_w=params[0].grad, out_b=params[1].grad,
+                                                  accumulate=True)
                     break
                 h = hidden[i - 1] if ctx.acts[i - 1] == ops.ACT_SIGMOID else None
                 g = ops.linear_dgrad_bf16(g, m_rows, n, w_t[i], k, h)

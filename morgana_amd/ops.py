@@ -427,6 +427,20 @@ def linear_bwd_fused_bf16(dz2, wt2, h1, a, rows, m, n_hidden, k0, out_w=None, ou
     return dw, db
 
 
+def linear_bwd_fused_slabs_bf16(dz2, wt2, h1, a, rows, m, n_hidden, k0, slab=None):
+    """linear_bwd_fused_bf16 without the reduce (mg_linear_bwd_fused_slabs_bf16): returns (slab buffer, n_slabs, stride) for the
+    optimiser's update kernel to sum; ``slab`` = a buffer to reuse (kept by the caller until the optimiser has consumed it)."""
+    lib = _lib.load()
+    nbytes = lib.mg_linear_bwd_fused_workspace_bytes(m, n_hidden, k0)
+    if slab is None or slab.numel() < nbytes:
+        slab = torch.empty(nbytes, dtype=torch.uint8, device=dz2.device)
+    n_slabs, stride = ctypes.c_int(0), ctypes.c_int64(0)
+    _lib.check(lib.mg_linear_bwd_fused_slabs_bf16(_p(dz2), dz2.shape[1], 128, _p(wt2), wt2.shape[1], _p(h1), h1.shape[1], _p(a), a.shape[1],
+                                                  _p(rows), m, n_hidden, k0, _p(slab), slab.numel(), ctypes.byref(n_slabs),
+                                                  ctypes.byref(stride), _stream()), 'mg_linear_bwd_fused_slabs_bf16')
+    return slab, n_slabs.value, stride.value
+
+
 def cast_params_bf16(weights, want_plain=True, want_t=()):
     """One launch: bf16 copies [N, pad_ld(K)] of every fp32 weight and, for the indices in `want_t`, the transposed
     copies [K, pad_ld(N)].  Returns (plain list, transposed list with None where not requested)."""
