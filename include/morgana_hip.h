@@ -33,6 +33,10 @@ extern "C" {
 
 #define MG_ACT_NONE 0
 #define MG_ACT_SIGMOID 1
+/* OR-ed into `act` of mg_linear_fwd_bf16: `rows` is made of RUNS of equal consecutive indices (the frame map of
+ * upsample_to_repetitions: every phone row repeated `dur` times).  A performance hint only - results do not depend on it: the
+ * gathered operand is then staged once per distinct row (csrc/gemm_nt_runs.hip); rows without runs cost up to 4 passes there. */
+#define MG_ACT_ROWS_RUNS 0x100
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Library

@@ -377,6 +377,8 @@ static bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 int mg_try_nt_big(const uint16_t* A, int lda, const int32_t* rows, int64_t M, int K, const uint16_t* Bm, int ldb, int N,
                   const float* bias, const uint16_t* H, int ldh, const int32_t* h_rows, void* C, int ldc, int c_f32, int epi,
                   hipStream_t st);
+int mg_try_nt_runs(const uint16_t* A, int lda, const int32_t* rows, int64_t M, int K, const uint16_t* Bm, int ldb, int N,
+                   const float* bias, uint16_t* C, int ldc, int sigmoid, hipStream_t st);       // gemm_nt_runs.hip
 int mg_wgrad_big_plan(int64_t M, int N, int K, int lda, int lddy, int* S_out, int* m_chunk_out);
 int mg_launch_wgrad_big(const uint16_t* dY, int lddy, const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K,
                         int S, int m_chunk, float* slab, float* bslab, int64_t sstride, hipStream_t st);
@@ -389,9 +391,17 @@ int mg_linear_fwd_bf16(const uint16_t* A, int lda, const int32_t* rows, int64_t 
     MG_CHECK_ARG(lda >= K && ldw >= K && ldy >= N && lda % 8 == 0 && ldw % 8 == 0 && ldy % 8 == 0,
                  "mg_linear_fwd_bf16: lda=%d ldw=%d ldy=%d must be multiples of 8 and cover K=%d / N=%d", lda, ldw, ldy, K, N);
     MG_CHECK_ARG(al16(A) && al16(W) && al16(Y), "mg_linear_fwd_bf16: buffers must be 16-byte aligned");
+    const int runs_hint = act & MG_ACT_ROWS_RUNS;
+    act &= ~MG_ACT_ROWS_RUNS;
     MG_CHECK_ARG(act == MG_ACT_NONE || act == MG_ACT_SIGMOID, "mg_linear_fwd_bf16: unknown activation %d", act);
     if (M == 0) return MG_OK;
     hipStream_t st = (hipStream_t)stream;
+    // rows made of runs (frame map of upsample_to_repetitions): the gathered operand staged once per distinct row, two workgroups per CU
+    if (runs_hint && rows && !y_f32 && ldy == N && g_mg_tuning[MG_TUNE_STAGGER] != 14 &&
+        mg_try_nt_runs(A, lda, rows, M, K, W, ldw, N, bias, (uint16_t*)Y, ldy, act == MG_ACT_SIGMOID, st) > 0) {
+        MG_CHECK_LAUNCH("mg_linear_fwd_bf16/runs");
+        return MG_OK;
+    }
     if (ldy == N && mg_try_nt_big(A, lda, rows, M, K, W, ldw, N, bias, nullptr, 0, nullptr, Y, ldy, y_f32,
                                   act == MG_ACT_SIGMOID ? EPI_BIAS_SIGMOID : EPI_BIAS, st) > 0) {
         MG_CHECK_LAUNCH("mg_linear_fwd_bf16/big");

@@ -1,0 +1,316 @@
+// K2 (bf16 throughput mode), first layer of a stack whose input is upsample_to_repetitions(lab, dur) (morgana/utils.py:175-228
+// feeding README.rst:65-73 via utils.py:401-418):   C[M, N] = epi(gather(A, rows)[M, K] B[N, K]^T + bias),   bf16 out.
+//
+// Every frame row is still multiplied (the reference's order of operations), but the A operand is STAGED BY RUNS: consecutive frames
+// of one phone point at the same source row (12.5 frames per phone at C2), so a 256-frame tile has ~21 distinct rows.  The LDS
+// stage holds each distinct row of the tile once (64 slots) and the A fragments are read through a per-frame slot table (lanes of
+// one run read the same address: a broadcast).  What that buys, measured on gemm_nt_persist<256> (gemm_bf16_big.hip, DESIGN.md
+// section 4): its 256 x 256 x 32 stage is 32 LDS-DMA pieces per k-step, which is what a CU's texture-address path takes in during the
+// k-step's 1,024 matrix cycles (LDS-DMA alone ran at 75 us, MFMAs alone 90-98 us, the kernel 181 us) - the feed, not the matrix
+// pipe, was the ceiling.  With A staged by runs the feed is the B tile only, so the tile can be HALVED along N at the same feed per
+// FLOP:  256 x 128 tiles, 256-thread workgroups, TWO workgroups per CU - one wave of each on every SIMD, and the two run
+// unsynchronised: one's epilogue (bias + sigmoid + bf16 + stores: a quarter of the old kernel, during which no wave of the
+// workgroup multiplies) passes under the other's k-steps, and a barrier wait of one is issue time for the other.
+//   * ring: 4 stages of [64 run slots + a zero slot | 128 weight rows] x 64 B, LDS-DMA with the stream running on across tile
+//     boundaries (as gemm_nt_persist), one counted vmcnt + barrier per k-step, 3 DMA pieces per wave and k-step (it was 4);
+//   * arbitrary `rows` still work: a tile with more than 64 runs is multiplied in passes of 64 runs (rows outside the pass read
+//     the zero slot), all-distinct rows cost four passes - the launcher sends inputs without a row map to gemm_nt_persist;
+//   * the accumulator tile is C^T (weights as the MFMA A operand), epilogue through a wave-private LDS patch to 16-byte stores.
+#include "common.h"
+
+typedef __bf16 bfv8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bfv2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+#define NR_EPI_BIAS 0
+#define NR_EPI_BIAS_SIGMOID 1
+#define NR_ZERO_ELEMS 16384
+__device__ uint16_t g_nr_zero_row[NR_ZERO_ELEMS];      // source of pad rows / unused run slots / out-of-range weight rows
+__device__ uint16_t g_nr_sink[64 * 8];                  // where the stores of rows past M go: every wave issues exactly NST stores
+
+__device__ __forceinline__ void nr_glds16(const uint16_t* src, unsigned char* lds_wave_base) {
+    const unsigned lds_off = (unsigned)(unsigned long long)((__attribute__((address_space(3))) unsigned char*)lds_wave_base);
+    const unsigned lds_uni = __builtin_amdgcn_readfirstlane(lds_off);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_uni)
+                 : "memory");
+}
+
+#define NR_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define NR_WAIT_CASE(N) case N: NR_WAIT(N); break;
+
+#define NR_MAXT 8
+#define NR_BM 256
+#define NR_BN 128
+#define NR_RA 64                                        // run slots of a stage
+#define NR_A_BYTES 4352                                 // 64 run slots + 4 zero slots (the first of them is what invalid rows read)
+#define NR_B_BYTES (NR_BN * 64)
+#define NR_STAGE (NR_A_BYTES + NR_B_BYTES)              // 12,544
+#define NR_NS 4
+#define NR_SLOT (NR_NS * NR_STAGE)                      // uint8 [MAXT][256]: run ordinal of each tile row
+#define NR_RUNROW (NR_SLOT + NR_MAXT * NR_BM)           // int32 [MAXT][256]: source row of each run
+#define NR_NRUNS (NR_RUNROW + NR_MAXT * NR_BM * 4)      // int32 [MAXT]
+#define NR_PATCH (NR_NRUNS + 64)                        // 4 waves x [32 rows x 128 B]
+#define NR_BIAS (NR_PATCH + 4 * 4096)
+#define NR_LDS (NR_BIAS + NR_BN * 4)                    // 77,376 B: two workgroups per CU
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_runs_kernel(const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
+                                                              int64_t M, int K, const uint16_t* __restrict__ Bm, int ldb, int N,
+                                                              const float* __restrict__ bias, uint16_t* __restrict__ C, int ldc,
+                                                              int tiles_m, int tiles_n) {
+    constexpr int BK = 32, KS = 2, TM = 4, TN = 2, NS = NR_NS, NL = 3, NST = TM * 4, SP = 128;
+    static_assert(NR_LDS <= 80 * 1024, "two workgroups per CU");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NR_LDS];
+    unsigned char* slot8 = smem + NR_SLOT;
+    int* run_row = reinterpret_cast<int*>(smem + NR_RUNROW);
+    int* nruns = reinterpret_cast<int*>(smem + NR_NRUNS);
+    float* bias_lds = reinterpret_cast<float*>(smem + NR_BIAS);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * 128, wn0 = (wave & 1) * 64;
+    const int n_kt = (K + BK - 1) / BK;
+
+    // Virtual block v = blockIdx.x + i gridDim.x (gridDim.x a multiple of 8 tiles_n): the N tiles of one M tile go to blocks 8 apart,
+    // which share an XCD and its L2; a workgroup keeps ONE N tile (its bias slice is parked once).
+    auto tile_of = [&](int i, int& tile_m, int& tile_n) {
+        const int v = blockIdx.x + i * gridDim.x;
+        const int xcd = v & 7, jj = v >> 3;
+        tile_n = jj % tiles_n;
+        tile_m = (jj / tiles_n) * 8 + xcd;
+    };
+    int n_my = 0;
+    for (int i = 0; i < NR_MAXT; ++i) {
+        int tm, tn;
+        tile_of(i, tm, tn);
+        if (tm < tiles_m) n_my = i + 1;
+    }
+    if (n_my == 0) return;
+
+    // ---- one-time: runs of equal consecutive source rows of every tile (wave w takes tiles w, w + 4: 4 rows per lane, one wave scan) ---
+    for (int i = wave; i < n_my; i += 4) {
+        int tm, tn;
+        tile_of(i, tm, tn);
+        int r[4], flag[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t m = (int64_t)tm * NR_BM + 4 * lane + e;
+            r[e] = (tm < tiles_m && m < M) ? (rows ? rows[m] : (int)m) : -1;
+        }
+        const int prev = __shfl_up(r[3], 1, 64);
+        flag[0] = (lane == 0) || (r[0] != prev);
+        int cnt = flag[0];
+#pragma unroll
+        for (int e = 1; e < 4; ++e) {
+            flag[e] = r[e] != r[e - 1];
+            cnt += flag[e];
+        }
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        int ord = incl - cnt - 1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ord += flag[e];
+            slot8[i * NR_BM + 4 * lane + e] = (unsigned char)ord;
+            if (flag[e]) run_row[i * NR_BM + ord] = r[e];
+        }
+        if (lane == 63) nruns[i] = incl;
+    }
+    // the zero slots of every stage (never a DMA target), the bias slice
+    if (tid < 16 * NS) *reinterpret_cast<u32x4_t*>(smem + (tid >> 4) * NR_STAGE + NR_RA * 64 + (tid & 15) * 16) = u32x4_t{0u, 0u, 0u, 0u};
+    {
+        int tm, tn;
+        tile_of(0, tm, tn);
+        for (int c = tid; c < NR_BN; c += 256) bias_lds[c] = (bias && tn * NR_BN + c < N) ? bias[tn * NR_BN + c] : 0.f;
+    }
+    __syncthreads();                                   // plain barrier: no LDS-DMA is in flight yet
+
+    auto n_pass = [&](int i) -> int { return __builtin_amdgcn_readfirstlane((nruns[i] + NR_RA - 1) >> 6); };
+    int g_total = 0;
+    for (int i = 0; i < n_my; ++i) g_total += n_pass(i) * n_kt;
+
+    // chunk swizzle of a 64-byte stage row (the same involution on the DMA source and on the fragment reads)
+    auto swz = [](int row) { return (row >> 2) & 3; };
+    // ---- issue cursor: tile i_t, pass i_p, k-tile i_k, ring slot i_s ---------------------------------------------------------
+    const uint16_t* asrc;
+    const uint16_t* bsrc[2];
+    int i_t = 0, i_p = 0, i_k = 0, i_s = 0, i_np = 0;
+    auto set_sources = [&](int i, int p) {
+        int tm, tn;
+        tile_of(i, tm, tn);
+        {
+            const int s = 16 * wave + (lane >> 2);                 // run slot of this lane's A piece (piece = wave)
+            const int c = (lane & 3) ^ swz(s);
+            const int run = NR_RA * p + s;
+            const int r = (run < nruns[i]) ? run_row[i * NR_BM + run] : -1;
+            asrc = (r >= 0 ? A + (size_t)r * lda : g_nr_zero_row) + c * 8;
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int row = (wave * 2 + g) * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ swz(row);
+            const int n = tn * NR_BN + row;
+            bsrc[g] = (n < N ? Bm + (size_t)n * ldb : g_nr_zero_row) + c * 8;
+        }
+    };
+    i_np = n_pass(0);
+    set_sources(0, 0);
+    auto issue_next = [&]() {                          // next stage of the stream, if any is left
+        if (i_t >= n_my) return;
+        unsigned char* st = smem + i_s * NR_STAGE;
+        nr_glds16(asrc + i_k * BK, st + wave * 1024);
+        nr_glds16(bsrc[0] + i_k * BK, st + NR_A_BYTES + (wave * 2) * 1024);
+        nr_glds16(bsrc[1] + i_k * BK, st + NR_A_BYTES + (wave * 2 + 1) * 1024);
+        i_s = (i_s + 1 == NS) ? 0 : i_s + 1;
+        if (++i_k == n_kt) {
+            i_k = 0;
+            if (++i_p == i_np) {
+                i_p = 0;
+                if (++i_t < n_my) i_np = n_pass(i_t);
+            }
+            if (i_t < n_my) set_sources(i_t, i_p);
+        }
+    };
+
+    const int lr = lane & 31, lh = lane >> 5;
+    int aoff[TM], boff[TN];                            // byte offset of this lane's fragment of MFMA step 0 inside a stage
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wn0 + j * 32 + lr;
+        boff[j] = NR_A_BYTES + row * 64 + ((lh ^ swz(row)) << 4);
+    }
+    auto set_frag_rows = [&](int ti, int p) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rel = (int)slot8[ti * NR_BM + wm0 + i * 32 + lr] - NR_RA * p;
+            const int s = ((unsigned)rel < (unsigned)NR_RA) ? rel : NR_RA;          // outside this pass: the zero slot
+            aoff[i] = s * 64 + ((lh ^ swz(s)) << 4);
+        }
+    };
+
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p) issue_next();
+
+    bfv8 fa[KS][TM], fb[KS][TN];
+    auto read_frags = [&](const unsigned char* st) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const bfv8*>(st + (aoff[i] ^ (ks << 5)));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[ks][j] = *reinterpret_cast<const bfv8*>(st + (boff[j] ^ (ks << 5)));
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, KS * (TM + TN), 0);
+    };
+
+    int g = 0, c_s = 0;
+    for (int ti = 0; ti < n_my; ++ti) {
+        int tile_m, tile_n;
+        tile_of(ti, tile_m, tile_n);
+        const int64_t m0 = (int64_t)tile_m * NR_BM;
+        const int n0 = tile_n * NR_BN;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        const int np = n_pass(ti);
+        for (int p = 0; p < np; ++p) {
+            set_frag_rows(ti, p);
+            for (int kt = 0; kt < n_kt; ++kt, ++g) {
+                // stage g must have landed; issued so far: min(g_total, g + NS - 1) stages, so min(g_total - 1 - g, NS - 2) younger
+                // ones may stay in flight, and the previous tile's NST stores while they are younger than stage g's DMA (first NS - 1
+                // k-steps of a tile).  The wait also retires this wave's LDS reads: the slot read in the previous step is refilled below.
+                const int allow = min(g_total - 1 - g, NS - 2) * NL + ((ti > 0 && p == 0 && kt < NS - 1) ? NST : 0);
+                __builtin_amdgcn_sched_barrier(0);
+                switch (allow) {
+                    NR_WAIT_CASE(3) NR_WAIT_CASE(6) NR_WAIT_CASE(16) NR_WAIT_CASE(19) NR_WAIT_CASE(22)
+                    default: NR_WAIT(0); break;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned char* st = smem + c_s * NR_STAGE;
+                issue_next();                          // refills the slot every wave finished with before this barrier
+                read_frags(st);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, KS * TM * TN, 0);
+                c_s = (c_s + 1 == NS) ? 0 : c_s + 1;
+            }
+        }
+
+        // ---- epilogue: bias (+ sigmoid), bf16, whole 128-byte row segments through the wave's LDS patch ------------------------
+        unsigned char* patch = smem + NR_PATCH + wave * 4096;
+        const int prow = lane >> 3, pchunk = lane & 7;
+        f32x4 bv[TN][4];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[j][q] = *reinterpret_cast<const f32x4*>(bias_lds + wn0 + j * 32 + 8 * q + 4 * lh);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = acc[i][j][4 * q + e] + bv[j][q][e];
+                        if (EPI == NR_EPI_BIAS_SIGMOID) x = mg_sigmoid_fast(x);
+                        v[e] = x;
+                    }
+                    const u32x2_t pk = u32x2_t{__builtin_bit_cast(unsigned int, bfv2{(__bf16)v[0], (__bf16)v[1]}),
+                                               __builtin_bit_cast(unsigned int, bfv2{(__bf16)v[2], (__bf16)v[3]})};
+                    const int chunk = 4 * j + q;                              // columns 32 j + 8 q .. + 7 of the 64-wide strip
+                    *reinterpret_cast<u32x2_t*>(patch + lr * SP + ((chunk ^ (lr & 7)) << 4) + 8 * lh) = pk;
+                }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int rl = it * 8 + prow;
+                const u32x4_t o = *reinterpret_cast<const u32x4_t*>(patch + rl * SP + ((pchunk ^ (rl & 7)) << 4));
+                const int64_t m = m0 + wm0 + i * 32 + rl;
+                uint16_t* dst = (m < M) ? C + (size_t)m * ldc + n0 + wn0 + pchunk * 8 : g_nr_sink + lane * 8;
+                *reinterpret_cast<u32x4_t*>(dst) = o;     // unconditional: the counted vmcnt waits rely on NST stores per wave
+            }
+        }
+    }
+}
+
+// Launch helper used by mg_try_nt_big (gemm_bf16_big.hip): 1 if it launched, 0 if the shape does not qualify.
+int mg_try_nt_runs(const uint16_t* A, int lda, const int32_t* rows, int64_t M, int K, const uint16_t* Bm, int ldb, int N,
+                   const float* bias, uint16_t* C, int ldc, int sigmoid, hipStream_t st) {
+    if (!rows || M < 2048 || M >= 2147483647LL || N % NR_BN != 0 || ldc != N) return 0;
+    if (lda % 64 != 0 || ldb % 64 != 0 || lda > NR_ZERO_ELEMS - 64 || ldb > NR_ZERO_ELEMS - 64) return 0;
+    if (lda < (K + 63) / 64 * 64 || ldb < (K + 63) / 64 * 64 || (K + 31) / 32 < 5) return 0;
+    const int tiles_n = N / NR_BN;
+    const int64_t tiles_m = mg_ceil_div(M, NR_BM);
+    if (64 % tiles_n != 0) return 0;                   // gridDim.x / 8 a multiple of tiles_n
+    const int64_t blocks = mg_ceil_div(tiles_m, 8) * 8 * tiles_n;
+    int64_t g = 512;                                   // two resident workgroups per CU
+    while (mg_ceil_div(blocks, g) > NR_MAXT) g += 512;
+    if (g > blocks) g = blocks;
+    if (g >= 2147483647LL) return 0;
+    dim3 grid((unsigned)g), block(256);
+    if (sigmoid)
+        hipLaunchKernelGGL((gemm_nt_runs_kernel<NR_EPI_BIAS_SIGMOID>), grid, block, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, C, ldc, (int)tiles_m,
+                           tiles_n);
+    else
+        hipLaunchKernelGGL((gemm_nt_runs_kernel<NR_EPI_BIAS>), grid, block, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, C, ldc, (int)tiles_m, tiles_n);
+    return 1;
+}

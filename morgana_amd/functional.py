@@ -85,6 +85,7 @@ class LinearStackFn(torch.autograd.Function):
     def forward(ctx, spec, x2d, rows, *params):
         acts, precision = spec[:2]
         extra = spec[2] if len(spec) > 2 else 0       # zero rows appended behind x2d (phone-rate tables: what padding frames gather)
+        rows_runs = bool(spec[3]) if len(spec) > 3 else False      # `rows` is an upsample frame map (runs of equal indices): a hint
         n_layers = len(acts)
         weights = [params[2 * i] for i in range(n_layers)]
         biases = [params[2 * i + 1] for i in range(n_layers)]
@@ -128,7 +129,7 @@ class LinearStackFn(torch.autograd.Function):
                 n, k = weights[i].shape
                 w_bf = ops.cast_pad_bf16(ops._require(weights[i], torch.float32, 'weight'))
                 last = i == n_layers - 1
-                a = ops.linear_fwd_bf16(a, r, m, k, w_bf, biases[i], n, acts[i], out_f32=last)
+                a = ops.linear_fwd_bf16(a, r, m, k, w_bf, biases[i], n, acts[i], out_f32=last, rows_runs=rows_runs)
                 r = None
                 hidden.append(a)
             n_last = weights[-1].shape[0]
@@ -402,7 +403,7 @@ class LinearStackMSEFn(torch.autograd.Function):
         hidden = []
         for i in range(lead - (1 if l2tail else 0)):
             n, k = weights[i].shape
-            a = ops.linear_fwd_bf16(a, r, m, k, w_bf[i], biases[i], n, acts[i])
+            a = ops.linear_fwd_bf16(a, r, m, k, w_bf[i], biases[i], n, acts[i], rows_runs=True)      # rows: the upsample frame map
             r = None
             hidden.append(a)
         sizes = [p.numel() for p in params]

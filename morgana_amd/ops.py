@@ -352,11 +352,17 @@ def cast_bf16_f32(x_bf16, cols):
     return out
 
 
-def linear_fwd_bf16(a, rows, m, k, w_bf16, bias, n, act, out_f32=False):
-    """a: (R, lda) bf16; w_bf16: (n, ldw) bf16.  Returns (m, pad8(n)) bf16 (or f32), padding columns zero."""
+ACT_ROWS_RUNS = 0x100      # MG_ACT_ROWS_RUNS: `rows` is a frame map of upsample_to_repetitions (runs of equal indices); a hint only
+
+
+def linear_fwd_bf16(a, rows, m, k, w_bf16, bias, n, act, out_f32=False, rows_runs=False):
+    """a: (R, lda) bf16; w_bf16: (n, ldw) bf16.  Returns (m, pad8(n)) bf16 (or f32), padding columns zero.
+    ``rows_runs``: the row map consists of runs of equal consecutive indices (performance hint, same results)."""
     lib = _lib.load()
     ldy = pad8(n)
     y = torch.empty((m, ldy), dtype=torch.float32 if out_f32 else torch.bfloat16, device=a.device)
+    if rows_runs and rows is not None:
+        act = act | ACT_ROWS_RUNS
     _lib.check(lib.mg_linear_fwd_bf16(_p(a), a.shape[1], _p(rows), m, k, _p(w_bf16), w_bf16.shape[1], _p(bias), n,
                                       _p(y), ldy, 1 if out_f32 else 0, act, _stream()), 'mg_linear_fwd_bf16')
     return y

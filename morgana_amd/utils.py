@@ -533,7 +533,8 @@ class SequentialWithRecurrent(nn.Sequential):
                 params = []
                 for lin, _ in run:
                     params += [lin.weight, lin.bias]
-                spec = (tuple(act for _, act in run), precision)
+                # rows here is the frame map of upsample_to_repetitions: runs of equal indices (a hint for the layer-1 loader)
+                spec = (tuple(act for _, act in run), precision, 0, rows is not None)
                 out = F_hip.LinearStackFn.apply(spec, x2d, rows, *params)
                 input = out.view(*lead, out.shape[-1])
                 i = end

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Micro-benchmark of the individual GEMM kernels at the C2 shapes (HIP-event timing on the launch stream).
-Usage: python scripts/kbench.py [iters] [which,comma,separated]   (which: fwd1,fwd2,dgrad2,wgrad1,wgrad2)"""
+Usage: python scripts/kbench.py [iters] [which,comma,separated]   (which: fwd1,fwd1r,fwd2,dgrad2,wgrad1,wgrad2,fused; fwd1r = fwd1 with the run-staged loader)"""
 import os
 import sys
 
@@ -35,6 +35,7 @@ def main():
     dz2 = (torch.randn(m, 128, device=dev) * 0.01).to(torch.bfloat16)
     cases = {
         'fwd1': (2.0 * m * 600 * 512, lambda: ops.linear_fwd_bf16(tab, rows, m, k, w1b, b1, 512, ops.ACT_SIGMOID)),
+        'fwd1r': (2.0 * m * 600 * 512, lambda: ops.linear_fwd_bf16(tab, rows, m, k, w1b, b1, 512, ops.ACT_SIGMOID, rows_runs=True)),
         'fwd2': (2.0 * m * 512 * 128, lambda: ops.linear_fwd_bf16(h1, None, m, 512, w2b, b2, 128, ops.ACT_SIGMOID)),
         'dgrad2': (2.0 * m * 512 * 128, lambda: ops.linear_dgrad_bf16(dz2, m, 128, w2t, 512, h1)),
         'wgrad1': (2.0 * m * 600 * 512, lambda: ops.linear_wgrad_bf16(dz1, tab, rows, m, 512, 600)),

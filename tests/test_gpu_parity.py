@@ -393,6 +393,29 @@ def test_fused_tail_kernel_vs_numpy(bt):
     assert abs(g[4160] - dpred.sum()) < 1e-2 * np.abs(dpred).sum()
 
 
+@pytest.mark.parametrize('rows_kind', ['runs', 'short_runs', 'random'])
+@pytest.mark.parametrize('m,n,act', [(70000, 512, 1), (4999, 128, 0), (25600, 256, 1)])
+def test_linear_fwd_run_staged_equals_frame_staged(m, n, act, rows_kind):
+    """mg_linear_fwd_bf16 with MG_ACT_ROWS_RUNS (csrc/gemm_nt_runs.hip: the gathered operand staged once per distinct row, 256 x 128
+    tiles, two workgroups per CU) against the same call without the hint (gemm_nt_persist, every frame row staged): the hint must
+    not change a bit - same products, same order of the contraction.  'runs' = phone-like runs incl. -1 pad rows, 'short_runs' =
+    runs of 1-4 frames (tiles with more than 64 runs: several passes), 'random' = every frame its own row (four passes)."""
+    k = 600
+    rng = np.random.RandomState(m + n)
+    table = ops.cast_pad_bf16(dev(rng.uniform(0, 1, (m // 9 + 3, k)).astype(np.float32)))
+    if rows_kind == 'random':
+        rows = rng.randint(-1, table.shape[0], size=m)
+    else:
+        lens = rng.randint(1, 40 if rows_kind == 'runs' else 5, size=m)
+        rows = np.repeat(rng.randint(-1, table.shape[0], size=m), lens)[:m]
+    rows = dev(rows.astype(np.int32))
+    (w_bf,), _ = ops.cast_params_bf16([dev(rng.uniform(-0.1, 0.1, (n, k)).astype(np.float32))])
+    bias = dev(rng.uniform(-0.5, 0.5, n).astype(np.float32))
+    want = ops.linear_fwd_bf16(table, rows, m, k, w_bf, bias, n, act)
+    got = ops.linear_fwd_bf16(table, rows, m, k, w_bf, bias, n, act, rows_runs=True)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+
+
 @pytest.mark.parametrize('bt', [(7, 45), (64, 1000), (3, 32), (1, 1)])
 def test_l2tail_kernel_vs_numpy_and_unfused_pair(bt):
     """mg_f0_l2tail_bf16 (the 512 -> 128 sigmoid layer inside the fused tail: README.rst:65-73 layers 2-4 + losses.py:29-51, forward
