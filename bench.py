@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument('--frames', type=int, default=1000)
     ap.add_argument('--no-generate', action='store_true',
                     help='lstm / f0gru: leave out the MLPG + metrics part of the step (the reference runs it inside predict / loss)')
+    ap.add_argument('--steps-per-replay', type=int, default=0,
+                    help='C2: training steps captured into one HIP graph (0 = the largest divisor of --steps up to 10)')
     ap.add_argument('--no-graph', action='store_true',
                     help='c2: launch every kernel of the step from Python instead of replaying the captured HIP graph')
     ap.add_argument('--no-compare', action='store_true',
@@ -478,22 +480,35 @@ def main():
     # The F0Model step's kernels sum to ~0.3 ms, less than the Python / autograd / launch path around them: replay the step as a
     # HIP graph (same kernels, same buffers; morgana_amd/graphs.py).  The longer recurrent steps gain nothing from it.
     graph_note = None
+    per_call = 1                                      # training steps one call of step() performs
     if args.config == 'c2' and not args.no_graph:
-        try:
-            from morgana_amd import graphs
-            step = graphs.GraphedTrainStep(model, optimizer, features)
-            graph_note = 'hip graph replay (%s)' % ('forward+backward graph, eager all-reduce, update kernel' if world > 1
-                                                    else 'one graph per step')
-        except Exception as exc:                      # capture refused: time the eager loop and say so
-            graph_note = 'eager launches (graph capture failed: %s)' % str(exc).splitlines()[0][:200]
-            torch.cuda.synchronize()
-    for _ in range(args.warmup):
+        # K steps per graph: the idle time between two graph launches (8-9 us) and the launch that stages Adam's step-dependent
+        # scalars (4.7 us) are then paid once per K steps; every step still does all of its work (morgana_amd/graphs.py)
+        want_k = args.steps_per_replay or max(k for k in range(1, min(10, args.steps) + 1) if args.steps % k == 0)
+        if args.steps % want_k:
+            raise SystemExit('--steps-per-replay must divide --steps')
+        from morgana_amd import graphs
+        for k in (want_k, 1):
+            try:
+                step = graphs.GraphedTrainStep(model, optimizer, features, steps_per_replay=k)
+                per_call = k
+                how = 'forward+backward graph, eager all-reduce, update kernel' if step.exchange_mode == 'eager' else \
+                    ('%d steps per graph' % k if k > 1 else 'one graph per step')
+                graph_note = 'hip graph replay (%s)' % how
+                break
+            except ValueError:                        # the eager exchange needs one step per replay
+                continue
+            except Exception as exc:                  # capture refused: time the eager loop and say so
+                graph_note = 'eager launches (graph capture failed: %s)' % str(exc).splitlines()[0][:200]
+                torch.cuda.synchronize()
+                break
+    for _ in range(-(-args.warmup // per_call)):
         loss = step()
     torch.cuda.synchronize()
     distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps // per_call):          # per_call divides --steps: exactly --steps steps are timed
         loss = step()
     torch.cuda.synchronize()
     distributed.barrier()
@@ -516,12 +531,13 @@ def main():
             from morgana_amd import graphs
             fr_model = models.F0Model(precision=args.precision).to(dev)
             fr_model.load_state_dict(model.state_dict())
-            fr_step = graphs.GraphedTrainStep(fr_model, optim.Adam(fr_model.parameters(), lr=0.01, fused_loop=True), features)
-            for _ in range(args.warmup):
+            fr_step = graphs.GraphedTrainStep(fr_model, optim.Adam(fr_model.parameters(), lr=0.01, fused_loop=True), features,
+                                              steps_per_replay=per_call)
+            for _ in range(-(-args.warmup // per_call)):
                 fr_step()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(args.steps // per_call):
                 fr_step()
             torch.cuda.synchronize()
             fr_ms = (time.perf_counter() - t1) / args.steps * 1e3

@@ -637,6 +637,10 @@ int mg_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp
 void mg_adam_scalars(float lr, float beta1, float beta2, int64_t step, float* out2);
 /* dst[0..1] = (a, b) in stream order, the values carried as kernel arguments (safe however far the host runs ahead). */
 int mg_store_pair_f32(float* dst, float a, float b, void* stream);
+/* dst[0 .. 2 n_pairs) = the pairs of the HOST array `values` (n_pairs <= MG_STORE_PAIRS_MAX), the same way: one launch stages the
+ * scalars of every step a multi-step graph replay performs (slot j = dst + 2 j, handed to the j-th update launch). */
+#define MG_STORE_PAIRS_MAX 32
+int mg_store_pairs_f32(float* dst, const float* values, int n_pairs, void* stream);
 int mg_adam_step_dev_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1,
                          float beta2, float eps, float weight_decay, const float* scalars, float grad_scale, void* stream);
 /* The update as the LAST node of a training step that hands it more than a finished gradient (scalars from device memory as in

@@ -108,6 +108,7 @@ SIGNATURES = {
     'mg_metric_accumulate_f32': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                          c_void_p, c_size_t, c_void_p]),
     'mg_store_pair_f32': (c_int, [c_void_p, c_float, c_float, c_void_p]),
+    'mg_store_pairs_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     'mg_adam_scalars': (None, [c_float, c_float, c_float, c_int64, c_void_p]),
     'mg_adam_step_dev_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p,
                                      c_float, c_void_p]),

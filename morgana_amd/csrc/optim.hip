@@ -280,6 +280,26 @@ int mg_store_pair_f32(float* dst, float a, float b, void* stream) {
     return MG_OK;
 }
 
+struct StorePairs {
+    float v[2 * MG_STORE_PAIRS_MAX];
+};
+__global__ void store_pairs_kernel(float* __restrict__ dst, StorePairs values, int n) {
+    if ((int)threadIdx.x < 2 * n) dst[threadIdx.x] = values.v[threadIdx.x];
+}
+
+// dst[0 .. 2 n) = the n pairs of the HOST array `values`, in stream order, carried as kernel arguments like mg_store_pair_f32: the
+// scalars of the n steps one graph replay performs (morgana_amd/graphs.py, steps_per_replay), staged by ONE launch.
+int mg_store_pairs_f32(float* dst, const float* values, int n_pairs, void* stream) {
+    MG_CHECK_ARG(dst && values && n_pairs >= 1 && n_pairs <= MG_STORE_PAIRS_MAX, "mg_store_pairs_f32: bad arguments (n_pairs=%d, at most %d)", n_pairs,
+                 MG_STORE_PAIRS_MAX);
+    StorePairs sp;
+    for (int i = 0; i < 2 * n_pairs; ++i) sp.v[i] = values[i];
+    for (int i = 2 * n_pairs; i < 2 * MG_STORE_PAIRS_MAX; ++i) sp.v[i] = 0.f;
+    hipLaunchKernelGGL(store_pairs_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dst, sp, n_pairs);
+    MG_CHECK_LAUNCH("mg_store_pairs_f32");
+    return MG_OK;
+}
+
 // (step_size, bc2_sqrt) of step `step` exactly as mg_adam_step_f32 forms them (host doubles), for mg_adam_step_dev_f32
 void mg_adam_scalars(float lr, float beta1, float beta2, int64_t step, float* out2) {
     const double bc1 = 1.0 - pow((double)beta1, (double)step);

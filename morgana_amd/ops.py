@@ -1082,6 +1082,15 @@ def store_pair(dst, a, b):
     _lib.check(_lib.load().mg_store_pair_f32(_p(dst), float(a), float(b), _stream()), 'mg_store_pair_f32')
 
 
+STORE_PAIRS_MAX = 32
+
+
+def store_pairs(dst, pairs):
+    """dst[2 j : 2 j + 2] = pairs[j] in stream order (mg_store_pairs_f32): the Adam scalars of the steps of one multi-step replay."""
+    flat = (ctypes.c_float * (2 * len(pairs)))(*[float(x) for pair in pairs for x in pair])
+    _lib.check(_lib.load().mg_store_pairs_f32(_p(dst), ctypes.cast(flat, ctypes.c_void_p), len(pairs), _stream()), 'mg_store_pairs_f32')
+
+
 def adam_step_dev(param, grad, exp_avg, exp_avg_sq, betas, eps, weight_decay, scalars, grad_scale=1.0):
     """adam_step with (step_size, bc2_sqrt) read from the 2-float device tensor ``scalars`` (capturable in a HIP graph)."""
     lib = _lib.load()

@@ -117,8 +117,8 @@ class Adam(torch.optim.Optimizer):
 
     # ---- HIP-graph support (morgana_amd/graphs.py): the captured update reads its step-dependent scalars from device memory
     def _scalar_buffers(self, flat):
-        if 'scalars' not in flat:
-            flat['scalars'] = torch.zeros(2, dtype=torch.float32, device=flat['param'].device)
+        if 'scalars' not in flat:          # slot j (floats 2 j, 2 j + 1): the scalars of the j-th step of a multi-step graph replay
+            flat['scalars'] = torch.zeros(2 * ops.STORE_PAIRS_MAX, dtype=torch.float32, device=flat['param'].device)
         return flat['scalars']
 
     def exchanging(self):
@@ -161,23 +161,31 @@ class Adam(torch.optim.Optimizer):
             if flat is not None:
                 self._scalar_buffers(flat)
 
-    def advance(self):
-        """Count one step and stage its (step_size, bc2_sqrt) for the captured update: one 1-thread launch per group on the current
-        stream ahead of the graph replay that consumes it, the two values carried as kernel arguments (the host runs many replays
-        ahead of the device; a copy from a reused host buffer would be read too late)."""
+    def advance(self, n=1):
+        """Count ``n`` steps and stage their (step_size, bc2_sqrt) for the captured updates: ONE small launch per group on the current
+        stream ahead of the graph replay that consumes them (slot j for the j-th step of the replay), the values carried as kernel
+        arguments (the host runs many replays ahead of the device; a copy from a reused host buffer would be read too late).  The
+        learning rate is the group's current one for all ``n`` steps."""
+        if not 1 <= n <= ops.STORE_PAIRS_MAX:
+            raise ValueError('advance: 1 <= n <= %d' % ops.STORE_PAIRS_MAX)
         for group, flat in zip(self.param_groups, self._flat):
             if flat is None:
                 continue
-            flat['step'] += 1
-            step_size, bc2_sqrt = ops.adam_scalars(group['lr'], group['betas'], flat['step'])
-            ops.store_pair(self._scalar_buffers(flat), step_size, bc2_sqrt)
+            pairs = []
+            for _ in range(n):
+                flat['step'] += 1
+                pairs.append(ops.adam_scalars(group['lr'], group['betas'], flat['step']))
+            if n == 1:
+                ops.store_pair(self._scalar_buffers(flat), *pairs[0])
+            else:
+                ops.store_pairs(self._scalar_buffers(flat), pairs)
 
-    def _launch(self, group, flat, world):
+    def _launch(self, group, flat, world, slot=0):
         """The update kernel with everything this step left for it (see the module docstring)."""
         shadows = self._shadows(flat)
         pending, flat['pending'] = flat['pending'], []
         ops.adam_step_plan(flat['param'], flat['grad'], flat['exp_avg'], flat['exp_avg_sq'], group['betas'], group['eps'],
-                           group['weight_decay'], self._scalar_buffers(flat), 1.0 / world, slab_srcs=pending,
+                           group['weight_decay'], self._scalar_buffers(flat)[2 * slot:], 1.0 / world, slab_srcs=pending,
                            shadows=[sh[:5] for sh in shadows], clear_grad=self.fused_loop)
         flat['clean'] = self.fused_loop
         for p in flat['params']:
@@ -187,12 +195,13 @@ class Adam(torch.optim.Optimizer):
             p._mg_shadow['version'] = (p._version, p._mg_updates)
 
     @torch.no_grad()
-    def step_captured(self):
-        """The parameter update alone, from device-resident scalars (call ``advance`` before each replay).  No all-reduce here."""
+    def step_captured(self, slot=0):
+        """The parameter update alone, from device-resident scalars (call ``advance`` before each replay; ``slot`` = which of the
+        staged pairs: the position of this step inside a multi-step replay).  No all-reduce here."""
         world = self._world()
         for group, flat in zip(self.param_groups, self._flat):
             if flat is not None:
-                self._launch(group, flat, world)
+                self._launch(group, flat, world, slot)
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -1696,6 +1696,46 @@ def test_graphed_train_step_equals_eager_steps():
         assert torch.equal(flat_e[key], flat_g[key]), key
 
 
+@pytest.mark.parametrize('phone_rate', [True, False])
+def test_multi_step_replay_equals_single_step_replays(phone_rate, monkeypatch):
+    """graphs.GraphedTrainStep(steps_per_replay=3): three training steps captured into ONE graph (each update reads its own slot of the
+    scalars staged by one launch, optim.Adam.advance(3)), two batches alternating inside the replay, against single-step replays on
+    the same sequence of batches: losses of every step, parameters and both Adam moments EQUAL bit for bit, at both orders of
+    operations, across a learning-rate change between replays."""
+    from morgana_amd import graphs, optim, ops
+    monkeypatch.setattr(ops, 'PHONE_RATE', phone_rate)
+    b0 = data.to_device(synthetic.make_batch(32, 200, seed=8), DEV)
+    b1 = data.to_device(synthetic.make_batch(32, 200, seed=9), DEV)
+    seq = [b0, b1, b0]
+
+    def fresh():
+        model = _load_state(models.F0Model(precision='bf16').to(DEV), synthetic.f0_model_state())
+        return model, optim.Adam(model.parameters(), lr=0.01)
+
+    model_1, opt_1 = fresh()
+    singles = [graphs.GraphedTrainStep(model_1, opt_1, b, warmup=(2 if i == 0 else 0)) for i, b in enumerate((b0, b1))]
+    losses_1 = []
+    for rep in range(2):
+        if rep == 1:
+            opt_1.param_groups[0]['lr'] = 0.004
+        for b in seq:
+            losses_1.append(singles[0 if b is b0 else 1]().clone())
+    model_k, opt_k = fresh()
+    multi = graphs.GraphedTrainStep(model_k, opt_k, seq, warmup=2, steps_per_replay=3)      # the same two eager steps on b0 first
+    losses_k = []
+    for rep in range(2):
+        if rep == 1:
+            opt_k.param_groups[0]['lr'] = 0.004
+        multi()
+        losses_k += [v.clone() for v in multi.losses]
+    assert multi.steps_done == 8
+    assert [v.item() for v in losses_k] == [v.item() for v in losses_1]
+    flat_1, flat_k = opt_1.flat_buffers(), opt_k.flat_buffers()
+    assert flat_1['step'] == flat_k['step'] == 8
+    for key in ('param', 'exp_avg', 'exp_avg_sq'):
+        assert torch.equal(flat_1[key], flat_k[key]), key
+
+
 def test_dgrad_with_table_gathered_sigmoid_outputs():
     """mg_linear_dgrad_gathered_bf16 (sigmoid outputs read from the per-phone table through a row map) against mg_linear_dgrad_bf16
     on the materialised frame-rate activation: same kernel, same arithmetic - EQUAL."""
