@@ -53,7 +53,7 @@ const char* mg_last_error(void);
                                  * finishes dW / db (results are then NOT valid) - lets bench.py time the kernel alone */
 #define MG_TUNE_LSTM_BWD_STACK 6 /* mg_lstm_pstack_bwd_bf16: 0 = 32 hidden units per slot where they fit (one workgroup per CU), 1 = 16 (two per CU) */
 #define MG_TUNE_WGRAD_SPLITS 4  /* wide weight-gradient kernel: != 0 overrides the planned number of split-M slabs (a multiple of 8) */
-#define MG_TUNE_PROBE 7         /* timing probes of mg_f0_l2tail_bf16 (results garbage): 1 = no H1 loads, 2 = no tail, 4 = no layer-2 MFMAs, 8 = no sigmoid of H2 */
+#define MG_TUNE_PROBE 7         /* mg_f0_l2tail_bf16: 0 = the product kernel (one wave per SIMD), 64 = the producer / consumer role split (experiment, measured slower), other values = the product kernel's timing probes (results garbage): 1 = no H1 loads, 2 = no tail, 4 = no layer-2 MFMAs, 8 = no sigmoid of H2, 16 = no steps 8-9, 32 = no step 9 */
 #define MG_TUNE_WGRAD_ORDER 5   /* wide weight-gradient kernel, block order: 0 = planned, 1 = n tile fastest, 2 = the n tiles of a split on one XCD */
 int mg_set_tuning(int key, int value);
 int mg_version(void);           /* ABI version, bumped on incompatible change */

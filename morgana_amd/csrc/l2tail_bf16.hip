@@ -447,6 +447,395 @@ __global__ __launch_bounds__(256, 1) void f0_l2tail_kernel(const uint16_t* __res
     for (int e = tid; e < LT_SLAB; e += 256) out[e] = ((red[e] + red[LT_SLAB + e]) + red[2 * LT_SLAB + e]) + red[3 * LT_SLAB + e];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same pass with the work of a tile split between the TWO waves of a SIMD (512 threads, 2 waves per SIMD, 256 registers each).
+// Why: in the kernel above a wave owns a tile from the first MFMA to the last store; one wave per SIMD (it needs ~490 registers: a
+// tile's H1 rows + the next tile's prefetch, the layer-2 accumulators, dW3's accumulators, the tail's temporaries) leaves every LDS
+// round trip, every dependent MFMA and the lone-wave VALU issue rate (half the pipe's) exposed: 96 us at C2 against 48 us for the
+// H1 stream alone (profiles/r2_kbench_l2tail.txt: the tail is 13,000 cycles per tile for ~5,000 of issue).  Here
+//   * waves 0-3 (PRODUCERS) stream H1, run the 128 layer-2 MFMAs of a tile, bias + sigmoid + bf16, and hand the tile's H2 over
+//     in the B-operand register layout (8 x 16 bytes per lane: the consumer's lane l takes what the producer's lane l stored);
+//   * waves 4-7 (CONSUMERS) run the tail on it (steps 3-9 above: 24 MFMAs, the transcendentals, dZ2 / pred stores, dW3 / db3 /
+//     dW4 / db4 / loss accumulators).  Producer w and consumer w + 4 sit on the same SIMD: the consumer's VALU / LDS work passes
+//     under the producer's MFMAs.
+//   * the hand-off goes through a 3-slot ring per pair in GLOBAL memory (8 KB per slot; the 24 MB of all pairs stay in L2 / MALL):
+//     LDS has no room (W2 fills 128 of its 160 KB).  Plain stores by the producer (written through to this XCD's L2), sc1 loads
+//     (L1 bypass) by the consumer on the same CU; the pair's `ready` / `done` counters live in LDS.  The producer publishes tile
+//     n - 1 when it is about to store tile n: vector memory retires in order, so s_waitcnt vmcnt(32) - the 32 row loads issued
+//     since - says those stores are complete without draining the prefetch.  Spins are bounded; a wait that gives up makes the loss NaN.
+// MEASURED SLOWER and kept as an experiment (MG_TUNE_PROBE = 64; correct: the parity tests pass on it): 107 us against 100 at C2,
+// 26.3 against 25.2 at the phone-rate rows.  The split moves the sigmoid of H2 to the producer, but the consumer still owns the tail's
+// dependent chain (8 + 2 + 2 dependent MFMAs, three LDS round trips, the loads of the hand-off: ~10,000 cycles per tile of which
+// ~4,000 are issue) and has ONE tile in flight; a second tile in flight per consumer does not fit 256 registers.
+// ---------------------------------------------------------------------------------------------------------------------
+#define LT_FLAGS (LT_WAVE0 + 4 * LT_WAVE_BYTES)          // int ready[4], done[4], error
+#define LT_LDS2 (LT_FLAGS + 64)
+#define LT_RING 3                                        // hand-off slots per producer / consumer pair
+#define LT_SLOT_VEC (8 * 64)                             // u32x4 per slot
+#define LT_SPIN_LIMIT (1 << 22)
+
+__global__ __launch_bounds__(512, 2) void f0_l2tail_split_kernel(const uint16_t* __restrict__ H1, int ldh1, const uint16_t* __restrict__ W2,
+                                                                 int ldw2, const float* __restrict__ b2, const float* __restrict__ W3,
+                                                                 const float* __restrict__ b3, const float* __restrict__ W4,
+                                                                 const float* __restrict__ b4, const float* __restrict__ target,
+                                                                 const int64_t* __restrict__ seq_len, int64_t M, int B, int T,
+                                                                 float grad_scale, float* __restrict__ pred, uint16_t* __restrict__ dZ2,
+                                                                 int lddz, float* __restrict__ slab, const float* __restrict__ row_weight,
+                                                                 u32x4* __restrict__ xbuf) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LT_LDS2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mi = lane & 31, lh = lane >> 5;
+    const int q = wave & 3;
+    volatile int* flags = reinterpret_cast<volatile int*>(smem + LT_FLAGS);       // [0..3] ready, [4..7] done, [8] error
+
+    // ---- one-time (all 8 waves): W2, the two permuted W3 fragment tables, b2 (as the kernel above) -----------------------------
+    {
+        unsigned short* w3s = reinterpret_cast<unsigned short*>(smem + LT_WAVE0);
+        float w3v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w3v[i] = W3[tid + 512 * i];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            u32x4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = tid + 512 * (8 * r + i), n = e >> 6, c = e & 63;
+                v[i] = *reinterpret_cast<const u32x4*>(W2 + (size_t)n * ldw2 + c * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = tid + 512 * (8 * r + i), n = e >> 6, c = e & 63;
+                *reinterpret_cast<u32x4*>(smem + LT_W2 + n * (LT_K * 2) + ((c ^ (n & 15)) << 4)) = v[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w3s[tid + 512 * i] = mg_f2bf(w3v[i]);
+        if (tid < LT_N2) *reinterpret_cast<float*>(smem + LT_B2 + tid * 4) = b2[tid];
+        if (tid < 16) flags[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 512 * i, l = f & 63, r = l & 31, h = l >> 5, g = (f >> 6) & 7;
+            unsigned short el[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int u = 8 * (j >> 2) + 4 * h + (j & 3);
+                el[j] = (f < 512) ? w3s[r * LT_N2 + 16 * g + u] : w3s[(16 * (g & 1) + u) * LT_N2 + 32 * (g >> 1) + r];
+            }
+            *reinterpret_cast<u32x4*>(smem + LT_ZF + f * 16) = u32x4{el[0] | ((unsigned)el[1] << 16), el[2] | ((unsigned)el[3] << 16),
+                                                                   el[4] | ((unsigned)el[5] << 16), el[6] | ((unsigned)el[7] << 16)};
+        }
+        __syncthreads();
+    }
+
+    const int64_t n_tiles = (M + 31) / 32;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    const int64_t tile0 = (int64_t)blockIdx.x * 4 + q;
+    u32x4* const xq = xbuf + ((size_t)blockIdx.x * 4 + q) * (LT_RING * LT_SLOT_VEC) + lane;
+    bool timed_out = false;
+
+    if (wave < 4) {
+        // =============================================== producer ===============================================
+        const int w2_lane = LT_W2 + mi * (LT_K * 2);
+        const int xl = (mi & 15) ^ (4 * lh);
+        auto load_half = [&](u32x4 (&dst)[16], int64_t tile, int half) {
+            int64_t mm = tile * 32 + mi;
+            if (mm > M - 1) mm = M - 1;
+            const uint16_t* hp = H1 + (size_t)mm * ldh1 + 256 * half + 32 * lh;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) dst[4 * a + c] = *reinterpret_cast<const u32x4*>(hp + 64 * a + 8 * c);
+        };
+        f32x16 acc[4];
+        auto bias_acc = [&]() {
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const f32x4 bq = *reinterpret_cast<const f32x4*>(smem + LT_B2 + (32 * blk + 8 * qq + 4 * lh) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[blk][4 * qq + e] = bq[e];
+                }
+        };
+        u32x4 ha[16], hb[16];
+        if (tile0 < n_tiles) {
+            load_half(ha, tile0, 0);
+            load_half(hb, tile0, 1);
+        }
+        int n = 0;                                           // ordinal of the tile inside this pair's sequence
+        for (int64_t tile = tile0; tile < n_tiles; tile += stride, ++n) {
+            bias_acc();
+            auto w2frag = [&](int j, int blk) -> bfv8 {
+                const int a = j >> 2, c = j & 3;
+                return *reinterpret_cast<const bfv8*>(smem + w2_lane + blk * 32 * (LT_K * 2) + (a >> 1) * 256 + ((xl ^ (8 * (a & 1) + c)) << 4));
+            };
+            bfv8 wf[2][4];
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) wf[0][blk] = w2frag(0, blk);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            const int64_t next = tile + stride;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                if (j + 1 < 32) {
+#pragma unroll
+                    for (int blk = 0; blk < 4; ++blk) wf[(j + 1) & 1][blk] = w2frag(j + 1, blk);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                }
+                const u32x4 hv = j < 16 ? ha[j & 15] : hb[j & 15];
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk)
+                    acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j & 1][blk], __builtin_bit_cast(bfv8, hv), acc[blk], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                if (j == 15) {
+                    load_half(ha, next, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 16, 0);
+                }
+            }
+            load_half(hb, next, 1);
+            asm volatile("" ::: "memory");                   // the 32 row loads of this phase stay behind the stores of the last tile
+            // sigmoid, bf16: hq[2 blk + s] = registers 8 s .. 8 s + 7 of block blk
+            u32x4 hq[8];
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) {
+                unsigned int w[8];
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = mg_sigmoid_fast(acc[blk][4 * qq + e]);
+                    w[2 * qq] = __builtin_bit_cast(unsigned int, bfv2{(__bf16)v[0], (__bf16)v[1]});
+                    w[2 * qq + 1] = __builtin_bit_cast(unsigned int, bfv2{(__bf16)v[2], (__bf16)v[3]});
+                }
+                hq[2 * blk] = u32x4{w[0], w[1], w[2], w[3]};
+                hq[2 * blk + 1] = u32x4{w[4], w[5], w[6], w[7]};
+            }
+            // publish tile n - 1: its stores are older than the 32 row loads issued since
+            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            if (lane == 0) flags[q] = n;
+            // slot n % LT_RING is free once the consumer has loaded tile n - LT_RING
+            if (n >= LT_RING) {
+                int spins = 0;
+                while (flags[4 + q] < n - LT_RING + 1) {
+                    if (++spins > LT_SPIN_LIMIT) {
+                        timed_out = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            u32x4* dst = xq + (n % LT_RING) * LT_SLOT_VEC;
+#pragma unroll
+            for (int st = 0; st < 8; ++st) dst[st * 64] = hq[st];
+            asm volatile("" ::: "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) flags[q] = n;                         // every tile published
+        if (timed_out && lane == 0) flags[8] = 1;
+    } else {
+        // =============================================== consumer ===============================================
+        unsigned char* patch = smem + LT_WAVE0 + q * LT_WAVE_BYTES;
+        const float b4v = b4[0];
+        f32x16 acc_w3[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_w3[kt][r] = 0.f;
+        float dw4p[16], db3p[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dw4p[r] = db3p[r] = 0.f;
+        float db4p = 0.f, lossp = 0.f;
+        float* const pred_sink = reinterpret_cast<float*>(g_lt_sink) + lane;
+        uint16_t* const dz_sink = reinterpret_cast<uint16_t*>(g_lt_sink) + lane * 8;
+
+        int n = 0;
+        for (int64_t tile = tile0; tile < n_tiles; tile += stride, ++n) {
+            const int64_t m = tile * 32 + mi;
+            const bool live = m < M;
+            // per-frame scalars of the loss (requested before the wait for the tile)
+            float tg, s1, s2;
+            {
+                int64_t mm = m;
+                if (mm > M - 1) mm = M - 1;
+                tg = target[mm];
+                if (row_weight) {
+                    s1 = row_weight[mm];
+                    s2 = 0.f;
+                } else {
+                    const unsigned mu = (unsigned)mm, b = mu / (unsigned)T, t = mu - b * (unsigned)T;
+                    int64_t nb = seq_len ? seq_len[b] : (int64_t)T;
+                    if (nb > T) nb = T;
+                    if (nb < 0) nb = 0;
+                    s1 = (int64_t)t < nb ? 1.f : 0.f;
+                    s2 = (float)nb;
+                }
+            }
+            {
+                int spins = 0;
+                while (flags[q] < n + 1) {
+                    if (++spins > LT_SPIN_LIMIT) {
+                        timed_out = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            u32x4 hq[8];
+            {
+                const u32x4* src = xq + (n % LT_RING) * LT_SLOT_VEC;
+#pragma unroll
+                for (int st = 0; st < 8; ++st) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(hq[st]) : "v"(src + st * 64) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int st = 0; st < 8; ++st) asm volatile("" : "+v"(hq[st]));
+                if (lane == 0) flags[4 + q] = n + 1;         // the slot may be refilled
+            }
+
+            // (3) Z3^T = W3 . H2^T
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                const bfv8 a = *reinterpret_cast<const bfv8*>(smem + LT_ZF + (st * 64 + lane) * 16);
+                z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bfv8, hq[st]), z, 0, 0, 0);
+            }
+            // (4) sigmoid, prediction (b3 / w4 per register <-> unit 8 (r >> 2) + 4 lh + (r & 3), read as 16-byte groups)
+            float h3[16], w4r[16];
+            float ph = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(b3 + 8 * g + 4 * lh);
+                const f32x4 ww = *reinterpret_cast<const f32x4*>(W4 + 8 * g + 4 * lh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    w4r[4 * g + e] = ww[e];
+                    h3[4 * g + e] = mg_sigmoid_fast(z[4 * g + e] + bb[e]);
+                    ph += h3[4 * g + e] * ww[e];
+                }
+            }
+            const auto phs = __builtin_amdgcn_permlane32_swap(__float_as_uint(ph), __float_as_uint(ph), false, false);
+            const float p = (__uint_as_float(phs[0]) + __uint_as_float(phs[1])) + b4v;
+            // (5) masked MSE of this frame (as above)
+            const float inv = 1.f / (s2 * (float)B);
+            const float cw = row_weight ? 2.f * grad_scale : 2.f * grad_scale * inv;
+            const float lw = row_weight ? 1.f : inv;
+            const float e = p - tg;
+            const float dpred = live ? (e * s1) * cw : 0.f;
+            if (lh == 0) {
+                lossp += live ? (e * e * s1) * lw : 0.f;
+                db4p += dpred;
+            }
+            *((live && lh == 0) ? pred + m : pred_sink) = p;
+            // (6) backward of layer 4 and of the layer-3 sigmoid
+            float dz3[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dz3[r] = dpred * w4r[r] * h3[r] * (1.f - h3[r]);
+                dw4p[r] += dpred * h3[r];
+                db3p[r] += dz3[r];
+            }
+            // (7) dZ3 as bf16
+            u32x4 dzf[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                unsigned int w[4];
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq)
+                    w[qq] = __builtin_bit_cast(unsigned int, bfv2{(__bf16)dz3[8 * s + 2 * qq], (__bf16)dz3[8 * s + 2 * qq + 1]});
+                dzf[s] = u32x4{w[0], w[1], w[2], w[3]};
+                *reinterpret_cast<u32x2*>(patch + mi * 64 + (16 * s + 4 * lh) * 2) = u32x2{w[0], w[1]};
+                *reinterpret_cast<u32x2*>(patch + mi * 64 + (16 * s + 8 + 4 * lh) * 2) = u32x2{w[2], w[3]};
+            }
+            bfv8 dzt[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) dzt[s] = lt_tr_frag(patch, lane, s, false);
+            // (8), (9)
+            uint16_t* const dzrow = live ? dZ2 + (size_t)m * lddz + 8 * lh : dz_sink;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                f32x16 d;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bfv8 a = *reinterpret_cast<const bfv8*>(smem + LT_W3P + ((kt * 2 + s) * 64 + lane) * 16);
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bfv8, dzf[s]), d, 0, 0, 0);
+                }
+                unsigned int pk[4][2];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const unsigned int w0 = hq[2 * kt + (g >> 1)][2 * (g & 1)], w1 = hq[2 * kt + (g >> 1)][2 * (g & 1) + 1];
+                    const float h[4] = {__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xffff0000u), __uint_as_float(w1 << 16),
+                                        __uint_as_float(w1 & 0xffff0000u)};
+                    float v[4];
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) v[e2] = d[4 * g + e2] * h[e2] * (1.f - h[e2]);
+                    pk[g][0] = __builtin_bit_cast(unsigned int, bfv2{(__bf16)v[0], (__bf16)v[1]});
+                    pk[g][1] = __builtin_bit_cast(unsigned int, bfv2{(__bf16)v[2], (__bf16)v[3]});
+                    *reinterpret_cast<u32x2*>(patch + mi * 64 + ((g ^ ((mi >> 2) & 3)) << 4) + 8 * lh) = u32x2{w0, w1};
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+                    *reinterpret_cast<u32x4*>(dzrow + 32 * kt + 8 * g) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bfv8 bq = lt_tr_frag(patch, lane, s, true);
+                    acc_w3[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dzt[s], bq, acc_w3[kt], 0, 0, 0);
+                }
+            }
+        }
+        if (timed_out && lane == 0) flags[8] = 1;
+
+        // ---- reduction: lanes (frames) -> wave, fixed order ------------------------------------------------------------------
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) {
+                dw4p[r] += __shfl_xor(dw4p[r], off, 64);
+                db3p[r] += __shfl_xor(db3p[r], off, 64);
+            }
+        }
+        db4p = mg_wave_sum(db4p);
+        lossp = mg_wave_sum(lossp);
+        __builtin_amdgcn_s_barrier();                      // (A) every producer is past its last W2 read: see below
+        float* mine = reinterpret_cast<float*>(smem + LT_W2) + q * LT_SLAB;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nn = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int k = 32 * kt + mi;
+                mine[nn * LT_N2 + k] = acc_w3[kt][r];
+            }
+        if (mi == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nn = 8 * (r >> 2) + 4 * lh + (r & 3);
+                mine[LT_N3 * LT_N2 + nn] = db3p[r];
+                mine[LT_N3 * LT_N2 + LT_N3 + nn] = dw4p[r];
+            }
+        }
+        if (lane == 0) {
+            mine[LT_N3 * LT_N2 + 2 * LT_N3] = db4p;
+            mine[LT_N3 * LT_N2 + 2 * LT_N3 + 1] = lossp;
+        }
+    }
+    if (wave < 4) __builtin_amdgcn_s_barrier();            // (A) pairs with the consumers' barrier: the W2 region becomes the sums
+    __syncthreads();
+    const float* red = reinterpret_cast<const float*>(smem + LT_W2);
+    float* out = slab + (size_t)blockIdx.x * LT_SLAB;
+    const bool failed = flags[8] != 0;                 // a wait gave up: the results are invalid and the loss says so (NaN)
+    for (int e = tid; e < LT_SLAB; e += 512) {
+        const float v = ((red[e] + red[LT_SLAB + e]) + red[2 * LT_SLAB + e]) + red[3 * LT_SLAB + e];
+        out[e] = (failed && e == LT_SLAB - 1) ? __builtin_nanf("") : v;
+    }
+}
+
 static int l2tail_blocks(int64_t M) {
     int64_t blocks = mg_ceil_div(mg_ceil_div(M, 32), 4);
     if (blocks > 256) blocks = 256;                    // one resident workgroup per CU (156 KB of LDS each)
@@ -455,7 +844,11 @@ static int l2tail_blocks(int64_t M) {
 
 extern "C" {
 
-size_t mg_f0_l2tail_workspace_bytes(int64_t M) { return mg_align_up((size_t)l2tail_blocks(M) * LT_SLAB * sizeof(float), 256); }
+static size_t l2tail_slab_bytes(int64_t M) { return mg_align_up((size_t)l2tail_blocks(M) * LT_SLAB * sizeof(float), 256); }
+// slabs of the workgroups' sums, then the hand-off ring of the role-split kernel: 3 slots x 8 KB per producer / consumer pair
+size_t mg_f0_l2tail_workspace_bytes(int64_t M) {
+    return l2tail_slab_bytes(M) + (size_t)l2tail_blocks(M) * 4 * LT_RING * LT_SLOT_VEC * sizeof(u32x4);
+}
 
 static int f0_l2tail_launch(const char* name, const uint16_t* H1, int ldh1, int K2, const uint16_t* W2, int ldw2, int N2, const float* b2,
                             const float* W3, const float* b3, const float* W4, const float* b4, const float* target,
@@ -475,7 +868,12 @@ static int f0_l2tail_launch(const char* name, const uint16_t* H1, int ldh1, int 
     const int blocks = l2tail_blocks(M);
     float* slab = (float*)workspace;
 #define LT_LAUNCH(P_) hipLaunchKernelGGL(f0_l2tail_kernel<P_>, dim3(blocks), dim3(256), 0, st, H1, ldh1, W2, ldw2, b2, W3, b3, W4, b4, target, seq_len, M, B, T, grad_scale, pred, dZ2, lddz, slab, row_weight)
-    switch (g_mg_tuning[MG_TUNE_PROBE]) {
+    if (g_mg_tuning[MG_TUNE_PROBE] == 64) {            // experiment (measured slower, see the kernel's comment): producer / consumer waves
+        u32x4* xbuf = reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(workspace) + l2tail_slab_bytes(M));
+        hipLaunchKernelGGL(f0_l2tail_split_kernel, dim3(blocks), dim3(512), 0, st, H1, ldh1, W2, ldw2, b2, W3, b3, W4, b4, target, seq_len, M, B, T,
+                           grad_scale, pred, dZ2, lddz, slab, row_weight, xbuf);
+    } else
+    switch (g_mg_tuning[MG_TUNE_PROBE]) {              // 0: the product kernel; other values: its timing probes
         case 1: LT_LAUNCH(1); break;
         case 2: LT_LAUNCH(2); break;
         case 3: LT_LAUNCH(3); break;
