@@ -70,6 +70,12 @@ def time_kernel(fn, iters=10, warm=2):
     return start.elapsed_time(end) / iters
 
 
+def l2tail_flops(rows):
+    """Products of mg_f0_l2tail_bf16 per row: layer 2 forward (512 x 128), layer 3 forward, dH2 and dW3 (3 x 128 x 32), layer 4 forward
+    and dW4 (2 x 32)."""
+    return 2.0 * rows * (512 * 128 + 3 * 128 * 32 + 2 * 32)
+
+
 def roofline_f0(features, model, precision):
     """Time the GEMM kernels of the step in isolation (HIP events on the launch stream) and report the dominant one
     against the MFMA roof.  FLOPs are the algorithmic 2*M*K*N of the products the launch replaces."""
@@ -101,10 +107,18 @@ def roofline_f0(features, model, precision):
         seq_len = features['n_frames']
         kernels.append(('gemm_nt_persist_kernel<256>: layer-1 forward at phone rate (%d rows, 600->512 + bias + sigmoid)' % r_tab,
                         2.0 * r_tab * k * n1, lambda: ops.linear_fwd_bf16(tab, None, r_tab, k, w1b, b1, n1, ops.ACT_SIGMOID)))
-        kernels.append(('gemm_nt_persist_kernel<128>: layer-2 forward at phone rate (512->128 + bias + sigmoid)',
-                        2.0 * r_tab * n1 * n2, lambda: ops.linear_fwd_bf16(h_tab, None, r_tab, n1, w2b, b2, n2, ops.ACT_SIGMOID)))
         kernels.append(('phone_target_stats_kernel: per-phone weight / mean target / constant of the masked MSE (reads the M targets)', 0.0,
                         lambda: ops.phone_target_stats(target, rows_p, seg, seq_len, b, t, b * p, extra)))
+        w3, b3, w4, b4 = lins[2].weight.detach(), lins[2].bias.detach(), lins[3].weight.detach(), lins[3].bias.detach()
+        if ops.l2tail_ok(w2, w3, w4, ops.ACT_SIGMOID):
+            ybar, weight, _ = ops.phone_target_stats(target, rows_p, seg, seq_len, b, t, b * p, extra)
+            tail_grads = torch.empty(w3.numel() + b3.numel() + w4.numel() + b4.numel() + 1, device=lab.device)
+            kernels.append(('f0_l2tail_kernel<0>: layer 2 + layers 3-4 + masked MSE + their backward at phone rate, one pass over H1', l2tail_flops(r_tab),
+                            lambda: ops.f0_l2tail_rows(h_tab, w2b, b2, w3, b3, w4, b4, ybar, weight, tail_grads)))
+            algo_bytes['f0_l2tail_kernel<0>'] = 2.0 * (r_tab * n1 + n2 * n1 + r_tab * n2) + 12.0 * r_tab
+        else:
+            kernels.append(('gemm_nt_persist_kernel<128>: layer-2 forward at phone rate (512->128 + bias + sigmoid)',
+                            2.0 * r_tab * n1 * n2, lambda: ops.linear_fwd_bf16(h_tab, None, r_tab, n1, w2b, b2, n2, ops.ACT_SIGMOID)))
         bound['phone_target_stats_kernel'] = ('hbm', m * 4.0 * 2 + r_tab * 8.0)
         ldk = tab.shape[1]
         algo_bytes.update({'gemm_nt_persist_kernel<256>': 2.0 * (r_tab * ldk + n1 * ldk + r_tab * n1),
@@ -124,10 +138,17 @@ def roofline_f0(features, model, precision):
         (w1b, w2b), (_, w2t) = ops.cast_params_bf16([w1, w2], want_t=(1,))
         h1 = ops.linear_fwd_bf16(tab, rows, m, k, w1b, b1, n1, ops.ACT_SIGMOID)
         dz2 = (torch.randn(m, ops.pad_ld(n2), device=lab.device) * 0.01).to(torch.bfloat16)
-        kernels.append(('gemm_nt_persist_kernel<256>: layer-1 forward (gather-fused 600->512 + bias + sigmoid)',
-                        2.0 * m * k * n1, lambda: ops.linear_fwd_bf16(tab, rows, m, k, w1b, b1, n1, ops.ACT_SIGMOID)))
-        kernels.append(('gemm_nt_persist_kernel<128>: layer-2 forward (512->128 + bias + sigmoid)', 2.0 * m * n1 * n2,
-                        lambda: ops.linear_fwd_bf16(h1, None, m, n1, w2b, b2, n2, ops.ACT_SIGMOID)))
+        kernels.append(('gemm_nt_runs_kernel<1>: layer-1 forward (gathered operand staged by runs, 600->512 + bias + sigmoid)',
+                        2.0 * m * k * n1, lambda: ops.linear_fwd_bf16(tab, rows, m, k, w1b, b1, n1, ops.ACT_SIGMOID, rows_runs=True)))
+        w3, b3, w4, b4 = lins[2].weight.detach(), lins[2].bias.detach(), lins[3].weight.detach(), lins[3].bias.detach()
+        if ops.l2tail_ok(w2, w3, w4, ops.ACT_SIGMOID):
+            tail_grads = torch.empty(w3.numel() + b3.numel() + w4.numel() + b4.numel() + 1, device=lab.device)
+            tgt, n_fr = features['normalised_lf0'].reshape(-1), features['n_frames']
+            kernels.append(('f0_l2tail_kernel<0>: layer 2 + layers 3-4 + masked MSE + their backward, one pass over H1', l2tail_flops(m),
+                            lambda: ops.f0_l2tail(h1, w2b, b2, w3, b3, w4, b4, tgt, n_fr, b, t, tail_grads)))
+        else:
+            kernels.append(('gemm_nt_persist_kernel<128>: layer-2 forward (512->128 + bias + sigmoid)', 2.0 * m * n1 * n2,
+                            lambda: ops.linear_fwd_bf16(h1, None, m, n1, w2b, b2, n2, ops.ACT_SIGMOID)))
         if ops.can_fuse_bwd(m, n2, n1, k, tab.shape[1]):
             kernels.append(('wgrad_fused_pipe_kernel: layer-2 dgrad + sigmoid-grad + layer-1 wgrad (gather-fused), dZ1 on chip',
                             2.0 * m * n1 * n2 + 2.0 * m * k * n1,
@@ -139,7 +160,8 @@ def roofline_f0(features, model, precision):
         kernels.append(('wgrad_big_kernel<8>: layer-2 wgrad (dZ2^T H1)', 2.0 * m * n1 * n2,
                         lambda: ops.linear_wgrad_bf16(dz2, h1, None, m, n2, n1)))
         n_tab, ldk = tab.shape
-        algo_bytes.update({'gemm_nt_persist_kernel<256>': 2.0 * (n_tab * ldk + n1 * ldk + m * n1) + 4.0 * m,
+        algo_bytes.update({'gemm_nt_runs_kernel<1>': 2.0 * (n_tab * ldk + n1 * ldk + m * n1) + 4.0 * m,
+                           'f0_l2tail_kernel<0>': 2.0 * (m * n1 + n2 * n1 + m * n2) + 12.0 * m,
                            'gemm_nt_persist_kernel<128>': 2.0 * (m * n1 + n2 * n1 + m * n2),
                            'wgrad_fused_pipe_kernel': 2.0 * (m * n2 + m * n1 + n_tab * ldk) + 4.0 * m + 4.0 * n1 * k,
                            'wgrad_big_kernel<10>': 2.0 * (m * n1 + n_tab * ldk) + 4.0 * m + 4.0 * n1 * k,
@@ -170,7 +192,7 @@ def roofline_f0(features, model, precision):
     # HBM bytes per launch of the dominant kernel from the committed PMC passes of this round (scripts/gpu_profile.sh:
     # 2 x FETCH_SIZE + WRITE_SIZE on gfx950, MI355X_MICROARCH.md), and the bytes the launch has to move at the very least
     traffic = None
-    for table_name in ('r2_hbm_traffic.json', 'r1_hbm_traffic.json'):
+    for table_name in (('r2_hbm_traffic.json', 'r1_hbm_traffic.json') if ops.PHONE_RATE else ('r2fr_hbm_traffic.json',)):
         try:
             table = json.load(open(os.path.join(REPO, 'profiles', table_name)))
             if table.get(short) is not None:

@@ -416,8 +416,19 @@ def test_linear_fwd_run_staged_equals_frame_staged(m, n, act, rows_kind):
     assert torch.equal(got.view(torch.int16), want.view(torch.int16))
 
 
+@pytest.fixture
+def l2tail_variant(request):
+    """MG_TUNE_PROBE for mg_f0_l2tail_bf16: 0 = the product kernel, 64 = the producer / consumer role split (an experiment that
+    must stay correct)."""
+    from morgana_amd import _lib
+    _lib.load().mg_set_tuning(7, request.param)
+    yield request.param
+    _lib.load().mg_set_tuning(7, 0)
+
+
+@pytest.mark.parametrize('l2tail_variant', [0, 64], indirect=True)
 @pytest.mark.parametrize('bt', [(7, 45), (64, 1000), (3, 32), (1, 1)])
-def test_l2tail_kernel_vs_numpy_and_unfused_pair(bt):
+def test_l2tail_kernel_vs_numpy_and_unfused_pair(bt, l2tail_variant):
     """mg_f0_l2tail_bf16 (the 512 -> 128 sigmoid layer inside the fused tail: README.rst:65-73 layers 2-4 + losses.py:29-51, forward
     and backward in one pass over H1) against a float64 restatement fed the same bf16 operands and the kernel's own bf16 rounding of
     H2, and against the unfused pair it replaces (mg_linear_fwd_bf16 + mg_f0_tail_bf16): those two differ only in the summation
