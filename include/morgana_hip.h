@@ -254,6 +254,11 @@ int mg_expand_column_f32(const float* table, const int32_t* rows, int64_t M, flo
 /* ... and mg_phone_loss_const_add in the same launch (stats_workspace as left by mg_phone_target_stats). */
 int mg_expand_column_loss_f32(const float* table, const int32_t* rows, int64_t M, float* out, const void* stats_workspace, int R,
                               int extra, float* loss, void* stream);
+/* ... and the ordered reduce of the fused tail's slabs in the same launch: dst[0 .. n) = sum of the S slabs (stride floats apart; the
+ * arithmetic of the library's slab reduce), dst[n - 1] - the loss, stored behind the gradients - additionally receives the loss's
+ * constant term.  Pairs with mg_f0_l2tail_rows_slabs_bf16. */
+int mg_expand_column_reduce_f32(const float* table, const int32_t* rows, int64_t M, float* out, const void* stats_workspace, int R,
+                                int extra, const float* slab, int64_t n, int64_t stride, int S, float* dst, void* stream);
 size_t mg_phone_target_stats_workspace_bytes(int R, int extra);
 /* loss_const may be NULL: then mg_phone_loss_const_add(workspace, R, extra, loss) adds the constant to a loss in place later on
  * (the workspace must be left untouched in between). */
@@ -359,6 +364,12 @@ int mg_f0_l2tail_rows_bf16(const uint16_t* H1, int ldh1, int K2, const uint16_t*
                            const float* b3, const float* W4, const float* b4, const float* target, const float* row_weight, int64_t M,
                            float grad_scale, float* pred, float* loss, uint16_t* dZ2, int lddz, float* grads, int accumulate,
                            void* workspace, size_t workspace_bytes, void* stream);
+/* mg_f0_l2tail_rows_bf16 without its reduce launch: the workgroups' sums (32*128 + 32 + 32 + 2 floats each: dW3 | db3 | dW4 | db4 | loss)
+ * stay at the start of `workspace`, *n_slabs of them, for mg_expand_column_reduce_f32. */
+int mg_f0_l2tail_rows_slabs_bf16(const uint16_t* H1, int ldh1, int K2, const uint16_t* W2, int ldw2, int N2, const float* b2, const float* W3,
+                                 const float* b3, const float* W4, const float* b4, const float* target, const float* row_weight, int64_t M,
+                                 float grad_scale, float* pred, uint16_t* dZ2, int lddz, void* workspace, size_t workspace_bytes, int* n_slabs,
+                                 void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * K3  GRU through RecurrentCuDNNWrapper   reference: morgana/utils.py:345-393 + torch.nn.GRU (gates r, z, n)

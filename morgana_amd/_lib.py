@@ -74,6 +74,11 @@ SIGNATURES = {
                                 c_void_p]),
     'mg_linear_bwd_fused_slabs_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                                c_int64, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    'mg_f0_l2tail_rows_slabs_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_int, c_void_p,
+                                             c_size_t, c_void_p, c_void_p]),
+    'mg_expand_column_reduce_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_int64,
+                                            c_int, c_void_p, c_void_p]),
     'mg_f0_l2tail_workspace_bytes': (c_size_t, [c_int64]),
     'mg_f0_l2tail_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,

@@ -854,8 +854,8 @@ static int f0_l2tail_launch(const char* name, const uint16_t* H1, int ldh1, int 
                             const float* W3, const float* b3, const float* W4, const float* b4, const float* target,
                             const int64_t* seq_len, const float* row_weight, int64_t M, int B, int T, float grad_scale, float* pred,
                             float* loss, uint16_t* dZ2, int lddz, float* grads, int accumulate, void* workspace, size_t workspace_bytes,
-                            void* stream) {
-    MG_CHECK_ARG(H1 && W2 && b2 && W3 && b3 && W4 && b4 && target && pred && loss && dZ2 && grads && M > 0 && M < 2147483647LL,
+                            void* stream, int* slabs_out = nullptr) {
+    MG_CHECK_ARG(H1 && W2 && b2 && W3 && b3 && W4 && b4 && target && pred && (slabs_out || (loss && grads)) && dZ2 && M > 0 && M < 2147483647LL,
                  "%s: bad arguments (M=%lld)", name, (long long)M);
     MG_CHECK_ARG(K2 == LT_K && N2 == LT_N2 && ldh1 >= LT_K && ldh1 % 8 == 0 && ldw2 >= LT_K && ldw2 % 8 == 0 && lddz >= LT_N2 && lddz % 8 == 0,
                  "%s: needs a 512 -> 128 layer (K2=%d N2=%d ldh1=%d ldw2=%d lddz=%d)", name, K2, N2, ldh1, ldw2, lddz);
@@ -888,6 +888,10 @@ static int f0_l2tail_launch(const char* name, const uint16_t* H1, int ldh1, int 
     }
 #undef LT_LAUNCH
     MG_CHECK_LAUNCH(name);
+    if (slabs_out) {                                   // the caller sums the slabs (mg_expand_column_reduce_f32)
+        *slabs_out = blocks;
+        return MG_OK;
+    }
     // grads = [dW3 (32*128) | db3 (32) | dW4 (32) | db4 (1)]; the loss is the last slab entry
     const int n_grads = LT_SLAB - 1;
     if (loss == grads + n_grads && !accumulate) {
@@ -917,6 +921,19 @@ int mg_f0_l2tail_rows_bf16(const uint16_t* H1, int ldh1, int K2, const uint16_t*
     return f0_l2tail_launch("mg_f0_l2tail_rows_bf16", H1, ldh1, K2, W2, ldw2, N2, b2, W3, b3, W4, b4, target, nullptr, row_weight, M, 1,
                             (int)(M < 2147483647LL ? M : 1), grad_scale, pred, loss, dZ2, lddz, grads, accumulate, workspace,
                             workspace_bytes, stream);
+}
+
+// mg_f0_l2tail_rows_bf16 without its reduce launch: the workgroups' sums stay in `workspace` as *n_slabs slabs of 32*128 + 32 + 32 + 2
+// floats (dW3 | db3 | dW4 | db4 | loss) from its start, for mg_expand_column_reduce_f32 to sum in the same launch that repeats the
+// prediction.
+int mg_f0_l2tail_rows_slabs_bf16(const uint16_t* H1, int ldh1, int K2, const uint16_t* W2, int ldw2, int N2, const float* b2, const float* W3,
+                                 const float* b3, const float* W4, const float* b4, const float* target, const float* row_weight, int64_t M,
+                                 float grad_scale, float* pred, uint16_t* dZ2, int lddz, void* workspace, size_t workspace_bytes, int* n_slabs,
+                                 void* stream) {
+    MG_CHECK_ARG(row_weight && n_slabs, "mg_f0_l2tail_rows_slabs_bf16: null argument");
+    return f0_l2tail_launch("mg_f0_l2tail_rows_slabs_bf16", H1, ldh1, K2, W2, ldw2, N2, b2, W3, b3, W4, b4, target, nullptr, row_weight, M, 1,
+                            (int)(M < 2147483647LL ? M : 1), grad_scale, pred, nullptr, dZ2, lddz, nullptr, 0, workspace, workspace_bytes, stream,
+                            n_slabs);
 }
 
 }  // extern "C"

@@ -233,6 +233,50 @@ __global__ __launch_bounds__(256) void expand_column_kernel(const float* __restr
     }
 }
 
+// expand_column_kernel and the ordered slab reduce of the fused tail in ONE launch (two nodes at the ~5 us launch floor become one):
+// block b repeats the prediction for its 256 frames and, while b < ceil(n / 16), reduces elements [16 b, 16 b + 16) of the S slabs with
+// mg_slab_reduce_kernel's arithmetic (16 interleaved partitions, each ascending, then ascending over the partitions: the same bits).
+// The block that owns the LAST element (the loss, stored behind the gradients) adds the sum of the per-block partial sums of the
+// loss's constant term to it, as the last block of expand_column_kernel did after the reduce launch.
+__global__ __launch_bounds__(256) void expand_reduce_kernel(const float* __restrict__ table, const int32_t* __restrict__ rows, int64_t M,
+                                                            float* __restrict__ out, const float* __restrict__ partial, int n_partial,
+                                                            const float* __restrict__ slab, int64_t n, int64_t stride, int S,
+                                                            float* __restrict__ dst) {
+    __shared__ float part[16][17];
+    __shared__ float red[256];
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f < M) out[f] = table[rows[f]];
+    const int64_t base = (int64_t)blockIdx.x * 16;
+    if (base >= n) return;                             // block-uniform
+    const int e = threadIdx.x & 15, p = threadIdx.x >> 4;
+    const int64_t i = base + e;
+    float v = 0.f;
+    if (i < n) {
+#pragma unroll 4
+        for (int s = p; s < S; s += 16) v += slab[(size_t)s * stride + i];
+    }
+    part[p][e] = v;
+    const bool owns_loss = base <= n - 1 && n - 1 < base + 16;        // block-uniform
+    float c = 0.f;
+    if (owns_loss)
+        for (int k = threadIdx.x; k < n_partial; k += 256) c += partial[k];
+    red[threadIdx.x] = c;
+    __syncthreads();
+    if (owns_loss) {
+        for (int s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+    }
+    if (p == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += part[q][e];
+        if (i == n - 1) t += red[0];
+        dst[i] = t;
+    }
+}
+
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int n, float* __restrict__ out,
                                                            int accumulate) {
     __shared__ float red[256];
@@ -335,6 +379,21 @@ int mg_expand_column_loss_f32(const float* table, const int32_t* rows, int64_t M
     hipLaunchKernelGGL(expand_column_kernel, dim3((unsigned)mg_ceil_div(M, 256)), dim3(256), 0, (hipStream_t)stream, table, rows, M, out,
                        (const float*)stats_workspace, n_partial, loss);
     MG_CHECK_LAUNCH("mg_expand_column_loss_f32");
+    return MG_OK;
+}
+
+// mg_expand_column_loss_f32 and the tail's slab reduce in one launch: dst[0 .. n) = ordered sum of the S slabs (mg_f0_l2tail_rows_slabs_bf16
+// leaves them), dst[n - 1] (the loss) + the loss's constant term, out = the repeated prediction.
+int mg_expand_column_reduce_f32(const float* table, const int32_t* rows, int64_t M, float* out, const void* stats_workspace, int R,
+                                int extra, const float* slab, int64_t n, int64_t stride, int S, float* dst, void* stream) {
+    MG_CHECK_ARG(table && rows && out && stats_workspace && slab && dst && M > 0 && R > 0 && extra >= 0 && n > 0 && stride >= n && S > 0,
+                 "mg_expand_column_reduce_f32: bad arguments (M=%lld n=%lld S=%d)", (long long)M, (long long)n, S);
+    const int n_partial = (int)(mg_ceil_div(R, 16) + mg_ceil_div(extra, 4));
+    int64_t blocks = mg_ceil_div(M, 256);
+    if (mg_ceil_div(n, 16) > blocks) blocks = mg_ceil_div(n, 16);
+    hipLaunchKernelGGL(expand_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, table, rows, M, out,
+                       (const float*)stats_workspace, n_partial, slab, n, stride, S, dst);
+    MG_CHECK_LAUNCH("mg_expand_column_reduce_f32");
     return MG_OK;
 }
 

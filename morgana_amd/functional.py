@@ -380,13 +380,20 @@ class LinearStackMSEFn(torch.autograd.Function):
                 offsets.append(offsets[-1] + sz)
             flat = torch.empty(sum(sizes) + 1, dtype=torch.float32, device=x2d.device)
             ybar, weight, partials = ops.phone_target_stats(target.reshape(-1), rows, seg, seq_len, b, t, n_table, extra)
-            if l2tail:
-                pred_rows, loss, dz2 = ops.f0_l2tail_rows(hidden[-1], w_bf[lead - 1], biases[lead - 1], weights[lead], biases[lead],
-                                                          weights[lead + 1], biases[lead + 1], ybar, weight, flat[offsets[2 * lead]:])
+            if l2tail and os.environ.get('MORGANA_EXPAND_REDUCE', '1') != '0':
+                # the tail's slab reduce rides in the launch that repeats the prediction (one node less, the same sums)
+                pred, loss, dz2 = ops.f0_l2tail_rows_expand(hidden[-1], w_bf[lead - 1], biases[lead - 1], weights[lead], biases[lead],
+                                                            weights[lead + 1], biases[lead + 1], ybar, weight, flat[offsets[2 * lead]:],
+                                                            rows, (partials, n_table, extra))
+                pred = pred.view(b, t, 1)
             else:
-                pred_rows, loss, dz2 = ops.f0_tail_rows(hidden[-1], weights[lead], biases[lead], weights[lead + 1], biases[lead + 1],
-                                                        ybar, weight, flat[offsets[2 * lead]:])
-            pred = ops.expand_column(pred_rows, rows, loss_const=(partials, n_table, extra, loss)).view(b, t, 1)
+                if l2tail:
+                    pred_rows, loss, dz2 = ops.f0_l2tail_rows(hidden[-1], w_bf[lead - 1], biases[lead - 1], weights[lead], biases[lead],
+                                                              weights[lead + 1], biases[lead + 1], ybar, weight, flat[offsets[2 * lead]:])
+                else:
+                    pred_rows, loss, dz2 = ops.f0_tail_rows(hidden[-1], weights[lead], biases[lead], weights[lead + 1], biases[lead + 1],
+                                                            ybar, weight, flat[offsets[2 * lead]:])
+                pred = ops.expand_column(pred_rows, rows, loss_const=(partials, n_table, extra, loss)).view(b, t, 1)
             ctx.acts, ctx.m, ctx.lead = acts, m, lead
             ctx.dims = [(w.shape[0], w.shape[1]) for w in weights]
             ctx.offsets = offsets

@@ -572,6 +572,30 @@ def f0_l2tail_rows(h1, w2_bf, b2, w3, b3, w4, b4, target_rows, row_weight, grads
     return pred, loss, dz2
 
 
+def f0_l2tail_rows_expand(h1, w2_bf, b2, w3, b3, w4, b4, target_rows, row_weight, grads_out, rows, loss_const, grad_scale=1.0):
+    """f0_l2tail_rows + expand_column with the tail's reduce folded into the expansion's launch (mg_f0_l2tail_rows_slabs_bf16 +
+    mg_expand_column_reduce_f32): one node less in the phone-rate step, same sums in the same order.  ``grads_out`` must have room for
+    the loss behind the tail's gradients; ``loss_const`` = (partials, n_table_rows, extra).  Returns (pred (frames,), loss, dz2)."""
+    lib = _lib.load()
+    m = h1.shape[0]
+    n = 32 * 128 + 32 + 32 + 2                           # dW3 | db3 | dW4 | db4 | loss
+    if grads_out.numel() < n:
+        raise ValueError('f0_l2tail_rows_expand: the gradient buffer needs one float behind the gradients for the loss')
+    pred_rows = torch.empty((m,), dtype=torch.float32, device=h1.device)
+    dz2 = torch.empty((m, 128), dtype=torch.bfloat16, device=h1.device)
+    ws = workspace(lib.mg_f0_l2tail_workspace_bytes(m), h1.device)
+    n_slabs = ctypes.c_int(0)
+    _lib.check(lib.mg_f0_l2tail_rows_slabs_bf16(_p(h1), h1.shape[1], 512, _p(w2_bf), w2_bf.shape[1], 128, _p(b2), _p(w3), _p(b3), _p(w4),
+                                                _p(b4), _p(target_rows), _p(row_weight), m, float(grad_scale), _p(pred_rows), _p(dz2),
+                                                128, _p(ws), ws.numel(), ctypes.byref(n_slabs), _stream()),
+               'mg_f0_l2tail_rows_slabs_bf16')
+    partials, n_table_rows, extra = loss_const
+    out = torch.empty((rows.numel(),), dtype=torch.float32, device=h1.device)
+    _lib.check(lib.mg_expand_column_reduce_f32(_p(pred_rows), _p(rows), rows.numel(), _p(out), _p(partials), n_table_rows, extra, _p(ws),
+                                               n, n, n_slabs.value, _p(grads_out), _stream()), 'mg_expand_column_reduce_f32')
+    return out, grads_out[n - 1], dz2
+
+
 def phone_target_stats(target, rows, seg, seq_len, b, t, n_table_rows, extra):
     """(ybar (R + extra,), weight (R + extra,), partials) of the masked MSE per table row (mg_phone_target_stats); ``partials`` holds
     the per-block sums of the loss's constant term for ``phone_loss_const_add``."""

@@ -510,6 +510,22 @@ def test_l2tail_rows_kernel_vs_unfused_pair():
     assert rel_err(dz2.float().cpu().numpy(), dz2_u[:, :128].float().cpu().numpy()) < 1e-2
     assert rel_err(grads[:4161].cpu().numpy(), grads_u[:4161].cpu().numpy()) < 1e-2
 
+    # the tail's reduce folded into the launch that repeats the prediction (mg_f0_l2tail_rows_slabs_bf16 + mg_expand_column_reduce_f32)
+    # against the two launches it replaces (reduce, then mg_expand_column_loss_f32): the same sums in the same order - EQUAL
+    frames = 50000
+    rows = dev(np.sort(rng.randint(0, m, size=frames)).astype(np.int32))
+    n_table, extra = m - 1024, 1024
+    partials = dev(rng.uniform(0, 1e-3, (n_table + 15) // 16 + extra // 4).astype(np.float32))    # per-block sums of the loss's constant term
+    assert partials.numel() == (n_table + 15) // 16 + extra // 4
+    loss_before = loss.clone()
+    want_pred = ops.expand_column(pred, rows, loss_const=(partials, n_table, extra, loss))       # adds the constant to `loss` in place
+    grads_f = torch.empty_like(grads)
+    got_pred, got_loss, dz2_f = ops.f0_l2tail_rows_expand(h1_d, w2_bf, b2, w3, b3, w4, b4, ybar, weight, grads_f, rows,
+                                                          (partials, n_table, extra))
+    assert torch.equal(got_pred, want_pred) and torch.equal(dz2_f, dz2)
+    assert torch.equal(grads_f[:4161], grads[:4161])
+    assert got_loss.item() == loss.item() and loss.item() != loss_before.item()
+
 
 @pytest.mark.parametrize('rows_kind', ['random', 'runs', 'identity'])
 @pytest.mark.parametrize('m,n_hidden', [(4999, 512), (9000, 256)])
