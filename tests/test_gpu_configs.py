@@ -221,8 +221,23 @@ def test_rccl_world1_graphed_step_equals_single_rank():
         losses_m = [multi().clone() for _ in range(5)]
         torch.cuda.synchronize()
         mode = multi.exchange_mode
+        # two steps per graph launch on the multi-rank path (bench.py's form when the exchange is captured): 2 + 2 x 2 steps against the
+        # first 6 of the single-rank run above; with an eager exchange the constructor must refuse (the collective sits between graphs)
+        model_k, opt_k = fresh(exchange_always=True)
+        losses_k, refused = [], False
+        try:
+            multi_k = graphs.GraphedTrainStep(model_k, opt_k, feats, warmup=2, steps_per_replay=2)
+            for _ in range(2):
+                multi_k()
+                losses_k += [v.clone() for v in multi_k.losses]
+            torch.cuda.synchronize()
+        except ValueError:
+            refused = True
     finally:
         dist.destroy_process_group()
+    assert refused == (mode == 'eager')
+    if not refused:
+        assert [v.item() for v in losses_k] == [v.item() for v in losses_s[:4]]
     assert mode in ('captured', 'eager')
     assert [v.item() for v in losses_m] == [v.item() for v in losses_s]
     for key in ('param', 'exp_avg', 'exp_avg_sq'):
