@@ -421,7 +421,7 @@ __global__ __launch_bounds__(512) void wgrad_fused_pipe_kernel(const uint16_t* _
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef MG_STAMPS
-    unsigned long long ts0, ts1 = 0, ts2, ts3, tr0, tr1, ta, tb, sum_wait_a = 0, sum_issue_x = 0, sum_body = 0;
+    unsigned long long ts0, ts1 = 0, ts2, ts3, tr0, tr1, ta, tb, sum_wait_a = 0, sum_issue_x = 0, sum_body = 0, sum_p2 = 0, sum_first = 0;
     MG_STAMP(ts0);
     MG_STAMP_REAL(tr0);
 #endif
@@ -724,8 +724,13 @@ __global__ __launch_bounds__(512) void wgrad_fused_pipe_kernel(const uint16_t* _
         read_slots(step + 1, sl_next);                    // step + 1 == n_steps reads the pad row
         MG_STAMP(ta);
         MG_STAMP_ADD(sum_issue_x, ta, tb);
+#ifdef MG_STAMPS
+        unsigned long long tc, td;
+#endif
         if (wave < 4 && step + 1 < n_steps) p1(tb_next, (step + 1) & 1);
+        MG_STAMP(tc);
         p2(step & 1, sl_cur);
+        MG_STAMP(td);
         if (wave >= 4) {
             if (step + 1 < n_steps) p1(tb_next, (step + 1) & 1);
             if (step + 1 < n_steps) issue_upto(ring_last);
@@ -733,6 +738,8 @@ __global__ __launch_bounds__(512) void wgrad_fused_pipe_kernel(const uint16_t* _
         }
         MG_STAMP(tb);
         MG_STAMP_ADD(sum_body, tb, ta);
+        MG_STAMP_ADD(sum_p2, td, tc);
+        MG_STAMP_ADD(sum_first, tc, ta);
         lg0 = lg1;
         lg1 = lg2;
         lg2 = __builtin_amdgcn_readfirstlane(la_last) >> 2;
@@ -784,6 +791,8 @@ __global__ __launch_bounds__(512) void wgrad_fused_pipe_kernel(const uint16_t* _
     MG_STAMP_STORE(g_stamps_fp, sb, wave, lane, 6, sum_wait_a);
     MG_STAMP_STORE(g_stamps_fp, sb, wave, lane, 7, sum_issue_x);
     MG_STAMP_STORE(g_stamps_fp, sb, wave, lane, 8, sum_body);
+    MG_STAMP_STORE(g_stamps_fp, sb, wave, lane, 9, sum_p2);
+    MG_STAMP_STORE(g_stamps_fp, sb, wave, lane, 10, sum_first);
 #endif
 }
 

@@ -43,6 +43,7 @@ def report(title, st, extra):
 
 
 def main():
+    only_fused = len(sys.argv) > 1 and sys.argv[1] == 'fused'
     dev = 'cuda:0'
     lib = _lib.load()
     feats = data.to_device(synthetic.make_batch(256, 1000), dev)
@@ -87,7 +88,8 @@ def main():
     torch.cuda.synchronize()
     s = read(lib, 'mg_diag_read_stamps_fp', 256)
     report('wgrad_fused_pipe (dgrad2 + wgrad1, gathered input)', s,
-           [('  loop: barrier', s[..., 6]), ('  loop: DMA issue + look-ahead reads', s[..., 7]), ('  loop: P1 and P2', s[..., 8])])
+           [('  loop: barrier', s[..., 6]), ('  loop: DMA issue + look-ahead reads', s[..., 7]), ('  loop: P1 and P2', s[..., 8]),
+            ('    of it: P2', s[..., 9]), ('    of it: what precedes P2 (waves 0-3: P1)', s[..., 10])])
 
 
 if __name__ == '__main__':
