@@ -435,6 +435,54 @@ def c4_leg(dev, precision):
             'note': 'T = 1000 dependent steps per direction bound the step (latency chain), not the MFMA rate'}
 
 
+def other_workloads(dev, precision):
+    """The other workloads of `--config` (C5, the shipped LSTM acoustic model, the shipped GRU F0 model) timed in the same run as the
+    headline - 5 eager steps after 2 warm-up steps each - so that their numbers are driver-timed as well (C4 has its own leg)."""
+    out = {}
+    specs = [
+        ('c5', 'C5: RNN_SPSS Linear-512 / GRU-512 / Linear-256 / 187, 64 utterances of 300-2000 frames (packed frames)',
+         lambda: (synthetic.make_batch(64, (300, 2000), out_dim=187, target_name='mcep'), models.RNNSPSS(output_dim=187, precision=precision),
+                  synthetic.rnn_spss_state(out_dim=187), False)),
+        ('lstm', 'shipped LSTM acoustic model 609-512-8xLSTM512-256-199, 64 x 1000 frames, with its per-step MLPG + 4 streaming metrics',
+         lambda: (synthetic.make_acoustic_batch(64, 1000, with_raw=True), models.LSTMAcousticModel(precision=precision, generate=True),
+                  synthetic.lstm_acoustic_state(), True)),
+        ('f0gru', 'shipped GRU F0 model 609-256-3xGRU64-64-3, 64 x 1000 frames, with its per-step MLPG + LF0 metric',
+         lambda: (synthetic.make_acoustic_batch(64, 1000, streams=(('lf0', 3, 'mse'),), with_raw=True),
+                  models.GRUF0Model(precision=precision, generate=True), synthetic.gru_f0_state(), True)),
+    ]
+    for key, what, make in specs:
+        try:
+            feats_np, model, state, acoustic = make()
+            model = model.to(dev)
+            own = model.state_dict()
+            for k, v in state.items():
+                own[k].copy_(torch.from_numpy(v))
+            if acoustic:
+                synthetic.acoustic_normalisers(model, device=dev)
+                model.mode = 'train'
+                model.metrics.reset_state('train')
+            feats = data.to_device(feats_np, dev)
+            if precision == 'bf16':
+                data.add_bf16_table(feats)
+            opt = optim.Adam(model.parameters(), lr=0.01, fused_loop=True)
+
+            def step():
+                opt.zero_grad()
+                loss, _ = model(feats)
+                F_hip.backward(loss)
+                opt.step()
+
+            ms = timed_leg(step, 5, 2)
+            ops.check_persistent_status()
+            frames = int(feats_np['n_frames'].sum())
+            out[key] = {'workload': what + ', eager launches, %s' % precision, 'ms_per_step': round(ms, 4),
+                        'value': round(frames / (ms * 1e-3), 1), 'unit': 'frames/s'}
+            del model, opt, feats
+        except Exception as exc:                          # noqa: BLE001 - a leg that fails is reported, the headline stands
+            out[key] = {'error': str(exc).splitlines()[0][:200]}
+    return out
+
+
 def main():
     args = parse_args()
     rank, local_rank, world = distributed.init()
@@ -647,6 +695,7 @@ def main():
             result['c4'] = c4_leg(dev, args.precision)
         except Exception as exc:
             result['c4'] = {'error': str(exc).splitlines()[0][:200]}
+        result['other_workloads'] = other_workloads(dev, args.precision)
         try:
             result['loss_curve_deviation'] = loss_curve_deviation(dev)
         except Exception as exc:
