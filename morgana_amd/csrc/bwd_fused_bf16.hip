@@ -326,7 +326,7 @@ __global__ __launch_bounds__(512) void wgrad_fused_kernel(const uint16_t* __rest
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < TKT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TKT; ++j) acc[i][j] = mg_mfma_32x32x16(a[i], b[j], acc[i][j]);
         }
         MG_STAMP(ta);
         MG_STAMP_ADD(sum_p2, ta, tb);
@@ -652,11 +652,11 @@ __global__ __launch_bounds__(512) void wgrad_fused_pipe_kernel(const uint16_t* _
                 a[1][0] = rd_a(1, 0);
                 a[1][1] = rd_a(1, 1);
             }
-            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], b[t], acc[0][j], 0, 0, 0);
-            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][1], b[t], acc[1][j], 0, 0, 0);
+            acc[0][j] = mg_mfma_32x32x16(a[ks][0], b[t], acc[0][j]);
+            acc[1][j] = mg_mfma_32x32x16(a[ks][1], b[t], acc[1][j]);
             constexpr int n_reads = (t + 2 < 2 * TKT ? 2 : 0) + (t == 2 ? 4 : 0);
             if constexpr (n_reads > 0) __builtin_amdgcn_sched_group_barrier(0x100, n_reads, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * MG_MFMA_PER_TILE, 0);
         };
         mm(std::integral_constant<int, 0>{});
         mm(std::integral_constant<int, 1>{});

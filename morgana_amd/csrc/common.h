@@ -55,6 +55,31 @@ __device__ __forceinline__ float mg_sigmoid_fast(float x) {
     return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
 }
 
+// The 32x32x16 bf16 MFMA of the large GEMM kernels behind one name, so that a PROBE build (make probe16 -> libmorgana_hip_probe16.so,
+// -DMG_PROBE16, results garbage, never loaded by the package) can issue two v_mfma_f32_16x16x32_bf16 in its place on the same
+// registers: same matrix cycles, same operand traffic, a different clock under load (MI355X_MICROARCH.md, DVFS give-back item 7).
+typedef __bf16 mg_bfv8 __attribute__((ext_vector_type(8)));
+#ifdef MG_PROBE16
+#define MG_MFMA_PER_TILE 2
+__device__ __forceinline__ f32x16 mg_mfma_32x32x16(mg_bfv8 a, mg_bfv8 b, f32x16 c) {
+    f32x4 lo = {c[0], c[1], c[2], c[3]}, hi = {c[8], c[9], c[10], c[11]};
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, lo, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, hi, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        c[r] = lo[r];
+        c[8 + r] = hi[r];
+    }
+    asm volatile("" : "+v"(c));                        // the other registers stay opaque: the epilogues keep all their work
+    return c;
+}
+#else
+#define MG_MFMA_PER_TILE 1
+__device__ __forceinline__ f32x16 mg_mfma_32x32x16(mg_bfv8 a, mg_bfv8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+#endif
+
 __device__ __forceinline__ float mg_wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -199,8 +199,8 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __rest
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if (EPI == EPI_SIGMOID_GRAD) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                    if (EPI == EPI_SIGMOID_GRAD) acc[i][j] = mg_mfma_32x32x16(a[i], b[j], acc[i][j]);
+                    else acc[i][j] = mg_mfma_32x32x16(b[j], a[i], acc[i][j]);
                 }
         }
     }
@@ -592,8 +592,8 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, KS * TM * TN, 0);
+                    acc[i][j] = mg_mfma_32x32x16(fb[ks][j], fa[ks][i], acc[i][j]);
+        __builtin_amdgcn_sched_group_barrier(0x008, KS * TM * TN * MG_MFMA_PER_TILE, 0);
         if (STAG) __builtin_amdgcn_s_setprio(0);
     };
 
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+                acc[i][j] = mg_mfma_32x32x16(fb[ks][j], fa[ks][i], acc[i][j]);
     };
 
     const int g_total = n_my * n_kt;
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
                 for (int mi = 0; mi < 16; ++mi) {
                     if (spread_off == (mi & 3)) issue_piece(mi >> 2);      // the slot every wave finished with before this barrier
                     const int ks = mi / (TM * TN), i = (mi / TN) % TM, j = mi % TN;
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mg_mfma_32x32x16(fb[ks][j], fa[ks][i], acc[i][j]);
                 }
                 advance_stage();
             } else if (ROLE) {
@@ -1033,10 +1033,10 @@ __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restri
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < TKT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TKT; ++j) acc[i][j] = mg_mfma_32x32x16(a[i], b[j], acc[i][j]);
             if (kExtraBias && bias_extra) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], ones, accb[i], 0, 0, 0);
+                for (int i = 0; i < 2; ++i) accb[i] = mg_mfma_32x32x16(a[i], ones, accb[i]);
             }
         }
         if (bias_valu && tid < BNT) {
