@@ -797,6 +797,369 @@ __global__ __launch_bounds__(512) void wgrad_fused_pipe_kernel(const uint16_t* _
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------
+// "Solo" form of the pipelined kernel: ONE wave per SIMD (256 threads, up to 512 registers per lane), P1 of step + 1 woven into P2 of
+// step inside one instruction stream.  Why (profiles/r2_stamps_fused.txt, cycles per 32-frame step of the 8-wave kernel, ~4,050 for
+// 2 x 768 matrix cycles per SIMD): every wave spends ~950 cycles in P1 - an LDS round trip, two 4-deep MFMA chains, ~25 dependent
+// VALU instructions and an LDS store for 128 matrix cycles - and ~700 issuing its share of the DMA, phases in which it feeds nothing
+// to the matrix pipe; its SIMD partner covers only part of that because it has the same phases, and at 254 registers (160 of them
+// accumulators) there is no room to interleave P1 with P2 inside a wave.  With one wave per SIMD the budget doubles: a wave owns all
+// 128 rows x 160 columns of the tile (320 accumulator registers), runs P1 for 32 of the 128 hidden units (W2^T fragments resident: 32
+// registers), and P1's reads, its 16 small MFMAs, its VALU tail and its LDS stores are placed between the groups of P2's 40 MFMAs,
+// whose operands are read two groups ahead: the chain of P1 never stands alone.  Same LDS layout, run staging, DMA ring, slabs and
+// reduce as the kernel above; 4 tr-reads fewer per MFMA than two waves per SIMD (36 per 40 MFMAs against 28 per 20).
+// MEASURED SLOWER - an experiment (MG_TUNE_STAGGER = 8), correct (dW, db bit-identical to the kernel above, also for row maps
+// without runs), not the product path: 492 us against 262 at C2.  320 accumulator registers leave 192 of the 256 VGPRs (the
+// accumulator file holds 256) for everything else and hipcc spills 60 of them; and the probe with a 128 x 512 tile (TKT = 4: 256
+// accumulators, no spill, 4/5 of the matrix work; MG_TUNE_STAGGER = 9, results incomplete) still takes 304 us - a lone in-order wave
+// whose LDS counter is shared by the operand reads of P2, the reads and stores of P1 and the look-ahead stands at s_waitcnt lgkmcnt
+// between every group; without a hand-placed stream the partner wave of the 8-wave form hides more than the wider budget buys.
+// ---------------------------------------------------------------------------------------------------------------------
+// TKT = 4 is a TIMING PROBE (the tile then covers 512 of the 640 columns: results incomplete): what the form does without spills.
+template <int TKT>
+__global__ __launch_bounds__(256, 1) void wgrad_fused_solo_kernel(const uint16_t* __restrict__ dZ2, int lddz, const uint16_t* __restrict__ W2T,
+                                                                  int ldwt, const uint16_t* __restrict__ H1, int ldh,
+                                                                  const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
+                                                                  int64_t M, int N, int K, int m_chunk, int n_splits,
+                                                                  float* __restrict__ slab, float* __restrict__ bslab, int64_t sstride) {
+    constexpr int PY = 256, PX = F_BKT * 2;
+    constexpr int NX = 5;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[P_LDS];
+    int* run_row = reinterpret_cast<int*>(smem + P_RUNROW);
+    unsigned short* slot_lds = reinterpret_cast<unsigned short*>(smem + P_SLOT);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk0 = wave * (TKT * 32);
+    const int tiles_n = N / F_BNT;
+    const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3;
+    const int n0 = (jq % tiles_n) * F_BNT;
+    const int s = (jq / tiles_n) * 8 + xcd;
+    if (s >= n_splits) return;
+    const int64_t m_lo = (int64_t)s * m_chunk;
+    const int64_t m_hi = min(M, m_lo + (int64_t)m_chunk);
+    const int n_rows = m_hi > m_lo ? (int)(m_hi - m_lo) : 0;
+
+    // ---- one-time: runs of equal consecutive source rows over this workgroup's frames (thread t owns frames 16 t .. 16 t + 15) ----
+    int n_runs;
+    {
+        int r[17], flag[16], cnt = 0;
+#pragma unroll
+        for (int e = 0; e < 17; ++e) {                    // r[0] is the frame before this thread's first one
+            const int i = 16 * tid + e - 1;
+            const int64_t m = m_lo + min(max(i, 0), max(n_rows - 1, 0));
+            const int v = rows[min(m, M - 1)];
+            r[e] = (i >= 0 && i < n_rows) ? v : -1;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            flag[e] = (tid == 0 && e == 0) ? 1 : (r[e + 1] != r[e]);
+            cnt += flag[e];
+        }
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        int* wtot = reinterpret_cast<int*>(smem + P_X);   // the ring is not in use yet
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        int base = incl - cnt;
+        for (int w = 0; w < wave; ++w) base += wtot[w];
+        int total = 0;
+        for (int w = 0; w < 4; ++w) total += wtot[w];
+        n_runs = __builtin_amdgcn_readfirstlane(total);
+        int ord = base - 1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            ord += flag[e];
+            slot_lds[16 * tid + e] = (unsigned short)ord;
+            if (flag[e]) run_row[ord] = r[e + 1];
+        }
+        if (tid < 32) slot_lds[F_ROWS_MAX + tid] = 0;     // pad row: look-ahead reads past the last step
+    }
+    __syncthreads();
+
+    // ---- DMA slots (as the kernel above) ------------------------------------------------------------------------------------------
+    auto x_slot = [&](int i, int& xr, int& xo) {
+        const int byte = i * 1024 + lane * 16;
+        xr = byte / PX;
+        const int cpos = (byte - xr * PX) >> 4;
+        xo = (cpos ^ ((xr & 3) << 2)) * 16;
+    };
+    const unsigned long long zero_ptr = (unsigned long long)g_fused_zero_row;
+    const unsigned long long a_ptr = (unsigned long long)A;
+    const unsigned lda_bytes = (unsigned)lda * 2u;
+    auto pick = [&](unsigned long long p, int neg) -> const uint16_t* {      // neg < 0 selects the zero row
+        const unsigned long long mask = (unsigned long long)(long long)(neg >> 31);
+        return (const uint16_t*)((p & ~mask) | (zero_ptr & mask));
+    };
+    auto issue_group = [&](int g) {                       // called by one wave: runs 4 g .. 4 g + 3 into ring slot g % P_GROUPS
+        unsigned char* st = smem + P_X + (g % P_GROUPS) * 5120;
+        int rr[NX], xo[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            int xr;
+            x_slot(i, xr, xo[i]);
+            const int run = 4 * g + xr;
+            rr[i] = run_row[min(run, F_ROWS_MAX - 1)];
+            if (run >= n_runs) rr[i] = -1;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+            fglds16(pick(a_ptr + (unsigned long long)(unsigned)rr[i] * lda_bytes + (unsigned)xo[i], rr[i]), st + i * 1024);
+    };
+    int g_issued = 0;
+    auto issue_upto = [&](int g_last) {
+        for (int g = g_issued; g <= g_last; ++g)
+            if ((g & 3) == wave) issue_group(g);
+        if (g_last >= g_issued) g_issued = g_last + 1;
+    };
+    auto group_of = [&](int frame) -> int { return __builtin_amdgcn_readfirstlane((int)slot_lds[frame]) >> 2; };
+
+    // small tiles: dZ2 piece pp (k-tile pp >> 1, rows 16 (pp & 1) ..) and H1 piece pp (rows 4 pp .. 4 pp + 3), pp = wave and wave + 4
+    int dz_row[2], dz_col[2], h1_row[2], h1_col[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int pp = wave + 4 * u;
+        dz_row[u] = 16 * (pp & 1) + (lane >> 2);
+        dz_col[u] = 32 * (pp >> 1) + 8 * ((lane & 3) ^ (((dz_row[u] >> 3) & 1) << 1));
+        h1_row[u] = 4 * pp + (lane >> 4);
+        h1_col[u] = n0 + 8 * ((lane & 15) ^ (h1_row[u] & 15));
+    }
+    auto issue_small = [&](int step, int buf) {           // tiles of `step` into buffer buf (= step % 3): 4 pieces per wave
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int pp = wave + 4 * u;
+            const int mz = step * 32 + dz_row[u], mh = step * 32 + h1_row[u];
+            fglds16(pick((unsigned long long)(dZ2 + (size_t)(m_lo + mz) * lddz + dz_col[u]), n_rows - 1 - mz),
+                    smem + P_DZ + buf * 8192 + pp * 1024);
+            fglds16(pick((unsigned long long)(H1 + (size_t)(m_lo + mh) * ldh + h1_col[u]), n_rows - 1 - mh),
+                    smem + P_H1 + buf * 8192 + pp * 1024);
+        }
+    };
+
+    f32x16 acc[4][TKT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TKT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const bool bias_free = bslab != nullptr && wave == 3;               // K <= 608: the last 32-column tile of k-wave 3 is padding
+    const __bf16 one_bf = (__bf16)1.0f;
+    const bfv8 ones = bfv8{one_bf, one_bf, one_bf, one_bf, one_bf, one_bf, one_bf, one_bf};
+
+    const int n_steps = (n_rows + 31) / 32;
+    const int li = lane & 15, g4 = lane >> 4;
+    const int q = li >> 2, p4 = li & 3;
+    const int cgrp = 16 * (g4 & 1) + 4 * p4;
+    const int rbase = 8 * (g4 >> 1) + q;                  // this lane's frame inside a 16-frame k-step (and + 4)
+    const int sw = q << 2;
+    int yoff[4], xk[TKT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int col = i * 32 + cgrp;
+        yoff[i] = P_YS + rbase * PY + ((((col >> 3) ^ sw) << 4) | ((col & 7) << 1));
+    }
+#pragma unroll
+    for (int j = 0; j < TKT; ++j) {
+        const int col = wk0 + j * 32 + cgrp;
+        xk[j] = P_X + (((col >> 3) << 4) | ((col & 7) << 1));
+    }
+    // P1 geometry: wave w owns hidden units 32 w .. 32 w + 31 as two 16-unit blocks ub; 16x16x32 MFMA, A = W2T rows (unit l15, k chunk
+    // lq), B = dZ2 rows (frame l15 of half t, k chunk lq); D: this lane holds units 32 w + 16 ub + 4 lq .. + 3 of frame 16 t + l15.
+    const int l15 = lane & 15, lq = lane >> 4;
+    bfv8 w2[2][4];
+#pragma unroll
+    for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            w2[ub][ks] = *reinterpret_cast<const bfv8*>(W2T + (size_t)(n0 + 32 * wave + 16 * ub + l15) * ldwt + 32 * ks + 8 * lq);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // landed here, re-defined behind the wait (see the kernel above)
+#pragma unroll
+    for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(w2[ub][ks]));
+    const int b_off0 = P_DZ + l15 * 64 + ((lq ^ (((l15 >> 3) & 1) << 1)) << 4);       // + 1024 t + 2048 per k-tile
+    int h_off0[2], y_off0[2];
+#pragma unroll
+    for (int ub = 0; ub < 2; ++ub) {
+        const int c16 = 4 * wave + 2 * ub + (lq >> 1);                                // 16-byte chunk of the 256-byte row
+        h_off0[ub] = P_H1 + l15 * 256 + ((c16 ^ l15) << 4) + 8 * (lq & 1);             // + 4096 t
+        y_off0[ub] = P_YS + l15 * 256 + ((c16 ^ ((l15 & 3) << 2)) << 4) + 8 * (lq & 1);
+    }
+
+    // P1 of one 16-unit block in two pieces (operand reads + MFMAs; the VALU tail + LDS store), so that the step loop can place them
+    // between P2's MFMA groups; the dZ2 fragments are read per block (twice per step: 16 ds_read_b128) to keep few registers live
+    f32x4 pd[2];
+    auto p1_mfma = [&](int ub, int tb3) {
+        const int bo = tb3 * 8192;
+        bfv8 pb[2][2];                                     // k-tile ks + 1 is read while k-tile ks multiplies
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            pb[0][t] = *reinterpret_cast<const bfv8*>(smem + bo + b_off0 + t * 1024);
+            pd[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) pb[(ks + 1) & 1][t] = *reinterpret_cast<const bfv8*>(smem + bo + b_off0 + t * 1024 + (ks + 1) * 2048);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) pd[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[ub][ks], pb[ks & 1][t], pd[t], 0, 0, 0);
+        }
+    };
+    auto p1_finish = [&](int ub, int tb3, int yb2) {
+        const int bo = tb3 * 8192, yo = yb2 * 8192;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const bfv4 hv = *reinterpret_cast<const bfv4*>(smem + bo + h_off0[ub] + t * 4096);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float h = (float)hv[e];
+                v[e] = pd[t][e] * h * (1.f - h);
+            }
+            const u32x2 pk = u32x2{__builtin_bit_cast(unsigned int, bfv2{(__bf16)v[0], (__bf16)v[1]}),
+                                   __builtin_bit_cast(unsigned int, bfv2{(__bf16)v[2], (__bf16)v[3]})};
+            *reinterpret_cast<u32x2*>(smem + yo + y_off0[ub] + t * 4096) = pk;
+        }
+    };
+    auto read_slots = [&](int step, unsigned (&slp)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned lo = slot_lds[step * 32 + rbase + 16 * h], hi = slot_lds[step * 32 + rbase + 4 + 16 * h];
+            slp[h] = lo | (hi << 16);
+        }
+    };
+
+    // ---- prologue: ring rows of steps 0 and 1, tiles of steps 0, 1, 2, P1 of step 0 -----------------------------------------
+    unsigned sl_cur[2] = {0u, 0u};
+    int lg0 = 0, lg1 = 0, lg2 = 0, fg0 = 0;
+    if (n_steps > 0) {
+        lg0 = group_of(31);
+        lg1 = group_of(min(1, n_steps - 1) * 32 + 31);
+        lg2 = group_of(min(2, n_steps - 1) * 32 + 31);
+        issue_upto(lg0);
+        issue_small(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        p1_mfma(0, 0);
+        p1_finish(0, 0, 0);
+        p1_mfma(1, 0);
+        p1_finish(1, 0, 0);
+        issue_upto(min(lg1, fg0 + P_GROUPS - 1));
+        issue_small(1, 1);                                // past the end: zero rows (pick), never read
+        issue_small(2, 2);
+        read_slots(0, sl_cur);
+    }
+    int tb_next = 1;                                      // tile buffer of step + 1 (= (step + 1) % 3)
+    for (int step = 0; step < n_steps; ++step) {
+        // ring rows and tiles of step + 1 landed (the 4 pieces of step + 2's tiles may still fly), dZ1(step) and the look-ahead reads
+        // complete; the buffers of the last step are free
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (lg0 >= g_issued) {                            // only when a step and its successor span more than the ring holds
+            issue_upto(lg0);
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        const int ring_last = min(lg2, fg0 + P_GROUPS - 1);
+        const int tb_new = tb_next == 0 ? 2 : tb_next - 1;              // (step + 3) % 3 == step % 3
+        if (step + 1 < n_steps) issue_upto(ring_last);
+        issue_small(step + 3, tb_new);
+        const int la_last = (int)slot_lds[min(step + 3, n_steps - 1) * 32 + 31];
+        const int la_first = (int)slot_lds[min(step + 1, n_steps - 1) * 32];
+        unsigned sl_next[2];
+        read_slots(step + 1, sl_next);                    // step + 1 == n_steps reads the pad row
+        const bool more = step + 1 < n_steps;             // P1 of the next step (wave-uniform)
+
+        // ---- P2 of this step with P1 of the next one between its MFMA groups ---------------------------------------------------
+        int xbase[4], xswz[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int sl = (f & 1) ? (int)(sl_cur[f >> 1] >> 16) : (int)(sl_cur[f >> 1] & 0xffffu);
+            const int g = sl >> 2;
+            const int gm = g - P_GROUPS * ((g * 6554) >> 16);                 // g % 10 for g < 16384
+            xbase[f] = (gm * 4 + (sl & 3)) * PX;
+            xswz[f] = (sl & 3) << 6;
+        }
+        const int yb = (step & 1) * 8192, ynext = (step + 1) & 1;
+        auto rd_a = [&](int ks, int i) -> bfv8 {
+            const unsigned char* ad = smem + yb + yoff[i] + ks * 16 * PY;
+            const bfv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(ad));
+            const bfv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(ad + 4 * PY));
+            return bfv8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+        auto rd_b = [&](int ks, int j) -> bfv8 {
+            if (bias_free && j == TKT - 1) return ones;
+            const unsigned char* alo = smem + xbase[2 * ks] + (xk[j] ^ xswz[2 * ks]);
+            const unsigned char* ahi = smem + xbase[2 * ks + 1] + (xk[j] ^ xswz[2 * ks + 1]);
+            const bfv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(alo));
+            const bfv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(ahi));
+            return bfv8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+        bfv8 fa[4], fbq[2 * TKT];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = rd_a(0, i);
+        fbq[0] = rd_b(0, 0);
+        fbq[1] = rd_b(0, 1);
+#pragma unroll
+        for (int t = 0; t < 2 * TKT; ++t) {               // group t: k-step t / TKT, column block t % TKT, 4 MFMAs
+            const int j = t % TKT;
+            if (t + 2 < 2 * TKT) fbq[t + 2] = rd_b((t + 2) / TKT, (t + 2) % TKT);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = mg_mfma_32x32x16(fa[i], fbq[t], acc[i][j]);
+            if (t == TKT - 1) {                           // the dZ1 fragments of the second k-step take the registers of the first:
+#pragma unroll                                            // their LDS latency passes under P1's second block right behind
+                for (int i = 0; i < 4; ++i) fa[i] = rd_a(1, i);
+            }
+            if (more) {                                   // P1 of the next step, one 16-unit block at a time
+                if (t == 0) p1_mfma(0, tb_next);
+                if (t == 3) p1_finish(0, tb_next, ynext);
+                if (t == 4) p1_mfma(1, tb_next);
+                if (t == 7) p1_finish(1, tb_next, ynext);
+            }
+            __builtin_amdgcn_sched_barrier(0);            // groups stay in this order: hoisted operand reads cost registers that are not there
+        }
+        lg0 = lg1;
+        lg1 = lg2;
+        lg2 = __builtin_amdgcn_readfirstlane(la_last) >> 2;
+        fg0 = __builtin_amdgcn_readfirstlane(la_first) >> 2;
+        sl_cur[0] = sl_next[0];
+        sl_cur[1] = sl_next[1];
+        tb_next = tb_next == 2 ? 0 : tb_next + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tiles fetched past the end
+
+    const int lr = lane & 31, lh = lane >> 5;
+    float* out = slab + (size_t)s * sstride;        // split s: [N*K weights | N bias sums], sstride floats apart
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < TKT; ++j) {
+            const int col = wk0 + j * 32 + lr;
+            if (col >= K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < N) out[(size_t)row * K + col] = acc[i][j][r];
+            }
+        }
+    }
+    if (bias_free && lr == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < N) bslab[(size_t)s * sstride + row] = acc[i][TKT - 1][r];
+            }
+    }
+}
+
+
 static void fused_plan(int64_t M, int N, int* S, int* m_chunk) {
     const int tiles_n = N / F_BNT;
     int64_t s = mg_ceil_div(256, tiles_n);
@@ -837,7 +1200,13 @@ static int fused_launch(const char* name, const uint16_t* dZ2, int lddz, int N2,
     const int64_t nk = (int64_t)N * K, sstride = nk + N;
     float* slab = (float*)workspace;
     float* bslab = slab + nk;
-    if (rows && g_mg_tuning[MG_TUNE_STAGGER] != 7)
+    if (rows && g_mg_tuning[MG_TUNE_STAGGER] == 9)      // timing probe: the same with a 128 x 512 tile (no spills; results incomplete)
+        hipLaunchKernelGGL(wgrad_fused_solo_kernel<4>, dim3((unsigned)((N / F_BNT) * mg_align_up((size_t)S, 8))), dim3(256), 0, st, dZ2, lddz, W2T,
+                           ldwt, H1, ldh, A, lda, rows, M, N, K, chunk, S, slab, bslab, sstride);
+    else if (rows && g_mg_tuning[MG_TUNE_STAGGER] == 8)      // one wave per SIMD, P1 woven into P2 (see the kernel's comment)
+        hipLaunchKernelGGL(wgrad_fused_solo_kernel<5>, dim3((unsigned)((N / F_BNT) * mg_align_up((size_t)S, 8))), dim3(256), 0, st, dZ2, lddz, W2T,
+                           ldwt, H1, ldh, A, lda, rows, M, N, K, chunk, S, slab, bslab, sstride);
+    else if (rows && g_mg_tuning[MG_TUNE_STAGGER] != 7)
         hipLaunchKernelGGL(wgrad_fused_pipe_kernel, dim3((unsigned)((N / F_BNT) * mg_align_up((size_t)S, 8))), dim3(512), 0, st, dZ2, lddz, W2T,
                            ldwt, H1, ldh, A, lda, rows, M, N, K, chunk, S, slab, bslab, sstride);
     else

@@ -527,6 +527,32 @@ def test_l2tail_rows_kernel_vs_unfused_pair():
     assert got_loss.item() == loss.item() and loss.item() != loss_before.item()
 
 
+def test_fused_backward_solo_experiment_equals_product_kernel():
+    """The one-wave-per-SIMD form of the fused backward (an experiment kept under MG_TUNE_STAGGER = 8, measured slower) must stay
+    correct: dW, db EQUAL to the product kernel's, for phone-like runs and for a row map without runs."""
+    from morgana_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(5)
+    m, k0 = 40000, 600
+    table = ops.cast_pad_bf16(dev(rng.uniform(0, 1, (m // 9, k0)).astype(np.float32)))
+    (_,), (w2t,) = ops.cast_params_bf16([dev(rng.uniform(-0.1, 0.1, (128, 512)).astype(np.float32))], want_plain=True, want_t=(0,))
+    h1 = ops.cast_pad_bf16(dev(rng.uniform(0.05, 0.95, (m, 512)).astype(np.float32)))
+    dz2 = ops.cast_pad_bf16(dev((rng.standard_normal((m, 128)) * 0.01).astype(np.float32)))
+    for kind in ('runs', 'random'):
+        if kind == 'runs':
+            rows = np.repeat(rng.randint(-1, table.shape[0], size=m), rng.randint(1, 40, size=m))[:m]
+        else:
+            rows = rng.randint(-1, table.shape[0], size=m)
+        rows = dev(rows.astype(np.int32))
+        want = ops.linear_bwd_fused_bf16(dz2, w2t, h1, table, rows, m, 512, k0)
+        lib.mg_set_tuning(0, 8)
+        try:
+            got = ops.linear_bwd_fused_bf16(dz2, w2t, h1, table, rows, m, 512, k0)
+        finally:
+            lib.mg_set_tuning(0, 0)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), kind
+
+
 @pytest.mark.parametrize('rows_kind', ['random', 'runs', 'identity'])
 @pytest.mark.parametrize('m,n_hidden', [(4999, 512), (9000, 256)])
 def test_fused_backward_kernel_vs_numpy(m, n_hidden, rows_kind):
