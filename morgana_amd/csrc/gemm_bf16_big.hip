@@ -1171,6 +1171,9 @@ int mg_wgrad_big_plan(int64_t M, int N, int K, int lda, int lddy, int* S_out, in
     // M = 21 504, N = 512, K = 600: a third less partial-slab traffic); never more splits than the workspace was sized for
     if (M <= 32768 && tiles_n >= 4) S = 192 / tiles_n;
     if (M <= 32768 && tiles_n == 1) S = 96;                  // N = 128 at the same M: 24.2 vs 27.7 us (224 splits write 59 MB of slabs)
+    // N = 128 at frame-rate row counts (M = 256 000, K = 512): 192 splits of ~1 334 rows beat one split per CU - a quarter less slab
+    // traffic (50 vs 67 MB written and read again by the reduce): 89.5 -> 80 us with the reduce (sweep 144 .. 512, scripts/kbench.py wgrad2)
+    if (M > 32768 && tiles_n == 1) S = 192;
     if (g_mg_tuning[MG_TUNE_WGRAD_SPLITS] > 0) S = g_mg_tuning[MG_TUNE_WGRAD_SPLITS];
     int64_t m_chunk = mg_align_up((size_t)mg_ceil_div(M, S), 32);
     while (m_chunk > WG_ROWS_MAX) {  // row indices of a workgroup's range live in LDS
