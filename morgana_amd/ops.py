@@ -396,8 +396,9 @@ def linear_wgrad_bf16(dy, a, rows, m, n, k, want_bias=True, out_w=None, out_b=No
 def wgrad_slabs_ok(m, n, k, lda, lddy):
     """Shapes whose weight gradient runs on the wide-tile kernel and can leave its split-M slabs to the optimiser
     (mg_linear_wgrad_slabs_bf16; the plan of csrc/gemm_bf16_big.hip)."""
-    # m <= 32768: the plan then cuts 48-96 slabs; at frame-rate row counts it cuts 256, which a reduce launch of its own sums faster
-    # than the update kernel's one thread per element (101 us measured for 256 slabs of the 128 x 512 gradient)
+    # m <= 32768: the plan then cuts 48-96 slabs; at frame-rate row counts it cuts 192-256, which a reduce launch of its own sums as
+    # fast as the update kernel would (A/B after the update kernel's rework: 0.591 vs 0.592 ms per frame-rate step; before it 101 us
+    # for 256 slabs of the 128 x 512 gradient on one thread per element)
     return (4096 <= m <= 32768 and n % 128 == 0 and lddy >= n and lddy % 8 == 0 and
             ((lda == 640 and 512 < k <= 640) or (lda == 512 and 384 < k <= 512)))
 
