@@ -52,7 +52,7 @@ int main(void) {
             acc += mg_pad_rows_colsum_workspace_bytes(a, b, 187);
             acc += mg_linear_wgrad_workspace_bytes((int64_t)a * 1000, b, 600) + mg_linear_wgrad_workspace_bytes(a, 512, b);
             acc += mg_linear_bwd_fused_workspace_bytes((int64_t)a * 1000, b, 600);
-            acc += mg_f0_tail_workspace_bytes((int64_t)a * b);
+            acc += mg_f0_tail_workspace_bytes((int64_t)a * b) + mg_f0_l2tail_workspace_bytes((int64_t)a * b);
             acc += mg_gru_bwd_workspace_bytes(a, b) + mg_gru_persist_workspace_bytes(a, b);
             acc += mg_phone_target_stats_workspace_bytes(a, b);
             acc += (size_t)mg_gru_persist_supported(a, 1000, b) + (size_t)mg_gru_persist_f32_supported(a, 1000, b) +
@@ -90,6 +90,19 @@ int main(void) {
     expect_code("linear_bwd_fused(null)", mg_linear_bwd_fused_bf16(NULL, 0, 0, NULL, 0, NULL, 0, NULL, 0, NULL, 0, 0, 0, NULL, NULL, 0, NULL, 0, NULL));
     expect_code("cast_pad_bf16(ld)", mg_cast_pad_bf16(df, 600, dh, 100, 64, 600, NULL));
     expect_code("f0_tail(null)", mg_f0_tail_bf16(NULL, 0, 0, NULL, NULL, NULL, NULL, NULL, NULL, 0, 0, 1.f, NULL, NULL, NULL, NULL, 0, NULL, 0, NULL));
+    expect_code("f0_l2tail(null)", mg_f0_l2tail_bf16(NULL, 0, 0, NULL, 0, 0, NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0, 0, 1.f, NULL, NULL, NULL, 0, NULL,
+                                                     0, NULL, 0, NULL));
+    expect_code("f0_l2tail(shape)", mg_f0_l2tail_bf16(dh, 512, 256, dh, 512, 128, df, df, df, df, df, df, dl, 64, 1000, 1.f, df, df, dh, 128, df, 0, d,
+                                                      1 << 20, NULL));
+    expect_code("f0_l2tail(small ws)", mg_f0_l2tail_bf16(dh, 512, 512, dh, 512, 128, df, df, df, df, df, df, dl, 64, 1000, 1.f, df, df, dh, 128, df, 0, d,
+                                                         64, NULL));
+    { int ns = 0; expect_code("f0_l2tail_rows_slabs(null)", mg_f0_l2tail_rows_slabs_bf16(dh, 512, 512, dh, 512, 128, df, df, df, df, df, df, NULL, 21504,
+                                                                                         1.f, df, dh, 128, d, 1 << 20, &ns, NULL)); }
+    expect_code("expand_column_reduce(null)", mg_expand_column_reduce_f32(NULL, NULL, 0, NULL, NULL, 0, 0, NULL, 0, 0, 0, NULL, NULL));
+    { float v[4] = {0.f, 0.f, 0.f, 0.f}; expect_code("store_pairs(n)", mg_store_pairs_f32(df, v, 99, NULL)); }
+    { int ns = 0; long long st = 0; expect_code("linear_bwd_fused_slabs(null)", mg_linear_bwd_fused_slabs_bf16(NULL, 0, 0, NULL, 0, NULL, 0, NULL, 0, NULL, 0,
+                                                                                                         0, 0, NULL, 0, &ns, (int64_t*)&st, NULL)); }
+    expect_code("linear_fwd_bf16(runs hint, bad act)", mg_linear_fwd_bf16(dh, 640, di, 4096, 600, dh, 640, df, 512, dh, 512, 0, MG_ACT_ROWS_RUNS | 7, NULL));
     expect_code("gru_fwd_f32(null)", mg_gru_fwd_f32(NULL, NULL, NULL, NULL, 0, 0, 0, NULL, NULL, NULL, NULL));
     expect_code("gru_fwd_bf16(H)", mg_gru_fwd_bf16(df, dh, 96, df, dl, 4, 10, 96, df, dh, df, df, NULL));
     expect_code("gru_fwd_persist(shape)", mg_gru_fwd_persist_bf16(df, dh, 512, df, dl, 4096, 10, 512, df, dh, df, df, d, 1 << 20, NULL));
@@ -109,6 +122,9 @@ int main(void) {
         const size_t ws2 = mg_linear_wgrad_workspace_bytes(21504, 512, 600);
         expect_code("linear_wgrad_bf16(phone rate)", mg_linear_wgrad_bf16(dh, 512, dh, 640, NULL, 21504, 512, 600, df, df, 1, d, ws2, NULL));
     }
+    expect_code("linear_fwd_bf16(C2 L1, runs)", mg_linear_fwd_bf16(dh, 640, di, 256000, 600, dh, 640, df, 512, dh, 512, 0, 1 | MG_ACT_ROWS_RUNS, NULL));
+    expect_code("f0_l2tail(C2)", mg_f0_l2tail_bf16(dh, 512, 512, dh, 512, 128, df, df, df, df, df, df, dl, 256, 1000, 1.f, df, df, dh, 128, df, 0, d,
+                                                   mg_f0_l2tail_workspace_bytes(256000), NULL));
     expect_code("masked_mse(C5)", mg_masked_mse_f32(df, df, dl, 64, 2000, 187, 1.f, df, df, d, mg_masked_mse_workspace_bytes(64, 2000, 187), NULL));
     expect_code("gru_fwd_f32(C4)", mg_gru_fwd_f32(df, df, df, dl, 64, 3, 512, df, df, df, NULL));
 
