@@ -558,7 +558,7 @@ def main():
         if args.steps % want_k:
             raise SystemExit('--steps-per-replay must divide --steps')
         from morgana_amd import graphs
-        for k in (want_k, 1):
+        for k in ((want_k, 1) if want_k > 1 else (1,)):
             try:
                 step = graphs.GraphedTrainStep(model, optimizer, features, steps_per_replay=k)
                 per_call = k
@@ -566,12 +566,10 @@ def main():
                     ('%d steps per graph' % k if k > 1 else 'one graph per step')
                 graph_note = 'hip graph replay (%s)' % how
                 break
-            except ValueError:                        # the eager exchange needs one step per replay
-                continue
-            except Exception as exc:                  # capture refused: time the eager loop and say so
+            except Exception as exc:                  # the eager exchange needs one step per replay (ValueError); a multi-step capture
+                torch.cuda.synchronize()              # that is refused falls back to one step per graph, and that to the eager loop
                 graph_note = 'eager launches (graph capture failed: %s)' % str(exc).splitlines()[0][:200]
-                torch.cuda.synchronize()
-                break
+                continue
     for _ in range(-(-args.warmup // per_call)):
         loss = step()
     torch.cuda.synchronize()
