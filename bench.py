@@ -558,25 +558,23 @@ def main():
         if args.steps % want_k:
             raise SystemExit('--steps-per-replay must divide --steps')
         from morgana_amd import graphs
-        for k in ((want_k, 1) if want_k > 1 else (1,)):
-            try:
-                step = graphs.GraphedTrainStep(model, optimizer, features, steps_per_replay=k)
-                per_call = k
-                how = 'forward+backward graph, eager all-reduce, update kernel' if step.exchange_mode == 'eager' else \
-                    ('%d steps per graph' % k if k > 1 else 'one graph per step')
-                graph_note = 'hip graph replay (%s)' % how
-                break
-            except Exception as exc:                  # the eager exchange needs one step per replay (ValueError); a multi-step capture
-                torch.cuda.synchronize()              # that is refused falls back to one step per graph, and that to the eager loop
-                graph_note = 'eager launches (graph capture failed: %s)' % str(exc).splitlines()[0][:200]
-                continue
+        try:
+            # with an eager gradient exchange (more than one rank and no RCCL capture) the object falls back to one step per replay
+            step = graphs.GraphedTrainStep(model, optimizer, features, steps_per_replay=want_k)
+            per_call = step.steps_per_replay
+            how = 'forward+backward graph, eager all-reduce, update kernel' if step.exchange_mode == 'eager' else \
+                ('%d steps per graph' % per_call if per_call > 1 else 'one graph per step')
+            graph_note = 'hip graph replay (%s)' % how
+        except Exception as exc:                      # capture refused: time the eager loop and say so
+            graph_note = 'eager launches (graph capture failed: %s)' % str(exc).splitlines()[0][:200]
+            torch.cuda.synchronize()
     for _ in range(-(-args.warmup // per_call)):
         loss = step()
     torch.cuda.synchronize()
     distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps // per_call):          # per_call divides --steps: exactly --steps steps are timed
+    for _ in range(args.steps // per_call):          # per_call divides --steps (it is want_k or 1): exactly --steps steps are timed
         loss = step()
     torch.cuda.synchronize()
     distributed.barrier()

@@ -23,13 +23,39 @@ import torch
 from . import functional
 
 
+_CAPTURE_VERDICT = {}
+
+
 def rccl_capture_works(device, group=None):
+    """Cached per process group: the probe captures (and may fail to capture) a collective, which is not something to repeat."""
+    import torch.distributed as dist
+    key = (str(device), id(group), dist.get_backend(group), dist.get_world_size(group))
+    if key not in _CAPTURE_VERDICT:
+        _CAPTURE_VERDICT[key] = _rccl_capture_probe(device, group)
+    return _CAPTURE_VERDICT[key]
+
+
+def _leave_failed_capture(entry_stream):
+    """A capture that raised inside torch.cuda.graph's block can leave the capture stream current (its context manager's exit fails
+    before it restores the stream): every later launch of the thread then fails with hipErrorStreamCaptureInvalidated.  Putting the
+    entry stream back makes the thread usable again (measured on this stack with a collective that cannot be captured)."""
+    try:
+        torch.cuda.set_stream(entry_stream)
+        torch.cuda.synchronize()
+    except Exception:                                                   # noqa: BLE001 - best effort; the caller reports its own error
+        pass
+
+
+def _rccl_capture_probe(device, group=None):
     """Can this stack capture an RCCL all-reduce into a HIP graph and replay it correctly?  Captures one on a scratch buffer,
     replays it twice and checks the sums; every rank then takes the minimum of the verdicts (one eager all-reduce), so that all ranks
     choose the same exchange mode.  Any exception on the way counts as "no"."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
+    if dist.get_backend(group) != 'nccl':              # gloo moves device tensors through the host: never capturable, and trying leaves
+        return False                                   # the thread's capture invalidated
     ok = 1.0
+    entry_stream = torch.cuda.current_stream()
     try:
         buf = torch.empty(1024, dtype=torch.float32, device=device)
         dist.all_reduce(buf.fill_(1.0), group=group)                   # communicator set-up outside the capture
@@ -51,6 +77,7 @@ def rccl_capture_works(device, group=None):
                 ok = 0.0
     except Exception:                                                   # noqa: BLE001 - any failure means "use the eager exchange"
         ok = 0.0
+        _leave_failed_capture(entry_stream)
     verdict = torch.full((1,), ok, dtype=torch.float32, device=device)
     dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=group)
     return bool(verdict.item() > 0.5)
@@ -108,7 +135,21 @@ class GraphedTrainStep(object):
         # with a process group alive its watchdog thread polls events while we capture: judge only this thread's calls
         mode = dict(capture_error_mode='thread_local') if self._multi else {}
         if self.steps_per_replay > 1 and self.exchange_mode == 'eager':
-            raise ValueError('steps_per_replay > 1 needs the whole step inside the graph (one rank, or a captured exchange)')
+            # the collective sits between graph launches: one step per replay.  One batch for all steps: fall back quietly (the caller
+            # reads steps_per_replay); a list of batches cannot be honoured
+            if any(bt is not self.batches[0] for bt in self.batches):
+                raise ValueError('steps_per_replay > 1 needs the whole step inside the graph (one rank, or a captured exchange)')
+            self.steps_per_replay = 1
+            self.batches = self.batches[:1]
+        entry_stream = torch.cuda.current_stream()
+        try:
+            self._capture(mode)
+        except Exception:
+            _leave_failed_capture(entry_stream)        # so that the caller's eager fallback finds a usable stream
+            raise
+        self.steps_done = warmup
+
+    def _capture(self, mode):
         with torch.cuda.graph(self._fwd_bwd, **mode):
             for j in range(self.steps_per_replay):
                 self.optimizer.zero_grad()
@@ -121,7 +162,6 @@ class GraphedTrainStep(object):
                     functional.backward(self.loss)
                     if not self._multi:
                         self.optimizer.step_captured(slot=j)
-        self.steps_done = warmup
 
     def _capture_backward_and_exchange(self):
         """Backward with the early bucket's all-reduce forked onto a side stream the moment its gradients are final (the hook fires
