@@ -656,6 +656,7 @@ def main():
         }
         if graph_note is not None:
             result['config']['launch'] = graph_note
+            result['config']['steps_per_graph_launch'] = per_call      # every step does all of its work; the launch gap is shared
         if frame_rate is not None:
             result['frame_rate_order'] = frame_rate
         if args.config == 'c2':
