@@ -292,6 +292,14 @@ int mg_linear_wgrad_bf16(const uint16_t* dY, int lddy, const uint16_t* A, int ld
  * plan has this form: returns MG_EINVAL for shapes mg_linear_wgrad_bf16 would run on its 128 x 128 kernels (call that instead). */
 int mg_linear_wgrad_slabs_bf16(const uint16_t* dY, int lddy, const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K,
                                void* workspace, size_t workspace_bytes, int* n_slabs, int64_t* stride, void* stream);
+/* mg_linear_wgrad_slabs_bf16 (no gather) and mg_linear_dgrad_bf16 of ONE layer whose input A bf16 [M, lda] is the output of the Sigmoid
+ * below it (reference: the autograd backward of nn.Linear + nn.Sigmoid inside F0Model, README.rst (the nn.Sequential of Linear + Sigmoid layers)): the slabs of
+ * dW = dY^T A, db, and dX bf16 [M, lddx] = (dY W) * A (1 - A), WT = W^T bf16 [K, ldwt].  The two products are independent; for the
+ * phone-rate shape of the README model (N = 128, K = lda = lddx = 512, the tiles of both within one wave of workgroups) they run as
+ * ONE grid, with the split count cut to what the dgrad tiles leave free per XCD (*n_slabs says how many); other shapes run the two
+ * launches.  Needs a wide-tile weight-gradient shape (as mg_linear_wgrad_slabs_bf16: MG_EINVAL otherwise); workspace as there. */
+int mg_linear_wgrad_dgrad_bf16(const uint16_t* dY, int lddy, const uint16_t* A, int lda, int64_t M, int N, int K, const uint16_t* WT, int ldwt,
+                               uint16_t* dX, int lddx, void* workspace, size_t workspace_bytes, int* n_slabs, int64_t* stride, void* stream);
 /* Fused backward of Linear(K -> N) + Sigmoid feeding Linear(N -> N2): dW, db of the FIRST layer straight from dZ2, the
  * pre-activation gradient of the second one, without materialising dZ1 = (dZ2 W2) * H1 (1 - H1):
  *   dZ2 bf16 [M, lddz] (N2 = 128 columns); W2T = W2^T bf16 [N, ldwt]; H1 bf16 [M, ldh] (sigmoid outputs, N % 128 == 0);

@@ -382,6 +382,8 @@ int mg_try_nt_runs(const uint16_t* A, int lda, const int32_t* rows, int64_t M, i
 int mg_wgrad_big_plan(int64_t M, int N, int K, int lda, int lddy, int* S_out, int* m_chunk_out);
 int mg_launch_wgrad_big(const uint16_t* dY, int lddy, const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K,
                         int S, int m_chunk, float* slab, float* bslab, int64_t sstride, hipStream_t st);
+int mg_launch_wgrad_dgrad_pair(const uint16_t* dY, int lddy, const uint16_t* A, int lda, int64_t M, int N, int K, const uint16_t* WT, int ldwt,
+                               uint16_t* dX, int lddx, float* slab, int64_t sstride, size_t slab_floats, int* S_out, hipStream_t st);
 
 extern "C" {
 
@@ -556,6 +558,31 @@ int mg_linear_wgrad_slabs_bf16(const uint16_t* dY, int lddy, const uint16_t* A, 
     *n_slabs = big_s;
     *stride = sstride;
     return MG_OK;
+}
+
+// Weight gradient (slabs, as mg_linear_wgrad_slabs_bf16 without a gather) and dX = (dY W) * A (1 - A) of ONE Linear + the Sigmoid
+// below it, A being both the layer's input and that sigmoid's output: one grid for both where the shapes allow
+// (mg_launch_wgrad_dgrad_pair), otherwise the two launches.
+int mg_linear_wgrad_dgrad_bf16(const uint16_t* dY, int lddy, const uint16_t* A, int lda, int64_t M, int N, int K, const uint16_t* WT, int ldwt,
+                               uint16_t* dX, int lddx, void* workspace, size_t workspace_bytes, int* n_slabs, int64_t* stride, void* stream) {
+    MG_CHECK_ARG(dY && A && WT && dX && workspace && n_slabs && stride && M > 0 && N > 0 && K > 0,
+                 "mg_linear_wgrad_dgrad_bf16: bad arguments (M=%lld N=%d K=%d)", (long long)M, N, K);
+    MG_CHECK_ARG(lddy >= N && lda >= K && ldwt >= N && lddx >= K && lddy % 8 == 0 && lda % 8 == 0 && ldwt % 8 == 0 && lddx % 8 == 0,
+                 "mg_linear_wgrad_dgrad_bf16: leading dimensions must be multiples of 8 and cover N=%d / K=%d (lddy=%d lda=%d ldwt=%d lddx=%d)", N, K,
+                 lddy, lda, ldwt, lddx);
+    MG_CHECK_ARG(al16(dY) && al16(A) && al16(WT) && al16(dX) && al16(workspace), "mg_linear_wgrad_dgrad_bf16: buffers must be 16-byte aligned");
+    const int64_t nk = (int64_t)N * K, sstride = nk + N;
+    int S = 0;
+    if (mg_launch_wgrad_dgrad_pair(dY, lddy, A, lda, M, N, K, WT, ldwt, dX, lddx, (float*)workspace, sstride, workspace_bytes / sizeof(float), &S,
+                                   (hipStream_t)stream) > 0) {
+        MG_CHECK_LAUNCH("mg_linear_wgrad_dgrad_bf16/pair");
+        *n_slabs = S;
+        *stride = sstride;
+        return MG_OK;
+    }
+    const int rc = mg_linear_wgrad_slabs_bf16(dY, lddy, A, lda, nullptr, M, N, K, workspace, workspace_bytes, n_slabs, stride, stream);
+    if (rc != MG_OK) return rc;
+    return mg_linear_dgrad_bf16(dY, lddy, M, N, WT, ldwt, K, A, lda, dX, lddx, 0, stream);
 }
 
 }  // extern "C"

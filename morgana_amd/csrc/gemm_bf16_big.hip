@@ -60,12 +60,15 @@ __device__ __forceinline__ void glds16(const uint16_t* src, unsigned char* lds_w
 // ---------------------------------------------------------------------------------------------------------------------
 MG_STAMP_DECL(g_stamps_nt);
 
+// The tile program is a device function on a caller-provided LDS block and block id, so that two independent launches can share one
+// grid (wgrad_dgrad_pair_kernel below); gemm_nt_big_kernel is the plain launch of it.
+#define NT_BIG_LDS(BN_) (((BN_) == 256 ? 4 : 6) * (256 * 64 + (BN_) * 64))
 template <int BN, int EPI>
-__global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
-                                                          int64_t M, int K, const uint16_t* __restrict__ Bm, int ldb, int N,
-                                                          const float* __restrict__ bias, const uint16_t* __restrict__ H, int ldh,
-                                                          const int32_t* __restrict__ h_rows, void* __restrict__ Cv, int ldc, int tiles_m,
-                                                          int tiles_n, int c_f32) {
+__device__ __forceinline__ void gemm_nt_big_body(unsigned char* __restrict__ smem, const unsigned block_id, const uint16_t* __restrict__ A,
+                                                 int lda, const int32_t* __restrict__ rows, int64_t M, int K, const uint16_t* __restrict__ Bm,
+                                                 int ldb, int N, const float* __restrict__ bias, const uint16_t* __restrict__ H, int ldh,
+                                                 const int32_t* __restrict__ h_rows, void* __restrict__ Cv, int ldc, int tiles_m, int tiles_n,
+                                                 int c_f32) {
     constexpr int BM = 256;
     constexpr int WAVES_N = BN / 64;              // 4 or 2
     constexpr int WAVES_M = 8 / WAVES_N;          // 2 or 4
@@ -80,11 +83,11 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __rest
     // from HBM - five tiles in flight per CU cover the HBM latency at ~6 TB/s, three do not (87 -> see DESIGN.md).
     constexpr int NS = (BN == 256) ? 4 : 6;
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
+    static_assert(NS * STAGE == NT_BIG_LDS(BN), "LDS size helper");
 
     // XCD-aware tile order: blocks b and b + 8 share an XCD (its L2); give them the N tiles of ONE M tile so the A rows
     // and the H tile are fetched into that L2 once.
-    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int xcd = block_id & 7, jj = block_id >> 3;
     const int tile_n = jj % tiles_n;
     const int tile_m = (jj / tiles_n) * 8 + xcd;
     if (tile_m >= tiles_m) return;
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __rest
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MG_STAMP(ts3);
     MG_STAMP_REAL(tr1);
-    const int sb = blockIdx.x;
+    const int sb = block_id;
     MG_STAMP_STORE(g_stamps_nt, sb, wave, lane, 0, ts0);
     MG_STAMP_STORE(g_stamps_nt, sb, wave, lane, 1, ts1);
     MG_STAMP_STORE(g_stamps_nt, sb, wave, lane, 2, ts2);
@@ -338,6 +341,16 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __rest
     MG_STAMP_STORE(g_stamps_nt, sb, wave, lane, 6, sum_wait);
     MG_STAMP_STORE(g_stamps_nt, sb, wave, lane, 7, sum_issue);
 #endif
+}
+
+template <int BN, int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
+                                                          int64_t M, int K, const uint16_t* __restrict__ Bm, int ldb, int N,
+                                                          const float* __restrict__ bias, const uint16_t* __restrict__ H, int ldh,
+                                                          const int32_t* __restrict__ h_rows, void* __restrict__ Cv, int ldc, int tiles_m,
+                                                          int tiles_n, int c_f32) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NT_BIG_LDS(BN)];
+    gemm_nt_big_body<BN, EPI>(smem, blockIdx.x, A, lda, rows, M, K, Bm, ldb, N, bias, H, ldh, h_rows, Cv, ldc, tiles_m, tiles_n, c_f32);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -869,10 +882,12 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
 #define WG_STAGES 3
 MG_STAMP_DECL(g_stamps_wg);
 
+#define WG_BIG_LDS(TKW_) (WG_STAGES * (32 * 256 + 32 * 64 * (TKW_) * 2) + WG_ROWS_MAX * 4)
 template <int TKW>
-__global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restrict__ dY, int lddy, const uint16_t* __restrict__ A, int lda,
-                                                        const int32_t* __restrict__ rows, int64_t M, int N, int K, int m_chunk,
-                                                        float* __restrict__ slab, float* __restrict__ bslab, int64_t sstride, int xcd_group) {
+__device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem, const unsigned block_id, const uint16_t* __restrict__ dY,
+                                               int lddy, const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows, int64_t M,
+                                               int N, int K, int m_chunk, float* __restrict__ slab, float* __restrict__ bslab, int64_t sstride,
+                                               int xcd_group) {
     constexpr int BNT = 128, BKT = 64 * TKW;
     constexpr int TKT = BKT / 4 / 32;             // 32-column MFMA tiles per wave along k (4 waves along k): 5 or 4
     constexpr int PY = BNT * 2, PX = BKT * 2;     // LDS row pitches in bytes: 256, 1280 / 1024
@@ -882,7 +897,7 @@ __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restri
     constexpr int NLW = 1 + NX;                   // + one for dY
     constexpr int LDS_BYTES = WG_STAGES * STAGE + WG_ROWS_MAX * 4;
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    static_assert(LDS_BYTES == WG_BIG_LDS(TKW), "LDS size helper");
     int* row_lds = reinterpret_cast<int*>(smem + WG_STAGES * STAGE);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -902,11 +917,11 @@ __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restri
     const int tiles_n = N / BNT;
     int n0, s;
     if (xcd_group) {
-        n0 = ((blockIdx.x >> 3) % tiles_n) * BNT;
-        s = (blockIdx.x / (8 * tiles_n)) * 8 + (blockIdx.x & 7);
+        n0 = ((block_id >> 3) % tiles_n) * BNT;
+        s = (block_id / (8 * tiles_n)) * 8 + (block_id & 7);
     } else {
-        n0 = (blockIdx.x % tiles_n) * BNT;
-        s = blockIdx.x / tiles_n;
+        n0 = (block_id % tiles_n) * BNT;
+        s = block_id / tiles_n;
     }
     const int64_t m_lo = (int64_t)s * m_chunk;
     const int64_t m_hi = min(M, m_lo + (int64_t)m_chunk);
@@ -1082,7 +1097,7 @@ __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restri
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MG_STAMP(ts3);
     MG_STAMP_REAL(tr1);
-    const int sb = blockIdx.x;
+    const int sb = block_id;
     MG_STAMP_STORE(g_stamps_wg, sb, wave, lane, 0, ts0);
     MG_STAMP_STORE(g_stamps_wg, sb, wave, lane, 1, ts1);
     MG_STAMP_STORE(g_stamps_wg, sb, wave, lane, 2, ts2);
@@ -1093,6 +1108,36 @@ __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restri
     MG_STAMP_STORE(g_stamps_wg, sb, wave, lane, 7, sum_issue);
 #endif
 }
+
+template <int TKW>
+__global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restrict__ dY, int lddy, const uint16_t* __restrict__ A, int lda,
+                                                        const int32_t* __restrict__ rows, int64_t M, int N, int K, int m_chunk,
+                                                        float* __restrict__ slab, float* __restrict__ bslab, int64_t sstride, int xcd_group) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WG_BIG_LDS(TKW)];
+    wgrad_big_body<TKW>(smem, blockIdx.x, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
+}
+
+// Two INDEPENDENT launches of a backward pass in one grid: the weight gradient of a layer (blocks [0, wg_blocks): dW = dY^T A as split-M
+// slabs) and the dgrad + sigmoid backward towards the layer below (the blocks behind them: dX = (dY W) * H (1 - H)).  Both read dY; at
+// the phone-rate row count of C2 the first fills 96 CUs for 18 us and the second 168 for 16 us, one after the other; as parallel
+// branches of the step's HIP graph they were SLOWER (fork and join nodes), as one grid they simply share the chip.  wg_blocks must be a
+// multiple of 8 (both tile programs derive the XCD of a block from its id modulo 8).
+template <int TKW, int BN>
+__global__ __launch_bounds__(512) void wgrad_dgrad_pair_kernel(unsigned wg_blocks, const uint16_t* __restrict__ dY, int lddy,
+                                                               const uint16_t* __restrict__ A, int lda, int64_t M, int N, int K, int m_chunk,
+                                                               float* __restrict__ slab, float* __restrict__ bslab, int64_t sstride,
+                                                               int xcd_group, const uint16_t* __restrict__ WT, int ldwt,
+                                                               const uint16_t* __restrict__ H, int ldh, void* __restrict__ dX, int lddx,
+                                                               int tiles_m, int tiles_n) {
+    constexpr int LDS = WG_BIG_LDS(TKW) > NT_BIG_LDS(BN) ? WG_BIG_LDS(TKW) : NT_BIG_LDS(BN);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS];
+    if (blockIdx.x < wg_blocks)
+        wgrad_big_body<TKW>(smem, blockIdx.x, dY, lddy, A, lda, nullptr, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
+    else        // C[M, K] = dY[M, N] WT[K, N]^T with the sigmoid-grad epilogue: contraction N, output width K (as mg_linear_dgrad_bf16)
+        gemm_nt_big_body<BN, EPI_SIGMOID_GRAD>(smem, blockIdx.x - wg_blocks, dY, lddy, nullptr, M, N, WT, ldwt, K, nullptr, H, ldh, nullptr, dX,
+                                               lddx, tiles_m, tiles_n, 0);
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Launch helpers used by the entry points in gemm_bf16.hip.  Each returns 1 if it launched, 0 if the shape does not
@@ -1199,6 +1244,37 @@ int mg_launch_wgrad_big(const uint16_t* dY, int lddy, const uint16_t* A, int lda
         hipLaunchKernelGGL((wgrad_big_kernel<10>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
     else
         hipLaunchKernelGGL((wgrad_big_kernel<8>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
+    return 1;
+}
+
+// The layer's weight gradient (slabs) and the dgrad + sigmoid backward towards the layer below in ONE grid (wgrad_dgrad_pair_kernel).
+// Qualifies when both are wide-tile shapes with a 128-wide dY (one n tile per split), A = H is the [M, 512] activation table, and
+// the blocks of both fit the chip at once: blocks are handed to the XCDs round robin and every workgroup here owns a CU, so an XCD
+// (32 CUs) takes ceil(tiles_m / 8) * tiles_n dgrad tiles plus S / 8 splits - S shrinks from the plan's to what is left (fewer, longer
+// splits; a 33rd workgroup on an XCD would wait for a whole tile program to finish).  Returns 1 and the split plan, or 0.
+int mg_launch_wgrad_dgrad_pair(const uint16_t* dY, int lddy, const uint16_t* A, int lda, int64_t M, int N, int K, const uint16_t* WT, int ldwt,
+                               uint16_t* dX, int lddx, float* slab, int64_t sstride, size_t slab_floats, int* S_out, hipStream_t st) {
+    if (g_mg_tuning[MG_TUNE_PROBE] == 65) return 0;                   // A/B: the two launches
+    int S = 0, m_chunk = 0;
+    if (N != 128 || K != 512 || lda != 512 || lddx != K || mg_wgrad_big_plan(M, N, K, lda, lddy, &S, &m_chunk) <= 0) return 0;
+    if (lddy % 64 != 0 || ldwt % 64 != 0 || lddy > MG_ZERO_ELEMS - 64 || ldwt > MG_ZERO_ELEMS - 64 || lddy < 128 || ldwt < 128) return 0;
+    if (!big16(dY) || !big16(A) || !big16(WT) || !big16(dX)) return 0;
+    const int tiles_n = K / 256;
+    const int64_t tiles_m = mg_ceil_div(M, 256);
+    const int64_t nt_per_xcd = mg_ceil_div(tiles_m, 8) * tiles_n;
+    const int64_t cap = 8 * (32 - nt_per_xcd);
+    if (cap < 48) return 0;
+    if (S > cap) {
+        m_chunk = (int)mg_align_up((size_t)mg_ceil_div(M, cap), 32);
+        if (m_chunk > WG_ROWS_MAX) return 0;
+        S = (int)mg_align_up((size_t)mg_ceil_div(M, m_chunk), 8);
+        if (S > cap) return 0;
+    }
+    if ((size_t)S * (size_t)sstride > slab_floats) return 0;
+    const unsigned nt_blocks = (unsigned)(mg_ceil_div(tiles_m, 8) * 8 * tiles_n);
+    hipLaunchKernelGGL((wgrad_dgrad_pair_kernel<8, 256>), dim3((unsigned)S + nt_blocks), dim3(512), 0, st, (unsigned)S, dY, lddy, A, lda, M, N, K,
+                       m_chunk, slab, slab + (int64_t)N * K, sstride, 1, WT, ldwt, A, lda, (void*)dX, lddx, (int)tiles_m, tiles_n);
+    *S_out = S;
     return 1;
 }
 

@@ -458,8 +458,19 @@ class LinearStackMSEFn(torch.autograd.Function):
             r0 = None if ctx.phone_rate else rows
             top = lead - 1                                            # the 128-wide layer: its dZ came out of the fused tail
             n, k = ctx.dims[top]
-            _wgrad_into(mode, opt, params[2 * top], params[2 * top + 1], g, hidden[top - 1] if top > 0 else a0, None if top > 0 else r0,
-                        m_rows, n, k)
+            g_below = None
+            if (mode == 'defer' and ctx.phone_rate and top > 0 and ctx.acts[top - 1] == ops.ACT_SIGMOID and
+                    ops.wgrad_slabs_ok(m_rows, n, k, hidden[top - 1].shape[1], g.shape[1])):
+                # this layer's weight gradient and the dgrad + sigmoid backward below it are independent and each fills part of the
+                # chip: one grid for both (mg_linear_wgrad_dgrad_bf16)
+                w_param = params[2 * top]
+                slab, n_slabs, stride, g_below = ops.linear_wgrad_dgrad_bf16(g, hidden[top - 1], m_rows, n, k, w_t[top],
+                                                                             slab=getattr(w_param, '_mg_slab_buf', None))
+                w_param._mg_slab_buf = slab
+                opt.defer_slabs(w_param, n * k + n, slab, n_slabs, stride)
+            else:
+                _wgrad_into(mode, opt, params[2 * top], params[2 * top + 1], g, hidden[top - 1] if top > 0 else a0,
+                            None if top > 0 else r0, m_rows, n, k)
             if mode == 'defer':
                 opt.defer_slabs(params[2 * lead], tail_count, flat[tail_off:tail_off + tail_count], 1, tail_count)
             else:
@@ -480,8 +491,11 @@ class LinearStackMSEFn(torch.autograd.Function):
                         ops.linear_bwd_fused_bf16(g, w_t[1], hidden[0], a0, rows, m, n0_, k0_, out_w=params[0].grad, out_b=params[1].grad,
                                                   accumulate=True)
                     break
-                h = hidden[i - 1] if ctx.acts[i - 1] == ops.ACT_SIGMOID else None
-                g = ops.linear_dgrad_bf16(g, m_rows, n, w_t[i], k, h)
+                if i == top and g_below is not None:
+                    g = g_below
+                else:
+                    h = hidden[i - 1] if ctx.acts[i - 1] == ops.ACT_SIGMOID else None
+                    g = ops.linear_dgrad_bf16(g, m_rows, n, w_t[i], k, h)
                 n_, k_ = ctx.dims[i - 1]
                 _wgrad_into(mode, opt, params[2 * (i - 1)], params[2 * (i - 1) + 1], g, hidden[i - 2] if i > 1 else a0,
                             None if i > 1 else r0, m_rows, n_, k_)

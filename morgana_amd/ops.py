@@ -416,6 +416,23 @@ def linear_wgrad_slabs_bf16(dy, a, rows, m, n, k, slab=None):
     return slab, n_slabs.value, stride.value
 
 
+def linear_wgrad_dgrad_bf16(dy, a, m, n, k, wt_bf16, slab=None):
+    """linear_wgrad_slabs_bf16(dy, a) and linear_dgrad_bf16(dy, wt_bf16, h=a) of a Linear(k -> n) whose input ``a`` (m, lda) is the
+    output of the Sigmoid below it - one grid for both where the shapes allow (mg_linear_wgrad_dgrad_bf16), the two launches otherwise.
+    Returns (slab buffer, n_slabs, stride, dx (m, pad8(k)) bf16).  Needs wgrad_slabs_ok(m, n, k, lda, lddy)."""
+    lib = _lib.load()
+    nbytes = lib.mg_linear_wgrad_workspace_bytes(m, n, k)
+    if slab is None or slab.numel() < nbytes:
+        slab = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
+    lddx = pad8(k)
+    dx = torch.empty((m, lddx), dtype=torch.bfloat16, device=dy.device)
+    n_slabs, stride = ctypes.c_int(0), ctypes.c_int64(0)
+    _lib.check(lib.mg_linear_wgrad_dgrad_bf16(_p(dy), dy.shape[1], _p(a), a.shape[1], m, n, k, _p(wt_bf16), wt_bf16.shape[1], _p(dx), lddx,
+                                              _p(slab), slab.numel(), ctypes.byref(n_slabs), ctypes.byref(stride), _stream()),
+               'mg_linear_wgrad_dgrad_bf16')
+    return slab, n_slabs.value, stride.value, dx
+
+
 def can_fuse_bwd(m, n2, n_hidden, k0, lda0):
     """Shapes mg_linear_bwd_fused_bf16 handles (the README F0Model's first two layers at training batch sizes)."""
     return n2 == 128 and n_hidden % 128 == 0 and 512 < k0 <= 608 and lda0 == 640 and m >= 4096

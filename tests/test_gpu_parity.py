@@ -527,6 +527,45 @@ def test_l2tail_rows_kernel_vs_unfused_pair():
     assert got_loss.item() == loss.item() and loss.item() != loss_before.item()
 
 
+@pytest.mark.parametrize('m', [21504, 21377, 8192, 30001, 4100])
+def test_wgrad_dgrad_pair_equals_the_two_launches(m):
+    """mg_linear_wgrad_dgrad_bf16 (one grid for a layer's weight-gradient slabs and the dgrad + sigmoid backward below it) against the
+    two launches it stands for: dX EQUAL, and the slabs EQUAL to mg_linear_wgrad_slabs_bf16 cut into the same number of splits (the
+    pair cuts fewer than the plan when the dgrad tiles leave less of an XCD free; a different split count is a different fp32
+    summation order).  m = 21 504 is C2's phone-rate row count; 30 001 leaves too little room (the entry then runs the two launches)."""
+    from morgana_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(m)
+    n, k = 128, 512
+    (_,), (wt,) = ops.cast_params_bf16([dev(rng.uniform(-0.1, 0.1, (n, k)).astype(np.float32))], want_plain=True, want_t=(0,))
+    h = ops.cast_pad_bf16(dev(rng.uniform(0.05, 0.95, (m, k)).astype(np.float32)))
+    dy = ops.cast_pad_bf16(dev((rng.standard_normal((m, n)) * 0.01).astype(np.float32)))
+    slab, n_slabs, stride, dx = ops.linear_wgrad_dgrad_bf16(dy, h, m, n, k, wt)
+    got = slab.view(torch.float32)[:n_slabs * stride].clone()
+    want_dx = ops.linear_dgrad_bf16(dy, m, n, wt, k, h)
+    assert torch.equal(dx, want_dx)
+    lib.mg_set_tuning(4, n_slabs)
+    try:
+        slab2, n2, stride2 = ops.linear_wgrad_slabs_bf16(dy, h, None, m, n, k)
+    finally:
+        lib.mg_set_tuning(4, 0)
+    assert (n2, stride2) == (n_slabs, stride)
+    assert torch.equal(got, slab2.view(torch.float32)[:n2 * stride2])
+    # and the sum of the slabs is the weight gradient
+    dw, db = ops.linear_wgrad_bf16(dy, h, None, m, n, k)
+    tot = got.view(n_slabs, stride).double().sum(0)
+    np.testing.assert_allclose(tot[:n * k].cpu().numpy(), dw.double().reshape(-1).cpu().numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(tot[n * k:].cpu().numpy(), db.double().cpu().numpy(), rtol=1e-4, atol=1e-6)
+    lib.mg_set_tuning(7, 65)                                   # the entry's two-launch form
+    try:
+        slab3, n3, stride3, dx3 = ops.linear_wgrad_dgrad_bf16(dy, h, m, n, k, wt)
+    finally:
+        lib.mg_set_tuning(7, 0)
+    assert torch.equal(dx3, want_dx)
+    tot3 = slab3.view(torch.float32)[:n3 * stride3].view(n3, stride3).double().sum(0)
+    np.testing.assert_allclose(tot3.cpu().numpy(), tot.cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
 def test_fused_backward_solo_experiment_equals_product_kernel():
     """The one-wave-per-SIMD form of the fused backward (an experiment kept under MG_TUNE_STAGGER = 8, measured slower) must stay
     correct: dW, db EQUAL to the product kernel's, for phone-like runs and for a row map without runs."""
