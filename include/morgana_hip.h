@@ -266,6 +266,24 @@ int mg_phone_loss_const_add(const void* workspace, int R, int extra, float* loss
 int mg_phone_target_stats(const float* target, const int32_t* rows, int64_t M, const int32_t* seg_start, const int32_t* seg_end,
                           const int64_t* seq_len, int B, int T, int R, int extra, float* ybar, float* weight, float* loss_const,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* The front of the phone-rate step in ONE launch: mg_upsample_index_maps (upsample_to_repetitions' frame map, morgana/utils.py:175-228)
+ * and mg_phone_target_stats (morgana/losses.py:29-51 per phone row) - a phone's statistics read only the frame run its own utterance's
+ * duration scan gives, so one workgroup per utterance does both (csrc/phone_front.h).  dur int64 [B, P]; target f32 [B*T] (T = the
+ * frame axis the map is cut to); R = B*P phone rows + `extra` rows for the padding frames.  rows32 / rows_mapped int32 [B*T],
+ * seg_start / seg_end int32 [R], ybar / weight f32 [R + extra]: bit for bit what the two launches write.  workspace
+ * (mg_phone_target_stats_workspace_bytes(R, extra)): partial sums of the loss's constant term for mg_phone_loss_const_add and the
+ * mg_expand_column_* launches, grouped per utterance (so the constant may differ from the two-launch one in its last bits).
+ * MG_EINVAL where the form does not apply (fewer than ~16 phones per utterance; extra rows that each span many utterances). */
+int mg_phone_front(const int64_t* dur, int B, int P, int T, const float* target, const int64_t* seq_len, int extra, int32_t* rows32,
+                   int32_t* rows_mapped, int pad_row, int32_t* seg_start, int32_t* seg_end, float* ybar, float* weight, void* workspace,
+                   size_t workspace_bytes, void* stream);
+/* mg_phone_front and mg_linear_fwd_bf16(A, rows = NULL, ... bf16 output) of the phone table's first layer (README.rst:66-67), which
+ * reads nothing the front writes: ONE grid where the GEMM is the persistent 256-wide form and leaves at least 32 CUs without a tile
+ * (C2: 168 tiles) - the front's jobs run on those CUs - otherwise the two launches.  Same results either way. */
+int mg_phone_front_linear_fwd_bf16(const int64_t* dur, int B, int P, int T, const float* target, const int64_t* seq_len, int extra,
+                                   int32_t* rows32, int32_t* rows_mapped, int pad_row, int32_t* seg_start, int32_t* seg_end, float* ybar,
+                                   float* weight, void* workspace, size_t workspace_bytes, const uint16_t* A, int lda, int64_t M, int K,
+                                   const uint16_t* W, int ldw, const float* bias, int N, uint16_t* Y, int ldy, int act, void* stream);
 int mg_segment_bounds(const int32_t* rows, int64_t M, int R, int32_t* seg_start, int32_t* seg_end, int32_t* rows_mapped,
                       int pad_row, void* stream);
 int mg_segment_sum(const void* G, int ldg, int g_bf16, const int32_t* rows, int64_t M, const int32_t* seg_start,

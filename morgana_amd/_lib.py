@@ -128,6 +128,11 @@ SIGNATURES = {
     'mg_phone_target_stats': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'mg_upsample_index_maps': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'mg_phone_front': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'mg_phone_front_linear_fwd_bf16': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int64, c_int, c_void_p,
+                                               c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     'mg_segment_bounds': (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'mg_linear_dgrad_gathered_bf16': (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                               c_int, c_int, c_void_p]),

@@ -80,6 +80,21 @@ __device__ __forceinline__ f32x16 mg_mfma_32x32x16(mg_bfv8 a, mg_bfv8 b, f32x16 
 }
 #endif
 
+// Sum over each row of 16 lanes, in every lane of the row, on the DPP path (row_ror 8, 4, 2, 1: four VALU instructions, where four
+// __shfl_xor go through the LDS crossbar one after the other).  Bit for bit the xor butterfly 8, 4, 2, 1: at every level a lane's
+// partner belongs to the same class of lanes either way, and a + b == b + a.
+template <int CTRL>
+__device__ __forceinline__ float mg_dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float mg_row16_sum(float v) {
+    v += mg_dpp_f32<0x128>(v);
+    v += mg_dpp_f32<0x124>(v);
+    v += mg_dpp_f32<0x122>(v);
+    v += mg_dpp_f32<0x121>(v);
+    return v;
+}
+
 __device__ __forceinline__ float mg_wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

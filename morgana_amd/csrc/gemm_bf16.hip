@@ -16,6 +16,7 @@
 // The layer-1 gather (upsample_to_repetitions) is fused into the A-tile loaders through the `rows` array.
 // Epilogues stage the fp32 accumulators through LDS so that every global store is a 16-byte lane (8 bf16).
 #include "common.h"
+#include "phone_front.h"
 #include "slab_reduce.h"
 
 typedef __bf16 bfv8 __attribute__((ext_vector_type(8)));
@@ -382,6 +383,11 @@ int mg_try_nt_runs(const uint16_t* A, int lda, const int32_t* rows, int64_t M, i
 int mg_wgrad_big_plan(int64_t M, int N, int K, int lda, int lddy, int* S_out, int* m_chunk_out);
 int mg_launch_wgrad_big(const uint16_t* dY, int lddy, const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K,
                         int S, int m_chunk, float* slab, float* bslab, int64_t sstride, hipStream_t st);
+int mg_launch_phone_front_gemm(const PhoneFrontArgs& pf, const uint16_t* A, int lda, int64_t M, int K, const uint16_t* Bm, int ldb, int N,
+                               const float* bias, uint16_t* C, int ldc, int epi, hipStream_t st);
+extern "C" int mg_phone_front_check(const int64_t* dur, int B, int P, int T, const float* target, int extra, const int32_t* rows32,
+                                    const int32_t* rows_mapped, const int32_t* seg_start, const int32_t* seg_end, const float* ybar,
+                                    const float* weight, const void* workspace, size_t workspace_bytes, const char* who);
 int mg_launch_wgrad_dgrad_pair(const uint16_t* dY, int lddy, const uint16_t* A, int lda, int64_t M, int N, int K, const uint16_t* WT, int ldwt,
                                uint16_t* dX, int lddx, float* slab, int64_t sstride, size_t slab_floats, int* S_out, hipStream_t st);
 
@@ -583,6 +589,30 @@ int mg_linear_wgrad_dgrad_bf16(const uint16_t* dY, int lddy, const uint16_t* A, 
     const int rc = mg_linear_wgrad_slabs_bf16(dY, lddy, A, lda, nullptr, M, N, K, workspace, workspace_bytes, n_slabs, stride, stream);
     if (rc != MG_OK) return rc;
     return mg_linear_dgrad_bf16(dY, lddy, M, N, WT, ldwt, K, A, lda, dX, lddx, 0, stream);
+}
+
+// mg_phone_front (frame map + per-phone loss statistics) and mg_linear_fwd_bf16 of the phone table's first layer - two launches that
+// read nothing of each other - as ONE grid where the GEMM leaves CUs idle (mg_launch_phone_front_gemm), otherwise one after the other.
+int mg_phone_front_linear_fwd_bf16(const int64_t* dur, int B, int P, int T, const float* target, const int64_t* seq_len, int extra,
+                                   int32_t* rows32, int32_t* rows_mapped, int pad_row, int32_t* seg_start, int32_t* seg_end, float* ybar,
+                                   float* weight, void* workspace, size_t workspace_bytes, const uint16_t* A, int lda, int64_t M, int K,
+                                   const uint16_t* W, int ldw, const float* bias, int N, uint16_t* Y, int ldy, int act, void* stream) {
+    int rc = mg_phone_front_check(dur, B, P, T, target, extra, rows32, rows_mapped, seg_start, seg_end, ybar, weight, workspace, workspace_bytes,
+                                  "mg_phone_front_linear_fwd_bf16");
+    if (rc != MG_OK) return rc;
+    MG_CHECK_ARG(A && W && Y && M > 0 && N > 0 && K > 0 && (act == MG_ACT_NONE || act == MG_ACT_SIGMOID),
+                 "mg_phone_front_linear_fwd_bf16: bad GEMM arguments (M=%lld N=%d K=%d act=%d)", (long long)M, N, K, act);
+    PhoneFrontArgs pf{dur, target, seq_len, B, P, T, extra, rows32, rows_mapped, pad_row, seg_start, seg_end, ybar, weight, (float*)workspace, 0, 0};
+    if (bias && lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0 &&
+        mg_launch_phone_front_gemm(pf, A, lda, M, K, W, ldw, N, bias, Y, ldy, act == MG_ACT_SIGMOID ? EPI_BIAS_SIGMOID : EPI_BIAS,
+                                   (hipStream_t)stream) > 0) {
+        MG_CHECK_LAUNCH("mg_phone_front_linear_fwd_bf16/one grid");
+        return MG_OK;
+    }
+    rc = mg_phone_front(dur, B, P, T, target, seq_len, extra, rows32, rows_mapped, pad_row, seg_start, seg_end, ybar, weight, workspace,
+                        workspace_bytes, stream);
+    if (rc != MG_OK) return rc;
+    return mg_linear_fwd_bf16(A, lda, nullptr, M, K, W, ldw, bias, N, Y, ldy, 0, act, stream);
 }
 
 }  // extern "C"

@@ -16,6 +16,7 @@
 // Tried and dropped (all within +-8 % on the layer-1 forward shape): 128 x 256 tiles x 2 workgroups per CU,
 // 128 x 128 x 3 per CU, 3 instead of 4 stages, two 64-deep stages, XCD-grouped wgrad block order, non-temporal streams.
 #include "common.h"
+#include "phone_front.h"
 
 #include <type_traits>
 
@@ -399,11 +400,22 @@ MG_STAMP_DECL(g_stamps_ntp);
 // MODE 5 = ROLE (timing probe, results garbage): can the MFMAs and the LDS-DMA of DIFFERENT waves overlap?  Waves 0-3 issue no DMA and
 // read no fragments but run every MFMA twice; waves 4-7 issue every piece twice, read their fragments and run no MFMA; every wait is
 // vmcnt(0).  Same DMA bytes and MFMA count per k-step as the real kernel.
+template <int BN, int BK, int MODE>
+constexpr int ntp_lds_bytes() {
+    constexpr int STAGE = 256 * BK * 2 + BN * BK * 2;
+    constexpr int NS = (BK == 64) ? 3 : ((BN == 256) ? 4 : 5);
+    constexpr int PATCH = NS * STAGE + NTP_MAX_TILES(BN) * 256 * 4;
+    constexpr bool kPatchInRing = MODE != 1 && STAGE >= 8 * 32 * 128;
+    return PATCH + (kPatchInRing ? 0 : (MODE == 1 ? 8 * 32 * 64 : 8 * 32 * 128)) + BN * 4;
+}
+
+// The tile program on a caller-provided LDS block, as workgroup `block_id` of `n_blocks` (gemm_nt_persist_kernel: the plain launch;
+// phone_front_gemm_kernel: behind the blocks of an unrelated small job).
 template <int BN, int EPI, bool STAG, int BK, int MODE = 0>
-__global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
-                                                              int64_t M, int K, const uint16_t* __restrict__ Bm, int ldb, int N,
-                                                              const float* __restrict__ bias, uint16_t* __restrict__ C, int ldc,
-                                                              int tiles_m, int tiles_n, int probe) {
+__device__ __forceinline__ void gemm_nt_persist_body(unsigned char* __restrict__ smem, const unsigned block_id, const unsigned n_blocks,
+                                                     const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows, int64_t M,
+                                                     int K, const uint16_t* __restrict__ Bm, int ldb, int N, const float* __restrict__ bias,
+                                                     uint16_t* __restrict__ C, int ldc, int tiles_m, int tiles_n, int probe) {
     constexpr bool PIPE = MODE == 1, ROLE = MODE == 5, SPREAD = MODE == 2;
     constexpr int BM = 256;
     constexpr int WAVES_N = BN / 64;              // 4 or 2
@@ -432,7 +444,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
     constexpr int LDS_BYTES = BIAS_OFF + BN * 4;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    static_assert(LDS_BYTES == ntp_lds_bytes<BN, BK, MODE>(), "LDS size helper");
     int* rowtab = reinterpret_cast<int*>(smem + ROWTAB);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -448,7 +460,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
     // Virtual block v = blockIdx.x + i gridDim.x (gridDim.x a multiple of 8) keeps the XCD-aware order of gemm_nt_big: the N
     // tiles of one M tile go to blocks 8 apart, which share an XCD and its L2.
     auto tile_of = [&](int i, int& tile_m, int& tile_n) {
-        const int v = blockIdx.x + i * gridDim.x;
+        const int v = (int)(block_id + i * n_blocks);
         const int xcd = v & 7, jj = v >> 3;
         tile_n = jj % tiles_n;
         tile_m = (jj / tiles_n) * 8 + xcd;
@@ -858,7 +870,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MG_STAMP(ts3);
     MG_STAMP_REAL(tr1);
-    const int sb = blockIdx.x;
+    const int sb = block_id;
     MG_STAMP_STORE(g_stamps_ntp, sb, wave, lane, 0, ts0);
     MG_STAMP_STORE(g_stamps_ntp, sb, wave, lane, 1, ts1);
     MG_STAMP_STORE(g_stamps_ntp, sb, wave, lane, 2, ts2);
@@ -868,6 +880,35 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
     MG_STAMP_STORE(g_stamps_ntp, sb, wave, lane, 6, sum_wait);
     MG_STAMP_STORE(g_stamps_ntp, sb, wave, lane, 7, sum_epi);
 #endif
+}
+
+template <int BN, int EPI, bool STAG, int BK, int MODE = 0>
+__global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
+                                                              int64_t M, int K, const uint16_t* __restrict__ Bm, int ldb, int N,
+                                                              const float* __restrict__ bias, uint16_t* __restrict__ C, int ldc,
+                                                              int tiles_m, int tiles_n, int probe) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[ntp_lds_bytes<BN, BK, MODE>()];
+    gemm_nt_persist_body<BN, EPI, STAG, BK, MODE>(smem, blockIdx.x, gridDim.x, A, lda, rows, M, K, Bm, ldb, N, bias, C, ldc, tiles_m, tiles_n,
+                                                  probe);
+}
+
+// The front of the phone-rate step (csrc/phone_front.h: frame map + per-phone loss statistics, one job per utterance) in the grid of
+// the first layer's GEMM, which reads none of its outputs: blocks [0, side_blocks) run the jobs, the blocks behind them are the persistent tile program.  The GEMM of
+// C2's phone table has 168 tiles, one per workgroup and CU: the jobs take CUs it leaves idle and two launch boundaries disappear.
+// side_blocks is a multiple of 8 (the tile order derives a block's XCD from its id modulo 8).
+template <int EPI>
+__global__ __launch_bounds__(512) void phone_front_gemm_kernel(unsigned side_blocks, PhoneFrontArgs pf, const uint16_t* __restrict__ A, int lda,
+                                                               int64_t M, int K, const uint16_t* __restrict__ Bm, int ldb, int N,
+                                                               const float* __restrict__ bias, uint16_t* __restrict__ C, int ldc, int tiles_m,
+                                                               int tiles_n) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[ntp_lds_bytes<256, 32, 0>()];
+    if (blockIdx.x < side_blocks) {
+        if (pf.lds_ints > 0) phone_front_block<512>(pf, blockIdx.x, side_blocks, reinterpret_cast<int*>(smem));
+        return;                                          // lds_ints == 0: timing probe, the rider's blocks leave at once
+    }
+    if (pf.probe & 8) return;
+    gemm_nt_persist_body<256, EPI, false, 32, 0>(smem, blockIdx.x - side_blocks, gridDim.x - side_blocks, A, lda, nullptr, M, K, Bm, ldb, N, bias, C,
+                                                 ldc, tiles_m, tiles_n, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1244,6 +1285,39 @@ int mg_launch_wgrad_big(const uint16_t* dY, int lddy, const uint16_t* A, int lda
         hipLaunchKernelGGL((wgrad_big_kernel<10>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
     else
         hipLaunchKernelGGL((wgrad_big_kernel<8>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
+    return 1;
+}
+
+// The phone-rate front (phone_front.h) in the grid of the persistent wide-tile GEMM C = act(A W^T + b) (phone_front_gemm_kernel).
+// Qualifies when the GEMM takes mg_try_nt_big's persistent 256-wide form without a gather and leaves at least 32 CUs idle, and
+// the GEMM's LDS block holds a job's scan.  Returns 1 if it launched, 0 otherwise (the caller runs the two launches).
+int mg_launch_phone_front_gemm(const PhoneFrontArgs& pf, const uint16_t* A, int lda, int64_t M, int K, const uint16_t* Bm, int ldb, int N,
+                               const float* bias, uint16_t* C, int ldc, int epi, hipStream_t st) {
+    if (g_mg_tuning[MG_TUNE_PROBE] == 66 || g_mg_tuning[MG_TUNE_STAGGER] != 0) return 0;      // A/B: the separate launches
+    if (M < 2048 || M >= 2147483647LL || lda % 64 != 0 || ldb % 64 != 0 || lda > MG_ZERO_ELEMS - 64 || ldb > MG_ZERO_ELEMS - 64) return 0;
+    if (N % 256 != 0 || ldc != N || !big16(A) || !big16(Bm) || !big16(C)) return 0;
+    if (lda < (K + 63) / 64 * 64 || ldb < (K + 63) / 64 * 64 || (K + 31) / 32 < 5) return 0;
+    if (epi != EPI_BIAS && epi != EPI_BIAS_SIGMOID) return 0;
+    const int tiles_n = N / 256;
+    if (32 % tiles_n != 0) return 0;
+    const int64_t tiles_m = mg_ceil_div(M, 256);
+    const int64_t blocks = mg_ceil_div(tiles_m, 8) * 8 * tiles_n;
+    if (blocks > 224) return 0;                                       // one tile per workgroup and at least 32 CUs left over
+    const int64_t g = mg_ceil_div(blocks, 8 * tiles_n) * 8 * tiles_n;
+    const int side = (int)((256 - g) / 8 * 8);
+    if (side < 32) return 0;
+    constexpr int LDS_INTS = ntp_lds_bytes<256, 32, 0>() / 4;
+    if (phone_front_lds_ints(pf.B, pf.P, pf.T, pf.extra) > LDS_INTS) return 0;
+    PhoneFrontArgs a = pf;
+    a.lds_ints = g_mg_tuning[MG_TUNE_PROBE] == 67 ? 0 : LDS_INTS;      // 67: timing probe (the front's outputs are not written)
+    if (g_mg_tuning[MG_TUNE_PROBE] >= 70 && g_mg_tuning[MG_TUNE_PROBE] < 86) a.probe = g_mg_tuning[MG_TUNE_PROBE] - 70;     // 70 + bits
+    dim3 grid((unsigned)(side + g)), block(512);
+    if (epi == EPI_BIAS)
+        hipLaunchKernelGGL((phone_front_gemm_kernel<EPI_BIAS>), grid, block, 0, st, (unsigned)side, a, A, lda, M, K, Bm, ldb, N, bias, C, ldc,
+                           (int)tiles_m, tiles_n);
+    else
+        hipLaunchKernelGGL((phone_front_gemm_kernel<EPI_BIAS_SIGMOID>), grid, block, 0, st, (unsigned)side, a, A, lda, M, K, Bm, ldb, N, bias, C, ldc,
+                           (int)tiles_m, tiles_n);
     return 1;
 }
 

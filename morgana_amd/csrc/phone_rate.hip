@@ -13,6 +13,7 @@
 // table rows behind the R phone rows (zero inputs: sigmoid(b)); their gradients are summed into those `extra` rows, so dW
 // ignores them (their input is zero) and the bias gradients still see every frame.
 #include "common.h"
+#include "phone_front.h"
 
 typedef uint32_t pr_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -120,15 +121,6 @@ __global__ __launch_bounds__(64) void segment_sum_kernel(const T* __restrict__ G
 // any prediction p shared by the row's frames, c_r = sum_f w_f (y_f - ybar[r])^2 (two passes over the row's frames).  The c_r are
 // summed per block into `partial`.  Blocks [0, phone_blocks): 16 lanes per phone row (its ~12 consecutive frames).  Blocks behind
 // them: one WAVE per extra row, which takes the padding frames of its share of the frame axis, 64 frames per look.
-__device__ __forceinline__ float pr_frame_weight(int64_t f, const int64_t* __restrict__ seq_len, int B, int T) {
-    const int b = (int)(f / T);
-    const int t = (int)(f - (int64_t)b * T);
-    int64_t nb = seq_len ? seq_len[b] : (int64_t)T;
-    if (nb > T) nb = T;
-    if (nb < 0) nb = 0;
-    const float maskf = (int64_t)t < nb ? 1.f : 0.f;
-    return maskf * (1.f / ((float)nb * (float)B));          // n_b == 0 -> 0 * inf = NaN, as the reference
-}
 
 __global__ __launch_bounds__(256) void phone_target_stats_kernel(const float* __restrict__ target, const int32_t* __restrict__ rows,
                                                                  int64_t M, const int32_t* __restrict__ seg_start,
@@ -181,7 +173,7 @@ __global__ __launch_bounds__(256) void phone_target_stats_kernel(const float* __
             for (int64_t f = lo + lane; f < hi; f += 64) {
                 const int rf = rows[f];
                 if (rf < 0 || rf >= R) {
-                    const float w = pr_frame_weight(f, seq_len, B, T);
+                    const float w = pf_frame_weight(f, seq_len, B, T);
                     w_sum += w;
                     wy += w * target[f];
                 }
@@ -193,7 +185,7 @@ __global__ __launch_bounds__(256) void phone_target_stats_kernel(const float* __
                 const int rf = rows[f];
                 if (rf < 0 || rf >= R) {
                     const float d = target[f] - mean;
-                    c += pr_frame_weight(f, seq_len, B, T) * d * d;
+                    c += pf_frame_weight(f, seq_len, B, T) * d * d;
                 }
             }
             if (lane == 0) {
@@ -291,6 +283,12 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
     if (threadIdx.x == 0) out[0] = accumulate ? out[0] + red[0] : red[0];
 }
 
+// The frame map and the statistics in one launch: one job per utterance / per four extra rows (phone_front.h)
+__global__ __launch_bounds__(256) void phone_front_kernel(PhoneFrontArgs a) {
+    extern __shared__ __attribute__((aligned(16))) int pf_lds[];
+    phone_front_block<256>(a, blockIdx.x, gridDim.x, pf_lds);
+}
+
 extern "C" {
 
 int mg_segment_bounds(const int32_t* rows, int64_t M, int R, int32_t* seg_start, int32_t* seg_end, int32_t* rows_mapped, int pad_row,
@@ -350,6 +348,50 @@ int mg_phone_target_stats(const float* target, const int32_t* rows, int64_t M, c
                        phone_blocks, ybar, weight, (float*)workspace);
     if (loss_const) hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, blocks, loss_const, 0);
     MG_CHECK_LAUNCH("mg_phone_target_stats");
+    return MG_OK;
+}
+
+// mg_upsample_index_maps + mg_phone_target_stats as one launch (phone_front.h).  The same rows32 / rows_mapped / seg_start / seg_end /
+// ybar / weight bit for bit; the workspace holds the constant's partial sums in another grouping (one per utterance instead of one per
+// 16 phone rows: the consumers sum all of its ceil(R / 16) + ceil(extra / 4) slots either way).
+int mg_phone_front_check(const int64_t* dur, int B, int P, int T, const float* target, int extra, const int32_t* rows32,
+                         const int32_t* rows_mapped, const int32_t* seg_start, const int32_t* seg_end, const float* ybar, const float* weight,
+                         const void* workspace, size_t workspace_bytes, const char* who) {
+    if (!(dur && target && rows32 && rows_mapped && seg_start && seg_end && ybar && weight && B > 0 && P > 0 && T > 0 && extra >= 0)) {
+        mg_set_error("%s: bad arguments (B=%d P=%d T=%d extra=%d)", who, B, P, T, extra);
+        return MG_EINVAL;
+    }
+    if (P > 12288 || (int64_t)B * P >= 2147483647LL || (int64_t)B * T >= 2147483647LL) {
+        mg_set_error("%s: P=%d exceeds 12288 phones per utterance or int32 ids overflow", who, P);
+        return MG_EINVAL;
+    }
+    if ((int64_t)B > mg_ceil_div((int64_t)B * P, 16)) {
+        mg_set_error("%s: B=%d utterances of P=%d phones leave no partial-sum slot per utterance (use the two launches)", who, B, P);
+        return MG_EINVAL;
+    }
+    if (phone_front_lds_ints(B, P, T, extra) > 16000) {
+        mg_set_error("%s: extra=%d rows over %lld frames span too many utterances per job (use the two launches)", who, extra, (long long)B * T);
+        return MG_EINVAL;
+    }
+    if (!workspace || workspace_bytes < mg_phone_target_stats_workspace_bytes(B * P, extra)) {
+        mg_set_error("%s: workspace of %zu bytes needed, got %zu", who, mg_phone_target_stats_workspace_bytes(B * P, extra), workspace_bytes);
+        return MG_EWORKSPACE;
+    }
+    return MG_OK;
+}
+
+int mg_phone_front(const int64_t* dur, int B, int P, int T, const float* target, const int64_t* seq_len, int extra, int32_t* rows32,
+                   int32_t* rows_mapped, int pad_row, int32_t* seg_start, int32_t* seg_end, float* ybar, float* weight, void* workspace,
+                   size_t workspace_bytes, void* stream) {
+    const int rc = mg_phone_front_check(dur, B, P, T, target, extra, rows32, rows_mapped, seg_start, seg_end, ybar, weight, workspace,
+                                        workspace_bytes, "mg_phone_front");
+    if (rc != MG_OK) return rc;
+    PhoneFrontArgs a{dur, target, seq_len, B, P, T, extra, rows32, rows_mapped, pad_row, seg_start, seg_end, ybar, weight, (float*)workspace, 0, 0};
+    const int64_t ints = phone_front_lds_ints(B, P, T, extra);
+    a.lds_ints = (int)ints;
+    hipLaunchKernelGGL(phone_front_kernel, dim3((unsigned)phone_front_jobs(B, extra)), dim3(256), (size_t)ints * sizeof(int), (hipStream_t)stream,
+                       a);
+    MG_CHECK_LAUNCH("mg_phone_front");
     return MG_OK;
 }
 

@@ -330,10 +330,14 @@ class LinearStackMSEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, acts, x2d, rows, target, seq_len, *params):
         acts_in = acts
-        maps = table_bf16 = None
+        maps = table_bf16 = pending = None
         if len(acts) in (2, 3) and not isinstance(acts[0], int):  # (acts, maps[, table]): phone-rate maps that came with the frame map,
             acts, maps = acts[0], acts[1]                         # and the loader's bf16 copy of the phone table (data.add_bf16_table)
             table_bf16 = acts_in[2] if len(acts_in) == 3 else None
+            if maps is not None and not isinstance(maps, tuple):
+                # an utils.UpsampledSequence whose frame map no kernel has built yet (rows is None): the phone-rate step builds it
+                # in the launch of its own front (ops.phone_front); every other path asks the sequence for it now
+                pending, maps = maps, None
         n_layers = len(acts)
         weights = [params[2 * i] for i in range(n_layers)]
         biases = [params[2 * i + 1] for i in range(n_layers)]
@@ -341,7 +345,13 @@ class LinearStackMSEFn(torch.autograd.Function):
         target = ops._require(target, torch.float32, 'targets')
         b, t = target.shape[0], target.shape[1]
         m = b * t
-        if (rows.numel() if rows is not None else x2d.shape[0]) != m:
+        n_layers_lead = n_layers - 2
+        front = (pending is not None and pending.t_cap == t and pending.dur.shape[0] == b and n_layers_lead == 2 and
+                 ops.phone_rate_table_ok(x2d.shape[0], m, weights[0].shape[0], weights[1].shape[0], acts[0]) and
+                 ops.phone_front_ok(b, pending.dur.shape[1], t, ops.PHONE_RATE_EXTRA))
+        if pending is not None and not front:
+            rows, maps = pending.rows.reshape(-1), pending.maps
+        if (m if front else rows.numel() if rows is not None else x2d.shape[0]) != m:
             raise ValueError('prediction rows (%d) and target rows (%d) differ' % (
                 rows.numel() if rows is not None else x2d.shape[0], m))
         lead = n_layers - 2
@@ -358,12 +368,13 @@ class LinearStackMSEFn(torch.autograd.Function):
         #     sum_f w_f (p - y_f)^2 = W (p - ybar)^2 + const        (W, ybar, const from the targets alone: mg_phone_target_stats)
         # whose gradient the fused tail forms per phone row.
         n_table = x2d.shape[0]
-        phone_rate = (rows is not None and lead == 2
-                      and ops.phone_rate_table_ok(n_table, m, weights[0].shape[0], weights[1].shape[0], acts[0]))
+        phone_rate = front or (rows is not None and lead == 2
+                               and ops.phone_rate_table_ok(n_table, m, weights[0].shape[0], weights[1].shape[0], acts[0]))
         ctx.phone_rate = phone_rate
         if phone_rate:
             extra = ops.PHONE_RATE_EXTRA
-            seg, rows = maps if maps is not None else ops.segment_bounds(rows, n_table, pad_row=n_table)
+            if not front:
+                seg, rows = maps if maps is not None else ops.segment_bounds(rows, n_table, pad_row=n_table)
             if table_bf16 is not None and tuple(table_bf16.shape) == (n_table + extra, ops.pad_ld(x2d.shape[1])):
                 a0 = table_bf16                                   # cast once when the batch was loaded, not once per step
             else:
@@ -372,14 +383,22 @@ class LinearStackMSEFn(torch.autograd.Function):
             hidden, a = [], a0
             for i in range(lead - (1 if l2tail else 0)):
                 n, k = weights[i].shape
-                a = ops.linear_fwd_bf16(a, None, n_rows, k, w_bf[i], biases[i], n, acts[i])
+                if front and i == 0:
+                    # the frame map, the per-phone loss statistics and this layer's GEMM read nothing of each other: one launch
+                    rows_bt, rows_mapped, seg, ybar, weight, partials, a = ops.phone_front(
+                        pending.dur, target.reshape(-1), seq_len, t, extra, linear=(a, k, w_bf[i], biases[i], n, acts[i]))
+                    rows = rows_mapped.reshape(-1)
+                    pending.adopt(rows_bt, (seg, rows))
+                else:
+                    a = ops.linear_fwd_bf16(a, None, n_rows, k, w_bf[i], biases[i], n, acts[i])
                 hidden.append(a)
             sizes = [p.numel() for p in params]
             offsets = [0]
             for sz in sizes[:-1]:
                 offsets.append(offsets[-1] + sz)
             flat = torch.empty(sum(sizes) + 1, dtype=torch.float32, device=x2d.device)
-            ybar, weight, partials = ops.phone_target_stats(target.reshape(-1), rows, seg, seq_len, b, t, n_table, extra)
+            if not front:
+                ybar, weight, partials = ops.phone_target_stats(target.reshape(-1), rows, seg, seq_len, b, t, n_table, extra)
             if l2tail and os.environ.get('MORGANA_EXPAND_REDUCE', '1') != '0':
                 # the tail's slab reduce rides in the launch that repeats the prediction (one node less, the same sums)
                 pred, loss, dz2 = ops.f0_l2tail_rows_expand(hidden[-1], w_bf[lead - 1], biases[lead - 1], weights[lead], biases[lead],

@@ -627,6 +627,43 @@ def phone_target_stats(target, rows, seg, seq_len, b, t, n_table_rows, extra):
     return stats[0], stats[1], ws
 
 
+def phone_front_ok(b, p, t, extra):
+    """Shapes the one-launch front of the phone-rate step takes (mg_phone_front): a partial-sum slot per utterance (about 16 phones per
+    utterance or more) and extra rows whose frame chunks span few utterances."""
+    if not (b > 0 and p > 0 and t > 0 and extra > 0 and p <= 12288 and b <= -(-(b * p) // 16)):
+        return False
+    chunk = -(-(b * t) // extra)
+    return 512 + max(p + t + 1, -(-(4 * chunk) // t) + 2) <= 16000
+
+
+def phone_front(dur, target, seq_len, t, extra, linear=None):
+    """upsample_index_maps + phone_target_stats in ONE launch (mg_phone_front): returns (rows (B, t), rows_mapped (B, t), seg (2, B*P),
+    ybar, weight, partials).  ``linear`` = (a bf16 (M, lda), k, w_bf16, bias, n, act): additionally y = act(a w^T + bias) (bf16 (M, n)),
+    appended to the result, in the SAME grid where the GEMM leaves CUs idle (mg_phone_front_linear_fwd_bf16)."""
+    lib = _lib.load()
+    dur = _require(dur, torch.int64, 'dur')
+    target = _require(target, torch.float32, 'targets')
+    b, p = dur.shape
+    if target.numel() != b * t:
+        raise ValueError('phone_front: %d targets for %d x %d frames' % (target.numel(), b, t))
+    r = b * p
+    rows = torch.empty((2, b, t), dtype=torch.int32, device=dur.device)
+    seg = torch.empty((2, r), dtype=torch.int32, device=dur.device)
+    stats = torch.empty((2, r + extra), dtype=torch.float32, device=dur.device)
+    ws = torch.empty(lib.mg_phone_target_stats_workspace_bytes(r, extra), dtype=torch.uint8, device=dur.device)
+    front = (_p(dur), b, p, int(t), _p(target), _p(seq_len), extra, _p(rows[0]), _p(rows[1]), r, _p(seg[0]), _p(seg[1]), _p(stats[0]),
+             _p(stats[1]), _p(ws), ws.numel())
+    if linear is None:
+        _lib.check(lib.mg_phone_front(*front, _stream()), 'mg_phone_front')
+        return rows[0], rows[1], seg, stats[0], stats[1], ws
+    a, k, w_bf16, bias, n, act = linear
+    m = a.shape[0]
+    y = torch.empty((m, pad8(n)), dtype=torch.bfloat16, device=a.device)
+    _lib.check(lib.mg_phone_front_linear_fwd_bf16(*front, _p(a), a.shape[1], m, k, _p(w_bf16), w_bf16.shape[1], _p(bias), n, _p(y), pad8(n), act,
+                                                  _stream()), 'mg_phone_front_linear_fwd_bf16')
+    return rows[0], rows[1], seg, stats[0], stats[1], ws, y
+
+
 def phone_loss_const_add(partials, n_table_rows, extra, loss):
     """loss (0-d f32, in place) += the constant term left by phone_target_stats."""
     _lib.check(_lib.load().mg_phone_loss_const_add(_p(partials), n_table_rows, extra, _p(loss), _stream()), 'mg_phone_loss_const_add')

@@ -51,13 +51,31 @@ class UpsampledSequence(object):
     (B, Tmax, feat) tensor never exists in HBM.  ``materialise()`` gives the ordinary dense tensor.
     """
 
-    def __init__(self, sequence_feature, dur2d, rows, maps=None, table_bf16=None):
+    def __init__(self, sequence_feature, dur2d, rows, maps=None, table_bf16=None, t_cap=None):
         self.source = sequence_feature
         self.dur = dur2d
-        self.rows = rows                       # int32 (B, Tmax): b*P + phone, or -1
+        # int32 (B, Tmax): b*P + phone, or -1.  None = not built yet (t_cap given): the first reader of ``rows`` launches the map
+        # kernel - unless the consumer is the phone-rate loss stack, which builds the maps together with its own front
+        # (functional.LinearStackMSEFn: ops.phone_front) and hands them back through ``adopt``
+        self._rows = rows
         self.maps = maps                       # (seg (2, B*P) frame runs, rows with -1 -> B*P) from the same launch, or None
         self.table_bf16 = table_bf16           # the loader's bf16 copy of the source rows (data.add_bf16_table), or None
-        self.shape = (sequence_feature.shape[0], rows.shape[1], sequence_feature.shape[2])
+        self.t_cap = int(rows.shape[1] if rows is not None else t_cap)
+        self.shape = (sequence_feature.shape[0], self.t_cap, sequence_feature.shape[2])
+
+    @property
+    def rows(self):
+        if self._rows is None:
+            rows, rows_mapped, seg = ops.upsample_index_maps(self.dur, self.t_cap)
+            self._rows, self.maps = rows, (seg, rows_mapped.reshape(-1))
+        return self._rows
+
+    def pending(self):
+        """True while no map kernel has run for this sequence."""
+        return self._rows is None
+
+    def adopt(self, rows, maps):
+        self._rows, self.maps = rows, maps
 
     def phone_maps(self):
         """(frame runs per phone row, row map with -1 -> the first row behind the B*P phone rows) for the phone-rate paths."""
@@ -67,7 +85,7 @@ class UpsampledSequence(object):
         return self.maps
 
     def materialise(self):
-        return F_hip.UpsampleFn.apply(self.source, self.dur, self.rows.shape[1])
+        return F_hip.UpsampleFn.apply(self.source, self.dur, self.t_cap)
 
 
 class PhoneTable(object):
@@ -187,8 +205,7 @@ def upsample_to_repetitions(sequence_feature, repeats, max_len=None, fused=False
         max_len = int(tmax.item())
     if fused and not sequence_feature.requires_grad:
         if ops.PHONE_RATE and int(max_len) > 0:
-            rows, rows_mapped, seg = ops.upsample_index_maps(dur2d, int(max_len))
-            return UpsampledSequence(sequence_feature, dur2d, rows, maps=(seg, rows_mapped.reshape(-1)), table_bf16=table_bf16)
+            return UpsampledSequence(sequence_feature, dur2d, None, table_bf16=table_bf16, t_cap=int(max_len))       # maps on first use
         _, rows = ops.upsample_index(dur2d, int(max_len))
         return UpsampledSequence(sequence_feature, dur2d, rows, table_bf16=table_bf16)
     return F_hip.UpsampleFn.apply(sequence_feature, dur2d, int(max_len))
@@ -455,8 +472,11 @@ class SequentialWithRecurrent(nn.Sequential):
         run, acts = fused
         maps = table = None
         if isinstance(input, UpsampledSequence):
-            x2d, rows, maps = input.source.reshape(-1, input.source.shape[-1]), input.rows.reshape(-1), input.maps
-            table = input.table_bf16
+            x2d, table = input.source.reshape(-1, input.source.shape[-1]), input.table_bf16
+            if input.pending():
+                rows, maps = None, input               # the stack builds the maps with its own front, or asks ``input.rows`` for them
+            else:
+                rows, maps = input.rows.reshape(-1), input.maps
         else:
             x2d, rows = input.reshape(-1, input.shape[-1]), None
         if seq_len is not None and seq_len.dtype != torch.int64:

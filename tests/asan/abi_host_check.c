@@ -104,6 +104,9 @@ int main(void) {
                                                                                                          0, 0, NULL, 0, &ns, (int64_t*)&st, NULL)); }
     { int ns = 0; long long st = 0; expect_code("linear_wgrad_dgrad(null)", mg_linear_wgrad_dgrad_bf16(NULL, 0, NULL, 0, 0, 0, 0, NULL, 0, NULL, 0, NULL, 0,
                                                                                                &ns, (int64_t*)&st, NULL)); }
+    expect_code("phone_front(null)", mg_phone_front(NULL, 0, 0, 0, NULL, NULL, 0, NULL, NULL, 0, NULL, NULL, NULL, NULL, NULL, 0, NULL));
+    expect_code("phone_front_linear_fwd(null)", mg_phone_front_linear_fwd_bf16(NULL, 0, 0, 0, NULL, NULL, 0, NULL, NULL, 0, NULL, NULL, NULL, NULL, NULL, 0,
+                                                                               NULL, 0, 0, 0, NULL, 0, NULL, 0, NULL, 0, 0, NULL));
     expect_code("linear_fwd_bf16(runs hint, bad act)", mg_linear_fwd_bf16(dh, 640, di, 4096, 600, dh, 640, df, 512, dh, 512, 0, MG_ACT_ROWS_RUNS | 7, NULL));
     expect_code("gru_fwd_f32(null)", mg_gru_fwd_f32(NULL, NULL, NULL, NULL, 0, 0, 0, NULL, NULL, NULL, NULL));
     expect_code("gru_fwd_bf16(H)", mg_gru_fwd_bf16(df, dh, 96, df, dl, 4, 10, 96, df, dh, df, df, NULL));

@@ -1946,6 +1946,63 @@ def test_upsample_index_maps_match_separate_launches():
         assert torch.equal(rows2, rows) and torch.equal(mapped2.reshape(-1), mapped) and torch.equal(seg2, seg)
 
 
+@pytest.mark.parametrize('case', ['ragged', 'c2', 'wide'])
+def test_phone_front_equals_the_separate_launches(case):
+    """mg_phone_front (frame map + per-phone loss statistics, one job per utterance) against mg_upsample_index_maps +
+    mg_phone_target_stats: rows, the pad-mapped rows, the frame runs, ybar and weight EQUAL; the loss's constant term (partial sums
+    grouped per utterance instead of per 16 rows) to 1e-6.  'ragged': zero durations, an empty utterance, totals short of and beyond the
+    frame axis, seq_len cutting into live frames; 'c2': the headline shape; 'wide': more phones than threads per utterance.
+    Then mg_phone_front_linear_fwd_bf16: the same outputs plus the first layer's GEMM EQUAL to mg_linear_fwd_bf16, in one grid
+    (where the GEMM leaves CUs idle: 'c2') and as its two launches (MG_TUNE_PROBE = 66)."""
+    from morgana_amd import ops, _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(31)
+    if case == 'ragged':
+        b, p, t, extra = 9, 23, 60, 8
+        dur = rng.randint(0, 6, size=(b, p)).astype(np.int64)
+        dur[3] = 0
+        dur[4, :5] = 40
+        seq_np = rng.randint(10, t + 1, size=b).astype(np.int64)
+    elif case == 'c2':
+        b, p, t, extra = 256, 80, 1000, ops.PHONE_RATE_EXTRA
+        dur = rng.randint(1, 25, size=(b, p)).astype(np.int64)
+        seq_np = np.minimum(dur.sum(1), t).astype(np.int64)
+    else:
+        b, p, t, extra = 5, 700, 2100, 16
+        dur = rng.randint(0, 7, size=(b, p)).astype(np.int64)
+        seq_np = None
+    target = rng.standard_normal(b * t).astype(np.float32)
+    seq = dev(seq_np) if seq_np is not None else None
+    assert ops.phone_front_ok(b, p, t, extra)
+    rows, mapped, seg = ops.upsample_index_maps(dev(dur), t)
+    ybar, weight, partials = ops.phone_target_stats(dev(target), mapped.reshape(-1), seg, seq, b, t, b * p, extra)
+    const = torch.zeros((), device=DEV)
+    ops.phone_loss_const_add(partials, b * p, extra, const)
+
+    def check(got):
+        rows2, mapped2, seg2, ybar2, weight2, partials2 = got[:6]
+        assert torch.equal(rows2, rows) and torch.equal(mapped2, mapped) and torch.equal(seg2, seg)
+        assert torch.equal(ybar2, ybar) and torch.equal(weight2, weight)
+        const2 = torch.zeros((), device=DEV)
+        ops.phone_loss_const_add(partials2, b * p, extra, const2)
+        np.testing.assert_allclose(const2.item(), const.item(), rtol=1e-6)
+
+    check(ops.phone_front(dev(dur), dev(target), seq, t, extra))
+    m, k, n = b * p + extra, 600, 512
+    a = ops.cast_pad_bf16(dev(rng.uniform(0, 1, (m, k)).astype(np.float32)))
+    (w_bf,), _ = ops.cast_params_bf16([dev(rng.uniform(-0.1, 0.1, (n, k)).astype(np.float32))], want_plain=True, want_t=())
+    bias = dev(rng.uniform(-0.1, 0.1, n).astype(np.float32))
+    want_y = ops.linear_fwd_bf16(a, None, m, k, w_bf, bias, n, ops.ACT_SIGMOID)
+    for probe in (0, 66):
+        lib.mg_set_tuning(7, probe)
+        try:
+            got = ops.phone_front(dev(dur), dev(target), seq, t, extra, linear=(a, k, w_bf, bias, n, ops.ACT_SIGMOID))
+        finally:
+            lib.mg_set_tuning(7, 0)
+        check(got)
+        assert torch.equal(got[6], want_y), probe
+
+
 @pytest.mark.parametrize('masked', [True, False])
 def test_phone_target_stats_reduce_the_masked_mse_exactly(masked):
     """mg_phone_target_stats / mg_phone_loss_const_add: for predictions that are constant over the frames of a table row the masked MSE
