@@ -1260,7 +1260,11 @@ int mg_wgrad_big_plan(int64_t M, int N, int K, int lda, int lddy, int* S_out, in
     // N = 128 at frame-rate row counts (M = 256 000, K = 512): 192 splits of ~1 334 rows beat one split per CU - a quarter less slab
     // traffic (50 vs 67 MB written and read again by the reduce): 89.5 -> 80 us with the reduce (sweep 144 .. 512, scripts/kbench.py wgrad2)
     if (M > 32768 && tiles_n == 1) S = 192;
-    if (g_mg_tuning[MG_TUNE_WGRAD_SPLITS] > 0) S = g_mg_tuning[MG_TUNE_WGRAD_SPLITS];
+    // experiments: a split count for every plan (< 1000), for the one-n-tile plans only (1000 + S) or for the plans of 4+ n tiles (2000 + S)
+    const int ts = g_mg_tuning[MG_TUNE_WGRAD_SPLITS];
+    if (ts > 0 && ts < 1000) S = ts;
+    if (ts > 1000 && ts < 2000 && tiles_n == 1) S = ts - 1000;
+    if (ts > 2000 && tiles_n >= 4) S = ts - 2000;
     int64_t m_chunk = mg_align_up((size_t)mg_ceil_div(M, S), 32);
     while (m_chunk > WG_ROWS_MAX) {  // row indices of a workgroup's range live in LDS
         S *= 2;
@@ -1335,15 +1339,33 @@ int mg_launch_wgrad_dgrad_pair(const uint16_t* dY, int lddy, const uint16_t* A, 
     if (!big16(dY) || !big16(A) || !big16(WT) || !big16(dX)) return 0;
     const int tiles_n = K / 256;
     const int64_t tiles_m = mg_ceil_div(M, 256);
-    const int64_t nt_per_xcd = mg_ceil_div(tiles_m, 8) * tiles_n;
-    const int64_t cap = 8 * (32 - nt_per_xcd);
-    if (cap < 48) return 0;
-    if (S > cap) {
-        m_chunk = (int)mg_align_up((size_t)mg_ceil_div(M, cap), 32);
-        if (m_chunk > WG_ROWS_MAX) return 0;
-        S = (int)mg_align_up((size_t)mg_ceil_div(M, m_chunk), 8);
-        if (S > cap) return 0;
+    // Blocks go to the XCDs round robin and every workgroup here owns a CU: XCD x takes the dgrad tiles of the M tiles x, x + 8, ...
+    // and the splits b = x (mod 8), of which the trailing ones are empty when M is not a multiple of the chunk (they write a zero slab
+    // and leave).  The largest split count, a multiple of 8 from the plan's down, with at most 32 working blocks on every XCD (a 33rd
+    // would wait for a whole tile program to finish).  Measured at C2's M = 21 504: 80 splits; 88 fit too when the splits are handed
+    // out from the last one down - the four empty ones then land on the XCDs with a dgrad tile more - and were 2.4 us per step SLOWER
+    // (every CU busy to the end, 8 more slabs for the update kernel to sum).
+    auto fits = [&](int S_, int chunk_) {
+        const int64_t s_real = mg_ceil_div(M, chunk_);
+        for (int x = 0; x < 8; ++x) {
+            const int64_t nt_x = (tiles_m > x ? mg_ceil_div(tiles_m - x, 8) : 0) * tiles_n;
+            int64_t wg_x = 0;
+            for (int b = x; b < S_; b += 8) wg_x += b < s_real ? 1 : 0;
+            if (nt_x + wg_x > 32) return false;
+        }
+        return true;
+    };
+    bool found = false;
+    for (int cand = S; cand >= 48 && !found; cand -= 8) {
+        const int chunk_ = cand == S ? m_chunk : (int)mg_align_up((size_t)mg_ceil_div(M, cand), 32);
+        if (chunk_ > WG_ROWS_MAX) break;
+        const int S_ = (int)mg_align_up((size_t)mg_ceil_div(M, chunk_), 8);
+        if (S_ > S || !fits(S_, chunk_)) continue;
+        found = true;
+        S = S_;
+        m_chunk = chunk_;
     }
+    if (!found) return 0;
     if ((size_t)S * (size_t)sstride > slab_floats) return 0;
     const unsigned nt_blocks = (unsigned)(mg_ceil_div(tiles_m, 8) * 8 * tiles_n);
     hipLaunchKernelGGL((wgrad_dgrad_pair_kernel<8, 256>), dim3((unsigned)S + nt_blocks), dim3(512), 0, st, (unsigned)S, dY, lddy, A, lda, M, N, K,
