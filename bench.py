@@ -57,11 +57,34 @@ def parse_args():
     return ap.parse_args()
 
 
-def time_kernel(fn, iters=10, warm=2):
-    """Average duration (ms) of `fn` (which launches on torch's current stream) measured with HIP events on it."""
+def time_kernel(fn, iters=10, warm=2, graph=False):
+    """Average duration (ms) of `fn` (which launches on torch's current stream), measured with HIP events on that stream around
+    replays of a HIP graph holding `iters` calls: the kernels of the phone-rate step take 20-30 us, less than the host needs to
+    issue one of them through Python, so timed launch by launch the result would be the host's rate (graph=True: the F0 step's kernels;
+    falls back to timing the launches themselves where a call cannot be captured)."""
     for _ in range(warm):
         fn()
+    torch.cuda.synchronize()
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    entry = torch.cuda.current_stream()
+    try:
+        if not graph:
+            raise RuntimeError('launch by launch')
+        captured = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(captured):
+            for _ in range(iters):
+                fn()
+        captured.replay()
+        torch.cuda.synchronize()
+        start.record()
+        for _ in range(3):
+            captured.replay()
+        end.record()
+        end.synchronize()
+        return start.elapsed_time(end) / (3 * iters)
+    except Exception:
+        torch.cuda.set_stream(entry)
+        torch.cuda.synchronize()
     start.record()
     for _ in range(iters):
         fn()
@@ -105,10 +128,15 @@ def roofline_f0(features, model, precision):
         dz1 = ops.linear_dgrad_bf16(dz2, r_tab, n2, w2t, n1, h_tab)
         target = features['normalised_lf0'].reshape(-1)
         seq_len = features['n_frames']
-        kernels.append(('gemm_nt_persist_kernel<256>: layer-1 forward at phone rate (%d rows, 600->512 + bias + sigmoid)' % r_tab,
-                        2.0 * r_tab * k * n1, lambda: ops.linear_fwd_bf16(tab, None, r_tab, k, w1b, b1, n1, ops.ACT_SIGMOID)))
-        kernels.append(('phone_target_stats_kernel: per-phone weight / mean target / constant of the masked MSE (reads the M targets)', 0.0,
-                        lambda: ops.phone_target_stats(target, rows_p, seg, seq_len, b, t, b * p, extra)))
+        if ops.phone_front_ok(b, p, t, extra):
+            kernels.append(('phone_front_gemm_kernel<1>: layer-1 forward at phone rate (%d rows, 600->512 + bias + sigmoid) with the frame map and '
+                            'the per-phone loss statistics riding on the CUs the GEMM leaves idle' % r_tab, 2.0 * r_tab * k * n1,
+                            lambda: ops.phone_front(dur2d, target, seq_len, t, extra, linear=(tab, k, w1b, b1, n1, ops.ACT_SIGMOID))))
+        else:
+            kernels.append(('gemm_nt_persist_kernel<256>: layer-1 forward at phone rate (%d rows, 600->512 + bias + sigmoid)' % r_tab,
+                            2.0 * r_tab * k * n1, lambda: ops.linear_fwd_bf16(tab, None, r_tab, k, w1b, b1, n1, ops.ACT_SIGMOID)))
+            kernels.append(('phone_target_stats_kernel: per-phone weight / mean target / constant of the masked MSE (reads the M targets)', 0.0,
+                            lambda: ops.phone_target_stats(target, rows_p, seg, seq_len, b, t, b * p, extra)))
         w3, b3, w4, b4 = lins[2].weight.detach(), lins[2].bias.detach(), lins[3].weight.detach(), lins[3].bias.detach()
         if ops.l2tail_ok(w2, w3, w4, ops.ACT_SIGMOID):
             ybar, weight, _ = ops.phone_target_stats(target, rows_p, seg, seq_len, b, t, b * p, extra)
@@ -121,15 +149,21 @@ def roofline_f0(features, model, precision):
                             2.0 * r_tab * n1 * n2, lambda: ops.linear_fwd_bf16(h_tab, None, r_tab, n1, w2b, b2, n2, ops.ACT_SIGMOID)))
         bound['phone_target_stats_kernel'] = ('hbm', m * 4.0 * 2 + r_tab * 8.0)
         ldk = tab.shape[1]
-        algo_bytes.update({'gemm_nt_persist_kernel<256>': 2.0 * (r_tab * ldk + n1 * ldk + r_tab * n1),
+        algo_bytes.update({'phone_front_gemm_kernel<1>': 2.0 * (r_tab * ldk + n1 * ldk + r_tab * n1) + m * 12.0 + b * p * 8.0 + r_tab * 16.0,
+                           'wgrad_dgrad_pair_kernel<8>': 2.0 * (r_tab * n2 + n1 * n2 + 2 * r_tab * n1) + 4.0 * n2 * n1,
+                           'gemm_nt_persist_kernel<256>': 2.0 * (r_tab * ldk + n1 * ldk + r_tab * n1),
                            'gemm_nt_persist_kernel<128>': 2.0 * (r_tab * n1 + n2 * n1 + r_tab * n2),
                            'wgrad_big_kernel<8>': 2.0 * (r_tab * n2 + r_tab * n1) + 4.0 * n2 * n1,
                            'gemm_nt_big_kernel<256>': 2.0 * (r_tab * n2 + n1 * n2 + 2 * r_tab * n1),
                            'wgrad_big_kernel<10>': 2.0 * (r_tab * n1 + r_tab * ldk) + 4.0 * n1 * k})
-        kernels.append(('wgrad_big_kernel<8>: layer-2 wgrad at phone rate (dZ2^T table)', 2.0 * r_tab * n1 * n2,
-                        lambda: ops.linear_wgrad_bf16(dz2, h_tab, None, r_tab, n2, n1)))
-        kernels.append(('gemm_nt_big_kernel<256>: layer-2 dgrad + sigmoid-grad at phone rate', 2.0 * r_tab * n1 * n2,
-                        lambda: ops.linear_dgrad_bf16(dz2, r_tab, n2, w2t, n1, h_tab)))
+        if ops.wgrad_slabs_ok(r_tab, n2, n1, h_tab.shape[1], dz2.shape[1]):
+            kernels.append(('wgrad_dgrad_pair_kernel<8>: layer-2 wgrad slabs (dZ2^T table) and layer-2 dgrad + sigmoid-grad at phone rate in '
+                            'one grid', 4.0 * r_tab * n1 * n2, lambda: ops.linear_wgrad_dgrad_bf16(dz2, h_tab, r_tab, n2, n1, w2t)))
+        else:
+            kernels.append(('wgrad_big_kernel<8>: layer-2 wgrad at phone rate (dZ2^T table)', 2.0 * r_tab * n1 * n2,
+                            lambda: ops.linear_wgrad_bf16(dz2, h_tab, None, r_tab, n2, n1)))
+            kernels.append(('gemm_nt_big_kernel<256>: layer-2 dgrad + sigmoid-grad at phone rate', 2.0 * r_tab * n1 * n2,
+                            lambda: ops.linear_dgrad_bf16(dz2, r_tab, n2, w2t, n1, h_tab)))
         kernels.append(('wgrad_big_kernel<10>: layer-1 wgrad at phone rate (dZ1^T lab)', 2.0 * r_tab * k * n1,
                         lambda: ops.linear_wgrad_bf16(dz1, tab, None, r_tab, n1, k)))
         peak = MFMA_BF16_PEAK_TFLOPS
@@ -183,7 +217,7 @@ def roofline_f0(features, model, precision):
     lib = _lib.load()
     lib.mg_set_tuning(1, 1)          # MG_TUNE_SKIP_REDUCE: time the GEMM kernel alone, without its slab-reduce launches
     for name, flops, fn in kernels:
-        ms = time_kernel(fn)
+        ms = time_kernel(fn, graph=True)
         measured.append({'kernel': name, 'ms': round(ms, 4), 'gflop': round(flops / 1e9, 1),
                          'tflops': round(flops / (ms * 1e-3) / 1e12, 2)})
     lib.mg_set_tuning(1, 0)

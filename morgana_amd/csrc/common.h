@@ -80,6 +80,20 @@ __device__ __forceinline__ f32x16 mg_mfma_32x32x16(mg_bfv8 a, mg_bfv8 b, f32x16 
 }
 #endif
 
+// LDS-DMA of 64 x 16 bytes: lane l's 16 bytes (from its own address `src`) land at LDS byte (lds_wave_base + 16 l); no VGPR staging,
+// completion counted by vmcnt.  Inline asm on purpose: hipcc keeps no record of the pending LDS write (its own waits stay
+// conservative - a wait for a tracked load also covers every older DMA); the caller drains vmcnt before the barrier in front of the
+// first read.  M0 is saved and restored inside the statement (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void mg_glds16(const void* src, unsigned char* lds_wave_base) {
+    const unsigned lds_off = (unsigned)(unsigned long long)((__attribute__((address_space(3))) unsigned char*)lds_wave_base);
+    const unsigned lds_uni = __builtin_amdgcn_readfirstlane(lds_off);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_uni)
+                 : "memory");
+}
+
 // Sum over each row of 16 lanes, in every lane of the row, on the DPP path (row_ror 8, 4, 2, 1: four VALU instructions, where four
 // __shfl_xor go through the LDS crossbar one after the other).  Bit for bit the xor butterfly 8, 4, 2, 1: at every level a lane's
 // partner belongs to the same class of lanes either way, and a + b == b + a.

@@ -77,48 +77,12 @@ __global__ __launch_bounds__(256, 1) void f0_l2tail_kernel(const uint16_t* __res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mi = lane & 31, lh = lane >> 5;
 
-    // ---- one-time: W2 (bf16 as it is), the two permuted W3 fragment tables, b2 ------------------------------------------
-    // Every load of a batch is in flight before the first LDS store (a copy loop of load -> store pairs cost ~15 us per launch: at
-    // the phone-rate row count the whole kernel is one tile per wave behind this prologue).
-    {
-        unsigned short* w3s = reinterpret_cast<unsigned short*>(smem + LT_WAVE0);       // W3 as bf16 [32][128], staged in the patches
-        float w3v[16];
+    // The loads of the one-time tables go out first, the first tile's rows and scalars behind them and the LDS-DMA of W2 last (vector
+    // memory returns in issue order): the W3 staging below waits for its own sixteen loads only, everything else lands meanwhile.
+    float w3v[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) w3v[i] = W3[tid + 256 * i];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            u32x4 v[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int e = tid + 256 * (8 * q + i), n = e >> 6, c = e & 63;
-                v[i] = *reinterpret_cast<const u32x4*>(W2 + (size_t)n * ldw2 + c * 8);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int e = tid + 256 * (8 * q + i), n = e >> 6, c = e & 63;
-                *reinterpret_cast<u32x4*>(smem + LT_W2 + n * (LT_K * 2) + ((c ^ (n & 15)) << 4)) = v[i];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) w3s[tid + 256 * i] = mg_f2bf(w3v[i]);
-        if (tid < LT_N2) *reinterpret_cast<float*>(smem + LT_B2 + tid * 4) = b2[tid];
-        __syncthreads();
-        // fragment f = tid + 256 i: f < 512 -> Z3 fragments [st = 2 blk + s][lane]: element j = W3[lane & 31][unit of B slot j];
-        //                           f >= 512 -> dH2 fragments [kt][s][lane]: element j = W3[unit3 of slot j][32 kt + (lane & 31)]
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = tid + 256 * i, l = f & 63, r = l & 31, h = l >> 5, g = (f >> 6) & 7;
-            unsigned short el[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int u = 8 * (j >> 2) + 4 * h + (j & 3);                             // slot j of lane half h inside a 16-unit step
-                el[j] = (f < 512) ? w3s[r * LT_N2 + 16 * g + u] : w3s[(16 * (g & 1) + u) * LT_N2 + 32 * (g >> 1) + r];
-            }
-            *reinterpret_cast<u32x4*>(smem + LT_ZF + f * 16) = u32x4{el[0] | ((unsigned)el[1] << 16), el[2] | ((unsigned)el[3] << 16),
-                                                                   el[4] | ((unsigned)el[5] << 16), el[6] | ((unsigned)el[7] << 16)};
-        }
-        __syncthreads();                                   // the staged W3 is done with: its bytes become the waves' patches
-    }
+    for (int i = 0; i < 16; ++i) w3v[i] = W3[tid + 256 * i];
+    const float b2v = tid < LT_N2 ? b2[tid] : 0.f;
 
     unsigned char* patch = smem + LT_WAVE0 + wave * LT_WAVE_BYTES;
 
@@ -194,7 +158,6 @@ __global__ __launch_bounds__(256, 1) void f0_l2tail_kernel(const uint16_t* __res
                 for (int e = 0; e < 4; ++e) acc[blk][4 * q + e] = bq[e];
             }
     };
-    bias_acc();
     float* const pred_sink = reinterpret_cast<float*>(g_lt_sink) + lane;
     uint16_t* const dz_sink = reinterpret_cast<uint16_t*>(g_lt_sink) + lane * 8;
 
@@ -216,6 +179,42 @@ __global__ __launch_bounds__(256, 1) void f0_l2tail_kernel(const uint16_t* __res
         load_half(ha, tile, 0);
         load_half(hb, tile, 1);
     }
+    // ---- one-time: W2 (bf16 as it is), the two permuted W3 fragment tables, b2 ------------------------------------------
+    // W2 goes to LDS by LDS-DMA, one row (64 lanes x 16 B) per instruction and 32 rows per wave, all in flight at once with no
+    // register staging: lane p of row n fetches the chunk that belongs at position p, c = p ^ (n & 15).  (A copy loop of load ->
+    // store pairs cost ~15 us per launch, batches of eight loads in front of eight stores still four trips to L2 - and at the
+    // phone-rate row count the whole kernel is one tile per wave behind this prologue.)
+    {
+        unsigned short* w3s = reinterpret_cast<unsigned short*>(smem + LT_WAVE0);       // W3 as bf16 [32][128], staged in the patches
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int n = wave * 32 + i;
+            mg_glds16(W2 + (size_t)n * ldw2 + ((lane ^ (n & 15)) << 3), smem + LT_W2 + n * (LT_K * 2));
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w3s[tid + 256 * i] = mg_f2bf(w3v[i]);
+        if (tid < LT_N2) *reinterpret_cast<float*>(smem + LT_B2 + tid * 4) = b2v;
+        __syncthreads();
+        // fragment f = tid + 256 i: f < 512 -> Z3 fragments [st = 2 blk + s][lane]: element j = W3[lane & 31][unit of B slot j];
+        //                           f >= 512 -> dH2 fragments [kt][s][lane]: element j = W3[unit3 of slot j][32 kt + (lane & 31)]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + 256 * i, l = f & 63, r = l & 31, h = l >> 5, g = (f >> 6) & 7;
+            unsigned short el[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int u = 8 * (j >> 2) + 4 * h + (j & 3);                             // slot j of lane half h inside a 16-unit step
+                el[j] = (f < 512) ? w3s[r * LT_N2 + 16 * g + u] : w3s[(16 * (g & 1) + u) * LT_N2 + 32 * (g >> 1) + r];
+            }
+            *reinterpret_cast<u32x4*>(smem + LT_ZF + f * 16) = u32x4{el[0] | ((unsigned)el[1] << 16), el[2] | ((unsigned)el[3] << 16),
+                                                                   el[4] | ((unsigned)el[5] << 16), el[6] | ((unsigned)el[7] << 16)};
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's rows of W2 have landed (the compiler does not count the DMAs)
+        __syncthreads();                                   // the staged W3 is done with: its bytes become the waves' patches
+    }
+
+    bias_acc();
+
     for (; tile < n_tiles; tile += stride) {
         const int64_t m = tile * 32 + mi;
         const bool live = m < M;
