@@ -52,6 +52,9 @@ def parse_args():
                     help='c2: launch every kernel of the step from Python instead of replaying the captured HIP graph')
     ap.add_argument('--no-compare', action='store_true',
                     help='c2: skip the extra leg that times the frame-rate order of operations (frame_rate_order in the JSON line)')
+    ap.add_argument('--rehearse-exchange', action='store_true',
+                    help='one rank only: run the MULTI-rank code path (gradient buckets, all-reduce through a world-size-1 RCCL group, '
+                         'no deferred slabs) - what a rank of an N-GPU job executes per step, without the peers')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     return ap.parse_args()
@@ -572,7 +575,15 @@ def main():
     if args.precision == 'bf16':
         data.add_bf16_table(features)    # loader-side half of bf16 mode: the phone table's bf16 copy is made when the batch is loaded
     frames_per_step = int(feats_np['n_frames'].sum())
-    optimizer = optim.Adam(model.parameters(), lr=0.01, fused_loop=True)    # the loop below is the reference's loop body
+    rehearse = bool(args.rehearse_exchange) and world == 1
+    if rehearse:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(dev)
+        torch.distributed.init_process_group(backend='nccl', rank=0, world_size=1)
+    # the loop below is the reference's loop body
+    optimizer = optim.Adam(model.parameters(), lr=0.01, fused_loop=True, exchange_always=rehearse)
 
     def step():
         optimizer.zero_grad()
@@ -691,6 +702,8 @@ def main():
         if graph_note is not None:
             result['config']['launch'] = graph_note
             result['config']['steps_per_graph_launch'] = per_call      # every step does all of its work; the launch gap is shared
+        if rehearse:
+            result['config']['rehearsal'] = 'multi-rank code path on one rank (world-size-1 RCCL group): not the headline form'
         if frame_rate is not None:
             result['frame_rate_order'] = frame_rate
         if args.config == 'c2':

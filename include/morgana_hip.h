@@ -318,6 +318,10 @@ int mg_linear_wgrad_slabs_bf16(const uint16_t* dY, int lddy, const uint16_t* A, 
  * launches.  Needs a wide-tile weight-gradient shape (as mg_linear_wgrad_slabs_bf16: MG_EINVAL otherwise); workspace as there. */
 int mg_linear_wgrad_dgrad_bf16(const uint16_t* dY, int lddy, const uint16_t* A, int lda, int64_t M, int N, int K, const uint16_t* WT, int ldwt,
                                uint16_t* dX, int lddx, void* workspace, size_t workspace_bytes, int* n_slabs, int64_t* stride, void* stream);
+/* dst[0 .. count) (+)= the ordered sum of n_slabs slabs, `stride` floats apart (the reduce launch of mg_linear_wgrad_bf16, bit for bit),
+ * for a caller that took slabs from mg_linear_wgrad_slabs_bf16 / mg_linear_wgrad_dgrad_bf16 and needs the finished gradient before the
+ * update (a data-parallel rank: its all-reduce comes first).  With db stored right behind dW (count = N*K + N) one launch does both. */
+int mg_slab_reduce_f32(const float* slab, int n_slabs, int64_t stride, int64_t count, float* dst, int accumulate, void* stream);
 /* Fused backward of Linear(K -> N) + Sigmoid feeding Linear(N -> N2): dW, db of the FIRST layer straight from dZ2, the
  * pre-activation gradient of the second one, without materialising dZ1 = (dZ2 W2) * H1 (1 - H1):
  *   dZ2 bf16 [M, lddz] (N2 = 128 columns); W2T = W2^T bf16 [N, ldwt]; H1 bf16 [M, ldh] (sigmoid outputs, N % 128 == 0);

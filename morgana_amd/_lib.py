@@ -62,6 +62,7 @@ SIGNATURES = {
                                            c_void_p, c_void_p, c_void_p]),
     'mg_linear_wgrad_dgrad_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                                            c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    'mg_slab_reduce_f32': (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_void_p]),
     'mg_adam_step_plan_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p,
                                       c_float, c_void_p, c_void_p]),
     'mg_cast_pad_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),

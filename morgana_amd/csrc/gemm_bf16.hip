@@ -615,4 +615,16 @@ int mg_phone_front_linear_fwd_bf16(const int64_t* dur, int B, int P, int T, cons
     return mg_linear_fwd_bf16(A, lda, nullptr, M, K, W, ldw, bias, N, Y, ldy, 0, act, stream);
 }
 
+// dst[0 .. count) (+)= the ordered sum of n_slabs slabs (stride floats apart): the library's slab reduce as a launch of its own, for a
+// caller that took split-M slabs (mg_linear_wgrad_slabs_bf16, mg_linear_wgrad_dgrad_bf16) and needs the finished gradient before
+// the update - a rank of a data-parallel job, whose all-reduce comes first.  A slab is [N*K weights | N bias sums], so with the bias
+// gradient stored right behind the weight gradient one launch finishes both.  Bit for bit mg_linear_wgrad_bf16's own reduce.
+int mg_slab_reduce_f32(const float* slab, int n_slabs, int64_t stride, int64_t count, float* dst, int accumulate, void* stream) {
+    MG_CHECK_ARG(slab && dst && n_slabs >= 1 && count > 0 && stride >= count, "mg_slab_reduce_f32: bad arguments (n_slabs=%d stride=%lld count=%lld)",
+                 n_slabs, (long long)stride, (long long)count);
+    mg_launch_slab_reduce(slab, count, stride, n_slabs, dst, accumulate, (hipStream_t)stream);
+    MG_CHECK_LAUNCH("mg_slab_reduce_f32");
+    return MG_OK;
+}
+
 }  // extern "C"

@@ -307,12 +307,28 @@ def _grad_mode(params, grad_loss):
     return 'direct', opt
 
 
-def _wgrad_into(mode, opt, w_param, b_param, g, a_in, rows, m, n, k):
-    """dW, db of one layer into the optimiser: deferred slabs where the shape has them, else reduced into .grad (accumulating)."""
-    if mode == 'defer' and ops.wgrad_slabs_ok(m, n, k, a_in.shape[1], g.shape[1]):
-        slab, n_slabs, stride = ops.linear_wgrad_slabs_bf16(g, a_in, rows, m, n, k, slab=getattr(w_param, '_mg_slab_buf', None))
-        w_param._mg_slab_buf = slab                      # one buffer per layer, reused every step (and by every graph replay)
+def _grads_adjacent(w_param, b_param):
+    """Is b.grad stored right behind W.grad (the optimiser's flat layout)?  Then one slab reduce finishes both."""
+    return (w_param.grad is not None and b_param.grad is not None and w_param.grad.is_contiguous() and
+            b_param.grad.data_ptr() == w_param.grad.data_ptr() + 4 * w_param.numel())
+
+
+def _slabs_into(mode, opt, w_param, b_param, slab, n_slabs, stride, n, k):
+    """Split-M slabs of one layer's dW | db to the optimiser: left for the update kernel to sum ('defer'), or summed now into .grad
+    (accumulating) by one reduce launch - a data-parallel rank needs the finished gradient for its all-reduce."""
+    w_param._mg_slab_buf = slab                          # one buffer per layer, reused every step (and by every graph replay)
+    if mode == 'defer':
         opt.defer_slabs(w_param, n * k + n, slab, n_slabs, stride)
+    else:
+        ops.slab_reduce(slab, n_slabs, stride, n * k + n, w_param.grad.reshape(-1).as_strided((n * k + n,), (1,)), accumulate=True)
+
+
+def _wgrad_into(mode, opt, w_param, b_param, g, a_in, rows, m, n, k):
+    """dW, db of one layer into the optimiser: as slabs where the shape has them (_slabs_into), else reduced into .grad (accumulating)
+    by the weight-gradient entry point's own two reduce launches."""
+    if ops.wgrad_slabs_ok(m, n, k, a_in.shape[1], g.shape[1]) and (mode == 'defer' or _grads_adjacent(w_param, b_param)):
+        slab, n_slabs, stride = ops.linear_wgrad_slabs_bf16(g, a_in, rows, m, n, k, slab=getattr(w_param, '_mg_slab_buf', None))
+        _slabs_into(mode, opt, w_param, b_param, slab, n_slabs, stride, n, k)
     else:
         ops.linear_wgrad_bf16(g, a_in, rows, m, n, k, out_w=w_param.grad, out_b=b_param.grad, accumulate=True)
 
@@ -478,15 +494,15 @@ class LinearStackMSEFn(torch.autograd.Function):
             top = lead - 1                                            # the 128-wide layer: its dZ came out of the fused tail
             n, k = ctx.dims[top]
             g_below = None
-            if (mode == 'defer' and ctx.phone_rate and top > 0 and ctx.acts[top - 1] == ops.ACT_SIGMOID and
-                    ops.wgrad_slabs_ok(m_rows, n, k, hidden[top - 1].shape[1], g.shape[1])):
+            if (ctx.phone_rate and top > 0 and ctx.acts[top - 1] == ops.ACT_SIGMOID and
+                    ops.wgrad_slabs_ok(m_rows, n, k, hidden[top - 1].shape[1], g.shape[1]) and
+                    (mode == 'defer' or _grads_adjacent(params[2 * top], params[2 * top + 1]))):
                 # this layer's weight gradient and the dgrad + sigmoid backward below it are independent and each fills part of the
                 # chip: one grid for both (mg_linear_wgrad_dgrad_bf16)
                 w_param = params[2 * top]
                 slab, n_slabs, stride, g_below = ops.linear_wgrad_dgrad_bf16(g, hidden[top - 1], m_rows, n, k, w_t[top],
                                                                              slab=getattr(w_param, '_mg_slab_buf', None))
-                w_param._mg_slab_buf = slab
-                opt.defer_slabs(w_param, n * k + n, slab, n_slabs, stride)
+                _slabs_into(mode, opt, w_param, params[2 * top + 1], slab, n_slabs, stride, n, k)
             else:
                 _wgrad_into(mode, opt, params[2 * top], params[2 * top + 1], g, hidden[top - 1] if top > 0 else a0,
                             None if top > 0 else r0, m_rows, n, k)

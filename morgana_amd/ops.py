@@ -433,6 +433,17 @@ def linear_wgrad_dgrad_bf16(dy, a, m, n, k, wt_bf16, slab=None):
     return slab, n_slabs.value, stride.value, dx
 
 
+def slab_reduce(slab, n_slabs, stride, count, dst, accumulate=False):
+    """dst[:count] (+)= ordered sum of the n_slabs slabs (f32, ``stride`` floats apart) in ``slab`` (a byte or float buffer): the reduce
+    launch of linear_wgrad_bf16 on slabs taken from linear_wgrad_slabs_bf16 / linear_wgrad_dgrad_bf16 (mg_slab_reduce_f32)."""
+    dst = _require(dst, torch.float32, 'dst')
+    if dst.numel() < count:
+        raise ValueError('slab_reduce: destination of %d floats for %d sums' % (dst.numel(), count))
+    _lib.check(_lib.load().mg_slab_reduce_f32(_p(slab), int(n_slabs), int(stride), int(count), _p(dst), int(bool(accumulate)), _stream()),
+               'mg_slab_reduce_f32')
+    return dst
+
+
 def can_fuse_bwd(m, n2, n_hidden, k0, lda0):
     """Shapes mg_linear_bwd_fused_bf16 handles (the README F0Model's first two layers at training batch sizes)."""
     return n2 == 128 and n_hidden % 128 == 0 and 512 < k0 <= 608 and lda0 == 640 and m >= 4096

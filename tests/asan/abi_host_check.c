@@ -104,6 +104,7 @@ int main(void) {
                                                                                                          0, 0, NULL, 0, &ns, (int64_t*)&st, NULL)); }
     { int ns = 0; long long st = 0; expect_code("linear_wgrad_dgrad(null)", mg_linear_wgrad_dgrad_bf16(NULL, 0, NULL, 0, 0, 0, 0, NULL, 0, NULL, 0, NULL, 0,
                                                                                                &ns, (int64_t*)&st, NULL)); }
+    expect_code("slab_reduce(null)", mg_slab_reduce_f32(NULL, 0, 0, 0, NULL, 0, NULL));
     expect_code("phone_front(null)", mg_phone_front(NULL, 0, 0, 0, NULL, NULL, 0, NULL, NULL, 0, NULL, NULL, NULL, NULL, NULL, 0, NULL));
     expect_code("phone_front_linear_fwd(null)", mg_phone_front_linear_fwd_bf16(NULL, 0, 0, 0, NULL, NULL, 0, NULL, NULL, 0, NULL, NULL, NULL, NULL, NULL, 0,
                                                                                NULL, 0, 0, 0, NULL, 0, NULL, 0, NULL, 0, 0, NULL));

@@ -193,18 +193,23 @@ def test_rccl_world1_graphed_step_equals_single_rank():
     """First contact with RCCL: a world-size-1 ``nccl`` process group on the one GPU.  ``GraphedTrainStep`` is forced onto its
     multi-rank path (forward + backward + early bucket exchange captured while the process group's watchdog thread is alive, the
     gradient all-reduce through RCCL, the Adam kernel behind it) and must reproduce the single-rank graphed step bit for bit: an
-    all-reduce over one rank is the identity and 1/world = 1."""
+    all-reduce over one rank is the identity and 1/world = 1.  Two batches: a small one (generic kernels) and C2's 256 x 1000 frames,
+    where the single-rank step leaves its weight-gradient slabs to the update kernel and the multi-rank step sums the same slabs with
+    one reduce launch per layer in front of the exchange (mg_slab_reduce_f32) - the same sums in the same order."""
     import torch.distributed as dist
     from morgana_amd import graphs
-    feats = data.to_device(synthetic.make_batch(32, 200, seed=8), DEV)
+    batches = [data.to_device(synthetic.make_batch(32, 200, seed=8), DEV), data.to_device(synthetic.make_batch(256, 1000, seed=9), DEV)]
+    data.add_bf16_table(batches[1])
 
     def fresh(**kw):
         model = _load_state(models.F0Model(precision='bf16').to(DEV), synthetic.f0_model_state())
         return model, optim.Adam(model.parameters(), lr=0.01, **kw)
 
-    model_s, opt_s = fresh()
-    single = graphs.GraphedTrainStep(model_s, opt_s, feats, warmup=2)
-    losses_s = [single().clone() for _ in range(5)]
+    losses_s = []
+    for feats in batches:
+        model_s, opt_s = fresh()
+        single = graphs.GraphedTrainStep(model_s, opt_s, feats, warmup=2)
+        losses_s.append([single().clone() for _ in range(5)])
 
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29531')
@@ -215,12 +220,15 @@ def test_rccl_world1_graphed_step_equals_single_rank():
         probe = torch.arange(8, dtype=torch.float32, device=DEV)
         dist.all_reduce(probe)                                   # RCCL communicator creation + one real collective
         assert torch.equal(probe, torch.arange(8, dtype=torch.float32, device=DEV))
-        model_m, opt_m = fresh(exchange_always=True)
-        multi = graphs.GraphedTrainStep(model_m, opt_m, feats, warmup=2)
-        assert multi._multi, 'the multi-rank path was not taken'
-        losses_m = [multi().clone() for _ in range(5)]
+        losses_m = []
+        for feats in batches:
+            model_m, opt_m = fresh(exchange_always=True)
+            multi = graphs.GraphedTrainStep(model_m, opt_m, feats, warmup=2)
+            assert multi._multi, 'the multi-rank path was not taken'
+            losses_m.append([multi().clone() for _ in range(5)])
         torch.cuda.synchronize()
         mode = multi.exchange_mode
+        feats = batches[0]
         # two steps per graph launch on the multi-rank path (bench.py's form when the exchange is captured): 2 + 2 x 2 steps against the
         # first 6 of the single-rank run above; with an eager exchange the object falls back to one step per replay
         model_k, opt_k = fresh(exchange_always=True)
@@ -233,10 +241,11 @@ def test_rccl_world1_graphed_step_equals_single_rank():
         torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
-    assert [v.item() for v in losses_k] == [v.item() for v in losses_s[:4]]
+    assert [v.item() for v in losses_k] == [v.item() for v in losses_s[0][:4]]
     assert mode in ('captured', 'eager')
-    assert [v.item() for v in losses_m] == [v.item() for v in losses_s]
-    for key in ('param', 'exp_avg', 'exp_avg_sq'):
+    for got, want in zip(losses_m, losses_s):
+        assert [v.item() for v in got] == [v.item() for v in want]
+    for key in ('param', 'exp_avg', 'exp_avg_sq'):               # the C2 batch's optimisers (the last of each loop)
         assert torch.equal(opt_m.flat_buffers()[key], opt_s.flat_buffers()[key]), key
     print('RCCL world-1 graphed step: exchange mode = %s' % mode)
 

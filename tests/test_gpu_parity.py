@@ -547,10 +547,18 @@ def test_wgrad_dgrad_pair_equals_the_two_launches(m):
     lib.mg_set_tuning(4, n_slabs)
     try:
         slab2, n2, stride2 = ops.linear_wgrad_slabs_bf16(dy, h, None, m, n, k)
+        slab2 = slab2.clone()                                  # (the workspace of the next call may be this buffer)
+        dw_same, db_same = ops.linear_wgrad_bf16(dy, h, None, m, n, k)       # the same splits, reduced by the entry point itself
     finally:
         lib.mg_set_tuning(4, 0)
     assert (n2, stride2) == (n_slabs, stride)
     assert torch.equal(got, slab2.view(torch.float32)[:n2 * stride2])
+    # mg_slab_reduce_f32 (what a data-parallel rank runs on the slabs before its all-reduce): dW | db in one launch, bit for bit the
+    # weight-gradient entry point's own two reduces; accumulating on top of what the destination holds
+    both = ops.slab_reduce(slab, n_slabs, stride, n * k + n, torch.empty(n * k + n, device=DEV))
+    assert torch.equal(both[:n * k].view(n, k), dw_same) and torch.equal(both[n * k:], db_same)
+    twice = ops.slab_reduce(slab, n_slabs, stride, n * k + n, both.clone(), accumulate=True)
+    np.testing.assert_allclose(twice.cpu().numpy(), (both + both).cpu().numpy(), rtol=1e-5, atol=1e-5)
     # and the sum of the slabs is the weight gradient
     dw, db = ops.linear_wgrad_bf16(dy, h, None, m, n, k)
     tot = got.view(n_slabs, stride).double().sum(0)
