@@ -329,6 +329,11 @@ def _wgrad_into(mode, opt, w_param, b_param, g, a_in, rows, m, n, k):
     if ops.wgrad_slabs_ok(m, n, k, a_in.shape[1], g.shape[1]) and (mode == 'defer' or _grads_adjacent(w_param, b_param)):
         slab, n_slabs, stride = ops.linear_wgrad_slabs_bf16(g, a_in, rows, m, n, k, slab=getattr(w_param, '_mg_slab_buf', None))
         _slabs_into(mode, opt, w_param, b_param, slab, n_slabs, stride, n, k)
+    elif ops.wgrad_wide_ok(m, n, k, a_in.shape[1], g.shape[1]) and _grads_adjacent(w_param, b_param):
+        # frame-rate row counts: 192-256 slabs, which a reduce launch of its own sums as fast as the update kernel would - one launch
+        # for dW | db instead of the entry point's two
+        slab, n_slabs, stride = ops.linear_wgrad_slabs_bf16(g, a_in, rows, m, n, k, slab=getattr(w_param, '_mg_slab_buf', None))
+        _slabs_into('direct', opt, w_param, b_param, slab, n_slabs, stride, n, k)
     else:
         ops.linear_wgrad_bf16(g, a_in, rows, m, n, k, out_w=w_param.grad, out_b=b_param.grad, accumulate=True)
 

@@ -403,6 +403,13 @@ def wgrad_slabs_ok(m, n, k, lda, lddy):
             ((lda == 640 and 512 < k <= 640) or (lda == 512 and 384 < k <= 512)))
 
 
+def wgrad_wide_ok(m, n, k, lda, lddy):
+    """Shapes whose weight gradient runs on the wide-tile kernel at all (any row count from 4096 up): its slabs can be taken with
+    linear_wgrad_slabs_bf16 and summed by ONE slab_reduce launch (dW | db together) instead of linear_wgrad_bf16's two."""
+    return (m >= 4096 and n % 128 == 0 and lddy >= n and lddy % 8 == 0 and
+            ((lda == 640 and 512 < k <= 640) or (lda == 512 and 384 < k <= 512)))
+
+
 def linear_wgrad_slabs_bf16(dy, a, rows, m, n, k, slab=None):
     """linear_wgrad_bf16 without the reduce: returns (slab buffer, n_slabs, stride); slab s holds [n*k weight partials | n bias
     partials].  ``slab`` = a buffer to reuse (kept by the caller until the optimiser has consumed it)."""
