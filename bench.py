@@ -36,8 +36,10 @@ F0_FLOPS_PER_FRAME = 1646784.0
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=None,
+                    help='timed steps (default 200 for c2 - a 0.13 ms step: the barrier + synchronize around the timed region and the gaps '
+                         'between graph launches weigh 4 %% on 30 steps - and 30 for the recurrent configs)')
+    ap.add_argument('--warmup', type=int, default=None, help='untimed steps in front (default 20 for c2, 5 otherwise)')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--config', default='c2', choices=['c2', 'c4', 'c5', 'lstm', 'f0gru'],
                     help='c2: F0Model 256x1000 (headline); c4: GRU-512 600->80, 64x1000; c5: GRU-512 600->187, 64 ragged 300-2000; '
@@ -57,7 +59,12 @@ def parse_args():
                          'no deferred slabs) - what a rank of an N-GPU job executes per step, without the peers')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 200 if args.config == 'c2' else 30
+    if args.warmup is None:
+        args.warmup = 20 if args.config == 'c2' else 5
+    return args
 
 
 def time_kernel(fn, iters=10, warm=2, graph=False):

@@ -13,6 +13,6 @@ run 900 tests.log python -m pytest tests -m gpu -q --tb=short -p no:cacheprovide
 tail -n 40 gpurun_out/tests.log
 run 300 smoke.log python -c "import __graft_entry__ as g; g.smoke()"
 tail -n 5 gpurun_out/smoke.log
-run 600 bench.log python bench.py --steps 20 --warmup 5 ${BENCH_ARGS}
+run 600 bench.log python bench.py ${BENCH_ARGS}
 tail -n 5 gpurun_out/bench.log
 exit 0
