@@ -46,6 +46,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define LT_WAVE_BYTES 2048
 #define LT_LDS (LT_WAVE0 + 4 * LT_WAVE_BYTES)            // 156,160 B: one workgroup per CU
 
+MG_STAMP_DECL(g_stamps_lt);
 __device__ unsigned int g_lt_sink[512];                   // where the stores of rows past M go (no branch around a store)
 
 // 16 x 16-bit transposed fragment of a [32 rows][64 B] patch: lane gets column 16 (g & 1) + (lane & 15)... as the 32x32x16 A / B
@@ -76,6 +77,11 @@ __global__ __launch_bounds__(256, 1) void f0_l2tail_kernel(const uint16_t* __res
     __shared__ __attribute__((aligned(16))) unsigned char smem[LT_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mi = lane & 31, lh = lane >> 5;
+#ifdef MG_STAMPS
+    unsigned long long ts0, ts1, ts2, ts3, tr0, tr1, ta = 0, tb = 0, tc = 0;
+    MG_STAMP(ts0);
+    MG_STAMP_REAL(tr0);
+#endif
 
     // The loads of the one-time tables go out first, the first tile's rows and scalars behind them and the LDS-DMA of W2 last (vector
     // memory returns in issue order): the W3 staging below waits for its own sixteen loads only, everything else lands meanwhile.
@@ -214,8 +220,12 @@ __global__ __launch_bounds__(256, 1) void f0_l2tail_kernel(const uint16_t* __res
     }
 
     bias_acc();
+    MG_STAMP(ts1);
 
     for (; tile < n_tiles; tile += stride) {
+#ifdef MG_STAMPS
+        if (ta == 0) MG_STAMP(ta);
+#endif
         const int64_t m = tile * 32 + mi;
         const bool live = m < M;
         const float tg = tg_n, s1 = s1_n, s2 = s2_n;
@@ -266,6 +276,9 @@ __global__ __launch_bounds__(256, 1) void f0_l2tail_kernel(const uint16_t* __res
                 __builtin_amdgcn_sched_group_barrier(0x020, 16, 0);
             }
         }
+#ifdef MG_STAMPS
+        if (tb == 0) MG_STAMP(tb);
+#endif
         load_half_p(hb, next, 1);
         if (PROBE & 2) {
 #pragma unroll
@@ -401,19 +414,24 @@ __global__ __launch_bounds__(256, 1) void f0_l2tail_kernel(const uint16_t* __res
         }
         dzp = live ? dZ2 + (size_t)m * lddz + 8 * lh : dz_sink;
         bias_acc();                                         // the next tile's accumulators (their registers were free until here)
+#ifdef MG_STAMPS
+        if (tc == 0) MG_STAMP(tc);
+#endif
     }
+    MG_STAMP(ts2);
     *predp = pst;                                          // the last tile's results
 #pragma unroll
     for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4*>(dzp + 32 * (i >> 1) + 16 * (i & 1)) = dzst[i];
 
     // ---- reduction: lanes (frames) -> wave -> workgroup, fixed order (as tail_bf16.hip) -----------------------------------
+    // over the 32 lanes of a half: the halves of 16 through the crossbar, the rest on the DPP path (mg_row16_sum: bit for bit the xor
+    // butterfly 8, 4, 2, 1 - 128 of the 160 cross-lane moves of a wave leave the LDS pipe)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) {
-            dw4p[r] += __shfl_xor(dw4p[r], off, 64);
-            db3p[r] += __shfl_xor(db3p[r], off, 64);
-        }
+        dw4p[r] += __shfl_xor(dw4p[r], 16, 64);
+        db3p[r] += __shfl_xor(db3p[r], 16, 64);
+        dw4p[r] = mg_row16_sum(dw4p[r]);
+        db3p[r] = mg_row16_sum(db3p[r]);
     }
     db4p = mg_wave_sum(db4p);
     lossp = mg_wave_sum(lossp);
@@ -444,6 +462,19 @@ __global__ __launch_bounds__(256, 1) void f0_l2tail_kernel(const uint16_t* __res
     __syncthreads();
     float* out = slab + (size_t)blockIdx.x * LT_SLAB;
     for (int e = tid; e < LT_SLAB; e += 256) out[e] = ((red[e] + red[LT_SLAB + e]) + red[2 * LT_SLAB + e]) + red[3 * LT_SLAB + e];
+#ifdef MG_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MG_STAMP(ts3);
+    MG_STAMP_REAL(tr1);
+    MG_STAMP_STORE(g_stamps_lt, blockIdx.x, wave, lane, 0, ts0);
+    MG_STAMP_STORE(g_stamps_lt, blockIdx.x, wave, lane, 1, ts1);
+    MG_STAMP_STORE(g_stamps_lt, blockIdx.x, wave, lane, 2, ts2);
+    MG_STAMP_STORE(g_stamps_lt, blockIdx.x, wave, lane, 3, ts3);
+    MG_STAMP_STORE(g_stamps_lt, blockIdx.x, wave, lane, 4, tr0);
+    MG_STAMP_STORE(g_stamps_lt, blockIdx.x, wave, lane, 5, tr1);
+    MG_STAMP_STORE(g_stamps_lt, blockIdx.x, wave, lane, 6, tb - ta);      // first tile: loop top -> layer-2 MFMAs issued
+    MG_STAMP_STORE(g_stamps_lt, blockIdx.x, wave, lane, 7, tc - tb);      // first tile: the tail (sigmoid .. dW3)
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -934,5 +965,11 @@ int mg_f0_l2tail_rows_slabs_bf16(const uint16_t* H1, int ldh1, int K2, const uin
                             (int)(M < 2147483647LL ? M : 1), grad_scale, pred, nullptr, dZ2, lddz, nullptr, 0, workspace, workspace_bytes, stream,
                             n_slabs);
 }
+
+#ifdef MG_STAMPS
+int mg_diag_read_stamps_lt(void* dst, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps_lt), bytes < sizeof(g_stamps_lt) ? bytes : sizeof(g_stamps_lt), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 }  // extern "C"

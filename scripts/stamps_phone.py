@@ -51,6 +51,21 @@ def main():
     report('wgrad_big<8> layer-2 weight gradient at phone rate (96 splits, 7 steps each)', s,
            [('  loop: vmcnt wait + barrier', s[..., 6]), ('  loop: LDS-DMA issue', s[..., 7])])
 
+    # layers 2-4 + loss + backward in one pass (one 32-row tile per wave at this row count)
+    w3, b3 = torch.randn(32, 128, device=dev) * 0.1, torch.zeros(32, device=dev)
+    w4, b4 = torch.randn(1, 32, device=dev) * 0.1, torch.zeros(1, device=dev)
+    ybar, weight = torch.randn(r_tab, device=dev), torch.rand(r_tab, device=dev) / r_tab
+    grads = torch.empty(4162, device=dev)
+    for _ in range(3):
+        ops.f0_l2tail_rows(h1, w2b, b2, w3, b3, w4, b4, ybar, weight, grads)
+    torch.cuda.synchronize()
+    s = read(lib, 'mg_diag_read_stamps_lt', 168)
+    t_start, t_end = s[:, 0, 4], s[:, 0, 5]                      # 100 MHz real-time clock at wave start / end, wave 0 of each workgroup
+    print('f0_l2tail_kernel: workgroup starts spread over %.2f us, ends over %.2f us; first start -> last end %.2f us' % (
+        (t_start.max() - t_start.min()) / 100.0, (t_end.max() - t_end.min()) / 100.0, (t_end.max() - t_start.min()) / 100.0))
+    report('f0_l2tail_kernel at phone rate (168 workgroups, one tile per wave; "main loop" = the tile, "entry" = the prologue)', s,
+           [('  tile: loop top -> layer-2 MFMAs issued', s[..., 6]), ('  tile: the tail (sigmoid .. dW3)', s[..., 7])])
+
 
 if __name__ == '__main__':
     main()
