@@ -923,19 +923,30 @@ __global__ __launch_bounds__(512) void phone_front_gemm_kernel(unsigned side_blo
 #define WG_STAGES 3
 MG_STAMP_DECL(g_stamps_wg);
 
-#define WG_BIG_LDS(TKW_) (WG_STAGES * (32 * 256 + 32 * 64 * (TKW_) * 2) + WG_ROWS_MAX * 4)
+// X tile row pitch: the k columns of the tile, rounded up to whole groups of 16 chunks (the chunk swizzle XORs bits 2-3 of the chunk index)
+#define WG_BIG_PX(TKW_) ((64 * (TKW_) * 2 + 255) / 256 * 256)
+#define WG_BIG_LDS(TKW_) (WG_STAGES * (32 * 256 + 32 * WG_BIG_PX(TKW_)) + WG_ROWS_MAX * 4)
 template <int TKW>
 __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem, const unsigned block_id, const uint16_t* __restrict__ dY,
                                                int lddy, const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows, int64_t M,
                                                int N, int K, int m_chunk, float* __restrict__ slab, float* __restrict__ bslab, int64_t sstride,
                                                int xcd_group) {
+    // TKW = 10 / 8: the workgroup's tile is 128 x 640 / 128 x 512 (all k columns of the operand), 2 waves along n x 4 along k.
+    // TKW = 5: 128 x 320 - HALF the k columns, two k halves per n tile (KH = 2), 4 waves along n x 2 along k: the same five k tiles per
+    // wave with one n tile instead of two.  Twice the tiles per split means two thirds of the splits for a full chip (8 x 32 instead of
+    // 4 x 48 workgroups at the phone-rate rows of C2): a third less slab traffic and half the epilogue per workgroup.
     constexpr int BNT = 128, BKT = 64 * TKW;
-    constexpr int TKT = BKT / 4 / 32;             // 32-column MFMA tiles per wave along k (4 waves along k): 5 or 4
-    constexpr int PY = BNT * 2, PX = BKT * 2;     // LDS row pitches in bytes: 256, 1280 / 1024
+    constexpr int WK = TKW == 5 ? 2 : 4;          // waves along k
+    constexpr int KH = TKW == 5 ? 2 : 1;          // k tiles per operand row
+    constexpr int TNW = BNT / 32 / (8 / WK);      // 32-row MFMA tiles per wave along n: 2 or 1
+    constexpr int TKT = BKT / WK / 32;            // 32-column MFMA tiles per wave along k: 5 or 4
+    constexpr int PY = BNT * 2, PX = WG_BIG_PX(TKW);      // LDS row pitches in bytes: 256; 1280 / 1024 / 768 (640 of it in use)
+    constexpr int XC = BKT * 2 / 16;              // 16-byte chunks of an X row that hold operand columns
     constexpr int Y_BYTES = 32 * PY, X_BYTES = 32 * PX;
     constexpr int STAGE = Y_BYTES + X_BYTES;
-    constexpr int NX = X_BYTES / 1024 / 8;        // X LDS-DMA instructions per wave per step: 5 or 4
+    constexpr int NX = X_BYTES / 1024 / 8;        // X LDS-DMA instructions per wave per step: 5, 4 or 3
     constexpr int NLW = 1 + NX;                   // + one for dY
+    static_assert(X_BYTES % 8192 == 0, "whole pieces per wave");
     constexpr int LDS_BYTES = WG_STAGES * STAGE + WG_ROWS_MAX * 4;
 
     static_assert(LDS_BYTES == WG_BIG_LDS(TKW), "LDS size helper");
@@ -948,22 +959,24 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
     MG_STAMP(ts0);
     MG_STAMP_REAL(tr0);
 #endif
-    const int wn0 = (wave >> 2) * 64;             // 2 waves along n
-    const int wk0 = (wave & 3) * (TKT * 32);      // 4 waves along k
+    const int wn0 = (wave / WK) * (TNW * 32);     // 2 (4) waves along n
+    const int wk0 = (wave % WK) * (TKT * 32);     // 4 (2) waves along k
     // Block order: n tile fastest, then split (measured: grouping the n tiles of a split on one XCD so that they share the
     // gathered X rows through its L2 was 15 % SLOWER, 249 vs 217 us on the C2 layer-1 shape).
     // xcd_group: blocks b, b + 8, b + 16, ... share an XCD (and its L2): give them the n tiles of ONE split, so the split's X rows
     // leave HBM once (phone-rate shapes, where X is a streamed table rather than an L2-resident set of gathered rows).  The number
     // of splits is a multiple of 8 (mg_wgrad_big_plan).
-    const int tiles_n = N / BNT;
-    int n0, s;
+    const int tiles = (N / BNT) * KH;             // workgroups per split: n tiles x k halves, k half fastest
+    int tile, s;
     if (xcd_group) {
-        n0 = ((block_id >> 3) % tiles_n) * BNT;
-        s = (block_id / (8 * tiles_n)) * 8 + (block_id & 7);
+        tile = (block_id >> 3) % tiles;
+        s = (block_id / (8 * tiles)) * 8 + (block_id & 7);
     } else {
-        n0 = (block_id % tiles_n) * BNT;
-        s = block_id / tiles_n;
+        tile = block_id % tiles;
+        s = block_id / tiles;
     }
+    const int n0 = (tile / KH) * BNT;
+    const int kh = tile % KH, k0 = kh * BKT;       // this workgroup's k columns: [k0, k0 + BKT)
     const int64_t m_lo = (int64_t)s * m_chunk;
     const int64_t m_hi = min(M, m_lo + (int64_t)m_chunk);
     const int n_rows = m_hi > m_lo ? (int)(m_hi - m_lo) : 0;     // trailing splits may be empty: they write zero slabs
@@ -986,7 +999,8 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
         const int byte = (wave * NX + i) * 1024 + lane * 16;
         x_row[i] = byte / PX;
         const int cpos = (byte % PX) >> 4;
-        x_off[i] = (cpos ^ ((x_row[i] & 3) << 2)) * 8;
+        const int src = cpos ^ ((x_row[i] & 3) << 2);         // source chunk that belongs at this position
+        x_off[i] = src < XC ? k0 + src * 8 : -1;              // (-1: a position of the pitch's padding - filled from the zero row)
     }
 
     auto issue = [&](int step) {                 // rows [32 step, 32 step + 32) of this workgroup's range
@@ -1001,14 +1015,14 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
         for (int i = 0; i < NX; ++i) rr[i] = row_lds[step * 32 + x_row[i]];     // all index reads first: one lgkmcnt wait
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const uint16_t* p = (rr[i] >= 0) ? A + (size_t)rr[i] * lda + x_off[i] : g_zero_row;
+            const uint16_t* p = (rr[i] >= 0 && x_off[i] >= 0) ? A + (size_t)rr[i] * lda + x_off[i] : g_zero_row;
             glds16(p, st + Y_BYTES + (wave * NX + i) * 1024);
         }
     };
 
-    f32x16 acc[2][TKT];
+    f32x16 acc[TNW][TKT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TNW; ++i)
 #pragma unroll
         for (int j = 0; j < TKT; ++j)
 #pragma unroll
@@ -1016,11 +1030,12 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
     // Bias gradient db[n] = sum_m dY[m][n] rides on the matrix pipe: dY^T times a block of ones.  With K <= BKT - 32 the
     // last 32-column tile of the k-wave 3 is pure padding, so its B fragment is replaced by ones (no extra MFMA, no
     // extra registers); otherwise k-wave 0 carries two extra accumulators (TKW == 8 has the registers for it).
+    // (TKW == 5: the padding tile, if there is one, is the last tile of the UPPER k half; the lower half's workgroups form no sums.)
     constexpr bool kExtraBias = (TKW == 8);
-    const bool free_tile = !kExtraBias && K <= BKT - 32;
-    const bool bias_free = bslab != nullptr && free_tile && (wave & 3) == 3;
+    const bool free_tile = !kExtraBias && K <= KH * BKT - 32;
+    const bool bias_free = bslab != nullptr && free_tile && kh == KH - 1 && (wave % WK) == WK - 1;
     const bool bias_extra = bslab != nullptr && kExtraBias && (wave & 3) == 0;
-    const bool bias_valu = bslab != nullptr && !kExtraBias && !free_tile;
+    const bool bias_valu = bslab != nullptr && !kExtraBias && !free_tile && kh == 0;
     f32x16 accb[kExtraBias ? 2 : 1];
 #pragma unroll
     for (int i = 0; i < (kExtraBias ? 2 : 1); ++i)
@@ -1038,9 +1053,9 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
     const int rbase = 8 * (g >> 1) + q;           // contraction row inside a 16-deep k-step
     // byte offsets of this lane's transposed reads for k-step 0 (k-step 1 = + 16 rows); row & 3 == q for both
     const int sw = q << 2;
-    int yoff[2], xoff[TKT];
+    int yoff[TNW], xoff[TKT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TNW; ++i) {
         const int col = wn0 + i * 32 + cgrp;
         yoff[i] = rbase * PY + ((((col >> 3) ^ sw) << 4) | ((col & 7) << 1));
     }
@@ -1055,7 +1070,7 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
     for (int step = 0; step < n_steps; ++step) {
         MG_STAMP(ta);
         if (step + 1 < n_steps) {
-            if (NLW == 6) WAIT_VM_BARRIER(6); else WAIT_VM_BARRIER(5);
+            if (NLW == 6) WAIT_VM_BARRIER(6); else if (NLW == 5) WAIT_VM_BARRIER(5); else WAIT_VM_BARRIER(4);
         } else {
             WAIT_VM_BARRIER(0);
         }
@@ -1070,9 +1085,9 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
         const unsigned char* st = smem + (step % WG_STAGES) * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bfv8 a[2], b[TKT];
+            bfv8 a[TNW], b[TKT];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < TNW; ++i) {
                 const unsigned char* ad = st + yoff[i] + ks * 16 * PY;
                 const bfv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(ad));
                 const bfv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(ad + 4 * PY));
@@ -1087,12 +1102,14 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
             }
             if (bias_free) b[TKT - 1] = ones;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TNW; ++i)
 #pragma unroll
                 for (int j = 0; j < TKT; ++j) acc[i][j] = mg_mfma_32x32x16(a[i], b[j], acc[i][j]);
-            if (kExtraBias && bias_extra) {
+            if constexpr (kExtraBias) {
+                if (bias_extra) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) accb[i] = mg_mfma_32x32x16(a[i], ones, accb[i]);
+                    for (int i = 0; i < 2; ++i) accb[i] = mg_mfma_32x32x16(a[i], ones, accb[i]);
+                }
             }
         }
         if (bias_valu && tid < BNT) {
@@ -1110,10 +1127,10 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
     const int lr = lane & 31, lh = lane >> 5;
     float* out = slab + (size_t)s * sstride;        // split s: [N*K weights | bias sums behind them when bslab = slab + N*K]
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TNW; ++i) {
 #pragma unroll
         for (int j = 0; j < TKT; ++j) {
-            const int col = wk0 + j * 32 + lr;
+            const int col = k0 + wk0 + j * 32 + lr;
             if (col >= K) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1125,7 +1142,7 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
     if (bias_valu && tid < BNT && n0 + tid < N) bslab[(size_t)s * sstride + n0 + tid] = bsum;
     if ((bias_free || bias_extra) && lr == 0) {            // every column of the ones-product holds the same sums
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TNW; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = n0 + wn0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -1247,6 +1264,11 @@ int mg_try_nt_big(const uint16_t* A, int lda, const int32_t* rows, int64_t M, in
     return 1;
 }
 
+// The 128 x 320 tile form (wgrad_big_body<5>: two k halves per n tile): phone-rate row counts of a 640-wide operand with 4+ n tiles
+static bool wgrad_ksplit(int64_t M, int N, int lda) {
+    return lda == 640 && M <= 32768 && N / 128 >= 4 && g_mg_tuning[MG_TUNE_PROBE] != 92;      // 92: A/B, the 128 x 640 tiles
+}
+
 // Plan of the split over M for the wide wgrad: S slabs of m_chunk rows.  Returns 0 if the shape does not qualify.
 int mg_wgrad_big_plan(int64_t M, int N, int K, int lda, int lddy, int* S_out, int* m_chunk_out) {
     if (M < 4096 || N % 128 != 0 || lddy < N || lddy % 8 != 0) return 0;
@@ -1256,6 +1278,7 @@ int mg_wgrad_big_plan(int64_t M, int N, int K, int lda, int lddy, int* S_out, in
     // phone-rate shapes (M ~ 2e4 rows): 48 splits x 4 n-tiles = 192 workgroups beat 64 x 4 (45.6 vs 49.7 us with the reduce at
     // M = 21 504, N = 512, K = 600: a third less partial-slab traffic); never more splits than the workspace was sized for
     if (M <= 32768 && tiles_n >= 4) S = 192 / tiles_n;
+    if (wgrad_ksplit(M, N, lda)) S = 256 / (2 * tiles_n);     // 8 tiles per split: 32 splits fill the chip, a third less slab traffic
     if (M <= 32768 && tiles_n == 1) S = 96;                  // N = 128 at the same M: 24.2 vs 27.7 us (224 splits write 59 MB of slabs)
     // N = 128 at frame-rate row counts (M = 256 000, K = 512): 192 splits of ~1 334 rows beat one split per CU - a quarter less slab
     // traffic (50 vs 67 MB written and read again by the reduce): 89.5 -> 80 us with the reduce (sweep 144 .. 512, scripts/kbench.py wgrad2)
@@ -1279,13 +1302,16 @@ int mg_wgrad_big_plan(int64_t M, int N, int K, int lda, int lddy, int* S_out, in
 
 int mg_launch_wgrad_big(const uint16_t* dY, int lddy, const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K,
                         int S, int m_chunk, float* slab, float* bslab, int64_t sstride, hipStream_t st) {
-    dim3 grid((unsigned)((N / 128) * S)), block(512);
+    const bool ksplit = wgrad_ksplit(M, N, lda);
+    dim3 grid((unsigned)((N / 128) * (ksplit ? 2 : 1) * S)), block(512);
     // block order: the n tiles of a split on one XCD when X is streamed (no gather: a table read once), n tile fastest when X is a
     // gathered, L2-resident set of rows (measured 15 % slower grouped on the C2 frame-rate shape)
     int xcd_group = (rows == nullptr && S % 8 == 0) ? 1 : 0;
     if (g_mg_tuning[MG_TUNE_WGRAD_ORDER] == 1) xcd_group = 0;
     if (g_mg_tuning[MG_TUNE_WGRAD_ORDER] == 2 && S % 8 == 0) xcd_group = 1;
-    if (lda == 640)
+    if (ksplit)
+        hipLaunchKernelGGL((wgrad_big_kernel<5>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
+    else if (lda == 640)
         hipLaunchKernelGGL((wgrad_big_kernel<10>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
     else
         hipLaunchKernelGGL((wgrad_big_kernel<8>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
