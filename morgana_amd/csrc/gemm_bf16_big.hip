@@ -920,12 +920,12 @@ __global__ __launch_bounds__(512) void phone_front_gemm_kernel(unsigned side_blo
 // Row indices of the workgroup's whole m range are parked in LDS first, so the loop issues no VGPR-destination loads.
 // ---------------------------------------------------------------------------------------------------------------------
 #define WG_ROWS_MAX 4096
-#define WG_STAGES 3
+#define WG_STAGES(TKW_) ((TKW_) == 5 ? 4 : 3)        // ring depth: the half-width tile has the LDS for a fourth stage
 MG_STAMP_DECL(g_stamps_wg);
 
 // X tile row pitch: the k columns of the tile, rounded up to whole groups of 16 chunks (the chunk swizzle XORs bits 2-3 of the chunk index)
 #define WG_BIG_PX(TKW_) ((64 * (TKW_) * 2 + 255) / 256 * 256)
-#define WG_BIG_LDS(TKW_) (WG_STAGES * (32 * 256 + 32 * WG_BIG_PX(TKW_)) + WG_ROWS_MAX * 4)
+#define WG_BIG_LDS(TKW_) (WG_STAGES(TKW_) * (32 * 256 + 32 * WG_BIG_PX(TKW_)) + WG_ROWS_MAX * 4)
 template <int TKW>
 __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem, const unsigned block_id, const uint16_t* __restrict__ dY,
                                                int lddy, const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows, int64_t M,
@@ -947,10 +947,11 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
     constexpr int NX = X_BYTES / 1024 / 8;        // X LDS-DMA instructions per wave per step: 5, 4 or 3
     constexpr int NLW = 1 + NX;                   // + one for dY
     static_assert(X_BYTES % 8192 == 0, "whole pieces per wave");
-    constexpr int LDS_BYTES = WG_STAGES * STAGE + WG_ROWS_MAX * 4;
+    constexpr int NSTG = WG_STAGES(TKW);
+    constexpr int LDS_BYTES = NSTG * STAGE + WG_ROWS_MAX * 4;
 
     static_assert(LDS_BYTES == WG_BIG_LDS(TKW), "LDS size helper");
-    int* row_lds = reinterpret_cast<int*>(smem + WG_STAGES * STAGE);
+    int* row_lds = reinterpret_cast<int*>(smem + NSTG * STAGE);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1004,7 +1005,7 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
     }
 
     auto issue = [&](int step) {                 // rows [32 step, 32 step + 32) of this workgroup's range
-        unsigned char* st = smem + (step % WG_STAGES) * STAGE;
+        unsigned char* st = smem + (step % NSTG) * STAGE;
         {
             const int ml = step * 32 + y_row;
             const uint16_t* p = (ml < n_rows) ? dY + (size_t)(m_lo + ml) * lddy + n0 + y_c * 8 : g_zero_row;
@@ -1065,11 +1066,15 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
         xoff[j] = Y_BYTES + rbase * PX + ((((col >> 3) ^ sw) << 4) | ((col & 7) << 1));
     }
 
-    if (n_steps > 0) issue(0);
-    if (n_steps > 1) issue(1);
+#pragma unroll
+    for (int p = 0; p < NSTG - 1; ++p)
+        if (p < n_steps) issue(p);
     for (int step = 0; step < n_steps; ++step) {
         MG_STAMP(ta);
-        if (step + 1 < n_steps) {
+        // stage `step` must have landed; up to NSTG - 2 younger stages (NLW LDS-DMA instructions each) may stay in flight
+        if (NSTG == 4 && step + 2 < n_steps) {
+            WAIT_VM_BARRIER(8);                   // (NSTG == 4 is the NLW == 4 variant)
+        } else if (step + 1 < n_steps) {
             if (NLW == 6) WAIT_VM_BARRIER(6); else if (NLW == 5) WAIT_VM_BARRIER(5); else WAIT_VM_BARRIER(4);
         } else {
             WAIT_VM_BARRIER(0);
@@ -1079,10 +1084,10 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
 #ifdef MG_STAMPS
         if (step == 0) ts1 = tb;
 #endif
-        if (step + 2 < n_steps) issue(step + 2);  // refills the stage every wave finished reading before this barrier
+        if (step + NSTG - 1 < n_steps) issue(step + NSTG - 1);        // refills the stage every wave finished reading before this barrier
         MG_STAMP(ta);
         MG_STAMP_ADD(sum_issue, ta, tb);
-        const unsigned char* st = smem + (step % WG_STAGES) * STAGE;
+        const unsigned char* st = smem + (step % NSTG) * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bfv8 a[TNW], b[TKT];
