@@ -920,7 +920,7 @@ __global__ __launch_bounds__(512) void phone_front_gemm_kernel(unsigned side_blo
 // Row indices of the workgroup's whole m range are parked in LDS first, so the loop issues no VGPR-destination loads.
 // ---------------------------------------------------------------------------------------------------------------------
 #define WG_ROWS_MAX 4096
-#define WG_STAGES(TKW_) ((TKW_) == 5 ? 4 : 3)        // ring depth: the half-width tile has the LDS for a fourth stage
+#define WG_STAGES(TKW_) (((TKW_) == 5 || (TKW_) == 4) ? 4 : 3)        // ring depth: the half-width tile has the LDS for a fourth stage
 MG_STAMP_DECL(g_stamps_wg);
 
 // X tile row pitch: the k columns of the tile, rounded up to whole groups of 16 chunks (the chunk swizzle XORs bits 2-3 of the chunk index)
@@ -936,8 +936,8 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
     // wave with one n tile instead of two.  Twice the tiles per split means two thirds of the splits for a full chip (8 x 32 instead of
     // 4 x 48 workgroups at the phone-rate rows of C2): a third less slab traffic and half the epilogue per workgroup.
     constexpr int BNT = 128, BKT = 64 * TKW;
-    constexpr int WK = TKW == 5 ? 2 : 4;          // waves along k
-    constexpr int KH = TKW == 5 ? 2 : 1;          // k tiles per operand row
+    constexpr int KH = (TKW == 5 || TKW == 4) ? 2 : 1;    // k tiles per operand row (TKW = 4: 128 x 256, the half of TKW = 8's tile)
+    constexpr int WK = KH == 2 ? 2 : 4;           // waves along k
     constexpr int TNW = BNT / 32 / (8 / WK);      // 32-row MFMA tiles per wave along n: 2 or 1
     constexpr int TKT = BKT / WK / 32;            // 32-column MFMA tiles per wave along k: 5 or 4
     constexpr int PY = BNT * 2, PX = WG_BIG_PX(TKW);      // LDS row pitches in bytes: 256; 1280 / 1024 / 768 (640 of it in use)
@@ -1032,14 +1032,14 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
     // last 32-column tile of the k-wave 3 is pure padding, so its B fragment is replaced by ones (no extra MFMA, no
     // extra registers); otherwise k-wave 0 carries two extra accumulators (TKW == 8 has the registers for it).
     // (TKW == 5: the padding tile, if there is one, is the last tile of the UPPER k half; the lower half's workgroups form no sums.)
-    constexpr bool kExtraBias = (TKW == 8);
+    constexpr bool kExtraBias = (TKW == 8 || TKW == 4);
     const bool free_tile = !kExtraBias && K <= KH * BKT - 32;
     const bool bias_free = bslab != nullptr && free_tile && kh == KH - 1 && (wave % WK) == WK - 1;
-    const bool bias_extra = bslab != nullptr && kExtraBias && (wave & 3) == 0;
+    const bool bias_extra = bslab != nullptr && kExtraBias && kh == 0 && (wave % WK) == 0;
     const bool bias_valu = bslab != nullptr && !kExtraBias && !free_tile && kh == 0;
-    f32x16 accb[kExtraBias ? 2 : 1];
+    f32x16 accb[kExtraBias ? TNW : 1];
 #pragma unroll
-    for (int i = 0; i < (kExtraBias ? 2 : 1); ++i)
+    for (int i = 0; i < (kExtraBias ? TNW : 1); ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
     const __bf16 one_bf = (__bf16)1.0f;
@@ -1073,9 +1073,9 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
         MG_STAMP(ta);
         // stage `step` must have landed; up to NSTG - 2 younger stages (NLW LDS-DMA instructions each) may stay in flight
         if (NSTG == 4 && step + 2 < n_steps) {
-            WAIT_VM_BARRIER(8);                   // (NSTG == 4 is the NLW == 4 variant)
+            if (NLW == 4) WAIT_VM_BARRIER(8); else WAIT_VM_BARRIER(6);       // (NSTG == 4: the half-width tiles, NLW 4 or 3)
         } else if (step + 1 < n_steps) {
-            if (NLW == 6) WAIT_VM_BARRIER(6); else if (NLW == 5) WAIT_VM_BARRIER(5); else WAIT_VM_BARRIER(4);
+            if (NLW == 6) WAIT_VM_BARRIER(6); else if (NLW == 5) WAIT_VM_BARRIER(5); else if (NLW == 4) WAIT_VM_BARRIER(4); else WAIT_VM_BARRIER(3);
         } else {
             WAIT_VM_BARRIER(0);
         }
@@ -1113,7 +1113,7 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
             if constexpr (kExtraBias) {
                 if (bias_extra) {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) accb[i] = mg_mfma_32x32x16(a[i], ones, accb[i]);
+                    for (int i = 0; i < TNW; ++i) accb[i] = mg_mfma_32x32x16(a[i], ones, accb[i]);
                 }
             }
         }
@@ -1271,7 +1271,10 @@ int mg_try_nt_big(const uint16_t* A, int lda, const int32_t* rows, int64_t M, in
 
 // The 128 x 320 tile form (wgrad_big_body<5>: two k halves per n tile): phone-rate row counts of a 640-wide operand with 4+ n tiles
 static bool wgrad_ksplit(int64_t M, int N, int lda) {
-    return lda == 640 && M <= 32768 && N / 128 >= 4 && g_mg_tuning[MG_TUNE_PROBE] != 92;      // 92: A/B, the 128 x 640 tiles
+    if (g_mg_tuning[MG_TUNE_PROBE] == 92) return false;                                       // 92: A/B, the full-width tiles
+    if (lda == 640) return M <= 32768 && N / 128 >= 4;
+    // N = 128 at phone-rate row counts only: at M = 256 000 the half-width tiles were 34 us per step SLOWER (0.607 vs 0.573 ms)
+    return lda == 512 && N == 128 && M <= 32768 && g_mg_tuning[MG_TUNE_PROBE] != 93;          // 93: A/B, 128 x 512 tiles for this shape
 }
 
 // Plan of the split over M for the wide wgrad: S slabs of m_chunk rows.  Returns 0 if the shape does not qualify.
@@ -1283,7 +1286,10 @@ int mg_wgrad_big_plan(int64_t M, int N, int K, int lda, int lddy, int* S_out, in
     // phone-rate shapes (M ~ 2e4 rows): 48 splits x 4 n-tiles = 192 workgroups beat 64 x 4 (45.6 vs 49.7 us with the reduce at
     // M = 21 504, N = 512, K = 600: a third less partial-slab traffic); never more splits than the workspace was sized for
     if (M <= 32768 && tiles_n >= 4) S = 192 / tiles_n;
-    if (wgrad_ksplit(M, N, lda)) S = 256 / (2 * tiles_n);     // 8 tiles per split: 32 splits fill the chip, a third less slab traffic
+    if (wgrad_ksplit(M, N, lda)) {
+        if (lda == 640) S = 256 / (2 * tiles_n);     // 8 tiles per split: 32 splits fill the chip, a third less slab traffic
+        else S = 48;                                 // N = 128: two tiles per split - 96 workgroups with half the slabs of 96 splits
+    }
     if (M <= 32768 && tiles_n == 1) S = 96;                  // N = 128 at the same M: 24.2 vs 27.7 us (224 splits write 59 MB of slabs)
     // N = 128 at frame-rate row counts (M = 256 000, K = 512): 192 splits of ~1 334 rows beat one split per CU - a quarter less slab
     // traffic (50 vs 67 MB written and read again by the reduce): 89.5 -> 80 us with the reduce (sweep 144 .. 512, scripts/kbench.py wgrad2)
@@ -1314,7 +1320,9 @@ int mg_launch_wgrad_big(const uint16_t* dY, int lddy, const uint16_t* A, int lda
     int xcd_group = (rows == nullptr && S % 8 == 0) ? 1 : 0;
     if (g_mg_tuning[MG_TUNE_WGRAD_ORDER] == 1) xcd_group = 0;
     if (g_mg_tuning[MG_TUNE_WGRAD_ORDER] == 2 && S % 8 == 0) xcd_group = 1;
-    if (ksplit)
+    if (ksplit && lda == 512)
+        hipLaunchKernelGGL((wgrad_big_kernel<4>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
+    else if (ksplit)
         hipLaunchKernelGGL((wgrad_big_kernel<5>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
     else if (lda == 640)
         hipLaunchKernelGGL((wgrad_big_kernel<10>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
@@ -1376,18 +1384,20 @@ int mg_launch_wgrad_dgrad_pair(const uint16_t* dY, int lddy, const uint16_t* A, 
     // would wait for a whole tile program to finish).  Measured at C2's M = 21 504: 80 splits; 88 fit too when the splits are handed
     // out from the last one down - the four empty ones then land on the XCDs with a dgrad tile more - and were 2.4 us per step SLOWER
     // (every CU busy to the end, 8 more slabs for the update kernel to sum).
+    const bool ksplit = wgrad_ksplit(M, N, lda);
+    const int kt = ksplit ? 2 : 1;                                    // workgroups per split
     auto fits = [&](int S_, int chunk_) {
         const int64_t s_real = mg_ceil_div(M, chunk_);
         for (int x = 0; x < 8; ++x) {
             const int64_t nt_x = (tiles_m > x ? mg_ceil_div(tiles_m - x, 8) : 0) * tiles_n;
             int64_t wg_x = 0;
-            for (int b = x; b < S_; b += 8) wg_x += b < s_real ? 1 : 0;
+            for (int b = x; b < S_; b += 8) wg_x += b < s_real ? kt : 0;        // the k halves of a split sit on one XCD
             if (nt_x + wg_x > 32) return false;
         }
         return true;
     };
     bool found = false;
-    for (int cand = S; cand >= 48 && !found; cand -= 8) {
+    for (int cand = S; cand >= 48 / kt && !found; cand -= 8) {
         const int chunk_ = cand == S ? m_chunk : (int)mg_align_up((size_t)mg_ceil_div(M, cand), 32);
         if (chunk_ > WG_ROWS_MAX) break;
         const int S_ = (int)mg_align_up((size_t)mg_ceil_div(M, chunk_), 8);
@@ -1399,8 +1409,12 @@ int mg_launch_wgrad_dgrad_pair(const uint16_t* dY, int lddy, const uint16_t* A, 
     if (!found) return 0;
     if ((size_t)S * (size_t)sstride > slab_floats) return 0;
     const unsigned nt_blocks = (unsigned)(mg_ceil_div(tiles_m, 8) * 8 * tiles_n);
-    hipLaunchKernelGGL((wgrad_dgrad_pair_kernel<8, 256>), dim3((unsigned)S + nt_blocks), dim3(512), 0, st, (unsigned)S, dY, lddy, A, lda, M, N, K,
-                       m_chunk, slab, slab + (int64_t)N * K, sstride, 1, WT, ldwt, A, lda, (void*)dX, lddx, (int)tiles_m, tiles_n);
+    if (ksplit)
+        hipLaunchKernelGGL((wgrad_dgrad_pair_kernel<4, 256>), dim3((unsigned)(2 * S) + nt_blocks), dim3(512), 0, st, (unsigned)(2 * S), dY, lddy, A,
+                           lda, M, N, K, m_chunk, slab, slab + (int64_t)N * K, sstride, 1, WT, ldwt, A, lda, (void*)dX, lddx, (int)tiles_m, tiles_n);
+    else
+        hipLaunchKernelGGL((wgrad_dgrad_pair_kernel<8, 256>), dim3((unsigned)S + nt_blocks), dim3(512), 0, st, (unsigned)S, dY, lddy, A, lda, M, N,
+                           K, m_chunk, slab, slab + (int64_t)N * K, sstride, 1, WT, ldwt, A, lda, (void*)dX, lddx, (int)tiles_m, tiles_n);
     *S_out = S;
     return 1;
 }
