@@ -160,21 +160,21 @@ def roofline_f0(features, model, precision):
         bound['phone_target_stats_kernel'] = ('hbm', m * 4.0 * 2 + r_tab * 8.0)
         ldk = tab.shape[1]
         algo_bytes.update({'phone_front_gemm_kernel<1>': 2.0 * (r_tab * ldk + n1 * ldk + r_tab * n1) + m * 12.0 + b * p * 8.0 + r_tab * 16.0,
-                           'wgrad_dgrad_pair_kernel<8>': 2.0 * (r_tab * n2 + n1 * n2 + 2 * r_tab * n1) + 4.0 * n2 * n1,
+                           'wgrad_dgrad_pair_kernel<4>': 2.0 * (r_tab * n2 + n1 * n2 + 2 * r_tab * n1) + 4.0 * n2 * n1,
                            'gemm_nt_persist_kernel<256>': 2.0 * (r_tab * ldk + n1 * ldk + r_tab * n1),
                            'gemm_nt_persist_kernel<128>': 2.0 * (r_tab * n1 + n2 * n1 + r_tab * n2),
                            'wgrad_big_kernel<8>': 2.0 * (r_tab * n2 + r_tab * n1) + 4.0 * n2 * n1,
                            'gemm_nt_big_kernel<256>': 2.0 * (r_tab * n2 + n1 * n2 + 2 * r_tab * n1),
-                           'wgrad_big_kernel<10>': 2.0 * (r_tab * n1 + r_tab * ldk) + 4.0 * n1 * k})
+                           'wgrad_big_kernel<5>': 2.0 * (r_tab * n1 + r_tab * ldk) + 4.0 * n1 * k})
         if ops.wgrad_slabs_ok(r_tab, n2, n1, h_tab.shape[1], dz2.shape[1]):
-            kernels.append(('wgrad_dgrad_pair_kernel<8>: layer-2 wgrad slabs (dZ2^T table) and layer-2 dgrad + sigmoid-grad at phone rate in '
+            kernels.append(('wgrad_dgrad_pair_kernel<4>: layer-2 wgrad slabs (dZ2^T table) and layer-2 dgrad + sigmoid-grad at phone rate in '
                             'one grid', 4.0 * r_tab * n1 * n2, lambda: ops.linear_wgrad_dgrad_bf16(dz2, h_tab, r_tab, n2, n1, w2t)))
         else:
             kernels.append(('wgrad_big_kernel<8>: layer-2 wgrad at phone rate (dZ2^T table)', 2.0 * r_tab * n1 * n2,
                             lambda: ops.linear_wgrad_bf16(dz2, h_tab, None, r_tab, n2, n1)))
             kernels.append(('gemm_nt_big_kernel<256>: layer-2 dgrad + sigmoid-grad at phone rate', 2.0 * r_tab * n1 * n2,
                             lambda: ops.linear_dgrad_bf16(dz2, r_tab, n2, w2t, n1, h_tab)))
-        kernels.append(('wgrad_big_kernel<10>: layer-1 wgrad at phone rate (dZ1^T lab)', 2.0 * r_tab * k * n1,
+        kernels.append(('wgrad_big_kernel<5>: layer-1 wgrad at phone rate (dZ1^T lab; 128 x 320 tiles, 32 split-M slabs)', 2.0 * r_tab * k * n1,
                         lambda: ops.linear_wgrad_bf16(dz1, tab, None, r_tab, n1, k)))
         peak = MFMA_BF16_PEAK_TFLOPS
     elif precision == 'bf16':
