@@ -54,6 +54,11 @@ const char* mg_last_error(void);
 #define MG_TUNE_LSTM_BWD_STACK 6 /* mg_lstm_pstack_bwd_bf16: 0 = 32 hidden units per slot where they fit (one workgroup per CU), 1 = 16 (two per CU) */
 #define MG_TUNE_WGRAD_SPLITS 4  /* wide weight-gradient kernel: != 0 overrides the planned number of split-M slabs (a multiple of 8) */
 #define MG_TUNE_PROBE 7         /* mg_f0_l2tail_bf16: 0 = the product kernel (one wave per SIMD), 64 = the producer / consumer role split (experiment, measured slower), other values = the product kernel's timing probes (results garbage): 1 = no H1 loads, 2 = no tail, 4 = no layer-2 MFMAs, 8 = no sigmoid of H2, 16 = no steps 8-9, 32 = no step 9 */
+/* MG_TUNE_PROBE, the A/B switches of the shared-grid launches and the half-width weight-gradient tiles (same results either way):
+ * 65 = mg_linear_wgrad_dgrad_bf16 as its two launches, 66 = mg_phone_front_linear_fwd_bf16 as its two launches, 92 = 128 x 640 tiles for
+ * the 640-wide weight gradient at phone-rate rows, 93 = 128 x 512 tiles for the 512-wide one; timing probes of the front's riders
+ * (results garbage): 67 = idle riders, 70 + bits (1 no utterance compute, 2 no extra-row compute, 4 no extra jobs, 8 no GEMM).
+ * MG_TUNE_WGRAD_SPLITS: 1000 + S / 2000 + S override the split count of the one-n-tile / the 4+-n-tile plans only. */
 #define MG_TUNE_WGRAD_ORDER 5   /* wide weight-gradient kernel, block order: 0 = planned, 1 = n tile fastest, 2 = the n tiles of a split on one XCD */
 int mg_set_tuning(int key, int value);
 int mg_version(void);           /* ABI version, bumped on incompatible change */
