@@ -41,14 +41,14 @@ def main():
     for _ in range(3):
         ops.linear_wgrad_bf16(dz1, tab, None, r_tab, n1, k)
     torch.cuda.synchronize()
-    s = read(lib, 'mg_diag_read_stamps_wg', 192)
-    report('wgrad_big<10> layer-1 weight gradient at phone rate (48 splits x 4 n tiles, 14 steps each)', s,
+    s = read(lib, 'mg_diag_read_stamps_wg', 256)
+    report('wgrad_big<5> layer-1 weight gradient at phone rate (32 splits x 8 tiles of 128 x 320, 21 steps each)', s,
            [('  loop: vmcnt wait + barrier', s[..., 6]), ('  loop: LDS-DMA issue', s[..., 7])])
     for _ in range(3):
         ops.linear_wgrad_bf16(dz2, h1, None, r_tab, n2, n1)
     torch.cuda.synchronize()
     s = read(lib, 'mg_diag_read_stamps_wg', 96)
-    report('wgrad_big<8> layer-2 weight gradient at phone rate (96 splits, 7 steps each)', s,
+    report('wgrad_big<4> layer-2 weight gradient at phone rate (48 splits x 2 tiles of 128 x 256, 14 steps each)', s,
            [('  loop: vmcnt wait + barrier', s[..., 6]), ('  loop: LDS-DMA issue', s[..., 7])])
 
     # layers 2-4 + loss + backward in one pass (one 32-row tile per wave at this row count)
