@@ -256,7 +256,9 @@ LINEAR_SHAPES = [(1000, 600, 512), (777, 609, 256), (300, 512, 128), (513, 128, 
                  (64, 40, 96),
                  # shapes that take the large-tile LDS-DMA kernels (M >= 2048 / 4096, N % 128 == 0), with ragged M tails
                  (4999, 600, 512), (4500, 512, 128), (4100, 128, 512), (6001, 200, 256), (5003, 600, 384),
-                 (8200, 512, 1536)]
+                 (8200, 512, 1536),
+                 # half-width weight-gradient tiles (k halves) without a padding tile for the bias sums (K > 608) and with all 640 columns
+                 (4800, 620, 512), (4321, 640, 512), (21504, 600, 512), (21504, 512, 128)]
 
 
 @pytest.mark.parametrize('shape', LINEAR_SHAPES)
