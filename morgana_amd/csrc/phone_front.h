@@ -82,10 +82,10 @@ __device__ __forceinline__ void pf_stage_utterances(const PhoneFrontArgs& a, int
         for (int u = 0; u < 4; ++u)
             if (where[u] >= 0) reg0[where[u]] = v[u];
     }
-    if (tid < n) {
-        const int b = first + tid * stride;
+    for (int k = tid; k < n; k += NT) {
+        const int b = first + k * stride;
         int64_t nb = a.seq_len ? a.seq_len[b] : (int64_t)T;
-        reg0[tid * ureg + per] = (int)(nb > T ? T : (nb < 0 ? 0 : nb));
+        reg0[k * ureg + per] = (int)(nb > T ? T : (nb < 0 ? 0 : nb));
     }
 }
 

@@ -1956,12 +1956,13 @@ def test_upsample_index_maps_match_separate_launches():
         assert torch.equal(rows2, rows) and torch.equal(mapped2.reshape(-1), mapped) and torch.equal(seg2, seg)
 
 
-@pytest.mark.parametrize('case', ['ragged', 'c2', 'wide'])
+@pytest.mark.parametrize('case', ['ragged', 'c2', 'wide', 'many'])
 def test_phone_front_equals_the_separate_launches(case):
     """mg_phone_front (frame map + per-phone loss statistics, one job per utterance) against mg_upsample_index_maps +
     mg_phone_target_stats: rows, the pad-mapped rows, the frame runs, ybar and weight EQUAL; the loss's constant term (partial sums
     grouped per utterance instead of per 16 rows) to 1e-6.  'ragged': zero durations, an empty utterance, totals short of and beyond the
-    frame axis, seq_len cutting into live frames; 'c2': the headline shape; 'wide': more phones than threads per utterance.
+    frame axis, seq_len cutting into live frames; 'c2': the headline shape; 'wide': more phones than threads per utterance; 'many':
+    many short utterances (a rider block works dozens of jobs off one staged batch).
     Then mg_phone_front_linear_fwd_bf16: the same outputs plus the first layer's GEMM EQUAL to mg_linear_fwd_bf16, in one grid
     (where the GEMM leaves CUs idle: 'c2') and as its two launches (MG_TUNE_PROBE = 66)."""
     from morgana_amd import ops, _lib
@@ -1977,6 +1978,10 @@ def test_phone_front_equals_the_separate_launches(case):
         b, p, t, extra = 256, 80, 1000, ops.PHONE_RATE_EXTRA
         dur = rng.randint(1, 25, size=(b, p)).astype(np.int64)
         seq_np = np.minimum(dur.sum(1), t).astype(np.int64)
+    elif case == 'many':                                             # 1 700 short utterances on 32 riders: 50+ jobs per block, staged
+        b, p, t, extra = 1700, 16, 20, 64                            # in one batch
+        dur = rng.randint(0, 3, size=(b, p)).astype(np.int64)
+        seq_np = rng.randint(1, t + 1, size=b).astype(np.int64)
     else:
         b, p, t, extra = 5, 700, 2100, 16
         dur = rng.randint(0, 7, size=(b, p)).astype(np.int64)
