@@ -58,6 +58,9 @@ def parse_args():
                     help='one rank only: run the MULTI-rank code path (gradient buckets, all-reduce through a world-size-1 RCCL group, '
                          'no deferred slabs) - what a rank of an N-GPU job executes per step, without the peers')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dry-run-ranks', action='store_true',
+                    help='rendezvous only: every rank joins the process group, one all-reduce counts them, rank 0 prints '
+                         '{"n_gpus": N, "dry_run": true} - checks the launcher path without touching a GPU')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
     if args.steps is None:
@@ -527,12 +530,44 @@ def other_workloads(dev, precision):
     return out
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver's command line would
+    (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>), as a CHILD
+    process - this process has made no GPU call yet and makes none - and exit with its code.  Rank 0 of the children prints the
+    JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:                    # a free port on the loopback interface
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be at least 1')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
     rank, local_rank, world = distributed.init()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:                           # never a silent N = 1: the line's n_gpus is the number of ranks that ran
         raise SystemExit('--gpus %d does not match WORLD_SIZE %d' % (args.gpus, world))
-    n_gpus = max(world, 1)
+    n_gpus = world
+    if args.dry_run_ranks:
+        count = torch.ones(1)
+        if world > 1:
+            if torch.distributed.get_backend() == 'nccl':
+                count = count.cuda()
+            torch.distributed.all_reduce(count)
+        if rank == 0:
+            print(json.dumps({'n_gpus': n_gpus, 'ranks_counted': int(count.item()), 'dry_run': True,
+                              'backend': torch.distributed.get_backend() if world > 1 else None}))
+        return
     n_dev = torch.cuda.device_count()
     dev_index = local_rank % max(n_dev, 1)          # several ranks may share one GPU in the gloo rehearsal on a 1-GPU box
     torch.cuda.set_device(dev_index)
@@ -706,6 +741,11 @@ def main():
                        'parallelism': 'dp%d' % n_gpus},
             'final_loss': round(final_loss, 6),
         }
+        # how the gradients crossed the ranks: a SCALE record then shows whether the step's graph really held a collective
+        result['exchange'] = {
+            'world_size': (torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1),
+            'backend': (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
+            'mode': (getattr(step, 'exchange_mode', None) or ('none (one rank)' if world == 1 and not rehearse else 'eager all-reduce'))}
         if graph_note is not None:
             result['config']['launch'] = graph_note
             result['config']['steps_per_graph_launch'] = per_call      # every step does all of its work; the launch gap is shared

@@ -1160,6 +1160,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_fused_solo_kernel(const uint16_t
 }
 
 
+void mg_launch_fused64(int nbt, const uint16_t* dZ2, int lddz, const uint16_t* W2T, int ldwt, const uint16_t* H1, int ldh, const uint16_t* A,
+                       int lda, const int32_t* rows, int64_t M, int N, int K, int m_chunk, int n_splits, float* slab, float* bslab,
+                       int64_t sstride, hipStream_t st);
+
 static void fused_plan(int64_t M, int N, int* S, int* m_chunk) {
     const int tiles_n = N / F_BNT;
     int64_t s = mg_ceil_div(256, tiles_n);
@@ -1200,7 +1204,10 @@ static int fused_launch(const char* name, const uint16_t* dZ2, int lddz, int N2,
     const int64_t nk = (int64_t)N * K, sstride = nk + N;
     float* slab = (float*)workspace;
     float* bslab = slab + nk;
-    if (rows && g_mg_tuning[MG_TUNE_STAGGER] == 9)      // timing probe: the same with a 128 x 512 tile (no spills; results incomplete)
+    if (rows && (g_mg_tuning[MG_TUNE_STAGGER] == 0 || g_mg_tuning[MG_TUNE_STAGGER] == 12))      // 64-frame steps (bwd_fused64_bf16.hip)
+        mg_launch_fused64(g_mg_tuning[MG_TUNE_STAGGER] == 12 ? 2 : 3, dZ2, lddz, W2T, ldwt, H1, ldh, A, lda, rows, M, N, K, chunk, S, slab, bslab,
+                          sstride, st);
+    else if (rows && g_mg_tuning[MG_TUNE_STAGGER] == 9)      // timing probe: the same with a 128 x 512 tile (no spills; results incomplete)
         hipLaunchKernelGGL(wgrad_fused_solo_kernel<4>, dim3((unsigned)((N / F_BNT) * mg_align_up((size_t)S, 8))), dim3(256), 0, st, dZ2, lddz, W2T,
                            ldwt, H1, ldh, A, lda, rows, M, N, K, chunk, S, slab, bslab, sstride);
     else if (rows && g_mg_tuning[MG_TUNE_STAGGER] == 8)      // one wave per SIMD, P1 woven into P2 (see the kernel's comment)

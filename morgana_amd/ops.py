@@ -48,6 +48,17 @@ def workspace(nbytes, device):
     return buf
 
 
+def _slab_buffer(slab, nbytes, device):
+    """A per-layer slab buffer of at least ``nbytes``: ``slab`` itself when it is large enough, else a new one - and the outgrown
+    buffer is RETIRED, not dropped (as `workspace` does): a HIP graph captured at the smaller shape still launches the weight-gradient
+    and update kernels with its address baked in, and torch's caching allocator would hand that memory to the next tensor."""
+    if slab is not None and slab.numel() >= nbytes:
+        return slab
+    if slab is not None:
+        _retired.append(slab)
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
 def pad_ld(n):
     """Leading dimension of a bf16 buffer with n columns: a multiple of 64 (the large-tile kernels' K step) once the
     row is at least 64 wide, a multiple of 8 (one 16-byte chunk) below that.  Padding columns hold zeros."""
@@ -415,8 +426,7 @@ def linear_wgrad_slabs_bf16(dy, a, rows, m, n, k, slab=None):
     partials].  ``slab`` = a buffer to reuse (kept by the caller until the optimiser has consumed it)."""
     lib = _lib.load()
     nbytes = lib.mg_linear_wgrad_workspace_bytes(m, n, k)
-    if slab is None or slab.numel() < nbytes:
-        slab = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
+    slab = _slab_buffer(slab, nbytes, dy.device)
     n_slabs, stride = ctypes.c_int(0), ctypes.c_int64(0)
     _lib.check(lib.mg_linear_wgrad_slabs_bf16(_p(dy), dy.shape[1], _p(a), a.shape[1], _p(rows), m, n, k, _p(slab), slab.numel(),
                                               ctypes.byref(n_slabs), ctypes.byref(stride), _stream()), 'mg_linear_wgrad_slabs_bf16')
@@ -429,8 +439,7 @@ def linear_wgrad_dgrad_bf16(dy, a, m, n, k, wt_bf16, slab=None):
     Returns (slab buffer, n_slabs, stride, dx (m, pad8(k)) bf16).  Needs wgrad_slabs_ok(m, n, k, lda, lddy)."""
     lib = _lib.load()
     nbytes = lib.mg_linear_wgrad_workspace_bytes(m, n, k)
-    if slab is None or slab.numel() < nbytes:
-        slab = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
+    slab = _slab_buffer(slab, nbytes, dy.device)
     lddx = pad8(k)
     dx = torch.empty((m, lddx), dtype=torch.bfloat16, device=dy.device)
     n_slabs, stride = ctypes.c_int(0), ctypes.c_int64(0)
@@ -474,8 +483,7 @@ def linear_bwd_fused_slabs_bf16(dz2, wt2, h1, a, rows, m, n_hidden, k0, slab=Non
     optimiser's update kernel to sum; ``slab`` = a buffer to reuse (kept by the caller until the optimiser has consumed it)."""
     lib = _lib.load()
     nbytes = lib.mg_linear_bwd_fused_workspace_bytes(m, n_hidden, k0)
-    if slab is None or slab.numel() < nbytes:
-        slab = torch.empty(nbytes, dtype=torch.uint8, device=dz2.device)
+    slab = _slab_buffer(slab, nbytes, dz2.device)
     n_slabs, stride = ctypes.c_int(0), ctypes.c_int64(0)
     _lib.check(lib.mg_linear_bwd_fused_slabs_bf16(_p(dz2), dz2.shape[1], 128, _p(wt2), wt2.shape[1], _p(h1), h1.shape[1], _p(a), a.shape[1],
                                                   _p(rows), m, n_hidden, k0, _p(slab), slab.numel(), ctypes.byref(n_slabs),

@@ -62,32 +62,45 @@ def main():
     w2t = ops.cast_transpose_bf16(w2)
     dz1 = (torch.randn(m, 512, device=dev) * 0.01).to(torch.bfloat16)
     dz2 = (torch.randn(m, 128, device=dev) * 0.01).to(torch.bfloat16)
-    h1 = None
-    for _ in range(3):
-        h1 = ops.linear_fwd_bf16(tab, rows, m, k, w1b, b1, 512, ops.ACT_SIGMOID)
-    torch.cuda.synchronize()
-    s = read(lib, 'mg_diag_read_stamps_ntp', 256)
-    report('gemm_nt_persist<256, sigmoid> (layer-1 forward; "main loop" spans all tiles of the workgroup)', s,
-           [('  vmcnt wait + barrier', s[..., 6]), ('  epilogues', s[..., 7])])
-    w2b = ops.cast_pad_bf16(w2)
-    b2 = torch.from_numpy(st['layers.2.bias']).to(dev)
-    for _ in range(3):
-        ops.linear_fwd_bf16(h1, None, m, 512, w2b, b2, 128, ops.ACT_SIGMOID)
-    torch.cuda.synchronize()
-    s = read(lib, 'mg_diag_read_stamps_ntp', 256)
-    report('gemm_nt_persist<128, sigmoid> (layer-2 forward)', s,
-           [('  vmcnt wait + barrier', s[..., 6]), ('  epilogues', s[..., 7])])
-    for _ in range(3):
-        ops.linear_wgrad_bf16(dz1, tab, rows, m, 512, 600)
-    torch.cuda.synchronize()
-    s = read(lib, 'mg_diag_read_stamps_wg', 256)
-    report('wgrad_big<10> (layer-1 weight gradient)', s,
-           [('  loop: vmcnt wait + barrier', s[..., 6]), ('  loop: LDS-DMA issue', s[..., 7])])
+    h1 = ops.linear_fwd_bf16(tab, rows, m, k, w1b, b1, 512, ops.ACT_SIGMOID)
+    if not only_fused:
+        for _ in range(3):
+            h1 = ops.linear_fwd_bf16(tab, rows, m, k, w1b, b1, 512, ops.ACT_SIGMOID)
+        torch.cuda.synchronize()
+        s = read(lib, 'mg_diag_read_stamps_ntp', 256)
+        report('gemm_nt_persist<256, sigmoid> (layer-1 forward; "main loop" spans all tiles of the workgroup)', s,
+               [('  vmcnt wait + barrier', s[..., 6]), ('  epilogues', s[..., 7])])
+        w2b = ops.cast_pad_bf16(w2)
+        b2 = torch.from_numpy(st['layers.2.bias']).to(dev)
+        for _ in range(3):
+            ops.linear_fwd_bf16(h1, None, m, 512, w2b, b2, 128, ops.ACT_SIGMOID)
+        torch.cuda.synchronize()
+        s = read(lib, 'mg_diag_read_stamps_ntp', 256)
+        report('gemm_nt_persist<128, sigmoid> (layer-2 forward)', s,
+               [('  vmcnt wait + barrier', s[..., 6]), ('  epilogues', s[..., 7])])
+        for _ in range(3):
+            ops.linear_wgrad_bf16(dz1, tab, rows, m, 512, 600)
+        torch.cuda.synchronize()
+        s = read(lib, 'mg_diag_read_stamps_wg', 256)
+        report('wgrad_big<10> (layer-1 weight gradient)', s,
+               [('  loop: vmcnt wait + barrier', s[..., 6]), ('  loop: LDS-DMA issue', s[..., 7])])
+    for knob, title in ((0, 'wgrad_fused64<3>'), (12, 'wgrad_fused64<2>')):
+        lib.mg_set_tuning(0, knob)
+        for _ in range(3):
+            ops.linear_bwd_fused_bf16(dz2, w2t, h1, tab, rows, m, 512, 600)
+        torch.cuda.synchronize()
+        lib.mg_set_tuning(0, 0)
+        s = read(lib, 'mg_diag_read_stamps_f64', 256)
+        report(title + ' (dgrad2 + wgrad1, gathered input, 64-frame steps)', s,
+               [('  loop: wait + barrier', s[..., 6]), ('  loop: run scan of the next step', s[..., 10]), ('  loop: fetch (DMA issue)', s[..., 7]),
+                ('  loop: P1', s[..., 8]), ('  loop: P2', s[..., 9])])
+    lib.mg_set_tuning(0, 13)
     for _ in range(3):
         ops.linear_bwd_fused_bf16(dz2, w2t, h1, tab, rows, m, 512, 600)
     torch.cuda.synchronize()
+    lib.mg_set_tuning(0, 0)
     s = read(lib, 'mg_diag_read_stamps_fp', 256)
-    report('wgrad_fused_pipe (dgrad2 + wgrad1, gathered input)', s,
+    report('wgrad_fused_pipe (dgrad2 + wgrad1, gathered input, 32-frame steps: the kernel it replaced)', s,
            [('  loop: barrier', s[..., 6]), ('  loop: DMA issue + look-ahead reads', s[..., 7]), ('  loop: P1 and P2', s[..., 8]),
             ('    of it: P2', s[..., 9]), ('    of it: what precedes P2 (waves 0-3: P1)', s[..., 10])])
 

@@ -576,30 +576,55 @@ def test_wgrad_dgrad_pair_equals_the_two_launches(m):
     np.testing.assert_allclose(tot3.cpu().numpy(), tot.cpu().numpy(), rtol=1e-4, atol=1e-6)
 
 
-def test_fused_backward_solo_experiment_equals_product_kernel():
-    """The one-wave-per-SIMD form of the fused backward (an experiment kept under MG_TUNE_STAGGER = 8, measured slower) must stay
-    correct: dW, db EQUAL to the product kernel's, for phone-like runs and for a row map without runs."""
+@pytest.mark.parametrize('nbt_knob', [0, 12])
+def test_fused_backward_64_frame_steps_equal_32_frame_kernel(nbt_knob):
+    """wgrad_fused64_kernel (csrc/bwd_fused64_bf16.hip: 64-frame steps, the run structure of a step from a ballot instead of LDS
+    tables, ring allocated by groups per step, passes for steps with more runs than the ring holds) against the 32-frame-step kernel
+    it replaces (MG_TUNE_STAGGER = 13), on the same frame ranges: dW, db EQUAL bit for bit where a step's runs fit the ring (the same
+    MFMAs on the same operands), to fp32 rounding where steps take several passes.  Row maps: phone-like runs with pad
+    frames (-1), short runs (several ring passes per step and steps that do not fit beside their predecessor: the on-demand fetch),
+    no runs at all (every frame its own row: the worst case), one long run; M not a multiple of the step.
+    nbt_knob: 0 = tiles fetched three steps ahead (the product form), 12 = two steps ahead with the larger ring."""
     from morgana_amd import _lib
     lib = _lib.load()
     rng = np.random.RandomState(5)
-    m, k0 = 40000, 600
-    table = ops.cast_pad_bf16(dev(rng.uniform(0, 1, (m // 9, k0)).astype(np.float32)))
-    (_,), (w2t,) = ops.cast_params_bf16([dev(rng.uniform(-0.1, 0.1, (128, 512)).astype(np.float32))], want_plain=True, want_t=(0,))
-    h1 = ops.cast_pad_bf16(dev(rng.uniform(0.05, 0.95, (m, 512)).astype(np.float32)))
-    dz2 = ops.cast_pad_bf16(dev((rng.standard_normal((m, 128)) * 0.01).astype(np.float32)))
-    for kind in ('runs', 'random'):
-        if kind == 'runs':
-            rows = np.repeat(rng.randint(-1, table.shape[0], size=m), rng.randint(1, 40, size=m))[:m]
-        else:
-            rows = rng.randint(-1, table.shape[0], size=m)
-        rows = dev(rows.astype(np.int32))
-        want = ops.linear_bwd_fused_bf16(dz2, w2t, h1, table, rows, m, 512, k0)
-        lib.mg_set_tuning(0, 8)
-        try:
-            got = ops.linear_bwd_fused_bf16(dz2, w2t, h1, table, rows, m, 512, k0)
-        finally:
-            lib.mg_set_tuning(0, 0)
-        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), kind
+    k0 = 600
+    for m in (40037, 8192):
+        table = ops.cast_pad_bf16(dev(rng.uniform(0, 1, (m // 9, k0)).astype(np.float32)))
+        (_,), (w2t,) = ops.cast_params_bf16([dev(rng.uniform(-0.1, 0.1, (128, 512)).astype(np.float32))], want_plain=True, want_t=(0,))
+        h1 = ops.cast_pad_bf16(dev(rng.uniform(0.05, 0.95, (m, 512)).astype(np.float32)))
+        dz2 = ops.cast_pad_bf16(dev((rng.standard_normal((m, 128)) * 0.01).astype(np.float32)))
+        for kind in ('runs', 'short', 'random', 'one', 'mixed'):
+            if kind == 'runs':
+                rows = np.repeat(rng.randint(-1, table.shape[0], size=m), rng.randint(1, 40, size=m))[:m]
+            elif kind == 'short':
+                rows = np.repeat(rng.randint(-1, table.shape[0], size=m), rng.randint(1, 5, size=m))[:m]
+            elif kind == 'random':
+                rows = rng.randint(-1, table.shape[0], size=m)
+            elif kind == 'one':
+                rows = np.full(m, 7)
+            else:                                          # stretches of every kind next to each other
+                parts, left = [], m
+                while left > 0:
+                    n = min(left, int(rng.randint(50, 400)))
+                    style = rng.randint(0, 4)
+                    hi = (40, 5, 2, 400)[style]
+                    parts.append(np.repeat(rng.randint(-1, table.shape[0], size=n), rng.randint(1, hi, size=n))[:n])
+                    left -= n
+                rows = np.concatenate(parts)
+            rows = dev(rows.astype(np.int32))
+            lib.mg_set_tuning(0, 13)
+            try:
+                want = ops.linear_bwd_fused_bf16(dz2, w2t, h1, table, rows, m, 512, k0)
+                lib.mg_set_tuning(0, nbt_knob)
+                got = ops.linear_bwd_fused_bf16(dz2, w2t, h1, table, rows, m, 512, k0)
+            finally:
+                lib.mg_set_tuning(0, 0)
+            if kind in ('runs', 'one'):                    # every step's runs fit the ring: the same MFMAs on the same operands
+                assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), (m, kind)
+            else:                                          # steps multiplied in passes: a 16-frame MFMA's products arrive in two
+                for g, w in zip(got, want):               # instructions instead of one, i.e. one more fp32 rounding per pass
+                    assert rel_err(g.cpu().numpy(), w.cpu().numpy()) < 1e-5, (m, kind)
 
 
 @pytest.mark.parametrize('rows_kind', ['random', 'runs', 'identity'])
