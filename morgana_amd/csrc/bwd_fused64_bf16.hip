@@ -74,7 +74,9 @@ struct W64Map {                                   // LDS map (bytes); NBT = buff
     static constexpr int LDS = ROWS + 3 * 256;
 };
 
-template <int NBT>
+// PROBE (diagnostic builds only, -DMG_PROBES; results garbage): timing experiments on parts of the step - 1 = every P2 operand read
+// from the zero row, 2 = no operand reads in P2 at all, 4 = no P1, 8 = no tile / staged-row DMA, 16 = P2 reads two pairs ahead instead of four.
+template <int NBT, int PROBE = 0>
 __global__ __launch_bounds__(512) void wgrad_fused64_kernel(const uint16_t* __restrict__ dZ2, int lddz, const uint16_t* __restrict__ W2T,
                                                             int ldwt, const uint16_t* __restrict__ H1, int ldh,
                                                             const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(512) void wgrad_fused64_kernel(const uint16_t* __re
         const int n_pieces = 5 * g_cnt;
         int pi = (wave - rot) & 3;
         if (wave >= 4 || pi >= n_pieces) return;          // wave-uniform: nothing for this wave
+        if ((PROBE & 8) && rot > 0) return;
         const int lane = opaque_lane();
         const bool flag = ((lane < 32 ? (mk.lo >> lane) : (mk.hi >> (lane - 32))) & 1u) != 0u;
         const int ord = (int)__builtin_amdgcn_mbcnt_hi(mk.hi, __builtin_amdgcn_mbcnt_lo(mk.lo, 0u)) + (flag ? 1 : 0) - 1;
@@ -203,6 +206,7 @@ __global__ __launch_bounds__(512) void wgrad_fused64_kernel(const uint16_t* __re
     auto issue_small = [&](int step, int buf) {
         constexpr int PW = NBT == 3 ? 2 : 4, PS = NBT == 3 ? 8 : 4;
         if (NBT != 3 && wave >= 4) return;
+        if ((PROBE & 8) && step > 2) return;
         const int lane = opaque_lane();
 #pragma unroll
         for (int h = 0; h < PW; ++h) {
@@ -247,6 +251,7 @@ __global__ __launch_bounds__(512) void wgrad_fused64_kernel(const uint16_t* __re
     // P1 of step u: dZ2 / H1 tiles of buffer tb, dZ1 tile to buffer yb2 (of 2); two rounds of two 16-frame blocks.  Frames past the
     // range (the last step's tail) give dZ1 = 0: their tile rows are copies of the range's last row.
     auto p1 = [&](int u, int tb, int yb2) {
+        if (PROBE & 4) return;
         const int lane = opaque_lane();
         const int l15 = lane & 15, lq = lane >> 4;
         const int c16 = 2 * wave + (lq >> 1);                                             // 16-byte chunk of the 256-byte row
@@ -254,36 +259,41 @@ __global__ __launch_bounds__(512) void wgrad_fused64_kernel(const uint16_t* __re
         const int h_off0 = L::H1 + l15 * 256 + ((c16 ^ l15) << 4) + 8 * (lq & 1);          // + 4096 t
         const int y_off0 = L::YS + l15 * 256 + ((c16 ^ ((l15 & 3) << 2)) << 4) + 8 * (lq & 1);
         const int bo = tb * 16384, yo = yb2 * 16384;
-        const int f_left = n_rows - u * W_F - l15;        // frame 16 t' + l15 of the step is inside the range iff 16 t' < f_left
+        const int f_left = n_rows - u * W_F - l15;        // frame 16 t + l15 of the step is inside the range iff 16 t < f_left
+        // The four 16-frame blocks are four independent accumulation chains, streamed k-tile by k-tile: an accumulator comes round
+        // every fourth MFMA (no dependent-issue stall), the operand reads run four MFMAs ahead in a ring of four fragments, and the
+        // tiles' latency is paid once per step (as two rounds of two blocks - read 8, multiply 8, tail - it was paid twice, with the
+        // 4-deep chains' latency and the VALU tail in line behind it: 1,700-2,000 cycles per step for 256 matrix cycles).
+        bfv8 b[4];
+        bfv4 hv[4];
+        f32x4 d[4];
+        auto rd = [&](int i) -> bfv8 {                     // operand of MFMA i = 4 ks + t
+            return *reinterpret_cast<const bfv8*>(smem + bo + b_off0 + (i & 3) * 1024 + (i >> 2) * 4096);
+        };
 #pragma unroll
-        for (int rnd = 0; rnd < 2; ++rnd) {
-            bfv8 b[2][4];
-            bfv4 hv[2];
+        for (int i = 0; i < 4; ++i) b[i] = rd(i);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 4; ++t) hv[t] = *reinterpret_cast<const bfv4*>(smem + bo + h_off0 + t * 4096);
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    b[t][ks] = *reinterpret_cast<const bfv8*>(smem + bo + b_off0 + (2 * rnd + t) * 1024 + ks * 4096);
+        for (int t = 0; t < 4; ++t) d[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int t = 0; t < 2; ++t) hv[t] = *reinterpret_cast<const bfv4*>(smem + bo + h_off0 + (2 * rnd + t) * 4096);
-            f32x4 d[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        for (int i = 0; i < 16; ++i) {
+            d[i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[i >> 2], b[i & 3], d[i & 3], 0, 0, 0);
+            if (i + 4 < 16) b[i & 3] = rd(i + 4);
+        }
+        const bool tail_step = f_left + l15 < W_F;        // wave-uniform: the range ends inside this step
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
+        for (int t = 0; t < 4; ++t) {
+            float v[4];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[ks], b[t][ks], d[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                float v[4];
-                const bool inside = 16 * (2 * rnd + t) < f_left;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float h = (float)hv[t][e];
-                    v[e] = inside ? d[t][e] * h * (1.f - h) : 0.f;
-                }
-                const u32x2 pk = u32x2{__builtin_bit_cast(unsigned int, bfv2{(__bf16)v[0], (__bf16)v[1]}),
-                                       __builtin_bit_cast(unsigned int, bfv2{(__bf16)v[2], (__bf16)v[3]})};
-                *reinterpret_cast<u32x2*>(smem + yo + y_off0 + (2 * rnd + t) * 4096) = pk;
+            for (int e = 0; e < 4; ++e) {
+                const float h = (float)hv[t][e];
+                v[e] = d[t][e] * h * (1.f - h);
             }
+            if (tail_step && !(16 * t < f_left)) v[0] = v[1] = v[2] = v[3] = 0.f;
+            const u32x2 pk = u32x2{__builtin_bit_cast(unsigned int, bfv2{(__bf16)v[0], (__bf16)v[1]}),
+                                   __builtin_bit_cast(unsigned int, bfv2{(__bf16)v[2], (__bf16)v[3]})};
+            *reinterpret_cast<u32x2*>(smem + yo + y_off0 + t * 4096) = pk;
         }
     };
 
@@ -328,38 +338,49 @@ __global__ __launch_bounds__(512) void wgrad_fused64_kernel(const uint16_t* __re
                 xb[fi] = in_pass ? L::X + (rg * 4 + (o & 3)) * PX : L::ZROW;
                 xs[fi] = in_pass ? (o & 3) << 6 : 0;
             }
+            bfv8 probe_frag;                               // PROBE & 2: stands for every operand (its value never matters)
+            if (PROBE & 2) asm volatile("" : "=v"(probe_frag));
             auto rd_a = [&](int ks, int i) -> bfv8 {
+                if (PROBE & 2) return probe_frag;
                 const unsigned char* ad = smem + yb + yoff[i] + ks * 16 * PY;
                 const bfv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(ad));
                 const bfv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(ad + 4 * PY));
                 return bfv8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             };
             auto rd_b = [&](int ks, int j) -> bfv8 {
-                const bool bias_blk = bias_free && j == TKT - 1;
+                if (PROBE & 2) return probe_frag;
+                const bool bias_blk = (bias_free && j == TKT - 1) || (PROBE & 1);
                 const unsigned char* alo = smem + (bias_blk ? bias_row : xb[2 * ks]) + (xk[j] ^ xs[2 * ks]);
                 const unsigned char* ahi = smem + (bias_blk ? bias_row : xb[2 * ks + 1]) + (xk[j] ^ xs[2 * ks + 1]);
                 const bfv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(alo));
                 const bfv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(ahi));
                 return bfv8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             };
-            // Fragment reads run two MFMA pairs ahead of their use (a rolling window instead of "all 14 reads, wait, 10 MFMAs" per
-            // k-step: with two waves per SIMD the LDS latency at the head of each k-step was exposed twice per step).
+            // Fragment reads run four MFMA pairs ahead of their use (a rolling window instead of "all 14 reads, wait, 10 MFMAs" per
+            // k-step; two pairs ahead measured 13 us slower at C2: the tr-reads take longer than two pairs' 128 matrix cycles to return
+            // while the other waves and the DMA keep the LDS busy).
             bfv8 a[2][2], b[2 * TKT];
             a[0][0] = rd_a(0, 0);
             a[0][1] = rd_a(0, 1);
+            constexpr int W = (PROBE & 16) ? 2 : 4;        // pairs the operand reads run ahead
+            constexpr int TA = (PROBE & 16) ? 2 : 1;       // the pair at which the next k-step's dZ1 fragments are read
             b[0] = rd_b(0, 0);
             b[1] = rd_b(0, 1);
+            if (W == 4) {
+                b[2] = rd_b(0, 2);
+                b[3] = rd_b(0, 3);
+            }
             auto mm = [&](auto tc) {                       // t = ks * TKT + j, a compile-time constant
                 constexpr int t = decltype(tc)::value;
                 constexpr int ks = t / TKT, j = t % TKT;
-                if constexpr (t + 2 < 2 * TKT) b[t + 2] = rd_b((t + 2) / TKT, (t + 2) % TKT);
-                if constexpr (t == 2) {
+                if constexpr (t + W < 2 * TKT) b[t + W] = rd_b((t + W) / TKT, (t + W) % TKT);
+                if constexpr (t == TA) {
                     a[1][0] = rd_a(1, 0);
                     a[1][1] = rd_a(1, 1);
                 }
                 acc[0][j] = mg_mfma_32x32x16(a[ks][0], b[t], acc[0][j]);
                 acc[1][j] = mg_mfma_32x32x16(a[ks][1], b[t], acc[1][j]);
-                constexpr int n_reads = (t + 2 < 2 * TKT ? 2 : 0) + (t == 2 ? 4 : 0);
+                constexpr int n_reads = (PROBE & 2) ? 0 : (t + W < 2 * TKT ? 2 : 0) + (t == TA ? 4 : 0);
                 if constexpr (n_reads > 0) __builtin_amdgcn_sched_group_barrier(0x100, n_reads, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 2 * MG_MFMA_PER_TILE, 0);
             };
@@ -519,13 +540,518 @@ __global__ __launch_bounds__(512) void wgrad_fused64_kernel(const uint16_t* __re
 #endif
 }
 
+// -------------------------------------------------------------------------------------------------------------------------------------
+// WOVEN form.  Stamps of the kernel above at C2 (profiles/r3_stamps_fused64.txt, cycles per 64-frame step of ~7,800 with 3,072 matrix
+// cycles per SIMD): a wave spends ~550 at the barrier, ~550 deriving the next step's runs (an LDS read, a cross-lane shift, a ballot: all
+// latency), 500-1,550 issuing its DMA pieces, 1,700-2,000 in P1 (two rounds of an LDS round trip, two 4-deep chains of small MFMAs, ~25
+// dependent VALU instructions, an LDS store) and 3,300-4,300 in P2 - phases that follow each other inside a wave, each mostly latency,
+// while its SIMD partner is in another such phase: the two fill 40 % of the matrix pipe.  Here ONE instruction stream per wave carries
+// all of it: P2 of the step is 20 slots of two 32x32x16 MFMAs, and into the slots go, by slot number,
+//   * P1 of the NEXT step, one 16-frame block per five slots: the block's operand reads one chain link ahead, one small MFMA per slot
+//     (the chain's latency passes under the slot's large MFMAs), the VALU tail and the LDS store in the slot behind the chain;
+//   * the fetches: the tile pieces of step + 2 in slots 0-3, the row indices in slot 0, the run scan in slot 4, the staged rows of
+//     step + 1 (waves 0-3) from slot 6 on;
+//   * P2's own operand reads two slots ahead, the dZ1 fragments and the frames' ring addresses of the next k-step three slots ahead.
+// Every slot ends in a scheduling fence, so the order above is the order of the binary and hipcc's counted lgkmcnt waits follow from it.
+// To make room (the weave keeps P1's and P2's operands live together) the W2^T block of P1 lives in LDS instead of 16 registers per
+// lane, which leaves two tile buffers (tiles fetched two steps ahead) and a 5-group ring.  Same results as the kernels above.
+// -------------------------------------------------------------------------------------------------------------------------------------
+struct W64WMap {
+    static constexpr int NG = 5;
+    static constexpr int X = 0;                   // ring of 20 source rows x 1280 B (tr-swizzled by row & 3)
+    static constexpr int ZROW = X + NG * W_GROUP;
+    static constexpr int ONES = ZROW + 1280;
+    static constexpr int DZ = ONES + 1280;        // 2 x (4 k-tiles x [64 rows x 64 B]), chunk ^ 2 ((row >> 3) & 1)
+    static constexpr int H1 = DZ + 2 * 16384;     // 2 x [64 m][256 B], chunk c of row m at position c ^ (m & 15)
+    static constexpr int YS = H1 + 2 * 16384;     // 2 x [64 m][256 B] tr-swizzled: the dZ1 tile
+    static constexpr int W2T = YS + 2 * 16384;    // 4 k-tiles x [128 rows x 64 B], chunk ^ 2 ((row >> 3) & 1): this block's rows of W2^T
+    static constexpr int RUNROW = W2T + 32768;    // 8 waves x int32[64]
+    static constexpr int ROWS = RUNROW + 8 * 256; // 3 x int32[64]
+    static constexpr int LDS = ROWS + 3 * 256;
+};
+
+MG_STAMP_DECL(g_stamps_f64w);
+
+__global__ __launch_bounds__(512) void wgrad_fused64w_kernel(const uint16_t* __restrict__ dZ2, int lddz, const uint16_t* __restrict__ W2T,
+                                                             int ldwt, const uint16_t* __restrict__ H1, int ldh,
+                                                             const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
+                                                             int64_t M, int N, int K, int m_chunk, int n_splits,
+                                                             float* __restrict__ slab, float* __restrict__ bslab, int64_t sstride) {
+    using L = W64WMap;
+    static_assert(L::LDS <= 160 * 1024, "one workgroup per CU");
+    constexpr int NG = L::NG;
+    constexpr int TKT = 5;
+    constexpr int PY = 256, PX = W_BKT * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[L::LDS];
+    const unsigned smem_lds = (unsigned)(unsigned long long)((__attribute__((address_space(3))) unsigned char*)smem);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef MG_STAMPS
+    unsigned long long ts0, ts1 = 0, ts2, ts3, tr0, tr1, ta, tb, sum_wait = 0, sum_stream = 0;
+    MG_STAMP(ts0);
+    MG_STAMP_REAL(tr0);
+#endif
+    const int wn0 = (wave >> 2) * 64;
+    const int wk0 = (wave & 3) * (TKT * 32);
+    const int tiles_n = N / W_BNT;
+    const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3;
+    const int n0 = (jq % tiles_n) * W_BNT;
+    const int s = (jq / tiles_n) * 8 + xcd;
+    if (s >= n_splits) return;
+    const int64_t m_lo = (int64_t)s * m_chunk;
+    const int64_t m_hi = min(M, m_lo + (int64_t)m_chunk);
+    const int n_rows = m_hi > m_lo ? (int)(m_hi - m_lo) : 0;
+    const int n_steps = (n_rows + W_F - 1) / W_F;
+
+    if (tid < 80) *reinterpret_cast<uint4*>(smem + L::ZROW + tid * 16) = uint4{0u, 0u, 0u, 0u};
+    if (tid >= 128 && tid < 208) *reinterpret_cast<uint4*>(smem + L::ONES + (tid - 128) * 16) = uint4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+
+    const unsigned long long a_ptr = (unsigned long long)A;
+    const unsigned lda_bytes = (unsigned)lda * 2u;
+    auto opaque_lane = [&]() -> int {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        return ln;
+    };
+
+    // ---- one-time: this workgroup's 128 rows of W2^T, 4 k-tiles of [128 rows x 64 B] (32 pieces, 4 per wave) -------------------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = wave * 4 + i;
+        const int kt = p >> 3;
+        const int row = 16 * (p & 7) + (lane >> 2);
+        const int c = (lane & 3) ^ (((row >> 3) & 1) << 1);
+        wglds16(W2T + (size_t)(n0 + row) * ldwt + 32 * kt + 8 * c, smem_lds + L::W2T + p * 1024);
+    }
+
+    auto issue_rows = [&](int u) {                        // wave 0 only: the row indices of step u into slot u % 3
+        const int lane = opaque_lane();
+        const int f = u * W_F + lane;
+        int64_t m = m_lo + min(f, max(n_rows - 1, 0));
+        if (m > M - 1) m = M - 1;
+        const int32_t* src = rows + m;
+        const unsigned lds_uni = __builtin_amdgcn_readfirstlane(smem_lds + L::ROWS + (u % 3) * 256);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src), "s"(lds_uni)
+                     : "memory");
+    };
+    auto read_rows_raw = [&](int u) -> int {
+        const int lane = opaque_lane();
+        return *reinterpret_cast<const int*>(smem + L::ROWS + (u % 3) * 256 + lane * 4);
+    };
+    auto fix_rows = [&](int u, int v) -> int {
+        const int lane = opaque_lane();
+        return (u * W_F + lane < n_rows) ? v : -1;
+    };
+    struct StepMasks {
+        unsigned lo, hi, plo, phi;
+    };
+    auto scan_mask = [&](int rr) -> StepMasks {
+        const int lane = opaque_lane();
+        const int prev = __shfl_up(rr, 1, 64);
+        const bool flag = (lane == 0) || (rr != prev);
+        const unsigned long long mk = __ballot(flag), pk = __ballot(rr < 0);
+        StepMasks m;
+        m.lo = __builtin_amdgcn_readfirstlane((unsigned)mk);
+        m.hi = __builtin_amdgcn_readfirstlane((unsigned)(mk >> 32));
+        m.plo = __builtin_amdgcn_readfirstlane((unsigned)pk);
+        m.phi = __builtin_amdgcn_readfirstlane((unsigned)(pk >> 32));
+        return m;
+    };
+    auto runs_of = [&](const StepMasks& m) -> int { return __builtin_popcount(m.lo) + __builtin_popcount(m.hi); };
+    auto groups_of = [&](const StepMasks& m) -> int { return (runs_of(m) + 3) >> 2; };
+    int* my_runrow = reinterpret_cast<int*>(smem + L::RUNROW + wave * 256);
+
+    // staged rows: the private run -> source row table of a step (waves 0-3), then its pieces one at a time
+    auto x_table = [&](int rr, const StepMasks& mk) {
+        const int lane = opaque_lane();
+        const bool flag = ((lane < 32 ? (mk.lo >> lane) : (mk.hi >> (lane - 32))) & 1u) != 0u;
+        const int ord = (int)__builtin_amdgcn_mbcnt_hi(mk.hi, __builtin_amdgcn_mbcnt_lo(mk.lo, 0u)) + (flag ? 1 : 0) - 1;
+        if (flag) my_runrow[ord] = rr;
+    };
+    auto x_piece = [&](int pi, int n_runs, int rp, int g_first) {      // piece pi of the span of groups that starts at g_first
+        const int lane = opaque_lane();
+        const int gl = pi / 5, i = pi - 5 * gl;
+        const int byte = i * 1024 + lane * 16;
+        const int xr = byte >= 3 * PX ? 3 : byte >= 2 * PX ? 2 : byte >= PX ? 1 : 0;
+        const int cpos = (byte - xr * PX) >> 4;
+        const int xo = (cpos ^ ((xr & 3) << 2)) * 16;
+        const int run = 4 * (g_first + gl) + xr;
+        int src = my_runrow[min(run, 63)];
+        if (run >= n_runs || src < 0) src = 0;
+        int rg = rp + gl;
+        rg -= (rg >= NG) ? NG : 0;
+        wglds16((const void*)(a_ptr + (unsigned long long)(unsigned)src * lda_bytes + (unsigned)xo), smem_lds + L::X + rg * W_GROUP + i * 1024);
+    };
+    auto issue_x = [&](int rr, const StepMasks& mk, int rp, int g_first, int g_cnt, int rot) {      // the slow paths: all pieces at once
+        const int n_pieces = 5 * g_cnt;
+        int pi = (wave - rot) & 3;
+        if (wave >= 4 || pi >= n_pieces) return;
+        x_table(rr, mk);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int n_runs = runs_of(mk);
+        for (; pi < n_pieces; pi += 4) x_piece(pi, n_runs, rp, g_first);
+    };
+
+    // tile pieces: h = 0, 1: dZ2 pieces wave + 8 h (piece p: k-tile p >> 2, rows 16 (p & 3) ..), h = 2, 3: H1 pieces wave + 8 (h - 2)
+    const uint16_t* dz_base = dZ2 + (size_t)m_lo * lddz;
+    const uint16_t* h1_base = H1 + (size_t)m_lo * ldh + n0;
+    const int last_row = max(n_rows - 1, 0);
+    auto tile_piece = [&](int step, int buf, int h) {
+        const int lane = opaque_lane();
+        const int p = wave + 8 * (h & 1);
+        if (h < 2) {
+            const int dz_row = 16 * (p & 3) + (lane >> 2);
+            const int dz_col = 32 * (p >> 2) + 8 * ((lane & 3) ^ (((dz_row >> 3) & 1) << 1));
+            const int mz = min(step * W_F + dz_row, last_row);
+            wglds16_off(dz_base, (unsigned)(mz * lddz + dz_col) * 2u, smem_lds + L::DZ + buf * 16384 + p * 1024);
+        } else {
+            const int h1_row = 4 * p + (lane >> 4);
+            const int h1_col = 8 * ((lane & 15) ^ (h1_row & 15));
+            const int mh = min(step * W_F + h1_row, last_row);
+            wglds16_off(h1_base, (unsigned)(mh * ldh + h1_col) * 2u, smem_lds + L::H1 + buf * 16384 + p * 1024);
+        }
+    };
+
+    f32x16 acc[2][TKT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TKT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const bool bias_free = bslab != nullptr && (wave & 3) == 3;        // K <= 608: last 32-column tile of k-wave 3 is padding
+
+    // One step's stream: P2 of `step` (buffer yb2, masks mk4, ring base rp, pass g_first) and, when weave is set, P1 of step + 1
+    // (tiles tb -> dZ1 buffer yb2 ^ 1) and the fetches.  State handed back: the next step's masks (scanned in slot 4).
+    struct Next {
+        StepMasks mk;
+        int g, rp;
+        bool pref;
+    };
+    auto stream = [&](int step, int yb2, const StepMasks& mk4, int rp, int g_first, int g_cur, bool weave, bool more, int tb, Next& nx) {
+        const int lane = opaque_lane();
+        const int li = lane & 15, g4 = lane >> 4;
+        const int q = li >> 2, p4 = li & 3;
+        const int cgrp = 16 * (g4 & 1) + 4 * p4;
+        const int rbase = 8 * (g4 >> 1) + q;              // this lane's frame inside a 16-frame k-step (and + 4)
+        const int sw = q << 2;
+        int yoff[2], xk[TKT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int col = wn0 + i * 32 + cgrp;
+            yoff[i] = L::YS + yb2 * 16384 + rbase * PY + ((((col >> 3) ^ sw) << 4) | ((col & 7) << 1));
+        }
+#pragma unroll
+        for (int j = 0; j < TKT; ++j) {
+            const int col = wk0 + j * 32 + cgrp;
+            xk[j] = ((col >> 3) << 4) | ((col & 7) << 1);
+        }
+        const int bias_row = weave || g_first == 0 ? L::ONES : L::ZROW;       // the pass that carries the bias sums (pass 0)
+        const int pc_lo = __builtin_popcount(mk4.lo);
+        // ring byte offset and swizzle of this lane's two frames of k-step ks (0..3): index [ks & 1][hi]
+        int xb[2][2], xs[2][2];
+        auto frame_addr = [&](int ks) {
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi) {
+                const int f = 16 * (ks & 1) + rbase + 4 * hi;          // bit inside the half's mask
+                const unsigned mk = ks >= 2 ? mk4.hi : mk4.lo, pad = ks >= 2 ? mk4.phi : mk4.plo;
+                const int o = (ks >= 2 ? pc_lo - 1 : -1) + __builtin_popcount(mk & ((2u << f) - 1u));
+                const int gl = (o >> 2) - g_first;
+                int rg = rp + gl;
+                rg -= (rg >= NG) ? NG : 0;
+                const bool in_pass = (unsigned)gl < (unsigned)NG && ((pad >> f) & 1u) == 0u;
+                xb[ks & 1][hi] = in_pass ? L::X + (rg * 4 + (o & 3)) * PX : L::ZROW;
+                xs[ks & 1][hi] = in_pass ? (o & 3) << 6 : 0;
+            }
+        };
+        auto rd_a = [&](int ks, int i) -> bfv8 {
+            const unsigned char* ad = smem + yoff[i] + ks * 16 * PY;
+            const bfv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(ad));
+            const bfv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(ad + 4 * PY));
+            return bfv8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+        auto rd_b = [&](int ks, int j) -> bfv8 {
+            const bool bias_blk = bias_free && j == TKT - 1;
+            const unsigned char* alo = smem + (bias_blk ? bias_row : xb[ks & 1][0]) + (xk[j] ^ xs[ks & 1][0]);
+            const unsigned char* ahi = smem + (bias_blk ? bias_row : xb[ks & 1][1]) + (xk[j] ^ xs[ks & 1][1]);
+            const bfv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(alo));
+            const bfv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(ahi));
+            return bfv8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+
+        // ---- P1 of step + 1: this wave's 16 hidden units, one 16-frame block k at a time --------------------------------------------
+        const int l15 = lane & 15, lq = lane >> 4;
+        const int c16 = 2 * wave + (lq >> 1);
+        const int a_row = 16 * wave + l15;
+        const int w_off0 = L::W2T + a_row * 64 + ((lq ^ (((a_row >> 3) & 1) << 1)) << 4);               // + 8192 per k-tile
+        const int b_off0 = L::DZ + tb * 16384 + l15 * 64 + ((lq ^ (((l15 >> 3) & 1) << 1)) << 4);       // + 1024 k + 4096 per k-tile
+        const int h_off0 = L::H1 + tb * 16384 + l15 * 256 + ((c16 ^ l15) << 4) + 8 * (lq & 1);          // + 4096 k
+        const int y_off0 = L::YS + (yb2 ^ 1) * 16384 + l15 * 256 + ((c16 ^ ((l15 & 3) << 2)) << 4) + 8 * (lq & 1);
+        const int f_left = n_rows - (step + 1) * W_F - l15;
+        bfv8 pw[2], pb[2];
+        bfv4 hv;
+        f32x4 pd = {0.f, 0.f, 0.f, 0.f};
+        auto p1_read = [&](int k, int c) {
+            pw[c & 1] = *reinterpret_cast<const bfv8*>(smem + w_off0 + c * 8192);
+            pb[c & 1] = *reinterpret_cast<const bfv8*>(smem + b_off0 + k * 1024 + c * 4096);
+        };
+        auto p1_mfma = [&](int c) {
+            if (c == 0) pd = f32x4{0.f, 0.f, 0.f, 0.f};
+            pd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pw[c & 1], pb[c & 1], pd, 0, 0, 0);
+        };
+        auto p1_hv = [&](int k) { hv = *reinterpret_cast<const bfv4*>(smem + h_off0 + k * 4096); };
+        auto p1_finish = [&](int k) {
+            float v[4];
+            const bool inside = 16 * k < f_left;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float h = (float)hv[e];
+                v[e] = inside ? pd[e] * h * (1.f - h) : 0.f;
+            }
+            const u32x2 pk = u32x2{__builtin_bit_cast(unsigned int, bfv2{(__bf16)v[0], (__bf16)v[1]}),
+                                   __builtin_bit_cast(unsigned int, bfv2{(__bf16)v[2], (__bf16)v[3]})};
+            *reinterpret_cast<u32x2*>(smem + y_off0 + k * 4096) = pk;
+        };
+        const bool do_p1 = weave && more;
+
+        // ---- fetch state -------------------------------------------------------------------------------------------------------------
+        int rv = 0;                                       // raw row index of frame `lane` of step + 1
+        int x_np = 0, x_nruns = 0;                        // pieces / runs of the staged rows of step + 1 (0: nothing to fetch ahead)
+
+        bfv8 a[2][2], b[4];                               // dZ1 fragments of k-step ks in a[ks & 1]; operand ring b[t & 3]
+        frame_addr(0);
+        a[0][0] = rd_a(0, 0);
+        a[0][1] = rd_a(0, 1);
+        b[0] = rd_b(0, 0);
+        b[1] = rd_b(0, 1);
+        if (weave) rv = read_rows_raw(step + 1);
+        __builtin_amdgcn_sched_barrier(0);
+
+        auto slot = [&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int ks = t / TKT, j = t % TKT;
+            // reads: P2's operand of slot t + 2; the dZ1 fragments of the next k-step; P1's chain operands one link ahead
+            if constexpr (t + 2 < 4 * TKT) b[(t + 2) & 3] = rd_b((t + 2) / TKT, (t + 2) % TKT);
+            if constexpr (j == 2 && ks + 1 < 4) {
+                a[(ks + 1) & 1][0] = rd_a(ks + 1, 0);
+                a[(ks + 1) & 1][1] = rd_a(ks + 1, 1);
+            }
+            constexpr int k1 = t / 5, c1 = t % 5;          // P1: block k1, position c1 inside the block's five slots
+            if (do_p1) {
+                if constexpr (c1 < 4) p1_read(k1, c1);
+                if constexpr (c1 == 3) p1_hv(k1);
+                if constexpr (c1 == 0 && k1 > 0) p1_finish(k1 - 1);
+                if constexpr (c1 >= 1) p1_mfma(c1 - 1);
+            }
+            // fetches
+            if (weave) {
+                if constexpr (t == 0) {
+                    if (wave == 0) issue_rows(step + 2);
+                }
+                if constexpr (t < 4) tile_piece(step + 2, step & 1, t);
+                if constexpr (t == 4) {
+                    nx.mk = scan_mask(fix_rows(step + 1, rv));
+                    nx.g = groups_of(nx.mk);
+                    nx.pref = more && g_cur <= NG && g_cur + min(nx.g, NG) <= NG;
+                    nx.rp = rp + g_cur;
+                    nx.rp -= (nx.rp >= NG) ? NG : 0;
+                    x_np = (nx.pref && wave < 4) ? 5 * min(nx.g, NG) : 0;
+                    x_nruns = runs_of(nx.mk);
+                }
+                if constexpr (t == 5) {
+                    if (x_np > 0) x_table(fix_rows(step + 1, rv), nx.mk);
+                }
+                if constexpr (t >= 6 && t < 13) {
+                    const int pi = ((wave - step) & 3) + 4 * (t - 6);
+                    if (pi < x_np) x_piece(pi, x_nruns, nx.rp, 0);
+                }
+            }
+            // P2
+            if constexpr (j == 1 && ks + 1 < 4) frame_addr(ks + 1);
+            acc[0][j] = mg_mfma_32x32x16(a[ks & 1][0], b[t & 3], acc[0][j]);
+            acc[1][j] = mg_mfma_32x32x16(a[ks & 1][1], b[t & 3], acc[1][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        slot(std::integral_constant<int, 0>{});
+        slot(std::integral_constant<int, 1>{});
+        slot(std::integral_constant<int, 2>{});
+        slot(std::integral_constant<int, 3>{});
+        slot(std::integral_constant<int, 4>{});
+        slot(std::integral_constant<int, 5>{});
+        slot(std::integral_constant<int, 6>{});
+        slot(std::integral_constant<int, 7>{});
+        slot(std::integral_constant<int, 8>{});
+        slot(std::integral_constant<int, 9>{});
+        slot(std::integral_constant<int, 10>{});
+        slot(std::integral_constant<int, 11>{});
+        slot(std::integral_constant<int, 12>{});
+        slot(std::integral_constant<int, 13>{});
+        slot(std::integral_constant<int, 14>{});
+        slot(std::integral_constant<int, 15>{});
+        slot(std::integral_constant<int, 16>{});
+        slot(std::integral_constant<int, 17>{});
+        slot(std::integral_constant<int, 18>{});
+        slot(std::integral_constant<int, 19>{});
+        if (do_p1) p1_finish(3);                          // (slots 6-12 take 7 x 4 = 28 staged-row pieces; a span has at most 5 NG = 25)
+    };
+
+    // ---- per-step state --------------------------------------------------------------------------------------------------------------
+    StepMasks mk_cur = {0u, 0u, 0u, 0u};
+    int rp_cur = 0;
+    bool have_cur = true;
+    if (n_steps > 0) {
+        // prologue: row indices of steps 0 and 1, staged rows and tiles of step 0 (and W2^T) waited for, P1 of step 0 as the
+        // un-woven chain, tiles of step 1 in flight
+        if (wave == 0) {
+            issue_rows(0);
+            issue_rows(1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        const int r0 = fix_rows(0, read_rows_raw(0));
+        mk_cur = scan_mask(r0);
+        issue_x(r0, mk_cur, 0, 0, min(groups_of(mk_cur), NG), 0);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) tile_piece(0, 0, h);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        {
+            const int lane = opaque_lane();
+            const int l15 = lane & 15, lq = lane >> 4;
+            const int c16 = 2 * wave + (lq >> 1);
+            const int a_row = 16 * wave + l15;
+            const int w_off0 = L::W2T + a_row * 64 + ((lq ^ (((a_row >> 3) & 1) << 1)) << 4);
+            const int b_off0 = L::DZ + l15 * 64 + ((lq ^ (((l15 >> 3) & 1) << 1)) << 4);
+            const int h_off0 = L::H1 + l15 * 256 + ((c16 ^ l15) << 4) + 8 * (lq & 1);
+            const int y_off0 = L::YS + l15 * 256 + ((c16 ^ ((l15 & 3) << 2)) << 4) + 8 * (lq & 1);
+            const int f_left = n_rows - l15;
+            for (int k = 0; k < 4; ++k) {
+                f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const bfv8 w = *reinterpret_cast<const bfv8*>(smem + w_off0 + c * 8192);
+                    const bfv8 bb = *reinterpret_cast<const bfv8*>(smem + b_off0 + k * 1024 + c * 4096);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, bb, d, 0, 0, 0);
+                }
+                const bfv4 hv = *reinterpret_cast<const bfv4*>(smem + h_off0 + k * 4096);
+                float v[4];
+                const bool inside = 16 * k < f_left;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float h = (float)hv[e];
+                    v[e] = inside ? d[e] * h * (1.f - h) : 0.f;
+                }
+                const u32x2 pk = u32x2{__builtin_bit_cast(unsigned int, bfv2{(__bf16)v[0], (__bf16)v[1]}),
+                                       __builtin_bit_cast(unsigned int, bfv2{(__bf16)v[2], (__bf16)v[3]})};
+                *reinterpret_cast<u32x2*>(smem + y_off0 + k * 4096) = pk;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) tile_piece(1, 1, h);
+    }
+    for (int step = 0; step < n_steps; ++step) {
+        // Landed: staged rows of this step (when fetched ahead), tiles and row indices of step + 1; dZ1(step) complete; the buffers of
+        // the last step are free.
+        MG_STAMP(ta);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        MG_STAMP(tb);
+        MG_STAMP_ADD(sum_wait, tb, ta);
+#ifdef MG_STAMPS
+        if (step == 0) ts1 = tb;
+#endif
+        const bool more = step + 1 < n_steps;
+        const int g_cur = groups_of(mk_cur);
+        if (!have_cur) {                                  // this step's rows did not fit beside its predecessor's: fetch them now
+            rp_cur = 0;
+            issue_x(fix_rows(step, read_rows_raw(step)), mk_cur, 0, 0, min(g_cur, NG), step);
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        Next nx = {{0u, 0u, 0u, 0u}, 0, 0, false};
+        for (int gf = 0;; gf += NG) {
+            if (gf > 0) {                                 // more runs than the ring holds: the remaining groups in passes (rare)
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                issue_x(fix_rows(step, read_rows_raw(step)), mk_cur, 0, gf, min(g_cur - gf, NG), step);
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            Next scratch = nx;
+            stream(step, step & 1, mk_cur, gf ? 0 : rp_cur, gf, g_cur, gf == 0, more, (step + 1) & 1, gf == 0 ? nx : scratch);
+            if (gf + NG >= g_cur) break;
+        }
+        MG_STAMP(ta);
+        MG_STAMP_ADD(sum_stream, ta, tb);
+        mk_cur = nx.mk;
+        rp_cur = nx.pref ? nx.rp : 0;
+        have_cur = nx.pref || !more;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tiles fetched past the end
+#ifdef MG_STAMPS
+    MG_STAMP(ts2);
+#endif
+
+    const int lr = lane & 31, lh = lane >> 5;
+    float* out = slab + (size_t)s * sstride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < TKT; ++j) {
+            const int col = wk0 + j * 32 + lr;
+            if (col >= K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n0 + wn0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < N) out[(size_t)row * K + col] = acc[i][j][r];
+            }
+        }
+    }
+    if (bias_free && lr == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n0 + wn0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < N) bslab[(size_t)s * sstride + row] = acc[i][TKT - 1][r];
+            }
+    }
+#ifdef MG_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MG_STAMP(ts3);
+    MG_STAMP_REAL(tr1);
+    const int sb = blockIdx.x;
+    MG_STAMP_STORE(g_stamps_f64w, sb, wave, lane, 0, ts0);
+    MG_STAMP_STORE(g_stamps_f64w, sb, wave, lane, 1, ts1);
+    MG_STAMP_STORE(g_stamps_f64w, sb, wave, lane, 2, ts2);
+    MG_STAMP_STORE(g_stamps_f64w, sb, wave, lane, 3, ts3);
+    MG_STAMP_STORE(g_stamps_f64w, sb, wave, lane, 4, tr0);
+    MG_STAMP_STORE(g_stamps_f64w, sb, wave, lane, 5, tr1);
+    MG_STAMP_STORE(g_stamps_f64w, sb, wave, lane, 6, sum_wait);
+    MG_STAMP_STORE(g_stamps_f64w, sb, wave, lane, 7, sum_stream);
+#endif
+}
+
 // Launch helper used by fused_launch (bwd_fused_bf16.hip): the 64-frame-step kernel on the plan of the 32-frame one (same frame
 // ranges, same slabs - the results are bit-identical).  nbt: 3 = tiles fetched three steps ahead (5 ring groups), 2 = two (8 groups).
 void mg_launch_fused64(int nbt, const uint16_t* dZ2, int lddz, const uint16_t* W2T, int ldwt, const uint16_t* H1, int ldh, const uint16_t* A,
                        int lda, const int32_t* rows, int64_t M, int N, int K, int m_chunk, int n_splits, float* slab, float* bslab,
                        int64_t sstride, hipStream_t st) {
     const dim3 grid((unsigned)((N / W_BNT) * mg_align_up((size_t)n_splits, 8))), block(512);
-    if (nbt == 2)
+#ifdef MG_PROBES
+#define W64_PROBE_CASE(P)                                                                                                                  \
+    case 100 + P:                                                                                                                          \
+        hipLaunchKernelGGL((wgrad_fused64_kernel<3, P>), grid, block, 0, st, dZ2, lddz, W2T, ldwt, H1, ldh, A, lda, rows, M, N, K, m_chunk,   \
+                           n_splits, slab, bslab, sstride);                                                                                \
+        return;
+    switch (nbt) {
+        W64_PROBE_CASE(1) W64_PROBE_CASE(2) W64_PROBE_CASE(4) W64_PROBE_CASE(6) W64_PROBE_CASE(8) W64_PROBE_CASE(12) W64_PROBE_CASE(14)
+        W64_PROBE_CASE(16)
+        default: break;
+    }
+#endif
+    if (nbt == 1)
+        hipLaunchKernelGGL(wgrad_fused64w_kernel, grid, block, 0, st, dZ2, lddz, W2T, ldwt, H1, ldh, A, lda, rows, M, N, K, m_chunk, n_splits, slab,
+                           bslab, sstride);
+    else if (nbt == 2)
         hipLaunchKernelGGL(wgrad_fused64_kernel<2>, grid, block, 0, st, dZ2, lddz, W2T, ldwt, H1, ldh, A, lda, rows, M, N, K, m_chunk, n_splits, slab,
                            bslab, sstride);
     else
@@ -534,6 +1060,9 @@ void mg_launch_fused64(int nbt, const uint16_t* dZ2, int lddz, const uint16_t* W
 }
 
 #ifdef MG_STAMPS
+extern "C" int mg_diag_read_stamps_f64w(void* dst, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps_f64w), bytes < sizeof(g_stamps_f64w) ? bytes : sizeof(g_stamps_f64w), 0, hipMemcpyDeviceToHost);
+}
 extern "C" int mg_diag_read_stamps_f64(void* dst, size_t bytes) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps_f64), bytes < sizeof(g_stamps_f64) ? bytes : sizeof(g_stamps_f64), 0, hipMemcpyDeviceToHost);
 }

@@ -1204,8 +1204,9 @@ static int fused_launch(const char* name, const uint16_t* dZ2, int lddz, int N2,
     const int64_t nk = (int64_t)N * K, sstride = nk + N;
     float* slab = (float*)workspace;
     float* bslab = slab + nk;
-    if (rows && (g_mg_tuning[MG_TUNE_STAGGER] == 0 || g_mg_tuning[MG_TUNE_STAGGER] == 12))      // 64-frame steps (bwd_fused64_bf16.hip)
-        mg_launch_fused64(g_mg_tuning[MG_TUNE_STAGGER] == 12 ? 2 : 3, dZ2, lddz, W2T, ldwt, H1, ldh, A, lda, rows, M, N, K, chunk, S, slab, bslab,
+    if (rows && (g_mg_tuning[MG_TUNE_STAGGER] == 0 || g_mg_tuning[MG_TUNE_STAGGER] == 12 || g_mg_tuning[MG_TUNE_STAGGER] == 14 ||
+                 g_mg_tuning[MG_TUNE_STAGGER] >= 100))      // 64-frame steps (bwd_fused64_bf16.hip); >= 100: its timing probes (-DMG_PROBES builds)
+        mg_launch_fused64(g_mg_tuning[MG_TUNE_STAGGER] >= 100 ? g_mg_tuning[MG_TUNE_STAGGER] : g_mg_tuning[MG_TUNE_STAGGER] == 12 ? 2 : g_mg_tuning[MG_TUNE_STAGGER] == 14 ? 1 : 3, dZ2, lddz, W2T, ldwt, H1, ldh, A, lda, rows, M, N, K, chunk, S, slab, bslab,
                           sstride, st);
     else if (rows && g_mg_tuning[MG_TUNE_STAGGER] == 9)      // timing probe: the same with a 128 x 512 tile (no spills; results incomplete)
         hipLaunchKernelGGL(wgrad_fused_solo_kernel<4>, dim3((unsigned)((N / F_BNT) * mg_align_up((size_t)S, 8))), dim3(256), 0, st, dZ2, lddz, W2T,

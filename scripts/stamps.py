@@ -94,6 +94,13 @@ def main():
         report(title + ' (dgrad2 + wgrad1, gathered input, 64-frame steps)', s,
                [('  loop: wait + barrier', s[..., 6]), ('  loop: run scan of the next step', s[..., 10]), ('  loop: fetch (DMA issue)', s[..., 7]),
                 ('  loop: P1', s[..., 8]), ('  loop: P2', s[..., 9])])
+    lib.mg_set_tuning(0, 14)
+    for _ in range(3):
+        ops.linear_bwd_fused_bf16(dz2, w2t, h1, tab, rows, m, 512, 600)
+    torch.cuda.synchronize()
+    lib.mg_set_tuning(0, 0)
+    s = read(lib, 'mg_diag_read_stamps_f64w', 256)
+    report('wgrad_fused64w (woven stream)', s, [('  loop: wait + barrier', s[..., 6]), ('  loop: the stream', s[..., 7])])
     lib.mg_set_tuning(0, 13)
     for _ in range(3):
         ops.linear_bwd_fused_bf16(dz2, w2t, h1, tab, rows, m, 512, 600)

@@ -576,7 +576,7 @@ def test_wgrad_dgrad_pair_equals_the_two_launches(m):
     np.testing.assert_allclose(tot3.cpu().numpy(), tot.cpu().numpy(), rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize('nbt_knob', [0, 12])
+@pytest.mark.parametrize('nbt_knob', [0, 12, 14])
 def test_fused_backward_64_frame_steps_equal_32_frame_kernel(nbt_knob):
     """wgrad_fused64_kernel (csrc/bwd_fused64_bf16.hip: 64-frame steps, the run structure of a step from a ballot instead of LDS
     tables, ring allocated by groups per step, passes for steps with more runs than the ring holds) against the 32-frame-step kernel
