@@ -508,9 +508,7 @@ def other_workloads(dev, precision):
                 synthetic.acoustic_normalisers(model, device=dev)
                 model.mode = 'train'
                 model.metrics.reset_state('train')
-            feats = data.to_device(feats_np, dev)
-            if precision == 'bf16':
-                data.add_bf16_table(feats)
+            feats = data.to_device(feats_np, dev, bf16_tables=model.bf16_table_features())
             opt = optim.Adam(model.parameters(), lr=0.01, fused_loop=True)
 
             def step():
@@ -613,9 +611,9 @@ def main():
         synthetic.acoustic_normalisers(model, device=dev)
         model.mode = 'train'
         model.metrics.reset_state('train')
-    features = data.to_device(feats_np, dev)
-    if args.precision == 'bf16':
-        data.add_bf16_table(features)    # loader-side half of bf16 mode: the phone table's bf16 copy is made when the batch is loaded
+    # the product's loader call (data.to_device = ToDeviceWrapper, data.py:648-663): in bf16 precision the batch carries the bf16
+    # operand table of the model's phone-level input, exactly as ExperimentBuilder.train_epoch's batches do
+    features = data.to_device(feats_np, dev, bf16_tables=model.bf16_table_features())
     frames_per_step = int(feats_np['n_frames'].sum())
     rehearse = bool(args.rehearse_exchange) and world == 1
     if rehearse:

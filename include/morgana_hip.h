@@ -219,6 +219,12 @@ int mg_mlpg_f32(const float* means, const float* variances, int var_per_frame, c
  * zero padded to T frames and its normalised twin (kind MG_NORM_MVN or MG_NORM_MINMAX), zero in the pad frames. */
 int mg_pad_normalise_f32(const float* packed, const int64_t* offsets, int B, int T, int D, const float* p0, const float* p1,
                          int kind, float* raw_out, float* norm_out, void* stream);
+/* The same pass with the loader-side half of bf16 mode (reference: the float32 cast on load, data.py:127 - here the bf16 operand of
+ * the first Linear is data preparation too): besides raw_out / norm_out (either may be NULL) it writes table_bf16
+ * [B*T + extra_rows, ldb] bf16 = the normalised feature's rows (zero in pad frames), columns D .. ldb-1 zero, extra_rows zero rows
+ * behind - what mg_cast_pad_bf16 would make of norm_out, without a second pass.  ldb >= D; kind MG_NORM_MVN or MG_NORM_MINMAX. */
+int mg_pad_normalise_bf16_f32(const float* packed, const int64_t* offsets, int B, int T, int D, const float* p0, const float* p1, int kind,
+                              float* raw_out, float* norm_out, uint16_t* table_bf16, int ldb, int extra_rows, void* stream);
 int mg_normalise_f32(const float* x, float* out, const float* p0, const float* p1, int64_t n_rows, int D, int kind,
                      void* stream);
 

@@ -42,6 +42,8 @@ SIGNATURES = {
                                    c_void_p, c_void_p, c_size_t, c_void_p]),
     'mg_pad_normalise_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                      c_void_p]),
+    'mg_pad_normalise_bf16_f32': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                          c_void_p, c_int, c_int, c_void_p]),
     'mg_normalise_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     'mg_linear_fwd_f32': (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                   c_int, c_int, c_void_p]),
@@ -280,7 +282,12 @@ def last_error():
     return load().mg_last_error().decode('utf-8', 'replace')
 
 
+CALL_LOG = None      # debugging aid: set to a list and every C-ABI call that went through check() appends its entry-point name
+
+
 def check(rc, what):
+    if CALL_LOG is not None:
+        CALL_LOG.append(what)
     if rc != 0:
         msg = last_error()
         if rc == -1:

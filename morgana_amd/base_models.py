@@ -60,6 +60,11 @@ class BaseModel(nn.Module):
         state = torch.load(checkpoint_path, map_location=device)
         self.load_state_dict(state, strict=strict)
 
+    def bf16_table_features(self):
+        """Names of the phone-level input features whose bf16 operand table this model reads when it runs in bf16 precision (the
+        loader then carries ``name + '__bf16_table'`` next to the feature: ``data.DeviceBatches.use_bf16_tables``); () otherwise."""
+        return ()
+
     # analysis hooks (no-ops here; base_models.py:177-253)
     def analysis_for_train_batch(self, features, output_features, out_dir, **kwargs):
         pass

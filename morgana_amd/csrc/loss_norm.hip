@@ -246,6 +246,52 @@ __global__ __launch_bounds__(256) void pad_normalise_kernel(const float* __restr
     }
 }
 
+// The same pass with the loader-side half of bf16 mode: next to the fp32 outputs it writes the bf16 OPERAND TABLE of the normalised
+// feature - [B*T + extra_rows, ldb] bf16, row b*T + t = the normalised frame (zero for pad frames), columns D .. ldb-1 zero (the
+// large-tile kernels' K padding), extra_rows zero rows behind (what pad frames gather in the phone-rate step).  One read of the
+// packed feature; the stand-alone cast (mg_cast_pad_bf16) re-read the 49 MB fp32 feature and wrote the table in every training
+// step of a loop whose loader did not provide it.  grid (chunks, B + 1): block row B zeroes the extra rows.
+__global__ __launch_bounds__(256) void pad_normalise_bf16_kernel(const float* __restrict__ packed, const int64_t* __restrict__ offsets,
+                                                                 int B, int T, int D, const float* __restrict__ p0,
+                                                                 const float* __restrict__ p1, int kind, float* __restrict__ raw_out,
+                                                                 float* __restrict__ norm_out, uint16_t* __restrict__ bf_out, int ldb,
+                                                                 int extra_rows) {
+    const int b = blockIdx.y;
+    if (b == B) {                                        // the zero rows behind the table
+        uint16_t* dst = bf_out + (size_t)B * T * ldb;
+        const int64_t n = (int64_t)extra_rows * ldb;
+        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) dst[e] = 0;
+        return;
+    }
+    const int64_t lo = offsets[b];
+    int64_t len = offsets[b + 1] - lo;
+    if (len > T) len = T;
+    const float* src = packed + lo * D;
+    const size_t base = (size_t)b * T * D, bf_base = (size_t)b * T * ldb;
+    const int64_t n = (int64_t)T * ldb;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int64_t t = e / ldb;
+        const int d = (int)(e - t * ldb);
+        float v = 0.f, r = 0.f;
+        if (d < D && t < len) {
+            v = src[t * D + d];
+            const float a = p0[d], c = p1[d];
+            if (kind == MG_NORM_MVN) {
+                r = (v - a) / (c + 1e-8f);
+            } else {
+                float scale = c - a;
+                if (fabsf(scale) <= 1e-8f) scale = 1.f;
+                r = (v - a) / scale;
+            }
+        }
+        if (d < D) {
+            if (raw_out) raw_out[base + t * D + d] = v;
+            if (norm_out) norm_out[base + t * D + d] = r;
+        }
+        bf_out[bf_base + e] = mg_f2bf(r);
+    }
+}
+
 static size_t masked_ws_bytes(int B, int T, int D) {
     const int64_t chunks = mg_ceil_div((int64_t)T * D, MSE_CHUNK);
     return mg_align_up((size_t)B * (size_t)(chunks < 1 ? 1 : chunks) * sizeof(float), 256);
@@ -353,6 +399,25 @@ int mg_pad_normalise_f32(const float* packed, const int64_t* offsets, int B, int
     hipLaunchKernelGGL(pad_normalise_kernel, dim3((unsigned)chunks, B), dim3(256), 0, (hipStream_t)stream, packed, offsets, T, D, p0, p1, kind,
                        raw_out, norm_out);
     MG_CHECK_LAUNCH("mg_pad_normalise_f32");
+    return MG_OK;
+}
+
+int mg_pad_normalise_bf16_f32(const float* packed, const int64_t* offsets, int B, int T, int D, const float* p0, const float* p1, int kind,
+                              float* raw_out, float* norm_out, uint16_t* table_bf16, int ldb, int extra_rows, void* stream) {
+    MG_CHECK_ARG(packed && offsets && table_bf16 && B > 0 && T >= 0 && D > 0, "mg_pad_normalise_bf16_f32: bad arguments (B=%d T=%d D=%d)", B, T,
+                 D);
+    MG_CHECK_ARG(p0 && p1 && (kind == MG_NORM_MVN || kind == MG_NORM_MINMAX),
+                 "mg_pad_normalise_bf16_f32: needs normaliser parameters and kind MG_NORM_MVN or MG_NORM_MINMAX (kind=%d)", kind);
+    MG_CHECK_ARG(ldb >= D && extra_rows >= 0, "mg_pad_normalise_bf16_f32: ldb=%d must cover D=%d, extra_rows=%d must not be negative", ldb, D,
+                 extra_rows);
+    MG_CHECK_ARG(B < 65535, "mg_pad_normalise_bf16_f32: B=%d exceeds 65534", B);
+    if (T == 0 && extra_rows == 0) return MG_OK;
+    int64_t chunks = mg_ceil_div((int64_t)T * ldb, 256 * 8);
+    if (chunks > 1024) chunks = 1024;
+    if (chunks < 1) chunks = 1;
+    hipLaunchKernelGGL(pad_normalise_bf16_kernel, dim3((unsigned)chunks, B + (extra_rows > 0 ? 1 : 0)), dim3(256), 0, (hipStream_t)stream,
+                       packed, offsets, B, T, D, p0, p1, kind, raw_out, norm_out, table_bf16, ldb, extra_rows);
+    MG_CHECK_LAUNCH("mg_pad_normalise_bf16_f32");
     return MG_OK;
 }
 

@@ -1,8 +1,8 @@
-"""Mirror of the normaliser part of ``morgana.data`` (the arithmetic is on the hot path; file/JSON plumbing is not).
+"""The normaliser and loader side of ``morgana.data`` in front of the HIP kernels.
 
-Reference: morgana/data.py - ``normalise_mvn`` / ``denormalise_mvn`` :533-538, ``normalise_minmax`` /
-``denormalise_minmax`` :579-590, ``_FeatureNormaliser`` :252-386, ``MeanVarianceNormaliser`` :541-564,
-``MinMaxNormaliser`` :593-616.
+Reference behaviour: morgana/data.py - ``normalise_mvn`` / ``denormalise_mvn`` :533-538, ``normalise_minmax`` /
+``denormalise_minmax`` :579-590, the normaliser classes :252-386, :541-616 (here: one affine-map class driven by a table of
+kinds, ``FeatureNormaliser``), ``collate_fn`` :159-224, ``FilesDataset`` :60-157, ``ToDeviceWrapper`` :648-663.
 
 As in the reference, every function works on NumPy arrays (loader side, host arithmetic: data.py:119-127) and on
 torch tensors (model side, README.rst:87); device tensors go through the fused HIP elementwise kernel.
@@ -14,10 +14,6 @@ import numpy as np
 import torch
 
 from . import ops
-
-
-def _is_np(x):
-    return isinstance(x, np.ndarray)
 
 
 class _NormFn(torch.autograd.Function):
@@ -54,131 +50,148 @@ def _device_norm(feature, p0, p1, kind):
     return _NormFn.apply(feature, p0, p1, kind)
 
 
+# One table describes every normalisation this package knows: a normaliser is an AFFINE map per feature column,
+#     normalise(x) = (x - offset) / divisor        denormalise(y) = y * multiplier + offset,
+# and a kind says how (offset, divisor, multiplier) follow from its two stored parameter vectors, which JSON file holds them and
+# which op code of the device kernel (mg_normalise_f32) computes the same map.  Reference arithmetic: data.py:533-538 (mvn),
+# :579-590 (minmax; a zero range divides by one).
+def _minmax_range(mmin, mmax):
+    span = mmax - mmin
+    return np.where(np.abs(span) <= 1e-8, np.ones_like(span), span)
+
+
+_KINDS = {
+    'mvn': {'params': ('mean', 'std_dev'), 'file': '{name}_mvn.json', 'forward': ops.NORM_MVN, 'inverse': ops.DENORM_MVN,
+            'affine': lambda mean, std_dev: (mean, std_dev + 1e-8, std_dev)},
+    'minmax': {'params': ('mmin', 'mmax'), 'file': '{name}_minmax.json', 'forward': ops.NORM_MINMAX, 'inverse': ops.DENORM_MINMAX,
+               'affine': lambda mmin, mmax: (mmin, _minmax_range(mmin, mmax), _minmax_range(mmin, mmax))},
+}
+
+
+def _apply_kind(kind, feature, p0, p1, inverse):
+    """The map of ``kind`` (or its inverse) over the last axis of ``feature``: NumPy on the host (the loader side, data.py:119-127),
+    the HIP elementwise kernel for device tensors (the model side, README.rst:87)."""
+    spec = _KINDS[kind]
+    if isinstance(feature, np.ndarray):
+        offset, divisor, multiplier = spec['affine'](p0, p1)
+        if inverse:
+            return (feature * multiplier[..., None, :]) + offset[..., None, :]
+        return (feature - offset[..., None, :]) / divisor[..., None, :]
+    return _device_norm(feature, p0, p1, spec['inverse' if inverse else 'forward'])
+
+
 def normalise_mvn(feature, mean, std_dev):
-    if _is_np(feature):
-        return (feature - mean[..., None, :]) / (std_dev[..., None, :] + 1e-8)      # data.py:533-534
-    return _device_norm(feature, mean, std_dev, ops.NORM_MVN)
+    return _apply_kind('mvn', feature, mean, std_dev, inverse=False)
 
 
 def denormalise_mvn(feature, mean, std_dev):
-    if _is_np(feature):
-        return (feature * std_dev[..., None, :]) + mean[..., None, :]              # data.py:537-538
-    return _device_norm(feature, mean, std_dev, ops.DENORM_MVN)
+    return _apply_kind('mvn', feature, mean, std_dev, inverse=True)
 
 
 def normalise_minmax(feature, mmin, mmax):
-    if _is_np(feature):
-        scale = mmax - mmin
-        scale[abs(scale) <= 1e-8] = 1.                                             # data.py:580-581
-        return (feature - mmin[..., None, :]) / scale[..., None, :]
-    return _device_norm(feature, mmin, mmax, ops.NORM_MINMAX)
+    return _apply_kind('minmax', feature, mmin, mmax, inverse=False)
 
 
 def denormalise_minmax(feature, mmin, mmax):
-    if _is_np(feature):
-        scale = mmax - mmin
-        scale[abs(scale) <= 1e-8] = 1.
-        return (feature * scale[..., None, :]) + mmin[..., None, :]
-    return _device_norm(feature, mmin, mmax, ops.DENORM_MINMAX)
+    return _apply_kind('minmax', feature, mmin, mmax, inverse=True)
 
 
-class _FeatureNormaliser(object):
-    """Abstract feature normaliser exposing ``normalise`` / ``denormalise`` (data.py:252-386)."""
+class _ParamGroup(object):
+    """The two parameter vectors of one normaliser (its statics, or its deltas): float32 NumPy arrays for the host path and the same
+    values as torch tensors on ``device`` for the device path."""
 
-    def __init__(self, name, use_deltas=False, file_pattern='{name}.json'):
+    def __init__(self, kind, values, device='cpu'):
+        names = _KINDS[kind]['params']
+        missing = [n for n in names if n not in values]
+        if missing:
+            raise KeyError('normaliser parameters %s missing (have %s)' % (missing, sorted(values)))
+        self.host = {n: np.asarray(values[n], dtype=np.float32) for n in values}
+        self.torch = {n: torch.tensor(v).to(device) for n, v in self.host.items()}
+
+    @classmethod
+    def from_json(cls, kind, path, device='cpu'):
+        with open(path, 'r') as f:
+            return cls(kind, json.load(f), device=device)
+
+
+class FeatureNormaliser(object):
+    """A named feature's normaliser: ``kind`` (a row of ``_KINDS``) + up to two parameter groups (the feature itself; its deltas when
+    ``use_deltas``).  Public surface of the reference's normalisers (data.py:252-386): ``normalise`` / ``denormalise`` on NumPy arrays
+    and tensors, ``fetch_params``, ``load_params`` from ``{name}_<kind>.json``, the ``params`` / ``params_torch`` / ``delta_params`` /
+    ``delta_params_torch`` dictionaries; ``set_params`` installs values directly (synthetic runs have no JSON files)."""
+
+    kind = None
+
+    def __init__(self, name, use_deltas=False):
+        if self.kind not in _KINDS:
+            raise NotImplementedError('FeatureNormaliser is abstract: use MeanVarianceNormaliser or MinMaxNormaliser')
         self.name = name
         self.use_deltas = use_deltas
-        self.file_pattern = file_pattern
-        self.params = None
-        self.params_torch = None
-        if self.use_deltas:
-            self.delta_params = None
-            self.delta_params_torch = None
+        self._groups = {}                                 # False -> the feature's parameters, True -> its deltas'
 
-    def _normalise(self, feature, **params):
-        raise NotImplementedError("Underlying calculation of normalisation should be implemented in a subclass.")
+    # -- parameters ------------------------------------------------------------------------------------------------------------------
+    def _view(self, deltas, side):
+        group = self._groups.get(bool(deltas))
+        return None if group is None else getattr(group, side)
 
-    def _denormalise(self, feature, **params):
-        raise NotImplementedError("Underlying calculation of denormalisation should be implemented in a subclass.")
-
-    def normalise(self, feature, deltas=False):
-        params = self.fetch_params(type(feature), deltas=deltas)
-        return self._normalise(feature, **params)
-
-    def denormalise(self, feature, deltas=False):
-        params = self.fetch_params(type(feature), deltas=deltas)
-        return self._denormalise(feature, **params)
+    params = property(lambda self: self._view(False, 'host'))
+    params_torch = property(lambda self: self._view(False, 'torch'))
+    delta_params = property(lambda self: self._view(True, 'host'))
+    delta_params_torch = property(lambda self: self._view(True, 'torch'))
 
     def fetch_params(self, data_type=np.ndarray, deltas=False):
-        if deltas:
-            return self.delta_params_torch if data_type == torch.Tensor else self.delta_params
-        return self.params_torch if data_type == torch.Tensor else self.params
-
-    @staticmethod
-    def _from_json(file_path):
-        with open(file_path, 'r') as f:
-            feat_params = json.load(f)
-        return {name: np.array(param, dtype=np.float32) for name, param in feat_params.items()}
-
-    @staticmethod
-    def _to_torch(params, device='cpu'):
-        return {name: torch.tensor(param).to(device) for name, param in params.items()}
+        return self._view(deltas, 'torch' if data_type == torch.Tensor else 'host')
 
     def set_params(self, params, delta_params=None, device='cpu'):
-        """Install parameters directly (synthetic runs have no JSON files)."""
-        self.params = {k: np.asarray(v, dtype=np.float32) for k, v in params.items()}
-        self.params_torch = self._to_torch(self.params, device=device)
+        self._groups[False] = _ParamGroup(self.kind, params, device=device)
         if self.use_deltas and delta_params is not None:
-            self.delta_params = {k: np.asarray(v, dtype=np.float32) for k, v in delta_params.items()}
-            self.delta_params_torch = self._to_torch(self.delta_params, device=device)
+            self._groups[True] = _ParamGroup(self.kind, delta_params, device=device)
         return self
 
     def load_params(self, data_dir, data_root='.', device='cpu'):
-        params_file = os.path.join(data_root, data_dir, self.file_pattern.format(name=self.name))
-        self.params = self._from_json(params_file)
-        self.params_torch = self._to_torch(self.params, device=device)
-        if self.use_deltas:
-            delta_file = os.path.join(data_root, data_dir, self.file_pattern.format(name=self.name + '_deltas'))
-            self.delta_params = self._from_json(delta_file)
-            self.delta_params_torch = self._to_torch(self.delta_params, device=device)
+        pattern = _KINDS[self.kind]['file']
+        for deltas in ((False, True) if self.use_deltas else (False,)):
+            file_name = pattern.format(name=self.name + ('_deltas' if deltas else ''))
+            self._groups[deltas] = _ParamGroup.from_json(self.kind, os.path.join(data_root, data_dir, file_name), device=device)
+
+    # -- the map ---------------------------------------------------------------------------------------------------------------------
+    def _map(self, feature, deltas, inverse):
+        values = self.fetch_params(type(feature), deltas=deltas)
+        if values is None:
+            raise RuntimeError('normaliser %r has no %sparameters: call load_params or set_params first' % (
+                self.name, 'delta ' if deltas else ''))
+        p0, p1 = (values[n] for n in _KINDS[self.kind]['params'])
+        return _apply_kind(self.kind, feature, p0, p1, inverse)
+
+    def normalise(self, feature, deltas=False):
+        return self._map(feature, deltas, inverse=False)
+
+    def denormalise(self, feature, deltas=False):
+        return self._map(feature, deltas, inverse=True)
 
 
-class MeanVarianceNormaliser(_FeatureNormaliser):
-    """Zero mean / unit variance; parameters ``mean`` / ``std_dev`` from ``{name}_mvn.json`` (data.py:541-564)."""
-
-    def __init__(self, name, use_deltas=False):
-        super(MeanVarianceNormaliser, self).__init__(name, use_deltas, '{name}_mvn.json')
-
-    def _normalise(self, feature, **params):
-        return normalise_mvn(feature, params['mean'], params['std_dev'])
-
-    def _denormalise(self, feature, **params):
-        return denormalise_mvn(feature, params['mean'], params['std_dev'])
+class MeanVarianceNormaliser(FeatureNormaliser):
+    """Zero mean / unit variance; ``mean`` / ``std_dev`` from ``{name}_mvn.json`` (data.py:541-564)."""
+    kind = 'mvn'
 
 
-class MinMaxNormaliser(_FeatureNormaliser):
-    """Range [0, 1]; parameters ``mmin`` / ``mmax`` from ``{name}_minmax.json`` (data.py:593-616)."""
+class MinMaxNormaliser(FeatureNormaliser):
+    """Range [0, 1]; ``mmin`` / ``mmax`` from ``{name}_minmax.json`` (data.py:593-616)."""
+    kind = 'minmax'
 
-    def __init__(self, name, use_deltas=False):
-        super(MinMaxNormaliser, self).__init__(name, use_deltas, '{name}_minmax.json')
 
-    def _normalise(self, feature, **params):
-        return normalise_minmax(feature, params['mmin'], params['mmax'])
-
-    def _denormalise(self, feature, **params):
-        return denormalise_minmax(feature, params['mmin'], params['mmax'])
+_FeatureNormaliser = FeatureNormaliser      # the reference's name for the base class
 
 
 class Normalisers(dict):
-    """Dictionary of normalisers that loads every member's parameters (data.py:225-247)."""
+    """name -> normaliser, every member's parameters loaded from ``data_root/normalisation_dir`` on construction (data.py:225-247)."""
 
     def __init__(self, normaliser_sources, normalisation_dir, data_root='.', device='cpu'):
-        super(Normalisers, self).__init__()
+        super(Normalisers, self).__init__(normaliser_sources)
         self.normalisation_dir = os.path.join(data_root, normalisation_dir)
         self.device = device
-        for name, source in normaliser_sources.items():
-            self[name] = source
-            self[name].load_params(self.normalisation_dir, device=self.device)
+        for normaliser in self.values():
+            normaliser.load_params(self.normalisation_dir, device=device)
 
 
 FRAME_COUNT_KEY = 'n_frames'
@@ -211,8 +224,11 @@ def add_bf16_table(features, key='normalised_lab', extra_rows=None):
     return features
 
 
-def to_device(features, device):
+def to_device(features, device, bf16_tables=()):
     """``ToDeviceWrapper.to_device`` over a feature dict (data.py:648-663); numpy arrays are uploaded too.
+
+    ``bf16_tables``: names of phone-level features whose bf16 operand table the batch should carry (``add_bf16_table``; what a
+    bf16-precision model's ``bf16_table_features()`` names) - the loader-side half of bf16 mode.
 
     One addition the reference's dict does not have: ``n_frames_total``, the python int sum of ``n_frames`` taken while the lengths
     are still on the host - it sizes the packed-frame layout of ragged batches (``utils.FrameLayout``) without a device -> host read.
@@ -225,6 +241,9 @@ def to_device(features, device):
     total = _host_total(features.get(FRAME_COUNT_KEY))
     if total is not None and FRAME_COUNT_KEY + '_total' not in out:
         out[FRAME_COUNT_KEY + '_total'] = total
+    for key in bf16_tables or ():
+        if key in out and key + BF16_TABLE_SUFFIX not in out:
+            add_bf16_table(out, key)
     return out
 
 
@@ -271,7 +290,7 @@ def load_utterance(features, normalisers):
     return out
 
 
-def collate_to_device(batch, normalisers, device):
+def collate_to_device(batch, normalisers, device, bf16_tables=()):
     """``load_utterance`` + ``collate_fn`` + ``to_device`` for a list of RAW per-utterance feature dicts, with the float
     sequence features normalised and zero padded on the device (reference: data.py:119-127, 159-224, 648-663).
 
@@ -279,8 +298,13 @@ def collate_to_device(batch, normalisers, device):
     kernel pass (mg_pad_normalise_f32) writes the padded raw feature and - where ``normalisers`` has its name - the
     ``normalised_`` twin; the host never touches per-frame data beyond the concatenation.  Other features (integer
     durations, scalars, names) take the ordinary collate path.  Same values as the reference's host pipeline to fp32
-    rounding of the normaliser arithmetic (the host version divides in float32 NumPy as well)."""
+    rounding of the normaliser arithmetic (the host version divides in float32 NumPy as well).
+
+    ``bf16_tables``: names of normalised phone-level features (``'normalised_lab'``) whose bf16 operand table the SAME pass writes
+    (``mg_pad_normalise_bf16_f32``): the batch then carries ``name + '__bf16_table'`` and a bf16-precision model's training step
+    launches no cast of the phone table (reference: the float32 cast on load, data.py:127)."""
     device = torch.device(device)
+    bf16_tables = tuple(bf16_tables or ())
     out, rest = {}, []
     for key in batch[0].keys():
         first = batch[0][key]
@@ -296,13 +320,14 @@ def collate_to_device(batch, normalisers, device):
         packed, offsets = packed.to(device, non_blocking=True), offsets.to(device, non_blocking=True)
         kind = p0 = p1 = None
         normaliser = normalisers.get(key) if normalisers is not None else None
-        if isinstance(normaliser, MeanVarianceNormaliser):
-            prm = normaliser.fetch_params(torch.Tensor)
-            kind, p0, p1 = ops.NORM_MVN, prm['mean'].to(device), prm['std_dev'].to(device)
-        elif isinstance(normaliser, MinMaxNormaliser):
-            prm = normaliser.fetch_params(torch.Tensor)
-            kind, p0, p1 = ops.NORM_MINMAX, prm['mmin'].to(device), prm['mmax'].to(device)
-        raw, norm = ops.pad_normalise(packed, offsets, int(lens.max()), p0, p1, kind)
+        if isinstance(normaliser, FeatureNormaliser):
+            spec, prm = _KINDS[normaliser.kind], normaliser.fetch_params(torch.Tensor)
+            kind, (p0, p1) = spec['forward'], (prm[n].to(device) for n in spec['params'])
+        if kind is not None and 'normalised_' + key in bf16_tables:
+            raw, norm, table = ops.pad_normalise(packed, offsets, int(lens.max()), p0, p1, kind, bf16_extra_rows=ops.PHONE_RATE_EXTRA)
+            out['normalised_' + key + BF16_TABLE_SUFFIX] = table
+        else:
+            raw, norm = ops.pad_normalise(packed, offsets, int(lens.max()), p0, p1, kind)
         out[key] = raw
         if norm is not None:
             out['normalised_' + key] = norm
@@ -318,6 +343,9 @@ def collate_to_device(batch, normalisers, device):
             if normaliser is not None and isinstance(batch[0][key], np.ndarray):
                 twin = collate_fn([{key: normaliser.normalise(item[key]).astype(np.float32)} for item in batch])[key]
                 out['normalised_' + key] = twin.to(device)
+    for key in bf16_tables:                               # features that did not take the fused pass (no normaliser, host path)
+        if key in out and isinstance(out[key], torch.Tensor) and out[key].is_cuda and key + BF16_TABLE_SUFFIX not in out:
+            add_bf16_table(out, key)
     return out
 
 
@@ -406,12 +434,12 @@ class FilesDataset(object):
     collate_fn = staticmethod(collate_fn)
 
 
-def batch(data_generator, batch_size=32, shuffle=True, num_data_threads=0, device='cuda:0'):
+def batch(data_generator, batch_size=32, shuffle=True, num_data_threads=0, device='cuda:0', bf16_tables=()):
     """The reference's ``data.batch`` (data.py:29-57) for a ``FilesDataset``: a loader of device-resident batches.  Files are read
     on the calling thread as each batch is formed (``num_data_threads`` is accepted for signature compatibility; worker
     subprocesses are the reference's answer to a host-bound collate, which here runs on the device)."""
     rng = np.random.RandomState(torch.initial_seed() % (2 ** 32)) if shuffle else None
-    return DeviceBatches(data_generator, batch_size, data_generator.normalisers, device, shuffle=rng)
+    return DeviceBatches(data_generator, batch_size, data_generator.normalisers, device, shuffle=rng, bf16_tables=bf16_tables)
 
 
 class DeviceBatches(object):
@@ -419,13 +447,13 @@ class DeviceBatches(object):
     each batch padded and normalised there by ``collate_to_device``.  ``utterances`` is a ``FilesDataset`` (read lazily, batch by
     batch, through ``raw``) or a sequence of utterances that are already in host memory.
 
-    ``utterances`` is a sequence of RAW per-utterance feature dicts (what a ``_DataSource`` returns: float32 ``(len, D)``
+    ``bf16_tables``: see ``collate_to_device``.  ``utterances`` is a sequence of RAW per-utterance feature dicts (what a ``_DataSource`` returns: float32 ``(len, D)``
     arrays, integer ``dur``, python ints, the name); ``normalisers`` maps feature names to normalisers (``Normalisers`` or a
     dict).  Batches are contiguous slices in the given order, or a fresh permutation per epoch from ``shuffle`` = a
     ``numpy.random.RandomState`` (the reference shuffles with torch's global generator, data.py:50); the last, smaller batch
     is kept, as ``DataLoader`` does by default.  ``ExperimentBuilder.train_epoch`` takes it like any other loader."""
 
-    def __init__(self, utterances, batch_size, normalisers, device, shuffle=None):
+    def __init__(self, utterances, batch_size, normalisers, device, shuffle=None, bf16_tables=()):
         if batch_size <= 0:
             raise ValueError('batch_size must be positive, got %r' % (batch_size,))
         self.utterances = utterances if isinstance(utterances, FilesDataset) else list(utterances)
@@ -433,6 +461,13 @@ class DeviceBatches(object):
         self.normalisers = normalisers
         self.device = torch.device(device)
         self.shuffle = shuffle
+        self.bf16_tables = tuple(bf16_tables or ())
+
+    def use_bf16_tables(self, names):
+        """The loader half of bf16 mode: every batch from now on carries the bf16 operand tables of these (normalised, phone-level)
+        features - ``ExperimentBuilder`` asks for what its model's ``bf16_table_features()`` names."""
+        self.bf16_tables = tuple(names or ())
+        return self
 
     def __len__(self):
         return (len(self.utterances) + self.batch_size - 1) // self.batch_size
@@ -444,4 +479,4 @@ class DeviceBatches(object):
         for start in range(0, len(order), self.batch_size):
             fetch = self.utterances.raw if isinstance(self.utterances, FilesDataset) else self.utterances.__getitem__
             batch = [fetch(int(i)) for i in order[start:start + self.batch_size]]
-            yield collate_to_device(batch, self.normalisers, self.device)
+            yield collate_to_device(batch, self.normalisers, self.device, bf16_tables=self.bf16_tables)

@@ -67,6 +67,11 @@ class ExperimentBuilder(object):
         if out_dir:
             os.makedirs(out_dir, exist_ok=True)
 
+        # the loader half of bf16 mode: the batches carry the bf16 operand table of the model's phone-level input (data.DeviceBatches
+        # writes it in the pass that pads and normalises), so the step below launches no cast of the 49 MB table
+        if hasattr(data_loader, 'use_bf16_tables'):
+            data_loader.use_bf16_tables(self.model.bf16_table_features())
+
         loss = None
         n_batches = len(data_loader)
         i = -1

@@ -61,6 +61,10 @@ class F0Model(BaseSPSS):
         return losses.mse(output_features['pred_norm_' + self.target_name],
                           features['normalised_' + self.target_name], features['n_frames'])
 
+    def bf16_table_features(self):
+        from . import functional as F_hip
+        return ('normalised_lab',) if (self.layers.precision or F_hip.get_precision()) == 'bf16' else ()
+
     def forward(self, features):
         """``predict`` + ``loss`` (base_models.py:279-285) with the stack's tail and the loss fused when a target is at hand
         (``SequentialWithRecurrent.forward_mse``); identical outputs otherwise."""

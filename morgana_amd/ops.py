@@ -268,8 +268,10 @@ def stream_loss(pred, targets, kinds, seq_len, want_grad, want_prob=False, grad_
     return loss, grad, prob
 
 
-def pad_normalise(packed, offsets, t, p0=None, p1=None, kind=None, want_raw=True):
-    """Packed utterances (sum len, D) + offsets (B+1) -> (raw (B,t,D) or None, normalised (B,t,D) or None)."""
+def pad_normalise(packed, offsets, t, p0=None, p1=None, kind=None, want_raw=True, bf16_extra_rows=None):
+    """Packed utterances (sum len, D) + offsets (B+1) -> (raw (B,t,D) or None, normalised (B,t,D) or None).
+    ``bf16_extra_rows`` (an int, needs ``kind``): the same pass also writes the normalised feature's bf16 operand table
+    (B*t + bf16_extra_rows, pad_ld(D)) - what cast_pad_bf16 would make of the normalised output - and it is returned as a third value."""
     lib = _lib.load()
     packed = _require(packed, torch.float32, 'packed feature')
     offsets = _require(offsets, torch.int64, 'offsets')
@@ -282,6 +284,14 @@ def pad_normalise(packed, offsets, t, p0=None, p1=None, kind=None, want_raw=True
         if p0.numel() != d or p1.numel() != d:
             raise ValueError('normaliser parameters have %d / %d entries, feature dim is %d' % (p0.numel(), p1.numel(), d))
         norm = torch.empty((b, t, d), dtype=torch.float32, device=packed.device)
+    if bf16_extra_rows is not None:
+        if kind is None:
+            raise ValueError('pad_normalise: the bf16 table is the NORMALISED feature: it needs normaliser parameters')
+        ldb = pad_ld(d)
+        table = torch.empty((b * int(t) + int(bf16_extra_rows), ldb), dtype=torch.bfloat16, device=packed.device)
+        _lib.check(lib.mg_pad_normalise_bf16_f32(_p(packed), _p(offsets), b, int(t), d, _p(p0), _p(p1), kind, _p(raw), _p(norm), _p(table), ldb,
+                                                 int(bf16_extra_rows), _stream()), 'mg_pad_normalise_bf16_f32')
+        return raw, norm, table
     _lib.check(lib.mg_pad_normalise_f32(_p(packed), _p(offsets), b, int(t), d, _p(p0), _p(p1), -1 if kind is None else kind,
                                         _p(raw), _p(norm), _stream()), 'mg_pad_normalise_f32')
     return raw, norm

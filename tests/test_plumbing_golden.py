@@ -238,3 +238,58 @@ def test_train_epoch_from_device_batches_matches_host_collate():
     shuffled = data.DeviceBatches(utterances, 4, norms, 'cuda:0', shuffle=np.random.RandomState(0))
     names = [n for batch in shuffled for n in batch['name']]
     assert sorted(names) == sorted(u['name'] for u in utterances) and names != [u['name'] for u in utterances]
+
+
+@pytest.mark.gpu
+def test_bf16_loader_table_and_launches_of_the_product_step():
+    """The loader half of bf16 mode is in the product: ``data.DeviceBatches`` - asked by
+    ``ExperimentBuilder.train_epoch`` for what the model's ``bf16_table_features()`` names - writes the bf16 operand table of the phone
+    input in the pass that pads and normalises (mg_pad_normalise_bf16_f32), bit for bit what casting the normalised feature gives
+    (zero padding columns, zero extra rows); the training step then launches NO cast of the phone table, and at C2-like shapes it is
+    the six-entry phone-rate step that bench.py times (entry-point calls counted through ``_lib.CALL_LOG``)."""
+    from morgana_amd import _lib, ops
+    rng = np.random.RandomState(11)
+    lab_dim, n_utt, n_ph, per_batch_utts = 600, 128, 40, 64          # 64 x 40 = 2,560 phone rows per batch: the phone-rate step engages
+    norms = {'lab': data.MinMaxNormaliser('lab').set_params({'mmin': (rng.rand(lab_dim) * 0.1).astype(np.float32),
+                                                             'mmax': (1.0 + rng.rand(lab_dim)).astype(np.float32)}, device='cuda:0'),
+             'lf0': data.MeanVarianceNormaliser('lf0').set_params({'mean': np.array([5.0], np.float32),
+                                                                   'std_dev': np.array([0.3], np.float32)}, device='cuda:0')}
+    utterances = []
+    for i in range(n_utt):
+        dur = rng.randint(5, 21, size=(n_ph, 1)).astype(np.int64)
+        n_fr = int(dur.sum())
+        utterances.append({'name': 'utt%03d' % i, 'n_frames': n_fr, 'n_phones': n_ph, 'dur': dur,
+                           'lab': rng.rand(n_ph, lab_dim).astype(np.float32),
+                           'lf0': (5.0 + 0.3 * rng.randn(n_fr, 1)).astype(np.float32)})
+    loader = data.DeviceBatches(utterances, per_batch_utts, norms, 'cuda:0')
+    # the table, against the stand-alone cast of the normalised feature
+    batch = next(iter(loader.use_bf16_tables(('normalised_lab',))))
+    table = batch['normalised_lab' + data.BF16_TABLE_SUFFIX]
+    lab = batch['normalised_lab']
+    want = ops.cast_pad_bf16(lab.reshape(-1, lab_dim), extra_rows=ops.PHONE_RATE_EXTRA)
+    assert table.shape == want.shape and torch.equal(table.view(torch.int16), want.view(torch.int16))
+    plain = next(iter(data.DeviceBatches(utterances, per_batch_utts, norms, 'cuda:0')))
+    assert 'normalised_lab' + data.BF16_TABLE_SUFFIX not in plain and torch.equal(plain['normalised_lab'], lab)
+
+    eb = experiment_builder.ExperimentBuilder(models.F0Model, model_kwargs={'precision': 'bf16'}, learning_rate=0.01, device='cuda:0')
+    own = eb.model.state_dict()
+    for k, v in synthetic.f0_model_state().items():
+        own[k].copy_(torch.from_numpy(v))
+    loader = data.DeviceBatches(utterances, per_batch_utts, norms, 'cuda:0')          # no tables requested: train_epoch asks for them
+    optimizer = eb.make_optimizer()
+    eb.train_epoch(loader, optimizer)                                     # first epoch: operand shadows, buffers
+    assert loader.bf16_tables == ('normalised_lab',)
+    _lib.CALL_LOG = []
+    try:
+        eb.train_epoch(loader, optimizer)
+        log = list(_lib.CALL_LOG)
+    finally:
+        _lib.CALL_LOG = None
+    loader_calls = ('mg_pad_normalise_f32', 'mg_pad_normalise_bf16_f32')
+    step_calls = [c for c in log if c not in loader_calls]
+    assert not any('cast' in c for c in step_calls), step_calls
+    assert log.count('mg_pad_normalise_bf16_f32') == len(loader), log
+    per_batch = len(step_calls) / float(len(loader))
+    # front + layer-1 GEMM, l2tail (+ expansion / reduce), layer-2 wgrad + dgrad, layer-1 wgrad, update; the epoch's metric and status reads
+    assert per_batch <= 8.0, (per_batch, step_calls)
+    assert sum(c.startswith('mg_phone_front') for c in step_calls) == len(loader), step_calls
