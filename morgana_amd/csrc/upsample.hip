@@ -163,6 +163,9 @@ __global__ __launch_bounds__(256) void frame_layout_fill_kernel(const int64_t* _
                                                                 int T, int total, int32_t* __restrict__ rows, int32_t* __restrict__ inverse) {
     const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (m == 0) rows[total] = -1;
+    // a host total LARGER than the device lengths add up to (taken before T clipped them): the surplus packed rows name no frame -
+    // they gather the zero row like the representative padding row instead of keeping whatever the allocation held (total <= B T)
+    if (m >= offsets[B] && m < total) rows[m] = -1;
     if (m >= (int64_t)B * T) return;
     const int b = (int)(m / T), t = (int)(m - (int64_t)b * T);
     const long long n = seq_len[b];

@@ -39,7 +39,8 @@ _EARLY_GRADS_HOOK = None
 
 
 def set_early_grads_hook(fn):
-    """Install (or with None remove) the callback described above; returns the previous one."""
+    """Install (or with None remove) the callback described above; returns the previous one.  The callback receives the firing
+    stack's parameter list (weight, bias, weight, ...): the step checks that this stack IS the model before it trusts the promise."""
     global _EARLY_GRADS_HOOK
     prev, _EARLY_GRADS_HOOK = _EARLY_GRADS_HOOK, fn
     return prev
@@ -275,7 +276,7 @@ def _deliver_early(params, flat, offsets, grad_loss):
     tail = _deliver_param_grads(params[2:], flat[offsets[2]:], [o - offsets[2] for o in offsets[2:]], grad_loss)
     if any(t is not None for t in tail):
         raise RuntimeError('early gradient exchange needs the parameters in morgana_amd.optim.Adam\'s flat buffer')
-    _EARLY_GRADS_HOOK()
+    _EARLY_GRADS_HOOK(params)
     return True
 
 
@@ -518,7 +519,7 @@ class LinearStackMSEFn(torch.autograd.Function):
             for i in range(top, 0, -1):
                 n, k = ctx.dims[i]
                 if i == 1 and _EARLY_GRADS_HOOK is not None:
-                    _EARLY_GRADS_HOOK()                               # everything but the first layer's gradient is final
+                    _EARLY_GRADS_HOOK(params)                         # everything but the first layer's gradient is final
                 if (not ctx.phone_rate and i == 1 and ctx.acts[0] == ops.ACT_SIGMOID and
                         ops.can_fuse_bwd(m, n, k, ctx.dims[0][1], a0.shape[1])):
                     n0_, k0_ = ctx.dims[0]

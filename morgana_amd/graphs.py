@@ -18,6 +18,9 @@ tensors.  The learning rate may change between replays (it enters through ``adva
 """
 import os
 
+import collections
+import warnings
+
 import torch
 
 from . import functional
@@ -170,7 +173,13 @@ class GraphedTrainStep(object):
         comm = torch.cuda.Stream()
         fired = []
 
-        def early_bucket_ready():
+        def early_bucket_ready(stack_params):
+            # "everything but the first layer's gradient is final" is a statement about the firing STACK.  It is a statement about
+            # the model's flat gradient only if that stack's parameters are the optimiser's, in its order, and all of them - a model
+            # with further trainable parameters, or two fused stacks, must not cut its exchange here (the late part would go out
+            # before it is final, or the early part twice): such steps keep the single collective behind the backward pass.
+            if fired or not early_exchange_is_safe(self.optimizer, stack_params):
+                return
             comm.wait_stream(main)
             with torch.cuda.stream(comm):
                 self.optimizer.exchange_gradients('early')
@@ -212,6 +221,17 @@ class GraphedTrainStep(object):
         return self.loss
 
 
+def early_exchange_is_safe(optimizer, stack_params, group=0):
+    """May the step all-reduce ``flat['grad'][bucket_split:]`` the moment a stack reports that everything but its first layer's
+    gradient is final?  Only when the stack's parameter list is exactly the optimiser's flat parameter list (same objects, same
+    order): then "[split:] is final" holds for the buffer that is exchanged."""
+    flat = optimizer.flat_buffers(group)
+    if flat is None or optimizer.bucket_split(group) <= 0:
+        return False
+    own = flat['params']
+    return len(stack_params) == len(own) and all(a is b for a, b in zip(stack_params, own))
+
+
 class GraphedStepCache(object):
     """Graph replay inside a training loop whose batches repeat a few shapes (``ExperimentBuilder(use_graphs=True)``).
 
@@ -220,10 +240,19 @@ class GraphedStepCache(object):
     nothing) and replayed, and every later one is copied into those buffers and replayed.  No step is ever run twice or skipped, so
     the loop trains exactly as the eager loop does (bit-identical, tests/test_gpu_parity.py)."""
 
+    MAX_SEEN = 1024      # signatures remembered as "ran once": a ragged loader whose frame totals never repeat must not grow this forever
+
     def __init__(self, model, optimizer, max_graphs=8):
         self.model, self.optimizer, self.max_graphs = model, optimizer, max_graphs
-        self._seen = set()
+        self._seen = collections.OrderedDict()
         self._steps = {}
+        self.eager_steps = self.replayed_steps = 0        # how the steps were run (see ``stats``)
+        self._warned = False
+
+    def stats(self):
+        """{'eager': steps run as ordinary launches, 'replayed': steps replayed from a graph, 'graphs': graphs held}.  Mostly eager
+        steps mean the batches do not repeat their signature: bucket ragged lengths to a few shapes for ``use_graphs`` to pay."""
+        return {'eager': self.eager_steps, 'replayed': self.replayed_steps, 'graphs': len(self._steps)}
 
     @staticmethod
     def signature(features):
@@ -244,8 +273,17 @@ class GraphedStepCache(object):
             for k, v in features.items():              # non-tensor entries (utterance names) follow the batch
                 if not isinstance(v, torch.Tensor):
                     graphed.features[k] = v
+            self.replayed_steps += 1
             return graphed().clone(), graphed.output      # the loss buffer is rewritten by the next replay: hand out a copy
-        self._seen.add(key)
+        self._seen[key] = True
+        self._seen.move_to_end(key)
+        while len(self._seen) > self.MAX_SEEN:
+            self._seen.popitem(last=False)
+        self.eager_steps += 1
+        if not self._warned and self.eager_steps >= 64 and self.replayed_steps == 0:
+            self._warned = True
+            warnings.warn('GraphedStepCache: %d steps and no batch signature has repeated - every step runs as eager launches '
+                          '(ragged batches: bucket the lengths to a few shapes, or turn use_graphs off)' % self.eager_steps)
         self.optimizer.zero_grad()
         loss, output = self.model(features)
         functional.backward(loss)

@@ -16,7 +16,7 @@ MI355X design: parameters, gradients and both moments are views into four contig
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import _lib, ops
 
 
 class Adam(torch.optim.Optimizer):
@@ -102,7 +102,13 @@ class Adam(torch.optim.Optimizer):
         ``n_slabs`` slabs of ``stride`` floats in ``slab`` (kept alive here until the step has consumed them)."""
         for flat in self._flat:
             if flat is not None and id(first_param) in flat['offsets']:
-                flat['pending'].append((flat['offsets'][id(first_param)], int(count), slab, int(n_slabs), int(stride)))
+                off = flat['offsets'][id(first_param)]
+                if len(flat['pending']) >= _lib.ADAM_MAX_SLABS:
+                    # the update kernel's plan holds ADAM_MAX_SLABS sources (a deep stack registers one per leading layer plus
+                    # the tail): any further one is summed now, by a reduce launch straight into the flat gradient
+                    ops.slab_reduce(slab, n_slabs, stride, count, flat['grad'][off:off + int(count)], accumulate=True)
+                else:
+                    flat['pending'].append((off, int(count), slab, int(n_slabs), int(stride)))
                 return
         raise ValueError('defer_slabs: the parameter is not one of this optimiser\'s')
 
@@ -182,7 +188,9 @@ class Adam(torch.optim.Optimizer):
 
     def _launch(self, group, flat, world, slot=0):
         """The update kernel with everything this step left for it (see the module docstring)."""
-        shadows = self._shadows(flat)
+        # the kernel's plan refreshes up to ADAM_MAX_SHADOWS operand copies; the others keep their old version stamp, so
+        # ops.param_shadows re-casts them when the next forward pass asks for them
+        shadows = self._shadows(flat)[:_lib.ADAM_MAX_SHADOWS]
         pending, flat['pending'] = flat['pending'], []
         ops.adam_step_plan(flat['param'], flat['grad'], flat['exp_avg'], flat['exp_avg_sq'], group['betas'], group['eps'],
                            group['weight_decay'], self._scalar_buffers(flat)[2 * slot:], 1.0 / world, slab_srcs=pending,

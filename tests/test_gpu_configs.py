@@ -647,3 +647,27 @@ def test_gru_f0_model_runs_on_the_stack_wavefront():
     assert abs(grads[True][0] - grads[False][0]) < 1e-5 * max(1.0, abs(grads[False][0]))
     for k, (g, w) in enumerate(zip(grads[True][1:], grads[False][1:])):
         assert rel_err(g, w) < 1e-4, (k, rel_err(g, w))
+
+
+def test_frame_layout_with_a_host_total_that_disagrees_with_the_lengths():
+    """mg_frame_layout with a host-side frame total above / below what the device lengths (clipped to T) add up to: surplus packed
+    rows must gather the zero row (-1), never whatever the allocation held (rows[sum .. total-1] were left
+    uninitialised and used as gather indices); surplus frames count as padding."""
+    seq = torch.tensor([5, 9, 3, 12], dtype=torch.int64, device=DEV)
+    t = 8                                                  # clips 9 and 12: the device sum is 5 + 8 + 3 + 8 = 24
+    for total in (24, 29, 20):
+        rows = None
+        for fill in (0x7fffffff, -7):                      # two poisons: whatever the allocator hands out must not show
+            torch.full((total + 64,), fill, dtype=torch.int32, device=DEV)
+            offsets, rows, inverse = ops.frame_layout(seq, t, total)
+            r, inv, off = rows.cpu().numpy(), inverse.cpu().numpy().reshape(4, t), offsets.cpu().numpy()
+            assert off.tolist() == [0, 5, 13, 16, 24]
+            assert r[total] == -1
+            valid = min(total, 24)
+            want = [b * t + f for b in range(4) for f in range(min(int(seq[b]), t))][:valid]
+            assert r[:valid].tolist() == want
+            assert (r[valid:total] == -1).all(), (total, r[valid:total])
+            for b in range(4):
+                for f in range(t):
+                    i = off[b] + f
+                    assert inv[b, f] == (i if f < int(seq[b]) and i < total else total)

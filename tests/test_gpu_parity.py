@@ -1904,6 +1904,67 @@ def test_experiment_builder_graph_replay_equals_eager_loop():
         assert torch.equal(params_g[name], params_e[name]), name
 
 
+def test_graph_replay_survives_a_larger_shape_between_replays():
+    """The per-layer slab buffers of the weight-gradient GEMMs grow with the row count.  A graph captured at the smaller shape has the
+    old buffer's address baked into its weight-gradient and update nodes, so an outgrown buffer must stay alive (ops._slab_buffer
+    retires it; ADVICE round 2 found it dropped: the next tensor took its memory and the replay wrote 48-256 slabs over it).  Shapes at
+    slab-taking row counts (>= 4096): 16 x 300 twice (second one captured), 32 x 1000 (reallocates), then 16 x 300 replayed, with a
+    burst of allocations in between that would land in freed memory - against the eager loop: losses and parameters EQUAL."""
+    from morgana_amd import experiment_builder
+    small = [data.to_device(synthetic.make_batch(16, 300, seed=60 + i), DEV) for i in range(4)]
+    big = data.to_device(synthetic.make_batch(32, 1000, seed=70), DEV)
+    batches = [small[0], small[1], big, small[2], small[3]]
+
+    def train(use_graphs):
+        torch.manual_seed(3)
+        builder = experiment_builder.ExperimentBuilder(models.F0Model, dict(precision='bf16'), learning_rate=0.01, device=DEV,
+                                                       end_epoch=1, use_graphs=use_graphs)
+        _load_state(builder.model, synthetic.f0_model_state())
+        optimizer = builder.make_optimizer()
+        losses = []
+        for i, feats in enumerate(batches):
+            losses.append(builder.train_epoch([feats], optimizer))
+            if i == 2:                                     # whatever was freed by the larger shape gets a new owner, filled with NaN
+                junk = [torch.full((1 << 20,), float('nan'), device=DEV) for _ in range(64)]
+                del junk
+        return losses, {k: v.detach().clone() for k, v in builder.model.named_parameters()}
+
+    old = ops.PHONE_RATE
+    for phone_rate in (True, False):
+        ops.PHONE_RATE = phone_rate
+        try:
+            loss_e, params_e = train(False)
+            loss_g, params_g = train(True)
+        finally:
+            ops.PHONE_RATE = old
+        assert loss_g == loss_e, phone_rate
+        for name in params_e:
+            assert torch.equal(params_g[name], params_e[name]), (phone_rate, name)
+
+
+def test_deep_stack_with_more_slab_sources_than_the_update_plan_holds():
+    """A 600-512-512-512-128-32-1 stack registers one split-M slab source per leading layer plus the tail: five, and the update
+    kernel's plan holds ADAM_MAX_SLABS = 4 (optimizer.step() raised on the first step).  The surplus source is summed
+    by a reduce launch of its own (optim.Adam.defer_slabs); the fused loop must train exactly as the plain loop."""
+    feats = data.to_device(synthetic.make_batch(16, 400, seed=21), DEV)
+    results = []
+    for fused in (False, True):
+        torch.manual_seed(0)
+        model = models.F0Model(hidden_dims=(512, 512, 512, 128, 32), precision='bf16').to(DEV)
+        opt = optim.Adam(model.parameters(), lr=0.01, fused_loop=fused)
+        losses = []
+        for _ in range(3):
+            opt.zero_grad()
+            loss, _ = model(feats)
+            F_hip.backward(loss)
+            opt.step()
+            losses.append(loss.item())
+        results.append((losses, [p.detach().clone() for p in model.parameters()]))
+    assert results[0][0] == results[1][0]
+    for a, b in zip(results[0][1], results[1][1]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('precision', ['bf16', 'fp32'])
 def test_phone_rate_gru_input_equals_frame_rate(precision):
     """RNN_SPSS layout (Linear-512 + Sigmoid on the upsampled labels, then GRU-512) with the Linear and the GRU's input projection run

@@ -185,3 +185,26 @@ def test_checkpoint_round_trip(tmp_path):
     other.load_parameters(path, device='cpu')
     for pa, pb in zip(model.parameters(), other.parameters()):
         assert torch.equal(pa, pb)
+
+
+def test_early_bucket_exchange_only_when_the_stack_is_the_model():
+    """The captured two-bucket exchange (graphs.GraphedTrainStep) cuts the flat gradient where the FIRING stack says its tail is
+    final.  That is only true of the whole buffer when the stack's parameters are exactly the optimiser's, in order:
+    a model with further trainable parameters, or a different order, keeps the single collective."""
+    from morgana_amd import graphs
+    torch.manual_seed(0)
+    stack = [torch.nn.Parameter(torch.randn(64, 48)), torch.nn.Parameter(torch.randn(64)),
+             torch.nn.Parameter(torch.randn(8, 64)), torch.nn.Parameter(torch.randn(8)),
+             torch.nn.Parameter(torch.randn(1, 8)), torch.nn.Parameter(torch.randn(1))]
+    opt = optim.Adam(stack, lr=0.01, kernel=helpers.cpu_adam_kernel)
+    assert opt.bucket_split() == 64 * 48 + 64
+    assert graphs.early_exchange_is_safe(opt, stack)
+    assert not graphs.early_exchange_is_safe(opt, stack[:4])                     # the stack is not the whole model
+    assert not graphs.early_exchange_is_safe(opt, stack[2:4] + stack[:2] + stack[4:])     # same parameters, another order
+    extra = torch.nn.Parameter(torch.randn(5))
+    opt2 = optim.Adam(stack + [extra], lr=0.01, kernel=helpers.cpu_adam_kernel)
+    assert not graphs.early_exchange_is_safe(opt2, stack)                        # the model has parameters outside the stack
+    small_first = [torch.nn.Parameter(torch.randn(2, 2)), torch.nn.Parameter(torch.randn(2)),
+                   torch.nn.Parameter(torch.randn(64, 64)), torch.nn.Parameter(torch.randn(64))]
+    opt3 = optim.Adam(small_first, lr=0.01, kernel=helpers.cpu_adam_kernel)
+    assert opt3.bucket_split() == 0 and not graphs.early_exchange_is_safe(opt3, small_first)
