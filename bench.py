@@ -126,6 +126,19 @@ def roofline_f0(features, model, precision):
     w1, b1, w2, b2 = lins[0].weight.detach(), lins[0].bias.detach(), lins[1].weight.detach(), lins[1].bias.detach()
     n1, n2 = w1.shape[0], w2.shape[0]
     kernels = []
+    slab_bufs = {}
+
+    def wgrad_alone(key, dy, a, r, m_, n_, k_):
+        """The weight-gradient GEMM kernel without its slab-reduce launch (the entry point that leaves the slabs to the caller),
+        into one persistent slab buffer per kernel; shapes without slabs run the complete entry point."""
+        if ops.wgrad_wide_ok(m_, n_, k_, a.shape[1], dy.shape[1]):
+            slab_bufs[key] = ops.linear_wgrad_slabs_bf16(dy, a, r, m_, n_, k_, slab=slab_bufs.get(key))[0]
+        else:
+            ops.linear_wgrad_bf16(dy, a, r, m_, n_, k_)
+
+    def fused_alone(*args):
+        slab_bufs['fused'] = ops.linear_bwd_fused_slabs_bf16(*args, slab=slab_bufs.get('fused'))[0]
+
     bound = {}
     algo_bytes = {}      # least bytes a launch of the kernel must move: operands once + result once (bf16 operands, fp32 gradients)
     if precision == 'bf16' and ops.phone_rate_table_ok(b * p, m, n1, n2, ops.ACT_SIGMOID):
@@ -174,11 +187,11 @@ def roofline_f0(features, model, precision):
                             'one grid', 4.0 * r_tab * n1 * n2, lambda: ops.linear_wgrad_dgrad_bf16(dz2, h_tab, r_tab, n2, n1, w2t)))
         else:
             kernels.append(('wgrad_big_kernel<8>: layer-2 wgrad at phone rate (dZ2^T table)', 2.0 * r_tab * n1 * n2,
-                            lambda: ops.linear_wgrad_bf16(dz2, h_tab, None, r_tab, n2, n1)))
+                            lambda: wgrad_alone('w2p', dz2, h_tab, None, r_tab, n2, n1)))
             kernels.append(('gemm_nt_big_kernel<256>: layer-2 dgrad + sigmoid-grad at phone rate', 2.0 * r_tab * n1 * n2,
                             lambda: ops.linear_dgrad_bf16(dz2, r_tab, n2, w2t, n1, h_tab)))
         kernels.append(('wgrad_big_kernel<5>: layer-1 wgrad at phone rate (dZ1^T lab; 128 x 320 tiles, 32 split-M slabs)', 2.0 * r_tab * k * n1,
-                        lambda: ops.linear_wgrad_bf16(dz1, tab, None, r_tab, n1, k)))
+                        lambda: wgrad_alone('w1p', dz1, tab, None, r_tab, n1, k)))
         peak = MFMA_BF16_PEAK_TFLOPS
     elif precision == 'bf16':
         tab = ops.cast_pad_bf16(lab.view(b * p, k))
@@ -197,20 +210,20 @@ def roofline_f0(features, model, precision):
             kernels.append(('gemm_nt_persist_kernel<128>: layer-2 forward (512->128 + bias + sigmoid)', 2.0 * m * n1 * n2,
                             lambda: ops.linear_fwd_bf16(h1, None, m, n1, w2b, b2, n2, ops.ACT_SIGMOID)))
         if ops.can_fuse_bwd(m, n2, n1, k, tab.shape[1]):
-            kernels.append(('wgrad_fused_pipe_kernel: layer-2 dgrad + sigmoid-grad + layer-1 wgrad (gather-fused), dZ1 on chip',
+            kernels.append(('wgrad_fused64_kernel<3>: layer-2 dgrad + sigmoid-grad + layer-1 wgrad (gather-fused), dZ1 on chip',
                             2.0 * m * n1 * n2 + 2.0 * m * k * n1,
-                            lambda: ops.linear_bwd_fused_bf16(dz2, w2t, h1, tab, rows, m, n1, k)))
+                            lambda: fused_alone(dz2, w2t, h1, tab, rows, m, n1, k)))
         else:
             dz1 = (torch.randn(m, n1, device=lab.device) * 0.01).to(torch.bfloat16)
             kernels.append(('wgrad_big_kernel<10>: layer-1 wgrad (gather-fused)', 2.0 * m * k * n1,
-                            lambda: ops.linear_wgrad_bf16(dz1, tab, rows, m, n1, k)))
+                            lambda: wgrad_alone('w1f', dz1, tab, rows, m, n1, k)))
         kernels.append(('wgrad_big_kernel<8>: layer-2 wgrad (dZ2^T H1)', 2.0 * m * n1 * n2,
-                        lambda: ops.linear_wgrad_bf16(dz2, h1, None, m, n2, n1)))
+                        lambda: wgrad_alone('w2f', dz2, h1, None, m, n2, n1)))
         n_tab, ldk = tab.shape
         algo_bytes.update({'gemm_nt_runs_kernel<1>': 2.0 * (n_tab * ldk + n1 * ldk + m * n1) + 4.0 * m,
                            'f0_l2tail_kernel<0>': 2.0 * (m * n1 + n2 * n1 + m * n2) + 12.0 * m,
                            'gemm_nt_persist_kernel<128>': 2.0 * (m * n1 + n2 * n1 + m * n2),
-                           'wgrad_fused_pipe_kernel': 2.0 * (m * n2 + m * n1 + n_tab * ldk) + 4.0 * m + 4.0 * n1 * k,
+                           'wgrad_fused64_kernel<3>': 2.0 * (m * n2 + m * n1 + n_tab * ldk) + 4.0 * m + 4.0 * n1 * k,
                            'wgrad_big_kernel<10>': 2.0 * (m * n1 + n_tab * ldk) + 4.0 * m + 4.0 * n1 * k,
                            'wgrad_big_kernel<8>': 2.0 * (m * n2 + m * n1) + 4.0 * n2 * n1})
         peak = MFMA_BF16_PEAK_TFLOPS
@@ -227,13 +240,10 @@ def roofline_f0(features, model, precision):
                         lambda: ops.linear_dgrad_f32(dz2, w2, h1)))
         peak = MFMA_F32_PEAK_TFLOPS
     measured = []
-    lib = _lib.load()
-    lib.mg_set_tuning(1, 1)          # MG_TUNE_SKIP_REDUCE: time the GEMM kernel alone, without its slab-reduce launches
     for name, flops, fn in kernels:
         ms = time_kernel(fn, graph=True)
         measured.append({'kernel': name, 'ms': round(ms, 4), 'gflop': round(flops / 1e9, 1),
                          'tflops': round(flops / (ms * 1e-3) / 1e12, 2)})
-    lib.mg_set_tuning(1, 0)
     dom = max(measured, key=lambda r: r['ms'])
     short = dom['kernel'].split(':')[0]
     # HBM bytes per launch of the dominant kernel from the committed PMC passes of this round (scripts/gpu_profile.sh:

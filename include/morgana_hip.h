@@ -42,24 +42,27 @@ extern "C" {
  * Library
  * ---------------------------------------------------------------------------------------------------------------- */
 const char* mg_last_error(void);
-/* Kernel scheduling knobs for experiments (A/B runs inside one process); every value computes the same results.
- * key MG_TUNE_STAGGER: 0 = default schedule of the large bf16 GEMM kernels, other values select measured alternatives
- * (6: per-tile instead of persistent NT kernel, 7: single-buffered instead of pipelined fused backward). */
+/* Scheduling choices: which of several kernels / split plans that compute THE SAME RESULTS an entry point launches.  For A/B runs
+ * inside one process and for the equality tests that hold the forms against each other.  PROCESS-GLOBAL state (not per call, not
+ * thread-local): set it between launches, not concurrently with them; everything else in this ABI is stateless apart from the
+ * thread-local error text.  Unknown keys and values are refused (MG_EINVAL).  Measured-slower experiments and timing probes are
+ * not in this library at all: they are compiled into the lab builds (make -C morgana_amd/csrc lab / diag) only. */
 #define MG_TUNING_KEYS 8
-#define MG_TUNE_STAGGER 0
-#define MG_TUNE_GRU_HANDOFF 2   /* persistent GRU kernels: 0 = groups found on one XCD hand the state over through that XCD's L2,
+#define MG_TUNE_FORM 0          /* large bf16 GEMM kernels: 0 = default; 3 = 32-deep instead of 64-deep stages of the 128-wide NT tile;
+                                 * 6 = per-tile instead of persistent NT kernel; 14 = frame-staged instead of run-staged layer-1 forward;
+                                 * fused backward: 12 = tiles two steps ahead (larger ring), 13 = 32-frame steps, 7 = single-buffered */
+#define MG_TUNE_GRU_HANDOFF 2   /* persistent GRU / LSTM kernels: 0 = groups found on one XCD hand the state over through that XCD's L2,
                                  * 1 = always write-through (sc1) stores, the placement-independent form */
-#define MG_TUNE_SKIP_REDUCE 1   /* != 0: weight-gradient entry points launch their GEMM kernel only, not the slab reduce that
-                                 * finishes dW / db (results are then NOT valid) - lets bench.py time the kernel alone */
-#define MG_TUNE_LSTM_BWD_STACK 6 /* mg_lstm_pstack_bwd_bf16: 0 = 32 hidden units per slot where they fit (one workgroup per CU), 1 = 16 (two per CU) */
-#define MG_TUNE_WGRAD_SPLITS 4  /* wide weight-gradient kernel: != 0 overrides the planned number of split-M slabs (a multiple of 8) */
-#define MG_TUNE_PROBE 7         /* mg_f0_l2tail_bf16: 0 = the product kernel (one wave per SIMD), 64 = the producer / consumer role split (experiment, measured slower), other values = the product kernel's timing probes (results garbage): 1 = no H1 loads, 2 = no tail, 4 = no layer-2 MFMAs, 8 = no sigmoid of H2, 16 = no steps 8-9, 32 = no step 9 */
-/* MG_TUNE_PROBE, the A/B switches of the shared-grid launches and the half-width weight-gradient tiles (same results either way):
- * 65 = mg_linear_wgrad_dgrad_bf16 as its two launches, 66 = mg_phone_front_linear_fwd_bf16 as its two launches, 92 = 128 x 640 tiles for
- * the 640-wide weight gradient at phone-rate rows, 93 = 128 x 512 tiles for the 512-wide one; timing probes of the front's riders
- * (results garbage): 67 = idle riders, 70 + bits (1 no utterance compute, 2 no extra-row compute, 4 no extra jobs, 8 no GEMM).
- * MG_TUNE_WGRAD_SPLITS: 1000 + S / 2000 + S override the split count of the one-n-tile / the 4+-n-tile plans only. */
-#define MG_TUNE_WGRAD_ORDER 5   /* wide weight-gradient kernel, block order: 0 = planned, 1 = n tile fastest, 2 = the n tiles of a split on one XCD */
+#define MG_TUNE_PERSISTENT 3    /* recurrences: 0 = persistent kernels where the shape has them, 1 = one launch per time step,
+                                 * 2 = H = 64 on the 16-row tile instead of the 4x4x1 blocks */
+#define MG_TUNE_WGRAD_SPLITS 4  /* wide weight-gradient kernel: != 0 overrides the planned number of split-M slabs (a multiple of 8);
+                                 * 1000 + S / 2000 + S override the one-n-tile / the 4+-n-tile plans only */
+#define MG_TUNE_WGRAD_ORDER 5   /* wide weight-gradient kernel, block order: 0 = planned, 1 = n tile fastest, 2 = the n tiles of a split
+                                 * on one XCD, 3 = the 128 x 128 kernel instead of the wide one */
+#define MG_TUNE_LSTM_BWD_STACK 6 /* mg_lstm_pstack_bwd_bf16: 0 = 32 hidden units per slot where they fit (one workgroup per CU), 1 = 16 */
+#define MG_TUNE_AB 7            /* shared-grid launches as their separate launches, half-width tiles off: 65 = mg_linear_wgrad_dgrad_bf16 as
+                                 * two launches, 66 = mg_phone_front_linear_fwd_bf16 as two, 92 = 128 x 640 tiles for the 640-wide weight
+                                 * gradient at phone-rate rows, 93 = 128 x 512 tiles for the 512-wide one */
 int mg_set_tuning(int key, int value);
 int mg_version(void);           /* ABI version, bumped on incompatible change */
 const char* mg_build_arch(void); /* "gfx950" */

@@ -74,7 +74,7 @@ struct W64Map {                                   // LDS map (bytes); NBT = buff
     static constexpr int LDS = ROWS + 3 * 256;
 };
 
-// PROBE (diagnostic builds only, -DMG_PROBES; results garbage): timing experiments on parts of the step - 1 = every P2 operand read
+// PROBE (lab builds only, -DMG_EXPERIMENTS; results garbage): timing experiments on parts of the step - 1 = every P2 operand read
 // from the zero row, 2 = no operand reads in P2 at all, 4 = no P1, 8 = no tile / staged-row DMA, 16 = P2 reads two pairs ahead instead of four.
 template <int NBT, int PROBE = 0>
 __global__ __launch_bounds__(512) void wgrad_fused64_kernel(const uint16_t* __restrict__ dZ2, int lddz, const uint16_t* __restrict__ W2T,
@@ -540,6 +540,7 @@ __global__ __launch_bounds__(512) void wgrad_fused64_kernel(const uint16_t* __re
 #endif
 }
 
+#ifdef MG_EXPERIMENTS      // lab builds only (make lab / diag)
 // -------------------------------------------------------------------------------------------------------------------------------------
 // WOVEN form.  Stamps of the kernel above at C2 (profiles/r3_stamps_fused64.txt, cycles per 64-frame step of ~7,800 with 3,072 matrix
 // cycles per SIMD): a wave spends ~550 at the barrier, ~550 deriving the next step's runs (an LDS read, a cross-lane shift, a ballot: all
@@ -1030,13 +1031,15 @@ __global__ __launch_bounds__(512) void wgrad_fused64w_kernel(const uint16_t* __r
 #endif
 }
 
+#endif  // MG_EXPERIMENTS
+
 // Launch helper used by fused_launch (bwd_fused_bf16.hip): the 64-frame-step kernel on the plan of the 32-frame one (same frame
-// ranges, same slabs - the results are bit-identical).  nbt: 3 = tiles fetched three steps ahead (5 ring groups), 2 = two (8 groups).
+// ranges, same slabs - the results are bit-identical).  nbt: 3 = tiles fetched three steps ahead (5 ring groups), 2 = two (8 groups); lab builds: 1 = the woven experiment, 100 + mask = probes.
 void mg_launch_fused64(int nbt, const uint16_t* dZ2, int lddz, const uint16_t* W2T, int ldwt, const uint16_t* H1, int ldh, const uint16_t* A,
                        int lda, const int32_t* rows, int64_t M, int N, int K, int m_chunk, int n_splits, float* slab, float* bslab,
                        int64_t sstride, hipStream_t st) {
     const dim3 grid((unsigned)((N / W_BNT) * mg_align_up((size_t)n_splits, 8))), block(512);
-#ifdef MG_PROBES
+#ifdef MG_EXPERIMENTS
 #define W64_PROBE_CASE(P)                                                                                                                  \
     case 100 + P:                                                                                                                          \
         hipLaunchKernelGGL((wgrad_fused64_kernel<3, P>), grid, block, 0, st, dZ2, lddz, W2T, ldwt, H1, ldh, A, lda, rows, M, N, K, m_chunk,   \
@@ -1047,11 +1050,13 @@ void mg_launch_fused64(int nbt, const uint16_t* dZ2, int lddz, const uint16_t* W
         W64_PROBE_CASE(16)
         default: break;
     }
-#endif
-    if (nbt == 1)
+    if (nbt == 1) {
         hipLaunchKernelGGL(wgrad_fused64w_kernel, grid, block, 0, st, dZ2, lddz, W2T, ldwt, H1, ldh, A, lda, rows, M, N, K, m_chunk, n_splits, slab,
                            bslab, sstride);
-    else if (nbt == 2)
+        return;
+    }
+#endif
+    if (nbt == 2)
         hipLaunchKernelGGL(wgrad_fused64_kernel<2>, grid, block, 0, st, dZ2, lddz, W2T, ldwt, H1, ldh, A, lda, rows, M, N, K, m_chunk, n_splits, slab,
                            bslab, sstride);
     else
@@ -1060,9 +1065,11 @@ void mg_launch_fused64(int nbt, const uint16_t* dZ2, int lddz, const uint16_t* W
 }
 
 #ifdef MG_STAMPS
+#ifdef MG_EXPERIMENTS
 extern "C" int mg_diag_read_stamps_f64w(void* dst, size_t bytes) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps_f64w), bytes < sizeof(g_stamps_f64w) ? bytes : sizeof(g_stamps_f64w), 0, hipMemcpyDeviceToHost);
 }
+#endif
 extern "C" int mg_diag_read_stamps_f64(void* dst, size_t bytes) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps_f64), bytes < sizeof(g_stamps_f64) ? bytes : sizeof(g_stamps_f64), 0, hipMemcpyDeviceToHost);
 }

@@ -797,6 +797,7 @@ __global__ __launch_bounds__(512) void wgrad_fused_pipe_kernel(const uint16_t* _
 }
 
 
+#ifdef MG_EXPERIMENTS      // lab builds only (make lab / diag): the one-wave-per-SIMD experiment, measured slower
 // ---------------------------------------------------------------------------------------------------------------------
 // "Solo" form of the pipelined kernel: ONE wave per SIMD (256 threads, up to 512 registers per lane), P1 of step + 1 woven into P2 of
 // step inside one instruction stream.  Why (profiles/r2_stamps_fused.txt, cycles per 32-frame step of the 8-wave kernel, ~4,050 for
@@ -808,10 +809,10 @@ __global__ __launch_bounds__(512) void wgrad_fused_pipe_kernel(const uint16_t* _
 // registers), and P1's reads, its 16 small MFMAs, its VALU tail and its LDS stores are placed between the groups of P2's 40 MFMAs,
 // whose operands are read two groups ahead: the chain of P1 never stands alone.  Same LDS layout, run staging, DMA ring, slabs and
 // reduce as the kernel above; 4 tr-reads fewer per MFMA than two waves per SIMD (36 per 40 MFMAs against 28 per 20).
-// MEASURED SLOWER - an experiment (MG_TUNE_STAGGER = 8), correct (dW, db bit-identical to the kernel above, also for row maps
+// MEASURED SLOWER - an experiment (MG_TUNE_FORM = 8), correct (dW, db bit-identical to the kernel above, also for row maps
 // without runs), not the product path: 492 us against 262 at C2.  320 accumulator registers leave 192 of the 256 VGPRs (the
 // accumulator file holds 256) for everything else and hipcc spills 60 of them; and the probe with a 128 x 512 tile (TKT = 4: 256
-// accumulators, no spill, 4/5 of the matrix work; MG_TUNE_STAGGER = 9, results incomplete) still takes 304 us - a lone in-order wave
+// accumulators, no spill, 4/5 of the matrix work; MG_TUNE_FORM = 9, results incomplete) still takes 304 us - a lone in-order wave
 // whose LDS counter is shared by the operand reads of P2, the reads and stores of P1 and the look-ahead stands at s_waitcnt lgkmcnt
 // between every group; without a hand-placed stream the partner wave of the 8-wave form hides more than the wider budget buys.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1160,6 +1161,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_fused_solo_kernel(const uint16_t
 }
 
 
+#endif  // MG_EXPERIMENTS
+
 void mg_launch_fused64(int nbt, const uint16_t* dZ2, int lddz, const uint16_t* W2T, int ldwt, const uint16_t* H1, int ldh, const uint16_t* A,
                        int lda, const int32_t* rows, int64_t M, int N, int K, int m_chunk, int n_splits, float* slab, float* bslab,
                        int64_t sstride, hipStream_t st);
@@ -1204,17 +1207,26 @@ static int fused_launch(const char* name, const uint16_t* dZ2, int lddz, int N2,
     const int64_t nk = (int64_t)N * K, sstride = nk + N;
     float* slab = (float*)workspace;
     float* bslab = slab + nk;
-    if (rows && (g_mg_tuning[MG_TUNE_STAGGER] == 0 || g_mg_tuning[MG_TUNE_STAGGER] == 12 || g_mg_tuning[MG_TUNE_STAGGER] == 14 ||
-                 g_mg_tuning[MG_TUNE_STAGGER] >= 100))      // 64-frame steps (bwd_fused64_bf16.hip); >= 100: its timing probes (-DMG_PROBES builds)
-        mg_launch_fused64(g_mg_tuning[MG_TUNE_STAGGER] >= 100 ? g_mg_tuning[MG_TUNE_STAGGER] : g_mg_tuning[MG_TUNE_STAGGER] == 12 ? 2 : g_mg_tuning[MG_TUNE_STAGGER] == 14 ? 1 : 3, dZ2, lddz, W2T, ldwt, H1, ldh, A, lda, rows, M, N, K, chunk, S, slab, bslab,
-                          sstride, st);
-    else if (rows && g_mg_tuning[MG_TUNE_STAGGER] == 9)      // timing probe: the same with a 128 x 512 tile (no spills; results incomplete)
+    // MG_TUNE_FORM (same results every way): 0 = 64-frame steps, tiles three steps ahead (bwd_fused64_bf16.hip); 12 = the same with
+    // tiles two steps ahead and the larger ring; 13 = the 32-frame-step kernel it replaced (its bit-exact reference in the tests);
+    // 7 = the single-buffered kernel (also what inputs without a row map take)
+    const int form = g_mg_tuning[MG_TUNE_FORM];
+#ifdef MG_EXPERIMENTS
+    // lab builds only: 15 = the woven single-stream experiment, 100 + mask = timing probes of the 64-frame kernel (results garbage),
+    // 8 / 9 = the one-wave-per-SIMD experiment and its 128 x 512 probe
+    if (rows && (form == 15 || form >= 100)) {
+        mg_launch_fused64(form == 15 ? 1 : form, dZ2, lddz, W2T, ldwt, H1, ldh, A, lda, rows, M, N, K, chunk, S, slab, bslab, sstride, st);
+    } else if (rows && form == 9) {
         hipLaunchKernelGGL(wgrad_fused_solo_kernel<4>, dim3((unsigned)((N / F_BNT) * mg_align_up((size_t)S, 8))), dim3(256), 0, st, dZ2, lddz, W2T,
                            ldwt, H1, ldh, A, lda, rows, M, N, K, chunk, S, slab, bslab, sstride);
-    else if (rows && g_mg_tuning[MG_TUNE_STAGGER] == 8)      // one wave per SIMD, P1 woven into P2 (see the kernel's comment)
+    } else if (rows && form == 8) {
         hipLaunchKernelGGL(wgrad_fused_solo_kernel<5>, dim3((unsigned)((N / F_BNT) * mg_align_up((size_t)S, 8))), dim3(256), 0, st, dZ2, lddz, W2T,
                            ldwt, H1, ldh, A, lda, rows, M, N, K, chunk, S, slab, bslab, sstride);
-    else if (rows && g_mg_tuning[MG_TUNE_STAGGER] != 7)
+    } else
+#endif
+    if (rows && (form == 0 || form == 12))
+        mg_launch_fused64(form == 12 ? 2 : 3, dZ2, lddz, W2T, ldwt, H1, ldh, A, lda, rows, M, N, K, chunk, S, slab, bslab, sstride, st);
+    else if (rows && form != 7)
         hipLaunchKernelGGL(wgrad_fused_pipe_kernel, dim3((unsigned)((N / F_BNT) * mg_align_up((size_t)S, 8))), dim3(512), 0, st, dZ2, lddz, W2T,
                            ldwt, H1, ldh, A, lda, rows, M, N, K, chunk, S, slab, bslab, sstride);
     else

@@ -31,6 +31,9 @@ void mg_set_error(const char* fmt, ...);
 
 static inline int64_t mg_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 extern int g_mg_tuning[];
+// Lab builds (make lab / diag, -DMG_EXPERIMENTS) only: key 1 != 0 makes the weight-gradient entry points skip their slab-reduce launch
+// (results then invalid) so that a script can time the producing kernel alone.  The product library refuses the key.
+#define MG_TUNE_SKIP_REDUCE 1
 
 static inline size_t mg_align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 

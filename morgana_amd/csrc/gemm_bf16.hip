@@ -405,7 +405,7 @@ int mg_linear_fwd_bf16(const uint16_t* A, int lda, const int32_t* rows, int64_t 
     if (M == 0) return MG_OK;
     hipStream_t st = (hipStream_t)stream;
     // rows made of runs (frame map of upsample_to_repetitions): the gathered operand staged once per distinct row, two workgroups per CU
-    if (runs_hint && rows && !y_f32 && ldy == N && g_mg_tuning[MG_TUNE_STAGGER] != 14 &&
+    if (runs_hint && rows && !y_f32 && ldy == N && g_mg_tuning[MG_TUNE_FORM] != 14 &&
         mg_try_nt_runs(A, lda, rows, M, K, W, ldw, N, bias, (uint16_t*)Y, ldy, act == MG_ACT_SIGMOID, st) > 0) {
         MG_CHECK_LAUNCH("mg_linear_fwd_bf16/runs");
         return MG_OK;

@@ -385,7 +385,7 @@ MG_STAMP_DECL(g_stamps_ntp);
 // in the second, so that on every SIMD one wave feeds the matrix pipe while the other one occupies LDS.  MEASURED SLOWER than both
 // groups in lockstep on this kernel (layer-1 forward 203 vs 180 us, stamps: an interval takes ~1 000 cycles, not the 512 of its 16
 // MFMAs - the reading group's 4 LDS-DMA pieces + 12 ds_read_b128 take that long to issue, MI355X_MICROARCH.md "LDS-DMA piece issue
-// cost"), so it is kept as an experiment only (MG_TUNE_STAGGER = 4).  The groups fall back into step at every tile end.
+// cost"), so it is kept as an experiment only (MG_TUNE_FORM = 4).  The groups fall back into step at every tile end.
 // PIPE (square tile, 32-deep stages, both wave groups in lockstep): the k-step as a half-step software pipeline.  The fragments of a
 // stage are two sets (MFMA steps ks = 0 / 1, 6 reads and 8 MFMAs each); a set is read half a step before it is multiplied, and the
 // stage boundary (counted vmcnt + barrier, then the LDS-DMA of the stage NS ahead into the slot just vacated) sits BETWEEN the two
@@ -1224,28 +1224,43 @@ int mg_try_nt_big(const uint16_t* A, int lda, const int32_t* rows, int64_t M, in
     // Persistent form: bias / bias + sigmoid with bf16 output, at least one ring of k-tiles per tile, a stores-per-row pattern
     // that needs every store of a row in range (M is arbitrary: rows past the end are skipped per lane).
     const int n_kt = (K + 31) / 32;
-    if (!c_f32 && epi != EPI_SIGMOID_GRAD && n_kt >= 5 && M < 2147483647LL && 32 % tiles_n == 0 && g_mg_tuning[MG_TUNE_STAGGER] != 6) {
+    if (!c_f32 && epi != EPI_SIGMOID_GRAD && n_kt >= 5 && M < 2147483647LL && 32 % tiles_n == 0 && g_mg_tuning[MG_TUNE_FORM] != 6) {
         int64_t g = 256;                                             // one resident workgroup per CU
         while (mg_ceil_div(blocks, g) > NTP_MAX_TILES(bn)) g += 256;    // more tiles than a workgroup parks rows for: more groups
         if (g > blocks) g = mg_ceil_div(blocks, 8 * tiles_n) * 8 * tiles_n;
         dim3 pgrid((unsigned)g), pblock(512);
-        const int probe = g_mg_tuning[MG_TUNE_STAGGER] >= 256 ? g_mg_tuning[MG_TUNE_STAGGER] - 256 : g_mg_tuning[MG_TUNE_STAGGER] >= 32 ? g_mg_tuning[MG_TUNE_STAGGER] - 32 : 0;      // timing probes: 32 + bit mask
 #define LAUNCH_NTP(BN_, EPI_, STAG_, BK_) hipLaunchKernelGGL((gemm_nt_persist_kernel<BN_, EPI_, STAG_, BK_>), pgrid, pblock, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, (uint16_t*)C, ldc, (int)tiles_m, tiles_n, probe)
-        const bool stag = g_mg_tuning[MG_TUNE_STAGGER] == 4;     // experiment: the two wave groups half a k-step apart (measured slower)
-        const bool deep = g_mg_tuning[MG_TUNE_STAGGER] != 3;     // 128-wide tile: 64-deep stages (whole 128-byte lines per DMA row); 3 = 32-deep
-        const bool pipe = g_mg_tuning[MG_TUNE_STAGGER] == 2;     // experiment: half-step software pipeline of the square tile
-        if (wide && (g_mg_tuning[MG_TUNE_STAGGER] == 5 || g_mg_tuning[MG_TUNE_STAGGER] == 11)) {     // SPREAD (11: every wave at the same slots)
-            const int pr = g_mg_tuning[MG_TUNE_STAGGER] == 11 ? 32 : 0;
+        const bool deep = g_mg_tuning[MG_TUNE_FORM] != 3;        // 128-wide tile: 64-deep stages (whole 128-byte lines per DMA row); 3 = 32-deep
+#ifdef MG_EXPERIMENTS
+        // Lab builds only (make lab / diag): measured alternatives of the square tile and its timing probes (results garbage for the
+        // probes) - MG_TUNE_FORM 4 = wave groups half a k-step apart, 2 = half-step software pipeline, 5 / 11 = DMA pieces spread between
+        // the MFMAs, 9 / 10 / 12 / 13 = role-split probes, 32 + mask / 256 + mask = parts of the k-step switched off.
+        const int form = g_mg_tuning[MG_TUNE_FORM];
+        const int probe = form >= 256 ? form - 256 : form >= 32 ? form - 32 : 0;
+        if (wide && (form == 5 || form == 11)) {
+            const int pr = form == 11 ? 32 : 0;
             if (epi == EPI_BIAS) hipLaunchKernelGGL((gemm_nt_persist_kernel<256, EPI_BIAS, false, 32, 2>), pgrid, pblock, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, (uint16_t*)C, ldc, (int)tiles_m, tiles_n, pr);
             else hipLaunchKernelGGL((gemm_nt_persist_kernel<256, EPI_BIAS_SIGMOID, false, 32, 2>), pgrid, pblock, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, (uint16_t*)C, ldc, (int)tiles_m, tiles_n, pr);
-        } else if (wide && (g_mg_tuning[MG_TUNE_STAGGER] == 9 || g_mg_tuning[MG_TUNE_STAGGER] == 10 || g_mg_tuning[MG_TUNE_STAGGER] == 12 || g_mg_tuning[MG_TUNE_STAGGER] == 13)) {             // ROLE probe, without the epilogue (10: and without the MFMAs)
-            hipLaunchKernelGGL((gemm_nt_persist_kernel<256, EPI_BIAS_SIGMOID, false, 32, 5>), pgrid, pblock, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, (uint16_t*)C, ldc, (int)tiles_m, tiles_n, g_mg_tuning[MG_TUNE_STAGGER] == 9 ? 16 : g_mg_tuning[MG_TUNE_STAGGER] == 10 ? 24 : g_mg_tuning[MG_TUNE_STAGGER] == 12 ? 23 : 23 + 64);   // 12: MFMAs only (waves 0-3, 32 per k-step), 13: and no barrier
-        } else if (wide && pipe) {
+            return 1;
+        }
+        if (wide && (form == 9 || form == 10 || form == 12 || form == 13)) {
+            hipLaunchKernelGGL((gemm_nt_persist_kernel<256, EPI_BIAS_SIGMOID, false, 32, 5>), pgrid, pblock, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, (uint16_t*)C, ldc, (int)tiles_m, tiles_n, form == 9 ? 16 : form == 10 ? 24 : form == 12 ? 23 : 23 + 64);
+            return 1;
+        }
+        if (wide && form == 2) {
             if (epi == EPI_BIAS) hipLaunchKernelGGL((gemm_nt_persist_kernel<256, EPI_BIAS, false, 32, 1>), pgrid, pblock, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, (uint16_t*)C, ldc, (int)tiles_m, tiles_n, probe);
             else hipLaunchKernelGGL((gemm_nt_persist_kernel<256, EPI_BIAS_SIGMOID, false, 32, 1>), pgrid, pblock, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, (uint16_t*)C, ldc, (int)tiles_m, tiles_n, probe);
-        } else if (wide) {
-            if (stag) { if (epi == EPI_BIAS) LAUNCH_NTP(256, EPI_BIAS, true, 32); else LAUNCH_NTP(256, EPI_BIAS_SIGMOID, true, 32); }
-            else { if (epi == EPI_BIAS) LAUNCH_NTP(256, EPI_BIAS, false, 32); else LAUNCH_NTP(256, EPI_BIAS_SIGMOID, false, 32); }
+            return 1;
+        }
+        if (wide && form == 4) {
+            if (epi == EPI_BIAS) LAUNCH_NTP(256, EPI_BIAS, true, 32); else LAUNCH_NTP(256, EPI_BIAS_SIGMOID, true, 32);
+            return 1;
+        }
+#else
+        const int probe = 0;
+#endif
+        if (wide) {
+            if (epi == EPI_BIAS) LAUNCH_NTP(256, EPI_BIAS, false, 32); else LAUNCH_NTP(256, EPI_BIAS_SIGMOID, false, 32);
         } else if (deep) {
             if (epi == EPI_BIAS) LAUNCH_NTP(128, EPI_BIAS, false, 64); else LAUNCH_NTP(128, EPI_BIAS_SIGMOID, false, 64);
         } else {
@@ -1271,10 +1286,10 @@ int mg_try_nt_big(const uint16_t* A, int lda, const int32_t* rows, int64_t M, in
 
 // The 128 x 320 tile form (wgrad_big_body<5>: two k halves per n tile): phone-rate row counts of a 640-wide operand with 4+ n tiles
 static bool wgrad_ksplit(int64_t M, int N, int lda) {
-    if (g_mg_tuning[MG_TUNE_PROBE] == 92) return false;                                       // 92: A/B, the full-width tiles
+    if (g_mg_tuning[MG_TUNE_AB] == 92) return false;                                       // 92: A/B, the full-width tiles
     if (lda == 640) return M <= 32768 && N / 128 >= 4;
     // N = 128 at phone-rate row counts only: at M = 256 000 the half-width tiles were 34 us per step SLOWER (0.607 vs 0.573 ms)
-    return lda == 512 && N == 128 && M <= 32768 && g_mg_tuning[MG_TUNE_PROBE] != 93;          // 93: A/B, 128 x 512 tiles for this shape
+    return lda == 512 && N == 128 && M <= 32768 && g_mg_tuning[MG_TUNE_AB] != 93;          // 93: A/B, 128 x 512 tiles for this shape
 }
 
 // Plan of the split over M for the wide wgrad: S slabs of m_chunk rows.  Returns 0 if the shape does not qualify.
@@ -1336,7 +1351,7 @@ int mg_launch_wgrad_big(const uint16_t* dY, int lddy, const uint16_t* A, int lda
 // the GEMM's LDS block holds a job's scan.  Returns 1 if it launched, 0 otherwise (the caller runs the two launches).
 int mg_launch_phone_front_gemm(const PhoneFrontArgs& pf, const uint16_t* A, int lda, int64_t M, int K, const uint16_t* Bm, int ldb, int N,
                                const float* bias, uint16_t* C, int ldc, int epi, hipStream_t st) {
-    if (g_mg_tuning[MG_TUNE_PROBE] == 66 || g_mg_tuning[MG_TUNE_STAGGER] != 0) return 0;      // A/B: the separate launches
+    if (g_mg_tuning[MG_TUNE_AB] == 66 || g_mg_tuning[MG_TUNE_FORM] != 0) return 0;      // A/B: the separate launches
     if (M < 2048 || M >= 2147483647LL || lda % 64 != 0 || ldb % 64 != 0 || lda > MG_ZERO_ELEMS - 64 || ldb > MG_ZERO_ELEMS - 64) return 0;
     if (N % 256 != 0 || ldc != N || !big16(A) || !big16(Bm) || !big16(C)) return 0;
     if (lda < (K + 63) / 64 * 64 || ldb < (K + 63) / 64 * 64 || (K + 31) / 32 < 5) return 0;
@@ -1352,8 +1367,11 @@ int mg_launch_phone_front_gemm(const PhoneFrontArgs& pf, const uint16_t* A, int 
     constexpr int LDS_INTS = ntp_lds_bytes<256, 32, 0>() / 4;
     if (phone_front_lds_ints(pf.B, pf.P, pf.T, pf.extra) > LDS_INTS) return 0;
     PhoneFrontArgs a = pf;
-    a.lds_ints = g_mg_tuning[MG_TUNE_PROBE] == 67 ? 0 : LDS_INTS;      // 67: timing probe (the front's outputs are not written)
-    if (g_mg_tuning[MG_TUNE_PROBE] >= 70 && g_mg_tuning[MG_TUNE_PROBE] < 86) a.probe = g_mg_tuning[MG_TUNE_PROBE] - 70;     // 70 + bits
+    a.lds_ints = LDS_INTS;
+#ifdef MG_EXPERIMENTS      // lab builds only: 67 = idle riders (the front's outputs are not written), 70 + mask = parts of the rider off
+    if (g_mg_tuning[MG_TUNE_AB] == 67) a.lds_ints = 0;
+    if (g_mg_tuning[MG_TUNE_AB] >= 70 && g_mg_tuning[MG_TUNE_AB] < 86) a.probe = g_mg_tuning[MG_TUNE_AB] - 70;
+#endif
     dim3 grid((unsigned)(side + g)), block(512);
     if (epi == EPI_BIAS)
         hipLaunchKernelGGL((phone_front_gemm_kernel<EPI_BIAS>), grid, block, 0, st, (unsigned)side, a, A, lda, M, K, Bm, ldb, N, bias, C, ldc,
@@ -1371,7 +1389,7 @@ int mg_launch_phone_front_gemm(const PhoneFrontArgs& pf, const uint16_t* A, int 
 // splits; a 33rd workgroup on an XCD would wait for a whole tile program to finish).  Returns 1 and the split plan, or 0.
 int mg_launch_wgrad_dgrad_pair(const uint16_t* dY, int lddy, const uint16_t* A, int lda, int64_t M, int N, int K, const uint16_t* WT, int ldwt,
                                uint16_t* dX, int lddx, float* slab, int64_t sstride, size_t slab_floats, int* S_out, hipStream_t st) {
-    if (g_mg_tuning[MG_TUNE_PROBE] == 65) return 0;                   // A/B: the two launches
+    if (g_mg_tuning[MG_TUNE_AB] == 65) return 0;                   // A/B: the two launches
     int S = 0, m_chunk = 0;
     if (N != 128 || K != 512 || lda != 512 || lddx != K || mg_wgrad_big_plan(M, N, K, lda, lddy, &S, &m_chunk) <= 0) return 0;
     if (lddy % 64 != 0 || ldwt % 64 != 0 || lddy > MG_ZERO_ELEMS - 64 || ldwt > MG_ZERO_ELEMS - 64 || lddy < 128 || ldwt < 128) return 0;

@@ -1012,7 +1012,7 @@ int mg_gru_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const f
 }
 
 int mg_gru_persist_f32_supported(int B, int T, int H) {
-    if (B <= 0 || T <= 0 || H <= 0 || g_mg_tuning[3] == 1) return 0;
+    if (B <= 0 || T <= 0 || H <= 0 || g_mg_tuning[MG_TUNE_PERSISTENT] == 1) return 0;
     if (H % 64 != 0 || H > 512 || H < 256) return 0;                       // H = 64 / 128: gru_small.hip
     if (mg_ceil_div(B, GP_GROUPS) > 16) return 0;                           // one 16-row MFMA tile per group
     return gp_device_holds((long)GP_GROUPS * (H / GT));

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void gru_bwd_small64_kernel(const float* __res
 
 extern "C" {
 
-int mg_gru_small_supported(int H) { return (H == 64 || H == 128) && g_mg_tuning[3] != 1; }
+int mg_gru_small_supported(int H) { return (H == 64 || H == 128) && g_mg_tuning[MG_TUNE_PERSISTENT] != 1; }
 
 int mg_gru_fwd_small_f32(const float* xproj, const float* w_hh, const float* b_hh, const int64_t* seq_len, int B, int T, int H, float* hstate,
                          float* out, float* saved, void* stream) {
@@ -348,7 +348,7 @@ int mg_gru_fwd_small_f32(const float* xproj, const float* w_hh, const float* b_h
     MG_CHECK_ARG(((uintptr_t)w_hh % 16) == 0, "mg_gru_fwd_small_f32: w_hh must be 16-byte aligned");
     const int R = 256 / H;
     const unsigned grid = (unsigned)mg_ceil_div(B, R);
-    if (H == 64 && g_mg_tuning[3] != 2)
+    if (H == 64 && g_mg_tuning[MG_TUNE_PERSISTENT] != 2)
         hipLaunchKernelGGL(gru_fwd_small64_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, xproj, w_hh, b_hh, seq_len, B, T, hstate, out, saved);
     else if (H == 64)
         hipLaunchKernelGGL(gru_fwd_small_kernel<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, xproj, w_hh, b_hh, seq_len, B, T, R, hstate, out, saved);
@@ -364,7 +364,7 @@ int mg_gru_bwd_small_f32(const float* grad_out, const float* grad_hn, const floa
                  "mg_gru_bwd_small_f32: bad arguments (B=%d T=%d H=%d; H must be 64 or 128)", B, T, H);
     const int R = 256 / H;
     const unsigned grid = (unsigned)mg_ceil_div(B, R);
-    if (H == 64 && g_mg_tuning[3] != 2)
+    if (H == 64 && g_mg_tuning[MG_TUNE_PERSISTENT] != 2)
         hipLaunchKernelGGL(gru_bwd_small64_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, grad_out, grad_hn, hstate, saved, w_hh, seq_len, B, T,
                            dxproj, dhproj, dh0);
     else if (H == 64)

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void gru_stack_bwd_small64_kernel(GssLayers a,
 extern "C" {
 
 int mg_gru_stack_small_supported(int B, int T, int H, int L) {
-    if (B <= 0 || T <= 0 || H != 64 || L < 2 || L > MG_GRU_STACK_MAX_LAYERS || g_mg_tuning[3] == 1) return 0;
+    if (B <= 0 || T <= 0 || H != 64 || L < 2 || L > MG_GRU_STACK_MAX_LAYERS || g_mg_tuning[MG_TUNE_PERSISTENT] == 1) return 0;
     // every (layer, item block) workgroup must be resident at once: one per CU is plenty at these sizes
     return gp_device_holds(2L * L * mg_ceil_div(B, 4));
 }

@@ -64,7 +64,7 @@ __device__ __forceinline__ bfv8 lt_tr_frag(const unsigned char* tile, int lane, 
     return bfv8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-// PROBE (timing experiments through MG_TUNE_PROBE, results garbage): 1 = no H1 loads inside the loop, 2 = no tail (steps 2-9),
+// PROBE (timing experiments through MG_TUNE_AB, results garbage): 1 = no H1 loads inside the loop, 2 = no tail (steps 2-9),
 // 4 = no layer-2 MFMAs, 8 = no sigmoid on H2, 16 = no steps 8-9, 32 = no step 9.  The product kernel is PROBE = 0.
 template <int PROBE>
 __global__ __launch_bounds__(256, 1) void f0_l2tail_kernel(const uint16_t* __restrict__ H1, int ldh1, const uint16_t* __restrict__ W2,
@@ -477,6 +477,7 @@ __global__ __launch_bounds__(256, 1) void f0_l2tail_kernel(const uint16_t* __res
 #endif
 }
 
+#ifdef MG_EXPERIMENTS      // lab builds only (make lab / diag): the role-split experiment below, measured slower
 // ---------------------------------------------------------------------------------------------------------------------
 // The same pass with the work of a tile split between the TWO waves of a SIMD (512 threads, 2 waves per SIMD, 256 registers each).
 // Why: in the kernel above a wave owns a tile from the first MFMA to the last store; one wave per SIMD (it needs ~490 registers: a
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(256, 1) void f0_l2tail_kernel(const uint16_t* __res
 //     (L1 bypass) by the consumer on the same CU; the pair's `ready` / `done` counters live in LDS.  The producer publishes tile
 //     n - 1 when it is about to store tile n: vector memory retires in order, so s_waitcnt vmcnt(32) - the 32 row loads issued
 //     since - says those stores are complete without draining the prefetch.  Spins are bounded; a wait that gives up makes the loss NaN.
-// MEASURED SLOWER and kept as an experiment (MG_TUNE_PROBE = 64; correct: the parity tests pass on it): 107 us against 100 at C2,
+// MEASURED SLOWER and kept as an experiment (MG_TUNE_AB = 64; correct: the parity tests pass on it): 107 us against 100 at C2,
 // 26.3 against 25.2 at the phone-rate rows.  The split moves the sigmoid of H2 to the producer, but the consumer still owns the tail's
 // dependent chain (8 + 2 + 2 dependent MFMAs, three LDS round trips, the loads of the hand-off: ~10,000 cycles per tile of which
 // ~4,000 are issue) and has ONE tile in flight; a second tile in flight per consumer does not fit 256 registers.
@@ -865,6 +866,7 @@ __global__ __launch_bounds__(512, 2) void f0_l2tail_split_kernel(const uint16_t*
         out[e] = (failed && e == LT_SLAB - 1) ? __builtin_nanf("") : v;
     }
 }
+#endif  // MG_EXPERIMENTS
 
 static int l2tail_blocks(int64_t M) {
     int64_t blocks = mg_ceil_div(mg_ceil_div(M, 32), 4);
@@ -875,9 +877,13 @@ static int l2tail_blocks(int64_t M) {
 extern "C" {
 
 static size_t l2tail_slab_bytes(int64_t M) { return mg_align_up((size_t)l2tail_blocks(M) * LT_SLAB * sizeof(float), 256); }
-// slabs of the workgroups' sums, then the hand-off ring of the role-split kernel: 3 slots x 8 KB per producer / consumer pair
+// slabs of the workgroups' sums (lab builds: + the hand-off ring of the role-split experiment, 3 slots x 8 KB per wave pair)
 size_t mg_f0_l2tail_workspace_bytes(int64_t M) {
+#ifdef MG_EXPERIMENTS
     return l2tail_slab_bytes(M) + (size_t)l2tail_blocks(M) * 4 * LT_RING * LT_SLOT_VEC * sizeof(u32x4);
+#else
+    return l2tail_slab_bytes(M);
+#endif
 }
 
 static int f0_l2tail_launch(const char* name, const uint16_t* H1, int ldh1, int K2, const uint16_t* W2, int ldw2, int N2, const float* b2,
@@ -898,12 +904,15 @@ static int f0_l2tail_launch(const char* name, const uint16_t* H1, int ldh1, int 
     const int blocks = l2tail_blocks(M);
     float* slab = (float*)workspace;
 #define LT_LAUNCH(P_) hipLaunchKernelGGL(f0_l2tail_kernel<P_>, dim3(blocks), dim3(256), 0, st, H1, ldh1, W2, ldw2, b2, W3, b3, W4, b4, target, seq_len, M, B, T, grad_scale, pred, dZ2, lddz, slab, row_weight)
-    if (g_mg_tuning[MG_TUNE_PROBE] == 64) {            // experiment (measured slower, see the kernel's comment): producer / consumer waves
+#ifdef MG_EXPERIMENTS
+    // lab builds only: MG_TUNE_AB 64 = the producer / consumer role split (same results, measured slower); 1 .. 32 = the product
+    // kernel with parts switched off (timing probes, results garbage)
+    if (g_mg_tuning[MG_TUNE_AB] == 64) {
         u32x4* xbuf = reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(workspace) + l2tail_slab_bytes(M));
         hipLaunchKernelGGL(f0_l2tail_split_kernel, dim3(blocks), dim3(512), 0, st, H1, ldh1, W2, ldw2, b2, W3, b3, W4, b4, target, seq_len, M, B, T,
                            grad_scale, pred, dZ2, lddz, slab, row_weight, xbuf);
     } else
-    switch (g_mg_tuning[MG_TUNE_PROBE]) {              // 0: the product kernel; other values: its timing probes
+    switch (g_mg_tuning[MG_TUNE_AB]) {
         case 1: LT_LAUNCH(1); break;
         case 2: LT_LAUNCH(2); break;
         case 3: LT_LAUNCH(3); break;
@@ -916,6 +925,9 @@ static int f0_l2tail_launch(const char* name, const uint16_t* H1, int ldh1, int 
         case 17: LT_LAUNCH(17); break;
         default: LT_LAUNCH(0); break;
     }
+#else
+    LT_LAUNCH(0);
+#endif
 #undef LT_LAUNCH
     MG_CHECK_LAUNCH(name);
     if (slabs_out) {                                   // the caller sums the slabs (mg_expand_column_reduce_f32)

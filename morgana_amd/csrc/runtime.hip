@@ -16,8 +16,32 @@ int g_mg_tuning[MG_TUNING_KEYS] = {0};
 
 extern "C" {
 
+// Which (key, value) pairs the PRODUCT library takes: choices between kernels / plans that compute the same results.  The lab
+// builds (make lab / diag: -DMG_EXPERIMENTS) take every value - measured-slower experiments and timing probes live there only.
+static bool tuning_allowed(int key, int value) {
+#ifdef MG_EXPERIMENTS
+    (void)key;
+    (void)value;
+    return true;
+#else
+    switch (key) {
+        case MG_TUNE_FORM: return value == 0 || value == 3 || value == 6 || value == 7 || value == 12 || value == 13 || value == 14;
+        case MG_TUNE_GRU_HANDOFF: return value == 0 || value == 1;
+        case MG_TUNE_PERSISTENT: return value >= 0 && value <= 2;
+        case MG_TUNE_WGRAD_SPLITS: return value >= 0;
+        case MG_TUNE_WGRAD_ORDER: return value >= 0 && value <= 3;
+        case MG_TUNE_LSTM_BWD_STACK: return value == 0 || value == 1;
+        case MG_TUNE_AB: return value == 0 || value == 65 || value == 66 || value == 92 || value == 93;
+        default: return false;
+    }
+#endif
+}
+
 int mg_set_tuning(int key, int value) {
     MG_CHECK_ARG(key >= 0 && key < MG_TUNING_KEYS, "mg_set_tuning: key %d not in 0..%d", key, MG_TUNING_KEYS - 1);
+    MG_CHECK_ARG(tuning_allowed(key, value),
+                 "mg_set_tuning: key %d does not take value %d in the product library (experiments and timing probes are compiled into the "
+                 "lab builds only: make -C morgana_amd/csrc lab)", key, value);
     g_mg_tuning[key] = value;
     return MG_OK;
 }

@@ -57,7 +57,9 @@ static __global__ __launch_bounds__(256) void mg_slab_reduce4_kernel(const float
 
 static inline void mg_launch_slab_reduce(const float* slab, int64_t n, int64_t stride, int S, float* dst, int accumulate,
                                          hipStream_t st) {
-    if (g_mg_tuning[MG_TUNE_SKIP_REDUCE]) return;     // bench.py times the producing kernel alone
+#ifdef MG_EXPERIMENTS
+    if (g_mg_tuning[MG_TUNE_SKIP_REDUCE]) return;     // lab builds only: time the producing kernel alone (results then invalid)
+#endif
     if (n % 4 == 0 && stride % 4 == 0 && n >= 4096 && (((uintptr_t)slab | (uintptr_t)dst) % 16) == 0) {
         int64_t blocks4 = mg_ceil_div(n, 64);
         if (blocks4 > 32768) blocks4 = 32768;

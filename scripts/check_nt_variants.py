@@ -1,5 +1,10 @@
 #!/usr/bin/env python
-"""The NT GEMM's schedule variants (MG_TUNE_STAGGER) must compute the same bits: layer-1 forward at the C2 frame-rate and phone-rate
+"""
+import os as _os
+import sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import _lab  # noqa: E402,F401  (the lab library, before morgana_amd loads one)
+The NT GEMM's schedule variants (MG_TUNE_FORM) must compute the same bits: layer-1 forward at the C2 frame-rate and phone-rate
 shapes, ragged M, with and without the gather.  Usage: python scripts/check_nt_variants.py 0 2 4"""
 import os
 import sys

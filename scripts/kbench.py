@@ -7,6 +7,9 @@ import sys
 import torch
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# experiments and timing probes live in the lab build (make -C morgana_amd/csrc lab); the product library refuses their knobs
+if os.path.exists(os.path.join(REPO, 'morgana_amd', 'libmorgana_hip_lab.so')):
+    os.environ.setdefault('MORGANA_HIP_LIB', os.path.join(REPO, 'morgana_amd', 'libmorgana_hip_lab.so'))
 sys.path.insert(0, REPO)
 from morgana_amd import ops, synthetic, data  # noqa: E402
 

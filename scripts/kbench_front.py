@@ -1,5 +1,10 @@
 """Timing of the phone-rate front beside the first layer's GEMM (C2 shapes): one grid, two launches, and the grid with idle rider blocks
-(MG_TUNE_PROBE = 67, results garbage).  Run on the GPU box: python scripts/kbench_front.py"""
+(MG_TUNE_AB = 67, results garbage).  Run on the GPU box: python scripts/kbench_front.py"""
+import os as _os
+import sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import _lab  # noqa: E402,F401  (the lab library, before morgana_amd loads one)
+
 import numpy as np
 import torch
 from morgana_amd import ops, _lib

@@ -1,6 +1,11 @@
 #!/usr/bin/env python
-"""Micro-benchmark of mg_f0_l2tail_bf16 (layer 2 + tail in one pass over H1) against the pair it replaces, at the C2 frame-rate and
-phone-rate shapes, with the kernel's timing probes (MG_TUNE_PROBE).  Usage: python scripts/kbench_l2tail.py [iters]"""
+"""
+import os as _os
+import sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import _lab  # noqa: E402,F401  (the lab library, before morgana_amd loads one)
+Micro-benchmark of mg_f0_l2tail_bf16 (layer 2 + tail in one pass over H1) against the pair it replaces, at the C2 frame-rate and
+phone-rate shapes, with the kernel's timing probes (MG_TUNE_AB).  Usage: python scripts/kbench_l2tail.py [iters]"""
 import os
 import sys
 

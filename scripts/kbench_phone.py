@@ -1,5 +1,10 @@
 #!/usr/bin/env python
-"""Micro-benchmark of the phone-rate step's GEMM kernels (M = B*P + 1024 = 21 504 table rows at C2) under tuning variants:
+"""
+import os as _os
+import sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import _lab  # noqa: E402,F401  (the lab library, before morgana_amd loads one)
+Micro-benchmark of the phone-rate step's GEMM kernels (M = B*P + 1024 = 21 504 table rows at C2) under tuning variants:
 interleaved rounds in one process, HIP-event timing on the launch stream.  Usage: python scripts/kbench_phone.py [iters]"""
 import os
 import sys

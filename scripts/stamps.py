@@ -94,7 +94,7 @@ def main():
         report(title + ' (dgrad2 + wgrad1, gathered input, 64-frame steps)', s,
                [('  loop: wait + barrier', s[..., 6]), ('  loop: run scan of the next step', s[..., 10]), ('  loop: fetch (DMA issue)', s[..., 7]),
                 ('  loop: P1', s[..., 8]), ('  loop: P2', s[..., 9])])
-    lib.mg_set_tuning(0, 14)
+    lib.mg_set_tuning(0, 15)
     for _ in range(3):
         ops.linear_bwd_fused_bf16(dz2, w2t, h1, tab, rows, m, 512, 600)
     torch.cuda.synchronize()

@@ -116,3 +116,25 @@ def test_state_dict_keys_match_reference_layout():
         ['layers.%d.%s' % (i, k) for i in (0, 2, 4, 6) for k in ('weight', 'bias')])
     keys = sorted(models.RNNSPSS().state_dict())
     assert 'layers.2.layer.weight_ih_l0' in keys and 'layers.5.bias' in keys
+
+
+def test_product_library_holds_no_experiments():
+    """Measured-slower experiments and timing probes are compiled into the lab builds only: the product
+    library's symbol table names none of their kernels, the header documents no value whose results are garbage, and mg_set_tuning
+    refuses every key / value that is not a choice between forms with the same results (needs no GPU: host code only)."""
+    import re
+    import subprocess
+    from morgana_amd import _lib
+    names = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH], universal_newlines=True)
+    for kernel in ('wgrad_fused_solo_kernel', 'wgrad_fused64w_kernel', 'f0_l2tail_split_kernel'):
+        assert kernel not in names, kernel
+    assert not re.search(r'wgrad_fused64_kernelILi3ELi[1-9]', names)              # the PROBE != 0 instantiations
+    assert not re.search(r'f0_l2tail_kernelILi[1-9]', names)
+    assert not re.search(r'gemm_nt_persist_kernelILi256ELi\dELb1', names)         # the staggered wave groups
+    header = open(os.path.join(REPO, 'include', 'morgana_hip.h')).read()
+    assert 'results garbage' not in header                                    # no documented value with invalid results
+    lib = _lib.load()
+    for key, value in ((0, 4), (0, 8), (0, 15), (0, 100), (0, 32), (1, 1), (7, 64), (7, 1), (7, 70), (9, 0), (-1, 0)):
+        assert lib.mg_set_tuning(key, value) != 0, (key, value)
+    for key, value in ((0, 13), (0, 12), (0, 0), (2, 1), (2, 0), (3, 1), (3, 0), (4, 48), (4, 0), (5, 2), (5, 0), (6, 1), (6, 0), (7, 65), (7, 0)):
+        assert lib.mg_set_tuning(key, value) == 0, (key, value)

@@ -420,10 +420,12 @@ def test_linear_fwd_run_staged_equals_frame_staged(m, n, act, rows_kind):
 
 @pytest.fixture
 def l2tail_variant(request):
-    """MG_TUNE_PROBE for mg_f0_l2tail_bf16: 0 = the product kernel, 64 = the producer / consumer role split (an experiment that
-    must stay correct)."""
+    """MG_TUNE_AB for mg_f0_l2tail_bf16: 0 = the product kernel, 64 = the producer / consumer role split - an experiment that must
+    stay correct, compiled into the lab build only (MORGANA_HIP_LIB=morgana_amd/libmorgana_hip_lab.so): the product library refuses
+    the value and the case is skipped."""
     from morgana_amd import _lib
-    _lib.load().mg_set_tuning(7, request.param)
+    if _lib.load().mg_set_tuning(7, request.param) != 0:
+        pytest.skip('experiment kernels are in the lab build only (make -C morgana_amd/csrc lab)')
     yield request.param
     _lib.load().mg_set_tuning(7, 0)
 
@@ -576,7 +578,7 @@ def test_wgrad_dgrad_pair_equals_the_two_launches(m):
     np.testing.assert_allclose(tot3.cpu().numpy(), tot.cpu().numpy(), rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize('nbt_knob', [0, 12, 14])
+@pytest.mark.parametrize('nbt_knob', [0, 12, 15])
 def test_fused_backward_64_frame_steps_equal_32_frame_kernel(nbt_knob):
     """wgrad_fused64_kernel (csrc/bwd_fused64_bf16.hip: 64-frame steps, the run structure of a step from a ballot instead of LDS
     tables, ring allocated by groups per step, passes for steps with more runs than the ring holds) against the 32-frame-step kernel
@@ -584,9 +586,13 @@ def test_fused_backward_64_frame_steps_equal_32_frame_kernel(nbt_knob):
     MFMAs on the same operands), to fp32 rounding where steps take several passes.  Row maps: phone-like runs with pad
     frames (-1), short runs (several ring passes per step and steps that do not fit beside their predecessor: the on-demand fetch),
     no runs at all (every frame its own row: the worst case), one long run; M not a multiple of the step.
-    nbt_knob: 0 = tiles fetched three steps ahead (the product form), 12 = two steps ahead with the larger ring."""
+    nbt_knob: 0 = tiles fetched three steps ahead (the product form), 12 = two steps ahead with the larger ring, 15 = the woven
+    single-stream experiment (lab build only)."""
     from morgana_amd import _lib
     lib = _lib.load()
+    if lib.mg_set_tuning(0, nbt_knob) != 0:
+        pytest.skip('experiment kernels are in the lab build only (make -C morgana_amd/csrc lab)')
+    lib.mg_set_tuning(0, 0)
     rng = np.random.RandomState(5)
     k0 = 600
     for m in (40037, 8192):
