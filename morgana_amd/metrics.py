@@ -1,7 +1,7 @@
-"""Mirror of ``morgana.metrics`` for the train loop: ``Handler``, the ``Mean`` loss metric and the streaming metrics the shipped
+"""The metrics of the train loop: a registry-based ``Handler``, the ``Mean`` loss metric and the streaming metrics the shipped
 acoustic model accumulates inside its ``loss`` every step (models/RNN_SPSS.py:44-48, :120-129).
 
-Reference: morgana/metrics.py - ``Handler.accumulate`` :133-153, ``Mean`` :359-397 (sum / (count + 1e-8)), ``RMSE`` :474-499,
+Reference behaviour: morgana/metrics.py - ``Handler`` :50-186, ``Mean`` :359-397 (sum / (count + 1e-8)), ``RMSE`` :474-499,
 ``MAE`` :556-576, ``F0Distortion`` / ``LF0Distortion`` :579-634, ``Distortion`` :637-669, ``MelCepDistortion`` :672-694.
 Everything stays on the device: the reference pulls the frame count to the host with ``.item()`` in every accumulate call
 (metrics.py:394, :610); here a call is two small launches into a (sum, count) accumulator (csrc/metrics.hip) and ``result``
@@ -140,59 +140,91 @@ class MelCepDistortion(RMSE):
         self._add(ops.METRIC_SQDIFF, target, pred, seq_len=seq_len, col0=1)
 
 
+def _call_spec(inputs):
+    """What a caller hands ``Handler.accumulate`` for one metric -> (positional, keyword) arguments of ``metric.accumulate``: a bare
+    value, or a tuple / list of positionals whose last item may be a dict of keyword arguments (``seq_len=...``)."""
+    args = list(inputs) if isinstance(inputs, (tuple, list)) else [inputs]
+    kwargs = args.pop() if args and isinstance(args[-1], dict) else {}
+    return args, kwargs
+
+
 class Handler(object):
-    """Container for running a set of metrics, morgana/metrics.py:50-186: named collections ('all', 'train', 'valid', 'test')
-    of name -> metric; the constructor's metrics go to 'all', 'train' and 'valid', ``add_metrics('all', ...)`` to every
-    collection, and a metric added to several collections is ONE object shared between them, as in the reference."""
+    """The metric container of the train loop (public surface of morgana/metrics.py:50-186: ``handler[collection]``, ``add_metrics``,
+    ``add_collection``, ``reset_state``, ``accumulate``, ``result``, ``results_as_json_dict``, ``results_as_str_dict``).
+
+    ONE registry holds every metric object by name; a collection ('all', 'train', 'valid', 'test', or one made by
+    ``add_collection``) is an ordered list of names into it, so a metric that belongs to several collections is one object by
+    construction and ``accumulate`` / ``reset_state`` dispatch through the names.  Metrics given to the constructor join 'all', 'train'
+    and 'valid'; ``add_metrics('all', ...)`` joins every collection there is; whatever is added also joins 'all'."""
+
+    BUILT_IN = ('all', 'train', 'valid', 'test')
 
     def __init__(self, **metrics):
         self.hidden = False
-        self.collections = {'all': metrics, 'train': {}, 'valid': {}, 'test': {}}
-        self.metrics = self.collections['all']
+        self._registry = {}
+        self._members = {name: [] for name in self.BUILT_IN}
         self.add_metrics(('train', 'valid'), **metrics)
 
-    def __getitem__(self, name):
-        if name in self.collections:
-            return self.collections[name]
-        raise ValueError("No collection found by the name {}".format(name))
+    # -- membership ------------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _names(spec):
+        return [spec] if isinstance(spec, str) or not hasattr(spec, '__iter__') else list(spec)
 
-    def add_metrics(self, collections=('all',), **kwargs):
-        if isinstance(collections, str) or not hasattr(collections, '__iter__'):
-            collections = [collections]
-        if 'all' in collections:
-            collections = list(self.collections.keys())
-        for collection_name in collections:
-            self.collections[collection_name].update(kwargs)
-        self.metrics.update(kwargs)
+    def _collection(self, name):
+        if name not in self._members:
+            raise ValueError("No collection found by the name {}".format(name))
+        return self._members[name]
+
+    def __getitem__(self, collection):
+        return {name: self._registry[name] for name in self._collection(collection)}
+
+    @property
+    def metrics(self):
+        return self['all']
+
+    @property
+    def collections(self):
+        return {collection: self[collection] for collection in self._members}
+
+    def add_metrics(self, collections=('all',), **metrics):
+        targets = self._names(collections)
+        if 'all' in targets:
+            targets = list(self._members)
+        self._registry.update(metrics)
+        for collection in dict.fromkeys(list(targets) + ['all']):
+            members = self._collection(collection)
+            members.extend(name for name in metrics if name not in members)
 
     def add_collection(self, collection, from_collections=tuple()):
-        if isinstance(from_collections, str) or not hasattr(from_collections, '__iter__'):
-            from_collections = [from_collections]
-        self.collections[collection] = {}
-        for from_collection in from_collections:
-            self[collection].update(self[from_collection])
+        merged = []
+        for source in self._names(from_collections):
+            merged.extend(name for name in self._collection(source) if name not in merged)
+        self._members[collection] = merged
 
+    # -- the loop's calls ------------------------------------------------------------------------------------------------------------
     def reset_state(self, collection, *args):
-        for metric in self[collection].values():
-            metric.reset_state()
+        for name in self._collection(collection):
+            self._registry[name].reset_state()
 
-    def accumulate(self, collection, **kwargs):
-        for metric_name, inputs in kwargs.items():
-            inputs = list(inputs) if isinstance(inputs, (tuple, list)) else [inputs]          # utils.listify
-            if isinstance(inputs[-1], dict):
-                inputs, kwinputs = inputs[:-1], inputs[-1]
-            else:
-                kwinputs = dict()
-            self[collection][metric_name].accumulate(*inputs, **kwinputs)
+    def accumulate(self, collection, **inputs_by_metric):
+        members = self._collection(collection)
+        for name, inputs in inputs_by_metric.items():
+            if name not in members:
+                raise KeyError(name)
+            args, kwargs = _call_spec(inputs)
+            self._registry[name].accumulate(*args, **kwargs)
+
+    def _visible(self, collection):
+        return [(name, self._registry[name]) for name in self._collection(collection) if not self._registry[name].hidden]
 
     def result(self, collection='all', *args):
-        return {name: metric.result(*args) for name, metric in self[collection].items()}
+        return {name: self._registry[name].result(*args) for name in self._collection(collection)}
 
     def results_as_json_dict(self, collection='all', prefix=''):
-        return {prefix + name: metric.result_as_json() for name, metric in self[collection].items() if not metric.hidden}
+        return {prefix + name: metric.result_as_json() for name, metric in self._visible(collection)}
 
     def results_as_str_dict(self, collection='all', prefix=''):
-        return {prefix + name: str(metric) for name, metric in self[collection].items() if not metric.hidden}
+        return {prefix + name: str(metric) for name, metric in self._visible(collection)}
 
     def __str__(self):
-        return ' | '.join('{} = {}'.format(name, value) for name, value in self.results_as_str_dict('all').items())
+        return ' | '.join('{} = {}'.format(name, text) for name, text in self.results_as_str_dict('all').items())

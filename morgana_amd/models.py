@@ -120,13 +120,174 @@ class RNNSPSS(BaseSPSS):
                           features['normalised_' + self.target_name], features['n_frames'])
 
 
-class LSTMAcousticModel(BaseSPSS):
-    """models/RNN_SPSS.py:20-139 against this package: same constructor arguments, layer container (so the reference's
-    state_dict keys ``layers.0.weight`` ... ``layers.{3+k}.layer.weight_ih_l0`` ... load unchanged), ``predict`` outputs and
-    ``loss``, and the metrics registered at :44-48 and accumulated in ``loss`` (:120-129).  ``_prepare_output`` (:107-118:
-    denormalise the delta streams, MLPG against the global delta variances, padding 100) runs on the device
-    (``viz.synthesis.MLPG``, csrc/mlpg.hip) instead of through numpy on the host; it and the metrics are active whenever the
-    normalisers carry delta parameters, i.e. under ``ExperimentBuilder`` as in the reference (``generate=False`` turns both off)."""
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The reference's two shipped models (models/RNN_SPSS.py, models/f0_test_model.py) are instances of ONE scheme: labels + counters
+# -> a layer stack -> a prediction that is split into output STREAMS, each with a masked loss, optionally a delta-feature
+# trajectory (MLPG) and a streaming metric.  A stream is a row of a table; the generic model below reads the table.
+# ---------------------------------------------------------------------------------------------------------------------------------
+class Stream(object):
+    """One output stream.  ``name``: feature name ('lf0'); ``dim``: columns of the prediction; ``loss``: 'mse' against
+    ``normalised_<name>_deltas`` (a delta stream: static + delta + delta-delta, denormalised and turned into a trajectory by MLPG)
+    or 'sigmoid_bce' against ``<name>`` (a probability stream).  ``metric`` = (registered name, factory, kind): kind 'trajectory'
+    feeds (target, trajectory, n_frames), 'voiced_trajectory' adds a voicing mask (the predicted probability stream ``voicing`` >
+    0.5, or the feature of that name when the model predicts none), 'accuracy' feeds the hit rate of a probability stream."""
+
+    def __init__(self, name, dim, loss='mse', metric=None, voicing='vuv'):
+        self.name, self.dim, self.loss, self.metric, self.voicing = name, dim, loss, metric, voicing
+
+    @property
+    def is_delta(self):
+        return self.loss == 'mse'
+
+    @property
+    def output_key(self):
+        return 'normalised_%s_deltas' % self.name if self.is_delta else self.name
+
+
+class StreamModel(BaseSPSS):
+    """``layers`` (a ``SequentialWithRecurrent`` whose last Linear is as wide as the streams together) + a stream table ->
+    ``predict`` / ``loss`` / ``forward`` as the shipped models define them: input = upsampled labels concatenated with the frame
+    counters, per-stream outputs under the reference's keys, loss = mean of the streams' masked losses, trajectories and metrics on
+    the device whenever the normalisers carry delta parameters (i.e. under ``ExperimentBuilder``; ``generate=False`` turns both off).
+    ``fused_loss``: the split, the sigmoid and all masked losses as one pass over the prediction (``losses.multi_stream``)."""
+
+    def __init__(self, layers, streams, fused_upsample=True, fused_loss=False, generate=True):
+        super(StreamModel, self).__init__()
+        self.layers = layers
+        self.streams = tuple(streams)
+        self.fused_upsample, self.fused_loss, self.generate = fused_upsample, fused_loss, generate
+        registered = {st.metric[0]: st.metric[1]() for st in self.streams if st.metric is not None}
+        if registered:
+            self.metrics.add_metrics('all', **registered)
+
+    def normaliser_sources(self):
+        sources = {'dur': data.MeanVarianceNormaliser('dur'), 'lab': data.MinMaxNormaliser('lab'),
+                   'counters': data.MinMaxNormaliser('counters')}
+        for st in self.streams:
+            if st.is_delta:
+                sources[st.name] = data.MeanVarianceNormaliser(st.name, use_deltas=True)
+        return sources
+
+    # -- pieces ----------------------------------------------------------------------------------------------------------------------
+    def _run_layers(self, features):
+        norm_counters = features['normalised_counters']
+        norm_lab_at_frame_rate = utils.upsample_to_repetitions(features['normalised_lab'], features['dur'],
+                                                               max_len=norm_counters.shape[1], fused=self.fused_upsample)
+        model_inputs = utils.concat_frame_features(norm_lab_at_frame_rate, norm_counters)
+        prediction, _ = self.layers(model_inputs, seq_len=features['n_frames'], max_len=norm_counters.shape[1])
+        return prediction
+
+    def _split(self, prediction, probabilities=None):
+        """Per-stream outputs under the reference's keys; ``probabilities``: the sigmoid of the probability streams when a fused
+        loss pass has computed it already."""
+        parts = torch.split(prediction, [st.dim for st in self.streams], dim=-1) if len(self.streams) > 1 else (prediction,)
+        outputs = {}
+        for st, part in zip(self.streams, parts):
+            if st.is_delta:
+                outputs[st.output_key] = part
+            else:
+                outputs[st.output_key] = torch.sigmoid(part) if probabilities is None else probabilities
+        return outputs
+
+    def _generating(self):
+        return self.generate and all(_has_delta_params(self.normalisers, st.name) for st in self.streams if st.is_delta)
+
+    def _trajectory(self, name, pred_norm_deltas, seq_len=None):
+        """Denormalised deltas -> most probable static trajectory under the global delta variances, padding 100
+        (models/RNN_SPSS.py:107-118, models/f0_test_model.py:83-89), without leaving the device."""
+        normaliser = self.normalisers[name]
+        pred_deltas = normaliser.denormalise(pred_norm_deltas.detach(), deltas=True)
+        return viz.synthesis.MLPG(means=pred_deltas, variances=normaliser.delta_params_torch['std_dev'] ** 2, padding_size=100,
+                                  seq_len=seq_len)
+
+    _prepare_output = _trajectory      # the reference's name for it
+
+    def _with_trajectories(self, outputs, n_frames):
+        if self._generating():
+            for st in self.streams:
+                if st.is_delta:
+                    outputs[st.name] = self._trajectory(st.name, outputs[st.output_key], n_frames)
+        return outputs
+
+    def _accumulate_metrics(self, features, outputs):
+        if not self._generating():
+            return
+        n_frames = features['n_frames']
+        predicted = {st.name for st in self.streams if not st.is_delta}
+        calls = {}
+        for st in self.streams:
+            if st.metric is None:
+                continue
+            metric_name, _, kind = st.metric
+            if kind == 'accuracy':
+                calls[metric_name] = ((features[st.name] == (outputs[st.name] > 0.5)).type(torch.float), n_frames)
+            elif kind == 'voiced_trajectory':
+                voiced = (outputs[st.voicing] > 0.5) if st.voicing in predicted else features[st.voicing]
+                calls[metric_name] = (features[st.name], outputs[st.name], voiced, n_frames)
+            else:
+                calls[metric_name] = (features[st.name], outputs[st.name], n_frames)
+        self.metrics.accumulate(self.mode, **calls)
+
+    def _target(self, features, st):
+        return features[st.output_key]
+
+    # -- the plugin surface ----------------------------------------------------------------------------------------------------------
+    def predict(self, features):
+        return self._with_trajectories(self._split(self._run_layers(features)), features['n_frames'])
+
+    def loss(self, features, output_features):
+        n_frames = features['n_frames']
+        self._accumulate_metrics(features, output_features)
+        total = 0.
+        for st in self.streams:                           # delta streams first, then the probability streams: the reference's order
+            if st.is_delta:
+                total = total + losses.mse(output_features[st.output_key], self._target(features, st), n_frames)
+        for st in self.streams:
+            if not st.is_delta:
+                total = total + losses.bce(output_features[st.output_key].type(torch.float), self._target(features, st).type(torch.float),
+                                           n_frames)
+        return total / float(len(self.streams)) if len(self.streams) > 1 else total
+
+    def forward(self, features):
+        if not self.fused_loss:
+            return super(StreamModel, self).forward(features)
+        prediction = self._run_layers(features)
+        targets = [self._target(features, st) for st in self.streams]
+        kinds = [st.loss for st in self.streams]
+        loss, probabilities = losses.multi_stream(prediction, targets, kinds, features['n_frames'], want_prob=True)
+        outputs = self._with_trajectories(self._split(prediction.detach(), probabilities), features['n_frames'])
+        self._accumulate_metrics(features, outputs)
+        return loss, outputs
+
+
+def _lstm_stack(input_dim, hidden_dim, post_dim, output_dim, num_layers, dropout_prob, precision):
+    """models/RNN_SPSS.py:32-42 (the container order fixes the reference's state_dict keys)."""
+    return utils.SequentialWithRecurrent(
+        nn.Linear(input_dim, hidden_dim), nn.Sigmoid(), nn.Dropout(p=dropout_prob),
+        *[utils.RecurrentCuDNNWrapper(nn.LSTM(hidden_dim, hidden_dim, dropout=dropout_prob, batch_first=True), precision=precision)
+          for _ in range(num_layers)],
+        nn.Linear(hidden_dim, post_dim), nn.Sigmoid(), nn.Dropout(p=dropout_prob),
+        nn.Linear(post_dim, output_dim),
+        precision=precision)
+
+
+def _gru_f0_stack(input_dim, output_dim, dropout_prob, precision):
+    """models/f0_test_model.py:28-45."""
+    def gru(n_in):
+        return utils.RecurrentCuDNNWrapper(nn.GRU(n_in, 64, batch_first=True), precision=precision)
+    return utils.SequentialWithRecurrent(
+        nn.Linear(input_dim, 256), nn.Sigmoid(), nn.Dropout(p=dropout_prob),
+        gru(256), nn.Dropout(p=dropout_prob), gru(64), nn.Dropout(p=dropout_prob), gru(64), nn.Dropout(p=dropout_prob),
+        nn.Linear(64, 64), nn.Sigmoid(), nn.Dropout(p=dropout_prob),
+        nn.Linear(64, output_dim),
+        precision=precision)
+
+
+class LSTMAcousticModel(StreamModel):
+    """The reference's shipped acoustic model (models/RNN_SPSS.py:20-139) as a stream table: lf0 / mcep / bap delta streams with
+    masked MSE, a vuv probability stream with masked BCE, loss = their mean; LF0 RMSE in Hz over the frames the model calls voiced,
+    V/UV accuracy, mel-cepstral and band-aperiodicity distortion (:44-48, :120-129).  Same constructor arguments and state_dict keys
+    (``layers.0.weight`` ... ``layers.{3+k}.layer.weight_ih_l0`` ...)."""
 
     STREAMS = ('lf0', 'vuv', 'mcep', 'bap')
 
@@ -134,170 +295,23 @@ class LSTMAcousticModel(BaseSPSS):
                  precision=None, fused_upsample=True, fused_loss=True, generate=True):
         if output_dims is None:
             output_dims = {'lf0': 1 * 3, 'vuv': 1, 'mcep': 60 * 3, 'bap': 5 * 3}
-        super(LSTMAcousticModel, self).__init__()
-        self.generate = generate
-        self.input_dim = input_dim
-        self.output_dims = output_dims
-        self.dropout_prob = dropout_prob
-        self.num_layers = num_layers
-        self.fused_upsample = fused_upsample
-        self.fused_loss = fused_loss
-        self.layers = utils.SequentialWithRecurrent(
-            nn.Linear(self.input_dim, hidden_dim),
-            nn.Sigmoid(),
-            nn.Dropout(p=self.dropout_prob),
-            *[utils.RecurrentCuDNNWrapper(nn.LSTM(hidden_dim, hidden_dim, dropout=self.dropout_prob, batch_first=True),
-                                          precision=precision)
-              for _ in range(self.num_layers)],
-            nn.Linear(hidden_dim, post_dim),
-            nn.Sigmoid(),
-            nn.Dropout(p=self.dropout_prob),
-            nn.Linear(post_dim, sum(self.output_dims.values())),
-            precision=precision)
-        self.metrics.add_metrics('all',                                              # models/RNN_SPSS.py:44-48
-                                 LF0_RMSE_Hz=metrics.LF0Distortion(),
-                                 VUV_accuracy=metrics.Mean(),
-                                 MCEP_distortion=metrics.MelCepDistortion(),
-                                 BAP_distortion=metrics.Distortion())
-
-    def normaliser_sources(self):
-        return {
-            'dur': data.MeanVarianceNormaliser('dur'),
-            'lab': data.MinMaxNormaliser('lab'),
-            'counters': data.MinMaxNormaliser('counters'),
-            'lf0': data.MeanVarianceNormaliser('lf0', use_deltas=True),
-            'mcep': data.MeanVarianceNormaliser('mcep', use_deltas=True),
-            'bap': data.MeanVarianceNormaliser('bap', use_deltas=True),
-        }
-
-    def _run_layers(self, features):
-        norm_counters = features['normalised_counters']
-        norm_lab_at_frame_rate = utils.upsample_to_repetitions(features['normalised_lab'], features['dur'],
-                                                               max_len=norm_counters.shape[1], fused=self.fused_upsample)
-        model_inputs = utils.concat_frame_features(norm_lab_at_frame_rate, norm_counters)
-        pred_norm_deltas, _ = self.layers(model_inputs, seq_len=features['n_frames'], max_len=norm_counters.shape[1])
-        return pred_norm_deltas
-
-    def _split(self, pred_norm_deltas, pred_vuv=None):
-        output_dims = [self.output_dims[n] for n in self.STREAMS]
-        lf0, vuv, mcep, bap = torch.split(pred_norm_deltas, output_dims, dim=-1)
-        return {
-            'normalised_lf0_deltas': lf0,
-            'normalised_mcep_deltas': mcep,
-            'normalised_bap_deltas': bap,
-            'vuv': torch.sigmoid(vuv) if pred_vuv is None else pred_vuv,
-        }
-
-    def _generating(self):
-        return self.generate and all(_has_delta_params(self.normalisers, n) for n in ('lf0', 'mcep', 'bap'))
-
-    def _prepare_output(self, name, pred_norm_deltas, seq_len=None):
-        """models/RNN_SPSS.py:107-118, without leaving the device."""
-        pred_deltas = self.normalisers[name].denormalise(pred_norm_deltas.detach(), deltas=True)
-        return viz.synthesis.MLPG(means=pred_deltas, variances=self.normalisers[name].delta_params_torch['std_dev'] ** 2,
-                                  padding_size=100, seq_len=seq_len)
-
-    def _with_trajectories(self, outputs, n_frames):
-        if self._generating():
-            for name in ('lf0', 'mcep', 'bap'):                                      # :88-93
-                outputs[name] = self._prepare_output(name, outputs['normalised_%s_deltas' % name], n_frames)
-        return outputs
-
-    def _accumulate_metrics(self, features, output_features):
-        if not self._generating():
-            return
-        n_frames = features['n_frames']
-        vuv = output_features['vuv'] > 0.5                                           # :121-129
-        self.metrics.accumulate(
-            self.mode,
-            LF0_RMSE_Hz=(features['lf0'], output_features['lf0'], vuv, n_frames),
-            VUV_accuracy=((features['vuv'] == vuv).type(torch.float), n_frames),
-            MCEP_distortion=(features['mcep'], output_features['mcep'], n_frames),
-            BAP_distortion=(features['bap'], output_features['bap'], n_frames))
-
-    def predict(self, features):
-        return self._with_trajectories(self._split(self._run_layers(features)), features['n_frames'])
-
-    def loss(self, features, output_features):
-        n_frames = features['n_frames']
-        self._accumulate_metrics(features, output_features)
-        loss = 0.
-        loss += losses.mse(output_features['normalised_lf0_deltas'], features['normalised_lf0_deltas'], n_frames)
-        loss += losses.mse(output_features['normalised_mcep_deltas'], features['normalised_mcep_deltas'], n_frames)
-        loss += losses.mse(output_features['normalised_bap_deltas'], features['normalised_bap_deltas'], n_frames)
-        loss += losses.bce(output_features['vuv'].type(torch.float), features['vuv'].type(torch.float), n_frames)
-        return loss / 4.
-
-    def forward(self, features):
-        """``predict`` + ``loss`` (base_models.py:279-285); with ``fused_loss`` the split, the sigmoid and the four masked
-        losses run as one pass over the prediction (``losses.multi_stream``), same numbers."""
-        if not self.fused_loss:
-            return super(LSTMAcousticModel, self).forward(features)
-        pred_norm_deltas = self._run_layers(features)
-        targets = [features['vuv'] if n == 'vuv' else features['normalised_%s_deltas' % n] for n in self.STREAMS]
-        kinds = ['sigmoid_bce' if n == 'vuv' else 'mse' for n in self.STREAMS]
-        loss, pred_vuv = losses.multi_stream(pred_norm_deltas, targets, kinds, features['n_frames'], want_prob=True)
-        outputs = self._with_trajectories(self._split(pred_norm_deltas.detach(), pred_vuv), features['n_frames'])
-        self._accumulate_metrics(features, outputs)
-        return loss, outputs
+        self.input_dim, self.output_dims, self.dropout_prob, self.num_layers = input_dim, output_dims, dropout_prob, num_layers
+        table = {'lf0': Stream('lf0', output_dims['lf0'], 'mse', ('LF0_RMSE_Hz', metrics.LF0Distortion, 'voiced_trajectory')),
+                 'vuv': Stream('vuv', output_dims['vuv'], 'sigmoid_bce', ('VUV_accuracy', metrics.Mean, 'accuracy')),
+                 'mcep': Stream('mcep', output_dims['mcep'], 'mse', ('MCEP_distortion', metrics.MelCepDistortion, 'trajectory')),
+                 'bap': Stream('bap', output_dims['bap'], 'mse', ('BAP_distortion', metrics.Distortion, 'trajectory'))}
+        layers = _lstm_stack(input_dim, hidden_dim, post_dim, sum(output_dims.values()), num_layers, dropout_prob, precision)
+        super(LSTMAcousticModel, self).__init__(layers, [table[name] for name in self.STREAMS], fused_upsample=fused_upsample,
+                                                fused_loss=fused_loss, generate=generate)
 
 
-class GRUF0Model(BaseSPSS):
-    """models/f0_test_model.py:21-107 against this package: same constructor arguments, the same layer container (state_dict
-    keys ``layers.0.weight``, ``layers.3.layer.weight_ih_l0`` ... load unchanged), ``predict`` / ``loss`` and the LF0 metric
-    (:47-48, :101-103).  MLPG (:86-89) runs on the device (``viz.synthesis.MLPG``, csrc/mlpg.hip); it and the metric are active
-    whenever the 'lf0' normaliser carries delta parameters, i.e. under ``ExperimentBuilder`` (``generate=False`` turns both off)."""
+class GRUF0Model(StreamModel):
+    """The reference's shipped F0 model (models/f0_test_model.py:21-107) as a one-row stream table: the lf0 delta stream with masked
+    MSE and the LF0 RMSE in Hz over the frames the DATA calls voiced (``features['vuv']``, :101-103).  Same constructor arguments and
+    state_dict keys (``layers.0.weight``, ``layers.3.layer.weight_ih_l0`` ...)."""
 
     def __init__(self, dropout_prob=0., input_dim=600 + 9, output_dim=1 * 3, precision=None, fused_upsample=True, generate=True):
-        super(GRUF0Model, self).__init__()
-        self.generate = generate
-        self.input_dim = input_dim
-        self.output_dim = output_dim
-        self.fused_upsample = fused_upsample
-        self.layers = utils.SequentialWithRecurrent(
-            nn.Linear(self.input_dim, 256),
-            nn.Sigmoid(),
-            nn.Dropout(p=dropout_prob),
-            utils.RecurrentCuDNNWrapper(nn.GRU(256, 64, batch_first=True), precision=precision),
-            nn.Dropout(p=dropout_prob),
-            utils.RecurrentCuDNNWrapper(nn.GRU(64, 64, batch_first=True), precision=precision),
-            nn.Dropout(p=dropout_prob),
-            utils.RecurrentCuDNNWrapper(nn.GRU(64, 64, batch_first=True), precision=precision),
-            nn.Dropout(p=dropout_prob),
-            nn.Linear(64, 64),
-            nn.Sigmoid(),
-            nn.Dropout(p=dropout_prob),
-            nn.Linear(64, self.output_dim),
-            precision=precision)
-        self.metrics.add_metrics('all', LF0_RMSE_Hz=metrics.LF0Distortion())         # models/f0_test_model.py:47-48
-
-    def normaliser_sources(self):
-        return {
-            'dur': data.MeanVarianceNormaliser('dur'),
-            'lab': data.MinMaxNormaliser('lab'),
-            'counters': data.MinMaxNormaliser('counters'),
-            'lf0': data.MeanVarianceNormaliser('lf0', use_deltas=True),
-        }
-
-    def predict(self, features):
-        norm_counters = features['normalised_counters']
-        norm_lab_at_frame_rate = utils.upsample_to_repetitions(features['normalised_lab'], features['dur'],
-                                                               max_len=norm_counters.shape[1], fused=self.fused_upsample)
-        model_inputs = utils.concat_frame_features(norm_lab_at_frame_rate, norm_counters)
-        n_frames = features['n_frames']
-        pred_norm_lf0_deltas, _ = self.layers(model_inputs, seq_len=n_frames, max_len=norm_counters.shape[1])
-        outputs = {'normalised_lf0_deltas': pred_norm_lf0_deltas}
-        if self.generate and _has_delta_params(self.normalisers, 'lf0'):
-            # MLPG to select the most probable trajectory given the delta and delta-delta features (:83-89)
-            pred_lf0_deltas = self.normalisers['lf0'].denormalise(pred_norm_lf0_deltas.detach(), deltas=True)
-            global_variance = self.normalisers['lf0'].delta_params_torch['std_dev'] ** 2
-            outputs['lf0'] = viz.synthesis.MLPG(pred_lf0_deltas, global_variance, padding_size=100, seq_len=n_frames)
-        return outputs
-
-    def loss(self, features, output_features):
-        seq_len = features['n_frames']
-        loss = losses.mse(output_features['normalised_lf0_deltas'], features['normalised_lf0_deltas'], seq_len)
-        if 'lf0' in output_features:
-            self.metrics.accumulate(self.mode,                                       # :101-103
-                                    LF0_RMSE_Hz=(features['lf0'], output_features['lf0'], features['vuv'], seq_len))
-        return loss
+        self.input_dim, self.output_dim = input_dim, output_dim
+        layers = _gru_f0_stack(input_dim, output_dim, dropout_prob, precision)
+        streams = [Stream('lf0', output_dim, 'mse', ('LF0_RMSE_Hz', metrics.LF0Distortion, 'voiced_trajectory'))]
+        super(GRUF0Model, self).__init__(layers, streams, fused_upsample=fused_upsample, fused_loss=False, generate=generate)

@@ -249,7 +249,7 @@ def test_bf16_loader_table_and_launches_of_the_product_step():
     the six-entry phone-rate step that bench.py times (entry-point calls counted through ``_lib.CALL_LOG``)."""
     from morgana_amd import _lib, ops
     rng = np.random.RandomState(11)
-    lab_dim, n_utt, n_ph, per_batch_utts = 600, 128, 40, 64          # 64 x 40 = 2,560 phone rows per batch: the phone-rate step engages
+    lab_dim, n_utt, n_ph, per_batch_utts = 600, 192, 40, 96          # 96 x 40 + 1,024 = 4,864 table rows: the slab-taking phone-rate step
     norms = {'lab': data.MinMaxNormaliser('lab').set_params({'mmin': (rng.rand(lab_dim) * 0.1).astype(np.float32),
                                                              'mmax': (1.0 + rng.rand(lab_dim)).astype(np.float32)}, device='cuda:0'),
              'lf0': data.MeanVarianceNormaliser('lf0').set_params({'mean': np.array([5.0], np.float32),
@@ -289,7 +289,11 @@ def test_bf16_loader_table_and_launches_of_the_product_step():
     step_calls = [c for c in log if c not in loader_calls]
     assert not any('cast' in c for c in step_calls), step_calls
     assert log.count('mg_pad_normalise_bf16_f32') == len(loader), log
-    per_batch = len(step_calls) / float(len(loader))
-    # front + layer-1 GEMM, l2tail (+ expansion / reduce), layer-2 wgrad + dgrad, layer-1 wgrad, update; the epoch's metric and status reads
-    assert per_batch <= 8.0, (per_batch, step_calls)
-    assert sum(c.startswith('mg_phone_front') for c in step_calls) == len(loader), step_calls
+    # per batch: front + layer-1 GEMM | layers 2-4 + loss + their backward | prediction expansion + tail reduce | layer-2 wgrad + dgrad |
+    # layer-1 wgrad | Adam's scalars | update - bench.py's graph replay stages the scalars once per ten steps, hence its "six"
+    want = ['mg_phone_front_linear_fwd_bf16', 'mg_f0_l2tail_rows_slabs_bf16', 'mg_expand_column_reduce_f32', 'mg_linear_wgrad_dgrad_bf16',
+            'mg_linear_wgrad_slabs_bf16', 'mg_store_pair_f32', 'mg_adam_step_plan_f32']
+    n = len(loader)
+    per_epoch = [c for c in step_calls if c not in want]
+    assert sorted(c for c in step_calls if c in want) == sorted(want * n), step_calls
+    assert len(per_epoch) <= 3, per_epoch                    # the epoch's reads of the loss metric / the persistent-kernel status
