@@ -49,7 +49,8 @@ const char* mg_last_error(void);
  * not in this library at all: they are compiled into the lab builds (make -C morgana_amd/csrc lab / diag) only. */
 #define MG_TUNING_KEYS 8
 #define MG_TUNE_FORM 0          /* large bf16 GEMM kernels: 0 = default; 3 = 32-deep instead of 64-deep stages of the 128-wide NT tile;
-                                 * 6 = per-tile instead of persistent NT kernel; 14 = frame-staged instead of run-staged layer-1 forward;
+                                 * 6 = per-tile instead of persistent NT kernel; 14 = frame-staged instead of run-staged layer-1 forward,
+                                 * 16 = its fragments read one k-step ahead;
                                  * fused backward: 12 = tiles two steps ahead (larger ring), 13 = 32-frame steps, 7 = single-buffered */
 #define MG_TUNE_GRU_HANDOFF 2   /* persistent GRU / LSTM kernels: 0 = groups found on one XCD hand the state over through that XCD's L2,
                                  * 1 = always write-through (sc1) stores, the placement-independent form */

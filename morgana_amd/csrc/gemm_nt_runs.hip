@@ -18,6 +18,8 @@
 //   * the accumulator tile is C^T (weights as the MFMA A operand), epilogue through a wave-private LDS patch to 16-byte stores.
 #include "common.h"
 
+#include <type_traits>
+
 typedef __bf16 bfv8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bfv2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
@@ -57,7 +59,11 @@ __device__ __forceinline__ void nr_glds16(const uint16_t* src, unsigned char* ld
 #define NR_BIAS (NR_PATCH + 4 * 4096)
 #define NR_LDS (NR_BIAS + NR_BN * 4)                    // 77,376 B: two workgroups per CU
 
-template <int EPI>
+// PF (prefetch): the fragments of k-step s + 1 are read while k-step s multiplies - the four weight fragments into a second register
+// set at the head of the step, each frame fragment into its own registers right behind the four MFMAs that used it last - so the
+// MFMAs of a step never wait for its LDS reads (they did at the head of every step: 12 reads, then 32 MFMAs).  The step's wait then
+// covers the NEXT stage as well (one stage in flight instead of two); the first step of a tile reads as before.
+template <int EPI, bool PF = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_runs_kernel(const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
                                                               int64_t M, int K, const uint16_t* __restrict__ Bm, int ldb, int N,
                                                               const float* __restrict__ bias, uint16_t* __restrict__ C, int ldc,
@@ -203,12 +209,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_runs_kernel(const uint16_t* __
 #pragma unroll
     for (int p = 0; p < NS - 1; ++p) issue_next();
 
-    bfv8 fa[TMB], fb[TNB];
+    bfv8 fa[TMB], fb[2][TNB];
     auto read_frags = [&](const unsigned char* st) {
 #pragma unroll
         for (int i = 0; i < TMB; ++i) fa[i] = *reinterpret_cast<const bfv8*>(st + aoff[i]);
 #pragma unroll
-        for (int j = 0; j < TNB; ++j) fb[j] = *reinterpret_cast<const bfv8*>(st + boff[j]);
+        for (int j = 0; j < TNB; ++j) fb[0][j] = *reinterpret_cast<const bfv8*>(st + boff[j]);
         __builtin_amdgcn_sched_group_barrier(0x100, TMB + TNB, 0);
     };
 
@@ -227,11 +233,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_runs_kernel(const uint16_t* __
         const int np = n_pass(ti);
         for (int p = 0; p < np; ++p) {
             set_frag_rows(ti, p);
-            for (int kt = 0; kt < n_kt; ++kt, ++g) {
-                // stage g must have landed; issued so far: min(g_total, g + NS - 1) stages, so min(g_total - 1 - g, NS - 2) younger
-                // ones may stay in flight, and the previous tile's NST stores while they are younger than stage g's DMA (first NS - 1
-                // k-steps of a tile).  The wait also retires this wave's LDS reads: the slot read in the previous step is refilled below.
-                const int allow = min(g_total - 1 - g, NS - 2) * NL + ((ti > 0 && p == 0 && kt < NS - 1) ? NST : 0);
+            // one k-step; CUR (compile time) = which weight-fragment set holds this step's operands when PF is on
+            auto kstep = [&](int kt, auto curc) {
+                constexpr int CUR = decltype(curc)::value;
+                // Stage g must have landed - and with PF stage g + 1 too, whose fragments this step reads ahead.  Issued so far:
+                // min(g_total, g + NS - 1) stages; the previous tile's NST stores sit in the queue behind the stages issued before them.
+                const int ahead = PF ? 1 : 0;
+                const int young = max(min(g_total - 1 - ahead - g, NS - 2 - ahead), 0);
+                const int allow = young * NL + ((ti > 0 && p == 0 && kt < NS - 1 - ahead) ? NST : 0);
                 __builtin_amdgcn_sched_barrier(0);
                 switch (allow) {
                     NR_WAIT_CASE(3) NR_WAIT_CASE(6) NR_WAIT_CASE(16) NR_WAIT_CASE(19) NR_WAIT_CASE(22)
@@ -240,13 +249,41 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_runs_kernel(const uint16_t* __
                 __builtin_amdgcn_sched_barrier(0);
                 const unsigned char* st = smem + c_s * NR_STAGE;
                 issue_next();                          // refills the slot every wave finished with before this barrier
-                read_frags(st);
-#pragma unroll
-                for (int i = 0; i < TMB; ++i)
-#pragma unroll
-                    for (int j = 0; j < TNB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, TMB * TNB, 0);
                 c_s = (c_s + 1 == NS) ? 0 : c_s + 1;
+                if (!PF) {
+                    read_frags(st);
+#pragma unroll
+                    for (int i = 0; i < TMB; ++i)
+#pragma unroll
+                        for (int j = 0; j < TNB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0][j], fa[i], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, TMB * TNB, 0);
+                } else {
+                    if (kt == 0) {                     // first step of a tile / pass: nothing was read ahead
+#pragma unroll
+                        for (int i = 0; i < TMB; ++i) fa[i] = *reinterpret_cast<const bfv8*>(st + aoff[i]);
+#pragma unroll
+                        for (int j = 0; j < TNB; ++j) fb[CUR][j] = *reinterpret_cast<const bfv8*>(st + boff[j]);
+                    }
+                    const bool more = kt + 1 < n_kt;   // wave-uniform: the next stage belongs to this tile and pass
+                    const unsigned char* nx = smem + c_s * NR_STAGE;
+                    if (more) {
+#pragma unroll
+                        for (int j = 0; j < TNB; ++j) fb[CUR ^ 1][j] = *reinterpret_cast<const bfv8*>(nx + boff[j]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < TMB; ++i) {
+#pragma unroll
+                        for (int j = 0; j < TNB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[CUR][j], fa[i], acc[i][j], 0, 0, 0);
+                        if (more) fa[i] = *reinterpret_cast<const bfv8*>(nx + aoff[i]);
+                        __builtin_amdgcn_sched_group_barrier(0x008, TNB, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
+                ++g;
+            };
+            for (int kt = 0; kt < n_kt; kt += 2) {
+                kstep(kt, std::integral_constant<int, 0>{});
+                if (kt + 1 < n_kt) kstep(kt + 1, std::integral_constant<int, 1>{});
             }
         }
 
@@ -303,8 +340,15 @@ int mg_try_nt_runs(const uint16_t* A, int lda, const int32_t* rows, int64_t M, i
     if (g > blocks) g = blocks;
     if (g >= 2147483647LL) return 0;
     dim3 grid((unsigned)g), block(256);
-    if (sigmoid)
+    const bool pf = g_mg_tuning[MG_TUNE_FORM] == 16;   // A/B: fragments read one k-step ahead
+    if (sigmoid && pf)
+        hipLaunchKernelGGL((gemm_nt_runs_kernel<NR_EPI_BIAS_SIGMOID, true>), grid, block, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, C, ldc,
+                           (int)tiles_m, tiles_n);
+    else if (sigmoid)
         hipLaunchKernelGGL((gemm_nt_runs_kernel<NR_EPI_BIAS_SIGMOID>), grid, block, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, C, ldc, (int)tiles_m,
+                           tiles_n);
+    else if (pf)
+        hipLaunchKernelGGL((gemm_nt_runs_kernel<NR_EPI_BIAS, true>), grid, block, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, C, ldc, (int)tiles_m,
                            tiles_n);
     else
         hipLaunchKernelGGL((gemm_nt_runs_kernel<NR_EPI_BIAS>), grid, block, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, C, ldc, (int)tiles_m, tiles_n);

@@ -416,6 +416,16 @@ def test_linear_fwd_run_staged_equals_frame_staged(m, n, act, rows_kind):
     want = ops.linear_fwd_bf16(table, rows, m, k, w_bf, bias, n, act)
     got = ops.linear_fwd_bf16(table, rows, m, k, w_bf, bias, n, act, rows_runs=True)
     assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    # the two schedules of the run-staged kernel (MG_TUNE_FORM 0 / 16: fragments read one k-step ahead or at the head of their own step)
+    from morgana_amd import _lib
+    lib = _lib.load()
+    other = 16 if lib.mg_set_tuning(0, 16) == 0 else None
+    try:
+        if other is not None:
+            alt = ops.linear_fwd_bf16(table, rows, m, k, w_bf, bias, n, act, rows_runs=True)
+            assert torch.equal(alt.view(torch.int16), want.view(torch.int16))
+    finally:
+        lib.mg_set_tuning(0, 0)
 
 
 @pytest.fixture
