@@ -248,17 +248,20 @@ def roofline_f0(features, model, precision):
     short = dom['kernel'].split(':')[0]
     # HBM bytes per launch of the dominant kernel from the committed PMC passes of this round (scripts/gpu_profile.sh:
     # 2 x FETCH_SIZE + WRITE_SIZE on gfx950, MI355X_MICROARCH.md), and the bytes the launch has to move at the very least
-    traffic = None
-    for table_name in (('r2_hbm_traffic.json', 'r1_hbm_traffic.json') if ops.PHONE_RATE else ('r2fr_hbm_traffic.json',)):
+    traffic = traffic_source = None
+    for table_name in (('r3_hbm_traffic.json', 'r2_hbm_traffic.json') if ops.PHONE_RATE else ('r3fr_hbm_traffic.json', 'r2fr_hbm_traffic.json')):
         try:
             table = json.load(open(os.path.join(REPO, 'profiles', table_name)))
             if table.get(short) is not None:
                 traffic = table.get(short)
+                traffic_source = ('profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the committed kernels '
+                                  '(2 x FETCH_SIZE + WRITE_SIZE per launch), not re-measured in this run' % table_name)
                 break
         except (OSError, ValueError):
             pass
     algorithmic_bytes = algo_bytes.get(short)
-    out = {'kernel': dom['kernel'], 'ms_per_launch': dom['ms'], 'traffic': traffic, 'algorithmic_bytes': algorithmic_bytes}
+    out = {'kernel': dom['kernel'], 'ms_per_launch': dom['ms'], 'traffic': traffic, 'traffic_source': traffic_source,
+           'algorithmic_bytes': algorithmic_bytes}
     # which roof bounds the launch is read off the counters: a kernel that moves more than 0.6 of the 8 TB/s spec is memory bound
     # whatever its FLOPs are (the first round labelled such a kernel "mfma")
     moved = traffic if traffic is not None else algorithmic_bytes
