@@ -351,6 +351,16 @@ int mg_linear_bwd_fused_bf16(const uint16_t* dZ2, int lddz, int N2, const uint16
 int mg_linear_bwd_fused_slabs_bf16(const uint16_t* dZ2, int lddz, int N2, const uint16_t* W2T, int ldwt, const uint16_t* H1, int ldh,
                                    const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K, void* workspace,
                                    size_t workspace_bytes, int* n_slabs, int64_t* stride, void* stream);
+/* The fused backward WITH the second layer's weight gradient: one launch leaves the split-M slabs of dW1 | db1 (as
+ * mg_linear_bwd_fused_slabs_bf16) AND of dW2 = dZ2^T H1 | db2 = column sums of dZ2 - the stand-alone weight-gradient launch of the
+ * N -> 128 layer, which re-read H1 and dZ2 from HBM, goes (reference: autograd of README.rst:65-73, the mm + sum of layer 2's
+ * backward).  Needs the row map (rows != NULL).  workspace (floats): [*n_slabs x *stride1] first-layer slabs as above, then from
+ * float *offset2 on [*n_slabs x *stride2] second-layer slabs, each [128 x N weight partials | 128 bias partials]; the caller sums
+ * them in order (mg_slab_reduce_f32 or the update kernel's plan). */
+size_t mg_linear_bwd_fused2_workspace_bytes(int64_t M, int N, int K);
+int mg_linear_bwd_fused2_slabs_bf16(const uint16_t* dZ2, int lddz, int N2, const uint16_t* W2T, int ldwt, const uint16_t* H1, int ldh,
+                                    const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K, void* workspace,
+                                    size_t workspace_bytes, int* n_slabs, int64_t* stride1, int64_t* offset2, int64_t* stride2, void* stream);
 
 /* dst[r, 0:cols] = bf16(src[r, 0:cols]), dst[r, cols:ldd] = 0.  src f32 [rows, cols] (lds). */
 int mg_cast_pad_bf16(const float* src, int lds, uint16_t* dst, int ldd, int64_t rows, int cols, void* stream);

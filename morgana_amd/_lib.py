@@ -79,6 +79,10 @@ SIGNATURES = {
                                 c_void_p]),
     'mg_linear_bwd_fused_slabs_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                                c_int64, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    'mg_linear_bwd_fused2_workspace_bytes': (c_size_t, [c_int64, c_int, c_int]),
+    'mg_linear_bwd_fused2_slabs_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                                c_int64, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                c_void_p]),
     'mg_f0_l2tail_rows_slabs_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_int, c_void_p,
                                              c_size_t, c_void_p, c_void_p]),

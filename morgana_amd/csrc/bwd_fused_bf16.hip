@@ -1167,6 +1167,10 @@ void mg_launch_fused64(int nbt, const uint16_t* dZ2, int lddz, const uint16_t* W
                        int lda, const int32_t* rows, int64_t M, int N, int K, int m_chunk, int n_splits, float* slab, float* bslab,
                        int64_t sstride, hipStream_t st);
 
+void mg_launch_fused3(const uint16_t* dZ2, int lddz, const uint16_t* W2T, int ldwt, const uint16_t* H1, int ldh, const uint16_t* A, int lda,
+                      const int32_t* rows, int64_t M, int N, int K, int m_chunk, int n_splits, float* slab, float* bslab, int64_t sstride,
+                      float* slab2, int64_t sstride2, hipStream_t st);
+
 static void fused_plan(int64_t M, int N, int* S, int* m_chunk) {
     const int tiles_n = N / F_BNT;
     int64_t s = mg_ceil_div(256, tiles_n);
@@ -1235,6 +1239,43 @@ static int fused_launch(const char* name, const uint16_t* dZ2, int lddz, int N2,
     MG_CHECK_LAUNCH(name);
     *S_out = S;
     *sstride_out = sstride;
+    return MG_OK;
+}
+
+size_t mg_linear_bwd_fused2_workspace_bytes(int64_t M, int N, int K) {
+    if (M <= 0 || N <= 0 || N % F_BNT != 0) return 256;
+    int S, chunk;
+    fused_plan(M, N, &S, &chunk);
+    return mg_align_up((size_t)S * (((size_t)N * K + N) + ((size_t)F_N2 * N + F_N2)) * sizeof(float), 256);
+}
+
+int mg_linear_bwd_fused2_slabs_bf16(const uint16_t* dZ2, int lddz, int N2, const uint16_t* W2T, int ldwt, const uint16_t* H1, int ldh,
+                                    const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K, void* workspace,
+                                    size_t workspace_bytes, int* n_slabs, int64_t* stride1, int64_t* offset2, int64_t* stride2, void* stream) {
+    const char* name = "mg_linear_bwd_fused2_slabs_bf16";
+    MG_CHECK_ARG(n_slabs && stride1 && offset2 && stride2, "%s: null output argument", name);
+    MG_CHECK_ARG(dZ2 && W2T && H1 && A && rows && M > 0, "%s: null argument (the row map is required) or empty batch", name);
+    MG_CHECK_ARG(N2 == F_N2 && lddz >= F_N2 && ldwt >= F_N2 && lddz % 8 == 0 && ldwt % 8 == 0,
+                 "%s: the second layer must have %d outputs (N2=%d lddz=%d ldwt=%d)", name, F_N2, N2, lddz, ldwt);
+    MG_CHECK_ARG(N % F_BNT == 0 && ldh >= N && ldh % 8 == 0, "%s: hidden width %d must be a multiple of %d (ldh=%d)", name, N, F_BNT, ldh);
+    MG_CHECK_ARG(lda == F_BKT && K > 512 && K <= F_BKT - 32, "%s: needs 512 < K <= 608 with lda = 640 (K=%d lda=%d)", name, K, lda);
+    MG_CHECK_ARG((((uintptr_t)dZ2 | (uintptr_t)W2T | (uintptr_t)H1 | (uintptr_t)A) % 16) == 0, "%s: buffers must be 16-byte aligned", name);
+    if (!workspace || workspace_bytes < mg_linear_bwd_fused2_workspace_bytes(M, N, K)) {
+        mg_set_error("%s: workspace of %zu bytes needed, got %zu", name, mg_linear_bwd_fused2_workspace_bytes(M, N, K), workspace_bytes);
+        return MG_EWORKSPACE;
+    }
+    int S, chunk;
+    fused_plan(M, N, &S, &chunk);
+    // [S x (N*K weight partials | N bias partials)] then [S x (128*N second-layer weight partials | 128 bias partials)]
+    const int64_t nk = (int64_t)N * K, s1 = nk + N, s2 = (int64_t)F_N2 * N + F_N2;
+    float* slab = (float*)workspace;
+    float* slab2 = slab + (int64_t)S * s1;
+    mg_launch_fused3(dZ2, lddz, W2T, ldwt, H1, ldh, A, lda, rows, M, N, K, chunk, S, slab, slab + nk, s1, slab2, s2, (hipStream_t)stream);
+    MG_CHECK_LAUNCH(name);
+    *n_slabs = S;
+    *stride1 = s1;
+    *offset2 = (int64_t)S * s1;
+    *stride2 = s2;
     return MG_OK;
 }
 

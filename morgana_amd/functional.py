@@ -500,6 +500,29 @@ class LinearStackMSEFn(torch.autograd.Function):
             top = lead - 1                                            # the 128-wide layer: its dZ came out of the fused tail
             n, k = ctx.dims[top]
             g_below = None
+            # Frame rate, Linear + Sigmoid -> Linear(. -> 128) at the bottom of the stack: the second layer's weight gradient rides in
+            # the fused backward of the first (ops.linear_bwd_fused2_slabs_bf16: the kernel stages dZ2 and H1 anyway), and the
+            # stand-alone launch that re-read H1 from HBM goes.  Not beside an early gradient exchange: that one promises the second
+            # layer's gradient final BEFORE the fused kernel starts.
+            fuse2 = (not ctx.phone_rate and top == 1 and rows is not None and ctx.acts[0] == ops.ACT_SIGMOID and _EARLY_GRADS_HOOK is None and
+                     os.environ.get('MORGANA_FUSE_WGRAD2', '1') != '0' and ops.can_fuse_bwd(m, n, k, ctx.dims[0][1], a0.shape[1]) and
+                     (mode == 'defer' or (_grads_adjacent(params[0], params[1]) and _grads_adjacent(params[2], params[3]))))
+            if fuse2:
+                n0_, k0_ = ctx.dims[0]
+                slab, n_slabs, (off1, st1, cnt1), (off2, st2, cnt2) = ops.linear_bwd_fused2_slabs_bf16(
+                    g, w_t[1], hidden[0], a0, rows, m, n0_, k0_, slab=getattr(params[0], '_mg_fused_slab_buf', None))
+                params[0]._mg_fused_slab_buf = slab
+                floats = slab.view(torch.float32)
+                for first, off, st, cnt in ((params[0], off1, st1, cnt1), (params[2], off2, st2, cnt2)):
+                    if mode == 'defer':                               # the update kernel sums the slabs
+                        opt.defer_slabs(first, cnt, floats[off:], n_slabs, st)
+                    else:
+                        ops.slab_reduce(floats[off:], n_slabs, st, cnt, first.grad.reshape(-1).as_strided((cnt,), (1,)), accumulate=True)
+                if mode == 'defer':
+                    opt.defer_slabs(params[2 * lead], tail_count, flat[tail_off:tail_off + tail_count], 1, tail_count)
+                else:
+                    params[2 * lead].grad.reshape(-1).as_strided((tail_count,), (1,)).add_(flat[tail_off:tail_off + tail_count])
+                return (None, None, None, None, None) + (None,) * len(params)
             if (ctx.phone_rate and top > 0 and ctx.acts[top - 1] == ops.ACT_SIGMOID and
                     ops.wgrad_slabs_ok(m_rows, n, k, hidden[top - 1].shape[1], g.shape[1]) and
                     (mode == 'defer' or _grads_adjacent(params[2 * top], params[2 * top + 1]))):

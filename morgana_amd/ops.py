@@ -501,6 +501,24 @@ def linear_bwd_fused_slabs_bf16(dz2, wt2, h1, a, rows, m, n_hidden, k0, slab=Non
     return slab, n_slabs.value, stride.value
 
 
+def linear_bwd_fused2_slabs_bf16(dz2, wt2, h1, a, rows, m, n_hidden, k0, slab=None):
+    """The fused backward with the second layer's weight gradient riding along (mg_linear_bwd_fused2_slabs_bf16): ONE launch leaves the
+    split-M slabs of (dW1 | db1) and of (dW2 | db2) of a Linear(k0 -> n_hidden) + Sigmoid -> Linear(n_hidden -> 128) pair whose input
+    is gathered through ``rows``.  Returns (slab buffer, n_slabs, (float offset, stride, count) of the first layer's slabs, the same
+    for the second layer's): slab i of a layer starts at float offset + i * stride and holds ``count`` partial sums."""
+    lib = _lib.load()
+    if rows is None:
+        raise ValueError('linear_bwd_fused2_slabs_bf16 needs the row map of the gathered input')
+    nbytes = lib.mg_linear_bwd_fused2_workspace_bytes(m, n_hidden, k0)
+    slab = _slab_buffer(slab, nbytes, dz2.device)
+    n_slabs, stride1, off2, stride2 = ctypes.c_int(0), ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.check(lib.mg_linear_bwd_fused2_slabs_bf16(_p(dz2), dz2.shape[1], 128, _p(wt2), wt2.shape[1], _p(h1), h1.shape[1], _p(a), a.shape[1],
+                                                   _p(rows), m, n_hidden, k0, _p(slab), slab.numel(), ctypes.byref(n_slabs),
+                                                   ctypes.byref(stride1), ctypes.byref(off2), ctypes.byref(stride2), _stream()),
+               'mg_linear_bwd_fused2_slabs_bf16')
+    return (slab, n_slabs.value, (0, stride1.value, n_hidden * k0 + n_hidden), (off2.value, stride2.value, 128 * n_hidden + 128))
+
+
 def cast_params_bf16(weights, want_plain=True, want_t=()):
     """One launch: bf16 copies [N, pad_ld(K)] of every fp32 weight and, for the indices in `want_t`, the transposed
     copies [K, pad_ld(N)].  Returns (plain list, transposed list with None where not requested)."""

@@ -36,6 +36,11 @@ def main():
     h1 = ops.linear_fwd_bf16(tab, rows, m, k, w1b, b1, 512, ops.ACT_SIGMOID)
     dz1 = (torch.randn(m, 512, device=dev) * 0.01).to(torch.bfloat16)
     dz2 = (torch.randn(m, 128, device=dev) * 0.01).to(torch.bfloat16)
+    bufs = {}
+
+    def keep(key, result):
+        bufs[key] = result[0]
+
     cases = {
         'fwd1': (2.0 * m * 600 * 512, lambda: ops.linear_fwd_bf16(tab, rows, m, k, w1b, b1, 512, ops.ACT_SIGMOID)),
         'fwd1r': (2.0 * m * 600 * 512, lambda: ops.linear_fwd_bf16(tab, rows, m, k, w1b, b1, 512, ops.ACT_SIGMOID, rows_runs=True)),
@@ -44,6 +49,11 @@ def main():
         'wgrad1': (2.0 * m * 600 * 512, lambda: ops.linear_wgrad_bf16(dz1, tab, rows, m, 512, 600)),
         'wgrad2': (2.0 * m * 512 * 128, lambda: ops.linear_wgrad_bf16(dz2, h1, None, m, 128, 512)),
         'fused': (2.0 * m * 600 * 512 + 2.0 * m * 512 * 128, lambda: ops.linear_bwd_fused_bf16(dz2, w2t, h1, tab, rows, m, 512, 600)),
+        # the kernels alone (their slabs left for the update kernel, as the training step does): fused backward, layer-2 weight gradient,
+        # and the fused backward that carries the layer-2 weight gradient (one launch for both)
+        'fuseds': (2.0 * m * 600 * 512 + 2.0 * m * 512 * 128, lambda: keep('f', ops.linear_bwd_fused_slabs_bf16(dz2, w2t, h1, tab, rows, m, 512, 600, slab=bufs.get('f')))),
+        'wgrad2s': (2.0 * m * 512 * 128, lambda: keep('w', ops.linear_wgrad_slabs_bf16(dz2, h1, None, m, 128, 512, slab=bufs.get('w')))),
+        'fused2': (2.0 * m * 600 * 512 + 4.0 * m * 512 * 128, lambda: keep('f2', ops.linear_bwd_fused2_slabs_bf16(dz2, w2t, h1, tab, rows, m, 512, 600, slab=bufs.get('f2')))),
     }
     from morgana_amd import _lib
     lib = _lib.load()

@@ -94,6 +94,13 @@ def main():
         report(title + ' (dgrad2 + wgrad1, gathered input, 64-frame steps)', s,
                [('  loop: wait + barrier', s[..., 6]), ('  loop: run scan of the next step', s[..., 10]), ('  loop: fetch (DMA issue)', s[..., 7]),
                 ('  loop: P1', s[..., 8]), ('  loop: P2', s[..., 9])])
+    for _ in range(3):
+        ops.linear_bwd_fused2_slabs_bf16(dz2, w2t, h1, tab, rows, m, 512, 600)
+    torch.cuda.synchronize()
+    s = read(lib, 'mg_diag_read_stamps_f3', 256)
+    report('wgrad_fused3 (dgrad2 + wgrad1 + wgrad2, 64-frame steps, W2^T in LDS, two tile buffers)', s,
+           [('  loop: wait + barrier', s[..., 6]), ('  loop: run scan of the next step', s[..., 10]), ('  loop: fetch (DMA issue)', s[..., 7]),
+            ('  loop: P1 + P3', s[..., 8]), ('  loop: P2', s[..., 9])])
     lib.mg_set_tuning(0, 15)
     for _ in range(3):
         ops.linear_bwd_fused_bf16(dz2, w2t, h1, tab, rows, m, 512, 600)

@@ -643,6 +643,47 @@ def test_fused_backward_64_frame_steps_equal_32_frame_kernel(nbt_knob):
                     assert rel_err(g.cpu().numpy(), w.cpu().numpy()) < 1e-5, (m, kind)
 
 
+@pytest.mark.parametrize('m', [40037, 8192, 4100])
+def test_fused_backward_with_second_layer_wgrad(m):
+    """mg_linear_bwd_fused2_slabs_bf16 (wgrad_fused3_kernel: the 64-frame fused backward with dW2 = dZ2^T H1 and db2 riding on the
+    tiles it stages anyway - the stand-alone layer-2 weight-gradient launch and its pass over H1 go): the first layer's slabs sum to
+    EXACTLY what mg_linear_bwd_fused_bf16 gives (same products in the same order; the tiles merely lie in the dual-use image), the
+    second layer's to what the stand-alone kernel (mg_linear_wgrad_bf16) and a float64 restatement give (frames summed in other
+    chunks: 1e-5).  Phone-like runs with pad frames, short runs (ring passes), no runs; M not a multiple of the 64-frame step (the
+    zeroed tail of the dZ2 tile)."""
+    rng = np.random.RandomState(m)
+    k0, n1 = 600, 512
+    table = ops.cast_pad_bf16(dev(rng.uniform(0, 1, (m // 9, k0)).astype(np.float32)))
+    (_,), (w2t,) = ops.cast_params_bf16([dev(rng.uniform(-0.1, 0.1, (128, n1)).astype(np.float32))], want_plain=True, want_t=(0,))
+    h1_np = _bf16_round(rng.uniform(0.05, 0.95, (m, n1)).astype(np.float32))
+    dz2_np = _bf16_round((rng.standard_normal((m, 128)) * 0.01).astype(np.float32))
+    h1, dz2 = ops.cast_pad_bf16(dev(h1_np)), ops.cast_pad_bf16(dev(dz2_np))
+    want_w2 = dz2_np.astype(np.float64).T @ h1_np.astype(np.float64)
+    want_b2 = dz2_np.astype(np.float64).sum(axis=0)
+    alone_w2, alone_b2 = ops.linear_wgrad_bf16(dz2, h1, None, m, 128, n1)
+    for kind in ('runs', 'short', 'random'):
+        if kind == 'runs':
+            rows = np.repeat(rng.randint(-1, table.shape[0], size=m), rng.randint(1, 40, size=m))[:m]
+        elif kind == 'short':
+            rows = np.repeat(rng.randint(-1, table.shape[0], size=m), rng.randint(1, 5, size=m))[:m]
+        else:
+            rows = rng.randint(-1, table.shape[0], size=m)
+        rows = dev(rows.astype(np.int32))
+        want_w1, want_b1 = ops.linear_bwd_fused_bf16(dz2, w2t, h1, table, rows, m, n1, k0)
+        slab, n_slabs, (off1, st1, cnt1), (off2, st2, cnt2) = ops.linear_bwd_fused2_slabs_bf16(dz2, w2t, h1, table, rows, m, n1, k0)
+        floats = slab.view(torch.float32)
+        got1 = ops.slab_reduce(floats[off1:], n_slabs, st1, cnt1, torch.empty(cnt1, device=DEV))
+        got2 = ops.slab_reduce(floats[off2:], n_slabs, st2, cnt2, torch.empty(cnt2, device=DEV))
+        if kind == 'runs':
+            assert torch.equal(got1[:n1 * k0].view(n1, k0), want_w1) and torch.equal(got1[n1 * k0:], want_b1), kind
+        else:
+            assert rel_err(got1[:n1 * k0].cpu().numpy(), want_w1.cpu().numpy().reshape(-1)) < 1e-5, kind
+            assert rel_err(got1[n1 * k0:].cpu().numpy(), want_b1.cpu().numpy()) < 1e-5, kind
+        w2, b2 = got2[:128 * n1].view(128, n1).cpu().numpy(), got2[128 * n1:].cpu().numpy()
+        assert rel_err(w2, want_w2) < 1e-5 and rel_err(b2, want_b2) < 1e-5, kind
+        assert rel_err(w2, alone_w2.cpu().numpy()) < 1e-5 and rel_err(b2, alone_b2.cpu().numpy()) < 1e-5, kind
+
+
 @pytest.mark.parametrize('rows_kind', ['random', 'runs', 'identity'])
 @pytest.mark.parametrize('m,n_hidden', [(4999, 512), (9000, 256)])
 def test_fused_backward_kernel_vs_numpy(m, n_hidden, rows_kind):
