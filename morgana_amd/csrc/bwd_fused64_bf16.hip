@@ -1016,25 +1016,29 @@ __global__ __launch_bounds__(512) void wgrad_fused3_kernel(const uint16_t* __res
             issue_x(read_rows(step), mk_cur, 0, 0, min(g_cur, NG), step);
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
-        // the next step: its run structure, whether its first groups fit in the ring beside this step's
-        const StepMasks mk_nxt = scan_mask(read_rows(step + 1));      // past the last step: all pad frames, unused
-        const int g_nxt = groups_of(mk_nxt);
-        const bool pref = more && g_cur <= NG && g_cur + min(g_nxt, NG) <= NG;
-        int rp_nxt = rp_cur + g_cur;
-        rp_nxt -= (rp_nxt >= NG) ? NG : 0;
-        const int tb_new = tb_next == 0 ? NBT - 1 : tb_next - 1;        // (step + NBT) % NBT == step % NBT
-        // Fetches of this iteration: the row indices of step + 2 (wave 0), the staged rows of step + 1, the tiles of step + NBT.  The
-        // lower half of the waves issues them now, the upper half after its matrix work: issued by all waves at once behind the
-        // barrier they serialise in the texture-address path while every matrix pipe waits.
-        auto fetch = [&]() {
-            if (wave == 0) issue_rows(step + 2);
-            if (pref) issue_x(read_rows(step + 1), mk_nxt, rp_nxt, 0, min(g_nxt, NG), step);
-            issue_small(step + NBT, tb_new);
+        // The next step's run structure (whether its first groups fit in the ring beside this step's) comes from its row indices in
+        // LDS: the read goes out now, the scan - a cross-lane shift, two ballots: all latency - runs once the wave has done something
+        // else (waves 0-3: the tile pieces, which need nothing of it; waves 4-7: P2), so the round trip is not paid at the head.
+        const int rv = read_rows(step + 1);               // past the last step: all pad frames, unused
+        StepMasks mk_nxt = {0u, 0u, 0u, 0u};
+        int g_nxt = 0, rp_nxt = 0;
+        bool pref = false;
+        auto scan_next = [&]() {
+            mk_nxt = scan_mask(rv);
+            g_nxt = groups_of(mk_nxt);
+            pref = more && g_cur <= NG && g_cur + min(g_nxt, NG) <= NG;
+            rp_nxt = rp_cur + g_cur;
+            rp_nxt -= (rp_nxt >= NG) ? NG : 0;
         };
+        const int tb_new = tb_next == 0 ? NBT - 1 : tb_next - 1;        // (step + NBT) % NBT == step % NBT
         MG_STAMP(ta);
         MG_STAMP_ADD(sum_scan, ta, tb);
         if (wave < 4) {
-            fetch();
+            // fetches of this iteration: the row indices of step + 2 (wave 0), the tiles of step + 2, the staged rows of step + 1
+            if (wave == 0) issue_rows(step + 2);
+            issue_small(step + NBT, tb_new);
+            scan_next();
+            if (pref) issue_x(rv, mk_nxt, rp_nxt, 0, min(g_nxt, NG), step);
             MG_STAMP(tb);
             MG_STAMP_ADD(sum_fetch, tb, ta);
             if (more) {
@@ -1064,7 +1068,7 @@ __global__ __launch_bounds__(512) void wgrad_fused3_kernel(const uint16_t* __res
             }
             MG_STAMP(ta);
             MG_STAMP_ADD(sum_p1, ta, tb);
-            fetch();
+            scan_next();
             MG_STAMP(tb);
             MG_STAMP_ADD(sum_fetch, tb, ta);
         }
