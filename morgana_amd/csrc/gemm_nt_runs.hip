@@ -63,7 +63,9 @@ __device__ __forceinline__ void nr_glds16(const uint16_t* src, unsigned char* ld
 // set at the head of the step, each frame fragment into its own registers right behind the four MFMAs that used it last - so the
 // MFMAs of a step never wait for its LDS reads (they did at the head of every step: 12 reads, then 32 MFMAs).  The step's wait then
 // covers the NEXT stage as well (one stage in flight instead of two); the first step of a tile reads as before.
-template <int EPI, bool PF = false>
+// PROBE (lab builds only; results garbage): 1 = no epilogue, 2 = no LDS-DMA behind the first ring fill, 4 = no fragment reads,
+// 8 = no MFMAs.
+template <int EPI, bool PF = false, int PROBE = 0>
 __global__ __launch_bounds__(256, 2) void gemm_nt_runs_kernel(const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
                                                               int64_t M, int K, const uint16_t* __restrict__ Bm, int ldb, int N,
                                                               const float* __restrict__ bias, uint16_t* __restrict__ C, int ldc,
@@ -170,8 +172,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_runs_kernel(const uint16_t* __
     };
     i_np = n_pass(0);
     set_sources(0, 0);
+    int issued = 0;
     auto issue_next = [&]() {                          // next stage of the stream, if any is left
         if (i_t >= n_my) return;
+        if ((PROBE & 2) && issued >= NS - 1) {             // probe: the cursor moves, nothing is fetched
+            i_s = (i_s + 1 == NS) ? 0 : i_s + 1;
+            if (++i_k == n_kt) {
+                i_k = 0;
+                if (++i_p == i_np) {
+                    i_p = 0;
+                    if (++i_t < n_my) i_np = n_pass(i_t);
+                }
+            }
+            return;
+        }
+        ++issued;
         unsigned char* st = smem + i_s * NR_STAGE;
         nr_glds16(asrc + i_k * BK, st + wave * 1024);
         nr_glds16(bsrc[0] + i_k * BK, st + NR_A_BYTES + (wave * 2) * 1024);
@@ -242,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_runs_kernel(const uint16_t* __
                 const int young = max(min(g_total - 1 - ahead - g, NS - 2 - ahead), 0);
                 const int allow = young * NL + ((ti > 0 && p == 0 && kt < NS - 1 - ahead) ? NST : 0);
                 __builtin_amdgcn_sched_barrier(0);
-                switch (allow) {
+                switch (PROBE ? 0 : allow) {
                     NR_WAIT_CASE(3) NR_WAIT_CASE(6) NR_WAIT_CASE(16) NR_WAIT_CASE(19) NR_WAIT_CASE(22)
                     default: NR_WAIT(0); break;
                 }
@@ -251,12 +266,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_runs_kernel(const uint16_t* __
                 issue_next();                          // refills the slot every wave finished with before this barrier
                 c_s = (c_s + 1 == NS) ? 0 : c_s + 1;
                 if (!PF) {
-                    read_frags(st);
+                    if (!(PROBE & 4) || g == 0) read_frags(st);
+                    if (!(PROBE & 8)) {
 #pragma unroll
-                    for (int i = 0; i < TMB; ++i)
+                        for (int i = 0; i < TMB; ++i)
 #pragma unroll
-                        for (int j = 0; j < TNB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0][j], fa[i], acc[i][j], 0, 0, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, TMB * TNB, 0);
+                            for (int j = 0; j < TNB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0][j], fa[i], acc[i][j], 0, 0, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, TMB * TNB, 0);
+                    }
                 } else {
                     if (kt == 0) {                     // first step of a tile / pass: nothing was read ahead
 #pragma unroll
@@ -288,6 +305,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_runs_kernel(const uint16_t* __
         }
 
         // ---- epilogue: bias (+ sigmoid), bf16, whole 128-byte row segments through the wave's LDS patch ------------------------
+        if (PROBE & 1) {                               // probe: the accumulators stay "used", nothing else happens
+#pragma unroll
+            for (int i = 0; i < TMB; ++i)
+#pragma unroll
+                for (int j = 0; j < TNB; ++j) asm volatile("" ::"v"(acc[i][j]));
+            continue;
+        }
         unsigned char* patch = smem + NR_PATCH + wave * 4096;
         const int prow = lane >> 3, pchunk = lane & 7;
         f32x4 bv[TNB];
@@ -340,6 +364,19 @@ int mg_try_nt_runs(const uint16_t* A, int lda, const int32_t* rows, int64_t M, i
     if (g > blocks) g = blocks;
     if (g >= 2147483647LL) return 0;
     dim3 grid((unsigned)g), block(256);
+#ifdef MG_EXPERIMENTS
+    if (sigmoid && g_mg_tuning[MG_TUNE_FORM] >= 200 && g_mg_tuning[MG_TUNE_FORM] < 216) {      // lab builds: timing probes 200 + mask
+#define NR_PROBE_CASE(P)                                                                                                                  \
+    case 200 + P:                                                                                                                          \
+        hipLaunchKernelGGL((gemm_nt_runs_kernel<NR_EPI_BIAS_SIGMOID, false, P>), grid, block, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, C, ldc, \
+                           (int)tiles_m, tiles_n);                                                                                         \
+        return 1;
+        switch (g_mg_tuning[MG_TUNE_FORM]) {
+            NR_PROBE_CASE(1) NR_PROBE_CASE(2) NR_PROBE_CASE(3) NR_PROBE_CASE(4) NR_PROBE_CASE(7) NR_PROBE_CASE(8) NR_PROBE_CASE(11) NR_PROBE_CASE(15)
+            default: break;
+        }
+    }
+#endif
     const bool pf = g_mg_tuning[MG_TUNE_FORM] == 16;   // A/B: fragments read one k-step ahead
     if (sigmoid && pf)
         hipLaunchKernelGGL((gemm_nt_runs_kernel<NR_EPI_BIAS_SIGMOID, true>), grid, block, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, C, ldc,
