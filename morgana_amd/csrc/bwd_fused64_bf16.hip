@@ -776,7 +776,7 @@ __global__ __launch_bounds__(512) void wgrad_fused3_kernel(const uint16_t* __res
         const int swm = w64_sw(l15);
         const int b_row0 = L::DZ + l15 * 256;                                             // + 4096 t; chunk 4 ks + lq at (4 ks + lq) ^ swm
         const int h_off0 = L::H1 + l15 * 256 + ((c16 ^ swm) << 4) + 8 * (lq & 1);          // + 4096 t
-        const int y_off0 = L::YS + l15 * 256 + ((c16 ^ ((l15 & 3) << 2)) << 4) + 8 * (lq & 1);
+        const int y_off0 = L::YS + l15 * 256 + ((c16 ^ swm) << 4) + 8 * (lq & 1);      // the dZ1 tile in the dual-use image as well
         const int a_row = 16 * wave + l15;
         const int w_off0 = L::W2T + a_row * 64 + ((lq ^ (((a_row >> 3) & 1) << 1)) << 4);  // + 8192 per k-tile
         const int bo = tb * 16384, yo = yb2 * 16384;
@@ -831,12 +831,17 @@ __global__ __launch_bounds__(512) void wgrad_fused3_kernel(const uint16_t* __res
         const int q = li >> 2, p4 = li & 3;
         const int cgrp = 16 * (g4 & 1) + 4 * p4;
         const int rbase = 8 * (g4 >> 1) + q;                  // this lane's frame inside a 16-frame k-step (and + 4)
-        const int sw = q << 2;
-        int yoff[2], xk[TKT];
+        // dZ1 tile (dual-use image: chunk ^ sw(row); the 8-byte stores of P1 were 8-way bank conflicted under the former (row & 3) << 2
+        // swizzle - 16 lanes, 16 rows, two distinct 128-byte phases): frames rbase and rbase + 4 of a k-step differ in (row >> 2) & 3
+        int yoff[2][2], xk[TKT];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int col = wn0 + i * 32 + cgrp;
-            yoff[i] = L::YS + rbase * PY + ((((col >> 3) ^ sw) << 4) | ((col & 7) << 1));
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi) {
+                const int row = rbase + 4 * hi;
+                yoff[i][hi] = L::YS + row * PY + ((((col >> 3) ^ w64_sw(row)) << 4) | ((col & 7) << 1));
+            }
         }
 #pragma unroll
         for (int j = 0; j < TKT; ++j) {
@@ -866,9 +871,8 @@ __global__ __launch_bounds__(512) void wgrad_fused3_kernel(const uint16_t* __res
             if (PROBE & 2) asm volatile("" : "=v"(probe_frag));
             auto rd_a = [&](int ks, int i) -> bfv8 {
                 if (PROBE & 2) return probe_frag;
-                const unsigned char* ad = smem + yb + yoff[i] + ks * 16 * PY;
-                const bfv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(ad));
-                const bfv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(ad + 4 * PY));
+                const bfv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(smem + yb + yoff[i][0] + ks * 16 * PY));
+                const bfv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(smem + yb + yoff[i][1] + ks * 16 * PY));
                 return bfv8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             };
             auto rd_b = [&](int ks, int j) -> bfv8 {
@@ -932,33 +936,42 @@ __global__ __launch_bounds__(512) void wgrad_fused3_kernel(const uint16_t* __res
         const int nb = wave >> 1, cb0 = 2 * (wave & 1);
         const int rb = 8 * (g4 >> 1) + q;
         const int cg = 16 * (g4 & 1) + 4 * p4;
-        const int dzb = L::DZ + tb * 16384, h1b = L::H1 + tb * 16384;
-        auto rd = [&](int base, int ks, int col) -> bfv8 {
-            const int r0 = 16 * ks + rb, r1 = r0 + 4;
-            const unsigned char* alo = smem + base + r0 * 256 + ((((col >> 3) ^ w64_sw(r0)) << 4) | ((col & 7) << 1));
-            const unsigned char* ahi = smem + base + r1 * 256 + ((((col >> 3) ^ w64_sw(r1)) << 4) | ((col & 7) << 1));
-            const bfv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(alo));
-            const bfv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(ahi));
+        // frame r = 16 ks + rb + 4 hi: sw(r) does not depend on ks (16 ks changes neither r & 3 nor (r >> 2) & 3), so an operand's
+        // address is one per-lane base per (operand, hi) + the k-step as an immediate offset (4096 ks)
+        int ad[3][2];
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi) {
+            const int r = rb + 4 * hi, swr = w64_sw(r);
+            const int cols[3] = {32 * nb + cg, 32 * cb0 + cg, 32 * (cb0 + 1) + cg};
+#pragma unroll
+            for (int o = 0; o < 3; ++o)
+                ad[o][hi] = (o == 0 ? L::DZ : L::H1) + tb * 16384 + r * 256 + ((((cols[o] >> 3) ^ swr) << 4) | ((cols[o] & 7) << 1));
+        }
+        auto rd = [&](int o, int ks) -> bfv8 {
+            const bfv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(smem + ad[o][0] + ks * 4096));
+            const bfv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(smem + ad[o][1] + ks * 4096));
             return bfv8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         };
+        const bfv2 one2 = bfv2{(__bf16)1.0f, (__bf16)1.0f};
         bfv8 a[2], b0[2], b1[2];
-        a[0] = rd(dzb, 0, 32 * nb + cg);
-        b0[0] = rd(h1b, 0, 32 * cb0 + cg);
-        b1[0] = rd(h1b, 0, 32 * (cb0 + 1) + cg);
+        a[0] = rd(0, 0);
+        b0[0] = rd(1, 0);
+        b1[0] = rd(2, 0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             if (ks + 1 < 4) {
-                a[(ks + 1) & 1] = rd(dzb, ks + 1, 32 * nb + cg);
-                b0[(ks + 1) & 1] = rd(h1b, ks + 1, 32 * cb0 + cg);
-                b1[(ks + 1) & 1] = rd(h1b, ks + 1, 32 * (cb0 + 1) + cg);
+                a[(ks + 1) & 1] = rd(0, ks + 1);
+                b0[(ks + 1) & 1] = rd(1, ks + 1);
+                b1[(ks + 1) & 1] = rd(2, ks + 1);
             }
             acc3[0] = mg_mfma_32x32x16(a[ks & 1], b0[ks & 1], acc3[0]);
             acc3[1] = mg_mfma_32x32x16(a[ks & 1], b1[ks & 1], acc3[1]);
             if ((wave & 1) == 0) {                         // the bias gradient from the dZ2^T fragment (this lane: one column, 8 frames)
-                float t = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) t += (float)a[ks & 1][e];
-                db2p += t;
+                const bfv8 v = a[ks & 1];
+                db2p = __builtin_amdgcn_fdot2_f32_bf16(bfv2{v[0], v[1]}, one2, db2p, false);
+                db2p = __builtin_amdgcn_fdot2_f32_bf16(bfv2{v[2], v[3]}, one2, db2p, false);
+                db2p = __builtin_amdgcn_fdot2_f32_bf16(bfv2{v[4], v[5]}, one2, db2p, false);
+                db2p = __builtin_amdgcn_fdot2_f32_bf16(bfv2{v[6], v[7]}, one2, db2p, false);
             }
         }
     };
