@@ -579,6 +579,17 @@ class LinearStackMSEFn(torch.autograd.Function):
             grads = _deliver_rest(ctx.params, flat[:flat.numel() - 1], ctx.offsets, grad_loss, early)
             return (None, None, None, None, None) + tuple(grads)
         early = False
+        if (lead == 2 and rows is not None and ctx.acts[0] == ops.ACT_SIGMOID and _EARLY_GRADS_HOOK is None and
+                os.environ.get('MORGANA_FUSE_WGRAD2', '1') != '0' and ops.can_fuse_bwd(m, ctx.dims[1][0], ctx.dims[1][1], ctx.dims[0][1], a0.shape[1])):
+            # the same one-launch backward as the optimiser-bound modes above (both layers' slabs, then the ordered reduces): whichever
+            # way the gradients are handed over, they are the same bits
+            n0_, k0_ = ctx.dims[0]
+            slab, n_slabs, (off1, st1, cnt1), (off2, st2, cnt2) = ops.linear_bwd_fused2_slabs_bf16(g, w_t[1], hidden[0], a0, rows, m, n0_, k0_)
+            floats = slab.view(torch.float32)
+            ops.slab_reduce(floats[off1:], n_slabs, st1, cnt1, flat[ctx.offsets[0]:ctx.offsets[0] + cnt1])
+            ops.slab_reduce(floats[off2:], n_slabs, st2, cnt2, flat[ctx.offsets[2]:ctx.offsets[2] + cnt2])
+            grads = _deliver_rest(ctx.params, flat[:flat.numel() - 1], ctx.offsets, grad_loss, False)
+            return (None, None, None, None, None) + tuple(grads)
         for i in range(lead - 1, -1, -1):
             n, k = ctx.dims[i]
             a_in, r = (a0, rows) if i == 0 else (hidden[i - 1], None)

@@ -1473,20 +1473,21 @@ def test_lstm_acoustic_model_shipped_shape_vs_oracle():
         assert rel_err(prm.grad.cpu().numpy(), want_grads[name]) < 1e-3, name
 
 
-class _ToyGRUF0(models.GRUF0Model):
-    """GRUF0Model with the layer widths of golden G13 (the class fixes 256 / 64 / 64 as the reference file does)."""
+class _ToyGRUF0(models.StreamModel):
+    """The shipped GRU F0 model's stream table (models.GRUF0Model) on the layer widths of golden G13 (the class itself fixes
+    256 / 64 / 64 as the reference file does)."""
 
     def __init__(self, input_dim, d1, hid, post, out_dim, precision, fused):
-        models.BaseSPSS.__init__(self)
         nn = torch.nn
-        self.fused_upsample = fused
-        self.generate = False
-        self.layers = utils.SequentialWithRecurrent(
+        layers = utils.SequentialWithRecurrent(
             nn.Linear(input_dim, d1), nn.Sigmoid(), nn.Dropout(p=0.),
             utils.RecurrentCuDNNWrapper(nn.GRU(d1, hid, batch_first=True), precision=precision), nn.Dropout(p=0.),
             utils.RecurrentCuDNNWrapper(nn.GRU(hid, hid, batch_first=True), precision=precision), nn.Dropout(p=0.),
             utils.RecurrentCuDNNWrapper(nn.GRU(hid, hid, batch_first=True), precision=precision), nn.Dropout(p=0.),
             nn.Linear(hid, post), nn.Sigmoid(), nn.Dropout(p=0.), nn.Linear(post, out_dim), precision=precision)
+        from morgana_amd import metrics
+        streams = [models.Stream('lf0', out_dim, 'mse', ('LF0_RMSE_Hz', metrics.LF0Distortion, 'voiced_trajectory'))]
+        models.StreamModel.__init__(self, layers, streams, fused_upsample=fused, fused_loss=False, generate=False)
 
 
 @pytest.mark.parametrize('fused', [True, False])

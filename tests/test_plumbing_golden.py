@@ -294,6 +294,6 @@ def test_bf16_loader_table_and_launches_of_the_product_step():
     want = ['mg_phone_front_linear_fwd_bf16', 'mg_f0_l2tail_rows_slabs_bf16', 'mg_expand_column_reduce_f32', 'mg_linear_wgrad_dgrad_bf16',
             'mg_linear_wgrad_slabs_bf16', 'mg_store_pair_f32', 'mg_adam_step_plan_f32']
     n = len(loader)
-    per_epoch = [c for c in step_calls if c not in want]
+    per_epoch = [c for c in step_calls if c not in want and not c.endswith('_status')]     # the epoch's time-out check reads status words
     assert sorted(c for c in step_calls if c in want) == sorted(want * n), step_calls
     assert len(per_epoch) <= 3, per_epoch                    # the epoch's reads of the loss metric / the persistent-kernel status
