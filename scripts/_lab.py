@@ -6,3 +6,8 @@ import os
 _LAB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'morgana_amd', 'libmorgana_hip_lab.so')
 if os.path.exists(_LAB):
     os.environ.setdefault('MORGANA_HIP_LIB', _LAB)
+
+import sys as _sys
+_REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if _REPO not in _sys.path:
+    _sys.path.insert(0, _REPO)
