@@ -535,6 +535,13 @@ def other_workloads(dev, precision):
             frames = int(feats_np['n_frames'].sum())
             out[key] = {'workload': what + ', eager launches, %s' % precision, 'ms_per_step': round(ms, 4),
                         'value': round(frames / (ms * 1e-3), 1), 'unit': 'frames/s'}
+            if key == 'c5':                               # the same batch with every row-wise product on all B * T padded rows
+                from morgana_amd import utils as mg_utils
+                mg_utils.set_packed_frames(False)
+                try:
+                    out[key]['padded_rows_ms_per_step'] = round(timed_leg(step, 5, 2), 4)
+                finally:
+                    mg_utils.set_packed_frames(True)
             del model, opt, feats
         except Exception as exc:                          # noqa: BLE001 - a leg that fails is reported, the headline stands
             out[key] = {'error': str(exc).splitlines()[0][:200]}

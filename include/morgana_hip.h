@@ -320,6 +320,15 @@ int mg_linear_wgrad_bf16(const uint16_t* dY, int lddy, const uint16_t* A, int ld
                          int N, int K, float* dW, float* db, int accumulate, void* workspace, size_t workspace_bytes,
                          void* stream);
 
+/* mg_linear_wgrad_bf16 with both operands gathered: dW = sum_{m < M} dY[dy_rows[m]]^T A[rows[m]] (rows NULL: A[dy_rows[m]]); M counts the
+ * index pairs.  What it replaces: the weight gradients autograd forms for nn.GRU / nn.LSTM on a PackedSequence
+ * (morgana/utils.py:366-385: pack_padded_sequence in front of the layer, pad_packed_sequence behind it) - here the recurrences keep
+ * padded (B, T) arrays and this product visits the sum_b T_b valid frames only.  Wide-tile shapes with lda == 512 (384 < K <= 512,
+ * N % 128 == 0, M >= 4096, not the half-width plan): MG_EINVAL otherwise, the caller then multiplies the padded rows.  workspace:
+ * mg_linear_wgrad_workspace_bytes(M, N, K). */
+int mg_linear_wgrad_rows_bf16(const uint16_t* dY, int lddy, const int32_t* dy_rows, const uint16_t* A, int lda, const int32_t* rows, int64_t M,
+                              int N, int K, float* dW, float* db, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
 /* mg_linear_wgrad_bf16 without its reduce launch: the split-M partial results stay in `workspace` as *n_slabs slabs of *stride floats,
  * slab s = [N*K weight partials | N bias partials], for a consumer that sums them itself (mg_adam_step_plan_f32).  Only the wide-tile
  * plan has this form: returns MG_EINVAL for shapes mg_linear_wgrad_bf16 would run on its 128 x 128 kernels (call that instead). */

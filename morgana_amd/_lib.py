@@ -57,6 +57,8 @@ SIGNATURES = {
                                      c_void_p, c_int, c_int, c_void_p]),
     'mg_linear_wgrad_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p,
                                      c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'mg_linear_wgrad_rows_bf16': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p,
+                                          c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'mg_linear_bwd_fused_workspace_bytes': (c_size_t, [c_int64, c_int, c_int]),
     'mg_linear_bwd_fused_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                          c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),

@@ -382,7 +382,7 @@ int mg_try_nt_runs(const uint16_t* A, int lda, const int32_t* rows, int64_t M, i
                    const float* bias, uint16_t* C, int ldc, int sigmoid, hipStream_t st);       // gemm_nt_runs.hip
 int mg_wgrad_big_plan(int64_t M, int N, int K, int lda, int lddy, int* S_out, int* m_chunk_out);
 int mg_launch_wgrad_big(const uint16_t* dY, int lddy, const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K,
-                        int S, int m_chunk, float* slab, float* bslab, int64_t sstride, hipStream_t st);
+                        int S, int m_chunk, float* slab, float* bslab, int64_t sstride, hipStream_t st, const int32_t* dy_rows = nullptr);
 int mg_launch_phone_front_gemm(const PhoneFrontArgs& pf, const uint16_t* A, int lda, int64_t M, int K, const uint16_t* Bm, int ldb, int N,
                                const float* bias, uint16_t* C, int ldc, int epi, hipStream_t st);
 extern "C" int mg_phone_front_check(const int64_t* dur, int B, int P, int T, const float* target, int extra, const int32_t* rows32,
@@ -563,6 +563,42 @@ int mg_linear_wgrad_slabs_bf16(const uint16_t* dY, int lddy, const uint16_t* A, 
     MG_CHECK_LAUNCH("mg_linear_wgrad_slabs_bf16");
     *n_slabs = big_s;
     *stride = sstride;
+    return MG_OK;
+}
+
+// mg_linear_wgrad_bf16 with BOTH operands gathered: dW = sum_m dY[dy_rows[m]]^T A[rows[m]] (rows == NULL: A[dy_rows[m]]), M = the number of
+// index pairs.  The weight gradients of a recurrent layer over the valid frames of a ragged batch only (the reference packs them away:
+// morgana/utils.py:366-385 pack_padded_sequence; here the recurrences write padded (B, T) arrays and the GEMM skips the padding).
+// Wide-tile shapes with lda == 512 only (MG_EINVAL otherwise: the caller keeps the padded form).
+int mg_linear_wgrad_rows_bf16(const uint16_t* dY, int lddy, const int32_t* dy_rows, const uint16_t* A, int lda, const int32_t* rows, int64_t M,
+                              int N, int K, float* dW, float* db, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    MG_CHECK_ARG(dY && dy_rows && A && dW && M > 0 && N > 0 && K > 0, "mg_linear_wgrad_rows_bf16: bad arguments (M=%lld N=%d K=%d)", (long long)M, N, K);
+    MG_CHECK_ARG(lddy >= N && lda >= K && lddy % 8 == 0 && lda % 8 == 0,
+                 "mg_linear_wgrad_rows_bf16: lddy=%d lda=%d must be multiples of 8 covering N=%d / K=%d", lddy, lda, N, K);
+    MG_CHECK_ARG(al16(dY) && al16(A), "mg_linear_wgrad_rows_bf16: buffers must be 16-byte aligned");
+    int big_s = 0, big_chunk = 0;
+    MG_CHECK_ARG(lda == 512 && mg_wgrad_big_plan(M, N, K, lda, lddy, &big_s, &big_chunk) > 0,
+                 "mg_linear_wgrad_rows_bf16: M=%lld N=%d K=%d lda=%d is not a 512-wide wide-tile shape", (long long)M, N, K, lda);
+    const int64_t nk = (int64_t)N * K, sstride = nk + N;
+    if (!workspace || (size_t)big_s * (size_t)sstride * sizeof(float) > workspace_bytes) {
+        mg_set_error("mg_linear_wgrad_rows_bf16: %d split slabs of %lld floats do not fit the %zu-byte workspace", big_s, (long long)sstride,
+                     workspace_bytes);
+        return MG_EWORKSPACE;
+    }
+    float* slab = (float*)workspace;
+    float* bslab = slab + nk;
+    hipStream_t st = (hipStream_t)stream;
+    MG_CHECK_ARG(mg_launch_wgrad_big(dY, lddy, A, lda, rows ? rows : dy_rows, M, N, K, big_s, big_chunk, slab, db ? bslab : nullptr, sstride, st,
+                                     dy_rows) > 0,
+                 "mg_linear_wgrad_rows_bf16: M=%lld N=%d takes the half-width tiles, which have no gathered-dY form", (long long)M, N);
+    MG_CHECK_LAUNCH("mg_linear_wgrad_rows_bf16/partial");
+    if (db && db == dW + nk) {
+        mg_launch_slab_reduce(slab, sstride, sstride, big_s, dW, accumulate, st);
+    } else {
+        mg_launch_slab_reduce(slab, nk, sstride, big_s, dW, accumulate, st);
+        if (db) mg_launch_slab_reduce(bslab, N, sstride, big_s, db, accumulate, st);
+    }
+    MG_CHECK_LAUNCH("mg_linear_wgrad_rows_bf16/reduce");
     return MG_OK;
 }
 

@@ -926,11 +926,14 @@ MG_STAMP_DECL(g_stamps_wg);
 // X tile row pitch: the k columns of the tile, rounded up to whole groups of 16 chunks (the chunk swizzle XORs bits 2-3 of the chunk index)
 #define WG_BIG_PX(TKW_) ((64 * (TKW_) * 2 + 255) / 256 * 256)
 #define WG_BIG_LDS(TKW_) (WG_STAGES(TKW_) * (32 * 256 + 32 * WG_BIG_PX(TKW_)) + WG_ROWS_MAX * 4)
-template <int TKW>
+// DYR: the dY operand is gathered too - row m of the product is dY[dy_rows[m]] (x) A[rows[m]]: the valid frames of a ragged batch picked
+// out of the padded (B, T) arrays a recurrence writes (morgana/utils.py:366-385 packs them away), so that the layer's weight
+// gradients multiply sum_b T_b rows instead of B T.  A second parked index table: 16 KB more LDS, a kernel of its own.
+template <int TKW, bool DYR = false>
 __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem, const unsigned block_id, const uint16_t* __restrict__ dY,
                                                int lddy, const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows, int64_t M,
                                                int N, int K, int m_chunk, float* __restrict__ slab, float* __restrict__ bslab, int64_t sstride,
-                                               int xcd_group) {
+                                               int xcd_group, const int32_t* __restrict__ dy_rows = nullptr) {
     // TKW = 10 / 8: the workgroup's tile is 128 x 640 / 128 x 512 (all k columns of the operand), 2 waves along n x 4 along k.
     // TKW = 5: 128 x 320 - HALF the k columns, two k halves per n tile (KH = 2), 4 waves along n x 2 along k: the same five k tiles per
     // wave with one n tile instead of two.  Twice the tiles per split means two thirds of the splits for a full chip (8 x 32 instead of
@@ -948,10 +951,11 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
     constexpr int NLW = 1 + NX;                   // + one for dY
     static_assert(X_BYTES % 8192 == 0, "whole pieces per wave");
     constexpr int NSTG = WG_STAGES(TKW);
-    constexpr int LDS_BYTES = NSTG * STAGE + WG_ROWS_MAX * 4;
+    constexpr int LDS_BYTES = NSTG * STAGE + WG_ROWS_MAX * 4 * (DYR ? 2 : 1);
 
-    static_assert(LDS_BYTES == WG_BIG_LDS(TKW), "LDS size helper");
+    static_assert(LDS_BYTES == WG_BIG_LDS(TKW) + (DYR ? WG_ROWS_MAX * 4 : 0) && LDS_BYTES <= 160 * 1024, "LDS size helper");
     int* row_lds = reinterpret_cast<int*>(smem + NSTG * STAGE);
+    int* dyrow_lds = row_lds + WG_ROWS_MAX;       // DYR only
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -987,6 +991,7 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
         int r = -1;
         if (i < n_rows) r = rows ? rows[m_lo + i] : (int)(m_lo + i);
         row_lds[i] = r;
+        if (DYR) dyrow_lds[i] = i < n_rows ? dy_rows[m_lo + i] : -1;
     }
     __syncthreads();
 
@@ -1006,7 +1011,11 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
 
     auto issue = [&](int step) {                 // rows [32 step, 32 step + 32) of this workgroup's range
         unsigned char* st = smem + (step % NSTG) * STAGE;
-        {
+        if (DYR) {
+            const int ry = dyrow_lds[step * 32 + y_row];
+            const uint16_t* p = ry >= 0 ? dY + (size_t)ry * lddy + n0 + y_c * 8 : g_zero_row;
+            glds16(p, st + wave * 1024);
+        } else {
             const int ml = step * 32 + y_row;
             const uint16_t* p = (ml < n_rows) ? dY + (size_t)(m_lo + ml) * lddy + n0 + y_c * 8 : g_zero_row;
             glds16(p, st + wave * 1024);
@@ -1180,6 +1189,15 @@ __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restri
     wgrad_big_body<TKW>(smem, blockIdx.x, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
 }
 
+template <int TKW>
+__global__ __launch_bounds__(512) void wgrad_big_rows_kernel(const uint16_t* __restrict__ dY, int lddy, const int32_t* __restrict__ dy_rows,
+                                                             const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows, int64_t M,
+                                                             int N, int K, int m_chunk, float* __restrict__ slab, float* __restrict__ bslab,
+                                                             int64_t sstride, int xcd_group) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WG_BIG_LDS(TKW) + WG_ROWS_MAX * 4];
+    wgrad_big_body<TKW, true>(smem, blockIdx.x, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group, dy_rows);
+}
+
 // Two INDEPENDENT launches of a backward pass in one grid: the weight gradient of a layer (blocks [0, wg_blocks): dW = dY^T A as split-M
 // slabs) and the dgrad + sigmoid backward towards the layer below (the blocks behind them: dX = (dY W) * H (1 - H)).  Both read dY; at
 // the phone-rate row count of C2 the first fills 96 CUs for 18 us and the second 168 for 16 us, one after the other; as parallel
@@ -1326,8 +1344,17 @@ int mg_wgrad_big_plan(int64_t M, int N, int K, int lda, int lddy, int* S_out, in
     return 1;
 }
 
+// dy_rows != nullptr: the dY operand gathered as well (wgrad_big_rows_kernel).  The 128 x 512 tile form only (lda == 512: the 640-wide
+// tile leaves no LDS for the second index table); returns 0 without launching for other shapes.
 int mg_launch_wgrad_big(const uint16_t* dY, int lddy, const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K,
-                        int S, int m_chunk, float* slab, float* bslab, int64_t sstride, hipStream_t st) {
+                        int S, int m_chunk, float* slab, float* bslab, int64_t sstride, hipStream_t st, const int32_t* dy_rows) {
+    if (dy_rows) {
+        if (lda != 512 || wgrad_ksplit(M, N, lda)) return 0;
+        dim3 grid((unsigned)((N / 128) * S)), block(512);
+        hipLaunchKernelGGL((wgrad_big_rows_kernel<8>), grid, block, 0, st, dY, lddy, dy_rows, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride,
+                           g_mg_tuning[MG_TUNE_WGRAD_ORDER] == 2 && S % 8 == 0 ? 1 : 0);
+        return 1;
+    }
     const bool ksplit = wgrad_ksplit(M, N, lda);
     dim3 grid((unsigned)((N / 128) * (ksplit ? 2 : 1) * S)), block(512);
     // block order: the n tiles of a split on one XCD when X is streamed (no gather: a table read once), n tile fastest when X is a

@@ -647,8 +647,9 @@ class GRUFn(torch.autograd.Function):
     weight-gradient and input-gradient GEMMs, which then run on table rows too."""
 
     @staticmethod
-    def forward(ctx, precision, x, h0, seq_len, w_ih, w_hh, b_ih, b_hh, rows=None, seg=None):
+    def forward(ctx, precision, x, h0, seq_len, w_ih, w_hh, b_ih, b_hh, rows=None, seg=None, layout=None):
         x = ops._require(x, torch.float32, 'inputs')
+        ctx.layout = layout            # utils.FrameLayout of a ragged batch or None: backward's weight gradients skip the padded frames
         hid = w_hh.shape[1]
         if rows is not None:
             (b, t), i_dim = rows.shape, x.shape[1]
@@ -723,15 +724,24 @@ class GRUFn(torch.autograd.Function):
             # the bf16 recurrence already wrote the bf16 shadows of dhproj and of the states
             dhp_bf = dhproj_bf.view(m, 3 * hid) if dhproj_bf is not None else ops.cast_pad_bf16(dhp2)
             hs_bf = hstate_bf.view(b * (t + 1), hid) if hstate_bf is not None else ops.cast_pad_bf16(hs2)
-            dw_ih, db_ih = ops.linear_wgrad_bf16(dxp_bf, x_saved, None, m_in, 3 * hid, i_dim)
-            dw_hh, db_hh = ops.linear_wgrad_bf16(dhp_bf, hs_bf, prev_rows, m, 3 * hid, hid)
+            # Ragged batch with its layout at hand: both products visit the sum_b T_b valid frames only (the gate gradients of the
+            # padded frames are zero rows; the reference's PackedSequence never holds them, utils.py:366-385)
+            lay = ctx.layout if (ctx.layout is not None and (ctx.layout.b, ctx.layout.t) == (b, t)) else None
+            if lay is not None and rows is None and ops.wgrad_rows_ok(lay.total, 3 * hid, i_dim, x_saved.shape[1], dxp_bf.shape[1]):
+                dw_ih, db_ih = ops.linear_wgrad_rows_bf16(dxp_bf, lay.frame_rows(), x_saved, None, lay.total, 3 * hid, i_dim)
+            else:
+                dw_ih, db_ih = ops.linear_wgrad_bf16(dxp_bf, x_saved, None, m_in, 3 * hid, i_dim)
+            if lay is not None and ops.wgrad_rows_ok(lay.total, 3 * hid, hid, hs_bf.shape[1], dhp_bf.shape[1]):
+                dw_hh, db_hh = ops.linear_wgrad_rows_bf16(dhp_bf, lay.frame_rows(), hs_bf, lay.state_rows(), lay.total, 3 * hid, hid)
+            else:
+                dw_hh, db_hh = ops.linear_wgrad_bf16(dhp_bf, hs_bf, prev_rows, m, 3 * hid, hid)
             if need_x:
                 dx = ops.linear_dgrad_bf16(dxp_bf, m_in, 3 * hid, ops.cast_transpose_bf16(w_ih), i_dim, None,
                                            out_f32=True)
                 if dx.shape[1] != i_dim:
                     dx = dx[:, :i_dim].contiguous()
                 dx = dx if rows is not None else dx.view(b, t, i_dim)
-        return (None, dx, dh0.view(1, b, hid) if ctx.has_h0 else None, None, dw_ih, dw_hh, db_ih, db_hh, None, None)
+        return (None, dx, dh0.view(1, b, hid) if ctx.has_h0 else None, None, dw_ih, dw_hh, db_ih, db_hh, None, None, None)
 
 
 def lstm_persistent(precision, b, t, hid):

@@ -414,6 +414,27 @@ def linear_wgrad_bf16(dy, a, rows, m, n, k, want_bias=True, out_w=None, out_b=No
     return dw, db
 
 
+def wgrad_rows_ok(m, n, k, lda, lddy):
+    """Shapes mg_linear_wgrad_rows_bf16 takes (both operands gathered: the valid frames of a ragged batch out of padded arrays): the
+    128 x 512 wide tiles, not their half-width plan (csrc/gemm_bf16_big.hip: wgrad_ksplit)."""
+    return (m >= 4096 and n % 128 == 0 and lddy >= n and lddy % 8 == 0 and lda == 512 and 384 < k <= 512 and
+            not (n == 128 and m <= 32768))
+
+
+def linear_wgrad_rows_bf16(dy, dy_rows, a, rows, m, n, k, want_bias=True):
+    """dW = sum_{i < m} dy[dy_rows[i]]^T a[rows[i]] (rows None: a[dy_rows[i]]), db = sum_i dy[dy_rows[i]]: linear_wgrad_bf16 on the m
+    index pairs only (``dy_rows`` int32, every entry a valid row of ``dy``)."""
+    lib = _lib.load()
+    dy_rows = _require(dy_rows, torch.int32, 'dy_rows')
+    dw = torch.empty((n, k), dtype=torch.float32, device=dy.device)
+    db = torch.empty((n,), dtype=torch.float32, device=dy.device) if want_bias else None
+    nbytes = lib.mg_linear_wgrad_workspace_bytes(m, n, k)
+    ws = workspace(nbytes, dy.device)
+    _lib.check(lib.mg_linear_wgrad_rows_bf16(_p(dy), dy.shape[1], _p(dy_rows), _p(a), a.shape[1], _p(rows), m, n, k, _p(dw), _p(db), 0,
+                                             _p(ws), ws.numel(), _stream()), 'mg_linear_wgrad_rows_bf16')
+    return dw, db
+
+
 def wgrad_slabs_ok(m, n, k, lda, lddy):
     """Shapes whose weight gradient runs on the wide-tile kernel and can leave its split-M slabs to the optimiser
     (mg_linear_wgrad_slabs_bf16; the plan of csrc/gemm_bf16_big.hip)."""

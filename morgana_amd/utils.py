@@ -152,6 +152,18 @@ class FrameLayout(object):
         out = F_hip.UnpackRowsFn.apply(packed, self.rows, self.inverse, self.seq_len, self.b, self.t)
         return out.view(self.b, self.t, packed.shape[1])
 
+    def frame_rows(self):
+        """int32 (total,): the dense row b * t + i of every valid frame, in packed order."""
+        return self.rows[:self.total]
+
+    def state_rows(self):
+        """int32 (total,): row b * (t + 1) + i of a (B, t + 1, H) state array for every valid frame (b, i) - the state the frame's
+        step STARTS from (functional.state_rows restricted to the valid frames).  Made once per layout."""
+        if getattr(self, '_state_rows', None) is None:
+            dense = self.frame_rows()
+            self._state_rows = (dense + torch.div(dense, self.t, rounding_mode='floor')).to(torch.int32).contiguous()
+        return self._state_rows
+
 
 class UpsampledConcat(object):
     """Lazy ``torch.cat((upsample_to_repetitions(sequence_feature, repeats), frame_feature), dim=-1)`` - the model input of
@@ -303,15 +315,19 @@ class RecurrentCuDNNWrapper(nn.Module):
                                               *self._lstm_params())
         return out, (hn, cn)
 
-    def _run_gru(self, inputs, hidden, seq_len):
+    def _run_gru(self, inputs, hidden, seq_len, layout=None):
         layer = self.layer
         precision = self.precision or F_hip.get_precision()
         if isinstance(inputs, PhoneTable):
             seg, rows = inputs.maps()
+            if layout is not None and (tuple(inputs.rows.shape) != (layout.b, layout.t) or not layout.worthwhile()):
+                layout = None
             return F_hip.GRUFn.apply(precision, inputs.table, hidden, seq_len, layer.weight_ih_l0, layer.weight_hh_l0,
-                                     layer.bias_ih_l0, layer.bias_hh_l0, rows.view(inputs.rows.shape), seg)
+                                     layer.bias_ih_l0, layer.bias_hh_l0, rows.view(inputs.rows.shape), seg, layout)
+        if layout is not None and (tuple(inputs.shape[:2]) != (layout.b, layout.t) or not layout.worthwhile()):
+            layout = None
         return F_hip.GRUFn.apply(precision, inputs, hidden, seq_len, layer.weight_ih_l0, layer.weight_hh_l0,
-                                 layer.bias_ih_l0, layer.bias_hh_l0)
+                                 layer.bias_ih_l0, layer.bias_hh_l0, None, None, layout)
 
     def _unsupported(self):
         layer = self.layer
@@ -330,8 +346,10 @@ class RecurrentCuDNNWrapper(nn.Module):
             return self.forward(inputs, hidden, None)
         return (self._run_gru if self._hip_gru() else self._run_lstm)(inputs.contiguous(), hidden, None)
 
-    def forward(self, inputs, hidden=None, seq_len=None, max_len=None):
-        """``max_len`` (not in the reference): the caller's upper bound on ``max(seq_len)``, normally the padded frame axis of the
+    def forward(self, inputs, hidden=None, seq_len=None, max_len=None, layout=None):
+        """``layout`` (not in the reference): the batch's ``FrameLayout`` - a GRU layer's weight gradients then multiply the valid
+        frames only (the reference gets the same from ``pack_padded_sequence``, utils.py:366-385); results unchanged.
+        ``max_len`` (not in the reference): the caller's upper bound on ``max(seq_len)``, normally the padded frame axis of the
         batch.  The reference crops the output to the longest item (``pad_packed_sequence``, utils.py:383), which costs a
         device -> host read of ``seq_len`` per call; when the input's time axis already equals ``max_len`` - every batch whose longest
         utterance defines its padding, i.e. every batch ``collate_fn`` builds - the result is identical without that read, and the
@@ -360,9 +378,11 @@ class RecurrentCuDNNWrapper(nn.Module):
         else:
             t_out = int(torch.max(seq_len).item())          # pad_packed_sequence crops to the longest item
         if isinstance(inputs, PhoneTable):
-            return self._run_gru(inputs.crop(t_out), hidden, seq_len.contiguous())
+            return self._run_gru(inputs.crop(t_out), hidden, seq_len.contiguous(), layout)
         if t_out != inputs.shape[1]:
             inputs = inputs[:, :t_out]
+        if self._hip_gru():
+            return self._run_gru(inputs.contiguous(), hidden, seq_len.contiguous(), layout)
         return run(inputs.contiguous(), hidden, seq_len.contiguous())
 
 
@@ -610,7 +630,7 @@ class SequentialWithRecurrent(nn.Sequential):
                     continue
 
             if isinstance(module, RecurrentCuDNNWrapper):
-                input, hiddens[i] = module(input, hiddens[i], seq_len, max_len=max_len)
+                input, hiddens[i] = module(input, hiddens[i], seq_len, max_len=max_len, layout=layout)
                 zero_padded = seq_len is not None
             elif isinstance(module, nn.RNNBase):
                 # a bare recurrent layer in the container (utils.py:412-413): every item runs the full padded length

@@ -541,6 +541,35 @@ def test_l2tail_rows_kernel_vs_unfused_pair():
     assert got_loss.item() == loss.item() and loss.item() != loss_before.item()
 
 
+@pytest.mark.parametrize('n,k,total', [(1536, 512, 9000), (384, 500, 4100), (1536, 512, 73613)])
+def test_wgrad_with_both_operands_gathered(n, k, total):
+    """mg_linear_wgrad_rows_bf16 (dW = sum_i dY[dy_rows[i]]^T A[rows[i]]: a recurrent layer's weight gradients over the valid frames of a
+    ragged batch, picked out of padded (B, T) / (B, T + 1) arrays) against mg_linear_wgrad_bf16 on explicitly gathered copies: the same
+    products in the same order -> EQUAL; and against a float64 product of the gathered operands."""
+    rng = np.random.RandomState(total)
+    b, t = 16, (total // 16) * 2
+    lens = rng.randint(1, t + 1, size=b)
+    lens[-1] = t
+    while lens.sum() < total:
+        lens[rng.randint(b)] = t
+    dense = np.concatenate([bb * t + np.arange(lens[bb]) for bb in range(b)])[:total].astype(np.int32)
+    state = (dense + dense // t).astype(np.int32)
+    dy = ops.cast_pad_bf16(dev((rng.standard_normal((b * t, n)) * 0.05).astype(np.float32)))
+    a = ops.cast_pad_bf16(dev(rng.uniform(-1, 1, (b * (t + 1), k)).astype(np.float32)))
+    assert ops.wgrad_rows_ok(total, n, k, a.shape[1], dy.shape[1])
+    dyr, ar = dev(dense), dev(state)
+    got_w, got_b = ops.linear_wgrad_rows_bf16(dy, dyr, a, ar, total, n, k)
+    dy_g, a_g = dy[dyr.long()].contiguous(), a[ar.long()].contiguous()
+    want_w, want_b = ops.linear_wgrad_bf16(dy_g, a_g, None, total, n, k)
+    assert torch.equal(got_w, want_w) and torch.equal(got_b, want_b)
+    ref = dy_g.double().t() @ a_g.double()[:, :k]
+    assert np.linalg.norm(got_w.cpu().numpy() - ref.cpu().numpy()) / np.linalg.norm(ref.cpu().numpy()) < 1e-5
+    # rows omitted: the A operand takes the dY row indices (a layer input stored like its gate gradients)
+    got_same, _ = ops.linear_wgrad_rows_bf16(dy, dyr, a, None, total, n, k)
+    want_same, _ = ops.linear_wgrad_bf16(dy_g, a[dyr.long()].contiguous(), None, total, n, k)
+    assert torch.equal(got_same, want_same)
+
+
 @pytest.mark.parametrize('m', [21504, 21377, 8192, 30001, 4100])
 def test_wgrad_dgrad_pair_equals_the_two_launches(m):
     """mg_linear_wgrad_dgrad_bf16 (one grid for a layer's weight-gradient slabs and the dgrad + sigmoid backward below it) against the
