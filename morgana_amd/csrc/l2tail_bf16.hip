@@ -78,16 +78,29 @@ __global__ __launch_bounds__(256, 1) void f0_l2tail_kernel(const uint16_t* __res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mi = lane & 31, lh = lane >> 5;
 #ifdef MG_STAMPS
-    unsigned long long ts0, ts1, ts2, ts3, tr0, tr1, ta = 0, tb = 0, tc = 0;
+    unsigned long long ts0, ts1, ts2, ts3, tr0, tr1, ta = 0, tb = 0, tc = 0, tp1 = 0, tp2 = 0, tp3 = 0, tp4 = 0, tp5 = 0;
     MG_STAMP(ts0);
     MG_STAMP_REAL(tr0);
 #endif
 
     // The loads of the one-time tables go out first, the first tile's rows and scalars behind them and the LDS-DMA of W2 last (vector
-    // memory returns in issue order): the W3 staging below waits for its own sixteen loads only, everything else lands meanwhile.
-    float w3v[16];
+    // memory returns in issue order).
+    // The two permuted W3 fragment tables are gathered straight from W3 (fp32 [32][128], 16 KB, L2 resident): per thread two
+    // fragments of each table - for a Z3 fragment two runs of four consecutive floats, for a dH2 fragment eight floats of one column.
+    // (They were built in LDS from a staged bf16 copy: sixteen loads, a cast pass, a barrier and 32 two-byte LDS reads per thread -
+    // 5,000 cycles of the 19,000-cycle prologue, stamps of round 3.)
+    f32x4 w3a[2][2];
+    float w3b[2][8];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) w3v[i] = W3[tid + 256 * i];
+    for (int i = 0; i < 2; ++i) {
+        const int f = tid + 256 * i, l = f & 63, r = l & 31, h = l >> 5, g = (f >> 6) & 7;
+        // Z3 fragment [st = g][lane l]: element j = W3[r][16 g + 8 (j >> 2) + 4 h + (j & 3)]
+        w3a[i][0] = *reinterpret_cast<const f32x4*>(W3 + r * LT_N2 + 16 * g + 4 * h);
+        w3a[i][1] = *reinterpret_cast<const f32x4*>(W3 + r * LT_N2 + 16 * g + 8 + 4 * h);
+        // dH2 fragment [kt = g >> 1][s = g & 1][lane l]: element j = W3[16 (g & 1) + 8 (j >> 2) + 4 h + (j & 3)][32 (g >> 1) + r]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w3b[i][j] = W3[(16 * (g & 1) + 8 * (j >> 2) + 4 * h + (j & 3)) * LT_N2 + 32 * (g >> 1) + r];
+    }
     const float b2v = tid < LT_N2 ? b2[tid] : 0.f;
 
     unsigned char* patch = smem + LT_WAVE0 + wave * LT_WAVE_BYTES;
@@ -191,32 +204,30 @@ __global__ __launch_bounds__(256, 1) void f0_l2tail_kernel(const uint16_t* __res
     // store pairs cost ~15 us per launch, batches of eight loads in front of eight stores still four trips to L2 - and at the
     // phone-rate row count the whole kernel is one tile per wave behind this prologue.)
     {
-        unsigned short* w3s = reinterpret_cast<unsigned short*>(smem + LT_WAVE0);       // W3 as bf16 [32][128], staged in the patches
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
             const int n = wave * 32 + i;
             mg_glds16(W2 + (size_t)n * ldw2 + ((lane ^ (n & 15)) << 3), smem + LT_W2 + n * (LT_K * 2));
         }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) w3s[tid + 256 * i] = mg_f2bf(w3v[i]);
+        MG_STAMP(tp1);
         if (tid < LT_N2) *reinterpret_cast<float*>(smem + LT_B2 + tid * 4) = b2v;
-        __syncthreads();
-        // fragment f = tid + 256 i: f < 512 -> Z3 fragments [st = 2 blk + s][lane]: element j = W3[lane & 31][unit of B slot j];
-        //                           f >= 512 -> dH2 fragments [kt][s][lane]: element j = W3[unit3 of slot j][32 kt + (lane & 31)]
+        MG_STAMP(tp2);
+        MG_STAMP(tp3);
+        // fragment f = tid + 256 i -> Z3 table [st = 2 blk + s][lane]; fragment 512 + f -> dH2 table [kt][s][lane]
+        typedef __bf16 bfv2_ __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = tid + 256 * i, l = f & 63, r = l & 31, h = l >> 5, g = (f >> 6) & 7;
-            unsigned short el[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int u = 8 * (j >> 2) + 4 * h + (j & 3);                             // slot j of lane half h inside a 16-unit step
-                el[j] = (f < 512) ? w3s[r * LT_N2 + 16 * g + u] : w3s[(16 * (g & 1) + u) * LT_N2 + 32 * (g >> 1) + r];
-            }
-            *reinterpret_cast<u32x4*>(smem + LT_ZF + f * 16) = u32x4{el[0] | ((unsigned)el[1] << 16), el[2] | ((unsigned)el[3] << 16),
-                                                                   el[4] | ((unsigned)el[5] << 16), el[6] | ((unsigned)el[7] << 16)};
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i;
+            auto pk = [](float a, float b) { return __builtin_bit_cast(unsigned int, bfv2_{(__bf16)a, (__bf16)b}); };
+            *reinterpret_cast<u32x4*>(smem + LT_ZF + f * 16) =
+                u32x4{pk(w3a[i][0][0], w3a[i][0][1]), pk(w3a[i][0][2], w3a[i][0][3]), pk(w3a[i][1][0], w3a[i][1][1]), pk(w3a[i][1][2], w3a[i][1][3])};
+            *reinterpret_cast<u32x4*>(smem + LT_ZF + (512 + f) * 16) =
+                u32x4{pk(w3b[i][0], w3b[i][1]), pk(w3b[i][2], w3b[i][3]), pk(w3b[i][4], w3b[i][5]), pk(w3b[i][6], w3b[i][7])};
         }
+        MG_STAMP(tp4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's rows of W2 have landed (the compiler does not count the DMAs)
-        __syncthreads();                                   // the staged W3 is done with: its bytes become the waves' patches
+        MG_STAMP(tp5);
+        __syncthreads();                                   // W2, the fragment tables and b2 are in place for every wave
     }
 
     bias_acc();
@@ -474,6 +485,12 @@ __global__ __launch_bounds__(256, 1) void f0_l2tail_kernel(const uint16_t* __res
     MG_STAMP_STORE(g_stamps_lt, blockIdx.x, wave, lane, 5, tr1);
     MG_STAMP_STORE(g_stamps_lt, blockIdx.x, wave, lane, 6, tb - ta);      // first tile: loop top -> layer-2 MFMAs issued
     MG_STAMP_STORE(g_stamps_lt, blockIdx.x, wave, lane, 7, tc - tb);      // first tile: the tail (sigmoid .. dW3)
+    MG_STAMP_STORE(g_stamps_lt, blockIdx.x, wave, lane, 8, tp1 - ts0);    // prologue: every load and the W2 DMA issued
+    MG_STAMP_STORE(g_stamps_lt, blockIdx.x, wave, lane, 9, tp2 - tp1);    //           W3 landed, cast, staged
+    MG_STAMP_STORE(g_stamps_lt, blockIdx.x, wave, lane, 10, tp3 - tp2);   //           barrier
+    MG_STAMP_STORE(g_stamps_lt, blockIdx.x, wave, lane, 11, tp4 - tp3);   //           fragment tables
+    MG_STAMP_STORE(g_stamps_lt, blockIdx.x, wave, lane, 12, tp5 - tp4);   //           rest of the DMA / first tile
+    MG_STAMP_STORE(g_stamps_lt, blockIdx.x, wave, lane, 13, ts1 - tp5);   //           barrier + bias
 #endif
 }
 

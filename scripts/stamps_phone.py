@@ -64,7 +64,10 @@ def main():
     print('f0_l2tail_kernel: workgroup starts spread over %.2f us, ends over %.2f us; first start -> last end %.2f us' % (
         (t_start.max() - t_start.min()) / 100.0, (t_end.max() - t_end.min()) / 100.0, (t_end.max() - t_start.min()) / 100.0))
     report('f0_l2tail_kernel at phone rate (168 workgroups, one tile per wave; "main loop" = the tile, "entry" = the prologue)', s,
-           [('  tile: loop top -> layer-2 MFMAs issued', s[..., 6]), ('  tile: the tail (sigmoid .. dW3)', s[..., 7])])
+           [('  tile: loop top -> layer-2 MFMAs issued', s[..., 6]), ('  tile: the tail (sigmoid .. dW3)', s[..., 7]),
+            ('  prologue: loads + W2 DMA issued', s[..., 8]), ('  prologue: W3 landed, cast, staged', s[..., 9]),
+            ('  prologue: barrier', s[..., 10]), ('  prologue: fragment tables', s[..., 11]),
+            ('  prologue: rest of DMA / first tile landed', s[..., 12]), ('  prologue: barrier + bias', s[..., 13])])
 
 
 if __name__ == '__main__':
