@@ -1327,6 +1327,15 @@ int mg_wgrad_big_plan(int64_t M, int N, int K, int lda, int lddy, int* S_out, in
     // N = 128 at frame-rate row counts (M = 256 000, K = 512): 192 splits of ~1 334 rows beat one split per CU - a quarter less slab
     // traffic (50 vs 67 MB written and read again by the reduce): 89.5 -> 80 us with the reduce (sweep 144 .. 512, scripts/kbench.py wgrad2)
     if (M > 32768 && tiles_n == 1) S = 192;
+    // An n-tile count that does not divide the chip (N = 1536, a GRU's three gates: 12 tiles) at the row count of a whole batch of
+    // frames: rounded up to a multiple of 8 the splits overshoot one workgroup per CU (24 x 12 = 288) and the 32 left over run as a second
+    // round - 231 us for the 64 000 x 1536 x 512 recurrent weight gradient of C4 where 21 splits (252 workgroups, no XCD grouping)
+    // take one round.  The largest split count that still fits one round, unaligned.
+    bool one_round = false;
+    if (M > 32768 && tiles_n > 1 && !wgrad_ksplit(M, N, lda) && (int64_t)mg_align_up((size_t)S, 8) * tiles_n > 256 && tiles_n <= 128) {
+        S = 256 / tiles_n;
+        one_round = true;
+    }
     // experiments: a split count for every plan (< 1000), for the one-n-tile plans only (1000 + S) or for the plans of 4+ n tiles (2000 + S)
     const int ts = g_mg_tuning[MG_TUNE_WGRAD_SPLITS];
     if (ts > 0 && ts < 1000) S = ts;
@@ -1337,7 +1346,8 @@ int mg_wgrad_big_plan(int64_t M, int N, int K, int lda, int lddy, int* S_out, in
         S *= 2;
         m_chunk = mg_align_up((size_t)mg_ceil_div(M, S), 32);
     }
-    S = mg_align_up((size_t)mg_ceil_div(M, m_chunk), 8);       // multiple of 8: one split per XCD and round
+    S = mg_ceil_div(M, m_chunk);
+    if (!one_round) S = mg_align_up((size_t)S, 8);             // multiple of 8: one split per XCD and round
     if (S > 65535) return 0;
     *S_out = (int)S;
     *m_chunk_out = (int)m_chunk;
