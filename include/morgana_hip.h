@@ -517,6 +517,12 @@ int mg_gru_persist_status(void* workspace, void* stream);
 int mg_gru_fwd_persist_bf16(const float* xproj, const uint16_t* w_hh_bf, int ldw, const float* b_hh, const int64_t* seq_len, int B,
                             int T, int H, float* hstate, uint16_t* hstate_bf, float* out, float* saved, void* workspace,
                             size_t workspace_bytes, void* stream);
+/* mg_gru_fwd_persist_bf16 with the input projections read through a row map: frame (b, t) takes row xrows[b * T + t] of the table xproj
+ * [n_rows, 3H] (int32, every entry in [0, n_rows)) - the repetition of upsample_to_repetitions (morgana/utils.py:175-228) applied
+ * inside the recurrence instead of to a [B, T, 3H] copy of the projected rows.  xrows NULL: xproj is [B, T, 3H] (the entry above). */
+int mg_gru_fwd_persist_rows_bf16(const float* xproj, const int32_t* xrows, int64_t n_rows, const uint16_t* w_hh_bf, int ldw, const float* b_hh,
+                                 const int64_t* seq_len, int B, int T, int H, float* hstate, uint16_t* hstate_bf, float* out, float* saved,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 /* backward: dxproj_bf (optional) = bf16 shadow of dxproj [B,T,3H]; dxproj and dhproj (both or neither) may be NULL when the caller
  * only needs the bf16 shadows (the weight- and input-gradient GEMMs of bf16 mode) - the fp32 arrays are then not written */
 int mg_gru_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const float* hstate, const float* saved,

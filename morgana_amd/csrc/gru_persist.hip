@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
                                                               const float* __restrict__ b_hh, const int64_t* __restrict__ seq_len,
                                                               int B, int T, int H, int R, float* __restrict__ hstate,
                                                               uint16_t* __restrict__ hstate_bf, float* __restrict__ out,
-                                                              float* __restrict__ saved, unsigned* sync, uint16_t* ring, int force_sc1) {
+                                                              float* __restrict__ saved, unsigned* sync, uint16_t* ring, int force_sc1,
+                                                              const int32_t* __restrict__ xrows) {
     __shared__ float red[4][3][MT][GT * GT];
     __shared__ __attribute__((aligned(16))) uint16_t hb[MT][GT][GT];
     __shared__ float res[MT][6][GT * GT];          // a step's fp32 results on their way to waves 2 and 3, which store them
@@ -96,6 +97,8 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
     int len[MT];
     bool mine[MT];
     const float* xp[MT];
+    const int32_t* xi[MT];
+    int xrow1[MT];                                 // table row of step t + 1 (xrows only)
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         mine[m] = 16 * m + bl < nrows;
@@ -103,10 +106,16 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
         hprev[m] = hstate[((size_t)b * (T + 1)) * H + j];
         len[m] = seq_len ? (int)min((int64_t)T, seq_len[b]) : T;
         hb[m][bl][jl] = mg_f2bf(hprev[m]);
-        xp[m] = xproj + (size_t)b * T * 3 * H + j;
-        xr[m] = xp[m][0];                        // input projections of step 0; step t + 1's are requested during step t
-        xz[m] = xp[m][H];
-        xn[m] = xp[m][2 * H];
+        // xrows: the input projections are a TABLE (one row per phone, upsample_to_repetitions' row map picks frame (b, t)'s row) - the
+        // recurrence reads the table through the map instead of a [B, T, 3H] copy of its rows written and read back once (393 MB at C4).
+        // The index of step t + 2 is requested during step t, the projections of step t + 1 through the index fetched a step before.
+        xi[m] = xrows ? xrows + (size_t)b * T : nullptr;
+        xp[m] = xrows ? xproj + j : xproj + (size_t)b * T * 3 * H + j;
+        const float* x0 = xrows ? xp[m] + (size_t)xi[m][0] * 3 * H : xp[m];
+        xrow1[m] = xrows ? xi[m][T > 1 ? 1 : 0] : 0;
+        xr[m] = x0[0];                           // input projections of step 0; step t + 1's are requested during step t
+        xz[m] = x0[H];
+        xn[m] = x0[2 * H];
     }
     __syncthreads();
 
@@ -161,13 +170,16 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
             for (int i = 0; i < KS; ++i) raw[m][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ring, off + i * rd_kstep, 0, 16);
         }
         float xr1[MT], xz1[MT], xn1[MT];
+        int xrow2[MT];
         const int t1 = t + 1 < T ? t + 1 : t;
+        const int t2 = t + 2 < T ? t + 2 : T - 1;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const float* x1 = xp[m] + (size_t)t1 * 3 * H;
+            const float* x1 = xrows ? xp[m] + (size_t)xrow1[m] * 3 * H : xp[m] + (size_t)t1 * 3 * H;
             xr1[m] = x1[0];
             xz1[m] = x1[H];
             xn1[m] = x1[2 * H];
+            xrow2[m] = xrows ? xi[m][t2] : 0;
         }
         __builtin_amdgcn_sched_barrier(0);          // every load in flight before the first MFMA waits (one round trip)
 #ifdef MG_STAMPS
@@ -245,6 +257,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
             xr[m] = xr1[m];
             xz[m] = xz1[m];
             xn[m] = xn1[m];
+            xrow1[m] = xrow2[m];
         }
     }
 #ifdef MG_STAMPS
@@ -934,7 +947,17 @@ int mg_gru_persist_status(void* workspace, void* stream) {
 int mg_gru_fwd_persist_bf16(const float* xproj, const uint16_t* w_hh_bf, int ldw, const float* b_hh, const int64_t* seq_len, int B, int T,
                             int H, float* hstate, uint16_t* hstate_bf, float* out, float* saved, void* workspace,
                             size_t workspace_bytes, void* stream) {
-    MG_CHECK_ARG(xproj && w_hh_bf && b_hh && hstate && hstate_bf && out && saved && B > 0 && T > 0 && H > 0,
+    return mg_gru_fwd_persist_rows_bf16(xproj, nullptr, 0, w_hh_bf, ldw, b_hh, seq_len, B, T, H, hstate, hstate_bf, out, saved, workspace,
+                                        workspace_bytes, stream);
+}
+
+// The same with the input projections read through a row map: frame (b, t) takes row xrows[b * T + t] of the table xproj
+// [n_rows, 3H] (every entry in [0, n_rows): the caller's map, e.g. upsample_to_repetitions' with the padding frames on a zero row).
+// xrows == NULL: xproj is [B, T, 3H] itself.
+int mg_gru_fwd_persist_rows_bf16(const float* xproj, const int32_t* xrows, int64_t n_rows, const uint16_t* w_hh_bf, int ldw, const float* b_hh,
+                                 const int64_t* seq_len, int B, int T, int H, float* hstate, uint16_t* hstate_bf, float* out, float* saved,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    MG_CHECK_ARG(xproj && w_hh_bf && b_hh && hstate && hstate_bf && out && saved && B > 0 && T > 0 && H > 0 && (!xrows || n_rows > 0),
                  "mg_gru_fwd_persist_bf16: bad arguments (B=%d T=%d H=%d)", B, T, H);
     MG_CHECK_ARG(mg_gru_persist_supported(B, T, H) && ldw >= H && ldw % 8 == 0,
                  "mg_gru_fwd_persist_bf16: unsupported shape (B=%d T=%d H=%d ldw=%d): needs H %% 128 == 0, H <= 512, B <= 256", B, T, H, ldw);
@@ -953,7 +976,7 @@ int mg_gru_fwd_persist_bf16(const float* xproj, const uint16_t* w_hh_bf, int ldw
     const unsigned grid = (unsigned)(GP_GROUPS * (H / GT));
 #define GP_FWD(MT, KS)                                                                                                                  \
     hipLaunchKernelGGL((gru_fwd_persist_kernel<MT, KS>), dim3(grid), dim3(256), 0, st, xproj, w_hh_bf, ldw, b_hh, seq_len, B, T, H, R, hstate, \
-                       hstate_bf, out, saved, (unsigned*)workspace, (uint16_t*)((char*)workspace + GP_RING_OFFSET), g_mg_tuning[MG_TUNE_GRU_HANDOFF] == 1)
+                       hstate_bf, out, saved, (unsigned*)workspace, (uint16_t*)((char*)workspace + GP_RING_OFFSET), g_mg_tuning[MG_TUNE_GRU_HANDOFF] == 1, xrows)
 #define GP_FWD_KS(MT)            \
     switch (H / 128) {           \
         case 1: GP_FWD(MT, 1); break; \

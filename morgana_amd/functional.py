@@ -666,11 +666,16 @@ class GRUFn(torch.autograd.Function):
                                         ops.ACT_NONE, out_f32=True)
             if xproj.shape[1] != 3 * hid:
                 xproj = xproj[:, :3 * hid].contiguous()
-        if rows is not None:
-            xproj = ops.gather_rows(xproj, rows.reshape(-1))          # the repetition, applied to the projected rows
         ctx.bf16_recurrence = precision == 'bf16' and RECURRENCE_BF16 and ops.gru_bf16_ok(hid)
+        in_kernel = rows is not None and ctx.bf16_recurrence and ops.gru_persist_ok(b, t, hid)
+        if rows is not None and not in_kernel:
+            xproj = ops.gather_rows(xproj, rows.reshape(-1))          # the repetition, applied to the projected rows
         hstate_bf = None
-        if ctx.bf16_recurrence:
+        if in_kernel:
+            # the persistent recurrence reads the projected table through the row map itself: no (B, T, 3H) copy of its rows
+            out, hstate, saved, hstate_bf = ops.gru_fwd_bf16(xproj.contiguous(), w_hh.contiguous(), b_hh.contiguous(), seq_len, h0, b, t, hid,
+                                                             xrows=rows)
+        elif ctx.bf16_recurrence:
             out, hstate, saved, hstate_bf = ops.gru_fwd_bf16(xproj.view(b, t, 3 * hid), w_hh.contiguous(), b_hh.contiguous(),
                                                              seq_len, h0, b, t, hid)
         else:

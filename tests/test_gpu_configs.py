@@ -143,6 +143,36 @@ def test_c4_persistent_recurrence_equals_step_kernels_at_t1000():
     assert torch.isfinite(dx_p).all()
 
 
+def test_persistent_gru_reads_its_input_projections_through_a_row_map():
+    """mg_gru_fwd_persist_rows_bf16 (the recurrence takes frame (b, t)'s input projection from row xrows[b, t] of a phone-level table:
+    upsample_to_repetitions applied inside the launch) against the same launch on the explicitly repeated rows: EQUAL in every output.
+    Ragged lengths, a table with runs of 1-30 frames per row and a shared zero row for the padding frames."""
+    b, t, hid = 24, 300, 512
+    rng = np.random.RandomState(7)
+    n_rows = 700
+    table = dev(rng.standard_normal((n_rows + 1, 3 * hid)).astype(np.float32))
+    table[n_rows].zero_()
+    lens = rng.randint(1, t + 1, size=b)
+    lens[0] = t
+    rows_np = np.full((b, t), n_rows, dtype=np.int32)
+    for i in range(b):
+        reps = rng.randint(1, 31, size=t)
+        ids = np.repeat(rng.randint(0, n_rows, size=t), reps)[:lens[i]]
+        rows_np[i, :lens[i]] = ids
+    rows, sl = dev(rows_np), dev(lens.astype(np.int64))
+    w_hh = dev((rng.uniform(-1, 1, (3 * hid, hid)) / np.sqrt(hid)).astype(np.float32))
+    b_hh = dev(rng.uniform(-0.1, 0.1, 3 * hid).astype(np.float32))
+    assert ops.gru_persist_ok(b, t, hid)
+    dense = table[rows.reshape(-1).long()].view(b, t, 3 * hid).contiguous()
+    want = ops.gru_fwd_bf16(dense, w_hh, b_hh, sl, None, b, t, hid, persistent=True)
+    got = ops.gru_fwd_bf16(table, w_hh, b_hh, sl, None, b, t, hid, persistent=True, xrows=rows)
+    ops.check_persistent_status()
+    valid = dev((np.arange(t)[None, :] < lens[:, None])[:, :, None])
+    zero = torch.zeros((), device=DEV)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and torch.equal(got[3], want[3])
+    assert torch.equal(torch.where(valid, got[2], zero), torch.where(valid, want[2], zero))
+
+
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
 def test_c4_model_t1000_vs_oracle(precision):
     """The C4 model (600 -> 512 -> GRU-512 -> 256 -> 80) on 8 fixed-length 1000-frame utterances (C4's chain length; a smaller batch
