@@ -49,7 +49,7 @@ def parse_args():
     ap.add_argument('--no-generate', action='store_true',
                     help='lstm / f0gru: leave out the MLPG + metrics part of the step (the reference runs it inside predict / loss)')
     ap.add_argument('--steps-per-replay', type=int, default=0,
-                    help='C2: training steps captured into one HIP graph (0 = the largest divisor of --steps up to 10)')
+                    help='C2: training steps captured into one HIP graph (0 = the largest divisor of --steps up to 25)')
     ap.add_argument('--no-graph', action='store_true',
                     help='c2: launch every kernel of the step from Python instead of replaying the captured HIP graph')
     ap.add_argument('--no-compare', action='store_true',
@@ -659,7 +659,7 @@ def main():
     if args.config == 'c2' and not args.no_graph:
         # K steps per graph: the idle time between two graph launches (8-9 us) and the launch that stages Adam's step-dependent
         # scalars (4.7 us) are then paid once per K steps; every step still does all of its work (morgana_amd/graphs.py)
-        want_k = args.steps_per_replay or max(k for k in range(1, min(10, args.steps) + 1) if args.steps % k == 0)
+        want_k = args.steps_per_replay or max(k for k in range(1, min(25, args.steps) + 1) if args.steps % k == 0)
         if args.steps % want_k:
             raise SystemExit('--steps-per-replay must divide --steps')
         from morgana_amd import graphs
