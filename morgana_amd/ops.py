@@ -403,10 +403,15 @@ def linear_dgrad_bf16(dy, m, n, wt_bf16, k, h, out_f32=False):
 def linear_wgrad_bf16(dy, a, rows, m, n, k, want_bias=True, out_w=None, out_b=None, accumulate=False):
     """out_w / out_b: optional preallocated fp32 destinations (e.g. slices of one gradient buffer); accumulate adds into them."""
     lib = _lib.load()
-    dw = out_w if out_w is not None else torch.empty((n, k), dtype=torch.float32, device=dy.device)
-    db = None
-    if want_bias:
-        db = out_b if out_b is not None else torch.empty((n,), dtype=torch.float32, device=dy.device)
+    if out_w is None and out_b is None and want_bias:
+        # db right behind dW in one buffer: the wide-tile path then finishes both with ONE reduce launch (a slab is [dW | db])
+        both = torch.empty((n * k + n,), dtype=torch.float32, device=dy.device)
+        dw, db = both[:n * k].view(n, k), both[n * k:]
+    else:
+        dw = out_w if out_w is not None else torch.empty((n, k), dtype=torch.float32, device=dy.device)
+        db = None
+        if want_bias:
+            db = out_b if out_b is not None else torch.empty((n,), dtype=torch.float32, device=dy.device)
     nbytes = lib.mg_linear_wgrad_workspace_bytes(m, n, k)
     ws = workspace(nbytes, dy.device)
     _lib.check(lib.mg_linear_wgrad_bf16(_p(dy), dy.shape[1], _p(a), a.shape[1], _p(rows), m, n, k, _p(dw), _p(db), int(bool(accumulate)),
@@ -426,8 +431,11 @@ def linear_wgrad_rows_bf16(dy, dy_rows, a, rows, m, n, k, want_bias=True):
     index pairs only (``dy_rows`` int32, every entry a valid row of ``dy``)."""
     lib = _lib.load()
     dy_rows = _require(dy_rows, torch.int32, 'dy_rows')
-    dw = torch.empty((n, k), dtype=torch.float32, device=dy.device)
-    db = torch.empty((n,), dtype=torch.float32, device=dy.device) if want_bias else None
+    if want_bias:                                  # db right behind dW: one reduce launch for both
+        both = torch.empty((n * k + n,), dtype=torch.float32, device=dy.device)
+        dw, db = both[:n * k].view(n, k), both[n * k:]
+    else:
+        dw, db = torch.empty((n, k), dtype=torch.float32, device=dy.device), None
     nbytes = lib.mg_linear_wgrad_workspace_bytes(m, n, k)
     ws = workspace(nbytes, dy.device)
     _lib.check(lib.mg_linear_wgrad_rows_bf16(_p(dy), dy.shape[1], _p(dy_rows), _p(a), a.shape[1], _p(rows), m, n, k, _p(dw), _p(db), 0,
