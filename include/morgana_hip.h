@@ -649,6 +649,10 @@ int mg_gru_stack_small_supported(int B, int T, int H, int L);
 size_t mg_gru_stack_small_workspace_bytes(void);
 int mg_gru_stack_fwd_small_f32(const mg_gru_stack_layer* layers, int L, const int64_t* seq_len, int B, int T, int H, void* workspace,
                                size_t workspace_bytes, void* stream);
+/* mg_gru_stack_fwd_small_f32 with the cell's sigmoid / tanh on v_exp_f32 / v_rcp_f32 (throughput mode, as the bf16-mode GRU-512
+ * recurrence); products exact fp32, same arguments, same backward launch. */
+int mg_gru_stack_fwd_small_fast_f32(const mg_gru_stack_layer* layers, int L, const int64_t* seq_len, int B, int T, int H, void* workspace,
+                                    size_t workspace_bytes, void* stream);
 int mg_gru_stack_bwd_small_f32(const mg_gru_stack_layer* layers, int L, const int64_t* seq_len, int B, int T, int H, void* workspace,
                                size_t workspace_bytes, void* stream);
 

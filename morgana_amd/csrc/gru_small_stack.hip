@@ -39,6 +39,9 @@ __device__ __forceinline__ float gss_take(float v, const float* p, bool& dead, g
     return 0.f;
 }
 
+// FAST (throughput mode, mg_gru_stack_fwd_small_fast_f32): the cell's sigmoids and tanh on v_exp_f32 / v_rcp_f32 as in the bf16-mode
+// GRU-512 recurrence (gru_cell.h) instead of expf / tanhf - the library calls are ~150 instructions of the step's dependent chain.
+template <bool FAST>
 __global__ __launch_bounds__(256) void gru_stack_fwd_small64_kernel(GssLayers a, const int64_t* __restrict__ seq_len, int B, int T, int L,
                                                                     int nblk, unsigned* sync) {
     constexpr int H = 64, G = 192, R = 4, LDH = H + 4, LDG = G + 4;
@@ -130,9 +133,9 @@ __global__ __launch_bounds__(256) void gru_stack_fwd_small64_kernel(GssLayers a,
         if (mine) {
             if (upper) xr = gx[er][ej] + bir, xz = gx[er][H + ej] + biz, xn = gx[er][2 * H + ej] + bin;
             const float hr = gl[er][ej] + bhr, hz = gl[er][H + ej] + bhz, hn = gl[er][2 * H + ej] + bhn;
-            const float r = mg_sigmoid(xr + hr);
-            const float z = mg_sigmoid(xz + hz);
-            const float n = tanhf(xn + r * hn);
+            const float r = FAST ? mg_sigmoid_fast(xr + hr) : mg_sigmoid(xr + hr);
+            const float z = FAST ? mg_sigmoid_fast(xz + hz) : mg_sigmoid(xz + hz);
+            const float n = FAST ? 2.f * mg_sigmoid_fast(2.f * (xn + r * hn)) - 1.f : tanhf(xn + r * hn);
             const float hnew = (1.f - z) * n + z * hprev;
             const bool active = t < len;
             hprev = active ? hnew : hprev;
@@ -314,8 +317,23 @@ static int gss_check(const char* who, const mg_gru_stack_layer* layers, int L, i
     return MG_OK;
 }
 
+static int gss_fwd(const mg_gru_stack_layer* layers, int L, const int64_t* seq_len, int B, int T, int H, void* workspace,
+                   size_t workspace_bytes, void* stream, bool fast);
+
 int mg_gru_stack_fwd_small_f32(const mg_gru_stack_layer* layers, int L, const int64_t* seq_len, int B, int T, int H, void* workspace,
                                size_t workspace_bytes, void* stream) {
+    return gss_fwd(layers, L, seq_len, B, T, H, workspace, workspace_bytes, stream, false);
+}
+
+// The same wavefront with the cell's sigmoid / tanh on the hardware's exp and reciprocal (1 ulp each): the throughput-mode ("bf16"
+// precision) form; matrix products stay exact fp32.  The backward launch is the same for both (it works from the saved gates).
+int mg_gru_stack_fwd_small_fast_f32(const mg_gru_stack_layer* layers, int L, const int64_t* seq_len, int B, int T, int H, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    return gss_fwd(layers, L, seq_len, B, T, H, workspace, workspace_bytes, stream, true);
+}
+
+static int gss_fwd(const mg_gru_stack_layer* layers, int L, const int64_t* seq_len, int B, int T, int H, void* workspace,
+                   size_t workspace_bytes, void* stream, bool fast) {
     const int rc = gss_check("mg_gru_stack_fwd_small_f32", layers, L, B, T, H, workspace, workspace_bytes);
     if (rc != MG_OK) return rc;
     GssLayers a;
@@ -333,7 +351,10 @@ int mg_gru_stack_fwd_small_f32(const mg_gru_stack_layer* layers, int L, const in
         }
     }
     const int nblk = (int)mg_ceil_div(B, 4);
-    hipLaunchKernelGGL(gru_stack_fwd_small64_kernel, dim3((unsigned)(L * nblk)), dim3(256), 0, st, a, seq_len, B, T, L, nblk, (unsigned*)workspace);
+    if (fast)
+        hipLaunchKernelGGL(gru_stack_fwd_small64_kernel<true>, dim3((unsigned)(L * nblk)), dim3(256), 0, st, a, seq_len, B, T, L, nblk, (unsigned*)workspace);
+    else
+        hipLaunchKernelGGL(gru_stack_fwd_small64_kernel<false>, dim3((unsigned)(L * nblk)), dim3(256), 0, st, a, seq_len, B, T, L, nblk, (unsigned*)workspace);
     MG_CHECK_LAUNCH("mg_gru_stack_fwd_small_f32");
     return MG_OK;
 }

@@ -792,7 +792,9 @@ class GRUStackSmallFn(torch.autograd.Function):
                                          out_f32=True)
             if xproj0.shape[1] != 3 * hid:
                 xproj0 = xproj0[:, :3 * hid].contiguous()
-        outs, hstates, saveds = ops.gru_stack_small_fwd(xproj0.view(b, t, 3 * hid), w_ih, w_hh, b_ih, b_hh, seq_len, h0s, b, t, hid)
+        # throughput mode: the cell's transcendentals on v_exp / v_rcp, as the bf16-mode GRU-512 recurrence (the products stay exact fp32)
+        outs, hstates, saveds = ops.gru_stack_small_fwd(xproj0.view(b, t, 3 * hid), w_ih, w_hh, b_ih, b_hh, seq_len, h0s, b, t, hid,
+                                                        fast=precision == 'bf16' and RECURRENCE_BF16)
         ctx.precision = precision
         ctx.shape = (b, t, i_dim, hid, n_layers)
         ctx.has_h0 = h0s is not None

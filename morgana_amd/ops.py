@@ -1104,9 +1104,10 @@ def _gru_stack_workspace(dev):
     return ws
 
 
-def gru_stack_small_fwd(xproj0, w_ih, w_hh, b_ih, b_hh, seq_len, h0s, b, t, h):
+def gru_stack_small_fwd(xproj0, w_ih, w_hh, b_ih, b_hh, seq_len, h0s, b, t, h, fast=False):
     """L stacked small GRU layers forward in one launch.  xproj0 (b,t,3h) f32 = layer 0's input projection incl. b_ih; w_ih[l], b_ih[l]
-    for l >= 1 (input size == h); h0s None or (L,b,h).  Returns per-layer lists (out, hstate, saved)."""
+    for l >= 1 (input size == h); h0s None or (L,b,h).  Returns per-layer lists (out, hstate, saved).
+    fast: the cell's sigmoid / tanh on the hardware exp / reciprocal (mg_gru_stack_fwd_small_fast_f32: throughput mode)."""
     lib = _lib.load()
     dev = xproj0.device
     n_layers = len(w_hh)
@@ -1129,8 +1130,9 @@ def gru_stack_small_fwd(xproj0, w_ih, w_hh, b_ih, b_hh, seq_len, h0s, b, t, h):
         d.hstate, d.out, d.saved = hs.data_ptr(), o.data_ptr(), sv.data_ptr()
         outs.append(o); hstates.append(hs); saveds.append(sv)
     ws = _gru_stack_workspace(dev)
-    _lib.check(lib.mg_gru_stack_fwd_small_f32(ctypes.cast(descs, ctypes.c_void_p), n_layers, _p(seq_len), b, t, h, _p(ws), ws.numel(),
-                                              _stream()), 'mg_gru_stack_fwd_small_f32')
+    entry = lib.mg_gru_stack_fwd_small_fast_f32 if fast else lib.mg_gru_stack_fwd_small_f32
+    _lib.check(entry(ctypes.cast(descs, ctypes.c_void_p), n_layers, _p(seq_len), b, t, h, _p(ws), ws.numel(), _stream()),
+               'mg_gru_stack_fwd_small_fast_f32' if fast else 'mg_gru_stack_fwd_small_f32')
     return outs, hstates, saveds
 
 
