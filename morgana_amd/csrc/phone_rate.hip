@@ -244,8 +244,18 @@ __global__ __launch_bounds__(256) void expand_reduce_kernel(const float* __restr
     const int64_t i = base + e;
     float v = 0.f;
     if (i < n) {
+        // the partition's slabs in ascending order, their loads eight at a time (168 slabs at C2: 10-11 per partition - two round
+        // trips instead of three)
+        int s = p;
+        for (; s + 112 < S; s += 128) {
+            float t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = slab[(size_t)(s + 16 * q) * stride + i];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v += t[q];
+        }
 #pragma unroll 4
-        for (int s = p; s < S; s += 16) v += slab[(size_t)s * stride + i];
+        for (; s < S; s += 16) v += slab[(size_t)s * stride + i];
     }
     part[p][e] = v;
     const bool owns_loss = base <= n - 1 && n - 1 < base + 16;        // block-uniform
