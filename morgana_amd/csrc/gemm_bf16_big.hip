@@ -411,7 +411,7 @@ constexpr int ntp_lds_bytes() {
 
 // The tile program on a caller-provided LDS block, as workgroup `block_id` of `n_blocks` (gemm_nt_persist_kernel: the plain launch;
 // phone_front_gemm_kernel: behind the blocks of an unrelated small job).
-template <int BN, int EPI, bool STAG, int BK, int MODE = 0>
+template <int BN, int EPI, bool STAG, int BK, int MODE = 0, int BMV = 256>
 __device__ __forceinline__ void gemm_nt_persist_body(unsigned char* __restrict__ smem, const unsigned block_id, const unsigned n_blocks,
                                                      const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows, int64_t M,
                                                      int K, const uint16_t* __restrict__ Bm, int ldb, int N, const float* __restrict__ bias,
@@ -420,7 +420,11 @@ __device__ __forceinline__ void gemm_nt_persist_body(unsigned char* __restrict__
     constexpr int BM = 256;
     constexpr int WAVES_N = BN / 64;              // 4 or 2
     constexpr int WAVES_M = 8 / WAVES_N;          // 2 or 4
-    constexpr int WM = BM / WAVES_M;              // 128 or 64
+    // BMV: rows of a tile that hold output (256, or 192 = the square tile cut to three quarters so that the 21 504-row phone table of C2
+    // makes 224 one-tile workgroups instead of 168: the LDS stage keeps its 256 row slots, the last 64 are fed from the zero row and
+    // never read).  The GEMM alone: 30.4 -> 24.3 us at that shape.
+    static_assert(BMV == 256 || (BMV == 192 && BN == 256 && BK == 32 && MODE == 0 && !STAG), "192-row tiles: the plain square form only");
+    constexpr int WM = BMV / WAVES_M;             // 128, 96 or 64
     constexpr int TM = WM / 32, TN = 2;
     constexpr int ROWB = BK * 2;                  // bytes of a stage row: 64 or 128
     constexpr int KS = BK / 16;                   // 16-deep MFMA steps per stage: 2 or 4
@@ -475,9 +479,9 @@ __device__ __forceinline__ void gemm_nt_persist_body(unsigned char* __restrict__
     for (int e = tid; e < n_my * BM; e += 512) {
         int tm, tn;
         tile_of(e / BM, tm, tn);
-        const int64_t m = (int64_t)tm * BM + (e % BM);
+        const int64_t m = (int64_t)tm * BMV + (e % BM);
         int r = -1;
-        if (m < M) r = rows ? rows[m] : (int)m;
+        if (m < M && (e % BM) < BMV) r = rows ? rows[m] : (int)m;
         rowtab[e] = r;
     }
     __syncthreads();
@@ -655,7 +659,7 @@ __device__ __forceinline__ void gemm_nt_persist_body(unsigned char* __restrict__
     for (int ti = 0; ti < n_my; ++ti) {
         int tile_m, tile_n;
         tile_of(ti, tile_m, tile_n);
-        const int64_t m0 = (int64_t)tile_m * BM;
+        const int64_t m0 = (int64_t)tile_m * BMV;
         const int n0 = tile_n * BN;
         f32x16 acc[TM][TN];
 #pragma unroll
@@ -896,18 +900,24 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
 // the first layer's GEMM, which reads none of its outputs: blocks [0, side_blocks) run the jobs, the blocks behind them are the persistent tile program.  The GEMM of
 // C2's phone table has 168 tiles, one per workgroup and CU: the jobs take CUs it leaves idle and two launch boundaries disappear.
 // side_blocks is a multiple of 8 (the tile order derives a block's XCD from its id modulo 8).
-template <int EPI>
-__global__ __launch_bounds__(512) void phone_front_gemm_kernel(unsigned side_blocks, PhoneFrontArgs pf, const uint16_t* __restrict__ A, int lda,
+template <int EPI, int BMV = 256>
+__global__ __launch_bounds__(512) void phone_front_gemm_kernel(unsigned side_blocks, int wave_ints, PhoneFrontArgs pf, const uint16_t* __restrict__ A, int lda,
                                                                int64_t M, int K, const uint16_t* __restrict__ Bm, int ldb, int N,
                                                                const float* __restrict__ bias, uint16_t* __restrict__ C, int ldc, int tiles_m,
                                                                int tiles_n) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[ntp_lds_bytes<256, 32, 0>()];
     if (blockIdx.x < side_blocks) {
-        if (pf.lds_ints > 0) phone_front_block<512>(pf, blockIdx.x, side_blocks, reinterpret_cast<int*>(smem));
+        if (pf.lds_ints > 0) {
+            if (wave_ints > 0)       // wave jobs (phone_front.h): the block's eight waves each work off jobs of their own, no barrier
+                phone_front_wave_jobs(pf, (int)blockIdx.x * 8 + (int)(threadIdx.x >> 6), (int)side_blocks * 8,
+                                      reinterpret_cast<int*>(smem) + (threadIdx.x >> 6) * wave_ints);
+            else
+                phone_front_block<512>(pf, blockIdx.x, side_blocks, reinterpret_cast<int*>(smem));
+        }
         return;                                          // lds_ints == 0: timing probe, the rider's blocks leave at once
     }
     if (pf.probe & 8) return;
-    gemm_nt_persist_body<256, EPI, false, 32, 0>(smem, blockIdx.x - side_blocks, gridDim.x - side_blocks, A, lda, nullptr, M, K, Bm, ldb, N, bias, C,
+    gemm_nt_persist_body<256, EPI, false, 32, 0, BMV>(smem, blockIdx.x - side_blocks, gridDim.x - side_blocks, A, lda, nullptr, M, K, Bm, ldb, N, bias, C,
                                                  ldc, tiles_m, tiles_n, 0);
 }
 
@@ -1395,13 +1405,20 @@ int mg_launch_phone_front_gemm(const PhoneFrontArgs& pf, const uint16_t* A, int 
     if (epi != EPI_BIAS && epi != EPI_BIAS_SIGMOID) return 0;
     const int tiles_n = N / 256;
     if (32 % tiles_n != 0) return 0;
-    const int64_t tiles_m = mg_ceil_div(M, 256);
+    constexpr int LDS_INTS = ntp_lds_bytes<256, 32, 0>() / 4;
+    // The front's jobs as WAVE jobs where eight of them fit the block's LDS (phone_front.h): 32 rider blocks then work off C2's 512
+    // jobs under the GEMM, which can take 192-row tiles - 224 one-tile workgroups instead of 168 (one tile per workgroup and at least
+    // 32 CUs left over either way).  MG_TUNE_AB 94: block jobs and 256-row tiles (the form of round 2).
+    const int64_t wave_ints_need = phone_front_wave_ints(pf.B, pf.P, pf.T, pf.extra);
+    const int wave_ints = (g_mg_tuning[MG_TUNE_AB] != 94 && 8 * wave_ints_need <= LDS_INTS) ? (int)wave_ints_need : 0;
+    int bmv = 256;
+    if (wave_ints > 0 && g_mg_tuning[MG_TUNE_AB] != 95 && mg_ceil_div(mg_ceil_div(M, 192), 8) * 8 * tiles_n <= 224) bmv = 192;
+    const int64_t tiles_m = mg_ceil_div(M, bmv);
     const int64_t blocks = mg_ceil_div(tiles_m, 8) * 8 * tiles_n;
-    if (blocks > 224) return 0;                                       // one tile per workgroup and at least 32 CUs left over
+    if (blocks > 224) return 0;
     const int64_t g = mg_ceil_div(blocks, 8 * tiles_n) * 8 * tiles_n;
     const int side = (int)((256 - g) / 8 * 8);
     if (side < 32) return 0;
-    constexpr int LDS_INTS = ntp_lds_bytes<256, 32, 0>() / 4;
     if (phone_front_lds_ints(pf.B, pf.P, pf.T, pf.extra) > LDS_INTS) return 0;
     PhoneFrontArgs a = pf;
     a.lds_ints = LDS_INTS;
@@ -1410,12 +1427,15 @@ int mg_launch_phone_front_gemm(const PhoneFrontArgs& pf, const uint16_t* A, int 
     if (g_mg_tuning[MG_TUNE_AB] >= 70 && g_mg_tuning[MG_TUNE_AB] < 86) a.probe = g_mg_tuning[MG_TUNE_AB] - 70;
 #endif
     dim3 grid((unsigned)(side + g)), block(512);
-    if (epi == EPI_BIAS)
-        hipLaunchKernelGGL((phone_front_gemm_kernel<EPI_BIAS>), grid, block, 0, st, (unsigned)side, a, A, lda, M, K, Bm, ldb, N, bias, C, ldc,
-                           (int)tiles_m, tiles_n);
-    else
-        hipLaunchKernelGGL((phone_front_gemm_kernel<EPI_BIAS_SIGMOID>), grid, block, 0, st, (unsigned)side, a, A, lda, M, K, Bm, ldb, N, bias, C, ldc,
-                           (int)tiles_m, tiles_n);
+#define LAUNCH_PFG(EPI_, BMV_)                                                                                                                  \
+    hipLaunchKernelGGL((phone_front_gemm_kernel<EPI_, BMV_>), grid, block, 0, st, (unsigned)side, wave_ints, a, A, lda, M, K, Bm, ldb, N, bias, C, \
+                       ldc, (int)tiles_m, tiles_n)
+    if (epi == EPI_BIAS) {
+        if (bmv == 192) LAUNCH_PFG(EPI_BIAS, 192); else LAUNCH_PFG(EPI_BIAS, 256);
+    } else {
+        if (bmv == 192) LAUNCH_PFG(EPI_BIAS_SIGMOID, 192); else LAUNCH_PFG(EPI_BIAS_SIGMOID, 256);
+    }
+#undef LAUNCH_PFG
     return 1;
 }
 

@@ -358,6 +358,153 @@ __device__ __forceinline__ void phone_front_block(const PhoneFrontArgs& a, int f
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// WAVE jobs: the same jobs, each worked off by ONE wave with no workgroup barrier - the form the riders of a GEMM grid take.  A block
+// job spreads an utterance over 256-512 threads that mostly wait for each other (two barriers in the scan, one per batch) and costs
+// its block ~2.3 us; a rider block is a whole CU because the grid's LDS size is the GEMM's, so 32 rider blocks took 37 us for C2's 512
+// jobs.  As wave jobs the eight waves of a rider block run eight jobs at once (~4 us each): 256 at a time on 32 CUs.
+// Outputs: rows32 / rows_mapped / seg_start / seg_end / ybar / weight bit for bit the block jobs' (the phone loop is the same code at
+// four phones per pass, 16 lanes per phone); partial[]: one sum per job in the job's own slot (same total, another order of sums).
+// LDS of a wave: max(P + T + 1, span + 2) ints (phone_front_wave_ints).
+__device__ __forceinline__ void pf_wave_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }      // LDS of ONE wave: in order
+
+__device__ __forceinline__ void pf_wave_utterance(const PhoneFrontArgs& a, int b, int* __restrict__ reg) {
+    const int lane = threadIdx.x & 63;
+    const int B = a.B, P = a.P, T = a.T;
+    int* cum = reg;
+    float* tgt = reinterpret_cast<float*>(reg + P);
+    for (int p = lane; p < P; p += 64) {
+        const long long d = a.dur[(size_t)b * P + p];
+        cum[p] = d > 0 ? (int)d : 0;
+    }
+    for (int t = lane; t < T; t += 64) tgt[t] = a.target[(size_t)b * T + t];
+    int64_t nbl = a.seq_len ? a.seq_len[b] : (int64_t)T;
+    const int nb = (int)(nbl > T ? T : (nbl < 0 ? 0 : nbl));
+    pf_wave_fence();
+    int carry = 0;                                       // inclusive scan of the durations, 64 at a time
+    for (int p0 = 0; p0 < P; p0 += 64) {
+        const int v = p0 + lane < P ? cum[p0 + lane] : 0;
+        int incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        if (p0 + lane < P) cum[p0 + lane] = carry + incl;
+        carry += __shfl(incl, 63, 64);
+    }
+    pf_wave_fence();
+    float c = 0.f;
+    const int total = P > 0 ? min(cum[P - 1], T) : 0;
+    for (int t = total + lane; t < T; t += 64) {
+        const size_t o = (size_t)b * T + t;
+        a.rows32[o] = -1;
+        a.rows_mapped[o] = a.pad_row;
+    }
+    const float inv = 1.f / ((float)nb * (float)B);      // n_b == 0 -> inf; 0 * inf = NaN below, as the reference
+    const int sub = lane & 15;
+    for (int p0 = 0; p0 < P; p0 += 4) {
+        const int p = p0 + (lane >> 4);
+        float w_sum = 0.f, wy = 0.f;
+        int s = 0, e = 0;
+        if (p < P) {
+            s = min(p ? cum[p - 1] : 0, T);
+            e = min(cum[p], T);
+            if (e <= s) s = e = 0;
+            if (sub == 0) {
+                a.seg_start[(size_t)b * P + p] = e > s ? b * T + s : 0;
+                a.seg_end[(size_t)b * P + p] = e > s ? b * T + e : 0;
+            }
+            for (int t = s + sub; t < e; t += 16) {
+                const float w = (t < nb ? 1.f : 0.f) * inv;
+                w_sum += w;
+                wy += w * tgt[t];
+                const size_t o = (size_t)b * T + t;
+                a.rows32[o] = b * P + p;
+                a.rows_mapped[o] = b * P + p;
+            }
+        }
+        w_sum = mg_row16_sum(w_sum);
+        wy = mg_row16_sum(wy);
+        const float mean = w_sum > 0.f ? wy / w_sum : 0.f;
+        for (int t = s + sub; t < e; t += 16) {
+            const float d = tgt[t] - mean;
+            c += ((t < nb ? 1.f : 0.f) * inv) * d * d;
+        }
+        if (p < P && sub == 0) {
+            a.ybar[(size_t)b * P + p] = mean;
+            a.weight[(size_t)b * P + p] = w_sum;
+        }
+    }
+    const int phone_blocks = (B * P + 15) / 16;
+    for (int i = B + b + lane * B; i < phone_blocks; i += 64 * B) a.partial[i] = 0.f;      // the slots no utterance owns
+    c = mg_wave_sum(c);
+    if (lane == 0) a.partial[b] = c;
+    pf_wave_fence();                                     // the region is staged again by the wave's next job
+}
+
+__device__ __forceinline__ void pf_wave_extras(const PhoneFrontArgs& a, int xj, int* __restrict__ reg) {
+    const int lane = threadIdx.x & 63;
+    const int T = a.T, P = a.P, R = a.B * a.P;
+    const unsigned M = (unsigned)a.B * (unsigned)T, chunk = pf_chunk(a);
+    int b_lo, b_hi;
+    pf_extra_span(a, xj, chunk, b_lo, b_hi);
+    for (int b = b_lo; b <= b_hi; ++b) {                 // totals of the utterances the four chunks span (pf_stage_extras' sums)
+        int s = 0;
+        for (int p = lane; p < P; p += 64) {
+            const long long d = a.dur[(size_t)b * P + p];
+            s += d > 0 ? (int)d : 0;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) reg[b - b_lo] = s;
+    }
+    pf_wave_fence();
+    float c = 0.f;
+    for (int r = 0; r < 4; ++r) {
+        const int j = 4 * xj + r;
+        if (j >= a.extra) break;
+        const unsigned lo_u = min((unsigned)j * chunk, M);
+        const int lo = (int)lo_u, hi = (int)min(lo_u + chunk, M);
+        bool any = false;                                // wave-uniform: does the chunk hold padding frames at all?
+        if (lo < hi)
+            for (int b = lo / T; b * T < hi; ++b) any = any || max(lo, b * T + min(reg[b - b_lo], T)) < min(hi, (b + 1) * T);
+        if (any) {
+            c += pf_extra_row(a, j, lo, hi, reg, b_lo);
+        } else if (lane == 0) {
+            a.ybar[R + j] = 0.f;
+            a.weight[R + j] = 0.f;
+        }
+    }
+    c = mg_wave_sum(c);
+    if (lane == 0) a.partial[(R + 15) / 16 + xj] = c;
+    pf_wave_fence();
+}
+
+// Every wave of the caller: jobs first_wave, first_wave + n_waves, ... (first_wave = this wave's index among all rider waves), on the
+// wave's own LDS region `reg`.
+__device__ __forceinline__ void phone_front_wave_jobs(const PhoneFrontArgs& a, int first_wave, int n_waves, int* __restrict__ reg) {
+    const int jobs = phone_front_jobs(a.B, a.extra);
+    for (int job = first_wave; job < jobs; job += n_waves) {
+        if (job < a.B) {
+            if (!(a.probe & 1)) pf_wave_utterance(a, job, reg);
+        } else if (!(a.probe & 2)) {
+            pf_wave_extras(a, job - a.B, reg);
+        }
+    }
+}
+
+// ints of LDS ONE WAVE needs for its jobs
+static inline int64_t phone_front_wave_ints(int B, int P, int T, int extra) {
+    int64_t need = (int64_t)P + T + 1;
+    if (extra > 0) {
+        const int64_t M = (int64_t)B * T, chunk = (M + extra - 1) / extra;
+        const int64_t span = (4 * chunk + T - 1) / T + 2;
+        if (span > need) need = span;
+    }
+    return (need + 3) / 4 * 4;
+}
+
 // ints of LDS one job needs (more holds a batch), for either block size (host side: the launchers check it against what their kernel provides)
 static inline int64_t phone_front_lds_ints(int B, int P, int T, int extra) {
     int64_t need = 512 + (int64_t)P + T + 1;
