@@ -64,7 +64,9 @@ const char* mg_last_error(void);
 #define MG_TUNE_AB 7            /* shared-grid launches as their separate launches, half-width tiles off: 65 = mg_linear_wgrad_dgrad_bf16 as
                                  * two launches, 66 = mg_phone_front_linear_fwd_bf16 as two, 92 = 128 x 640 tiles for the 640-wide weight
                                  * gradient at phone-rate rows, 93 = 128 x 512 tiles for the 512-wide one, 94 = mg_phone_front_linear_fwd_bf16 with the
-                                 * front's jobs as block jobs and 256-row tiles (round 2's form), 95 = wave jobs but 256-row tiles */
+                                 * front's jobs as block jobs and 256-row tiles (round 2's form), 95 = wave jobs but 256-row tiles,
+                                 * 96 = mg_f0_l2tail_*_bf16 walks H1 from its first tile at every size (default: from the last one when
+                                 * H1 is larger than the L2s hold; per-workgroup sums then add in another order) */
 int mg_set_tuning(int key, int value);
 int mg_version(void);           /* ABI version, bumped on incompatible change */
 const char* mg_build_arch(void); /* "gfx950" */

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, 1) void f0_l2tail_kernel(const uint16_t* __res
                                                            const float* __restrict__ b4, const float* __restrict__ target,
                                                            const int64_t* __restrict__ seq_len, int64_t M, int B, int T,
                                                            float grad_scale, float* __restrict__ pred, uint16_t* __restrict__ dZ2,
-                                                           int lddz, float* __restrict__ slab, const float* __restrict__ row_weight) {
+                                                           int lddz, float* __restrict__ slab, const float* __restrict__ row_weight, int rev) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[LT_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mi = lane & 31, lh = lane >> 5;
@@ -133,8 +133,11 @@ __global__ __launch_bounds__(256, 1) void f0_l2tail_kernel(const uint16_t* __res
 
     const int64_t n_tiles = (M + 31) / 32;
     const int64_t stride = (int64_t)gridDim.x * 4;
+    // rev: the tiles are walked from the END of H1 (tile ordinal t -> rows of tile n_tiles - 1 - t): the layer-1 forward wrote H1 in
+    // ascending order, so its last rows are the ones still held by L2 / the memory-side cache when this launch starts.
+    auto first_row = [&](int64_t t) -> int64_t { return (rev ? (t < n_tiles ? n_tiles - 1 - t : 0) : t) * 32; };
     auto load_half = [&](u32x4 (&dst)[16], int64_t tile, int half) {
-        int64_t mm = tile * 32 + mi;
+        int64_t mm = first_row(tile) + mi;
         if (mm > M - 1) mm = M - 1;                         // rows past the end: any valid row (their results are discarded)
         const uint16_t* hp = H1 + (size_t)mm * ldh1 + 256 * half + 32 * lh;
 #pragma unroll
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256, 1) void f0_l2tail_kernel(const uint16_t* __res
     // order, so a target load issued inside the tail would wait for the whole prefetch of the next tile.
     //   row_weight mode: s1 = weight;  seq_len mode: s1 = [t < n_b], s2 = (float) n_b
     auto load_scalars = [&](int64_t tile_, float& tg, float& s1, float& s2) {
-        int64_t mm = tile_ * 32 + mi;
+        int64_t mm = first_row(tile_) + mi;
         if (mm > M - 1) mm = M - 1;
         tg = target[mm];
         if (row_weight) {
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(256, 1) void f0_l2tail_kernel(const uint16_t* __res
 #ifdef MG_STAMPS
         if (ta == 0) MG_STAMP(ta);
 #endif
-        const int64_t m = tile * 32 + mi;
+        const int64_t m = first_row(tile) + mi;
         const bool live = m < M;
         const float tg = tg_n, s1 = s1_n, s2 = s2_n;
         load_scalars(tile + stride, tg_n, s1_n, s2_n);
@@ -920,7 +923,11 @@ static int f0_l2tail_launch(const char* name, const uint16_t* H1, int ldh1, int 
     hipStream_t st = (hipStream_t)stream;
     const int blocks = l2tail_blocks(M);
     float* slab = (float*)workspace;
-#define LT_LAUNCH(P_) hipLaunchKernelGGL(f0_l2tail_kernel<P_>, dim3(blocks), dim3(256), 0, st, H1, ldh1, W2, ldw2, b2, W3, b3, W4, b4, target, seq_len, M, B, T, grad_scale, pred, dZ2, lddz, slab, row_weight)
+    // Large H1 (more than the 8 L2s hold): walk the tiles from the END - the rows the layer-1 forward wrote last are the ones L2 and
+    // the memory-side cache still hold (C2 at frame rate: the step 0.5043 -> 0.5008 ms in a same-box A/B; at phone-rate row counts
+    // everything is resident either way and the forward walk is 1 us faster).  MG_TUNE_AB = 96: the forward walk at every size (A/B).
+    const int rev = (M >= 65536 && g_mg_tuning[MG_TUNE_AB] != 96) ? 1 : 0;
+#define LT_LAUNCH(P_) hipLaunchKernelGGL(f0_l2tail_kernel<P_>, dim3(blocks), dim3(256), 0, st, H1, ldh1, W2, ldw2, b2, W3, b3, W4, b4, target, seq_len, M, B, T, grad_scale, pred, dZ2, lddz, slab, row_weight, rev)
 #ifdef MG_EXPERIMENTS
     // lab builds only: MG_TUNE_AB 64 = the producer / consumer role split (same results, measured slower); 1 .. 32 = the product
     // kernel with parts switched off (timing probes, results garbage)

@@ -9,13 +9,14 @@ if [ -n "$K" ]; then
   [ $rc -ne 0 ] && exit $rc
 fi
 EXTRA=${MG_BENCH_EXTRA:-}
+NOCMP=--no-compare; [ -n "$MG_BENCH_COMPARE" ] && NOCMP=   # MG_BENCH_COMPARE=1: time the frame-rate order as well
 for i in 1 2 3; do
   for leg in "$@"; do
     tag=$(echo "$leg" | tr ':,' '__')
     if [ "$leg" = "-" ]; then
-      timeout -k 10 300 python bench.py --steps 200 --warmup 20 --no-roofline --no-cpu-baseline --no-compare $EXTRA > gpurun_out/abn_${tag}_$i.log 2>&1 || exit 1
+      timeout -k 10 300 python bench.py --steps 200 --warmup 20 --no-roofline --no-cpu-baseline $NOCMP $EXTRA > gpurun_out/abn_${tag}_$i.log 2>&1 || exit 1
     else
-      MG_TUNE=$leg timeout -k 10 300 python bench.py --steps 200 --warmup 20 --no-roofline --no-cpu-baseline --no-compare $EXTRA > gpurun_out/abn_${tag}_$i.log 2>&1 || exit 1
+      MG_TUNE=$leg timeout -k 10 300 python bench.py --steps 200 --warmup 20 --no-roofline --no-cpu-baseline $NOCMP $EXTRA > gpurun_out/abn_${tag}_$i.log 2>&1 || exit 1
     fi
   done
 done

@@ -280,6 +280,41 @@ def test_rccl_world1_graphed_step_equals_single_rank():
     print('RCCL world-1 graphed step: exchange mode = %s' % mode)
 
 
+@pytest.mark.parametrize('precision,form,ragged', [('fp32', 'eager', True), ('fp32', 'graph', False), ('bf16', 'graph', True)])
+def test_two_ranks_on_one_gpu_equal_the_global_batch(tmp_path, precision, form, ragged):
+    """The N > 1 leg of C3 / C5 with device tensors: two ranks share the box's one GPU (gloo process group - RCCL refuses two ranks on
+    one device), each runs the PRODUCT step on its contiguous shard of 16 utterances (HIP kernels, flat fp32 gradient bucket on the
+    device, the eager all-reduce of optim.Adam / GraphedTrainStep between the backward graph and the update kernel, 1 / world folded
+    into the update) and must reproduce the one-rank run on the global batch: replicas bit-identical to each other, parameters and
+    losses equal to the single run up to the order of the fp32 sums (L = mean_r L_r for equal shard sizes)."""
+    import socket
+    import subprocess
+    import sys
+    import _dist_gpu_worker as worker
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    out = str(tmp_path / 'dp_gpu.npz')
+    n_steps = 4
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   OMP_NUM_THREADS='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(repo, 'tests', '_dist_gpu_worker.py'), out, str(n_steps), precision, form,
+                                       '1' if ragged else '0'], env=env, cwd=repo))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    got = np.load(out)
+    assert np.array_equal(got['replicas'][0], got['replicas'][1])            # the ranks hold identical parameters after every update
+    assert str(got['mode']) == ('eager' if form == 'graph' else 'eager loop')  # gloo is never captured into the graph
+    batch = synthetic.make_batch(16, (120, 400) if ragged else 250, seed=23)
+    want_flat, want_losses, _ = worker.run_steps(batch, n_steps, precision, form, torch.device(DEV))
+    tol = RTOL if precision == 'fp32' else 2e-3
+    assert rel_l2(got['replicas'][0], want_flat.cpu().numpy()) < tol
+    np.testing.assert_allclose(got['losses'], want_losses, rtol=tol)
+
+
 # ------------------------------------------------------------------------------------------------------------ contracts
 @pytest.mark.parametrize('b,t,hid,form', [(16, 50, 512, 'step_bf16'), (16, 50, 512, 'persist_bf16'), (16, 50, 512, 'step_f32'),
                                           (16, 50, 256, 'persist_f32'), (12, 40, 64, 'small_f32'), (12, 40, 128, 'small_f32')])
