@@ -64,7 +64,8 @@ __device__ __forceinline__ void nr_glds16(const uint16_t* src, unsigned char* ld
 // MFMAs of a step never wait for its LDS reads (they did at the head of every step: 12 reads, then 32 MFMAs).  The step's wait then
 // covers the NEXT stage as well (one stage in flight instead of two); the first step of a tile reads as before.
 // PROBE (lab builds only; results garbage): 1 = no epilogue, 2 = no LDS-DMA behind the first ring fill, 4 = no fragment reads,
-// 8 = no MFMAs.
+// 8 = no MFMAs, 16 = every store of the epilogue goes to the L2-resident sink (no HBM write stream), 32 = non-temporal stores
+// (results valid), 64 = eight start phases (results valid).
 template <int EPI, bool PF = false, int PROBE = 0>
 __global__ __launch_bounds__(256, 2) void gemm_nt_runs_kernel(const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
                                                               int64_t M, int K, const uint16_t* __restrict__ Bm, int ldb, int N,
@@ -98,6 +99,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_runs_kernel(const uint16_t* __
         if (tm < tiles_m) n_my = i + 1;
     }
     if (n_my == 0) return;
+    if (PROBE & 64) {                                  // probe: eight start phases an eighth of a tile period apart (results valid)
+        const int phase = ((blockIdx.x >> 3) + 4 * (blockIdx.x >> 8)) & 7;
+        for (int i = 0; i < phase; ++i) __builtin_amdgcn_s_sleep(80);
+    }
 
     // ---- one-time: runs of equal consecutive source rows of every tile (wave w takes tiles w, w + 4: 4 rows per lane, one wave scan) ---
     for (int i = wave; i < n_my; i += 4) {
@@ -255,9 +260,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_runs_kernel(const uint16_t* __
                 // min(g_total, g + NS - 1) stages; the previous tile's NST stores sit in the queue behind the stages issued before them.
                 const int ahead = PF ? 1 : 0;
                 const int young = max(min(g_total - 1 - ahead - g, NS - 2 - ahead), 0);
-                const int allow = young * NL + ((ti > 0 && p == 0 && kt < NS - 1 - ahead) ? NST : 0);
+                // probe 128 (results garbage): the previous tile's stores are never waited for - the counted wait lets NST more
+                // operations stay in flight at every k-step, so it can pass before its stage has landed
+                const int allow = young * NL + ((ti > 0 && ((PROBE & 128) || (p == 0 && kt < NS - 1 - ahead))) ? NST : 0);
                 __builtin_amdgcn_sched_barrier(0);
-                switch (PROBE ? 0 : allow) {
+                switch ((PROBE & ~128) ? 0 : allow) {
                     NR_WAIT_CASE(3) NR_WAIT_CASE(6) NR_WAIT_CASE(16) NR_WAIT_CASE(19) NR_WAIT_CASE(22)
                     default: NR_WAIT(0); break;
                 }
@@ -342,8 +349,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_runs_kernel(const uint16_t* __
                 const int rl = it * 8 + prow;
                 const u32x4_t o = *reinterpret_cast<const u32x4_t*>(patch + rl * SP + ((pchunk ^ (rl & 7)) << 4));
                 const int64_t m = m0 + wm0 + p * 32 + rl;
-                uint16_t* dst = (m < M) ? C + (size_t)m * ldc + n0 + wn0 + pchunk * 8 : g_nr_sink + lane * 8;
-                *reinterpret_cast<u32x4_t*>(dst) = o;     // unconditional: the counted vmcnt waits rely on NST stores per wave
+                uint16_t* dst = (m < M && !(PROBE & 16)) ? C + (size_t)m * ldc + n0 + wn0 + pchunk * 8 : g_nr_sink + lane * 8;
+                if (PROBE & 32)
+                    __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t*>(dst));
+                else
+                    *reinterpret_cast<u32x4_t*>(dst) = o; // unconditional: the counted vmcnt waits rely on NST stores per wave
             }
         }
     }
@@ -365,14 +375,14 @@ int mg_try_nt_runs(const uint16_t* A, int lda, const int32_t* rows, int64_t M, i
     if (g >= 2147483647LL) return 0;
     dim3 grid((unsigned)g), block(256);
 #ifdef MG_EXPERIMENTS
-    if (sigmoid && g_mg_tuning[MG_TUNE_FORM] >= 200 && g_mg_tuning[MG_TUNE_FORM] < 216) {      // lab builds: timing probes 200 + mask
+    if (sigmoid && g_mg_tuning[MG_TUNE_FORM] >= 200 && g_mg_tuning[MG_TUNE_FORM] < 456) {      // lab builds: timing probes 200 + mask
 #define NR_PROBE_CASE(P)                                                                                                                  \
     case 200 + P:                                                                                                                          \
         hipLaunchKernelGGL((gemm_nt_runs_kernel<NR_EPI_BIAS_SIGMOID, false, P>), grid, block, 0, st, A, lda, rows, M, K, Bm, ldb, N, bias, C, ldc, \
                            (int)tiles_m, tiles_n);                                                                                         \
         return 1;
         switch (g_mg_tuning[MG_TUNE_FORM]) {
-            NR_PROBE_CASE(1) NR_PROBE_CASE(2) NR_PROBE_CASE(3) NR_PROBE_CASE(4) NR_PROBE_CASE(7) NR_PROBE_CASE(8) NR_PROBE_CASE(11) NR_PROBE_CASE(15)
+            NR_PROBE_CASE(1) NR_PROBE_CASE(2) NR_PROBE_CASE(3) NR_PROBE_CASE(4) NR_PROBE_CASE(7) NR_PROBE_CASE(8) NR_PROBE_CASE(11) NR_PROBE_CASE(15) NR_PROBE_CASE(16) NR_PROBE_CASE(32) NR_PROBE_CASE(24) NR_PROBE_CASE(40) NR_PROBE_CASE(64) NR_PROBE_CASE(96) NR_PROBE_CASE(65) NR_PROBE_CASE(128)
             default: break;
         }
     }

@@ -36,6 +36,11 @@ def main():
     h1 = ops.linear_fwd_bf16(tab, rows, m, k, w1b, b1, 512, ops.ACT_SIGMOID)
     dz1 = (torch.randn(m, 512, device=dev) * 0.01).to(torch.bfloat16)
     dz2 = (torch.randn(m, 128, device=dev) * 0.01).to(torch.bfloat16)
+    if os.environ.get('MG_ZERO') == '1':                  # power probe: the same launches on all-zero operands (no bit toggles in the
+        for tns in (tab, w1b, w2b, w2t, h1, dz1, dz2):    # matrix pipe or on the memory buses; MI355X_MICROARCH.md, DVFS give-back item 1)
+            tns.zero_()
+        b1, b2 = torch.zeros_like(b1), torch.zeros_like(b2)
+        print('all operands zero (power probe)')
     bufs = {}
 
     def keep(key, result):
