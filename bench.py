@@ -814,7 +814,7 @@ def main():
     distributed.barrier()
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if torch.distributed.is_initialized():           # the ranks' group, or the one-rank rehearsal's
         torch.distributed.destroy_process_group()
 
 

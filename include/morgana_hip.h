@@ -66,7 +66,9 @@ const char* mg_last_error(void);
                                  * gradient at phone-rate rows, 93 = 128 x 512 tiles for the 512-wide one, 94 = mg_phone_front_linear_fwd_bf16 with the
                                  * front's jobs as block jobs and 256-row tiles (round 2's form), 95 = wave jobs but 256-row tiles,
                                  * 96 = mg_f0_l2tail_*_bf16 walks H1 from its first tile at every size (default: from the last one when
-                                 * H1 is larger than the L2s hold; per-workgroup sums then add in another order) */
+                                 * H1 is larger than the L2s hold; per-workgroup sums then add in another order);
+                                 * the wide NT GEMM's tile for few-tile shapes: 97 = 256-wide whenever N allows, 99 = 128-wide always,
+                                 * 98 = under 32,768 rows the 128 x 128 kernel (default: 128-wide when 256-wide tiles would be < 128) */
 int mg_set_tuning(int key, int value);
 int mg_version(void);           /* ABI version, bumped on incompatible change */
 const char* mg_build_arch(void); /* "gfx950" */

@@ -1243,7 +1243,15 @@ int mg_try_nt_big(const uint16_t* A, int lda, const int32_t* rows, int64_t M, in
     if (N % 128 != 0 || ldc < N || ldc % 8 != 0 || !big16(A) || !big16(Bm) || !big16(C)) return 0;
     if (epi == EPI_SIGMOID_GRAD && (!H || ldh % 8 != 0 || ldh < N)) return 0;
     if (ldc != N || lda < (K + 63) / 64 * 64 || ldb < (K + 63) / 64 * 64) return 0;
-    const bool wide = (N % 256 == 0);
+    // Tile width: 256 where N allows it - unless that leaves most of the chip idle.  At the phone-rate row counts of the recurrent
+    // models (RNN_SPSS at C4 / C5: 6,144 table rows = 24 M tiles) a 512-wide layer is 48 workgroups of 256 x 256 on 256 CUs, each a
+    // chain of K / 32 dependent k-steps; 128-wide tiles are twice the workgroups at the same chain length.
+    // MG_TUNE_AB (A/B): 97 = 256-wide whenever N allows (the rule before), 99 = 128-wide always, 98 = leave row counts under 32,768
+    // to the 128 x 128 kernel of gemm_bf16.hip.
+    const int ab = g_mg_tuning[MG_TUNE_AB];
+    if (ab == 98 && M < 32768) return 0;
+    bool wide = (N % 256 == 0);
+    if (wide && ab != 97 && (ab == 99 || mg_ceil_div(M, 256) * (N / 256) < 128)) wide = false;
     const int bn = wide ? 256 : 128;
     const int tiles_n = N / bn;
     const int64_t tiles_m = mg_ceil_div(M, 256);

@@ -49,11 +49,51 @@ def set_early_grads_hook(fn):
 def backward(loss):
     """``loss.backward()`` (experiment_builder.py:473) with the implicit gradient of one taken from a per-device cache:
     autograd otherwise allocates and fills a fresh ``ones_like(loss)`` every step - a launch of its own at the ~5 us floor."""
+    global _DIRECT_BACKWARD
     key = (loss.device, loss.dtype)
     one = _ONES.get(key)
     if one is None:
         one = _ONES[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
-    loss.backward(gradient=one if loss.dim() == 0 else None)
+    _DIRECT_BACKWARD += 1          # the row-wise and recurrent layers may add their weight gradients straight into .grad (_direct_params)
+    try:
+        loss.backward(gradient=one if loss.dim() == 0 else None)
+    finally:
+        _DIRECT_BACKWARD -= 1
+
+
+_DIRECT_BACKWARD = 0
+DIRECT_GRADS = os.environ.get('MORGANA_DIRECT_GRADS', '1') != '0'          # A/B switches of the two launch savers below
+WEIGHT_SHADOWS = os.environ.get('MORGANA_WEIGHT_SHADOWS', '1') != '0'
+
+
+def _w_plain(weights):
+    """bf16 [N, pad_ld(K)] operands of a list of fp32 weights: the shadows that live on the parameters and that the optimiser's update
+    kernel keeps current (ops.param_shadows: no cast launch per layer and step), or a cast each (MORGANA_WEIGHT_SHADOWS=0)."""
+    if WEIGHT_SHADOWS:
+        return ops.param_shadows(list(weights))[0]
+    return [ops.cast_pad_bf16(ops._require(w, torch.float32, 'weight')) for w in weights]
+
+
+def _w_t(w):
+    """bf16 W^T [K, pad_ld(N)] (the dgrad operand) of one fp32 weight, from its shadow where there is one."""
+    return ops.param_shadows([w], want_t=(0,))[1][0] if WEIGHT_SHADOWS else ops.cast_transpose_bf16(w)
+
+
+def _direct_params(*params):
+    """May a layer's backward add its parameter gradients straight into ``.grad`` and hand autograd ``None`` for them?  Only inside
+    ``backward`` above (``torch.autograd.grad`` and double backward must get tensors), and only when every parameter's ``.grad`` is
+    a live fp32 view of ``morgana_amd.optim.Adam``'s flat gradient.  What it saves: autograd's AccumulateGrad adds the returned
+    tensor into the existing ``.grad`` with one elementwise launch PER PARAMETER (ten of them in an RNN_SPSS step)."""
+    return (DIRECT_GRADS and _DIRECT_BACKWARD > 0 and not torch.is_grad_enabled() and
+            all(p is not None and getattr(p, '_mg_direct_grad', False) and p.grad is not None and p.grad.is_contiguous() and
+                p.grad.dtype == torch.float32 for p in params))
+
+
+def _linear_grads_direct(w_param, b_param, g, a_in, rows, m, n, k):
+    """dW | db of one bf16 Linear into the optimiser (slabs deferred to its update kernel or reduced into .grad: _wgrad_into)."""
+    opt = getattr(w_param, '_mg_optimizer', None)
+    mode = 'defer' if (opt is not None and opt.defers_slabs() and _grads_adjacent(w_param, b_param)) else 'direct'
+    _wgrad_into(mode, opt, w_param, b_param, g, a_in, rows, m, n, k)
 
 
 class UpsampleFn(torch.autograd.Function):
@@ -126,11 +166,13 @@ class LinearStackFn(torch.autograd.Function):
             else:
                 a = x2d if pre_cast else ops.cast_pad_bf16(x2d, extra_rows=extra)
             a0, r = a, rows_k
+            # bf16 operands of the weights: copies that live on the parameters, refreshed by the optimiser's update kernel
+            # (ops.param_shadows) - no cast launch per layer and step
+            w_bfs = _w_plain(weights)
             for i in range(n_layers):
                 n, k = weights[i].shape
-                w_bf = ops.cast_pad_bf16(ops._require(weights[i], torch.float32, 'weight'))
                 last = i == n_layers - 1
-                a = ops.linear_fwd_bf16(a, r, m, k, w_bf, biases[i], n, acts[i], out_f32=last, rows_runs=rows_runs)
+                a = ops.linear_fwd_bf16(a, r, m, k, w_bfs[i], biases[i], n, acts[i], out_f32=last, rows_runs=rows_runs)
                 r = None
                 hidden.append(a)
             n_last = weights[-1].shape[0]
@@ -139,6 +181,7 @@ class LinearStackFn(torch.autograd.Function):
                 out = out[:, :n_last].contiguous()
                 # keep the padded fp32 activation only if a trailing sigmoid needs it in backward
             ctx.save_for_backward(a0, rows_k, rows if gathered_grad else None, *weights, *hidden[:-1], out)
+            ctx.param_refs = (list(weights), list(biases))        # the Parameter objects (their .grad views, their shadows)
         return out
 
     @staticmethod
@@ -169,17 +212,22 @@ class LinearStackFn(torch.autograd.Function):
                     grad_x = ops.linear_dgrad_f32(g, weights[0], None)
         else:
             g = ops.cast_pad_bf16(g)
+            w_params, b_params = ctx.param_refs
+            direct = all(ctx.has_bias) and _direct_params(*w_params, *b_params)
             for i in range(n_layers - 1, -1, -1):
                 n, k = ctx.dims[i]
                 a_in, r = (x_in, rows) if i == 0 else (hidden[i - 1], None)
-                dw, db = ops.linear_wgrad_bf16(g, a_in, r, m, n, k, want_bias=ctx.has_bias[i])
-                grads[2 * i], grads[2 * i + 1] = dw, db
+                if direct:
+                    _linear_grads_direct(w_params[i], b_params[i], g, a_in, r, m, n, k)
+                else:
+                    dw, db = ops.linear_wgrad_bf16(g, a_in, r, m, n, k, want_bias=ctx.has_bias[i])
+                    grads[2 * i], grads[2 * i + 1] = dw, db
                 if i > 0:
-                    wt = ops.cast_transpose_bf16(weights[i])
+                    wt = _w_t(w_params[i])
                     h = hidden[i - 1] if acts[i - 1] == ops.ACT_SIGMOID else None
                     g = ops.linear_dgrad_bf16(g, m, n, wt, k, h)
                 elif need_x:
-                    wt = ops.cast_transpose_bf16(weights[0])
+                    wt = _w_t(w_params[0])
                     grad_x = ops.linear_dgrad_bf16(g, m, n, wt, k, None, out_f32=True)
                     if grad_x.shape[1] != k:
                         grad_x = grad_x[:, :k].contiguous()
@@ -662,10 +710,11 @@ class GRUFn(torch.autograd.Function):
             x_saved = x2
         else:
             x_saved = ops.cast_pad_bf16(x2)
-            xproj = ops.linear_fwd_bf16(x_saved, None, m_in, i_dim, ops.cast_pad_bf16(w_ih), b_ih, 3 * hid,
+            xproj = ops.linear_fwd_bf16(x_saved, None, m_in, i_dim, _w_plain([w_ih])[0], b_ih, 3 * hid,
                                         ops.ACT_NONE, out_f32=True)
             if xproj.shape[1] != 3 * hid:
                 xproj = xproj[:, :3 * hid].contiguous()
+        ctx.param_refs = (w_ih, w_hh, b_ih, b_hh)
         ctx.bf16_recurrence = precision == 'bf16' and RECURRENCE_BF16 and ops.gru_bf16_ok(hid)
         in_kernel = rows is not None and ctx.bf16_recurrence and ops.gru_persist_ok(b, t, hid)
         if rows is not None and not in_kernel:
@@ -732,16 +781,24 @@ class GRUFn(torch.autograd.Function):
             # Ragged batch with its layout at hand: both products visit the sum_b T_b valid frames only (the gate gradients of the
             # padded frames are zero rows; the reference's PackedSequence never holds them, utils.py:366-385)
             lay = ctx.layout if (ctx.layout is not None and (ctx.layout.b, ctx.layout.t) == (b, t)) else None
+            p_ih, p_hh, pb_ih, pb_hh = ctx.param_refs
+            # inside functional.backward the four gradients are added straight into the optimiser's flat gradient (no AccumulateGrad
+            # launch per parameter); autograd gets None for them
+            into = dict(accumulate=True) if _direct_params(p_ih, p_hh, pb_ih, pb_hh) else None
+            kw_ih = dict(out_w=p_ih.grad, out_b=pb_ih.grad, **into) if into else {}
+            kw_hh = dict(out_w=p_hh.grad, out_b=pb_hh.grad, **into) if into else {}
             if lay is not None and rows is None and ops.wgrad_rows_ok(lay.total, 3 * hid, i_dim, x_saved.shape[1], dxp_bf.shape[1]):
-                dw_ih, db_ih = ops.linear_wgrad_rows_bf16(dxp_bf, lay.frame_rows(), x_saved, None, lay.total, 3 * hid, i_dim)
+                dw_ih, db_ih = ops.linear_wgrad_rows_bf16(dxp_bf, lay.frame_rows(), x_saved, None, lay.total, 3 * hid, i_dim, **kw_ih)
             else:
-                dw_ih, db_ih = ops.linear_wgrad_bf16(dxp_bf, x_saved, None, m_in, 3 * hid, i_dim)
+                dw_ih, db_ih = ops.linear_wgrad_bf16(dxp_bf, x_saved, None, m_in, 3 * hid, i_dim, **kw_ih)
             if lay is not None and ops.wgrad_rows_ok(lay.total, 3 * hid, hid, hs_bf.shape[1], dhp_bf.shape[1]):
-                dw_hh, db_hh = ops.linear_wgrad_rows_bf16(dhp_bf, lay.frame_rows(), hs_bf, lay.state_rows(), lay.total, 3 * hid, hid)
+                dw_hh, db_hh = ops.linear_wgrad_rows_bf16(dhp_bf, lay.frame_rows(), hs_bf, lay.state_rows(), lay.total, 3 * hid, hid, **kw_hh)
             else:
-                dw_hh, db_hh = ops.linear_wgrad_bf16(dhp_bf, hs_bf, prev_rows, m, 3 * hid, hid)
+                dw_hh, db_hh = ops.linear_wgrad_bf16(dhp_bf, hs_bf, prev_rows, m, 3 * hid, hid, **kw_hh)
+            if into:
+                dw_ih = dw_hh = db_ih = db_hh = None
             if need_x:
-                dx = ops.linear_dgrad_bf16(dxp_bf, m_in, 3 * hid, ops.cast_transpose_bf16(w_ih), i_dim, None,
+                dx = ops.linear_dgrad_bf16(dxp_bf, m_in, 3 * hid, _w_t(p_ih), i_dim, None,
                                            out_f32=True)
                 if dx.shape[1] != i_dim:
                     dx = dx[:, :i_dim].contiguous()

@@ -426,20 +426,23 @@ def wgrad_rows_ok(m, n, k, lda, lddy):
             not (n == 128 and m <= 32768))
 
 
-def linear_wgrad_rows_bf16(dy, dy_rows, a, rows, m, n, k, want_bias=True):
+def linear_wgrad_rows_bf16(dy, dy_rows, a, rows, m, n, k, want_bias=True, out_w=None, out_b=None, accumulate=False):
     """dW = sum_{i < m} dy[dy_rows[i]]^T a[rows[i]] (rows None: a[dy_rows[i]]), db = sum_i dy[dy_rows[i]]: linear_wgrad_bf16 on the m
-    index pairs only (``dy_rows`` int32, every entry a valid row of ``dy``)."""
+    index pairs only (``dy_rows`` int32, every entry a valid row of ``dy``).  out_w / out_b / accumulate as linear_wgrad_bf16."""
     lib = _lib.load()
     dy_rows = _require(dy_rows, torch.int32, 'dy_rows')
-    if want_bias:                                  # db right behind dW: one reduce launch for both
+    if out_w is not None or out_b is not None:
+        dw = out_w if out_w is not None else torch.empty((n, k), dtype=torch.float32, device=dy.device)
+        db = (out_b if out_b is not None else torch.empty((n,), dtype=torch.float32, device=dy.device)) if want_bias else None
+    elif want_bias:                                # db right behind dW: one reduce launch for both
         both = torch.empty((n * k + n,), dtype=torch.float32, device=dy.device)
         dw, db = both[:n * k].view(n, k), both[n * k:]
     else:
         dw, db = torch.empty((n, k), dtype=torch.float32, device=dy.device), None
     nbytes = lib.mg_linear_wgrad_workspace_bytes(m, n, k)
     ws = workspace(nbytes, dy.device)
-    _lib.check(lib.mg_linear_wgrad_rows_bf16(_p(dy), dy.shape[1], _p(dy_rows), _p(a), a.shape[1], _p(rows), m, n, k, _p(dw), _p(db), 0,
-                                             _p(ws), ws.numel(), _stream()), 'mg_linear_wgrad_rows_bf16')
+    _lib.check(lib.mg_linear_wgrad_rows_bf16(_p(dy), dy.shape[1], _p(dy_rows), _p(a), a.shape[1], _p(rows), m, n, k, _p(dw), _p(db),
+                                             int(bool(accumulate)), _p(ws), ws.numel(), _stream()), 'mg_linear_wgrad_rows_bf16')
     return dw, db
 
 
