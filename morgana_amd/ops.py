@@ -377,10 +377,12 @@ ACT_ROWS_RUNS = 0x100      # MG_ACT_ROWS_RUNS: `rows` is a frame map of upsample
 
 
 def linear_fwd_bf16(a, rows, m, k, w_bf16, bias, n, act, out_f32=False, rows_runs=False):
-    """a: (R, lda) bf16; w_bf16: (n, ldw) bf16.  Returns (m, pad8(n)) bf16 (or f32), padding columns zero.
+    """a: (R, lda) bf16; w_bf16: (n, ldw) bf16.  Returns (m, pad8(n)) bf16 (or (m, n rounded up to 8) f32), padding columns zero.
     ``rows_runs``: the row map consists of runs of equal consecutive indices (performance hint, same results)."""
     lib = _lib.load()
-    ldy = pad8(n)
+    # a bf16 result is the next layer's operand (rows padded to the large tiles' k step); an fp32 one leaves the stack: padded to the
+    # 16-byte chunk only, so that its consumer needs no slice-and-copy pass (N = 80: 64,000 x 128 -> x 80 was a 41 MB copy at C4)
+    ldy = (n + 7) // 8 * 8 if out_f32 else pad8(n)
     y = torch.empty((m, ldy), dtype=torch.float32 if out_f32 else torch.bfloat16, device=a.device)
     if rows_runs and rows is not None:
         act = act | ACT_ROWS_RUNS
