@@ -68,7 +68,7 @@ def _is_unit_grad(g):
     """Is ``g`` the cached gradient of one that ``backward`` above hands to autograd (the loss IS the root: multiplying by it is a no-op)?"""
     return g is not None and any(g.data_ptr() == one.data_ptr() for one in _ONES.values())
 DIRECT_GRADS = os.environ.get('MORGANA_DIRECT_GRADS', '1') != '0'          # A/B switches of the two launch savers below
-WEIGHT_SHADOWS = os.environ.get('MORGANA_WEIGHT_SHADOWS', '1') != '0'
+WEIGHT_SHADOWS = ops.WEIGHT_SHADOWS
 
 
 def _w_plain(weights):
@@ -1012,12 +1012,13 @@ class LSTMStackPersistFn(torch.autograd.Function):
         b, t, i_dim = x.shape
         hid = w_hh[0].shape[1]
         x_saved = ops.cast_pad_bf16(x.view(b * t, i_dim))
-        xproj0 = ops.linear_fwd_bf16(x_saved, None, b * t, i_dim, ops.cast_pad_bf16(w_ih[0]), b_ih[0], 4 * hid, ops.ACT_NONE,
+        xproj0 = ops.linear_fwd_bf16(x_saved, None, b * t, i_dim, _w_plain([w_ih[0]])[0], b_ih[0], 4 * hid, ops.ACT_NONE,
                                      out_f32=True)
         if xproj0.shape[1] != 4 * hid:
             xproj0 = xproj0[:, :4 * hid].contiguous()
         out, hstate, cstate, saved, hstate_bf = ops.lstm_pstack_fwd(xproj0.view(b, t, 4 * hid), w_ih, w_hh, b_ih, b_hh, seq_len, h0s, c0s,
                                                                     b, t, hid)
+        ctx.param_refs = list(params)                    # the Parameter objects: their .grad views (direct gradients), their shadows
         ctx.shape = (b, t, i_dim, hid, n_layers)
         ctx.has_h0, ctx.has_c0 = h0s is not None, c0s is not None
         ctx.save_for_backward(x_saved, seq_len, *w_ih, *w_hh, *cstate, *saved, *hstate_bf)
@@ -1047,17 +1048,27 @@ class LSTMStackPersistFn(torch.autograd.Function):
             # one wavefront launch for every layer's recurrence and the input gradients between the layers, then the weight gradients
             g_hn = [grad_hn[l] for l in range(n_layers)] if grad_hn is not None else None
             g_cn = [grad_cn[l] for l in range(n_layers)] if grad_cn is not None else None
-            _, dg_bfs, dh0, dc0 = ops.lstm_pstack_bwd(g_out, g_hn, g_cn, cstate, saved, w_ih, w_hh, seq_len, b, t, hid)
+            prm = ctx.param_refs
+            _, dg_bfs, dh0, dc0 = ops.lstm_pstack_bwd(g_out, g_hn, g_cn, cstate, saved, [prm[4 * l] for l in range(n_layers)],
+                                                      [prm[4 * l + 1] for l in range(n_layers)], seq_len, b, t, hid)
+            # inside functional.backward the sixteen weight gradients and their bias sums are added straight into the optimiser's flat
+            # gradient (both weight-gradient launches of a layer produce the bias sums: b_ih and b_hh receive the same values), and
+            # autograd gets None: no AccumulateGrad launch per parameter, no clone of db
+            direct = _direct_params(*prm)
             for l in range(n_layers):
                 dg_bf = dg_bfs[l].view(m, 4 * hid)
+                p_ih, p_hh, pb_ih, pb_hh = prm[4 * l:4 * l + 4]
+                kw_ih = dict(out_w=p_ih.grad, out_b=pb_ih.grad, accumulate=True) if direct else {}
+                kw_hh = dict(out_w=p_hh.grad, out_b=pb_hh.grad, accumulate=True) if direct else dict(want_bias=False)
                 if l == 0:
-                    dw_ih, db = ops.linear_wgrad_bf16(dg_bf, x_saved, None, m, 4 * hid, i_dim)
+                    dw_ih, db = ops.linear_wgrad_bf16(dg_bf, x_saved, None, m, 4 * hid, i_dim, **kw_ih)
                 else:
-                    dw_ih, db = ops.linear_wgrad_bf16(dg_bf, hstate_bf[l - 1].view(b * (t + 1), hid), next_rows, m, 4 * hid, hid)
-                dw_hh, _ = ops.linear_wgrad_bf16(dg_bf, hstate_bf[l].view(b * (t + 1), hid), prev_rows, m, 4 * hid, hid, want_bias=False)
-                grads[4 * l:4 * l + 4] = [dw_ih, dw_hh, db, db.clone()]
+                    dw_ih, db = ops.linear_wgrad_bf16(dg_bf, hstate_bf[l - 1].view(b * (t + 1), hid), next_rows, m, 4 * hid, hid, **kw_ih)
+                dw_hh, _ = ops.linear_wgrad_bf16(dg_bf, hstate_bf[l].view(b * (t + 1), hid), prev_rows, m, 4 * hid, hid, **kw_hh)
+                if not direct:
+                    grads[4 * l:4 * l + 4] = [dw_ih, dw_hh, db, db.clone()]
             if ctx.needs_input_grad[0]:
-                dx = ops.linear_dgrad_bf16(dg_bfs[0].view(m, 4 * hid), m, 4 * hid, ops.cast_transpose_bf16(w_ih[0]), i_dim, None, out_f32=True)
+                dx = ops.linear_dgrad_bf16(dg_bfs[0].view(m, 4 * hid), m, 4 * hid, _w_t(prm[0]), i_dim, None, out_f32=True)
                 if dx.shape[1] != i_dim:
                     dx = dx[:, :i_dim].contiguous()
                 dx = dx.view(b, t, i_dim)

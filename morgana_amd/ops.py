@@ -576,6 +576,24 @@ def cast_params_bf16(weights, want_plain=True, want_t=()):
     return plain, trans
 
 
+WEIGHT_SHADOWS = os.environ.get('MORGANA_WEIGHT_SHADOWS', '1') != '0'      # A/B: 0 = a cast launch per weight and step, as before
+
+
+def weight_operands(weights, transposed=False):
+    """bf16 operands ([N, pad_ld(K)], or the transposes [K, pad_ld(N)]) of a list of fp32 weights: the shadows that live on the
+    parameters (param_shadows: kept current by the optimiser's update kernel, stale ones re-cast by ONE batched launch), or a cast
+    launch each (MORGANA_WEIGHT_SHADOWS=0)."""
+    weights = list(weights)
+    if not WEIGHT_SHADOWS:
+        return [cast_transpose_bf16(w) if transposed else cast_pad_bf16(_require(w, torch.float32, 'weight')) for w in weights]
+    out = []
+    for i in range(0, len(weights), _lib.CAST_MAX):      # mg_cast_params_bf16 takes at most MG_CAST_MAX descriptors per launch
+        part = weights[i:i + _lib.CAST_MAX]
+        plain, trans = param_shadows(part, want_t=tuple(range(len(part))) if transposed else ())
+        out += trans if transposed else plain
+    return out
+
+
 def param_shadows(weights, want_t=()):
     """bf16 operands of a run of fp32 weight matrices: ([N, pad_ld(K)] copies, transposes [K, pad_ld(N)] for the indices in
     ``want_t``, None elsewhere).  The copies live ON the parameter (``w._mg_shadow``) and are kept current by
@@ -1056,25 +1074,30 @@ def lstm_pstack_fwd(xproj0, w_ih, w_hh, b_ih, b_hh, seq_len, h0s, c0s, b, t, h):
     n_layers = len(w_hh)
     hstate, cstate, saved, hstate_bf, keep, o = [], [], [], [], [], None
     descs = (_lib.LstmPStackLayer * n_layers)()
+    # the state arrays of all layers in three allocations: their initial rows are set by three launches, not three per layer
+    hs_all = torch.empty((n_layers, b, t + 1, h), dtype=torch.float32, device=dev)
+    cs_all = torch.empty((n_layers, b, t + 1, h), dtype=torch.float32, device=dev)
+    hb_all = torch.empty((n_layers, b, t + 1, h), dtype=torch.bfloat16, device=dev)
+    for state, init in ((hs_all, h0s), (cs_all, c0s), (hb_all, h0s)):
+        if init is None:
+            state[:, :, 0].zero_()
+        else:
+            state[:, :, 0].copy_(init.reshape(n_layers, b, h))
+    # bf16 operands of W_hh (every layer) and W_ih (layers 1..): the parameters' shadows, stale ones re-cast by one batched launch
+    wh_bf = weight_operands(w_hh)
+    wi_bf = [None] + weight_operands(w_ih[1:])
     for l in range(n_layers):
-        hs = torch.empty((b, t + 1, h), dtype=torch.float32, device=dev)
-        cs = torch.empty((b, t + 1, h), dtype=torch.float32, device=dev)
-        hb = torch.empty((b, t + 1, h), dtype=torch.bfloat16, device=dev)
-        for state, init in ((hs, h0s), (cs, c0s), (hb, h0s)):
-            if init is None:
-                state[:, 0].zero_()
-            else:
-                state[:, 0].copy_(init[l].reshape(b, h))
+        hs, cs, hb = hs_all[l], cs_all[l], hb_all[l]
         if l == n_layers - 1:
             o = torch.empty((b, t, h), dtype=torch.float32, device=dev)
         sv = torch.empty((b, t, 4 * h), dtype=torch.float32, device=dev)
-        whb = cast_pad_bf16(w_hh[l])
+        whb = wh_bf[l]
         d = descs[l]
         d.w_hh_bf, d.ldwh, d.b_hh = whb.data_ptr(), whb.shape[1], b_hh[l].data_ptr()
         if l == 0:
             d.xproj = xproj0.data_ptr()
         else:
-            wib = cast_pad_bf16(w_ih[l])
+            wib = wi_bf[l]
             d.w_ih_bf, d.ldwi, d.b_ih = wib.data_ptr(), wib.shape[1], b_ih[l].data_ptr()
             keep.append(wib)
         d.hstate, d.cstate, d.hstate_bf, d.saved = hs.data_ptr(), cs.data_ptr(), hb.data_ptr(), sv.data_ptr()
@@ -1192,13 +1215,15 @@ def lstm_pstack_bwd(grad_out, grad_hn, grad_cn, cstate, saved, w_ih, w_hh, seq_l
     dgates, dgates_bf, keep = [], [], []
     dh0 = torch.empty((n_layers, b, h), dtype=torch.float32, device=dev)
     dc0 = torch.empty((n_layers, b, h), dtype=torch.float32, device=dev)
+    wh_t = weight_operands(w_hh, transposed=True)                        # (h, 4h) each: the parameters' shadows
+    wi_t = [None] + weight_operands(w_ih[1:], transposed=True)
     for l in range(n_layers):
         d = descs[l]
-        wt = cast_transpose_bf16(w_hh[l])                                # (h, 4h)
+        wt = wh_t[l]
         keep.append(wt)
         d.w_hh_t_bf, d.ldt = wt.data_ptr(), wt.shape[1]
         if l + 1 < n_layers:
-            wu = cast_transpose_bf16(w_ih[l + 1])                        # (h, 4h): the layer above reads this layer's outputs
+            wu = wi_t[l + 1]                                             # (h, 4h): the layer above reads this layer's outputs
             keep.append(wu)
             d.w_ih_up_t_bf, d.ldt_up = wu.data_ptr(), wu.shape[1]
         else:
