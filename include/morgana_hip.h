@@ -347,6 +347,18 @@ int mg_linear_wgrad_slabs_bf16(const uint16_t* dY, int lddy, const uint16_t* A, 
  * launches.  Needs a wide-tile weight-gradient shape (as mg_linear_wgrad_slabs_bf16: MG_EINVAL otherwise); workspace as there. */
 int mg_linear_wgrad_dgrad_bf16(const uint16_t* dY, int lddy, const uint16_t* A, int lda, int64_t M, int N, int K, const uint16_t* WT, int ldwt,
                                uint16_t* dX, int lddx, void* workspace, size_t workspace_bytes, int* n_slabs, int64_t* stride, void* stream);
+/* mg_linear_wgrad_dgrad_bf16 with mg_expand_column_reduce_f32 (K1 section) riding at the end of the same grid: the phone-rate step's
+ * repeated prediction (out[f] = table[rows[f]], `frames` of them) and the ordered sum of the fused tail's slabs into tail_dst (+ the
+ * loss's constant term from stats_workspace / R / extra) are read by nothing before the update, so a step captured as a HIP graph
+ * lets them start on the CUs the dgrad tiles free first instead of paying a launch of their own.  Arguments as the two entry points;
+ * the same results bit for bit; shapes the one-grid form does not take run the separate launches.  loss_only != 0: of the slab sum
+ * only the last 16-element chunk - the one that holds the loss at tail_dst[tail_n - 1] - is formed (the caller's update kernel sums
+ * the slabs of the gradients itself: mg_adam_step_plan_f32 with the tail's slabs as a source). */
+int mg_linear_wgrad_dgrad_expand_bf16(const uint16_t* dY, int lddy, const uint16_t* A, int lda, int64_t M, int N, int K, const uint16_t* WT,
+                                      int ldwt, uint16_t* dX, int lddx, void* workspace, size_t workspace_bytes, int* n_slabs, int64_t* stride,
+                                      const float* table, const int32_t* rows, int64_t frames, float* out, const void* stats_workspace, int R,
+                                      int extra, const float* tail_slab, int64_t tail_n, int64_t tail_stride, int tail_S, float* tail_dst,
+                                      int loss_only, void* stream);
 /* dst[0 .. count) (+)= the ordered sum of n_slabs slabs, `stride` floats apart (the reduce launch of mg_linear_wgrad_bf16, bit for bit),
  * for a caller that took slabs from mg_linear_wgrad_slabs_bf16 / mg_linear_wgrad_dgrad_bf16 and needs the finished gradient before the
  * update (a data-parallel rank: its all-reduce comes first).  With db stored right behind dW (count = N*K + N) one launch does both. */
@@ -434,7 +446,9 @@ int mg_f0_l2tail_rows_bf16(const uint16_t* H1, int ldh1, int K2, const uint16_t*
                            float grad_scale, float* pred, float* loss, uint16_t* dZ2, int lddz, float* grads, int accumulate,
                            void* workspace, size_t workspace_bytes, void* stream);
 /* mg_f0_l2tail_rows_bf16 without its reduce launch: the workgroups' sums (32*128 + 32 + 32 + 2 floats each: dW3 | db3 | dW4 | db4 | loss)
- * stay at the start of `workspace`, *n_slabs of them, for mg_expand_column_reduce_f32. */
+ * stay at the start of `workspace`, *n_slabs of them, mg_f0_l2tail_slab_stride() floats apart, for mg_expand_column_reduce_f32 (or the
+ * update kernel's plan) to sum. */
+int64_t mg_f0_l2tail_slab_stride(void);
 int mg_f0_l2tail_rows_slabs_bf16(const uint16_t* H1, int ldh1, int K2, const uint16_t* W2, int ldw2, int N2, const float* b2, const float* W3,
                                  const float* b3, const float* W4, const float* b4, const float* target, const float* row_weight, int64_t M,
                                  float grad_scale, float* pred, uint16_t* dZ2, int lddz, void* workspace, size_t workspace_bytes, int* n_slabs,

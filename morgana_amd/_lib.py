@@ -66,6 +66,10 @@ SIGNATURES = {
                                            c_void_p, c_void_p, c_void_p]),
     'mg_linear_wgrad_dgrad_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                                            c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    'mg_linear_wgrad_dgrad_expand_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
+                                                  c_void_p, c_size_t, c_void_p, c_void_p,
+                                                  c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_int64,
+                                                  c_int, c_void_p, c_int, c_void_p]),
     'mg_slab_reduce_f32': (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_void_p]),
     'mg_adam_step_plan_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p,
                                       c_float, c_void_p, c_void_p]),
@@ -91,6 +95,7 @@ SIGNATURES = {
     'mg_expand_column_reduce_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_int64,
                                             c_int, c_void_p, c_void_p]),
     'mg_f0_l2tail_workspace_bytes': (c_size_t, [c_int64]),
+    'mg_f0_l2tail_slab_stride': (c_int64, []),
     'mg_f0_l2tail_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                   c_void_p, c_size_t, c_void_p]),

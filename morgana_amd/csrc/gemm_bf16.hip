@@ -16,6 +16,7 @@
 // The layer-1 gather (upsample_to_repetitions) is fused into the A-tile loaders through the `rows` array.
 // Epilogues stage the fp32 accumulators through LDS so that every global store is a 16-byte lane (8 bf16).
 #include "common.h"
+#include "expand_reduce.h"
 #include "phone_front.h"
 #include "slab_reduce.h"
 
@@ -389,7 +390,8 @@ extern "C" int mg_phone_front_check(const int64_t* dur, int B, int P, int T, con
                                     const int32_t* rows_mapped, const int32_t* seg_start, const int32_t* seg_end, const float* ybar,
                                     const float* weight, const void* workspace, size_t workspace_bytes, const char* who);
 int mg_launch_wgrad_dgrad_pair(const uint16_t* dY, int lddy, const uint16_t* A, int lda, int64_t M, int N, int K, const uint16_t* WT, int ldwt,
-                               uint16_t* dX, int lddx, float* slab, int64_t sstride, size_t slab_floats, int* S_out, hipStream_t st);
+                               uint16_t* dX, int lddx, float* slab, int64_t sstride, size_t slab_floats, int* S_out, hipStream_t st,
+                               const ExpandReduceArgs* rider);
 
 extern "C" {
 
@@ -616,7 +618,7 @@ int mg_linear_wgrad_dgrad_bf16(const uint16_t* dY, int lddy, const uint16_t* A, 
     const int64_t nk = (int64_t)N * K, sstride = nk + N;
     int S = 0;
     if (mg_launch_wgrad_dgrad_pair(dY, lddy, A, lda, M, N, K, WT, ldwt, dX, lddx, (float*)workspace, sstride, workspace_bytes / sizeof(float), &S,
-                                   (hipStream_t)stream) > 0) {
+                                   (hipStream_t)stream, nullptr) > 0) {
         MG_CHECK_LAUNCH("mg_linear_wgrad_dgrad_bf16/pair");
         *n_slabs = S;
         *stride = sstride;
@@ -625,6 +627,40 @@ int mg_linear_wgrad_dgrad_bf16(const uint16_t* dY, int lddy, const uint16_t* A, 
     const int rc = mg_linear_wgrad_slabs_bf16(dY, lddy, A, lda, nullptr, M, N, K, workspace, workspace_bytes, n_slabs, stride, stream);
     if (rc != MG_OK) return rc;
     return mg_linear_dgrad_bf16(dY, lddy, M, N, WT, ldwt, K, A, lda, dX, lddx, 0, stream);
+}
+
+// mg_linear_wgrad_dgrad_bf16 with mg_expand_column_reduce_f32 riding at the end of its grid (the repeated prediction and the ordered
+// sum of the fused tail's slabs: two jobs of the step's forward that nothing reads before the update); where the one-grid form does
+// not take the shape, the launches one after the other.  The same results as the separate calls, bit for bit.
+int mg_linear_wgrad_dgrad_expand_bf16(const uint16_t* dY, int lddy, const uint16_t* A, int lda, int64_t M, int N, int K, const uint16_t* WT,
+                                      int ldwt, uint16_t* dX, int lddx, void* workspace, size_t workspace_bytes, int* n_slabs, int64_t* stride,
+                                      const float* table, const int32_t* rows, int64_t frames, float* out, const void* stats_workspace, int R,
+                                      int extra, const float* tail_slab, int64_t tail_n, int64_t tail_stride, int tail_S, float* tail_dst,
+                                      int loss_only, void* stream) {
+    MG_CHECK_ARG(dY && A && WT && dX && workspace && n_slabs && stride && M > 0 && N > 0 && K > 0,
+                 "mg_linear_wgrad_dgrad_expand_bf16: bad arguments (M=%lld N=%d K=%d)", (long long)M, N, K);
+    MG_CHECK_ARG(lddy >= N && lda >= K && ldwt >= N && lddx >= K && lddy % 8 == 0 && lda % 8 == 0 && ldwt % 8 == 0 && lddx % 8 == 0,
+                 "mg_linear_wgrad_dgrad_expand_bf16: leading dimensions must be multiples of 8 and cover N=%d / K=%d (lddy=%d lda=%d ldwt=%d lddx=%d)",
+                 N, K, lddy, lda, ldwt, lddx);
+    MG_CHECK_ARG(al16(dY) && al16(A) && al16(WT) && al16(dX) && al16(workspace), "mg_linear_wgrad_dgrad_expand_bf16: buffers must be 16-byte aligned");
+    MG_CHECK_ARG(table && rows && out && stats_workspace && tail_slab && tail_dst && frames > 0 && R > 0 && extra >= 0 && tail_n > 0 &&
+                 tail_stride >= tail_n && tail_S > 0,
+                 "mg_linear_wgrad_dgrad_expand_bf16: bad rider arguments (frames=%lld n=%lld S=%d)", (long long)frames, (long long)tail_n, tail_S);
+    const int64_t nk = (int64_t)N * K, sstride = nk + N;
+    const ExpandReduceArgs xr{table, rows, frames, out, (const float*)stats_workspace, (int)(mg_ceil_div(R, 16) + mg_ceil_div(extra, 4)),
+                              tail_slab, tail_n, tail_stride, tail_S, tail_dst, loss_only ? (tail_n - 1) / 16 : 0};
+    int S = 0;
+    if (mg_launch_wgrad_dgrad_pair(dY, lddy, A, lda, M, N, K, WT, ldwt, dX, lddx, (float*)workspace, sstride, workspace_bytes / sizeof(float), &S,
+                                   (hipStream_t)stream, &xr) > 0) {
+        MG_CHECK_LAUNCH("mg_linear_wgrad_dgrad_expand_bf16/pair");
+        *n_slabs = S;
+        *stride = sstride;
+        return MG_OK;
+    }
+    // (loss_only: the separate launch sums every element - more than asked for, the same values where both write)
+    int rc = mg_expand_column_reduce_f32(table, rows, frames, out, stats_workspace, R, extra, tail_slab, tail_n, tail_stride, tail_S, tail_dst, stream);
+    if (rc != MG_OK) return rc;
+    return mg_linear_wgrad_dgrad_bf16(dY, lddy, A, lda, M, N, K, WT, ldwt, dX, lddx, workspace, workspace_bytes, n_slabs, stride, stream);
 }
 
 // mg_phone_front (frame map + per-phone loss statistics) and mg_linear_fwd_bf16 of the phone table's first layer - two launches that

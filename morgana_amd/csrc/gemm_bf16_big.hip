@@ -17,6 +17,7 @@
 // 128 x 128 x 3 per CU, 3 instead of 4 stages, two 64-deep stages, XCD-grouped wgrad block order, non-temporal streams.
 #include "common.h"
 #include "phone_front.h"
+#include "expand_reduce.h"
 
 #include <type_traits>
 
@@ -1213,20 +1214,27 @@ __global__ __launch_bounds__(512) void wgrad_big_rows_kernel(const uint16_t* __r
 // the phone-rate row count of C2 the first fills 96 CUs for 18 us and the second 168 for 16 us, one after the other; as parallel
 // branches of the step's HIP graph they were SLOWER (fork and join nodes), as one grid they simply share the chip.  wg_blocks must be a
 // multiple of 8 (both tile programs derive the XCD of a block from its id modulo 8).
+// With `riders` > 0 the grid ends in that many RIDER blocks (expand_reduce.h): the repeated prediction and the ordered sum of the fused
+// tail's slabs, two small jobs of the step's forward that nothing needs before the update - as a launch of their own they cost the
+// step 5.8 us plus a kernel boundary; here they start on the CUs the dgrad tiles free first (blocks are dispatched in id order) and
+// end about when the weight-gradient blocks do.
 template <int TKW, int BN>
 __global__ __launch_bounds__(512) void wgrad_dgrad_pair_kernel(unsigned wg_blocks, const uint16_t* __restrict__ dY, int lddy,
                                                                const uint16_t* __restrict__ A, int lda, int64_t M, int N, int K, int m_chunk,
                                                                float* __restrict__ slab, float* __restrict__ bslab, int64_t sstride,
                                                                int xcd_group, const uint16_t* __restrict__ WT, int ldwt,
                                                                const uint16_t* __restrict__ H, int ldh, void* __restrict__ dX, int lddx,
-                                                               int tiles_m, int tiles_n) {
+                                                               int tiles_m, int tiles_n, unsigned nt_blocks, ExpandReduceArgs xr, int riders) {
     constexpr int LDS = WG_BIG_LDS(TKW) > NT_BIG_LDS(BN) ? WG_BIG_LDS(TKW) : NT_BIG_LDS(BN);
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS];
     if (blockIdx.x < wg_blocks)
         wgrad_big_body<TKW>(smem, blockIdx.x, dY, lddy, A, lda, nullptr, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
-    else        // C[M, K] = dY[M, N] WT[K, N]^T with the sigmoid-grad epilogue: contraction N, output width K (as mg_linear_dgrad_bf16)
+    else if (blockIdx.x < wg_blocks + nt_blocks)
+        // C[M, K] = dY[M, N] WT[K, N]^T with the sigmoid-grad epilogue: contraction N, output width K (as mg_linear_dgrad_bf16)
         gemm_nt_big_body<BN, EPI_SIGMOID_GRAD>(smem, blockIdx.x - wg_blocks, dY, lddy, nullptr, M, N, WT, ldwt, K, nullptr, H, ldh, nullptr, dX,
                                                lddx, tiles_m, tiles_n, 0);
+    else
+        mg_expand_reduce_rider<512>(xr, (int)(blockIdx.x - wg_blocks - nt_blocks), riders, smem);
 }
 
 
@@ -1453,7 +1461,8 @@ int mg_launch_phone_front_gemm(const PhoneFrontArgs& pf, const uint16_t* A, int 
 // (32 CUs) takes ceil(tiles_m / 8) * tiles_n dgrad tiles plus S / 8 splits - S shrinks from the plan's to what is left (fewer, longer
 // splits; a 33rd workgroup on an XCD would wait for a whole tile program to finish).  Returns 1 and the split plan, or 0.
 int mg_launch_wgrad_dgrad_pair(const uint16_t* dY, int lddy, const uint16_t* A, int lda, int64_t M, int N, int K, const uint16_t* WT, int ldwt,
-                               uint16_t* dX, int lddx, float* slab, int64_t sstride, size_t slab_floats, int* S_out, hipStream_t st) {
+                               uint16_t* dX, int lddx, float* slab, int64_t sstride, size_t slab_floats, int* S_out, hipStream_t st,
+                               const ExpandReduceArgs* rider) {
     if (g_mg_tuning[MG_TUNE_AB] == 65) return 0;                   // A/B: the two launches
     int S = 0, m_chunk = 0;
     if (N != 128 || K != 512 || lda != 512 || lddx != K || mg_wgrad_big_plan(M, N, K, lda, lddy, &S, &m_chunk) <= 0) return 0;
@@ -1492,12 +1501,24 @@ int mg_launch_wgrad_dgrad_pair(const uint16_t* dY, int lddy, const uint16_t* A, 
     if (!found) return 0;
     if ((size_t)S * (size_t)sstride > slab_floats) return 0;
     const unsigned nt_blocks = (unsigned)(mg_ceil_div(tiles_m, 8) * 8 * tiles_n);
+    // riders: 2,048 frames (four per thread) and at most two 16-element chunks of the slab sum each
+    ExpandReduceArgs xr{};
+    int riders = 0;
+    if (rider) {
+        xr = *rider;
+        const int64_t by_frames = mg_ceil_div(xr.M, 2048), by_chunks = mg_ceil_div(mg_ceil_div(xr.n, 16) - xr.first_chunk, 2);
+        riders = (int)(by_frames > by_chunks ? by_frames : by_chunks);
+        if (riders < 1) riders = 1;
+        if (riders > 1024) riders = 1024;
+    }
     if (ksplit)
-        hipLaunchKernelGGL((wgrad_dgrad_pair_kernel<4, 256>), dim3((unsigned)(2 * S) + nt_blocks), dim3(512), 0, st, (unsigned)(2 * S), dY, lddy, A,
-                           lda, M, N, K, m_chunk, slab, slab + (int64_t)N * K, sstride, 1, WT, ldwt, A, lda, (void*)dX, lddx, (int)tiles_m, tiles_n);
+        hipLaunchKernelGGL((wgrad_dgrad_pair_kernel<4, 256>), dim3((unsigned)(2 * S) + nt_blocks + riders), dim3(512), 0, st, (unsigned)(2 * S), dY,
+                           lddy, A, lda, M, N, K, m_chunk, slab, slab + (int64_t)N * K, sstride, 1, WT, ldwt, A, lda, (void*)dX, lddx, (int)tiles_m,
+                           tiles_n, nt_blocks, xr, riders);
     else
-        hipLaunchKernelGGL((wgrad_dgrad_pair_kernel<8, 256>), dim3((unsigned)S + nt_blocks), dim3(512), 0, st, (unsigned)S, dY, lddy, A, lda, M, N,
-                           K, m_chunk, slab, slab + (int64_t)N * K, sstride, 1, WT, ldwt, A, lda, (void*)dX, lddx, (int)tiles_m, tiles_n);
+        hipLaunchKernelGGL((wgrad_dgrad_pair_kernel<8, 256>), dim3((unsigned)S + nt_blocks + riders), dim3(512), 0, st, (unsigned)S, dY, lddy, A, lda,
+                           M, N, K, m_chunk, slab, slab + (int64_t)N * K, sstride, 1, WT, ldwt, A, lda, (void*)dX, lddx, (int)tiles_m, tiles_n,
+                           nt_blocks, xr, riders);
     *S_out = S;
     return 1;
 }

@@ -36,6 +36,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define LT_N2 128
 #define LT_N3 32
 #define LT_SLAB (LT_N3 * LT_N2 + LT_N3 + LT_N3 + 2)      // dW3 | db3 | dW4 | db4 | loss   (the tail kernel's slab)
+#define LT_SLAB_STRIDE ((LT_SLAB + 3) / 4 * 4)           // floats between two workgroups' slabs: rows a consumer can read 16 bytes at a time
 
 // LDS map (bytes)
 #define LT_W2 0                                          // 128 rows x 1024 B, chunk c of row n at c ^ (n & 15)
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(256, 1) void f0_l2tail_kernel(const uint16_t* __res
         mine[LT_N3 * LT_N2 + 2 * LT_N3 + 1] = lossp;
     }
     __syncthreads();
-    float* out = slab + (size_t)blockIdx.x * LT_SLAB;
+    float* out = slab + (size_t)blockIdx.x * LT_SLAB_STRIDE;
     for (int e = tid; e < LT_SLAB; e += 256) out[e] = ((red[e] + red[LT_SLAB + e]) + red[2 * LT_SLAB + e]) + red[3 * LT_SLAB + e];
 #ifdef MG_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -879,7 +880,7 @@ __global__ __launch_bounds__(512, 2) void f0_l2tail_split_kernel(const uint16_t*
     if (wave < 4) __builtin_amdgcn_s_barrier();            // (A) pairs with the consumers' barrier: the W2 region becomes the sums
     __syncthreads();
     const float* red = reinterpret_cast<const float*>(smem + LT_W2);
-    float* out = slab + (size_t)blockIdx.x * LT_SLAB;
+    float* out = slab + (size_t)blockIdx.x * LT_SLAB_STRIDE;
     const bool failed = flags[8] != 0;                 // a wait gave up: the results are invalid and the loss says so (NaN)
     for (int e = tid; e < LT_SLAB; e += 512) {
         const float v = ((red[e] + red[LT_SLAB + e]) + red[2 * LT_SLAB + e]) + red[3 * LT_SLAB + e];
@@ -896,7 +897,7 @@ static int l2tail_blocks(int64_t M) {
 
 extern "C" {
 
-static size_t l2tail_slab_bytes(int64_t M) { return mg_align_up((size_t)l2tail_blocks(M) * LT_SLAB * sizeof(float), 256); }
+static size_t l2tail_slab_bytes(int64_t M) { return mg_align_up((size_t)l2tail_blocks(M) * LT_SLAB_STRIDE * sizeof(float), 256); }
 // slabs of the workgroups' sums (lab builds: + the hand-off ring of the role-split experiment, 3 slots x 8 KB per wave pair)
 size_t mg_f0_l2tail_workspace_bytes(int64_t M) {
 #ifdef MG_EXPERIMENTS
@@ -961,10 +962,10 @@ static int f0_l2tail_launch(const char* name, const uint16_t* H1, int ldh1, int 
     // grads = [dW3 (32*128) | db3 (32) | dW4 (32) | db4 (1)]; the loss is the last slab entry
     const int n_grads = LT_SLAB - 1;
     if (loss == grads + n_grads && !accumulate) {
-        mg_launch_slab_reduce(slab, LT_SLAB, LT_SLAB, blocks, grads, 0, st);          // loss stored right behind the gradients
+        mg_launch_slab_reduce(slab, LT_SLAB, LT_SLAB_STRIDE, blocks, grads, 0, st);   // loss stored right behind the gradients
     } else {
-        mg_launch_slab_reduce(slab, n_grads, LT_SLAB, blocks, grads, accumulate, st);
-        mg_launch_slab_reduce(slab + (LT_SLAB - 1), 1, LT_SLAB, blocks, loss, 0, st);
+        mg_launch_slab_reduce(slab, n_grads, LT_SLAB_STRIDE, blocks, grads, accumulate, st);
+        mg_launch_slab_reduce(slab + (LT_SLAB - 1), 1, LT_SLAB_STRIDE, blocks, loss, 0, st);
     }
     MG_CHECK_LAUNCH(name);
     return MG_OK;
@@ -1001,6 +1002,9 @@ int mg_f0_l2tail_rows_slabs_bf16(const uint16_t* H1, int ldh1, int K2, const uin
                             (int)(M < 2147483647LL ? M : 1), grad_scale, pred, nullptr, dZ2, lddz, nullptr, 0, workspace, workspace_bytes, stream,
                             n_slabs);
 }
+
+// floats between two slabs of mg_f0_l2tail_rows_slabs_bf16 (a multiple of 4: 16-byte loads for whoever sums them)
+int64_t mg_f0_l2tail_slab_stride(void) { return LT_SLAB_STRIDE; }
 
 #ifdef MG_STAMPS
 int mg_diag_read_stamps_lt(void* dst, size_t bytes) {

@@ -14,6 +14,7 @@
 // ignores them (their input is zero) and the bias gradients still see every frame.
 #include "common.h"
 #include "phone_front.h"
+#include "expand_reduce.h"
 
 typedef uint32_t pr_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -230,53 +231,12 @@ __global__ __launch_bounds__(256) void expand_column_kernel(const float* __restr
 // mg_slab_reduce_kernel's arithmetic (16 interleaved partitions, each ascending, then ascending over the partitions: the same bits).
 // The block that owns the LAST element (the loss, stored behind the gradients) adds the sum of the per-block partial sums of the
 // loss's constant term to it, as the last block of expand_column_kernel did after the reduce launch.
-__global__ __launch_bounds__(256) void expand_reduce_kernel(const float* __restrict__ table, const int32_t* __restrict__ rows, int64_t M,
-                                                            float* __restrict__ out, const float* __restrict__ partial, int n_partial,
-                                                            const float* __restrict__ slab, int64_t n, int64_t stride, int S,
-                                                            float* __restrict__ dst) {
+__global__ __launch_bounds__(256) void expand_reduce_kernel(ExpandReduceArgs a) {
     __shared__ float part[16][17];
     __shared__ float red[256];
     const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (f < M) out[f] = table[rows[f]];
-    const int64_t base = (int64_t)blockIdx.x * 16;
-    if (base >= n) return;                             // block-uniform
-    const int e = threadIdx.x & 15, p = threadIdx.x >> 4;
-    const int64_t i = base + e;
-    float v = 0.f;
-    if (i < n) {
-        // the partition's slabs in ascending order, their loads eight at a time (168 slabs at C2: 10-11 per partition - two round
-        // trips instead of three)
-        int s = p;
-        for (; s + 112 < S; s += 128) {
-            float t[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) t[q] = slab[(size_t)(s + 16 * q) * stride + i];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v += t[q];
-        }
-#pragma unroll 4
-        for (; s < S; s += 16) v += slab[(size_t)s * stride + i];
-    }
-    part[p][e] = v;
-    const bool owns_loss = base <= n - 1 && n - 1 < base + 16;        // block-uniform
-    float c = 0.f;
-    if (owns_loss)
-        for (int k = threadIdx.x; k < n_partial; k += 256) c += partial[k];
-    red[threadIdx.x] = c;
-    __syncthreads();
-    if (owns_loss) {
-        for (int s = 128; s > 0; s >>= 1) {
-            if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-            __syncthreads();
-        }
-    }
-    if (p == 0 && i < n) {
-        float t = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) t += part[q][e];
-        if (i == n - 1) t += red[0];
-        dst[i] = t;
-    }
+    if (f < a.M) a.out[f] = a.table[a.rows[f]];
+    mg_tail_chunk_reduce(a, (int64_t)blockIdx.x * 16, threadIdx.x, true, part, red);       // expand_reduce.h: the riders' arithmetic
 }
 
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int n, float* __restrict__ out,
@@ -443,8 +403,8 @@ int mg_expand_column_reduce_f32(const float* table, const int32_t* rows, int64_t
     const int n_partial = (int)(mg_ceil_div(R, 16) + mg_ceil_div(extra, 4));
     int64_t blocks = mg_ceil_div(M, 256);
     if (mg_ceil_div(n, 16) > blocks) blocks = mg_ceil_div(n, 16);
-    hipLaunchKernelGGL(expand_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, table, rows, M, out,
-                       (const float*)stats_workspace, n_partial, slab, n, stride, S, dst);
+    const ExpandReduceArgs xa{table, rows, M, out, (const float*)stats_workspace, n_partial, slab, n, stride, S, dst, 0};
+    hipLaunchKernelGGL(expand_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, xa);
     MG_CHECK_LAUNCH("mg_expand_column_reduce_f32");
     return MG_OK;
 }

@@ -62,6 +62,15 @@ def backward(loss):
 
 
 _DIRECT_BACKWARD = 0
+# Set by graphs.GraphedTrainStep while it captures a whole training step: the phone-rate stack then leaves the last two small jobs of
+# its forward (the repeated prediction, the fused tail's slab sum) to the end of the backward's first launch (LinearStackMSEFn).
+DEFER_TAIL = False
+
+
+def set_defer_tail(enabled):
+    global DEFER_TAIL
+    prev, DEFER_TAIL = DEFER_TAIL, bool(enabled) and os.environ.get('MORGANA_DEFER_TAIL', '1') != '0'
+    return prev
 
 
 def _is_unit_grad(g):
@@ -474,11 +483,18 @@ class LinearStackMSEFn(torch.autograd.Function):
             flat = torch.empty(sum(sizes) + 1, dtype=torch.float32, device=x2d.device)
             if not front:
                 ybar, weight, partials = ops.phone_target_stats(target.reshape(-1), rows, seg, seq_len, b, t, n_table, extra)
+            ctx.deferred_tail = None
             if l2tail and os.environ.get('MORGANA_EXPAND_REDUCE', '1') != '0':
-                # the tail's slab reduce rides in the launch that repeats the prediction (one node less, the same sums)
-                pred, loss, dz2 = ops.f0_l2tail_rows_expand(hidden[-1], w_bf[lead - 1], biases[lead - 1], weights[lead], biases[lead],
-                                                            weights[lead + 1], biases[lead + 1], ybar, weight, flat[offsets[2 * lead]:],
-                                                            rows, (partials, n_table, extra))
+                # the tail's slab reduce rides in the launch that repeats the prediction (one node less, the same sums) - and inside a
+                # step captured whole into a HIP graph (DEFER_TAIL: graphs.GraphedTrainStep) both ride at the end of the backward's
+                # first launch instead (ops.linear_wgrad_dgrad_bf16(tail=...)): pred / loss / the tail's gradients are then complete
+                # when the graph's backward part has run, which is all a replay can observe
+                defer = DEFER_TAIL and any(ctx.needs_input_grad[5:])        # (a backward pass will come: graphs.GraphedTrainStep)
+                res = ops.f0_l2tail_rows_expand(hidden[-1], w_bf[lead - 1], biases[lead - 1], weights[lead], biases[lead],
+                                                weights[lead + 1], biases[lead + 1], ybar, weight, flat[offsets[2 * lead]:],
+                                                rows, (partials, n_table, extra), defer=defer)
+                pred, loss, dz2 = res[:3]
+                ctx.deferred_tail = res[3] if defer else None
                 pred = pred.view(b, t, 1)
             else:
                 if l2tail:
@@ -542,6 +558,8 @@ class LinearStackMSEFn(torch.autograd.Function):
                     flat[ctx.offsets[2 * i + 1]:ctx.offsets[2 * i + 1] + n_])
 
         mode, opt = _grad_mode(ctx.params, grad_loss)
+        tail = getattr(ctx, 'deferred_tail', None)            # forward left the repeated prediction and the tail's slab sum to us
+        ctx.deferred_tail = None
         if mode != 'temp':
             # The gradients go where the optimiser reads them, without a temporary and an add in between: either straight into its flat
             # buffer (the reduce launches accumulate there) or - one rank, fused loop - as split-M slabs the update kernel sums itself.
@@ -553,6 +571,12 @@ class LinearStackMSEFn(torch.autograd.Function):
             top = lead - 1                                            # the 128-wide layer: its dZ came out of the fused tail
             n, k = ctx.dims[top]
             g_below = None
+            pair = (ctx.phone_rate and top > 0 and ctx.acts[top - 1] == ops.ACT_SIGMOID and
+                    ops.wgrad_slabs_ok(m_rows, n, k, hidden[top - 1].shape[1], g.shape[1]) and
+                    (mode == 'defer' or _grads_adjacent(params[2 * top], params[2 * top + 1])))
+            if tail is not None and not pair:                         # no launch to ride in: the two jobs run now, as their own launch
+                ops.finish_deferred_tail(tail)
+                tail = None
             # Frame rate, Linear + Sigmoid -> Linear(. -> 128) at the bottom of the stack: the second layer's weight gradient rides in
             # the fused backward of the first (ops.linear_bwd_fused2_slabs_bf16: the kernel stages dZ2 and H1 anyway), and the
             # stand-alone launch that re-read H1 from HBM goes.  Not beside an early gradient exchange: that one promises the second
@@ -576,19 +600,26 @@ class LinearStackMSEFn(torch.autograd.Function):
                 else:
                     params[2 * lead].grad.reshape(-1).as_strided((tail_count,), (1,)).add_(flat[tail_off:tail_off + tail_count])
                 return (None, None, None, None, None) + (None,) * len(params)
-            if (ctx.phone_rate and top > 0 and ctx.acts[top - 1] == ops.ACT_SIGMOID and
-                    ops.wgrad_slabs_ok(m_rows, n, k, hidden[top - 1].shape[1], g.shape[1]) and
-                    (mode == 'defer' or _grads_adjacent(params[2 * top], params[2 * top + 1]))):
+            tail_slabs = None
+            if pair and tail is not None and mode == 'defer':
+                # the update kernel sums the tail's slabs itself (one more source of its plan): the riders only repeat the prediction
+                # and finish the loss
+                tail = dict(tail, loss_only=True)
+                tail_slabs = (tail['ws'].view(torch.float32), tail['n_slabs'], tail['stride'])
+            if pair:
                 # this layer's weight gradient and the dgrad + sigmoid backward below it are independent and each fills part of the
                 # chip: one grid for both (mg_linear_wgrad_dgrad_bf16)
                 w_param = params[2 * top]
                 slab, n_slabs, stride, g_below = ops.linear_wgrad_dgrad_bf16(g, hidden[top - 1], m_rows, n, k, w_t[top],
-                                                                             slab=getattr(w_param, '_mg_slab_buf', None))
+                                                                             slab=getattr(w_param, '_mg_slab_buf', None), tail=tail)
+                tail = None
                 _slabs_into(mode, opt, w_param, params[2 * top + 1], slab, n_slabs, stride, n, k)
             else:
                 _wgrad_into(mode, opt, params[2 * top], params[2 * top + 1], g, hidden[top - 1] if top > 0 else a0,
                             None if top > 0 else r0, m_rows, n, k)
-            if mode == 'defer':
+            if tail_slabs is not None:
+                opt.defer_slabs(params[2 * lead], tail_count, tail_slabs[0], tail_slabs[1], tail_slabs[2])
+            elif mode == 'defer':
                 opt.defer_slabs(params[2 * lead], tail_count, flat[tail_off:tail_off + tail_count], 1, tail_count)
             else:
                 params[2 * lead].grad.reshape(-1).as_strided((tail_count,), (1,)).add_(flat[tail_off:tail_off + tail_count])
@@ -618,6 +649,9 @@ class LinearStackMSEFn(torch.autograd.Function):
                             None if i > 1 else r0, m_rows, n_, k_)
             return (None, None, None, None, None) + (None,) * len(params)
 
+        if tail is not None:                                          # gradients as tensors for autograd: nothing to ride in
+            ops.finish_deferred_tail(tail)
+            tail = None
         if ctx.phone_rate:
             # g is dL/dZ_1 per TABLE row already (the tail ran on phone rows with the frames' summed loss weights), so the remaining
             # backward is the ordinary chain on R + extra rows:  dW_1 = g^T H_table,  dZ_0 = (g W_1) * H (1 - H),  dW_0 = dZ_0^T X

@@ -153,6 +153,15 @@ class GraphedTrainStep(object):
         self.steps_done = warmup
 
     def _capture(self, mode):
+        # a step captured whole: what the forward leaves for the backward's first launch to finish (functional.DEFER_TAIL) cannot be
+        # observed half done - a replay runs forward and backward as one unit
+        prev = functional.set_defer_tail(True)
+        try:
+            self._capture_steps(mode)
+        finally:
+            functional.set_defer_tail(prev)
+
+    def _capture_steps(self, mode):
         with torch.cuda.graph(self._fwd_bwd, **mode):
             for j in range(self.steps_per_replay):
                 self.optimizer.zero_grad()

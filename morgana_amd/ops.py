@@ -48,6 +48,22 @@ def workspace(nbytes, device):
     return buf
 
 
+_tail_slab_bufs = {}
+
+
+def _tail_slabs(nbytes, device):
+    """Grow-only buffer per device for the fused tail's slabs when their sum is deferred (f0_l2tail_rows_expand(defer=True)); an
+    outgrown one is retired, not dropped (captured graphs keep its address)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    buf = _tail_slab_bufs.get(key)
+    if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _retired.append(buf)
+        buf = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=device)
+        _tail_slab_bufs[key] = buf
+    return buf
+
+
 def _slab_buffer(slab, nbytes, device):
     """A per-layer slab buffer of at least ``nbytes``: ``slab`` itself when it is large enough, else a new one - and the outgrown
     buffer is RETIRED, not dropped (as `workspace` does): a HIP graph captured at the smaller shape still launches the weight-gradient
@@ -477,20 +493,38 @@ def linear_wgrad_slabs_bf16(dy, a, rows, m, n, k, slab=None):
     return slab, n_slabs.value, stride.value
 
 
-def linear_wgrad_dgrad_bf16(dy, a, m, n, k, wt_bf16, slab=None):
+def linear_wgrad_dgrad_bf16(dy, a, m, n, k, wt_bf16, slab=None, tail=None):
     """linear_wgrad_slabs_bf16(dy, a) and linear_dgrad_bf16(dy, wt_bf16, h=a) of a Linear(k -> n) whose input ``a`` (m, lda) is the
     output of the Sigmoid below it - one grid for both where the shapes allow (mg_linear_wgrad_dgrad_bf16), the two launches otherwise.
-    Returns (slab buffer, n_slabs, stride, dx (m, pad8(k)) bf16).  Needs wgrad_slabs_ok(m, n, k, lda, lddy)."""
+    Returns (slab buffer, n_slabs, stride, dx (m, pad8(k)) bf16).  Needs wgrad_slabs_ok(m, n, k, lda, lddy).
+    ``tail``: the deferred end of f0_l2tail_rows_expand (its ``defer=True`` return) - the repeated prediction and the tail's slab sum
+    then ride at the end of this grid (mg_linear_wgrad_dgrad_expand_bf16)."""
     lib = _lib.load()
     nbytes = lib.mg_linear_wgrad_workspace_bytes(m, n, k)
     slab = _slab_buffer(slab, nbytes, dy.device)
     lddx = pad8(k)
     dx = torch.empty((m, lddx), dtype=torch.bfloat16, device=dy.device)
     n_slabs, stride = ctypes.c_int(0), ctypes.c_int64(0)
+    if tail is not None:
+        _lib.check(lib.mg_linear_wgrad_dgrad_expand_bf16(
+            _p(dy), dy.shape[1], _p(a), a.shape[1], m, n, k, _p(wt_bf16), wt_bf16.shape[1], _p(dx), lddx, _p(slab), slab.numel(),
+            ctypes.byref(n_slabs), ctypes.byref(stride), _p(tail['pred_rows']), _p(tail['rows']), tail['rows'].numel(), _p(tail['out']),
+            _p(tail['partials']), tail['n_table_rows'], tail['extra'], _p(tail['ws']), tail['n'], tail['stride'], tail['n_slabs'],
+            _p(tail['grads_out']), 1 if tail.get('loss_only') else 0, _stream()), 'mg_linear_wgrad_dgrad_expand_bf16')
+        return slab, n_slabs.value, stride.value, dx
     _lib.check(lib.mg_linear_wgrad_dgrad_bf16(_p(dy), dy.shape[1], _p(a), a.shape[1], m, n, k, _p(wt_bf16), wt_bf16.shape[1], _p(dx), lddx,
                                               _p(slab), slab.numel(), ctypes.byref(n_slabs), ctypes.byref(stride), _stream()),
                'mg_linear_wgrad_dgrad_bf16')
     return slab, n_slabs.value, stride.value, dx
+
+
+def finish_deferred_tail(tail):
+    """The deferred end of f0_l2tail_rows_expand as its own launch (mg_expand_column_reduce_f32) - for a backward pass that turns
+    out not to run the launch the tail was meant to ride in."""
+    _lib.check(_lib.load().mg_expand_column_reduce_f32(_p(tail['pred_rows']), _p(tail['rows']), tail['rows'].numel(), _p(tail['out']),
+                                                        _p(tail['partials']), tail['n_table_rows'], tail['extra'], _p(tail['ws']), tail['n'],
+                                                        tail['stride'], tail['n_slabs'], _p(tail['grads_out']), _stream()),
+               'mg_expand_column_reduce_f32')
 
 
 def slab_reduce(slab, n_slabs, stride, count, dst, accumulate=False):
@@ -696,10 +730,13 @@ def f0_l2tail_rows(h1, w2_bf, b2, w3, b3, w4, b4, target_rows, row_weight, grads
     return pred, loss, dz2
 
 
-def f0_l2tail_rows_expand(h1, w2_bf, b2, w3, b3, w4, b4, target_rows, row_weight, grads_out, rows, loss_const, grad_scale=1.0):
+def f0_l2tail_rows_expand(h1, w2_bf, b2, w3, b3, w4, b4, target_rows, row_weight, grads_out, rows, loss_const, grad_scale=1.0, defer=False):
     """f0_l2tail_rows + expand_column with the tail's reduce folded into the expansion's launch (mg_f0_l2tail_rows_slabs_bf16 +
     mg_expand_column_reduce_f32): one node less in the phone-rate step, same sums in the same order.  ``grads_out`` must have room for
-    the loss behind the tail's gradients; ``loss_const`` = (partials, n_table_rows, extra).  Returns (pred (frames,), loss, dz2)."""
+    the loss behind the tail's gradients; ``loss_const`` = (partials, n_table_rows, extra).  Returns (pred (frames,), loss, dz2).
+    ``defer``: the second launch is NOT made; a fourth return value describes it, for linear_wgrad_dgrad_bf16(tail=...) /
+    finish_deferred_tail - pred, loss and the tail's gradients are valid only after one of them ran (a step captured whole into a
+    HIP graph: functional.DEFER_TAIL)."""
     lib = _lib.load()
     m = h1.shape[0]
     n = 32 * 128 + 32 + 32 + 2                           # dW3 | db3 | dW4 | db4 | loss
@@ -707,7 +744,9 @@ def f0_l2tail_rows_expand(h1, w2_bf, b2, w3, b3, w4, b4, target_rows, row_weight
         raise ValueError('f0_l2tail_rows_expand: the gradient buffer needs one float behind the gradients for the loss')
     pred_rows = torch.empty((m,), dtype=torch.float32, device=h1.device)
     dz2 = torch.empty((m, 128), dtype=torch.bfloat16, device=h1.device)
-    ws = workspace(lib.mg_f0_l2tail_workspace_bytes(m), h1.device)
+    # deferred: the slabs must outlive this call (they are summed at the end of a later launch), so they do not go to the scratch
+    # buffer every kernel of the step shares
+    ws = (_tail_slabs if defer else workspace)(lib.mg_f0_l2tail_workspace_bytes(m), h1.device)
     n_slabs = ctypes.c_int(0)
     _lib.check(lib.mg_f0_l2tail_rows_slabs_bf16(_p(h1), h1.shape[1], 512, _p(w2_bf), w2_bf.shape[1], 128, _p(b2), _p(w3), _p(b3), _p(w4),
                                                 _p(b4), _p(target_rows), _p(row_weight), m, float(grad_scale), _p(pred_rows), _p(dz2),
@@ -715,8 +754,13 @@ def f0_l2tail_rows_expand(h1, w2_bf, b2, w3, b3, w4, b4, target_rows, row_weight
                'mg_f0_l2tail_rows_slabs_bf16')
     partials, n_table_rows, extra = loss_const
     out = torch.empty((rows.numel(),), dtype=torch.float32, device=h1.device)
+    stride = int(lib.mg_f0_l2tail_slab_stride())
+    if defer:
+        tail = dict(pred_rows=pred_rows, rows=rows, out=out, partials=partials, n_table_rows=int(n_table_rows), extra=int(extra), ws=ws,
+                    n=n, stride=stride, n_slabs=n_slabs.value, grads_out=grads_out)
+        return out, grads_out[n - 1], dz2, tail
     _lib.check(lib.mg_expand_column_reduce_f32(_p(pred_rows), _p(rows), rows.numel(), _p(out), _p(partials), n_table_rows, extra, _p(ws),
-                                               n, n, n_slabs.value, _p(grads_out), _stream()), 'mg_expand_column_reduce_f32')
+                                               n, stride, n_slabs.value, _p(grads_out), _stream()), 'mg_expand_column_reduce_f32')
     return out, grads_out[n - 1], dz2
 
 

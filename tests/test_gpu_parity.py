@@ -540,6 +540,43 @@ def test_l2tail_rows_kernel_vs_unfused_pair():
     assert torch.equal(grads_f[:4161], grads[:4161])
     assert got_loss.item() == loss.item() and loss.item() != loss_before.item()
 
+    # ... and both jobs DEFERRED to the end of the backward's first launch (a step captured whole into a HIP graph:
+    # mg_linear_wgrad_dgrad_expand_bf16 - rider blocks behind the weight-gradient and dgrad tiles of the 512 -> 128 layer): every
+    # output of the tail and of the pair EQUAL to the separate launches; nothing of the tail's is written before that launch
+    (_,), (w2_t,) = ops.cast_params_bf16([dev(rng.uniform(-0.08, 0.08, (128, 512)).astype(np.float32))], want_plain=True, want_t=(0,))
+    for frames_d in (frames, 256000):
+        rows_d = rows if frames_d == frames else dev(np.sort(rng.randint(0, m, size=frames_d)).astype(np.int32))
+        grads_w = torch.empty_like(grads)
+        want_p, want_l, dz2_w = ops.f0_l2tail_rows_expand(h1_d, w2_bf, b2, w3, b3, w4, b4, ybar, weight, grads_w, rows_d,
+                                                          (partials, n_table, extra))
+        want_l = want_l.clone()
+        slab_w, ns_w, st_w, dx_w = ops.linear_wgrad_dgrad_bf16(dz2_w, h1_d, m, 128, 512, w2_t)
+        slab_w = slab_w.view(torch.float32)[:ns_w * st_w].clone()
+        grads_d = torch.full_like(grads, float('nan'))
+        got_p, got_l, dz2_d, tail = ops.f0_l2tail_rows_expand(h1_d, w2_bf, b2, w3, b3, w4, b4, ybar, weight, grads_d, rows_d,
+                                                              (partials, n_table, extra), defer=True)
+        got_p.fill_(float('nan'))
+        assert torch.isnan(grads_d).all()                                 # deferred means deferred
+        slab_d, ns_d, st_d, dx_d = ops.linear_wgrad_dgrad_bf16(dz2_d, h1_d, m, 128, 512, w2_t, tail=tail)
+        assert (ns_d, st_d) == (ns_w, st_w) and torch.equal(dx_d, dx_w) and torch.equal(dz2_d, dz2_w)
+        assert torch.equal(slab_d.view(torch.float32)[:ns_d * st_d], slab_w)
+        assert torch.equal(got_p, want_p) and torch.equal(grads_d[:4162], grads_w[:4162]) and got_l.item() == want_l.item()
+        # ... or finished by a launch of its own when the backward pass has nothing for it to ride in
+        grads_e = torch.full_like(grads, float('nan'))
+        got_e, _, _, tail = ops.f0_l2tail_rows_expand(h1_d, w2_bf, b2, w3, b3, w4, b4, ybar, weight, grads_e, rows_d,
+                                                      (partials, n_table, extra), defer=True)
+        ops.finish_deferred_tail(tail)
+        assert torch.equal(got_e, want_p) and torch.equal(grads_e[:4162], grads_w[:4162])
+        # loss_only: the riders leave the gradients' sums to the update kernel (which takes the slabs as a source of its plan) and
+        # form the chunk that holds the loss
+        grads_l = torch.full_like(grads, float('nan'))
+        got_lp, got_ll, dz2_l, tail = ops.f0_l2tail_rows_expand(h1_d, w2_bf, b2, w3, b3, w4, b4, ybar, weight, grads_l, rows_d,
+                                                                (partials, n_table, extra), defer=True)
+        ops.linear_wgrad_dgrad_bf16(dz2_l, h1_d, m, 128, 512, w2_t, tail=dict(tail, loss_only=True))
+        assert torch.equal(got_lp, want_p) and got_ll.item() == want_l.item() and torch.isnan(grads_l[:4176 - 16]).all()
+        sums = ops.slab_reduce(tail['ws'], tail['n_slabs'], tail['stride'], 4161, torch.empty(4161, device=DEV))
+        assert torch.equal(sums, grads_w[:4161])                          # what the update kernel will form from the slabs
+
 
 @pytest.mark.parametrize('n,k,total', [(1536, 512, 9000), (384, 500, 4100), (1536, 512, 73613)])
 def test_wgrad_with_both_operands_gathered(n, k, total):
@@ -1908,6 +1945,47 @@ def test_graphed_train_step_equals_eager_steps():
     assert flat_e['step'] == flat_g['step'] == 9
     for key in ('param', 'exp_avg', 'exp_avg_sq'):
         assert torch.equal(flat_e[key], flat_g[key]), key
+
+
+def test_graphed_step_defers_the_tail():
+    """A C2 step captured whole (graphs.GraphedTrainStep) leaves the last two small jobs of the phone-rate forward - the repeated
+    prediction, the fused tail's slab sum - to rider blocks at the end of the backward's first launch
+    (mg_linear_wgrad_dgrad_expand_bf16 instead of mg_expand_column_reduce_f32 + mg_linear_wgrad_dgrad_bf16: five launches per step
+    instead of six); the eager loop keeps the separate launch, where forward outputs must be complete when forward returns.  Losses,
+    predictions, parameters and Adam moments of the two: EQUAL bit for bit."""
+    from morgana_amd import _lib, graphs, optim
+    feats = data.to_device(synthetic.make_batch(256, 1000, seed=9), DEV)
+    data.add_bf16_table(feats)
+
+    def fresh():
+        model = _load_state(models.F0Model(precision='bf16').to(DEV), synthetic.f0_model_state())
+        return model, optim.Adam(model.parameters(), lr=0.01, fused_loop=True)
+
+    model_e, opt_e = fresh()
+    losses_e = []
+    for i in range(5):
+        opt_e.zero_grad()
+        loss, out_e = model_e(feats)
+        F_hip.backward(loss)
+        opt_e.step()
+        losses_e.append(loss.item())
+    pred_e = (next(iter(out_e.values())) if isinstance(out_e, dict) else out_e).clone()
+    model_g, opt_g = fresh()
+    _lib.CALL_LOG = []
+    try:
+        step = graphs.GraphedTrainStep(model_g, opt_g, feats, warmup=2)
+        log = list(_lib.CALL_LOG)
+    finally:
+        _lib.CALL_LOG = None
+    captured = log[len(log) - [c for c in reversed(log)].index('mg_phone_front_linear_fwd_bf16') - 1:]      # the calls of the captured step
+    assert 'mg_linear_wgrad_dgrad_expand_bf16' in captured and 'mg_expand_column_reduce_f32' not in captured, captured
+    assert 'mg_expand_column_reduce_f32' in log                       # the two eager warm-up steps keep their own launch
+    losses_g = [step().clone() for _ in range(3)]
+    assert [v.item() for v in losses_g] == losses_e[2:]
+    pred_g = next(iter(step.output.values())) if isinstance(step.output, dict) else step.output
+    assert torch.equal(pred_g, pred_e)
+    for key in ('param', 'exp_avg', 'exp_avg_sq'):
+        assert torch.equal(opt_e.flat_buffers()[key], opt_g.flat_buffers()[key]), key
 
 
 @pytest.mark.parametrize('phone_rate', [True, False])
