@@ -455,13 +455,40 @@ def loss_curve_deviation(dev):
 
 
 def timed_leg(step, steps, warmup):
+    """ms per step of an eager loop.  Python's cyclic collector is run first and kept off while the clock runs: the legs before this
+    one leave captured HIP graphs and their private memory pools in reference cycles, and a collection that happens to fall into the
+    timed steps destroys them there - device frees that stall the host for tens of milliseconds with every kernel at its usual
+    duration (seen as 17 -> 25-43 ms on the LSTM leg, at random; profiles/r3_notes_power.txt, last section)."""
+    import gc
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
+    gc.collect()
+    torch.cuda.synchronize()
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        return _timed_steps(step, steps)
+    finally:
+        if gc_was_on:
+            gc.enable()
+
+
+def _timed_steps(step, steps):
+    debug = os.environ.get('MG_BENCH_DEBUG') == '1'
+    if debug:
+        st0 = torch.cuda.memory_stats()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    t_host = time.perf_counter() - t0
     torch.cuda.synchronize()
+    if debug:
+        st1 = torch.cuda.memory_stats()
+        sys.stderr.write('timed_leg: host issue %.2f ms/step, total %.2f ms/step, device mallocs %d frees %d retries %d reserved %.1f GB\n' % (
+            t_host / steps * 1e3, (time.perf_counter() - t0) / steps * 1e3, st1['num_device_alloc'] - st0['num_device_alloc'],
+            st1['num_device_free'] - st0['num_device_free'], st1['num_alloc_retries'] - st0['num_alloc_retries'],
+            st1['reserved_bytes.all.current'] / 1e9))
     return (time.perf_counter() - t0) / steps * 1e3
 
 
@@ -673,9 +700,12 @@ def main():
         except Exception as exc:                      # capture refused: time the eager loop and say so
             graph_note = 'eager launches (graph capture failed: %s)' % str(exc).splitlines()[0][:200]
             torch.cuda.synchronize()
+    import gc
     for _ in range(-(-args.warmup // per_call)):
         loss = step()
     torch.cuda.synchronize()
+    gc.collect()                                     # no cyclic collection (and none of the device frees it can trigger) inside a timed region
+    gc.disable()
     distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -685,6 +715,7 @@ def main():
     distributed.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -707,11 +738,14 @@ def main():
             for _ in range(-(-args.warmup // per_call)):
                 fr_step()
             torch.cuda.synchronize()
+            gc.collect()
+            gc.disable()
             t1 = time.perf_counter()
             for _ in range(args.steps // per_call):
                 fr_step()
             torch.cuda.synchronize()
             fr_ms = (time.perf_counter() - t1) / args.steps * 1e3
+            gc.enable()
             fr_tflops = F0_FLOPS_PER_FRAME * frames_per_step / (fr_ms * 1e-3) / 1e12
             frame_rate = {'ms_per_step': round(fr_ms, 4), 'value': round(frames_per_step / (fr_ms * 1e-3), 1), 'unit': 'frames/s',
                           'tflops': round(fr_tflops, 1), 'frac_of_mfma_peak': round(fr_tflops / MFMA_BF16_PEAK_TFLOPS, 4),

@@ -1119,14 +1119,25 @@ def lstm_pstack_fwd(xproj0, w_ih, w_hh, b_ih, b_hh, seq_len, h0s, c0s, b, t, h):
     hstate, cstate, saved, hstate_bf, keep, o = [], [], [], [], [], None
     descs = (_lib.LstmPStackLayer * n_layers)()
     # the state arrays of all layers in three allocations: their initial rows are set by three launches, not three per layer
-    hs_all = torch.empty((n_layers, b, t + 1, h), dtype=torch.float32, device=dev)
-    cs_all = torch.empty((n_layers, b, t + 1, h), dtype=torch.float32, device=dev)
-    hb_all = torch.empty((n_layers, b, t + 1, h), dtype=torch.bfloat16, device=dev)
-    for state, init in ((hs_all, h0s), (cs_all, c0s), (hb_all, h0s)):
-        if init is None:
-            state[:, :, 0].zero_()
-        else:
-            state[:, :, 0].copy_(init.reshape(n_layers, b, h))
+    if os.environ.get('MORGANA_LSTM_BATCH_STATES', '1') != '0':
+        hs_all = torch.empty((n_layers, b, t + 1, h), dtype=torch.float32, device=dev)
+        cs_all = torch.empty((n_layers, b, t + 1, h), dtype=torch.float32, device=dev)
+        hb_all = torch.empty((n_layers, b, t + 1, h), dtype=torch.bfloat16, device=dev)
+        for state, init in ((hs_all, h0s), (cs_all, c0s), (hb_all, h0s)):
+            if init is None:
+                state[:, :, 0].zero_()
+            else:
+                state[:, :, 0].copy_(init.reshape(n_layers, b, h))
+    else:
+        hs_all = [torch.empty((b, t + 1, h), dtype=torch.float32, device=dev) for _ in range(n_layers)]
+        cs_all = [torch.empty((b, t + 1, h), dtype=torch.float32, device=dev) for _ in range(n_layers)]
+        hb_all = [torch.empty((b, t + 1, h), dtype=torch.bfloat16, device=dev) for _ in range(n_layers)]
+        for l in range(n_layers):
+            for state, init in ((hs_all[l], h0s), (cs_all[l], c0s), (hb_all[l], h0s)):
+                if init is None:
+                    state[:, 0].zero_()
+                else:
+                    state[:, 0].copy_(init[l].reshape(b, h))
     # bf16 operands of W_hh (every layer) and W_ih (layers 1..): the parameters' shadows, stale ones re-cast by one batched launch
     wh_bf = weight_operands(w_hh)
     wi_bf = [None] + weight_operands(w_ih[1:])
