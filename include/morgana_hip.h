@@ -774,12 +774,30 @@ typedef struct {
     uint16_t* dst_t;
     int ldt;
 } mg_adam_shadow;
+/* What a step captured whole into a HIP graph leaves of its FORWARD for the update's launch (nothing can observe the step half done
+ * inside a replay): the per-phone prediction repeated to frames (out[f] = table[rows[f]], `frames` of them; 0 = none) and the loss =
+ * ordered sum over n_slabs slabs of their element n - 1 (+ the constant term: n_partial partial sums, or none), stored at dst[n - 1]
+ * (the 16-element chunk that holds it is formed: dst[16 ((n - 1) / 16) .. n)); n == 0: none.  Done by the launch's first blocks
+ * before their share of the update; the arithmetic of mg_expand_column_reduce_f32. */
+typedef struct {
+    const float* table;
+    const int32_t* rows;
+    int64_t frames;
+    float* out;
+    const float* partial;
+    int n_partial;
+    const float* slab;
+    int64_t n, stride;
+    int n_slabs;
+    float* dst;
+} mg_adam_tail;
 typedef struct {
     int n_slab_srcs;
     mg_adam_slab_src slabs[MG_ADAM_MAX_SLABS];
     int n_shadows;
     mg_adam_shadow shadows[MG_ADAM_MAX_SHADOWS];
     int clear_grad;
+    mg_adam_tail tail;
 } mg_adam_plan;
 int mg_adam_step_plan_f32(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1, float beta2, float eps,
                           float weight_decay, const float* scalars, float grad_scale, const mg_adam_plan* plan, void* stream);

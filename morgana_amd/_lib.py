@@ -253,10 +253,16 @@ class AdamShadow(ctypes.Structure):
 ADAM_MAX_SLABS, ADAM_MAX_SHADOWS = 4, 8
 
 
+class AdamTail(ctypes.Structure):
+    """mg_adam_tail of include/morgana_hip.h."""
+    _fields_ = [('table', c_void_p), ('rows', c_void_p), ('frames', c_int64), ('out', c_void_p), ('partial', c_void_p),
+                ('n_partial', c_int), ('slab', c_void_p), ('n', c_int64), ('stride', c_int64), ('n_slabs', c_int), ('dst', c_void_p)]
+
+
 class AdamPlan(ctypes.Structure):
     """mg_adam_plan of include/morgana_hip.h."""
     _fields_ = [('n_slab_srcs', c_int), ('slabs', AdamSlabSrc * ADAM_MAX_SLABS), ('n_shadows', c_int),
-                ('shadows', AdamShadow * ADAM_MAX_SHADOWS), ('clear_grad', c_int)]
+                ('shadows', AdamShadow * ADAM_MAX_SHADOWS), ('clear_grad', c_int), ('tail', AdamTail)]
 
 
 LSTM_MAX_LAYERS = 8

@@ -2,6 +2,7 @@
 // EMA (morgana/utils.py:443-456), fp32<->bf16 casts for the bf16 GEMM operands, stand-alone sigmoid.
 // All HBM-bound; one pass over flat buffers (the reference's foreach Adam is ~10 passes over 8 tensors).
 #include "common.h"
+#include "expand_reduce.h"
 
 #include <math.h>
 
@@ -62,6 +63,19 @@ __global__ __launch_bounds__(256) void adam_plan_kernel(float* __restrict__ para
                                                         float weight_decay, const float* __restrict__ scalars, float grad_scale,
                                                         mg_adam_plan plan) {
     __shared__ float part[16][68];
+    // the forward's deferred tail (mg_adam_tail): the first blocks repeat the prediction / form the loss before their share of the update
+    if (plan.tail.frames > 0 || plan.tail.n > 0) {
+        const mg_adam_tail& t = plan.tail;
+        const int64_t by_frames = (t.frames + 2047) / 2048;
+        int riders = (int)(by_frames > 1 ? by_frames : 1);
+        if (riders > (int)gridDim.x) riders = (int)gridDim.x;
+        if ((int)blockIdx.x < riders) {
+            const int64_t chunks = (t.n + 15) / 16;
+            const ExpandReduceArgs xr{t.table, t.rows, t.frames, t.out, t.partial, t.n_partial, t.slab, t.n, t.stride, t.n_slabs, t.dst,
+                                      t.n > 0 ? (t.n - 1) / 16 : chunks};
+            mg_expand_reduce_rider<256>(xr, (int)blockIdx.x, riders, reinterpret_cast<unsigned char*>(part));
+        }
+    }
     const float step_size = scalars[0], bc2_sqrt = scalars[1];
     const int e = threadIdx.x & 15, p = threadIdx.x >> 4;
     for (int64_t base = (int64_t)blockIdx.x * 64; base < n; base += (int64_t)gridDim.x * 64) {
@@ -337,6 +351,13 @@ int mg_adam_step_plan_f32(float* param, float* grad, float* exp_avg, float* exp_
                      "mg_adam_step_plan_f32: shadow %d does not lie inside the flat buffer", k);
         MG_CHECK_ARG((!sh.dst || sh.ldd >= sh.cols) && (!sh.dst_t || sh.ldt >= sh.rows), "mg_adam_step_plan_f32: shadow %d: ldd %d / ldt %d too small", k,
                      sh.ldd, sh.ldt);
+    }
+    {
+        const mg_adam_tail& t = plan->tail;
+        MG_CHECK_ARG(t.frames >= 0 && t.n >= 0 && (t.frames == 0 || (t.table && t.rows && t.out)) &&
+                         (t.n == 0 || (t.slab && t.dst && t.stride >= t.n && t.n_slabs >= 1 && (t.n_partial == 0 || t.partial))),
+                     "mg_adam_step_plan_f32: bad deferred tail (frames %lld, n %lld)", (long long)t.frames, (long long)t.n);
+        MG_CHECK_ARG((t.frames == 0 && t.n == 0) || n > 0, "mg_adam_step_plan_f32: a deferred tail needs a launch (n = 0)");
     }
     if (n == 0) return MG_OK;
     hipLaunchKernelGGL(adam_plan_kernel, dim3((unsigned)mg_ceil_div(n, 64)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,

@@ -602,10 +602,16 @@ class LinearStackMSEFn(torch.autograd.Function):
                 return (None, None, None, None, None) + (None,) * len(params)
             tail_slabs = None
             if pair and tail is not None and mode == 'defer':
-                # the update kernel sums the tail's slabs itself (one more source of its plan): the riders only repeat the prediction
-                # and finish the loss
-                tail = dict(tail, loss_only=True)
+                # the update kernel sums the tail's slabs itself (one more source of its plan), and its launch's first blocks repeat
+                # the prediction and form the loss (optim.Adam.defer_tail: mg_adam_tail) - measured against riders at the end of the
+                # pair grid below, which is where these two jobs go when the gradients must be complete before the update (a
+                # data-parallel rank: mode 'direct')
                 tail_slabs = (tail['ws'].view(torch.float32), tail['n_slabs'], tail['stride'])
+                if os.environ.get('MORGANA_TAIL_RIDERS', 'adam') == 'adam':
+                    opt.defer_tail(params[2 * lead], tail)
+                    tail = None
+                else:
+                    tail = dict(tail, loss_only=True)
             if pair:
                 # this layer's weight gradient and the dgrad + sigmoid backward below it are independent and each fills part of the
                 # chip: one grid for both (mg_linear_wgrad_dgrad_bf16)

@@ -1361,7 +1361,7 @@ def adam_step_dev(param, grad, exp_avg, exp_avg_sq, betas, eps, weight_decay, sc
 
 
 def adam_step_plan(param, grad, exp_avg, exp_avg_sq, betas, eps, weight_decay, scalars, grad_scale=1.0, slab_srcs=(), shadows=(),
-                   clear_grad=False):
+                   clear_grad=False, tail=None):
     """The update as the last node of a step (mg_adam_step_plan_f32): ``slab_srcs`` = [(begin, count, slab tensor, n_slabs, stride)]
     are summed into the gradient on the fly (split-M partial results of the weight-gradient GEMMs, in the slab reduce's order),
     ``shadows`` = [(offset, rows, cols, bf16 [rows, ldd] or None, bf16 transpose [cols, ldt] or None)] are refreshed from the
@@ -1379,6 +1379,17 @@ def adam_step_plan(param, grad, exp_avg, exp_avg_sq, betas, eps, weight_decay, s
         sh.offset, sh.rows, sh.cols = int(offset), int(rows), int(cols)
         sh.dst, sh.ldd = (dst.data_ptr(), dst.shape[1]) if dst is not None else (None, 0)
         sh.dst_t, sh.ldt = (dst_t.data_ptr(), dst_t.shape[1]) if dst_t is not None else (None, 0)
+    if tail is not None:
+        # the forward's deferred tail (f0_l2tail_rows_expand(defer=True) / f0_l2tail(defer=True)): the launch's first blocks repeat the
+        # prediction and form the loss
+        t = plan.tail
+        if tail.get('rows') is not None:
+            t.table, t.rows, t.frames, t.out = tail['pred_rows'].data_ptr(), tail['rows'].data_ptr(), tail['rows'].numel(), tail['out'].data_ptr()
+        if tail.get('partials') is not None:
+            t.partial = tail['partials'].data_ptr()
+            t.n_partial = (int(tail['n_table_rows']) + 15) // 16 + (int(tail['extra']) + 3) // 4
+        t.slab, t.n, t.stride, t.n_slabs, t.dst = tail['ws'].data_ptr(), int(tail['n']), int(tail['stride']), int(tail['n_slabs']), \
+            tail['grads_out'].data_ptr()
     _lib.check(lib.mg_adam_step_plan_f32(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), float(betas[0]),
                                          float(betas[1]), float(eps), float(weight_decay), _p(scalars), float(grad_scale),
                                          ctypes.byref(plan), _stream()), 'mg_adam_step_plan_f32')

@@ -79,6 +79,9 @@ class Adam(torch.optim.Optimizer):
                 else:
                     flat['grad'].zero_()
                 flat['pending'] = []              # partial results nobody consumed belong to a gradient that is being dropped
+                if flat.get('tail') is not None:  # a forward's deferred tail whose update never came: finish it as its own launch
+                    ops.finish_deferred_tail(flat['tail'])
+                    flat['tail'] = None
                 off = 0
                 for p in flat['params']:          # re-attach views a caller may have dropped (set_to_none habits)
                     n = p.numel()
@@ -111,6 +114,18 @@ class Adam(torch.optim.Optimizer):
                     flat['pending'].append((off, int(count), slab, int(n_slabs), int(stride)))
                 return
         raise ValueError('defer_slabs: the parameter is not one of this optimiser\'s')
+
+    def defer_tail(self, first_param, tail):
+        """A forward pass's deferred tail (ops.f0_l2tail_rows_expand(defer=True)): the next update launch of the group that holds
+        ``first_param`` repeats the prediction and forms the loss in its first blocks (mg_adam_tail).  Only inside a step captured
+        whole into a HIP graph: until that launch has run, the loss and the frame-level prediction are not valid."""
+        for flat in self._flat:
+            if flat is not None and id(first_param) in flat['offsets']:
+                if flat.get('tail') is not None:
+                    raise RuntimeError('defer_tail: the previous deferred tail was never consumed')
+                flat['tail'] = tail
+                return
+        raise ValueError('defer_tail: the parameter is not one of this optimiser\'s')
 
     def _shadows(self, flat):
         """(offset, rows, cols, plain, transposed) for every 2-D parameter that carries bf16 operand copies (ops.param_shadows)."""
@@ -192,9 +207,10 @@ class Adam(torch.optim.Optimizer):
         # ops.param_shadows re-casts them when the next forward pass asks for them
         shadows = self._shadows(flat)[:_lib.ADAM_MAX_SHADOWS]
         pending, flat['pending'] = flat['pending'], []
+        tail, flat['tail'] = flat.get('tail'), None
         ops.adam_step_plan(flat['param'], flat['grad'], flat['exp_avg'], flat['exp_avg_sq'], group['betas'], group['eps'],
                            group['weight_decay'], self._scalar_buffers(flat)[2 * slot:], 1.0 / world, slab_srcs=pending,
-                           shadows=[sh[:5] for sh in shadows], clear_grad=self.fused_loop)
+                           shadows=[sh[:5] for sh in shadows], clear_grad=self.fused_loop, tail=tail)
         flat['clean'] = self.fused_loop
         for p in flat['params']:
             p._mg_updates = getattr(p, '_mg_updates', 0) + 1

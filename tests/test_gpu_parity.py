@@ -1978,7 +1978,9 @@ def test_graphed_step_defers_the_tail():
     finally:
         _lib.CALL_LOG = None
     captured = log[len(log) - [c for c in reversed(log)].index('mg_phone_front_linear_fwd_bf16') - 1:]      # the calls of the captured step
-    assert 'mg_linear_wgrad_dgrad_expand_bf16' in captured and 'mg_expand_column_reduce_f32' not in captured, captured
+    # one rank, fused loop: the two jobs ride in the UPDATE launch's first blocks (mg_adam_tail), the tail's slabs are a source of its
+    # plan; a rank whose gradients must be complete before the update takes mg_linear_wgrad_dgrad_expand_bf16 (riders behind the pair grid)
+    assert 'mg_expand_column_reduce_f32' not in captured and 'mg_linear_wgrad_dgrad_bf16' in captured, captured
     assert 'mg_expand_column_reduce_f32' in log                       # the two eager warm-up steps keep their own launch
     losses_g = [step().clone() for _ in range(3)]
     assert [v.item() for v in losses_g] == losses_e[2:]
