@@ -440,6 +440,12 @@ int mg_f0_l2tail_bf16(const uint16_t* H1, int ldh1, int K2, const uint16_t* W2, 
                       const float* b3, const float* W4, const float* b4, const float* target, const int64_t* seq_len, int B, int T,
                       float grad_scale, float* pred, float* loss, uint16_t* dZ2, int lddz, float* grads, int accumulate, void* workspace,
                       size_t workspace_bytes, void* stream);
+/* mg_f0_l2tail_bf16 without its reduce launch (as mg_f0_l2tail_rows_slabs_bf16 below): the slabs stay in `workspace` for the update
+ * kernel's plan - gradients as a slab source, the loss through mg_adam_tail.  For a step captured whole into a HIP graph. */
+int mg_f0_l2tail_slabs_bf16(const uint16_t* H1, int ldh1, int K2, const uint16_t* W2, int ldw2, int N2, const float* b2, const float* W3,
+                            const float* b3, const float* W4, const float* b4, const float* target, const int64_t* seq_len, int B, int T,
+                            float grad_scale, float* pred, uint16_t* dZ2, int lddz, void* workspace, size_t workspace_bytes, int* n_slabs,
+                            void* stream);
 /* ... on M rows that each stand for a group of frames (phone-rate step), as mg_f0_tail_rows_bf16. */
 int mg_f0_l2tail_rows_bf16(const uint16_t* H1, int ldh1, int K2, const uint16_t* W2, int ldw2, int N2, const float* b2, const float* W3,
                            const float* b3, const float* W4, const float* b4, const float* target, const float* row_weight, int64_t M,

@@ -89,6 +89,9 @@ SIGNATURES = {
     'mg_linear_bwd_fused2_slabs_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                                 c_int64, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
                                                 c_void_p]),
+    'mg_f0_l2tail_slabs_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p,
+                                        c_void_p]),
     'mg_f0_l2tail_rows_slabs_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_int, c_void_p,
                                              c_size_t, c_void_p, c_void_p]),

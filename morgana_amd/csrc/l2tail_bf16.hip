@@ -980,6 +980,18 @@ int mg_f0_l2tail_bf16(const uint16_t* H1, int ldh1, int K2, const uint16_t* W2, 
                             grad_scale, pred, loss, dZ2, lddz, grads, accumulate, workspace, workspace_bytes, stream);
 }
 
+// mg_f0_l2tail_bf16 without its reduce launch: the workgroups' sums stay in `workspace` as *n_slabs slabs (mg_f0_l2tail_slab_stride()
+// floats apart; 32*128 + 32 + 32 + 2 floats used: dW3 | db3 | dW4 | db4 | loss) for the update kernel's plan to sum (gradients: a slab
+// source; loss: mg_adam_tail) - a step captured whole into a HIP graph, where nothing reads the loss before the update has run.
+int mg_f0_l2tail_slabs_bf16(const uint16_t* H1, int ldh1, int K2, const uint16_t* W2, int ldw2, int N2, const float* b2, const float* W3,
+                            const float* b3, const float* W4, const float* b4, const float* target, const int64_t* seq_len, int B, int T,
+                            float grad_scale, float* pred, uint16_t* dZ2, int lddz, void* workspace, size_t workspace_bytes, int* n_slabs,
+                            void* stream) {
+    MG_CHECK_ARG(B > 0 && T > 0 && n_slabs, "mg_f0_l2tail_slabs_bf16: bad arguments (B=%d T=%d)", B, T);
+    return f0_l2tail_launch("mg_f0_l2tail_slabs_bf16", H1, ldh1, K2, W2, ldw2, N2, b2, W3, b3, W4, b4, target, seq_len, nullptr, (int64_t)B * T, B, T,
+                            grad_scale, pred, nullptr, dZ2, lddz, nullptr, 0, workspace, workspace_bytes, stream, n_slabs);
+}
+
 int mg_f0_l2tail_rows_bf16(const uint16_t* H1, int ldh1, int K2, const uint16_t* W2, int ldw2, int N2, const float* b2, const float* W3,
                            const float* b3, const float* W4, const float* b4, const float* target, const float* row_weight, int64_t M,
                            float grad_scale, float* pred, float* loss, uint16_t* dZ2, int lddz, float* grads, int accumulate,

@@ -529,9 +529,15 @@ class LinearStackMSEFn(torch.autograd.Function):
             offsets.append(offsets[-1] + sz)
         flat = torch.empty(sum(sizes) + 1, dtype=torch.float32, device=x2d.device)    # + 1: the loss (see ops.f0_tail)
         tail_off = offsets[2 * lead]
+        ctx.deferred_tail = None
         if l2tail:
-            pred, loss, dz2 = ops.f0_l2tail(hidden[-1], w_bf[lead - 1], biases[lead - 1], weights[lead], biases[lead], weights[lead + 1],
-                                            biases[lead + 1], target.reshape(-1), seq_len, b, t, flat[tail_off:])
+            # inside a step captured whole (DEFER_TAIL) the tail's reduce launch is left out: the update kernel sums the slabs (a source
+            # of its plan) and forms the loss (optim.Adam.defer_tail) - see the phone-rate branch above
+            defer = DEFER_TAIL and any(ctx.needs_input_grad[5:])
+            res = ops.f0_l2tail(hidden[-1], w_bf[lead - 1], biases[lead - 1], weights[lead], biases[lead], weights[lead + 1],
+                                biases[lead + 1], target.reshape(-1), seq_len, b, t, flat[tail_off:], defer=defer)
+            pred, loss, dz2 = res[:3]
+            ctx.deferred_tail = res[3] if defer else None
         else:
             pred, loss, dz2 = ops.f0_tail(hidden[-1], weights[lead], biases[lead], weights[lead + 1], biases[lead + 1],
                                           target.reshape(-1), seq_len, b, t, flat[tail_off:])
@@ -574,9 +580,25 @@ class LinearStackMSEFn(torch.autograd.Function):
             pair = (ctx.phone_rate and top > 0 and ctx.acts[top - 1] == ops.ACT_SIGMOID and
                     ops.wgrad_slabs_ok(m_rows, n, k, hidden[top - 1].shape[1], g.shape[1]) and
                     (mode == 'defer' or _grads_adjacent(params[2 * top], params[2 * top + 1])))
+            tail_slabs = None
+            if tail is not None and tail.get('rows') is None:         # frame-rate tail: only its reduce launch was left out
+                if mode == 'defer':
+                    tail_slabs = (tail['ws'].view(torch.float32), tail['n_slabs'], tail['stride'])
+                    opt.defer_tail(params[2 * lead], tail)            # the update launch forms the loss
+                else:
+                    ops.finish_deferred_tail(tail)
+                tail = None
             if tail is not None and not pair:                         # no launch to ride in: the two jobs run now, as their own launch
                 ops.finish_deferred_tail(tail)
                 tail = None
+
+            def hand_over_tail_grads():
+                if tail_slabs is not None:                            # the update kernel sums the tail's slabs itself
+                    opt.defer_slabs(params[2 * lead], tail_count, tail_slabs[0], tail_slabs[1], tail_slabs[2])
+                elif mode == 'defer':
+                    opt.defer_slabs(params[2 * lead], tail_count, flat[tail_off:tail_off + tail_count], 1, tail_count)
+                else:
+                    params[2 * lead].grad.reshape(-1).as_strided((tail_count,), (1,)).add_(flat[tail_off:tail_off + tail_count])
             # Frame rate, Linear + Sigmoid -> Linear(. -> 128) at the bottom of the stack: the second layer's weight gradient rides in
             # the fused backward of the first (ops.linear_bwd_fused2_slabs_bf16: the kernel stages dZ2 and H1 anyway), and the
             # stand-alone launch that re-read H1 from HBM goes.  Not beside an early gradient exchange: that one promises the second
@@ -595,12 +617,8 @@ class LinearStackMSEFn(torch.autograd.Function):
                         opt.defer_slabs(first, cnt, floats[off:], n_slabs, st)
                     else:
                         ops.slab_reduce(floats[off:], n_slabs, st, cnt, first.grad.reshape(-1).as_strided((cnt,), (1,)), accumulate=True)
-                if mode == 'defer':
-                    opt.defer_slabs(params[2 * lead], tail_count, flat[tail_off:tail_off + tail_count], 1, tail_count)
-                else:
-                    params[2 * lead].grad.reshape(-1).as_strided((tail_count,), (1,)).add_(flat[tail_off:tail_off + tail_count])
+                hand_over_tail_grads()
                 return (None, None, None, None, None) + (None,) * len(params)
-            tail_slabs = None
             if pair and tail is not None and mode == 'defer':
                 # the update kernel sums the tail's slabs itself (one more source of its plan), and its launch's first blocks repeat
                 # the prediction and form the loss (optim.Adam.defer_tail: mg_adam_tail) - measured against riders at the end of the
@@ -623,12 +641,7 @@ class LinearStackMSEFn(torch.autograd.Function):
             else:
                 _wgrad_into(mode, opt, params[2 * top], params[2 * top + 1], g, hidden[top - 1] if top > 0 else a0,
                             None if top > 0 else r0, m_rows, n, k)
-            if tail_slabs is not None:
-                opt.defer_slabs(params[2 * lead], tail_count, tail_slabs[0], tail_slabs[1], tail_slabs[2])
-            elif mode == 'defer':
-                opt.defer_slabs(params[2 * lead], tail_count, flat[tail_off:tail_off + tail_count], 1, tail_count)
-            else:
-                params[2 * lead].grad.reshape(-1).as_strided((tail_count,), (1,)).add_(flat[tail_off:tail_off + tail_count])
+            hand_over_tail_grads()
             for i in range(top, 0, -1):
                 n, k = ctx.dims[i]
                 if i == 1 and _EARLY_GRADS_HOOK is not None:

@@ -520,7 +520,10 @@ def linear_wgrad_dgrad_bf16(dy, a, m, n, k, wt_bf16, slab=None, tail=None):
 
 def finish_deferred_tail(tail):
     """The deferred end of f0_l2tail_rows_expand as its own launch (mg_expand_column_reduce_f32) - for a backward pass that turns
-    out not to run the launch the tail was meant to ride in."""
+    out not to run the launch the tail was meant to ride in; of f0_l2tail(defer=True): its reduce launch (mg_slab_reduce_f32)."""
+    if tail.get('rows') is None:
+        slab_reduce(tail['ws'], tail['n_slabs'], tail['stride'], tail['n'], tail['grads_out'])
+        return
     _lib.check(_lib.load().mg_expand_column_reduce_f32(_p(tail['pred_rows']), _p(tail['rows']), tail['rows'].numel(), _p(tail['out']),
                                                         _p(tail['partials']), tail['n_table_rows'], tail['extra'], _p(tail['ws']), tail['n'],
                                                         tail['stride'], tail['n_slabs'], _p(tail['grads_out']), _stream()),
@@ -699,15 +702,28 @@ def l2tail_ok(w2, w3, w4, act2):
             and os.environ.get('MORGANA_L2TAIL', '1') != '0')
 
 
-def f0_l2tail(h1, w2_bf, b2, w3, b3, w4, b4, target, seq_len, b, t, grads_out, grad_scale=1.0):
+def f0_l2tail(h1, w2_bf, b2, w3, b3, w4, b4, target, seq_len, b, t, grads_out, grad_scale=1.0, defer=False):
     """Layer 2 (512 -> 128, sigmoid) + layers 3-4 + masked MSE, forward and backward, in one pass over H1 (mg_f0_l2tail_bf16).
-    Returns (pred (b*t,), loss 0-d, dz2 (b*t, 128) bf16); the 128-wide activation is never written."""
+    Returns (pred (b*t,), loss 0-d, dz2 (b*t, 128) bf16); the 128-wide activation is never written.
+    ``defer``: the reduce launch is NOT made (mg_f0_l2tail_slabs_bf16); a fourth return value describes what is left - the sum of the
+    workgroups' slabs into ``grads_out`` (gradients and, behind them, the loss) - for optim.Adam.defer_tail / finish_deferred_tail."""
     lib = _lib.load()
     m = b * t
     pred = torch.empty((m,), dtype=torch.float32, device=h1.device)
     n_grads = 32 * 128 + 32 + 32 + 1
     loss = grads_out[n_grads] if grads_out.numel() > n_grads else torch.empty((), dtype=torch.float32, device=h1.device)
     dz2 = torch.empty((m, 128), dtype=torch.bfloat16, device=h1.device)
+    if defer:
+        if grads_out.numel() <= n_grads:
+            raise ValueError('f0_l2tail(defer=True): the gradient buffer needs one float behind the gradients for the loss')
+        ws = _tail_slabs(lib.mg_f0_l2tail_workspace_bytes(m), h1.device)
+        n_slabs = ctypes.c_int(0)
+        _lib.check(lib.mg_f0_l2tail_slabs_bf16(_p(h1), h1.shape[1], 512, _p(w2_bf), w2_bf.shape[1], 128, _p(b2), _p(w3), _p(b3), _p(w4),
+                                               _p(b4), _p(target), _p(seq_len), b, t, float(grad_scale), _p(pred), _p(dz2), 128, _p(ws),
+                                               ws.numel(), ctypes.byref(n_slabs), _stream()), 'mg_f0_l2tail_slabs_bf16')
+        tail = dict(rows=None, partials=None, ws=ws, n=n_grads + 1, stride=int(lib.mg_f0_l2tail_slab_stride()), n_slabs=n_slabs.value,
+                    grads_out=grads_out)
+        return pred, loss, dz2, tail
     ws = workspace(lib.mg_f0_l2tail_workspace_bytes(m), h1.device)
     _lib.check(lib.mg_f0_l2tail_bf16(_p(h1), h1.shape[1], 512, _p(w2_bf), w2_bf.shape[1], 128, _p(b2), _p(w3), _p(b3), _p(w4), _p(b4),
                                      _p(target), _p(seq_len), b, t, float(grad_scale), _p(pred), _p(loss), _p(dz2), 128,

@@ -1947,14 +1947,16 @@ def test_graphed_train_step_equals_eager_steps():
         assert torch.equal(flat_e[key], flat_g[key]), key
 
 
-def test_graphed_step_defers_the_tail():
+@pytest.mark.parametrize('phone_rate', [True, False])
+def test_graphed_step_defers_the_tail(phone_rate, monkeypatch):
     """A C2 step captured whole (graphs.GraphedTrainStep) leaves the last two small jobs of the phone-rate forward - the repeated
     prediction, the fused tail's slab sum - to rider blocks at the end of the backward's first launch
     (mg_linear_wgrad_dgrad_expand_bf16 instead of mg_expand_column_reduce_f32 + mg_linear_wgrad_dgrad_bf16: five launches per step
     instead of six); the eager loop keeps the separate launch, where forward outputs must be complete when forward returns.  Losses,
     predictions, parameters and Adam moments of the two: EQUAL bit for bit."""
     from morgana_amd import _lib, graphs, optim
-    feats = data.to_device(synthetic.make_batch(256, 1000, seed=9), DEV)
+    monkeypatch.setattr(ops, 'PHONE_RATE', phone_rate)       # False: the reference's order of operations - there the tail's reduce launch
+    feats = data.to_device(synthetic.make_batch(256, 1000, seed=9), DEV)      # (mg_slab_reduce_f32 inside mg_f0_l2tail_bf16) is what goes
     data.add_bf16_table(feats)
 
     def fresh():
@@ -1977,11 +1979,17 @@ def test_graphed_step_defers_the_tail():
         log = list(_lib.CALL_LOG)
     finally:
         _lib.CALL_LOG = None
-    captured = log[len(log) - [c for c in reversed(log)].index('mg_phone_front_linear_fwd_bf16') - 1:]      # the calls of the captured step
+    first = 'mg_phone_front_linear_fwd_bf16' if phone_rate else 'mg_upsample_index_maps'
+    first = first if first in log else [c for c in log if 'upsample' in c][0]
+    captured = log[len(log) - [c for c in reversed(log)].index(first) - 1:]      # the calls of the captured step
     # one rank, fused loop: the two jobs ride in the UPDATE launch's first blocks (mg_adam_tail), the tail's slabs are a source of its
     # plan; a rank whose gradients must be complete before the update takes mg_linear_wgrad_dgrad_expand_bf16 (riders behind the pair grid)
-    assert 'mg_expand_column_reduce_f32' not in captured and 'mg_linear_wgrad_dgrad_bf16' in captured, captured
-    assert 'mg_expand_column_reduce_f32' in log                       # the two eager warm-up steps keep their own launch
+    if phone_rate:
+        assert 'mg_expand_column_reduce_f32' not in captured and 'mg_linear_wgrad_dgrad_bf16' in captured, captured
+        assert 'mg_expand_column_reduce_f32' in log                   # the two eager warm-up steps keep their own launch
+    else:
+        assert 'mg_f0_l2tail_slabs_bf16' in captured and 'mg_f0_l2tail_bf16' not in captured, captured
+        assert 'mg_f0_l2tail_bf16' in log
     losses_g = [step().clone() for _ in range(3)]
     assert [v.item() for v in losses_g] == losses_e[2:]
     pred_g = next(iter(step.output.values())) if isinstance(step.output, dict) else step.output
