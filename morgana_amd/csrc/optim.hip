@@ -78,7 +78,11 @@ __global__ __launch_bounds__(256) void adam_plan_kernel(float* __restrict__ para
     }
     const float step_size = scalars[0], bc2_sqrt = scalars[1];
     const int e = threadIdx.x & 15, p = threadIdx.x >> 4;
-    for (int64_t base = (int64_t)blockIdx.x * 64; base < n; base += (int64_t)gridDim.x * 64) {
+    // Blocks walk the flat buffer from its END: the last parameters are the fused tail's (their source has 168-256 slabs, five times
+    // the loads of the others), and the blocks that are dispatched first should be the ones that take longest.
+    const int64_t n_chunks = (n + 63) / 64;
+    for (int64_t c = n_chunks - 1 - (int64_t)blockIdx.x; c >= 0; c -= (int64_t)gridDim.x) {
+        const int64_t base = c * 64;
         const int64_t i0 = base + 4 * e;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         bool any = false;
