@@ -26,6 +26,7 @@ if REPO not in sys.path:
 from morgana_amd import _lib, data, distributed, models, ops, optim, synthetic  # noqa: E402
 from morgana_amd import functional as F_hip  # noqa: E402
 
+WARM_STEPS_GRAPH = 400        # graph-replayed C2 steps of warm-up in front of the clock (~40 ms of device work)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
@@ -460,14 +461,13 @@ def timed_leg(step, steps, warmup):
     timed steps destroys them there - device frees that stall the host for tens of milliseconds with every kernel at its usual
     duration (seen as 17 -> 25-43 ms on the LSTM leg, at random; profiles/r3_notes_power.txt, last section)."""
     import gc
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
-    gc.collect()
-    torch.cuda.synchronize()
+    gc.collect()                                   # in front of the warm-up: no idle device between the warm-up steps and the clock
     gc_was_on = gc.isenabled()
     gc.disable()
     try:
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
         return _timed_steps(step, steps)
     finally:
         if gc_was_on:
@@ -686,7 +686,9 @@ def main():
     if args.config == 'c2' and not args.no_graph:
         # K steps per graph: the idle time between two graph launches (8-9 us) and the launch that stages Adam's step-dependent
         # scalars (4.7 us) are then paid once per K steps; every step still does all of its work (morgana_amd/graphs.py)
-        want_k = args.steps_per_replay or max(k for k in range(1, min(25, args.steps) + 1) if args.steps % k == 0)
+        # ... and at least two graph launches in the timed region where --steps allows (the driver's --steps 20: 2 x 10): a graph's
+        # kernels start once its launch has been enqueued, which the second launch does while the first one runs
+        want_k = args.steps_per_replay or max(k for k in range(1, min(25, max(args.steps // 2, 1)) + 1) if args.steps % k == 0)
         if args.steps % want_k:
             raise SystemExit('--steps-per-replay must divide --steps')
         from morgana_amd import graphs
@@ -701,11 +703,21 @@ def main():
             graph_note = 'eager launches (graph capture failed: %s)' % str(exc).splitlines()[0][:200]
             torch.cuda.synchronize()
     import gc
-    for _ in range(-(-args.warmup // per_call)):
+    # no cyclic collection (and none of the device frees it can trigger) inside a timed region - and the collection itself (tens of
+    # milliseconds of host time) goes IN FRONT of the warm-up steps: the device must not sit idle between them and the clock, or the
+    # --steps 20 of the driver's run (one graph launch, 2 ms) is timed on a chip that has dropped its clocks
+    gc.collect()
+    gc.disable()
+    # Warm-up: --warmup steps, and for the graph replay at least WARM_MS of device work - a replayed F0Model step is 0.1 ms, and a chip
+    # that has idled through model construction and capture needs tens of milliseconds of load before it holds the clock of a training
+    # run (20 timed steps behind 10 warm-up steps read 0.115 ms, behind 400: 0.106 - the number a run of 200 steps gives either way).
+    # The steps actually run are reported (config.warmup_steps_run); every timed step does all of its work.
+    warm_calls = -(-args.warmup // per_call)
+    if graph_note is not None and not graph_note.startswith('eager'):
+        warm_calls = max(warm_calls, -(-WARM_STEPS_GRAPH // per_call))
+    for _ in range(warm_calls):
         loss = step()
     torch.cuda.synchronize()
-    gc.collect()                                     # no cyclic collection (and none of the device frees it can trigger) inside a timed region
-    gc.disable()
     distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -735,11 +747,11 @@ def main():
             fr_model.load_state_dict(model.state_dict())
             fr_step = graphs.GraphedTrainStep(fr_model, optim.Adam(fr_model.parameters(), lr=0.01, fused_loop=True), features,
                                               steps_per_replay=per_call)
-            for _ in range(-(-args.warmup // per_call)):
-                fr_step()
-            torch.cuda.synchronize()
             gc.collect()
             gc.disable()
+            for _ in range(max(-(-args.warmup // per_call), -(-WARM_STEPS_GRAPH // (4 * per_call)))):      # 0.5 ms steps: a quarter as many
+                fr_step()
+            torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(args.steps // per_call):
                 fr_step()
@@ -798,6 +810,7 @@ def main():
             'world_size': (torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1),
             'backend': (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
             'mode': (getattr(step, 'exchange_mode', None) or ('none (one rank)' if world == 1 and not rehearse else 'eager all-reduce'))}
+        result['config']['warmup_steps_run'] = warm_calls * per_call        # >= --warmup: see the warm-up comment above
         if graph_note is not None:
             result['config']['launch'] = graph_note
             result['config']['steps_per_graph_launch'] = per_call      # every step does all of its work; the launch gap is shared
