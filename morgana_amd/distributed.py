@@ -44,6 +44,7 @@ def broadcast_parameters(model, src=0):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         for p in model.parameters():
             dist.broadcast(p.data, src=src)
+            p._mg_updates = getattr(p, '_mg_updates', 0) + 1      # written through .data: bf16 operand copies of it are stale (ops.mark_updated)
 
 
 def mean_scalar(value):

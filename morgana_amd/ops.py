@@ -631,6 +631,12 @@ def weight_operands(weights, transposed=False):
     return out
 
 
+def mark_updated(param):
+    """A parameter's storage was written by something torch's version counter does not see (a HIP kernel on ``param.data``, a
+    collective on ``param.data``): its bf16 operand copies (param_shadows) are stale from here on."""
+    param._mg_updates = getattr(param, '_mg_updates', 0) + 1
+
+
 def param_shadows(weights, want_t=()):
     """bf16 operands of a run of fp32 weight matrices: ([N, pad_ld(K)] copies, transposes [K, pad_ld(N)] for the indices in
     ``want_t``, None elsewhere).  The copies live ON the parameter (``w._mg_shadow``) and are kept current by

@@ -674,13 +674,18 @@ class ExponentialMovingAverage(object):
         self.model = model
         self.decay = decay
         self.shadow = {}
+        self._params = {}
         for name, param in self.model.named_parameters():
             if param.requires_grad:
                 self.shadow[name] = param.data
+                self._params[name] = param
 
     def _update_param(self, name, x):
         assert name in self.shadow
         ops.ema_update(self.shadow[name], x.contiguous(), self.decay)
+        # the kernel wrote the EMA model's weight through ``param.data`` (no version bump on the Parameter): say so, or a bf16 operand
+        # copy of it made by an earlier forward pass of the EMA model (ops.param_shadows) would be taken for current
+        ops.mark_updated(self._params[name])
 
     def update_params(self, other_model):
         assert other_model is not self.model

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from morgana_amd import data, experiment_builder, models, synthetic
+from morgana_amd import data, experiment_builder, models, synthetic, utils
 
 import helpers
 
@@ -194,6 +194,47 @@ def test_train_epoch_with_ema_and_noam_on_gpu():
         np.testing.assert_allclose(v.cpu().numpy(), ref.state_dict()[k].numpy(), rtol=1e-3, atol=1e-5)
     for k, v in eb.ema_model.state_dict().items():
         np.testing.assert_allclose(v.cpu().numpy(), shadow[k], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('model_name', ['f0', 'rnn'])
+def test_ema_twin_in_bf16_mode_sees_its_updates(model_name):
+    """The EMA twin's weights are written by a HIP kernel through ``param.data`` (utils.ExponentialMovingAverage, morgana/utils.py:
+    443-456), which torch's version counter does not see.  In bf16 mode the layers multiply by bf16 COPIES of the weights that live on
+    the parameters (ops.param_shadows): a copy made by an earlier forward pass of the twin must not survive an EMA update.  Evaluate
+    the twin, update it towards a different model, evaluate again: the second output must equal a fresh model's with the same
+    weights (it did not change at all before ops.mark_updated)."""
+    if model_name == 'f0':
+        make = lambda: models.F0Model(precision='bf16').to('cuda:0')
+        state_a, state_b = synthetic.f0_model_state(seed=3), synthetic.f0_model_state(seed=4)
+        feats = data.to_device(synthetic.make_batch(16, (150, 300), seed=5), 'cuda:0')
+    else:
+        make = lambda: models.RNNSPSS(precision='bf16').to('cuda:0')
+        state_a, state_b = synthetic.rnn_spss_state(seed=3), synthetic.rnn_spss_state(seed=4)
+        feats = data.to_device(synthetic.make_batch(8, (100, 200), out_dim=80, target_name='mcep', seed=5), 'cuda:0')
+
+    def load(model, state):
+        own = model.state_dict()
+        for k, v in state.items():
+            own[k].copy_(torch.from_numpy(v))
+        return model
+
+    def output_of(model):
+        with torch.no_grad():
+            _, out = model(feats)
+        out = next(iter(out.values())) if isinstance(out, dict) else out
+        return out.clone()
+
+    twin, other = load(make(), state_a), load(make(), state_b)
+    ema = utils.ExponentialMovingAverage(twin, 0.25)
+    before = output_of(twin)                                   # creates the twin's bf16 operand copies
+    ema.update_params(other)                                   # shadow = 0.25 shadow + 0.75 other
+    after = output_of(twin)
+    fresh = make()
+    fresh.load_state_dict(twin.state_dict())
+    want = output_of(fresh)
+    assert not torch.equal(after, before)
+    assert torch.equal(after, want)
 
 
 @pytest.mark.gpu
