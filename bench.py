@@ -769,6 +769,7 @@ def main():
             frame_rate = {'error': str(exc).splitlines()[0][:200]}
         finally:
             ops.PHONE_RATE = True
+            gc.enable()
 
     result = None
     form_note = ''
