@@ -315,6 +315,42 @@ def test_two_ranks_on_one_gpu_equal_the_global_batch(tmp_path, precision, form, 
     np.testing.assert_allclose(got['losses'], want_losses, rtol=tol)
 
 
+@pytest.mark.parametrize('which', ['rnn_spss', 'rnn_spss_ragged', 'lstm'])
+def test_direct_gradients_equal_autograd_accumulation(which):
+    """Inside functional.backward the row-wise, GRU and LSTM-stack layers outside the fused stack add their weight gradients and bias
+    sums straight into morgana_amd.optim.Adam's flat gradient and hand autograd None (functional._direct_params; weight operands from
+    the parameters' shadows) - against a plain ``loss.backward()`` on a twin model, where autograd accumulates returned tensors:
+    the same kernels on the same data, every parameter's gradient EQUAL bit for bit, and so are the parameters after an update."""
+    if which == 'lstm':
+        feats = data.to_device(synthetic.make_acoustic_batch(64, 120, seed=11, with_raw=True), DEV)
+        make = lambda: _load_state(models.LSTMAcousticModel(precision='bf16', generate=False).to(DEV), synthetic.lstm_acoustic_state())
+    else:
+        frames = (60, 150) if which == 'rnn_spss_ragged' else 120
+        feats = data.to_device(synthetic.make_batch(64, frames, out_dim=80, target_name='mcep', seed=11), DEV)
+        make = lambda: _load_state(models.RNNSPSS(precision='bf16').to(DEV), synthetic.rnn_spss_state())
+    grads, params = {}, {}
+    for mode in ('autograd', 'direct'):
+        model = make()
+        if which == 'lstm':
+            synthetic.acoustic_normalisers(model, device=DEV)
+            model.mode = 'train'
+            model.metrics.reset_state('train')
+        opt = optim.Adam(model.parameters(), lr=0.01)
+        for _ in range(2):                                            # the second step runs on shadows the update kernel refreshed
+            opt.zero_grad()
+            loss, _ = model(feats)
+            if mode == 'direct':
+                F_hip.backward(loss)
+            else:
+                loss.backward()
+            g = opt.flat_buffers()['grad'].clone()
+            opt.step()
+        ops.check_persistent_status()
+        grads[mode], params[mode] = g, opt.flat_buffers()['param'].clone()
+    assert torch.equal(grads['direct'], grads['autograd'])
+    assert torch.equal(params['direct'], params['autograd'])
+
+
 # ------------------------------------------------------------------------------------------------------------ contracts
 @pytest.mark.parametrize('b,t,hid,form', [(16, 50, 512, 'step_bf16'), (16, 50, 512, 'persist_bf16'), (16, 50, 512, 'step_f32'),
                                           (16, 50, 256, 'persist_f32'), (12, 40, 64, 'small_f32'), (12, 40, 128, 'small_f32')])
