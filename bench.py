@@ -526,6 +526,13 @@ def c4_leg(dev, precision):
 
     ms = timed_leg(step, 10, 3)
     ops.check_persistent_status()
+    if os.environ.get('MG_BENCH_DEBUG') == '1':          # where the last persistent launch's workgroups sat: XCC ids per group
+        import collections
+        for key, ws in ops._PERSIST_WORKSPACES.items():
+            words = ws.view(torch.int32)[256:512].cpu().reshape(8, 32)
+            sys.stderr.write('c4 leg blocks %s; XCC ids per group of the last launch: %s\n' % (LAST_BLOCKS, '  '.join(
+                'g%d:%s' % (g, ','.join('%dx%d' % (k, n) for k, n in sorted(collections.Counter(int(v) - 1 for v in words[g] if int(v) > 0).items())))
+                for g in range(8))))
     frames = int(feats_np['n_frames'].sum())
     # fwd MACs per frame 307,200 + 786,432 + 786,432 + 131,072 + 20,480; backward = wgrad of everything + dgrad of all
     # but the first layer
