@@ -578,6 +578,44 @@ def test_l2tail_rows_kernel_vs_unfused_pair():
         assert torch.equal(sums, grads_w[:4161])                          # what the update kernel will form from the slabs
 
 
+@pytest.mark.parametrize('m,frames,n_slabs', [(21504, 256000, 168), (30001, 70001, 235), (21504, 1000, 3)])
+def test_deferred_tail_riders_on_synthetic_slabs(m, frames, n_slabs):
+    """mg_linear_wgrad_dgrad_expand_bf16 and the update kernel's mg_adam_tail against mg_expand_column_reduce_f32 on made-up inputs
+    (random slabs, row map, partial sums): the repeated prediction, every element of the slab sum and the loss EQUAL bit for bit - for
+    the C2 shape (riders behind the pair grid), for a row count the one-grid form does not take (the entry point then runs the
+    separate launches), and for a frame count smaller than one rider's share."""
+    rng = np.random.RandomState(m + frames)
+    n, stride = 4162, 4164
+    n_table, extra = m - 1024, 1024
+    (_,), (wt,) = ops.cast_params_bf16([dev(rng.uniform(-0.1, 0.1, (128, 512)).astype(np.float32))], want_plain=True, want_t=(0,))
+    h = ops.cast_pad_bf16(dev(rng.uniform(0.05, 0.95, (m, 512)).astype(np.float32)))
+    dy = ops.cast_pad_bf16(dev((rng.standard_normal((m, 128)) * 0.01).astype(np.float32)))
+    ws = dev((rng.standard_normal(n_slabs * stride) * 0.1).astype(np.float32))
+    base = dict(pred_rows=dev(rng.standard_normal(m).astype(np.float32)), rows=dev(np.sort(rng.randint(0, m, size=frames)).astype(np.int32)),
+                partials=dev(rng.uniform(0, 1e-3, (n_table + 15) // 16 + extra // 4).astype(np.float32)), n_table_rows=n_table, extra=extra,
+                ws=ws.view(torch.uint8), n=n, stride=stride, n_slabs=n_slabs)
+
+    def fresh():
+        return dict(base, out=torch.full((frames,), float('nan'), device=DEV), grads_out=torch.full((n,), float('nan'), device=DEV))
+
+    want = fresh()
+    ops.finish_deferred_tail(want)
+    assert not torch.isnan(want['out']).any() and not torch.isnan(want['grads_out']).any()
+    got = fresh()                                                           # riders behind the pair grid: everything
+    ops.linear_wgrad_dgrad_bf16(dy, h, m, 128, 512, wt, tail=got)
+    assert torch.equal(got['out'], want['out']) and torch.equal(got['grads_out'], want['grads_out'])
+    got = fresh()                                                           # ... the loss chunk only
+    ops.linear_wgrad_dgrad_bf16(dy, h, m, 128, 512, wt, tail=dict(got, loss_only=True))
+    assert torch.equal(got['out'], want['out']) and torch.equal(got['grads_out'][-2:], want['grads_out'][-2:])
+    # the update launch's first blocks (mg_adam_tail): repeated prediction + the loss chunk, next to an ordinary update
+    got = fresh()
+    nparam = 20000
+    p_, g_, m_, v_ = (torch.zeros(nparam, device=DEV) for _ in range(4))
+    scal = torch.tensor([0.01, 1.0], device=DEV)
+    ops.adam_step_plan(p_, g_, m_, v_, (0.9, 0.999), 1e-8, 0.0, scal, tail=got)
+    assert torch.equal(got['out'], want['out']) and torch.equal(got['grads_out'][-2:], want['grads_out'][-2:])
+
+
 @pytest.mark.parametrize('n,k,total', [(1536, 512, 9000), (384, 500, 4100), (1536, 512, 73613)])
 def test_wgrad_with_both_operands_gathered(n, k, total):
     """mg_linear_wgrad_rows_bf16 (dW = sum_i dY[dy_rows[i]]^T A[rows[i]]: a recurrent layer's weight gradients over the valid frames of a
