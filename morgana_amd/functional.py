@@ -62,8 +62,10 @@ def backward(loss):
 
 
 _DIRECT_BACKWARD = 0
-# Set by graphs.GraphedTrainStep while it captures a whole training step: the phone-rate stack then leaves the last two small jobs of
-# its forward (the repeated prediction, the fused tail's slab sum) to the end of the backward's first launch (LinearStackMSEFn).
+# Set by graphs.GraphedTrainStep while it captures a whole training step: the fused stack then leaves the last small jobs of its forward
+# (phone rate: the repeated prediction and the fused tail's slab sum; frame rate: the tail's slab sum) to a later launch of the same
+# step - the update launch's first blocks on one rank, rider blocks behind the backward's first grid on a data-parallel rank
+# (LinearStackMSEFn).  A replay cannot observe the step half done; the eager loop keeps the separate launches.
 DEFER_TAIL = False
 
 
@@ -486,9 +488,9 @@ class LinearStackMSEFn(torch.autograd.Function):
             ctx.deferred_tail = None
             if l2tail and os.environ.get('MORGANA_EXPAND_REDUCE', '1') != '0':
                 # the tail's slab reduce rides in the launch that repeats the prediction (one node less, the same sums) - and inside a
-                # step captured whole into a HIP graph (DEFER_TAIL: graphs.GraphedTrainStep) both ride at the end of the backward's
-                # first launch instead (ops.linear_wgrad_dgrad_bf16(tail=...)): pred / loss / the tail's gradients are then complete
-                # when the graph's backward part has run, which is all a replay can observe
+                # step captured whole into a HIP graph (DEFER_TAIL: graphs.GraphedTrainStep) both are left to a later launch of the
+                # step (backward decides which: the update launch's first blocks, or riders behind its first grid): pred / loss / the
+                # tail's gradients are then complete when the graph's update has run, which is all a replay can observe
                 defer = DEFER_TAIL and any(ctx.needs_input_grad[5:])        # (a backward pass will come: graphs.GraphedTrainStep)
                 res = ops.f0_l2tail_rows_expand(hidden[-1], w_bf[lead - 1], biases[lead - 1], weights[lead], biases[lead],
                                                 weights[lead + 1], biases[lead + 1], ybar, weight, flat[offsets[2 * lead]:],
