@@ -809,6 +809,12 @@ def main():
                          'times that order); bf16 phone table prepared by the loader'
                          % (lab_shape[0] * lab_shape[1], ops.PHONE_RATE_EXTRA, frames_per_step,
                             frames_per_step / float(lab_shape[0] * lab_shape[1] + ops.PHONE_RATE_EXTRA)))
+        elif args.precision == 'fp32' and ops.phone_rate_gru_ok(lab_shape[0] * lab_shape[1], frames_per_step, 8):
+            # fp32 parity mode takes the generic phone-rate form (utils.SequentialWithRecurrent: the row-wise stack on the phone rows,
+            # its output repeated, exact-fp32 MFMA products): not the reference's order of operations either
+            form_note = ('; fp32 parity mode AT PHONE RATE as well (generic form: the Linear / Sigmoid stack on the %d phone rows + %d zero '
+                         'rows, its output repeated to the %d frames; exact-fp32 MFMA products, the loss curve matches the reference to 1e-7)'
+                         % (lab_shape[0] * lab_shape[1], ops.PHONE_RATE_EXTRA, frames_per_step))
         else:
             form_note = '; every product at frame rate (the reference\'s order of operations)'
     if rank == 0:
