@@ -578,6 +578,45 @@ def test_l2tail_rows_kernel_vs_unfused_pair():
         assert torch.equal(sums, grads_w[:4161])                          # what the update kernel will form from the slabs
 
 
+@pytest.mark.parametrize('m', [6144, 12288, 6000])
+def test_few_tile_gemms_take_narrow_tiles_with_the_same_results(m):
+    """mg_try_nt_big's tile rule (128-wide tiles when 256-wide ones would be fewer than 128: the 6,144-row GEMMs of RNN_SPSS) against
+    the rule before it (MG_TUNE_AB 97: 256-wide whenever N allows) and against the 128 x 128 kernel (98): the same products in the same
+    k order - EQUAL bit for bit - for a sigmoid forward, a wide forward with fp32 output, a dgrad with fp32 output and a 256-wide
+    forward; and each against a float64 product of the same bf16 operands."""
+    from morgana_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(m)
+    for k, n, kind in ((600, 512, 'fwd_sig'), (512, 1536, 'fwd'), (1536, 512, 'dgrad'), (512, 256, 'fwd_bf')):
+        a = ops.cast_pad_bf16(dev((rng.standard_normal((m, k)) * 0.5).astype(np.float32)))
+        w = ops.cast_pad_bf16(dev((rng.standard_normal((n, k)) * 0.05).astype(np.float32)))
+        bias = dev(rng.standard_normal(n).astype(np.float32))
+
+        def run():
+            if kind == 'dgrad':
+                return ops.linear_dgrad_bf16(a, m, k, w, n, None, out_f32=True)
+            act = ops.ACT_SIGMOID if kind == 'fwd_sig' else ops.ACT_NONE
+            return ops.linear_fwd_bf16(a, None, m, k, w, bias, n, act, out_f32=(kind == 'fwd'))
+
+        outs = {}
+        try:
+            for v in (0, 97, 98):
+                lib.mg_set_tuning(7, v)
+                outs[v] = run().clone()
+        finally:
+            lib.mg_set_tuning(7, 0)
+        assert torch.equal(outs[0], outs[97]), (kind, 'rule vs wide tiles')
+        if kind != 'fwd_sig':                                   # (the 128 x 128 kernel's sigmoid epilogue rounds through another path)
+            assert torch.equal(outs[0][:, :n], outs[98][:, :n]), (kind, 'rule vs 128 x 128')
+        ref = a[:, :k].double() @ w[:, :k].double().t()
+        if kind != 'dgrad':
+            ref = ref + bias.double()
+        if kind == 'fwd_sig':
+            ref = torch.sigmoid(ref)
+        err = (outs[0][:, :n].double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < (1e-2 if outs[0].dtype == torch.bfloat16 else 1e-5), (kind, err)
+
+
 @pytest.mark.parametrize('m,frames,n_slabs', [(21504, 256000, 168), (30001, 70001, 235), (21504, 1000, 3)])
 def test_deferred_tail_riders_on_synthetic_slabs(m, frames, n_slabs):
     """mg_linear_wgrad_dgrad_expand_bf16 and the update kernel's mg_adam_tail against mg_expand_column_reduce_f32 on made-up inputs
