@@ -38,6 +38,11 @@ def run(name, feats_np, model_kwargs, state):
         torch.cuda.synchronize()
         print('%s %s: %.3f ms/step' % (name, mode, (time.perf_counter() - t0) / 10 * 1e3))
         ops.check_persistent_status()
+        import collections
+        for key, ws in ops._PERSIST_WORKSPACES.items():          # where the last persistent launch's workgroups sat (XCC id per group)
+            words = ws.view(torch.int32)[256:512].cpu().reshape(8, 32)
+            print('   XCC ids per group: ' + '  '.join('g%d:%s' % (g, ','.join('%dx%d' % (k, n) for k, n in sorted(
+                collections.Counter(int(v) - 1 for v in words[g] if int(v) > 0).items()))) for g in range(8)))
 
 
 run('C4', synthetic.make_batch(64, 1000, out_dim=80, target_name='mcep'), {}, synthetic.rnn_spss_state())
