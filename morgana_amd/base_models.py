@@ -15,6 +15,11 @@ from . import metrics
 class BaseModel(nn.Module):
     """Abstract model with the attributes ExperimentBuilder relies on (base_models.py:27-34)."""
 
+    # Order of operations of the layers behind ``utils.upsample_to_repetitions`` (not in the reference): None = the process default
+    # (MORGANA_PHONE_RATE), True = layers that commute with the repetition run once per phone row, False = every product on the
+    # frame rows as the reference orders them.  Models hand it to ``upsample_to_repetitions(phone_rate=)``; same outputs either way.
+    phone_rate = None
+
     def __init__(self):
         super(BaseModel, self).__init__()
         self.normalisers = {}

@@ -98,11 +98,17 @@ def _w_t(w):
 def _direct_params(*params):
     """May a layer's backward add its parameter gradients straight into ``.grad`` and hand autograd ``None`` for them?  Only inside
     ``backward`` above (``torch.autograd.grad`` and double backward must get tensors), and only when every parameter's ``.grad`` is
-    a live fp32 view of ``morgana_amd.optim.Adam``'s flat gradient.  What it saves: autograd's AccumulateGrad adds the returned
-    tensor into the existing ``.grad`` with one elementwise launch PER PARAMETER (ten of them in an RNN_SPSS step)."""
+    a live fp32 view of ``morgana_amd.optim.Adam``'s flat gradient, still asks for a gradient (a parameter frozen after the optimiser
+    was built must receive none) and carries no hook (tensor hooks and post-accumulate-grad hooks fire from autograd's own
+    accumulation, which this path bypasses).  What it saves: autograd's AccumulateGrad adds the returned tensor into the existing
+    ``.grad`` with one elementwise launch PER PARAMETER (ten of them in an RNN_SPSS step)."""
     return (DIRECT_GRADS and _DIRECT_BACKWARD > 0 and not torch.is_grad_enabled() and
-            all(p is not None and getattr(p, '_mg_direct_grad', False) and p.grad is not None and p.grad.is_contiguous() and
-                p.grad.dtype == torch.float32 for p in params))
+            all(p is not None and getattr(p, '_mg_direct_grad', False) and p.requires_grad and p.grad is not None and
+                p.grad.is_contiguous() and p.grad.dtype == torch.float32 and not _has_hooks(p) for p in params))
+
+
+def _has_hooks(p):
+    return bool(getattr(p, '_backward_hooks', None)) or bool(getattr(p, '_post_accumulate_grad_hooks', None))
 
 
 def _linear_grads_direct(w_param, b_param, g, a_in, rows, m, n, k):
@@ -416,10 +422,11 @@ class LinearStackMSEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, acts, x2d, rows, target, seq_len, *params):
         acts_in = acts
-        maps = table_bf16 = pending = None
-        if len(acts) in (2, 3) and not isinstance(acts[0], int):  # (acts, maps[, table]): phone-rate maps that came with the frame map,
-            acts, maps = acts[0], acts[1]                         # and the loader's bf16 copy of the phone table (data.add_bf16_table)
-            table_bf16 = acts_in[2] if len(acts_in) == 3 else None
+        maps = table_bf16 = pending = order = None
+        if len(acts) in (2, 3, 4) and not isinstance(acts[0], int):  # (acts, maps[, table[, phone_rate]]): phone-rate maps that came with
+            acts, maps = acts[0], acts[1]                            # the frame map, the loader's bf16 copy of the phone table
+            table_bf16 = acts_in[2] if len(acts_in) >= 3 else None   # (data.add_bf16_table), and the caller's order of operations
+            order = acts_in[3] if len(acts_in) == 4 else None        # (utils.upsample_to_repetitions(phone_rate=); None = default)
             if maps is not None and not isinstance(maps, tuple):
                 # an utils.UpsampledSequence whose frame map no kernel has built yet (rows is None): the phone-rate step builds it
                 # in the launch of its own front (ops.phone_front); every other path asks the sequence for it now
@@ -433,7 +440,7 @@ class LinearStackMSEFn(torch.autograd.Function):
         m = b * t
         n_layers_lead = n_layers - 2
         front = (pending is not None and pending.t_cap == t and pending.dur.shape[0] == b and n_layers_lead == 2 and
-                 ops.phone_rate_table_ok(x2d.shape[0], m, weights[0].shape[0], weights[1].shape[0], acts[0]) and
+                 ops.phone_rate_table_ok(x2d.shape[0], m, weights[0].shape[0], weights[1].shape[0], acts[0], order) and
                  ops.phone_front_ok(b, pending.dur.shape[1], t, ops.PHONE_RATE_EXTRA))
         if pending is not None and not front:
             rows, maps = pending.rows.reshape(-1), pending.maps
@@ -455,7 +462,7 @@ class LinearStackMSEFn(torch.autograd.Function):
         # whose gradient the fused tail forms per phone row.
         n_table = x2d.shape[0]
         phone_rate = front or (rows is not None and lead == 2
-                               and ops.phone_rate_table_ok(n_table, m, weights[0].shape[0], weights[1].shape[0], acts[0]))
+                               and ops.phone_rate_table_ok(n_table, m, weights[0].shape[0], weights[1].shape[0], acts[0], order))
         ctx.phone_rate = phone_rate
         if phone_rate:
             extra = ops.PHONE_RATE_EXTRA

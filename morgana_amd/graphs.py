@@ -150,6 +150,8 @@ class GraphedTrainStep(object):
         except Exception:
             _leave_failed_capture(entry_stream)        # so that the caller's eager fallback finds a usable stream
             raise
+        # the bf16 operand copies the captured update keeps current: what a replay re-stamps (optim.Adam.note_replayed)
+        self._refreshed = self.optimizer.refreshed_shadows() if hasattr(self.optimizer, 'refreshed_shadows') else []
         self.steps_done = warmup
 
     def _capture(self, mode):
@@ -226,6 +228,8 @@ class GraphedTrainStep(object):
         if self.exchange_mode == 'eager':
             self.optimizer.exchange_gradients()        # the step's one RCCL all-reduce, outside the graph
             self.optimizer.step_captured()             # one kernel: launched directly
+        elif hasattr(self.optimizer, 'note_replayed'):
+            self.optimizer.note_replayed(self._refreshed, self.steps_per_replay)
         self.steps_done += self.steps_per_replay
         return self.loss
 

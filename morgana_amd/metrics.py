@@ -150,19 +150,20 @@ def _call_spec(inputs):
 
 class Handler(object):
     """The metric container of the train loop (public surface of morgana/metrics.py:50-186: ``handler[collection]``, ``add_metrics``,
-    ``add_collection``, ``reset_state``, ``accumulate``, ``result``, ``results_as_json_dict``, ``results_as_str_dict``).
+    ``add_collection``, ``reset_state``, ``accumulate``, ``result``, ``results_as_json_dict``, ``results_as_str_dict``, and the live
+    ``collections`` / ``metrics`` mappings).
 
-    ONE registry holds every metric object by name; a collection ('all', 'train', 'valid', 'test', or one made by
-    ``add_collection``) is an ordered list of names into it, so a metric that belongs to several collections is one object by
-    construction and ``accumulate`` / ``reset_state`` dispatch through the names.  Metrics given to the constructor join 'all', 'train'
-    and 'valid'; ``add_metrics('all', ...)`` joins every collection there is; whatever is added also joins 'all'."""
+    Every collection ('all', 'train', 'valid', 'test', or one made by ``add_collection``) is its own name -> metric mapping, handed
+    out LIVE: ``handler['train'][name] = metric`` and ``handler.metrics.update(...)`` register metrics as they do in the reference,
+    and the same name may hold different metric objects in different collections (``add_metrics('train', loss=a)`` then
+    ``add_metrics('valid', loss=b)``).  Metrics given to the constructor join 'all', 'train' and 'valid'; ``add_metrics('all', ...)``
+    joins every collection there is; whatever is added also joins 'all' (the last object added under a name is the one 'all' holds)."""
 
     BUILT_IN = ('all', 'train', 'valid', 'test')
 
     def __init__(self, **metrics):
         self.hidden = False
-        self._registry = {}
-        self._members = {name: [] for name in self.BUILT_IN}
+        self._members = {name: {} for name in self.BUILT_IN}
         self.add_metrics(('train', 'valid'), **metrics)
 
     # -- membership ------------------------------------------------------------------------------------------------------------------
@@ -170,55 +171,48 @@ class Handler(object):
     def _names(spec):
         return [spec] if isinstance(spec, str) or not hasattr(spec, '__iter__') else list(spec)
 
-    def _collection(self, name):
-        if name not in self._members:
-            raise ValueError("No collection found by the name {}".format(name))
-        return self._members[name]
-
     def __getitem__(self, collection):
-        return {name: self._registry[name] for name in self._collection(collection)}
+        if collection not in self._members:
+            raise ValueError("No collection found by the name {}".format(collection))
+        return self._members[collection]
 
     @property
     def metrics(self):
-        return self['all']
+        return self._members['all']
 
     @property
     def collections(self):
-        return {collection: self[collection] for collection in self._members}
+        return self._members
 
     def add_metrics(self, collections=('all',), **metrics):
         targets = self._names(collections)
         if 'all' in targets:
             targets = list(self._members)
-        self._registry.update(metrics)
         for collection in dict.fromkeys(list(targets) + ['all']):
-            members = self._collection(collection)
-            members.extend(name for name in metrics if name not in members)
+            self[collection].update(metrics)
 
     def add_collection(self, collection, from_collections=tuple()):
-        merged = []
+        merged = {}
         for source in self._names(from_collections):
-            merged.extend(name for name in self._collection(source) if name not in merged)
+            merged.update(self[source])
         self._members[collection] = merged
 
     # -- the loop's calls ------------------------------------------------------------------------------------------------------------
     def reset_state(self, collection, *args):
-        for name in self._collection(collection):
-            self._registry[name].reset_state()
+        for metric in self[collection].values():
+            metric.reset_state()
 
     def accumulate(self, collection, **inputs_by_metric):
-        members = self._collection(collection)
+        members = self[collection]
         for name, inputs in inputs_by_metric.items():
-            if name not in members:
-                raise KeyError(name)
             args, kwargs = _call_spec(inputs)
-            self._registry[name].accumulate(*args, **kwargs)
+            members[name].accumulate(*args, **kwargs)          # KeyError for a name the collection does not hold, as the reference
 
     def _visible(self, collection):
-        return [(name, self._registry[name]) for name in self._collection(collection) if not self._registry[name].hidden]
+        return [(name, metric) for name, metric in self[collection].items() if not metric.hidden]
 
     def result(self, collection='all', *args):
-        return {name: self._registry[name].result(*args) for name in self._collection(collection)}
+        return {name: metric.result(*args) for name, metric in self[collection].items()}
 
     def results_as_json_dict(self, collection='all', prefix=''):
         return {prefix + name: metric.result_as_json() for name, metric in self._visible(collection)}

@@ -27,9 +27,10 @@ def _has_delta_params(normalisers, name):
 
 class F0Model(BaseSPSS):
     def __init__(self, input_dim=600, hidden_dims=(512, 128, 32), output_dim=1, target_name='lf0', precision=None,
-                 fused_upsample=True, fused_loss=True):
+                 fused_upsample=True, fused_loss=True, phone_rate=None):
         super(F0Model, self).__init__()
         self.fused_loss = fused_loss
+        self.phone_rate = phone_rate          # order of operations of THIS model (base_models.BaseModel.phone_rate)
         dims = (input_dim,) + tuple(hidden_dims) + (output_dim,)
         mods = []
         for i in range(len(dims) - 1):
@@ -50,7 +51,7 @@ class F0Model(BaseSPSS):
         target = features.get('normalised_' + self.target_name)
         max_len = target.shape[1] if target is not None else None
         norm_lab_at_frame_rate = utils.upsample_to_repetitions(features['normalised_lab'], features['dur'],
-                                                               max_len=max_len, fused=self.fused_upsample)
+                                                               max_len=max_len, fused=self.fused_upsample, phone_rate=self.phone_rate)
         pred_norm, _ = self.layers(norm_lab_at_frame_rate, seq_len=features['n_frames'])
         outputs = {'pred_norm_' + self.target_name: pred_norm}
         if self.target_name in self.normalisers:
@@ -72,7 +73,8 @@ class F0Model(BaseSPSS):
         if target is None or not self.fused_loss:
             return super(F0Model, self).forward(features)
         x = utils.upsample_to_repetitions(features['normalised_lab'], features['dur'], max_len=target.shape[1],
-                                          fused=self.fused_upsample, table_bf16=features.get('normalised_lab' + data.BF16_TABLE_SUFFIX))
+                                          fused=self.fused_upsample, table_bf16=features.get('normalised_lab' + data.BF16_TABLE_SUFFIX),
+                                          phone_rate=self.phone_rate)
         loss, pred_norm = self.layers.forward_mse(x, target, seq_len=features['n_frames'])
         outputs = {'pred_norm_' + self.target_name: pred_norm}
         if self.target_name in self.normalisers:
@@ -82,8 +84,9 @@ class F0Model(BaseSPSS):
 
 class RNNSPSS(BaseSPSS):
     def __init__(self, input_dim=600, hidden_dim=512, post_dim=256, output_dim=80, target_name='mcep', precision=None,
-                 fused_upsample=True):
+                 fused_upsample=True, phone_rate=None):
         super(RNNSPSS, self).__init__()
+        self.phone_rate = phone_rate
         self.layers = utils.SequentialWithRecurrent(
             nn.Linear(input_dim, hidden_dim),
             nn.Sigmoid(),
@@ -105,7 +108,7 @@ class RNNSPSS(BaseSPSS):
         target = features.get('normalised_' + self.target_name)
         max_len = target.shape[1] if target is not None else None
         norm_lab_at_frame_rate = utils.upsample_to_repetitions(features['normalised_lab'], features['dur'],
-                                                               max_len=max_len, fused=self.fused_upsample)
+                                                               max_len=max_len, fused=self.fused_upsample, phone_rate=self.phone_rate)
         # max_len: the padded frame axis is the longest utterance (collate_fn, data.py:183-193), so the GRU wrapper need not read
         # seq_len back to crop its output (utils.py:383) - no host sync in the step, which makes it capturable as a HIP graph
         layout = utils.FrameLayout.for_batch(features, max_len) if max_len is not None else None
@@ -172,7 +175,8 @@ class StreamModel(BaseSPSS):
     def _run_layers(self, features):
         norm_counters = features['normalised_counters']
         norm_lab_at_frame_rate = utils.upsample_to_repetitions(features['normalised_lab'], features['dur'],
-                                                               max_len=norm_counters.shape[1], fused=self.fused_upsample)
+                                                               max_len=norm_counters.shape[1], fused=self.fused_upsample,
+                                                               phone_rate=self.phone_rate)
         model_inputs = utils.concat_frame_features(norm_lab_at_frame_rate, norm_counters)
         prediction, _ = self.layers(model_inputs, seq_len=features['n_frames'], max_len=norm_counters.shape[1])
         return prediction

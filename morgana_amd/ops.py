@@ -671,6 +671,24 @@ def param_shadows(weights, want_t=()):
     return [w._mg_shadow['plain'] for w in weights], [w._mg_shadow['t'] if i in want_t else None for i, w in enumerate(weights)]
 
 
+def refresh_shadows(params):
+    """Re-cast the EXISTING bf16 operand copies of ``params`` (plain, and transposed where one is allocated) from their fp32 weights:
+    one batched launch per MG_CAST_MAX parameters on the current stream, no allocation, no stamp (the caller stamps).  Used by
+    ``optim.Adam`` for the copies its update kernel's plan has no room for, so that EVERY copy is current when an update ends -
+    inside a captured step as well, where nothing on the host can notice a stale copy later."""
+    lib = _lib.load()
+    for i in range(0, len(params), _lib.CAST_MAX):
+        chunk = params[i:i + _lib.CAST_MAX]
+        descs = (_lib.CastDesc * len(chunk))()
+        for j, w in enumerate(chunk):
+            sh = w._mg_shadow
+            n, k = w.shape
+            descs[j].src, descs[j].rows, descs[j].cols = w.data_ptr(), n, k
+            descs[j].dst, descs[j].ldd = sh['plain'].data_ptr(), sh['plain'].shape[1]
+            descs[j].dst_t, descs[j].ldt = (sh['t'].data_ptr(), sh['t'].shape[1]) if sh['t'] is not None else (None, 0)
+        _lib.check(lib.mg_cast_params_bf16(ctypes.cast(descs, ctypes.c_void_p), len(chunk), _stream()), 'mg_cast_params_bf16')
+
+
 def f0_tail(h2, w3, b3, w4, b4, target, seq_len, b, t, grads_out, grad_scale=1.0):
     """Fused layers 3-4 + masked MSE, forward and backward (mg_f0_tail_bf16).  Returns (pred (b*t,), loss 0-d, dz2)."""
     lib = _lib.load()
@@ -1497,8 +1515,16 @@ def mlpg(means, variances, windows, padding_size=0, seq_len=None, out_dtype=torc
 
 
 # ---------------------------------------------------------------------------------------------- phone-rate first layer
-# MORGANA_PHONE_RATE=0: every product at frame rate (the reference's order of operations)
+# MORGANA_PHONE_RATE=0: every product at frame rate (the reference's order of operations).  This is only the DEFAULT of a per-call
+# choice: utils.upsample_to_repetitions(..., phone_rate=) records the choice on the lazy sequence it returns, the layers that consume
+# the sequence read it there (models pass their own ``phone_rate`` attribute), so two models with different orders of operations
+# live in one process without anybody writing a global.
 PHONE_RATE = os.environ.get('MORGANA_PHONE_RATE', '1') != '0'
+
+
+def phone_rate_choice(choice=None):
+    """The order of operations a call asks for: ``choice`` if given, else the process default (MORGANA_PHONE_RATE)."""
+    return PHONE_RATE if choice is None else bool(choice)
 PHONE_RATE_EXTRA = 1024          # rows behind the table that collect the gradients of padding frames (for the bias gradient)
 
 
@@ -1513,17 +1539,17 @@ def segment_bounds(rows, n_table_rows, pad_row=None):
     return seg if pad_row is None else (seg, mapped)
 
 
-def phone_rate_table_ok(n_table_rows, m, n0, n1, act):
+def phone_rate_table_ok(n_table_rows, m, n0, n1, act, enabled=None):
     """The table form of the phone-rate first layer (bf16 mode): sigmoid(X_phone W0^T + b0) is kept per phone and the second
     layer's GEMMs gather its rows, so the frame-rate activation never exists.  Needs the wide-tile kernels' shapes."""
-    return (PHONE_RATE and act == ACT_SIGMOID and n_table_rows < m and m >= 4096 and n_table_rows >= 2048
+    return (phone_rate_choice(enabled) and act == ACT_SIGMOID and n_table_rows < m and m >= 4096 and n_table_rows >= 2048
             and n0 % 128 == 0 and 384 < n0 <= 512 and pad8(n1) % 64 == 0)
 
 
-def phone_rate_gru_ok(n_table_rows, m, width):
+def phone_rate_gru_ok(n_table_rows, m, width, enabled=None):
     """Linear / Sigmoid layers between an upsample and a GRU wrapper on the phone rows (utils.PhoneTable): worth it when there are
     several frames per phone; the table's width must suit mg_segment_sum (multiple of 8)."""
-    return PHONE_RATE and width % 8 == 0 and 2 * (n_table_rows + PHONE_RATE_EXTRA) <= m
+    return phone_rate_choice(enabled) and width % 8 == 0 and 2 * (n_table_rows + PHONE_RATE_EXTRA) <= m
 
 
 def linear_dgrad_gathered_bf16(dy, m, n, wt_bf16, k, h_table, h_rows):

@@ -203,20 +203,50 @@ class Adam(torch.optim.Optimizer):
 
     def _launch(self, group, flat, world, slot=0):
         """The update kernel with everything this step left for it (see the module docstring)."""
-        # the kernel's plan refreshes up to ADAM_MAX_SHADOWS operand copies; the others keep their old version stamp, so
-        # ops.param_shadows re-casts them when the next forward pass asks for them
-        shadows = self._shadows(flat)[:_lib.ADAM_MAX_SHADOWS]
+        # the kernel's plan refreshes up to ADAM_MAX_SHADOWS operand copies; the others are re-cast by ONE batched launch right behind
+        # it (ops.refresh_shadows), so that every copy is current when the update ends.  (They used to keep a stale stamp for the next
+        # forward pass to notice - which a step captured into a HIP graph cannot do: a replay moves no stamp, and a capture that
+        # followed a no_grad forward found every stamp current and recorded no cast, so the layers past the plan multiplied by
+        # stale bf16 weights from the second replay on.  ADVICE round 3.)
+        every = self._shadows(flat)
+        shadows, rest = every[:_lib.ADAM_MAX_SHADOWS], every[_lib.ADAM_MAX_SHADOWS:]
         pending, flat['pending'] = flat['pending'], []
         tail, flat['tail'] = flat.get('tail'), None
         ops.adam_step_plan(flat['param'], flat['grad'], flat['exp_avg'], flat['exp_avg_sq'], group['betas'], group['eps'],
                            group['weight_decay'], self._scalar_buffers(flat)[2 * slot:], 1.0 / world, slab_srcs=pending,
                            shadows=[sh[:5] for sh in shadows], clear_grad=self.fused_loop, tail=tail)
+        if rest:
+            ops.refresh_shadows([sh[5] for sh in rest])
         flat['clean'] = self.fused_loop
         for p in flat['params']:
             p._mg_updates = getattr(p, '_mg_updates', 0) + 1
-        for sh in shadows:                                   # refreshed by the kernel: current again
+        for sh in every:                                     # refreshed by this update: current again
             p = sh[5]
             p._mg_shadow['version'] = (p._version, p._mg_updates)
+        # what this update refreshed, by identity of the copies: a graph that captured it re-stamps exactly these after a replay
+        flat['refreshed'] = [(sh[5], sh[3], sh[4]) for sh in every]
+
+    def refreshed_shadows(self):
+        """[(parameter, plain copy, transposed copy or None)] the last update kernel launch (or its capture) kept current."""
+        out = []
+        for flat in self._flat:
+            if flat is not None:
+                out += flat.get('refreshed', [])
+        return out
+
+    def note_replayed(self, refreshed, n_steps=1):
+        """Book-keeping for ``n_steps`` updates that ran inside a graph replay (the host saw none of them): every parameter counts
+        as updated, and of the bf16 operand copies only those the captured update refreshes (``refreshed``: what ``refreshed_shadows``
+        returned right after the capture) are current - a copy allocated since, e.g. a transposed one first asked for by a later
+        eager pass, keeps its old stamp and is cast again by its next reader (ops.param_shadows)."""
+        for flat in self._flat:
+            if flat is not None:
+                for p in flat['params']:
+                    p._mg_updates = getattr(p, '_mg_updates', 0) + n_steps
+        for p, plain, trans in refreshed:
+            sh = getattr(p, '_mg_shadow', None)
+            if sh is not None and sh['plain'] is plain and sh['t'] is trans:
+                sh['version'] = (p._version, p._mg_updates)
 
     @torch.no_grad()
     def step_captured(self, slot=0):

@@ -51,8 +51,11 @@ class UpsampledSequence(object):
     (B, Tmax, feat) tensor never exists in HBM.  ``materialise()`` gives the ordinary dense tensor.
     """
 
-    def __init__(self, sequence_feature, dur2d, rows, maps=None, table_bf16=None, t_cap=None):
+    def __init__(self, sequence_feature, dur2d, rows, maps=None, table_bf16=None, t_cap=None, phone_rate=None):
         self.source = sequence_feature
+        # the order of operations the caller chose (ops.phone_rate_choice): True = layers that commute with the repetition may run
+        # on the phone rows, False = every product on the frame rows (the reference's order); the consumers read it here
+        self.phone_rate = ops.phone_rate_choice(phone_rate)
         self.dur = dur2d
         # int32 (B, Tmax): b*P + phone, or -1.  None = not built yet (t_cap given): the first reader of ``rows`` launches the map
         # kernel - unless the consumer is the phone-rate loss stack, which builds the maps together with its own front
@@ -196,12 +199,15 @@ def concat_frame_features(upsampled, frame_feature):
     return torch.cat((upsampled, frame_feature), dim=-1)
 
 
-def upsample_to_repetitions(sequence_feature, repeats, max_len=None, fused=False, table_bf16=None):
+def upsample_to_repetitions(sequence_feature, repeats, max_len=None, fused=False, table_bf16=None, phone_rate=None):
     """Copies sequence items according to a number of repetitions, as ``np.repeat`` does.  morgana/utils.py:175-228.
 
     sequence_feature (B, P, F) float32; repeats (B, P, 1) or (B, P) integer -> (B, max_b sum_p repeats, F).
     ``max_len`` (optional, not in the reference) supplies Tmax when the caller knows it (the padded target length),
     which removes the one device->host sync that sizing the output otherwise needs; the reference has three.
+    ``phone_rate`` (not in the reference; ``fused`` only): the order of operations of the layers that consume the lazy result -
+    True lets layers that commute with the repetition run once per phone row, False keeps every product on the frame rows (the
+    reference's order), None = the process default (``MORGANA_PHONE_RATE``).  Same outputs either way.
     """
     if repeats.is_floating_point() or repeats.dtype == torch.bool:
         raise TypeError('upsample_to_repetitions: repeats must be an integer tensor, got %s' % repeats.dtype)
@@ -216,10 +222,11 @@ def upsample_to_repetitions(sequence_feature, repeats, max_len=None, fused=False
         _, tmax = ops.upsample_lengths(dur2d)
         max_len = int(tmax.item())
     if fused and not sequence_feature.requires_grad:
-        if ops.PHONE_RATE and int(max_len) > 0:
-            return UpsampledSequence(sequence_feature, dur2d, None, table_bf16=table_bf16, t_cap=int(max_len))       # maps on first use
+        if ops.phone_rate_choice(phone_rate) and int(max_len) > 0:
+            return UpsampledSequence(sequence_feature, dur2d, None, table_bf16=table_bf16, t_cap=int(max_len),
+                                     phone_rate=True)                                                                # maps on first use
         _, rows = ops.upsample_index(dur2d, int(max_len))
-        return UpsampledSequence(sequence_feature, dur2d, rows, table_bf16=table_bf16)
+        return UpsampledSequence(sequence_feature, dur2d, rows, table_bf16=table_bf16, phone_rate=ops.phone_rate_choice(phone_rate))
     return F_hip.UpsampleFn.apply(sequence_feature, dur2d, int(max_len))
 
 
@@ -490,8 +497,9 @@ class SequentialWithRecurrent(nn.Sequential):
             out, _ = self.forward(input, seq_len=seq_len)
             return losses.mse(out, targets, seq_len), out
         run, acts = fused
-        maps = table = None
+        maps = table = phone_rate = None
         if isinstance(input, UpsampledSequence):
+            phone_rate = input.phone_rate
             x2d, table = input.source.reshape(-1, input.source.shape[-1]), input.table_bf16
             if input.pending():
                 rows, maps = None, input               # the stack builds the maps with its own front, or asks ``input.rows`` for them
@@ -504,7 +512,7 @@ class SequentialWithRecurrent(nn.Sequential):
         params = []
         for lin, _ in run:
             params += [lin.weight, lin.bias]
-        return F_hip.LinearStackMSEFn.apply((acts, maps, table), x2d, rows, targets, seq_len, *params)
+        return F_hip.LinearStackMSEFn.apply((acts, maps, table, phone_rate), x2d, rows, targets, seq_len, *params)
 
     def forward(self, input, hiddens=None, seq_len=None, max_len=None, layout=None):
         """``max_len`` (not in the reference) is handed to the recurrent wrappers: see ``RecurrentCuDNNWrapper.forward``.
@@ -538,7 +546,7 @@ class SequentialWithRecurrent(nn.Sequential):
                 nxt = modules[end] if end < len(modules) else None
                 n_src = input.source.shape[0] * input.source.shape[1] if isinstance(input, UpsampledSequence) else 0
                 if (isinstance(input, UpsampledSequence) and isinstance(nxt, RecurrentCuDNNWrapper) and nxt._hip_gru()
-                        and seq_len is not None and ops.phone_rate_gru_ok(n_src, input.rows.numel(), run[-1][0].weight.shape[0])):
+                        and seq_len is not None and ops.phone_rate_gru_ok(n_src, input.rows.numel(), run[-1][0].weight.shape[0], input.phone_rate)):
                     # Linear / Sigmoid commute with the row repetition of the upsample: run them on the phone rows (+ zero rows for
                     # the padding frames) and hand the GRU wrapper a table + row map; it repeats the rows of its own input projection
                     params = []
@@ -550,7 +558,7 @@ class SequentialWithRecurrent(nn.Sequential):
                     i = end
                     continue
                 if (isinstance(input, UpsampledSequence) and end == len(modules)
-                        and ops.phone_rate_gru_ok(n_src, input.rows.numel(), 8)):
+                        and ops.phone_rate_gru_ok(n_src, input.rows.numel(), 8, input.phone_rate)):
                     # the stack ends in this run and sees nothing but the repeated phone rows: every layer commutes with the
                     # repetition, so the run works on the phone rows (+ zero rows for padding frames) and its OUTPUT is repeated
                     params = []

@@ -84,6 +84,35 @@ def test_metrics_handler_collections():
         handler.accumulate('', loss=torch.tensor([1.]))
     handler.add_collection('synth', from_collections='test')
     assert set(handler['synth']) == {'extra', 'only_test'}
+    # the mappings are LIVE, as the reference's dicts (morgana/metrics.py:65-83): a metric written into one is registered
+    direct = metrics.Mean()
+    handler['train']['direct'] = direct
+    handler.metrics.update(via_all=metrics.Mean())
+    handler.accumulate('train', direct=torch.tensor([4.]))
+    assert handler.result('train')['direct'] == pytest.approx(4.0) and 'via_all' in handler.collections['all']
+    assert handler.collections['train'] is handler['train'] and handler.metrics is handler['all']
+    # the same name may hold different objects in different collections (:95-101)
+    a, b = metrics.Mean(), metrics.Mean()
+    handler.add_metrics('train', shared_name=a)
+    handler.add_metrics('valid', shared_name=b)
+    assert handler['train']['shared_name'] is a and handler['valid']['shared_name'] is b and handler['all']['shared_name'] is b
+    with pytest.raises(KeyError):
+        handler.accumulate('test', loss=torch.tensor([1.]))           # 'test' holds no metric of that name
+
+
+def test_order_of_operations_is_a_per_call_choice():
+    """utils.upsample_to_repetitions(phone_rate=) records the caller's order of operations on the lazy sequence; None = the process
+    default (MORGANA_PHONE_RATE); models carry it as an attribute (base_models.BaseModel.phone_rate) - nothing writes a global."""
+    from morgana_amd import models, ops, utils
+    assert ops.phone_rate_choice(None) == ops.PHONE_RATE and ops.phone_rate_choice(False) is False and ops.phone_rate_choice(1) is True
+    lab, dur = torch.zeros(2, 3, 8), torch.ones(2, 3, dtype=torch.int64)
+    seq = utils.upsample_to_repetitions(lab, dur, max_len=3, fused=True, phone_rate=True)     # lazy: no kernel behind this call
+    assert isinstance(seq, utils.UpsampledSequence) and seq.phone_rate is True and seq.pending()
+    assert models.F0Model().phone_rate is None and models.F0Model(phone_rate=False).phone_rate is False
+    assert models.RNNSPSS(phone_rate=True).phone_rate is True
+    assert not ops.phone_rate_table_ok(20480, 256000, 512, 128, ops.ACT_SIGMOID, enabled=False)
+    assert ops.phone_rate_table_ok(20480, 256000, 512, 128, ops.ACT_SIGMOID, enabled=True)
+    assert not ops.phone_rate_gru_ok(4096, 64000, 512, enabled=False) and ops.phone_rate_gru_ok(4096, 64000, 512, enabled=True)
 
 
 def test_device_batches_shapes_without_a_gpu():

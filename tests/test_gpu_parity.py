@@ -2194,6 +2194,44 @@ def test_graph_replay_survives_a_larger_shape_between_replays():
             assert torch.equal(params_g[name], params_e[name]), (phone_rate, name)
 
 
+def test_graph_captured_after_a_no_grad_forward_keeps_every_operand_copy_current():
+    """a model with more bf16 operand copies than the update kernel's plan holds (ADAM_MAX_SHADOWS = 8; here eleven
+    Linear layers), a validation pass (no_grad forward: every copy stamped current) right before the step that is captured.  The
+    copies past the plan used to be left to the next forward's version stamps - which a graph replay never moves: from the second
+    replay on those layers multiplied by stale bf16 weights.  Now the update re-casts them itself (one batched launch), captured or
+    not: the graph loop must train bit for bit as the eager loop, and a copy allocated AFTER the capture must not be taken for
+    current after a replay."""
+    from morgana_amd import experiment_builder
+    same = [data.to_device(synthetic.make_batch(16, 300, seed=90 + i), DEV) for i in range(6)]
+
+    def train(use_graphs):
+        torch.manual_seed(5)
+        builder = experiment_builder.ExperimentBuilder(models.F0Model, dict(precision='bf16', hidden_dims=(512,) * 8 + (128, 32)),
+                                                       learning_rate=0.01, device=DEV, end_epoch=1, use_graphs=use_graphs)
+        optimizer = builder.make_optimizer()
+        losses = []
+        for i, feats in enumerate(same):
+            losses.append(builder.train_epoch([feats], optimizer))
+            with torch.no_grad():                          # a validation pass between the steps (stamps every copy current)
+                builder.model(feats)
+        n_copies = sum(1 for p in builder.model.parameters() if getattr(p, '_mg_shadow', None) is not None)
+        return losses, {k: v.detach().clone() for k, v in builder.model.named_parameters()}, n_copies, builder
+
+    loss_e, params_e, n_e, _ = train(False)
+    loss_g, params_g, n_g, builder = train(True)
+    assert n_g > 8 and n_e == n_g
+    assert loss_g == loss_e
+    for name in params_e:
+        assert torch.equal(params_g[name], params_e[name]), name
+    # every copy equals a fresh cast of its weight after the last replay
+    for p in builder.model.parameters():
+        sh = getattr(p, '_mg_shadow', None)
+        if sh is not None:
+            assert torch.equal(sh['plain'][:, :p.shape[1]], p.detach().to(torch.bfloat16))
+            if sh['t'] is not None:
+                assert torch.equal(sh['t'][:, :p.shape[0]], p.detach().t().to(torch.bfloat16))
+
+
 def test_deep_stack_with_more_slab_sources_than_the_update_plan_holds():
     """A 600-512-512-512-128-32-1 stack registers one split-M slab source per leading layer plus the tail: five, and the update
     kernel's plan holds ADAM_MAX_SLABS = 4 (optimizer.step() raised on the first step).  The surplus source is summed
