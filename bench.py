@@ -608,6 +608,61 @@ def other_workloads(dev, precision):
     return out
 
 
+def exchange_record(optimizer, step, world, rehearse, device, calls=20):
+    """First-contact diagnostics of the gradient exchange, carried by EVERY bench line:
+    how many ranks a real all-reduce counted, how the exchange ran (mode), what one exchange of the model's flat gradient costs on
+    its own (`us`: device events around `calls` back-to-back all-reduces of a buffer of that size, per-call mean, MAX over ranks;
+    host clock when the group's tensors live on the CPU), and what the capture probe found (`capture_probe`: its verdict, whether the
+    captured graph held a collective at all, whether the replayed sums equalled the world size).  `exposed_us` - the step with the
+    exchange minus the step without it - is filled in by the caller (it needs a second timed loop).  Works on any process group:
+    the CPU / gloo test drives it without a GPU."""
+    dist = torch.distributed
+    live = dist.is_available() and dist.is_initialized()
+    rec = {'world_size': dist.get_world_size() if live else 1, 'backend': dist.get_backend() if live else None,
+           'mode': (getattr(step, 'exchange_mode', None) or ('none (one rank)' if world == 1 and not rehearse else 'eager all-reduce')),
+           'ranks_counted': 1, 'us': None, 'bytes': None, 'exposed_us': None, 'capture_probe': None}
+    if not live:
+        return rec
+    on_gpu = dist.get_backend() == 'nccl'
+    where = device if on_gpu else torch.device('cpu')
+    count = torch.ones(1, dtype=torch.float32, device=where)
+    dist.all_reduce(count)                                             # a real collective: every rank that is really there adds 1
+    rec['ranks_counted'] = int(round(float(count.item())))
+    flat = optimizer.flat_buffers() if optimizer is not None else None
+    if flat is not None and optimizer.exchanging():
+        scratch = torch.zeros(flat['grad'].numel(), dtype=torch.float32, device=flat['grad'].device)
+        rec['bytes'] = int(scratch.numel() * 4)
+        dist.all_reduce(scratch)                                       # communicator / buffers warm
+        if scratch.is_cuda:
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(calls):
+                dist.all_reduce(scratch)
+            e1.record()
+            e1.synchronize()
+            us = e0.elapsed_time(e1) / calls * 1e3
+        else:
+            t0 = time.perf_counter()
+            for _ in range(calls):
+                dist.all_reduce(scratch)
+            us = (time.perf_counter() - t0) / calls * 1e6
+        worst = torch.tensor([us], dtype=torch.float64, device=where)
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        rec['us'] = round(float(worst.item()), 2)
+    if on_gpu:
+        from morgana_amd import graphs
+        probe = dict(graphs.rccl_capture_report(device))
+        if probe['world'] > 1 and probe['verdict']:
+            # more than one rank and a green verdict: the replayed graph DID sum over the ranks
+            assert probe['graph_held_collective'] and probe['replayed_sum_equals_world'], probe
+        rec['capture_probe'] = probe
+    else:
+        rec['capture_probe'] = {'verdict': False, 'world': rec['world_size'], 'backend': rec['backend'],
+                                'error': 'not an RCCL group: nothing to capture'}
+    return rec
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver's command line would
     (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>), as a CHILD
@@ -768,6 +823,49 @@ def main():
     ops.check_persistent_status()        # raises if a persistent recurrent kernel timed out (results would be invalid)
     final_loss = float(distributed.mean_scalar(loss.detach()).item())
 
+    # the exchange's own record (every rank takes part in its collectives), and - where the step has an exchange - the same step
+    # timed WITHOUT it right after: exposed_us = what the data-parallel form costs a step beyond the one-rank step
+    exchange = exchange_record(optimizer, step, world, rehearse, dev)
+    if optimizer.exchanging() and args.config == 'c2' and not args.no_compare:
+        try:
+            from morgana_amd import graphs
+            alone_model = models.F0Model(precision=args.precision).to(dev)
+            alone_model.load_state_dict(model.state_dict())
+            alone_opt = optim.Adam(alone_model.parameters(), lr=0.01, fused_loop=True, exchange_never=True)
+            if per_call > 1 or (graph_note is not None and not graph_note.startswith('eager')):
+                alone = graphs.GraphedTrainStep(alone_model, alone_opt, features, steps_per_replay=per_call)
+            else:
+                def alone():
+                    alone_opt.zero_grad()
+                    alone_loss, _ = alone_model(features)
+                    F_hip.backward(alone_loss)
+                    alone_opt.step()
+            gc.collect()
+            gc.disable()
+            for _ in range(max(warm_calls // 4, 2)):
+                alone()
+            torch.cuda.synchronize()
+            distributed.barrier()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(args.steps // per_call):
+                alone()
+            torch.cuda.synchronize()
+            distributed.barrier()
+            torch.cuda.synchronize()
+            alone_s = time.perf_counter() - t2
+            gc.enable()
+            if world > 1:
+                tmax2 = torch.tensor([alone_s], dtype=torch.float64, device=dev)
+                torch.distributed.all_reduce(tmax2, op=torch.distributed.ReduceOp.MAX)
+                alone_s = float(tmax2.item())
+            exchange['step_without_exchange_ms'] = round(alone_s / args.steps * 1e3, 4)
+            exchange['exposed_us'] = round((elapsed - alone_s) / args.steps * 1e6, 2)
+        except Exception as exc:                                            # noqa: BLE001 - a diagnostic leg: reported, never fatal
+            exchange['exposed_us_error'] = str(exc).splitlines()[0][:200]
+        finally:
+            gc.enable()
+
     # C2, one rank: the same model and batch with every product at frame rate (the reference's order of operations,
     # MORGANA_PHONE_RATE=0), timed the same way right after - reported next to the headline value, never as it
     frame_rate = None
@@ -844,11 +942,8 @@ def main():
                        'parallelism': 'dp%d' % n_gpus},
             'final_loss': round(final_loss, 6),
         }
-        # how the gradients crossed the ranks: a SCALE record then shows whether the step's graph really held a collective
-        result['exchange'] = {
-            'world_size': (torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1),
-            'backend': (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
-            'mode': (getattr(step, 'exchange_mode', None) or ('none (one rank)' if world == 1 and not rehearse else 'eager all-reduce'))}
+        result['exchange'] = exchange          # how the gradients crossed the ranks (exchange_record), all ranks took part
+        result['ranks_counted'] = exchange['ranks_counted']
         # top-level `warmup` = the untimed steps that actually ran in front of the clock (>= the flag: see the warm-up comment above)
         result['config']['warmup_flag'] = args.warmup
         result['config']['warmup_steps_run'] = warm_calls * per_call

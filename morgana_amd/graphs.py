@@ -29,13 +29,21 @@ from . import functional
 _CAPTURE_VERDICT = {}
 
 
-def rccl_capture_works(device, group=None):
-    """Cached per process group: the probe captures (and may fail to capture) a collective, which is not something to repeat."""
+def rccl_capture_report(device, group=None):
+    """What the capture probe found, cached per process group (the probe captures - and may fail to capture - a collective, which is
+    not something to repeat): {'verdict': use the captured exchange?, 'world', 'backend', 'graph_held_collective': did the captured
+    graph contain a node at all (torch warns "The CUDA Graph is empty" when a one-rank collective is elided),
+    'replayed_sum_equals_world': did both replays leave world x 1.0 in the buffer (None if nothing was replayed), 'error'}.
+    At world size 1 a green verdict says nothing about a LIVE collective - the report says so ('vacuous')."""
     import torch.distributed as dist
     key = (str(device), id(group), dist.get_backend(group), dist.get_world_size(group))
     if key not in _CAPTURE_VERDICT:
         _CAPTURE_VERDICT[key] = _rccl_capture_probe(device, group)
     return _CAPTURE_VERDICT[key]
+
+
+def rccl_capture_works(device, group=None):
+    return rccl_capture_report(device, group)['verdict']
 
 
 def _leave_failed_capture(entry_stream):
@@ -55,8 +63,11 @@ def _rccl_capture_probe(device, group=None):
     choose the same exchange mode.  Any exception on the way counts as "no"."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
+    report = {'verdict': False, 'world': world, 'backend': dist.get_backend(group), 'graph_held_collective': None,
+              'replayed_sum_equals_world': None, 'error': None, 'vacuous': world == 1}
     if dist.get_backend(group) != 'nccl':              # gloo moves device tensors through the host: never capturable, and trying leaves
-        return False                                   # the thread's capture invalidated
+        report['error'] = 'backend %s: not capturable (not tried)' % dist.get_backend(group)      # the thread's capture invalidated
+        return report
     ok = 1.0
     entry_stream = torch.cuda.current_stream()
     try:
@@ -70,20 +81,29 @@ def _rccl_capture_probe(device, group=None):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode='thread_local'):
-            dist.all_reduce(buf, group=group)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter('always')
+            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                dist.all_reduce(buf, group=group)
+        report['graph_held_collective'] = not any('Graph is empty' in str(w.message) for w in caught)
+        sums_ok = True
         for _ in range(2):
             buf.fill_(1.0)
             graph.replay()
             torch.cuda.synchronize()
             if not bool((buf == float(world)).all().item()):
-                ok = 0.0
-    except Exception:                                                   # noqa: BLE001 - any failure means "use the eager exchange"
+                ok, sums_ok = 0.0, False
+        report['replayed_sum_equals_world'] = sums_ok
+        if world > 1 and not report['graph_held_collective']:
+            ok = 0.0                                   # more than one rank and a graph without the collective: never "captured"
+    except Exception as exc:                                            # noqa: BLE001 - any failure means "use the eager exchange"
         ok = 0.0
+        report['error'] = str(exc).splitlines()[0][:200] if str(exc) else type(exc).__name__
         _leave_failed_capture(entry_stream)
     verdict = torch.full((1,), ok, dtype=torch.float32, device=device)
     dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=group)
-    return bool(verdict.item() > 0.5)
+    report['verdict'] = bool(verdict.item() > 0.5)
+    return report
 
 
 class GraphedTrainStep(object):

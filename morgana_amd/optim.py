@@ -31,13 +31,16 @@ class Adam(torch.optim.Optimizer):
     semantics to the letter (``.grad`` complete after ``backward``, untouched by ``step``)."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, process_group=None,
-                 kernel=None, exchange_always=False, fused_loop=False):
+                 kernel=None, exchange_always=False, fused_loop=False, exchange_never=False):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super(Adam, self).__init__(params, defaults)
         self.process_group = process_group
         # exchange_always: run the gradient exchange whenever a process group exists, also at world size 1 (where it is the
         # identity) - lets the one-GPU box exercise the multi-rank code path on a live RCCL communicator
         self.exchange_always = exchange_always
+        # exchange_never: no gradient exchange even with several ranks (each rank then trains on its own shard) - a MEASUREMENT
+        # switch: bench.py times the step without its exchange beside the step with it (exchange.exposed_us), never a training mode
+        self.exchange_never = bool(exchange_never)
         self.fused_loop = bool(fused_loop)
         self._kernel = kernel
         self._flat = []
@@ -90,6 +93,8 @@ class Adam(torch.optim.Optimizer):
                     off += n
 
     def _world(self):
+        if self.exchange_never:
+            return 1
         if dist.is_available() and dist.is_initialized():
             return dist.get_world_size(self.process_group)
         return 1
@@ -144,7 +149,7 @@ class Adam(torch.optim.Optimizer):
 
     def exchanging(self):
         """True when ``step`` has a gradient exchange to do."""
-        if not (dist.is_available() and dist.is_initialized()):
+        if self.exchange_never or not (dist.is_available() and dist.is_initialized()):
             return False
         return self._world() > 1 or self.exchange_always
 

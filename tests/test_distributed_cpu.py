@@ -123,6 +123,54 @@ def test_two_bucket_exchange_equals_single_all_reduce(tmp_path):
     np.testing.assert_array_equal(a, want)
 
 
+def _exchange_record_worker(rank, world, port, out_dir):
+    import json
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    from morgana_amd import optim
+    import helpers
+    sys.path.insert(0, REPO)
+    import bench
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        model = helpers.init_small(helpers.CpuF0Model(dims=(24, 16, 8, 1)), seed=3)
+        opt = optim.Adam(model.parameters(), lr=0.01, kernel=helpers.cpu_adam_kernel)
+        rec = bench.exchange_record(opt, None, world, False, torch.device('cpu'), calls=3)
+        alone = optim.Adam(helpers.init_small(helpers.CpuF0Model(dims=(24, 16, 8, 1)), seed=3).parameters(), lr=0.01,
+                           kernel=helpers.cpu_adam_kernel, exchange_never=True)
+        rec['alone_exchanging'] = alone.exchanging()
+        rec['alone_world'] = alone._world()
+        with open(os.path.join(out_dir, 'exchange_rank%d.json' % rank), 'w') as f:
+            json.dump(rec, f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_record_fields_over_gloo(tmp_path):
+    """bench.py's `exchange` record on a live two-rank gloo group, no GPU: the ranks are COUNTED by a real
+    all-reduce, the exchange of the flat gradient is timed on its own, the capture probe reports why nothing was captured, and the
+    measurement switch `exchange_never` gives an optimiser that does not exchange (the `exposed_us` leg's step)."""
+    import json
+    import torch.multiprocessing as mp
+    mp.spawn(_exchange_record_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    recs = [json.load(open(tmp_path / ('exchange_rank%d.json' % r))) for r in range(2)]
+    for rec in recs:
+        assert rec['world_size'] == 2 and rec['ranks_counted'] == 2 and rec['backend'] == 'gloo'
+        assert rec['mode'] == 'eager all-reduce'
+        assert rec['us'] is not None and rec['us'] > 0 and rec['bytes'] == 4 * (24 * 16 + 16 + 16 * 8 + 8 + 8 + 1)
+        assert 'exposed_us' in rec and rec['capture_probe']['verdict'] is False and 'error' in rec['capture_probe']
+        assert rec['alone_exchanging'] is False and rec['alone_world'] == 1
+    assert recs[0]['us'] == recs[1]['us']                             # the MAX over ranks: every rank holds the same number
+    # one rank, no process group: the record still has every field
+    sys.path.insert(0, REPO)
+    import bench
+    solo = bench.exchange_record(None, None, 1, False, torch.device('cpu'))
+    assert solo['ranks_counted'] == 1 and solo['mode'] == 'none (one rank)' and solo['us'] is None and solo['capture_probe'] is None
+
+
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus N` without a launcher must start N ranks itself (torch.distributed.run as a child process, before
     any GPU call) and report n_gpus = N; a WORLD_SIZE that disagrees with --gpus is an error, never a silent single-rank run

@@ -115,6 +115,57 @@ def test_c5_packed_rows_equal_padded_rows(c5_case):
         assert rel_l2(grads_p[name].cpu().numpy(), grads_d[name].cpu().numpy()) < 1e-4, name
 
 
+def test_c5_at_its_per_rank_size():
+    """BASELINE C5 at the size ONE RANK runs it (64 utterances of 300-2000 frames, 187 outputs), bf16 mode,
+    through properties that do not need 80 s of oracle time:
+      * the phone-rate GRU input and the persistent recurrence engage, the persistent status word stays clean;
+      * packed frame rows == padded rows: valid predictions bit for bit, loss to 1e-6, gradients to 1e-4 (another split order);
+      * utterances are independent (morgana/losses.py:37-42: a mean over utterances of per-utterance means): the two half batches
+        give the SAME valid predictions bit for bit, the mean of their losses is the loss, the mean of their gradients the gradient;
+      * the first 8 utterances' predictions against the oracle (the only part that costs oracle time: 8 utterances)."""
+    feats = synthetic.make_batch(64, (300, 2000), out_dim=187, target_name='world', seed=5)
+    state = synthetic.rnn_spss_state(out_dim=187)
+    b, t = feats['normalised_world'].shape[:2]
+    assert ops.phone_rate_gru_ok(feats['normalised_lab'].shape[0] * feats['normalised_lab'].shape[1], b * t, 512)
+    assert ops.gru_persist_ok(b, t, 512)
+
+    def run(batch, packed=True):
+        utils.set_packed_frames(packed)
+        try:
+            model = _load_state(models.RNNSPSS(output_dim=187, target_name='world', precision='bf16').to(DEV), state)
+            loss, out = model(data.to_device(batch, DEV))
+            loss.backward()
+            ops.check_persistent_status()              # raises if a persistent launch gave up on a peer
+        finally:
+            utils.set_packed_frames(True)
+        tt = batch['normalised_world'].shape[1]
+        valid = torch.from_numpy((np.arange(tt)[None, :] < batch['n_frames'][:, None])[:, :, None]).to(DEV)
+        pred = torch.where(valid, out['pred_norm_world'].detach(), torch.zeros((), device=DEV))
+        return loss.item(), pred, {n: p.grad.detach().cpu().numpy().astype(np.float64) for n, p in model.named_parameters()}
+
+    loss_p, pred_p, grads_p = run(feats, packed=True)
+    loss_d, pred_d, grads_d = run(feats, packed=False)
+    assert torch.equal(pred_p, pred_d)
+    np.testing.assert_allclose(loss_p, loss_d, rtol=1e-6)
+    for name in grads_d:
+        assert rel_l2(grads_p[name], grads_d[name]) < 1e-4, name
+
+    halves = [run(synthetic.shard_batch(feats, r, 2)) for r in range(2)]
+    for r, (_, pred_h, _) in enumerate(halves):
+        th = pred_h.shape[1]
+        assert torch.equal(pred_h, pred_p[32 * r:32 * (r + 1), :th]), r
+        assert not bool(pred_p[32 * r:32 * (r + 1), th:].any())            # nothing valid beyond the half's own longest utterance
+    np.testing.assert_allclose(0.5 * (halves[0][0] + halves[1][0]), loss_p, rtol=1e-5)
+    for name in grads_p:
+        assert rel_l2(0.5 * (halves[0][2][name] + halves[1][2][name]), grads_p[name]) < 1e-4, name
+
+    sub = synthetic.shard_batch(feats, 0, 8)
+    _, want_pred, _ = ref_cpu.rnn_forward_backward(state, sub, target_key='normalised_world')
+    t8 = want_pred.shape[1]
+    valid8 = (np.arange(t8)[None, :] < sub['n_frames'][:, None])[:, :, None]
+    assert rel_err(pred_p[:8, :t8].cpu().numpy(), np.where(valid8, want_pred, 0)) < RTOL_BF16
+
+
 # ------------------------------------------------------------------------------------------------------------ C4
 def test_c4_persistent_recurrence_equals_step_kernels_at_t1000():
     """mg_gru_fwd_persist_bf16 / mg_gru_bwd_persist_bf16 at the full C4 shape (64, 1000, 512) against the per-step kernels that
