@@ -41,7 +41,7 @@ def parse_args():
                     help='timed steps (default 200 for c2 - a 0.13 ms step: the barrier + synchronize around the timed region and the gaps '
                          'between graph launches weigh 4 %% on 30 steps - and 30 for the recurrent configs)')
     ap.add_argument('--warmup', type=int, default=None, help='untimed steps in front (default 20 for c2, 5 otherwise)')
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32', 'bf16x3'])
     ap.add_argument('--config', default='c2', choices=['c2', 'c4', 'c5', 'lstm', 'f0gru'],
                     help='c2: F0Model 256x1000 (headline); c4: GRU-512 600->80, 64x1000; c5: GRU-512 600->187, 64 ragged 300-2000; '
                          'lstm: the shipped LSTMAcousticModel 609->512->8xLSTM-512->256->199, 64x1000')
@@ -438,7 +438,7 @@ def loss_curve_deviation(dev):
     batches = [data.to_device(synthetic.make_batch(8, 200, seed=synthetic.REFERENCE_SEED + 100 * i), dev) for i in range(4)]
     out = {'reference': 'tests/golden/g6_f0_model.npz: 20 Adam steps (lr 0.01) of the README F0Model at config C1, computed by the imported '
                         'reference on CPU in fp32', 'what': 'max over the 20 steps of |loss - reference loss| / reference loss'}
-    for precision in ('bf16', 'fp32'):
+    for precision in ('bf16', 'bf16x3', 'fp32'):
         model = models.F0Model(precision=precision).to(dev)
         own = model.state_dict()
         for key, value in synthetic.f0_model_state().items():
@@ -515,6 +515,48 @@ def _timed_steps(step, steps):
             st1['num_device_free'] - st0['num_device_free'], st1['num_alloc_retries'] - st0['num_alloc_retries'],
             st1['reserved_bytes.all.current'] / 1e9))
     return (time.perf_counter() - t0) / steps * 1e3
+
+
+def bf16x3_legs(dev, features, state_dict, steps, frames_per_step):
+    """Precision mode 'bf16x3' (split-bf16 operands: three bf16 MFMA products per fp32 product, fp32 activations - the mode that
+    meets the reference's loss curve to 1e-4, `loss_curve_deviation.bf16x3`) timed on the C2 batch in the same run as the bf16
+    headline, in BOTH orders of operations, graph replayed like the headline.  tflops counts the bf16
+    products the matrix cores execute: three per product of the order's step."""
+    from morgana_amd import graphs
+    import gc
+    out = {}
+    for key, phone_rate in (('phone_rate', True), ('frame_rate_order', False)):
+        try:
+            model = models.F0Model(precision='bf16x3', phone_rate=phone_rate).to(dev)
+            model.load_state_dict(state_dict)
+            opt = optim.Adam(model.parameters(), lr=0.01, fused_loop=True)
+            n = max(k for k in range(1, min(10, max(steps // 2, 1)) + 1) if steps % k == 0)
+            step = graphs.GraphedTrainStep(model, opt, features, steps_per_replay=n)
+            gc.collect()
+            gc.disable()
+            for _ in range(max(40 // n, 2)):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps // n):
+                step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            gc.enable()
+            out[key] = {'ms_per_step': round(ms, 4), 'value': round(frames_per_step / (ms * 1e-3), 1), 'unit': 'frames/s',
+                        'steps': steps, 'launch': 'hip graph replay, %d steps per graph' % n}
+            if not phone_rate:
+                tf = 3.0 * F0_FLOPS_PER_FRAME * frames_per_step / (ms * 1e-3) / 1e12
+                out[key].update({'tflops_bf16_products': round(tf, 1), 'frac_of_mfma_peak': round(tf / MFMA_BF16_PEAK_TFLOPS, 4)})
+            del step, model, opt
+        except Exception as exc:                          # noqa: BLE001 - a leg that fails is reported, the headline stands
+            out[key] = {'error': str(exc).splitlines()[0][:200]}
+        finally:
+            gc.enable()
+    out['what'] = ("F0Model(precision='bf16x3'): x = hi + lo in bf16, x w ~= hi hi + hi lo + lo hi as one bf16 GEMM over a three times longer "
+                   "contraction index (csrc/split3.hip), fp32 activations and accumulators; phone_rate = the headline's order of operations "
+                   "(generic row-wise stack on the phone rows), frame_rate_order = every product on the B*T frame rows")
+    return out
 
 
 def c4_leg(dev, precision):
@@ -915,12 +957,14 @@ def main():
                          'times that order); bf16 phone table prepared by the loader'
                          % (lab_shape[0] * lab_shape[1], ops.PHONE_RATE_EXTRA, frames_per_step,
                             frames_per_step / float(lab_shape[0] * lab_shape[1] + ops.PHONE_RATE_EXTRA)))
-        elif args.precision == 'fp32' and ops.phone_rate_gru_ok(lab_shape[0] * lab_shape[1], frames_per_step, 8):
+        elif args.precision in ('fp32', 'bf16x3') and ops.phone_rate_gru_ok(lab_shape[0] * lab_shape[1], frames_per_step, 8):
             # fp32 parity mode takes the generic phone-rate form (utils.SequentialWithRecurrent: the row-wise stack on the phone rows,
             # its output repeated, exact-fp32 MFMA products): not the reference's order of operations either
-            form_note = ('; fp32 parity mode AT PHONE RATE as well (generic form: the Linear / Sigmoid stack on the %d phone rows + %d zero '
-                         'rows, its output repeated to the %d frames; exact-fp32 MFMA products, the loss curve matches the reference to 1e-7)'
-                         % (lab_shape[0] * lab_shape[1], ops.PHONE_RATE_EXTRA, frames_per_step))
+            form_note = ('; %s parity mode AT PHONE RATE as well (generic form: the Linear / Sigmoid stack on the %d phone rows + %d zero '
+                         'rows, its output repeated to the %d frames; %s)'
+                         % (args.precision, lab_shape[0] * lab_shape[1], ops.PHONE_RATE_EXTRA, frames_per_step,
+                            'exact-fp32 MFMA products, the loss curve matches the reference to 1e-7' if args.precision == 'fp32' else
+                            'split-bf16 operands: three bf16 MFMA products per fp32 product'))
         else:
             form_note = '; every product at frame rate (the reference\'s order of operations)'
     if rank == 0:
@@ -988,6 +1032,7 @@ def main():
         except Exception as exc:
             result['c4'] = {'error': str(exc).splitlines()[0][:200]}
         result['other_workloads'] = other_workloads(dev, args.precision)
+        result['bf16x3'] = bf16x3_legs(dev, features, model.state_dict(), args.steps, frames_per_step)
         try:
             result['loss_curve_deviation'] = loss_curve_deviation(dev)
         except Exception as exc:

@@ -404,6 +404,23 @@ typedef struct {
     int ldt;
 } mg_cast_desc;
 int mg_cast_params_bf16(const mg_cast_desc* descs, int count, void* stream);
+/* Operand splits of precision mode 'bf16x3' (split-bf16: hi = bf16(x), lo = bf16(x - hi); x w ~= hi hi + hi lo + lo hi as ONE bf16
+ * GEMM over a contraction index three times as long; csrc/split3.hip).  The reference computes these products in fp32
+ * (morgana/experiment_builder.py:262-263: no autocast, morgana/data.py:127: float32 features); this mode reproduces them to ~1e-5
+ * at three bf16 MFMA products each.  For each descriptor: dst bf16 [rows, 3 ldp] = three planes of ldp columns (zero padded):
+ * order 0 -> [hi | hi | lo] (the activation side of a product), order 1 -> [hi | lo | hi] (the weight side); transpose != 0 -> the
+ * planes hold the split of src^T: dst [cols, 3 ldp] with ldp >= rows.  `descs` is a HOST array, count <= MG_SPLIT3_MAX. */
+#define MG_SPLIT3_MAX 16
+typedef struct {
+    const float* src; /* device, fp32 [rows, cols], row stride lds */
+    int64_t rows;
+    int cols, lds;
+    uint16_t* dst;    /* device, bf16, 16-byte aligned: [rows, 3 ldp], or [cols, 3 ldp] when transposed */
+    int ldp;          /* columns per plane: multiple of 8, >= cols (>= rows when transposed) */
+    int order;        /* 0: hi | hi | lo;  1: hi | lo | hi */
+    int transpose;
+} mg_split3_desc;
+int mg_split3_bf16(const mg_split3_desc* descs, int count, void* stream);
 /* dst f32 [rows, cols] = src bf16 [rows, cols] (lds). */
 int mg_cast_bf16_f32(const uint16_t* src, int lds, float* dst, int ldd, int64_t rows, int cols, void* stream);
 /* elementwise sigmoid forward / backward for a stand-alone nn.Sigmoid. */

@@ -77,6 +77,7 @@ SIGNATURES = {
     'mg_cast_transpose_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     'mg_cast_params_bf16': (c_int, [c_void_p, c_int, c_void_p]),
     'mg_cast_bf16_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    'mg_split3_bf16': (c_int, [c_void_p, c_int, c_void_p]),
     'mg_sigmoid_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     'mg_sigmoid_grad_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     'mg_f0_tail_workspace_bytes': (c_size_t, [c_int64]),
@@ -203,6 +204,12 @@ class CastDesc(ctypes.Structure):
                 ('dst_t', c_void_p), ('ldt', c_int)]
 
 
+class Split3Desc(ctypes.Structure):
+    """mg_split3_desc of include/morgana_hip.h."""
+    _fields_ = [('src', c_void_p), ('rows', c_int64), ('cols', c_int), ('lds', c_int), ('dst', c_void_p), ('ldp', c_int),
+                ('order', c_int), ('transpose', c_int)]
+
+
 class StreamDesc(ctypes.Structure):
     """mg_stream_desc of include/morgana_hip.h."""
     _fields_ = [('target', c_void_p), ('ldt', c_int), ('col0', c_int), ('width', c_int), ('kind', c_int)]
@@ -270,6 +277,7 @@ class AdamPlan(ctypes.Structure):
 
 LSTM_MAX_LAYERS = 8
 CAST_MAX = 16
+SPLIT3_MAX = 16
 STREAMS_MAX = 8
 LOSS_MSE, LOSS_SIGMOID_BCE = 0, 1
 _lib = None

@@ -7,7 +7,9 @@ Three nodes cover the hot path of the reference's train step (experiment_builder
   MaskedMSEFn     losses.mse (losses.py:29-51): loss and d loss / d prediction come out of one kernel pass
 
 Precision: 'fp32' = exact-fp32 MFMA (parity mode, 1e-4 vs the reference), 'bf16' = bf16 operands / fp32 accumulate
-(throughput mode; master weights, biases, loss and optimiser state stay fp32).
+(throughput mode; master weights, biases, loss and optimiser state stay fp32), 'bf16x3' = split-bf16 operands (hi + lo, three
+bf16 MFMA products per fp32 product, fp32 accumulate and fp32 activations: parity grade - 1e-4 vs the reference - at the bf16
+matrix rate; row-wise Linear / Sigmoid layers only, recurrent cells run their exact-fp32 form in this mode).
 """
 import os
 
@@ -19,11 +21,20 @@ _PRECISION = 'fp32'
 
 
 def set_precision(precision):
-    """Global default for modules that do not pin their own precision: 'fp32' or 'bf16'."""
+    """Global default for modules that do not pin their own precision: 'fp32', 'bf16' or 'bf16x3'."""
     global _PRECISION
-    if precision not in ('fp32', 'bf16'):
-        raise ValueError("precision must be 'fp32' or 'bf16', got %r" % (precision,))
+    if precision not in PRECISIONS:
+        raise ValueError("precision must be one of %s, got %r" % (', '.join(repr(p) for p in PRECISIONS), precision))
     _PRECISION = precision
+
+
+PRECISIONS = ('fp32', 'bf16', 'bf16x3')
+
+
+def recurrent_precision(precision):
+    """The precision a recurrent cell runs in when its container asks for ``precision``: 'bf16x3' is a mode of the row-wise layers
+    (their operands are split); a recurrence under it takes its exact-fp32 form."""
+    return 'fp32' if precision == 'bf16x3' else precision
 
 
 def get_precision():
@@ -179,6 +190,20 @@ class LinearStackFn(torch.autograd.Function):
                 hidden.append(a)
             out = a
             ctx.save_for_backward(x2d, rows_k, rows if gathered_grad else None, *weights, *hidden)
+        elif precision == 'bf16x3':
+            # split-bf16: fp32 activations as in fp32 mode, every product as ONE bf16 GEMM over split operands (csrc/split3.hip)
+            if extra:
+                x2d = torch.cat((x2d, x2d.new_zeros((extra, x2d.shape[1]))))
+            a, r = x2d, rows
+            w3s = ops.x3_weight_operands(weights)[0]
+            for i in range(n_layers):
+                a3 = ops.split3([(a, 0, False)])[0]
+                a = ops.linear_fwd_x3(a3, r, m, w3s[i], biases[i], weights[i].shape[0], acts[i])
+                r = None
+                hidden.append(a)
+            out = a
+            ctx.save_for_backward(x2d, rows_k, rows if gathered_grad else None, *weights, *hidden)
+            ctx.param_refs = (list(weights), list(biases))
         else:
             if gathered_grad:
                 if pre_cast:
@@ -232,6 +257,25 @@ class LinearStackFn(torch.autograd.Function):
                     g = ops.linear_dgrad_f32(g, weights[i], h)
                 elif need_x:
                     grad_x = ops.linear_dgrad_f32(g, weights[0], None)
+        elif precision == 'bf16x3':
+            w_params, b_params = ctx.param_refs
+            direct = all(ctx.has_bias) and _direct_params(*w_params, *b_params)
+            wt3s = ops.x3_weight_operands(w_params, want_t=tuple(range(1 if not need_x else 0, n_layers)))[1]
+            for i in range(n_layers - 1, -1, -1):
+                n, k = ctx.dims[i]
+                a_in, r = (x_in, rows) if i == 0 else (hidden[i - 1], None)
+                g3, a3 = ops.split3([(g, 0, False), (a_in, 0, False)])
+                if direct:
+                    ops.linear_wgrad_x3(g3, a3, r, m, n, k, out_w=w_params[i].grad, out_b=b_params[i].grad, accumulate=True)
+                else:
+                    dw, db = ops.linear_wgrad_x3(g3, a3, r, m, n, k)
+                    grads[2 * i], grads[2 * i + 1] = dw, (db if ctx.has_bias[i] else None)
+                if i > 0:
+                    g = ops.linear_dgrad_x3(g3, m, wt3s[i], k)
+                    if acts[i - 1] == ops.ACT_SIGMOID:
+                        g = ops.sigmoid_grad(g, hidden[i - 1])
+                elif need_x:
+                    grad_x = ops.linear_dgrad_x3(g3, m, wt3s[0], k)
         else:
             g = ops.cast_pad_bf16(g)
             w_params, b_params = ctx.param_refs

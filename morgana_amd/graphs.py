@@ -178,6 +178,8 @@ class GraphedTrainStep(object):
         # a step captured whole: what the forward leaves for the backward's first launch to finish (functional.DEFER_TAIL) cannot be
         # observed half done - a replay runs forward and backward as one unit
         prev = functional.set_defer_tail(True)
+        from . import ops
+        ops.begin_capture_epoch()                      # operand splits of 'bf16x3' are recorded afresh in every capture
         try:
             self._capture_steps(mode)
         finally:

@@ -689,6 +689,101 @@ def refresh_shadows(params):
         _lib.check(lib.mg_cast_params_bf16(ctypes.cast(descs, ctypes.c_void_p), len(chunk), _stream()), 'mg_cast_params_bf16')
 
 
+# ----------------------------------------------------------------------------------------- precision 'bf16x3' (split-bf16 operands)
+CAPTURE_EPOCH = [0]      # bumped by graphs.GraphedTrainStep at the start of every capture (see x3_weight_operands)
+
+
+def begin_capture_epoch():
+    CAPTURE_EPOCH[0] += 1
+
+
+def split3(jobs):
+    """Operand splits of precision mode 'bf16x3' (csrc/split3.hip): ``jobs`` = [(fp32 2-D tensor, order, transpose)] with order 0 =
+    [hi | hi | lo] (activation side), 1 = [hi | lo | hi] (weight side); one batched launch per MG_SPLIT3_MAX jobs.  Returns one bf16
+    tensor (rows, 3 ldp) per job - (cols, 3 ldp) with ``transpose`` - where ldp = pad_ld(columns of a plane)."""
+    lib = _lib.load()
+    outs = []
+    for i in range(0, len(jobs), _lib.SPLIT3_MAX):
+        chunk = jobs[i:i + _lib.SPLIT3_MAX]
+        descs = (_lib.Split3Desc * len(chunk))()
+        for j, (x, order, transpose) in enumerate(chunk):
+            if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
+                raise TypeError('split3: operands must be 2-D float32 with unit column stride')
+            rows, cols = x.shape
+            ldp = pad_ld(rows if transpose else cols)
+            out = torch.empty((cols if transpose else rows, 3 * ldp), dtype=torch.bfloat16, device=x.device)
+            descs[j].src, descs[j].rows, descs[j].cols, descs[j].lds = x.data_ptr(), rows, cols, x.stride(0)
+            descs[j].dst, descs[j].ldp, descs[j].order, descs[j].transpose = out.data_ptr(), ldp, int(order), int(bool(transpose))
+            outs.append(out)
+        if chunk:
+            _lib.check(lib.mg_split3_bf16(ctypes.cast(descs, ctypes.c_void_p), len(chunk), _stream()), 'mg_split3_bf16')
+    return outs
+
+
+def x3_weight_operands(weights, want_t=()):
+    """Weight-side operands of 'bf16x3' for a run of fp32 weight matrices [N, K]: ([N, 3 pad_ld(K)] splits in order 1, and for the
+    indices in ``want_t`` the order-1 splits of W^T [K, 3 pad_ld(N)] (the dgrad operand), None elsewhere).  Cached on the parameter
+    under the same version stamps as the bf16 operand copies (param_shadows); every stale one is re-split by ONE batched launch."""
+    jobs, slots = [], []
+    # inside a stream capture a split that is current NOW says nothing about the replays: every step of a captured graph re-splits
+    # the weights it reads (once per capture epoch and update count - graphs.GraphedTrainStep opens an epoch per capture)
+    capturing = bool(weights) and weights[0].is_cuda and torch.cuda.is_current_stream_capturing()
+    for i, w in enumerate(weights):
+        st = getattr(w, '_mg_x3', None)
+        stamp = (w._version, getattr(w, '_mg_updates', 0), CAPTURE_EPOCH[0] if capturing else -1)
+        if st is None or st['version'] != stamp or st['plain'].device != w.device:
+            st = w._mg_x3 = {'plain': None, 't': None, 'version': stamp}
+        if st['plain'] is None:
+            jobs.append((_require(w, torch.float32, 'weight'), 1, False))
+            slots.append((st, 'plain'))
+        if i in want_t and st['t'] is None:
+            jobs.append((_require(w, torch.float32, 'weight'), 1, True))
+            slots.append((st, 't'))
+    for (st, key), out in zip(slots, split3(jobs)):
+        st[key] = out
+    return [w._mg_x3['plain'] for w in weights], [w._mg_x3['t'] if i in want_t else None for i, w in enumerate(weights)]
+
+
+def linear_fwd_x3(a3, rows, m, w3, bias, n, act):
+    """fp32 (m, n) = act(gather(A, rows) W^T + bias) from split operands: a3 (R, 3 ldp) order 0, w3 (n, 3 ldp) order 1 - the bf16
+    tile programs over a contraction index of 3 ldp (mg_linear_fwd_bf16, fp32 output)."""
+    if a3.shape[1] != w3.shape[1]:
+        raise ValueError('linear_fwd_x3: operand planes differ (%d vs %d columns)' % (a3.shape[1], w3.shape[1]))
+    y = linear_fwd_bf16(a3, rows, m, a3.shape[1], w3, bias, n, act, out_f32=True)
+    return y if y.shape[1] == n else y[:, :n].contiguous()
+
+
+def linear_dgrad_x3(g3, m, wt3, k):
+    """fp32 (m, k) = dY W from split operands: g3 (m, 3 ldp(n)) order 0, wt3 = split of W^T (k, 3 ldp(n)) order 1."""
+    if g3.shape[1] != wt3.shape[1]:
+        raise ValueError('linear_dgrad_x3: operand planes differ (%d vs %d columns)' % (g3.shape[1], wt3.shape[1]))
+    dx = linear_dgrad_bf16(g3, m, g3.shape[1], wt3, k, None, out_f32=True)
+    return dx if dx.shape[1] == k else dx[:, :k].contiguous()
+
+
+def linear_wgrad_x3(g3, a3, rows, m, n, k, out_w=None, out_b=None, accumulate=False):
+    """dW (n, k), db (n,) from split operands g3 (m, 3 ldp(n)) and a3 (R, 3 ldp(k)), both order 0 = [hi | hi | lo].  A weight
+    gradient contracts over the ROWS, so the three products are three accumulating launches on column planes of the two buffers:
+    hi^T hi (+ the bias sums of hi), hi^T lo, lo^T hi (+ the bias sums of lo)."""
+    lib = _lib.load()
+    ldn, ldk = g3.shape[1] // 3, a3.shape[1] // 3
+    if out_w is None:
+        both = torch.empty((n * k + n,), dtype=torch.float32, device=g3.device)
+        dw, db = both[:n * k].view(n, k), both[n * k:]
+    else:
+        dw, db = out_w, out_b
+    ws = workspace(lib.mg_linear_wgrad_workspace_bytes(m, n, k), g3.device)
+    esz = 2
+    plans = ((0, 0, True), (0, 2 * ldk, False), (2 * ldn, 0, True))       # (dY plane, A plane, with bias sums)
+    for idx, (goff, aoff, with_b) in enumerate(plans):
+        acc = int(bool(accumulate)) if idx == 0 else 1
+        _lib.check(lib.mg_linear_wgrad_bf16(ctypes.c_void_p(g3.data_ptr() + goff * esz), g3.shape[1],
+                                            ctypes.c_void_p(a3.data_ptr() + aoff * esz), a3.shape[1], _p(rows), m, n, k, _p(dw),
+                                            _p(db) if (with_b and db is not None) else None, acc, _p(ws), ws.numel(), _stream()),
+                   'mg_linear_wgrad_bf16')
+    return dw, db
+
+
 def f0_tail(h2, w3, b3, w4, b4, target, seq_len, b, t, grads_out, grad_scale=1.0):
     """Fused layers 3-4 + masked MSE, forward and backward (mg_f0_tail_bf16).  Returns (pred (b*t,), loss 0-d, dz2)."""
     lib = _lib.load()

@@ -301,7 +301,7 @@ class RecurrentCuDNNWrapper(nn.Module):
         """nn.LSTM with num_layers >= 1; hidden = (h0, c0), each (num_layers, B, H), returned in the same layout
         (utils.py:374-375, 388-389).  Several layers run as one time-skewed stack (functional.LSTMStackFn)."""
         layer = self.layer
-        precision = self.precision or F_hip.get_precision()
+        precision = F_hip.recurrent_precision(self.precision or F_hip.get_precision())
         h0s, c0s = (None, None) if hidden is None else hidden
         if layer.num_layers == 1:
             out, hn, cn = F_hip.LSTMFn.apply(precision, inputs.contiguous(), h0s, c0s, seq_len, *self._lstm_params())
@@ -324,7 +324,7 @@ class RecurrentCuDNNWrapper(nn.Module):
 
     def _run_gru(self, inputs, hidden, seq_len, layout=None):
         layer = self.layer
-        precision = self.precision or F_hip.get_precision()
+        precision = F_hip.recurrent_precision(self.precision or F_hip.get_precision())
         if isinstance(inputs, PhoneTable):
             seg, rows = inputs.maps()
             if layout is not None and (tuple(inputs.rows.shape) != (layout.b, layout.t) or not layout.worthwhile()):
@@ -522,6 +522,7 @@ class SequentialWithRecurrent(nn.Sequential):
         if hiddens is None:
             hiddens = [None] * len(modules)
         precision = self.precision or F_hip.get_precision()
+        rec_precision = F_hip.recurrent_precision(precision)      # 'bf16x3' splits the row-wise layers' operands; cells run exact fp32
         zero_padded = False          # input is (B, T, .) with exactly zero rows past seq_len (it came out of a recurrent wrapper)
 
         i = 0
@@ -601,7 +602,7 @@ class SequentialWithRecurrent(nn.Sequential):
                     for k in run:
                         params += modules[k]._gru_params()
                     sl = seq_len if seq_len.dtype == torch.int64 else seq_len.long()
-                    input, hn = F_hip.GRUStackSmallFn.apply(precision, input.contiguous(), sl.contiguous(), None, *params)
+                    input, hn = F_hip.GRUStackSmallFn.apply(rec_precision, input.contiguous(), sl.contiguous(), None, *params)
                     for pos, k in enumerate(run):
                         hiddens[k] = hn[pos:pos + 1]
                     zero_padded = True
@@ -611,7 +612,7 @@ class SequentialWithRecurrent(nn.Sequential):
             if isinstance(module, RecurrentCuDNNWrapper):
                 end, run = self._lstm_run(modules, i, hiddens, seq_len)
                 hid = modules[run[0]].layer.hidden_size if run else 0
-                if len(run) > 1 and F_hip.lstm_stack_persistent(precision, input.shape[0], input.shape[1], hid, len(run)):
+                if len(run) > 1 and F_hip.lstm_stack_persistent(rec_precision, input.shape[0], input.shape[1], hid, len(run)):
                     # consecutive single-layer LSTM wrappers (models/RNN_SPSS.py:36-37): the whole stack's forward is one
                     # persistent launch (a wavefront over layers and time)
                     params = []
@@ -623,13 +624,13 @@ class SequentialWithRecurrent(nn.Sequential):
                     zero_padded = True
                     i = end
                     continue
-                if len(run) > 1 and not F_hip.lstm_layerwise(precision, input.shape[0], input.shape[1], hid):
+                if len(run) > 1 and not F_hip.lstm_layerwise(rec_precision, input.shape[0], input.shape[1], hid):
                     # consecutive single-layer LSTM wrappers (models/RNN_SPSS.py:36-37): one time-skewed stack (per-step
                     # launches); with the persistent recurrence each wrapper is two launches and runs on its own below
                     params = []
                     for k in run:
                         params += modules[k]._lstm_params()
-                    input, hn, cn = F_hip.LSTMStackFn.apply(precision, F_hip.LSTM_STACK_LAG, input.contiguous(), seq_len, None,
+                    input, hn, cn = F_hip.LSTMStackFn.apply(rec_precision, F_hip.LSTM_STACK_LAG, input.contiguous(), seq_len, None,
                                                             None, *params)
                     for pos, k in enumerate(run):
                         hiddens[k] = (hn[pos:pos + 1], cn[pos:pos + 1])
@@ -642,7 +643,7 @@ class SequentialWithRecurrent(nn.Sequential):
                 zero_padded = seq_len is not None
             elif isinstance(module, nn.RNNBase):
                 # a bare recurrent layer in the container (utils.py:412-413): every item runs the full padded length
-                input, hiddens[i] = RecurrentCuDNNWrapper(module, precision=precision).run_full_length(input, hiddens[i])
+                input, hiddens[i] = RecurrentCuDNNWrapper(module, precision=rec_precision).run_full_length(input, hiddens[i])
                 zero_padded = False
             elif type(module) is nn.Sigmoid:
                 shape = input.shape

@@ -884,10 +884,12 @@ def _train(model, batches, n_steps, lr, weight_decay=0.0):
     return curve
 
 
-@pytest.mark.parametrize('fused', [True, False])
-def test_f0_model_fp32_golden_curve_and_grads(golden, fused):
+@pytest.mark.parametrize('fused,precision', [(True, 'fp32'), (False, 'fp32'), (True, 'bf16x3'), (False, 'bf16x3')])
+def test_f0_model_fp32_golden_curve_and_grads(golden, fused, precision):
+    """The reference's own 20-step run (G6) at the north star's 1e-4 - in fp32 mode (exact-fp32 MFMA) and in 'bf16x3' (split-bf16
+    operands: three bf16 MFMA products per fp32 product, csrc/split3.hip), the parity-grade mode at the bf16 matrix rate."""
     g = golden('g6_f0_model.npz')
-    model = _load_state(models.F0Model(precision='fp32', fused_upsample=fused).to(DEV), synthetic.f0_model_state())
+    model = _load_state(models.F0Model(precision=precision, fused_upsample=fused).to(DEV), synthetic.f0_model_state())
     batches = _c1_batches()
     loss, out = model(batches[0])
     loss.backward()
@@ -942,7 +944,7 @@ def test_f0_model_bf16_fused_and_unfused_agree_on_ragged_batch():
     assert rel_err(out[True][2], out[False][2]) < 3e-2
 
 
-@pytest.mark.parametrize('precision,tol', [('fp32', RTOL), ('bf16', RTOL_BF16)])
+@pytest.mark.parametrize('precision,tol', [('fp32', RTOL), ('bf16x3', RTOL), ('bf16', RTOL_BF16)])
 def test_f0_model_full_size_vs_oracle(precision, tol):
     """BASELINE config C2 (256 x 1000 frames) forward + backward against the numpy oracle."""
     feats = synthetic.make_batch(256, 1000)
@@ -954,14 +956,55 @@ def test_f0_model_full_size_vs_oracle(precision, tol):
     np.testing.assert_allclose(loss.item(), want_loss, rtol=tol)
     pred = out['pred_norm_lf0'].detach().cpu().numpy()
     assert pred.shape == want_pred.shape
-    if precision == 'fp32':
+    if precision in ('fp32', 'bf16x3'):
         assert rel_err(pred, want_pred) < 1e-4
     else:
         # The prediction is a cancelling sum of 32 O(0.1) terms built from bf16-rounded O(1) activations, so the bf16
         # mode is held to an ABSOLUTE 5e-3 (activation scale 1), not to a relative bound on the small result.
         assert np.abs(pred - want_pred).max() < 5e-3
     for name, prm in model.named_parameters():
-        assert rel_err(prm.grad.cpu().numpy(), want_grads[name]) < (1e-3 if precision == 'fp32' else 5e-2), name
+        assert rel_err(prm.grad.cpu().numpy(), want_grads[name]) < (1e-3 if precision in ('fp32', 'bf16x3') else 5e-2), name
+
+
+@pytest.mark.parametrize('phone_rate', [True, False])
+def test_bf16x3_orders_of_operations_agree_and_track_fp32(phone_rate):
+    """'bf16x3' at both orders of operations (F0Model(phone_rate=)) against fp32 mode on a batch the phone-rate form takes: loss and
+    prediction to 1e-4, every gradient to 1e-4 of its largest element - the bar of fp32 mode, three bf16 MFMA products per product."""
+    feats = data.to_device(synthetic.make_batch(32, 400, seed=12), DEV)
+    got = {}
+    for precision in ('fp32', 'bf16x3'):
+        model = _load_state(models.F0Model(precision=precision, phone_rate=phone_rate).to(DEV), synthetic.f0_model_state())
+        loss, out = model(feats)
+        loss.backward()
+        got[precision] = (loss.item(), out['pred_norm_lf0'].detach().cpu().numpy(),
+                          {n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters()})
+    np.testing.assert_allclose(got['bf16x3'][0], got['fp32'][0], rtol=RTOL)
+    assert rel_err(got['bf16x3'][1], got['fp32'][1]) < RTOL
+    for name in got['fp32'][2]:
+        assert rel_err(got['bf16x3'][2][name], got['fp32'][2][name]) < RTOL, name
+
+
+@pytest.mark.parametrize('rows,cols,lds_extra', [(37, 600, 0), (256, 128, 8), (5, 9, 3), (1024, 512, 0)])
+def test_split3_planes(rows, cols, lds_extra):
+    """mg_split3_bf16 (csrc/split3.hip): hi = bf16(x), lo = bf16(x - hi), planes [hi | hi | lo] (order 0) / [hi | lo | hi] (order 1),
+    zero padding, plain and transposed - bit-exact against the same arithmetic in torch - and hi + lo carries x to 2^-16."""
+    rng = np.random.RandomState(rows + cols)
+    full = dev((rng.standard_normal((rows, cols + lds_extra)) * np.exp(rng.uniform(-3, 3, (rows, 1)))).astype(np.float32))
+    x = full[:, :cols]                                               # a row stride larger than the width
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    assert float(((hi.float() + lo.float()) - x).abs().max() / x.abs().max()) < 2.0 ** -16
+    a3, w3, t3 = ops.split3([(x, 0, False), (x, 1, False), (x, 1, True)])
+    ldp = ops.pad_ld(cols)
+    assert tuple(a3.shape) == (rows, 3 * ldp) and tuple(t3.shape) == (cols, 3 * ops.pad_ld(rows))
+    for got, planes in ((a3, (hi, hi, lo)), (w3, (hi, lo, hi))):
+        for q, want in enumerate(planes):
+            assert torch.equal(got[:, q * ldp:q * ldp + cols], want), q
+            assert not bool(got[:, q * ldp + cols:(q + 1) * ldp].any())
+    ldt = ops.pad_ld(rows)
+    for q, want in enumerate((hi, lo, hi)):
+        assert torch.equal(t3[:, q * ldt:q * ldt + rows], want.t())
+        assert not bool(t3[:, q * ldt + rows:(q + 1) * ldt].any())
 
 
 @pytest.mark.parametrize('tag', ['h8', 'h32'])
