@@ -517,6 +517,35 @@ def _timed_steps(step, steps):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+def sustained_mfma_tflops(dev, launches=4, trips=20000):
+    """The bf16 MFMA rate this chip sustains on RANDOM operands when nothing but its matrix pipe works (mg_calib_mfma_bf16: register
+    operands, two waves per SIMD on every CU, no LDS or memory traffic in the loop) - about 20 ms of launches timed with HIP events
+    on the launch stream, right after the frame-rate leg so that the chip is in the state the step was timed in.  The guide's
+    2.5 PFLOP/s dense peak assumes 2.4 GHz; under its power limit the chip holds less on real data (MI355X_MICROARCH.md, DVFS
+    give-back), and the step's fraction of THAT rate is what separates "the kernels leave matrix cycles unused" from "the chip gives
+    fewer cycles" (VERDICT round 3, item 1c)."""
+    import ctypes
+    lib = _lib.load()
+    n_wg = torch.cuda.get_device_properties(dev).multi_processor_count
+    operands = (torch.rand(4096 * 64, device=dev) * 2.0 - 1.0).to(torch.bfloat16)
+    sink = torch.empty(n_wg * 512, dtype=torch.float32, device=dev)
+    flop = ctypes.c_double(0.0)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def launch():
+        _lib.check(lib.mg_calib_mfma_bf16(ctypes.c_void_p(operands.data_ptr()), ctypes.c_void_p(sink.data_ptr()), n_wg, trips,
+                                          ctypes.byref(flop), stream), 'mg_calib_mfma_bf16')
+    launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        launch()
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1)
+    return launches * flop.value / (ms * 1e-3) / 1e12, ms, n_wg
+
+
 def bf16x3_legs(dev, features, state_dict, steps, frames_per_step):
     """Precision mode 'bf16x3' (split-bf16 operands: three bf16 MFMA products per fp32 product, fp32 activations - the mode that
     meets the reference's loss curve to 1e-4, `loss_curve_deviation.bf16x3`) timed on the C2 batch in the same run as the bf16
@@ -932,8 +961,17 @@ def main():
             fr_ms = (time.perf_counter() - t1) / args.steps * 1e3
             gc.enable()
             fr_tflops = F0_FLOPS_PER_FRAME * frames_per_step / (fr_ms * 1e-3) / 1e12
+            try:
+                sustained, calib_ms, calib_wgs = sustained_mfma_tflops(dev)
+                calibration = {'sustained_bf16_mfma_tflops': round(sustained, 1), 'frac_of_mfma_peak': round(sustained / MFMA_BF16_PEAK_TFLOPS, 4),
+                               'what': 'mg_calib_mfma_bf16 right after the frame-rate leg: register-operand v_mfma_f32_16x16x32_bf16 loop on '
+                                       'random operands, %d workgroups x 8 waves, %.1f ms of launches under HIP events - the matrix rate THIS '
+                                       'chip holds under its power limit (the 2.5 PFLOP/s peak assumes 2.4 GHz)' % (calib_wgs, calib_ms)}
+            except Exception as exc:                                        # noqa: BLE001 - calibration only
+                sustained, calibration = None, {'error': str(exc).splitlines()[0][:200]}
             frame_rate = {'ms_per_step': round(fr_ms, 4), 'value': round(frames_per_step / (fr_ms * 1e-3), 1), 'unit': 'frames/s',
                           'tflops': round(fr_tflops, 1), 'frac_of_mfma_peak': round(fr_tflops / MFMA_BF16_PEAK_TFLOPS, 4),
+                          'frac_of_sustained': (round(fr_tflops / sustained, 4) if sustained else None), 'calibration': calibration,
                           'what': 'F0Model(phone_rate=False): the reference\'s order of operations - every product on the B*T frame rows '
                                   '(gather-fused layer-1 GEMM, fused dgrad+wgrad), same graph replay; tflops = the algorithmic '
                                   '%.1f GFLOP per step (SURVEY.md section 8d) over this time: an ACHIEVED rate, the matrix cores '

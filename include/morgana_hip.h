@@ -409,7 +409,9 @@ int mg_cast_params_bf16(const mg_cast_desc* descs, int count, void* stream);
  * (morgana/experiment_builder.py:262-263: no autocast, morgana/data.py:127: float32 features); this mode reproduces them to ~1e-5
  * at three bf16 MFMA products each.  For each descriptor: dst bf16 [rows, 3 ldp] = three planes of ldp columns (zero padded):
  * order 0 -> [hi | hi | lo] (the activation side of a product), order 1 -> [hi | lo | hi] (the weight side); transpose != 0 -> the
- * planes hold the split of src^T: dst [cols, 3 ldp] with ldp >= rows.  `descs` is a HOST array, count <= MG_SPLIT3_MAX. */
+ * planes hold the split of src^T: dst [cols, 3 ldp] with ldp >= rows.  order 2 (not transposed) -> dst bf16 [2, rows, ldp]: the hi
+ * plane, then the lo plane, each a matrix of its own (the operands of a weight gradient, which contracts over the rows: three
+ * accumulating launches of mg_linear_wgrad_bf16 on plane pairs).  `descs` is a HOST array, count <= MG_SPLIT3_MAX. */
 #define MG_SPLIT3_MAX 16
 typedef struct {
     const float* src; /* device, fp32 [rows, cols], row stride lds */
@@ -417,10 +419,16 @@ typedef struct {
     int cols, lds;
     uint16_t* dst;    /* device, bf16, 16-byte aligned: [rows, 3 ldp], or [cols, 3 ldp] when transposed */
     int ldp;          /* columns per plane: multiple of 8, >= cols (>= rows when transposed) */
-    int order;        /* 0: hi | hi | lo;  1: hi | lo | hi */
+    int order;        /* 0: hi | hi | lo;  1: hi | lo | hi;  2: two planes [hi ; lo] of [rows, ldp] */
     int transpose;
 } mg_split3_desc;
 int mg_split3_bf16(const mg_split3_desc* descs, int count, void* stream);
+/* CALIBRATION (a measurement entry; no training step calls it): one launch of a register-operand bf16 MFMA loop - n_workgroups x 512
+ * threads (two waves per SIMD), every wave issues 16 x trips v_mfma_f32_16x16x32_bf16 on operands read once from `operands`
+ * (bf16, at least 4096 x 64 values: the caller chooses the data, e.g. random) and writes one float per thread to `sink`
+ * (n_workgroups x 512 floats).  *flop (host, optional) receives the launch's FLOP count; the caller times it with events.
+ * Used by bench.py for `frac_of_sustained`: what the matrix pipe of THIS chip holds under its power limit. */
+int mg_calib_mfma_bf16(const uint16_t* operands, float* sink, int n_workgroups, int trips, double* flop, void* stream);
 /* dst f32 [rows, cols] = src bf16 [rows, cols] (lds). */
 int mg_cast_bf16_f32(const uint16_t* src, int lds, float* dst, int ldd, int64_t rows, int cols, void* stream);
 /* elementwise sigmoid forward / backward for a stand-alone nn.Sigmoid. */

@@ -12,7 +12,9 @@
 // side), `order` 1 the right one (weight side); each of the three planes is padded with zeros to `ldp` columns (a multiple of 8,
 // 64 for the wide tile programs), which both sides share, so padding multiplies padding.  With `transpose` the planes hold the
 // split of src^T (the dgrad operand W^T without a transposed fp32 copy).  Weight gradients contract over the ROWS: they take the
-// planes one pair at a time (column slices of these buffers, three accumulating launches; ops.linear_wgrad_x3).
+// planes one pair at a time, three accumulating launches (ops.linear_wgrad_x3) - from `order` 2, two SEPARATE planes [hi ; lo], each
+// [rows, ldp] with its own zero padding (the weight-gradient tile programs read a row up to its leading dimension: a plane cut out of
+// a three-plane row would hand them its neighbours as padding).
 #include "common.h"
 
 #define MG_SPLIT3_MAX_ 16
@@ -59,10 +61,16 @@ __global__ __launch_bounds__(256) void split3_kernel(Split3Batch batch) {
                               (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16)};
             };
             const su32x4 ph = pack(hi), pl = pack(lo);
-            uint16_t* dst = d.dst + (size_t)r * (3 * (size_t)d.ldp) + c0;
-            *reinterpret_cast<su32x4*>(dst) = ph;
-            *reinterpret_cast<su32x4*>(dst + d.ldp) = second ? pl : ph;
-            *reinterpret_cast<su32x4*>(dst + 2 * (size_t)d.ldp) = second ? ph : pl;
+            if (d.order == 2) {
+                uint16_t* dst = d.dst + (size_t)r * d.ldp + c0;
+                *reinterpret_cast<su32x4*>(dst) = ph;
+                *reinterpret_cast<su32x4*>(dst + (size_t)d.rows * d.ldp) = pl;
+            } else {
+                uint16_t* dst = d.dst + (size_t)r * (3 * (size_t)d.ldp) + c0;
+                *reinterpret_cast<su32x4*>(dst) = ph;
+                *reinterpret_cast<su32x4*>(dst + d.ldp) = second ? pl : ph;
+                *reinterpret_cast<su32x4*>(dst + 2 * (size_t)d.ldp) = second ? ph : pl;
+            }
         }
     } else {
         // dst [cols, 3 ldp]: row c of dst = column c of src; plane columns r < rows hold values, rows <= r < ldp zeros
@@ -103,7 +111,8 @@ int mg_split3_bf16(const mg_split3_desc* descs, int count, void* stream) {
     for (int i = 0; i < count; ++i) {
         const mg_split3_desc& d = descs[i];
         MG_CHECK_ARG(d.src && d.dst && d.rows > 0 && d.cols > 0 && d.lds >= d.cols, "mg_split3_bf16: bad descriptor %d", i);
-        MG_CHECK_ARG(d.order == 0 || d.order == 1, "mg_split3_bf16: descriptor %d: order %d is neither 0 (hi|hi|lo) nor 1 (hi|lo|hi)", i, d.order);
+        MG_CHECK_ARG(d.order == 0 || d.order == 1 || (d.order == 2 && !d.transpose),
+                     "mg_split3_bf16: descriptor %d: order %d is none of 0 (hi|hi|lo), 1 (hi|lo|hi), 2 (separate planes hi ; lo, not transposed)", i, d.order);
         MG_CHECK_ARG(d.ldp % 8 == 0 && ((size_t)d.dst & 15) == 0, "mg_split3_bf16: descriptor %d: ldp %d must be a multiple of 8 and dst 16-byte aligned", i, d.ldp);
         if (d.transpose)
             MG_CHECK_ARG(d.ldp >= d.rows && d.rows < 2147483647LL, "mg_split3_bf16: descriptor %d: transposed planes of %d columns cannot hold %lld rows", i, d.ldp, (long long)d.rows);

@@ -264,11 +264,13 @@ class LinearStackFn(torch.autograd.Function):
             for i in range(n_layers - 1, -1, -1):
                 n, k = ctx.dims[i]
                 a_in, r = (x_in, rows) if i == 0 else (hidden[i - 1], None)
-                g3, a3 = ops.split3([(g, 0, False), (a_in, 0, False)])
+                need_g3 = i > 0 or need_x
+                parts = ops.split3([(g, 2, False), (a_in, 2, False)] + ([(g, 0, False)] if need_g3 else []))
+                g2, a2, g3 = parts[0], parts[1], (parts[2] if need_g3 else None)
                 if direct:
-                    ops.linear_wgrad_x3(g3, a3, r, m, n, k, out_w=w_params[i].grad, out_b=b_params[i].grad, accumulate=True)
+                    ops.linear_wgrad_x3(g2, a2, r, m, n, k, out_w=w_params[i].grad, out_b=b_params[i].grad, accumulate=True)
                 else:
-                    dw, db = ops.linear_wgrad_x3(g3, a3, r, m, n, k)
+                    dw, db = ops.linear_wgrad_x3(g2, a2, r, m, n, k)
                     grads[2 * i], grads[2 * i + 1] = dw, (db if ctx.has_bias[i] else None)
                 if i > 0:
                     g = ops.linear_dgrad_x3(g3, m, wt3s[i], k)

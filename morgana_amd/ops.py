@@ -699,8 +699,9 @@ def begin_capture_epoch():
 
 def split3(jobs):
     """Operand splits of precision mode 'bf16x3' (csrc/split3.hip): ``jobs`` = [(fp32 2-D tensor, order, transpose)] with order 0 =
-    [hi | hi | lo] (activation side), 1 = [hi | lo | hi] (weight side); one batched launch per MG_SPLIT3_MAX jobs.  Returns one bf16
-    tensor (rows, 3 ldp) per job - (cols, 3 ldp) with ``transpose`` - where ldp = pad_ld(columns of a plane)."""
+    [hi | hi | lo] (activation side), 1 = [hi | lo | hi] (weight side), 2 = two separate planes; one batched launch per MG_SPLIT3_MAX
+    jobs.  Returns one bf16 tensor per job: (rows, 3 ldp) - (cols, 3 ldp) with ``transpose`` - or (2, rows, ldp) for order 2, where
+    ldp = pad_ld(columns of a plane)."""
     lib = _lib.load()
     outs = []
     for i in range(0, len(jobs), _lib.SPLIT3_MAX):
@@ -711,7 +712,8 @@ def split3(jobs):
                 raise TypeError('split3: operands must be 2-D float32 with unit column stride')
             rows, cols = x.shape
             ldp = pad_ld(rows if transpose else cols)
-            out = torch.empty((cols if transpose else rows, 3 * ldp), dtype=torch.bfloat16, device=x.device)
+            out = torch.empty((2, rows, ldp) if order == 2 else (cols if transpose else rows, 3 * ldp), dtype=torch.bfloat16,
+                              device=x.device)
             descs[j].src, descs[j].rows, descs[j].cols, descs[j].lds = x.data_ptr(), rows, cols, x.stride(0)
             descs[j].dst, descs[j].ldp, descs[j].order, descs[j].transpose = out.data_ptr(), ldp, int(order), int(bool(transpose))
             outs.append(out)
@@ -761,24 +763,21 @@ def linear_dgrad_x3(g3, m, wt3, k):
     return dx if dx.shape[1] == k else dx[:, :k].contiguous()
 
 
-def linear_wgrad_x3(g3, a3, rows, m, n, k, out_w=None, out_b=None, accumulate=False):
-    """dW (n, k), db (n,) from split operands g3 (m, 3 ldp(n)) and a3 (R, 3 ldp(k)), both order 0 = [hi | hi | lo].  A weight
-    gradient contracts over the ROWS, so the three products are three accumulating launches on column planes of the two buffers:
-    hi^T hi (+ the bias sums of hi), hi^T lo, lo^T hi (+ the bias sums of lo)."""
+def linear_wgrad_x3(g2, a2, rows, m, n, k, out_w=None, out_b=None, accumulate=False):
+    """dW (n, k), db (n,) from split operands in separate planes (split3 order 2): g2 (2, m, ldp(n)), a2 (2, R, ldp(k)).  A weight
+    gradient contracts over the ROWS, so the three products are three accumulating launches on plane pairs: hi^T hi (+ the bias
+    sums of hi), hi^T lo, lo^T hi (+ the bias sums of lo)."""
     lib = _lib.load()
-    ldn, ldk = g3.shape[1] // 3, a3.shape[1] // 3
     if out_w is None:
-        both = torch.empty((n * k + n,), dtype=torch.float32, device=g3.device)
+        both = torch.empty((n * k + n,), dtype=torch.float32, device=g2.device)
         dw, db = both[:n * k].view(n, k), both[n * k:]
     else:
         dw, db = out_w, out_b
-    ws = workspace(lib.mg_linear_wgrad_workspace_bytes(m, n, k), g3.device)
-    esz = 2
-    plans = ((0, 0, True), (0, 2 * ldk, False), (2 * ldn, 0, True))       # (dY plane, A plane, with bias sums)
-    for idx, (goff, aoff, with_b) in enumerate(plans):
+    ws = workspace(lib.mg_linear_wgrad_workspace_bytes(m, n, k), g2.device)
+    plans = ((0, 0, True), (0, 1, False), (1, 0, True))                   # (dY plane, A plane, with bias sums)
+    for idx, (gp, ap, with_b) in enumerate(plans):
         acc = int(bool(accumulate)) if idx == 0 else 1
-        _lib.check(lib.mg_linear_wgrad_bf16(ctypes.c_void_p(g3.data_ptr() + goff * esz), g3.shape[1],
-                                            ctypes.c_void_p(a3.data_ptr() + aoff * esz), a3.shape[1], _p(rows), m, n, k, _p(dw),
+        _lib.check(lib.mg_linear_wgrad_bf16(_p(g2[gp]), g2.shape[2], _p(a2[ap]), a2.shape[2], _p(rows), m, n, k, _p(dw),
                                             _p(db) if (with_b and db is not None) else None, acc, _p(ws), ws.numel(), _stream()),
                    'mg_linear_wgrad_bf16')
     return dw, db

@@ -1001,6 +1001,9 @@ def test_split3_planes(rows, cols, lds_extra):
         for q, want in enumerate(planes):
             assert torch.equal(got[:, q * ldp:q * ldp + cols], want), q
             assert not bool(got[:, q * ldp + cols:(q + 1) * ldp].any())
+    p2 = ops.split3([(x, 2, False)])[0]
+    assert tuple(p2.shape) == (2, rows, ldp)
+    assert torch.equal(p2[0, :, :cols], hi) and torch.equal(p2[1, :, :cols], lo) and not bool(p2[:, :, cols:].any())
     ldt = ops.pad_ld(rows)
     for q, want in enumerate((hi, lo, hi)):
         assert torch.equal(t3[:, q * ldt:q * ldt + rows], want.t())
