@@ -118,6 +118,14 @@ def _direct_params(*params):
                 p.grad.is_contiguous() and p.grad.dtype == torch.float32 and not _has_hooks(p) for p in params))
 
 
+def _x3_layer(w):
+    """Does a Linear layer of this weight run on split-bf16 operands in 'bf16x3' mode?  The wide layers do (that is where the
+    products are); a narrow one - fewer than 16,384 weights: the README stack's 128 -> 32 and 32 -> 1 - runs the exact-fp32 tile
+    programs of fp32 mode instead: its cost is nothing, and its output is a cancelling sum of a few O(0.1) terms, where the 2^-17
+    of a split operand is a visible fraction of the result (C2 prediction vs the oracle: 1.6e-4 split, 2e-5 exact)."""
+    return w.shape[0] * w.shape[1] >= 16384
+
+
 def _has_hooks(p):
     return bool(getattr(p, '_backward_hooks', None)) or bool(getattr(p, '_post_accumulate_grad_hooks', None))
 
@@ -195,10 +203,14 @@ class LinearStackFn(torch.autograd.Function):
             if extra:
                 x2d = torch.cat((x2d, x2d.new_zeros((extra, x2d.shape[1]))))
             a, r = x2d, rows
-            w3s = ops.x3_weight_operands(weights)[0]
+            split = [_x3_layer(w) for w in weights]
+            w3s = ops.x3_weight_operands([w for w, s in zip(weights, split) if s])[0]
             for i in range(n_layers):
-                a3 = ops.split3([(a, 0, False)])[0]
-                a = ops.linear_fwd_x3(a3, r, m, w3s[i], biases[i], weights[i].shape[0], acts[i])
+                if split[i]:
+                    a3 = ops.split3([(a, 0, False)])[0]
+                    a = ops.linear_fwd_x3(a3, r, m, w3s.pop(0), biases[i], weights[i].shape[0], acts[i])
+                else:
+                    a = ops.linear_fwd_f32(a, r, m, ops._require(weights[i], torch.float32, 'weight'), biases[i], acts[i])
                 r = None
                 hidden.append(a)
             out = a
@@ -260,10 +272,20 @@ class LinearStackFn(torch.autograd.Function):
         elif precision == 'bf16x3':
             w_params, b_params = ctx.param_refs
             direct = all(ctx.has_bias) and _direct_params(*w_params, *b_params)
-            wt3s = ops.x3_weight_operands(w_params, want_t=tuple(range(1 if not need_x else 0, n_layers)))[1]
+            split = [_x3_layer(w) for w in w_params]
+            dgrad_of = [i for i in range(n_layers) if split[i] and (i > 0 or need_x)]
+            wt3_list = ops.x3_weight_operands([w_params[i] for i in dgrad_of], want_t=tuple(range(len(dgrad_of))))[1]
+            wt3s = dict(zip(dgrad_of, wt3_list))
             for i in range(n_layers - 1, -1, -1):
                 n, k = ctx.dims[i]
                 a_in, r = (x_in, rows) if i == 0 else (hidden[i - 1], None)
+                if not split[i]:                       # a narrow layer: exact fp32 products (see _x3_layer)
+                    grads[2 * i], grads[2 * i + 1] = ops.linear_wgrad_f32(g, a_in, r, n, k, want_bias=ctx.has_bias[i])
+                    if i > 0:
+                        g = ops.linear_dgrad_f32(g, weights[i], hidden[i - 1] if acts[i - 1] == ops.ACT_SIGMOID else None)
+                    elif need_x:
+                        grad_x = ops.linear_dgrad_f32(g, weights[0], None)
+                    continue
                 need_g3 = i > 0 or need_x
                 parts = ops.split3([(g, 2, False), (a_in, 2, False)] + ([(g, 0, False)] if need_g3 else []))
                 g2, a2, g3 = parts[0], parts[1], (parts[2] if need_g3 else None)
