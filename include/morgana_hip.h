@@ -53,7 +53,8 @@ const char* mg_last_error(void);
                                  * 16 = its fragments read one k-step ahead;
                                  * fused backward: 12 = tiles two steps ahead (larger ring), 13 = 32-frame steps, 7 = single-buffered */
 #define MG_TUNE_GRU_HANDOFF 2   /* persistent GRU / LSTM kernels: 0 = groups found on one XCD hand the state over through that XCD's L2,
-                                 * 1 = always write-through (sc1) stores, the placement-independent form */
+                                 * bit 0 (1) = always write-through (sc1) stores, the placement-independent form; bit 1 (2) = group
+                                 * membership from the block index (block % 8) instead of a ticket of the XCD a workgroup runs on */
 #define MG_TUNE_PERSISTENT 3    /* recurrences: 0 = persistent kernels where the shape has them, 1 = one launch per time step,
                                  * 2 = H = 64 on the 16-row tile instead of the 4x4x1 blocks */
 #define MG_TUNE_WGRAD_SPLITS 4  /* wide weight-gradient kernel: != 0 overrides the planned number of split-M slabs (a multiple of 8);
@@ -419,8 +420,9 @@ typedef struct {
     int cols, lds;
     uint16_t* dst;    /* device, bf16, 16-byte aligned: [rows, 3 ldp], or [cols, 3 ldp] when transposed */
     int ldp;          /* columns per plane: multiple of 8, >= cols (>= rows when transposed) */
-    int order;        /* 0: hi | hi | lo;  1: hi | lo | hi;  2: two planes [hi ; lo] of [rows, ldp] */
+    int order;        /* 0: hi | hi | lo;  1: hi | lo | hi;  2: two planes [hi ; lo] of [plane_rows, ldp] */
     int transpose;
+    int64_t plane_rows; /* order 2: rows of one plane in dst (>= rows; the caller owns the rows behind the split, e.g. zeros); 0 = rows */
 } mg_split3_desc;
 int mg_split3_bf16(const mg_split3_desc* descs, int count, void* stream);
 /* CALIBRATION (a measurement entry; no training step calls it): one launch of a register-operand bf16 MFMA loop - n_workgroups x 512

@@ -208,7 +208,7 @@ class CastDesc(ctypes.Structure):
 class Split3Desc(ctypes.Structure):
     """mg_split3_desc of include/morgana_hip.h."""
     _fields_ = [('src', c_void_p), ('rows', c_int64), ('cols', c_int), ('lds', c_int), ('dst', c_void_p), ('ldp', c_int),
-                ('order', c_int), ('transpose', c_int)]
+                ('order', c_int), ('transpose', c_int), ('plane_rows', c_int64)]
 
 
 class StreamDesc(ctypes.Structure):

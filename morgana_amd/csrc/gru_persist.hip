@@ -42,8 +42,11 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
     __shared__ int s_abort, s_xcd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
-    const int group = blockIdx.x % GP_GROUPS, slot = blockIdx.x / GP_GROUPS;
     const int n_slots = H / GT;
+    // which (group, slot) this workgroup serves: a ticket of the XCD it finds itself on (persist_common.h), not its block index
+    const int claim = gp_claim_slot((gu32*)sync + GP_TICKET_OFFSET, n_slots, tid, &s_xcd, force_sc1 & 2);
+    if (claim < 0) return;
+    const int group = claim / GP_SLOTS, slot = claim % GP_SLOTS;
     const int row0 = group * R;
     const int nrows = min(R, B - row0);
     if (slot >= n_slots || nrows <= 0) return;
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
     gu32* flags = (gu32*)sync + group * GP_SLOTS;
     gu32* status = (gu32*)sync + GP_FLAG_WORDS;
     if (tid == 0) s_abort = 0;
-    const int one_xcd = force_sc1 ? 0 : gp_group_on_one_xcd((gu32*)sync + GP_GROUPS * GP_SLOTS + group * GP_SLOTS, slot, n_slots, tid, &s_xcd);
+    const int one_xcd = (force_sc1 & 1) ? 0 : gp_group_on_one_xcd((gu32*)sync + GP_GROUPS * GP_SLOTS + group * GP_SLOTS, slot, n_slots, tid, &s_xcd);
     if (one_xcd < 0) {
         if (tid == 0) __hip_atomic_store(status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
@@ -315,8 +318,11 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
     __shared__ int s_abort, s_xcd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
-    const int group = blockIdx.x % GP_GROUPS, slot = blockIdx.x / GP_GROUPS;
     const int n_slots = H / GT;
+    // which (group, slot) this workgroup serves: a ticket of the XCD it finds itself on (persist_common.h), not its block index
+    const int claim = gp_claim_slot((gu32*)sync + GP_TICKET_OFFSET, n_slots, tid, &s_xcd, force_sc1 & 2);
+    if (claim < 0) return;
+    const int group = claim / GP_SLOTS, slot = claim % GP_SLOTS;
     const int row0 = group * R;
     const int nrows = min(R, B - row0);
     if (slot >= n_slots || nrows <= 0) return;
@@ -325,7 +331,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
     gu32* flags = (gu32*)sync + group * GP_SLOTS;
     gu32* status = (gu32*)sync + GP_FLAG_WORDS;
     if (tid == 0) s_abort = 0;
-    const int one_xcd = force_sc1 ? 0 : gp_group_on_one_xcd((gu32*)sync + GP_GROUPS * GP_SLOTS + group * GP_SLOTS, slot, n_slots, tid, &s_xcd);
+    const int one_xcd = (force_sc1 & 1) ? 0 : gp_group_on_one_xcd((gu32*)sync + GP_GROUPS * GP_SLOTS + group * GP_SLOTS, slot, n_slots, tid, &s_xcd);
     if (one_xcd < 0) {
         if (tid == 0) __hip_atomic_store(status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
@@ -595,8 +601,11 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_f32_kernel(const float* _
     __shared__ int s_abort, s_xcd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
-    const int group = blockIdx.x % GP_GROUPS, slot = blockIdx.x / GP_GROUPS;
     const int n_slots = H / GT;
+    // which (group, slot) this workgroup serves: a ticket of the XCD it finds itself on (persist_common.h), not its block index
+    const int claim = gp_claim_slot((gu32*)sync + GP_TICKET_OFFSET, n_slots, tid, &s_xcd, force_sc1 & 2);
+    if (claim < 0) return;
+    const int group = claim / GP_SLOTS, slot = claim % GP_SLOTS;
     const int row0 = group * R;
     const int nrows = min(R, B - row0);
     if (slot >= n_slots || nrows <= 0) return;
@@ -604,7 +613,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_f32_kernel(const float* _
     gu32* flags = (gu32*)sync + group * GP_SLOTS;
     gu32* status = (gu32*)sync + GP_FLAG_WORDS;
     if (tid == 0) s_abort = 0;
-    const int one_xcd = force_sc1 ? 0 : gp_group_on_one_xcd((gu32*)sync + GP_GROUPS * GP_SLOTS + group * GP_SLOTS, slot, n_slots, tid, &s_xcd);
+    const int one_xcd = (force_sc1 & 1) ? 0 : gp_group_on_one_xcd((gu32*)sync + GP_GROUPS * GP_SLOTS + group * GP_SLOTS, slot, n_slots, tid, &s_xcd);
     if (one_xcd < 0) {
         if (tid == 0) __hip_atomic_store(status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
@@ -766,8 +775,11 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_f32_kernel(const float* _
     __shared__ int s_abort, s_xcd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
-    const int group = blockIdx.x % GP_GROUPS, slot = blockIdx.x / GP_GROUPS;
     const int n_slots = H / GT;
+    // which (group, slot) this workgroup serves: a ticket of the XCD it finds itself on (persist_common.h), not its block index
+    const int claim = gp_claim_slot((gu32*)sync + GP_TICKET_OFFSET, n_slots, tid, &s_xcd, force_sc1 & 2);
+    if (claim < 0) return;
+    const int group = claim / GP_SLOTS, slot = claim % GP_SLOTS;
     const int row0 = group * R;
     const int nrows = min(R, B - row0);
     if (slot >= n_slots || nrows <= 0) return;
@@ -776,7 +788,7 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_f32_kernel(const float* _
     gu32* flags = (gu32*)sync + group * GP_SLOTS;
     gu32* status = (gu32*)sync + GP_FLAG_WORDS;
     if (tid == 0) s_abort = 0;
-    const int one_xcd = force_sc1 ? 0 : gp_group_on_one_xcd((gu32*)sync + GP_GROUPS * GP_SLOTS + group * GP_SLOTS, slot, n_slots, tid, &s_xcd);
+    const int one_xcd = (force_sc1 & 1) ? 0 : gp_group_on_one_xcd((gu32*)sync + GP_GROUPS * GP_SLOTS + group * GP_SLOTS, slot, n_slots, tid, &s_xcd);
     if (one_xcd < 0) {
         if (tid == 0) __hip_atomic_store(status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
@@ -976,7 +988,7 @@ int mg_gru_fwd_persist_rows_bf16(const float* xproj, const int32_t* xrows, int64
     const unsigned grid = (unsigned)(GP_GROUPS * (H / GT));
 #define GP_FWD(MT, KS)                                                                                                                  \
     hipLaunchKernelGGL((gru_fwd_persist_kernel<MT, KS>), dim3(grid), dim3(256), 0, st, xproj, w_hh_bf, ldw, b_hh, seq_len, B, T, H, R, hstate, \
-                       hstate_bf, out, saved, (unsigned*)workspace, (uint16_t*)((char*)workspace + GP_RING_OFFSET), g_mg_tuning[MG_TUNE_GRU_HANDOFF] == 1, xrows)
+                       hstate_bf, out, saved, (unsigned*)workspace, (uint16_t*)((char*)workspace + GP_RING_OFFSET), g_mg_tuning[MG_TUNE_GRU_HANDOFF], xrows)
 #define GP_FWD_KS(MT)            \
     switch (H / 128) {           \
         case 1: GP_FWD(MT, 1); break; \
@@ -1017,7 +1029,7 @@ int mg_gru_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const f
 #define GP_BWD(MT, KS)                                                                                                                      \
     hipLaunchKernelGGL((gru_bwd_persist_kernel<MT, KS>), dim3(grid), dim3(256), 0, st, grad_out, grad_hn, hstate, saved, w_hh_t_bf, ldt, seq_len, \
                        B, T, H, R, dxproj, dhproj, dhproj_bf, dxproj_bf, dh0, (unsigned*)workspace, (uint16_t*)((char*)workspace + GP_RING_OFFSET),           \
-                       g_mg_tuning[MG_TUNE_GRU_HANDOFF] == 1)
+                       g_mg_tuning[MG_TUNE_GRU_HANDOFF])
 #define GP_BWD_KS(MT)                  \
     switch (H / 128) {                 \
         case 1: GP_BWD(MT, 3); break;  \
@@ -1058,7 +1070,7 @@ int mg_gru_fwd_persist_f32(const float* xproj, const float* w_hh, const float* b
     const int R = (int)mg_ceil_div(B, GP_GROUPS);
     const unsigned grid = (unsigned)(GP_GROUPS * (H / GT));
     float* ring = (float*)((char*)workspace + GP_RING_OFFSET);
-    const int force = g_mg_tuning[MG_TUNE_GRU_HANDOFF] == 1;
+    const int force = g_mg_tuning[MG_TUNE_GRU_HANDOFF];
 #define GPF_FWD(KS) hipLaunchKernelGGL((gru_fwd_persist_f32_kernel<KS>), dim3(grid), dim3(256), 0, st, xproj, w_hh, b_hh, seq_len, B, T, H, R, hstate, out, saved, (unsigned*)workspace, ring, force)
     switch (H / 64) {
         case 4: GPF_FWD(4); break;
@@ -1089,7 +1101,7 @@ int mg_gru_bwd_persist_f32(const float* grad_out, const float* grad_hn, const fl
     const int R = (int)mg_ceil_div(B, GP_GROUPS);
     const unsigned grid = (unsigned)(GP_GROUPS * (H / GT));
     float* ring = (float*)((char*)workspace + GP_RING_OFFSET);
-    const int force = g_mg_tuning[MG_TUNE_GRU_HANDOFF] == 1;
+    const int force = g_mg_tuning[MG_TUNE_GRU_HANDOFF];
 #define GPF_BWD(KS) hipLaunchKernelGGL((gru_bwd_persist_f32_kernel<KS>), dim3(grid), dim3(256), 0, st, grad_out, grad_hn, hstate, saved, w_hh, seq_len, B, T, H, R, dxproj, dhproj, dh0, (unsigned*)workspace, ring, force)
     switch (H / 64) {
         case 4: GPF_BWD(12); break;

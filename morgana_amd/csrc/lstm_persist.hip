@@ -24,8 +24,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(const float* __re
     __shared__ int s_abort, s_xcd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
-    const int group = blockIdx.x % GP_GROUPS, slot = blockIdx.x / GP_GROUPS;
     const int n_slots = H / GT;
+    // which (group, slot) this workgroup serves: a ticket of the XCD it finds itself on (persist_common.h), not its block index
+    const int claim = gp_claim_slot((gu32*)sync + GP_TICKET_OFFSET, n_slots, tid, &s_xcd, force_sc1 & 2);
+    if (claim < 0) return;
+    const int group = claim / GP_SLOTS, slot = claim % GP_SLOTS;
     const int row0 = group * R;
     const int nrows = min(R, B - row0);
     if (slot >= n_slots || nrows <= 0) return;
@@ -33,7 +36,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_kernel(const float* __re
     gu32* flags = (gu32*)sync + group * GP_SLOTS;
     gu32* status = (gu32*)sync + GP_FLAG_WORDS;
     if (tid == 0) s_abort = 0;
-    const int one_xcd = force_sc1 ? 0 : gp_group_on_one_xcd((gu32*)sync + GP_GROUPS * GP_SLOTS + group * GP_SLOTS, slot, n_slots, tid, &s_xcd);
+    const int one_xcd = (force_sc1 & 1) ? 0 : gp_group_on_one_xcd((gu32*)sync + GP_GROUPS * GP_SLOTS + group * GP_SLOTS, slot, n_slots, tid, &s_xcd);
     if (one_xcd < 0) {
         if (tid == 0) __hip_atomic_store(status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
@@ -237,8 +240,11 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(const float* __re
     __shared__ int s_abort, s_xcd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
-    const int group = blockIdx.x % GP_GROUPS, slot = blockIdx.x / GP_GROUPS;
     const int n_slots = H / GT;
+    // which (group, slot) this workgroup serves: a ticket of the XCD it finds itself on (persist_common.h), not its block index
+    const int claim = gp_claim_slot((gu32*)sync + GP_TICKET_OFFSET, n_slots, tid, &s_xcd, force_sc1 & 2);
+    if (claim < 0) return;
+    const int group = claim / GP_SLOTS, slot = claim % GP_SLOTS;
     const int row0 = group * R;
     const int nrows = min(R, B - row0);
     if (slot >= n_slots || nrows <= 0) return;
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_kernel(const float* __re
     gu32* flags = (gu32*)sync + group * GP_SLOTS;
     gu32* status = (gu32*)sync + GP_FLAG_WORDS;
     if (tid == 0) s_abort = 0;
-    const int one_xcd = force_sc1 ? 0 : gp_group_on_one_xcd((gu32*)sync + GP_GROUPS * GP_SLOTS + group * GP_SLOTS, slot, n_slots, tid, &s_xcd);
+    const int one_xcd = (force_sc1 & 1) ? 0 : gp_group_on_one_xcd((gu32*)sync + GP_GROUPS * GP_SLOTS + group * GP_SLOTS, slot, n_slots, tid, &s_xcd);
     if (one_xcd < 0) {
         if (tid == 0) __hip_atomic_store(status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void lstm_stack_fwd_persist_kernel(LstmPSta
     gu32* flags_up = layer + 1 < L ? flags_x + G * GP_SLOTS : (gu32*)nullptr;
     gu32* status = (gu32*)sync + GP_FLAG_WORDS;
     if (tid == 0) s_abort = 0;
-    const int one_xcd = force_sc1 ? 0 : gp_group_on_one_xcd((gu32*)sync + LPS_XCC_WORD + id * GP_SLOTS, slot, n_slots, tid, &s_xcd);
+    const int one_xcd = (force_sc1 & 1) ? 0 : gp_group_on_one_xcd((gu32*)sync + LPS_XCC_WORD + id * GP_SLOTS, slot, n_slots, tid, &s_xcd);
     if (one_xcd < 0) {
         if (tid == 0) __hip_atomic_store(status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
@@ -936,7 +942,7 @@ __global__ __launch_bounds__(256, UT == 1 ? 2 : 1) void lstm_stack_bwd_persist_k
     gu32* flags_lo = layer > 0 ? flags_x - G * GP_SLOTS : (gu32*)nullptr;
     gu32* status = (gu32*)sync + GP_FLAG_WORDS;
     if (tid == 0) s_abort = 0;
-    const int one_xcd = force_sc1 ? 0 : gp_group_on_one_xcd((gu32*)sync + LPS_XCC_WORD + id * GP_SLOTS, slot, n_slots, tid, &s_xcd);
+    const int one_xcd = (force_sc1 & 1) ? 0 : gp_group_on_one_xcd((gu32*)sync + LPS_XCC_WORD + id * GP_SLOTS, slot, n_slots, tid, &s_xcd);
     if (one_xcd < 0) {
         if (tid == 0) __hip_atomic_store(status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
@@ -1272,7 +1278,7 @@ int mg_lstm_fwd_persist_bf16(const float* xproj, const uint16_t* w_hh_bf, int ld
 #define LP_FWD(MT, KS)                                                                                                                          \
     hipLaunchKernelGGL((lstm_fwd_persist_kernel<MT, KS>), dim3(grid), dim3(256), 0, st, xproj, w_hh_bf, ldw, b_hh, seq_len, B, T, H, R, hstate, \
                        cstate, hstate_bf, out, saved, (unsigned*)workspace, (uint16_t*)((char*)workspace + GP_RING_OFFSET),                   \
-                       g_mg_tuning[MG_TUNE_GRU_HANDOFF] == 1)
+                       g_mg_tuning[MG_TUNE_GRU_HANDOFF])
 #define LP_FWD_KS(MT)                 \
     switch (H / 128) {                \
         case 1: LP_FWD(MT, 1); break; \
@@ -1312,7 +1318,7 @@ int mg_lstm_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const 
 #define LP_BWD(MT, KS)                                                                                                                        \
     hipLaunchKernelGGL((lstm_bwd_persist_kernel<MT, KS>), dim3(grid), dim3(256), 0, st, grad_out, grad_hn, grad_cn, cstate, saved, w_hh_t_bf, ldt, \
                        seq_len, B, T, H, R, dgates, dgates_bf, dh0, dc0, (unsigned*)workspace,                                              \
-                       (uint16_t*)((char*)workspace + GP_RING_OFFSET), g_mg_tuning[MG_TUNE_GRU_HANDOFF] == 1)
+                       (uint16_t*)((char*)workspace + GP_RING_OFFSET), g_mg_tuning[MG_TUNE_GRU_HANDOFF])
 #define LP_BWD_KS(MT)                   \
     switch (H / 128) {                  \
         case 1: LP_BWD(MT, 4); break;   \
@@ -1380,7 +1386,7 @@ int mg_lstm_pstack_fwd_bf16(const mg_lstm_pstack_layer* layers, int L, const int
     const int R = (int)mg_ceil_div(B, G);
     const unsigned grid = (unsigned)(L * G * (H / GT));
     uint16_t* rings = (uint16_t*)((char*)workspace + LPS_RING_OFFSET);
-    const int force = g_mg_tuning[MG_TUNE_GRU_HANDOFF] == 1;
+    const int force = g_mg_tuning[MG_TUNE_GRU_HANDOFF];
 #define LPS_FWD(MT, KS)                                                                                                                  \
     hipLaunchKernelGGL((lstm_stack_fwd_persist_kernel<MT, KS>), dim3(grid), dim3(256), 0, st, a, seq_len, B, T, H, L, G, R, (unsigned*)workspace, \
                        rings, force)
@@ -1459,7 +1465,7 @@ int mg_lstm_pstack_bwd_bf16(const mg_lstm_pstack_bwd_layer* layers, int L, const
     const int R = (int)mg_ceil_div(B, G);
     const unsigned grid = (unsigned)(L * G * (H / (GT * UT)));
     uint16_t* rings = (uint16_t*)((char*)workspace + LPS_RING_OFFSET);
-    const int force = g_mg_tuning[MG_TUNE_GRU_HANDOFF] == 1;
+    const int force = g_mg_tuning[MG_TUNE_GRU_HANDOFF];
 #define LPS_BWD(MT, KS, UT_)                                                                                                               \
     hipLaunchKernelGGL((lstm_stack_bwd_persist_kernel<MT, KS, UT_>), dim3(grid), dim3(256), 0, st, a, seq_len, B, T, H, L, G, R, (unsigned*)workspace, \
                        rings, force)

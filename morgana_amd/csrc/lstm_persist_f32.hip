@@ -31,8 +31,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_f32_kernel(const float* 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, q = lane >> 4;
-    const int group = blockIdx.x % GP_GROUPS, slot = blockIdx.x / GP_GROUPS;
     const int n_slots = H / GT;
+    // which (group, slot) this workgroup serves: a ticket of the XCD it finds itself on (persist_common.h), not its block index
+    const int claim = gp_claim_slot((gu32*)sync + GP_TICKET_OFFSET, n_slots, tid, &s_xcd, force_sc1 & 2);
+    if (claim < 0) return;
+    const int group = claim / GP_SLOTS, slot = claim % GP_SLOTS;
     const int row0 = group * R;
     const int nrows = min(R, B - row0);
     if (slot >= n_slots || nrows <= 0) return;
@@ -40,7 +43,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_persist_f32_kernel(const float* 
     gu32* flags = (gu32*)sync + group * GP_SLOTS;
     gu32* status = (gu32*)sync + GP_FLAG_WORDS;
     if (tid == 0) s_abort = 0;
-    const int one_xcd = force_sc1 ? 0 : gp_group_on_one_xcd((gu32*)sync + GP_GROUPS * GP_SLOTS + group * GP_SLOTS, slot, n_slots, tid, &s_xcd);
+    const int one_xcd = (force_sc1 & 1) ? 0 : gp_group_on_one_xcd((gu32*)sync + GP_GROUPS * GP_SLOTS + group * GP_SLOTS, slot, n_slots, tid, &s_xcd);
     if (one_xcd < 0) {
         if (tid == 0) __hip_atomic_store(status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
@@ -216,8 +219,11 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_f32_kernel(const float* 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, q = lane >> 4;
-    const int group = blockIdx.x % GP_GROUPS, slot = blockIdx.x / GP_GROUPS;
     const int n_slots = H / GT;
+    // which (group, slot) this workgroup serves: a ticket of the XCD it finds itself on (persist_common.h), not its block index
+    const int claim = gp_claim_slot((gu32*)sync + GP_TICKET_OFFSET, n_slots, tid, &s_xcd, force_sc1 & 2);
+    if (claim < 0) return;
+    const int group = claim / GP_SLOTS, slot = claim % GP_SLOTS;
     const int row0 = group * R;
     const int nrows = min(R, B - row0);
     if (slot >= n_slots || nrows <= 0) return;
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist_f32_kernel(const float* 
     gu32* flags = (gu32*)sync + group * GP_SLOTS;
     gu32* status = (gu32*)sync + GP_FLAG_WORDS;
     if (tid == 0) s_abort = 0;
-    const int one_xcd = force_sc1 ? 0 : gp_group_on_one_xcd((gu32*)sync + GP_GROUPS * GP_SLOTS + group * GP_SLOTS, slot, n_slots, tid, &s_xcd);
+    const int one_xcd = (force_sc1 & 1) ? 0 : gp_group_on_one_xcd((gu32*)sync + GP_GROUPS * GP_SLOTS + group * GP_SLOTS, slot, n_slots, tid, &s_xcd);
     if (one_xcd < 0) {
         if (tid == 0) __hip_atomic_store(status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
@@ -410,7 +416,7 @@ int mg_lstm_fwd_persist_f32(const float* xproj, const float* w_hh, const float* 
     const int R = (int)mg_ceil_div(B, GP_GROUPS);
     const unsigned grid = (unsigned)(GP_GROUPS * (H / GT));
     float* ring = (float*)((char*)workspace + GP_RING_OFFSET);
-    const int force = g_mg_tuning[MG_TUNE_GRU_HANDOFF] == 1;
+    const int force = g_mg_tuning[MG_TUNE_GRU_HANDOFF];
 #define LPF_FWD(KS) hipLaunchKernelGGL((lstm_fwd_persist_f32_kernel<KS>), dim3(grid), dim3(256), 0, st, xproj, w_hh, b_hh, seq_len, B, T, H, R, hstate, cstate, out, saved, (unsigned*)workspace, ring, force)
     switch (H / 64) {
         case 4: LPF_FWD(4); break;
@@ -433,7 +439,7 @@ int mg_lstm_bwd_persist_f32(const float* grad_out, const float* grad_hn, const f
     const int R = (int)mg_ceil_div(B, GP_GROUPS);
     const unsigned grid = (unsigned)(GP_GROUPS * (H / GT));
     float* ring = (float*)((char*)workspace + GP_RING_OFFSET);
-    const int force = g_mg_tuning[MG_TUNE_GRU_HANDOFF] == 1;
+    const int force = g_mg_tuning[MG_TUNE_GRU_HANDOFF];
 #define LPF_BWD(KS) hipLaunchKernelGGL((lstm_bwd_persist_f32_kernel<KS>), dim3(grid), dim3(256), 0, st, grad_out, grad_hn, grad_cn, cstate, saved, w_hh, seq_len, B, T, H, R, dgates, dh0, dc0, (unsigned*)workspace, ring, force)
     switch (H / 64) {
         case 4: LPF_BWD(16); break;

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void split3_kernel(Split3Batch batch) {
             if (d.order == 2) {
                 uint16_t* dst = d.dst + (size_t)r * d.ldp + c0;
                 *reinterpret_cast<su32x4*>(dst) = ph;
-                *reinterpret_cast<su32x4*>(dst + (size_t)d.rows * d.ldp) = pl;
+                *reinterpret_cast<su32x4*>(dst + (size_t)(d.plane_rows > 0 ? d.plane_rows : d.rows) * d.ldp) = pl;
             } else {
                 uint16_t* dst = d.dst + (size_t)r * (3 * (size_t)d.ldp) + c0;
                 *reinterpret_cast<su32x4*>(dst) = ph;
@@ -113,6 +113,7 @@ int mg_split3_bf16(const mg_split3_desc* descs, int count, void* stream) {
         MG_CHECK_ARG(d.src && d.dst && d.rows > 0 && d.cols > 0 && d.lds >= d.cols, "mg_split3_bf16: bad descriptor %d", i);
         MG_CHECK_ARG(d.order == 0 || d.order == 1 || (d.order == 2 && !d.transpose),
                      "mg_split3_bf16: descriptor %d: order %d is none of 0 (hi|hi|lo), 1 (hi|lo|hi), 2 (separate planes hi ; lo, not transposed)", i, d.order);
+        MG_CHECK_ARG(d.plane_rows == 0 || (d.order == 2 && d.plane_rows >= d.rows), "mg_split3_bf16: descriptor %d: plane_rows %lld goes with order 2 and must cover the %lld rows", i, (long long)d.plane_rows, (long long)d.rows);
         MG_CHECK_ARG(d.ldp % 8 == 0 && ((size_t)d.dst & 15) == 0, "mg_split3_bf16: descriptor %d: ldp %d must be a multiple of 8 and dst 16-byte aligned", i, d.ldp);
         if (d.transpose)
             MG_CHECK_ARG(d.ldp >= d.rows && d.rows < 2147483647LL, "mg_split3_bf16: descriptor %d: transposed planes of %d columns cannot hold %lld rows", i, d.ldp, (long long)d.rows);

@@ -200,14 +200,15 @@ class LinearStackFn(torch.autograd.Function):
             ctx.save_for_backward(x2d, rows_k, rows if gathered_grad else None, *weights, *hidden)
         elif precision == 'bf16x3':
             # split-bf16: fp32 activations as in fp32 mode, every product as ONE bf16 GEMM over split operands (csrc/split3.hip)
-            if extra:
-                x2d = torch.cat((x2d, x2d.new_zeros((extra, x2d.shape[1]))))
-            a, r = x2d, rows
             split = [_x3_layer(w) for w in weights]
+            if extra and not split[0]:
+                x2d, extra = torch.cat((x2d, x2d.new_zeros((extra, x2d.shape[1])))), 0
+            a, r = x2d, rows
             w3s = ops.x3_weight_operands([w for w, s in zip(weights, split) if s])[0]
             for i in range(n_layers):
                 if split[i]:
-                    a3 = ops.split3([(a, 0, False)])[0]
+                    # the zero rows behind a phone table (what padding frames gather) are rows of the split operand, never of an fp32 copy
+                    a3 = ops.split3([(a, 0, False, extra if i == 0 else 0)])[0]
                     a = ops.linear_fwd_x3(a3, r, m, w3s.pop(0), biases[i], weights[i].shape[0], acts[i])
                 else:
                     a = ops.linear_fwd_f32(a, r, m, ops._require(weights[i], torch.float32, 'weight'), biases[i], acts[i])
@@ -216,6 +217,7 @@ class LinearStackFn(torch.autograd.Function):
             out = a
             ctx.save_for_backward(x2d, rows_k, rows if gathered_grad else None, *weights, *hidden)
             ctx.param_refs = (list(weights), list(biases))
+            ctx.x3_extra = extra
         else:
             if gathered_grad:
                 if pre_cast:
@@ -287,7 +289,7 @@ class LinearStackFn(torch.autograd.Function):
                         grad_x = ops.linear_dgrad_f32(g, weights[0], None)
                     continue
                 need_g3 = i > 0 or need_x
-                parts = ops.split3([(g, 2, False), (a_in, 2, False)] + ([(g, 0, False)] if need_g3 else []))
+                parts = ops.split3([(g, 2, False), (a_in, 2, False, ctx.x3_extra if i == 0 else 0)] + ([(g, 0, False)] if need_g3 else []))
                 g2, a2, g3 = parts[0], parts[1], (parts[2] if need_g3 else None)
                 if direct:
                     ops.linear_wgrad_x3(g2, a2, r, m, n, k, out_w=w_params[i].grad, out_b=b_params[i].grad, accumulate=True)

@@ -707,15 +707,22 @@ def split3(jobs):
     for i in range(0, len(jobs), _lib.SPLIT3_MAX):
         chunk = jobs[i:i + _lib.SPLIT3_MAX]
         descs = (_lib.Split3Desc * len(chunk))()
-        for j, (x, order, transpose) in enumerate(chunk):
+        for j, job in enumerate(chunk):
+            x, order, transpose = job[:3]
+            extra = int(job[3]) if len(job) > 3 else 0          # zero rows appended behind the split (not with transpose)
             if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
                 raise TypeError('split3: operands must be 2-D float32 with unit column stride')
+            if extra and transpose:
+                raise ValueError('split3: extra zero rows go with the plain layouts')
             rows, cols = x.shape
             ldp = pad_ld(rows if transpose else cols)
-            out = torch.empty((2, rows, ldp) if order == 2 else (cols if transpose else rows, 3 * ldp), dtype=torch.bfloat16,
-                              device=x.device)
+            out = torch.empty((2, rows + extra, ldp) if order == 2 else ((cols if transpose else rows) + extra, 3 * ldp),
+                              dtype=torch.bfloat16, device=x.device)
+            if extra:
+                (out[:, rows:] if order == 2 else out[rows:]).zero_()
             descs[j].src, descs[j].rows, descs[j].cols, descs[j].lds = x.data_ptr(), rows, cols, x.stride(0)
             descs[j].dst, descs[j].ldp, descs[j].order, descs[j].transpose = out.data_ptr(), ldp, int(order), int(bool(transpose))
+            descs[j].plane_rows = rows + extra
             outs.append(out)
         if chunk:
             _lib.check(lib.mg_split3_bf16(ctypes.cast(descs, ctypes.c_void_p), len(chunk), _stream()), 'mg_split3_bf16')
