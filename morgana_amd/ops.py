@@ -722,7 +722,7 @@ def split3(jobs):
                 (out[:, rows:] if order == 2 else out[rows:]).zero_()
             descs[j].src, descs[j].rows, descs[j].cols, descs[j].lds = x.data_ptr(), rows, cols, x.stride(0)
             descs[j].dst, descs[j].ldp, descs[j].order, descs[j].transpose = out.data_ptr(), ldp, int(order), int(bool(transpose))
-            descs[j].plane_rows = rows + extra
+            descs[j].plane_rows = rows + extra if order == 2 else 0
             outs.append(out)
         if chunk:
             _lib.check(lib.mg_split3_bf16(ctypes.cast(descs, ctypes.c_void_p), len(chunk), _stream()), 'mg_split3_bf16')
