@@ -70,6 +70,56 @@ def backward(loss):
         loss.backward(gradient=one if loss.dim() == 0 else None)
     finally:
         _DIRECT_BACKWARD -= 1
+        _join_side()               # weight gradients that ran beside the backward pass are complete before anything that follows
+
+
+# ---- weight gradients beside the backward pass ------------------------------------------------------------------------------------
+# In a backward pass the gradient chain (dgrad, the recurrence) is the critical path; a layer's WEIGHT gradient feeds nothing but the
+# update at the very end.  Inside ``backward`` above - where the parameter gradients go straight into the optimiser's flat buffer and
+# nobody reads them before the update - the row-wise layers outside the fused F0 stack and the GRU wrapper issue their weight-gradient
+# GEMMs on a side stream: behind the event "their operands are ready", beside the rest of the pass (C4: the post-GRU layers' weight
+# gradients run beside the backward recurrence's first steps, the 100 GFLOP recurrent weight gradient beside the input-side chain
+# segment sum -> input weight gradient -> dgrad -> first layer).  ``backward`` joins the stream before it returns.  Scratch is per
+# stream (ops.workspace), operands stay referenced until the join; inside a stream capture fork and join become graph edges.
+SIDE_STREAMS = os.environ.get('MORGANA_SIDE_STREAMS', '1') != '0'
+_side_streams = {}
+_side_pending = []      # (main stream, side stream, tensors the side work reads) since the last join
+
+
+def _side_ok(device):
+    return (SIDE_STREAMS and _DIRECT_BACKWARD > 0 and _EARLY_GRADS_HOOK is None and device.type == 'cuda')
+
+
+class _Beside(object):
+    """``with _Beside(device, *tensors):`` - the launches inside go to the device's side stream, ordered behind everything the current
+    stream holds so far; ``tensors`` (what those launches read) stay alive until ``_join_side``."""
+
+    def __init__(self, device, *keep):
+        self.device, self.keep = device, keep
+
+    def __enter__(self):
+        main = torch.cuda.current_stream(self.device)
+        side = _side_streams.get(self.device.index)
+        if side is None:
+            side = _side_streams[self.device.index] = torch.cuda.Stream(self.device)
+            ops.SIDE_STREAM_IDS.add(side.cuda_stream)
+        side.wait_stream(main)
+        _side_pending.append((main, side, self.keep))
+        self._ctx = torch.cuda.stream(side)
+        self._ctx.__enter__()
+        return side
+
+    def __exit__(self, *exc):
+        return self._ctx.__exit__(*exc)
+
+
+def _join_side():
+    joined = set()
+    for main, side, _ in _side_pending:
+        if (main.cuda_stream, side.cuda_stream) not in joined:
+            joined.add((main.cuda_stream, side.cuda_stream))
+            main.wait_stream(side)
+    del _side_pending[:]
 
 
 _DIRECT_BACKWARD = 0
@@ -306,10 +356,16 @@ class LinearStackFn(torch.autograd.Function):
             g = ops.cast_pad_bf16(g)
             w_params, b_params = ctx.param_refs
             direct = all(ctx.has_bias) and _direct_params(*w_params, *b_params)
+            beside = direct and _side_ok(g.device)
             for i in range(n_layers - 1, -1, -1):
                 n, k = ctx.dims[i]
                 a_in, r = (x_in, rows) if i == 0 else (hidden[i - 1], None)
-                if direct:
+                if beside and (i > 0 or need_x):
+                    # the weight gradient feeds only the update: beside the dgrad chain (the last layer of the pass has no chain left
+                    # on this node, its weight gradient stays in line)
+                    with _Beside(g.device, g, a_in, r):
+                        _linear_grads_direct(w_params[i], b_params[i], g, a_in, r, m, n, k)
+                elif direct:
                     _linear_grads_direct(w_params[i], b_params[i], g, a_in, r, m, n, k)
                 else:
                     dw, db = ops.linear_wgrad_bf16(g, a_in, r, m, n, k, want_bias=ctx.has_bias[i])
@@ -909,9 +965,6 @@ class GRUFn(torch.autograd.Function):
                 dx = ops.linear_dgrad_f32(dxp2, w_ih, None)
                 dx = dx if rows is not None else dx.view(b, t, i_dim)
         else:
-            dxp_bf = dxproj_bf.view(m, 3 * hid) if dxproj_bf is not None else ops.cast_pad_bf16(dxp2)
-            if rows is not None:
-                dxp_bf = ops.segment_sum(dxp_bf, rows.reshape(-1), seg, n_phone, 3 * hid)
             # the bf16 recurrence already wrote the bf16 shadows of dhproj and of the states
             dhp_bf = dhproj_bf.view(m, 3 * hid) if dhproj_bf is not None else ops.cast_pad_bf16(dhp2)
             hs_bf = hstate_bf.view(b * (t + 1), hid) if hstate_bf is not None else ops.cast_pad_bf16(hs2)
@@ -924,14 +977,28 @@ class GRUFn(torch.autograd.Function):
             into = dict(accumulate=True) if _direct_params(p_ih, p_hh, pb_ih, pb_hh) else None
             kw_ih = dict(out_w=p_ih.grad, out_b=pb_ih.grad, **into) if into else {}
             kw_hh = dict(out_w=p_hh.grad, out_b=pb_hh.grad, **into) if into else {}
+
+            def recurrent_wgrad():
+                if lay is not None and ops.wgrad_rows_ok(lay.total, 3 * hid, hid, hs_bf.shape[1], dhp_bf.shape[1]):
+                    return ops.linear_wgrad_rows_bf16(dhp_bf, lay.frame_rows(), hs_bf, lay.state_rows(), lay.total, 3 * hid, hid, **kw_hh)
+                return ops.linear_wgrad_bf16(dhp_bf, hs_bf, prev_rows, m, 3 * hid, hid, **kw_hh)
+
+            # The recurrent weight gradient (C4: 100 GFLOP, the longest launch behind the recurrence) feeds nothing but the update: it
+            # goes beside the input-side chain below (segment sum -> input weight gradient -> dgrad -> the layers in front)
+            recurrent_wgrad_out = None
+            if into and _side_ok(hs_bf.device):
+                if lay is not None:
+                    lay.frame_rows(), lay.state_rows()     # built (once per layout) on the main stream, not inside the fork
+                with _Beside(hs_bf.device, dhp_bf, hs_bf, prev_rows, lay):
+                    recurrent_wgrad_out = recurrent_wgrad()
+            dxp_bf = dxproj_bf.view(m, 3 * hid) if dxproj_bf is not None else ops.cast_pad_bf16(dxp2)
+            if rows is not None:
+                dxp_bf = ops.segment_sum(dxp_bf, rows.reshape(-1), seg, n_phone, 3 * hid)
             if lay is not None and rows is None and ops.wgrad_rows_ok(lay.total, 3 * hid, i_dim, x_saved.shape[1], dxp_bf.shape[1]):
                 dw_ih, db_ih = ops.linear_wgrad_rows_bf16(dxp_bf, lay.frame_rows(), x_saved, None, lay.total, 3 * hid, i_dim, **kw_ih)
             else:
                 dw_ih, db_ih = ops.linear_wgrad_bf16(dxp_bf, x_saved, None, m_in, 3 * hid, i_dim, **kw_ih)
-            if lay is not None and ops.wgrad_rows_ok(lay.total, 3 * hid, hid, hs_bf.shape[1], dhp_bf.shape[1]):
-                dw_hh, db_hh = ops.linear_wgrad_rows_bf16(dhp_bf, lay.frame_rows(), hs_bf, lay.state_rows(), lay.total, 3 * hid, hid, **kw_hh)
-            else:
-                dw_hh, db_hh = ops.linear_wgrad_bf16(dhp_bf, hs_bf, prev_rows, m, 3 * hid, hid, **kw_hh)
+            dw_hh, db_hh = recurrent_wgrad_out if recurrent_wgrad_out is not None else recurrent_wgrad()
             if into:
                 dw_ih = dw_hh = db_ih = db_hh = None
             if need_x:

@@ -13,6 +13,7 @@ ACT_NONE, ACT_SIGMOID = 0, 1
 NORM_MVN, DENORM_MVN, NORM_MINMAX, DENORM_MINMAX = 0, 1, 2, 3
 
 _workspaces = {}
+SIDE_STREAM_IDS = set()      # raw handles of the side streams functional._Beside launches on (their scratch is their own)
 _retired = []
 
 
@@ -40,7 +41,9 @@ def _require(t, dtype, name):
 def workspace(nbytes, device):
     """One grow-only scratch buffer per device; all kernels of a step run on one stream, so it is shared.  A buffer that is
     outgrown is kept alive (``_retired``): a captured HIP graph (morgana_amd/graphs.py) may still launch kernels that point at it."""
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    # ... and one more for launches that run BESIDE the step on a side stream (functional._Beside): they must not share scratch with it
+    key = (index, bool(SIDE_STREAM_IDS) and device.type == 'cuda' and torch._C._cuda_getCurrentRawStream(index) in SIDE_STREAM_IDS)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:
