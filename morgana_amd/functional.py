@@ -81,13 +81,13 @@ def backward(loss):
 # gradients run beside the backward recurrence's first steps, the 100 GFLOP recurrent weight gradient beside the input-side chain
 # segment sum -> input weight gradient -> dgrad -> first layer).  ``backward`` joins the stream before it returns.  Scratch is per
 # stream (ops.workspace), operands stay referenced until the join; inside a stream capture fork and join become graph edges.
-SIDE_STREAMS = os.environ.get('MORGANA_SIDE_STREAMS', '1') != '0'
+SIDE_STREAMS = int(os.environ.get('MORGANA_SIDE_STREAMS', '1'))      # 0 = off, 1 = the recurrent weight gradient, 2 = row-wise stacks too
 _side_streams = {}
 _side_pending = []      # (main stream, side stream, tensors the side work reads) since the last join
 
 
-def _side_ok(device):
-    return (SIDE_STREAMS and _DIRECT_BACKWARD > 0 and _EARLY_GRADS_HOOK is None and device.type == 'cuda')
+def _side_ok(device, level=1):
+    return (SIDE_STREAMS >= level and _DIRECT_BACKWARD > 0 and _EARLY_GRADS_HOOK is None and device.type == 'cuda')
 
 
 class _Beside(object):
@@ -356,7 +356,7 @@ class LinearStackFn(torch.autograd.Function):
             g = ops.cast_pad_bf16(g)
             w_params, b_params = ctx.param_refs
             direct = all(ctx.has_bias) and _direct_params(*w_params, *b_params)
-            beside = direct and _side_ok(g.device)
+            beside = direct and _side_ok(g.device, level=2)
             for i in range(n_layers - 1, -1, -1):
                 n, k = ctx.dims[i]
                 a_in, r = (x_in, rows) if i == 0 else (hidden[i - 1], None)
