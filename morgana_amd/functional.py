@@ -81,7 +81,12 @@ def backward(loss):
 # gradients run beside the backward recurrence's first steps, the 100 GFLOP recurrent weight gradient beside the input-side chain
 # segment sum -> input weight gradient -> dgrad -> first layer).  ``backward`` joins the stream before it returns.  Scratch is per
 # stream (ops.workspace), operands stay referenced until the join; inside a stream capture fork and join become graph edges.
-SIDE_STREAMS = int(os.environ.get('MORGANA_SIDE_STREAMS', '1'))      # 0 = off, 1 = the recurrent weight gradient, 2 = row-wise stacks too
+# MEASURED (round 4, same-box A/B, profiles/r4_notes_side_streams.txt) and therefore OFF by default: level 1 (the recurrent weight
+# gradient beside the input-side chain) changes nothing - C4 3.383-3.393 against 3.391-3.392 ms, C5 6.598-6.615 against 6.606-6.620: each
+# of these GEMMs fills every CU with a 512-thread workgroup, so the "two streams" take turns - and level 2 (the post-GRU layers'
+# weight gradients too, which then run when the backward recurrence is launched) costs C4 0.7 ms (4.10-4.12 ms): the persistent
+# launch finds CUs taken, its workgroups land unevenly over the XCDs and the groups fall to the write-through hand-off.
+SIDE_STREAMS = int(os.environ.get('MORGANA_SIDE_STREAMS', '0'))      # 0 = off, 1 = the recurrent weight gradient, 2 = row-wise stacks too
 _side_streams = {}
 _side_pending = []      # (main stream, side stream, tensors the side work reads) since the last join
 
