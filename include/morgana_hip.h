@@ -425,6 +425,17 @@ typedef struct {
     int64_t plane_rows; /* order 2: rows of one plane in dst (>= rows; the caller owns the rows behind the split, e.g. zeros); 0 = rows */
 } mg_split3_desc;
 int mg_split3_bf16(const mg_split3_desc* descs, int count, void* stream);
+/* Active dropout (nn.Dropout(p) of the shipped models in training mode: /root/reference/models/RNN_SPSS.py:19,34,40,
+ * /root/reference/models/f0_test_model.py:22,31-43; torch.nn.functional.dropout semantics: y = x * keep / (1 - p), keep ~ Bernoulli(1 - p)
+ * per element).  The mask is a function of (seed, site, *counter, element index) through Philox4x32-10 and is never stored: the
+ * backward pass calls the same entry on the gradient with the same four numbers.  x, y: n elements, fp32 (bf16 = 0) or bf16 (bf16 = 1),
+ * y may be x.  counter: DEVICE uint64 (NULL = 0) - the step counter this call draws from; mg_dropout_advance(state, used) copies
+ * *state to *used (the word a call's backward keeps) and increments *state, in stream order, so that a replayed HIP graph draws a new
+ * mask every replay.  Bit parity with torch's mask stream is not attempted (its Philox offsets depend on its launch geometry). */
+int mg_dropout(const void* x, void* y, int64_t n, int bf16, float p, uint64_t seed, uint32_t site, const uint64_t* counter, void* stream);
+int mg_dropout_advance(uint64_t* state, uint64_t* used, void* stream);
+/* Host-only: one Philox4x32-10 block (the generator mg_dropout draws from), for known-answer tests. */
+void mg_philox4x32_10(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
 /* CALIBRATION (a measurement entry; no training step calls it): one launch of a register-operand bf16 MFMA loop - n_workgroups x 512
  * threads (two waves per SIMD), every wave issues 16 x trips v_mfma_f32_16x16x32_bf16 on operands read once from `operands`
  * (bf16, at least 4096 x 64 values: the caller chooses the data, e.g. random) and writes one float per thread to `sink`

@@ -78,6 +78,9 @@ SIGNATURES = {
     'mg_cast_params_bf16': (c_int, [c_void_p, c_int, c_void_p]),
     'mg_cast_bf16_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
     'mg_split3_bf16': (c_int, [c_void_p, c_int, c_void_p]),
+    'mg_dropout': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, ctypes.c_uint64, ctypes.c_uint32, c_void_p, c_void_p]),
+    'mg_dropout_advance': (c_int, [c_void_p, c_void_p, c_void_p]),
+    'mg_philox4x32_10': (None, [c_void_p, c_void_p, c_void_p]),
     'mg_calib_mfma_bf16': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'mg_sigmoid_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     'mg_sigmoid_grad_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

@@ -209,6 +209,43 @@ class UpsampleFn(torch.autograd.Function):
         return ops.upsample_backward(grad_out.contiguous(), dur2d, ctx.n_phones), None, None
 
 
+class DropoutFn(torch.autograd.Function):
+    """Active ``nn.Dropout(p)`` (training mode) as a HIP kernel: y = x * keep / (1 - p); the mask is a function of (torch's seed, site,
+    the device's step counter, element index) - csrc/dropout.hip - and the backward regenerates it.  forward(ctx, x, p, site)."""
+
+    @staticmethod
+    def forward(ctx, x, p, site):
+        x = x.contiguous()
+        seed, used = ops.dropout_seed(), ops.dropout_draw(x.device)
+        ctx.args = (float(p), seed, int(site))
+        ctx.save_for_backward(used)
+        return ops.dropout(x, p, seed, site, used)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (used,) = ctx.saved_tensors
+        p, seed, site = ctx.args
+        return ops.dropout(grad.contiguous(), p, seed, site, used), None, None
+
+
+class _RunDropout(object):
+    """The dropout masks of one LinearStackFn node: ``drops[i]`` = probability behind layer i (0 = none), one draw of the device's
+    step counter for the node, site = site0 + i.  ``apply`` is forward and backward alike (the mask multiplies either)."""
+
+    def __init__(self, spec, device):
+        self.drops, self.site0 = spec
+        self.seed, self.used = ops.dropout_seed(), ops.dropout_draw(device)
+
+    def active(self, i):
+        return 0 <= i < len(self.drops) and self.drops[i] > 0
+
+    def apply(self, x, i, inplace=False):
+        if not self.active(i):
+            return x
+        x = x if x.is_contiguous() else x.contiguous()
+        return ops.dropout(x, self.drops[i], self.seed, self.site0 + i, self.used, out=x if inplace else None)
+
+
 class LinearStackFn(torch.autograd.Function):
     """y = L_n(...sigma(L_1(x))...) over rows of a 2-D input (or of a gathered table).
 
@@ -223,6 +260,10 @@ class LinearStackFn(torch.autograd.Function):
         acts, precision = spec[:2]
         extra = spec[2] if len(spec) > 2 else 0       # zero rows appended behind x2d (phone-rate tables: what padding frames gather)
         rows_runs = bool(spec[3]) if len(spec) > 3 else False      # `rows` is an upsample frame map (runs of equal indices): a hint
+        # active dropout behind layers of the run (utils._Run.drop_spec): masks drawn here, regenerated in backward; the activation
+        # saved for the backward is the one BEFORE the mask (the sigmoid gradient needs it), the masked copy feeds the next layer
+        drop = _RunDropout(spec[4], x2d.device) if len(spec) > 4 and spec[4] is not None else None
+        ctx.drop = drop
         n_layers = len(acts)
         weights = [params[2 * i] for i in range(n_layers)]
         biases = [params[2 * i + 1] for i in range(n_layers)]
@@ -251,6 +292,8 @@ class LinearStackFn(torch.autograd.Function):
                 a = ops.linear_fwd_f32(a, r, m, w, biases[i], acts[i])
                 r = None
                 hidden.append(a)
+                if drop is not None:
+                    a = drop.apply(a, i)
             out = a
             ctx.save_for_backward(x2d, rows_k, rows if gathered_grad else None, *weights, *hidden)
         elif precision == 'bf16x3':
@@ -269,6 +312,8 @@ class LinearStackFn(torch.autograd.Function):
                     a = ops.linear_fwd_f32(a, r, m, ops._require(weights[i], torch.float32, 'weight'), biases[i], acts[i])
                 r = None
                 hidden.append(a)
+                if drop is not None:
+                    a = drop.apply(a, i)
             out = a
             ctx.save_for_backward(x2d, rows_k, rows if gathered_grad else None, *weights, *hidden)
             ctx.param_refs = (list(weights), list(biases))
@@ -291,12 +336,16 @@ class LinearStackFn(torch.autograd.Function):
                 a = ops.linear_fwd_bf16(a, r, m, k, w_bfs[i], biases[i], n, acts[i], out_f32=last, rows_runs=rows_runs)
                 r = None
                 hidden.append(a)
+                if drop is not None and not last:
+                    a = drop.apply(a, i)                 # over the padded bf16 buffer: zero padding stays zero
             n_last = weights[-1].shape[0]
             out = hidden[-1]
             if out.shape[1] != n_last:
                 out = out[:, :n_last].contiguous()
-                # keep the padded fp32 activation only if a trailing sigmoid needs it in backward
-            ctx.save_for_backward(a0, rows_k, rows if gathered_grad else None, *weights, *hidden[:-1], out)
+            unmasked = out                               # what a trailing sigmoid's gradient reads in backward
+            if drop is not None:
+                out = drop.apply(out, n_layers - 1)
+            ctx.save_for_backward(a0, rows_k, rows if gathered_grad else None, *weights, *hidden[:-1], unmasked)
             ctx.param_refs = (list(weights), list(biases))        # the Parameter objects (their .grad views, their shadows)
         return out
 
@@ -311,19 +360,32 @@ class LinearStackFn(torch.autograd.Function):
         m = ctx.m
         grads = [None] * (2 * n_layers)
         need_x = ctx.needs_input_grad[1]
+        drop = getattr(ctx, 'drop', None)
+
+        def masked_input(i):
+            # the operand layer i multiplied in the forward pass: the saved activation of layer i - 1 under its dropout mask (regenerated)
+            return hidden[i - 1] if drop is None else drop.apply(hidden[i - 1], i - 1)
+
+        def unmask(g_, i):
+            # a gradient with respect to a MASKED activation -> with respect to the activation: the same mask (it commutes with the
+            # sigmoid gradient the dgrad kernels fuse, which reads the unmasked activation)
+            return g_ if drop is None else drop.apply(g_, i, inplace=True)
+
         g = grad_out.contiguous()
+        if drop is not None and drop.active(n_layers - 1):
+            g = drop.apply(g, n_layers - 1)
         if acts[-1] == ops.ACT_SIGMOID:
             g = ops.sigmoid_grad(g, hidden[-1])
         grad_x = None
         if precision == 'fp32':
             for i in range(n_layers - 1, -1, -1):
                 n, k = ctx.dims[i]
-                a_in, r = (x_in, rows) if i == 0 else (hidden[i - 1], None)
+                a_in, r = (x_in, rows) if i == 0 else (masked_input(i), None)
                 dw, db = ops.linear_wgrad_f32(g, a_in, r, n, k, want_bias=ctx.has_bias[i])
                 grads[2 * i], grads[2 * i + 1] = dw, db
                 if i > 0:
                     h = hidden[i - 1] if acts[i - 1] == ops.ACT_SIGMOID else None
-                    g = ops.linear_dgrad_f32(g, weights[i], h)
+                    g = unmask(ops.linear_dgrad_f32(g, weights[i], h), i - 1)
                 elif need_x:
                     grad_x = ops.linear_dgrad_f32(g, weights[0], None)
         elif precision == 'bf16x3':
@@ -335,11 +397,11 @@ class LinearStackFn(torch.autograd.Function):
             wt3s = dict(zip(dgrad_of, wt3_list))
             for i in range(n_layers - 1, -1, -1):
                 n, k = ctx.dims[i]
-                a_in, r = (x_in, rows) if i == 0 else (hidden[i - 1], None)
+                a_in, r = (x_in, rows) if i == 0 else (masked_input(i), None)
                 if not split[i]:                       # a narrow layer: exact fp32 products (see _x3_layer)
                     grads[2 * i], grads[2 * i + 1] = ops.linear_wgrad_f32(g, a_in, r, n, k, want_bias=ctx.has_bias[i])
                     if i > 0:
-                        g = ops.linear_dgrad_f32(g, weights[i], hidden[i - 1] if acts[i - 1] == ops.ACT_SIGMOID else None)
+                        g = unmask(ops.linear_dgrad_f32(g, weights[i], hidden[i - 1] if acts[i - 1] == ops.ACT_SIGMOID else None), i - 1)
                     elif need_x:
                         grad_x = ops.linear_dgrad_f32(g, weights[0], None)
                     continue
@@ -355,6 +417,7 @@ class LinearStackFn(torch.autograd.Function):
                     g = ops.linear_dgrad_x3(g3, m, wt3s[i], k)
                     if acts[i - 1] == ops.ACT_SIGMOID:
                         g = ops.sigmoid_grad(g, hidden[i - 1])
+                    g = unmask(g, i - 1)
                 elif need_x:
                     grad_x = ops.linear_dgrad_x3(g3, m, wt3s[0], k)
         else:
@@ -364,7 +427,7 @@ class LinearStackFn(torch.autograd.Function):
             beside = direct and _side_ok(g.device, level=2)
             for i in range(n_layers - 1, -1, -1):
                 n, k = ctx.dims[i]
-                a_in, r = (x_in, rows) if i == 0 else (hidden[i - 1], None)
+                a_in, r = (x_in, rows) if i == 0 else (masked_input(i), None)
                 if beside and (i > 0 or need_x):
                     # the weight gradient feeds only the update: beside the dgrad chain (the last layer of the pass has no chain left
                     # on this node, its weight gradient stays in line)
@@ -378,7 +441,7 @@ class LinearStackFn(torch.autograd.Function):
                 if i > 0:
                     wt = _w_t(w_params[i])
                     h = hidden[i - 1] if acts[i - 1] == ops.ACT_SIGMOID else None
-                    g = ops.linear_dgrad_bf16(g, m, n, wt, k, h)
+                    g = unmask(ops.linear_dgrad_bf16(g, m, n, wt, k, h), i - 1)
                 elif need_x:
                     wt = _w_t(w_params[0])
                     grad_x = ops.linear_dgrad_bf16(g, m, n, wt, k, None, out_f32=True)

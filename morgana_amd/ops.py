@@ -692,6 +692,38 @@ def refresh_shadows(params):
         _lib.check(lib.mg_cast_params_bf16(ctypes.cast(descs, ctypes.c_void_p), len(chunk), _stream()), 'mg_cast_params_bf16')
 
 
+# ------------------------------------------------------------------------------------------------------------------ active dropout
+_dropout_state = {}      # device index -> int64 (1,) step counter on the device (mg_dropout_advance increments it per call)
+
+
+def dropout_seed():
+    """The 64-bit key of the dropout masks: torch's seed (``torch.manual_seed`` makes runs repeatable, as it does for nn.Dropout)."""
+    return int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+
+
+def dropout_draw(device):
+    """Reserve one draw of the device's dropout step counter: returns a (1,) int64 device tensor holding the counter value this call
+    (and its backward) uses; the device counter moves on in stream order - also inside a replayed HIP graph (csrc/dropout.hip)."""
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    state = _dropout_state.get(index)
+    if state is None:
+        state = _dropout_state[index] = torch.zeros(1, dtype=torch.int64, device=device)
+    used = torch.empty(1, dtype=torch.int64, device=device)
+    _lib.check(_lib.load().mg_dropout_advance(_p(state), _p(used), _stream()), 'mg_dropout_advance')
+    return used
+
+
+def dropout(x, p, seed, site, used, out=None):
+    """y = x * keep / (1 - p) with the mask of (seed, site, used[0], element index) - mg_dropout.  x: contiguous fp32 or bf16; ``out``
+    may be x (in place).  The same call on a gradient with the same (seed, site, used) is the backward."""
+    if x.dtype not in (torch.float32, torch.bfloat16) or not x.is_contiguous():
+        raise TypeError('dropout: a contiguous float32 or bfloat16 tensor is required')
+    y = torch.empty_like(x) if out is None else out
+    _lib.check(_lib.load().mg_dropout(_p(x), _p(y), x.numel(), int(x.dtype == torch.bfloat16), float(p), int(seed), int(site) & 0xFFFFFFFF,
+                                      _p(used), _stream()), 'mg_dropout')
+    return y
+
+
 # ----------------------------------------------------------------------------------------- precision 'bf16x3' (split-bf16 operands)
 CAPTURE_EPOCH = [0]      # bumped by graphs.GraphedTrainStep at the start of every capture (see x3_weight_operands)
 

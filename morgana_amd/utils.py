@@ -283,7 +283,8 @@ class RecurrentCuDNNWrapper(nn.Module):
     def _hip_lstm(self):
         layer = self.layer
         return (isinstance(layer, nn.LSTM) and not layer.bidirectional and layer.batch_first and layer.bias and
-                getattr(layer, 'proj_size', 0) == 0 and (layer.dropout == 0 or not layer.training))
+                getattr(layer, 'proj_size', 0) == 0 and
+                (layer.dropout == 0 or not layer.training or layer.num_layers == 1))      # one layer: nn.LSTM's dropout acts BETWEEN layers
 
     def _lstm_params(self):
         layer = self.layer
@@ -406,22 +407,28 @@ class SequentialWithRecurrent(nn.Sequential):
         self.precision = precision
 
     def _linear_run(self, modules, start):
-        """Collect [Linear, Sigmoid?, identity Dropout?]+ starting at ``start``; returns (end, [(linear, act), ...]).
-        ``nn.Dropout`` with p == 0 or in eval mode (the reference's models pass dropout_prob=0., models/RNN_SPSS.py:21) is the
-        identity and does not break a run; an active dropout does."""
-        def identity_dropout(mod):
-            return type(mod) is nn.Dropout and (mod.p == 0 or not mod.training)
-
-        run, i = [], start
+        """Collect [Linear, Sigmoid?, Dropout*]+ starting at ``start``; returns (end, run) with run = [(linear, act), ...] and
+        ``run.drops`` = the dropout probability behind each layer (0 = none: ``nn.Dropout`` with p == 0 or in eval mode is the
+        identity - the reference's models pass dropout_prob=0., models/RNN_SPSS.py:21).  An ACTIVE dropout does not break the run
+        either: the run's autograd node draws its mask in a HIP kernel behind the layer and regenerates it in its backward
+        (functional.LinearStackFn, csrc/dropout.hip) - no torch kernel, no cut in the fused run.  ``run.site0`` numbers the masks."""
+        run, drops, i = _Run(), [], start
         while i < len(modules) and type(modules[i]) is nn.Linear:
             act = ops.ACT_NONE
             nxt = i + 1
             if nxt < len(modules) and type(modules[nxt]) is nn.Sigmoid:
                 act, nxt = ops.ACT_SIGMOID, nxt + 1
-            while nxt < len(modules) and identity_dropout(modules[nxt]):
+            keep = 1.0
+            while nxt < len(modules) and type(modules[nxt]) is nn.Dropout:
+                if modules[nxt].p != 0 and modules[nxt].training:
+                    if modules[nxt].p >= 1:
+                        break                                   # p == 1 zeroes everything: left to the module loop (no scale exists)
+                    keep *= 1.0 - modules[nxt].p                # consecutive dropouts: one mask of the joint keep probability
                 nxt += 1
             run.append((modules[i], act))
+            drops.append(1.0 - keep)
             i = nxt
+        run.drops, run.site0 = tuple(drops), start
         return i, run
 
     @staticmethod
@@ -474,7 +481,7 @@ class SequentialWithRecurrent(nn.Sequential):
         bf16 mode with a 1-dimensional target (the README F0Model shape) - the case mg_f0_tail_bf16 fuses; else None."""
         modules = list(self._modules.values())
         end, run = self._linear_run(modules, 0)
-        if end != len(modules) or len(run) < 3 or precision != 'bf16' or targets.shape[-1] != 1:
+        if end != len(modules) or len(run) < 3 or precision != 'bf16' or targets.shape[-1] != 1 or any(run.drops):
             return None
         dims = [lin.weight.shape for lin, _ in run]
         acts = tuple(act for _, act in run)
@@ -537,7 +544,7 @@ class SequentialWithRecurrent(nn.Sequential):
                     params = []
                     for lin, _ in run:
                         params += [lin.weight, lin.bias]
-                    spec = (tuple(act for _, act in run), precision)
+                    spec = (tuple(act for _, act in run), precision, 0, False, run.drop_spec())
                     packed = F_hip.LinearStackFn.apply(spec, input.reshape(-1, input.shape[-1]), layout.rows, *params)
                     input = layout.unpack(packed)
                     zero_padded = False
@@ -547,7 +554,8 @@ class SequentialWithRecurrent(nn.Sequential):
                 nxt = modules[end] if end < len(modules) else None
                 n_src = input.source.shape[0] * input.source.shape[1] if isinstance(input, UpsampledSequence) else 0
                 if (isinstance(input, UpsampledSequence) and isinstance(nxt, RecurrentCuDNNWrapper) and nxt._hip_gru()
-                        and seq_len is not None and ops.phone_rate_gru_ok(n_src, input.rows.numel(), run[-1][0].weight.shape[0], input.phone_rate)):
+                        and seq_len is not None and not any(run.drops)         # a frame's dropout mask is its own: no phone-rate form
+                        and ops.phone_rate_gru_ok(n_src, input.rows.numel(), run[-1][0].weight.shape[0], input.phone_rate)):
                     # Linear / Sigmoid commute with the row repetition of the upsample: run them on the phone rows (+ zero rows for
                     # the padding frames) and hand the GRU wrapper a table + row map; it repeats the rows of its own input projection
                     params = []
@@ -558,7 +566,7 @@ class SequentialWithRecurrent(nn.Sequential):
                     input = PhoneTable(table, input.rows, n_src, maps=input.phone_maps())
                     i = end
                     continue
-                if (isinstance(input, UpsampledSequence) and end == len(modules)
+                if (isinstance(input, UpsampledSequence) and end == len(modules) and not any(run.drops)
                         and ops.phone_rate_gru_ok(n_src, input.rows.numel(), 8, input.phone_rate)):
                     # the stack ends in this run and sees nothing but the repeated phone rows: every layer commutes with the
                     # repetition, so the run works on the phone rows (+ zero rows for padding frames) and its OUTPUT is repeated
@@ -583,7 +591,7 @@ class SequentialWithRecurrent(nn.Sequential):
                 for lin, _ in run:
                     params += [lin.weight, lin.bias]
                 # rows here is the frame map of upsample_to_repetitions: runs of equal indices (a hint for the layer-1 loader)
-                spec = (tuple(act for _, act in run), precision, 0, rows is not None)
+                spec = (tuple(act for _, act in run), precision, 0, rows is not None, run.drop_spec())
                 out = F_hip.LinearStackFn.apply(spec, x2d, rows, *params)
                 input = out.view(*lead, out.shape[-1])
                 i = end
@@ -649,15 +657,32 @@ class SequentialWithRecurrent(nn.Sequential):
                 shape = input.shape
                 input = _SigmoidFn.apply(input.reshape(-1)).view(shape)
                 zero_padded = False
+            elif type(module) is nn.Dropout:
+                identity = module.p == 0 or not module.training
+                if not identity and module.p < 1:
+                    # active dropout outside a Linear run (between the recurrent wrappers of models/f0_test_model.py:31-43): the HIP
+                    # mask kernel, regenerated in the backward - never torch's nn.Dropout kernel
+                    input = F_hip.DropoutFn.apply(input, float(module.p), i)
+                elif not identity:
+                    input = input * 0.0                               # p == 1: everything dropped (torch's result)
+                zero_padded = zero_padded                             # zero rows stay zero under any mask
             else:
-                identity = type(module) is nn.Dropout and (module.p == 0 or not module.training)
-                input = input if identity else module(input)
-                zero_padded = zero_padded and identity
+                input = module(input)
+                zero_padded = False
             i += 1
 
         if isinstance(input, (UpsampledSequence, UpsampledConcat)):
             input = input.materialise()
         return input, hiddens
+
+
+class _Run(list):
+    """[(linear, act), ...] of ``SequentialWithRecurrent._linear_run`` plus ``drops`` (dropout probability behind each layer) and
+    ``site0`` (index of the run's first module: numbers the dropout masks)."""
+    drops, site0 = (), 0
+
+    def drop_spec(self):
+        return (self.drops, self.site0) if any(self.drops) else None
 
 
 class _SigmoidFn(torch.autograd.Function):
