@@ -631,7 +631,7 @@ def other_workloads(dev, precision):
     headline - 5 eager steps after 2 warm-up steps each - so that their numbers are driver-timed as well (C4 has its own leg)."""
     out = {}
     specs = [
-        ('c5', 'C5: RNN_SPSS Linear-512 / GRU-512 / Linear-256 / 187, 64 utterances of 300-2000 frames (packed frames)',
+        ('c5', 'C5: RNN_SPSS Linear-512 / GRU-512 / Linear-256 / 187, 64 utterances of 300-2000 frames',
          lambda: (synthetic.make_batch(64, (300, 2000), out_dim=187, target_name='mcep'), models.RNNSPSS(output_dim=187, precision=precision),
                   synthetic.rnn_spss_state(out_dim=187), False)),
         ('lstm', 'shipped LSTM acoustic model 609-512-8xLSTM512-256-199, 64 x 1000 frames, with its per-step MLPG + 4 streaming metrics',
@@ -666,13 +666,20 @@ def other_workloads(dev, precision):
             frames = int(feats_np['n_frames'].sum())
             out[key] = {'workload': what + ', eager launches, %s' % precision, 'ms_per_step': round(ms, 4),
                         'value': round(frames / (ms * 1e-3), 1), 'unit': 'frames/s', **blocks_report(5, 2)}
-            if key == 'c5':                               # the same batch with every row-wise product on all B * T padded rows
+            if key == 'c5':
+                # the same batch (a) with every row-wise product AND the recurrent weight gradients on all B * T padded rows, (b) with
+                # the row-wise runs packed as well (the default packs the recurrent weight gradients only: utils.PACK_ROWS_MIN_PADDING)
                 from morgana_amd import utils as mg_utils
-                mg_utils.set_packed_frames(False)
+                default_min = mg_utils.PACK_ROWS_MIN_PADDING
                 try:
+                    mg_utils.set_packed_frames(False)
                     out[key]['padded_rows_ms_per_step'] = round(timed_leg(step, 5, 2), 4)
+                    mg_utils.set_packed_frames(True, rows_min_padding=0.1)
+                    out[key]['all_runs_packed_ms_per_step'] = round(timed_leg(step, 5, 2), 4)
                 finally:
-                    mg_utils.set_packed_frames(True)
+                    mg_utils.set_packed_frames(True, rows_min_padding=default_min)
+                out[key]['packing'] = ('default: recurrent weight gradients over the valid frames, row-wise runs on the padded rows '
+                                       '(utils.PACK_ROWS_MIN_PADDING = %.2f)' % default_min)
             del model, opt, feats
         except Exception as exc:                          # noqa: BLE001 - a leg that fails is reported, the headline stands
             out[key] = {'error': str(exc).splitlines()[0][:200]}

@@ -116,11 +116,24 @@ class PhoneTable(object):
 PACKED_FRAMES = os.environ.get('MORGANA_PACKED_FRAMES', '1') != '0'
 
 
-def set_packed_frames(enabled):
-    """Row-wise layers behind a recurrent wrapper run on the valid frames of a ragged batch only (``FrameLayout``); off = on all
-    B * T padded rows as the reference does.  Results are the same either way (tests/test_gpu_configs.py)."""
-    global PACKED_FRAMES
+# Row-wise layers behind a recurrent wrapper are packed only when at least this share of the B * T rows is padding.  Measured at C5
+# (64 utterances of 300-2000 frames, 41 % padding; profiles/r4_c5_packed_vs_padded.txt): the packed Linear stack + loss saves 140 us of
+# GEMM / cast time and pays 257 us for the way there and back (unpack gather of the prediction 44, pack of its gradient 32, column
+# sums of the padding rows' gradient 84, zero fill + scatter of the input gradient 97) - a loss of 120 us - while the recurrent
+# layers' weight gradients over the valid frames only (``worthwhile``) win 109 us.  Break-even for the stack is about three
+# quarters padding; the recurrent weight gradients keep the 10 % rule.
+PACK_ROWS_MIN_PADDING = float(os.environ.get('MORGANA_PACK_ROWS_MIN_PADDING', '0.75'))
+
+
+def set_packed_frames(enabled, rows_min_padding=None):
+    """Layers behind a recurrent wrapper may work on the valid frames of a ragged batch only (``FrameLayout``); off = on all B * T
+    padded rows as the reference does.  ``rows_min_padding``: share of padding rows from which the row-wise Linear / Sigmoid runs are
+    packed too (default ``PACK_ROWS_MIN_PADDING``; 0.1 packs them whenever the recurrent layers are).  Results are the same either way
+    (tests/test_gpu_configs.py)."""
+    global PACKED_FRAMES, PACK_ROWS_MIN_PADDING
     PACKED_FRAMES = bool(enabled)
+    if rows_min_padding is not None:
+        PACK_ROWS_MIN_PADDING = float(rows_min_padding)
 
 
 class FrameLayout(object):
@@ -148,8 +161,12 @@ class FrameLayout(object):
         return cls(features[seq_len_key], t, min(int(total), features[seq_len_key].numel() * int(t)))
 
     def worthwhile(self):
-        """Packing costs a gather each way: use it when at least a tenth of the rows are padding."""
+        """The recurrent layers' weight gradients over the valid frames only: when at least a tenth of the rows are padding."""
         return 10 * (self.total + 1) <= 9 * self.b * self.t
+
+    def worthwhile_for_rows(self):
+        """Packing a row-wise run costs a gather each way, the padding rows' column sums and a scatter: see PACK_ROWS_MIN_PADDING."""
+        return self.worthwhile() and (self.total + 1) <= (1.0 - PACK_ROWS_MIN_PADDING) * self.b * self.t
 
     def unpack(self, packed):
         out = F_hip.UnpackRowsFn.apply(packed, self.rows, self.inverse, self.seq_len, self.b, self.t)
@@ -538,7 +555,7 @@ class SequentialWithRecurrent(nn.Sequential):
             if type(module) is nn.Linear:
                 end, run = self._linear_run(modules, i)
                 if (zero_padded and layout is not None and torch.is_tensor(input) and input.ndim == 3 and
-                        tuple(input.shape[:2]) == (layout.b, layout.t) and layout.worthwhile()):
+                        tuple(input.shape[:2]) == (layout.b, layout.t) and layout.worthwhile_for_rows()):
                     # packed frames: the run's GEMMs take sum_b T_b + 1 rows instead of B * T; the first layer's loader (fp32) or one
                     # gather + cast pass (bf16) packs, ``layout.unpack`` restores (B, T, .) with the representative row on the padding
                     params = []

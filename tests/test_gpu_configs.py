@@ -73,13 +73,13 @@ def test_c5_ragged_187_model_vs_oracle(c5_case, precision, packed):
     assert ops.phone_rate_gru_ok(n_rows, b * t, 512), 'C5 test batch misses the phone-rate GRU input'
     if precision == 'bf16':
         assert ops.gru_persist_ok(b, t, 512), 'C5 test batch misses the persistent recurrence'
-    utils.set_packed_frames(packed)
+    utils.set_packed_frames(packed, rows_min_padding=0.1)      # 0.1: the row-wise runs packed too
     try:
         model = _load_state(models.RNNSPSS(output_dim=187, target_name='world', precision=precision).to(DEV), state)
         loss, out = model(data.to_device(feats, DEV))
         loss.backward()
     finally:
-        utils.set_packed_frames(True)
+        utils.set_packed_frames(True, rows_min_padding=0.75)
     pred = out['pred_norm_world'].detach().cpu().numpy()
     assert pred.shape == want_pred.shape
     valid = (np.arange(t)[None, :] < feats['n_frames'][:, None])[:, :, None]
@@ -99,13 +99,13 @@ def test_c5_packed_rows_equal_padded_rows(c5_case):
     valid = torch.from_numpy((np.arange(t)[None, :] < feats['n_frames'][:, None])[:, :, None]).to(DEV)
     results = []
     for packed in (True, False):
-        utils.set_packed_frames(packed)
+        utils.set_packed_frames(packed, rows_min_padding=0.1)      # 0.1: the row-wise runs packed too
         try:
             model = _load_state(models.RNNSPSS(output_dim=187, target_name='world', precision='bf16').to(DEV), state)
             loss, out = model(data.to_device(feats, DEV))
             loss.backward()
         finally:
-            utils.set_packed_frames(True)
+            utils.set_packed_frames(True, rows_min_padding=0.75)
         results.append((loss.detach().clone(), torch.where(valid, out['pred_norm_world'].detach(), torch.zeros((), device=DEV)),
                         {n: p.grad.detach().clone() for n, p in model.named_parameters()}))
     (loss_p, pred_p, grads_p), (loss_d, pred_d, grads_d) = results
@@ -130,14 +130,14 @@ def test_c5_at_its_per_rank_size():
     assert ops.gru_persist_ok(b, t, 512)
 
     def run(batch, packed=True):
-        utils.set_packed_frames(packed)
+        utils.set_packed_frames(packed, rows_min_padding=0.1)      # 0.1: the row-wise runs packed too
         try:
             model = _load_state(models.RNNSPSS(output_dim=187, target_name='world', precision='bf16').to(DEV), state)
             loss, out = model(data.to_device(batch, DEV))
             loss.backward()
             ops.check_persistent_status()              # raises if a persistent launch gave up on a peer
         finally:
-            utils.set_packed_frames(True)
+            utils.set_packed_frames(True, rows_min_padding=0.75)
         tt = batch['normalised_world'].shape[1]
         valid = torch.from_numpy((np.arange(tt)[None, :] < batch['n_frames'][:, None])[:, :, None]).to(DEV)
         pred = torch.where(valid, out['pred_norm_world'].detach(), torch.zeros((), device=DEV))
