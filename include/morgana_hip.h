@@ -586,6 +586,11 @@ int mg_gru_fwd_persist_bf16(const float* xproj, const uint16_t* w_hh_bf, int ldw
 int mg_gru_fwd_persist_rows_bf16(const float* xproj, const int32_t* xrows, int64_t n_rows, const uint16_t* w_hh_bf, int ldw, const float* b_hh,
                                  const int64_t* seq_len, int B, int T, int H, float* hstate, uint16_t* hstate_bf, float* out, float* saved,
                                  void* workspace, size_t workspace_bytes, void* stream);
+/* mg_gru_fwd_persist_rows_bf16 that also writes out_bf (optional, may be NULL): the bf16 copy of `out` [B, T, H] (zero past each item's
+ * length) - the operand of the nn.Linear that follows the wrapper in models/RNN_SPSS.py:38, without a cast pass over [B, T, H]. */
+int mg_gru_fwd_persist_out_bf16(const float* xproj, const int32_t* xrows, int64_t n_rows, const uint16_t* w_hh_bf, int ldw, const float* b_hh,
+                                const int64_t* seq_len, int B, int T, int H, float* hstate, uint16_t* hstate_bf, float* out, uint16_t* out_bf,
+                                float* saved, void* workspace, size_t workspace_bytes, void* stream);
 /* backward: dxproj_bf (optional) = bf16 shadow of dxproj [B,T,3H]; dxproj and dhproj (both or neither) may be NULL when the caller
  * only needs the bf16 shadows (the weight- and input-gradient GEMMs of bf16 mode) - the fp32 arrays are then not written */
 int mg_gru_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const float* hstate, const float* saved,

@@ -128,6 +128,8 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_size_t, c_void_p]),
     'mg_gru_fwd_persist_rows_bf16': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'mg_gru_fwd_persist_out_bf16': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'mg_gru_bwd_persist_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'mg_lstm_persist_supported': (c_int, [c_int, c_int, c_int]),

@@ -264,6 +264,8 @@ class LinearStackFn(torch.autograd.Function):
         # saved for the backward is the one BEFORE the mask (the sigmoid gradient needs it), the masked copy feeds the next layer
         drop = _RunDropout(spec[4], x2d.device) if len(spec) > 4 and spec[4] is not None else None
         ctx.drop = drop
+        # a bf16 copy of x2d somebody already made (the GRU recurrence writes one of its output: GRUFn out_bf): the first layer's operand
+        shadow = spec[5] if len(spec) > 5 else None
         n_layers = len(acts)
         weights = [params[2 * i] for i in range(n_layers)]
         biases = [params[2 * i + 1] for i in range(n_layers)]
@@ -324,6 +326,9 @@ class LinearStackFn(torch.autograd.Function):
                     raise ValueError('LinearStackFn: a gathered input that needs a gradient must be fp32')
                 # pack and cast in one pass: the bf16 operand holds exactly the gathered rows
                 a, rows_k = ops.gather_rows(x2d, rows, out_bf16=True, ld=ops.pad_ld(k_in)), None
+            elif (shadow is not None and not pre_cast and not extra and shadow.dtype == torch.bfloat16 and shadow.is_contiguous()
+                  and tuple(shadow.shape) == (x2d.shape[0], ops.pad_ld(k_in)) and k_in == ops.pad_ld(k_in)):
+                a = shadow
             else:
                 a = x2d if pre_cast else ops.cast_pad_bf16(x2d, extra_rows=extra)
             a0, r = a, rows_k
@@ -947,6 +952,11 @@ def set_recurrence_bf16(enabled):
     RECURRENCE_BF16 = bool(enabled)
 
 
+def gru_shadow_ok(precision, b, t, hid):
+    """Will GRUFn run the launch that can write a bf16 copy of its output (the persistent bf16 recurrence)?"""
+    return precision == 'bf16' and RECURRENCE_BF16 and ops.gru_bf16_ok(hid) and ops.gru_persist_ok(b, t, hid)
+
+
 class GRUFn(torch.autograd.Function):
     """One GRU layer (batch_first) restricted to seq_len[b] steps per item; returns (outputs, h_n).
 
@@ -956,7 +966,7 @@ class GRUFn(torch.autograd.Function):
     weight-gradient and input-gradient GEMMs, which then run on table rows too."""
 
     @staticmethod
-    def forward(ctx, precision, x, h0, seq_len, w_ih, w_hh, b_ih, b_hh, rows=None, seg=None, layout=None):
+    def forward(ctx, precision, x, h0, seq_len, w_ih, w_hh, b_ih, b_hh, rows=None, seg=None, layout=None, out_bf=None):
         x = ops._require(x, torch.float32, 'inputs')
         ctx.layout = layout            # utils.FrameLayout of a ragged batch or None: backward's weight gradients skip the padded frames
         hid = w_hh.shape[1]
@@ -981,13 +991,17 @@ class GRUFn(torch.autograd.Function):
         if rows is not None and not in_kernel:
             xproj = ops.gather_rows(xproj, rows.reshape(-1))          # the repetition, applied to the projected rows
         hstate_bf = None
+        # out_bf (optional, from the caller): a (B, T, H) bf16 buffer the persistent recurrence fills with the bf16 copy of its output -
+        # the operand of a Linear layer behind the wrapper (gru_shadow_ok says when the launch that writes it will run)
+        if out_bf is not None and not gru_shadow_ok(precision, b, t, hid):
+            raise ValueError('GRUFn: out_bf needs the persistent bf16 recurrence')
         if in_kernel:
             # the persistent recurrence reads the projected table through the row map itself: no (B, T, 3H) copy of its rows
             out, hstate, saved, hstate_bf = ops.gru_fwd_bf16(xproj.contiguous(), w_hh.contiguous(), b_hh.contiguous(), seq_len, h0, b, t, hid,
-                                                             xrows=rows)
+                                                             xrows=rows, out_bf=out_bf)
         elif ctx.bf16_recurrence:
             out, hstate, saved, hstate_bf = ops.gru_fwd_bf16(xproj.view(b, t, 3 * hid), w_hh.contiguous(), b_hh.contiguous(),
-                                                             seq_len, h0, b, t, hid)
+                                                             seq_len, h0, b, t, hid, out_bf=out_bf)
         else:
             out, hstate, saved = ops.gru_fwd(xproj.view(b, t, 3 * hid), w_hh.contiguous(), b_hh.contiguous(), seq_len, h0,
                                              b, t, hid)
@@ -1075,7 +1089,7 @@ class GRUFn(torch.autograd.Function):
                 if dx.shape[1] != i_dim:
                     dx = dx[:, :i_dim].contiguous()
                 dx = dx if rows is not None else dx.view(b, t, i_dim)
-        return (None, dx, dh0.view(1, b, hid) if ctx.has_h0 else None, None, dw_ih, dw_hh, db_ih, db_hh, None, None, None)
+        return (None, dx, dh0.view(1, b, hid) if ctx.has_h0 else None, None, dw_ih, dw_hh, db_ih, db_hh, None, None, None, None)
 
 
 def lstm_persistent(precision, b, t, hid):

@@ -1110,8 +1110,9 @@ def check_persistent_status():
         _lib.check(lib.mg_gru_persist_status(_p(ws), ctypes.c_void_p(key[1])), 'mg_gru_persist_status')
 
 
-def gru_fwd_bf16(xproj, w_hh, b_hh, seq_len, h0, b, t, h, persistent=None, xrows=None):
+def gru_fwd_bf16(xproj, w_hh, b_hh, seq_len, h0, b, t, h, persistent=None, xrows=None, out_bf=None):
     """gru_fwd with bf16 matmul operands.  Returns (out, hstate, saved, hstate_bf (b,t+1,h) bf16).
+    out_bf (persistent launch only): a (b, t, h) bf16 tensor that receives the bf16 copy of ``out`` from the recurrence itself.
     persistent: one launch for all steps (None = whenever the shape is covered).
     xrows (persistent launch only): int32 (b, t) row map - ``xproj`` is then a table (rows, 3h) and frame (b, t) takes row
     ``xrows[b, t]`` of it (mg_gru_fwd_persist_rows_bf16: the repetition applied inside the recurrence)."""
@@ -1120,6 +1121,8 @@ def gru_fwd_bf16(xproj, w_hh, b_hh, seq_len, h0, b, t, h, persistent=None, xrows
         persistent = gru_persist_ok(b, t, h)
     if xrows is not None and not persistent:
         raise ValueError('gru_fwd_bf16: a row map needs the persistent launch (gather the rows first)')
+    if out_bf is not None and (not persistent or out_bf.dtype != torch.bfloat16 or tuple(out_bf.shape) != (b, t, h) or not out_bf.is_contiguous()):
+        raise ValueError('gru_fwd_bf16: out_bf must be a contiguous (b, t, h) bfloat16 tensor and needs the persistent launch')
     dev = xproj.device
     hstate = torch.empty((b, t + 1, h), dtype=torch.float32, device=dev)
     hstate_bf = torch.empty((b, t + 1, h), dtype=torch.bfloat16, device=dev)
@@ -1138,13 +1141,13 @@ def gru_fwd_bf16(xproj, w_hh, b_hh, seq_len, h0, b, t, h, persistent=None, xrows
             xrows = _require(xrows, torch.int32, 'xrows')
             if xrows.numel() != b * t or xproj.ndim != 2 or xproj.shape[1] != 3 * h:
                 raise ValueError('gru_fwd_bf16: row map of %d entries / table %s for b=%d t=%d h=%d' % (xrows.numel(), tuple(xproj.shape), b, t, h))
-            _lib.check(lib.mg_gru_fwd_persist_rows_bf16(_p(xproj), _p(xrows), xproj.shape[0], _p(w_bf), w_bf.shape[1], _p(b_hh), _p(seq_len),
-                                                        b, t, h, _p(hstate), _p(hstate_bf), _p(out), _p(saved), _p(ws), ws.numel(), _stream()),
-                       'mg_gru_fwd_persist_rows_bf16')
+            _lib.check(lib.mg_gru_fwd_persist_out_bf16(_p(xproj), _p(xrows), xproj.shape[0], _p(w_bf), w_bf.shape[1], _p(b_hh), _p(seq_len),
+                                                       b, t, h, _p(hstate), _p(hstate_bf), _p(out), _p(out_bf), _p(saved), _p(ws), ws.numel(),
+                                                       _stream()), 'mg_gru_fwd_persist_out_bf16')
             return out, hstate, saved, hstate_bf
-        _lib.check(lib.mg_gru_fwd_persist_bf16(_p(xproj), _p(w_bf), w_bf.shape[1], _p(b_hh), _p(seq_len), b, t, h, _p(hstate),
-                                               _p(hstate_bf), _p(out), _p(saved), _p(ws), ws.numel(), _stream()),
-                   'mg_gru_fwd_persist_bf16')
+        _lib.check(lib.mg_gru_fwd_persist_out_bf16(_p(xproj), None, 0, _p(w_bf), w_bf.shape[1], _p(b_hh), _p(seq_len), b, t, h, _p(hstate),
+                                                   _p(hstate_bf), _p(out), _p(out_bf), _p(saved), _p(ws), ws.numel(), _stream()),
+                   'mg_gru_fwd_persist_out_bf16')
     else:
         _lib.check(lib.mg_gru_fwd_bf16(_p(xproj), _p(w_bf), w_bf.shape[1], _p(b_hh), _p(seq_len), b, t, h, _p(hstate), _p(hstate_bf),
                                        _p(out), _p(saved), _stream()), 'mg_gru_fwd_bf16')

@@ -114,6 +114,7 @@ class PhoneTable(object):
 
 
 PACKED_FRAMES = os.environ.get('MORGANA_PACKED_FRAMES', '1') != '0'
+OUT_SHADOW = os.environ.get('MORGANA_OUT_SHADOW', '1') != '0'      # the persistent GRU writes the bf16 copy of its output (A/B switch)
 
 
 # Row-wise layers behind a recurrent wrapper are packed only when at least this share of the B * T rows is padding.  Measured at C5
@@ -347,12 +348,28 @@ class RecurrentCuDNNWrapper(nn.Module):
             seg, rows = inputs.maps()
             if layout is not None and (tuple(inputs.rows.shape) != (layout.b, layout.t) or not layout.worthwhile()):
                 layout = None
-            return F_hip.GRUFn.apply(precision, inputs.table, hidden, seq_len, layer.weight_ih_l0, layer.weight_hh_l0,
-                                     layer.bias_ih_l0, layer.bias_hh_l0, rows.view(inputs.rows.shape), seg, layout)
+            out_bf = self._out_shadow(precision, inputs.rows.shape[0], inputs.rows.shape[1], inputs.table.device)
+            out, hn = F_hip.GRUFn.apply(precision, inputs.table, hidden, seq_len, layer.weight_ih_l0, layer.weight_hh_l0,
+                                        layer.bias_ih_l0, layer.bias_hh_l0, rows.view(inputs.rows.shape), seg, layout, out_bf)
+            if out_bf is not None:
+                out._mg_bf16 = out_bf
+            return out, hn
         if layout is not None and (tuple(inputs.shape[:2]) != (layout.b, layout.t) or not layout.worthwhile()):
             layout = None
-        return F_hip.GRUFn.apply(precision, inputs, hidden, seq_len, layer.weight_ih_l0, layer.weight_hh_l0,
-                                 layer.bias_ih_l0, layer.bias_hh_l0, None, None, layout)
+        out_bf = self._out_shadow(precision, inputs.shape[0], inputs.shape[1], inputs.device)
+        out, hn = F_hip.GRUFn.apply(precision, inputs, hidden, seq_len, layer.weight_ih_l0, layer.weight_hh_l0,
+                                    layer.bias_ih_l0, layer.bias_hh_l0, None, None, layout, out_bf)
+        if out_bf is not None:
+            out._mg_bf16 = out_bf
+        return out, hn
+
+    def _out_shadow(self, precision, b, t, device):
+        """A (B, T, H) bf16 buffer for the recurrence to fill with the bf16 copy of its output (the operand of a Linear layer that
+        follows the wrapper: no cast pass over [B, T, H]) - when the persistent bf16 recurrence will run and the width needs no padding."""
+        hid = self.layer.hidden_size
+        if OUT_SHADOW and hid == ops.pad_ld(hid) and F_hip.gru_shadow_ok(precision, b, t, hid):
+            return torch.empty((b, t, hid), dtype=torch.bfloat16, device=device)
+        return None
 
     def _unsupported(self):
         layer = self.layer
@@ -608,7 +625,9 @@ class SequentialWithRecurrent(nn.Sequential):
                 for lin, _ in run:
                     params += [lin.weight, lin.bias]
                 # rows here is the frame map of upsample_to_repetitions: runs of equal indices (a hint for the layer-1 loader)
-                spec = (tuple(act for _, act in run), precision, 0, rows is not None, run.drop_spec())
+                shadow = getattr(input, '_mg_bf16', None) if (torch.is_tensor(input) and precision == 'bf16') else None
+                spec = (tuple(act for _, act in run), precision, 0, rows is not None, run.drop_spec(),
+                        shadow.view(-1, shadow.shape[-1]) if shadow is not None else None)
                 out = F_hip.LinearStackFn.apply(spec, x2d, rows, *params)
                 input = out.view(*lead, out.shape[-1])
                 i = end
