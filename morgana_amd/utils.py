@@ -114,7 +114,11 @@ class PhoneTable(object):
 
 
 PACKED_FRAMES = os.environ.get('MORGANA_PACKED_FRAMES', '1') != '0'
-OUT_SHADOW = os.environ.get('MORGANA_OUT_SHADOW', '1') != '0'      # the persistent GRU writes the bf16 copy of its output (A/B switch)
+# The persistent GRU forward can write the bf16 copy of its output itself (mg_gru_fwd_persist_out_bf16), which saves the cast pass of the
+# Linear run behind the wrapper (C4 37 us, C5 98 us).  MEASURED (round 4, same-box A/B) and OFF: the 2-byte stores ride in the
+# recurrence's per-step store traffic and cost the chain more than the cast saved - C5 6.541 / 6.546 against 6.486 / 6.510 ms, C4
+# 3.445 / 3.358 against 3.394 / 3.401.
+OUT_SHADOW = os.environ.get('MORGANA_OUT_SHADOW', '0') != '0'
 
 
 # Row-wise layers behind a recurrent wrapper are packed only when at least this share of the B * T rows is padding.  Measured at C5
