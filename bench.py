@@ -250,7 +250,7 @@ def roofline_f0(features, model, precision):
     # HBM bytes per launch of the dominant kernel from the committed PMC passes of this round (scripts/gpu_profile.sh:
     # 2 x FETCH_SIZE + WRITE_SIZE on gfx950, MI355X_MICROARCH.md), and the bytes the launch has to move at the very least
     traffic = traffic_source = None
-    for table_name in (('r3_hbm_traffic.json', 'r2_hbm_traffic.json') if ops.PHONE_RATE else ('r3fr_hbm_traffic.json', 'r2fr_hbm_traffic.json')):
+    for table_name in (('r4_hbm_traffic.json', 'r3_hbm_traffic.json') if ops.PHONE_RATE else ('r4fr_hbm_traffic.json', 'r3fr_hbm_traffic.json')):
         try:
             table = json.load(open(os.path.join(REPO, 'profiles', table_name)))
             if table.get(short) is not None:
