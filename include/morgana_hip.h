@@ -423,6 +423,9 @@ typedef struct {
     int order;        /* 0: hi | hi | lo;  1: hi | lo | hi;  2: two planes [hi ; lo] of [plane_rows, ldp] */
     int transpose;
     int64_t plane_rows; /* order 2: rows of one plane in dst (>= rows; the caller owns the rows behind the split, e.g. zeros); 0 = rows */
+    const float* sig; /* optional (not transposed): fp32 [rows, cols] (ldsig) sigmoid outputs s - the split is taken of src * s * (1 - s):
+                       * the sigmoid gradient of autograd (README.rst:65-73's nn.Sigmoid) fused into the split of the gradient */
+    int ldsig;
 } mg_split3_desc;
 int mg_split3_bf16(const mg_split3_desc* descs, int count, void* stream);
 /* Active dropout (nn.Dropout(p) of the shipped models in training mode: /root/reference/models/RNN_SPSS.py:19,34,40,

@@ -53,6 +53,15 @@ __global__ __launch_bounds__(256) void split3_kernel(Split3Batch batch) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x[e] = c0 + e < d.cols ? src[e] : 0.f;
             }
+            if (d.sig) {                                   // the sigmoid gradient, fused: x <- x s (1 - s)  (the product order of sigmoid_grad_kernel)
+                const float* sg = d.sig + (size_t)r * d.ldsig + c0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (c0 + e < d.cols) {
+                        const float s = sg[e];
+                        x[e] = x[e] * s * (1.f - s);
+                    }
+            }
             uint16_t hi[8], lo[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) split_pair(x[e], hi[e], lo[e]);
@@ -111,6 +120,7 @@ int mg_split3_bf16(const mg_split3_desc* descs, int count, void* stream) {
     for (int i = 0; i < count; ++i) {
         const mg_split3_desc& d = descs[i];
         MG_CHECK_ARG(d.src && d.dst && d.rows > 0 && d.cols > 0 && d.lds >= d.cols, "mg_split3_bf16: bad descriptor %d", i);
+        MG_CHECK_ARG(!d.sig || (!d.transpose && d.ldsig >= d.cols), "mg_split3_bf16: descriptor %d: a fused sigmoid gradient goes with the plain layouts and needs ldsig >= cols", i);
         MG_CHECK_ARG(d.order == 0 || d.order == 1 || (d.order == 2 && !d.transpose),
                      "mg_split3_bf16: descriptor %d: order %d is none of 0 (hi|hi|lo), 1 (hi|lo|hi), 2 (separate planes hi ; lo, not transposed)", i, d.order);
         MG_CHECK_ARG(d.plane_rows == 0 || (d.order == 2 && d.plane_rows >= d.rows), "mg_split3_bf16: descriptor %d: plane_rows %lld goes with order 2 and must cover the %lld rows", i, (long long)d.plane_rows, (long long)d.rows);

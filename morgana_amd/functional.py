@@ -400,6 +400,7 @@ class LinearStackFn(torch.autograd.Function):
             dgrad_of = [i for i in range(n_layers) if split[i] and (i > 0 or need_x)]
             wt3_list = ops.x3_weight_operands([w_params[i] for i in dgrad_of], want_t=tuple(range(len(dgrad_of))))[1]
             wt3s = dict(zip(dgrad_of, wt3_list))
+            sig = None        # sigmoid outputs whose gradient factor s (1 - s) g still lacks: fused into the next split of g (one pass less)
             for i in range(n_layers - 1, -1, -1):
                 n, k = ctx.dims[i]
                 a_in, r = (x_in, rows) if i == 0 else (masked_input(i), None)
@@ -411,7 +412,9 @@ class LinearStackFn(torch.autograd.Function):
                         grad_x = ops.linear_dgrad_f32(g, weights[0], None)
                     continue
                 need_g3 = i > 0 or need_x
-                parts = ops.split3([(g, 2, False), (a_in, 2, False, ctx.x3_extra if i == 0 else 0)] + ([(g, 0, False)] if need_g3 else []))
+                parts = ops.split3([(g, 2, False, 0, sig), (a_in, 2, False, ctx.x3_extra if i == 0 else 0)] +
+                                   ([(g, 0, False, 0, sig)] if need_g3 else []))
+                sig = None
                 g2, a2, g3 = parts[0], parts[1], (parts[2] if need_g3 else None)
                 if direct:
                     ops.linear_wgrad_x3(g2, a2, r, m, n, k, out_w=w_params[i].grad, out_b=b_params[i].grad, accumulate=True)
@@ -419,10 +422,12 @@ class LinearStackFn(torch.autograd.Function):
                     dw, db = ops.linear_wgrad_x3(g2, a2, r, m, n, k)
                     grads[2 * i], grads[2 * i + 1] = dw, (db if ctx.has_bias[i] else None)
                 if i > 0:
-                    g = ops.linear_dgrad_x3(g3, m, wt3s[i], k)
+                    g = unmask(ops.linear_dgrad_x3(g3, m, wt3s[i], k), i - 1)
                     if acts[i - 1] == ops.ACT_SIGMOID:
-                        g = ops.sigmoid_grad(g, hidden[i - 1])
-                    g = unmask(g, i - 1)
+                        if split[i - 1]:
+                            sig = hidden[i - 1]             # layer i - 1 splits g next: the sigmoid gradient rides in that pass
+                        else:
+                            g = ops.sigmoid_grad(g, hidden[i - 1])
                 elif need_x:
                     grad_x = ops.linear_dgrad_x3(g3, m, wt3s[0], k)
         else:

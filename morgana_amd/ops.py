@@ -745,6 +745,9 @@ def split3(jobs):
         for j, job in enumerate(chunk):
             x, order, transpose = job[:3]
             extra = int(job[3]) if len(job) > 3 else 0          # zero rows appended behind the split (not with transpose)
+            sig = job[4] if len(job) > 4 else None              # fp32 sigmoid outputs of x's shape: split x * s * (1 - s) instead of x
+            if sig is not None and (transpose or sig.dtype != torch.float32 or tuple(sig.shape) != tuple(x.shape) or sig.stride(1) != 1):
+                raise ValueError('split3: the fused sigmoid gradient needs an fp32 tensor of the operand\'s shape (plain layouts)')
             if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
                 raise TypeError('split3: operands must be 2-D float32 with unit column stride')
             if extra and transpose:
@@ -758,6 +761,7 @@ def split3(jobs):
             descs[j].src, descs[j].rows, descs[j].cols, descs[j].lds = x.data_ptr(), rows, cols, x.stride(0)
             descs[j].dst, descs[j].ldp, descs[j].order, descs[j].transpose = out.data_ptr(), ldp, int(order), int(bool(transpose))
             descs[j].plane_rows = rows + extra if order == 2 else 0
+            descs[j].sig, descs[j].ldsig = (sig.data_ptr(), sig.stride(0)) if sig is not None else (None, 0)
             outs.append(out)
         if chunk:
             _lib.check(lib.mg_split3_bf16(ctypes.cast(descs, ctypes.c_void_p), len(chunk), _stream()), 'mg_split3_bf16')

@@ -1004,6 +1004,11 @@ def test_split3_planes(rows, cols, lds_extra):
     p2 = ops.split3([(x, 2, False)])[0]
     assert tuple(p2.shape) == (2, rows, ldp)
     assert torch.equal(p2[0, :, :cols], hi) and torch.equal(p2[1, :, :cols], lo) and not bool(p2[:, :, cols:].any())
+    # the fused sigmoid gradient: the split of x * s * (1 - s), bit for bit the separate pass followed by the split
+    s = torch.sigmoid(dev(rng.standard_normal((rows, cols)).astype(np.float32)))
+    y = ops.sigmoid_grad(x.contiguous(), s)
+    fused, plain = ops.split3([(x, 2, False, 0, s)])[0], ops.split3([(y, 2, False)])[0]
+    assert torch.equal(fused, plain)
     ldt = ops.pad_ld(rows)
     for q, want in enumerate((hi, lo, hi)):
         assert torch.equal(t3[:, q * ldt:q * ldt + rows], want.t())
