@@ -286,7 +286,18 @@ __global__ __launch_bounds__(256, 1) void f0_l2tail_kernel(const uint16_t* __res
                 acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j % (LT_AHEAD + 1)][blk], __builtin_bit_cast(bfv8, hv), acc[blk], 0, 0, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            if (j == 15) {                                   // the registers just consumed take the next tile's first half
+            if (PROBE & 256) {
+                // EXPERIMENT (lab builds, MG_TUNE_AB = 68; results valid): rolling prefetch - the register step j has just read takes the
+                // NEXT tile's step j at once, so that the row loads go out all through the MFMA phase instead of as two bulk issues
+                // at j = 15 and j = 31 (the probes say the phases add: loads 25 + MFMAs 9 + tail 29 us of a 92 us launch).  MEASURED
+                // SLOWER: 99.9 against 89.8 us in kbench_l2tail.py, the C2 frame-rate step 0.5150-0.5158 against 0.5126-0.5137 ms
+                int64_t mm = first_row(next) + mi;
+                if (mm > M - 1) mm = M - 1;
+                const uint16_t* hp = H1 + (size_t)mm * ldh1 + 256 * (j >> 4) + 32 * lh + 64 * ((j & 15) >> 2) + 8 * (j & 3);
+                if (j < 16) ha[j & 15] = *reinterpret_cast<const u32x4*>(hp);
+                else hb[j & 15] = *reinterpret_cast<const u32x4*>(hp);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            } else if (j == 15) {                            // the registers just consumed take the next tile's first half
                 load_half_p(ha, next, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 16, 0);
             }
@@ -294,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void f0_l2tail_kernel(const uint16_t* __res
 #ifdef MG_STAMPS
         if (tb == 0) MG_STAMP(tb);
 #endif
-        load_half_p(hb, next, 1);
+        if (!(PROBE & 256)) load_half_p(hb, next, 1);
         if (PROBE & 2) {
 #pragma unroll
             for (int blk = 0; blk < 4; ++blk)
@@ -889,6 +900,405 @@ __global__ __launch_bounds__(512, 2) void f0_l2tail_split_kernel(const uint16_t*
 }
 #endif  // MG_EXPERIMENTS
 
+
+#ifdef MG_EXPERIMENTS
+// ---------------------------------------------------------------------------------------------------------------------
+// EXPERIMENT (lab builds only; round 4; MG_TUNE_AB = 67): the same pass on the 16x16x32 MFMA shape.  MEASURED EQUAL TO SLOWER - in the
+// C2 frame-rate step 0.5153-0.5186 ms against 0.5126-0.5137 for the kernel above (same box, three alternating runs), 98.4 against
+// 89.8 us in scripts/kbench_l2tail.py - and kept as evidence: the hypothesis it tests is false.  The hypothesis: f0_l2tail_kernel is a stream (48 us of H1 at C2, 53 with the layer-2
+// MFMAs) plus a DEPENDENT CHAIN per 32-frame tile that nothing covers on a wave without a partner (13,000 cycles for ~5,000 of
+// issue: eight dependent 32x32x16 MFMAs for Z3, per 32-unit slice two more dependent ones in front of the dZ2 arithmetic, three LDS
+// round trips).  A second wave per SIMD does not fit (256 registers: DESIGN.md R4.1).  On 16 x 16 blocks the same tile is TWO
+// independent 16-frame sub-tiles per wave iteration - a lane owns frame f of each and 4 consecutive units of every 16-unit block -
+// so every step of the chain exists twice, independently (the scheduler interleaves them), and the chains themselves get
+// shorter: Z3 is 2 unit blocks x 4 dependent k-steps (it was 8 dependent MFMAs), dH2^T = W3^T dZ3^T is ONE 32-deep MFMA per
+// 16-unit block, all eight independent (K = the 32 units of Z3 is exactly one k-step), and dW3 += dZ3^T H2 contracts over the 32
+// frames of both sub-tiles in one k-step per block.  Same LDS map, same W2 image and swizzle (conflict free for the 16-row A
+// operand: chunk (4 s + g) ^ u over u = 0..15, g = 0..3 hits 16 different 16-byte bank groups per ds_read_b128 lane group), same
+// W2 bytes per FLOP (a fragment feeds both sub-tiles), same arithmetic up to the summation order inside the dot products.
+//   lane l = (f, g) = (l & 15, l >> 4); C^T block of 16 units x 16 frames: register r <-> unit 16 ub + 4 g + r, frame f.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bfv8 l16_tr_frag(const unsigned char* tile, int lane, int cb, bool swz) {
+    // 16x16x32 operand whose contraction index is the LDS row (32 rows x 64 B): lane group G = lane >> 4 takes contraction rows
+    // 8 G .. 8 G + 7 (two 4 x 16 blocks, ds_read_b64_tr_b16 each), lane i = lane & 15 receives column 16 cb + i; lane 4 q + p of a
+    // group supplies the address of row q, columns 4 p .. 4 p + 3 of the block.
+    const int i = lane & 15, G = lane >> 4;
+    const int q = i >> 2, p = i & 3;
+    const int row0 = 8 * G + q;
+    const int col = 16 * cb + 4 * p;
+    const int c = col >> 3, in = (col & 7) << 1;
+    const int c_lo = swz ? (c ^ ((row0 >> 2) & 3)) : c;
+    const int c_hi = swz ? (c ^ (((row0 + 4) >> 2) & 3)) : c;
+    const bfv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(tile + row0 * 64 + ((c_lo << 4) | in)));
+    const bfv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(tile + (row0 + 4) * 64 + ((c_hi << 4) | in)));
+    return bfv8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__global__ __launch_bounds__(256, 1) void f0_l2tail16_kernel(const uint16_t* __restrict__ H1, int ldh1, const uint16_t* __restrict__ W2,
+                                                             int ldw2, const float* __restrict__ b2, const float* __restrict__ W3,
+                                                             const float* __restrict__ b3, const float* __restrict__ W4,
+                                                             const float* __restrict__ b4, const float* __restrict__ target,
+                                                             const int64_t* __restrict__ seq_len, int64_t M, int B, int T,
+                                                             float grad_scale, float* __restrict__ pred, uint16_t* __restrict__ dZ2,
+                                                             int lddz, float* __restrict__ slab, const float* __restrict__ row_weight, int rev) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LT_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f = lane & 15, g = lane >> 4;
+
+    // ---- the two W3 fragment tables, gathered straight from W3 (fp32 [32][128]): two fragments of each per thread -----------------
+    f32x4 w3a[2][2];
+    float w3b[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int fr = tid + 256 * i, l = fr & 63, u = l & 15, gg = l >> 4, q = (fr >> 6) & 7;
+        // Z3 fragment [ob = q >> 2][s3 = q & 3][lane l]: element j = W3[16 ob + u][32 s3 + (j < 4 ? 4 gg + j : 16 + 4 gg + j - 4)]
+        const float* zr = W3 + (16 * (q >> 2) + u) * LT_N2 + 32 * (q & 3) + 4 * gg;
+        w3a[i][0] = *reinterpret_cast<const f32x4*>(zr);
+        w3a[i][1] = *reinterpret_cast<const f32x4*>(zr + 16);
+        // dH2 fragment [ub = q][lane l]: element j = W3[j < 4 ? 4 gg + j : 16 + 4 gg + j - 4][16 ub + u]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w3b[i][j] = W3[((j < 4 ? 0 : 12) + 4 * gg + j) * LT_N2 + 16 * q + u];
+    }
+    const float b2v = tid < LT_N2 ? b2[tid] : 0.f;
+    unsigned char* patch = smem + LT_WAVE0 + wave * LT_WAVE_BYTES;
+
+    float b3v[2][4], w4v[2][4];                            // [ob][r] <-> unit 16 ob + 4 g + r of the 32-wide layer
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            b3v[ob][r] = b3[16 * ob + 4 * g + r];
+            w4v[ob][r] = W4[16 * ob + 4 * g + r];
+        }
+    const float b4v = b4[0];
+
+    f32x4 acc_w3[2][8];                                    // dW3 block (nb, ubk): row 16 nb + 4 g + r, column 16 ubk + f
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc_w3[nb][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dw4p[2][4], db3p[2][4];
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dw4p[ob][r] = db3p[ob][r] = 0.f;
+    float db4p = 0.f, lossp = 0.f;
+
+    const int64_t n_tiles = (M + 31) / 32;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    auto first_row = [&](int64_t t) -> int64_t { return (rev ? (t < n_tiles ? n_tiles - 1 - t : 0) : t) * 32; };
+    // H1 operand registers: k-steps 0-7 of both sub-tiles in h0, 8-15 in h1 (entry 2 s' + t); a lane's 16 bytes of k-step s are
+    // bytes [64 s + 16 g, + 16) of its frame's row - the four lanes of a frame read 64 contiguous bytes per instruction
+    auto load_half = [&](u32x4 (&dst)[16], int64_t tile_, int half) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            int64_t mm = first_row(tile_) + 16 * t + f;
+            if (mm > M - 1) mm = M - 1;                     // rows past the end: any valid row (their results are discarded)
+            const uint16_t* hp = H1 + (size_t)mm * ldh1 + 256 * half + 8 * g;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) dst[2 * s + t] = *reinterpret_cast<const u32x4*>(hp + 32 * s);
+        }
+    };
+    auto load_scalars = [&](int64_t tile_, int t, float& tg, float& s1, float& s2) {
+        int64_t mm = first_row(tile_) + 16 * t + f;
+        if (mm > M - 1) mm = M - 1;
+        tg = target[mm];
+        if (row_weight) {
+            s1 = row_weight[mm];
+            s2 = 0.f;
+        } else {
+            const unsigned mu = (unsigned)mm, b = mu / (unsigned)T, tt = mu - b * (unsigned)T;     // M < 2^31 (checked by the launcher)
+            int64_t nb = seq_len ? seq_len[b] : (int64_t)T;
+            if (nb > T) nb = T;
+            if (nb < 0) nb = 0;
+            s1 = (int64_t)tt < nb ? 1.f : 0.f;
+            s2 = (float)nb;
+        }
+    };
+
+    f32x4 acc[2][8];
+    auto bias_acc = [&]() {
+#pragma unroll
+        for (int ub = 0; ub < 8; ++ub) {
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(smem + LT_B2 + (16 * ub + 4 * g) * 4);
+            acc[0][ub] = bq;
+            acc[1][ub] = bq;
+        }
+    };
+    float* const pred_sink = reinterpret_cast<float*>(g_lt_sink) + lane;
+    uint16_t* const dz_sink = reinterpret_cast<uint16_t*>(g_lt_sink) + lane * 8;
+
+    // dZ2 / pred of a tile are stored at the top of the NEXT iteration, in front of that iteration's prefetch (as the kernel above)
+    u32x4 dzst[2][4];
+    uint16_t* dzp[2] = {dz_sink, dz_sink};
+    float* predp[2] = {pred_sink, pred_sink};
+    float pst[2] = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dzst[t][j] = u32x4{0u, 0u, 0u, 0u};
+
+    u32x4 h0[16], h1[16];
+    float tg_n[2] = {0.f, 0.f}, s1_n[2] = {0.f, 0.f}, s2_n[2] = {0.f, 0.f};
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile < n_tiles) {
+        load_scalars(tile, 0, tg_n[0], s1_n[0], s2_n[0]);
+        load_scalars(tile, 1, tg_n[1], s1_n[1], s2_n[1]);
+        load_half(h0, tile, 0);
+        load_half(h1, tile, 1);
+    }
+    // ---- one-time: W2 by LDS-DMA (position p of row n holds chunk p ^ (n & 15)), b2, the fragment tables -------------------------
+    {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int n = wave * 32 + i;
+            mg_glds16(W2 + (size_t)n * ldw2 + ((lane ^ (n & 15)) << 3), smem + LT_W2 + n * (LT_K * 2));
+        }
+        if (tid < LT_N2) *reinterpret_cast<float*>(smem + LT_B2 + tid * 4) = b2v;
+        typedef __bf16 bfv2_ __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int fr = tid + 256 * i;
+            auto pk = [](float a, float b) { return __builtin_bit_cast(unsigned int, bfv2_{(__bf16)a, (__bf16)b}); };
+            *reinterpret_cast<u32x4*>(smem + LT_ZF + fr * 16) =
+                u32x4{pk(w3a[i][0][0], w3a[i][0][1]), pk(w3a[i][0][2], w3a[i][0][3]), pk(w3a[i][1][0], w3a[i][1][1]), pk(w3a[i][1][2], w3a[i][1][3])};
+            *reinterpret_cast<u32x4*>(smem + LT_ZF + (512 + fr) * 16) =
+                u32x4{pk(w3b[i][0], w3b[i][1]), pk(w3b[i][2], w3b[i][3]), pk(w3b[i][4], w3b[i][5]), pk(w3b[i][6], w3b[i][7])};
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's rows of W2 have landed (the compiler does not count the DMAs)
+        __syncthreads();
+    }
+    bias_acc();
+
+    // W2 fragment of k-step s, unit block ub: row 16 ub + f, chunk 4 s + g at position (4 s + g) ^ f
+    const int w2_lane = LT_W2 + f * (LT_K * 2);
+    const int xlow = (g ^ (f & 3)) << 4, fh = f >> 2;
+    auto w2frag = [&](int s, int ub) -> bfv8 {
+        return *reinterpret_cast<const bfv8*>(smem + w2_lane + ub * 16 * (LT_K * 2) + ((s ^ fh) << 6) + xlow);
+    };
+
+    for (; tile < n_tiles; tile += stride) {
+        int64_t m[2];
+        bool live[2];
+        float tg[2], s1[2], s2[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            m[t] = first_row(tile) + 16 * t + f;
+            live[t] = m[t] < M;
+            tg[t] = tg_n[t], s1[t] = s1_n[t], s2[t] = s2_n[t];
+            load_scalars(tile + stride, t, tg_n[t], s1_n[t], s2_n[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            *predp[t] = pst[t];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(dzp[t] + 32 * j) = dzst[t][j];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // (1) H2^T = W2 . H1^T + b2 for both sub-tiles: a W2 fragment feeds two MFMAs; fragments read one k-step ahead
+        const int64_t next = tile + stride;
+        bfv8 wf[2][8];
+#pragma unroll
+        for (int ub = 0; ub < 8; ++ub) wf[0][ub] = w2frag(0, ub);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            if (s + 1 < 16) {
+#pragma unroll
+                for (int ub = 0; ub < 8; ++ub) wf[(s + 1) & 1][ub] = w2frag(s + 1, ub);
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            }
+            const u32x4 hv0 = s < 8 ? h0[2 * (s & 7)] : h1[2 * (s & 7)];
+            const u32x4 hv1 = s < 8 ? h0[2 * (s & 7) + 1] : h1[2 * (s & 7) + 1];
+#pragma unroll
+            for (int ub = 0; ub < 8; ++ub) {
+                acc[0][ub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s & 1][ub], __builtin_bit_cast(bfv8, hv0), acc[0][ub], 0, 0, 0);
+                acc[1][ub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s & 1][ub], __builtin_bit_cast(bfv8, hv1), acc[1][ub], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            if (s == 7) {                                    // the registers just consumed take the next tile's first k-half
+                load_half(h0, next, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 16, 0);
+            }
+        }
+        load_half(h1, next, 1);
+
+        // (2) sigmoid, bf16: hq[t][ub] = the lane's 4 units of block ub; B fragment of Z3's k-step s3 = blocks 2 s3, 2 s3 + 1
+        bfv8 zf[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) zf[q] = *reinterpret_cast<const bfv8*>(smem + LT_ZF + (q * 64 + lane) * 16);
+        u32x2 hq[2][8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ub = 0; ub < 8; ++ub) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = mg_sigmoid_fast(acc[t][ub][e]);
+                hq[t][ub] = u32x2{__builtin_bit_cast(unsigned int, bfv2{(__bf16)v[0], (__bf16)v[1]}),
+                                  __builtin_bit_cast(unsigned int, bfv2{(__bf16)v[2], (__bf16)v[3]})};
+            }
+
+        // (3) Z3^T = W3 . H2^T: per sub-tile two unit blocks x four k-steps
+        f32x4 z[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) z[t][ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s3 = 0; s3 < 4; ++s3)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const u32x4 bv = u32x4{hq[t][2 * s3][0], hq[t][2 * s3][1], hq[t][2 * s3 + 1][0], hq[t][2 * s3 + 1][1]};
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob)
+                    z[t][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf[ob * 4 + s3], __builtin_bit_cast(bfv8, bv), z[t][ob], 0, 0, 0);
+            }
+        bfv8 w3p[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) w3p[q] = *reinterpret_cast<const bfv8*>(smem + LT_W3P + (q * 64 + lane) * 16);
+
+        // (4)-(7) per sub-tile: sigmoid, prediction (sum over the four lanes of a frame: xor 16, xor 32), loss term, dZ3
+        float dz3[2][2][4];
+        u32x4 dzf[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float h3[2][4];
+            float ph = 0.f;
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    h3[ob][r] = mg_sigmoid_fast(z[t][ob][r] + b3v[ob][r]);
+                    ph += h3[ob][r] * w4v[ob][r];
+                }
+            ph += __shfl_xor(ph, 16, 64);
+            ph += __shfl_xor(ph, 32, 64);
+            const float p = ph + b4v;
+            const float inv = 1.f / (s2[t] * (float)B);
+            const float cw = row_weight ? 2.f * grad_scale : 2.f * grad_scale * inv;
+            const float lw = row_weight ? 1.f : inv;
+            const float e = p - tg[t];
+            const float dpred = live[t] ? (e * s1[t]) * cw : 0.f;
+            if (g == 0) {
+                lossp += live[t] ? (e * e * s1[t]) * lw : 0.f;
+                db4p += dpred;
+            }
+            predp[t] = (live[t] && g == 0) ? pred + m[t] : pred_sink;
+            pst[t] = p;
+            unsigned int w[4];
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dz3[t][ob][r] = dpred * w4v[ob][r] * h3[ob][r] * (1.f - h3[ob][r]);
+                    dw4p[ob][r] += dpred * h3[ob][r];
+                    db3p[ob][r] += dz3[t][ob][r];
+                }
+                w[2 * ob] = __builtin_bit_cast(unsigned int, bfv2{(__bf16)dz3[t][ob][0], (__bf16)dz3[t][ob][1]});
+                w[2 * ob + 1] = __builtin_bit_cast(unsigned int, bfv2{(__bf16)dz3[t][ob][2], (__bf16)dz3[t][ob][3]});
+            }
+            dzf[t] = u32x4{w[0], w[1], w[2], w[3]};       // B fragment of dH2's one k-step: units 4 g + j | 16 + 4 g + j
+            // row-major copy for the transposed reads of dW3: row 16 t + f, units 4 g .. (block 0) at byte 8 g, block 1 at 32 + 8 g
+            *reinterpret_cast<u32x2*>(patch + (16 * t + f) * 64 + 8 * g) = u32x2{w[0], w[1]};
+            *reinterpret_cast<u32x2*>(patch + (16 * t + f) * 64 + 32 + 8 * g) = u32x2{w[2], w[3]};
+        }
+        bfv8 dzt[2];                                        // dZ3^T fragments of the dW3 product (contraction over the 32 frames)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) dzt[nb] = l16_tr_frag(patch, lane, nb, false);
+
+        // (8) dH2^T = W3^T . dZ3^T (one MFMA per 16-unit block), dZ2 = dH2 * H2 (1 - H2); pairs of blocks trade halves between the
+        //     lanes g, g ^ 1 of a frame (v_permlane16_swap) so that every lane stores 16 bytes: g even -> block 2 j, units 8 (g / 2) ..,
+        //     g odd -> block 2 j + 1;   (9) per 32-unit slice: dW3[:, slice] += dZ3^T . H2[:, slice] through the patch
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            unsigned int pk[2][2][2];                        // [t][block of the pair][word]
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int ub = 2 * kt + c;
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                    const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3p[ub], __builtin_bit_cast(bfv8, dzf[t]), zero, 0, 0, 0);
+                    const unsigned int w0 = hq[t][ub][0], w1 = hq[t][ub][1];
+                    const float h[4] = {__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xffff0000u), __uint_as_float(w1 << 16),
+                                        __uint_as_float(w1 & 0xffff0000u)};
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = d[e] * h[e] * (1.f - h[e]);
+                    pk[t][c][0] = __builtin_bit_cast(unsigned int, bfv2{(__bf16)v[0], (__bf16)v[1]});
+                    pk[t][c][1] = __builtin_bit_cast(unsigned int, bfv2{(__bf16)v[2], (__bf16)v[3]});
+                    // H2 slice row 16 t + f: block c of the slice = columns 16 c + 4 g .. -> chunk 2 c + (g >> 1), half g & 1
+                    const int row = 16 * t + f;
+                    *reinterpret_cast<u32x2*>(patch + row * 64 + (((2 * c + (g >> 1)) ^ ((row >> 2) & 3)) << 4) + 8 * (g & 1)) = u32x2{w0, w1};
+                }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const auto r0 = __builtin_amdgcn_permlane16_swap(pk[t][0][0], pk[t][1][0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane16_swap(pk[t][0][1], pk[t][1][1], false, false);
+                dzst[t][kt] = u32x4{r0[0], r1[0], r0[1], r1[1]};
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const bfv8 bq = l16_tr_frag(patch, lane, c, true);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc_w3[nb][2 * kt + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dzt[nb], bq, acc_w3[nb][2 * kt + c], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)                          // 16 bytes per store: block 2 j + (g & 1), units 8 (g >> 1) .. + 7; j -> + 32 columns
+            dzp[t] = live[t] ? dZ2 + (size_t)m[t] * lddz + 16 * (g & 1) + 8 * (g >> 1) : dz_sink;
+        bias_acc();
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        *predp[t] = pst[t];                                  // the last tile's results
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(dzp[t] + 32 * j) = dzst[t][j];
+    }
+
+    // ---- reduction: the 16 frames of a lane row on the DPP path, then wave -> workgroup in a fixed order --------------------------
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dw4p[ob][r] = mg_row16_sum(dw4p[ob][r]);
+            db3p[ob][r] = mg_row16_sum(db3p[ob][r]);
+        }
+    db4p = mg_wave_sum(db4p);
+    lossp = mg_wave_sum(lossp);
+
+    __syncthreads();                                   // every wave is done with W2: its region takes the four waves' sums
+    float* red = reinterpret_cast<float*>(smem + LT_W2);               // [4 waves][LT_SLAB]
+    float* mine = red + wave * LT_SLAB;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mine[(16 * nb + 4 * g + r) * LT_N2 + 16 * k + f] = acc_w3[nb][k][r];
+    if (f == 0) {
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                mine[LT_N3 * LT_N2 + 16 * ob + 4 * g + r] = db3p[ob][r];
+                mine[LT_N3 * LT_N2 + LT_N3 + 16 * ob + 4 * g + r] = dw4p[ob][r];
+            }
+    }
+    if (lane == 0) {
+        mine[LT_N3 * LT_N2 + 2 * LT_N3] = db4p;
+        mine[LT_N3 * LT_N2 + 2 * LT_N3 + 1] = lossp;
+    }
+    __syncthreads();
+    float* out = slab + (size_t)blockIdx.x * LT_SLAB_STRIDE;
+    for (int e = tid; e < LT_SLAB; e += 256) out[e] = ((red[e] + red[LT_SLAB + e]) + red[2 * LT_SLAB + e]) + red[3 * LT_SLAB + e];
+}
+
+#endif  // MG_EXPERIMENTS (f0_l2tail16_kernel)
+
 static int l2tail_blocks(int64_t M) {
     int64_t blocks = mg_ceil_div(mg_ceil_div(M, 32), 4);
     if (blocks > 256) blocks = 256;                    // one resident workgroup per CU (156 KB of LDS each)
@@ -948,6 +1358,11 @@ static int f0_l2tail_launch(const char* name, const uint16_t* H1, int ldh1, int 
         case 16: LT_LAUNCH(16); break;
         case 32: LT_LAUNCH(32); break;
         case 17: LT_LAUNCH(17); break;
+        case 68: LT_LAUNCH(256); break;
+        case 67:
+            hipLaunchKernelGGL(f0_l2tail16_kernel, dim3(blocks), dim3(256), 0, st, H1, ldh1, W2, ldw2, b2, W3, b3, W4, b4, target, seq_len, M, B, T,
+                               grad_scale, pred, dZ2, lddz, slab, row_weight, rev);
+            break;
         default: LT_LAUNCH(0); break;
     }
 #else

@@ -15,7 +15,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from morgana_amd import _lib, ops  # noqa: E402
 
-PROBES = {0: 'product', 64: 'role split (experiment)', 1: 'no H1 loads in the loop', 2: 'no tail', 3: 'no loads, no tail', 4: 'no layer-2 MFMAs', 6: 'loads only',
+PROBES = {0: 'product', 68: 'rolling prefetch', 67: '16x16x32 form (f0_l2tail16_kernel)', 64: 'role split (experiment)', 1: 'no H1 loads in the loop', 2: 'no tail', 3: 'no loads, no tail', 4: 'no layer-2 MFMAs', 6: 'loads only',
           7: 'nothing but the loop', 8: 'no sigmoid on H2', 16: 'no steps 8-9', 32: 'no step 9 (dW3)', 17: 'no loads, no steps 8-9'}
 
 
@@ -55,7 +55,7 @@ def main():
 
         print('M = %d rows' % m)
         print('  unfused pair (gemm_nt_persist<128> + f0_tail)  %8.1f us' % timed(pair, iters))
-        for probe, what in [(k, v) for k, v in PROBES.items() if not FAST or k in (0, 64)]:
+        for probe, what in [(k, v) for k, v in PROBES.items() if not FAST or k in (0, 68, 67, 64)]:
             lib.mg_set_tuning(7, probe)
             us = timed(lambda: ops.f0_l2tail(h1, w2b, b2, w3, b3, w4, b4, tgt, sl, b, t, grads), iters)
             print('  l2tail probe %d (%-26s)  %8.1f us   %6.2f TB/s of H1 + dZ2' % (probe, what, us, (m * 1280) / us / 1e6))
