@@ -224,7 +224,7 @@ def test_persistent_gru_reads_its_input_projections_through_a_row_map():
     assert torch.equal(torch.where(valid, got[2], zero), torch.where(valid, want[2], zero))
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3', 'bf16'])
 def test_c4_model_t1000_vs_oracle(precision):
     """The C4 model (600 -> 512 -> GRU-512 -> 256 -> 80) on 8 fixed-length 1000-frame utterances (C4's chain length; a smaller batch
     keeps the numpy oracle at seconds) against the oracle, fp32 at 1e-4 / 1e-3, bf16 at 2e-2 / 5e-2 (relative L2 on gradients)."""
@@ -234,11 +234,13 @@ def test_c4_model_t1000_vs_oracle(precision):
     model = _load_state(models.RNNSPSS(precision=precision).to(DEV), state)
     loss, out = model(data.to_device(feats, DEV))
     loss.backward()
-    tol, gtol = (RTOL, 1e-3) if precision == 'fp32' else (RTOL_BF16, 5e-2)
+    # 'bf16x3' (split-bf16 row-wise layers, exact-fp32 recurrence) is held to fp32 mode's bars
+    exact = precision in ('fp32', 'bf16x3')
+    tol, gtol = (RTOL, 1e-3) if exact else (RTOL_BF16, 5e-2)
     np.testing.assert_allclose(loss.item(), want_loss, rtol=tol)
     assert rel_err(out['pred_norm_mcep'].detach().cpu().numpy(), want_pred) < tol
     for name, prm in model.named_parameters():
-        err = rel_err(prm.grad.cpu().numpy(), want_grads[name]) if precision == 'fp32' else rel_l2(prm.grad.cpu().numpy(), want_grads[name])
+        err = rel_err(prm.grad.cpu().numpy(), want_grads[name]) if exact else rel_l2(prm.grad.cpu().numpy(), want_grads[name])
         assert err < gtol, (name, err)
 
 
