@@ -45,6 +45,48 @@ def test_argument_errors_are_reported_without_a_gpu():
         _lib.check(rc, 'mg_upsample_index')
 
 
+def test_philox_block_function_known_answers():
+    """mg_philox4x32_10 (host side of csrc/dropout.hip: the generator mg_dropout draws its masks from) against the three known-answer
+    vectors of Random123's Philox4x32-10 (Salmon et al., SC'11; kat_vectors of the Random123 distribution)."""
+    import ctypes
+    lib = _lib.load()
+
+    def block(counter, key):
+        c, k, out = (ctypes.c_uint32 * 4)(*counter), (ctypes.c_uint32 * 2)(*key), (ctypes.c_uint32 * 4)()
+        lib.mg_philox4x32_10(c, k, out)
+        return [int(v) for v in out]
+
+    assert block([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert block([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert block([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_new_entry_points_validate_their_arguments_without_a_gpu():
+    """mg_split3_bf16 / mg_dropout / mg_calib_mfma_bf16: the host side refuses bad descriptors before any launch (return code -1 and a
+    message), as every other entry point does."""
+    import ctypes
+    lib = _lib.load()
+    desc = (_lib.Split3Desc * 1)()
+    desc[0].src, desc[0].rows, desc[0].cols, desc[0].lds = 16, 4, 8, 8
+    desc[0].dst, desc[0].ldp, desc[0].order, desc[0].transpose = 32, 8, 7, 0           # order 7 does not exist
+    assert lib.mg_split3_bf16(ctypes.cast(desc, ctypes.c_void_p), 1, None) == -1 and 'order 7' in _lib.last_error()
+    desc[0].order, desc[0].ldp = 0, 12                                                  # planes must be multiples of 8 columns
+    assert lib.mg_split3_bf16(ctypes.cast(desc, ctypes.c_void_p), 1, None) == -1 and 'multiple of 8' in _lib.last_error()
+    desc[0].ldp, desc[0].plane_rows = 8, 2                                              # plane_rows goes with order 2 and must cover the rows
+    assert lib.mg_split3_bf16(ctypes.cast(desc, ctypes.c_void_p), 1, None) == -1 and 'plane_rows' in _lib.last_error()
+    assert lib.mg_split3_bf16(ctypes.cast(desc, ctypes.c_void_p), 0, None) == -1
+    assert lib.mg_dropout(16, 16, 8, 0, 1.0, 1, 0, None, None) == -1 and 'p must be in [0, 1)' in _lib.last_error()
+    assert lib.mg_dropout(16, 16, 0, 0, 0.5, 1, 0, None, None) == 0                      # nothing to do: no launch
+    assert lib.mg_calib_mfma_bf16(None, None, 256, 10, None, None) == -1
+    for precision in ('fp32', 'bf16', 'bf16x3'):
+        from morgana_amd import functional as F_hip
+        F_hip.set_precision(precision)
+    F_hip.set_precision('fp32')
+    with pytest.raises(ValueError):
+        F_hip.set_precision('fp16')
+    assert F_hip.recurrent_precision('bf16x3') == 'fp32' and F_hip.recurrent_precision('bf16') == 'bf16'
+
+
 def test_no_cpu_fallback():
     from morgana_amd import utils, losses
     x = torch.zeros(2, 3, 4)
