@@ -117,6 +117,28 @@ int main(void) {
     expect_code("adam(null)", mg_adam_step_f32(NULL, NULL, NULL, NULL, 0, 0.f, 0.f, 0.f, 0.f, 0.f, 0, 1.f, NULL));
     { float two[2]; mg_adam_scalars(0.01f, 0.9f, 0.999f, 1, two); if (!(two[0] > 0.f && two[1] > 0.f)) { fprintf(stderr, "mg_adam_scalars\n"); ++n_bad; } }
     expect_code("ema(null)", mg_ema_update_f32(NULL, NULL, 0, 0.5f, NULL));
+    /* round 4 entry points: operand splits of precision 'bf16x3', dropout, the calibration loop, the GRU recurrence with a bf16 output copy */
+    {
+        mg_split3_desc sd[2];
+        memset(sd, 0, sizeof(sd));
+        expect_code("split3(count)", mg_split3_bf16(sd, 0, NULL));
+        expect_code("split3(count big)", mg_split3_bf16(sd, MG_SPLIT3_MAX + 1, NULL));
+        expect_code("split3(null desc)", mg_split3_bf16(sd, 2, NULL));
+        sd[0].src = df; sd[0].rows = 21504; sd[0].cols = 600; sd[0].lds = 600; sd[0].dst = dh; sd[0].ldp = 640; sd[0].order = 0;
+        sd[1] = sd[0]; sd[1].order = 2; sd[1].plane_rows = 22528;
+        expect_code("split3(C2 table)", mg_split3_bf16(sd, 2, NULL));
+        sd[1].order = 1; sd[1].transpose = 1; sd[1].plane_rows = 0;                       /* 21504 rows do not fit planes of 640 columns */
+        expect_code("split3(transposed too tall)", mg_split3_bf16(sd, 2, NULL));
+        sd[1].transpose = 0; sd[1].sig = df; sd[1].ldsig = 8;                             /* ldsig < cols */
+        expect_code("split3(bad sig)", mg_split3_bf16(sd, 2, NULL));
+    }
+    expect_code("dropout(p)", mg_dropout(df, df, 100, 0, 1.5f, 1, 0, NULL, NULL));
+    expect_code("dropout(ok)", mg_dropout(df, df, 1 << 20, 1, 0.25f, 0x1234567890abcdefull, 3, (const uint64_t*)d, NULL));
+    expect_code("dropout_advance(null)", mg_dropout_advance(NULL, NULL, NULL));
+    { uint32_t c[4] = {0, 0, 0, 0}, k[2] = {0, 0}, o[4]; mg_philox4x32_10(c, k, o); if (o[0] != 0x6627e8d5u) { fprintf(stderr, "mg_philox4x32_10\n"); ++n_bad; } }
+    { double fl = 0.0; expect_code("calib_mfma(null)", mg_calib_mfma_bf16(NULL, NULL, 256, 10, &fl, NULL));
+      expect_code("calib_mfma(ok)", mg_calib_mfma_bf16(dh, df, 256, 100, &fl, NULL)); }
+    expect_code("gru_fwd_persist_out(shape)", mg_gru_fwd_persist_out_bf16(df, NULL, 0, dh, 512, df, dl, 64, 1000, 512, df, dh, df, dh, df, d, 16, NULL));
 
     /* plausible shapes: the host path runs its planning and set-up; without a device the launch itself fails (MG_ELAUNCH) */
     expect_code("upsample_index(C2)", mg_upsample_index(dl, 256, 80, 1000, NULL, di, NULL));
