@@ -803,6 +803,31 @@ def test_gru_f0_model_runs_on_the_stack_wavefront():
         assert rel_err(g, w) < 1e-4, (k, rel_err(g, w))
 
 
+@pytest.mark.parametrize('which', ['gru_f0', 'lstm'])
+def test_shipped_models_in_bf16x3_track_fp32(which):
+    """The reference's two shipped models (models/f0_test_model.py, models/RNN_SPSS.py: 609-dim input with frame-level counters,
+    recurrent stacks, multi-stream loss) in precision 'bf16x3' - split-bf16 row-wise layers, exact-fp32 recurrences - against fp32
+    mode on a ragged batch: loss to 1e-4, every parameter gradient to 1e-3 of its largest element (fp32 mode's own bars vs the oracle)."""
+    if which == 'gru_f0':
+        feats_np = synthetic.make_acoustic_batch(6, (60, 150), streams=(('lf0', 3, 'mse'),), seed=5)
+        make = lambda prec: models.GRUF0Model(precision=prec, generate=False)
+    else:
+        feats_np = synthetic.make_acoustic_batch(4, (40, 90), seed=6)
+        make = lambda prec: models.LSTMAcousticModel(precision=prec, num_layers=2, generate=False)
+    feats = data.to_device(feats_np, DEV)
+    got = {}
+    for prec in ('fp32', 'bf16x3'):
+        torch.manual_seed(2)
+        model = make(prec).to(DEV)
+        loss, _ = model(feats)
+        loss.backward()
+        ops.check_persistent_status()
+        got[prec] = (float(loss.detach()), {n: p.grad.detach().cpu().numpy().copy() for n, p in model.named_parameters()})
+    np.testing.assert_allclose(got['bf16x3'][0], got['fp32'][0], rtol=RTOL)
+    for name, want in got['fp32'][1].items():
+        assert rel_err(got['bf16x3'][1][name], want) < 1e-3, name
+
+
 def test_frame_layout_with_a_host_total_that_disagrees_with_the_lengths():
     """mg_frame_layout with a host-side frame total above / below what the device lengths (clipped to T) add up to: surplus packed
     rows must gather the zero row (-1), never whatever the allocation held (rows[sum .. total-1] were left
