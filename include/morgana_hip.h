@@ -309,6 +309,24 @@ int mg_segment_bounds(const int32_t* rows, int64_t M, int R, int32_t* seg_start,
                       int pad_row, void* stream);
 int mg_segment_sum(const void* G, int ldg, int g_bf16, const int32_t* rows, int64_t M, const int32_t* seg_start,
                    const int32_t* seg_end, int R, int extra, int N, void* out, int ldo, void* stream);
+/* mg_segment_sum (bf16) and, in the same pass over G, the weight gradient of C <= 16 per-frame input features (the frame counters behind
+ * the repeated phone rows, /root/reference/models/RNN_SPSS.py:76-81): partial sums  slab[b][c][n] = sum over workgroup b's frames of
+ * G[f, n] feat[f, c]  into `slabs` (mg_segment_sum_feat_workspace_bytes(C, ldo) bytes; must stay untouched until the reduce);
+ * mg_feat_wgrad_reduce then writes dW[n, col0 + c] (+)= sum_b slab[b][c][n].  feat f32 [M, C].  Deterministic. */
+size_t mg_segment_sum_feat_workspace_bytes(int C, int ldo);
+int mg_segment_sum_feat_bf16(const uint16_t* G, int ldg, const int32_t* rows, int64_t M, const int32_t* seg_start, const int32_t* seg_end,
+                             int R, int extra, int N, uint16_t* out, int ldo, const float* feat, int C, void* slabs, size_t slabs_bytes,
+                             void* stream);
+int mg_feat_wgrad_reduce(const void* slabs, int C, int ldo, int N, float* dW, int ldw, int col0, int accumulate, void* stream);
+/* The first Linear of a model whose input is cat(upsample_to_repetitions(lab, durations), frame counters)
+ * (/root/reference/models/RNN_SPSS.py:76-81, models/f0_test_model.py:78-79), with W = [W_lab | W_cnt]: the lab part runs once per phone
+ * (P = table W_lab^T through mg_linear_fwd_bf16, f32 output, no bias) and this kernel finishes the layer per frame,
+ *   Y[f, n] = act(P[rows[f], n] + sum_c feat[f, c] W[n, col0 + c] + bias[n]),   n < N; Y's padding columns [N, ldy) zero.
+ * P f32 [table rows, ldp] (ldp >= N rounded up to 8); rows int32 [M], every entry a row of P (-1 already mapped to a zero-input
+ * row); feat f32 [M, C], 1 <= C <= 16; W f32 [N, ldw] with the counters' weights in columns col0 .. col0 + C; Y [M, ldy] bf16, or
+ * f32 with y_f32 != 0 (the layer's output leaves the fused run). */
+int mg_phone_concat_layer_bf16(const float* P, int ldp, const int32_t* rows, int64_t M, const float* feat, int C, const float* W, int ldw,
+                               int col0, const float* bias, int N, int act, void* Y, int ldy, int y_f32, void* stream);
 
 /* bf16 variants: A, W, H, Y are bf16; K and N of the bf16 buffers are padded: lda/ldw/ldy multiples of 8 elements,
  * padding columns must be zero (mg_cast_pad_bf16 / mg_gather_rows_bf16 produce such buffers).  bias, dW, db f32. */

@@ -164,6 +164,12 @@ SIGNATURES = {
                                               c_int, c_int, c_void_p]),
     'mg_segment_sum': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
                                c_void_p]),
+    'mg_segment_sum_feat_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'mg_segment_sum_feat_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
+                                         c_int, c_void_p, c_size_t, c_void_p]),
+    'mg_feat_wgrad_reduce': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'mg_phone_concat_layer_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
+                                           c_void_p, c_int, c_int, c_void_p]),
     'mg_mlpg_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'mg_mlpg_f32': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                             c_void_p, c_int, c_void_p, c_size_t, c_void_p]),

@@ -259,6 +259,212 @@ __global__ __launch_bounds__(256) void phone_front_kernel(PhoneFrontArgs a) {
     phone_front_block<256>(a, blockIdx.x, gridDim.x, pf_lds);
 }
 
+// mg_segment_sum of a bf16 gradient and, in the same pass over G, the weight gradient of C per-frame input features (the frame
+// counters behind the repeated phone rows, models/RNN_SPSS.py:76-81):  slab[b][c][n] = sum over workgroup b's frames of
+// G[f, n] feat[f, c];  feat_wgrad_reduce_kernel sums the slabs in index order into dW[n, col0 + c].  A wave takes a contiguous
+// range of table rows (their frames are consecutive), 8 columns per lane; the C x 8 products per frame ride on the row that the
+// sum loads anyway.  Deterministic: fixed row ranges, the waves of a workgroup added in wave order, the slabs in slab order.
+#define SSF_WAVES 8
+#define SSF_BLOCKS 256
+__global__ __launch_bounds__(64 * SSF_WAVES) void segment_sum_feat_kernel(const uint16_t* __restrict__ G, int ldg, const int32_t* __restrict__ rows,
+                                                                          int64_t M, const int32_t* __restrict__ seg_start,
+                                                                          const int32_t* __restrict__ seg_end, int R, int extra, int N,
+                                                                          uint16_t* __restrict__ out, int ldo, const float* __restrict__ feat,
+                                                                          int C, float* __restrict__ slab) {
+    __shared__ float red[16 * 512];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = (blockIdx.y * 64 + lane) * 8;
+    const bool live = c < N;
+    float cacc[16][8];
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cacc[cc][e] = 0.f;
+    const int n_rows = R + extra;
+    const int per = (n_rows + (int)gridDim.x * SSF_WAVES - 1) / ((int)gridDim.x * SSF_WAVES);
+    const int r_lo = ((int)blockIdx.x * SSF_WAVES + wave) * per, r_hi = r_lo + per < n_rows ? r_lo + per : n_rows;
+
+    // one frame: its 8 gradient columns into the row's sum and, times each feature, into the feature gradients
+    auto frame = [&](int64_t f, float (&acc)[8]) {
+        float t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = 0.f;
+        const float fv = lane < C ? feat[f * C + lane] : 0.f;
+        if (live) PrLoad<uint16_t>::add(G + (size_t)f * ldg + c, t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += t[e];
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) {
+            const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fv), cc));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cacc[cc][e] = fmaf(x, t[e], cacc[cc][e]);
+        }
+    };
+
+    for (int r = r_lo; r < r_hi; ++r) {
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        if (r < R) {
+            const int f0 = seg_start[r], f1 = seg_end[r];
+#pragma unroll 4
+            for (int f = f0; f < f1; ++f) frame(f, acc);
+        } else {
+            // padding frames of this row's share of the frame axis, as segment_sum_kernel finds them
+            const int64_t chunk = (M + extra - 1) / extra, lo = (int64_t)(r - R) * chunk, hi = lo + chunk < M ? lo + chunk : M;
+            for (int64_t base = lo; base < hi; base += 64) {
+                const int64_t mine = base + lane;
+                unsigned long long pads = __ballot(mine < hi && (rows[mine] < 0 || rows[mine] >= R));
+                while (pads) {
+                    const int bit = __builtin_ctzll(pads);
+                    pads &= pads - 1;
+                    frame(base + bit, acc);
+                }
+            }
+        }
+        if (c < ldo) PrStore<uint16_t>::put(out + (size_t)r * ldo + c, acc);
+    }
+    // the workgroup's waves, added in wave order
+    for (int wv = 0; wv < SSF_WAVES; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) {
+                if (cc < C) {
+                    float* dst = red + cc * 512 + lane * 8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dst[e] = (wv == 0 ? 0.f : dst[e]) + cacc[cc][e];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < C * 512; i += 64 * SSF_WAVES) {
+        const int cc = i >> 9, col = blockIdx.y * 512 + (i & 511);
+        if (col < ldo) slab[((size_t)blockIdx.x * C + cc) * ldo + col] = red[i];
+    }
+}
+
+// dW[n, col0 + c] (+)= sum_b slab[b][c][n], b in index order.  blockIdx.x = 64 columns n, blockIdx.y = c; thread (q, n): the slabs
+// b = q mod 4, partial sums added in q order.
+__global__ __launch_bounds__(256) void feat_wgrad_reduce_kernel(const float* __restrict__ slab, int n_slabs, int C, int ldo, int N,
+                                                                float* __restrict__ dW, int ldw, int col0, int accumulate) {
+    __shared__ float part[4][64];
+    const int q = threadIdx.x >> 6, nl = threadIdx.x & 63, n = blockIdx.x * 64 + nl, c = blockIdx.y;
+    float s = 0.f;
+    if (n < N)
+        for (int b = q; b < n_slabs; b += 4) s += slab[((size_t)b * C + c) * ldo + n];
+    part[q][nl] = s;
+    __syncthreads();
+    if (q == 0 && n < N) {
+        const float total = ((part[0][nl] + part[1][nl]) + part[2][nl]) + part[3][nl];
+        float* dst = dW + (size_t)n * ldw + col0 + c;
+        *dst = accumulate ? *dst + total : total;
+    }
+}
+
+// The first Linear of a model whose input is cat(upsample_to_repetitions(lab, durations), counters) (models/RNN_SPSS.py:76-81,
+// models/f0_test_model.py:78-79): W = [W_lab | W_cnt], so z[f] = (lab W_lab^T)[phone(f)] + counters[f] W_cnt^T + b.  The first
+// product runs once per phone (mg_linear_fwd_bf16 on the table, f32 output, no bias); this kernel adds the per-frame part:
+//   Y[f, n] = act(P[rows[f], n] + sum_c feat[f, c] W[n, col0 + c] + bias[n])     (bf16 or f32, the padding columns of Y zero)
+// A wave takes chunks of 16 CONSECUTIVE frames, COLS columns per lane (blockIdx.y = chunk of 64 COLS columns): a phone's frames
+// follow each other, so the wave fetches a row of P only where the row id changes (~ once per 11 frames) and keeps it in
+// registers; the lane's C x COLS counter weights come through LDS once per workgroup (W's rows are 4 ldw bytes apart: read per
+// lane they cost a cache line each, per wave) and stay in registers.  Write bound: 4 N (f32) or 2 N bytes per frame out.
+#define PCL_CHUNK 16
+template <int COLS, typename OutT> struct PclStore;
+template <> struct PclStore<8, uint16_t> { static __device__ __forceinline__ void put(uint16_t* d, const float (&v)[8]) { PrStore<uint16_t>::put(d, v); } };
+template <> struct PclStore<8, float> { static __device__ __forceinline__ void put(float* d, const float (&v)[8]) { PrStore<float>::put(d, v); } };
+template <> struct PclStore<4, uint16_t> {
+    static __device__ __forceinline__ void put(uint16_t* d, const float (&v)[4]) {
+        uint2 pk;
+        pk.x = (uint32_t)mg_f2bf(v[0]) | ((uint32_t)mg_f2bf(v[1]) << 16);
+        pk.y = (uint32_t)mg_f2bf(v[2]) | ((uint32_t)mg_f2bf(v[3]) << 16);
+        *reinterpret_cast<uint2*>(d) = pk;
+    }
+};
+template <> struct PclStore<4, float> {
+    static __device__ __forceinline__ void put(float* d, const float (&v)[4]) { *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]}; }
+};
+
+template <int ACT, typename OutT, int COLS>
+__global__ __launch_bounds__(256) void phone_concat_layer_kernel(const float* __restrict__ P, int ldp, const int32_t* __restrict__ rows,
+                                                                 int64_t M, const float* __restrict__ feat, int C,
+                                                                 const float* __restrict__ W, int ldw, int col0,
+                                                                 const float* __restrict__ bias, int N, OutT* __restrict__ Y, int ldy) {
+    __shared__ float wl[64 * COLS * 16];                     // [this block's 64 COLS columns][C]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int cbase = blockIdx.y * 64 * COLS;
+    for (int i = tid; i < 64 * COLS * C; i += 256) {
+        const int n = cbase + i / C;
+        wl[i] = n < N ? W[(size_t)n * ldw + col0 + i % C] : 0.f;
+    }
+    __syncthreads();
+    const int c0 = cbase + lane * COLS;
+    const bool live = c0 < ldy;                             // this lane writes Y[f, c0 .. c0 + COLS); columns >= N get zeros
+    const bool has_p = c0 < N;                              // ldp >= N rounded up to 8 (and COLS divides 8): the lane's columns exist in P
+    float wc[16][COLS], bv[COLS];
+#pragma unroll
+    for (int e = 0; e < COLS; ++e) {
+        bv[e] = (c0 + e < N && bias) ? bias[c0 + e] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) wc[c][e] = c < C ? wl[(lane * COLS + e) * C + c] : 0.f;
+    }
+    const int64_t chunks = (M + PCL_CHUNK - 1) / PCL_CHUNK;
+    for (int64_t ch = (int64_t)blockIdx.x * 4 + (tid >> 6); ch < chunks; ch += (int64_t)gridDim.x * 4) {
+        const int64_t f0 = ch * PCL_CHUNK;
+        const int rv = (lane < PCL_CHUNK && f0 + lane < M) ? rows[f0 + lane] : -1;
+        int prev = -1;
+        float pz[COLS];
+#pragma unroll
+        for (int e = 0; e < COLS; ++e) pz[e] = bv[e];
+#pragma unroll
+        for (int j = 0; j < PCL_CHUNK; j += 4) {
+            float fv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) fv[u] = (f0 + j + u < M && lane < C) ? feat[(f0 + j + u) * C + lane] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t f = f0 + j + u;
+                if (f < M) {                                 // wave-uniform
+                    const int row = __builtin_amdgcn_readlane(rv, j + u);
+                    if (row != prev) {                       // wave-uniform: the phone changed
+                        prev = row;
+#pragma unroll
+                        for (int e = 0; e < COLS; ++e) pz[e] = bv[e];
+                        if (has_p) {
+                            const float* src = P + (size_t)row * ldp + c0;
+#pragma unroll
+                            for (int q = 0; q < COLS / 4; ++q) {
+                                const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * q);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) pz[4 * q + e] += v[e];
+                            }
+                        }
+                    }
+                    float z[COLS];
+#pragma unroll
+                    for (int e = 0; e < COLS; ++e) z[e] = pz[e];
+                    // the counters after the table part, in column order: the order the frame-rate GEMM's k loop meets them
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fv[u]), c));
+#pragma unroll
+                        for (int e = 0; e < COLS; ++e) z[e] = fmaf(x, wc[c][e], z[e]);
+                    }
+                    if (live) {
+#pragma unroll
+                        for (int e = 0; e < COLS; ++e) {
+                            if (ACT == MG_ACT_SIGMOID) z[e] = mg_sigmoid_fast(z[e]);
+                            if (c0 + e >= N) z[e] = 0.f;
+                        }
+                        PclStore<COLS, OutT>::put(Y + (size_t)f * ldy + c0, z);
+                    }
+                }
+            }
+        }
+    }
+}
+
 extern "C" {
 
 int mg_segment_bounds(const int32_t* rows, int64_t M, int R, int32_t* seg_start, int32_t* seg_end, int32_t* rows_mapped, int pad_row,
@@ -294,6 +500,64 @@ int mg_segment_sum(const void* G, int ldg, int g_bf16, const int32_t* rows, int6
         hipLaunchKernelGGL((segment_sum_kernel<float>), grid, dim3(64), 0, st, (const float*)G, ldg, rows, M, seg_start, seg_end, R, extra, N,
                            (float*)out, ldo);
     MG_CHECK_LAUNCH("mg_segment_sum");
+    return MG_OK;
+}
+
+size_t mg_segment_sum_feat_workspace_bytes(int C, int ldo) {
+    return C > 0 && ldo > 0 ? (size_t)SSF_BLOCKS * (size_t)C * (size_t)ldo * sizeof(float) : 0;
+}
+
+int mg_segment_sum_feat_bf16(const uint16_t* G, int ldg, const int32_t* rows, int64_t M, const int32_t* seg_start, const int32_t* seg_end,
+                             int R, int extra, int N, uint16_t* out, int ldo, const float* feat, int C, void* slabs, size_t slabs_bytes,
+                             void* stream) {
+    MG_CHECK_ARG(G && rows && seg_start && seg_end && out && feat && slabs && M > 0 && R > 0 && extra >= 0 && N > 0,
+                 "mg_segment_sum_feat_bf16: bad arguments (M=%lld R=%d extra=%d N=%d)", (long long)M, R, extra, N);
+    MG_CHECK_ARG(N % 8 == 0 && ldg % 8 == 0 && ldg >= N && ldo % 8 == 0 && ldo >= N, "mg_segment_sum_feat_bf16: N=%d ldg=%d ldo=%d must be multiples of 8",
+                 N, ldg, ldo);
+    MG_CHECK_ARG(C >= 1 && C <= 16, "mg_segment_sum_feat_bf16: C=%d (1..16)", C);
+    MG_CHECK_ARG(slabs_bytes >= mg_segment_sum_feat_workspace_bytes(C, ldo), "mg_segment_sum_feat_bf16: slabs too small (%zu bytes)", slabs_bytes);
+    MG_CHECK_ARG(((uintptr_t)G % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)slabs % 16) == 0,
+                 "mg_segment_sum_feat_bf16: buffers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(SSF_BLOCKS, (unsigned)mg_ceil_div(ldo / 8, 64));
+    hipLaunchKernelGGL(segment_sum_feat_kernel, grid, dim3(64 * SSF_WAVES), 0, st, G, ldg, rows, M, seg_start, seg_end, R, extra, N, out, ldo, feat, C,
+                       (float*)slabs);
+    MG_CHECK_LAUNCH("mg_segment_sum_feat_bf16");
+    return MG_OK;
+}
+
+int mg_feat_wgrad_reduce(const void* slabs, int C, int ldo, int N, float* dW, int ldw, int col0, int accumulate, void* stream) {
+    MG_CHECK_ARG(slabs && dW && C >= 1 && C <= 16 && N > 0 && ldo >= N && col0 >= 0 && ldw >= col0 + C,
+                 "mg_feat_wgrad_reduce: bad arguments (C=%d N=%d ldo=%d ldw=%d col0=%d)", C, N, ldo, ldw, col0);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(feat_wgrad_reduce_kernel, dim3((unsigned)mg_ceil_div(N, 64), (unsigned)C), dim3(256), 0, st, (const float*)slabs, SSF_BLOCKS, C,
+                       ldo, N, dW, ldw, col0, accumulate);
+    MG_CHECK_LAUNCH("mg_feat_wgrad_reduce");
+    return MG_OK;
+}
+
+int mg_phone_concat_layer_bf16(const float* P, int ldp, const int32_t* rows, int64_t M, const float* feat, int C, const float* W, int ldw,
+                               int col0, const float* bias, int N, int act, void* Y, int ldy, int y_f32, void* stream) {
+    MG_CHECK_ARG(P && rows && feat && W && Y && M > 0 && N > 0, "mg_phone_concat_layer_bf16: bad arguments (M=%lld N=%d)", (long long)M, N);
+    MG_CHECK_ARG(C >= 1 && C <= 16 && col0 >= 0 && ldw >= col0 + C, "mg_phone_concat_layer_bf16: C=%d (1..16) col0=%d ldw=%d", C, col0, ldw);
+    MG_CHECK_ARG(ldp % 8 == 0 && ldp >= ((N + 7) / 8) * 8 && ldy % 8 == 0 && ldy >= N,
+                 "mg_phone_concat_layer_bf16: N=%d ldp=%d ldy=%d (multiples of 8, ldp >= N rounded up to 8)", N, ldp, ldy);
+    MG_CHECK_ARG(act == MG_ACT_NONE || act == MG_ACT_SIGMOID, "mg_phone_concat_layer_bf16: act=%d", act);
+    MG_CHECK_ARG(((uintptr_t)P % 16) == 0 && ((uintptr_t)Y % 16) == 0, "mg_phone_concat_layer_bf16: buffers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int cols = ldy <= 256 ? 4 : 8;                                // columns per lane: 64 lanes cover 256 / 512 columns per pass
+    const int64_t want = mg_ceil_div(mg_ceil_div(M, PCL_CHUNK), 4 * 4);  // ~4 chunks of 16 frames per wave
+    const dim3 grid((unsigned)(want < 1024 ? (want < 1 ? 1 : want) : 1024), (unsigned)mg_ceil_div(ldy, 64 * cols));
+#define LAUNCH_PCL(ACT_, T_, COLS_) hipLaunchKernelGGL((phone_concat_layer_kernel<ACT_, T_, COLS_>), grid, dim3(256), 0, st, P, ldp, rows, M, feat, C, W, ldw, col0, bias, N, (T_*)Y, ldy)
+#define LAUNCH_PCL_T(ACT_, T_) do { if (cols == 4) LAUNCH_PCL(ACT_, T_, 4); else LAUNCH_PCL(ACT_, T_, 8); } while (0)
+    if (act == MG_ACT_SIGMOID) {
+        if (y_f32) LAUNCH_PCL_T(MG_ACT_SIGMOID, float); else LAUNCH_PCL_T(MG_ACT_SIGMOID, uint16_t);
+    } else {
+        if (y_f32) LAUNCH_PCL_T(MG_ACT_NONE, float); else LAUNCH_PCL_T(MG_ACT_NONE, uint16_t);
+    }
+#undef LAUNCH_PCL_T
+#undef LAUNCH_PCL
+    MG_CHECK_LAUNCH("mg_phone_concat_layer_bf16");
     return MG_OK;
 }
 

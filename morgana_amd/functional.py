@@ -266,6 +266,10 @@ class LinearStackFn(torch.autograd.Function):
         ctx.drop = drop
         # a bf16 copy of x2d somebody already made (the GRU recurrence writes one of its output: GRUFn out_bf): the first layer's operand
         shadow = spec[5] if len(spec) > 5 else None
+        # `front` = (rows, seg, frame features): the input is cat(x2d[rows], frame features) - the table of phone rows repeated by
+        # upsample_to_repetitions with per-frame counters behind it (models/RNN_SPSS.py:76-81).  bf16 mode: the table's part of the first
+        # layer runs once per phone, ops.phone_concat_layer adds the counters' part per frame; rows: -1 mapped to the first extra row
+        front = spec[6] if len(spec) > 6 else None
         n_layers = len(acts)
         weights = [params[2 * i] for i in range(n_layers)]
         biases = [params[2 * i + 1] for i in range(n_layers)]
@@ -275,13 +279,17 @@ class LinearStackFn(torch.autograd.Function):
         if extra and (pre_cast or rows is not None or ctx.needs_input_grad[1]):
             raise ValueError('LinearStackFn: extra zero rows go with a plain fp32 input that needs no gradient')
         m = rows.numel() if rows is not None else x2d.shape[0] + extra
+        if front is not None:
+            if precision != 'bf16' or pre_cast or rows is not None or ctx.needs_input_grad[1] or not extra:
+                raise ValueError('LinearStackFn: a phone table with frame features is a bf16-mode input that needs no gradient')
+            m = front[0].numel()
         ctx.spec, ctx.m = spec, m
         ctx.n_src = x2d.shape[0]
         gathered_grad = rows is not None and ctx.needs_input_grad[1]
         rows_k = rows                                  # the row map the kernels' loaders apply (None once the input is packed)
         ctx.has_bias = [b is not None for b in biases]
         ctx.dims = [(w.shape[0], w.shape[1]) for w in weights]
-        k_in = weights[0].shape[1]
+        k_in = weights[0].shape[1] - (front[2].shape[1] if front is not None else 0)
         if x2d.shape[1] != (ops.pad_ld(k_in) if pre_cast else k_in):
             raise ValueError('Linear expects %d input features, got %d' % (k_in, x2d.shape[1]))
         hidden = []
@@ -330,7 +338,10 @@ class LinearStackFn(torch.autograd.Function):
                   and tuple(shadow.shape) == (x2d.shape[0], ops.pad_ld(k_in)) and k_in == ops.pad_ld(k_in)):
                 a = shadow
             else:
-                a = x2d if pre_cast else ops.cast_pad_bf16(x2d, extra_rows=extra)
+                # (a phone table in front of frame features is padded to the layer's full input width: its weight gradient then
+                # spans all of dW, with zeros in the features' columns - ops.feat_wgrad_reduce fills those)
+                a = x2d if pre_cast else ops.cast_pad_bf16(x2d, ld=ops.pad_ld(weights[0].shape[1]) if front is not None else None,
+                                                           extra_rows=extra)
             a0, r = a, rows_k
             # bf16 operands of the weights: copies that live on the parameters, refreshed by the optimiser's update kernel
             # (ops.param_shadows) - no cast launch per layer and step
@@ -338,7 +349,10 @@ class LinearStackFn(torch.autograd.Function):
             for i in range(n_layers):
                 n, k = weights[i].shape
                 last = i == n_layers - 1
-                a = ops.linear_fwd_bf16(a, r, m, k, w_bfs[i], biases[i], n, acts[i], out_f32=last, rows_runs=rows_runs)
+                if i == 0 and front is not None:
+                    a = ops.phone_concat_layer(a0, k_in, front[0], front[2], weights[0], w_bfs[0], biases[0], n, acts[0], out_f32=last)
+                else:
+                    a = ops.linear_fwd_bf16(a, r, m, k, w_bfs[i], biases[i], n, acts[i], out_f32=last, rows_runs=rows_runs)
                 r = None
                 hidden.append(a)
                 if drop is not None and not last:
@@ -435,9 +449,26 @@ class LinearStackFn(torch.autograd.Function):
             w_params, b_params = ctx.param_refs
             direct = all(ctx.has_bias) and _direct_params(*w_params, *b_params)
             beside = direct and _side_ok(g.device, level=2)
+            front = ctx.spec[6] if len(ctx.spec) > 6 else None
+            extra0 = ctx.spec[2] if len(ctx.spec) > 2 else 0
             for i in range(n_layers - 1, -1, -1):
                 n, k = ctx.dims[i]
                 a_in, r = (x_in, rows) if i == 0 else (masked_input(i), None)
+                if i == 0 and front is not None:
+                    # dW = [dW_lab | dW_cnt]: the table's part from the per-phone sums of g (every frame of a phone multiplied the same
+                    # table row; the table's columns behind the labels are zero), the counters' part from the same pass over g
+                    # (slabs, reduced into their columns of dW afterwards); db = the column sums of the sums
+                    rows_f, seg_f, feat = front
+                    k_lab, n_tab = k - feat.shape[1], x_in.shape[0]
+                    sums, slabs = ops.segment_sum_feat(g, rows_f, seg_f, n_tab - extra0, g.shape[1], feat, extra=extra0)
+                    if direct:
+                        ops.linear_wgrad_bf16(sums, x_in, None, n_tab, n, k, out_w=w_params[0].grad, out_b=b_params[0].grad, accumulate=True)
+                        ops.feat_wgrad_reduce(slabs, feat.shape[1], sums.shape[1], n, w_params[0].grad, k_lab)
+                    else:
+                        dw, db = ops.linear_wgrad_bf16(sums, x_in, None, n_tab, n, k, want_bias=ctx.has_bias[0])
+                        ops.feat_wgrad_reduce(slabs, feat.shape[1], sums.shape[1], n, dw, k_lab)
+                        grads[0], grads[1] = dw, db
+                    continue
                 if beside and (i > 0 or need_x):
                     # the weight gradient feeds only the update: beside the dgrad chain (the last layer of the pass has no chain left
                     # on this node, its weight gradient stays in line)

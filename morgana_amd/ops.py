@@ -1705,6 +1705,42 @@ def linear_dgrad_gathered_bf16(dy, m, n, wt_bf16, k, h_table, h_rows):
     return dx
 
 
+def phone_concat_layer(table_bf16, k_lab, rows_mapped, feat, w, w_bf16, bias, n, act, out_f32=False):
+    """First Linear of ``cat(upsampled lab, frame counters)`` with the lab part at phone rate: ``act(P[rows] + feat W_cnt^T + b)``
+    with P = table W_lab^T (one small GEMM, f32).  table_bf16 (R + extra, ld) bf16; feat (M, C) f32; w (n, k_lab + C) f32 and
+    its bf16 copy w_bf16 (n, ldw).  Returns (M, pad8(n)) bf16 - the operand of the next layer - or (M, n rounded up to 8) f32."""
+    lib = _lib.load()
+    feat = _require(feat, torch.float32, 'frame features')
+    w = _require(w, torch.float32, 'weight')
+    m, c = feat.shape
+    part = linear_fwd_bf16(table_bf16, None, table_bf16.shape[0], k_lab, w_bf16, None, n, ACT_NONE, out_f32=True)
+    y = torch.empty((m, (n + 7) // 8 * 8 if out_f32 else pad8(n)), dtype=torch.float32 if out_f32 else torch.bfloat16, device=feat.device)
+    _lib.check(lib.mg_phone_concat_layer_bf16(_p(part), part.shape[1], _p(rows_mapped), m, _p(feat), c, _p(w), w.shape[1], k_lab, _p(bias), n,
+                                              act, _p(y), y.shape[1], int(bool(out_f32)), _stream()), 'mg_phone_concat_layer_bf16')
+    return y
+
+
+def segment_sum_feat(g, rows, seg, n_table_rows, n, feat, extra=PHONE_RATE_EXTRA):
+    """``segment_sum`` of a bf16 gradient plus, from the same pass, the slabs of the frame features' weight gradient (g^T feat):
+    returns (sums (R + extra, ld) bf16, slabs) - ``feat_wgrad_reduce`` adds the slabs into the features' columns of dW."""
+    lib = _lib.load()
+    g = _require(g, torch.bfloat16, 'gradient')
+    feat = _require(feat, torch.float32, 'frame features')
+    c = feat.shape[1]
+    out = torch.empty((n_table_rows + extra, g.shape[1]), dtype=g.dtype, device=g.device)
+    nbytes = lib.mg_segment_sum_feat_workspace_bytes(c, out.shape[1])
+    slabs = torch.empty((nbytes // 4,), dtype=torch.float32, device=g.device)
+    _lib.check(lib.mg_segment_sum_feat_bf16(_p(g), g.shape[1], _p(rows), rows.numel(), _p(seg[0]), _p(seg[1]), n_table_rows, extra, n, _p(out),
+                                            out.shape[1], _p(feat), c, _p(slabs), nbytes, _stream()), 'mg_segment_sum_feat_bf16')
+    return out, slabs
+
+
+def feat_wgrad_reduce(slabs, c, ldo, n, dw, col0, accumulate=True):
+    """dw[:, col0 : col0 + c] (+)= the sum of segment_sum_feat's slabs; dw (n, ldw) f32 contiguous."""
+    lib = _lib.load()
+    _lib.check(lib.mg_feat_wgrad_reduce(_p(slabs), c, ldo, n, _p(dw), dw.shape[1], col0, int(bool(accumulate)), _stream()), 'mg_feat_wgrad_reduce')
+
+
 def segment_sum(g, rows, seg, n_table_rows, n, extra=PHONE_RATE_EXTRA):
     """(R + extra, ld) sums of the frame-rate rows of g per table row; the extra rows take the frames with row -1."""
     lib = _lib.load()

@@ -121,6 +121,14 @@ PACKED_FRAMES = os.environ.get('MORGANA_PACKED_FRAMES', '1') != '0'
 OUT_SHADOW = os.environ.get('MORGANA_OUT_SHADOW', '0') != '0'
 
 
+# The first Linear of the 609-input models (cat(repeated phone rows, 9 frame counters), models/RNN_SPSS.py:76-81) with the labels' 600
+# columns at phone rate (ops.phone_concat_layer; backward ops.segment_sum_feat).  MEASURED (round 4, same-box A/B, profiles/
+# r4_phone_rate_609.txt) and OFF: the layer's output must still be written per frame in fp32 (it leaves the fused run for the recurrent
+# wrapper) and its gradient read per frame twice over, so the GEMM the form removes (37 us at N = 256, M = 64,000) is replaced by
+# latency-bound passes that cost as much or more - GRU-F0 3.52 against 3.44 ms, LSTM 16.15 against 16.01 ms.
+CONCAT_PHONE_RATE = os.environ.get('MORGANA_CONCAT_PHONE_RATE', '0') != '0'
+
+
 # Row-wise layers behind a recurrent wrapper are packed only when at least this share of the B * T rows is padding.  Measured at C5
 # (64 utterances of 300-2000 frames, 41 % padding; profiles/r4_c5_packed_vs_padded.txt): the packed Linear stack + loss saves 140 us of
 # GEMM / cast time and pays 257 us for the way there and back (unpack gather of the prediction 44, pack of its gradient 32, column
@@ -621,6 +629,24 @@ class SequentialWithRecurrent(nn.Sequential):
                 if isinstance(input, UpsampledSequence):
                     lead, x2d, rows = input.shape[:2], input.source.reshape(-1, input.source.shape[-1]), \
                         input.rows.reshape(-1)
+                elif (isinstance(input, UpsampledConcat) and precision == 'bf16' and CONCAT_PHONE_RATE
+                      and input.frame_feature.shape[-1] <= 16
+                      and ops.phone_rate_gru_ok(input.upsampled.source.shape[0] * input.upsampled.source.shape[1],
+                                                input.upsampled.rows.numel(), 8, input.upsampled.phone_rate)):
+                    # cat(repeated phone rows, frame counters) (models/RNN_SPSS.py:76-81): W = [W_lab | W_cnt], the lab part of the
+                    # first layer commutes with the repetition and runs once per phone, the counters' part per frame
+                    up = input.upsampled
+                    seg, rows_mapped = up.phone_maps()
+                    feat = input.frame_feature.reshape(-1, input.frame_feature.shape[-1])
+                    params = []
+                    for lin, _ in run:
+                        params += [lin.weight, lin.bias]
+                    spec = (tuple(act for _, act in run), precision, ops.PHONE_RATE_EXTRA, False, run.drop_spec(), None,
+                            (rows_mapped.reshape(-1), seg, feat.contiguous()))
+                    out = F_hip.LinearStackFn.apply(spec, up.source.reshape(-1, up.source.shape[-1]), None, *params)
+                    input = out.view(*input.shape[:2], out.shape[-1])
+                    i = end
+                    continue
                 elif isinstance(input, UpsampledConcat):
                     lead, x2d, rows = input.shape[:2], input.operand(precision == 'bf16'), None
                 else:

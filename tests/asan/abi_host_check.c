@@ -138,6 +138,8 @@ int main(void) {
     { uint32_t c[4] = {0, 0, 0, 0}, k[2] = {0, 0}, o[4]; mg_philox4x32_10(c, k, o); if (o[0] != 0x6627e8d5u) { fprintf(stderr, "mg_philox4x32_10\n"); ++n_bad; } }
     { double fl = 0.0; expect_code("calib_mfma(null)", mg_calib_mfma_bf16(NULL, NULL, 256, 10, &fl, NULL));
       expect_code("calib_mfma(ok)", mg_calib_mfma_bf16(dh, df, 256, 100, &fl, NULL)); }
+    expect_code("phone_concat_layer(C)", mg_phone_concat_layer_bf16(df, 512, di, 64000, df, 17, df, 609, 600, df, 512, MG_ACT_SIGMOID, dh, 512, 0, NULL));
+    expect_code("phone_concat_layer(ok)", mg_phone_concat_layer_bf16(df, 512, di, 64000, df, 9, df, 609, 600, df, 512, MG_ACT_SIGMOID, dh, 512, 0, NULL));
     expect_code("gru_fwd_persist_out(shape)", mg_gru_fwd_persist_out_bf16(df, NULL, 0, dh, 512, df, dl, 64, 1000, 512, df, dh, df, dh, df, d, 16, NULL));
 
     /* plausible shapes: the host path runs its planning and set-up; without a device the launch itself fails (MG_ELAUNCH) */

@@ -78,6 +78,13 @@ def test_new_entry_points_validate_their_arguments_without_a_gpu():
     assert lib.mg_dropout(16, 16, 8, 0, 1.0, 1, 0, None, None) == -1 and 'p must be in [0, 1)' in _lib.last_error()
     assert lib.mg_dropout(16, 16, 0, 0, 0.5, 1, 0, None, None) == 0                      # nothing to do: no launch
     assert lib.mg_calib_mfma_bf16(None, None, 256, 10, None, None) == -1
+    # mg_phone_concat_layer_bf16: at most 16 frame features, their columns inside W, P as wide as N rounded up to 8
+    assert lib.mg_phone_concat_layer_bf16(16, 512, 16, 8, 16, 17, 16, 640, 600, None, 512, 1, 32, 512, 0, None) == -1 and 'C=17' in _lib.last_error()
+    assert lib.mg_phone_concat_layer_bf16(16, 512, 16, 8, 16, 9, 16, 608, 600, None, 512, 1, 32, 512, 0, None) == -1
+    assert lib.mg_segment_sum_feat_bf16(16, 512, 16, 64, 16, 16, 8, 4, 512, 16, 512, 16, 9, 16, 1024, None) == -1 and 'slabs too small' in _lib.last_error()
+    assert lib.mg_segment_sum_feat_workspace_bytes(9, 512) % (9 * 512 * 4) == 0
+    assert lib.mg_feat_wgrad_reduce(16, 9, 512, 512, 16, 608, 600, 0, None) == -1
+    assert lib.mg_phone_concat_layer_bf16(16, 96, 16, 8, 16, 9, 16, 609, 600, None, 100, 1, 32, 128, 0, None) == -1 and 'ldp=96' in _lib.last_error()
     for precision in ('fp32', 'bf16', 'bf16x3'):
         from morgana_amd import functional as F_hip
         F_hip.set_precision(precision)

@@ -850,3 +850,124 @@ def test_frame_layout_with_a_host_total_that_disagrees_with_the_lengths():
                 for f in range(t):
                     i = off[b] + f
                     assert inv[b, f] == (i if f < int(seq[b]) and i < total else total)
+
+
+@pytest.mark.parametrize('n,act,out_f32', [(512, ops.ACT_SIGMOID, False), (256, ops.ACT_SIGMOID, True), (100, ops.ACT_NONE, False),
+                                           (20, ops.ACT_NONE, True)])
+def test_phone_concat_layer_kernel(n, act, out_f32):
+    """mg_phone_concat_layer_bf16 (csrc/phone_rate.hip): act(P[rows] + counters W_cnt^T + b) with P = table W_lab^T at phone rate, against
+    the same arithmetic in torch (bf16-rounded table and lab weights, fp32 counters and their weights, fp32 accumulation): fp32
+    output to 1e-5 of the largest value, bf16 output to one bf16 step; padding columns zero; padding frames (row -1 -> the zero
+    row behind the table) see the bias and their counters only."""
+    rng = np.random.RandomState(n)
+    r, k_lab, c, extra = 37, 600, 9, 5
+    counts = rng.randint(1, 9, size=r)
+    rows_np = np.concatenate([np.repeat(np.arange(r), counts), -np.ones(11)]).astype(np.int32)
+    m = rows_np.size
+    table = dev(rng.uniform(0, 1, (r, k_lab)).astype(np.float32))
+    feat = dev(rng.uniform(0, 1, (m, c)).astype(np.float32))
+    w = dev((rng.standard_normal((n, k_lab + c)) * 0.05).astype(np.float32))
+    b = dev((rng.standard_normal(n) * 0.1).astype(np.float32))
+    rows = torch.from_numpy(rows_np).to(DEV)
+    seg, mapped = ops.segment_bounds(rows, r, pad_row=r)
+    table_bf = ops.cast_pad_bf16(table, extra_rows=extra)
+    w_bf = ops.cast_pad_bf16(w)
+    got = ops.phone_concat_layer(table_bf, k_lab, mapped, feat, w, w_bf, b, n, act, out_f32=out_f32)
+    assert got.dtype == (torch.float32 if out_f32 else torch.bfloat16)
+    assert got.shape[1] == ((n + 7) // 8 * 8 if out_f32 else ops.pad8(n)) and not bool(got[:, n:].any())
+    lab = torch.cat((table.to(torch.bfloat16).double(), torch.zeros((1, k_lab), dtype=torch.float64, device=DEV)))[mapped.long()]
+    z = lab @ w[:, :k_lab].to(torch.bfloat16).double().t() + feat.double() @ w[:, k_lab:].double().t() + b.double()
+    want = torch.sigmoid(z) if act == ops.ACT_SIGMOID else z
+    err = float((got[:, :n].double() - want).abs().max() / want.abs().max())
+    assert err < (1e-5 if out_f32 else 2.0 ** -8), err
+    pad = rows_np < 0
+    z_pad = feat.double()[torch.from_numpy(pad).to(DEV)] @ w[:, k_lab:].double().t() + b.double()
+    want_pad = torch.sigmoid(z_pad) if act == ops.ACT_SIGMOID else z_pad
+    assert float((got[torch.from_numpy(pad).to(DEV), :n].double() - want_pad).abs().max()) < (1e-5 if out_f32 else 2.0 ** -7)
+
+
+@pytest.mark.parametrize('which', ['gru_f0', 'lstm'])
+def test_first_layer_of_the_609_input_models_at_phone_rate(which, monkeypatch):
+    """cat(upsampled labels, frame counters) -> Linear (models/RNN_SPSS.py:76-81, models/f0_test_model.py:78-79) in bf16 mode at both
+    orders of operations: phone rate = the labels' 600 columns multiplied once per phone (mg_phone_concat_layer_bf16 adds the counters'
+    9 columns per frame; backward: per-phone sums of the gradient), frame rate = one gather + concat pass and the 609-column GEMM per
+    frame.  Same loss and gradients to bf16 tolerance, both tracking fp32 mode; also with active dropout behind the layer."""
+    if which == 'gru_f0':
+        feats_np = synthetic.make_acoustic_batch(16, (300, 400), streams=(('lf0', 3, 'mse'),), seed=5)
+        make = lambda prec, p=0.: models.GRUF0Model(precision=prec, dropout_prob=p, generate=False)
+    else:
+        feats_np = synthetic.make_acoustic_batch(16, (300, 400), seed=6)
+        make = lambda prec, p=0.: models.LSTMAcousticModel(precision=prec, num_layers=2, dropout_prob=p, generate=False)
+    feats = data.to_device(feats_np, DEV)
+    got = {}
+    monkeypatch.setattr(utils, 'CONCAT_PHONE_RATE', True)             # measured and off by default (utils.CONCAT_PHONE_RATE)
+    for tag, prec, choice in (('fp32', 'fp32', None), ('phone', 'bf16', True), ('frame', 'bf16', False)):
+        torch.manual_seed(2)
+        model = make(prec).to(DEV)
+        model.phone_rate = choice
+        calls = []
+        _lib.CALL_LOG = calls
+        try:
+            loss, _ = model(feats)
+            F_hip.backward(loss)
+        finally:
+            _lib.CALL_LOG = None
+        ops.check_persistent_status()
+        assert (calls.count('mg_phone_concat_layer_bf16') == 1) == (tag == 'phone'), (tag, calls.count('mg_phone_concat_layer_bf16'))
+        assert (calls.count('mg_segment_sum_feat_bf16') == 1) == (tag == 'phone') == (calls.count('mg_feat_wgrad_reduce') == 1)
+        assert (calls.count('mg_gather_concat_bf16') == 1) == (tag == 'frame')
+        got[tag] = (float(loss.detach()), {n: p.grad.detach().cpu().numpy().copy() for n, p in model.named_parameters()})
+    for tag in ('phone', 'frame'):
+        np.testing.assert_allclose(got[tag][0], got['fp32'][0], rtol=RTOL_BF16)
+        for name, want in got['fp32'][1].items():
+            assert rel_err(got[tag][1][name], want) < 5e-2, (tag, name, rel_err(got[tag][1][name], want))
+    for name, want in got['frame'][1].items():
+        assert rel_err(got['phone'][1][name], want) < 3e-2, (name, rel_err(got['phone'][1][name], want))
+    # active dropout behind the first layer: the mask is per frame, drawn over the layer's frame-rate output either way
+    torch.manual_seed(2)
+    model = make('bf16', 0.2).to(DEV)
+    model.phone_rate = True
+    model.train()
+    calls = []
+    _lib.CALL_LOG = calls
+    try:
+        loss, _ = model(feats)
+        F_hip.backward(loss)
+    finally:
+        _lib.CALL_LOG = None
+    assert calls.count('mg_phone_concat_layer_bf16') == 1 and calls.count('mg_dropout') >= 2
+    assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+@pytest.mark.parametrize('n,c', [(512, 9), (256, 9), (104, 3), (1024, 16)])
+def test_segment_sum_with_frame_feature_gradients(n, c):
+    """mg_segment_sum_feat_bf16 + mg_feat_wgrad_reduce (csrc/phone_rate.hip): the per-phone sums of a bf16 gradient - bit for bit
+    mg_segment_sum's - and from the same pass dW[:, col0:col0+C] = g^T feat (fp32 sums of bf16 g times fp32 features: 1e-5 of the
+    largest element against float64), overwriting or accumulating; padding frames (row -1) count; run twice: the same bits."""
+    rng = np.random.RandomState(n + c)
+    r, extra, col0 = 700, 1024, 600
+    counts = rng.randint(0, 24, size=r)
+    pieces = []
+    for i, k in enumerate(counts):
+        pieces.append(np.full(k, i))
+        if i % 97 == 96:
+            pieces.append(-np.ones(rng.randint(1, 40)))
+    rows_np = np.concatenate(pieces).astype(np.int32)
+    m = rows_np.size
+    rows = torch.from_numpy(rows_np).to(DEV)
+    seg, mapped = ops.segment_bounds(rows, r, pad_row=r)
+    g = ops.cast_pad_bf16(dev(rng.standard_normal((m, n)).astype(np.float32)))
+    feat = dev(rng.uniform(0, 1, (m, c)).astype(np.float32))
+    want_sums = ops.segment_sum(g, mapped, seg, r, g.shape[1], extra=extra)
+    sums, slabs = ops.segment_sum_feat(g, mapped, seg, r, g.shape[1], feat, extra=extra)
+    assert torch.equal(sums, want_sums)
+    dw = torch.full((n, col0 + c + 2), 7.0, device=DEV)
+    ops.feat_wgrad_reduce(slabs, c, sums.shape[1], n, dw, col0, accumulate=False)
+    want = (g[:, :n].double().t() @ feat.double())
+    got = dw[:, col0:col0 + c].double()
+    assert float((got - want).abs().max() / want.abs().max()) < 1e-5
+    assert bool((dw[:, :col0] == 7.0).all()) and bool((dw[:, col0 + c:] == 7.0).all())
+    ops.feat_wgrad_reduce(slabs, c, sums.shape[1], n, dw, col0, accumulate=True)
+    assert torch.allclose(dw[:, col0:col0 + c].double(), 2 * got, rtol=1e-6)
+    sums2, slabs2 = ops.segment_sum_feat(g, mapped, seg, r, g.shape[1], feat, extra=extra)
+    assert torch.equal(slabs2, slabs) and torch.equal(sums2, sums)
