@@ -61,7 +61,8 @@ const char* mg_last_error(void);
                                  * 1000 + S / 2000 + S override the one-n-tile / the 4+-n-tile plans only */
 #define MG_TUNE_WGRAD_ORDER 5   /* wide weight-gradient kernel, block order: 0 = planned, 1 = n tile fastest, 2 = the n tiles of a split
                                  * on one XCD, 3 = the 128 x 128 kernel instead of the wide one */
-#define MG_TUNE_LSTM_BWD_STACK 6 /* mg_lstm_pstack_bwd_bf16: 0 = 32 hidden units per slot where they fit (one workgroup per CU), 1 = 16 */
+#define MG_TUNE_LSTM_BWD_STACK 6 /* LSTM stack wavefronts, hidden units per slot: 0 = backward 32 where they fit (one workgroup per CU),
+                                 * forward 16 (two per CU); bit 0 (1) = backward 16; bit 1 (2) = forward 32 (same bits, measured slower) */
 #define MG_TUNE_AB 7            /* shared-grid launches as their separate launches, half-width tiles off: 65 = mg_linear_wgrad_dgrad_bf16 as
                                  * two launches, 66 = mg_phone_front_linear_fwd_bf16 as two, 92 = 128 x 640 tiles for the 640-wide weight
                                  * gradient at phone-rate rows, 93 = 128 x 512 tiles for the 512-wide one, 94 = mg_phone_front_linear_fwd_bf16 with the

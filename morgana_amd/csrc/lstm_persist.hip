@@ -522,24 +522,29 @@ __device__ __forceinline__ bool lps_wait(gu32* own, unsigned need_own, gu32* low
     }
 }
 
-template <int MT, int KS>
-__global__ __launch_bounds__(256, 2) void lstm_stack_fwd_persist_kernel(LstmPStack a, const int64_t* __restrict__ seq_len, int B, int T, int H,
-                                                                        int L, int G, int R, unsigned* sync, uint16_t* rings, int force_sc1) {
-    __shared__ float red[4][4][MT][GT * GT];
-    __shared__ __attribute__((aligned(16))) uint16_t hb[MT][GT][GT];
-    __shared__ __attribute__((aligned(16))) float res[MT][6][GT * GT];   // c, out, i, f, g, o of the step on their way to waves 2 and 3
+// UT = hidden-unit tiles of 16 per workgroup.  UT = 1 (default): two workgroups per CU (256 VGPRs each), each taking in the whole state of
+// its group and of the group below - 128 KB per CU and step.  UT = 2 (MG_TUNE_LSTM_BWD_STACK bit 1): ONE workgroup per CU with up to 512
+// VGPRs owns 32 units - both unit tiles' weight slices resident (256 registers), every tile read once per CU and multiplied against
+// both: half the intake, same bits - and 8 % slower on the shipped stack (see mg_lstm_pstack_fwd_bf16).
+template <int MT, int KS, int UT>
+__global__ __launch_bounds__(256, UT == 1 ? 2 : 1) void lstm_stack_fwd_persist_kernel(LstmPStack a, const int64_t* __restrict__ seq_len, int B, int T,
+                                                                                      int H, int L, int G, int R, unsigned* sync, uint16_t* rings,
+                                                                                      int force_sc1) {
+    __shared__ float red[4][4][UT][MT][GT * GT];
+    __shared__ __attribute__((aligned(16))) uint16_t hb[UT][MT][GT][GT];
+    __shared__ __attribute__((aligned(16))) float res[UT][MT][6][GT * GT];   // c, out, i, f, g, o of the step on their way to waves 2 and 3
     __shared__ int s_abort, s_xcd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
     const int n_ids = L * G;
     const int id = blockIdx.x % n_ids, slot = blockIdx.x / n_ids;
     const int layer = id / G, group = id - layer * G;
-    const int n_slots = H / GT;
+    const int n16 = H / GT, n_slots = n16 / UT;
     const int row0 = group * R;
     const int nrows = min(R, B - row0);
     if (slot >= n_slots || nrows <= 0) return;
     const mg_lstm_pstack_layer& P = a.l[layer];
-    const int j0 = slot * GT;
+    const int j0 = slot * GT * UT;
     gu32* flags_a = (gu32*)sync + LPS_FLAGA_WORD + id * GP_SLOTS;
     gu32* flags_x = (gu32*)sync + LPS_FLAGX_WORD + id * GP_SLOTS;
     gu32* flags_lo = layer > 0 ? flags_x - G * GP_SLOTS : (gu32*)nullptr;
@@ -559,40 +564,44 @@ __global__ __launch_bounds__(256, 2) void lstm_stack_fwd_persist_kernel(LstmPSta
     const int kbase = wave * (H / 4) + 8 * q;
     // fwi: the W_ih slice of a layer above the first.  Layer 0 has no such slice and keeps its xproj values of the current
     // step in the same registers (XG below) - the kernel sits at the 256-VGPR limit of two workgroups per CU.
-    gbf8 fwh[4][KS];
-    u32x4 fwi[4][KS];
+    gbf8 fwh[UT][4][KS];
+    u32x4 fwi[UT][4][KS];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const uint16_t* wp = P.w_hh_bf + ((size_t)g * H + j0 + li) * P.ldwh + kbase;
+    for (int u = 0; u < UT; ++u)
 #pragma unroll
-        for (int i = 0; i < KS; ++i) {
-            fwh[g][i] = *reinterpret_cast<const gbf8*>(wp + 32 * i);
-            fwi[g][i] = u32x4{0u, 0u, 0u, 0u};
+        for (int g = 0; g < 4; ++g) {
+            const uint16_t* wp = P.w_hh_bf + ((size_t)g * H + j0 + GT * u + li) * P.ldwh + kbase;
+#pragma unroll
+            for (int i = 0; i < KS; ++i) {
+                fwh[u][g][i] = *reinterpret_cast<const gbf8*>(wp + 32 * i);
+                fwi[u][g][i] = u32x4{0u, 0u, 0u, 0u};
+            }
+            if (layer > 0) {
+                const uint16_t* wi = P.w_ih_bf + ((size_t)g * H + j0 + GT * u + li) * P.ldwi + kbase;
+#pragma unroll
+                for (int i = 0; i < KS; ++i) fwi[u][g][i] = *reinterpret_cast<const u32x4*>(wi + 32 * i);
+            }
         }
-        if (layer > 0) {
-            const uint16_t* wi = P.w_ih_bf + ((size_t)g * H + j0 + li) * P.ldwi + kbase;
-#pragma unroll
-            for (int i = 0; i < KS; ++i) fwi[g][i] = *reinterpret_cast<const u32x4*>(wi + 32 * i);
-        }
-    }
-#define XG(m, g) fwi[(m) / KS][(m) % KS][g]                    /* layer 0: xproj of this step, item tile m, gate g */
+#define XG(u, m, g) fwi[u][(m) / KS][(m) % KS][g]              /* layer 0: xproj of this step, unit tile u, item tile m, gate g */
     // rings: A [layer][2 epochs][G groups][H / 16 slots][R items][16 units] bf16, then X [layer][4 epochs][...]
-    const unsigned par_bytes = (unsigned)(G * n_slots * R * 32);
+    const unsigned par_bytes = (unsigned)(G * n16 * R * 32);
     const unsigned x_base = (unsigned)L * 2 * par_bytes;
     const auto rs_ring = __builtin_amdgcn_make_buffer_rsrc((void*)rings, 0, (int)((2 + LPS_XDEPTH) * par_bytes * L), 0x00020000);
     const unsigned ring_own = (unsigned)layer * 2 * par_bytes;
     const unsigned ring_x = x_base + (unsigned)layer * LPS_XDEPTH * par_bytes;
     const unsigned ring_lo = x_base + (unsigned)(layer > 0 ? layer - 1 : 0) * LPS_XDEPTH * par_bytes;
-    const unsigned rd_base = (unsigned)(((group * n_slots + (kbase >> 4)) * R) * 32 + 16 * (q & 1));
+    const unsigned rd_base = (unsigned)(((group * n16 + (kbase >> 4)) * R) * 32 + 16 * (q & 1));
     const unsigned rd_kstep = (unsigned)(2 * R * 32);
-    const unsigned wr_base = (unsigned)(((group * n_slots + slot) * R) * 32);
+    const unsigned wr_base = (unsigned)(((group * n16 + slot * UT) * R) * 32);       // unit tile u: + u R 32
 
     const int bl = tid >> 4, jl = tid & 15;
-    const int j = j0 + jl;
-    float bsum[4];
+    const int j = j0 + jl;                            // the thread's unit of tile 0; tile u: + 16 u
+    float bsum[UT][4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) bsum[g] = P.b_hh[g * H + j] + (layer > 0 ? P.b_ih[g * H + j] : 0.f);
-    float hprev[MT], cprev[MT];
+    for (int u = 0; u < UT; ++u)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bsum[u][g] = P.b_hh[g * H + j + GT * u] + (layer > 0 ? P.b_ih[g * H + j + GT * u] : 0.f);
+    float hprev[UT][MT], cprev[UT][MT];
     int len[MT];
     bool mine[MT];
     const float* xp[MT];
@@ -600,14 +609,17 @@ __global__ __launch_bounds__(256, 2) void lstm_stack_fwd_persist_kernel(LstmPSta
     for (int m = 0; m < MT; ++m) {
         mine[m] = 16 * m + bl < nrows;
         const int b = row0 + (mine[m] ? 16 * m + bl : 0);
-        hprev[m] = P.hstate[((size_t)b * (T + 1)) * H + j];
-        cprev[m] = P.cstate[((size_t)b * (T + 1)) * H + j];
         len[m] = seq_len ? (int)min((int64_t)T, seq_len[b]) : T;
-        hb[m][bl][jl] = mg_f2bf(hprev[m]);
         xp[m] = (layer == 0 ? P.xproj : P.b_hh) + (layer == 0 ? (size_t)b * T * 4 * H + j : 0);
-        if (layer == 0) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) XG(m, g) = __float_as_uint(xp[m][g * H]);
+        for (int u = 0; u < UT; ++u) {
+            hprev[u][m] = P.hstate[((size_t)b * (T + 1)) * H + j + GT * u];
+            cprev[u][m] = P.cstate[((size_t)b * (T + 1)) * H + j + GT * u];
+            hb[u][m][bl][jl] = mg_f2bf(hprev[u][m]);
+            if (layer == 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) XG(u, m, g) = __float_as_uint(xp[m][g * H + GT * u]);
+            }
         }
     }
     __syncthreads();
@@ -619,18 +631,22 @@ __global__ __launch_bounds__(256, 2) void lstm_stack_fwd_persist_kernel(LstmPSta
             if (lane < 2 * 16 * MT) {
                 const int rrow = lane >> 1, half = lane & 1;
                 if (rrow < nrows) {
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(&hb[rrow >> 4][rrow & 15][8 * half]);
-                    const unsigned tile = wr_base + (unsigned)(rrow * 32 + half * 16);
-                    if (wave == 0) {
-                        const unsigned off = ring_own + (e & 1) * par_bytes + tile;
-                        if (one_xcd)
-                            __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 0);
-                        else
-                            __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 16);
-                    } else {
-                        if (layer + 1 < L)
-                            __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, ring_x + (e & (LPS_XDEPTH - 1)) * par_bytes + tile, 0, 16);
-                        if (e > 0) *reinterpret_cast<u32x4*>(P.hstate_bf + ((size_t)(row0 + rrow) * (T + 1) + e) * H + j0 + 8 * half) = v;
+#pragma unroll
+                    for (int u = 0; u < UT; ++u) {
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(&hb[u][rrow >> 4][rrow & 15][8 * half]);
+                        const unsigned tile = wr_base + (unsigned)(u * R * 32 + rrow * 32 + half * 16);
+                        if (wave == 0) {
+                            const unsigned off = ring_own + (e & 1) * par_bytes + tile;
+                            if (one_xcd)
+                                __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 0);
+                            else
+                                __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 16);
+                        } else {
+                            if (layer + 1 < L)
+                                __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, ring_x + (e & (LPS_XDEPTH - 1)) * par_bytes + tile, 0, 16);
+                            if (e > 0)
+                                *reinterpret_cast<u32x4*>(P.hstate_bf + ((size_t)(row0 + rrow) * (T + 1) + e) * H + j0 + GT * u + 8 * half) = v;
+                        }
                     }
                 }
             }
@@ -658,7 +674,7 @@ __global__ __launch_bounds__(256, 2) void lstm_stack_fwd_persist_kernel(LstmPSta
 #endif
 
     for (int t = 0; t < gmax; ++t) {
-        float xg1[MT][4];                            // layer 0: the next step's xproj values, in flight until the end of the step
+        float xg1[UT][MT][4];                        // layer 0: the next step's xproj values, in flight until the end of the step
         MG_STAMP(ta);
         if (wave == 0 && !lps_wait(flags_a, (unsigned)(t + 1), flags_lo, t + 2, seen_lo, flags_up, t - (LPS_XDEPTH - 2), seen_up, n_slots, lane))
             s_abort = 1;
@@ -696,14 +712,18 @@ __global__ __launch_bounds__(256, 2) void lstm_stack_fwd_persist_kernel(LstmPSta
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const unsigned rn = m + 1 < MT ? tile_off(m + 1) : 0u;
-            f32x4 acc[4];
+            f32x4 acc[UT][4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < UT; ++u)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[u][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < KS; ++i) {
                 const gbf8 av = as_bf8(raw[i]);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, fwh[g][i], acc[g], 0, 0, 0);
+                for (int u = 0; u < UT; ++u)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[u][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, fwh[u][g][i], acc[u][g], 0, 0, 0);
                 if (m + 1 < MT) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ring, own0 + rn + i * rd_kstep, 0, 16);
             }
             if (layer > 0) {
@@ -711,7 +731,10 @@ __global__ __launch_bounds__(256, 2) void lstm_stack_fwd_persist_kernel(LstmPSta
                 for (int i = 0; i < KS; ++i) {
                     const gbf8 av = as_bf8(rawx[i]);
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, as_bf8(fwi[g][i]), acc[g], 0, 0, 0);
+                    for (int u = 0; u < UT; ++u)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            acc[u][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, as_bf8(fwi[u][g][i]), acc[u][g], 0, 0, 0);
                     if (m + 1 < MT) rawx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ring, low0 + rn + i * rd_kstep, 0, 16);
                 }
             }
@@ -719,7 +742,9 @@ __global__ __launch_bounds__(256, 2) void lstm_stack_fwd_persist_kernel(LstmPSta
             for (int r = 0; r < 4; ++r) {
                 const int e = (4 * q + r) * GT + li;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) red[wave][g][m][e] = acc[g][r];
+                for (int u = 0; u < UT; ++u)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) red[wave][g][u][m][e] = acc[u][g][r];
             }
         }
         if (t > 0) raise_x(t);                        // epoch t's write-through stores (issued a step ago) have long landed
@@ -728,35 +753,39 @@ __global__ __launch_bounds__(256, 2) void lstm_stack_fwd_persist_kernel(LstmPSta
             // step - memory returns in order, and the second tile's loads must not wait for these
             const int t1 = t + 1 < T ? t + 1 : t;
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int u = 0; u < UT; ++u)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) xg1[m][g] = xp[m][(size_t)t1 * 4 * H + g * H];
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) xg1[u][m][g] = xp[m][(size_t)t1 * 4 * H + g * H + GT * u];
         }
         gp_lds_barrier();
         MG_STAMP(tb);
         MG_STAMP_ADD(sum_mm, tb, ta);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int e = bl * GT + jl;
-            float pre[4];
+        for (int u = 0; u < UT; ++u)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                pre[g] = (layer == 0 ? __uint_as_float(XG(m, g)) : 0.f) +
-                         (((red[0][g][m][e] + red[1][g][m][e]) + (red[2][g][m][e] + red[3][g][m][e])) + bsum[g]);
-            const float ig = mg_sigmoid_fast(pre[0]), fg = mg_sigmoid_fast(pre[1]), gg = lp_tanh_fast(pre[2]), og = mg_sigmoid_fast(pre[3]);
-            const float cnew = fg * cprev[m] + ig * gg;
-            const float hnew = og * lp_tanh_fast(cnew);
-            const bool active = t < len[m];
-            hprev[m] = active ? hnew : hprev[m];
-            cprev[m] = active ? cnew : cprev[m];
-            hb[m][bl][jl] = mg_f2bf(hprev[m]);
-            res[m][0][e] = cprev[m];
-            res[m][1][e] = active ? hnew : 0.f;
-            res[m][2][e] = ig;
-            res[m][3][e] = fg;
-            res[m][4][e] = gg;
-            res[m][5][e] = og;
-        }
+            for (int m = 0; m < MT; ++m) {
+                const int e = bl * GT + jl;
+                float pre[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    pre[g] = (layer == 0 ? __uint_as_float(XG(u, m, g)) : 0.f) +
+                             (((red[0][g][u][m][e] + red[1][g][u][m][e]) + (red[2][g][u][m][e] + red[3][g][u][m][e])) + bsum[u][g]);
+                const float ig = mg_sigmoid_fast(pre[0]), fg = mg_sigmoid_fast(pre[1]), gg = lp_tanh_fast(pre[2]), og = mg_sigmoid_fast(pre[3]);
+                const float cnew = fg * cprev[u][m] + ig * gg;
+                const float hnew = og * lp_tanh_fast(cnew);
+                const bool active = t < len[m];
+                hprev[u][m] = active ? hnew : hprev[u][m];
+                cprev[u][m] = active ? cnew : cprev[u][m];
+                hb[u][m][bl][jl] = mg_f2bf(hprev[u][m]);
+                res[u][m][0][e] = cprev[u][m];
+                res[u][m][1][e] = active ? hnew : 0.f;
+                res[u][m][2][e] = ig;
+                res[u][m][3][e] = fg;
+                res[u][m][4][e] = gg;
+                res[u][m][5][e] = og;
+            }
         gp_lds_barrier();
         MG_STAMP(ta);
         MG_STAMP_ADD(sum_cell, ta, tb);
@@ -769,23 +798,25 @@ __global__ __launch_bounds__(256, 2) void lstm_stack_fwd_persist_kernel(LstmPSta
             // 16-byte stores: job = (array, item tile), 64 lanes per job = 16 items x 4 column quads; wave 2 and wave 3 split the jobs.
             const int n_arrays = layer + 1 == L ? 6 : 5;              // array 1 = out: top layer only
             const int rb = lane >> 2, c4 = 4 * (lane & 3);
-            for (int job = wave - 2; job < n_arrays * MT; job += 2) {
-                const int m = job % MT, k0 = job / MT, k = (k0 >= 1 && n_arrays == 5) ? k0 + 1 : k0;
+            for (int job = wave - 2; job < n_arrays * MT * UT; job += 2) {
+                const int u = job % UT, jm = job / UT, m = jm % MT, k0 = jm / MT, k = (k0 >= 1 && n_arrays == 5) ? k0 + 1 : k0;
                 if (16 * m + rb < nrows) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(&res[m][k][rb * GT + c4]);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(&res[u][m][k][rb * GT + c4]);
                     const int b = row0 + 16 * m + rb;
                     float* dst = k == 0   ? P.cstate + ((size_t)b * (T + 1) + t + 1) * H
                                  : k == 1 ? P.out + ((size_t)b * T + t) * H
                                           : P.saved + ((size_t)b * T + t) * 4 * H + (size_t)(k - 2) * H;
-                    *reinterpret_cast<f32x4*>(dst + j0 + c4) = v;
+                    *reinterpret_cast<f32x4*>(dst + j0 + GT * u + c4) = v;
                 }
             }
         }
         if (layer == 0) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int u = 0; u < UT; ++u)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) XG(m, g) = __float_as_uint(xg1[m][g]);
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) XG(u, m, g) = __float_as_uint(xg1[u][m][g]);
         }
     }
 #undef XG
@@ -811,21 +842,28 @@ __global__ __launch_bounds__(256, 2) void lstm_stack_fwd_persist_kernel(LstmPSta
             if (mine[m]) {
                 const int b = row0 + 16 * m + bl;
                 const size_t row = (size_t)b * T + t;
-                const size_t nxt = ((size_t)b * (T + 1) + t + 1) * H + j;
-                P.cstate[nxt] = cprev[m];
-                P.hstate_bf[nxt] = mg_f2bf(hprev[m]);
-                if (layer + 1 == L) P.out[row * H + j] = 0.f;
-                float* sv = P.saved + row * 4 * H;
-                sv[j] = 0.f;
-                sv[H + j] = 0.f;
-                sv[2 * H + j] = 0.f;
-                sv[3 * H + j] = 0.f;
+#pragma unroll
+                for (int u = 0; u < UT; ++u) {
+                    const int ju = j + GT * u;
+                    const size_t nxt = ((size_t)b * (T + 1) + t + 1) * H + ju;
+                    P.cstate[nxt] = cprev[u][m];
+                    P.hstate_bf[nxt] = mg_f2bf(hprev[u][m]);
+                    if (layer + 1 == L) P.out[row * H + ju] = 0.f;
+                    float* sv = P.saved + row * 4 * H;
+                    sv[ju] = 0.f;
+                    sv[H + ju] = 0.f;
+                    sv[2 * H + ju] = 0.f;
+                    sv[3 * H + ju] = 0.f;
+                }
             }
     }
     // h_n: the only fp32 state row kept (slot T of hstate)
 #pragma unroll
     for (int m = 0; m < MT; ++m)
-        if (mine[m]) P.hstate[((size_t)(row0 + 16 * m + bl) * (T + 1) + T) * H + j] = hprev[m];
+        if (mine[m]) {
+#pragma unroll
+            for (int u = 0; u < UT; ++u) P.hstate[((size_t)(row0 + 16 * m + bl) * (T + 1) + T) * H + j + GT * u] = hprev[u][m];
+        }
 }
 
 // =====================================================================================================================
@@ -1384,23 +1422,30 @@ int mg_lstm_pstack_fwd_bf16(const mg_lstm_pstack_layer* layers, int L, const int
     }
     const int G = lps_groups(B, H, L);
     const int R = (int)mg_ceil_div(B, G);
-    const unsigned grid = (unsigned)(L * G * (H / GT));
+    // 16 hidden units per workgroup, two workgroups per CU.  The 32-unit form (one workgroup per CU, each hand-off tile read once per
+    // CU: what pays in the backward, whose tiles are four times larger) is built and bit-equal (MG_TUNE_LSTM_BWD_STACK bit 1, R > 16)
+    // but MEASURED slower here: the shipped 8 x LSTM-512 step 17.37-17.42 against 16.07-16.16 ms (round 4, same box, alternating) -
+    // one workgroup's MFMA and cell phases double and nothing runs on the CU while it waits, which the halved intake does not buy back
+    const int UT = (R > 16 && (H / GT) % 2 == 0 && (g_mg_tuning[MG_TUNE_LSTM_BWD_STACK] & 2)) ? 2 : 1;
+    const unsigned grid = (unsigned)(L * G * (H / (GT * UT)));
     uint16_t* rings = (uint16_t*)((char*)workspace + LPS_RING_OFFSET);
     const int force = g_mg_tuning[MG_TUNE_GRU_HANDOFF];
-#define LPS_FWD(MT, KS)                                                                                                                  \
-    hipLaunchKernelGGL((lstm_stack_fwd_persist_kernel<MT, KS>), dim3(grid), dim3(256), 0, st, a, seq_len, B, T, H, L, G, R, (unsigned*)workspace, \
+#define LPS_FWD(MT, KS, UT_)                                                                                                             \
+    hipLaunchKernelGGL((lstm_stack_fwd_persist_kernel<MT, KS, UT_>), dim3(grid), dim3(256), 0, st, a, seq_len, B, T, H, L, G, R, (unsigned*)workspace, \
                        rings, force)
-#define LPS_FWD_KS(MT)                 \
+#define LPS_FWD_KS(MT, UT_)                 \
     switch (H / 128) {                 \
-        case 1: LPS_FWD(MT, 1); break; \
-        case 2: LPS_FWD(MT, 2); break; \
-        case 3: LPS_FWD(MT, 3); break; \
-        default: LPS_FWD(MT, 4); break; \
+        case 1: LPS_FWD(MT, 1, UT_); break; \
+        case 2: LPS_FWD(MT, 2, UT_); break; \
+        case 3: LPS_FWD(MT, 3, UT_); break; \
+        default: LPS_FWD(MT, 4, UT_); break; \
     }
     if (R <= 16) {
-        LPS_FWD_KS(1)
+        LPS_FWD_KS(1, 1)
+    } else if (UT == 2) {
+        LPS_FWD_KS(2, 2)
     } else {
-        LPS_FWD_KS(2)
+        LPS_FWD_KS(2, 1)
     }
     MG_CHECK_LAUNCH("mg_lstm_pstack_fwd_bf16");
     return MG_OK;
@@ -1410,7 +1455,7 @@ int mg_lstm_pstack_fwd_bf16(const mg_lstm_pstack_layer* layers, int L, const int
 static int lpsb_plan(int B, int H, int L, int* G_out, int* UT_out) {
     // units per slot: 32 (UT = 2, one workgroup per CU) unless MG_TUNE_LSTM_BWD_STACK = 1 asks for 16 (two per CU); the largest G in
     // {8, 4, 2, 1} whose L G H / (16 UT) workgroups are all resident, with at most 32 items per group and L G <= 64 flag rows
-    for (int UT = g_mg_tuning[MG_TUNE_LSTM_BWD_STACK] == 1 ? 1 : 2; UT >= 1; --UT)
+    for (int UT = (g_mg_tuning[MG_TUNE_LSTM_BWD_STACK] & 1) ? 1 : 2; UT >= 1; --UT)
         for (int G = 8; G >= 1; G >>= 1) {
             const long wgs = (long)L * G * (H / (GT * UT));
             if (wgs > (UT == 2 ? 256 : 512) || L * G > LPS_MAX_IDS || !gp_device_holds(UT == 2 ? 2 * wgs : wgs)) continue;

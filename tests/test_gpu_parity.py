@@ -1384,8 +1384,17 @@ def test_lstm_stack_wavefront_vs_chained_layers(b, t, i_dim, hid, n_layers):
             torch.cuda.synchronize()
             for k, (g, w) in enumerate(zip(got, first)):
                 np.testing.assert_array_equal(g, w, err_msg='output %d under concurrent load' % k)
+            # hidden units per workgroup - backward 16 (two workgroups per CU, tuning bit 0) instead of its default 32 (one per CU,
+            # each hand-off tile read once), forward 32 (bit 1) instead of its default 16: the same products in the same order per
+            # unit, identical bits
+            for form in (2, 1, 3):
+                _lib.load().mg_set_tuning(6, form)
+                got = run('wavefront')
+                for k, (g, w) in enumerate(zip(got, first)):
+                    np.testing.assert_array_equal(g, w, err_msg='output %d, MG_TUNE_LSTM_BWD_STACK %d' % (k, form))
     finally:
         _lib.load().mg_set_tuning(2, 0)
+        _lib.load().mg_set_tuning(6, 0)
 
 
 @pytest.mark.parametrize('b,t,hid', [(5, 37, 64), (64, 50, 64), (1, 9, 128), (37, 21, 128)])
