@@ -271,6 +271,12 @@ int mg_linear_wgrad_f32(const float* dY, const float* A, int lda, const int32_t*
  *                     mean target, loss_const = sum_r sum_f w_f (y_f - ybar[r])^2.  Then
  *                     loss = sum_r weight[r] (pred[r] - ybar[r])^2 + loss_const  exactly, with the same gradient (mg_f0_tail_rows_bf16).
  *                     target f32 [B*T]; ybar, weight f32 [R + extra]; rows R.. take the padding frames. */
+/*  mg_phone_mse_rows_f32  the masked MSE of a ONE-column prediction that is constant over each table row's frames, exact-fp32 modes:
+ *                     loss[0] = sum_r weight[r] (pred[r * ldp] - ybar[r])^2 over the R + extra rows of mg_phone_target_stats (its constant
+ *                     term is added by mg_phone_loss_const_add / mg_expand_column_loss_f32), dpred[r] = 2 weight[r] (pred[r * ldp] - ybar[r]).
+ *                     One workgroup, fixed summation order (double partial sums). */
+int mg_phone_mse_rows_f32(const float* pred, int ldp, const float* ybar, const float* weight, int n_rows, float* loss, float* dpred,
+                          void* stream);
 /*  mg_expand_column_f32  out[f] = table[rows[f]] for a one-column f32 table (the per-phone prediction repeated to frames); rows >= 0. */
 int mg_expand_column_f32(const float* table, const int32_t* rows, int64_t M, float* out, void* stream);
 /* ... and mg_phone_loss_const_add in the same launch (stats_workspace as left by mg_phone_target_stats). */

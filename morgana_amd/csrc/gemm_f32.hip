@@ -338,7 +338,9 @@ static WgradPlan wgrad_plan(int64_t M, int N, int K) {
     p.tiles_k = (int)mg_ceil_div(K, 128);
     const int64_t tiles = (int64_t)p.tiles_n * p.tiles_k;
     int64_t S = mg_ceil_div(1024, tiles);
-    const int64_t max_s = mg_ceil_div(M, 512);
+    // at least 512 rows per split where there are tiles enough to fill the chip; a one- or two-tile product (the 128 -> 32 -> 1 tail of
+    // the README model at phone rate: M = 22,528) would otherwise run on M / 512 = 44 workgroups - 31-39 us for 0.2 GFLOP
+    const int64_t max_s = mg_ceil_div(M, tiles <= 2 ? 128 : 512);
     if (S > max_s) S = max_s;
     if (S < 1) S = 1;
     if (S > 65535) S = 65535;

@@ -465,6 +465,30 @@ __global__ __launch_bounds__(256) void phone_concat_layer_kernel(const float* __
     }
 }
 
+// The masked MSE (morgana/losses.py:29-51) of a ONE-column prediction that is constant over each table row's frames, from the per-row
+// statistics of mg_phone_target_stats / mg_phone_front:  sum_f w_f (p_r - y_f)^2 = weight[r] (p_r - ybar[r])^2 + c_r.  This kernel:
+// loss = sum_r weight[r] (pred[r] - ybar[r])^2 (the c_r are added by mg_phone_loss_const_add / mg_expand_column_loss_f32) and
+// dpred[r] = 2 weight[r] (pred[r] - ybar[r]).  ONE workgroup, fixed order: thread t sums rows t, t + 1024, ... in double, tree in LDS.
+__global__ __launch_bounds__(1024) void phone_mse_rows_kernel(const float* __restrict__ pred, int ldp, const float* __restrict__ ybar,
+                                                              const float* __restrict__ weight, int n, float* __restrict__ loss,
+                                                              float* __restrict__ dpred) {
+    __shared__ double part[1024];
+    double acc = 0.0;
+    for (int r = threadIdx.x; r < n; r += 1024) {
+        const float w = weight[r];
+        const float d = w > 0.f ? pred[(size_t)r * ldp] - ybar[r] : 0.f;
+        dpred[r] = 2.f * w * d;
+        acc += (double)(w * d) * (double)d;
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = (float)part[0];
+}
+
 extern "C" {
 
 int mg_segment_bounds(const int32_t* rows, int64_t M, int R, int32_t* seg_start, int32_t* seg_end, int32_t* rows_mapped, int pad_row,
@@ -635,6 +659,15 @@ int mg_phone_loss_const_add(const void* workspace, int R, int extra, float* loss
     const int blocks = (int)(mg_ceil_div(R, 16) + mg_ceil_div(extra, 4));
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, blocks, loss, 1);
     MG_CHECK_LAUNCH("mg_phone_loss_const_add");
+    return MG_OK;
+}
+
+int mg_phone_mse_rows_f32(const float* pred, int ldp, const float* ybar, const float* weight, int n_rows, float* loss, float* dpred,
+                          void* stream) {
+    MG_CHECK_ARG(pred && ybar && weight && loss && dpred && n_rows > 0 && ldp >= 1, "mg_phone_mse_rows_f32: bad arguments (n_rows=%d ldp=%d)",
+                 n_rows, ldp);
+    hipLaunchKernelGGL(phone_mse_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, ldp, ybar, weight, n_rows, loss, dpred);
+    MG_CHECK_LAUNCH("mg_phone_mse_rows_f32");
     return MG_OK;
 }
 

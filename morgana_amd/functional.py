@@ -517,6 +517,49 @@ class RepeatTableRowsFn(torch.autograd.Function):
         return (sums[:, :width].contiguous() if sums.shape[1] != width else sums), None, None, None
 
 
+class PhoneMSEFn(torch.autograd.Function):
+    """``losses.mse(upsample_to_repetitions(table), target, seq_len)`` (morgana/losses.py:29-51 behind utils.py:175-228) for a ONE-column
+    table of per-phone predictions, without the frame-rate tensor in the differentiable path: every frame of a phone shares the
+    phone's prediction p, so  sum_f w_f (p - y_f)^2 = weight (p - ybar)^2 + c  with the phone's weighted target mean ybar and a
+    constant c (ops.phone_front / phone_target_stats); loss and d loss / d table come from the table rows (``mg_phone_mse_rows_f32``)
+    - no gather of the prediction in front of the loss, no segment sum of its gradient behind it.  The exact-fp32 modes' counterpart
+    of the bf16 step's fused tail.  forward(ctx, table (R + extra, 1), target (B, T, 1), seq_len, holder) -> (loss, prediction
+    (B, T, 1), repeated for reporting, not differentiable).  ``holder``: the ``utils.UpsampledSequence`` that owns the frame map."""
+
+    @staticmethod
+    def forward(ctx, table, target, seq_len, holder):
+        table = ops._require(table, torch.float32, 'prediction table')
+        target = ops._require(target, torch.float32, 'targets')
+        b, t = target.shape[0], target.shape[1]
+        n_src = holder.source.shape[0] * holder.source.shape[1]
+        extra = table.shape[0] - n_src
+        if seq_len.dtype != torch.int64:
+            seq_len = seq_len.long()
+        if holder.pending() and holder.t_cap == t and ops.phone_front_ok(holder.source.shape[0], holder.source.shape[1], t, extra):
+            rows, rows_mapped, seg, ybar, weight, partials = ops.phone_front(holder.dur, target.reshape(-1), seq_len, t, extra)
+            holder.adopt(rows, (seg, rows_mapped.reshape(-1)))
+        else:
+            rows = holder.rows
+            seg, rows_mapped = holder.phone_maps()
+            ybar, weight, partials = ops.phone_target_stats(target.reshape(-1), rows.reshape(-1), seg, seq_len, b, t, n_src, extra)
+        loss, dpred = ops.phone_mse_rows(table, ybar, weight)
+        pred = ops.expand_column(table.reshape(-1) if table.shape[1] == 1 else table[:, 0].contiguous(), rows_mapped.reshape(-1),
+                                 loss_const=(partials, n_src, extra, loss))
+        ctx.save_for_backward(dpred)
+        ctx.cols = table.shape[1]
+        pred = pred.view(b, t, 1)
+        ctx.mark_non_differentiable(pred)
+        return loss.reshape(()), pred
+
+    @staticmethod
+    def backward(ctx, grad_loss, grad_pred):
+        (dpred,) = ctx.saved_tensors
+        g = (dpred * grad_loss).unsqueeze(1)
+        if ctx.cols != 1:
+            g = torch.nn.functional.pad(g, (0, ctx.cols - 1))
+        return g, None, None, None
+
+
 class UnpackRowsFn(torch.autograd.Function):
     """Packed rows (total + 1, D) -> dense (B*T, D): dense row (b, t) takes its packed row, every padded frame takes the one
     representative row (index ``total``).  Backward: the valid rows' gradients are gathered back by ``rows`` and the representative

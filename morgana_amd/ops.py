@@ -996,6 +996,19 @@ def phone_front(dur, target, seq_len, t, extra, linear=None):
     return rows[0], rows[1], seg, stats[0], stats[1], ws, y
 
 
+def phone_mse_rows(pred_table, ybar, weight):
+    """(loss (1,) without the constant term, dpred (rows,)) of the masked MSE of a one-column prediction per table row
+    (mg_phone_mse_rows_f32); pred_table (rows, ld) f32, column 0."""
+    pred_table = _require(pred_table, torch.float32, 'prediction')
+    n = ybar.numel()
+    if pred_table.shape[0] != n:
+        raise ValueError('phone_mse_rows: %d prediction rows for %d statistics rows' % (pred_table.shape[0], n))
+    out = torch.empty((n + 1,), dtype=torch.float32, device=pred_table.device)
+    _lib.check(_lib.load().mg_phone_mse_rows_f32(_p(pred_table), pred_table.shape[1], _p(ybar), _p(weight), n, _p(out[n:]), _p(out), _stream()),
+               'mg_phone_mse_rows_f32')
+    return out[n:], out[:n]
+
+
 def phone_loss_const_add(partials, n_table_rows, extra, loss):
     """loss (0-d f32, in place) += the constant term left by phone_target_stats."""
     _lib.check(_lib.load().mg_phone_loss_const_add(_p(partials), n_table_rows, extra, _p(loss), _stream()), 'mg_phone_loss_const_add')

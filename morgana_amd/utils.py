@@ -547,6 +547,12 @@ class SequentialWithRecurrent(nn.Sequential):
         precision = self.precision or F_hip.get_precision()
         fused = self._fused_mse_spec(targets, precision)
         if fused is None:
+            table = self._phone_rate_table(input, targets, seq_len, precision)
+            if table is not None:
+                # exact-fp32 modes, a stack of Linear / Sigmoid layers on repeated phone rows ending in ONE output column: the layers
+                # run on the phone rows (as ``forward`` runs them) and the masked MSE on the per-phone predictions and target
+                # statistics - the frame-rate prediction is produced for reporting only (functional.PhoneMSEFn)
+                return F_hip.PhoneMSEFn.apply(table, targets, seq_len, input)
             out, _ = self.forward(input, seq_len=seq_len)
             return losses.mse(out, targets, seq_len), out
         run, acts = fused
@@ -566,6 +572,25 @@ class SequentialWithRecurrent(nn.Sequential):
         for lin, _ in run:
             params += [lin.weight, lin.bias]
         return F_hip.LinearStackMSEFn.apply((acts, maps, table, phone_rate), x2d, rows, targets, seq_len, *params)
+
+    def _phone_rate_table(self, input, targets, seq_len, precision):
+        """The (B * P + extra, 1) table of per-phone predictions when the whole container is one Linear / Sigmoid run on an
+        ``UpsampledSequence`` at phone rate with a one-column output and (B, T, 1) targets; else None."""
+        modules = list(self._modules.values())
+        if (not isinstance(input, UpsampledSequence) or seq_len is None or not modules or type(modules[0]) is not nn.Linear
+                or precision not in ('fp32', 'bf16x3') or targets.ndim != 3 or targets.shape[2] != 1
+                or tuple(targets.shape[:2]) != tuple(input.shape[:2])):
+            return None
+        end, run = self._linear_run(modules, 0)
+        n_src = input.source.shape[0] * input.source.shape[1]
+        if (end != len(modules) or any(run.drops) or run[-1][0].weight.shape[0] != 1
+                or not ops.phone_rate_gru_ok(n_src, input.shape[0] * input.shape[1], 8, input.phone_rate)):
+            return None
+        params = []
+        for lin, _ in run:
+            params += [lin.weight, lin.bias]
+        spec = (tuple(act for _, act in run), precision, ops.PHONE_RATE_EXTRA)
+        return F_hip.LinearStackFn.apply(spec, input.source.reshape(-1, input.source.shape[-1]), None, *params)
 
     def forward(self, input, hiddens=None, seq_len=None, max_len=None, layout=None):
         """``max_len`` (not in the reference) is handed to the recurrent wrappers: see ``RecurrentCuDNNWrapper.forward``.

@@ -2483,3 +2483,29 @@ def test_phone_target_stats_reduce_the_masked_mse_exactly(masked):
     frame_loss = float((w * (pred_rows[row_of] - target) ** 2).sum())
     got = float((weight.double().cpu().numpy() * (pred_rows - ybar.double().cpu().numpy()) ** 2).sum() + loss.item())
     np.testing.assert_allclose(got, frame_loss, rtol=1e-5)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_phone_rate_loss_of_the_exact_modes_equals_the_frame_rate_loss(precision):
+    """functional.PhoneMSEFn (the masked MSE on per-phone predictions and target statistics, mg_phone_mse_rows_f32) against the same
+    model with the loss at frame rate (predict + losses.mse: the table's rows repeated, masked MSE over the frames, segment sums
+    behind it) - the same algebra, fp32 rounding apart: loss and every gradient to 1e-5, the reported prediction bit for bit."""
+    from morgana_amd import _lib
+    feats = data.to_device(synthetic.make_batch(32, 400, seed=21), DEV)
+    got = {}
+    for fused in (True, False):
+        model = _load_state(models.F0Model(precision=precision, fused_loss=fused, phone_rate=True).to(DEV), synthetic.f0_model_state())
+        calls = []
+        _lib.CALL_LOG = calls
+        try:
+            loss, out = model(feats)
+            loss.backward()
+        finally:
+            _lib.CALL_LOG = None
+        assert (calls.count('mg_phone_mse_rows_f32') == 1) == fused and (calls.count('mg_segment_sum') == 0) == fused, calls
+        got[fused] = (loss.item(), out['pred_norm_lf0'].detach().cpu().numpy(),
+                      {n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters()})
+    np.testing.assert_allclose(got[True][0], got[False][0], rtol=1e-5)
+    assert np.array_equal(got[True][1], got[False][1])
+    for name in got[False][2]:
+        assert rel_err(got[True][2][name], got[False][2][name]) < 1e-5, name
