@@ -437,7 +437,9 @@ int mg_cast_params_bf16(const mg_cast_desc* descs, int count, void* stream);
  * order 0 -> [hi | hi | lo] (the activation side of a product), order 1 -> [hi | lo | hi] (the weight side); transpose != 0 -> the
  * planes hold the split of src^T: dst [cols, 3 ldp] with ldp >= rows.  order 2 (not transposed) -> dst bf16 [2, rows, ldp]: the hi
  * plane, then the lo plane, each a matrix of its own (the operands of a weight gradient, which contracts over the rows: three
- * accumulating launches of mg_linear_wgrad_bf16 on plane pairs).  `descs` is a HOST array, count <= MG_SPLIT3_MAX. */
+ * accumulating launches of mg_linear_wgrad_bf16 on plane pairs).  order 3 / 4 (not transposed) -> dst bf16 [3, rows, ldp]: three
+ * row-stacked planes [hi ; hi ; lo] / [hi ; lo ; hi] - the same three products as ONE mg_linear_wgrad_bf16 launch over 3 rows rows
+ * (dY = the order-3 planes, A = the order-4 planes); its bias gradient comes from `colsum`.  `descs` is a HOST array, count <= MG_SPLIT3_MAX. */
 #define MG_SPLIT3_MAX 16
 typedef struct {
     const float* src; /* device, fp32 [rows, cols], row stride lds */
@@ -445,12 +447,15 @@ typedef struct {
     int cols, lds;
     uint16_t* dst;    /* device, bf16, 16-byte aligned: [rows, 3 ldp], or [cols, 3 ldp] when transposed */
     int ldp;          /* columns per plane: multiple of 8, >= cols (>= rows when transposed) */
-    int order;        /* 0: hi | hi | lo;  1: hi | lo | hi;  2: two planes [hi ; lo] of [plane_rows, ldp] */
+    int order;        /* 0: hi | hi | lo;  1: hi | lo | hi;  2: two planes [hi ; lo] of [plane_rows, ldp];  3: [hi ; hi ; lo];  4: [hi ; lo ; hi] */
     int transpose;
-    int64_t plane_rows; /* order 2: rows of one plane in dst (>= rows; the caller owns the rows behind the split, e.g. zeros); 0 = rows */
+    int64_t plane_rows; /* orders 2-4: rows of one plane in dst (>= rows; the caller owns the rows behind the split, e.g. zeros); 0 = rows */
     const float* sig; /* optional (not transposed): fp32 [rows, cols] (ldsig) sigmoid outputs s - the split is taken of src * s * (1 - s):
                        * the sigmoid gradient of autograd (README.rst:65-73's nn.Sigmoid) fused into the split of the gradient */
     int ldsig;
+    float* colsum;    /* optional (orders 2-4): f32 [colsum_blocks, ldp] - workgroup b's partial column sums of the (sigmoid-gradient-fused)
+                       * source values over its share of the rows; summed in slab order they are the bias gradient of the layer, exact */
+    int colsum_blocks;
 } mg_split3_desc;
 int mg_split3_bf16(const mg_split3_desc* descs, int count, void* stream);
 /* Active dropout (nn.Dropout(p) of the shipped models in training mode: /root/reference/models/RNN_SPSS.py:19,34,40,

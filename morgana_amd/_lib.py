@@ -220,7 +220,8 @@ class CastDesc(ctypes.Structure):
 class Split3Desc(ctypes.Structure):
     """mg_split3_desc of include/morgana_hip.h."""
     _fields_ = [('src', c_void_p), ('rows', c_int64), ('cols', c_int), ('lds', c_int), ('dst', c_void_p), ('ldp', c_int),
-                ('order', c_int), ('transpose', c_int), ('plane_rows', c_int64), ('sig', c_void_p), ('ldsig', c_int)]
+                ('order', c_int), ('transpose', c_int), ('plane_rows', c_int64), ('sig', c_void_p), ('ldsig', c_int), ('colsum', c_void_p),
+                ('colsum_blocks', c_int)]
 
 
 class StreamDesc(ctypes.Structure):

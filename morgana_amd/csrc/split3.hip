@@ -14,7 +14,10 @@
 // split of src^T (the dgrad operand W^T without a transposed fp32 copy).  Weight gradients contract over the ROWS: they take the
 // planes one pair at a time, three accumulating launches (ops.linear_wgrad_x3) - from `order` 2, two SEPARATE planes [hi ; lo], each
 // [rows, ldp] with its own zero padding (the weight-gradient tile programs read a row up to its leading dimension: a plane cut out of
-// a three-plane row would hand them its neighbours as padding).
+// a three-plane row would hand them its neighbours as padding).  `order` 3 / 4: THREE row-stacked planes [hi ; hi ; lo] / [hi ; lo ; hi] -
+// the three products as ONE weight-gradient launch over a three times longer row axis, [hi ; hi ; lo]^T [hi ; lo ; hi]; the bias
+// gradient (the column sums of the UNSPLIT fp32 values, exact) then comes out of the split pass itself: `colsum` slabs, one per
+// workgroup, summed by the library's ordered slab reduce.
 #include "common.h"
 
 #define MG_SPLIT3_MAX_ 16
@@ -36,7 +39,76 @@ typedef unsigned int su32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void split3_kernel(Split3Batch batch) {
     __shared__ float tile[32][33];
     const mg_split3_desc d = batch.d[blockIdx.y];
-    const int second = d.order == 0 ? 0 : 1;           // what the middle plane holds: 0 = hi again, 1 = lo
+    const int second = (d.order == 0 || d.order == 3) ? 0 : 1;           // what the middle plane holds: 0 = hi again, 1 = lo
+    auto pack = [](const uint16_t* v) {
+        return su32x4{(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
+                      (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16)};
+    };
+    // one row's 8-column chunk: load (+ the fused sigmoid gradient); false where the row has no such chunk
+    auto load_chunk = [&](int64_t r, int c0, bool vec, float (&x)[8]) {
+        const float* src = d.src + (size_t)r * d.lds + c0;
+        if (vec && c0 + 8 <= d.cols) {
+            const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+            x[0] = a.x, x[1] = a.y, x[2] = a.z, x[3] = a.w, x[4] = b.x, x[5] = b.y, x[6] = b.z, x[7] = b.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = c0 + e < d.cols ? src[e] : 0.f;
+        }
+        if (d.sig) {                                   // the sigmoid gradient, fused: x <- x s (1 - s)  (the product order of sigmoid_grad_kernel)
+            const float* sg = d.sig + (size_t)r * d.ldsig + c0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (c0 + e < d.cols) {
+                    const float s = sg[e];
+                    x[e] = x[e] * s * (1.f - s);
+                }
+        }
+    };
+    if (!d.transpose && d.colsum) {
+        // row-stacked planes WITH the column sums of the values: workgroup b < colsum_blocks owns a fixed range of rows, thread =
+        // (row lane, 8-column chunk) so that a thread's sums stay in one chunk; lanes added in lane order through LDS
+        if ((int)blockIdx.x >= d.colsum_blocks) return;
+        const int chunks = d.ldp >> 3, lanes = 256 / chunks;               // host: 256 % chunks == 0
+        const int ch = threadIdx.x % chunks, ln = threadIdx.x / chunks, c0 = ch * 8;
+        const int64_t per = (d.rows + d.colsum_blocks - 1) / d.colsum_blocks, r_lo = (int64_t)blockIdx.x * per,
+                      r_hi = r_lo + per < d.rows ? r_lo + per : d.rows;
+        const bool vec = (d.lds & 3) == 0 && ((size_t)d.src & 15) == 0;
+        const size_t plane = (size_t)(d.plane_rows > 0 ? d.plane_rows : d.rows) * d.ldp;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int64_t r = r_lo + ln; r < r_hi; r += lanes) {
+            float x[8];
+            load_chunk(r, c0, vec, x);
+            uint16_t hi[8], lo[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                split_pair(x[e], hi[e], lo[e]);
+                acc[e] += x[e];
+            }
+            const su32x4 ph = pack(hi), pl = pack(lo);
+            uint16_t* dst = d.dst + (size_t)r * d.ldp + c0;
+            *reinterpret_cast<su32x4*>(dst) = ph;
+            *reinterpret_cast<su32x4*>(dst + plane) = second ? pl : ph;
+            *reinterpret_cast<su32x4*>(dst + 2 * plane) = second ? ph : pl;
+        }
+        __shared__ float sums[256 * 8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sums[(ln * chunks + ch) * 8 + e] = acc[e];
+        __syncthreads();
+        if (ln == 0) {
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = 0.f;
+            for (int l = 0; l < lanes; ++l)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] += sums[(l * chunks + ch) * 8 + e];
+            float* out = d.colsum + (size_t)blockIdx.x * d.ldp + c0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) out[e] = t[e];
+        }
+        return;
+    }
     if (!d.transpose) {
         const int chunks = d.ldp >> 3;
         const int64_t n = d.rows * (int64_t)chunks;
@@ -45,35 +117,21 @@ __global__ __launch_bounds__(256) void split3_kernel(Split3Batch batch) {
             const int64_t r = i / chunks;
             const int c0 = (int)(i - r * chunks) * 8;
             float x[8];
-            const float* src = d.src + (size_t)r * d.lds + c0;
-            if (vec && c0 + 8 <= d.cols) {
-                const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
-                x[0] = a.x, x[1] = a.y, x[2] = a.z, x[3] = a.w, x[4] = b.x, x[5] = b.y, x[6] = b.z, x[7] = b.w;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = c0 + e < d.cols ? src[e] : 0.f;
-            }
-            if (d.sig) {                                   // the sigmoid gradient, fused: x <- x s (1 - s)  (the product order of sigmoid_grad_kernel)
-                const float* sg = d.sig + (size_t)r * d.ldsig + c0;
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (c0 + e < d.cols) {
-                        const float s = sg[e];
-                        x[e] = x[e] * s * (1.f - s);
-                    }
-            }
+            load_chunk(r, c0, vec, x);
             uint16_t hi[8], lo[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) split_pair(x[e], hi[e], lo[e]);
-            auto pack = [](const uint16_t* v) {
-                return su32x4{(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
-                              (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16)};
-            };
             const su32x4 ph = pack(hi), pl = pack(lo);
             if (d.order == 2) {
                 uint16_t* dst = d.dst + (size_t)r * d.ldp + c0;
                 *reinterpret_cast<su32x4*>(dst) = ph;
                 *reinterpret_cast<su32x4*>(dst + (size_t)(d.plane_rows > 0 ? d.plane_rows : d.rows) * d.ldp) = pl;
+            } else if (d.order >= 3) {
+                const size_t plane = (size_t)(d.plane_rows > 0 ? d.plane_rows : d.rows) * d.ldp;
+                uint16_t* dst = d.dst + (size_t)r * d.ldp + c0;
+                *reinterpret_cast<su32x4*>(dst) = ph;
+                *reinterpret_cast<su32x4*>(dst + plane) = second ? pl : ph;
+                *reinterpret_cast<su32x4*>(dst + 2 * plane) = second ? ph : pl;
             } else {
                 uint16_t* dst = d.dst + (size_t)r * (3 * (size_t)d.ldp) + c0;
                 *reinterpret_cast<su32x4*>(dst) = ph;
@@ -121,9 +179,11 @@ int mg_split3_bf16(const mg_split3_desc* descs, int count, void* stream) {
         const mg_split3_desc& d = descs[i];
         MG_CHECK_ARG(d.src && d.dst && d.rows > 0 && d.cols > 0 && d.lds >= d.cols, "mg_split3_bf16: bad descriptor %d", i);
         MG_CHECK_ARG(!d.sig || (!d.transpose && d.ldsig >= d.cols), "mg_split3_bf16: descriptor %d: a fused sigmoid gradient goes with the plain layouts and needs ldsig >= cols", i);
-        MG_CHECK_ARG(d.order == 0 || d.order == 1 || (d.order == 2 && !d.transpose),
-                     "mg_split3_bf16: descriptor %d: order %d is none of 0 (hi|hi|lo), 1 (hi|lo|hi), 2 (separate planes hi ; lo, not transposed)", i, d.order);
-        MG_CHECK_ARG(d.plane_rows == 0 || (d.order == 2 && d.plane_rows >= d.rows), "mg_split3_bf16: descriptor %d: plane_rows %lld goes with order 2 and must cover the %lld rows", i, (long long)d.plane_rows, (long long)d.rows);
+        MG_CHECK_ARG(d.order == 0 || d.order == 1 || (d.order >= 2 && d.order <= 4 && !d.transpose),
+                     "mg_split3_bf16: descriptor %d: order %d is none of 0 (hi|hi|lo), 1 (hi|lo|hi), 2 (separate planes hi ; lo), 3 (hi ; hi ; lo), 4 (hi ; lo ; hi) (2-4 not transposed)", i, d.order);
+        MG_CHECK_ARG(d.plane_rows == 0 || (d.order >= 2 && d.plane_rows >= d.rows), "mg_split3_bf16: descriptor %d: plane_rows %lld goes with order 2 and must cover the %lld rows", i, (long long)d.plane_rows, (long long)d.rows);
+        MG_CHECK_ARG(!d.colsum || (d.order >= 2 && d.colsum_blocks >= 1 && d.colsum_blocks <= 4096 && d.ldp <= 2048 && 256 % (d.ldp / 8) == 0),
+                     "mg_split3_bf16: descriptor %d: column sums go with the row-stacked orders, 1..4096 blocks and plane widths of 8, 16, ... 2048 columns that divide 2048 (ldp %d)", i, d.ldp);
         MG_CHECK_ARG(d.ldp % 8 == 0 && ((size_t)d.dst & 15) == 0, "mg_split3_bf16: descriptor %d: ldp %d must be a multiple of 8 and dst 16-byte aligned", i, d.ldp);
         if (d.transpose)
             MG_CHECK_ARG(d.ldp >= d.rows && d.rows < 2147483647LL, "mg_split3_bf16: descriptor %d: transposed planes of %d columns cannot hold %lld rows", i, d.ldp, (long long)d.rows);
@@ -132,6 +192,7 @@ int mg_split3_bf16(const mg_split3_desc* descs, int count, void* stream) {
         batch.d[i] = d;
         const int64_t work = d.transpose ? (int64_t)((d.cols + 31) / 32) * ((d.ldp + 31) / 32) : mg_ceil_div(d.rows * (int64_t)(d.ldp / 8), 256);
         if (work > most) most = work;
+        if (d.colsum && d.colsum_blocks > most) most = d.colsum_blocks;
     }
     int64_t blocks = most;
     if (blocks > 4096) blocks = 4096;

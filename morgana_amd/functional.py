@@ -426,15 +426,28 @@ class LinearStackFn(torch.autograd.Function):
                         grad_x = ops.linear_dgrad_f32(g, weights[0], None)
                     continue
                 need_g3 = i > 0 or need_x
-                parts = ops.split3([(g, 2, False, 0, sig), (a_in, 2, False, ctx.x3_extra if i == 0 else 0)] +
-                                   ([(g, 0, False, 0, sig)] if need_g3 else []))
-                sig = None
-                g2, a2, g3 = parts[0], parts[1], (parts[2] if need_g3 else None)
-                if direct:
-                    ops.linear_wgrad_x3(g2, a2, r, m, n, k, out_w=w_params[i].grad, out_b=b_params[i].grad, accumulate=True)
+                if r is None and ops.split3_colsum_ok(n):
+                    # no row map: the three products of the weight gradient as ONE launch over row-stacked planes, [hi ; hi ; lo]^T
+                    # [hi ; lo ; hi]; the bias gradient = the column sums of the fp32 gradient, taken by the split pass itself
+                    parts = ops.split3([(g, 3, False, 0, sig, True), (a_in, 4, False, ctx.x3_extra if i == 0 else 0)] +
+                                       ([(g, 0, False, 0, sig)] if need_g3 else []))
+                    sig = None
+                    (g3s, colsum), a3s, g3 = parts[0], parts[1], (parts[2] if need_g3 else None)
+                    if direct:
+                        ops.linear_wgrad_x3_stacked(g3s, colsum, a3s, n, k, out_w=w_params[i].grad, out_b=b_params[i].grad, accumulate=True)
+                    else:
+                        dw, db = ops.linear_wgrad_x3_stacked(g3s, colsum if ctx.has_bias[i] else None, a3s, n, k)
+                        grads[2 * i], grads[2 * i + 1] = dw, db
                 else:
-                    dw, db = ops.linear_wgrad_x3(g2, a2, r, m, n, k)
-                    grads[2 * i], grads[2 * i + 1] = dw, (db if ctx.has_bias[i] else None)
+                    parts = ops.split3([(g, 2, False, 0, sig), (a_in, 2, False, ctx.x3_extra if i == 0 else 0)] +
+                                       ([(g, 0, False, 0, sig)] if need_g3 else []))
+                    sig = None
+                    g2, a2, g3 = parts[0], parts[1], (parts[2] if need_g3 else None)
+                    if direct:
+                        ops.linear_wgrad_x3(g2, a2, r, m, n, k, out_w=w_params[i].grad, out_b=b_params[i].grad, accumulate=True)
+                    else:
+                        dw, db = ops.linear_wgrad_x3(g2, a2, r, m, n, k)
+                        grads[2 * i], grads[2 * i + 1] = dw, (db if ctx.has_bias[i] else None)
                 if i > 0:
                     g = unmask(ops.linear_dgrad_x3(g3, m, wt3s[i], k), i - 1)
                     if acts[i - 1] == ops.ACT_SIGMOID:

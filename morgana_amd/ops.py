@@ -732,11 +732,20 @@ def begin_capture_epoch():
     CAPTURE_EPOCH[0] += 1
 
 
+SPLIT3_COLSUM_BLOCKS = 256       # workgroups (= slabs) of a split that also sums its columns
+
+
+def split3_colsum_ok(cols):
+    """Plane widths whose 8-column chunks divide a 256-thread workgroup (mg_split3_bf16's column-sum form)."""
+    return 256 % (pad_ld(cols) // 8) == 0
+
+
 def split3(jobs):
     """Operand splits of precision mode 'bf16x3' (csrc/split3.hip): ``jobs`` = [(fp32 2-D tensor, order, transpose)] with order 0 =
-    [hi | hi | lo] (activation side), 1 = [hi | lo | hi] (weight side), 2 = two separate planes; one batched launch per MG_SPLIT3_MAX
-    jobs.  Returns one bf16 tensor per job: (rows, 3 ldp) - (cols, 3 ldp) with ``transpose`` - or (2, rows, ldp) for order 2, where
-    ldp = pad_ld(columns of a plane)."""
+    [hi | hi | lo] (activation side), 1 = [hi | lo | hi] (weight side), 2 = two separate planes, 3 / 4 = three row-stacked planes
+    [hi ; hi ; lo] / [hi ; lo ; hi]; one batched launch per MG_SPLIT3_MAX jobs.  Returns one bf16 tensor per job: (rows, 3 ldp) -
+    (cols, 3 ldp) with ``transpose`` - or (2 or 3, rows, ldp) for orders 2-4, where ldp = pad_ld(columns of a plane).  A job with a
+    sixth element True (orders 2-4) returns (planes, slabs): the per-workgroup column sums of the split values (``colsum_reduce``)."""
     lib = _lib.load()
     outs = []
     for i in range(0, len(jobs), _lib.SPLIT3_MAX):
@@ -746,6 +755,7 @@ def split3(jobs):
             x, order, transpose = job[:3]
             extra = int(job[3]) if len(job) > 3 else 0          # zero rows appended behind the split (not with transpose)
             sig = job[4] if len(job) > 4 else None              # fp32 sigmoid outputs of x's shape: split x * s * (1 - s) instead of x
+            want_colsum = bool(job[5]) if len(job) > 5 else False
             if sig is not None and (transpose or sig.dtype != torch.float32 or tuple(sig.shape) != tuple(x.shape) or sig.stride(1) != 1):
                 raise ValueError('split3: the fused sigmoid gradient needs an fp32 tensor of the operand\'s shape (plain layouts)')
             if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
@@ -754,15 +764,24 @@ def split3(jobs):
                 raise ValueError('split3: extra zero rows go with the plain layouts')
             rows, cols = x.shape
             ldp = pad_ld(rows if transpose else cols)
-            out = torch.empty((2, rows + extra, ldp) if order == 2 else ((cols if transpose else rows) + extra, 3 * ldp),
+            stacked = order >= 2
+            out = torch.empty((2 if order == 2 else 3, rows + extra, ldp) if stacked else ((cols if transpose else rows) + extra, 3 * ldp),
                               dtype=torch.bfloat16, device=x.device)
             if extra:
-                (out[:, rows:] if order == 2 else out[rows:]).zero_()
+                (out[:, rows:] if stacked else out[rows:]).zero_()
             descs[j].src, descs[j].rows, descs[j].cols, descs[j].lds = x.data_ptr(), rows, cols, x.stride(0)
             descs[j].dst, descs[j].ldp, descs[j].order, descs[j].transpose = out.data_ptr(), ldp, int(order), int(bool(transpose))
-            descs[j].plane_rows = rows + extra if order == 2 else 0
+            descs[j].plane_rows = rows + extra if stacked else 0
             descs[j].sig, descs[j].ldsig = (sig.data_ptr(), sig.stride(0)) if sig is not None else (None, 0)
-            outs.append(out)
+            if want_colsum:
+                if not stacked or 256 % (ldp // 8) != 0:
+                    raise ValueError('split3: column sums go with the row-stacked orders and plane widths that divide 2048')
+                slabs = torch.empty((SPLIT3_COLSUM_BLOCKS, ldp), dtype=torch.float32, device=x.device)
+                descs[j].colsum, descs[j].colsum_blocks = slabs.data_ptr(), SPLIT3_COLSUM_BLOCKS
+                outs.append((out, slabs))
+            else:
+                descs[j].colsum, descs[j].colsum_blocks = None, 0
+                outs.append(out)
         if chunk:
             _lib.check(lib.mg_split3_bf16(ctypes.cast(descs, ctypes.c_void_p), len(chunk), _stream()), 'mg_split3_bf16')
     return outs
@@ -807,6 +826,27 @@ def linear_dgrad_x3(g3, m, wt3, k):
         raise ValueError('linear_dgrad_x3: operand planes differ (%d vs %d columns)' % (g3.shape[1], wt3.shape[1]))
     dx = linear_dgrad_bf16(g3, m, g3.shape[1], wt3, k, None, out_f32=True)
     return dx if dx.shape[1] == k else dx[:, :k].contiguous()
+
+
+def linear_wgrad_x3_stacked(g3, colsum, a3, n, k, out_w=None, out_b=None, accumulate=False):
+    """dW (n, k), db (n,) of split operands as ONE launch: g3 (3, m, ldp(n)) = [hi ; hi ; lo] (split3 order 3), a3 (3, m, ldp(k)) =
+    [hi ; lo ; hi] (order 4): [hi ; hi ; lo]^T [hi ; lo ; hi] over 3 m rows = the three products of ``linear_wgrad_x3``.  db = the
+    ordered sum of ``colsum`` (the split pass's per-workgroup column sums of the fp32 gradient: exact), or None."""
+    lib = _lib.load()
+    if g3.shape[0] != 3 or a3.shape[0] != 3 or g3.shape[1] != a3.shape[1]:
+        raise ValueError('linear_wgrad_x3_stacked: operands must be three row-stacked planes of equal row count')
+    m3 = 3 * g3.shape[1]
+    if out_w is None:
+        both = torch.empty((n * k + n,), dtype=torch.float32, device=g3.device)
+        dw, db = both[:n * k].view(n, k), (both[n * k:] if colsum is not None else None)
+    else:
+        dw, db = out_w, (out_b if colsum is not None else None)
+    ws = workspace(lib.mg_linear_wgrad_workspace_bytes(m3, n, k), g3.device)
+    _lib.check(lib.mg_linear_wgrad_bf16(_p(g3), g3.shape[2], _p(a3), a3.shape[2], None, m3, n, k, _p(dw), None, int(bool(accumulate)),
+                                        _p(ws), ws.numel(), _stream()), 'mg_linear_wgrad_bf16')
+    if db is not None:
+        slab_reduce(colsum, colsum.shape[0], colsum.shape[1], n, db, accumulate=accumulate)
+    return dw, db
 
 
 def linear_wgrad_x3(g2, a2, rows, m, n, k, out_w=None, out_b=None, accumulate=False):

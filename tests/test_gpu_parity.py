@@ -1004,6 +1004,20 @@ def test_split3_planes(rows, cols, lds_extra):
     p2 = ops.split3([(x, 2, False)])[0]
     assert tuple(p2.shape) == (2, rows, ldp)
     assert torch.equal(p2[0, :, :cols], hi) and torch.equal(p2[1, :, :cols], lo) and not bool(p2[:, :, cols:].any())
+    # three row-stacked planes (the one-launch weight gradient's operands), with the column sums of the values where the plane width allows
+    p4 = ops.split3([(x, 4, False)])[0]
+    assert tuple(p4.shape) == (3, rows, ldp) and not bool(p4[:, :, cols:].any())
+    assert torch.equal(p4[0, :, :cols], hi) and torch.equal(p4[1, :, :cols], lo) and torch.equal(p4[2, :, :cols], hi)
+    if ops.split3_colsum_ok(cols):
+        p3, slabs = ops.split3([(x, 3, False, 2, None, True)])[0]
+        assert tuple(p3.shape) == (3, rows + 2, ldp) and not bool(p3[:, rows:].any()) and not bool(p3[:, :, cols:].any())
+        assert torch.equal(p3[0, :rows, :cols], hi) and torch.equal(p3[1, :rows, :cols], hi) and torch.equal(p3[2, :rows, :cols], lo)
+        want_sum = x.double().sum(0)
+        got_sum = ops.slab_reduce(slabs, slabs.shape[0], slabs.shape[1], cols, torch.empty(cols, device=DEV)).double()
+        assert float((got_sum - want_sum).abs().max() / x.abs().double().sum(0).max()) < 1e-6
+    else:
+        with pytest.raises(ValueError):
+            ops.split3([(x, 3, False, 0, None, True)])
     # the fused sigmoid gradient: the split of x * s * (1 - s), bit for bit the separate pass followed by the split
     s = torch.sigmoid(dev(rng.standard_normal((rows, cols)).astype(np.float32)))
     y = ops.sigmoid_grad(x.contiguous(), s)
