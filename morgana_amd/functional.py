@@ -544,19 +544,10 @@ class PhoneMSEFn(torch.autograd.Function):
         table = ops._require(table, torch.float32, 'prediction table')
         target = ops._require(target, torch.float32, 'targets')
         b, t = target.shape[0], target.shape[1]
-        n_src = holder.source.shape[0] * holder.source.shape[1]
-        extra = table.shape[0] - n_src
-        if seq_len.dtype != torch.int64:
-            seq_len = seq_len.long()
-        if holder.pending() and holder.t_cap == t and ops.phone_front_ok(holder.source.shape[0], holder.source.shape[1], t, extra):
-            rows, rows_mapped, seg, ybar, weight, partials = ops.phone_front(holder.dur, target.reshape(-1), seq_len, t, extra)
-            holder.adopt(rows, (seg, rows_mapped.reshape(-1)))
-        else:
-            rows = holder.rows
-            seg, rows_mapped = holder.phone_maps()
-            ybar, weight, partials = ops.phone_target_stats(target.reshape(-1), rows.reshape(-1), seg, seq_len, b, t, n_src, extra)
+        extra = table.shape[0] - holder.source.shape[0] * holder.source.shape[1]
+        rows_mapped, ybar, weight, partials, n_src = _phone_stats(holder, target, seq_len, extra)
         loss, dpred = ops.phone_mse_rows(table, ybar, weight)
-        pred = ops.expand_column(table.reshape(-1) if table.shape[1] == 1 else table[:, 0].contiguous(), rows_mapped.reshape(-1),
+        pred = ops.expand_column(table.reshape(-1) if table.shape[1] == 1 else table[:, 0].contiguous(), rows_mapped,
                                  loss_const=(partials, n_src, extra, loss))
         ctx.save_for_backward(dpred)
         ctx.cols = table.shape[1]
@@ -567,10 +558,58 @@ class PhoneMSEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_loss, grad_pred):
         (dpred,) = ctx.saved_tensors
-        g = (dpred * grad_loss).unsqueeze(1)
+        g = (dpred if _is_unit_grad(grad_loss) else dpred * grad_loss).unsqueeze(1)
         if ctx.cols != 1:
             g = torch.nn.functional.pad(g, (0, ctx.cols - 1))
         return g, None, None, None
+
+
+def _phone_stats(holder, target, seq_len, extra):
+    """(rows_mapped, ybar, weight, partials, n_src) of the per-phone masked MSE for the frame map ``holder`` owns: map and statistics
+    from ONE launch where the map has not been built yet (ops.phone_front), else the statistics alone."""
+    b, t = target.shape[0], target.shape[1]
+    n_src = holder.source.shape[0] * holder.source.shape[1]
+    if seq_len.dtype != torch.int64:
+        seq_len = seq_len.long()
+    if holder.pending() and holder.t_cap == t and ops.phone_front_ok(holder.source.shape[0], holder.source.shape[1], t, extra):
+        rows, rows_mapped, seg, ybar, weight, partials = ops.phone_front(holder.dur, target.reshape(-1), seq_len, t, extra)
+        holder.adopt(rows, (seg, rows_mapped.reshape(-1)))
+    else:
+        rows = holder.rows
+        seg, rows_mapped = holder.phone_maps()
+        ybar, weight, partials = ops.phone_target_stats(target.reshape(-1), rows.reshape(-1), seg, seq_len, b, t, n_src, extra)
+    return rows_mapped.reshape(-1), ybar, weight, partials, n_src
+
+
+class F0TailRowsF32Fn(torch.autograd.Function):
+    """The README F0Model's tail ``Sigmoid -> Linear(128, 32) -> Sigmoid -> Linear(32, 1)`` (README.rst:65-73) TOGETHER with
+    ``losses.mse`` (morgana/losses.py:29-51) on per-phone rows, exact fp32, forward and backward in one launch (``mg_f0_tail_rows_f32``):
+    the ``fp32`` / ``bf16x3`` modes' counterpart of the bf16 step's fused tail.  forward(ctx, z2 (R + extra, 128) pre-activations of
+    the 128-wide layer, target (B, T, 1), seq_len, holder, w3, b3, w4, b4) -> (loss, prediction (B, T, 1): repeated for reporting, not
+    differentiable).  The backward hands out what the forward's launch computed."""
+
+    @staticmethod
+    def forward(ctx, z2, target, seq_len, holder, w3, b3, w4, b4):
+        target = ops._require(target, torch.float32, 'targets')
+        b, t = target.shape[0], target.shape[1]
+        extra = z2.shape[0] - holder.source.shape[0] * holder.source.shape[1]
+        rows_mapped, ybar, weight, partials, n_src = _phone_stats(holder, target, seq_len, extra)
+        pred_rows, dz2, flat = ops.f0_tail_rows_f32(z2, w3, b3, w4, b4, ybar, weight)
+        n_g = ops.F0_TAIL_F32_GRADS
+        loss = flat[n_g:n_g + 1]
+        pred = ops.expand_column(pred_rows, rows_mapped, loss_const=(partials, n_src, extra, loss)).view(b, t, 1)
+        ctx.save_for_backward(dz2, flat)
+        ctx.params = (w3, b3, w4, b4)
+        ctx.mark_non_differentiable(pred)
+        return loss.reshape(()), pred
+
+    @staticmethod
+    def backward(ctx, grad_loss, grad_pred):
+        dz2, flat = ctx.saved_tensors
+        unit = _is_unit_grad(grad_loss)
+        n_g = ops.F0_TAIL_F32_GRADS
+        grads = _deliver_param_grads(ctx.params, flat[:n_g], [0, 32 * 128, 32 * 128 + 32, 32 * 128 + 64], None if unit else grad_loss)
+        return (dz2 if unit else dz2 * grad_loss, None, None, None) + tuple(grads)
 
 
 class UnpackRowsFn(torch.autograd.Function):

@@ -129,6 +129,10 @@ OUT_SHADOW = os.environ.get('MORGANA_OUT_SHADOW', '0') != '0'
 CONCAT_PHONE_RATE = os.environ.get('MORGANA_CONCAT_PHONE_RATE', '0') != '0'
 
 
+# The exact-fp32 modes' fused tail (functional.F0TailRowsF32Fn); 0 = the two layers and the loss as their generic launches (A/B, tests)
+F0_TAIL_F32 = os.environ.get('MORGANA_F0_TAIL_F32', '1') != '0'
+
+
 # Row-wise layers behind a recurrent wrapper are packed only when at least this share of the B * T rows is padding.  Measured at C5
 # (64 utterances of 300-2000 frames, 41 % padding; profiles/r4_c5_packed_vs_padded.txt): the packed Linear stack + loss saves 140 us of
 # GEMM / cast time and pays 257 us for the way there and back (unpack gather of the prediction 44, pack of its gradient 32, column
@@ -547,6 +551,12 @@ class SequentialWithRecurrent(nn.Sequential):
         precision = self.precision or F_hip.get_precision()
         fused = self._fused_mse_spec(targets, precision)
         if fused is None:
+            tail = self._phone_rate_f32_tail(input, targets, seq_len, precision)
+            if tail is not None:
+                # exact-fp32 modes, the README stack on repeated phone rows: the layers up to the 128-wide one on the phone rows, then
+                # Sigmoid -> Linear(128, 32) -> Sigmoid -> Linear(32, 1) + the masked MSE + their backward as ONE launch (mg_f0_tail_rows_f32)
+                z2, lin3, lin4 = tail
+                return F_hip.F0TailRowsF32Fn.apply(z2, targets, seq_len, input, lin3.weight, lin3.bias, lin4.weight, lin4.bias)
             table = self._phone_rate_table(input, targets, seq_len, precision)
             if table is not None:
                 # exact-fp32 modes, a stack of Linear / Sigmoid layers on repeated phone rows ending in ONE output column: the layers
@@ -572,6 +582,32 @@ class SequentialWithRecurrent(nn.Sequential):
         for lin, _ in run:
             params += [lin.weight, lin.bias]
         return F_hip.LinearStackMSEFn.apply((acts, maps, table, phone_rate), x2d, rows, targets, seq_len, *params)
+
+    def _phone_rate_f32_tail(self, input, targets, seq_len, precision):
+        """(pre-activations of the 128-wide layer on the phone rows (B * P + extra, 128), Linear(128, 32), Linear(32, 1)) when the whole
+        container is Linear / Sigmoid layers ending in ``-> 128 -> Sigmoid -> 32 -> Sigmoid -> 1`` on an ``UpsampledSequence`` at
+        phone rate, exact-fp32 modes, (B, T, 1) targets; else None."""
+        modules = list(self._modules.values())
+        if (not F0_TAIL_F32 or not isinstance(input, UpsampledSequence) or seq_len is None or not modules or type(modules[0]) is not nn.Linear
+                or precision not in ('fp32', 'bf16x3') or targets.ndim != 3 or targets.shape[2] != 1
+                or tuple(targets.shape[:2]) != tuple(input.shape[:2])):
+            return None
+        end, run = self._linear_run(modules, 0)
+        n_src = input.source.shape[0] * input.source.shape[1]
+        if (end != len(modules) or len(run) < 3 or any(run.drops)
+                or not ops.phone_rate_gru_ok(n_src, input.shape[0] * input.shape[1], 8, input.phone_rate)):
+            return None
+        (lin2, act2), (lin3, act3), (lin4, act4) = run[-3], run[-2], run[-1]
+        if (act2 != ops.ACT_SIGMOID or act3 != ops.ACT_SIGMOID or act4 != ops.ACT_NONE or tuple(lin3.weight.shape) != (32, 128)
+                or tuple(lin4.weight.shape) != (1, 32) or lin3.bias is None or lin4.bias is None or lin2.weight.shape[0] != 128):
+            return None
+        params = []
+        for lin, _ in run[:-2]:
+            params += [lin.weight, lin.bias]
+        acts = tuple(act for _, act in run[:-3]) + (ops.ACT_NONE,)          # the 128-wide layer's sigmoid is taken by the tail kernel
+        spec = (acts, precision, ops.PHONE_RATE_EXTRA)
+        z2 = F_hip.LinearStackFn.apply(spec, input.source.reshape(-1, input.source.shape[-1]), None, *params)
+        return z2, lin3, lin4
 
     def _phone_rate_table(self, input, targets, seq_len, precision):
         """The (B * P + extra, 1) table of per-phone predictions when the whole container is one Linear / Sigmoid run on an

@@ -2500,15 +2500,18 @@ def test_phone_target_stats_reduce_the_masked_mse_exactly(masked):
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
-def test_phone_rate_loss_of_the_exact_modes_equals_the_frame_rate_loss(precision):
-    """functional.PhoneMSEFn (the masked MSE on per-phone predictions and target statistics, mg_phone_mse_rows_f32) against the same
-    model with the loss at frame rate (predict + losses.mse: the table's rows repeated, masked MSE over the frames, segment sums
-    behind it) - the same algebra, fp32 rounding apart: loss and every gradient to 1e-5, the reported prediction bit for bit."""
+def test_phone_rate_loss_of_the_exact_modes_equals_the_frame_rate_loss(precision, monkeypatch):
+    """The exact modes' loss on the phone rows - functional.F0TailRowsF32Fn (the 128 -> 32 -> 1 tail, the masked MSE on per-phone
+    predictions and target statistics and their backward as ONE launch, mg_f0_tail_rows_f32) and functional.PhoneMSEFn (the loss
+    alone, mg_phone_mse_rows_f32, behind the generic layers) - against the same model with the loss at frame rate (predict +
+    losses.mse: the table's rows repeated, masked MSE over the frames, segment sums behind it): the same algebra, fp32 rounding
+    apart - loss, every gradient and the reported prediction to 1e-5 (the prediction bit for bit where the layers are the same launches)."""
     from morgana_amd import _lib
     feats = data.to_device(synthetic.make_batch(32, 400, seed=21), DEV)
     got = {}
-    for fused in (True, False):
-        model = _load_state(models.F0Model(precision=precision, fused_loss=fused, phone_rate=True).to(DEV), synthetic.f0_model_state())
+    for form in ('tail', 'rows', 'frames'):
+        monkeypatch.setattr(utils, 'F0_TAIL_F32', form == 'tail')
+        model = _load_state(models.F0Model(precision=precision, fused_loss=form != 'frames', phone_rate=True).to(DEV), synthetic.f0_model_state())
         calls = []
         _lib.CALL_LOG = calls
         try:
@@ -2516,10 +2519,47 @@ def test_phone_rate_loss_of_the_exact_modes_equals_the_frame_rate_loss(precision
             loss.backward()
         finally:
             _lib.CALL_LOG = None
-        assert (calls.count('mg_phone_mse_rows_f32') == 1) == fused and (calls.count('mg_segment_sum') == 0) == fused, calls
-        got[fused] = (loss.item(), out['pred_norm_lf0'].detach().cpu().numpy(),
-                      {n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters()})
-    np.testing.assert_allclose(got[True][0], got[False][0], rtol=1e-5)
-    assert np.array_equal(got[True][1], got[False][1])
-    for name in got[False][2]:
-        assert rel_err(got[True][2][name], got[False][2][name]) < 1e-5, name
+        assert (calls.count('mg_f0_tail_rows_f32') == 1) == (form == 'tail'), calls
+        assert (calls.count('mg_phone_mse_rows_f32') == 1) == (form == 'rows') and (calls.count('mg_segment_sum') == 0) == (form != 'frames'), calls
+        got[form] = (loss.item(), out['pred_norm_lf0'].detach().cpu().numpy(),
+                     {n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters()})
+    assert np.array_equal(got['rows'][1], got['frames'][1])
+    for form in ('tail', 'rows'):
+        np.testing.assert_allclose(got[form][0], got['frames'][0], rtol=1e-5)
+        assert rel_err(got[form][1], got['frames'][1]) < 1e-5          # the prediction is a cancelling sum of O(1) terms: 2.5e-6 seen
+        for name in got['frames'][2]:
+            assert rel_err(got[form][2][name], got['frames'][2][name]) < 1e-5, (form, name)
+
+
+@pytest.mark.parametrize('m', [16, 37, 4099])
+def test_f0_tail_rows_f32_kernel(m):
+    """mg_f0_tail_rows_f32 (csrc/tail_f32.hip) against the same tail in float64 torch autograd on random rows, weights and per-row
+    statistics (some weights zero: rows without frames): prediction, loss, d loss / d Z2 and the four parameter gradients to 2e-6 of
+    their largest element; two runs give the same bits."""
+    rng = np.random.RandomState(m)
+    z2 = dev(rng.standard_normal((m, 128)).astype(np.float32) * 2)
+    w3 = dev((rng.standard_normal((32, 128)) / 8).astype(np.float32))
+    b3 = dev((rng.standard_normal(32) * 0.1).astype(np.float32))
+    w4 = dev((rng.standard_normal((1, 32)) / 4).astype(np.float32))
+    b4 = dev(np.array([0.3], dtype=np.float32))
+    ybar = dev(rng.standard_normal(m).astype(np.float32))
+    wnp = rng.uniform(0, 1e-3, m).astype(np.float32)
+    wnp[rng.uniform(size=m) < 0.2] = 0
+    weight = dev(wnp)
+    pred, dz2, flat = ops.f0_tail_rows_f32(z2, w3, b3, w4, b4, ybar, weight)
+    again = ops.f0_tail_rows_f32(z2, w3, b3, w4, b4, ybar, weight)
+    for a, b in zip((pred, dz2, flat[:ops.F0_TAIL_F32_GRADS + 1]), (again[0], again[1], again[2][:ops.F0_TAIL_F32_GRADS + 1])):
+        assert torch.equal(a, b)
+    zt, w3t, b3t, w4t, b4t = [t.double().requires_grad_(True) for t in (z2, w3, b3, w4, b4)]
+    p = torch.sigmoid(torch.sigmoid(zt) @ w3t.t() + b3t) @ w4t.t() + b4t
+    loss = (weight.double() * (p[:, 0] - ybar.double()) ** 2).sum()
+    loss.backward()
+    n_g = ops.F0_TAIL_F32_GRADS
+
+    def close(got, want, tol=2e-6):
+        return float((got.double() - want).abs().max() / want.abs().max()) < tol
+    assert close(pred, p[:, 0].detach()) and close(flat[n_g], loss.detach().reshape(())) and close(dz2, zt.grad)
+    assert close(flat[:4096].view(32, 128), w3t.grad) and close(flat[4096:4128], b3t.grad)
+    assert close(flat[4128:4160].view(1, 32), w4t.grad) and close(flat[4160:4161], b4t.grad)
+
+
