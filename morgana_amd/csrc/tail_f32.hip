@@ -23,7 +23,7 @@
 #define TF_N3 32
 #define TF_K3 128
 #define TF_SLAB 4164                        // dW3 4096 | db3 32 | dW4 32 | db4 | loss | 2 pad
-#define TF_MAX_BLOCKS 512
+#define TF_MAX_BLOCKS 256                   // one workgroup per CU (296 registers per lane): a second round of workgroups costs a whole prologue + reduce
 
 __device__ __forceinline__ f32x4 tf_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 

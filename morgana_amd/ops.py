@@ -732,7 +732,7 @@ def begin_capture_epoch():
     CAPTURE_EPOCH[0] += 1
 
 
-SPLIT3_COLSUM_BLOCKS = 256       # workgroups (= slabs) of a split that also sums its columns
+SPLIT3_COLSUM_BLOCKS = int(os.environ.get('MORGANA_SPLIT3_COLSUM_BLOCKS', '512'))      # workgroups (= slabs) of a split that also sums its columns; C2 bf16x3 step by count: 64 0.555, 128 0.488, 256 0.458, 512 0.457, 1024 0.463, 2048 0.480 ms
 
 
 def split3_colsum_ok(cols):
