@@ -18,6 +18,15 @@
 #include "persist_common.h"
 
 #define GSS_SENTINEL 0xFFFFFFFFu
+// A consuming layer starts only once its producer is GSS_LAG steps into its own pass: layers of equal step time keep whatever distance
+// they start with, and started together the consumer's look-ahead loads (two steps early) would find the sentinel and poll every
+// step.  (Measured neutral at the shipped model's shape - 3.45 ms with and without - the polls were not what the step waits for.)
+// What the forward step spends (timing probes of round 4, private builds with parts removed, T = 1000, ms of the launch's ~1.25):
+// products section 0.64 (LDS reads, 16 MFMAs, LDS writes - a dependent chain on the critical path; independent accumulators: equal),
+// hand-off between the layers 0.29, the step's seven result stores 0.17, next step's xproj loads 0.00.
+#define GSS_LAG 6
+
+MG_STAMP_DECL(g_stamps_gss);
 
 struct GssLayers {
     mg_gru_stack_layer l[MG_GRU_STACK_MAX_LAYERS];
@@ -40,7 +49,28 @@ __device__ __forceinline__ float gss_take(float v, const float* p, bool& dead, g
 }
 
 // FAST (throughput mode, mg_gru_stack_fwd_small_fast_f32): the cell's sigmoids and tanh on v_exp_f32 / v_rcp_f32 as in the bf16-mode
-// GRU-512 recurrence (gru_cell.h) instead of expf / tanhf - the library calls are ~150 instructions of the step's dependent chain.
+// GRU-512 recurrence (gru_cell.h) instead of expf / tanhf - the library calls are ~150 instructions of the step's dependent chain - and
+// the step's products on v_mfma_f32_16x16x32_bf16 with bf16 operands (W_hh / W_ih fragments, the state and the lower layer's output
+// rounded as that recurrence rounds them), fp32 accumulation: the exact-fp32 form issues 64 (layer 0) / 128 (above) v_mfma_f32_4x4x1
+// per wave and step - stamps (scripts/stamps_gru_small.py): 1,135 / 2,027 of the step's 2,299 / 3,296 cycles - the bf16 form 8 / 16
+// MFMAs of 16 rows (4 items + 12 zero rows).  The state itself, the cell and everything stored stay fp32.
+typedef __bf16 gss_bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned int gss_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ gss_bf8 gss_as_bf8(gss_u32x4 v) {
+    union { gss_u32x4 u; gss_bf8 b; } c;
+    c.u = v;
+    return c.b;
+}
+// 8 consecutive fp32 values -> 8 bf16 (a weight fragment, converted once per launch)
+__device__ __forceinline__ gss_bf8 gss_cvt8(const float* p) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    gss_u32x4 u;
+    u[0] = (unsigned)mg_f2bf(a[0]) | ((unsigned)mg_f2bf(a[1]) << 16);
+    u[1] = (unsigned)mg_f2bf(a[2]) | ((unsigned)mg_f2bf(a[3]) << 16);
+    u[2] = (unsigned)mg_f2bf(b[0]) | ((unsigned)mg_f2bf(b[1]) << 16);
+    u[3] = (unsigned)mg_f2bf(b[2]) | ((unsigned)mg_f2bf(b[3]) << 16);
+    return gss_as_bf8(u);
+}
 template <bool FAST>
 __global__ __launch_bounds__(256) void gru_stack_fwd_small64_kernel(GssLayers a, const int64_t* __restrict__ seq_len, int B, int T, int L,
                                                                     int nblk, unsigned* sync) {
@@ -49,7 +79,11 @@ __global__ __launch_bounds__(256) void gru_stack_fwd_small64_kernel(GssLayers a,
     __shared__ __attribute__((aligned(16))) float xs[2][R][LDH];    // upper layers: the lower layer's output of step t (parity t & 1)
     __shared__ __attribute__((aligned(16))) float gl[R][LDG];       // recurrent pre-activations of the three gates
     __shared__ __attribute__((aligned(16))) float gx[R][LDG];       // upper layers: input pre-activations
+    constexpr int LDB = H + 8;                                       // FAST: bf16 copies of hs / xs, the MFMA A operands
+    __shared__ __attribute__((aligned(16))) uint16_t hb[R][LDB];
+    __shared__ __attribute__((aligned(16))) uint16_t xsb[2][R][LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
     const int layer = blockIdx.x / nblk, blk = blockIdx.x - layer * nblk;
     const mg_gru_stack_layer& P = a.l[layer];
     const bool upper = layer > 0, hands_up = layer + 1 < L;
@@ -57,8 +91,20 @@ __global__ __launch_bounds__(256) void gru_stack_fwd_small64_kernel(GssLayers a,
     const int row0 = blk * R;
     const int nrows = min(R, B - row0);
     // wave g < 3 owns gate g: lane L holds row g H + L of W_hh (and of W_ih above the first layer) for the whole launch
-    f32x4 fw[H / 4], fwi[H / 4];
-    if (wave < 3) {
+    f32x4 fw[FAST ? 1 : H / 4], fwi[FAST ? 1 : H / 4];
+    // FAST: the 192 gate columns are 12 tiles of 16, three per wave (all four waves); tile nt of this wave, k-step ks: row
+    // 16 (3 wave + nt) + li of W, columns 32 ks + 8 q .. + 7
+    gss_bf8 fwb[3][2], fwib[3][2];
+    if (FAST) {
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                fwb[nt][ks] = gss_cvt8(P.w_hh + (size_t)(16 * (3 * wave + nt) + li) * H + 32 * ks + 8 * q);
+                fwib[nt][ks] = upper ? gss_cvt8(P.w_ih + (size_t)(16 * (3 * wave + nt) + li) * H + 32 * ks + 8 * q) : fwb[nt][ks];
+            }
+    }
+    if (!FAST && wave < 3) {
         const float* wp = P.w_hh + (size_t)(wave * H + lane) * H;
 #pragma unroll
         for (int k4 = 0; k4 < H / 4; ++k4) {
@@ -76,6 +122,11 @@ __global__ __launch_bounds__(256) void gru_stack_fwd_small64_kernel(GssLayers a,
         (&xs[0][0][0])[e] = 0.f;
         (&xs[1][0][0])[e] = 0.f;
     }
+    for (int e = tid; e < R * LDB; e += 256) {
+        (&hb[0][0])[e] = 0;
+        (&xsb[0][0][0])[e] = 0;
+        (&xsb[1][0][0])[e] = 0;
+    }
     __syncthreads();
     const int er = tid >> 6, ej = tid & 63;                          // cell role: item er, unit ej
     const bool mine = er < nrows;
@@ -84,7 +135,10 @@ __global__ __launch_bounds__(256) void gru_stack_fwd_small64_kernel(GssLayers a,
     const float bhr = P.b_hh[ej], bhz = P.b_hh[H + ej], bhn = P.b_hh[2 * H + ej];
     const float bir = upper ? P.b_ih[ej] : 0.f, biz = upper ? P.b_ih[H + ej] : 0.f, bin = upper ? P.b_ih[2 * H + ej] : 0.f;
     float hprev = mine ? P.hstate[((size_t)b * (T + 1)) * H + ej] : 0.f;
-    if (mine) hs[er][ej] = hprev;
+    if (mine) {
+        hs[er][ej] = hprev;
+        hb[er][ej] = mg_f2bf(hprev);
+    }
     const float* xp = (upper ? P.b_hh : P.xproj + (size_t)b * T * G) + (upper ? 0 : ej);        // layer 0: projected input rows
     const float* xin = upper ? a.l[layer - 1].out + (size_t)b * T * H + ej : P.b_hh;             // above: the lower layer's outputs
     float xr = 0.f, xz = 0.f, xn = 0.f;
@@ -93,19 +147,59 @@ __global__ __launch_bounds__(256) void gru_stack_fwd_small64_kernel(GssLayers a,
     if (!upper) {
         xr = xp[0], xz = xp[H], xn = xp[2 * H];
     } else if (mine) {
+        const int t_lag = T - 1 < GSS_LAG ? T - 1 : GSS_LAG;
+        (void)gss_take(gss_load(xin + (size_t)t_lag * H), xin + (size_t)t_lag * H, dead, status, 8u);     // the start lag (see GSS_LAG)
         float x0 = gss_load(xin);
         xa = T > 1 ? gss_load(xin + H) : 0.f;
         xb = T > 2 ? gss_load(xin + 2 * H) : 0.f;
         xs[0][er][ej] = gss_take(x0, xin, dead, status, 8u);
+        xsb[0][er][ej] = mg_f2bf(xs[0][er][ej]);
     }
     __syncthreads();
 
     // one step; x_use holds x_{t+1} (consumed at the end of the step, then reloaded with x_{t+3})
+#ifdef MG_STAMPS
+    unsigned long long ta = 0, tb = 0, ts0 = 0, ts1 = 0, tr0 = 0, tr1 = 0, sum_mm = 0, sum_b1 = 0, sum_cell = 0, sum_take = 0, sum_b2 = 0;
+    MG_STAMP(ts0);
+    MG_STAMP_REAL(tr0);
+#endif
     auto step = [&](int t, float& x_use) {
         const int t1 = t + 1 < T ? t + 1 : t;
         float xr1 = 0.f, xz1 = 0.f, xn1 = 0.f;
+        MG_STAMP(ta);
         if (!upper) xr1 = xp[(size_t)t1 * G], xz1 = xp[(size_t)t1 * G + H], xn1 = xp[(size_t)t1 * G + 2 * H];
-        if (wave < 3) {
+        if (FAST) {
+            // rows = the 4 items (A rows 4 .. 15 zero), 16 columns of the wave's gate per tile, K = 64 in two MFMAs
+            const gss_u32x4 zero = {0u, 0u, 0u, 0u};
+            gss_bf8 ah[2], ax[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                ah[ks] = gss_as_bf8(li < R ? *reinterpret_cast<const gss_u32x4*>(&hb[li & 3][32 * ks + 8 * q]) : zero);
+                ax[ks] = gss_as_bf8((upper && li < R) ? *reinterpret_cast<const gss_u32x4*>(&xsb[t & 1][li & 3][32 * ks + 8 * q]) : zero);
+            }
+            // W as the A operand, the items as the columns: a lane (item li, q) then holds four CONSECUTIVE gate columns 4 q + r of its
+            // item - one 16-byte LDS write per tile instead of four 4-byte ones from the lanes of one row
+            f32x4 acc[3], acx[3];
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) acc[nt] = acx[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwb[nt][ks], ah[ks], acc[nt], 0, 0, 0);
+                if (upper) {
+#pragma unroll
+                    for (int nt = 0; nt < 3; ++nt) acx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwib[nt][ks], ax[ks], acx[nt], 0, 0, 0);
+                }
+            }
+            if (li < R) {
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt) {
+                    *reinterpret_cast<f32x4*>(&gl[li][16 * (3 * wave + nt) + 4 * q]) = acc[nt];
+                    if (upper) *reinterpret_cast<f32x4*>(&gx[li][16 * (3 * wave + nt) + 4 * q]) = acx[nt];
+                }
+            }
+        }
+        if (!FAST && wave < 3) {
             f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int k4 = 0; k4 < H / 4; ++k4) {
@@ -129,7 +223,11 @@ __global__ __launch_bounds__(256) void gru_stack_fwd_small64_kernel(GssLayers a,
                 for (int i = 0; i < R; ++i) gx[i][wave * H + lane] = sx[i];
             }
         }
+        MG_STAMP(tb);
+        MG_STAMP_ADD(sum_mm, tb, ta);
         gp_lds_barrier();
+        MG_STAMP(ta);
+        MG_STAMP_ADD(sum_b1, ta, tb);
         if (mine) {
             if (upper) xr = gx[er][ej] + bir, xz = gx[er][H + ej] + biz, xn = gx[er][2 * H + ej] + bin;
             const float hr = gl[er][ej] + bhr, hz = gl[er][H + ej] + bhz, hn = gl[er][2 * H + ej] + bhn;
@@ -140,6 +238,7 @@ __global__ __launch_bounds__(256) void gru_stack_fwd_small64_kernel(GssLayers a,
             const bool active = t < len;
             hprev = active ? hnew : hprev;
             hs[er][ej] = hprev;
+            if (FAST) hb[er][ej] = mg_f2bf(hprev);
             const size_t row = (size_t)b * T + t;
             P.hstate[((size_t)b * (T + 1) + t + 1) * H + ej] = hprev;
             if (hands_up)
@@ -151,15 +250,23 @@ __global__ __launch_bounds__(256) void gru_stack_fwd_small64_kernel(GssLayers a,
             sv[H + ej] = z;
             sv[2 * H + ej] = n;
             sv[3 * H + ej] = hn;
+            MG_STAMP(tb);
+            MG_STAMP_ADD(sum_cell, tb, ta);
             if (upper && t + 1 < T) {
-                xs[(t + 1) & 1][er][ej] = gss_take(x_use, xin + (size_t)(t + 1) * H, dead, status, 8u);
+                const float xv = gss_take(x_use, xin + (size_t)(t + 1) * H, dead, status, 8u);
+                xs[(t + 1) & 1][er][ej] = xv;
+                if (FAST) xsb[(t + 1) & 1][er][ej] = mg_f2bf(xv);
                 if (t + 3 < T) x_use = gss_load(xin + (size_t)(t + 3) * H);
             }
+            MG_STAMP(ta);
+            MG_STAMP_ADD(sum_take, ta, tb);
         }
         xr = xr1;
         xz = xz1;
         xn = xn1;
         gp_lds_barrier();
+        MG_STAMP(tb);
+        MG_STAMP_ADD(sum_b2, tb, ta);
     };
     int t = 0;
     for (; t + 1 < T; t += 2) {
@@ -167,6 +274,20 @@ __global__ __launch_bounds__(256) void gru_stack_fwd_small64_kernel(GssLayers a,
         step(t + 1, xb);
     }
     if (t < T) step(t, xa);
+#ifdef MG_STAMPS
+    MG_STAMP(ts1);
+    MG_STAMP_REAL(tr1);
+    MG_STAMP_STORE(g_stamps_gss, blockIdx.x, wave, lane, 0, ts0);
+    MG_STAMP_STORE(g_stamps_gss, blockIdx.x, wave, lane, 1, ts1);
+    MG_STAMP_STORE(g_stamps_gss, blockIdx.x, wave, lane, 2, tr0);
+    MG_STAMP_STORE(g_stamps_gss, blockIdx.x, wave, lane, 3, tr1);
+    MG_STAMP_STORE(g_stamps_gss, blockIdx.x, wave, lane, 4, sum_mm);
+    MG_STAMP_STORE(g_stamps_gss, blockIdx.x, wave, lane, 5, sum_b1);
+    MG_STAMP_STORE(g_stamps_gss, blockIdx.x, wave, lane, 6, sum_cell);
+    MG_STAMP_STORE(g_stamps_gss, blockIdx.x, wave, lane, 7, sum_take);
+    MG_STAMP_STORE(g_stamps_gss, blockIdx.x, wave, lane, 8, sum_b2);
+    MG_STAMP_STORE(g_stamps_gss, blockIdx.x, wave, lane, 9, (unsigned long long)layer);
+#endif
 }
 
 // Backward.  dl = dhproj_{t+1} = (dr, dz, dn r) feeds dstate_t = carry + dl W_hh as in gru_bwd_small64_kernel; above the first layer
@@ -211,6 +332,10 @@ __global__ __launch_bounds__(256) void gru_stack_bwd_small64_kernel(GssLayers a,
     float ga = 0.f, gb = 0.f;
     bool dead = false;
     if (mine) {
+        if (!top) {                                  // the start lag (see GSS_LAG): the layer above is GSS_LAG steps down its pass
+            const int t_lag = T - 1 - GSS_LAG > 0 ? T - 1 - GSS_LAG : 0;
+            (void)gss_take(gss_load(p_g + (size_t)t_lag * H), p_g + (size_t)t_lag * H, dead, status, 9u);
+        }
         ga = top ? p_g[(size_t)(T - 1) * H] : gss_load(p_g + (size_t)(T - 1) * H);
         if (T > 1) gb = top ? p_g[(size_t)(T - 2) * H] : gss_load(p_g + (size_t)(T - 2) * H);
     }
@@ -383,3 +508,9 @@ int mg_gru_stack_bwd_small_f32(const mg_gru_stack_layer* layers, int L, const in
 }
 
 }  // extern "C"
+
+#ifdef MG_STAMPS
+extern "C" int mg_diag_read_stamps_gss(void* dst, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps_gss), bytes < sizeof(g_stamps_gss) ? bytes : sizeof(g_stamps_gss), 0, hipMemcpyDeviceToHost);
+}
+#endif
