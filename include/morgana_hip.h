@@ -760,12 +760,15 @@ int mg_gru_stack_small_supported(int B, int T, int H, int L);
 size_t mg_gru_stack_small_workspace_bytes(void);
 int mg_gru_stack_fwd_small_f32(const mg_gru_stack_layer* layers, int L, const int64_t* seq_len, int B, int T, int H, void* workspace,
                                size_t workspace_bytes, void* stream);
-/* mg_gru_stack_fwd_small_f32 with the cell's sigmoid / tanh on v_exp_f32 / v_rcp_f32 (throughput mode, as the bf16-mode GRU-512
- * recurrence); products exact fp32, same arguments, same backward launch. */
+/* The throughput-mode ("bf16" precision) forms, same arguments: the cell's sigmoid / tanh on v_exp_f32 / v_rcp_f32 and the step's
+ * products on v_mfma_f32_16x16x32_bf16 (W_hh / W_ih, the state and what the layers hand each other rounded to bf16 as operands, fp32
+ * accumulation - as the bf16-mode GRU-512 recurrence); state, cell and everything stored stay fp32.  The _f32 entries are exact fp32. */
 int mg_gru_stack_fwd_small_fast_f32(const mg_gru_stack_layer* layers, int L, const int64_t* seq_len, int B, int T, int H, void* workspace,
                                     size_t workspace_bytes, void* stream);
 int mg_gru_stack_bwd_small_f32(const mg_gru_stack_layer* layers, int L, const int64_t* seq_len, int B, int T, int H, void* workspace,
                                size_t workspace_bytes, void* stream);
+int mg_gru_stack_bwd_small_fast_f32(const mg_gru_stack_layer* layers, int L, const int64_t* seq_len, int B, int T, int H, void* workspace,
+                                    size_t workspace_bytes, void* stream);
 
 /* LSTM through RecurrentCuDNNWrapper   reference: morgana/utils.py:345-393 + torch.nn.LSTM (gates i, f, g, o), the cell of
  * the reference's shipped acoustic model (models/RNN_SPSS.py:36-37).  Same conventions as the GRU entry points:

@@ -199,6 +199,7 @@ SIGNATURES = {
     'mg_gru_stack_fwd_small_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'mg_gru_stack_fwd_small_fast_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'mg_gru_stack_bwd_small_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'mg_gru_stack_bwd_small_fast_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'mg_lstm_pstack_supported': (c_int, [c_int, c_int, c_int, c_int]),
     'mg_lstm_pstack_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'mg_lstm_pstack_fwd_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),

@@ -293,29 +293,63 @@ __global__ __launch_bounds__(256) void gru_stack_fwd_small64_kernel(GssLayers a,
 // Backward.  dl = dhproj_{t+1} = (dr, dz, dn r) feeds dstate_t = carry + dl W_hh as in gru_bwd_small64_kernel; above the first layer
 // dlx = dxproj_{t+1} = (dr, dz, dn) also goes through the layer's own W_ih in the same phase: d x_{t+1} = dlx W_ih is what the layer
 // below adds to its state gradient in place of a grad_out row, and is handed down through `dxin` (sentinel protocol above).
+// FAST (throughput mode, mg_gru_stack_bwd_small_fast_f32): the two products of a step on v_mfma_f32_16x16x32_bf16 - gate gradients and
+// W rounded to bf16 as the GRU-512 backward rounds them, fp32 accumulation; wave w owns output columns 16 w .. 16 w + 15 over the whole
+// contraction (6 MFMAs per product instead of 48 v_mfma_f32_4x4x1 and a four-way partial sum) - W^T as the A operand, the items as
+// columns, so a lane writes its item's four consecutive columns as one 16-byte LDS store (see the forward kernel).
+template <bool FAST>
 __global__ __launch_bounds__(256) void gru_stack_bwd_small64_kernel(GssLayers a, const int64_t* __restrict__ seq_len, int B, int T, int L,
                                                                     int nblk, unsigned* sync) {
     constexpr int H = 64, G = 192, R = 4, LDG = G + 4, KW = G / 4;  // KW = 48 gate rows per wave
     __shared__ __attribute__((aligned(16))) float dl[R][LDG];
     __shared__ __attribute__((aligned(16))) float dlx[R][LDG];
-    __shared__ float part[4][R][H];
-    __shared__ float partx[4][R][H];
+    __shared__ __attribute__((aligned(16))) float part[4][R][H];
+    __shared__ __attribute__((aligned(16))) float partx[4][R][H];
+    constexpr int LDGB = G + 8;
+    __shared__ __attribute__((aligned(16))) uint16_t dlb[R][LDGB];      // FAST: bf16 copies of dl / dlx, the MFMA B operands
+    __shared__ __attribute__((aligned(16))) uint16_t dlxb[R][LDGB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
     const int layer = blockIdx.x / nblk, blk = blockIdx.x - layer * nblk;
     const mg_gru_stack_layer& P = a.l[layer];
     const bool upper = layer > 0, top = layer + 1 == L;
     gu32* status = (gu32*)sync + GP_FLAG_WORDS;
     const int row0 = blk * R;
     const int nrows = min(R, B - row0);
-    float fw[KW], fwi[KW];
+    float fw[FAST ? 1 : KW], fwi[FAST ? 1 : KW];
+    // FAST: A operand = W^T: row = output column 16 wave + li, k-step ks: gate rows 32 ks + 8 q .. + 7 (a strided gather, once)
+    gss_bf8 fwb[6], fwib[6];
+    if (FAST) {
 #pragma unroll
-    for (int k = 0; k < KW; ++k) {
-        fw[k] = P.w_hh[(size_t)(wave * KW + k) * H + lane];
-        fwi[k] = upper ? P.w_ih[(size_t)(wave * KW + k) * H + lane] : 0.f;
+        for (int ks = 0; ks < 6; ++ks) {
+            gss_u32x4 u, ui;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const size_t g0 = (size_t)(32 * ks + 8 * q + 2 * j) * H + 16 * wave + li;
+                u[j] = (unsigned)mg_f2bf(P.w_hh[g0]) | ((unsigned)mg_f2bf(P.w_hh[g0 + H]) << 16);
+                ui[j] = upper ? ((unsigned)mg_f2bf(P.w_ih[g0]) | ((unsigned)mg_f2bf(P.w_ih[g0 + H]) << 16)) : 0u;
+            }
+            fwb[ks] = gss_as_bf8(u);
+            fwib[ks] = gss_as_bf8(ui);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < (FAST ? 1 : KW); ++k) {
+            fw[k] = P.w_hh[(size_t)(wave * KW + k) * H + lane];
+            fwi[k] = upper ? P.w_ih[(size_t)(wave * KW + k) * H + lane] : 0.f;
+        }
     }
     for (int e = tid; e < R * LDG; e += 256) {
         (&dl[0][0])[e] = 0.f;
         (&dlx[0][0])[e] = 0.f;
+    }
+    for (int e = tid; e < R * LDGB; e += 256) {
+        (&dlb[0][0])[e] = 0;
+        (&dlxb[0][0])[e] = 0;
+    }
+    for (int e = tid; e < 4 * R * H; e += 256) {          // FAST writes part[0] / partx[0] only: the other three stay zero
+        (&part[0][0][0])[e] = 0.f;
+        (&partx[0][0][0])[e] = 0.f;
     }
     const int er = tid >> 6, ej = tid & 63;
     const bool mine = er < nrows;
@@ -346,7 +380,28 @@ __global__ __launch_bounds__(256) void gru_stack_bwd_small64_kernel(GssLayers a,
         const int t1 = t > 0 ? t - 1 : 0;
         const float s_r1 = p_sv[(size_t)t1 * 4 * H], s_z1 = p_sv[(size_t)t1 * 4 * H + H], s_n1 = p_sv[(size_t)t1 * 4 * H + 2 * H],
                     s_hn1 = p_sv[(size_t)t1 * 4 * H + 3 * H], hprev1 = p_h[(size_t)t1 * H];
-        if (t + 1 < T) {
+        if (FAST && t + 1 < T) {
+            const gss_u32x4 zero = {0u, 0u, 0u, 0u};
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = acc, acx = acc, acx2 = acc;
+#pragma unroll
+            for (int ks = 0; ks < 6; ks += 2) {
+                const gss_bf8 b0 = gss_as_bf8(li < R ? *reinterpret_cast<const gss_u32x4*>(&dlb[li & 3][32 * ks + 8 * q]) : zero);
+                const gss_bf8 b1 = gss_as_bf8(li < R ? *reinterpret_cast<const gss_u32x4*>(&dlb[li & 3][32 * (ks + 1) + 8 * q]) : zero);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwb[ks], b0, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwb[ks + 1], b1, acc2, 0, 0, 0);
+                if (upper) {
+                    const gss_bf8 x0 = gss_as_bf8(li < R ? *reinterpret_cast<const gss_u32x4*>(&dlxb[li & 3][32 * ks + 8 * q]) : zero);
+                    const gss_bf8 x1 = gss_as_bf8(li < R ? *reinterpret_cast<const gss_u32x4*>(&dlxb[li & 3][32 * (ks + 1) + 8 * q]) : zero);
+                    acx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwib[ks], x0, acx, 0, 0, 0);
+                    acx2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwib[ks + 1], x1, acx2, 0, 0, 0);
+                }
+            }
+            if (li < R) {                            // lane (item li, q): columns 16 wave + 4 q .. + 3
+                *reinterpret_cast<f32x4*>(&part[0][li][16 * wave + 4 * q]) = acc + acc2;
+                if (upper) *reinterpret_cast<f32x4*>(&partx[0][li][16 * wave + 4 * q]) = acx + acx2;
+            }
+        }
+        if (!FAST && t + 1 < T) {
             f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int k4 = 0; k4 < KW / 4; ++k4) {
@@ -397,6 +452,16 @@ __global__ __launch_bounds__(256) void gru_stack_bwd_small64_kernel(GssLayers a,
                     dlx[er][ej] = dr;
                     dlx[er][H + ej] = dz;
                     dlx[er][2 * H + ej] = dn;
+                }
+                if (FAST) {
+                    dlb[er][ej] = mg_f2bf(dr);
+                    dlb[er][H + ej] = mg_f2bf(dz);
+                    dlb[er][2 * H + ej] = mg_f2bf(dnr);
+                    if (upper) {
+                        dlxb[er][ej] = mg_f2bf(dr);
+                        dlxb[er][H + ej] = mg_f2bf(dz);
+                        dlxb[er][2 * H + ej] = mg_f2bf(dn);
+                    }
                 }
                 const size_t row = (size_t)b * T + t;
                 float* dx = P.dxproj + row * G;
@@ -484,8 +549,23 @@ static int gss_fwd(const mg_gru_stack_layer* layers, int L, const int64_t* seq_l
     return MG_OK;
 }
 
+static int gss_bwd(const mg_gru_stack_layer* layers, int L, const int64_t* seq_len, int B, int T, int H, void* workspace,
+                   size_t workspace_bytes, void* stream, bool fast);
+
 int mg_gru_stack_bwd_small_f32(const mg_gru_stack_layer* layers, int L, const int64_t* seq_len, int B, int T, int H, void* workspace,
                                size_t workspace_bytes, void* stream) {
+    return gss_bwd(layers, L, seq_len, B, T, H, workspace, workspace_bytes, stream, false);
+}
+
+// The throughput-mode ("bf16" precision) backward: the same wavefront with the step's products on bf16 MFMAs (operands rounded to
+// bf16, fp32 accumulation), as mg_gru_stack_fwd_small_fast_f32's.
+int mg_gru_stack_bwd_small_fast_f32(const mg_gru_stack_layer* layers, int L, const int64_t* seq_len, int B, int T, int H, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    return gss_bwd(layers, L, seq_len, B, T, H, workspace, workspace_bytes, stream, true);
+}
+
+static int gss_bwd(const mg_gru_stack_layer* layers, int L, const int64_t* seq_len, int B, int T, int H, void* workspace,
+                   size_t workspace_bytes, void* stream, bool fast) {
     const int rc = gss_check("mg_gru_stack_bwd_small_f32", layers, L, B, T, H, workspace, workspace_bytes);
     if (rc != MG_OK) return rc;
     GssLayers a;
@@ -502,7 +582,10 @@ int mg_gru_stack_bwd_small_f32(const mg_gru_stack_layer* layers, int L, const in
         }
     }
     const int nblk = (int)mg_ceil_div(B, 4);
-    hipLaunchKernelGGL(gru_stack_bwd_small64_kernel, dim3((unsigned)(L * nblk)), dim3(256), 0, st, a, seq_len, B, T, L, nblk, (unsigned*)workspace);
+    if (fast)
+        hipLaunchKernelGGL(gru_stack_bwd_small64_kernel<true>, dim3((unsigned)(L * nblk)), dim3(256), 0, st, a, seq_len, B, T, L, nblk, (unsigned*)workspace);
+    else
+        hipLaunchKernelGGL(gru_stack_bwd_small64_kernel<false>, dim3((unsigned)(L * nblk)), dim3(256), 0, st, a, seq_len, B, T, L, nblk, (unsigned*)workspace);
     MG_CHECK_LAUNCH("mg_gru_stack_bwd_small_f32");
     return MG_OK;
 }

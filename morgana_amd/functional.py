@@ -1266,7 +1266,7 @@ class GRUStackSmallFn(torch.autograd.Function):
                                          out_f32=True)
             if xproj0.shape[1] != 3 * hid:
                 xproj0 = xproj0[:, :3 * hid].contiguous()
-        # throughput mode: the cell's transcendentals on v_exp / v_rcp, as the bf16-mode GRU-512 recurrence (the products stay exact fp32)
+        # throughput mode: the cell's transcendentals on v_exp / v_rcp and the step's products on bf16 MFMAs, as the bf16-mode GRU-512 recurrence
         outs, hstates, saveds = ops.gru_stack_small_fwd(xproj0.view(b, t, 3 * hid), w_ih, w_hh, b_ih, b_hh, seq_len, h0s, b, t, hid,
                                                         fast=precision == 'bf16' and RECURRENCE_BF16)
         ctx.precision = precision
@@ -1291,7 +1291,8 @@ class GRUStackSmallFn(torch.autograd.Function):
         m = b * t
         g_out = grad_out.contiguous() if grad_out is not None else torch.zeros((b, t, hid), dtype=torch.float32, device=dev)
         g_hn = [grad_hn[l] for l in range(n_layers)] if grad_hn is not None else None
-        dxprojs, dhprojs, dh0 = ops.gru_stack_small_bwd(g_out, g_hn, hstate, saved, w_ih, w_hh, seq_len, b, t, hid)
+        dxprojs, dhprojs, dh0 = ops.gru_stack_small_bwd(g_out, g_hn, hstate, saved, w_ih, w_hh, seq_len, b, t, hid,
+                                                        fast=ctx.precision == 'bf16' and RECURRENCE_BF16)
         prev_rows = state_rows(b, t, dev)
         grads = [None] * (4 * n_layers)
         dx = None

@@ -1479,7 +1479,7 @@ def gru_stack_small_fwd(xproj0, w_ih, w_hh, b_ih, b_hh, seq_len, h0s, b, t, h, f
     return outs, hstates, saveds
 
 
-def gru_stack_small_bwd(grad_out, grad_hn, hstate, saved, w_ih, w_hh, seq_len, b, t, h):
+def gru_stack_small_bwd(grad_out, grad_hn, hstate, saved, w_ih, w_hh, seq_len, b, t, h, fast=False):
     """The backward of gru_stack_small_fwd in one launch.  grad_out (b,t,h) = gradient of the TOP layer's outputs; grad_hn None or a
     per-layer list of (b,h) tensors / None.  Returns per-layer lists (dxproj, dhproj) and dh0 (L,b,h)."""
     lib = _lib.load()
@@ -1509,8 +1509,9 @@ def gru_stack_small_bwd(grad_out, grad_hn, hstate, saved, w_ih, w_hh, seq_len, b
         d.dxproj, d.dhproj, d.dh0 = dxp.data_ptr(), dhp.data_ptr(), dh0[l].data_ptr()
         dxprojs.append(dxp); dhprojs.append(dhp)
     ws = _gru_stack_workspace(dev)
-    _lib.check(lib.mg_gru_stack_bwd_small_f32(ctypes.cast(descs, ctypes.c_void_p), n_layers, _p(seq_len), b, t, h, _p(ws), ws.numel(),
-                                              _stream()), 'mg_gru_stack_bwd_small_f32')
+    entry = lib.mg_gru_stack_bwd_small_fast_f32 if fast else lib.mg_gru_stack_bwd_small_f32      # fast: bf16-operand products (throughput mode)
+    _lib.check(entry(ctypes.cast(descs, ctypes.c_void_p), n_layers, _p(seq_len), b, t, h, _p(ws), ws.numel(), _stream()),
+               'mg_gru_stack_bwd_small_fast_f32' if fast else 'mg_gru_stack_bwd_small_f32')
     return dxprojs, dhprojs, dh0
 
 
