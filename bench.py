@@ -584,7 +584,7 @@ def bf16x3_legs(dev, features, state_dict, steps, frames_per_step):
             gc.enable()
     out['what'] = ("F0Model(precision='bf16x3'): x = hi + lo in bf16, x w ~= hi hi + hi lo + lo hi as one bf16 GEMM over a three times longer "
                    "contraction index (csrc/split3.hip), fp32 activations and accumulators; phone_rate = the headline's order of operations "
-                   "(generic row-wise stack on the phone rows), frame_rate_order = every product on the B*T frame rows")
+                   "(row-wise layers on the phone rows; the 128 -> 32 -> 1 tail, the per-phone masked MSE and their backward as one exact-fp32 launch), frame_rate_order = every product on the B*T frame rows")
     return out
 
 
