@@ -274,13 +274,15 @@ int mg_linear_wgrad_f32(const float* dY, const float* A, int lda, const int32_t*
 /*  mg_f0_tail_rows_f32  the README F0Model's tail (Linear(128, 32) -> Sigmoid -> Linear(32, 1), /root/reference/README.rst:65-73) with the
  *                     masked MSE in its per-phone form, forward AND backward, exact fp32 (v_mfma_f32_16x16x4_f32), ONE launch + the ordered
  *                     slab reduce - the fp32 / bf16x3 modes' counterpart of mg_f0_tail_rows_bf16 (csrc/tail_f32.hip).  Z2 f32 [M, ldz]: the
- *                     128-wide layer's PRE-activations (h2 = sigmoid(Z2) is taken here); ybar, weight f32 [M] as mg_phone_front leaves them.
+ *                     128-wide layer's PRE-activations (h2 = sigmoid(Z2) is taken here); ybar, weight f32 [M] as mg_phone_front leaves them -
+ *                     or weight == NULL: the rows are the B x T frames, ybar = the targets [B * T], and the kernel forms the masked MSE's own
+ *                     weights [t < n_b] / (n_b B) from seq_len (NULL = all T; an utterance without frames gives NaN, as the reference's mean).
  *                     pred f32 [M]; dZ2 f32 [M, lddz] = d loss / d Z2; grads_out f32 [4164] = dW3 [32 x 128] | db3 [32] | dW4 [32] | db4 |
  *                     loss (= sum_m weight (pred - ybar)^2, the constant term excluded) | 2 unused. */
 size_t mg_f0_tail_rows_f32_workspace_bytes(int64_t M);
 int mg_f0_tail_rows_f32(const float* Z2, int ldz, const float* W3, const float* b3, const float* W4, const float* b4, const float* ybar,
-                        const float* weight, int64_t M, float* pred, float* dZ2, int lddz, float* grads_out, void* workspace,
-                        size_t workspace_bytes, void* stream);
+                        const float* weight, const int64_t* seq_len, int B, int T, int64_t M, float* pred, float* dZ2, int lddz,
+                        float* grads_out, void* workspace, size_t workspace_bytes, void* stream);
 /*  mg_phone_mse_rows_f32  the masked MSE of a ONE-column prediction that is constant over each table row's frames, exact-fp32 modes:
  *                     loss[0] = sum_r weight[r] (pred[r * ldp] - ybar[r])^2 over the R + extra rows of mg_phone_target_stats (its constant
  *                     term is added by mg_phone_loss_const_add / mg_expand_column_loss_f32), dpred[r] = 2 weight[r] (pred[r * ldp] - ybar[r]).

@@ -169,8 +169,8 @@ SIGNATURES = {
                                          c_int, c_void_p, c_size_t, c_void_p]),
     'mg_feat_wgrad_reduce': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     'mg_f0_tail_rows_f32_workspace_bytes': (c_size_t, [c_int64]),
-    'mg_f0_tail_rows_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int,
-                                    c_void_p, c_void_p, c_size_t, c_void_p]),
+    'mg_f0_tail_rows_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
+                                    c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'mg_phone_mse_rows_f32': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     'mg_phone_concat_layer_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
                                            c_void_p, c_int, c_int, c_void_p]),

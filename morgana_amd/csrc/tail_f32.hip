@@ -30,7 +30,8 @@ __device__ __forceinline__ f32x4 tf_mfma(float a, float b, f32x4 c) { return __b
 __global__ __launch_bounds__(256) void f0_tail_rows_f32_kernel(const float* __restrict__ Z2, int ldz, const float* __restrict__ W3,
                                                                const float* __restrict__ b3, const float* __restrict__ W4,
                                                                const float* __restrict__ b4, const float* __restrict__ ybar,
-                                                               const float* __restrict__ weight, int64_t M, float* __restrict__ pred,
+                                                               const float* __restrict__ weight, const int64_t* __restrict__ seq_len,
+                                                               int B, int T, int64_t M, float* __restrict__ pred,
                                                                float* __restrict__ dZ2, int lddz, float* __restrict__ slab) {
     __shared__ __attribute__((aligned(16))) float th[4][16][TF_K3 + 4];       // per wave: the tile's h2 [row][k]
     __shared__ __attribute__((aligned(16))) float t3[4][16][TF_N3 + 4];       // per wave: the tile's dz3 [row][j]
@@ -87,7 +88,19 @@ __global__ __launch_bounds__(256) void f0_tail_rows_f32_kernel(const float* __re
         for (int r = 0; r < 4; ++r) {
             const bool v = rc + r < M;
             yb[r] = v ? ybar[rc + r] : 0.f;
-            wt[r] = v ? weight[rc + r] : 0.f;
+            if (weight) {
+                wt[r] = v ? weight[rc + r] : 0.f;
+            } else {
+                // rows are frames (b, t): the masked MSE's own weights [t < n_b] / (n_b B) (morgana/losses.py:29-51); an utterance
+                // without frames gives NaN, as the reference's mean over no frames does
+                wt[r] = 0.f;
+                if (v) {
+                    const int64_t bi = (rc + r) / T;
+                    const int ti = (int)((rc + r) - bi * T);
+                    const int64_t nb = seq_len ? (seq_len[bi] < T ? seq_len[bi] : (int64_t)T) : (int64_t)T;
+                    wt[r] = nb == 0 ? (ti == 0 ? __builtin_nanf("") : 0.f) : (ti < nb ? 1.f / ((float)nb * (float)B) : 0.f);
+                }
+            }
         }
         f32x4 h3[2], dz3[2];
 #pragma unroll
@@ -206,10 +219,12 @@ size_t mg_f0_tail_rows_f32_workspace_bytes(int64_t M) {
 }
 
 int mg_f0_tail_rows_f32(const float* Z2, int ldz, const float* W3, const float* b3, const float* W4, const float* b4, const float* ybar,
-                        const float* weight, int64_t M, float* pred, float* dZ2, int lddz, float* grads_out, void* workspace,
-                        size_t workspace_bytes, void* stream) {
-    MG_CHECK_ARG(Z2 && W3 && b3 && W4 && b4 && ybar && weight && pred && dZ2 && grads_out && M > 0,
+                        const float* weight, const int64_t* seq_len, int B, int T, int64_t M, float* pred, float* dZ2, int lddz,
+                        float* grads_out, void* workspace, size_t workspace_bytes, void* stream) {
+    MG_CHECK_ARG(Z2 && W3 && b3 && W4 && b4 && ybar && pred && dZ2 && grads_out && M > 0,
                  "mg_f0_tail_rows_f32: bad arguments (M=%lld)", (long long)M);
+    MG_CHECK_ARG(weight || (B > 0 && T > 0 && (int64_t)B * T == M),
+                 "mg_f0_tail_rows_f32: without per-row weights the rows are the B x T frames (B=%d T=%d M=%lld)", B, T, (long long)M);
     MG_CHECK_ARG(ldz >= TF_K3 && ldz % 4 == 0 && lddz >= TF_K3 && ((uintptr_t)Z2 % 16) == 0 && ((uintptr_t)W3 % 16) == 0 &&
                      ((uintptr_t)grads_out % 16) == 0,
                  "mg_f0_tail_rows_f32: ldz=%d (multiple of 4, >= 128) lddz=%d (>= 128); Z2, W3 and grads_out 16-byte aligned", ldz, lddz);
@@ -221,7 +236,7 @@ int mg_f0_tail_rows_f32(const float* Z2, int ldz, const float* W3, const float* 
     int64_t blocks = mg_ceil_div(mg_ceil_div(M, 16), 4);
     if (blocks > TF_MAX_BLOCKS) blocks = TF_MAX_BLOCKS;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(f0_tail_rows_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Z2, ldz, W3, b3, W4, b4, ybar, weight, M, pred, dZ2, lddz,
+    hipLaunchKernelGGL(f0_tail_rows_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Z2, ldz, W3, b3, W4, b4, ybar, weight, seq_len, B, T, M, pred, dZ2, lddz,
                        (float*)workspace);
     MG_CHECK_LAUNCH("mg_f0_tail_rows_f32");
     mg_launch_slab_reduce((const float*)workspace, TF_SLAB, TF_SLAB, (int)blocks, grads_out, 0, st);

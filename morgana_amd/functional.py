@@ -586,18 +586,26 @@ class F0TailRowsF32Fn(torch.autograd.Function):
     ``losses.mse`` (morgana/losses.py:29-51) on per-phone rows, exact fp32, forward and backward in one launch (``mg_f0_tail_rows_f32``):
     the ``fp32`` / ``bf16x3`` modes' counterpart of the bf16 step's fused tail.  forward(ctx, z2 (R + extra, 128) pre-activations of
     the 128-wide layer, target (B, T, 1), seq_len, holder, w3, b3, w4, b4) -> (loss, prediction (B, T, 1): repeated for reporting, not
-    differentiable).  The backward hands out what the forward's launch computed."""
+    differentiable).  ``holder`` None: z2 holds the (B * T, 128) frame rows themselves (the reference's order of operations) and the
+    kernel takes the targets and the loss's own weights per frame.  The backward hands out what the forward's launch computed."""
 
     @staticmethod
     def forward(ctx, z2, target, seq_len, holder, w3, b3, w4, b4):
         target = ops._require(target, torch.float32, 'targets')
         b, t = target.shape[0], target.shape[1]
-        extra = z2.shape[0] - holder.source.shape[0] * holder.source.shape[1]
-        rows_mapped, ybar, weight, partials, n_src = _phone_stats(holder, target, seq_len, extra)
-        pred_rows, dz2, flat = ops.f0_tail_rows_f32(z2, w3, b3, w4, b4, ybar, weight)
         n_g = ops.F0_TAIL_F32_GRADS
-        loss = flat[n_g:n_g + 1]
-        pred = ops.expand_column(pred_rows, rows_mapped, loss_const=(partials, n_src, extra, loss)).view(b, t, 1)
+        if holder is None:
+            # rows = the B x T frames themselves (the reference's order of operations): targets and the masked MSE's own weights per row
+            sl = seq_len if (seq_len is None or seq_len.dtype == torch.int64) else seq_len.long()
+            pred_rows, dz2, flat = ops.f0_tail_rows_f32(z2, w3, b3, w4, b4, target.reshape(-1), None, seq_len=sl, frames=(b, t))
+            loss = flat[n_g:n_g + 1]
+            pred = pred_rows.view(b, t, 1)
+        else:
+            extra = z2.shape[0] - holder.source.shape[0] * holder.source.shape[1]
+            rows_mapped, ybar, weight, partials, n_src = _phone_stats(holder, target, seq_len, extra)
+            pred_rows, dz2, flat = ops.f0_tail_rows_f32(z2, w3, b3, w4, b4, ybar, weight)
+            loss = flat[n_g:n_g + 1]
+            pred = ops.expand_column(pred_rows, rows_mapped, loss_const=(partials, n_src, extra, loss)).view(b, t, 1)
         ctx.save_for_backward(dz2, flat)
         ctx.params = (w3, b3, w4, b4)
         ctx.mark_non_differentiable(pred)

@@ -1039,21 +1039,24 @@ def phone_front(dur, target, seq_len, t, extra, linear=None):
 F0_TAIL_F32_GRADS = 32 * 128 + 32 + 32 + 1          # dW3 | db3 | dW4 | db4, then the loss (and two unused floats)
 
 
-def f0_tail_rows_f32(z2, w3, b3, w4, b4, ybar, weight):
+def f0_tail_rows_f32(z2, w3, b3, w4, b4, ybar, weight, seq_len=None, frames=None):
     """The README tail 128 -> 32 -> 1 with the per-phone masked MSE, forward and backward, exact fp32, one launch (mg_f0_tail_rows_f32).
     z2 (rows, 128) f32 pre-activations of the 128-wide layer.  Returns (pred (rows,), dz2 (rows, 128), flat (4164,) = the tail's
-    parameter gradients in parameter order, the loss without its constant term at index F0_TAIL_F32_GRADS)."""
+    parameter gradients in parameter order, the loss without its constant term at index F0_TAIL_F32_GRADS).
+    ``weight`` None with ``frames`` = (B, T): the rows are the frames, ``ybar`` the targets, the weights the masked MSE's own (from seq_len)."""
     lib = _lib.load()
     z2 = _require(z2, torch.float32, 'pre-activations')
     m = z2.shape[0]
-    if z2.shape[1] != 128 or tuple(w3.shape) != (32, 128) or tuple(w4.shape) != (1, 32) or ybar.numel() != m or weight.numel() != m:
+    if (z2.shape[1] != 128 or tuple(w3.shape) != (32, 128) or tuple(w4.shape) != (1, 32) or ybar.numel() != m
+            or (weight.numel() != m if weight is not None else (frames is None or frames[0] * frames[1] != m))):
         raise ValueError('f0_tail_rows_f32: needs (rows, 128) pre-activations, a 128 -> 32 -> 1 tail and one statistics row per table row')
     pred = torch.empty((m,), dtype=torch.float32, device=z2.device)
     dz2 = torch.empty((m, 128), dtype=torch.float32, device=z2.device)
     flat = torch.empty((F0_TAIL_F32_GRADS + 3,), dtype=torch.float32, device=z2.device)
     ws = workspace(lib.mg_f0_tail_rows_f32_workspace_bytes(m), z2.device)
     _lib.check(lib.mg_f0_tail_rows_f32(_p(z2), z2.shape[1], _p(_require(w3, torch.float32, 'w3')), _p(b3), _p(_require(w4, torch.float32, 'w4')),
-                                       _p(b4), _p(ybar), _p(weight), m, _p(pred), _p(dz2), dz2.shape[1], _p(flat), _p(ws), ws.numel(), _stream()),
+                                       _p(b4), _p(ybar), _p(weight), _p(seq_len), frames[0] if frames else 0, frames[1] if frames else 0, m,
+                                       _p(pred), _p(dz2), dz2.shape[1], _p(flat), _p(ws), ws.numel(), _stream()),
                'mg_f0_tail_rows_f32')
     return pred, dz2, flat
 

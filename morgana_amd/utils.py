@@ -557,6 +557,10 @@ class SequentialWithRecurrent(nn.Sequential):
                 # Sigmoid -> Linear(128, 32) -> Sigmoid -> Linear(32, 1) + the masked MSE + their backward as ONE launch (mg_f0_tail_rows_f32)
                 z2, lin3, lin4 = tail
                 return F_hip.F0TailRowsF32Fn.apply(z2, targets, seq_len, input, lin3.weight, lin3.bias, lin4.weight, lin4.bias)
+            tail = self._frame_rate_f32_tail(input, targets, seq_len, precision)
+            if tail is not None:
+                z2, lin3, lin4 = tail                      # the same launch on the B * T frame rows (the reference's order of operations)
+                return F_hip.F0TailRowsF32Fn.apply(z2, targets, seq_len, None, lin3.weight, lin3.bias, lin4.weight, lin4.bias)
             table = self._phone_rate_table(input, targets, seq_len, precision)
             if table is not None:
                 # exact-fp32 modes, a stack of Linear / Sigmoid layers on repeated phone rows ending in ONE output column: the layers
@@ -607,6 +611,46 @@ class SequentialWithRecurrent(nn.Sequential):
         acts = tuple(act for _, act in run[:-3]) + (ops.ACT_NONE,)          # the 128-wide layer's sigmoid is taken by the tail kernel
         spec = (acts, precision, ops.PHONE_RATE_EXTRA)
         z2 = F_hip.LinearStackFn.apply(spec, input.source.reshape(-1, input.source.shape[-1]), None, *params)
+        return z2, lin3, lin4
+
+    def _readme_tail(self, targets, precision):
+        """(run, Linear(128, 32), Linear(32, 1)) when the whole container is Linear / Sigmoid layers ending in ``-> 128 -> Sigmoid -> 32 ->
+        Sigmoid -> 1`` without dropout, an exact-fp32 mode and (B, T, 1) targets; else None."""
+        modules = list(self._modules.values())
+        if (not F0_TAIL_F32 or not modules or type(modules[0]) is not nn.Linear or precision not in ('fp32', 'bf16x3')
+                or targets.ndim != 3 or targets.shape[2] != 1):
+            return None
+        end, run = self._linear_run(modules, 0)
+        if end != len(modules) or len(run) < 3 or any(run.drops):
+            return None
+        (lin2, act2), (lin3, act3), (lin4, act4) = run[-3], run[-2], run[-1]
+        if (act2 != ops.ACT_SIGMOID or act3 != ops.ACT_SIGMOID or act4 != ops.ACT_NONE or tuple(lin3.weight.shape) != (32, 128)
+                or tuple(lin4.weight.shape) != (1, 32) or lin3.bias is None or lin4.bias is None or lin2.weight.shape[0] != 128):
+            return None
+        return run, lin3, lin4
+
+    def _frame_rate_f32_tail(self, input, targets, seq_len, precision):
+        """As ``_phone_rate_f32_tail`` for inputs that stay at frame rate: (pre-activations of the 128-wide layer on the B * T frame
+        rows, Linear(128, 32), Linear(32, 1)), or None."""
+        found = self._readme_tail(targets, precision)
+        if found is None or tuple(targets.shape[:2]) != tuple(input.shape[:2]):
+            return None
+        run, lin3, lin4 = found
+        if isinstance(input, UpsampledSequence):
+            n_src = input.source.shape[0] * input.source.shape[1]
+            if seq_len is not None and ops.phone_rate_gru_ok(n_src, input.shape[0] * input.shape[1], 8, input.phone_rate):
+                return None                                # the phone-rate form takes it
+            x2d, rows = input.source.reshape(-1, input.source.shape[-1]), input.rows.reshape(-1)
+        elif torch.is_tensor(input) and input.ndim == 3:
+            x2d, rows = input.reshape(-1, input.shape[-1]), None
+        else:
+            return None
+        params = []
+        for lin, _ in run[:-2]:
+            params += [lin.weight, lin.bias]
+        acts = tuple(act for _, act in run[:-3]) + (ops.ACT_NONE,)
+        spec = (acts, precision, 0, rows is not None, None)
+        z2 = F_hip.LinearStackFn.apply(spec, x2d, rows, *params)
         return z2, lin3, lin4
 
     def _phone_rate_table(self, input, targets, seq_len, precision):

@@ -140,8 +140,8 @@ int main(void) {
       expect_code("calib_mfma(ok)", mg_calib_mfma_bf16(dh, df, 256, 100, &fl, NULL)); }
     expect_code("phone_concat_layer(C)", mg_phone_concat_layer_bf16(df, 512, di, 64000, df, 17, df, 609, 600, df, 512, MG_ACT_SIGMOID, dh, 512, 0, NULL));
     expect_code("phone_concat_layer(ok)", mg_phone_concat_layer_bf16(df, 512, di, 64000, df, 9, df, 609, 600, df, 512, MG_ACT_SIGMOID, dh, 512, 0, NULL));
-    expect_code("f0_tail_rows_f32(ldz)", mg_f0_tail_rows_f32(df, 130, df, df, df, df, df, df, 22528, df, df, 128, df, d, 1 << 24, NULL));
-    expect_code("f0_tail_rows_f32(ok)", mg_f0_tail_rows_f32(df, 128, df, df, df, df, df, df, 22528, df, df, 128, df, d, 1 << 24, NULL));
+    expect_code("f0_tail_rows_f32(ldz)", mg_f0_tail_rows_f32(df, 130, df, df, df, df, df, df, NULL, 0, 0, 22528, df, df, 128, df, d, 1 << 24, NULL));
+    expect_code("f0_tail_rows_f32(ok)", mg_f0_tail_rows_f32(df, 128, df, df, df, df, df, NULL, dl, 64, 352, 22528, df, df, 128, df, d, 1 << 24, NULL));
     expect_code("phone_mse_rows(ok)", mg_phone_mse_rows_f32(df, 1, df, df, 22528, df, df, NULL));
     expect_code("segment_sum_feat(small slabs)", mg_segment_sum_feat_bf16(dh, 512, di, 64000, di, di, 5000, 1024, 512, dh, 512, df, 9, d, 16, NULL));
     expect_code("feat_wgrad_reduce(ok)", mg_feat_wgrad_reduce(d, 9, 512, 512, df, 609, 600, 1, NULL));

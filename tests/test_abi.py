@@ -84,8 +84,9 @@ def test_new_entry_points_validate_their_arguments_without_a_gpu():
     assert lib.mg_segment_sum_feat_bf16(16, 512, 16, 64, 16, 16, 8, 4, 512, 16, 512, 16, 9, 16, 1024, None) == -1 and 'slabs too small' in _lib.last_error()
     assert lib.mg_segment_sum_feat_workspace_bytes(9, 512) % (9 * 512 * 4) == 0
     assert lib.mg_feat_wgrad_reduce(16, 9, 512, 512, 16, 608, 600, 0, None) == -1
-    assert lib.mg_f0_tail_rows_f32(16, 130, 16, 16, 16, 16, 16, 16, 64, 16, 16, 128, 16, 16, 1 << 20, None) == -1 and 'ldz=130' in _lib.last_error()
-    assert lib.mg_f0_tail_rows_f32(16, 128, 16, 16, 16, 16, 16, 16, 64, 16, 16, 128, 16, 16, 64, None) == -3     # MG_EWORKSPACE
+    assert lib.mg_f0_tail_rows_f32(16, 130, 16, 16, 16, 16, 16, 16, None, 0, 0, 64, 16, 16, 128, 16, 16, 1 << 20, None) == -1 and 'ldz=130' in _lib.last_error()
+    assert lib.mg_f0_tail_rows_f32(16, 128, 16, 16, 16, 16, 16, 16, None, 0, 0, 64, 16, 16, 128, 16, 16, 64, None) == -3     # MG_EWORKSPACE
+    assert lib.mg_f0_tail_rows_f32(16, 128, 16, 16, 16, 16, 16, None, None, 3, 20, 64, 16, 16, 128, 16, 16, 1 << 20, None) == -1 and "B x T frames" in _lib.last_error()
     assert lib.mg_f0_tail_rows_f32_workspace_bytes(22528) == 256 * 4164 * 4
     assert lib.mg_phone_mse_rows_f32(16, 0, 16, 16, 8, 16, 16, None) == -1
     assert lib.mg_phone_concat_layer_bf16(16, 96, 16, 8, 16, 9, 16, 609, 600, None, 100, 1, 32, 128, 0, None) == -1 and 'ldp=96' in _lib.last_error()
