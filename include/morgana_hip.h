@@ -465,7 +465,7 @@ typedef struct {
     const float* sig; /* optional (not transposed): fp32 [rows, cols] (ldsig) sigmoid outputs s - the split is taken of src * s * (1 - s):
                        * the sigmoid gradient of autograd (README.rst:65-73's nn.Sigmoid) fused into the split of the gradient */
     int ldsig;
-    float* colsum;    /* optional (orders 2-4): f32 [colsum_blocks, ldp] - workgroup b's partial column sums of the (sigmoid-gradient-fused)
+    float* colsum;    /* optional (not transposed): f32 [colsum_blocks, ldp] - workgroup b's partial column sums of the (sigmoid-gradient-fused)
                        * source values over its share of the rows; summed in slab order they are the bias gradient of the layer, exact */
     int colsum_blocks;
 } mg_split3_desc;

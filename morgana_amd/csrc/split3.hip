@@ -17,7 +17,10 @@
 // a three-plane row would hand them its neighbours as padding).  `order` 3 / 4: THREE row-stacked planes [hi ; hi ; lo] / [hi ; lo ; hi] -
 // the three products as ONE weight-gradient launch over a three times longer row axis, [hi ; hi ; lo]^T [hi ; lo ; hi]; the bias
 // gradient (the column sums of the UNSPLIT fp32 values, exact) then comes out of the split pass itself: `colsum` slabs, one per
-// workgroup, summed by the library's ordered slab reduce.
+// workgroup, summed by the library's ordered slab reduce.  The same one-launch weight gradient needs NO row-stacked planes at all:
+// a three-plane buffer [rows, 3 ldp] read as [3 rows, ldp] IS a row-interleaved stack, so the gradient split [hi | lo | hi] (order 1,
+// the layout its dgrad takes against W^T in order 0) against the forward's own activation split [hi | hi | lo] (order 0) pairs
+// (hi, hi), (lo, hi), (hi, lo) - the three products - and the backward splits only the gradient, once (functional.LinearStackFn).
 #include "common.h"
 
 #define MG_SPLIT3_MAX_ 16
@@ -73,7 +76,10 @@ __global__ __launch_bounds__(256) void split3_kernel(Split3Batch batch) {
         const int64_t per = (d.rows + d.colsum_blocks - 1) / d.colsum_blocks, r_lo = (int64_t)blockIdx.x * per,
                       r_hi = r_lo + per < d.rows ? r_lo + per : d.rows;
         const bool vec = (d.lds & 3) == 0 && ((size_t)d.src & 15) == 0;
-        const size_t plane = (size_t)(d.plane_rows > 0 ? d.plane_rows : d.rows) * d.ldp;
+        // row-stacked planes (orders 2-4) lie plane_rows x ldp apart, the planes of a three-plane row (orders 0 / 1) ldp apart
+        const bool stacked = d.order >= 2;
+        const size_t plane = stacked ? (size_t)(d.plane_rows > 0 ? d.plane_rows : d.rows) * d.ldp : (size_t)d.ldp;
+        const size_t row_stride = stacked ? (size_t)d.ldp : 3 * (size_t)d.ldp;
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
@@ -87,10 +93,14 @@ __global__ __launch_bounds__(256) void split3_kernel(Split3Batch batch) {
                 acc[e] += x[e];
             }
             const su32x4 ph = pack(hi), pl = pack(lo);
-            uint16_t* dst = d.dst + (size_t)r * d.ldp + c0;
+            uint16_t* dst = d.dst + (size_t)r * row_stride + c0;
             *reinterpret_cast<su32x4*>(dst) = ph;
-            *reinterpret_cast<su32x4*>(dst + plane) = second ? pl : ph;
-            *reinterpret_cast<su32x4*>(dst + 2 * plane) = second ? ph : pl;
+            if (d.order == 2) {
+                *reinterpret_cast<su32x4*>(dst + plane) = pl;
+            } else {
+                *reinterpret_cast<su32x4*>(dst + plane) = second ? pl : ph;
+                *reinterpret_cast<su32x4*>(dst + 2 * plane) = second ? ph : pl;
+            }
         }
         __shared__ float sums[256 * 8];
 #pragma unroll
@@ -182,8 +192,8 @@ int mg_split3_bf16(const mg_split3_desc* descs, int count, void* stream) {
         MG_CHECK_ARG(d.order == 0 || d.order == 1 || (d.order >= 2 && d.order <= 4 && !d.transpose),
                      "mg_split3_bf16: descriptor %d: order %d is none of 0 (hi|hi|lo), 1 (hi|lo|hi), 2 (separate planes hi ; lo), 3 (hi ; hi ; lo), 4 (hi ; lo ; hi) (2-4 not transposed)", i, d.order);
         MG_CHECK_ARG(d.plane_rows == 0 || (d.order >= 2 && d.plane_rows >= d.rows), "mg_split3_bf16: descriptor %d: plane_rows %lld goes with order 2 and must cover the %lld rows", i, (long long)d.plane_rows, (long long)d.rows);
-        MG_CHECK_ARG(!d.colsum || (d.order >= 2 && d.colsum_blocks >= 1 && d.colsum_blocks <= 4096 && d.ldp <= 2048 && 256 % (d.ldp / 8) == 0),
-                     "mg_split3_bf16: descriptor %d: column sums go with the row-stacked orders, 1..4096 blocks and plane widths of 8, 16, ... 2048 columns that divide 2048 (ldp %d)", i, d.ldp);
+        MG_CHECK_ARG(!d.colsum || (!d.transpose && d.colsum_blocks >= 1 && d.colsum_blocks <= 4096 && d.ldp <= 2048 && 256 % (d.ldp / 8) == 0),
+                     "mg_split3_bf16: descriptor %d: column sums go with the plain layouts, 1..4096 blocks and plane widths of 8, 16, ... 2048 columns that divide 2048 (ldp %d)", i, d.ldp);
         MG_CHECK_ARG(d.ldp % 8 == 0 && ((size_t)d.dst & 15) == 0, "mg_split3_bf16: descriptor %d: ldp %d must be a multiple of 8 and dst 16-byte aligned", i, d.ldp);
         if (d.transpose)
             MG_CHECK_ARG(d.ldp >= d.rows && d.rows < 2147483647LL, "mg_split3_bf16: descriptor %d: transposed planes of %d columns cannot hold %lld rows", i, d.ldp, (long long)d.rows);

@@ -313,10 +313,12 @@ class LinearStackFn(torch.autograd.Function):
                 x2d, extra = torch.cat((x2d, x2d.new_zeros((extra, x2d.shape[1])))), 0
             a, r = x2d, rows
             w3s = ops.x3_weight_operands([w for w, s in zip(weights, split) if s])[0]
+            kept = [None] * n_layers              # the activation splits: the backward's weight gradients multiply with them again
             for i in range(n_layers):
                 if split[i]:
                     # the zero rows behind a phone table (what padding frames gather) are rows of the split operand, never of an fp32 copy
                     a3 = ops.split3([(a, 0, False, extra if i == 0 else 0)])[0]
+                    kept[i] = a3
                     a = ops.linear_fwd_x3(a3, r, m, w3s.pop(0), biases[i], weights[i].shape[0], acts[i])
                 else:
                     a = ops.linear_fwd_f32(a, r, m, ops._require(weights[i], torch.float32, 'weight'), biases[i], acts[i])
@@ -328,6 +330,7 @@ class LinearStackFn(torch.autograd.Function):
             ctx.save_for_backward(x2d, rows_k, rows if gathered_grad else None, *weights, *hidden)
             ctx.param_refs = (list(weights), list(biases))
             ctx.x3_extra = extra
+            ctx.x3_kept = kept
         else:
             if gathered_grad:
                 if pre_cast:
@@ -426,21 +429,23 @@ class LinearStackFn(torch.autograd.Function):
                         grad_x = ops.linear_dgrad_f32(g, weights[0], None)
                     continue
                 need_g3 = i > 0 or need_x
-                if r is None and ops.split3_colsum_ok(n):
-                    # no row map: the three products of the weight gradient as ONE launch over row-stacked planes, [hi ; hi ; lo]^T
-                    # [hi ; lo ; hi]; the bias gradient = the column sums of the fp32 gradient, taken by the split pass itself
-                    parts = ops.split3([(g, 3, False, 0, sig, True), (a_in, 4, False, ctx.x3_extra if i == 0 else 0)] +
-                                       ([(g, 0, False, 0, sig)] if need_g3 else []))
+                kept = ctx.x3_kept[i]
+                if r is None and kept is not None and ops.split3_colsum_ok(n):
+                    # no row map: the gradient is split ONCE, [hi | lo | hi] - the layout its dgrad takes against W^T [hi | hi | lo] - and
+                    # the weight gradient is one launch of that buffer against the FORWARD's split of the layer's input, both read as
+                    # row-interleaved (3 m, ldp) stacks (ops.linear_wgrad_x3_rows); the bias gradient = the exact column sums of the
+                    # fp32 gradient, taken by the split pass.  (Was: gradient and input split again into row-stacked planes.)
+                    g1, colsum = ops.split3([(g, 1, False, 0, sig, True)])[0]
                     sig = None
-                    (g3s, colsum), a3s, g3 = parts[0], parts[1], (parts[2] if need_g3 else None)
+                    g3 = g1
                     if direct:
-                        ops.linear_wgrad_x3_stacked(g3s, colsum, a3s, n, k, out_w=w_params[i].grad, out_b=b_params[i].grad, accumulate=True)
+                        ops.linear_wgrad_x3_rows(g1, colsum, kept, n, k, out_w=w_params[i].grad, out_b=b_params[i].grad, accumulate=True)
                     else:
-                        dw, db = ops.linear_wgrad_x3_stacked(g3s, colsum if ctx.has_bias[i] else None, a3s, n, k)
+                        dw, db = ops.linear_wgrad_x3_rows(g1, colsum if ctx.has_bias[i] else None, kept, n, k)
                         grads[2 * i], grads[2 * i + 1] = dw, db
                 else:
                     parts = ops.split3([(g, 2, False, 0, sig), (a_in, 2, False, ctx.x3_extra if i == 0 else 0)] +
-                                       ([(g, 0, False, 0, sig)] if need_g3 else []))
+                                       ([(g, 1, False, 0, sig)] if need_g3 else []))
                     sig = None
                     g2, a2, g3 = parts[0], parts[1], (parts[2] if need_g3 else None)
                     if direct:

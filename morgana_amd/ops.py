@@ -745,7 +745,7 @@ def split3(jobs):
     [hi | hi | lo] (activation side), 1 = [hi | lo | hi] (weight side), 2 = two separate planes, 3 / 4 = three row-stacked planes
     [hi ; hi ; lo] / [hi ; lo ; hi]; one batched launch per MG_SPLIT3_MAX jobs.  Returns one bf16 tensor per job: (rows, 3 ldp) -
     (cols, 3 ldp) with ``transpose`` - or (2 or 3, rows, ldp) for orders 2-4, where ldp = pad_ld(columns of a plane).  A job with a
-    sixth element True (orders 2-4) returns (planes, slabs): the per-workgroup column sums of the split values (``colsum_reduce``)."""
+    sixth element True (plain layouts) returns (planes, slabs): the per-workgroup column sums of the split values (``slab_reduce``)."""
     lib = _lib.load()
     outs = []
     for i in range(0, len(jobs), _lib.SPLIT3_MAX):
@@ -774,8 +774,8 @@ def split3(jobs):
             descs[j].plane_rows = rows + extra if stacked else 0
             descs[j].sig, descs[j].ldsig = (sig.data_ptr(), sig.stride(0)) if sig is not None else (None, 0)
             if want_colsum:
-                if not stacked or 256 % (ldp // 8) != 0:
-                    raise ValueError('split3: column sums go with the row-stacked orders and plane widths that divide 2048')
+                if transpose or 256 % (ldp // 8) != 0:
+                    raise ValueError('split3: column sums go with the plain layouts and plane widths that divide 2048')
                 slabs = torch.empty((SPLIT3_COLSUM_BLOCKS, ldp), dtype=torch.float32, device=x.device)
                 descs[j].colsum, descs[j].colsum_blocks = slabs.data_ptr(), SPLIT3_COLSUM_BLOCKS
                 outs.append((out, slabs))
@@ -789,7 +789,7 @@ def split3(jobs):
 
 def x3_weight_operands(weights, want_t=()):
     """Weight-side operands of 'bf16x3' for a run of fp32 weight matrices [N, K]: ([N, 3 pad_ld(K)] splits in order 1, and for the
-    indices in ``want_t`` the order-1 splits of W^T [K, 3 pad_ld(N)] (the dgrad operand), None elsewhere).  Cached on the parameter
+    indices in ``want_t`` the order-0 splits of W^T [K, 3 pad_ld(N)] (the dgrad operand, against gradients in order 1), None elsewhere).  Cached on the parameter
     under the same version stamps as the bf16 operand copies (param_shadows); every stale one is re-split by ONE batched launch."""
     jobs, slots = [], []
     # inside a stream capture a split that is current NOW says nothing about the replays: every step of a captured graph re-splits
@@ -804,7 +804,7 @@ def x3_weight_operands(weights, want_t=()):
             jobs.append((_require(w, torch.float32, 'weight'), 1, False))
             slots.append((st, 'plain'))
         if i in want_t and st['t'] is None:
-            jobs.append((_require(w, torch.float32, 'weight'), 1, True))
+            jobs.append((_require(w, torch.float32, 'weight'), 0, True))          # W^T [hi | hi | lo]: against gradients split [hi | lo | hi]
             slots.append((st, 't'))
     for (st, key), out in zip(slots, split3(jobs)):
         st[key] = out
@@ -821,11 +821,33 @@ def linear_fwd_x3(a3, rows, m, w3, bias, n, act):
 
 
 def linear_dgrad_x3(g3, m, wt3, k):
-    """fp32 (m, k) = dY W from split operands: g3 (m, 3 ldp(n)) order 0, wt3 = split of W^T (k, 3 ldp(n)) order 1."""
+    """fp32 (m, k) = dY W from split operands: g3 (m, 3 ldp(n)) order 1 [hi | lo | hi], wt3 = split of W^T (k, 3 ldp(n)) order 0."""
     if g3.shape[1] != wt3.shape[1]:
         raise ValueError('linear_dgrad_x3: operand planes differ (%d vs %d columns)' % (g3.shape[1], wt3.shape[1]))
     dx = linear_dgrad_bf16(g3, m, g3.shape[1], wt3, k, None, out_f32=True)
     return dx if dx.shape[1] == k else dx[:, :k].contiguous()
+
+
+def linear_wgrad_x3_rows(g1, colsum, a0, n, k, out_w=None, out_b=None, accumulate=False):
+    """dW (n, k), db (n,) as ONE launch from the three-plane buffers the other products of the layer use anyway: g1 (m, 3 ldp(n)) = the
+    gradient split [hi | lo | hi] (order 1), a0 (m, 3 ldp(k)) = the forward's activation split [hi | hi | lo] (order 0).  Read as
+    (3 m, ldp) matrices they are row-interleaved stacks pairing (hi, hi), (lo, hi), (hi, lo): the three products of the weight
+    gradient in one contraction over 3 m rows.  db = the ordered sum of ``colsum`` (split3's column sums of the fp32 gradient)."""
+    lib = _lib.load()
+    if g1.dim() != 2 or a0.dim() != 2 or g1.shape[0] != a0.shape[0] or g1.shape[1] % 3 or a0.shape[1] % 3:
+        raise ValueError('linear_wgrad_x3_rows: operands must be three-plane buffers of equal row count')
+    m3, ldn, ldk = 3 * g1.shape[0], g1.shape[1] // 3, a0.shape[1] // 3
+    if out_w is None:
+        both = torch.empty((n * k + n,), dtype=torch.float32, device=g1.device)
+        dw, db = both[:n * k].view(n, k), (both[n * k:] if colsum is not None else None)
+    else:
+        dw, db = out_w, (out_b if colsum is not None else None)
+    ws = workspace(lib.mg_linear_wgrad_workspace_bytes(m3, n, k), g1.device)
+    _lib.check(lib.mg_linear_wgrad_bf16(_p(g1), ldn, _p(a0), ldk, None, m3, n, k, _p(dw), None, int(bool(accumulate)), _p(ws), ws.numel(),
+                                        _stream()), 'mg_linear_wgrad_bf16')
+    if db is not None:
+        slab_reduce(colsum, colsum.shape[0], colsum.shape[1], n, db, accumulate=accumulate)
+    return dw, db
 
 
 def linear_wgrad_x3_stacked(g3, colsum, a3, n, k, out_w=None, out_b=None, accumulate=False):

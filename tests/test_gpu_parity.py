@@ -1015,6 +1015,11 @@ def test_split3_planes(rows, cols, lds_extra):
         want_sum = x.double().sum(0)
         got_sum = ops.slab_reduce(slabs, slabs.shape[0], slabs.shape[1], cols, torch.empty(cols, device=DEV)).double()
         assert float((got_sum - want_sum).abs().max() / x.abs().double().sum(0).max()) < 1e-6
+        # the same sums from the three-plane layouts (what the backward of 'bf16x3' takes: the gradient split once, [hi | lo | hi])
+        g1, slabs1 = ops.split3([(x, 1, False, 0, None, True)])[0]
+        assert torch.equal(g1, w3)
+        got1 = ops.slab_reduce(slabs1, slabs1.shape[0], slabs1.shape[1], cols, torch.empty(cols, device=DEV)).double()
+        assert float((got1 - want_sum).abs().max() / x.abs().double().sum(0).max()) < 1e-6
     else:
         with pytest.raises(ValueError):
             ops.split3([(x, 3, False, 0, None, True)])
