@@ -9,6 +9,8 @@
                  counters), Linear-512 / sigmoid / 8 x LSTM-512 / Linear-256 / sigmoid / Linear-199, four output streams.
 ``SequentialWithRecurrent`` returns ``(output, hiddens)`` (utils.py:418), so all of them unpack it.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -147,6 +149,18 @@ class Stream(object):
         return 'normalised_%s_deltas' % self.name if self.is_delta else self.name
 
 
+# The delta streams' MLPG launches on streams of their own (StreamModel._with_trajectories); 0 = one after the other on the current stream
+TRAJECTORY_STREAMS = os.environ.get('MORGANA_TRAJECTORY_STREAMS', '1') != '0'
+_traj_streams = {}
+
+
+def _trajectory_streams(device, n):
+    pool = _traj_streams.setdefault(device.index, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device))
+    return pool[:n]
+
+
 class StreamModel(BaseSPSS):
     """``layers`` (a ``SequentialWithRecurrent`` whose last Linear is as wide as the streams together) + a stream table ->
     ``predict`` / ``loss`` / ``forward`` as the shipped models define them: input = upsampled labels concatenated with the frame
@@ -208,8 +222,24 @@ class StreamModel(BaseSPSS):
 
     def _with_trajectories(self, outputs, n_frames):
         if self._generating():
-            for st in self.streams:
-                if st.is_delta:
+            delta = [st for st in self.streams if st.is_delta]
+            first = outputs[delta[0].output_key] if delta else None
+            if len(delta) > 1 and TRAJECTORY_STREAMS and torch.is_tensor(first) and first.is_cuda:
+                # The streams' trajectories are independent, and each MLPG launch is ONE dependent chain per (utterance, dimension) over
+                # the frame axis on a few waves (lf0: 64 systems = one wave; mcep: 3,840): launched one after the other their chain
+                # latencies add (the shipped acoustic model: 0.15 + 0.35 + 0.15 ms per step), side by side on streams of their own
+                # they overlap.  Fork behind the current stream, join before anything reads a trajectory.
+                main = torch.cuda.current_stream(first.device)
+                pool = _trajectory_streams(first.device, len(delta))
+                for st, side in zip(delta, pool):
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        outputs[st.name] = self._trajectory(st.name, outputs[st.output_key], n_frames)
+                for st, side in zip(delta, pool):
+                    main.wait_stream(side)
+                    outputs[st.name].record_stream(main)
+            else:
+                for st in delta:
                     outputs[st.name] = self._trajectory(st.name, outputs[st.output_key], n_frames)
         return outputs
 

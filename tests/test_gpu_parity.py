@@ -1940,6 +1940,14 @@ def test_lstm_acoustic_model_generation_and_metrics(fused_loss):
         np.testing.assert_allclose(results[metric_name], ref_cpu.metric_result(kind, 2 * s, 2 * c), rtol=1e-4, err_msg=metric_name)
     s, c = ref_cpu.metric_sums('mean', (feats_np['vuv'] == vuv).astype(np.float32), seq_len=seq)
     np.testing.assert_allclose(results['VUV_accuracy'], ref_cpu.metric_result('mean', s, c), rtol=1e-6)
+    # the three streams' MLPG launches run side by side on streams of their own (models.TRAJECTORY_STREAMS): the same bits as one after the other
+    models.TRAJECTORY_STREAMS = False
+    try:
+        _, out_serial = model(feats)
+    finally:
+        models.TRAJECTORY_STREAMS = True
+    for name in kinds:
+        assert torch.equal(out_serial[name], out[name]), name
     # generation off: the training outputs only, no metric touched
     quiet = models.LSTMAcousticModel(num_layers=2, precision='fp32', generate=False).to(DEV)
     synthetic.acoustic_normalisers(quiet, device=DEV)
