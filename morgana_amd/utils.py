@@ -591,19 +591,13 @@ class SequentialWithRecurrent(nn.Sequential):
         """(pre-activations of the 128-wide layer on the phone rows (B * P + extra, 128), Linear(128, 32), Linear(32, 1)) when the whole
         container is Linear / Sigmoid layers ending in ``-> 128 -> Sigmoid -> 32 -> Sigmoid -> 1`` on an ``UpsampledSequence`` at
         phone rate, exact-fp32 modes, (B, T, 1) targets; else None."""
-        modules = list(self._modules.values())
-        if (not F0_TAIL_F32 or not isinstance(input, UpsampledSequence) or seq_len is None or not modules or type(modules[0]) is not nn.Linear
-                or precision not in ('fp32', 'bf16x3') or targets.ndim != 3 or targets.shape[2] != 1
+        found = self._readme_tail(targets, precision)
+        if (found is None or not isinstance(input, UpsampledSequence) or seq_len is None
                 or tuple(targets.shape[:2]) != tuple(input.shape[:2])):
             return None
-        end, run = self._linear_run(modules, 0)
+        run, lin3, lin4 = found
         n_src = input.source.shape[0] * input.source.shape[1]
-        if (end != len(modules) or len(run) < 3 or any(run.drops)
-                or not ops.phone_rate_gru_ok(n_src, input.shape[0] * input.shape[1], 8, input.phone_rate)):
-            return None
-        (lin2, act2), (lin3, act3), (lin4, act4) = run[-3], run[-2], run[-1]
-        if (act2 != ops.ACT_SIGMOID or act3 != ops.ACT_SIGMOID or act4 != ops.ACT_NONE or tuple(lin3.weight.shape) != (32, 128)
-                or tuple(lin4.weight.shape) != (1, 32) or lin3.bias is None or lin4.bias is None or lin2.weight.shape[0] != 128):
+        if not ops.phone_rate_gru_ok(n_src, input.shape[0] * input.shape[1], 8, input.phone_rate):
             return None
         params = []
         for lin, _ in run[:-2]:
