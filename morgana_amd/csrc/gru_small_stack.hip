@@ -72,13 +72,18 @@ __device__ __forceinline__ gss_bf8 gss_cvt8(const float* p) {
     return gss_as_bf8(u);
 }
 template <bool FAST>
-__global__ __launch_bounds__(256) void gru_stack_fwd_small64_kernel(GssLayers a, const int64_t* __restrict__ seq_len, int B, int T, int L,
+__global__ __launch_bounds__(512) void gru_stack_fwd_small64_kernel(GssLayers a, const int64_t* __restrict__ seq_len, int B, int T, int L,
                                                                     int nblk, unsigned* sync) {
     constexpr int H = 64, G = 192, R = 4, LDH = H + 4, LDG = G + 4;
     __shared__ __attribute__((aligned(16))) float hs[R][LDH];       // h_{t-1}; rows of missing items stay zero
     __shared__ __attribute__((aligned(16))) float xs[2][R][LDH];    // upper layers: the lower layer's output of step t (parity t & 1)
     __shared__ __attribute__((aligned(16))) float gl[R][LDG];       // recurrent pre-activations of the three gates
     __shared__ __attribute__((aligned(16))) float gx[R][LDG];       // upper layers: input pre-activations
+    // Waves 4 .. 7 only STORE: a step leaves seven values per element for after the launch (state, output, the saved gates) on lines
+    // nobody has touched - their acknowledgements take about a step - and a wave's loads and stores complete in order (one vmcnt): in
+    // the waves that also load (the next step's input rows, the lower layer's outputs) every such wait was a wait for old stores too
+    // (probe: 0.17 ms of the launch's 1.25).  The computing waves 0 .. 3 leave the values in `stg`; wave 4 + i stores item i's.
+    __shared__ float stg[7][R][H];
     constexpr int LDB = H + 8;                                       // FAST: bf16 copies of hs / xs, the MFMA A operands
     __shared__ __attribute__((aligned(16))) uint16_t hb[R][LDB];
     __shared__ __attribute__((aligned(16))) uint16_t xsb[2][R][LDB];
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(256) void gru_stack_fwd_small64_kernel(GssLayers a,
     // FAST: the 192 gate columns are 12 tiles of 16, three per wave (all four waves); tile nt of this wave, k-step ks: row
     // 16 (3 wave + nt) + li of W, columns 32 ks + 8 q .. + 7
     gss_bf8 fwb[3][2], fwib[3][2];
-    if (FAST) {
+    if (FAST && wave < 4) {
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt)
 #pragma unroll
@@ -117,12 +122,12 @@ __global__ __launch_bounds__(256) void gru_stack_fwd_small64_kernel(GssLayers a,
             for (int k4 = 0; k4 < H / 4; ++k4) fwi[k4] = *reinterpret_cast<const f32x4*>(wi + 4 * k4);
         }
     }
-    for (int e = tid; e < R * LDH; e += 256) {
+    for (int e = tid; e < R * LDH; e += 512) {
         (&hs[0][0])[e] = 0.f;
         (&xs[0][0][0])[e] = 0.f;
         (&xs[1][0][0])[e] = 0.f;
     }
-    for (int e = tid; e < R * LDB; e += 256) {
+    for (int e = tid; e < R * LDB; e += 512) {
         (&hb[0][0])[e] = 0;
         (&xsb[0][0][0])[e] = 0;
         (&xsb[1][0][0])[e] = 0;
@@ -157,6 +162,31 @@ __global__ __launch_bounds__(256) void gru_stack_fwd_small64_kernel(GssLayers a,
     }
     __syncthreads();
 
+    if (wave >= 4) {
+        // the storing waves' whole launch: the two barriers of every step, then item wave - 4's values of the step out of `stg` (read
+        // before the next barrier: the cell phase behind it overwrites them).  They never wait for memory.
+        const int si = wave - 4, sb = row0 + (si < nrows ? si : 0);
+        for (int t = 0; t < T; ++t) {
+            gp_lds_barrier();
+            gp_lds_barrier();
+            if (si < nrows) {
+                const float v_h = stg[0][si][lane], v_o = stg[1][si][lane], v_r = stg[2][si][lane], v_z = stg[3][si][lane],
+                            v_n = stg[4][si][lane], v_hn = stg[5][si][lane];
+                const size_t row = (size_t)sb * T + t;
+                P.hstate[((size_t)sb * (T + 1) + t + 1) * H + lane] = v_h;
+                if (hands_up)
+                    gss_store(P.out + row * H + lane, v_o);
+                else
+                    P.out[row * H + lane] = v_o;
+                float* sv = P.saved + row * 4 * H;
+                sv[lane] = v_r;
+                sv[H + lane] = v_z;
+                sv[2 * H + lane] = v_n;
+                sv[3 * H + lane] = v_hn;
+            }
+        }
+        return;
+    }
     // one step; x_use holds x_{t+1} (consumed at the end of the step, then reloaded with x_{t+3})
 #ifdef MG_STAMPS
     unsigned long long ta = 0, tb = 0, ts0 = 0, ts1 = 0, tr0 = 0, tr1 = 0, sum_mm = 0, sum_b1 = 0, sum_cell = 0, sum_take = 0, sum_b2 = 0;
@@ -168,7 +198,7 @@ __global__ __launch_bounds__(256) void gru_stack_fwd_small64_kernel(GssLayers a,
         float xr1 = 0.f, xz1 = 0.f, xn1 = 0.f;
         MG_STAMP(ta);
         if (!upper) xr1 = xp[(size_t)t1 * G], xz1 = xp[(size_t)t1 * G + H], xn1 = xp[(size_t)t1 * G + 2 * H];
-        if (FAST) {
+        if (FAST && wave < 4) {
             // rows = the 4 items (A rows 4 .. 15 zero), 16 columns of the wave's gate per tile, K = 64 in two MFMAs
             const gss_u32x4 zero = {0u, 0u, 0u, 0u};
             gss_bf8 ah[2], ax[2];
@@ -239,17 +269,12 @@ __global__ __launch_bounds__(256) void gru_stack_fwd_small64_kernel(GssLayers a,
             hprev = active ? hnew : hprev;
             hs[er][ej] = hprev;
             if (FAST) hb[er][ej] = mg_f2bf(hprev);
-            const size_t row = (size_t)b * T + t;
-            P.hstate[((size_t)b * (T + 1) + t + 1) * H + ej] = hprev;
-            if (hands_up)
-                gss_store(P.out + row * H + ej, active ? hnew : 0.f);
-            else
-                P.out[row * H + ej] = active ? hnew : 0.f;
-            float* sv = P.saved + row * 4 * H;
-            sv[ej] = r;
-            sv[H + ej] = z;
-            sv[2 * H + ej] = n;
-            sv[3 * H + ej] = hn;
+            stg[0][er][ej] = hprev;
+            stg[1][er][ej] = active ? hnew : 0.f;
+            stg[2][er][ej] = r;
+            stg[3][er][ej] = z;
+            stg[4][er][ej] = n;
+            stg[5][er][ej] = hn;
             MG_STAMP(tb);
             MG_STAMP_ADD(sum_cell, tb, ta);
             if (upper && t + 1 < T) {
@@ -298,7 +323,7 @@ __global__ __launch_bounds__(256) void gru_stack_fwd_small64_kernel(GssLayers a,
 // contraction (6 MFMAs per product instead of 48 v_mfma_f32_4x4x1 and a four-way partial sum) - W^T as the A operand, the items as
 // columns, so a lane writes its item's four consecutive columns as one 16-byte LDS store (see the forward kernel).
 template <bool FAST>
-__global__ __launch_bounds__(256) void gru_stack_bwd_small64_kernel(GssLayers a, const int64_t* __restrict__ seq_len, int B, int T, int L,
+__global__ __launch_bounds__(512) void gru_stack_bwd_small64_kernel(GssLayers a, const int64_t* __restrict__ seq_len, int B, int T, int L,
                                                                     int nblk, unsigned* sync) {
     constexpr int H = 64, G = 192, R = 4, LDG = G + 4, KW = G / 4;  // KW = 48 gate rows per wave
     __shared__ __attribute__((aligned(16))) float dl[R][LDG];
@@ -308,6 +333,7 @@ __global__ __launch_bounds__(256) void gru_stack_bwd_small64_kernel(GssLayers a,
     constexpr int LDGB = G + 8;
     __shared__ __attribute__((aligned(16))) uint16_t dlb[R][LDGB];      // FAST: bf16 copies of dl / dlx, the MFMA B operands
     __shared__ __attribute__((aligned(16))) uint16_t dlxb[R][LDGB];
+    __shared__ float stg[5][R][H];                   // dr, dz, dn, dn r, d x_{t+1}: what waves 4 .. 7 store (see the forward kernel)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
     const int layer = blockIdx.x / nblk, blk = blockIdx.x - layer * nblk;
@@ -319,7 +345,7 @@ __global__ __launch_bounds__(256) void gru_stack_bwd_small64_kernel(GssLayers a,
     float fw[FAST ? 1 : KW], fwi[FAST ? 1 : KW];
     // FAST: A operand = W^T: row = output column 16 wave + li, k-step ks: gate rows 32 ks + 8 q .. + 7 (a strided gather, once)
     gss_bf8 fwb[6], fwib[6];
-    if (FAST) {
+    if (FAST && wave < 4) {
 #pragma unroll
         for (int ks = 0; ks < 6; ++ks) {
             gss_u32x4 u, ui;
@@ -332,22 +358,22 @@ __global__ __launch_bounds__(256) void gru_stack_bwd_small64_kernel(GssLayers a,
             fwb[ks] = gss_as_bf8(u);
             fwib[ks] = gss_as_bf8(ui);
         }
-    } else {
+    } else if (wave < 4) {
 #pragma unroll
         for (int k = 0; k < (FAST ? 1 : KW); ++k) {
             fw[k] = P.w_hh[(size_t)(wave * KW + k) * H + lane];
             fwi[k] = upper ? P.w_ih[(size_t)(wave * KW + k) * H + lane] : 0.f;
         }
     }
-    for (int e = tid; e < R * LDG; e += 256) {
+    for (int e = tid; e < R * LDG; e += 512) {
         (&dl[0][0])[e] = 0.f;
         (&dlx[0][0])[e] = 0.f;
     }
-    for (int e = tid; e < R * LDGB; e += 256) {
+    for (int e = tid; e < R * LDGB; e += 512) {
         (&dlb[0][0])[e] = 0;
         (&dlxb[0][0])[e] = 0;
     }
-    for (int e = tid; e < 4 * R * H; e += 256) {          // FAST writes part[0] / partx[0] only: the other three stay zero
+    for (int e = tid; e < 4 * R * H; e += 512) {          // FAST writes part[0] / partx[0] only: the other three stay zero
         (&part[0][0][0])[e] = 0.f;
         (&partx[0][0][0])[e] = 0.f;
     }
@@ -375,6 +401,27 @@ __global__ __launch_bounds__(256) void gru_stack_bwd_small64_kernel(GssLayers a,
     }
     __syncthreads();
 
+    if (wave >= 4) {
+        // the storing waves' whole launch (see the forward kernel): steps T - 1 .. -1, two barriers each, then item wave - 4's values
+        const int si = wave - 4, sb = row0 + (si < nrows ? si : 0);
+        float* sdx = upper ? a.l[layer - 1].dxin + (size_t)sb * T * H + lane : (float*)nullptr;
+        for (int t = T - 1; t >= -1; --t) {
+            gp_lds_barrier();
+            gp_lds_barrier();
+            if (si < nrows) {
+                if (upper && t + 1 < T) gss_store(sdx + (size_t)(t + 1) * H, stg[4][si][lane]);
+                if (t >= 0) {
+                    const float v_r = stg[0][si][lane], v_z = stg[1][si][lane], v_n = stg[2][si][lane], v_nr = stg[3][si][lane];
+                    const size_t row = (size_t)sb * T + t;
+                    float* dx = P.dxproj + row * G;
+                    float* dhp = P.dhproj + row * G;
+                    dx[lane] = v_r;  dx[H + lane] = v_z;  dx[2 * H + lane] = v_n;
+                    dhp[lane] = v_r; dhp[H + lane] = v_z; dhp[2 * H + lane] = v_nr;
+                }
+            }
+        }
+        return;
+    }
     // one step; g_use holds grad row t (taken in the cell phase, then reloaded with row t - 2)
     auto step = [&](int t, float& g_use) {
         const int t1 = t > 0 ? t - 1 : 0;
@@ -428,7 +475,7 @@ __global__ __launch_bounds__(256) void gru_stack_bwd_small64_kernel(GssLayers a,
         gp_lds_barrier();
         if (mine) {
             if (upper && t + 1 < T)           // d x_{t+1}: the row the layer below takes as its grad_out of step t + 1
-                gss_store(p_dx + (size_t)(t + 1) * H, (partx[0][er][ej] + partx[1][er][ej]) + (partx[2][er][ej] + partx[3][er][ej]));
+                stg[4][er][ej] = (partx[0][er][ej] + partx[1][er][ej]) + (partx[2][er][ej] + partx[3][er][ej]);
             const float dstate = carry + (t + 1 < T ? ((part[0][er][ej] + part[1][er][ej]) + (part[2][er][ej] + part[3][er][ej])) : 0.f);
             if (t < 0) {
                 P.dh0[(size_t)b * H + ej] = dstate;
@@ -463,11 +510,10 @@ __global__ __launch_bounds__(256) void gru_stack_bwd_small64_kernel(GssLayers a,
                         dlxb[er][2 * H + ej] = mg_f2bf(dn);
                     }
                 }
-                const size_t row = (size_t)b * T + t;
-                float* dx = P.dxproj + row * G;
-                float* dhp = P.dhproj + row * G;
-                dx[ej] = dr;  dx[H + ej] = dz;  dx[2 * H + ej] = dn;
-                dhp[ej] = dr; dhp[H + ej] = dz; dhp[2 * H + ej] = dnr;
+                stg[0][er][ej] = dr;
+                stg[1][er][ej] = dz;
+                stg[2][er][ej] = dn;
+                stg[3][er][ej] = dnr;
             }
         }
         s_r = s_r1; s_z = s_z1; s_n = s_n1; s_hn = s_hn1; hprev = hprev1;
@@ -542,9 +588,9 @@ static int gss_fwd(const mg_gru_stack_layer* layers, int L, const int64_t* seq_l
     }
     const int nblk = (int)mg_ceil_div(B, 4);
     if (fast)
-        hipLaunchKernelGGL(gru_stack_fwd_small64_kernel<true>, dim3((unsigned)(L * nblk)), dim3(256), 0, st, a, seq_len, B, T, L, nblk, (unsigned*)workspace);
+        hipLaunchKernelGGL(gru_stack_fwd_small64_kernel<true>, dim3((unsigned)(L * nblk)), dim3(512), 0, st, a, seq_len, B, T, L, nblk, (unsigned*)workspace);
     else
-        hipLaunchKernelGGL(gru_stack_fwd_small64_kernel<false>, dim3((unsigned)(L * nblk)), dim3(256), 0, st, a, seq_len, B, T, L, nblk, (unsigned*)workspace);
+        hipLaunchKernelGGL(gru_stack_fwd_small64_kernel<false>, dim3((unsigned)(L * nblk)), dim3(512), 0, st, a, seq_len, B, T, L, nblk, (unsigned*)workspace);
     MG_CHECK_LAUNCH("mg_gru_stack_fwd_small_f32");
     return MG_OK;
 }
@@ -583,9 +629,9 @@ static int gss_bwd(const mg_gru_stack_layer* layers, int L, const int64_t* seq_l
     }
     const int nblk = (int)mg_ceil_div(B, 4);
     if (fast)
-        hipLaunchKernelGGL(gru_stack_bwd_small64_kernel<true>, dim3((unsigned)(L * nblk)), dim3(256), 0, st, a, seq_len, B, T, L, nblk, (unsigned*)workspace);
+        hipLaunchKernelGGL(gru_stack_bwd_small64_kernel<true>, dim3((unsigned)(L * nblk)), dim3(512), 0, st, a, seq_len, B, T, L, nblk, (unsigned*)workspace);
     else
-        hipLaunchKernelGGL(gru_stack_bwd_small64_kernel<false>, dim3((unsigned)(L * nblk)), dim3(256), 0, st, a, seq_len, B, T, L, nblk, (unsigned*)workspace);
+        hipLaunchKernelGGL(gru_stack_bwd_small64_kernel<false>, dim3((unsigned)(L * nblk)), dim3(512), 0, st, a, seq_len, B, T, L, nblk, (unsigned*)workspace);
     MG_CHECK_LAUNCH("mg_gru_stack_bwd_small_f32");
     return MG_OK;
 }
