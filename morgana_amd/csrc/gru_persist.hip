@@ -30,7 +30,7 @@ MG_STAMP_DECL(g_stamps_gp);
 MG_STAMP_DECL(g_stamps_gpb);
 
 template <int MT, int KS>
-__global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __restrict__ xproj, const uint16_t* __restrict__ w_bf, int ldw,
+__global__ __launch_bounds__(384) void gru_fwd_persist_kernel(const float* __restrict__ xproj, const uint16_t* __restrict__ w_bf, int ldw,
                                                               const float* __restrict__ b_hh, const int64_t* __restrict__ seq_len,
                                                               int B, int T, int H, int R, float* __restrict__ hstate,
                                                               uint16_t* __restrict__ hstate_bf, float* __restrict__ out,
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
     }
 
     // W_hh fragments of this slot, for the whole launch
-    const int kbase = wave * (H / 4) + 8 * q;
+    const int kbase = (wave & 3) * (H / 4) + 8 * q;   // (the storing waves 4, 5 run the prologue as waves 0, 1: same loads, same LDS values)
     gbf8 fr[KS], fz[KS], fn[KS];
     {
         const uint16_t* wr = w_bf + (size_t)(j0 + li) * ldw;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
     const unsigned wr_base = (unsigned)(((group * n_slots + slot) * R) * 32);
 
     // cell role: thread (bl, jl) owns element (row0 + 16 m + bl, j0 + jl) in every step
-    const int bl = tid >> 4, jl = tid & 15;
+    const int bl = (tid & 255) >> 4, jl = tid & 15;
     const int j = j0 + jl;
     const float bhr = b_hh[j], bhz = b_hh[H + j], bhn = b_hh[2 * H + j];
     float hprev[MT], xr[MT], xz[MT], xn[MT];
@@ -122,22 +122,23 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
     }
     __syncthreads();
 
-    // wave 0 publishes the tile in hb as epoch e (state h_e) into ring parity e & 1, then raises the slot's flag to e + 1;
-    // wave 1 writes the same tile to the bf16 shadow of the state (read by the weight-gradient GEMM after the launch)
+    // wave 0 publishes the tile in hb as epoch e (state h_e) into ring parity e & 1, then raises the slot's flag to e + 1.
+    // Everything a step leaves for AFTER the launch - the bf16 shadow of the state, the fp32 state / output / saved gate values - is
+    // stored by waves 4 and 5, which do nothing else: those stores go to lines nobody has touched, their acknowledgements take
+    // about a step, and a wave's loads and stores complete in order (one vmcnt) - in a wave that also fetches the next state tile
+    // every such fetch waits for the old stores first (the small GRU stack gained 10 % from the same split, profiles/r4_gru_small_stack.txt;
+    // here, where waves 2 and 3 stored before: C4 3.396 -> 3.378, C5 6.435 -> 6.406 ms.  The same split of the BACKWARD kernel - wave 1's
+    // bf16 shadows to a storing wave - measured +1.1 %: not adopted).
     auto publish = [&](int e) {
-        if (wave <= 1 && lane < 2 * 16 * MT) {
+        if (wave == 0 && lane < 2 * 16 * MT) {
             const int rrow = lane >> 1, half = lane & 1;
             if (rrow < nrows) {
                 const u32x4 v = *reinterpret_cast<const u32x4*>(&hb[rrow >> 4][rrow & 15][8 * half]);
-                if (wave == 0) {
-                    const unsigned off = (e & 1) * par_bytes + wr_base + (unsigned)(rrow * 32 + half * 16);
-                    if (one_xcd)
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 0);      // stays in the group's L2
-                    else
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 16);     // sc1: written through
-                } else if (e > 0) {
-                    *reinterpret_cast<u32x4*>(hstate_bf + ((size_t)(row0 + rrow) * (T + 1) + e) * H + j0 + 8 * half) = v;
-                }
+                const unsigned off = (e & 1) * par_bytes + wr_base + (unsigned)(rrow * 32 + half * 16);
+                if (one_xcd)
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 0);      // stays in the group's L2
+                else
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 16);     // sc1: written through
             }
         }
         if (wave == 0) {
@@ -146,6 +147,44 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
         }
     };
     publish(0);
+    if (wave >= 4) {
+        // the storing waves' whole launch: the three barriers of every step (leaving with the others on a time-out), then the step's
+        // values out of hb / res - both rewritten only behind the next step's second barrier
+        const int st = tid - 256;                        // 0 .. 127
+        for (int t = 0; t < gmax; ++t) {
+            gp_lds_barrier();
+            if (s_abort) return;
+            gp_lds_barrier();
+            gp_lds_barrier();
+            if (wave == 4 && lane < 2 * 16 * MT) {
+                const int rrow = lane >> 1, half = lane & 1;
+                if (rrow < nrows)
+                    *reinterpret_cast<u32x4*>(hstate_bf + ((size_t)(row0 + rrow) * (T + 1) + t + 1) * H + j0 + 8 * half) =
+                        *reinterpret_cast<const u32x4*>(&hb[rrow >> 4][rrow & 15][8 * half]);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int e = st + 128 * half, rb = e >> 4, cj = j0 + (e & 15);
+                    if (16 * m + rb < nrows) {
+                        const int b = row0 + 16 * m + rb;
+                        const size_t row = (size_t)b * T + t;
+                        hstate[((size_t)b * (T + 1) + t + 1) * H + cj] = res[m][0][e];
+                        out[row * H + cj] = res[m][1][e];
+                        // bf16 copy of the output row (zero past the item's length, as `out`): the operand of the Linear layer behind
+                        // the wrapper, which otherwise costs a cast pass over [B, T, H] (C4 37 us, C5 98 us)
+                        if (out_bf) out_bf[row * H + cj] = mg_f2bf(res[m][1][e]);
+                        float* sv = saved + row * 4 * H + cj;
+                        sv[0] = res[m][2][e];
+                        sv[H] = res[m][3][e];
+                        sv[2 * H] = res[m][4][e];
+                        sv[3 * H] = res[m][5][e];
+                    }
+                }
+        }
+        return;
+    }
 
 #ifdef MG_STAMPS
     unsigned long long ta = 0, tb = 0, ts0 = 0, ts1 = 0, tr0 = 0, tr1 = 0, sum_poll = 0, sum_load = 0, sum_mm = 0, sum_cell = 0, sum_pub = 0;
@@ -233,31 +272,6 @@ __global__ __launch_bounds__(256) void gru_fwd_persist_kernel(const float* __res
         publish(t + 1);                             // first: the other workgroups wait for exactly this
         MG_STAMP(tb);
         MG_STAMP_ADD(sum_pub, tb, ta);
-        // fp32 results of the step (nobody reads them before the kernel ends): written by waves 2 and 3 only.  The acknowledgement
-        // of a store to a fresh line takes about as long as a whole step; in wave 0's in-order memory queue it would sit in front of
-        // the flag poll and the publish drain, and waves 2 and 3 only wait at the next barrier anyway.
-        if (wave >= 2) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int e = (tid - 128) + 128 * half, rb = e >> 4, cj = j0 + (e & 15);
-                    if (16 * m + rb < nrows) {
-                        const int b = row0 + 16 * m + rb;
-                        const size_t row = (size_t)b * T + t;
-                        hstate[((size_t)b * (T + 1) + t + 1) * H + cj] = res[m][0][e];
-                        out[row * H + cj] = res[m][1][e];
-                        // bf16 copy of the output row (zero past the item's length, as `out`): the operand of the Linear layer behind
-                        // the wrapper, which otherwise costs a cast pass over [B, T, H] (C4 37 us, C5 98 us)
-                        if (out_bf) out_bf[row * H + cj] = mg_f2bf(res[m][1][e]);
-                        float* sv = saved + row * 4 * H + cj;
-                        sv[0] = res[m][2][e];
-                        sv[H] = res[m][3][e];
-                        sv[2 * H] = res[m][4][e];
-                        sv[3 * H] = res[m][5][e];
-                    }
-                }
-        }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             xr[m] = xr1[m];
@@ -999,7 +1013,7 @@ int mg_gru_fwd_persist_out_bf16(const float* xproj, const int32_t* xrows, int64_
     const int R = (int)mg_ceil_div(B, GP_GROUPS);
     const unsigned grid = (unsigned)(GP_GROUPS * (H / GT));
 #define GP_FWD(MT, KS)                                                                                                                  \
-    hipLaunchKernelGGL((gru_fwd_persist_kernel<MT, KS>), dim3(grid), dim3(256), 0, st, xproj, w_hh_bf, ldw, b_hh, seq_len, B, T, H, R, hstate, \
+    hipLaunchKernelGGL((gru_fwd_persist_kernel<MT, KS>), dim3(grid), dim3(384), 0, st, xproj, w_hh_bf, ldw, b_hh, seq_len, B, T, H, R, hstate, \
                        hstate_bf, out, saved, (unsigned*)workspace, (uint16_t*)((char*)workspace + GP_RING_OFFSET), g_mg_tuning[MG_TUNE_GRU_HANDOFF], xrows, out_bf)
 #define GP_FWD_KS(MT)            \
     switch (H / 128) {           \
