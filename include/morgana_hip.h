@@ -64,7 +64,8 @@ const char* mg_last_error(void);
 #define MG_TUNE_LSTM_BWD_STACK 6 /* LSTM stack wavefronts, hidden units per slot: 0 = backward 32 where they fit (one workgroup per CU),
                                  * forward 16 (two per CU); bit 0 (1) = backward 16; bit 1 (2) = forward 32 (same bits, measured slower) */
 #define MG_TUNE_AB 7            /* shared-grid launches as their separate launches, half-width tiles off: 65 = mg_linear_wgrad_dgrad_bf16 as
-                                 * two launches, 66 = mg_phone_front_linear_fwd_bf16 as two, 92 = 128 x 640 tiles for the 640-wide weight
+                                 * two launches, 66 = mg_phone_front_linear_fwd_bf16 as two, 91 = 128 x 512 tiles for the 512-wide weight
+                                 * gradient where the square 256 x 256 tile is the default (N a multiple of 256), 92 = 128 x 640 tiles for the 640-wide weight
                                  * gradient at phone-rate rows, 93 = 128 x 512 tiles for the 512-wide one, 94 = mg_phone_front_linear_fwd_bf16 with the
                                  * front's jobs as block jobs and 256-row tiles (round 2's form), 95 = wave jobs but 256-row tiles,
                                  * 96 = mg_f0_l2tail_*_bf16 walks H1 from its first tile at every size (default: from the last one when

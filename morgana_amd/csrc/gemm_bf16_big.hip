@@ -937,10 +937,15 @@ MG_STAMP_DECL(g_stamps_wg);
 // X tile row pitch: the k columns of the tile, rounded up to whole groups of 16 chunks (the chunk swizzle XORs bits 2-3 of the chunk index)
 #define WG_BIG_PX(TKW_) ((64 * (TKW_) * 2 + 255) / 256 * 256)
 #define WG_BIG_LDS(TKW_) (WG_STAGES(TKW_) * (32 * 256 + 32 * WG_BIG_PX(TKW_)) + WG_ROWS_MAX * 4)
+#define WG_BIG_LDS_NW(TKW_, NW_) (WG_STAGES(TKW_) * (32 * 256 * (NW_) + 32 * WG_BIG_PX(TKW_)) + WG_ROWS_MAX * 4)      // NW_ x 128 n columns
 // DYR: the dY operand is gathered too - row m of the product is dY[dy_rows[m]] (x) A[rows[m]]: the valid frames of a ragged batch picked
 // out of the padded (B, T) arrays a recurrence writes (morgana/utils.py:366-385 packs them away), so that the layer's weight
 // gradients multiply sum_b T_b rows instead of B T.  A second parked index table: 16 KB more LDS, a kernel of its own.
-template <int TKW, bool DYR = false>
+// NW = 2 (with TKW = 4): the SQUARE tile 256 (n) x 256 (k), two k halves per n tile, 4 waves along n x 2 along k - the wave's 64 x 128 part
+// and its fragment reads are those of the 128 x 512 tile, the stage holds 256 + 256 instead of 128 + 512 operand columns: a fifth
+// fewer 128-byte lines per step for the same products, and the loop is bound by the lines a CU can request (~8 cycles each;
+// profiles/r4_notes_falsified_kernel_ideas.txt).  Same number of tiles per split as the 128 x 512 form, so the same plan.
+template <int TKW, bool DYR = false, int NW = 1>
 __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem, const unsigned block_id, const uint16_t* __restrict__ dY,
                                                int lddy, const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows, int64_t M,
                                                int N, int K, int m_chunk, float* __restrict__ slab, float* __restrict__ bslab, int64_t sstride,
@@ -949,7 +954,8 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
     // TKW = 5: 128 x 320 - HALF the k columns, two k halves per n tile (KH = 2), 4 waves along n x 2 along k: the same five k tiles per
     // wave with one n tile instead of two.  Twice the tiles per split means two thirds of the splits for a full chip (8 x 32 instead of
     // 4 x 48 workgroups at the phone-rate rows of C2): a third less slab traffic and half the epilogue per workgroup.
-    constexpr int BNT = 128, BKT = 64 * TKW;
+    static_assert(NW == 1 || (NW == 2 && TKW == 4), "the 256-wide n tile goes with the 256-wide k half");
+    constexpr int BNT = 128 * NW, BKT = 64 * TKW;
     constexpr int KH = (TKW == 5 || TKW == 4) ? 2 : 1;    // k tiles per operand row (TKW = 4: 128 x 256, the half of TKW = 8's tile)
     constexpr int WK = KH == 2 ? 2 : 4;           // waves along k
     constexpr int TNW = BNT / 32 / (8 / WK);      // 32-row MFMA tiles per wave along n: 2 or 1
@@ -958,13 +964,14 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
     constexpr int XC = BKT * 2 / 16;              // 16-byte chunks of an X row that hold operand columns
     constexpr int Y_BYTES = 32 * PY, X_BYTES = 32 * PX;
     constexpr int STAGE = Y_BYTES + X_BYTES;
-    constexpr int NX = X_BYTES / 1024 / 8;        // X LDS-DMA instructions per wave per step: 5, 4 or 3
-    constexpr int NLW = 1 + NX;                   // + one for dY
+    constexpr int NX = X_BYTES / 1024 / 8;        // X LDS-DMA instructions per wave per step: 5, 4, 3 or 2
+    constexpr int NY = Y_BYTES / 1024 / 8;        // dY: 1 (2 for the 256-wide n tile)
+    constexpr int NLW = NY + NX;
     static_assert(X_BYTES % 8192 == 0, "whole pieces per wave");
     constexpr int NSTG = WG_STAGES(TKW);
     constexpr int LDS_BYTES = NSTG * STAGE + WG_ROWS_MAX * 4 * (DYR ? 2 : 1);
 
-    static_assert(LDS_BYTES == WG_BIG_LDS(TKW) + (DYR ? WG_ROWS_MAX * 4 : 0) && LDS_BYTES <= 160 * 1024, "LDS size helper");
+    static_assert(LDS_BYTES == WG_BIG_LDS_NW(TKW, NW) + (DYR ? WG_ROWS_MAX * 4 : 0) && LDS_BYTES <= 160 * 1024, "LDS size helper");
     int* row_lds = reinterpret_cast<int*>(smem + NSTG * STAGE);
     int* dyrow_lds = row_lds + WG_ROWS_MAX;       // DYR only
 
@@ -1008,8 +1015,13 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
 
     // DMA slots.  dY: one 1 KB piece (4 rows of 256 B) per wave.  X: NX pieces per wave, piece t = wave*NX + i covers
     // linear tile bytes [1024 t, 1024 t + 1024); a lane's byte decides its tile row and chunk position.
-    const int y_row = wave * 4 + (lane >> 4);
-    const int y_c = (lane & 15) ^ ((y_row & 3) << 2);
+    int y_row[NY], y_c[NY];
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {                // (one piece of a 128-wide tile: row wave * 4 + lane / 16, chunk lane % 16 swizzled)
+        const int byte = (wave * NY + i) * 1024 + lane * 16;
+        y_row[i] = byte / PY;
+        y_c[i] = ((byte % PY) >> 4) ^ ((y_row[i] & 3) << 2);
+    }
     int x_row[NX], x_off[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -1022,14 +1034,17 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
 
     auto issue = [&](int step) {                 // rows [32 step, 32 step + 32) of this workgroup's range
         unsigned char* st = smem + (step % NSTG) * STAGE;
-        if (DYR) {
-            const int ry = dyrow_lds[step * 32 + y_row];
-            const uint16_t* p = ry >= 0 ? dY + (size_t)ry * lddy + n0 + y_c * 8 : g_zero_row;
-            glds16(p, st + wave * 1024);
-        } else {
-            const int ml = step * 32 + y_row;
-            const uint16_t* p = (ml < n_rows) ? dY + (size_t)(m_lo + ml) * lddy + n0 + y_c * 8 : g_zero_row;
-            glds16(p, st + wave * 1024);
+#pragma unroll
+        for (int i = 0; i < NY; ++i) {
+            if (DYR) {
+                const int ry = dyrow_lds[step * 32 + y_row[i]];
+                const uint16_t* p = ry >= 0 ? dY + (size_t)ry * lddy + n0 + y_c[i] * 8 : g_zero_row;
+                glds16(p, st + (wave * NY + i) * 1024);
+            } else {
+                const int ml = step * 32 + y_row[i];
+                const uint16_t* p = (ml < n_rows) ? dY + (size_t)(m_lo + ml) * lddy + n0 + y_c[i] * 8 : g_zero_row;
+                glds16(p, st + (wave * NY + i) * 1024);
+            }
         }
         int rr[NX];
 #pragma unroll
@@ -1192,21 +1207,21 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
 #endif
 }
 
-template <int TKW>
+template <int TKW, int NW = 1>
 __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restrict__ dY, int lddy, const uint16_t* __restrict__ A, int lda,
                                                         const int32_t* __restrict__ rows, int64_t M, int N, int K, int m_chunk,
                                                         float* __restrict__ slab, float* __restrict__ bslab, int64_t sstride, int xcd_group) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[WG_BIG_LDS(TKW)];
-    wgrad_big_body<TKW>(smem, blockIdx.x, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WG_BIG_LDS_NW(TKW, NW)];
+    wgrad_big_body<TKW, false, NW>(smem, blockIdx.x, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
 }
 
-template <int TKW>
+template <int TKW, int NW = 1>
 __global__ __launch_bounds__(512) void wgrad_big_rows_kernel(const uint16_t* __restrict__ dY, int lddy, const int32_t* __restrict__ dy_rows,
                                                              const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows, int64_t M,
                                                              int N, int K, int m_chunk, float* __restrict__ slab, float* __restrict__ bslab,
                                                              int64_t sstride, int xcd_group) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[WG_BIG_LDS(TKW) + WG_ROWS_MAX * 4];
-    wgrad_big_body<TKW, true>(smem, blockIdx.x, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group, dy_rows);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WG_BIG_LDS_NW(TKW, NW) + WG_ROWS_MAX * 4];
+    wgrad_big_body<TKW, true, NW>(smem, blockIdx.x, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group, dy_rows);
 }
 
 // Two INDEPENDENT launches of a backward pass in one grid: the weight gradient of a layer (blocks [0, wg_blocks): dW = dY^T A as split-M
@@ -1387,8 +1402,13 @@ int mg_launch_wgrad_big(const uint16_t* dY, int lddy, const uint16_t* A, int lda
     if (dy_rows) {
         if (lda != 512 || wgrad_ksplit(M, N, lda)) return 0;
         dim3 grid((unsigned)((N / 128) * S)), block(512);
-        hipLaunchKernelGGL((wgrad_big_rows_kernel<8>), grid, block, 0, st, dY, lddy, dy_rows, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride,
-                           g_mg_tuning[MG_TUNE_WGRAD_ORDER] == 2 && S % 8 == 0 ? 1 : 0);
+        const int xg = g_mg_tuning[MG_TUNE_WGRAD_ORDER] == 2 && S % 8 == 0 ? 1 : 0;
+        if (N % 256 == 0 && g_mg_tuning[MG_TUNE_AB] != 91)            // the square tile (see below): both index tables fill the LDS exactly
+            hipLaunchKernelGGL((wgrad_big_rows_kernel<4, 2>), grid, block, 0, st, dY, lddy, dy_rows, A, lda, rows, M, N, K, m_chunk, slab, bslab,
+                               sstride, xg);
+        else
+            hipLaunchKernelGGL((wgrad_big_rows_kernel<8>), grid, block, 0, st, dY, lddy, dy_rows, A, lda, rows, M, N, K, m_chunk, slab, bslab,
+                               sstride, xg);
         return 1;
     }
     const bool ksplit = wgrad_ksplit(M, N, lda);
@@ -1398,7 +1418,11 @@ int mg_launch_wgrad_big(const uint16_t* dY, int lddy, const uint16_t* A, int lda
     int xcd_group = (rows == nullptr && S % 8 == 0) ? 1 : 0;
     if (g_mg_tuning[MG_TUNE_WGRAD_ORDER] == 1) xcd_group = 0;
     if (g_mg_tuning[MG_TUNE_WGRAD_ORDER] == 2 && S % 8 == 0) xcd_group = 1;
-    if (ksplit && lda == 512)
+    // a 512-wide operand with an even number of n tiles: the square 256 x 256 tile (N / 256 n tiles x two k halves = the N / 128 tiles
+    // per split the plan counted): 121 vs 143 us at 64 000 x 1536 x 512, 150-160 vs 166-182 at 64 000 x 2048 x 512
+    if (!ksplit && lda == 512 && N % 256 == 0 && g_mg_tuning[MG_TUNE_AB] != 91)                       // 91: A/B, the 128 x 512 tiles
+        hipLaunchKernelGGL((wgrad_big_kernel<4, 2>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
+    else if (ksplit && lda == 512)
         hipLaunchKernelGGL((wgrad_big_kernel<4>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
     else if (ksplit)
         hipLaunchKernelGGL((wgrad_big_kernel<5>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);

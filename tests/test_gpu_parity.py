@@ -655,6 +655,36 @@ def test_deferred_tail_riders_on_synthetic_slabs(m, frames, n_slabs):
     assert torch.equal(got['out'], want['out']) and torch.equal(got['grads_out'][-2:], want['grads_out'][-2:])
 
 
+@pytest.mark.parametrize('m,n,k', [(64000, 1536, 512), (40003, 2048, 500), (9000, 256, 400), (4100, 512, 512), (70001, 768, 512)])
+def test_wgrad_square_tile_equals_the_wide_tile(m, n, k):
+    """The 256 x 256 tile of the wide weight-gradient kernel (default for a 512-wide operand when N is a multiple of 256) against its
+    128 x 512 tile (MG_TUNE_AB = 91): every element is summed over the same rows in the same order by one wave -> EQUAL slabs, dW and db;
+    and against a float64 product of the same bf16 operands."""
+    from morgana_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(m + n)
+    dy = ops.cast_pad_bf16(dev((rng.standard_normal((m, n)) * 0.05).astype(np.float32)))
+    a = torch.zeros((m, 512), dtype=torch.bfloat16, device=DEV)              # a 512-wide activation table with k columns in use
+    a[:, :k] = dev(rng.uniform(-1, 1, (m, k)).astype(np.float32)).to(torch.bfloat16)
+    try:
+        assert lib.mg_set_tuning(7, 91) == 0
+        want_w, want_b = ops.linear_wgrad_bf16(dy, a, None, m, n, k)
+        want_slab, want_ns, want_stride = ops.linear_wgrad_slabs_bf16(dy, a, None, m, n, k)
+    finally:
+        lib.mg_set_tuning(7, 0)
+    got_w, got_b = ops.linear_wgrad_bf16(dy, a, None, m, n, k)
+    got_slab, got_ns, got_stride = ops.linear_wgrad_slabs_bf16(dy, a, None, m, n, k)
+    assert (got_ns, got_stride) == (want_ns, want_stride)
+    gs, ws = got_slab.view(torch.float32), want_slab.view(torch.float32)
+    for i in range(got_ns):
+        assert torch.equal(gs[i * got_stride:i * got_stride + n * k + n], ws[i * got_stride:i * got_stride + n * k + n])
+    assert torch.equal(got_w, want_w) and torch.equal(got_b, want_b)
+    ref = dy.double().t() @ a.double()[:, :k]
+    assert np.linalg.norm(got_w.cpu().numpy() - ref.cpu().numpy()) / np.linalg.norm(ref.cpu().numpy()) < 1e-5
+    ref_b = dy.double().sum(0)
+    assert (got_b.double() - ref_b).abs().max().item() <= 1e-5 * ref_b.abs().max().item() + 1e-6
+
+
 @pytest.mark.parametrize('n,k,total', [(1536, 512, 9000), (384, 500, 4100), (1536, 512, 73613)])
 def test_wgrad_with_both_operands_gathered(n, k, total):
     """mg_linear_wgrad_rows_bf16 (dW = sum_i dY[dy_rows[i]]^T A[rows[i]]: a recurrent layer's weight gradients over the valid frames of a
