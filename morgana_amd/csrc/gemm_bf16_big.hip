@@ -937,10 +937,12 @@ MG_STAMP_DECL(g_stamps_wg);
 // X tile row pitch: the k columns of the tile, rounded up to whole groups of 16 chunks (the chunk swizzle XORs bits 2-3 of the chunk index)
 #define WG_BIG_PX(TKW_) ((64 * (TKW_) * 2 + 255) / 256 * 256)
 #define WG_BIG_LDS(TKW_) (WG_STAGES(TKW_) * (32 * 256 + 32 * WG_BIG_PX(TKW_)) + WG_ROWS_MAX * 4)
-#define WG_BIG_LDS_NW(TKW_, NW_) (WG_STAGES(TKW_) * (32 * 256 * (NW_) + 32 * WG_BIG_PX(TKW_)) + WG_ROWS_MAX * 4)      // NW_ x 128 n columns
+#define WG_STAGES_NW(TKW_, NW_) (((NW_) == 2 && (TKW_) == 5) ? 3 : WG_STAGES(TKW_))          // 256 x 320: 40 KB stages
+#define WG_BIG_LDS_NW(TKW_, NW_) (WG_STAGES_NW(TKW_, NW_) * (32 * 256 * (NW_) + 32 * WG_BIG_PX(TKW_)) + WG_ROWS_MAX * 4)      // NW_ x 128 n columns
 // DYR: the dY operand is gathered too - row m of the product is dY[dy_rows[m]] (x) A[rows[m]]: the valid frames of a ragged batch picked
 // out of the padded (B, T) arrays a recurrence writes (morgana/utils.py:366-385 packs them away), so that the layer's weight
 // gradients multiply sum_b T_b rows instead of B T.  A second parked index table: 16 KB more LDS, a kernel of its own.
+// (NW = 2 with TKW = 5: 256 x 320, the same for the 640-wide operand - 288 lines per step where the 128 x 640 tile asks for 384.)
 // NW = 2 (with TKW = 4): the SQUARE tile 256 (n) x 256 (k), two k halves per n tile, 4 waves along n x 2 along k - the wave's 64 x 128 part
 // and its fragment reads are those of the 128 x 512 tile, the stage holds 256 + 256 instead of 128 + 512 operand columns: a fifth
 // fewer 128-byte lines per step for the same products, and the loop is bound by the lines a CU can request (~8 cycles each;
@@ -954,7 +956,7 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
     // TKW = 5: 128 x 320 - HALF the k columns, two k halves per n tile (KH = 2), 4 waves along n x 2 along k: the same five k tiles per
     // wave with one n tile instead of two.  Twice the tiles per split means two thirds of the splits for a full chip (8 x 32 instead of
     // 4 x 48 workgroups at the phone-rate rows of C2): a third less slab traffic and half the epilogue per workgroup.
-    static_assert(NW == 1 || (NW == 2 && TKW == 4), "the 256-wide n tile goes with the 256-wide k half");
+    static_assert(NW == 1 || (NW == 2 && (TKW == 4 || TKW == 5)), "the 256-wide n tile goes with a k half (256 or 320 columns)");
     constexpr int BNT = 128 * NW, BKT = 64 * TKW;
     constexpr int KH = (TKW == 5 || TKW == 4) ? 2 : 1;    // k tiles per operand row (TKW = 4: 128 x 256, the half of TKW = 8's tile)
     constexpr int WK = KH == 2 ? 2 : 4;           // waves along k
@@ -968,7 +970,7 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
     constexpr int NY = Y_BYTES / 1024 / 8;        // dY: 1 (2 for the 256-wide n tile)
     constexpr int NLW = NY + NX;
     static_assert(X_BYTES % 8192 == 0, "whole pieces per wave");
-    constexpr int NSTG = WG_STAGES(TKW);
+    constexpr int NSTG = WG_STAGES_NW(TKW, NW);
     constexpr int LDS_BYTES = NSTG * STAGE + WG_ROWS_MAX * 4 * (DYR ? 2 : 1);
 
     static_assert(LDS_BYTES == WG_BIG_LDS_NW(TKW, NW) + (DYR ? WG_ROWS_MAX * 4 : 0) && LDS_BYTES <= 160 * 1024, "LDS size helper");
@@ -1426,6 +1428,8 @@ int mg_launch_wgrad_big(const uint16_t* dY, int lddy, const uint16_t* A, int lda
         hipLaunchKernelGGL((wgrad_big_kernel<4>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
     else if (ksplit)
         hipLaunchKernelGGL((wgrad_big_kernel<5>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
+    else if (lda == 640 && N % 256 == 0 && g_mg_tuning[MG_TUNE_AB] != 91)
+        hipLaunchKernelGGL((wgrad_big_kernel<5, 2>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
     else if (lda == 640)
         hipLaunchKernelGGL((wgrad_big_kernel<10>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
     else

@@ -655,16 +655,18 @@ def test_deferred_tail_riders_on_synthetic_slabs(m, frames, n_slabs):
     assert torch.equal(got['out'], want['out']) and torch.equal(got['grads_out'][-2:], want['grads_out'][-2:])
 
 
-@pytest.mark.parametrize('m,n,k', [(64000, 1536, 512), (40003, 2048, 500), (9000, 256, 400), (4100, 512, 512), (70001, 768, 512)])
-def test_wgrad_square_tile_equals_the_wide_tile(m, n, k):
-    """The 256 x 256 tile of the wide weight-gradient kernel (default for a 512-wide operand when N is a multiple of 256) against its
-    128 x 512 tile (MG_TUNE_AB = 91): every element is summed over the same rows in the same order by one wave -> EQUAL slabs, dW and db;
-    and against a float64 product of the same bf16 operands."""
+@pytest.mark.parametrize('m,n,k,lda', [(64000, 1536, 512, 512), (40003, 2048, 500, 512), (9000, 256, 400, 512), (4100, 512, 512, 512),
+                                       (70001, 768, 512, 512), (64000, 512, 600, 640), (40003, 512, 609, 640), (9000, 256, 630, 640),
+                                       (70001, 256, 640, 640)])
+def test_wgrad_square_tile_equals_the_wide_tile(m, n, k, lda):
+    """The 256 x 256 tile of the wide weight-gradient kernel (default for a 512-wide operand when N is a multiple of 256; 256 x 320 for a
+    640-wide one) against its 128 x 512 / 128 x 640 tile (MG_TUNE_AB = 91): every element is summed over the same rows in the same order
+    by one wave -> EQUAL slabs, dW and db; and against a float64 product of the same bf16 operands."""
     from morgana_amd import _lib
     lib = _lib.load()
     rng = np.random.RandomState(m + n)
     dy = ops.cast_pad_bf16(dev((rng.standard_normal((m, n)) * 0.05).astype(np.float32)))
-    a = torch.zeros((m, 512), dtype=torch.bfloat16, device=DEV)              # a 512-wide activation table with k columns in use
+    a = torch.zeros((m, lda), dtype=torch.bfloat16, device=DEV)              # a 512- / 640-wide table with k columns in use
     a[:, :k] = dev(rng.uniform(-1, 1, (m, k)).astype(np.float32)).to(torch.bfloat16)
     try:
         assert lib.mg_set_tuning(7, 91) == 0
