@@ -54,7 +54,8 @@ const char* mg_last_error(void);
                                  * fused backward: 12 = tiles two steps ahead (larger ring), 13 = 32-frame steps, 7 = single-buffered */
 #define MG_TUNE_GRU_HANDOFF 2   /* persistent GRU / LSTM kernels: 0 = groups found on one XCD hand the state over through that XCD's L2,
                                  * bit 0 (1) = always write-through (sc1) stores, the placement-independent form; bit 1 (2) = group
-                                 * membership from the block index (block % 8) instead of a ticket of the XCD a workgroup runs on */
+                                 * membership from the block index (block % 8) instead of a ticket of the XCD a workgroup runs on;
+                                 * bit 2 (4) = the bf16 GRU backward with 8 groups x 16-unit slots (default: 16 groups x 32-unit slots, B <= 128) */
 #define MG_TUNE_PERSISTENT 3    /* recurrences: 0 = persistent kernels where the shape has them, 1 = one launch per time step,
                                  * 2 = H = 64 on the 16-row tile instead of the 4x4x1 blocks */
 #define MG_TUNE_WGRAD_SPLITS 4  /* wide weight-gradient kernel: != 0 overrides the planned number of split-M slabs (a multiple of 8);

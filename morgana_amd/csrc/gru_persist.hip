@@ -599,6 +599,234 @@ __global__ __launch_bounds__(256) void gru_bwd_persist_kernel(const float* __res
 #endif
 }
 
+// The backward recurrence with WIDE slots: 16 groups of R = ceil(B / 16) items (two per XCD) x H / 32 slots of 32 hidden units - the
+// same H / 16 workgroups per XCD, the same grid and tickets as the kernel above.  Why: a step's hand-off intake is what a CU can
+// request, one 128-byte line per ~8 cycles (profiles/r4_notes_falsified_kernel_ideas.txt; DESIGN R4.12), and a slot needs the gate
+// gradients of ALL 3 H gate columns of its group's items: 8 items x 3 H bf16 = 192 lines = ~1 500 of the step's ~3 200 cycles.  Half
+// the items per group is half the lines; the slot then owns twice the units (2 x 12 resident W_hh^T fragments per lane = 96 VGPRs,
+// 24 instead of 12 MFMAs per wave and step: +190 cycles) so that the groups still fill one CU per slot.  The M dimension of the MFMA
+// holds 4 valid items of 16 either way.  Products, their order and the sums are those of the kernel above: results EQUAL (tested).
+// Ring: [2 (t parity)][16 groups][H / 32 slots][3 gates][R items][32 units] bf16 - a k-step of 32 gate columns is one slot's row
+// of one gate: per instruction R x 64 contiguous bytes.  Flags / XCC table: the XCD group's 32 words, 16 per virtual group.
+template <int KS>
+__global__ __launch_bounds__(256) void gru_bwd_persist_wide_kernel(const float* __restrict__ grad_out, const float* __restrict__ grad_hn,
+                                                                   const float* __restrict__ hstate, const float* __restrict__ saved,
+                                                                   const uint16_t* __restrict__ wt_bf, int ldt,
+                                                                   const int64_t* __restrict__ seq_len, int B, int T, int H, int R,
+                                                                   float* __restrict__ dxproj, float* __restrict__ dhproj,
+                                                                   uint16_t* __restrict__ dhproj_bf, uint16_t* __restrict__ dxproj_bf,
+                                                                   float* __restrict__ dh0, unsigned* sync, uint16_t* ring, int force_sc1) {
+    constexpr int UW = 32;                         // hidden units per slot
+    constexpr int RM = 8;                          // items per group at most (B <= 128)
+    __shared__ float red[4][2][GT * GT];           // [k quarter = wave][unit tile][item x unit]
+    __shared__ __attribute__((aligned(16))) uint16_t pub[4][RM][UW];      // dr, dz, dn r (the hand-off) and dn (dxproj shadow only)
+    __shared__ float res[4][RM][UW];               // dr, dz, dn, dn r of the step for waves 2 and 3, which store them
+    __shared__ int s_abort, s_xcd;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    const int n_slots = H / GT;                    // tickets per XCD group: as many workgroups as the narrow kernel's
+    const int n_vslots = H / UW;
+    const int claim = gp_claim_slot((gu32*)sync + GP_TICKET_OFFSET, n_slots, tid, &s_xcd, force_sc1 & 2);
+    if (claim < 0) return;
+    const int xg = claim / GP_SLOTS, ticket = claim % GP_SLOTS;
+    if (ticket >= n_slots) return;
+    const int vsub = ticket / n_vslots, slot = ticket - vsub * n_vslots;       // n_slots = 2 n_vslots: vsub is 0 or 1
+    const int group = 2 * xg + vsub;               // virtual group 0 .. 15
+    const int row0 = group * R;
+    const int nrows = min(R, B - row0);
+    if (nrows <= 0) return;                        // (a whole virtual group: its 16 workgroups leave together)
+    const int j0 = slot * UW;
+    const int G = 3 * H;
+    gu32* flags = (gu32*)sync + xg * GP_SLOTS + vsub * n_vslots;
+    gu32* status = (gu32*)sync + GP_FLAG_WORDS;
+    if (tid == 0) s_abort = 0;
+    const int one_xcd = (force_sc1 & 1) ? 0
+                                        : gp_group_on_one_xcd((gu32*)sync + GP_GROUPS * GP_SLOTS + xg * GP_SLOTS + vsub * n_vslots, slot,
+                                                              n_vslots, tid, &s_xcd);
+    if (one_xcd < 0) {
+        if (tid == 0) __hip_atomic_store(status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+
+    int gmax = 0;
+    for (int r = 0; r < nrows; ++r) {
+        const int64_t n = seq_len ? seq_len[row0 + r] : (int64_t)T;
+        gmax = max(gmax, (int)(n < T ? n : T));
+    }
+
+    // W_hh^T fragments: lane (li, q) holds rows j0 + 16 u + li, gate columns gk + 32 i + 8 q .. + 7 (gk = the wave's quarter of 3 H)
+    const int gk = wave * (G / 4);
+    gbf8 fb[2][KS];
+    unsigned rd_off[KS];                               // ring offset of k-step i (item 0, parity 0)
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+        const int g = gk + 32 * i, gate = g / H, col = g - gate * H;       // 32 | H and 32 | G / 4: a k-step is one slot's row of one gate
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            fb[u][i] = *reinterpret_cast<const gbf8*>(wt_bf + (size_t)(j0 + 16 * u + li) * ldt + g + 8 * q);
+        rd_off[i] = (unsigned)((((group * n_vslots + (col >> 5)) * 3 + gate) * R) * 64 + 16 * q);
+    }
+    const unsigned par_bytes = (unsigned)(2 * GP_GROUPS * n_vslots * R * 192);
+    const auto rs_ring = __builtin_amdgcn_make_buffer_rsrc((void*)ring, 0, (int)(2 * par_bytes), 0x00020000);
+    const unsigned wr_base = (unsigned)(((group * n_vslots + slot) * 3 * R) * 64);
+
+    const int bl = tid >> 5, jl = tid & 31;            // cell element: item bl (8 rows of threads), unit j0 + jl
+    const int j = j0 + jl;
+    const int eu = jl >> 4, ee = bl * GT + (jl & 15);  // ... = element ee of unit tile eu in `red`
+    const bool mine = bl < nrows;
+    const int b_own = row0 + (mine ? bl : 0);
+    float carry = grad_hn ? grad_hn[(size_t)b_own * H + j] : 0.f;
+    const int len = seq_len ? (int)min((int64_t)T, seq_len[b_own]) : T;
+    const float* p_sv = saved + (size_t)b_own * T * 4 * H + j;
+    const float* p_h = hstate + (size_t)b_own * (T + 1) * H + j;
+    const float* p_g = grad_out + (size_t)b_own * T * H + j;
+    // rows beyond the group's longest sequence: zero gradients, carry untouched, nothing to wait for
+    for (int t = T - 1; t >= gmax; --t) {
+        if (mine) {
+            const size_t row = (size_t)b_own * T + t;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                if (dxproj) dxproj[row * G + g * H + j] = 0.f;
+                if (dhproj) dhproj[row * G + g * H + j] = 0.f;
+                dhproj_bf[row * G + g * H + j] = 0;
+                if (dxproj_bf) dxproj_bf[row * G + g * H + j] = 0;
+            }
+        }
+    }
+    // the slot's tile as 16-byte pieces in ring order: piece p = ((gate R + item) 4 + quarter); lane handles pieces lane, lane + 64
+    constexpr int PIECES = (3 * RM * 4 + 63) / 64;
+    bool pc_ok[PIECES], pc_gate2[PIECES];
+    int pc_lds[PIECES];
+    size_t pc_shadow[PIECES];
+#pragma unroll
+    for (int k = 0; k < PIECES; ++k) {
+        const int pc = lane + 64 * k, gate = pc / (4 * R), rem = pc - gate * 4 * R, rrow = rem >> 2, quarter = rem & 3;
+        pc_ok[k] = gate < 3 && rrow < nrows;
+        pc_gate2[k] = gate == 2;
+        pc_lds[k] = ((gate < 3 ? gate : 0) * RM + rrow) * UW + 8 * quarter;
+        pc_shadow[k] = (size_t)(row0 + rrow) * T * G + (size_t)(gate < 3 ? gate : 0) * H + j0 + 8 * quarter;
+    }
+    // cell operands of step gmax - 1; step t - 1's are requested during step t
+    float s_r, s_z, s_n, s_hn, hprev, gout;
+    {
+        const int t0 = gmax > 0 ? gmax - 1 : 0;
+        const float* sv = p_sv + (size_t)t0 * 4 * H;
+        s_r = sv[0];
+        s_z = sv[H];
+        s_n = sv[2 * H];
+        s_hn = sv[3 * H];
+        hprev = p_h[(size_t)t0 * H];
+        gout = p_g[(size_t)t0 * H];
+    }
+    __syncthreads();
+
+    for (int t = gmax - 1; t >= -1; --t) {
+        const bool need_mm = t + 1 < gmax;               // row t + 1 holds gradients of a live step
+        u32x4 raw[KS];
+        if (need_mm) {
+            if (wave == 0 && !gp_wait_flags(flags, n_vslots, (unsigned)(gmax - t - 1), lane)) s_abort = 1;
+            gp_lds_barrier();
+            if (s_abort) {
+                if (tid == 0) __hip_atomic_store(status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            const unsigned off = ((t + 1) & 1) * par_bytes + (unsigned)((li < nrows ? li : 0) * 64);
+#pragma unroll
+            for (int i = 0; i < KS; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ring, off + rd_off[i], 0, 16);
+        }
+        // the next step's cell operands (first touch: HBM latency), queued BEHIND the hand-off loads
+        float s_r1, s_z1, s_n1, s_hn1, hprev1, gout1;
+        {
+            const int t1 = t > 0 ? t - 1 : 0;
+            const float* sv = p_sv + (size_t)t1 * 4 * H;
+            s_r1 = sv[0];
+            s_z1 = sv[H];
+            s_n1 = sv[2 * H];
+            s_hn1 = sv[3 * H];
+            hprev1 = p_h[(size_t)t1 * H];
+            gout1 = p_g[(size_t)t1 * H];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (need_mm) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                f32x4 acc3[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // KS is a multiple of 3
+#pragma unroll
+                for (int i = 0; i < KS; ++i)
+                    acc3[i % 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(raw[i]), fb[u][i], acc3[i % 3], 0, 0, 0);
+                const f32x4 acc = (acc3[0] + acc3[1]) + acc3[2];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave][u][(4 * q + r) * GT + li] = acc[r];
+            }
+            gp_lds_barrier();
+        }
+        {
+            const float dstate = need_mm ? mg_gru_dstate(carry, red[0][eu][ee], red[1][eu][ee], red[2][eu][ee], red[3][eu][ee]) : carry;
+            float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, c = dstate;
+            if (t >= 0 && t < len) {
+                const mg_gru_cell_grad g = mg_gru_cell_bwd(dstate, gout, s_r, s_z, s_n, s_hn, hprev);
+                dr = g.dr; dz = g.dz; dn = g.dn; dnr = g.dnr; c = g.carry;
+            }
+            carry = c;
+            res[0][bl][jl] = dr;
+            res[1][bl][jl] = dz;
+            res[2][bl][jl] = dn;
+            res[3][bl][jl] = dnr;
+            pub[0][bl][jl] = mg_f2bf(dr);
+            pub[1][bl][jl] = mg_f2bf(dz);
+            pub[2][bl][jl] = mg_f2bf(dnr);
+            pub[3][bl][jl] = mg_f2bf(dn);
+        }
+        if (t < 0) {
+            if (mine) dh0[(size_t)b_own * H + j] = carry;
+            break;
+        }
+        gp_lds_barrier();
+        if (wave <= 1) {
+            // wave 0 publishes the slot's 3 R x 64 contiguous bytes of the ring, wave 1 writes the bf16 shadow for the weight-gradient GEMM
+#pragma unroll
+            for (int k = 0; k < PIECES; ++k) {
+                if (pc_ok[k]) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(&pub[0][0][0] + pc_lds[k]);
+                    if (wave == 0) {
+                        const unsigned off = (t & 1) * par_bytes + wr_base + (unsigned)((lane + 64 * k) * 16);
+                        if (one_xcd)
+                            __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 0);
+                        else
+                            __builtin_amdgcn_raw_buffer_store_b128(v, rs_ring, off, 0, 16);
+                    } else {
+                        *reinterpret_cast<u32x4*>(dhproj_bf + pc_shadow[k] + (size_t)t * G) = v;
+                        if (dxproj_bf) {                 // (dr, dz, dn): the n plane differs from the hand-off's dn r
+                            const u32x4 vx = pc_gate2[k] ? *reinterpret_cast<const u32x4*>(&pub[0][0][0] + pc_lds[k] + RM * UW) : v;
+                            *reinterpret_cast<u32x4*>(dxproj_bf + pc_shadow[k] + (size_t)t * G) = vx;
+                        }
+                    }
+                }
+            }
+            if (wave == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) gp_store_flag(flags + slot, (unsigned)(gmax - t), one_xcd);
+            }
+        }
+        if (wave >= 2 && dxproj) {                      // fp32 results (optional): waves 2 and 3 only (see the forward kernel)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int e = (tid - 128) + 128 * half, rb = e >> 5, cj = e & 31;
+                if (rb < nrows) {
+                    const size_t row = (size_t)(row0 + rb) * T + t;
+                    float* dx = dxproj + row * G + j0 + cj;
+                    float* dhp = dhproj + row * G + j0 + cj;
+                    const float dr = res[0][rb][cj], dz = res[1][rb][cj];
+                    dx[0] = dr;  dx[H] = dz;  dx[2 * H] = res[2][rb][cj];
+                    dhp[0] = dr; dhp[H] = dz; dhp[2 * H] = res[3][rb][cj];
+                }
+            }
+        }
+        s_r = s_r1; s_z = s_z1; s_n = s_n1; s_hn = s_hn1;
+        hprev = hprev1; gout = gout1;
+    }
+}
+
 // =====================================================================================================================
 // fp32 parity mode, persistent: the same group / slot scheme with exact-fp32 operands - fp32 hand-off tiles (64 bytes per
 // item and slot), v_mfma_f32_16x16x4_f32 with the launch-per-step kernels' block order (wave w owns the 16-deep blocks
@@ -1063,7 +1291,22 @@ int mg_gru_bwd_persist_bf16(const float* grad_out, const float* grad_hn, const f
         case 3: GP_BWD(MT, 9); break;  \
         default: GP_BWD(MT, 12); break; \
     }
-    if (R <= 16) {
+    // Wide slots (gru_bwd_persist_wide_kernel): 16 groups of at most 8 items, two per XCD - half the hand-off lines per step and slot.
+    // MG_TUNE_GRU_HANDOFF bit 2 (4): the narrow kernel for A/B.
+    const int Rw = (int)mg_ceil_div(B, 2 * GP_GROUPS);
+    if (Rw <= 8 && !(g_mg_tuning[MG_TUNE_GRU_HANDOFF] & 4)) {
+#define GP_BWDW(KS)                                                                                                                          \
+    hipLaunchKernelGGL((gru_bwd_persist_wide_kernel<KS>), dim3(grid), dim3(256), 0, st, grad_out, grad_hn, hstate, saved, w_hh_t_bf, ldt, seq_len, \
+                       B, T, H, Rw, dxproj, dhproj, dhproj_bf, dxproj_bf, dh0, (unsigned*)workspace, (uint16_t*)((char*)workspace + GP_RING_OFFSET),  \
+                       g_mg_tuning[MG_TUNE_GRU_HANDOFF] & 3)
+        switch (H / 128) {
+            case 1: GP_BWDW(3); break;
+            case 2: GP_BWDW(6); break;
+            case 3: GP_BWDW(9); break;
+            default: GP_BWDW(12); break;
+        }
+#undef GP_BWDW
+    } else if (R <= 16) {
         GP_BWD_KS(1)
     } else {
         GP_BWD_KS(2)

@@ -26,7 +26,7 @@ static bool tuning_allowed(int key, int value) {
 #else
     switch (key) {
         case MG_TUNE_FORM: return value == 0 || value == 3 || value == 6 || value == 7 || value == 12 || value == 13 || value == 14 || value == 16;
-        case MG_TUNE_GRU_HANDOFF: return value >= 0 && value <= 3;
+        case MG_TUNE_GRU_HANDOFF: return value >= 0 && value <= 7;
         case MG_TUNE_PERSISTENT: return value >= 0 && value <= 2;
         case MG_TUNE_WGRAD_SPLITS: return value >= 0;
         case MG_TUNE_WGRAD_ORDER: return value >= 0 && value <= 3;

@@ -1264,8 +1264,8 @@ def gru_handoff(request):
     _lib.load().mg_set_tuning(2, 0)
 
 
-@pytest.mark.parametrize('gru_handoff', [0, 1], indirect=True)
-@pytest.mark.parametrize('b,t,hid', [(64, 60, 512), (5, 37, 128), (33, 20, 256), (200, 9, 128), (130, 25, 384)])
+@pytest.mark.parametrize('gru_handoff', [0, 1, 4], indirect=True)          # 4: the backward with 8 groups x 16-unit slots
+@pytest.mark.parametrize('b,t,hid', [(64, 60, 512), (5, 37, 128), (33, 20, 256), (200, 9, 128), (130, 25, 384), (128, 12, 512), (17, 30, 384)])
 def test_gru_persistent_equals_stepwise(b, t, hid, gru_handoff):
     """The one-launch recurrence (gru_persist.hip: W_hh in registers, state handed between workgroups with write-through
     stores and flags) against the launch-per-step kernels on the same inputs: same operands, same summation order and the
