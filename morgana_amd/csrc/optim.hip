@@ -77,6 +77,33 @@ __global__ __launch_bounds__(256) void adam_plan_kernel(float* __restrict__ para
         }
     }
     const float step_size = scalars[0], bc2_sqrt = scalars[1];
+    if (plan.n_slab_srcs == 0) {
+        // No slabs to sum (the recurrent models' eager steps: their weight-gradient launches reduce into `grad` themselves): one element
+        // per thread of the whole workgroup, 256 consecutive elements per pass, no LDS and no barrier - the same arithmetic per element
+        // (the host sizes the grid for 256-element chunks in this case).
+        const int64_t n_chunks = (n + 255) / 256;
+        for (int64_t c = n_chunks - 1 - (int64_t)blockIdx.x; c >= 0; c -= (int64_t)gridDim.x) {
+            const int64_t i = c * 256 + threadIdx.x;
+            if (i >= n) continue;
+            const float g = grad[i];
+            if (plan.clear_grad) grad[i] = 0.f;
+            const mg_adam_out o = mg_adam_update(param[i], g, m[i], v[i], beta1, beta2, eps, weight_decay, step_size, bc2_sqrt, grad_scale);
+            const float w = o.p;
+            param[i] = w;
+            m[i] = o.m;
+            v[i] = o.v;
+            for (int k = 0; k < plan.n_shadows; ++k) {
+                const mg_adam_shadow sh = plan.shadows[k];
+                const int64_t j = i - sh.offset;
+                if (j < 0 || j >= (int64_t)sh.rows * sh.cols) continue;
+                const unsigned r = (unsigned)j / (unsigned)sh.cols, cc = (unsigned)j - r * (unsigned)sh.cols;
+                const uint16_t b = mg_f2bf(w);
+                if (sh.dst) sh.dst[(size_t)r * sh.ldd + cc] = b;
+                if (sh.dst_t) sh.dst_t[(size_t)cc * sh.ldt + r] = b;
+            }
+        }
+        return;
+    }
     const int e = threadIdx.x & 15, p = threadIdx.x >> 4;
     // Blocks walk the flat buffer from its END: the last parameters are the fused tail's (their source has 168-256 slabs, five times
     // the loads of the others), and the blocks that are dispatched first should be the ones that take longest.
@@ -364,7 +391,7 @@ int mg_adam_step_plan_f32(float* param, float* grad, float* exp_avg, float* exp_
         MG_CHECK_ARG((t.frames == 0 && t.n == 0) || n > 0, "mg_adam_step_plan_f32: a deferred tail needs a launch (n = 0)");
     }
     if (n == 0) return MG_OK;
-    hipLaunchKernelGGL(adam_plan_kernel, dim3((unsigned)mg_ceil_div(n, 64)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
+    hipLaunchKernelGGL(adam_plan_kernel, dim3((unsigned)mg_ceil_div(n, plan->n_slab_srcs == 0 ? 256 : 64)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
                        beta1, beta2, eps, weight_decay, scalars, grad_scale, *plan);
     MG_CHECK_LAUNCH("mg_adam_step_plan_f32");
     return MG_OK;
