@@ -217,7 +217,7 @@ def test_product_library_holds_no_experiments():
     header = open(os.path.join(REPO, 'include', 'morgana_hip.h')).read()
     assert 'results garbage' not in header                                    # no documented value with invalid results
     lib = _lib.load()
-    for key, value in ((0, 4), (0, 8), (0, 15), (0, 100), (0, 32), (1, 1), (7, 64), (7, 1), (7, 70), (9, 0), (-1, 0)):
+    for key, value in ((0, 4), (0, 8), (0, 15), (0, 100), (0, 32), (1, 1), (7, 64), (7, 1), (7, 70), (2, 8), (9, 0), (-1, 0)):
         assert lib.mg_set_tuning(key, value) != 0, (key, value)
-    for key, value in ((0, 13), (0, 12), (0, 0), (2, 1), (2, 0), (3, 1), (3, 0), (4, 48), (4, 0), (5, 2), (5, 0), (6, 1), (6, 0), (7, 65), (7, 0)):
+    for key, value in ((0, 13), (0, 12), (0, 0), (2, 1), (2, 0), (3, 1), (3, 0), (4, 48), (4, 0), (5, 2), (5, 0), (6, 1), (6, 0), (7, 65), (7, 91), (2, 4), (7, 0), (2, 0)):
         assert lib.mg_set_tuning(key, value) == 0, (key, value)
