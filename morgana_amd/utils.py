@@ -115,10 +115,11 @@ class PhoneTable(object):
 
 PACKED_FRAMES = os.environ.get('MORGANA_PACKED_FRAMES', '1') != '0'
 # The persistent GRU forward can write the bf16 copy of its output itself (mg_gru_fwd_persist_out_bf16), which saves the cast pass of the
-# Linear run behind the wrapper (C4 37 us, C5 98 us).  MEASURED (round 4, same-box A/B) and OFF: the 2-byte stores ride in the
-# recurrence's per-step store traffic and cost the chain more than the cast saved - C5 6.541 / 6.546 against 6.486 / 6.510 ms, C4
-# 3.445 / 3.358 against 3.394 / 3.401.
-OUT_SHADOW = os.environ.get('MORGANA_OUT_SHADOW', '0') != '0'
+# Linear run behind the wrapper (C4 37 us, C5 98 us).  MEASURED twice (round 4, same-box A/B): with the recurrence's computing waves
+# storing their own results the 2-byte stores cost the chain more than the cast saved (C5 6.541 / 6.546 against 6.486 / 6.510 ms, C4
+# 3.445 / 3.358 against 3.394 / 3.401) and it was off; since the forward kernel has dedicated storing waves (R4.9) they ride there:
+# C4 3.308 / 3.301 against 3.336 / 3.334 ms, C5 6.398 / 6.423 against 6.398 / 6.419 - ON.
+OUT_SHADOW = os.environ.get('MORGANA_OUT_SHADOW', '1') != '0'
 
 
 # The first Linear of the 609-input models (cat(repeated phone rows, 9 frame counters), models/RNN_SPSS.py:76-81) with the labels' 600

@@ -368,6 +368,28 @@ def test_two_ranks_on_one_gpu_equal_the_global_batch(tmp_path, precision, form, 
     np.testing.assert_allclose(got['losses'], want_losses, rtol=tol)
 
 
+@pytest.mark.parametrize('ragged', [False, True])
+def test_recurrence_output_shadow_equals_the_cast_pass(ragged, monkeypatch):
+    """utils.OUT_SHADOW (default on): the persistent GRU forward writes the bf16 copy of its output itself
+    (mg_gru_fwd_persist_out_bf16) and the Linear run behind the wrapper takes it as its operand instead of casting [B, T, H] in a
+    pass of its own.  The copy is bf16(out) element for element, so the loss, the prediction and every gradient are EQUAL."""
+    feats = synthetic.make_batch(16, (150, 400) if ragged else 300, out_dim=80, target_name='mcep', seed=11)
+    state = synthetic.rnn_spss_state()
+    results = []
+    for shadow in (True, False):
+        monkeypatch.setattr(utils, 'OUT_SHADOW', shadow)
+        model = _load_state(models.RNNSPSS(precision='bf16').to(DEV), state)
+        loss, out = model(data.to_device(feats, DEV))
+        loss.backward()
+        ops.check_persistent_status()
+        results.append((loss.detach().clone(), out['pred_norm_mcep'].detach().clone(),
+                        {n: p.grad.detach().clone() for n, p in model.named_parameters()}))
+    (loss_s, pred_s, grads_s), (loss_c, pred_c, grads_c) = results
+    assert torch.equal(loss_s, loss_c) and torch.equal(pred_s, pred_c)
+    for name in grads_c:
+        assert torch.equal(grads_s[name], grads_c[name]), name
+
+
 @pytest.mark.parametrize('which', ['rnn_spss', 'rnn_spss_ragged', 'lstm'])
 def test_direct_gradients_equal_autograd_accumulation(which):
     """Inside functional.backward the row-wise, GRU and LSTM-stack layers outside the fused stack add their weight gradients and bias
