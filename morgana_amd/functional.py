@@ -1139,13 +1139,16 @@ class GRUFn(torch.autograd.Function):
         # the operand of a Linear layer behind the wrapper (gru_shadow_ok says when the launch that writes it will run)
         if out_bf is not None and not gru_shadow_ok(precision, b, t, hid):
             raise ValueError('GRUFn: out_bf needs the persistent bf16 recurrence')
+        # bf16 operands of W_hh (plain for this launch, transposed for the backward's): copies that live on the parameter, kept current
+        # by the optimiser's update kernel (ops.param_shadows) - no cast launch per step and direction
+        w_hh_bf = ops.param_shadows([w_hh], want_t=(0,))[0][0] if (ctx.bf16_recurrence and hid == ops.pad_ld(hid)) else None
         if in_kernel:
             # the persistent recurrence reads the projected table through the row map itself: no (B, T, 3H) copy of its rows
             out, hstate, saved, hstate_bf = ops.gru_fwd_bf16(xproj.contiguous(), w_hh.contiguous(), b_hh.contiguous(), seq_len, h0, b, t, hid,
-                                                             xrows=rows, out_bf=out_bf)
+                                                             xrows=rows, out_bf=out_bf, w_bf=w_hh_bf)
         elif ctx.bf16_recurrence:
             out, hstate, saved, hstate_bf = ops.gru_fwd_bf16(xproj.view(b, t, 3 * hid), w_hh.contiguous(), b_hh.contiguous(),
-                                                             seq_len, h0, b, t, hid, out_bf=out_bf)
+                                                             seq_len, h0, b, t, hid, out_bf=out_bf, w_bf=w_hh_bf)
         else:
             out, hstate, saved = ops.gru_fwd(xproj.view(b, t, 3 * hid), w_hh.contiguous(), b_hh.contiguous(), seq_len, h0,
                                              b, t, hid)
@@ -1166,9 +1169,11 @@ class GRUFn(torch.autograd.Function):
         m = b * t
         if ctx.bf16_recurrence and ops.gru_persist_ok(b, t, hid):
             # persistent recurrence: only the bf16 shadows of the gate gradients are written (the GEMMs below take bf16)
-            dxproj_bf, dhproj_bf, dh0 = ops.gru_bwd_bf16(g_out, g_hn, hstate, saved, w_hh, seq_len, b, t, hid, shadows_only=True)
+            wt_bf = ops.param_shadows([ctx.param_refs[1]], want_t=(0,))[1][0] if hid == ops.pad_ld(hid) else None
+            dxproj_bf, dhproj_bf, dh0 = ops.gru_bwd_bf16(g_out, g_hn, hstate, saved, w_hh, seq_len, b, t, hid, shadows_only=True, wt_bf=wt_bf)
         elif ctx.bf16_recurrence:
-            dxproj, dhproj, dh0, dhproj_bf = ops.gru_bwd_bf16(g_out, g_hn, hstate, saved, w_hh, seq_len, b, t, hid)
+            wt_bf = ops.param_shadows([ctx.param_refs[1]], want_t=(0,))[1][0] if hid == ops.pad_ld(hid) else None
+            dxproj, dhproj, dh0, dhproj_bf = ops.gru_bwd_bf16(g_out, g_hn, hstate, saved, w_hh, seq_len, b, t, hid, wt_bf=wt_bf)
             dxp2, dhp2 = dxproj.view(m, 3 * hid), dhproj.view(m, 3 * hid)
         else:
             dxproj, dhproj, dh0 = ops.gru_bwd(g_out, g_hn, hstate, saved, w_hh, seq_len, b, t, hid)

@@ -1214,12 +1214,13 @@ def check_persistent_status():
         _lib.check(lib.mg_gru_persist_status(_p(ws), ctypes.c_void_p(key[1])), 'mg_gru_persist_status')
 
 
-def gru_fwd_bf16(xproj, w_hh, b_hh, seq_len, h0, b, t, h, persistent=None, xrows=None, out_bf=None):
+def gru_fwd_bf16(xproj, w_hh, b_hh, seq_len, h0, b, t, h, persistent=None, xrows=None, out_bf=None, w_bf=None):
     """gru_fwd with bf16 matmul operands.  Returns (out, hstate, saved, hstate_bf (b,t+1,h) bf16).
     out_bf (persistent launch only): a (b, t, h) bf16 tensor that receives the bf16 copy of ``out`` from the recurrence itself.
     persistent: one launch for all steps (None = whenever the shape is covered).
     xrows (persistent launch only): int32 (b, t) row map - ``xproj`` is then a table (rows, 3h) and frame (b, t) takes row
-    ``xrows[b, t]`` of it (mg_gru_fwd_persist_rows_bf16: the repetition applied inside the recurrence)."""
+    ``xrows[b, t]`` of it (mg_gru_fwd_persist_rows_bf16: the repetition applied inside the recurrence).
+    w_bf: the (3h, pad_ld(h)) bf16 copy of ``w_hh`` if the caller holds a current one (param_shadows); cast here otherwise."""
     lib = _lib.load()
     if persistent is None:
         persistent = gru_persist_ok(b, t, h)
@@ -1236,7 +1237,8 @@ def gru_fwd_bf16(xproj, w_hh, b_hh, seq_len, h0, b, t, h, persistent=None, xrows
     else:
         hstate[:, 0].copy_(h0.reshape(b, h))
         hstate_bf[:, 0].copy_(h0.reshape(b, h))
-    w_bf = cast_pad_bf16(w_hh)
+    if w_bf is None or w_bf.dtype != torch.bfloat16 or w_bf.shape[0] != 3 * h or w_bf.shape[1] < h or not w_bf.is_contiguous():
+        w_bf = cast_pad_bf16(w_hh)
     out = torch.empty((b, t, h), dtype=torch.float32, device=dev)
     saved = torch.empty((b, t, 4 * h), dtype=torch.float32, device=dev)
     if persistent:
@@ -1258,18 +1260,22 @@ def gru_fwd_bf16(xproj, w_hh, b_hh, seq_len, h0, b, t, h, persistent=None, xrows
     return out, hstate, saved, hstate_bf
 
 
-def gru_bwd_bf16(grad_out, grad_hn, hstate, saved, w_hh, seq_len, b, t, h, persistent=None, shadows_only=False):
+def gru_bwd_bf16(grad_out, grad_hn, hstate, saved, w_hh, seq_len, b, t, h, persistent=None, shadows_only=False, wt_bf=None):
     """gru_bwd with bf16 matmul operands.  Returns (dxproj, dhproj, dh0, dhproj_bf (b,t,3h) bf16).
-    shadows_only (persistent kernel only): returns (dxproj_bf, dhproj_bf, dh0) and does not write the fp32 arrays."""
+    shadows_only (persistent kernel only): returns (dxproj_bf, dhproj_bf, dh0) and does not write the fp32 arrays.
+    wt_bf: the (h, pad_ld(3h)) bf16 transpose of ``w_hh`` if the caller holds a current one (param_shadows); cast here otherwise."""
     lib = _lib.load()
     if persistent is None:
         persistent = gru_persist_ok(b, t, h)
     dev = grad_out.device
+    if wt_bf is not None and (wt_bf.dtype != torch.bfloat16 or wt_bf.shape[0] != h or wt_bf.shape[1] < 3 * h or not wt_bf.is_contiguous()):
+        wt_bf = None
     if shadows_only and persistent:
         dxproj_bf = torch.empty((b, t, 3 * h), dtype=torch.bfloat16, device=dev)
         dhproj_bf = torch.empty((b, t, 3 * h), dtype=torch.bfloat16, device=dev)
         dh0 = torch.empty((b, h), dtype=torch.float32, device=dev)
-        wt_bf = cast_transpose_bf16(w_hh)
+        if wt_bf is None:
+            wt_bf = cast_transpose_bf16(w_hh)
         ws = _persist_workspace(dev, b, h)
         _lib.check(lib.mg_gru_bwd_persist_bf16(_p(grad_out), _p(grad_hn), _p(hstate), _p(saved), _p(wt_bf), wt_bf.shape[1], _p(seq_len),
                                                b, t, h, None, None, _p(dhproj_bf), _p(dxproj_bf), _p(dh0), _p(ws), ws.numel(),
@@ -1279,7 +1285,8 @@ def gru_bwd_bf16(grad_out, grad_hn, hstate, saved, w_hh, seq_len, b, t, h, persi
     dhproj = torch.empty((b, t, 3 * h), dtype=torch.float32, device=dev)
     dhproj_bf = torch.empty((b, t, 3 * h), dtype=torch.bfloat16, device=dev)
     dh0 = torch.empty((b, h), dtype=torch.float32, device=dev)
-    wt_bf = cast_transpose_bf16(w_hh)                              # (h, 3h)
+    if wt_bf is None:
+        wt_bf = cast_transpose_bf16(w_hh)                          # (h, 3h)
     if persistent:
         ws = _persist_workspace(dev, b, h)
         _lib.check(lib.mg_gru_bwd_persist_bf16(_p(grad_out), _p(grad_hn), _p(hstate), _p(saved), _p(wt_bf), wt_bf.shape[1], _p(seq_len),
