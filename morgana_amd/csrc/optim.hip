@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ param
 __global__ __launch_bounds__(256) void adam_plan_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m,
                                                         float* __restrict__ v, int64_t n, float beta1, float beta2, float eps,
                                                         float weight_decay, const float* __restrict__ scalars, float grad_scale,
-                                                        mg_adam_plan plan) {
+                                                        mg_adam_plan plan, int wide_chunks) {
     __shared__ float part[16][68];
     // the forward's deferred tail (mg_adam_tail): the first blocks repeat the prediction / form the loss before their share of the update
     if (plan.tail.frames > 0 || plan.tail.n > 0) {
@@ -77,39 +77,27 @@ __global__ __launch_bounds__(256) void adam_plan_kernel(float* __restrict__ para
         }
     }
     const float step_size = scalars[0], bc2_sqrt = scalars[1];
-    if (plan.n_slab_srcs == 0) {
-        // No slabs to sum (the recurrent models' eager steps: their weight-gradient launches reduce into `grad` themselves): one element
-        // per thread of the whole workgroup, 256 consecutive elements per pass, no LDS and no barrier - the same arithmetic per element
-        // (the host sizes the grid for 256-element chunks in this case).
-        const int64_t n_chunks = (n + 255) / 256;
-        for (int64_t c = n_chunks - 1 - (int64_t)blockIdx.x; c >= 0; c -= (int64_t)gridDim.x) {
-            const int64_t i = c * 256 + threadIdx.x;
-            if (i >= n) continue;
-            const float g = grad[i];
-            if (plan.clear_grad) grad[i] = 0.f;
-            const mg_adam_out o = mg_adam_update(param[i], g, m[i], v[i], beta1, beta2, eps, weight_decay, step_size, bc2_sqrt, grad_scale);
-            const float w = o.p;
-            param[i] = w;
-            m[i] = o.m;
-            v[i] = o.v;
-            for (int k = 0; k < plan.n_shadows; ++k) {
-                const mg_adam_shadow sh = plan.shadows[k];
-                const int64_t j = i - sh.offset;
-                if (j < 0 || j >= (int64_t)sh.rows * sh.cols) continue;
-                const unsigned r = (unsigned)j / (unsigned)sh.cols, cc = (unsigned)j - r * (unsigned)sh.cols;
-                const uint16_t b = mg_f2bf(w);
-                if (sh.dst) sh.dst[(size_t)r * sh.ldd + cc] = b;
-                if (sh.dst_t) sh.dst_t[(size_t)cc * sh.ldt + r] = b;
-            }
+    // one element: the update, the gradient zeroed behind the read, the bf16 operand copies refreshed
+    auto update = [&](int64_t i, float g) {
+        if (plan.clear_grad) grad[i] = 0.f;
+        const mg_adam_out o = mg_adam_update(param[i], g, m[i], v[i], beta1, beta2, eps, weight_decay, step_size, bc2_sqrt, grad_scale);
+        const float w = o.p;
+        param[i] = w;
+        m[i] = o.m;
+        v[i] = o.v;
+        for (int k = 0; k < plan.n_shadows; ++k) {
+            const mg_adam_shadow sh = plan.shadows[k];
+            const int64_t j = i - sh.offset;
+            if (j < 0 || j >= (int64_t)sh.rows * sh.cols) continue;
+            const unsigned r = (unsigned)j / (unsigned)sh.cols, cc = (unsigned)j - r * (unsigned)sh.cols;     // rows * cols < 2^31 (checked)
+            const uint16_t b = mg_f2bf(w);
+            if (sh.dst) sh.dst[(size_t)r * sh.ldd + cc] = b;
+            if (sh.dst_t) sh.dst_t[(size_t)cc * sh.ldt + r] = b;
         }
-        return;
-    }
+    };
     const int e = threadIdx.x & 15, p = threadIdx.x >> 4;
-    // Blocks walk the flat buffer from its END: the last parameters are the fused tail's (their source has 168-256 slabs, five times
-    // the loads of the others), and the blocks that are dispatched first should be the ones that take longest.
-    const int64_t n_chunks = (n + 63) / 64;
-    for (int64_t c = n_chunks - 1 - (int64_t)blockIdx.x; c >= 0; c -= (int64_t)gridDim.x) {
-        const int64_t base = c * 64;
+    // 64 consecutive elements with slab sources to sum (all threads: barriers inside)
+    auto slab_chunk = [&](int64_t base) {
         const int64_t i0 = base + 4 * e;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         bool any = false;
@@ -147,25 +135,36 @@ __global__ __launch_bounds__(256) void adam_plan_kernel(float* __restrict__ para
 #pragma unroll
                     for (int q = 0; q < 16; ++q) g += part[q][threadIdx.x];
                 }
-                if (plan.clear_grad) grad[i] = 0.f;
-                const mg_adam_out o = mg_adam_update(param[i], g, m[i], v[i], beta1, beta2, eps, weight_decay, step_size, bc2_sqrt, grad_scale);
-                const float w = o.p;
-                param[i] = w;
-                m[i] = o.m;
-                v[i] = o.v;
-                for (int k = 0; k < plan.n_shadows; ++k) {
-                    const mg_adam_shadow sh = plan.shadows[k];
-                    const int64_t j = i - sh.offset;
-                    if (j < 0 || j >= (int64_t)sh.rows * sh.cols) continue;
-                    const unsigned r = (unsigned)j / (unsigned)sh.cols, cc = (unsigned)j - r * (unsigned)sh.cols;     // rows * cols < 2^31 (checked)
-                    const uint16_t b = mg_f2bf(w);
-                    if (sh.dst) sh.dst[(size_t)r * sh.ldd + cc] = b;
-                    if (sh.dst_t) sh.dst_t[(size_t)cc * sh.ldt + r] = b;
-                }
+                update(i, g);
             }
         }
         if (block_any) __syncthreads();
+    };
+    if (wide_chunks) {
+        // Few or no slabs to sum (the recurrent models' steps: their large weight-gradient launches reduce into `grad` themselves): a
+        // workgroup takes 256 consecutive elements - one per thread, no LDS and no barrier, where no slab source reaches into them
+        // (it was one wave of the workgroup per 64 elements: 274 us for the LSTM model's 17.5 M parameters, now 142), as four 64-element
+        // chunks of the summing form where one does.  The same arithmetic per element either way.
+        const int64_t n_chunks = (n + 255) / 256;
+        for (int64_t c = n_chunks - 1 - (int64_t)blockIdx.x; c >= 0; c -= (int64_t)gridDim.x) {
+            const int64_t sbase = c * 256;
+            bool hit = false;
+            for (int k = 0; k < plan.n_slab_srcs; ++k)
+                if (sbase < plan.slabs[k].begin + plan.slabs[k].count && sbase + 256 > plan.slabs[k].begin) hit = true;
+            if (!hit) {
+                const int64_t i = sbase + threadIdx.x;
+                if (i < n) update(i, grad[i]);
+                continue;
+            }
+            for (int sub = 3; sub >= 0; --sub)
+                if (sbase + 64 * sub < n) slab_chunk(sbase + 64 * sub);
+        }
+        return;
     }
+    // Blocks walk the flat buffer from its END: the last parameters are the fused tail's (their source has 168-256 slabs, five times
+    // the loads of the others), and the blocks that are dispatched first should be the ones that take longest.
+    const int64_t n_chunks = (n + 63) / 64;
+    for (int64_t c = n_chunks - 1 - (int64_t)blockIdx.x; c >= 0; c -= (int64_t)gridDim.x) slab_chunk(c * 64);
 }
 
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ shadow, const float* __restrict__ param, int64_t n, float one_minus_decay) {
@@ -391,8 +390,12 @@ int mg_adam_step_plan_f32(float* param, float* grad, float* exp_avg, float* exp_
         MG_CHECK_ARG((t.frames == 0 && t.n == 0) || n > 0, "mg_adam_step_plan_f32: a deferred tail needs a launch (n = 0)");
     }
     if (n == 0) return MG_OK;
-    hipLaunchKernelGGL(adam_plan_kernel, dim3((unsigned)mg_ceil_div(n, plan->n_slab_srcs == 0 ? 256 : 64)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
-                       beta1, beta2, eps, weight_decay, scalars, grad_scale, *plan);
+    // 256-element chunks when slab sources cover less than half of the buffer (adam_plan_kernel: wide_chunks)
+    int64_t covered = 0;
+    for (int k = 0; k < plan->n_slab_srcs; ++k) covered += plan->slabs[k].count;
+    const int wide = 2 * covered < n ? 1 : 0;
+    hipLaunchKernelGGL(adam_plan_kernel, dim3((unsigned)mg_ceil_div(n, wide ? 256 : 64)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, n, beta1, beta2, eps, weight_decay, scalars, grad_scale, *plan, wide);
     MG_CHECK_LAUNCH("mg_adam_step_plan_f32");
     return MG_OK;
 }
