@@ -558,6 +558,10 @@ def bf16x3_legs(dev, features, state_dict, steps, frames_per_step):
         try:
             model = models.F0Model(precision='bf16x3', phone_rate=phone_rate).to(dev)
             model.load_state_dict(state_dict)
+            # the loader's half of the mode, as ExperimentBuilder.train_epoch asks for it (DeviceBatches.use_bf16_tables): the phone
+            # table's [hi | lo] pair planes, made once per batch
+            for name in model.bf16_table_features():
+                data.add_bf16_table(features, name)
             opt = optim.Adam(model.parameters(), lr=0.01, fused_loop=True)
             n = max(k for k in range(1, min(10, max(steps // 2, 1)) + 1) if steps % k == 0)
             step = graphs.GraphedTrainStep(model, opt, features, steps_per_replay=n)

@@ -65,7 +65,10 @@ const char* mg_last_error(void);
 #define MG_TUNE_LSTM_BWD_STACK 6 /* LSTM stack wavefronts, hidden units per slot: 0 = backward 32 where they fit (one workgroup per CU),
                                  * forward 16 (two per CU); bit 0 (1) = backward 16; bit 1 (2) = forward 32 (same bits, measured slower) */
 #define MG_TUNE_AB 7            /* shared-grid launches as their separate launches, half-width tiles off: 65 = mg_linear_wgrad_dgrad_bf16 as
-                                 * two launches, 66 = mg_phone_front_linear_fwd_bf16 as two, 91 = 128 x 512 tiles for the 512-wide weight
+                                 * two launches, 66 = mg_phone_front_linear_fwd_bf16 as two, 89 = the pair-plane forward GEMM (mg_phone_front_linear_fwd_x3) as three passes
+                                 * over the plane (default: all four planes' k-tile per stage), 90 = the pair-plane weight gradients
+                                 * (mg_linear_wgrad_slabs_x3) as three walks over their rows (default: one walk, all four planes per
+                                 * stage - the same products in another order), 91 = 128 x 512 tiles for the 512-wide weight
                                  * gradient where the square 256 x 256 tile is the default (N a multiple of 256), 92 = 128 x 640 tiles for the 640-wide weight
                                  * gradient at phone-rate rows, 93 = 128 x 512 tiles for the 512-wide one, 94 = mg_phone_front_linear_fwd_bf16 with the
                                  * front's jobs as block jobs and 256-row tiles (round 2's form), 95 = wave jobs but 256-row tiles,
@@ -461,7 +464,8 @@ typedef struct {
     int cols, lds;
     uint16_t* dst;    /* device, bf16, 16-byte aligned: [rows, 3 ldp], or [cols, 3 ldp] when transposed */
     int ldp;          /* columns per plane: multiple of 8, >= cols (>= rows when transposed) */
-    int order;        /* 0: hi | hi | lo;  1: hi | lo | hi;  2: two planes [hi ; lo] of [plane_rows, ldp];  3: [hi ; hi ; lo];  4: [hi ; lo ; hi] */
+    int order;        /* 0: hi | hi | lo;  1: hi | lo | hi;  2: two planes [hi ; lo] of [plane_rows, ldp];  3: [hi ; hi ; lo];  4: [hi ; lo ; hi];
+                       * 5: PAIR PLANES hi | lo, dst bf16 [rows, 2 ldp] ([cols, 2 ldp] with transpose): the operands of the mg_*_x3 entry points */
     int transpose;
     int64_t plane_rows; /* orders 2-4: rows of one plane in dst (>= rows; the caller owns the rows behind the split, e.g. zeros); 0 = rows */
     const float* sig; /* optional (not transposed): fp32 [rows, cols] (ldsig) sigmoid outputs s - the split is taken of src * s * (1 - s):
@@ -472,6 +476,51 @@ typedef struct {
     int colsum_blocks;
 } mg_split3_desc;
 int mg_split3_bf16(const mg_split3_desc* descs, int count, void* stream);
+
+/* ---- The FUSED step of precision mode 'bf16x3' on PAIR PLANES -------------------------------------------------------------------
+ * Reference arithmetic is fp32 end to end (/root/reference/morgana/experiment_builder.py:262-263, /root/reference/morgana/data.py:127);
+ * x = hi + lo with hi = bf16(x), lo = bf16(x - hi), x w ~= hi hi + hi lo + lo hi, every product exact in the fp32 accumulator of a bf16
+ * MFMA.  A pair-plane operand is bf16 [rows, ld] with ld = 2 ldp: columns [0, ldp) = hi, [ldp, 2 ldp) = lo (ldp a multiple of 64,
+ * padding columns zero) - mg_split3_bf16 order 5 writes one, the update kernel keeps the weights' pairs current (mg_adam_shadow.pair),
+ * and the entry points below write their outputs split in their epilogues, so a training step of the README F0Model at phone rate
+ * (/root/reference/README.rst:65-73 behind /root/reference/morgana/utils.py:175-228) launches no split pass and no cast.  The tile programs
+ * are those of bf16 mode with the contraction run three times over the plane pairs (csrc/gemm_bf16_big.hip, "pair planes").
+ *
+ *  mg_phone_front_linear_fwd_x3   mg_phone_front + Y = split(act(A W^T + b)): A [M, lda = 2 pa] the phone table's pair, W [N, ldw = 2 pw]
+ *                     (pa, pw >= K rounded up to 64; N a multiple of 256), Y bf16 [M, ldy = 2 N] the activation's pair.  One grid where
+ *                     the GEMM leaves CUs idle (as mg_phone_front_linear_fwd_bf16), else two launches.  dur == NULL: the GEMM alone.
+ *  mg_linear_fwd_x3_f32  Y f32 [M, N] = act(A W^T + b) from pair-plane operands (N a multiple of 128, ldy == N).  parts == 3 (act none):
+ *                     Y is [3, M, N] - the partial sums of the three products hi hi (+ b), hi lo, lo hi from three sets of workgroups
+ *                     (a few-tile GEMM fills the chip with chains a third as long); the consumer adds them (mg_f0_tail_rows_x3 z_parts).
+ *  mg_f0_tail_rows_x3  mg_f0_tail_rows_f32 with Z2 f32 [z_parts, M, ldz] given as z_parts (1 or 3) partial sums to add, dZ2 as a pair
+ *                     [M, lddz >= 256] and the 128-wide layer's bias gradient (the column sums of
+ *                     the fp32 dZ2) in front of the tail's gradients: slabs of MG_F0_TAIL_X3_SLAB floats = db2 [128] | dW3 [32 x 128] |
+ *                     db3 [32] | dW4 [32] | db4 | loss | 2 unused, *n_slabs of them *stride floats apart in `workspace`
+ *                     (mg_f0_tail_rows_x3_workspace_bytes(M)), reduced into grads_out [MG_F0_TAIL_X3_SLAB] when that is not NULL.
+ *  mg_linear_wgrad_dgrad_x3  the 512 -> 128 layer's backward as ONE grid: dW slabs (N K floats used of each `*stride`, no bias sums) from
+ *                     dY pair [M, lddy = 2 * 128] and A = H pair [M, lda = 2 * 512], and dX pair [M, lddx = 2 K] = split((dY W) * H (1 - H)),
+ *                     H = hi + lo; `colsum` f32 receives *n_colsum slabs of K floats whose ordered sum is the column sum of the fp32 dX
+ *                     (the bias gradient of the layer below; 2 ceil(M / 256) slabs: mg_linear_wgrad_dgrad_x3_colsum_floats(M, K) floats).
+ *                     WT [K, ldwt = 2 * 128] = the pair of W^T.  N == 128, K == 512 only (MG_EINVAL otherwise).
+ *  mg_linear_wgrad_slabs_x3  mg_linear_wgrad_slabs_bf16 on pairs: dY [M, lddy = 2 pn], A [M, lda = 2 pk], slabs of N K floats (+ N unused,
+ *                     the bf16 layout's stride), no bias sums; the wide-tile shapes only (pk 640 or 512). */
+#define MG_F0_TAIL_X3_SLAB 4292
+int mg_phone_front_linear_fwd_x3(const int64_t* dur, int B, int P, int T, const float* target, const int64_t* seq_len, int extra,
+                                 int32_t* rows32, int32_t* rows_mapped, int pad_row, int32_t* seg_start, int32_t* seg_end, float* ybar,
+                                 float* weight, void* workspace, size_t workspace_bytes, const uint16_t* A, int lda, int64_t M, int K,
+                                 const uint16_t* W, int ldw, const float* bias, int N, uint16_t* Y, int ldy, int act, void* stream);
+int mg_linear_fwd_x3_f32(const uint16_t* A, int lda, int64_t M, int K, const uint16_t* W, int ldw, const float* bias, int N, float* Y,
+                         int ldy, int act, int parts, void* stream);
+size_t mg_f0_tail_rows_x3_workspace_bytes(int64_t M);
+int mg_f0_tail_rows_x3(const float* Z2, int ldz, int z_parts, const float* W3, const float* b3, const float* W4, const float* b4,
+                       const float* ybar, const float* weight, int64_t M, float* pred, uint16_t* dZ2, int lddz, float* grads_out,
+                       void* workspace, size_t workspace_bytes, int* n_slabs, int64_t* stride, void* stream);
+size_t mg_linear_wgrad_dgrad_x3_colsum_floats(int64_t M, int K);
+int mg_linear_wgrad_dgrad_x3(const uint16_t* dY, int lddy, const uint16_t* A, int lda, int64_t M, int N, int K, const uint16_t* WT, int ldwt,
+                             uint16_t* dX, int lddx, void* workspace, size_t workspace_bytes, int* n_slabs, int64_t* stride, float* colsum,
+                             size_t colsum_floats, int* n_colsum, void* stream);
+int mg_linear_wgrad_slabs_x3(const uint16_t* dY, int lddy, const uint16_t* A, int lda, int64_t M, int N, int K, void* workspace,
+                             size_t workspace_bytes, int* n_slabs, int64_t* stride, void* stream);
 /* Active dropout (nn.Dropout(p) of the shipped models in training mode: /root/reference/models/RNN_SPSS.py:19,34,40,
  * /root/reference/models/f0_test_model.py:22,31-43; torch.nn.functional.dropout semantics: y = x * keep / (1 - p), keep ~ Bernoulli(1 - p)
  * per element).  The mask is a function of (seed, site, *counter, element index) through Philox4x32-10 and is never stored: the
@@ -872,6 +921,8 @@ typedef struct {
     int ldd;
     uint16_t* dst_t;
     int ldt;
+    int pair;       /* != 0: dst / dst_t are [hi | lo] PAIR PLANES (precision 'bf16x3', the mg_*_x3 entry points): ldd / ldt = the row stride
+                     * of both planes, hi = bf16(w) at column c, lo = bf16(w - hi) at column ldd / 2 + c (ldt / 2 + r for the transpose) */
 } mg_adam_shadow;
 /* What a step captured whole into a HIP graph leaves of its FORWARD for the update's launch (nothing can observe the step half done
  * inside a replay): the per-phone prediction repeated to frames (out[f] = table[rows[f]], `frames` of them; 0 = none) and the loss =

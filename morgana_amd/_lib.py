@@ -78,6 +78,18 @@ SIGNATURES = {
     'mg_cast_params_bf16': (c_int, [c_void_p, c_int, c_void_p]),
     'mg_cast_bf16_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
     'mg_split3_bf16': (c_int, [c_void_p, c_int, c_void_p]),
+    'mg_phone_front_linear_fwd_x3': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int64, c_int, c_void_p,
+                                             c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    'mg_linear_fwd_x3_f32': (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'mg_f0_tail_rows_x3_workspace_bytes': (c_size_t, [c_int64]),
+    'mg_f0_tail_rows_x3': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                   c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    'mg_linear_wgrad_dgrad_x3_colsum_floats': (c_size_t, [c_int64, c_int]),
+    'mg_linear_wgrad_dgrad_x3': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
+                                         c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    'mg_linear_wgrad_slabs_x3': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p,
+                                         c_void_p]),
     'mg_dropout': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, ctypes.c_uint64, ctypes.c_uint32, c_void_p, c_void_p]),
     'mg_dropout_advance': (c_int, [c_void_p, c_void_p, c_void_p]),
     'mg_philox4x32_10': (None, [c_void_p, c_void_p, c_void_p]),
@@ -275,7 +287,7 @@ class AdamSlabSrc(ctypes.Structure):
 class AdamShadow(ctypes.Structure):
     """mg_adam_shadow of include/morgana_hip.h."""
     _fields_ = [('offset', c_int64), ('rows', c_int), ('cols', c_int), ('dst', c_void_p), ('ldd', c_int), ('dst_t', c_void_p),
-                ('ldt', c_int)]
+                ('ldt', c_int), ('pair', c_int)]
 
 
 ADAM_MAX_SLABS, ADAM_MAX_SHADOWS = 4, 8

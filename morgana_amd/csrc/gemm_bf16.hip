@@ -383,7 +383,11 @@ int mg_try_nt_runs(const uint16_t* A, int lda, const int32_t* rows, int64_t M, i
                    const float* bias, uint16_t* C, int ldc, int sigmoid, hipStream_t st);       // gemm_nt_runs.hip
 int mg_wgrad_big_plan(int64_t M, int N, int K, int lda, int lddy, int* S_out, int* m_chunk_out);
 int mg_launch_wgrad_big(const uint16_t* dY, int lddy, const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K,
-                        int S, int m_chunk, float* slab, float* bslab, int64_t sstride, hipStream_t st, const int32_t* dy_rows = nullptr);
+                        int S, int m_chunk, float* slab, float* bslab, int64_t sstride, hipStream_t st, const int32_t* dy_rows = nullptr, int x3 = 0);
+int mg_launch_nt_persist_x3(const PhoneFrontArgs* pf, const uint16_t* A, int lda, int64_t M, int K, const uint16_t* Bm, int ldb, int N,
+                            const float* bias, uint16_t* C, int ldc, int epi, hipStream_t st, int* front_rode);
+int mg_launch_nt_big_x3_f32(const uint16_t* A, int lda, int64_t M, int K, const uint16_t* Bm, int ldb, int N, const float* bias, float* C,
+                            int ldc, int epi, hipStream_t st, int parts = 1);
 int mg_launch_phone_front_gemm(const PhoneFrontArgs& pf, const uint16_t* A, int lda, int64_t M, int K, const uint16_t* Bm, int ldb, int N,
                                const float* bias, uint16_t* C, int ldc, int epi, hipStream_t st);
 extern "C" int mg_phone_front_check(const int64_t* dur, int B, int P, int T, const float* target, int extra, const int32_t* rows32,
@@ -391,7 +395,7 @@ extern "C" int mg_phone_front_check(const int64_t* dur, int B, int P, int T, con
                                     const float* weight, const void* workspace, size_t workspace_bytes, const char* who);
 int mg_launch_wgrad_dgrad_pair(const uint16_t* dY, int lddy, const uint16_t* A, int lda, int64_t M, int N, int K, const uint16_t* WT, int ldwt,
                                uint16_t* dX, int lddx, float* slab, int64_t sstride, size_t slab_floats, int* S_out, hipStream_t st,
-                               const ExpandReduceArgs* rider);
+                               const ExpandReduceArgs* rider, int x3 = 0, float* colsum = nullptr);
 
 extern "C" {
 
@@ -685,6 +689,106 @@ int mg_phone_front_linear_fwd_bf16(const int64_t* dur, int B, int P, int T, cons
                         workspace_bytes, stream);
     if (rc != MG_OK) return rc;
     return mg_linear_fwd_bf16(A, lda, nullptr, M, K, W, ldw, bias, N, Y, ldy, 0, act, stream);
+}
+
+// ---- pair planes: the fused step of precision mode 'bf16x3' (include/morgana_hip.h; kernels in gemm_bf16_big.hip) -------------------
+int mg_phone_front_linear_fwd_x3(const int64_t* dur, int B, int P, int T, const float* target, const int64_t* seq_len, int extra,
+                                 int32_t* rows32, int32_t* rows_mapped, int pad_row, int32_t* seg_start, int32_t* seg_end, float* ybar,
+                                 float* weight, void* workspace, size_t workspace_bytes, const uint16_t* A, int lda, int64_t M, int K,
+                                 const uint16_t* W, int ldw, const float* bias, int N, uint16_t* Y, int ldy, int act, void* stream) {
+    MG_CHECK_ARG(A && W && Y && bias && M > 0 && N > 0 && K > 0 && (act == MG_ACT_NONE || act == MG_ACT_SIGMOID),
+                 "mg_phone_front_linear_fwd_x3: bad GEMM arguments (M=%lld N=%d K=%d act=%d)", (long long)M, N, K, act);
+    MG_CHECK_ARG(lda % 128 == 0 && ldw % 128 == 0 && lda / 2 >= K && ldw / 2 >= K && ldy == 2 * N && N % 256 == 0 && al16(A) && al16(W) && al16(Y),
+                 "mg_phone_front_linear_fwd_x3: pair planes need lda=%d, ldw=%d multiples of 128 with planes >= K=%d, ldy=%d == 2 N, N=%d a multiple of 256, 16-byte aligned buffers",
+                 lda, ldw, K, ldy, N);
+    PhoneFrontArgs pf{};
+    if (dur) {
+        const int rc = mg_phone_front_check(dur, B, P, T, target, extra, rows32, rows_mapped, seg_start, seg_end, ybar, weight, workspace,
+                                            workspace_bytes, "mg_phone_front_linear_fwd_x3");
+        if (rc != MG_OK) return rc;
+        pf = PhoneFrontArgs{dur, target, seq_len, B, P, T, extra, rows32, rows_mapped, pad_row, seg_start, seg_end, ybar, weight, (float*)workspace, 0, 0};
+    }
+    // does the front ride in the GEMM's grid?  Asked first (nothing is launched when it does not): the front must precede nothing of
+    // the GEMM, but a launch order of "front, then GEMM" keeps the two-launch form the one of mg_phone_front_linear_fwd_bf16
+    int rode = 0;
+    const int epi = act == MG_ACT_SIGMOID ? EPI_BIAS_SIGMOID : EPI_BIAS;
+    const int launched = mg_launch_nt_persist_x3(dur ? &pf : nullptr, A, lda, M, K, W, ldw, N, bias, Y, ldy, epi, (hipStream_t)stream, &rode);
+    if (launched <= 0) {
+        mg_set_error("mg_phone_front_linear_fwd_x3: shape outside the wide-tile kernel (M=%lld N=%d K=%d lda=%d ldw=%d)", (long long)M, N, K, lda, ldw);
+        return MG_EINVAL;
+    }
+    MG_CHECK_LAUNCH("mg_phone_front_linear_fwd_x3");
+    if (dur && !rode)
+        return mg_phone_front(dur, B, P, T, target, seq_len, extra, rows32, rows_mapped, pad_row, seg_start, seg_end, ybar, weight, workspace,
+                              workspace_bytes, stream);
+    return MG_OK;
+}
+
+int mg_linear_fwd_x3_f32(const uint16_t* A, int lda, int64_t M, int K, const uint16_t* W, int ldw, const float* bias, int N, float* Y,
+                         int ldy, int act, int parts, void* stream) {
+    MG_CHECK_ARG(A && W && Y && M > 0 && N > 0 && K > 0 && (act == MG_ACT_NONE || act == MG_ACT_SIGMOID),
+                 "mg_linear_fwd_x3_f32: bad arguments (M=%lld N=%d K=%d act=%d)", (long long)M, N, K, act);
+    MG_CHECK_ARG(parts == 1 || (parts == 3 && act == MG_ACT_NONE), "mg_linear_fwd_x3_f32: parts=%d (1, or 3 without an activation)", parts);
+    MG_CHECK_ARG(lda % 128 == 0 && ldw % 128 == 0 && lda / 2 >= K && ldw / 2 >= K && ldy == N && N % 128 == 0 && al16(A) && al16(W) && al16(Y),
+                 "mg_linear_fwd_x3_f32: pair planes need lda=%d, ldw=%d multiples of 128 with planes >= K=%d, ldy=%d == N, N=%d a multiple of 128, 16-byte aligned buffers",
+                 lda, ldw, K, ldy, N);
+    if (mg_launch_nt_big_x3_f32(A, lda, M, K, W, ldw, N, bias, Y, ldy, act == MG_ACT_SIGMOID ? EPI_BIAS_SIGMOID : EPI_BIAS, (hipStream_t)stream, parts) <= 0) {
+        mg_set_error("mg_linear_fwd_x3_f32: shape outside the wide-tile kernel (M=%lld N=%d K=%d lda=%d ldw=%d)", (long long)M, N, K, lda, ldw);
+        return MG_EINVAL;
+    }
+    MG_CHECK_LAUNCH("mg_linear_fwd_x3_f32");
+    return MG_OK;
+}
+
+size_t mg_linear_wgrad_dgrad_x3_colsum_floats(int64_t M, int K) { return M > 0 && K > 0 ? (size_t)(2 * mg_ceil_div(M, 256)) * (size_t)K : 0; }
+
+int mg_linear_wgrad_dgrad_x3(const uint16_t* dY, int lddy, const uint16_t* A, int lda, int64_t M, int N, int K, const uint16_t* WT, int ldwt,
+                             uint16_t* dX, int lddx, void* workspace, size_t workspace_bytes, int* n_slabs, int64_t* stride, float* colsum,
+                             size_t colsum_floats, int* n_colsum, void* stream) {
+    MG_CHECK_ARG(dY && A && WT && dX && workspace && n_slabs && stride && colsum && n_colsum && M > 0 && N > 0 && K > 0,
+                 "mg_linear_wgrad_dgrad_x3: bad arguments (M=%lld N=%d K=%d)", (long long)M, N, K);
+    MG_CHECK_ARG(lddy % 128 == 0 && lda % 128 == 0 && ldwt % 128 == 0 && lddy / 2 >= N && lda / 2 >= K && ldwt / 2 >= N && lddx == 2 * K,
+                 "mg_linear_wgrad_dgrad_x3: pair planes need lddy=%d lda=%d ldwt=%d multiples of 128 covering N=%d / K=%d and lddx=%d == 2 K", lddy, lda,
+                 ldwt, N, K, lddx);
+    MG_CHECK_ARG(al16(dY) && al16(A) && al16(WT) && al16(dX) && al16(workspace) && al16(colsum), "mg_linear_wgrad_dgrad_x3: buffers must be 16-byte aligned");
+    MG_CHECK_ARG(colsum_floats >= mg_linear_wgrad_dgrad_x3_colsum_floats(M, K), "mg_linear_wgrad_dgrad_x3: colsum holds %zu floats, %zu needed",
+                 colsum_floats, mg_linear_wgrad_dgrad_x3_colsum_floats(M, K));
+    const int64_t nk = (int64_t)N * K, sstride = nk + N;
+    int S = 0;
+    if (mg_launch_wgrad_dgrad_pair(dY, lddy, A, lda, M, N, K, WT, ldwt, dX, lddx, (float*)workspace, sstride, workspace_bytes / sizeof(float), &S,
+                                   (hipStream_t)stream, nullptr, 1, colsum) <= 0) {
+        mg_set_error("mg_linear_wgrad_dgrad_x3: M=%lld N=%d K=%d is not the 512 -> 128 pair shape (or the workspace of %zu bytes is too small)",
+                     (long long)M, N, K, workspace_bytes);
+        return MG_EINVAL;
+    }
+    MG_CHECK_LAUNCH("mg_linear_wgrad_dgrad_x3");
+    *n_slabs = S;
+    *stride = sstride;
+    *n_colsum = (int)(2 * mg_ceil_div(M, 256));
+    return MG_OK;
+}
+
+int mg_linear_wgrad_slabs_x3(const uint16_t* dY, int lddy, const uint16_t* A, int lda, int64_t M, int N, int K, void* workspace,
+                             size_t workspace_bytes, int* n_slabs, int64_t* stride, void* stream) {
+    MG_CHECK_ARG(dY && A && workspace && n_slabs && stride && M > 0 && N > 0 && K > 0, "mg_linear_wgrad_slabs_x3: bad arguments (M=%lld N=%d K=%d)",
+                 (long long)M, N, K);
+    MG_CHECK_ARG(lddy % 128 == 0 && lda % 128 == 0 && lddy / 2 >= N && lda / 2 >= K, "mg_linear_wgrad_slabs_x3: pair planes need lddy=%d lda=%d multiples of 128 covering N=%d / K=%d",
+                 lddy, lda, N, K);
+    MG_CHECK_ARG(al16(dY) && al16(A) && al16(workspace), "mg_linear_wgrad_slabs_x3: buffers must be 16-byte aligned");
+    int big_s = 0, big_chunk = 0;
+    MG_CHECK_ARG(mg_wgrad_big_plan(M, N, K, lda / 2, lddy / 2, &big_s, &big_chunk) > 0,
+                 "mg_linear_wgrad_slabs_x3: M=%lld N=%d K=%d plane=%d is not a wide-tile shape", (long long)M, N, K, lda / 2);
+    const int64_t nk = (int64_t)N * K, sstride = nk + N;
+    if ((size_t)big_s * (size_t)sstride * sizeof(float) > workspace_bytes) {
+        mg_set_error("mg_linear_wgrad_slabs_x3: %d split slabs of %lld floats do not fit the %zu-byte workspace", big_s, (long long)sstride, workspace_bytes);
+        return MG_EWORKSPACE;
+    }
+    MG_CHECK_ARG(mg_launch_wgrad_big(dY, lddy, A, lda, nullptr, M, N, K, big_s, big_chunk, (float*)workspace, nullptr, sstride, (hipStream_t)stream, nullptr, 1) > 0,
+                 "mg_linear_wgrad_slabs_x3: no pair-plane tile program for M=%lld N=%d K=%d", (long long)M, N, K);
+    MG_CHECK_LAUNCH("mg_linear_wgrad_slabs_x3");
+    *n_slabs = big_s;
+    *stride = sstride;
+    return MG_OK;
 }
 
 // dst[0 .. count) (+)= the ordered sum of n_slabs slabs (stride floats apart): the library's slab reduce as a launch of its own, for a

@@ -65,12 +65,20 @@ MG_STAMP_DECL(g_stamps_nt);
 // The tile program is a device function on a caller-provided LDS block and block id, so that two independent launches can share one
 // grid (wgrad_dgrad_pair_kernel below); gemm_nt_big_kernel is the plain launch of it.
 #define NT_BIG_LDS(BN_) (((BN_) == 256 ? 4 : 6) * (256 * 64 + (BN_) * 64))
-template <int BN, int EPI>
+// X3 (precision mode 'bf16x3', fused step - see the section "pair planes" at the end of this file): both operands are PAIR PLANES
+// [hi | lo] (row stride lda / ldb, planes lda / 2 / ldb / 2 apart; K = the contraction length of ONE plane), and the k loop runs three
+// times over the plane: (A hi, B hi), (A hi, B lo), (A lo, B hi) - three bf16 products into one fp32 accumulator per fp32 product.
+// EPI_SIGMOID_GRAD then reads H as pair planes too (h = hi + lo), writes dX as pair planes (ldc = row stride, planes ldc / 2 apart)
+// and leaves the column sums of the fp32 dX (the bias gradient of the layer below) in `colsum`: one 64-column strip per wave,
+// slab (tile_m * WAVES_M + wave row) of `N` floats.
+template <int BN, int EPI, int X3 = 0>
 __device__ __forceinline__ void gemm_nt_big_body(unsigned char* __restrict__ smem, const unsigned block_id, const uint16_t* __restrict__ A,
                                                  int lda, const int32_t* __restrict__ rows, int64_t M, int K, const uint16_t* __restrict__ Bm,
-                                                 int ldb, int N, const float* __restrict__ bias, const uint16_t* __restrict__ H, int ldh,
-                                                 const int32_t* __restrict__ h_rows, void* __restrict__ Cv, int ldc, int tiles_m, int tiles_n,
-                                                 int c_f32) {
+                                                 int ldb, int N, const float* __restrict__ bias_in, const uint16_t* __restrict__ H, int ldh,
+                                                 const int32_t* __restrict__ h_rows, void* __restrict__ Cv_in, int ldc, int tiles_m, int tiles_n,
+                                                 int c_f32, float* __restrict__ colsum = nullptr) {
+    const float* bias = bias_in;
+    void* Cv = Cv_in;
     constexpr int BM = 256;
     constexpr int WAVES_N = BN / 64;              // 4 or 2
     constexpr int WAVES_M = 8 / WAVES_N;          // 2 or 4
@@ -89,7 +97,18 @@ __device__ __forceinline__ void gemm_nt_big_body(unsigned char* __restrict__ sme
 
     // XCD-aware tile order: blocks b and b + 8 share an XCD (its L2); give them the N tiles of ONE M tile so the A rows
     // and the H tile are fetched into that L2 once.
-    const int xcd = block_id & 7, jj = block_id >> 3;
+    // X3 == 2 (fp32 output, EPI_BIAS): the three passes as three SETS of workgroups - the grid is three times the tiles, set p runs
+    // pass p over the plane and writes its partial sums to C + p * M * ldc (the bias rides in set 0); the consumer adds the three
+    // partial results.  A few-tile GEMM (the 128-wide layer of the phone table: 84 tiles on 256 CUs) then fills the chip with chains a
+    // third as long.
+    unsigned tile_id = block_id;
+    int my_pass = 0;
+    if (X3 == 2) {
+        const unsigned per_pass = (unsigned)((tiles_m + 7) / 8) * 8u * (unsigned)tiles_n;
+        my_pass = (int)(block_id / per_pass);
+        tile_id = block_id - (unsigned)my_pass * per_pass;
+    }
+    const int xcd = tile_id & 7, jj = tile_id >> 3;
     const int tile_n = jj % tiles_n;
     const int tile_m = (jj / tiles_n) * 8 + xcd;
     if (tile_m >= tiles_m) return;
@@ -104,7 +123,13 @@ __device__ __forceinline__ void gemm_nt_big_body(unsigned char* __restrict__ sme
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * 64;
     const int64_t m0 = (int64_t)tile_m * BM;
     const int n0 = tile_n * BN;
-    const int n_kt = (K + 31) / 32;               // stages that hold real columns (lda, ldb >= 64 * ceil(K / 64))
+    const int n_kp = (K + 31) / 32;               // stages that hold real columns (lda, ldb >= 64 * ceil(K / 64))
+    const int n_kt = X3 == 1 ? 3 * n_kp : n_kp;   // X3: three passes over the plane (X3 == 2: this workgroup's one)
+    const int a_lo = lda >> 1, b_lo = ldb >> 1;   // X3: element offset of an operand's lo plane
+    if (X3 == 2) {
+        if (my_pass > 0) bias = nullptr;
+        Cv = reinterpret_cast<float*>(Cv) + (size_t)my_pass * (size_t)M * ldc;
+    }
 
     // Per-lane DMA sources.  Piece g covers tile rows 16g..16g+15; lane l writes row 16g + (l>>2), chunk position l&3,
     // and therefore fetches source chunk (l&3) ^ ((row>>2)&3) of that row.
@@ -136,10 +161,17 @@ __device__ __forceinline__ void gemm_nt_big_body(unsigned char* __restrict__ sme
 
     auto issue = [&](int kt) {
         unsigned char* st = smem + (kt % NS) * STAGE;
+        int ka = kt * 32, kb = kt * 32;
+        if (X3) {                                  // pass 0: (hi, hi), 1: (hi, lo), 2: (lo, hi)
+            // (pass fastest: the second read of an operand's k-tile follows the first by a stage or two and is served by the XCD's L2)
+            const int pass = X3 == 2 ? my_pass : kt % 3, w = (X3 == 2 ? kt : kt / 3) * 32;
+            ka = w + (pass == 2 ? a_lo : 0);
+            kb = w + (pass == 1 ? b_lo : 0);
+        }
 #pragma unroll
-        for (int i = 0; i < GA; ++i) glds16(asrc[i] + kt * 32, st + (wave * GA + i) * 1024);
+        for (int i = 0; i < GA; ++i) glds16(asrc[i] + ka, st + (wave * GA + i) * 1024);
 #pragma unroll
-        for (int i = 0; i < GB; ++i) glds16(bsrc[i] + kt * 32, st + A_BYTES + (wave * GB + i) * 1024);
+        for (int i = 0; i < GB; ++i) glds16(bsrc[i] + kb, st + A_BYTES + (wave * GB + i) * 1024);
     };
 
     // acc[i][j] holds C^T of the (i, j) 32 x 32 sub-tile: lane&31 = frame row, registers = output columns.
@@ -220,6 +252,9 @@ __device__ __forceinline__ void gemm_nt_big_body(unsigned char* __restrict__ sme
         constexpr int STG_LD = 68;
         WAIT_LGKM_BARRIER();                                   // all waves are done with the tile stages
         float* stg = reinterpret_cast<float*>(smem) + wave * 32 * STG_LD;
+        float csum[8];                             // X3: this lane's share of the column sums of dX (its 8 columns, its rows)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csum[e] = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -239,6 +274,24 @@ __device__ __forceinline__ void gemm_nt_big_body(unsigned char* __restrict__ sme
                 const int64_t hrow = h_rows ? (int64_t)h_rows[row] : row;
                 const bfv8 hv = *reinterpret_cast<const bfv8*>(H + (size_t)hrow * ldh + col);
                 float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                if (X3) {
+                    // pair planes: h = hi + lo (exact in fp32), dX split again; the bias gradient of the layer below = the column
+                    // sums of the fp32 values, in a fixed order (row blocks i, it ascending per lane; lanes and waves below)
+                    const bfv8 hl = *reinterpret_cast<const bfv8*>(H + (size_t)hrow * ldh + (ldh >> 1) + col);
+                    bfv8 o_hi, o_lo;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float h = (float)hv[e] + (float)hl[e];
+                        const float x = v[e] * h * (1.f - h);
+                        csum[e] += x;
+                        o_hi[e] = (__bf16)x;
+                        o_lo[e] = (__bf16)(x - (float)o_hi[e]);
+                    }
+                    uint16_t* crow = reinterpret_cast<uint16_t*>(Cv) + (size_t)row * ldc + col;
+                    *reinterpret_cast<bfv8*>(crow) = o_hi;
+                    *reinterpret_cast<bfv8*>(crow + (ldc >> 1)) = o_lo;
+                    continue;
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float h = (float)hv[e];
@@ -254,6 +307,20 @@ __device__ __forceinline__ void gemm_nt_big_body(unsigned char* __restrict__ sme
                     for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
                     *reinterpret_cast<bfv8*>(reinterpret_cast<uint16_t*>(Cv) + (size_t)row * ldc + col) = o;
                 }
+            }
+        }
+        if (X3 && colsum) {
+            // the eight row lanes of a column chunk (lane >> 3), added in a fixed butterfly; one slab per (M tile, wave row)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                csum[e] += __shfl_xor(csum[e], 8, 64);
+                csum[e] += __shfl_xor(csum[e], 16, 64);
+                csum[e] += __shfl_xor(csum[e], 32, 64);
+            }
+            if (lane < 8) {
+                float* dst = colsum + ((size_t)tile_m * WAVES_M + (wave / WAVES_N)) * N + n0 + wn0 + lane * 8;
+                *reinterpret_cast<f32x4*>(dst) = f32x4{csum[0], csum[1], csum[2], csum[3]};
+                *reinterpret_cast<f32x4*>(dst + 4) = f32x4{csum[4], csum[5], csum[6], csum[7]};
             }
         }
         return;
@@ -345,14 +412,14 @@ __device__ __forceinline__ void gemm_nt_big_body(unsigned char* __restrict__ sme
 #endif
 }
 
-template <int BN, int EPI>
+template <int BN, int EPI, int X3 = 0>
 __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows,
                                                           int64_t M, int K, const uint16_t* __restrict__ Bm, int ldb, int N,
                                                           const float* __restrict__ bias, const uint16_t* __restrict__ H, int ldh,
                                                           const int32_t* __restrict__ h_rows, void* __restrict__ Cv, int ldc, int tiles_m,
                                                           int tiles_n, int c_f32) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[NT_BIG_LDS(BN)];
-    gemm_nt_big_body<BN, EPI>(smem, blockIdx.x, A, lda, rows, M, K, Bm, ldb, N, bias, H, ldh, h_rows, Cv, ldc, tiles_m, tiles_n, c_f32);
+    gemm_nt_big_body<BN, EPI, X3>(smem, blockIdx.x, A, lda, rows, M, K, Bm, ldb, N, bias, H, ldh, h_rows, Cv, ldc, tiles_m, tiles_n, c_f32);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -412,7 +479,10 @@ constexpr int ntp_lds_bytes() {
 
 // The tile program on a caller-provided LDS block, as workgroup `block_id` of `n_blocks` (gemm_nt_persist_kernel: the plain launch;
 // phone_front_gemm_kernel: behind the blocks of an unrelated small job).
-template <int BN, int EPI, bool STAG, int BK, int MODE = 0, int BMV = 256>
+// X3: pair-plane operands and a pair-plane output (see gemm_nt_big_body): A [M, lda] = [hi | lo] planes lda / 2 apart, B likewise, K =
+// the contraction length of one plane, three passes (hi, hi), (hi, lo), (lo, hi); C [M, ldc] = [hi | lo] of the fp32 result (N columns
+// per plane, planes ldc / 2 apart): twice the epilogue stores per tile.
+template <int BN, int EPI, bool STAG, int BK, int MODE = 0, int BMV = 256, int X3 = 0>
 __device__ __forceinline__ void gemm_nt_persist_body(unsigned char* __restrict__ smem, const unsigned block_id, const unsigned n_blocks,
                                                      const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows, int64_t M,
                                                      int K, const uint16_t* __restrict__ Bm, int ldb, int N, const float* __restrict__ bias,
@@ -431,13 +501,19 @@ __device__ __forceinline__ void gemm_nt_persist_body(unsigned char* __restrict__
     constexpr int KS = BK / 16;                   // 16-deep MFMA steps per stage: 2 or 4
     constexpr int LPR = ROWB / 16;                // lanes (16-byte chunks) per row: 4 or 8
     constexpr int RPP = 64 / LPR;                 // rows per 1 KB DMA piece: 16 or 8
+    // X3 == 2 ("native" pair planes): ONE ring slot holds the k-tile of all four planes - [A hi | B hi] and behind them [A lo | B lo],
+    // each in the layout of a plain stage - and the step multiplies three times from it: four tile fills per k-tile where the three
+    // passes of X3 == 1 make six.  Two slots of twice the size in the LDS of the four-slot ring.
+    constexpr bool NATIVE = X3 == 2;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
-    constexpr int STAGE = A_BYTES + B_BYTES;      // 32 KB (BN 256, BK 32), 24 KB (BN 128, BK 32) or 48 KB (BN 128, BK 64)
+    constexpr int PLANE = A_BYTES + B_BYTES;      // one plane pair's images
+    constexpr int STAGE = NATIVE ? 2 * PLANE : PLANE;      // 32 KB (BN 256, BK 32), 24 KB (BN 128, BK 32) or 48 KB (BN 128, BK 64); native: twice
     constexpr int GA = BM / RPP / 8;              // 1 KB pieces per wave for A: 2 or 4
     constexpr int GB = BN / RPP / 8;              // for B: 2, 1 or 2
-    constexpr int NL = GA + GB;                   // LDS-DMA instructions per wave per stage: 4, 3 or 6
-    constexpr int NS = (BK == 64) ? 3 : ((BN == 256) ? 4 : 5);
-    constexpr int NST = TM * 4;                   // epilogue stores per wave per tile: 16 or 8
+    constexpr int NL = (GA + GB) * (NATIVE ? 2 : 1);       // LDS-DMA instructions per wave per stage: 4, 3 or 6
+    constexpr int NS = NATIVE ? 2 : ((BK == 64) ? 3 : ((BN == 256) ? 4 : 5));
+    constexpr int NST = TM * 4 * (X3 ? 2 : 1);    // epilogue stores per wave per tile: 16 or 8 (X3: both planes)
+    static_assert(!X3 || (MODE == 0 && !STAG && BN == 256 && BK == 32), "X3: the plain square form only");
     constexpr int ROWTAB = NS * STAGE;            // int32[MAXT][256]
     constexpr int MAXT = NTP_MAX_TILES(BN);
     constexpr int PATCH = ROWTAB + MAXT * BM * 4;
@@ -460,7 +536,9 @@ __device__ __forceinline__ void gemm_nt_persist_body(unsigned char* __restrict__
     MG_STAMP_REAL(tr0);
 #endif
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * 64;
-    const int n_kt = (K + BK - 1) / BK;           // stages that hold real columns (lda, ldb >= 64 * ceil(K / 64))
+    const int n_kp = (K + BK - 1) / BK;           // stages that hold real columns (lda, ldb >= 64 * ceil(K / 64))
+    const int n_kt = X3 == 1 ? 3 * n_kp : n_kp;   // X3 == 1: three passes over the plane
+    const int a_lo = lda >> 1, b_lo = ldb >> 1;   // X3: element offset of an operand's lo plane
 
     // Virtual block v = blockIdx.x + i gridDim.x (gridDim.x a multiple of 8) keeps the XCD-aware order of gemm_nt_big: the N
     // tiles of one M tile go to blocks 8 apart, which share an XCD and its L2.
@@ -512,23 +590,40 @@ __device__ __forceinline__ void gemm_nt_persist_body(unsigned char* __restrict__
             bsrc[g] = (n < N ? Bm + (size_t)n * ldb : g_zero_row) + c * 8;
         }
     };
-    int i_t = 0, i_k = 0, i_s = 0;
+    int i_t = 0, i_k = 0, i_s = 0, i_p = 0, i_w = 0;          // (X3: pass i_p, k-tile i_w of the plane; i_k counts both)
     set_sources(0);
     auto issue_next = [&](int reps = 1) {         // next stage of the stream, if any is left
         if (i_t >= n_my) return;
         unsigned char* st = smem + i_s * STAGE;
+        const int ka = X3 == 1 ? i_w * BK + (i_p == 2 ? a_lo : 0) : i_k * BK;
+        const int kb = X3 == 1 ? i_w * BK + (i_p == 1 ? b_lo : 0) : i_k * BK;
+        if (NATIVE) {
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                for (int g = 0; g < GA; ++g) glds16(asrc[g] + ka + pl * a_lo, st + pl * PLANE + (wave * GA + g) * 1024);
+#pragma unroll
+                for (int g = 0; g < GB; ++g) glds16(bsrc[g] + kb + pl * b_lo, st + pl * PLANE + A_BYTES + (wave * GB + g) * 1024);
+            }
+        } else
         // probe bits (timing experiments, results garbage): 1 = no A pieces, 2 = no B pieces, 4 = no fragment reads, 8 = no MFMAs, 16 = no epilogue
         for (int rep = 0; rep < reps; ++rep) {
 #pragma unroll
         for (int g = 0; g < GA; ++g)
-            if (!(probe & 1)) glds16(asrc[g] + i_k * BK, st + (wave * GA + g) * 1024);
+            if (!(probe & 1)) glds16(asrc[g] + ka, st + (wave * GA + g) * 1024);
 #pragma unroll
         for (int g = 0; g < GB; ++g)
-            if (!(probe & 2)) glds16(bsrc[g] + i_k * BK, st + A_BYTES + (wave * GB + g) * 1024);
+            if (!(probe & 2)) glds16(bsrc[g] + kb, st + A_BYTES + (wave * GB + g) * 1024);
         }
         i_s = (i_s + 1 == NS) ? 0 : i_s + 1;
+        if (X3 == 1 && ++i_p == 3) {              // pass fastest: an operand's k-tile is read again while the XCD's L2 still holds it
+            i_p = 0;
+            ++i_w;
+        }
         if (++i_k == n_kt) {
             i_k = 0;
+            i_p = 0;
+            i_w = 0;
             if (++i_t < n_my) set_sources(i_t);
         }
     };
@@ -711,7 +806,7 @@ __device__ __forceinline__ void gemm_nt_persist_body(unsigned char* __restrict__
                 switch (allow) {
                     NTP_WAIT_CASE(0) NTP_WAIT_CASE(3) NTP_WAIT_CASE(4) NTP_WAIT_CASE(6) NTP_WAIT_CASE(8) NTP_WAIT_CASE(9)
                     NTP_WAIT_CASE(11) NTP_WAIT_CASE(12) NTP_WAIT_CASE(14) NTP_WAIT_CASE(16) NTP_WAIT_CASE(17) NTP_WAIT_CASE(20)
-                    NTP_WAIT_CASE(24)
+                    NTP_WAIT_CASE(24) NTP_WAIT_CASE(28) NTP_WAIT_CASE(32) NTP_WAIT_CASE(36) NTP_WAIT_CASE(40)
                     default: WAIT_VM_LGKM_BARRIER(0); break;
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -746,6 +841,33 @@ __device__ __forceinline__ void gemm_nt_persist_body(unsigned char* __restrict__
                 } else {
                     mfma_all(acc);
                     mfma_all(acc);
+                }
+            } else if (NATIVE) {
+                issue_next();                     // the other slot: every wave finished with it before this barrier
+                // one 16-deep step at a time (both planes' fragments of a step: as many registers as a plain stage's)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    bfv8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        ah[i] = *reinterpret_cast<const bfv8*>(st + abase[i] + ((asw[i] ^ (2 * ks)) << 4));
+                        al[i] = *reinterpret_cast<const bfv8*>(st + PLANE + abase[i] + ((asw[i] ^ (2 * ks)) << 4));
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        bh[j] = *reinterpret_cast<const bfv8*>(st + bbase[j] + ((bsw[j] ^ (2 * ks)) << 4));
+                        bl[j] = *reinterpret_cast<const bfv8*>(st + PLANE + bbase[j] + ((bsw[j] ^ (2 * ks)) << 4));
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            acc[i][j] = mg_mfma_32x32x16(bh[j], ah[i], acc[i][j]);
+                            acc[i][j] = mg_mfma_32x32x16(bl[j], ah[i], acc[i][j]);
+                            acc[i][j] = mg_mfma_32x32x16(bh[j], al[i], acc[i][j]);
+                        }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3 * TM * TN * MG_MFMA_PER_TILE, 0);
                 }
             } else if (!STAG) {
                 issue_next();                     // refills the slot every wave finished with before this barrier
@@ -837,6 +959,9 @@ __device__ __forceinline__ void gemm_nt_persist_body(unsigned char* __restrict__
             for (int q = 0; q < 4; ++q) bv[j][q] = *reinterpret_cast<const f32x4*>(bias_lds + wn0 + j * 32 + 8 * q + 4 * lh);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            typedef __bf16 bfv2 __attribute__((ext_vector_type(2)));
+            typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+            u32x2_t pk_lo[X3 ? TN : 1][4];                                    // X3: the lo plane's values, written in a second pass
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -848,10 +973,13 @@ __device__ __forceinline__ void gemm_nt_persist_body(unsigned char* __restrict__
                         if (EPI == EPI_BIAS_SIGMOID) x = mg_sigmoid_fast(x);
                         v[e] = x;
                     }
-                    typedef __bf16 bfv2 __attribute__((ext_vector_type(2)));
-                    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-                    const u32x2_t pk = u32x2_t{__builtin_bit_cast(unsigned int, bfv2{(__bf16)v[0], (__bf16)v[1]}),
-                                               __builtin_bit_cast(unsigned int, bfv2{(__bf16)v[2], (__bf16)v[3]})};
+                    const bfv2 h01 = bfv2{(__bf16)v[0], (__bf16)v[1]}, h23 = bfv2{(__bf16)v[2], (__bf16)v[3]};
+                    const u32x2_t pk = u32x2_t{__builtin_bit_cast(unsigned int, h01), __builtin_bit_cast(unsigned int, h23)};
+                    if (X3) {
+                        const bfv2 l01 = bfv2{(__bf16)(v[0] - (float)h01[0]), (__bf16)(v[1] - (float)h01[1])};
+                        const bfv2 l23 = bfv2{(__bf16)(v[2] - (float)h23[0]), (__bf16)(v[3] - (float)h23[1])};
+                        pk_lo[X3 ? j : 0][q] = u32x2_t{__builtin_bit_cast(unsigned int, l01), __builtin_bit_cast(unsigned int, l23)};
+                    }
                     const int chunk = 4 * j + q;                              // columns 32 j + 8 q .. + 7 of the 64-wide strip
                     *reinterpret_cast<u32x2_t*>(patch + lr * SP + ((chunk ^ (lr & 7)) << 4) + 8 * lh) = pk;
                 }
@@ -863,6 +991,23 @@ __device__ __forceinline__ void gemm_nt_persist_body(unsigned char* __restrict__
                 const int64_t m = m0 + wm0 + i * 32 + rl;
                 uint16_t* dst = (m < M) ? C + (size_t)m * ldc + n0 + wn0 + pchunk * 8 : g_ntp_sink + lane * 8;
                 *reinterpret_cast<u32x4_t*>(dst) = o;     // unconditional: the counted vmcnt waits rely on NST stores per wave
+            }
+            if (X3) {
+                // the lo plane through the same wave-private patch (a wave's LDS operations complete in order)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<u32x2_t*>(patch + lr * SP + (((4 * j + q) ^ (lr & 7)) << 4) + 8 * lh) = pk_lo[X3 ? j : 0][q];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+                    const int rl = it * 8 + prow;
+                    const u32x4_t o = *reinterpret_cast<const u32x4_t*>(patch + rl * SP + ((pchunk ^ (rl & 7)) << 4));
+                    const int64_t m = m0 + wm0 + i * 32 + rl;
+                    uint16_t* dst = (m < M) ? C + (size_t)m * ldc + (ldc >> 1) + n0 + wn0 + pchunk * 8 : g_ntp_sink + lane * 8;
+                    *reinterpret_cast<u32x4_t*>(dst) = o;
+                }
             }
         }
         MG_STAMP(tb);
@@ -901,7 +1046,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
 // the first layer's GEMM, which reads none of its outputs: blocks [0, side_blocks) run the jobs, the blocks behind them are the persistent tile program.  The GEMM of
 // C2's phone table has 168 tiles, one per workgroup and CU: the jobs take CUs it leaves idle and two launch boundaries disappear.
 // side_blocks is a multiple of 8 (the tile order derives a block's XCD from its id modulo 8).
-template <int EPI, int BMV = 256>
+template <int EPI, int BMV = 256, int X3 = 0>
 __global__ __launch_bounds__(512) void phone_front_gemm_kernel(unsigned side_blocks, int wave_ints, PhoneFrontArgs pf, const uint16_t* __restrict__ A, int lda,
                                                                int64_t M, int K, const uint16_t* __restrict__ Bm, int ldb, int N,
                                                                const float* __restrict__ bias, uint16_t* __restrict__ C, int ldc, int tiles_m,
@@ -918,8 +1063,8 @@ __global__ __launch_bounds__(512) void phone_front_gemm_kernel(unsigned side_blo
         return;                                          // lds_ints == 0: timing probe, the rider's blocks leave at once
     }
     if (pf.probe & 8) return;
-    gemm_nt_persist_body<256, EPI, false, 32, 0, BMV>(smem, blockIdx.x - side_blocks, gridDim.x - side_blocks, A, lda, nullptr, M, K, Bm, ldb, N, bias, C,
-                                                 ldc, tiles_m, tiles_n, 0);
+    gemm_nt_persist_body<256, EPI, false, 32, 0, BMV, X3>(smem, blockIdx.x - side_blocks, gridDim.x - side_blocks, A, lda, nullptr, M, K, Bm, ldb, N, bias, C,
+                                                     ldc, tiles_m, tiles_n, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -947,11 +1092,15 @@ MG_STAMP_DECL(g_stamps_wg);
 // and its fragment reads are those of the 128 x 512 tile, the stage holds 256 + 256 instead of 128 + 512 operand columns: a fifth
 // fewer 128-byte lines per step for the same products, and the loop is bound by the lines a CU can request (~8 cycles each;
 // profiles/r4_notes_falsified_kernel_ideas.txt).  Same number of tiles per split as the 128 x 512 form, so the same plan.
-template <int TKW, bool DYR = false, int NW = 1>
+// X3 (pair planes, see gemm_nt_big_body): dY [M, lddy] and A [M, lda] are [hi | lo] pairs (planes lddy / 2 / lda / 2 apart); the
+// workgroup walks its row range three times - (dY hi, A hi), (dY lo, A hi), (dY hi, A lo) - into the same accumulators.  No bias sums
+// here (the column sums of the fp32 gradient come from the kernel that produced it).
+template <int TKW, bool DYR = false, int NW = 1, int X3 = 0>
 __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem, const unsigned block_id, const uint16_t* __restrict__ dY,
                                                int lddy, const uint16_t* __restrict__ A, int lda, const int32_t* __restrict__ rows, int64_t M,
                                                int N, int K, int m_chunk, float* __restrict__ slab, float* __restrict__ bslab, int64_t sstride,
                                                int xcd_group, const int32_t* __restrict__ dy_rows = nullptr) {
+    static_assert(!X3 || !DYR, "X3: no gathered dY form");
     // TKW = 10 / 8: the workgroup's tile is 128 x 640 / 128 x 512 (all k columns of the operand), 2 waves along n x 4 along k.
     // TKW = 5: 128 x 320 - HALF the k columns, two k halves per n tile (KH = 2), 4 waves along n x 2 along k: the same five k tiles per
     // wave with one n tile instead of two.  Twice the tiles per split means two thirds of the splits for a full chip (8 x 32 instead of
@@ -970,11 +1119,18 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
     constexpr int NY = Y_BYTES / 1024 / 8;        // dY: 1 (2 for the 256-wide n tile)
     constexpr int NLW = NY + NX;
     static_assert(X_BYTES % 8192 == 0, "whole pieces per wave");
-    constexpr int NSTG = WG_STAGES_NW(TKW, NW);
-    constexpr int LDS_BYTES = NSTG * STAGE + WG_ROWS_MAX * 4 * (DYR ? 2 : 1);
+    // X3 == 2 ("native" pair planes): ONE ring slot holds the step's rows of all four planes - [dY hi | A hi] and behind them
+    // [dY lo | A lo], each in the layout of a plain stage - and the step multiplies three times from it: 14 lines per row where the
+    // three walks of X3 == 1 request 21 (the loop is bound by the lines a CU can request, profiles/r4_notes_falsified_kernel_ideas.txt).
+    // Two slots of twice the size in the LDS of the four-slot ring.
+    constexpr bool NATIVE = X3 == 2;
+    static_assert(!NATIVE || WG_STAGES_NW(TKW, NW) == 4, "native pair planes: the tiles whose ring has four slots");
+    constexpr int NSTG = NATIVE ? 2 : WG_STAGES_NW(TKW, NW);
+    constexpr int SLOT = NATIVE ? 2 * STAGE : STAGE;
+    constexpr int LDS_BYTES = NSTG * SLOT + WG_ROWS_MAX * 4 * (DYR ? 2 : 1);
 
     static_assert(LDS_BYTES == WG_BIG_LDS_NW(TKW, NW) + (DYR ? WG_ROWS_MAX * 4 : 0) && LDS_BYTES <= 160 * 1024, "LDS size helper");
-    int* row_lds = reinterpret_cast<int*>(smem + NSTG * STAGE);
+    int* row_lds = reinterpret_cast<int*>(smem + NSTG * SLOT);
     int* dyrow_lds = row_lds + WG_ROWS_MAX;       // DYR only
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1034,8 +1190,37 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
         x_off[i] = src < XC ? k0 + src * 8 : -1;              // (-1: a position of the pitch's padding - filled from the zero row)
     }
 
-    auto issue = [&](int step) {                 // rows [32 step, 32 step + 32) of this workgroup's range
-        unsigned char* st = smem + (step % NSTG) * STAGE;
+    const int n_steps1 = (n_rows + 31) / 32;     // steps of one walk over the workgroup's rows
+    auto issue = [&](int step_all) {             // rows [32 step, 32 step + 32) of this workgroup's range (X3: step = step_all / 3, pass step_all % 3)
+        unsigned char* st = smem + (step_all % NSTG) * SLOT;
+        int step = step_all, y_plane = 0, a_plane = 0;
+        if (NATIVE) {
+            // both planes of both operands, the lo planes' images one plain stage further
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                for (int i = 0; i < NY; ++i) {
+                    const int ml = step * 32 + y_row[i];
+                    const uint16_t* p = (ml < n_rows) ? dY + (size_t)(m_lo + ml) * lddy + pl * (lddy >> 1) + n0 + y_c[i] * 8 : g_zero_row;
+                    glds16(p, st + pl * STAGE + (wave * NY + i) * 1024);
+                }
+                int rn[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) rn[i] = row_lds[step * 32 + x_row[i]];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    const uint16_t* p = (rn[i] >= 0 && x_off[i] >= 0) ? A + (size_t)rn[i] * lda + pl * (lda >> 1) + x_off[i] : g_zero_row;
+                    glds16(p, st + pl * STAGE + Y_BYTES + (wave * NX + i) * 1024);
+                }
+            }
+            return;
+        }
+        if (X3) {                                 // pass fastest: the rows of a step are read again while the XCD's L2 still holds them
+            step = step_all / 3;
+            const int pass = step_all - 3 * step;
+            y_plane = pass == 1 ? (lddy >> 1) : 0;
+            a_plane = pass == 2 ? (lda >> 1) : 0;
+        }
 #pragma unroll
         for (int i = 0; i < NY; ++i) {
             if (DYR) {
@@ -1044,7 +1229,7 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
                 glds16(p, st + (wave * NY + i) * 1024);
             } else {
                 const int ml = step * 32 + y_row[i];
-                const uint16_t* p = (ml < n_rows) ? dY + (size_t)(m_lo + ml) * lddy + n0 + y_c[i] * 8 : g_zero_row;
+                const uint16_t* p = (ml < n_rows) ? dY + (size_t)(m_lo + ml) * lddy + y_plane + n0 + y_c[i] * 8 : g_zero_row;
                 glds16(p, st + (wave * NY + i) * 1024);
             }
         }
@@ -1053,7 +1238,7 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
         for (int i = 0; i < NX; ++i) rr[i] = row_lds[step * 32 + x_row[i]];     // all index reads first: one lgkmcnt wait
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const uint16_t* p = (rr[i] >= 0 && x_off[i] >= 0) ? A + (size_t)rr[i] * lda + x_off[i] : g_zero_row;
+            const uint16_t* p = (rr[i] >= 0 && x_off[i] >= 0) ? A + (size_t)rr[i] * lda + a_plane + x_off[i] : g_zero_row;
             glds16(p, st + Y_BYTES + (wave * NX + i) * 1024);
         }
     };
@@ -1083,7 +1268,7 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
     const bfv8 ones = bfv8{one_bf, one_bf, one_bf, one_bf, one_bf, one_bf, one_bf, one_bf};
     float bsum = 0.f;
 
-    const int n_steps = (n_rows + 31) / 32;
+    const int n_steps = X3 == 1 ? 3 * n_steps1 : n_steps1;
     // transposed-read lane geometry (see tr_frag in gemm_bf16.hip)
     const int li = lane & 15, g = lane >> 4;
     const int q = li >> 2, p4 = li & 3;
@@ -1109,7 +1294,9 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
     for (int step = 0; step < n_steps; ++step) {
         MG_STAMP(ta);
         // stage `step` must have landed; up to NSTG - 2 younger stages (NLW LDS-DMA instructions each) may stay in flight
-        if (NSTG == 4 && step + 2 < n_steps) {
+        if (NATIVE) {
+            WAIT_VM_BARRIER(0);                   // two slots: nothing younger is in flight when a step starts
+        } else if (NSTG == 4 && step + 2 < n_steps) {
             if (NLW == 4) WAIT_VM_BARRIER(8); else WAIT_VM_BARRIER(6);       // (NSTG == 4: the half-width tiles, NLW 4 or 3)
         } else if (step + 1 < n_steps) {
             if (NLW == 6) WAIT_VM_BARRIER(6); else if (NLW == 5) WAIT_VM_BARRIER(5); else if (NLW == 4) WAIT_VM_BARRIER(4); else WAIT_VM_BARRIER(3);
@@ -1124,7 +1311,40 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
         if (step + NSTG - 1 < n_steps) issue(step + NSTG - 1);        // refills the stage every wave finished reading before this barrier
         MG_STAMP(ta);
         MG_STAMP_ADD(sum_issue, ta, tb);
-        const unsigned char* st = smem + (step % NSTG) * STAGE;
+        const unsigned char* st = smem + (step % NSTG) * SLOT;
+        if constexpr (NATIVE) {
+            // (dY hi, A hi), (dY lo, A hi), (dY hi, A lo) from the one slot: the lo planes' images lie one plain stage behind the hi ones
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bfv8 a[2][TNW], b[2][TKT];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                    for (int i = 0; i < TNW; ++i) {
+                        const unsigned char* ad = st + pl * STAGE + yoff[i] + ks * 16 * PY;
+                        const bfv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(ad));
+                        const bfv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(ad + 4 * PY));
+                        a[pl][i] = bfv8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
+#pragma unroll
+                    for (int j = 0; j < TKT; ++j) {
+                        const unsigned char* ad = st + pl * STAGE + xoff[j] + ks * 16 * PX;
+                        const bfv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(ad));
+                        const bfv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bfv4*)(ad + 4 * PX));
+                        b[pl][j] = bfv8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TNW; ++i)
+#pragma unroll
+                    for (int j = 0; j < TKT; ++j) {
+                        acc[i][j] = mg_mfma_32x32x16(a[0][i], b[0][j], acc[i][j]);
+                        acc[i][j] = mg_mfma_32x32x16(a[1][i], b[0][j], acc[i][j]);
+                        acc[i][j] = mg_mfma_32x32x16(a[0][i], b[1][j], acc[i][j]);
+                    }
+            }
+            continue;
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bfv8 a[TNW], b[TKT];
@@ -1209,12 +1429,12 @@ __device__ __forceinline__ void wgrad_big_body(unsigned char* __restrict__ smem,
 #endif
 }
 
-template <int TKW, int NW = 1>
+template <int TKW, int NW = 1, int X3 = 0>
 __global__ __launch_bounds__(512) void wgrad_big_kernel(const uint16_t* __restrict__ dY, int lddy, const uint16_t* __restrict__ A, int lda,
                                                         const int32_t* __restrict__ rows, int64_t M, int N, int K, int m_chunk,
                                                         float* __restrict__ slab, float* __restrict__ bslab, int64_t sstride, int xcd_group) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[WG_BIG_LDS_NW(TKW, NW)];
-    wgrad_big_body<TKW, false, NW>(smem, blockIdx.x, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
+    wgrad_big_body<TKW, false, NW, X3>(smem, blockIdx.x, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
 }
 
 template <int TKW, int NW = 1>
@@ -1235,21 +1455,23 @@ __global__ __launch_bounds__(512) void wgrad_big_rows_kernel(const uint16_t* __r
 // tail's slabs, two small jobs of the step's forward that nothing needs before the update - as a launch of their own they cost the
 // step 5.8 us plus a kernel boundary; here they start on the CUs the dgrad tiles free first (blocks are dispatched in id order) and
 // end about when the weight-gradient blocks do.
-template <int TKW, int BN>
+template <int TKW, int BN, int X3 = 0>
 __global__ __launch_bounds__(512) void wgrad_dgrad_pair_kernel(unsigned wg_blocks, const uint16_t* __restrict__ dY, int lddy,
                                                                const uint16_t* __restrict__ A, int lda, int64_t M, int N, int K, int m_chunk,
                                                                float* __restrict__ slab, float* __restrict__ bslab, int64_t sstride,
                                                                int xcd_group, const uint16_t* __restrict__ WT, int ldwt,
                                                                const uint16_t* __restrict__ H, int ldh, void* __restrict__ dX, int lddx,
-                                                               int tiles_m, int tiles_n, unsigned nt_blocks, ExpandReduceArgs xr, int riders) {
+                                                               int tiles_m, int tiles_n, unsigned nt_blocks, ExpandReduceArgs xr, int riders,
+                                                               float* __restrict__ colsum) {
     constexpr int LDS = WG_BIG_LDS(TKW) > NT_BIG_LDS(BN) ? WG_BIG_LDS(TKW) : NT_BIG_LDS(BN);
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS];
     if (blockIdx.x < wg_blocks)
-        wgrad_big_body<TKW>(smem, blockIdx.x, dY, lddy, A, lda, nullptr, M, N, K, m_chunk, slab, bslab, sstride, xcd_group);
+        wgrad_big_body<TKW, false, 1, (X3 && WG_STAGES(TKW) == 4) ? 2 : X3>(smem, blockIdx.x, dY, lddy, A, lda, nullptr, M, N, K, m_chunk, slab, bslab, sstride,
+                                                                            xcd_group);       // (native pair planes where the ring has four slots)
     else if (blockIdx.x < wg_blocks + nt_blocks)
         // C[M, K] = dY[M, N] WT[K, N]^T with the sigmoid-grad epilogue: contraction N, output width K (as mg_linear_dgrad_bf16)
-        gemm_nt_big_body<BN, EPI_SIGMOID_GRAD>(smem, blockIdx.x - wg_blocks, dY, lddy, nullptr, M, N, WT, ldwt, K, nullptr, H, ldh, nullptr, dX,
-                                               lddx, tiles_m, tiles_n, 0);
+        gemm_nt_big_body<BN, EPI_SIGMOID_GRAD, X3>(smem, blockIdx.x - wg_blocks, dY, lddy, nullptr, M, N, WT, ldwt, K, nullptr, H, ldh, nullptr, dX,
+                                                   lddx, tiles_m, tiles_n, 0, colsum);
     else
         mg_expand_reduce_rider<512>(xr, (int)(blockIdx.x - wg_blocks - nt_blocks), riders, smem);
 }
@@ -1400,7 +1622,27 @@ int mg_wgrad_big_plan(int64_t M, int N, int K, int lda, int lddy, int* S_out, in
 // dy_rows != nullptr: the dY operand gathered as well (wgrad_big_rows_kernel).  The 128 x 512 tile form only (lda == 512: the 640-wide
 // tile leaves no LDS for the second index table); returns 0 without launching for other shapes.
 int mg_launch_wgrad_big(const uint16_t* dY, int lddy, const uint16_t* A, int lda, const int32_t* rows, int64_t M, int N, int K,
-                        int S, int m_chunk, float* slab, float* bslab, int64_t sstride, hipStream_t st, const int32_t* dy_rows) {
+                        int S, int m_chunk, float* slab, float* bslab, int64_t sstride, hipStream_t st, const int32_t* dy_rows, int x3) {
+    if (x3) {
+        // pair planes (wgrad_big_body X3): the plan was made for the PLANE widths lda / 2, lddy / 2; no bias sums, no gathers
+        if (dy_rows || rows || bslab) return 0;
+        const int pa = lda / 2;
+        const bool ks = wgrad_ksplit(M, N, pa);
+        dim3 grid((unsigned)((N / 128) * (ks ? 2 : 1) * S)), block(512);
+        const int xg = (S % 8 == 0) ? 1 : 0;
+#define LAUNCH_WG3(TKW_, NW_, X3_) hipLaunchKernelGGL((wgrad_big_kernel<TKW_, NW_, X3_>), grid, block, 0, st, dY, lddy, A, lda, rows, M, N, K, m_chunk, slab, bslab, sstride, xg)
+        // X3_ = 2: the native form (one slot holds all four planes' rows) where the tile's ring has the LDS for it; MG_TUNE_AB 90 (A/B):
+        // three walks over the rows everywhere
+        const bool walks = g_mg_tuning[MG_TUNE_AB] == 90;
+        if (!ks && pa == 512 && N % 256 == 0) { if (walks) LAUNCH_WG3(4, 2, 1); else LAUNCH_WG3(4, 2, 2); }
+        else if (ks && pa == 512) { if (walks) LAUNCH_WG3(4, 1, 1); else LAUNCH_WG3(4, 1, 2); }
+        else if (ks) { if (walks) LAUNCH_WG3(5, 1, 1); else LAUNCH_WG3(5, 1, 2); }
+        else if (pa == 640 && N % 256 == 0) LAUNCH_WG3(5, 2, 1);
+        else if (pa == 640) LAUNCH_WG3(10, 1, 1);
+        else LAUNCH_WG3(8, 1, 1);
+#undef LAUNCH_WG3
+        return 1;
+    }
     if (dy_rows) {
         if (lda != 512 || wgrad_ksplit(M, N, lda)) return 0;
         dim3 grid((unsigned)((N / 128) * S)), block(512);
@@ -1488,13 +1730,18 @@ int mg_launch_phone_front_gemm(const PhoneFrontArgs& pf, const uint16_t* A, int 
 // the blocks of both fit the chip at once: blocks are handed to the XCDs round robin and every workgroup here owns a CU, so an XCD
 // (32 CUs) takes ceil(tiles_m / 8) * tiles_n dgrad tiles plus S / 8 splits - S shrinks from the plan's to what is left (fewer, longer
 // splits; a 33rd workgroup on an XCD would wait for a whole tile program to finish).  Returns 1 and the split plan, or 0.
+// x3 != 0: every operand and dX are pair planes (leading dimensions = two planes); `colsum` then receives the column sums of the fp32 dX
+// as 2 ceil(M / 256) slabs of K floats (gemm_nt_big_body X3), and the weight-gradient slabs carry no bias sums.
 int mg_launch_wgrad_dgrad_pair(const uint16_t* dY, int lddy, const uint16_t* A, int lda, int64_t M, int N, int K, const uint16_t* WT, int ldwt,
                                uint16_t* dX, int lddx, float* slab, int64_t sstride, size_t slab_floats, int* S_out, hipStream_t st,
-                               const ExpandReduceArgs* rider) {
+                               const ExpandReduceArgs* rider, int x3, float* colsum) {
     if (g_mg_tuning[MG_TUNE_AB] == 65) return 0;                   // A/B: the two launches
     int S = 0, m_chunk = 0;
-    if (N != 128 || K != 512 || lda != 512 || lddx != K || mg_wgrad_big_plan(M, N, K, lda, lddy, &S, &m_chunk) <= 0) return 0;
-    if (lddy % 64 != 0 || ldwt % 64 != 0 || lddy > MG_ZERO_ELEMS - 64 || ldwt > MG_ZERO_ELEMS - 64 || lddy < 128 || ldwt < 128) return 0;
+    const int pl = x3 ? 2 : 1;                                       // planes per row
+    if (x3 && (lddy % 2 || lda % 2 || ldwt % 2 || lddx % 2 || !colsum)) return 0;
+    const int lda_p = lda / pl, lddy_p = lddy / pl, ldwt_p = ldwt / pl;
+    if (N != 128 || K != 512 || lda_p != 512 || lddx != pl * K || mg_wgrad_big_plan(M, N, K, lda_p, lddy_p, &S, &m_chunk) <= 0) return 0;
+    if (lddy_p % 64 != 0 || ldwt_p % 64 != 0 || lddy > MG_ZERO_ELEMS - 64 || ldwt > MG_ZERO_ELEMS - 64 || lddy_p < 128 || ldwt_p < 128) return 0;
     if (!big16(dY) || !big16(A) || !big16(WT) || !big16(dX)) return 0;
     const int tiles_n = K / 256;
     const int64_t tiles_m = mg_ceil_div(M, 256);
@@ -1504,7 +1751,7 @@ int mg_launch_wgrad_dgrad_pair(const uint16_t* dY, int lddy, const uint16_t* A, 
     // would wait for a whole tile program to finish).  Measured at C2's M = 21 504: 80 splits; 88 fit too when the splits are handed
     // out from the last one down - the four empty ones then land on the XCDs with a dgrad tile more - and were 2.4 us per step SLOWER
     // (every CU busy to the end, 8 more slabs for the update kernel to sum).
-    const bool ksplit = wgrad_ksplit(M, N, lda);
+    const bool ksplit = wgrad_ksplit(M, N, lda_p);
     const int kt = ksplit ? 2 : 1;                                    // workgroups per split
     auto fits = [&](int S_, int chunk_) {
         const int64_t s_real = mg_ceil_div(M, chunk_);
@@ -1539,15 +1786,132 @@ int mg_launch_wgrad_dgrad_pair(const uint16_t* dY, int lddy, const uint16_t* A, 
         if (riders < 1) riders = 1;
         if (riders > 1024) riders = 1024;
     }
+    if (x3) {
+        // pair planes: no bias slabs (the sums of the split values would count hi twice); riders as in the bf16 form
+        if (ksplit)
+            hipLaunchKernelGGL((wgrad_dgrad_pair_kernel<4, 256, 1>), dim3((unsigned)(2 * S) + nt_blocks + riders), dim3(512), 0, st, (unsigned)(2 * S),
+                               dY, lddy, A, lda, M, N, K, m_chunk, slab, (float*)nullptr, sstride, 1, WT, ldwt, A, lda, (void*)dX, lddx, (int)tiles_m,
+                               tiles_n, nt_blocks, xr, riders, colsum);
+        else
+            hipLaunchKernelGGL((wgrad_dgrad_pair_kernel<8, 256, 1>), dim3((unsigned)S + nt_blocks + riders), dim3(512), 0, st, (unsigned)S, dY, lddy,
+                               A, lda, M, N, K, m_chunk, slab, (float*)nullptr, sstride, 1, WT, ldwt, A, lda, (void*)dX, lddx, (int)tiles_m, tiles_n,
+                               nt_blocks, xr, riders, colsum);
+        *S_out = S;
+        return 1;
+    }
     if (ksplit)
         hipLaunchKernelGGL((wgrad_dgrad_pair_kernel<4, 256>), dim3((unsigned)(2 * S) + nt_blocks + riders), dim3(512), 0, st, (unsigned)(2 * S), dY,
                            lddy, A, lda, M, N, K, m_chunk, slab, slab + (int64_t)N * K, sstride, 1, WT, ldwt, A, lda, (void*)dX, lddx, (int)tiles_m,
-                           tiles_n, nt_blocks, xr, riders);
+                           tiles_n, nt_blocks, xr, riders, (float*)nullptr);
     else
         hipLaunchKernelGGL((wgrad_dgrad_pair_kernel<8, 256>), dim3((unsigned)S + nt_blocks + riders), dim3(512), 0, st, (unsigned)S, dY, lddy, A, lda,
                            M, N, K, m_chunk, slab, slab + (int64_t)N * K, sstride, 1, WT, ldwt, A, lda, (void*)dX, lddx, (int)tiles_m, tiles_n,
-                           nt_blocks, xr, riders);
+                           nt_blocks, xr, riders, (float*)nullptr);
     *S_out = S;
+    return 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Pair planes: the fused step of precision mode 'bf16x3' (csrc/split3.hip has the arithmetic).  Every bf16 operand of the step is a
+// [hi | lo] pair of planes in one row (row stride = two planes): the phone table (written once by the loader), the weights and
+// W2^T (kept current by the update kernel), H1 (written split by the first layer's epilogue), dZ2 (by the fp32 tail), dZ1 (by the
+// dgrad epilogue).  The tile programs above run the contraction three times over the plane pairs instead of reading three-plane
+// buffers: a third less operand memory, and no split pass anywhere in the step.
+// ---------------------------------------------------------------------------------------------------------------------
+// C [M, 2 N] = split(act(A W^T + b)), A [M, 2 pa], W [N, 2 pw]; with `pf` the phone-rate front rides in the grid where the GEMM leaves
+// CUs idle (*front_rode = 1), as mg_launch_phone_front_gemm.  Returns 1 if it launched, 0 if the shape does not qualify.
+int mg_launch_nt_persist_x3(const PhoneFrontArgs* pf, const uint16_t* A, int lda, int64_t M, int K, const uint16_t* Bm, int ldb, int N,
+                            const float* bias, uint16_t* C, int ldc, int epi, hipStream_t st, int* front_rode) {
+    if (front_rode) *front_rode = 0;
+    if (M < 1 || M >= 2147483647LL || lda % 128 != 0 || ldb % 128 != 0 || lda > MG_ZERO_ELEMS - 64 || ldb > MG_ZERO_ELEMS - 64) return 0;
+    const int pa = lda / 2, pb = ldb / 2;
+    if (N % 256 != 0 || ldc != 2 * N || !big16(A) || !big16(Bm) || !big16(C)) return 0;
+    if (pa < (K + 63) / 64 * 64 || pb < (K + 63) / 64 * 64 || (K + 31) / 32 < 2) return 0;
+    if (epi != EPI_BIAS && epi != EPI_BIAS_SIGMOID) return 0;
+    const int tiles_n = N / 256;
+    if (32 % tiles_n != 0) return 0;
+    constexpr int LDS_INTS = ntp_lds_bytes<256, 32, 0>() / 4;
+    PhoneFrontArgs a{};
+    int side = 0, wave_ints = 0, bmv = 256;
+    int64_t g = 0, tiles_m = 0;
+    if (pf && g_mg_tuning[MG_TUNE_AB] != 66) {
+        const int64_t wave_ints_need = phone_front_wave_ints(pf->B, pf->P, pf->T, pf->extra);
+        wave_ints = (8 * wave_ints_need <= LDS_INTS) ? (int)wave_ints_need : 0;
+        if (wave_ints > 0 && mg_ceil_div(mg_ceil_div(M, 192), 8) * 8 * tiles_n <= 224) bmv = 192;
+        tiles_m = mg_ceil_div(M, bmv);
+        const int64_t blocks = mg_ceil_div(tiles_m, 8) * 8 * tiles_n;
+        g = mg_ceil_div(blocks, 8 * tiles_n) * 8 * tiles_n;
+        side = (int)((256 - g) / 8 * 8);
+        if (blocks <= 224 && side >= 32 && phone_front_lds_ints(pf->B, pf->P, pf->T, pf->extra) <= LDS_INTS) {
+            a = *pf;
+            a.lds_ints = LDS_INTS;
+            if (front_rode) *front_rode = 1;
+        } else {
+            side = 0;
+        }
+    }
+    if (side == 0) {
+        // the GEMM alone: one resident workgroup per CU walking its tiles (mg_try_nt_big's persistent form)
+        bmv = 256;
+        wave_ints = 0;
+        tiles_m = mg_ceil_div(M, 256);
+        const int64_t blocks = mg_ceil_div(tiles_m, 8) * 8 * tiles_n;
+        g = 256;
+        while (mg_ceil_div(blocks, g) > NTP_MAX_TILES(256)) g += 256;
+        if (g > blocks) g = mg_ceil_div(blocks, 8 * tiles_n) * 8 * tiles_n;
+    }
+    dim3 grid((unsigned)(side + g)), block(512);
+#define LAUNCH_PFG3(EPI_, BMV_, X3_)                                                                                                             \
+    hipLaunchKernelGGL((phone_front_gemm_kernel<EPI_, BMV_, X3_>), grid, block, 0, st, (unsigned)side, wave_ints, a, A, lda, M, K, Bm, ldb, N, bias, C, \
+                       ldc, (int)tiles_m, tiles_n)
+    // X3_ = 2: the native form (one ring slot holds the k-tile of all four planes); MG_TUNE_AB 89 (A/B): three passes over the plane
+    const bool passes = g_mg_tuning[MG_TUNE_AB] == 89;
+    if (epi == EPI_BIAS) {
+        if (bmv == 192) { if (passes) LAUNCH_PFG3(EPI_BIAS, 192, 1); else LAUNCH_PFG3(EPI_BIAS, 192, 2); }
+        else { if (passes) LAUNCH_PFG3(EPI_BIAS, 256, 1); else LAUNCH_PFG3(EPI_BIAS, 256, 2); }
+    } else {
+        if (bmv == 192) { if (passes) LAUNCH_PFG3(EPI_BIAS_SIGMOID, 192, 1); else LAUNCH_PFG3(EPI_BIAS_SIGMOID, 192, 2); }
+        else { if (passes) LAUNCH_PFG3(EPI_BIAS_SIGMOID, 256, 1); else LAUNCH_PFG3(EPI_BIAS_SIGMOID, 256, 2); }
+    }
+#undef LAUNCH_PFG3
+    return 1;
+}
+
+// C fp32 [M, N] = act(A W^T + b) from pair-plane operands (the 128-wide layer in front of the exact-fp32 tail).  1 = launched.
+// parts == 3 (epi == EPI_BIAS only): C is [3, M, N] - the three passes' partial sums from three sets of workgroups (gemm_nt_big_body
+// X3 == 2); the consumer adds them.
+int mg_launch_nt_big_x3_f32(const uint16_t* A, int lda, int64_t M, int K, const uint16_t* Bm, int ldb, int N, const float* bias, float* C,
+                            int ldc, int epi, hipStream_t st, int parts) {
+    if (parts == 3) {
+        if (M < 1 || lda % 128 != 0 || ldb % 128 != 0 || lda > MG_ZERO_ELEMS - 64 || ldb > MG_ZERO_ELEMS - 64 || epi != EPI_BIAS) return 0;
+        if (N % 128 != 0 || ldc != N || !big16(A) || !big16(Bm) || !big16(C) || lda / 2 < (K + 63) / 64 * 64 || ldb / 2 < (K + 63) / 64 * 64) return 0;
+        const int64_t tm = mg_ceil_div(M, 256);
+        const int tn = N / 128;
+        const int64_t per_pass = mg_ceil_div(tm, 8) * 8 * tn;
+        if (3 * per_pass >= 2147483647LL) return 0;
+        hipLaunchKernelGGL((gemm_nt_big_kernel<128, EPI_BIAS, 2>), dim3((unsigned)(3 * per_pass)), dim3(512), 0, st, A, lda, (const int32_t*)nullptr, M, K,
+                           Bm, ldb, N, bias, (const uint16_t*)nullptr, 0, (const int32_t*)nullptr, (void*)C, ldc, (int)tm, tn, 1);
+        return 1;
+    }
+    if (parts != 1) return 0;
+    if (M < 1 || lda % 128 != 0 || ldb % 128 != 0 || lda > MG_ZERO_ELEMS - 64 || ldb > MG_ZERO_ELEMS - 64) return 0;
+    const int pa = lda / 2, pb = ldb / 2;
+    if (N % 128 != 0 || ldc != N || !big16(A) || !big16(Bm) || !big16(C)) return 0;
+    if (pa < (K + 63) / 64 * 64 || pb < (K + 63) / 64 * 64) return 0;
+    if (epi != EPI_BIAS && epi != EPI_BIAS_SIGMOID) return 0;
+    const int64_t tiles_m = mg_ceil_div(M, 256);
+    const bool wide = N % 256 == 0 && tiles_m * (N / 256) >= 128;
+    const int bn = wide ? 256 : 128, tiles_n = N / bn;
+    const int64_t blocks = mg_ceil_div(tiles_m, 8) * 8 * tiles_n;
+    if (blocks >= 2147483647LL) return 0;
+    dim3 grid((unsigned)blocks), block(512);
+#define LAUNCH_NT3(BN_, EPI_) hipLaunchKernelGGL((gemm_nt_big_kernel<BN_, EPI_, 1>), grid, block, 0, st, A, lda, (const int32_t*)nullptr, M, K, Bm, ldb, N, bias, (const uint16_t*)nullptr, 0, (const int32_t*)nullptr, (void*)C, ldc, (int)tiles_m, tiles_n, 1)
+    if (wide) {
+        if (epi == EPI_BIAS) LAUNCH_NT3(256, EPI_BIAS); else LAUNCH_NT3(256, EPI_BIAS_SIGMOID);
+    } else {
+        if (epi == EPI_BIAS) LAUNCH_NT3(128, EPI_BIAS); else LAUNCH_NT3(128, EPI_BIAS_SIGMOID);
+    }
+#undef LAUNCH_NT3
     return 1;
 }
 

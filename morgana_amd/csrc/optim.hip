@@ -93,6 +93,11 @@ __global__ __launch_bounds__(256) void adam_plan_kernel(float* __restrict__ para
             const uint16_t b = mg_f2bf(w);
             if (sh.dst) sh.dst[(size_t)r * sh.ldd + cc] = b;
             if (sh.dst_t) sh.dst_t[(size_t)cc * sh.ldt + r] = b;
+            if (sh.pair) {                             // [hi | lo] pair planes (precision 'bf16x3'): the lo plane half a row further
+                const uint16_t lo = mg_f2bf(w - mg_bf2f(b));
+                if (sh.dst) sh.dst[(size_t)r * sh.ldd + (sh.ldd >> 1) + cc] = lo;
+                if (sh.dst_t) sh.dst_t[(size_t)cc * sh.ldt + (sh.ldt >> 1) + r] = lo;
+            }
         }
     };
     const int e = threadIdx.x & 15, p = threadIdx.x >> 4;
@@ -381,6 +386,8 @@ int mg_adam_step_plan_f32(float* param, float* grad, float* exp_avg, float* exp_
                      "mg_adam_step_plan_f32: shadow %d does not lie inside the flat buffer", k);
         MG_CHECK_ARG((!sh.dst || sh.ldd >= sh.cols) && (!sh.dst_t || sh.ldt >= sh.rows), "mg_adam_step_plan_f32: shadow %d: ldd %d / ldt %d too small", k,
                      sh.ldd, sh.ldt);
+        MG_CHECK_ARG(!sh.pair || ((!sh.dst || (sh.ldd % 2 == 0 && sh.ldd / 2 >= sh.cols)) && (!sh.dst_t || (sh.ldt % 2 == 0 && sh.ldt / 2 >= sh.rows))),
+                     "mg_adam_step_plan_f32: shadow %d: pair planes need even ldd %d / ldt %d with half of it covering the matrix", k, sh.ldd, sh.ldt);
     }
     {
         const mg_adam_tail& t = plan->tail;

@@ -132,7 +132,11 @@ __global__ __launch_bounds__(256) void split3_kernel(Split3Batch batch) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) split_pair(x[e], hi[e], lo[e]);
             const su32x4 ph = pack(hi), pl = pack(lo);
-            if (d.order == 2) {
+            if (d.order == 5) {                        // pair planes [hi | lo] in one row of 2 ldp columns
+                uint16_t* dst = d.dst + (size_t)r * (2 * (size_t)d.ldp) + c0;
+                *reinterpret_cast<su32x4*>(dst) = ph;
+                *reinterpret_cast<su32x4*>(dst + d.ldp) = pl;
+            } else if (d.order == 2) {
                 uint16_t* dst = d.dst + (size_t)r * d.ldp + c0;
                 *reinterpret_cast<su32x4*>(dst) = ph;
                 *reinterpret_cast<su32x4*>(dst + (size_t)(d.plane_rows > 0 ? d.plane_rows : d.rows) * d.ldp) = pl;
@@ -167,6 +171,12 @@ __global__ __launch_bounds__(256) void split3_kernel(Split3Batch batch) {
                 if (c < d.cols && r < d.ldp) {
                     uint16_t hi, lo;
                     split_pair(tile[tx][j], hi, lo);
+                    if (d.order == 5) {
+                        uint16_t* dst = d.dst + (size_t)c * (2 * (size_t)d.ldp) + r;
+                        dst[0] = hi;
+                        dst[d.ldp] = lo;
+                        continue;
+                    }
                     uint16_t* dst = d.dst + (size_t)c * (3 * (size_t)d.ldp) + r;
                     dst[0] = hi;
                     dst[d.ldp] = second ? lo : hi;
@@ -189,9 +199,10 @@ int mg_split3_bf16(const mg_split3_desc* descs, int count, void* stream) {
         const mg_split3_desc& d = descs[i];
         MG_CHECK_ARG(d.src && d.dst && d.rows > 0 && d.cols > 0 && d.lds >= d.cols, "mg_split3_bf16: bad descriptor %d", i);
         MG_CHECK_ARG(!d.sig || (!d.transpose && d.ldsig >= d.cols), "mg_split3_bf16: descriptor %d: a fused sigmoid gradient goes with the plain layouts and needs ldsig >= cols", i);
-        MG_CHECK_ARG(d.order == 0 || d.order == 1 || (d.order >= 2 && d.order <= 4 && !d.transpose),
-                     "mg_split3_bf16: descriptor %d: order %d is none of 0 (hi|hi|lo), 1 (hi|lo|hi), 2 (separate planes hi ; lo), 3 (hi ; hi ; lo), 4 (hi ; lo ; hi) (2-4 not transposed)", i, d.order);
-        MG_CHECK_ARG(d.plane_rows == 0 || (d.order >= 2 && d.plane_rows >= d.rows), "mg_split3_bf16: descriptor %d: plane_rows %lld goes with order 2 and must cover the %lld rows", i, (long long)d.plane_rows, (long long)d.rows);
+        MG_CHECK_ARG(d.order == 0 || d.order == 1 || d.order == 5 || (d.order >= 2 && d.order <= 4 && !d.transpose),
+                     "mg_split3_bf16: descriptor %d: order %d is none of 0 (hi|hi|lo), 1 (hi|lo|hi), 2 (separate planes hi ; lo), 3 (hi ; hi ; lo), 4 (hi ; lo ; hi) (2-4 not transposed), 5 (pair planes hi|lo)", i, d.order);
+        MG_CHECK_ARG(d.order != 5 || (!d.colsum && !d.sig), "mg_split3_bf16: descriptor %d: pair planes take neither column sums nor a fused sigmoid gradient", i);
+        MG_CHECK_ARG(d.plane_rows == 0 || (d.order >= 2 && d.order <= 4 && d.plane_rows >= d.rows), "mg_split3_bf16: descriptor %d: plane_rows %lld goes with order 2 and must cover the %lld rows", i, (long long)d.plane_rows, (long long)d.rows);
         MG_CHECK_ARG(!d.colsum || (!d.transpose && d.colsum_blocks >= 1 && d.colsum_blocks <= 4096 && d.ldp <= 2048 && 256 % (d.ldp / 8) == 0),
                      "mg_split3_bf16: descriptor %d: column sums go with the plain layouts, 1..4096 blocks and plane widths of 8, 16, ... 2048 columns that divide 2048 (ldp %d)", i, d.ldp);
         MG_CHECK_ARG(d.ldp % 8 == 0 && ((size_t)d.dst & 15) == 0, "mg_split3_bf16: descriptor %d: ldp %d must be a multiple of 8 and dst 16-byte aligned", i, d.ldp);

@@ -27,12 +27,23 @@
 
 __device__ __forceinline__ f32x4 tf_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// X3 (the fused step of precision mode 'bf16x3', gemm_bf16_big.hip "pair planes"): dZ2 leaves as a [hi | lo] pair of bf16 planes
+// (row stride lddz, planes lddz / 2 apart) - the operand the layer's dgrad and weight gradient multiply - and the slab starts with
+// the column sums of the fp32 dZ2, the 128-wide layer's bias gradient: [db2 128 | dW3 4096 | db3 32 | dW4 32 | db4 | loss | 2 pad].
+#define TF_SLAB_X3 (TF_SLAB + TF_K3)
+template <int X3>
 __global__ __launch_bounds__(256) void f0_tail_rows_f32_kernel(const float* __restrict__ Z2, int ldz, const float* __restrict__ W3,
                                                                const float* __restrict__ b3, const float* __restrict__ W4,
                                                                const float* __restrict__ b4, const float* __restrict__ ybar,
                                                                const float* __restrict__ weight, const int64_t* __restrict__ seq_len,
                                                                int B, int T, int64_t M, float* __restrict__ pred,
-                                                               float* __restrict__ dZ2, int lddz, float* __restrict__ slab) {
+                                                               void* __restrict__ dZ2v, int lddz, float* __restrict__ slab, int z_parts) {
+    float* dZ2 = reinterpret_cast<float*>(dZ2v);
+    uint16_t* dZ2p = reinterpret_cast<uint16_t*>(dZ2v);
+    __shared__ float acc_c[X3 ? 4 : 1][TF_K3];
+    float dbz[8];                               // X3: this lane's share of the column sums of dZ2 (column kt 16 + li)
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) dbz[kt] = 0.f;
     __shared__ __attribute__((aligned(16))) float th[4][16][TF_K3 + 4];       // per wave: the tile's h2 [row][k]
     __shared__ __attribute__((aligned(16))) float t3[4][16][TF_N3 + 4];       // per wave: the tile's dz3 [row][j]
     __shared__ float acc_w[TF_N3 * TF_K3];
@@ -70,6 +81,11 @@ __global__ __launch_bounds__(256) void f0_tail_rows_f32_kernel(const float* __re
         for (int kb = 0; kb < 8; ++kb) {
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
             if (va) z = *reinterpret_cast<const f32x4*>(Z2 + (size_t)ra * ldz + 16 * kb + 4 * q);
+            if (X3 && z_parts == 3 && va) {         // the pre-activations as three partial sums (mg_linear_fwd_x3_f32 parts == 3)
+                const f32x4 z1 = *reinterpret_cast<const f32x4*>(Z2 + ((size_t)M + ra) * ldz + 16 * kb + 4 * q);
+                const f32x4 z2 = *reinterpret_cast<const f32x4*>(Z2 + (2 * (size_t)M + ra) * ldz + 16 * kb + 4 * q);
+                z = (z + z1) + z2;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) h2a[kb][e] = va ? mg_sigmoid(z[e]) : 0.f;
             *reinterpret_cast<f32x4*>(&th[wave][li][16 * kb + 4 * q]) = h2a[kb];
@@ -154,7 +170,18 @@ __global__ __launch_bounds__(256) void f0_tail_rows_f32_kernel(const float* __re
                 for (int e = 0; e < 4; ++e) dh = tf_mfma(dz3a[jb][e], w3b[kt][jb][e], dh);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (rc + r < M) dZ2[(size_t)(rc + r) * lddz + kt * 16 + li] = dh[r] * hc[r] * (1.f - hc[r]);
+                if (rc + r < M) {
+                    const float x = dh[r] * hc[r] * (1.f - hc[r]);
+                    if (X3) {
+                        const uint16_t hi = mg_f2bf(x);
+                        uint16_t* dst = dZ2p + (size_t)(rc + r) * lddz + kt * 16 + li;
+                        dst[0] = hi;
+                        dst[lddz >> 1] = mg_f2bf(x - mg_bf2f(hi));
+                        dbz[kt] += x;
+                    } else {
+                        dZ2[(size_t)(rc + r) * lddz + kt * 16 + li] = x;
+                    }
+                }
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
@@ -203,8 +230,22 @@ __global__ __launch_bounds__(256) void f0_tail_rows_f32_kernel(const float* __re
             acc_s[wave][65] = b;
         }
     }
+    if (X3) {
+        // the column sums of dZ2: over a wave's four row groups (xor 16, xor 32), then over the waves in wave order
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) {
+            float a = dbz[kt];
+            a += __shfl_xor(a, 16, 64);
+            a += __shfl_xor(a, 32, 64);
+            if (q == 0) acc_c[X3 ? wave : 0][kt * 16 + li] = a;
+        }
+    }
     __syncthreads();
-    float* out = slab + (size_t)blockIdx.x * TF_SLAB;
+    float* out = slab + (size_t)blockIdx.x * (X3 ? TF_SLAB_X3 : TF_SLAB);
+    if (X3) {
+        if (tid < TF_K3) out[tid] = ((acc_c[0][tid] + acc_c[X3 ? 1 : 0][tid]) + acc_c[X3 ? 2 : 0][tid]) + acc_c[X3 ? 3 : 0][tid];
+        out += TF_K3;
+    }
     for (int i = tid; i < TF_N3 * TF_K3; i += 256) out[i] = acc_w[i];
     if (tid < 68) out[TF_N3 * TF_K3 + tid] = tid < 66 ? ((acc_s[0][tid] + acc_s[1][tid]) + acc_s[2][tid]) + acc_s[3][tid] : 0.f;
 }
@@ -236,11 +277,50 @@ int mg_f0_tail_rows_f32(const float* Z2, int ldz, const float* W3, const float* 
     int64_t blocks = mg_ceil_div(mg_ceil_div(M, 16), 4);
     if (blocks > TF_MAX_BLOCKS) blocks = TF_MAX_BLOCKS;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(f0_tail_rows_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Z2, ldz, W3, b3, W4, b4, ybar, weight, seq_len, B, T, M, pred, dZ2, lddz,
-                       (float*)workspace);
+    hipLaunchKernelGGL(f0_tail_rows_f32_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, Z2, ldz, W3, b3, W4, b4, ybar, weight, seq_len, B, T, M, pred,
+                       (void*)dZ2, lddz, (float*)workspace, 1);
     MG_CHECK_LAUNCH("mg_f0_tail_rows_f32");
     mg_launch_slab_reduce((const float*)workspace, TF_SLAB, TF_SLAB, (int)blocks, grads_out, 0, st);
     MG_CHECK_LAUNCH("mg_f0_tail_rows_f32/reduce");
+    return MG_OK;
+}
+
+size_t mg_f0_tail_rows_x3_workspace_bytes(int64_t M) {
+    if (M <= 0) return 256;
+    int64_t blocks = mg_ceil_div(mg_ceil_div(M, 16), 4);
+    if (blocks > TF_MAX_BLOCKS) blocks = TF_MAX_BLOCKS;
+    return mg_align_up((size_t)blocks * TF_SLAB_X3 * sizeof(float), 256);
+}
+
+// mg_f0_tail_rows_f32 for the fused 'bf16x3' step: dZ2 as a [hi | lo] pair of bf16 planes [M, lddz] (planes lddz / 2 apart), slabs of
+// MG_F0_TAIL_X3_SLAB floats [db2 | dW3 | db3 | dW4 | db4 | loss | pad] left in `workspace` (*n_slabs of them, *stride floats apart) for
+// the caller's ordered reduce (mg_slab_reduce_f32) or the update kernel's plan; grads_out != NULL: reduced here (MG_F0_TAIL_X3_SLAB floats).
+int mg_f0_tail_rows_x3(const float* Z2, int ldz, int z_parts, const float* W3, const float* b3, const float* W4, const float* b4,
+                       const float* ybar, const float* weight, int64_t M, float* pred, uint16_t* dZ2, int lddz, float* grads_out,
+                       void* workspace, size_t workspace_bytes, int* n_slabs, int64_t* stride, void* stream) {
+    MG_CHECK_ARG(Z2 && W3 && b3 && W4 && b4 && ybar && weight && pred && dZ2 && n_slabs && stride && M > 0 && (z_parts == 1 || z_parts == 3),
+                 "mg_f0_tail_rows_x3: bad arguments (M=%lld z_parts=%d)", (long long)M, z_parts);
+    MG_CHECK_ARG(ldz >= TF_K3 && ldz % 4 == 0 && lddz >= 2 * TF_K3 && lddz % 16 == 0 && ((uintptr_t)Z2 % 16) == 0 && ((uintptr_t)W3 % 16) == 0 &&
+                     ((uintptr_t)dZ2 % 16) == 0 && (!grads_out || ((uintptr_t)grads_out % 16) == 0),
+                 "mg_f0_tail_rows_x3: ldz=%d (multiple of 4, >= 128) lddz=%d (two planes of >= 128, multiple of 16); Z2, W3, dZ2, grads_out 16-byte aligned",
+                 ldz, lddz);
+    static_assert(TF_SLAB_X3 == MG_F0_TAIL_X3_SLAB, "header and kernel disagree");
+    if (!workspace || workspace_bytes < mg_f0_tail_rows_x3_workspace_bytes(M) || ((uintptr_t)workspace % 16) != 0) {
+        mg_set_error("mg_f0_tail_rows_x3: 16-byte aligned workspace of %zu bytes needed, got %zu", mg_f0_tail_rows_x3_workspace_bytes(M), workspace_bytes);
+        return MG_EWORKSPACE;
+    }
+    int64_t blocks = mg_ceil_div(mg_ceil_div(M, 16), 4);
+    if (blocks > TF_MAX_BLOCKS) blocks = TF_MAX_BLOCKS;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(f0_tail_rows_f32_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, Z2, ldz, W3, b3, W4, b4, ybar, weight,
+                       (const int64_t*)nullptr, 0, 0, M, pred, (void*)dZ2, lddz, (float*)workspace, z_parts);
+    MG_CHECK_LAUNCH("mg_f0_tail_rows_x3");
+    *n_slabs = (int)blocks;
+    *stride = TF_SLAB_X3;
+    if (grads_out) {
+        mg_launch_slab_reduce((const float*)workspace, TF_SLAB_X3, TF_SLAB_X3, (int)blocks, grads_out, 0, st);
+        MG_CHECK_LAUNCH("mg_f0_tail_rows_x3/reduce");
+    }
     return MG_OK;
 }
 

@@ -208,6 +208,7 @@ def _host_total(value):
 
 
 BF16_TABLE_SUFFIX = '__bf16_table'
+X3_TABLE_SUFFIX = '__x3_table'         # the [hi | lo] pair planes of precision 'bf16x3' (ops.split_pair); asked for as 'name:x3'
 
 
 def add_bf16_table(features, key='normalised_lab', extra_rows=None):
@@ -217,10 +218,16 @@ def add_bf16_table(features, key='normalised_lab', extra_rows=None):
     float32 cast of data.py:127 - instead of one cast kernel over the 49 MB table in every training step.  The fp32 feature stays
     in the dict (the reference's key, and the operand of fp32 mode); models fall back to casting it themselves when this entry is
     missing."""
+    key, _, kind = key.partition(':')
     x = features[key]
     if extra_rows is None:
         extra_rows = ops.PHONE_RATE_EXTRA
-    features[key + BF16_TABLE_SUFFIX] = ops.cast_pad_bf16(x.reshape(-1, x.shape[-1]), extra_rows=extra_rows)
+    if kind == 'x3':
+        # precision 'bf16x3': the table as a [hi | lo] pair of bf16 planes (x = hi + lo to 16 significant bits) - the operand of the
+        # fused step's first layer and of its weight gradient (functional.F0StackX3Fn)
+        features[key + X3_TABLE_SUFFIX] = ops.split_pair(x.reshape(-1, x.shape[-1]), extra_rows=extra_rows)
+    else:
+        features[key + BF16_TABLE_SUFFIX] = ops.cast_pad_bf16(x.reshape(-1, x.shape[-1]), extra_rows=extra_rows)
     return features
 
 
@@ -242,7 +249,8 @@ def to_device(features, device, bf16_tables=()):
     if total is not None and FRAME_COUNT_KEY + '_total' not in out:
         out[FRAME_COUNT_KEY + '_total'] = total
     for key in bf16_tables or ():
-        if key in out and key + BF16_TABLE_SUFFIX not in out:
+        name, _, kind = key.partition(':')
+        if name in out and name + (X3_TABLE_SUFFIX if kind == 'x3' else BF16_TABLE_SUFFIX) not in out:
             add_bf16_table(out, key)
     return out
 
@@ -343,8 +351,10 @@ def collate_to_device(batch, normalisers, device, bf16_tables=()):
             if normaliser is not None and isinstance(batch[0][key], np.ndarray):
                 twin = collate_fn([{key: normaliser.normalise(item[key]).astype(np.float32)} for item in batch])[key]
                 out['normalised_' + key] = twin.to(device)
-    for key in bf16_tables:                               # features that did not take the fused pass (no normaliser, host path)
-        if key in out and isinstance(out[key], torch.Tensor) and out[key].is_cuda and key + BF16_TABLE_SUFFIX not in out:
+    for key in bf16_tables:                               # features that did not take the fused pass (no normaliser, host path; pair planes)
+        name, _, kind = key.partition(':')
+        suffix = X3_TABLE_SUFFIX if kind == 'x3' else BF16_TABLE_SUFFIX
+        if name in out and isinstance(out[name], torch.Tensor) and out[name].is_cuda and name + suffix not in out:
             add_bf16_table(out, key)
     return out
 

@@ -1069,6 +1069,131 @@ class LinearStackMSEFn(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(grads)
 
 
+class F0StackX3Fn(torch.autograd.Function):
+    """The README F0Model's stack ``Linear(k, 512) Sigmoid Linear(512, 128) Sigmoid Linear(128, 32) Sigmoid Linear(32, 1)``
+    (README.rst:65-73) on an ``upsample_to_repetitions`` input (morgana/utils.py:175-228) TOGETHER with ``losses.mse``
+    (morgana/losses.py:29-51), precision mode 'bf16x3', at phone rate - the parity-grade counterpart of ``LinearStackMSEFn``'s
+    phone-rate step: SIX launches inside a captured step (five kernels + the update) where the generic 'bf16x3' path takes 25.
+
+    Every bf16 operand is a [hi | lo] PAIR of planes (ops.split_pair): the phone table's pair comes from the loader, the weights'
+    pairs are kept current by the optimiser's update kernel (ops.pair_shadows), H1 / dZ2 / dZ1 leave the kernels that produce them
+    already split, and the tile programs run each contraction three times over the plane pairs (csrc/gemm_bf16_big.hip).  The
+    128 -> 32 -> 1 tail, the loss and their backward stay exact fp32 (csrc/tail_f32.hip); bias gradients are column sums of the
+    fp32 gradients, taken by the kernels that produce them.
+
+    forward(ctx, info, x2d (B*P, k) f32, target (B, T, 1), seq_len, w1, b1, w2, b2, w3, b3, w4, b4) -> (loss, pred (B, T, 1));
+    ``info`` = (the ``utils.UpsampledSequence`` that owns the frame map, the loader's pair table or None).  ``pred`` is returned for
+    reporting only (non-differentiable)."""
+
+    @staticmethod
+    def forward(ctx, info, x2d, target, seq_len, *params):
+        holder, table = info
+        w1, b1, w2, b2, w3, b3, w4, b4 = params
+        x2d = ops._require(x2d, torch.float32, 'input')
+        target = ops._require(target, torch.float32, 'targets')
+        b, t = target.shape[0], target.shape[1]
+        m, n_table, extra = b * t, x2d.shape[0], ops.PHONE_RATE_EXTRA
+        (n1, k0), (n2, k1) = w1.shape, w2.shape
+        if table is not None and tuple(table.shape) == (n_table + extra, 2 * ops.pad_ld(k0)) and table.dtype == torch.bfloat16:
+            a0 = table                                         # split once when the batch was loaded, not once per step
+        else:
+            a0 = ops.split_pair(x2d, extra_rows=extra)
+        n_rows = a0.shape[0]
+        (w1p, w2p), (_, w2tp) = ops.pair_shadows([w1, w2], want_t=(1,))
+        lin1 = (a0, k0, w1p, b1, n1, ops.ACT_SIGMOID)
+        if holder.pending() and holder.t_cap == t and holder.dur.shape[0] == b and ops.phone_front_ok(b, holder.dur.shape[1], t, extra):
+            # the frame map, the per-phone loss statistics and the first layer's GEMM read nothing of each other: one launch
+            rows_bt, rows_mapped, seg, ybar, weight, partials, h1 = ops.phone_front_x3((holder.dur, target.reshape(-1), seq_len, t, extra), lin1)
+            rows = rows_mapped.reshape(-1)
+            holder.adopt(rows_bt, (seg, rows))
+        else:
+            seg, rows = holder.phone_maps()
+            ybar, weight, partials = ops.phone_target_stats(target.reshape(-1), holder.rows.reshape(-1), seg, seq_len, b, t, n_table, extra)
+            (h1,) = ops.phone_front_x3(None, lin1)
+        if rows.numel() != m:
+            raise ValueError('prediction rows (%d) and target rows (%d) differ' % (rows.numel(), m))
+        # the 128-wide layer is 84 tiles at C2's table: its three passes run as three sets of workgroups, the tail adds the partial sums
+        z2 = ops.linear_fwd_x3_f32(h1, k1, w2p, b2, n2, ops.ACT_NONE, parts=ops.X3_FWD_PARTS)
+        # inside a step captured whole (DEFER_TAIL: graphs.GraphedTrainStep) the repeated prediction and the tail's slab sum are left to
+        # the update launch's first blocks, as in LinearStackMSEFn
+        defer = DEFER_TAIL and any(ctx.needs_input_grad[4:])
+        pred_rows, dz2, ws, n_slabs, stride = ops.f0_tail_rows_x3(z2, w3, b3, w4, b4, ybar, weight, keep_slabs=defer)
+        n = ops.F0_TAIL_X3_N
+        flat_tail = torch.empty((ops.F0_TAIL_X3_SLAB,), dtype=torch.float32, device=x2d.device)
+        pred = torch.empty((m,), dtype=torch.float32, device=x2d.device)
+        tail = dict(pred_rows=pred_rows, rows=rows, out=pred, partials=partials, n_table_rows=int(n_table), extra=int(extra), ws=ws, n=n,
+                    stride=stride, n_slabs=n_slabs, grads_out=flat_tail)
+        if defer:
+            ctx.deferred_tail = tail
+        else:
+            ops.finish_deferred_tail(tail)
+            ctx.deferred_tail = None
+        ctx.params = list(params)
+        ctx.n_rows = n_rows
+        ctx.save_for_backward(a0, h1, dz2, flat_tail, w2tp)
+        pred = pred.view(b, t, 1)
+        ctx.mark_non_differentiable(pred)
+        ctx.set_materialize_grads(False)
+        return flat_tail[n - 1], pred
+
+    @staticmethod
+    def backward(ctx, grad_loss, grad_pred):
+        a0, h1, dz2, flat_tail, w2tp = ctx.saved_tensors
+        params = ctx.params
+        w1, b1, w2, b2, w3 = params[:5]
+        (n1, k0), (n2, k1) = w1.shape, w2.shape
+        m = ctx.n_rows
+        mode, opt = _grad_mode(params, grad_loss)
+        tail = getattr(ctx, 'deferred_tail', None)
+        ctx.deferred_tail = None
+        n_tail = ops.F0_TAIL_X3_N - 1                             # db2 | dW3 | db3 | dW4 | db4 (the loss behind them)
+        tail_slabs = None
+        if tail is not None:
+            if mode == 'defer' and os.environ.get('MORGANA_TAIL_RIDERS', 'adam') == 'adam':
+                # the update kernel sums the tail's slabs (one more source of its plan), its first blocks repeat the prediction and
+                # form the loss (optim.Adam.defer_tail)
+                tail_slabs = (tail['ws'].view(torch.float32), tail['n_slabs'], tail['stride'])
+                opt.defer_tail(b2, tail)
+            else:
+                ops.finish_deferred_tail(tail)
+        slab2, s2, st2, dz1, colsum, n_cs = ops.linear_wgrad_dgrad_x3(dz2, h1, m, n2, k1, w2tp, slab=getattr(w2, '_mg_slab_buf', None),
+                                                                      colsum=getattr(b1, '_mg_slab_buf', None))
+        w2._mg_slab_buf, b1._mg_slab_buf = slab2, colsum
+        if mode == 'defer':
+            if tail_slabs is not None:
+                opt.defer_slabs(b2, n_tail, tail_slabs[0], tail_slabs[1], tail_slabs[2])
+            else:
+                opt.defer_slabs(b2, n_tail, flat_tail, 1, n_tail)
+            opt.defer_slabs(w2, n2 * k1, slab2, s2, st2)
+            opt.defer_slabs(b1, n1, colsum.view(torch.float32), n_cs, n1)
+        elif mode == 'direct':
+            b2.grad.reshape(-1).as_strided((n_tail,), (1,)).add_(flat_tail[:n_tail])
+            ops.slab_reduce(slab2, s2, st2, n2 * k1, w2.grad.reshape(-1), accumulate=True)
+            ops.slab_reduce(colsum, n_cs, n1, n1, b1.grad, accumulate=True)
+            if _EARLY_GRADS_HOOK is not None:
+                _EARLY_GRADS_HOOK(params)                         # everything but the first layer's weight gradient is final
+        slab1, s1, st1 = ops.linear_wgrad_slabs_x3(dz1, a0, m, n1, k0, slab=getattr(w1, '_mg_slab_buf', None))
+        w1._mg_slab_buf = slab1
+        if mode == 'defer':
+            opt.defer_slabs(w1, n1 * k0, slab1, s1, st1)
+            return (None, None, None, None) + (None,) * len(params)
+        if mode == 'direct':
+            ops.slab_reduce(slab1, s1, st1, n1 * k0, w1.grad.reshape(-1), accumulate=True)
+            return (None, None, None, None) + (None,) * len(params)
+        # gradients as tensors for autograd
+        sizes = [p.numel() for p in params]
+        offsets = [0]
+        for sz in sizes[:-1]:
+            offsets.append(offsets[-1] + sz)
+        flat = torch.empty((sum(sizes),), dtype=torch.float32, device=a0.device)
+        ops.slab_reduce(slab1, s1, st1, n1 * k0, flat[offsets[0]:offsets[0] + n1 * k0])
+        ops.slab_reduce(colsum, n_cs, n1, n1, flat[offsets[1]:offsets[1] + n1])
+        ops.slab_reduce(slab2, s2, st2, n2 * k1, flat[offsets[2]:offsets[2] + n2 * k1])
+        flat[offsets[3]:offsets[3] + n_tail].copy_(flat_tail[:n_tail])
+        grads = _deliver_param_grads(params, flat, offsets, None if _is_unit_grad(grad_loss) else grad_loss)
+        return (None, None, None, None) + tuple(grads)
+
+
 _STATE_ROWS = {}
 
 

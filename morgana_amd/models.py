@@ -66,7 +66,9 @@ class F0Model(BaseSPSS):
 
     def bf16_table_features(self):
         from . import functional as F_hip
-        return ('normalised_lab',) if (self.layers.precision or F_hip.get_precision()) == 'bf16' else ()
+        precision = self.layers.precision or F_hip.get_precision()
+        # 'bf16': the table's bf16 copy; 'bf16x3': its [hi | lo] pair planes (data.add_bf16_table) - made once per batch by the loader
+        return ('normalised_lab',) if precision == 'bf16' else ('normalised_lab:x3',) if precision == 'bf16x3' else ()
 
     def forward(self, features):
         """``predict`` + ``loss`` (base_models.py:279-285) with the stack's tail and the loss fused when a target is at hand
@@ -74,9 +76,11 @@ class F0Model(BaseSPSS):
         target = features.get('normalised_' + self.target_name)
         if target is None or not self.fused_loss:
             return super(F0Model, self).forward(features)
+        # the loader's operand table of the phone rows, if the batch carries the one this precision reads (bf16_table_features)
+        x3 = (self.layers.precision or utils.F_hip.get_precision()) == 'bf16x3'
+        table = features.get('normalised_lab' + (data.X3_TABLE_SUFFIX if x3 else data.BF16_TABLE_SUFFIX))
         x = utils.upsample_to_repetitions(features['normalised_lab'], features['dur'], max_len=target.shape[1],
-                                          fused=self.fused_upsample, table_bf16=features.get('normalised_lab' + data.BF16_TABLE_SUFFIX),
-                                          phone_rate=self.phone_rate)
+                                          fused=self.fused_upsample, table_bf16=table, phone_rate=self.phone_rate)
         loss, pred_norm = self.layers.forward_mse(x, target, seq_len=features['n_frames'])
         outputs = {'pred_norm_' + self.target_name: pred_norm}
         if self.target_name in self.normalisers:

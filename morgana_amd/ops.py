@@ -891,6 +891,167 @@ def linear_wgrad_x3(g2, a2, rows, m, n, k, out_w=None, out_b=None, accumulate=Fa
     return dw, db
 
 
+# ------------------------------------------------------------------------------- precision 'bf16x3', the FUSED step on pair planes
+# (include/morgana_hip.h, "The FUSED step of precision mode 'bf16x3' on PAIR PLANES").  A pair is a bf16 (rows, 2 ldp) buffer [hi | lo].
+F0_TAIL_X3_SLAB = 4292                 # MG_F0_TAIL_X3_SLAB: db2 128 | dW3 4096 | db3 32 | dW4 32 | db4 | loss | 2 unused
+F0_TAIL_X3_N = F0_TAIL_X3_SLAB - 2     # ... up to and including the loss
+
+
+def split_pair(x2d, transpose=False, extra_rows=0):
+    """[hi | lo] pair planes of an fp32 matrix (mg_split3_bf16 order 5): (rows + extra_rows, 2 pad_ld(cols)) bf16, the extra rows zero;
+    ``transpose``: the pair of x2d^T, (cols, 2 pad_ld(rows))."""
+    lib = _lib.load()
+    x2d = _require(x2d, torch.float32, 'operand')
+    if x2d.dim() != 2:
+        raise ValueError('split_pair: a 2-D operand is required')
+    rows, cols = x2d.shape
+    if transpose and extra_rows:
+        raise ValueError('split_pair: extra zero rows go with the plain layout')
+    ldp = pad_ld(rows if transpose else cols)
+    out = torch.empty(((cols if transpose else rows) + extra_rows, 2 * ldp), dtype=torch.bfloat16, device=x2d.device)
+    if extra_rows:
+        out[rows:].zero_()
+    descs = (_lib.Split3Desc * 1)()
+    d = descs[0]
+    d.src, d.rows, d.cols, d.lds = x2d.data_ptr(), rows, cols, x2d.stride(0)
+    d.dst, d.ldp, d.order, d.transpose, d.plane_rows = out.data_ptr(), ldp, 5, int(bool(transpose)), 0
+    d.sig, d.ldsig, d.colsum, d.colsum_blocks = None, 0, None, 0
+    _lib.check(lib.mg_split3_bf16(ctypes.cast(descs, ctypes.c_void_p), 1, _stream()), 'mg_split3_bf16')
+    return out
+
+
+def pair_shadows(weights, want_t=()):
+    """Pair-plane operands of a run of fp32 weight matrices: ([N, 2 pad_ld(K)] pairs, pairs of W^T [K, 2 pad_ld(N)] for the indices in
+    ``want_t``, None elsewhere).  As ``param_shadows``: the pairs live ON the parameter (``w._mg_pair``), ``morgana_amd.optim.Adam``'s
+    update kernel re-splits every weight it has just changed (mg_adam_shadow.pair), so a training step launches no split; a weight
+    changed by anything else is split again here."""
+    plain, trans = [], []
+    for i, w in enumerate(weights):
+        sh = getattr(w, '_mg_pair', None)
+        ok = (sh is not None and sh['version'] == (w._version, getattr(w, '_mg_updates', 0)) and sh['plain'].device == w.device
+              and (i not in want_t or sh['t'] is not None))
+        if not ok:
+            w32 = _require(w, torch.float32, 'weight')
+            n, k = w32.shape
+            old = sh if sh is not None and sh['plain'].device == w.device else None
+            # re-split INTO the existing buffers (a captured graph reads them by address)
+            new_plain = split_pair(w32.detach())
+            if old is not None:
+                old['plain'].copy_(new_plain)
+                new_plain = old['plain']
+            new_t = old['t'] if old is not None else None
+            if i in want_t or new_t is not None:
+                fresh = split_pair(w32.detach(), transpose=True)
+                if new_t is not None:
+                    new_t.copy_(fresh)
+                else:
+                    new_t = fresh
+            w._mg_pair = {'plain': new_plain, 't': new_t, 'version': (w._version, getattr(w, '_mg_updates', 0))}
+        plain.append(w._mg_pair['plain'])
+        trans.append(w._mg_pair['t'] if i in want_t else None)
+    return plain, trans
+
+
+def x3_step_ok(n_table_rows, m, k0, n0, n1, extra=None):
+    """Shapes of the fused 'bf16x3' phone-rate step: Linear(k0 -> 512) + Sigmoid, Linear(512 -> 128) on a phone table whose row
+    count takes the wide weight-gradient tiles, k0's plane 640 or 512 columns wide."""
+    extra = PHONE_RATE_EXTRA if extra is None else extra
+    rows = n_table_rows + extra
+    ldp = pad_ld(k0)
+    return (n0 == 512 and n1 == 128 and 4096 <= rows and rows < m and
+            ((ldp == 640 and 512 < k0 <= 640) or (ldp == 512 and 384 < k0 <= 512)))
+
+
+def phone_front_x3(front, linear):
+    """``phone_front`` with the first layer on PAIR PLANES: ``front`` = (dur, target, seq_len, t, extra) or None (the GEMM alone),
+    ``linear`` = (a pair (M, 2 pa), k, w pair (n, 2 pw), bias, n, act).  Returns the front's six results (when asked for) + y, the pair
+    (M, 2 n) of act(a w^T + bias) (mg_phone_front_linear_fwd_x3)."""
+    lib = _lib.load()
+    a, k, w2, bias, n, act = linear
+    m = a.shape[0]
+    y = torch.empty((m, 2 * n), dtype=torch.bfloat16, device=a.device)
+    if front is None:
+        _lib.check(lib.mg_phone_front_linear_fwd_x3(None, 0, 0, 0, None, None, 0, None, None, 0, None, None, None, None, None, 0,
+                                                    _p(a), a.shape[1], m, k, _p(w2), w2.shape[1], _p(bias), n, _p(y), 2 * n, act, _stream()),
+                   'mg_phone_front_linear_fwd_x3')
+        return (y,)
+    dur, target, seq_len, t, extra = front
+    dur = _require(dur, torch.int64, 'dur')
+    target = _require(target, torch.float32, 'targets')
+    b, p = dur.shape
+    if target.numel() != b * t:
+        raise ValueError('phone_front_x3: %d targets for %d x %d frames' % (target.numel(), b, t))
+    r = b * p
+    rows = torch.empty((2, b, t), dtype=torch.int32, device=dur.device)
+    seg = torch.empty((2, r), dtype=torch.int32, device=dur.device)
+    stats = torch.empty((2, r + extra), dtype=torch.float32, device=dur.device)
+    ws = torch.empty(lib.mg_phone_target_stats_workspace_bytes(r, extra), dtype=torch.uint8, device=dur.device)
+    _lib.check(lib.mg_phone_front_linear_fwd_x3(_p(dur), b, p, int(t), _p(target), _p(seq_len), extra, _p(rows[0]), _p(rows[1]), r, _p(seg[0]),
+                                                _p(seg[1]), _p(stats[0]), _p(stats[1]), _p(ws), ws.numel(), _p(a), a.shape[1], m, k, _p(w2),
+                                                w2.shape[1], _p(bias), n, _p(y), 2 * n, act, _stream()), 'mg_phone_front_linear_fwd_x3')
+    return rows[0], rows[1], seg, stats[0], stats[1], ws, y
+
+
+X3_FWD_PARTS = int(os.environ.get('MORGANA_X3_FWD_PARTS', '3'))      # A/B: 1 = the 128-wide layer's three passes in one workgroup per tile
+
+
+def linear_fwd_x3_f32(a2, k, w2, bias, n, act, parts=1):
+    """fp32 (M, n) = act(a w^T + bias) from pair-plane operands a2 (M, 2 pa), w2 (n, 2 pw) (mg_linear_fwd_x3_f32).  ``parts`` = 3
+    (no activation): (3, M, n) partial sums of the three products, from three sets of workgroups - the consumer adds them."""
+    m = a2.shape[0]
+    y = torch.empty((m, n) if parts == 1 else (parts, m, n), dtype=torch.float32, device=a2.device)
+    _lib.check(_lib.load().mg_linear_fwd_x3_f32(_p(a2), a2.shape[1], m, k, _p(w2), w2.shape[1], _p(bias), n, _p(y), n, act, int(parts), _stream()),
+               'mg_linear_fwd_x3_f32')
+    return y
+
+
+def f0_tail_rows_x3(z2, w3, b3, w4, b4, ybar, weight, keep_slabs=False):
+    """``f0_tail_rows_f32`` of the fused 'bf16x3' step (mg_f0_tail_rows_x3): returns (pred (rows,), dz2 PAIR (rows, 256) bf16, slab buffer,
+    n_slabs, stride); the slabs [db2 | dW3 | db3 | dW4 | db4 | loss | pad] are left unreduced for the caller (``slab_reduce``,
+    mg_expand_column_reduce_f32 or the update kernel's plan).  ``keep_slabs``: a buffer of their own (they outlive the next launches)."""
+    lib = _lib.load()
+    z2 = _require(z2, torch.float32, 'pre-activations')
+    z_parts = z2.shape[0] if z2.dim() == 3 else 1              # (3, rows, 128): three partial sums to add (linear_fwd_x3_f32 parts = 3)
+    m = z2.shape[-2]
+    if (z_parts not in (1, 3) or z2.shape[-1] != 128 or tuple(w3.shape) != (32, 128) or tuple(w4.shape) != (1, 32) or ybar.numel() != m
+            or weight.numel() != m):
+        raise ValueError('f0_tail_rows_x3: needs (rows, 128) pre-activations, a 128 -> 32 -> 1 tail and one statistics row per table row')
+    pred = torch.empty((m,), dtype=torch.float32, device=z2.device)
+    dz2 = torch.empty((m, 256), dtype=torch.bfloat16, device=z2.device)
+    ws = (_tail_slabs if keep_slabs else workspace)(lib.mg_f0_tail_rows_x3_workspace_bytes(m), z2.device)
+    n_slabs, stride = ctypes.c_int(0), ctypes.c_int64(0)
+    _lib.check(lib.mg_f0_tail_rows_x3(_p(z2), z2.shape[-1], z_parts, _p(_require(w3, torch.float32, 'w3')), _p(b3), _p(_require(w4, torch.float32, 'w4')),
+                                      _p(b4), _p(ybar), _p(weight), m, _p(pred), _p(dz2), 256, None, _p(ws), ws.numel(),
+                                      ctypes.byref(n_slabs), ctypes.byref(stride), _stream()), 'mg_f0_tail_rows_x3')
+    return pred, dz2, ws, n_slabs.value, stride.value
+
+
+def linear_wgrad_dgrad_x3(dy2, a2, m, n, k, wt2, slab=None, colsum=None):
+    """The 512 -> 128 layer's backward of the fused 'bf16x3' step as one grid (mg_linear_wgrad_dgrad_x3): dy2 pair (m, 2 * 128), a2 = the
+    sigmoid output's pair (m, 2 * 512), wt2 = the pair of W^T (k, 2 * 128).  Returns (slab buffer, n_slabs, stride, dx pair (m, 2 k),
+    colsum buffer (n_colsum, k) f32 - its ordered sum is the bias gradient of the layer below, n_colsum)."""
+    lib = _lib.load()
+    slab = _slab_buffer(slab, lib.mg_linear_wgrad_workspace_bytes(m, n, k), dy2.device)
+    need = lib.mg_linear_wgrad_dgrad_x3_colsum_floats(m, k)
+    colsum = _slab_buffer(colsum, 4 * need, dy2.device)
+    dx = torch.empty((m, 2 * k), dtype=torch.bfloat16, device=dy2.device)
+    n_slabs, stride, n_colsum = ctypes.c_int(0), ctypes.c_int64(0), ctypes.c_int(0)
+    _lib.check(lib.mg_linear_wgrad_dgrad_x3(_p(dy2), dy2.shape[1], _p(a2), a2.shape[1], m, n, k, _p(wt2), wt2.shape[1], _p(dx), 2 * k, _p(slab),
+                                            slab.numel(), ctypes.byref(n_slabs), ctypes.byref(stride), _p(colsum), colsum.numel() // 4,
+                                            ctypes.byref(n_colsum), _stream()), 'mg_linear_wgrad_dgrad_x3')
+    return slab, n_slabs.value, stride.value, dx, colsum, n_colsum.value
+
+
+def linear_wgrad_slabs_x3(dy2, a2, m, n, k, slab=None):
+    """``linear_wgrad_slabs_bf16`` on pair planes (mg_linear_wgrad_slabs_x3): slabs of n k weight partials (stride n k + n), no bias sums."""
+    lib = _lib.load()
+    slab = _slab_buffer(slab, lib.mg_linear_wgrad_workspace_bytes(m, n, k), dy2.device)
+    n_slabs, stride = ctypes.c_int(0), ctypes.c_int64(0)
+    _lib.check(lib.mg_linear_wgrad_slabs_x3(_p(dy2), dy2.shape[1], _p(a2), a2.shape[1], m, n, k, _p(slab), slab.numel(), ctypes.byref(n_slabs),
+                                            ctypes.byref(stride), _stream()), 'mg_linear_wgrad_slabs_x3')
+    return slab, n_slabs.value, stride.value
+
+
 def f0_tail(h2, w3, b3, w4, b4, target, seq_len, b, t, grads_out, grad_scale=1.0):
     """Fused layers 3-4 + masked MSE, forward and backward (mg_f0_tail_bf16).  Returns (pred (b*t,), loss 0-d, dz2)."""
     lib = _lib.load()
@@ -1667,8 +1828,10 @@ def adam_step_plan(param, grad, exp_avg, exp_avg_sq, betas, eps, weight_decay, s
     for i, (begin, count, slab, n_slabs, stride) in enumerate(slab_srcs):
         src = plan.slabs[i]
         src.begin, src.count, src.slab, src.n_slabs, src.stride = int(begin), int(count), slab.data_ptr(), int(n_slabs), int(stride)
-    for i, (offset, rows, cols, dst, dst_t) in enumerate(shadows):
+    for i, entry in enumerate(shadows):
+        offset, rows, cols, dst, dst_t = entry[:5]
         sh = plan.shadows[i]
+        sh.pair = int(bool(entry[5])) if len(entry) > 5 else 0        # [hi | lo] pair planes (pair_shadows)
         sh.offset, sh.rows, sh.cols = int(offset), int(rows), int(cols)
         sh.dst, sh.ldd = (dst.data_ptr(), dst.shape[1]) if dst is not None else (None, 0)
         sh.dst_t, sh.ldt = (dst_t.data_ptr(), dst_t.shape[1]) if dst_t is not None else (None, 0)

@@ -138,7 +138,10 @@ class Adam(torch.optim.Optimizer):
         for p in flat['params']:
             sh = getattr(p, '_mg_shadow', None)
             if sh is not None and p.dim() == 2 and sh['plain'].device == p.device:
-                out.append((flat['offsets'][id(p)], p.shape[0], p.shape[1], sh['plain'], sh['t'], p))
+                out.append((flat['offsets'][id(p)], p.shape[0], p.shape[1], sh['plain'], sh['t'], p, False))
+            pr = getattr(p, '_mg_pair', None)              # [hi | lo] pair planes of precision 'bf16x3' (ops.pair_shadows)
+            if pr is not None and p.dim() == 2 and pr['plain'].device == p.device:
+                out.append((flat['offsets'][id(p)], p.shape[0], p.shape[1], pr['plain'], pr['t'], p, True))
         return out
 
     # ---- HIP-graph support (morgana_amd/graphs.py): the captured update reads its step-dependent scalars from device memory
@@ -214,22 +217,28 @@ class Adam(torch.optim.Optimizer):
         # followed a no_grad forward found every stamp current and recorded no cast, so the layers past the plan multiplied by
         # stale bf16 weights from the second replay on.  ADVICE round 3.)
         every = self._shadows(flat)
+        pairs = [sh for sh in every if sh[6]]               # pair planes have no batched re-split launch: they go first
+        every = pairs + [sh for sh in every if not sh[6]]
         shadows, rest = every[:_lib.ADAM_MAX_SHADOWS], every[_lib.ADAM_MAX_SHADOWS:]
+        stale_pairs = [sh for sh in rest if sh[6]]
+        rest = [sh for sh in rest if not sh[6]]
         pending, flat['pending'] = flat['pending'], []
         tail, flat['tail'] = flat.get('tail'), None
         ops.adam_step_plan(flat['param'], flat['grad'], flat['exp_avg'], flat['exp_avg_sq'], group['betas'], group['eps'],
                            group['weight_decay'], self._scalar_buffers(flat)[2 * slot:], 1.0 / world, slab_srcs=pending,
-                           shadows=[sh[:5] for sh in shadows], clear_grad=self.fused_loop, tail=tail)
+                           shadows=[sh[:5] + (sh[6],) for sh in shadows], clear_grad=self.fused_loop, tail=tail)
         if rest:
             ops.refresh_shadows([sh[5] for sh in rest])
         flat['clean'] = self.fused_loop
         for p in flat['params']:
             p._mg_updates = getattr(p, '_mg_updates', 0) + 1
         for sh in every:                                     # refreshed by this update: current again
+            if sh in stale_pairs:
+                continue                                     # (more pairs than the plan holds: their next reader splits them again)
             p = sh[5]
-            p._mg_shadow['version'] = (p._version, p._mg_updates)
+            (p._mg_pair if sh[6] else p._mg_shadow)['version'] = (p._version, p._mg_updates)
         # what this update refreshed, by identity of the copies: a graph that captured it re-stamps exactly these after a replay
-        flat['refreshed'] = [(sh[5], sh[3], sh[4]) for sh in every]
+        flat['refreshed'] = [(sh[5], sh[3], sh[4]) for sh in every if sh not in stale_pairs]
 
     def refreshed_shadows(self):
         """[(parameter, plain copy, transposed copy or None)] the last update kernel launch (or its capture) kept current."""
@@ -249,9 +258,9 @@ class Adam(torch.optim.Optimizer):
                 for p in flat['params']:
                     p._mg_updates = getattr(p, '_mg_updates', 0) + n_steps
         for p, plain, trans in refreshed:
-            sh = getattr(p, '_mg_shadow', None)
-            if sh is not None and sh['plain'] is plain and sh['t'] is trans:
-                sh['version'] = (p._version, p._mg_updates)
+            for sh in (getattr(p, '_mg_shadow', None), getattr(p, '_mg_pair', None)):
+                if sh is not None and sh['plain'] is plain and sh['t'] is trans:
+                    sh['version'] = (p._version, p._mg_updates)
 
     @torch.no_grad()
     def step_captured(self, slot=0):

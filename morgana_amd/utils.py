@@ -132,6 +132,8 @@ CONCAT_PHONE_RATE = os.environ.get('MORGANA_CONCAT_PHONE_RATE', '0') != '0'
 
 # The exact-fp32 modes' fused tail (functional.F0TailRowsF32Fn); 0 = the two layers and the loss as their generic launches (A/B, tests)
 F0_TAIL_F32 = os.environ.get('MORGANA_F0_TAIL_F32', '1') != '0'
+# Precision 'bf16x3': the README stack's phone-rate step on pair planes (functional.F0StackX3Fn); 0 = the generic row-wise path (A/B, tests)
+X3_FUSED = os.environ.get('MORGANA_X3_FUSED', '1') != '0'
 
 
 # Row-wise layers behind a recurrent wrapper are packed only when at least this share of the B * T rows is padding.  Measured at C5
@@ -552,6 +554,11 @@ class SequentialWithRecurrent(nn.Sequential):
         precision = self.precision or F_hip.get_precision()
         fused = self._fused_mse_spec(targets, precision)
         if fused is None:
+            x3 = self._fused_x3_params(input, targets, seq_len, precision)
+            if x3 is not None:
+                # 'bf16x3', the README stack on repeated phone rows: the whole step on [hi | lo] pair planes (functional.F0StackX3Fn)
+                sl = seq_len if seq_len.dtype == torch.int64 else seq_len.long()
+                return F_hip.F0StackX3Fn.apply((input, input.table_bf16), input.source.reshape(-1, input.source.shape[-1]), targets, sl, *x3)
             tail = self._phone_rate_f32_tail(input, targets, seq_len, precision)
             if tail is not None:
                 # exact-fp32 modes, the README stack on repeated phone rows: the layers up to the 128-wide one on the phone rows, then
@@ -587,6 +594,29 @@ class SequentialWithRecurrent(nn.Sequential):
         for lin, _ in run:
             params += [lin.weight, lin.bias]
         return F_hip.LinearStackMSEFn.apply((acts, maps, table, phone_rate), x2d, rows, targets, seq_len, *params)
+
+    def _fused_x3_params(self, input, targets, seq_len, precision):
+        """The eight parameters of the stack when it is the README F0Model's (... -> 512 -> 128 -> 32 -> 1, sigmoids between, README.rst:65-73)
+        in precision 'bf16x3' on an ``UpsampledSequence`` at phone rate with (B, T, 1) targets - what functional.F0StackX3Fn fuses; else None."""
+        if precision != 'bf16x3' or not X3_FUSED or not isinstance(input, UpsampledSequence) or seq_len is None:
+            return None
+        found = self._readme_tail(targets, precision)
+        if found is None or tuple(targets.shape[:2]) != tuple(input.shape[:2]):
+            return None
+        run, lin3, lin4 = found
+        if len(run) != 4 or run[0][1] != ops.ACT_SIGMOID or any(lin.bias is None for lin, _ in run):
+            return None
+        lin1, lin2 = run[0][0], run[1][0]
+        n_src = input.source.shape[0] * input.source.shape[1]
+        m = input.shape[0] * input.shape[1]
+        if (lin1.weight.shape[1] != input.source.shape[-1] or lin2.weight.shape[1] != lin1.weight.shape[0]
+                or not ops.phone_rate_choice(input.phone_rate)
+                or not ops.x3_step_ok(n_src, m, lin1.weight.shape[1], lin1.weight.shape[0], lin2.weight.shape[0])):
+            return None
+        params = []
+        for lin, _ in run:
+            params += [lin.weight, lin.bias]
+        return params
 
     def _phone_rate_f32_tail(self, input, targets, seq_len, precision):
         """(pre-activations of the 128-wide layer on the phone rows (B * P + extra, 128), Linear(128, 32), Linear(32, 1)) when the whole
