@@ -497,6 +497,10 @@ int mg_split3_bf16(const mg_split3_desc* descs, int count, void* stream);
  *                     the fp32 dZ2) in front of the tail's gradients: slabs of MG_F0_TAIL_X3_SLAB floats = db2 [128] | dW3 [32 x 128] |
  *                     db3 [32] | dW4 [32] | db4 | loss | 2 unused, *n_slabs of them *stride floats apart in `workspace`
  *                     (mg_f0_tail_rows_x3_workspace_bytes(M)), reduced into grads_out [MG_F0_TAIL_X3_SLAB] when that is not NULL.
+ *  mg_f0_l2tail_x3    mg_linear_fwd_x3_f32 of the 512 -> 128 layer AND mg_f0_tail_rows_x3 as ONE launch (csrc/l2tail_x3.hip): a workgroup
+ *                     owns <= 96 consecutive rows, streams its rows of H1 (pair [M, 1024], whole lines, once) and W2's pair [128, 1024]
+ *                     through LDS, keeps Z2 = H1 W2^T + b2 on chip and runs the exact-fp32 tail on it.  Outputs and slab layout as
+ *                     mg_f0_tail_rows_x3 (workspace mg_f0_l2tail_x3_workspace_bytes(M)).
  *  mg_linear_wgrad_dgrad_x3  the 512 -> 128 layer's backward as ONE grid: dW slabs (N K floats used of each `*stride`, no bias sums) from
  *                     dY pair [M, lddy = 2 * 128] and A = H pair [M, lda = 2 * 512], and dX pair [M, lddx = 2 K] = split((dY W) * H (1 - H)),
  *                     H = hi + lo; `colsum` f32 receives *n_colsum slabs of K floats whose ordered sum is the column sum of the fp32 dX
@@ -515,6 +519,10 @@ size_t mg_f0_tail_rows_x3_workspace_bytes(int64_t M);
 int mg_f0_tail_rows_x3(const float* Z2, int ldz, int z_parts, const float* W3, const float* b3, const float* W4, const float* b4,
                        const float* ybar, const float* weight, int64_t M, float* pred, uint16_t* dZ2, int lddz, float* grads_out,
                        void* workspace, size_t workspace_bytes, int* n_slabs, int64_t* stride, void* stream);
+size_t mg_f0_l2tail_x3_workspace_bytes(int64_t M);
+int mg_f0_l2tail_x3(const uint16_t* H1, int ldh, const uint16_t* W2, int ldw, const float* b2, const float* W3, const float* b3,
+                    const float* W4, const float* b4, const float* ybar, const float* weight, int64_t M, float* pred, uint16_t* dZ2,
+                    int lddz, float* grads_out, void* workspace, size_t workspace_bytes, int* n_slabs, int64_t* stride, void* stream);
 size_t mg_linear_wgrad_dgrad_x3_colsum_floats(int64_t M, int K);
 int mg_linear_wgrad_dgrad_x3(const uint16_t* dY, int lddy, const uint16_t* A, int lda, int64_t M, int N, int K, const uint16_t* WT, int ldwt,
                              uint16_t* dX, int lddx, void* workspace, size_t workspace_bytes, int* n_slabs, int64_t* stride, float* colsum,

@@ -85,6 +85,9 @@ SIGNATURES = {
     'mg_f0_tail_rows_x3_workspace_bytes': (c_size_t, [c_int64]),
     'mg_f0_tail_rows_x3': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                    c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    'mg_f0_l2tail_x3_workspace_bytes': (c_size_t, [c_int64]),
+    'mg_f0_l2tail_x3': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     'mg_linear_wgrad_dgrad_x3_colsum_floats': (c_size_t, [c_int64, c_int]),
     'mg_linear_wgrad_dgrad_x3': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                                          c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),

@@ -281,6 +281,7 @@ __device__ __forceinline__ void gemm_nt_big_body(unsigned char* __restrict__ sme
                     bfv8 o_hi, o_lo;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
+#pragma clang fp contract(off)
                         const float h = (float)hv[e] + (float)hl[e];
                         const float x = v[e] * h * (1.f - h);
                         csum[e] += x;

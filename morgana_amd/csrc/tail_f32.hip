@@ -173,6 +173,8 @@ __global__ __launch_bounds__(256) void f0_tail_rows_f32_kernel(const float* __re
                 if (rc + r < M) {
                     const float x = dh[r] * hc[r] * (1.f - hc[r]);
                     if (X3) {
+                        // (lo from the ROUNDED product: left to the compiler the subtraction contracts with the product's last multiply)
+#pragma clang fp contract(off)
                         const uint16_t hi = mg_f2bf(x);
                         uint16_t* dst = dZ2p + (size_t)(rc + r) * lddz + kt * 16 + li;
                         dst[0] = hi;

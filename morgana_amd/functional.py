@@ -1112,12 +1112,16 @@ class F0StackX3Fn(torch.autograd.Function):
             (h1,) = ops.phone_front_x3(None, lin1)
         if rows.numel() != m:
             raise ValueError('prediction rows (%d) and target rows (%d) differ' % (rows.numel(), m))
-        # the 128-wide layer is 84 tiles at C2's table: its three passes run as three sets of workgroups, the tail adds the partial sums
-        z2 = ops.linear_fwd_x3_f32(h1, k1, w2p, b2, n2, ops.ACT_NONE, parts=ops.X3_FWD_PARTS)
         # inside a step captured whole (DEFER_TAIL: graphs.GraphedTrainStep) the repeated prediction and the tail's slab sum are left to
         # the update launch's first blocks, as in LinearStackMSEFn
         defer = DEFER_TAIL and any(ctx.needs_input_grad[4:])
-        pred_rows, dz2, ws, n_slabs, stride = ops.f0_tail_rows_x3(z2, w3, b3, w4, b4, ybar, weight, keep_slabs=defer)
+        if ops.X3_L2TAIL:
+            # the 128-wide layer, the exact-fp32 tail, the loss and their backward in one launch: Z2 never leaves the chip
+            pred_rows, dz2, ws, n_slabs, stride = ops.f0_l2tail_x3(h1, w2p, b2, w3, b3, w4, b4, ybar, weight, keep_slabs=defer)
+        else:
+            # (A/B: two launches - the layer's three passes as three sets of workgroups, the tail adds the partial sums)
+            z2 = ops.linear_fwd_x3_f32(h1, k1, w2p, b2, n2, ops.ACT_NONE, parts=ops.X3_FWD_PARTS)
+            pred_rows, dz2, ws, n_slabs, stride = ops.f0_tail_rows_x3(z2, w3, b3, w4, b4, ybar, weight, keep_slabs=defer)
         n = ops.F0_TAIL_X3_N
         flat_tail = torch.empty((ops.F0_TAIL_X3_SLAB,), dtype=torch.float32, device=x2d.device)
         pred = torch.empty((m,), dtype=torch.float32, device=x2d.device)

@@ -1026,6 +1026,27 @@ def f0_tail_rows_x3(z2, w3, b3, w4, b4, ybar, weight, keep_slabs=False):
     return pred, dz2, ws, n_slabs.value, stride.value
 
 
+X3_L2TAIL = os.environ.get('MORGANA_X3_L2TAIL', '1') != '0'      # A/B: 0 = the 128-wide layer and the fp32 tail as two launches
+
+
+def f0_l2tail_x3(h1, w2p, b2, w3, b3, w4, b4, ybar, weight, keep_slabs=False):
+    """``linear_fwd_x3_f32`` of the 512 -> 128 layer and ``f0_tail_rows_x3`` as ONE launch (mg_f0_l2tail_x3): h1 pair (rows, 1024), w2p
+    pair (128, 1024).  Returns what ``f0_tail_rows_x3`` returns."""
+    lib = _lib.load()
+    m = h1.shape[0]
+    if (h1.shape[1] != 1024 or tuple(w2p.shape) != (128, 1024) or tuple(w3.shape) != (32, 128) or tuple(w4.shape) != (1, 32)
+            or ybar.numel() != m or weight.numel() != m):
+        raise ValueError('f0_l2tail_x3: needs the (rows, 1024) pair of a 512-wide activation, a 512 -> 128 -> 32 -> 1 tail and one statistics row per table row')
+    pred = torch.empty((m,), dtype=torch.float32, device=h1.device)
+    dz2 = torch.empty((m, 256), dtype=torch.bfloat16, device=h1.device)
+    ws = (_tail_slabs if keep_slabs else workspace)(lib.mg_f0_l2tail_x3_workspace_bytes(m), h1.device)
+    n_slabs, stride = ctypes.c_int(0), ctypes.c_int64(0)
+    _lib.check(lib.mg_f0_l2tail_x3(_p(h1), h1.shape[1], _p(w2p), w2p.shape[1], _p(b2), _p(_require(w3, torch.float32, 'w3')), _p(b3),
+                                   _p(_require(w4, torch.float32, 'w4')), _p(b4), _p(ybar), _p(weight), m, _p(pred), _p(dz2), 256, None,
+                                   _p(ws), ws.numel(), ctypes.byref(n_slabs), ctypes.byref(stride), _stream()), 'mg_f0_l2tail_x3')
+    return pred, dz2, ws, n_slabs.value, stride.value
+
+
 def linear_wgrad_dgrad_x3(dy2, a2, m, n, k, wt2, slab=None, colsum=None):
     """The 512 -> 128 layer's backward of the fused 'bf16x3' step as one grid (mg_linear_wgrad_dgrad_x3): dy2 pair (m, 2 * 128), a2 = the
     sigmoid output's pair (m, 2 * 512), wt2 = the pair of W^T (k, 2 * 128).  Returns (slab buffer, n_slabs, stride, dx pair (m, 2 k),
