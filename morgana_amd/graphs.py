@@ -155,6 +155,13 @@ class GraphedTrainStep(object):
             self.exchange_mode = 'captured' if captured else 'eager'
         self._fwd_bwd = torch.cuda.CUDAGraph()
         self.optimizer.prepare_capture()               # capture records the launches, it does not run them
+        # the dropout step counter must exist before the capture opens (warmup=0: no eager step has created it) - created inside, it
+        # would be reset by every replay (ops.dropout_state)
+        from . import ops as _ops
+        for p in model.parameters():
+            if p.is_cuda:
+                _ops.dropout_state(p.device)
+                break
         # with a process group alive its watchdog thread polls events while we capture: judge only this thread's calls
         mode = dict(capture_error_mode='thread_local') if self._multi else {}
         if self.steps_per_replay > 1 and self.exchange_mode == 'eager':

@@ -701,13 +701,25 @@ def dropout_seed():
     return int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
 
 
-def dropout_draw(device):
-    """Reserve one draw of the device's dropout step counter: returns a (1,) int64 device tensor holding the counter value this call
-    (and its backward) uses; the device counter moves on in stream order - also inside a replayed HIP graph (csrc/dropout.hip)."""
+def dropout_state(device):
+    """The device's dropout step counter (created on first use, OUTSIDE any stream capture: a counter zero-filled inside a capture would
+    live in the graph's private pool and be reset by every replay - all replays would then draw the same masks, silently)."""
+    device = torch.device(device)
     index = device.index if device.index is not None else torch.cuda.current_device()
     state = _dropout_state.get(index)
     if state is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('dropout: the device step counter does not exist yet and cannot be created inside a stream capture (every '
+                               'replay would reset it and repeat its masks): call morgana_amd.ops.dropout_state(device) - or run one eager '
+                               'step - before the capture (graphs.GraphedTrainStep does)')
         state = _dropout_state[index] = torch.zeros(1, dtype=torch.int64, device=device)
+    return state
+
+
+def dropout_draw(device):
+    """Reserve one draw of the device's dropout step counter: returns a (1,) int64 device tensor holding the counter value this call
+    (and its backward) uses; the device counter moves on in stream order - also inside a replayed HIP graph (csrc/dropout.hip)."""
+    state = dropout_state(device)
     used = torch.empty(1, dtype=torch.int64, device=device)
     _lib.check(_lib.load().mg_dropout_advance(_p(state), _p(used), _stream()), 'mg_dropout_advance')
     return used

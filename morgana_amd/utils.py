@@ -91,6 +91,16 @@ class UpsampledSequence(object):
         return F_hip.UpsampleFn.apply(self.source, self.dur, self.t_cap)
 
 
+def bf16_copy_of(tensor):
+    """The bf16 copy a recurrence attached to its fp32 output (``RecurrentCuDNNWrapper._run_gru``), or None when there is none or the
+    fp32 tensor has been written in place since (its version counter moved: the copy no longer holds its values - ADVICE round 4)."""
+    entry = getattr(tensor, '_mg_bf16', None)
+    if entry is None:
+        return None
+    copy, version = entry
+    return copy if tensor._version == version else None
+
+
 class PhoneTable(object):
     """Lazy frame-rate tensor whose frames repeat the rows of a TABLE: ``table`` (B*P + extra rows, F) holds one row per phone
     (the extra rows: what padding frames gather) and ``rows`` (B, T) int32 is the frame -> phone-row map of the upsample (-1 =
@@ -371,7 +381,7 @@ class RecurrentCuDNNWrapper(nn.Module):
             out, hn = F_hip.GRUFn.apply(precision, inputs.table, hidden, seq_len, layer.weight_ih_l0, layer.weight_hh_l0,
                                         layer.bias_ih_l0, layer.bias_hh_l0, rows.view(inputs.rows.shape), seg, layout, out_bf)
             if out_bf is not None:
-                out._mg_bf16 = out_bf
+                out._mg_bf16 = (out_bf, out._version)          # valid while nobody has written `out` in place (see bf16_copy_of)
             return out, hn
         if layout is not None and (tuple(inputs.shape[:2]) != (layout.b, layout.t) or not layout.worthwhile()):
             layout = None
@@ -379,13 +389,17 @@ class RecurrentCuDNNWrapper(nn.Module):
         out, hn = F_hip.GRUFn.apply(precision, inputs, hidden, seq_len, layer.weight_ih_l0, layer.weight_hh_l0,
                                     layer.bias_ih_l0, layer.bias_hh_l0, None, None, layout, out_bf)
         if out_bf is not None:
-            out._mg_bf16 = out_bf
+            out._mg_bf16 = (out_bf, out._version)
         return out, hn
 
     def _out_shadow(self, precision, b, t, device):
         """A (B, T, H) bf16 buffer for the recurrence to fill with the bf16 copy of its output (the operand of a Linear layer that
-        follows the wrapper: no cast pass over [B, T, H]) - when the persistent bf16 recurrence will run and the width needs no padding."""
+        follows the wrapper: no cast pass over [B, T, H]) - when the caller asked for one (``want_out_shadow``: SequentialWithRecurrent
+        does when a bf16 Linear run on the unpacked rows comes next; a direct call of the wrapper does not pay for a copy nobody
+        reads), the persistent bf16 recurrence will run and the width needs no padding."""
         hid = self.layer.hidden_size
+        if not getattr(self, 'want_out_shadow', False):
+            return None
         if OUT_SHADOW and hid == ops.pad_ld(hid) and F_hip.gru_shadow_ok(precision, b, t, hid):
             return torch.empty((b, t, hid), dtype=torch.bfloat16, device=device)
         return None
@@ -785,7 +799,7 @@ class SequentialWithRecurrent(nn.Sequential):
                 for lin, _ in run:
                     params += [lin.weight, lin.bias]
                 # rows here is the frame map of upsample_to_repetitions: runs of equal indices (a hint for the layer-1 loader)
-                shadow = getattr(input, '_mg_bf16', None) if (torch.is_tensor(input) and precision == 'bf16') else None
+                shadow = bf16_copy_of(input) if (torch.is_tensor(input) and precision == 'bf16') else None
                 spec = (tuple(act for _, act in run), precision, 0, rows is not None, run.drop_spec(),
                         shadow.view(-1, shadow.shape[-1]) if shadow is not None else None)
                 out = F_hip.LinearStackFn.apply(spec, x2d, rows, *params)
@@ -843,7 +857,16 @@ class SequentialWithRecurrent(nn.Sequential):
                     continue
 
             if isinstance(module, RecurrentCuDNNWrapper):
-                input, hiddens[i] = module(input, hiddens[i], seq_len, max_len=max_len, layout=layout)
+                # the recurrence writes the bf16 copy of its output only when a bf16 Linear run on the unpacked rows reads it next
+                nxt = i + 1
+                while nxt < len(modules) and type(modules[nxt]) is nn.Dropout and (modules[nxt].p == 0 or not modules[nxt].training):
+                    nxt += 1
+                module.want_out_shadow = (precision == 'bf16' and nxt < len(modules) and type(modules[nxt]) is nn.Linear and
+                                          not (layout is not None and layout.worthwhile_for_rows()))
+                try:
+                    input, hiddens[i] = module(input, hiddens[i], seq_len, max_len=max_len, layout=layout)
+                finally:
+                    module.want_out_shadow = False
                 zero_padded = seq_len is not None
             elif isinstance(module, nn.RNNBase):
                 # a bare recurrent layer in the container (utils.py:412-413): every item runs the full padded length
@@ -860,7 +883,10 @@ class SequentialWithRecurrent(nn.Sequential):
                     # mask kernel, regenerated in the backward - never torch's nn.Dropout kernel
                     input = F_hip.DropoutFn.apply(input, float(module.p), i)
                 elif not identity:
-                    input = input * 0.0                               # p == 1: everything dropped (torch's result)
+                    # p == 1: everything dropped.  torch's own result (at::dropout multiplies by a zero scalar: 0 for finite values,
+                    # NaN for inf / NaN, -0 for negative ones - checked against torch 2.10 in tests/test_host_logic.py; ADVICE round 4
+                    # expected exact zeros, which is not what the reference's nn.Dropout returns)
+                    input = input * 0.0
                 zero_padded = zero_padded                             # zero rows stay zero under any mask
             else:
                 input = module(input)

@@ -31,3 +31,13 @@ def _persistent_kernels_completed(request):
     if request.node.get_closest_marker('gpu') is not None:
         from morgana_amd import ops
         ops.check_persistent_status()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """The GPU suite's observed parity errors -> gpurun_out/parity_report.json (tests/parity_report.py)."""
+    import parity_report
+    if parity_report.RECORDS:
+        try:
+            parity_report.write(os.path.join(REPO, 'gpurun_out', 'parity_report.json'))
+        except OSError:
+            pass

@@ -187,3 +187,44 @@ def test_graph_replay_draws_a_new_mask_every_replay():
     assert not torch.equal(masks[0], masks[1]) and not torch.equal(masks[1], masks[2])
     for mk in masks:
         assert abs(float(mk.float().mean()) - 0.5) < 0.02
+
+
+def test_graphed_step_with_warmup_zero_still_draws_new_masks(monkeypatch):
+    """the dropout step counter must never be created inside a stream capture (every replay would reset it and repeat its
+    masks).  ops.dropout_state refuses to; graphs.GraphedTrainStep creates it before its capture opens, so warmup=0 - the form
+    GraphedStepCache uses - replays with a new mask per step."""
+    from morgana_amd import graphs, optim
+    monkeypatch.setattr(ops, '_dropout_state', {})                    # a process that has never drawn a mask
+    graph = torch.cuda.CUDAGraph()
+    x = torch.rand(64, 64, device=DEV)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match='inside a stream capture'):
+        with torch.cuda.graph(graph):
+            F_hip.DropoutFn.apply(x, 0.5, 1)
+    torch.cuda.synchronize()
+    assert ops._dropout_state == {}
+
+    torch.manual_seed(3)
+    stack = utils.SequentialWithRecurrent(torch.nn.Linear(32, 64), torch.nn.Sigmoid(), torch.nn.Dropout(0.5), torch.nn.Linear(64, 8)).to(DEV)
+
+    class _Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.layers = stack
+            self.seen = None
+
+        def forward(self, feats):
+            h, _ = self.layers(feats['x'])
+            self.seen = h
+            return (h * h).mean(), {'h': h}
+
+    model = _Model().to(DEV).train()
+    feats = {'x': torch.rand(4, 16, 32, device=DEV)}
+    opt = optim.Adam(model.parameters(), lr=0.0)                       # lr 0: the weights stay, only the masks change the output
+    step = graphs.GraphedTrainStep(model, opt, feats, warmup=0)
+    outs = []
+    for _ in range(3):
+        step()
+        torch.cuda.synchronize()
+        outs.append(step.output['h'].detach().clone())
+    assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2])

@@ -25,9 +25,7 @@ def dev(x, dtype=None):
     return t if dtype is None else t.to(dtype)
 
 
-def rel_err(got, want):
-    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
-    return np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
+from parity_report import rel_err          # noqa: E402,F401  max |got - want| / max |want|, recorded per test (gpurun_out/parity_report.json)
 
 
 # ------------------------------------------------------------------------------------------------------------ K1
@@ -932,9 +930,10 @@ def test_f0_model_fp32_golden_curve_and_grads(golden, fused, precision):
         flat = prm.grad.cpu().numpy().ravel()
         np.testing.assert_allclose(np.sqrt((flat.astype(np.float64) ** 2).sum()), g['step1_gradnorm__' + name],
                                    rtol=RTOL)
+        # the reference's own 64 sampled gradient elements per parameter: 1e-4 of the largest of them (was
+        # rtol 1e-3 + atol 1e-4 max - observed errors are a few 1e-6: gpurun_out/parity_report.json)
         want = g['step1_gradval__' + name]
-        np.testing.assert_allclose(flat[g['step1_gradidx__' + name]], want, rtol=1e-3,
-                                   atol=1e-4 * np.abs(want).max())
+        assert rel_err(flat[g['step1_gradidx__' + name]], want, 'grad samples ' + name) < RTOL, name
     model.zero_grad()
     curve = _train(model, batches, 20, lr=0.01)
     np.testing.assert_allclose(curve, g['loss_curve'], rtol=RTOL)            # 20-step Adam loss curve, 1e-4
@@ -976,26 +975,42 @@ def test_f0_model_bf16_fused_and_unfused_agree_on_ragged_batch():
     assert rel_err(out[True][2], out[False][2]) < 3e-2
 
 
+_C2_ORACLE = {}
+
+
+def _c2_oracle():
+    """(features, state, oracle loss / prediction / gradients) of BASELINE config C2, computed once per session (the oracle takes seconds)."""
+    if not _C2_ORACLE:
+        feats = synthetic.make_batch(256, 1000)
+        state = synthetic.f0_model_state()
+        _C2_ORACLE['v'] = (feats, state) + tuple(ref_cpu.f0_forward_backward(state, feats))
+    return _C2_ORACLE['v']
+
+
+@pytest.mark.parametrize('phone_rate', [True, False])
 @pytest.mark.parametrize('precision,tol', [('fp32', RTOL), ('bf16x3', RTOL), ('bf16', RTOL_BF16)])
-def test_f0_model_full_size_vs_oracle(precision, tol):
-    """BASELINE config C2 (256 x 1000 frames) forward + backward against the numpy oracle."""
-    feats = synthetic.make_batch(256, 1000)
-    state = synthetic.f0_model_state()
-    want_loss, want_pred, want_grads = ref_cpu.f0_forward_backward(state, feats)
-    model = _load_state(models.F0Model(precision=precision).to(DEV), state)
-    loss, out = model(data.to_device(feats, DEV))
+def test_f0_model_full_size_vs_oracle(precision, tol, phone_rate):
+    """BASELINE config C2 (256 x 1000 frames) forward + backward against the numpy oracle, in BOTH orders of operations: phone rate
+    (the headline's: row-wise layers once per phone row) and ``phone_rate=False`` - every product on the 256 000 frame rows, the
+    reference's order, whose own kernels (gemm_nt_runs_kernel, wgrad_fused3_kernel, f0_l2tail_kernel at M = 256 000) thereby meet the
+    oracle directly.  The exact modes are held to 1e-4 on loss, prediction and every gradient."""
+    from parity_report import note
+    feats, state, want_loss, want_pred, want_grads = _c2_oracle()
+    model = _load_state(models.F0Model(precision=precision, phone_rate=phone_rate).to(DEV), state)
+    loss, out = model(data.to_device(feats, DEV, bf16_tables=model.bf16_table_features()))
     loss.backward()
+    note(abs(loss.item() - want_loss) / abs(want_loss), 'loss')
     np.testing.assert_allclose(loss.item(), want_loss, rtol=tol)
     pred = out['pred_norm_lf0'].detach().cpu().numpy()
     assert pred.shape == want_pred.shape
     if precision in ('fp32', 'bf16x3'):
-        assert rel_err(pred, want_pred) < 1e-4
+        assert rel_err(pred, want_pred, 'prediction') < 1e-4
     else:
         # The prediction is a cancelling sum of 32 O(0.1) terms built from bf16-rounded O(1) activations, so the bf16
         # mode is held to an ABSOLUTE 5e-3 (activation scale 1), not to a relative bound on the small result.
         assert np.abs(pred - want_pred).max() < 5e-3
     for name, prm in model.named_parameters():
-        assert rel_err(prm.grad.cpu().numpy(), want_grads[name]) < (1e-3 if precision in ('fp32', 'bf16x3') else 5e-2), name
+        assert rel_err(prm.grad.cpu().numpy(), want_grads[name], 'grad ' + name) < (RTOL if precision in ('fp32', 'bf16x3') else 5e-2), name
 
 
 @pytest.mark.parametrize('phone_rate', [True, False])

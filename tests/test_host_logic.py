@@ -208,3 +208,35 @@ def test_early_bucket_exchange_only_when_the_stack_is_the_model():
                    torch.nn.Parameter(torch.randn(64, 64)), torch.nn.Parameter(torch.randn(64))]
     opt3 = optim.Adam(small_first, lr=0.01, kernel=helpers.cpu_adam_kernel)
     assert opt3.bucket_split() == 0 and not graphs.early_exchange_is_safe(opt3, small_first)
+
+
+def test_bf16_copy_of_a_recurrence_output_is_dropped_after_an_in_place_write():
+    """the bf16 copy a recurrence attaches to its fp32 output (utils.bf16_copy_of) is the next Linear run's operand only
+    while the fp32 tensor still holds the values it copied - an in-place write (out.mul_(), out[:, k:] = 0, a hook) moves the version
+    counter and the copy is ignored (the run casts the tensor again)."""
+    from morgana_amd import utils
+    out = torch.rand(2, 3, 8)
+    copy = out.to(torch.bfloat16)
+    assert utils.bf16_copy_of(out) is None
+    out._mg_bf16 = (copy, out._version)
+    assert utils.bf16_copy_of(out) is copy
+    out.mul_(2.0)
+    assert utils.bf16_copy_of(out) is None
+
+
+def test_dropout_with_p_one_equals_torch_also_for_non_finite_activations():
+    """ADVICE round 4 asked for exact zeros from an active nn.Dropout(p=1) inside SequentialWithRecurrent; the reference's module is
+    torch's, whose result is input * 0 (0 for finite values, NaN for inf / NaN, -0 for negative ones) with a zero gradient - that is
+    the parity target, and what the container returns on any device."""
+    from morgana_amd import utils
+    stack = utils.SequentialWithRecurrent(torch.nn.Dropout(p=1.0))
+    stack.train()
+    x = torch.tensor([[[1.0, float('inf'), float('nan'), -2.0]]], requires_grad=True)
+    y, _ = stack(x)
+    want_in = x.detach().clone().requires_grad_(True)
+    want = torch.nn.functional.dropout(want_in, p=1.0, training=True)
+    assert torch.equal(torch.nan_to_num(y.detach(), nan=7.0), torch.nan_to_num(want.detach(), nan=7.0))
+    assert torch.equal(torch.signbit(y.detach()), torch.signbit(want.detach()))
+    y[..., 0].sum().backward()
+    want[..., 0].sum().backward()
+    assert torch.equal(x.grad, want_in.grad)
