@@ -250,7 +250,8 @@ def roofline_f0(features, model, precision):
     # HBM bytes per launch of the dominant kernel from the committed PMC passes of this round (scripts/gpu_profile.sh:
     # 2 x FETCH_SIZE + WRITE_SIZE on gfx950, MI355X_MICROARCH.md), and the bytes the launch has to move at the very least
     traffic = traffic_source = None
-    for table_name in (('r4_hbm_traffic.json', 'r3_hbm_traffic.json') if ops.PHONE_RATE else ('r4fr_hbm_traffic.json', 'r3fr_hbm_traffic.json')):
+    for table_name in (('r5_hbm_traffic.json', 'r4_hbm_traffic.json', 'r3_hbm_traffic.json') if ops.PHONE_RATE else
+                       ('r5fr_hbm_traffic.json', 'r4fr_hbm_traffic.json', 'r3fr_hbm_traffic.json')):
         try:
             table = json.load(open(os.path.join(REPO, 'profiles', table_name)))
             if table.get(short) is not None:
@@ -275,6 +276,18 @@ def roofline_f0(features, model, precision):
     else:
         out.update({'bound': 'mfma', 'achieved': dom['tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(dom['tflops'] / peak, 4),
                     'measured_traffic_gbs': round(hbm_gbs, 1)})
+    # Both fractions, whichever roof `bound` names, and what the kernel's own measurements say limits it: at
+    # phone-rate row counts the wide tile programs wait for LDS-DMA line requests - a CU takes in about one 128-byte line per 10 cycles
+    # from beyond its XCD's L2 (4 from it) - not for the matrix pipe and not for HBM bandwidth (profiles/r4_notes_falsified_kernel_ideas.txt;
+    # round 5: the pair-plane weight gradient went from 63 to 45 us when its line requests per row went from 21 to 14, same FLOPs, same bytes)
+    out['frac_mfma'] = round(dom['tflops'] / peak, 4)
+    if traffic is not None:
+        out['frac_hbm_measured'] = round(traffic / (dom['ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    if algorithmic_bytes:
+        out['frac_hbm_algorithmic'] = round(algorithmic_bytes / (dom['ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    if ops.PHONE_RATE and precision == 'bf16':
+        out['bound_detail'] = ('neither roof: LDS-DMA line-request intake (about one 128-byte line per 10 cycles and CU from beyond the XCD\'s L2, '
+                               '~7 TB/s over the chip) - `bound` names the roof the contraction would meet first, `frac` the fraction of it')
     out['kernels'] = measured
     return out
 
@@ -546,6 +559,74 @@ def sustained_mfma_tflops(dev, launches=4, trips=20000):
     return launches * flop.value / (ms * 1e-3) / 1e12, ms, n_wg
 
 
+def roofline_f0_x3(features, model):
+    """The five launches of the fused 'bf16x3' phone-rate step (functional.F0StackX3Fn) timed in isolation with HIP events through a
+    graph, the dominant one against the bf16 MFMA roof.  FLOPs = the bf16 products the matrix cores execute: three per product of the
+    step (the exact-fp32 tail's products counted once); algorithmic bytes = pair-plane operands once + results once."""
+    lab = features['normalised_lab']
+    b, p, k = lab.shape
+    target = features['normalised_lf0'].reshape(-1)
+    t = features['normalised_lf0'].shape[1]
+    seq_len = features['n_frames']
+    extra = ops.PHONE_RATE_EXTRA
+    r_tab = b * p + extra
+    lins = [mod for mod in model.layers if isinstance(mod, torch.nn.Linear)]
+    w1, b1, w2, b2, w3, b3, w4, b4 = [t_.detach() for lin in lins for t_ in (lin.weight, lin.bias)]
+    n1, n2 = w1.shape[0], w2.shape[0]
+    tab = features.get('normalised_lab' + data.X3_TABLE_SUFFIX)
+    if tab is None:
+        tab = ops.split_pair(lab.view(b * p, k), extra_rows=extra)
+    w1p, w2p, w2tp = ops.split_pair(w1), ops.split_pair(w2), ops.split_pair(w2, transpose=True)
+    dur2d = features['dur'].reshape(b, -1).contiguous()
+    front = (dur2d, target, seq_len, t, extra)
+    res = ops.phone_front_x3(front, (tab, k, w1p, b1, n1, ops.ACT_SIGMOID))
+    ybar, weight, h1 = res[3], res[4], res[6]
+    _, dz2, _, _, _ = ops.f0_l2tail_x3(h1, w2p, b2, w3, b3, w4, b4, ybar, weight)
+    dz2 = dz2.clone()
+    bufs = {}
+
+    def pair():
+        bufs['s2'], _, _, dz1, bufs['cs'], _ = ops.linear_wgrad_dgrad_x3(dz2, h1, r_tab, n2, n1, w2tp, slab=bufs.get('s2'), colsum=bufs.get('cs'))
+        return dz1
+    dz1 = pair().clone()
+
+    def wgrad1():
+        bufs['s1'], _, _ = ops.linear_wgrad_slabs_x3(dz1, tab, r_tab, n1, k, slab=bufs.get('s1'))
+    ldk = tab.shape[1] // 2
+    kernels = [
+        ('phone_front_gemm_kernel<1,192,2>: layer-1 forward on pair planes (%d rows, 600->512 + bias + sigmoid, output split) with the frame map and '
+         'the per-phone loss statistics riding' % r_tab, 3 * 2.0 * r_tab * k * n1,
+         2.0 * (2 * r_tab * ldk + 2 * n1 * ldk + 2 * r_tab * n1) + b * t * 12.0,
+         lambda: ops.phone_front_x3(front, (tab, k, w1p, b1, n1, ops.ACT_SIGMOID))),
+        ('f0_l2tail_x3_kernel: layer 2 on pair planes (Z2 on chip) + the exact-fp32 tail + masked MSE + their backward', 3 * 2.0 * r_tab * n1 * n2 + 2.0 * r_tab * (3 * 128 * 32 + 64),
+         2.0 * (2 * r_tab * n1 + 2 * n2 * n1 + 2 * r_tab * n2) + 12.0 * r_tab,
+         lambda: ops.f0_l2tail_x3(h1, w2p, b2, w3, b3, w4, b4, ybar, weight)),
+        ('wgrad_dgrad_pair_kernel<4,256,1>: layer-2 wgrad slabs and layer-2 dgrad + sigmoid-grad (output split, bias column sums) in one grid',
+         3 * 4.0 * r_tab * n1 * n2, 2.0 * (2 * r_tab * n2 + 2 * n1 * n2 + 4 * r_tab * n1) + 4.0 * n2 * n1, pair),
+        ('wgrad_big_kernel<5,1,2>: layer-1 wgrad on pair planes (all four planes per stage, 32 split-M slabs)', 3 * 2.0 * r_tab * k * n1,
+         2.0 * (2 * r_tab * n1 + 2 * r_tab * ldk) + 4.0 * n1 * k, wgrad1),
+    ]
+    measured = []
+    for name, flops, nbytes, fn in kernels:
+        ms = time_kernel(fn, graph=True)
+        measured.append({'kernel': name, 'ms': round(ms, 4), 'gflop': round(flops / 1e9, 1), 'tflops': round(flops / (ms * 1e-3) / 1e12, 2),
+                         'algorithmic_bytes': round(nbytes), 'algorithmic_gbs': round(nbytes / (ms * 1e-3) / 1e9, 1)})
+    dom = max(measured, key=lambda r: r['ms'])
+    traffic = traffic_source = None
+    try:
+        table = json.load(open(os.path.join(REPO, 'profiles', 'r5x3_hbm_traffic.json')))
+        traffic = table.get(dom['kernel'].split(':')[0].split('<')[0])
+        traffic_source = 'profiles/r5x3_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (2 x FETCH_SIZE + WRITE_SIZE per launch), not re-measured in this run'
+    except (OSError, ValueError):
+        pass
+    return {'kernel': dom['kernel'], 'ms_per_launch': dom['ms'], 'bound': 'mfma', 'achieved': dom['tflops'], 'peak': MFMA_BF16_PEAK_TFLOPS,
+            'unit': 'TFLOP/s', 'frac': round(dom['tflops'] / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_source,
+            'algorithmic_bytes': dom['algorithmic_bytes'],
+            'frac_hbm_algorithmic': round(dom['algorithmic_gbs'] / HBM_PEAK_GBS, 4),
+            'bound_detail': 'LDS-DMA line-request intake, as the bf16 step\'s kernels (roofline.bound_detail); tflops counts three bf16 products per product',
+            'kernels': measured}
+
+
 def bf16x3_legs(dev, features, state_dict, steps, frames_per_step):
     """Precision mode 'bf16x3' (split-bf16 operands: three bf16 MFMA products per fp32 product, fp32 activations - the mode that
     meets the reference's loss curve to 1e-4, `loss_curve_deviation.bf16x3`) timed on the C2 batch in the same run as the bf16
@@ -581,14 +662,126 @@ def bf16x3_legs(dev, features, state_dict, steps, frames_per_step):
             if not phone_rate:
                 tf = 3.0 * F0_FLOPS_PER_FRAME * frames_per_step / (ms * 1e-3) / 1e12
                 out[key].update({'tflops_bf16_products': round(tf, 1), 'frac_of_mfma_peak': round(tf / MFMA_BF16_PEAK_TFLOPS, 4)})
+            else:
+                import morgana_amd._lib as _l
+                _l.CALL_LOG = []
+                try:
+                    probe = graphs.GraphedTrainStep(model, opt, features, warmup=0)       # a capture runs nothing: counts the step's entry points
+                    out[key]['launches_per_step'] = len(_l.CALL_LOG)
+                    out[key]['entry_points'] = list(_l.CALL_LOG)
+                    del probe
+                finally:
+                    _l.CALL_LOG = None
+                try:
+                    out[key]['roofline'] = roofline_f0_x3(features, model)
+                except Exception as exc:                  # noqa: BLE001
+                    out[key]['roofline'] = {'error': str(exc).splitlines()[0][:200]}
             del step, model, opt
         except Exception as exc:                          # noqa: BLE001 - a leg that fails is reported, the headline stands
             out[key] = {'error': str(exc).splitlines()[0][:200]}
         finally:
             gc.enable()
-    out['what'] = ("F0Model(precision='bf16x3'): x = hi + lo in bf16, x w ~= hi hi + hi lo + lo hi as one bf16 GEMM over a three times longer "
-                   "contraction index (csrc/split3.hip), fp32 activations and accumulators; phone_rate = the headline's order of operations "
-                   "(row-wise layers on the phone rows; the 128 -> 32 -> 1 tail, the per-phone masked MSE and their backward as one exact-fp32 launch), frame_rate_order = every product on the B*T frame rows")
+    out['what'] = ("F0Model(precision='bf16x3'): x = hi + lo in bf16, x w ~= hi hi + hi lo + lo hi, fp32 accumulators.  phone_rate = the headline's "
+                   "order of operations as the FUSED step on [hi | lo] pair planes (functional.F0StackX3Fn: five launches - layer 1 with the front "
+                   "riding, layers 2-4 + loss + their backward with Z2 on chip and the 128 -> 32 -> 1 tail exact fp32, the pair grid, the "
+                   "layer-1 weight gradient, the update, which keeps the weights' pairs current); frame_rate_order = every product on the B*T "
+                   "frame rows through the generic row-wise path (three-plane operands split in passes of their own, csrc/split3.hip)")
+    return out
+
+
+def train_epoch_block(dev, state_dict, headline_ms, n_batches=52):
+    """The loop the north star names - ``ExperimentBuilder.train_epoch`` (/root/reference/morgana/experiment_builder.py:464-494) - timed over
+    DISTINCT batches: ``n_batches`` C2-shaped batches resident on the device, each with its own operand table
+    (the loader's half of the precision mode, made per batch by data.add_bf16_table and timed beside the loop), through the product's
+    ``train_epoch`` as eager launches and with ``use_graphs=True`` (graphs.GraphedStepCache: a batch signature is captured once and
+    replayed on every later batch, only what the step reads copied into the graph's buffers), for the bf16 headline and for 'bf16x3';
+    and a ragged variant (600-1000 frames per utterance, padded lengths bucketed to four shapes) with the cache's hits counted.  Inputs
+    are in HBM when the clock starts; one synchronisation per epoch, as the product's loop has (the reference reads the loss every batch)."""
+    import gc
+    from morgana_amd import experiment_builder
+    out = {'what': 'ExperimentBuilder.train_epoch over %d distinct device-resident batches (lab drawn on the device per batch; durations and '
+                   'targets from four host-made batches rolled along the batch axis): ms per step = epoch wall time / steps incl. the '
+                   'epoch\'s one synchronisation; host_us_per_step = time the host took to issue the epoch' % n_batches}
+
+    def resident(host_batches):
+        batches = []
+        for i in range(n_batches):
+            h = host_batches[i % len(host_batches)]
+            roll = (i // len(host_batches)) * 7
+            feats = {k: (np.roll(v, roll, axis=0) if isinstance(v, np.ndarray) else v[roll % len(v):] + v[:roll % len(v)]) for k, v in h.items()}
+            b = data.to_device(feats, dev)
+            keep = (b['dur'] > 0).to(torch.float32)                                    # phones past an utterance's end stay zero rows
+            b['normalised_lab'] = torch.rand(b['normalised_lab'].shape, device=dev) * keep
+            batches.append(b)
+        return batches
+
+    def run(batches, precision, use_graphs, frames):
+        eb = experiment_builder.ExperimentBuilder(models.F0Model, model_kwargs={'precision': precision}, learning_rate=0.01, device=dev,
+                                                  use_graphs=use_graphs)
+        eb.model.load_state_dict(state_dict)
+        tables = eb.model.bf16_table_features()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for b in batches:
+            for stale in [k for k in b if k.endswith(data.BF16_TABLE_SUFFIX) or k.endswith(data.X3_TABLE_SUFFIX)]:
+                del b[stale]
+            for name in tables:
+                data.add_bf16_table(b, name)
+        e1.record()
+        e1.synchronize()
+        table_us = e0.elapsed_time(e1) * 1e3 / len(batches)
+        optimizer = eb.make_optimizer()
+        eb.train_epoch(batches, optimizer)                       # first epoch: buffers, operand shadows, the graphs of the shapes
+        gc.collect()
+        gc.disable()
+        try:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eb.train_epoch(batches, optimizer)
+            dt = time.perf_counter() - t0
+        finally:
+            gc.enable()
+        ms = dt / len(batches) * 1e3
+        rec = {'ms_per_step': round(ms, 4), 'value': round(frames / (ms * 1e-3), 1), 'unit': 'frames/s', 'steps': len(batches),
+               'host_us_per_step': round(eb.last_epoch_stats['host_issue_s'] / eb.last_epoch_stats['steps'] * 1e6, 1),
+               'loader_table_us_per_batch': round(table_us, 1),
+               'vs_headline': round(ms / headline_ms, 3) if precision == 'bf16' else None}
+        if use_graphs and eb._graph_cache is not None:
+            rec['graph_cache'] = eb._graph_cache.stats()          # over both epochs: eager = first batch of a signature
+        del eb, optimizer
+        return rec
+
+    try:
+        fixed_host = [synthetic.make_batch(256, 1000, seed=synthetic.REFERENCE_SEED + 1000 + i) for i in range(4)]
+        fixed = resident(fixed_host)
+        frames = int(fixed_host[0]['n_frames'].sum())
+        out['fixed_shape'] = {'batches': '%d x (256 utterances x 1000 frames)' % n_batches}
+        for precision in ('bf16', 'bf16x3'):
+            for use_graphs in (True, False):
+                out['fixed_shape']['%s_%s' % (precision, 'graphs' if use_graphs else 'eager')] = run(fixed, precision, use_graphs, frames)
+        del fixed
+        ragged_host = []
+        for i, t_pad in enumerate((700, 800, 900, 1000)):
+            h = synthetic.make_batch(256, (600, t_pad), seed=synthetic.REFERENCE_SEED + 2000 + i)
+            p_pad = int(round(t_pad / 12.5))
+            for key in list(h):
+                v = h[key]
+                if isinstance(v, np.ndarray) and v.ndim == 3:           # pad to the bucket's shape (collate pads to the batch's longest item)
+                    want = p_pad if key in ('dur', 'normalised_lab') else t_pad
+                    if v.shape[1] < want:
+                        h[key] = np.concatenate([v, np.zeros((v.shape[0], want - v.shape[1], v.shape[2]), v.dtype)], axis=1)
+            ragged_host.append(h)
+        ragged = resident(ragged_host)
+        mean_frames = int(np.mean([int(h['n_frames'].sum()) for h in ragged_host]))
+        out['ragged'] = {'batches': '%d x 256 utterances of 600-1000 frames, padded lengths 700 / 800 / 900 / 1000 in turn' % n_batches,
+                         'frames_per_step_mean': mean_frames}
+        for use_graphs in (True, False):
+            out['ragged']['bf16_%s' % ('graphs' if use_graphs else 'eager')] = run(ragged, 'bf16', use_graphs, mean_frames)
+        del ragged
+    except Exception as exc:                          # noqa: BLE001 - a block that fails is reported, the headline stands
+        out['error'] = str(exc).splitlines()[0][:300] if str(exc) else type(exc).__name__
+    gc.collect()
+    torch.cuda.empty_cache()
     return out
 
 
@@ -1060,6 +1253,30 @@ def main():
             result['step_executed'] = {'gflop_per_step': round(executed / 1e9, 1), 'tflops': round(ex_tflops, 2),
                                        'frac_of_mfma_peak': round(ex_tflops / peak, 4),
                                        'what': 'what the matrix cores multiply in one step of the headline form'}
+            if phone_rate_step and args.precision == 'bf16':
+                # The whole step against its floors.  Algorithmic bytes = every operand once per kernel that
+                # needs it + every result once, in the precision the step stores them (no split-M slabs: those are the implementation's):
+                #   layer-1 forward   table bf16 + W1 + H1 write | frame map + targets + statistics
+                #   layers 2-4 + loss H1 read + dZ2 write (bf16) + the per-phone prediction
+                #   pair              dZ2 + H1 + W2^T read, dZ1 write, dW2
+                #   layer-1 wgrad     dZ1 + table read, dW1
+                #   update            p, m, v read + written, gradient read, bf16 operand copies written; prediction repeated to frames
+                ldk = ops.pad_ld(lab_shape[2])
+                n_par = sum(p.numel() for p in model.parameters())
+                table_b, h1_b, dz2_b, dz1_b = 2.0 * r_tab * ldk, 2.0 * r_tab * 512, 2.0 * r_tab * 128, 2.0 * r_tab * 512
+                w_b = 2.0 * (512 * ldk + 2 * 128 * 512)
+                step_bytes = ((table_b + w_b + h1_b + 12.0 * frames_per_step + 16.0 * r_tab) + (h1_b + dz2_b + 8.0 * r_tab) +
+                              (dz2_b + h1_b + dz1_b + 4.0 * 128 * 512) + (dz1_b + table_b + 4.0 * 512 * lab_shape[2]) +
+                              (28.0 * n_par + w_b + 8.0 * frames_per_step))
+                floor_hbm_ms = step_bytes / (HBM_PEAK_GBS * 1e9) * 1e3
+                floor_mfma_ms = executed / (peak * 1e12) * 1e3
+                floor_ms = max(floor_hbm_ms, floor_mfma_ms)
+                result['step_floor'] = {'algorithmic_bytes': round(step_bytes), 'gflop': round(executed / 1e9, 1),
+                                        'hbm_floor_ms': round(floor_hbm_ms, 4), 'mfma_floor_ms': round(floor_mfma_ms, 4),
+                                        'floor_ms': round(floor_ms, 4), 'ms_per_step_over_floor': round(ms_per_step / floor_ms, 2),
+                                        'what': 'the step\'s algorithmic HBM bytes (operands and results once per kernel, no split-M slabs) at 8 TB/s and '
+                                                'its executed FLOPs at the 2.5 PFLOP/s bf16 MFMA peak; the larger is the floor.  The step is five '
+                                                'launches of one-tile latency chains: DESIGN.md says where the factor goes'}
             if phone_rate_step:
                 # NOT a fraction of peak: the reference algorithm's FLOPs over a step that performs 12x fewer of them
                 result['reference_equivalent'] = {'gflop_per_step': round(algorithmic / 1e9, 1),
@@ -1082,6 +1299,7 @@ def main():
             result['c4'] = {'error': str(exc).splitlines()[0][:200]}
         result['other_workloads'] = other_workloads(dev, args.precision)
         result['bf16x3'] = bf16x3_legs(dev, features, model.state_dict(), args.steps, frames_per_step)
+        result['train_epoch'] = train_epoch_block(dev, model.state_dict(), ms_per_step)
         try:
             result['loss_curve_deviation'] = loss_curve_deviation(dev)
         except Exception as exc:

@@ -447,6 +447,17 @@ typedef struct {
     int ldt;
 } mg_cast_desc;
 int mg_cast_params_bf16(const mg_cast_desc* descs, int count, void* stream);
+/* Up to MG_COPY_MAX device-to-device copies as ONE launch (dst[i][0 .. bytes[i]) = src[i][...], buffers 16-byte aligned or any size
+ * handled bytewise at the ends): a captured training step replayed on a NEW batch takes the batch's tensors into its static buffers
+ * this way - the feature dict of /root/reference/morgana/data.py:648-663 is five tensors at BASELINE config C2, five copy launches of
+ * 3-15 us each where one does (graphs.GraphedTrainStep.load).  `descs` is a HOST array. */
+#define MG_COPY_MAX 16
+typedef struct {
+    const void* src;
+    void* dst;
+    int64_t bytes;
+} mg_copy_desc;
+int mg_copy_many(const mg_copy_desc* descs, int count, void* stream);
 /* Operand splits of precision mode 'bf16x3' (split-bf16: hi = bf16(x), lo = bf16(x - hi); x w ~= hi hi + hi lo + lo hi as ONE bf16
  * GEMM over a contraction index three times as long; csrc/split3.hip).  The reference computes these products in fp32
  * (morgana/experiment_builder.py:262-263: no autocast, morgana/data.py:127: float32 features); this mode reproduces them to ~1e-5

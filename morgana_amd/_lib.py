@@ -77,6 +77,7 @@ SIGNATURES = {
     'mg_cast_transpose_bf16': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     'mg_cast_params_bf16': (c_int, [c_void_p, c_int, c_void_p]),
     'mg_cast_bf16_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    'mg_copy_many': (c_int, [c_void_p, c_int, c_void_p]),
     'mg_split3_bf16': (c_int, [c_void_p, c_int, c_void_p]),
     'mg_phone_front_linear_fwd_x3': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int64, c_int, c_void_p,
@@ -234,6 +235,14 @@ class CastDesc(ctypes.Structure):
     """mg_cast_desc of include/morgana_hip.h."""
     _fields_ = [('src', c_void_p), ('rows', c_int), ('cols', c_int), ('dst', c_void_p), ('ldd', c_int),
                 ('dst_t', c_void_p), ('ldt', c_int)]
+
+
+class CopyDesc(ctypes.Structure):
+    """mg_copy_desc of include/morgana_hip.h."""
+    _fields_ = [('src', c_void_p), ('dst', c_void_p), ('bytes', c_int64)]
+
+
+COPY_MAX = 16
 
 
 class Split3Desc(ctypes.Structure):

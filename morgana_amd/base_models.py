@@ -65,6 +65,14 @@ class BaseModel(nn.Module):
         state = torch.load(checkpoint_path, map_location=device)
         self.load_state_dict(state, strict=strict)
 
+    def step_input_keys(self, features):
+        """Names of the tensors of ``features`` that the captured training step READS (``graphs.GraphedStepCache`` copies only those into a
+        graph's static buffers when it replays the step on a new batch; the other entries are handed over by reference).  None = all of
+        them (the default: correct for any model).  A model whose step reads an operand table instead of the fp32 feature it was made
+        from names the table and leaves the feature out - the copy of the 49 MB ``normalised_lab`` is most of what a replay on a new
+        batch would cost at BASELINE config C2."""
+        return None
+
     def bf16_table_features(self):
         """Names of the phone-level input features whose bf16 operand table this model reads when it runs in bf16 precision (the
         loader then carries ``name + '__bf16_table'`` next to the feature: ``data.DeviceBatches.use_bf16_tables``); () otherwise."""

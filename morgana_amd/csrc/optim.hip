@@ -291,6 +291,27 @@ __global__ __launch_bounds__(256) void cast_params_kernel(CastBatch batch) {
     }
 }
 
+struct CopyBatch {
+    mg_copy_desc d[MG_COPY_MAX];
+};
+
+// blockIdx.y = descriptor; 16 bytes per thread and trip where both ends are 16-byte aligned, bytes otherwise
+__global__ __launch_bounds__(256) void copy_many_kernel(CopyBatch batch) {
+    const mg_copy_desc d = batch.d[blockIdx.y];
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(d.src);
+    unsigned char* dst = reinterpret_cast<unsigned char*>(d.dst);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        const int64_t n16 = d.bytes >> 4;
+        typedef unsigned int cm_u32x4 __attribute__((ext_vector_type(4)));
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride)
+            reinterpret_cast<cm_u32x4*>(dst)[i] = reinterpret_cast<const cm_u32x4*>(src)[i];
+        for (int64_t i = (n16 << 4) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.bytes; i += stride) dst[i] = src[i];
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.bytes; i += stride) dst[i] = src[i];
+    }
+}
+
 static int flat_grid(int64_t n) {
     int64_t blocks = mg_ceil_div(n, 256 * 4);
     if (blocks > 4096) blocks = 4096;
@@ -449,6 +470,24 @@ int mg_cast_params_bf16(const mg_cast_desc* descs, int count, void* stream) {
     }
     hipLaunchKernelGGL(cast_params_kernel, dim3(256, count), dim3(256), 0, (hipStream_t)stream, batch);
     MG_CHECK_LAUNCH("mg_cast_params_bf16");
+    return MG_OK;
+}
+
+int mg_copy_many(const mg_copy_desc* descs, int count, void* stream) {
+    MG_CHECK_ARG(descs && count > 0 && count <= MG_COPY_MAX, "mg_copy_many: count %d not in 1..%d", count, MG_COPY_MAX);
+    CopyBatch batch;
+    int64_t most = 0;
+    for (int i = 0; i < count; ++i) {
+        MG_CHECK_ARG(descs[i].bytes >= 0 && (descs[i].bytes == 0 || (descs[i].src && descs[i].dst)), "mg_copy_many: bad descriptor %d", i);
+        batch.d[i] = descs[i];
+        if (descs[i].bytes > most) most = descs[i].bytes;
+    }
+    if (most == 0) return MG_OK;
+    int64_t blocks = mg_ceil_div(most, 256 * 16 * 4);          // ~4 trips of 16 bytes per thread for the largest one
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(copy_many_kernel, dim3((unsigned)blocks, count), dim3(256), 0, (hipStream_t)stream, batch);
+    MG_CHECK_LAUNCH("mg_copy_many");
     return MG_OK;
 }
 

@@ -75,6 +75,8 @@ class ExperimentBuilder(object):
         loss = None
         n_batches = len(data_loader)
         i = -1
+        import time
+        t_loop = time.perf_counter()
         for i, features in enumerate(data_loader):
             self.model.step = (self.epoch - 1) * n_batches + i + 1
 
@@ -104,6 +106,8 @@ class ExperimentBuilder(object):
             if gen_output:
                 self.model.analysis_for_train_batch(features, output_features, out_dir=out_dir,
                                                     **self.analysis_kwargs)
+        # how long the host took to ISSUE the epoch's steps (the device may still be working: the one sync of the epoch comes below)
+        self.last_epoch_stats = {'steps': i + 1, 'host_issue_s': time.perf_counter() - t_loop}
         if gen_output:
             self.model.analysis_for_train_epoch(out_dir=out_dir, **self.analysis_kwargs)
         if out_dir:

@@ -243,11 +243,21 @@ class GraphedTrainStep(object):
         functional.backward(loss)
         self.optimizer.step()
 
-    def load(self, features, slot=0):
-        """Copy a new batch (same keys, shapes and dtypes) into the captured buffers (of step ``slot`` of a multi-step replay)."""
+    def load(self, features, slot=0, keys=None):
+        """Copy a new batch (same keys, shapes and dtypes) into the captured buffers (of step ``slot`` of a multi-step replay).
+        ``keys``: the tensors the captured step reads (``BaseModel.step_input_keys``); None = every tensor of the batch."""
+        pairs, rest = [], []
         for key, value in features.items():
-            if isinstance(value, torch.Tensor):
-                self.batches[slot][key].copy_(value, non_blocking=True)
+            if isinstance(value, torch.Tensor) and (keys is None or key in keys):
+                dst = self.batches[slot][key]
+                ok = (value.is_cuda and dst.is_cuda and value.device == dst.device and value.dtype == dst.dtype and value.is_contiguous()
+                      and dst.is_contiguous() and value.numel() == dst.numel())
+                (pairs if ok else rest).append((dst, value))
+        if pairs:
+            from . import ops
+            ops.copy_many(pairs)                       # one launch for the batch's tensors (a copy kernel each: 3-15 us apiece)
+        for dst, value in rest:
+            dst.copy_(value, non_blocking=True)
 
     def __call__(self):
         """``steps_per_replay`` training steps (one by default); returns the (device, 0-d) loss tensor of the last of them - valid
@@ -310,7 +320,11 @@ class GraphedStepCache(object):
             static = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in features.items()}
             graphed = self._steps[key] = GraphedTrainStep(self.model, self.optimizer, static, warmup=0)
         elif graphed is not None:
-            graphed.load(features)
+            # only what the captured step reads is copied into the graph's static buffers (BaseModel.step_input_keys); a tensor the step
+            # never reads (the fp32 phone feature beside its operand table: 49 MB at C2) stays where it is, and the entry the captured
+            # graph holds for it keeps its own static copy (nobody reads that one)
+            keys = self.model.step_input_keys(features) if hasattr(self.model, 'step_input_keys') else None
+            graphed.load(features, keys=None if keys is None else set(keys))
         if graphed is not None:
             for k, v in features.items():              # non-tensor entries (utterance names) follow the batch
                 if not isinstance(v, torch.Tensor):

@@ -70,6 +70,14 @@ class F0Model(BaseSPSS):
         # 'bf16': the table's bf16 copy; 'bf16x3': its [hi | lo] pair planes (data.add_bf16_table) - made once per batch by the loader
         return ('normalised_lab',) if precision == 'bf16' else ('normalised_lab:x3',) if precision == 'bf16x3' else ()
 
+    def step_input_keys(self, features):
+        # with the loader's operand table of this precision in the batch the fused steps read the table, never the fp32 feature
+        precision = self.layers.precision or utils.F_hip.get_precision()
+        suffix = {'bf16': data.BF16_TABLE_SUFFIX, 'bf16x3': data.X3_TABLE_SUFFIX}.get(precision)
+        if suffix is None or not self.fused_loss or not self.fused_upsample or 'normalised_lab' + suffix not in features:
+            return None
+        return [k for k, v in features.items() if isinstance(v, torch.Tensor) and k not in ('normalised_lab', 'lab')]
+
     def forward(self, features):
         """``predict`` + ``loss`` (base_models.py:279-285) with the stack's tail and the loss fused when a target is at hand
         (``SequentialWithRecurrent.forward_mse``); identical outputs otherwise."""

@@ -595,6 +595,22 @@ def linear_bwd_fused2_slabs_bf16(dz2, wt2, h1, a, rows, m, n_hidden, k0, slab=No
     return (slab, n_slabs.value, (0, stride1.value, n_hidden * k0 + n_hidden), (off2.value, stride2.value, 128 * n_hidden + 128))
 
 
+def copy_many(pairs):
+    """dst.copy_(src) for every (dst, src) pair of equal-sized contiguous device tensors, MG_COPY_MAX pairs per launch (mg_copy_many):
+    the tensors of a new batch into a captured step's static buffers as one launch instead of one per tensor."""
+    lib = _lib.load()
+    pairs = list(pairs)
+    for i in range(0, len(pairs), _lib.COPY_MAX):
+        chunk = pairs[i:i + _lib.COPY_MAX]
+        descs = (_lib.CopyDesc * len(chunk))()
+        for j, (dst, src) in enumerate(chunk):
+            if (not dst.is_cuda or not src.is_cuda or dst.device != src.device or not dst.is_contiguous() or not src.is_contiguous()
+                    or dst.dtype != src.dtype or dst.numel() != src.numel()):
+                raise ValueError('copy_many: pairs of contiguous tensors of one device, dtype and size are required')
+            descs[j].src, descs[j].dst, descs[j].bytes = src.data_ptr(), dst.data_ptr(), src.numel() * src.element_size()
+        _lib.check(lib.mg_copy_many(ctypes.cast(descs, ctypes.c_void_p), len(chunk), _stream()), 'mg_copy_many')
+
+
 def cast_params_bf16(weights, want_plain=True, want_t=()):
     """One launch: bf16 copies [N, pad_ld(K)] of every fp32 weight and, for the indices in `want_t`, the transposed
     copies [K, pad_ld(N)].  Returns (plain list, transposed list with None where not requested)."""
