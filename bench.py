@@ -615,7 +615,10 @@ def roofline_f0_x3(features, model):
     traffic = traffic_source = None
     try:
         table = json.load(open(os.path.join(REPO, 'profiles', 'r5x3_hbm_traffic.json')))
-        traffic = table.get(dom['kernel'].split(':')[0].split('<')[0])
+        import re
+        head = dom['kernel'].split(':')[0]
+        m_ = re.match(r'([^<]+)<([^,>]+)', head)
+        traffic = table.get('%s<%s>' % (m_.group(1), m_.group(2)) if m_ else head)          # summarise_profile.short's key
         traffic_source = 'profiles/r5x3_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (2 x FETCH_SIZE + WRITE_SIZE per launch), not re-measured in this run'
     except (OSError, ValueError):
         pass
