@@ -472,7 +472,7 @@ MG_STAMP_DECL(g_stamps_ntp);
 template <int BN, int BK, int MODE>
 constexpr int ntp_lds_bytes() {
     constexpr int STAGE = 256 * BK * 2 + BN * BK * 2;
-    constexpr int NS = (BK == 64) ? 3 : ((BN == 256) ? 4 : 5);
+    constexpr int NS = (BK == 64) ? (BN == 256 ? 2 : 3) : ((BN == 256) ? 4 : 5);
     constexpr int PATCH = NS * STAGE + NTP_MAX_TILES(BN) * 256 * 4;
     constexpr bool kPatchInRing = MODE != 1 && STAGE >= 8 * 32 * 128;
     return PATCH + (kPatchInRing ? 0 : (MODE == 1 ? 8 * 32 * 64 : 8 * 32 * 128)) + BN * 4;
@@ -495,7 +495,7 @@ __device__ __forceinline__ void gemm_nt_persist_body(unsigned char* __restrict__
     // BMV: rows of a tile that hold output (256, or 192 = the square tile cut to three quarters so that the 21 504-row phone table of C2
     // makes 224 one-tile workgroups instead of 168: the LDS stage keeps its 256 row slots, the last 64 are fed from the zero row and
     // never read).  The GEMM alone: 30.4 -> 24.3 us at that shape.
-    static_assert(BMV == 256 || (BMV == 192 && BN == 256 && BK == 32 && MODE == 0 && !STAG), "192-row tiles: the plain square form only");
+    static_assert(BMV == 256 || (BMV == 192 && BN == 256 && MODE == 0 && !STAG), "192-row tiles: the plain square form only");
     constexpr int WM = BMV / WAVES_M;             // 128, 96 or 64
     constexpr int TM = WM / 32, TN = 2;
     constexpr int ROWB = BK * 2;                  // bytes of a stage row: 64 or 128
@@ -512,9 +512,10 @@ __device__ __forceinline__ void gemm_nt_persist_body(unsigned char* __restrict__
     constexpr int GA = BM / RPP / 8;              // 1 KB pieces per wave for A: 2 or 4
     constexpr int GB = BN / RPP / 8;              // for B: 2, 1 or 2
     constexpr int NL = (GA + GB) * (NATIVE ? 2 : 1);       // LDS-DMA instructions per wave per stage: 4, 3 or 6
-    constexpr int NS = NATIVE ? 2 : ((BK == 64) ? 3 : ((BN == 256) ? 4 : 5));
+    // (BN 256 with 64-deep stages: two slots of 64 KB - a DMA row is a whole 128-byte line, half the line requests of two 32-deep stages)
+    constexpr int NS = NATIVE ? 2 : ((BK == 64) ? (BN == 256 ? 2 : 3) : ((BN == 256) ? 4 : 5));
     constexpr int NST = TM * 4 * (X3 ? 2 : 1);    // epilogue stores per wave per tile: 16 or 8 (X3: both planes)
-    static_assert(!X3 || (MODE == 0 && !STAG && BN == 256 && BK == 32), "X3: the plain square form only");
+    static_assert(!X3 || (MODE == 0 && !STAG && BN == 256 && (BK == 32 || X3 == 1)), "X3: the plain square form only (native: 32-deep)");
     constexpr int ROWTAB = NS * STAGE;            // int32[MAXT][256]
     constexpr int MAXT = NTP_MAX_TILES(BN);
     constexpr int PATCH = ROWTAB + MAXT * BM * 4;
@@ -1047,12 +1048,13 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const uint16_t* __
 // the first layer's GEMM, which reads none of its outputs: blocks [0, side_blocks) run the jobs, the blocks behind them are the persistent tile program.  The GEMM of
 // C2's phone table has 168 tiles, one per workgroup and CU: the jobs take CUs it leaves idle and two launch boundaries disappear.
 // side_blocks is a multiple of 8 (the tile order derives a block's XCD from its id modulo 8).
-template <int EPI, int BMV = 256, int X3 = 0>
+template <int EPI, int BMV = 256, int X3 = 0, int BK = 32>
 __global__ __launch_bounds__(512) void phone_front_gemm_kernel(unsigned side_blocks, int wave_ints, PhoneFrontArgs pf, const uint16_t* __restrict__ A, int lda,
                                                                int64_t M, int K, const uint16_t* __restrict__ Bm, int ldb, int N,
                                                                const float* __restrict__ bias, uint16_t* __restrict__ C, int ldc, int tiles_m,
                                                                int tiles_n) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[ntp_lds_bytes<256, 32, 0>()];
+    static_assert(ntp_lds_bytes<256, BK, 0>() == ntp_lds_bytes<256, 32, 0>(), "the front's jobs were sized for this LDS block");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[ntp_lds_bytes<256, BK, 0>()];
     if (blockIdx.x < side_blocks) {
         if (pf.lds_ints > 0) {
             if (wave_ints > 0)       // wave jobs (phone_front.h): the block's eight waves each work off jobs of their own, no barrier
@@ -1064,7 +1066,7 @@ __global__ __launch_bounds__(512) void phone_front_gemm_kernel(unsigned side_blo
         return;                                          // lds_ints == 0: timing probe, the rider's blocks leave at once
     }
     if (pf.probe & 8) return;
-    gemm_nt_persist_body<256, EPI, false, 32, 0, BMV, X3>(smem, blockIdx.x - side_blocks, gridDim.x - side_blocks, A, lda, nullptr, M, K, Bm, ldb, N, bias, C,
+    gemm_nt_persist_body<256, EPI, false, BK, 0, BMV, X3>(smem, blockIdx.x - side_blocks, gridDim.x - side_blocks, A, lda, nullptr, M, K, Bm, ldb, N, bias, C,
                                                      ldc, tiles_m, tiles_n, 0);
 }
 
@@ -1714,13 +1716,19 @@ int mg_launch_phone_front_gemm(const PhoneFrontArgs& pf, const uint16_t* A, int 
     if (g_mg_tuning[MG_TUNE_AB] >= 70 && g_mg_tuning[MG_TUNE_AB] < 86) a.probe = g_mg_tuning[MG_TUNE_AB] - 70;
 #endif
     dim3 grid((unsigned)(side + g)), block(512);
-#define LAUNCH_PFG(EPI_, BMV_)                                                                                                                  \
-    hipLaunchKernelGGL((phone_front_gemm_kernel<EPI_, BMV_>), grid, block, 0, st, (unsigned)side, wave_ints, a, A, lda, M, K, Bm, ldb, N, bias, C, \
+#define LAUNCH_PFG(EPI_, BMV_, BK_)                                                                                                             \
+    hipLaunchKernelGGL((phone_front_gemm_kernel<EPI_, BMV_, 0, BK_>), grid, block, 0, st, (unsigned)side, wave_ints, a, A, lda, M, K, Bm, ldb, N, bias, C, \
                        ldc, (int)tiles_m, tiles_n)
+    // MG_TUNE_AB 88 (A/B, round 5): 64-deep stages in two 64 KB slots - a DMA row is then a whole 128-byte line, half the line requests
+    // of two 32-deep stages for the same bytes.  MEASURED EQUAL (C2 step 0.1041 vs 0.1050 ms, box noise): the front's intake follows the
+    // bytes, not the request count; the pair-plane form with 64-deep three-pass stages (87) was 4 % slower than the native 32-deep one.
+    const bool deep64 = g_mg_tuning[MG_TUNE_AB] == 88 && lda % 64 == 0 && ldb % 64 == 0;
     if (epi == EPI_BIAS) {
-        if (bmv == 192) LAUNCH_PFG(EPI_BIAS, 192); else LAUNCH_PFG(EPI_BIAS, 256);
+        if (bmv == 192) { if (deep64) LAUNCH_PFG(EPI_BIAS, 192, 64); else LAUNCH_PFG(EPI_BIAS, 192, 32); }
+        else { if (deep64) LAUNCH_PFG(EPI_BIAS, 256, 64); else LAUNCH_PFG(EPI_BIAS, 256, 32); }
     } else {
-        if (bmv == 192) LAUNCH_PFG(EPI_BIAS_SIGMOID, 192); else LAUNCH_PFG(EPI_BIAS_SIGMOID, 256);
+        if (bmv == 192) { if (deep64) LAUNCH_PFG(EPI_BIAS_SIGMOID, 192, 64); else LAUNCH_PFG(EPI_BIAS_SIGMOID, 192, 32); }
+        else { if (deep64) LAUNCH_PFG(EPI_BIAS_SIGMOID, 256, 64); else LAUNCH_PFG(EPI_BIAS_SIGMOID, 256, 32); }
     }
 #undef LAUNCH_PFG
     return 1;
@@ -1862,17 +1870,24 @@ int mg_launch_nt_persist_x3(const PhoneFrontArgs* pf, const uint16_t* A, int lda
         if (g > blocks) g = mg_ceil_div(blocks, 8 * tiles_n) * 8 * tiles_n;
     }
     dim3 grid((unsigned)(side + g)), block(512);
-#define LAUNCH_PFG3(EPI_, BMV_, X3_)                                                                                                             \
-    hipLaunchKernelGGL((phone_front_gemm_kernel<EPI_, BMV_, X3_>), grid, block, 0, st, (unsigned)side, wave_ints, a, A, lda, M, K, Bm, ldb, N, bias, C, \
+#define LAUNCH_PFG3(EPI_, BMV_, X3_, BK_)                                                                                                        \
+    hipLaunchKernelGGL((phone_front_gemm_kernel<EPI_, BMV_, X3_, BK_>), grid, block, 0, st, (unsigned)side, wave_ints, a, A, lda, M, K, Bm, ldb, N, bias, C, \
                        ldc, (int)tiles_m, tiles_n)
-    // X3_ = 2: the native form (one ring slot holds the k-tile of all four planes); MG_TUNE_AB 89 (A/B): three passes over the plane
-    const bool passes = g_mg_tuning[MG_TUNE_AB] == 89;
+    // X3_ = 2: the native form (one ring slot holds the 32-deep k-tile of all four planes); MG_TUNE_AB 89 (A/B): three passes over the
+    // plane, 32-deep; 87 (A/B): three passes with 64-deep stages (whole-line DMA rows, 1.5x the bytes of the native form)
+    const int ab3 = g_mg_tuning[MG_TUNE_AB];
+    if (ab3 == 87) {
+        if (epi == EPI_BIAS) { if (bmv == 192) LAUNCH_PFG3(EPI_BIAS, 192, 1, 64); else LAUNCH_PFG3(EPI_BIAS, 256, 1, 64); }
+        else { if (bmv == 192) LAUNCH_PFG3(EPI_BIAS_SIGMOID, 192, 1, 64); else LAUNCH_PFG3(EPI_BIAS_SIGMOID, 256, 1, 64); }
+        return 1;
+    }
+    const bool passes = ab3 == 89;
     if (epi == EPI_BIAS) {
-        if (bmv == 192) { if (passes) LAUNCH_PFG3(EPI_BIAS, 192, 1); else LAUNCH_PFG3(EPI_BIAS, 192, 2); }
-        else { if (passes) LAUNCH_PFG3(EPI_BIAS, 256, 1); else LAUNCH_PFG3(EPI_BIAS, 256, 2); }
+        if (bmv == 192) { if (passes) LAUNCH_PFG3(EPI_BIAS, 192, 1, 32); else LAUNCH_PFG3(EPI_BIAS, 192, 2, 32); }
+        else { if (passes) LAUNCH_PFG3(EPI_BIAS, 256, 1, 32); else LAUNCH_PFG3(EPI_BIAS, 256, 2, 32); }
     } else {
-        if (bmv == 192) { if (passes) LAUNCH_PFG3(EPI_BIAS_SIGMOID, 192, 1); else LAUNCH_PFG3(EPI_BIAS_SIGMOID, 192, 2); }
-        else { if (passes) LAUNCH_PFG3(EPI_BIAS_SIGMOID, 256, 1); else LAUNCH_PFG3(EPI_BIAS_SIGMOID, 256, 2); }
+        if (bmv == 192) { if (passes) LAUNCH_PFG3(EPI_BIAS_SIGMOID, 192, 1, 32); else LAUNCH_PFG3(EPI_BIAS_SIGMOID, 192, 2, 32); }
+        else { if (passes) LAUNCH_PFG3(EPI_BIAS_SIGMOID, 256, 1, 32); else LAUNCH_PFG3(EPI_BIAS_SIGMOID, 256, 2, 32); }
     }
 #undef LAUNCH_PFG3
     return 1;
