@@ -651,7 +651,7 @@ def bf16x3_legs(dev, features, state_dict, steps, frames_per_step):
             step = graphs.GraphedTrainStep(model, opt, features, steps_per_replay=n)
             gc.collect()
             gc.disable()
-            for _ in range(max(40 // n, 2)):
+            for _ in range(max(400 // n, 2)):           # the headline's warm-up: ~400 steps in front of the clock (see main)
                 step()
             torch.cuda.synchronize()
             t0 = time.perf_counter()

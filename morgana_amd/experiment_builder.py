@@ -77,7 +77,12 @@ class ExperimentBuilder(object):
         i = -1
         import time
         t_loop = time.perf_counter()
-        for i, features in enumerate(data_loader):
+        loss_log = None
+        batches = iter(data_loader)
+        ahead = next(batches, None)                     # one batch of look-ahead (the graph cache loads it beside the current step)
+        while ahead is not None:
+            i, features = i + 1, ahead
+            ahead = next(batches, None)
             self.model.step = (self.epoch - 1) * n_batches + i + 1
 
             if self.use_graphs:
@@ -85,7 +90,8 @@ class ExperimentBuilder(object):
                 if self._graph_cache is None or self._graph_cache.optimizer is not optimizer:
                     from . import graphs
                     self._graph_cache = graphs.GraphedStepCache(self.model, optimizer)
-                batch_loss, output_features = self._graph_cache.step(features)
+                batch_loss, output_features = self._graph_cache.step(features, clone_loss=False)
+                self._graph_cache.prefetch(ahead)                                # the next batch into the idle buffers, beside this step
             else:
                 optimizer.zero_grad()                                            # :468
                 batch_loss, output_features = self.model(features)               # :471
@@ -95,19 +101,26 @@ class ExperimentBuilder(object):
             if lr_schedule is not None and self.lr_schedule_name in lr_schedules.BATCH_LR_SCHEDULES:
                 lr_schedule.step()                                               # :477-478
 
-            batch_loss = batch_loss.detach()
-            loss = batch_loss if loss is None else loss + batch_loss             # :480, kept on the device
+            # :480, :487 - the batch losses are filed on the device, one slot per batch (ONE small launch per step where the running sum, the
+            # metric's sum and its add and a copy of the replayed graph's loss were four); the epoch's sum and the 'loss' metric are taken
+            # from the log once, behind the loop: the same sums (metrics.Mean: sum of the batch losses / their count)
+            if loss_log is None:
+                loss_log = torch.zeros(max(n_batches, 1), dtype=torch.float32, device=batch_loss.device)
+            if i >= loss_log.numel():                                            # a loader that yields more than its len(): grow
+                loss_log = torch.cat((loss_log, torch.zeros_like(loss_log)))
+            loss_log[i].copy_(batch_loss.detach())
 
             if self.ema_decay:
                 self.ema.update_params(self.model)                               # :483-484
-
-            self.model.metrics.accumulate(self.model.mode, loss=batch_loss)      # :487
 
             if gen_output:
                 self.model.analysis_for_train_batch(features, output_features, out_dir=out_dir,
                                                     **self.analysis_kwargs)
         # how long the host took to ISSUE the epoch's steps (the device may still be working: the one sync of the epoch comes below)
         self.last_epoch_stats = {'steps': i + 1, 'host_issue_s': time.perf_counter() - t_loop}
+        if loss_log is not None:
+            self.model.metrics.accumulate(self.model.mode, loss=loss_log[:i + 1])
+            loss = loss_log[:i + 1].sum()
         if gen_output:
             self.model.analysis_for_train_epoch(out_dir=out_dir, **self.analysis_kwargs)
         if out_dir:

@@ -290,21 +290,72 @@ class GraphedStepCache(object):
     A batch whose (name, shape, dtype) signature is new runs eagerly - an ordinary training step, which also warms up allocator and
     workspaces for that shape; the second batch of a signature is captured into static copies of its tensors (capture runs
     nothing) and replayed, and every later one is copied into those buffers and replayed.  No step is ever run twice or skipped, so
-    the loop trains exactly as the eager loop does (bit-identical, tests/test_gpu_parity.py)."""
+    the loop trains exactly as the eager loop does (bit-identical, tests/test_gpu_parity.py).
+
+    ``prefetch`` (optional, called right AFTER ``step`` with the batch that comes next - what ``ExperimentBuilder.train_epoch`` does with
+    one batch of look-ahead): a signature holds TWO captured
+    steps with a set of static buffers each, used in turn, and the NEXT batch is copied into the idle set on a side stream while the
+    current step's graph runs - the copy of a batch (27.5 MB operand table at BASELINE config C2: ~15 us) then costs the step nothing.
+    Without ``prefetch`` the copy runs in line in front of the replay, as before."""
 
     MAX_SEEN = 1024      # signatures remembered as "ran once": a ragged loader whose frame totals never repeat must not grow this forever
 
     def __init__(self, model, optimizer, max_graphs=8):
         self.model, self.optimizer, self.max_graphs = model, optimizer, max_graphs
         self._seen = collections.OrderedDict()
-        self._steps = {}
-        self.eager_steps = self.replayed_steps = 0        # how the steps were run (see ``stats``)
+        self._steps = {}                                  # signature -> [GraphedTrainStep, ...] (at most two: the ping-pong pair)
+        self._turn = {}                                   # signature -> index of the step object the next batch takes
+        self._copy_stream = None
+        self._prefetched = None                           # (features object, signature, step object) of the batch loaded ahead
+        self._before_replay = None                        # event on the main stream in front of the last replay (see ``prefetch``)
+        self.eager_steps = self.replayed_steps = self.prefetched_steps = 0        # how the steps were run (see ``stats``)
         self._warned = False
 
     def stats(self):
-        """{'eager': steps run as ordinary launches, 'replayed': steps replayed from a graph, 'graphs': graphs held}.  Mostly eager
-        steps mean the batches do not repeat their signature: bucket ragged lengths to a few shapes for ``use_graphs`` to pay."""
-        return {'eager': self.eager_steps, 'replayed': self.replayed_steps, 'graphs': len(self._steps)}
+        """{'eager': steps run as ordinary launches, 'replayed': steps replayed from a graph, 'graphs': graphs held, 'prefetched':
+        replays whose batch was loaded ahead on the side stream}.  Mostly eager steps mean the batches do not repeat their signature:
+        bucket ragged lengths to a few shapes for ``use_graphs`` to pay."""
+        return {'eager': self.eager_steps, 'replayed': self.replayed_steps, 'graphs': sum(len(v) for v in self._steps.values()),
+                'prefetched': self.prefetched_steps}
+
+    def _keys(self, features):
+        keys = self.model.step_input_keys(features) if hasattr(self.model, 'step_input_keys') else None
+        return None if keys is None else set(keys)
+
+    def prefetch(self, features):
+        """Load ``features`` (the batch ``step`` will be called with NEXT; call this right after the current ``step``) into the idle
+        static buffers of its signature on a side stream, beside the step that has just been launched.  A no-op unless the signature
+        has its two captured steps already."""
+        if features is None or self._prefetched is not None:
+            return
+        key = self.signature(features)
+        pair = self._steps.get(key)
+        if pair is None or len(pair) < 2:
+            return
+        graphed = pair[self._turn.get(key, 0)]
+        main = torch.cuda.current_stream()
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream()
+        side = self._copy_stream
+        # The copy may start once (a) the loader's kernels that produced this batch and (b) the last replay that read the target buffers
+        # have run.  Both were enqueued on `main` BEFORE the replay of the step that is running now (`_before_replay`: recorded by
+        # ``step`` right in front of its replay; the caller fetched this batch before it called ``step``) - so the copy waits for that
+        # point, not for the running step, and runs beside it.
+        if self._before_replay is not None:
+            side.wait_event(self._before_replay)
+        else:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            graphed.load(features, keys=self._keys(features))
+            for v in features.values():
+                if isinstance(v, torch.Tensor) and v.is_cuda:
+                    v.record_stream(side)                  # the batch's memory must outlive the copy, whatever frees it on `main`
+            done = torch.cuda.Event()
+            done.record(side)
+        self._prefetched = (features, key, graphed, done)
+
+    def graph_count(self):
+        return sum(len(v) for v in self._steps.values())
 
     @staticmethod
     def signature(features):
@@ -312,25 +363,43 @@ class GraphedStepCache(object):
         return tuple(sorted((k, tuple(v.shape), str(v.dtype)) if isinstance(v, torch.Tensor) else (k, v)
                             for k, v in features.items() if isinstance(v, (torch.Tensor, int))))
 
-    def step(self, features):
-        """zero_grad, forward, backward, optimizer step on ``features``; returns (loss, output_features)."""
+    def step(self, features, clone_loss=True):
+        """zero_grad, forward, backward, optimizer step on ``features``; returns (loss, output_features).  ``clone_loss`` False: the
+        replayed graph's own loss tensor is handed out - valid until the next replay of that graph (a caller that files it away at once)."""
         key = self.signature(features)
-        graphed = self._steps.get(key)
-        if graphed is None and key in self._seen and len(self._steps) < self.max_graphs:
+        pair = self._steps.get(key)
+        graphed = None
+        ahead, self._prefetched = self._prefetched, None
+        if ahead is not None and ahead[0] is features:
+            graphed = ahead[2]                            # loaded ahead on the side stream: the replay waits for that copy only
+            torch.cuda.current_stream().wait_event(ahead[3])
+            self.prefetched_steps += 1
+        elif ahead is not None:
+            torch.cuda.current_stream().wait_event(ahead[3])      # a batch loaded ahead that did not come next: its copy must still land
+        if graphed is None and key in self._seen and (pair is None or len(pair) < 2) and self.graph_count() < 2 * self.max_graphs:
+            # the second (third) batch of a signature: capture a step on static copies of its tensors - two per signature, taken in turn
             static = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in features.items()}
-            graphed = self._steps[key] = GraphedTrainStep(self.model, self.optimizer, static, warmup=0)
-        elif graphed is not None:
+            graphed = GraphedTrainStep(self.model, self.optimizer, static, warmup=0)
+            self._steps.setdefault(key, []).append(graphed)
+            self._turn[key] = 0 if len(self._steps[key]) < 2 else 1
+        elif graphed is None and pair:
             # only what the captured step reads is copied into the graph's static buffers (BaseModel.step_input_keys); a tensor the step
             # never reads (the fp32 phone feature beside its operand table: 49 MB at C2) stays where it is, and the entry the captured
             # graph holds for it keeps its own static copy (nobody reads that one)
-            keys = self.model.step_input_keys(features) if hasattr(self.model, 'step_input_keys') else None
-            graphed.load(features, keys=None if keys is None else set(keys))
+            graphed = pair[self._turn.get(key, 0)]
+            graphed.load(features, keys=self._keys(features))
         if graphed is not None:
+            if len(self._steps[key]) == 2:
+                self._turn[key] = 1 - self._steps[key].index(graphed)
             for k, v in features.items():              # non-tensor entries (utterance names) follow the batch
                 if not isinstance(v, torch.Tensor):
                     graphed.features[k] = v
             self.replayed_steps += 1
-            return graphed().clone(), graphed.output      # the loss buffer is rewritten by the next replay: hand out a copy
+            self._before_replay = torch.cuda.Event()
+            self._before_replay.record(torch.cuda.current_stream())
+            loss = graphed()
+            return (loss.clone() if clone_loss else loss), graphed.output      # the loss buffer is rewritten by that graph's next replay
+        self._before_replay = None                        # an eager step: a batch loaded ahead waits for all of it
         self._seen[key] = True
         self._seen.move_to_end(key)
         while len(self._seen) > self.MAX_SEEN:

@@ -71,12 +71,28 @@ class F0Model(BaseSPSS):
         return ('normalised_lab',) if precision == 'bf16' else ('normalised_lab:x3',) if precision == 'bf16x3' else ()
 
     def step_input_keys(self, features):
-        # with the loader's operand table of this precision in the batch the fused steps read the table, never the fp32 feature
+        # With the loader's operand table of this precision in the batch the FUSED steps read the table, never the fp32 feature - but
+        # only they do: any other path of the stack (a batch too small for the fused 'bf16x3' step, a stack that is not the README's)
+        # casts or splits the fp32 feature inside the step.  Decided by the very predicates the forward pass uses.
+        from . import ops
         precision = self.layers.precision or utils.F_hip.get_precision()
         suffix = {'bf16': data.BF16_TABLE_SUFFIX, 'bf16x3': data.X3_TABLE_SUFFIX}.get(precision)
-        if suffix is None or not self.fused_loss or not self.fused_upsample or 'normalised_lab' + suffix not in features:
+        lab, target = features.get('normalised_lab'), features.get('normalised_' + self.target_name)
+        table = features.get('normalised_lab' + suffix) if suffix is not None else None
+        if table is None or lab is None or target is None or not self.fused_loss or not self.fused_upsample:
             return None
-        return [k for k, v in features.items() if isinstance(v, torch.Tensor) and k not in ('normalised_lab', 'lab')]
+        rows, k = lab.shape[0] * lab.shape[1] + ops.PHONE_RATE_EXTRA, lab.shape[2]
+        if precision == 'bf16':
+            reads_table = self.layers._fused_mse_spec(target, precision) is not None and tuple(table.shape) == (rows, ops.pad_ld(k))
+        else:
+            reads_table = False
+            if ops.phone_rate_choice(self.phone_rate) and tuple(table.shape) == (rows, 2 * ops.pad_ld(k)):
+                x = utils.upsample_to_repetitions(lab, features['dur'], max_len=target.shape[1], fused=True, table_bf16=table, phone_rate=True)
+                reads_table = (isinstance(x, utils.UpsampledSequence) and
+                               self.layers._fused_x3_params(x, target, features['n_frames'], precision) is not None)
+        if not reads_table:
+            return None
+        return [k_ for k_, v in features.items() if isinstance(v, torch.Tensor) and k_ not in ('normalised_lab', 'lab')]
 
     def forward(self, features):
         """``predict`` + ``loss`` (base_models.py:279-285) with the stack's tail and the loss fused when a target is at hand

@@ -2626,3 +2626,34 @@ def test_f0_tail_rows_f32_kernel(m):
     assert close(flat[4128:4160].view(1, 32), w4t.grad) and close(flat[4160:4161], b4t.grad)
 
 
+
+
+@pytest.mark.parametrize('precision,shape', [('bf16', (64, 300)), ('bf16x3', (64, 300)), ('bf16x3', (96, 500))])
+def test_graph_cache_loads_the_next_batch_beside_the_running_step(precision, shape):
+    """graphs.GraphedStepCache with one batch of look-ahead (ExperimentBuilder.train_epoch): a signature holds two captured steps used in
+    turn, and the NEXT batch is copied into the idle one's static buffers on a side stream while the current step runs (only the tensors
+    the step reads: BaseModel.step_input_keys - the operand table, not the fp32 feature it was made from).  Eight distinct batches of a
+    slab-taking shape, two epochs, against the eager loop: epoch losses and final parameters EQUAL, and the replays were loaded ahead."""
+    from morgana_amd import experiment_builder
+    # (64 x 300: 2 560 table rows - the fused bf16 step, but the GENERIC 'bf16x3' path, which splits the fp32 feature inside the step: the
+    # model must then name every tensor; 96 x 500: 4 864 rows - the fused 'bf16x3' step, which reads the pair table only)
+    batches = [synthetic.make_batch(shape[0], shape[1], seed=300 + i) for i in range(8)]
+
+    def train(use_graphs):
+        torch.manual_seed(3)
+        builder = experiment_builder.ExperimentBuilder(models.F0Model, dict(precision=precision), learning_rate=0.01, device=DEV, end_epoch=2,
+                                                       use_graphs=use_graphs)
+        _load_state(builder.model, synthetic.f0_model_state())
+        dev_batches = [data.to_device(b, DEV, bf16_tables=builder.model.bf16_table_features()) for b in batches]
+        history = builder.run_train(dev_batches)
+        return history, {k: v.detach().clone() for k, v in builder.model.named_parameters()}, builder
+
+    hist_e, params_e, _ = train(False)
+    hist_g, params_g, builder = train(True)
+    assert hist_g == hist_e
+    for name in params_e:
+        assert torch.equal(params_g[name], params_e[name]), name
+    stats = builder._graph_cache.stats()
+    assert stats['graphs'] == 2 and stats['eager'] == 1 and stats['replayed'] == 15 and stats['prefetched'] >= 11, stats
+    keys = builder.model.step_input_keys(data.to_device(batches[0], DEV, bf16_tables=builder.model.bf16_table_features()))
+    assert (keys is None) == (precision == 'bf16x3' and shape == (64, 300))           # only the fused steps leave the fp32 feature out
