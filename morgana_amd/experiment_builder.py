@@ -90,8 +90,12 @@ class ExperimentBuilder(object):
                 if self._graph_cache is None or self._graph_cache.optimizer is not optimizer:
                     from . import graphs
                     self._graph_cache = graphs.GraphedStepCache(self.model, optimizer)
-                batch_loss, output_features = self._graph_cache.step(features, clone_loss=False)
-                self._graph_cache.prefetch(ahead)                                # the next batch into the idle buffers, beside this step
+                if loss_log is None:
+                    loss_log = torch.zeros(max(n_batches, 1), dtype=torch.float32, device=self.device)
+                slot = loss_log[i] if i < loss_log.numel() else None
+                batch_loss, output_features = self._graph_cache.step(features, clone_loss=False, loss_slot=slot)
+                filed = slot is not None and self._graph_cache._pending_loss is not None      # rides in the next batch's load launch
+                self._graph_cache.prefetch(ahead)                                # (MORGANA_GRAPH_PREFETCH: measured, off)
             else:
                 optimizer.zero_grad()                                            # :468
                 batch_loss, output_features = self.model(features)               # :471
@@ -107,8 +111,11 @@ class ExperimentBuilder(object):
             if loss_log is None:
                 loss_log = torch.zeros(max(n_batches, 1), dtype=torch.float32, device=batch_loss.device)
             if i >= loss_log.numel():                                            # a loader that yields more than its len(): grow
+                if self.use_graphs and self._graph_cache is not None:
+                    self._graph_cache.flush()
                 loss_log = torch.cat((loss_log, torch.zeros_like(loss_log)))
-            loss_log[i].copy_(batch_loss.detach())
+            if not (self.use_graphs and filed):
+                loss_log[i].copy_(batch_loss.detach().reshape(()))
 
             if self.ema_decay:
                 self.ema.update_params(self.model)                               # :483-484
@@ -118,6 +125,8 @@ class ExperimentBuilder(object):
                                                     **self.analysis_kwargs)
         # how long the host took to ISSUE the epoch's steps (the device may still be working: the one sync of the epoch comes below)
         self.last_epoch_stats = {'steps': i + 1, 'host_issue_s': time.perf_counter() - t_loop}
+        if self.use_graphs and self._graph_cache is not None:
+            self._graph_cache.flush()                                            # the last step's loss into its slot
         if loss_log is not None:
             self.model.metrics.accumulate(self.model.mode, loss=loss_log[:i + 1])
             loss = loss_log[:i + 1].sum()

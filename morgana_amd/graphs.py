@@ -243,10 +243,11 @@ class GraphedTrainStep(object):
         functional.backward(loss)
         self.optimizer.step()
 
-    def load(self, features, slot=0, keys=None):
+    def load(self, features, slot=0, keys=None, extra_pairs=()):
         """Copy a new batch (same keys, shapes and dtypes) into the captured buffers (of step ``slot`` of a multi-step replay).
-        ``keys``: the tensors the captured step reads (``BaseModel.step_input_keys``); None = every tensor of the batch."""
-        pairs, rest = [], []
+        ``keys``: the tensors the captured step reads (``BaseModel.step_input_keys``); None = every tensor of the batch.
+        ``extra_pairs``: further (dst, src) device copies that ride in the same launch (GraphedStepCache files the previous step's loss)."""
+        pairs, rest = list(extra_pairs), []
         for key, value in features.items():
             if isinstance(value, torch.Tensor) and (keys is None or key in keys):
                 dst = self.batches[slot][key]
@@ -284,6 +285,13 @@ def early_exchange_is_safe(optimizer, stack_params, group=0):
     return len(stack_params) == len(own) and all(a is b for a, b in zip(stack_params, own))
 
 
+# Load the next batch into a second captured step's buffers on a side stream while the current step runs (GraphedStepCache.prefetch).
+# MEASURED (round 5, C2, profiles/r5_train_epoch_timeline.txt) and OFF: the copy does run beside the step, but it takes bandwidth and CUs
+# from the weight-gradient kernel it overlaps (26 -> 37-41 us) and the replay's wait for the side stream's event costs the ~20 us the
+# copy would have - 0.158 ms per step either way.
+PREFETCH = os.environ.get('MORGANA_GRAPH_PREFETCH', '0') != '0'
+
+
 class GraphedStepCache(object):
     """Graph replay inside a training loop whose batches repeat a few shapes (``ExperimentBuilder(use_graphs=True)``).
 
@@ -308,6 +316,7 @@ class GraphedStepCache(object):
         self._copy_stream = None
         self._prefetched = None                           # (features object, signature, step object) of the batch loaded ahead
         self._before_replay = None                        # event on the main stream in front of the last replay (see ``prefetch``)
+        self._pending_loss = None                         # (slot, loss tensor) of the last replayed step, not yet filed
         self.eager_steps = self.replayed_steps = self.prefetched_steps = 0        # how the steps were run (see ``stats``)
         self._warned = False
 
@@ -326,7 +335,7 @@ class GraphedStepCache(object):
         """Load ``features`` (the batch ``step`` will be called with NEXT; call this right after the current ``step``) into the idle
         static buffers of its signature on a side stream, beside the step that has just been launched.  A no-op unless the signature
         has its two captured steps already."""
-        if features is None or self._prefetched is not None:
+        if features is None or self._prefetched is not None or not PREFETCH:
             return
         key = self.signature(features)
         pair = self._steps.get(key)
@@ -363,9 +372,18 @@ class GraphedStepCache(object):
         return tuple(sorted((k, tuple(v.shape), str(v.dtype)) if isinstance(v, torch.Tensor) else (k, v)
                             for k, v in features.items() if isinstance(v, (torch.Tensor, int))))
 
-    def step(self, features, clone_loss=True):
+    def flush(self):
+        """File the last step's loss (``step(..., loss_slot=)``) if it still waits for a launch to ride in."""
+        if self._pending_loss is not None:
+            dst, src = self._pending_loss
+            self._pending_loss = None
+            dst.copy_(src)
+
+    def step(self, features, clone_loss=True, loss_slot=None):
         """zero_grad, forward, backward, optimizer step on ``features``; returns (loss, output_features).  ``clone_loss`` False: the
-        replayed graph's own loss tensor is handed out - valid until the next replay of that graph (a caller that files it away at once)."""
+        replayed graph's own loss tensor is handed out - valid until the next replay of that graph (a caller that files it away at once).
+        ``loss_slot``: a 0-d device tensor that receives the step's loss - for a replayed step LATER, in the launch that loads the next
+        batch (or in ``flush``): a small copy of its own costs a launch and its gap, 14 us of a 0.1 ms step."""
         key = self.signature(features)
         pair = self._steps.get(key)
         graphed = None
@@ -387,7 +405,8 @@ class GraphedStepCache(object):
             # never reads (the fp32 phone feature beside its operand table: 49 MB at C2) stays where it is, and the entry the captured
             # graph holds for it keeps its own static copy (nobody reads that one)
             graphed = pair[self._turn.get(key, 0)]
-            graphed.load(features, keys=self._keys(features))
+            extra, self._pending_loss = ([self._pending_loss] if self._pending_loss is not None else []), None
+            graphed.load(features, keys=self._keys(features), extra_pairs=extra)
         if graphed is not None:
             if len(self._steps[key]) == 2:
                 self._turn[key] = 1 - self._steps[key].index(graphed)
@@ -395,11 +414,16 @@ class GraphedStepCache(object):
                 if not isinstance(v, torch.Tensor):
                     graphed.features[k] = v
             self.replayed_steps += 1
-            self._before_replay = torch.cuda.Event()
-            self._before_replay.record(torch.cuda.current_stream())
+            self.flush()                                  # (a loss still pending here: this replay did not load a batch - captures)
+            if PREFETCH:
+                self._before_replay = torch.cuda.Event()
+                self._before_replay.record(torch.cuda.current_stream())
             loss = graphed()
+            if loss_slot is not None:
+                self._pending_loss = (loss_slot, loss.detach().reshape(loss_slot.shape))
             return (loss.clone() if clone_loss else loss), graphed.output      # the loss buffer is rewritten by that graph's next replay
         self._before_replay = None                        # an eager step: a batch loaded ahead waits for all of it
+        self.flush()
         self._seen[key] = True
         self._seen.move_to_end(key)
         while len(self._seen) > self.MAX_SEEN:

@@ -2628,13 +2628,17 @@ def test_f0_tail_rows_f32_kernel(m):
 
 
 
+@pytest.mark.parametrize('prefetch', [False, True])
 @pytest.mark.parametrize('precision,shape', [('bf16', (64, 300)), ('bf16x3', (64, 300)), ('bf16x3', (96, 500))])
-def test_graph_cache_loads_the_next_batch_beside_the_running_step(precision, shape):
+def test_graph_cache_loads_the_next_batch_beside_the_running_step(precision, shape, prefetch, monkeypatch):
     """graphs.GraphedStepCache with one batch of look-ahead (ExperimentBuilder.train_epoch): a signature holds two captured steps used in
     turn, and the NEXT batch is copied into the idle one's static buffers on a side stream while the current step runs (only the tensors
     the step reads: BaseModel.step_input_keys - the operand table, not the fp32 feature it was made from).  Eight distinct batches of a
     slab-taking shape, two epochs, against the eager loop: epoch losses and final parameters EQUAL, and the replays were loaded ahead."""
-    from morgana_amd import experiment_builder
+    from morgana_amd import experiment_builder, graphs
+    # ``prefetch`` (graphs.PREFETCH, off by default: measured equal to slower) loads ahead on the side stream; without it the batch is
+    # loaded in line in front of the replay, in ONE launch that also files the previous step's loss
+    monkeypatch.setattr(graphs, 'PREFETCH', prefetch)
     # (64 x 300: 2 560 table rows - the fused bf16 step, but the GENERIC 'bf16x3' path, which splits the fp32 feature inside the step: the
     # model must then name every tensor; 96 x 500: 4 864 rows - the fused 'bf16x3' step, which reads the pair table only)
     batches = [synthetic.make_batch(shape[0], shape[1], seed=300 + i) for i in range(8)]
@@ -2654,6 +2658,6 @@ def test_graph_cache_loads_the_next_batch_beside_the_running_step(precision, sha
     for name in params_e:
         assert torch.equal(params_g[name], params_e[name]), name
     stats = builder._graph_cache.stats()
-    assert stats['graphs'] == 2 and stats['eager'] == 1 and stats['replayed'] == 15 and stats['prefetched'] >= 11, stats
+    assert stats['graphs'] == 2 and stats['eager'] == 1 and stats['replayed'] == 15 and (stats['prefetched'] >= 11) == prefetch, stats
     keys = builder.model.step_input_keys(data.to_device(batches[0], DEV, bf16_tables=builder.model.bf16_table_features()))
     assert (keys is None) == (precision == 'bf16x3' and shape == (64, 300))           # only the fused steps leave the fp32 feature out
