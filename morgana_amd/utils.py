@@ -333,6 +333,68 @@ class RecurrentCuDNNWrapper(nn.Module):
                 getattr(layer, 'proj_size', 0) == 0 and
                 (layer.dropout == 0 or not layer.training or layer.num_layers == 1))      # one layer: nn.LSTM's dropout acts BETWEEN layers
 
+    def _hip_general(self):
+        """Any batch_first nn.GRU / nn.LSTM with biases and no projection - several layers, both directions: the general form of the
+        reference's wrapper (morgana/utils.py:333-343 wraps any nn.RNNBase).  Runs layer by layer and direction by direction on the
+        single-layer HIP recurrences (``_run_general``); the shapes the shipped models use keep their own faster paths
+        (``_hip_gru`` / ``_hip_lstm``)."""
+        layer = self.layer
+        return (isinstance(layer, (nn.GRU, nn.LSTM)) and layer.batch_first and layer.bias and getattr(layer, 'proj_size', 0) == 0)
+
+    def _layer_params(self, k, reverse):
+        layer, sfx = self.layer, '_l%d%s' % (k, '_reverse' if reverse else '')
+        return [getattr(layer, name + sfx) for name in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+
+    @staticmethod
+    def _reverse_rows(seq_len, b, t, device):
+        """int32 (B * T,) row map that reverses every item's first ``seq_len[b]`` frames in place (-1 = zero row past the end): what
+        pack_padded_sequence gives the backward direction of a bidirectional layer (morgana/utils.py:366-385).  Its own inverse."""
+        steps = torch.arange(t, device=device).unsqueeze(0)
+        lens = (seq_len.to(device).clamp(max=t) if seq_len is not None else torch.full((b,), t, device=device)).unsqueeze(1)
+        src = lens - 1 - steps
+        rows = torch.where(src >= 0, src + torch.arange(b, device=device).unsqueeze(1) * t, torch.full_like(src, -1))
+        return rows.reshape(-1).to(torch.int32).contiguous()
+
+    def _run_general(self, inputs, hidden, seq_len):
+        """Multi-layer and / or bidirectional nn.GRU / nn.LSTM: layer k, direction d = one single-layer HIP recurrence (functional.GRUFn /
+        LSTMFn) on the output of layer k - 1 (both directions concatenated); the backward direction runs on every item's frames
+        reversed within its own length and is reversed back.  Inter-layer dropout (``layer.dropout``, training) draws its masks in the
+        HIP kernel (functional.DropoutFn).  Hidden states in torch's layout: (num_layers * num_directions, B, H), index 2 k + d."""
+        layer = self.layer
+        is_lstm = isinstance(layer, nn.LSTM)
+        precision = F_hip.recurrent_precision(self.precision or F_hip.get_precision())
+        n_dir = 2 if layer.bidirectional else 1
+        b, t = inputs.shape[0], inputs.shape[1]
+        h0s, c0s = (hidden if is_lstm else (hidden, None)) if hidden is not None else (None, None)
+        rev = self._reverse_rows(seq_len, b, t, inputs.device) if n_dir == 2 else None
+        out, hns, cns = inputs.contiguous(), [], []
+        for k in range(layer.num_layers):
+            outs = []
+            for d in range(n_dir):
+                x = out
+                if d == 1:
+                    x = F_hip.GatherRowsFn.apply(out.reshape(b * t, -1), rev).view(b, t, -1)
+                idx = k * n_dir + d
+                h0 = None if h0s is None else h0s[idx:idx + 1].contiguous()
+                if is_lstm:
+                    c0 = None if c0s is None else c0s[idx:idx + 1].contiguous()
+                    y, hn, cn = F_hip.LSTMFn.apply(precision, x.contiguous(), h0, c0, seq_len, *self._layer_params(k, d == 1))
+                    cns.append(cn)
+                else:
+                    y, hn = F_hip.GRUFn.apply(precision, x.contiguous(), h0, seq_len, *self._layer_params(k, d == 1), None, None, None, None)
+                if d == 1:
+                    y = F_hip.GatherRowsFn.apply(y.reshape(b * t, -1), rev).view(b, t, -1)
+                outs.append(y)
+                hns.append(hn)
+            out = outs[0] if n_dir == 1 else torch.cat(outs, dim=-1)
+            if layer.dropout > 0 and layer.training and k + 1 < layer.num_layers:
+                if layer.dropout >= 1:
+                    out = out * 0.0
+                else:
+                    out = F_hip.DropoutFn.apply(out.contiguous(), float(layer.dropout), 7919 + k)
+        hn = torch.cat(hns, 0)
+        return out, ((hn, torch.cat(cns, 0)) if is_lstm else hn)
+
     def _lstm_params(self):
         layer = self.layer
         params = []
@@ -408,18 +470,19 @@ class RecurrentCuDNNWrapper(nn.Module):
         layer = self.layer
         return _lib.MorganaHipError(
             'RecurrentCuDNNWrapper: %s(num_layers=%s, bidirectional=%s, batch_first=%s, bias=%s, proj_size=%s) has no HIP recurrence '
-            'in libmorgana_hip.so (built: single-layer unidirectional batch_first nn.GRU, unidirectional batch_first nn.LSTM with any '
-            'number of layers); there is no torch / MIOpen fallback'
+            'in libmorgana_hip.so (built: batch_first nn.GRU / nn.LSTM with biases and without projection, any number of layers, one or '
+            'both directions); there is no torch / MIOpen fallback'
             % (type(layer).__name__, getattr(layer, 'num_layers', '?'), getattr(layer, 'bidirectional', '?'),
                getattr(layer, 'batch_first', '?'), getattr(layer, 'bias', '?'), getattr(layer, 'proj_size', 0)))
 
     def run_full_length(self, inputs, hidden=None):
         """The wrapped layer on a padded (B, T, F) batch with every item running all T steps: what calling the bare torch layer does."""
-        if not (self._hip_gru() or self._hip_lstm()):
+        if not (self._hip_gru() or self._hip_lstm() or self._hip_general()):
             raise self._unsupported()
         if isinstance(inputs, nn.utils.rnn.PackedSequence) or inputs.ndim != 3:
             return self.forward(inputs, hidden, None)
-        return (self._run_gru if self._hip_gru() else self._run_lstm)(inputs.contiguous(), hidden, None)
+        run = self._run_gru if self._hip_gru() else self._run_lstm if self._hip_lstm() else self._run_general
+        return run(inputs.contiguous(), hidden, None)
 
     def forward(self, inputs, hidden=None, seq_len=None, max_len=None, layout=None):
         """``layout`` (not in the reference): the batch's ``FrameLayout`` - a GRU layer's weight gradients then multiply the valid
@@ -429,9 +492,9 @@ class RecurrentCuDNNWrapper(nn.Module):
         device -> host read of ``seq_len`` per call; when the input's time axis already equals ``max_len`` - every batch whose longest
         utterance defines its padding, i.e. every batch ``collate_fn`` builds - the result is identical without that read, and the
         step stays capturable as a HIP graph.  ``SequentialWithRecurrent`` passes it when its own caller does."""
-        if not (self._hip_gru() or self._hip_lstm()):
+        if not (self._hip_gru() or self._hip_lstm() or self._hip_general()):
             raise self._unsupported()
-        run = self._run_gru if self._hip_gru() else self._run_lstm
+        run = self._run_gru if self._hip_gru() else self._run_lstm if self._hip_lstm() else self._run_general
         if seq_len is None:
             if isinstance(inputs, nn.utils.rnn.PackedSequence):
                 # already packed (utils.py:347-349): unpack to the padded layout the kernels work on, pack the result again
@@ -453,6 +516,8 @@ class RecurrentCuDNNWrapper(nn.Module):
         else:
             t_out = int(torch.max(seq_len).item())          # pad_packed_sequence crops to the longest item
         if isinstance(inputs, PhoneTable):
+            if not self._hip_gru():
+                raise self._unsupported()                   # (SequentialWithRecurrent hands a PhoneTable to single-layer GRU wrappers only)
             return self._run_gru(inputs.crop(t_out), hidden, seq_len.contiguous(), layout)
         if t_out != inputs.shape[1]:
             inputs = inputs[:, :t_out]

@@ -476,10 +476,55 @@ def test_unsupported_recurrent_layers_raise():
     """No torch / MIOpen fallback: layer types without a HIP recurrence raise MorganaHipError."""
     x = torch.zeros(2, 5, 16, device=DEV)
     sl = torch.tensor([5, 3], device=DEV)
-    for layer in (nn.GRU(16, 8, batch_first=True, bidirectional=True), nn.GRU(16, 8, num_layers=2, batch_first=True),
-                  nn.GRU(16, 8), nn.LSTM(16, 8, batch_first=True, bidirectional=True), nn.RNN(16, 8, batch_first=True)):
+    for layer in (nn.GRU(16, 8), nn.LSTM(16, 8, batch_first=True, proj_size=4), nn.GRU(16, 8, batch_first=True, bias=False),
+                  nn.RNN(16, 8, batch_first=True)):
         with pytest.raises(_lib.MorganaHipError, match='no HIP recurrence'):
             utils.RecurrentCuDNNWrapper(layer.to(DEV))(x, None, sl)
+
+
+@pytest.mark.parametrize('kind,num_layers,bidirectional,hid', [('gru', 2, False, 128), ('gru', 1, True, 128), ('gru', 2, True, 64), ('lstm', 1, True, 128),
+                                                             ('lstm', 2, True, 64)])
+def test_multi_layer_and_bidirectional_wrappers_vs_torch(kind, num_layers, bidirectional, hid):
+    """The reference's wrapper takes any nn.RNNBase (/root/reference/morgana/utils.py:333-343): multi-layer and bidirectional nn.GRU /
+    nn.LSTM run layer by layer and direction by direction on the single-layer HIP recurrences (RecurrentCuDNNWrapper._run_general; the
+    backward direction on every item's frames reversed within its own length).  fp32 mode against torch's CPU layer behind
+    pack_padded_sequence / pad_packed_sequence - the reference's own call sequence (utils.py:366-385): outputs, final states and every
+    gradient to 1e-4 of the largest element; ragged lengths, initial states given."""
+    rng = np.random.RandomState(11)
+    b, t, f = 5, 17, 24
+    make = nn.GRU if kind == 'gru' else nn.LSTM
+    torch.manual_seed(7)
+    ref = make(f, hid, num_layers=num_layers, batch_first=True, bidirectional=bidirectional)
+    own = make(f, hid, num_layers=num_layers, batch_first=True, bidirectional=bidirectional).to(DEV)
+    own.load_state_dict(ref.state_dict())
+    x_np = rng.standard_normal((b, t, f)).astype(np.float32)
+    lens = np.array([17, 9, 1, 12, 17], dtype=np.int64)
+    for i, n in enumerate(lens):
+        x_np[i, n:] = 0.0
+    n_state = num_layers * (2 if bidirectional else 1)
+    h0_np = (rng.standard_normal((n_state, b, hid)) * 0.3).astype(np.float32)
+    c0_np = (rng.standard_normal((n_state, b, hid)) * 0.3).astype(np.float32)
+    g_np = rng.standard_normal((b, t, hid * (2 if bidirectional else 1))).astype(np.float32)
+
+    # the reference's call sequence on CPU
+    x_r = torch.from_numpy(x_np).requires_grad_(True)
+    hid_r = (torch.from_numpy(h0_np), torch.from_numpy(c0_np)) if kind == 'lstm' else torch.from_numpy(h0_np)
+    packed = nn.utils.rnn.pack_padded_sequence(x_r, torch.from_numpy(lens), batch_first=True, enforce_sorted=False)
+    out_p, hn_r = ref(packed, hid_r)
+    out_r, _ = nn.utils.rnn.pad_packed_sequence(out_p, batch_first=True, total_length=t)
+    (out_r * torch.from_numpy(g_np)).sum().backward()
+
+    wrapper = utils.RecurrentCuDNNWrapper(own, precision='fp32')
+    x_o = dev(x_np).requires_grad_(True)
+    hid_o = (dev(h0_np), dev(c0_np)) if kind == 'lstm' else dev(h0_np)
+    out_o, hn_o = wrapper(x_o, hid_o, dev(lens))
+    (out_o * dev(g_np)).sum().backward()
+    assert rel_err(out_o.detach().cpu().numpy(), out_r.detach().numpy(), 'output') < RTOL
+    for got, want in zip(hn_o if kind == 'lstm' else (hn_o,), hn_r if kind == 'lstm' else (hn_r,)):
+        assert rel_err(got.detach().cpu().numpy(), want.detach().numpy(), 'final state') < RTOL
+    assert rel_err(x_o.grad.cpu().numpy(), x_r.grad.numpy(), 'input gradient') < RTOL
+    for (name, p_o), (_, p_r) in zip(own.named_parameters(), ref.named_parameters()):
+        assert rel_err(p_o.grad.cpu().numpy(), p_r.grad.numpy(), name) < RTOL, name
 
 
 def test_wrapper_accepts_packed_sequences():
