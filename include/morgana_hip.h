@@ -65,7 +65,7 @@ const char* mg_last_error(void);
 #define MG_TUNE_LSTM_BWD_STACK 6 /* LSTM stack wavefronts, hidden units per slot: 0 = backward 32 where they fit (one workgroup per CU),
                                  * forward 16 (two per CU); bit 0 (1) = backward 16; bit 1 (2) = forward 32 (same bits, measured slower) */
 #define MG_TUNE_AB 7            /* shared-grid launches as their separate launches, half-width tiles off: 65 = mg_linear_wgrad_dgrad_bf16 as
-                                 * two launches, 66 = mg_phone_front_linear_fwd_bf16 as two, 87 / 88 = 64-deep LDS stages in the phone-rate forward GEMM (pair planes,
+                                 * two launches, 66 = mg_phone_front_linear_fwd_bf16 as two, 86 = mg_f0_l2tail_x3 with four waves per workgroup (default: eight), 87 / 88 = 64-deep LDS stages in the phone-rate forward GEMM (pair planes,
                                  * three passes / bf16; measured equal to slower, round 5), 89 = the pair-plane forward GEMM (mg_phone_front_linear_fwd_x3) as three passes
                                  * over the plane (default: all four planes' k-tile per stage), 90 = the pair-plane weight gradients
                                  * (mg_linear_wgrad_slabs_x3) as three walks over their rows (default: one walk, all four planes per

@@ -31,7 +31,7 @@ static bool tuning_allowed(int key, int value) {
         case MG_TUNE_WGRAD_SPLITS: return value >= 0;
         case MG_TUNE_WGRAD_ORDER: return value >= 0 && value <= 3;
         case MG_TUNE_LSTM_BWD_STACK: return value >= 0 && value <= 3;
-        case MG_TUNE_AB: return value == 0 || value == 65 || value == 66 || value == 87 || value == 88 || value == 89 || value == 90 || value == 91 || value == 92 || value == 93 || value == 94 || value == 95 || value == 96 || value == 97 || value == 98 || value == 99;
+        case MG_TUNE_AB: return value == 0 || value == 65 || value == 66 || value == 86 || value == 87 || value == 88 || value == 89 || value == 90 || value == 91 || value == 92 || value == 93 || value == 94 || value == 95 || value == 96 || value == 97 || value == 98 || value == 99;
         default: return false;
     }
 #endif
