@@ -692,12 +692,13 @@ def bf16x3_legs(dev, features, state_dict, steps, frames_per_step):
     return out
 
 
-def train_epoch_block(dev, state_dict, headline_ms, n_batches=52):
+def train_epoch_block(dev, state_dict, headline_ms, n_batches=200):
     """The loop the north star names - ``ExperimentBuilder.train_epoch`` (/root/reference/morgana/experiment_builder.py:464-494) - timed over
     DISTINCT batches: ``n_batches`` C2-shaped batches resident on the device, each with its own operand table
     (the loader's half of the precision mode, made per batch by data.add_bf16_table and timed beside the loop), through the product's
-    ``train_epoch`` as eager launches and with ``use_graphs=True`` (graphs.GraphedStepCache: a batch signature is captured once and
-    replayed on every later batch, only what the step reads copied into the graph's buffers), for the bf16 headline and for 'bf16x3';
+    ``train_epoch`` as eager launches and with ``use_graphs=True`` (graphs.GraphedStepCache: a list of resident batches is captured ten
+    consecutive batches per graph, read where they lie - ``*_graphs``; ``*_graphs_load_per_batch`` = the streaming form: a batch signature
+    is captured once and every later batch is copied into the graph's buffers, only what the step reads), for the bf16 headline and for 'bf16x3';
     and a ragged variant (600-1000 frames per utterance, padded lengths bucketed to four shapes) with the cache's hits counted.  Inputs
     are in HBM when the clock starts; one synchronisation per epoch, as the product's loop has (the reference reads the loss every batch)."""
     import gc
@@ -718,9 +719,9 @@ def train_epoch_block(dev, state_dict, headline_ms, n_batches=52):
             batches.append(b)
         return batches
 
-    def run(batches, precision, use_graphs, frames):
+    def run(batches, precision, use_graphs, frames, graph_group=10):
         eb = experiment_builder.ExperimentBuilder(models.F0Model, model_kwargs={'precision': precision}, learning_rate=0.01, device=dev,
-                                                  use_graphs=use_graphs)
+                                                  use_graphs=use_graphs, graph_group=graph_group)
         eb.model.load_state_dict(state_dict)
         tables = eb.model.bf16_table_features()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -735,6 +736,8 @@ def train_epoch_block(dev, state_dict, headline_ms, n_batches=52):
         table_us = e0.elapsed_time(e1) * 1e3 / len(batches)
         optimizer = eb.make_optimizer()
         eb.train_epoch(batches, optimizer)                       # first epoch: buffers, operand shadows, the graphs of the shapes
+        if use_graphs and graph_group > 1:
+            eb.train_epoch(batches, optimizer)                   # resident groups: first epoch eager, second captures, third on replay
         gc.collect()
         gc.disable()
         try:
@@ -750,7 +753,8 @@ def train_epoch_block(dev, state_dict, headline_ms, n_batches=52):
                'loader_table_us_per_batch': round(table_us, 1),
                'vs_headline': round(ms / headline_ms, 3) if precision == 'bf16' else None}
         if use_graphs and eb._graph_cache is not None:
-            rec['graph_cache'] = eb._graph_cache.stats()          # over both epochs: eager = first batch of a signature
+            rec['graph_cache'] = eb._graph_cache.stats()          # over all epochs run: eager = first batch of a signature / first epoch of a group
+            rec['steps_per_graph'] = graph_group
         del eb, optimizer
         return rec
 
@@ -762,6 +766,8 @@ def train_epoch_block(dev, state_dict, headline_ms, n_batches=52):
         for precision in ('bf16', 'bf16x3'):
             for use_graphs in (True, False):
                 out['fixed_shape']['%s_%s' % (precision, 'graphs' if use_graphs else 'eager')] = run(fixed, precision, use_graphs, frames)
+        # the streaming form (a loader that hands over a fresh batch every step): one graph per shape, every batch loaded into its buffers
+        out['fixed_shape']['bf16_graphs_load_per_batch'] = run(fixed, 'bf16', True, frames, graph_group=1)
         del fixed
         ragged_host = []
         for i, t_pad in enumerate((700, 800, 900, 1000)):
@@ -780,6 +786,7 @@ def train_epoch_block(dev, state_dict, headline_ms, n_batches=52):
                          'frames_per_step_mean': mean_frames}
         for use_graphs in (True, False):
             out['ragged']['bf16_%s' % ('graphs' if use_graphs else 'eager')] = run(ragged, 'bf16', use_graphs, mean_frames)
+        out['ragged']['bf16_graphs_load_per_batch'] = run(ragged, 'bf16', True, mean_frames, graph_group=1)
         del ragged
     except Exception as exc:                          # noqa: BLE001 - a block that fails is reported, the headline stands
         out['error'] = str(exc).splitlines()[0][:300] if str(exc) else type(exc).__name__

@@ -24,7 +24,7 @@ from .optim import Adam
 class ExperimentBuilder(object):
     def __init__(self, model_class, model_kwargs=None, learning_rate=0.01, weight_decay=0., lr_schedule_name='constant',
                  lr_schedule_kwargs=None, ema_decay=0., device='cuda:0', start_epoch=1, end_epoch=50,
-                 experiment_dir=None, model_checkpoint_interval=1, checkpoint_path=None, use_graphs=False, **unused):
+                 experiment_dir=None, model_checkpoint_interval=1, checkpoint_path=None, use_graphs=False, graph_group=10, **unused):
         self.model_class = model_class
         self.model_kwargs = model_kwargs or {}
         self.learning_rate = learning_rate
@@ -40,6 +40,9 @@ class ExperimentBuilder(object):
         self.model_checkpoint_interval = model_checkpoint_interval
         self.analysis_kwargs = {}
         self.use_graphs = use_graphs          # replay repeated batch shapes as HIP graphs (morgana_amd/graphs.py); off = eager launches
+        # use_graphs with a RESIDENT loader (a list / tuple of device batches kept from epoch to epoch): this many consecutive batches are
+        # captured into one graph that reads them in place (graphs.GraphedStepCache.step_group); 1 = a graph launch and a load per batch
+        self.graph_group = int(graph_group)
         self._graph_cache = None
         self._lr_schedule = lr_schedules.init_lr_schedule(lr_schedule_name, **self.lr_schedule_kwargs)
 
@@ -60,6 +63,26 @@ class ExperimentBuilder(object):
         kwargs.setdefault('fused_loop', True)
         return Adam(self.model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay, **kwargs)  # :516
 
+    def _cache_for(self, optimizer):
+        if self._graph_cache is None or self._graph_cache.optimizer is not optimizer:
+            from . import graphs
+            self._graph_cache = graphs.GraphedStepCache(self.model, optimizer)
+        return self._graph_cache
+
+    def _resident_group(self, data_loader, lr_schedule, gen_output):
+        """Steps per captured graph for this epoch: ``graph_group`` when the loader is a list / tuple of batches that live on the device
+        and nothing has to happen between two steps on the host (a per-batch LR schedule, EMA, per-batch analysis output), else 1."""
+        if not self.use_graphs or self.graph_group <= 1 or not isinstance(data_loader, (list, tuple)) or len(data_loader) < 2:
+            return 1
+        if gen_output or self.ema_decay:
+            return 1
+        if lr_schedule is not None and self.lr_schedule_name in lr_schedules.BATCH_LR_SCHEDULES:
+            return 1
+        for features in data_loader:
+            if not isinstance(features, dict) or not all(v.is_cuda for v in features.values() if isinstance(v, torch.Tensor)):
+                return 1
+        return self.graph_group
+
     def train_epoch(self, data_loader, optimizer, lr_schedule=None, gen_output=False, out_dir=None):
         """One pass over ``data_loader`` (an iterable of feature dicts already on the device); returns the mean loss."""
         self.model.mode = 'train'
@@ -78,8 +101,19 @@ class ExperimentBuilder(object):
         import time
         t_loop = time.perf_counter()
         loss_log = None
-        batches = iter(data_loader)
-        ahead = next(batches, None)                     # one batch of look-ahead (the graph cache loads it beside the current step)
+        group = self._resident_group(data_loader, lr_schedule, gen_output)
+        if group > 1:
+            # resident epoch: K steps per graph launch, the batches read where they lie (no load launch); the K losses filed by one launch
+            cache = self._cache_for(optimizer)
+            loss_log = torch.zeros(max(n_batches, 1), dtype=torch.float32, device=self.device)
+            for start in range(0, n_batches, group):
+                chunk = data_loader[start:start + group]
+                self.model.step = (self.epoch - 1) * n_batches + start + len(chunk)
+                cache.step_group(chunk, [loss_log[start + j] for j in range(len(chunk))])
+            i, ahead = n_batches - 1, None
+        else:
+            batches = iter(data_loader)
+            ahead = next(batches, None)                 # one batch of look-ahead (the graph cache loads it beside the current step)
         while ahead is not None:
             i, features = i + 1, ahead
             ahead = next(batches, None)
@@ -87,9 +121,7 @@ class ExperimentBuilder(object):
 
             if self.use_graphs:
                 # the same four calls, captured once per batch shape and replayed (graphs.GraphedStepCache)
-                if self._graph_cache is None or self._graph_cache.optimizer is not optimizer:
-                    from . import graphs
-                    self._graph_cache = graphs.GraphedStepCache(self.model, optimizer)
+                self._cache_for(optimizer)
                 if loss_log is None:
                     loss_log = torch.zeros(max(n_batches, 1), dtype=torch.float32, device=self.device)
                 slot = loss_log[i] if i < loss_log.numel() else None

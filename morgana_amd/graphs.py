@@ -308,8 +308,10 @@ class GraphedStepCache(object):
 
     MAX_SEEN = 1024      # signatures remembered as "ran once": a ragged loader whose frame totals never repeat must not grow this forever
 
-    def __init__(self, model, optimizer, max_graphs=8):
-        self.model, self.optimizer, self.max_graphs = model, optimizer, max_graphs
+    def __init__(self, model, optimizer, max_graphs=8, max_group_graphs=256):
+        self.model, self.optimizer, self.max_graphs, self.max_group_graphs = model, optimizer, max_graphs, max_group_graphs
+        self._groups = {}                                 # group_key -> GraphedTrainStep over K resident batches (``step_group``)
+        self.group_replays = 0
         self._seen = collections.OrderedDict()
         self._steps = {}                                  # signature -> [GraphedTrainStep, ...] (at most two: the ping-pong pair)
         self._turn = {}                                   # signature -> index of the step object the next batch takes
@@ -325,7 +327,7 @@ class GraphedStepCache(object):
         replays whose batch was loaded ahead on the side stream}.  Mostly eager steps mean the batches do not repeat their signature:
         bucket ragged lengths to a few shapes for ``use_graphs`` to pay."""
         return {'eager': self.eager_steps, 'replayed': self.replayed_steps, 'graphs': sum(len(v) for v in self._steps.values()),
-                'prefetched': self.prefetched_steps}
+                'prefetched': self.prefetched_steps, 'group_graphs': len(self._groups), 'group_replays': self.group_replays}
 
     def _keys(self, features):
         keys = self.model.step_input_keys(features) if hasattr(self.model, 'step_input_keys') else None
@@ -371,6 +373,76 @@ class GraphedStepCache(object):
         # host-side integers (n_frames_total sizes the packed-frame layout) are part of what a captured step was built for
         return tuple(sorted((k, tuple(v.shape), str(v.dtype)) if isinstance(v, torch.Tensor) else (k, v)
                             for k, v in features.items() if isinstance(v, (torch.Tensor, int))))
+
+    @staticmethod
+    def group_key(batches):
+        """What a graph captured over RESIDENT batches was built on: every tensor's address, shape and dtype and every host integer of
+        every batch, in order.  (The graph keeps the batches alive, so an address in a key cannot come to mean another tensor.)"""
+        return tuple(tuple(sorted((k, v.data_ptr(), tuple(v.shape), str(v.dtype)) if isinstance(v, torch.Tensor) else (k, v)
+                                  for k, v in f.items() if isinstance(v, (torch.Tensor, int))))
+                     for f in batches)
+
+    def _file_losses(self, pairs):
+        from . import ops
+        pairs = [(dst, src.detach().reshape(dst.shape)) for dst, src in pairs if dst is not None]
+        if pairs:
+            ops.copy_many(pairs)                          # MG_COPY_MAX pairs per launch
+
+    def step_group(self, batches, loss_slots=None):
+        """K consecutive training steps on K batches that STAY where they are (a resident epoch: the loader is a list of device
+        batches, kept by the caller from epoch to epoch - 288 GB of HBM hold the corpora this model family trains on).  The first time
+        a group is seen with all of its batch signatures warmed up, the K steps are captured into ONE graph that reads the batches in
+        place - no load launch, no static copies - and every later epoch replays it: one graph launch and one scalar-staging launch per
+        K steps instead of per step, ragged shapes included (each step of the graph is captured on its own batch's shapes).  A group
+        with a signature that has not run yet runs as eager steps (which warm up allocator and workspaces, as in ``step``); beyond
+        ``max_group_graphs`` graphs, with more than one rank, or with non-resident batches the steps take the single-step path.
+        No step is run twice or skipped.  ``loss_slots``: K 0-d device tensors that receive the steps' losses (one launch per group).
+        Returns the list of the K loss tensors (replayed: the graph's own, valid until its next replay)."""
+        batches = list(batches)
+        slots = list(loss_slots) if loss_slots is not None else [None] * len(batches)
+        ahead, self._prefetched = self._prefetched, None
+        if ahead is not None:
+            torch.cuda.current_stream().wait_event(ahead[3])
+        self.flush()
+        sigs = [self.signature(f) for f in batches]
+        resident = all(v.is_cuda for f in batches for v in f.values() if isinstance(v, torch.Tensor))
+        if any(sig not in self._seen for sig in sigs):
+            losses = [self._eager(f, sig)[0] for f, sig in zip(batches, sigs)]
+            self._file_losses(zip(slots, losses))
+            return losses
+        key = self.group_key(batches) if resident else None
+        graphed = self._groups.get(key) if key is not None else None
+        if graphed is None and (key is None or self.optimizer.exchanging() or len(self._groups) >= self.max_group_graphs):
+            losses = []
+            for f, slot in zip(batches, slots):
+                losses.append(self.step(f, clone_loss=slot is None, loss_slot=slot)[0])
+            return losses
+        if graphed is None:
+            graphed = GraphedTrainStep(self.model, self.optimizer, batches, warmup=0, steps_per_replay=len(batches))
+            self._groups[key] = graphed
+        graphed()
+        self.replayed_steps += len(batches)
+        self.group_replays += 1
+        self._file_losses(zip(slots, graphed.losses))
+        return list(graphed.losses)
+
+    def _eager(self, features, key):
+        self._before_replay = None                        # an eager step: a batch loaded ahead waits for all of it
+        self.flush()
+        self._seen[key] = True
+        self._seen.move_to_end(key)
+        while len(self._seen) > self.MAX_SEEN:
+            self._seen.popitem(last=False)
+        self.eager_steps += 1
+        if not self._warned and self.eager_steps >= 64 and self.replayed_steps == 0:
+            self._warned = True
+            warnings.warn('GraphedStepCache: %d steps and no batch signature has repeated - every step runs as eager launches '
+                          '(ragged batches: bucket the lengths to a few shapes, or turn use_graphs off)' % self.eager_steps)
+        self.optimizer.zero_grad()
+        loss, output = self.model(features)
+        functional.backward(loss)
+        self.optimizer.step()
+        return loss, output
 
     def flush(self):
         """File the last step's loss (``step(..., loss_slot=)``) if it still waits for a launch to ride in."""
@@ -422,19 +494,4 @@ class GraphedStepCache(object):
             if loss_slot is not None:
                 self._pending_loss = (loss_slot, loss.detach().reshape(loss_slot.shape))
             return (loss.clone() if clone_loss else loss), graphed.output      # the loss buffer is rewritten by that graph's next replay
-        self._before_replay = None                        # an eager step: a batch loaded ahead waits for all of it
-        self.flush()
-        self._seen[key] = True
-        self._seen.move_to_end(key)
-        while len(self._seen) > self.MAX_SEEN:
-            self._seen.popitem(last=False)
-        self.eager_steps += 1
-        if not self._warned and self.eager_steps >= 64 and self.replayed_steps == 0:
-            self._warned = True
-            warnings.warn('GraphedStepCache: %d steps and no batch signature has repeated - every step runs as eager launches '
-                          '(ragged batches: bucket the lengths to a few shapes, or turn use_graphs off)' % self.eager_steps)
-        self.optimizer.zero_grad()
-        loss, output = self.model(features)
-        functional.backward(loss)
-        self.optimizer.step()
-        return loss, output
+        return self._eager(features, key)

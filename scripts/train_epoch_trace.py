@@ -1,5 +1,5 @@
 """Kernel timeline of ExperimentBuilder.train_epoch(use_graphs=True) over distinct C2 batches (run under rocprofv3 --kernel-trace):
-prints nothing itself; scripts/train_epoch_gaps.py reads the trace.  usage: python scripts/train_epoch_trace.py [precision] [n_batches]"""
+prints nothing itself; scripts/train_epoch_gaps.py reads the trace.  usage: python scripts/train_epoch_trace.py [precision] [n_batches] [steps per graph]"""
 import os
 import sys
 
@@ -11,9 +11,11 @@ from morgana_amd import data, experiment_builder, models, synthetic   # noqa: E4
 
 precision = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+group = int(sys.argv[3]) if len(sys.argv) > 3 else 10          # steps per graph over the resident list (1 = the per-batch load path)
 dev = torch.device('cuda:0')
 host = [synthetic.make_batch(256, 1000, seed=synthetic.REFERENCE_SEED + 1000 + i) for i in range(2)]
-eb = experiment_builder.ExperimentBuilder(models.F0Model, model_kwargs={'precision': precision}, learning_rate=0.01, device=dev, use_graphs=True)
+eb = experiment_builder.ExperimentBuilder(models.F0Model, model_kwargs={'precision': precision}, learning_rate=0.01, device=dev, use_graphs=True,
+                                          graph_group=group)
 batches = []
 for i in range(n):
     b = data.to_device(host[i % 2], dev)
@@ -22,6 +24,7 @@ for i in range(n):
         data.add_bf16_table(b, name)
     batches.append(b)
 opt = eb.make_optimizer()
+eb.train_epoch(batches, opt)
 eb.train_epoch(batches, opt)
 torch.cuda.synchronize()
 import time

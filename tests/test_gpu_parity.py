@@ -2646,7 +2646,7 @@ def test_graph_cache_loads_the_next_batch_beside_the_running_step(precision, sha
     def train(use_graphs):
         torch.manual_seed(3)
         builder = experiment_builder.ExperimentBuilder(models.F0Model, dict(precision=precision), learning_rate=0.01, device=DEV, end_epoch=2,
-                                                       use_graphs=use_graphs)
+                                                       use_graphs=use_graphs, graph_group=1)       # (the per-batch load path)
         _load_state(builder.model, synthetic.f0_model_state())
         dev_batches = [data.to_device(b, DEV, bf16_tables=builder.model.bf16_table_features()) for b in batches]
         history = builder.run_train(dev_batches)
@@ -2661,3 +2661,42 @@ def test_graph_cache_loads_the_next_batch_beside_the_running_step(precision, sha
     assert stats['graphs'] == 2 and stats['eager'] == 1 and stats['replayed'] == 15 and (stats['prefetched'] >= 11) == prefetch, stats
     keys = builder.model.step_input_keys(data.to_device(batches[0], DEV, bf16_tables=builder.model.bf16_table_features()))
     assert (keys is None) == (precision == 'bf16x3' and shape == (64, 300))           # only the fused steps leave the fp32 feature out
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'bf16x3', 'fp32'])
+def test_resident_epoch_groups_equal_the_eager_loop(precision):
+    """ExperimentBuilder(use_graphs=True) over a RESIDENT loader (a list of device batches): ``graph_group`` consecutive batches are
+    captured into one graph that reads them where they lie (graphs.GraphedStepCache.step_group) - no load launch, one graph launch per
+    group, ragged shapes in one graph.  Seven batches of three shapes in groups of three, three epochs (eager, capture + replay,
+    replay), against the eager loop: epoch losses and final parameters EQUAL; then one batch's CONTENT is changed in place and both
+    loops run another epoch - the graph reads the batch, not a copy of it."""
+    from morgana_amd import experiment_builder
+    shapes = [(64, 300)] * 4 + [(96, 500)] * 2 + [(16, 120)]
+    batches = [synthetic.make_batch(b, t, seed=500 + i) for i, (b, t) in enumerate(shapes)]
+    other = synthetic.make_batch(64, 300, seed=599)
+
+    def train_by_hand(use_graphs):
+        torch.manual_seed(3)
+        builder = experiment_builder.ExperimentBuilder(models.F0Model, dict(precision=precision), learning_rate=0.01, device=DEV,
+                                                       use_graphs=use_graphs, graph_group=3)
+        _load_state(builder.model, synthetic.f0_model_state())
+        tables = builder.model.bf16_table_features()
+        dev_batches = [data.to_device(b, DEV, bf16_tables=tables) for b in batches]
+        optimizer = builder.make_optimizer()
+        history = [builder.train_epoch(dev_batches, optimizer) for _ in range(3)]
+        fresh = data.to_device(other, DEV, bf16_tables=tables)
+        for key, value in dev_batches[1].items():          # new content at the old addresses
+            if isinstance(value, torch.Tensor):
+                value.copy_(fresh[key])
+        history.append(builder.train_epoch(dev_batches, optimizer))
+        return history, {k: v.detach().clone() for k, v in builder.model.named_parameters()}, builder
+
+    hist_e, params_e, _ = train_by_hand(False)
+    hist_g, params_g, builder = train_by_hand(True)
+    assert hist_g == hist_e
+    assert hist_e[3] != hist_e[2]
+    for name in params_e:
+        assert torch.equal(params_g[name], params_e[name]), name
+    stats = builder._graph_cache.stats()
+    assert stats['eager'] == 7 and stats['replayed'] == 21 and stats['group_graphs'] == 3 and stats['group_replays'] == 9, stats
+    assert stats['graphs'] == 0                                # no single-step graphs, no static copies
