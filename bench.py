@@ -788,11 +788,64 @@ def train_epoch_block(dev, state_dict, headline_ms, n_batches=200):
             out['ragged']['bf16_%s' % ('graphs' if use_graphs else 'eager')] = run(ragged, 'bf16', use_graphs, mean_frames)
         out['ragged']['bf16_graphs_load_per_batch'] = run(ragged, 'bf16', True, mean_frames, graph_group=1)
         del ragged
+        out['streaming'] = streaming_epoch(dev, state_dict)
     except Exception as exc:                          # noqa: BLE001 - a block that fails is reported, the headline stands
         out['error'] = str(exc).splitlines()[0][:300] if str(exc) else type(exc).__name__
     gc.collect()
     torch.cuda.empty_cache()
     return out
+
+
+def streaming_epoch(dev, state_dict, n_batches=6):
+    """The PCIe-inclusive rate (never the headline's ``value``): ``data.DeviceBatches`` over raw host utterances - what the reference's
+    DataLoader + ToDeviceWrapper hand over (/root/reference/morgana/data.py:50-55, :648-663) - feeding ``train_epoch(use_graphs=True)``:
+    per batch the host packs 256 utterances (49 MB of float32 phone features), one pinned copy crosses PCIe and one kernel pads,
+    normalises and writes the bf16 operand table; then the same batches kept on the device (``DeviceBatches.resident``)."""
+    from morgana_amd import experiment_builder
+    rng = np.random.RandomState(synthetic.REFERENCE_SEED + 77)
+    lab_dim, n_ph, per_batch = 600, 80, 256
+    norms = {'lab': data.MinMaxNormaliser('lab').set_params({'mmin': (rng.rand(lab_dim) * 0.1).astype(np.float32),
+                                                             'mmax': (1.0 + rng.rand(lab_dim)).astype(np.float32)}, device=dev),
+             'lf0': data.MeanVarianceNormaliser('lf0').set_params({'mean': np.array([5.0], np.float32),
+                                                                   'std_dev': np.array([0.3], np.float32)}, device=dev)}
+    utterances = []
+    for i in range(per_batch * n_batches):
+        dur = np.full((n_ph, 1), 12, np.int64)
+        dur[::2] += 1                                                           # 12.5 frames per phone, 1000 frames per utterance
+        n_fr = int(dur.sum())
+        utterances.append({'name': 'utt%05d' % i, 'n_frames': n_fr, 'n_phones': n_ph, 'dur': dur,
+                           'lab': rng.rand(n_ph, lab_dim).astype(np.float32),
+                           'lf0': (5.0 + 0.3 * rng.randn(n_fr, 1)).astype(np.float32)})
+    frames = per_batch * 1000
+    eb = experiment_builder.ExperimentBuilder(models.F0Model, model_kwargs={'precision': 'bf16'}, learning_rate=0.01, device=dev, use_graphs=True)
+    eb.model.load_state_dict(state_dict)
+    optimizer = eb.make_optimizer()
+    loader = data.DeviceBatches(utterances, per_batch, norms, dev)
+    eb.train_epoch(loader, optimizer)                                           # graphs, buffers, pinned-memory pools
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eb.train_epoch(loader, optimizer)
+    ms_stream = (time.perf_counter() - t0) / n_batches * 1e3
+    t0 = time.perf_counter()
+    for _ in loader:
+        pass
+    torch.cuda.synchronize()
+    ms_loader = (time.perf_counter() - t0) / n_batches * 1e3
+    resident = loader.resident()
+    for _ in range(2):
+        eb.train_epoch(resident, optimizer)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eb.train_epoch(resident, optimizer)
+    ms_res = (time.perf_counter() - t0) / n_batches * 1e3
+    mb = per_batch * (n_ph * lab_dim + 1000) * 4 / 1e6
+    del resident, loader
+    return {'what': 'data.DeviceBatches over %d raw host utterances, %d per batch (C2 shape): host packing + pinned H2D copy of %.1f MB per batch + '
+                    'mg_pad_normalise_bf16_f32 + the graphed step; then the same batches resident' % (len(utterances), per_batch, mb),
+            'pcie_inclusive': {'ms_per_step': round(ms_stream, 3), 'value': round(frames / (ms_stream * 1e-3), 1), 'unit': 'frames/s',
+                               'loader_alone_ms_per_batch': round(ms_loader, 3), 'host_mb_per_batch': round(mb, 1)},
+            'resident_after_first_epoch': {'ms_per_step': round(ms_res, 4), 'value': round(frames / (ms_res * 1e-3), 1), 'unit': 'frames/s',
+                                           'steps': n_batches, 'note': 'six-step epochs: the epoch\'s fixed cost (one sync, first launch) is in'}}
 
 
 def c4_leg(dev, precision):

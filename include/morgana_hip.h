@@ -459,6 +459,11 @@ typedef struct {
     int64_t bytes;
 } mg_copy_desc;
 int mg_copy_many(const mg_copy_desc* descs, int count, void* stream);
+/* HOST half of the loader (no device work): `count` utterance arrays (srcs[i], bytes[i]) laid back to back at dst - the pinned staging
+ * buffer one H2D copy then takes across PCIe - by `threads` host threads (1..64).  Replaces the np / torch concatenation in front of
+ * /root/reference/morgana/data.py:159-224 (collate_fn's per-utterance pad copies; there the padding happens on the host, here on the
+ * device: mg_pad_normalise_f32).  dst_bytes = capacity of dst; MG_EINVAL when the pieces do not fit. */
+int mg_host_pack(const void* const* srcs, const int64_t* bytes, int count, void* dst, int64_t dst_bytes, int threads);
 /* Operand splits of precision mode 'bf16x3' (split-bf16: hi = bf16(x), lo = bf16(x - hi); x w ~= hi hi + hi lo + lo hi as ONE bf16
  * GEMM over a contraction index three times as long; csrc/split3.hip).  The reference computes these products in fp32
  * (morgana/experiment_builder.py:262-263: no autocast, morgana/data.py:127: float32 features); this mode reproduces them to ~1e-5

@@ -78,6 +78,7 @@ SIGNATURES = {
     'mg_cast_params_bf16': (c_int, [c_void_p, c_int, c_void_p]),
     'mg_cast_bf16_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
     'mg_copy_many': (c_int, [c_void_p, c_int, c_void_p]),
+    'mg_host_pack': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int]),
     'mg_split3_bf16': (c_int, [c_void_p, c_int, c_void_p]),
     'mg_phone_front_linear_fwd_x3': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int64, c_int, c_void_p,

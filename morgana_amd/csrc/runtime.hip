@@ -2,6 +2,10 @@
 #include "common.h"
 
 #include <stdarg.h>
+#include <string.h>
+
+#include <thread>
+#include <vector>
 
 static thread_local char g_error[512] = "";
 
@@ -51,5 +55,40 @@ const char* mg_last_error(void) { return g_error; }
 int mg_version(void) { return 1; }
 
 const char* mg_build_arch(void) { return "gfx950"; }
+
+// The loader's host half: `count` utterance arrays laid back to back into one (pinned) staging buffer by `threads` host threads - the
+// np.concatenate of data.collate_to_device (49 MB per C2 batch: 4-5 ms on one core, 80 ms when the destination is a fresh allocation).
+// Pieces are dealt to the threads by bytes; a piece is one memcpy.  Pure host code: no HIP call, no stream.
+int mg_host_pack(const void* const* srcs, const int64_t* bytes, int count, void* dst, int64_t dst_bytes, int threads) {
+    MG_CHECK_ARG(srcs && bytes && dst && count > 0 && threads > 0 && threads <= 64, "mg_host_pack: bad arguments (count=%d threads=%d)", count,
+                 threads);
+    int64_t total = 0;
+    for (int i = 0; i < count; ++i) {
+        MG_CHECK_ARG(bytes[i] >= 0 && (bytes[i] == 0 || srcs[i]), "mg_host_pack: bad piece %d", i);
+        total += bytes[i];
+    }
+    MG_CHECK_ARG(total <= dst_bytes, "mg_host_pack: %lld bytes do not fit the destination's %lld", (long long)total, (long long)dst_bytes);
+    if (total == 0) return MG_OK;
+    auto work = [&](int64_t lo, int64_t hi) {            // bytes [lo, hi) of the packed image
+        int64_t at = 0;
+        for (int i = 0; i < count && at < hi; ++i) {
+            const int64_t b = bytes[i], p_lo = lo > at ? lo : at, p_hi = hi < at + b ? hi : at + b;
+            if (p_hi > p_lo) memcpy((char*)dst + p_lo, (const char*)srcs[i] + (p_lo - at), (size_t)(p_hi - p_lo));
+            at += b;
+        }
+    };
+    int n = threads;
+    if (total < (int64_t)n * (1 << 20)) n = (int)(total >> 20) + 1;      // at least 1 MB per thread
+    if (n <= 1) {
+        work(0, total);
+        return MG_OK;
+    }
+    const int64_t per = ((total + n - 1) / n + 63) / 64 * 64;
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n; ++t) pool.emplace_back(work, (int64_t)t * per < total ? (int64_t)t * per : total, (int64_t)(t + 1) * per < total ? (int64_t)(t + 1) * per : total);
+    work(0, per < total ? per : total);
+    for (auto& th : pool) th.join();
+    return MG_OK;
+}
 
 }  // extern "C"

@@ -298,6 +298,68 @@ def load_utterance(features, normalisers):
     return out
 
 
+class _Staging(object):
+    """Pinned host staging for the loader's packed features: per (device, feature) TWO buffers used in turn - the copy of the batch
+    before last has certainly been issued when a buffer comes round again, and its event says when it has finished - grown
+    geometrically, never returned.  (``tensor.pin_memory()`` per batch allocates and page-locks 49 MB every time: with the fresh
+    ``np.concatenate`` result in front of it, 80 ms of a C2 batch's 82.)"""
+
+    def __init__(self):
+        self._slots = {}
+        self._turn = {}
+
+    def take(self, device, key, n_bytes):
+        turn = self._turn.get((device, key), 0)
+        self._turn[(device, key)] = 1 - turn
+        slot = self._slots.get((device, key, turn))
+        if slot is not None and slot[1] is not None:
+            slot[1].synchronize()                         # the H2D copy that last read this buffer
+        if slot is None or slot[0].numel() < n_bytes:
+            size = max(int(n_bytes * 1.25), 1 << 16)
+            slot = [torch.empty(size, dtype=torch.uint8).pin_memory(), None]
+            self._slots[(device, key, turn)] = slot
+        return slot
+
+    def clear(self):
+        self._slots.clear()
+        self._turn.clear()
+
+
+_STAGING = _Staging()
+HOST_PACK_THREADS = max(1, min(8, (os.cpu_count() or 2) // 2))
+
+
+def _pack_pinned(items, device, key):
+    """``np.concatenate(items)`` of 2-D float32 arrays into a pinned staging buffer (mg_host_pack: threaded memcpy), its asynchronous
+    copy to ``device`` and the row offsets (int64, ``len(items) + 1``) beside it.  Returns (packed device tensor, offsets device tensor)."""
+    import ctypes
+    from . import _lib
+    width = items[0].shape[1]
+    lens = np.array([x.shape[0] for x in items], dtype=np.int64)
+    total = int(lens.sum())
+    n_off = len(items) + 1
+    off_bytes = (n_off * 8 + 63) // 64 * 64
+    n_bytes = off_bytes + total * width * 4
+    slot = _STAGING.take(str(device), key, n_bytes)
+    host = slot[0]
+    offsets_host = host[:n_off * 8].view(torch.int64)
+    offsets_host[0] = 0
+    offsets_host[1:] = torch.from_numpy(np.cumsum(lens))
+    arrays = [x if (x.flags['C_CONTIGUOUS'] and x.dtype == np.float32) else np.ascontiguousarray(x, dtype=np.float32) for x in items]
+    srcs = (ctypes.c_void_p * len(arrays))(*[a.ctypes.data for a in arrays])
+    sizes = (ctypes.c_int64 * len(arrays))(*[a.nbytes for a in arrays])
+    lib = _lib.load()
+    _lib.check(lib.mg_host_pack(ctypes.cast(srcs, ctypes.c_void_p), ctypes.cast(sizes, ctypes.c_void_p), len(arrays),
+                                ctypes.c_void_p(host.data_ptr() + off_bytes), ctypes.c_int64(host.numel() - off_bytes), HOST_PACK_THREADS),
+               'mg_host_pack')
+    staged = host[:n_bytes].to(device, non_blocking=True)                       # ONE copy across PCIe: offsets + rows
+    slot[1] = torch.cuda.Event()
+    slot[1].record(torch.cuda.current_stream(device))
+    offsets = staged[:n_off * 8].view(torch.int64)
+    packed = staged[off_bytes:].view(torch.float32).view(total, width)
+    return packed, offsets, lens
+
+
 def collate_to_device(batch, normalisers, device, bf16_tables=()):
     """``load_utterance`` + ``collate_fn`` + ``to_device`` for a list of RAW per-utterance feature dicts, with the float
     sequence features normalised and zero padded on the device (reference: data.py:119-127, 159-224, 648-663).
@@ -320,12 +382,13 @@ def collate_to_device(batch, normalisers, device, bf16_tables=()):
             rest.append(key)
             continue
         items = [item[key] for item in batch]
-        lens = np.array([x.shape[0] for x in items], dtype=np.int64)
-        offsets = torch.from_numpy(np.concatenate(([0], np.cumsum(lens))).astype(np.int64))
-        packed = torch.from_numpy(np.ascontiguousarray(np.concatenate(items, axis=0)))
         if device.type == 'cuda':
-            packed, offsets = packed.pin_memory(), offsets.pin_memory()
-        packed, offsets = packed.to(device, non_blocking=True), offsets.to(device, non_blocking=True)
+            # pinned staging kept from batch to batch, packed by host threads, one H2D copy for rows and offsets
+            packed, offsets, lens = _pack_pinned(items, device, key)
+        else:
+            lens = np.array([x.shape[0] for x in items], dtype=np.int64)
+            offsets = torch.from_numpy(np.concatenate(([0], np.cumsum(lens))).astype(np.int64))
+            packed = torch.from_numpy(np.ascontiguousarray(np.concatenate(items, axis=0)))
         kind = p0 = p1 = None
         normaliser = normalisers.get(key) if normalisers is not None else None
         if isinstance(normaliser, FeatureNormaliser):
@@ -481,6 +544,14 @@ class DeviceBatches(object):
 
     def __len__(self):
         return (len(self.utterances) + self.batch_size - 1) // self.batch_size
+
+    def resident(self):
+        """One pass of this loader kept on the device: the list of its batches (operand tables included).  A corpus of this model
+        family fits the 288 GB of an MI355X many times over, and a host loader cannot feed the step (a C2 batch is 49 MB of float32
+        over PCIe: >= 1 ms against a 0.1 ms step) - so later epochs take the list: ``ExperimentBuilder.train_epoch(use_graphs=True)``
+        replays ``graph_group`` consecutive batches per graph launch, read where they lie.  The batches keep this pass's composition
+        and order (a ``shuffle`` applies to the pass that builds the list)."""
+        return list(iter(self))
 
     def __iter__(self):
         order = np.arange(len(self.utterances))

@@ -221,3 +221,28 @@ def test_product_library_holds_no_experiments():
         assert lib.mg_set_tuning(key, value) != 0, (key, value)
     for key, value in ((0, 13), (0, 12), (0, 0), (2, 1), (2, 0), (3, 1), (3, 0), (4, 48), (4, 0), (5, 2), (5, 0), (6, 1), (6, 0), (7, 65), (7, 91), (2, 4), (7, 0), (2, 0)):
         assert lib.mg_set_tuning(key, value) == 0, (key, value)
+
+
+def test_host_pack_equals_concatenate():
+    """mg_host_pack (the loader's host half: utterance arrays back to back into the pinned staging buffer, by host threads) against
+    np.concatenate for ragged pieces, every thread count, a zero-length piece; a destination that is too small is refused."""
+    import ctypes
+    lib = _lib.load()
+    rng = np.random.RandomState(3)
+    items = [rng.rand(int(n), 37).astype(np.float32) for n in rng.randint(0, 3000, size=41)]
+    items[5] = np.zeros((0, 37), np.float32)
+    want = np.concatenate(items, axis=0)
+    srcs = (ctypes.c_void_p * len(items))(*[a.ctypes.data for a in items])
+    sizes = (ctypes.c_int64 * len(items))(*[a.nbytes for a in items])
+
+    def pack(out, capacity, threads):
+        return lib.mg_host_pack(ctypes.cast(srcs, ctypes.c_void_p), ctypes.cast(sizes, ctypes.c_void_p), len(items),
+                                ctypes.c_void_p(out.ctypes.data), ctypes.c_int64(capacity), threads)
+
+    for threads in (1, 2, 3, 8, 64):
+        out = np.full(want.shape[0] * 37 + 16, -1.0, np.float32)
+        assert pack(out, out.nbytes, threads) == 0, lib.mg_last_error()
+        assert np.array_equal(out[:want.size].reshape(want.shape), want) and np.all(out[want.size:] == -1.0)
+    out = np.empty(want.size, np.float32)
+    assert pack(out, out.nbytes - 4, 4) != 0 and b'do not fit' in lib.mg_last_error()
+    assert pack(out, out.nbytes, 0) != 0 and pack(out, out.nbytes, 65) != 0

@@ -358,10 +358,16 @@ def test_two_ranks_on_one_gpu_equal_the_global_batch(tmp_path, precision, form, 
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                    OMP_NUM_THREADS='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
-        procs.append(subprocess.Popen([sys.executable, os.path.join(repo, 'tests', '_dist_gpu_worker.py'), out, str(n_steps), precision, form,
-                                       '1' if ragged else '0', which], env=env, cwd=repo))
-    for p in procs:
-        assert p.wait(timeout=600) == 0
+        log = open(str(tmp_path / ('rank%d.log' % rank)), 'w')
+        procs.append((subprocess.Popen([sys.executable, os.path.join(repo, 'tests', '_dist_gpu_worker.py'), out, str(n_steps), precision, form,
+                                        '1' if ragged else '0', which], env=env, cwd=repo, stdout=log, stderr=subprocess.STDOUT), log))
+    codes = []
+    for p, log in procs:
+        codes.append(p.wait(timeout=600))
+        log.close()
+    # a rank that died says why (one failure of this test in round 5 left no trace: the workers' output went to the terminal)
+    assert codes == [0, 0], '\n'.join('--- rank %d (exit %s)\n%s' % (r, codes[r], open(str(tmp_path / ('rank%d.log' % r))).read()[-3000:])
+                                      for r in range(2))
     got = np.load(out)
     assert np.array_equal(got['replicas'][0], got['replicas'][1])            # the ranks hold identical parameters after every update
     assert str(got['mode']) == ('eager' if form == 'graph' else 'eager loop')  # gloo is never captured into the graph
@@ -369,7 +375,8 @@ def test_two_ranks_on_one_gpu_equal_the_global_batch(tmp_path, precision, form, 
     want_flat, want_losses, _ = worker.run_steps(batch, n_steps, precision, form, torch.device(DEV), which)
     # the exact modes to 1e-4 (F0Model) / 1e-3 (the recurrent model: BPTT sums in another order per shard), bf16 to 2e-3 / 5e-3
     tol = {'fp32': RTOL, 'bf16x3': RTOL}.get(precision, 2e-3) * (1.0 if which == 'f0' else (10.0 if precision == 'fp32' else 2.5))
-    assert rel_l2(got['replicas'][0], want_flat.cpu().numpy()) < tol
+    err = rel_l2(got['replicas'][0], want_flat.cpu().numpy())
+    assert err < tol, (err, tol, got['losses'], want_losses)
     np.testing.assert_allclose(got['losses'], want_losses, rtol=tol)
 
 

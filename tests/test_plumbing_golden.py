@@ -326,10 +326,10 @@ def test_bf16_loader_table_and_launches_of_the_product_step():
         log = list(_lib.CALL_LOG)
     finally:
         _lib.CALL_LOG = None
-    loader_calls = ('mg_pad_normalise_f32', 'mg_pad_normalise_bf16_f32')
+    loader_calls = ('mg_pad_normalise_f32', 'mg_pad_normalise_bf16_f32', 'mg_host_pack')      # (host pack: one per float feature and batch)
     step_calls = [c for c in log if c not in loader_calls]
     assert not any('cast' in c for c in step_calls), step_calls
-    assert log.count('mg_pad_normalise_bf16_f32') == len(loader), log
+    assert log.count('mg_pad_normalise_bf16_f32') == len(loader) and log.count('mg_host_pack') == 2 * len(loader), log
     # per batch: front + layer-1 GEMM | layers 2-4 + loss + their backward | prediction expansion + tail reduce | layer-2 wgrad + dgrad |
     # layer-1 wgrad | Adam's scalars | update - bench.py's graph replay stages the scalars once per ten steps, hence its "six"
     # (eager launches, as here; a step captured into a HIP graph has one entry point less: the third rides at the end of the fourth,
