@@ -360,6 +360,39 @@ def _pack_pinned(items, device, key):
     return packed, offsets, lens
 
 
+def _small_to_device(plain, device):
+    """The batch's small host tensors (durations, lengths, ...) to ``device`` as ONE asynchronous copy out of pinned staging.  A
+    ``tensor.to(device)`` from pageable memory is a synchronous copy on the current stream: it returns when everything queued there
+    has run - the 49 MB feature copy in front of it included - so the host could not pack the next batch beside this one's transfer."""
+    device = torch.device(device)
+    tensors = [(k, v.contiguous()) for k, v in plain.items() if isinstance(v, torch.Tensor)]
+    out = {k: v for k, v in plain.items() if not isinstance(v, torch.Tensor)}
+    if device.type != 'cuda' or not tensors:
+        out.update((k, v.to(device)) for k, v in tensors)
+        return out
+    spans, at = [], 0
+    for _, v in tensors:
+        spans.append(at)
+        at += (v.numel() * v.element_size() + 63) // 64 * 64
+    slot = _STAGING.take(str(device), '__small__', max(at, 64))
+    host = slot[0]
+    import ctypes
+    for (_, v), lo in zip(tensors, spans):
+        n = v.numel() * v.element_size()
+        if n:
+            # (memmove, not tensor.copy_: above 32 K elements a torch CPU op opens an OpenMP region on every core of the host, whose
+            # workers then spin - on a box with a CPU quota that throttles the whole process for the rest of the scheduler period:
+            # 90 ms stalls at random points of the loop, profiles/r5_notes_loader.txt)
+            ctypes.memmove(host.data_ptr() + lo, v.data_ptr(), n)
+    staged = host[:max(at, 64)].to(device, non_blocking=True)
+    slot[1] = torch.cuda.Event()
+    slot[1].record(torch.cuda.current_stream(device))
+    for (k, v), lo in zip(tensors, spans):
+        n = v.numel() * v.element_size()
+        out[k] = staged[lo:lo + n].view(v.dtype).view(v.shape) if n else torch.empty(v.shape, dtype=v.dtype, device=device)
+    return out
+
+
 def collate_to_device(batch, normalisers, device, bf16_tables=()):
     """``load_utterance`` + ``collate_fn`` + ``to_device`` for a list of RAW per-utterance feature dicts, with the float
     sequence features normalised and zero padded on the device (reference: data.py:119-127, 159-224, 648-663).
@@ -407,13 +440,11 @@ def collate_to_device(batch, normalisers, device, bf16_tables=()):
         total = _host_total(plain.get(FRAME_COUNT_KEY))
         if total is not None:
             out[FRAME_COUNT_KEY + '_total'] = total          # see to_device
-        for key, value in plain.items():
-            out[key] = value.to(device) if isinstance(value, torch.Tensor) else value
         for key in rest:                                  # integer sequence features with a normaliser (dur) stay on the host path
             normaliser = normalisers.get(key) if normalisers is not None else None
             if normaliser is not None and isinstance(batch[0][key], np.ndarray):
-                twin = collate_fn([{key: normaliser.normalise(item[key]).astype(np.float32)} for item in batch])[key]
-                out['normalised_' + key] = twin.to(device)
+                plain['normalised_' + key] = collate_fn([{key: normaliser.normalise(item[key]).astype(np.float32)} for item in batch])[key]
+        out.update(_small_to_device(plain, device))
     for key in bf16_tables:                               # features that did not take the fused pass (no normaliser, host path; pair planes)
         name, _, kind = key.partition(':')
         suffix = X3_TABLE_SUFFIX if kind == 'x3' else BF16_TABLE_SUFFIX
