@@ -310,6 +310,7 @@ class GraphedStepCache(object):
 
     def __init__(self, model, optimizer, max_graphs=8, max_group_graphs=256):
         self.model, self.optimizer, self.max_graphs, self.max_group_graphs = model, optimizer, max_graphs, max_group_graphs
+        self._no_capture = set()                          # signatures whose capture failed: ordinary launches from then on
         self._groups = {}                                 # group_key -> GraphedTrainStep over K resident batches (``step_group``)
         self.group_replays = 0
         self._seen = collections.OrderedDict()
@@ -418,13 +419,31 @@ class GraphedStepCache(object):
                 losses.append(self.step(f, clone_loss=slot is None, loss_slot=slot)[0])
             return losses
         if graphed is None:
-            graphed = GraphedTrainStep(self.model, self.optimizer, batches, warmup=0, steps_per_replay=len(batches))
+            graphed = None if any(sig in self._no_capture for sig in sigs) else self._try_capture(sigs[0], batches, len(batches))
+            if graphed is None:                           # a step that cannot be captured: ordinary launches from now on
+                for sig in sigs:
+                    self._no_capture.add(sig)
+                losses = [self._eager(f, sig)[0] for f, sig in zip(batches, sigs)]
+                self._file_losses(zip(slots, losses))
+                return losses
             self._groups[key] = graphed
         graphed()
         self.replayed_steps += len(batches)
         self.group_replays += 1
         self._file_losses(zip(slots, graphed.losses))
         return list(graphed.losses)
+
+    def _try_capture(self, key, features, k):
+        """A captured step (of ``k`` batches), or None when the model's step cannot be captured - a forward that reads a device value
+        back (``.item()``, a sizing sync), say: HIP refuses the call inside a capture.  The signature then stays on ordinary launches
+        (one warning); training goes on - capture runs nothing, so no step is lost."""
+        try:
+            return GraphedTrainStep(self.model, self.optimizer, features, warmup=0, steps_per_replay=k)
+        except Exception as exc:                          # noqa: BLE001 - whatever the capture tripped over, the eager loop does not
+            self._no_capture.add(key)
+            warnings.warn('GraphedStepCache: this step cannot be captured into a HIP graph (%s) - batches of this shape run as ordinary '
+                          'launches' % (str(exc).splitlines()[0][:160] if str(exc) else type(exc).__name__))
+            return None
 
     def _eager(self, features, key):
         self._before_replay = None                        # an eager step: a batch loaded ahead waits for all of it
@@ -466,10 +485,13 @@ class GraphedStepCache(object):
             self.prefetched_steps += 1
         elif ahead is not None:
             torch.cuda.current_stream().wait_event(ahead[3])      # a batch loaded ahead that did not come next: its copy must still land
-        if graphed is None and key in self._seen and (pair is None or len(pair) < 2) and self.graph_count() < 2 * self.max_graphs:
+        if graphed is None and key in self._seen and key not in self._no_capture and (pair is None or len(pair) < 2) \
+                and self.graph_count() < 2 * self.max_graphs:
             # the second (third) batch of a signature: capture a step on static copies of its tensors - two per signature, taken in turn
             static = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in features.items()}
-            graphed = GraphedTrainStep(self.model, self.optimizer, static, warmup=0)
+            graphed = self._try_capture(key, static, 1)
+            if graphed is None:
+                return self._eager(features, key)         # (capture runs nothing: the step has not been taken yet)
             self._steps.setdefault(key, []).append(graphed)
             self._turn[key] = 0 if len(self._steps[key]) < 2 else 1
         elif graphed is None and pair:

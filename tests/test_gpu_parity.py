@@ -2700,3 +2700,42 @@ def test_resident_epoch_groups_equal_the_eager_loop(precision):
     stats = builder._graph_cache.stats()
     assert stats['eager'] == 7 and stats['replayed'] == 21 and stats['group_graphs'] == 3 and stats['group_replays'] == 9, stats
     assert stats['graphs'] == 0                                # no single-step graphs, no static copies
+
+
+@pytest.mark.parametrize('group', [1, 3])
+def test_a_step_that_cannot_be_captured_trains_on_ordinary_launches(group):
+    """ExperimentBuilder(use_graphs=True) with a model whose forward reads a device value back on every call (HIP refuses that inside a
+    capture): the capture attempt fails, the cache warns once, keeps that batch shape on ordinary launches and the epoch goes on - no
+    step lost, none run twice: losses and parameters EQUAL to the eager loop; per-batch form and resident groups."""
+    from morgana_amd import experiment_builder
+
+    class Syncing(models.F0Model):
+        def forward(self, features):
+            self.frames_seen = getattr(self, 'frames_seen', 0) + int(features['n_frames'].sum().item())      # a host read per step
+            return super().forward(features)
+
+    batches = [synthetic.make_batch(16, 120, seed=700 + i) for i in range(5)]
+
+    def train(use_graphs):
+        torch.manual_seed(3)
+        builder = experiment_builder.ExperimentBuilder(Syncing, dict(precision='bf16'), learning_rate=0.01, device=DEV, use_graphs=use_graphs,
+                                                       graph_group=group)
+        _load_state(builder.model, synthetic.f0_model_state())
+        dev_batches = [data.to_device(b, DEV, bf16_tables=builder.model.bf16_table_features()) for b in batches]
+        optimizer = builder.make_optimizer()
+        history = [builder.train_epoch(dev_batches, optimizer) for _ in range(3)]
+        return history, {k: v.detach().clone() for k, v in builder.model.named_parameters()}, builder
+
+    hist_e, params_e, eager = train(False)
+    with pytest.warns(UserWarning, match='cannot be captured'):
+        hist_g, params_g, builder = train(True)
+    assert hist_g == hist_e and builder.model.frames_seen == eager.model.frames_seen
+    for name in params_e:
+        assert torch.equal(params_g[name], params_e[name]), name
+    stats = builder._graph_cache.stats()
+    assert stats['eager'] == 15 and stats['replayed'] == 0 and stats['graphs'] == 0 and stats['group_graphs'] == 0, stats
+    # the thread is usable afterwards: an ordinary model still captures and replays
+    plain = experiment_builder.ExperimentBuilder(models.F0Model, dict(precision='bf16'), learning_rate=0.01, device=DEV, use_graphs=True, graph_group=1)
+    dev_batches = [data.to_device(b, DEV, bf16_tables=plain.model.bf16_table_features()) for b in batches]
+    plain.train_epoch(dev_batches, plain.make_optimizer())
+    assert plain._graph_cache.stats()['replayed'] == 4
