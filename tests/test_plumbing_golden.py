@@ -340,3 +340,40 @@ def test_bf16_loader_table_and_launches_of_the_product_step():
     per_epoch = [c for c in step_calls if c not in want and not c.endswith('_status')]     # the epoch's time-out check reads status words
     assert sorted(c for c in step_calls if c in want) == sorted(want * n), step_calls
     assert len(per_epoch) <= 3, per_epoch                    # the epoch's reads of the loss metric / the persistent-kernel status
+
+
+@pytest.mark.gpu
+def test_streamed_batches_do_not_share_staging():
+    """data.collate_to_device packs every batch into pinned staging that is REUSED (two buffers per feature, in turn, an event each) and
+    copies it asynchronously: eight batches are built back to back with no synchronisation in between - the host runs far ahead of the
+    copies - and only then compared with the host pipeline (collate_fn on normalised utterances): every batch holds its own rows.
+    Ragged lengths, batches of different sizes (the staging grows), and ``DeviceBatches.resident`` = the same list."""
+    rng = np.random.RandomState(21)
+    lab_dim = 600
+    norms = {'lab': data.MinMaxNormaliser('lab').set_params({'mmin': (rng.rand(lab_dim) * 0.1).astype(np.float32),
+                                                             'mmax': (1.0 + rng.rand(lab_dim)).astype(np.float32)}, device='cuda:0'),
+             'lf0': data.MeanVarianceNormaliser('lf0').set_params({'mean': np.array([5.0], np.float32),
+                                                                   'std_dev': np.array([0.3], np.float32)}, device='cuda:0')}
+    utterances = []
+    for i in range(8 * 48 + 17):
+        n_ph = int(rng.randint(20, 90))
+        dur = rng.randint(5, 21, size=(n_ph, 1)).astype(np.int64)
+        n_fr = int(dur.sum())
+        utterances.append({'name': 'utt%04d' % i, 'n_frames': n_fr, 'n_phones': n_ph, 'dur': dur,
+                           'lab': rng.rand(n_ph, lab_dim).astype(np.float32),
+                           'lf0': (5.0 + 0.3 * rng.randn(n_fr, 1)).astype(np.float32)})
+    loader = data.DeviceBatches(utterances, 48, norms, 'cuda:0', bf16_tables=('normalised_lab',))
+    batches = loader.resident()                                  # nine batches (the last of 17 utterances), no sync in between
+    assert len(batches) == len(loader) == 9
+    torch.cuda.synchronize()
+    for b, got in enumerate(batches):
+        items = utterances[48 * b:48 * (b + 1)]
+        want = data.collate_fn([data.load_utterance(u, norms) for u in items])
+        assert got['name'] == [u['name'] for u in items]
+        for key in ('lab', 'lf0', 'dur', 'n_frames', 'n_phones'):
+            assert torch.equal(got[key].cpu(), want[key]), (b, key)
+        for key in ('normalised_lab', 'normalised_lf0'):
+            np.testing.assert_allclose(got[key].cpu().numpy(), want[key].numpy(), rtol=0, atol=2e-6, err_msg='%d %s' % (b, key))
+        table = got['normalised_lab' + data.BF16_TABLE_SUFFIX]
+        rows = got['normalised_lab'].shape[0] * got['normalised_lab'].shape[1]
+        assert torch.equal(table[:rows, :lab_dim], got['normalised_lab'].reshape(rows, lab_dim).to(torch.bfloat16))
