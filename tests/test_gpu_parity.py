@@ -2739,3 +2739,29 @@ def test_a_step_that_cannot_be_captured_trains_on_ordinary_launches(group):
     dev_batches = [data.to_device(b, DEV, bf16_tables=plain.model.bf16_table_features()) for b in batches]
     plain.train_epoch(dev_batches, plain.make_optimizer())
     assert plain._graph_cache.stats()['replayed'] == 4
+
+
+def test_resident_groups_follow_an_epoch_level_learning_rate_schedule():
+    """Resident groups (ten batches per graph) under an epoch-level schedule ('exponential', gamma 0.7) through ``run_train``: the captured
+    update kernels read the step's scalars from the staging launch of every replay, so the learning rate that changed between two epochs
+    is the one the replayed steps use - four epochs, losses and parameters EQUAL to the eager loop."""
+    from morgana_amd import experiment_builder
+    batches = [synthetic.make_batch(64, 300, seed=800 + i) for i in range(6)]
+
+    def train(use_graphs):
+        torch.manual_seed(3)
+        builder = experiment_builder.ExperimentBuilder(models.F0Model, dict(precision='bf16'), learning_rate=0.02, lr_schedule_name='exponential',
+                                                       lr_schedule_kwargs=dict(gamma=0.7), device=DEV, end_epoch=4, use_graphs=use_graphs,
+                                                       graph_group=4)
+        _load_state(builder.model, synthetic.f0_model_state())
+        dev_batches = [data.to_device(b, DEV, bf16_tables=builder.model.bf16_table_features()) for b in batches]
+        history = builder.run_train(dev_batches)
+        return history, {k: v.detach().clone() for k, v in builder.model.named_parameters()}, builder
+
+    hist_e, params_e, _ = train(False)
+    hist_g, params_g, builder = train(True)
+    assert hist_g == hist_e
+    for name in params_e:
+        assert torch.equal(params_g[name], params_e[name]), name
+    stats = builder._graph_cache.stats()
+    assert stats['group_graphs'] == 2 and stats['group_replays'] == 7 and stats['eager'] == 4, stats
