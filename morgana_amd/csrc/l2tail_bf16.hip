@@ -1299,6 +1299,14 @@ __global__ __launch_bounds__(256, 1) void f0_l2tail16_kernel(const uint16_t* __r
 
 #endif  // MG_EXPERIMENTS (f0_l2tail16_kernel)
 
+#ifdef MG_EXPERIMENTS
+// l2tail_wide.hip (lab builds, MG_TUNE_AB = 69 and its probes 101-108): the pass with W2 in registers and H1 through an LDS ring
+void mg_launch_f0_l2tail_wide(const uint16_t* H1, int ldh1, const uint16_t* W2, int ldw2, const float* b2, const float* W3, const float* b3,
+                              const float* W4, const float* b4, const float* target, const int64_t* seq_len, int64_t M, int B, int T,
+                              float grad_scale, float* pred, uint16_t* dZ2, int lddz, float* slab, const float* row_weight, int rev, int grid,
+                              hipStream_t st);
+#endif
+
 static int l2tail_blocks(int64_t M) {
     int64_t blocks = mg_ceil_div(mg_ceil_div(M, 32), 4);
     if (blocks > 256) blocks = 256;                    // one resident workgroup per CU (156 KB of LDS each)
@@ -1342,7 +1350,10 @@ static int f0_l2tail_launch(const char* name, const uint16_t* H1, int ldh1, int 
 #ifdef MG_EXPERIMENTS
     // lab builds only: MG_TUNE_AB 64 = the producer / consumer role split (same results, measured slower); 1 .. 32 = the product
     // kernel with parts switched off (timing probes, results garbage)
-    if (g_mg_tuning[MG_TUNE_AB] == 64) {
+    if (g_mg_tuning[MG_TUNE_AB] == 69 || g_mg_tuning[MG_TUNE_AB] > 100) {          // the wide form and its timing probes
+        mg_launch_f0_l2tail_wide(H1, ldh1, W2, ldw2, b2, W3, b3, W4, b4, target, seq_len, M, B, T, grad_scale, pred, dZ2, lddz, slab, row_weight, rev,
+                                 blocks, st);
+    } else if (g_mg_tuning[MG_TUNE_AB] == 64) {
         u32x4* xbuf = reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(workspace) + l2tail_slab_bytes(M));
         hipLaunchKernelGGL(f0_l2tail_split_kernel, dim3(blocks), dim3(512), 0, st, H1, ldh1, W2, ldw2, b2, W3, b3, W4, b4, target, seq_len, M, B, T,
                            grad_scale, pred, dZ2, lddz, slab, row_weight, xbuf);

@@ -209,7 +209,7 @@ def test_product_library_holds_no_experiments():
     import subprocess
     from morgana_amd import _lib
     names = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH], universal_newlines=True)
-    for kernel in ('wgrad_fused_solo_kernel', 'wgrad_fused64w_kernel', 'f0_l2tail_split_kernel'):
+    for kernel in ('wgrad_fused_solo_kernel', 'wgrad_fused64w_kernel', 'f0_l2tail_split_kernel', 'f0_l2tail_wide_kernel'):
         assert kernel not in names, kernel
     assert not re.search(r'wgrad_fused64_kernelILi3ELi[1-9]', names)              # the PROBE != 0 instantiations
     assert not re.search(r'f0_l2tail_kernelILi[1-9]', names)

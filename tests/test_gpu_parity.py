@@ -438,8 +438,8 @@ def l2tail_variant(request):
     _lib.load().mg_set_tuning(7, 0)
 
 
-@pytest.mark.parametrize('l2tail_variant', [0, 67, 68, 64], indirect=True)      # 67 = the 16x16x32 form (f0_l2tail16_kernel)
-@pytest.mark.parametrize('bt', [(7, 45), (64, 1000), (3, 32), (1, 1), (5, 333)])
+@pytest.mark.parametrize('l2tail_variant', [0, 67, 68, 64, 69], indirect=True)  # 67 = the 16x16x32 form (f0_l2tail16_kernel), 69 = the wide form (l2tail_wide.hip)
+@pytest.mark.parametrize('bt', [(7, 45), (64, 1000), (3, 32), (1, 1), (5, 333), (37, 901)])
 def test_l2tail_kernel_vs_numpy_and_unfused_pair(bt, l2tail_variant):
     """mg_f0_l2tail_bf16 (the 512 -> 128 sigmoid layer inside the fused tail: README.rst:65-73 layers 2-4 + losses.py:29-51, forward
     and backward in one pass over H1) against a float64 restatement fed the same bf16 operands and the kernel's own bf16 rounding of
