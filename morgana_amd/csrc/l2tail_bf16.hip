@@ -24,6 +24,7 @@
 //     ds_read_b64_tr_b16 (the H2 tile goes through a 2 KB per-wave LDS patch in four 32-unit slices).
 // Partial sums are reduced lane -> wave -> workgroup in a fixed order and finished by an ordered slab reduce (no atomics).
 #include "common.h"
+#include <stdlib.h>
 #include "slab_reduce.h"
 
 typedef __bf16 bfv8 __attribute__((ext_vector_type(8)));
@@ -1301,10 +1302,10 @@ __global__ __launch_bounds__(256, 1) void f0_l2tail16_kernel(const uint16_t* __r
 
 #ifdef MG_EXPERIMENTS
 // l2tail_wide.hip (lab builds, MG_TUNE_AB = 69 and its probes 101-108): the pass with W2 in registers and H1 through an LDS ring
-void mg_launch_f0_l2tail_wide(const uint16_t* H1, int ldh1, const uint16_t* W2, int ldw2, const float* b2, const float* W3, const float* b3,
-                              const float* W4, const float* b4, const float* target, const int64_t* seq_len, int64_t M, int B, int T,
-                              float grad_scale, float* pred, uint16_t* dZ2, int lddz, float* slab, const float* row_weight, int rev, int grid,
-                              hipStream_t st);
+int mg_launch_f0_l2tail_wide(const uint16_t* H1, int ldh1, const uint16_t* W2, int ldw2, const float* b2, const float* W3, const float* b3,
+                             const float* W4, const float* b4, const float* target, const int64_t* seq_len, int64_t M, int B, int T,
+                             float grad_scale, float* pred, uint16_t* dZ2, int lddz, float* slab, const float* row_weight, int rev, int grid,
+                             hipStream_t st);
 #endif
 
 static int l2tail_blocks(int64_t M) {
@@ -1340,7 +1341,7 @@ static int f0_l2tail_launch(const char* name, const uint16_t* H1, int ldh1, int 
         return MG_EWORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    const int blocks = l2tail_blocks(M);
+    int blocks = l2tail_blocks(M);
     float* slab = (float*)workspace;
     // Large H1 (more than the 8 L2s hold): walk the tiles from the END - the rows the layer-1 forward wrote last are the ones L2 and
     // the memory-side cache still hold (C2 at frame rate: the step 0.5043 -> 0.5008 ms in a same-box A/B; at phone-rate row counts
@@ -1350,9 +1351,11 @@ static int f0_l2tail_launch(const char* name, const uint16_t* H1, int ldh1, int 
 #ifdef MG_EXPERIMENTS
     // lab builds only: MG_TUNE_AB 64 = the producer / consumer role split (same results, measured slower); 1 .. 32 = the product
     // kernel with parts switched off (timing probes, results garbage)
-    if (g_mg_tuning[MG_TUNE_AB] == 69 || g_mg_tuning[MG_TUNE_AB] > 100) {          // the wide form and its timing probes
-        mg_launch_f0_l2tail_wide(H1, ldh1, W2, ldw2, b2, W3, b3, W4, b4, target, seq_len, M, B, T, grad_scale, pred, dZ2, lddz, slab, row_weight, rev,
-                                 blocks, st);
+    static const int wide_env = getenv("MG_L2TAIL_WIDE") ? atoi(getenv("MG_L2TAIL_WIDE")) : 0;      // lab: the wide form with every other switch at its default
+    if (g_mg_tuning[MG_TUNE_AB] == 69 || g_mg_tuning[MG_TUNE_AB] > 100 || (wide_env && g_mg_tuning[MG_TUNE_AB] == 0)) {          // the wide form and its timing probes
+        // (up to 256 slabs: the lab build's workspace holds them - the role split's ring lies behind the slab area)
+        blocks = mg_launch_f0_l2tail_wide(H1, ldh1, W2, ldw2, b2, W3, b3, W4, b4, target, seq_len, M, B, T, grad_scale, pred, dZ2, lddz, slab,
+                                          row_weight, rev, 256, st);
     } else if (g_mg_tuning[MG_TUNE_AB] == 64) {
         u32x4* xbuf = reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(workspace) + l2tail_slab_bytes(M));
         hipLaunchKernelGGL(f0_l2tail_split_kernel, dim3(blocks), dim3(512), 0, st, H1, ldh1, W2, ldw2, b2, W3, b3, W4, b4, target, seq_len, M, B, T,

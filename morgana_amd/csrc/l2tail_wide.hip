@@ -32,7 +32,9 @@
 // form - the sigmoids of H2, the tail's VALU work and the barriers do not shrink with the operand layout, and with everything
 // resident the second wave per SIMD has the same VALU to share.  Halving the fragment reads (32-unit slices: 128 registers of W2
 // per lane) needs dW3 moved out of the per-wave registers (a slice per wave over all frames, two more block barriers); sized at
-// ~76 us, compute-bound still - not built.
+// ~76 us, compute-bound still - not built.  At phone-rate row counts (21 504 rows: one round of 224 blocks of 96 rows, NFT = 6;
+// MG_L2TAIL_WIDE=1 in the lab build) 20.6 us against f0_l2tail_kernel's 17.2: the step 0.1067 against 0.1025 ms - the one block per CU
+// pays the prologue (W2 slice, W3 images) and eight barrier steps for 96 rows.
 #ifdef MG_EXPERIMENTS
 #include "common.h"
 #include "slab_reduce.h"
@@ -60,11 +62,11 @@ typedef unsigned int lw_u32x2 __attribute__((ext_vector_type(2)));
 #define LW_SLAB (LW_N3 * LW_N2 + LW_N3 + LW_N3 + 2)       // dW3 | db3 | dW4 | db4 | loss: f0_l2tail_kernel's slab
 #define LW_SLAB_STRIDE ((LW_SLAB + 3) / 4 * 4)
 
-__device__ uint16_t g_lw_zero[LW_K + 64];         // what the rows past the end of H1 read
 
 // PROBE (lab builds only, timing experiments, results garbage): 1 = no phase 2, 2 = no fragment reads / MFMAs in phase 1, 4 = no stream (tiles
 // are not fetched), 8 = phase 2 without its dZ2 / pred stores.
-template <int PROBE>
+// NFT = 16-frame tiles of a block (8: blocks of up to 128 rows; 6: up to 96 - the rows of a one-round launch at phone-rate row counts)
+template <int PROBE, int NFT>
 __global__ __launch_bounds__(512) void f0_l2tail_wide_kernel(const uint16_t* __restrict__ H1, int ldh1, const uint16_t* __restrict__ W2, int ldw2,
                                                              const float* __restrict__ b2, const float* __restrict__ W3,
                                                              const float* __restrict__ b3, const float* __restrict__ W4,
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(512) void f0_l2tail_wide_kernel(const uint16_t* __r
                                                              const int64_t* __restrict__ seq_len, int64_t M, int B, int T, float grad_scale,
                                                              float* __restrict__ pred, uint16_t* __restrict__ dZ2, int lddz,
                                                              float* __restrict__ slab, const float* __restrict__ row_weight, int rev,
-                                                             int n_blocks) {
+                                                             int n_blocks, int rows_per) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[LW_LDS];
     static_assert(LW_LDS <= 160 * 1024, "one workgroup per CU");
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, q = lane >> 4;
@@ -108,24 +110,28 @@ __global__ __launch_bounds__(512) void f0_l2tail_wide_kernel(const uint16_t* __r
     float db4p = 0.f, lossp = 0.f;
 
     // ---- the stream: tile qt = 8 it + kt is k-tile kt of this workgroup's it-th block, in ring slot qt % LW_NS.  A slot = 16 pieces of
-    // 1 KB (8 rows x 128 B); wave w issues pieces w and w + 8.  Tiles past the last block read the zero row (the issue count per step
-    // stays constant, so the counted waits below hold to the end).
+    // 1 KB (8 rows x 128 B); wave w issues pieces w and w + 8.  Tiles past the last block are fetched all the same (the issue count per
+    // step stays constant, so the counted waits below hold to the end).
     const int prow = lane >> 3, pch = lane & 7;
     auto block_row0 = [&](int it) -> int64_t {
         const int64_t blk = (int64_t)blockIdx.x + (int64_t)it * gridDim.x;
         if (blk >= n_blocks) return -1;
-        return (rev ? (int64_t)n_blocks - 1 - blk : blk) * LW_ROWS;
+        return (rev ? (int64_t)n_blocks - 1 - blk : blk) * rows_per;          // blocks of rows_per <= 128 rows (the rest of a slot: zero rows)
     };
+    const int n_pieces = (wave + 8 < 2 * NFT) ? 2 : 1;          // pieces w and w + 8 of the 2 NFT pieces that hold the block's tiles
     auto issue = [&](int qt) {
         const int it = qt >> 3, kt = qt & 7;
         const int64_t r0 = block_row0(it);
+        // tiles past the last block fetch VALID rows nobody uses (this workgroup's first block again): the issue count stays constant
+        const int base = (int)(r0 >= 0 ? r0 : block_row0(0));
         unsigned char* slot = smem + (qt % LW_NS) * LW_SLOT;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            if (i >= n_pieces) break;
             const int piece = wave + 8 * i, row = piece * 8 + prow;
-            const int64_t m = r0 + row;
-            const uint16_t* src = (r0 >= 0 && m < M) ? H1 + (size_t)m * ldh1 + kt * LW_BK : g_lw_zero;
-            if (!(PROBE & 4)) mg_glds16(src + ((pch ^ ((row >> 1) & 7)) << 3), slot + piece * 1024);
+            int m = base + row;                           // rows past the block's own: the next block's (or the last row) - valid, unused
+            if (m > (int)M - 1) m = (int)M - 1;
+            if (!(PROBE & 4)) mg_glds16(H1 + (size_t)m * ldh1 + kt * LW_BK + ((pch ^ ((row >> 1) & 7)) << 3), slot + piece * 1024);
         }
     };
     const int n_iters = (int)((n_blocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);
@@ -138,31 +144,35 @@ __global__ __launch_bounds__(512) void f0_l2tail_wide_kernel(const uint16_t* __r
     int qt = 0;
     for (int it = 0; it < n_iters; ++it) {
         const int64_t row0 = block_row0(it);
-        f32x4 acc[8];
+        const int n_rows = (int)(row0 + rows_per <= M ? (int64_t)rows_per : M - row0);      // rows of this block (> 0)
+        f32x4 acc[NFT];
 #pragma unroll
-        for (int ft = 0; ft < 8; ++ft) acc[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ft = 0; ft < NFT; ++ft) acc[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < LW_NKT; ++kt, ++qt) {
             // tile qt has landed when at most the four tiles behind it are still in flight (two pieces per tile and wave); then every
             // wave is done with tile qt - 1, whose slot takes tile qt + LW_NS - 1 (step 0: issued at the start of the tail before)
-            asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            if (n_pieces == 2)
+                asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
             if (kt > 0) issue(qt + LW_NS - 1);
             const unsigned char* slot = smem + (qt % LW_NS) * LW_SLOT;
 #pragma unroll
             for (int ks = 0; ks < ((PROBE & 2) ? 0 : 2); ++ks) {
-                lw_bfv8 bf[8];
+                lw_bfv8 bf[NFT];
 #pragma unroll
-                for (int ft = 0; ft < 8; ++ft) {
+                for (int ft = 0; ft < NFT; ++ft) {
                     const int row = 16 * ft + li;
                     bf[ft] = *reinterpret_cast<const lw_bfv8*>(slot + row * 128 + (((4 * ks + q) ^ ((row >> 1) & 7)) << 4));
                 }
 #pragma unroll
-                for (int ft = 0; ft < 8; ++ft) acc[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[2 * kt + ks], bf[ft], acc[ft], 0, 0, 0);
+                for (int ft = 0; ft < NFT; ++ft) acc[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[2 * kt + ks], bf[ft], acc[ft], 0, 0, 0);
             }
         }
         // H2 of the block into LDS: this lane holds units 16 wave + 4 q + r (r = 0..3) of frame 16 ft + li
 #pragma unroll
-        for (int ft = 0; ft < 8; ++ft) {
+        for (int ft = 0; ft < NFT; ++ft) {
             const int row = 16 * ft + li;
             float v[4];
 #pragma unroll
@@ -178,13 +188,13 @@ __global__ __launch_bounds__(512) void f0_l2tail_wide_kernel(const uint16_t* __r
         // units (4 q + r) of ITS frame li, so the per-frame scalars are computed once per lane and every LDS access of the phase is an
         // 8- or 16-byte piece of a row (the first version had the frames in the registers: 2-byte accesses, ~1 500 VALU instructions per
         // tile - 50 us of the launch). ----------------------------------------------------------------------------------------------------
-        if (!(PROBE & 1)) {
+        if (!(PROBE & 1) && 16 * wave < n_rows) {
             int lane_o = lane;                              // (addresses of this phase re-derived from an opaque lane id: not hoisted across phase 1)
             asm volatile("" : "+v"(lane_o));
             const int li = lane_o & 15, q = lane_o >> 4;
             const int r_t = 16 * wave;                      // first row of the tile inside the block
             const int64_t m = row0 + r_t + li;              // this lane's frame
-            const bool live = m < M;
+            const bool live = r_t + li < n_rows;            // (rows past the block's end belong to the next block)
             const int64_t mm = live ? m : M - 1;
             const float tg = target[mm];
             float s1, cw, lw;
@@ -346,14 +356,26 @@ __global__ __launch_bounds__(512) void f0_l2tail_wide_kernel(const uint16_t* __r
 }
 
 // blocks of 128 frames over at most 256 workgroups (one per CU); the slab count the caller's workspace is sized for
-void mg_launch_f0_l2tail_wide(const uint16_t* H1, int ldh1, const uint16_t* W2, int ldw2, const float* b2, const float* W3, const float* b3,
-                              const float* W4, const float* b4, const float* target, const int64_t* seq_len, int64_t M, int B, int T,
-                              float grad_scale, float* pred, uint16_t* dZ2, int lddz, float* slab, const float* row_weight, int rev, int grid,
-                              hipStream_t st) {
-    const int n_blocks = (int)mg_ceil_div(M, LW_ROWS);
-#define LW_LAUNCH(P_)                                                                                                                            \
-    hipLaunchKernelGGL(f0_l2tail_wide_kernel<P_>, dim3((unsigned)grid), dim3(512), 0, st, H1, ldh1, W2, ldw2, b2, W3, b3, W4, b4, target, seq_len, M, \
-                       B, T, grad_scale, pred, dZ2, lddz, slab, row_weight, rev, n_blocks)
+int mg_launch_f0_l2tail_wide(const uint16_t* H1, int ldh1, const uint16_t* W2, int ldw2, const float* b2, const float* W3, const float* b3,
+                             const float* W4, const float* b4, const float* target, const int64_t* seq_len, int64_t M, int B, int T,
+                             float grad_scale, float* pred, uint16_t* dZ2, int lddz, float* slab, const float* row_weight, int rev, int grid,
+                             hipStream_t st) {
+    // blocks of at most 128 rows; one round of at most 256 workgroups when the rows allow it (every CU a block: rows_per = ceil(M / 256)
+    // rounded up to whole 16-row tiles), whole rounds of 128-row blocks otherwise
+    int rows_per = LW_ROWS;
+    if (mg_ceil_div(M, LW_ROWS) < grid) rows_per = (int)(mg_ceil_div(mg_ceil_div(M, grid), 16) * 16);
+    const int n_blocks = (int)mg_ceil_div(M, rows_per);
+    if (n_blocks < grid) grid = n_blocks;
+#define LW_LAUNCH_N(P_, N_)                                                                                                                      \
+    hipLaunchKernelGGL((f0_l2tail_wide_kernel<P_, N_>), dim3((unsigned)grid), dim3(512), 0, st, H1, ldh1, W2, ldw2, b2, W3, b3, W4, b4, target, seq_len, \
+                       M, B, T, grad_scale, pred, dZ2, lddz, slab, row_weight, rev, n_blocks, rows_per)
+#define LW_LAUNCH(P_)                \
+    do {                             \
+        if (rows_per <= 96)          \
+            LW_LAUNCH_N(P_, 6);      \
+        else                         \
+            LW_LAUNCH_N(P_, 8);      \
+    } while (0)
     switch (g_mg_tuning[MG_TUNE_AB]) {                  // 101.. = timing probes (results garbage)
         case 101: LW_LAUNCH(1); break;
         case 102: LW_LAUNCH(2); break;
@@ -365,5 +387,7 @@ void mg_launch_f0_l2tail_wide(const uint16_t* H1, int ldh1, const uint16_t* W2, 
         default: LW_LAUNCH(0); break;
     }
 #undef LW_LAUNCH
+#undef LW_LAUNCH_N
+    return grid;                                        // slabs written
 }
 #endif  // MG_EXPERIMENTS
