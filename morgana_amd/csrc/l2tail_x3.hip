@@ -32,7 +32,6 @@
 
 typedef __bf16 lx_bfv8 __attribute__((ext_vector_type(8)));
 
-__device__ uint16_t g_lx_zero[LX_K2 * 2 + 64];           // source of the rows past the end of a block (zero-initialised)
 
 __device__ __forceinline__ f32x4 lx_mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -119,7 +118,10 @@ __global__ __launch_bounds__(256) void f0_l2tail_x3_kernel(const uint16_t* __res
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
             const int row = (wave + 4 * g) * 8 + prow;
-            asrc[g] = (row < n_rows ? H1 + (size_t)(row_lo + row) * ldh : g_lx_zero) + ((pch ^ ((row >> 1) & 7)) << 3);
+            // (rows past the block's end fetch valid rows nobody uses - the row clamped into H1 - not one shared zero row: every
+            // workgroup reading the same few lines of one L2 channel is a hot spot, profiles/r5_kbench_l2tail_wide.txt)
+            const int64_t mr = row_lo + row < M ? row_lo + row : M - 1;
+            asrc[g] = H1 + (size_t)mr * ldh + ((pch ^ ((row >> 1) & 7)) << 3);
         }
         auto issue = [&](int kt) {
             unsigned char* st = smem + (kt & 1) * LX_SLOT;
@@ -412,8 +414,11 @@ __global__ __launch_bounds__(512) void f0_l2tail_x3w_kernel(const uint16_t* __re
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
             const int row = pc_row[j], sw = (pch ^ ((row >> 1) & 7)) << 3;
-            if (pc_kind[j] < 2)
-                src[j] = (row < n_rows ? H1 + (size_t)(row_lo + row) * ldh + (pc_kind[j] == 1 ? a_lo : 0) : g_lx_zero) + sw;
+            if (pc_kind[j] < 2) {
+                // (rows past the block's end fetch valid rows nobody uses, not one shared zero row: see the four-wave kernel)
+                const int64_t mr = row_lo + row < M ? row_lo + row : M - 1;
+                src[j] = H1 + (size_t)mr * ldh + (pc_kind[j] == 1 ? a_lo : 0) + sw;
+            }
             else
                 src[j] = W2 + (size_t)row * ldw + (pc_kind[j] == 3 ? b_lo : 0) + sw;
         }
