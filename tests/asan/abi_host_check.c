@@ -163,6 +163,40 @@ int main(void) {
     expect_code("masked_mse(C5)", mg_masked_mse_f32(df, df, dl, 64, 2000, 187, 1.f, df, df, d, mg_masked_mse_workspace_bytes(64, 2000, 187), NULL));
     expect_code("gru_fwd_f32(C4)", mg_gru_fwd_f32(df, df, df, dl, 64, 3, 512, df, df, df, NULL));
 
+    /* mg_host_pack is pure host code on real memory: ragged pieces (one empty) into an exactly-sized destination, every thread count -
+     * an overrun or a torn range is ASan's to see; a destination that is one byte short must be refused */
+    {
+        enum { PIECES = 37 };
+        const void* srcs[PIECES];
+        int64_t bytes[PIECES], total = 0;
+        for (int i = 0; i < PIECES; ++i) {
+            bytes[i] = i == 5 ? 0 : (int64_t)(1 + (i * 7919) % 300000);
+            unsigned char* p = (unsigned char*)malloc((size_t)bytes[i] + 1);
+            for (int64_t k = 0; k < bytes[i]; ++k) p[k] = (unsigned char)(i + k);
+            srcs[i] = p;
+            total += bytes[i];
+        }
+        unsigned char* dst = (unsigned char*)malloc((size_t)total);
+        const int threads[] = {1, 2, 3, 8, 64};
+        for (int t = 0; t < 5; ++t) {
+            memset(dst, 0xee, (size_t)total);
+            expect_code("host_pack", mg_host_pack(srcs, bytes, PIECES, dst, total, threads[t]));
+            int64_t at = 0;
+            for (int i = 0; i < PIECES; ++i) {
+                if (memcmp(dst + at, srcs[i], (size_t)bytes[i]) != 0) {
+                    fprintf(stderr, "host_pack: piece %d differs with %d threads\n", i, threads[t]);
+                    ++n_bad;
+                }
+                at += bytes[i];
+            }
+        }
+        expect_code("host_pack(short)", mg_host_pack(srcs, bytes, PIECES, dst, total - 1, 4));
+        expect_code("host_pack(threads)", mg_host_pack(srcs, bytes, PIECES, dst, total, 0));
+        expect_code("host_pack(null)", mg_host_pack(NULL, bytes, PIECES, dst, total, 1));
+        for (int i = 0; i < PIECES; ++i) free((void*)srcs[i]);
+        free(dst);
+    }
+
     printf("%d calls, %d unexpected results\n", n_calls, n_bad);
     return n_bad ? 1 : 0;
 }
